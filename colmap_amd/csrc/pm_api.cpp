@@ -1,0 +1,698 @@
+// pm_api.cpp -- host side of the PatchMatch C ABI (include/colmap_amd_pm.h).
+//
+// Mirrors the host half of the reference's PatchMatchCuda
+// (src/colmap/mvs/patch_match_cuda.cu:1290-1939): option/problem validation,
+// uploads, pose tables for the four sweep directions, the sweep schedule. The
+// device half lives in pm_kernels.hip. Compiled with hipcc; no CPU fallback:
+// every entry point fails with an error if there is no usable HIP device.
+#include "../../include/colmap_amd_pm.h"
+#include "pm_internal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <set>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+using namespace colmap_amd;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+struct PmError : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+
+#define PM_CHECK(cond, msg)                                              \
+  do {                                                                   \
+    if (!(cond)) throw PmError(std::string("Check failed: ") + #cond + " " + (msg)); \
+  } while (0)
+
+#define HIP_CALL(expr)                                                                  \
+  do {                                                                                  \
+    hipError_t e_ = (expr);                                                             \
+    if (e_ != hipSuccess)                                                               \
+      throw PmError(std::string("HIP error: ") + hipGetErrorString(e_) + " at " #expr); \
+  } while (0)
+
+template <typename T>
+struct DevBuf {
+  T* ptr = nullptr;
+  size_t count = 0;
+  void alloc(size_t n) {
+    free();
+    if (n == 0) return;
+    HIP_CALL(hipMalloc(reinterpret_cast<void**>(&ptr), n * sizeof(T)));
+    count = n;
+  }
+  void free() {
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    count = 0;
+  }
+  ~DevBuf() { free(); }
+};
+
+// ---- host pose helpers (reference mvs/image.cc:97-150), float like the reference ----
+void Mat33Mul(const float A[9], const float B[9], float C[9]) {
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j)
+      C[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+}
+
+void ComputeRelativePose(const float R1[9], const float T1[3], const float R2[9], const float T2[3],
+                         float R[9], float T[3]) {
+  float R1t[9];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) R1t[3 * i + j] = R1[3 * j + i];
+  Mat33Mul(R2, R1t, R);
+  for (int i = 0; i < 3; ++i)
+    T[i] = T2[i] - (R[3 * i] * T1[0] + R[3 * i + 1] * T1[1] + R[3 * i + 2] * T1[2]);
+}
+
+void ComposeProjectionMatrix(const float K[9], const float R[9], const float T[3], float P[12]) {
+  float RT[12];
+  for (int i = 0; i < 3; ++i) {
+    RT[4 * i] = R[3 * i];
+    RT[4 * i + 1] = R[3 * i + 1];
+    RT[4 * i + 2] = R[3 * i + 2];
+    RT[4 * i + 3] = T[i];
+  }
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 4; ++j)
+      P[4 * i + j] = K[3 * i] * RT[j] + K[3 * i + 1] * RT[4 + j] + K[3 * i + 2] * RT[8 + j];
+}
+
+void ComposeInverseProjectionMatrix(const float K[9], const float R[9], const float T[3],
+                                    float inv_P[12]) {
+  float m[16];
+  ComposeProjectionMatrix(K, R, T, m);
+  m[12] = m[13] = m[14] = 0.0f;
+  m[15] = 1.0f;
+  // explicit cofactor table (general 4x4 inverse), term order fixed so that the
+  // result is a deterministic function of m
+  float inv[16];
+  inv[0] = m[5] * m[10] * m[15] - m[5] * m[11] * m[14] - m[9] * m[6] * m[15] + m[9] * m[7] * m[14] + m[13] * m[6] * m[11] - m[13] * m[7] * m[10];
+  inv[4] = -m[4] * m[10] * m[15] + m[4] * m[11] * m[14] + m[8] * m[6] * m[15] - m[8] * m[7] * m[14] - m[12] * m[6] * m[11] + m[12] * m[7] * m[10];
+  inv[8] = m[4] * m[9] * m[15] - m[4] * m[11] * m[13] - m[8] * m[5] * m[15] + m[8] * m[7] * m[13] + m[12] * m[5] * m[11] - m[12] * m[7] * m[9];
+  inv[12] = -m[4] * m[9] * m[14] + m[4] * m[10] * m[13] + m[8] * m[5] * m[14] - m[8] * m[6] * m[13] - m[12] * m[5] * m[10] + m[12] * m[6] * m[9];
+  inv[1] = -m[1] * m[10] * m[15] + m[1] * m[11] * m[14] + m[9] * m[2] * m[15] - m[9] * m[3] * m[14] - m[13] * m[2] * m[11] + m[13] * m[3] * m[10];
+  inv[5] = m[0] * m[10] * m[15] - m[0] * m[11] * m[14] - m[8] * m[2] * m[15] + m[8] * m[3] * m[14] + m[12] * m[2] * m[11] - m[12] * m[3] * m[10];
+  inv[9] = -m[0] * m[9] * m[15] + m[0] * m[11] * m[13] + m[8] * m[1] * m[15] - m[8] * m[3] * m[13] - m[12] * m[1] * m[11] + m[12] * m[3] * m[9];
+  inv[2] = m[1] * m[6] * m[15] - m[1] * m[7] * m[14] - m[5] * m[2] * m[15] + m[5] * m[3] * m[14] + m[13] * m[2] * m[7] - m[13] * m[3] * m[6];
+  inv[6] = -m[0] * m[6] * m[15] + m[0] * m[7] * m[14] + m[4] * m[2] * m[15] - m[4] * m[3] * m[14] - m[12] * m[2] * m[7] + m[12] * m[3] * m[6];
+  inv[10] = m[0] * m[5] * m[15] - m[0] * m[7] * m[13] - m[4] * m[1] * m[15] + m[4] * m[3] * m[13] + m[12] * m[1] * m[7] - m[12] * m[3] * m[5];
+  inv[3] = -m[1] * m[6] * m[11] + m[1] * m[7] * m[10] + m[5] * m[2] * m[11] - m[5] * m[3] * m[10] - m[9] * m[2] * m[7] + m[9] * m[3] * m[6];
+  inv[7] = m[0] * m[6] * m[11] - m[0] * m[7] * m[10] - m[4] * m[2] * m[11] + m[4] * m[3] * m[10] + m[8] * m[2] * m[7] - m[8] * m[3] * m[6];
+  inv[11] = -m[0] * m[5] * m[11] + m[0] * m[7] * m[9] + m[4] * m[1] * m[11] - m[4] * m[3] * m[9] - m[8] * m[1] * m[7] + m[8] * m[3] * m[5];
+  const float det = m[0] * inv[0] + m[1] * inv[4] + m[2] * inv[8] + m[3] * inv[12];
+  const float inv_det = 1.0f / det;
+  for (int i = 0; i < 12; ++i) inv_P[i] = inv[i] * inv_det;
+}
+
+void ComputeProjectionCenter(const float R[9], const float T[3], float C[3]) {
+  for (int i = 0; i < 3; ++i) C[i] = -(R[i] * T[0] + R[3 + i] * T[1] + R[6 + i] * T[2]);
+}
+
+void RotatePose(const float RR[9], float R[9], float T[3]) {
+  float Rn[9], Tn[3];
+  Mat33Mul(RR, R, Rn);
+  for (int i = 0; i < 3; ++i) Tn[i] = RR[3 * i] * T[0] + RR[3 * i + 1] * T[1] + RR[3 * i + 2] * T[2];
+  std::memcpy(R, Rn, sizeof(Rn));
+  std::memcpy(T, Tn, sizeof(Tn));
+}
+
+void CheckOptions(const pm_options& o) {
+  // PatchMatchOptions::Check, reference mvs/patch_match_options.cc:73-100
+  if (o.depth_min != -1.0f || o.depth_max != -1.0f) {
+    PM_CHECK(o.depth_min <= o.depth_max, "depth_min <= depth_max");
+    PM_CHECK(o.depth_min >= 0.0, "depth_min >= 0");
+  }
+  PM_CHECK(o.window_radius <= 32, "window_radius <= kMaxPatchMatchWindowRadius");
+  PM_CHECK(o.sigma_color > 0.0, "");
+  PM_CHECK(o.window_radius > 0, "");
+  PM_CHECK(o.window_step > 0, "");
+  PM_CHECK(o.window_step <= 2, "");
+  PM_CHECK(o.num_samples > 0, "");
+  PM_CHECK(o.ncc_sigma > 0.0, "");
+  PM_CHECK(o.min_triangulation_angle >= 0.0, "");
+  PM_CHECK(o.min_triangulation_angle < 180.0, "");
+  PM_CHECK(o.incident_angle_sigma > 0.0, "");
+  PM_CHECK(o.num_iterations > 0, "");
+  PM_CHECK(o.geom_consistency_regularizer >= 0.0, "");
+  PM_CHECK(o.geom_consistency_max_cost >= 0.0, "");
+  PM_CHECK(o.filter_min_ncc >= -1.0, "");
+  PM_CHECK(o.filter_min_ncc <= 1.0, "");
+  PM_CHECK(o.filter_min_triangulation_angle >= 0.0, "");
+  PM_CHECK(o.filter_min_triangulation_angle <= 180.0, "");
+  PM_CHECK(o.filter_min_num_consistent >= 0, "");
+  PM_CHECK(o.filter_geom_consistency_max_cost >= 0.0, "");
+  // the reference's kernel dispatch only instantiates radius 1..20 (patch_match_cuda.cu:1313-1337)
+  PM_CHECK(o.window_radius <= 20, "window size not supported (reference instantiates radius 1..20)");
+  PM_CHECK(o.sigma_spatial > 0.0,
+           "sigma_spatial must be resolved by the caller (PatchMatchController sets it to "
+           "window_radius, patch_match.cc:436-438)");
+  PM_CHECK(o.depth_min > 0.0 && o.depth_max > 0.0,
+           "depth range must be set (PatchMatchController::ProcessProblem, patch_match.cc:425-434)");
+}
+
+void CheckProblem(const pm_options& o, const pm_problem& p) {
+  // PatchMatch::Check, reference mvs/patch_match.cc:67-126
+  PM_CHECK(o.gpu_index >= -1, "gpu_index >= -1");
+  PM_CHECK(p.images != nullptr, "problem.images");
+  PM_CHECK(p.num_src_images > 0, "src_image_idxs.size() > 0");
+  PM_CHECK(p.src_image_idxs != nullptr, "src_image_idxs");
+  std::set<int> unique(p.src_image_idxs, p.src_image_idxs + p.num_src_images);
+  unique.insert(p.ref_image_idx);
+  PM_CHECK((int)unique.size() == p.num_src_images + 1,
+           "duplicate source images or reference image used as source");
+  for (int idx : unique) {
+    PM_CHECK(idx >= 0, "image_idx >= 0");
+    PM_CHECK(idx < p.num_images, "image_idx < images.size()");
+    const pm_image& im = p.images[idx];
+    PM_CHECK(im.width > 0 && im.height > 0, "bitmap size");
+    PM_CHECK(im.gray != nullptr, "grey bitmap");
+    PM_CHECK(std::abs(im.K[1] - 0.0f) < 1e-6f, "K[1]");
+    PM_CHECK(std::abs(im.K[3] - 0.0f) < 1e-6f, "K[3]");
+    PM_CHECK(std::abs(im.K[6] - 0.0f) < 1e-6f, "K[6]");
+    PM_CHECK(std::abs(im.K[7] - 0.0f) < 1e-6f, "K[7]");
+    PM_CHECK(std::abs(im.K[8] - 1.0f) < 1e-6f, "K[8]");
+    if (o.geom_consistency) PM_CHECK(im.depth_map != nullptr, "depth map for geom_consistency");
+  }
+  if (o.geom_consistency) {
+    PM_CHECK(p.images[p.ref_image_idx].normal_map != nullptr, "reference normal map");
+    PM_CHECK(p.images[p.ref_image_idx].depth_map != nullptr, "reference depth map");
+  }
+}
+
+}  // namespace
+
+struct pm_handle {
+  pm_options opt;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int W = 0, H = 0, S = 0, src_w = 0, src_h = 0;
+  std::vector<int> src_idxs;
+  // host pose tables
+  std::vector<float> poses_host;  // [4][S][43]
+  float ref_K[4][4], ref_inv_K[4][4];
+  // device buffers
+  DevBuf<float> rec;
+  DevBuf<uint32_t> src_fp;
+  DevBuf<float> src_depth;
+  DevBuf<uint8_t> ref_img;
+  DevBuf<float> ref_sum, ref_sqsum;
+  DevBuf<uint32_t> rng;
+  DevBuf<uint8_t> mask;
+  DevBuf<float> poses;  // [4][S][43]
+  DevBuf<float> out_depth, out_normal, out_sel, out_cost;
+  PmParams base;
+  int threads = 64;
+  int sweeps_done = 0;
+  int final_sel_off = 0;
+  bool ran = false;
+  std::vector<hipEvent_t> ev;
+  double sweep_ms = 0.0;
+  int sweep_launches = 0;
+
+  ~pm_handle() {
+    for (auto e : ev) (void)hipEventDestroy(e);
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+};
+
+namespace {
+
+void BuildPoseTables(pm_handle* h, const pm_problem& prob) {
+  // InitTransforms, reference patch_match_cuda.cu:1694-1808
+  const pm_image& ref = prob.images[prob.ref_image_idx];
+  for (int i = 0; i < 4; ++i) {
+    h->ref_K[i][0] = ref.K[0];
+    h->ref_K[i][1] = ref.K[2];
+    h->ref_K[i][2] = ref.K[4];
+    h->ref_K[i][3] = ref.K[5];
+  }
+  std::swap(h->ref_K[1][0], h->ref_K[1][2]);
+  std::swap(h->ref_K[1][1], h->ref_K[1][3]);
+  h->ref_K[1][3] = h->W - 1 - h->ref_K[1][3];
+  h->ref_K[2][1] = h->W - 1 - h->ref_K[2][1];
+  h->ref_K[2][3] = h->H - 1 - h->ref_K[2][3];
+  std::swap(h->ref_K[3][0], h->ref_K[3][2]);
+  std::swap(h->ref_K[3][1], h->ref_K[3][3]);
+  h->ref_K[3][1] = h->H - 1 - h->ref_K[3][1];
+  for (int i = 0; i < 4; ++i) {
+    h->ref_inv_K[i][0] = 1.0f / h->ref_K[i][0];
+    h->ref_inv_K[i][1] = -h->ref_K[i][1] / h->ref_K[i][0];
+    h->ref_inv_K[i][2] = 1.0f / h->ref_K[i][2];
+    h->ref_inv_K[i][3] = -h->ref_K[i][3] / h->ref_K[i][2];
+  }
+  float rotated_R[9], rotated_T[3];
+  std::memcpy(rotated_R, ref.R, sizeof(rotated_R));
+  std::memcpy(rotated_T, ref.T, sizeof(rotated_T));
+  const float R_z90[9] = {0, 1, 0, -1, 0, 0, 0, 0, 1};
+  h->poses_host.assign((size_t)4 * h->S * kPoseStride, 0.0f);
+  for (int i = 0; i < 4; ++i) {
+    for (int s = 0; s < h->S; ++s) {
+      const pm_image& im = prob.images[h->src_idxs[s]];
+      float* p = h->poses_host.data() + ((size_t)i * h->S + s) * kPoseStride;
+      p[0] = im.K[0]; p[1] = im.K[2]; p[2] = im.K[4]; p[3] = im.K[5];
+      float rel_R[9], rel_T[3];
+      ComputeRelativePose(rotated_R, rotated_T, im.R, im.T, rel_R, rel_T);
+      std::memcpy(p + 4, rel_R, sizeof(rel_R));
+      std::memcpy(p + 13, rel_T, sizeof(rel_T));
+      ComputeProjectionCenter(rel_R, rel_T, p + 16);
+      ComposeProjectionMatrix(im.K, rel_R, rel_T, p + 19);
+      ComposeInverseProjectionMatrix(im.K, rel_R, rel_T, p + 31);
+    }
+    RotatePose(R_z90, rotated_R, rotated_T);
+  }
+}
+
+PmParams ParamsForSweep(const pm_handle* h, int rot) {
+  PmParams p = h->base;
+  p.rot = rot;
+  for (int k = 0; k < 4; ++k) {
+    p.refK[k] = h->ref_K[rot][k];
+    p.refInvK[k] = h->ref_inv_K[rot][k];
+  }
+  p.poses = h->poses.ptr + (size_t)rot * h->S * kPoseStride;
+  return p;
+}
+
+void Create(const pm_options& opt_in, const pm_problem& prob, pm_handle* h) {
+  CheckOptions(opt_in);
+  CheckProblem(opt_in, prob);
+  h->opt = opt_in;
+  const pm_options& opt = h->opt;
+
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0)
+    throw PmError("no HIP device available: the MI355X PatchMatch path has no CPU fallback");
+  if (opt.gpu_index >= 0) {
+    PM_CHECK(opt.gpu_index < ndev, "gpu_index < device count");
+    h->device = opt.gpu_index;
+  } else {
+    HIP_CALL(hipGetDevice(&h->device));
+  }
+  HIP_CALL(hipSetDevice(h->device));
+  HIP_CALL(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+
+  const pm_image& ref = prob.images[prob.ref_image_idx];
+  h->W = ref.width;
+  h->H = ref.height;
+  h->S = prob.num_src_images;
+  h->src_idxs.assign(prob.src_image_idxs, prob.src_image_idxs + prob.num_src_images);
+  const int W = h->W, H = h->H, S = h->S;
+  const hipMemcpyKind in_kind = opt.inputs_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+
+  // ---- InitSourceImages (reference patch_match_cuda.cu:1595-1692) ------------------
+  for (int s = 0; s < S; ++s) {
+    const pm_image& im = prob.images[h->src_idxs[s]];
+    h->src_w = std::max(h->src_w, im.width);
+    h->src_h = std::max(h->src_h, im.height);
+  }
+  const size_t slot = (size_t)h->src_w * h->src_h;
+  {
+    DevBuf<uint8_t> staging;
+    staging.alloc(slot * S);
+    HIP_CALL(hipMemsetAsync(staging.ptr, 0, slot * S, h->stream));
+    for (int s = 0; s < S; ++s) {
+      const pm_image& im = prob.images[h->src_idxs[s]];
+      // contiguous copy into the max-size slot without re-pitching, exactly as the
+      // reference's memcpy (patch_match_cuda.cu:1617-1622)
+      HIP_CALL(hipMemcpyAsync(staging.ptr + slot * s, im.gray, (size_t)im.width * im.height, in_kind,
+                              h->stream));
+    }
+    h->src_fp.alloc((size_t)S * (h->src_w + 3) * (h->src_h + 3));
+    pm_launch_build_footprint(staging.ptr, h->src_fp.ptr, S, h->src_w, h->src_h, h->stream);
+    HIP_CALL(hipStreamSynchronize(h->stream));
+  }
+  if (opt.geom_consistency) {
+    h->src_depth.alloc(slot * S);
+    HIP_CALL(hipMemsetAsync(h->src_depth.ptr, 0, slot * S * sizeof(float), h->stream));
+    for (int s = 0; s < S; ++s) {
+      const pm_image& im = prob.images[h->src_idxs[s]];
+      // row copy into the padded slot (patch_match_cuda.cu:1668-1673)
+      HIP_CALL(hipMemcpy2DAsync(h->src_depth.ptr + slot * s, (size_t)h->src_w * sizeof(float),
+                                im.depth_map, (size_t)im.width * sizeof(float),
+                                (size_t)im.width * sizeof(float), im.height, in_kind, h->stream));
+    }
+  }
+
+  // ---- InitRefImage (reference :1578-1593) ---------------------------------------
+  h->ref_img.alloc((size_t)W * H);
+  h->ref_sum.alloc((size_t)W * H);
+  h->ref_sqsum.alloc((size_t)W * H);
+  {
+    DevBuf<uint8_t> gray;
+    gray.alloc((size_t)W * H);
+    HIP_CALL(hipMemcpyAsync(gray.ptr, ref.gray, (size_t)W * H, in_kind, h->stream));
+    pm_launch_filter_ref(gray.ptr, W, H, opt.window_radius, opt.window_step, (float)opt.sigma_spatial,
+                         (float)opt.sigma_color, h->ref_img.ptr, h->ref_sum.ptr, h->ref_sqsum.ptr,
+                         h->stream);
+    HIP_CALL(hipStreamSynchronize(h->stream));
+  }
+
+  // ---- InitTransforms -------------------------------------------------------------
+  BuildPoseTables(h, prob);
+  h->poses.alloc(h->poses_host.size());
+  HIP_CALL(hipMemcpyAsync(h->poses.ptr, h->poses_host.data(), h->poses_host.size() * sizeof(float),
+                          hipMemcpyHostToDevice, h->stream));
+
+  // ---- InitWorkspaceMemory (reference :1810-1857) ---------------------------------
+  PmParams& b = h->base;
+  std::memset(&b, 0, sizeof(b));
+  b.W = W; b.H = H; b.S = S; b.src_w = h->src_w; b.src_h = h->src_h;
+  b.radius = opt.window_radius;
+  b.step = opt.window_step;
+  b.ntap1d = (2 * b.radius) / b.step + 1;
+  b.ntaps = b.ntap1d * b.ntap1d;
+  b.num_samples = opt.num_samples;
+  b.rec_stride = 4 + 3 * S;
+  b.sel_out_off = 4 + S;       // sweep 0 writes half A ...
+  b.sel_in_off = 4 + 2 * S;    // ... and reads half B (= 0.5)
+  b.C = pm_pick_columns(S, b.ntaps, b.num_samples, opt.geom_consistency != 0, b.radius,
+                        opt.columns_per_group);
+  h->threads = opt.threads_per_group > 0 ? ((opt.threads_per_group + 63) / 64) * 64 : 64;
+  h->threads = std::min(h->threads, 256);  // pm_sweep_kernel __launch_bounds__
+  // SweepOptions (reference :1420-1438); doubles narrowed to float where the reference does
+  const float sigma_spatial = (float)opt.sigma_spatial;
+  const float sigma_color = (float)opt.sigma_color;
+  b.spatial_norm = 1.0f / (2.0f * sigma_spatial * sigma_spatial);
+  b.color_norm = 1.0f / (2.0f * sigma_color * sigma_color);
+  const float ncc_sigma = (float)opt.ncc_sigma;
+  const float min_tri = (float)(opt.min_triangulation_angle * 0.0174532925199432);
+  const float inc_sigma = (float)opt.incident_angle_sigma;
+  // LikelihoodComputer ctor (reference :700-707, 796-802)
+  b.cos_min_tri = std::cos(min_tri);
+  b.inv_inc_sigma_sq = -0.5f / (inc_sigma * inc_sigma);
+  b.inv_ncc_sigma_sq = -0.5f / (ncc_sigma * ncc_sigma);
+  b.ncc_norm = (float)(2.0f / (std::sqrt(2.0f * M_PI) * ncc_sigma *
+                               erff(2.0f / (ncc_sigma * 1.414213562f))));
+  b.geom_reg = (float)opt.geom_consistency_regularizer;
+  b.geom_max_cost = (float)opt.geom_consistency_max_cost;
+  b.filter_min_ncc = (float)opt.filter_min_ncc;
+  b.filter_cos_min_tri =
+      std::cos((float)(opt.filter_min_triangulation_angle * 0.0174532925199432));
+  b.filter_geom_max_cost = (float)opt.filter_geom_consistency_max_cost;
+  b.filter_min_num_consistent = opt.filter_min_num_consistent;
+
+  h->rec.alloc((size_t)W * H * b.rec_stride);
+  h->rng.alloc((size_t)W * H * kRngWords);
+  b.rec = h->rec.ptr;
+  b.src_fp = h->src_fp.ptr;
+  b.src_depth = h->src_depth.ptr;
+  b.ref_img = h->ref_img.ptr;
+  b.ref_sum = h->ref_sum.ptr;
+  b.ref_sqsum = h->ref_sqsum.ptr;
+  b.rng = h->rng.ptr;
+  b.mask = nullptr;
+
+  PmParams p0 = ParamsForSweep(h, 0);
+  if (opt.geom_consistency) {
+    DevBuf<float> d, n;
+    d.alloc((size_t)W * H);
+    n.alloc((size_t)3 * W * H);
+    HIP_CALL(hipMemcpyAsync(d.ptr, ref.depth_map, (size_t)W * H * sizeof(float), in_kind, h->stream));
+    HIP_CALL(hipMemcpyAsync(n.ptr, ref.normal_map, (size_t)3 * W * H * sizeof(float), in_kind,
+                            h->stream));
+    pm_launch_init_state(p0, false, 0.0f, 0.0f, d.ptr, n.ptr, h->stream);
+    HIP_CALL(hipStreamSynchronize(h->stream));
+  } else {
+    pm_launch_init_state(p0, true, (float)opt.depth_min, (float)opt.depth_max, nullptr, nullptr,
+                         h->stream);
+  }
+  if (opt.filter) {
+    h->mask.alloc((size_t)S * W * H);
+    b.mask = h->mask.ptr;
+  }
+  h->out_depth.alloc((size_t)W * H);
+  h->out_normal.alloc((size_t)3 * W * H);
+  h->out_sel.alloc((size_t)S * W * H);
+  h->out_cost.alloc((size_t)S * W * H);
+  const int total_sweeps = opt.num_iterations * 4;
+  h->ev.resize((size_t)2 * total_sweeps);
+  for (auto& e2 : h->ev) HIP_CALL(hipEventCreate(&e2));
+  HIP_CALL(hipGetLastError());
+  HIP_CALL(hipStreamSynchronize(h->stream));
+}
+
+// RunWithWindowSizeAndStep, reference patch_match_cuda.cu:1393-1546
+void RunAsync(pm_handle* h) {
+  HIP_CALL(hipSetDevice(h->device));
+  const pm_options& opt = h->opt;
+  PmParams p0 = ParamsForSweep(h, 0);
+  pm_launch_initial_cost(p0, h->stream);
+
+  const float total_num_steps = (float)(opt.num_iterations * 4);
+  int sweeps = 0;
+  int sel_out = h->base.sel_out_off, sel_in = h->base.sel_in_off;
+  const int limit = opt.max_sweeps > 0 ? opt.max_sweeps : (opt.max_sweeps < 0 ? 0 : opt.num_iterations * 4);
+  if (h->mask.ptr) HIP_CALL(hipMemsetAsync(h->mask.ptr, 0, h->mask.count, h->stream));
+  for (int iter = 0; iter < opt.num_iterations && sweeps < limit; ++iter) {
+    for (int sweep = 0; sweep < 4 && sweeps < limit; ++sweep) {
+      const int rot = (iter * 4 + sweep) % 4;
+      PmParams p = ParamsForSweep(h, rot);
+      p.perturbation = 1.0f / std::pow(2.0f, iter + sweep / 4.0f);
+      p.perturbation_pi = (float)(p.perturbation * M_PI);
+      p.prev_sel_prob_weight = (float)(iter * 4 + sweep) / total_num_steps;
+      p.sel_out_off = sel_out;
+      p.sel_in_off = sel_in;
+      const bool last_sweep = iter == opt.num_iterations - 1 && sweep == 3;
+      const bool geom = opt.geom_consistency != 0;
+      const bool fphoto = last_sweep && opt.filter;
+      const bool fgeom = last_sweep && opt.filter && geom;
+      HIP_CALL(hipEventRecord(h->ev[2 * sweeps], h->stream));
+      pm_launch_sweep(p, h->threads, geom, fphoto, fgeom, h->stream);
+      HIP_CALL(hipEventRecord(h->ev[2 * sweeps + 1], h->stream));
+      std::swap(sel_out, sel_in);  // Rotate(): prev_sel_prob <- sel_prob (reference :1911-1915)
+      ++sweeps;
+    }
+  }
+  h->sweeps_done = sweeps;
+  h->final_sel_off = sel_in;  // the half written by the last sweep
+  PmParams pe = ParamsForSweep(h, 0);
+  pm_launch_extract(pe, h->final_sel_off, h->out_depth.ptr, h->out_normal.ptr, h->out_sel.ptr,
+                    h->out_cost.ptr, h->stream);
+  HIP_CALL(hipGetLastError());
+  h->ran = true;
+}
+
+void Synchronize(pm_handle* h) {
+  HIP_CALL(hipSetDevice(h->device));
+  HIP_CALL(hipStreamSynchronize(h->stream));
+  h->sweep_ms = 0.0;
+  h->sweep_launches = h->sweeps_done;
+  for (int i = 0; i < h->sweeps_done; ++i) {
+    float ms = 0.0f;
+    HIP_CALL(hipEventElapsedTime(&ms, h->ev[2 * i], h->ev[2 * i + 1]));
+    h->sweep_ms += ms;
+  }
+}
+
+template <typename T>
+void CopyOut(pm_handle* h, const T* dev, T* out, size_t n) {
+  PM_CHECK(h->ran, "pm_run must be called first");
+  HIP_CALL(hipSetDevice(h->device));
+  HIP_CALL(hipMemcpyAsync(out, dev, n * sizeof(T), hipMemcpyDeviceToHost, h->stream));
+  HIP_CALL(hipStreamSynchronize(h->stream));
+}
+
+template <typename F>
+int Guard(F&& f) {
+  try {
+    f();
+    return 0;
+  } catch (const std::exception& e) {
+    g_last_error = e.what();
+    return 1;
+  } catch (...) {
+    g_last_error = "unknown error";
+    return 2;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+void pm_options_init(pm_options* o) {
+  // reference mvs/patch_match_options.h:37-126 (float literals narrowed like the source)
+  std::memset(o, 0, sizeof(*o));
+  o->depth_min = -1.0f;
+  o->depth_max = -1.0f;
+  o->sigma_spatial = -1;
+  o->sigma_color = 0.2f;
+  o->ncc_sigma = 0.6f;
+  o->min_triangulation_angle = 1.0f;
+  o->incident_angle_sigma = 0.9f;
+  o->geom_consistency_regularizer = 0.3f;
+  o->geom_consistency_max_cost = 3.0f;
+  o->filter_min_ncc = 0.1f;
+  o->filter_min_triangulation_angle = 3.0f;
+  o->filter_geom_consistency_max_cost = 1.0f;
+  o->window_radius = 5;
+  o->window_step = 1;
+  o->num_samples = 15;
+  o->num_iterations = 5;
+  o->filter_min_num_consistent = 2;
+  o->geom_consistency = 1;
+  o->filter = 1;
+  o->gpu_index = -1;
+}
+
+int pm_check(const pm_options* options, const pm_problem* problem) {
+  return Guard([&] {
+    PM_CHECK(options && problem, "null argument");
+    CheckOptions(*options);
+    CheckProblem(*options, *problem);
+  });
+}
+
+int pm_create(const pm_options* options, const pm_problem* problem, pm_handle** out) {
+  if (out) *out = nullptr;
+  pm_handle* h = nullptr;
+  const int rc = Guard([&] {
+    PM_CHECK(options && problem && out, "null argument");
+    h = new pm_handle();
+    Create(*options, *problem, h);
+  });
+  if (rc != 0) {
+    delete h;
+    return rc;
+  }
+  *out = h;
+  return 0;
+}
+
+int pm_run_async(pm_handle* h) {
+  return Guard([&] {
+    PM_CHECK(h, "null handle");
+    RunAsync(h);
+  });
+}
+
+int pm_synchronize(pm_handle* h) {
+  return Guard([&] {
+    PM_CHECK(h, "null handle");
+    Synchronize(h);
+  });
+}
+
+int pm_run(pm_handle* h) {
+  return Guard([&] {
+    PM_CHECK(h, "null handle");
+    RunAsync(h);
+    Synchronize(h);
+  });
+}
+
+int pm_get_depth_map(pm_handle* h, float* out) {
+  return Guard([&] { PM_CHECK(h && out, "null"); CopyOut(h, h->out_depth.ptr, out, (size_t)h->W * h->H); });
+}
+int pm_get_normal_map(pm_handle* h, float* out) {
+  return Guard([&] { PM_CHECK(h && out, "null"); CopyOut(h, h->out_normal.ptr, out, (size_t)3 * h->W * h->H); });
+}
+int pm_get_sel_prob_map(pm_handle* h, float* out) {
+  return Guard([&] { PM_CHECK(h && out, "null"); CopyOut(h, h->out_sel.ptr, out, (size_t)h->S * h->W * h->H); });
+}
+int pm_get_cost_map(pm_handle* h, float* out) {
+  return Guard([&] { PM_CHECK(h && out, "null"); CopyOut(h, h->out_cost.ptr, out, (size_t)h->S * h->W * h->H); });
+}
+
+int pm_get_consistency_mask(pm_handle* h, uint8_t* out) {
+  return Guard([&] {
+    PM_CHECK(h && out, "null");
+    const size_t n = (size_t)h->S * h->W * h->H;
+    if (h->mask.ptr) CopyOut(h, h->mask.ptr, out, n);
+    else std::memset(out, 0, n);
+  });
+}
+
+int pm_get_consistent_image_idxs(pm_handle* h, int32_t* buf, size_t capacity, size_t* count) {
+  // GetConsistentImageIdxs, reference patch_match_cuda.cu:1367-1391
+  return Guard([&] {
+    PM_CHECK(h && count, "null");
+    const size_t n = (size_t)h->S * h->W * h->H;
+    std::vector<uint8_t> mask(n, 0);
+    if (h->mask.ptr) CopyOut(h, h->mask.ptr, mask.data(), n);
+    std::vector<int32_t> out;
+    std::vector<int32_t> pix;
+    for (int r = 0; r < h->H; ++r) {
+      for (int c = 0; c < h->W; ++c) {
+        pix.clear();
+        for (int d = 0; d < h->S; ++d)
+          if (mask[((size_t)d * h->H + r) * h->W + c]) pix.push_back(h->src_idxs[d]);
+        if (!pix.empty()) {
+          out.push_back(c);
+          out.push_back(r);
+          out.push_back((int32_t)pix.size());
+          out.insert(out.end(), pix.begin(), pix.end());
+        }
+      }
+    }
+    *count = out.size();
+    if (buf) {
+      PM_CHECK(capacity >= out.size(), "buffer too small");
+      std::memcpy(buf, out.data(), out.size() * sizeof(int32_t));
+    }
+  });
+}
+
+int pm_get_ref_filter(pm_handle* h, uint8_t* image, float* sum, float* sqsum) {
+  return Guard([&] {
+    PM_CHECK(h, "null");
+    HIP_CALL(hipSetDevice(h->device));
+    const size_t n = (size_t)h->W * h->H;
+    if (image) HIP_CALL(hipMemcpy(image, h->ref_img.ptr, n, hipMemcpyDeviceToHost));
+    if (sum) HIP_CALL(hipMemcpy(sum, h->ref_sum.ptr, n * sizeof(float), hipMemcpyDeviceToHost));
+    if (sqsum) HIP_CALL(hipMemcpy(sqsum, h->ref_sqsum.ptr, n * sizeof(float), hipMemcpyDeviceToHost));
+  });
+}
+
+int pm_get_pose_tables(pm_handle* h, float* poses, float* ref_K, float* ref_inv_K) {
+  return Guard([&] {
+    PM_CHECK(h, "null");
+    if (poses) std::memcpy(poses, h->poses_host.data(), h->poses_host.size() * sizeof(float));
+    if (ref_K) std::memcpy(ref_K, h->ref_K, sizeof(h->ref_K));
+    if (ref_inv_K) std::memcpy(ref_inv_K, h->ref_inv_K, sizeof(h->ref_inv_K));
+  });
+}
+
+int pm_get_sweep_timing(pm_handle* h, double* total_ms, int32_t* num_launches) {
+  return Guard([&] {
+    PM_CHECK(h, "null");
+    if (total_ms) *total_ms = h->sweep_ms;
+    if (num_launches) *num_launches = h->sweep_launches;
+  });
+}
+
+int pm_get_device_maps(pm_handle* h, const float** depth, const float** normal) {
+  return Guard([&] {
+    PM_CHECK(h && h->ran, "run first");
+    if (depth) *depth = h->out_depth.ptr;
+    if (normal) *normal = h->out_normal.ptr;
+  });
+}
+
+void pm_destroy(pm_handle* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  delete h;
+}
+
+const char* pm_last_error(void) { return g_last_error.c_str(); }
+
+int pm_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+}  // extern "C"

@@ -1,0 +1,66 @@
+// Internal interface between the C-ABI host code (pm_api.cpp) and the gfx950
+// kernels (pm_kernels.hip). Not installed.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace colmap_amd {
+
+constexpr int kPoseStride = 43;  // K4 R9 T3 C3 P12 invP12 (reference patch_match_cuda.cu:1762)
+constexpr int kRngWords = 6;     // XORWOW: x[5] + d
+
+// Per-sweep kernel parameters (reference SweepOptions, patch_match_cuda.cu:914-931,
+// plus the geometry of the virtual rotation).
+struct PmParams {
+  // geometry
+  int W, H;         // un-rotated reference image size
+  int rot;          // number of 90-degree CCW rotations of the sweep frame (0..3)
+  int S;            // number of source images
+  int src_w, src_h; // source slot size (max over sources)
+  int radius, step, ntap1d, ntaps;
+  int num_samples;
+  int rec_stride;   // floats per pixel record: 4 + 3*S
+  int sel_in_off;   // record offset of prev_sel_prob (read)
+  int sel_out_off;  // record offset of sel_prob (backward msgs, then written)
+  int C;            // image columns per workgroup
+  float refK[4];    // rotated {fx, cx, fy, cy}
+  float refInvK[4]; // rotated {1/fx, -cx/fx, 1/fy, -cy/fy}
+  float perturbation;
+  float perturbation_pi;
+  float prev_sel_prob_weight;
+  float spatial_norm, color_norm;
+  float cos_min_tri, inv_inc_sigma_sq, inv_ncc_sigma_sq, ncc_norm;
+  float geom_reg, geom_max_cost;
+  float filter_min_ncc;
+  float filter_cos_min_tri;
+  float filter_geom_max_cost;
+  int filter_min_num_consistent;
+  // device pointers
+  float* rec;               // [H*W][rec_stride]
+  const uint32_t* src_fp;   // [S][src_h+3][src_w+3] packed 2x2 footprints
+  const float* src_depth;   // [S][src_h][src_w] or null
+  const uint8_t* ref_img;   // [H][W]
+  const float* ref_sum;     // [H][W]
+  const float* ref_sqsum;   // [H][W]
+  uint32_t* rng;            // [H*W][6]
+  uint8_t* mask;            // [S][H][W] or null
+  const float* poses;       // [S][43] for this rotation
+};
+
+size_t pm_sweep_lds_bytes(const PmParams& p, bool geom);
+int pm_pick_columns(int S, int ntaps, int num_samples, bool geom, int radius, int requested);
+
+void pm_launch_build_footprint(const uint8_t* src, uint32_t* fp, int S, int w, int h, hipStream_t st);
+void pm_launch_filter_ref(const uint8_t* gray, int W, int H, int radius, int step, float sigma_spatial,
+                          float sigma_color, uint8_t* out_img, float* out_sum, float* out_sqsum,
+                          hipStream_t st);
+void pm_launch_init_state(const PmParams& p, bool random_init, float depth_min, float depth_max,
+                          const float* init_depth, const float* init_normal, hipStream_t st);
+void pm_launch_initial_cost(const PmParams& p, hipStream_t st);
+void pm_launch_sweep(const PmParams& p, int threads, bool geom, bool filter_photo, bool filter_geom,
+                     hipStream_t st);
+void pm_launch_extract(const PmParams& p, int sel_off, float* depth, float* normal, float* sel,
+                       float* cost, hipStream_t st);
+
+}  // namespace colmap_amd

@@ -1,0 +1,1067 @@
+// pm_kernels.hip -- gfx950 (MI355X / CDNA4) PatchMatch multi-view-stereo kernels.
+//
+// What the reference computes: src/colmap/mvs/patch_match_cuda.cu (one CUDA
+// thread per image column, 32-thread blocks, every buffer physically rotated by
+// 90 degrees between sweeps). How it is computed here is different by design:
+//
+//  * A workgroup owns C adjacent image columns of the (virtually rotated) sweep
+//    frame and walks them row by row. Inside one row step the independent pieces
+//    of work -- per-view priors (C*S items) and the bilaterally weighted NCC
+//    evaluations (up to C*4*min(M,S) + C*S items) -- are spread over all lanes of
+//    the workgroup through an LDS task list, so the 64-wide wavefronts stay
+//    densely packed although the algorithm is sequential along a column.
+//  * Identical NCC evaluations inside a row step (the same hypothesis/view pair
+//    drawn by several Monte-Carlo samples, patch_match_cuda.cu:1128-1172, and the
+//    re-evaluation of the winner, :1188-1197) are computed once. The 121
+//    bilateral weights of the reference patch (recomputed per evaluation by the
+//    reference, :538-539) are computed once per row step into LDS.
+//  * No buffer is ever rotated (reference Rotate(), :1859-1939, ~470 B/pixel/sweep
+//    of pure HBM traffic): the sweep frame is a coordinate transform. Per-pixel
+//    state is one contiguous record {depth, normal, cost[S], selA[S], selB[S]} so
+//    that every sweep direction touches whole cache lines.
+//  * Source images are stored as packed 2x2 bilinear footprints with a zero
+//    border ring: one aligned 4-byte gather per tap instead of four byte
+//    gathers plus bounds checks (gfx9 has no linear-filtered layered textures,
+//    patch_match_cuda.cu:416-425).
+//
+// Arithmetic is specified in oracle/pm_oracle.c (header) and implemented here
+// independently; compile with -ffp-contract=off.
+#include "pm_internal.h"
+
+#include <float.h>
+#include <math.h>
+
+namespace colmap_amd {
+
+// ---------------------------------------------------------------------------
+// Scalar helpers (arithmetic spec)
+// ---------------------------------------------------------------------------
+
+__device__ __forceinline__ float pm_exp(float x) {
+  if (!(x >= -87.0f)) {
+    if (x != x) return x;
+    return 0.0f;
+  }
+  if (x > 88.0f) x = 88.0f;
+  const float n = rintf(x * 1.44269504088896341f);
+  float r = fmaf(n, -0.693359375f, x);
+  r = fmaf(n, 2.12194440e-4f, r);
+  float p = 1.9875691500e-4f;
+  p = fmaf(p, r, 1.3981999507e-3f);
+  p = fmaf(p, r, 8.3334519073e-3f);
+  p = fmaf(p, r, 4.1665795894e-2f);
+  p = fmaf(p, r, 1.6666665459e-1f);
+  p = fmaf(p, r, 5.0000001201e-1f);
+  const float r2 = r * r;
+  const float y = fmaf(p, r2, r) + 1.0f;
+  const int ni = (int)n;
+  return y * __uint_as_float((unsigned)(ni + 127) << 23);
+}
+
+__device__ __forceinline__ void pm_sincos(float a, float* s_out, float* c_out) {
+  const float q = rintf(a * 0.636619772367581343f);
+  float r = fmaf(q, -1.5703125f, a);
+  r = fmaf(q, -4.837512969970703125e-4f, r);
+  r = fmaf(q, -7.54978995489188216e-8f, r);
+  const float z = r * r;
+  float sp = -1.9515295891e-4f;
+  sp = fmaf(sp, z, 8.3321608736e-3f);
+  sp = fmaf(sp, z, -1.6666654611e-1f);
+  const float sv = fmaf(sp * z, r, r);
+  float cp = 2.443315711809948e-5f;
+  cp = fmaf(cp, z, -1.388731625493765e-3f);
+  cp = fmaf(cp, z, 4.166664568298827e-2f);
+  const float cv = fmaf(cp * z, z, fmaf(-0.5f, z, 1.0f));
+  const int qi = ((int)q) & 3;
+  const float s = (qi == 0) ? sv : (qi == 1) ? cv : (qi == 2) ? -sv : -cv;
+  const float c = (qi == 0) ? cv : (qi == 1) ? -sv : (qi == 2) ? -cv : sv;
+  *s_out = s;
+  *c_out = c;
+}
+
+__device__ __forceinline__ float pm_rsqrt(float x) { return 1.0f / sqrtf(x); }
+
+// (float)b / 255.0f for an integer-valued b in [0,255], exactly, in three VALU ops.
+__device__ __forceinline__ float texel_norm(float b) {
+  const float r = 0x1.010102p-8f;
+  const float q = b * r;
+  const float e = fmaf(-255.0f, q, b);
+  return fmaf(e, r, q);
+}
+
+struct Rng {
+  uint32_t x0, x1, x2, x3, x4, d;
+};
+
+__device__ __forceinline__ void rng_init(Rng& st, unsigned long long seed) {
+  st.x0 = 123456789U; st.x1 = 362436069U; st.x2 = 521288629U; st.x3 = 88675123U;
+  st.x4 = 5783321U; st.d = 6615241U;
+  const uint32_t s0 = (uint32_t)seed ^ 0x2c7f967fU;
+  const uint32_t s1 = (uint32_t)(seed >> 32) ^ 0xa03697cbU;
+  const uint32_t t0 = 1228688033U * s0;
+  const uint32_t t1 = 2073658381U * s1;
+  st.x0 += t0; st.x1 ^= t0; st.x2 += t1; st.x3 ^= t1; st.x4 += t0;
+  st.d += t1 + t0;
+}
+
+__device__ __forceinline__ float rng_uniform(Rng& st) {
+  const uint32_t t = st.x0 ^ (st.x0 >> 2);
+  st.x0 = st.x1; st.x1 = st.x2; st.x2 = st.x3; st.x3 = st.x4;
+  st.x4 = (st.x4 ^ (st.x4 << 4)) ^ (t ^ (t << 1));
+  st.d += 362437U;
+  const uint32_t v = st.d + st.x4;
+  return 2.3283064e-10f + ((float)v * 2.3283064e-10f);
+}
+
+__device__ __forceinline__ Rng rng_load(const uint32_t* p) {
+  Rng r; r.x0 = p[0]; r.x1 = p[1]; r.x2 = p[2]; r.x3 = p[3]; r.x4 = p[4]; r.d = p[5]; return r;
+}
+__device__ __forceinline__ void rng_store(uint32_t* p, const Rng& r) {
+  p[0] = r.x0; p[1] = r.x1; p[2] = r.x2; p[3] = r.x3; p[4] = r.x4; p[5] = r.d;
+}
+
+// ---------------------------------------------------------------------------
+// Virtual rotation: sweep-frame (row, col) -> un-rotated pixel index.
+// Equivalent to applying CudaRotateKernel (reference cuda_rotate.h:57-75)
+// `rot` times: rot 1: x = W-1-row, y = col; rot 2: y = H-1-row, x = W-1-col;
+// rot 3: x = row, y = H-1-col.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int rot_width(const PmParams& p) { return (p.rot & 1) ? p.H : p.W; }
+__device__ __forceinline__ int rot_height(const PmParams& p) { return (p.rot & 1) ? p.W : p.H; }
+
+__device__ __forceinline__ int pix_index(const PmParams& p, int row, int col) {
+  int x, y;
+  switch (p.rot) {
+    case 0: x = col; y = row; break;
+    case 1: x = p.W - 1 - row; y = col; break;
+    case 2: x = p.W - 1 - col; y = p.H - 1 - row; break;
+    default: x = row; y = p.H - 1 - col; break;
+  }
+  return y * p.W + x;
+}
+
+// normals are stored in the un-rotated frame; RotateNormalMap (reference
+// patch_match_cuda.cu:849-861) applied `rot` times is a signed swap (exact).
+__device__ __forceinline__ void normal_to_sweep(int rot, float nx, float ny, float& ox, float& oy) {
+  switch (rot) {
+    case 0: ox = nx; oy = ny; break;
+    case 1: ox = ny; oy = -nx; break;
+    case 2: ox = -nx; oy = -ny; break;
+    default: ox = -ny; oy = nx; break;
+  }
+}
+__device__ __forceinline__ void normal_from_sweep(int rot, float sx, float sy, float& nx, float& ny) {
+  switch (rot) {
+    case 0: nx = sx; ny = sy; break;
+    case 1: nx = -sy; ny = sx; break;
+    case 2: nx = -sx; ny = -sy; break;
+    default: nx = sy; ny = -sx; break;
+  }
+}
+
+// reference-image texel in the sweep frame: point fetch, border 0, /255
+__device__ __forceinline__ float ref_texel(const PmParams& p, int row, int col) {
+  if (row < 0 || col < 0 || row >= rot_height(p) || col >= rot_width(p)) return 0.0f;
+  return texel_norm((float)p.ref_img[pix_index(p, row, col)]);
+}
+
+// ---------------------------------------------------------------------------
+// Geometry (restating patch_match_cuda.cu device functions)
+// ---------------------------------------------------------------------------
+
+__device__ __forceinline__ float dot3(float a0, float a1, float a2, float b0, float b1, float b2) {
+  return a0 * b0 + a1 * b1 + a2 * b2;
+}
+
+// ComposeHomography, patch_match_cuda.cu:271-332
+__device__ __forceinline__ void compose_homography(const float* iK, const float* pose, int row,
+                                                   int col, float depth, float n0, float n1,
+                                                   float n2, float H[9]) {
+  const float* K = pose;
+  const float* R = pose + 4;
+  const float* T = pose + 13;
+  const float dist = depth * (n0 * (iK[0] * col + iK[1]) + n1 * (iK[2] * row + iK[3]) + n2);
+  const float inv_dist = 1.0f / dist;
+  const float N0 = inv_dist * n0;
+  const float N1 = inv_dist * n1;
+  const float N2 = inv_dist * n2;
+  H[0] = iK[0] * (K[0] * (R[0] + N0 * T[0]) + K[1] * (R[6] + N0 * T[2]));
+  H[1] = iK[2] * (K[0] * (R[1] + N1 * T[0]) + K[1] * (R[7] + N1 * T[2]));
+  H[2] = K[0] * (R[2] + N2 * T[0]) + K[1] * (R[8] + N2 * T[2]) +
+         iK[1] * (K[0] * (R[0] + N0 * T[0]) + K[1] * (R[6] + N0 * T[2])) +
+         iK[3] * (K[0] * (R[1] + N1 * T[0]) + K[1] * (R[7] + N1 * T[2]));
+  H[3] = iK[0] * (K[2] * (R[3] + N0 * T[1]) + K[3] * (R[6] + N0 * T[2]));
+  H[4] = iK[2] * (K[2] * (R[4] + N1 * T[1]) + K[3] * (R[7] + N1 * T[2]));
+  H[5] = K[2] * (R[5] + N2 * T[1]) + K[3] * (R[8] + N2 * T[2]) +
+         iK[1] * (K[2] * (R[3] + N0 * T[1]) + K[3] * (R[6] + N0 * T[2])) +
+         iK[3] * (K[2] * (R[4] + N1 * T[1]) + K[3] * (R[7] + N1 * T[2]));
+  H[6] = iK[0] * (R[6] + N0 * T[2]);
+  H[7] = iK[2] * (R[7] + N1 * T[2]);
+  H[8] = R[8] + iK[1] * (R[6] + N0 * T[2]) + iK[3] * (R[7] + N1 * T[2]) + N2 * T[2];
+}
+
+// BilateralWeightComputer::Compute, gpu_mat_ref_image.h:70-90
+__device__ __forceinline__ float bilateral_weight(float spatial_norm, float color_norm,
+                                                  float row_diff, float col_diff, float c1,
+                                                  float c2) {
+  const float sds = row_diff * row_diff + col_diff * col_diff;
+  const float cd = c1 - c2;
+  return pm_exp(-sds * spatial_norm - cd * cd * color_norm);
+}
+
+// PhotoConsistencyCostComputer::Compute, patch_match_cuda.cu:489-593. `wr` holds
+// (bilateral weight, reference colour) per tap in row-major window order (LDS).
+__device__ __forceinline__ float ncc_eval(const PmParams& p, const float* pose,
+                                          const uint32_t* __restrict__ fp, const float2* wr,
+                                          int row, int col, float depth, float n0, float n1,
+                                          float n2, float ref_sum, float ref_sqsum) {
+  float tf[9];
+  compose_homography(p.refInvK, pose, row, col, depth, n0, n1, n2, tf);
+  const float fstep = (float)p.step;
+  const float st0 = fstep * tf[0], st1 = fstep * tf[1], st3 = fstep * tf[3], st4 = fstep * tf[4],
+              st6 = fstep * tf[6], st7 = fstep * tf[7];
+  const int row_start = row - p.radius;
+  const int col_start = col - p.radius;
+  float col_src = tf[0] * col_start + tf[1] * row_start + tf[2];
+  float row_src = tf[3] * col_start + tf[4] * row_start + tf[5];
+  float z = tf[6] * col_start + tf[7] * row_start + tf[8];
+  float base_col = col_src, base_row = row_src, base_z = z;
+  float s_sum = 0.0f, s_sq = 0.0f, s_ref = 0.0f, w_sum = 0.0f;
+  const int fpw = p.src_w + 3;
+  const int n1d = p.ntap1d;
+  int tap = 0;
+  for (int wrow = 0; wrow < n1d; ++wrow) {
+    for (int wcol = 0; wcol < n1d; ++wcol, ++tap) {
+      const float inv_z = 1.0f / z;
+      const float x = fmaf(inv_z, col_src, 0.5f);
+      const float y = fmaf(inv_z, row_src, 0.5f);
+      // SampleLayeredBilinear, patch_match_cuda.cu:426-442
+      const float px = x - 0.5f;
+      const float py = y - 0.5f;
+      const float fx = floorf(px);
+      const float fy = floorf(py);
+      const float wx = px - fx;
+      const float wy = py - fy;
+      int ix = (int)fx;
+      int iy = (int)fy;
+      ix = min(max(ix, -2), p.src_w);
+      iy = min(max(iy, -2), p.src_h);
+      const uint32_t t = fp[(iy + 2) * fpw + (ix + 2)];
+      const float c00 = texel_norm((float)(t & 0xffu));
+      const float c10 = texel_norm((float)((t >> 8) & 0xffu));
+      const float c01 = texel_norm((float)((t >> 16) & 0xffu));
+      const float c11 = texel_norm((float)(t >> 24));
+      const float top = fmaf(c10, wx, c00 * (1.0f - wx));
+      const float bot = fmaf(c11, wx, c01 * (1.0f - wx));
+      const float src = fmaf(bot, wy, top * (1.0f - wy));
+      const float2 w = wr[tap];
+      const float bws = w.x * src;
+      s_sum += bws;
+      s_sq = fmaf(bws, src, s_sq);
+      s_ref = fmaf(bws, w.y, s_ref);
+      w_sum += w.x;
+      col_src += st0;
+      row_src += st3;
+      z += st6;
+    }
+    base_col += st1;
+    base_row += st4;
+    base_z += st7;
+    col_src = base_col;
+    row_src = base_row;
+    z = base_z;
+  }
+  const float inv_w = 1.0f / w_sum;
+  s_sum *= inv_w;
+  s_sq *= inv_w;
+  s_ref *= inv_w;
+  const float ref_var = ref_sqsum - ref_sum * ref_sum;
+  const float src_var = s_sq - s_sum * s_sum;
+  const float kMinVar = 1e-5f;
+  if (ref_var < kMinVar || src_var < kMinVar) return 2.0f;
+  const float covar = s_ref - ref_sum * s_sum;
+  const float var = sqrtf(ref_var * src_var);
+  return fmaxf(0.0f, fminf(2.0f, 1.0f - covar / var));
+}
+
+// ComputeGeomConsistencyCost, patch_match_cuda.cu:601-667
+__device__ __forceinline__ float geom_cost(const PmParams& p, const float* pose, int s, float row,
+                                           float col, float depth) {
+  const float* P = pose + 19;
+  const float* iP = pose + 31;
+  const float* iK = p.refInvK;
+  const float f0 = depth * (iK[0] * col + iK[1]);
+  const float f1 = depth * (iK[2] * row + iK[3]);
+  const float f2 = depth;
+  const float inv_fz = 1.0f / (P[8] * f0 + P[9] * f1 + P[10] * f2 + P[11]);
+  float src_col = inv_fz * (P[0] * f0 + P[1] * f1 + P[2] * f2 + P[3]);
+  float src_row = inv_fz * (P[4] * f0 + P[5] * f1 + P[6] * f2 + P[7]);
+  const float sx = floorf(src_col + 0.5f);
+  const float sy = floorf(src_row + 0.5f);
+  float src_depth = 0.0f;
+  if (sx >= 0.0f && sy >= 0.0f && sx < (float)p.src_w && sy < (float)p.src_h) {
+    src_depth = p.src_depth[((size_t)s * p.src_h + (int)sy) * p.src_w + (int)sx];
+  }
+  if (src_depth == 0.0f) return p.geom_max_cost;
+  src_col *= src_depth;
+  src_row *= src_depth;
+  const float bx = iP[0] * src_col + iP[1] * src_row + iP[2] * src_depth + iP[3];
+  const float by = iP[4] * src_col + iP[5] * src_row + iP[6] * src_depth + iP[7];
+  const float bz = iP[8] * src_col + iP[9] * src_row + iP[10] * src_depth + iP[11];
+  const float inv_bz = 1.0f / bz;
+  const float back_col = inv_bz * (p.refK[0] * bx + p.refK[1] * bz);
+  const float back_row = inv_bz * (p.refK[2] * by + p.refK[3] * bz);
+  const float dc = col - back_col;
+  const float dr = row - back_row;
+  return fminf(p.geom_max_cost, sqrtf(dc * dc + dr * dr));
+}
+
+// LikelihoodComputer, patch_match_cuda.cu:698-832
+__device__ __forceinline__ float ncc_prob(const PmParams& p, float cost) {
+  return pm_exp(cost * cost * p.inv_ncc_sigma_sq) * p.ncc_norm;
+}
+
+template <bool kForward>
+__device__ __forceinline__ float hmm_message(const PmParams& p, float cost, float prev) {
+  const float kUniformProb = 0.5f;
+  const float kNoChangeProb = 0.99999f;
+  const float kChangeProb = 1.0f - kNoChangeProb;
+  const float emission = ncc_prob(p, cost);
+  float zn0, zn1;
+  if (kForward) {
+    zn0 = (prev * kChangeProb + (1.0f - prev) * kNoChangeProb) * kUniformProb;
+    zn1 = (prev * kNoChangeProb + (1.0f - prev) * kChangeProb) * emission;
+  } else {
+    zn0 = prev * emission * kChangeProb + (1.0f - prev) * kUniformProb * kNoChangeProb;
+    zn1 = prev * emission * kNoChangeProb + (1.0f - prev) * kUniformProb * kChangeProb;
+  }
+  return zn1 / (zn0 + zn1);
+}
+
+__device__ __forceinline__ float sel_prob_fn(float alpha, float beta, float prev, float w) {
+  const float zn0 = (1.0f - alpha) * (1.0f - beta);
+  const float zn1 = alpha * beta;
+  const float curr = zn1 / (zn0 + zn1);
+  return w * prev + (1.0f - w) * curr;
+}
+
+// ComputeViewingAngles, patch_match_cuda.cu:241-269
+__device__ __forceinline__ void viewing_angles(const float* pose, float p0, float p1, float p2,
+                                               float n0, float n1, float n2, float& cos_tri,
+                                               float& cos_inc) {
+  const float* C = pose + 16;
+  const float s0 = C[0] - p0, s1 = C[1] - p1, s2 = C[2] - p2;
+  const float rx_inv = pm_rsqrt(dot3(p0, p1, p2, p0, p1, p2));
+  const float sx_inv = pm_rsqrt(dot3(s0, s1, s2, s0, s1, s2));
+  cos_inc = dot3(s0, s1, s2, n0, n1, n2) * sx_inv;
+  cos_tri = -dot3(s0, s1, s2, p0, p1, p2) * rx_inv * sx_inv;
+}
+
+__device__ __forceinline__ float tri_prob(const PmParams& p, float cos_tri) {
+  if (cos_tri > p.cos_min_tri) {
+    const float scaled = 1.0f - (1.0f - cos_tri) / (1.0f - p.cos_min_tri);
+    const float lik = 1.0f - scaled * scaled;
+    return fminf(1.0f, fmaxf(0.0f, lik));
+  }
+  return 1.0f;
+}
+
+__device__ __forceinline__ float inc_prob(const PmParams& p, float cos_inc) {
+  const float x = 1.0f - fmaxf(0.0f, cos_inc);
+  return pm_exp(x * x * p.inv_inc_sigma_sq);
+}
+
+__device__ __forceinline__ void h_apply(const float H[9], float v0, float v1, float& r0, float& r1) {
+  const float inv_z = 1.0f / (H[6] * v0 + H[7] * v1 + H[8]);
+  r0 = inv_z * (H[0] * v0 + H[1] * v1 + H[2]);
+  r1 = inv_z * (H[3] * v0 + H[4] * v1 + H[5]);
+}
+
+// ComputeResolutionProb, patch_match_cuda.cu:759-791
+__device__ __forceinline__ float res_prob(const float H[9], float row, float col, int radius) {
+  const int ws = 2 * radius + 1;
+  float a0, a1, b0, b1, c0, c1, d0, d1;
+  h_apply(H, col - radius, row - radius, a0, a1);
+  h_apply(H, col - radius, row + radius, b0, b1);
+  h_apply(H, col + radius, row + radius, c0, c1);
+  h_apply(H, col + radius, row - radius, d0, d1);
+  const float ref_area = (float)(ws * ws);
+  const float src_area = fabsf(0.5f * (a0 * b1 - b0 * a1 - a0 * d1 + b0 * c1 - c0 * b1 + d0 * a1 +
+                                       c0 * d1 - d0 * c1));
+  if (ref_area > src_area) return src_area / ref_area;
+  return ref_area / src_area;
+}
+
+// PropagateDepth, patch_match_cuda.cu:210-236
+__device__ __forceinline__ float propagate_depth(const float* iK, float depth1, float n1y,
+                                                 float n1z, float row1, float row2) {
+  const float x1 = depth1 * (iK[2] * row1 + iK[3]);
+  const float y1 = depth1;
+  const float x2 = x1 + n1z;
+  const float y2 = y1 - n1y;
+  const float x4 = iK[2] * row2 + iK[3];
+  const float denom = x2 - x1 + x4 * (y1 - y2);
+  if (fabsf(denom) < 1e-5f) return depth1;
+  const float nom = y1 * x2 - x1 * y2;
+  return nom / denom;
+}
+
+// PerturbNormal, patch_match_cuda.cu:133-196 (recursion as a loop)
+__device__ __forceinline__ void perturb_normal(const float* iK, int row, int col, float perturbation,
+                                               float n0, float n1, float n2, Rng& rng, float& o0,
+                                               float& o1, float& o2) {
+  for (int trial = 0;; ++trial) {
+    const float a1 = (rng_uniform(rng) - 0.5f) * perturbation;
+    const float a2 = (rng_uniform(rng) - 0.5f) * perturbation;
+    const float a3 = (rng_uniform(rng) - 0.5f) * perturbation;
+    float s1, s2, s3, c1, c2, c3;
+    pm_sincos(a1, &s1, &c1);
+    pm_sincos(a2, &s2, &c2);
+    pm_sincos(a3, &s3, &c3);
+    const float R0 = c2 * c3;
+    const float R1 = -c2 * s3;
+    const float R2 = s2;
+    const float R3 = c1 * s3 + c3 * s1 * s2;
+    const float R4 = c1 * c3 - s1 * s2 * s3;
+    const float R5 = -c2 * s1;
+    const float R6 = s1 * s3 - c1 * c3 * s2;
+    const float R7 = c3 * s1 + c1 * s2 * s3;
+    const float R8 = c1 * c2;
+    o0 = R0 * n0 + R1 * n1 + R2 * n2;
+    o1 = R3 * n0 + R4 * n1 + R5 * n2;
+    o2 = R6 * n0 + R7 * n1 + R8 * n2;
+    const float v0 = iK[0] * col + iK[1];
+    const float v1 = iK[2] * row + iK[3];
+    if (dot3(o0, o1, o2, v0, v1, 1.0f) >= 0.0f) {
+      if (trial < 3) {
+        perturbation = 0.5f * perturbation;
+        continue;
+      }
+      o0 = n0; o1 = n1; o2 = n2;
+      return;
+    }
+    const float inv_norm = pm_rsqrt(dot3(o0, o1, o2, o0, o1, o2));
+    o0 *= inv_norm; o1 *= inv_norm; o2 *= inv_norm;
+    return;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Setup kernels
+// ---------------------------------------------------------------------------
+
+// 2x2 footprint packing with a zero ring: entry (ey, ex) covers texels
+// (x, y) = (ex-2, ey-2) .. (x+1, y+1) for x in [-2, w], y in [-2, h]; out-of-image
+// texels are 0 (border mode, patch_match_cuda.cu:1627-1629). Entries x = -2 and
+// x = w (y likewise) are entirely zero, so clamping a tap's integer coordinate to
+// [-2, w] reproduces the border for arbitrarily distant taps.
+__global__ void pm_build_footprint_kernel(const uint8_t* __restrict__ src, uint32_t* __restrict__ fp,
+                                          int w, int h) {
+  const int ex = blockIdx.x * blockDim.x + threadIdx.x;
+  const int ey = blockIdx.y;
+  const int s = blockIdx.z;
+  if (ex >= w + 3) return;
+  const int x = ex - 2, y = ey - 2;
+  const uint8_t* img = src + (size_t)s * w * h;
+  auto tex = [&](int xx, int yy) -> uint32_t {
+    return (xx >= 0 && yy >= 0 && xx < w && yy < h) ? (uint32_t)img[(size_t)yy * w + xx] : 0u;
+  };
+  fp[((size_t)s * (h + 3) + ey) * (w + 3) + ex] =
+      tex(x, y) | (tex(x + 1, y) << 8) | (tex(x, y + 1) << 16) | (tex(x + 1, y + 1) << 24);
+}
+
+// FilterKernel, gpu_mat_ref_image.cu:39-81
+__global__ void pm_filter_ref_kernel(const uint8_t* __restrict__ gray, int W, int H, int radius,
+                                     int step, float spatial_norm, float color_norm,
+                                     uint8_t* __restrict__ out_img, float* __restrict__ out_sum,
+                                     float* __restrict__ out_sqsum) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  const int row = blockIdx.y * blockDim.y + threadIdx.y;
+  if (col >= W || row >= H) return;
+  const float center = texel_norm((float)gray[(size_t)row * W + col]);
+  float color_sum = 0.0f, color_sq = 0.0f, bws = 0.0f;
+  for (int wr = -radius; wr <= radius; wr += step) {
+    for (int wc = -radius; wc <= radius; wc += step) {
+      const int r = row + wr, c = col + wc;
+      const float color =
+          (r < 0 || c < 0 || r >= H || c >= W) ? 0.0f : texel_norm((float)gray[(size_t)r * W + c]);
+      const float bw = bilateral_weight(spatial_norm, color_norm, (float)wr, (float)wc, center, color);
+      color_sum += bw * color;
+      color_sq += bw * color * color;
+      bws += bw;
+    }
+  }
+  color_sum /= bws;
+  color_sq /= bws;
+  out_img[(size_t)row * W + col] = (uint8_t)(255.0f * center);
+  out_sum[(size_t)row * W + col] = color_sum;
+  out_sqsum[(size_t)row * W + col] = color_sq;
+}
+
+// InitRandomStateKernel (gpu_mat_prng.cu:36-48) + FillWithRandomNumbersKernel
+// (gpu_mat.h:370-387) + InitNormalMap (patch_match_cuda.cu:835-846) + the
+// prev_sel_prob fill (:1833-1835), fused: one pass over the pixel records.
+__global__ void pm_init_state_kernel(PmParams p, int random_init, float depth_min, float depth_max,
+                                     const float* __restrict__ init_depth,
+                                     const float* __restrict__ init_normal) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  const int row = blockIdx.y * blockDim.y + threadIdx.y;
+  if (col >= p.W || row >= p.H) return;
+  const int pix = row * p.W + col;
+  // seed = linear thread id of the reference's 32x16-block launch
+  const unsigned long long gx = (unsigned long long)((p.W - 1) / 32 + 1);
+  const unsigned long long block = (unsigned long long)(row / 16) * gx + (unsigned long long)(col / 32);
+  const unsigned long long id = block * 512ull + (unsigned long long)(row % 16) * 32ull + (col % 32);
+  Rng rng;
+  rng_init(rng, id);
+  float* rec = p.rec + (size_t)pix * p.rec_stride;
+  float depth, n0, n1, n2;
+  if (random_init) {
+    depth = rng_uniform(rng) * (depth_max - depth_min) + depth_min;
+    // GenerateRandomNormal, patch_match_cuda.cu:94-123 (rotation 0 calibration)
+    float v1 = 0.0f, v2 = 0.0f, s = 2.0f;
+    while (s >= 1.0f) {
+      v1 = 2.0f * rng_uniform(rng) - 1.0f;
+      v2 = 2.0f * rng_uniform(rng) - 1.0f;
+      s = v1 * v1 + v2 * v2;
+    }
+    const float s_norm = sqrtf(1.0f - s);
+    n0 = 2.0f * v1 * s_norm;
+    n1 = 2.0f * v2 * s_norm;
+    n2 = 1.0f - 2.0f * s;
+    const float r0 = p.refInvK[0] * col + p.refInvK[1];
+    const float r1 = p.refInvK[2] * row + p.refInvK[3];
+    if (dot3(n0, n1, n2, r0, r1, 1.0f) > 0) {
+      n0 = -n0; n1 = -n1; n2 = -n2;
+    }
+  } else {
+    depth = init_depth[pix];
+    n0 = init_normal[pix];
+    n1 = init_normal[(size_t)p.W * p.H + pix];
+    n2 = init_normal[(size_t)2 * p.W * p.H + pix];
+  }
+  rec[0] = depth; rec[1] = n0; rec[2] = n1; rec[3] = n2;
+  for (int s = 0; s < p.S; ++s) {
+    rec[p.sel_in_off + s] = 0.5f;
+    rec[p.sel_out_off + s] = 0.0f;
+  }
+  rng_store(p.rng + (size_t)pix * kRngWords, rng);
+}
+
+// ---------------------------------------------------------------------------
+// LDS carve-up shared by the initial-cost and sweep kernels
+// ---------------------------------------------------------------------------
+struct Lds {
+  float* poses;   // [S][43]
+  float* tile;    // [win][C + 2r] reference colours, ring-buffered rows
+  float2* wr;     // [C][ntaps] (bilateral weight, reference colour)
+  float* fm;      // [C][S] forward messages
+  float* q;       // [C][S] sampling pdf -> cdf
+  float* costv;   // [C][S] cost_map values of this row
+  float* betav;   // [C][S] backward messages of this row
+  float* prevv;   // [C][S] previous sel probs of this row
+  float* ncc;     // [C][5][S] NCC per hypothesis/view, < 0: not computed
+  float* geo;     // [C][5][S] geometric cost (GEOM only)
+  float* hyp;     // [C][5][4] depth, normal
+  float* colf;    // [C][8] ref_sum, ref_sqsum, point[3], pad
+  float* us;      // [C][M] uniform draws
+  int* sv;        // [C][M] sampled view per draw (-1: none)
+  int* best;      // [C]
+  int* flags;     // [C][S] filter flags
+  uint32_t* tasks;
+  int* ntasks;
+};
+
+__host__ __device__ inline size_t lds_layout(Lds* L, char* base, int C, int S, int radius, int ntaps,
+                                             int M, bool geom) {
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    char* ptr = base ? base + off : nullptr;
+    off += (bytes + 15) & ~(size_t)15;
+    return ptr;
+  };
+  const int win = 2 * radius + 1;
+  const int tw = C + 2 * radius;
+  const int max_tasks = C * (5 * (M < S ? M : S) > S ? 5 * (M < S ? M : S) : S);
+  float* poses = (float*)take(sizeof(float) * S * kPoseStride);
+  float* tile = (float*)take(sizeof(float) * win * tw);
+  float2* wr = (float2*)take(sizeof(float2) * C * ntaps);
+  float* fm = (float*)take(sizeof(float) * C * S);
+  float* q = (float*)take(sizeof(float) * C * S);
+  float* costv = (float*)take(sizeof(float) * C * S);
+  float* betav = (float*)take(sizeof(float) * C * S);
+  float* prevv = (float*)take(sizeof(float) * C * S);
+  float* ncc = (float*)take(sizeof(float) * C * 5 * S);
+  float* geo = (float*)take(geom ? sizeof(float) * C * 5 * S : 0);
+  float* hyp = (float*)take(sizeof(float) * C * 20);
+  float* colf = (float*)take(sizeof(float) * C * 8);
+  float* us = (float*)take(sizeof(float) * C * M);
+  int* sv = (int*)take(sizeof(int) * C * M);
+  int* best = (int*)take(sizeof(int) * C);
+  int* flags = (int*)take(sizeof(int) * C * S);
+  uint32_t* tasks = (uint32_t*)take(sizeof(uint32_t) * max_tasks);
+  int* ntasks = (int*)take(sizeof(int) * 4);
+  if (L) {
+    L->poses = poses; L->tile = tile; L->wr = wr; L->fm = fm; L->q = q; L->costv = costv;
+    L->betav = betav; L->prevv = prevv; L->ncc = ncc; L->geo = geo; L->hyp = hyp; L->colf = colf;
+    L->us = us; L->sv = sv; L->best = best; L->flags = flags; L->tasks = tasks; L->ntasks = ntasks;
+  }
+  return off;
+}
+
+__device__ __forceinline__ uint32_t task_pack(int c, int i, int s, int geom_only) {
+  return ((uint32_t)c << 24) | ((uint32_t)geom_only << 23) | ((uint32_t)i << 20) | (uint32_t)s;
+}
+
+// Load one sweep-frame row of the reference image into the LDS ring tile.
+__device__ __forceinline__ void tile_load_row(const PmParams& p, const Lds& L, int col0, int row,
+                                              int tid, int nthreads) {
+  const int win = 2 * p.radius + 1;
+  const int tw = p.C + 2 * p.radius;
+  int slot = row % win;
+  if (slot < 0) slot += win;
+  for (int lc = tid; lc < tw; lc += nthreads) {
+    L.tile[slot * tw + lc] = ref_texel(p, row, col0 - p.radius + lc);
+  }
+}
+
+// Bilateral weights + reference colours of the patches centred on (row, col0+c).
+__device__ __forceinline__ void patch_weights(const PmParams& p, const Lds& L, int row, int tid,
+                                              int nthreads) {
+  const int win = 2 * p.radius + 1;
+  const int tw = p.C + 2 * p.radius;
+  const int total = p.C * p.ntaps;
+  for (int item = tid; item < total; item += nthreads) {
+    const int c = item / p.ntaps;
+    const int tap = item - c * p.ntaps;
+    const int trow = tap / p.ntap1d;
+    const int tcol = tap - trow * p.ntap1d;
+    const int wr_ = -p.radius + trow * p.step;
+    const int wc_ = -p.radius + tcol * p.step;
+    int slot_c = row % win;
+    int slot = (row + wr_) % win;
+    if (slot < 0) slot += win;
+    if (slot_c < 0) slot_c += win;
+    const float center = L.tile[slot_c * tw + c + p.radius];
+    const float color = L.tile[slot * tw + c + p.radius + wc_];
+    const float bw = bilateral_weight(p.spatial_norm, p.color_norm, (float)wr_, (float)wc_, center, color);
+    L.wr[item] = make_float2(bw, color);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// ComputeInitialCost (patch_match_cuda.cu:863-912): C adjacent pixels of one row
+// per workgroup, C*S NCC evaluations spread over the lanes. Rotation 0.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) pm_initial_cost_kernel(PmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  Lds L;
+  lds_layout(&L, smem, p.C, p.S, p.radius, p.ntaps, p.num_samples, false);
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int row = blockIdx.y;
+  const int col0 = blockIdx.x * p.C;
+  for (int i = tid; i < p.S * kPoseStride; i += nt) L.poses[i] = p.poses[i];
+  for (int r = row - p.radius; r <= row + p.radius; ++r) tile_load_row(p, L, col0, r, tid, nt);
+  __syncthreads();
+  patch_weights(p, L, row, tid, nt);
+  __syncthreads();
+  const int fp_slice = (p.src_w + 3) * (p.src_h + 3);
+  for (int item = tid; item < p.C * p.S; item += nt) {
+    const int c = item / p.S;
+    const int s = item - c * p.S;
+    const int col = col0 + c;
+    if (col >= p.W) continue;
+    const int pix = row * p.W + col;
+    const float* rec = p.rec + (size_t)pix * p.rec_stride;
+    const float cost = ncc_eval(p, L.poses + s * kPoseStride, p.src_fp + (size_t)s * fp_slice,
+                                L.wr + c * p.ntaps, row, col, rec[0], rec[1], rec[2], rec[3],
+                                p.ref_sum[pix], p.ref_sqsum[pix]);
+    p.rec[(size_t)pix * p.rec_stride + 4 + s] = cost;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// SweepFromTopToBottom (patch_match_cuda.cu:933-1288)
+// ---------------------------------------------------------------------------
+
+// Run every queued NCC / geometric-cost task; one task per lane.
+template <bool GEOM>
+__device__ __forceinline__ void run_tasks(const PmParams& p, const Lds& L, int row, int col0,
+                                          int tid, int nt) {
+  const int n = *L.ntasks;
+  const int fp_slice = (p.src_w + 3) * (p.src_h + 3);
+  for (int t = tid; t < n; t += nt) {
+    const uint32_t task = L.tasks[t];
+    const int c = task >> 24;
+    const int geom_only = (task >> 23) & 1;
+    const int i = (task >> 20) & 7;
+    const int s = task & 0xfffff;
+    const float* h = L.hyp + (c * 5 + i) * 4;
+    const float* pose = L.poses + s * kPoseStride;
+    const int col = col0 + c;
+    if (!geom_only) {
+      L.ncc[(c * 5 + i) * p.S + s] =
+          ncc_eval(p, pose, p.src_fp + (size_t)s * fp_slice, L.wr + c * p.ntaps, row, col, h[0],
+                   h[1], h[2], h[3], L.colf[c * 8 + 0], L.colf[c * 8 + 1]);
+    }
+    if (GEOM) {
+      L.geo[(c * 5 + i) * p.S + s] = geom_cost(p, pose, s, (float)row, (float)col, h[0]);
+    }
+  }
+}
+
+template <bool GEOM, bool FILTER_PHOTO, bool FILTER_GEOM>
+__global__ void __launch_bounds__(256) pm_sweep_kernel(PmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  Lds L;
+  lds_layout(&L, smem, p.C, p.S, p.radius, p.ntaps, p.num_samples, GEOM);
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int S = p.S, M = p.num_samples, C = p.C;
+  const int RW = rot_width(p), RH = rot_height(p);
+  const int col0 = blockIdx.x * C;
+  const int ncols = min(C, RW - col0);  // valid columns of this group
+  const float* iK = p.refInvK;
+
+  for (int i = tid; i < S * kPoseStride; i += nt) L.poses[i] = p.poses[i];
+
+  // ---- backward messages for all rows (:976-989); stored in sel_out ----------
+  for (int item = tid; item < ncols * S; item += nt) {
+    const int c = item / S;
+    const int s = item - c * S;
+    float beta = 0.5f;
+    for (int row = RH - 1; row >= 0; --row) {
+      float* rec = p.rec + (size_t)pix_index(p, row, col0 + c) * p.rec_stride;
+      beta = hmm_message<false>(p, rec[4 + s], beta);
+      rec[p.sel_out_off + s] = beta;
+    }
+    L.fm[c * S + s] = 0.5f;
+  }
+
+  // ---- per-column state kept by the column's lane (:1022-1028) ---------------
+  Rng rng;
+  rng.x0 = rng.x1 = rng.x2 = rng.x3 = rng.x4 = rng.d = 0;
+  const bool col_lane = tid < ncols;
+  if (col_lane) {
+    const int pix0 = pix_index(p, 0, col0 + tid);
+    rng = rng_load(p.rng + (size_t)pix0 * kRngWords);
+    const float* rec = p.rec + (size_t)pix0 * p.rec_stride;
+    float sx, sy;
+    normal_to_sweep(p.rot, rec[1], rec[2], sx, sy);
+    float* h1 = L.hyp + (tid * 5 + 1) * 4;
+    h1[0] = rec[0]; h1[1] = sx; h1[2] = sy; h1[3] = rec[3];
+  }
+  // reference tile rows [-r, r-1]; row r arrives in the first loop iteration
+  for (int r = -p.radius; r < p.radius; ++r) tile_load_row(p, L, col0, r, tid, nt);
+  __syncthreads();
+
+  for (int row = 0; row < RH; ++row) {
+    // ---- P0: scroll the reference tile (LocalRefImage::Read, :357-410) -------
+    tile_load_row(p, L, col0, row + p.radius, tid, nt);
+    if (tid == 0) *L.ntasks = 0;
+    __syncthreads();
+
+    // ---- P1: hypotheses (lane per column) + patch weights (all lanes) --------
+    if (col_lane) {
+      const int c = tid;
+      const int col = col0 + c;
+      const int pix = pix_index(p, row, col);
+      const float* rec = p.rec + (size_t)pix * p.rec_stride;
+      float* h = L.hyp + c * 20;
+      // propagate the previous row's plane (:1047-1048)
+      h[4] = propagate_depth(iK, h[4], h[6], h[7], (float)(row - 1), (float)row);
+      // current parameters (:1051-1052)
+      const float cd = rec[0];
+      float cn0, cn1;
+      normal_to_sweep(p.rot, rec[1], rec[2], cn0, cn1);
+      const float cn2 = rec[3];
+      // random parameters (:1055-1062)
+      const float dmin = (1.0f - p.perturbation) * cd;
+      const float dmax = (1.0f + p.perturbation) * cd;
+      const float rd = rng_uniform(rng) * (dmax - dmin) + dmin;
+      float rn0, rn1, rn2;
+      perturb_normal(iK, row, col, p.perturbation_pi, cn0, cn1, cn2, rng, rn0, rn1, rn2);
+      for (int m = 0; m < M; ++m) L.us[c * M + m] = rng_uniform(rng) - FLT_EPSILON;  // :1129
+      h[0] = cd; h[1] = cn0; h[2] = cn1; h[3] = cn2;
+      h[8] = rd; h[9] = rn0; h[10] = rn1; h[11] = rn2;
+      h[12] = cd; h[13] = rn0; h[14] = rn1; h[15] = rn2;
+      h[16] = rd; h[17] = cn0; h[18] = cn1; h[19] = cn2;
+      float* cf = L.colf + c * 8;
+      cf[0] = p.ref_sum[pix];
+      cf[1] = p.ref_sqsum[pix];
+      // ComputePointAtDepth (:1067-1068)
+      cf[2] = cd * (iK[0] * col + iK[1]);
+      cf[3] = cd * (iK[2] * row + iK[3]);
+      cf[4] = cd;
+    }
+    patch_weights(p, L, row, tid, nt);
+    for (int item = tid; item < ncols * 5 * S; item += nt) L.ncc[item] = -1.0f;
+    __syncthreads();
+
+    // ---- P2: per-view selection priors (:1070-1104), lane per (column, view) --
+    for (int item = tid; item < ncols * S; item += nt) {
+      const int c = item / S;
+      const int s = item - c * S;
+      const int col = col0 + c;
+      const float* rec = p.rec + (size_t)pix_index(p, row, col) * p.rec_stride;
+      const float* pose = L.poses + s * kPoseStride;
+      const float* h = L.hyp + c * 20;
+      const float* cf = L.colf + c * 8;
+      const float cost = rec[4 + s];
+      const float beta = rec[p.sel_out_off + s];
+      const float prev = rec[p.sel_in_off + s];
+      L.costv[item] = cost;
+      L.betav[item] = beta;
+      L.prevv[item] = prev;
+      const float alpha = hmm_message<true>(p, cost, L.fm[item]);
+      const float sp = sel_prob_fn(alpha, beta, prev, p.prev_sel_prob_weight);
+      float cos_tri, cos_inc;
+      viewing_angles(pose, cf[2], cf[3], cf[4], h[1], h[2], h[3], cos_tri, cos_inc);
+      const float tp = tri_prob(p, cos_tri);
+      const float ip = inc_prob(p, cos_inc);
+      float Hm[9];
+      compose_homography(iK, pose, row, col, h[0], h[1], h[2], h[3], Hm);
+      const float rp = res_prob(Hm, (float)row, (float)col, p.radius);
+      L.q[item] = sp * tp * ip * rp;
+    }
+    __syncthreads();
+
+    // ---- P3: CDF, Monte-Carlo view draws, first task list (lane per column) --
+    if (col_lane) {
+      const int c = tid;
+      float* q = L.q + c * S;
+      float prob_sum = 0.0f;
+      for (int i = 0; i < S; ++i) prob_sum += q[i];
+      const float inv_prob_sum = 1.0f / prob_sum;
+      float cum = 0.0f;
+      for (int i = 0; i < S; ++i) {
+        cum += q[i] * inv_prob_sum;
+        q[i] = cum;
+      }
+      for (int m = 0; m < M; ++m) {
+        const float u = L.us[c * M + m];
+        int src = -1;
+        for (int s = 0; s < S; ++s) {
+          if (q[s] > u) { src = s; break; }
+        }
+        L.sv[c * M + m] = src;
+        if (src >= 0 && L.ncc[(c * 5 + 1) * S + src] == -1.0f) {
+          L.ncc[(c * 5 + 1) * S + src] = -2.0f;  // queued
+          const int n_new = GEOM ? 5 : 4;
+          const int base = atomicAdd(L.ntasks, n_new);
+          for (int i = 1; i < 5; ++i) L.tasks[base + i - 1] = task_pack(c, i, src, 0);
+          if (GEOM) L.tasks[base + 4] = task_pack(c, 0, src, 1);
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- P4: NCC of hypotheses 1..4 against the drawn views (:1157-1172) -----
+    run_tasks<GEOM>(p, L, row, col0, tid, nt);
+    __syncthreads();
+    if (tid == 0) *L.ntasks = 0;
+    __syncthreads();
+
+    // ---- P5: accumulate in draw order, argmin, store (:1144-1182) -------------
+    if (col_lane) {
+      const int c = tid;
+      float costs[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+      for (int m = 0; m < M; ++m) {
+        const int src = L.sv[c * M + m];
+        if (src < 0) continue;
+        costs[0] += L.costv[c * S + src];
+        if (GEOM) costs[0] += p.geom_reg * L.geo[(c * 5 + 0) * S + src];
+#pragma unroll
+        for (int i = 1; i < 5; ++i) {
+          costs[i] += L.ncc[(c * 5 + i) * S + src];
+          if (GEOM) costs[i] += p.geom_reg * L.geo[(c * 5 + i) * S + src];
+        }
+      }
+      int min_idx = 0;
+      float min_cost = costs[0];
+#pragma unroll
+      for (int i = 1; i < 5; ++i) {
+        if (costs[i] <= min_cost) { min_cost = costs[i]; min_idx = i; }
+      }
+      L.best[c] = min_idx;
+      const float* hb = L.hyp + (c * 5 + min_idx) * 4;
+      const float bd = hb[0], b0 = hb[1], b1 = hb[2], b2 = hb[3];
+      float* rec = p.rec + (size_t)pix_index(p, row, col0 + c) * p.rec_stride;
+      float nx, ny;
+      normal_from_sweep(p.rot, b0, b1, nx, ny);
+      rec[0] = bd; rec[1] = nx; rec[2] = ny; rec[3] = b2;
+      // previous-row state for the next step (:1279-1282)
+      float* h1 = L.hyp + (c * 5 + 1) * 4;
+      h1[0] = bd; h1[1] = b0; h1[2] = b1; h1[3] = b2;
+      if (min_idx != 0) {
+        for (int s = 0; s < S; ++s) {
+          if (L.ncc[(c * 5 + min_idx) * S + s] < 0.0f) {
+            const int base = atomicAdd(L.ntasks, 1);
+            L.tasks[base] = task_pack(c, min_idx, s, 0);
+          }
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- P6: NCC of the winner against the remaining views (:1188-1197) ------
+    run_tasks<false>(p, L, row, col0, tid, nt);
+    __syncthreads();
+
+    // ---- P7: cost map, forward message, selection probability (:1186-1207) ---
+    for (int item = tid; item < ncols * S; item += nt) {
+      const int c = item / S;
+      const int s = item - c * S;
+      const int col = col0 + c;
+      const int k = L.best[c];
+      float* rec = p.rec + (size_t)pix_index(p, row, col) * p.rec_stride;
+      float cost;
+      if (k == 0) {
+        cost = L.costv[item];
+      } else {
+        cost = L.ncc[(c * 5 + k) * S + s];
+        rec[4 + s] = cost;
+      }
+      const float alpha = hmm_message<true>(p, cost, L.fm[item]);
+      const float prob = sel_prob_fn(alpha, L.betav[item], L.prevv[item], p.prev_sel_prob_weight);
+      L.fm[item] = alpha;
+      rec[p.sel_out_off + s] = prob;
+      if (FILTER_PHOTO || FILTER_GEOM) {
+        // :1209-1265
+        const float* hb = L.hyp + (c * 5 + 1) * 4;  // == best (stored in P5)
+        const float* pose = L.poses + s * kPoseStride;
+        const float bp0 = hb[0] * (iK[0] * col + iK[1]);
+        const float bp1 = hb[0] * (iK[2] * row + iK[3]);
+        const float bp2 = hb[0];
+        float cos_tri, cos_inc;
+        viewing_angles(pose, bp0, bp1, bp2, hb[1], hb[2], hb[3], cos_tri, cos_inc);
+        int ok = 0;
+        if (!(cos_tri > p.filter_cos_min_tri || cos_inc <= 0.0f)) {
+          const float min_ncc_prob = ncc_prob(p, 1.0f - p.filter_min_ncc);
+          bool photo_ok = true, geom_ok = true;
+          if (FILTER_PHOTO) photo_ok = prob >= min_ncc_prob;
+          if (FILTER_GEOM)
+            geom_ok = geom_cost(p, pose, s, (float)row, (float)col, hb[0]) <= p.filter_geom_max_cost;
+          ok = (photo_ok && geom_ok) ? 1 : 0;
+        }
+        L.flags[item] = ok;
+      }
+    }
+    if (FILTER_PHOTO || FILTER_GEOM) {
+      __syncthreads();
+      // ---- P8: consistency count (:1267-1275) ---------------------------------
+      if (col_lane) {
+        const int c = tid;
+        int num = 0;
+        for (int s = 0; s < S; ++s) num += L.flags[c * S + s];
+        const int pix = pix_index(p, row, col0 + c);
+        if (num < p.filter_min_num_consistent) {
+          float* rec = p.rec + (size_t)pix * p.rec_stride;
+          rec[0] = 0.0f; rec[1] = 0.0f; rec[2] = 0.0f; rec[3] = 0.0f;
+        } else {
+          for (int s = 0; s < S; ++s)
+            if (L.flags[c * S + s]) p.mask[(size_t)s * p.W * p.H + pix] = 1;
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  if (col_lane) {
+    rng_store(p.rng + (size_t)pix_index(p, 0, col0 + tid) * kRngWords, rng);  // :1285-1287
+  }
+}
+
+// pixel records -> API layout (Mat<float> slice-major, mat.h:107-109)
+__global__ void pm_extract_kernel(PmParams p, int sel_off, float* __restrict__ depth,
+                                  float* __restrict__ normal, float* __restrict__ sel,
+                                  float* __restrict__ cost) {
+  const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = p.W * p.H;
+  if (pix >= n) return;
+  const float* rec = p.rec + (size_t)pix * p.rec_stride;
+  if (depth) depth[pix] = rec[0];
+  if (normal) {
+    normal[pix] = rec[1];
+    normal[(size_t)n + pix] = rec[2];
+    normal[(size_t)2 * n + pix] = rec[3];
+  }
+  for (int s = 0; s < p.S; ++s) {
+    if (sel) sel[(size_t)s * n + pix] = rec[sel_off + s];
+    if (cost) cost[(size_t)s * n + pix] = rec[4 + s];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Launchers
+// ---------------------------------------------------------------------------
+
+size_t pm_sweep_lds_bytes(const PmParams& p, bool geom) {
+  return lds_layout(nullptr, nullptr, p.C, p.S, p.radius, p.ntaps, p.num_samples, geom);
+}
+
+int pm_pick_columns(int S, int ntaps, int num_samples, bool geom, int radius, int requested) {
+  const size_t budget = 60 * 1024;
+  int c = requested > 0 ? requested : 4;
+  if (c > 64) c = 64;
+  while (c > 1 && lds_layout(nullptr, nullptr, c, S, radius, ntaps, num_samples, geom) > budget) --c;
+  return c;
+}
+
+void pm_launch_build_footprint(const uint8_t* src, uint32_t* fp, int S, int w, int h, hipStream_t st) {
+  dim3 block(256, 1, 1);
+  dim3 grid((w + 3 + 255) / 256, h + 3, S);
+  hipLaunchKernelGGL(pm_build_footprint_kernel, grid, block, 0, st, src, fp, w, h);
+}
+
+void pm_launch_filter_ref(const uint8_t* gray, int W, int H, int radius, int step, float sigma_spatial,
+                          float sigma_color, uint8_t* out_img, float* out_sum, float* out_sqsum,
+                          hipStream_t st) {
+  const float sn = 1.0f / (2.0f * sigma_spatial * sigma_spatial);
+  const float cn = 1.0f / (2.0f * sigma_color * sigma_color);
+  dim3 block(64, 4, 1);
+  dim3 grid((W + 63) / 64, (H + 3) / 4, 1);
+  hipLaunchKernelGGL(pm_filter_ref_kernel, grid, block, 0, st, gray, W, H, radius, step, sn, cn,
+                     out_img, out_sum, out_sqsum);
+}
+
+void pm_launch_init_state(const PmParams& p, bool random_init, float depth_min, float depth_max,
+                          const float* init_depth, const float* init_normal, hipStream_t st) {
+  dim3 block(64, 4, 1);
+  dim3 grid((p.W + 63) / 64, (p.H + 3) / 4, 1);
+  hipLaunchKernelGGL(pm_init_state_kernel, grid, block, 0, st, p, random_init ? 1 : 0, depth_min,
+                     depth_max, init_depth, init_normal);
+}
+
+void pm_launch_initial_cost(const PmParams& p, hipStream_t st) {
+  const size_t lds = lds_layout(nullptr, nullptr, p.C, p.S, p.radius, p.ntaps, p.num_samples, false);
+  dim3 block(64, 1, 1);
+  dim3 grid((p.W + p.C - 1) / p.C, p.H, 1);
+  hipLaunchKernelGGL(pm_initial_cost_kernel, grid, block, lds, st, p);
+}
+
+void pm_launch_sweep(const PmParams& p, int threads, bool geom, bool filter_photo, bool filter_geom,
+                     hipStream_t st) {
+  const size_t lds = pm_sweep_lds_bytes(p, geom);
+  const int rw = (p.rot & 1) ? p.H : p.W;
+  dim3 block(threads, 1, 1);
+  dim3 grid((rw + p.C - 1) / p.C, 1, 1);
+#define PM_LAUNCH(G, FP, FG) \
+  hipLaunchKernelGGL((pm_sweep_kernel<G, FP, FG>), grid, block, lds, st, p)
+  if (geom) {
+    if (filter_photo && filter_geom) PM_LAUNCH(true, true, true);
+    else PM_LAUNCH(true, false, false);
+  } else {
+    if (filter_photo) PM_LAUNCH(false, true, false);
+    else PM_LAUNCH(false, false, false);
+  }
+#undef PM_LAUNCH
+}
+
+void pm_launch_extract(const PmParams& p, int sel_off, float* depth, float* normal, float* sel,
+                       float* cost, hipStream_t st) {
+  const int n = p.W * p.H;
+  hipLaunchKernelGGL(pm_extract_kernel, dim3((n + 255) / 256), dim3(256), 0, st, p, sel_off, depth,
+                     normal, sel, cost);
+}
+
+}  // namespace colmap_amd

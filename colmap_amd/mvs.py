@@ -1,0 +1,328 @@
+"""Host-side mirror of the reference's PatchMatch interface over the C ABI.
+
+Same names and argument meaning as colmap::mvs (reference src/colmap/mvs/
+patch_match.h:55-96, patch_match_options.h:37-126) / pycolmap.PatchMatchOptions
+(src/pycolmap/pipeline/mvs.cc:27-117): `PatchMatchOptions`, `Image`,
+`PatchMatch.Problem`, `PatchMatch(options, problem).Run()`, `GetDepthMap()`,
+`GetNormalMap()`, `GetSelProbMap()`, `GetConsistencyGraph()`. All compute happens
+in colmap_amd/lib/libcolmap_amd.so (HIP, gfx950); this module is ctypes plumbing.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from ._lib import lib
+
+
+class pm_options(C.Structure):
+    _fields_ = [
+        ("depth_min", C.c_double), ("depth_max", C.c_double),
+        ("sigma_spatial", C.c_double), ("sigma_color", C.c_double),
+        ("ncc_sigma", C.c_double),
+        ("min_triangulation_angle", C.c_double),
+        ("incident_angle_sigma", C.c_double),
+        ("geom_consistency_regularizer", C.c_double),
+        ("geom_consistency_max_cost", C.c_double),
+        ("filter_min_ncc", C.c_double),
+        ("filter_min_triangulation_angle", C.c_double),
+        ("filter_geom_consistency_max_cost", C.c_double),
+        ("window_radius", C.c_int32), ("window_step", C.c_int32),
+        ("num_samples", C.c_int32), ("num_iterations", C.c_int32),
+        ("filter_min_num_consistent", C.c_int32),
+        ("geom_consistency", C.c_int32), ("filter", C.c_int32),
+        ("gpu_index", C.c_int32),
+        ("max_sweeps", C.c_int32), ("inputs_on_device", C.c_int32),
+        ("columns_per_group", C.c_int32), ("threads_per_group", C.c_int32),
+    ]
+
+
+class pm_image(C.Structure):
+    _fields_ = [
+        ("width", C.c_int32), ("height", C.c_int32),
+        ("K", C.c_float * 9), ("R", C.c_float * 9), ("T", C.c_float * 3),
+        ("gray", C.c_void_p), ("depth_map", C.c_void_p), ("normal_map", C.c_void_p),
+    ]
+
+
+class pm_problem(C.Structure):
+    _fields_ = [
+        ("ref_image_idx", C.c_int32), ("num_src_images", C.c_int32),
+        ("src_image_idxs", C.POINTER(C.c_int32)),
+        ("num_images", C.c_int32), ("images", C.POINTER(pm_image)),
+    ]
+
+
+class PatchMatchError(RuntimeError):
+    pass
+
+
+def _check(rc: int):
+    if rc != 0:
+        raise PatchMatchError(lib().pm_last_error().decode())
+
+
+@dataclass
+class PatchMatchOptions:
+    """colmap::mvs::PatchMatchOptions (reference patch_match_options.h:37-126)."""
+    depth_min: float = -1.0
+    depth_max: float = -1.0
+    sigma_spatial: float = -1.0
+    sigma_color: float = float(np.float32(0.2))
+    ncc_sigma: float = float(np.float32(0.6))
+    min_triangulation_angle: float = 1.0
+    incident_angle_sigma: float = float(np.float32(0.9))
+    geom_consistency_regularizer: float = float(np.float32(0.3))
+    geom_consistency_max_cost: float = 3.0
+    filter_min_ncc: float = float(np.float32(0.1))
+    filter_min_triangulation_angle: float = 3.0
+    filter_geom_consistency_max_cost: float = 1.0
+    cache_size: float = 32.0
+    gpu_index: str = "-1"
+    max_image_size: int = -1
+    window_radius: int = 5
+    window_step: int = 1
+    num_samples: int = 15
+    num_iterations: int = 5
+    filter_min_num_consistent: int = 2
+    num_threads: int = -1
+    geom_consistency: bool = True
+    filter: bool = True
+    allow_missing_files: bool = False
+    write_consistency_graph: bool = False
+    # extensions (not in the reference)
+    max_sweeps: int = 0
+    columns_per_group: int = 0
+    threads_per_group: int = 0
+
+    def to_c(self, inputs_on_device: bool = False) -> pm_options:
+        o = pm_options()
+        for name, _ in pm_options._fields_:
+            if name in ("gpu_index", "inputs_on_device"):
+                continue
+            setattr(o, name, getattr(self, name))
+        gpu = [int(x) for x in str(self.gpu_index).split(",") if x.strip() != ""]
+        if len(gpu) != 1:
+            # PatchMatch::Check, reference patch_match.cc:70-73
+            raise PatchMatchError("Check failed: gpu_indices.size() == 1")
+        o.gpu_index = gpu[0]
+        o.inputs_on_device = 1 if inputs_on_device else 0
+        return o
+
+
+@dataclass
+class Image:
+    """colmap::mvs::Image (reference mvs/image.h:40-98) with its grey bitmap."""
+    K: np.ndarray
+    R: np.ndarray
+    T: np.ndarray
+    bitmap: object  # (H, W) uint8 numpy array, or a torch CUDA tensor of that shape
+
+    def GetWidth(self) -> int:
+        return int(self.bitmap.shape[1])
+
+    def GetHeight(self) -> int:
+        return int(self.bitmap.shape[0])
+
+
+def _ptr_of(a, dtype, keep: list):
+    """Pointer to a host numpy array or a device torch tensor."""
+    if a is None:
+        return None, False
+    if hasattr(a, "data_ptr"):  # torch tensor
+        t = a.contiguous()
+        keep.append(t)
+        return t.data_ptr(), bool(t.is_cuda)
+    arr = np.ascontiguousarray(a, dtype=dtype)
+    keep.append(arr)
+    return arr.ctypes.data, False
+
+
+class PatchMatch:
+    """colmap::mvs::PatchMatch (reference mvs/patch_match.h:55-96)."""
+
+    @dataclass
+    class Problem:
+        ref_image_idx: int = -1
+        src_image_idxs: List[int] = field(default_factory=list)
+        images: Optional[Sequence[Image]] = None
+        depth_maps: Optional[Sequence[Optional[np.ndarray]]] = None   # (H, W) float32 each
+        normal_maps: Optional[Sequence[Optional[np.ndarray]]] = None  # (3, H, W) float32 each
+
+    def __init__(self, options: PatchMatchOptions, problem: "PatchMatch.Problem"):
+        self.options_ = options
+        self.problem_ = problem
+        self._h = None
+        self._dims = None
+
+    def __del__(self):
+        self.close()
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().pm_destroy(self._h)
+            self._h = None
+
+    # -- marshalling -----------------------------------------------------------------
+    def _marshal(self):
+        prob = self.problem_
+        if prob.images is None:
+            raise PatchMatchError("Check failed: problem_.images != nullptr")
+        keep: list = []
+        n = len(prob.images)
+        arr = (pm_image * n)()
+        on_device = None
+        used = set(prob.src_image_idxs) | {prob.ref_image_idx}
+        for i, im in enumerate(prob.images):
+            if i not in used:
+                continue
+            arr[i].width, arr[i].height = im.GetWidth(), im.GetHeight()
+            arr[i].K[:] = np.asarray(im.K, np.float32).ravel().tolist()
+            arr[i].R[:] = np.asarray(im.R, np.float32).ravel().tolist()
+            arr[i].T[:] = np.asarray(im.T, np.float32).ravel().tolist()
+            ptr, dev = _ptr_of(im.bitmap, np.uint8, keep)
+            arr[i].gray = ptr
+            flags = [dev]
+            if prob.depth_maps is not None and i < len(prob.depth_maps) and prob.depth_maps[i] is not None:
+                d = prob.depth_maps[i]
+                if tuple(d.shape) != (im.GetHeight(), im.GetWidth()):
+                    raise PatchMatchError("Check failed: depth map size == image size")
+                ptr, dev = _ptr_of(d, np.float32, keep)
+                arr[i].depth_map = ptr
+                flags.append(dev)
+            if prob.normal_maps is not None and i < len(prob.normal_maps) and prob.normal_maps[i] is not None:
+                nm = prob.normal_maps[i]
+                if tuple(nm.shape) != (3, im.GetHeight(), im.GetWidth()):
+                    raise PatchMatchError("Check failed: normal map size == image size")
+                ptr, dev = _ptr_of(nm, np.float32, keep)
+                arr[i].normal_map = ptr
+                flags.append(dev)
+            for f in flags:
+                if on_device is None:
+                    on_device = f
+                elif on_device != f:
+                    raise PatchMatchError("inputs must be all host arrays or all device tensors")
+        src = (C.c_int32 * len(prob.src_image_idxs))(*prob.src_image_idxs)
+        cprob = pm_problem(int(prob.ref_image_idx), len(prob.src_image_idxs), src, n, arr)
+        keep += [arr, src]
+        return cprob, keep, bool(on_device)
+
+    # -- reference surface --------------------------------------------------------------
+    def Check(self):
+        cprob, keep, on_device = self._marshal()
+        copt = self.options_.to_c(on_device)
+        _check(lib().pm_check(C.byref(copt), C.byref(cprob)))
+
+    def Create(self):
+        """The reference constructs PatchMatchCuda inside Run(); split out so that callers
+        (bench) can time upload and solve separately."""
+        cprob, keep, on_device = self._marshal()
+        copt = self.options_.to_c(on_device)
+        self.close()
+        h = C.c_void_p()
+        _check(lib().pm_create(C.byref(copt), C.byref(cprob), C.byref(h)))
+        self._h = h
+        ref = self.problem_.images[self.problem_.ref_image_idx]
+        self._dims = (ref.GetHeight(), ref.GetWidth(), len(self.problem_.src_image_idxs))
+
+    def Run(self):
+        if self._h is None:
+            self.Create()
+        _check(lib().pm_run(self._h))
+
+    def RunAsync(self):
+        if self._h is None:
+            self.Create()
+        _check(lib().pm_run_async(self._h))
+
+    def Synchronize(self):
+        _check(lib().pm_synchronize(self._h))
+
+    def _get(self, fn, shape, dtype=np.float32):
+        out = np.empty(shape, dtype)
+        _check(fn(self._h, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def GetDepthMap(self) -> np.ndarray:
+        H, W, S = self._dims
+        return self._get(lib().pm_get_depth_map, (H, W))
+
+    def GetNormalMap(self) -> np.ndarray:
+        H, W, S = self._dims
+        return self._get(lib().pm_get_normal_map, (3, H, W))
+
+    def GetSelProbMap(self) -> np.ndarray:
+        H, W, S = self._dims
+        return self._get(lib().pm_get_sel_prob_map, (S, H, W))
+
+    def GetConsistentImageIdxs(self) -> np.ndarray:
+        n = C.c_size_t(0)
+        _check(lib().pm_get_consistent_image_idxs(self._h, None, C.c_size_t(0), C.byref(n)))
+        buf = np.empty(n.value, np.int32)
+        _check(lib().pm_get_consistent_image_idxs(self._h, buf.ctypes.data_as(C.c_void_p),
+                                                  C.c_size_t(n.value), C.byref(n)))
+        return buf
+
+    def GetConsistencyGraph(self):
+        """(width, height, flat idx list) = the ctor arguments of ConsistencyGraph
+        (reference patch_match.cc:149-154, consistency_graph.cc:121-139)."""
+        H, W, S = self._dims
+        return W, H, self.GetConsistentImageIdxs()
+
+    # -- extras --------------------------------------------------------------------------
+    def GetCostMap(self) -> np.ndarray:
+        H, W, S = self._dims
+        return self._get(lib().pm_get_cost_map, (S, H, W))
+
+    def GetConsistencyMask(self) -> np.ndarray:
+        H, W, S = self._dims
+        return self._get(lib().pm_get_consistency_mask, (S, H, W), np.uint8)
+
+    def GetRefFilter(self):
+        H, W, S = self._dims
+        img = np.empty((H, W), np.uint8)
+        s = np.empty((H, W), np.float32)
+        ss = np.empty((H, W), np.float32)
+        _check(lib().pm_get_ref_filter(self._h, img.ctypes.data_as(C.c_void_p),
+                                       s.ctypes.data_as(C.c_void_p), ss.ctypes.data_as(C.c_void_p)))
+        return img, s, ss
+
+    def GetPoseTables(self):
+        H, W, S = self._dims
+        poses = np.empty((4, S, 43), np.float32)
+        K = np.empty((4, 4), np.float32)
+        iK = np.empty((4, 4), np.float32)
+        _check(lib().pm_get_pose_tables(self._h, poses.ctypes.data_as(C.c_void_p),
+                                        K.ctypes.data_as(C.c_void_p), iK.ctypes.data_as(C.c_void_p)))
+        return poses, K, iK
+
+    def GetSweepTiming(self):
+        ms = C.c_double(0)
+        n = C.c_int32(0)
+        _check(lib().pm_get_sweep_timing(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+
+def write_mat(path: str, a: np.ndarray):
+    """Mat<float>::Write (reference mvs/mat.cc:58-65): ASCII `W&H&D&` + little-endian
+    float32, slice-major."""
+    a = np.asarray(a, np.float32)
+    if a.ndim == 2:
+        a = a[None]
+    d, h, w = a.shape
+    with open(path, "wb") as f:
+        f.write(f"{w}&{h}&{d}&".encode())
+        f.write(a.astype("<f4").tobytes())
+
+
+def read_mat(path: str) -> np.ndarray:
+    """Mat<float>::Read (reference mvs/mat.cc:41-56)."""
+    with open(path, "rb") as f:
+        data = f.read()
+    parts = data.split(b"&", 3)
+    w, h, d = int(parts[0]), int(parts[1]), int(parts[2])
+    arr = np.frombuffer(parts[3], dtype="<f4", count=w * h * d).reshape(d, h, w)
+    return arr[0] if d == 1 else arr

@@ -1,0 +1,143 @@
+/*
+ * colmap_amd_pm.h -- C ABI of the MI355X-native PatchMatch multi-view stereo.
+ *
+ * Drop-in boundary: the private pimpl `std::unique_ptr<PatchMatchCuda>` inside
+ * colmap::mvs::PatchMatch (reference src/colmap/mvs/patch_match.h:95, used at
+ * patch_match.cc:128-153). Each entry point below replaces one member of
+ * `class PatchMatchCuda` (reference src/colmap/mvs/patch_match_cuda.h:49-59);
+ * INTEGRATION.md shows the C++ shim a COLMAP maintainer would add.
+ *
+ * Conventions
+ *   - plain C types only, no torch/HIP types; all matrices row-major float.
+ *   - every function returns 0 on success, non-zero on error; the message of
+ *     the last error on the calling thread is pm_last_error() (the reference
+ *     throws from THROW_CHECK / CUDA_SAFE_CALL, util/cudacc.cc:56-65; the shim
+ *     re-throws).
+ *   - the caller owns all input buffers for the lifetime of pm_create() only:
+ *     inputs are copied to HBM inside pm_create (the reference's ctor uploads in
+ *     InitRefImage/InitSourceImages, patch_match_cuda.cu:1290-1302).
+ *   - handles are independent and re-entrant across host threads; one handle is
+ *     bound to one GPU (options.gpu_index) and one HIP stream, so a host thread
+ *     per GPU (reference PatchMatchController, patch_match.cc:177,394) or several
+ *     handles per GPU both work.
+ */
+#ifndef COLMAP_AMD_PM_H_
+#define COLMAP_AMD_PM_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* colmap::mvs::PatchMatchOptions (reference mvs/patch_match_options.h:37-126),
+ * same names, same units (angles in degrees), same defaults via
+ * pm_options_init(). Fields that only concern the controller (cache_size,
+ * max_image_size, num_threads, allow_missing_files, write_consistency_graph)
+ * stay on the host side. */
+typedef struct pm_options {
+  double depth_min;
+  double depth_max;
+  double sigma_spatial;
+  double sigma_color;
+  double ncc_sigma;
+  double min_triangulation_angle;
+  double incident_angle_sigma;
+  double geom_consistency_regularizer;
+  double geom_consistency_max_cost;
+  double filter_min_ncc;
+  double filter_min_triangulation_angle;
+  double filter_geom_consistency_max_cost;
+  int32_t window_radius;
+  int32_t window_step;
+  int32_t num_samples;
+  int32_t num_iterations;
+  int32_t filter_min_num_consistent;
+  int32_t geom_consistency; /* bool */
+  int32_t filter;           /* bool */
+  int32_t gpu_index;        /* single device ordinal; -1 = current device */
+  /* extensions (0 = reference behaviour) */
+  int32_t max_sweeps;       /* debug: >0 stop after this many sweeps; 0: all; <0: initial cost only */
+  int32_t inputs_on_device; /* 1: gray/depth/normal pointers are device pointers */
+  int32_t columns_per_group;/* tuning: image columns per workgroup, 0 = auto */
+  int32_t threads_per_group;/* tuning: 0 = auto */
+} pm_options;
+
+/* colmap::mvs::Image (reference mvs/image.h:40-98) + the DepthMap / NormalMap of
+ * the same image (PatchMatch::Problem::depth_maps / normal_maps,
+ * mvs/patch_match.h:57-75). */
+typedef struct pm_image {
+  int32_t width, height;
+  float K[9];            /* only fx, fy, cx, cy may be non-trivial (patch_match.cc:101-106) */
+  float R[9];
+  float T[3];
+  const uint8_t* gray;   /* height*width grey bitmap, tightly packed rows */
+  const float* depth_map;  /* height*width, or NULL */
+  const float* normal_map; /* 3*height*width slice-major (Mat<float>, mat.h:107-109), or NULL */
+} pm_image;
+
+/* colmap::mvs::PatchMatch::Problem (reference mvs/patch_match.h:57-75) */
+typedef struct pm_problem {
+  int32_t ref_image_idx;
+  int32_t num_src_images;
+  const int32_t* src_image_idxs;
+  int32_t num_images;
+  const pm_image* images;
+} pm_problem;
+
+typedef struct pm_handle pm_handle;
+
+/* PatchMatchOptions default member initialisers (patch_match_options.h:37-126). */
+void pm_options_init(pm_options* options);
+
+/* PatchMatchOptions::Check (patch_match_options.cc:73-100) + PatchMatch::Check
+ * (patch_match.cc:67-126). */
+int pm_check(const pm_options* options, const pm_problem* problem);
+
+/* PatchMatchCuda::PatchMatchCuda(options, problem) (patch_match_cuda.cu:1290-1302):
+ * validates, uploads, filters the reference image, builds the pose tables,
+ * initialises depth/normal/PRNG state. */
+int pm_create(const pm_options* options, const pm_problem* problem, pm_handle** out);
+
+/* PatchMatchCuda::Run() (patch_match_cuda.cu:1304-1352,1393-1546): blocking. */
+int pm_run(pm_handle* h);
+/* Same work, enqueued on the handle's stream; pm_synchronize() waits. */
+int pm_run_async(pm_handle* h);
+int pm_synchronize(pm_handle* h);
+
+/* PatchMatchCuda::GetDepthMap / GetNormalMap / GetSelProbMap
+ * (patch_match_cuda.cu:1354-1365). out buffers are host memory:
+ * depth H*W, normal 3*H*W slice-major, sel_prob S*H*W slice-major. */
+int pm_get_depth_map(pm_handle* h, float* out);
+int pm_get_normal_map(pm_handle* h, float* out);
+int pm_get_sel_prob_map(pm_handle* h, float* out);
+
+/* PatchMatchCuda::GetConsistentImageIdxs (patch_match_cuda.cu:1367-1391): flat
+ * list [col, row, n, idx_1..idx_n]* with idx = problem.src_image_idxs[d]
+ * (consumed by ConsistencyGraph, mvs/consistency_graph.cc:121-139). Call with
+ * buf == NULL to obtain the required length in *count. */
+int pm_get_consistent_image_idxs(pm_handle* h, int32_t* buf, size_t capacity, size_t* count);
+
+/* Extras used by tests/bench (no reference counterpart). */
+int pm_get_cost_map(pm_handle* h, float* out);            /* S*H*W */
+int pm_get_consistency_mask(pm_handle* h, uint8_t* out);  /* S*H*W */
+int pm_get_ref_filter(pm_handle* h, uint8_t* image, float* sum, float* sqsum); /* H*W each */
+int pm_get_pose_tables(pm_handle* h, float* poses /*4*S*43*/, float* ref_K /*16*/, float* ref_inv_K /*16*/);
+/* HIP-event timing of the sweep kernel launches of the last run, measured on
+ * the handle's stream: total ms and launch count. */
+int pm_get_sweep_timing(pm_handle* h, double* total_ms, int32_t* num_launches);
+/* Device pointers of the result maps in API layout (valid after pm_synchronize;
+ * for consumers that stay on the GPU, e.g. the geometric pass). */
+int pm_get_device_maps(pm_handle* h, const float** depth, const float** normal);
+
+void pm_destroy(pm_handle* h);
+const char* pm_last_error(void);
+/* Number of visible GPUs (controller: gpu_index == -1 -> all devices,
+ * patch_match.cc:375-383). */
+int pm_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COLMAP_AMD_PM_H_ */

@@ -331,10 +331,10 @@ static inline float tex_src_bilinear(const pmo_state* st, int s, float x, float 
 /* source depth: point filter, element type, border 0, sampled at (+0.5,+0.5)
  * (patch_match_cuda.cu:635-636, 1677-1690) */
 static inline float tex_src_depth(const pmo_state* st, int s, float x, float y) {
-  const int ix = sat_f2i(floorf(x));
-  const int iy = sat_f2i(floorf(y));
-  if (ix < 0 || iy < 0 || ix >= st->src_w || iy >= st->src_h) return 0.0f;
-  return st->src_depths[((size_t)s * st->src_h + iy) * st->src_w + ix];
+  const float fx = floorf(x), fy = floorf(y);
+  /* float-domain range test so that NaN/inf coordinates hit the border */
+  if (!(fx >= 0.0f && fy >= 0.0f && fx < (float)st->src_w && fy < (float)st->src_h)) return 0.0f;
+  return st->src_depths[((size_t)s * st->src_h + (int)fy) * st->src_w + (int)fx];
 }
 
 /* ------------------------------------------------------------------------- */

@@ -1,0 +1,161 @@
+"""GPU parity tests: the HIP PatchMatch path (through the C ABI) against the CPU oracle.
+
+The arithmetic of the path is specified operation by operation (oracle/pm_oracle.c
+header), so the bar is BIT-EXACT equality of every output map, not a tolerance:
+a stochastic argmin algorithm amplifies one-ulp differences into different depth
+maps, so anything weaker than exact equality would not be a meaningful check.
+"""
+import numpy as np
+import pytest
+
+from pm_common import scene, oracle_inputs, hip_problem, paired_options
+from colmap_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_both(pm_oracle, views, ref, src, maps=None, **kw):
+    from colmap_amd import mvs
+    dmin, dmax = syn.depth_range(views, ref)
+    o, h = paired_options(pm_oracle, depth_min=dmin, depth_max=dmax, **kw)
+    imgs = oracle_inputs(views, maps is not None, maps)
+    want = pm_oracle.run(o, imgs, ref, src, want_cost=True)
+    pm = mvs.PatchMatch(h, hip_problem(views, ref, src, maps))
+    pm.Run()
+    got = dict(depth=pm.GetDepthMap(), normal=pm.GetNormalMap(), sel_prob=pm.GetSelProbMap(),
+               cost=pm.GetCostMap(), mask=pm.GetConsistencyMask())
+    return want, got, pm
+
+
+def _assert_equal(want, got, keys=("depth", "normal", "cost", "sel_prob", "mask")):
+    for k in keys:
+        a, b = want[k], got[k]
+        if not np.array_equal(a, b):
+            bad = np.argwhere(a != b)
+            raise AssertionError(f"{k}: {len(bad)} of {a.size} values differ, first at {bad[0]}: "
+                                 f"oracle {a[tuple(bad[0])]!r} hip {b[tuple(bad[0])]!r}")
+
+
+def test_pose_tables_and_ref_filter(pm_oracle):
+    from colmap_amd import mvs
+    views = scene()
+    _, h = paired_options(pm_oracle, depth_min=1.0, depth_max=10.0, geom_consistency=0, filter=0)
+    pm = mvs.PatchMatch(h, hip_problem(views, 2, [0, 1, 3, 4]))
+    pm.Create()
+    poses, K, iK = pm.GetPoseTables()
+    o_poses, o_K, o_iK = pm_oracle.pose_tables(oracle_inputs(views), 2, [0, 1, 3, 4])
+    assert np.array_equal(K, o_K) and np.array_equal(iK, o_iK)
+    assert np.array_equal(poses, o_poses)
+    img, s, ss = pm.GetRefFilter()
+    o_img, o_s, o_ss = pm_oracle.filter_ref_image(views[2].gray, 5, 1, 5.0, float(np.float32(0.2)))
+    assert np.array_equal(img, o_img) and np.array_equal(s, o_s) and np.array_equal(ss, o_ss)
+
+
+def test_initial_state_and_cost(pm_oracle):
+    """PRNG seeding, random depth/normal initialisation, ComputeInitialCost."""
+    views = scene()
+    want, got, _ = _run_both(pm_oracle, views, 2, [0, 1, 3, 4], geom_consistency=0, filter=0,
+                             max_sweeps=0)
+    _assert_equal(want, got, ("depth", "normal", "cost"))
+
+
+@pytest.mark.parametrize("nsweeps", [1, 2, 3, 4])
+def test_each_sweep_direction(pm_oracle, nsweeps):
+    """Every sweep direction of the virtual rotation against the oracle's physical rotation."""
+    views = scene()
+    want, got, _ = _run_both(pm_oracle, views, 2, [0, 1, 3, 4], geom_consistency=0, filter=0,
+                             max_sweeps=nsweeps)
+    _assert_equal(want, got, ("depth", "normal", "cost", "sel_prob"))
+
+
+def test_full_photometric_with_filter(pm_oracle):
+    views = scene()
+    want, got, pm = _run_both(pm_oracle, views, 2, [0, 1, 3, 4], geom_consistency=0, filter=1)
+    _assert_equal(want, got)
+    # consistency graph list (GetConsistentImageIdxs, reference patch_match_cuda.cu:1367-1391)
+    flat = pm.GetConsistentImageIdxs()
+    mask = want["mask"]
+    src = [0, 1, 3, 4]
+    expect = []
+    for r in range(mask.shape[1]):
+        for c in range(mask.shape[2]):
+            ids = [src[d] for d in range(mask.shape[0]) if mask[d, r, c]]
+            if ids:
+                expect += [c, r, len(ids)] + ids
+    assert np.array_equal(flat, np.array(expect, np.int32))
+    ms, n = pm.GetSweepTiming()
+    assert n == 20 and ms > 0
+
+
+def test_geometric_consistency_and_filter(pm_oracle):
+    views = scene(3, 80, 60)
+    maps = []
+    for ref in range(3):
+        dmin, dmax = syn.depth_range(views, ref)
+        o = pm_oracle.default_options(depth_min=dmin, depth_max=dmax, geom_consistency=0, filter=0,
+                                      num_iterations=1)
+        r = pm_oracle.run(o, oracle_inputs(views), ref, [i for i in range(3) if i != ref])
+        maps.append((r["depth"], r["normal"]))
+    want, got, _ = _run_both(pm_oracle, views, 1, [0, 2], maps=maps, geom_consistency=1, filter=1,
+                             num_iterations=2)
+    _assert_equal(want, got)
+    want, got, _ = _run_both(pm_oracle, views, 1, [0, 2], maps=maps, geom_consistency=1, filter=0,
+                             num_iterations=1)
+    _assert_equal(want, got)
+
+
+@pytest.mark.parametrize("radius,step", [(3, 1), (5, 2), (8, 1), (4, 2)])
+def test_window_shapes(pm_oracle, radius, step):
+    views = scene(4, 64, 48)
+    want, got, _ = _run_both(pm_oracle, views, 1, [0, 2, 3], geom_consistency=0, filter=1,
+                             window_radius=radius, window_step=step, num_iterations=1)
+    _assert_equal(want, got)
+
+
+@pytest.mark.parametrize("cols,threads", [(1, 64), (3, 64), (4, 128), (8, 256), (16, 64)])
+def test_group_shapes_do_not_change_results(pm_oracle, cols, threads):
+    """Ragged image width (67 is not a multiple of any group width) and every
+    workgroup geometry give the same bits."""
+    views = scene(4, 67, 45)
+    want, got, _ = _run_both(pm_oracle, views, 1, [0, 2, 3], geom_consistency=0, filter=1,
+                             num_iterations=1, columns_per_group=cols, threads_per_group=threads)
+    _assert_equal(want, got)
+
+
+def test_single_source_and_many_samples(pm_oracle):
+    views = scene(4, 64, 48)
+    want, got, _ = _run_both(pm_oracle, views, 1, [2], geom_consistency=0, filter=1,
+                             filter_min_num_consistent=1, num_iterations=1, num_samples=25)
+    _assert_equal(want, got)
+
+
+def test_sources_larger_than_reference_slot(pm_oracle):
+    """Source images of unequal size share a max-size slot (reference :1596-1622)."""
+    big = scene(3, 96, 72)
+    small = scene(3, 64, 48)
+    views = [small[0], big[1], big[2]]
+    want, got, _ = _run_both(pm_oracle, views, 1, [0, 2], geom_consistency=0, filter=0,
+                             num_iterations=1)
+    _assert_equal(want, got)
+
+
+def test_error_behaviour():
+    from colmap_amd import mvs
+    views = scene(3, 64, 48)
+    opt = mvs.PatchMatchOptions(gpu_index="0", depth_min=1.0, depth_max=5.0, sigma_spatial=5.0,
+                                geom_consistency=False)
+    with pytest.raises(mvs.PatchMatchError):
+        mvs.PatchMatch(opt, hip_problem(views, 1, [1, 2])).Run()      # ref as source
+    with pytest.raises(mvs.PatchMatchError):
+        mvs.PatchMatch(opt, hip_problem(views, 1, [])).Run()          # no sources
+    bad = mvs.PatchMatchOptions(gpu_index="0,1", depth_min=1.0, depth_max=5.0, sigma_spatial=5.0)
+    with pytest.raises(mvs.PatchMatchError):
+        mvs.PatchMatch(bad, hip_problem(views, 1, [0, 2])).Run()      # exactly one GPU index
+    geo = mvs.PatchMatchOptions(gpu_index="0", depth_min=1.0, depth_max=5.0, sigma_spatial=5.0,
+                                geom_consistency=True)
+    with pytest.raises(mvs.PatchMatchError):
+        mvs.PatchMatch(geo, hip_problem(views, 1, [0, 2])).Run()      # missing depth/normal maps
+    win = mvs.PatchMatchOptions(gpu_index="0", depth_min=1.0, depth_max=5.0, sigma_spatial=5.0,
+                                geom_consistency=False, window_step=3)
+    with pytest.raises(mvs.PatchMatchError):
+        mvs.PatchMatch(win, hip_problem(views, 1, [0, 2])).Run()      # window_step <= 2

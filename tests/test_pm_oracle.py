@@ -1,0 +1,221 @@
+"""CPU tests of the PatchMatch oracle: known answers the reference's own tests hold for
+the pieces either side of the kernel, the arithmetic spec, and end-to-end sanity."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from pm_common import scene, oracle_inputs
+from colmap_amd import synthetic as syn
+
+
+def _f(*v):
+    return (C.c_float * len(v))(*v)
+
+
+# ---- known answers from the reference's mvs/image_test.cc ------------------------------
+
+def test_compute_projection_center_identity(pm_oracle):
+    # image_test.cc:147-156
+    Cc = (C.c_float * 3)()
+    pm_oracle.lib().pmo_compute_projection_center(_f(1, 0, 0, 0, 1, 0, 0, 0, 1), _f(1, 2, 3), Cc)
+    assert list(Cc) == [-1.0, -2.0, -3.0]
+
+
+def test_compose_projection_matrix(pm_oracle):
+    # image_test.cc:158-169
+    P = (C.c_float * 12)()
+    pm_oracle.lib().pmo_compose_projection_matrix(_f(2, 0, 0, 0, 2, 0, 0, 0, 1), _f(0, 1, 0, 1, 0, 0, 0, 0, 1),
+                                                  _f(1, 2, 3), P)
+    assert list(P) == [0, 2, 0, 2, 2, 0, 0, 4, 0, 0, 1, 3]
+
+
+def test_rotate_pose(pm_oracle):
+    # image_test.cc:171-209
+    R = _f(1, 0, 0, 0, 1, 0, 0, 0, 1)
+    T = _f(1, 2, 3)
+    pm_oracle.lib().pmo_rotate_pose(_f(1, 0, 0, 0, 1, 0, 0, 0, 1), R, T)
+    assert list(R) == [1, 0, 0, 0, 1, 0, 0, 0, 1] and list(T) == [1, 2, 3]
+    R = _f(1, 0, 0, 0, 1, 0, 0, 0, 1)
+    T = _f(1, 0, 0)
+    pm_oracle.lib().pmo_rotate_pose(_f(0, -1, 0, 1, 0, 0, 0, 0, 1), R, T)
+    assert list(R) == [0, -1, 0, 1, 0, 0, 0, 0, 1] and list(T) == [0, 1, 0]
+
+
+def test_inverse_projection_matrix(pm_oracle):
+    rng = np.random.default_rng(0)
+    K = np.array([[500, 0, 320], [0, 510, 240], [0, 0, 1]], np.float32)
+    q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+    R = (q * np.sign(np.linalg.det(q))).astype(np.float32)
+    T = rng.normal(size=3).astype(np.float32)
+    out = (C.c_float * 12)()
+    pm_oracle.lib().pmo_compose_inverse_projection_matrix(_f(*K.ravel()), _f(*R.ravel()), _f(*T), out)
+    P = np.eye(4)
+    P[:3] = K.astype(np.float64) @ np.concatenate([R, T[:, None]], 1).astype(np.float64)
+    np.testing.assert_allclose(np.array(out).reshape(3, 4), np.linalg.inv(P)[:3], rtol=2e-4, atol=2e-5)
+
+
+def test_rotate_matches_gpu_mat_test(pm_oracle):
+    # expectation of TestRotateImage, reference mvs/gpu_mat_test.cu:151-186
+    for (w, h, d) in [(20, 40, 1), (60, 20, 3), (40, 40, 2)]:
+        a = np.random.default_rng(1).uniform(0, 100, (d, h, w)).astype(np.float32)
+        out = np.zeros((d, w, h), np.float32)
+        pm_oracle.lib().pmo_rotate_f32(a.ctypes.data_as(C.c_void_p), w, h, d, out.ctypes.data_as(C.c_void_p))
+        ch, cv, ang = w / 2.0 - 0.5, h / 2.0 - 0.5, -np.pi / 2
+        for r in range(h):
+            for c in range(w):
+                rotc = int(round(np.cos(ang) * (c - ch) - np.sin(ang) * (r - cv) + cv))
+                rotr = int(round(np.sin(ang) * (c - ch) + np.cos(ang) * (r - cv) + ch))
+                assert np.array_equal(a[:, r, c], out[:, rotr, rotc])
+
+
+# ---- arithmetic spec -------------------------------------------------------------------
+
+def test_exp_polynomial(pm_oracle):
+    x = np.concatenate([np.linspace(-87, 2, 4001), [-1e-8, 0.0, -100.0, -87.5]]).astype(np.float32)
+    y = pm_oracle.exp_f32(x)
+    ref = np.exp(x.astype(np.float64))
+    ok = x >= -87
+    assert np.max(np.abs(y[ok] - ref[ok]) / ref[ok]) < 2.5e-7
+    assert np.all(y[~ok] == 0)
+
+
+def test_sincos_polynomial(pm_oracle):
+    a = np.linspace(-7, 7, 5001).astype(np.float32)
+    s, c = pm_oracle.sincos_f32(a)
+    assert np.max(np.abs(s - np.sin(a.astype(np.float64)))) < 3e-7
+    assert np.max(np.abs(c - np.cos(a.astype(np.float64)))) < 3e-7
+
+
+def test_xorwow_stream(pm_oracle):
+    """Generator recurrence + rocRAND seeding (rocrand_xorwow.h), independent numpy restatement."""
+    def stream(seed, n):
+        M = 0xFFFFFFFF
+        x = [123456789, 362436069, 521288629, 88675123, 5783321]
+        d = 6615241
+        s0 = (seed & M) ^ 0x2c7f967f
+        s1 = (seed >> 32) ^ 0xa03697cb
+        t0 = (1228688033 * s0) & M
+        t1 = (2073658381 * s1) & M
+        x[0] = (x[0] + t0) & M; x[1] ^= t0; x[2] = (x[2] + t1) & M; x[3] ^= t1; x[4] = (x[4] + t0) & M
+        d = (d + t1 + t0) & M
+        out = []
+        for _ in range(n):
+            t = x[0] ^ (x[0] >> 2)
+            x = x[1:] + [((x[4] ^ (x[4] << 4)) ^ (t ^ (t << 1))) & M]
+            d = (d + 362437) & M
+            out.append((d + x[4]) & M)
+        return np.array(out, np.uint32)
+    for seed in (0, 1, 511, 123456, 2**33 + 5):
+        raw, uni = pm_oracle.rng_stream(seed, 64)
+        assert np.array_equal(raw, stream(seed, 64))
+        expect = np.float32(2.3283064e-10) + raw.astype(np.float32) * np.float32(2.3283064e-10)
+        assert np.array_equal(uni, expect.astype(np.float32))
+        assert np.all(uni > 0) and np.all(uni <= 1)
+
+
+def test_texel_requantisation_is_identity():
+    """FilterKernel re-quantises the reference image as uint8(255 * (b/255)) (reference
+    gpu_mat_ref_image.cu:77); with correctly rounded b/255 this maps every byte to itself."""
+    b = np.arange(256, dtype=np.float32)
+    t = (b / np.float32(255.0)).astype(np.float32)
+    assert np.array_equal((np.float32(255.0) * t).astype(np.uint8), np.arange(256))
+
+
+# ---- algorithm-level sanity ---------------------------------------------------------------
+
+def test_ref_filter_matches_numpy(pm_oracle):
+    v = scene()[2]
+    img, s, ss = pm_oracle.filter_ref_image(v.gray, 3, 1, 3.0, 0.2)
+    assert np.array_equal(img, v.gray)
+    g = np.pad(v.gray.astype(np.float64) / 255.0, 3)
+    H, W = v.gray.shape
+    r, c = 17, 29
+    acc = np.zeros(3)
+    for dr in range(-3, 4):
+        for dc in range(-3, 4):
+            col = g[r + 3 + dr, c + 3 + dc]
+            w = np.exp(-(dr * dr + dc * dc) / (2 * 9.0) - (g[r + 3, c + 3] - col) ** 2 / (2 * 0.04))
+            acc += [w * col, w * col * col, w]
+    assert abs(s[r, c] - acc[0] / acc[2]) < 1e-5 and abs(ss[r, c] - acc[1] / acc[2]) < 1e-5
+
+
+def test_memoised_equals_plain(pm_oracle):
+    """Caching bit-identical NCC values / bilateral weights inside a row step (what the
+    HIP kernel does) does not change a single bit of the result."""
+    views = scene(4, 64, 48)
+    imgs = oracle_inputs(views)
+    dmin, dmax = syn.depth_range(views, 1)
+    outs = []
+    for memo in (0, 1):
+        o = pm_oracle.default_options(depth_min=dmin, depth_max=dmax, geom_consistency=0, filter=1,
+                                      num_iterations=1, memoize=memo)
+        outs.append(pm_oracle.run(o, imgs, 1, [0, 2, 3], want_cost=True))
+    for k in outs[0]:
+        assert np.array_equal(outs[0][k], outs[1][k]), k
+
+
+def test_thread_count_does_not_change_result(pm_oracle):
+    views = scene(4, 64, 48)
+    imgs = oracle_inputs(views)
+    dmin, dmax = syn.depth_range(views, 1)
+    outs = []
+    for nt in (1, 3):
+        o = pm_oracle.default_options(depth_min=dmin, depth_max=dmax, geom_consistency=0, filter=0,
+                                      num_iterations=1, num_threads=nt)
+        outs.append(pm_oracle.run(o, imgs, 1, [0, 2, 3]))
+    assert np.array_equal(outs[0]["depth"], outs[1]["depth"])
+
+
+def test_recovers_ground_truth_depth(pm_oracle):
+    views = scene(5, 128, 96)
+    imgs = oracle_inputs(views)
+    dmin, dmax = syn.depth_range(views, 2)
+    o = pm_oracle.default_options(depth_min=dmin, depth_max=dmax, geom_consistency=0, filter=0)
+    out = pm_oracle.run(o, imgs, 2, [0, 1, 3, 4])
+    gt = views[2].depth
+    rel = np.abs(out["depth"] - gt) / gt
+    assert np.median(rel) < 0.01
+    assert (rel < 0.05).mean() > 0.8
+    nrm = np.linalg.norm(out["normal"], axis=0)
+    np.testing.assert_allclose(nrm, 1.0, atol=1e-4)
+
+
+def test_geometric_pass_and_filter(pm_oracle):
+    """Two-pass flow of PatchMatchController::Run (reference patch_match.cc:183-204):
+    photometric without filtering for every image, then geometric + filter."""
+    views = scene(3, 64, 48)
+    imgs = oracle_inputs(views)
+    maps = []
+    for ref in range(3):
+        dmin, dmax = syn.depth_range(views, ref)
+        o = pm_oracle.default_options(depth_min=dmin, depth_max=dmax, geom_consistency=0, filter=0,
+                                      num_iterations=2)
+        r = pm_oracle.run(o, imgs, ref, [i for i in range(3) if i != ref])
+        maps.append((r["depth"], r["normal"]))
+    imgs2 = oracle_inputs(views, True, maps)
+    dmin, dmax = syn.depth_range(views, 1)
+    o = pm_oracle.default_options(depth_min=dmin, depth_max=dmax, geom_consistency=1, filter=1,
+                                  num_iterations=2)
+    r = pm_oracle.run(o, imgs2, 1, [0, 2])
+    kept = r["depth"] > 0
+    assert 0.2 < kept.mean() <= 1.0
+    # filtered pixels: depth, normal and mask all zero (reference :1267-1275)
+    assert np.all(r["normal"][:, ~kept] == 0) and np.all(r["mask"][:, ~kept] == 0)
+    # kept pixels have >= filter_min_num_consistent consistent views
+    assert np.all(r["mask"][:, kept].sum(0) >= 2)
+    gt = views[1].depth
+    rel = np.abs(r["depth"][kept] - gt[kept]) / gt[kept]
+    assert np.median(rel) < 0.03  # 64x48 images, two iterations
+
+
+def test_problem_checks(pm_oracle):
+    views = scene(3, 64, 48)
+    imgs = oracle_inputs(views)
+    o = pm_oracle.default_options(depth_min=1, depth_max=10, geom_consistency=0, filter=0)
+    with pytest.raises(RuntimeError):
+        pm_oracle.run(o, imgs, 1, [1, 2])  # reference image as source (patch_match.cc:87-91)
+    with pytest.raises(RuntimeError):
+        pm_oracle.run(o, imgs, 1, [0, 0])  # duplicates
+    with pytest.raises(RuntimeError):
+        pm_oracle.run(o, imgs, 1, [])      # no sources (:85)
