@@ -1,0 +1,211 @@
+#!/usr/bin/env python
+"""bench.py -- PatchMatch MVS throughput on MI355X (BASELINE.json metric:
+"PatchMatch Mpix/s @2560x1920", config[1]: 100-image ring, S=20, photometric only).
+
+One process per GPU (torch.distributed / RCCL only for the barrier and the
+max-over-ranks reduction: the path shards by reference image, no data-path
+collective -- SURVEY.md section 8e). A "step" is one batch of `--batch` reference images
+solved concurrently on this rank's GPU (each: upload from HBM-resident inputs,
+reference filter, 2x2 footprint packing, initial cost, 5 x 4 sweeps, extraction).
+
+Prints ONE JSON line (rank 0). See DESIGN.md "Measurement" for the derivation of
+roofline.achieved (algorithmic bytes per sweep launch) and the CPU baseline sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--width", type=int, default=2560)
+    ap.add_argument("--height", type=int, default=1920)
+    ap.add_argument("--num-src", type=int, default=20)
+    ap.add_argument("--ring", type=int, default=100, help="cameras on the full ring (config[1]: 100)")
+    ap.add_argument("--batch", type=int, default=8, help="reference images solved concurrently per step")
+    ap.add_argument("--cols", type=int, default=0)
+    ap.add_argument("--threads", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-crop", type=str, default="512x384")
+    return ap.parse_args()
+
+
+def cpu_baseline(views, ref, src, dmin, dmax, crop_wh):
+    """Oracle (CPU restatement, all host cores) on a bounded sample of the same workload:
+    a centre crop of one full-resolution reference image against its full-resolution
+    sources, all 20 sweeps. Per-pixel work is that of the full image."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pm_oracle
+    cw, ch = crop_wh
+    v = views[ref]
+    H, W = v.gray.shape
+    x0, y0 = (W - cw) // 2, (H - ch) // 2
+    K = v.K.copy()
+    K[0, 2] -= x0
+    K[1, 2] -= y0
+    imgs = []
+    for i, vv in enumerate(views):
+        if i == ref:
+            imgs.append(dict(K=K, R=vv.R, T=vv.T, gray=np.ascontiguousarray(vv.gray[y0:y0 + ch, x0:x0 + cw])))
+        else:
+            imgs.append(dict(K=vv.K, R=vv.R, T=vv.T, gray=vv.gray))
+    o = pm_oracle.default_options(depth_min=dmin, depth_max=dmax, geom_consistency=0, filter=1)
+    t = time.time()
+    pm_oracle.run(o, imgs, ref, src)
+    dt = time.time() - t
+    return dict(value=cw * ch / 1e6 / dt, unit="Mpix/s", cores=int(pm_oracle.lib().pmo_num_threads()),
+                kind="port",
+                sample=f"oracle/pm_oracle.c on a {cw}x{ch} centre crop of one {W}x{H} reference image, "
+                       f"S={len(src)} full-resolution sources, 5x4 sweeps, {dt:.1f} s wall")
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from colmap_amd import mvs, synthetic as syn
+
+    S = a.num_src
+    nsteps = a.steps + a.warmup
+    nref = nsteps * a.batch
+    # this rank's window of the ring: `nref` consecutive reference cameras + S/2 neighbours either side
+    half = S // 2
+    step_deg = 360.0 / a.ring
+    first = rank * nref  # disjoint reference images per rank (weak scaling)
+    idx0 = first - half
+    nviews = nref + S
+    cams = syn.ring_cameras(nviews, a.width, a.height, 2400.0 * a.width / 2560.0, arc_deg=step_deg * (nviews - 1),
+                            start_deg=idx0 * step_deg)
+    views = []
+    for (K, R, T) in cams:
+        g, d, n = syn.render_view(K, R, T, a.width, a.height, seed=0, device=str(dev))
+        views.append((K, R, T, g, float(d.min()), float(d.max())))
+    images = [mvs.Image(K, R, T, g) for (K, R, T, g, _, _) in views]
+
+    def problem(j):  # j-th reference image of this rank
+        ref = half + j
+        src = [ref + o for o in range(-half, half + 1) if o != 0][:S]
+        dmin, dmax = views[ref][4] * 0.9, views[ref][5] * 1.1
+        opt = mvs.PatchMatchOptions(gpu_index=str(local_rank), depth_min=dmin, depth_max=dmax,
+                                    sigma_spatial=5.0, geom_consistency=False, filter=True,
+                                    columns_per_group=a.cols, threads_per_group=a.threads)
+        return mvs.PatchMatch(opt, mvs.PatchMatch.Problem(ref, src, images)), (ref, src, dmin, dmax)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    sweep_ms, sweep_n = 0.0, 0
+
+    def run_step(step, record):
+        nonlocal sweep_ms, sweep_n
+        pms = [problem(step * a.batch + b)[0] for b in range(a.batch)]
+        for pm in pms:
+            pm.Create()
+        mvs.run_batch(pms)  # one launch per sweep covers the whole batch
+        if record:
+            ms, n = pms[0].GetSweepTiming()
+            sweep_ms += ms
+            sweep_n += n
+        for pm in pms:
+            pm.close()
+
+    for w in range(a.warmup):
+        run_step(w, False)
+    barrier()
+    t0 = time.time()
+    for k in range(a.steps):
+        run_step(a.warmup + k, True)
+    barrier()
+    dt = time.time() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        pix_per_image = a.width * a.height
+        total_images = a.steps * a.batch * world
+        value = total_images * pix_per_image / 1e6 / dt
+        # (40 + 24*S) algorithmic HBM bytes per pixel per sweep launch
+        alg_bytes = (40 + 24 * S) * pix_per_image * a.batch  # one launch sweeps the whole batch
+        avg_ms = sweep_ms / max(sweep_n, 1)
+        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+        out = {
+            "metric": "PatchMatch Mpix/s @2560x1920",
+            "value": value,
+            "unit": "Mpix/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": dt / a.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"PatchMatch MVS, photometric only (geom_consistency=false, filter=true), "
+                            f"{a.ring}-camera ring stand-in for Gerrard-Hall, {a.width}x{a.height}, "
+                            f"S={S} sources, window 11x11, 15 samples, 5x4 sweeps; "
+                            f"{a.batch} reference images per step per GPU",
+                "images_per_step_per_gpu": a.batch,
+                "parallelism": f"reference images sharded over {world} GPU(s), no data-path collective",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "pm_sweep_kernel",
+                "achieved": achieved,
+                "peak": 8000.0,
+                "unit": "GB/s",
+                "frac": achieved / 8000.0,
+                "traffic": None,
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "avg_launch_ms": avg_ms,
+                "launches_timed": sweep_n,
+                "images_per_launch": a.batch,
+                "note": "fp32-VALU bound by construction (SURVEY.md 8d: HBM floor ~6 ms vs VALU floor "
+                        "~185 ms per image), no dense contraction, so neither the HBM nor the MFMA "
+                        "roofline can be approached; see DESIGN.md for the VALU-issue accounting",
+            },
+        }
+        if not a.no_cpu_baseline:
+            ref, src, dmin, dmax = problem(0)[1]
+            cw, ch = [int(x) for x in a.cpu_crop.split("x")]
+            host_views = [syn.View(K, R, T, g.cpu().numpy(), None, None) for (K, R, T, g, _, _) in views]
+            out["cpu_baseline"] = cpu_baseline(host_views, ref, src, dmin, dmax, (cw, ch))
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

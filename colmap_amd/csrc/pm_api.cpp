@@ -210,6 +210,9 @@ struct pm_handle {
   DevBuf<uint8_t> mask;
   DevBuf<float> poses;  // [4][S][43]
   DevBuf<float> out_depth, out_normal, out_sel, out_cost;
+  DevBuf<unsigned long long> prof;
+  DevBuf<PmParams> plan;  // per-launch parameter blocks of the last (batched) run
+  hipStream_t run_stream = nullptr;  // stream the last run was enqueued on
   PmParams base;
   int threads = 64;
   int sweeps_done = 0;
@@ -378,7 +381,7 @@ void Create(const pm_options& opt_in, const pm_problem& prob, pm_handle* h) {
   b.sel_in_off = 4 + 2 * S;    // ... and reads half B (= 0.5)
   b.C = pm_pick_columns(S, b.ntaps, b.num_samples, opt.geom_consistency != 0, b.radius,
                         opt.columns_per_group);
-  h->threads = opt.threads_per_group > 0 ? ((opt.threads_per_group + 63) / 64) * 64 : 64;
+  h->threads = opt.threads_per_group > 0 ? ((opt.threads_per_group + 63) / 64) * 64 : 128;
   h->threads = std::min(h->threads, 256);  // pm_sweep_kernel __launch_bounds__
   // SweepOptions (reference :1420-1438); doubles narrowed to float where the reference does
   const float sigma_spatial = (float)opt.sigma_spatial;
@@ -442,50 +445,96 @@ void Create(const pm_options& opt_in, const pm_problem& prob, pm_handle* h) {
   HIP_CALL(hipStreamSynchronize(h->stream));
 }
 
-// RunWithWindowSizeAndStep, reference patch_match_cuda.cu:1393-1546
-void RunAsync(pm_handle* h) {
-  HIP_CALL(hipSetDevice(h->device));
-  const pm_options& opt = h->opt;
-  PmParams p0 = ParamsForSweep(h, 0);
-  pm_launch_initial_cost(p0, h->stream);
-
-  const float total_num_steps = (float)(opt.num_iterations * 4);
-  int sweeps = 0;
-  int sel_out = h->base.sel_out_off, sel_in = h->base.sel_in_off;
-  const int limit = opt.max_sweeps > 0 ? opt.max_sweeps : (opt.max_sweeps < 0 ? 0 : opt.num_iterations * 4);
-  if (h->mask.ptr) HIP_CALL(hipMemsetAsync(h->mask.ptr, 0, h->mask.count, h->stream));
-  for (int iter = 0; iter < opt.num_iterations && sweeps < limit; ++iter) {
-    for (int sweep = 0; sweep < 4 && sweeps < limit; ++sweep) {
-      const int rot = (iter * 4 + sweep) % 4;
-      PmParams p = ParamsForSweep(h, rot);
+// RunWithWindowSizeAndStep, reference patch_match_cuda.cu:1393-1546, for a batch of
+// `n` problems of identical shape solved together: every kernel launch covers all n
+// reference images (grid.y / grid.z = problem), so one sweep launch fills the GPU
+// even when a single image has too few columns. All work is enqueued on hs[0]'s
+// stream; n == 1 is the reference's one-problem-at-a-time Run().
+void RunBatchAsync(pm_handle** hs, int n) {
+  PM_CHECK(n >= 1, "empty batch");
+  pm_handle* h0 = hs[0];
+  HIP_CALL(hipSetDevice(h0->device));
+  const pm_options& opt = h0->opt;
+  for (int b = 1; b < n; ++b) {
+    const pm_handle* h = hs[b];
+    PM_CHECK(h->device == h0->device, "batch on one device");
+    PM_CHECK(h->W == h0->W && h->H == h0->H && h->S == h0->S && h->src_w == h0->src_w &&
+                 h->src_h == h0->src_h,
+             "batched problems must have identical image sizes and source counts");
+    const pm_options& o = h->opt;
+    PM_CHECK(o.window_radius == opt.window_radius && o.window_step == opt.window_step &&
+                 o.num_samples == opt.num_samples && o.num_iterations == opt.num_iterations &&
+                 o.geom_consistency == opt.geom_consistency && o.filter == opt.filter &&
+                 o.max_sweeps == opt.max_sweeps,
+             "batched problems must share window / sample / iteration / filter options");
+    // work enqueued on other streams at create time must be complete
+    HIP_CALL(hipStreamSynchronize(h->stream));
+  }
+  const int total_sweeps = opt.num_iterations * 4;
+  const int limit = opt.max_sweeps > 0 ? std::min(opt.max_sweeps, total_sweeps)
+                                       : (opt.max_sweeps < 0 ? 0 : total_sweeps);
+  // parameter blocks: [initial cost | sweep 0 | ... | sweep limit-1] x n problems
+  std::vector<PmParams> host((size_t)(limit + 1) * n);
+  for (int b = 0; b < n; ++b) host[b] = ParamsForSweep(hs[b], 0);
+  const float total_num_steps = (float)total_sweeps;
+  int sel_out = h0->base.sel_out_off, sel_in = h0->base.sel_in_off;
+  for (int k = 0; k < limit; ++k) {
+    const int iter = k / 4, sweep = k % 4;
+    for (int b = 0; b < n; ++b) {
+      PmParams p = ParamsForSweep(hs[b], k % 4);
+      // exponentially reduce the perturbation, linearly increase the influence of the
+      // previous selection probabilities (reference :1446-1451)
       p.perturbation = 1.0f / std::pow(2.0f, iter + sweep / 4.0f);
       p.perturbation_pi = (float)(p.perturbation * M_PI);
       p.prev_sel_prob_weight = (float)(iter * 4 + sweep) / total_num_steps;
       p.sel_out_off = sel_out;
       p.sel_in_off = sel_in;
-      const bool last_sweep = iter == opt.num_iterations - 1 && sweep == 3;
-      const bool geom = opt.geom_consistency != 0;
-      const bool fphoto = last_sweep && opt.filter;
-      const bool fgeom = last_sweep && opt.filter && geom;
-      HIP_CALL(hipEventRecord(h->ev[2 * sweeps], h->stream));
-      pm_launch_sweep(p, h->threads, geom, fphoto, fgeom, h->stream);
-      HIP_CALL(hipEventRecord(h->ev[2 * sweeps + 1], h->stream));
-      std::swap(sel_out, sel_in);  // Rotate(): prev_sel_prob <- sel_prob (reference :1911-1915)
-      ++sweeps;
+      host[(size_t)(k + 1) * n + b] = p;
     }
+    std::swap(sel_out, sel_in);  // Rotate(): prev_sel_prob <- sel_prob (reference :1911-1915)
   }
-  h->sweeps_done = sweeps;
-  h->final_sel_off = sel_in;  // the half written by the last sweep
-  PmParams pe = ParamsForSweep(h, 0);
-  pm_launch_extract(pe, h->final_sel_off, h->out_depth.ptr, h->out_normal.ptr, h->out_sel.ptr,
-                    h->out_cost.ptr, h->stream);
+  h0->plan.alloc(host.size());
+  HIP_CALL(hipMemcpyAsync(h0->plan.ptr, host.data(), host.size() * sizeof(PmParams),
+                          hipMemcpyHostToDevice, h0->stream));
+  // the stream-ordered copy reads `host` asynchronously only for pageable memory in
+  // theory; make the lifetime explicit
+  HIP_CALL(hipStreamSynchronize(h0->stream));
+
+  for (int b = 0; b < n; ++b) {
+    pm_handle* h = hs[b];
+    if (h->mask.ptr) HIP_CALL(hipMemsetAsync(h->mask.ptr, 0, h->mask.count, h0->stream));
+    if (h->prof.ptr)
+      HIP_CALL(hipMemsetAsync(h->prof.ptr, 0, 10 * sizeof(unsigned long long), h0->stream));
+  }
+  pm_launch_initial_cost(host[0], h0->plan.ptr, n, h0->stream);
+  const bool geom = opt.geom_consistency != 0;
+  for (int k = 0; k < limit; ++k) {
+    const bool last_sweep = k == total_sweeps - 1;
+    const bool fphoto = last_sweep && opt.filter;
+    const bool fgeom = last_sweep && opt.filter && geom;
+    HIP_CALL(hipEventRecord(h0->ev[2 * k], h0->stream));
+    pm_launch_sweep(host[(size_t)(k + 1) * n], h0->plan.ptr + (size_t)(k + 1) * n, n, h0->threads,
+                    geom, fphoto, fgeom, h0->stream);
+    HIP_CALL(hipEventRecord(h0->ev[2 * k + 1], h0->stream));
+  }
+  for (int b = 0; b < n; ++b) {
+    pm_handle* h = hs[b];
+    h->sweeps_done = b == 0 ? limit : 0;
+    h->final_sel_off = sel_in;  // the half written by the last sweep
+    PmParams pe = ParamsForSweep(h, 0);
+    pm_launch_extract(pe, h->final_sel_off, h->out_depth.ptr, h->out_normal.ptr, h->out_sel.ptr,
+                      h->out_cost.ptr, h0->stream);
+    h->ran = true;
+    h->run_stream = h0->stream;
+  }
   HIP_CALL(hipGetLastError());
-  h->ran = true;
 }
+
+void RunAsync(pm_handle* h) { RunBatchAsync(&h, 1); }
 
 void Synchronize(pm_handle* h) {
   HIP_CALL(hipSetDevice(h->device));
-  HIP_CALL(hipStreamSynchronize(h->stream));
+  HIP_CALL(hipStreamSynchronize(h->run_stream ? h->run_stream : h->stream));
   h->sweep_ms = 0.0;
   h->sweep_launches = h->sweeps_done;
   for (int i = 0; i < h->sweeps_done; ++i) {
@@ -499,8 +548,9 @@ template <typename T>
 void CopyOut(pm_handle* h, const T* dev, T* out, size_t n) {
   PM_CHECK(h->ran, "pm_run must be called first");
   HIP_CALL(hipSetDevice(h->device));
-  HIP_CALL(hipMemcpyAsync(out, dev, n * sizeof(T), hipMemcpyDeviceToHost, h->stream));
-  HIP_CALL(hipStreamSynchronize(h->stream));
+  hipStream_t st = h->run_stream ? h->run_stream : h->stream;
+  HIP_CALL(hipMemcpyAsync(out, dev, n * sizeof(T), hipMemcpyDeviceToHost, st));
+  HIP_CALL(hipStreamSynchronize(st));
 }
 
 template <typename F>
@@ -592,6 +642,23 @@ int pm_run(pm_handle* h) {
   });
 }
 
+int pm_run_batch_async(pm_handle** handles, int32_t n) {
+  return Guard([&] {
+    PM_CHECK(handles && n >= 1, "empty batch");
+    for (int i = 0; i < n; ++i) PM_CHECK(handles[i], "null handle");
+    RunBatchAsync(handles, n);
+  });
+}
+
+int pm_run_batch(pm_handle** handles, int32_t n) {
+  return Guard([&] {
+    PM_CHECK(handles && n >= 1, "empty batch");
+    for (int i = 0; i < n; ++i) PM_CHECK(handles[i], "null handle");
+    RunBatchAsync(handles, n);
+    for (int i = 0; i < n; ++i) Synchronize(handles[i]);
+  });
+}
+
 int pm_get_depth_map(pm_handle* h, float* out) {
   return Guard([&] { PM_CHECK(h && out, "null"); CopyOut(h, h->out_depth.ptr, out, (size_t)h->W * h->H); });
 }
@@ -677,6 +744,27 @@ int pm_get_device_maps(pm_handle* h, const float** depth, const float** normal) 
     PM_CHECK(h && h->ran, "run first");
     if (depth) *depth = h->out_depth.ptr;
     if (normal) *normal = h->out_normal.ptr;
+  });
+}
+
+int pm_enable_phase_profile(pm_handle* h, int enable) {
+  return Guard([&] {
+    PM_CHECK(h, "null");
+    HIP_CALL(hipSetDevice(h->device));
+    if (enable) {
+      h->prof.alloc(10);
+      h->base.prof = h->prof.ptr;
+    } else {
+      h->base.prof = nullptr;
+    }
+  });
+}
+
+int pm_get_phase_profile(pm_handle* h, unsigned long long* out10) {
+  return Guard([&] {
+    PM_CHECK(h && out10 && h->prof.ptr, "profile not enabled");
+    HIP_CALL(hipSetDevice(h->device));
+    HIP_CALL(hipMemcpy(out10, h->prof.ptr, 10 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   });
 }
 

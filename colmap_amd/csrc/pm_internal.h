@@ -46,6 +46,7 @@ struct PmParams {
   uint32_t* rng;            // [H*W][6]
   uint8_t* mask;            // [S][H][W] or null
   const float* poses;       // [S][43] for this rotation
+  unsigned long long* prof; // optional phase-cycle counters [10] (debug), else null
 };
 
 size_t pm_sweep_lds_bytes(const PmParams& p, bool geom);
@@ -57,9 +58,11 @@ void pm_launch_filter_ref(const uint8_t* gray, int W, int H, int radius, int ste
                           hipStream_t st);
 void pm_launch_init_state(const PmParams& p, bool random_init, float depth_min, float depth_max,
                           const float* init_depth, const float* init_normal, hipStream_t st);
-void pm_launch_initial_cost(const PmParams& p, hipStream_t st);
-void pm_launch_sweep(const PmParams& p, int threads, bool geom, bool filter_photo, bool filter_geom,
-                     hipStream_t st);
+// `p` describes the (identical) shape of every problem of the batch; `dev_params` is the
+// device array of per-problem parameter blocks the kernel indexes with its batch coordinate.
+void pm_launch_initial_cost(const PmParams& p, const PmParams* dev_params, int batch, hipStream_t st);
+void pm_launch_sweep(const PmParams& p, const PmParams* dev_params, int batch, int threads, bool geom,
+                     bool filter_photo, bool filter_geom, hipStream_t st);
 void pm_launch_extract(const PmParams& p, int sel_off, float* depth, float* normal, float* sel,
                        float* cost, hipStream_t st);
 

@@ -7,9 +7,13 @@
 //  * A workgroup owns C adjacent image columns of the (virtually rotated) sweep
 //    frame and walks them row by row. Inside one row step the independent pieces
 //    of work -- per-view priors (C*S items) and the bilaterally weighted NCC
-//    evaluations (up to C*4*min(M,S) + C*S items) -- are spread over all lanes of
-//    the workgroup through an LDS task list, so the 64-wide wavefronts stay
-//    densely packed although the algorithm is sequential along a column.
+//    evaluations (up to C*4*min(M,S) + C*S items) -- are spread over the workgroup
+//    through an LDS task list. Each NCC evaluation is computed by a 16-lane group
+//    (taps dealt to lanes, DPP tree sum): the lanes of one gather instruction then
+//    touch a few cache lines of ONE warped patch instead of 64 unrelated patches
+//    (measured: the lane-per-evaluation version was bound by the L1 tag rate of
+//    64-line gathers, not by VALU), and the wavefronts stay densely packed although
+//    the algorithm is sequential along a column.
 //  * Identical NCC evaluations inside a row step (the same hypothesis/view pair
 //    drawn by several Monte-Carlo samples, patch_match_cuda.cu:1128-1172, and the
 //    re-evaluation of the winner, :1188-1197) are computed once. The 121
@@ -169,17 +173,31 @@ __device__ __forceinline__ float ref_texel(const PmParams& p, int row, int col) 
 // Geometry (restating patch_match_cuda.cu device functions)
 // ---------------------------------------------------------------------------
 
+// LDS pointers carry address space 3 explicitly so that every access is a ds_*
+// instruction (generic pointers kept in a struct degrade to flat_* loads).
+#define LDS_AS __attribute__((address_space(3)))
+typedef LDS_AS float lds_f32;
+struct __attribute__((aligned(8))) WeightRef {
+  float w;  // bilateral weight
+  float c;  // reference colour
+};
+typedef LDS_AS WeightRef lds_f32x2;
+typedef LDS_AS int lds_i32;
+typedef LDS_AS uint32_t lds_u32;
+typedef LDS_AS char lds_char;
+
+
 __device__ __forceinline__ float dot3(float a0, float a1, float a2, float b0, float b1, float b2) {
   return a0 * b0 + a1 * b1 + a2 * b2;
 }
 
 // ComposeHomography, patch_match_cuda.cu:271-332
-__device__ __forceinline__ void compose_homography(const float* iK, const float* pose, int row,
+__device__ __forceinline__ void compose_homography(const float* iK, const lds_f32* pose, int row,
                                                    int col, float depth, float n0, float n1,
                                                    float n2, float H[9]) {
-  const float* K = pose;
-  const float* R = pose + 4;
-  const float* T = pose + 13;
+  const lds_f32* K = pose;
+  const lds_f32* R = pose + 4;
+  const lds_f32* T = pose + 13;
   const float dist = depth * (n0 * (iK[0] * col + iK[1]) + n1 * (iK[2] * row + iK[3]) + n2);
   const float inv_dist = 1.0f / dist;
   const float N0 = inv_dist * n0;
@@ -209,69 +227,122 @@ __device__ __forceinline__ float bilateral_weight(float spatial_norm, float colo
   return pm_exp(-sds * spatial_norm - cd * cd * color_norm);
 }
 
-// PhotoConsistencyCostComputer::Compute, patch_match_cuda.cu:489-593. `wr` holds
-// (bilateral weight, reference colour) per tap in row-major window order (LDS).
-__device__ __forceinline__ float ncc_eval(const PmParams& p, const float* pose,
-                                          const uint32_t* __restrict__ fp, const float2* wr,
-                                          int row, int col, float depth, float n0, float n1,
-                                          float n2, float ref_sum, float ref_sqsum) {
-  float tf[9];
-  compose_homography(p.refInvK, pose, row, col, depth, n0, n1, n2, tf);
-  const float fstep = (float)p.step;
-  const float st0 = fstep * tf[0], st1 = fstep * tf[1], st3 = fstep * tf[3], st4 = fstep * tf[4],
-              st6 = fstep * tf[6], st7 = fstep * tf[7];
-  const int row_start = row - p.radius;
-  const int col_start = col - p.radius;
-  float col_src = tf[0] * col_start + tf[1] * row_start + tf[2];
-  float row_src = tf[3] * col_start + tf[4] * row_start + tf[5];
-  float z = tf[6] * col_start + tf[7] * row_start + tf[8];
-  float base_col = col_src, base_row = row_src, base_z = z;
-  float s_sum = 0.0f, s_sq = 0.0f, s_ref = 0.0f, w_sum = 0.0f;
-  const int fpw = p.src_w + 3;
-  const int n1d = p.ntap1d;
-  int tap = 0;
-  for (int wrow = 0; wrow < n1d; ++wrow) {
-    for (int wcol = 0; wcol < n1d; ++wcol, ++tap) {
-      const float inv_z = 1.0f / z;
-      const float x = fmaf(inv_z, col_src, 0.5f);
-      const float y = fmaf(inv_z, row_src, 0.5f);
-      // SampleLayeredBilinear, patch_match_cuda.cu:426-442
-      const float px = x - 0.5f;
-      const float py = y - 0.5f;
-      const float fx = floorf(px);
-      const float fy = floorf(py);
-      const float wx = px - fx;
-      const float wy = py - fy;
-      int ix = (int)fx;
-      int iy = (int)fy;
-      ix = min(max(ix, -2), p.src_w);
-      iy = min(max(iy, -2), p.src_h);
-      const uint32_t t = fp[(iy + 2) * fpw + (ix + 2)];
-      const float c00 = texel_norm((float)(t & 0xffu));
-      const float c10 = texel_norm((float)((t >> 8) & 0xffu));
-      const float c01 = texel_norm((float)((t >> 16) & 0xffu));
-      const float c11 = texel_norm((float)(t >> 24));
-      const float top = fmaf(c10, wx, c00 * (1.0f - wx));
-      const float bot = fmaf(c11, wx, c01 * (1.0f - wx));
-      const float src = fmaf(bot, wy, top * (1.0f - wy));
-      const float2 w = wr[tap];
-      const float bws = w.x * src;
-      s_sum += bws;
-      s_sq = fmaf(bws, src, s_sq);
-      s_ref = fmaf(bws, w.y, s_ref);
-      w_sum += w.x;
-      col_src += st0;
-      row_src += st3;
-      z += st6;
+// One tap's source coordinate -> footprint address + bilinear fractions
+// (SampleLayeredBilinear, patch_match_cuda.cu:426-442).
+struct TapAddr {
+  uint32_t texels;
+  float wx, wy;
+};
+
+__device__ __forceinline__ void tap_fetch(const PmParams& p, const uint32_t* __restrict__ fp,
+                                          unsigned fpw, float col_src, float row_src, float z,
+                                          TapAddr& t) {
+  const float inv_z = 1.0f / z;
+  const float x = fmaf(inv_z, col_src, 0.5f);
+  const float y = fmaf(inv_z, row_src, 0.5f);
+  const float px = x - 0.5f;
+  const float py = y - 0.5f;
+  const float fx = floorf(px);
+  const float fy = floorf(py);
+  t.wx = px - fx;
+  t.wy = py - fy;
+  // clamp to the zero ring [-2, w] x [-2, h] in the float domain (one v_med3 each), so
+  // that arbitrarily distant / non-finite taps read an all-zero footprint entry
+  const int ix = (int)__builtin_amdgcn_fmed3f(fx, -2.0f, (float)p.src_w);
+  const int iy = (int)__builtin_amdgcn_fmed3f(fy, -2.0f, (float)p.src_h);
+  const unsigned off = (unsigned)(iy + 2) * fpw + (unsigned)(ix + 2);
+  t.texels = fp[off];
+}
+
+// Bilinear blend of the four raw texels (exact small integers in float), then one
+// scale by 1/255: the device-order reading of "bilinear fetch of a normalised
+// uint8 texture" (oracle/pm_oracle.c: tex_src_bilinear_raw).
+__device__ __forceinline__ float tap_sample(const TapAddr& t) {
+  const float c00 = (float)(t.texels & 0xffu);
+  const float c10 = (float)((t.texels >> 8) & 0xffu);
+  const float c01 = (float)((t.texels >> 16) & 0xffu);
+  const float c11 = (float)(t.texels >> 24);
+  const float top = fmaf(c10, t.wx, c00 * (1.0f - t.wx));
+  const float bot = fmaf(c11, t.wx, c01 * (1.0f - t.wx));
+  return fmaf(bot, t.wy, top * (1.0f - t.wy)) * 0x1.010102p-8f;
+}
+
+// Cross-lane add inside a 16-lane DPP row. The four steps (row_mirror,
+// row_half_mirror, quad reverse, quad swap) leave in every lane
+//   ((q0+q7)+(q3+q4)) + ((q1+q6)+(q2+q5)),  q_l = p_l + p_(15-l)
+// -- the tree oracle/pm_oracle.c:tree16 restates.
+template <int CTRL>
+__device__ __forceinline__ float dpp_row(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float reduce16(float v) {
+  v = v + dpp_row<0x140>(v);  // row_mirror:      l <-> 15-l
+  v = v + dpp_row<0x141>(v);  // row_half_mirror: l <-> 7-l within each half
+  v = v + dpp_row<0x1B>(v);   // quad_perm [3,2,1,0]
+  v = v + dpp_row<0xB1>(v);   // quad_perm [1,0,3,2]
+  return v;
+}
+
+// PhotoConsistencyCostComputer::Compute, patch_match_cuda.cu:489-593, evaluated by a
+// 16-lane group: tap t = wrow*n1d + wcol belongs to lane t % 16, so one gather
+// instruction of a group covers 16 consecutive taps (~1.5 window rows, a handful of
+// cache lines) instead of 16 unrelated patches. `H` is the homography of the
+// (hypothesis, view) pair (LDS, precomputed once per task), `wr` holds (bilateral
+// weight, reference colour) per tap. All 16 lanes return the same cost.
+template <int N1D>
+__device__ __forceinline__ float ncc_group(const PmParams& p, const lds_f32* H,
+                                           const uint32_t* __restrict__ fp, const lds_f32x2* wr,
+                                           int row, int col, float ref_sum, float ref_sqsum,
+                                           float inv_w, int j) {
+  const float h0 = H[0], h1 = H[1], h2 = H[2], h3 = H[3], h4 = H[4], h5 = H[5], h6 = H[6],
+              h7 = H[7], h8 = H[8];
+  const int n1d = N1D > 0 ? N1D : p.ntap1d;
+  const int ntaps = n1d * n1d;
+  const unsigned fpw = (unsigned)(p.src_w + 3);
+  const int x0 = col - p.radius, y0 = row - p.radius;
+  float s_sum = 0.0f, s_sq = 0.0f, s_ref = 0.0f;
+  auto fetch = [&](int t, TapAddr& ta) {
+    const int wrow = t / n1d;
+    const int wcol = t - wrow * n1d;
+    const float xf = (float)(x0 + wcol * p.step);
+    const float yf = (float)(y0 + wrow * p.step);
+    const float col_src = fmaf(h0, xf, fmaf(h1, yf, h2));
+    const float row_src = fmaf(h3, xf, fmaf(h4, yf, h5));
+    const float z = fmaf(h6, xf, fmaf(h7, yf, h8));
+    tap_fetch(p, fp, fpw, col_src, row_src, z, ta);
+  };
+  auto accumulate = [&](int t, const TapAddr& ta) {
+    const float src = tap_sample(ta);
+    const float wgt = wr[t].w;
+    const float refc = wr[t].c;
+    const float bws = wgt * src;
+    s_sum += bws;
+    s_sq = fmaf(bws, src, s_sq);
+    s_ref = fmaf(bws, refc, s_ref);
+  };
+  if (N1D > 0) {
+    constexpr int K = (N1D * N1D + 15) / 16 > 0 ? (N1D * N1D + 15) / 16 : 1;
+    TapAddr ta[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int t = j + 16 * k;
+      if (t < ntaps) fetch(t, ta[k]);
     }
-    base_col += st1;
-    base_row += st4;
-    base_z += st7;
-    col_src = base_col;
-    row_src = base_row;
-    z = base_z;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int t = j + 16 * k;
+      if (t < ntaps) accumulate(t, ta[k]);
+    }
+  } else {
+    for (int t = j; t < ntaps; t += 16) {
+      TapAddr ta;
+      fetch(t, ta);
+      accumulate(t, ta);
+    }
   }
-  const float inv_w = 1.0f / w_sum;
+  s_sum = reduce16(s_sum);
+  s_sq = reduce16(s_sq);
+  s_ref = reduce16(s_ref);
   s_sum *= inv_w;
   s_sq *= inv_w;
   s_ref *= inv_w;
@@ -285,10 +356,10 @@ __device__ __forceinline__ float ncc_eval(const PmParams& p, const float* pose,
 }
 
 // ComputeGeomConsistencyCost, patch_match_cuda.cu:601-667
-__device__ __forceinline__ float geom_cost(const PmParams& p, const float* pose, int s, float row,
+__device__ __forceinline__ float geom_cost(const PmParams& p, const lds_f32* pose, int s, float row,
                                            float col, float depth) {
-  const float* P = pose + 19;
-  const float* iP = pose + 31;
+  const lds_f32* P = pose + 19;
+  const lds_f32* iP = pose + 31;
   const float* iK = p.refInvK;
   const float f0 = depth * (iK[0] * col + iK[1]);
   const float f1 = depth * (iK[2] * row + iK[3]);
@@ -346,10 +417,10 @@ __device__ __forceinline__ float sel_prob_fn(float alpha, float beta, float prev
 }
 
 // ComputeViewingAngles, patch_match_cuda.cu:241-269
-__device__ __forceinline__ void viewing_angles(const float* pose, float p0, float p1, float p2,
+__device__ __forceinline__ void viewing_angles(const lds_f32* pose, float p0, float p1, float p2,
                                                float n0, float n1, float n2, float& cos_tri,
                                                float& cos_inc) {
-  const float* C = pose + 16;
+  const lds_f32* C = pose + 16;
   const float s0 = C[0] - p0, s1 = C[1] - p1, s2 = C[2] - p2;
   const float rx_inv = pm_rsqrt(dot3(p0, p1, p2, p0, p1, p2));
   const float sx_inv = pm_rsqrt(dot3(s0, s1, s2, s0, s1, s2));
@@ -501,7 +572,7 @@ __global__ void pm_filter_ref_kernel(const uint8_t* __restrict__ gray, int W, in
 // InitRandomStateKernel (gpu_mat_prng.cu:36-48) + FillWithRandomNumbersKernel
 // (gpu_mat.h:370-387) + InitNormalMap (patch_match_cuda.cu:835-846) + the
 // prev_sel_prob fill (:1833-1835), fused: one pass over the pixel records.
-__global__ void pm_init_state_kernel(PmParams p, int random_init, float depth_min, float depth_max,
+__global__ void pm_init_state_kernel(const PmParams p, int random_init, float depth_min, float depth_max,
                                      const float* __restrict__ init_depth,
                                      const float* __restrict__ init_normal) {
   const int col = blockIdx.x * blockDim.x + threadIdx.x;
@@ -552,61 +623,91 @@ __global__ void pm_init_state_kernel(PmParams p, int random_init, float depth_mi
 // LDS carve-up shared by the initial-cost and sweep kernels
 // ---------------------------------------------------------------------------
 struct Lds {
-  float* poses;   // [S][43]
-  float* tile;    // [win][C + 2r] reference colours, ring-buffered rows
-  float2* wr;     // [C][ntaps] (bilateral weight, reference colour)
-  float* fm;      // [C][S] forward messages
-  float* q;       // [C][S] sampling pdf -> cdf
-  float* costv;   // [C][S] cost_map values of this row
-  float* betav;   // [C][S] backward messages of this row
-  float* prevv;   // [C][S] previous sel probs of this row
-  float* ncc;     // [C][5][S] NCC per hypothesis/view, < 0: not computed
-  float* geo;     // [C][5][S] geometric cost (GEOM only)
-  float* hyp;     // [C][5][4] depth, normal
-  float* colf;    // [C][8] ref_sum, ref_sqsum, point[3], pad
-  float* us;      // [C][M] uniform draws
-  int* sv;        // [C][M] sampled view per draw (-1: none)
-  int* best;      // [C]
-  int* flags;     // [C][S] filter flags
-  uint32_t* tasks;
-  int* ntasks;
+  lds_f32* poses;   // [S][43]
+  lds_f32* tile;    // [win][C + 2r] reference colours, ring-buffered rows
+  lds_f32x2* wr;    // [C][ntaps] (bilateral weight, reference colour)
+  lds_f32* fm;      // [C][S] forward messages
+  lds_f32* q;       // [C][S] sampling pdf -> cdf
+  lds_f32* costv;   // [C][S] cost_map values of this row
+  lds_f32* betav;   // [C][S] backward messages of this row
+  lds_f32* prevv;   // [C][S] previous sel probs of this row
+  lds_f32* ncc;     // [C][5][S] NCC per hypothesis/view, < 0: not computed
+  lds_f32* geo;     // [C][5][S] geometric cost (GEOM only)
+  lds_f32* hyp;     // [C][5][4] depth, normal
+  lds_f32* colf;    // [C][8] ref_sum, ref_sqsum, point[3], pad
+  lds_f32* us;      // [C][M] uniform draws
+  lds_i32* sv;      // [C][M] sampled view per draw (-1: none)
+  lds_i32* best;    // [C]
+  lds_f32* csum;    // [C][5] accumulated hypothesis costs
+  lds_i32* flags;   // [C][S] filter flags
+  lds_u32* tasks;
+  lds_f32* th;      // [max_tasks][9] homography of each queued NCC task
+  lds_i32* ntasks;
 };
 
-__host__ __device__ inline size_t lds_layout(Lds* L, char* base, int C, int S, int radius, int ntaps,
-                                             int M, bool geom) {
-  size_t off = 0;
-  auto take = [&](size_t bytes) {
-    char* ptr = base ? base + off : nullptr;
-    off += (bytes + 15) & ~(size_t)15;
-    return ptr;
+struct LdsOffsets {
+  uint32_t poses, tile, wr, fm, q, costv, betav, prevv, ncc, geo, hyp, colf, us, sv, best, csum,
+      flags, tasks, th, ntasks, total;
+};
+
+__host__ __device__ inline LdsOffsets lds_offsets(int C, int S, int radius, int ntaps, int M,
+                                                  bool geom) {
+  LdsOffsets o;
+  uint32_t off = 0;
+  auto take = [&](uint32_t bytes) {
+    const uint32_t at = off;
+    off += (bytes + 15u) & ~15u;
+    return at;
   };
   const int win = 2 * radius + 1;
   const int tw = C + 2 * radius;
-  const int max_tasks = C * (5 * (M < S ? M : S) > S ? 5 * (M < S ? M : S) : S);
-  float* poses = (float*)take(sizeof(float) * S * kPoseStride);
-  float* tile = (float*)take(sizeof(float) * win * tw);
-  float2* wr = (float2*)take(sizeof(float2) * C * ntaps);
-  float* fm = (float*)take(sizeof(float) * C * S);
-  float* q = (float*)take(sizeof(float) * C * S);
-  float* costv = (float*)take(sizeof(float) * C * S);
-  float* betav = (float*)take(sizeof(float) * C * S);
-  float* prevv = (float*)take(sizeof(float) * C * S);
-  float* ncc = (float*)take(sizeof(float) * C * 5 * S);
-  float* geo = (float*)take(geom ? sizeof(float) * C * 5 * S : 0);
-  float* hyp = (float*)take(sizeof(float) * C * 20);
-  float* colf = (float*)take(sizeof(float) * C * 8);
-  float* us = (float*)take(sizeof(float) * C * M);
-  int* sv = (int*)take(sizeof(int) * C * M);
-  int* best = (int*)take(sizeof(int) * C);
-  int* flags = (int*)take(sizeof(int) * C * S);
-  uint32_t* tasks = (uint32_t*)take(sizeof(uint32_t) * max_tasks);
-  int* ntasks = (int*)take(sizeof(int) * 4);
-  if (L) {
-    L->poses = poses; L->tile = tile; L->wr = wr; L->fm = fm; L->q = q; L->costv = costv;
-    L->betav = betav; L->prevv = prevv; L->ncc = ncc; L->geo = geo; L->hyp = hyp; L->colf = colf;
-    L->us = us; L->sv = sv; L->best = best; L->flags = flags; L->tasks = tasks; L->ntasks = ntasks;
-  }
-  return off;
+  const int ms = M < S ? M : S;
+  const int max_tasks = C * (5 * ms > S ? 5 * ms : S);
+  o.poses = take(4u * S * kPoseStride);
+  o.tile = take(4u * win * tw);
+  o.wr = take(8u * C * ntaps);
+  o.fm = take(4u * C * S);
+  o.q = take(4u * C * S);
+  o.costv = take(4u * C * S);
+  o.betav = take(4u * C * S);
+  o.prevv = take(4u * C * S);
+  o.ncc = take(4u * C * 5 * S);
+  o.geo = take(geom ? 4u * C * 5 * S : 0u);
+  o.hyp = take(4u * C * 20);
+  o.colf = take(4u * C * 8);
+  o.us = take(4u * C * M);
+  o.sv = take(4u * C * M);
+  o.best = take(4u * C);
+  o.csum = take(4u * C * 5);
+  o.flags = take(4u * C * S);
+  o.tasks = take(4u * max_tasks);
+  o.th = take(36u * max_tasks);
+  o.ntasks = take(16u);
+  o.total = off;
+  return o;
+}
+
+__device__ __forceinline__ void lds_bind(Lds& L, lds_char* base, const LdsOffsets& o) {
+  L.poses = (lds_f32*)(base + o.poses);
+  L.tile = (lds_f32*)(base + o.tile);
+  L.wr = (lds_f32x2*)(base + o.wr);
+  L.fm = (lds_f32*)(base + o.fm);
+  L.q = (lds_f32*)(base + o.q);
+  L.costv = (lds_f32*)(base + o.costv);
+  L.betav = (lds_f32*)(base + o.betav);
+  L.prevv = (lds_f32*)(base + o.prevv);
+  L.ncc = (lds_f32*)(base + o.ncc);
+  L.geo = (lds_f32*)(base + o.geo);
+  L.hyp = (lds_f32*)(base + o.hyp);
+  L.colf = (lds_f32*)(base + o.colf);
+  L.us = (lds_f32*)(base + o.us);
+  L.sv = (lds_i32*)(base + o.sv);
+  L.best = (lds_i32*)(base + o.best);
+  L.csum = (lds_f32*)(base + o.csum);
+  L.flags = (lds_i32*)(base + o.flags);
+  L.tasks = (lds_u32*)(base + o.tasks);
+  L.th = (lds_f32*)(base + o.th);
+  L.ntasks = (lds_i32*)(base + o.ntasks);
 }
 
 __device__ __forceinline__ uint32_t task_pack(int c, int i, int s, int geom_only) {
@@ -645,7 +746,22 @@ __device__ __forceinline__ void patch_weights(const PmParams& p, const Lds& L, i
     const float center = L.tile[slot_c * tw + c + p.radius];
     const float color = L.tile[slot * tw + c + p.radius + wc_];
     const float bw = bilateral_weight(p.spatial_norm, p.color_norm, (float)wr_, (float)wc_, center, color);
-    L.wr[item] = make_float2(bw, color);
+    L.wr[item].w = bw;
+    L.wr[item].c = color;
+  }
+}
+
+// 1 / (sum of the bilateral weights of column c's patch), summed in the same lane
+// partition and tree as the other NCC sums: the reference accumulates this sum inside
+// every evaluation (:546,571) although it only depends on the reference patch.
+__device__ __forceinline__ void patch_weight_sums(const PmParams& p, const Lds& L, int ncols,
+                                                  int tid, int nthreads) {
+  const int g = tid >> 4, j = tid & 15, ng = nthreads >> 4;
+  for (int c = g; c < ncols; c += ng) {
+    float w_sum = 0.0f;
+    for (int t = j; t < p.ntaps; t += 16) w_sum += L.wr[c * p.ntaps + t].w;
+    w_sum = reduce16(w_sum);
+    if (j == 0) L.colf[c * 8 + 5] = 1.0f / w_sum;
   }
 }
 
@@ -653,10 +769,12 @@ __device__ __forceinline__ void patch_weights(const PmParams& p, const Lds& L, i
 // ComputeInitialCost (patch_match_cuda.cu:863-912): C adjacent pixels of one row
 // per workgroup, C*S NCC evaluations spread over the lanes. Rotation 0.
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) pm_initial_cost_kernel(PmParams p) {
+template <int N1D>
+__global__ void __launch_bounds__(64) pm_initial_cost_kernel(const PmParams* __restrict__ pp) {
+  const PmParams& p = pp[blockIdx.z];  // batch of reference images: one launch, grid.z problems
   extern __shared__ __attribute__((aligned(16))) char smem[];
   Lds L;
-  lds_layout(&L, smem, p.C, p.S, p.radius, p.ntaps, p.num_samples, false);
+  lds_bind(L, (lds_char*)smem, lds_offsets(p.C, p.S, p.radius, p.ntaps, p.num_samples, false));
   const int tid = threadIdx.x, nt = blockDim.x;
   const int row = blockIdx.y;
   const int col0 = blockIdx.x * p.C;
@@ -665,18 +783,32 @@ __global__ void __launch_bounds__(64) pm_initial_cost_kernel(PmParams p) {
   __syncthreads();
   patch_weights(p, L, row, tid, nt);
   __syncthreads();
+  patch_weight_sums(p, L, p.C, tid, nt);
   const int fp_slice = (p.src_w + 3) * (p.src_h + 3);
+  // per (pixel, view): homography, lane per task
   for (int item = tid; item < p.C * p.S; item += nt) {
     const int c = item / p.S;
     const int s = item - c * p.S;
     const int col = col0 + c;
     if (col >= p.W) continue;
+    const float* rec = p.rec + (size_t)(row * p.W + col) * p.rec_stride;
+    float Hm[9];
+    compose_homography(p.refInvK, L.poses + s * kPoseStride, row, col, rec[0], rec[1], rec[2], rec[3], Hm);
+    for (int k = 0; k < 9; ++k) L.th[item * 9 + k] = Hm[k];
+  }
+  __syncthreads();
+  // NCC: 16-lane group per task
+  const int g = tid >> 4, j = tid & 15, ng = nt >> 4;
+  for (int item = g; item < p.C * p.S; item += ng) {
+    const int c = item / p.S;
+    const int s = item - c * p.S;
+    const int col = col0 + c;
+    if (col >= p.W) continue;
     const int pix = row * p.W + col;
-    const float* rec = p.rec + (size_t)pix * p.rec_stride;
-    const float cost = ncc_eval(p, L.poses + s * kPoseStride, p.src_fp + (size_t)s * fp_slice,
-                                L.wr + c * p.ntaps, row, col, rec[0], rec[1], rec[2], rec[3],
-                                p.ref_sum[pix], p.ref_sqsum[pix]);
-    p.rec[(size_t)pix * p.rec_stride + 4 + s] = cost;
+    const float cost = ncc_group<N1D>(p, L.th + item * 9, p.src_fp + (size_t)s * fp_slice,
+                                      L.wr + c * p.ntaps, row, col, p.ref_sum[pix], p.ref_sqsum[pix],
+                                      L.colf[c * 8 + 5], j);
+    if (j == 0) p.rec[(size_t)pix * p.rec_stride + 4 + s] = cost;
   }
 }
 
@@ -684,8 +816,10 @@ __global__ void __launch_bounds__(64) pm_initial_cost_kernel(PmParams p) {
 // SweepFromTopToBottom (patch_match_cuda.cu:933-1288)
 // ---------------------------------------------------------------------------
 
-// Run every queued NCC / geometric-cost task; one task per lane.
-template <bool GEOM>
+// Run every queued NCC / geometric-cost task. Pass A (lane per task): homography of
+// the (hypothesis, view) pair and, with GEOM, the geometric consistency cost. Pass B
+// (16-lane group per task): the bilaterally weighted NCC.
+template <int N1D, bool GEOM>
 __device__ __forceinline__ void run_tasks(const PmParams& p, const Lds& L, int row, int col0,
                                           int tid, int nt) {
   const int n = *L.ntasks;
@@ -696,31 +830,57 @@ __device__ __forceinline__ void run_tasks(const PmParams& p, const Lds& L, int r
     const int geom_only = (task >> 23) & 1;
     const int i = (task >> 20) & 7;
     const int s = task & 0xfffff;
-    const float* h = L.hyp + (c * 5 + i) * 4;
-    const float* pose = L.poses + s * kPoseStride;
+    const lds_f32* h = L.hyp + (c * 5 + i) * 4;
+    const lds_f32* pose = L.poses + s * kPoseStride;
     const int col = col0 + c;
     if (!geom_only) {
-      L.ncc[(c * 5 + i) * p.S + s] =
-          ncc_eval(p, pose, p.src_fp + (size_t)s * fp_slice, L.wr + c * p.ntaps, row, col, h[0],
-                   h[1], h[2], h[3], L.colf[c * 8 + 0], L.colf[c * 8 + 1]);
+      float Hm[9];
+      compose_homography(p.refInvK, pose, row, col, h[0], h[1], h[2], h[3], Hm);
+      for (int k = 0; k < 9; ++k) L.th[t * 9 + k] = Hm[k];
     }
     if (GEOM) {
       L.geo[(c * 5 + i) * p.S + s] = geom_cost(p, pose, s, (float)row, (float)col, h[0]);
     }
   }
+  __syncthreads();
+  const int g = tid >> 4, j = tid & 15, ng = nt >> 4;
+  for (int t = g; t < n; t += ng) {
+    const uint32_t task = L.tasks[t];
+    if ((task >> 23) & 1) continue;  // geometric cost only
+    const int c = task >> 24;
+    const int i = (task >> 20) & 7;
+    const int s = task & 0xfffff;
+    const float cost = ncc_group<N1D>(p, L.th + t * 9, p.src_fp + (size_t)s * fp_slice,
+                                      L.wr + c * p.ntaps, row, col0 + c, L.colf[c * 8 + 0],
+                                      L.colf[c * 8 + 1], L.colf[c * 8 + 5], j);
+    if (j == 0) L.ncc[(c * 5 + i) * p.S + s] = cost;
+  }
 }
 
-template <bool GEOM, bool FILTER_PHOTO, bool FILTER_GEOM>
-__global__ void __launch_bounds__(256) pm_sweep_kernel(PmParams p) {
+// Optional phase profile: PROF instantiation only; wave 0 / lane 0 accumulates
+// shader-clock deltas per phase and adds them to p.prof[] at the end.
+#define PM_PROF_MARK(slot)                                   \
+  if (PROF) {                                                \
+    const unsigned long long now_ = __builtin_readcyclecounter(); \
+    prof_acc[slot] += now_ - prof_t;                         \
+    prof_t = now_;                                           \
+  }
+
+template <int N1D, bool GEOM, bool FILTER_PHOTO, bool FILTER_GEOM, bool PROF>
+__global__ void __launch_bounds__(256, 3) pm_sweep_kernel(const PmParams* __restrict__ pp) {
+  const PmParams& p = pp[blockIdx.y];  // batch of reference images: one launch, grid.y problems
   extern __shared__ __attribute__((aligned(16))) char smem[];
   Lds L;
-  lds_layout(&L, smem, p.C, p.S, p.radius, p.ntaps, p.num_samples, GEOM);
+  lds_bind(L, (lds_char*)smem, lds_offsets(p.C, p.S, p.radius, p.ntaps, p.num_samples, GEOM));
   const int tid = threadIdx.x, nt = blockDim.x;
   const int S = p.S, M = p.num_samples, C = p.C;
   const int RW = rot_width(p), RH = rot_height(p);
   const int col0 = blockIdx.x * C;
   const int ncols = min(C, RW - col0);  // valid columns of this group
   const float* iK = p.refInvK;
+
+  unsigned long long prof_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long prof_t = PROF ? __builtin_readcyclecounter() : 0ull;
 
   for (int i = tid; i < S * kPoseStride; i += nt) L.poses[i] = p.poses[i];
 
@@ -747,18 +907,20 @@ __global__ void __launch_bounds__(256) pm_sweep_kernel(PmParams p) {
     const float* rec = p.rec + (size_t)pix0 * p.rec_stride;
     float sx, sy;
     normal_to_sweep(p.rot, rec[1], rec[2], sx, sy);
-    float* h1 = L.hyp + (tid * 5 + 1) * 4;
+    lds_f32* h1 = L.hyp + (tid * 5 + 1) * 4;
     h1[0] = rec[0]; h1[1] = sx; h1[2] = sy; h1[3] = rec[3];
   }
   // reference tile rows [-r, r-1]; row r arrives in the first loop iteration
   for (int r = -p.radius; r < p.radius; ++r) tile_load_row(p, L, col0, r, tid, nt);
   __syncthreads();
+  PM_PROF_MARK(0)
 
   for (int row = 0; row < RH; ++row) {
     // ---- P0: scroll the reference tile (LocalRefImage::Read, :357-410) -------
     tile_load_row(p, L, col0, row + p.radius, tid, nt);
     if (tid == 0) *L.ntasks = 0;
     __syncthreads();
+    PM_PROF_MARK(1)
 
     // ---- P1: hypotheses (lane per column) + patch weights (all lanes) --------
     if (col_lane) {
@@ -766,7 +928,7 @@ __global__ void __launch_bounds__(256) pm_sweep_kernel(PmParams p) {
       const int col = col0 + c;
       const int pix = pix_index(p, row, col);
       const float* rec = p.rec + (size_t)pix * p.rec_stride;
-      float* h = L.hyp + c * 20;
+      lds_f32* h = L.hyp + c * 20;
       // propagate the previous row's plane (:1047-1048)
       h[4] = propagate_depth(iK, h[4], h[6], h[7], (float)(row - 1), (float)row);
       // current parameters (:1051-1052)
@@ -785,7 +947,7 @@ __global__ void __launch_bounds__(256) pm_sweep_kernel(PmParams p) {
       h[8] = rd; h[9] = rn0; h[10] = rn1; h[11] = rn2;
       h[12] = cd; h[13] = rn0; h[14] = rn1; h[15] = rn2;
       h[16] = rd; h[17] = cn0; h[18] = cn1; h[19] = cn2;
-      float* cf = L.colf + c * 8;
+      lds_f32* cf = L.colf + c * 8;
       cf[0] = p.ref_sum[pix];
       cf[1] = p.ref_sqsum[pix];
       // ComputePointAtDepth (:1067-1068)
@@ -796,16 +958,18 @@ __global__ void __launch_bounds__(256) pm_sweep_kernel(PmParams p) {
     patch_weights(p, L, row, tid, nt);
     for (int item = tid; item < ncols * 5 * S; item += nt) L.ncc[item] = -1.0f;
     __syncthreads();
+    PM_PROF_MARK(2)
 
     // ---- P2: per-view selection priors (:1070-1104), lane per (column, view) --
+    patch_weight_sums(p, L, ncols, tid, nt);
     for (int item = tid; item < ncols * S; item += nt) {
       const int c = item / S;
       const int s = item - c * S;
       const int col = col0 + c;
       const float* rec = p.rec + (size_t)pix_index(p, row, col) * p.rec_stride;
-      const float* pose = L.poses + s * kPoseStride;
-      const float* h = L.hyp + c * 20;
-      const float* cf = L.colf + c * 8;
+      const lds_f32* pose = L.poses + s * kPoseStride;
+      const lds_f32* h = L.hyp + c * 20;
+      const lds_f32* cf = L.colf + c * 8;
       const float cost = rec[4 + s];
       const float beta = rec[p.sel_out_off + s];
       const float prev = rec[p.sel_in_off + s];
@@ -824,88 +988,111 @@ __global__ void __launch_bounds__(256) pm_sweep_kernel(PmParams p) {
       L.q[item] = sp * tp * ip * rp;
     }
     __syncthreads();
+    PM_PROF_MARK(3)
 
-    // ---- P3: CDF, Monte-Carlo view draws, first task list (lane per column) --
+    // ---- P3a: TransformPDFToCDF (:683-696), sequential sum order, lane per column
     if (col_lane) {
       const int c = tid;
-      float* q = L.q + c * S;
+      lds_f32* q = L.q + c * S;
       float prob_sum = 0.0f;
+#pragma unroll 4
       for (int i = 0; i < S; ++i) prob_sum += q[i];
       const float inv_prob_sum = 1.0f / prob_sum;
       float cum = 0.0f;
+#pragma unroll 4
       for (int i = 0; i < S; ++i) {
         cum += q[i] * inv_prob_sum;
         q[i] = cum;
       }
-      for (int m = 0; m < M; ++m) {
-        const float u = L.us[c * M + m];
-        int src = -1;
-        for (int s = 0; s < S; ++s) {
-          if (q[s] > u) { src = s; break; }
-        }
-        L.sv[c * M + m] = src;
-        if (src >= 0 && L.ncc[(c * 5 + 1) * S + src] == -1.0f) {
-          L.ncc[(c * 5 + 1) * S + src] = -2.0f;  // queued
-          const int n_new = GEOM ? 5 : 4;
-          const int base = atomicAdd(L.ntasks, n_new);
-          for (int i = 1; i < 5; ++i) L.tasks[base + i - 1] = task_pack(c, i, src, 0);
-          if (GEOM) L.tasks[base + 4] = task_pack(c, 0, src, 1);
-        }
+    }
+    __syncthreads();
+    // ---- P3b: Monte-Carlo view draws (:1128-1138), lane per (column, draw) ----
+    for (int item = tid; item < ncols * M; item += nt) {
+      const int c = item / M;
+      const float u = L.us[item];
+      const lds_f32* q = L.q + c * S;
+      int src = -1;
+      for (int s = 0; s < S; ++s) {
+        if (q[s] > u) { src = s; break; }
+      }
+      L.sv[item] = src;
+    }
+    __syncthreads();
+    // ---- P3c: one task set per distinct drawn view, lane per (column, view) ---
+    for (int item = tid; item < ncols * S; item += nt) {
+      const int c = item / S;
+      const int s = item - c * S;
+      bool drawn = false;
+      for (int m = 0; m < M; ++m) drawn |= (L.sv[c * M + m] == s);
+      if (drawn) {
+        const int n_new = GEOM ? 5 : 4;
+        const int base = __hip_atomic_fetch_add(L.ntasks, n_new, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        for (int i = 1; i < 5; ++i) L.tasks[base + i - 1] = task_pack(c, i, s, 0);
+        if (GEOM) L.tasks[base + 4] = task_pack(c, 0, s, 1);
       }
     }
     __syncthreads();
+    PM_PROF_MARK(4)
 
     // ---- P4: NCC of hypotheses 1..4 against the drawn views (:1157-1172) -----
-    run_tasks<GEOM>(p, L, row, col0, tid, nt);
+    run_tasks<N1D, GEOM>(p, L, row, col0, tid, nt);
     __syncthreads();
     if (tid == 0) *L.ntasks = 0;
     __syncthreads();
+    PM_PROF_MARK(5)
 
-    // ---- P5: accumulate in draw order, argmin, store (:1144-1182) -------------
-    if (col_lane) {
-      const int c = tid;
-      float costs[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    // ---- P5a: accumulate in draw order (:1144-1172), lane per (column, hypothesis)
+    for (int item = tid; item < ncols * 5; item += nt) {
+      const int c = item / 5;
+      const int i = item - c * 5;
+      float acc = 0.0f;
       for (int m = 0; m < M; ++m) {
         const int src = L.sv[c * M + m];
         if (src < 0) continue;
-        costs[0] += L.costv[c * S + src];
-        if (GEOM) costs[0] += p.geom_reg * L.geo[(c * 5 + 0) * S + src];
-#pragma unroll
-        for (int i = 1; i < 5; ++i) {
-          costs[i] += L.ncc[(c * 5 + i) * S + src];
-          if (GEOM) costs[i] += p.geom_reg * L.geo[(c * 5 + i) * S + src];
-        }
+        acc += (i == 0) ? L.costv[c * S + src] : L.ncc[(c * 5 + i) * S + src];
+        if (GEOM) acc += p.geom_reg * L.geo[(c * 5 + i) * S + src];
       }
+      L.csum[item] = acc;
+    }
+    __syncthreads();
+    // ---- P5b: argmin, store, next row's previous state (:1176-1182,1279-1282) --
+    if (col_lane) {
+      const int c = tid;
       int min_idx = 0;
-      float min_cost = costs[0];
+      float min_cost = L.csum[c * 5];
 #pragma unroll
       for (int i = 1; i < 5; ++i) {
-        if (costs[i] <= min_cost) { min_cost = costs[i]; min_idx = i; }
+        const float ci = L.csum[c * 5 + i];
+        if (ci <= min_cost) { min_cost = ci; min_idx = i; }
       }
       L.best[c] = min_idx;
-      const float* hb = L.hyp + (c * 5 + min_idx) * 4;
+      const lds_f32* hb = L.hyp + (c * 5 + min_idx) * 4;
       const float bd = hb[0], b0 = hb[1], b1 = hb[2], b2 = hb[3];
       float* rec = p.rec + (size_t)pix_index(p, row, col0 + c) * p.rec_stride;
       float nx, ny;
       normal_from_sweep(p.rot, b0, b1, nx, ny);
       rec[0] = bd; rec[1] = nx; rec[2] = ny; rec[3] = b2;
-      // previous-row state for the next step (:1279-1282)
-      float* h1 = L.hyp + (c * 5 + 1) * 4;
+      lds_f32* h1 = L.hyp + (c * 5 + 1) * 4;
       h1[0] = bd; h1[1] = b0; h1[2] = b1; h1[3] = b2;
-      if (min_idx != 0) {
-        for (int s = 0; s < S; ++s) {
-          if (L.ncc[(c * 5 + min_idx) * S + s] < 0.0f) {
-            const int base = atomicAdd(L.ntasks, 1);
-            L.tasks[base] = task_pack(c, min_idx, s, 0);
-          }
-        }
+    }
+    __syncthreads();
+    // ---- P5c: winner vs. the views not evaluated yet, lane per (column, view) --
+    for (int item = tid; item < ncols * S; item += nt) {
+      const int c = item / S;
+      const int s = item - c * S;
+      const int k = L.best[c];
+      if (k != 0 && L.ncc[(c * 5 + k) * S + s] < 0.0f) {
+        const int base = __hip_atomic_fetch_add(L.ntasks, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        L.tasks[base] = task_pack(c, k, s, 0);
       }
     }
     __syncthreads();
+    PM_PROF_MARK(6)
 
     // ---- P6: NCC of the winner against the remaining views (:1188-1197) ------
-    run_tasks<false>(p, L, row, col0, tid, nt);
+    run_tasks<N1D, false>(p, L, row, col0, tid, nt);
     __syncthreads();
+    PM_PROF_MARK(7)
 
     // ---- P7: cost map, forward message, selection probability (:1186-1207) ---
     for (int item = tid; item < ncols * S; item += nt) {
@@ -927,8 +1114,8 @@ __global__ void __launch_bounds__(256) pm_sweep_kernel(PmParams p) {
       rec[p.sel_out_off + s] = prob;
       if (FILTER_PHOTO || FILTER_GEOM) {
         // :1209-1265
-        const float* hb = L.hyp + (c * 5 + 1) * 4;  // == best (stored in P5)
-        const float* pose = L.poses + s * kPoseStride;
+        const lds_f32* hb = L.hyp + (c * 5 + 1) * 4;  // == best (stored in P5)
+        const lds_f32* pose = L.poses + s * kPoseStride;
         const float bp0 = hb[0] * (iK[0] * col + iK[1]);
         const float bp1 = hb[0] * (iK[2] * row + iK[3]);
         const float bp2 = hb[0];
@@ -964,15 +1151,19 @@ __global__ void __launch_bounds__(256) pm_sweep_kernel(PmParams p) {
       }
     }
     __syncthreads();
+    PM_PROF_MARK(8)
   }
 
   if (col_lane) {
     rng_store(p.rng + (size_t)pix_index(p, 0, col0 + tid) * kRngWords, rng);  // :1285-1287
   }
+  if (PROF && tid == 0 && p.prof) {
+    for (int i = 0; i < 10; ++i) atomicAdd(p.prof + i, prof_acc[i]);
+  }
 }
 
 // pixel records -> API layout (Mat<float> slice-major, mat.h:107-109)
-__global__ void pm_extract_kernel(PmParams p, int sel_off, float* __restrict__ depth,
+__global__ void pm_extract_kernel(const PmParams p, int sel_off, float* __restrict__ depth,
                                   float* __restrict__ normal, float* __restrict__ sel,
                                   float* __restrict__ cost) {
   const int pix = blockIdx.x * blockDim.x + threadIdx.x;
@@ -996,14 +1187,14 @@ __global__ void pm_extract_kernel(PmParams p, int sel_off, float* __restrict__ d
 // ---------------------------------------------------------------------------
 
 size_t pm_sweep_lds_bytes(const PmParams& p, bool geom) {
-  return lds_layout(nullptr, nullptr, p.C, p.S, p.radius, p.ntaps, p.num_samples, geom);
+  return lds_offsets(p.C, p.S, p.radius, p.ntaps, p.num_samples, geom).total;
 }
 
 int pm_pick_columns(int S, int ntaps, int num_samples, bool geom, int radius, int requested) {
   const size_t budget = 60 * 1024;
   int c = requested > 0 ? requested : 4;
   if (c > 64) c = 64;
-  while (c > 1 && lds_layout(nullptr, nullptr, c, S, radius, ntaps, num_samples, geom) > budget) --c;
+  while (c > 1 && lds_offsets(c, S, radius, ntaps, num_samples, geom).total > budget) --c;
   return c;
 }
 
@@ -1032,21 +1223,31 @@ void pm_launch_init_state(const PmParams& p, bool random_init, float depth_min, 
                      depth_max, init_depth, init_normal);
 }
 
-void pm_launch_initial_cost(const PmParams& p, hipStream_t st) {
-  const size_t lds = lds_layout(nullptr, nullptr, p.C, p.S, p.radius, p.ntaps, p.num_samples, false);
+void pm_launch_initial_cost(const PmParams& p, const PmParams* dev_params, int batch, hipStream_t st) {
+  const size_t lds = lds_offsets(p.C, p.S, p.radius, p.ntaps, p.num_samples, false).total;
   dim3 block(64, 1, 1);
-  dim3 grid((p.W + p.C - 1) / p.C, p.H, 1);
-  hipLaunchKernelGGL(pm_initial_cost_kernel, grid, block, lds, st, p);
+  dim3 grid((p.W + p.C - 1) / p.C, p.H, batch);
+  if (p.ntap1d == 11) hipLaunchKernelGGL(pm_initial_cost_kernel<11>, grid, block, lds, st, dev_params);
+  else hipLaunchKernelGGL(pm_initial_cost_kernel<0>, grid, block, lds, st, dev_params);
 }
 
-void pm_launch_sweep(const PmParams& p, int threads, bool geom, bool filter_photo, bool filter_geom,
-                     hipStream_t st) {
+void pm_launch_sweep(const PmParams& p, const PmParams* dev_params, int batch, int threads, bool geom,
+                     bool filter_photo, bool filter_geom, hipStream_t st) {
   const size_t lds = pm_sweep_lds_bytes(p, geom);
   const int rw = (p.rot & 1) ? p.H : p.W;
   dim3 block(threads, 1, 1);
-  dim3 grid((rw + p.C - 1) / p.C, 1, 1);
-#define PM_LAUNCH(G, FP, FG) \
-  hipLaunchKernelGGL((pm_sweep_kernel<G, FP, FG>), grid, block, lds, st, p)
+  dim3 grid((rw + p.C - 1) / p.C, batch, 1);
+#define PM_LAUNCH_N(N, G, FP, FG, PR) \
+  hipLaunchKernelGGL((pm_sweep_kernel<N, G, FP, FG, PR>), grid, block, lds, st, dev_params)
+#define PM_LAUNCH(G, FP, FG)                      \
+  do {                                            \
+    if (p.ntap1d == 11) PM_LAUNCH_N(11, G, FP, FG, false); \
+    else PM_LAUNCH_N(0, G, FP, FG, false);        \
+  } while (0)
+  if (p.prof && !geom && !filter_photo && p.ntap1d == 11) {
+    PM_LAUNCH_N(11, false, false, false, true);
+    return;
+  }
   if (geom) {
     if (filter_photo && filter_geom) PM_LAUNCH(true, true, true);
     else PM_LAUNCH(true, false, false);
@@ -1054,6 +1255,7 @@ void pm_launch_sweep(const PmParams& p, int threads, bool geom, bool filter_phot
     if (filter_photo) PM_LAUNCH(false, true, false);
     else PM_LAUNCH(false, false, false);
   }
+#undef PM_LAUNCH_N
 #undef PM_LAUNCH
 }
 

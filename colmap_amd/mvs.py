@@ -159,12 +159,15 @@ class PatchMatch:
         self._dims = None
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:  # interpreter shutdown
+            pass
 
     def close(self):
         if getattr(self, "_h", None):
-            lib().pm_destroy(self._h)
-            self._h = None
+            h, self._h = self._h, None
+            lib().pm_destroy(h)
 
     # -- marshalling -----------------------------------------------------------------
     def _marshal(self):
@@ -299,11 +302,32 @@ class PatchMatch:
                                         K.ctypes.data_as(C.c_void_p), iK.ctypes.data_as(C.c_void_p)))
         return poses, K, iK
 
+    def EnablePhaseProfile(self, enable=True):
+        _check(lib().pm_enable_phase_profile(self._h, 1 if enable else 0))
+
+    def GetPhaseProfile(self):
+        out = (C.c_ulonglong * 10)()
+        _check(lib().pm_get_phase_profile(self._h, out))
+        return list(out)
+
     def GetSweepTiming(self):
         ms = C.c_double(0)
         n = C.c_int32(0)
         _check(lib().pm_get_sweep_timing(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+
+def run_batch(pms: Sequence[PatchMatch], wait: bool = True):
+    """Solve several same-shaped problems in one batched run (pm_run_batch): every
+    kernel launch covers all of them. Bit-identical to running them one by one."""
+    for pm in pms:
+        if pm._h is None:
+            pm.Create()
+    arr = (C.c_void_p * len(pms))(*[pm._h for pm in pms])
+    if wait:
+        _check(lib().pm_run_batch(arr, len(pms)))
+    else:
+        _check(lib().pm_run_batch_async(arr, len(pms)))
 
 
 def write_mat(path: str, a: np.ndarray):

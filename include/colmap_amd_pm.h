@@ -106,6 +106,14 @@ int pm_run(pm_handle* h);
 int pm_run_async(pm_handle* h);
 int pm_synchronize(pm_handle* h);
 
+/* Solve `n` problems of identical image size / source count / options together: each
+ * kernel launch covers all n reference images (the reference runs one problem per
+ * GPU at a time, patch_match.cc:394; a single 2560-wide image cannot fill 256 CUs).
+ * Results are bit-identical to n separate pm_run() calls. Timing of the batched
+ * sweep launches is reported by pm_get_sweep_timing(handles[0]). */
+int pm_run_batch(pm_handle** handles, int32_t n);
+int pm_run_batch_async(pm_handle** handles, int32_t n); /* then pm_synchronize() each */
+
 /* PatchMatchCuda::GetDepthMap / GetNormalMap / GetSelProbMap
  * (patch_match_cuda.cu:1354-1365). out buffers are host memory:
  * depth H*W, normal 3*H*W slice-major, sel_prob S*H*W slice-major. */
@@ -130,6 +138,11 @@ int pm_get_sweep_timing(pm_handle* h, double* total_ms, int32_t* num_launches);
 /* Device pointers of the result maps in API layout (valid after pm_synchronize;
  * for consumers that stay on the GPU, e.g. the geometric pass). */
 int pm_get_device_maps(pm_handle* h, const float** depth, const float** normal);
+
+/* Debug: per-phase shader-clock totals of the sweep kernel (wave 0 of every
+ * workgroup, summed); only for the photometric no-filter radius-5 variant. */
+int pm_enable_phase_profile(pm_handle* h, int enable);
+int pm_get_phase_profile(pm_handle* h, unsigned long long* out10);
 
 void pm_destroy(pm_handle* h);
 const char* pm_last_error(void);

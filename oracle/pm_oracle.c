@@ -76,6 +76,10 @@ typedef struct {
   int max_sweeps;  /* <0: all 4*num_iterations; else stop after this many */
   int memoize;     /* 1: reuse bit-identical NCC values within a pixel step */
   int num_threads; /* <=0: OpenMP default */
+  int order;       /* 0: reference order (sequential taps, incremental homography
+                      stepping, patch_match_cuda.cu:503-569); 1: device order (taps
+                      dealt to 16 lanes, per-tap direct homography, fixed 16-lane tree
+                      sum) -- the order the HIP kernel evaluates the same sums in */
 } pmo_options;
 
 /* Mirrors mvs::Image (image.h:40-98): K,R,T row-major float + grey bitmap. */
@@ -328,6 +332,33 @@ static inline float tex_src_bilinear(const pmo_state* st, int s, float x, float 
   return fmaf(bot, wy, top * (1.0f - wy));
 }
 
+/* Device-order variant: blend the four raw texels (exact integers in float) and scale
+ * the blend once by 1/255 (the float nearest to 1/255, 0x1.010102p-8), instead of
+ * normalising each texel first. Same bilinear polynomial, one rounding order. */
+static inline float tex_src_raw(const pmo_state* st, int s, int ix, int iy) {
+  if (ix < 0 || iy < 0 || ix >= st->src_w || iy >= st->src_h) return 0.0f;
+  return (float)st->src_images[((size_t)s * st->src_h + iy) * st->src_w + ix];
+}
+static inline float tex_src_bilinear_raw(const pmo_state* st, int s, float x, float y) {
+  const float px = x - 0.5f;
+  const float py = y - 0.5f;
+  const float fx = floorf(px);
+  const float fy = floorf(py);
+  const float wx = px - fx;
+  const float wy = py - fy;
+  const int ix = sat_f2i(fx);
+  const int iy = sat_f2i(fy);
+  const int ix1 = ix == INT32_MAX ? ix : ix + 1;
+  const int iy1 = iy == INT32_MAX ? iy : iy + 1;
+  const float c00 = tex_src_raw(st, s, ix, iy);
+  const float c10 = tex_src_raw(st, s, ix1, iy);
+  const float c01 = tex_src_raw(st, s, ix, iy1);
+  const float c11 = tex_src_raw(st, s, ix1, iy1);
+  const float top = fmaf(c10, wx, c00 * (1.0f - wx));
+  const float bot = fmaf(c11, wx, c01 * (1.0f - wx));
+  return fmaf(bot, wy, top * (1.0f - wy)) * 0x1.010102p-8f;
+}
+
 /* source depth: point filter, element type, border 0, sampled at (+0.5,+0.5)
  * (patch_match_cuda.cu:635-636, 1677-1690) */
 static inline float tex_src_depth(const pmo_state* st, int s, float x, float y) {
@@ -558,6 +589,83 @@ static float ncc_cost(const pmo_state* st, const ncc_params* np, const float inv
   return fmaxf(0.0f, fminf(kMaxCost, 1.0f - covar / var));
 }
 
+/* The same cost as ncc_cost() evaluated in the HIP kernel's order ("device order"):
+ *  - tap t = wrow * n1d + wcol is dealt to lane j = t % 16 of a 16-lane group; a
+ *    lane accumulates its taps in increasing t;
+ *  - the warped coordinate of a tap is evaluated directly from the homography,
+ *    fma(H0, x, fma(H1, y, H2)) with x, y the integer pixel position of the tap,
+ *    instead of the reference's running sums (:554-568);
+ *  - the bilinear blend is taken over the raw texels and scaled once by 1/255
+ *    (tex_src_bilinear_raw) instead of normalising the four texels first;
+ *  - the 16 partial sums are combined by the fixed tree the DPP cross-lane adds
+ *    implement (row_mirror, row_half_mirror, quad reverse, quad swap):
+ *    total = ((q0+q7)+(q3+q4)) + ((q1+q6)+(q2+q5)),  q_l = p_l + p_(15-l).
+ * Mathematically identical to :489-593; only the rounding order differs. */
+static inline float tree16(const float p[16]) {
+  float q[8];
+  for (int l = 0; l < 8; ++l) q[l] = p[l] + p[15 - l];
+  return ((q[0] + q[7]) + (q[3] + q[4])) + ((q[1] + q[6]) + (q[2] + q[5]));
+}
+
+static float ncc_cost_device(const pmo_state* st, const ncc_params* np, const float inv_K[4],
+                             const float* pose, int s, int row, int col, float depth,
+                             const float normal[3], float ref_sum, float ref_sqsum,
+                             const float* weights, const float* refc) {
+  float tf[9];
+  compose_homography(inv_K, pose, row, col, depth, normal, tf);
+  const int n1d = (2 * np->radius) / np->step + 1;
+  const int ntaps = n1d * n1d;
+  float a_sum[16], a_sq[16], a_ref[16], a_w[16];
+  for (int j = 0; j < 16; ++j) a_sum[j] = a_sq[j] = a_ref[j] = a_w[j] = 0.0f;
+  for (int t = 0; t < ntaps; ++t) {
+    const int j = t & 15;
+    const int wrow = t / n1d, wcol = t - wrow * n1d;
+    const float xf = (float)(col - np->radius + wcol * np->step);
+    const float yf = (float)(row - np->radius + wrow * np->step);
+    const float col_src = fmaf(tf[0], xf, fmaf(tf[1], yf, tf[2]));
+    const float row_src = fmaf(tf[3], xf, fmaf(tf[4], yf, tf[5]));
+    const float z = fmaf(tf[6], xf, fmaf(tf[7], yf, tf[8]));
+    const float inv_z = 1.0f / z;
+    const float norm_col_src = fmaf(inv_z, col_src, 0.5f);
+    const float norm_row_src = fmaf(inv_z, row_src, 0.5f);
+    const float src_color = tex_src_bilinear_raw(st, s, norm_col_src, norm_row_src);
+    const float bw = weights[t];
+    const float bws = bw * src_color;
+    a_sum[j] += bws;
+    a_sq[j] = fmaf(bws, src_color, a_sq[j]);
+    a_ref[j] = fmaf(bws, refc[t], a_ref[j]);
+    a_w[j] += bw;
+  }
+  float src_color_sum = tree16(a_sum);
+  float src_color_squared_sum = tree16(a_sq);
+  float src_ref_color_sum = tree16(a_ref);
+  const float bilateral_weight_sum = tree16(a_w);
+  const float inv_bws = 1.0f / bilateral_weight_sum;
+  src_color_sum *= inv_bws;
+  src_color_squared_sum *= inv_bws;
+  src_ref_color_sum *= inv_bws;
+  const float ref_color_var = ref_sqsum - ref_sum * ref_sum;
+  const float src_color_var = src_color_squared_sum - src_color_sum * src_color_sum;
+  const float kMinVar = 1e-5f;
+  const float kMaxCost = 2.0f;
+  if (ref_color_var < kMinVar || src_color_var < kMinVar) return kMaxCost;
+  const float covar = src_ref_color_sum - ref_sum * src_color_sum;
+  const float var = sqrtf(ref_color_var * src_color_var);
+  return fmaxf(0.0f, fminf(kMaxCost, 1.0f - covar / var));
+}
+
+/* order dispatch */
+static float ncc_any(const pmo_options* opt, const pmo_state* st, const ncc_params* np,
+                     const float inv_K[4], const float* pose, int s, int row, int col, float depth,
+                     const float normal[3], float ref_sum, float ref_sqsum, const float* weights,
+                     const float* refc) {
+  if (opt->order == 1)
+    return ncc_cost_device(st, np, inv_K, pose, s, row, col, depth, normal, ref_sum, ref_sqsum,
+                           weights, refc);
+  return ncc_cost(st, np, inv_K, pose, s, row, col, depth, normal, ref_sum, ref_sqsum,
+                  opt->memoize ? weights : NULL, opt->memoize ? refc : NULL);
+}
+
 /* ComputeGeomConsistencyCost, patch_match_cuda.cu:601-667 */
 static float geom_cost(const pmo_state* st, const float K4[4], const float inv_K[4],
                        const float* pose, int s, float row, float col, float depth,
@@ -718,11 +826,11 @@ static void compute_initial_cost(pmo_state* st, const pmo_options* opt) {
         for (int k = 0; k < 3; ++k) normal[k] = st->normal[idx3(st, k, row, col)];
         const float rs = st->ref_sum[(size_t)row * st->W + col];
         const float rss = st->ref_sqsum[(size_t)row * st->W + col];
-        if (opt->memoize) patch_weights(st, &np, row, col, w, rc);
+        if (opt->memoize || opt->order == 1) patch_weights(st, &np, row, col, w, rc);
         for (int s = 0; s < st->S; ++s) {
           st->cost[idx3(st, s, row, col)] =
-              ncc_cost(st, &np, inv_K, st->poses[st->rot] + s * PMO_POSE_STRIDE, s, row, col,
-                       depth, normal, rs, rss, opt->memoize ? w : NULL, opt->memoize ? rc : NULL);
+              ncc_any(opt, st, &np, inv_K, st->poses[st->rot] + s * PMO_POSE_STRIDE, s, row, col,
+                      depth, normal, rs, rss, w, rc);
         }
       }
     }
@@ -777,10 +885,8 @@ static void sweep_column(pmo_state* st, const pmo_options* opt, const sweep_opti
   for (int row = 0; row < H; ++row) {
     const float ref_sum = st->ref_sum[(size_t)row * st->W + col];
     const float ref_sqsum = st->ref_sqsum[(size_t)row * st->W + col];
-    if (opt->memoize) {
-      patch_weights(st, &np, row, col, w, rc);
-      memset(memo_valid, 0, 5 * S);
-    }
+    if (opt->memoize || opt->order == 1) patch_weights(st, &np, row, col, w, rc);
+    if (opt->memoize) memset(memo_valid, 0, 5 * S);
 
     /* :1047-1048 */
     prev_depth = propagate_depth(inv_K, prev_depth, prev_normal, (float)(row - 1), (float)row);
@@ -853,8 +959,8 @@ static void sweep_column(pmo_state* st, const pmo_options* opt, const sweep_opti
         if (opt->memoize && memo_valid[i * S + src]) {
           c = memo[i * S + src];
         } else {
-          c = ncc_cost(st, &np, inv_K, pose, src, row, col, depths[i], normals[i], ref_sum,
-                       ref_sqsum, opt->memoize ? w : NULL, opt->memoize ? rc : NULL);
+          c = ncc_any(opt, st, &np, inv_K, pose, src, row, col, depths[i], normals[i], ref_sum,
+                      ref_sqsum, w, rc);
           if (opt->memoize) { memo[i * S + src] = c; memo_valid[i * S + src] = 1; }
         }
         costs[i] += c;
@@ -888,9 +994,8 @@ static void sweep_column(pmo_state* st, const pmo_options* opt, const sweep_opti
         if (opt->memoize && memo_valid[min_idx * S + s]) {
           cost = memo[min_idx * S + s];
         } else {
-          cost = ncc_cost(st, &np, inv_K, poses + s * PMO_POSE_STRIDE, s, row, col, best_depth,
-                          best_normal, ref_sum, ref_sqsum, opt->memoize ? w : NULL,
-                          opt->memoize ? rc : NULL);
+          cost = ncc_any(opt, st, &np, inv_K, poses + s * PMO_POSE_STRIDE, s, row, col, best_depth,
+                         best_normal, ref_sum, ref_sqsum, w, rc);
         }
         st->cost[idx3(st, s, row, col)] = cost;
       }

@@ -42,6 +42,7 @@ class Options(C.Structure):
         ("filter_min_num_consistent", C.c_int),
         ("geom_consistency", C.c_int), ("filter", C.c_int),
         ("max_sweeps", C.c_int), ("memoize", C.c_int), ("num_threads", C.c_int),
+        ("order", C.c_int),
     ]
 
 
@@ -94,6 +95,7 @@ def default_options(**kw) -> Options:
     o.filter_min_num_consistent = 2
     o.geom_consistency, o.filter = 1, 1
     o.max_sweeps, o.memoize, o.num_threads = -1, 1, 0
+    o.order = 0  # 0: reference evaluation order, 1: device (HIP kernel) order
     for k, v in kw.items():
         if not hasattr(o, k):
             raise AttributeError(k)

@@ -9,7 +9,7 @@ ap.add_argument("--w", type=int, default=640); ap.add_argument("--h", type=int, 
 ap.add_argument("--views", type=int, default=9); ap.add_argument("--iters", type=int, default=5)
 ap.add_argument("--cols", type=int, default=0); ap.add_argument("--threads", type=int, default=0)
 ap.add_argument("--conc", type=int, default=1); ap.add_argument("--arc", type=float, default=30.0)
-ap.add_argument("--sweeps", type=int, default=0)
+ap.add_argument("--sweeps", type=int, default=0); ap.add_argument("--prof", type=int, default=0); ap.add_argument("--batched", type=int, default=1); ap.add_argument("--nofilter", type=int, default=0)
 a = ap.parse_args()
 t = time.time()
 views = syn.make_scene(a.views, a.w, a.h, arc_deg=a.arc, device="cuda")
@@ -18,21 +18,30 @@ ref = a.views // 2
 src = [i for i in range(a.views) if i != ref]
 dmin, dmax = syn.depth_range(views, ref)
 opt = mvs.PatchMatchOptions(gpu_index="0", depth_min=dmin, depth_max=dmax, sigma_spatial=5.0, geom_consistency=False,
-                            filter=True, num_iterations=a.iters, columns_per_group=a.cols, threads_per_group=a.threads,
+                            filter=not a.nofilter, num_iterations=a.iters, columns_per_group=a.cols, threads_per_group=a.threads,
                             max_sweeps=a.sweeps)
 images = [mvs.Image(v.K, v.R, v.T, torch.from_numpy(v.gray).cuda()) for v in views]
 pms = [mvs.PatchMatch(opt, mvs.PatchMatch.Problem(ref, src, images)) for _ in range(a.conc)]
 t = time.time()
 for pm in pms: pm.Create()
 torch.cuda.synchronize(); tc = time.time() - t
+if a.prof:
+    for pm in pms: pm.EnablePhaseProfile()
 t = time.time()
-for pm in pms: pm.RunAsync()
-for pm in pms: pm.Synchronize()
+if a.batched:
+    mvs.run_batch(pms)
+else:
+    for pm in pms: pm.RunAsync()
+    for pm in pms: pm.Synchronize()
 tr = time.time() - t
 ms, n = pms[0].GetSweepTiming()
 mpix = a.w * a.h * a.conc / 1e6
 print(f"W={a.w} H={a.h} S={len(src)} conc={a.conc} C={a.cols} T={a.threads}: create {tc:.3f}s run {tr:.3f}s "
       f"-> {mpix/tr:.3f} Mpix/s (run only), {mpix/(tr+tc):.3f} incl create; sweep kernel avg {ms/max(n,1):.2f} ms x{n}")
+if a.prof:
+    pr = pms[0].GetPhaseProfile(); tot = sum(pr)
+    names = ["setup+backward", "P0 tile", "P1 hyp+weights", "P2 priors", "P3 cdf+draws", "P4 ncc", "P5 argmin", "P6 ncc-winner", "P7-8 update", "-"]
+    print("phase profile: " + ", ".join(f"{n} {100*v/max(tot,1):.1f}%" for n, v in zip(names, pr)))
 d = pms[0].GetDepthMap(); gt = views[ref].depth
 ok = d > 0
 rel = np.abs(d[ok] - gt[ok]) / gt[ok]

@@ -43,6 +43,7 @@ def paired_options(pm_oracle, **kw):
     tuning = {k: kw.pop(k) for k in ("columns_per_group", "threads_per_group") if k in kw}
     o = pm_oracle.default_options(**kw)
     o.max_sweeps = max_sweeps
+    o.order = 1  # the HIP kernel's evaluation order (oracle/pm_oracle.c: ncc_cost_device)
     h = mvs.PatchMatchOptions(gpu_index="0", **tuning)
     for f in OPTION_FIELDS:
         v = getattr(o, f)

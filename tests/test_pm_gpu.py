@@ -4,6 +4,9 @@ The arithmetic of the path is specified operation by operation (oracle/pm_oracle
 header), so the bar is BIT-EXACT equality of every output map, not a tolerance:
 a stochastic argmin algorithm amplifies one-ulp differences into different depth
 maps, so anything weaker than exact equality would not be a meaningful check.
+The oracle runs in `order=1` (the kernel's evaluation order of the NCC sums);
+tests/test_pm_oracle.py bounds the difference between that order and the
+reference's sequential order (`order=0`).
 """
 import numpy as np
 import pytest
@@ -93,7 +96,7 @@ def test_geometric_consistency_and_filter(pm_oracle):
     for ref in range(3):
         dmin, dmax = syn.depth_range(views, ref)
         o = pm_oracle.default_options(depth_min=dmin, depth_max=dmax, geom_consistency=0, filter=0,
-                                      num_iterations=1)
+                                      num_iterations=1, order=1)
         r = pm_oracle.run(o, oracle_inputs(views), ref, [i for i in range(3) if i != ref])
         maps.append((r["depth"], r["normal"]))
     want, got, _ = _run_both(pm_oracle, views, 1, [0, 2], maps=maps, geom_consistency=1, filter=1,
@@ -137,6 +140,33 @@ def test_sources_larger_than_reference_slot(pm_oracle):
     want, got, _ = _run_both(pm_oracle, views, 1, [0, 2], geom_consistency=0, filter=0,
                              num_iterations=1)
     _assert_equal(want, got)
+
+
+def test_batched_run_equals_single_runs(pm_oracle):
+    """pm_run_batch: three different reference images solved by shared launches give the
+    same bits as the oracle run on each problem separately."""
+    from colmap_amd import mvs
+    views = scene(5, 67, 45)
+    probs = [(1, [0, 2, 3]), (2, [1, 3, 4]), (3, [1, 2, 4])]
+    pms, wants = [], []
+    for ref, src in probs:
+        dmin, dmax = syn.depth_range(views, ref)
+        o, h = paired_options(pm_oracle, depth_min=dmin, depth_max=dmax, geom_consistency=0, filter=1,
+                              num_iterations=1, columns_per_group=2, threads_per_group=128)
+        wants.append(pm_oracle.run(o, oracle_inputs(views), ref, src, want_cost=True))
+        pms.append(mvs.PatchMatch(h, hip_problem(views, ref, src)))
+    mvs.run_batch(pms)
+    for pm, want in zip(pms, wants):
+        got = dict(depth=pm.GetDepthMap(), normal=pm.GetNormalMap(), sel_prob=pm.GetSelProbMap(),
+                   cost=pm.GetCostMap(), mask=pm.GetConsistencyMask())
+        _assert_equal(want, got)
+    # mismatched shapes are rejected
+    other = scene(4, 64, 48)
+    dmin, dmax = syn.depth_range(other, 1)
+    _, h2 = paired_options(pm_oracle, depth_min=dmin, depth_max=dmax, geom_consistency=0, filter=1,
+                           num_iterations=1)
+    with pytest.raises(mvs.PatchMatchError):
+        mvs.run_batch([pms[0], mvs.PatchMatch(h2, hip_problem(other, 1, [0, 2, 3]))])
 
 
 def test_error_behaviour():
