@@ -176,6 +176,9 @@ __device__ __forceinline__ float ref_texel(const PmParams& p, int row, int col) 
 // LDS pointers carry address space 3 explicitly so that every access is a ds_*
 // instruction (generic pointers kept in a struct degrade to flat_* loads).
 #define LDS_AS __attribute__((address_space(3)))
+// global (address space 1) view of a pointer loaded from the parameter block: without it
+// the gathers compile to flat_load (pointer provenance is unknown to the compiler)
+typedef __attribute__((address_space(1))) const uint32_t gbl_u32;
 typedef LDS_AS float lds_f32;
 struct __attribute__((aligned(8))) WeightRef {
   float w;  // bilateral weight
@@ -234,9 +237,8 @@ struct TapAddr {
   float wx, wy;
 };
 
-__device__ __forceinline__ void tap_fetch(const PmParams& p, const uint32_t* __restrict__ fp,
-                                          unsigned fpw, float col_src, float row_src, float z,
-                                          TapAddr& t) {
+__device__ __forceinline__ void tap_fetch(const PmParams& p, gbl_u32* fp, unsigned fpw,
+                                          float col_src, float row_src, float z, TapAddr& t) {
   const float inv_z = 1.0f / z;
   const float x = fmaf(inv_z, col_src, 0.5f);
   const float y = fmaf(inv_z, row_src, 0.5f);
@@ -290,8 +292,8 @@ __device__ __forceinline__ float reduce16(float v) {
 // (hypothesis, view) pair (LDS, precomputed once per task), `wr` holds (bilateral
 // weight, reference colour) per tap. All 16 lanes return the same cost.
 template <int N1D>
-__device__ __forceinline__ float ncc_group(const PmParams& p, const lds_f32* H,
-                                           const uint32_t* __restrict__ fp, const lds_f32x2* wr,
+__device__ __forceinline__ float ncc_group(const PmParams& p, const lds_f32* H, gbl_u32* fp,
+                                           const lds_f32x2* wr,
                                            int row, int col, float ref_sum, float ref_sqsum,
                                            float inv_w, int j) {
   const float h0 = H[0], h1 = H[1], h2 = H[2], h3 = H[3], h4 = H[4], h5 = H[5], h6 = H[6],
@@ -805,7 +807,7 @@ __global__ void __launch_bounds__(64) pm_initial_cost_kernel(const PmParams* __r
     const int col = col0 + c;
     if (col >= p.W) continue;
     const int pix = row * p.W + col;
-    const float cost = ncc_group<N1D>(p, L.th + item * 9, p.src_fp + (size_t)s * fp_slice,
+    const float cost = ncc_group<N1D>(p, L.th + item * 9, (gbl_u32*)p.src_fp + (size_t)s * fp_slice,
                                       L.wr + c * p.ntaps, row, col, p.ref_sum[pix], p.ref_sqsum[pix],
                                       L.colf[c * 8 + 5], j);
     if (j == 0) p.rec[(size_t)pix * p.rec_stride + 4 + s] = cost;
@@ -850,7 +852,7 @@ __device__ __forceinline__ void run_tasks(const PmParams& p, const Lds& L, int r
     const int c = task >> 24;
     const int i = (task >> 20) & 7;
     const int s = task & 0xfffff;
-    const float cost = ncc_group<N1D>(p, L.th + t * 9, p.src_fp + (size_t)s * fp_slice,
+    const float cost = ncc_group<N1D>(p, L.th + t * 9, (gbl_u32*)p.src_fp + (size_t)s * fp_slice,
                                       L.wr + c * p.ntaps, row, col0 + c, L.colf[c * 8 + 0],
                                       L.colf[c * 8 + 1], L.colf[c * 8 + 5], j);
     if (j == 0) L.ncc[(c * 5 + i) * p.S + s] = cost;

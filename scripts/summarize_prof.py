@@ -1,0 +1,39 @@
+"""Summarise rocprofv3 CSV output into small files (run on the GPU box)."""
+import csv, glob, json, os, sys
+from collections import defaultdict
+
+out = sys.argv[1]
+summary = {}
+# kernel stats
+for f in glob.glob(os.path.join(out, "stats", "**", "*kernel_stats.csv"), recursive=True):
+    rows = list(csv.DictReader(open(f)))
+    keep = [r for r in rows if "pm_" in r.get("Name", "")] + rows[:5]
+    with open(os.path.join(out, "kernel_stats_summary.csv"), "w") as g:
+        w = csv.DictWriter(g, fieldnames=rows[0].keys())
+        w.writeheader()
+        seen = set()
+        for r in keep:
+            if r["Name"] in seen:
+                continue
+            seen.add(r["Name"])
+            w.writerow(r)
+# PMC passes
+for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
+    if not os.path.isdir(d):
+        continue
+    agg = defaultdict(lambda: defaultdict(float))
+    ndisp = defaultdict(set)
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            name = r.get("Kernel_Name", "")
+            if "pm_sweep_kernel" in name:
+                k = "pm_sweep_kernel"
+            elif "pm_initial_cost" in name:
+                k = "pm_initial_cost_kernel"
+            else:
+                continue
+            agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            ndisp[k].add(r.get("Dispatch_Id"))
+    summary[os.path.basename(d)] = {k: dict(v, dispatches=len(ndisp[k])) for k, v in agg.items()}
+json.dump(summary, open(os.path.join(out, "pmc_summary.json"), "w"), indent=1)
+print(json.dumps(summary, indent=1))
