@@ -1,0 +1,568 @@
+"""Host-side mirror of the reference's bundle-adjustment interface over the C ABI.
+
+Same names / meaning as colmap (reference src/colmap/estimators/bundle_adjustment.h:50-234):
+`BundleAdjustmentGauge`, `BundleAdjustmentTerminationType`, `BundleAdjustmentBackend` (with
+the new value `MI355X` after CERES=0, CASPAR=1 -- pycolmap pins those two,
+pycolmap/estimators/bundle_adjustment_test.py:27-39), `BundleAdjustmentConfig`,
+`BundleAdjustmentOptions`, `BundleAdjustmentSummary`, `BundleAdjuster`,
+`CreateDefaultBundleAdjuster(options, config, reconstruction)`.
+
+`flatten()` is the adapter: it applies the problem-construction rules of
+`DefaultBundleAdjuster` (bundle_adjustment_ceres.cc:606-889) -- which observations become
+residuals, which blocks are constant, gauge fixing -- and produces the SoA `ba_problem` of
+include/colmap_amd_ba.h, the way CasparBundleAdjuster does for its solver
+(bundle_adjustment_caspar.cc:61-377). `Solve()` writes variable blocks back in place
+(:767-801). All numerics happen behind `ba_solve` in libcolmap_amd.so (HIP, gfx950).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import enum
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Set
+
+import numpy as np
+
+from . import scene
+from ._lib import lib
+
+CAM_STRIDE = 12
+
+
+class BundleAdjustmentGauge(enum.IntEnum):
+    UNSPECIFIED = -1
+    TWO_CAMS_FROM_WORLD = 0
+    THREE_POINTS = 1
+
+
+class BundleAdjustmentTerminationType(enum.IntEnum):
+    CONVERGENCE = 0
+    NO_CONVERGENCE = 1
+    FAILURE = 2
+    USER_SUCCESS = 3
+    USER_FAILURE = 4
+
+
+class BundleAdjustmentBackend(enum.IntEnum):
+    CERES = 0
+    CASPAR = 1
+    MI355X = 2
+
+
+class BundleAdjustmentConfig:
+    """colmap::BundleAdjustmentConfig (bundle_adjustment.h:77-150)."""
+
+    def __init__(self):
+        self.fixed_gauge_ = BundleAdjustmentGauge.UNSPECIFIED
+        self.image_ids_: Set[int] = set()
+        self.variable_point3D_ids_: Set[int] = set()
+        self.constant_point3D_ids_: Set[int] = set()
+        self.ignored_point3D_ids_: Set[int] = set()
+        self.constant_cam_intrinsics_: Set[int] = set()
+        self.constant_rig_from_world_poses_: Set[int] = set()
+
+    def FixGauge(self, gauge):
+        self.fixed_gauge_ = BundleAdjustmentGauge(gauge)
+
+    def FixedGauge(self):
+        return self.fixed_gauge_
+
+    def NumImages(self):
+        return len(self.image_ids_)
+
+    def AddImage(self, image_id):
+        self.image_ids_.add(image_id)
+
+    def HasImage(self, image_id):
+        return image_id in self.image_ids_
+
+    def RemoveImage(self, image_id):
+        self.image_ids_.discard(image_id)
+
+    def Images(self):
+        return sorted(self.image_ids_)
+
+    def SetConstantCamIntrinsics(self, camera_id):
+        self.constant_cam_intrinsics_.add(camera_id)
+
+    def SetVariableCamIntrinsics(self, camera_id):
+        self.constant_cam_intrinsics_.discard(camera_id)
+
+    def HasConstantCamIntrinsics(self, camera_id):
+        return camera_id in self.constant_cam_intrinsics_
+
+    def SetConstantRigFromWorldPose(self, frame_id):
+        self.constant_rig_from_world_poses_.add(frame_id)
+
+    def SetVariableRigFromWorldPose(self, frame_id):
+        self.constant_rig_from_world_poses_.discard(frame_id)
+
+    def HasConstantRigFromWorldPose(self, frame_id):
+        return frame_id in self.constant_rig_from_world_poses_
+
+    def AddVariablePoint(self, point3D_id):
+        assert point3D_id not in self.constant_point3D_ids_ and point3D_id not in self.ignored_point3D_ids_
+        self.variable_point3D_ids_.add(point3D_id)
+
+    def AddConstantPoint(self, point3D_id):
+        assert point3D_id not in self.variable_point3D_ids_ and point3D_id not in self.ignored_point3D_ids_
+        self.constant_point3D_ids_.add(point3D_id)
+
+    def IgnorePoint(self, point3D_id):
+        self.ignored_point3D_ids_.add(point3D_id)
+
+    def IsIgnoredPoint(self, point3D_id):
+        return point3D_id in self.ignored_point3D_ids_
+
+    def VariablePoints(self):
+        return sorted(self.variable_point3D_ids_)
+
+    def ConstantPoints(self):
+        return sorted(self.constant_point3D_ids_)
+
+
+@dataclass
+class SolverOptions:
+    """The ceres::Solver::Options fields COLMAP sets (bundle_adjustment_ceres.cc:102-115) plus
+    the Ceres defaults the solve depends on (trust-region schedule)."""
+    max_num_iterations: int = 100
+    max_linear_solver_iterations: int = 200
+    function_tolerance: float = 0.0
+    gradient_tolerance: float = 1e-4
+    parameter_tolerance: float = 0.0
+    initial_trust_region_radius: float = 1e4
+    max_trust_region_radius: float = 1e16
+    min_trust_region_radius: float = 1e-32
+    min_relative_decrease: float = 1e-3
+    min_lm_diagonal: float = 1e-6
+    max_lm_diagonal: float = 1e32
+    eta: float = 1e-1
+    max_num_consecutive_invalid_steps: int = 10
+    jacobi_scaling: bool = True
+
+
+@dataclass
+class BundleAdjustmentOptions:
+    """colmap::BundleAdjustmentOptions (bundle_adjustment.h:173-209)."""
+    refine_focal_length: bool = True
+    refine_principal_point: bool = False
+    refine_extra_params: bool = True
+    refine_sensor_from_rig: bool = True
+    refine_rig_from_world: bool = True
+    refine_points3D: bool = True
+    min_track_length: int = 0
+    constant_rig_from_world_rotation: bool = False
+    print_summary: bool = True
+    backend: BundleAdjustmentBackend = BundleAdjustmentBackend.MI355X
+    gpu_index: str = "-1"
+    solver_options: SolverOptions = field(default_factory=SolverOptions)
+
+    def Check(self) -> bool:
+        return self.min_track_length >= 0
+
+
+@dataclass
+class BundleAdjustmentSummary:
+    """colmap::BundleAdjustmentSummary (bundle_adjustment.h:63-74) + solver statistics."""
+    termination_type: BundleAdjustmentTerminationType = BundleAdjustmentTerminationType.FAILURE
+    num_residuals: int = 0
+    num_iterations: int = 0
+    num_successful_steps: int = 0
+    num_effective_parameters: int = 0
+    total_linear_iterations: int = 0
+    initial_cost: float = 0.0
+    final_cost: float = 0.0
+    lm_seconds: float = 0.0
+    log_cost: Optional[np.ndarray] = None
+    log_linear_iters: Optional[np.ndarray] = None
+
+    def IsSolutionUsable(self) -> bool:
+        return self.termination_type in (BundleAdjustmentTerminationType.CONVERGENCE,
+                                         BundleAdjustmentTerminationType.NO_CONVERGENCE,
+                                         BundleAdjustmentTerminationType.USER_SUCCESS)
+
+    def BriefReport(self) -> str:
+        return (f"{self.termination_type.name}: {self.num_residuals} residuals, "
+                f"{self.num_iterations} iterations, cost {self.initial_cost:.6e} -> {self.final_cost:.6e}")
+
+
+# ---------------------------------------------------------------------------------------------
+# Flat problem (SoA) shared by the C ABI binding and the oracle binding
+# ---------------------------------------------------------------------------------------------
+
+@dataclass
+class FlatProblem:
+    poses: np.ndarray          # (N_c, 7) f64
+    cams: np.ndarray           # (N_k, 12) f64
+    cam_model: np.ndarray      # (N_k,) i32
+    points: np.ndarray         # (N_p, 3) f64
+    obs_pose: np.ndarray       # (N_o,) i32
+    obs_cam: np.ndarray
+    obs_point: np.ndarray
+    obs_xy: np.ndarray         # (N_o, 2) f64
+    pose_const: np.ndarray     # (N_c,) u8
+    pose_fixed_t: np.ndarray   # (N_c,) i8
+    cam_const: np.ndarray      # (N_k, 12) u8
+    point_const: np.ndarray    # (N_p,) u8
+    # id maps for write-back
+    pose_ids: List[int] = field(default_factory=list)
+    cam_ids: List[int] = field(default_factory=list)
+    point_ids: List[int] = field(default_factory=list)
+
+    @staticmethod
+    def from_arrays(d: dict, refine_focal=True, refine_pp=False, refine_extra=True) -> "FlatProblem":
+        """Flat arrays of scene.synthesize_flat -> problem with COLMAP's default constant-ness
+        (principal point fixed) and no gauge fixing yet."""
+        n_c, n_k, n_p = len(d["poses"]), len(d["cams"]), len(d["points"])
+        cam_const = np.ones((n_k, CAM_STRIDE), np.uint8)
+        for k in range(n_k):
+            m = int(d["cam_model"][k])
+            if refine_focal:
+                cam_const[k, scene.MODEL_FOCAL_IDXS[m]] = 0
+            if refine_pp:
+                cam_const[k, scene.MODEL_PP_IDXS[m]] = 0
+            if refine_extra and scene.MODEL_EXTRA_IDXS[m]:
+                cam_const[k, scene.MODEL_EXTRA_IDXS[m]] = 0
+        return FlatProblem(
+            poses=np.ascontiguousarray(d["poses"], np.float64), cams=np.ascontiguousarray(d["cams"], np.float64),
+            cam_model=np.ascontiguousarray(d["cam_model"], np.int32),
+            points=np.ascontiguousarray(d["points"], np.float64),
+            obs_pose=np.ascontiguousarray(d["obs_pose"], np.int32), obs_cam=np.ascontiguousarray(d["obs_cam"], np.int32),
+            obs_point=np.ascontiguousarray(d["obs_point"], np.int32), obs_xy=np.ascontiguousarray(d["obs_xy"], np.float64),
+            pose_const=np.zeros(n_c, np.uint8), pose_fixed_t=np.full(n_c, -1, np.int8), cam_const=cam_const,
+            point_const=np.zeros(n_p, np.uint8))
+
+    def copy(self) -> "FlatProblem":
+        import copy
+        return copy.deepcopy(self)
+
+
+def fix_gauge_two_cams(fp: FlatProblem, order: Optional[List[int]] = None):
+    """FixGaugeWithTwoCamsFromWorld (bundle_adjustment_ceres.cc:308-416) on a flat problem whose
+    poses are all trivial-rig frames: frame 1 fully constant, the largest-baseline translation
+    coordinate of frame 2 constant. Returns True when the gauge was fixed with two cameras."""
+    idx = order if order is not None else list(range(len(fp.poses)))
+    used = np.zeros(len(fp.poses), bool)
+    used[fp.obs_pose] = True
+    idx = [i for i in idx if used[i]]
+    const = [i for i in idx if fp.pose_const[i]]
+    if len(const) >= 2:
+        return True  # two frames already fixed (:352-354)
+    image1 = const[0] if const else None
+    image2, fixed_dim = None, 0
+    for i in idx:
+        if image1 is None:
+            image1 = i
+            continue
+        if i == image1 or fp.pose_const[i]:
+            continue
+        # baseline = (frame1_from_world * inverse(frame2_from_world)).translation (:374-377)
+        q1, t1 = fp.poses[image1, :4], fp.poses[image1, 4:]
+        q2, t2 = fp.poses[i, :4], fp.poses[i, 4:]
+        R1, R2 = scene.quat_to_rot(q1), scene.quat_to_rot(q2)
+        baseline = t1 - R1 @ R2.T @ t2
+        k = int(np.argmax(np.abs(baseline)))
+        if abs(baseline[k]) > 1e-9:
+            image2, fixed_dim = i, k
+            break
+    if image1 is None or image2 is None:
+        return False
+    fp.pose_const[image1] = 1
+    fp.pose_fixed_t[image2] = fixed_dim
+    return True
+
+
+def fix_gauge_three_points(fp: FlatProblem):
+    """FixGaugeWithThreePoints (bundle_adjustment_ceres.cc:270-301): hold three points whose
+    coordinates span rank 3 (already-constant points count first)."""
+    used = np.zeros(len(fp.points), bool)
+    used[fp.obs_point] = True
+    chosen: List[np.ndarray] = []
+
+    def maybe(pt):
+        M = np.stack(chosen + [pt], 1)
+        if np.linalg.matrix_rank(M) > len(chosen):
+            chosen.append(pt)
+            return True
+        return False
+
+    for j in np.nonzero(used)[0]:
+        if fp.point_const[j] and maybe(fp.points[j]) and len(chosen) >= 3:
+            return True
+    for j in np.nonzero(used)[0]:
+        if not fp.point_const[j] and maybe(fp.points[j]):
+            fp.point_const[j] = 1
+            if len(chosen) >= 3:
+                return True
+    return False
+
+
+def flatten(options: BundleAdjustmentOptions, config: BundleAdjustmentConfig,
+            rec: scene.Reconstruction) -> FlatProblem:
+    """DefaultBundleAdjuster ctor (bundle_adjustment_ceres.cc:606-664)."""
+    config_const_cams = set(config.constant_cam_intrinsics_)
+    pose_ids: List[int] = []
+    pose_index: Dict[int, int] = {}
+    cam_ids: List[int] = []
+    cam_index: Dict[int, int] = {}
+    point_ids: List[int] = []
+    point_index: Dict[int, int] = {}
+    pose_is_const: List[int] = []
+    obs = []  # (pose, cam, point, x, y)
+    num_obs_of_point: Dict[int, int] = {}
+
+    def pose_slot(image_id, const):
+        key = (image_id, const)
+        if key not in pose_index:
+            pose_index[key] = len(pose_ids)
+            pose_ids.append(image_id)
+            pose_is_const.append(1 if const else 0)
+        return pose_index[key]
+
+    def cam_slot(camera_id):
+        if camera_id not in cam_index:
+            cam_index[camera_id] = len(cam_ids)
+            cam_ids.append(camera_id)
+        return cam_index[camera_id]
+
+    def point_slot(pid):
+        if pid not in point_index:
+            point_index[pid] = len(point_ids)
+            point_ids.append(pid)
+        return point_index[pid]
+
+    parameterized_cams: Set[int] = set()
+    # AddImageToProblem / AddImageWithTrivialFrame (:688-750)
+    for image_id in config.Images():
+        img = rec.images[image_id]
+        const_pose = (not options.refine_rig_from_world) or config.HasConstantRigFromWorldPose(img.frame_id)
+        n = 0
+        for p2 in img.points2D:
+            if not p2.HasPoint3D() or config.IsIgnoredPoint(p2.point3D_id):
+                continue
+            pt = rec.points3D[p2.point3D_id]
+            assert len(pt.track) > 1
+            if options.min_track_length > 0 and len(pt.track) < options.min_track_length:
+                continue
+            n += 1
+            num_obs_of_point[p2.point3D_id] = num_obs_of_point.get(p2.point3D_id, 0) + 1
+            obs.append((pose_slot(image_id, const_pose), cam_slot(img.camera_id), point_slot(p2.point3D_id),
+                        p2.xy[0], p2.xy[1]))
+        if n > 0:
+            parameterized_cams.add(img.camera_id)
+    # AddPointToProblem (:826-887): observations from images outside the config, constant pose
+    for pid in config.VariablePoints() + config.ConstantPoints():
+        pt = rec.points3D[pid]
+        if options.min_track_length > 0 and len(pt.track) < options.min_track_length:
+            continue
+        if num_obs_of_point.get(pid, 0) == len(pt.track):
+            num_obs_of_point.setdefault(pid, 0)
+            continue
+        num_obs_of_point.setdefault(pid, 0)
+        for (im, idx) in pt.track:
+            if config.HasImage(im):
+                continue
+            num_obs_of_point[pid] += 1
+            img = rec.images[im]
+            p2 = img.points2D[idx]
+            obs.append((pose_slot(im, True), cam_slot(img.camera_id), point_slot(pid), p2.xy[0], p2.xy[1]))
+            if img.camera_id not in parameterized_cams:
+                parameterized_cams.add(img.camera_id)
+                config_const_cams.add(img.camera_id)  # (:883-886)
+
+    n_c, n_k, n_p = len(pose_ids), len(cam_ids), len(point_ids)
+    poses = np.array([rec.images[i].cam_from_world for i in pose_ids], np.float64).reshape(n_c, 7)
+    cams = np.zeros((n_k, CAM_STRIDE))
+    cam_model = np.zeros(n_k, np.int32)
+    cam_const = np.ones((n_k, CAM_STRIDE), np.uint8)
+    # ParameterizeCameras (:419-469)
+    constant_camera = not (options.refine_focal_length or options.refine_principal_point or
+                           options.refine_extra_params)
+    for k, cid in enumerate(cam_ids):
+        cam = rec.cameras[cid]
+        m = cam.model_id
+        if m not in scene.MODEL_NUM_PARAMS:
+            raise ValueError(f"camera model {m} is not supported by the MI355X backend yet")
+        cams[k, : len(cam.params)] = cam.params
+        cam_model[k] = m
+        if constant_camera or cid in config_const_cams:
+            continue
+        if options.refine_focal_length:
+            cam_const[k, scene.MODEL_FOCAL_IDXS[m]] = 0
+        if options.refine_principal_point:
+            cam_const[k, scene.MODEL_PP_IDXS[m]] = 0
+        if options.refine_extra_params and scene.MODEL_EXTRA_IDXS[m]:
+            cam_const[k, scene.MODEL_EXTRA_IDXS[m]] = 0
+    points = np.array([rec.points3D[i].xyz for i in point_ids], np.float64).reshape(n_p, 3)
+    # ParameterizePoints (:548-563)
+    point_const = np.zeros(n_p, np.uint8)
+    for j, pid in enumerate(point_ids):
+        if (not options.refine_points3D) or len(rec.points3D[pid].track) > num_obs_of_point.get(pid, 0):
+            point_const[j] = 1
+    for pid in config.ConstantPoints():
+        if pid in point_index:
+            point_const[point_index[pid]] = 1
+    o = np.array(obs, np.float64).reshape(-1, 5)
+    fp = FlatProblem(
+        poses=poses, cams=cams, cam_model=cam_model, points=points,
+        obs_pose=o[:, 0].astype(np.int32), obs_cam=o[:, 1].astype(np.int32),
+        obs_point=o[:, 2].astype(np.int32), obs_xy=np.ascontiguousarray(o[:, 3:5]),
+        pose_const=np.array(pose_is_const, np.uint8), pose_fixed_t=np.full(n_c, -1, np.int8),
+        cam_const=cam_const, point_const=point_const, pose_ids=pose_ids, cam_ids=cam_ids,
+        point_ids=point_ids)
+    # gauge (:646-663)
+    if config.FixedGauge() == BundleAdjustmentGauge.TWO_CAMS_FROM_WORLD:
+        if options.refine_rig_from_world:
+            order = sorted(range(n_c), key=lambda i: pose_ids[i])  # std::set<image_t> order
+            if not fix_gauge_two_cams(fp, order):
+                fix_gauge_three_points(fp)
+    elif config.FixedGauge() == BundleAdjustmentGauge.THREE_POINTS:
+        fix_gauge_three_points(fp)
+    if options.constant_rig_from_world_rotation:
+        raise NotImplementedError("constant_rig_from_world_rotation is not supported by the MI355X backend yet")
+    return fp
+
+
+# ---------------------------------------------------------------------------------------------
+# C ABI binding
+# ---------------------------------------------------------------------------------------------
+
+class ba_problem(C.Structure):
+    _fields_ = [
+        ("num_poses", C.c_int32), ("num_cams", C.c_int32), ("num_points", C.c_int32),
+        ("num_obs", C.c_int64),
+        ("poses", C.c_void_p), ("cams", C.c_void_p), ("cam_model", C.c_void_p), ("points", C.c_void_p),
+        ("obs_pose", C.c_void_p), ("obs_cam", C.c_void_p), ("obs_point", C.c_void_p), ("obs_xy", C.c_void_p),
+        ("pose_const", C.c_void_p), ("pose_fixed_t", C.c_void_p), ("cam_const", C.c_void_p),
+        ("point_const", C.c_void_p),
+    ]
+
+
+class ba_options(C.Structure):
+    _fields_ = [
+        ("max_num_iterations", C.c_int32), ("max_linear_solver_iterations", C.c_int32),
+        ("function_tolerance", C.c_double), ("gradient_tolerance", C.c_double),
+        ("parameter_tolerance", C.c_double),
+        ("initial_trust_region_radius", C.c_double), ("max_trust_region_radius", C.c_double),
+        ("min_trust_region_radius", C.c_double),
+        ("min_relative_decrease", C.c_double), ("min_lm_diagonal", C.c_double),
+        ("max_lm_diagonal", C.c_double), ("eta", C.c_double),
+        ("max_num_consecutive_invalid_steps", C.c_int32), ("jacobi_scaling", C.c_int32),
+        ("num_threads", C.c_int32), ("max_log", C.c_int32),
+    ]
+
+
+class ba_result(C.Structure):
+    _fields_ = [
+        ("termination_type", C.c_int32), ("num_residuals", C.c_int32),
+        ("num_iterations", C.c_int32), ("num_successful_steps", C.c_int32),
+        ("num_effective_parameters", C.c_int32), ("total_linear_iterations", C.c_int64),
+        ("initial_cost", C.c_double), ("final_cost", C.c_double), ("lm_seconds", C.c_double),
+        ("num_logged", C.c_int32),
+        ("log_cost", C.c_void_p), ("log_radius", C.c_void_p), ("log_linear_iters", C.c_void_p),
+    ]
+
+
+def marshal_problem(fp: FlatProblem) -> ba_problem:
+    p = ba_problem()
+    p.num_poses, p.num_cams, p.num_points = len(fp.poses), len(fp.cams), len(fp.points)
+    p.num_obs = len(fp.obs_pose)
+    for name in ("poses", "cams", "cam_model", "points", "obs_pose", "obs_cam", "obs_point", "obs_xy",
+                 "pose_const", "pose_fixed_t", "cam_const", "point_const"):
+        a = getattr(fp, name)
+        assert a.flags["C_CONTIGUOUS"], name
+        setattr(p, name, a.ctypes.data)
+    return p
+
+
+def marshal_options(so: SolverOptions, max_log: int = 0, num_threads: int = 0) -> ba_options:
+    o = ba_options()
+    for name, _ in ba_options._fields_:
+        if name in ("num_threads", "max_log"):
+            continue
+        setattr(o, name, getattr(so, name))
+    o.jacobi_scaling = 1 if so.jacobi_scaling else 0
+    o.num_threads = num_threads
+    o.max_log = max_log
+    return o
+
+
+def solve_flat(fp: FlatProblem, so: Optional[SolverOptions] = None, gpu_index: int = -1,
+               max_log: int = 256, solve_fn=None) -> BundleAdjustmentSummary:
+    """ba_solve on a flat problem (in place). `solve_fn` lets the tests route the identical
+    marshalled structs to the oracle library instead."""
+    so = so or SolverOptions()
+    p = marshal_problem(fp)
+    o = marshal_options(so, max_log=max_log)
+    r = ba_result()
+    log_cost = np.zeros(max(max_log, 1))
+    log_radius = np.zeros(max(max_log, 1))
+    log_lin = np.zeros(max(max_log, 1), np.int32)
+    r.log_cost, r.log_radius, r.log_linear_iters = log_cost.ctypes.data, log_radius.ctypes.data, log_lin.ctypes.data
+    if solve_fn is None:
+        L = lib()
+        rc = L.ba_solve(C.byref(p), C.byref(o), C.c_int32(gpu_index), C.byref(r))
+        if rc != 0:
+            raise RuntimeError(L.ba_last_error().decode())
+    else:
+        rc = solve_fn(C.byref(p), C.byref(o), C.byref(r))
+        if rc != 0:
+            raise RuntimeError(f"oracle failed: {rc}")
+    return BundleAdjustmentSummary(
+        termination_type=BundleAdjustmentTerminationType(r.termination_type), num_residuals=r.num_residuals,
+        num_iterations=r.num_iterations, num_successful_steps=r.num_successful_steps,
+        num_effective_parameters=r.num_effective_parameters,
+        total_linear_iterations=r.total_linear_iterations, initial_cost=r.initial_cost,
+        final_cost=r.final_cost, lm_seconds=r.lm_seconds, log_cost=log_cost[: r.num_logged].copy(),
+        log_linear_iters=log_lin[: r.num_logged].copy())
+
+
+class BundleAdjuster:
+    """colmap::BundleAdjuster (bundle_adjustment.h:212-228) for backend MI355X."""
+
+    def __init__(self, options: BundleAdjustmentOptions, config: BundleAdjustmentConfig,
+                 reconstruction: scene.Reconstruction, solve_fn=None):
+        assert options.Check()
+        self.options_ = options
+        self.config_ = config
+        self.reconstruction_ = reconstruction
+        self.problem_ = flatten(options, config, reconstruction)
+        self._solve_fn = solve_fn
+
+    def Options(self):
+        return self.options_
+
+    def Config(self):
+        return self.config_
+
+    def Solve(self) -> BundleAdjustmentSummary:
+        fp = self.problem_
+        if len(fp.obs_pose) == 0:
+            return BundleAdjustmentSummary()  # zero residuals -> default summary (:667-669)
+        gpu = [int(x) for x in str(self.options_.gpu_index).split(",") if x.strip()]
+        summary = solve_flat(fp, self.options_.solver_options, gpu[0] if gpu else -1,
+                             solve_fn=self._solve_fn)
+        if summary.num_residuals == 0:
+            return BundleAdjustmentSummary()
+        # WriteResultsToReconstruction: only variable blocks (bundle_adjustment_caspar.cc:767-801)
+        rec = self.reconstruction_
+        for i, image_id in enumerate(fp.pose_ids):
+            if not fp.pose_const[i]:
+                rec.images[image_id].cam_from_world = fp.poses[i].copy()
+        for k, cid in enumerate(fp.cam_ids):
+            n = len(rec.cameras[cid].params)
+            if not fp.cam_const[k, :n].all():
+                rec.cameras[cid].params = fp.cams[k, :n].copy()
+        for j, pid in enumerate(fp.point_ids):
+            if not fp.point_const[j]:
+                rec.points3D[pid].xyz = fp.points[j].copy()
+        return summary
+
+
+def CreateDefaultBundleAdjuster(options: BundleAdjustmentOptions, config: BundleAdjustmentConfig,
+                                reconstruction: scene.Reconstruction) -> BundleAdjuster:
+    """colmap::CreateDefaultBundleAdjuster (bundle_adjustment.cc:314-334): backend switch."""
+    if options.backend != BundleAdjustmentBackend.MI355X:
+        raise ValueError(f"backend {options.backend!r} is not built here: only MI355X "
+                         "(the reference's CERES/CASPAR need Ceres/CUDA)")
+    return BundleAdjuster(options, config, reconstruction)

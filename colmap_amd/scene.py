@@ -1,0 +1,305 @@
+"""Minimal scene containers + the synthetic dataset generator the reference's BA tests and
+benchmarks are built on (no COLMAP database / rigs-with-offsets / descriptors).
+
+Restates the semantics of scene/synthetic.cc (SynthesizeDataset :339-672, SynthesizeNoise
+:674-770): 3-D points = normalised uniform [-1,1]^3 vectors on the unit sphere (:370-377);
+frames on a radius-5 sphere looking at the origin (:458-464), one reference camera per frame
+(trivial sensor_from_rig); default camera SIMPLE_RADIAL {1280, 512, 384, 0.05}, 1024x768
+(synthetic.h:54-57); dense visibility or tracks pruned to `track_length` (:648-668); noise on
+2-D points, 3-D points, rig translation and rotation about the rig z axis (:686-728).
+Random streams are numpy's, not the reference's PRNG: the tests that consume this use
+properties (counts, accuracy), not the raw numbers.
+"""
+from __future__ import annotations
+
+import copy
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+# colmap::CameraModelId (sensor/models.h:90-111)
+SIMPLE_PINHOLE, PINHOLE, SIMPLE_RADIAL = 0, 1, 2
+MODEL_NUM_PARAMS = {SIMPLE_PINHOLE: 3, PINHOLE: 4, SIMPLE_RADIAL: 4}
+# FocalLengthIdxs / PrincipalPointIdxs / ExtraParamsIdxs (sensor/models.h)
+MODEL_FOCAL_IDXS = {SIMPLE_PINHOLE: [0], PINHOLE: [0, 1], SIMPLE_RADIAL: [0]}
+MODEL_PP_IDXS = {SIMPLE_PINHOLE: [1, 2], PINHOLE: [2, 3], SIMPLE_RADIAL: [1, 2]}
+MODEL_EXTRA_IDXS = {SIMPLE_PINHOLE: [], PINHOLE: [], SIMPLE_RADIAL: [3]}
+
+
+@dataclass
+class Camera:
+    camera_id: int
+    model_id: int
+    width: int
+    height: int
+    params: np.ndarray  # float64
+
+
+@dataclass
+class Point2D:
+    xy: np.ndarray
+    point3D_id: int = -1
+
+    def HasPoint3D(self) -> bool:
+        return self.point3D_id >= 0
+
+
+@dataclass
+class Image:
+    """One image = one frame with a trivial rig (the image's camera is the reference sensor)."""
+    image_id: int
+    camera_id: int
+    cam_from_world: np.ndarray  # 7 doubles: qx qy qz qw tx ty tz (Rigid3d::params, geometry/rigid3.h:46-70)
+    points2D: List[Point2D] = field(default_factory=list)
+
+    @property
+    def frame_id(self) -> int:
+        return self.image_id
+
+
+@dataclass
+class Point3D:
+    xyz: np.ndarray
+    track: List[Tuple[int, int]] = field(default_factory=list)  # (image_id, point2D_idx)
+
+
+class Reconstruction:
+    def __init__(self):
+        self.cameras: Dict[int, Camera] = {}
+        self.images: Dict[int, Image] = {}
+        self.points3D: Dict[int, Point3D] = {}
+
+    def RegImageIds(self) -> List[int]:
+        return sorted(self.images)
+
+    def NumPoints3D(self) -> int:
+        return len(self.points3D)
+
+    def DeleteObservation(self, image_id: int, point2D_idx: int):
+        """Reconstruction::DeleteObservation: removes the track element; a track that drops to
+        length < 2 deletes the 3-D point (scene/reconstruction.cc)."""
+        p2 = self.images[image_id].points2D[point2D_idx]
+        pid = p2.point3D_id
+        pt = self.points3D[pid]
+        if len(pt.track) <= 2:
+            for (im, idx) in pt.track:
+                self.images[im].points2D[idx].point3D_id = -1
+            del self.points3D[pid]
+            return
+        pt.track.remove((image_id, point2D_idx))
+        p2.point3D_id = -1
+
+    def copy(self) -> "Reconstruction":
+        return copy.deepcopy(self)
+
+
+def quat_from_two_vectors(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """Eigen::Quaterniond::FromTwoVectors (xyzw)."""
+    a = a / np.linalg.norm(a)
+    b = b / np.linalg.norm(b)
+    c = float(a @ b)
+    if c < -1 + 1e-12:
+        axis = np.cross(a, [1.0, 0, 0])
+        if np.linalg.norm(axis) < 1e-6:
+            axis = np.cross(a, [0, 1.0, 0])
+        axis /= np.linalg.norm(axis)
+        return np.array([axis[0], axis[1], axis[2], 0.0])
+    axis = np.cross(a, b)
+    s = np.sqrt((1 + c) * 2)
+    return np.array([axis[0] / s, axis[1] / s, axis[2] / s, s / 2])
+
+
+def quat_to_rot(q: np.ndarray) -> np.ndarray:
+    x, y, z, w = q
+    return np.array([
+        [1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+        [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+        [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def quat_mul(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    ax, ay, az, aw = a
+    bx, by, bz, bw = b
+    return np.array([aw * bx + ax * bw + ay * bz - az * by,
+                     aw * by - ax * bz + ay * bw + az * bx,
+                     aw * bz + ax * by - ay * bx + az * bw,
+                     aw * bw - ax * bx - ay * by - az * bz])
+
+
+def img_from_cam(model_id: int, params: np.ndarray, uvw: np.ndarray) -> np.ndarray:
+    """CameraModel::ImgFromCam for the supported models (sensor/models.h:1231-1404); uvw (N,3)."""
+    uu = uvw[:, 0] / uvw[:, 2]
+    vv = uvw[:, 1] / uvw[:, 2]
+    if model_id == SIMPLE_PINHOLE:
+        f, c1, c2 = params
+        return np.stack([f * uu + c1, f * vv + c2], 1)
+    if model_id == PINHOLE:
+        f1, f2, c1, c2 = params
+        return np.stack([f1 * uu + c1, f2 * vv + c2], 1)
+    f, c1, c2, k = params
+    a = 1 + k * (uu * uu + vv * vv)
+    return np.stack([f * a * uu + c1, f * a * vv + c2], 1)
+
+
+@dataclass
+class SyntheticDatasetOptions:
+    num_rigs: int = 2
+    num_cameras_per_rig: int = 1
+    num_frames_per_rig: int = 5
+    num_points3D: int = 100
+    track_length: int = -1
+    camera_width: int = 1024
+    camera_height: int = 768
+    camera_model_id: int = SIMPLE_RADIAL
+    camera_params: Tuple[float, ...] = (1280.0, 512.0, 384.0, 0.05)
+    num_points2D_without_point3D: int = 10
+    # extension: alternate camera models per rig (BASELINE config 5 "mixed camera models")
+    mixed_models: bool = False
+
+
+@dataclass
+class SyntheticNoiseOptions:
+    rig_from_world_translation_stddev: float = 0.0
+    rig_from_world_rotation_stddev: float = 0.0
+    point3D_stddev: float = 0.0
+    point2D_stddev: float = 0.0
+
+
+def SynthesizeDataset(options: SyntheticDatasetOptions, seed: int = 0) -> Reconstruction:
+    assert options.num_cameras_per_rig == 1, "non-trivial rigs are not part of this round's scope"
+    assert options.track_length == -1 or options.track_length >= 2
+    rng = np.random.default_rng(seed)
+    rec = Reconstruction()
+    pts = rng.uniform(-1, 1, (options.num_points3D, 3))
+    pts /= np.linalg.norm(pts, axis=1, keepdims=True)
+    for i in range(options.num_points3D):
+        rec.points3D[i + 1] = Point3D(pts[i].copy())
+    image_id = 0
+    for rig_idx in range(options.num_rigs):
+        cam_id = rig_idx + 1
+        model, params = options.camera_model_id, np.array(options.camera_params, np.float64)
+        if options.mixed_models and rig_idx % 2 == 1:
+            model = PINHOLE
+            params = np.array([options.camera_params[0], options.camera_params[0],
+                               options.camera_params[1], options.camera_params[2]], np.float64)
+        rec.cameras[cam_id] = Camera(cam_id, model, options.camera_width, options.camera_height, params)
+        for _ in range(options.num_frames_per_rig):
+            image_id += 1
+            v = rng.uniform(-1, 1, 3)
+            view_dir = -v / np.linalg.norm(v)
+            proj_center = -5.0 * view_dir
+            q = quat_from_two_vectors(view_dir, np.array([0.0, 0.0, 1.0]))
+            t = quat_to_rot(q) @ (-proj_center)
+            img = Image(image_id, cam_id, np.concatenate([q, t]))
+            uvw = pts @ quat_to_rot(q).T + t
+            xy = img_from_cam(model, params, uvw)
+            vis = (xy[:, 0] >= 0) & (xy[:, 1] >= 0) & (xy[:, 0] <= options.camera_width) & \
+                  (xy[:, 1] <= options.camera_height)
+            p2 = [Point2D(xy[i].copy(), i + 1) for i in np.nonzero(vis)[0]]
+            for _ in range(options.num_points2D_without_point3D):
+                p2.append(Point2D(np.array([rng.uniform(0, options.camera_width),
+                                            rng.uniform(0, options.camera_height)])))
+            order = rng.permutation(len(p2))
+            img.points2D = [p2[i] for i in order]
+            for idx, p in enumerate(img.points2D):
+                if p.HasPoint3D():
+                    rec.points3D[p.point3D_id].track.append((image_id, idx))
+            rec.images[image_id] = img
+    if options.track_length > 0:
+        for pid in list(rec.points3D):
+            tr = rec.points3D[pid].track
+            if len(tr) <= options.track_length:
+                continue
+            order = rng.permutation(len(tr))
+            for k in order[: len(tr) - options.track_length]:
+                im, idx = tr[k]
+                rec.images[im].points2D[idx].point3D_id = -1
+            keep = sorted(order[len(tr) - options.track_length:])
+            rec.points3D[pid].track = [tr[k] for k in keep]
+    return rec
+
+
+def SynthesizeNoise(options: SyntheticNoiseOptions, rec: Reconstruction, seed: int = 1):
+    rng = np.random.default_rng(seed)
+    for image_id in rec.RegImageIds():
+        img = rec.images[image_id]
+        if options.rig_from_world_rotation_stddev > 0:
+            ang = np.deg2rad(np.clip(rng.normal(0, options.rig_from_world_rotation_stddev), -180, 180))
+            dq = np.array([0, 0, np.sin(ang / 2), np.cos(ang / 2)])
+            img.cam_from_world[:4] = quat_mul(img.cam_from_world[:4], dq)
+        if options.rig_from_world_translation_stddev > 0:
+            img.cam_from_world[4:] += rng.normal(0, options.rig_from_world_translation_stddev, 3)
+    if options.point2D_stddev > 0:
+        for image_id in sorted(rec.images):
+            for p in rec.images[image_id].points2D:
+                p.xy = p.xy + rng.normal(0, options.point2D_stddev, 2)
+    if options.point3D_stddev > 0:
+        for pid in sorted(rec.points3D):
+            rec.points3D[pid].xyz = rec.points3D[pid].xyz + rng.normal(0, options.point3D_stddev, 3)
+
+
+def synthesize_flat(num_frames: int, num_points: int, track_length: int, seed: int = 42,
+                    mixed_models: bool = False, noise: Optional[SyntheticNoiseOptions] = None):
+    """Vectorised generator for the large bench configs (1000 frames x 200k points would take
+    minutes through the object model): returns flat arrays directly, same distributions as
+    SynthesizeDataset/SynthesizeNoise with one camera per frame (num_rigs = num_frames)."""
+    rng = np.random.default_rng(seed)
+    pts = rng.uniform(-1, 1, (num_points, 3))
+    pts /= np.linalg.norm(pts, axis=1, keepdims=True)
+    v = rng.uniform(-1, 1, (num_frames, 3))
+    view = -v / np.linalg.norm(v, axis=1, keepdims=True)
+    poses = np.zeros((num_frames, 7))
+    Rs = np.zeros((num_frames, 3, 3))
+    for i in range(num_frames):
+        q = quat_from_two_vectors(view[i], np.array([0.0, 0.0, 1.0]))
+        Rs[i] = quat_to_rot(q)
+        poses[i, :4] = q
+        poses[i, 4:] = Rs[i] @ (5.0 * view[i])
+    cams = np.zeros((num_frames, 12))
+    model = np.full(num_frames, SIMPLE_RADIAL, np.int32)
+    cams[:, :4] = [1280.0, 512.0, 384.0, 0.05]
+    if mixed_models:
+        model[1::2] = PINHOLE
+        cams[1::2, :4] = [1280.0, 1280.0, 512.0, 384.0]
+    # every frame sees every point (all points project inside 1024x768 from radius 5); each
+    # track = `track_length` distinct random frames (the reference shuffles and deletes, :662-668)
+    obs_pose = rng.integers(0, num_frames, (num_points, track_length))
+    obs_pose.sort(axis=1)
+    for _ in range(64):
+        dup = np.zeros_like(obs_pose, bool)
+        dup[:, 1:] = obs_pose[:, 1:] == obs_pose[:, :-1]
+        if not dup.any():
+            break
+        obs_pose[dup] = rng.integers(0, num_frames, int(dup.sum()))
+        obs_pose.sort(axis=1)
+    obs_point = np.repeat(np.arange(num_points), track_length)
+    obs_pose = obs_pose.reshape(-1)
+    uvw = np.einsum("nij,nj->ni", Rs[obs_pose], pts[obs_point]) + poses[obs_pose, 4:]
+    xy = np.zeros((len(obs_pose), 2))
+    for m in (SIMPLE_RADIAL, PINHOLE):
+        sel = model[obs_pose] == m
+        if sel.any():
+            # per-observation params
+            pr = cams[obs_pose[sel]]
+            uu = uvw[sel, 0] / uvw[sel, 2]
+            vv = uvw[sel, 1] / uvw[sel, 2]
+            if m == SIMPLE_RADIAL:
+                a = 1 + pr[:, 3] * (uu * uu + vv * vv)
+                xy[sel] = np.stack([pr[:, 0] * a * uu + pr[:, 1], pr[:, 0] * a * vv + pr[:, 2]], 1)
+            else:
+                xy[sel] = np.stack([pr[:, 0] * uu + pr[:, 2], pr[:, 1] * vv + pr[:, 3]], 1)
+    if noise is not None:
+        if noise.rig_from_world_rotation_stddev > 0:
+            ang = np.deg2rad(np.clip(rng.normal(0, noise.rig_from_world_rotation_stddev, num_frames), -180, 180))
+            for i in range(num_frames):
+                poses[i, :4] = quat_mul(poses[i, :4], np.array([0, 0, np.sin(ang[i] / 2), np.cos(ang[i] / 2)]))
+        if noise.rig_from_world_translation_stddev > 0:
+            poses[:, 4:] += rng.normal(0, noise.rig_from_world_translation_stddev, (num_frames, 3))
+        if noise.point2D_stddev > 0:
+            xy += rng.normal(0, noise.point2D_stddev, xy.shape)
+        if noise.point3D_stddev > 0:
+            pts = pts + rng.normal(0, noise.point3D_stddev, pts.shape)
+    return dict(poses=poses, cams=cams, cam_model=model, points=pts,
+                obs_pose=obs_pose.astype(np.int32), obs_cam=obs_pose.astype(np.int32),
+                obs_point=obs_point.astype(np.int32), obs_xy=xy)

@@ -1,0 +1,973 @@
+/*
+ * ba_oracle.c -- CPU restatement (fp64) of COLMAP's bundle-adjustment solve.
+ *
+ * THIS FILE IS TEST INFRASTRUCTURE: the checker the HIP path is compared against
+ * (tests/, __graft_entry__.smoke(), bench.py's cpu_baseline leg). The product
+ * (colmap_amd/) never includes, links or calls it.
+ *
+ * Two layers, two pinning levels:
+ *  (1) COLMAP-side arithmetic -- reprojection residual + analytic Jacobians -- follows the
+ *      in-tree sources line by line and IS pinned by the reference's own tests
+ *      (tests/test_ba_oracle.py restates reprojection_error_test.cc:41-72 and checks the
+ *      Jacobians against finite differences like :211-325):
+ *        estimators/cost_functions/reprojection_error.h:61-138   (residual, J layout)
+ *        estimators/cost_functions/quaternion_utils.h:105-153    (R(q) p and d/dq)
+ *        sensor/models_jacobian.h:139-321                        (SIMPLE_PINHOLE, PINHOLE, SIMPLE_RADIAL)
+ *        sensor/models.h:281-285                                 (HasProjectableDepth)
+ *  (2) The Levenberg-Marquardt / Schur / PCG arithmetic lives in ceres-solver, a
+ *      third-party dependency that is NOT vendored in /root/reference (find_package(Ceres),
+ *      cmake/FindDependencies.cmake:108-116; unpinned version, vcpkg.json:15-22). It is
+ *      restated here from Ceres' published algorithm (trust_region_minimizer.cc,
+ *      levenberg_marquardt_strategy.cc, implicit_schur_complement.cc,
+ *      conjugate_gradients_solver.cc, schur_jacobi_preconditioner.cc) with the options
+ *      COLMAP sets at its call sites (bundle_adjustment_ceres.cc:102-115,122-232):
+ *      **iteration-trajectory parity with Ceres is unpinned**; the final solution is
+ *      pinned against scipy.optimize.least_squares and the reference tests' expectations
+ *      (residual counts 594 / 80, constant blocks untouched, 0.1 deg / 0.1 accuracy).
+ *
+ * Build: oracle/Makefile.
+ */
+#include <math.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define BAO_API __attribute__((visibility("default")))
+#define BAO_CAM_STRIDE 12
+
+/* COLMAP CameraModelId values (sensor/models.h:90-111) */
+enum { BAO_SIMPLE_PINHOLE = 0, BAO_PINHOLE = 1, BAO_SIMPLE_RADIAL = 2 };
+
+typedef struct {
+  int32_t num_poses, num_cams, num_points;
+  int64_t num_obs;
+  double* poses;       /* [num_poses][7] qx qy qz qw tx ty tz (Rigid3d::params) */
+  double* cams;        /* [num_cams][12] */
+  int32_t* cam_model;  /* [num_cams] */
+  double* points;      /* [num_points][3] */
+  int32_t* obs_pose;   /* [num_obs] */
+  int32_t* obs_cam;
+  int32_t* obs_point;
+  double* obs_xy;      /* [num_obs][2] */
+  uint8_t* pose_const;    /* [num_poses] 1: SetParameterBlockConstant */
+  int8_t* pose_fixed_t;   /* [num_poses] -1 or translation coordinate held by the gauge */
+  uint8_t* cam_const;     /* [num_cams][12] per-parameter constant mask (SubsetManifold) */
+  uint8_t* point_const;   /* [num_points] */
+} bao_problem;
+
+typedef struct {
+  int32_t max_num_iterations;
+  int32_t max_linear_solver_iterations;
+  double function_tolerance, gradient_tolerance, parameter_tolerance;
+  double initial_trust_region_radius, max_trust_region_radius, min_trust_region_radius;
+  double min_relative_decrease, min_lm_diagonal, max_lm_diagonal, eta;
+  int32_t max_num_consecutive_invalid_steps;
+  int32_t jacobi_scaling;
+  int32_t num_threads;
+  int32_t max_log; /* capacity of the per-iteration log arrays in bao_result */
+} bao_options;
+
+/* BundleAdjustmentTerminationType (estimators/bundle_adjustment.h:50-57) */
+enum { BAO_CONVERGENCE = 0, BAO_NO_CONVERGENCE = 1, BAO_FAILURE = 2 };
+
+typedef struct {
+  int32_t termination_type;
+  int32_t num_residuals; /* residuals touching >= 1 variable block */
+  int32_t num_iterations, num_successful_steps;
+  int32_t num_effective_parameters;
+  int64_t total_linear_iterations;
+  double initial_cost, final_cost;
+  double lm_seconds; /* time inside the LM loop (linearise + solve + evaluate) */
+  int32_t num_logged;
+  double* log_cost;      /* [max_log] cost after each iteration */
+  double* log_radius;
+  int32_t* log_linear_iters;
+} bao_result;
+
+/* ------------------------------------------------------------------------- */
+/* Per-residual math                                                          */
+/* ------------------------------------------------------------------------- */
+
+/* QuaternionRotatePointWithJac, quaternion_utils.h:105-153 */
+static void quat_rotate_jac(const double* q, const double* pt, double out[3], double* J) {
+  const double qx = q[0], qy = q[1], qz = q[2], qw = q[3];
+  const double px = pt[0], py = pt[1], pz = pt[2];
+  const double qx_py = qx * py, qx_pz = qx * pz;
+  const double qy_px = qy * px, qy_pz = qy * pz;
+  const double qz_px = qz * px, qz_py = qz * py;
+  const double v_x_p0 = qy_pz - qz_py;
+  const double v_x_p1 = qz_px - qx_pz;
+  const double v_x_p2 = qx_py - qy_px;
+  const double vv0 = qy * v_x_p2 - qz * v_x_p1;
+  const double vv1 = qz * v_x_p0 - qx * v_x_p2;
+  const double vv2 = qx * v_x_p1 - qy * v_x_p0;
+  out[0] = px + 2.0 * (qw * v_x_p0 + vv0);
+  out[1] = py + 2.0 * (qw * v_x_p1 + vv1);
+  out[2] = pz + 2.0 * (qw * v_x_p2 + vv2);
+  if (J) {
+    const double qx_px = qx * px, qy_py = qy * py, qz_pz = qz * pz;
+    const double qw_px = qw * px, qw_py = qw * py, qw_pz = qw * pz;
+    J[0] = 2.0 * (qy_py + qz_pz);
+    J[1] = 2.0 * (-2.0 * qy_px + qx_py + qw_pz);
+    J[2] = 2.0 * (-2.0 * qz_px - qw_py + qx_pz);
+    J[3] = 2.0 * (-qz_py + qy_pz);
+    J[4] = 2.0 * (qy_px - 2.0 * qx_py - qw_pz);
+    J[5] = 2.0 * (qx_px + qz_pz);
+    J[6] = 2.0 * (qw_px - 2.0 * qz_py + qy_pz);
+    J[7] = 2.0 * (qz_px - qx_pz);
+    J[8] = 2.0 * (qz_px + qw_py - 2.0 * qx_pz);
+    J[9] = 2.0 * (-qw_px + qz_py - 2.0 * qy_pz);
+    J[10] = 2.0 * (qx_px + qy_py);
+    J[11] = 2.0 * (-qy_px + qx_py);
+  }
+}
+
+/* Eigen::Quaterniond::toRotationMatrix for xyzw storage */
+static void quat_to_rot(const double* q, double R[9]) {
+  const double x = q[0], y = q[1], z = q[2], w = q[3];
+  const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+  const double twx = tx * w, twy = ty * w, twz = tz * w;
+  const double txx = tx * x, txy = ty * x, txz = tz * x;
+  const double tyy = ty * y, tyz = tz * y, tzz = tz * z;
+  R[0] = 1 - (tyy + tzz); R[1] = txy - twz;       R[2] = txz + twy;
+  R[3] = txy + twz;       R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+  R[6] = txz - twy;       R[7] = tyz + twx;       R[8] = 1 - (txx + tyy);
+}
+
+static int num_params_of(int model) {
+  switch (model) {
+    case BAO_SIMPLE_PINHOLE: return 3;
+    case BAO_PINHOLE: return 4;
+    case BAO_SIMPLE_RADIAL: return 4;
+    default: return -1;
+  }
+}
+
+/* ImgFromCamWithJac, sensor/models_jacobian.h:139-321. J_params row-major 2 x P. */
+static int img_from_cam_jac(int model, const double* params, double u, double v, double w,
+                            double* x, double* y, double* J_params, double* J_uvw) {
+  /* HasProjectableDepth (models.h:281-285), check_cheirality = true */
+  if (!(w >= 2.220446049250313e-16)) return 0;
+  const double inv_w = 1.0 / w;
+  const double uu = u * inv_w, vv = v * inv_w;
+  if (model == BAO_SIMPLE_PINHOLE) {
+    const double f = params[0], c1 = params[1], c2 = params[2];
+    *x = f * uu + c1;
+    *y = f * vv + c2;
+    if (J_uvw) {
+      const double f_inv_w = f * inv_w;
+      J_uvw[0] = f_inv_w; J_uvw[1] = 0.0; J_uvw[2] = -f_inv_w * uu;
+      J_uvw[3] = 0.0; J_uvw[4] = f_inv_w; J_uvw[5] = -f_inv_w * vv;
+    }
+    if (J_params) {
+      J_params[0] = uu; J_params[1] = 1.0; J_params[2] = 0.0;
+      J_params[3] = vv; J_params[4] = 0.0; J_params[5] = 1.0;
+    }
+    return 1;
+  }
+  if (model == BAO_PINHOLE) {
+    const double f1 = params[0], f2 = params[1], c1 = params[2], c2 = params[3];
+    *x = f1 * uu + c1;
+    *y = f2 * vv + c2;
+    if (J_uvw) {
+      J_uvw[0] = f1 * inv_w; J_uvw[1] = 0.0; J_uvw[2] = -f1 * inv_w * uu;
+      J_uvw[3] = 0.0; J_uvw[4] = f2 * inv_w; J_uvw[5] = -f2 * inv_w * vv;
+    }
+    if (J_params) {
+      J_params[0] = uu; J_params[1] = 0.0; J_params[2] = 1.0; J_params[3] = 0.0;
+      J_params[4] = 0.0; J_params[5] = vv; J_params[6] = 0.0; J_params[7] = 1.0;
+    }
+    return 1;
+  }
+  /* SIMPLE_RADIAL */
+  {
+    const double f = params[0], c1 = params[1], c2 = params[2], k = params[3];
+    const double uu2 = uu * uu, vv2 = vv * vv;
+    const double r2 = uu2 + vv2;
+    const double k_r2 = k * r2;
+    const double alpha = 1.0 + k_r2;
+    const double xd = alpha * uu, yd = alpha * vv;
+    *x = f * xd + c1;
+    *y = f * yd + c2;
+    if (J_uvw) {
+      const double two_k = 2.0 * k;
+      const double f_inv_w = f * inv_w;
+      const double beta = 1.0 + 3.0 * k_r2;
+      const double two_k_uu_vv = two_k * uu * vv;
+      J_uvw[0] = f_inv_w * (alpha + two_k * uu2);
+      J_uvw[1] = f_inv_w * two_k_uu_vv;
+      J_uvw[2] = -f_inv_w * uu * beta;
+      J_uvw[3] = f_inv_w * two_k_uu_vv;
+      J_uvw[4] = f_inv_w * (alpha + two_k * vv2);
+      J_uvw[5] = -f_inv_w * vv * beta;
+    }
+    if (J_params) {
+      J_params[0] = xd; J_params[1] = 1.0; J_params[2] = 0.0; J_params[3] = f * uu * r2;
+      J_params[4] = yd; J_params[5] = 0.0; J_params[6] = 1.0; J_params[7] = f * vv * r2;
+    }
+    return 1;
+  }
+}
+
+/* AnalyticalReprojErrorCostFunction::Evaluate, reprojection_error.h:68-134.
+ * J_point 2x3, J_pose 2x7 (quaternion xyzw then translation), J_params 2xP, row-major. */
+BAO_API int bao_reproj_error(int model, const double* point, const double* pose,
+                             const double* params, const double* xy, double* residuals,
+                             double* J_point, double* J_pose, double* J_params) {
+  double J_Rp_quat[12], J_uvw[6], pc[3];
+  const int P = num_params_of(model);
+  quat_rotate_jac(pose, point, pc, J_pose ? J_Rp_quat : NULL);
+  pc[0] += pose[4]; pc[1] += pose[5]; pc[2] += pose[6];
+  if (!img_from_cam_jac(model, params, pc[0], pc[1], pc[2], &residuals[0], &residuals[1],
+                        J_params, (J_point || J_pose) ? J_uvw : NULL)) {
+    residuals[0] = residuals[1] = 0.0;
+    if (J_pose) memset(J_pose, 0, sizeof(double) * 14);
+    if (J_point) memset(J_point, 0, sizeof(double) * 6);
+    if (J_params) memset(J_params, 0, sizeof(double) * 2 * P);
+    return 1;
+  }
+  residuals[0] -= xy[0];
+  residuals[1] -= xy[1];
+  if (J_point) {
+    double R[9];
+    quat_to_rot(pose, R);
+    for (int r = 0; r < 2; ++r)
+      for (int c = 0; c < 3; ++c)
+        J_point[3 * r + c] = J_uvw[3 * r] * R[c] + J_uvw[3 * r + 1] * R[3 + c] + J_uvw[3 * r + 2] * R[6 + c];
+  }
+  if (J_pose) {
+    for (int r = 0; r < 2; ++r) {
+      for (int c = 0; c < 4; ++c)
+        J_pose[7 * r + c] = J_uvw[3 * r] * J_Rp_quat[c] + J_uvw[3 * r + 1] * J_Rp_quat[4 + c] +
+                            J_uvw[3 * r + 2] * J_Rp_quat[8 + c];
+      for (int c = 0; c < 3; ++c) J_pose[7 * r + 4 + c] = J_uvw[3 * r + c];
+    }
+  }
+  return 1;
+}
+
+/* ceres::EigenQuaternionManifold (xyzw storage): x_plus = [sin|d|/|d| d, cos|d|] (*) x ;
+ * PlusJacobian at d = 0 (4x3 row-major) = [[w, z,-y],[-z, w, x],[y,-x, w],[-x,-y,-z]]. */
+BAO_API void bao_quat_plus(const double* q, const double* d, double* out) {
+  const double n = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+  if (n == 0.0) { memcpy(out, q, 32); return; }
+  const double s = sin(n) / n;
+  const double dx = s * d[0], dy = s * d[1], dz = s * d[2], dw = cos(n);
+  const double x = q[0], y = q[1], z = q[2], w = q[3];
+  /* Hamilton product dq * q */
+  out[0] = dw * x + dx * w + dy * z - dz * y;
+  out[1] = dw * y - dx * z + dy * w + dz * x;
+  out[2] = dw * z + dx * y - dy * x + dz * w;
+  out[3] = dw * w - dx * x - dy * y - dz * z;
+}
+
+static void quat_plus_jac(const double* q, double J[12]) {
+  const double x = q[0], y = q[1], z = q[2], w = q[3];
+  J[0] = w;  J[1] = z;  J[2] = -y;
+  J[3] = -z; J[4] = w;  J[5] = x;
+  J[6] = y;  J[7] = -x; J[8] = w;
+  J[9] = -x; J[10] = -y; J[11] = -z;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Program: tangent-space layout of the variable blocks                        */
+/* ------------------------------------------------------------------------- */
+
+#define MAX_CB 8 /* max tangent width of a camera-side block seen by one residual: 6 + P_t */
+
+typedef struct {
+  const bao_problem* p;
+  int64_t n_obs;       /* active observations */
+  int64_t* obs;        /* indices into the problem's observation arrays */
+  int* pose_off;       /* [num_poses] offset into the camera-side vector, -1 const */
+  int* pose_dim;       /* 0, 5 or 6 */
+  int* cam_off;        /* [num_cams] */
+  int* cam_dim;
+  int* cam_var;        /* [num_cams][12] indices of variable params */
+  int* point_off;      /* [num_points] offset into point-side vector (3 each), -1 const */
+  int n_c, n_p;        /* sizes of camera-side / point-side tangent vectors */
+  /* CSR by point and by pose/cam of active observation slots */
+  int64_t *pt_ptr, *pt_idx;
+} program;
+
+static void program_free(program* g) {
+  free(g->obs); free(g->pose_off); free(g->pose_dim); free(g->cam_off); free(g->cam_dim);
+  free(g->cam_var); free(g->point_off); free(g->pt_ptr); free(g->pt_idx);
+}
+
+static void program_build(program* g, const bao_problem* p) {
+  memset(g, 0, sizeof(*g));
+  g->p = p;
+  g->pose_off = (int*)malloc(sizeof(int) * (p->num_poses + 1));
+  g->pose_dim = (int*)calloc(p->num_poses + 1, sizeof(int));
+  g->cam_off = (int*)malloc(sizeof(int) * (p->num_cams + 1));
+  g->cam_dim = (int*)calloc(p->num_cams + 1, sizeof(int));
+  g->cam_var = (int*)calloc((size_t)(p->num_cams + 1) * BAO_CAM_STRIDE, sizeof(int));
+  g->point_off = (int*)malloc(sizeof(int) * (p->num_points + 1));
+  /* which blocks are referenced by an observation that has >= 1 variable block */
+  uint8_t* pose_used = (uint8_t*)calloc(p->num_poses + 1, 1);
+  uint8_t* cam_used = (uint8_t*)calloc(p->num_cams + 1, 1);
+  uint8_t* point_used = (uint8_t*)calloc(p->num_points + 1, 1);
+  int* cam_nvar = (int*)calloc(p->num_cams + 1, sizeof(int));
+  for (int k = 0; k < p->num_cams; ++k) {
+    const int P = num_params_of(p->cam_model[k]);
+    for (int j = 0; j < P; ++j)
+      if (!p->cam_const[(size_t)k * BAO_CAM_STRIDE + j]) cam_nvar[k]++;
+  }
+  g->obs = (int64_t*)malloc(sizeof(int64_t) * (p->num_obs + 1));
+  for (int64_t o = 0; o < p->num_obs; ++o) {
+    const int pi = p->obs_pose[o], ci = p->obs_cam[o], xi = p->obs_point[o];
+    const int var = (!p->pose_const[pi]) || cam_nvar[ci] > 0 || (!p->point_const[xi]);
+    if (!var) continue; /* all blocks constant: not part of the reduced program */
+    g->obs[g->n_obs++] = o;
+    pose_used[pi] = cam_used[ci] = point_used[xi] = 1;
+  }
+  int off = 0;
+  for (int i = 0; i < p->num_poses; ++i) {
+    if (p->pose_const[i] || !pose_used[i]) { g->pose_off[i] = -1; g->pose_dim[i] = 0; continue; }
+    g->pose_dim[i] = p->pose_fixed_t[i] >= 0 ? 5 : 6;
+    g->pose_off[i] = off;
+    off += g->pose_dim[i];
+  }
+  for (int k = 0; k < p->num_cams; ++k) {
+    if (cam_nvar[k] == 0 || !cam_used[k]) { g->cam_off[k] = -1; g->cam_dim[k] = 0; continue; }
+    const int P = num_params_of(p->cam_model[k]);
+    int d = 0;
+    for (int j = 0; j < P; ++j)
+      if (!p->cam_const[(size_t)k * BAO_CAM_STRIDE + j]) g->cam_var[(size_t)k * BAO_CAM_STRIDE + d++] = j;
+    g->cam_dim[k] = d;
+    g->cam_off[k] = off;
+    off += d;
+  }
+  g->n_c = off;
+  int poff = 0;
+  for (int j = 0; j < p->num_points; ++j) {
+    if (p->point_const[j] || !point_used[j]) { g->point_off[j] = -1; continue; }
+    g->point_off[j] = poff;
+    poff += 3;
+  }
+  g->n_p = poff;
+  /* CSR of active observations by point */
+  g->pt_ptr = (int64_t*)calloc((size_t)p->num_points + 2, sizeof(int64_t));
+  g->pt_idx = (int64_t*)malloc(sizeof(int64_t) * (g->n_obs + 1));
+  for (int64_t a = 0; a < g->n_obs; ++a) g->pt_ptr[p->obs_point[g->obs[a]] + 1]++;
+  for (int j = 0; j < p->num_points; ++j) g->pt_ptr[j + 1] += g->pt_ptr[j];
+  int64_t* fill = (int64_t*)calloc((size_t)p->num_points + 1, sizeof(int64_t));
+  for (int64_t a = 0; a < g->n_obs; ++a) {
+    const int j = p->obs_point[g->obs[a]];
+    g->pt_idx[g->pt_ptr[j] + fill[j]++] = a;
+  }
+  free(fill); free(pose_used); free(cam_used); free(point_used); free(cam_nvar);
+}
+
+/* per-active-observation linearisation in the tangent space */
+typedef struct {
+  double r[2];
+  double Jc[2][MAX_CB]; /* pose tangent columns then intrinsics tangent columns */
+  double Jp[2][3];
+  int pose_dim, cam_dim; /* widths inside Jc */
+} lin_obs;
+
+static void linearize_obs(const program* g, const double* poses, const double* cams,
+                          const double* points, int64_t a, lin_obs* L, int want_jac) {
+  const bao_problem* p = g->p;
+  const int64_t o = g->obs[a];
+  const int pi = p->obs_pose[o], ci = p->obs_cam[o], xi = p->obs_point[o];
+  const int model = p->cam_model[ci];
+  double Jpt[6], Jpose[14], Jpar[24];
+  bao_reproj_error(model, points + 3 * (size_t)xi, poses + 7 * (size_t)pi,
+                   cams + (size_t)ci * BAO_CAM_STRIDE, p->obs_xy + 2 * o, L->r,
+                   want_jac ? Jpt : NULL, want_jac ? Jpose : NULL, want_jac ? Jpar : NULL);
+  L->pose_dim = g->pose_dim[pi];
+  L->cam_dim = g->cam_dim[ci];
+  if (!want_jac) return;
+  memset(L->Jc, 0, sizeof(L->Jc));
+  memset(L->Jp, 0, sizeof(L->Jp));
+  if (L->pose_dim > 0) {
+    double PJ[12];
+    quat_plus_jac(poses + 7 * (size_t)pi, PJ);
+    const int fixed = p->pose_fixed_t[pi];
+    for (int r = 0; r < 2; ++r) {
+      for (int c = 0; c < 3; ++c)
+        L->Jc[r][c] = Jpose[7 * r + 0] * PJ[c] + Jpose[7 * r + 1] * PJ[3 + c] +
+                      Jpose[7 * r + 2] * PJ[6 + c] + Jpose[7 * r + 3] * PJ[9 + c];
+      int d = 3;
+      for (int c = 0; c < 3; ++c) {
+        if (c == fixed) continue;
+        L->Jc[r][d++] = Jpose[7 * r + 4 + c];
+      }
+    }
+  }
+  if (L->cam_dim > 0) {
+    const int P = num_params_of(model);
+    for (int r = 0; r < 2; ++r)
+      for (int d = 0; d < L->cam_dim; ++d)
+        L->Jc[r][L->pose_dim + d] = Jpar[P * r + g->cam_var[(size_t)ci * BAO_CAM_STRIDE + d]];
+  }
+  if (g->point_off[xi] >= 0)
+    for (int r = 0; r < 2; ++r)
+      for (int c = 0; c < 3; ++c) L->Jp[r][c] = Jpt[3 * r + c];
+}
+
+static double evaluate_cost(const program* g, const double* poses, const double* cams,
+                            const double* points) {
+  double cost = 0.0;
+#pragma omp parallel for reduction(+ : cost) schedule(static)
+  for (int64_t a = 0; a < g->n_obs; ++a) {
+    lin_obs L;
+    linearize_obs(g, poses, cams, points, a, &L, 0);
+    cost += 0.5 * (L.r[0] * L.r[0] + L.r[1] * L.r[1]);
+  }
+  return cost;
+}
+
+/* x_plus = Plus(x, delta) for every variable block */
+static void apply_step(const program* g, const double* dc, const double* dp, const double* poses,
+                       const double* cams, const double* points, double* nposes, double* ncams,
+                       double* npoints) {
+  const bao_problem* p = g->p;
+  memcpy(nposes, poses, sizeof(double) * 7 * (size_t)p->num_poses);
+  memcpy(ncams, cams, sizeof(double) * BAO_CAM_STRIDE * (size_t)p->num_cams);
+  memcpy(npoints, points, sizeof(double) * 3 * (size_t)p->num_points);
+  for (int i = 0; i < p->num_poses; ++i) {
+    if (g->pose_off[i] < 0) continue;
+    const double* d = dc + g->pose_off[i];
+    bao_quat_plus(poses + 7 * (size_t)i, d, nposes + 7 * (size_t)i);
+    int k = 3;
+    for (int c = 0; c < 3; ++c) {
+      if (c == p->pose_fixed_t[i]) continue;
+      nposes[7 * (size_t)i + 4 + c] += d[k++];
+    }
+  }
+  for (int k = 0; k < p->num_cams; ++k) {
+    if (g->cam_off[k] < 0) continue;
+    for (int d = 0; d < g->cam_dim[k]; ++d)
+      ncams[(size_t)k * BAO_CAM_STRIDE + g->cam_var[(size_t)k * BAO_CAM_STRIDE + d]] += dc[g->cam_off[k] + d];
+  }
+  for (int j = 0; j < p->num_points; ++j) {
+    if (g->point_off[j] < 0) continue;
+    for (int c = 0; c < 3; ++c) npoints[3 * (size_t)j + c] += dp[g->point_off[j] + c];
+  }
+}
+
+/* ------------------------------------------------------------------------- */
+/* Linear algebra on the block-sparse Jacobian                                 */
+/* ------------------------------------------------------------------------- */
+
+typedef struct {
+  const program* g;
+  lin_obs* L;         /* [n_obs] scaled Jacobian blocks and residuals */
+  double* Dc;         /* [n_c] LM diagonal (D, not D^2), camera side */
+  double* Dp;         /* [n_p] point side */
+  double* Cinv;       /* [num_points][9] inverse of (E^T E + Dp^2) blocks */
+  double* Minv;       /* block-Jacobi preconditioner: per camera-side block, dim x dim inverse, packed */
+  int* blk_off;       /* offset in the camera-side vector per block */
+  int* blk_dim;
+  int64_t* blk_moff;  /* offset into Minv */
+  int n_blk;
+} linsys;
+
+static int cam_offsets(const program* g, int64_t a, int* po, int* co) {
+  const bao_problem* p = g->p;
+  const int64_t o = g->obs[a];
+  *po = g->pose_off[p->obs_pose[o]];
+  *co = g->cam_off[p->obs_cam[o]];
+  return 0;
+}
+
+/* gather the camera-side entries a residual sees */
+static inline void gather_c(const program* g, const lin_obs* L, int po, int co, const double* x,
+                            double* xc) {
+  for (int d = 0; d < L->pose_dim; ++d) xc[d] = x[po + d];
+  for (int d = 0; d < L->cam_dim; ++d) xc[L->pose_dim + d] = x[co + d];
+}
+
+static void invert_sym(const double* A, int n, double* Ainv) {
+  /* Gauss-Jordan with partial pivoting on a small dense block */
+  double M[MAX_CB][2 * MAX_CB];
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j) { M[i][j] = A[i * n + j]; M[i][n + j] = (i == j); }
+  for (int c = 0; c < n; ++c) {
+    int piv = c;
+    for (int r = c + 1; r < n; ++r) if (fabs(M[r][c]) > fabs(M[piv][c])) piv = r;
+    if (piv != c) for (int j = 0; j < 2 * n; ++j) { double t = M[c][j]; M[c][j] = M[piv][j]; M[piv][j] = t; }
+    const double inv = 1.0 / M[c][c];
+    for (int j = 0; j < 2 * n; ++j) M[c][j] *= inv;
+    for (int r = 0; r < n; ++r) {
+      if (r == c) continue;
+      const double f = M[r][c];
+      if (f != 0.0) for (int j = 0; j < 2 * n; ++j) M[r][j] -= f * M[c][j];
+    }
+  }
+  for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) Ainv[i * n + j] = M[i][n + j];
+}
+
+/* y = S x = (B + Dc^2) x - E C^-1 E^T x   (implicit Schur complement) */
+static void schur_multiply(const linsys* s, const double* x, double* y, double* tmp_p) {
+  const program* g = s->g;
+  const bao_problem* p = g->p;
+  /* point pass: u_j = C_j^-1 E_j^T x */
+#pragma omp parallel for schedule(static)
+  for (int j = 0; j < p->num_points; ++j) {
+    if (g->point_off[j] < 0) continue;
+    double t[3] = {0, 0, 0};
+    for (int64_t k = g->pt_ptr[j]; k < g->pt_ptr[j + 1]; ++k) {
+      const int64_t a = g->pt_idx[k];
+      const lin_obs* L = &s->L[a];
+      int po, co;
+      cam_offsets(g, a, &po, &co);
+      double xc[MAX_CB];
+      gather_c(g, L, po, co, x, xc);
+      const int w = L->pose_dim + L->cam_dim;
+      for (int r = 0; r < 2; ++r) {
+        double jx = 0.0;
+        for (int d = 0; d < w; ++d) jx += L->Jc[r][d] * xc[d];
+        for (int c = 0; c < 3; ++c) t[c] += L->Jp[r][c] * jx;
+      }
+    }
+    const double* Ci = s->Cinv + 9 * (size_t)j;
+    double* u = tmp_p + g->point_off[j];
+    for (int r = 0; r < 3; ++r) u[r] = Ci[3 * r] * t[0] + Ci[3 * r + 1] * t[1] + Ci[3 * r + 2] * t[2];
+  }
+  /* camera pass: y = Dc^2 x + sum_obs Jc^T (Jc x - Jp u) */
+  for (int i = 0; i < g->n_c; ++i) y[i] = s->Dc[i] * s->Dc[i] * x[i];
+  for (int64_t a = 0; a < g->n_obs; ++a) {
+    const lin_obs* L = &s->L[a];
+    int po, co;
+    cam_offsets(g, a, &po, &co);
+    const int w = L->pose_dim + L->cam_dim;
+    if (w == 0) continue;
+    double xc[MAX_CB];
+    gather_c(g, L, po, co, x, xc);
+    const int xi = p->obs_point[g->obs[a]];
+    const double* u = g->point_off[xi] >= 0 ? tmp_p + g->point_off[xi] : NULL;
+    for (int r = 0; r < 2; ++r) {
+      double v = 0.0;
+      for (int d = 0; d < w; ++d) v += L->Jc[r][d] * xc[d];
+      if (u) v -= L->Jp[r][0] * u[0] + L->Jp[r][1] * u[1] + L->Jp[r][2] * u[2];
+      for (int d = 0; d < L->pose_dim; ++d) y[po + d] += L->Jc[r][d] * v;
+      for (int d = 0; d < L->cam_dim; ++d) y[co + d] += L->Jc[r][L->pose_dim + d] * v;
+    }
+  }
+}
+
+static void precond_apply(const linsys* s, const double* r, double* z) {
+  for (int b = 0; b < s->n_blk; ++b) {
+    const int n = s->blk_dim[b], off = s->blk_off[b];
+    const double* Mi = s->Minv + s->blk_moff[b];
+    for (int i = 0; i < n; ++i) {
+      double v = 0.0;
+      for (int j = 0; j < n; ++j) v += Mi[i * n + j] * r[off + j];
+      z[off + i] = v;
+    }
+  }
+}
+
+static double dot(const double* a, const double* b, int n) {
+  double s = 0.0;
+  for (int i = 0; i < n; ++i) s += a[i] * b[i];
+  return s;
+}
+
+/* Ceres ConjugateGradientsSolver (conjugate_gradients_solver.cc): preconditioned CG with the
+ * Q-decrease termination  zeta = k (Q_k - Q_{k-1}) / Q_k < q_tolerance  (r_tolerance unused). */
+static int pcg(const linsys* s, const double* b, double* x, int max_iter, double q_tol,
+               double* ws /* 5*n_c + n_p */) {
+  const int n = s->g->n_c;
+  double *r = ws, *z = ws + n, *pdir = ws + 2 * n, *q = ws + 3 * n, *tmp = ws + 4 * n;
+  double* tmp_p = ws + 5 * n;
+  memset(x, 0, sizeof(double) * n);
+  memcpy(r, b, sizeof(double) * n);
+  const double norm_b = sqrt(dot(b, b, n));
+  if (norm_b == 0.0) return 0;
+  double rho = 1.0, Q0 = -0.5 * dot(x, b, n); /* x = 0 */
+  int it = 0;
+  for (it = 1; it <= max_iter; ++it) {
+    precond_apply(s, r, z);
+    const double last_rho = rho;
+    rho = dot(r, z, n);
+    if (!(rho > 0.0) || !isfinite(rho)) break;
+    if (it == 1) memcpy(pdir, z, sizeof(double) * n);
+    else {
+      const double beta = rho / last_rho;
+      for (int i = 0; i < n; ++i) pdir[i] = z[i] + beta * pdir[i];
+    }
+    schur_multiply(s, pdir, q, tmp_p);
+    const double pq = dot(pdir, q, n);
+    if (!(pq > 0.0) || !isfinite(pq)) break;
+    const double alpha = rho / pq;
+    for (int i = 0; i < n; ++i) x[i] += alpha * pdir[i];
+    for (int i = 0; i < n; ++i) r[i] -= alpha * q[i];
+    /* Q = -0.5 x^T (b + r) */
+    for (int i = 0; i < n; ++i) tmp[i] = b[i] + r[i];
+    const double Q1 = -0.5 * dot(x, tmp, n);
+    const double zeta = it * (Q1 - Q0) / Q1;
+    if (zeta < q_tol) break;
+    Q0 = Q1;
+    if (sqrt(dot(r, r, n)) <= 1e-30 * norm_b) break;
+  }
+  return it > max_iter ? max_iter : it;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Levenberg-Marquardt (Ceres TrustRegionMinimizer + LevenbergMarquardtStrategy) */
+/* ------------------------------------------------------------------------- */
+
+BAO_API void bao_options_init(bao_options* o) {
+  /* COLMAP's CeresBundleAdjustmentOptions ctor (bundle_adjustment_ceres.cc:102-115) over
+   * Ceres Solver::Options defaults */
+  o->max_num_iterations = 100;
+  o->max_linear_solver_iterations = 200;
+  o->function_tolerance = 0.0;
+  o->gradient_tolerance = 1e-4;
+  o->parameter_tolerance = 0.0;
+  o->initial_trust_region_radius = 1e4;
+  o->max_trust_region_radius = 1e16;
+  o->min_trust_region_radius = 1e-32;
+  o->min_relative_decrease = 1e-3;
+  o->min_lm_diagonal = 1e-6;
+  o->max_lm_diagonal = 1e32;
+  o->eta = 1e-1;
+  o->max_num_consecutive_invalid_steps = 10;
+  o->jacobi_scaling = 1;
+  o->num_threads = 0;
+  o->max_log = 0;
+}
+
+static double now_s(void) {
+#ifdef _OPENMP
+  return omp_get_wtime();
+#else
+  return 0.0;
+#endif
+}
+
+BAO_API int bao_solve(bao_problem* p, const bao_options* opt, bao_result* res) {
+#ifdef _OPENMP
+  if (opt->num_threads > 0) omp_set_num_threads(opt->num_threads);
+#endif
+  program g;
+  program_build(&g, p);
+  memset(res, 0, offsetof(bao_result, log_cost));
+  res->num_residuals = (int32_t)(2 * g.n_obs);
+  res->num_effective_parameters = g.n_c + g.n_p;
+  res->termination_type = BAO_FAILURE;
+  if (g.n_obs == 0) { program_free(&g); return 0; }
+
+  const int nc = g.n_c, np = g.n_p;
+  linsys s;
+  memset(&s, 0, sizeof(s));
+  s.g = &g;
+  s.L = (lin_obs*)malloc(sizeof(lin_obs) * g.n_obs);
+  s.Dc = (double*)calloc(nc + 1, sizeof(double));
+  s.Dp = (double*)calloc(np + 1, sizeof(double));
+  s.Cinv = (double*)calloc((size_t)p->num_points * 9 + 1, sizeof(double));
+  /* camera-side blocks */
+  s.blk_off = (int*)malloc(sizeof(int) * (p->num_poses + p->num_cams + 1));
+  s.blk_dim = (int*)malloc(sizeof(int) * (p->num_poses + p->num_cams + 1));
+  s.blk_moff = (int64_t*)malloc(sizeof(int64_t) * (p->num_poses + p->num_cams + 1));
+  int64_t moff = 0;
+  for (int i = 0; i < p->num_poses; ++i)
+    if (g.pose_off[i] >= 0) { s.blk_off[s.n_blk] = g.pose_off[i]; s.blk_dim[s.n_blk] = g.pose_dim[i]; s.blk_moff[s.n_blk++] = moff; moff += g.pose_dim[i] * g.pose_dim[i]; }
+  for (int k = 0; k < p->num_cams; ++k)
+    if (g.cam_off[k] >= 0) { s.blk_off[s.n_blk] = g.cam_off[k]; s.blk_dim[s.n_blk] = g.cam_dim[k]; s.blk_moff[s.n_blk++] = moff; moff += g.cam_dim[k] * g.cam_dim[k]; }
+  s.Minv = (double*)calloc(moff + 1, sizeof(double));
+  int* blk_of = (int*)malloc(sizeof(int) * (nc + 1)); /* camera-side index -> block */
+  for (int b = 0; b < s.n_blk; ++b) for (int d = 0; d < s.blk_dim[b]; ++d) blk_of[s.blk_off[b] + d] = b;
+
+  double* scale_c = (double*)malloc(sizeof(double) * (nc + 1));
+  double* scale_p = (double*)malloc(sizeof(double) * (np + 1));
+  double* gc = (double*)malloc(sizeof(double) * (nc + 1));
+  double* gp = (double*)malloc(sizeof(double) * (np + 1));
+  double* diag_c = (double*)malloc(sizeof(double) * (nc + 1));
+  double* diag_p = (double*)malloc(sizeof(double) * (np + 1));
+  double* rhs = (double*)malloc(sizeof(double) * (nc + 1));
+  double* dc = (double*)malloc(sizeof(double) * (nc + 1));
+  double* dp = (double*)malloc(sizeof(double) * (np + 1));
+  double* ws = (double*)malloc(sizeof(double) * ((size_t)5 * nc + np + 8));
+  double* Mblk = (double*)calloc(moff + 1, sizeof(double));
+  double* nposes = (double*)malloc(sizeof(double) * 7 * (size_t)p->num_poses + 8);
+  double* ncams = (double*)malloc(sizeof(double) * BAO_CAM_STRIDE * (size_t)p->num_cams + 8);
+  double* npoints = (double*)malloc(sizeof(double) * 3 * (size_t)p->num_points + 8);
+
+  double radius = opt->initial_trust_region_radius;
+  double decrease_factor = 2.0;
+  int invalid_steps = 0;
+  int need_linearize = 1;
+  int have_scale = 0;
+  double cost = 0.0;
+  const double t_start = now_s();
+
+  for (int iter = 0;; ++iter) {
+    if (need_linearize) {
+      /* residuals + Jacobians (Evaluate) */
+      double c = 0.0;
+#pragma omp parallel for reduction(+ : c) schedule(static)
+      for (int64_t a = 0; a < g.n_obs; ++a) {
+        linearize_obs(&g, p->poses, p->cams, p->points, a, &s.L[a], 1);
+        c += 0.5 * (s.L[a].r[0] * s.L[a].r[0] + s.L[a].r[1] * s.L[a].r[1]);
+      }
+      cost = c;
+      if (iter == 0) res->initial_cost = cost;
+      /* gradient (unscaled) g = J^T r, and column norms */
+      memset(gc, 0, sizeof(double) * nc); memset(gp, 0, sizeof(double) * np);
+      memset(diag_c, 0, sizeof(double) * nc); memset(diag_p, 0, sizeof(double) * np);
+      for (int64_t a = 0; a < g.n_obs; ++a) {
+        const lin_obs* L = &s.L[a];
+        int po, co; cam_offsets(&g, a, &po, &co);
+        const int xi = p->obs_point[g.obs[a]];
+        const int pto = g.point_off[xi];
+        for (int r = 0; r < 2; ++r) {
+          for (int d = 0; d < L->pose_dim; ++d) { gc[po + d] += L->Jc[r][d] * L->r[r]; diag_c[po + d] += L->Jc[r][d] * L->Jc[r][d]; }
+          for (int d = 0; d < L->cam_dim; ++d) { const double v = L->Jc[r][L->pose_dim + d]; gc[co + d] += v * L->r[r]; diag_c[co + d] += v * v; }
+          if (pto >= 0) for (int c2 = 0; c2 < 3; ++c2) { gp[pto + c2] += L->Jp[r][c2] * L->r[r]; diag_p[pto + c2] += L->Jp[r][c2] * L->Jp[r][c2]; }
+        }
+      }
+      /* convergence test on the projected gradient: ||x - Plus(x, -g)||_inf */
+      {
+        for (int i = 0; i < nc; ++i) dc[i] = -gc[i];
+        for (int i = 0; i < np; ++i) dp[i] = -gp[i];
+        apply_step(&g, dc, dp, p->poses, p->cams, p->points, nposes, ncams, npoints);
+        double gmax = 0.0;
+        for (size_t i = 0; i < 7 * (size_t)p->num_poses; ++i) gmax = fmax(gmax, fabs(nposes[i] - p->poses[i]));
+        for (size_t i = 0; i < BAO_CAM_STRIDE * (size_t)p->num_cams; ++i) gmax = fmax(gmax, fabs(ncams[i] - p->cams[i]));
+        for (size_t i = 0; i < 3 * (size_t)p->num_points; ++i) gmax = fmax(gmax, fabs(npoints[i] - p->points[i]));
+        if (gmax <= opt->gradient_tolerance) { res->termination_type = BAO_CONVERGENCE; res->num_iterations = iter; break; }
+      }
+      /* Jacobi scaling, computed once from the initial Jacobian: 1 / (1 + ||col||) */
+      if (!have_scale) {
+        for (int i = 0; i < nc; ++i) scale_c[i] = opt->jacobi_scaling ? 1.0 / (1.0 + sqrt(diag_c[i])) : 1.0;
+        for (int i = 0; i < np; ++i) scale_p[i] = opt->jacobi_scaling ? 1.0 / (1.0 + sqrt(diag_p[i])) : 1.0;
+        have_scale = 1;
+      }
+      /* scale the Jacobian columns in place */
+#pragma omp parallel for schedule(static)
+      for (int64_t a = 0; a < g.n_obs; ++a) {
+        lin_obs* L = &s.L[a];
+        int po, co; cam_offsets(&g, a, &po, &co);
+        const int pto = g.point_off[p->obs_point[g.obs[a]]];
+        for (int r = 0; r < 2; ++r) {
+          for (int d = 0; d < L->pose_dim; ++d) L->Jc[r][d] *= scale_c[po + d];
+          for (int d = 0; d < L->cam_dim; ++d) L->Jc[r][L->pose_dim + d] *= scale_c[co + d];
+          if (pto >= 0) for (int c2 = 0; c2 < 3; ++c2) L->Jp[r][c2] *= scale_p[pto + c2];
+        }
+      }
+      for (int i = 0; i < nc; ++i) { diag_c[i] *= scale_c[i] * scale_c[i]; gc[i] *= scale_c[i]; }
+      for (int i = 0; i < np; ++i) { diag_p[i] *= scale_p[i] * scale_p[i]; gp[i] *= scale_p[i]; }
+      need_linearize = 0;
+    }
+    if (iter >= opt->max_num_iterations) { res->termination_type = BAO_NO_CONVERGENCE; res->num_iterations = iter; break; }
+
+    /* LM diagonal D = sqrt(clamp(diag(J^T J)) / radius) */
+    for (int i = 0; i < nc; ++i) s.Dc[i] = sqrt(fmin(fmax(diag_c[i], opt->min_lm_diagonal), opt->max_lm_diagonal) / radius);
+    for (int i = 0; i < np; ++i) s.Dp[i] = sqrt(fmin(fmax(diag_p[i], opt->min_lm_diagonal), opt->max_lm_diagonal) / radius);
+
+    /* point blocks C_j = E_j^T E_j + Dp^2 and their inverses; camera blocks of B + Dc^2 */
+    memset(Mblk, 0, sizeof(double) * moff);
+#pragma omp parallel for schedule(static)
+    for (int j = 0; j < p->num_points; ++j) {
+      if (g.point_off[j] < 0) continue;
+      double C[9] = {0};
+      for (int64_t k = g.pt_ptr[j]; k < g.pt_ptr[j + 1]; ++k) {
+        const lin_obs* L = &s.L[g.pt_idx[k]];
+        for (int r = 0; r < 2; ++r)
+          for (int x = 0; x < 3; ++x)
+            for (int y = 0; y < 3; ++y) C[3 * x + y] += L->Jp[r][x] * L->Jp[r][y];
+      }
+      for (int x = 0; x < 3; ++x) C[4 * x] += s.Dp[g.point_off[j] + x] * s.Dp[g.point_off[j] + x];
+      invert_sym(C, 3, s.Cinv + 9 * (size_t)j);
+    }
+    /* SCHUR_JACOBI: block diagonal of S = B + Dc^2 - E C^-1 E^T, per camera-side block */
+    for (int64_t a = 0; a < g.n_obs; ++a) {
+      const lin_obs* L = &s.L[a];
+      int po, co; cam_offsets(&g, a, &po, &co);
+      for (int part = 0; part < 2; ++part) {
+        const int off = part == 0 ? po : co;
+        const int dim = part == 0 ? L->pose_dim : L->cam_dim;
+        const int base = part == 0 ? 0 : L->pose_dim;
+        if (dim == 0) continue;
+        double* M = Mblk + s.blk_moff[blk_of[off]];
+        for (int r = 0; r < 2; ++r)
+          for (int x = 0; x < dim; ++x)
+            for (int y = 0; y < dim; ++y) M[x * dim + y] += L->Jc[r][base + x] * L->Jc[r][base + y];
+      }
+    }
+    /* - sum_j (E_ij C_j^-1 E_ij'^T) restricted to the diagonal blocks: for each point, for each
+     * pair of its observations that share the same camera-side block */
+    for (int j = 0; j < p->num_points; ++j) {
+      if (g.point_off[j] < 0) continue;
+      const double* Ci = s.Cinv + 9 * (size_t)j;
+      for (int64_t k1 = g.pt_ptr[j]; k1 < g.pt_ptr[j + 1]; ++k1) {
+        const int64_t a1 = g.pt_idx[k1];
+        const lin_obs* L1 = &s.L[a1];
+        int po1, co1; cam_offsets(&g, a1, &po1, &co1);
+        for (int64_t k2 = g.pt_ptr[j]; k2 < g.pt_ptr[j + 1]; ++k2) {
+          const int64_t a2 = g.pt_idx[k2];
+          const lin_obs* L2 = &s.L[a2];
+          int po2, co2; cam_offsets(&g, a2, &po2, &co2);
+          for (int part = 0; part < 2; ++part) {
+            const int off1 = part == 0 ? po1 : co1, off2 = part == 0 ? po2 : co2;
+            if (off1 < 0 || off1 != off2) continue;
+            const int dim = part == 0 ? L1->pose_dim : L1->cam_dim;
+            const int b1 = part == 0 ? 0 : L1->pose_dim, b2 = part == 0 ? 0 : L2->pose_dim;
+            /* W1 = Jc1^T Jp1 (dim x 3), W2 likewise; M -= W1 Cinv W2^T */
+            double W1[MAX_CB][3], W2[MAX_CB][3];
+            for (int x = 0; x < dim; ++x)
+              for (int c = 0; c < 3; ++c) {
+                W1[x][c] = L1->Jc[0][b1 + x] * L1->Jp[0][c] + L1->Jc[1][b1 + x] * L1->Jp[1][c];
+                W2[x][c] = L2->Jc[0][b2 + x] * L2->Jp[0][c] + L2->Jc[1][b2 + x] * L2->Jp[1][c];
+              }
+            double* M = Mblk + s.blk_moff[blk_of[off1]];
+            for (int x = 0; x < dim; ++x) {
+              double t[3];
+              for (int c = 0; c < 3; ++c) t[c] = W1[x][0] * Ci[c] + W1[x][1] * Ci[3 + c] + W1[x][2] * Ci[6 + c];
+              for (int y = 0; y < dim; ++y) M[x * dim + y] -= t[0] * W2[y][0] + t[1] * W2[y][1] + t[2] * W2[y][2];
+            }
+          }
+        }
+      }
+    }
+    for (int b = 0; b < s.n_blk; ++b) {
+      const int n = s.blk_dim[b];
+      double* M = Mblk + s.blk_moff[b];
+      for (int d = 0; d < n; ++d) M[d * n + d] += s.Dc[s.blk_off[b] + d] * s.Dc[s.blk_off[b] + d];
+      invert_sym(M, n, s.Minv + s.blk_moff[b]);
+    }
+
+    /* reduced right-hand side: solve (J^T J + D^2) y = J^T r ; step = -y.
+     * rhs = g_c - E C^-1 g_p */
+    {
+      double* u = ws; /* C^-1 g_p per point */
+      for (int j = 0; j < p->num_points; ++j) {
+        if (g.point_off[j] < 0) continue;
+        const double* Ci = s.Cinv + 9 * (size_t)j;
+        const double* gj = gp + g.point_off[j];
+        for (int r = 0; r < 3; ++r) u[g.point_off[j] + r] = Ci[3 * r] * gj[0] + Ci[3 * r + 1] * gj[1] + Ci[3 * r + 2] * gj[2];
+      }
+      memcpy(rhs, gc, sizeof(double) * nc);
+      for (int64_t a = 0; a < g.n_obs; ++a) {
+        const lin_obs* L = &s.L[a];
+        int po, co; cam_offsets(&g, a, &po, &co);
+        const int pto = g.point_off[p->obs_point[g.obs[a]]];
+        if (pto < 0) continue;
+        for (int r = 0; r < 2; ++r) {
+          const double v = L->Jp[r][0] * u[pto] + L->Jp[r][1] * u[pto + 1] + L->Jp[r][2] * u[pto + 2];
+          for (int d = 0; d < L->pose_dim; ++d) rhs[po + d] -= L->Jc[r][d] * v;
+          for (int d = 0; d < L->cam_dim; ++d) rhs[co + d] -= L->Jc[r][L->pose_dim + d] * v;
+        }
+      }
+    }
+    int lin_iters = 0;
+    if (nc > 0) lin_iters = pcg(&s, rhs, dc, opt->max_linear_solver_iterations, opt->eta, ws);
+    res->total_linear_iterations += lin_iters;
+    /* back-substitution: y_p = C^-1 (g_p - E^T y_c) */
+    for (int j = 0; j < p->num_points; ++j) {
+      if (g.point_off[j] < 0) continue;
+      double t[3] = {gp[g.point_off[j]], gp[g.point_off[j] + 1], gp[g.point_off[j] + 2]};
+      for (int64_t k = g.pt_ptr[j]; k < g.pt_ptr[j + 1]; ++k) {
+        const int64_t a = g.pt_idx[k];
+        const lin_obs* L = &s.L[a];
+        int po, co; cam_offsets(&g, a, &po, &co);
+        double xc[MAX_CB];
+        gather_c(&g, L, po, co, dc, xc);
+        const int w = L->pose_dim + L->cam_dim;
+        for (int r = 0; r < 2; ++r) {
+          double jx = 0.0;
+          for (int d = 0; d < w; ++d) jx += L->Jc[r][d] * xc[d];
+          for (int c = 0; c < 3; ++c) t[c] -= L->Jp[r][c] * jx;
+        }
+      }
+      const double* Ci = s.Cinv + 9 * (size_t)j;
+      for (int r = 0; r < 3; ++r) dp[g.point_off[j] + r] = Ci[3 * r] * t[0] + Ci[3 * r + 1] * t[1] + Ci[3 * r + 2] * t[2];
+    }
+    /* step = -y ; model cost change = -(J step) . (r + J step / 2) */
+    for (int i = 0; i < nc; ++i) dc[i] = -dc[i];
+    for (int i = 0; i < np; ++i) dp[i] = -dp[i];
+    double model_change = 0.0;
+#pragma omp parallel for reduction(+ : model_change) schedule(static)
+    for (int64_t a = 0; a < g.n_obs; ++a) {
+      const lin_obs* L = &s.L[a];
+      int po, co; cam_offsets(&g, a, &po, &co);
+      const int pto = g.point_off[p->obs_point[g.obs[a]]];
+      double xc[MAX_CB];
+      gather_c(&g, L, po, co, dc, xc);
+      const int w = L->pose_dim + L->cam_dim;
+      for (int r = 0; r < 2; ++r) {
+        double m = 0.0;
+        for (int d = 0; d < w; ++d) m += L->Jc[r][d] * xc[d];
+        if (pto >= 0) m += L->Jp[r][0] * dp[pto] + L->Jp[r][1] * dp[pto + 1] + L->Jp[r][2] * dp[pto + 2];
+        model_change -= m * (L->r[r] + 0.5 * m);
+      }
+    }
+    int accepted = 0;
+    double new_cost = cost;
+    if (!(model_change > 0.0) || !isfinite(model_change)) {
+      if (++invalid_steps >= opt->max_num_consecutive_invalid_steps) { res->termination_type = BAO_FAILURE; res->num_iterations = iter + 1; break; }
+      radius /= decrease_factor; decrease_factor *= 2.0;
+    } else {
+      invalid_steps = 0;
+      /* undo the Jacobi scaling of the step, x_plus = Plus(x, step) */
+      for (int i = 0; i < nc; ++i) ws[i] = dc[i] * scale_c[i];
+      double* dps = ws + nc;
+      for (int i = 0; i < np; ++i) dps[i] = dp[i] * scale_p[i];
+      apply_step(&g, ws, dps, p->poses, p->cams, p->points, nposes, ncams, npoints);
+      new_cost = evaluate_cost(&g, nposes, ncams, npoints);
+      const double rho = (cost - new_cost) / model_change;
+      if (rho > opt->min_relative_decrease) {
+        accepted = 1;
+        memcpy(p->poses, nposes, sizeof(double) * 7 * (size_t)p->num_poses);
+        memcpy(p->cams, ncams, sizeof(double) * BAO_CAM_STRIDE * (size_t)p->num_cams);
+        memcpy(p->points, npoints, sizeof(double) * 3 * (size_t)p->num_points);
+        const double t = 2.0 * rho - 1.0;
+        radius = radius / fmax(1.0 / 3.0, 1.0 - t * t * t);
+        radius = fmin(opt->max_trust_region_radius, radius);
+        decrease_factor = 2.0;
+        res->num_successful_steps++;
+        need_linearize = 1;
+        const double change = fabs(cost - new_cost);
+        if (change <= opt->function_tolerance * cost && opt->function_tolerance > 0) {
+          cost = new_cost; res->termination_type = BAO_CONVERGENCE; res->num_iterations = iter + 1;
+          if (res->num_logged < opt->max_log) { res->log_cost[res->num_logged] = cost; res->log_radius[res->num_logged] = radius; res->log_linear_iters[res->num_logged++] = lin_iters; }
+          break;
+        }
+      } else {
+        radius /= decrease_factor; decrease_factor *= 2.0;
+      }
+    }
+    if (res->num_logged < opt->max_log) {
+      res->log_cost[res->num_logged] = accepted ? new_cost : cost;
+      res->log_radius[res->num_logged] = radius;
+      res->log_linear_iters[res->num_logged++] = lin_iters;
+    }
+    if (radius < opt->min_trust_region_radius) { res->termination_type = BAO_CONVERGENCE; res->num_iterations = iter + 1; break; }
+  }
+  res->final_cost = evaluate_cost(&g, p->poses, p->cams, p->points);
+  res->lm_seconds = now_s() - t_start;
+  /* quaternions are re-normalised when written back (bundle_adjustment_ceres.cc:491,508) */
+  for (int i = 0; i < p->num_poses; ++i) {
+    if (g.pose_off[i] < 0) continue;
+    double* q = p->poses + 7 * (size_t)i;
+    const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    for (int c = 0; c < 4; ++c) q[c] /= n;
+  }
+
+  free(s.L); free(s.Dc); free(s.Dp); free(s.Cinv); free(s.Minv); free(s.blk_off); free(s.blk_dim);
+  free(s.blk_moff); free(blk_of); free(scale_c); free(scale_p); free(gc); free(gp); free(diag_c);
+  free(diag_p); free(rhs); free(dc); free(dp); free(ws); free(Mblk); free(nposes); free(ncams);
+  free(npoints);
+  program_free(&g);
+  return 0;
+}
+
+BAO_API int bao_num_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}

@@ -1,0 +1,62 @@
+"""ctypes binding of oracle/libba_oracle.so (fp64 CPU restatement of the BA solve).
+
+TEST INFRASTRUCTURE ONLY (tests/, __graft_entry__.smoke(), bench.py cpu_baseline leg).
+The struct layouts are those of include/colmap_amd_ba.h, so the marshalled problem of
+colmap_amd.estimators can be handed to either library unchanged.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libba_oracle.so")
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    if force or not os.path.exists(_LIB_PATH) or (
+            os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "ba_oracle.c"))):
+        subprocess.check_call(["make", "-C", _HERE, "libba_oracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+        _lib.bao_solve.restype = C.c_int
+        _lib.bao_num_threads.restype = C.c_int
+    return _lib
+
+
+def solve_fn(p, o, r):
+    """Drop-in for colmap_amd.estimators.solve_flat(solve_fn=...)."""
+    return lib().bao_solve(p, o, r)
+
+
+def reproj_error(model, point, pose, params, xy, want_jac=True):
+    point = np.ascontiguousarray(point, np.float64)
+    pose = np.ascontiguousarray(pose, np.float64)
+    prm = np.zeros(12)
+    prm[: len(params)] = params
+    xy = np.ascontiguousarray(xy, np.float64)
+    P = {0: 3, 1: 4, 2: 4}[model]
+    r = np.zeros(2)
+    Jpt, Jpose, Jpar = np.zeros((2, 3)), np.zeros((2, 7)), np.zeros((2, P))
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    lib().bao_reproj_error(C.c_int(model), vp(point), vp(pose), vp(prm), vp(xy), vp(r),
+                           vp(Jpt) if want_jac else None, vp(Jpose) if want_jac else None,
+                           vp(Jpar) if want_jac else None)
+    return r, Jpt, Jpose, Jpar
+
+
+def quat_plus(q, d):
+    q = np.ascontiguousarray(q, np.float64)
+    d = np.ascontiguousarray(d, np.float64)
+    out = np.zeros(4)
+    lib().bao_quat_plus(q.ctypes.data_as(C.c_void_p), d.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+    return out
