@@ -39,6 +39,11 @@ def parse():
     ap.add_argument("--cols", type=int, default=0)
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ba", action="store_true", help="skip the secondary bundle-adjustment measurement")
+    ap.add_argument("--ba-frames", type=int, default=1000)
+    ap.add_argument("--ba-points", type=int, default=200000)
+    ap.add_argument("--ba-track", type=int, default=10)
+    ap.add_argument("--ba-iters", type=int, default=10)
     ap.add_argument("--cpu-crop", type=str, default="512x384")
     return ap.parse_args()
 
@@ -70,6 +75,54 @@ def cpu_baseline(views, ref, src, dmin, dmax, crop_wh):
                 kind="port",
                 sample=f"oracle/pm_oracle.c on a {cw}x{ch} centre crop of one {W}x{H} reference image, "
                        f"S={len(src)} full-resolution sources, 5x4 sweeps, {dt:.1f} s wall")
+
+
+def ba_secondary(a, local_rank, with_cpu):
+    """BASELINE.json config[3]: global BA, 1000 cameras x 200k points, SIMPLE_RADIAL, track length 10
+    (benchmark/runtime/bundle_adjustment.cc noise model), Schur-PCG on one MI355X: LM iterations per
+    second over the first `--ba-iters` iterations (linearise + Schur-Jacobi + PCG + step evaluation,
+    inputs resident in HBM), with the fp64 CPU oracle timed on the same problem."""
+    import ctypes as C
+    from colmap_amd import estimators as est, scene
+    from colmap_amd._lib import lib
+    d = scene.synthesize_flat(a.ba_frames, a.ba_points, a.ba_track, seed=42,
+                              noise=scene.SyntheticNoiseOptions(0.01, 1.0, 0.05, 1.0))
+    fp = est.FlatProblem.from_arrays(d)
+    est.fix_gauge_two_cams(fp)
+    so = est.SolverOptions(max_num_iterations=a.ba_iters)
+    est.solve_flat(fp.copy(), est.SolverOptions(max_num_iterations=2), gpu_index=local_rank)  # warm-up
+    g = fp.copy()
+    s = est.solve_flat(g, so, gpu_index=local_rank)
+    ms, n, _ = C.c_double(), C.c_int64(), C.c_int64()
+    lib().ba_last_spmv_timing(C.byref(ms), C.byref(n), C.byref(_))
+    n_obs = len(fp.obs_pose)
+    alg = 352 * n_obs  # 2 passes over the fp64 Jacobian rows: 2 x 2 x (6 + 2 + 3) x 8 B per observation
+    avg_ms = ms.value / max(n.value, 1)
+    out = {
+        "metric": "BA LM-iterations/s @1000 imgs",
+        "value": s.num_iterations / s.lm_seconds,
+        "unit": "LM-iterations/s",
+        "dtype": "f64",
+        "config": {"workload": f"global BA, {a.ba_frames} cameras x {a.ba_points} points, SIMPLE_RADIAL, "
+                               f"track length {a.ba_track} ({n_obs} observations), gauge TWO_CAMS_FROM_WORLD, "
+                               f"implicit Schur PCG + Schur-Jacobi, first {a.ba_iters} LM iterations",
+                   "lm_iterations": s.num_iterations, "pcg_iterations": int(s.total_linear_iterations),
+                   "cost": [s.initial_cost, s.final_cost]},
+        "roofline": {"bound": "hbm", "kernel": "implicit Schur product (ba_obs_jx + ba_point_pass + ba_block_jtv)",
+                     "achieved": alg / (avg_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                     "frac": alg / (avg_ms * 1e-3) / 1e9 / 8000.0, "traffic": None,
+                     "algorithmic_bytes_per_launch": alg, "avg_launch_ms": avg_ms, "launches_timed": int(n.value)},
+    }
+    if with_cpu:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import ba_oracle
+        c = fp.copy()
+        sc = est.solve_flat(c, est.SolverOptions(max_num_iterations=3), solve_fn=ba_oracle.solve_fn)
+        out["cpu_baseline"] = dict(value=sc.num_iterations / sc.lm_seconds, unit="LM-iterations/s",
+                                   cores=int(ba_oracle.lib().bao_num_threads()), kind="port",
+                                   sample=f"oracle/ba_oracle.c (fp64, OpenMP), first {sc.num_iterations} LM iterations "
+                                          f"of the same problem, {sc.lm_seconds:.1f} s")
+    return out
 
 
 def main():
@@ -121,6 +174,7 @@ def main():
         torch.cuda.synchronize()
 
     sweep_ms, sweep_n = 0.0, 0
+    pms_keepalive = []
 
     def run_step(step, record):
         nonlocal sweep_ms, sweep_n
@@ -200,6 +254,10 @@ def main():
             cw, ch = [int(x) for x in a.cpu_crop.split("x")]
             host_views = [syn.View(K, R, T, g.cpu().numpy(), None, None) for (K, R, T, g, _, _) in views]
             out["cpu_baseline"] = cpu_baseline(host_views, ref, src, dmin, dmax, (cw, ch))
+        if not a.no_ba:
+            del pms_keepalive[:]
+            torch.cuda.empty_cache()
+            out["secondary"] = ba_secondary(a, local_rank, not a.no_cpu_baseline)
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist

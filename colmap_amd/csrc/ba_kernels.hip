@@ -1,0 +1,1248 @@
+// ba_kernels.hip -- gfx950 bundle-adjustment solve: Jacobian builder (one reprojection
+// residual per lane) + Levenberg-Marquardt with an implicit-Schur preconditioned CG.
+//
+// What it replaces: ceres::Solve as COLMAP configures it for large problems
+// (ITERATIVE_SCHUR + SCHUR_JACOBI, reference estimators/bundle_adjustment_ceres.cc:203-213)
+// together with the in-tree cost functions it evaluates
+// (cost_functions/reprojection_error.h:61-212, quaternion_utils.h:105-153,
+// sensor/models_jacobian.h:139-321). Semantics of the trust-region loop follow Ceres
+// (restated in oracle/ba_oracle.c, which this file is tested against); the layout is new:
+//
+//  * SoA Jacobian in HBM, fp64: per observation 2x6 pose-tangent, 2x4 intrinsics-tangent,
+//    2x3 point columns and the residual, each column contiguous over observations so that
+//    the observation-parallel kernels (one lane per residual) read/write coalesced.
+//  * Observations are sorted by 3-D point once on the host: the point-side passes
+//    (C_j = E_j^T E_j + D, C^-1 E^T x, back-substitution) are a lane per point walking a
+//    contiguous segment -- no atomics, deterministic.
+//  * Camera-side reductions (gradient, J^T v, block-Jacobi Gram blocks) run a workgroup per
+//    chunk of a parameter block's observation list with a wave-level tree reduction; blocks
+//    with very long lists (shared intrinsics) are split into chunks that combine with fp64
+//    atomics.
+//  * The Schur-Jacobi blocks B_ii = sum J_i^T J_i (pose 6x6 / intrinsics up to 4x4 per
+//    block, K = 2 x #observations) are dense Gram contractions and run on the f64 matrix
+//    cores (v_mfma_f64_16x16x4_f64: A = B = a 4-row slab of J, D accumulates the 16x16
+//    Gram tile).
+//  * S x = (B + D^2) x - E C^-1 E^T x is never formed: three kernels per product.
+#include "../../include/colmap_amd_ba.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_ba_error;
+thread_local double g_spmv_ms = 0.0;
+thread_local long long g_spmv_launches = 0;
+thread_local long long g_spmv_bytes = 0;
+
+#define BA_HIP(expr)                                                                           \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess)                                                                      \
+      throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(e_) + " at " #expr); \
+  } while (0)
+
+constexpr int PD = 6;        // pose tangent width (5 when the gauge holds a translation coordinate)
+constexpr int KD = 4;        // max intrinsics tangent width
+constexpr int CHUNK = 2048;  // observations per camera-side reduction chunk
+constexpr int NSCALAR = 16;
+
+enum Scalar { S_COST = 0, S_GMAX, S_RHO, S_RHO_LAST, S_PQ, S_Q, S_MODEL, S_NEWCOST, S_ITER };
+
+// ------------------------------------------------------------------------------------------
+// Device-side view of the problem
+// ------------------------------------------------------------------------------------------
+struct View {
+  int n_obs, n_poses, n_cams, n_points, n_c, n_p, n_blk, n_chunks;
+  // parameters (current / candidate)
+  double *poses, *cams, *points;
+  // topology
+  const int *o_pose, *o_cam, *o_pt;  // per observation (sorted by point)
+  const double* o_xy;
+  const int *pose_off, *pose_dim, *pose_fix;
+  const int *cam_off, *cam_dim, *cam_var, *cam_model;
+  const int *pt_off, *pt_ptr;
+  const int *blk_off, *blk_dim, *blk_kind, *blk_moff;
+  const int *chunk_blk, *chunk_beg, *chunk_end, *blk_obs;
+  // linearisation
+  double *Jpose, *Jcam, *Jpt, *res;
+  double *scale_c, *scale_p;
+  double* scalars;
+};
+
+__device__ __forceinline__ double wave_sum(double v) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// Deterministic workgroup sum (fixed tree: lanes by xor-shuffle, then waves in index order).
+__device__ __forceinline__ double block_sum(double v) {
+  __shared__ double wave_part[16];
+  v = wave_sum(v);
+  const int wave = threadIdx.x >> 6, nwaves = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) wave_part[wave] = v;
+  __syncthreads();
+  double total = 0.0;
+  for (int w = 0; w < nwaves; ++w) total += wave_part[w];
+  return total;
+}
+
+// out[0] = sum(partials[0..n)) in a fixed order (single workgroup)
+__global__ void __launch_bounds__(1024) ba_final_sum_kernel(const double* __restrict__ partials, int n,
+                                                            double* __restrict__ out) {
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < n; i += 1024) acc += partials[i];
+  const double total = block_sum(acc);
+  if (threadIdx.x == 0) *out = total;
+}
+
+__device__ __forceinline__ void atomic_max_pos(double* addr, double v) {
+  // non-negative doubles order like their bit patterns
+  atomicMax(reinterpret_cast<unsigned long long*>(addr), (unsigned long long)__double_as_longlong(v));
+}
+
+// ------------------------------------------------------------------------------------------
+// Per-residual math (reference reprojection_error.h:68-134)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int num_params_of(int model) { return model == BA_SIMPLE_PINHOLE ? 3 : 4; }
+
+// QuaternionRotatePointWithJac, quaternion_utils.h:105-153
+__device__ __forceinline__ void quat_rotate(const double* q, const double* p, double out[3], double* J) {
+  const double qx = q[0], qy = q[1], qz = q[2], qw = q[3];
+  const double px = p[0], py = p[1], pz = p[2];
+  const double qx_py = qx * py, qx_pz = qx * pz, qy_px = qy * px, qy_pz = qy * pz, qz_px = qz * px,
+               qz_py = qz * py;
+  const double c0 = qy_pz - qz_py, c1 = qz_px - qx_pz, c2 = qx_py - qy_px;
+  const double d0 = qy * c2 - qz * c1, d1 = qz * c0 - qx * c2, d2 = qx * c1 - qy * c0;
+  out[0] = px + 2.0 * (qw * c0 + d0);
+  out[1] = py + 2.0 * (qw * c1 + d1);
+  out[2] = pz + 2.0 * (qw * c2 + d2);
+  if (J) {
+    const double qx_px = qx * px, qy_py = qy * py, qz_pz = qz * pz, qw_px = qw * px, qw_py = qw * py,
+                 qw_pz = qw * pz;
+    J[0] = 2.0 * (qy_py + qz_pz);
+    J[1] = 2.0 * (-2.0 * qy_px + qx_py + qw_pz);
+    J[2] = 2.0 * (-2.0 * qz_px - qw_py + qx_pz);
+    J[3] = 2.0 * (-qz_py + qy_pz);
+    J[4] = 2.0 * (qy_px - 2.0 * qx_py - qw_pz);
+    J[5] = 2.0 * (qx_px + qz_pz);
+    J[6] = 2.0 * (qw_px - 2.0 * qz_py + qy_pz);
+    J[7] = 2.0 * (qz_px - qx_pz);
+    J[8] = 2.0 * (qz_px + qw_py - 2.0 * qx_pz);
+    J[9] = 2.0 * (-qw_px + qz_py - 2.0 * qy_pz);
+    J[10] = 2.0 * (qx_px + qy_py);
+    J[11] = 2.0 * (-qy_px + qx_py);
+  }
+}
+
+// ImgFromCamWithJac, sensor/models_jacobian.h:139-321 (+ HasProjectableDepth, models.h:281-285)
+template <bool JAC>
+__device__ __forceinline__ bool img_from_cam(int model, const double* prm, double u, double v, double w,
+                                             double& x, double& y, double* Jpar, double* Juvw) {
+  if (!(w >= 2.220446049250313e-16)) return false;
+  const double inv_w = 1.0 / w;
+  const double uu = u * inv_w, vv = v * inv_w;
+  if (model == BA_SIMPLE_PINHOLE) {
+    const double f = prm[0];
+    x = f * uu + prm[1];
+    y = f * vv + prm[2];
+    if (JAC) {
+      const double fw = f * inv_w;
+      Juvw[0] = fw; Juvw[1] = 0.0; Juvw[2] = -fw * uu; Juvw[3] = 0.0; Juvw[4] = fw; Juvw[5] = -fw * vv;
+      Jpar[0] = uu; Jpar[1] = 1.0; Jpar[2] = 0.0; Jpar[3] = 0.0;
+      Jpar[4] = vv; Jpar[5] = 0.0; Jpar[6] = 1.0; Jpar[7] = 0.0;
+    }
+    return true;
+  }
+  if (model == BA_PINHOLE) {
+    const double f1 = prm[0], f2 = prm[1];
+    x = f1 * uu + prm[2];
+    y = f2 * vv + prm[3];
+    if (JAC) {
+      Juvw[0] = f1 * inv_w; Juvw[1] = 0.0; Juvw[2] = -f1 * inv_w * uu;
+      Juvw[3] = 0.0; Juvw[4] = f2 * inv_w; Juvw[5] = -f2 * inv_w * vv;
+      Jpar[0] = uu; Jpar[1] = 0.0; Jpar[2] = 1.0; Jpar[3] = 0.0;
+      Jpar[4] = 0.0; Jpar[5] = vv; Jpar[6] = 0.0; Jpar[7] = 1.0;
+    }
+    return true;
+  }
+  const double f = prm[0], k = prm[3];
+  const double uu2 = uu * uu, vv2 = vv * vv, r2 = uu2 + vv2, k_r2 = k * r2, alpha = 1.0 + k_r2;
+  const double xd = alpha * uu, yd = alpha * vv;
+  x = f * xd + prm[1];
+  y = f * yd + prm[2];
+  if (JAC) {
+    const double two_k = 2.0 * k, fw = f * inv_w, beta = 1.0 + 3.0 * k_r2, tkuv = two_k * uu * vv;
+    Juvw[0] = fw * (alpha + two_k * uu2); Juvw[1] = fw * tkuv; Juvw[2] = -fw * uu * beta;
+    Juvw[3] = fw * tkuv; Juvw[4] = fw * (alpha + two_k * vv2); Juvw[5] = -fw * vv * beta;
+    Jpar[0] = xd; Jpar[1] = 1.0; Jpar[2] = 0.0; Jpar[3] = f * uu * r2;
+    Jpar[4] = yd; Jpar[5] = 0.0; Jpar[6] = 1.0; Jpar[7] = f * vv * r2;
+  }
+  return true;
+}
+
+// Evaluate one observation; JAC: also the tangent-space, column-scaled Jacobian blocks.
+// Jpar is laid out 2 x 4 (unused columns zero) whatever the model.
+template <bool JAC>
+__global__ void __launch_bounds__(256) ba_linearize_kernel(View V, const double* __restrict__ poses,
+                                                          const double* __restrict__ cams,
+                                                          const double* __restrict__ points,
+                                                          double* __restrict__ partials) {
+  const int o = blockIdx.x * blockDim.x + threadIdx.x;
+  double cost = 0.0;
+  if (o < V.n_obs) {
+    const int pi = V.o_pose[o], ci = V.o_cam[o], xi = V.o_pt[o];
+    const double* q = poses + 7 * (size_t)pi;
+    const double* prm = cams + BA_CAM_STRIDE * (size_t)ci;
+    const double* X = points + 3 * (size_t)xi;
+    const int model = V.cam_model[ci];
+    double JR[12], Juvw[6], Jpar[8], pc[3];
+    quat_rotate(q, X, pc, JAC ? JR : nullptr);
+    pc[0] += q[4]; pc[1] += q[5]; pc[2] += q[6];
+    double rx = 0.0, ry = 0.0;
+    const bool ok = img_from_cam<JAC>(model, prm, pc[0], pc[1], pc[2], rx, ry, Jpar, Juvw);
+    if (ok) {
+      rx -= V.o_xy[2 * (size_t)o];
+      ry -= V.o_xy[2 * (size_t)o + 1];
+    } else {
+      rx = ry = 0.0;  // behind the camera: zero residual and Jacobian (:96-116)
+    }
+    cost = 0.5 * (rx * rx + ry * ry);
+    if (JAC) {
+      const size_t N = (size_t)V.n_obs;
+      V.res[o] = rx;
+      V.res[N + o] = ry;
+      const int pdim = V.pose_dim[pi], poff = V.pose_off[pi];
+      const int cdim = V.cam_dim[ci], coff = V.cam_off[ci];
+      const int ptoff = V.pt_off[xi];
+      // pose block: J_uvw * dRp/dq * PlusJacobian (EigenQuaternionManifold, xyzw) | J_uvw
+      double Jp[2][PD];
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int c = 0; c < PD; ++c) Jp[r][c] = 0.0;
+      if (ok && pdim > 0) {
+        const double x = q[0], y = q[1], z = q[2], w = q[3];
+        const double PJ[12] = {w, z, -y, -z, w, x, y, -x, w, -x, -y, -z};
+        const int fix = V.pose_fix[pi];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          double Jq[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            Jq[c] = Juvw[3 * r] * JR[c] + Juvw[3 * r + 1] * JR[4 + c] + Juvw[3 * r + 2] * JR[8 + c];
+#pragma unroll
+          for (int c = 0; c < 3; ++c)
+            Jp[r][c] = Jq[0] * PJ[c] + Jq[1] * PJ[3 + c] + Jq[2] * PJ[6 + c] + Jq[3] * PJ[9 + c];
+          int d = 3;
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            if (c == fix) continue;
+            Jp[r][d++] = Juvw[3 * r + c];
+          }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int c = 0; c < PD; ++c) {
+          const double s = (c < pdim) ? V.scale_c[poff + c] : 0.0;
+          V.Jpose[(size_t)(r * PD + c) * N + o] = Jp[r][c] * s;
+        }
+      // intrinsics block: variable subset of the model's parameters
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int c = 0; c < KD; ++c) {
+          double val = 0.0;
+          if (ok && c < cdim) val = Jpar[4 * r + V.cam_var[KD * ci + c]] * V.scale_c[coff + c];
+          V.Jcam[(size_t)(r * KD + c) * N + o] = val;
+        }
+      // point block: J_uvw * R(q)
+      double R[9];
+      {
+        const double x = q[0], y = q[1], z = q[2], w = q[3];
+        const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+        const double twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x,
+                     tyy = ty * y, tyz = tz * y, tzz = tz * z;
+        R[0] = 1 - (tyy + tzz); R[1] = txy - twz; R[2] = txz + twy;
+        R[3] = txy + twz; R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+        R[6] = txz - twy; R[7] = tyz + twx; R[8] = 1 - (txx + tyy);
+      }
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          double val = 0.0;
+          if (ok && ptoff >= 0)
+            val = (Juvw[3 * r] * R[c] + Juvw[3 * r + 1] * R[3 + c] + Juvw[3 * r + 2] * R[6 + c]) *
+                  V.scale_p[ptoff + c];
+          V.Jpt[(size_t)(r * 3 + c) * N + o] = val;
+        }
+    }
+  }
+  cost = block_sum(cost);
+  if (threadIdx.x == 0) partials[blockIdx.x] = cost;
+}
+
+// ------------------------------------------------------------------------------------------
+// Point-side passes: one lane per 3-D point, contiguous observation segment
+// ------------------------------------------------------------------------------------------
+
+// g_p = E^T r and diag(E^T E)
+__global__ void ba_point_grad_kernel(View V, double* __restrict__ gp, double* __restrict__ diag_p) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= V.n_points) return;
+  const int off = V.pt_off[j];
+  if (off < 0) return;
+  const size_t N = (size_t)V.n_obs;
+  double g[3] = {0, 0, 0}, d[3] = {0, 0, 0};
+  for (int o = V.pt_ptr[j]; o < V.pt_ptr[j + 1]; ++o)
+    for (int r = 0; r < 2; ++r) {
+      const double rr = V.res[r * N + o];
+      for (int c = 0; c < 3; ++c) {
+        const double J = V.Jpt[(size_t)(r * 3 + c) * N + o];
+        g[c] += J * rr;
+        d[c] += J * J;
+      }
+    }
+  for (int c = 0; c < 3; ++c) {
+    gp[off + c] = g[c];
+    diag_p[off + c] = d[c];
+  }
+}
+
+// C_j = E_j^T E_j + Dp^2, inverted (3x3 cofactor inverse)
+__global__ void ba_point_blocks_kernel(View V, const double* __restrict__ Dp, double* __restrict__ Cinv) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= V.n_points) return;
+  const int off = V.pt_off[j];
+  if (off < 0) return;
+  const size_t N = (size_t)V.n_obs;
+  double C[6] = {0, 0, 0, 0, 0, 0};  // xx xy xz yy yz zz
+  for (int o = V.pt_ptr[j]; o < V.pt_ptr[j + 1]; ++o)
+    for (int r = 0; r < 2; ++r) {
+      const double a = V.Jpt[(size_t)(r * 3 + 0) * N + o], b = V.Jpt[(size_t)(r * 3 + 1) * N + o],
+                   c = V.Jpt[(size_t)(r * 3 + 2) * N + o];
+      C[0] += a * a; C[1] += a * b; C[2] += a * c; C[3] += b * b; C[4] += b * c; C[5] += c * c;
+    }
+  C[0] += Dp[off] * Dp[off];
+  C[3] += Dp[off + 1] * Dp[off + 1];
+  C[5] += Dp[off + 2] * Dp[off + 2];
+  const double a = C[0], b = C[1], c = C[2], d = C[3], e = C[4], f = C[5];
+  const double A = d * f - e * e, B = c * e - b * f, Cc = b * e - c * d;
+  const double det = a * A + b * B + c * Cc;
+  const double id = 1.0 / det;
+  double* out = Cinv + 9 * (size_t)j;
+  out[0] = A * id; out[1] = B * id; out[2] = Cc * id;
+  out[3] = B * id; out[4] = (a * f - c * c) * id; out[5] = (b * c - a * e) * id;
+  out[6] = Cc * id; out[7] = (b * c - a * e) * id; out[8] = (a * d - b * b) * id;
+}
+
+// MODE 0 (Schur product): u = C^-1 E^T jx ; v_o = jx_o - E_o u
+// MODE 1 (reduced rhs):   u = C^-1 g_p     ; v_o = -E_o u
+// MODE 2 (back-subst.):   dp = C^-1 (g_p - E^T jx)
+template <int MODE>
+__global__ void ba_point_pass_kernel(View V, const double* __restrict__ Cinv, const double* __restrict__ jx,
+                                     const double* __restrict__ gp, double* __restrict__ v,
+                                     double* __restrict__ dp) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= V.n_points) return;
+  const int off = V.pt_off[j];
+  const size_t N = (size_t)V.n_obs;
+  const int beg = V.pt_ptr[j], end = V.pt_ptr[j + 1];
+  if (off < 0) {  // constant point: no point block
+    if (MODE == 0) for (int o = beg; o < end; ++o) { v[o] = jx[o]; v[N + o] = jx[N + o]; }
+    if (MODE == 1) for (int o = beg; o < end; ++o) { v[o] = 0.0; v[N + o] = 0.0; }
+    return;
+  }
+  double t[3] = {0, 0, 0};
+  if (MODE != 1) {
+    for (int o = beg; o < end; ++o)
+      for (int r = 0; r < 2; ++r) {
+        const double x = jx[r * N + o];
+        for (int c = 0; c < 3; ++c) t[c] += V.Jpt[(size_t)(r * 3 + c) * N + o] * x;
+      }
+  }
+  if (MODE == 1) for (int c = 0; c < 3; ++c) t[c] = gp[off + c];
+  if (MODE == 2) for (int c = 0; c < 3; ++c) t[c] = gp[off + c] - t[c];
+  const double* Ci = Cinv + 9 * (size_t)j;
+  double u[3];
+  for (int r = 0; r < 3; ++r) u[r] = Ci[3 * r] * t[0] + Ci[3 * r + 1] * t[1] + Ci[3 * r + 2] * t[2];
+  if (MODE == 2) {
+    for (int c = 0; c < 3; ++c) dp[off + c] = u[c];
+    return;
+  }
+  for (int o = beg; o < end; ++o)
+    for (int r = 0; r < 2; ++r) {
+      const double eu = V.Jpt[(size_t)(r * 3 + 0) * N + o] * u[0] + V.Jpt[(size_t)(r * 3 + 1) * N + o] * u[1] +
+                        V.Jpt[(size_t)(r * 3 + 2) * N + o] * u[2];
+      v[r * N + o] = (MODE == 0 ? jx[r * N + o] : 0.0) - eu;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Observation-parallel passes
+// ------------------------------------------------------------------------------------------
+
+// jx_o = Jc_o x  (both residual rows), x a camera-side vector
+__global__ void ba_obs_jx_kernel(View V, const double* __restrict__ x, double* __restrict__ jx) {
+  const int o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= V.n_obs) return;
+  const size_t N = (size_t)V.n_obs;
+  const int pi = V.o_pose[o], ci = V.o_cam[o];
+  const int pdim = V.pose_dim[pi], poff = V.pose_off[pi], cdim = V.cam_dim[ci], coff = V.cam_off[ci];
+  double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+  for (int c = 0; c < PD; ++c)
+    if (c < pdim) {
+      const double xv = x[poff + c];
+      a0 += V.Jpose[(size_t)c * N + o] * xv;
+      a1 += V.Jpose[(size_t)(PD + c) * N + o] * xv;
+    }
+#pragma unroll
+  for (int c = 0; c < KD; ++c)
+    if (c < cdim) {
+      const double xv = x[coff + c];
+      a0 += V.Jcam[(size_t)c * N + o] * xv;
+      a1 += V.Jcam[(size_t)(KD + c) * N + o] * xv;
+    }
+  jx[o] = a0;
+  jx[N + o] = a1;
+}
+
+// model cost change: -(J step) . (r + J step / 2), step = (dc, dp) already negated
+__global__ void __launch_bounds__(256) ba_model_kernel(View V, const double* __restrict__ dc,
+                                                      const double* __restrict__ dp,
+                                                      double* __restrict__ partials) {
+  const int o = blockIdx.x * blockDim.x + threadIdx.x;
+  double acc = 0.0;
+  if (o < V.n_obs) {
+    const size_t N = (size_t)V.n_obs;
+    const int pi = V.o_pose[o], ci = V.o_cam[o], xi = V.o_pt[o];
+    const int pdim = V.pose_dim[pi], poff = V.pose_off[pi], cdim = V.cam_dim[ci], coff = V.cam_off[ci];
+    const int ptoff = V.pt_off[xi];
+    for (int r = 0; r < 2; ++r) {
+      double m = 0.0;
+      for (int c = 0; c < pdim; ++c) m += V.Jpose[(size_t)(r * PD + c) * N + o] * dc[poff + c];
+      for (int c = 0; c < cdim; ++c) m += V.Jcam[(size_t)(r * KD + c) * N + o] * dc[coff + c];
+      if (ptoff >= 0)
+        for (int c = 0; c < 3; ++c) m += V.Jpt[(size_t)(r * 3 + c) * N + o] * dp[ptoff + c];
+      acc -= m * (V.res[r * N + o] + 0.5 * m);
+    }
+  }
+  acc = block_sum(acc);
+  if (threadIdx.x == 0) partials[blockIdx.x] = acc;
+}
+
+// ------------------------------------------------------------------------------------------
+// Camera-side reductions: one wave per chunk of a parameter block's observation list
+// ------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ const double* blk_col(const View& V, int kind, int r, int c) {
+  const size_t N = (size_t)V.n_obs;
+  return kind == 0 ? V.Jpose + (size_t)(r * PD + c) * N : V.Jcam + (size_t)(r * KD + c) * N;
+}
+
+// y_b += J_b^T v  (v: 2 rows per observation). With DIAG: also diag_b += colsq(J_b).
+template <bool DIAG>
+__global__ void __launch_bounds__(64) ba_block_jtv_kernel(View V, const double* __restrict__ v,
+                                                         double* __restrict__ y, double* __restrict__ diag) {
+  const int ch = blockIdx.x;
+  const int b = V.chunk_blk[ch];
+  const int kind = V.blk_kind[b], dim = V.blk_dim[b], off = V.blk_off[b];
+  const size_t N = (size_t)V.n_obs;
+  double acc[PD] = {0, 0, 0, 0, 0, 0}, dacc[PD] = {0, 0, 0, 0, 0, 0};
+  for (int k = V.chunk_beg[ch] + threadIdx.x; k < V.chunk_end[ch]; k += 64) {
+    const int o = V.blk_obs[k];
+    const double v0 = v[o], v1 = v[N + o];
+#pragma unroll
+    for (int c = 0; c < PD; ++c)
+      if (c < dim) {
+        const double j0 = blk_col(V, kind, 0, c)[o], j1 = blk_col(V, kind, 1, c)[o];
+        acc[c] += j0 * v0 + j1 * v1;
+        if (DIAG) dacc[c] += j0 * j0 + j1 * j1;
+      }
+  }
+#pragma unroll
+  for (int c = 0; c < PD; ++c)
+    if (c < dim) {
+      const double s = wave_sum(acc[c]);
+      if (threadIdx.x == 0) atomicAdd(y + off + c, s);
+      if (DIAG) {
+        const double d = wave_sum(dacc[c]);
+        if (threadIdx.x == 0) atomicAdd(diag + off + c, d);
+      }
+    }
+}
+
+// Schur-Jacobi diagonal blocks, part 1: B_bb = sum_o J_b,o^T J_b,o on the f64 matrix cores.
+// One wave per chunk. Lane l holds element (row k = l >> 4 of the current 4-row slab, column
+// i = l & 15) of the slab of J_b; with A = B = that slab, v_mfma_f64_16x16x4_f64 accumulates the
+// 16x16 Gram tile (columns >= dim are zero). C/D layout: col = l & 15, row = (l >> 4) + 4 * reg.
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+
+__global__ void __launch_bounds__(64) ba_block_gram_kernel(View V, double* __restrict__ M) {
+  const int ch = blockIdx.x;
+  const int b = V.chunk_blk[ch];
+  const int kind = V.blk_kind[b], dim = V.blk_dim[b];
+  const int lane = threadIdx.x;
+  const int i = lane & 15, k = lane >> 4;  // column, row-in-slab (k = 2 * obs_in_slab + residual row)
+  const int beg = V.chunk_beg[ch], end = V.chunk_end[ch];
+  v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+  const double* col = (i < dim) ? blk_col(V, kind, k & 1, i) : nullptr;
+  for (int s = beg; s < end; s += 2) {  // two observations = four residual rows per MFMA
+    const int idx = s + (k >> 1);
+    double a = 0.0;
+    if (col != nullptr && idx < end) a = col[V.blk_obs[idx]];
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, acc, 0, 0, 0);
+  }
+  double* Mb = M + V.blk_moff[b];
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) {
+    const int row = k + 4 * reg;
+    if (row < dim && i < dim) atomicAdd(Mb + row * dim + i, acc[reg]);
+  }
+}
+
+// Schur-Jacobi diagonal blocks, part 2: - sum_j W C_j^-1 W'^T over pairs of observations of the
+// same point that share the block (W = J_b^T E, dim x 3). One lane per observation of the block.
+__global__ void __launch_bounds__(64) ba_block_schur_corr_kernel(View V, const double* __restrict__ Cinv,
+                                                                double* __restrict__ M) {
+  const int ch = blockIdx.x;
+  const int b = V.chunk_blk[ch];
+  const int kind = V.blk_kind[b], dim = V.blk_dim[b], boff = V.blk_off[b];
+  const size_t N = (size_t)V.n_obs;
+  double acc[PD * PD];
+#pragma unroll
+  for (int e = 0; e < PD * PD; ++e) acc[e] = 0.0;
+  for (int kk = V.chunk_beg[ch] + threadIdx.x; kk < V.chunk_end[ch]; kk += 64) {
+    const int o = V.blk_obs[kk];
+    const int xi = V.o_pt[o];
+    if (V.pt_off[xi] < 0) continue;
+    const double* Ci = Cinv + 9 * (size_t)xi;
+    double W1[PD][3];
+#pragma unroll
+    for (int x = 0; x < PD; ++x)
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        W1[x][c] = (x < dim) ? blk_col(V, kind, 0, x)[o] * V.Jpt[(size_t)c * N + o] +
+                                   blk_col(V, kind, 1, x)[o] * V.Jpt[(size_t)(3 + c) * N + o]
+                             : 0.0;
+    double T[PD][3];  // W1 * Cinv
+#pragma unroll
+    for (int x = 0; x < PD; ++x)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) T[x][c] = W1[x][0] * Ci[c] + W1[x][1] * Ci[3 + c] + W1[x][2] * Ci[6 + c];
+    // partners: observations of the same point that map to the same block (self included)
+    for (int o2 = V.pt_ptr[xi]; o2 < V.pt_ptr[xi + 1]; ++o2) {
+      const int off2 = kind == 0 ? V.pose_off[V.o_pose[o2]] : V.cam_off[V.o_cam[o2]];
+      if (off2 != boff) continue;
+#pragma unroll
+      for (int y = 0; y < PD; ++y) {
+        if (y >= dim) continue;
+        double W2[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+          W2[c] = blk_col(V, kind, 0, y)[o2] * V.Jpt[(size_t)c * N + o2] +
+                  blk_col(V, kind, 1, y)[o2] * V.Jpt[(size_t)(3 + c) * N + o2];
+#pragma unroll
+        for (int x = 0; x < PD; ++x)
+          if (x < dim) acc[x * PD + y] -= T[x][0] * W2[0] + T[x][1] * W2[1] + T[x][2] * W2[2];
+      }
+    }
+  }
+  double* Mb = M + V.blk_moff[b];
+#pragma unroll
+  for (int x = 0; x < PD; ++x)
+#pragma unroll
+    for (int y = 0; y < PD; ++y)
+      if (x < dim && y < dim) {
+        const double s = wave_sum(acc[x * PD + y]);
+        if (threadIdx.x == 0) atomicAdd(Mb + x * dim + y, s);
+      }
+}
+
+// M_b += Dc^2 on the diagonal, then invert (Gauss-Jordan with partial pivoting); lane per block
+__global__ void ba_block_invert_kernel(View V, const double* __restrict__ Dc, const double* __restrict__ M,
+                                       double* __restrict__ Minv) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= V.n_blk) return;
+  const int n = V.blk_dim[b], off = V.blk_off[b];
+  double A[PD][2 * PD];
+  for (int i = 0; i < PD; ++i)
+    for (int j = 0; j < 2 * PD; ++j) A[i][j] = 0.0;
+  for (int i = 0; i < n; ++i) {
+    for (int j = 0; j < n; ++j) A[i][j] = M[V.blk_moff[b] + i * n + j];
+    A[i][i] += Dc[off + i] * Dc[off + i];
+    A[i][PD + i] = 1.0;
+  }
+  for (int c = 0; c < n; ++c) {
+    int piv = c;
+    for (int r = c + 1; r < n; ++r)
+      if (fabs(A[r][c]) > fabs(A[piv][c])) piv = r;
+    if (piv != c)
+      for (int j = 0; j < 2 * PD; ++j) { const double t = A[c][j]; A[c][j] = A[piv][j]; A[piv][j] = t; }
+    const double inv = 1.0 / A[c][c];
+    for (int j = 0; j < 2 * PD; ++j) A[c][j] *= inv;
+    for (int r = 0; r < n; ++r) {
+      if (r == c) continue;
+      const double f = A[r][c];
+      for (int j = 0; j < 2 * PD; ++j) A[r][j] -= f * A[c][j];
+    }
+  }
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j) Minv[V.blk_moff[b] + i * n + j] = A[i][PD + j];
+}
+
+// ------------------------------------------------------------------------------------------
+// Small vector kernels (camera-side vectors are a few thousand entries)
+// ------------------------------------------------------------------------------------------
+__global__ void ba_lm_diag_kernel(int n, const double* __restrict__ diag, double radius, double lo, double hi,
+                                  double* __restrict__ D) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) D[i] = sqrt(fmin(fmax(diag[i], lo), hi) / radius);
+}
+__global__ void ba_scale_kernel(int n, const double* __restrict__ diag, int enable, double* __restrict__ s) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) s[i] = enable ? 1.0 / (1.0 + sqrt(diag[i])) : 1.0;
+}
+__global__ void ba_dsq_x_kernel(int n, const double* __restrict__ D, const double* __restrict__ x,
+                                double* __restrict__ y) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = D[i] * D[i] * x[i];
+}
+// z_b = Minv_b r_b ; rho = r.z   (single workgroup: deterministic sum)
+__global__ void __launch_bounds__(1024) ba_pcg_precond_kernel(View V, const double* __restrict__ Minv,
+                                                              const double* __restrict__ r,
+                                                              double* __restrict__ z) {
+  double rho = 0.0;
+  for (int b = threadIdx.x; b < V.n_blk; b += 1024) {
+    const int n = V.blk_dim[b], off = V.blk_off[b];
+    const double* Mi = Minv + V.blk_moff[b];
+    for (int i = 0; i < n; ++i) {
+      double s = 0.0;
+      for (int j = 0; j < n; ++j) s += Mi[i * n + j] * r[off + j];
+      z[off + i] = s;
+      rho += s * r[off + i];
+    }
+  }
+  rho = block_sum(rho);
+  if (threadIdx.x == 0) V.scalars[S_RHO] = rho;
+}
+// p = z + (rho / rho_last) p   (first iteration: p = z)
+__global__ void ba_pcg_dir_kernel(int n, const double* __restrict__ scalars, int first, const double* __restrict__ z,
+                                  double* __restrict__ p) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  p[i] = first ? z[i] : z[i] + (scalars[S_RHO] / scalars[S_RHO_LAST]) * p[i];
+}
+__global__ void __launch_bounds__(1024) ba_dot_kernel(int n, const double* __restrict__ a,
+                                                      const double* __restrict__ b, double* __restrict__ out) {
+  double v = 0.0;
+  for (int i = threadIdx.x; i < n; i += 1024) v += a[i] * b[i];
+  v = block_sum(v);
+  if (threadIdx.x == 0) *out = v;
+}
+// alpha = rho / pq ; x += alpha p ; r -= alpha q ; Q = -0.5 x (b + r)
+__global__ void __launch_bounds__(1024) ba_pcg_update_kernel(int n, double* __restrict__ scalars,
+                                                             const double* __restrict__ p,
+                                                             const double* __restrict__ q,
+                                                             const double* __restrict__ b, double* __restrict__ x,
+                                                             double* __restrict__ r) {
+  double Q = 0.0;
+  const double alpha = scalars[S_RHO] / scalars[S_PQ];
+  for (int i = threadIdx.x; i < n; i += 1024) {
+    const double xn = x[i] + alpha * p[i];
+    const double rn = r[i] - alpha * q[i];
+    x[i] = xn;
+    r[i] = rn;
+    Q += -0.5 * xn * (b[i] + rn);
+  }
+  Q = block_sum(Q);
+  if (threadIdx.x == 0) scalars[S_Q] = Q;
+}
+// y = a * x / s  (s may be null)
+__global__ void ba_scaled_div_kernel(int n, double a, const double* __restrict__ x, const double* __restrict__ s,
+                                     double* __restrict__ y) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = a * x[i] / (s ? s[i] : 1.0);
+}
+__global__ void ba_axpby_kernel(int n, double a, const double* __restrict__ x, const double* __restrict__ s,
+                                double* __restrict__ y) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = a * x[i] * (s ? s[i] : 1.0);
+}
+
+// x_plus = Plus(x, step): quaternion (x) translation, subset of intrinsics, points
+__global__ void ba_apply_pose_kernel(View V, const double* __restrict__ step, const double* __restrict__ in,
+                                     double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= V.n_poses) return;
+  const double* q = in + 7 * (size_t)i;
+  double* o = out + 7 * (size_t)i;
+  for (int c = 0; c < 7; ++c) o[c] = q[c];
+  const int off = V.pose_off[i];
+  if (off < 0) return;
+  const double* d = step + off;
+  const double n = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+  if (n != 0.0) {
+    const double s = sin(n) / n;
+    const double dx = s * d[0], dy = s * d[1], dz = s * d[2], dw = cos(n);
+    const double x = q[0], y = q[1], z = q[2], w = q[3];
+    o[0] = dw * x + dx * w + dy * z - dz * y;
+    o[1] = dw * y - dx * z + dy * w + dz * x;
+    o[2] = dw * z + dx * y - dy * x + dz * w;
+    o[3] = dw * w - dx * x - dy * y - dz * z;
+  }
+  int k = 3;
+  const int fix = V.pose_fix[i];
+  for (int c = 0; c < 3; ++c) {
+    if (c == fix) continue;
+    o[4 + c] += d[k++];
+  }
+}
+__global__ void ba_apply_cam_kernel(View V, const double* __restrict__ step, const double* __restrict__ in,
+                                    double* __restrict__ out) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= V.n_cams) return;
+  for (int c = 0; c < BA_CAM_STRIDE; ++c) out[BA_CAM_STRIDE * (size_t)k + c] = in[BA_CAM_STRIDE * (size_t)k + c];
+  const int off = V.cam_off[k];
+  if (off < 0) return;
+  for (int d = 0; d < V.cam_dim[k]; ++d) out[BA_CAM_STRIDE * (size_t)k + V.cam_var[KD * k + d]] += step[off + d];
+}
+__global__ void ba_apply_point_kernel(View V, const double* __restrict__ step, const double* __restrict__ in,
+                                      double* __restrict__ out) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= V.n_points) return;
+  const int off = V.pt_off[j];
+  for (int c = 0; c < 3; ++c) out[3 * (size_t)j + c] = in[3 * (size_t)j + c] + (off >= 0 ? step[off + c] : 0.0);
+}
+// max |a - b| over n doubles -> scalars[S_GMAX]
+__global__ void ba_maxdiff_kernel(size_t n, const double* __restrict__ a, const double* __restrict__ b,
+                                  double* __restrict__ scalars) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  double v = (i < n) ? fabs(a[i] - b[i]) : 0.0;
+  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+  if ((threadIdx.x & 63) == 0) atomic_max_pos(scalars + S_GMAX, v);
+}
+__global__ void ba_renorm_quat_kernel(View V, double* __restrict__ poses) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= V.n_poses || V.pose_off[i] < 0) return;
+  double* q = poses + 7 * (size_t)i;
+  const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  for (int c = 0; c < 4; ++c) q[c] /= n;
+}
+
+// ------------------------------------------------------------------------------------------
+// Host-side solver
+// ------------------------------------------------------------------------------------------
+template <typename T>
+struct Buf {
+  T* p = nullptr;
+  size_t n = 0;
+  void alloc(size_t count) {
+    release();
+    n = count;
+    BA_HIP(hipMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(count, 1) * sizeof(T)));
+    BA_HIP(hipMemset(p, 0, std::max<size_t>(count, 1) * sizeof(T)));
+  }
+  void upload(const std::vector<T>& h) {
+    alloc(h.size());
+    if (!h.empty()) BA_HIP(hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  ~Buf() { release(); }
+};
+
+inline int grid_for(size_t n, int block) { return (int)((n + block - 1) / block); }
+
+static const bool g_ba_debug = std::getenv("COLMAP_AMD_BA_DEBUG") != nullptr;
+#define BA_LAUNCH(kernel, grid, block, stream, ...)                                    \
+  do {                                                                                 \
+    hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__);                   \
+    if (g_ba_debug) {                                                                  \
+      hipError_t e_ = hipStreamSynchronize(stream);                                    \
+      if (e_ == hipSuccess) e_ = hipGetLastError();                                    \
+      std::fprintf(stderr, "[ba] %s grid=%d -> %s\n", #kernel, (int)(grid).x, hipGetErrorString(e_)); \
+      if (e_ != hipSuccess) throw std::runtime_error(std::string("kernel failed: ") + #kernel); \
+    }                                                                                  \
+  } while (0)
+
+struct Solver {
+  const ba_options& opt;
+  ba_problem& prob;
+  View V{};
+  hipStream_t st = nullptr;
+  // topology
+  Buf<int> o_pose, o_cam, o_pt, pose_off, pose_dim, pose_fix, cam_off, cam_dim, cam_var, cam_model, pt_off,
+      pt_ptr, blk_off, blk_dim, blk_kind, blk_moff, chunk_blk, chunk_beg, chunk_end, blk_obs;
+  Buf<double> o_xy, poses, cams, points, poses2, cams2, points2, Jpose, Jcam, Jpt, res, scale_c, scale_p,
+      scalars, gc, gp, diag_c, diag_p, Dc, Dp, Cinv, M, Minv, rhs, x, r, z, pdir, q, dp, jx, v, stepc, stepp, partials;
+  int moff_total = 0;
+  std::vector<int> h_pose_off, h_cam_off, h_pt_off;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+  Solver(ba_problem& p_, const ba_options& o_) : opt(o_), prob(p_) {}
+  ~Solver() {
+    if (ev0) (void)hipEventDestroy(ev0);
+    if (ev1) (void)hipEventDestroy(ev1);
+    if (st) (void)hipStreamDestroy(st);
+  }
+
+  double scalar(int slot) {
+    double v = 0.0;
+    BA_HIP(hipMemcpyAsync(&v, scalars.p + slot, sizeof(double), hipMemcpyDeviceToHost, st));
+    BA_HIP(hipStreamSynchronize(st));
+    return v;
+  }
+  void zero_scalar(int slot) { BA_HIP(hipMemsetAsync(scalars.p + slot, 0, sizeof(double), st)); }
+
+  // Reduced program: active observations (>= 1 variable block), tangent offsets, CSR structures.
+  int build(ba_result* res_out) {
+    const ba_problem& p = prob;
+    std::vector<int> cam_nvar(p.num_cams, 0);
+    std::vector<int> h_cam_var((size_t)p.num_cams * KD, 0), h_cam_dim(p.num_cams, 0);
+    for (int k = 0; k < p.num_cams; ++k) {
+      const int model = p.cam_model[k];
+      if (model != BA_SIMPLE_PINHOLE && model != BA_PINHOLE && model != BA_SIMPLE_RADIAL)
+        throw std::runtime_error("unsupported camera model id " + std::to_string(model) +
+                                 " (supported: SIMPLE_PINHOLE, PINHOLE, SIMPLE_RADIAL)");
+      const int P = model == BA_SIMPLE_PINHOLE ? 3 : 4;
+      for (int j = 0; j < P; ++j)
+        if (!p.cam_const[(size_t)k * BA_CAM_STRIDE + j]) h_cam_var[(size_t)k * KD + cam_nvar[k]++] = j;
+    }
+    std::vector<int64_t> active;
+    active.reserve(p.num_obs);
+    std::vector<char> pose_used(p.num_poses, 0), cam_used(p.num_cams, 0), pt_used(p.num_points, 0);
+    for (int64_t o = 0; o < p.num_obs; ++o) {
+      const int pi = p.obs_pose[o], ci = p.obs_cam[o], xi = p.obs_point[o];
+      if (pi < 0 || pi >= p.num_poses || ci < 0 || ci >= p.num_cams || xi < 0 || xi >= p.num_points)
+        throw std::runtime_error("observation index out of range");
+      if (p.pose_const[pi] && cam_nvar[ci] == 0 && p.point_const[xi]) continue;
+      active.push_back(o);
+      pose_used[pi] = cam_used[ci] = pt_used[xi] = 1;
+    }
+    const int n = (int)active.size();
+    // sort by point (stable: keeps the caller's order inside a track)
+    std::stable_sort(active.begin(), active.end(),
+                     [&](int64_t a, int64_t b) { return p.obs_point[a] < p.obs_point[b]; });
+    std::vector<int> h_o_pose(n), h_o_cam(n), h_o_pt(n);
+    std::vector<double> h_xy((size_t)2 * n);
+    std::vector<int> h_pt_ptr(p.num_points + 1, 0);
+    for (int a = 0; a < n; ++a) {
+      const int64_t o = active[a];
+      h_o_pose[a] = p.obs_pose[o];
+      h_o_cam[a] = p.obs_cam[o];
+      h_o_pt[a] = p.obs_point[o];
+      h_xy[2 * (size_t)a] = p.obs_xy[2 * o];
+      h_xy[2 * (size_t)a + 1] = p.obs_xy[2 * o + 1];
+      h_pt_ptr[p.obs_point[o] + 1]++;
+    }
+    for (int j = 0; j < p.num_points; ++j) h_pt_ptr[j + 1] += h_pt_ptr[j];
+    // tangent layout: pose blocks, then intrinsics blocks (camera side); points
+    h_pose_off.assign(p.num_poses, -1);
+    h_cam_off.assign(p.num_cams, -1);
+    h_pt_off.assign(p.num_points, -1);
+    std::vector<int> h_pose_dim(p.num_poses, 0), h_pose_fix(p.num_poses, -1);
+    std::vector<int> h_blk_off, h_blk_dim, h_blk_kind, h_blk_moff;
+    std::vector<int> blk_of_pose(p.num_poses, -1), blk_of_cam(p.num_cams, -1);
+    int off = 0, moff = 0;
+    for (int i = 0; i < p.num_poses; ++i) {
+      if (p.pose_const[i] || !pose_used[i]) continue;
+      h_pose_fix[i] = p.pose_fixed_t[i];
+      h_pose_dim[i] = p.pose_fixed_t[i] >= 0 ? 5 : 6;
+      h_pose_off[i] = off;
+      blk_of_pose[i] = (int)h_blk_off.size();
+      h_blk_off.push_back(off); h_blk_dim.push_back(h_pose_dim[i]); h_blk_kind.push_back(0);
+      h_blk_moff.push_back(moff);
+      off += h_pose_dim[i];
+      moff += h_pose_dim[i] * h_pose_dim[i];
+    }
+    for (int k = 0; k < p.num_cams; ++k) {
+      if (cam_nvar[k] == 0 || !cam_used[k]) continue;
+      h_cam_dim[k] = cam_nvar[k];
+      h_cam_off[k] = off;
+      blk_of_cam[k] = (int)h_blk_off.size();
+      h_blk_off.push_back(off); h_blk_dim.push_back(cam_nvar[k]); h_blk_kind.push_back(1);
+      h_blk_moff.push_back(moff);
+      off += cam_nvar[k];
+      moff += cam_nvar[k] * cam_nvar[k];
+    }
+    const int n_c = off;
+    moff_total = moff;
+    int poff = 0;
+    for (int j = 0; j < p.num_points; ++j) {
+      if (p.point_const[j] || !pt_used[j]) continue;
+      h_pt_off[j] = poff;
+      poff += 3;
+    }
+    // per-block observation lists, split into chunks
+    const int n_blk = (int)h_blk_off.size();
+    std::vector<int> cnt(n_blk + 1, 0);
+    for (int a = 0; a < n; ++a) {
+      if (blk_of_pose[h_o_pose[a]] >= 0) cnt[blk_of_pose[h_o_pose[a]] + 1]++;
+      if (blk_of_cam[h_o_cam[a]] >= 0) cnt[blk_of_cam[h_o_cam[a]] + 1]++;
+    }
+    for (int b = 0; b < n_blk; ++b) cnt[b + 1] += cnt[b];
+    std::vector<int> h_blk_obs(cnt[n_blk]), fill(cnt.begin(), cnt.end() - 1);
+    for (int a = 0; a < n; ++a) {
+      const int bp = blk_of_pose[h_o_pose[a]], bc = blk_of_cam[h_o_cam[a]];
+      if (bp >= 0) h_blk_obs[fill[bp]++] = a;
+      if (bc >= 0) h_blk_obs[fill[bc]++] = a;
+    }
+    std::vector<int> h_chunk_blk, h_chunk_beg, h_chunk_end;
+    for (int b = 0; b < n_blk; ++b)
+      for (int s = cnt[b]; s < cnt[b + 1]; s += CHUNK) {
+        h_chunk_blk.push_back(b);
+        h_chunk_beg.push_back(s);
+        h_chunk_end.push_back(std::min(s + CHUNK, cnt[b + 1]));
+      }
+
+    res_out->num_residuals = 2 * n;
+    res_out->num_effective_parameters = n_c + poff;
+    if (n == 0) return 0;
+
+    // upload
+    o_pose.upload(h_o_pose); o_cam.upload(h_o_cam); o_pt.upload(h_o_pt); o_xy.upload(h_xy);
+    pose_off.upload(h_pose_off); pose_dim.upload(h_pose_dim); pose_fix.upload(h_pose_fix);
+    cam_off.upload(h_cam_off); cam_dim.upload(h_cam_dim); cam_var.upload(h_cam_var);
+    cam_model.upload(std::vector<int>(p.cam_model, p.cam_model + p.num_cams));
+    pt_off.upload(h_pt_off); pt_ptr.upload(h_pt_ptr);
+    blk_off.upload(h_blk_off); blk_dim.upload(h_blk_dim); blk_kind.upload(h_blk_kind); blk_moff.upload(h_blk_moff);
+    chunk_blk.upload(h_chunk_blk); chunk_beg.upload(h_chunk_beg); chunk_end.upload(h_chunk_end);
+    blk_obs.upload(h_blk_obs);
+    poses.upload(std::vector<double>(p.poses, p.poses + 7 * (size_t)p.num_poses));
+    cams.upload(std::vector<double>(p.cams, p.cams + BA_CAM_STRIDE * (size_t)p.num_cams));
+    points.upload(std::vector<double>(p.points, p.points + 3 * (size_t)p.num_points));
+    poses2.alloc(poses.n); cams2.alloc(cams.n); points2.alloc(points.n);
+    const size_t N = (size_t)n;
+    Jpose.alloc(2 * PD * N); Jcam.alloc(2 * KD * N); Jpt.alloc(6 * N); res.alloc(2 * N);
+    jx.alloc(2 * N); v.alloc(2 * N);
+    scale_c.alloc(n_c); scale_p.alloc(poff); gc.alloc(n_c); gp.alloc(poff); diag_c.alloc(n_c); diag_p.alloc(poff);
+    Dc.alloc(n_c); Dp.alloc(poff); rhs.alloc(n_c); x.alloc(n_c); r.alloc(n_c); z.alloc(n_c); pdir.alloc(n_c);
+    q.alloc(n_c); dp.alloc(poff); stepc.alloc(n_c); stepp.alloc(poff);
+    Cinv.alloc(9 * (size_t)p.num_points); M.alloc(moff); Minv.alloc(moff);
+    scalars.alloc(NSCALAR);
+    partials.alloc((size_t)grid_for(n, 256) + 1);
+
+    V.n_obs = n; V.n_poses = p.num_poses; V.n_cams = p.num_cams; V.n_points = p.num_points;
+    V.n_c = n_c; V.n_p = poff; V.n_blk = n_blk; V.n_chunks = (int)h_chunk_blk.size();
+    V.poses = poses.p; V.cams = cams.p; V.points = points.p;
+    V.o_pose = o_pose.p; V.o_cam = o_cam.p; V.o_pt = o_pt.p; V.o_xy = o_xy.p;
+    V.pose_off = pose_off.p; V.pose_dim = pose_dim.p; V.pose_fix = pose_fix.p;
+    V.cam_off = cam_off.p; V.cam_dim = cam_dim.p; V.cam_var = cam_var.p; V.cam_model = cam_model.p;
+    V.pt_off = pt_off.p; V.pt_ptr = pt_ptr.p;
+    V.blk_off = blk_off.p; V.blk_dim = blk_dim.p; V.blk_kind = blk_kind.p; V.blk_moff = blk_moff.p;
+    V.chunk_blk = chunk_blk.p; V.chunk_beg = chunk_beg.p; V.chunk_end = chunk_end.p; V.blk_obs = blk_obs.p;
+    V.Jpose = Jpose.p; V.Jcam = Jcam.p; V.Jpt = Jpt.p; V.res = res.p;
+    V.scale_c = scale_c.p; V.scale_p = scale_p.p; V.scalars = scalars.p;
+    // uploads / memsets above ran on the NULL stream, the solve runs on a non-blocking stream
+    BA_HIP(hipDeviceSynchronize());
+    return n;
+  }
+
+  void launch_linearize(bool jac, const double* P, const double* Cm, const double* X, int slot) {
+    const int g = grid_for(V.n_obs, 256);
+    if (jac) BA_LAUNCH(ba_linearize_kernel<true>, dim3(g), dim3(256), st, V, P, Cm, X, partials.p);
+    else BA_LAUNCH(ba_linearize_kernel<false>, dim3(g), dim3(256), st, V, P, Cm, X, partials.p);
+    BA_LAUNCH(ba_final_sum_kernel, dim3(1), dim3(1024), st, partials.p, g, scalars.p + slot);
+  }
+
+  // gradient of the (scaled) Jacobian and its squared column norms
+  void gradient_and_diag() {
+    BA_HIP(hipMemsetAsync(gc.p, 0, sizeof(double) * std::max(V.n_c, 1), st));
+    BA_HIP(hipMemsetAsync(diag_c.p, 0, sizeof(double) * std::max(V.n_c, 1), st));
+    if (V.n_chunks > 0)
+      BA_LAUNCH(ba_block_jtv_kernel<true>, dim3(V.n_chunks), dim3(64), st, V, res.p, gc.p, diag_c.p);
+    BA_LAUNCH(ba_point_grad_kernel, dim3(grid_for(V.n_points, 128)), dim3(128), st, V, gp.p, diag_p.p);
+  }
+
+  // q = S x = (B + Dc^2) x - E C^-1 E^T x
+  void schur_multiply(const double* xin, double* qout) {
+    const int go = grid_for(V.n_obs, 256);
+    BA_LAUNCH(ba_obs_jx_kernel, dim3(go), dim3(256), st, V, xin, jx.p);
+    BA_LAUNCH(ba_point_pass_kernel<0>, dim3(grid_for(V.n_points, 128)), dim3(128), st, V, Cinv.p,
+                       jx.p, gp.p, v.p, dp.p);
+    BA_LAUNCH(ba_dsq_x_kernel, dim3(grid_for(V.n_c, 256)), dim3(256), st, V.n_c, Dc.p, xin, qout);
+    BA_LAUNCH(ba_block_jtv_kernel<false>, dim3(V.n_chunks), dim3(64), st, V, v.p, qout, nullptr);
+  }
+
+  int pcg(int max_iter, double q_tol) {
+    const int n = V.n_c;
+    const int gv = grid_for(n, 256);
+    BA_HIP(hipMemsetAsync(x.p, 0, sizeof(double) * n, st));
+    BA_HIP(hipMemcpyAsync(r.p, rhs.p, sizeof(double) * n, hipMemcpyDeviceToDevice, st));
+    BA_LAUNCH(ba_dot_kernel, dim3(1), dim3(1024), st, n, rhs.p, rhs.p, scalars.p + S_RHO);
+    if (scalar(S_RHO) == 0.0) return 0;
+    double Q0 = 0.0;
+    int it;
+    for (it = 1; it <= max_iter; ++it) {
+      BA_HIP(hipMemcpyAsync(scalars.p + S_RHO_LAST, scalars.p + S_RHO, sizeof(double), hipMemcpyDeviceToDevice, st));
+      BA_LAUNCH(ba_pcg_precond_kernel, dim3(1), dim3(1024), st, V, Minv.p, r.p, z.p);
+      BA_LAUNCH(ba_pcg_dir_kernel, dim3(gv), dim3(256), st, n, scalars.p, it == 1 ? 1 : 0, z.p, pdir.p);
+      BA_HIP(hipEventRecord(ev0, st));
+      schur_multiply(pdir.p, q.p);
+      BA_HIP(hipEventRecord(ev1, st));
+      BA_LAUNCH(ba_dot_kernel, dim3(1), dim3(1024), st, n, pdir.p, q.p, scalars.p + S_PQ);
+      BA_LAUNCH(ba_pcg_update_kernel, dim3(1), dim3(1024), st, n, scalars.p, pdir.p, q.p, rhs.p, x.p, r.p);
+      double h[NSCALAR];
+      BA_HIP(hipMemcpyAsync(h, scalars.p, sizeof(h), hipMemcpyDeviceToHost, st));
+      BA_HIP(hipStreamSynchronize(st));
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) { g_spmv_ms += ms; g_spmv_launches += 1; }
+      const double rho = h[S_RHO], pq = h[S_PQ], Q1 = h[S_Q];
+      if (!(rho > 0.0) || !std::isfinite(rho) || !(pq > 0.0) || !std::isfinite(pq)) break;
+      const double zeta = it * (Q1 - Q0) / Q1;
+      if (zeta < q_tol) break;
+      Q0 = Q1;
+    }
+    return std::min(it, max_iter);
+  }
+
+  void apply_step(const double* sc, const double* sp, double* P2, double* C2, double* X2) {
+    BA_LAUNCH(ba_apply_pose_kernel, dim3(grid_for(V.n_poses, 128)), dim3(128), st, V, sc, poses.p, P2);
+    BA_LAUNCH(ba_apply_cam_kernel, dim3(grid_for(V.n_cams, 128)), dim3(128), st, V, sc, cams.p, C2);
+    BA_LAUNCH(ba_apply_point_kernel, dim3(grid_for(V.n_points, 128)), dim3(128), st, V, sp, points.p, X2);
+  }
+
+  void run(ba_result* out) {
+    BA_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    BA_HIP(hipEventCreate(&ev0));
+    BA_HIP(hipEventCreate(&ev1));
+    out->termination_type = BA_FAILURE;
+    const int n = build(out);
+    if (n == 0) return;
+    const int nc = V.n_c, np = V.n_p;
+    const int gvc = grid_for(nc, 256), gvp = grid_for(np, 256);
+    g_spmv_ms = 0.0; g_spmv_launches = 0;
+    // bytes one implicit-Schur product streams: Jc (2x10) once for jx, Jp (2x3) twice, jx/v, Jc again
+    g_spmv_bytes = (long long)n * (2 * (PD + KD) * 8 * 2 + 6 * 8 * 2 + 4 * 8 * 3);
+
+    double radius = opt.initial_trust_region_radius, decrease_factor = 2.0;
+    int invalid_steps = 0;
+    bool need_linearize = true, have_scale = false;
+    double cost = 0.0;
+    // scale = 1 until computed
+    BA_LAUNCH(ba_scale_kernel, dim3(std::max(gvc, 1)), dim3(256), st, nc, diag_c.p, 0, scale_c.p);
+    BA_LAUNCH(ba_scale_kernel, dim3(std::max(gvp, 1)), dim3(256), st, np, diag_p.p, 0, scale_p.p);
+    BA_HIP(hipStreamSynchronize(st));
+    const auto t_start = std::chrono::steady_clock::now();
+
+    for (int iter = 0;; ++iter) {
+      if (need_linearize) {
+        launch_linearize(true, poses.p, cams.p, points.p, S_COST);
+        gradient_and_diag();
+        if (!have_scale) {
+          // Jacobi scaling from the initial Jacobian, then re-linearise with it
+          BA_LAUNCH(ba_scale_kernel, dim3(std::max(gvc, 1)), dim3(256), st, nc, diag_c.p,
+                             opt.jacobi_scaling, scale_c.p);
+          BA_LAUNCH(ba_scale_kernel, dim3(std::max(gvp, 1)), dim3(256), st, np, diag_p.p,
+                             opt.jacobi_scaling, scale_p.p);
+          launch_linearize(true, poses.p, cams.p, points.p, S_COST);
+          gradient_and_diag();
+          have_scale = true;
+        }
+        cost = scalar(S_COST);
+        if (iter == 0) out->initial_cost = cost;
+        // projected-gradient test: ||x - Plus(x, -g)||_inf with the unscaled gradient g = s * g_scaled
+        // (the stored Jacobian is column-scaled: g_scaled = s * g, so g = g_scaled / s)
+        BA_LAUNCH(ba_scaled_div_kernel, dim3(std::max(gvc, 1)), dim3(256), st, nc, -1.0, gc.p, scale_c.p, stepc.p);
+        BA_LAUNCH(ba_scaled_div_kernel, dim3(std::max(gvp, 1)), dim3(256), st, np, -1.0, gp.p, scale_p.p, stepp.p);
+        apply_step(stepc.p, stepp.p, poses2.p, cams2.p, points2.p);
+        zero_scalar(S_GMAX);
+        BA_LAUNCH(ba_maxdiff_kernel, dim3(grid_for(poses.n, 256)), dim3(256), st, poses.n, poses.p, poses2.p, scalars.p);
+        BA_LAUNCH(ba_maxdiff_kernel, dim3(grid_for(cams.n, 256)), dim3(256), st, cams.n, cams.p, cams2.p, scalars.p);
+        BA_LAUNCH(ba_maxdiff_kernel, dim3(grid_for(points.n, 256)), dim3(256), st, points.n, points.p, points2.p, scalars.p);
+        const double gmax = scalar(S_GMAX);
+        if (gmax <= opt.gradient_tolerance) {
+          out->termination_type = BA_CONVERGENCE;
+          out->num_iterations = iter;
+          break;
+        }
+        need_linearize = false;
+      }
+      if (iter >= opt.max_num_iterations) {
+        out->termination_type = BA_NO_CONVERGENCE;
+        out->num_iterations = iter;
+        break;
+      }
+      // LM diagonal, point blocks, Schur-Jacobi preconditioner
+      BA_LAUNCH(ba_lm_diag_kernel, dim3(std::max(gvc, 1)), dim3(256), st, nc, diag_c.p, radius,
+                         opt.min_lm_diagonal, opt.max_lm_diagonal, Dc.p);
+      BA_LAUNCH(ba_lm_diag_kernel, dim3(std::max(gvp, 1)), dim3(256), st, np, diag_p.p, radius,
+                         opt.min_lm_diagonal, opt.max_lm_diagonal, Dp.p);
+      BA_LAUNCH(ba_point_blocks_kernel, dim3(grid_for(V.n_points, 128)), dim3(128), st, V, Dp.p, Cinv.p);
+      int lin_iters = 0;
+      if (nc > 0) {
+        BA_HIP(hipMemsetAsync(M.p, 0, sizeof(double) * std::max(moff_total, 1), st));
+        BA_LAUNCH(ba_block_gram_kernel, dim3(V.n_chunks), dim3(64), st, V, M.p);
+        BA_LAUNCH(ba_block_schur_corr_kernel, dim3(V.n_chunks), dim3(64), st, V, Cinv.p, M.p);
+        BA_LAUNCH(ba_block_invert_kernel, dim3(grid_for(V.n_blk, 64)), dim3(64), st, V, Dc.p, M.p, Minv.p);
+        // reduced rhs = g_c - E C^-1 g_p
+        BA_LAUNCH(ba_point_pass_kernel<1>, dim3(grid_for(V.n_points, 128)), dim3(128), st, V, Cinv.p,
+                           jx.p, gp.p, v.p, dp.p);
+        BA_HIP(hipMemcpyAsync(rhs.p, gc.p, sizeof(double) * nc, hipMemcpyDeviceToDevice, st));
+        BA_LAUNCH(ba_block_jtv_kernel<false>, dim3(V.n_chunks), dim3(64), st, V, v.p, rhs.p, nullptr);
+        lin_iters = pcg(opt.max_linear_solver_iterations, opt.eta);
+        out->total_linear_iterations += lin_iters;
+      }
+      // back-substitution y_p = C^-1 (g_p - E^T y_c); step = -(y_c, y_p)
+      BA_LAUNCH(ba_obs_jx_kernel, dim3(grid_for(V.n_obs, 256)), dim3(256), st, V, x.p, jx.p);
+      BA_LAUNCH(ba_point_pass_kernel<2>, dim3(grid_for(V.n_points, 128)), dim3(128), st, V, Cinv.p,
+                         jx.p, gp.p, v.p, dp.p);
+      BA_LAUNCH(ba_axpby_kernel, dim3(std::max(gvc, 1)), dim3(256), st, nc, -1.0, x.p, nullptr, stepc.p);
+      BA_LAUNCH(ba_axpby_kernel, dim3(std::max(gvp, 1)), dim3(256), st, np, -1.0, dp.p, nullptr, stepp.p);
+      BA_LAUNCH(ba_model_kernel, dim3(grid_for(V.n_obs, 256)), dim3(256), st, V, stepc.p, stepp.p, partials.p);
+      BA_LAUNCH(ba_final_sum_kernel, dim3(1), dim3(1024), st, partials.p, grid_for(V.n_obs, 256), scalars.p + S_MODEL);
+      const double model_change = scalar(S_MODEL);
+      bool accepted = false;
+      double new_cost = cost;
+      if (!(model_change > 0.0) || !std::isfinite(model_change)) {
+        if (++invalid_steps >= opt.max_num_consecutive_invalid_steps) {
+          out->termination_type = BA_FAILURE;
+          out->num_iterations = iter + 1;
+          break;
+        }
+        radius /= decrease_factor;
+        decrease_factor *= 2.0;
+      } else {
+        invalid_steps = 0;
+        // undo the Jacobi scaling of the step and evaluate the candidate
+        BA_LAUNCH(ba_axpby_kernel, dim3(std::max(gvc, 1)), dim3(256), st, nc, 1.0, stepc.p, scale_c.p, stepc.p);
+        BA_LAUNCH(ba_axpby_kernel, dim3(std::max(gvp, 1)), dim3(256), st, np, 1.0, stepp.p, scale_p.p, stepp.p);
+        apply_step(stepc.p, stepp.p, poses2.p, cams2.p, points2.p);
+        launch_linearize(false, poses2.p, cams2.p, points2.p, S_NEWCOST);
+        new_cost = scalar(S_NEWCOST);
+        const double rho = (cost - new_cost) / model_change;
+        if (rho > opt.min_relative_decrease) {
+          accepted = true;
+          std::swap(poses.p, poses2.p);
+          std::swap(cams.p, cams2.p);
+          std::swap(points.p, points2.p);
+          V.poses = poses.p; V.cams = cams.p; V.points = points.p;
+          const double t = 2.0 * rho - 1.0;
+          radius = radius / std::max(1.0 / 3.0, 1.0 - t * t * t);
+          radius = std::min(opt.max_trust_region_radius, radius);
+          decrease_factor = 2.0;
+          out->num_successful_steps++;
+          need_linearize = true;
+          if (opt.function_tolerance > 0 && std::fabs(cost - new_cost) <= opt.function_tolerance * cost) {
+            log(out, new_cost, radius, lin_iters);
+            out->termination_type = BA_CONVERGENCE;
+            out->num_iterations = iter + 1;
+            break;
+          }
+        } else {
+          radius /= decrease_factor;
+          decrease_factor *= 2.0;
+        }
+      }
+      log(out, accepted ? new_cost : cost, radius, lin_iters);
+      if (radius < opt.min_trust_region_radius) {
+        out->termination_type = BA_CONVERGENCE;
+        out->num_iterations = iter + 1;
+        break;
+      }
+    }
+    launch_linearize(false, poses.p, cams.p, points.p, S_NEWCOST);
+    out->final_cost = scalar(S_NEWCOST);
+    out->lm_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+    BA_LAUNCH(ba_renorm_quat_kernel, dim3(grid_for(V.n_poses, 128)), dim3(128), st, V, poses.p);
+    // write back variable blocks only (constant blocks stay bit-identical)
+    std::vector<double> hp(poses.n), hc(cams.n), hx(points.n);
+    BA_HIP(hipMemcpyAsync(hp.data(), poses.p, sizeof(double) * poses.n, hipMemcpyDeviceToHost, st));
+    BA_HIP(hipMemcpyAsync(hc.data(), cams.p, sizeof(double) * cams.n, hipMemcpyDeviceToHost, st));
+    BA_HIP(hipMemcpyAsync(hx.data(), points.p, sizeof(double) * points.n, hipMemcpyDeviceToHost, st));
+    BA_HIP(hipStreamSynchronize(st));
+    for (int i = 0; i < prob.num_poses; ++i)
+      if (h_pose_off[i] >= 0) std::memcpy(prob.poses + 7 * (size_t)i, hp.data() + 7 * (size_t)i, 7 * sizeof(double));
+    for (int k = 0; k < prob.num_cams; ++k)
+      if (h_cam_off[k] >= 0)
+        std::memcpy(prob.cams + BA_CAM_STRIDE * (size_t)k, hc.data() + BA_CAM_STRIDE * (size_t)k,
+                    BA_CAM_STRIDE * sizeof(double));
+    for (int j = 0; j < prob.num_points; ++j)
+      if (h_pt_off[j] >= 0) std::memcpy(prob.points + 3 * (size_t)j, hx.data() + 3 * (size_t)j, 3 * sizeof(double));
+  }
+
+  void log(ba_result* out, double c, double rad, int lin) {
+    if (out->log_cost && out->num_logged < opt.max_log) {
+      out->log_cost[out->num_logged] = c;
+      if (out->log_radius) out->log_radius[out->num_logged] = rad;
+      if (out->log_linear_iters) out->log_linear_iters[out->num_logged] = lin;
+      out->num_logged++;
+    }
+  }
+};
+
+}  // namespace
+
+extern "C" {
+
+void ba_options_init(ba_options* o) {
+  // CeresBundleAdjustmentOptions ctor (bundle_adjustment_ceres.cc:102-115) over Ceres defaults
+  std::memset(o, 0, sizeof(*o));
+  o->max_num_iterations = 100;
+  o->max_linear_solver_iterations = 200;
+  o->function_tolerance = 0.0;
+  o->gradient_tolerance = 1e-4;
+  o->parameter_tolerance = 0.0;
+  o->initial_trust_region_radius = 1e4;
+  o->max_trust_region_radius = 1e16;
+  o->min_trust_region_radius = 1e-32;
+  o->min_relative_decrease = 1e-3;
+  o->min_lm_diagonal = 1e-6;
+  o->max_lm_diagonal = 1e32;
+  o->eta = 1e-1;
+  o->max_num_consecutive_invalid_steps = 10;
+  o->jacobi_scaling = 1;
+}
+
+int ba_solve(ba_problem* problem, const ba_options* options, int32_t gpu_index, ba_result* result) {
+  try {
+    if (!problem || !options || !result) throw std::runtime_error("null argument");
+    double* lc = result->log_cost;
+    double* lr = result->log_radius;
+    int32_t* ll = result->log_linear_iters;
+    std::memset(result, 0, sizeof(*result));
+    result->log_cost = lc; result->log_radius = lr; result->log_linear_iters = ll;
+    result->termination_type = BA_FAILURE;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+      throw std::runtime_error("no HIP device available: the MI355X bundle-adjustment backend has no CPU fallback");
+    if (gpu_index >= ndev) throw std::runtime_error("gpu_index out of range");
+    if (gpu_index >= 0) BA_HIP(hipSetDevice(gpu_index));
+    Solver s(*problem, *options);
+    s.run(result);
+    return 0;
+  } catch (const std::exception& e) {
+    g_ba_error = e.what();
+    return 1;
+  }
+}
+
+int ba_last_spmv_timing(double* total_ms, int64_t* launches, int64_t* bytes_per_launch) {
+  if (total_ms) *total_ms = g_spmv_ms;
+  if (launches) *launches = g_spmv_launches;
+  if (bytes_per_launch) *bytes_per_launch = g_spmv_bytes;
+  return 0;
+}
+
+const char* ba_last_error(void) { return g_ba_error.c_str(); }
+
+}  // extern "C"

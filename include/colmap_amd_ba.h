@@ -1,0 +1,105 @@
+/*
+ * colmap_amd_ba.h -- C ABI of the MI355X-native bundle-adjustment solve.
+ *
+ * Drop-in boundary: colmap::BundleAdjuster::Solve() behind
+ * CreateDefaultBundleAdjuster (reference src/colmap/estimators/bundle_adjustment.h:212-234,
+ * bundle_adjustment.cc:314-334), as a third BundleAdjustmentBackend value next to CERES and
+ * CASPAR (bundle_adjustment.h:60). The adapter (a BundleAdjuster subclass, see
+ * INTEGRATION.md) flattens the Reconstruction into `ba_problem` exactly like
+ * CasparBundleAdjuster does for its solver (bundle_adjustment_caspar.cc:61-377), calls
+ * ba_solve(), and writes the variable blocks back (:767-801). ba_solve() replaces
+ * ceres::Solve (bundle_adjustment_ceres.cc:582) with its COLMAP-side cost functions
+ * (cost_functions/reprojection_error.h:61-212, sensor/models_jacobian.h:139-321): a
+ * Levenberg-Marquardt loop whose linear step is an implicit-Schur preconditioned CG
+ * (Ceres ITERATIVE_SCHUR + SCHUR_JACOBI, bundle_adjustment_ceres.cc:203-213) on the GPU.
+ *
+ * Plain C types only; arrays are host memory, row-major, updated in place for variable blocks.
+ * Returns 0 on success; ba_last_error() holds the message otherwise. No CPU fallback.
+ */
+#ifndef COLMAP_AMD_BA_H_
+#define COLMAP_AMD_BA_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BA_CAM_STRIDE 12 /* doubles reserved per camera parameter block */
+
+/* colmap::CameraModelId values of the supported models (sensor/models.h:90-111) */
+enum { BA_SIMPLE_PINHOLE = 0, BA_PINHOLE = 1, BA_SIMPLE_RADIAL = 2 };
+
+typedef struct ba_problem {
+  int32_t num_poses, num_cams, num_points;
+  int64_t num_obs;
+  double* poses;      /* [num_poses][7]  Rigid3d::params: qx qy qz qw tx ty tz (geometry/rigid3.h:46-70) */
+  double* cams;       /* [num_cams][BA_CAM_STRIDE]  Camera::params (scene/camera.h:61) */
+  int32_t* cam_model; /* [num_cams] */
+  double* points;     /* [num_points][3]  Point3D::xyz */
+  int32_t* obs_pose;  /* [num_obs] index of the cam_from_world pose block */
+  int32_t* obs_cam;   /* [num_obs] index of the camera (intrinsics) block */
+  int32_t* obs_point; /* [num_obs] index of the 3-D point block */
+  double* obs_xy;     /* [num_obs][2] Point2D::xy */
+  /* constant-ness, as ceres::Problem would hold it after DefaultBundleAdjuster's ctor */
+  uint8_t* pose_const;   /* [num_poses] SetParameterBlockConstant */
+  int8_t* pose_fixed_t;  /* [num_poses] -1, or the translation coordinate the gauge holds
+                            (SubsetManifold, bundle_adjustment_ceres.cc:402-415) */
+  uint8_t* cam_const;    /* [num_cams][BA_CAM_STRIDE] per-parameter mask (SubsetManifold, :419-469) */
+  uint8_t* point_const;  /* [num_points] */
+} ba_problem;
+
+/* ceres::Solver::Options fields that reach the solve (COLMAP's values:
+ * bundle_adjustment_ceres.cc:102-115; the rest are Ceres defaults). */
+typedef struct ba_options {
+  int32_t max_num_iterations;           /* 100 */
+  int32_t max_linear_solver_iterations; /* 200 */
+  double function_tolerance;            /* 0 */
+  double gradient_tolerance;            /* 1e-4 */
+  double parameter_tolerance;           /* 0 */
+  double initial_trust_region_radius;   /* 1e4 */
+  double max_trust_region_radius;       /* 1e16 */
+  double min_trust_region_radius;       /* 1e-32 */
+  double min_relative_decrease;         /* 1e-3 */
+  double min_lm_diagonal;               /* 1e-6 */
+  double max_lm_diagonal;               /* 1e32 */
+  double eta;                           /* 1e-1: inexact-Newton forcing, CG Q-tolerance */
+  int32_t max_num_consecutive_invalid_steps; /* 10 */
+  int32_t jacobi_scaling;               /* 1 */
+  int32_t num_threads;                  /* unused on the GPU */
+  int32_t max_log;                      /* capacity of the log arrays in ba_result */
+} ba_options;
+
+/* colmap::BundleAdjustmentTerminationType (bundle_adjustment.h:50-57) */
+enum { BA_CONVERGENCE = 0, BA_NO_CONVERGENCE = 1, BA_FAILURE = 2 };
+
+/* colmap::BundleAdjustmentSummary (bundle_adjustment.h:63-74) + solver statistics */
+typedef struct ba_result {
+  int32_t termination_type;
+  int32_t num_residuals;             /* residuals touching >= 1 variable block */
+  int32_t num_iterations, num_successful_steps;
+  int32_t num_effective_parameters;
+  int64_t total_linear_iterations;
+  double initial_cost, final_cost;
+  double lm_seconds;                 /* wall time of the LM loop, inputs resident in HBM */
+  int32_t num_logged;
+  double* log_cost;                  /* [max_log] or NULL */
+  double* log_radius;
+  int32_t* log_linear_iters;
+} ba_result;
+
+void ba_options_init(ba_options* options);
+
+/* BundleAdjuster::Solve for a flattened problem. gpu_index: device ordinal, -1 = current. */
+int ba_solve(ba_problem* problem, const ba_options* options, int32_t gpu_index, ba_result* result);
+
+/* Per-kernel HIP-event timing of the last ba_solve on this thread (roofline accounting):
+ * milliseconds and launch count of the dominant kernel family (implicit Schur product). */
+int ba_last_spmv_timing(double* total_ms, int64_t* launches, int64_t* bytes_per_launch);
+
+const char* ba_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COLMAP_AMD_BA_H_ */

@@ -291,13 +291,17 @@ typedef struct {
   int* cam_var;        /* [num_cams][12] indices of variable params */
   int* point_off;      /* [num_points] offset into point-side vector (3 each), -1 const */
   int n_c, n_p;        /* sizes of camera-side / point-side tangent vectors */
-  /* CSR by point and by pose/cam of active observation slots */
+  /* CSR by point and by camera-side block of active observation slots */
   int64_t *pt_ptr, *pt_idx;
+  int n_blk;
+  int *blk_off, *blk_dim, *blk_kind; /* kind 0: pose block, 1: intrinsics block */
+  int64_t *blk_ptr, *blk_idx;
 } program;
 
 static void program_free(program* g) {
   free(g->obs); free(g->pose_off); free(g->pose_dim); free(g->cam_off); free(g->cam_dim);
   free(g->cam_var); free(g->point_off); free(g->pt_ptr); free(g->pt_idx);
+  free(g->blk_off); free(g->blk_dim); free(g->blk_kind); free(g->blk_ptr); free(g->blk_idx);
 }
 
 static void program_build(program* g, const bao_problem* p) {
@@ -362,8 +366,46 @@ static void program_build(program* g, const bao_problem* p) {
     const int j = p->obs_point[g->obs[a]];
     g->pt_idx[g->pt_ptr[j] + fill[j]++] = a;
   }
-  free(fill); free(pose_used); free(cam_used); free(point_used); free(cam_nvar);
+  free(fill);
+  /* camera-side blocks and their observation lists */
+  g->blk_off = (int*)malloc(sizeof(int) * (p->num_poses + p->num_cams + 1));
+  g->blk_dim = (int*)malloc(sizeof(int) * (p->num_poses + p->num_cams + 1));
+  g->blk_kind = (int*)malloc(sizeof(int) * (p->num_poses + p->num_cams + 1));
+  int* blk_of_pose = (int*)malloc(sizeof(int) * (p->num_poses + 1));
+  int* blk_of_cam = (int*)malloc(sizeof(int) * (p->num_cams + 1));
+  for (int i = 0; i < p->num_poses; ++i) {
+    blk_of_pose[i] = -1;
+    if (g->pose_off[i] < 0) continue;
+    blk_of_pose[i] = g->n_blk;
+    g->blk_off[g->n_blk] = g->pose_off[i]; g->blk_dim[g->n_blk] = g->pose_dim[i]; g->blk_kind[g->n_blk++] = 0;
+  }
+  for (int k = 0; k < p->num_cams; ++k) {
+    blk_of_cam[k] = -1;
+    if (g->cam_off[k] < 0) continue;
+    blk_of_cam[k] = g->n_blk;
+    g->blk_off[g->n_blk] = g->cam_off[k]; g->blk_dim[g->n_blk] = g->cam_dim[k]; g->blk_kind[g->n_blk++] = 1;
+  }
+  g->blk_ptr = (int64_t*)calloc((size_t)g->n_blk + 2, sizeof(int64_t));
+  for (int64_t a = 0; a < g->n_obs; ++a) {
+    const int bp = blk_of_pose[p->obs_pose[g->obs[a]]], bc = blk_of_cam[p->obs_cam[g->obs[a]]];
+    if (bp >= 0) g->blk_ptr[bp + 1]++;
+    if (bc >= 0) g->blk_ptr[bc + 1]++;
+  }
+  for (int b = 0; b < g->n_blk; ++b) g->blk_ptr[b + 1] += g->blk_ptr[b];
+  g->blk_idx = (int64_t*)malloc(sizeof(int64_t) * (g->blk_ptr[g->n_blk] + 1));
+  int64_t* bfill = (int64_t*)calloc((size_t)g->n_blk + 1, sizeof(int64_t));
+  for (int64_t a = 0; a < g->n_obs; ++a) {
+    const int bp = blk_of_pose[p->obs_pose[g->obs[a]]], bc = blk_of_cam[p->obs_cam[g->obs[a]]];
+    if (bp >= 0) g->blk_idx[g->blk_ptr[bp] + bfill[bp]++] = a;
+    if (bc >= 0) g->blk_idx[g->blk_ptr[bc] + bfill[bc]++] = a;
+  }
+  free(bfill); free(blk_of_pose); free(blk_of_cam);
+  free(pose_used); free(cam_used); free(point_used); free(cam_nvar);
 }
+
+/* OpenMP only pays off on large problems (and a 128-thread team spinning on a 40-point loop
+ * is pathologically slow) */
+#define BAO_PAR(n) if ((n) > 20000)
 
 /* per-active-observation linearisation in the tangent space */
 typedef struct {
@@ -417,7 +459,7 @@ static void linearize_obs(const program* g, const double* poses, const double* c
 static double evaluate_cost(const program* g, const double* poses, const double* cams,
                             const double* points) {
   double cost = 0.0;
-#pragma omp parallel for reduction(+ : cost) schedule(static)
+#pragma omp parallel for reduction(+ : cost) schedule(static) BAO_PAR(g->n_obs)
   for (int64_t a = 0; a < g->n_obs; ++a) {
     lin_obs L;
     linearize_obs(g, poses, cams, points, a, &L, 0);
@@ -512,7 +554,7 @@ static void schur_multiply(const linsys* s, const double* x, double* y, double* 
   const program* g = s->g;
   const bao_problem* p = g->p;
   /* point pass: u_j = C_j^-1 E_j^T x */
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) BAO_PAR(g->n_obs)
   for (int j = 0; j < p->num_points; ++j) {
     if (g->point_off[j] < 0) continue;
     double t[3] = {0, 0, 0};
@@ -534,25 +576,31 @@ static void schur_multiply(const linsys* s, const double* x, double* y, double* 
     double* u = tmp_p + g->point_off[j];
     for (int r = 0; r < 3; ++r) u[r] = Ci[3 * r] * t[0] + Ci[3 * r + 1] * t[1] + Ci[3 * r + 2] * t[2];
   }
-  /* camera pass: y = Dc^2 x + sum_obs Jc^T (Jc x - Jp u) */
-  for (int i = 0; i < g->n_c; ++i) y[i] = s->Dc[i] * s->Dc[i] * x[i];
-  for (int64_t a = 0; a < g->n_obs; ++a) {
-    const lin_obs* L = &s->L[a];
-    int po, co;
-    cam_offsets(g, a, &po, &co);
-    const int w = L->pose_dim + L->cam_dim;
-    if (w == 0) continue;
-    double xc[MAX_CB];
-    gather_c(g, L, po, co, x, xc);
-    const int xi = p->obs_point[g->obs[a]];
-    const double* u = g->point_off[xi] >= 0 ? tmp_p + g->point_off[xi] : NULL;
-    for (int r = 0; r < 2; ++r) {
-      double v = 0.0;
-      for (int d = 0; d < w; ++d) v += L->Jc[r][d] * xc[d];
-      if (u) v -= L->Jp[r][0] * u[0] + L->Jp[r][1] * u[1] + L->Jp[r][2] * u[2];
-      for (int d = 0; d < L->pose_dim; ++d) y[po + d] += L->Jc[r][d] * v;
-      for (int d = 0; d < L->cam_dim; ++d) y[co + d] += L->Jc[r][L->pose_dim + d] * v;
+  /* camera pass: y = Dc^2 x + sum_obs Jc^T (Jc x - Jp u), accumulated block by block */
+#pragma omp parallel for schedule(dynamic, 8) BAO_PAR(g->n_obs)
+  for (int b = 0; b < g->n_blk; ++b) {
+    const int off = g->blk_off[b], dim = g->blk_dim[b], kind = g->blk_kind[b];
+    double acc[MAX_CB];
+    for (int d = 0; d < dim; ++d) acc[d] = s->Dc[off + d] * s->Dc[off + d] * x[off + d];
+    for (int64_t k = g->blk_ptr[b]; k < g->blk_ptr[b + 1]; ++k) {
+      const int64_t a = g->blk_idx[k];
+      const lin_obs* L = &s->L[a];
+      int po, co;
+      cam_offsets(g, a, &po, &co);
+      const int w = L->pose_dim + L->cam_dim;
+      double xc[MAX_CB];
+      gather_c(g, L, po, co, x, xc);
+      const int xi = p->obs_point[g->obs[a]];
+      const double* u = g->point_off[xi] >= 0 ? tmp_p + g->point_off[xi] : NULL;
+      const int base = kind == 0 ? 0 : L->pose_dim;
+      for (int r = 0; r < 2; ++r) {
+        double v = 0.0;
+        for (int d = 0; d < w; ++d) v += L->Jc[r][d] * xc[d];
+        if (u) v -= L->Jp[r][0] * u[0] + L->Jp[r][1] * u[1] + L->Jp[r][2] * u[2];
+        for (int d = 0; d < dim; ++d) acc[d] += L->Jc[r][base + d] * v;
+      }
     }
+    for (int d = 0; d < dim; ++d) y[off + d] = acc[d];
   }
 }
 
@@ -667,15 +715,16 @@ BAO_API int bao_solve(bao_problem* p, const bao_options* opt, bao_result* res) {
   s.Dc = (double*)calloc(nc + 1, sizeof(double));
   s.Dp = (double*)calloc(np + 1, sizeof(double));
   s.Cinv = (double*)calloc((size_t)p->num_points * 9 + 1, sizeof(double));
-  /* camera-side blocks */
-  s.blk_off = (int*)malloc(sizeof(int) * (p->num_poses + p->num_cams + 1));
-  s.blk_dim = (int*)malloc(sizeof(int) * (p->num_poses + p->num_cams + 1));
-  s.blk_moff = (int64_t*)malloc(sizeof(int64_t) * (p->num_poses + p->num_cams + 1));
+  /* camera-side blocks (same order as program.blk_*) */
+  s.blk_off = (int*)malloc(sizeof(int) * (g.n_blk + 1));
+  s.blk_dim = (int*)malloc(sizeof(int) * (g.n_blk + 1));
+  s.blk_moff = (int64_t*)malloc(sizeof(int64_t) * (g.n_blk + 1));
   int64_t moff = 0;
-  for (int i = 0; i < p->num_poses; ++i)
-    if (g.pose_off[i] >= 0) { s.blk_off[s.n_blk] = g.pose_off[i]; s.blk_dim[s.n_blk] = g.pose_dim[i]; s.blk_moff[s.n_blk++] = moff; moff += g.pose_dim[i] * g.pose_dim[i]; }
-  for (int k = 0; k < p->num_cams; ++k)
-    if (g.cam_off[k] >= 0) { s.blk_off[s.n_blk] = g.cam_off[k]; s.blk_dim[s.n_blk] = g.cam_dim[k]; s.blk_moff[s.n_blk++] = moff; moff += g.cam_dim[k] * g.cam_dim[k]; }
+  for (int b = 0; b < g.n_blk; ++b) {
+    s.blk_off[b] = g.blk_off[b]; s.blk_dim[b] = g.blk_dim[b]; s.blk_moff[b] = moff;
+    moff += g.blk_dim[b] * g.blk_dim[b];
+  }
+  s.n_blk = g.n_blk;
   s.Minv = (double*)calloc(moff + 1, sizeof(double));
   int* blk_of = (int*)malloc(sizeof(int) * (nc + 1)); /* camera-side index -> block */
   for (int b = 0; b < s.n_blk; ++b) for (int d = 0; d < s.blk_dim[b]; ++d) blk_of[s.blk_off[b] + d] = b;
@@ -707,26 +756,37 @@ BAO_API int bao_solve(bao_problem* p, const bao_options* opt, bao_result* res) {
     if (need_linearize) {
       /* residuals + Jacobians (Evaluate) */
       double c = 0.0;
-#pragma omp parallel for reduction(+ : c) schedule(static)
+#pragma omp parallel for reduction(+ : c) schedule(static) BAO_PAR(g.n_obs)
       for (int64_t a = 0; a < g.n_obs; ++a) {
         linearize_obs(&g, p->poses, p->cams, p->points, a, &s.L[a], 1);
         c += 0.5 * (s.L[a].r[0] * s.L[a].r[0] + s.L[a].r[1] * s.L[a].r[1]);
       }
       cost = c;
       if (iter == 0) res->initial_cost = cost;
-      /* gradient (unscaled) g = J^T r, and column norms */
-      memset(gc, 0, sizeof(double) * nc); memset(gp, 0, sizeof(double) * np);
-      memset(diag_c, 0, sizeof(double) * nc); memset(diag_p, 0, sizeof(double) * np);
-      for (int64_t a = 0; a < g.n_obs; ++a) {
-        const lin_obs* L = &s.L[a];
-        int po, co; cam_offsets(&g, a, &po, &co);
-        const int xi = p->obs_point[g.obs[a]];
-        const int pto = g.point_off[xi];
-        for (int r = 0; r < 2; ++r) {
-          for (int d = 0; d < L->pose_dim; ++d) { gc[po + d] += L->Jc[r][d] * L->r[r]; diag_c[po + d] += L->Jc[r][d] * L->Jc[r][d]; }
-          for (int d = 0; d < L->cam_dim; ++d) { const double v = L->Jc[r][L->pose_dim + d]; gc[co + d] += v * L->r[r]; diag_c[co + d] += v * v; }
-          if (pto >= 0) for (int c2 = 0; c2 < 3; ++c2) { gp[pto + c2] += L->Jp[r][c2] * L->r[r]; diag_p[pto + c2] += L->Jp[r][c2] * L->Jp[r][c2]; }
+      /* gradient (unscaled) g = J^T r, and column norms: camera side per block, point side per point */
+#pragma omp parallel for schedule(dynamic, 8) BAO_PAR(g.n_obs)
+      for (int b = 0; b < g.n_blk; ++b) {
+        const int off = g.blk_off[b], dim = g.blk_dim[b], kind = g.blk_kind[b];
+        double ga[MAX_CB] = {0}, da[MAX_CB] = {0};
+        for (int64_t k = g.blk_ptr[b]; k < g.blk_ptr[b + 1]; ++k) {
+          const lin_obs* L = &s.L[g.blk_idx[k]];
+          const int base = kind == 0 ? 0 : L->pose_dim;
+          for (int r = 0; r < 2; ++r)
+            for (int d = 0; d < dim; ++d) { const double v = L->Jc[r][base + d]; ga[d] += v * L->r[r]; da[d] += v * v; }
         }
+        for (int d = 0; d < dim; ++d) { gc[off + d] = ga[d]; diag_c[off + d] = da[d]; }
+      }
+#pragma omp parallel for schedule(static) BAO_PAR(g.n_obs)
+      for (int j = 0; j < p->num_points; ++j) {
+        const int pto = g.point_off[j];
+        if (pto < 0) continue;
+        double ga[3] = {0, 0, 0}, da[3] = {0, 0, 0};
+        for (int64_t k = g.pt_ptr[j]; k < g.pt_ptr[j + 1]; ++k) {
+          const lin_obs* L = &s.L[g.pt_idx[k]];
+          for (int r = 0; r < 2; ++r)
+            for (int c2 = 0; c2 < 3; ++c2) { ga[c2] += L->Jp[r][c2] * L->r[r]; da[c2] += L->Jp[r][c2] * L->Jp[r][c2]; }
+        }
+        for (int c2 = 0; c2 < 3; ++c2) { gp[pto + c2] = ga[c2]; diag_p[pto + c2] = da[c2]; }
       }
       /* convergence test on the projected gradient: ||x - Plus(x, -g)||_inf */
       {
@@ -746,7 +806,7 @@ BAO_API int bao_solve(bao_problem* p, const bao_options* opt, bao_result* res) {
         have_scale = 1;
       }
       /* scale the Jacobian columns in place */
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) BAO_PAR(g.n_obs)
       for (int64_t a = 0; a < g.n_obs; ++a) {
         lin_obs* L = &s.L[a];
         int po, co; cam_offsets(&g, a, &po, &co);
@@ -769,7 +829,7 @@ BAO_API int bao_solve(bao_problem* p, const bao_options* opt, bao_result* res) {
 
     /* point blocks C_j = E_j^T E_j + Dp^2 and their inverses; camera blocks of B + Dc^2 */
     memset(Mblk, 0, sizeof(double) * moff);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) BAO_PAR(g.n_obs)
     for (int j = 0; j < p->num_points; ++j) {
       if (g.point_off[j] < 0) continue;
       double C[9] = {0};
@@ -782,61 +842,43 @@ BAO_API int bao_solve(bao_problem* p, const bao_options* opt, bao_result* res) {
       for (int x = 0; x < 3; ++x) C[4 * x] += s.Dp[g.point_off[j] + x] * s.Dp[g.point_off[j] + x];
       invert_sym(C, 3, s.Cinv + 9 * (size_t)j);
     }
-    /* SCHUR_JACOBI: block diagonal of S = B + Dc^2 - E C^-1 E^T, per camera-side block */
-    for (int64_t a = 0; a < g.n_obs; ++a) {
-      const lin_obs* L = &s.L[a];
-      int po, co; cam_offsets(&g, a, &po, &co);
-      for (int part = 0; part < 2; ++part) {
-        const int off = part == 0 ? po : co;
-        const int dim = part == 0 ? L->pose_dim : L->cam_dim;
-        const int base = part == 0 ? 0 : L->pose_dim;
-        if (dim == 0) continue;
-        double* M = Mblk + s.blk_moff[blk_of[off]];
+    /* SCHUR_JACOBI: block diagonal of S = B + Dc^2 - E C^-1 E^T, per camera-side block:
+     * B_bb = sum_o J_b,o^T J_b,o ; correction = sum over pairs (o, o') of observations of the
+     * same point that share the block of W_o C^-1 W_o'^T with W = J_b^T J_p */
+#pragma omp parallel for schedule(dynamic, 8) BAO_PAR(g.n_obs)
+    for (int b = 0; b < s.n_blk; ++b) {
+      const int off = g.blk_off[b], dim = g.blk_dim[b], kind = g.blk_kind[b];
+      double* M = Mblk + s.blk_moff[b];
+      for (int64_t k = g.blk_ptr[b]; k < g.blk_ptr[b + 1]; ++k) {
+        const int64_t a1 = g.blk_idx[k];
+        const lin_obs* L1 = &s.L[a1];
+        const int b1 = kind == 0 ? 0 : L1->pose_dim;
         for (int r = 0; r < 2; ++r)
           for (int x = 0; x < dim; ++x)
-            for (int y = 0; y < dim; ++y) M[x * dim + y] += L->Jc[r][base + x] * L->Jc[r][base + y];
-      }
-    }
-    /* - sum_j (E_ij C_j^-1 E_ij'^T) restricted to the diagonal blocks: for each point, for each
-     * pair of its observations that share the same camera-side block */
-    for (int j = 0; j < p->num_points; ++j) {
-      if (g.point_off[j] < 0) continue;
-      const double* Ci = s.Cinv + 9 * (size_t)j;
-      for (int64_t k1 = g.pt_ptr[j]; k1 < g.pt_ptr[j + 1]; ++k1) {
-        const int64_t a1 = g.pt_idx[k1];
-        const lin_obs* L1 = &s.L[a1];
-        int po1, co1; cam_offsets(&g, a1, &po1, &co1);
+            for (int y = 0; y < dim; ++y) M[x * dim + y] += L1->Jc[r][b1 + x] * L1->Jc[r][b1 + y];
+        const int j = p->obs_point[g.obs[a1]];
+        if (g.point_off[j] < 0) continue;
+        const double* Ci = s.Cinv + 9 * (size_t)j;
+        double W1[MAX_CB][3], T[MAX_CB][3];
+        for (int x = 0; x < dim; ++x)
+          for (int c = 0; c < 3; ++c) W1[x][c] = L1->Jc[0][b1 + x] * L1->Jp[0][c] + L1->Jc[1][b1 + x] * L1->Jp[1][c];
+        for (int x = 0; x < dim; ++x)
+          for (int c = 0; c < 3; ++c) T[x][c] = W1[x][0] * Ci[c] + W1[x][1] * Ci[3 + c] + W1[x][2] * Ci[6 + c];
         for (int64_t k2 = g.pt_ptr[j]; k2 < g.pt_ptr[j + 1]; ++k2) {
           const int64_t a2 = g.pt_idx[k2];
-          const lin_obs* L2 = &s.L[a2];
           int po2, co2; cam_offsets(&g, a2, &po2, &co2);
-          for (int part = 0; part < 2; ++part) {
-            const int off1 = part == 0 ? po1 : co1, off2 = part == 0 ? po2 : co2;
-            if (off1 < 0 || off1 != off2) continue;
-            const int dim = part == 0 ? L1->pose_dim : L1->cam_dim;
-            const int b1 = part == 0 ? 0 : L1->pose_dim, b2 = part == 0 ? 0 : L2->pose_dim;
-            /* W1 = Jc1^T Jp1 (dim x 3), W2 likewise; M -= W1 Cinv W2^T */
-            double W1[MAX_CB][3], W2[MAX_CB][3];
-            for (int x = 0; x < dim; ++x)
-              for (int c = 0; c < 3; ++c) {
-                W1[x][c] = L1->Jc[0][b1 + x] * L1->Jp[0][c] + L1->Jc[1][b1 + x] * L1->Jp[1][c];
-                W2[x][c] = L2->Jc[0][b2 + x] * L2->Jp[0][c] + L2->Jc[1][b2 + x] * L2->Jp[1][c];
-              }
-            double* M = Mblk + s.blk_moff[blk_of[off1]];
-            for (int x = 0; x < dim; ++x) {
-              double t[3];
-              for (int c = 0; c < 3; ++c) t[c] = W1[x][0] * Ci[c] + W1[x][1] * Ci[3 + c] + W1[x][2] * Ci[6 + c];
-              for (int y = 0; y < dim; ++y) M[x * dim + y] -= t[0] * W2[y][0] + t[1] * W2[y][1] + t[2] * W2[y][2];
-            }
+          if ((kind == 0 ? po2 : co2) != off) continue;
+          const lin_obs* L2 = &s.L[a2];
+          const int b2 = kind == 0 ? 0 : L2->pose_dim;
+          for (int y = 0; y < dim; ++y) {
+            double W2[3];
+            for (int c = 0; c < 3; ++c) W2[c] = L2->Jc[0][b2 + y] * L2->Jp[0][c] + L2->Jc[1][b2 + y] * L2->Jp[1][c];
+            for (int x = 0; x < dim; ++x) M[x * dim + y] -= T[x][0] * W2[0] + T[x][1] * W2[1] + T[x][2] * W2[2];
           }
         }
       }
-    }
-    for (int b = 0; b < s.n_blk; ++b) {
-      const int n = s.blk_dim[b];
-      double* M = Mblk + s.blk_moff[b];
-      for (int d = 0; d < n; ++d) M[d * n + d] += s.Dc[s.blk_off[b] + d] * s.Dc[s.blk_off[b] + d];
-      invert_sym(M, n, s.Minv + s.blk_moff[b]);
+      for (int d = 0; d < dim; ++d) M[d * dim + d] += s.Dc[off + d] * s.Dc[off + d];
+      invert_sym(M, dim, s.Minv + s.blk_moff[b]);
     }
 
     /* reduced right-hand side: solve (J^T J + D^2) y = J^T r ; step = -y.
@@ -849,17 +891,23 @@ BAO_API int bao_solve(bao_problem* p, const bao_options* opt, bao_result* res) {
         const double* gj = gp + g.point_off[j];
         for (int r = 0; r < 3; ++r) u[g.point_off[j] + r] = Ci[3 * r] * gj[0] + Ci[3 * r + 1] * gj[1] + Ci[3 * r + 2] * gj[2];
       }
-      memcpy(rhs, gc, sizeof(double) * nc);
-      for (int64_t a = 0; a < g.n_obs; ++a) {
-        const lin_obs* L = &s.L[a];
-        int po, co; cam_offsets(&g, a, &po, &co);
-        const int pto = g.point_off[p->obs_point[g.obs[a]]];
-        if (pto < 0) continue;
-        for (int r = 0; r < 2; ++r) {
-          const double v = L->Jp[r][0] * u[pto] + L->Jp[r][1] * u[pto + 1] + L->Jp[r][2] * u[pto + 2];
-          for (int d = 0; d < L->pose_dim; ++d) rhs[po + d] -= L->Jc[r][d] * v;
-          for (int d = 0; d < L->cam_dim; ++d) rhs[co + d] -= L->Jc[r][L->pose_dim + d] * v;
+#pragma omp parallel for schedule(dynamic, 8) BAO_PAR(g.n_obs)
+      for (int b = 0; b < g.n_blk; ++b) {
+        const int off = g.blk_off[b], dim = g.blk_dim[b], kind = g.blk_kind[b];
+        double acc[MAX_CB];
+        for (int d = 0; d < dim; ++d) acc[d] = gc[off + d];
+        for (int64_t k = g.blk_ptr[b]; k < g.blk_ptr[b + 1]; ++k) {
+          const int64_t a = g.blk_idx[k];
+          const lin_obs* L = &s.L[a];
+          const int pto = g.point_off[p->obs_point[g.obs[a]]];
+          if (pto < 0) continue;
+          const int base = kind == 0 ? 0 : L->pose_dim;
+          for (int r = 0; r < 2; ++r) {
+            const double v = L->Jp[r][0] * u[pto] + L->Jp[r][1] * u[pto + 1] + L->Jp[r][2] * u[pto + 2];
+            for (int d = 0; d < dim; ++d) acc[d] -= L->Jc[r][base + d] * v;
+          }
         }
+        for (int d = 0; d < dim; ++d) rhs[off + d] = acc[d];
       }
     }
     int lin_iters = 0;
@@ -889,7 +937,7 @@ BAO_API int bao_solve(bao_problem* p, const bao_options* opt, bao_result* res) {
     for (int i = 0; i < nc; ++i) dc[i] = -dc[i];
     for (int i = 0; i < np; ++i) dp[i] = -dp[i];
     double model_change = 0.0;
-#pragma omp parallel for reduction(+ : model_change) schedule(static)
+#pragma omp parallel for reduction(+ : model_change) schedule(static) BAO_PAR(g.n_obs)
     for (int64_t a = 0; a < g.n_obs; ++a) {
       const lin_obs* L = &s.L[a];
       int po, co; cam_offsets(&g, a, &po, &co);

@@ -1,0 +1,196 @@
+"""GPU parity tests: the HIP bundle-adjustment solve (through the C ABI) against the fp64
+CPU oracle on the same flattened problems.
+
+Tolerances (fp64 on both sides; the only differences are summation orders): the first LM
+iterations follow the oracle's trajectory to 1e-9 relative cost, the final cost agrees to 1e-8
+relative under a tight gradient tolerance, parameters to 1e-6; residual / parameter counts are
+exact; constant blocks are bit-identical.
+"""
+import numpy as np
+import pytest
+
+import ba_oracle
+from colmap_amd import estimators as est
+from colmap_amd import scene
+
+pytestmark = pytest.mark.gpu
+
+TIGHT = dict(gradient_tolerance=1e-10, max_num_iterations=200)
+
+
+def _both(fp, **so_kw):
+    so = est.SolverOptions(**so_kw)
+    a, b = fp.copy(), fp.copy()
+    want = est.solve_flat(a, so, solve_fn=ba_oracle.solve_fn)
+    got = est.solve_flat(b, so, gpu_index=0)
+    return (a, want), (b, got)
+
+
+def _assert_close(a, want, b, got, cost_rtol=1e-8, param_atol=1e-6):
+    assert got.num_residuals == want.num_residuals
+    assert got.num_effective_parameters == want.num_effective_parameters
+    assert got.termination_type == want.termination_type
+    assert abs(got.initial_cost - want.initial_cost) <= 1e-12 * want.initial_cost
+    assert abs(got.final_cost - want.final_cost) <= cost_rtol * want.final_cost, (got.final_cost, want.final_cost)
+    n = min(4, len(want.log_cost), len(got.log_cost))
+    np.testing.assert_allclose(got.log_cost[:n], want.log_cost[:n], rtol=1e-7)
+    np.testing.assert_allclose(b.points, a.points, atol=param_atol)
+    np.testing.assert_allclose(b.cams, a.cams, rtol=1e-7, atol=param_atol)
+    np.testing.assert_allclose(b.poses, a.poses, atol=param_atol)
+
+
+def _flat(frames, points, track, seed, mixed=False, noise=None):
+    noise = noise or scene.SyntheticNoiseOptions(0.01, 1.0, 0.05, 1.0)
+    return est.FlatProblem.from_arrays(scene.synthesize_flat(frames, points, track, seed=seed, mixed_models=mixed,
+                                                            noise=noise))
+
+
+@pytest.mark.parametrize("frames,points,track,mixed", [(6, 40, 4, True), (12, 300, 5, False), (40, 2000, 8, True)])
+def test_solution_matches_oracle(frames, points, track, mixed):
+    fp = _flat(frames, points, track, seed=frames, mixed=mixed)
+    assert est.fix_gauge_two_cams(fp)
+    (a, want), (b, got) = _both(fp, **TIGHT)
+    assert want.IsSolutionUsable() and got.IsSolutionUsable()
+    _assert_close(a, want, b, got)
+    assert got.final_cost < 0.2 * got.initial_cost
+
+
+def test_run_to_run_determinism():
+    """All reductions use fixed trees (per-workgroup partials + single-workgroup finals); parameter
+    blocks whose observation list fits one chunk accumulate without atomics."""
+    fp = _flat(40, 3000, 8, seed=5)
+    assert est.fix_gauge_two_cams(fp)
+    runs = []
+    for _ in range(2):
+        b = fp.copy()
+        s = est.solve_flat(b, est.SolverOptions(max_num_iterations=15), gpu_index=0)
+        runs.append((b, s))
+    assert runs[0][1].final_cost == runs[1][1].final_cost
+    assert np.array_equal(runs[0][0].poses, runs[1][0].poses) and np.array_equal(runs[0][0].points, runs[1][0].points)
+    assert np.array_equal(runs[0][1].log_linear_iters, runs[1][1].log_linear_iters)
+
+
+def test_default_options_benchmark_noise():
+    """COLMAP's default tolerances (gradient 1e-4, <= 100 iterations) on the benchmark's noise model
+    (benchmark/runtime/bundle_adjustment.cc:76-81)."""
+    fp = _flat(30, 1500, 6, seed=42)
+    assert est.fix_gauge_two_cams(fp)
+    (a, want), (b, got) = _both(fp)
+    assert got.termination_type == want.termination_type
+    assert abs(got.final_cost - want.final_cost) <= 1e-6 * want.final_cost
+    # iteration counts are not compared: near convergence the accept/reject decisions of an
+    # inexact-Newton LM flip on round-off (the oracle itself changes count with its thread count)
+    np.testing.assert_allclose(got.log_cost[:4], want.log_cost[:4], rtol=1e-7)
+
+
+def test_constant_blocks_are_untouched_bitwise():
+    fp = _flat(8, 120, 4, seed=7)
+    assert est.fix_gauge_two_cams(fp)
+    fp.pose_const[5] = 1
+    fp.point_const[::7] = 1
+    fp.cam_const[3, :] = 1
+    orig = fp.copy()
+    (a, want), (b, got) = _both(fp, **TIGHT)
+    _assert_close(a, want, b, got)
+    assert np.array_equal(b.poses[5], orig.poses[5]) and np.array_equal(b.poses[fp.pose_const == 1], orig.poses[fp.pose_const == 1])
+    assert np.array_equal(b.points[::7], orig.points[::7])
+    assert np.array_equal(b.cams[3], orig.cams[3])
+    assert np.array_equal(b.cams[:, 1:3], orig.cams[:, 1:3])          # principal points never refined
+    k = int(np.nonzero(fp.pose_fixed_t >= 0)[0][0])
+    assert b.poses[k, 4 + fp.pose_fixed_t[k]] == orig.poses[k, 4 + fp.pose_fixed_t[k]]
+    np.testing.assert_allclose(np.linalg.norm(b.poses[:, :4], axis=1), 1.0, atol=1e-12)
+
+
+def test_shared_intrinsics_and_three_point_gauge():
+    """One camera shared by every image: the intrinsics block of the Schur-Jacobi preconditioner
+    couples all observations of a point (the FAQ's dense case, doc/faq.rst:626-632)."""
+    d = scene.synthesize_flat(10, 200, 5, seed=11, noise=scene.SyntheticNoiseOptions(0.01, 0.5, 0.03, 0.5))
+    d["obs_cam"] = np.zeros_like(d["obs_cam"])
+    d["cams"] = d["cams"][:1].copy()
+    d["cam_model"] = d["cam_model"][:1].copy()
+    fp = est.FlatProblem.from_arrays(d)
+    assert est.fix_gauge_three_points(fp)
+    # this configuration converges slowly for both solvers (inexact steps, eta = 0.1), so the
+    # comparison is on the early trajectory, not on a converged minimum
+    (a, want), (b, got) = _both(fp, max_num_iterations=25)
+    assert got.num_residuals == want.num_residuals == 2000
+    assert got.num_effective_parameters == want.num_effective_parameters
+    np.testing.assert_allclose(got.log_cost[:5], want.log_cost[:5], rtol=1e-7)
+    np.testing.assert_array_equal(got.log_linear_iters[:3], want.log_linear_iters[:3])
+    assert abs(got.final_cost - want.final_cost) <= 0.02 * want.final_cost
+    assert got.final_cost < 0.05 * got.initial_cost
+
+
+def test_only_points_variable_and_only_cameras_variable():
+    fp = _flat(6, 80, 4, seed=13)
+    pts_only = fp.copy()
+    pts_only.pose_const[:] = 1
+    pts_only.cam_const[:] = 1
+    (a, want), (b, got) = _both(pts_only, **TIGHT)
+    _assert_close(a, want, b, got)
+    cams_only = fp.copy()
+    cams_only.point_const[:] = 1
+    (a, want), (b, got) = _both(cams_only, **TIGHT)
+    _assert_close(a, want, b, got)
+
+
+def _config(rec, gauge=est.BundleAdjustmentGauge.TWO_CAMS_FROM_WORLD):
+    cfg = est.BundleAdjustmentConfig()
+    for i in rec.RegImageIds():
+        cfg.AddImage(i)
+    cfg.FixGauge(gauge)
+    return cfg
+
+
+def test_backend_interface_reference_cases():
+    """bundle_adjustment_test.cc:303-412 through CreateDefaultBundleAdjuster(backend=MI355X)."""
+    opt = est.BundleAdjustmentOptions(gpu_index="0")
+    assert opt.backend == est.BundleAdjustmentBackend.MI355X
+    # MinimumTrackLength: 594 residuals
+    rec = scene.SynthesizeDataset(scene.SyntheticDatasetOptions(num_rigs=3, num_frames_per_rig=1, num_points3D=100,
+                                                               num_points2D_without_point3D=0))
+    scene.SynthesizeNoise(scene.SyntheticNoiseOptions(point2D_stddev=1), rec)
+    idx = next(i for i, p in enumerate(rec.images[3].points2D) if p.HasPoint3D())
+    rec.DeleteObservation(3, idx)
+    o = est.BundleAdjustmentOptions(gpu_index="0", min_track_length=3)
+    s = est.CreateDefaultBundleAdjuster(o, _config(rec), rec).Solve()
+    assert s.IsSolutionUsable() and s.num_residuals == 594
+    # ConstantPoints3D: 80 residuals, points bit-identical
+    rec = scene.SynthesizeDataset(scene.SyntheticDatasetOptions(num_rigs=2, num_frames_per_rig=1, num_points3D=20))
+    scene.SynthesizeNoise(scene.SyntheticNoiseOptions(point2D_stddev=1), rec)
+    orig = rec.copy()
+    o = est.BundleAdjustmentOptions(gpu_index="0", refine_points3D=False)
+    s = est.CreateDefaultBundleAdjuster(o, _config(rec, est.BundleAdjustmentGauge.UNSPECIFIED), rec).Solve()
+    assert s.IsSolutionUsable() and s.num_residuals == 80
+    for pid, pt in rec.points3D.items():
+        assert np.array_equal(pt.xyz, orig.points3D[pid].xyz)
+    # Nominal: usable solution near ground truth
+    gt = scene.SynthesizeDataset(scene.SyntheticDatasetOptions(num_rigs=1, num_frames_per_rig=10, num_points3D=200))
+    rec = gt.copy()
+    scene.SynthesizeNoise(scene.SyntheticNoiseOptions(point2D_stddev=0.5, point3D_stddev=0.1), rec)
+    rng = np.random.default_rng(5)
+    for i in rec.RegImageIds()[2:]:
+        rec.images[i].cam_from_world[4:] += rng.normal(0, 0.1, 3)
+    ba = est.CreateDefaultBundleAdjuster(opt, _config(rec), rec)
+    assert ba.Config().NumImages() == 10 and ba.Options().backend == est.BundleAdjustmentBackend.MI355X
+    s = ba.Solve()
+    assert s.IsSolutionUsable() and s.num_residuals > 0
+    for i in gt.RegImageIds():
+        a, b = gt.images[i].cam_from_world, rec.images[i].cam_from_world
+        R = scene.quat_to_rot(a[:4]).T @ scene.quat_to_rot(b[:4])
+        assert np.degrees(np.arccos(np.clip((np.trace(R) - 1) / 2, -1, 1))) < 0.1
+        ca, cb = -scene.quat_to_rot(a[:4]).T @ a[4:], -scene.quat_to_rot(b[:4]).T @ b[4:]
+        assert np.linalg.norm(ca - cb) < 0.1
+
+
+def test_error_behaviour():
+    fp = _flat(4, 20, 3, seed=1)
+    fp.cam_model[0] = 9  # unsupported model id
+    with pytest.raises(RuntimeError, match="unsupported camera model"):
+        est.solve_flat(fp, gpu_index=0)
+    fp = _flat(4, 20, 3, seed=1)
+    with pytest.raises(RuntimeError, match="gpu_index"):
+        est.solve_flat(fp, gpu_index=99)
+    with pytest.raises(ValueError):
+        est.CreateDefaultBundleAdjuster(est.BundleAdjustmentOptions(backend=est.BundleAdjustmentBackend.CERES),
+                                        est.BundleAdjustmentConfig(), scene.Reconstruction())
