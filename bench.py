@@ -138,7 +138,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    from colmap_amd import mvs, synthetic as syn
+    from colmap_amd import distributed as D, mvs, synthetic as syn
 
     S = a.num_src
     nsteps = a.steps + a.warmup
@@ -146,9 +146,8 @@ def main():
     # this rank's window of the ring: `nref` consecutive reference cameras + S/2 neighbours either side
     half = S // 2
     step_deg = 360.0 / a.ring
-    first = rank * nref  # disjoint reference images per rank (weak scaling)
-    idx0 = first - half
-    nviews = nref + S
+    # disjoint reference images per rank (weak scaling)
+    idx0, nviews = D.rank_window(rank, nref, half)
     cams = syn.ring_cameras(nviews, a.width, a.height, 2400.0 * a.width / 2560.0, arc_deg=step_deg * (nviews - 1),
                             start_deg=idx0 * step_deg)
     views = []
@@ -197,15 +196,12 @@ def main():
         run_step(a.warmup + k, True)
     barrier()
     dt = time.time() - t0
-    if world > 1:
-        import torch.distributed as dist
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = D.max_over_ranks(dt, dev)
+    images_done = sum(D.gather_counts(a.steps * a.batch, dev))
 
     if rank == 0:
         pix_per_image = a.width * a.height
-        total_images = a.steps * a.batch * world
+        total_images = images_done
         value = total_images * pix_per_image / 1e6 / dt
         # (40 + 24*S) algorithmic HBM bytes per pixel per sweep launch
         alg_bytes = (40 + 24 * S) * pix_per_image * a.batch  # one launch sweeps the whole batch

@@ -1,0 +1,67 @@
+"""Multi-GPU work partitioning for the two hot paths (one process per GPU, torch.distributed).
+
+PatchMatch shards by reference image exactly like the reference's thread-per-GPU problem pool
+(mvs/patch_match.cc:177,190-204,394): no data-path collective, only a barrier and a max-reduce of
+the elapsed time (bench.py). The helpers live here so that the N > 1 path is testable on CPU with
+the gloo backend (tests/test_distributed.py).
+"""
+from __future__ import annotations
+
+from typing import List, Sequence, Tuple
+
+
+def shard_problems(num_problems: int, rank: int, world_size: int) -> List[int]:
+    """Round-robin assignment of problem indices to ranks (the reference hands problems to
+    whichever GPU worker is free; with equal-cost problems that is round-robin)."""
+    if not (0 <= rank < world_size):
+        raise ValueError("rank out of range")
+    return list(range(rank, num_problems, world_size))
+
+
+def rank_window(rank: int, refs_per_rank: int, half_window: int) -> Tuple[int, int]:
+    """Weak-scaling layout used by bench.py: rank r owns `refs_per_rank` consecutive reference
+    cameras of the ring starting at r * refs_per_rank and needs `half_window` neighbours on both
+    sides as sources. Returns (first_view_index, num_views)."""
+    first_ref = rank * refs_per_rank
+    return first_ref - half_window, refs_per_rank + 2 * half_window
+
+
+def max_over_ranks(value: float, device=None) -> float:
+    """Elapsed time of the slowest rank (bench contract: barrier, time, MAX over ranks)."""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+        return float(value)
+    t = torch.tensor([value], dtype=torch.float64, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def gather_counts(local_count: int, device=None) -> List[int]:
+    """Units (reference images) processed by every rank: value = sum(units) / max(time)."""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+        return [int(local_count)]
+    t = torch.tensor([local_count], dtype=torch.int64, device=device if device is not None else "cpu")
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [int(x.item()) for x in out]
+
+
+def exchange_maps(local: dict, device=None) -> dict:
+    """All-gather of per-image results (image index -> tensor) between the photometric and the
+    geometric pass: every rank ends up with every image's depth/normal map,
+    replacing the reference's write-to-disk / read-back (patch_match.cc:507-508,530-531).
+    Works with gloo (CPU tensors) and nccl/RCCL (device tensors)."""
+    import torch.distributed as dist
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+        return dict(local)
+    gathered: List[dict] = [None] * dist.get_world_size()  # type: ignore
+    dist.all_gather_object(gathered, {k: v.cpu() for k, v in local.items()})
+    merged: dict = {}
+    for part in gathered:
+        merged.update(part)
+    if device is not None:
+        merged = {k: v.to(device) for k, v in merged.items()}
+    return merged

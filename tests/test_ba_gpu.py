@@ -194,3 +194,45 @@ def test_error_behaviour():
     with pytest.raises(ValueError):
         est.CreateDefaultBundleAdjuster(est.BundleAdjustmentOptions(backend=est.BundleAdjustmentBackend.CERES),
                                         est.BundleAdjustmentConfig(), scene.Reconstruction())
+
+
+def test_against_committed_golden_fixture():
+    """tests/golden/ba_6x40.npz (oracle solution, committed) reproduced by the HIP solver."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ba_6x40.npz"))
+    fp = est.FlatProblem(**{k: g[f"in_{k}"].copy() for k in ("poses", "cams", "cam_model", "points", "obs_pose", "obs_cam",
+                                                           "obs_point", "obs_xy", "pose_const", "pose_fixed_t",
+                                                           "cam_const", "point_const")})
+    s = est.solve_flat(fp, est.SolverOptions(gradient_tolerance=1e-10, max_num_iterations=200), gpu_index=0)
+    assert [s.num_residuals, s.num_effective_parameters] == list(g["counts"])
+    assert abs(s.initial_cost - g["costs"][0]) <= 1e-12 * g["costs"][0]
+    assert abs(s.final_cost - g["costs"][1]) <= 1e-8 * g["costs"][1]
+    np.testing.assert_allclose(fp.points, g["out_points"], atol=1e-6)
+    np.testing.assert_allclose(fp.poses, g["out_poses"], atol=1e-6)
+    np.testing.assert_allclose(fp.cams, g["out_cams"], rtol=1e-7, atol=1e-6)
+
+
+def test_full_size_properties():
+    """BASELINE.json config[3] shape (1000 cameras x 200k points, 2 M observations) through
+    size-independent properties."""
+    fp = _flat(1000, 200000, 10, seed=42)
+    assert est.fix_gauge_two_cams(fp)
+    fp.point_const[::1000] = 1
+    orig = fp.copy()
+    s = est.solve_flat(fp, est.SolverOptions(max_num_iterations=12), gpu_index=0)
+    assert s.IsSolutionUsable()
+    assert s.num_residuals == 2 * len(fp.obs_pose) == 4000000
+    assert s.num_effective_parameters == 6 * 998 + 5 + 2 * 1000 + 3 * (200000 - 200)
+    # accepted steps never increase the cost (monotonic trust region); the noise floor is reached
+    assert np.all(np.diff(s.log_cost) <= 1e-9 * s.log_cost[:-1])
+    assert s.final_cost < 0.01 * s.initial_cost
+    # final cost ~ N_residuals/2 * sigma^2 for 1 px observation noise
+    assert 0.3 < s.final_cost / (0.5 * s.num_residuals) < 1.2
+    np.testing.assert_allclose(np.linalg.norm(fp.poses[:, :4], axis=1), 1.0, atol=1e-12)
+    assert np.array_equal(fp.points[::1000], orig.points[::1000])           # constant points bit-identical
+    assert np.array_equal(fp.poses[fp.pose_const == 1], orig.poses[fp.pose_const == 1])
+    assert np.array_equal(fp.cams[:, 1:3], orig.cams[:, 1:3])               # principal points
+    # idempotence: a second identical solve reproduces the same bits
+    again = orig.copy()
+    s2 = est.solve_flat(again, est.SolverOptions(max_num_iterations=12), gpu_index=0)
+    assert s2.final_cost == s.final_cost and np.array_equal(again.poses, fp.poses)

@@ -1,0 +1,75 @@
+"""N > 1 path on CPU: two gloo processes exercise the sharding, the max-over-ranks timing
+reduction and the photometric->geometric map exchange (no GPU compute)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from colmap_amd import distributed as D
+
+
+def test_shard_problems_partition():
+    for n in (0, 1, 7, 100):
+        for w in (1, 2, 3, 8):
+            shards = [D.shard_problems(n, r, w) for r in range(w)]
+            flat = sorted(i for s in shards for i in s)
+            assert flat == list(range(n))
+            assert max(len(s) for s in shards) - min(len(s) for s in shards) <= 1
+    with pytest.raises(ValueError):
+        D.shard_problems(4, 2, 2)
+
+
+def test_rank_windows_are_disjoint_in_references():
+    w0 = D.rank_window(0, 24, 10)
+    w1 = D.rank_window(1, 24, 10)
+    assert w0 == (-10, 44) and w1 == (14, 44)
+    refs0 = set(range(w0[0] + 10, w0[0] + 10 + 24))
+    refs1 = set(range(w1[0] + 10, w1[0] + 10 + 24))
+    assert not (refs0 & refs1)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        mine = D.shard_problems(5, rank, world)
+        elapsed = 1.0 + rank  # rank 1 is the slow one
+        t = D.max_over_ranks(elapsed)
+        counts = D.gather_counts(len(mine))
+        local = {i: torch.full((2, 3), float(i)) for i in mine}
+        merged = D.exchange_maps(local)
+        dist.barrier()
+        q.put((rank, mine, t, counts, sorted(merged), [float(merged[k][0, 0]) for k in sorted(merged)]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_roundtrip():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, mine0, t0, c0, keys0, vals0), (r1, mine1, t1, c1, keys1, vals1) = res
+    assert mine0 == [0, 2, 4] and mine1 == [1, 3]
+    assert t0 == t1 == 2.0                       # MAX over ranks
+    assert c0 == c1 == [3, 2]                    # units per rank -> aggregate = 5
+    assert keys0 == keys1 == [0, 1, 2, 3, 4]     # every rank holds every image's maps
+    assert vals0 == vals1 == [0.0, 1.0, 2.0, 3.0, 4.0]

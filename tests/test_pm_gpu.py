@@ -189,3 +189,65 @@ def test_error_behaviour():
                                 geom_consistency=False, window_step=3)
     with pytest.raises(mvs.PatchMatchError):
         mvs.PatchMatch(win, hip_problem(views, 1, [0, 2])).Run()      # window_step <= 2
+
+
+def test_against_committed_golden_fixture():
+    """tests/golden/pm_48x36.npz (device-order oracle output, committed) reproduced by the HIP path."""
+    import os
+    from colmap_amd import mvs
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pm_48x36.npz"))
+    images = [mvs.Image(g["K"][i], g["R"][i], g["T"][i], g["gray"][i]) for i in range(len(g["gray"]))]
+    dmin, dmax = [float(x) for x in g["depth_range"]]
+    opt = mvs.PatchMatchOptions(gpu_index="0", depth_min=dmin, depth_max=dmax, sigma_spatial=5.0,
+                                geom_consistency=False, filter=True, num_iterations=1)
+    pm = mvs.PatchMatch(opt, mvs.PatchMatch.Problem(1, [0, 2, 3], images))
+    pm.Run()
+    got = dict(depth=pm.GetDepthMap(), normal=pm.GetNormalMap(), sel_prob=pm.GetSelProbMap(),
+               cost=pm.GetCostMap(), mask=pm.GetConsistencyMask())
+    _assert_equal({k: g[f"order1_{k}"] for k in got}, got)
+
+
+def test_full_size_properties():
+    """BASELINE.json config[1] shape (2560x1920, S=20, photometric + filter) through
+    size-independent properties: the oracle would need hours at this size."""
+    import torch
+    from colmap_amd import mvs
+    W, H, S = 2560, 1920, 20
+    views = syn.make_scene(S + 2, W, H, arc_deg=3.6 * (S + 1), device="cuda")
+    images = [mvs.Image(v.K, v.R, v.T, torch.from_numpy(v.gray).cuda()) for v in views]
+    outs = []
+    for ref in (S // 2, S // 2 + 1):
+        src = [i for i in range(ref - S // 2, ref + S // 2 + 1) if i != ref][:S]
+        dmin, dmax = syn.depth_range(views, ref)
+        opt = mvs.PatchMatchOptions(gpu_index="0", depth_min=dmin, depth_max=dmax, sigma_spatial=5.0,
+                                    geom_consistency=False, filter=True)
+        outs.append((ref, src, dmin, dmax, mvs.PatchMatch(opt, mvs.PatchMatch.Problem(ref, src, images))))
+    mvs.run_batch([o[-1] for o in outs])
+    for ref, src, dmin, dmax, pm in outs:
+        depth, normal, mask, sel = pm.GetDepthMap(), pm.GetNormalMap(), pm.GetConsistencyMask(), pm.GetSelProbMap()
+        kept = depth > 0
+        assert 0.5 < kept.mean() <= 1.0
+        nrm = np.linalg.norm(normal, axis=0)
+        np.testing.assert_allclose(nrm[kept], 1.0, atol=1e-4)             # unit normals where kept
+        assert np.all(normal[:, ~kept] == 0) and np.all(mask[:, ~kept] == 0)  # filtered pixels fully zeroed
+        assert np.all(mask[:, kept].sum(0) >= 2)                          # filter_min_num_consistent
+        assert np.all((sel >= 0) & (sel <= 1)) and np.isfinite(sel).all()
+        # normals face the camera (GenerateRandomNormal / PerturbNormal keep n . ray < 0)
+        ys, xs = np.nonzero(kept)
+        K = views[ref].K
+        ray = np.stack([(xs - K[0, 2]) / K[0, 0], (ys - K[1, 2]) / K[1, 1], np.ones_like(xs, float)], 0)
+        assert ((normal[:, ys, xs] * ray).sum(0) < 0).mean() > 0.999
+        gt = views[ref].depth
+        rel = np.abs(depth[kept] - gt[kept]) / gt[kept]
+        assert np.median(rel) < 2e-3 and (rel < 0.01).mean() > 0.9        # accuracy vs ground truth
+        # the consistency-graph list is consistent with the mask
+        flat = pm.GetConsistentImageIdxs()
+        assert len(flat) == 3 * int(kept.sum()) + int(mask.sum())
+    # idempotence of the deterministic pipeline: solving the first problem alone gives the same bits
+    ref, src, dmin, dmax, pm = outs[0]
+    opt = mvs.PatchMatchOptions(gpu_index="0", depth_min=dmin, depth_max=dmax, sigma_spatial=5.0,
+                                geom_consistency=False, filter=True)
+    solo = mvs.PatchMatch(opt, mvs.PatchMatch.Problem(ref, src, images))
+    solo.Run()
+    assert np.array_equal(solo.GetDepthMap(), pm.GetDepthMap())
+    assert np.array_equal(solo.GetNormalMap(), pm.GetNormalMap())
