@@ -14,10 +14,10 @@
 //  * Observations are sorted by 3-D point once on the host: the point-side passes
 //    (C_j = E_j^T E_j + D, C^-1 E^T x, back-substitution) are a lane per point walking a
 //    contiguous segment -- no atomics, deterministic.
-//  * Camera-side reductions (gradient, J^T v, block-Jacobi Gram blocks) run a workgroup per
-//    chunk of a parameter block's observation list with a wave-level tree reduction; blocks
-//    with very long lists (shared intrinsics) are split into chunks that combine with fp64
-//    atomics.
+//  * Camera-side reductions (gradient, J^T v, block-Jacobi Gram blocks) run a wave per chunk
+//    of a parameter block's observation list with a wave-level tree reduction into a
+//    per-chunk partial; a second tiny kernel adds a block's chunks in order. No atomics
+//    anywhere: results are bit-reproducible run to run.
 //  * The Schur-Jacobi blocks B_ii = sum J_i^T J_i (pose 6x6 / intrinsics up to 4x4 per
 //    block, K = 2 x #observations) are dense Gram contractions and run on the f64 matrix
 //    cores (v_mfma_f64_16x16x4_f64: A = B = a 4-row slab of J, D accumulates the 16x16
@@ -74,6 +74,8 @@ struct View {
   const int *pt_off, *pt_ptr;
   const int *blk_off, *blk_dim, *blk_kind, *blk_moff;
   const int *chunk_blk, *chunk_beg, *chunk_end, *blk_obs;
+  const int* blk_chunk_ptr;  // chunks of block b: [blk_chunk_ptr[b], blk_chunk_ptr[b+1])
+  double* cpart;             // [n_chunks][PD*PD] per-chunk partial results (no atomics)
   // linearisation
   double *Jpose, *Jcam, *Jpt, *res;
   double *scale_c, *scale_p;
@@ -475,16 +477,48 @@ __global__ void __launch_bounds__(64) ba_block_jtv_kernel(View V, const double* 
         if (DIAG) dacc[c] += j0 * j0 + j1 * j1;
       }
   }
+  (void)off;
 #pragma unroll
   for (int c = 0; c < PD; ++c)
     if (c < dim) {
       const double s = wave_sum(acc[c]);
-      if (threadIdx.x == 0) atomicAdd(y + off + c, s);
+      if (threadIdx.x == 0) V.cpart[(size_t)ch * PD * PD + c] = s;
       if (DIAG) {
         const double d = wave_sum(dacc[c]);
-        if (threadIdx.x == 0) atomicAdd(diag + off + c, d);
+        if (threadIdx.x == 0) V.cpart[(size_t)ch * PD * PD + PD + c] = d;
       }
     }
+}
+
+// y_b += sum over the block's chunks, in chunk order (deterministic); lane per block
+template <bool DIAG>
+__global__ void ba_block_vec_finalize_kernel(View V, double* __restrict__ y, double* __restrict__ diag) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= V.n_blk) return;
+  const int dim = V.blk_dim[b], off = V.blk_off[b];
+  for (int c = 0; c < dim; ++c) {
+    double s = 0.0, d = 0.0;
+    for (int ch = V.blk_chunk_ptr[b]; ch < V.blk_chunk_ptr[b + 1]; ++ch) {
+      s += V.cpart[(size_t)ch * PD * PD + c];
+      if (DIAG) d += V.cpart[(size_t)ch * PD * PD + PD + c];
+    }
+    y[off + c] += s;
+    if (DIAG) diag[off + c] += d;
+  }
+}
+
+// M_b (+)= sum over the block's chunks of the dim x dim partials; lane per block
+template <bool ACCUMULATE>
+__global__ void ba_block_mat_finalize_kernel(View V, double* __restrict__ M) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= V.n_blk) return;
+  const int dim = V.blk_dim[b];
+  double* Mb = M + V.blk_moff[b];
+  for (int e = 0; e < dim * dim; ++e) {
+    double s = 0.0;
+    for (int ch = V.blk_chunk_ptr[b]; ch < V.blk_chunk_ptr[b + 1]; ++ch) s += V.cpart[(size_t)ch * PD * PD + e];
+    Mb[e] = ACCUMULATE ? Mb[e] + s : s;
+  }
 }
 
 // Schur-Jacobi diagonal blocks, part 1: B_bb = sum_o J_b,o^T J_b,o on the f64 matrix cores.
@@ -508,11 +542,11 @@ __global__ void __launch_bounds__(64) ba_block_gram_kernel(View V, double* __res
     if (col != nullptr && idx < end) a = col[V.blk_obs[idx]];
     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, acc, 0, 0, 0);
   }
-  double* Mb = M + V.blk_moff[b];
+  (void)M;
 #pragma unroll
   for (int reg = 0; reg < 4; ++reg) {
     const int row = k + 4 * reg;
-    if (row < dim && i < dim) atomicAdd(Mb + row * dim + i, acc[reg]);
+    if (row < dim && i < dim) V.cpart[(size_t)ch * PD * PD + row * dim + i] = acc[reg];
   }
 }
 
@@ -563,14 +597,14 @@ __global__ void __launch_bounds__(64) ba_block_schur_corr_kernel(View V, const d
       }
     }
   }
-  double* Mb = M + V.blk_moff[b];
+  (void)M;
 #pragma unroll
   for (int x = 0; x < PD; ++x)
 #pragma unroll
     for (int y = 0; y < PD; ++y)
       if (x < dim && y < dim) {
         const double s = wave_sum(acc[x * PD + y]);
-        if (threadIdx.x == 0) atomicAdd(Mb + x * dim + y, s);
+        if (threadIdx.x == 0) V.cpart[(size_t)ch * PD * PD + x * dim + y] = s;
       }
 }
 
@@ -791,9 +825,9 @@ struct Solver {
   hipStream_t st = nullptr;
   // topology
   Buf<int> o_pose, o_cam, o_pt, pose_off, pose_dim, pose_fix, cam_off, cam_dim, cam_var, cam_model, pt_off,
-      pt_ptr, blk_off, blk_dim, blk_kind, blk_moff, chunk_blk, chunk_beg, chunk_end, blk_obs;
+      pt_ptr, blk_off, blk_dim, blk_kind, blk_moff, chunk_blk, chunk_beg, chunk_end, blk_obs, blk_chunk_ptr;
   Buf<double> o_xy, poses, cams, points, poses2, cams2, points2, Jpose, Jcam, Jpt, res, scale_c, scale_p,
-      scalars, gc, gp, diag_c, diag_p, Dc, Dp, Cinv, M, Minv, rhs, x, r, z, pdir, q, dp, jx, v, stepc, stepp, partials;
+      scalars, gc, gp, diag_c, diag_p, Dc, Dp, Cinv, M, Minv, rhs, x, r, z, pdir, q, dp, jx, v, stepc, stepp, partials, cpart;
   int moff_total = 0;
   std::vector<int> h_pose_off, h_cam_off, h_pt_off;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -906,13 +940,16 @@ struct Solver {
       if (bp >= 0) h_blk_obs[fill[bp]++] = a;
       if (bc >= 0) h_blk_obs[fill[bc]++] = a;
     }
-    std::vector<int> h_chunk_blk, h_chunk_beg, h_chunk_end;
-    for (int b = 0; b < n_blk; ++b)
+    std::vector<int> h_chunk_blk, h_chunk_beg, h_chunk_end, h_blk_chunk_ptr(n_blk + 1, 0);
+    for (int b = 0; b < n_blk; ++b) {
+      h_blk_chunk_ptr[b] = (int)h_chunk_blk.size();
       for (int s = cnt[b]; s < cnt[b + 1]; s += CHUNK) {
         h_chunk_blk.push_back(b);
         h_chunk_beg.push_back(s);
         h_chunk_end.push_back(std::min(s + CHUNK, cnt[b + 1]));
       }
+    }
+    h_blk_chunk_ptr[n_blk] = (int)h_chunk_blk.size();
 
     res_out->num_residuals = 2 * n;
     res_out->num_effective_parameters = n_c + poff;
@@ -927,6 +964,8 @@ struct Solver {
     blk_off.upload(h_blk_off); blk_dim.upload(h_blk_dim); blk_kind.upload(h_blk_kind); blk_moff.upload(h_blk_moff);
     chunk_blk.upload(h_chunk_blk); chunk_beg.upload(h_chunk_beg); chunk_end.upload(h_chunk_end);
     blk_obs.upload(h_blk_obs);
+    blk_chunk_ptr.upload(h_blk_chunk_ptr);
+    cpart.alloc((size_t)h_chunk_blk.size() * PD * PD);
     poses.upload(std::vector<double>(p.poses, p.poses + 7 * (size_t)p.num_poses));
     cams.upload(std::vector<double>(p.cams, p.cams + BA_CAM_STRIDE * (size_t)p.num_cams));
     points.upload(std::vector<double>(p.points, p.points + 3 * (size_t)p.num_points));
@@ -950,6 +989,7 @@ struct Solver {
     V.pt_off = pt_off.p; V.pt_ptr = pt_ptr.p;
     V.blk_off = blk_off.p; V.blk_dim = blk_dim.p; V.blk_kind = blk_kind.p; V.blk_moff = blk_moff.p;
     V.chunk_blk = chunk_blk.p; V.chunk_beg = chunk_beg.p; V.chunk_end = chunk_end.p; V.blk_obs = blk_obs.p;
+    V.blk_chunk_ptr = blk_chunk_ptr.p; V.cpart = cpart.p;
     V.Jpose = Jpose.p; V.Jcam = Jcam.p; V.Jpt = Jpt.p; V.res = res.p;
     V.scale_c = scale_c.p; V.scale_p = scale_p.p; V.scalars = scalars.p;
     // uploads / memsets above ran on the NULL stream, the solve runs on a non-blocking stream
@@ -968,8 +1008,10 @@ struct Solver {
   void gradient_and_diag() {
     BA_HIP(hipMemsetAsync(gc.p, 0, sizeof(double) * std::max(V.n_c, 1), st));
     BA_HIP(hipMemsetAsync(diag_c.p, 0, sizeof(double) * std::max(V.n_c, 1), st));
-    if (V.n_chunks > 0)
+    if (V.n_chunks > 0) {
       BA_LAUNCH(ba_block_jtv_kernel<true>, dim3(V.n_chunks), dim3(64), st, V, res.p, gc.p, diag_c.p);
+      BA_LAUNCH(ba_block_vec_finalize_kernel<true>, dim3(grid_for(V.n_blk, 128)), dim3(128), st, V, gc.p, diag_c.p);
+    }
     BA_LAUNCH(ba_point_grad_kernel, dim3(grid_for(V.n_points, 128)), dim3(128), st, V, gp.p, diag_p.p);
   }
 
@@ -981,6 +1023,7 @@ struct Solver {
                        jx.p, gp.p, v.p, dp.p);
     BA_LAUNCH(ba_dsq_x_kernel, dim3(grid_for(V.n_c, 256)), dim3(256), st, V.n_c, Dc.p, xin, qout);
     BA_LAUNCH(ba_block_jtv_kernel<false>, dim3(V.n_chunks), dim3(64), st, V, v.p, qout, nullptr);
+    BA_LAUNCH(ba_block_vec_finalize_kernel<false>, dim3(grid_for(V.n_blk, 128)), dim3(128), st, V, qout, nullptr);
   }
 
   int pcg(int max_iter, double q_tol) {
@@ -1090,15 +1133,17 @@ struct Solver {
       BA_LAUNCH(ba_point_blocks_kernel, dim3(grid_for(V.n_points, 128)), dim3(128), st, V, Dp.p, Cinv.p);
       int lin_iters = 0;
       if (nc > 0) {
-        BA_HIP(hipMemsetAsync(M.p, 0, sizeof(double) * std::max(moff_total, 1), st));
         BA_LAUNCH(ba_block_gram_kernel, dim3(V.n_chunks), dim3(64), st, V, M.p);
+        BA_LAUNCH(ba_block_mat_finalize_kernel<false>, dim3(grid_for(V.n_blk, 128)), dim3(128), st, V, M.p);
         BA_LAUNCH(ba_block_schur_corr_kernel, dim3(V.n_chunks), dim3(64), st, V, Cinv.p, M.p);
+        BA_LAUNCH(ba_block_mat_finalize_kernel<true>, dim3(grid_for(V.n_blk, 128)), dim3(128), st, V, M.p);
         BA_LAUNCH(ba_block_invert_kernel, dim3(grid_for(V.n_blk, 64)), dim3(64), st, V, Dc.p, M.p, Minv.p);
         // reduced rhs = g_c - E C^-1 g_p
         BA_LAUNCH(ba_point_pass_kernel<1>, dim3(grid_for(V.n_points, 128)), dim3(128), st, V, Cinv.p,
                            jx.p, gp.p, v.p, dp.p);
         BA_HIP(hipMemcpyAsync(rhs.p, gc.p, sizeof(double) * nc, hipMemcpyDeviceToDevice, st));
         BA_LAUNCH(ba_block_jtv_kernel<false>, dim3(V.n_chunks), dim3(64), st, V, v.p, rhs.p, nullptr);
+        BA_LAUNCH(ba_block_vec_finalize_kernel<false>, dim3(grid_for(V.n_blk, 128)), dim3(128), st, V, rhs.p, nullptr);
         lin_iters = pcg(opt.max_linear_solver_iterations, opt.eta);
         out->total_linear_iterations += lin_iters;
       }
