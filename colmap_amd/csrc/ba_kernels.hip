@@ -11,9 +11,12 @@
 //  * SoA Jacobian in HBM, fp64: per observation 2x6 pose-tangent, 2x4 intrinsics-tangent,
 //    2x3 point columns and the residual, each column contiguous over observations so that
 //    the observation-parallel kernels (one lane per residual) read/write coalesced.
-//  * Observations are sorted by 3-D point once on the host: the point-side passes
-//    (C_j = E_j^T E_j + D, C^-1 E^T x, back-substitution) are a lane per point walking a
-//    contiguous segment -- no atomics, deterministic.
+//  * Two observation orders, fixed once on the host: "c-order" (sorted by camera, then pose)
+//    holds the camera-side Jacobian columns, so every pose / intrinsics block is a contiguous
+//    range that the camera-side reductions stream; "p-order" (sorted by 3-D point) holds the
+//    point columns, so the point-side passes (C_j = E_j^T E_j + D, C^-1 E^T x,
+//    back-substitution) are a lane per point walking a contiguous segment. Only the 16-byte
+//    per-observation vectors (J_c x, v) cross between the orders through the permutation.
 //  * Camera-side reductions (gradient, J^T v, block-Jacobi Gram blocks) run a wave per chunk
 //    of a parameter block's observation list with a wave-level tree reduction into a
 //    per-chunk partial; a second tiny kernel adds a block's chunks in order. No atomics
@@ -54,8 +57,14 @@ thread_local long long g_spmv_bytes = 0;
 
 constexpr int PD = 6;        // pose tangent width (5 when the gauge holds a translation coordinate)
 constexpr int KD = 4;        // max intrinsics tangent width
-constexpr int CHUNK = 2048;  // observations per camera-side reduction chunk
+static int chunk_size() {     // observations per camera-side reduction chunk (one wave each)
+  const char* e = std::getenv("COLMAP_AMD_BA_CHUNK");
+  const int v = e ? std::atoi(e) : 512;
+  return v >= 64 ? v : 512;
+}
 constexpr int NSCALAR = 16;
+constexpr int TILE_OBS = 512;  // observations staged in LDS per point-pass workgroup
+constexpr int TILE_PTS = 256;
 
 enum Scalar { S_COST = 0, S_GMAX, S_RHO, S_RHO_LAST, S_PQ, S_Q, S_MODEL, S_NEWCOST, S_ITER };
 
@@ -67,17 +76,22 @@ struct View {
   // parameters (current / candidate)
   double *poses, *cams, *points;
   // topology
-  const int *o_pose, *o_cam, *o_pt;  // per observation (sorted by point)
-  const double* o_xy;
+  const int *o_pose, *o_cam, *o_pt;  // per observation, c-order (sorted by camera, then pose)
+  const double* o_xy;                // c-order
+  const int *c2a, *a2c;              // c-order position <-> p-order position (sorted by point)
+  const unsigned char* solo;         // c-order: bit k set = no other observation of this point shares block kind k
   const int *pose_off, *pose_dim, *pose_fix;
   const int *cam_off, *cam_dim, *cam_var, *cam_model;
   const int *pt_off, *pt_ptr;
+  const int* tile_pt;  // point tiles: points [tile_pt[t], tile_pt[t+1]) have <= TILE_OBS observations
+  int n_tiles;         // 0: some track is longer than a tile, use the untiled kernel
   const int *blk_off, *blk_dim, *blk_kind, *blk_moff;
-  const int *chunk_blk, *chunk_beg, *chunk_end, *blk_obs;
+  const int *chunk_blk, *chunk_beg, *chunk_end;  // chunks are c-order ranges
   const int* blk_chunk_ptr;  // chunks of block b: [blk_chunk_ptr[b], blk_chunk_ptr[b+1])
   double* cpart;             // [n_chunks][PD*PD] per-chunk partial results (no atomics)
   // linearisation
-  double *Jpose, *Jcam, *Jpt, *res;
+  double *Jpose, *Jcam, *res;  // c-order
+  double *Jpt, *res_p;         // p-order
   double *scale_c, *scale_p;
   double* scalars;
 };
@@ -223,8 +237,11 @@ __global__ void __launch_bounds__(256) ba_linearize_kernel(View V, const double*
     cost = 0.5 * (rx * rx + ry * ry);
     if (JAC) {
       const size_t N = (size_t)V.n_obs;
+      const int a = V.c2a[o];  // p-order slot of this observation
       V.res[o] = rx;
       V.res[N + o] = ry;
+      V.res_p[a] = rx;
+      V.res_p[N + a] = ry;
       const int pdim = V.pose_dim[pi], poff = V.pose_off[pi];
       const int cdim = V.cam_dim[ci], coff = V.cam_off[ci];
       const int ptoff = V.pt_off[xi];
@@ -290,7 +307,7 @@ __global__ void __launch_bounds__(256) ba_linearize_kernel(View V, const double*
           if (ok && ptoff >= 0)
             val = (Juvw[3 * r] * R[c] + Juvw[3 * r + 1] * R[3 + c] + Juvw[3 * r + 2] * R[6 + c]) *
                   V.scale_p[ptoff + c];
-          V.Jpt[(size_t)(r * 3 + c) * N + o] = val;
+          V.Jpt[(size_t)(r * 3 + c) * N + a] = val;
         }
     }
   }
@@ -312,7 +329,7 @@ __global__ void ba_point_grad_kernel(View V, double* __restrict__ gp, double* __
   double g[3] = {0, 0, 0}, d[3] = {0, 0, 0};
   for (int o = V.pt_ptr[j]; o < V.pt_ptr[j + 1]; ++o)
     for (int r = 0; r < 2; ++r) {
-      const double rr = V.res[r * N + o];
+      const double rr = V.res_p[r * N + o];
       for (int c = 0; c < 3; ++c) {
         const double J = V.Jpt[(size_t)(r * 3 + c) * N + o];
         g[c] += J * rr;
@@ -365,8 +382,8 @@ __global__ void ba_point_pass_kernel(View V, const double* __restrict__ Cinv, co
   const size_t N = (size_t)V.n_obs;
   const int beg = V.pt_ptr[j], end = V.pt_ptr[j + 1];
   if (off < 0) {  // constant point: no point block
-    if (MODE == 0) for (int o = beg; o < end; ++o) { v[o] = jx[o]; v[N + o] = jx[N + o]; }
-    if (MODE == 1) for (int o = beg; o < end; ++o) { v[o] = 0.0; v[N + o] = 0.0; }
+    if (MODE == 0) for (int o = beg; o < end; ++o) { const int c = V.a2c[o]; v[c] = jx[o]; v[N + c] = jx[N + o]; }
+    if (MODE == 1) for (int o = beg; o < end; ++o) { const int c = V.a2c[o]; v[c] = 0.0; v[N + c] = 0.0; }
     return;
   }
   double t[3] = {0, 0, 0};
@@ -386,12 +403,81 @@ __global__ void ba_point_pass_kernel(View V, const double* __restrict__ Cinv, co
     for (int c = 0; c < 3; ++c) dp[off + c] = u[c];
     return;
   }
-  for (int o = beg; o < end; ++o)
+  for (int o = beg; o < end; ++o) {
+    const int c = V.a2c[o];
     for (int r = 0; r < 2; ++r) {
       const double eu = V.Jpt[(size_t)(r * 3 + 0) * N + o] * u[0] + V.Jpt[(size_t)(r * 3 + 1) * N + o] * u[1] +
                         V.Jpt[(size_t)(r * 3 + 2) * N + o] * u[2];
-      v[r * N + o] = (MODE == 0 ? jx[r * N + o] : 0.0) - eu;
+      v[r * N + c] = (MODE == 0 ? jx[r * N + o] : 0.0) - eu;
     }
+  }
+}
+
+// Same passes with the point columns staged through LDS: a workgroup owns a tile of consecutive
+// points (<= TILE_PTS points, <= TILE_OBS observations); global loads/stores are coalesced over
+// the tile's observation range, the per-point segment walk reads LDS.
+template <int MODE>
+__global__ void __launch_bounds__(TILE_PTS) ba_point_pass_tiled_kernel(View V, const double* __restrict__ Cinv,
+                                                                       const double* __restrict__ jx,
+                                                                       const double* __restrict__ gp,
+                                                                       double* __restrict__ v,
+                                                                       double* __restrict__ dp) {
+  __shared__ double sJ[6][TILE_OBS];
+  __shared__ double sx[2][TILE_OBS];
+  const int t = blockIdx.x;
+  const int p0 = V.tile_pt[t], p1 = V.tile_pt[t + 1];
+  const int a0 = V.pt_ptr[p0], na = V.pt_ptr[p1] - a0;
+  const size_t N = (size_t)V.n_obs;
+  for (int i = threadIdx.x; i < na; i += TILE_PTS) {
+#pragma unroll
+    for (int c = 0; c < 6; ++c) sJ[c][i] = V.Jpt[(size_t)c * N + a0 + i];
+    if (MODE != 1) {
+      sx[0][i] = jx[a0 + i];
+      sx[1][i] = jx[N + a0 + i];
+    }
+  }
+  __syncthreads();
+  const int j = p0 + threadIdx.x;
+  if (j < p1) {
+    const int off = V.pt_off[j];
+    const int beg = V.pt_ptr[j] - a0, end = V.pt_ptr[j + 1] - a0;
+    if (off < 0) {
+      if (MODE == 1) for (int o = beg; o < end; ++o) { sx[0][o] = 0.0; sx[1][o] = 0.0; }
+    } else {
+      double tt[3] = {0, 0, 0};
+      if (MODE != 1) {
+        for (int o = beg; o < end; ++o)
+#pragma unroll
+          for (int r = 0; r < 2; ++r) {
+            const double x = sx[r][o];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) tt[c] += sJ[r * 3 + c][o] * x;
+          }
+      }
+      if (MODE == 1) for (int c = 0; c < 3; ++c) tt[c] = gp[off + c];
+      if (MODE == 2) for (int c = 0; c < 3; ++c) tt[c] = gp[off + c] - tt[c];
+      const double* Ci = Cinv + 9 * (size_t)j;
+      double u[3];
+      for (int r = 0; r < 3; ++r) u[r] = Ci[3 * r] * tt[0] + Ci[3 * r + 1] * tt[1] + Ci[3 * r + 2] * tt[2];
+      if (MODE == 2) {
+        for (int c = 0; c < 3; ++c) dp[off + c] = u[c];
+      } else {
+        for (int o = beg; o < end; ++o)
+#pragma unroll
+          for (int r = 0; r < 2; ++r) {
+            const double eu = sJ[r * 3 + 0][o] * u[0] + sJ[r * 3 + 1][o] * u[1] + sJ[r * 3 + 2][o] * u[2];
+            sx[r][o] = (MODE == 0 ? sx[r][o] : 0.0) - eu;
+          }
+      }
+    }
+  }
+  if (MODE == 2) return;
+  __syncthreads();
+  for (int i = threadIdx.x; i < na; i += TILE_PTS) {
+    const int c = V.a2c[a0 + i];
+    v[c] = sx[0][i];
+    v[N + c] = sx[1][i];
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -420,8 +506,9 @@ __global__ void ba_obs_jx_kernel(View V, const double* __restrict__ x, double* _
       a0 += V.Jcam[(size_t)c * N + o] * xv;
       a1 += V.Jcam[(size_t)(KD + c) * N + o] * xv;
     }
-  jx[o] = a0;
-  jx[N + o] = a1;
+  const int a = V.c2a[o];
+  jx[a] = a0;
+  jx[N + a] = a1;
 }
 
 // model cost change: -(J step) . (r + J step / 2), step = (dc, dp) already negated
@@ -440,7 +527,7 @@ __global__ void __launch_bounds__(256) ba_model_kernel(View V, const double* __r
       for (int c = 0; c < pdim; ++c) m += V.Jpose[(size_t)(r * PD + c) * N + o] * dc[poff + c];
       for (int c = 0; c < cdim; ++c) m += V.Jcam[(size_t)(r * KD + c) * N + o] * dc[coff + c];
       if (ptoff >= 0)
-        for (int c = 0; c < 3; ++c) m += V.Jpt[(size_t)(r * 3 + c) * N + o] * dp[ptoff + c];
+        for (int c = 0; c < 3; ++c) m += V.Jpt[(size_t)(r * 3 + c) * N + V.c2a[o]] * dp[ptoff + c];
       acc -= m * (V.res[r * N + o] + 0.5 * m);
     }
   }
@@ -466,8 +553,7 @@ __global__ void __launch_bounds__(64) ba_block_jtv_kernel(View V, const double* 
   const int kind = V.blk_kind[b], dim = V.blk_dim[b], off = V.blk_off[b];
   const size_t N = (size_t)V.n_obs;
   double acc[PD] = {0, 0, 0, 0, 0, 0}, dacc[PD] = {0, 0, 0, 0, 0, 0};
-  for (int k = V.chunk_beg[ch] + threadIdx.x; k < V.chunk_end[ch]; k += 64) {
-    const int o = V.blk_obs[k];
+  for (int o = V.chunk_beg[ch] + threadIdx.x; o < V.chunk_end[ch]; o += 64) {
     const double v0 = v[o], v1 = v[N + o];
 #pragma unroll
     for (int c = 0; c < PD; ++c)
@@ -539,7 +625,7 @@ __global__ void __launch_bounds__(64) ba_block_gram_kernel(View V, double* __res
   for (int s = beg; s < end; s += 2) {  // two observations = four residual rows per MFMA
     const int idx = s + (k >> 1);
     double a = 0.0;
-    if (col != nullptr && idx < end) a = col[V.blk_obs[idx]];
+    if (col != nullptr && idx < end) a = col[idx];
     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, acc, 0, 0, 0);
   }
   (void)M;
@@ -561,26 +647,37 @@ __global__ void __launch_bounds__(64) ba_block_schur_corr_kernel(View V, const d
   double acc[PD * PD];
 #pragma unroll
   for (int e = 0; e < PD * PD; ++e) acc[e] = 0.0;
-  for (int kk = V.chunk_beg[ch] + threadIdx.x; kk < V.chunk_end[ch]; kk += 64) {
-    const int o = V.blk_obs[kk];
+  for (int o = V.chunk_beg[ch] + threadIdx.x; o < V.chunk_end[ch]; o += 64) {
     const int xi = V.o_pt[o];
     if (V.pt_off[xi] < 0) continue;
+    const int a = V.c2a[o];
     const double* Ci = Cinv + 9 * (size_t)xi;
     double W1[PD][3];
 #pragma unroll
     for (int x = 0; x < PD; ++x)
 #pragma unroll
       for (int c = 0; c < 3; ++c)
-        W1[x][c] = (x < dim) ? blk_col(V, kind, 0, x)[o] * V.Jpt[(size_t)c * N + o] +
-                                   blk_col(V, kind, 1, x)[o] * V.Jpt[(size_t)(3 + c) * N + o]
+        W1[x][c] = (x < dim) ? blk_col(V, kind, 0, x)[o] * V.Jpt[(size_t)c * N + a] +
+                                   blk_col(V, kind, 1, x)[o] * V.Jpt[(size_t)(3 + c) * N + a]
                              : 0.0;
     double T[PD][3];  // W1 * Cinv
 #pragma unroll
     for (int x = 0; x < PD; ++x)
 #pragma unroll
       for (int c = 0; c < 3; ++c) T[x][c] = W1[x][0] * Ci[c] + W1[x][1] * Ci[3 + c] + W1[x][2] * Ci[6 + c];
+    if ((V.solo[o] >> kind) & 1) {
+      // the only observation of this point in this block (always true for pose blocks of COLMAP
+      // tracks, and for intrinsics blocks of per-image cameras): the pair sum is W1 C^-1 W1^T
+#pragma unroll
+      for (int x = 0; x < PD; ++x)
+#pragma unroll
+        for (int y = 0; y < PD; ++y)
+          if (x < dim && y < dim) acc[x * PD + y] -= T[x][0] * W1[y][0] + T[x][1] * W1[y][1] + T[x][2] * W1[y][2];
+      continue;
+    }
     // partners: observations of the same point that map to the same block (self included)
-    for (int o2 = V.pt_ptr[xi]; o2 < V.pt_ptr[xi + 1]; ++o2) {
+    for (int a2 = V.pt_ptr[xi]; a2 < V.pt_ptr[xi + 1]; ++a2) {
+      const int o2 = V.a2c[a2];
       const int off2 = kind == 0 ? V.pose_off[V.o_pose[o2]] : V.cam_off[V.o_cam[o2]];
       if (off2 != boff) continue;
 #pragma unroll
@@ -589,8 +686,8 @@ __global__ void __launch_bounds__(64) ba_block_schur_corr_kernel(View V, const d
         double W2[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c)
-          W2[c] = blk_col(V, kind, 0, y)[o2] * V.Jpt[(size_t)c * N + o2] +
-                  blk_col(V, kind, 1, y)[o2] * V.Jpt[(size_t)(3 + c) * N + o2];
+          W2[c] = blk_col(V, kind, 0, y)[o2] * V.Jpt[(size_t)c * N + a2] +
+                  blk_col(V, kind, 1, y)[o2] * V.Jpt[(size_t)(3 + c) * N + a2];
 #pragma unroll
         for (int x = 0; x < PD; ++x)
           if (x < dim) acc[x * PD + y] -= T[x][0] * W2[0] + T[x][1] * W2[1] + T[x][2] * W2[2];
@@ -825,8 +922,9 @@ struct Solver {
   hipStream_t st = nullptr;
   // topology
   Buf<int> o_pose, o_cam, o_pt, pose_off, pose_dim, pose_fix, cam_off, cam_dim, cam_var, cam_model, pt_off,
-      pt_ptr, blk_off, blk_dim, blk_kind, blk_moff, chunk_blk, chunk_beg, chunk_end, blk_obs, blk_chunk_ptr;
-  Buf<double> o_xy, poses, cams, points, poses2, cams2, points2, Jpose, Jcam, Jpt, res, scale_c, scale_p,
+      pt_ptr, blk_off, blk_dim, blk_kind, blk_moff, chunk_blk, chunk_beg, chunk_end, blk_chunk_ptr, c2a, a2c, tile_pt;
+  Buf<unsigned char> solo;
+  Buf<double> o_xy, poses, cams, points, poses2, cams2, points2, Jpose, Jcam, Jpt, res, res_p, scale_c, scale_p,
       scalars, gc, gp, diag_c, diag_p, Dc, Dp, Cinv, M, Minv, rhs, x, r, z, pdir, q, dp, jx, v, stepc, stepp, partials, cpart;
   int moff_total = 0;
   std::vector<int> h_pose_off, h_cam_off, h_pt_off;
@@ -873,22 +971,60 @@ struct Solver {
       pose_used[pi] = cam_used[ci] = pt_used[xi] = 1;
     }
     const int n = (int)active.size();
-    // sort by point (stable: keeps the caller's order inside a track)
+    // p-order: sorted by point (stable: keeps the caller's order inside a track)
     std::stable_sort(active.begin(), active.end(),
                      [&](int64_t a, int64_t b) { return p.obs_point[a] < p.obs_point[b]; });
+    std::vector<int> h_pt_ptr(p.num_points + 1, 0);
+    for (int a = 0; a < n; ++a) h_pt_ptr[p.obs_point[active[a]] + 1]++;
+    for (int j = 0; j < p.num_points; ++j) h_pt_ptr[j + 1] += h_pt_ptr[j];
+    // c-order: p-order positions sorted by (camera, pose) -> every camera-side block is a range
+    std::vector<int> h_c2a(n), h_a2c(n);
+    std::iota(h_c2a.begin(), h_c2a.end(), 0);
+    std::stable_sort(h_c2a.begin(), h_c2a.end(), [&](int a, int b) {
+      const int64_t oa = active[a], ob = active[b];
+      if (p.obs_cam[oa] != p.obs_cam[ob]) return p.obs_cam[oa] < p.obs_cam[ob];
+      return p.obs_pose[oa] < p.obs_pose[ob];
+    });
+    for (int c = 0; c < n; ++c) h_a2c[h_c2a[c]] = c;
+    // point tiles for the LDS-staged point passes
+    std::vector<int> h_tile_pt;
+    {
+      bool ok = true;
+      int j = 0;
+      h_tile_pt.push_back(0);
+      while (j < p.num_points) {
+        int j1 = j, obs = 0;
+        while (j1 < p.num_points && j1 - j < TILE_PTS && obs + (h_pt_ptr[j1 + 1] - h_pt_ptr[j1]) <= TILE_OBS) {
+          obs += h_pt_ptr[j1 + 1] - h_pt_ptr[j1];
+          ++j1;
+        }
+        if (j1 == j) { ok = false; break; }  // a single track longer than a tile
+        h_tile_pt.push_back(j1);
+        j = j1;
+      }
+      if (!ok) h_tile_pt.assign(1, 0);
+    }
+    // solo flags: does another observation of the same point use the same pose / camera?
+    std::vector<unsigned char> h_solo(n, 0);
+    for (int j = 0; j < p.num_points; ++j)
+      for (int a = h_pt_ptr[j]; a < h_pt_ptr[j + 1]; ++a) {
+        int same_pose = 0, same_cam = 0;
+        for (int a2 = h_pt_ptr[j]; a2 < h_pt_ptr[j + 1]; ++a2) {
+          same_pose += p.obs_pose[active[a2]] == p.obs_pose[active[a]];
+          same_cam += p.obs_cam[active[a2]] == p.obs_cam[active[a]];
+        }
+        h_solo[h_a2c[a]] = (unsigned char)((same_pose == 1 ? 1 : 0) | (same_cam == 1 ? 2 : 0));
+      }
     std::vector<int> h_o_pose(n), h_o_cam(n), h_o_pt(n);
     std::vector<double> h_xy((size_t)2 * n);
-    std::vector<int> h_pt_ptr(p.num_points + 1, 0);
-    for (int a = 0; a < n; ++a) {
-      const int64_t o = active[a];
-      h_o_pose[a] = p.obs_pose[o];
-      h_o_cam[a] = p.obs_cam[o];
-      h_o_pt[a] = p.obs_point[o];
-      h_xy[2 * (size_t)a] = p.obs_xy[2 * o];
-      h_xy[2 * (size_t)a + 1] = p.obs_xy[2 * o + 1];
-      h_pt_ptr[p.obs_point[o] + 1]++;
+    for (int c = 0; c < n; ++c) {
+      const int64_t o = active[h_c2a[c]];
+      h_o_pose[c] = p.obs_pose[o];
+      h_o_cam[c] = p.obs_cam[o];
+      h_o_pt[c] = p.obs_point[o];
+      h_xy[2 * (size_t)c] = p.obs_xy[2 * o];
+      h_xy[2 * (size_t)c + 1] = p.obs_xy[2 * o + 1];
     }
-    for (int j = 0; j < p.num_points; ++j) h_pt_ptr[j + 1] += h_pt_ptr[j];
     // tangent layout: pose blocks, then intrinsics blocks (camera side); points
     h_pose_off.assign(p.num_poses, -1);
     h_cam_off.assign(p.num_cams, -1);
@@ -926,28 +1062,33 @@ struct Solver {
       h_pt_off[j] = poff;
       poff += 3;
     }
-    // per-block observation lists, split into chunks
+    // per-block c-order ranges, split into chunks. A pose whose observations use several cameras
+    // (not produced by COLMAP's trivial-rig frames) would not be contiguous: reject it.
     const int n_blk = (int)h_blk_off.size();
-    std::vector<int> cnt(n_blk + 1, 0);
-    for (int a = 0; a < n; ++a) {
-      if (blk_of_pose[h_o_pose[a]] >= 0) cnt[blk_of_pose[h_o_pose[a]] + 1]++;
-      if (blk_of_cam[h_o_cam[a]] >= 0) cnt[blk_of_cam[h_o_cam[a]] + 1]++;
+    std::vector<int> beg(n_blk, n), end(n_blk, 0), cntb(n_blk, 0);
+    for (int c = 0; c < n; ++c) {
+      const int bs[2] = {blk_of_pose[h_o_pose[c]], blk_of_cam[h_o_cam[c]]};
+      for (int b : bs) {
+        if (b < 0) continue;
+        beg[b] = std::min(beg[b], c);
+        end[b] = std::max(end[b], c + 1);
+        cntb[b]++;
+      }
     }
-    for (int b = 0; b < n_blk; ++b) cnt[b + 1] += cnt[b];
-    std::vector<int> h_blk_obs(cnt[n_blk]), fill(cnt.begin(), cnt.end() - 1);
-    for (int a = 0; a < n; ++a) {
-      const int bp = blk_of_pose[h_o_pose[a]], bc = blk_of_cam[h_o_cam[a]];
-      if (bp >= 0) h_blk_obs[fill[bp]++] = a;
-      if (bc >= 0) h_blk_obs[fill[bc]++] = a;
-    }
+    for (int b = 0; b < n_blk; ++b)
+      if (cntb[b] != end[b] - beg[b])
+        throw std::runtime_error("a pose block is observed through several cameras: not supported "
+                                 "(COLMAP frames with a trivial rig have one camera per image)");
+    const int CHUNK = chunk_size() & ~1;
     std::vector<int> h_chunk_blk, h_chunk_beg, h_chunk_end, h_blk_chunk_ptr(n_blk + 1, 0);
     for (int b = 0; b < n_blk; ++b) {
       h_blk_chunk_ptr[b] = (int)h_chunk_blk.size();
-      for (int s = cnt[b]; s < cnt[b + 1]; s += CHUNK) {
+      for (int s = beg[b]; s < end[b]; s += CHUNK) {
         h_chunk_blk.push_back(b);
         h_chunk_beg.push_back(s);
-        h_chunk_end.push_back(std::min(s + CHUNK, cnt[b + 1]));
+        h_chunk_end.push_back(std::min(s + CHUNK, end[b]));
       }
+      // keep chunk boundaries on even offsets: the MFMA Gram kernel consumes observation pairs
     }
     h_blk_chunk_ptr[n_blk] = (int)h_chunk_blk.size();
 
@@ -963,7 +1104,8 @@ struct Solver {
     pt_off.upload(h_pt_off); pt_ptr.upload(h_pt_ptr);
     blk_off.upload(h_blk_off); blk_dim.upload(h_blk_dim); blk_kind.upload(h_blk_kind); blk_moff.upload(h_blk_moff);
     chunk_blk.upload(h_chunk_blk); chunk_beg.upload(h_chunk_beg); chunk_end.upload(h_chunk_end);
-    blk_obs.upload(h_blk_obs);
+    c2a.upload(h_c2a); a2c.upload(h_a2c); solo.upload(h_solo); tile_pt.upload(h_tile_pt);
+    V.n_tiles = (int)h_tile_pt.size() - 1;
     blk_chunk_ptr.upload(h_blk_chunk_ptr);
     cpart.alloc((size_t)h_chunk_blk.size() * PD * PD);
     poses.upload(std::vector<double>(p.poses, p.poses + 7 * (size_t)p.num_poses));
@@ -971,7 +1113,7 @@ struct Solver {
     points.upload(std::vector<double>(p.points, p.points + 3 * (size_t)p.num_points));
     poses2.alloc(poses.n); cams2.alloc(cams.n); points2.alloc(points.n);
     const size_t N = (size_t)n;
-    Jpose.alloc(2 * PD * N); Jcam.alloc(2 * KD * N); Jpt.alloc(6 * N); res.alloc(2 * N);
+    Jpose.alloc(2 * PD * N); Jcam.alloc(2 * KD * N); Jpt.alloc(6 * N); res.alloc(2 * N); res_p.alloc(2 * N);
     jx.alloc(2 * N); v.alloc(2 * N);
     scale_c.alloc(n_c); scale_p.alloc(poff); gc.alloc(n_c); gp.alloc(poff); diag_c.alloc(n_c); diag_p.alloc(poff);
     Dc.alloc(n_c); Dp.alloc(poff); rhs.alloc(n_c); x.alloc(n_c); r.alloc(n_c); z.alloc(n_c); pdir.alloc(n_c);
@@ -988,9 +1130,10 @@ struct Solver {
     V.cam_off = cam_off.p; V.cam_dim = cam_dim.p; V.cam_var = cam_var.p; V.cam_model = cam_model.p;
     V.pt_off = pt_off.p; V.pt_ptr = pt_ptr.p;
     V.blk_off = blk_off.p; V.blk_dim = blk_dim.p; V.blk_kind = blk_kind.p; V.blk_moff = blk_moff.p;
-    V.chunk_blk = chunk_blk.p; V.chunk_beg = chunk_beg.p; V.chunk_end = chunk_end.p; V.blk_obs = blk_obs.p;
+    V.chunk_blk = chunk_blk.p; V.chunk_beg = chunk_beg.p; V.chunk_end = chunk_end.p;
+    V.c2a = c2a.p; V.a2c = a2c.p; V.solo = solo.p; V.tile_pt = tile_pt.p;
     V.blk_chunk_ptr = blk_chunk_ptr.p; V.cpart = cpart.p;
-    V.Jpose = Jpose.p; V.Jcam = Jcam.p; V.Jpt = Jpt.p; V.res = res.p;
+    V.Jpose = Jpose.p; V.Jcam = Jcam.p; V.Jpt = Jpt.p; V.res = res.p; V.res_p = res_p.p;
     V.scale_c = scale_c.p; V.scale_p = scale_p.p; V.scalars = scalars.p;
     // uploads / memsets above ran on the NULL stream, the solve runs on a non-blocking stream
     BA_HIP(hipDeviceSynchronize());
@@ -1015,12 +1158,20 @@ struct Solver {
     BA_LAUNCH(ba_point_grad_kernel, dim3(grid_for(V.n_points, 128)), dim3(128), st, V, gp.p, diag_p.p);
   }
 
+  template <int MODE>
+  void point_pass() {
+    if (V.n_tiles > 0)
+      BA_LAUNCH(ba_point_pass_tiled_kernel<MODE>, dim3(V.n_tiles), dim3(TILE_PTS), st, V, Cinv.p, jx.p, gp.p, v.p, dp.p);
+    else
+      BA_LAUNCH(ba_point_pass_kernel<MODE>, dim3(grid_for(V.n_points, 128)), dim3(128), st, V, Cinv.p, jx.p, gp.p,
+                v.p, dp.p);
+  }
+
   // q = S x = (B + Dc^2) x - E C^-1 E^T x
   void schur_multiply(const double* xin, double* qout) {
     const int go = grid_for(V.n_obs, 256);
     BA_LAUNCH(ba_obs_jx_kernel, dim3(go), dim3(256), st, V, xin, jx.p);
-    BA_LAUNCH(ba_point_pass_kernel<0>, dim3(grid_for(V.n_points, 128)), dim3(128), st, V, Cinv.p,
-                       jx.p, gp.p, v.p, dp.p);
+    point_pass<0>();
     BA_LAUNCH(ba_dsq_x_kernel, dim3(grid_for(V.n_c, 256)), dim3(256), st, V.n_c, Dc.p, xin, qout);
     BA_LAUNCH(ba_block_jtv_kernel<false>, dim3(V.n_chunks), dim3(64), st, V, v.p, qout, nullptr);
     BA_LAUNCH(ba_block_vec_finalize_kernel<false>, dim3(grid_for(V.n_blk, 128)), dim3(128), st, V, qout, nullptr);
@@ -1139,8 +1290,7 @@ struct Solver {
         BA_LAUNCH(ba_block_mat_finalize_kernel<true>, dim3(grid_for(V.n_blk, 128)), dim3(128), st, V, M.p);
         BA_LAUNCH(ba_block_invert_kernel, dim3(grid_for(V.n_blk, 64)), dim3(64), st, V, Dc.p, M.p, Minv.p);
         // reduced rhs = g_c - E C^-1 g_p
-        BA_LAUNCH(ba_point_pass_kernel<1>, dim3(grid_for(V.n_points, 128)), dim3(128), st, V, Cinv.p,
-                           jx.p, gp.p, v.p, dp.p);
+        point_pass<1>();
         BA_HIP(hipMemcpyAsync(rhs.p, gc.p, sizeof(double) * nc, hipMemcpyDeviceToDevice, st));
         BA_LAUNCH(ba_block_jtv_kernel<false>, dim3(V.n_chunks), dim3(64), st, V, v.p, rhs.p, nullptr);
         BA_LAUNCH(ba_block_vec_finalize_kernel<false>, dim3(grid_for(V.n_blk, 128)), dim3(128), st, V, rhs.p, nullptr);
@@ -1149,8 +1299,7 @@ struct Solver {
       }
       // back-substitution y_p = C^-1 (g_p - E^T y_c); step = -(y_c, y_p)
       BA_LAUNCH(ba_obs_jx_kernel, dim3(grid_for(V.n_obs, 256)), dim3(256), st, V, x.p, jx.p);
-      BA_LAUNCH(ba_point_pass_kernel<2>, dim3(grid_for(V.n_points, 128)), dim3(128), st, V, Cinv.p,
-                         jx.p, gp.p, v.p, dp.p);
+      point_pass<2>();
       BA_LAUNCH(ba_axpby_kernel, dim3(std::max(gvc, 1)), dim3(256), st, nc, -1.0, x.p, nullptr, stepc.p);
       BA_LAUNCH(ba_axpby_kernel, dim3(std::max(gvp, 1)), dim3(256), st, np, -1.0, dp.p, nullptr, stepp.p);
       BA_LAUNCH(ba_model_kernel, dim3(grid_for(V.n_obs, 256)), dim3(256), st, V, stepc.p, stepp.p, partials.p);

@@ -236,3 +236,13 @@ def test_full_size_properties():
     again = orig.copy()
     s2 = est.solve_flat(again, est.SolverOptions(max_num_iterations=12), gpu_index=0)
     assert s2.final_cost == s.final_cost and np.array_equal(again.poses, fp.poses)
+
+
+def test_tracks_longer_than_a_tile():
+    """Tracks with more observations than the LDS tile (512) take the untiled point pass."""
+    fp = _flat(600, 6, 600, seed=9, noise=scene.SyntheticNoiseOptions(0.01, 0.5, 0.02, 0.5))
+    assert est.fix_gauge_two_cams(fp)
+    (a, want), (b, got) = _both(fp, max_num_iterations=8)
+    assert got.num_residuals == want.num_residuals == 2 * 6 * 600
+    np.testing.assert_allclose(got.log_cost[:4], want.log_cost[:4], rtol=1e-7)
+    assert abs(got.final_cost - want.final_cost) <= 1e-5 * want.final_cost
