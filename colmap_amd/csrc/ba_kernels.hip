@@ -29,6 +29,7 @@
 #include "../../include/colmap_amd_ba.h"
 
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
 
 #include <algorithm>
 #include <chrono>
@@ -65,6 +66,34 @@ static int chunk_size() {     // observations per camera-side reduction chunk (o
 constexpr int NSCALAR = 16;
 constexpr int TILE_OBS = 512;  // observations staged in LDS per point-pass workgroup
 constexpr int TILE_PTS = 256;
+
+// Sum over ranks of a device vector (in place). world == 1: nothing. Two transports: a caller
+// supplied host callback (any communicator: gloo, MPI, ...) or RCCL on the solver's stream.
+struct Comm {
+  int rank = 0, world = 1;
+  ba_allreduce_fn fn = nullptr;
+  void* user = nullptr;
+  ncclComm_t nccl = nullptr;
+  std::vector<double> host;
+  long long calls = 0, doubles = 0;
+
+  void allreduce(double* dev, size_t n, hipStream_t st) {
+    if (world <= 1 || n == 0) return;
+    ++calls;
+    doubles += (long long)n;
+    if (nccl) {
+      const ncclResult_t r = ncclAllReduce(dev, dev, n, ncclDouble, ncclSum, nccl, st);
+      if (r != ncclSuccess) throw std::runtime_error(std::string("RCCL all-reduce failed: ") + ncclGetErrorString(r));
+      return;
+    }
+    host.resize(n);
+    BA_HIP(hipMemcpyAsync(host.data(), dev, n * sizeof(double), hipMemcpyDeviceToHost, st));
+    BA_HIP(hipStreamSynchronize(st));
+    if (fn(user, host.data(), (int64_t)n) != 0) throw std::runtime_error("all-reduce callback failed");
+    BA_HIP(hipMemcpyAsync(dev, host.data(), n * sizeof(double), hipMemcpyHostToDevice, st));
+    BA_HIP(hipStreamSynchronize(st));
+  }
+};
 
 enum Scalar { S_COST = 0, S_GMAX, S_RHO, S_RHO_LAST, S_PQ, S_Q, S_MODEL, S_NEWCOST, S_ITER };
 
@@ -342,20 +371,31 @@ __global__ void ba_point_grad_kernel(View V, double* __restrict__ gp, double* __
   }
 }
 
-// C_j = E_j^T E_j + Dp^2, inverted (3x3 cofactor inverse)
-__global__ void ba_point_blocks_kernel(View V, const double* __restrict__ Dp, double* __restrict__ Cinv) {
+// E_j^T E_j of this rank's observations (upper triangle xx xy xz yy yz zz), [6][n_points]
+__global__ void ba_point_gram_kernel(View V, double* __restrict__ Craw) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= V.n_points) return;
+  const size_t N = (size_t)V.n_obs;
+  double C[6] = {0, 0, 0, 0, 0, 0};
+  if (V.pt_off[j] >= 0)
+    for (int o = V.pt_ptr[j]; o < V.pt_ptr[j + 1]; ++o)
+      for (int r = 0; r < 2; ++r) {
+        const double a = V.Jpt[(size_t)(r * 3 + 0) * N + o], b = V.Jpt[(size_t)(r * 3 + 1) * N + o],
+                     c = V.Jpt[(size_t)(r * 3 + 2) * N + o];
+        C[0] += a * a; C[1] += a * b; C[2] += a * c; C[3] += b * b; C[4] += b * c; C[5] += c * c;
+      }
+  for (int e = 0; e < 6; ++e) Craw[(size_t)e * V.n_points + j] = C[e];
+}
+
+// C_j = (sum over ranks of E_j^T E_j) + Dp^2, inverted (3x3 cofactor inverse)
+__global__ void ba_point_blocks_kernel(View V, const double* __restrict__ Craw, const double* __restrict__ Dp,
+                                       double* __restrict__ Cinv) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= V.n_points) return;
   const int off = V.pt_off[j];
   if (off < 0) return;
-  const size_t N = (size_t)V.n_obs;
-  double C[6] = {0, 0, 0, 0, 0, 0};  // xx xy xz yy yz zz
-  for (int o = V.pt_ptr[j]; o < V.pt_ptr[j + 1]; ++o)
-    for (int r = 0; r < 2; ++r) {
-      const double a = V.Jpt[(size_t)(r * 3 + 0) * N + o], b = V.Jpt[(size_t)(r * 3 + 1) * N + o],
-                   c = V.Jpt[(size_t)(r * 3 + 2) * N + o];
-      C[0] += a * a; C[1] += a * b; C[2] += a * c; C[3] += b * b; C[4] += b * c; C[5] += c * c;
-    }
+  double C[6];
+  for (int e = 0; e < 6; ++e) C[e] = Craw[(size_t)e * V.n_points + j];
   C[0] += Dp[off] * Dp[off];
   C[3] += Dp[off + 1] * Dp[off + 1];
   C[5] += Dp[off + 2] * Dp[off + 2];
@@ -409,6 +449,55 @@ __global__ void ba_point_pass_kernel(View V, const double* __restrict__ Cinv, co
       const double eu = V.Jpt[(size_t)(r * 3 + 0) * N + o] * u[0] + V.Jpt[(size_t)(r * 3 + 1) * N + o] * u[1] +
                         V.Jpt[(size_t)(r * 3 + 2) * N + o] * u[2];
       v[r * N + c] = (MODE == 0 ? jx[r * N + o] : 0.0) - eu;
+    }
+  }
+}
+
+// Sharded variants (observations of a point live on several ranks): E^T jx partial -> all-reduce
+// -> C^-1 and the per-observation update.
+__global__ void ba_point_t_kernel(View V, const double* __restrict__ jx, double* __restrict__ t) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= V.n_points) return;
+  const int off = V.pt_off[j];
+  if (off < 0) return;
+  const size_t N = (size_t)V.n_obs;
+  double acc[3] = {0, 0, 0};
+  for (int o = V.pt_ptr[j]; o < V.pt_ptr[j + 1]; ++o)
+    for (int r = 0; r < 2; ++r) {
+      const double x = jx[r * N + o];
+      for (int c = 0; c < 3; ++c) acc[c] += V.Jpt[(size_t)(r * 3 + c) * N + o] * x;
+    }
+  for (int c = 0; c < 3; ++c) t[off + c] = acc[c];
+}
+// MODE 0: v_o = jx_o - E_o C^-1 t ; MODE 2: dp = C^-1 (g_p - t)
+template <int MODE>
+__global__ void ba_point_apply_kernel(View V, const double* __restrict__ Cinv, const double* __restrict__ jx,
+                                      const double* __restrict__ gp, const double* __restrict__ t,
+                                      double* __restrict__ v, double* __restrict__ dp) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= V.n_points) return;
+  const int off = V.pt_off[j];
+  const size_t N = (size_t)V.n_obs;
+  const int beg = V.pt_ptr[j], end = V.pt_ptr[j + 1];
+  if (off < 0) {
+    if (MODE == 0) for (int o = beg; o < end; ++o) { const int c = V.a2c[o]; v[c] = jx[o]; v[N + c] = jx[N + o]; }
+    return;
+  }
+  double tt[3];
+  for (int c = 0; c < 3; ++c) tt[c] = MODE == 2 ? gp[off + c] - t[off + c] : t[off + c];
+  const double* Ci = Cinv + 9 * (size_t)j;
+  double u[3];
+  for (int r = 0; r < 3; ++r) u[r] = Ci[3 * r] * tt[0] + Ci[3 * r + 1] * tt[1] + Ci[3 * r + 2] * tt[2];
+  if (MODE == 2) {
+    for (int c = 0; c < 3; ++c) dp[off + c] = u[c];
+    return;
+  }
+  for (int o = beg; o < end; ++o) {
+    const int c = V.a2c[o];
+    for (int r = 0; r < 2; ++r) {
+      const double eu = V.Jpt[(size_t)(r * 3 + 0) * N + o] * u[0] + V.Jpt[(size_t)(r * 3 + 1) * N + o] * u[1] +
+                        V.Jpt[(size_t)(r * 3 + 2) * N + o] * u[2];
+      v[r * N + c] = jx[r * N + o] - eu;
     }
   }
 }
@@ -749,6 +838,10 @@ __global__ void ba_scale_kernel(int n, const double* __restrict__ diag, int enab
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) s[i] = enable ? 1.0 / (1.0 + sqrt(diag[i])) : 1.0;
 }
+__global__ void ba_add_kernel(int n, const double* __restrict__ x, double* __restrict__ y) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] += x[i];
+}
 __global__ void ba_dsq_x_kernel(int n, const double* __restrict__ D, const double* __restrict__ x,
                                 double* __restrict__ y) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -918,6 +1011,7 @@ static const bool g_ba_debug = std::getenv("COLMAP_AMD_BA_DEBUG") != nullptr;
 struct Solver {
   const ba_options& opt;
   ba_problem& prob;
+  Comm& comm;
   View V{};
   hipStream_t st = nullptr;
   // topology
@@ -925,12 +1019,12 @@ struct Solver {
       pt_ptr, blk_off, blk_dim, blk_kind, blk_moff, chunk_blk, chunk_beg, chunk_end, blk_chunk_ptr, c2a, a2c, tile_pt;
   Buf<unsigned char> solo;
   Buf<double> o_xy, poses, cams, points, poses2, cams2, points2, Jpose, Jcam, Jpt, res, res_p, scale_c, scale_p,
-      scalars, gc, gp, diag_c, diag_p, Dc, Dp, Cinv, M, Minv, rhs, x, r, z, pdir, q, dp, jx, v, stepc, stepp, partials, cpart;
+      scalars, gc, gp, diag_c, diag_p, Dc, Dp, Cinv, M, Minv, rhs, x, r, z, pdir, q, dp, jx, v, stepc, stepp, partials, cpart, Craw, tbuf, tmpc;
   int moff_total = 0;
   std::vector<int> h_pose_off, h_cam_off, h_pt_off;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
-  Solver(ba_problem& p_, const ba_options& o_) : opt(o_), prob(p_) {}
+  Solver(ba_problem& p_, const ba_options& o_, Comm& c_) : opt(o_), prob(p_), comm(c_) {}
   ~Solver() {
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
@@ -942,6 +1036,10 @@ struct Solver {
     BA_HIP(hipMemcpyAsync(&v, scalars.p + slot, sizeof(double), hipMemcpyDeviceToHost, st));
     BA_HIP(hipStreamSynchronize(st));
     return v;
+  }
+  double scalar_sum(int slot) {  // value summed over ranks
+    comm.allreduce(scalars.p + slot, 1, st);
+    return scalar(slot);
   }
   void zero_scalar(int slot) { BA_HIP(hipMemsetAsync(scalars.p + slot, 0, sizeof(double), st)); }
 
@@ -960,15 +1058,17 @@ struct Solver {
         if (!p.cam_const[(size_t)k * BA_CAM_STRIDE + j]) h_cam_var[(size_t)k * KD + cam_nvar[k]++] = j;
     }
     std::vector<int64_t> active;
-    active.reserve(p.num_obs);
+    active.reserve(p.num_obs / comm.world + 1);
+    int64_t n_active_global = 0;
     std::vector<char> pose_used(p.num_poses, 0), cam_used(p.num_cams, 0), pt_used(p.num_points, 0);
     for (int64_t o = 0; o < p.num_obs; ++o) {
       const int pi = p.obs_pose[o], ci = p.obs_cam[o], xi = p.obs_point[o];
       if (pi < 0 || pi >= p.num_poses || ci < 0 || ci >= p.num_cams || xi < 0 || xi >= p.num_points)
         throw std::runtime_error("observation index out of range");
       if (p.pose_const[pi] && cam_nvar[ci] == 0 && p.point_const[xi]) continue;
-      active.push_back(o);
-      pose_used[pi] = cam_used[ci] = pt_used[xi] = 1;
+      ++n_active_global;
+      pose_used[pi] = cam_used[ci] = pt_used[xi] = 1;  // layout = all ranks' observations
+      if (pi % comm.world == comm.rank) active.push_back(o);  // image sharding
     }
     const int n = (int)active.size();
     // p-order: sorted by point (stable: keeps the caller's order inside a track)
@@ -1075,10 +1175,12 @@ struct Solver {
         cntb[b]++;
       }
     }
-    for (int b = 0; b < n_blk; ++b)
+    for (int b = 0; b < n_blk; ++b) {
+      if (cntb[b] == 0) beg[b] = end[b] = 0;  // block without observations on this rank
       if (cntb[b] != end[b] - beg[b])
         throw std::runtime_error("a pose block is observed through several cameras: not supported "
                                  "(COLMAP frames with a trivial rig have one camera per image)");
+    }
     const int CHUNK = chunk_size() & ~1;
     std::vector<int> h_chunk_blk, h_chunk_beg, h_chunk_end, h_blk_chunk_ptr(n_blk + 1, 0);
     for (int b = 0; b < n_blk; ++b) {
@@ -1092,9 +1194,12 @@ struct Solver {
     }
     h_blk_chunk_ptr[n_blk] = (int)h_chunk_blk.size();
 
-    res_out->num_residuals = 2 * n;
+    res_out->num_residuals = (int32_t)(2 * n_active_global);
     res_out->num_effective_parameters = n_c + poff;
-    if (n == 0) return 0;
+    if (n_active_global == 0) return 0;
+    if (n == 0)
+      throw std::runtime_error("rank " + std::to_string(comm.rank) + " holds no observation: use fewer ranks "
+                               "than images");
 
     // upload
     o_pose.upload(h_o_pose); o_cam.upload(h_o_cam); o_pt.upload(h_o_pt); o_xy.upload(h_xy);
@@ -1119,6 +1224,7 @@ struct Solver {
     Dc.alloc(n_c); Dp.alloc(poff); rhs.alloc(n_c); x.alloc(n_c); r.alloc(n_c); z.alloc(n_c); pdir.alloc(n_c);
     q.alloc(n_c); dp.alloc(poff); stepc.alloc(n_c); stepp.alloc(poff);
     Cinv.alloc(9 * (size_t)p.num_points); M.alloc(moff); Minv.alloc(moff);
+    Craw.alloc(6 * (size_t)p.num_points); tbuf.alloc(poff); tmpc.alloc(n_c);
     scalars.alloc(NSCALAR);
     partials.alloc((size_t)grid_for(n, 256) + 1);
 
@@ -1137,7 +1243,7 @@ struct Solver {
     V.scale_c = scale_c.p; V.scale_p = scale_p.p; V.scalars = scalars.p;
     // uploads / memsets above ran on the NULL stream, the solve runs on a non-blocking stream
     BA_HIP(hipDeviceSynchronize());
-    return n;
+    return (int)std::min<int64_t>(n_active_global, 1 << 30);
   }
 
   void launch_linearize(bool jac, const double* P, const double* Cm, const double* X, int slot) {
@@ -1155,7 +1261,23 @@ struct Solver {
       BA_LAUNCH(ba_block_jtv_kernel<true>, dim3(V.n_chunks), dim3(64), st, V, res.p, gc.p, diag_c.p);
       BA_LAUNCH(ba_block_vec_finalize_kernel<true>, dim3(grid_for(V.n_blk, 128)), dim3(128), st, V, gc.p, diag_c.p);
     }
+    BA_HIP(hipMemsetAsync(gp.p, 0, sizeof(double) * std::max(V.n_p, 1), st));
+    BA_HIP(hipMemsetAsync(diag_p.p, 0, sizeof(double) * std::max(V.n_p, 1), st));
     BA_LAUNCH(ba_point_grad_kernel, dim3(grid_for(V.n_points, 128)), dim3(128), st, V, gp.p, diag_p.p);
+    comm.allreduce(gc.p, V.n_c, st);
+    comm.allreduce(diag_c.p, V.n_c, st);
+    comm.allreduce(gp.p, V.n_p, st);
+    comm.allreduce(diag_p.p, V.n_p, st);
+  }
+
+  // y = (sum over ranks of J_c^T v) for this rank's observations, into tmpc
+  void block_jtv_reduced(const double* vin) {
+    BA_HIP(hipMemsetAsync(tmpc.p, 0, sizeof(double) * std::max(V.n_c, 1), st));
+    if (V.n_chunks > 0) {
+      BA_LAUNCH(ba_block_jtv_kernel<false>, dim3(V.n_chunks), dim3(64), st, V, vin, tmpc.p, nullptr);
+      BA_LAUNCH(ba_block_vec_finalize_kernel<false>, dim3(grid_for(V.n_blk, 128)), dim3(128), st, V, tmpc.p, nullptr);
+    }
+    comm.allreduce(tmpc.p, V.n_c, st);
   }
 
   template <int MODE>
@@ -1170,11 +1292,19 @@ struct Solver {
   // q = S x = (B + Dc^2) x - E C^-1 E^T x
   void schur_multiply(const double* xin, double* qout) {
     const int go = grid_for(V.n_obs, 256);
-    BA_LAUNCH(ba_obs_jx_kernel, dim3(go), dim3(256), st, V, xin, jx.p);
-    point_pass<0>();
+    if (V.n_obs > 0) BA_LAUNCH(ba_obs_jx_kernel, dim3(go), dim3(256), st, V, xin, jx.p);
+    if (comm.world == 1) {
+      point_pass<0>();
+    } else {
+      BA_HIP(hipMemsetAsync(tbuf.p, 0, sizeof(double) * std::max(V.n_p, 1), st));
+      BA_LAUNCH(ba_point_t_kernel, dim3(grid_for(V.n_points, 128)), dim3(128), st, V, jx.p, tbuf.p);
+      comm.allreduce(tbuf.p, V.n_p, st);
+      BA_LAUNCH(ba_point_apply_kernel<0>, dim3(grid_for(V.n_points, 128)), dim3(128), st, V, Cinv.p, jx.p, gp.p,
+                tbuf.p, v.p, dp.p);
+    }
+    block_jtv_reduced(v.p);
     BA_LAUNCH(ba_dsq_x_kernel, dim3(grid_for(V.n_c, 256)), dim3(256), st, V.n_c, Dc.p, xin, qout);
-    BA_LAUNCH(ba_block_jtv_kernel<false>, dim3(V.n_chunks), dim3(64), st, V, v.p, qout, nullptr);
-    BA_LAUNCH(ba_block_vec_finalize_kernel<false>, dim3(grid_for(V.n_blk, 128)), dim3(128), st, V, qout, nullptr);
+    BA_LAUNCH(ba_add_kernel, dim3(grid_for(V.n_c, 256)), dim3(256), st, V.n_c, tmpc.p, qout);
   }
 
   int pcg(int max_iter, double q_tol) {
@@ -1226,7 +1356,7 @@ struct Solver {
     const int gvc = grid_for(nc, 256), gvp = grid_for(np, 256);
     g_spmv_ms = 0.0; g_spmv_launches = 0;
     // bytes one implicit-Schur product streams: Jc (2x10) once for jx, Jp (2x3) twice, jx/v, Jc again
-    g_spmv_bytes = (long long)n * (2 * (PD + KD) * 8 * 2 + 6 * 8 * 2 + 4 * 8 * 3);
+    g_spmv_bytes = (long long)V.n_obs * (2 * (PD + KD) * 8 * 2 + 6 * 8 * 2 + 4 * 8 * 3);
 
     double radius = opt.initial_trust_region_radius, decrease_factor = 2.0;
     int invalid_steps = 0;
@@ -1252,7 +1382,7 @@ struct Solver {
           gradient_and_diag();
           have_scale = true;
         }
-        cost = scalar(S_COST);
+        cost = scalar_sum(S_COST);
         if (iter == 0) out->initial_cost = cost;
         // projected-gradient test: ||x - Plus(x, -g)||_inf with the unscaled gradient g = s * g_scaled
         // (the stored Jacobian is column-scaled: g_scaled = s * g, so g = g_scaled / s)
@@ -1281,30 +1411,44 @@ struct Solver {
                          opt.min_lm_diagonal, opt.max_lm_diagonal, Dc.p);
       BA_LAUNCH(ba_lm_diag_kernel, dim3(std::max(gvp, 1)), dim3(256), st, np, diag_p.p, radius,
                          opt.min_lm_diagonal, opt.max_lm_diagonal, Dp.p);
-      BA_LAUNCH(ba_point_blocks_kernel, dim3(grid_for(V.n_points, 128)), dim3(128), st, V, Dp.p, Cinv.p);
+      BA_LAUNCH(ba_point_gram_kernel, dim3(grid_for(V.n_points, 128)), dim3(128), st, V, Craw.p);
+      comm.allreduce(Craw.p, 6 * (size_t)V.n_points, st);
+      BA_LAUNCH(ba_point_blocks_kernel, dim3(grid_for(V.n_points, 128)), dim3(128), st, V, Craw.p, Dp.p, Cinv.p);
       int lin_iters = 0;
       if (nc > 0) {
-        BA_LAUNCH(ba_block_gram_kernel, dim3(V.n_chunks), dim3(64), st, V, M.p);
-        BA_LAUNCH(ba_block_mat_finalize_kernel<false>, dim3(grid_for(V.n_blk, 128)), dim3(128), st, V, M.p);
-        BA_LAUNCH(ba_block_schur_corr_kernel, dim3(V.n_chunks), dim3(64), st, V, Cinv.p, M.p);
-        BA_LAUNCH(ba_block_mat_finalize_kernel<true>, dim3(grid_for(V.n_blk, 128)), dim3(128), st, V, M.p);
+        BA_HIP(hipMemsetAsync(M.p, 0, sizeof(double) * std::max(moff_total, 1), st));
+        if (V.n_chunks > 0) {
+          BA_LAUNCH(ba_block_gram_kernel, dim3(V.n_chunks), dim3(64), st, V, M.p);
+          BA_LAUNCH(ba_block_mat_finalize_kernel<false>, dim3(grid_for(V.n_blk, 128)), dim3(128), st, V, M.p);
+          BA_LAUNCH(ba_block_schur_corr_kernel, dim3(V.n_chunks), dim3(64), st, V, Cinv.p, M.p);
+          BA_LAUNCH(ba_block_mat_finalize_kernel<true>, dim3(grid_for(V.n_blk, 128)), dim3(128), st, V, M.p);
+        }
+        comm.allreduce(M.p, (size_t)moff_total, st);
         BA_LAUNCH(ba_block_invert_kernel, dim3(grid_for(V.n_blk, 64)), dim3(64), st, V, Dc.p, M.p, Minv.p);
-        // reduced rhs = g_c - E C^-1 g_p
+        // reduced rhs = g_c - E C^-1 g_p  (g_p, C^-1 are global; the J_c^T part is summed over ranks)
         point_pass<1>();
+        block_jtv_reduced(v.p);
         BA_HIP(hipMemcpyAsync(rhs.p, gc.p, sizeof(double) * nc, hipMemcpyDeviceToDevice, st));
-        BA_LAUNCH(ba_block_jtv_kernel<false>, dim3(V.n_chunks), dim3(64), st, V, v.p, rhs.p, nullptr);
-        BA_LAUNCH(ba_block_vec_finalize_kernel<false>, dim3(grid_for(V.n_blk, 128)), dim3(128), st, V, rhs.p, nullptr);
+        BA_LAUNCH(ba_add_kernel, dim3(grid_for(nc, 256)), dim3(256), st, nc, tmpc.p, rhs.p);
         lin_iters = pcg(opt.max_linear_solver_iterations, opt.eta);
         out->total_linear_iterations += lin_iters;
       }
       // back-substitution y_p = C^-1 (g_p - E^T y_c); step = -(y_c, y_p)
-      BA_LAUNCH(ba_obs_jx_kernel, dim3(grid_for(V.n_obs, 256)), dim3(256), st, V, x.p, jx.p);
-      point_pass<2>();
+      if (V.n_obs > 0) BA_LAUNCH(ba_obs_jx_kernel, dim3(grid_for(V.n_obs, 256)), dim3(256), st, V, x.p, jx.p);
+      if (comm.world == 1) {
+        point_pass<2>();
+      } else {
+        BA_HIP(hipMemsetAsync(tbuf.p, 0, sizeof(double) * std::max(np, 1), st));
+        BA_LAUNCH(ba_point_t_kernel, dim3(grid_for(V.n_points, 128)), dim3(128), st, V, jx.p, tbuf.p);
+        comm.allreduce(tbuf.p, np, st);
+        BA_LAUNCH(ba_point_apply_kernel<2>, dim3(grid_for(V.n_points, 128)), dim3(128), st, V, Cinv.p, jx.p, gp.p,
+                  tbuf.p, v.p, dp.p);
+      }
       BA_LAUNCH(ba_axpby_kernel, dim3(std::max(gvc, 1)), dim3(256), st, nc, -1.0, x.p, nullptr, stepc.p);
       BA_LAUNCH(ba_axpby_kernel, dim3(std::max(gvp, 1)), dim3(256), st, np, -1.0, dp.p, nullptr, stepp.p);
       BA_LAUNCH(ba_model_kernel, dim3(grid_for(V.n_obs, 256)), dim3(256), st, V, stepc.p, stepp.p, partials.p);
       BA_LAUNCH(ba_final_sum_kernel, dim3(1), dim3(1024), st, partials.p, grid_for(V.n_obs, 256), scalars.p + S_MODEL);
-      const double model_change = scalar(S_MODEL);
+      const double model_change = scalar_sum(S_MODEL);
       bool accepted = false;
       double new_cost = cost;
       if (!(model_change > 0.0) || !std::isfinite(model_change)) {
@@ -1322,7 +1466,7 @@ struct Solver {
         BA_LAUNCH(ba_axpby_kernel, dim3(std::max(gvp, 1)), dim3(256), st, np, 1.0, stepp.p, scale_p.p, stepp.p);
         apply_step(stepc.p, stepp.p, poses2.p, cams2.p, points2.p);
         launch_linearize(false, poses2.p, cams2.p, points2.p, S_NEWCOST);
-        new_cost = scalar(S_NEWCOST);
+        new_cost = scalar_sum(S_NEWCOST);
         const double rho = (cost - new_cost) / model_change;
         if (rho > opt.min_relative_decrease) {
           accepted = true;
@@ -1355,7 +1499,7 @@ struct Solver {
       }
     }
     launch_linearize(false, poses.p, cams.p, points.p, S_NEWCOST);
-    out->final_cost = scalar(S_NEWCOST);
+    out->final_cost = scalar_sum(S_NEWCOST);
     out->lm_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
     BA_LAUNCH(ba_renorm_quat_kernel, dim3(grid_for(V.n_poses, 128)), dim3(128), st, V, poses.p);
     // write back variable blocks only (constant blocks stay bit-identical)
@@ -1407,7 +1551,8 @@ void ba_options_init(ba_options* o) {
   o->jacobi_scaling = 1;
 }
 
-int ba_solve(ba_problem* problem, const ba_options* options, int32_t gpu_index, ba_result* result) {
+static int SolveImpl(ba_problem* problem, const ba_options* options, int32_t gpu_index, const ba_comm* c,
+                     ba_result* result) {
   try {
     if (!problem || !options || !result) throw std::runtime_error("null argument");
     double* lc = result->log_cost;
@@ -1421,13 +1566,79 @@ int ba_solve(ba_problem* problem, const ba_options* options, int32_t gpu_index, 
       throw std::runtime_error("no HIP device available: the MI355X bundle-adjustment backend has no CPU fallback");
     if (gpu_index >= ndev) throw std::runtime_error("gpu_index out of range");
     if (gpu_index >= 0) BA_HIP(hipSetDevice(gpu_index));
-    Solver s(*problem, *options);
+    Comm comm;
+    if (c) {
+      if (c->world_size < 1 || c->rank < 0 || c->rank >= c->world_size) throw std::runtime_error("bad rank / world_size");
+      comm.rank = c->rank;
+      comm.world = c->world_size;
+      comm.fn = c->allreduce;
+      comm.user = c->user;
+      comm.nccl = reinterpret_cast<ncclComm_t>(c->rccl_comm);
+      if (comm.world > 1 && !comm.nccl && !comm.fn) throw std::runtime_error("ba_comm needs rccl_comm or an allreduce callback");
+    }
+    Solver s(*problem, *options, comm);
     s.run(result);
     return 0;
   } catch (const std::exception& e) {
     g_ba_error = e.what();
     return 1;
   }
+}
+
+int ba_solve(ba_problem* problem, const ba_options* options, int32_t gpu_index, ba_result* result) {
+  return SolveImpl(problem, options, gpu_index, nullptr, result);
+}
+
+int ba_solve_sharded(ba_problem* problem, const ba_options* options, int32_t gpu_index, const ba_comm* comm,
+                     ba_result* result) {
+  return SolveImpl(problem, options, gpu_index, comm, result);
+}
+
+int64_t ba_shard_num_observations(const ba_problem* p, int32_t rank, int32_t world_size) {
+  if (!p || world_size < 1 || rank < 0 || rank >= world_size) return -1;
+  std::vector<char> cam_var(p->num_cams, 0);
+  for (int k = 0; k < p->num_cams; ++k) {
+    const int P = p->cam_model[k] == BA_SIMPLE_PINHOLE ? 3 : 4;
+    for (int j = 0; j < P; ++j)
+      if (!p->cam_const[(size_t)k * BA_CAM_STRIDE + j]) cam_var[k] = 1;
+  }
+  int64_t n = 0;
+  for (int64_t o = 0; o < p->num_obs; ++o) {
+    const int pi = p->obs_pose[o];
+    if (p->pose_const[pi] && !cam_var[p->obs_cam[o]] && p->point_const[p->obs_point[o]]) continue;
+    if (pi % world_size == rank) ++n;
+  }
+  return n;
+}
+
+int ba_rccl_unique_id(char id[128]) {
+  static_assert(sizeof(ncclUniqueId) <= 128, "ncclUniqueId larger than the ABI buffer");
+  ncclUniqueId u;
+  if (ncclGetUniqueId(&u) != ncclSuccess) { g_ba_error = "ncclGetUniqueId failed"; return 1; }
+  std::memset(id, 0, 128);
+  std::memcpy(id, &u, sizeof(u));
+  return 0;
+}
+
+int ba_rccl_comm_create(const char id[128], int32_t rank, int32_t world_size, int32_t gpu_index, void** comm) {
+  try {
+    if (!comm) throw std::runtime_error("null argument");
+    if (gpu_index >= 0) BA_HIP(hipSetDevice(gpu_index));
+    ncclUniqueId u;
+    std::memcpy(&u, id, sizeof(u));
+    ncclComm_t c = nullptr;
+    const ncclResult_t r = ncclCommInitRank(&c, world_size, u, rank);
+    if (r != ncclSuccess) throw std::runtime_error(std::string("ncclCommInitRank failed: ") + ncclGetErrorString(r));
+    *comm = c;
+    return 0;
+  } catch (const std::exception& e) {
+    g_ba_error = e.what();
+    return 1;
+  }
+}
+
+void ba_rccl_comm_destroy(void* comm) {
+  if (comm) (void)ncclCommDestroy(reinterpret_cast<ncclComm_t>(comm));
 }
 
 int ba_last_spmv_timing(double* total_ms, int64_t* launches, int64_t* bytes_per_launch) {

@@ -463,6 +463,69 @@ class ba_result(C.Structure):
     ]
 
 
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int64)
+
+
+class ba_comm(C.Structure):
+    _fields_ = [("rank", C.c_int32), ("world_size", C.c_int32), ("allreduce", ALLREDUCE_FN),
+                ("user", C.c_void_p), ("rccl_comm", C.c_void_p)]
+
+
+class Communicator:
+    """Sum-over-ranks transport for ba_solve_sharded: `backend="callback"` routes the all-reduce
+    through torch.distributed on host memory (gloo: CPU-testable, also works with several ranks on
+    one GPU); `backend="rccl"` creates an RCCL communicator inside the library (one GPU per rank,
+    all-reduce on the solver's stream over xGMI)."""
+
+    def __init__(self, backend: str = "callback", gpu_index: int = -1):
+        import torch.distributed as dist
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.world_size = dist.get_world_size() if dist.is_initialized() else 1
+        self.backend = backend
+        self._rccl = None
+        self.calls = 0
+
+        def _cb(user, buf, n):
+            try:
+                import numpy as np
+                import torch
+                arr = np.ctypeslib.as_array(buf, shape=(n,))
+                t = torch.from_numpy(arr)
+                if self.world_size > 1:
+                    dist.all_reduce(t)  # in place on the caller's buffer
+                self.calls += 1
+                return 0
+            except Exception:  # never raise through the C frame
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        self._cb = ALLREDUCE_FN(_cb)
+        if backend == "rccl":
+            L = lib()
+            ident = C.create_string_buffer(128)
+            if self.rank == 0 and L.ba_rccl_unique_id(ident) != 0:
+                raise RuntimeError(L.ba_last_error().decode())
+            if self.world_size > 1:
+                obj = [ident.raw]
+                dist.broadcast_object_list(obj, src=0)
+                ident = C.create_string_buffer(obj[0], 128)
+            h = C.c_void_p()
+            if L.ba_rccl_comm_create(ident, self.rank, self.world_size, gpu_index, C.byref(h)) != 0:
+                raise RuntimeError(L.ba_last_error().decode())
+            self._rccl = h
+        elif backend != "callback":
+            raise ValueError(backend)
+
+    def to_c(self) -> ba_comm:
+        return ba_comm(self.rank, self.world_size, self._cb, None, self._rccl)
+
+    def close(self):
+        if self._rccl:
+            lib().ba_rccl_comm_destroy(self._rccl)
+            self._rccl = None
+
+
 def marshal_problem(fp: FlatProblem) -> ba_problem:
     p = ba_problem()
     p.num_poses, p.num_cams, p.num_points = len(fp.poses), len(fp.cams), len(fp.points)
@@ -488,7 +551,7 @@ def marshal_options(so: SolverOptions, max_log: int = 0, num_threads: int = 0) -
 
 
 def solve_flat(fp: FlatProblem, so: Optional[SolverOptions] = None, gpu_index: int = -1,
-               max_log: int = 256, solve_fn=None) -> BundleAdjustmentSummary:
+               max_log: int = 256, solve_fn=None, comm: Optional[Communicator] = None) -> BundleAdjustmentSummary:
     """ba_solve on a flat problem (in place). `solve_fn` lets the tests route the identical
     marshalled structs to the oracle library instead."""
     so = so or SolverOptions()
@@ -501,7 +564,11 @@ def solve_flat(fp: FlatProblem, so: Optional[SolverOptions] = None, gpu_index: i
     r.log_cost, r.log_radius, r.log_linear_iters = log_cost.ctypes.data, log_radius.ctypes.data, log_lin.ctypes.data
     if solve_fn is None:
         L = lib()
-        rc = L.ba_solve(C.byref(p), C.byref(o), C.c_int32(gpu_index), C.byref(r))
+        if comm is not None:
+            cc = comm.to_c()
+            rc = L.ba_solve_sharded(C.byref(p), C.byref(o), C.c_int32(gpu_index), C.byref(cc), C.byref(r))
+        else:
+            rc = L.ba_solve(C.byref(p), C.byref(o), C.c_int32(gpu_index), C.byref(r))
         if rc != 0:
             raise RuntimeError(L.ba_last_error().decode())
     else:
@@ -515,6 +582,14 @@ def solve_flat(fp: FlatProblem, so: Optional[SolverOptions] = None, gpu_index: i
         total_linear_iterations=r.total_linear_iterations, initial_cost=r.initial_cost,
         final_cost=r.final_cost, lm_seconds=r.lm_seconds, log_cost=log_cost[: r.num_logged].copy(),
         log_linear_iters=log_lin[: r.num_logged].copy())
+
+
+def shard_num_observations(fp: FlatProblem, rank: int, world_size: int) -> int:
+    """Observations rank `rank` works on under image sharding (host-only, no GPU needed)."""
+    L = lib()
+    L.ba_shard_num_observations.restype = C.c_int64
+    p = marshal_problem(fp)
+    return int(L.ba_shard_num_observations(C.byref(p), C.c_int32(rank), C.c_int32(world_size)))
 
 
 class BundleAdjuster:

@@ -88,7 +88,33 @@ typedef struct ba_result {
   int32_t* log_linear_iters;
 } ba_result;
 
+/* Multi-GPU: observations sharded by image (obs_pose % world_size == rank), every rank holds the
+ * full parameter set and calls ba_solve_sharded with the SAME problem; partial sums of the
+ * point-side quantities and of J^T v are combined by an in-place sum over ranks:
+ *   per LM iteration: cost scalars, J^T r + column norms, E^T E (6 / point), Schur-Jacobi blocks;
+ *   per PCG iteration: E^T x (3 doubles / point) and the camera-space vector J_c^T v.
+ * Transport: either a host callback (any communicator: gloo, MPI, ...) or an RCCL communicator
+ * created with ba_rccl_comm_create (all-reduce on the solver's stream, xGMI). No counterpart in the
+ * reference: Ceres and Caspar are single-device (bundle_adjustment_ceres.cc:189-191). */
+typedef int (*ba_allreduce_fn)(void* user, double* buffer, int64_t count); /* in-place sum, host memory; 0 = ok */
+typedef struct ba_comm {
+  int32_t rank, world_size;
+  ba_allreduce_fn allreduce; /* used when rccl_comm is NULL */
+  void* user;
+  void* rccl_comm;           /* from ba_rccl_comm_create, or NULL */
+} ba_comm;
+
 void ba_options_init(ba_options* options);
+
+int ba_solve_sharded(ba_problem* problem, const ba_options* options, int32_t gpu_index, const ba_comm* comm,
+                     ba_result* result);
+/* Number of observations rank `rank` of `world_size` works on (host-only helper, no GPU needed):
+ * active observations (>= 1 variable block) whose pose index satisfies pose % world_size == rank. */
+int64_t ba_shard_num_observations(const ba_problem* problem, int32_t rank, int32_t world_size);
+/* RCCL transport: rank 0 obtains a 128-byte id, every rank creates its communicator from it. */
+int ba_rccl_unique_id(char id[128]);
+int ba_rccl_comm_create(const char id[128], int32_t rank, int32_t world_size, int32_t gpu_index, void** comm);
+void ba_rccl_comm_destroy(void* comm);
 
 /* BundleAdjuster::Solve for a flattened problem. gpu_index: device ordinal, -1 = current. */
 int ba_solve(ba_problem* problem, const ba_options* options, int32_t gpu_index, ba_result* result);

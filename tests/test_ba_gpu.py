@@ -246,3 +246,64 @@ def test_tracks_longer_than_a_tile():
     assert got.num_residuals == want.num_residuals == 2 * 6 * 600
     np.testing.assert_allclose(got.log_cost[:4], want.log_cost[:4], rtol=1e-7)
     assert abs(got.final_cost - want.final_cost) <= 1e-5 * want.final_cost
+
+
+def _sharded_worker(rank, world, port, backend, q):
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        fp = _flat(12, 300, 5, seed=21, mixed=True)
+        assert est.fix_gauge_two_cams(fp)
+        comm = est.Communicator(backend, gpu_index=0)
+        s = est.solve_flat(fp, est.SolverOptions(**TIGHT), gpu_index=0, comm=comm)
+        q.put((rank, s.final_cost, s.num_residuals, s.num_iterations, fp.poses.copy(), fp.points.copy(), comm.calls))
+        comm.close()
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_sharded_solve_matches_single_gpu():
+    """Image sharding with the sum-over-ranks callback (gloo): two processes share GPU 0, each
+    linearises only its images' observations; the solution equals the single-rank solve."""
+    import socket
+    import torch.multiprocessing as mp
+    fp = _flat(12, 300, 5, seed=21, mixed=True)
+    assert est.fix_gauge_two_cams(fp)
+    single = fp.copy()
+    s1 = est.solve_flat(single, est.SolverOptions(**TIGHT), gpu_index=0)
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, "callback", q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, c0, n0, it0, poses0, pts0, calls0), (r1, c1, n1, it1, poses1, pts1, calls1) = res
+    assert c0 == c1 and np.array_equal(poses0, poses1) and np.array_equal(pts0, pts1)   # ranks agree bitwise
+    assert n0 == n1 == s1.num_residuals
+    assert calls0 == calls1 > 0
+    assert abs(c0 - s1.final_cost) <= 1e-9 * s1.final_cost
+    np.testing.assert_allclose(pts0, single.points, atol=1e-7)
+    np.testing.assert_allclose(poses0, single.poses, atol=1e-7)
+
+
+def test_rccl_transport_world_size_one():
+    """RCCL communicator plumbing on the one GPU available here (all-reduce over one rank is the
+    identity): bit-identical to the plain solve."""
+    fp = _flat(10, 200, 5, seed=23)
+    assert est.fix_gauge_two_cams(fp)
+    a, b = fp.copy(), fp.copy()
+    s0 = est.solve_flat(a, est.SolverOptions(max_num_iterations=20), gpu_index=0)
+    comm = est.Communicator("rccl", gpu_index=0)
+    try:
+        s1 = est.solve_flat(b, est.SolverOptions(max_num_iterations=20), gpu_index=0, comm=comm)
+    finally:
+        comm.close()
+    assert s0.final_cost == s1.final_cost and np.array_equal(a.poses, b.poses) and np.array_equal(a.points, b.points)

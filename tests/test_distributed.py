@@ -73,3 +73,28 @@ def test_two_rank_gloo_roundtrip():
     assert c0 == c1 == [3, 2]                    # units per rank -> aggregate = 5
     assert keys0 == keys1 == [0, 1, 2, 3, 4]     # every rank holds every image's maps
     assert vals0 == vals1 == [0.0, 1.0, 2.0, 3.0, 4.0]
+
+
+def test_ba_image_sharding_partitions_the_observations():
+    """ba_shard_num_observations (host-only C ABI helper): shards by pose index partition the
+    active observation set; constant-everything observations belong to no shard."""
+    from colmap_amd import estimators as est, scene
+    d = scene.synthesize_flat(9, 60, 4, seed=2)
+    fp = est.FlatProblem.from_arrays(d)
+    est.fix_gauge_two_cams(fp)
+    total = est.shard_num_observations(fp, 0, 1)
+    assert total == len(fp.obs_pose)
+    for world in (2, 3, 8):
+        parts = [est.shard_num_observations(fp, r, world) for r in range(world)]
+        assert sum(parts) == total
+        want = [int(np.sum(fp.obs_pose % world == r)) for r in range(world)]
+        assert parts == want
+    # an observation whose pose, intrinsics and point are all constant is not part of the program
+    fp.pose_const[:] = 1
+    fp.cam_const[:] = 1
+    fp.point_const[:5] = 1
+    n_dead = int(np.sum(np.isin(fp.obs_point, np.arange(5))))
+    assert est.shard_num_observations(fp, 0, 1) == total - n_dead
+
+
+import numpy as np  # noqa: E402
