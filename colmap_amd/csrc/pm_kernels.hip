@@ -230,20 +230,16 @@ __device__ __forceinline__ float bilateral_weight(float spatial_norm, float colo
   return pm_exp(-sds * spatial_norm - cd * cd * color_norm);
 }
 
-// One tap's source coordinate -> footprint address + bilinear fractions
-// (SampleLayeredBilinear, patch_match_cuda.cu:426-442).
+// One tap: warped source coordinate (px, py) = (col_src, row_src) * inv_z -> footprint gather +
+// bilinear fractions (SampleLayeredBilinear, patch_match_cuda.cu:426-442; the +0.5 / -0.5 texel
+// centre round trip of the reference cancels and is not evaluated in device order).
 struct TapAddr {
   uint32_t texels;
   float wx, wy;
 };
 
-__device__ __forceinline__ void tap_fetch(const PmParams& p, gbl_u32* fp, unsigned fpw,
-                                          float col_src, float row_src, float z, TapAddr& t) {
-  const float inv_z = 1.0f / z;
-  const float x = fmaf(inv_z, col_src, 0.5f);
-  const float y = fmaf(inv_z, row_src, 0.5f);
-  const float px = x - 0.5f;
-  const float py = y - 0.5f;
+__device__ __forceinline__ void tap_gather(const PmParams& p, gbl_u32* fp, unsigned fpw, float px,
+                                           float py, TapAddr& t) {
   const float fx = floorf(px);
   const float fy = floorf(py);
   t.wx = px - fx;
@@ -256,17 +252,17 @@ __device__ __forceinline__ void tap_fetch(const PmParams& p, gbl_u32* fp, unsign
   t.texels = fp[off];
 }
 
-// Bilinear blend of the four raw texels (exact small integers in float), then one
-// scale by 1/255: the device-order reading of "bilinear fetch of a normalised
-// uint8 texture" (oracle/pm_oracle.c: tex_src_bilinear_raw).
+// Bilinear blend of the four raw texels (exact small integers in float) in lerp form, then one
+// scale by 1/255: the device-order reading of "bilinear fetch of a normalised uint8 texture"
+// (oracle/pm_oracle.c: tex_src_bilinear_raw).
 __device__ __forceinline__ float tap_sample(const TapAddr& t) {
   const float c00 = (float)(t.texels & 0xffu);
   const float c10 = (float)((t.texels >> 8) & 0xffu);
   const float c01 = (float)((t.texels >> 16) & 0xffu);
   const float c11 = (float)(t.texels >> 24);
-  const float top = fmaf(c10, t.wx, c00 * (1.0f - t.wx));
-  const float bot = fmaf(c11, t.wx, c01 * (1.0f - t.wx));
-  return fmaf(bot, t.wy, top * (1.0f - t.wy)) * 0x1.010102p-8f;
+  const float top = fmaf(t.wx, c10 - c00, c00);
+  const float bot = fmaf(t.wx, c11 - c01, c01);
+  return fmaf(t.wy, bot - top, top) * 0x1.010102p-8f;
 }
 
 // Cross-lane add inside a 16-lane DPP row. The four steps (row_mirror,
@@ -303,44 +299,59 @@ __device__ __forceinline__ float ncc_group(const PmParams& p, const lds_f32* H, 
   const unsigned fpw = (unsigned)(p.src_w + 3);
   const int x0 = col - p.radius, y0 = row - p.radius;
   float s_sum = 0.0f, s_sq = 0.0f, s_ref = 0.0f;
-  auto fetch = [&](int t, TapAddr& ta) {
-    const int wrow = t / n1d;
-    const int wcol = t - wrow * n1d;
-    const float xf = (float)(x0 + wcol * p.step);
-    const float yf = (float)(y0 + wrow * p.step);
-    const float col_src = fmaf(h0, xf, fmaf(h1, yf, h2));
-    const float row_src = fmaf(h3, xf, fmaf(h4, yf, h5));
-    const float z = fmaf(h6, xf, fmaf(h7, yf, h8));
-    tap_fetch(p, fp, fpw, col_src, row_src, z, ta);
-  };
-  auto accumulate = [&](int t, const TapAddr& ta) {
-    const float src = tap_sample(ta);
-    const float wgt = wr[t].w;
-    const float refc = wr[t].c;
-    const float bws = wgt * src;
-    s_sum += bws;
-    s_sq = fmaf(bws, src, s_sq);
-    s_ref = fmaf(bws, refc, s_ref);
+  // A lane's taps t = j + 16 k are processed in chunks of 8: the eight projective divisors z_k
+  // share ONE correctly rounded division -- inv_k = (prod_{i<k} z_i * prod_{i>k} z_i) / prod z_i,
+  // with prefix products taken in increasing k and the suffix product in decreasing k (exactly
+  // restated in oracle/pm_oracle.c: ncc_cost_device). Taps beyond the window use z = 1.
+  auto chunk = [&](int kb) {
+    float csrc[8], rsrc[8], zz[8], pre[8];
+    float run = 1.0f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int t = j + 16 * (kb + k);
+      const bool valid = t < ntaps;
+      const int tt = valid ? t : 0;
+      const int wrow = tt / n1d;
+      const int wcol = tt - wrow * n1d;
+      const float xf = (float)(x0 + wcol * p.step);
+      const float yf = (float)(y0 + wrow * p.step);
+      csrc[k] = fmaf(h0, xf, fmaf(h1, yf, h2));
+      rsrc[k] = fmaf(h3, xf, fmaf(h4, yf, h5));
+      zz[k] = valid ? fmaf(h6, xf, fmaf(h7, yf, h8)) : 1.0f;
+      pre[k] = run;
+      run = run * zz[k];
+    }
+    const float rinv = 1.0f / run;
+    TapAddr ta[8];
+    float suf = 1.0f;
+#pragma unroll
+    for (int k = 7; k >= 0; --k) {
+      const float inv_z = (pre[k] * suf) * rinv;
+      suf = suf * zz[k];
+      const int t = j + 16 * (kb + k);
+      if (t < ntaps) tap_gather(p, fp, fpw, inv_z * csrc[k], inv_z * rsrc[k], ta[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int t = j + 16 * (kb + k);
+      if (t < ntaps) {
+        const float src = tap_sample(ta[k]);
+        const float wgt = wr[t].w;
+        const float refc = wr[t].c;
+        const float bws = wgt * src;
+        s_sum += bws;
+        s_sq = fmaf(bws, src, s_sq);
+        s_ref = fmaf(bws, refc, s_ref);
+      }
+    }
   };
   if (N1D > 0) {
-    constexpr int K = (N1D * N1D + 15) / 16 > 0 ? (N1D * N1D + 15) / 16 : 1;
-    TapAddr ta[K];
+    constexpr int NCHUNK = (N1D * N1D + 127) / 128 > 0 ? (N1D * N1D + 127) / 128 : 1;
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-      const int t = j + 16 * k;
-      if (t < ntaps) fetch(t, ta[k]);
-    }
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-      const int t = j + 16 * k;
-      if (t < ntaps) accumulate(t, ta[k]);
-    }
+    for (int c = 0; c < NCHUNK; ++c) chunk(8 * c);
   } else {
-    for (int t = j; t < ntaps; t += 16) {
-      TapAddr ta;
-      fetch(t, ta);
-      accumulate(t, ta);
-    }
+    const int nchunk = (ntaps + 127) / 128;
+    for (int c = 0; c < nchunk; ++c) chunk(8 * c);
   }
   s_sum = reduce16(s_sum);
   s_sq = reduce16(s_sq);

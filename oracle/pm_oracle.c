@@ -339,9 +339,10 @@ static inline float tex_src_raw(const pmo_state* st, int s, int ix, int iy) {
   if (ix < 0 || iy < 0 || ix >= st->src_w || iy >= st->src_h) return 0.0f;
   return (float)st->src_images[((size_t)s * st->src_h + iy) * st->src_w + ix];
 }
-static inline float tex_src_bilinear_raw(const pmo_state* st, int s, float x, float y) {
-  const float px = x - 0.5f;
-  const float py = y - 0.5f;
+static inline float tex_src_bilinear_raw(const pmo_state* st, int s, float px, float py) {
+  /* (px, py) are texel-space coordinates: the reference's +0.5 (texture centre, :527-528) and the
+   * -0.5 of its own four-point emulation (:430-431) cancel and are not evaluated in device order;
+   * the blend is written in lerp form */
   const float fx = floorf(px);
   const float fy = floorf(py);
   const float wx = px - fx;
@@ -354,9 +355,9 @@ static inline float tex_src_bilinear_raw(const pmo_state* st, int s, float x, fl
   const float c10 = tex_src_raw(st, s, ix1, iy);
   const float c01 = tex_src_raw(st, s, ix, iy1);
   const float c11 = tex_src_raw(st, s, ix1, iy1);
-  const float top = fmaf(c10, wx, c00 * (1.0f - wx));
-  const float bot = fmaf(c11, wx, c01 * (1.0f - wx));
-  return fmaf(bot, wy, top * (1.0f - wy)) * 0x1.010102p-8f;
+  const float top = fmaf(wx, c10 - c00, c00);
+  const float bot = fmaf(wx, c11 - c01, c01);
+  return fmaf(wy, bot - top, top) * 0x1.010102p-8f;
 }
 
 /* source depth: point filter, element type, border 0, sampled at (+0.5,+0.5)
@@ -594,7 +595,8 @@ static float ncc_cost(const pmo_state* st, const ncc_params* np, const float inv
  *    lane accumulates its taps in increasing t;
  *  - the warped coordinate of a tap is evaluated directly from the homography,
  *    fma(H0, x, fma(H1, y, H2)) with x, y the integer pixel position of the tap,
- *    instead of the reference's running sums (:554-568);
+ *    instead of the reference's running sums (:554-568); eight taps of a lane share one
+ *    division (prefix/suffix products), and the +0.5/-0.5 texel-centre round trip is dropped;
  *  - the bilinear blend is taken over the raw texels and scaled once by 1/255
  *    (tex_src_bilinear_raw) instead of normalising the four texels first;
  *  - the 16 partial sums are combined by the fixed tree the DPP cross-lane adds
@@ -617,24 +619,46 @@ static float ncc_cost_device(const pmo_state* st, const ncc_params* np, const fl
   const int ntaps = n1d * n1d;
   float a_sum[16], a_sq[16], a_ref[16], a_w[16];
   for (int j = 0; j < 16; ++j) a_sum[j] = a_sq[j] = a_ref[j] = a_w[j] = 0.0f;
-  for (int t = 0; t < ntaps; ++t) {
-    const int j = t & 15;
-    const int wrow = t / n1d, wcol = t - wrow * n1d;
-    const float xf = (float)(col - np->radius + wcol * np->step);
-    const float yf = (float)(row - np->radius + wrow * np->step);
-    const float col_src = fmaf(tf[0], xf, fmaf(tf[1], yf, tf[2]));
-    const float row_src = fmaf(tf[3], xf, fmaf(tf[4], yf, tf[5]));
-    const float z = fmaf(tf[6], xf, fmaf(tf[7], yf, tf[8]));
-    const float inv_z = 1.0f / z;
-    const float norm_col_src = fmaf(inv_z, col_src, 0.5f);
-    const float norm_row_src = fmaf(inv_z, row_src, 0.5f);
-    const float src_color = tex_src_bilinear_raw(st, s, norm_col_src, norm_row_src);
-    const float bw = weights[t];
-    const float bws = bw * src_color;
-    a_sum[j] += bws;
-    a_sq[j] = fmaf(bws, src_color, a_sq[j]);
-    a_ref[j] = fmaf(bws, refc[t], a_ref[j]);
-    a_w[j] += bw;
+  /* lane j owns taps t = j + 16 k; they are processed in chunks of eight k: the eight projective
+   * divisors share one correctly rounded division,
+   *   inv_k = (prefix_k * suffix_k) * (1 / prod z),  prefix in increasing k, suffix in decreasing k,
+   * taps beyond the window contribute z = 1 (they are not sampled) */
+  const int nchunk = (ntaps + 127) / 128;
+  for (int j = 0; j < 16; ++j) {
+    for (int cb = 0; cb < nchunk; ++cb) {
+      float csrc[8], rsrc[8], zz[8], pre[8], inv[8];
+      float run = 1.0f;
+      for (int k = 0; k < 8; ++k) {
+        const int t = j + 16 * (8 * cb + k);
+        const int valid = t < ntaps;
+        const int tt = valid ? t : 0;
+        const int wrow = tt / n1d, wcol = tt - wrow * n1d;
+        const float xf = (float)(col - np->radius + wcol * np->step);
+        const float yf = (float)(row - np->radius + wrow * np->step);
+        csrc[k] = fmaf(tf[0], xf, fmaf(tf[1], yf, tf[2]));
+        rsrc[k] = fmaf(tf[3], xf, fmaf(tf[4], yf, tf[5]));
+        zz[k] = valid ? fmaf(tf[6], xf, fmaf(tf[7], yf, tf[8])) : 1.0f;
+        pre[k] = run;
+        run = run * zz[k];
+      }
+      const float rinv = 1.0f / run;
+      float suf = 1.0f;
+      for (int k = 7; k >= 0; --k) {
+        inv[k] = (pre[k] * suf) * rinv;
+        suf = suf * zz[k];
+      }
+      for (int k = 0; k < 8; ++k) {
+        const int t = j + 16 * (8 * cb + k);
+        if (t >= ntaps) continue;
+        const float src_color = tex_src_bilinear_raw(st, s, inv[k] * csrc[k], inv[k] * rsrc[k]);
+        const float bw = weights[t];
+        const float bws = bw * src_color;
+        a_sum[j] += bws;
+        a_sq[j] = fmaf(bws, src_color, a_sq[j]);
+        a_ref[j] = fmaf(bws, refc[t], a_ref[j]);
+        a_w[j] += bw;
+      }
+    }
   }
   float src_color_sum = tree16(a_sum);
   float src_color_squared_sum = tree16(a_sq);

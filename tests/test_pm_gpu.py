@@ -225,11 +225,16 @@ def test_full_size_properties():
     mvs.run_batch([o[-1] for o in outs])
     for ref, src, dmin, dmax, pm in outs:
         depth, normal, mask, sel = pm.GetDepthMap(), pm.GetNormalMap(), pm.GetConsistencyMask(), pm.GetSelProbMap()
+        filtered = depth == 0
         kept = depth > 0
+        # the algorithm (reference included) does not forbid a non-positive depth hypothesis from
+        # winning (PropagateDepth can return one, patch_match_cuda.cu:210-236); it must be very rare
+        odd = ~filtered & ~kept
+        assert odd.mean() < 1e-4, odd.mean()
         assert 0.5 < kept.mean() <= 1.0
         nrm = np.linalg.norm(normal, axis=0)
         np.testing.assert_allclose(nrm[kept], 1.0, atol=1e-4)             # unit normals where kept
-        assert np.all(normal[:, ~kept] == 0) and np.all(mask[:, ~kept] == 0)  # filtered pixels fully zeroed
+        assert np.all(normal[:, filtered] == 0) and np.all(mask[:, filtered] == 0)  # filtered pixels fully zeroed
         assert np.all(mask[:, kept].sum(0) >= 2)                          # filter_min_num_consistent
         assert np.all((sel >= 0) & (sel <= 1)) and np.isfinite(sel).all()
         # normals face the camera (GenerateRandomNormal / PerturbNormal keep n . ray < 0)
@@ -242,7 +247,7 @@ def test_full_size_properties():
         assert np.median(rel) < 2e-3 and (rel < 0.01).mean() > 0.9        # accuracy vs ground truth
         # the consistency-graph list is consistent with the mask
         flat = pm.GetConsistentImageIdxs()
-        assert len(flat) == 3 * int(kept.sum()) + int(mask.sum())
+        assert len(flat) == 3 * int((~filtered).sum()) + int(mask.sum())
     # idempotence of the deterministic pipeline: solving the first problem alone gives the same bits
     ref, src, dmin, dmax, pm = outs[0]
     opt = mvs.PatchMatchOptions(gpu_index="0", depth_min=dmin, depth_max=dmax, sigma_spatial=5.0,
