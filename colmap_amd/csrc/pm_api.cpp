@@ -535,6 +535,9 @@ void RunAsync(pm_handle* h) { RunBatchAsync(&h, 1); }
 void Synchronize(pm_handle* h) {
   HIP_CALL(hipSetDevice(h->device));
   HIP_CALL(hipStreamSynchronize(h->run_stream ? h->run_stream : h->stream));
+  // the batch's work is complete: later copies use the handle's own stream (the stream of the
+  // batch leader may be destroyed before this handle)
+  h->run_stream = nullptr;
   h->sweep_ms = 0.0;
   h->sweep_launches = h->sweeps_done;
   for (int i = 0; i < h->sweeps_done; ++i) {

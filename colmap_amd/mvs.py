@@ -350,3 +350,146 @@ def read_mat(path: str) -> np.ndarray:
     w, h, d = int(parts[0]), int(parts[1]), int(parts[2])
     arr = np.frombuffer(parts[3], dtype="<f4", count=w * h * d).reshape(d, h, w)
     return arr[0] if d == 1 else arr
+
+
+# ---------------------------------------------------------------------------------------------
+# PatchMatchController: problem list, two-pass schedule, output files, resume
+# ---------------------------------------------------------------------------------------------
+
+@dataclass
+class WorkspaceImage:
+    """What the controller needs from the workspace per image (reference mvs/workspace.h,
+    model.h): a name relative to `images/`, calibration, pose and the grey bitmap."""
+    name: str
+    K: np.ndarray
+    R: np.ndarray
+    T: np.ndarray
+    bitmap: object
+    depth_range: Optional[tuple] = None  # (min, max); reference: Model::ComputeDepthRanges (model.cc:178-218)
+
+
+class PatchMatchController:
+    """colmap::mvs::PatchMatchController (reference mvs/patch_match.cc:156-535) for an in-memory
+    workspace:
+      * problems from a `patch-match.cfg`-style list of (reference name, source spec) pairs where
+        the source spec is "__all__" or an explicit list of names (:239-359; "__auto__" needs the
+        sparse model's shared-point statistics and is left to the caller);
+      * with geom_consistency: pass 1 = photometric, no filtering, ALL problems; barrier; pass 2 =
+        the requested options (:183-204);
+      * outputs `<workspace>/stereo/{depth_maps,normal_maps}/<name>.<photometric|geometric>.bin`
+        in Mat<float> format (:530-534, mat.cc:58-65); a problem whose outputs exist is skipped
+        (:410-414) -- the reference's resume mechanism;
+      * problems are sharded over ranks like the thread-per-GPU pool (:177,190-204,394) and, unlike
+        the reference, up to `batch_size` same-shaped problems of a rank share every kernel launch;
+        between the passes the photometric maps are exchanged in memory
+        (colmap_amd.distributed.exchange_maps) instead of through the file system.
+    """
+
+    def __init__(self, options: PatchMatchOptions, images: Sequence[WorkspaceImage], workspace_path: str,
+                 problems: Optional[Sequence[tuple]] = None, batch_size: int = 8, rank: int = 0,
+                 world_size: int = 1):
+        self.options_ = options
+        self.images_ = list(images)
+        self.workspace_path_ = workspace_path
+        self.batch_size_ = max(1, batch_size)
+        self.rank_, self.world_ = rank, world_size
+        names = [im.name for im in self.images_]
+        self.index_ = {n: i for i, n in enumerate(names)}
+        if problems is None:
+            problems = [(n, "__all__") for n in names]
+        self.problems_ = []
+        for ref_name, spec in problems:
+            ref = self.index_[ref_name]
+            if spec == "__all__":
+                src = [i for i in range(len(names)) if i != ref]
+            elif isinstance(spec, str) and spec.startswith("__auto__"):
+                raise PatchMatchError("__auto__ source selection needs the sparse model (not available here)")
+            else:
+                src = [self.index_[n] for n in spec]
+            if not src:
+                raise PatchMatchError(f"No source images for reference image {ref_name}")
+            self.problems_.append((ref, src))
+        self.timings = {}
+
+    # -- paths ------------------------------------------------------------------------------
+    def _paths(self, image_idx: int, output_type: str):
+        import os
+        name = f"{self.images_[image_idx].name}.{output_type}.bin"
+        base = os.path.join(self.workspace_path_, "stereo")
+        return os.path.join(base, "depth_maps", name), os.path.join(base, "normal_maps", name)
+
+    def _run_pass(self, options: PatchMatchOptions, maps: Optional[dict]):
+        import os
+        from . import distributed as D
+        output_type = "geometric" if options.geom_consistency else "photometric"
+        mine = [self.problems_[i] for i in D.shard_problems(len(self.problems_), self.rank_, self.world_)]
+        images = [Image(im.K, im.R, im.T, im.bitmap) for im in self.images_]
+        results = {}
+        todo = []
+        for ref, src in mine:
+            dpath, npath = self._paths(ref, output_type)
+            if os.path.exists(dpath) and os.path.exists(npath):  # resume (:410-414)
+                results[ref] = (read_mat(dpath), read_mat(npath))
+                continue
+            todo.append((ref, src))
+        # batches of same-shaped problems
+        def shape_key(prob):
+            ref, src = prob
+            return (self.images_[ref].bitmap.shape, len(src), tuple(sorted({self.images_[s].bitmap.shape for s in src})))
+        todo.sort(key=shape_key)
+        i = 0
+        while i < len(todo):
+            j = i
+            while j < len(todo) and j - i < self.batch_size_ and shape_key(todo[j]) == shape_key(todo[i]):
+                j += 1
+            pms = []
+            for ref, src in todo[i:j]:
+                o = PatchMatchOptions(**{**options.__dict__})
+                o.gpu_index = options.gpu_index
+                rng = self.images_[ref].depth_range
+                if (o.depth_min < 0 or o.depth_max < 0):
+                    if rng is None:
+                        raise PatchMatchError("You must manually set the minimum and maximum depth, since no "
+                                              "sparse model is provided in the workspace.")  # (:425-434)
+                    o.depth_min, o.depth_max = rng
+                if o.sigma_spatial <= 0:
+                    o.sigma_spatial = float(o.window_radius)  # (:436-438)
+                o.filter_min_num_consistent = min(len(src), o.filter_min_num_consistent)  # (:458-460)
+                prob = PatchMatch.Problem(ref, list(src), images)
+                if options.geom_consistency:
+                    prob.depth_maps = [maps[k][0] if k in maps else None for k in range(len(images))]
+                    prob.normal_maps = [maps[k][1] if k in maps else None for k in range(len(images))]
+                pms.append(PatchMatch(o, prob))
+            run_batch(pms)
+            for (ref, src), pm in zip(todo[i:j], pms):
+                depth, normal = pm.GetDepthMap(), pm.GetNormalMap()
+                dpath, npath = self._paths(ref, output_type)
+                os.makedirs(os.path.dirname(dpath), exist_ok=True)
+                os.makedirs(os.path.dirname(npath), exist_ok=True)
+                write_mat(dpath, depth)
+                write_mat(npath, normal)
+                results[ref] = (depth, normal)
+                pm.close()
+            i = j
+        return results
+
+    def Run(self):
+        import time
+        from . import distributed as D
+        import torch
+        opt = self.options_
+        maps = None
+        if opt.geom_consistency:
+            photo = PatchMatchOptions(**{**opt.__dict__})
+            photo.geom_consistency = False
+            photo.filter = False
+            t = time.time()
+            local = self._run_pass(photo, None)
+            # every rank needs the maps of its problems' sources: exchange in memory
+            merged = D.exchange_maps({k: torch.from_numpy(np.concatenate([d[None], n], 0)) for k, (d, n) in local.items()})
+            maps = {k: (np.ascontiguousarray(v[0].numpy()), np.ascontiguousarray(v[1:].numpy())) for k, v in merged.items()}
+            self.timings["photometric_s"] = time.time() - t
+        t = time.time()
+        out = self._run_pass(opt, maps)
+        self.timings["geometric_s" if opt.geom_consistency else "photometric_s"] = time.time() - t
+        return out

@@ -112,7 +112,7 @@ int pm_synchronize(pm_handle* h);
  * Results are bit-identical to n separate pm_run() calls. Timing of the batched
  * sweep launches is reported by pm_get_sweep_timing(handles[0]). */
 int pm_run_batch(pm_handle** handles, int32_t n);
-int pm_run_batch_async(pm_handle** handles, int32_t n); /* then pm_synchronize() each */
+int pm_run_batch_async(pm_handle** handles, int32_t n); /* then pm_synchronize() each, before destroying any */
 
 /* PatchMatchCuda::GetDepthMap / GetNormalMap / GetSelProbMap
  * (patch_match_cuda.cu:1354-1365). out buffers are host memory:

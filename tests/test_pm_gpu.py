@@ -256,3 +256,35 @@ def test_full_size_properties():
     solo.Run()
     assert np.array_equal(solo.GetDepthMap(), pm.GetDepthMap())
     assert np.array_equal(solo.GetNormalMap(), pm.GetNormalMap())
+
+
+def test_controller_two_pass_files_and_resume(pm_oracle, tmp_path):
+    """PatchMatchController: photometric pass for all images, in-memory exchange, geometric pass
+    with filtering (reference patch_match.cc:183-204); outputs in Mat format; resume skips work.
+    The whole two-pass pipeline is bit-identical to the oracle run the same way."""
+    import os
+    from colmap_amd import mvs
+    views = scene(3, 64, 48)
+    ws = [mvs.WorkspaceImage(f"img{i}.png", v.K, v.R, v.T, v.gray, syn.depth_range(views, i)) for i, v in enumerate(views)]
+    opt = mvs.PatchMatchOptions(gpu_index="0", geom_consistency=True, filter=True, num_iterations=1)
+    ctl = mvs.PatchMatchController(opt, ws, str(tmp_path), batch_size=3)
+    out = ctl.Run()
+    # oracle, same schedule
+    maps = []
+    for ref in range(3):
+        dmin, dmax = syn.depth_range(views, ref)
+        o = pm_oracle.default_options(depth_min=dmin, depth_max=dmax, geom_consistency=0, filter=0, num_iterations=1, order=1)
+        r = pm_oracle.run(o, oracle_inputs(views), ref, [i for i in range(3) if i != ref])
+        maps.append((r["depth"], r["normal"]))
+    for ref in range(3):
+        dmin, dmax = syn.depth_range(views, ref)
+        o = pm_oracle.default_options(depth_min=dmin, depth_max=dmax, geom_consistency=1, filter=1, num_iterations=1, order=1)
+        r = pm_oracle.run(o, oracle_inputs(views, True, maps), ref, [i for i in range(3) if i != ref])
+        assert np.array_equal(out[ref][0], r["depth"]) and np.array_equal(out[ref][1], r["normal"])
+        for kind in ("photometric", "geometric"):
+            assert os.path.exists(tmp_path / "stereo" / "depth_maps" / f"img{ref}.png.{kind}.bin")
+        assert np.array_equal(mvs.read_mat(str(tmp_path / "stereo" / "normal_maps" / f"img{ref}.png.geometric.bin")), r["normal"])
+    # resume: everything exists -> no GPU work, same results
+    ctl2 = mvs.PatchMatchController(opt, ws, str(tmp_path), batch_size=3)
+    out2 = ctl2.Run()
+    assert all(np.array_equal(out2[k][0], out[k][0]) for k in out)
