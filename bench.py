@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--cols", type=int, default=0)
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-image-cache", action="store_true",
+                    help="pack every problem's source images privately instead of sharing them")
     ap.add_argument("--no-ba", action="store_true", help="skip the secondary bundle-adjustment measurement")
     ap.add_argument("--ba-frames", type=int, default=1000)
     ap.add_argument("--ba-points", type=int, default=200000)
@@ -156,6 +158,10 @@ def main():
         views.append((K, R, T, g, float(d.min()), float(d.max())))
     images = [mvs.Image(K, R, T, g) for (K, R, T, g, _, _) in views]
 
+    # packed source images are shared between the problems that use them (as the reference's
+    # CachedWorkspace shares bitmaps on the host); --no-image-cache packs them per problem
+    cache = None if a.no_image_cache else mvs.ImageCache(local_rank)
+
     def problem(j):  # j-th reference image of this rank
         ref = half + j
         src = [ref + o for o in range(-half, half + 1) if o != 0][:S]
@@ -163,7 +169,7 @@ def main():
         opt = mvs.PatchMatchOptions(gpu_index=str(local_rank), depth_min=dmin, depth_max=dmax,
                                     sigma_spatial=5.0, geom_consistency=False, filter=True,
                                     columns_per_group=a.cols, threads_per_group=a.threads)
-        return mvs.PatchMatch(opt, mvs.PatchMatch.Problem(ref, src, images)), (ref, src, dmin, dmax)
+        return mvs.PatchMatch(opt, mvs.PatchMatch.Problem(ref, src, images), cache), (ref, src, dmin, dmax)
 
     def barrier():
         torch.cuda.synchronize()
@@ -226,6 +232,7 @@ def main():
                             f"S={S} sources, window 11x11, 15 samples, 5x4 sweeps; "
                             f"{a.batch} reference images per step per GPU",
                 "images_per_step_per_gpu": a.batch,
+                "shared_source_images": not a.no_image_cache,
                 "parallelism": f"reference images sharded over {world} GPU(s), no data-path collective",
             },
             "roofline": {

@@ -12,7 +12,11 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
 #include <set>
+#include <tuple>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -191,6 +195,39 @@ void CheckProblem(const pm_options& o, const pm_problem& p) {
 
 }  // namespace
 
+// A packed source image (2x2 footprints + zero ring) in HBM. Shared between problems through
+// pm_image_cache: neighbouring reference images use mostly the same sources (28 distinct images
+// for 8 consecutive references with S = 20), so a batch gathers from one copy instead of eight.
+struct FpEntry {
+  DevBuf<uint32_t> data;
+};
+
+struct pm_image_cache {
+  int device = 0;
+  std::mutex mu;
+  // key: (caller's bitmap pointer, image width, image height, slot width, slot height)
+  using Key = std::tuple<const void*, int, int, int, int>;
+  std::map<Key, std::shared_ptr<FpEntry>> entries;
+  std::vector<Key> order;  // insertion order, for eviction
+  size_t hits = 0, misses = 0;
+  size_t bytes = 0, capacity = ~(size_t)0;
+
+  // Drops the oldest entries no live problem references until the cache fits its capacity.
+  void Trim() {
+    size_t keep = 0;
+    for (size_t i = 0; i < order.size(); ++i) {
+      auto it = entries.find(order[i]);
+      if (bytes > capacity && it != entries.end() && it->second.use_count() == 1) {
+        bytes -= it->second->data.count * sizeof(uint32_t);
+        entries.erase(it);
+      } else {
+        order[keep++] = order[i];
+      }
+    }
+    order.resize(keep);
+  }
+};
+
 struct pm_handle {
   pm_options opt;
   int device = 0;
@@ -202,7 +239,8 @@ struct pm_handle {
   float ref_K[4][4], ref_inv_K[4][4];
   // device buffers
   DevBuf<float> rec;
-  DevBuf<uint32_t> src_fp;
+  std::vector<std::shared_ptr<FpEntry>> src_fp;  // per source image (possibly shared)
+  DevBuf<const uint32_t*> src_fp_tab;
   DevBuf<float> src_depth;
   DevBuf<uint8_t> ref_img;
   DevBuf<float> ref_sum, ref_sqsum;
@@ -286,7 +324,7 @@ PmParams ParamsForSweep(const pm_handle* h, int rot) {
   return p;
 }
 
-void Create(const pm_options& opt_in, const pm_problem& prob, pm_handle* h) {
+void Create(const pm_options& opt_in, const pm_problem& prob, pm_image_cache* cache, pm_handle* h) {
   CheckOptions(opt_in);
   CheckProblem(opt_in, prob);
   h->opt = opt_in;
@@ -322,17 +360,46 @@ void Create(const pm_options& opt_in, const pm_problem& prob, pm_handle* h) {
   const size_t slot = (size_t)h->src_w * h->src_h;
   {
     DevBuf<uint8_t> staging;
-    staging.alloc(slot * S);
-    HIP_CALL(hipMemsetAsync(staging.ptr, 0, slot * S, h->stream));
+    const size_t fp_count = (size_t)(h->src_w + 3) * (h->src_h + 3);
+    std::vector<const uint32_t*> tab(S);
+    h->src_fp.resize(S);
     for (int s = 0; s < S; ++s) {
       const pm_image& im = prob.images[h->src_idxs[s]];
-      // contiguous copy into the max-size slot without re-pitching, exactly as the
-      // reference's memcpy (patch_match_cuda.cu:1617-1622)
-      HIP_CALL(hipMemcpyAsync(staging.ptr + slot * s, im.gray, (size_t)im.width * im.height, in_kind,
-                              h->stream));
+      std::shared_ptr<FpEntry> e;
+      const auto key = std::make_tuple((const void*)im.gray, im.width, im.height, h->src_w, h->src_h);
+      if (cache) {
+        std::lock_guard<std::mutex> lock(cache->mu);
+        auto it = cache->entries.find(key);
+        if (it != cache->entries.end()) {
+          e = it->second;
+          ++cache->hits;
+        }
+      }
+      if (!e) {
+        e = std::make_shared<FpEntry>();
+        e->data.alloc(fp_count);
+        if (!staging.ptr) staging.alloc(slot);
+        HIP_CALL(hipMemsetAsync(staging.ptr, 0, slot, h->stream));
+        // contiguous copy into the max-size slot without re-pitching, exactly as the
+        // reference's memcpy (patch_match_cuda.cu:1617-1622)
+        HIP_CALL(hipMemcpyAsync(staging.ptr, im.gray, (size_t)im.width * im.height, in_kind, h->stream));
+        pm_launch_build_footprint(staging.ptr, e->data.ptr, 1, h->src_w, h->src_h, h->stream);
+        HIP_CALL(hipStreamSynchronize(h->stream));
+        if (cache) {
+          std::lock_guard<std::mutex> lock(cache->mu);
+          cache->entries.emplace(key, e);
+          cache->order.push_back(key);
+          cache->bytes += fp_count * sizeof(uint32_t);
+          ++cache->misses;
+          cache->Trim();
+        }
+      }
+      h->src_fp[s] = e;
+      tab[s] = e->data.ptr;
     }
-    h->src_fp.alloc((size_t)S * (h->src_w + 3) * (h->src_h + 3));
-    pm_launch_build_footprint(staging.ptr, h->src_fp.ptr, S, h->src_w, h->src_h, h->stream);
+    h->src_fp_tab.alloc(S);
+    HIP_CALL(hipMemcpyAsync(h->src_fp_tab.ptr, tab.data(), S * sizeof(const uint32_t*), hipMemcpyHostToDevice,
+                            h->stream));
     HIP_CALL(hipStreamSynchronize(h->stream));
   }
   if (opt.geom_consistency) {
@@ -371,6 +438,7 @@ void Create(const pm_options& opt_in, const pm_problem& prob, pm_handle* h) {
   PmParams& b = h->base;
   std::memset(&b, 0, sizeof(b));
   b.W = W; b.H = H; b.S = S; b.src_w = h->src_w; b.src_h = h->src_h;
+  b.fp_xmax = (float)(h->src_w + 2); b.fp_ymax = (float)(h->src_h + 2);
   b.radius = opt.window_radius;
   b.step = opt.window_step;
   b.ntap1d = (2 * b.radius) / b.step + 1;
@@ -408,7 +476,7 @@ void Create(const pm_options& opt_in, const pm_problem& prob, pm_handle* h) {
   h->rec.alloc((size_t)W * H * b.rec_stride);
   h->rng.alloc((size_t)W * H * kRngWords);
   b.rec = h->rec.ptr;
-  b.src_fp = h->src_fp.ptr;
+  b.src_fp_tab = h->src_fp_tab.ptr;
   b.src_depth = h->src_depth.ptr;
   b.ref_img = h->ref_img.ptr;
   b.ref_sum = h->ref_sum.ptr;
@@ -607,13 +675,43 @@ int pm_check(const pm_options* options, const pm_problem* problem) {
   });
 }
 
-int pm_create(const pm_options* options, const pm_problem* problem, pm_handle** out) {
+int pm_image_cache_create(int32_t gpu_index, pm_image_cache** out) {
+  return Guard([&] {
+    PM_CHECK(out, "null argument");
+    auto* c = new pm_image_cache();
+    c->device = gpu_index;
+    *out = c;
+  });
+}
+
+void pm_image_cache_destroy(pm_image_cache* cache) { delete cache; }
+
+int pm_image_cache_set_capacity(pm_image_cache* cache, size_t max_bytes) {
+  return Guard([&] {
+    PM_CHECK(cache, "null argument");
+    std::lock_guard<std::mutex> lock(cache->mu);
+    cache->capacity = max_bytes;
+    cache->Trim();
+  });
+}
+
+int pm_image_cache_stats(pm_image_cache* cache, size_t* entries, size_t* hits, size_t* misses) {
+  return Guard([&] {
+    PM_CHECK(cache, "null argument");
+    std::lock_guard<std::mutex> lock(cache->mu);
+    if (entries) *entries = cache->entries.size();
+    if (hits) *hits = cache->hits;
+    if (misses) *misses = cache->misses;
+  });
+}
+
+static int CreateImpl(const pm_options* options, const pm_problem* problem, pm_image_cache* cache, pm_handle** out) {
   if (out) *out = nullptr;
   pm_handle* h = nullptr;
   const int rc = Guard([&] {
     PM_CHECK(options && problem && out, "null argument");
     h = new pm_handle();
-    Create(*options, *problem, h);
+    Create(*options, *problem, cache, h);
   });
   if (rc != 0) {
     delete h;
@@ -621,6 +719,15 @@ int pm_create(const pm_options* options, const pm_problem* problem, pm_handle** 
   }
   *out = h;
   return 0;
+}
+
+int pm_create(const pm_options* options, const pm_problem* problem, pm_handle** out) {
+  return CreateImpl(options, problem, nullptr, out);
+}
+
+int pm_create_cached(const pm_options* options, const pm_problem* problem, pm_image_cache* cache,
+                     pm_handle** out) {
+  return CreateImpl(options, problem, cache, out);
 }
 
 int pm_run_async(pm_handle* h) {

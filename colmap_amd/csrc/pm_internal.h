@@ -18,6 +18,7 @@ struct PmParams {
   int rot;          // number of 90-degree CCW rotations of the sweep frame (0..3)
   int S;            // number of source images
   int src_w, src_h; // source slot size (max over sources)
+  float fp_xmax, fp_ymax;  // src_w + 2, src_h + 2: last column / row of the packed image
   int radius, step, ntap1d, ntaps;
   int num_samples;
   int rec_stride;   // floats per pixel record: 4 + 3*S
@@ -38,7 +39,8 @@ struct PmParams {
   int filter_min_num_consistent;
   // device pointers
   float* rec;               // [H*W][rec_stride]
-  const uint32_t* src_fp;   // [S][src_h+3][src_w+3] packed 2x2 footprints
+  const uint32_t* const* src_fp_tab;  // [S] pointers to [src_h+3][src_w+3] packed 2x2 footprints
+                                      // (separate allocations: shareable between problems)
   const float* src_depth;   // [S][src_h][src_w] or null
   const uint8_t* ref_img;   // [H][W]
   const float* ref_sum;     // [H][W]

@@ -180,13 +180,9 @@ __device__ __forceinline__ float ref_texel(const PmParams& p, int row, int col) 
 // the gathers compile to flat_load (pointer provenance is unknown to the compiler)
 typedef __attribute__((address_space(1))) const uint32_t gbl_u32;
 typedef LDS_AS float lds_f32;
-struct __attribute__((aligned(8))) WeightRef {
-  float w;  // bilateral weight
-  float c;  // reference colour
-};
-typedef LDS_AS WeightRef lds_f32x2;
 typedef LDS_AS int lds_i32;
 typedef LDS_AS uint32_t lds_u32;
+typedef LDS_AS uint64_t lds_u64;
 typedef LDS_AS char lds_char;
 
 
@@ -230,40 +226,41 @@ __device__ __forceinline__ float bilateral_weight(float spatial_norm, float colo
   return pm_exp(-sds * spatial_norm - cd * cd * color_norm);
 }
 
-// One tap: warped source coordinate (px, py) = (col_src, row_src) * inv_z -> footprint gather +
-// bilinear fractions (SampleLayeredBilinear, patch_match_cuda.cu:426-442; the +0.5 / -0.5 texel
-// centre round trip of the reference cancels and is not evaluated in device order).
-struct TapAddr {
-  uint32_t texels;
-  float wx, wy;
-};
+// Two-wide fp32 vectors: CDNA4 issues v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 on register
+// pairs at the rate of the scalar forms, so the NCC arithmetic is written on pairs of taps.
+// Every packed operation is the IEEE operation of its two halves (bit-identical to scalar code).
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2f pk_bcast(float a) { return (v2f)(a); }
 
-__device__ __forceinline__ void tap_gather(const PmParams& p, gbl_u32* fp, unsigned fpw, float px,
-                                           float py, TapAddr& t) {
-  const float fx = floorf(px);
-  const float fy = floorf(py);
-  t.wx = px - fx;
-  t.wy = py - fy;
-  // clamp to the zero ring [-2, w] x [-2, h] in the float domain (one v_med3 each), so
-  // that arbitrarily distant / non-finite taps read an all-zero footprint entry
-  const int ix = (int)__builtin_amdgcn_fmed3f(fx, -2.0f, (float)p.src_w);
-  const int iy = (int)__builtin_amdgcn_fmed3f(fy, -2.0f, (float)p.src_h);
-  const unsigned off = (unsigned)(iy + 2) * fpw + (unsigned)(ix + 2);
-  t.texels = fp[off];
+// Footprint gather of one tap: floor of the warped coordinate clamped to the zero ring
+// [-2, w] x [-2, h] in the float domain (one v_med3 each), so that arbitrarily distant /
+// non-finite taps read an all-zero footprint entry (SampleLayeredBilinear,
+// patch_match_cuda.cu:426-442; the +0.5 / -0.5 texel centre round trip of the reference cancels
+// and is not evaluated in device order).
+__device__ __forceinline__ uint32_t tap_gather(const PmParams& p, gbl_u32* fp, unsigned fpw, float fx2,
+                                               float fy2) {
+  // fx2 = floor(x) + 2, fy2 = floor(y) + 2 (the ring offset is added in the float domain, packed)
+  const unsigned ix = (unsigned)(int)__builtin_amdgcn_fmed3f(fx2, 0.0f, p.fp_xmax);
+  const unsigned iy = (unsigned)(int)__builtin_amdgcn_fmed3f(fy2, 0.0f, p.fp_ymax);
+  // 24-bit multiply-add (full rate; v_mul_lo_u32 is quarter rate): rows and pitch < 2^24
+  return fp[__umul24(iy, fpw) + ix];
 }
 
-// Bilinear blend of the four raw texels (exact small integers in float) in lerp form, then one
-// scale by 1/255: the device-order reading of "bilinear fetch of a normalised uint8 texture"
-// (oracle/pm_oracle.c: tex_src_bilinear_raw).
-__device__ __forceinline__ float tap_sample(const TapAddr& t) {
-  const float c00 = (float)(t.texels & 0xffu);
-  const float c10 = (float)((t.texels >> 8) & 0xffu);
-  const float c01 = (float)((t.texels >> 16) & 0xffu);
-  const float c11 = (float)(t.texels >> 24);
-  const float top = fmaf(t.wx, c10 - c00, c00);
-  const float bot = fmaf(t.wx, c11 - c01, c01);
-  return fmaf(t.wy, bot - top, top) * 0x1.010102p-8f;
-}
+// Byte k of a packed footprint entry as float. Inline asm keeps the four conversions as four
+// full-rate v_cvt_f32_ubyteK: left to itself the compiler rewrites (float)b - (float)a into an
+// integer subtract + v_cvt_f32_i32 pair per difference (8 instead of 5 instructions per tap).
+#define PM_UBYTE(K)                                                              \
+  __device__ __forceinline__ float ubyte##K(uint32_t x) {                        \
+    float f;                                                                     \
+    asm("v_cvt_f32_ubyte" #K " %0, %1" : "=v"(f) : "v"(x));                      \
+    return f;                                                                    \
+  }
+PM_UBYTE(0)
+PM_UBYTE(1)
+PM_UBYTE(2)
+PM_UBYTE(3)
+#undef PM_UBYTE
 
 // Cross-lane add inside a 16-lane DPP row. The four steps (row_mirror,
 // row_half_mirror, quad reverse, quad swap) leave in every lane
@@ -281,68 +278,118 @@ __device__ __forceinline__ float reduce16(float v) {
   return v;
 }
 
+// Stride of one column's per-tap planes in LDS: taps padded to whole 128-tap chunks, the padding
+// holds weight 0 / colour 0 so that the tail of the last chunk needs no predication.
+__host__ __device__ inline int tap_stride(int ntaps) { return ((ntaps + 127) / 128) * 128; }
+
 // PhotoConsistencyCostComputer::Compute, patch_match_cuda.cu:489-593, evaluated by a
 // 16-lane group: tap t = wrow*n1d + wcol belongs to lane t % 16, so one gather
 // instruction of a group covers 16 consecutive taps (~1.5 window rows, a handful of
 // cache lines) instead of 16 unrelated patches. `H` is the homography of the
-// (hypothesis, view) pair (LDS, precomputed once per task), `wr` holds (bilateral
-// weight, reference colour) per tap. All 16 lanes return the same cost.
+// (hypothesis, view) pair with its constant column already moved to the window origin
+// (centre_homography below; LDS, precomputed once per task), `wgt` / `refc` are the per-tap
+// bilateral weights and reference colours of the pixel's column. All 16 lanes return the same cost.
+//
+// Device order (restated in oracle/pm_oracle.c: ncc_cost_device): a lane's taps t = j + 16 k are
+// processed in chunks of 8; tap pairs (k, k+1) travel through the arithmetic as the two halves
+// of packed registers; the eight projective divisors z_k of a chunk share ONE correctly rounded
+// division -- inv_k = (prod_{i<k} z_i * prod_{i>k} z_i) / prod z_i, prefix products taken in
+// increasing k and the suffix product in decreasing k; taps beyond the window use z = 1, weight 0;
+// even-k and odd-k taps accumulate separately and are added before the cross-lane tree.
 template <int N1D>
 __device__ __forceinline__ float ncc_group(const PmParams& p, const lds_f32* H, gbl_u32* fp,
-                                           const lds_f32x2* wr,
-                                           int row, int col, float ref_sum, float ref_sqsum,
-                                           float inv_w, int j) {
+                                           const lds_f32* wgt, const lds_f32* refc,
+                                           float ref_sum, float ref_sqsum, float inv_w, int j) {
   const float h0 = H[0], h1 = H[1], h2 = H[2], h3 = H[3], h4 = H[4], h5 = H[5], h6 = H[6],
               h7 = H[7], h8 = H[8];
   const int n1d = N1D > 0 ? N1D : p.ntap1d;
   const int ntaps = n1d * n1d;
   const unsigned fpw = (unsigned)(p.src_w + 3);
-  const int x0 = col - p.radius, y0 = row - p.radius;
-  float s_sum = 0.0f, s_sq = 0.0f, s_ref = 0.0f;
-  // A lane's taps t = j + 16 k are processed in chunks of 8: the eight projective divisors z_k
-  // share ONE correctly rounded division -- inv_k = (prod_{i<k} z_i * prod_{i>k} z_i) / prod z_i,
-  // with prefix products taken in increasing k and the suffix product in decreasing k (exactly
-  // restated in oracle/pm_oracle.c: ncc_cost_device). Taps beyond the window use z = 1.
+  const lds_f32* wj = wgt + j;
+  const lds_f32* rj = refc + j;
+  v2f a_sum = pk_bcast(0.0f), a_sq = pk_bcast(0.0f), a_ref = pk_bcast(0.0f);
   auto chunk = [&](int kb) {
-    float csrc[8], rsrc[8], zz[8], pre[8];
+    v2f csrc[4], rsrc[4], pre[4], suf[4];
+    float zz[8];
     float run = 1.0f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int t = j + 16 * (kb + k);
-      const bool valid = t < ntaps;
-      const int tt = valid ? t : 0;
-      const int wrow = tt / n1d;
-      const int wcol = tt - wrow * n1d;
-      const float xf = (float)(x0 + wcol * p.step);
-      const float yf = (float)(y0 + wrow * p.step);
-      csrc[k] = fmaf(h0, xf, fmaf(h1, yf, h2));
-      rsrc[k] = fmaf(h3, xf, fmaf(h4, yf, h5));
-      zz[k] = valid ? fmaf(h6, xf, fmaf(h7, yf, h8)) : 1.0f;
-      pre[k] = run;
-      run = run * zz[k];
+    for (int q = 0; q < 4; ++q) {
+      v2f dx, dy;
+      bool valid[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int t = j + 16 * (kb + 2 * q + e);
+        valid[e] = t < ntaps;
+        const int tt = valid[e] ? t : 0;
+        const int wrow = tt / n1d;
+        const int wcol = tt - wrow * n1d;
+        dx[e] = (float)(wcol * p.step);
+        dy[e] = (float)(wrow * p.step);
+      }
+      csrc[q] = pk_fma(pk_bcast(h0), dx, pk_fma(pk_bcast(h1), dy, pk_bcast(h2)));
+      rsrc[q] = pk_fma(pk_bcast(h3), dx, pk_fma(pk_bcast(h4), dy, pk_bcast(h5)));
+      const v2f z = pk_fma(pk_bcast(h6), dx, pk_fma(pk_bcast(h7), dy, pk_bcast(h8)));
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        zz[2 * q + e] = valid[e] ? z[e] : 1.0f;
+        pre[q][e] = run;
+        run = run * zz[2 * q + e];
+      }
     }
     const float rinv = 1.0f / run;
-    TapAddr ta[8];
-    float suf = 1.0f;
+    float sfx = 1.0f;
 #pragma unroll
     for (int k = 7; k >= 0; --k) {
-      const float inv_z = (pre[k] * suf) * rinv;
-      suf = suf * zz[k];
-      const int t = j + 16 * (kb + k);
-      if (t < ntaps) tap_gather(p, fp, fpw, inv_z * csrc[k], inv_z * rsrc[k], ta[k]);
+      suf[k >> 1][k & 1] = sfx;
+      sfx = sfx * zz[k];
+    }
+    v2f wx[4], wy[4];
+    uint32_t tex[8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const v2f inv_z = (pre[q] * suf[q]) * pk_bcast(rinv);
+      const v2f px = inv_z * csrc[q];
+      const v2f py = inv_z * rsrc[q];
+      v2f fx, fy;
+      fx[0] = floorf(px[0]);
+      fx[1] = floorf(px[1]);
+      fy[0] = floorf(py[0]);
+      fy[1] = floorf(py[1]);
+      wx[q] = px - fx;
+      wy[q] = py - fy;
+      const v2f fx2 = fx + pk_bcast(2.0f);
+      const v2f fy2 = fy + pk_bcast(2.0f);
+      tex[2 * q] = tap_gather(p, fp, fpw, fx2[0], fy2[0]);
+      tex[2 * q + 1] = tap_gather(p, fp, fpw, fx2[1], fy2[1]);
     }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int t = j + 16 * (kb + k);
-      if (t < ntaps) {
-        const float src = tap_sample(ta[k]);
-        const float wgt = wr[t].w;
-        const float refc = wr[t].c;
-        const float bws = wgt * src;
-        s_sum += bws;
-        s_sq = fmaf(bws, src, s_sq);
-        s_ref = fmaf(bws, refc, s_ref);
+    for (int q = 0; q < 4; ++q) {
+      // bilinear blend of the four raw texels (exact small integers in float) in lerp form, then
+      // one scale by 1/255: the device-order reading of "bilinear fetch of a normalised uint8
+      // texture" (oracle/pm_oracle.c: tex_src_bilinear_raw)
+      v2f c00, c10, c01, c11;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int t = j + 16 * (kb + 2 * q + e);
+        const uint32_t x = t < ntaps ? tex[2 * q + e] : 0u;
+        c00[e] = ubyte0(x);
+        c10[e] = ubyte1(x);
+        c01[e] = ubyte2(x);
+        c11[e] = ubyte3(x);
       }
+      const v2f top = pk_fma(wx[q], c10 - c00, c00);
+      const v2f bot = pk_fma(wx[q], c11 - c01, c01);
+      const v2f src = pk_fma(wy[q], bot - top, top) * pk_bcast(0x1.010102p-8f);
+      const int t0 = 16 * (kb + 2 * q);  // one base register + immediate offsets: ds_read2_b32
+      v2f w2, r2;
+      w2[0] = wj[t0];
+      w2[1] = wj[t0 + 16];
+      r2[0] = rj[t0];
+      r2[1] = rj[t0 + 16];
+      const v2f bws = w2 * src;
+      a_sum = a_sum + bws;
+      a_sq = pk_fma(bws, src, a_sq);
+      a_ref = pk_fma(bws, r2, a_ref);
     }
   };
   if (N1D > 0) {
@@ -353,9 +400,9 @@ __device__ __forceinline__ float ncc_group(const PmParams& p, const lds_f32* H, 
     const int nchunk = (ntaps + 127) / 128;
     for (int c = 0; c < nchunk; ++c) chunk(8 * c);
   }
-  s_sum = reduce16(s_sum);
-  s_sq = reduce16(s_sq);
-  s_ref = reduce16(s_ref);
+  float s_sum = reduce16(a_sum[0] + a_sum[1]);
+  float s_sq = reduce16(a_sq[0] + a_sq[1]);
+  float s_ref = reduce16(a_ref[0] + a_ref[1]);
   s_sum *= inv_w;
   s_sq *= inv_w;
   s_ref *= inv_w;
@@ -366,6 +413,15 @@ __device__ __forceinline__ float ncc_group(const PmParams& p, const lds_f32* H, 
   const float covar = s_ref - ref_sum * s_sum;
   const float var = sqrtf(ref_var * src_var);
   return fmaxf(0.0f, fminf(2.0f, 1.0f - covar / var));
+}
+
+// Moves the constant column of a homography to the window origin (col - r, row - r): taps then
+// address the patch by small non-negative offsets (device order, oracle: ncc_cost_device).
+__device__ __forceinline__ void centre_homography(float* Hm, int row, int col, int radius) {
+  const float x0 = (float)(col - radius), y0 = (float)(row - radius);
+  Hm[2] = fmaf(Hm[0], x0, fmaf(Hm[1], y0, Hm[2]));
+  Hm[5] = fmaf(Hm[3], x0, fmaf(Hm[4], y0, Hm[5]));
+  Hm[8] = fmaf(Hm[6], x0, fmaf(Hm[7], y0, Hm[8]));
 }
 
 // ComputeGeomConsistencyCost, patch_match_cuda.cu:601-667
@@ -637,8 +693,10 @@ __global__ void pm_init_state_kernel(const PmParams p, int random_init, float de
 // ---------------------------------------------------------------------------
 struct Lds {
   lds_f32* poses;   // [S][43]
+  lds_u64* fpb;     // [S] packed source images (global addresses)
   lds_f32* tile;    // [win][C + 2r] reference colours, ring-buffered rows
-  lds_f32x2* wr;    // [C][ntaps] (bilateral weight, reference colour)
+  lds_f32* wgt;     // [C][tap_stride] bilateral weights (0 beyond ntaps)
+  lds_f32* refc;    // [C][tap_stride] reference colours of the taps
   lds_f32* fm;      // [C][S] forward messages
   lds_f32* q;       // [C][S] sampling pdf -> cdf
   lds_f32* costv;   // [C][S] cost_map values of this row
@@ -659,7 +717,7 @@ struct Lds {
 };
 
 struct LdsOffsets {
-  uint32_t poses, tile, wr, fm, q, costv, betav, prevv, ncc, geo, hyp, colf, us, sv, best, csum,
+  uint32_t poses, fpb, tile, wgt, refc, fm, q, costv, betav, prevv, ncc, geo, hyp, colf, us, sv, best, csum,
       flags, tasks, th, ntasks, total;
 };
 
@@ -677,8 +735,10 @@ __host__ __device__ inline LdsOffsets lds_offsets(int C, int S, int radius, int 
   const int ms = M < S ? M : S;
   const int max_tasks = C * (5 * ms > S ? 5 * ms : S);
   o.poses = take(4u * S * kPoseStride);
+  o.fpb = take(8u * S);
   o.tile = take(4u * win * tw);
-  o.wr = take(8u * C * ntaps);
+  o.wgt = take(4u * C * tap_stride(ntaps));
+  o.refc = take(4u * C * tap_stride(ntaps));
   o.fm = take(4u * C * S);
   o.q = take(4u * C * S);
   o.costv = take(4u * C * S);
@@ -702,8 +762,10 @@ __host__ __device__ inline LdsOffsets lds_offsets(int C, int S, int radius, int 
 
 __device__ __forceinline__ void lds_bind(Lds& L, lds_char* base, const LdsOffsets& o) {
   L.poses = (lds_f32*)(base + o.poses);
+  L.fpb = (lds_u64*)(base + o.fpb);
   L.tile = (lds_f32*)(base + o.tile);
-  L.wr = (lds_f32x2*)(base + o.wr);
+  L.wgt = (lds_f32*)(base + o.wgt);
+  L.refc = (lds_f32*)(base + o.refc);
   L.fm = (lds_f32*)(base + o.fm);
   L.q = (lds_f32*)(base + o.q);
   L.costv = (lds_f32*)(base + o.costv);
@@ -744,10 +806,16 @@ __device__ __forceinline__ void patch_weights(const PmParams& p, const Lds& L, i
                                               int nthreads) {
   const int win = 2 * p.radius + 1;
   const int tw = p.C + 2 * p.radius;
-  const int total = p.C * p.ntaps;
+  const int ts = tap_stride(p.ntaps);
+  const int total = p.C * ts;
   for (int item = tid; item < total; item += nthreads) {
-    const int c = item / p.ntaps;
-    const int tap = item - c * p.ntaps;
+    const int c = item / ts;
+    const int tap = item - c * ts;
+    if (tap >= p.ntaps) {
+      L.wgt[item] = 0.0f;
+      L.refc[item] = 0.0f;
+      continue;
+    }
     const int trow = tap / p.ntap1d;
     const int tcol = tap - trow * p.ntap1d;
     const int wr_ = -p.radius + trow * p.step;
@@ -759,8 +827,8 @@ __device__ __forceinline__ void patch_weights(const PmParams& p, const Lds& L, i
     const float center = L.tile[slot_c * tw + c + p.radius];
     const float color = L.tile[slot * tw + c + p.radius + wc_];
     const float bw = bilateral_weight(p.spatial_norm, p.color_norm, (float)wr_, (float)wc_, center, color);
-    L.wr[item].w = bw;
-    L.wr[item].c = color;
+    L.wgt[item] = bw;
+    L.refc[item] = color;
   }
 }
 
@@ -772,7 +840,7 @@ __device__ __forceinline__ void patch_weight_sums(const PmParams& p, const Lds& 
   const int g = tid >> 4, j = tid & 15, ng = nthreads >> 4;
   for (int c = g; c < ncols; c += ng) {
     float w_sum = 0.0f;
-    for (int t = j; t < p.ntaps; t += 16) w_sum += L.wr[c * p.ntaps + t].w;
+    for (int t = j; t < p.ntaps; t += 16) w_sum += L.wgt[c * tap_stride(p.ntaps) + t];
     w_sum = reduce16(w_sum);
     if (j == 0) L.colf[c * 8 + 5] = 1.0f / w_sum;
   }
@@ -792,12 +860,12 @@ __global__ void __launch_bounds__(64) pm_initial_cost_kernel(const PmParams* __r
   const int row = blockIdx.y;
   const int col0 = blockIdx.x * p.C;
   for (int i = tid; i < p.S * kPoseStride; i += nt) L.poses[i] = p.poses[i];
+  for (int i = tid; i < p.S; i += nt) L.fpb[i] = (uint64_t)p.src_fp_tab[i];
   for (int r = row - p.radius; r <= row + p.radius; ++r) tile_load_row(p, L, col0, r, tid, nt);
   __syncthreads();
   patch_weights(p, L, row, tid, nt);
   __syncthreads();
   patch_weight_sums(p, L, p.C, tid, nt);
-  const int fp_slice = (p.src_w + 3) * (p.src_h + 3);
   // per (pixel, view): homography, lane per task
   for (int item = tid; item < p.C * p.S; item += nt) {
     const int c = item / p.S;
@@ -807,6 +875,7 @@ __global__ void __launch_bounds__(64) pm_initial_cost_kernel(const PmParams* __r
     const float* rec = p.rec + (size_t)(row * p.W + col) * p.rec_stride;
     float Hm[9];
     compose_homography(p.refInvK, L.poses + s * kPoseStride, row, col, rec[0], rec[1], rec[2], rec[3], Hm);
+    centre_homography(Hm, row, col, p.radius);
     for (int k = 0; k < 9; ++k) L.th[item * 9 + k] = Hm[k];
   }
   __syncthreads();
@@ -818,9 +887,9 @@ __global__ void __launch_bounds__(64) pm_initial_cost_kernel(const PmParams* __r
     const int col = col0 + c;
     if (col >= p.W) continue;
     const int pix = row * p.W + col;
-    const float cost = ncc_group<N1D>(p, L.th + item * 9, (gbl_u32*)p.src_fp + (size_t)s * fp_slice,
-                                      L.wr + c * p.ntaps, row, col, p.ref_sum[pix], p.ref_sqsum[pix],
-                                      L.colf[c * 8 + 5], j);
+    const float cost = ncc_group<N1D>(p, L.th + item * 9, (gbl_u32*)L.fpb[s],
+                                      L.wgt + c * tap_stride(p.ntaps), L.refc + c * tap_stride(p.ntaps),
+                                      p.ref_sum[pix], p.ref_sqsum[pix], L.colf[c * 8 + 5], j);
     if (j == 0) p.rec[(size_t)pix * p.rec_stride + 4 + s] = cost;
   }
 }
@@ -836,7 +905,6 @@ template <int N1D, bool GEOM>
 __device__ __forceinline__ void run_tasks(const PmParams& p, const Lds& L, int row, int col0,
                                           int tid, int nt) {
   const int n = *L.ntasks;
-  const int fp_slice = (p.src_w + 3) * (p.src_h + 3);
   for (int t = tid; t < n; t += nt) {
     const uint32_t task = L.tasks[t];
     const int c = task >> 24;
@@ -849,6 +917,7 @@ __device__ __forceinline__ void run_tasks(const PmParams& p, const Lds& L, int r
     if (!geom_only) {
       float Hm[9];
       compose_homography(p.refInvK, pose, row, col, h[0], h[1], h[2], h[3], Hm);
+      centre_homography(Hm, row, col, p.radius);
       for (int k = 0; k < 9; ++k) L.th[t * 9 + k] = Hm[k];
     }
     if (GEOM) {
@@ -863,9 +932,9 @@ __device__ __forceinline__ void run_tasks(const PmParams& p, const Lds& L, int r
     const int c = task >> 24;
     const int i = (task >> 20) & 7;
     const int s = task & 0xfffff;
-    const float cost = ncc_group<N1D>(p, L.th + t * 9, (gbl_u32*)p.src_fp + (size_t)s * fp_slice,
-                                      L.wr + c * p.ntaps, row, col0 + c, L.colf[c * 8 + 0],
-                                      L.colf[c * 8 + 1], L.colf[c * 8 + 5], j);
+    const float cost = ncc_group<N1D>(p, L.th + t * 9, (gbl_u32*)L.fpb[s],
+                                      L.wgt + c * tap_stride(p.ntaps), L.refc + c * tap_stride(p.ntaps),
+                                      L.colf[c * 8 + 0], L.colf[c * 8 + 1], L.colf[c * 8 + 5], j);
     if (j == 0) L.ncc[(c * 5 + i) * p.S + s] = cost;
   }
 }
@@ -881,14 +950,19 @@ __device__ __forceinline__ void run_tasks(const PmParams& p, const Lds& L, int r
 
 template <int N1D, bool GEOM, bool FILTER_PHOTO, bool FILTER_GEOM, bool PROF>
 __global__ void __launch_bounds__(256, 3) pm_sweep_kernel(const PmParams* __restrict__ pp) {
-  const PmParams& p = pp[blockIdx.y];  // batch of reference images: one launch, grid.y problems
+  // Batch of reference images: one launch, grid.y problems. Workgroups are dealt to the 8 XCDs
+  // round-robin by linear id, so problem = id % batch keeps each problem's source-image band in
+  // (at most 8 / batch) XCD L2s instead of spreading every problem over all eight.
+  const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y;
+  const unsigned group = lin / gridDim.y;
+  const PmParams& p = pp[lin - group * gridDim.y];
   extern __shared__ __attribute__((aligned(16))) char smem[];
   Lds L;
   lds_bind(L, (lds_char*)smem, lds_offsets(p.C, p.S, p.radius, p.ntaps, p.num_samples, GEOM));
   const int tid = threadIdx.x, nt = blockDim.x;
   const int S = p.S, M = p.num_samples, C = p.C;
   const int RW = rot_width(p), RH = rot_height(p);
-  const int col0 = blockIdx.x * C;
+  const int col0 = group * C;
   const int ncols = min(C, RW - col0);  // valid columns of this group
   const float* iK = p.refInvK;
 
@@ -896,6 +970,7 @@ __global__ void __launch_bounds__(256, 3) pm_sweep_kernel(const PmParams* __rest
   unsigned long long prof_t = PROF ? __builtin_readcyclecounter() : 0ull;
 
   for (int i = tid; i < S * kPoseStride; i += nt) L.poses[i] = p.poses[i];
+  for (int i = tid; i < S; i += nt) L.fpb[i] = (uint64_t)p.src_fp_tab[i];
 
   // ---- backward messages for all rows (:976-989); stored in sel_out ----------
   for (int item = tid; item < ncols * S; item += nt) {

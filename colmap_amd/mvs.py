@@ -141,6 +141,34 @@ def _ptr_of(a, dtype, keep: list):
     return arr.ctypes.data, False
 
 
+class ImageCache:
+    """Device-side cache of packed source images shared between problems (pm_image_cache)."""
+
+    def __init__(self, gpu_index: int = -1):
+        self._c = C.c_void_p()
+        self._pinned: dict = {}  # id -> bitmap: a cached address must not be recycled
+        _check(lib().pm_image_cache_create(C.c_int32(gpu_index), C.byref(self._c)))
+
+    def set_capacity(self, max_bytes: int):
+        _check(lib().pm_image_cache_set_capacity(self._c, C.c_size_t(max_bytes)))
+
+    def stats(self):
+        e, h, m = C.c_size_t(), C.c_size_t(), C.c_size_t()
+        _check(lib().pm_image_cache_stats(self._c, C.byref(e), C.byref(h), C.byref(m)))
+        return dict(entries=e.value, hits=h.value, misses=m.value)
+
+    def close(self):
+        if self._c:
+            lib().pm_image_cache_destroy(self._c)
+            self._c = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class PatchMatch:
     """colmap::mvs::PatchMatch (reference mvs/patch_match.h:55-96)."""
 
@@ -152,9 +180,11 @@ class PatchMatch:
         depth_maps: Optional[Sequence[Optional[np.ndarray]]] = None   # (H, W) float32 each
         normal_maps: Optional[Sequence[Optional[np.ndarray]]] = None  # (3, H, W) float32 each
 
-    def __init__(self, options: PatchMatchOptions, problem: "PatchMatch.Problem"):
+    def __init__(self, options: PatchMatchOptions, problem: "PatchMatch.Problem",
+                 cache: Optional[ImageCache] = None):
         self.options_ = options
         self.problem_ = problem
+        self.cache_ = cache
         self._h = None
         self._dims = None
 
@@ -188,6 +218,8 @@ class PatchMatch:
             arr[i].T[:] = np.asarray(im.T, np.float32).ravel().tolist()
             ptr, dev = _ptr_of(im.bitmap, np.uint8, keep)
             arr[i].gray = ptr
+            if self.cache_ is not None:
+                self.cache_._pinned[ptr] = keep[-1]
             flags = [dev]
             if prob.depth_maps is not None and i < len(prob.depth_maps) and prob.depth_maps[i] is not None:
                 d = prob.depth_maps[i]
@@ -226,7 +258,10 @@ class PatchMatch:
         copt = self.options_.to_c(on_device)
         self.close()
         h = C.c_void_p()
-        _check(lib().pm_create(C.byref(copt), C.byref(cprob), C.byref(h)))
+        if self.cache_ is not None:
+            _check(lib().pm_create_cached(C.byref(copt), C.byref(cprob), self.cache_._c, C.byref(h)))
+        else:
+            _check(lib().pm_create(C.byref(copt), C.byref(cprob), C.byref(h)))
         self._h = h
         ref = self.problem_.images[self.problem_.ref_image_idx]
         self._dims = (ref.GetHeight(), ref.GetWidth(), len(self.problem_.src_image_idxs))
@@ -393,6 +428,7 @@ class PatchMatchController:
         self.workspace_path_ = workspace_path
         self.batch_size_ = max(1, batch_size)
         self.rank_, self.world_ = rank, world_size
+        self.image_cache_: Optional[ImageCache] = None  # packed sources shared by all problems
         names = [im.name for im in self.images_]
         self.index_ = {n: i for i, n in enumerate(names)}
         if problems is None:
@@ -424,6 +460,8 @@ class PatchMatchController:
         output_type = "geometric" if options.geom_consistency else "photometric"
         mine = [self.problems_[i] for i in D.shard_problems(len(self.problems_), self.rank_, self.world_)]
         images = [Image(im.K, im.R, im.T, im.bitmap) for im in self.images_]
+        if self.image_cache_ is None:
+            self.image_cache_ = ImageCache(int(options.gpu_index))
         results = {}
         todo = []
         for ref, src in mine:
@@ -459,7 +497,7 @@ class PatchMatchController:
                 if options.geom_consistency:
                     prob.depth_maps = [maps[k][0] if k in maps else None for k in range(len(images))]
                     prob.normal_maps = [maps[k][1] if k in maps else None for k in range(len(images))]
-                pms.append(PatchMatch(o, prob))
+                pms.append(PatchMatch(o, prob, self.image_cache_))
             run_batch(pms)
             for (ref, src), pm in zip(todo[i:j], pms):
                 depth, normal = pm.GetDepthMap(), pm.GetNormalMap()

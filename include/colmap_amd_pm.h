@@ -100,6 +100,21 @@ int pm_check(const pm_options* options, const pm_problem* problem);
  * initialises depth/normal/PRNG state. */
 int pm_create(const pm_options* options, const pm_problem* problem, pm_handle** out);
 
+/* Device-side cache of packed source images shared by problems (the reference re-uploads every
+ * source bitmap for every problem, patch_match_cuda.cu:1595-1654; its host-side equivalent is the
+ * CachedWorkspace, mvs/workspace.h). Entries are keyed by the caller's bitmap pointer and sizes, so
+ * the caller must keep a bitmap's address stable and unmodified while it is cached. Handles keep
+ * their sources alive; destroy the cache when no problem will reuse it. */
+typedef struct pm_image_cache pm_image_cache;
+int pm_image_cache_create(int32_t gpu_index, pm_image_cache** out);
+void pm_image_cache_destroy(pm_image_cache* cache);
+/* Soft limit in bytes (default: unlimited): on insertion the oldest entries that no live problem
+ * references are dropped until the cache fits. */
+int pm_image_cache_set_capacity(pm_image_cache* cache, size_t max_bytes);
+int pm_image_cache_stats(pm_image_cache* cache, size_t* entries, size_t* hits, size_t* misses);
+int pm_create_cached(const pm_options* options, const pm_problem* problem, pm_image_cache* cache,
+                     pm_handle** out);
+
 /* PatchMatchCuda::Run() (patch_match_cuda.cu:1304-1352,1393-1546): blocking. */
 int pm_run(pm_handle* h);
 /* Same work, enqueued on the handle's stream; pm_synchronize() waits. */

@@ -592,9 +592,11 @@ static float ncc_cost(const pmo_state* st, const ncc_params* np, const float inv
 
 /* The same cost as ncc_cost() evaluated in the HIP kernel's order ("device order"):
  *  - tap t = wrow * n1d + wcol is dealt to lane j = t % 16 of a 16-lane group; a
- *    lane accumulates its taps in increasing t;
- *  - the warped coordinate of a tap is evaluated directly from the homography,
- *    fma(H0, x, fma(H1, y, H2)) with x, y the integer pixel position of the tap,
+ *    lane accumulates its taps t = j + 16 k in increasing k, even k and odd k separately
+ *    (the halves of the packed fp32 registers), and adds the two partial sums;
+ *  - the warped coordinate of a tap is evaluated directly from the homography whose constant
+ *    column was moved to the window origin, fma(H0, dx, fma(H1, dy, C2)) with
+ *    C2 = fma(H0, col - r, fma(H1, row - r, H2)) and dx, dy the tap's offset in the window,
  *    instead of the reference's running sums (:554-568); eight taps of a lane share one
  *    division (prefix/suffix products), and the +0.5/-0.5 texel-centre round trip is dropped;
  *  - the bilinear blend is taken over the raw texels and scaled once by 1/255
@@ -617,14 +619,22 @@ static float ncc_cost_device(const pmo_state* st, const ncc_params* np, const fl
   compose_homography(inv_K, pose, row, col, depth, normal, tf);
   const int n1d = (2 * np->radius) / np->step + 1;
   const int ntaps = n1d * n1d;
+  /* device order: the constant column of the homography is moved to the window origin once per
+   * evaluation, taps address the patch by small non-negative offsets */
+  const float x0f = (float)(col - np->radius), y0f = (float)(row - np->radius);
+  const float c2 = fmaf(tf[0], x0f, fmaf(tf[1], y0f, tf[2]));
+  const float c5 = fmaf(tf[3], x0f, fmaf(tf[4], y0f, tf[5]));
+  const float c8 = fmaf(tf[6], x0f, fmaf(tf[7], y0f, tf[8]));
   float a_sum[16], a_sq[16], a_ref[16], a_w[16];
-  for (int j = 0; j < 16; ++j) a_sum[j] = a_sq[j] = a_ref[j] = a_w[j] = 0.0f;
   /* lane j owns taps t = j + 16 k; they are processed in chunks of eight k: the eight projective
    * divisors share one correctly rounded division,
    *   inv_k = (prefix_k * suffix_k) * (1 / prod z),  prefix in increasing k, suffix in decreasing k,
-   * taps beyond the window contribute z = 1 (they are not sampled) */
+   * taps beyond the window contribute z = 1 (they are not sampled). Even-k and odd-k taps (the
+   * two halves of the device's packed registers) accumulate separately and are added per lane. */
   const int nchunk = (ntaps + 127) / 128;
   for (int j = 0; j < 16; ++j) {
+    float e_sum[2] = {0.0f, 0.0f}, e_sq[2] = {0.0f, 0.0f}, e_ref[2] = {0.0f, 0.0f};
+    a_w[j] = 0.0f;
     for (int cb = 0; cb < nchunk; ++cb) {
       float csrc[8], rsrc[8], zz[8], pre[8], inv[8];
       float run = 1.0f;
@@ -633,11 +643,11 @@ static float ncc_cost_device(const pmo_state* st, const ncc_params* np, const fl
         const int valid = t < ntaps;
         const int tt = valid ? t : 0;
         const int wrow = tt / n1d, wcol = tt - wrow * n1d;
-        const float xf = (float)(col - np->radius + wcol * np->step);
-        const float yf = (float)(row - np->radius + wrow * np->step);
-        csrc[k] = fmaf(tf[0], xf, fmaf(tf[1], yf, tf[2]));
-        rsrc[k] = fmaf(tf[3], xf, fmaf(tf[4], yf, tf[5]));
-        zz[k] = valid ? fmaf(tf[6], xf, fmaf(tf[7], yf, tf[8])) : 1.0f;
+        const float dx = (float)(wcol * np->step);
+        const float dy = (float)(wrow * np->step);
+        csrc[k] = fmaf(tf[0], dx, fmaf(tf[1], dy, c2));
+        rsrc[k] = fmaf(tf[3], dx, fmaf(tf[4], dy, c5));
+        zz[k] = valid ? fmaf(tf[6], dx, fmaf(tf[7], dy, c8)) : 1.0f;
         pre[k] = run;
         run = run * zz[k];
       }
@@ -653,12 +663,15 @@ static float ncc_cost_device(const pmo_state* st, const ncc_params* np, const fl
         const float src_color = tex_src_bilinear_raw(st, s, inv[k] * csrc[k], inv[k] * rsrc[k]);
         const float bw = weights[t];
         const float bws = bw * src_color;
-        a_sum[j] += bws;
-        a_sq[j] = fmaf(bws, src_color, a_sq[j]);
-        a_ref[j] = fmaf(bws, refc[t], a_ref[j]);
+        e_sum[k & 1] += bws;
+        e_sq[k & 1] = fmaf(bws, src_color, e_sq[k & 1]);
+        e_ref[k & 1] = fmaf(bws, refc[t], e_ref[k & 1]);
         a_w[j] += bw;
       }
     }
+    a_sum[j] = e_sum[0] + e_sum[1];
+    a_sq[j] = e_sq[0] + e_sq[1];
+    a_ref[j] = e_ref[0] + e_ref[1];
   }
   float src_color_sum = tree16(a_sum);
   float src_color_squared_sum = tree16(a_sq);

@@ -169,6 +169,44 @@ def test_batched_run_equals_single_runs(pm_oracle):
         mvs.run_batch([pms[0], mvs.PatchMatch(h2, hip_problem(other, 1, [0, 2, 3]))])
 
 
+def test_image_cache_shares_sources_without_changing_results(pm_oracle):
+    """pm_create_cached: problems that name the same bitmaps gather from one packed copy; the
+    outputs are the bits of the uncached run, and eviction never drops an image in use."""
+    from colmap_amd import mvs
+    views = scene(5, 67, 45)
+    images = hip_problem(views, 1, [0, 2]).images
+    probs = [(1, [0, 2, 3]), (2, [1, 3, 4]), (3, [1, 2, 4])]
+    cache = mvs.ImageCache(0)
+    cached, plain = [], []
+    for ref, src in probs:
+        dmin, dmax = syn.depth_range(views, ref)
+        _, h = paired_options(pm_oracle, depth_min=dmin, depth_max=dmax, geom_consistency=0, filter=1,
+                              num_iterations=1)
+        cached.append(mvs.PatchMatch(h, mvs.PatchMatch.Problem(ref, src, images), cache))
+        plain.append(mvs.PatchMatch(h, mvs.PatchMatch.Problem(ref, src, images)))
+    mvs.run_batch(cached)
+    mvs.run_batch(plain)
+    st = cache.stats()
+    assert st["entries"] == 5 and st["misses"] == 5 and st["hits"] == 4
+    for a, b in zip(cached, plain):
+        np.testing.assert_array_equal(a.GetDepthMap(), b.GetDepthMap())
+        np.testing.assert_array_equal(a.GetNormalMap(), b.GetNormalMap())
+        np.testing.assert_array_equal(a.GetSelProbMap(), b.GetSelProbMap())
+    # capacity 0: only entries no live problem uses may go
+    cached[1].close(); cached[2].close()
+    cache.set_capacity(0)
+    assert cache.stats()["entries"] == 3           # sources 0, 2, 3 of the live problem stay
+    again = mvs.PatchMatch(cached[0].options_, cached[0].problem_, cache)   # three hits
+    again.Run()
+    np.testing.assert_array_equal(again.GetDepthMap(), plain[0].GetDepthMap())
+    assert cache.stats()["hits"] == 7
+    again.close()
+    cached[0].close()
+    cache.set_capacity(0)
+    assert cache.stats()["entries"] == 0
+    cache.close()
+
+
 def test_error_behaviour():
     from colmap_amd import mvs
     views = scene(3, 64, 48)
