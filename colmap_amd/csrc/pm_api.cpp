@@ -439,6 +439,7 @@ void Create(const pm_options& opt_in, const pm_problem& prob, pm_image_cache* ca
   std::memset(&b, 0, sizeof(b));
   b.W = W; b.H = H; b.S = S; b.src_w = h->src_w; b.src_h = h->src_h;
   b.fp_xmax = (float)(h->src_w + 2); b.fp_ymax = (float)(h->src_h + 2);
+  b.fp_pitch = (float)(h->src_w + 3);
   b.radius = opt.window_radius;
   b.step = opt.window_step;
   b.ntap1d = (2 * b.radius) / b.step + 1;

@@ -19,6 +19,7 @@ struct PmParams {
   int S;            // number of source images
   int src_w, src_h; // source slot size (max over sources)
   float fp_xmax, fp_ymax;  // src_w + 2, src_h + 2: last column / row of the packed image
+  float fp_pitch;          // src_w + 3 as float
   int radius, step, ntap1d, ntaps;
   int num_samples;
   int rec_stride;   // floats per pixel record: 4 + 3*S

@@ -238,13 +238,19 @@ __device__ __forceinline__ v2f pk_bcast(float a) { return (v2f)(a); }
 // non-finite taps read an all-zero footprint entry (SampleLayeredBilinear,
 // patch_match_cuda.cu:426-442; the +0.5 / -0.5 texel centre round trip of the reference cancels
 // and is not evaluated in device order).
+template <bool FOFF>
 __device__ __forceinline__ uint32_t tap_gather(const PmParams& p, gbl_u32* fp, unsigned fpw, float fx2,
                                                float fy2) {
   // fx2 = floor(x) + 2, fy2 = floor(y) + 2 (the ring offset is added in the float domain, packed)
-  const unsigned ix = (unsigned)(int)__builtin_amdgcn_fmed3f(fx2, 0.0f, p.fp_xmax);
-  const unsigned iy = (unsigned)(int)__builtin_amdgcn_fmed3f(fy2, 0.0f, p.fp_ymax);
+  const float cx = __builtin_amdgcn_fmed3f(fx2, 0.0f, p.fp_xmax);
+  const float cy = __builtin_amdgcn_fmed3f(fy2, 0.0f, p.fp_ymax);
+  if (FOFF) {
+    // packed images below 2^24 entries: the entry index row * pitch + col is exact in fp32, one
+    // fma + one conversion instead of two conversions + an integer multiply-add
+    return fp[(unsigned)(int)fmaf(cy, p.fp_pitch, cx)];
+  }
   // 24-bit multiply-add (full rate; v_mul_lo_u32 is quarter rate): rows and pitch < 2^24
-  return fp[__umul24(iy, fpw) + ix];
+  return fp[__umul24((unsigned)(int)cy, fpw) + (unsigned)(int)cx];
 }
 
 // Byte k of a packed footprint entry as float. Inline asm keeps the four conversions as four
@@ -282,6 +288,27 @@ __device__ __forceinline__ float reduce16(float v) {
 // holds weight 0 / colour 0 so that the tail of the last chunk needs no predication.
 __host__ __device__ inline int tap_stride(int ntaps) { return ((ntaps + 127) / 128) * 128; }
 
+// Per-tap bilateral weights and reference colours of one lane (taps j + 16 k, k = 0..7) held in
+// registers across consecutive evaluations of the same pixel column (fixed window <= 128 taps).
+struct TapRegs {
+  v2f w[4], r[4];
+};
+template <int N1D>
+struct TapRegsUsed {
+  static constexpr bool value = N1D > 0 && N1D * N1D <= 128;
+};
+__device__ __forceinline__ void tap_regs_load(TapRegs& R, const lds_f32* wgt, const lds_f32* refc, int j) {
+  const lds_f32* wj = wgt + j;
+  const lds_f32* rj = refc + j;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    R.w[q][0] = wj[32 * q];
+    R.w[q][1] = wj[32 * q + 16];
+    R.r[q][0] = rj[32 * q];
+    R.r[q][1] = rj[32 * q + 16];
+  }
+}
+
 // PhotoConsistencyCostComputer::Compute, patch_match_cuda.cu:489-593, evaluated by a
 // 16-lane group: tap t = wrow*n1d + wcol belongs to lane t % 16, so one gather
 // instruction of a group covers 16 consecutive taps (~1.5 window rows, a handful of
@@ -298,7 +325,7 @@ __host__ __device__ inline int tap_stride(int ntaps) { return ((ntaps + 127) / 1
 // even-k and odd-k taps accumulate separately and are added before the cross-lane tree.
 template <int N1D>
 __device__ __forceinline__ float ncc_group(const PmParams& p, const lds_f32* H, gbl_u32* fp,
-                                           const lds_f32* wgt, const lds_f32* refc,
+                                           const lds_f32* wgt, const lds_f32* refc, const TapRegs& R,
                                            float ref_sum, float ref_sqsum, float inv_w, int j) {
   const float h0 = H[0], h1 = H[1], h2 = H[2], h3 = H[3], h4 = H[4], h5 = H[5], h6 = H[6],
               h7 = H[7], h8 = H[8];
@@ -359,8 +386,8 @@ __device__ __forceinline__ float ncc_group(const PmParams& p, const lds_f32* H, 
       wy[q] = py - fy;
       const v2f fx2 = fx + pk_bcast(2.0f);
       const v2f fy2 = fy + pk_bcast(2.0f);
-      tex[2 * q] = tap_gather(p, fp, fpw, fx2[0], fy2[0]);
-      tex[2 * q + 1] = tap_gather(p, fp, fpw, fx2[1], fy2[1]);
+      tex[2 * q] = tap_gather<(N1D > 0)>(p, fp, fpw, fx2[0], fy2[0]);
+      tex[2 * q + 1] = tap_gather<(N1D > 0)>(p, fp, fpw, fx2[1], fy2[1]);
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -382,10 +409,15 @@ __device__ __forceinline__ float ncc_group(const PmParams& p, const lds_f32* H, 
       const v2f src = pk_fma(wy[q], bot - top, top) * pk_bcast(0x1.010102p-8f);
       const int t0 = 16 * (kb + 2 * q);  // one base register + immediate offsets: ds_read2_b32
       v2f w2, r2;
-      w2[0] = wj[t0];
-      w2[1] = wj[t0 + 16];
-      r2[0] = rj[t0];
-      r2[1] = rj[t0 + 16];
+      if (TapRegsUsed<N1D>::value) {
+        w2 = R.w[q];
+        r2 = R.r[q];
+      } else {
+        w2[0] = wj[t0];
+        w2[1] = wj[t0 + 16];
+        r2[0] = rj[t0];
+        r2[1] = rj[t0 + 16];
+      }
       const v2f bws = w2 * src;
       a_sum = a_sum + bws;
       a_sq = pk_fma(bws, src, a_sq);
@@ -881,14 +913,20 @@ __global__ void __launch_bounds__(64) pm_initial_cost_kernel(const PmParams* __r
   __syncthreads();
   // NCC: 16-lane group per task
   const int g = tid >> 4, j = tid & 15, ng = nt >> 4;
+  TapRegs R;
+  int c_held = -1;
   for (int item = g; item < p.C * p.S; item += ng) {
     const int c = item / p.S;
     const int s = item - c * p.S;
     const int col = col0 + c;
     if (col >= p.W) continue;
     const int pix = row * p.W + col;
+    if (TapRegsUsed<N1D>::value && c != c_held) {
+      tap_regs_load(R, L.wgt + c * tap_stride(p.ntaps), L.refc + c * tap_stride(p.ntaps), j);
+      c_held = c;
+    }
     const float cost = ncc_group<N1D>(p, L.th + item * 9, (gbl_u32*)L.fpb[s],
-                                      L.wgt + c * tap_stride(p.ntaps), L.refc + c * tap_stride(p.ntaps),
+                                      L.wgt + c * tap_stride(p.ntaps), L.refc + c * tap_stride(p.ntaps), R,
                                       p.ref_sum[pix], p.ref_sqsum[pix], L.colf[c * 8 + 5], j);
     if (j == 0) p.rec[(size_t)pix * p.rec_stride + 4 + s] = cost;
   }
@@ -926,14 +964,23 @@ __device__ __forceinline__ void run_tasks(const PmParams& p, const Lds& L, int r
   }
   __syncthreads();
   const int g = tid >> 4, j = tid & 15, ng = nt >> 4;
+  // A wave's four groups work on the four hypotheses of one (column, view) block, and the blocks
+  // of a column are mostly adjacent in the list: the column's tap weights stay in registers
+  // until the column changes.
+  TapRegs R;
+  int c_held = -1;
   for (int t = g; t < n; t += ng) {
     const uint32_t task = L.tasks[t];
     if ((task >> 23) & 1) continue;  // geometric cost only
     const int c = task >> 24;
     const int i = (task >> 20) & 7;
     const int s = task & 0xfffff;
+    if (TapRegsUsed<N1D>::value && c != c_held) {
+      tap_regs_load(R, L.wgt + c * tap_stride(p.ntaps), L.refc + c * tap_stride(p.ntaps), j);
+      c_held = c;
+    }
     const float cost = ncc_group<N1D>(p, L.th + t * 9, (gbl_u32*)L.fpb[s],
-                                      L.wgt + c * tap_stride(p.ntaps), L.refc + c * tap_stride(p.ntaps),
+                                      L.wgt + c * tap_stride(p.ntaps), L.refc + c * tap_stride(p.ntaps), R,
                                       L.colf[c * 8 + 0], L.colf[c * 8 + 1], L.colf[c * 8 + 5], j);
     if (j == 0) L.ncc[(c * 5 + i) * p.S + s] = cost;
   }
@@ -1286,6 +1333,12 @@ int pm_pick_columns(int S, int ntaps, int num_samples, bool geom, int radius, in
   return c;
 }
 
+// The fixed-window (11 x 11) kernels index packed images through fp32 (tap_gather<true>): exact
+// while an image has fewer than 2^24 entries; larger images take the generic kernels.
+static bool pm_fixed_window_ok(const PmParams& p) {
+  return (long long)(p.src_w + 3) * (p.src_h + 3) < (1ll << 24);
+}
+
 void pm_launch_build_footprint(const uint8_t* src, uint32_t* fp, int S, int w, int h, hipStream_t st) {
   dim3 block(256, 1, 1);
   dim3 grid((w + 3 + 255) / 256, h + 3, S);
@@ -1315,7 +1368,7 @@ void pm_launch_initial_cost(const PmParams& p, const PmParams* dev_params, int b
   const size_t lds = lds_offsets(p.C, p.S, p.radius, p.ntaps, p.num_samples, false).total;
   dim3 block(64, 1, 1);
   dim3 grid((p.W + p.C - 1) / p.C, p.H, batch);
-  if (p.ntap1d == 11) hipLaunchKernelGGL(pm_initial_cost_kernel<11>, grid, block, lds, st, dev_params);
+  if (p.ntap1d == 11 && pm_fixed_window_ok(p)) hipLaunchKernelGGL(pm_initial_cost_kernel<11>, grid, block, lds, st, dev_params);
   else hipLaunchKernelGGL(pm_initial_cost_kernel<0>, grid, block, lds, st, dev_params);
 }
 
@@ -1329,10 +1382,10 @@ void pm_launch_sweep(const PmParams& p, const PmParams* dev_params, int batch, i
   hipLaunchKernelGGL((pm_sweep_kernel<N, G, FP, FG, PR>), grid, block, lds, st, dev_params)
 #define PM_LAUNCH(G, FP, FG)                      \
   do {                                            \
-    if (p.ntap1d == 11) PM_LAUNCH_N(11, G, FP, FG, false); \
+    if (p.ntap1d == 11 && pm_fixed_window_ok(p)) PM_LAUNCH_N(11, G, FP, FG, false); \
     else PM_LAUNCH_N(0, G, FP, FG, false);        \
   } while (0)
-  if (p.prof && !geom && !filter_photo && p.ntap1d == 11) {
+  if (p.prof && !geom && !filter_photo && p.ntap1d == 11 && pm_fixed_window_ok(p)) {
     PM_LAUNCH_N(11, false, false, false, true);
     return;
   }
