@@ -324,9 +324,9 @@ __device__ __forceinline__ void tap_regs_load(TapRegs& R, const lds_f32* wgt, co
 // increasing k and the suffix product in decreasing k; taps beyond the window use z = 1, weight 0;
 // even-k and odd-k taps accumulate separately and are added before the cross-lane tree.
 template <int N1D>
-__device__ __forceinline__ float ncc_group(const PmParams& p, const lds_f32* H, gbl_u32* fp,
-                                           const lds_f32* wgt, const lds_f32* refc, const TapRegs& R,
-                                           float ref_sum, float ref_sqsum, float inv_w, int j) {
+__device__ __forceinline__ void ncc_group(const PmParams& p, const lds_f32* H, gbl_u32* fp,
+                                          const lds_f32* wgt, const lds_f32* refc, const TapRegs& R,
+                                          int j, float& s_sum, float& s_sq, float& s_ref) {
   const float h0 = H[0], h1 = H[1], h2 = H[2], h3 = H[3], h4 = H[4], h5 = H[5], h6 = H[6],
               h7 = H[7], h8 = H[8];
   const int n1d = N1D > 0 ? N1D : p.ntap1d;
@@ -432,9 +432,17 @@ __device__ __forceinline__ float ncc_group(const PmParams& p, const lds_f32* H, 
     const int nchunk = (ntaps + 127) / 128;
     for (int c = 0; c < nchunk; ++c) chunk(8 * c);
   }
-  float s_sum = reduce16(a_sum[0] + a_sum[1]);
-  float s_sq = reduce16(a_sq[0] + a_sq[1]);
-  float s_ref = reduce16(a_ref[0] + a_ref[1]);
+  // The three window sums (not yet normalised); ncc_finish() turns them into the cost. The callers
+  // park them in LDS and finish all evaluations of a phase lane-per-evaluation: square root and
+  // division are then paid once per evaluation instead of once per lane of its group.
+  s_sum = reduce16(a_sum[0] + a_sum[1]);
+  s_sq = reduce16(a_sq[0] + a_sq[1]);
+  s_ref = reduce16(a_ref[0] + a_ref[1]);
+}
+
+// Tail of PhotoConsistencyCostComputer::Compute (patch_match_cuda.cu:575-592).
+__device__ __forceinline__ float ncc_finish(float s_sum, float s_sq, float s_ref, float ref_sum,
+                                            float ref_sqsum, float inv_w) {
   s_sum *= inv_w;
   s_sq *= inv_w;
   s_ref *= inv_w;
@@ -920,15 +928,29 @@ __global__ void __launch_bounds__(64) pm_initial_cost_kernel(const PmParams* __r
     const int s = item - c * p.S;
     const int col = col0 + c;
     if (col >= p.W) continue;
-    const int pix = row * p.W + col;
     if (TapRegsUsed<N1D>::value && c != c_held) {
       tap_regs_load(R, L.wgt + c * tap_stride(p.ntaps), L.refc + c * tap_stride(p.ntaps), j);
       c_held = c;
     }
-    const float cost = ncc_group<N1D>(p, L.th + item * 9, (gbl_u32*)L.fpb[s],
-                                      L.wgt + c * tap_stride(p.ntaps), L.refc + c * tap_stride(p.ntaps), R,
-                                      p.ref_sum[pix], p.ref_sqsum[pix], L.colf[c * 8 + 5], j);
-    if (j == 0) p.rec[(size_t)pix * p.rec_stride + 4 + s] = cost;
+    float s_sum, s_sq, s_ref;
+    ncc_group<N1D>(p, L.th + item * 9, (gbl_u32*)L.fpb[s], L.wgt + c * tap_stride(p.ntaps),
+                   L.refc + c * tap_stride(p.ntaps), R, j, s_sum, s_sq, s_ref);
+    if (j == 0) {
+      L.th[item * 9 + 0] = s_sum;  // the homography of this evaluation is no longer needed
+      L.th[item * 9 + 1] = s_sq;
+      L.th[item * 9 + 2] = s_ref;
+    }
+  }
+  __syncthreads();
+  for (int item = tid; item < p.C * p.S; item += nt) {
+    const int c = item / p.S;
+    const int s = item - c * p.S;
+    const int col = col0 + c;
+    if (col >= p.W) continue;
+    const int pix = row * p.W + col;
+    p.rec[(size_t)pix * p.rec_stride + 4 + s] =
+        ncc_finish(L.th[item * 9 + 0], L.th[item * 9 + 1], L.th[item * 9 + 2], p.ref_sum[pix],
+                   p.ref_sqsum[pix], L.colf[c * 8 + 5]);
   }
 }
 
@@ -973,16 +995,30 @@ __device__ __forceinline__ void run_tasks(const PmParams& p, const Lds& L, int r
     const uint32_t task = L.tasks[t];
     if ((task >> 23) & 1) continue;  // geometric cost only
     const int c = task >> 24;
-    const int i = (task >> 20) & 7;
     const int s = task & 0xfffff;
     if (TapRegsUsed<N1D>::value && c != c_held) {
       tap_regs_load(R, L.wgt + c * tap_stride(p.ntaps), L.refc + c * tap_stride(p.ntaps), j);
       c_held = c;
     }
-    const float cost = ncc_group<N1D>(p, L.th + t * 9, (gbl_u32*)L.fpb[s],
-                                      L.wgt + c * tap_stride(p.ntaps), L.refc + c * tap_stride(p.ntaps), R,
-                                      L.colf[c * 8 + 0], L.colf[c * 8 + 1], L.colf[c * 8 + 5], j);
-    if (j == 0) L.ncc[(c * 5 + i) * p.S + s] = cost;
+    float s_sum, s_sq, s_ref;
+    ncc_group<N1D>(p, L.th + t * 9, (gbl_u32*)L.fpb[s], L.wgt + c * tap_stride(p.ntaps),
+                   L.refc + c * tap_stride(p.ntaps), R, j, s_sum, s_sq, s_ref);
+    if (j == 0) {
+      L.th[t * 9 + 0] = s_sum;  // the homography of this task is no longer needed
+      L.th[t * 9 + 1] = s_sq;
+      L.th[t * 9 + 2] = s_ref;
+    }
+  }
+  __syncthreads();
+  // lane per task: normalisation, variances, square root, division
+  for (int t = tid; t < n; t += nt) {
+    const uint32_t task = L.tasks[t];
+    if ((task >> 23) & 1) continue;
+    const int c = task >> 24;
+    const int i = (task >> 20) & 7;
+    const int s = task & 0xfffff;
+    L.ncc[(c * 5 + i) * p.S + s] = ncc_finish(L.th[t * 9 + 0], L.th[t * 9 + 1], L.th[t * 9 + 2],
+                                              L.colf[c * 8 + 0], L.colf[c * 8 + 1], L.colf[c * 8 + 5]);
   }
 }
 
