@@ -35,10 +35,12 @@ def parse():
     ap.add_argument("--height", type=int, default=1920)
     ap.add_argument("--num-src", type=int, default=20)
     ap.add_argument("--ring", type=int, default=100, help="cameras on the full ring (config[1]: 100)")
-    ap.add_argument("--batch", type=int, default=8, help="reference images solved concurrently per step")
+    ap.add_argument("--batch", type=int, default=16, help="reference images solved concurrently per step")
     ap.add_argument("--cols", type=int, default=0)
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--groups", type=int, default=1,
+                    help="batches per step, each on its own stream (their sweep launches overlap)")
     ap.add_argument("--no-image-cache", action="store_true",
                     help="pack every problem's source images privately instead of sharing them")
     ap.add_argument("--no-ba", action="store_true", help="skip the secondary bundle-adjustment measurement")
@@ -127,6 +129,21 @@ def ba_secondary(a, local_rank, with_cpu):
     return out
 
 
+def pmc_traffic(images_per_launch):
+    """HBM-side bytes per sweep launch from the committed rocprofv3 PMC passes (FETCH_SIZE +
+    WRITE_SIZE of pm_sweep_kernel, scripts/profile_pm.sh; counters cannot be read from inside
+    this process). None when no pass matches this launch shape."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pm_sweep_traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        if int(t["images_per_launch"]) != int(images_per_launch):
+            return None
+        return float(t["fetch_bytes_per_launch"]) + float(t["write_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -144,7 +161,7 @@ def main():
 
     S = a.num_src
     nsteps = a.steps + a.warmup
-    nref = nsteps * a.batch
+    nref = nsteps * a.batch * a.groups
     # this rank's window of the ring: `nref` consecutive reference cameras + S/2 neighbours either side
     half = S // 2
     step_deg = 360.0 / a.ring
@@ -183,16 +200,23 @@ def main():
 
     def run_step(step, record):
         nonlocal sweep_ms, sweep_n
-        pms = [problem(step * a.batch + b)[0] for b in range(a.batch)]
-        for pm in pms:
-            pm.Create()
-        mvs.run_batch(pms)  # one launch per sweep covers the whole batch
+        grps = [[problem((step * a.groups + g) * a.batch + b)[0] for b in range(a.batch)]
+                for g in range(a.groups)]
+        for pms in grps:
+            for pm in pms:
+                pm.Create()
+        for pms in grps:
+            mvs.run_batch(pms, wait=False)  # one launch per sweep covers the whole batch
+        for pms in grps:
+            for pm in pms:
+                pm.Synchronize()
         if record:
-            ms, n = pms[0].GetSweepTiming()
+            ms, n = grps[0][0].GetSweepTiming()
             sweep_ms += ms
             sweep_n += n
-        for pm in pms:
-            pm.close()
+        for pms in grps:
+            for pm in pms:
+                pm.close()
 
     for w in range(a.warmup):
         run_step(w, False)
@@ -203,7 +227,7 @@ def main():
     barrier()
     dt = time.time() - t0
     dt = D.max_over_ranks(dt, dev)
-    images_done = sum(D.gather_counts(a.steps * a.batch, dev))
+    images_done = sum(D.gather_counts(a.steps * a.batch * a.groups, dev))
 
     if rank == 0:
         pix_per_image = a.width * a.height
@@ -242,7 +266,7 @@ def main():
                 "peak": 8000.0,
                 "unit": "GB/s",
                 "frac": achieved / 8000.0,
-                "traffic": None,
+                "traffic": pmc_traffic(a.batch),
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "avg_launch_ms": avg_ms,
                 "launches_timed": sweep_n,

@@ -732,7 +732,8 @@ __global__ void pm_init_state_kernel(const PmParams p, int random_init, float de
 // LDS carve-up shared by the initial-cost and sweep kernels
 // ---------------------------------------------------------------------------
 struct Lds {
-  lds_f32* poses;   // [S][43]
+  lds_f32* poses;   // [S][pstride]
+  int pstride;
   lds_u64* fpb;     // [S] packed source images (global addresses)
   lds_f32* tile;    // [win][C + 2r] reference colours, ring-buffered rows
   lds_f32* wgt;     // [C][tap_stride] bilateral weights (0 beyond ntaps)
@@ -750,7 +751,7 @@ struct Lds {
   lds_i32* sv;      // [C][M] sampled view per draw (-1: none)
   lds_i32* best;    // [C]
   lds_f32* csum;    // [C][5] accumulated hypothesis costs
-  lds_i32* flags;   // [C][S] filter flags
+  LDS_AS uint8_t* flags;  // [C][S] filter flags
   lds_u32* tasks;
   lds_f32* th;      // [max_tasks][9] homography of each queued NCC task
   lds_i32* ntasks;
@@ -760,6 +761,10 @@ struct LdsOffsets {
   uint32_t poses, fpb, tile, wgt, refc, fm, q, costv, betav, prevv, ncc, geo, hyp, colf, us, sv, best, csum,
       flags, tasks, th, ntasks, total;
 };
+
+// Pose record kept in LDS: K4 R9 T3 C3 always; the projection matrices P12 invP12 only serve the
+// geometric consistency term.
+__host__ __device__ inline int lds_pose_stride(bool geom) { return geom ? kPoseStride : 19; }
 
 __host__ __device__ inline LdsOffsets lds_offsets(int C, int S, int radius, int ntaps, int M,
                                                   bool geom) {
@@ -773,8 +778,10 @@ __host__ __device__ inline LdsOffsets lds_offsets(int C, int S, int radius, int 
   const int win = 2 * radius + 1;
   const int tw = C + 2 * radius;
   const int ms = M < S ? M : S;
-  const int max_tasks = C * (5 * ms > S ? 5 * ms : S);
-  o.poses = take(4u * S * kPoseStride);
+  // per drawn view: hypotheses 1..4 (+ one geometric-cost-only task); winner pass: <= S per column
+  const int per_view = geom ? 5 : 4;
+  const int max_tasks = C * (per_view * ms > S ? per_view * ms : S);
+  o.poses = take(4u * S * lds_pose_stride(geom));
   o.fpb = take(8u * S);
   o.tile = take(4u * win * tw);
   o.wgt = take(4u * C * tap_stride(ntaps));
@@ -792,12 +799,21 @@ __host__ __device__ inline LdsOffsets lds_offsets(int C, int S, int radius, int 
   o.sv = take(4u * C * M);
   o.best = take(4u * C);
   o.csum = take(4u * C * 5);
-  o.flags = take(4u * C * S);
+  o.flags = take(1u * C * S);
   o.tasks = take(4u * max_tasks);
   o.th = take(36u * max_tasks);
   o.ntasks = take(16u);
   o.total = off;
   return o;
+}
+
+__device__ __forceinline__ void lds_load_poses(const PmParams& p, Lds& L, bool geom, int tid, int nt) {
+  L.pstride = lds_pose_stride(geom);
+  for (int i = tid; i < p.S * L.pstride; i += nt) {
+    const int s = i / L.pstride;
+    L.poses[i] = p.poses[s * kPoseStride + (i - s * L.pstride)];
+  }
+  for (int i = tid; i < p.S; i += nt) L.fpb[i] = (uint64_t)p.src_fp_tab[i];
 }
 
 __device__ __forceinline__ void lds_bind(Lds& L, lds_char* base, const LdsOffsets& o) {
@@ -819,7 +835,7 @@ __device__ __forceinline__ void lds_bind(Lds& L, lds_char* base, const LdsOffset
   L.sv = (lds_i32*)(base + o.sv);
   L.best = (lds_i32*)(base + o.best);
   L.csum = (lds_f32*)(base + o.csum);
-  L.flags = (lds_i32*)(base + o.flags);
+  L.flags = (LDS_AS uint8_t*)(base + o.flags);
   L.tasks = (lds_u32*)(base + o.tasks);
   L.th = (lds_f32*)(base + o.th);
   L.ntasks = (lds_i32*)(base + o.ntasks);
@@ -899,8 +915,7 @@ __global__ void __launch_bounds__(64) pm_initial_cost_kernel(const PmParams* __r
   const int tid = threadIdx.x, nt = blockDim.x;
   const int row = blockIdx.y;
   const int col0 = blockIdx.x * p.C;
-  for (int i = tid; i < p.S * kPoseStride; i += nt) L.poses[i] = p.poses[i];
-  for (int i = tid; i < p.S; i += nt) L.fpb[i] = (uint64_t)p.src_fp_tab[i];
+  lds_load_poses(p, L, false, tid, nt);
   for (int r = row - p.radius; r <= row + p.radius; ++r) tile_load_row(p, L, col0, r, tid, nt);
   __syncthreads();
   patch_weights(p, L, row, tid, nt);
@@ -914,7 +929,7 @@ __global__ void __launch_bounds__(64) pm_initial_cost_kernel(const PmParams* __r
     if (col >= p.W) continue;
     const float* rec = p.rec + (size_t)(row * p.W + col) * p.rec_stride;
     float Hm[9];
-    compose_homography(p.refInvK, L.poses + s * kPoseStride, row, col, rec[0], rec[1], rec[2], rec[3], Hm);
+    compose_homography(p.refInvK, L.poses + s * L.pstride, row, col, rec[0], rec[1], rec[2], rec[3], Hm);
     centre_homography(Hm, row, col, p.radius);
     for (int k = 0; k < 9; ++k) L.th[item * 9 + k] = Hm[k];
   }
@@ -972,7 +987,7 @@ __device__ __forceinline__ void run_tasks(const PmParams& p, const Lds& L, int r
     const int i = (task >> 20) & 7;
     const int s = task & 0xfffff;
     const lds_f32* h = L.hyp + (c * 5 + i) * 4;
-    const lds_f32* pose = L.poses + s * kPoseStride;
+    const lds_f32* pose = L.poses + s * L.pstride;
     const int col = col0 + c;
     if (!geom_only) {
       float Hm[9];
@@ -1052,8 +1067,7 @@ __global__ void __launch_bounds__(256, 3) pm_sweep_kernel(const PmParams* __rest
   unsigned long long prof_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long prof_t = PROF ? __builtin_readcyclecounter() : 0ull;
 
-  for (int i = tid; i < S * kPoseStride; i += nt) L.poses[i] = p.poses[i];
-  for (int i = tid; i < S; i += nt) L.fpb[i] = (uint64_t)p.src_fp_tab[i];
+  lds_load_poses(p, L, GEOM, tid, nt);
 
   // ---- backward messages for all rows (:976-989); stored in sel_out ----------
   for (int item = tid; item < ncols * S; item += nt) {
@@ -1138,7 +1152,7 @@ __global__ void __launch_bounds__(256, 3) pm_sweep_kernel(const PmParams* __rest
       const int s = item - c * S;
       const int col = col0 + c;
       const float* rec = p.rec + (size_t)pix_index(p, row, col) * p.rec_stride;
-      const lds_f32* pose = L.poses + s * kPoseStride;
+      const lds_f32* pose = L.poses + s * L.pstride;
       const lds_f32* h = L.hyp + c * 20;
       const lds_f32* cf = L.colf + c * 8;
       const float cost = rec[4 + s];
@@ -1286,7 +1300,7 @@ __global__ void __launch_bounds__(256, 3) pm_sweep_kernel(const PmParams* __rest
       if (FILTER_PHOTO || FILTER_GEOM) {
         // :1209-1265
         const lds_f32* hb = L.hyp + (c * 5 + 1) * 4;  // == best (stored in P5)
-        const lds_f32* pose = L.poses + s * kPoseStride;
+        const lds_f32* pose = L.poses + s * L.pstride;
         const float bp0 = hb[0] * (iK[0] * col + iK[1]);
         const float bp1 = hb[0] * (iK[2] * row + iK[3]);
         const float bp2 = hb[0];

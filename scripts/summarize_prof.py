@@ -35,5 +35,11 @@ for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
             agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
             ndisp[k].add(r.get("Dispatch_Id"))
     summary[os.path.basename(d)] = {k: dict(v, dispatches=len(ndisp[k])) for k, v in agg.items()}
-json.dump(summary, open(os.path.join(out, "pmc_summary.json"), "w"), indent=1)
+prev_path = os.path.join(out, "pmc_summary.json")
+if os.path.exists(prev_path):  # passes summarised earlier whose bulk output is already deleted
+    prev = json.load(open(prev_path))
+    for k, v in prev.items():
+        if k not in summary or not summary[k]:
+            summary[k] = v
+json.dump(summary, open(prev_path, "w"), indent=1)
 print(json.dumps(summary, indent=1))
