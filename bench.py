@@ -271,9 +271,10 @@ def main():
                 "avg_launch_ms": avg_ms,
                 "launches_timed": sweep_n,
                 "images_per_launch": a.batch,
-                "note": "fp32-VALU bound by construction (SURVEY.md 8d: HBM floor ~6 ms vs VALU floor "
-                        "~185 ms per image), no dense contraction, so neither the HBM nor the MFMA "
-                        "roofline can be approached; see DESIGN.md for the VALU-issue accounting",
+                "note": "gather/latency-limited fp32 VALU kernel, no dense contraction: VALU issue ~58 % busy, "
+                        "4-byte footprint gathers miss the XCD L2 69 % of the time (fabric reads ~33x the "
+                        "algorithmic bytes); the HBM fraction is reported because BASELINE.json asks for it, "
+                        "see DESIGN.md 1.5 for the PMC accounting",
             },
         }
         if not a.no_cpu_baseline:
