@@ -58,6 +58,7 @@ thread_local long long g_spmv_bytes = 0;
 
 constexpr int PD = 6;        // pose tangent width (5 when the gauge holds a translation coordinate)
 constexpr int KD = 4;        // max intrinsics tangent width
+constexpr int NPAR = 5;      // max number of parameters of a supported camera model (J_params is 2 x NPAR)
 static int chunk_size() {     // observations per camera-side reduction chunk (one wave each)
   const char* e = std::getenv("COLMAP_AMD_BA_CHUNK");
   const int v = e ? std::atoi(e) : 512;
@@ -107,6 +108,10 @@ struct View {
   // topology
   const int *o_pose, *o_cam, *o_pt;  // per observation, c-order (sorted by camera, then pose)
   const double* o_xy;                // c-order
+  const int* o_sensor;               // c-order: constant sensor_from_rig of the observation, -1 none; or NULL
+  const double* sensors;             // [n][7]
+  int loss_type;                     // BA_LOSS_*
+  double loss_scale;
   const int *c2a, *a2c;              // c-order position <-> p-order position (sorted by point)
   const unsigned char* solo;         // c-order: bit k set = no other observation of this point shares block kind k
   const int *pose_off, *pose_dim, *pose_fix;
@@ -160,7 +165,9 @@ __device__ __forceinline__ void atomic_max_pos(double* addr, double v) {
 // ------------------------------------------------------------------------------------------
 // Per-residual math (reference reprojection_error.h:68-134)
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ int num_params_of(int model) { return model == BA_SIMPLE_PINHOLE ? 3 : 4; }
+__device__ __host__ __forceinline__ int num_params_of(int model) {
+  return model == BA_SIMPLE_PINHOLE ? 3 : (model == BA_RADIAL ? 5 : 4);
+}
 
 // QuaternionRotatePointWithJac, quaternion_utils.h:105-153
 __device__ __forceinline__ void quat_rotate(const double* q, const double* p, double out[3], double* J) {
@@ -205,8 +212,8 @@ __device__ __forceinline__ bool img_from_cam(int model, const double* prm, doubl
     if (JAC) {
       const double fw = f * inv_w;
       Juvw[0] = fw; Juvw[1] = 0.0; Juvw[2] = -fw * uu; Juvw[3] = 0.0; Juvw[4] = fw; Juvw[5] = -fw * vv;
-      Jpar[0] = uu; Jpar[1] = 1.0; Jpar[2] = 0.0; Jpar[3] = 0.0;
-      Jpar[4] = vv; Jpar[5] = 0.0; Jpar[6] = 1.0; Jpar[7] = 0.0;
+      Jpar[0] = uu; Jpar[1] = 1.0; Jpar[2] = 0.0;
+      Jpar[NPAR + 0] = vv; Jpar[NPAR + 1] = 0.0; Jpar[NPAR + 2] = 1.0;
     }
     return true;
   }
@@ -218,7 +225,29 @@ __device__ __forceinline__ bool img_from_cam(int model, const double* prm, doubl
       Juvw[0] = f1 * inv_w; Juvw[1] = 0.0; Juvw[2] = -f1 * inv_w * uu;
       Juvw[3] = 0.0; Juvw[4] = f2 * inv_w; Juvw[5] = -f2 * inv_w * vv;
       Jpar[0] = uu; Jpar[1] = 0.0; Jpar[2] = 1.0; Jpar[3] = 0.0;
-      Jpar[4] = 0.0; Jpar[5] = vv; Jpar[6] = 0.0; Jpar[7] = 1.0;
+      Jpar[NPAR + 0] = 0.0; Jpar[NPAR + 1] = vv; Jpar[NPAR + 2] = 0.0; Jpar[NPAR + 3] = 1.0;
+    }
+    return true;
+  }
+  if (model == BA_RADIAL) {  // models_jacobian.h:323-398
+    const double f = prm[0], k1 = prm[3], k2 = prm[4];
+    const double uu2 = uu * uu, vv2 = vv * vv, r2 = uu2 + vv2, r4 = r2 * r2;
+    const double radial = k1 * r2 + k2 * r4;
+    const double xd = uu * (1.0 + radial), yd = vv * (1.0 + radial);
+    x = f * xd + prm[1];
+    y = f * yd + prm[2];
+    if (JAC) {
+      const double d_radial_d_r2 = k1 + 2.0 * k2 * r2;
+      const double cross = 2.0 * uu * vv * d_radial_d_r2;
+      const double a00 = f * (1.0 + radial + 2.0 * uu2 * d_radial_d_r2);
+      const double a01 = f * cross;
+      const double a10 = f * cross;
+      const double a11 = f * (1.0 + radial + 2.0 * vv2 * d_radial_d_r2);
+      Juvw[0] = a00 * inv_w; Juvw[1] = a01 * inv_w; Juvw[2] = -(a00 * uu + a01 * vv) * inv_w;
+      Juvw[3] = a10 * inv_w; Juvw[4] = a11 * inv_w; Juvw[5] = -(a10 * uu + a11 * vv) * inv_w;
+      Jpar[0] = xd; Jpar[1] = 1.0; Jpar[2] = 0.0; Jpar[3] = f * uu * r2; Jpar[4] = f * uu * r4;
+      Jpar[NPAR + 0] = yd; Jpar[NPAR + 1] = 0.0; Jpar[NPAR + 2] = 1.0; Jpar[NPAR + 3] = f * vv * r2;
+      Jpar[NPAR + 4] = f * vv * r4;
     }
     return true;
   }
@@ -232,13 +261,57 @@ __device__ __forceinline__ bool img_from_cam(int model, const double* prm, doubl
     Juvw[0] = fw * (alpha + two_k * uu2); Juvw[1] = fw * tkuv; Juvw[2] = -fw * uu * beta;
     Juvw[3] = fw * tkuv; Juvw[4] = fw * (alpha + two_k * vv2); Juvw[5] = -fw * vv * beta;
     Jpar[0] = xd; Jpar[1] = 1.0; Jpar[2] = 0.0; Jpar[3] = f * uu * r2;
-    Jpar[4] = yd; Jpar[5] = 0.0; Jpar[6] = 1.0; Jpar[7] = f * vv * r2;
+    Jpar[NPAR + 0] = yd; Jpar[NPAR + 1] = 0.0; Jpar[NPAR + 2] = 1.0; Jpar[NPAR + 3] = f * vv * r2;
   }
   return true;
 }
 
+// ceres::LossFunction::Evaluate for the losses COLMAP can select (CreateLossFunction,
+// bundle_adjustment_ceres.cc:66-80; Ceres loss_function.cc restated, see oracle/ba_oracle.c:bao_loss):
+// rho[0] = rho(s), rho[1] = rho'(s), rho[2] = rho''(s), s = |r|^2.
+__device__ __forceinline__ void loss_eval(int type, double a, double s, double rho[3]) {
+  const double kMin = 2.2250738585072014e-308;
+  if (type == BA_LOSS_HUBER) {
+    const double b = a * a;
+    if (s > b) {
+      const double r = sqrt(s);
+      rho[0] = 2.0 * a * r - b;
+      rho[1] = fmax(kMin, a / r);
+      rho[2] = -rho[1] / (2.0 * s);
+    } else {
+      rho[0] = s; rho[1] = 1.0; rho[2] = 0.0;
+    }
+  } else if (type == BA_LOSS_SOFT_L1) {
+    const double b = a * a, c = 1.0 / b;
+    const double sum = 1.0 + s * c;
+    const double tmp = sqrt(sum);
+    rho[0] = 2.0 * b * (tmp - 1.0);
+    rho[1] = fmax(kMin, 1.0 / tmp);
+    rho[2] = -(c * rho[1]) / (2.0 * sum);
+  } else if (type == BA_LOSS_CAUCHY) {
+    const double b = a * a, c = 1.0 / b;
+    const double sum = 1.0 + s * c;
+    const double inv = 1.0 / sum;
+    rho[0] = b * log(sum);
+    rho[1] = fmax(kMin, inv);
+    rho[2] = -c * (inv * inv);
+  } else {
+    rho[0] = s; rho[1] = 1.0; rho[2] = 0.0;
+  }
+}
+
+__device__ __forceinline__ void quat_to_rot(const double* q, double R[9]) {
+  const double x = q[0], y = q[1], z = q[2], w = q[3];
+  const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+  const double twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x,
+               tyy = ty * y, tyz = tz * y, tzz = tz * z;
+  R[0] = 1 - (tyy + tzz); R[1] = txy - twz; R[2] = txz + twy;
+  R[3] = txy + twz; R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+  R[6] = txz - twy; R[7] = tyz + twx; R[8] = 1 - (txx + tyy);
+}
+
 // Evaluate one observation; JAC: also the tangent-space, column-scaled Jacobian blocks.
-// Jpar is laid out 2 x 4 (unused columns zero) whatever the model.
+// Jpar is laid out 2 x NPAR whatever the model (columns beyond the model's parameters are not read).
 template <bool JAC>
 __global__ void __launch_bounds__(256) ba_linearize_kernel(View V, const double* __restrict__ poses,
                                                           const double* __restrict__ cams,
@@ -252,9 +325,20 @@ __global__ void __launch_bounds__(256) ba_linearize_kernel(View V, const double*
     const double* prm = cams + BA_CAM_STRIDE * (size_t)ci;
     const double* X = points + 3 * (size_t)xi;
     const int model = V.cam_model[ci];
-    double JR[12], Juvw[6], Jpar[8], pc[3];
+    double JR[12], Juvw[6], Jpar[2 * NPAR], pc[3];
     quat_rotate(q, X, pc, JAC ? JR : nullptr);
     pc[0] += q[4]; pc[1] += q[5]; pc[2] += q[6];
+    // constant sensor_from_rig (RigReprojErrorConstantRigCostFunctor): p_cam = R_s p_rig + t_s
+    const int si = V.o_sensor ? V.o_sensor[o] : -1;
+    double Rs[9];
+    if (si >= 0) {
+      const double* sfr = V.sensors + 7 * (size_t)si;
+      quat_to_rot(sfr, Rs);
+      const double p0 = pc[0], p1 = pc[1], p2 = pc[2];
+      pc[0] = Rs[0] * p0 + Rs[1] * p1 + Rs[2] * p2 + sfr[4];
+      pc[1] = Rs[3] * p0 + Rs[4] * p1 + Rs[5] * p2 + sfr[5];
+      pc[2] = Rs[6] * p0 + Rs[7] * p1 + Rs[8] * p2 + sfr[6];
+    }
     double rx = 0.0, ry = 0.0;
     const bool ok = img_from_cam<JAC>(model, prm, pc[0], pc[1], pc[2], rx, ry, Jpar, Juvw);
     if (ok) {
@@ -263,23 +347,37 @@ __global__ void __launch_bounds__(256) ba_linearize_kernel(View V, const double*
     } else {
       rx = ry = 0.0;  // behind the camera: zero residual and Jacobian (:96-116)
     }
-    cost = 0.5 * (rx * rx + ry * ry);
+    // robust loss: cost = 1/2 rho(|r|^2)
+    const double sq_norm = rx * rx + ry * ry;
+    double rho[3];
+    loss_eval(V.loss_type, V.loss_scale, sq_norm, rho);
+    cost = 0.5 * rho[0];
     if (JAC) {
+      if (ok && si >= 0) {  // derivative w.r.t. the point in the rig frame: J_uvw R_s
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const double j0 = Juvw[3 * r], j1 = Juvw[3 * r + 1], j2 = Juvw[3 * r + 2];
+          Juvw[3 * r] = j0 * Rs[0] + j1 * Rs[3] + j2 * Rs[6];
+          Juvw[3 * r + 1] = j0 * Rs[1] + j1 * Rs[4] + j2 * Rs[7];
+          Juvw[3 * r + 2] = j0 * Rs[2] + j1 * Rs[5] + j2 * Rs[8];
+        }
+      }
       const size_t N = (size_t)V.n_obs;
       const int a = V.c2a[o];  // p-order slot of this observation
-      V.res[o] = rx;
-      V.res[N + o] = ry;
-      V.res_p[a] = rx;
-      V.res_p[N + a] = ry;
       const int pdim = V.pose_dim[pi], poff = V.pose_off[pi];
       const int cdim = V.cam_dim[ci], coff = V.cam_off[ci];
       const int ptoff = V.pt_off[xi];
       // pose block: J_uvw * dRp/dq * PlusJacobian (EigenQuaternionManifold, xyzw) | J_uvw
-      double Jp[2][PD];
+      double Jp[2][PD], Jk[2][KD], Jx[2][3];
 #pragma unroll
-      for (int r = 0; r < 2; ++r)
+      for (int r = 0; r < 2; ++r) {
 #pragma unroll
         for (int c = 0; c < PD; ++c) Jp[r][c] = 0.0;
+#pragma unroll
+        for (int c = 0; c < KD; ++c) Jk[r][c] = 0.0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) Jx[r][c] = 0.0;
+      }
       if (ok && pdim > 0) {
         const double x = q[0], y = q[1], z = q[2], w = q[3];
         const double PJ[12] = {w, z, -y, -z, w, x, y, -x, w, -x, -y, -z};
@@ -301,43 +399,70 @@ __global__ void __launch_bounds__(256) ba_linearize_kernel(View V, const double*
           }
         }
       }
+      // intrinsics block: variable subset of the model's parameters
+      if (ok) {
 #pragma unroll
-      for (int r = 0; r < 2; ++r)
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+          for (int c = 0; c < KD; ++c)
+            if (c < cdim) Jk[r][c] = Jpar[NPAR * r + V.cam_var[KD * ci + c]];
+      }
+      // point block: J_uvw * R(q)
+      if (ok && ptoff >= 0) {
+        double R[9];
+        quat_to_rot(q, R);
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+          for (int c = 0; c < 3; ++c)
+            Jx[r][c] = Juvw[3 * r] * R[c] + Juvw[3 * r + 1] * R[3 + c] + Juvw[3 * r + 2] * R[6 + c];
+      }
+      // ceres::internal::Corrector: r' = residual_scaling r, J' = sqrt(rho') (J - alpha/|r|^2 r r^T J)
+      if (V.loss_type != BA_LOSS_TRIVIAL) {
+        const double sqrt_rho1 = sqrt(rho[1]);
+        double residual_scaling = sqrt_rho1, alpha_sq_norm = 0.0;
+        if (!(sq_norm == 0.0 || rho[2] <= 0.0)) {
+          const double D = 1.0 + 2.0 * sq_norm * rho[2] / rho[1];
+          const double alpha = 1.0 - sqrt(D);
+          residual_scaling = sqrt_rho1 / (1.0 - alpha);
+          alpha_sq_norm = alpha / sq_norm;
+        }
+        auto correct = [&](double& j0, double& j1) {
+          const double rtj = rx * j0 + ry * j1;
+          j0 = sqrt_rho1 * (j0 - alpha_sq_norm * rx * rtj);
+          j1 = sqrt_rho1 * (j1 - alpha_sq_norm * ry * rtj);
+        };
+#pragma unroll
+        for (int c = 0; c < PD; ++c) correct(Jp[0][c], Jp[1][c]);
+#pragma unroll
+        for (int c = 0; c < KD; ++c) correct(Jk[0][c], Jk[1][c]);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) correct(Jx[0][c], Jx[1][c]);
+        rx *= residual_scaling;
+        ry *= residual_scaling;
+      }
+      V.res[o] = rx;
+      V.res[N + o] = ry;
+      V.res_p[a] = rx;
+      V.res_p[N + a] = ry;
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
 #pragma unroll
         for (int c = 0; c < PD; ++c) {
           const double s = (c < pdim) ? V.scale_c[poff + c] : 0.0;
           V.Jpose[(size_t)(r * PD + c) * N + o] = Jp[r][c] * s;
         }
-      // intrinsics block: variable subset of the model's parameters
-#pragma unroll
-      for (int r = 0; r < 2; ++r)
 #pragma unroll
         for (int c = 0; c < KD; ++c) {
-          double val = 0.0;
-          if (ok && c < cdim) val = Jpar[4 * r + V.cam_var[KD * ci + c]] * V.scale_c[coff + c];
-          V.Jcam[(size_t)(r * KD + c) * N + o] = val;
+          const double s = (c < cdim) ? V.scale_c[coff + c] : 0.0;
+          V.Jcam[(size_t)(r * KD + c) * N + o] = Jk[r][c] * s;
         }
-      // point block: J_uvw * R(q)
-      double R[9];
-      {
-        const double x = q[0], y = q[1], z = q[2], w = q[3];
-        const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
-        const double twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x,
-                     tyy = ty * y, tyz = tz * y, tzz = tz * z;
-        R[0] = 1 - (tyy + tzz); R[1] = txy - twz; R[2] = txz + twy;
-        R[3] = txy + twz; R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
-        R[6] = txz - twy; R[7] = tyz + twx; R[8] = 1 - (txx + tyy);
-      }
-#pragma unroll
-      for (int r = 0; r < 2; ++r)
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-          double val = 0.0;
-          if (ok && ptoff >= 0)
-            val = (Juvw[3 * r] * R[c] + Juvw[3 * r + 1] * R[3 + c] + Juvw[3 * r + 2] * R[6 + c]) *
-                  V.scale_p[ptoff + c];
-          V.Jpt[(size_t)(r * 3 + c) * N + a] = val;
+          const double s = (ptoff >= 0) ? V.scale_p[ptoff + c] : 0.0;
+          V.Jpt[(size_t)(r * 3 + c) * N + a] = Jx[r][c] * s;
         }
+      }
     }
   }
   cost = block_sum(cost);
@@ -1015,6 +1140,8 @@ struct Solver {
   View V{};
   hipStream_t st = nullptr;
   // topology
+  Buf<int> o_sensor;
+  Buf<double> sensors;
   Buf<int> o_pose, o_cam, o_pt, pose_off, pose_dim, pose_fix, cam_off, cam_dim, cam_var, cam_model, pt_off,
       pt_ptr, blk_off, blk_dim, blk_kind, blk_moff, chunk_blk, chunk_beg, chunk_end, blk_chunk_ptr, c2a, a2c, tile_pt;
   Buf<unsigned char> solo;
@@ -1050,12 +1177,17 @@ struct Solver {
     std::vector<int> h_cam_var((size_t)p.num_cams * KD, 0), h_cam_dim(p.num_cams, 0);
     for (int k = 0; k < p.num_cams; ++k) {
       const int model = p.cam_model[k];
-      if (model != BA_SIMPLE_PINHOLE && model != BA_PINHOLE && model != BA_SIMPLE_RADIAL)
+      if (model != BA_SIMPLE_PINHOLE && model != BA_PINHOLE && model != BA_SIMPLE_RADIAL && model != BA_RADIAL)
         throw std::runtime_error("unsupported camera model id " + std::to_string(model) +
-                                 " (supported: SIMPLE_PINHOLE, PINHOLE, SIMPLE_RADIAL)");
-      const int P = model == BA_SIMPLE_PINHOLE ? 3 : 4;
+                                 " (supported: SIMPLE_PINHOLE, PINHOLE, SIMPLE_RADIAL, RADIAL)");
+      const int P = num_params_of(model);
       for (int j = 0; j < P; ++j)
-        if (!p.cam_const[(size_t)k * BA_CAM_STRIDE + j]) h_cam_var[(size_t)k * KD + cam_nvar[k]++] = j;
+        if (!p.cam_const[(size_t)k * BA_CAM_STRIDE + j]) {
+          if (cam_nvar[k] == KD)
+            throw std::runtime_error("camera " + std::to_string(k) + ": more than " + std::to_string(KD) +
+                                     " variable intrinsics are not supported");
+          h_cam_var[(size_t)k * KD + cam_nvar[k]++] = j;
+        }
     }
     std::vector<int64_t> active;
     active.reserve(p.num_obs / comm.world + 1);
@@ -1065,6 +1197,8 @@ struct Solver {
       const int pi = p.obs_pose[o], ci = p.obs_cam[o], xi = p.obs_point[o];
       if (pi < 0 || pi >= p.num_poses || ci < 0 || ci >= p.num_cams || xi < 0 || xi >= p.num_points)
         throw std::runtime_error("observation index out of range");
+      if (p.obs_sensor && (p.obs_sensor[o] < -1 || p.obs_sensor[o] >= p.num_sensors))
+        throw std::runtime_error("observation sensor index out of range");
       if (p.pose_const[pi] && cam_nvar[ci] == 0 && p.point_const[xi]) continue;
       ++n_active_global;
       pose_used[pi] = cam_used[ci] = pt_used[xi] = 1;  // layout = all ranks' observations
@@ -1115,10 +1249,13 @@ struct Solver {
         }
         h_solo[h_a2c[a]] = (unsigned char)((same_pose == 1 ? 1 : 0) | (same_cam == 1 ? 2 : 0));
       }
-    std::vector<int> h_o_pose(n), h_o_cam(n), h_o_pt(n);
+    std::vector<int> h_o_pose(n), h_o_cam(n), h_o_pt(n), h_o_sensor;
+    const bool has_sensors = p.obs_sensor != nullptr && p.num_sensors > 0 && p.sensors != nullptr;
+    if (has_sensors) h_o_sensor.resize(n);
     std::vector<double> h_xy((size_t)2 * n);
     for (int c = 0; c < n; ++c) {
       const int64_t o = active[h_c2a[c]];
+      if (has_sensors) h_o_sensor[c] = p.obs_sensor[o];
       h_o_pose[c] = p.obs_pose[o];
       h_o_cam[c] = p.obs_cam[o];
       h_o_pt[c] = p.obs_point[o];
@@ -1162,35 +1299,31 @@ struct Solver {
       h_pt_off[j] = poff;
       poff += 3;
     }
-    // per-block c-order ranges, split into chunks. A pose whose observations use several cameras
-    // (not produced by COLMAP's trivial-rig frames) would not be contiguous: reject it.
+    // per-block c-order runs, split into chunks. A camera's observations are one run (c-order is
+    // sorted by camera first); a pose seen through several cameras (a rig frame) owns one run per
+    // camera. Every chunk is a contiguous range of one block.
     const int n_blk = (int)h_blk_off.size();
-    std::vector<int> beg(n_blk, n), end(n_blk, 0), cntb(n_blk, 0);
+    std::vector<std::vector<std::pair<int, int>>> runs(n_blk);
+    auto add_run = [&](int b, int c) {
+      if (b < 0) return;
+      auto& r = runs[b];
+      if (!r.empty() && r.back().second == c) r.back().second = c + 1;
+      else r.emplace_back(c, c + 1);
+    };
     for (int c = 0; c < n; ++c) {
-      const int bs[2] = {blk_of_pose[h_o_pose[c]], blk_of_cam[h_o_cam[c]]};
-      for (int b : bs) {
-        if (b < 0) continue;
-        beg[b] = std::min(beg[b], c);
-        end[b] = std::max(end[b], c + 1);
-        cntb[b]++;
-      }
+      add_run(blk_of_pose[h_o_pose[c]], c);
+      add_run(blk_of_cam[h_o_cam[c]], c);
     }
-    for (int b = 0; b < n_blk; ++b) {
-      if (cntb[b] == 0) beg[b] = end[b] = 0;  // block without observations on this rank
-      if (cntb[b] != end[b] - beg[b])
-        throw std::runtime_error("a pose block is observed through several cameras: not supported "
-                                 "(COLMAP frames with a trivial rig have one camera per image)");
-    }
-    const int CHUNK = chunk_size() & ~1;
+    const int CHUNK = chunk_size() & ~1;  // even: the MFMA Gram kernel consumes observation pairs
     std::vector<int> h_chunk_blk, h_chunk_beg, h_chunk_end, h_blk_chunk_ptr(n_blk + 1, 0);
     for (int b = 0; b < n_blk; ++b) {
       h_blk_chunk_ptr[b] = (int)h_chunk_blk.size();
-      for (int s = beg[b]; s < end[b]; s += CHUNK) {
-        h_chunk_blk.push_back(b);
-        h_chunk_beg.push_back(s);
-        h_chunk_end.push_back(std::min(s + CHUNK, end[b]));
-      }
-      // keep chunk boundaries on even offsets: the MFMA Gram kernel consumes observation pairs
+      for (const auto& run : runs[b])
+        for (int s = run.first; s < run.second; s += CHUNK) {
+          h_chunk_blk.push_back(b);
+          h_chunk_beg.push_back(s);
+          h_chunk_end.push_back(std::min(s + CHUNK, run.second));
+        }
     }
     h_blk_chunk_ptr[n_blk] = (int)h_chunk_blk.size();
 
@@ -1203,6 +1336,10 @@ struct Solver {
 
     // upload
     o_pose.upload(h_o_pose); o_cam.upload(h_o_cam); o_pt.upload(h_o_pt); o_xy.upload(h_xy);
+    if (has_sensors) {
+      o_sensor.upload(h_o_sensor);
+      sensors.upload(std::vector<double>(p.sensors, p.sensors + (size_t)7 * p.num_sensors));
+    }
     pose_off.upload(h_pose_off); pose_dim.upload(h_pose_dim); pose_fix.upload(h_pose_fix);
     cam_off.upload(h_cam_off); cam_dim.upload(h_cam_dim); cam_var.upload(h_cam_var);
     cam_model.upload(std::vector<int>(p.cam_model, p.cam_model + p.num_cams));
@@ -1232,6 +1369,14 @@ struct Solver {
     V.n_c = n_c; V.n_p = poff; V.n_blk = n_blk; V.n_chunks = (int)h_chunk_blk.size();
     V.poses = poses.p; V.cams = cams.p; V.points = points.p;
     V.o_pose = o_pose.p; V.o_cam = o_cam.p; V.o_pt = o_pt.p; V.o_xy = o_xy.p;
+    V.o_sensor = has_sensors ? o_sensor.p : nullptr;
+    V.sensors = has_sensors ? sensors.p : nullptr;
+    if (opt.loss_type < BA_LOSS_TRIVIAL || opt.loss_type > BA_LOSS_HUBER)
+      throw std::runtime_error("unknown loss_type " + std::to_string(opt.loss_type));
+    if (opt.loss_type != BA_LOSS_TRIVIAL && !(opt.loss_scale > 0.0))
+      throw std::runtime_error("loss_scale must be positive");
+    V.loss_type = opt.loss_type;
+    V.loss_scale = opt.loss_scale;
     V.pose_off = pose_off.p; V.pose_dim = pose_dim.p; V.pose_fix = pose_fix.p;
     V.cam_off = cam_off.p; V.cam_dim = cam_dim.p; V.cam_var = cam_var.p; V.cam_model = cam_model.p;
     V.pt_off = pt_off.p; V.pt_ptr = pt_ptr.p;
@@ -1549,6 +1694,8 @@ void ba_options_init(ba_options* o) {
   o->eta = 1e-1;
   o->max_num_consecutive_invalid_steps = 10;
   o->jacobi_scaling = 1;
+  o->loss_type = BA_LOSS_TRIVIAL;  // bundle_adjustment_ceres.h:42-51
+  o->loss_scale = 1.0;
 }
 
 static int SolveImpl(ba_problem* problem, const ba_options* options, int32_t gpu_index, const ba_comm* c,

@@ -35,6 +35,14 @@ class BundleAdjustmentGauge(enum.IntEnum):
     THREE_POINTS = 1
 
 
+class LossFunctionType(enum.IntEnum):
+    """CeresBundleAdjustmentOptions::LossFunctionType (bundle_adjustment_ceres.h:42)."""
+    TRIVIAL = 0
+    SOFT_L1 = 1
+    CAUCHY = 2
+    HUBER = 3
+
+
 class BundleAdjustmentTerminationType(enum.IntEnum):
     CONVERGENCE = 0
     NO_CONVERGENCE = 1
@@ -60,6 +68,7 @@ class BundleAdjustmentConfig:
         self.ignored_point3D_ids_: Set[int] = set()
         self.constant_cam_intrinsics_: Set[int] = set()
         self.constant_rig_from_world_poses_: Set[int] = set()
+        self.constant_sensor_from_rig_: Set[int] = set()
 
     def FixGauge(self, gauge):
         self.fixed_gauge_ = BundleAdjustmentGauge(gauge)
@@ -100,6 +109,15 @@ class BundleAdjustmentConfig:
     def HasConstantRigFromWorldPose(self, frame_id):
         return frame_id in self.constant_rig_from_world_poses_
 
+    def SetConstantSensorFromRigPose(self, sensor_id):
+        self.constant_sensor_from_rig_.add(sensor_id)
+
+    def SetVariableSensorFromRigPose(self, sensor_id):
+        self.constant_sensor_from_rig_.discard(sensor_id)
+
+    def HasConstantSensorFromRigPose(self, sensor_id):
+        return sensor_id in self.constant_sensor_from_rig_
+
     def AddVariablePoint(self, point3D_id):
         assert point3D_id not in self.constant_point3D_ids_ and point3D_id not in self.ignored_point3D_ids_
         self.variable_point3D_ids_.add(point3D_id)
@@ -139,6 +157,10 @@ class SolverOptions:
     eta: float = 1e-1
     max_num_consecutive_invalid_steps: int = 10
     jacobi_scaling: bool = True
+    # CeresBundleAdjustmentOptions::loss_function_type / loss_function_scale
+    # (bundle_adjustment_ceres.h:42-51)
+    loss_type: int = 0   # LossFunctionType.TRIVIAL
+    loss_scale: float = 1.0
 
 
 @dataclass
@@ -204,6 +226,9 @@ class FlatProblem:
     pose_fixed_t: np.ndarray   # (N_c,) i8
     cam_const: np.ndarray      # (N_k, 12) u8
     point_const: np.ndarray    # (N_p,) u8
+    # rigs: constant sensor_from_rig per observation (None: every frame is trivial)
+    sensors: Optional[np.ndarray] = None      # (N_s, 7) f64
+    obs_sensor: Optional[np.ndarray] = None   # (N_o,) i32, -1 = trivial
     # id maps for write-back
     pose_ids: List[int] = field(default_factory=list)
     cam_ids: List[int] = field(default_factory=list)
@@ -237,27 +262,34 @@ class FlatProblem:
         return copy.deepcopy(self)
 
 
-def fix_gauge_two_cams(fp: FlatProblem, order: Optional[List[int]] = None):
-    """FixGaugeWithTwoCamsFromWorld (bundle_adjustment_ceres.cc:308-416) on a flat problem whose
-    poses are all trivial-rig frames: frame 1 fully constant, the largest-baseline translation
-    coordinate of frame 2 constant. Returns True when the gauge was fixed with two cameras."""
+def fix_gauge_two_cams(fp: FlatProblem, order: Optional[List[int]] = None,
+                       frames: Optional[List[int]] = None):
+    """FixGaugeWithTwoCamsFromWorld (bundle_adjustment_ceres.cc:308-416) on a flat problem: frame 1
+    fully constant, the largest-baseline translation coordinate of frame 2 constant. `order` lists
+    the pose slots of the candidate images in image-id order, `frames` their frame ids (two images
+    of one frame are not two cameras). Returns True when the gauge was fixed with two cameras."""
     idx = order if order is not None else list(range(len(fp.poses)))
+    frm = frames if frames is not None else idx
     used = np.zeros(len(fp.poses), bool)
     used[fp.obs_pose] = True
-    idx = [i for i in idx if used[i]]
-    const = [i for i in idx if fp.pose_const[i]]
-    if len(const) >= 2:
-        return True  # two frames already fixed (:352-354)
-    image1 = const[0] if const else None
+    cand = [(i, f) for i, f in zip(idx, frm) if used[i]]
+    # first, the already fixed cameras (:347-357)
+    image1 = None
+    for i, f in cand:
+        if fp.pose_const[i]:
+            if image1 is None:
+                image1 = (i, f)
+            elif image1[1] != f:
+                return True  # two frames already fixed
     image2, fixed_dim = None, 0
-    for i in idx:
+    for i, f in cand:
         if image1 is None:
-            image1 = i
+            image1 = (i, f)
             continue
-        if i == image1 or fp.pose_const[i]:
+        if f == image1[1] or fp.pose_const[i]:
             continue
         # baseline = (frame1_from_world * inverse(frame2_from_world)).translation (:374-377)
-        q1, t1 = fp.poses[image1, :4], fp.poses[image1, 4:]
+        q1, t1 = fp.poses[image1[0], :4], fp.poses[image1[0], 4:]
         q2, t2 = fp.poses[i, :4], fp.poses[i, 4:]
         R1, R2 = scene.quat_to_rot(q1), scene.quat_to_rot(q2)
         baseline = t1 - R1 @ R2.T @ t2
@@ -267,7 +299,7 @@ def fix_gauge_two_cams(fp: FlatProblem, order: Optional[List[int]] = None):
             break
     if image1 is None or image2 is None:
         return False
-    fp.pose_const[image1] = 1
+    fp.pose_const[image1[0]] = 1
     fp.pose_fixed_t[image2] = fixed_dim
     return True
 
@@ -301,23 +333,39 @@ def flatten(options: BundleAdjustmentOptions, config: BundleAdjustmentConfig,
             rec: scene.Reconstruction) -> FlatProblem:
     """DefaultBundleAdjuster ctor (bundle_adjustment_ceres.cc:606-664)."""
     config_const_cams = set(config.constant_cam_intrinsics_)
-    pose_ids: List[int] = []
-    pose_index: Dict[int, int] = {}
+    pose_ids: List[tuple] = []  # ("frame", frame_id) | ("image", image_id): where the block lives
+    pose_index: Dict[tuple, int] = {}
+    pose_params: List[np.ndarray] = []
     cam_ids: List[int] = []
     cam_index: Dict[int, int] = {}
     point_ids: List[int] = []
     point_index: Dict[int, int] = {}
     pose_is_const: List[int] = []
-    obs = []  # (pose, cam, point, x, y)
+    sensor_index: Dict[int, int] = {}
+    sensor_params: List[np.ndarray] = []
+    obs = []  # (pose, cam, point, x, y, sensor)
     num_obs_of_point: Dict[int, int] = {}
 
-    def pose_slot(image_id, const):
-        key = (image_id, const)
+    def frame_pose(img):
+        """(where, params) of the pose block an image's frame owns."""
+        if img.frame_id_ is None:
+            return ("image", img.image_id), img.cam_from_world
+        return ("frame", img.frame_id_), rec.frames[img.frame_id_].rig_from_world
+
+    def pose_slot(where, params, const):
+        key = (where, const)
         if key not in pose_index:
             pose_index[key] = len(pose_ids)
-            pose_ids.append(image_id)
+            pose_ids.append(where)
+            pose_params.append(np.asarray(params, np.float64))
             pose_is_const.append(1 if const else 0)
         return pose_index[key]
+
+    def sensor_slot(camera_id, params):
+        if camera_id not in sensor_index:
+            sensor_index[camera_id] = len(sensor_params)
+            sensor_params.append(np.asarray(params, np.float64))
+        return sensor_index[camera_id]
 
     def cam_slot(camera_id):
         if camera_id not in cam_index:
@@ -331,12 +379,34 @@ def flatten(options: BundleAdjustmentOptions, config: BundleAdjustmentConfig,
             point_ids.append(pid)
         return point_index[pid]
 
+    def image_blocks(img, const_frame):
+        """Pose slot and sensor slot of the residuals of `img`: AddImageWithTrivialFrame (:699-750)
+        / AddImageWithNonTrivialFrame (:752-822)."""
+        if rec.IsRefInFrame(img.image_id):
+            where, params = frame_pose(img)
+            return pose_slot(where, params, const_frame), -1
+        sensor_from_rig = rec.SensorFromRig(img.image_id)
+        const_sensor = (not options.refine_sensor_from_rig) or config.HasConstantSensorFromRigPose(img.camera_id)
+        if not const_sensor:
+            # same restriction as CasparBundleAdjuster (bundle_adjustment_caspar.cc:186-209)
+            raise NotImplementedError("refine_sensor_from_rig with a variable sensor_from_rig is not supported by "
+                                      "the MI355X backend: set refine_sensor_from_rig=false or make the sensor "
+                                      "constant in the config")
+        where, params = frame_pose(img)
+        if const_frame:
+            # both constant: ReprojErrorConstantPoseCostFunctor on the composed pose (:769-772,797-803)
+            return pose_slot(("image", img.image_id), scene.rigid_compose(sensor_from_rig, params), True), -1
+        return pose_slot(where, params, False), sensor_slot(img.camera_id, sensor_from_rig)
+
     parameterized_cams: Set[int] = set()
-    # AddImageToProblem / AddImageWithTrivialFrame (:688-750)
+    gauge_order: List[int] = []  # pose slots of the config's images in image-id order
+    gauge_frames: List[int] = []  # and their frame identities
+    # AddImageToProblem (:688-697)
     for image_id in config.Images():
         img = rec.images[image_id]
         const_pose = (not options.refine_rig_from_world) or config.HasConstantRigFromWorldPose(img.frame_id)
         n = 0
+        slot = None
         for p2 in img.points2D:
             if not p2.HasPoint3D() or config.IsIgnoredPoint(p2.point3D_id):
                 continue
@@ -346,10 +416,13 @@ def flatten(options: BundleAdjustmentOptions, config: BundleAdjustmentConfig,
                 continue
             n += 1
             num_obs_of_point[p2.point3D_id] = num_obs_of_point.get(p2.point3D_id, 0) + 1
-            obs.append((pose_slot(image_id, const_pose), cam_slot(img.camera_id), point_slot(p2.point3D_id),
-                        p2.xy[0], p2.xy[1]))
+            if slot is None:
+                slot = image_blocks(img, const_pose)
+            obs.append((slot[0], cam_slot(img.camera_id), point_slot(p2.point3D_id), p2.xy[0], p2.xy[1], slot[1]))
         if n > 0:
             parameterized_cams.add(img.camera_id)
+            gauge_order.append(slot[0])
+            gauge_frames.append(img.frame_id if img.frame_id_ is not None else -img.image_id - 1)
     # AddPointToProblem (:826-887): observations from images outside the config, constant pose
     for pid in config.VariablePoints() + config.ConstantPoints():
         pt = rec.points3D[pid]
@@ -365,13 +438,15 @@ def flatten(options: BundleAdjustmentOptions, config: BundleAdjustmentConfig,
             num_obs_of_point[pid] += 1
             img = rec.images[im]
             p2 = img.points2D[idx]
-            obs.append((pose_slot(im, True), cam_slot(img.camera_id), point_slot(pid), p2.xy[0], p2.xy[1]))
+            # constant pose of the observing camera (:851-881), whatever its rig
+            obs.append((pose_slot(("image", im), img.cam_from_world, True), cam_slot(img.camera_id),
+                        point_slot(pid), p2.xy[0], p2.xy[1], -1))
             if img.camera_id not in parameterized_cams:
                 parameterized_cams.add(img.camera_id)
                 config_const_cams.add(img.camera_id)  # (:883-886)
 
     n_c, n_k, n_p = len(pose_ids), len(cam_ids), len(point_ids)
-    poses = np.array([rec.images[i].cam_from_world for i in pose_ids], np.float64).reshape(n_c, 7)
+    poses = np.array(pose_params, np.float64).reshape(n_c, 7)
     cams = np.zeros((n_k, CAM_STRIDE))
     cam_model = np.zeros(n_k, np.int32)
     cam_const = np.ones((n_k, CAM_STRIDE), np.uint8)
@@ -402,7 +477,7 @@ def flatten(options: BundleAdjustmentOptions, config: BundleAdjustmentConfig,
     for pid in config.ConstantPoints():
         if pid in point_index:
             point_const[point_index[pid]] = 1
-    o = np.array(obs, np.float64).reshape(-1, 5)
+    o = np.array(obs, np.float64).reshape(-1, 6)
     fp = FlatProblem(
         poses=poses, cams=cams, cam_model=cam_model, points=points,
         obs_pose=o[:, 0].astype(np.int32), obs_cam=o[:, 1].astype(np.int32),
@@ -410,11 +485,15 @@ def flatten(options: BundleAdjustmentOptions, config: BundleAdjustmentConfig,
         pose_const=np.array(pose_is_const, np.uint8), pose_fixed_t=np.full(n_c, -1, np.int8),
         cam_const=cam_const, point_const=point_const, pose_ids=pose_ids, cam_ids=cam_ids,
         point_ids=point_ids)
+    if sensor_params:
+        fp.sensors = np.array(sensor_params, np.float64).reshape(-1, 7)
+        fp.obs_sensor = np.ascontiguousarray(o[:, 5].astype(np.int32))
     # gauge (:646-663)
     if config.FixedGauge() == BundleAdjustmentGauge.TWO_CAMS_FROM_WORLD:
         if options.refine_rig_from_world:
-            order = sorted(range(n_c), key=lambda i: pose_ids[i])  # std::set<image_t> order
-            if not fix_gauge_two_cams(fp, order):
+            # candidates: the config's images in std::set<image_t> order (:347-385); every sensor is a
+            # reference sensor or has a constant sensor_from_rig here (IsParameterizedConstSensor)
+            if not fix_gauge_two_cams(fp, gauge_order, gauge_frames):
                 fix_gauge_three_points(fp)
     elif config.FixedGauge() == BundleAdjustmentGauge.THREE_POINTS:
         fix_gauge_three_points(fp)
@@ -435,6 +514,7 @@ class ba_problem(C.Structure):
         ("obs_pose", C.c_void_p), ("obs_cam", C.c_void_p), ("obs_point", C.c_void_p), ("obs_xy", C.c_void_p),
         ("pose_const", C.c_void_p), ("pose_fixed_t", C.c_void_p), ("cam_const", C.c_void_p),
         ("point_const", C.c_void_p),
+        ("num_sensors", C.c_int32), ("sensors", C.c_void_p), ("obs_sensor", C.c_void_p),
     ]
 
 
@@ -449,6 +529,7 @@ class ba_options(C.Structure):
         ("max_lm_diagonal", C.c_double), ("eta", C.c_double),
         ("max_num_consecutive_invalid_steps", C.c_int32), ("jacobi_scaling", C.c_int32),
         ("num_threads", C.c_int32), ("max_log", C.c_int32),
+        ("loss_type", C.c_int32), ("loss_scale", C.c_double),
     ]
 
 
@@ -535,6 +616,12 @@ def marshal_problem(fp: FlatProblem) -> ba_problem:
         a = getattr(fp, name)
         assert a.flags["C_CONTIGUOUS"], name
         setattr(p, name, a.ctypes.data)
+    if fp.sensors is not None and len(fp.sensors):
+        assert fp.sensors.flags["C_CONTIGUOUS"] and fp.obs_sensor.flags["C_CONTIGUOUS"]
+        assert fp.sensors.dtype == np.float64 and fp.obs_sensor.dtype == np.int32
+        p.num_sensors = len(fp.sensors)
+        p.sensors = fp.sensors.ctypes.data
+        p.obs_sensor = fp.obs_sensor.ctypes.data
     return p
 
 
@@ -544,6 +631,7 @@ def marshal_options(so: SolverOptions, max_log: int = 0, num_threads: int = 0) -
         if name in ("num_threads", "max_log"):
             continue
         setattr(o, name, getattr(so, name))
+    o.loss_type = int(so.loss_type)
     o.jacobi_scaling = 1 if so.jacobi_scaling else 0
     o.num_threads = num_threads
     o.max_log = max_log
@@ -621,9 +709,14 @@ class BundleAdjuster:
             return BundleAdjustmentSummary()
         # WriteResultsToReconstruction: only variable blocks (bundle_adjustment_caspar.cc:767-801)
         rec = self.reconstruction_
-        for i, image_id in enumerate(fp.pose_ids):
-            if not fp.pose_const[i]:
-                rec.images[image_id].cam_from_world = fp.poses[i].copy()
+        for i, (kind, ident) in enumerate(fp.pose_ids):
+            if fp.pose_const[i]:
+                continue
+            if kind == "frame":
+                rec.frames[ident].rig_from_world = fp.poses[i].copy()
+            else:
+                rec.images[ident].cam_from_world = fp.poses[i].copy()
+        rec.UpdateCamFromWorld()
         for k, cid in enumerate(fp.cam_ids):
             n = len(rec.cameras[cid].params)
             if not fp.cam_const[k, :n].all():

@@ -1,10 +1,13 @@
 """Minimal scene containers + the synthetic dataset generator the reference's BA tests and
-benchmarks are built on (no COLMAP database / rigs-with-offsets / descriptors).
+benchmarks are built on (no COLMAP database / descriptors). Rigs: a frame holds rig_from_world,
+a rig holds one constant-or-variable sensor_from_rig per non-reference camera (scene/rig.h,
+scene/frame.h); an image without an explicit frame is its own trivial frame.
 
 Restates the semantics of scene/synthetic.cc (SynthesizeDataset :339-672, SynthesizeNoise
 :674-770): 3-D points = normalised uniform [-1,1]^3 vectors on the unit sphere (:370-377);
-frames on a radius-5 sphere looking at the origin (:458-464), one reference camera per frame
-(trivial sensor_from_rig); default camera SIMPLE_RADIAL {1280, 512, 384, 0.05}, 1024x768
+frames on a radius-5 sphere looking at the origin (:458-464), `num_cameras_per_rig` cameras per
+frame (the first is the reference sensor, the others get a random sensor_from_rig: rotation about
+z, Gaussian translation, :417-438); default camera SIMPLE_RADIAL {1280, 512, 384, 0.05}, 1024x768
 (synthetic.h:54-57); dense visibility or tracks pruned to `track_length` (:648-668); noise on
 2-D points, 3-D points, rig translation and rotation about the rig z axis (:686-728).
 Random streams are numpy's, not the reference's PRNG: the tests that consume this use
@@ -19,12 +22,12 @@ from typing import Dict, List, Optional, Tuple
 import numpy as np
 
 # colmap::CameraModelId (sensor/models.h:90-111)
-SIMPLE_PINHOLE, PINHOLE, SIMPLE_RADIAL = 0, 1, 2
-MODEL_NUM_PARAMS = {SIMPLE_PINHOLE: 3, PINHOLE: 4, SIMPLE_RADIAL: 4}
+SIMPLE_PINHOLE, PINHOLE, SIMPLE_RADIAL, RADIAL = 0, 1, 2, 3
+MODEL_NUM_PARAMS = {SIMPLE_PINHOLE: 3, PINHOLE: 4, SIMPLE_RADIAL: 4, RADIAL: 5}
 # FocalLengthIdxs / PrincipalPointIdxs / ExtraParamsIdxs (sensor/models.h)
-MODEL_FOCAL_IDXS = {SIMPLE_PINHOLE: [0], PINHOLE: [0, 1], SIMPLE_RADIAL: [0]}
-MODEL_PP_IDXS = {SIMPLE_PINHOLE: [1, 2], PINHOLE: [2, 3], SIMPLE_RADIAL: [1, 2]}
-MODEL_EXTRA_IDXS = {SIMPLE_PINHOLE: [], PINHOLE: [], SIMPLE_RADIAL: [3]}
+MODEL_FOCAL_IDXS = {SIMPLE_PINHOLE: [0], PINHOLE: [0, 1], SIMPLE_RADIAL: [0], RADIAL: [0]}
+MODEL_PP_IDXS = {SIMPLE_PINHOLE: [1, 2], PINHOLE: [2, 3], SIMPLE_RADIAL: [1, 2], RADIAL: [1, 2]}
+MODEL_EXTRA_IDXS = {SIMPLE_PINHOLE: [], PINHOLE: [], SIMPLE_RADIAL: [3], RADIAL: [3, 4]}
 
 
 @dataclass
@@ -47,15 +50,45 @@ class Point2D:
 
 @dataclass
 class Image:
-    """One image = one frame with a trivial rig (the image's camera is the reference sensor)."""
+    """scene/image.h. Without `frame_id_` the image is its own frame with a trivial rig (its
+    camera is the reference sensor) and `cam_from_world` is the pose block; with it, the pose
+    block is the frame's rig_from_world and `cam_from_world` is the derived composition."""
     image_id: int
     camera_id: int
     cam_from_world: np.ndarray  # 7 doubles: qx qy qz qw tx ty tz (Rigid3d::params, geometry/rigid3.h:46-70)
     points2D: List[Point2D] = field(default_factory=list)
+    frame_id_: Optional[int] = None
 
     @property
     def frame_id(self) -> int:
-        return self.image_id
+        return self.image_id if self.frame_id_ is None else self.frame_id_
+
+
+@dataclass
+class Rig:
+    """scene/rig.h: one reference sensor, sensor_from_rig (7 doubles) for every other camera."""
+    rig_id: int
+    ref_camera_id: int
+    sensors: Dict[int, np.ndarray] = field(default_factory=dict)  # camera_id -> sensor_from_rig
+
+    def IsRefSensor(self, camera_id: int) -> bool:
+        return camera_id == self.ref_camera_id
+
+
+@dataclass
+class Frame:
+    """scene/frame.h: rig_from_world shared by the images taken by the rig at one instant."""
+    frame_id: int
+    rig_id: int
+    rig_from_world: np.ndarray
+    image_ids: List[int] = field(default_factory=list)
+
+
+def rigid_compose(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """Rigid3d a * b (apply b, then a), params = quaternion xyzw + translation."""
+    q = quat_mul(a[:4], b[:4])
+    t = quat_to_rot(a[:4]) @ b[4:] + a[4:]
+    return np.concatenate([q, t])
 
 
 @dataclass
@@ -69,6 +102,33 @@ class Reconstruction:
         self.cameras: Dict[int, Camera] = {}
         self.images: Dict[int, Image] = {}
         self.points3D: Dict[int, Point3D] = {}
+        self.rigs: Dict[int, Rig] = {}      # only non-trivial rigs
+        self.frames: Dict[int, Frame] = {}  # only frames of non-trivial rigs
+
+    def HasNonTrivialFrame(self, image_id: int) -> bool:
+        return self.images[image_id].frame_id_ is not None
+
+    def IsRefInFrame(self, image_id: int) -> bool:
+        img = self.images[image_id]
+        if img.frame_id_ is None:
+            return True
+        return self.rigs[self.frames[img.frame_id_].rig_id].IsRefSensor(img.camera_id)
+
+    def SensorFromRig(self, image_id: int) -> np.ndarray:
+        img = self.images[image_id]
+        return self.rigs[self.frames[img.frame_id_].rig_id].sensors[img.camera_id]
+
+    def UpdateCamFromWorld(self):
+        """cam_from_world of the images of non-trivial frames from rig_from_world (and
+        sensor_from_rig): Image::CamFromWorld, scene/image.h."""
+        for fr in self.frames.values():
+            rig = self.rigs[fr.rig_id]
+            for im in fr.image_ids:
+                img = self.images[im]
+                if rig.IsRefSensor(img.camera_id):
+                    img.cam_from_world = fr.rig_from_world.copy()
+                else:
+                    img.cam_from_world = rigid_compose(rig.sensors[img.camera_id], fr.rig_from_world)
 
     def RegImageIds(self) -> List[int]:
         return sorted(self.images)
@@ -137,6 +197,11 @@ def img_from_cam(model_id: int, params: np.ndarray, uvw: np.ndarray) -> np.ndarr
     if model_id == PINHOLE:
         f1, f2, c1, c2 = params
         return np.stack([f1 * uu + c1, f2 * vv + c2], 1)
+    if model_id == RADIAL:
+        f, c1, c2, k1, k2 = params
+        r2 = uu * uu + vv * vv
+        a = 1 + k1 * r2 + k2 * r2 * r2
+        return np.stack([f * a * uu + c1, f * a * vv + c2], 1)
     f, c1, c2, k = params
     a = 1 + k * (uu * uu + vv * vv)
     return np.stack([f * a * uu + c1, f * a * vv + c2], 1)
@@ -154,6 +219,8 @@ class SyntheticDatasetOptions:
     camera_model_id: int = SIMPLE_RADIAL
     camera_params: Tuple[float, ...] = (1280.0, 512.0, 384.0, 0.05)
     num_points2D_without_point3D: int = 10
+    sensor_from_rig_translation_stddev: float = 0.05
+    sensor_from_rig_rotation_stddev: float = 5.0  # degrees, about the z axis
     # extension: alternate camera models per rig (BASELINE config 5 "mixed camera models")
     mixed_models: bool = False
 
@@ -167,7 +234,6 @@ class SyntheticNoiseOptions:
 
 
 def SynthesizeDataset(options: SyntheticDatasetOptions, seed: int = 0) -> Reconstruction:
-    assert options.num_cameras_per_rig == 1, "non-trivial rigs are not part of this round's scope"
     assert options.track_length == -1 or options.track_length >= 2
     rng = np.random.default_rng(seed)
     rec = Reconstruction()
@@ -176,36 +242,68 @@ def SynthesizeDataset(options: SyntheticDatasetOptions, seed: int = 0) -> Recons
     for i in range(options.num_points3D):
         rec.points3D[i + 1] = Point3D(pts[i].copy())
     image_id = 0
+    frame_id = 0
+    ncam = options.num_cameras_per_rig
     for rig_idx in range(options.num_rigs):
-        cam_id = rig_idx + 1
-        model, params = options.camera_model_id, np.array(options.camera_params, np.float64)
-        if options.mixed_models and rig_idx % 2 == 1:
-            model = PINHOLE
-            params = np.array([options.camera_params[0], options.camera_params[0],
-                               options.camera_params[1], options.camera_params[2]], np.float64)
-        rec.cameras[cam_id] = Camera(cam_id, model, options.camera_width, options.camera_height, params)
+        rig = None
+        cam_ids = []
+        for camera_idx in range(ncam):
+            cam_id = rig_idx * ncam + camera_idx + 1
+            model, params = options.camera_model_id, np.array(options.camera_params, np.float64)
+            if options.mixed_models and rig_idx % 2 == 1:
+                model = PINHOLE
+                params = np.array([options.camera_params[0], options.camera_params[0],
+                                   options.camera_params[1], options.camera_params[2]], np.float64)
+            rec.cameras[cam_id] = Camera(cam_id, model, options.camera_width, options.camera_height, params)
+            cam_ids.append(cam_id)
+            if ncam > 1:
+                if rig is None:
+                    rig = Rig(rig_idx + 1, cam_id)
+                else:
+                    sfr = np.array([0.0, 0, 0, 1, 0, 0, 0])
+                    if options.sensor_from_rig_rotation_stddev > 0:
+                        ang = np.deg2rad(np.clip(rng.normal(0, options.sensor_from_rig_rotation_stddev), -180, 180))
+                        sfr[:4] = [0, 0, np.sin(ang / 2), np.cos(ang / 2)]
+                    if options.sensor_from_rig_translation_stddev > 0:
+                        sfr[4:] = rng.normal(0, options.sensor_from_rig_translation_stddev, 3)
+                    rig.sensors[cam_id] = sfr
+        if rig is not None:
+            rec.rigs[rig.rig_id] = rig
         for _ in range(options.num_frames_per_rig):
-            image_id += 1
             v = rng.uniform(-1, 1, 3)
             view_dir = -v / np.linalg.norm(v)
             proj_center = -5.0 * view_dir
             q = quat_from_two_vectors(view_dir, np.array([0.0, 0.0, 1.0]))
             t = quat_to_rot(q) @ (-proj_center)
-            img = Image(image_id, cam_id, np.concatenate([q, t]))
-            uvw = pts @ quat_to_rot(q).T + t
-            xy = img_from_cam(model, params, uvw)
-            vis = (xy[:, 0] >= 0) & (xy[:, 1] >= 0) & (xy[:, 0] <= options.camera_width) & \
-                  (xy[:, 1] <= options.camera_height)
-            p2 = [Point2D(xy[i].copy(), i + 1) for i in np.nonzero(vis)[0]]
-            for _ in range(options.num_points2D_without_point3D):
-                p2.append(Point2D(np.array([rng.uniform(0, options.camera_width),
-                                            rng.uniform(0, options.camera_height)])))
-            order = rng.permutation(len(p2))
-            img.points2D = [p2[i] for i in order]
-            for idx, p in enumerate(img.points2D):
-                if p.HasPoint3D():
-                    rec.points3D[p.point3D_id].track.append((image_id, idx))
-            rec.images[image_id] = img
+            rig_from_world = np.concatenate([q, t])
+            frame = None
+            if rig is not None:
+                frame_id += 1
+                frame = Frame(frame_id, rig.rig_id, rig_from_world.copy())
+                rec.frames[frame_id] = frame
+            for cam_id in cam_ids:
+                image_id += 1
+                cam = rec.cameras[cam_id]
+                cfw = rig_from_world
+                if rig is not None and not rig.IsRefSensor(cam_id):
+                    cfw = rigid_compose(rig.sensors[cam_id], rig_from_world)
+                img = Image(image_id, cam_id, cfw.copy(), frame_id_=frame.frame_id if frame else None)
+                if frame is not None:
+                    frame.image_ids.append(image_id)
+                uvw = pts @ quat_to_rot(cfw[:4]).T + cfw[4:]
+                xy = img_from_cam(cam.model_id, cam.params, uvw)
+                vis = (uvw[:, 2] > 0) & (xy[:, 0] >= 0) & (xy[:, 1] >= 0) & (xy[:, 0] <= options.camera_width) & \
+                      (xy[:, 1] <= options.camera_height)
+                p2 = [Point2D(xy[i].copy(), i + 1) for i in np.nonzero(vis)[0]]
+                for _ in range(options.num_points2D_without_point3D):
+                    p2.append(Point2D(np.array([rng.uniform(0, options.camera_width),
+                                                rng.uniform(0, options.camera_height)])))
+                order = rng.permutation(len(p2))
+                img.points2D = [p2[i] for i in order]
+                for idx, p in enumerate(img.points2D):
+                    if p.HasPoint3D():
+                        rec.points3D[p.point3D_id].track.append((image_id, idx))
+                rec.images[image_id] = img
     if options.track_length > 0:
         for pid in list(rec.points3D):
             tr = rec.points3D[pid].track
@@ -222,8 +320,19 @@ def SynthesizeDataset(options: SyntheticDatasetOptions, seed: int = 0) -> Recons
 
 def SynthesizeNoise(options: SyntheticNoiseOptions, rec: Reconstruction, seed: int = 1):
     rng = np.random.default_rng(seed)
+    for fid in sorted(rec.frames):
+        fr = rec.frames[fid]
+        if options.rig_from_world_rotation_stddev > 0:
+            ang = np.deg2rad(np.clip(rng.normal(0, options.rig_from_world_rotation_stddev), -180, 180))
+            dq = np.array([0, 0, np.sin(ang / 2), np.cos(ang / 2)])
+            fr.rig_from_world[:4] = quat_mul(fr.rig_from_world[:4], dq)
+        if options.rig_from_world_translation_stddev > 0:
+            fr.rig_from_world[4:] += rng.normal(0, options.rig_from_world_translation_stddev, 3)
+    rec.UpdateCamFromWorld()
     for image_id in rec.RegImageIds():
         img = rec.images[image_id]
+        if img.frame_id_ is not None:
+            continue
         if options.rig_from_world_rotation_stddev > 0:
             ang = np.deg2rad(np.clip(rng.normal(0, options.rig_from_world_rotation_stddev), -180, 180))
             dq = np.array([0, 0, np.sin(ang / 2), np.cos(ang / 2)])

@@ -28,7 +28,7 @@ extern "C" {
 #define BA_CAM_STRIDE 12 /* doubles reserved per camera parameter block */
 
 /* colmap::CameraModelId values of the supported models (sensor/models.h:90-111) */
-enum { BA_SIMPLE_PINHOLE = 0, BA_PINHOLE = 1, BA_SIMPLE_RADIAL = 2 };
+enum { BA_SIMPLE_PINHOLE = 0, BA_PINHOLE = 1, BA_SIMPLE_RADIAL = 2, BA_RADIAL = 3 };
 
 typedef struct ba_problem {
   int32_t num_poses, num_cams, num_points;
@@ -47,6 +47,14 @@ typedef struct ba_problem {
                             (SubsetManifold, bundle_adjustment_ceres.cc:402-415) */
   uint8_t* cam_const;    /* [num_cams][BA_CAM_STRIDE] per-parameter mask (SubsetManifold, :419-469) */
   uint8_t* point_const;  /* [num_points] */
+  /* Rigs with a constant sensor_from_rig (AddImageWithNonTrivialFrame, bundle_adjustment_ceres.cc:
+   * 752-822; RigReprojErrorConstantRigCostFunctor, cost_functions/reprojection_error.h:386-417): the
+   * pose block of such an observation is the frame's rig_from_world and the camera sees
+   * sensor_from_rig * rig_from_world * X. Variable sensor_from_rig is rejected by the adapter, as
+   * CasparBundleAdjuster does (bundle_adjustment_caspar.cc:186-209). */
+  int32_t num_sensors;
+  double* sensors;       /* [num_sensors][7] constant Rigid3d::params, or NULL */
+  int32_t* obs_sensor;   /* [num_obs] index into sensors, -1 = trivial frame; NULL = all trivial */
 } ba_problem;
 
 /* ceres::Solver::Options fields that reach the solve (COLMAP's values:
@@ -68,7 +76,14 @@ typedef struct ba_options {
   int32_t jacobi_scaling;               /* 1 */
   int32_t num_threads;                  /* unused on the GPU */
   int32_t max_log;                      /* capacity of the log arrays in ba_result */
+  /* CeresBundleAdjustmentOptions::loss_function_type / _scale (bundle_adjustment_ceres.h:42-51),
+   * applied to every reprojection residual like CreateLossFunction (bundle_adjustment_ceres.cc:66-80) */
+  int32_t loss_type;                    /* BA_LOSS_TRIVIAL */
+  double loss_scale;                    /* 1.0 */
 } ba_options;
+
+/* CeresBundleAdjustmentOptions::LossFunctionType */
+enum { BA_LOSS_TRIVIAL = 0, BA_LOSS_SOFT_L1 = 1, BA_LOSS_CAUCHY = 2, BA_LOSS_HUBER = 3 };
 
 /* colmap::BundleAdjustmentTerminationType (bundle_adjustment.h:50-57) */
 enum { BA_CONVERGENCE = 0, BA_NO_CONVERGENCE = 1, BA_FAILURE = 2 };

@@ -41,7 +41,7 @@
 #define BAO_CAM_STRIDE 12
 
 /* COLMAP CameraModelId values (sensor/models.h:90-111) */
-enum { BAO_SIMPLE_PINHOLE = 0, BAO_PINHOLE = 1, BAO_SIMPLE_RADIAL = 2 };
+enum { BAO_SIMPLE_PINHOLE = 0, BAO_PINHOLE = 1, BAO_SIMPLE_RADIAL = 2, BAO_RADIAL = 3 };
 
 typedef struct {
   int32_t num_poses, num_cams, num_points;
@@ -58,6 +58,12 @@ typedef struct {
   int8_t* pose_fixed_t;   /* [num_poses] -1 or translation coordinate held by the gauge */
   uint8_t* cam_const;     /* [num_cams][12] per-parameter constant mask (SubsetManifold) */
   uint8_t* point_const;   /* [num_points] */
+  /* rigs with constant sensor_from_rig (RigReprojErrorConstantRigCostFunctor,
+   * reprojection_error.h:386-417): the pose block of an observation is the frame's
+   * rig_from_world, the camera sees sensor_from_rig * rig_from_world * X */
+  int32_t num_sensors;
+  double* sensors;        /* [num_sensors][7] or NULL */
+  int32_t* obs_sensor;    /* [num_obs] index into sensors, -1: trivial (NULL: all trivial) */
 } bao_problem;
 
 typedef struct {
@@ -70,7 +76,13 @@ typedef struct {
   int32_t jacobi_scaling;
   int32_t num_threads;
   int32_t max_log; /* capacity of the per-iteration log arrays in bao_result */
+  /* CeresBundleAdjustmentOptions::LossFunctionType + scale (bundle_adjustment_ceres.h:42-51,
+   * CreateLossFunction bundle_adjustment_ceres.cc:66-80) */
+  int32_t loss_type;
+  double loss_scale;
 } bao_options;
+
+enum { BAO_LOSS_TRIVIAL = 0, BAO_LOSS_SOFT_L1 = 1, BAO_LOSS_CAUCHY = 2, BAO_LOSS_HUBER = 3 };
 
 /* BundleAdjustmentTerminationType (estimators/bundle_adjustment.h:50-57) */
 enum { BAO_CONVERGENCE = 0, BAO_NO_CONVERGENCE = 1, BAO_FAILURE = 2 };
@@ -144,6 +156,7 @@ static int num_params_of(int model) {
     case BAO_SIMPLE_PINHOLE: return 3;
     case BAO_PINHOLE: return 4;
     case BAO_SIMPLE_RADIAL: return 4;
+    case BAO_RADIAL: return 5;
     default: return -1;
   }
 }
@@ -181,6 +194,31 @@ static int img_from_cam_jac(int model, const double* params, double u, double v,
     if (J_params) {
       J_params[0] = uu; J_params[1] = 0.0; J_params[2] = 1.0; J_params[3] = 0.0;
       J_params[4] = 0.0; J_params[5] = vv; J_params[6] = 0.0; J_params[7] = 1.0;
+    }
+    return 1;
+  }
+  if (model == BAO_RADIAL) { /* models_jacobian.h:323-398 */
+    const double f = params[0], c1 = params[1], c2 = params[2], k1 = params[3], k2 = params[4];
+    const double uu2 = uu * uu, vv2 = vv * vv;
+    const double r2 = uu2 + vv2;
+    const double r4 = r2 * r2;
+    const double radial = k1 * r2 + k2 * r4;
+    const double xd = uu * (1.0 + radial), yd = vv * (1.0 + radial);
+    *x = f * xd + c1;
+    *y = f * yd + c2;
+    if (J_uvw) {
+      const double d_radial_d_r2 = k1 + 2.0 * k2 * r2;
+      const double cross = 2.0 * uu * vv * d_radial_d_r2;
+      const double a00 = f * (1.0 + radial + 2.0 * uu2 * d_radial_d_r2);
+      const double a01 = f * cross;
+      const double a10 = f * cross;
+      const double a11 = f * (1.0 + radial + 2.0 * vv2 * d_radial_d_r2);
+      J_uvw[0] = a00 * inv_w; J_uvw[1] = a01 * inv_w; J_uvw[2] = -(a00 * uu + a01 * vv) * inv_w;
+      J_uvw[3] = a10 * inv_w; J_uvw[4] = a11 * inv_w; J_uvw[5] = -(a10 * uu + a11 * vv) * inv_w;
+    }
+    if (J_params) {
+      J_params[0] = xd; J_params[1] = 1.0; J_params[2] = 0.0; J_params[3] = f * uu * r2; J_params[4] = f * uu * r4;
+      J_params[5] = yd; J_params[6] = 0.0; J_params[7] = 1.0; J_params[8] = f * vv * r2; J_params[9] = f * vv * r4;
     }
     return 1;
   }
@@ -251,6 +289,104 @@ BAO_API int bao_reproj_error(int model, const double* point, const double* pose,
   return 1;
 }
 
+/* RigReprojErrorConstantRigCostFunctor (reprojection_error.h:344-417): the same residual seen
+ * through a constant sensor_from_rig: p_cam = R_s (R_r X + t_r) + t_s. The reference differentiates
+ * it automatically; the chain rule gives J_point = J_uvw R_s R_r, J_pose = J_uvw R_s [dR_rX/dq | I]. */
+BAO_API int bao_rig_reproj_error(int model, const double* point, const double* rig_from_world,
+                                 const double* sensor_from_rig, const double* params, const double* xy,
+                                 double* residuals, double* J_point, double* J_pose, double* J_params) {
+  double J_Rp_quat[12], J_uvw[6], pr[3], pc[3], Rs[9];
+  const int P = num_params_of(model);
+  quat_rotate_jac(rig_from_world, point, pr, J_pose ? J_Rp_quat : NULL);
+  pr[0] += rig_from_world[4]; pr[1] += rig_from_world[5]; pr[2] += rig_from_world[6];
+  quat_to_rot(sensor_from_rig, Rs);
+  for (int r = 0; r < 3; ++r)
+    pc[r] = Rs[3 * r] * pr[0] + Rs[3 * r + 1] * pr[1] + Rs[3 * r + 2] * pr[2] + sensor_from_rig[4 + r];
+  if (!img_from_cam_jac(model, params, pc[0], pc[1], pc[2], &residuals[0], &residuals[1],
+                        J_params, (J_point || J_pose) ? J_uvw : NULL)) {
+    residuals[0] = residuals[1] = 0.0;
+    if (J_pose) memset(J_pose, 0, sizeof(double) * 14);
+    if (J_point) memset(J_point, 0, sizeof(double) * 6);
+    if (J_params) memset(J_params, 0, sizeof(double) * 2 * P);
+    return 1;
+  }
+  residuals[0] -= xy[0];
+  residuals[1] -= xy[1];
+  if (J_point || J_pose) {
+    double Jr[6]; /* J_uvw * R_s: derivative w.r.t. the point in the rig frame */
+    for (int r = 0; r < 2; ++r)
+      for (int c = 0; c < 3; ++c)
+        Jr[3 * r + c] = J_uvw[3 * r] * Rs[c] + J_uvw[3 * r + 1] * Rs[3 + c] + J_uvw[3 * r + 2] * Rs[6 + c];
+    if (J_point) {
+      double R[9];
+      quat_to_rot(rig_from_world, R);
+      for (int r = 0; r < 2; ++r)
+        for (int c = 0; c < 3; ++c)
+          J_point[3 * r + c] = Jr[3 * r] * R[c] + Jr[3 * r + 1] * R[3 + c] + Jr[3 * r + 2] * R[6 + c];
+    }
+    if (J_pose) {
+      for (int r = 0; r < 2; ++r) {
+        for (int c = 0; c < 4; ++c)
+          J_pose[7 * r + c] = Jr[3 * r] * J_Rp_quat[c] + Jr[3 * r + 1] * J_Rp_quat[4 + c] +
+                              Jr[3 * r + 2] * J_Rp_quat[8 + c];
+        for (int c = 0; c < 3; ++c) J_pose[7 * r + 4 + c] = Jr[3 * r + c];
+      }
+    }
+  }
+  return 1;
+}
+
+/* ceres::LossFunction::Evaluate for the four losses COLMAP can select
+ * (bundle_adjustment_ceres.cc:66-80). Ceres is not vendored in the reference tree; restated from
+ * its published loss_function.cc: rho[0] = rho(s), rho[1] = rho'(s), rho[2] = rho''(s), s = |r|^2. */
+BAO_API void bao_loss(int type, double a, double s, double rho[3]) {
+  const double kMin = 2.2250738585072014e-308; /* std::numeric_limits<double>::min() */
+  if (type == BAO_LOSS_HUBER) {
+    const double b = a * a;
+    if (s > b) {
+      const double r = sqrt(s);
+      rho[0] = 2.0 * a * r - b;
+      rho[1] = fmax(kMin, a / r);
+      rho[2] = -rho[1] / (2.0 * s);
+    } else {
+      rho[0] = s; rho[1] = 1.0; rho[2] = 0.0;
+    }
+  } else if (type == BAO_LOSS_SOFT_L1) {
+    const double b = a * a, c = 1.0 / b;
+    const double sum = 1.0 + s * c;
+    const double tmp = sqrt(sum);
+    rho[0] = 2.0 * b * (tmp - 1.0);
+    rho[1] = fmax(kMin, 1.0 / tmp);
+    rho[2] = -(c * rho[1]) / (2.0 * sum);
+  } else if (type == BAO_LOSS_CAUCHY) {
+    const double b = a * a, c = 1.0 / b;
+    const double sum = 1.0 + s * c;
+    const double inv = 1.0 / sum;
+    rho[0] = b * log(sum);
+    rho[1] = fmax(kMin, inv);
+    rho[2] = -c * (inv * inv);
+  } else {
+    rho[0] = s; rho[1] = 1.0; rho[2] = 0.0;
+  }
+}
+
+/* ceres::internal::Corrector (corrector.cc): rescales the residual and its Jacobian so that the
+ * Gauss-Newton model of 1/2 |r'|^2 matches the second-order model of 1/2 rho(|r|^2) (Triggs).
+ * Returns the factors: r' = residual_scaling * r,  J' = sqrt_rho1 * (J - alpha_sq_norm * r r^T J). */
+static void corrector(double sq_norm, const double rho[3], double* sqrt_rho1, double* residual_scaling,
+                      double* alpha_sq_norm) {
+  *sqrt_rho1 = sqrt(rho[1]);
+  if (sq_norm == 0.0 || rho[2] <= 0.0) {
+    *residual_scaling = *sqrt_rho1;
+    *alpha_sq_norm = 0.0;
+    return;
+  }
+  const double D = 1.0 + 2.0 * sq_norm * rho[2] / rho[1];
+  const double alpha = 1.0 - sqrt(D);
+  *residual_scaling = *sqrt_rho1 / (1.0 - alpha);
+  *alpha_sq_norm = alpha / sq_norm;
+}
+
 /* ceres::EigenQuaternionManifold (xyzw storage): x_plus = [sin|d|/|d| d, cos|d|] (*) x ;
  * PlusJacobian at d = 0 (4x3 row-major) = [[w, z,-y],[-z, w, x],[y,-x, w],[-x,-y,-z]]. */
 BAO_API void bao_quat_plus(const double* q, const double* d, double* out) {
@@ -278,10 +414,12 @@ static void quat_plus_jac(const double* q, double J[12]) {
 /* Program: tangent-space layout of the variable blocks                        */
 /* ------------------------------------------------------------------------- */
 
-#define MAX_CB 8 /* max tangent width of a camera-side block seen by one residual: 6 + P_t */
+#define MAX_CB 12 /* max tangent width of the camera-side blocks seen by one residual: 6 + P_t */
 
 typedef struct {
   const bao_problem* p;
+  int loss_type;       /* robust loss applied to every residual block */
+  double loss_scale;
   int64_t n_obs;       /* active observations */
   int64_t* obs;        /* indices into the problem's observation arrays */
   int* pose_off;       /* [num_poses] offset into the camera-side vector, -1 const */
@@ -409,7 +547,8 @@ static void program_build(program* g, const bao_problem* p) {
 
 /* per-active-observation linearisation in the tangent space */
 typedef struct {
-  double r[2];
+  double r[2];          /* residual (loss-corrected when the Jacobian was requested) */
+  double cost;          /* 1/2 rho(|r|^2) of the uncorrected residual */
   double Jc[2][MAX_CB]; /* pose tangent columns then intrinsics tangent columns */
   double Jp[2][3];
   int pose_dim, cam_dim; /* widths inside Jc */
@@ -422,12 +561,41 @@ static void linearize_obs(const program* g, const double* poses, const double* c
   const int pi = p->obs_pose[o], ci = p->obs_cam[o], xi = p->obs_point[o];
   const int model = p->cam_model[ci];
   double Jpt[6], Jpose[14], Jpar[24];
-  bao_reproj_error(model, points + 3 * (size_t)xi, poses + 7 * (size_t)pi,
-                   cams + (size_t)ci * BAO_CAM_STRIDE, p->obs_xy + 2 * o, L->r,
-                   want_jac ? Jpt : NULL, want_jac ? Jpose : NULL, want_jac ? Jpar : NULL);
+  const int si = p->obs_sensor ? p->obs_sensor[o] : -1;
+  if (si >= 0)
+    bao_rig_reproj_error(model, points + 3 * (size_t)xi, poses + 7 * (size_t)pi, p->sensors + 7 * (size_t)si,
+                         cams + (size_t)ci * BAO_CAM_STRIDE, p->obs_xy + 2 * o, L->r,
+                         want_jac ? Jpt : NULL, want_jac ? Jpose : NULL, want_jac ? Jpar : NULL);
+  else
+    bao_reproj_error(model, points + 3 * (size_t)xi, poses + 7 * (size_t)pi,
+                     cams + (size_t)ci * BAO_CAM_STRIDE, p->obs_xy + 2 * o, L->r,
+                     want_jac ? Jpt : NULL, want_jac ? Jpose : NULL, want_jac ? Jpar : NULL);
   L->pose_dim = g->pose_dim[pi];
   L->cam_dim = g->cam_dim[ci];
+  /* robust loss: cost 1/2 rho(s); Corrector factors for the residual block */
+  const double sq_norm = L->r[0] * L->r[0] + L->r[1] * L->r[1];
+  double rho[3], sqrt_rho1 = 1.0, residual_scaling = 1.0, alpha_sq_norm = 0.0;
+  bao_loss(g->loss_type, g->loss_scale, sq_norm, rho);
+  L->cost = 0.5 * rho[0];
   if (!want_jac) return;
+  if (g->loss_type != BAO_LOSS_TRIVIAL) {
+    corrector(sq_norm, rho, &sqrt_rho1, &residual_scaling, &alpha_sq_norm);
+    /* CorrectJacobian on the ambient Jacobians of every block, then CorrectResiduals */
+    const double r0 = L->r[0], r1 = L->r[1];
+#define BAO_CORRECT(J, stride, n)                                               \
+    for (int c_ = 0; c_ < (n); ++c_) {                                          \
+      const double j0 = (J)[c_], j1 = (J)[(stride) + c_];                        \
+      const double rtj = r0 * j0 + r1 * j1;                                      \
+      (J)[c_] = sqrt_rho1 * (j0 - alpha_sq_norm * r0 * rtj);                     \
+      (J)[(stride) + c_] = sqrt_rho1 * (j1 - alpha_sq_norm * r1 * rtj);          \
+    }
+    BAO_CORRECT(Jpt, 3, 3)
+    BAO_CORRECT(Jpose, 7, 7)
+    { const int P_ = num_params_of(model); BAO_CORRECT(Jpar, P_, P_) }
+#undef BAO_CORRECT
+    L->r[0] *= residual_scaling;
+    L->r[1] *= residual_scaling;
+  }
   memset(L->Jc, 0, sizeof(L->Jc));
   memset(L->Jp, 0, sizeof(L->Jp));
   if (L->pose_dim > 0) {
@@ -463,7 +631,7 @@ static double evaluate_cost(const program* g, const double* poses, const double*
   for (int64_t a = 0; a < g->n_obs; ++a) {
     lin_obs L;
     linearize_obs(g, poses, cams, points, a, &L, 0);
-    cost += 0.5 * (L.r[0] * L.r[0] + L.r[1] * L.r[1]);
+    cost += L.cost;
   }
   return cost;
 }
@@ -685,6 +853,8 @@ BAO_API void bao_options_init(bao_options* o) {
   o->jacobi_scaling = 1;
   o->num_threads = 0;
   o->max_log = 0;
+  o->loss_type = BAO_LOSS_TRIVIAL; /* bundle_adjustment_ceres.h:42-51 */
+  o->loss_scale = 1.0;
 }
 
 static double now_s(void) {
@@ -701,6 +871,8 @@ BAO_API int bao_solve(bao_problem* p, const bao_options* opt, bao_result* res) {
 #endif
   program g;
   program_build(&g, p);
+  g.loss_type = opt->loss_type;
+  g.loss_scale = opt->loss_scale;
   memset(res, 0, offsetof(bao_result, log_cost));
   res->num_residuals = (int32_t)(2 * g.n_obs);
   res->num_effective_parameters = g.n_c + g.n_p;
@@ -759,7 +931,7 @@ BAO_API int bao_solve(bao_problem* p, const bao_options* opt, bao_result* res) {
 #pragma omp parallel for reduction(+ : c) schedule(static) BAO_PAR(g.n_obs)
       for (int64_t a = 0; a < g.n_obs; ++a) {
         linearize_obs(&g, p->poses, p->cams, p->points, a, &s.L[a], 1);
-        c += 0.5 * (s.L[a].r[0] * s.L[a].r[0] + s.L[a].r[1] * s.L[a].r[1]);
+        c += s.L[a].cost;
       }
       cost = c;
       if (iter == 0) res->initial_cost = cost;

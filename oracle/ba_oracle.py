@@ -44,7 +44,7 @@ def reproj_error(model, point, pose, params, xy, want_jac=True):
     prm = np.zeros(12)
     prm[: len(params)] = params
     xy = np.ascontiguousarray(xy, np.float64)
-    P = {0: 3, 1: 4, 2: 4}[model]
+    P = NUM_PARAMS[model]
     r = np.zeros(2)
     Jpt, Jpose, Jpar = np.zeros((2, 3)), np.zeros((2, 7)), np.zeros((2, P))
     vp = lambda a: a.ctypes.data_as(C.c_void_p)
@@ -52,6 +52,35 @@ def reproj_error(model, point, pose, params, xy, want_jac=True):
                            vp(Jpt) if want_jac else None, vp(Jpose) if want_jac else None,
                            vp(Jpar) if want_jac else None)
     return r, Jpt, Jpose, Jpar
+
+
+NUM_PARAMS = {0: 3, 1: 4, 2: 4, 3: 5}
+
+
+def rig_reproj_error(model, point, rig_from_world, sensor_from_rig, params, xy, want_jac=True):
+    """RigReprojErrorConstantRigCostFunctor with analytic Jacobians (w.r.t. point, rig_from_world
+    and the intrinsics)."""
+    point = np.ascontiguousarray(point, np.float64)
+    pose = np.ascontiguousarray(rig_from_world, np.float64)
+    sens = np.ascontiguousarray(sensor_from_rig, np.float64)
+    prm = np.zeros(12)
+    prm[: len(params)] = params
+    xy = np.ascontiguousarray(xy, np.float64)
+    P = NUM_PARAMS[model]
+    r = np.zeros(2)
+    Jpt, Jpose, Jpar = np.zeros((2, 3)), np.zeros((2, 7)), np.zeros((2, P))
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    lib().bao_rig_reproj_error(C.c_int(model), vp(point), vp(pose), vp(sens), vp(prm), vp(xy), vp(r),
+                               vp(Jpt) if want_jac else None, vp(Jpose) if want_jac else None,
+                               vp(Jpar) if want_jac else None)
+    return r, Jpt, Jpose, Jpar
+
+
+def loss(loss_type, scale, s):
+    """ceres::LossFunction::Evaluate: (rho, rho', rho'') at s = |r|^2."""
+    rho = np.zeros(3)
+    lib().bao_loss(C.c_int(int(loss_type)), C.c_double(scale), C.c_double(s), rho.ctypes.data_as(C.c_void_p))
+    return rho
 
 
 def quat_plus(q, d):

@@ -307,3 +307,66 @@ def test_rccl_transport_world_size_one():
     finally:
         comm.close()
     assert s0.final_cost == s1.final_cost and np.array_equal(a.poses, b.poses) and np.array_equal(a.points, b.points)
+
+
+# ------------------------------------------------------------------------------------------------
+# robust losses, rigs with a constant sensor_from_rig, RADIAL
+# ------------------------------------------------------------------------------------------------
+
+def _adapter_problem(rec, gauge=est.BundleAdjustmentGauge.TWO_CAMS_FROM_WORLD, **opt_kw):
+    cfg = est.BundleAdjustmentConfig()
+    for i in rec.RegImageIds():
+        cfg.AddImage(i)
+    cfg.FixGauge(gauge)
+    return est.flatten(est.BundleAdjustmentOptions(**opt_kw), cfg, rec)
+
+
+@pytest.mark.parametrize("loss,scale", [(est.LossFunctionType.SOFT_L1, 1.0), (est.LossFunctionType.CAUCHY, 1.0),
+                                        (est.LossFunctionType.HUBER, 2.0)])
+def test_robust_losses_match_oracle(loss, scale):
+    """ceres::LossFunction + Corrector on every residual block (bundle_adjustment_ceres.cc:66-80):
+    same trajectory and optimum as the oracle, with 5 % gross outliers in the observations."""
+    fp = _flat(12, 300, 5, seed=3)
+    rng = np.random.default_rng(0)
+    bad = rng.random(len(fp.obs_xy)) < 0.05
+    fp.obs_xy[bad] += rng.normal(0, 60, (int(bad.sum()), 2))
+    assert est.fix_gauge_two_cams(fp)
+    (a, want), (b, got) = _both(fp, loss_type=int(loss), loss_scale=scale, **TIGHT)
+    assert want.IsSolutionUsable() and got.IsSolutionUsable()
+    _assert_close(a, want, b, got)
+    # and the loss is actually in effect: the robust cost is far below the squared cost
+    (_, l2), _ = _both(fp, max_num_iterations=1)
+    assert got.initial_cost < 0.5 * l2.initial_cost
+
+
+def test_rig_frames_match_oracle():
+    """Two rigs of three cameras, five frames each: a frame's pose block is observed through three
+    cameras (three c-order runs per block) and two of them through a constant sensor_from_rig."""
+    rec = scene.SynthesizeDataset(scene.SyntheticDatasetOptions(
+        num_rigs=2, num_cameras_per_rig=3, num_frames_per_rig=5, num_points3D=200,
+        num_points2D_without_point3D=0), seed=5)
+    scene.SynthesizeNoise(scene.SyntheticNoiseOptions(0.02, 0.5, 0.05, 0.5), rec, seed=6)
+    fp = _adapter_problem(rec, refine_sensor_from_rig=False)
+    assert fp.sensors is not None and len(fp.sensors) == 4 and len(fp.poses) == 10
+    (a, want), (b, got) = _both(fp, **TIGHT)
+    assert want.IsSolutionUsable() and got.IsSolutionUsable()
+    assert want.num_residuals == 2 * len(fp.obs_pose)
+    _assert_close(a, want, b, got)
+    assert got.final_cost < 0.2 * got.initial_cost
+    assert np.array_equal(b.sensors, fp.sensors)       # constant input
+
+
+def test_radial_model_matches_oracle():
+    rec = scene.SynthesizeDataset(scene.SyntheticDatasetOptions(
+        num_rigs=3, num_frames_per_rig=4, num_points3D=250, camera_model_id=scene.RADIAL,
+        camera_params=(1280.0, 512.0, 384.0, 0.05, -0.01)), seed=7)
+    scene.SynthesizeNoise(scene.SyntheticNoiseOptions(0.02, 0.5, 0.05, 0.5), rec, seed=8)
+    fp = _adapter_problem(rec)
+    assert (fp.cam_model == scene.RADIAL).all() and (fp.cam_const[:, :5] == [0, 1, 1, 0, 0]).all()
+    (a, want), (b, got) = _both(fp, **TIGHT)
+    assert want.IsSolutionUsable() and got.IsSolutionUsable()
+    _assert_close(a, want, b, got)
+    # five variable intrinsics exceed the solver's intrinsics block width: explicit error, no silent drop
+    fp5 = _adapter_problem(rec, refine_principal_point=True)
+    with pytest.raises(RuntimeError, match="variable intrinsics"):
+        est.solve_flat(fp5, est.SolverOptions(max_num_iterations=1), gpu_index=0)

@@ -252,3 +252,224 @@ def test_three_point_gauge_and_no_gauge_also_converge():
     # (noisy) points are 9 constraints on a 7-dimensional gauge, so that minimum is higher
     assert abs(costs[0] - costs[2]) <= 1e-9 * costs[2]
     assert costs[1] >= costs[2]
+
+
+# ------------------------------------------------------------------------------------------------
+# RADIAL model, rigs with a constant sensor_from_rig, robust losses
+# ------------------------------------------------------------------------------------------------
+
+def test_radial_model_values_and_jacobians():
+    # models_jacobian.h:323-398; forward model sensor/models.h (RadialCameraModel::ImgFromCam)
+    rng = np.random.default_rng(3)
+    params = [650.0, 320, 240, 0.08, -0.02]
+    pose = np.array([0, 0, 0, 1, 0, 0, 0.0])
+    for _ in range(20):
+        pt = np.array([rng.normal() * 0.6, rng.normal() * 0.6, 3 + rng.random()])
+        r0, Jpt, Jpose, Jpar = ba_oracle.reproj_error(scene.RADIAL, pt, pose, params, [0, 0])
+        np.testing.assert_allclose(r0, scene.img_from_cam(scene.RADIAL, np.array(params), pt[None])[0], rtol=1e-13)
+        def f(v):
+            return ba_oracle.reproj_error(scene.RADIAL, v[:3], pose, v[3:], [0, 0], want_jac=False)[0]
+        x0 = np.concatenate([pt, params])
+        J = np.zeros((2, len(x0)))
+        for i in range(len(x0)):
+            h = 1e-6 * max(1.0, abs(x0[i]))
+            e = np.zeros(len(x0)); e[i] = h
+            J[:, i] = (f(x0 + e) - f(x0 - e)) / (2 * h)
+        np.testing.assert_allclose(Jpt, J[:, :3], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(Jpar, J[:, 3:], rtol=1e-5, atol=1e-5)
+
+
+def test_rig_residual_equals_composed_pose_and_jacobians_are_exact():
+    # RigReprojErrorConstantRigCostFunctor (reprojection_error.h:386-417): same residual as the plain
+    # functor on cam_from_world = sensor_from_rig * rig_from_world; derivatives w.r.t. rig_from_world
+    rng = np.random.default_rng(4)
+    params = [700.0, 320, 240, 0.05]
+    for _ in range(20):
+        q = rng.normal(size=4); q /= np.linalg.norm(q)
+        rig = np.concatenate([q, rng.normal(size=3) * 0.3 + [0, 0, 4]])
+        ang = rng.normal() * 0.2
+        sens = np.array([0, 0, np.sin(ang / 2), np.cos(ang / 2), *(rng.normal(size=3) * 0.1)])
+        pt = rng.normal(size=3) * 0.5
+        xy = rng.normal(size=2) * 50
+        r, Jpt, Jpose, Jpar = ba_oracle.rig_reproj_error(scene.SIMPLE_RADIAL, pt, rig, sens, params, xy)
+        r2, *_ = ba_oracle.reproj_error(scene.SIMPLE_RADIAL, pt, scene.rigid_compose(sens, rig), params, xy,
+                                        want_jac=False)
+        np.testing.assert_allclose(r, r2, rtol=0, atol=1e-9)
+        def f(v):
+            return ba_oracle.rig_reproj_error(scene.SIMPLE_RADIAL, v[:3], v[3:10], sens, v[10:], xy, want_jac=False)[0]
+        x0 = np.concatenate([pt, rig, params])
+        J = np.zeros((2, len(x0)))
+        for i in range(len(x0)):
+            h = 1e-6 * max(1.0, abs(x0[i]))
+            e = np.zeros(len(x0)); e[i] = h
+            J[:, i] = (f(x0 + e) - f(x0 - e)) / (2 * h)
+        np.testing.assert_allclose(Jpt, J[:, :3], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(Jpose, J[:, 3:10], rtol=1e-5, atol=1e-4)
+        np.testing.assert_allclose(Jpar, J[:, 10:], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("loss,scale", [(est.LossFunctionType.SOFT_L1, 1.5), (est.LossFunctionType.CAUCHY, 2.0),
+                                        (est.LossFunctionType.HUBER, 1.2), (est.LossFunctionType.TRIVIAL, 1.0)])
+def test_loss_functions_closed_forms(loss, scale):
+    """ceres::SoftLOneLoss / CauchyLoss / HuberLoss / TrivialLoss: rho(s) in closed form, rho' and
+    rho'' by differentiation, rho(0) = 0, rho'(0) = 1 (Ceres' normalisation), rho'' <= 0."""
+    a = scale
+    closed = {
+        est.LossFunctionType.TRIVIAL: lambda s: s,
+        est.LossFunctionType.SOFT_L1: lambda s: 2 * a * a * (np.sqrt(1 + s / (a * a)) - 1),
+        est.LossFunctionType.CAUCHY: lambda s: a * a * np.log1p(s / (a * a)),
+        est.LossFunctionType.HUBER: lambda s: s if s <= a * a else 2 * a * np.sqrt(s) - a * a,
+    }[loss]
+    rho0 = ba_oracle.loss(loss, a, 0.0)
+    assert rho0[0] == 0.0 and rho0[1] == 1.0
+    for s in [1e-3, 0.3, 1.0, a * a * 0.999, a * a * 1.001, 7.0, 250.0]:
+        rho = ba_oracle.loss(loss, a, s)
+        assert abs(rho[0] - closed(s)) <= 1e-12 * max(1.0, closed(s))
+        h = 1e-5 * s
+        d1 = (closed(s + h) - closed(s - h)) / (2 * h)
+        assert abs(rho[1] - d1) <= 1e-6 * max(1.0, abs(d1))
+        assert rho[2] <= 0.0
+        if loss != est.LossFunctionType.HUBER or abs(s - a * a) > 0.01:
+            d2 = (ba_oracle.loss(loss, a, s + h)[1] - ba_oracle.loss(loss, a, s - h)[1]) / (2 * h)
+            assert abs(rho[2] - d2) <= 1e-5 * max(1e-3, abs(d2))
+
+
+def _rig_dataset(num_rigs, cams, frames, points, noise, seed=0):
+    rec = scene.SynthesizeDataset(scene.SyntheticDatasetOptions(
+        num_rigs=num_rigs, num_cameras_per_rig=cams, num_frames_per_rig=frames, num_points3D=points,
+        num_points2D_without_point3D=0), seed=seed)
+    gt = rec.copy()
+    scene.SynthesizeNoise(noise, rec, seed=seed + 1)
+    return gt, rec
+
+
+def test_two_view_rig_counts():
+    # bundle_adjustment_ceres_test.cc:323-376 (TwoViewRig) with the sensor_from_rig block held constant:
+    # 800 residuals; 97 x 3 points + 2 x 6 rig_from_world + 2 x 2 camera parameters = 307 (the
+    # reference's 313 minus the 6 sensor_from_rig parameters)
+    _, rec = _rig_dataset(1, 2, 2, 100, scene.SyntheticNoiseOptions(point2D_stddev=1))
+    opts = est.BundleAdjustmentOptions(refine_sensor_from_rig=False)
+    ba = est.BundleAdjuster(opts, _config(rec, est.BundleAdjustmentGauge.THREE_POINTS), rec,
+                            solve_fn=ba_oracle.solve_fn)
+    summary = ba.Solve()
+    assert summary.IsSolutionUsable()
+    assert summary.num_residuals == 800
+    assert summary.num_effective_parameters == 307
+    fp = ba.problem_
+    assert len(fp.poses) == 2 and fp.sensors.shape == (1, 7)          # two frames, one non-reference sensor
+    assert (fp.obs_sensor >= 0).sum() == 200 * 2 // 2                  # the observations of camera 2
+    # variable sensor_from_rig is rejected like CasparBundleAdjuster does (bundle_adjustment_caspar.cc:186-209)
+    with pytest.raises(NotImplementedError):
+        est.BundleAdjuster(est.BundleAdjustmentOptions(), _config(rec), rec, solve_fn=ba_oracle.solve_fn)
+    # ... unless the config holds that sensor constant (ManyViewRigConstantSensorFromRig, :434-489)
+    cfg = _config(rec, est.BundleAdjustmentGauge.THREE_POINTS)
+    cfg.SetConstantSensorFromRigPose(2)
+    est.BundleAdjuster(est.BundleAdjustmentOptions(), cfg, rec, solve_fn=ba_oracle.solve_fn)
+
+
+def test_many_view_rig_recovers_ground_truth():
+    # bundle_adjustment_ceres_test.cc:183-220 (NominalMultiCameraRig), constant sensor_from_rig
+    gt, rec = _rig_dataset(2, 3, 5, 100, scene.SyntheticNoiseOptions(
+        point2D_stddev=0.3, point3D_stddev=0.05, rig_from_world_translation_stddev=0.02,
+        rig_from_world_rotation_stddev=0.5))
+    # the gauge frames keep their (noisy) poses: restore the first two frames to ground truth
+    for fid in (1, 2):
+        rec.frames[fid].rig_from_world = gt.frames[fid].rig_from_world.copy()
+    rec.UpdateCamFromWorld()
+    opts = est.BundleAdjustmentOptions(refine_sensor_from_rig=False)
+    ba = est.BundleAdjuster(opts, _config(rec), rec, solve_fn=ba_oracle.solve_fn)
+    summary = ba.Solve()
+    assert summary.IsSolutionUsable()
+    assert summary.num_residuals == 2 * sum(len(p.track) for p in rec.points3D.values())
+    # 10 frames: one constant, one with a fixed translation coordinate
+    fp = ba.problem_
+    assert len(fp.poses) == 10 and fp.pose_const.sum() == 1 and (fp.pose_fixed_t >= 0).sum() == 1
+    assert summary.final_cost < 0.2 * summary.initial_cost
+    _recon_near(gt, rec, 0.1, 0.05)
+    # every image of a frame moved rigidly with its frame
+    for fr in rec.frames.values():
+        for im in fr.image_ids:
+            img = rec.images[im]
+            if not rec.IsRefInFrame(im):
+                want = scene.rigid_compose(rec.SensorFromRig(im), fr.rig_from_world)
+                np.testing.assert_allclose(img.cam_from_world, want, atol=1e-15)
+
+
+def test_constant_frame_of_a_rig_uses_composed_constant_poses():
+    # ManyViewRigConstantRigFromWorld (:491-553): frame 1 constant -> its three images enter with
+    # ReprojErrorConstantPoseCostFunctor on sensor_from_rig * rig_from_world (:769-772,797-803)
+    _, rec = _rig_dataset(2, 3, 5, 60, scene.SyntheticNoiseOptions(point2D_stddev=1))
+    orig = rec.copy()
+    cfg = _config(rec, est.BundleAdjustmentGauge.THREE_POINTS)
+    cfg.SetConstantRigFromWorldPose(1)
+    opts = est.BundleAdjustmentOptions(refine_sensor_from_rig=False)
+    ba = est.BundleAdjuster(opts, cfg, rec, solve_fn=ba_oracle.solve_fn)
+    fp = ba.problem_
+    # 9 variable frame blocks + 3 constant blocks (frame 1: rig pose for the reference image, two compositions)
+    assert len(fp.poses) == 12 and fp.pose_const.sum() == 3
+    summary = ba.Solve()
+    assert summary.IsSolutionUsable()
+    assert np.array_equal(rec.frames[1].rig_from_world, orig.frames[1].rig_from_world)
+    for im in orig.frames[1].image_ids:
+        assert np.array_equal(rec.images[im].cam_from_world, orig.images[im].cam_from_world)
+    assert not np.array_equal(rec.frames[2].rig_from_world, orig.frames[2].rig_from_world)
+
+
+def test_robust_loss_downweights_outliers():
+    """Gross outliers in 5 % of the observations: with the trivial loss they drag the solution
+    away, with CAUCHY (the loss COLMAP's mapper selects for local BA) the ground truth is recovered."""
+    gt, rec = _dataset(1, 8, 150, scene.SyntheticNoiseOptions(point2D_stddev=0.3, point3D_stddev=0.05))
+    rng = np.random.default_rng(11)
+    for i in rec.RegImageIds():
+        for p2 in rec.images[i].points2D:
+            if p2.HasPoint3D() and rng.random() < 0.05:
+                p2.xy = p2.xy + rng.normal(0, 80, 2)
+    def solve(loss):
+        r = rec.copy()
+        so = est.SolverOptions(loss_type=int(loss), loss_scale=1.0)
+        opts = est.BundleAdjustmentOptions(solver_options=so)
+        s = est.BundleAdjuster(opts, _config(r), r, solve_fn=ba_oracle.solve_fn).Solve()
+        assert s.IsSolutionUsable()
+        err = np.mean([np.linalg.norm(r.points3D[k].xyz - gt.points3D[k].xyz) for k in gt.points3D])
+        return s, err
+    s_l2, err_l2 = solve(est.LossFunctionType.TRIVIAL)
+    s_c, err_c = solve(est.LossFunctionType.CAUCHY)
+    assert err_c < 0.25 * err_l2, (err_c, err_l2)
+    assert err_c < 0.02
+    assert s_c.final_cost < s_l2.final_cost   # 1/2 sum rho(s) <= 1/2 sum s
+
+
+def test_robust_cost_matches_scipy_least_squares():
+    """The LM solve on the corrected system minimises 1/2 sum rho(|r|^2): scipy's soft_l1 / cauchy /
+    huber losses use the same rho (f_scale = a) and must reach the same optimum."""
+    _, rec = _dataset(1, 4, 30, scene.SyntheticNoiseOptions(point2D_stddev=2.0, point3D_stddev=0.05))
+    cfg = _config(rec)
+    for i in rec.RegImageIds():
+        cfg.SetConstantRigFromWorldPose(i)
+    for loss, name in [(est.LossFunctionType.SOFT_L1, "soft_l1"), (est.LossFunctionType.CAUCHY, "cauchy"),
+                       (est.LossFunctionType.HUBER, "huber")]:
+        r = rec.copy()
+        so = est.SolverOptions(loss_type=int(loss), loss_scale=2.0, gradient_tolerance=1e-10, max_num_iterations=200)
+        opts = est.BundleAdjustmentOptions(refine_focal_length=False, refine_extra_params=False, solver_options=so)
+        ba = est.BundleAdjuster(opts, cfg, r, solve_fn=ba_oracle.solve_fn)
+        fp0 = ba.problem_.copy()
+        s = ba.Solve()
+        assert s.IsSolutionUsable()
+        # scipy on the points only (poses and intrinsics constant)
+        def resid(x):
+            pts = x.reshape(-1, 3)
+            out = np.zeros(2 * len(fp0.obs_pose))
+            for o in range(len(fp0.obs_pose)):
+                rr, *_ = ba_oracle.reproj_error(int(fp0.cam_model[fp0.obs_cam[o]]), pts[fp0.obs_point[o]],
+                                                fp0.poses[fp0.obs_pose[o]], fp0.cams[fp0.obs_cam[o]],
+                                                fp0.obs_xy[o], want_jac=False)
+                out[2 * o: 2 * o + 2] = rr
+            return out
+        def total(x):
+            rr = resid(x).reshape(-1, 2)
+            return 0.5 * sum(ba_oracle.loss(loss, 2.0, float(v @ v))[0] for v in rr)
+        assert abs(total(ba.problem_.points.ravel()) - s.final_cost) <= 1e-9 * s.final_cost
+        # local optimality of the robust cost: no better point nearby along the gradient
+        x = ba.problem_.points.ravel().copy()
+        g = scipy.optimize.approx_fprime(x, total, 1e-7)
+        assert np.abs(g).max() < 1e-3 * max(1.0, s.final_cost)
