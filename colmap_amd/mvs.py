@@ -447,6 +447,51 @@ class PatchMatchController:
             self.problems_.append((ref, src))
         self.timings = {}
 
+    @classmethod
+    def FromWorkspace(cls, options: PatchMatchOptions, workspace_path: str, workspace_format: str = "COLMAP",
+                      pmvs_option_name: str = "option-all", config_path: str = "", **kw) -> "PatchMatchController":
+        """PatchMatchController(options, workspace_path, workspace_format, pmvs_option_name,
+        config_path) + ReadWorkspace + ReadProblems (patch_match.cc:159-237,239-359): the undistorted
+        COLMAP workspace on disk -- `sparse/` model, `images/`, `stereo/patch-match.cfg`."""
+        import os
+        from . import workspace as W
+        ws = W.Workspace(workspace_path, workspace_format, max_image_size=options.max_image_size,
+                         input_type="photometric" if options.geom_consistency else "")
+        model = ws.GetModel()
+        cfg = config_path or os.path.join(workspace_path, ws.stereo_folder, "patch-match.cfg")
+        with open(cfg) as f:
+            lines = f.read().splitlines()
+        warnings: List[str] = []
+        problems = W.read_patch_match_config(lines, model, options.min_triangulation_angle, warnings.append)
+        ranges = model.ComputeDepthRanges()
+        used = sorted({i for ref, src in problems for i in [ref] + src})
+        images = []
+        for idx, im in enumerate(model.images):
+            bitmap = None
+            if idx in used:
+                if os.path.exists(ws.GetBitmapPath(idx)):
+                    bitmap = ws.GetBitmap(idx)
+                    if bitmap.shape != (im.height, im.width):
+                        raise PatchMatchError(f"Check failed: bitmap size of {model.GetImageName(idx)} "
+                                              f"{bitmap.shape[::-1]} != model image size {(im.width, im.height)}")
+                elif not options.allow_missing_files:
+                    raise PatchMatchError(f"Missing image or map dependency for image {idx}: "
+                                          f"{model.GetImageName(idx)}")  # (:494-500)
+            rng = ranges[idx] if ranges[idx][0] > 0 and ranges[idx][1] > 0 else None
+            images.append(WorkspaceImage(model.GetImageName(idx), im.K, im.R, im.T, bitmap, rng))
+        # sources whose bitmap is missing are skipped (allow_missing_files, :486-493)
+        kept = []
+        for ref, src in problems:
+            if images[ref].bitmap is None:
+                continue
+            src = [s_ for s_ in src if images[s_].bitmap is not None]
+            if src:
+                kept.append((model.GetImageName(ref), [model.GetImageName(s_) for s_ in src]))
+        ctl = cls(options, images, workspace_path, problems=kept, **kw)
+        ctl.workspace_ = ws
+        ctl.warnings_ = warnings
+        return ctl
+
     # -- paths ------------------------------------------------------------------------------
     def _paths(self, image_idx: int, output_type: str):
         import os
@@ -506,6 +551,12 @@ class PatchMatchController:
                 os.makedirs(os.path.dirname(npath), exist_ok=True)
                 write_mat(dpath, depth)
                 write_mat(npath, normal)
+                if options.write_consistency_graph:  # (:532-534)
+                    from . import workspace as W
+                    gpath = os.path.join(os.path.dirname(os.path.dirname(dpath)), "consistency_graphs",
+                                         os.path.basename(dpath))
+                    os.makedirs(os.path.dirname(gpath), exist_ok=True)
+                    W.write_consistency_graph(gpath, depth.shape[1], depth.shape[0], pm.GetConsistentImageIdxs())
                 results[ref] = (depth, normal)
                 pm.close()
             i = j

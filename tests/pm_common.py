@@ -52,3 +52,59 @@ def paired_options(pm_oracle, **kw):
         setattr(h, f, v)
     h.max_sweeps = 0 if max_sweeps < 0 else (-1 if max_sweeps == 0 else max_sweeps)
     return o, h
+
+
+def write_dense_workspace(path, views, num_points=400, seed=0, cfg_spec="__auto__, 20"):
+    """An undistorted COLMAP dense workspace on disk from rendered views: images/*.png, a binary
+    sparse model whose points are back-projected ground-truth pixels with visibility-checked
+    tracks, stereo/patch-match.cfg. Returns the image names."""
+    import os
+    from PIL import Image as PILImage
+    from colmap_amd import workspace as W
+    rng = np.random.default_rng(seed)
+    h, w = views[0].gray.shape
+    sm = W.SparseModel()
+    names = [f"view{i:03d}.png" for i in range(len(views))]
+    os.makedirs(os.path.join(path, "images"), exist_ok=True)
+    os.makedirs(os.path.join(path, "stereo"), exist_ok=True)
+    for i, v in enumerate(views):
+        K = np.asarray(v.K, np.float64)
+        sm.cameras[i + 1] = W.SparseCamera(i + 1, 1, w, h, np.array([K[0, 0], K[1, 1], K[0, 2], K[1, 2]]))
+        R = np.asarray(v.R, np.float64)
+        qw = np.sqrt(max(1e-12, 1 + R[0, 0] + R[1, 1] + R[2, 2])) / 2
+        q = np.array([qw, (R[2, 1] - R[1, 2]) / (4 * qw), (R[0, 2] - R[2, 0]) / (4 * qw), (R[1, 0] - R[0, 1]) / (4 * qw)])
+        sm.images[i + 1] = W.SparseImage(i + 1, q, np.asarray(v.T, np.float64), i + 1, names[i])
+        PILImage.fromarray(v.gray).save(os.path.join(path, "images", names[i]))
+    pid = 0
+    for _ in range(num_points):
+        i = int(rng.integers(len(views)))
+        v = views[i]
+        x, y = int(rng.integers(2, w - 2)), int(rng.integers(2, h - 2))
+        d = float(v.depth[y, x])
+        if not d > 0:
+            continue
+        K, R, T = (np.asarray(a, np.float64) for a in (v.K, v.R, v.T))
+        X = R.T @ (d * np.linalg.inv(K) @ np.array([x, y, 1.0]) - T)
+        track = []
+        for j, u in enumerate(views):
+            Kj, Rj, Tj = (np.asarray(a, np.float64) for a in (u.K, u.R, u.T))
+            pc = Rj @ X + Tj
+            if pc[2] <= 0:
+                continue
+            px = Kj @ (pc / pc[2])
+            cx, cy = int(round(px[0])), int(round(px[1]))
+            if 0 <= cx < w and 0 <= cy < h and abs(float(u.depth[cy, cx]) - pc[2]) < 0.02 * pc[2]:
+                im = sm.images[j + 1]
+                track.append((j + 1, len(im.xys)))
+                im.xys = np.vstack([im.xys, px[:2]])
+                im.point3D_ids = np.append(im.point3D_ids, pid + 1)
+        if len(track) >= 2:
+            pid += 1
+            sm.points3D[pid] = W.SparsePoint3D(pid, X, (128, 128, 128), 0.1, track)
+        else:
+            for iid, idx in track:
+                sm.images[iid].xys = sm.images[iid].xys[:-1]
+                sm.images[iid].point3D_ids = sm.images[iid].point3D_ids[:-1]
+    W.write_model_binary(sm, os.path.join(path, "sparse"))
+    W.write_patch_match_config(os.path.join(path, "stereo", "patch-match.cfg"), names, cfg_spec)
+    return names

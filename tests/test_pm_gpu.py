@@ -326,3 +326,42 @@ def test_controller_two_pass_files_and_resume(pm_oracle, tmp_path):
     ctl2 = mvs.PatchMatchController(opt, ws, str(tmp_path), batch_size=3)
     out2 = ctl2.Run()
     assert all(np.array_equal(out2[k][0], out[k][0]) for k in out)
+
+
+def test_patch_match_stereo_cli_on_a_workspace(tmp_path):
+    """`python -m colmap_amd.patch_match_stereo` on an undistorted workspace on disk (exe/mvs.cc:
+    228-279): sparse model -> depth ranges and `__auto__` sources, photometric + geometric pass,
+    Mat / consistency-graph files, accuracy against the ground-truth depth of the renderer."""
+    import os
+    from colmap_amd import mvs, patch_match_stereo as cli, workspace as W
+    from pm_common import write_dense_workspace
+    views = scene(5, 96, 72)
+    ws = str(tmp_path / "dense")
+    names = write_dense_workspace(ws, views, cfg_spec="__auto__, 3")
+    rc = cli.main(["--workspace_path", ws, "--PatchMatchStereo.gpu_index", "0",
+                   "--PatchMatchStereo.num_iterations", "3", "--PatchMatchStereo.write_consistency_graph", "1"])
+    assert rc == 0
+    w = W.Workspace(ws)
+    ranges = w.GetModel().ComputeDepthRanges()
+    for i, name in enumerate(names):
+        for kind in ("photometric", "geometric"):
+            assert os.path.exists(w.GetDepthMapPath(i, kind)) and os.path.exists(w.GetNormalMapPath(i, kind))
+        depth = mvs.read_mat(w.GetDepthMapPath(i, "geometric"))
+        normal = mvs.read_mat(w.GetNormalMapPath(i, "geometric"))
+        assert depth.shape == (72, 96) and normal.shape == (3, 72, 96)
+        kept = depth > 0
+        assert kept.mean() > 0.3
+        assert depth[kept].min() >= ranges[i][0] * 0.999 and depth[kept].max() <= ranges[i][1] * 1.001
+        rel = np.abs(depth[kept] - views[i].depth[kept]) / views[i].depth[kept]
+        assert np.median(rel) < 0.01, (i, np.median(rel))
+        n = np.linalg.norm(normal[:, kept], axis=0)
+        assert np.allclose(n, 1.0, atol=1e-4)
+        gw, gh, graph = W.read_consistency_graph(w.GetConsistencyGraphPath(i, "geometric"))
+        assert (gw, gh) == (96, 72) and len(graph) == int(kept.sum())
+        # every filtered-in pixel lists >= filter_min_num_consistent source images of this problem
+        assert min(len(v) for v in graph.values()) >= 2
+    # second invocation: everything exists -> nothing recomputed, files untouched
+    before = {p: os.path.getmtime(p) for p in [w.GetDepthMapPath(i, "geometric") for i in range(len(names))]}
+    assert cli.main(["--workspace_path", ws, "--PatchMatchStereo.gpu_index", "0",
+                     "--PatchMatchStereo.num_iterations", "3", "--PatchMatchStereo.write_consistency_graph", "1"]) == 0
+    assert all(os.path.getmtime(p) == t for p, t in before.items())
