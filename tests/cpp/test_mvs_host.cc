@@ -1,0 +1,247 @@
+// Exercises include/colmap_amd/mvs.hpp (the C++ host side of the PatchMatch path).
+//   test_mvs_host check              host-only: checks, file formats (no GPU)
+//   test_mvs_host run DIR            runs the problem described in DIR/problem.txt on the GPU and
+//                                    writes DIR/{depth,normal,sel_prob}.bin + DIR/graph.bin
+#include <cstdio>
+#include <fstream>
+#include <iostream>
+
+#include "colmap_amd/mvs.hpp"
+
+using namespace colmap_amd::mvs;
+
+#define EXPECT(cond)                                                              \
+  do {                                                                            \
+    if (!(cond)) {                                                                \
+      std::fprintf(stderr, "%s:%d: EXPECT failed: %s\n", __FILE__, __LINE__, #cond); \
+      return 1;                                                                   \
+    }                                                                             \
+  } while (0)
+
+template <typename F>
+static bool Throws(F&& f) {
+  try {
+    f();
+  } catch (const std::invalid_argument&) {
+    return true;
+  }
+  return false;
+}
+
+static std::vector<Image> MakeImages(int n, int w, int h) {
+  std::vector<Image> images;
+  for (int i = 0; i < n; ++i) {
+    const float K[9] = {100, 0, w / 2.0f, 0, 100, h / 2.0f, 0, 0, 1};
+    const float R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    const float T[3] = {0.1f * i, 0, 0};
+    images.emplace_back("", w, h, K, R, T);
+    images.back().SetBitmap(Bitmap(w, h, std::vector<uint8_t>(static_cast<size_t>(w) * h, 100)));
+  }
+  return images;
+}
+
+static int HostChecks(const std::string& tmp) {
+  // Mat round trip (mat.h:150-204)
+  Mat<float> m(4, 3, 2);
+  for (size_t s = 0; s < 2; ++s)
+    for (size_t r = 0; r < 3; ++r)
+      for (size_t c = 0; c < 4; ++c) m.Set(r, c, s, static_cast<float>(100 * s + 10 * r + c));
+  m.Write(tmp + "/m.bin");
+  Mat<float> m2;
+  m2.Read(tmp + "/m.bin");
+  EXPECT(m2.GetWidth() == 4 && m2.GetHeight() == 3 && m2.GetDepth() == 2);
+  EXPECT(m2.GetData() == m.GetData());
+  EXPECT(m2.Get(2, 3, 1) == 123.0f);
+  float slice[2];
+  m2.GetSlice(1, 2, slice);
+  EXPECT(slice[0] == 12.0f && slice[1] == 112.0f);
+  {
+    std::ifstream f(tmp + "/m.bin", std::ios::binary);
+    char head[7] = {0};
+    f.read(head, 6);
+    EXPECT(std::string(head) == "4&3&2&");
+  }
+  EXPECT(Throws([&] { DepthMap d(m, 0, 1); }));   // depth must be 1
+  EXPECT(Throws([&] { NormalMap n(m); }));        // depth must be 3
+
+  // ConsistencyGraph (consistency_graph.cc:42-139)
+  ConsistencyGraph g(5, 4, {3, 0, 2, 7, 9, 1, 2, 1, 4});
+  int n = 0;
+  const int* idxs = nullptr;
+  g.GetImageIdxs(0, 3, &n, &idxs);
+  EXPECT(n == 2 && idxs[0] == 7 && idxs[1] == 9);
+  g.GetImageIdxs(1, 1, &n, &idxs);
+  EXPECT(n == 0 && idxs == nullptr);
+  g.Write(tmp + "/g.bin");
+  ConsistencyGraph g2;
+  g2.Read(tmp + "/g.bin");
+  g2.GetImageIdxs(2, 1, &n, &idxs);
+  EXPECT(n == 1 && idxs[0] == 4);
+  EXPECT(Throws([] { ConsistencyGraph bad(5, 4, {9, 0, 1, 2}); }));
+
+  // PatchMatchOptions::Check (patch_match_options.cc:73-100)
+  PatchMatchOptions o;
+  EXPECT(o.Check());
+  o.window_step = 3;
+  EXPECT(!o.Check());
+  o = PatchMatchOptions();
+  o.window_radius = 33;
+  EXPECT(!o.Check());
+  o = PatchMatchOptions();
+  o.depth_min = 2;
+  o.depth_max = 1;
+  EXPECT(!o.Check());
+  o = PatchMatchOptions();
+  o.filter_min_ncc = 1.5;
+  EXPECT(!o.Check());
+
+  // PatchMatch::Check (patch_match.cc:67-126)
+  auto images = MakeImages(3, 32, 24);
+  PatchMatchOptions opt;
+  opt.gpu_index = "0";
+  opt.geom_consistency = false;
+  opt.depth_min = 1;
+  opt.depth_max = 5;
+  PatchMatch::Problem p;
+  p.ref_image_idx = 1;
+  p.src_image_idxs = {0, 2};
+  p.images = &images;
+  PatchMatch(opt, p).Check();
+  {
+    auto q = p;
+    q.src_image_idxs = {1, 2};  // reference as a source
+    EXPECT(Throws([&] { PatchMatch(opt, q).Check(); }));
+    q.src_image_idxs = {0, 0};  // duplicate
+    EXPECT(Throws([&] { PatchMatch(opt, q).Check(); }));
+    q.src_image_idxs = {};
+    EXPECT(Throws([&] { PatchMatch(opt, q).Check(); }));
+    q.src_image_idxs = {0, 7};  // out of range
+    EXPECT(Throws([&] { PatchMatch(opt, q).Check(); }));
+    q = p;
+    q.images = nullptr;
+    EXPECT(Throws([&] { PatchMatch(opt, q).Check(); }));
+  }
+  {
+    auto o2 = opt;
+    o2.gpu_index = "0,1";  // exactly one index
+    EXPECT(Throws([&] { PatchMatch(o2, p).Check(); }));
+    o2.gpu_index = "";
+    EXPECT(Throws([&] { PatchMatch(o2, p).Check(); }));
+    o2 = opt;
+    o2.geom_consistency = true;  // maps missing
+    EXPECT(Throws([&] { PatchMatch(o2, p).Check(); }));
+    std::vector<DepthMap> dm(3, DepthMap(32, 24, 1, 5));
+    std::vector<NormalMap> nm(3, NormalMap(32, 24));
+    auto q = p;
+    q.depth_maps = &dm;
+    q.normal_maps = &nm;
+    PatchMatch(o2, q).Check();
+    dm[0] = DepthMap(16, 24, 1, 5);  // size mismatch of a source depth map
+    EXPECT(Throws([&] { PatchMatch(o2, q).Check(); }));
+  }
+  {
+    const float K[9] = {100, 0.5f, 16, 0, 100, 12, 0, 0, 1};  // skew
+    const float R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    const float T[3] = {0, 0, 0};
+    auto bad = images;
+    bad[0] = Image("", 32, 24, K, R, T);
+    bad[0].SetBitmap(Bitmap(32, 24, std::vector<uint8_t>(32 * 24, 1)));
+    auto q = p;
+    q.images = &bad;
+    EXPECT(Throws([&] { PatchMatch(opt, q).Check(); }));
+    EXPECT(Throws([&] { bad[1].SetBitmap(Bitmap(16, 24, std::vector<uint8_t>(16 * 24, 1))); }));
+  }
+  // getters before Run
+  {
+    PatchMatch pm(opt, p);
+    bool threw = false;
+    try {
+      pm.GetDepthMap();
+    } catch (const std::logic_error&) {
+      threw = true;
+    }
+    EXPECT(threw);
+  }
+  // pose helper
+  {
+    float P[12];
+    ComposeProjectionMatrix(images[1].GetK(), images[1].GetR(), images[1].GetT(), P);
+    EXPECT(P[3] == 100 * 0.1f && P[11] == 0.0f && P[0] == 100.0f);
+    float C[3];
+    ComputeProjectionCenter(images[1].GetR(), images[1].GetT(), C);
+    EXPECT(C[0] == -0.1f);
+  }
+  std::printf("host checks OK\n");
+  return 0;
+}
+
+static int RunProblem(const std::string& dir) {
+  std::ifstream f(dir + "/problem.txt");
+  if (!f.is_open()) {
+    std::fprintf(stderr, "cannot open %s/problem.txt\n", dir.c_str());
+    return 2;
+  }
+  int n, w, h, ref, nsrc, geom, filter, iters;
+  double dmin, dmax;
+  f >> n >> w >> h >> ref >> nsrc >> geom >> filter >> iters >> dmin >> dmax;
+  std::vector<int> src(nsrc);
+  for (auto& s : src) f >> s;
+  std::vector<Image> images;
+  std::vector<DepthMap> depth_maps;
+  std::vector<NormalMap> normal_maps;
+  for (int i = 0; i < n; ++i) {
+    float K[9], R[9], T[3];
+    for (auto& v : K) f >> v;
+    for (auto& v : R) f >> v;
+    for (auto& v : T) f >> v;
+    images.emplace_back(dir + "/img" + std::to_string(i), w, h, K, R, T);
+    std::vector<uint8_t> grey(static_cast<size_t>(w) * h);
+    std::ifstream g(dir + "/img" + std::to_string(i) + ".gray", std::ios::binary);
+    g.read(reinterpret_cast<char*>(grey.data()), static_cast<std::streamsize>(grey.size()));
+    images.back().SetBitmap(Bitmap(w, h, std::move(grey)));
+    if (geom) {
+      Mat<float> d, nm;
+      d.Read(dir + "/in_depth" + std::to_string(i) + ".bin");
+      nm.Read(dir + "/in_normal" + std::to_string(i) + ".bin");
+      depth_maps.emplace_back(d, static_cast<float>(dmin), static_cast<float>(dmax));
+      normal_maps.emplace_back(nm);
+    }
+  }
+  PatchMatchOptions opt;
+  opt.gpu_index = "0";
+  opt.depth_min = dmin;
+  opt.depth_max = dmax;
+  opt.sigma_spatial = opt.window_radius;  // what the controller sets (patch_match.cc:436-438)
+  opt.geom_consistency = geom != 0;
+  opt.filter = filter != 0;
+  opt.num_iterations = iters;
+  opt.filter_min_num_consistent = std::min(nsrc, opt.filter_min_num_consistent);
+  PatchMatch::Problem problem;
+  problem.ref_image_idx = ref;
+  problem.src_image_idxs = src;
+  problem.images = &images;
+  if (geom) {
+    problem.depth_maps = &depth_maps;
+    problem.normal_maps = &normal_maps;
+  }
+  PatchMatch pm(opt, problem);
+  pm.Run();
+  pm.GetDepthMap().Write(dir + "/depth.bin");
+  pm.GetNormalMap().Write(dir + "/normal.bin");
+  pm.GetSelProbMap().Write(dir + "/sel_prob.bin");
+  pm.GetConsistencyGraph().Write(dir + "/graph.bin");
+  std::printf("run OK\n");
+  return 0;
+}
+
+int main(int argc, char** argv) {
+  try {
+    if (argc >= 3 && std::string(argv[1]) == "check") return HostChecks(argv[2]);
+    if (argc >= 3 && std::string(argv[1]) == "run") return RunProblem(argv[2]);
+  } catch (const std::exception& e) {
+    std::fprintf(stderr, "exception: %s\n", e.what());
+    return 3;
+  }
+  std::fprintf(stderr, "usage: test_mvs_host check TMPDIR | run DIR\n");
+  return 2;
+}
