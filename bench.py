@@ -277,12 +277,13 @@ def main():
                         "see DESIGN.md 1.5 for the PMC accounting",
             },
         }
-        if not a.no_cpu_baseline:
+        # the CPU baseline and the secondary (single-GPU) BA measurement belong to the N = 1 run only
+        if not a.no_cpu_baseline and world == 1:
             ref, src, dmin, dmax = problem(0)[1]
             cw, ch = [int(x) for x in a.cpu_crop.split("x")]
             host_views = [syn.View(K, R, T, g.cpu().numpy(), None, None) for (K, R, T, g, _, _) in views]
             out["cpu_baseline"] = cpu_baseline(host_views, ref, src, dmin, dmax, (cw, ch))
-        if not a.no_ba:
+        if not a.no_ba and world == 1:
             del pms_keepalive[:]
             torch.cuda.empty_cache()
             out["secondary"] = ba_secondary(a, local_rank, not a.no_cpu_baseline)

@@ -341,6 +341,12 @@ void Create(const pm_options& opt_in, const pm_problem& prob, pm_image_cache* ca
     HIP_CALL(hipGetDevice(&h->device));
   }
   HIP_CALL(hipSetDevice(h->device));
+  if (cache) {
+    // a cache holds device pointers of one GPU: bind it on first use, refuse another device later
+    std::lock_guard<std::mutex> lock(cache->mu);
+    if (cache->device < 0) cache->device = h->device;
+    PM_CHECK(cache->device == h->device, "image cache and problem are on the same GPU");
+  }
   HIP_CALL(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
 
   const pm_image& ref = prob.images[prob.ref_image_idx];
@@ -679,8 +685,9 @@ int pm_check(const pm_options* options, const pm_problem* problem) {
 int pm_image_cache_create(int32_t gpu_index, pm_image_cache** out) {
   return Guard([&] {
     PM_CHECK(out, "null argument");
+    PM_CHECK(gpu_index >= -1, "gpu_index >= -1");
     auto* c = new pm_image_cache();
-    c->device = gpu_index;
+    c->device = gpu_index;  // -1: the device of the first problem that uses the cache
     *out = c;
   });
 }

@@ -104,7 +104,9 @@ int pm_create(const pm_options* options, const pm_problem* problem, pm_handle** 
  * source bitmap for every problem, patch_match_cuda.cu:1595-1654; its host-side equivalent is the
  * CachedWorkspace, mvs/workspace.h). Entries are keyed by the caller's bitmap pointer and sizes, so
  * the caller must keep a bitmap's address stable and unmodified while it is cached. Handles keep
- * their sources alive; destroy the cache when no problem will reuse it. */
+ * their sources alive; destroy the cache when no problem will reuse it. A cache belongs to one GPU
+ * (gpu_index, or with -1 the device of the first problem created with it): pm_create_cached fails
+ * for a problem on another device. Thread-safe. */
 typedef struct pm_image_cache pm_image_cache;
 int pm_image_cache_create(int32_t gpu_index, pm_image_cache** out);
 void pm_image_cache_destroy(pm_image_cache* cache);
