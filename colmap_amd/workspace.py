@@ -82,10 +82,30 @@ class SparsePoint3D:
 
 
 @dataclass
+class SparseRig:
+    """scene/rig.h: reference sensor + (sensor id -> optional sensor_from_rig as w x y z tx ty tz);
+    a sensor id is (type, id) with type 0 = CAMERA, 1 = IMU (util/types.h:144-148)."""
+    rig_id: int
+    ref_sensor: Optional[Tuple[int, int]] = None
+    sensors: Dict[Tuple[int, int], Optional[np.ndarray]] = field(default_factory=dict)
+
+
+@dataclass
+class SparseFrame:
+    """scene/frame.h: rig_from_world (w x y z tx ty tz) and the data ids (sensor type, sensor id, data id)."""
+    frame_id: int
+    rig_id: int
+    rig_from_world: np.ndarray
+    data_ids: List[Tuple[int, int, int]] = field(default_factory=list)
+
+
+@dataclass
 class SparseModel:
     cameras: Dict[int, SparseCamera] = field(default_factory=dict)
     images: Dict[int, SparseImage] = field(default_factory=dict)
     points3D: Dict[int, SparsePoint3D] = field(default_factory=dict)
+    rigs: Dict[int, SparseRig] = field(default_factory=dict)      # empty: legacy model, one rig per camera
+    frames: Dict[int, SparseFrame] = field(default_factory=dict)  # empty: legacy model, one frame per image
 
 
 # ------------------------------------------------------------------------------------------------
@@ -150,9 +170,68 @@ def read_points3D_binary(path: str) -> Dict[int, SparsePoint3D]:
     return pts
 
 
+def read_rigs_binary(path: str) -> Dict[int, SparseRig]:
+    """ReadRigsBinary (reconstruction_io_binary.cc:47-98)."""
+    rigs = {}
+    with open(path, "rb") as f:
+        (n,) = _rd(f, "Q")
+        for _ in range(n):
+            rid, ns = _rd(f, "II")
+            rig = SparseRig(rid)
+            if ns > 0:
+                rig.ref_sensor = tuple(_rd(f, "iI"))
+            for _ in range(max(0, ns - 1)):
+                sid = tuple(_rd(f, "iI"))
+                (has_pose,) = _rd(f, "B")
+                rig.sensors[sid] = np.array(_rd(f, "ddddddd")) if has_pose else None
+            rigs[rid] = rig
+    return rigs
+
+
+def read_frames_binary(path: str) -> Dict[int, SparseFrame]:
+    """ReadFramesBinary (reconstruction_io_binary.cc:132-164)."""
+    frames = {}
+    with open(path, "rb") as f:
+        (n,) = _rd(f, "Q")
+        for _ in range(n):
+            fid, rid = _rd(f, "II")
+            pose = np.array(_rd(f, "ddddddd"))
+            (nd,) = _rd(f, "I")
+            frames[fid] = SparseFrame(fid, rid, pose, [tuple(_rd(f, "iIQ")) for _ in range(nd)])
+    return frames
+
+
+def write_rigs_frames_binary(model: SparseModel, path: str):
+    """WriteRigsBinary / WriteFramesBinary (reconstruction_io_binary.cc:293-399)."""
+    with open(os.path.join(path, "rigs.bin"), "wb") as f:
+        f.write(struct.pack("<Q", len(model.rigs)))
+        for rid in sorted(model.rigs):
+            rig = model.rigs[rid]
+            ns = (1 if rig.ref_sensor is not None else 0) + len(rig.sensors)
+            f.write(struct.pack("<II", rid, ns))
+            if rig.ref_sensor is not None:
+                f.write(struct.pack("<iI", *rig.ref_sensor))
+            for sid in sorted(rig.sensors):
+                pose = rig.sensors[sid]
+                f.write(struct.pack("<iIB", sid[0], sid[1], 0 if pose is None else 1))
+                if pose is not None:
+                    f.write(np.asarray(pose, "<f8").tobytes())
+    with open(os.path.join(path, "frames.bin"), "wb") as f:
+        f.write(struct.pack("<Q", len(model.frames)))
+        for fid in sorted(model.frames):
+            fr = model.frames[fid]
+            f.write(struct.pack("<II", fid, fr.rig_id) + np.asarray(fr.rig_from_world, "<f8").tobytes())
+            f.write(struct.pack("<I", len(fr.data_ids)))
+            for d in sorted(fr.data_ids):
+                f.write(struct.pack("<iIQ", *d))
+
+
 def write_model_binary(model: SparseModel, path: str):
-    """WriteCamerasBinary / WriteImagesBinary / WritePoints3DBinary (sorted ids like the reference)."""
+    """WriteCamerasBinary / WriteImagesBinary / WritePoints3DBinary (sorted ids like the reference);
+    rigs.bin / frames.bin too when the model carries rigs."""
     os.makedirs(path, exist_ok=True)
+    if model.rigs or model.frames:
+        write_rigs_frames_binary(model, path)
     with open(os.path.join(path, "cameras.bin"), "wb") as f:
         f.write(struct.pack("<Q", len(model.cameras)))
         for cid in sorted(model.cameras):
@@ -261,9 +340,14 @@ def write_model_text(model: SparseModel, path: str):
 def read_sparse_model(path: str) -> SparseModel:
     """Reconstruction::Read: binary files if present, else text (scene/reconstruction.cc)."""
     if os.path.exists(os.path.join(path, "cameras.bin")):
-        return SparseModel(read_cameras_binary(os.path.join(path, "cameras.bin")),
-                           read_images_binary(os.path.join(path, "images.bin")),
-                           read_points3D_binary(os.path.join(path, "points3D.bin")))
+        m = SparseModel(read_cameras_binary(os.path.join(path, "cameras.bin")),
+                        read_images_binary(os.path.join(path, "images.bin")),
+                        read_points3D_binary(os.path.join(path, "points3D.bin")))
+        # newer models also carry rigs.bin / frames.bin (Reconstruction::ReadBinary); legacy ones do not
+        if os.path.exists(os.path.join(path, "rigs.bin")) and os.path.exists(os.path.join(path, "frames.bin")):
+            m.rigs = read_rigs_binary(os.path.join(path, "rigs.bin"))
+            m.frames = read_frames_binary(os.path.join(path, "frames.bin"))
+        return m
     if os.path.exists(os.path.join(path, "cameras.txt")):
         return SparseModel(read_cameras_text(os.path.join(path, "cameras.txt")),
                            read_images_text(os.path.join(path, "images.txt")),

@@ -1,0 +1,125 @@
+"""`python -m colmap_amd.bundle_adjuster` (reference exe/sfm.cc:175-206, controllers/bundle_adjustment.cc):
+model files in -> adjusted model files out. CPU tests route the solve to the oracle library; the GPU
+test runs the real backend and must agree with the oracle run."""
+import os
+
+import numpy as np
+import pytest
+
+import ba_oracle
+from colmap_amd import bundle_adjuster as cli
+from colmap_amd import scene, workspace as W
+
+
+def _dataset(cams_per_rig=1, seed=0):
+    rec = scene.SynthesizeDataset(scene.SyntheticDatasetOptions(
+        num_rigs=2, num_cameras_per_rig=cams_per_rig, num_frames_per_rig=4, num_points3D=120,
+        num_points2D_without_point3D=3), seed=seed)
+    gt = rec.copy()
+    scene.SynthesizeNoise(scene.SyntheticNoiseOptions(0.02, 0.5, 0.05, 0.5), rec, seed=seed + 1)
+    return gt, rec
+
+
+def test_model_conversion_round_trip(tmp_path):
+    _, rec = _dataset(2)
+    sm = cli.sparse_model_from_reconstruction(rec)
+    W.write_model_binary(sm, str(tmp_path))
+    assert os.path.exists(tmp_path / "rigs.bin") and os.path.exists(tmp_path / "frames.bin")
+    back = cli.reconstruction_from_sparse_model(W.read_sparse_model(str(tmp_path)))
+    assert sorted(back.rigs) == sorted(rec.rigs) and sorted(back.frames) == sorted(rec.frames)
+    for fid, fr in rec.frames.items():
+        assert np.array_equal(back.frames[fid].rig_from_world, fr.rig_from_world)
+        assert back.frames[fid].image_ids == fr.image_ids
+    for rid, rig in rec.rigs.items():
+        assert back.rigs[rid].ref_camera_id == rig.ref_camera_id
+        for cid, pose in rig.sensors.items():
+            assert np.array_equal(back.rigs[rid].sensors[cid], pose)
+    for iid, img in rec.images.items():
+        b = back.images[iid]
+        assert b.frame_id_ == img.frame_id_ and b.camera_id == img.camera_id
+        assert np.array_equal(b.cam_from_world, img.cam_from_world)
+        assert [p.point3D_id for p in b.points2D] == [p.point3D_id for p in img.points2D]
+        assert all(np.array_equal(p.xy, q.xy) for p, q in zip(b.points2D, img.points2D))
+    for pid, pt in rec.points3D.items():
+        assert np.array_equal(back.points3D[pid].xyz, pt.xyz) and back.points3D[pid].track == pt.track
+    # a legacy model (no rigs.bin / frames.bin) reads as one trivial frame per image
+    _, legacy = _dataset(1)
+    W.write_model_binary(cli.sparse_model_from_reconstruction(legacy), str(tmp_path / "legacy"))
+    assert not os.path.exists(tmp_path / "legacy" / "rigs.bin")
+    back = cli.reconstruction_from_sparse_model(W.read_sparse_model(str(tmp_path / "legacy")))
+    assert not back.frames and all(i.frame_id == i.image_id for i in back.images.values())
+
+
+def test_negative_depth_filter_and_point_errors():
+    gt, rec = _dataset(1)
+    # put an observation behind its camera: flip a point to the far side of image 1
+    img = rec.images[1]
+    idx = next(i for i, p in enumerate(img.points2D) if p.HasPoint3D())
+    pid = img.points2D[idx].point3D_id
+    R = scene.quat_to_rot(img.cam_from_world[:4])
+    center = -R.T @ img.cam_from_world[4:]
+    rec.points3D[pid].xyz = center + 3.0 * (center / np.linalg.norm(center))   # behind the camera (it looks at 0)
+    n_track = len(rec.points3D[pid].track)
+    removed = cli.filter_observations_with_negative_depth(rec)
+    assert removed >= 1
+    assert rec.images[1].points2D[idx].point3D_id == -1
+    assert pid not in rec.points3D or len(rec.points3D[pid].track) < n_track
+    # errors: mean pixel distance over the track (reconstruction.cc:959-975); ~0 on noise-free data
+    errs = cli.point3D_errors(gt)
+    assert max(errs.values()) < 1e-9
+    noisy = cli.point3D_errors(rec)
+    assert 0.1 < np.median(list(noisy.values())) < 100
+
+
+@pytest.mark.parametrize("cams_per_rig", [1, 2])
+def test_bundle_adjuster_cli_with_oracle_backend(tmp_path, cams_per_rig):
+    gt, rec = _dataset(cams_per_rig, seed=4)
+    inp, out = tmp_path / "in", tmp_path / "out"
+    os.makedirs(out)
+    W.write_model_binary(cli.sparse_model_from_reconstruction(rec), str(inp))
+    args = ["--input_path", str(inp), "--output_path", str(out), "--BundleAdjustmentCeres.max_num_iterations", "50",
+            "--BundleAdjustment.refine_sensor_from_rig", "0"]
+    assert cli.main(args, solve_fn=ba_oracle.solve_fn) == 0
+    res = cli.reconstruction_from_sparse_model(W.read_sparse_model(str(out)))
+    sm_out = W.read_sparse_model(str(out))
+    # (the gauge frames keep their noisy poses, so the result lives in a slightly different similarity
+    # frame than the ground truth: judge by the gauge-invariant reprojection errors)
+    errs = [p.error for p in sm_out.points3D.values()]
+    assert 0 < np.median(errs) < 1.5          # ~ the 0.5 px observation noise after adjustment
+    in_errs = list(cli.point3D_errors(rec).values())
+    assert np.median(errs) < 0.5 * np.median(in_errs)
+    if cams_per_rig > 1:
+        assert len(sm_out.frames) == 8 and len(sm_out.rigs) == 2
+        res.UpdateCamFromWorld()
+        for iid, img in res.images.items():  # images.bin poses are the compositions of the written frames
+            p = sm_out.images[iid]
+            want = np.array([img.cam_from_world[3], *img.cam_from_world[:3]])
+            np.testing.assert_allclose(p.qvec, want, atol=1e-12)
+    # error paths of the command (exe/sfm.cc:187-195)
+    assert cli.main(["--input_path", str(tmp_path / "nope"), "--output_path", str(out)]) == 1
+    assert cli.main(["--input_path", str(inp), "--output_path", str(tmp_path / "nope")]) == 1
+    with pytest.raises(SystemExit):
+        cli.main(["--input_path", str(inp), "--output_path", str(out), "--BundleAdjustment.backend", "CERES"])
+
+
+@pytest.mark.gpu
+def test_bundle_adjuster_cli_on_gpu_matches_oracle_run(tmp_path):
+    _, rec = _dataset(2, seed=9)
+    inp = tmp_path / "in"
+    W.write_model_binary(cli.sparse_model_from_reconstruction(rec), str(inp))
+    outs = {}
+    for name, fn in (("gpu", None), ("oracle", ba_oracle.solve_fn)):
+        out = tmp_path / name
+        os.makedirs(out)
+        assert cli.main(["--input_path", str(inp), "--output_path", str(out), "--BundleAdjustmentCeres.gpu_index", "0",
+                         "--BundleAdjustment.refine_sensor_from_rig", "0",
+                         "--BundleAdjustmentCeres.gradient_tolerance", "1e-10",
+                         "--BundleAdjustmentCeres.max_num_iterations", "200",
+                         "--BundleAdjustmentCeres.loss_function_type", "CAUCHY"], solve_fn=fn) == 0
+        outs[name] = W.read_sparse_model(str(out))
+    for iid in outs["gpu"].images:
+        np.testing.assert_allclose(outs["gpu"].images[iid].qvec, outs["oracle"].images[iid].qvec, atol=1e-6)
+        np.testing.assert_allclose(outs["gpu"].images[iid].tvec, outs["oracle"].images[iid].tvec, atol=1e-6)
+    for pid in outs["gpu"].points3D:
+        np.testing.assert_allclose(outs["gpu"].points3D[pid].xyz, outs["oracle"].points3D[pid].xyz, atol=1e-6)
+        assert abs(outs["gpu"].points3D[pid].error - outs["oracle"].points3D[pid].error) < 1e-5
