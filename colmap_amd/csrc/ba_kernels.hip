@@ -57,8 +57,13 @@ thread_local long long g_spmv_bytes = 0;
   } while (0)
 
 constexpr int PD = 6;        // pose tangent width (5 when the gauge holds a translation coordinate)
-constexpr int KD = 4;        // max intrinsics tangent width
-constexpr int NPAR = 5;      // max number of parameters of a supported camera model (J_params is 2 x NPAR)
+// The intrinsics tangent width KD (row stride of Jcam / cam_var) and the widest camera-side block BD
+// (stride of the per-chunk partials) are chosen per problem: <KD, BD> = <4, 6> when no camera has
+// more than 4 variable intrinsics (every model with the principal point fixed except OPENCV), else
+// <8, 8>. The kernels whose register footprint depends on them are templates; the others read
+// V.kd / V.bd.
+constexpr int KD_MAX = 8;
+constexpr int NPAR = 8;      // max number of parameters of a supported camera model (J_params is 2 x NPAR)
 static int chunk_size() {     // observations per camera-side reduction chunk (one wave each)
   const char* e = std::getenv("COLMAP_AMD_BA_CHUNK");
   const int v = e ? std::atoi(e) : 512;
@@ -122,7 +127,8 @@ struct View {
   const int *blk_off, *blk_dim, *blk_kind, *blk_moff;
   const int *chunk_blk, *chunk_beg, *chunk_end;  // chunks are c-order ranges
   const int* blk_chunk_ptr;  // chunks of block b: [blk_chunk_ptr[b], blk_chunk_ptr[b+1])
-  double* cpart;             // [n_chunks][PD*PD] per-chunk partial results (no atomics)
+  double* cpart;             // [n_chunks][bd*bd] per-chunk partial results (no atomics)
+  int kd, bd;                // intrinsics tangent width (Jcam / cam_var row stride), widest block
   // linearisation
   double *Jpose, *Jcam, *res;  // c-order
   double *Jpt, *res_p;         // p-order
@@ -166,7 +172,7 @@ __device__ __forceinline__ void atomic_max_pos(double* addr, double v) {
 // Per-residual math (reference reprojection_error.h:68-134)
 // ------------------------------------------------------------------------------------------
 __device__ __host__ __forceinline__ int num_params_of(int model) {
-  return model == BA_SIMPLE_PINHOLE ? 3 : (model == BA_RADIAL ? 5 : 4);
+  return model == BA_SIMPLE_PINHOLE ? 3 : (model == BA_RADIAL ? 5 : (model == BA_OPENCV ? 8 : 4));
 }
 
 // QuaternionRotatePointWithJac, quaternion_utils.h:105-153
@@ -226,6 +232,36 @@ __device__ __forceinline__ bool img_from_cam(int model, const double* prm, doubl
       Juvw[3] = 0.0; Juvw[4] = f2 * inv_w; Juvw[5] = -f2 * inv_w * vv;
       Jpar[0] = uu; Jpar[1] = 0.0; Jpar[2] = 1.0; Jpar[3] = 0.0;
       Jpar[NPAR + 0] = 0.0; Jpar[NPAR + 1] = vv; Jpar[NPAR + 2] = 0.0; Jpar[NPAR + 3] = 1.0;
+    }
+    return true;
+  }
+  if (model == BA_OPENCV) {  // models_jacobian.h:401-496
+    const double f1 = prm[0], f2 = prm[1], k1 = prm[4], k2 = prm[5], p1 = prm[6], p2 = prm[7];
+    const double uu2 = uu * uu, vv2 = vv * vv, uv = uu * vv, r2 = uu2 + vv2, r4 = r2 * r2;
+    const double radial = k1 * r2 + k2 * r4;
+    const double du = uu * radial + 2.0 * p1 * uv + p2 * (r2 + 2.0 * uu2);
+    const double dv = vv * radial + 2.0 * p2 * uv + p1 * (r2 + 2.0 * vv2);
+    const double xd = uu + du, yd = vv + dv;
+    x = f1 * xd + prm[2];
+    y = f2 * yd + prm[3];
+    if (JAC) {
+      const double d_radial_d_r2 = k1 + 2.0 * k2 * r2;
+      const double cross = 2.0 * uv * d_radial_d_r2;
+      const double du_duu = radial + 2.0 * uu2 * d_radial_d_r2 + 2.0 * p1 * vv + 6.0 * p2 * uu;
+      const double du_dvv = cross + 2.0 * p1 * uu + 2.0 * p2 * vv;
+      const double dv_duu = cross + 2.0 * p2 * vv + 2.0 * p1 * uu;
+      const double dv_dvv = radial + 2.0 * vv2 * d_radial_d_r2 + 2.0 * p2 * uu + 6.0 * p1 * vv;
+      const double a00 = f1 * (1.0 + du_duu);
+      const double a01 = f1 * du_dvv;
+      const double a10 = f2 * dv_duu;
+      const double a11 = f2 * (1.0 + dv_dvv);
+      Juvw[0] = a00 * inv_w; Juvw[1] = a01 * inv_w; Juvw[2] = -(a00 * uu + a01 * vv) * inv_w;
+      Juvw[3] = a10 * inv_w; Juvw[4] = a11 * inv_w; Juvw[5] = -(a10 * uu + a11 * vv) * inv_w;
+      Jpar[0] = xd; Jpar[1] = 0.0; Jpar[2] = 1.0; Jpar[3] = 0.0;
+      Jpar[4] = f1 * uu * r2; Jpar[5] = f1 * uu * r4; Jpar[6] = f1 * 2.0 * uv; Jpar[7] = f1 * (r2 + 2.0 * uu2);
+      Jpar[NPAR + 0] = 0.0; Jpar[NPAR + 1] = yd; Jpar[NPAR + 2] = 0.0; Jpar[NPAR + 3] = 1.0;
+      Jpar[NPAR + 4] = f2 * vv * r2; Jpar[NPAR + 5] = f2 * vv * r4; Jpar[NPAR + 6] = f2 * (r2 + 2.0 * vv2);
+      Jpar[NPAR + 7] = f2 * 2.0 * uv;
     }
     return true;
   }
@@ -312,7 +348,7 @@ __device__ __forceinline__ void quat_to_rot(const double* q, double R[9]) {
 
 // Evaluate one observation; JAC: also the tangent-space, column-scaled Jacobian blocks.
 // Jpar is laid out 2 x NPAR whatever the model (columns beyond the model's parameters are not read).
-template <bool JAC>
+template <bool JAC, int KD>
 __global__ void __launch_bounds__(256) ba_linearize_kernel(View V, const double* __restrict__ poses,
                                                           const double* __restrict__ cams,
                                                           const double* __restrict__ points,
@@ -699,6 +735,7 @@ __global__ void __launch_bounds__(TILE_PTS) ba_point_pass_tiled_kernel(View V, c
 // ------------------------------------------------------------------------------------------
 
 // jx_o = Jc_o x  (both residual rows), x a camera-side vector
+template <int KD>
 __global__ void ba_obs_jx_kernel(View V, const double* __restrict__ x, double* __restrict__ jx) {
   const int o = blockIdx.x * blockDim.x + threadIdx.x;
   if (o >= V.n_obs) return;
@@ -739,7 +776,7 @@ __global__ void __launch_bounds__(256) ba_model_kernel(View V, const double* __r
     for (int r = 0; r < 2; ++r) {
       double m = 0.0;
       for (int c = 0; c < pdim; ++c) m += V.Jpose[(size_t)(r * PD + c) * N + o] * dc[poff + c];
-      for (int c = 0; c < cdim; ++c) m += V.Jcam[(size_t)(r * KD + c) * N + o] * dc[coff + c];
+      for (int c = 0; c < cdim; ++c) m += V.Jcam[(size_t)(r * V.kd + c) * N + o] * dc[coff + c];
       if (ptoff >= 0)
         for (int c = 0; c < 3; ++c) m += V.Jpt[(size_t)(r * 3 + c) * N + V.c2a[o]] * dp[ptoff + c];
       acc -= m * (V.res[r * N + o] + 0.5 * m);
@@ -755,22 +792,24 @@ __global__ void __launch_bounds__(256) ba_model_kernel(View V, const double* __r
 
 __device__ __forceinline__ const double* blk_col(const View& V, int kind, int r, int c) {
   const size_t N = (size_t)V.n_obs;
-  return kind == 0 ? V.Jpose + (size_t)(r * PD + c) * N : V.Jcam + (size_t)(r * KD + c) * N;
+  return kind == 0 ? V.Jpose + (size_t)(r * PD + c) * N : V.Jcam + (size_t)(r * V.kd + c) * N;
 }
 
 // y_b += J_b^T v  (v: 2 rows per observation). With DIAG: also diag_b += colsq(J_b).
-template <bool DIAG>
+template <bool DIAG, int BD>
 __global__ void __launch_bounds__(64) ba_block_jtv_kernel(View V, const double* __restrict__ v,
                                                          double* __restrict__ y, double* __restrict__ diag) {
   const int ch = blockIdx.x;
   const int b = V.chunk_blk[ch];
   const int kind = V.blk_kind[b], dim = V.blk_dim[b], off = V.blk_off[b];
   const size_t N = (size_t)V.n_obs;
-  double acc[PD] = {0, 0, 0, 0, 0, 0}, dacc[PD] = {0, 0, 0, 0, 0, 0};
+  double acc[BD], dacc[BD];
+#pragma unroll
+  for (int c = 0; c < BD; ++c) acc[c] = dacc[c] = 0.0;
   for (int o = V.chunk_beg[ch] + threadIdx.x; o < V.chunk_end[ch]; o += 64) {
     const double v0 = v[o], v1 = v[N + o];
 #pragma unroll
-    for (int c = 0; c < PD; ++c)
+    for (int c = 0; c < BD; ++c)
       if (c < dim) {
         const double j0 = blk_col(V, kind, 0, c)[o], j1 = blk_col(V, kind, 1, c)[o];
         acc[c] += j0 * v0 + j1 * v1;
@@ -779,13 +818,13 @@ __global__ void __launch_bounds__(64) ba_block_jtv_kernel(View V, const double* 
   }
   (void)off;
 #pragma unroll
-  for (int c = 0; c < PD; ++c)
+  for (int c = 0; c < BD; ++c)
     if (c < dim) {
       const double s = wave_sum(acc[c]);
-      if (threadIdx.x == 0) V.cpart[(size_t)ch * PD * PD + c] = s;
+      if (threadIdx.x == 0) V.cpart[(size_t)ch * BD * BD + c] = s;
       if (DIAG) {
         const double d = wave_sum(dacc[c]);
-        if (threadIdx.x == 0) V.cpart[(size_t)ch * PD * PD + PD + c] = d;
+        if (threadIdx.x == 0) V.cpart[(size_t)ch * BD * BD + BD + c] = d;
       }
     }
 }
@@ -799,8 +838,8 @@ __global__ void ba_block_vec_finalize_kernel(View V, double* __restrict__ y, dou
   for (int c = 0; c < dim; ++c) {
     double s = 0.0, d = 0.0;
     for (int ch = V.blk_chunk_ptr[b]; ch < V.blk_chunk_ptr[b + 1]; ++ch) {
-      s += V.cpart[(size_t)ch * PD * PD + c];
-      if (DIAG) d += V.cpart[(size_t)ch * PD * PD + PD + c];
+      s += V.cpart[(size_t)ch * V.bd * V.bd + c];
+      if (DIAG) d += V.cpart[(size_t)ch * V.bd * V.bd + V.bd + c];
     }
     y[off + c] += s;
     if (DIAG) diag[off + c] += d;
@@ -816,7 +855,7 @@ __global__ void ba_block_mat_finalize_kernel(View V, double* __restrict__ M) {
   double* Mb = M + V.blk_moff[b];
   for (int e = 0; e < dim * dim; ++e) {
     double s = 0.0;
-    for (int ch = V.blk_chunk_ptr[b]; ch < V.blk_chunk_ptr[b + 1]; ++ch) s += V.cpart[(size_t)ch * PD * PD + e];
+    for (int ch = V.blk_chunk_ptr[b]; ch < V.blk_chunk_ptr[b + 1]; ++ch) s += V.cpart[(size_t)ch * V.bd * V.bd + e];
     Mb[e] = ACCUMULATE ? Mb[e] + s : s;
   }
 }
@@ -846,47 +885,48 @@ __global__ void __launch_bounds__(64) ba_block_gram_kernel(View V, double* __res
 #pragma unroll
   for (int reg = 0; reg < 4; ++reg) {
     const int row = k + 4 * reg;
-    if (row < dim && i < dim) V.cpart[(size_t)ch * PD * PD + row * dim + i] = acc[reg];
+    if (row < dim && i < dim) V.cpart[(size_t)ch * V.bd * V.bd + row * dim + i] = acc[reg];
   }
 }
 
 // Schur-Jacobi diagonal blocks, part 2: - sum_j W C_j^-1 W'^T over pairs of observations of the
 // same point that share the block (W = J_b^T E, dim x 3). One lane per observation of the block.
+template <int BD>
 __global__ void __launch_bounds__(64) ba_block_schur_corr_kernel(View V, const double* __restrict__ Cinv,
                                                                 double* __restrict__ M) {
   const int ch = blockIdx.x;
   const int b = V.chunk_blk[ch];
   const int kind = V.blk_kind[b], dim = V.blk_dim[b], boff = V.blk_off[b];
   const size_t N = (size_t)V.n_obs;
-  double acc[PD * PD];
+  double acc[BD * BD];
 #pragma unroll
-  for (int e = 0; e < PD * PD; ++e) acc[e] = 0.0;
+  for (int e = 0; e < BD * BD; ++e) acc[e] = 0.0;
   for (int o = V.chunk_beg[ch] + threadIdx.x; o < V.chunk_end[ch]; o += 64) {
     const int xi = V.o_pt[o];
     if (V.pt_off[xi] < 0) continue;
     const int a = V.c2a[o];
     const double* Ci = Cinv + 9 * (size_t)xi;
-    double W1[PD][3];
+    double W1[BD][3];
 #pragma unroll
-    for (int x = 0; x < PD; ++x)
+    for (int x = 0; x < BD; ++x)
 #pragma unroll
       for (int c = 0; c < 3; ++c)
         W1[x][c] = (x < dim) ? blk_col(V, kind, 0, x)[o] * V.Jpt[(size_t)c * N + a] +
                                    blk_col(V, kind, 1, x)[o] * V.Jpt[(size_t)(3 + c) * N + a]
                              : 0.0;
-    double T[PD][3];  // W1 * Cinv
+    double T[BD][3];  // W1 * Cinv
 #pragma unroll
-    for (int x = 0; x < PD; ++x)
+    for (int x = 0; x < BD; ++x)
 #pragma unroll
       for (int c = 0; c < 3; ++c) T[x][c] = W1[x][0] * Ci[c] + W1[x][1] * Ci[3 + c] + W1[x][2] * Ci[6 + c];
     if ((V.solo[o] >> kind) & 1) {
       // the only observation of this point in this block (always true for pose blocks of COLMAP
       // tracks, and for intrinsics blocks of per-image cameras): the pair sum is W1 C^-1 W1^T
 #pragma unroll
-      for (int x = 0; x < PD; ++x)
+      for (int x = 0; x < BD; ++x)
 #pragma unroll
-        for (int y = 0; y < PD; ++y)
-          if (x < dim && y < dim) acc[x * PD + y] -= T[x][0] * W1[y][0] + T[x][1] * W1[y][1] + T[x][2] * W1[y][2];
+        for (int y = 0; y < BD; ++y)
+          if (x < dim && y < dim) acc[x * BD + y] -= T[x][0] * W1[y][0] + T[x][1] * W1[y][1] + T[x][2] * W1[y][2];
       continue;
     }
     // partners: observations of the same point that map to the same block (self included)
@@ -895,7 +935,7 @@ __global__ void __launch_bounds__(64) ba_block_schur_corr_kernel(View V, const d
       const int off2 = kind == 0 ? V.pose_off[V.o_pose[o2]] : V.cam_off[V.o_cam[o2]];
       if (off2 != boff) continue;
 #pragma unroll
-      for (int y = 0; y < PD; ++y) {
+      for (int y = 0; y < BD; ++y) {
         if (y >= dim) continue;
         double W2[3];
 #pragma unroll
@@ -903,52 +943,53 @@ __global__ void __launch_bounds__(64) ba_block_schur_corr_kernel(View V, const d
           W2[c] = blk_col(V, kind, 0, y)[o2] * V.Jpt[(size_t)c * N + a2] +
                   blk_col(V, kind, 1, y)[o2] * V.Jpt[(size_t)(3 + c) * N + a2];
 #pragma unroll
-        for (int x = 0; x < PD; ++x)
-          if (x < dim) acc[x * PD + y] -= T[x][0] * W2[0] + T[x][1] * W2[1] + T[x][2] * W2[2];
+        for (int x = 0; x < BD; ++x)
+          if (x < dim) acc[x * BD + y] -= T[x][0] * W2[0] + T[x][1] * W2[1] + T[x][2] * W2[2];
       }
     }
   }
   (void)M;
 #pragma unroll
-  for (int x = 0; x < PD; ++x)
+  for (int x = 0; x < BD; ++x)
 #pragma unroll
-    for (int y = 0; y < PD; ++y)
+    for (int y = 0; y < BD; ++y)
       if (x < dim && y < dim) {
-        const double s = wave_sum(acc[x * PD + y]);
-        if (threadIdx.x == 0) V.cpart[(size_t)ch * PD * PD + x * dim + y] = s;
+        const double s = wave_sum(acc[x * BD + y]);
+        if (threadIdx.x == 0) V.cpart[(size_t)ch * BD * BD + x * dim + y] = s;
       }
 }
 
 // M_b += Dc^2 on the diagonal, then invert (Gauss-Jordan with partial pivoting); lane per block
+template <int BD>
 __global__ void ba_block_invert_kernel(View V, const double* __restrict__ Dc, const double* __restrict__ M,
                                        double* __restrict__ Minv) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= V.n_blk) return;
   const int n = V.blk_dim[b], off = V.blk_off[b];
-  double A[PD][2 * PD];
-  for (int i = 0; i < PD; ++i)
-    for (int j = 0; j < 2 * PD; ++j) A[i][j] = 0.0;
+  double A[BD][2 * BD];
+  for (int i = 0; i < BD; ++i)
+    for (int j = 0; j < 2 * BD; ++j) A[i][j] = 0.0;
   for (int i = 0; i < n; ++i) {
     for (int j = 0; j < n; ++j) A[i][j] = M[V.blk_moff[b] + i * n + j];
     A[i][i] += Dc[off + i] * Dc[off + i];
-    A[i][PD + i] = 1.0;
+    A[i][BD + i] = 1.0;
   }
   for (int c = 0; c < n; ++c) {
     int piv = c;
     for (int r = c + 1; r < n; ++r)
       if (fabs(A[r][c]) > fabs(A[piv][c])) piv = r;
     if (piv != c)
-      for (int j = 0; j < 2 * PD; ++j) { const double t = A[c][j]; A[c][j] = A[piv][j]; A[piv][j] = t; }
+      for (int j = 0; j < 2 * BD; ++j) { const double t = A[c][j]; A[c][j] = A[piv][j]; A[piv][j] = t; }
     const double inv = 1.0 / A[c][c];
-    for (int j = 0; j < 2 * PD; ++j) A[c][j] *= inv;
+    for (int j = 0; j < 2 * BD; ++j) A[c][j] *= inv;
     for (int r = 0; r < n; ++r) {
       if (r == c) continue;
       const double f = A[r][c];
-      for (int j = 0; j < 2 * PD; ++j) A[r][j] -= f * A[c][j];
+      for (int j = 0; j < 2 * BD; ++j) A[r][j] -= f * A[c][j];
     }
   }
   for (int i = 0; i < n; ++i)
-    for (int j = 0; j < n; ++j) Minv[V.blk_moff[b] + i * n + j] = A[i][PD + j];
+    for (int j = 0; j < n; ++j) Minv[V.blk_moff[b] + i * n + j] = A[i][BD + j];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1069,7 +1110,7 @@ __global__ void ba_apply_cam_kernel(View V, const double* __restrict__ step, con
   for (int c = 0; c < BA_CAM_STRIDE; ++c) out[BA_CAM_STRIDE * (size_t)k + c] = in[BA_CAM_STRIDE * (size_t)k + c];
   const int off = V.cam_off[k];
   if (off < 0) return;
-  for (int d = 0; d < V.cam_dim[k]; ++d) out[BA_CAM_STRIDE * (size_t)k + V.cam_var[KD * k + d]] += step[off + d];
+  for (int d = 0; d < V.cam_dim[k]; ++d) out[BA_CAM_STRIDE * (size_t)k + V.cam_var[V.kd * k + d]] += step[off + d];
 }
 __global__ void ba_apply_point_kernel(View V, const double* __restrict__ step, const double* __restrict__ in,
                                       double* __restrict__ out) {
@@ -1148,6 +1189,7 @@ struct Solver {
   Buf<double> o_xy, poses, cams, points, poses2, cams2, points2, Jpose, Jcam, Jpt, res, res_p, scale_c, scale_p,
       scalars, gc, gp, diag_c, diag_p, Dc, Dp, Cinv, M, Minv, rhs, x, r, z, pdir, q, dp, jx, v, stepc, stepp, partials, cpart, Craw, tbuf, tmpc;
   int moff_total = 0;
+  int kd = 4, bd = PD;  // intrinsics tangent width / widest camera-side block of this problem
   std::vector<int> h_pose_off, h_cam_off, h_pt_off;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
@@ -1174,21 +1216,25 @@ struct Solver {
   int build(ba_result* res_out) {
     const ba_problem& p = prob;
     std::vector<int> cam_nvar(p.num_cams, 0);
-    std::vector<int> h_cam_var((size_t)p.num_cams * KD, 0), h_cam_dim(p.num_cams, 0);
+    std::vector<int> wide_cam_var((size_t)p.num_cams * KD_MAX, 0), h_cam_dim(p.num_cams, 0);
+    int max_nvar = 0;
     for (int k = 0; k < p.num_cams; ++k) {
       const int model = p.cam_model[k];
-      if (model != BA_SIMPLE_PINHOLE && model != BA_PINHOLE && model != BA_SIMPLE_RADIAL && model != BA_RADIAL)
+      if (model != BA_SIMPLE_PINHOLE && model != BA_PINHOLE && model != BA_SIMPLE_RADIAL && model != BA_RADIAL &&
+          model != BA_OPENCV)
         throw std::runtime_error("unsupported camera model id " + std::to_string(model) +
-                                 " (supported: SIMPLE_PINHOLE, PINHOLE, SIMPLE_RADIAL, RADIAL)");
+                                 " (supported: SIMPLE_PINHOLE, PINHOLE, SIMPLE_RADIAL, RADIAL, OPENCV)");
       const int P = num_params_of(model);
       for (int j = 0; j < P; ++j)
-        if (!p.cam_const[(size_t)k * BA_CAM_STRIDE + j]) {
-          if (cam_nvar[k] == KD)
-            throw std::runtime_error("camera " + std::to_string(k) + ": more than " + std::to_string(KD) +
-                                     " variable intrinsics are not supported");
-          h_cam_var[(size_t)k * KD + cam_nvar[k]++] = j;
-        }
+        if (!p.cam_const[(size_t)k * BA_CAM_STRIDE + j]) wide_cam_var[(size_t)k * KD_MAX + cam_nvar[k]++] = j;
+      max_nvar = std::max(max_nvar, cam_nvar[k]);
     }
+    // <KD, BD> of this problem (see the constants at the top of the file)
+    kd = max_nvar <= 4 ? 4 : KD_MAX;
+    bd = max_nvar <= 4 ? PD : KD_MAX;
+    std::vector<int> h_cam_var((size_t)p.num_cams * kd, 0);
+    for (int k = 0; k < p.num_cams; ++k)
+      for (int d = 0; d < cam_nvar[k]; ++d) h_cam_var[(size_t)k * kd + d] = wide_cam_var[(size_t)k * KD_MAX + d];
     std::vector<int64_t> active;
     active.reserve(p.num_obs / comm.world + 1);
     int64_t n_active_global = 0;
@@ -1349,13 +1395,13 @@ struct Solver {
     c2a.upload(h_c2a); a2c.upload(h_a2c); solo.upload(h_solo); tile_pt.upload(h_tile_pt);
     V.n_tiles = (int)h_tile_pt.size() - 1;
     blk_chunk_ptr.upload(h_blk_chunk_ptr);
-    cpart.alloc((size_t)h_chunk_blk.size() * PD * PD);
+    cpart.alloc((size_t)h_chunk_blk.size() * bd * bd);
     poses.upload(std::vector<double>(p.poses, p.poses + 7 * (size_t)p.num_poses));
     cams.upload(std::vector<double>(p.cams, p.cams + BA_CAM_STRIDE * (size_t)p.num_cams));
     points.upload(std::vector<double>(p.points, p.points + 3 * (size_t)p.num_points));
     poses2.alloc(poses.n); cams2.alloc(cams.n); points2.alloc(points.n);
     const size_t N = (size_t)n;
-    Jpose.alloc(2 * PD * N); Jcam.alloc(2 * KD * N); Jpt.alloc(6 * N); res.alloc(2 * N); res_p.alloc(2 * N);
+    Jpose.alloc(2 * PD * N); Jcam.alloc(2 * (size_t)kd * N); Jpt.alloc(6 * N); res.alloc(2 * N); res_p.alloc(2 * N);
     jx.alloc(2 * N); v.alloc(2 * N);
     scale_c.alloc(n_c); scale_p.alloc(poff); gc.alloc(n_c); gp.alloc(poff); diag_c.alloc(n_c); diag_p.alloc(poff);
     Dc.alloc(n_c); Dp.alloc(poff); rhs.alloc(n_c); x.alloc(n_c); r.alloc(n_c); z.alloc(n_c); pdir.alloc(n_c);
@@ -1369,6 +1415,8 @@ struct Solver {
     V.n_c = n_c; V.n_p = poff; V.n_blk = n_blk; V.n_chunks = (int)h_chunk_blk.size();
     V.poses = poses.p; V.cams = cams.p; V.points = points.p;
     V.o_pose = o_pose.p; V.o_cam = o_cam.p; V.o_pt = o_pt.p; V.o_xy = o_xy.p;
+    V.kd = kd;
+    V.bd = bd;
     V.o_sensor = has_sensors ? o_sensor.p : nullptr;
     V.sensors = has_sensors ? sensors.p : nullptr;
     if (opt.loss_type < BA_LOSS_TRIVIAL || opt.loss_type > BA_LOSS_HUBER)
@@ -1393,8 +1441,13 @@ struct Solver {
 
   void launch_linearize(bool jac, const double* P, const double* Cm, const double* X, int slot) {
     const int g = grid_for(V.n_obs, 256);
-    if (jac) BA_LAUNCH(ba_linearize_kernel<true>, dim3(g), dim3(256), st, V, P, Cm, X, partials.p);
-    else BA_LAUNCH(ba_linearize_kernel<false>, dim3(g), dim3(256), st, V, P, Cm, X, partials.p);
+    if (kd == 4) {
+      if (jac) BA_LAUNCH((ba_linearize_kernel<true, 4>), dim3(g), dim3(256), st, V, P, Cm, X, partials.p);
+      else BA_LAUNCH((ba_linearize_kernel<false, 4>), dim3(g), dim3(256), st, V, P, Cm, X, partials.p);
+    } else {
+      if (jac) BA_LAUNCH((ba_linearize_kernel<true, KD_MAX>), dim3(g), dim3(256), st, V, P, Cm, X, partials.p);
+      else BA_LAUNCH((ba_linearize_kernel<false, KD_MAX>), dim3(g), dim3(256), st, V, P, Cm, X, partials.p);
+    }
     BA_LAUNCH(ba_final_sum_kernel, dim3(1), dim3(1024), st, partials.p, g, scalars.p + slot);
   }
 
@@ -1403,7 +1456,8 @@ struct Solver {
     BA_HIP(hipMemsetAsync(gc.p, 0, sizeof(double) * std::max(V.n_c, 1), st));
     BA_HIP(hipMemsetAsync(diag_c.p, 0, sizeof(double) * std::max(V.n_c, 1), st));
     if (V.n_chunks > 0) {
-      BA_LAUNCH(ba_block_jtv_kernel<true>, dim3(V.n_chunks), dim3(64), st, V, res.p, gc.p, diag_c.p);
+      if (bd == PD) BA_LAUNCH((ba_block_jtv_kernel<true, PD>), dim3(V.n_chunks), dim3(64), st, V, res.p, gc.p, diag_c.p);
+      else BA_LAUNCH((ba_block_jtv_kernel<true, KD_MAX>), dim3(V.n_chunks), dim3(64), st, V, res.p, gc.p, diag_c.p);
       BA_LAUNCH(ba_block_vec_finalize_kernel<true>, dim3(grid_for(V.n_blk, 128)), dim3(128), st, V, gc.p, diag_c.p);
     }
     BA_HIP(hipMemsetAsync(gp.p, 0, sizeof(double) * std::max(V.n_p, 1), st));
@@ -1419,7 +1473,8 @@ struct Solver {
   void block_jtv_reduced(const double* vin) {
     BA_HIP(hipMemsetAsync(tmpc.p, 0, sizeof(double) * std::max(V.n_c, 1), st));
     if (V.n_chunks > 0) {
-      BA_LAUNCH(ba_block_jtv_kernel<false>, dim3(V.n_chunks), dim3(64), st, V, vin, tmpc.p, nullptr);
+      if (bd == PD) BA_LAUNCH((ba_block_jtv_kernel<false, PD>), dim3(V.n_chunks), dim3(64), st, V, vin, tmpc.p, nullptr);
+      else BA_LAUNCH((ba_block_jtv_kernel<false, KD_MAX>), dim3(V.n_chunks), dim3(64), st, V, vin, tmpc.p, nullptr);
       BA_LAUNCH(ba_block_vec_finalize_kernel<false>, dim3(grid_for(V.n_blk, 128)), dim3(128), st, V, tmpc.p, nullptr);
     }
     comm.allreduce(tmpc.p, V.n_c, st);
@@ -1437,7 +1492,10 @@ struct Solver {
   // q = S x = (B + Dc^2) x - E C^-1 E^T x
   void schur_multiply(const double* xin, double* qout) {
     const int go = grid_for(V.n_obs, 256);
-    if (V.n_obs > 0) BA_LAUNCH(ba_obs_jx_kernel, dim3(go), dim3(256), st, V, xin, jx.p);
+    if (V.n_obs > 0) {
+      if (kd == 4) BA_LAUNCH(ba_obs_jx_kernel<4>, dim3(go), dim3(256), st, V, xin, jx.p);
+      else BA_LAUNCH(ba_obs_jx_kernel<KD_MAX>, dim3(go), dim3(256), st, V, xin, jx.p);
+    }
     if (comm.world == 1) {
       point_pass<0>();
     } else {
@@ -1501,7 +1559,7 @@ struct Solver {
     const int gvc = grid_for(nc, 256), gvp = grid_for(np, 256);
     g_spmv_ms = 0.0; g_spmv_launches = 0;
     // bytes one implicit-Schur product streams: Jc (2x10) once for jx, Jp (2x3) twice, jx/v, Jc again
-    g_spmv_bytes = (long long)V.n_obs * (2 * (PD + KD) * 8 * 2 + 6 * 8 * 2 + 4 * 8 * 3);
+    g_spmv_bytes = (long long)V.n_obs * (2 * (PD + kd) * 8 * 2 + 6 * 8 * 2 + 4 * 8 * 3);
 
     double radius = opt.initial_trust_region_radius, decrease_factor = 2.0;
     int invalid_steps = 0;
@@ -1565,11 +1623,13 @@ struct Solver {
         if (V.n_chunks > 0) {
           BA_LAUNCH(ba_block_gram_kernel, dim3(V.n_chunks), dim3(64), st, V, M.p);
           BA_LAUNCH(ba_block_mat_finalize_kernel<false>, dim3(grid_for(V.n_blk, 128)), dim3(128), st, V, M.p);
-          BA_LAUNCH(ba_block_schur_corr_kernel, dim3(V.n_chunks), dim3(64), st, V, Cinv.p, M.p);
+          if (bd == PD) BA_LAUNCH(ba_block_schur_corr_kernel<PD>, dim3(V.n_chunks), dim3(64), st, V, Cinv.p, M.p);
+          else BA_LAUNCH(ba_block_schur_corr_kernel<KD_MAX>, dim3(V.n_chunks), dim3(64), st, V, Cinv.p, M.p);
           BA_LAUNCH(ba_block_mat_finalize_kernel<true>, dim3(grid_for(V.n_blk, 128)), dim3(128), st, V, M.p);
         }
         comm.allreduce(M.p, (size_t)moff_total, st);
-        BA_LAUNCH(ba_block_invert_kernel, dim3(grid_for(V.n_blk, 64)), dim3(64), st, V, Dc.p, M.p, Minv.p);
+        if (bd == PD) BA_LAUNCH(ba_block_invert_kernel<PD>, dim3(grid_for(V.n_blk, 64)), dim3(64), st, V, Dc.p, M.p, Minv.p);
+        else BA_LAUNCH(ba_block_invert_kernel<KD_MAX>, dim3(grid_for(V.n_blk, 64)), dim3(64), st, V, Dc.p, M.p, Minv.p);
         // reduced rhs = g_c - E C^-1 g_p  (g_p, C^-1 are global; the J_c^T part is summed over ranks)
         point_pass<1>();
         block_jtv_reduced(v.p);
@@ -1579,7 +1639,10 @@ struct Solver {
         out->total_linear_iterations += lin_iters;
       }
       // back-substitution y_p = C^-1 (g_p - E^T y_c); step = -(y_c, y_p)
-      if (V.n_obs > 0) BA_LAUNCH(ba_obs_jx_kernel, dim3(grid_for(V.n_obs, 256)), dim3(256), st, V, x.p, jx.p);
+      if (V.n_obs > 0) {
+        if (kd == 4) BA_LAUNCH(ba_obs_jx_kernel<4>, dim3(grid_for(V.n_obs, 256)), dim3(256), st, V, x.p, jx.p);
+        else BA_LAUNCH(ba_obs_jx_kernel<KD_MAX>, dim3(grid_for(V.n_obs, 256)), dim3(256), st, V, x.p, jx.p);
+      }
       if (comm.world == 1) {
         point_pass<2>();
       } else {

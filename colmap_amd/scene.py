@@ -22,12 +22,12 @@ from typing import Dict, List, Optional, Tuple
 import numpy as np
 
 # colmap::CameraModelId (sensor/models.h:90-111)
-SIMPLE_PINHOLE, PINHOLE, SIMPLE_RADIAL, RADIAL = 0, 1, 2, 3
-MODEL_NUM_PARAMS = {SIMPLE_PINHOLE: 3, PINHOLE: 4, SIMPLE_RADIAL: 4, RADIAL: 5}
+SIMPLE_PINHOLE, PINHOLE, SIMPLE_RADIAL, RADIAL, OPENCV = 0, 1, 2, 3, 4
+MODEL_NUM_PARAMS = {SIMPLE_PINHOLE: 3, PINHOLE: 4, SIMPLE_RADIAL: 4, RADIAL: 5, OPENCV: 8}
 # FocalLengthIdxs / PrincipalPointIdxs / ExtraParamsIdxs (sensor/models.h)
-MODEL_FOCAL_IDXS = {SIMPLE_PINHOLE: [0], PINHOLE: [0, 1], SIMPLE_RADIAL: [0], RADIAL: [0]}
-MODEL_PP_IDXS = {SIMPLE_PINHOLE: [1, 2], PINHOLE: [2, 3], SIMPLE_RADIAL: [1, 2], RADIAL: [1, 2]}
-MODEL_EXTRA_IDXS = {SIMPLE_PINHOLE: [], PINHOLE: [], SIMPLE_RADIAL: [3], RADIAL: [3, 4]}
+MODEL_FOCAL_IDXS = {SIMPLE_PINHOLE: [0], PINHOLE: [0, 1], SIMPLE_RADIAL: [0], RADIAL: [0], OPENCV: [0, 1]}
+MODEL_PP_IDXS = {SIMPLE_PINHOLE: [1, 2], PINHOLE: [2, 3], SIMPLE_RADIAL: [1, 2], RADIAL: [1, 2], OPENCV: [2, 3]}
+MODEL_EXTRA_IDXS = {SIMPLE_PINHOLE: [], PINHOLE: [], SIMPLE_RADIAL: [3], RADIAL: [3, 4], OPENCV: [4, 5, 6, 7]}
 
 
 @dataclass
@@ -197,6 +197,13 @@ def img_from_cam(model_id: int, params: np.ndarray, uvw: np.ndarray) -> np.ndarr
     if model_id == PINHOLE:
         f1, f2, c1, c2 = params
         return np.stack([f1 * uu + c1, f2 * vv + c2], 1)
+    if model_id == OPENCV:  # sensor/models.h OpenCVCameraModel::ImgFromCam / Distortion
+        f1, f2, c1, c2, k1, k2, p1, p2 = params
+        r2 = uu * uu + vv * vv
+        radial = k1 * r2 + k2 * r2 * r2
+        du = uu * radial + 2 * p1 * uu * vv + p2 * (r2 + 2 * uu * uu)
+        dv = vv * radial + 2 * p2 * uu * vv + p1 * (r2 + 2 * vv * vv)
+        return np.stack([f1 * (uu + du) + c1, f2 * (vv + dv) + c2], 1)
     if model_id == RADIAL:
         f, c1, c2, k1, k2 = params
         r2 = uu * uu + vv * vv

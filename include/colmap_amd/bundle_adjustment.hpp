@@ -84,7 +84,7 @@ inline Rigid3d Compose(const Rigid3d& a, const Rigid3d& b) {
 }
 
 // CameraModelId (sensor/models.h:90-111): the models the MI355X backend supports.
-enum class CameraModelId : int { SIMPLE_PINHOLE = 0, PINHOLE = 1, SIMPLE_RADIAL = 2, RADIAL = 3 };
+enum class CameraModelId : int { SIMPLE_PINHOLE = 0, PINHOLE = 1, SIMPLE_RADIAL = 2, RADIAL = 3, OPENCV = 4 };
 
 struct CameraModelInfo {
   int num_params;
@@ -92,11 +92,12 @@ struct CameraModelInfo {
 };
 
 inline const CameraModelInfo* GetCameraModelInfo(int model_id) {
-  static const CameraModelInfo kInfos[4] = {{3, {0}, {1, 2}, {}},
+  static const CameraModelInfo kInfos[5] = {{3, {0}, {1, 2}, {}},
                                             {4, {0, 1}, {2, 3}, {}},
                                             {4, {0}, {1, 2}, {3}},
-                                            {5, {0}, {1, 2}, {3, 4}}};
-  return (model_id >= 0 && model_id < 4) ? &kInfos[model_id] : nullptr;
+                                            {5, {0}, {1, 2}, {3, 4}},
+                                            {8, {0, 1}, {2, 3}, {4, 5, 6, 7}}};
+  return (model_id >= 0 && model_id < 5) ? &kInfos[model_id] : nullptr;
 }
 
 struct Camera {  // scene/camera.h

@@ -41,7 +41,7 @@
 #define BAO_CAM_STRIDE 12
 
 /* COLMAP CameraModelId values (sensor/models.h:90-111) */
-enum { BAO_SIMPLE_PINHOLE = 0, BAO_PINHOLE = 1, BAO_SIMPLE_RADIAL = 2, BAO_RADIAL = 3 };
+enum { BAO_SIMPLE_PINHOLE = 0, BAO_PINHOLE = 1, BAO_SIMPLE_RADIAL = 2, BAO_RADIAL = 3, BAO_OPENCV = 4 };
 
 typedef struct {
   int32_t num_poses, num_cams, num_points;
@@ -157,6 +157,7 @@ static int num_params_of(int model) {
     case BAO_PINHOLE: return 4;
     case BAO_SIMPLE_RADIAL: return 4;
     case BAO_RADIAL: return 5;
+    case BAO_OPENCV: return 8;
     default: return -1;
   }
 }
@@ -194,6 +195,42 @@ static int img_from_cam_jac(int model, const double* params, double u, double v,
     if (J_params) {
       J_params[0] = uu; J_params[1] = 0.0; J_params[2] = 1.0; J_params[3] = 0.0;
       J_params[4] = 0.0; J_params[5] = vv; J_params[6] = 0.0; J_params[7] = 1.0;
+    }
+    return 1;
+  }
+  if (model == BAO_OPENCV) { /* models_jacobian.h:401-496 */
+    const double f1 = params[0], f2 = params[1], c1 = params[2], c2 = params[3];
+    const double k1 = params[4], k2 = params[5], p1 = params[6], p2 = params[7];
+    const double uu2 = uu * uu, vv2 = vv * vv, uv = uu * vv;
+    const double r2 = uu2 + vv2;
+    const double r4 = r2 * r2;
+    const double radial = k1 * r2 + k2 * r4;
+    const double du = uu * radial + 2.0 * p1 * uv + p2 * (r2 + 2.0 * uu2);
+    const double dv = vv * radial + 2.0 * p2 * uv + p1 * (r2 + 2.0 * vv2);
+    const double xd = uu + du, yd = vv + dv;
+    *x = f1 * xd + c1;
+    *y = f2 * yd + c2;
+    if (J_uvw) {
+      const double d_radial_d_r2 = k1 + 2.0 * k2 * r2;
+      const double cross = 2.0 * uv * d_radial_d_r2;
+      const double du_duu = radial + 2.0 * uu2 * d_radial_d_r2 + 2.0 * p1 * vv + 6.0 * p2 * uu;
+      const double du_dvv = cross + 2.0 * p1 * uu + 2.0 * p2 * vv;
+      const double dv_duu = cross + 2.0 * p2 * vv + 2.0 * p1 * uu;
+      const double dv_dvv = radial + 2.0 * vv2 * d_radial_d_r2 + 2.0 * p2 * uu + 6.0 * p1 * vv;
+      const double a00 = f1 * (1.0 + du_duu);
+      const double a01 = f1 * du_dvv;
+      const double a10 = f2 * dv_duu;
+      const double a11 = f2 * (1.0 + dv_dvv);
+      J_uvw[0] = a00 * inv_w; J_uvw[1] = a01 * inv_w; J_uvw[2] = -(a00 * uu + a01 * vv) * inv_w;
+      J_uvw[3] = a10 * inv_w; J_uvw[4] = a11 * inv_w; J_uvw[5] = -(a10 * uu + a11 * vv) * inv_w;
+    }
+    if (J_params) {
+      J_params[0] = xd; J_params[1] = 0.0; J_params[2] = 1.0; J_params[3] = 0.0;
+      J_params[4] = f1 * uu * r2; J_params[5] = f1 * uu * r4; J_params[6] = f1 * 2.0 * uv;
+      J_params[7] = f1 * (r2 + 2.0 * uu2);
+      J_params[8] = 0.0; J_params[9] = yd; J_params[10] = 0.0; J_params[11] = 1.0;
+      J_params[12] = f2 * vv * r2; J_params[13] = f2 * vv * r4; J_params[14] = f2 * (r2 + 2.0 * vv2);
+      J_params[15] = f2 * 2.0 * uv;
     }
     return 1;
   }
@@ -414,7 +451,7 @@ static void quat_plus_jac(const double* q, double J[12]) {
 /* Program: tangent-space layout of the variable blocks                        */
 /* ------------------------------------------------------------------------- */
 
-#define MAX_CB 12 /* max tangent width of the camera-side blocks seen by one residual: 6 + P_t */
+#define MAX_CB 14 /* max tangent width of the camera-side blocks seen by one residual: 6 + P_t (P_t <= 8) */
 
 typedef struct {
   const bao_problem* p;

@@ -473,3 +473,46 @@ def test_robust_cost_matches_scipy_least_squares():
         x = ba.problem_.points.ravel().copy()
         g = scipy.optimize.approx_fprime(x, total, 1e-7)
         assert np.abs(g).max() < 1e-3 * max(1.0, s.final_cost)
+
+
+def test_opencv_model_values_and_jacobians():
+    # models_jacobian.h:401-496; forward model = OpenCVCameraModel::ImgFromCam (sensor/models.h)
+    rng = np.random.default_rng(5)
+    params = [640.0, 655.0, 320, 240, 0.08, -0.03, 0.002, -0.001]
+    pose = np.array([0, 0, 0, 1, 0, 0, 0.0])
+    for _ in range(20):
+        pt = np.array([rng.normal() * 0.6, rng.normal() * 0.6, 3 + rng.random()])
+        r0, Jpt, Jpose, Jpar = ba_oracle.reproj_error(scene.OPENCV, pt, pose, params, [0, 0])
+        np.testing.assert_allclose(r0, scene.img_from_cam(scene.OPENCV, np.array(params), pt[None])[0], rtol=1e-13)
+        def f(v):
+            return ba_oracle.reproj_error(scene.OPENCV, v[:3], pose, v[3:], [0, 0], want_jac=False)[0]
+        x0 = np.concatenate([pt, params])
+        J = np.zeros((2, len(x0)))
+        for i in range(len(x0)):
+            h = 1e-6 * max(1.0, abs(x0[i]))
+            e = np.zeros(len(x0)); e[i] = h
+            J[:, i] = (f(x0 + e) - f(x0 - e)) / (2 * h)
+        np.testing.assert_allclose(Jpt, J[:, :3], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(Jpar, J[:, 3:], rtol=1e-5, atol=2e-5)
+
+
+def test_opencv_cameras_six_variable_intrinsics():
+    """OPENCV with COLMAP's default refinement (focal + extra, principal point fixed): six variable
+    intrinsics per camera (fx fy k1 k2 p1 p2) -- wider than the pose blocks' neighbours in the tangent vector."""
+    rec = scene.SynthesizeDataset(scene.SyntheticDatasetOptions(
+        num_rigs=3, num_frames_per_rig=4, num_points3D=200, camera_model_id=scene.OPENCV,
+        camera_params=(1280.0, 1290.0, 512.0, 384.0, 0.05, -0.01, 0.001, -0.002)), seed=2)
+    gt = rec.copy()
+    scene.SynthesizeNoise(scene.SyntheticNoiseOptions(point2D_stddev=0.3, point3D_stddev=0.05), rec, seed=3)
+    for c in rec.cameras.values():
+        c.params = c.params * np.array([1.01, 0.99, 1, 1, 1.2, 0.8, 1.3, 0.7])
+    ba = est.BundleAdjuster(est.BundleAdjustmentOptions(), _config(rec), rec, solve_fn=ba_oracle.solve_fn)
+    fp = ba.problem_
+    assert (fp.cam_const[:, :8] == [0, 0, 1, 1, 0, 0, 0, 0]).all()
+    s = ba.Solve()
+    assert s.IsSolutionUsable() and s.final_cost < 0.05 * s.initial_cost
+    # 200 points x 3 + 12 frames (6 x 10 + 5, one constant) + 3 cameras x 6
+    assert s.num_effective_parameters == 3 * len(fp.points) + 6 * 10 + 5 + 18
+    for cid, c in rec.cameras.items():
+        np.testing.assert_allclose(c.params[:2], gt.cameras[cid].params[:2], rtol=2e-3)
+        assert not np.array_equal(c.params[4:], gt.cameras[cid].params[4:] * [1.2, 0.8, 1.3, 0.7])  # distortion moved
