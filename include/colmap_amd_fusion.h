@@ -1,0 +1,71 @@
+/*
+ * colmap_amd_fusion.h -- C ABI of the depth-map fusion step that consumes the PatchMatch output
+ * (SURVEY.md section 8f row 3).
+ *
+ * Replaces colmap::mvs::StereoFusion::Run / Fuse (reference src/colmap/mvs/fusion.cc:135-524) for
+ * inputs that are already in memory: the caller (colmap_amd/fusion.py, the `stereo_fusion` command)
+ * does the workspace reading the reference does through mvs::Workspace. Host code, like the
+ * reference's: one thread, i.e. the reference's behaviour with StereoFusionOptions::num_threads = 1
+ * (with more threads the reference's result depends on the thread interleaving).
+ */
+#ifndef COLMAP_AMD_FUSION_H_
+#define COLMAP_AMD_FUSION_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* colmap::mvs::StereoFusionOptions (mvs/fusion.h:46-94); the workspace-side fields (mask_path,
+ * num_threads, max_image_size, use_cache, cache_size) stay with the caller. */
+typedef struct fusion_options {
+  int32_t min_num_pixels;      /* 5 */
+  int32_t max_num_pixels;      /* 10000 */
+  int32_t max_traversal_depth; /* 100 */
+  int32_t check_num_images;    /* 50 (used by the caller to build the overlap lists) */
+  double max_reproj_error;     /* 2 px */
+  double max_depth_error;      /* 0.01 relative */
+  double max_normal_error;     /* 10 degrees */
+  float bbox_min[3], bbox_max[3]; /* -FLT_MAX / FLT_MAX */
+} fusion_options;
+
+/* One workspace image: mvs::Image pose at the MODEL image size, its colour bitmap, and the depth /
+ * normal maps (Mat<float>, normal slice-major) at the depth-map size. used = 0 skips the image
+ * (fusion.cc:204-213). mask: optional depth-map-sized bytes, non-zero = pre-masked pixel (:374-399). */
+typedef struct fusion_image {
+  int32_t width, height;
+  float K[9], R[9], T[3];
+  const uint8_t* rgb; /* bitmap_height * bitmap_width * 3, or NULL (colour 0) */
+  int32_t bitmap_width, bitmap_height;
+  const float* depth_map;
+  const float* normal_map;
+  int32_t depth_width, depth_height;
+  const uint8_t* mask;
+  int32_t used;
+} fusion_image;
+
+typedef struct fusion_result fusion_result;
+
+void fusion_options_init(fusion_options* options);
+/* StereoFusionOptions::Check (fusion.cc:96-106): 0 = valid. */
+int fusion_options_check(const fusion_options* options);
+
+/* overlapping images of image i: overlap_idx[overlap_ptr[i] .. overlap_ptr[i+1])
+ * (Model::GetMaxOverlappingImages(check_num_images, 0), fusion.cc:180-186). */
+int fusion_run(const fusion_options* options, int32_t num_images, const fusion_image* images,
+               const int32_t* overlap_ptr, const int32_t* overlap_idx, fusion_result** out);
+
+size_t fusion_num_points(const fusion_result* r);
+/* PlyPoint fields: xyz_normal [n][6] floats, rgb [n][3] */
+int fusion_get_points(const fusion_result* r, float* xyz_normal, uint8_t* rgb);
+/* visibility (fusion.cc:514-517): vis_ptr [n+1], vis_idx [vis_ptr[n]]; pass NULLs to query the total */
+int fusion_get_visibility(const fusion_result* r, int64_t* vis_ptr, int32_t* vis_idx, size_t* total);
+void fusion_free(fusion_result* r);
+const char* fusion_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COLMAP_AMD_FUSION_H_ */

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared(header):
     text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b((?:pm|ba)_[a-z0-9_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b((?:pm|ba|fusion)_[a-z0-9_]+)\s*\(", text)))
 
 
 @pytest.fixture(scope="module")
@@ -22,7 +22,7 @@ def lib():
     return ctypes.CDLL(build.LIB_PATH)
 
 
-@pytest.mark.parametrize("header", [h for h in ("colmap_amd_pm.h", "colmap_amd_ba.h")
+@pytest.mark.parametrize("header", [h for h in ("colmap_amd_pm.h", "colmap_amd_ba.h", "colmap_amd_fusion.h")
                                     if os.path.exists(os.path.join(ROOT, "include", h))])
 def test_exports_every_declared_symbol(lib, header):
     names = _declared(header)

@@ -1,0 +1,291 @@
+"""Depth-map fusion (colmap_amd/fusion.py + colmap_amd/csrc/fusion.cpp) against a pure-Python float32
+restatement of StereoFusion::Fuse (reference mvs/fusion.cc:401-524) and against the ground truth of
+the synthetic renderer. Host code only: no GPU."""
+import os
+
+import numpy as np
+import pytest
+
+from colmap_amd import fusion, mvs, workspace as W
+from pm_common import scene, write_dense_workspace
+
+f32 = np.float32
+
+
+def _images(views, with_rgb=True):
+    out = []
+    for v in views:
+        h, w = v.gray.shape
+        rgb = np.stack([v.gray, 255 - v.gray, (v.gray // 2)], -1) if with_rgb else None
+        out.append(fusion.FusionImage(w, h, v.K, v.R, v.T, rgb, v.depth.copy(), v.normal.copy()))
+    return out
+
+
+def _overlap(n):
+    return [[j for j in range(n) if j != i] for i in range(n)]
+
+
+def _median(vals):
+    v = np.sort(np.asarray(vals, np.float64))
+    idx = 0.5 * (len(v) - 1)
+    lo, hi = int(np.floor(idx)), int(np.ceil(idx))
+    return v[hi] if lo == hi else (hi - idx) * v[lo] + (idx - lo) * v[hi]
+
+
+def _fuse_reference(opt, images, overlap):
+    """fusion.cc:188-524 in float32 scalar arithmetic, one thread."""
+    n = len(images)
+    P, iP, iR, masks = [], [], [], []
+    for im in images:
+        K = np.asarray(im.K, f32).reshape(3, 3).copy()
+        R = np.asarray(im.R, f32).reshape(3, 3)
+        T = np.asarray(im.T, f32).reshape(3)
+        dh, dw = im.depth_map.shape
+        sx, sy = f32(dw) / f32(im.width), f32(dh) / f32(im.height)
+        K[0, 0] *= sx; K[0, 2] *= sx; K[1, 1] *= sy; K[1, 2] *= sy
+        RT = np.concatenate([R, T[:, None]], 1)
+        Pm = np.zeros((3, 4), f32)
+        for r in range(3):
+            for c in range(4):
+                Pm[r, c] = f32(f32(K[r, 0] * RT[0, c]) + f32(K[r, 1] * RT[1, c])) + f32(K[r, 2] * RT[2, c])
+        a, b, c_, d, e, f_, g, h, i = [f32(x) for x in Pm[:, :3].ravel()]
+        A = f32(e * i) - f32(f_ * h); B = -(f32(d * i) - f32(f_ * g)); Cc = f32(d * h) - f32(e * g)
+        det = f32(f32(a * A) + f32(b * B)) + f32(c_ * Cc)
+        inv_det = f32(1.0) / det
+        Mi = np.array([[A * inv_det, -(f32(b * i) - f32(c_ * h)) * inv_det, (f32(b * f_) - f32(c_ * e)) * inv_det],
+                       [B * inv_det, (f32(a * i) - f32(c_ * g)) * inv_det, -(f32(a * f_) - f32(c_ * d)) * inv_det],
+                       [Cc * inv_det, -(f32(a * h) - f32(b * g)) * inv_det, (f32(a * e) - f32(b * d)) * inv_det]], f32)
+        inv = np.zeros((3, 4), f32)
+        inv[:, :3] = Mi
+        for r in range(3):
+            inv[r, 3] = -(f32(f32(Mi[r, 0] * Pm[0, 3]) + f32(Mi[r, 1] * Pm[1, 3])) + f32(Mi[r, 2] * Pm[2, 3]))
+        P.append(Pm); iP.append(inv); iR.append(R.T.copy())
+        masks.append(np.zeros((dh, dw), bool) if im.mask is None else (np.asarray(im.mask) != 0))
+    max_sq = f32(opt.max_reproj_error * opt.max_reproj_error)
+    min_cos = f32(np.cos(opt.max_normal_error * 0.017453292519943295769))
+    used = [im.used for im in images]
+    fused = [False] * n
+    pts, nrm, col, vis = [], [], [], []
+
+    def dot4(row, x):
+        return f32(f32(f32(row[0] * x[0]) + f32(row[1] * x[1])) + f32(row[2] * x[2])) + f32(row[3] * x[3])
+
+    def fuse_pixel(i0, r0, c0):
+        queue = [(i0, r0, c0, 0)]
+        ref_pt = np.zeros(4, f32); ref_n = np.zeros(3, f32)
+        acc = [[] for _ in range(9)]
+        seen = set()
+        while queue:
+            ii, row, cc, lvl = queue.pop()
+            im = images[ii]
+            if masks[ii][row, cc]:
+                continue
+            depth = f32(im.depth_map[row, cc])
+            if depth <= 0:
+                continue
+            if lvl > 0:
+                proj = [dot4(P[ii][r], ref_pt) for r in range(3)]
+                if abs(f32(f32(proj[2] - depth) / depth)) > opt.max_depth_error:
+                    continue
+                cd = f32(f32(proj[0] / proj[2]) - f32(cc)); rd = f32(f32(proj[1] / proj[2]) - f32(row))
+                if f32(f32(cd * cd) + f32(rd * rd)) > max_sq:
+                    continue
+            nl = [f32(im.normal_map[k, row, cc]) for k in range(3)]
+            normal = np.array([f32(f32(f32(iR[ii][r, 0] * nl[0]) + f32(iR[ii][r, 1] * nl[1])) + f32(iR[ii][r, 2] * nl[2]))
+                               for r in range(3)], f32)
+            if lvl > 0:
+                cosn = f32(f32(f32(ref_n[0] * normal[0]) + f32(ref_n[1] * normal[1])) + f32(ref_n[2] * normal[2]))
+                if cosn < min_cos:
+                    continue
+            hx, hy = f32(f32(cc) * depth), f32(f32(row) * depth)
+            xyz = np.array([f32(f32(f32(f32(iP[ii][r, 0] * hx) + f32(iP[ii][r, 1] * hy)) + f32(iP[ii][r, 2] * depth)) +
+                                f32(iP[ii][r, 3] * f32(1))) for r in range(3)], f32)
+            color = (0, 0, 0)
+            if im.rgb is not None:
+                dh, dw = im.depth_map.shape
+                sx, sy = f32(dw) / f32(im.width), f32(dh) / f32(im.height)
+                xx = int(np.floor(float(f32(cc) / sx) + 0.5)); yy = int(np.floor(float(f32(row) / sy) + 0.5))
+                if 0 <= xx < im.rgb.shape[1] and 0 <= yy < im.rgb.shape[0]:
+                    color = tuple(int(v) for v in im.rgb[yy, xx])
+            masks[ii][row, cc] = True
+            lo, hi = opt.bounding_box
+            if any(xyz[k] < f32(lo[k]) or xyz[k] > f32(hi[k]) for k in range(3)):
+                continue
+            for k in range(3):
+                acc[k].append(xyz[k]); acc[3 + k].append(normal[k]); acc[6 + k].append(color[k])
+            seen.add(ii)
+            if lvl == 0:
+                ref_pt = np.array([xyz[0], xyz[1], xyz[2], 1], f32); ref_n = normal
+            if len(acc[0]) >= opt.max_num_pixels:
+                break
+            if lvl >= opt.max_traversal_depth - 1:
+                continue
+            for nxt in overlap[ii]:
+                if not used[nxt] or fused[nxt]:
+                    continue
+                x4 = np.array([xyz[0], xyz[1], xyz[2], 1], f32)
+                npj = [f32(f32(f32(f32(P[nxt][r, 0] * x4[0]) + f32(P[nxt][r, 1] * x4[1])) + f32(P[nxt][r, 2] * x4[2])) + P[nxt][r, 3])
+                       for r in range(3)]
+                with np.errstate(all="ignore"):
+                    qc, qr = f32(npj[0] / npj[2]), f32(npj[1] / npj[2])
+                if not (np.isfinite(qc) and np.isfinite(qr)):
+                    continue
+                ncol = int(np.floor(float(qc) + 0.5)) if qc >= 0 else -int(np.floor(-float(qc) + 0.5))
+                nrow = int(np.floor(float(qr) + 0.5)) if qr >= 0 else -int(np.floor(-float(qr) + 0.5))
+                dh2, dw2 = images[nxt].depth_map.shape
+                if ncol < 0 or nrow < 0 or ncol >= dw2 or nrow >= dh2:
+                    continue
+                queue.append((nxt, nrow, ncol, lvl + 1))
+        if len(acc[0]) < opt.min_num_pixels:
+            return
+        fn = np.array([f32(_median(acc[3 + k])) for k in range(3)], f32)
+        norm = f32(np.sqrt(f32(f32(f32(fn[0] * fn[0]) + f32(fn[1] * fn[1])) + f32(fn[2] * fn[2]))))
+        if norm < np.finfo(f32).eps:
+            return
+        pts.append([f32(_median(acc[k])) for k in range(3)])
+        nrm.append([f32(fn[k] / norm) for k in range(3)])
+        col.append([int(min(255, max(0, np.floor(float(f32(_median(acc[6 + k]))) + 0.5)))) for k in range(3)])
+        vis.append(sorted(seen))
+
+    idx = 0
+    while idx >= 0:
+        if used[idx]:
+            dh, dw = images[idx].depth_map.shape
+            for r in range(dh):
+                for c in range(dw):
+                    fuse_pixel(idx, r, c)
+        fused[idx] = True
+        nxt = -1
+        for j in overlap[idx]:
+            if used[j] and not fused[j]:
+                nxt = j
+                break
+        if nxt < 0:
+            nxt = next((j for j in range(n) if used[j] and not fused[j]), -1)
+        idx = nxt
+    return np.array(pts, f32).reshape(-1, 3), np.array(nrm, f32).reshape(-1, 3), np.array(col, np.uint8).reshape(-1, 3), vis
+
+
+def test_fusion_equals_python_restatement():
+    views = scene(4, 32, 24)
+    images = _images(views)
+    opt = fusion.StereoFusionOptions(min_num_pixels=3, max_reproj_error=1.5, max_depth_error=0.02)
+    got = fusion.fuse(opt, images, _overlap(4))
+    wp, wn, wc, wv = _fuse_reference(opt, _images(views), _overlap(4))
+    assert len(got.xyz) == len(wp) > 50
+    assert np.array_equal(got.xyz, wp) and np.array_equal(got.normal, wn) and np.array_equal(got.rgb, wc)
+    assert all(list(a) == b for a, b in zip(got.visibility, wv))
+    # deterministic
+    again = fusion.fuse(opt, _images(views), _overlap(4))
+    assert np.array_equal(again.xyz, got.xyz)
+
+
+def test_fused_points_lie_on_the_ground_truth_surface():
+    views = scene(5, 64, 48)
+    got = fusion.fuse(fusion.StereoFusionOptions(), _images(views), _overlap(5))
+    assert len(got.xyz) > 300
+    np.testing.assert_allclose(np.linalg.norm(got.normal, axis=1), 1.0, atol=1e-5)
+    # every fused point reprojects onto the ground-truth depth of the images that saw it
+    checked = 0
+    for p, vis in zip(got.xyz, got.visibility):
+        assert len(vis) >= 1 and len(set(vis)) == len(vis)
+        for i in vis:
+            v = views[i]
+            pc = np.asarray(v.R, np.float64) @ p + np.asarray(v.T, np.float64)
+            px = np.asarray(v.K, np.float64) @ (pc / pc[2])
+            c, r = int(round(px[0])), int(round(px[1]))
+            if 1 <= c < 63 and 1 <= r < 47:
+                d = v.depth[r - 1:r + 2, c - 1:c + 2]
+                assert np.min(np.abs(d - pc[2]) / pc[2]) < 0.03
+                checked += 1
+    assert checked > 500
+    # each pixel is consumed at most once: fused pixels <= valid pixels
+    assert sum(len(v) for v in got.visibility) <= 5 * len(got.xyz)
+
+
+def test_fusion_options_masks_and_bounding_box():
+    views = scene(4, 48, 36)
+    base = fusion.fuse(fusion.StereoFusionOptions(min_num_pixels=2), _images(views), _overlap(4))
+    # a higher minimum support yields a subset-sized result
+    strict = fusion.fuse(fusion.StereoFusionOptions(min_num_pixels=4), _images(views), _overlap(4))
+    assert 0 < len(strict.xyz) < len(base.xyz)
+    assert all(len(v) >= 1 for v in strict.visibility)
+    # bounding box: no point outside
+    lo, hi = (-0.3, -0.3, -10.0), (0.3, 0.3, 10.0)
+    boxed = fusion.fuse(fusion.StereoFusionOptions(min_num_pixels=2, bounding_box=(lo, hi)), _images(views), _overlap(4))
+    assert 0 < len(boxed.xyz) < len(base.xyz)
+    assert (boxed.xyz >= np.array(lo, np.float32) - 1e-3).all() and (boxed.xyz <= np.array(hi, np.float32) + 1e-3).all()
+    # masking all of image 0 removes it from every visibility list
+    imgs = _images(views)
+    imgs[0].mask = np.ones(views[0].gray.shape, np.uint8)
+    masked = fusion.fuse(fusion.StereoFusionOptions(min_num_pixels=2), imgs, _overlap(4))
+    assert all(0 not in v for v in masked.visibility) and len(masked.xyz) > 0
+    # an unused image (missing inputs) is skipped the same way
+    imgs = _images(views)
+    imgs[0].used = False
+    skipped = fusion.fuse(fusion.StereoFusionOptions(min_num_pixels=2), imgs, _overlap(4))
+    assert all(0 not in v for v in skipped.visibility)
+    # non-positive depths are never fused
+    imgs = _images(views)
+    for im in imgs:
+        im.depth_map[:] = 0
+    assert len(fusion.fuse(fusion.StereoFusionOptions(), imgs, _overlap(4)).xyz) == 0
+    # option checks (fusion.cc:96-106)
+    assert not fusion.StereoFusionOptions(min_num_pixels=10, max_num_pixels=5).Check()
+    assert not fusion.StereoFusionOptions(max_traversal_depth=0).Check()
+    with pytest.raises(ValueError):
+        fusion.fuse(fusion.StereoFusionOptions(check_num_images=0), _images(views), _overlap(4))
+    # max_num_pixels caps the support of a point
+    capped = fusion.fuse(fusion.StereoFusionOptions(min_num_pixels=2, max_num_pixels=2), _images(views), _overlap(4))
+    assert len(capped.xyz) > 0 and max(len(v) for v in capped.visibility) <= 2
+
+
+def test_ply_and_visibility_files(tmp_path):
+    pts = fusion.FusedPoints(np.arange(12, dtype=np.float32).reshape(4, 3), np.eye(4, 3, dtype=np.float32),
+                             np.arange(12, dtype=np.uint8).reshape(4, 3), [np.array([0, 2]), np.array([1]), np.array([], int), np.array([3, 4, 5])])
+    p = str(tmp_path / "fused.ply")
+    fusion.write_binary_ply_points(p, pts)
+    raw = open(p, "rb").read()
+    assert raw.startswith(b"ply\nformat binary_little_endian 1.0\nelement vertex 4\nproperty float x\n")
+    assert len(raw.split(b"end_header\n", 1)[1]) == 4 * (6 * 4 + 3)          # util/ply.cc:412-428
+    back = fusion.read_binary_ply_points(p)
+    assert np.array_equal(back.xyz, pts.xyz) and np.array_equal(back.normal, pts.normal) and np.array_equal(back.rgb, pts.rgb)
+    fusion.write_points_visibility(p + ".vis", pts.visibility)
+    assert os.path.getsize(p + ".vis") == 8 + 4 * 4 + 4 * 6                  # fusion.cc:526-541
+    vis = fusion.read_points_visibility(p + ".vis", 4)
+    assert all(np.array_equal(a, b) for a, b in zip(vis, pts.visibility))
+    with pytest.raises(ValueError):
+        fusion.read_points_visibility(p + ".vis", 5)
+
+
+def test_stereo_fusion_command_on_a_workspace(tmp_path):
+    """exe/mvs.cc:299-386: workspace with geometric maps + fusion.cfg -> fused.ply + fused.ply.vis."""
+    views = scene(5, 64, 48)
+    ws = str(tmp_path / "dense")
+    names = write_dense_workspace(ws, views)
+    w = W.Workspace(ws)
+    for i, v in enumerate(views):
+        for path, arr in ((w.GetDepthMapPath(i, "geometric"), v.depth), (w.GetNormalMapPath(i, "geometric"), v.normal)):
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            mvs.write_mat(path, arr)
+    with open(os.path.join(ws, "stereo", "fusion.cfg"), "w") as f:
+        f.write("\n".join(names[:4]) + "\nmissing.png\n" if False else "\n".join(names[:4]) + "\n")
+    out = str(tmp_path / "fused.ply")
+    assert fusion.main(["--workspace_path", ws, "--output_path", out, "--StereoFusion.min_num_pixels", "3"]) == 0
+    pts = fusion.read_binary_ply_points(out)
+    vis = fusion.read_points_visibility(out + ".vis", len(pts.xyz))
+    assert len(pts.xyz) > 200 and all(set(v) <= {0, 1, 2, 3} for v in vis)      # image 4 is not in fusion.cfg
+    # grey images: r = g = b = the bitmap value at the pixel
+    assert (pts.rgb[:, 0] == pts.rgb[:, 1]).all() and (pts.rgb[:, 1] == pts.rgb[:, 2]).all()
+    # the same through the class, and as a model (output_type BIN): sparse points replaced by the fused ones
+    fuser = fusion.StereoFusion(fusion.StereoFusionOptions(min_num_pixels=3), ws)
+    fuser.Run()
+    assert np.array_equal(fuser.GetFusedPoints().xyz, pts.xyz)
+    out_model = str(tmp_path / "fused_model")
+    assert fusion.main(["--workspace_path", ws, "--output_path", out_model, "--output_type", "BIN",
+                        "--StereoFusion.min_num_pixels", "3"]) == 0
+    sm = W.read_sparse_model(out_model)
+    assert len(sm.points3D) == len(pts.xyz) and len(sm.images) == 5
+    np.testing.assert_array_equal(sm.points3D[1].xyz.astype(np.float32), pts.xyz[0])
+    with pytest.raises(SystemExit):
+        fusion.main(["--workspace_path", ws, "--output_path", out, "--input_type", "depth"])
