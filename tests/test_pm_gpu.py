@@ -360,6 +360,26 @@ def test_patch_match_stereo_cli_on_a_workspace(tmp_path):
         assert (gw, gh) == (96, 72) and len(graph) == int(kept.sum())
         # every filtered-in pixel lists >= filter_min_num_consistent source images of this problem
         assert min(len(v) for v in graph.values()) >= 2
+    # the consumer of the maps: stereo_fusion on the same workspace (exe/mvs.cc:299-386)
+    from colmap_amd import fusion
+    from colmap_amd.__main__ import main as colmap_amd_main
+    with open(os.path.join(ws, "stereo", "fusion.cfg"), "w") as f:
+        f.write("\n".join(names) + "\n")
+    ply = os.path.join(ws, "fused.ply")
+    assert colmap_amd_main(["stereo_fusion", "--workspace_path", ws, "--output_path", ply,
+                            "--StereoFusion.min_num_pixels", "3"]) == 0
+    pts = fusion.read_binary_ply_points(ply)
+    vis = fusion.read_points_visibility(ply + ".vis", len(pts.xyz))
+    assert len(pts.xyz) > 100
+    errs = []
+    for p, v in zip(pts.xyz[::5], vis[::5]):        # fused points sit on the rendered surfaces
+        i = int(v[0])
+        pc = np.asarray(views[i].R, np.float64) @ p + np.asarray(views[i].T, np.float64)
+        px = np.asarray(views[i].K, np.float64) @ (pc / pc[2])
+        c, r = int(round(px[0])), int(round(px[1]))
+        if 0 <= c < 96 and 0 <= r < 72:
+            errs.append(abs(views[i].depth[r, c] - pc[2]) / pc[2])
+    assert len(errs) > 10 and np.median(errs) < 0.02
     # second invocation: everything exists -> nothing recomputed, files untouched
     before = {p: os.path.getmtime(p) for p in [w.GetDepthMapPath(i, "geometric") for i in range(len(names))]}
     assert cli.main(["--workspace_path", ws, "--PatchMatchStereo.gpu_index", "0",
