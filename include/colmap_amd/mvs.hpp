@@ -26,6 +26,7 @@
 #include <string>
 #include <vector>
 
+#include "../colmap_amd_fusion.h"
 #include "../colmap_amd_pm.h"
 
 namespace colmap_amd {
@@ -517,6 +518,129 @@ class PatchMatch {
   const PatchMatchOptions options_;
   const Problem problem_;
   pm_handle* handle_ = nullptr;
+};
+
+// ---------------------------------------------------------------------------------------------
+// Depth-map fusion (reference mvs/fusion.h:46-139, fusion.cc) on in-memory inputs. The workspace
+// reading of StereoFusion::Run stays with the caller; the traversal is the reference's with one thread.
+// ---------------------------------------------------------------------------------------------
+struct StereoFusionOptions {  // fusion.h:46-94 (the fields that reach the traversal)
+  int min_num_pixels = 5;
+  int max_num_pixels = 10000;
+  int max_traversal_depth = 100;
+  double max_reproj_error = 2.0f;
+  double max_depth_error = 0.01f;
+  double max_normal_error = 10.0f;
+  int check_num_images = 50;
+  float bounding_box_min[3] = {-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f};
+  float bounding_box_max[3] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f};
+
+  bool Check() const {  // fusion.cc:96-106
+    return min_num_pixels >= 0 && min_num_pixels <= max_num_pixels && max_traversal_depth > 0 &&
+           max_reproj_error >= 0 && max_depth_error >= 0 && max_normal_error >= 0 && check_num_images > 0;
+  }
+};
+
+struct PlyPoint {  // util/ply.h:39-49
+  float x = 0, y = 0, z = 0, nx = 0, ny = 0, nz = 0;
+  uint8_t r = 0, g = 0, b = 0;
+};
+
+struct FusionInput {  // one workspace image: pose at the model size, colour bitmap, depth / normal maps
+  const Image* image = nullptr;
+  const uint8_t* rgb = nullptr;  // bitmap_height x bitmap_width x 3, or nullptr
+  int bitmap_width = 0, bitmap_height = 0;
+  const DepthMap* depth_map = nullptr;  // nullptr: the image is not used (fusion.cc:204-213)
+  const NormalMap* normal_map = nullptr;
+  const Mat<char>* mask = nullptr;      // depth-map sized, > 0 = pre-masked (fusion.cc:359-399)
+};
+
+class StereoFusion {
+ public:
+  explicit StereoFusion(const StereoFusionOptions& options) : options_(options) { COLMAP_AMD_CHECK(options_.Check()); }
+
+  // overlapping_images[i]: Model::GetMaxOverlappingImages(check_num_images, 0) of image i
+  void Run(const std::vector<FusionInput>& inputs, const std::vector<std::vector<int>>& overlapping_images) {
+    COLMAP_AMD_CHECK(inputs.size() == overlapping_images.size());
+    fusion_options o;
+    fusion_options_init(&o);
+    o.min_num_pixels = options_.min_num_pixels;
+    o.max_num_pixels = options_.max_num_pixels;
+    o.max_traversal_depth = options_.max_traversal_depth;
+    o.check_num_images = options_.check_num_images;
+    o.max_reproj_error = options_.max_reproj_error;
+    o.max_depth_error = options_.max_depth_error;
+    o.max_normal_error = options_.max_normal_error;
+    std::memcpy(o.bbox_min, options_.bounding_box_min, sizeof(o.bbox_min));
+    std::memcpy(o.bbox_max, options_.bounding_box_max, sizeof(o.bbox_max));
+    std::vector<fusion_image> images(inputs.size());
+    std::memset(images.data(), 0, images.size() * sizeof(fusion_image));
+    std::vector<std::vector<uint8_t>> masks(inputs.size());
+    for (size_t i = 0; i < inputs.size(); ++i) {
+      const FusionInput& in = inputs[i];
+      COLMAP_AMD_CHECK(in.image != nullptr);
+      fusion_image& f = images[i];
+      f.width = static_cast<int32_t>(in.image->GetWidth());
+      f.height = static_cast<int32_t>(in.image->GetHeight());
+      std::memcpy(f.K, in.image->GetK(), sizeof(f.K));
+      std::memcpy(f.R, in.image->GetR(), sizeof(f.R));
+      std::memcpy(f.T, in.image->GetT(), sizeof(f.T));
+      f.used = in.depth_map != nullptr && in.normal_map != nullptr;
+      if (!f.used) continue;
+      COLMAP_AMD_CHECK(in.depth_map->GetWidth() == in.normal_map->GetWidth());
+      COLMAP_AMD_CHECK(in.depth_map->GetHeight() == in.normal_map->GetHeight());
+      f.depth_map = in.depth_map->GetPtr();
+      f.normal_map = in.normal_map->GetPtr();
+      f.depth_width = static_cast<int32_t>(in.depth_map->GetWidth());
+      f.depth_height = static_cast<int32_t>(in.depth_map->GetHeight());
+      f.rgb = in.rgb;
+      f.bitmap_width = in.bitmap_width;
+      f.bitmap_height = in.bitmap_height;
+      if (in.mask) {
+        COLMAP_AMD_CHECK(in.mask->GetWidth() == in.depth_map->GetWidth());
+        COLMAP_AMD_CHECK(in.mask->GetHeight() == in.depth_map->GetHeight());
+        masks[i].resize(in.mask->GetData().size());
+        for (size_t k = 0; k < masks[i].size(); ++k) masks[i][k] = in.mask->GetData()[k] > 0 ? 1 : 0;
+        f.mask = masks[i].data();
+      }
+    }
+    std::vector<int32_t> ptr(inputs.size() + 1, 0), idx;
+    for (size_t i = 0; i < inputs.size(); ++i) {
+      idx.insert(idx.end(), overlapping_images[i].begin(), overlapping_images[i].end());
+      ptr[i + 1] = static_cast<int32_t>(idx.size());
+    }
+    fusion_result* res = nullptr;
+    if (fusion_run(&o, static_cast<int32_t>(images.size()), images.data(), ptr.data(), idx.empty() ? nullptr : idx.data(),
+                   &res) != 0)
+      throw std::runtime_error(fusion_last_error());
+    const size_t n = fusion_num_points(res);
+    std::vector<float> xn(6 * n);
+    std::vector<uint8_t> rgb(3 * n);
+    fusion_get_points(res, xn.data(), rgb.data());
+    size_t total = 0;
+    fusion_get_visibility(res, nullptr, nullptr, &total);
+    std::vector<int64_t> vptr(n + 1, 0);
+    std::vector<int32_t> vidx(total + 1, 0);
+    fusion_get_visibility(res, vptr.data(), vidx.data(), &total);
+    fusion_free(res);
+    fused_points_.assign(n, PlyPoint());
+    fused_points_visibility_.assign(n, {});
+    for (size_t k = 0; k < n; ++k) {
+      PlyPoint& p = fused_points_[k];
+      p.x = xn[6 * k]; p.y = xn[6 * k + 1]; p.z = xn[6 * k + 2];
+      p.nx = xn[6 * k + 3]; p.ny = xn[6 * k + 4]; p.nz = xn[6 * k + 5];
+      p.r = rgb[3 * k]; p.g = rgb[3 * k + 1]; p.b = rgb[3 * k + 2];
+      fused_points_visibility_[k].assign(vidx.begin() + vptr[k], vidx.begin() + vptr[k + 1]);
+    }
+  }
+
+  const std::vector<PlyPoint>& GetFusedPoints() const { return fused_points_; }
+  const std::vector<std::vector<int>>& GetFusedPointsVisibility() const { return fused_points_visibility_; }
+
+ private:
+  const StereoFusionOptions options_;
+  std::vector<PlyPoint> fused_points_;
+  std::vector<std::vector<int>> fused_points_visibility_;
 };
 
 }  // namespace mvs

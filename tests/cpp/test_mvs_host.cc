@@ -171,6 +171,43 @@ static int HostChecks(const std::string& tmp) {
     ComputeProjectionCenter(images[1].GetR(), images[1].GetT(), C);
     EXPECT(C[0] == -0.1f);
   }
+  // StereoFusion on two fronto-parallel views of the plane z = 4 (fusion.cc:401-524)
+  {
+    const int w = 16, h = 12;
+    auto imgs = MakeImages(2, w, h);
+    std::vector<DepthMap> dm(2, DepthMap(w, h, 1, 10));
+    std::vector<NormalMap> nm(2, NormalMap(w, h));
+    for (auto& d : dm) d.Fill(4.0f);
+    for (auto& n : nm)
+      for (int r = 0; r < h; ++r)
+        for (int c = 0; c < w; ++c) n.Set(r, c, 2, -1.0f);
+    std::vector<uint8_t> rgb(static_cast<size_t>(w) * h * 3, 200);
+    std::vector<FusionInput> in(2);
+    for (int i = 0; i < 2; ++i) {
+      in[i].image = &imgs[i];
+      in[i].rgb = rgb.data();
+      in[i].bitmap_width = w;
+      in[i].bitmap_height = h;
+      in[i].depth_map = &dm[i];
+      in[i].normal_map = &nm[i];
+    }
+    StereoFusionOptions fo;
+    fo.min_num_pixels = 2;
+    StereoFusion fusion(fo);
+    fusion.Run(in, {{1}, {0}});
+    const auto& pts = fusion.GetFusedPoints();
+    EXPECT(!pts.empty() && pts.size() == fusion.GetFusedPointsVisibility().size());
+    for (size_t k = 0; k < pts.size(); ++k) {
+      EXPECT(std::abs(pts[k].z - 4.0f) < 1e-4f && std::abs(pts[k].nz + 1.0f) < 1e-6f && pts[k].r == 200);
+      EXPECT(fusion.GetFusedPointsVisibility()[k].size() == 2);
+    }
+    fo.min_num_pixels = 3;  // only two views: nothing reaches three pixels... unless neighbours merge
+    StereoFusion strict(fo);
+    strict.Run(in, {{1}, {0}});
+    EXPECT(strict.GetFusedPoints().size() <= pts.size());
+    fo.max_traversal_depth = 0;
+    EXPECT(Throws([&] { StereoFusion bad(fo); }));
+  }
   std::printf("host checks OK\n");
   return 0;
 }
