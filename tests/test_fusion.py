@@ -289,3 +289,8 @@ def test_stereo_fusion_command_on_a_workspace(tmp_path):
     np.testing.assert_array_equal(sm.points3D[1].xyz.astype(np.float32), pts.xyz[0])
     with pytest.raises(SystemExit):
         fusion.main(["--workspace_path", ws, "--output_path", out, "--input_type", "depth"])
+    # pycolmap.stereo_fusion(output_path, workspace_path, ..., options, output_type) (pycolmap/pipeline/mvs.cc:182-193)
+    import colmap_amd
+    out2 = str(tmp_path / "fused2.ply")
+    again = colmap_amd.stereo_fusion(out2, ws, options=fusion.StereoFusionOptions(min_num_pixels=3), output_type="ply")
+    assert np.array_equal(again.xyz, pts.xyz) and open(out2, "rb").read() == open(out, "rb").read()
