@@ -1,11 +1,11 @@
 """smoke(): one small bundle-adjustment solve on cuda:0 through the C ABI, checked against the
-fp64 CPU oracle (test infrastructure; imported only from __graft_entry__.smoke())."""
+fp64 CPU oracle (test infrastructure; imported only from __graft_entry__.smoke(); lives under tests/ because it uses the oracle)."""
 import numpy as np
 
 
 def run():
     import ba_oracle
-    from . import estimators as est, scene
+    from colmap_amd import estimators as est, scene
     d = scene.synthesize_flat(12, 300, 5, seed=3, mixed_models=True,
                               noise=scene.SyntheticNoiseOptions(0.01, 1.0, 0.05, 1.0))
     fp = est.FlatProblem.from_arrays(d)

@@ -290,7 +290,7 @@ def test_stereo_fusion_command_on_a_workspace(tmp_path):
     with pytest.raises(SystemExit):
         fusion.main(["--workspace_path", ws, "--output_path", out, "--input_type", "depth"])
     # pycolmap.stereo_fusion(output_path, workspace_path, ..., options, output_type) (pycolmap/pipeline/mvs.cc:182-193)
-    import colmap_amd
+    from colmap_amd import pipeline
     out2 = str(tmp_path / "fused2.ply")
-    again = colmap_amd.stereo_fusion(out2, ws, options=fusion.StereoFusionOptions(min_num_pixels=3), output_type="ply")
+    again = pipeline.stereo_fusion(out2, ws, options=fusion.StereoFusionOptions(min_num_pixels=3), output_type="ply")
     assert np.array_equal(again.xyz, pts.xyz) and open(out2, "rb").read() == open(out, "rb").read()
