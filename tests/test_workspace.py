@@ -223,3 +223,41 @@ def test_cli_option_surface():
                  "filter_min_num_consistent", "filter_geom_consistency_max_cost", "cache_size",
                  "allow_missing_files", "write_consistency_graph", "num_threads"]:
         assert hasattr(a, "pm_" + name), name
+
+
+def test_text_model_edge_cases(tmp_path):
+    """images.txt: an image without observations has an EMPTY second line; names may contain spaces;
+    comment / blank lines are skipped (scene/reconstruction_io_text.cc)."""
+    d = tmp_path / "m"
+    os.makedirs(d)
+    (d / "cameras.txt").write_text("# Camera list\n\n1 SIMPLE_RADIAL 100 80 90.5 50 40 0.01\n2 OPENCV 64 48 70 71 32 24 0.1 0.01 0 0\n")
+    (d / "images.txt").write_text(
+        "# Image list with two lines of data per image:\n"
+        "1 1 0 0 0 0.5 0 2 1 my image 01.png\n"
+        "10.5 20.25 7 30 40 -1\n"
+        "2 0.5 0.5 0.5 0.5 0 0 0 2 b.png\n"
+        "\n"
+        "3 1 0 0 0 0 0 1 1 c.png\n"
+        "1 2 7\n")
+    (d / "points3D.txt").write_text("# points\n7 0.1 0.2 0.3 255 0 10 0.75 1 0 3 0\n")
+    sm = W.read_sparse_model(str(d))
+    assert sm.cameras[2].model_id == 4 and len(sm.cameras[2].params) == 8
+    assert sm.images[1].name == "my image 01.png" and sm.images[1].xys.shape == (2, 2)
+    assert list(sm.images[1].point3D_ids) == [7, -1]
+    assert sm.images[2].xys.shape == (0, 2) and sm.images[2].name == "b.png"
+    assert sm.images[3].name == "c.png" and list(sm.images[3].point3D_ids) == [7]
+    assert sm.points3D[7].track == [(1, 0), (3, 0)] and sm.points3D[7].rgb == (255, 0, 10) and sm.points3D[7].error == 0.75
+    K = sm.cameras[2].CalibrationMatrix()
+    assert (K[0, 0], K[1, 1], K[0, 2], K[1, 2]) == (70, 71, 32, 24)
+    # rotation of quaternion (w x y z) = (.5 .5 .5 .5): cyclic permutation of the axes
+    np.testing.assert_allclose(sm.images[2].RotationMatrix(), [[0, 0, 1], [1, 0, 0], [0, 1, 0]], atol=1e-15)
+    # text -> binary -> text keeps everything
+    W.write_model_binary(sm, str(tmp_path / "b"))
+    back = W.read_sparse_model(str(tmp_path / "b"))
+    _assert_models_equal(sm, back)
+    # patch-match.cfg with CRLF line endings and trailing blanks
+    m = W.Model.FromSparseModel(sm, "")
+    probs = W.read_patch_match_config("my image 01.png\r\n__all__\r\n\r\nb.png  \r\nc.png , my image 01.png\r\n".splitlines(), m)
+    assert probs == [(0, [1, 2]), (1, [2, 0])]
+    # a dangling reference image line without a source line is ignored like the reference's parser does
+    assert W.read_patch_match_config(["b.png"], m) == []
