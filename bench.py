@@ -103,7 +103,7 @@ def ba_secondary(a, local_rank, with_cpu):
     alg = 352 * n_obs  # 2 passes over the fp64 Jacobian rows: 2 x 2 x (6 + 2 + 3) x 8 B per observation
     avg_ms = ms.value / max(n.value, 1)
     out = {
-        "metric": "BA LM-iterations/s @1000 imgs",
+        "metric": "BA LM-iters/s @1000 imgs",
         "value": s.num_iterations / s.lm_seconds,
         "unit": "LM-iterations/s",
         "dtype": "f64",
@@ -238,7 +238,7 @@ def main():
         avg_ms = sweep_ms / max(sweep_n, 1)
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
         out = {
-            "metric": "PatchMatch Mpix/s @2560x1920",
+            "metric": "PatchMatch Mpix/s @2560×1920",
             "value": value,
             "unit": "Mpix/s",
             "n_gpus": world,
