@@ -172,7 +172,17 @@ __device__ __forceinline__ void atomic_max_pos(double* addr, double v) {
 // Per-residual math (reference reprojection_error.h:68-134)
 // ------------------------------------------------------------------------------------------
 __device__ __host__ __forceinline__ int num_params_of(int model) {
-  return model == BA_SIMPLE_PINHOLE ? 3 : (model == BA_RADIAL ? 5 : (model == BA_OPENCV ? 8 : 4));
+  switch (model) {
+    case BA_SIMPLE_PINHOLE: return 3;
+    case BA_RADIAL: case BA_RADIAL_FISHEYE: return 5;
+    case BA_OPENCV: case BA_OPENCV_FISHEYE: return 8;
+    default: return 4;  // PINHOLE, SIMPLE_RADIAL, SIMPLE_RADIAL_FISHEYE
+  }
+}
+__host__ inline bool model_supported(int model) {
+  return model == BA_SIMPLE_PINHOLE || model == BA_PINHOLE || model == BA_SIMPLE_RADIAL || model == BA_RADIAL ||
+         model == BA_OPENCV || model == BA_OPENCV_FISHEYE || model == BA_SIMPLE_RADIAL_FISHEYE ||
+         model == BA_RADIAL_FISHEYE;
 }
 
 // QuaternionRotatePointWithJac, quaternion_utils.h:105-153
@@ -232,6 +242,62 @@ __device__ __forceinline__ bool img_from_cam(int model, const double* prm, doubl
       Juvw[3] = 0.0; Juvw[4] = f2 * inv_w; Juvw[5] = -f2 * inv_w * vv;
       Jpar[0] = uu; Jpar[1] = 0.0; Jpar[2] = 1.0; Jpar[3] = 0.0;
       Jpar[NPAR + 0] = 0.0; Jpar[NPAR + 1] = vv; Jpar[NPAR + 2] = 0.0; Jpar[NPAR + 3] = 1.0;
+    }
+    return true;
+  }
+  if (model == BA_OPENCV_FISHEYE || model == BA_SIMPLE_RADIAL_FISHEYE || model == BA_RADIAL_FISHEYE) {
+    // equidistant projection (internal::FisheyeProjectionWithJac, models_jacobian.h:51-80) followed by a
+    // radial polynomial in the squared fisheye radius (:726-942)
+    const bool two_f = model == BA_OPENCV_FISHEYE;
+    const double f1 = prm[0], f2 = two_f ? prm[1] : prm[0];
+    const int ic = two_f ? 2 : 1;                                  // index of cx
+    const int nk = two_f ? 4 : (model == BA_RADIAL_FISHEYE ? 2 : 1);
+    const double* k = prm + ic + 2;
+    const double a = uu, b = vv;                                   // normalised coordinates
+    const double r2 = a * a + b * b;
+    const double r = sqrt(r2);
+    double fu, fv, Jf0 = 1.0, Jf1 = 0.0, Jf2 = 0.0, Jf3 = 1.0;
+    if (r < 2.220446049250313e-16) {
+      fu = a;
+      fv = b;
+    } else {
+      const double theta = atan(r);
+      const double sc = theta / r;
+      fu = sc * a;
+      fv = sc * b;
+      if (JAC) {
+        const double g = (r / (1.0 + r2) - theta) / (r2 * r);
+        Jf0 = sc + a * a * g; Jf1 = a * b * g; Jf2 = a * b * g; Jf3 = sc + b * b * g;
+      }
+    }
+    const double fu2 = fu * fu, fv2 = fv * fv, t2 = fu2 + fv2;
+    double tp[4];
+    tp[0] = t2; tp[1] = t2 * t2; tp[2] = tp[1] * t2; tp[3] = tp[1] * tp[1];
+    double radial = 0.0;
+    for (int i = 0; i < nk; ++i) radial += k[i] * tp[i];
+    const double fu_d = fu + fu * radial, fv_d = fv + fv * radial;
+    x = f1 * fu_d + prm[ic];
+    y = f2 * fv_d + prm[ic + 1];
+    if (JAC) {
+      double d_radial = 0.0;
+      for (int i = 0; i < nk; ++i) d_radial += (double)(i + 1) * k[i] * (i == 0 ? 1.0 : tp[i - 1]);
+      const double cross = 2.0 * fu * fv * d_radial;
+      const double i0 = 1.0 + radial + 2.0 * fu2 * d_radial, i3 = 1.0 + radial + 2.0 * fv2 * d_radial;
+      const double m0 = i0 * Jf0 + cross * Jf2, m1 = i0 * Jf1 + cross * Jf3;
+      const double m2 = cross * Jf0 + i3 * Jf2, m3 = cross * Jf1 + i3 * Jf3;
+      const double A0 = f1 * m0, A1 = f1 * m1, A2 = f2 * m2, A3 = f2 * m3;
+      Juvw[0] = A0 * inv_w; Juvw[1] = A1 * inv_w; Juvw[2] = -(A0 * a + A1 * b) * inv_w;
+      Juvw[3] = A2 * inv_w; Juvw[4] = A3 * inv_w; Juvw[5] = -(A2 * a + A3 * b) * inv_w;
+#pragma unroll
+      for (int c = 0; c < NPAR; ++c) Jpar[c] = Jpar[NPAR + c] = 0.0;
+      Jpar[0] = fu_d;
+      Jpar[NPAR + (two_f ? 1 : 0)] = fv_d;
+      Jpar[ic] = 1.0;
+      Jpar[NPAR + ic + 1] = 1.0;
+      for (int i = 0; i < nk; ++i) {
+        Jpar[ic + 2 + i] = f1 * fu * tp[i];
+        Jpar[NPAR + ic + 2 + i] = f2 * fv * tp[i];
+      }
     }
     return true;
   }
@@ -1220,10 +1286,10 @@ struct Solver {
     int max_nvar = 0;
     for (int k = 0; k < p.num_cams; ++k) {
       const int model = p.cam_model[k];
-      if (model != BA_SIMPLE_PINHOLE && model != BA_PINHOLE && model != BA_SIMPLE_RADIAL && model != BA_RADIAL &&
-          model != BA_OPENCV)
+      if (!model_supported(model))
         throw std::runtime_error("unsupported camera model id " + std::to_string(model) +
-                                 " (supported: SIMPLE_PINHOLE, PINHOLE, SIMPLE_RADIAL, RADIAL, OPENCV)");
+                                 " (supported: SIMPLE_PINHOLE, PINHOLE, SIMPLE_RADIAL, RADIAL, OPENCV, "
+                                 "OPENCV_FISHEYE, SIMPLE_RADIAL_FISHEYE, RADIAL_FISHEYE)");
       const int P = num_params_of(model);
       for (int j = 0; j < P; ++j)
         if (!p.cam_const[(size_t)k * BA_CAM_STRIDE + j]) wide_cam_var[(size_t)k * KD_MAX + cam_nvar[k]++] = j;

@@ -23,11 +23,16 @@ import numpy as np
 
 # colmap::CameraModelId (sensor/models.h:90-111)
 SIMPLE_PINHOLE, PINHOLE, SIMPLE_RADIAL, RADIAL, OPENCV = 0, 1, 2, 3, 4
-MODEL_NUM_PARAMS = {SIMPLE_PINHOLE: 3, PINHOLE: 4, SIMPLE_RADIAL: 4, RADIAL: 5, OPENCV: 8}
+OPENCV_FISHEYE, SIMPLE_RADIAL_FISHEYE, RADIAL_FISHEYE = 5, 8, 9
+MODEL_NUM_PARAMS = {SIMPLE_PINHOLE: 3, PINHOLE: 4, SIMPLE_RADIAL: 4, RADIAL: 5, OPENCV: 8,
+                    OPENCV_FISHEYE: 8, SIMPLE_RADIAL_FISHEYE: 4, RADIAL_FISHEYE: 5}
 # FocalLengthIdxs / PrincipalPointIdxs / ExtraParamsIdxs (sensor/models.h)
-MODEL_FOCAL_IDXS = {SIMPLE_PINHOLE: [0], PINHOLE: [0, 1], SIMPLE_RADIAL: [0], RADIAL: [0], OPENCV: [0, 1]}
-MODEL_PP_IDXS = {SIMPLE_PINHOLE: [1, 2], PINHOLE: [2, 3], SIMPLE_RADIAL: [1, 2], RADIAL: [1, 2], OPENCV: [2, 3]}
-MODEL_EXTRA_IDXS = {SIMPLE_PINHOLE: [], PINHOLE: [], SIMPLE_RADIAL: [3], RADIAL: [3, 4], OPENCV: [4, 5, 6, 7]}
+MODEL_FOCAL_IDXS = {SIMPLE_PINHOLE: [0], PINHOLE: [0, 1], SIMPLE_RADIAL: [0], RADIAL: [0], OPENCV: [0, 1],
+                    OPENCV_FISHEYE: [0, 1], SIMPLE_RADIAL_FISHEYE: [0], RADIAL_FISHEYE: [0]}
+MODEL_PP_IDXS = {SIMPLE_PINHOLE: [1, 2], PINHOLE: [2, 3], SIMPLE_RADIAL: [1, 2], RADIAL: [1, 2], OPENCV: [2, 3],
+                 OPENCV_FISHEYE: [2, 3], SIMPLE_RADIAL_FISHEYE: [1, 2], RADIAL_FISHEYE: [1, 2]}
+MODEL_EXTRA_IDXS = {SIMPLE_PINHOLE: [], PINHOLE: [], SIMPLE_RADIAL: [3], RADIAL: [3, 4], OPENCV: [4, 5, 6, 7],
+                    OPENCV_FISHEYE: [4, 5, 6, 7], SIMPLE_RADIAL_FISHEYE: [3], RADIAL_FISHEYE: [3, 4]}
 
 
 @dataclass
@@ -197,6 +202,22 @@ def img_from_cam(model_id: int, params: np.ndarray, uvw: np.ndarray) -> np.ndarr
     if model_id == PINHOLE:
         f1, f2, c1, c2 = params
         return np.stack([f1 * uu + c1, f2 * vv + c2], 1)
+    if model_id in (OPENCV_FISHEYE, SIMPLE_RADIAL_FISHEYE, RADIAL_FISHEYE):
+        # BasePerspectiveFisheyeCameraModel: equidistant projection, then a radial polynomial in theta^2
+        r = np.sqrt(uu * uu + vv * vv)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            sc = np.where(r < np.finfo(np.float64).eps, 1.0, np.arctan(r) / r)
+        fu, fv = sc * uu, sc * vv
+        t2 = fu * fu + fv * fv
+        if model_id == OPENCV_FISHEYE:
+            f1, f2, c1, c2 = params[:4]
+            ks = params[4:8]
+        else:
+            f1 = f2 = params[0]
+            c1, c2 = params[1:3]
+            ks = params[3:]
+        radial = sum(k * t2 ** (i + 1) for i, k in enumerate(ks))
+        return np.stack([f1 * (fu + fu * radial) + c1, f2 * (fv + fv * radial) + c2], 1)
     if model_id == OPENCV:  # sensor/models.h OpenCVCameraModel::ImgFromCam / Distortion
         f1, f2, c1, c2, k1, k2, p1, p2 = params
         r2 = uu * uu + vv * vv

@@ -84,7 +84,10 @@ inline Rigid3d Compose(const Rigid3d& a, const Rigid3d& b) {
 }
 
 // CameraModelId (sensor/models.h:90-111): the models the MI355X backend supports.
-enum class CameraModelId : int { SIMPLE_PINHOLE = 0, PINHOLE = 1, SIMPLE_RADIAL = 2, RADIAL = 3, OPENCV = 4 };
+enum class CameraModelId : int {
+  SIMPLE_PINHOLE = 0, PINHOLE = 1, SIMPLE_RADIAL = 2, RADIAL = 3, OPENCV = 4,
+  OPENCV_FISHEYE = 5, SIMPLE_RADIAL_FISHEYE = 8, RADIAL_FISHEYE = 9
+};
 
 struct CameraModelInfo {
   int num_params;
@@ -92,12 +95,16 @@ struct CameraModelInfo {
 };
 
 inline const CameraModelInfo* GetCameraModelInfo(int model_id) {
-  static const CameraModelInfo kInfos[5] = {{3, {0}, {1, 2}, {}},
-                                            {4, {0, 1}, {2, 3}, {}},
-                                            {4, {0}, {1, 2}, {3}},
-                                            {5, {0}, {1, 2}, {3, 4}},
-                                            {8, {0, 1}, {2, 3}, {4, 5, 6, 7}}};
-  return (model_id >= 0 && model_id < 5) ? &kInfos[model_id] : nullptr;
+  static const CameraModelInfo kSimplePinhole{3, {0}, {1, 2}, {}}, kPinhole{4, {0, 1}, {2, 3}, {}},
+      kSimpleRadial{4, {0}, {1, 2}, {3}}, kRadial{5, {0}, {1, 2}, {3, 4}}, kOpenCV{8, {0, 1}, {2, 3}, {4, 5, 6, 7}};
+  switch (model_id) {
+    case 0: return &kSimplePinhole;
+    case 1: return &kPinhole;
+    case 2: case 8: return &kSimpleRadial;   // SIMPLE_RADIAL, SIMPLE_RADIAL_FISHEYE: f cx cy k
+    case 3: case 9: return &kRadial;         // RADIAL, RADIAL_FISHEYE: f cx cy k1 k2
+    case 4: case 5: return &kOpenCV;         // OPENCV, OPENCV_FISHEYE: fx fy cx cy + four extra
+    default: return nullptr;
+  }
 }
 
 struct Camera {  // scene/camera.h

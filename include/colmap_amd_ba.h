@@ -28,7 +28,10 @@ extern "C" {
 #define BA_CAM_STRIDE 12 /* doubles reserved per camera parameter block */
 
 /* colmap::CameraModelId values of the supported models (sensor/models.h:90-111) */
-enum { BA_SIMPLE_PINHOLE = 0, BA_PINHOLE = 1, BA_SIMPLE_RADIAL = 2, BA_RADIAL = 3, BA_OPENCV = 4 };
+enum {
+  BA_SIMPLE_PINHOLE = 0, BA_PINHOLE = 1, BA_SIMPLE_RADIAL = 2, BA_RADIAL = 3, BA_OPENCV = 4,
+  BA_OPENCV_FISHEYE = 5, BA_SIMPLE_RADIAL_FISHEYE = 8, BA_RADIAL_FISHEYE = 9
+};
 
 typedef struct ba_problem {
   int32_t num_poses, num_cams, num_points;

@@ -41,7 +41,10 @@
 #define BAO_CAM_STRIDE 12
 
 /* COLMAP CameraModelId values (sensor/models.h:90-111) */
-enum { BAO_SIMPLE_PINHOLE = 0, BAO_PINHOLE = 1, BAO_SIMPLE_RADIAL = 2, BAO_RADIAL = 3, BAO_OPENCV = 4 };
+enum {
+  BAO_SIMPLE_PINHOLE = 0, BAO_PINHOLE = 1, BAO_SIMPLE_RADIAL = 2, BAO_RADIAL = 3, BAO_OPENCV = 4,
+  BAO_OPENCV_FISHEYE = 5, BAO_SIMPLE_RADIAL_FISHEYE = 8, BAO_RADIAL_FISHEYE = 9
+};
 
 typedef struct {
   int32_t num_poses, num_cams, num_points;
@@ -158,7 +161,76 @@ static int num_params_of(int model) {
     case BAO_SIMPLE_RADIAL: return 4;
     case BAO_RADIAL: return 5;
     case BAO_OPENCV: return 8;
+    case BAO_OPENCV_FISHEYE: return 8;
+    case BAO_SIMPLE_RADIAL_FISHEYE: return 4;
+    case BAO_RADIAL_FISHEYE: return 5;
     default: return -1;
+  }
+}
+
+/* internal::FisheyeProjectionWithJac (sensor/models_jacobian.h:51-80): equidistant projection of the
+ * normalised coordinates (a, b), J = d(uu, vv) / d(a, b) row-major 2 x 2 */
+static void fisheye_projection_with_jac(double a, double b, double* uu, double* vv, double* J) {
+  const double r2 = a * a + b * b;
+  const double r = sqrt(r2);
+  if (r < 2.220446049250313e-16) {
+    *uu = a;
+    *vv = b;
+    if (J) { J[0] = 1.0; J[1] = 0.0; J[2] = 0.0; J[3] = 1.0; }
+    return;
+  }
+  const double theta = atan(r);
+  const double s = theta / r;
+  *uu = s * a;
+  *vv = s * b;
+  if (J) {
+    const double g = (r / (1.0 + r2) - theta) / (r2 * r);
+    J[0] = s + a * a * g;
+    J[1] = a * b * g;
+    J[2] = a * b * g;
+    J[3] = s + b * b * g;
+  }
+}
+
+/* the three radial fisheye models (models_jacobian.h:726-942): radial polynomial of the squared
+ * fisheye radius t2 with nk coefficients k[], focal lengths (f1, f2), applied after the equidistant
+ * projection; J_params columns: [focal..., cx, cy, k...] in the model's parameter order */
+static void radial_fisheye_with_jac(double f1, double f2, double c1, double c2, const double* k, int nk,
+                                    int two_focals, double u, double v, double w, double* x, double* y,
+                                    double* J_params, double* J_uvw) {
+  const double inv_w = 1.0 / w;
+  const double a = u * inv_w, b = v * inv_w;
+  double uu, vv, Jf[4] = {0, 0, 0, 0};
+  fisheye_projection_with_jac(a, b, &uu, &vv, J_uvw ? Jf : NULL);
+  const double uu2 = uu * uu, vv2 = vv * vv;
+  const double t2 = uu2 + vv2;
+  double tp[4]; /* t2, t4, t6, t8 */
+  tp[0] = t2; tp[1] = t2 * t2; tp[2] = tp[1] * t2; tp[3] = tp[1] * tp[1];
+  double radial = 0.0;
+  for (int i = 0; i < nk; ++i) radial += k[i] * tp[i];
+  const double uu_d = uu + uu * radial, vv_d = vv + vv * radial;
+  *x = f1 * uu_d + c1;
+  *y = f2 * vv_d + c2;
+  if (J_uvw) {
+    double d_radial = 0.0;
+    for (int i = 0; i < nk; ++i) d_radial += (double)(i + 1) * k[i] * (i == 0 ? 1.0 : tp[i - 1]);
+    const double cross = 2.0 * uu * vv * d_radial;
+    const double ipjd[4] = {1.0 + radial + 2.0 * uu2 * d_radial, cross, cross, 1.0 + radial + 2.0 * vv2 * d_radial};
+    const double m[4] = {ipjd[0] * Jf[0] + ipjd[1] * Jf[2], ipjd[0] * Jf[1] + ipjd[1] * Jf[3],
+                         ipjd[2] * Jf[0] + ipjd[3] * Jf[2], ipjd[2] * Jf[1] + ipjd[3] * Jf[3]};
+    const double Jab[4] = {f1 * m[0], f1 * m[1], f2 * m[2], f2 * m[3]};
+    J_uvw[0] = Jab[0] * inv_w; J_uvw[1] = Jab[1] * inv_w; J_uvw[2] = -(Jab[0] * a + Jab[1] * b) * inv_w;
+    J_uvw[3] = Jab[2] * inv_w; J_uvw[4] = Jab[3] * inv_w; J_uvw[5] = -(Jab[2] * a + Jab[3] * b) * inv_w;
+  }
+  if (J_params) {
+    const int P = (two_focals ? 4 : 3) + nk;
+    double* r0 = J_params;
+    double* r1 = J_params + P;
+    int c = 0;
+    if (two_focals) { r0[0] = uu_d; r0[1] = 0.0; r1[0] = 0.0; r1[1] = vv_d; c = 2; }
+    else { r0[0] = uu_d; r1[0] = vv_d; c = 1; }
+    r0[c] = 1.0; r0[c + 1] = 0.0; r1[c] = 0.0; r1[c + 1] = 1.0;
+    for (int i = 0; i < nk; ++i) { r0[c + 2 + i] = f1 * uu * tp[i]; r1[c + 2 + i] = f2 * vv * tp[i]; }
   }
 }
 
@@ -196,6 +268,16 @@ static int img_from_cam_jac(int model, const double* params, double u, double v,
       J_params[0] = uu; J_params[1] = 0.0; J_params[2] = 1.0; J_params[3] = 0.0;
       J_params[4] = 0.0; J_params[5] = vv; J_params[6] = 0.0; J_params[7] = 1.0;
     }
+    return 1;
+  }
+  if (model == BAO_SIMPLE_RADIAL_FISHEYE || model == BAO_RADIAL_FISHEYE) { /* :726-859 */
+    radial_fisheye_with_jac(params[0], params[0], params[1], params[2], params + 3,
+                            model == BAO_SIMPLE_RADIAL_FISHEYE ? 1 : 2, 0, u, v, w, x, y, J_params, J_uvw);
+    return 1;
+  }
+  if (model == BAO_OPENCV_FISHEYE) { /* :862-942 */
+    radial_fisheye_with_jac(params[0], params[1], params[2], params[3], params + 4, 4, 1, u, v, w, x, y,
+                            J_params, J_uvw);
     return 1;
   }
   if (model == BAO_OPENCV) { /* models_jacobian.h:401-496 */

@@ -185,7 +185,7 @@ def test_backend_interface_reference_cases():
 
 def test_error_behaviour():
     fp = _flat(4, 20, 3, seed=1)
-    fp.cam_model[0] = 9  # unsupported model id (RADIAL_FISHEYE)
+    fp.cam_model[0] = 7  # unsupported model id (FOV)
     with pytest.raises(RuntimeError, match="unsupported camera model"):
         est.solve_flat(fp, gpu_index=0)
     fp = _flat(4, 20, 3, seed=1)
@@ -405,3 +405,21 @@ def test_opencv_model_matches_oracle():
         assert got.num_effective_parameters == want.num_effective_parameters
         _assert_close(a, want, b, got, cost_rtol=1e-7, param_atol=1e-5, traj_rtol=1e-3)
         assert got.final_cost < 0.2 * got.initial_cost
+
+
+@pytest.mark.parametrize("model,params", [
+    (scene.SIMPLE_RADIAL_FISHEYE, (900.0, 512.0, 384.0, 0.03)),
+    (scene.RADIAL_FISHEYE, (900.0, 512.0, 384.0, 0.03, -0.004)),
+    (scene.OPENCV_FISHEYE, (900.0, 910.0, 512.0, 384.0, 0.03, -0.004, 0.001, -0.0002))])
+def test_fisheye_models_match_oracle(model, params):
+    """Equidistant fisheye projection + radial polynomial (models_jacobian.h:51-80,726-942)."""
+    rec = scene.SynthesizeDataset(scene.SyntheticDatasetOptions(
+        num_rigs=3, num_frames_per_rig=4, num_points3D=250, camera_model_id=model, camera_params=params), seed=21)
+    scene.SynthesizeNoise(scene.SyntheticNoiseOptions(0.02, 0.5, 0.05, 0.5), rec, seed=22)
+    fp = _adapter_problem(rec)
+    assert (fp.cam_model == model).all()
+    (a, want), (b, got) = _both(fp, gradient_tolerance=1e-10, max_num_iterations=60)
+    assert want.IsSolutionUsable() and got.IsSolutionUsable()
+    assert got.num_effective_parameters == want.num_effective_parameters
+    _assert_close(a, want, b, got, cost_rtol=1e-7, param_atol=1e-5, traj_rtol=1e-5)
+    assert got.final_cost < 0.2 * got.initial_cost

@@ -516,3 +516,28 @@ def test_opencv_cameras_six_variable_intrinsics():
     for cid, c in rec.cameras.items():
         np.testing.assert_allclose(c.params[:2], gt.cameras[cid].params[:2], rtol=2e-3)
         assert not np.array_equal(c.params[4:], gt.cameras[cid].params[4:] * [1.2, 0.8, 1.3, 0.7])  # distortion moved
+
+
+@pytest.mark.parametrize("model,params", [
+    (scene.SIMPLE_RADIAL_FISHEYE, [500.0, 320, 240, 0.03]),
+    (scene.RADIAL_FISHEYE, [500.0, 320, 240, 0.03, -0.004]),
+    (scene.OPENCV_FISHEYE, [500.0, 510.0, 320, 240, 0.03, -0.004, 0.001, -0.0002])])
+def test_fisheye_models_values_and_jacobians(model, params):
+    # models_jacobian.h:726-942 on top of internal::FisheyeProjectionWithJac (:51-80)
+    rng = np.random.default_rng(int(model))
+    pose = np.array([0, 0, 0, 1, 0, 0, 0.0])
+    pts = [np.array([rng.normal() * 1.5, rng.normal() * 1.5, 1 + rng.random()]) for _ in range(20)]
+    pts.append(np.array([0.0, 0.0, 2.0]))          # on the optical axis: the r -> 0 branch
+    for pt in pts:
+        r0, Jpt, Jpose, Jpar = ba_oracle.reproj_error(model, pt, pose, params, [0, 0])
+        np.testing.assert_allclose(r0, scene.img_from_cam(model, np.array(params), pt[None])[0], rtol=1e-12, atol=1e-10)
+        def f(v):
+            return ba_oracle.reproj_error(model, v[:3], pose, v[3:], [0, 0], want_jac=False)[0]
+        x0 = np.concatenate([pt, params])
+        J = np.zeros((2, len(x0)))
+        for i in range(len(x0)):
+            h = 1e-6 * max(1.0, abs(x0[i]))
+            e = np.zeros(len(x0)); e[i] = h
+            J[:, i] = (f(x0 + e) - f(x0 - e)) / (2 * h)
+        np.testing.assert_allclose(Jpt, J[:, :3], rtol=2e-5, atol=2e-5)
+        np.testing.assert_allclose(Jpar, J[:, 3:], rtol=2e-5, atol=5e-5)
