@@ -507,6 +507,9 @@ class PatchMatchController:
         images = [Image(im.K, im.R, im.T, im.bitmap) for im in self.images_]
         if self.image_cache_ is None:
             self.image_cache_ = ImageCache(int(options.gpu_index))
+            # PatchMatchOptions::cache_size (GB) bounds the reference's CachedWorkspace
+            # (patch_match_options.h:118-125); here it bounds the packed sources kept in HBM
+            self.image_cache_.set_capacity(int(options.cache_size * (1 << 30)))
         results = {}
         todo = []
         for ref, src in mine:
