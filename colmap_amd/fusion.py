@@ -232,6 +232,7 @@ class StereoFusion:
         self.options_ = options
         self.workspace_path_ = workspace_path
         self.workspace_format_ = workspace_format
+        self.pmvs_option_name_ = pmvs_option_name
         self.input_type_ = input_type
         self.fused_: Optional[FusedPoints] = None
         self.warnings_: List[str] = []
@@ -244,13 +245,16 @@ class StereoFusion:
 
     def Run(self):
         from PIL import Image as PILImage
+        pmvs = self.workspace_format_.lower() == "pmvs"
         ws = W.Workspace(self.workspace_path_, self.workspace_format_, input_type=self.input_type_,
-                         max_image_size=self.options_.max_image_size)
+                         max_image_size=self.options_.max_image_size,
+                         stereo_folder=f"stereo-{self.pmvs_option_name_}" if pmvs else "stereo")  # (:151-156)
         model = ws.GetModel()
         cfg = os.path.join(self.workspace_path_, ws.stereo_folder, "fusion.cfg")
         with open(cfg) as f:
             names = [l.strip() for l in f if l.strip() and not l.startswith("#")]
-        overlapping = model.GetMaxOverlappingImages(self.options_.check_num_images, 0.0)
+        overlapping = model.GetMaxOverlappingImagesFromPMVS() or \
+            model.GetMaxOverlappingImages(self.options_.check_num_images, 0.0)  # (:180-186)
         images = [FusionImage(im.width, im.height, im.K, im.R, im.T, None, None, None, used=False) for im in model.images]
         for name in names:
             idx = model.GetImageIdx(name)

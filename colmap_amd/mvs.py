@@ -455,8 +455,12 @@ class PatchMatchController:
         COLMAP workspace on disk -- `sparse/` model, `images/`, `stereo/patch-match.cfg`."""
         import os
         from . import workspace as W
+        pmvs = workspace_format.lower() == "pmvs"
         ws = W.Workspace(workspace_path, workspace_format, max_image_size=options.max_image_size,
-                         input_type="photometric" if options.geom_consistency else "")
+                         input_type="photometric" if options.geom_consistency else "",
+                         stereo_folder=f"stereo-{pmvs_option_name}" if pmvs else "stereo")  # (:212-216)
+        if pmvs:
+            W.import_pmvs_workspace(ws, pmvs_option_name)  # (:229-233)
         model = ws.GetModel()
         cfg = config_path or os.path.join(workspace_path, ws.stereo_folder, "patch-match.cfg")
         with open(cfg) as f:
@@ -496,7 +500,7 @@ class PatchMatchController:
     def _paths(self, image_idx: int, output_type: str):
         import os
         name = f"{self.images_[image_idx].name}.{output_type}.bin"
-        base = os.path.join(self.workspace_path_, "stereo")
+        base = os.path.join(self.workspace_path_, getattr(getattr(self, "workspace_", None), "stereo_folder", "stereo"))
         return os.path.join(base, "depth_maps", name), os.path.join(base, "normal_maps", name)
 
     def _run_pass(self, options: PatchMatchOptions, maps: Optional[dict]):

@@ -421,6 +421,128 @@ class Model:
                                        float(np.float32(p.xyz[2])), [id_to_idx[i] for i, _ in p.track]))
         return m
 
+    # -- PMVS workspaces (mvs/model.cc:100-104,282-454) ---------------------------------------------
+    @staticmethod
+    def ReadFromPMVS(path: str) -> "Model":
+        """Model::ReadFromPMVS: a Bundler export (`bundle.rd.out`) or a raw PMVS folder (`vis.dat`,
+        `txt/%08d.txt` projection matrices); images are `visualize/%08d.jpg` in both."""
+        m = Model()
+        m.pmvs_vis_dat_ = []
+        if m._read_from_bundler_pmvs(path) or m._read_from_raw_pmvs(path):
+            return m
+        raise ValueError("Invalid PMVS format")
+
+    def GetMaxOverlappingImagesFromPMVS(self) -> List[List[int]]:
+        return getattr(self, "pmvs_vis_dat_", [])
+
+    def _add_pmvs_image(self, path, idx, K, R, T):
+        from PIL import Image as PILImage
+        name = f"{idx:08d}.jpg"
+        image_path = os.path.join(path, "visualize", name)
+        with PILImage.open(image_path) as b:
+            w, h = b.size
+        self.images.append(ModelImage(image_path, w, h, np.asarray(K, np.float32).reshape(3, 3),
+                                      np.asarray(R, np.float32).reshape(3, 3), np.asarray(T, np.float32).reshape(3)))
+        self.image_names_.append(name)
+        self.image_name_to_idx_[name] = idx
+        return w, h
+
+    def _read_from_bundler_pmvs(self, path: str) -> bool:
+        """Model::ReadFromBundlerPMVS (model.cc:282-356)."""
+        bundle = os.path.join(path, "bundle.rd.out")
+        if not os.path.exists(bundle):
+            return False
+        with open(bundle) as f:
+            f.readline()  # header
+            tok = f.read().split()
+        it = iter(tok)
+        num_images, num_points = int(next(it)), int(next(it))
+        from PIL import Image as PILImage
+        for idx in range(num_images):
+            fl = np.float32(next(it))
+            k1, k2 = np.float32(next(it)), np.float32(next(it))
+            if k1 != 0 or k2 != 0:
+                raise ValueError("Check failed: k1 == 0 && k2 == 0 (undistorted images expected)")
+            R = np.array([np.float32(next(it)) for _ in range(9)], np.float32)
+            R[3:] = -R[3:]
+            T = np.array([np.float32(next(it)) for _ in range(3)], np.float32)
+            T[1:] = -T[1:]
+            with PILImage.open(os.path.join(path, "visualize", f"{idx:08d}.jpg")) as b:
+                w, h = b.size
+            K = np.array([fl, 0, w / 2.0, 0, fl, h / 2.0, 0, 0, 1], np.float32)
+            self._add_pmvs_image(path, idx, K, R, T)
+        for _ in range(num_points):
+            x, y, z = float(np.float32(next(it))), float(np.float32(next(it))), float(np.float32(next(it)))
+            for _c in range(3):
+                next(it)
+            n = int(next(it))
+            track = []
+            for _k in range(n):
+                track.append(int(next(it)))
+                next(it); next(it); next(it)
+                if not track[-1] < len(self.images):
+                    raise ValueError("Check failed: point.track[i] < images.size()")
+            self.points.append(ModelPoint(x, y, z, track))
+        return True
+
+    def _read_from_raw_pmvs(self, path: str) -> bool:
+        """Model::ReadFromRawPMVS (model.cc:358-454): P = K [R | T] decomposed by RQ
+        (DecomposeProjectionMatrix, geometry/pose.cc:98-130), skew dropped."""
+        vis = os.path.join(path, "vis.dat")
+        if not os.path.exists(vis):
+            return False
+        import scipy.linalg
+        idx = 0
+        while os.path.exists(os.path.join(path, "visualize", f"{idx:08d}.jpg")):
+            with open(os.path.join(path, "txt", f"{idx:08d}.txt")) as f:
+                tok = f.read().split()
+            if tok[0] != "CONTOUR":
+                raise ValueError("Check failed: contour == CONTOUR")
+            P = np.array(tok[1:13], np.float64).reshape(3, 4)
+            RR, QQ = scipy.linalg.rq(P[:, :3])
+            if np.linalg.det(QQ) < 0:  # DecomposeMatrixRQ makes the factorisation unique (math/matrix.h:69-73)
+                QQ[1, :] *= -1.0
+                RR[:, 1] *= -1.0
+            U, _, Vt = np.linalg.svd(QQ)  # ComputeClosestRotationMatrix (geometry/pose.cc:88-96)
+            R = U @ Vt
+            if np.linalg.det(R) < 0:
+                R = -R
+            det_k = np.linalg.det(RR)
+            if det_k == 0:
+                raise ValueError("degenerate projection matrix")
+            K = RR if det_k > 0 else -RR
+            for i in range(3):
+                if K[i, i] < 0:
+                    K[:, i] = -K[:, i]
+                    R[i, :] = -R[i, :]
+            T = np.linalg.solve(np.triu(K), P[:, 3])
+            if det_k < 0:
+                T = -T
+            K[0, 1] = K[1, 0] = K[2, 0] = K[2, 1] = 0.0
+            K[2, 2] = 1.0
+            self._add_pmvs_image(path, idx, K, R, T)
+            idx += 1
+        with open(vis) as f:
+            tok = f.read().split()
+        if tok[0] != "VISDATA":
+            raise ValueError("Check failed: visdata == VISDATA")
+        n = int(tok[1])
+        if n != len(self.images):
+            raise ValueError("Check failed: num_images == images.size()")
+        self.pmvs_vis_dat_ = [[] for _ in range(n)]
+        k = 2
+        for _ in range(n):
+            image_idx, m = int(tok[k]), int(tok[k + 1])
+            k += 2
+            for j in range(m):
+                v = int(tok[k + j])
+                if not (0 <= v < n):
+                    raise ValueError("Check failed: visible_image_idx < num_images")
+                if v != image_idx:
+                    self.pmvs_vis_dat_[image_idx].append(v)
+            k += m
+        return True
+
     def GetImageIdx(self, name: str) -> int:
         if name not in self.image_name_to_idx_:
             raise KeyError(f"Image with name `{name}` does not exist")  # (:106-110)
@@ -575,13 +697,14 @@ class Workspace:
 
     def __init__(self, workspace_path: str, workspace_format: str = "COLMAP", stereo_folder: str = "stereo",
                  input_type: str = "", max_image_size: int = -1):
-        if workspace_format.lower() != "colmap":
-            raise ValueError("only the COLMAP workspace format is supported (PMVS import is not)")
+        fmt = workspace_format.lower()
+        if fmt not in ("colmap", "pmvs"):
+            raise ValueError("Invalid input format")  # Model::Read (model.cc:45-55)
         self.workspace_path = workspace_path
         self.stereo_folder = stereo_folder
         self.input_type = input_type
         self.max_image_size = max_image_size
-        self.model = Model.ReadFromCOLMAP(workspace_path)
+        self.model = Model.ReadFromCOLMAP(workspace_path) if fmt == "colmap" else Model.ReadFromPMVS(workspace_path)
         if max_image_size > 0:
             for im in self.model.images:  # mvs::Image::Downsize (image.cc:75-95) via Workspace ctor (:44-48)
                 _downsize(im, max_image_size, max_image_size)
@@ -620,6 +743,43 @@ class Workspace:
                     PILImage.fromarray(bmp).resize((im.width, im.height), PILImage.BILINEAR), np.uint8))
             self._bitmaps[image_idx] = bmp
         return self._bitmaps[image_idx]
+
+
+def import_pmvs_workspace(workspace: "Workspace", option_name: str):
+    """ImportPMVSWorkspace (mvs/workspace.cc:250-322): output folders + patch-match.cfg / fusion.cfg from
+    the `timages` line of the PMVS option file and the visibility lists of vis.dat."""
+    base = os.path.join(workspace.workspace_path, workspace.stereo_folder)
+    for sub in ("", "depth_maps", "normal_maps", "consistency_graphs"):
+        os.makedirs(os.path.join(base, sub), exist_ok=True)
+    model = workspace.GetModel()
+    with open(os.path.join(workspace.workspace_path, option_name)) as f:
+        lines = [l.strip() for l in f]
+    for line in lines:
+        if not line.startswith("timages"):
+            continue
+        elems = line.split()
+        num = int(elems[1])
+        if num == -1:
+            if len(elems) != 4:
+                raise ValueError("Check failed: elems.size() == 4")
+            lo, hi = int(elems[2]), int(elems[3])
+            if not lo < hi:
+                raise ValueError("Check failed: range_lower < range_upper")
+            idxs = list(range(lo, hi))
+        else:
+            if num + 2 != len(elems):
+                raise ValueError("Check failed: num_images + 2 == elems.size()")
+            idxs = [int(e) for e in elems[2:]]
+        names = [model.GetImageName(i) for i in idxs]
+        overlapping = model.GetMaxOverlappingImagesFromPMVS()
+        with open(os.path.join(base, "patch-match.cfg"), "w") as pm, open(os.path.join(base, "fusion.cfg"), "w") as fu:
+            for i, name in enumerate(names):
+                pm.write(name + "\n")
+                if not overlapping:
+                    pm.write("__auto__, 20\n")
+                else:
+                    pm.write("".join(model.GetImageName(j) + ", " for j in overlapping[i]) + "\n")
+                fu.write(name + "\n")
 
 
 def _downsize(im: ModelImage, max_width: int, max_height: int):

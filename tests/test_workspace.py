@@ -261,3 +261,54 @@ def test_text_model_edge_cases(tmp_path):
     assert probs == [(0, [1, 2]), (1, [2, 0])]
     # a dangling reference image line without a source line is ignored like the reference's parser does
     assert W.read_patch_match_config(["b.png"], m) == []
+
+
+def test_pmvs_workspace_import(tmp_path):
+    """workspace_format PMVS (mvs/model.cc:358-454, workspace.cc:250-322): projection matrices in
+    txt/%08d.txt, vis.dat, option file -> model + patch-match.cfg / fusion.cfg under stereo-<option>."""
+    from PIL import Image as PILImage
+    cams = syn.ring_cameras(4, 64, 48, 60.0, arc_deg=30.0)
+    root = tmp_path / "pmvs"
+    os.makedirs(root / "visualize"); os.makedirs(root / "txt")
+    rng = np.random.default_rng(0)
+    for i, (K, R, T) in enumerate(cams):
+        PILImage.fromarray(rng.integers(0, 255, (48, 64), dtype=np.uint8)).save(root / "visualize" / f"{i:08d}.jpg")
+        P = np.asarray(K, np.float64) @ np.concatenate([np.asarray(R, np.float64), np.asarray(T, np.float64)[:, None]], 1)
+        (root / "txt" / f"{i:08d}.txt").write_text("CONTOUR\n" + "\n".join(" ".join(repr(float(v)) for v in row) for row in P) + "\n")
+    (root / "vis.dat").write_text("VISDATA\n4\n0 2 1 2\n1 3 0 2 3\n2 3 0 1 3\n3 2 1 2\n")
+    (root / "option-all").write_text("# comment\nlevel 1\ntimages -1 0 4\noimages 0\n")
+    ws = W.Workspace(str(root), "PMVS", stereo_folder="stereo-option-all")
+    m = ws.GetModel()
+    assert [os.path.basename(im.path) for im in m.images] == [f"{i:08d}.jpg" for i in range(4)]
+    for im, (K, R, T) in zip(m.images, cams):
+        assert (im.width, im.height) == (64, 48)
+        np.testing.assert_allclose(im.K, np.asarray(K, np.float32), rtol=1e-5, atol=1e-4)
+        np.testing.assert_allclose(im.R, np.asarray(R, np.float32), atol=1e-5)
+        np.testing.assert_allclose(im.T, np.asarray(T, np.float32), atol=1e-4)
+        assert im.K[0, 1] == 0 and im.K[2, 2] == 1                 # skew dropped (:396-402)
+    assert m.GetMaxOverlappingImagesFromPMVS() == [[1, 2], [0, 2, 3], [0, 1, 3], [1, 2]]
+    W.import_pmvs_workspace(ws, "option-all")
+    base = root / "stereo-option-all"
+    assert (base / "depth_maps").is_dir() and (base / "consistency_graphs").is_dir()
+    cfg = (base / "patch-match.cfg").read_text().splitlines()
+    assert cfg[0] == "00000000.jpg" and cfg[1] == "00000001.jpg, 00000002.jpg, "
+    assert (base / "fusion.cfg").read_text().split() == [f"{i:08d}.jpg" for i in range(4)]
+    # the written configuration parses back into the visibility lists
+    probs = W.read_patch_match_config(cfg, m)
+    assert probs == [(0, [1, 2]), (1, [0, 2, 3]), (2, [0, 1, 3]), (3, [1, 2])]
+    # explicit image list in the option file; malformed line
+    (root / "option-some").write_text("timages 2 1 3\n")
+    W.import_pmvs_workspace(ws, "option-some")
+    assert (base / "fusion.cfg").read_text().split() == ["00000001.jpg", "00000003.jpg"]
+    (root / "option-bad").write_text("timages 3 1 3\n")
+    with pytest.raises(ValueError):
+        W.import_pmvs_workspace(ws, "option-bad")
+    with pytest.raises(ValueError):
+        W.Workspace(str(tmp_path), "PMVS")                          # neither bundle.rd.out nor vis.dat
+    with pytest.raises(ValueError):
+        W.Workspace(str(root), "NVM")
+    # the controller sets the workspace up the same way (patch_match.cc:212-233)
+    ctl = mvs.PatchMatchController.FromWorkspace(
+        mvs.PatchMatchOptions(gpu_index="0", depth_min=1.0, depth_max=10.0), str(root), "PMVS", "option-all")
+    assert ctl.problems_ == [(0, [1, 2]), (1, [0, 2, 3]), (2, [0, 1, 3]), (3, [1, 2])]
+    assert ctl._paths(0, "photometric")[0] == str(base / "depth_maps" / "00000000.jpg.photometric.bin")
