@@ -13,7 +13,7 @@ CSRC = os.path.join(_ROOT, "csrc")
 LIB_DIR = os.path.join(_ROOT, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libcolmap_amd.so")
 
-SOURCES = ["pm_api.cpp", "pm_kernels.hip", "ba_api.cpp", "ba_kernels.hip", "fusion.cpp"]
+SOURCES = ["pm_api.cpp", "pm_kernels.hip", "ba_kernels.hip", "fusion.cpp"]
 
 # -ffp-contract=off: fused multiply-adds only where the source says fmaf(); the
 # arithmetic is specified operation by operation (oracle/pm_oracle.c header).
@@ -22,7 +22,11 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"
 
 
 def _sources():
-    return [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    paths = [os.path.join(CSRC, s) for s in SOURCES]
+    missing = [p for p in paths if not os.path.exists(p)]
+    if missing:  # a renamed / deleted source must not silently produce a partial library
+        raise FileNotFoundError(f"colmap_amd.build: missing sources {missing}")
+    return paths
 
 
 def needs_build() -> bool:

@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -552,6 +553,9 @@ void RunBatchAsync(pm_handle** hs, int n) {
   std::vector<PmParams> host((size_t)(limit + 1) * n);
   for (int b = 0; b < n; ++b) host[b] = ParamsForSweep(hs[b], 0);
   const float total_num_steps = (float)total_sweeps;
+  // workgroup -> (problem, column group) mapping of a batched sweep launch (pm_sweep_kernel)
+  static const int xcd_map_env = [] { const char* e = getenv("COLMAP_AMD_PM_XCD_MAP"); return e ? atoi(e) : 0; }();
+  const int xcd_map = (xcd_map_env == 1 && n % 8 == 0) ? 1 : 0;
   int sel_out = h0->base.sel_out_off, sel_in = h0->base.sel_in_off;
   for (int k = 0; k < limit; ++k) {
     const int iter = k / 4, sweep = k % 4;
@@ -564,6 +568,7 @@ void RunBatchAsync(pm_handle** hs, int n) {
       p.prev_sel_prob_weight = (float)(iter * 4 + sweep) / total_num_steps;
       p.sel_out_off = sel_out;
       p.sel_in_off = sel_in;
+      p.xcd_map = xcd_map;
       host[(size_t)(k + 1) * n + b] = p;
     }
     std::swap(sel_out, sel_in);  // Rotate(): prev_sel_prob <- sel_prob (reference :1911-1915)
@@ -846,6 +851,22 @@ int pm_get_pose_tables(pm_handle* h, float* poses, float* ref_K, float* ref_inv_
     if (poses) std::memcpy(poses, h->poses_host.data(), h->poses_host.size() * sizeof(float));
     if (ref_K) std::memcpy(ref_K, h->ref_K, sizeof(h->ref_K));
     if (ref_inv_K) std::memcpy(ref_inv_K, h->ref_inv_K, sizeof(h->ref_inv_K));
+  });
+}
+
+int pm_debug_rng_streams(int32_t gpu_index, const uint64_t* seeds, int32_t nseeds, int32_t ndraws,
+                         float* out) {
+  return Guard([&] {
+    PM_CHECK(seeds && out && nseeds > 0 && ndraws > 0, "bad arguments");
+    HIP_CALL(hipSetDevice(gpu_index));
+    DevBuf<unsigned long long> d_seeds;
+    DevBuf<float> d_out;
+    d_seeds.alloc((size_t)nseeds);
+    d_out.alloc((size_t)nseeds * ndraws);
+    HIP_CALL(hipMemcpy(d_seeds.ptr, seeds, sizeof(uint64_t) * nseeds, hipMemcpyHostToDevice));
+    pm_launch_rng_streams(d_seeds.ptr, nseeds, ndraws, d_out.ptr, nullptr);
+    HIP_CALL(hipDeviceSynchronize());
+    HIP_CALL(hipMemcpy(out, d_out.ptr, sizeof(float) * (size_t)nseeds * ndraws, hipMemcpyDeviceToHost));
   });
 }
 

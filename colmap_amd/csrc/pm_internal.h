@@ -26,6 +26,7 @@ struct PmParams {
   int sel_in_off;   // record offset of prev_sel_prob (read)
   int sel_out_off;  // record offset of sel_prob (backward msgs, then written)
   int C;            // image columns per workgroup
+  int xcd_map;      // batched launch: 0 problem = id % batch, 1 neighbouring problems per XCD
   float refK[4];    // rotated {fx, cx, fy, cy}
   float refInvK[4]; // rotated {1/fx, -cx/fx, 1/fy, -cy/fy}
   float perturbation;
@@ -66,6 +67,8 @@ void pm_launch_init_state(const PmParams& p, bool random_init, float depth_min, 
 void pm_launch_initial_cost(const PmParams& p, const PmParams* dev_params, int batch, hipStream_t st);
 void pm_launch_sweep(const PmParams& p, const PmParams* dev_params, int batch, int threads, bool geom,
                      bool filter_photo, bool filter_geom, hipStream_t st);
+void pm_launch_rng_streams(const unsigned long long* seeds, int nseeds, int ndraws, float* out,
+                           hipStream_t st);
 void pm_launch_extract(const PmParams& p, int sel_off, float* depth, float* normal, float* sel,
                        float* cost, hipStream_t st);
 

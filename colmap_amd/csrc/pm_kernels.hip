@@ -34,6 +34,7 @@
 
 #include <float.h>
 #include <math.h>
+#include <stdlib.h>
 
 namespace colmap_amd {
 
@@ -1055,7 +1056,13 @@ __global__ void __launch_bounds__(256, 3) pm_sweep_kernel(const PmParams* __rest
   // L2 even better but loses 11 % to load imbalance between image regions.)
   const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y;
   const unsigned group = lin / gridDim.y;
-  const PmParams& p = pp[lin - group * gridDim.y];
+  unsigned prob = lin - group * gridDim.y;
+  if (pp[0].xcd_map == 1) {
+    // neighbouring reference images on one XCD (batch a multiple of 8): XCD x = lin % 8 sweeps
+    // problems x * nb/8 .. (x + 1) * nb/8 - 1, which share all but one of their source images
+    prob = (prob & 7u) * (gridDim.y >> 3) + (prob >> 3);
+  }
+  const PmParams& p = pp[prob];
   extern __shared__ __attribute__((aligned(16))) char smem[];
   Lds L;
   lds_bind(L, (lds_char*)smem, lds_offsets(p.C, p.S, p.radius, p.ntaps, p.num_samples, GEOM));
@@ -1349,6 +1356,17 @@ __global__ void __launch_bounds__(256, 3) pm_sweep_kernel(const PmParams* __rest
   }
 }
 
+// Debug: raw XORWOW streams of the generator above (seed = sequence id, as InitRandomStateKernel
+// seeds it), for the bit comparison with rocRAND's rocrand_init / rocrand_uniform in the tests.
+__global__ void pm_rng_streams_kernel(const unsigned long long* __restrict__ seeds, int nseeds, int ndraws,
+                                      float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nseeds) return;
+  Rng rng;
+  rng_init(rng, seeds[i]);
+  for (int k = 0; k < ndraws; ++k) out[(size_t)i * ndraws + k] = rng_uniform(rng);
+}
+
 // pixel records -> API layout (Mat<float> slice-major, mat.h:107-109)
 __global__ void pm_extract_kernel(const PmParams p, int sel_off, float* __restrict__ depth,
                                   float* __restrict__ normal, float* __restrict__ sel,
@@ -1426,7 +1444,9 @@ void pm_launch_initial_cost(const PmParams& p, const PmParams* dev_params, int b
 
 void pm_launch_sweep(const PmParams& p, const PmParams* dev_params, int batch, int threads, bool geom,
                      bool filter_photo, bool filter_geom, hipStream_t st) {
-  const size_t lds = pm_sweep_lds_bytes(p, geom);
+  // debug knob: extra dynamic LDS per workgroup limits the workgroups resident per CU (occupancy curve)
+  static const size_t lds_pad = [] { const char* e = getenv("COLMAP_AMD_PM_LDS_PAD"); return e ? (size_t)atol(e) : 0; }();
+  const size_t lds = pm_sweep_lds_bytes(p, geom) + lds_pad;
   const int rw = (p.rot & 1) ? p.H : p.W;
   dim3 block(threads, 1, 1);
   dim3 grid((rw + p.C - 1) / p.C, batch, 1);
@@ -1450,6 +1470,12 @@ void pm_launch_sweep(const PmParams& p, const PmParams* dev_params, int batch, i
   }
 #undef PM_LAUNCH_N
 #undef PM_LAUNCH
+}
+
+void pm_launch_rng_streams(const unsigned long long* seeds, int nseeds, int ndraws, float* out,
+                           hipStream_t st) {
+  hipLaunchKernelGGL(pm_rng_streams_kernel, dim3((nseeds + 63) / 64), dim3(64), 0, st, seeds, nseeds,
+                     ndraws, out);
 }
 
 void pm_launch_extract(const PmParams& p, int sel_off, float* depth, float* normal, float* sel,

@@ -161,6 +161,13 @@ int pm_get_device_maps(pm_handle* h, const float** depth, const float** normal);
 int pm_enable_phase_profile(pm_handle* h, int enable);
 int pm_get_phase_profile(pm_handle* h, unsigned long long* out10);
 
+/* Debug: the first `ndraws` uniforms of the kernels' XORWOW generator for each 64-bit seed
+ * (= curand_init(seed, 0, 0) + curand_uniform, gpu_mat_prng.cu:36-48), computed on GPU
+ * `gpu_index`; out is host memory [nseeds][ndraws]. The tests compare it bit for bit with
+ * rocRAND (the library the reference's HIP build links). */
+int pm_debug_rng_streams(int32_t gpu_index, const uint64_t* seeds, int32_t nseeds, int32_t ndraws,
+                         float* out);
+
 void pm_destroy(pm_handle* h);
 const char* pm_last_error(void);
 /* Number of visible GPUs (controller: gpu_index == -1 -> all devices,

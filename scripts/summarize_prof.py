@@ -3,7 +3,9 @@ import csv, glob, json, os, sys
 from collections import defaultdict
 
 out = sys.argv[1]
+per_dispatch = "--per-dispatch" in sys.argv
 summary = {}
+dispatch_rows = {}
 # kernel stats
 for f in glob.glob(os.path.join(out, "stats", "**", "*kernel_stats.csv"), recursive=True):
     rows = list(csv.DictReader(open(f)))
@@ -34,6 +36,9 @@ for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
                 continue
             agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
             ndisp[k].add(r.get("Dispatch_Id"))
+            if per_dispatch and k == "pm_sweep_kernel":
+                row = dispatch_rows.setdefault(os.path.basename(d), {}).setdefault(int(r.get("Dispatch_Id", 0)), {})
+                row[r["Counter_Name"]] = row.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
     summary[os.path.basename(d)] = {k: dict(v, dispatches=len(ndisp[k])) for k, v in agg.items()}
 prev_path = os.path.join(out, "pmc_summary.json")
 if os.path.exists(prev_path):  # passes summarised earlier whose bulk output is already deleted
@@ -41,5 +46,11 @@ if os.path.exists(prev_path):  # passes summarised earlier whose bulk output is 
     for k, v in prev.items():
         if k not in summary or not summary[k]:
             summary[k] = v
+if per_dispatch:
+    pd_path = os.path.join(out, "pmc_per_dispatch.json")
+    prev_pd = json.load(open(pd_path)) if os.path.exists(pd_path) else {}
+    for k, v in dispatch_rows.items():
+        prev_pd[k] = [dict(v[i], dispatch=i) for i in sorted(v)]
+    json.dump(prev_pd, open(pd_path, "w"), indent=1)
 json.dump(summary, open(prev_path, "w"), indent=1)
 print(json.dumps(summary, indent=1))

@@ -229,6 +229,97 @@ def test_error_behaviour():
         mvs.PatchMatch(win, hip_problem(views, 1, [0, 2])).Run()      # window_step <= 2
 
 
+def test_device_xorwow_equals_rocrand_device():
+    """rng_init / rng_uniform of the product kernels against rocrand_init(seed, 0, 0) /
+    rocrand_uniform executed on the same GPU (tests/hip/rocrand_pin.hip), 1006 seeds x 40 draws."""
+    import ctypes as C
+    from colmap_amd._lib import lib
+    from test_pm_oracle import _pin_seeds, rocrand_pin_lib
+    seeds, nd = _pin_seeds(), 40
+    want = np.zeros((len(seeds), nd), np.float32)
+    got = np.zeros_like(want)
+    assert rocrand_pin_lib().rocrand_pin_device(seeds.ctypes.data_as(C.c_void_p), len(seeds), nd,
+                                                want.ctypes.data_as(C.c_void_p)) == 0
+    assert lib().pm_debug_rng_streams(0, seeds.ctypes.data_as(C.c_void_p), len(seeds), nd,
+                                      got.ctypes.data_as(C.c_void_p)) == 0
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+# ---- BASELINE.json shapes against the oracle (VERDICT r01: S = 20 / M = 15 was only property-tested) ----
+
+def test_baseline_source_count_s20_m15_photometric(pm_oracle):
+    """config[1]'s view count and sample count (S = 20 sources, 15 Monte-Carlo samples, 5 x 4 sweeps,
+    photometric + filter: task lists of up to 4 x 15 + 20 entries per column, 20 pose records,
+    20-wide CDF) on 96 x 72 images, bit-compared with the oracle."""
+    views = scene(22, 96, 72, 3.6 * 21)
+    ref = 10
+    src = [i for i in range(21) if i != ref]
+    assert len(src) == 20
+    want, got, _ = _run_both(pm_oracle, views, ref, src, geom_consistency=0, filter=1)
+    _assert_equal(want, got)
+
+
+def test_baseline_source_count_s20_m15_geometric(pm_oracle):
+    """The same shape with the geometric consistency term and both filters (config[2]'s pass 2);
+    source depth / normal maps = the renderer's ground truth."""
+    views = scene(22, 96, 72, 3.6 * 21)
+    ref = 11
+    src = [i for i in range(1, 22) if i != ref]
+    maps = [(v.depth, v.normal) for v in views]
+    want, got, _ = _run_both(pm_oracle, views, ref, src, maps=maps, geom_consistency=1, filter=1,
+                             num_iterations=2)
+    _assert_equal(want, got)
+
+
+def test_baseline_config0_640x480_two_pass(pm_oracle):
+    """BASELINE.json config[0]: 3 pinhole images 640 x 480 (f = 600), S = 2, default options --
+    photometric pass for every image, then the geometric pass on the middle one, all bit-compared."""
+    from colmap_amd import mvs
+    views = syn.make_scene(3, 640, 480, focal=600.0, arc_deg=8.0)
+    maps = []
+    for ref in range(3):
+        src = [i for i in range(3) if i != ref]
+        want, got, _ = _run_both(pm_oracle, views, ref, src, geom_consistency=0, filter=0)
+        _assert_equal(want, got, ("depth", "normal", "cost", "sel_prob"))
+        maps.append((got["depth"], got["normal"]))
+    want, got, _ = _run_both(pm_oracle, views, 1, [0, 2], maps=maps, geom_consistency=1, filter=1)
+    _assert_equal(want, got)
+    kept = got["depth"] > 0
+    rel = np.abs(got["depth"][kept] - views[1].depth[kept]) / views[1].depth[kept]
+    assert kept.mean() > 0.5 and np.median(rel) < 5e-3
+
+
+def test_bench_cpu_baseline_crop_problem(pm_oracle):
+    """The exact problem bench.py hands to the oracle for `cpu_baseline` (a 512 x 384 centre crop of a
+    2560 x 1920 reference image against its 20 full-resolution sources, 5 x 4 sweeps, photometric +
+    filter): the HIP path on the same inputs gives the same bits -- full-resolution source images
+    (packed 2563 x 1923 footprints, fp32 entry index), S = 20, M = 15."""
+    from colmap_amd import mvs
+    W, H, S, cw, ch = 2560, 1920, 20, 512, 384
+    views = syn.make_scene(S + 1, W, H, arc_deg=3.6 * S, device="cuda")
+    ref = S // 2
+    src = [i for i in range(S + 1) if i != ref]
+    x0, y0 = (W - cw) // 2, (H - ch) // 2
+    v = views[ref]
+    K = v.K.copy()
+    K[0, 2] -= x0
+    K[1, 2] -= y0
+    crop = syn.View(K, v.R, v.T, np.ascontiguousarray(v.gray[y0:y0 + ch, x0:x0 + cw]),
+                    np.ascontiguousarray(v.depth[y0:y0 + ch, x0:x0 + cw]), None)
+    mixed = [crop if i == ref else u for i, u in enumerate(views)]
+    dmin, dmax = float(v.depth.min() * 0.9), float(v.depth.max() * 1.1)
+    o, h = paired_options(pm_oracle, depth_min=dmin, depth_max=dmax, geom_consistency=0, filter=1)
+    want = pm_oracle.run(o, oracle_inputs(mixed), ref, src, want_cost=True)
+    pm = mvs.PatchMatch(h, hip_problem(mixed, ref, src))
+    pm.Run()
+    got = dict(depth=pm.GetDepthMap(), normal=pm.GetNormalMap(), sel_prob=pm.GetSelProbMap(),
+               cost=pm.GetCostMap(), mask=pm.GetConsistencyMask())
+    _assert_equal(want, got)
+    kept = got["depth"] > 0
+    rel = np.abs(got["depth"][kept] - crop.depth[kept]) / crop.depth[kept]
+    assert kept.mean() > 0.5 and np.median(rel) < 5e-3
+
+
 def test_against_committed_golden_fixture():
     """tests/golden/pm_48x36.npz (device-order oracle output, committed) reproduced by the HIP path."""
     import os

@@ -114,6 +114,37 @@ def test_xorwow_stream(pm_oracle):
         assert np.all(uni > 0) and np.all(uni <= 1)
 
 
+def _pin_seeds():
+    """Sequence ids as InitRandomStateKernel produces them (small), 32-bit boundary cases and random
+    64-bit values (both halves of the seed enter rocRAND's scrambling)."""
+    return np.concatenate([np.arange(0, 600, dtype=np.uint64),
+                           np.array([2**32 - 1, 2**32, 2**32 + 5, 2**40 + 123, 2**63 + 17, 2**64 - 1], np.uint64),
+                           np.random.default_rng(0).integers(0, 2**63, 400).astype(np.uint64)])
+
+
+def rocrand_pin_lib():
+    import ctypes as C, os, subprocess
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hip")
+    path = os.path.join(d, "librocrand_pin.so")
+    if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(os.path.join(d, "rocrand_pin.hip")):
+        subprocess.check_call(["make", "-C", d], stdout=subprocess.DEVNULL)
+    return C.CDLL(path)
+
+
+def test_xorwow_equals_rocrand_host_engine(pm_oracle):
+    """The oracle's generator against rocRAND itself -- rocrand_init(seed, 0, 0) + rocrand_uniform on
+    rocrand_state_xorwow, what curand_init / curand_uniform (gpu_mat_prng.cu:36-48) resolve to in the
+    reference's own HIP build -- through rocRAND's host path (tests/hip/rocrand_pin.hip), bit for bit."""
+    import ctypes as C
+    seeds, nd = _pin_seeds(), 40
+    want = np.zeros((len(seeds), nd), np.float32)
+    rocrand_pin_lib().rocrand_pin_host(seeds.ctypes.data_as(C.c_void_p), len(seeds), nd,
+                                       want.ctypes.data_as(C.c_void_p))
+    got = np.stack([pm_oracle.rng_stream(int(sd), nd)[1] for sd in seeds])
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert np.all(want > 0) and np.all(want <= 1)
+
+
 def test_texel_requantisation_is_identity():
     """FilterKernel re-quantises the reference image as uint8(255 * (b/255)) (reference
     gpu_mat_ref_image.cu:77); with correctly rounded b/255 this maps every byte to itself."""
