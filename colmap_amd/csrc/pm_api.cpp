@@ -555,7 +555,7 @@ void RunBatchAsync(pm_handle** hs, int n) {
   const float total_num_steps = (float)total_sweeps;
   // workgroup -> (problem, column group) mapping of a batched sweep launch (pm_sweep_kernel)
   static const int xcd_map_env = [] { const char* e = getenv("COLMAP_AMD_PM_XCD_MAP"); return e ? atoi(e) : 0; }();
-  const int xcd_map = (xcd_map_env == 1 && n % 8 == 0) ? 1 : 0;
+  const int xcd_map = (xcd_map_env == 1 && n % 8 == 0) ? 1 : (xcd_map_env == 2 ? 2 : 0);
   int sel_out = h0->base.sel_out_off, sel_in = h0->base.sel_in_off;
   for (int k = 0; k < limit; ++k) {
     const int iter = k / 4, sweep = k % 4;

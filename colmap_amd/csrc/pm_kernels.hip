@@ -1038,6 +1038,133 @@ __device__ __forceinline__ void run_tasks(const PmParams& p, const Lds& L, int r
   }
 }
 
+// ---------------------------------------------------------------------------
+// Single-wave workgroups (pm_sweep_wave_kernel below): the NCC evaluation split into the part
+// before the footprint gathers (warp, shared division, clamp, address: ncc_front) and the part
+// after them (byte conversion, lerp, window sums: ncc_back), so that all eight gathers of a lane
+// are in flight before the first texel is consumed. Arithmetic and order are those of ncc_group
+// (oracle/pm_oracle.c: ncc_cost_device); fixed 11 x 11 window (121 taps = one 128-tap chunk).
+// ---------------------------------------------------------------------------
+struct NccStage {
+  uint32_t tex[8];
+  v2f wx[4], wy[4];
+};
+
+// per-lane constants of the 11 x 11 window: tap offsets (dx, dy) * step of taps j + 16 k
+struct TapGeom {
+  v2f dx[4], dy[4];
+};
+__device__ __forceinline__ void tap_geom_init(TapGeom& G, int j, int step) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int t = j + 16 * (2 * q + e);
+      const int tt = t < 121 ? t : 0;
+      const int wrow = tt / 11;
+      const int wcol = tt - wrow * 11;
+      G.dx[q][e] = (float)(wcol * step);
+      G.dy[q][e] = (float)(wrow * step);
+    }
+  }
+}
+
+__device__ __forceinline__ void ncc_front(const PmParams& p, const lds_f32* H, gbl_u32* fp,
+                                          const TapGeom& G, int j, NccStage& st) {
+  const float h0 = H[0], h1 = H[1], h2 = H[2], h3 = H[3], h4 = H[4], h5 = H[5], h6 = H[6],
+              h7 = H[7], h8 = H[8];
+  v2f csrc[4], rsrc[4], pre[4], suf[4];
+  float zz[8];
+  float run = 1.0f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    csrc[q] = pk_fma(pk_bcast(h0), G.dx[q], pk_fma(pk_bcast(h1), G.dy[q], pk_bcast(h2)));
+    rsrc[q] = pk_fma(pk_bcast(h3), G.dx[q], pk_fma(pk_bcast(h4), G.dy[q], pk_bcast(h5)));
+    const v2f z = pk_fma(pk_bcast(h6), G.dx[q], pk_fma(pk_bcast(h7), G.dy[q], pk_bcast(h8)));
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const bool valid = j + 16 * (2 * q + e) < 121;
+      zz[2 * q + e] = valid ? z[e] : 1.0f;
+      pre[q][e] = run;
+      run = run * zz[2 * q + e];
+    }
+  }
+  const float rinv = 1.0f / run;
+  float sfx = 1.0f;
+#pragma unroll
+  for (int k = 7; k >= 0; --k) {
+    suf[k >> 1][k & 1] = sfx;
+    sfx = sfx * zz[k];
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const v2f inv_z = (pre[q] * suf[q]) * pk_bcast(rinv);
+    const v2f px = inv_z * csrc[q];
+    const v2f py = inv_z * rsrc[q];
+    v2f fx, fy;
+    fx[0] = floorf(px[0]);
+    fx[1] = floorf(px[1]);
+    fy[0] = floorf(py[0]);
+    fy[1] = floorf(py[1]);
+    st.wx[q] = px - fx;
+    st.wy[q] = py - fy;
+    const v2f fx2 = fx + pk_bcast(2.0f);
+    const v2f fy2 = fy + pk_bcast(2.0f);
+    st.tex[2 * q] = tap_gather<true>(p, fp, 0u, fx2[0], fy2[0]);
+    st.tex[2 * q + 1] = tap_gather<true>(p, fp, 0u, fx2[1], fy2[1]);
+  }
+}
+
+// The three 16-lane tree sums of an evaluation in one instruction block: 12 v_add_f32_dpp, each
+// value's next step separated from its previous one by the other two values' steps (the DPP
+// read-after-VALU-write hazard needs two wait states; inline asm is not seen by the compiler's
+// hazard recogniser, hence the leading s_nop). Same tree as reduce16.
+__device__ __forceinline__ void reduce16x3(float& a, float& b, float& c) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %1, %1 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %2, %2, %2 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %2, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %0, %0 quad_perm:[3,2,1,0] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %1, %1 quad_perm:[3,2,1,0] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %2, %2, %2 quad_perm:[3,2,1,0] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+      : "+v"(a), "+v"(b), "+v"(c));
+}
+
+__device__ __forceinline__ void ncc_back(const NccStage& st, const TapRegs& R, int j, float& s_sum,
+                                         float& s_sq, float& s_ref) {
+  v2f a_sum = pk_bcast(0.0f), a_sq = pk_bcast(0.0f), a_ref = pk_bcast(0.0f);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    v2f c00, c10, c01, c11;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const uint32_t x = j + 16 * (2 * q + e) < 121 ? st.tex[2 * q + e] : 0u;
+      c00[e] = ubyte0(x);
+      c10[e] = ubyte1(x);
+      c01[e] = ubyte2(x);
+      c11[e] = ubyte3(x);
+    }
+    const v2f top = pk_fma(st.wx[q], c10 - c00, c00);
+    const v2f bot = pk_fma(st.wx[q], c11 - c01, c01);
+    const v2f src = pk_fma(st.wy[q], bot - top, top) * pk_bcast(0x1.010102p-8f);
+    const v2f bws = R.w[q] * src;
+    a_sum = a_sum + bws;
+    a_sq = pk_fma(bws, src, a_sq);
+    a_ref = pk_fma(bws, R.r[q], a_ref);
+  }
+  s_sum = a_sum[0] + a_sum[1];
+  s_sq = a_sq[0] + a_sq[1];
+  s_ref = a_ref[0] + a_ref[1];
+  reduce16x3(s_sum, s_sq, s_ref);
+}
+
 // Optional phase profile: PROF instantiation only; wave 0 / lane 0 accumulates
 // shader-clock deltas per phase and adds them to p.prof[] at the end.
 #define PM_PROF_MARK(slot)                                   \
@@ -1356,6 +1483,433 @@ __global__ void __launch_bounds__(256, 3) pm_sweep_kernel(const PmParams* __rest
   }
 }
 
+// ---------------------------------------------------------------------------
+// SweepFromTopToBottom, single-wave workgroups (the default for the 11 x 11 window).
+//
+// Same algorithm, phases and arithmetic as pm_sweep_kernel above -- results are bit-identical --
+// but a workgroup is ONE wavefront that owns C (= 4) columns:
+//  * no workgroup barriers: with at most 64 threads per workgroup the compiler drops every
+//    s_barrier, the phases of a row step are ordered by LDS program order alone, and a wave is never
+//    parked behind its partner wave (in the two-wave version the waves spent most of their
+//    time at the ~14 barriers of a row step while 3 waves per SIMD had to hide the gathers);
+//  * twice as many independent waves per CU at the same register budget (12 workgroups per CU:
+//    the LDS carve-up below fits 12,800 B = 10 allocation granules of 1,280 B);
+//  * NCC tasks run in batches of kWaveThCap: homographies of a batch lane-per-task, then rounds of
+//    four 16-lane evaluations (ncc_front -> all eight gathers in flight -> ncc_back), then the
+//    normalisation lane-per-task.
+// ---------------------------------------------------------------------------
+constexpr int kWaveThCap = 48;  // NCC tasks per batch (homography ring in LDS)
+
+__device__ __forceinline__ uint32_t task16_pack(int c, int i, int s, int geom_only) {
+  return ((uint32_t)c << 13) | ((uint32_t)geom_only << 12) | ((uint32_t)i << 9) | (uint32_t)s;
+}
+
+__host__ __device__ inline LdsOffsets lds_offsets_wave(int C, int S, int radius, int ntaps, int M,
+                                                       bool geom) {
+  LdsOffsets o;
+  uint32_t off = 0;
+  auto take = [&](uint32_t bytes) {
+    const uint32_t at = off;
+    off += (bytes + 15u) & ~15u;
+    return at;
+  };
+  const int win = 2 * radius + 1;
+  const int tw = C + 2 * radius;
+  const int ms = M < S ? M : S;
+  const int per_view = geom ? 5 : 4;
+  const int max_tasks = C * (per_view * ms > S ? per_view * ms : S);
+  o.poses = take(4u * S * lds_pose_stride(geom));
+  o.fpb = take(8u * S);
+  o.tile = take(4u * win * tw);
+  o.wgt = take(4u * C * tap_stride(ntaps));
+  o.refc = take(4u * C * tap_stride(ntaps));
+  o.fm = take(4u * C * S);
+  o.q = take(4u * C * S);
+  o.costv = take(4u * C * S);
+  o.betav = take(4u * C * S);
+  o.prevv = take(4u * C * S);
+  o.ncc = take(4u * C * 4 * S);               // hypotheses 1..4 (0 is the cached cost map)
+  o.geo = take(geom ? 4u * C * 5 * S : 0u);
+  o.hyp = take(4u * C * 20);
+  o.colf = take(4u * C * 8);
+  const uint32_t us_bytes = 4u * C * M > 1u * C * S ? 4u * C * M : 1u * C * S;
+  o.us = take(us_bytes);
+  o.flags = o.us;                             // filter flags reuse the (then dead) uniform draws
+  o.sv = take(4u * C * M);
+  o.best = take(4u * C);
+  o.csum = take(4u * C * 5);
+  o.tasks = take(2u * max_tasks);             // 16-bit task words
+  o.th = take(36u * kWaveThCap);
+  o.ntasks = take(16u);
+  o.total = off;
+  return o;
+}
+
+template <bool GEOM>
+__device__ __forceinline__ void run_tasks_wave(const PmParams& p, const Lds& L, const TapGeom& G, int row,
+                                               int col0, int tid) {
+  const int n = *L.ntasks;
+  const LDS_AS uint16_t* tasks = (const LDS_AS uint16_t*)L.tasks;
+  const int g = tid >> 4, j = tid & 15;
+  const int S = p.S;
+  TapRegs R;
+  int c_held = -1;
+  for (int base = 0; base < n; base += kWaveThCap) {
+    const int nb = min(kWaveThCap, n - base);
+    // pass A, lane per task: homography of the (hypothesis, view) pair (+ geometric cost)
+    if (tid < nb) {
+      const uint32_t task = tasks[base + tid];
+      const int c = task >> 13;
+      const int geom_only = (task >> 12) & 1;
+      const int i = (task >> 9) & 7;
+      const int s = task & 0x1ff;
+      const lds_f32* h = L.hyp + (c * 5 + i) * 4;
+      const lds_f32* pose = L.poses + s * L.pstride;
+      const int col = col0 + c;
+      if (!geom_only) {
+        float Hm[9];
+        compose_homography(p.refInvK, pose, row, col, h[0], h[1], h[2], h[3], Hm);
+        centre_homography(Hm, row, col, p.radius);
+        for (int k = 0; k < 9; ++k) L.th[tid * 9 + k] = Hm[k];
+      }
+      if (GEOM) L.geo[(c * 5 + i) * S + s] = geom_cost(p, pose, s, (float)row, (float)col, h[0]);
+    }
+    __syncthreads();
+    // pass B, 16-lane group per task
+    for (int t = g; t < nb; t += 4) {
+      const uint32_t task = tasks[base + t];
+      if ((task >> 12) & 1) continue;  // geometric cost only
+      const int c = task >> 13;
+      const int s = task & 0x1ff;
+      if (c != c_held) {
+        tap_regs_load(R, L.wgt + c * 128, L.refc + c * 128, j);
+        c_held = c;
+      }
+      NccStage st;
+      ncc_front(p, L.th + t * 9, (gbl_u32*)L.fpb[s], G, j, st);
+      __builtin_amdgcn_sched_barrier(0);
+      float s_sum, s_sq, s_ref;
+      ncc_back(st, R, j, s_sum, s_sq, s_ref);
+      if (j == 0) {
+        L.th[t * 9 + 0] = s_sum;  // the homography of this task is no longer needed
+        L.th[t * 9 + 1] = s_sq;
+        L.th[t * 9 + 2] = s_ref;
+      }
+    }
+    __syncthreads();
+    // lane per task: normalisation, variances, square root, division
+    if (tid < nb) {
+      const uint32_t task = tasks[base + tid];
+      if (!((task >> 12) & 1)) {
+        const int c = task >> 13;
+        const int i = (task >> 9) & 7;
+        const int s = task & 0x1ff;
+        L.ncc[(c * 4 + i - 1) * S + s] = ncc_finish(L.th[tid * 9 + 0], L.th[tid * 9 + 1], L.th[tid * 9 + 2],
+                                                    L.colf[c * 8 + 0], L.colf[c * 8 + 1], L.colf[c * 8 + 5]);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <bool GEOM, bool FILTER_PHOTO, bool FILTER_GEOM>
+__global__ void __launch_bounds__(64, 3) pm_sweep_wave_kernel(const PmParams* __restrict__ pp) {
+  const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y;
+  unsigned group = lin / gridDim.y;
+  unsigned prob = lin - group * gridDim.y;
+  if (pp[0].xcd_map == 1) prob = (prob & 7u) * (gridDim.y >> 3) + (prob >> 3);  // see pm_sweep_kernel
+  if (pp[0].xcd_map == 2) {
+    // column-contiguous XCDs: workgroups are dealt to the 8 XCDs round-robin by linear id, so XCD
+    // x = lin % 8 takes, of every problem, the chunks of 8 adjacent column groups k = x, x + 8, ...
+    // (32 adjacent columns share one 128-byte line of a packed source row). The launcher pads
+    // grid.x to a multiple of 64 groups; surplus workgroups exit.
+    const unsigned x = lin & 7u, i = lin >> 3;
+    prob = i % gridDim.y;
+    const unsigned t = i / gridDim.y;
+    group = (((t >> 3) << 3) + x) * 8u + (t & 7u);
+    const PmParams& q = pp[prob];
+    const unsigned rw = (q.rot & 1) ? q.H : q.W;
+    if (group * q.C >= rw) return;
+  }
+  const PmParams& p = pp[prob];
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  Lds L;
+  lds_bind(L, (lds_char*)smem, lds_offsets_wave(p.C, p.S, p.radius, p.ntaps, p.num_samples, GEOM));
+  const int tid = threadIdx.x;
+  constexpr int nt = 64;
+  const int S = p.S, M = p.num_samples, C = p.C;
+  const int RW = rot_width(p), RH = rot_height(p);
+  const int col0 = group * C;
+  const int ncols = min(C, RW - col0);
+  const float* iK = p.refInvK;
+  TapGeom G;
+  tap_geom_init(G, tid & 15, p.step);
+
+  lds_load_poses(p, L, GEOM, tid, nt);
+
+  // ---- backward messages for all rows (:976-989); stored in sel_out ----------
+  for (int item = tid; item < ncols * S; item += nt) {
+    const int c = item / S;
+    const int s = item - c * S;
+    float beta = 0.5f;
+    for (int row = RH - 1; row >= 0; --row) {
+      float* rec = p.rec + (size_t)pix_index(p, row, col0 + c) * p.rec_stride;
+      beta = hmm_message<false>(p, rec[4 + s], beta);
+      rec[p.sel_out_off + s] = beta;
+    }
+    L.fm[c * S + s] = 0.5f;
+  }
+
+  // ---- per-column state kept by the column's lane (:1022-1028) ---------------
+  Rng rng;
+  rng.x0 = rng.x1 = rng.x2 = rng.x3 = rng.x4 = rng.d = 0;
+  const bool col_lane = tid < ncols;
+  if (col_lane) {
+    const int pix0 = pix_index(p, 0, col0 + tid);
+    rng = rng_load(p.rng + (size_t)pix0 * kRngWords);
+    const float* rec = p.rec + (size_t)pix0 * p.rec_stride;
+    float sx, sy;
+    normal_to_sweep(p.rot, rec[1], rec[2], sx, sy);
+    lds_f32* h1 = L.hyp + (tid * 5 + 1) * 4;
+    h1[0] = rec[0]; h1[1] = sx; h1[2] = sy; h1[3] = rec[3];
+  }
+  for (int r = -p.radius; r < p.radius; ++r) tile_load_row(p, L, col0, r, tid, nt);
+  __syncthreads();
+
+  for (int row = 0; row < RH; ++row) {
+    // ---- P0: scroll the reference tile (LocalRefImage::Read, :357-410) -------
+    tile_load_row(p, L, col0, row + p.radius, tid, nt);
+    if (tid == 0) *L.ntasks = 0;
+    __syncthreads();
+
+    // ---- P1: hypotheses (lane per column) + patch weights (all lanes) --------
+    if (col_lane) {
+      const int c = tid;
+      const int col = col0 + c;
+      const int pix = pix_index(p, row, col);
+      const float* rec = p.rec + (size_t)pix * p.rec_stride;
+      lds_f32* h = L.hyp + c * 20;
+      h[4] = propagate_depth(iK, h[4], h[6], h[7], (float)(row - 1), (float)row);
+      const float cd = rec[0];
+      float cn0, cn1;
+      normal_to_sweep(p.rot, rec[1], rec[2], cn0, cn1);
+      const float cn2 = rec[3];
+      const float dmin = (1.0f - p.perturbation) * cd;
+      const float dmax = (1.0f + p.perturbation) * cd;
+      const float rd = rng_uniform(rng) * (dmax - dmin) + dmin;
+      float rn0, rn1, rn2;
+      perturb_normal(iK, row, col, p.perturbation_pi, cn0, cn1, cn2, rng, rn0, rn1, rn2);
+      for (int m = 0; m < M; ++m) L.us[c * M + m] = rng_uniform(rng) - FLT_EPSILON;  // :1129
+      h[0] = cd; h[1] = cn0; h[2] = cn1; h[3] = cn2;
+      h[8] = rd; h[9] = rn0; h[10] = rn1; h[11] = rn2;
+      h[12] = cd; h[13] = rn0; h[14] = rn1; h[15] = rn2;
+      h[16] = rd; h[17] = cn0; h[18] = cn1; h[19] = cn2;
+      lds_f32* cf = L.colf + c * 8;
+      cf[0] = p.ref_sum[pix];
+      cf[1] = p.ref_sqsum[pix];
+      cf[2] = cd * (iK[0] * col + iK[1]);
+      cf[3] = cd * (iK[2] * row + iK[3]);
+      cf[4] = cd;
+    }
+    patch_weights(p, L, row, tid, nt);
+    for (int item = tid; item < ncols * 4 * S; item += nt) L.ncc[item] = -1.0f;
+    __syncthreads();
+
+    // ---- P2: per-view selection priors (:1070-1104), lane per (column, view) --
+    patch_weight_sums(p, L, ncols, tid, nt);
+    for (int item = tid; item < ncols * S; item += nt) {
+      const int c = item / S;
+      const int s = item - c * S;
+      const int col = col0 + c;
+      const float* rec = p.rec + (size_t)pix_index(p, row, col) * p.rec_stride;
+      const lds_f32* pose = L.poses + s * L.pstride;
+      const lds_f32* h = L.hyp + c * 20;
+      const lds_f32* cf = L.colf + c * 8;
+      const float cost = rec[4 + s];
+      const float beta = rec[p.sel_out_off + s];
+      const float prev = rec[p.sel_in_off + s];
+      L.costv[item] = cost;
+      L.betav[item] = beta;
+      L.prevv[item] = prev;
+      const float alpha = hmm_message<true>(p, cost, L.fm[item]);
+      const float sp = sel_prob_fn(alpha, beta, prev, p.prev_sel_prob_weight);
+      float cos_tri, cos_inc;
+      viewing_angles(pose, cf[2], cf[3], cf[4], h[1], h[2], h[3], cos_tri, cos_inc);
+      const float tp = tri_prob(p, cos_tri);
+      const float ip = inc_prob(p, cos_inc);
+      float Hm[9];
+      compose_homography(iK, pose, row, col, h[0], h[1], h[2], h[3], Hm);
+      const float rp = res_prob(Hm, (float)row, (float)col, p.radius);
+      L.q[item] = sp * tp * ip * rp;
+    }
+    __syncthreads();
+
+    // ---- P3a: TransformPDFToCDF (:683-696), sequential sum order, lane per column
+    if (col_lane) {
+      const int c = tid;
+      lds_f32* q = L.q + c * S;
+      float prob_sum = 0.0f;
+#pragma unroll 4
+      for (int i = 0; i < S; ++i) prob_sum += q[i];
+      const float inv_prob_sum = 1.0f / prob_sum;
+      float cum = 0.0f;
+#pragma unroll 4
+      for (int i = 0; i < S; ++i) {
+        cum += q[i] * inv_prob_sum;
+        q[i] = cum;
+      }
+    }
+    __syncthreads();
+    // ---- P3b: Monte-Carlo view draws (:1128-1138), lane per (column, draw) ----
+    for (int item = tid; item < ncols * M; item += nt) {
+      const int c = item / M;
+      const float u = L.us[item];
+      const lds_f32* q = L.q + c * S;
+      int src = -1;
+      for (int s = 0; s < S; ++s) {
+        if (q[s] > u) { src = s; break; }
+      }
+      L.sv[item] = src;
+    }
+    __syncthreads();
+    // ---- P3c: one task set per distinct drawn view, lane per (column, view) ---
+    {
+      LDS_AS uint16_t* tasks = (LDS_AS uint16_t*)L.tasks;
+      for (int item = tid; item < ncols * S; item += nt) {
+        const int c = item / S;
+        const int s = item - c * S;
+        bool drawn = false;
+        for (int m = 0; m < M; ++m) drawn |= (L.sv[c * M + m] == s);
+        if (drawn) {
+          const int n_new = GEOM ? 5 : 4;
+          const int base = __hip_atomic_fetch_add(L.ntasks, n_new, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          for (int i = 1; i < 5; ++i) tasks[base + i - 1] = (uint16_t)task16_pack(c, i, s, 0);
+          if (GEOM) tasks[base + 4] = (uint16_t)task16_pack(c, 0, s, 1);
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- P4: NCC of hypotheses 1..4 against the drawn views (:1157-1172) -----
+    run_tasks_wave<GEOM>(p, L, G, row, col0, tid);
+    if (tid == 0) *L.ntasks = 0;
+    __syncthreads();
+
+    // ---- P5a: accumulate in draw order (:1144-1172), lane per (column, hypothesis)
+    for (int item = tid; item < ncols * 5; item += nt) {
+      const int c = item / 5;
+      const int i = item - c * 5;
+      float acc = 0.0f;
+      for (int m = 0; m < M; ++m) {
+        const int src = L.sv[c * M + m];
+        if (src < 0) continue;
+        acc += (i == 0) ? L.costv[c * S + src] : L.ncc[(c * 4 + i - 1) * S + src];
+        if (GEOM) acc += p.geom_reg * L.geo[(c * 5 + i) * S + src];
+      }
+      L.csum[item] = acc;
+    }
+    __syncthreads();
+    // ---- P5b: argmin, store, next row's previous state (:1176-1182,1279-1282) --
+    if (col_lane) {
+      const int c = tid;
+      int min_idx = 0;
+      float min_cost = L.csum[c * 5];
+#pragma unroll
+      for (int i = 1; i < 5; ++i) {
+        const float ci = L.csum[c * 5 + i];
+        if (ci <= min_cost) { min_cost = ci; min_idx = i; }
+      }
+      L.best[c] = min_idx;
+      const lds_f32* hb = L.hyp + (c * 5 + min_idx) * 4;
+      const float bd = hb[0], b0 = hb[1], b1 = hb[2], b2 = hb[3];
+      float* rec = p.rec + (size_t)pix_index(p, row, col0 + c) * p.rec_stride;
+      float nx, ny;
+      normal_from_sweep(p.rot, b0, b1, nx, ny);
+      rec[0] = bd; rec[1] = nx; rec[2] = ny; rec[3] = b2;
+      lds_f32* h1 = L.hyp + (c * 5 + 1) * 4;
+      h1[0] = bd; h1[1] = b0; h1[2] = b1; h1[3] = b2;
+    }
+    __syncthreads();
+    // ---- P5c: winner vs. the views not evaluated yet, lane per (column, view) --
+    {
+      LDS_AS uint16_t* tasks = (LDS_AS uint16_t*)L.tasks;
+      for (int item = tid; item < ncols * S; item += nt) {
+        const int c = item / S;
+        const int s = item - c * S;
+        const int k = L.best[c];
+        if (k != 0 && L.ncc[(c * 4 + k - 1) * S + s] < 0.0f) {
+          const int base = __hip_atomic_fetch_add(L.ntasks, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          tasks[base] = (uint16_t)task16_pack(c, k, s, 0);
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- P6: NCC of the winner against the remaining views (:1188-1197) ------
+    run_tasks_wave<false>(p, L, G, row, col0, tid);
+
+    // ---- P7: cost map, forward message, selection probability (:1186-1207) ---
+    for (int item = tid; item < ncols * S; item += nt) {
+      const int c = item / S;
+      const int s = item - c * S;
+      const int col = col0 + c;
+      const int k = L.best[c];
+      float* rec = p.rec + (size_t)pix_index(p, row, col) * p.rec_stride;
+      float cost;
+      if (k == 0) {
+        cost = L.costv[item];
+      } else {
+        cost = L.ncc[(c * 4 + k - 1) * S + s];
+        rec[4 + s] = cost;
+      }
+      const float alpha = hmm_message<true>(p, cost, L.fm[item]);
+      const float prob = sel_prob_fn(alpha, L.betav[item], L.prevv[item], p.prev_sel_prob_weight);
+      L.fm[item] = alpha;
+      rec[p.sel_out_off + s] = prob;
+      if (FILTER_PHOTO || FILTER_GEOM) {
+        const lds_f32* hb = L.hyp + (c * 5 + 1) * 4;  // == best (stored in P5)
+        const lds_f32* pose = L.poses + s * L.pstride;
+        const float bp0 = hb[0] * (iK[0] * col + iK[1]);
+        const float bp1 = hb[0] * (iK[2] * row + iK[3]);
+        const float bp2 = hb[0];
+        float cos_tri, cos_inc;
+        viewing_angles(pose, bp0, bp1, bp2, hb[1], hb[2], hb[3], cos_tri, cos_inc);
+        int ok = 0;
+        if (!(cos_tri > p.filter_cos_min_tri || cos_inc <= 0.0f)) {
+          const float min_ncc_prob = ncc_prob(p, 1.0f - p.filter_min_ncc);
+          bool photo_ok = true, geom_ok = true;
+          if (FILTER_PHOTO) photo_ok = prob >= min_ncc_prob;
+          if (FILTER_GEOM)
+            geom_ok = geom_cost(p, pose, s, (float)row, (float)col, hb[0]) <= p.filter_geom_max_cost;
+          ok = (photo_ok && geom_ok) ? 1 : 0;
+        }
+        L.flags[item] = ok;
+      }
+    }
+    if (FILTER_PHOTO || FILTER_GEOM) {
+      __syncthreads();
+      if (col_lane) {
+        const int c = tid;
+        int num = 0;
+        for (int s = 0; s < S; ++s) num += L.flags[c * S + s];
+        const int pix = pix_index(p, row, col0 + c);
+        if (num < p.filter_min_num_consistent) {
+          float* rec = p.rec + (size_t)pix * p.rec_stride;
+          rec[0] = 0.0f; rec[1] = 0.0f; rec[2] = 0.0f; rec[3] = 0.0f;
+        } else {
+          for (int s = 0; s < S; ++s)
+            if (L.flags[c * S + s]) p.mask[(size_t)s * p.W * p.H + pix] = 1;
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  if (col_lane) {
+    rng_store(p.rng + (size_t)pix_index(p, 0, col0 + tid) * kRngWords, rng);  // :1285-1287
+  }
+}
+
 // Debug: raw XORWOW streams of the generator above (seed = sequence id, as InitRandomStateKernel
 // seeds it), for the bit comparison with rocRAND's rocrand_init / rocrand_uniform in the tests.
 __global__ void pm_rng_streams_kernel(const unsigned long long* __restrict__ seeds, int nseeds, int ndraws,
@@ -1450,6 +2004,27 @@ void pm_launch_sweep(const PmParams& p, const PmParams* dev_params, int batch, i
   const int rw = (p.rot & 1) ? p.H : p.W;
   dim3 block(threads, 1, 1);
   dim3 grid((rw + p.C - 1) / p.C, batch, 1);
+  // Default for the 11 x 11 window: single-wave workgroups (pm_sweep_wave_kernel); the two-wave
+  // kernel remains for other windows, very wide groups and as the A/B reference
+  // (COLMAP_AMD_PM_WAVE=0).
+  static const bool wave_enabled = [] { const char* e = getenv("COLMAP_AMD_PM_WAVE"); return !e || atoi(e) != 0; }();
+  if (wave_enabled && !p.prof && p.ntap1d == 11 && p.step >= 1 && pm_fixed_window_ok(p) && p.S <= 512 && p.C <= 8) {
+    const size_t wlds = lds_offsets_wave(p.C, p.S, p.radius, p.ntaps, p.num_samples, geom).total + lds_pad;
+    dim3 wblock(64, 1, 1);
+    dim3 wgrid = grid;
+    if (p.xcd_map == 2) wgrid.x = ((grid.x + 63) / 64) * 64;
+#define PM_LAUNCH_W(G, FP, FG) \
+  hipLaunchKernelGGL((pm_sweep_wave_kernel<G, FP, FG>), wgrid, wblock, wlds, st, dev_params)
+    if (geom) {
+      if (filter_photo && filter_geom) PM_LAUNCH_W(true, true, true);
+      else PM_LAUNCH_W(true, false, false);
+    } else {
+      if (filter_photo) PM_LAUNCH_W(false, true, false);
+      else PM_LAUNCH_W(false, false, false);
+    }
+#undef PM_LAUNCH_W
+    return;
+  }
 #define PM_LAUNCH_N(N, G, FP, FG, PR) \
   hipLaunchKernelGGL((pm_sweep_kernel<N, G, FP, FG, PR>), grid, block, lds, st, dev_params)
 #define PM_LAUNCH(G, FP, FG)                      \

@@ -28,7 +28,7 @@ for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             name = r.get("Kernel_Name", "")
-            if "pm_sweep_kernel" in name:
+            if "pm_sweep" in name:
                 k = "pm_sweep_kernel"
             elif "pm_initial_cost" in name:
                 k = "pm_initial_cost_kernel"

@@ -286,7 +286,9 @@ def test_baseline_config0_640x480_two_pass(pm_oracle):
     _assert_equal(want, got)
     kept = got["depth"] > 0
     rel = np.abs(got["depth"][kept] - views[1].depth[kept]) / views[1].depth[kept]
-    assert kept.mean() > 0.5 and np.median(rel) < 5e-3
+    # with S = 2 the filter needs BOTH sources consistent (filter_min_num_consistent = 2): about half
+    # of the pixels survive on this scene (0.49 for the oracle)
+    assert kept.mean() > 0.3 and np.median(rel) < 5e-3
 
 
 def test_bench_cpu_baseline_crop_problem(pm_oracle):
