@@ -32,6 +32,22 @@ def _wxyz_t(xyzw_t: np.ndarray) -> np.ndarray:
     return np.array([xyzw_t[3], xyzw_t[0], xyzw_t[1], xyzw_t[2], xyzw_t[4], xyzw_t[5], xyzw_t[6]], np.float64)
 
 
+def _rigid_inverse(p: np.ndarray) -> np.ndarray:
+    """Inverse(Rigid3d) on xyzw + t params (geometry/rigid3.h:97-103)."""
+    q = np.array([-p[0], -p[1], -p[2], p[3]], np.float64)
+    return np.concatenate([q, -(scene.quat_to_rot(q) @ p[4:])])
+
+
+def _sensor_from_rig_of(sm: W.SparseModel, rig_id: int, camera_id: int) -> Optional[np.ndarray]:
+    """xyzw + t sensor_from_rig of a camera in a rig of the file model; None for the reference sensor
+    (identity) or when the rig does not list the camera."""
+    rig = sm.rigs.get(rig_id)
+    if rig is None or rig.ref_sensor == (_CAMERA, camera_id):
+        return None
+    pose = rig.sensors.get((_CAMERA, camera_id))
+    return None if pose is None else _xyzw_t(pose)
+
+
 def reconstruction_from_sparse_model(sm: W.SparseModel) -> scene.Reconstruction:
     """The slice of colmap::Reconstruction bundle adjustment touches. A legacy model (no rigs /
     frames files) gets one trivial frame per image (CreateOneRigPerCamera / CreateFrameForImage,
@@ -59,8 +75,21 @@ def reconstruction_from_sparse_model(sm: W.SparseModel) -> scene.Reconstruction:
                 f.image_ids.append(int(data_id))
                 frame_of_image[int(data_id)] = fid
         rec.frames[fid] = f
+    # With rigs / frames files the frame poses are authoritative: the reference ignores the pose
+    # stored in images.bin (reconstruction_io_binary.cc:176-214). Images of trivial (single-camera)
+    # rigs therefore take cam_from_world = sensor_from_rig * rig_from_world from their frame.
+    file_frame_pose = {}
+    for fid, fr in sm.frames.items():
+        if fr.rig_id in rec.rigs:
+            continue
+        for (stype, sid, data_id) in fr.data_ids:
+            if stype == _CAMERA and data_id in sm.images:
+                rfw = _xyzw_t(fr.rig_from_world)
+                sfr = _sensor_from_rig_of(sm, fr.rig_id, int(sid))
+                file_frame_pose[int(data_id)] = rfw if sfr is None else scene.rigid_compose(sfr, rfw)
     for iid, im in sm.images.items():
         pose = np.concatenate([[im.qvec[1], im.qvec[2], im.qvec[3], im.qvec[0]], im.tvec]).astype(np.float64)
+        pose = file_frame_pose.get(iid, pose)
         img = scene.Image(iid, im.camera_id, pose, frame_id_=frame_of_image.get(iid))
         img.points2D = [scene.Point2D(np.array(xy, np.float64), int(pid) if pid >= 0 and int(pid) in sm.points3D else -1)
                         for xy, pid in zip(im.xys, im.point3D_ids)]
@@ -143,6 +172,19 @@ def update_sparse_model(sm: W.SparseModel, rec: scene.Reconstruction):
         im.point3D_ids = np.array([q.point3D_id for q in img.points2D], np.int64)
     for fid, fr in rec.frames.items():
         sm.frames[fid].rig_from_world = _wxyz_t(fr.rig_from_world)
+    # frames of trivial (single-camera) rigs are not in rec.frames: their rig_from_world follows the
+    # adjusted image pose -- rig_from_world = inverse(sensor_from_rig) * cam_from_world -- because a
+    # reader of the output takes poses from frames.bin, not from images.bin
+    for fid, fr in sm.frames.items():
+        if fid in rec.frames:
+            continue
+        for (stype, sid, data_id) in fr.data_ids:
+            if stype == _CAMERA and int(data_id) in rec.images:
+                cfw = rec.images[int(data_id)].cam_from_world
+                sfr = _sensor_from_rig_of(sm, fr.rig_id, int(sid))
+                rfw = cfw if sfr is None else scene.rigid_compose(_rigid_inverse(sfr), cfw)
+                fr.rig_from_world = _wxyz_t(rfw)
+                break
     errs = point3D_errors(rec)
     for pid in list(sm.points3D):
         if pid not in rec.points3D:

@@ -872,14 +872,33 @@ __global__ void __launch_bounds__(64) ba_block_jtv_kernel(View V, const double* 
   double acc[BD], dacc[BD];
 #pragma unroll
   for (int c = 0; c < BD; ++c) acc[c] = dacc[c] = 0.0;
-  for (int o = V.chunk_beg[ch] + threadIdx.x; o < V.chunk_end[ch]; o += 64) {
+  // two observations per lane and trip (o, o + 64): twice the loads in flight; the accumulation order
+  // of a lane stays o, o + 64, o + 128, ... as in the rolled loop
+  const int end = V.chunk_end[ch];
+  for (int o = V.chunk_beg[ch] + threadIdx.x; o < end; o += 128) {
+    const int o2 = o + 64;
+    const bool two = o2 < end;
+    const int oz = two ? o2 : o;
     const double v0 = v[o], v1 = v[N + o];
+    const double w0 = v[oz], w1 = v[N + oz];
+    double j0[BD], j1[BD], k0[BD], k1[BD];
 #pragma unroll
     for (int c = 0; c < BD; ++c)
       if (c < dim) {
-        const double j0 = blk_col(V, kind, 0, c)[o], j1 = blk_col(V, kind, 1, c)[o];
-        acc[c] += j0 * v0 + j1 * v1;
-        if (DIAG) dacc[c] += j0 * j0 + j1 * j1;
+        const double* c0 = blk_col(V, kind, 0, c);
+        const double* c1 = blk_col(V, kind, 1, c);
+        j0[c] = c0[o]; j1[c] = c1[o];
+        k0[c] = c0[oz]; k1[c] = c1[oz];
+      }
+#pragma unroll
+    for (int c = 0; c < BD; ++c)
+      if (c < dim) {
+        acc[c] += j0[c] * v0 + j1[c] * v1;
+        if (DIAG) dacc[c] += j0[c] * j0[c] + j1[c] * j1[c];
+        if (two) {
+          acc[c] += k0[c] * w0 + k1[c] * w1;
+          if (DIAG) dacc[c] += k0[c] * k0[c] + k1[c] * k1[c];
+        }
       }
   }
   (void)off;
@@ -926,28 +945,80 @@ __global__ void ba_block_mat_finalize_kernel(View V, double* __restrict__ M) {
   }
 }
 
-// Schur-Jacobi diagonal blocks, part 1: B_bb = sum_o J_b,o^T J_b,o on the f64 matrix cores.
-// One wave per chunk. Lane l holds element (row k = l >> 4 of the current 4-row slab, column
-// i = l & 15) of the slab of J_b; with A = B = that slab, v_mfma_f64_16x16x4_f64 accumulates the
-// 16x16 Gram tile (columns >= dim are zero). C/D layout: col = l & 15, row = (l >> 4) + 4 * reg.
+// Schur-Jacobi diagonal blocks on the f64 matrix cores.
+//
+// M_b = B_bb - sum_j W_bj C_j^-1 W_bj^T with W_bj = sum_{o in (b,j)} J_b,o^T E_o. For an observation
+// that is the only one of its point in block b (every pose block of a COLMAP track, every
+// intrinsics block of a per-image camera) the point's term is J_b,o^T G_o J_b,o with the 2 x 2
+// G_o = E_o C_j^-1 E_o^T, so the block is ONE Gram-like contraction
+//     M_b = sum_o J_b,o^T (I - G_o) J_b,o
+// -- A = a 4-row slab of J_b (two observations x two residual rows), B = (I - G) applied to the
+// same slab, v_mfma_f64_16x16x4_f64 accumulates the 16 x 16 tile (columns >= dim are zero). G_o is
+// computed where C^-1 is local (ba_obs_schur_g_kernel, p-order) and stored in c-order. Observation
+// pairs of one point inside one block (shared intrinsics, rig frames) add their cross terms in
+// ba_block_schur_cross_kernel; the self term is already in (I - G).
+// One wave per chunk. Lane l holds column i = l & 15 and slab row k = l >> 4 (k = 2 * observation
+// in slab + residual row). C/D layout: col = l & 15, row = (l >> 4) + 4 * reg.
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 
-__global__ void __launch_bounds__(64) ba_block_gram_kernel(View V, double* __restrict__ M) {
+// G_o = E_o C_j^-1 E_o^T (g00, g01, g11), lane per observation in p-order, stored at the c-order
+// position; constant points (no point block) have G = 0.
+__global__ void __launch_bounds__(256) ba_obs_schur_g_kernel(View V, const double* __restrict__ Cinv,
+                                                             double* __restrict__ G) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= V.n_obs) return;
+  const size_t N = (size_t)V.n_obs;
+  const int c = V.a2c[a];
+  const int j = V.o_pt[c];
+  double g00 = 0.0, g01 = 0.0, g11 = 0.0;
+  if (V.pt_off[j] >= 0) {
+    const double* Ci = Cinv + 9 * (size_t)j;
+    const double e00 = V.Jpt[a], e01 = V.Jpt[N + a], e02 = V.Jpt[2 * N + a];
+    const double e10 = V.Jpt[3 * N + a], e11 = V.Jpt[4 * N + a], e12 = V.Jpt[5 * N + a];
+    // T = E C^-1 (2 x 3)
+    const double t00 = e00 * Ci[0] + e01 * Ci[3] + e02 * Ci[6], t01 = e00 * Ci[1] + e01 * Ci[4] + e02 * Ci[7],
+                 t02 = e00 * Ci[2] + e01 * Ci[5] + e02 * Ci[8];
+    const double t10 = e10 * Ci[0] + e11 * Ci[3] + e12 * Ci[6], t11 = e10 * Ci[1] + e11 * Ci[4] + e12 * Ci[7],
+                 t12 = e10 * Ci[2] + e11 * Ci[5] + e12 * Ci[8];
+    g00 = t00 * e00 + t01 * e01 + t02 * e02;
+    g01 = t00 * e10 + t01 * e11 + t02 * e12;
+    g11 = t10 * e10 + t11 * e11 + t12 * e12;
+  }
+  G[c] = g00;
+  G[N + c] = g01;
+  G[2 * N + c] = g11;
+}
+
+__global__ void __launch_bounds__(64) ba_block_gram_kernel(View V, const double* __restrict__ G) {
   const int ch = blockIdx.x;
   const int b = V.chunk_blk[ch];
   const int kind = V.blk_kind[b], dim = V.blk_dim[b];
   const int lane = threadIdx.x;
-  const int i = lane & 15, k = lane >> 4;  // column, row-in-slab (k = 2 * obs_in_slab + residual row)
+  const int i = lane & 15, k = lane >> 4;  // column, row-in-slab
+  const int r = k & 1, oo = k >> 1;        // residual row, observation within the slab
   const int beg = V.chunk_beg[ch], end = V.chunk_end[ch];
+  const size_t N = (size_t)V.n_obs;
   v4f64 acc = {0.0, 0.0, 0.0, 0.0};
-  const double* col = (i < dim) ? blk_col(V, kind, k & 1, i) : nullptr;
-  for (int s = beg; s < end; s += 2) {  // two observations = four residual rows per MFMA
-    const int idx = s + (k >> 1);
-    double a = 0.0;
-    if (col != nullptr && idx < end) a = col[idx];
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, acc, 0, 0, 0);
+  const bool col_ok = i < dim;
+  const double* col0 = col_ok ? blk_col(V, kind, 0, i) : nullptr;
+  const double* col1 = col_ok ? blk_col(V, kind, 1, i) : nullptr;
+  constexpr int U = 4;  // slabs per trip: the loads of four MFMAs are in flight together
+  for (int s = beg; s < end; s += 2 * U) {
+    double a[U], bb[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int idx = s + 2 * u + oo;
+      a[u] = bb[u] = 0.0;
+      if (col_ok && idx < end) {
+        const double j0 = col0[idx], j1 = col1[idx];
+        const double g00 = G[idx], g01 = G[N + idx], g11 = G[2 * N + idx];
+        a[u] = r ? j1 : j0;
+        bb[u] = r ? j1 - (g01 * j0 + g11 * j1) : j0 - (g00 * j0 + g01 * j1);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], bb[u], acc, 0, 0, 0);
   }
-  (void)M;
 #pragma unroll
   for (int reg = 0; reg < 4; ++reg) {
     const int row = k + 4 * reg;
@@ -955,11 +1026,10 @@ __global__ void __launch_bounds__(64) ba_block_gram_kernel(View V, double* __res
   }
 }
 
-// Schur-Jacobi diagonal blocks, part 2: - sum_j W C_j^-1 W'^T over pairs of observations of the
-// same point that share the block (W = J_b^T E, dim x 3). One lane per observation of the block.
+// Cross terms - sum_{o != o2 in (b,j)} (J_b,o^T E_o) C_j^-1 (J_b,o2^T E_o2)^T of observation pairs of one
+// point inside one block (only launched when such pairs exist). One lane per observation.
 template <int BD>
-__global__ void __launch_bounds__(64) ba_block_schur_corr_kernel(View V, const double* __restrict__ Cinv,
-                                                                double* __restrict__ M) {
+__global__ void __launch_bounds__(64) ba_block_schur_cross_kernel(View V, const double* __restrict__ Cinv) {
   const int ch = blockIdx.x;
   const int b = V.chunk_blk[ch];
   const int kind = V.blk_kind[b], dim = V.blk_dim[b], boff = V.blk_off[b];
@@ -968,6 +1038,7 @@ __global__ void __launch_bounds__(64) ba_block_schur_corr_kernel(View V, const d
 #pragma unroll
   for (int e = 0; e < BD * BD; ++e) acc[e] = 0.0;
   for (int o = V.chunk_beg[ch] + threadIdx.x; o < V.chunk_end[ch]; o += 64) {
+    if ((V.solo[o] >> kind) & 1) continue;  // no partner in this block
     const int xi = V.o_pt[o];
     if (V.pt_off[xi] < 0) continue;
     const int a = V.c2a[o];
@@ -985,18 +1056,8 @@ __global__ void __launch_bounds__(64) ba_block_schur_corr_kernel(View V, const d
     for (int x = 0; x < BD; ++x)
 #pragma unroll
       for (int c = 0; c < 3; ++c) T[x][c] = W1[x][0] * Ci[c] + W1[x][1] * Ci[3 + c] + W1[x][2] * Ci[6 + c];
-    if ((V.solo[o] >> kind) & 1) {
-      // the only observation of this point in this block (always true for pose blocks of COLMAP
-      // tracks, and for intrinsics blocks of per-image cameras): the pair sum is W1 C^-1 W1^T
-#pragma unroll
-      for (int x = 0; x < BD; ++x)
-#pragma unroll
-        for (int y = 0; y < BD; ++y)
-          if (x < dim && y < dim) acc[x * BD + y] -= T[x][0] * W1[y][0] + T[x][1] * W1[y][1] + T[x][2] * W1[y][2];
-      continue;
-    }
-    // partners: observations of the same point that map to the same block (self included)
     for (int a2 = V.pt_ptr[xi]; a2 < V.pt_ptr[xi + 1]; ++a2) {
+      if (a2 == a) continue;  // the self term is part of (I - G) in the Gram kernel
       const int o2 = V.a2c[a2];
       const int off2 = kind == 0 ? V.pose_off[V.o_pose[o2]] : V.cam_off[V.o_cam[o2]];
       if (off2 != boff) continue;
@@ -1014,14 +1075,13 @@ __global__ void __launch_bounds__(64) ba_block_schur_corr_kernel(View V, const d
       }
     }
   }
-  (void)M;
 #pragma unroll
   for (int x = 0; x < BD; ++x)
 #pragma unroll
     for (int y = 0; y < BD; ++y)
       if (x < dim && y < dim) {
-        const double s = wave_sum(acc[x * BD + y]);
-        if (threadIdx.x == 0) V.cpart[(size_t)ch * BD * BD + x * dim + y] = s;
+        const double sx = wave_sum(acc[x * BD + y]);
+        if (threadIdx.x == 0) V.cpart[(size_t)ch * BD * BD + x * dim + y] = sx;
       }
 }
 
@@ -1079,12 +1139,14 @@ __global__ void ba_dsq_x_kernel(int n, const double* __restrict__ D, const doubl
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) y[i] = D[i] * D[i] * x[i];
 }
-// z_b = Minv_b r_b ; rho = r.z   (single workgroup: deterministic sum)
-__global__ void __launch_bounds__(1024) ba_pcg_precond_kernel(View V, const double* __restrict__ Minv,
-                                                              const double* __restrict__ r,
-                                                              double* __restrict__ z) {
+// z_b = Minv_b r_b, lane per block over many workgroups; rho = r.z as one partial per workgroup
+// (fixed tree inside a workgroup, partials added in index order by pcg_rho: deterministic).
+__global__ void __launch_bounds__(256) ba_pcg_precond_kernel(View V, const double* __restrict__ Minv,
+                                                             const double* __restrict__ r,
+                                                             double* __restrict__ z, double* __restrict__ part) {
   double rho = 0.0;
-  for (int b = threadIdx.x; b < V.n_blk; b += 1024) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b < V.n_blk) {
     const int n = V.blk_dim[b], off = V.blk_off[b];
     const double* Mi = Minv + V.blk_moff[b];
     for (int i = 0; i < n; ++i) {
@@ -1095,14 +1157,19 @@ __global__ void __launch_bounds__(1024) ba_pcg_precond_kernel(View V, const doub
     }
   }
   rho = block_sum(rho);
-  if (threadIdx.x == 0) V.scalars[S_RHO] = rho;
+  if (threadIdx.x == 0) part[blockIdx.x] = rho;
+}
+__device__ __forceinline__ double pcg_rho(const double* __restrict__ part, int nparts) {
+  double rho = 0.0;
+  for (int w = 0; w < nparts; ++w) rho += part[w];
+  return rho;
 }
 // p = z + (rho / rho_last) p   (first iteration: p = z)
-__global__ void ba_pcg_dir_kernel(int n, const double* __restrict__ scalars, int first, const double* __restrict__ z,
-                                  double* __restrict__ p) {
+__global__ void ba_pcg_dir_kernel(int n, const double* __restrict__ scalars, const double* __restrict__ part,
+                                  int nparts, int first, const double* __restrict__ z, double* __restrict__ p) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  p[i] = first ? z[i] : z[i] + (scalars[S_RHO] / scalars[S_RHO_LAST]) * p[i];
+  p[i] = first ? z[i] : z[i] + (pcg_rho(part, nparts) / scalars[S_RHO_LAST]) * p[i];
 }
 __global__ void __launch_bounds__(1024) ba_dot_kernel(int n, const double* __restrict__ a,
                                                       const double* __restrict__ b, double* __restrict__ out) {
@@ -1111,14 +1178,20 @@ __global__ void __launch_bounds__(1024) ba_dot_kernel(int n, const double* __res
   v = block_sum(v);
   if (threadIdx.x == 0) *out = v;
 }
-// alpha = rho / pq ; x += alpha p ; r -= alpha q ; Q = -0.5 x (b + r)
+// pq = p.q ; alpha = rho / pq ; x += alpha p ; r -= alpha q ; Q = -0.5 x (b + r); publishes rho
+// (for the host and as the next iteration's rho_last)
 __global__ void __launch_bounds__(1024) ba_pcg_update_kernel(int n, double* __restrict__ scalars,
+                                                             const double* __restrict__ part, int nparts,
                                                              const double* __restrict__ p,
                                                              const double* __restrict__ q,
                                                              const double* __restrict__ b, double* __restrict__ x,
                                                              double* __restrict__ r) {
+  double pq = 0.0;
+  for (int i = threadIdx.x; i < n; i += 1024) pq += p[i] * q[i];
+  pq = block_sum(pq);
+  const double rho = pcg_rho(part, nparts);
   double Q = 0.0;
-  const double alpha = scalars[S_RHO] / scalars[S_PQ];
+  const double alpha = rho / pq;
   for (int i = threadIdx.x; i < n; i += 1024) {
     const double xn = x[i] + alpha * p[i];
     const double rn = r[i] - alpha * q[i];
@@ -1127,7 +1200,12 @@ __global__ void __launch_bounds__(1024) ba_pcg_update_kernel(int n, double* __re
     Q += -0.5 * xn * (b[i] + rn);
   }
   Q = block_sum(Q);
-  if (threadIdx.x == 0) scalars[S_Q] = Q;
+  if (threadIdx.x == 0) {
+    scalars[S_Q] = Q;
+    scalars[S_PQ] = pq;
+    scalars[S_RHO] = rho;
+    scalars[S_RHO_LAST] = rho;
+  }
 }
 // y = a * x / s  (s may be null)
 __global__ void ba_scaled_div_kernel(int n, double a, const double* __restrict__ x, const double* __restrict__ s,
@@ -1253,8 +1331,9 @@ struct Solver {
       pt_ptr, blk_off, blk_dim, blk_kind, blk_moff, chunk_blk, chunk_beg, chunk_end, blk_chunk_ptr, c2a, a2c, tile_pt;
   Buf<unsigned char> solo;
   Buf<double> o_xy, poses, cams, points, poses2, cams2, points2, Jpose, Jcam, Jpt, res, res_p, scale_c, scale_p,
-      scalars, gc, gp, diag_c, diag_p, Dc, Dp, Cinv, M, Minv, rhs, x, r, z, pdir, q, dp, jx, v, stepc, stepp, partials, cpart, Craw, tbuf, tmpc;
+      scalars, gc, gp, diag_c, diag_p, Dc, Dp, Cinv, M, Minv, rhs, x, r, z, pdir, q, dp, jx, v, stepc, stepp, partials, cpart, Craw, tbuf, tmpc, Gobs, pcg_part;
   int moff_total = 0;
+  long long n_paired = 0;  // (observation, block kind) slots that have a partner of the same point in the block
   int kd = 4, bd = PD;  // intrinsics tangent width / widest camera-side block of this problem
   std::vector<int> h_pose_off, h_cam_off, h_pt_off;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -1360,6 +1439,8 @@ struct Solver {
           same_cam += p.obs_cam[active[a2]] == p.obs_cam[active[a]];
         }
         h_solo[h_a2c[a]] = (unsigned char)((same_pose == 1 ? 1 : 0) | (same_cam == 1 ? 2 : 0));
+        const int64_t oa = active[a];
+        n_paired += (same_pose != 1 && !p.pose_const[p.obs_pose[oa]]) + (same_cam != 1 && cam_nvar[p.obs_cam[oa]] > 0);
       }
     std::vector<int> h_o_pose(n), h_o_cam(n), h_o_pt(n), h_o_sensor;
     const bool has_sensors = p.obs_sensor != nullptr && p.num_sensors > 0 && p.sensors != nullptr;
@@ -1468,13 +1549,14 @@ struct Solver {
     poses2.alloc(poses.n); cams2.alloc(cams.n); points2.alloc(points.n);
     const size_t N = (size_t)n;
     Jpose.alloc(2 * PD * N); Jcam.alloc(2 * (size_t)kd * N); Jpt.alloc(6 * N); res.alloc(2 * N); res_p.alloc(2 * N);
-    jx.alloc(2 * N); v.alloc(2 * N);
+    jx.alloc(2 * N); v.alloc(2 * N); Gobs.alloc(3 * N);
     scale_c.alloc(n_c); scale_p.alloc(poff); gc.alloc(n_c); gp.alloc(poff); diag_c.alloc(n_c); diag_p.alloc(poff);
     Dc.alloc(n_c); Dp.alloc(poff); rhs.alloc(n_c); x.alloc(n_c); r.alloc(n_c); z.alloc(n_c); pdir.alloc(n_c);
     q.alloc(n_c); dp.alloc(poff); stepc.alloc(n_c); stepp.alloc(poff);
     Cinv.alloc(9 * (size_t)p.num_points); M.alloc(moff); Minv.alloc(moff);
     Craw.alloc(6 * (size_t)p.num_points); tbuf.alloc(poff); tmpc.alloc(n_c);
     scalars.alloc(NSCALAR);
+    pcg_part.alloc((size_t)grid_for(n_blk, 256) + 1);
     partials.alloc((size_t)grid_for(n, 256) + 1);
 
     V.n_obs = n; V.n_poses = p.num_poses; V.n_cams = p.num_cams; V.n_points = p.num_points;
@@ -1585,15 +1667,14 @@ struct Solver {
     if (scalar(S_RHO) == 0.0) return 0;
     double Q0 = 0.0;
     int it;
+    const int nparts = grid_for(V.n_blk, 256);
     for (it = 1; it <= max_iter; ++it) {
-      BA_HIP(hipMemcpyAsync(scalars.p + S_RHO_LAST, scalars.p + S_RHO, sizeof(double), hipMemcpyDeviceToDevice, st));
-      BA_LAUNCH(ba_pcg_precond_kernel, dim3(1), dim3(1024), st, V, Minv.p, r.p, z.p);
-      BA_LAUNCH(ba_pcg_dir_kernel, dim3(gv), dim3(256), st, n, scalars.p, it == 1 ? 1 : 0, z.p, pdir.p);
+      BA_LAUNCH(ba_pcg_precond_kernel, dim3(nparts), dim3(256), st, V, Minv.p, r.p, z.p, pcg_part.p);
+      BA_LAUNCH(ba_pcg_dir_kernel, dim3(gv), dim3(256), st, n, scalars.p, pcg_part.p, nparts, it == 1 ? 1 : 0, z.p, pdir.p);
       BA_HIP(hipEventRecord(ev0, st));
       schur_multiply(pdir.p, q.p);
       BA_HIP(hipEventRecord(ev1, st));
-      BA_LAUNCH(ba_dot_kernel, dim3(1), dim3(1024), st, n, pdir.p, q.p, scalars.p + S_PQ);
-      BA_LAUNCH(ba_pcg_update_kernel, dim3(1), dim3(1024), st, n, scalars.p, pdir.p, q.p, rhs.p, x.p, r.p);
+      BA_LAUNCH(ba_pcg_update_kernel, dim3(1), dim3(1024), st, n, scalars.p, pcg_part.p, nparts, pdir.p, q.p, rhs.p, x.p, r.p);
       double h[NSCALAR];
       BA_HIP(hipMemcpyAsync(h, scalars.p, sizeof(h), hipMemcpyDeviceToHost, st));
       BA_HIP(hipStreamSynchronize(st));
@@ -1687,11 +1768,14 @@ struct Solver {
       if (nc > 0) {
         BA_HIP(hipMemsetAsync(M.p, 0, sizeof(double) * std::max(moff_total, 1), st));
         if (V.n_chunks > 0) {
-          BA_LAUNCH(ba_block_gram_kernel, dim3(V.n_chunks), dim3(64), st, V, M.p);
+          BA_LAUNCH(ba_obs_schur_g_kernel, dim3(grid_for(V.n_obs, 256)), dim3(256), st, V, Cinv.p, Gobs.p);
+          BA_LAUNCH(ba_block_gram_kernel, dim3(V.n_chunks), dim3(64), st, V, Gobs.p);
           BA_LAUNCH(ba_block_mat_finalize_kernel<false>, dim3(grid_for(V.n_blk, 128)), dim3(128), st, V, M.p);
-          if (bd == PD) BA_LAUNCH(ba_block_schur_corr_kernel<PD>, dim3(V.n_chunks), dim3(64), st, V, Cinv.p, M.p);
-          else BA_LAUNCH(ba_block_schur_corr_kernel<KD_MAX>, dim3(V.n_chunks), dim3(64), st, V, Cinv.p, M.p);
-          BA_LAUNCH(ba_block_mat_finalize_kernel<true>, dim3(grid_for(V.n_blk, 128)), dim3(128), st, V, M.p);
+          if (n_paired > 0) {  // observation pairs of a point inside one block: shared intrinsics, rig frames
+            if (bd == PD) BA_LAUNCH(ba_block_schur_cross_kernel<PD>, dim3(V.n_chunks), dim3(64), st, V, Cinv.p);
+            else BA_LAUNCH(ba_block_schur_cross_kernel<KD_MAX>, dim3(V.n_chunks), dim3(64), st, V, Cinv.p);
+            BA_LAUNCH(ba_block_mat_finalize_kernel<true>, dim3(grid_for(V.n_blk, 128)), dim3(128), st, V, M.p);
+          }
         }
         comm.allreduce(M.p, (size_t)moff_total, st);
         if (bd == PD) BA_LAUNCH(ba_block_invert_kernel<PD>, dim3(grid_for(V.n_blk, 64)), dim3(64), st, V, Dc.p, M.p, Minv.p);

@@ -349,8 +349,11 @@ __device__ __forceinline__ void ncc_group(const PmParams& p, const lds_f32* H, g
         const int t = j + 16 * (kb + 2 * q + e);
         valid[e] = t < ntaps;
         const int tt = valid[e] ? t : 0;
-        const int wrow = tt / n1d;
-        const int wcol = tt - wrow * n1d;
+        int wrow = tt / n1d;
+        int wcol = tt - wrow * n1d;
+        if (p.rot & 1) {  // odd sweep directions: taps dealt column-major (see patch_weights)
+          const int sw = wrow; wrow = wcol; wcol = sw;
+        }
         dx[e] = (float)(wcol * p.step);
         dy[e] = (float)(wrow * p.step);
       }
@@ -756,11 +759,13 @@ struct Lds {
   lds_u32* tasks;
   lds_f32* th;      // [max_tasks][9] homography of each queued NCC task
   lds_i32* ntasks;
+  lds_f32* tapg;    // wave kernel: [2][8][16] window offsets (dx, dy) of tap j + 16 k, times step
+  lds_u32* ring;    // wave kernel: [2][8][64] landing zone of the footprint gathers
 };
 
 struct LdsOffsets {
   uint32_t poses, fpb, tile, wgt, refc, fm, q, costv, betav, prevv, ncc, geo, hyp, colf, us, sv, best, csum,
-      flags, tasks, th, ntasks, total;
+      flags, tasks, th, ntasks, tapg, ring, total;
 };
 
 // Pose record kept in LDS: K4 R9 T3 C3 always; the projection matrices P12 invP12 only serve the
@@ -804,6 +809,8 @@ __host__ __device__ inline LdsOffsets lds_offsets(int C, int S, int radius, int 
   o.tasks = take(4u * max_tasks);
   o.th = take(36u * max_tasks);
   o.ntasks = take(16u);
+  o.tapg = 0;
+  o.ring = 0;
   o.total = off;
   return o;
 }
@@ -840,6 +847,8 @@ __device__ __forceinline__ void lds_bind(Lds& L, lds_char* base, const LdsOffset
   L.tasks = (lds_u32*)(base + o.tasks);
   L.th = (lds_f32*)(base + o.th);
   L.ntasks = (lds_i32*)(base + o.ntasks);
+  L.tapg = (lds_f32*)(base + o.tapg);
+  L.ring = (lds_u32*)(base + o.ring);
 }
 
 __device__ __forceinline__ uint32_t task_pack(int c, int i, int s, int geom_only) {
@@ -873,8 +882,15 @@ __device__ __forceinline__ void patch_weights(const PmParams& p, const Lds& L, i
       L.refc[item] = 0.0f;
       continue;
     }
-    const int trow = tap / p.ntap1d;
-    const int tcol = tap - trow * p.ntap1d;
+    // Tap index -> window position: row-major, but column-major in the odd sweep directions, where a
+    // row of the rotated window runs along a COLUMN of the (never rotated) source images: the 16
+    // consecutive taps of one gather instruction then still fall into one or two source rows
+    // (oracle/pm_oracle.c: ncc_cost_device, `transpose`).
+    int trow = tap / p.ntap1d;
+    int tcol = tap - trow * p.ntap1d;
+    if (p.rot & 1) {
+      const int sw = trow; trow = tcol; tcol = sw;
+    }
     const int wr_ = -p.radius + trow * p.step;
     const int wc_ = -p.radius + tcol * p.step;
     int slot_c = row % win;
@@ -1045,42 +1061,99 @@ __device__ __forceinline__ void run_tasks(const PmParams& p, const Lds& L, int r
 // are in flight before the first texel is consumed. Arithmetic and order are those of ncc_group
 // (oracle/pm_oracle.c: ncc_cost_device); fixed 11 x 11 window (121 taps = one 128-tap chunk).
 // ---------------------------------------------------------------------------
-struct NccStage {
-  uint32_t tex[8];
+struct NccStage {  // VGPR half of a pipeline stage; the eight texels are in flight to the LDS ring
   v2f wx[4], wy[4];
 };
 
-// per-lane constants of the 11 x 11 window: tap offsets (dx, dy) * step of taps j + 16 k
-struct TapGeom {
-  v2f dx[4], dy[4];
-};
-__device__ __forceinline__ void tap_geom_init(TapGeom& G, int j, int step) {
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      const int t = j + 16 * (2 * q + e);
-      const int tt = t < 121 ? t : 0;
-      const int wrow = tt / 11;
-      const int wcol = tt - wrow * 11;
-      G.dx[q][e] = (float)(wcol * step);
-      G.dy[q][e] = (float)(wrow * step);
+// Window offsets (dx, dy) * step of the taps j + 16 k of the 11 x 11 window, as an LDS table
+// [2][8][16] (dx then dy; k; lane j) filled once per workgroup: the 16 lane constants would
+// otherwise occupy 16 VGPRs for the whole kernel. `transpose`: column-major tap order of the odd
+// sweep directions (patch_weights).
+__device__ __forceinline__ void tap_geom_init(lds_f32* tapg, int tid, int step, bool transpose) {
+  for (int idx = tid; idx < 256; idx += 64) {
+    const int j = idx & 15, k = (idx >> 4) & 7, is_dy = idx >> 7;
+    const int t = j + 16 * k;
+    const int tt = t < 121 ? t : 0;
+    int wrow = tt / 11;
+    int wcol = tt - wrow * 11;
+    if (transpose) {
+      const int sw = wrow; wrow = wcol; wcol = sw;
     }
+    tapg[idx] = (float)((is_dy ? wrow : wcol) * step);
   }
 }
 
+// Address of the footprint entry of a tap (see tap_gather<true>: clamp in the float domain, fp32
+// entry index).
+__device__ __forceinline__ gbl_u32* tap_address(const PmParams& p, gbl_u32* fp, float fx2, float fy2) {
+  const float cx = __builtin_amdgcn_fmed3f(fx2, 0.0f, p.fp_xmax);
+  const float cy = __builtin_amdgcn_fmed3f(fy2, 0.0f, p.fp_ymax);
+  return fp + (unsigned)(int)fmaf(cy, p.fp_pitch, cx);
+}
+
+// The footprint gathers of the software-pipelined NCC loop land in LDS, not in registers
+// (global_load_lds_dword: every lane's dword goes to M0 + slot offset + 4 * lane; "LDS-DMA"):
+//  * the compiler's wait-count insertion merges the loop-carried "loads in flight" state
+//    conservatively and would wait with vmcnt(0) right after the NEXT task's gathers were issued,
+//    exposing the full gather latency again; these asm loads are invisible to that pass and
+//    gather_wait<NEWER>() is the explicit wait (vector-memory loads complete in issue order; any
+//    other VMEM operation the compiler places in between only makes the wait more conservative);
+//  * a register with a load in flight must not be touched by compiler-generated code (a copy
+//    inserted by register allocation before the wait would read stale data -- observed with both
+//    VGPR and AGPR destinations); a landing zone in LDS has no such hazard and costs no VGPRs:
+//    the texels are read back with ds_read_b32 after the wait.
+// Ring: [2 stages][8 gathers][64 lanes] dwords = 4 KB per workgroup.
+constexpr int kGatherRingBytes = 2 * 8 * 64 * 4;
+
+template <int SLOT>
+__device__ __forceinline__ void gather_issue(gbl_u32* addr, uint32_t ring_lds_addr) {
+  // M0 = LDS base of the ring (the compiler does not use M0 in this kernel; it is set per gather
+  // anyway: a scalar move), instruction offset = slot
+  asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dword %0, off offset:%2"
+               :
+               : "v"(addr), "s"(ring_lds_addr), "n"(SLOT * 256)
+               : "memory");
+}
+// slot index known after unrolling: the switch folds to the one asm statement
+template <int STAGE>
+__device__ __forceinline__ void gather_issue_k(int k, gbl_u32* addr, uint32_t ring_lds_addr) {
+  switch (k) {
+    case 0: gather_issue<8 * STAGE + 0>(addr, ring_lds_addr); break;
+    case 1: gather_issue<8 * STAGE + 1>(addr, ring_lds_addr); break;
+    case 2: gather_issue<8 * STAGE + 2>(addr, ring_lds_addr); break;
+    case 3: gather_issue<8 * STAGE + 3>(addr, ring_lds_addr); break;
+    case 4: gather_issue<8 * STAGE + 4>(addr, ring_lds_addr); break;
+    case 5: gather_issue<8 * STAGE + 5>(addr, ring_lds_addr); break;
+    case 6: gather_issue<8 * STAGE + 6>(addr, ring_lds_addr); break;
+    default: gather_issue<8 * STAGE + 7>(addr, ring_lds_addr); break;
+  }
+}
+// Wait until at most NEWER vector-memory operations issued after a stage's eight gathers are
+// outstanding; the "memory" clobber keeps the LDS reads of the texels behind it.
+template <int NEWER>
+__device__ __forceinline__ void gather_wait() {
+  asm volatile("s_waitcnt vmcnt(%0)" : : "n"(NEWER) : "memory");
+}
+
+template <int STAGE>
 __device__ __forceinline__ void ncc_front(const PmParams& p, const lds_f32* H, gbl_u32* fp,
-                                          const TapGeom& G, int j, NccStage& st) {
+                                          const lds_f32* tg, uint32_t ring_lds_addr, int j, NccStage& st) {
   const float h0 = H[0], h1 = H[1], h2 = H[2], h3 = H[3], h4 = H[4], h5 = H[5], h6 = H[6],
               h7 = H[7], h8 = H[8];
   v2f csrc[4], rsrc[4], pre[4], suf[4];
   float zz[8];
   float run = 1.0f;
+  const lds_f32* tj = tg + j;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    csrc[q] = pk_fma(pk_bcast(h0), G.dx[q], pk_fma(pk_bcast(h1), G.dy[q], pk_bcast(h2)));
-    rsrc[q] = pk_fma(pk_bcast(h3), G.dx[q], pk_fma(pk_bcast(h4), G.dy[q], pk_bcast(h5)));
-    const v2f z = pk_fma(pk_bcast(h6), G.dx[q], pk_fma(pk_bcast(h7), G.dy[q], pk_bcast(h8)));
+    v2f dx, dy;
+    dx[0] = tj[32 * q];
+    dx[1] = tj[32 * q + 16];
+    dy[0] = tj[128 + 32 * q];
+    dy[1] = tj[128 + 32 * q + 16];
+    csrc[q] = pk_fma(pk_bcast(h0), dx, pk_fma(pk_bcast(h1), dy, pk_bcast(h2)));
+    rsrc[q] = pk_fma(pk_bcast(h3), dx, pk_fma(pk_bcast(h4), dy, pk_bcast(h5)));
+    const v2f z = pk_fma(pk_bcast(h6), dx, pk_fma(pk_bcast(h7), dy, pk_bcast(h8)));
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       const bool valid = j + 16 * (2 * q + e) < 121;
@@ -1110,8 +1183,8 @@ __device__ __forceinline__ void ncc_front(const PmParams& p, const lds_f32* H, g
     st.wy[q] = py - fy;
     const v2f fx2 = fx + pk_bcast(2.0f);
     const v2f fy2 = fy + pk_bcast(2.0f);
-    st.tex[2 * q] = tap_gather<true>(p, fp, 0u, fx2[0], fy2[0]);
-    st.tex[2 * q + 1] = tap_gather<true>(p, fp, 0u, fx2[1], fy2[1]);
+    gather_issue_k<STAGE>(2 * q, tap_address(p, fp, fx2[0], fy2[0]), ring_lds_addr);
+    gather_issue_k<STAGE>(2 * q + 1, tap_address(p, fp, fx2[1], fy2[1]), ring_lds_addr);
   }
 }
 
@@ -1137,15 +1210,15 @@ __device__ __forceinline__ void reduce16x3(float& a, float& b, float& c) {
       : "+v"(a), "+v"(b), "+v"(c));
 }
 
-__device__ __forceinline__ void ncc_back(const NccStage& st, const TapRegs& R, int j, float& s_sum,
-                                         float& s_sq, float& s_ref) {
+__device__ __forceinline__ void ncc_back(const NccStage& st, const uint32_t tex[8], const TapRegs& R, int j,
+                                         float& s_sum, float& s_sq, float& s_ref) {
   v2f a_sum = pk_bcast(0.0f), a_sq = pk_bcast(0.0f), a_ref = pk_bcast(0.0f);
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     v2f c00, c10, c01, c11;
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
-      const uint32_t x = j + 16 * (2 * q + e) < 121 ? st.tex[2 * q + e] : 0u;
+      const uint32_t x = j + 16 * (2 * q + e) < 121 ? tex[2 * q + e] : 0u;
       c00[e] = ubyte0(x);
       c10[e] = ubyte1(x);
       c01[e] = ubyte2(x);
@@ -1498,10 +1571,16 @@ __global__ void __launch_bounds__(256, 3) pm_sweep_kernel(const PmParams* __rest
 //    four 16-lane evaluations (ncc_front -> all eight gathers in flight -> ncc_back), then the
 //    normalisation lane-per-task.
 // ---------------------------------------------------------------------------
-constexpr int kWaveThCap = 48;  // NCC tasks per batch (homography ring in LDS)
+constexpr int kWaveThCap = 40;  // NCC tasks per batch (homography ring in LDS; sized so that C = 3, S = 20 fits 10 workgroups per CU)
 
 __device__ __forceinline__ uint32_t task16_pack(int c, int i, int s, int geom_only) {
   return ((uint32_t)c << 13) | ((uint32_t)geom_only << 12) | ((uint32_t)i << 9) | (uint32_t)s;
+}
+
+// NCC tasks of one phase: 4 hypotheses per distinct drawn view, or the winner against <= S views
+__host__ __device__ inline int wave_max_tasks(int C, int S, int M) {
+  const int ms = M < S ? M : S;
+  return C * (4 * ms > S ? 4 * ms : S);
 }
 
 __host__ __device__ inline LdsOffsets lds_offsets_wave(int C, int S, int radius, int ntaps, int M,
@@ -1515,9 +1594,7 @@ __host__ __device__ inline LdsOffsets lds_offsets_wave(int C, int S, int radius,
   };
   const int win = 2 * radius + 1;
   const int tw = C + 2 * radius;
-  const int ms = M < S ? M : S;
-  const int per_view = geom ? 5 : 4;
-  const int max_tasks = C * (per_view * ms > S ? per_view * ms : S);
+  const int max_tasks = wave_max_tasks(C, S, M);
   o.poses = take(4u * S * lds_pose_stride(geom));
   o.fpb = take(8u * S);
   o.tile = take(4u * win * tw);
@@ -1538,75 +1615,127 @@ __host__ __device__ inline LdsOffsets lds_offsets_wave(int C, int S, int radius,
   o.sv = take(4u * C * M);
   o.best = take(4u * C);
   o.csum = take(4u * C * 5);
-  o.tasks = take(2u * max_tasks);             // 16-bit task words
+  o.tasks = take(2u * max_tasks + (geom ? 2u * C * S : 0u));  // 16-bit task words: NCC tasks, then
+                                                              // (GEOM) the geometric-cost-only list
   o.th = take(36u * kWaveThCap);
   o.ntasks = take(16u);
+  o.tapg = take(4u * 256);
+  o.ring = take((uint32_t)kGatherRingBytes);
   o.total = off;
   return o;
 }
 
+// Run the queued NCC tasks (and, with GEOM, the geometric-cost-only list) of one phase.
 template <bool GEOM>
-__device__ __forceinline__ void run_tasks_wave(const PmParams& p, const Lds& L, const TapGeom& G, int row,
-                                               int col0, int tid) {
-  const int n = *L.ntasks;
+__device__ __forceinline__ void run_tasks_wave(const PmParams& p, const Lds& L, int row, int col0, int tid) {
+  const lds_f32* G = L.tapg;
+  const int n = L.ntasks[0];
   const LDS_AS uint16_t* tasks = (const LDS_AS uint16_t*)L.tasks;
   const int g = tid >> 4, j = tid & 15;
   const int S = p.S;
-  TapRegs R;
-  int c_held = -1;
+  if (GEOM) {
+    // geometric consistency cost of hypothesis 0 against the drawn views (no NCC: cached cost map)
+    const int ng = L.ntasks[1];
+    const LDS_AS uint16_t* gtasks = tasks + wave_max_tasks(p.C, S, p.num_samples);
+    for (int t = tid; t < ng; t += 64) {
+      const uint32_t task = gtasks[t];
+      const int c = task >> 13, i = (task >> 9) & 7, s = task & 0x1ff;
+      const lds_f32* h = L.hyp + (c * 5 + i) * 4;
+      L.geo[(c * 5 + i) * S + s] = geom_cost(p, L.poses + s * L.pstride, s, (float)row, (float)(col0 + c), h[0]);
+    }
+  }
   for (int base = 0; base < n; base += kWaveThCap) {
     const int nb = min(kWaveThCap, n - base);
     // pass A, lane per task: homography of the (hypothesis, view) pair (+ geometric cost)
     if (tid < nb) {
       const uint32_t task = tasks[base + tid];
       const int c = task >> 13;
-      const int geom_only = (task >> 12) & 1;
       const int i = (task >> 9) & 7;
       const int s = task & 0x1ff;
       const lds_f32* h = L.hyp + (c * 5 + i) * 4;
       const lds_f32* pose = L.poses + s * L.pstride;
       const int col = col0 + c;
-      if (!geom_only) {
-        float Hm[9];
-        compose_homography(p.refInvK, pose, row, col, h[0], h[1], h[2], h[3], Hm);
-        centre_homography(Hm, row, col, p.radius);
-        for (int k = 0; k < 9; ++k) L.th[tid * 9 + k] = Hm[k];
-      }
+      float Hm[9];
+      compose_homography(p.refInvK, pose, row, col, h[0], h[1], h[2], h[3], Hm);
+      centre_homography(Hm, row, col, p.radius);
+      for (int k = 0; k < 9; ++k) L.th[tid * 9 + k] = Hm[k];
       if (GEOM) L.geo[(c * 5 + i) * S + s] = geom_cost(p, pose, s, (float)row, (float)col, h[0]);
     }
     __syncthreads();
-    // pass B, 16-lane group per task
-    for (int t = g; t < nb; t += 4) {
-      const uint32_t task = tasks[base + t];
-      if ((task >> 12) & 1) continue;  // geometric cost only
-      const int c = task >> 13;
-      const int s = task & 0x1ff;
-      if (c != c_held) {
-        tap_regs_load(R, L.wgt + c * 128, L.refc + c * 128, j);
-        c_held = c;
+    // pass B, 16-lane group per task, software-pipelined: the gathers of a group's NEXT task are
+    // issued (ncc_front) before the texels of its current task are consumed (ncc_back), so a wave
+    // waits for memory only when a round's arithmetic is shorter than the gather latency. Two stage
+    // register sets ping-pong (loop unrolled by two: no register copies). Control flow is
+    // wave-uniform -- every group runs ceil(nb / 4) rounds, a group without a task in the last
+    // round recomputes the batch's last task and drops the result -- so that front / back pairs
+    // sit in straight-line code (the compiler then waits with vmcnt(8), not vmcnt(0)) and the DPP
+    // rows are always fully active.
+    {
+      const int rounds = (nb + 3) >> 2;
+      const lds_u32* ring = L.ring;
+      const uint32_t ring_addr = (uint32_t)(uintptr_t)L.ring;
+      NccStage A, B;
+      int ta, tb, ca, cb;
+      bool wa, wb;
+      auto prep = [&](int r, int& t, int& c, bool& own) -> uint32_t {
+        const int tr = g + 4 * r;
+        own = tr < nb;
+        t = own ? tr : nb - 1;
+        const uint32_t task = tasks[base + t];
+        c = task >> 13;
+        return task & 0x1ff;
+      };
+      // (a recomputed task may already hold its sums instead of its homography: the gathers clamp
+      // any coordinate, the result is dropped)
+#define PM_FRONT(STAGE, r, st, t, c, own)                                                  \
+  do {                                                                                     \
+    const uint32_t sv_ = prep(r, t, c, own);                                               \
+    ncc_front<STAGE>(p, L.th + (t) * 9, (gbl_u32*)L.fpb[sv_], G, ring_addr, j, st);        \
+  } while (0)
+#define PM_BACK(STAGE, NEWER, st, t, c, own)                                               \
+  do {                                                                                     \
+    TapRegs R_;                                                                            \
+    tap_regs_load(R_, L.wgt + (c) * 128, L.refc + (c) * 128, j);                           \
+    uint32_t tex_[8];                                                                      \
+    gather_wait<NEWER>();                                                                  \
+    _Pragma("unroll") for (int k_ = 0; k_ < 8; ++k_) tex_[k_] = ring[((STAGE) * 8 + k_) * 64 + tid]; \
+    float s_sum_, s_sq_, s_ref_;                                                           \
+    ncc_back(st, tex_, R_, j, s_sum_, s_sq_, s_ref_);                                      \
+    if (j == 0 && (own)) {                                                                 \
+      L.th[(t) * 9 + 0] = s_sum_; /* the homography of this task is no longer needed */    \
+      L.th[(t) * 9 + 1] = s_sq_;                                                           \
+      L.th[(t) * 9 + 2] = s_ref_;                                                          \
+    }                                                                                      \
+  } while (0)
+      PM_FRONT(0, 0, A, ta, ca, wa);
+      for (int r = 0;;) {
+        if (r + 1 >= rounds) {
+          PM_BACK(0, 0, A, ta, ca, wa);
+          break;
+        }
+        PM_FRONT(1, r + 1, B, tb, cb, wb);
+        PM_BACK(0, 8, A, ta, ca, wa);
+        ++r;
+        if (r + 1 >= rounds) {
+          PM_BACK(1, 0, B, tb, cb, wb);
+          break;
+        }
+        PM_FRONT(0, r + 1, A, ta, ca, wa);
+        PM_BACK(1, 8, B, tb, cb, wb);
+        ++r;
       }
-      NccStage st;
-      ncc_front(p, L.th + t * 9, (gbl_u32*)L.fpb[s], G, j, st);
-      __builtin_amdgcn_sched_barrier(0);
-      float s_sum, s_sq, s_ref;
-      ncc_back(st, R, j, s_sum, s_sq, s_ref);
-      if (j == 0) {
-        L.th[t * 9 + 0] = s_sum;  // the homography of this task is no longer needed
-        L.th[t * 9 + 1] = s_sq;
-        L.th[t * 9 + 2] = s_ref;
-      }
+#undef PM_FRONT
+#undef PM_BACK
     }
     __syncthreads();
     // lane per task: normalisation, variances, square root, division
     if (tid < nb) {
       const uint32_t task = tasks[base + tid];
-      if (!((task >> 12) & 1)) {
-        const int c = task >> 13;
-        const int i = (task >> 9) & 7;
-        const int s = task & 0x1ff;
-        L.ncc[(c * 4 + i - 1) * S + s] = ncc_finish(L.th[tid * 9 + 0], L.th[tid * 9 + 1], L.th[tid * 9 + 2],
-                                                    L.colf[c * 8 + 0], L.colf[c * 8 + 1], L.colf[c * 8 + 5]);
-      }
+      const int c = task >> 13;
+      const int i = (task >> 9) & 7;
+      const int s = task & 0x1ff;
+      L.ncc[(c * 4 + i - 1) * S + s] = ncc_finish(L.th[tid * 9 + 0], L.th[tid * 9 + 1], L.th[tid * 9 + 2],
+                                                  L.colf[c * 8 + 0], L.colf[c * 8 + 1], L.colf[c * 8 + 5]);
     }
     __syncthreads();
   }
@@ -1635,15 +1764,15 @@ __global__ void __launch_bounds__(64, 3) pm_sweep_wave_kernel(const PmParams* __
   extern __shared__ __attribute__((aligned(16))) char smem[];
   Lds L;
   lds_bind(L, (lds_char*)smem, lds_offsets_wave(p.C, p.S, p.radius, p.ntaps, p.num_samples, GEOM));
-  const int tid = threadIdx.x;
+  const int tid_entry = threadIdx.x;
+  const int tid = tid_entry;
   constexpr int nt = 64;
   const int S = p.S, M = p.num_samples, C = p.C;
   const int RW = rot_width(p), RH = rot_height(p);
   const int col0 = group * C;
   const int ncols = min(C, RW - col0);
   const float* iK = p.refInvK;
-  TapGeom G;
-  tap_geom_init(G, tid & 15, p.step);
+  tap_geom_init(L.tapg, tid, p.step, (p.rot & 1) != 0);
 
   lds_load_poses(p, L, GEOM, tid, nt);
 
@@ -1676,10 +1805,17 @@ __global__ void __launch_bounds__(64, 3) pm_sweep_wave_kernel(const PmParams* __
   for (int r = -p.radius; r < p.radius; ++r) tile_load_row(p, L, col0, r, tid, nt);
   __syncthreads();
 
+  const int tid0 = tid_entry;
   for (int row = 0; row < RH; ++row) {
+    // The lane id is laundered through an empty asm once per row: everything the phases derive from
+    // it (item -> column / view, LDS addresses) is then recomputed per row instead of being hoisted
+    // out of the row loop and held in VGPRs across the NCC loop, whose two gather stages need them.
+    int tid = tid0;
+    asm volatile("" : "+v"(tid));
+    const bool col_lane = tid < ncols;
     // ---- P0: scroll the reference tile (LocalRefImage::Read, :357-410) -------
     tile_load_row(p, L, col0, row + p.radius, tid, nt);
-    if (tid == 0) *L.ntasks = 0;
+    if (tid == 0) { L.ntasks[0] = 0; L.ntasks[1] = 0; }
     __syncthreads();
 
     // ---- P1: hypotheses (lane per column) + patch weights (all lanes) --------
@@ -1781,18 +1917,20 @@ __global__ void __launch_bounds__(64, 3) pm_sweep_wave_kernel(const PmParams* __
         bool drawn = false;
         for (int m = 0; m < M; ++m) drawn |= (L.sv[c * M + m] == s);
         if (drawn) {
-          const int n_new = GEOM ? 5 : 4;
-          const int base = __hip_atomic_fetch_add(L.ntasks, n_new, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          const int base = __hip_atomic_fetch_add(L.ntasks, 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           for (int i = 1; i < 5; ++i) tasks[base + i - 1] = (uint16_t)task16_pack(c, i, s, 0);
-          if (GEOM) tasks[base + 4] = (uint16_t)task16_pack(c, 0, s, 1);
+          if (GEOM) {
+            const int gb = __hip_atomic_fetch_add(L.ntasks + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            tasks[wave_max_tasks(C, S, M) + gb] = (uint16_t)task16_pack(c, 0, s, 1);
+          }
         }
       }
     }
     __syncthreads();
 
     // ---- P4: NCC of hypotheses 1..4 against the drawn views (:1157-1172) -----
-    run_tasks_wave<GEOM>(p, L, G, row, col0, tid);
-    if (tid == 0) *L.ntasks = 0;
+    run_tasks_wave<GEOM>(p, L, row, col0, tid);
+    if (tid == 0) { L.ntasks[0] = 0; L.ntasks[1] = 0; }
     __syncthreads();
 
     // ---- P5a: accumulate in draw order (:1144-1172), lane per (column, hypothesis)
@@ -1846,7 +1984,7 @@ __global__ void __launch_bounds__(64, 3) pm_sweep_wave_kernel(const PmParams* __
     __syncthreads();
 
     // ---- P6: NCC of the winner against the remaining views (:1188-1197) ------
-    run_tasks_wave<false>(p, L, G, row, col0, tid);
+    run_tasks_wave<false>(p, L, row, col0, tid);
 
     // ---- P7: cost map, forward message, selection probability (:1186-1207) ---
     for (int item = tid; item < ncols * S; item += nt) {
@@ -1951,7 +2089,9 @@ size_t pm_sweep_lds_bytes(const PmParams& p, bool geom) {
 
 int pm_pick_columns(int S, int ntaps, int num_samples, bool geom, int radius, int requested) {
   const size_t budget = 60 * 1024;
-  int c = requested > 0 ? requested : 4;
+  // default: 3 columns per single-wave workgroup of the 11 x 11 kernel (C * S = 60 <= 64 lanes: the
+  // lane-per-(column, view) phases are one pass; measured best), 4 for the two-wave kernels
+  int c = requested > 0 ? requested : (ntaps == 121 ? 3 : 4);
   if (c > 64) c = 64;
   while (c > 1 && lds_offsets(c, S, radius, ntaps, num_samples, geom).total > budget) --c;
   return c;

@@ -591,7 +591,8 @@ static float ncc_cost(const pmo_state* st, const ncc_params* np, const float inv
 }
 
 /* The same cost as ncc_cost() evaluated in the HIP kernel's order ("device order"):
- *  - tap t = wrow * n1d + wcol is dealt to lane j = t % 16 of a 16-lane group; a
+ *  - tap t = wrow * n1d + wcol (t = wcol * n1d + wrow in the odd sweep directions, st->rot & 1)
+ *    is dealt to lane j = t % 16 of a 16-lane group; a
  *    lane accumulates its taps t = j + 16 k in increasing k, even k and odd k separately
  *    (the halves of the packed fp32 registers), and adds the two partial sums;
  *  - the warped coordinate of a tap is evaluated directly from the homography whose constant
@@ -619,6 +620,11 @@ static float ncc_cost_device(const pmo_state* st, const ncc_params* np, const fl
   compose_homography(inv_K, pose, row, col, depth, normal, tf);
   const int n1d = (2 * np->radius) / np->step + 1;
   const int ntaps = n1d * n1d;
+  /* In the odd sweep directions (the buffers are rotated by 90 or 270 degrees) the device deals the
+   * taps to the lanes column-major -- tap t sits at window (row, col) = (t % n1d, t / n1d) -- so that
+   * consecutive lanes still walk along a row of the (never rotated) source image: the sums are the
+   * same sums, grouped differently. */
+  const int transpose = st->rot & 1;
   /* device order: the constant column of the homography is moved to the window origin once per
    * evaluation, taps address the patch by small non-negative offsets */
   const float x0f = (float)(col - np->radius), y0f = (float)(row - np->radius);
@@ -637,12 +643,15 @@ static float ncc_cost_device(const pmo_state* st, const ncc_params* np, const fl
     a_w[j] = 0.0f;
     for (int cb = 0; cb < nchunk; ++cb) {
       float csrc[8], rsrc[8], zz[8], pre[8], inv[8];
+      int pos[8];
       float run = 1.0f;
       for (int k = 0; k < 8; ++k) {
         const int t = j + 16 * (8 * cb + k);
         const int valid = t < ntaps;
         const int tt = valid ? t : 0;
-        const int wrow = tt / n1d, wcol = tt - wrow * n1d;
+        int wrow = tt / n1d, wcol = tt - wrow * n1d;
+        if (transpose) { const int sw = wrow; wrow = wcol; wcol = sw; }
+        pos[k] = wrow * n1d + wcol;
         const float dx = (float)(wcol * np->step);
         const float dy = (float)(wrow * np->step);
         csrc[k] = fmaf(tf[0], dx, fmaf(tf[1], dy, c2));
@@ -661,11 +670,11 @@ static float ncc_cost_device(const pmo_state* st, const ncc_params* np, const fl
         const int t = j + 16 * (8 * cb + k);
         if (t >= ntaps) continue;
         const float src_color = tex_src_bilinear_raw(st, s, inv[k] * csrc[k], inv[k] * rsrc[k]);
-        const float bw = weights[t];
+        const float bw = weights[pos[k]];
         const float bws = bw * src_color;
         e_sum[k & 1] += bws;
         e_sq[k & 1] = fmaf(bws, src_color, e_sq[k & 1]);
-        e_ref[k & 1] = fmaf(bws, refc[t], e_ref[k & 1]);
+        e_ref[k & 1] = fmaf(bws, refc[pos[k]], e_ref[k & 1]);
         a_w[j] += bw;
       }
     }

@@ -71,3 +71,43 @@ def test_mat_file_roundtrip(tmp_path):
     assert np.array_equal(mvs.read_mat(str(p)), a)
     mvs.write_mat(str(p), a[0])
     assert np.array_equal(mvs.read_mat(str(p)), a[0])
+
+
+def test_pipelined_gather_waits_survive_compilation(tmp_path):
+    """pm_sweep_wave_kernel issues its footprint gathers as LDS-DMA loads by hand and waits for them
+    with explicit vmcnt(8) / vmcnt(0) (pm_kernels.hip: gather_issue / gather_wait). Compile the
+    kernels to ISA (CPU only) and check that every variant still has the pipelined structure: 8 + 8
+    + 8 LDS-DMA gathers per NCC loop, the partial wait, no compiler-generated full wait between a
+    stage's issue and the partial wait, no scratch, at least 3 waves per SIMD."""
+    import os, re, subprocess
+    from colmap_amd import build as B
+    src = os.path.join(B.CSRC, "pm_kernels.hip")
+    out = str(tmp_path / "pm.s")
+    flags = [f for f in B.HIPCC_FLAGS if f not in ("-shared", "-fPIC")]
+    subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")] + flags +
+                          ["-S", "--cuda-device-only", "-o", out, src], stderr=subprocess.DEVNULL)
+    text = open(out).read()
+    kernels = re.findall(r"^(_ZN10colmap_amd20pm_sweep_wave_kernel\w+):.*?\.end_amdhsa_kernel", text, re.S | re.M)
+    assert len(kernels) == 4
+    for name in kernels:
+        body = text[text.index(name + ":"):]
+        body = body[:body.index(".end_amdhsa_kernel")]
+        lines = [l.split(";")[0].strip() for l in body.splitlines()]
+        lines = [l for l in lines if l and not l.startswith(".")]
+        assert sum(l.startswith("global_load_lds_dword") for l in lines) == 2 * 24   # P4 and P6 loops
+        assert sum(l == "s_waitcnt vmcnt(8)" for l in lines) == 2 * 2
+        # steady state of each loop: 8 gathers of the next stage, then the partial wait, with no
+        # compiler-generated vector-memory wait in between (it would serialise the pipeline again)
+        idx = [i for i, l in enumerate(lines) if l == "s_waitcnt vmcnt(8)"]
+        for i in idx:
+            k = i - 1
+            seen = 0
+            while seen < 8:
+                assert "vmcnt" not in lines[k], lines[k]
+                seen += lines[k].startswith("global_load_lds_dword")
+                k -= 1
+        meta = text[text.index(".name:           " + name):]
+        meta = meta[:meta.index(".wavefront_size")] if ".wavefront_size" in meta else meta[:2000]
+        assert int(re.search(r"\.vgpr_count:\s+(\d+)", meta).group(1)) <= 168
+        assert int(re.search(r"\.vgpr_spill_count:\s+(\d+)", meta).group(1)) == 0
+        assert int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", meta).group(1)) == 0
