@@ -81,43 +81,77 @@ def cpu_baseline(views, ref, src, dmin, dmax, crop_wh):
                        f"S={len(src)} full-resolution sources, 5x4 sweeps, {dt:.1f} s wall")
 
 
-def ba_secondary(a, local_rank, with_cpu):
+def ba_secondary(a, local_rank, with_cpu, rank=0, world=1, dev=None):
     """BASELINE.json config[3]: global BA, 1000 cameras x 200k points, SIMPLE_RADIAL, track length 10
-    (benchmark/runtime/bundle_adjustment.cc noise model), Schur-PCG on one MI355X: LM iterations per
-    second over the first `--ba-iters` iterations (linearise + Schur-Jacobi + PCG + step evaluation,
-    inputs resident in HBM), with the fp64 CPU oracle timed on the same problem."""
+    (benchmark/runtime/bundle_adjustment.cc noise model), Schur-PCG: LM iterations per second over
+    the first `--ba-iters` iterations (linearise + Schur-Jacobi + PCG + step evaluation, inputs
+    resident in HBM), with the fp64 CPU oracle timed on the same problem at N = 1.
+    N > 1: the SAME problem solved by all ranks together (strong scaling), observations sharded
+    over the GPUs, partial sums combined by RCCL all-reduces on the solver's stream inside
+    ba_solve_sharded -- once sharded by image (what BASELINE.json names) and once by point (only
+    camera-space vectors travel); the time of a solve is the max over ranks. Called by every rank."""
     import ctypes as C
-    from colmap_amd import estimators as est, scene
+    from colmap_amd import distributed as D, estimators as est, scene
     from colmap_amd._lib import lib
     d = scene.synthesize_flat(a.ba_frames, a.ba_points, a.ba_track, seed=42,
                               noise=scene.SyntheticNoiseOptions(0.01, 1.0, 0.05, 1.0))
     fp = est.FlatProblem.from_arrays(d)
     est.fix_gauge_two_cams(fp)
     so = est.SolverOptions(max_num_iterations=a.ba_iters)
-    est.solve_flat(fp.copy(), est.SolverOptions(max_num_iterations=2), gpu_index=local_rank)  # warm-up
-    g = fp.copy()
-    s = est.solve_flat(g, so, gpu_index=local_rank)
+    n_obs = len(fp.obs_pose)
+    sharded = {}
+    if world == 1:
+        est.solve_flat(fp.copy(), est.SolverOptions(max_num_iterations=2), gpu_index=local_rank)  # warm-up
+        s = est.solve_flat(fp.copy(), so, gpu_index=local_rank)
+        seconds = s.lm_seconds
+        parallelism = "one GPU"
+        n_obs_rank = n_obs
+    else:
+        comm = est.Communicator("rccl", gpu_index=local_rank)
+        best = None
+        for name, mode in (("image", est.SHARD_BY_IMAGE), ("point", est.SHARD_BY_POINT)):
+            comm.sharding = mode
+            est.solve_flat(fp.copy(), est.SolverOptions(max_num_iterations=2), gpu_index=local_rank, comm=comm)  # warm-up
+            si = est.solve_flat(fp.copy(), so, gpu_index=local_rank, comm=comm)
+            ti = D.max_over_ranks(si.lm_seconds, dev)
+            sharded[name] = {"LM_iterations_per_s": si.num_iterations / ti, "lm_iterations": si.num_iterations,
+                             "pcg_iterations": int(si.total_linear_iterations), "final_cost": si.final_cost,
+                             "observations_on_rank0": est.shard_num_observations(fp, 0, world, mode)}
+            if best is None or ti < best[1]:
+                best = (si, ti, name, mode)
+        s, seconds, best_name, best_mode = best
+        # leave the timing of the best mode in the library's per-thread counters
+        comm.sharding = best_mode
+        s = est.solve_flat(fp.copy(), so, gpu_index=local_rank, comm=comm)
+        seconds = D.max_over_ranks(s.lm_seconds, dev)
+        comm.close()
+        parallelism = (f"observations sharded by {best_name} over {world} GPUs, RCCL all-reduce on the solver's "
+                       f"stream (both shardings measured, see `sharded`)")
+        n_obs_rank = est.shard_num_observations(fp, rank, world, best_mode)
     ms, n, _ = C.c_double(), C.c_int64(), C.c_int64()
     lib().ba_last_spmv_timing(C.byref(ms), C.byref(n), C.byref(_))
-    n_obs = len(fp.obs_pose)
-    alg = 352 * n_obs  # 2 passes over the fp64 Jacobian rows: 2 x 2 x (6 + 2 + 3) x 8 B per observation
+    alg = 352 * n_obs_rank  # 2 passes over the fp64 Jacobian rows: 2 x 2 x (6 + 2 + 3) x 8 B per observation
     avg_ms = ms.value / max(n.value, 1)
     out = {
         "metric": "BA LM-iters/s @1000 imgs",
-        "value": s.num_iterations / s.lm_seconds,
+        "value": s.num_iterations / seconds,
         "unit": "LM-iterations/s",
+        "n_gpus": world,
+        "scaling": "strong",
         "dtype": "f64",
         "config": {"workload": f"global BA, {a.ba_frames} cameras x {a.ba_points} points, SIMPLE_RADIAL, "
                                f"track length {a.ba_track} ({n_obs} observations), gauge TWO_CAMS_FROM_WORLD, "
                                f"implicit Schur PCG + Schur-Jacobi, first {a.ba_iters} LM iterations",
                    "lm_iterations": s.num_iterations, "pcg_iterations": int(s.total_linear_iterations),
-                   "cost": [s.initial_cost, s.final_cost]},
+                   "cost": [s.initial_cost, s.final_cost], "parallelism": parallelism},
         "roofline": {"bound": "hbm", "kernel": "implicit Schur product (ba_obs_jx + ba_point_pass + ba_block_jtv)",
                      "achieved": alg / (avg_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                      "frac": alg / (avg_ms * 1e-3) / 1e9 / 8000.0, "traffic": None,
                      "algorithmic_bytes_per_launch": alg, "avg_launch_ms": avg_ms, "launches_timed": int(n.value)},
     }
-    if with_cpu:
+    if sharded:
+        out["sharded"] = sharded
+    if with_cpu and world == 1:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import ba_oracle
         c = fp.copy()
@@ -196,10 +230,11 @@ def main():
         torch.cuda.synchronize()
 
     sweep_ms, sweep_n = 0.0, 0
+    evals_sweep, evals_init = 0, 0   # NCC evaluations executed in the timed steps (this rank)
     pms_keepalive = []
 
     def run_step(step, record):
-        nonlocal sweep_ms, sweep_n
+        nonlocal sweep_ms, sweep_n, evals_sweep, evals_init
         grps = [[problem((step * a.groups + g) * a.batch + b)[0] for b in range(a.batch)]
                 for g in range(a.groups)]
         for pms in grps:
@@ -214,6 +249,11 @@ def main():
             ms, n = grps[0][0].GetSweepTiming()
             sweep_ms += ms
             sweep_n += n
+            for pms in grps:
+                for pm in pms:
+                    a_, b_ = pm.GetEvaluationCount()
+                    evals_sweep += a_
+                    evals_init += b_
         for pms in grps:
             for pm in pms:
                 pm.close()
@@ -271,6 +311,12 @@ def main():
                 "avg_launch_ms": avg_ms,
                 "launches_timed": sweep_n,
                 "images_per_launch": a.batch,
+                # what the kernel is actually bound by: NCC evaluations counted
+                # in-kernel (identical hypothesis / view pairs of a pixel are evaluated once) x 121
+                # taps x ~30 flop per tap against the 157.3 TFLOP/s fp32 vector peak; rank 0's counts
+                "taps_per_s": (evals_sweep + evals_init) * 121 / dt,
+                "valu_frac": (evals_sweep + evals_init) * 121 * 30.0 / dt / 157.3e12,
+                "ncc_evaluations_per_pixel_per_sweep": evals_sweep / max(a.steps * a.batch * a.groups * pix_per_image * 20, 1),
                 "note": "gather/latency-limited fp32 VALU kernel, no dense contraction: VALU issue ~58 % busy, "
                         "4-byte footprint gathers miss the XCD L2 69 % of the time (fabric reads ~33x the "
                         "algorithmic bytes); the HBM fraction is reported because BASELINE.json asks for it, "
@@ -287,6 +333,13 @@ def main():
             del pms_keepalive[:]
             torch.cuda.empty_cache()
             out["secondary"] = ba_secondary(a, local_rank, not a.no_cpu_baseline)
+    # N > 1: the secondary (bundle adjustment) leg is ONE solve sharded over all ranks
+    if not a.no_ba and world > 1:
+        torch.cuda.empty_cache()
+        sec = ba_secondary(a, local_rank, False, rank, world, dev)
+        if rank == 0:
+            out["secondary"] = sec
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist

@@ -77,6 +77,7 @@ constexpr int TILE_PTS = 256;
 // supplied host callback (any communicator: gloo, MPI, ...) or RCCL on the solver's stream.
 struct Comm {
   int rank = 0, world = 1;
+  bool by_point = false;  // observations sharded by 3-D point instead of by image (ba_comm::sharding)
   ba_allreduce_fn fn = nullptr;
   void* user = nullptr;
   ncclComm_t nccl = nullptr;
@@ -1271,6 +1272,13 @@ __global__ void ba_maxdiff_kernel(size_t n, const double* __restrict__ a, const 
   for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
   if ((threadIdx.x & 63) == 0) atomic_max_pos(scalars + S_GMAX, v);
 }
+// point sharding: zero the variable points another rank owns (point index % world != rank)
+__global__ void ba_keep_own_points_kernel(View V, int rank, int world, double* __restrict__ points) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= V.n_points || V.pt_off[j] < 0 || j % world == rank) return;
+  points[3 * (size_t)j] = points[3 * (size_t)j + 1] = points[3 * (size_t)j + 2] = 0.0;
+}
+
 __global__ void ba_renorm_quat_kernel(View V, double* __restrict__ poses) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= V.n_poses || V.pose_off[i] < 0) return;
@@ -1331,7 +1339,7 @@ struct Solver {
       pt_ptr, blk_off, blk_dim, blk_kind, blk_moff, chunk_blk, chunk_beg, chunk_end, blk_chunk_ptr, c2a, a2c, tile_pt;
   Buf<unsigned char> solo;
   Buf<double> o_xy, poses, cams, points, poses2, cams2, points2, Jpose, Jcam, Jpt, res, res_p, scale_c, scale_p,
-      scalars, gc, gp, diag_c, diag_p, Dc, Dp, Cinv, M, Minv, rhs, x, r, z, pdir, q, dp, jx, v, stepc, stepp, partials, cpart, Craw, tbuf, tmpc, Gobs, pcg_part;
+      scalars, gc, gp, diag_c, diag_p, Dc, Dp, Cinv, M, Minv, rhs, x, r, z, pdir, q, dp, jx, v, stepc, stepp, partials, cpart, Craw, tbuf, tmpc, Gobs, pcg_part, maxbuf;
   int moff_total = 0;
   long long n_paired = 0;  // (observation, block kind) slots that have a partner of the same point in the block
   int kd = 4, bd = PD;  // intrinsics tangent width / widest camera-side block of this problem
@@ -1354,6 +1362,20 @@ struct Solver {
   double scalar_sum(int slot) {  // value summed over ranks
     comm.allreduce(scalars.p + slot, 1, st);
     return scalar(slot);
+  }
+  // max over ranks of a non-negative scalar through the sum transport: every rank contributes its
+  // value in its own slot of a zeroed world-sized vector. Only point sharding needs it (there a
+  // rank sees the gradient of its own points only; with image sharding all vectors are replicated).
+  double scalar_max(int slot) {
+    if (comm.world == 1 || !comm.by_point) return scalar(slot);
+    if (maxbuf.n < (size_t)comm.world) maxbuf.alloc(comm.world);
+    BA_HIP(hipMemsetAsync(maxbuf.p, 0, sizeof(double) * comm.world, st));
+    BA_HIP(hipMemcpyAsync(maxbuf.p + comm.rank, scalars.p + slot, sizeof(double), hipMemcpyDeviceToDevice, st));
+    comm.allreduce(maxbuf.p, comm.world, st);
+    std::vector<double> h(comm.world);
+    BA_HIP(hipMemcpyAsync(h.data(), maxbuf.p, sizeof(double) * comm.world, hipMemcpyDeviceToHost, st));
+    BA_HIP(hipStreamSynchronize(st));
+    return *std::max_element(h.begin(), h.end());
   }
   void zero_scalar(int slot) { BA_HIP(hipMemsetAsync(scalars.p + slot, 0, sizeof(double), st)); }
 
@@ -1393,7 +1415,9 @@ struct Solver {
       if (p.pose_const[pi] && cam_nvar[ci] == 0 && p.point_const[xi]) continue;
       ++n_active_global;
       pose_used[pi] = cam_used[ci] = pt_used[xi] = 1;  // layout = all ranks' observations
-      if (pi % comm.world == comm.rank) active.push_back(o);  // image sharding
+      // image sharding (BASELINE.json: "images shard across the GPUs") or point sharding (every
+      // observation of a point on one rank: the point-side quantities stay local)
+      if ((comm.by_point ? xi : pi) % comm.world == comm.rank) active.push_back(o);
     }
     const int n = (int)active.size();
     // p-order: sorted by point (stable: keeps the caller's order inside a track)
@@ -1613,8 +1637,10 @@ struct Solver {
     BA_LAUNCH(ba_point_grad_kernel, dim3(grid_for(V.n_points, 128)), dim3(128), st, V, gp.p, diag_p.p);
     comm.allreduce(gc.p, V.n_c, st);
     comm.allreduce(diag_c.p, V.n_c, st);
-    comm.allreduce(gp.p, V.n_p, st);
-    comm.allreduce(diag_p.p, V.n_p, st);
+    if (!comm.by_point) {  // point sharding: a point's gradient and column norms are complete locally
+      comm.allreduce(gp.p, V.n_p, st);
+      comm.allreduce(diag_p.p, V.n_p, st);
+    }
   }
 
   // y = (sum over ranks of J_c^T v) for this rank's observations, into tmpc
@@ -1644,8 +1670,8 @@ struct Solver {
       if (kd == 4) BA_LAUNCH(ba_obs_jx_kernel<4>, dim3(go), dim3(256), st, V, xin, jx.p);
       else BA_LAUNCH(ba_obs_jx_kernel<KD_MAX>, dim3(go), dim3(256), st, V, xin, jx.p);
     }
-    if (comm.world == 1) {
-      point_pass<0>();
+    if (comm.world == 1 || comm.by_point) {
+      point_pass<0>();  // E^T x, C^-1 and E u of a point are local
     } else {
       BA_HIP(hipMemsetAsync(tbuf.p, 0, sizeof(double) * std::max(V.n_p, 1), st));
       BA_LAUNCH(ba_point_t_kernel, dim3(grid_for(V.n_points, 128)), dim3(128), st, V, jx.p, tbuf.p);
@@ -1743,7 +1769,7 @@ struct Solver {
         BA_LAUNCH(ba_maxdiff_kernel, dim3(grid_for(poses.n, 256)), dim3(256), st, poses.n, poses.p, poses2.p, scalars.p);
         BA_LAUNCH(ba_maxdiff_kernel, dim3(grid_for(cams.n, 256)), dim3(256), st, cams.n, cams.p, cams2.p, scalars.p);
         BA_LAUNCH(ba_maxdiff_kernel, dim3(grid_for(points.n, 256)), dim3(256), st, points.n, points.p, points2.p, scalars.p);
-        const double gmax = scalar(S_GMAX);
+        const double gmax = scalar_max(S_GMAX);
         if (gmax <= opt.gradient_tolerance) {
           out->termination_type = BA_CONVERGENCE;
           out->num_iterations = iter;
@@ -1762,7 +1788,7 @@ struct Solver {
       BA_LAUNCH(ba_lm_diag_kernel, dim3(std::max(gvp, 1)), dim3(256), st, np, diag_p.p, radius,
                          opt.min_lm_diagonal, opt.max_lm_diagonal, Dp.p);
       BA_LAUNCH(ba_point_gram_kernel, dim3(grid_for(V.n_points, 128)), dim3(128), st, V, Craw.p);
-      comm.allreduce(Craw.p, 6 * (size_t)V.n_points, st);
+      if (!comm.by_point) comm.allreduce(Craw.p, 6 * (size_t)V.n_points, st);
       BA_LAUNCH(ba_point_blocks_kernel, dim3(grid_for(V.n_points, 128)), dim3(128), st, V, Craw.p, Dp.p, Cinv.p);
       int lin_iters = 0;
       if (nc > 0) {
@@ -1793,7 +1819,7 @@ struct Solver {
         if (kd == 4) BA_LAUNCH(ba_obs_jx_kernel<4>, dim3(grid_for(V.n_obs, 256)), dim3(256), st, V, x.p, jx.p);
         else BA_LAUNCH(ba_obs_jx_kernel<KD_MAX>, dim3(grid_for(V.n_obs, 256)), dim3(256), st, V, x.p, jx.p);
       }
-      if (comm.world == 1) {
+      if (comm.world == 1 || comm.by_point) {
         point_pass<2>();
       } else {
         BA_HIP(hipMemsetAsync(tbuf.p, 0, sizeof(double) * std::max(np, 1), st));
@@ -1860,6 +1886,11 @@ struct Solver {
     out->final_cost = scalar_sum(S_NEWCOST);
     out->lm_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
     BA_LAUNCH(ba_renorm_quat_kernel, dim3(grid_for(V.n_poses, 128)), dim3(128), st, V, poses.p);
+    if (comm.world > 1 && comm.by_point) {
+      // every rank moved its own points only: zero the others' variable points and sum over ranks
+      BA_LAUNCH(ba_keep_own_points_kernel, dim3(grid_for(V.n_points, 128)), dim3(128), st, V, comm.rank, comm.world, points.p);
+      comm.allreduce(points.p, 3 * (size_t)V.n_points, st);
+    }
     // write back variable blocks only (constant blocks stay bit-identical)
     std::vector<double> hp(poses.n), hc(cams.n), hx(points.n);
     BA_HIP(hipMemcpyAsync(hp.data(), poses.p, sizeof(double) * poses.n, hipMemcpyDeviceToHost, st));
@@ -1934,6 +1965,9 @@ static int SolveImpl(ba_problem* problem, const ba_options* options, int32_t gpu
       comm.fn = c->allreduce;
       comm.user = c->user;
       comm.nccl = reinterpret_cast<ncclComm_t>(c->rccl_comm);
+      comm.by_point = c->sharding == BA_SHARD_BY_POINT;
+      if (c->sharding != BA_SHARD_BY_IMAGE && c->sharding != BA_SHARD_BY_POINT)
+        throw std::runtime_error("ba_comm.sharding must be BA_SHARD_BY_IMAGE or BA_SHARD_BY_POINT");
       if (comm.world > 1 && !comm.nccl && !comm.fn) throw std::runtime_error("ba_comm needs rccl_comm or an allreduce callback");
     }
     Solver s(*problem, *options, comm);
@@ -1954,21 +1988,28 @@ int ba_solve_sharded(ba_problem* problem, const ba_options* options, int32_t gpu
   return SolveImpl(problem, options, gpu_index, comm, result);
 }
 
-int64_t ba_shard_num_observations(const ba_problem* p, int32_t rank, int32_t world_size) {
+static int64_t ShardNumObservations(const ba_problem* p, int32_t rank, int32_t world_size, bool by_point) {
   if (!p || world_size < 1 || rank < 0 || rank >= world_size) return -1;
   std::vector<char> cam_var(p->num_cams, 0);
   for (int k = 0; k < p->num_cams; ++k) {
-    const int P = p->cam_model[k] == BA_SIMPLE_PINHOLE ? 3 : 4;
+    const int P = num_params_of(p->cam_model[k]);
     for (int j = 0; j < P; ++j)
       if (!p->cam_const[(size_t)k * BA_CAM_STRIDE + j]) cam_var[k] = 1;
   }
   int64_t n = 0;
   for (int64_t o = 0; o < p->num_obs; ++o) {
-    const int pi = p->obs_pose[o];
-    if (p->pose_const[pi] && !cam_var[p->obs_cam[o]] && p->point_const[p->obs_point[o]]) continue;
-    if (pi % world_size == rank) ++n;
+    const int pi = p->obs_pose[o], xi = p->obs_point[o];
+    if (p->pose_const[pi] && !cam_var[p->obs_cam[o]] && p->point_const[xi]) continue;
+    if ((by_point ? xi : pi) % world_size == rank) ++n;
   }
   return n;
+}
+
+int64_t ba_shard_num_observations(const ba_problem* p, int32_t rank, int32_t world_size) {
+  return ShardNumObservations(p, rank, world_size, false);
+}
+int64_t ba_shard_num_observations_by_point(const ba_problem* p, int32_t rank, int32_t world_size) {
+  return ShardNumObservations(p, rank, world_size, true);
 }
 
 int ba_rccl_unique_id(char id[128]) {

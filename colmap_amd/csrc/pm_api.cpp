@@ -250,6 +250,7 @@ struct pm_handle {
   DevBuf<float> poses;  // [4][S][43]
   DevBuf<float> out_depth, out_normal, out_sel, out_cost;
   DevBuf<unsigned long long> prof;
+  DevBuf<unsigned long long> evals;  // NCC evaluations of the sweep launches of the last run
   DevBuf<PmParams> plan;  // per-launch parameter blocks of the last (batched) run
   hipStream_t run_stream = nullptr;  // stream the last run was enqueued on
   PmParams base;
@@ -510,6 +511,8 @@ void Create(const pm_options& opt_in, const pm_problem& prob, pm_image_cache* ca
     h->mask.alloc((size_t)S * W * H);
     b.mask = h->mask.ptr;
   }
+  h->evals.alloc(1);
+  b.evals = h->evals.ptr;
   h->out_depth.alloc((size_t)W * H);
   h->out_normal.alloc((size_t)3 * W * H);
   h->out_sel.alloc((size_t)S * W * H);
@@ -585,6 +588,7 @@ void RunBatchAsync(pm_handle** hs, int n) {
     if (h->mask.ptr) HIP_CALL(hipMemsetAsync(h->mask.ptr, 0, h->mask.count, h0->stream));
     if (h->prof.ptr)
       HIP_CALL(hipMemsetAsync(h->prof.ptr, 0, 10 * sizeof(unsigned long long), h0->stream));
+    HIP_CALL(hipMemsetAsync(h->evals.ptr, 0, sizeof(unsigned long long), h0->stream));
   }
   pm_launch_initial_cost(host[0], h0->plan.ptr, n, h0->stream);
   const bool geom = opt.geom_consistency != 0;
@@ -883,6 +887,16 @@ int pm_get_device_maps(pm_handle* h, const float** depth, const float** normal) 
     PM_CHECK(h && h->ran, "run first");
     if (depth) *depth = h->out_depth.ptr;
     if (normal) *normal = h->out_normal.ptr;
+  });
+}
+
+int pm_get_evaluation_count(pm_handle* h, unsigned long long* sweep_evals, unsigned long long* initial_evals) {
+  return Guard([&] {
+    PM_CHECK(h && h->ran, "pm_run must be called first");
+    HIP_CALL(hipSetDevice(h->device));
+    if (sweep_evals)
+      HIP_CALL(hipMemcpy(sweep_evals, h->evals.ptr, sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (initial_evals) *initial_evals = (unsigned long long)h->W * h->H * h->S;  // ComputeInitialCost
   });
 }
 

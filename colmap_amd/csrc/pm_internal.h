@@ -51,6 +51,8 @@ struct PmParams {
   uint8_t* mask;            // [S][H][W] or null
   const float* poses;       // [S][43] for this rotation
   unsigned long long* prof; // optional phase-cycle counters [10] (debug), else null
+  unsigned long long* evals; // NCC evaluations executed by the sweep kernels of this run (one atomic
+                             // add per workgroup at its end), always allocated
 };
 
 size_t pm_sweep_lds_bytes(const PmParams& p, bool geom);

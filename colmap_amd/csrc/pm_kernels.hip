@@ -994,8 +994,8 @@ __global__ void __launch_bounds__(64) pm_initial_cost_kernel(const PmParams* __r
 // the (hypothesis, view) pair and, with GEOM, the geometric consistency cost. Pass B
 // (16-lane group per task): the bilaterally weighted NCC.
 template <int N1D, bool GEOM>
-__device__ __forceinline__ void run_tasks(const PmParams& p, const Lds& L, int row, int col0,
-                                          int tid, int nt) {
+__device__ __forceinline__ int run_tasks(const PmParams& p, const Lds& L, int row, int col0,
+                                         int tid, int nt) {
   const int n = *L.ntasks;
   for (int t = tid; t < n; t += nt) {
     const uint32_t task = L.tasks[t];
@@ -1052,6 +1052,7 @@ __device__ __forceinline__ void run_tasks(const PmParams& p, const Lds& L, int r
     L.ncc[(c * 5 + i) * p.S + s] = ncc_finish(L.th[t * 9 + 0], L.th[t * 9 + 1], L.th[t * 9 + 2],
                                               L.colf[c * 8 + 0], L.colf[c * 8 + 1], L.colf[c * 8 + 5]);
   }
+  return n;  // queued tasks (with GEOM this includes the geometric-cost-only entries)
 }
 
 // ---------------------------------------------------------------------------
@@ -1106,26 +1107,25 @@ __device__ __forceinline__ gbl_u32* tap_address(const PmParams& p, gbl_u32* fp, 
 constexpr int kGatherRingBytes = 2 * 8 * 64 * 4;
 
 template <int SLOT>
-__device__ __forceinline__ void gather_issue(gbl_u32* addr, uint32_t ring_lds_addr) {
-  // M0 = LDS base of the ring (the compiler does not use M0 in this kernel; it is set per gather
-  // anyway: a scalar move), instruction offset = slot
-  asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dword %0, off offset:%2"
-               :
-               : "v"(addr), "s"(ring_lds_addr), "n"(SLOT * 256)
-               : "memory");
+__device__ __forceinline__ void gather_issue(gbl_u32* addr) {
+  // LDS address of lane l = M0[15:0] + instruction offset + 4 l. The instruction offset would be
+  // added to the GLOBAL address as well, so the slot is selected through M0 (a scalar move per
+  // gather; the compiler does not use M0 in this kernel). The ring is the first thing in the
+  // workgroup's LDS (offset 0: checked at kernel entry), which makes M0 a literal.
+  asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dword %0, off" : : "v"(addr), "n"(SLOT * 256) : "memory");
 }
 // slot index known after unrolling: the switch folds to the one asm statement
 template <int STAGE>
-__device__ __forceinline__ void gather_issue_k(int k, gbl_u32* addr, uint32_t ring_lds_addr) {
+__device__ __forceinline__ void gather_issue_k(int k, gbl_u32* addr) {
   switch (k) {
-    case 0: gather_issue<8 * STAGE + 0>(addr, ring_lds_addr); break;
-    case 1: gather_issue<8 * STAGE + 1>(addr, ring_lds_addr); break;
-    case 2: gather_issue<8 * STAGE + 2>(addr, ring_lds_addr); break;
-    case 3: gather_issue<8 * STAGE + 3>(addr, ring_lds_addr); break;
-    case 4: gather_issue<8 * STAGE + 4>(addr, ring_lds_addr); break;
-    case 5: gather_issue<8 * STAGE + 5>(addr, ring_lds_addr); break;
-    case 6: gather_issue<8 * STAGE + 6>(addr, ring_lds_addr); break;
-    default: gather_issue<8 * STAGE + 7>(addr, ring_lds_addr); break;
+    case 0: gather_issue<8 * STAGE + 0>(addr); break;
+    case 1: gather_issue<8 * STAGE + 1>(addr); break;
+    case 2: gather_issue<8 * STAGE + 2>(addr); break;
+    case 3: gather_issue<8 * STAGE + 3>(addr); break;
+    case 4: gather_issue<8 * STAGE + 4>(addr); break;
+    case 5: gather_issue<8 * STAGE + 5>(addr); break;
+    case 6: gather_issue<8 * STAGE + 6>(addr); break;
+    default: gather_issue<8 * STAGE + 7>(addr); break;
   }
 }
 // Wait until at most NEWER vector-memory operations issued after a stage's eight gathers are
@@ -1135,9 +1135,11 @@ __device__ __forceinline__ void gather_wait() {
   asm volatile("s_waitcnt vmcnt(%0)" : : "n"(NEWER) : "memory");
 }
 
+// STAGE 0 / 1: the gathers go to that stage of the LDS ring (software-pipelined loop); STAGE < 0:
+// plain loads into `tex` (the compiler tracks and waits for them).
 template <int STAGE>
 __device__ __forceinline__ void ncc_front(const PmParams& p, const lds_f32* H, gbl_u32* fp,
-                                          const lds_f32* tg, uint32_t ring_lds_addr, int j, NccStage& st) {
+                                          const lds_f32* tg, int j, NccStage& st, uint32_t* tex = nullptr) {
   const float h0 = H[0], h1 = H[1], h2 = H[2], h3 = H[3], h4 = H[4], h5 = H[5], h6 = H[6],
               h7 = H[7], h8 = H[8];
   v2f csrc[4], rsrc[4], pre[4], suf[4];
@@ -1183,8 +1185,13 @@ __device__ __forceinline__ void ncc_front(const PmParams& p, const lds_f32* H, g
     st.wy[q] = py - fy;
     const v2f fx2 = fx + pk_bcast(2.0f);
     const v2f fy2 = fy + pk_bcast(2.0f);
-    gather_issue_k<STAGE>(2 * q, tap_address(p, fp, fx2[0], fy2[0]), ring_lds_addr);
-    gather_issue_k<STAGE>(2 * q + 1, tap_address(p, fp, fx2[1], fy2[1]), ring_lds_addr);
+    if (STAGE >= 0) {
+      gather_issue_k<(STAGE >= 0 ? STAGE : 0)>(2 * q, tap_address(p, fp, fx2[0], fy2[0]));
+      gather_issue_k<(STAGE >= 0 ? STAGE : 0)>(2 * q + 1, tap_address(p, fp, fx2[1], fy2[1]));
+    } else {
+      tex[2 * q] = *tap_address(p, fp, fx2[0], fy2[0]);
+      tex[2 * q + 1] = *tap_address(p, fp, fx2[1], fy2[1]);
+    }
   }
 }
 
@@ -1309,6 +1316,7 @@ __global__ void __launch_bounds__(256, 3) pm_sweep_kernel(const PmParams* __rest
   __syncthreads();
   PM_PROF_MARK(0)
 
+  unsigned evals2 = 0;
   for (int row = 0; row < RH; ++row) {
     // ---- P0: scroll the reference tile (LocalRefImage::Read, :357-410) -------
     tile_load_row(p, L, col0, row + p.radius, tid, nt);
@@ -1429,7 +1437,7 @@ __global__ void __launch_bounds__(256, 3) pm_sweep_kernel(const PmParams* __rest
     PM_PROF_MARK(4)
 
     // ---- P4: NCC of hypotheses 1..4 against the drawn views (:1157-1172) -----
-    run_tasks<N1D, GEOM>(p, L, row, col0, tid, nt);
+    evals2 += (unsigned)run_tasks<N1D, GEOM>(p, L, row, col0, tid, nt);
     __syncthreads();
     if (tid == 0) *L.ntasks = 0;
     __syncthreads();
@@ -1484,7 +1492,7 @@ __global__ void __launch_bounds__(256, 3) pm_sweep_kernel(const PmParams* __rest
     PM_PROF_MARK(6)
 
     // ---- P6: NCC of the winner against the remaining views (:1188-1197) ------
-    run_tasks<N1D, false>(p, L, row, col0, tid, nt);
+    evals2 += (unsigned)run_tasks<N1D, false>(p, L, row, col0, tid, nt);
     __syncthreads();
     PM_PROF_MARK(7)
 
@@ -1551,6 +1559,7 @@ __global__ void __launch_bounds__(256, 3) pm_sweep_kernel(const PmParams* __rest
   if (col_lane) {
     rng_store(p.rng + (size_t)pix_index(p, 0, col0 + tid) * kRngWords, rng);  // :1285-1287
   }
+  if (tid == 0 && p.evals) atomicAdd(p.evals, (unsigned long long)evals2);
   if (PROF && tid == 0 && p.prof) {
     for (int i = 0; i < 10; ++i) atomicAdd(p.prof + i, prof_acc[i]);
   }
@@ -1584,7 +1593,7 @@ __host__ __device__ inline int wave_max_tasks(int C, int S, int M) {
 }
 
 __host__ __device__ inline LdsOffsets lds_offsets_wave(int C, int S, int radius, int ntaps, int M,
-                                                       bool geom) {
+                                                       bool geom, bool pipe) {
   LdsOffsets o;
   uint32_t off = 0;
   auto take = [&](uint32_t bytes) {
@@ -1595,6 +1604,7 @@ __host__ __device__ inline LdsOffsets lds_offsets_wave(int C, int S, int radius,
   const int win = 2 * radius + 1;
   const int tw = C + 2 * radius;
   const int max_tasks = wave_max_tasks(C, S, M);
+  o.ring = take(pipe ? (uint32_t)kGatherRingBytes : 0u);  // must be at LDS offset 0 (gather_issue)
   o.poses = take(4u * S * lds_pose_stride(geom));
   o.fpb = take(8u * S);
   o.tile = take(4u * win * tw);
@@ -1620,16 +1630,17 @@ __host__ __device__ inline LdsOffsets lds_offsets_wave(int C, int S, int radius,
   o.th = take(36u * kWaveThCap);
   o.ntasks = take(16u);
   o.tapg = take(4u * 256);
-  o.ring = take((uint32_t)kGatherRingBytes);
   o.total = off;
   return o;
 }
 
 // Run the queued NCC tasks (and, with GEOM, the geometric-cost-only list) of one phase.
-template <bool GEOM>
-__device__ __forceinline__ void run_tasks_wave(const PmParams& p, const Lds& L, int row, int col0, int tid) {
+template <bool GEOM, bool PIPE>
+__device__ __forceinline__ void run_tasks_wave(const PmParams& p, const Lds& L, int row, int col0, int tid,
+                                               unsigned& evals) {
   const lds_f32* G = L.tapg;
   const int n = L.ntasks[0];
+  evals += (unsigned)n;
   const LDS_AS uint16_t* tasks = (const LDS_AS uint16_t*)L.tasks;
   const int g = tid >> 4, j = tid & 15;
   const int S = p.S;
@@ -1673,7 +1684,6 @@ __device__ __forceinline__ void run_tasks_wave(const PmParams& p, const Lds& L, 
     {
       const int rounds = (nb + 3) >> 2;
       const lds_u32* ring = L.ring;
-      const uint32_t ring_addr = (uint32_t)(uintptr_t)L.ring;
       NccStage A, B;
       int ta, tb, ca, cb;
       bool wa, wb;
@@ -1690,7 +1700,7 @@ __device__ __forceinline__ void run_tasks_wave(const PmParams& p, const Lds& L, 
 #define PM_FRONT(STAGE, r, st, t, c, own)                                                  \
   do {                                                                                     \
     const uint32_t sv_ = prep(r, t, c, own);                                               \
-    ncc_front<STAGE>(p, L.th + (t) * 9, (gbl_u32*)L.fpb[sv_], G, ring_addr, j, st);        \
+    ncc_front<STAGE>(p, L.th + (t) * 9, (gbl_u32*)L.fpb[sv_], G, j, st);                   \
   } while (0)
 #define PM_BACK(STAGE, NEWER, st, t, c, own)                                               \
   do {                                                                                     \
@@ -1707,6 +1717,25 @@ __device__ __forceinline__ void run_tasks_wave(const PmParams& p, const Lds& L, 
       L.th[(t) * 9 + 2] = s_ref_;                                                          \
     }                                                                                      \
   } while (0)
+      if (!PIPE) {
+        // plain variant: one round at a time, all eight gathers of a lane in flight before the first
+        // texel is consumed (fewer registers and no LDS ring: more waves per SIMD instead)
+        for (int r = 0; r < rounds; ++r) {
+          const uint32_t sv_ = prep(r, ta, ca, wa);
+          uint32_t tex_[8];
+          ncc_front<-1>(p, L.th + ta * 9, (gbl_u32*)L.fpb[sv_], G, j, A, tex_);
+          __builtin_amdgcn_sched_barrier(0);
+          TapRegs R_;
+          tap_regs_load(R_, L.wgt + ca * 128, L.refc + ca * 128, j);
+          float s_sum_, s_sq_, s_ref_;
+          ncc_back(A, tex_, R_, j, s_sum_, s_sq_, s_ref_);
+          if (j == 0 && wa) {
+            L.th[ta * 9 + 0] = s_sum_;
+            L.th[ta * 9 + 1] = s_sq_;
+            L.th[ta * 9 + 2] = s_ref_;
+          }
+        }
+      } else {
       PM_FRONT(0, 0, A, ta, ca, wa);
       for (int r = 0;;) {
         if (r + 1 >= rounds) {
@@ -1723,6 +1752,7 @@ __device__ __forceinline__ void run_tasks_wave(const PmParams& p, const Lds& L, 
         PM_FRONT(0, r + 1, A, ta, ca, wa);
         PM_BACK(1, 8, B, tb, cb, wb);
         ++r;
+      }
       }
 #undef PM_FRONT
 #undef PM_BACK
@@ -1741,8 +1771,8 @@ __device__ __forceinline__ void run_tasks_wave(const PmParams& p, const Lds& L, 
   }
 }
 
-template <bool GEOM, bool FILTER_PHOTO, bool FILTER_GEOM>
-__global__ void __launch_bounds__(64, 3) pm_sweep_wave_kernel(const PmParams* __restrict__ pp) {
+template <bool GEOM, bool FILTER_PHOTO, bool FILTER_GEOM, bool PIPE>
+__device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp) {
   const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y;
   unsigned group = lin / gridDim.y;
   unsigned prob = lin - group * gridDim.y;
@@ -1763,7 +1793,7 @@ __global__ void __launch_bounds__(64, 3) pm_sweep_wave_kernel(const PmParams* __
   const PmParams& p = pp[prob];
   extern __shared__ __attribute__((aligned(16))) char smem[];
   Lds L;
-  lds_bind(L, (lds_char*)smem, lds_offsets_wave(p.C, p.S, p.radius, p.ntaps, p.num_samples, GEOM));
+  lds_bind(L, (lds_char*)smem, lds_offsets_wave(p.C, p.S, p.radius, p.ntaps, p.num_samples, GEOM, PIPE));
   const int tid_entry = threadIdx.x;
   const int tid = tid_entry;
   constexpr int nt = 64;
@@ -1772,6 +1802,7 @@ __global__ void __launch_bounds__(64, 3) pm_sweep_wave_kernel(const PmParams* __
   const int col0 = group * C;
   const int ncols = min(C, RW - col0);
   const float* iK = p.refInvK;
+  if (PIPE && (uint32_t)(uintptr_t)L.ring != 0u) __builtin_trap();  // gather_issue addresses the ring through a literal M0
   tap_geom_init(L.tapg, tid, p.step, (p.rot & 1) != 0);
 
   lds_load_poses(p, L, GEOM, tid, nt);
@@ -1806,6 +1837,7 @@ __global__ void __launch_bounds__(64, 3) pm_sweep_wave_kernel(const PmParams* __
   __syncthreads();
 
   const int tid0 = tid_entry;
+  unsigned evals = 0;  // NCC evaluations of this workgroup (< 2^32: RH * C * (4 M + S) per sweep)
   for (int row = 0; row < RH; ++row) {
     // The lane id is laundered through an empty asm once per row: everything the phases derive from
     // it (item -> column / view, LDS addresses) is then recomputed per row instead of being hoisted
@@ -1929,7 +1961,7 @@ __global__ void __launch_bounds__(64, 3) pm_sweep_wave_kernel(const PmParams* __
     __syncthreads();
 
     // ---- P4: NCC of hypotheses 1..4 against the drawn views (:1157-1172) -----
-    run_tasks_wave<GEOM>(p, L, row, col0, tid);
+    run_tasks_wave<GEOM, PIPE>(p, L, row, col0, tid, evals);
     if (tid == 0) { L.ntasks[0] = 0; L.ntasks[1] = 0; }
     __syncthreads();
 
@@ -1984,7 +2016,7 @@ __global__ void __launch_bounds__(64, 3) pm_sweep_wave_kernel(const PmParams* __
     __syncthreads();
 
     // ---- P6: NCC of the winner against the remaining views (:1188-1197) ------
-    run_tasks_wave<false>(p, L, row, col0, tid);
+    run_tasks_wave<false, PIPE>(p, L, row, col0, tid, evals);
 
     // ---- P7: cost map, forward message, selection probability (:1186-1207) ---
     for (int item = tid; item < ncols * S; item += nt) {
@@ -2046,6 +2078,18 @@ __global__ void __launch_bounds__(64, 3) pm_sweep_wave_kernel(const PmParams* __
   if (col_lane) {
     rng_store(p.rng + (size_t)pix_index(p, 0, col0 + tid) * kRngWords, rng);  // :1285-1287
   }
+  if (tid == 0 && p.evals) atomicAdd(p.evals, (unsigned long long)evals);
+}
+
+// Two builds of the same body: the software-pipelined one (3 waves per SIMD, 4 KB gather ring in
+// LDS) and the plain one (4 waves per SIMD by registers, no ring).
+template <bool GEOM, bool FILTER_PHOTO, bool FILTER_GEOM>
+__global__ void __launch_bounds__(64, 3) pm_sweep_wave_kernel(const PmParams* __restrict__ pp) {
+  sweep_wave_body<GEOM, FILTER_PHOTO, FILTER_GEOM, true>(pp);
+}
+template <bool GEOM, bool FILTER_PHOTO, bool FILTER_GEOM>
+__global__ void __launch_bounds__(64, 4) pm_sweep_wave4_kernel(const PmParams* __restrict__ pp) {
+  sweep_wave_body<GEOM, FILTER_PHOTO, FILTER_GEOM, false>(pp);
 }
 
 // Debug: raw XORWOW streams of the generator above (seed = sequence id, as InitRandomStateKernel
@@ -2149,12 +2193,16 @@ void pm_launch_sweep(const PmParams& p, const PmParams* dev_params, int batch, i
   // (COLMAP_AMD_PM_WAVE=0).
   static const bool wave_enabled = [] { const char* e = getenv("COLMAP_AMD_PM_WAVE"); return !e || atoi(e) != 0; }();
   if (wave_enabled && !p.prof && p.ntap1d == 11 && p.step >= 1 && pm_fixed_window_ok(p) && p.S <= 512 && p.C <= 8) {
-    const size_t wlds = lds_offsets_wave(p.C, p.S, p.radius, p.ntaps, p.num_samples, geom).total + lds_pad;
+    static const bool pipe = [] { const char* e = getenv("COLMAP_AMD_PM_PIPE"); return !e || atoi(e) != 0; }();
+    const size_t wlds = lds_offsets_wave(p.C, p.S, p.radius, p.ntaps, p.num_samples, geom, pipe).total + lds_pad;
     dim3 wblock(64, 1, 1);
     dim3 wgrid = grid;
     if (p.xcd_map == 2) wgrid.x = ((grid.x + 63) / 64) * 64;
-#define PM_LAUNCH_W(G, FP, FG) \
-  hipLaunchKernelGGL((pm_sweep_wave_kernel<G, FP, FG>), wgrid, wblock, wlds, st, dev_params)
+#define PM_LAUNCH_W(G, FP, FG)                                                                              \
+  do {                                                                                                      \
+    if (pipe) hipLaunchKernelGGL((pm_sweep_wave_kernel<G, FP, FG>), wgrid, wblock, wlds, st, dev_params);   \
+    else hipLaunchKernelGGL((pm_sweep_wave4_kernel<G, FP, FG>), wgrid, wblock, wlds, st, dev_params);       \
+  } while (0)
     if (geom) {
       if (filter_photo && filter_geom) PM_LAUNCH_W(true, true, true);
       else PM_LAUNCH_W(true, false, false);

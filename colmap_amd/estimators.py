@@ -549,7 +549,10 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int64
 
 class ba_comm(C.Structure):
     _fields_ = [("rank", C.c_int32), ("world_size", C.c_int32), ("allreduce", ALLREDUCE_FN),
-                ("user", C.c_void_p), ("rccl_comm", C.c_void_p)]
+                ("user", C.c_void_p), ("rccl_comm", C.c_void_p), ("sharding", C.c_int32)]
+
+
+SHARD_BY_IMAGE, SHARD_BY_POINT = 0, 1
 
 
 class Communicator:
@@ -558,8 +561,9 @@ class Communicator:
     one GPU); `backend="rccl"` creates an RCCL communicator inside the library (one GPU per rank,
     all-reduce on the solver's stream over xGMI)."""
 
-    def __init__(self, backend: str = "callback", gpu_index: int = -1):
+    def __init__(self, backend: str = "callback", gpu_index: int = -1, sharding: int = SHARD_BY_IMAGE):
         import torch.distributed as dist
+        self.sharding = int(sharding)  # SHARD_BY_IMAGE (BASELINE.json) or SHARD_BY_POINT (less traffic)
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.world_size = dist.get_world_size() if dist.is_initialized() else 1
         self.backend = backend
@@ -599,7 +603,7 @@ class Communicator:
             raise ValueError(backend)
 
     def to_c(self) -> ba_comm:
-        return ba_comm(self.rank, self.world_size, self._cb, None, self._rccl)
+        return ba_comm(self.rank, self.world_size, self._cb, None, self._rccl, self.sharding)
 
     def close(self):
         if self._rccl:
@@ -672,12 +676,13 @@ def solve_flat(fp: FlatProblem, so: Optional[SolverOptions] = None, gpu_index: i
         log_linear_iters=log_lin[: r.num_logged].copy())
 
 
-def shard_num_observations(fp: FlatProblem, rank: int, world_size: int) -> int:
-    """Observations rank `rank` works on under image sharding (host-only, no GPU needed)."""
+def shard_num_observations(fp: FlatProblem, rank: int, world_size: int, sharding: int = SHARD_BY_IMAGE) -> int:
+    """Observations rank `rank` works on under image / point sharding (host-only, no GPU needed)."""
     L = lib()
-    L.ba_shard_num_observations.restype = C.c_int64
+    fn = L.ba_shard_num_observations_by_point if sharding == SHARD_BY_POINT else L.ba_shard_num_observations
+    fn.restype = C.c_int64
     p = marshal_problem(fp)
-    return int(L.ba_shard_num_observations(C.byref(p), C.c_int32(rank), C.c_int32(world_size)))
+    return int(fn(C.byref(p), C.c_int32(rank), C.c_int32(world_size)))
 
 
 class BundleAdjuster:

@@ -337,6 +337,12 @@ class PatchMatch:
                                         K.ctypes.data_as(C.c_void_p), iK.ctypes.data_as(C.c_void_p)))
         return poses, K, iK
 
+    def GetEvaluationCount(self):
+        """(NCC evaluations executed by the sweep launches, by ComputeInitialCost) of the last run."""
+        a, b = C.c_ulonglong(), C.c_ulonglong()
+        _check(lib().pm_get_evaluation_count(self._h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
     def EnablePhaseProfile(self, enable=True):
         _check(lib().pm_enable_phase_profile(self._h, 1 if enable else 0))
 

@@ -106,11 +106,15 @@ typedef struct ba_result {
   int32_t* log_linear_iters;
 } ba_result;
 
-/* Multi-GPU: observations sharded by image (obs_pose % world_size == rank), every rank holds the
- * full parameter set and calls ba_solve_sharded with the SAME problem; partial sums of the
- * point-side quantities and of J^T v are combined by an in-place sum over ranks:
+/* Multi-GPU: every rank holds the full parameter set and calls ba_solve_sharded with the SAME
+ * problem; the observations are sharded and partial sums are combined by an in-place sum over ranks.
+ *  BA_SHARD_BY_IMAGE (obs_pose % world_size == rank; what BASELINE.json names):
  *   per LM iteration: cost scalars, J^T r + column norms, E^T E (6 / point), Schur-Jacobi blocks;
  *   per PCG iteration: E^T x (3 doubles / point) and the camera-space vector J_c^T v.
+ *  BA_SHARD_BY_POINT (obs_point % world_size == rank; SURVEY.md section 8e's alternative): all
+ *   observations of a point are on one rank, so E^T E, C^-1, E^T x stay local and only camera-space
+ *   vectors travel: per LM iteration cost scalars, J_c^T r + column norms, Schur-Jacobi blocks, per
+ *   PCG iteration J_c^T v (6 N_c + sum P_t doubles); the points are gathered once at the end.
  * Transport: either a host callback (any communicator: gloo, MPI, ...) or an RCCL communicator
  * created with ba_rccl_comm_create (all-reduce on the solver's stream, xGMI). No counterpart in the
  * reference: Ceres and Caspar are single-device (bundle_adjustment_ceres.cc:189-191). */
@@ -120,7 +124,9 @@ typedef struct ba_comm {
   ba_allreduce_fn allreduce; /* used when rccl_comm is NULL */
   void* user;
   void* rccl_comm;           /* from ba_rccl_comm_create, or NULL */
+  int32_t sharding;          /* BA_SHARD_BY_IMAGE (0) or BA_SHARD_BY_POINT (1) */
 } ba_comm;
+enum { BA_SHARD_BY_IMAGE = 0, BA_SHARD_BY_POINT = 1 };
 
 void ba_options_init(ba_options* options);
 
@@ -129,6 +135,8 @@ int ba_solve_sharded(ba_problem* problem, const ba_options* options, int32_t gpu
 /* Number of observations rank `rank` of `world_size` works on (host-only helper, no GPU needed):
  * active observations (>= 1 variable block) whose pose index satisfies pose % world_size == rank. */
 int64_t ba_shard_num_observations(const ba_problem* problem, int32_t rank, int32_t world_size);
+/* The same for BA_SHARD_BY_POINT (point % world_size == rank). */
+int64_t ba_shard_num_observations_by_point(const ba_problem* problem, int32_t rank, int32_t world_size);
 /* RCCL transport: rank 0 obtains a 128-byte id, every rank creates its communicator from it. */
 int ba_rccl_unique_id(char id[128]);
 int ba_rccl_comm_create(const char id[128], int32_t rank, int32_t world_size, int32_t gpu_index, void** comm);

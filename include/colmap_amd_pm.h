@@ -152,6 +152,12 @@ int pm_get_pose_tables(pm_handle* h, float* poses /*4*S*43*/, float* ref_K /*16*
 /* HIP-event timing of the sweep kernel launches of the last run, measured on
  * the handle's stream: total ms and launch count. */
 int pm_get_sweep_timing(pm_handle* h, double* total_ms, int32_t* num_launches);
+/* Bilaterally weighted NCC evaluations (PhotoConsistencyCostComputer::Compute,
+ * patch_match_cuda.cu:489-593; (2 r / step + 1)^2 taps each) the last run actually executed: in the
+ * sweep launches (identical hypothesis / view pairs of a pixel are evaluated once) and in
+ * ComputeInitialCost (W * H * S). With geom_consistency the sweep count also includes the
+ * geometric-cost-only entries when the two-wave kernel runs. bench.py turns it into taps/s. */
+int pm_get_evaluation_count(pm_handle* h, unsigned long long* sweep_evals, unsigned long long* initial_evals);
 /* Device pointers of the result maps in API layout (valid after pm_synchronize;
  * for consumers that stay on the GPU, e.g. the geometric pass). */
 int pm_get_device_maps(pm_handle* h, const float** depth, const float** normal);

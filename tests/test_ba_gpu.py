@@ -248,7 +248,7 @@ def test_tracks_longer_than_a_tile():
     assert abs(got.final_cost - want.final_cost) <= 1e-5 * want.final_cost
 
 
-def _sharded_worker(rank, world, port, backend, q):
+def _sharded_worker(rank, world, port, backend, q, sharding=0):
     import os
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -257,7 +257,7 @@ def _sharded_worker(rank, world, port, backend, q):
     try:
         fp = _flat(12, 300, 5, seed=21, mixed=True)
         assert est.fix_gauge_two_cams(fp)
-        comm = est.Communicator(backend, gpu_index=0)
+        comm = est.Communicator(backend, gpu_index=0, sharding=sharding)
         s = est.solve_flat(fp, est.SolverOptions(**TIGHT), gpu_index=0, comm=comm)
         q.put((rank, s.final_cost, s.num_residuals, s.num_iterations, fp.poses.copy(), fp.points.copy(), comm.calls))
         comm.close()
@@ -266,9 +266,11 @@ def _sharded_worker(rank, world, port, backend, q):
         dist.destroy_process_group()
 
 
-def test_two_rank_sharded_solve_matches_single_gpu():
-    """Image sharding with the sum-over-ranks callback (gloo): two processes share GPU 0, each
-    linearises only its images' observations; the solution equals the single-rank solve."""
+@pytest.mark.parametrize("sharding", [est.SHARD_BY_IMAGE, est.SHARD_BY_POINT])
+def test_two_rank_sharded_solve_matches_single_gpu(sharding):
+    """Image sharding / point sharding with the sum-over-ranks callback (gloo): two processes share
+    GPU 0, each linearises only its own observations; the solution equals the single-rank solve.
+    Point sharding moves only camera-space vectors (fewer, smaller all-reduces)."""
     import socket
     import torch.multiprocessing as mp
     fp = _flat(12, 300, 5, seed=21, mixed=True)
@@ -278,7 +280,7 @@ def test_two_rank_sharded_solve_matches_single_gpu():
     sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, "callback", q)) for r in range(2)]
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, "callback", q, sharding)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])

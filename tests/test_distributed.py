@@ -89,6 +89,9 @@ def test_ba_image_sharding_partitions_the_observations():
         assert sum(parts) == total
         want = [int(np.sum(fp.obs_pose % world == r)) for r in range(world)]
         assert parts == want
+        by_point = [est.shard_num_observations(fp, r, world, est.SHARD_BY_POINT) for r in range(world)]
+        assert sum(by_point) == total
+        assert by_point == [int(np.sum(fp.obs_point % world == r)) for r in range(world)]
     # an observation whose pose, intrinsics and point are all constant is not part of the program
     fp.pose_const[:] = 1
     fp.cam_const[:] = 1
