@@ -174,16 +174,18 @@ __device__ __forceinline__ void atomic_max_pos(double* addr, double v) {
 // ------------------------------------------------------------------------------------------
 __device__ __host__ __forceinline__ int num_params_of(int model) {
   switch (model) {
-    case BA_SIMPLE_PINHOLE: return 3;
-    case BA_RADIAL: case BA_RADIAL_FISHEYE: return 5;
+    case BA_SIMPLE_PINHOLE: case BA_SIMPLE_FISHEYE: return 3;
+    case BA_RADIAL: case BA_RADIAL_FISHEYE: case BA_FOV: case BA_DIVISION: return 5;
+    case BA_EUCM: return 6;
     case BA_OPENCV: case BA_OPENCV_FISHEYE: return 8;
-    default: return 4;  // PINHOLE, SIMPLE_RADIAL, SIMPLE_RADIAL_FISHEYE
+    default: return 4;  // PINHOLE, SIMPLE_RADIAL, SIMPLE_RADIAL_FISHEYE, SIMPLE_DIVISION, FISHEYE
   }
 }
 __host__ inline bool model_supported(int model) {
   return model == BA_SIMPLE_PINHOLE || model == BA_PINHOLE || model == BA_SIMPLE_RADIAL || model == BA_RADIAL ||
          model == BA_OPENCV || model == BA_OPENCV_FISHEYE || model == BA_SIMPLE_RADIAL_FISHEYE ||
-         model == BA_RADIAL_FISHEYE;
+         model == BA_RADIAL_FISHEYE || model == BA_FOV || model == BA_SIMPLE_DIVISION || model == BA_DIVISION ||
+         model == BA_SIMPLE_FISHEYE || model == BA_FISHEYE || model == BA_EUCM;
 }
 
 // QuaternionRotatePointWithJac, quaternion_utils.h:105-153
@@ -219,9 +221,108 @@ __device__ __forceinline__ void quat_rotate(const double* q, const double* p, do
 template <bool JAC>
 __device__ __forceinline__ bool img_from_cam(int model, const double* prm, double u, double v, double w,
                                              double& x, double& y, double* Jpar, double* Juvw) {
+  if (model == BA_SIMPLE_DIVISION || model == BA_DIVISION) {
+    // Fitzgibbon's one-parameter division model, closed form (internal::DivisionScaleWithJac,
+    // models_jacobian.h:88-113; :1291-1411): no cheirality test, the discriminant decides
+    const bool two_f = model == BA_DIVISION;
+    const double f1 = prm[0], f2 = two_f ? prm[1] : prm[0];
+    const int ic = two_f ? 2 : 1;
+    const double k = prm[ic + 2];
+    const double rho2 = u * u + v * v;
+    const double disc_sq = w * w - 4.0 * rho2 * k;
+    if (disc_sq < 0.0) return false;
+    const double disc = sqrt(disc_sq);
+    const double r = 2.0 / (w + disc);
+    x = f1 * r * u + prm[ic];
+    y = f2 * r * v + prm[ic + 1];
+    if (JAC) {
+      const double inv_disc = 1.0 / disc, r_sq = r * r;
+      const double dr_du = 2.0 * r_sq * k * u * inv_disc, dr_dv = 2.0 * r_sq * k * v * inv_disc;
+      const double dr_dw = -0.5 * r_sq * (1.0 + w * inv_disc), dr_dk = r_sq * rho2 * inv_disc;
+      Juvw[0] = f1 * (r + u * dr_du); Juvw[1] = f1 * u * dr_dv; Juvw[2] = f1 * u * dr_dw;
+      Juvw[3] = f2 * v * dr_du; Juvw[4] = f2 * (r + v * dr_dv); Juvw[5] = f2 * v * dr_dw;
+#pragma unroll
+      for (int c = 0; c < NPAR; ++c) Jpar[c] = Jpar[NPAR + c] = 0.0;
+      Jpar[0] = r * u;
+      Jpar[NPAR + (two_f ? 1 : 0)] = r * v;
+      Jpar[ic] = 1.0;
+      Jpar[NPAR + ic + 1] = 1.0;
+      Jpar[ic + 2] = f1 * u * dr_dk;
+      Jpar[NPAR + ic + 2] = f2 * v * dr_dk;
+    }
+    return true;
+  }
   if (!(w >= 2.220446049250313e-16)) return false;
+  if (model == BA_EUCM) {  // models_jacobian.h:1413-1500
+    const double f1 = prm[0], f2 = prm[1], alpha = prm[4], beta = prm[5];
+    const double q = u * u + v * v;
+    const double rho2 = beta * q + w * w;
+    if (rho2 < 0.0) return false;
+    const double rho = sqrt(rho2);
+    const double den = alpha * rho + (1.0 - alpha) * w;
+    if (!(den >= 2.220446049250313e-16)) return false;
+    const double xn = u / den, yn = v / den;
+    x = f1 * xn + prm[2];
+    y = f2 * yn + prm[3];
+    if (JAC) {
+      const double inv_rho = 1.0 / rho, inv_den = 1.0 / den, inv_den2 = inv_den * inv_den;
+      const double dden_du = alpha * beta * u * inv_rho, dden_dv = alpha * beta * v * inv_rho;
+      const double dden_dw = alpha * w * inv_rho + (1.0 - alpha);
+      const double dden_dalpha = rho - w, dden_dbeta = alpha * q * 0.5 * inv_rho;
+      Juvw[0] = f1 * (inv_den - u * dden_du * inv_den2); Juvw[1] = f1 * (-u * dden_dv * inv_den2);
+      Juvw[2] = f1 * (-u * dden_dw * inv_den2);
+      Juvw[3] = f2 * (-v * dden_du * inv_den2); Juvw[4] = f2 * (inv_den - v * dden_dv * inv_den2);
+      Juvw[5] = f2 * (-v * dden_dw * inv_den2);
+      Jpar[0] = xn; Jpar[1] = 0.0; Jpar[2] = 1.0; Jpar[3] = 0.0;
+      Jpar[4] = f1 * (-u * dden_dalpha * inv_den2); Jpar[5] = f1 * (-u * dden_dbeta * inv_den2);
+      Jpar[NPAR + 0] = 0.0; Jpar[NPAR + 1] = yn; Jpar[NPAR + 2] = 0.0; Jpar[NPAR + 3] = 1.0;
+      Jpar[NPAR + 4] = f2 * (-v * dden_dalpha * inv_den2); Jpar[NPAR + 5] = f2 * (-v * dden_dbeta * inv_den2);
+    }
+    return true;
+  }
   const double inv_w = 1.0 / w;
   const double uu = u * inv_w, vv = v * inv_w;
+  if (model == BA_FOV) {  // models_jacobian.h:627-724 (the three branches of FOVCameraModel::Distortion)
+    const double f1 = prm[0], f2 = prm[1], omega = prm[4];
+    const double a = uu, b = vv;
+    const double radius2 = a * a + b * b, omega2 = omega * omega;
+    const double kEpsilon = 1e-4;
+    double factor, factor_r, factor_omega;
+    if (omega2 < kEpsilon) {
+      factor = (omega2 * radius2) / 3.0 - omega2 / 12.0 + 1.0;
+      factor_r = omega2 / 3.0;
+      factor_omega = 2.0 * omega * radius2 / 3.0 - omega / 6.0;
+    } else if (radius2 < kEpsilon) {
+      const double t = tan(omega / 2.0), t2 = t * t;
+      const double Q = t * (4.0 * t2 * radius2 - 3.0);
+      factor = -2.0 * Q / (3.0 * omega);
+      factor_r = -8.0 * t * t2 / (3.0 * omega);
+      const double dt_domega = 0.5 * (1.0 + t2);
+      const double Q_omega = dt_domega * (12.0 * t2 * radius2 - 3.0);
+      factor_omega = -2.0 / (3.0 * omega2) * (Q_omega * omega - Q);
+    } else {
+      const double radius = sqrt(radius2), t = tan(omega / 2.0);
+      const double arg = 2.0 * radius * t, atan_arg = atan(arg);
+      const double inv_denom_arg = 1.0 / (1.0 + arg * arg);
+      factor = atan_arg / (radius * omega);
+      factor_r = (2.0 * t * radius * inv_denom_arg - atan_arg) / (2.0 * radius2 * radius * omega);
+      factor_omega = (radius * omega * (1.0 + t * t) * inv_denom_arg - atan_arg) / (radius * omega2);
+    }
+    const double du = a * factor, dv = b * factor;
+    x = f1 * du + prm[2];
+    y = f2 * dv + prm[3];
+    if (JAC) {
+      const double cross = 2.0 * a * b * factor_r;
+      const double A0 = f1 * (factor + 2.0 * a * a * factor_r), A1 = f1 * cross, A2 = f2 * cross,
+                   A3 = f2 * (factor + 2.0 * b * b * factor_r);
+      Juvw[0] = A0 * inv_w; Juvw[1] = A1 * inv_w; Juvw[2] = -(A0 * a + A1 * b) * inv_w;
+      Juvw[3] = A2 * inv_w; Juvw[4] = A3 * inv_w; Juvw[5] = -(A2 * a + A3 * b) * inv_w;
+      Jpar[0] = du; Jpar[1] = 0.0; Jpar[2] = 1.0; Jpar[3] = 0.0; Jpar[4] = f1 * a * factor_omega;
+      Jpar[NPAR + 0] = 0.0; Jpar[NPAR + 1] = dv; Jpar[NPAR + 2] = 0.0; Jpar[NPAR + 3] = 1.0;
+      Jpar[NPAR + 4] = f2 * b * factor_omega;
+    }
+    return true;
+  }
   if (model == BA_SIMPLE_PINHOLE) {
     const double f = prm[0];
     x = f * uu + prm[1];
@@ -246,13 +347,16 @@ __device__ __forceinline__ bool img_from_cam(int model, const double* prm, doubl
     }
     return true;
   }
-  if (model == BA_OPENCV_FISHEYE || model == BA_SIMPLE_RADIAL_FISHEYE || model == BA_RADIAL_FISHEYE) {
+  if (model == BA_OPENCV_FISHEYE || model == BA_SIMPLE_RADIAL_FISHEYE || model == BA_RADIAL_FISHEYE ||
+      model == BA_SIMPLE_FISHEYE || model == BA_FISHEYE) {
     // equidistant projection (internal::FisheyeProjectionWithJac, models_jacobian.h:51-80) followed by a
-    // radial polynomial in the squared fisheye radius (:726-942)
-    const bool two_f = model == BA_OPENCV_FISHEYE;
+    // radial polynomial in the squared fisheye radius (:726-942); SIMPLE_FISHEYE / FISHEYE (:1190-1288)
+    // are the same projection without distortion coefficients (nk = 0: identical values, the
+    // polynomial terms vanish exactly)
+    const bool two_f = model == BA_OPENCV_FISHEYE || model == BA_FISHEYE;
     const double f1 = prm[0], f2 = two_f ? prm[1] : prm[0];
     const int ic = two_f ? 2 : 1;                                  // index of cx
-    const int nk = two_f ? 4 : (model == BA_RADIAL_FISHEYE ? 2 : 1);
+    const int nk = model == BA_OPENCV_FISHEYE ? 4 : (model == BA_RADIAL_FISHEYE ? 2 : (model == BA_SIMPLE_RADIAL_FISHEYE ? 1 : 0));
     const double* k = prm + ic + 2;
     const double a = uu, b = vv;                                   // normalised coordinates
     const double r2 = a * a + b * b;
@@ -1390,7 +1494,8 @@ struct Solver {
       if (!model_supported(model))
         throw std::runtime_error("unsupported camera model id " + std::to_string(model) +
                                  " (supported: SIMPLE_PINHOLE, PINHOLE, SIMPLE_RADIAL, RADIAL, OPENCV, "
-                                 "OPENCV_FISHEYE, SIMPLE_RADIAL_FISHEYE, RADIAL_FISHEYE)");
+                                 "OPENCV_FISHEYE, FOV, SIMPLE_RADIAL_FISHEYE, RADIAL_FISHEYE, SIMPLE_DIVISION, "
+                                 "DIVISION, SIMPLE_FISHEYE, FISHEYE, EUCM)");
       const int P = num_params_of(model);
       for (int j = 0; j < P; ++j)
         if (!p.cam_const[(size_t)k * BA_CAM_STRIDE + j]) wide_cam_var[(size_t)k * KD_MAX + cam_nvar[k]++] = j;

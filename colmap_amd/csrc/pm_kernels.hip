@@ -761,11 +761,12 @@ struct Lds {
   lds_i32* ntasks;
   lds_f32* tapg;    // wave kernel: [2][8][16] window offsets (dx, dy) of tap j + 16 k, times step
   lds_u32* ring;    // wave kernel: [2][8][64] landing zone of the footprint gathers
+  LDS_AS uint8_t* tin;  // wave kernel: [kWaveThCap] 1 = every tap of the task's patch is inside the image
 };
 
 struct LdsOffsets {
   uint32_t poses, fpb, tile, wgt, refc, fm, q, costv, betav, prevv, ncc, geo, hyp, colf, us, sv, best, csum,
-      flags, tasks, th, ntasks, tapg, ring, total;
+      flags, tasks, th, ntasks, tapg, ring, tin, total;
 };
 
 // Pose record kept in LDS: K4 R9 T3 C3 always; the projection matrices P12 invP12 only serve the
@@ -811,6 +812,7 @@ __host__ __device__ inline LdsOffsets lds_offsets(int C, int S, int radius, int 
   o.ntasks = take(16u);
   o.tapg = 0;
   o.ring = 0;
+  o.tin = 0;
   o.total = off;
   return o;
 }
@@ -849,6 +851,7 @@ __device__ __forceinline__ void lds_bind(Lds& L, lds_char* base, const LdsOffset
   L.ntasks = (lds_i32*)(base + o.ntasks);
   L.tapg = (lds_f32*)(base + o.tapg);
   L.ring = (lds_u32*)(base + o.ring);
+  L.tin = (LDS_AS uint8_t*)(base + o.tin);
 }
 
 __device__ __forceinline__ uint32_t task_pack(int c, int i, int s, int geom_only) {
@@ -1137,7 +1140,11 @@ __device__ __forceinline__ void gather_wait() {
 
 // STAGE 0 / 1: the gathers go to that stage of the LDS ring (software-pipelined loop); STAGE < 0:
 // plain loads into `tex` (the compiler tracks and waits for them).
-template <int STAGE>
+// FAST: every tap of the four evaluations of this round is known to fall inside the packed image
+// (patch_inside below), so the clamp of the tap coordinate to the zero ring and the ring offset
+// are dropped: the address is formed from floor(x), floor(y) >= 0 directly against the entry of
+// texel (0, 0). Same entry, same bits.
+template <int STAGE, bool FAST>
 __device__ __forceinline__ void ncc_front(const PmParams& p, const lds_f32* H, gbl_u32* fp,
                                           const lds_f32* tg, int j, NccStage& st, uint32_t* tex = nullptr) {
   const float h0 = H[0], h1 = H[1], h2 = H[2], h3 = H[3], h4 = H[4], h5 = H[5], h6 = H[6],
@@ -1183,14 +1190,23 @@ __device__ __forceinline__ void ncc_front(const PmParams& p, const lds_f32* H, g
     fy[1] = floorf(py[1]);
     st.wx[q] = px - fx;
     st.wy[q] = py - fy;
-    const v2f fx2 = fx + pk_bcast(2.0f);
-    const v2f fy2 = fy + pk_bcast(2.0f);
-    if (STAGE >= 0) {
-      gather_issue_k<(STAGE >= 0 ? STAGE : 0)>(2 * q, tap_address(p, fp, fx2[0], fy2[0]));
-      gather_issue_k<(STAGE >= 0 ? STAGE : 0)>(2 * q + 1, tap_address(p, fp, fx2[1], fy2[1]));
+    gbl_u32 *a0, *a1;
+    if (FAST) {
+      // fp already points at the entry of texel (0, 0) (the caller added 2 * pitch + 2)
+      a0 = fp + (unsigned)(int)fmaf(fy[0], p.fp_pitch, fx[0]);
+      a1 = fp + (unsigned)(int)fmaf(fy[1], p.fp_pitch, fx[1]);
     } else {
-      tex[2 * q] = *tap_address(p, fp, fx2[0], fy2[0]);
-      tex[2 * q + 1] = *tap_address(p, fp, fx2[1], fy2[1]);
+      const v2f fx2 = fx + pk_bcast(2.0f);
+      const v2f fy2 = fy + pk_bcast(2.0f);
+      a0 = tap_address(p, fp, fx2[0], fy2[0]);
+      a1 = tap_address(p, fp, fx2[1], fy2[1]);
+    }
+    if (STAGE >= 0) {
+      gather_issue_k<(STAGE >= 0 ? STAGE : 0)>(2 * q, a0);
+      gather_issue_k<(STAGE >= 0 ? STAGE : 0)>(2 * q + 1, a1);
+    } else {
+      tex[2 * q] = *a0;
+      tex[2 * q + 1] = *a1;
     }
   }
 }
@@ -1630,8 +1646,30 @@ __host__ __device__ inline LdsOffsets lds_offsets_wave(int C, int S, int radius,
   o.th = take(36u * kWaveThCap);
   o.ntasks = take(16u);
   o.tapg = take(4u * 256);
+  o.tin = take((uint32_t)kWaveThCap);
   o.total = off;
   return o;
+}
+
+// Does every tap of the patch with (centred) homography Hm provably fall on texels x in [0, w - 1],
+// y in [0, h - 1] of the source image? The window maps to a convex quadrilateral when the projective
+// divisor is positive at its four corners, so the taps lie inside the corners' bounding box; one
+// texel of margin absorbs the rounding of the per-tap evaluation. NaNs compare false.
+__device__ __forceinline__ bool patch_inside(const PmParams& p, const float Hm[9]) {
+  const float e = (float)(2 * p.radius);  // window extent: taps at offsets 0 .. 2 r
+  float xmin = 3.0e38f, xmax = -3.0e38f, ymin = 3.0e38f, ymax = -3.0e38f;
+  bool ok = true;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float dx = (k & 1) ? e : 0.0f, dy = (k & 2) ? e : 0.0f;
+    const float z = Hm[6] * dx + Hm[7] * dy + Hm[8];
+    const float x = (Hm[0] * dx + Hm[1] * dy + Hm[2]) / z;
+    const float y = (Hm[3] * dx + Hm[4] * dy + Hm[5]) / z;
+    ok = ok && (z > 0.0f);
+    xmin = fminf(xmin, x); xmax = fmaxf(xmax, x);
+    ymin = fminf(ymin, y); ymax = fmaxf(ymax, y);
+  }
+  return ok && xmin >= 1.0f && ymin >= 1.0f && xmax <= (float)(p.src_w - 2) && ymax <= (float)(p.src_h - 2);
 }
 
 // Run the queued NCC tasks (and, with GEOM, the geometric-cost-only list) of one phase.
@@ -1670,6 +1708,7 @@ __device__ __forceinline__ void run_tasks_wave(const PmParams& p, const Lds& L, 
       compose_homography(p.refInvK, pose, row, col, h[0], h[1], h[2], h[3], Hm);
       centre_homography(Hm, row, col, p.radius);
       for (int k = 0; k < 9; ++k) L.th[tid * 9 + k] = Hm[k];
+      L.tin[tid] = patch_inside(p, Hm) ? 1 : 0;
       if (GEOM) L.geo[(c * 5 + i) * S + s] = geom_cost(p, pose, s, (float)row, (float)col, h[0]);
     }
     __syncthreads();
@@ -1687,20 +1726,25 @@ __device__ __forceinline__ void run_tasks_wave(const PmParams& p, const Lds& L, 
       NccStage A, B;
       int ta, tb, ca, cb;
       bool wa, wb;
-      auto prep = [&](int r, int& t, int& c, bool& own) -> uint32_t {
+      const int fp_origin = 2 * (p.src_w + 3) + 2;  // entry of texel (0, 0) in a packed image
+      auto prep = [&](int r, int& t, int& c, bool& own, bool& fast) -> uint32_t {
         const int tr = g + 4 * r;
         own = tr < nb;
         t = own ? tr : nb - 1;
         const uint32_t task = tasks[base + t];
         c = task >> 13;
+        // wave-uniform: the unclamped addressing only when all four patches of the round are inside
+        // (a recomputed task may already hold its sums instead of its homography: it must take the
+        // clamping path, where any coordinate is safe and the result is dropped)
+        fast = __all(own && L.tin[t] != 0) != 0;
         return task & 0x1ff;
       };
-      // (a recomputed task may already hold its sums instead of its homography: the gathers clamp
-      // any coordinate, the result is dropped)
 #define PM_FRONT(STAGE, r, st, t, c, own)                                                  \
   do {                                                                                     \
-    const uint32_t sv_ = prep(r, t, c, own);                                               \
-    ncc_front<STAGE>(p, L.th + (t) * 9, (gbl_u32*)L.fpb[sv_], G, j, st);                   \
+    bool fast_;                                                                            \
+    const uint32_t sv_ = prep(r, t, c, own, fast_);                                        \
+    if (fast_) ncc_front<STAGE, true>(p, L.th + (t) * 9, (gbl_u32*)L.fpb[sv_] + fp_origin, G, j, st); \
+    else ncc_front<STAGE, false>(p, L.th + (t) * 9, (gbl_u32*)L.fpb[sv_], G, j, st);       \
   } while (0)
 #define PM_BACK(STAGE, NEWER, st, t, c, own)                                               \
   do {                                                                                     \
@@ -1721,9 +1765,11 @@ __device__ __forceinline__ void run_tasks_wave(const PmParams& p, const Lds& L, 
         // plain variant: one round at a time, all eight gathers of a lane in flight before the first
         // texel is consumed (fewer registers and no LDS ring: more waves per SIMD instead)
         for (int r = 0; r < rounds; ++r) {
-          const uint32_t sv_ = prep(r, ta, ca, wa);
+          bool fast_;
+          const uint32_t sv_ = prep(r, ta, ca, wa, fast_);
           uint32_t tex_[8];
-          ncc_front<-1>(p, L.th + ta * 9, (gbl_u32*)L.fpb[sv_], G, j, A, tex_);
+          if (fast_) ncc_front<-1, true>(p, L.th + ta * 9, (gbl_u32*)L.fpb[sv_] + fp_origin, G, j, A, tex_);
+          else ncc_front<-1, false>(p, L.th + ta * 9, (gbl_u32*)L.fpb[sv_], G, j, A, tex_);
           __builtin_amdgcn_sched_barrier(0);
           TapRegs R_;
           tap_regs_load(R_, L.wgt + ca * 128, L.refc + ca * 128, j);
@@ -2133,9 +2179,10 @@ size_t pm_sweep_lds_bytes(const PmParams& p, bool geom) {
 
 int pm_pick_columns(int S, int ntaps, int num_samples, bool geom, int radius, int requested) {
   const size_t budget = 60 * 1024;
-  // default: 3 columns per single-wave workgroup of the 11 x 11 kernel (C * S = 60 <= 64 lanes: the
-  // lane-per-(column, view) phases are one pass; measured best), 4 for the two-wave kernels
-  int c = requested > 0 ? requested : (ntaps == 121 ? 3 : 4);
+  // default: 2 columns per single-wave workgroup of the 11 x 11 kernel (16 workgroups = 4 waves per
+  // SIMD resident per CU, the lane-per-(column, view) phases are one pass; measured 604 / 643 / 718 ms
+  // per 16-image launch for C = 2 / 3 / 4), 4 for the two-wave kernels
+  int c = requested > 0 ? requested : (ntaps == 121 ? 2 : 4);
   if (c > 64) c = 64;
   while (c > 1 && lds_offsets(c, S, radius, ntaps, num_samples, geom).total > budget) --c;
   return c;
@@ -2193,7 +2240,10 @@ void pm_launch_sweep(const PmParams& p, const PmParams* dev_params, int batch, i
   // (COLMAP_AMD_PM_WAVE=0).
   static const bool wave_enabled = [] { const char* e = getenv("COLMAP_AMD_PM_WAVE"); return !e || atoi(e) != 0; }();
   if (wave_enabled && !p.prof && p.ntap1d == 11 && p.step >= 1 && pm_fixed_window_ok(p) && p.S <= 512 && p.C <= 8) {
-    static const bool pipe = [] { const char* e = getenv("COLMAP_AMD_PM_PIPE"); return !e || atoi(e) != 0; }();
+    // plain build (4 waves per SIMD) by default: measured 604 ms per 16-image launch against 649 ms for
+    // the LDS-DMA pipelined build (3 waves per SIMD, 10 workgroups per CU); COLMAP_AMD_PM_PIPE=1 selects
+    // the latter
+    static const bool pipe = [] { const char* e = getenv("COLMAP_AMD_PM_PIPE"); return e && atoi(e) != 0; }();
     const size_t wlds = lds_offsets_wave(p.C, p.S, p.radius, p.ntaps, p.num_samples, geom, pipe).total + lds_pad;
     dim3 wblock(64, 1, 1);
     dim3 wgrid = grid;

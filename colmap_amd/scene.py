@@ -23,16 +23,21 @@ import numpy as np
 
 # colmap::CameraModelId (sensor/models.h:90-111)
 SIMPLE_PINHOLE, PINHOLE, SIMPLE_RADIAL, RADIAL, OPENCV = 0, 1, 2, 3, 4
-OPENCV_FISHEYE, SIMPLE_RADIAL_FISHEYE, RADIAL_FISHEYE = 5, 8, 9
+OPENCV_FISHEYE, FOV, SIMPLE_RADIAL_FISHEYE, RADIAL_FISHEYE = 5, 7, 8, 9
+SIMPLE_DIVISION, DIVISION, SIMPLE_FISHEYE, FISHEYE, EUCM = 12, 13, 14, 15, 16
+MODEL_NAMES = {SIMPLE_PINHOLE: "SIMPLE_PINHOLE", PINHOLE: "PINHOLE", SIMPLE_RADIAL: "SIMPLE_RADIAL", RADIAL: "RADIAL",
+               OPENCV: "OPENCV", OPENCV_FISHEYE: "OPENCV_FISHEYE", FOV: "FOV",
+               SIMPLE_RADIAL_FISHEYE: "SIMPLE_RADIAL_FISHEYE", RADIAL_FISHEYE: "RADIAL_FISHEYE",
+               SIMPLE_DIVISION: "SIMPLE_DIVISION", DIVISION: "DIVISION", SIMPLE_FISHEYE: "SIMPLE_FISHEYE",
+               FISHEYE: "FISHEYE", EUCM: "EUCM"}
 MODEL_NUM_PARAMS = {SIMPLE_PINHOLE: 3, PINHOLE: 4, SIMPLE_RADIAL: 4, RADIAL: 5, OPENCV: 8,
-                    OPENCV_FISHEYE: 8, SIMPLE_RADIAL_FISHEYE: 4, RADIAL_FISHEYE: 5}
+                    OPENCV_FISHEYE: 8, FOV: 5, SIMPLE_RADIAL_FISHEYE: 4, RADIAL_FISHEYE: 5,
+                    SIMPLE_DIVISION: 4, DIVISION: 5, SIMPLE_FISHEYE: 3, FISHEYE: 4, EUCM: 6}
 # FocalLengthIdxs / PrincipalPointIdxs / ExtraParamsIdxs (sensor/models.h)
-MODEL_FOCAL_IDXS = {SIMPLE_PINHOLE: [0], PINHOLE: [0, 1], SIMPLE_RADIAL: [0], RADIAL: [0], OPENCV: [0, 1],
-                    OPENCV_FISHEYE: [0, 1], SIMPLE_RADIAL_FISHEYE: [0], RADIAL_FISHEYE: [0]}
-MODEL_PP_IDXS = {SIMPLE_PINHOLE: [1, 2], PINHOLE: [2, 3], SIMPLE_RADIAL: [1, 2], RADIAL: [1, 2], OPENCV: [2, 3],
-                 OPENCV_FISHEYE: [2, 3], SIMPLE_RADIAL_FISHEYE: [1, 2], RADIAL_FISHEYE: [1, 2]}
-MODEL_EXTRA_IDXS = {SIMPLE_PINHOLE: [], PINHOLE: [], SIMPLE_RADIAL: [3], RADIAL: [3, 4], OPENCV: [4, 5, 6, 7],
-                    OPENCV_FISHEYE: [4, 5, 6, 7], SIMPLE_RADIAL_FISHEYE: [3], RADIAL_FISHEYE: [3, 4]}
+_ONE_F = (SIMPLE_PINHOLE, SIMPLE_RADIAL, RADIAL, SIMPLE_RADIAL_FISHEYE, RADIAL_FISHEYE, SIMPLE_DIVISION, SIMPLE_FISHEYE)
+MODEL_FOCAL_IDXS = {m: ([0] if m in _ONE_F else [0, 1]) for m in MODEL_NUM_PARAMS}
+MODEL_PP_IDXS = {m: ([1, 2] if m in _ONE_F else [2, 3]) for m in MODEL_NUM_PARAMS}
+MODEL_EXTRA_IDXS = {m: list(range(3 if m in _ONE_F else 4, n)) for m, n in MODEL_NUM_PARAMS.items()}
 
 
 @dataclass
@@ -194,8 +199,35 @@ def quat_mul(a: np.ndarray, b: np.ndarray) -> np.ndarray:
 
 def img_from_cam(model_id: int, params: np.ndarray, uvw: np.ndarray) -> np.ndarray:
     """CameraModel::ImgFromCam for the supported models (sensor/models.h:1231-1404); uvw (N,3)."""
+    if model_id in (SIMPLE_DIVISION, DIVISION):  # closed-form division model (models.h DivisionCameraModel)
+        f1 = params[0]
+        f2 = params[1] if model_id == DIVISION else params[0]
+        ic = 2 if model_id == DIVISION else 1
+        u, v, w = uvw[:, 0], uvw[:, 1], uvw[:, 2]
+        r = 2.0 / (w + np.sqrt(w * w - 4.0 * (u * u + v * v) * params[ic + 2]))
+        return np.stack([f1 * r * u + params[ic], f2 * r * v + params[ic + 1]], 1)
+    if model_id == EUCM:
+        f1, f2, c1, c2, alpha, beta = params
+        u, v, w = uvw[:, 0], uvw[:, 1], uvw[:, 2]
+        den = alpha * np.sqrt(beta * (u * u + v * v) + w * w) + (1.0 - alpha) * w
+        return np.stack([f1 * u / den + c1, f2 * v / den + c2], 1)
     uu = uvw[:, 0] / uvw[:, 2]
     vv = uvw[:, 1] / uvw[:, 2]
+    if model_id == FOV:  # FOVCameraModel::Distortion, general branch (omega, radius away from 0)
+        f1, f2, c1, c2, omega = params
+        radius = np.sqrt(uu * uu + vv * vv)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            factor = np.where(radius * radius < 1e-4,
+                              -2.0 * (np.tan(omega / 2) * (4 * np.tan(omega / 2) ** 2 * radius ** 2 - 3)) / (3 * omega),
+                              np.arctan(2.0 * radius * np.tan(omega / 2.0)) / (radius * omega))
+        return np.stack([f1 * uu * factor + c1, f2 * vv * factor + c2], 1)
+    if model_id in (SIMPLE_FISHEYE, FISHEYE):
+        r = np.sqrt(uu * uu + vv * vv)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            sc = np.where(r < np.finfo(np.float64).eps, 1.0, np.arctan(r) / r)
+        if model_id == FISHEYE:
+            return np.stack([params[0] * sc * uu + params[2], params[1] * sc * vv + params[3]], 1)
+        return np.stack([params[0] * sc * uu + params[1], params[0] * sc * vv + params[2]], 1)
     if model_id == SIMPLE_PINHOLE:
         f, c1, c2 = params
         return np.stack([f * uu + c1, f * vv + c2], 1)

@@ -43,7 +43,8 @@
 /* COLMAP CameraModelId values (sensor/models.h:90-111) */
 enum {
   BAO_SIMPLE_PINHOLE = 0, BAO_PINHOLE = 1, BAO_SIMPLE_RADIAL = 2, BAO_RADIAL = 3, BAO_OPENCV = 4,
-  BAO_OPENCV_FISHEYE = 5, BAO_SIMPLE_RADIAL_FISHEYE = 8, BAO_RADIAL_FISHEYE = 9
+  BAO_OPENCV_FISHEYE = 5, BAO_FOV = 7, BAO_SIMPLE_RADIAL_FISHEYE = 8, BAO_RADIAL_FISHEYE = 9,
+  BAO_SIMPLE_DIVISION = 12, BAO_DIVISION = 13, BAO_SIMPLE_FISHEYE = 14, BAO_FISHEYE = 15, BAO_EUCM = 16
 };
 
 typedef struct {
@@ -164,6 +165,12 @@ static int num_params_of(int model) {
     case BAO_OPENCV_FISHEYE: return 8;
     case BAO_SIMPLE_RADIAL_FISHEYE: return 4;
     case BAO_RADIAL_FISHEYE: return 5;
+    case BAO_FOV: return 5;
+    case BAO_SIMPLE_DIVISION: return 4;
+    case BAO_DIVISION: return 5;
+    case BAO_SIMPLE_FISHEYE: return 3;
+    case BAO_FISHEYE: return 4;
+    case BAO_EUCM: return 6;
     default: return -1;
   }
 }
@@ -237,10 +244,126 @@ static void radial_fisheye_with_jac(double f1, double f2, double c1, double c2, 
 /* ImgFromCamWithJac, sensor/models_jacobian.h:139-321. J_params row-major 2 x P. */
 static int img_from_cam_jac(int model, const double* params, double u, double v, double w,
                             double* x, double* y, double* J_params, double* J_uvw) {
+  if (model == BAO_SIMPLE_DIVISION || model == BAO_DIVISION) {
+    /* models_jacobian.h:1291-1411 + internal::DivisionScaleWithJac :88-113 (no cheirality test) */
+    const int two = model == BAO_DIVISION;
+    const double f1 = params[0], f2 = two ? params[1] : params[0];
+    const int ic = two ? 2 : 1;
+    const double c1 = params[ic], c2 = params[ic + 1], k = params[ic + 2];
+    const double rho2 = u * u + v * v;
+    const double disc_sq = w * w - 4.0 * rho2 * k;
+    if (disc_sq < 0.0) return 0;
+    const double disc = sqrt(disc_sq);
+    const double r = 2.0 / (w + disc);
+    const double inv_disc = 1.0 / disc, r_sq = r * r;
+    const double dr_du = 2.0 * r_sq * k * u * inv_disc, dr_dv = 2.0 * r_sq * k * v * inv_disc;
+    const double dr_dw = -0.5 * r_sq * (1.0 + w * inv_disc), dr_dk = r_sq * rho2 * inv_disc;
+    *x = f1 * r * u + c1;
+    *y = f2 * r * v + c2;
+    if (J_uvw) {
+      J_uvw[0] = f1 * (r + u * dr_du); J_uvw[1] = f1 * u * dr_dv; J_uvw[2] = f1 * u * dr_dw;
+      J_uvw[3] = f2 * v * dr_du; J_uvw[4] = f2 * (r + v * dr_dv); J_uvw[5] = f2 * v * dr_dw;
+    }
+    if (J_params) {
+      const int P = two ? 5 : 4;
+      for (int i = 0; i < 2 * P; ++i) J_params[i] = 0.0;
+      J_params[0] = r * u;
+      J_params[P + (two ? 1 : 0)] = r * v;
+      J_params[ic] = 1.0;
+      J_params[P + ic + 1] = 1.0;
+      J_params[ic + 2] = f1 * u * dr_dk;
+      J_params[P + ic + 2] = f2 * v * dr_dk;
+    }
+    return 1;
+  }
   /* HasProjectableDepth (models.h:281-285), check_cheirality = true */
   if (!(w >= 2.220446049250313e-16)) return 0;
+  if (model == BAO_EUCM) { /* models_jacobian.h:1413-1500 */
+    const double f1 = params[0], f2 = params[1], c1 = params[2], c2 = params[3];
+    const double alpha = params[4], beta = params[5];
+    const double q = u * u + v * v;
+    const double rho2 = beta * q + w * w;
+    if (rho2 < 0.0) return 0;
+    const double rho = sqrt(rho2);
+    const double den = alpha * rho + (1.0 - alpha) * w;
+    if (!(den >= 2.220446049250313e-16)) return 0;
+    const double xn = u / den, yn = v / den;
+    *x = f1 * xn + c1;
+    *y = f2 * yn + c2;
+    const double inv_rho = 1.0 / rho, inv_den = 1.0 / den, inv_den2 = inv_den * inv_den;
+    const double dden_du = alpha * beta * u * inv_rho, dden_dv = alpha * beta * v * inv_rho;
+    const double dden_dw = alpha * w * inv_rho + (1.0 - alpha);
+    const double dden_dalpha = rho - w, dden_dbeta = alpha * q * 0.5 * inv_rho;
+    if (J_uvw) {
+      J_uvw[0] = f1 * (inv_den - u * dden_du * inv_den2);
+      J_uvw[1] = f1 * (-u * dden_dv * inv_den2);
+      J_uvw[2] = f1 * (-u * dden_dw * inv_den2);
+      J_uvw[3] = f2 * (-v * dden_du * inv_den2);
+      J_uvw[4] = f2 * (inv_den - v * dden_dv * inv_den2);
+      J_uvw[5] = f2 * (-v * dden_dw * inv_den2);
+    }
+    if (J_params) {
+      J_params[0] = xn; J_params[1] = 0.0; J_params[2] = 1.0; J_params[3] = 0.0;
+      J_params[4] = f1 * (-u * dden_dalpha * inv_den2); J_params[5] = f1 * (-u * dden_dbeta * inv_den2);
+      J_params[6] = 0.0; J_params[7] = yn; J_params[8] = 0.0; J_params[9] = 1.0;
+      J_params[10] = f2 * (-v * dden_dalpha * inv_den2); J_params[11] = f2 * (-v * dden_dbeta * inv_den2);
+    }
+    return 1;
+  }
   const double inv_w = 1.0 / w;
   const double uu = u * inv_w, vv = v * inv_w;
+  if (model == BAO_FOV) { /* models_jacobian.h:627-724 */
+    const double f1 = params[0], f2 = params[1], c1 = params[2], c2 = params[3], omega = params[4];
+    const double a = uu, b = vv;
+    const double radius2 = a * a + b * b, omega2 = omega * omega;
+    const double kEpsilon = 1e-4;
+    double factor, factor_r, factor_omega;
+    if (omega2 < kEpsilon) {
+      factor = (omega2 * radius2) / 3.0 - omega2 / 12.0 + 1.0;
+      factor_r = omega2 / 3.0;
+      factor_omega = 2.0 * omega * radius2 / 3.0 - omega / 6.0;
+    } else if (radius2 < kEpsilon) {
+      const double t = tan(omega / 2.0), t2 = t * t;
+      const double Q = t * (4.0 * t2 * radius2 - 3.0);
+      factor = -2.0 * Q / (3.0 * omega);
+      factor_r = -8.0 * t * t2 / (3.0 * omega);
+      const double dt_domega = 0.5 * (1.0 + t2);
+      const double Q_omega = dt_domega * (12.0 * t2 * radius2 - 3.0);
+      factor_omega = -2.0 / (3.0 * omega2) * (Q_omega * omega - Q);
+    } else {
+      const double radius = sqrt(radius2), t = tan(omega / 2.0);
+      const double arg = 2.0 * radius * t, atan_arg = atan(arg);
+      const double inv_denom_arg = 1.0 / (1.0 + arg * arg);
+      factor = atan_arg / (radius * omega);
+      factor_r = (2.0 * t * radius * inv_denom_arg - atan_arg) / (2.0 * radius2 * radius * omega);
+      factor_omega = (radius * omega * (1.0 + t * t) * inv_denom_arg - atan_arg) / (radius * omega2);
+    }
+    const double du = a * factor, dv = b * factor;
+    *x = f1 * du + c1;
+    *y = f2 * dv + c2;
+    if (J_uvw) {
+      const double cross = 2.0 * a * b * factor_r;
+      const double Jab[4] = {f1 * (factor + 2.0 * a * a * factor_r), f1 * cross, f2 * cross,
+                             f2 * (factor + 2.0 * b * b * factor_r)};
+      J_uvw[0] = Jab[0] * inv_w; J_uvw[1] = Jab[1] * inv_w; J_uvw[2] = -(Jab[0] * a + Jab[1] * b) * inv_w;
+      J_uvw[3] = Jab[2] * inv_w; J_uvw[4] = Jab[3] * inv_w; J_uvw[5] = -(Jab[2] * a + Jab[3] * b) * inv_w;
+    }
+    if (J_params) {
+      J_params[0] = du; J_params[1] = 0.0; J_params[2] = 1.0; J_params[3] = 0.0; J_params[4] = f1 * a * factor_omega;
+      J_params[5] = 0.0; J_params[6] = dv; J_params[7] = 0.0; J_params[8] = 1.0; J_params[9] = f2 * b * factor_omega;
+    }
+    return 1;
+  }
+  if (model == BAO_SIMPLE_FISHEYE) { /* :1190-1236: equidistant projection, no distortion */
+    radial_fisheye_with_jac(params[0], params[0], params[1], params[2], params + 3, 0, 0, u, v, w, x, y,
+                            J_params, J_uvw);
+    return 1;
+  }
+  if (model == BAO_FISHEYE) { /* :1238-1288 */
+    radial_fisheye_with_jac(params[0], params[1], params[2], params[3], params + 4, 0, 1, u, v, w, x, y,
+                            J_params, J_uvw);
+    return 1;
+  }
   if (model == BAO_SIMPLE_PINHOLE) {
     const double f = params[0], c1 = params[1], c2 = params[2];
     *x = f * uu + c1;
