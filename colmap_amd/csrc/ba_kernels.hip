@@ -120,7 +120,8 @@ struct View {
   double loss_scale;
   const int *c2a, *a2c;              // c-order position <-> p-order position (sorted by point)
   const unsigned char* solo;         // c-order: bit k set = no other observation of this point shares block kind k
-  const int *pose_off, *pose_dim, *pose_fix;
+  const int *pose_off, *pose_dim, *pose_fix;  // pose_fix: held translation coordinate or -1, + 4 when
+                                              // the rotation is held (ba_problem::pose_fixed_t)
   const int *cam_off, *cam_dim, *cam_var, *cam_model;
   const int *pt_off, *pt_ptr;
   const int* tile_pt;  // point tiles: points [tile_pt[t], tile_pt[t+1]) have <= TILE_OBS observations
@@ -588,17 +589,22 @@ __global__ void __launch_bounds__(256) ba_linearize_kernel(View V, const double*
       if (ok && pdim > 0) {
         const double x = q[0], y = q[1], z = q[2], w = q[3];
         const double PJ[12] = {w, z, -y, -z, w, x, y, -x, w, -x, -y, -z};
-        const int fix = V.pose_fix[pi];
+        const int pf = V.pose_fix[pi];
+        const bool rotc = pf >= 4;  // constant_rig_from_world_rotation: translation columns only
+        const int fix = pf < 0 ? -1 : ((pf & 3) == 3 ? -1 : (pf & 3));
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-          double Jq[4];
+          int d = 0;
+          if (!rotc) {
+            double Jq[4];
 #pragma unroll
-          for (int c = 0; c < 4; ++c)
-            Jq[c] = Juvw[3 * r] * JR[c] + Juvw[3 * r + 1] * JR[4 + c] + Juvw[3 * r + 2] * JR[8 + c];
+            for (int c = 0; c < 4; ++c)
+              Jq[c] = Juvw[3 * r] * JR[c] + Juvw[3 * r + 1] * JR[4 + c] + Juvw[3 * r + 2] * JR[8 + c];
 #pragma unroll
-          for (int c = 0; c < 3; ++c)
-            Jp[r][c] = Jq[0] * PJ[c] + Jq[1] * PJ[3 + c] + Jq[2] * PJ[6 + c] + Jq[3] * PJ[9 + c];
-          int d = 3;
+            for (int c = 0; c < 3; ++c)
+              Jp[r][c] = Jq[0] * PJ[c] + Jq[1] * PJ[3 + c] + Jq[2] * PJ[6 + c] + Jq[3] * PJ[9 + c];
+            d = 3;
+          }
 #pragma unroll
           for (int c = 0; c < 3; ++c) {
             if (c == fix) continue;
@@ -1335,7 +1341,9 @@ __global__ void ba_apply_pose_kernel(View V, const double* __restrict__ step, co
   const int off = V.pose_off[i];
   if (off < 0) return;
   const double* d = step + off;
-  const double n = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+  const int pf = V.pose_fix[i];
+  const bool rotc = pf >= 4;
+  const double n = rotc ? 0.0 : sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
   if (n != 0.0) {
     const double s = sin(n) / n;
     const double dx = s * d[0], dy = s * d[1], dz = s * d[2], dw = cos(n);
@@ -1345,8 +1353,8 @@ __global__ void ba_apply_pose_kernel(View V, const double* __restrict__ step, co
     o[2] = dw * z + dx * y - dy * x + dz * w;
     o[3] = dw * w - dx * x - dy * y - dz * z;
   }
-  int k = 3;
-  const int fix = V.pose_fix[i];
+  int k = rotc ? 0 : 3;
+  const int fix = pf < 0 ? -1 : ((pf & 3) == 3 ? -1 : (pf & 3));
   for (int c = 0; c < 3; ++c) {
     if (c == fix) continue;
     o[4 + c] += d[k++];
@@ -1594,8 +1602,10 @@ struct Solver {
     int off = 0, moff = 0;
     for (int i = 0; i < p.num_poses; ++i) {
       if (p.pose_const[i] || !pose_used[i]) continue;
-      h_pose_fix[i] = p.pose_fixed_t[i];
-      h_pose_dim[i] = p.pose_fixed_t[i] >= 0 ? 5 : 6;
+      const int pf = p.pose_fixed_t[i];
+      if (pf < -1 || pf > 7) throw std::runtime_error("pose_fixed_t out of range");
+      h_pose_fix[i] = pf;
+      h_pose_dim[i] = (pf >= 4 ? 0 : 3) + ((pf >= 0 && (pf & 3) != 3) ? 2 : 3);
       h_pose_off[i] = off;
       blk_of_pose[i] = (int)h_blk_off.size();
       h_blk_off.push_back(off); h_blk_dim.push_back(h_pose_dim[i]); h_blk_kind.push_back(0);

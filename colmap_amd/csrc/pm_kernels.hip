@@ -1192,9 +1192,12 @@ __device__ __forceinline__ void ncc_front(const PmParams& p, const lds_f32* H, g
     st.wy[q] = py - fy;
     gbl_u32 *a0, *a1;
     if (FAST) {
-      // fp already points at the entry of texel (0, 0) (the caller added 2 * pitch + 2)
-      a0 = fp + (unsigned)(int)fmaf(fy[0], p.fp_pitch, fx[0]);
-      a1 = fp + (unsigned)(int)fmaf(fy[1], p.fp_pitch, fx[1]);
+      // fp already points at the entry of texel (0, 0) (the caller added 2 * pitch + 2). Lanes whose
+      // tap lies beyond the window (t >= 121: weight 0, divisor forced to 1, so the coordinate is
+      // the un-normalised numerator) have no inside guarantee: they read entry (0, 0) instead.
+      const bool v0 = j + 16 * (2 * q) < 121, v1 = j + 16 * (2 * q + 1) < 121;
+      a0 = fp + (v0 ? (unsigned)(int)fmaf(fy[0], p.fp_pitch, fx[0]) : 0u);
+      a1 = fp + (v1 ? (unsigned)(int)fmaf(fy[1], p.fp_pitch, fx[1]) : 0u);
     } else {
       const v2f fx2 = fx + pk_bcast(2.0f);
       const v2f fy2 = fy + pk_bcast(2.0f);

@@ -498,7 +498,12 @@ def flatten(options: BundleAdjustmentOptions, config: BundleAdjustmentConfig,
     elif config.FixedGauge() == BundleAdjustmentGauge.THREE_POINTS:
         fix_gauge_three_points(fp)
     if options.constant_rig_from_world_rotation:
-        raise NotImplementedError("constant_rig_from_world_rotation is not supported by the MI355X backend yet")
+        # SubsetManifold(7, {0, 1, 2, 3[, 4 + fixed_dim]}) on every variable rig_from_world
+        # (bundle_adjustment_ceres.cc:404-408, 513-516): the rotation is held, only the translation
+        # (minus the gauge coordinate of the second gauge frame) is refined
+        var = fp.pose_const == 0
+        k = fp.pose_fixed_t[var]
+        fp.pose_fixed_t[var] = POSE_ROT_CONST + np.where(k >= 0, k, 3).astype(np.int8)
     return fp
 
 
@@ -553,6 +558,7 @@ class ba_comm(C.Structure):
 
 
 SHARD_BY_IMAGE, SHARD_BY_POINT = 0, 1
+POSE_ROT_CONST = 4  # ba_problem.pose_fixed_t: + 4 = the rotation of the pose block is held (colmap_amd_ba.h)
 
 
 class Communicator:

@@ -33,6 +33,12 @@ CAMERA_MODELS = {
     8: ("SIMPLE_RADIAL_FISHEYE", 4, 0, 0, 1, 2),
     9: ("RADIAL_FISHEYE", 5, 0, 0, 1, 2),
     10: ("THIN_PRISM_FISHEYE", 12, 0, 1, 2, 3),
+    11: ("RAD_TAN_THIN_PRISM_FISHEYE", 16, 0, 1, 2, 3),
+    12: ("SIMPLE_DIVISION", 4, 0, 0, 1, 2),
+    13: ("DIVISION", 5, 0, 1, 2, 3),
+    14: ("SIMPLE_FISHEYE", 3, 0, 0, 1, 2),
+    15: ("FISHEYE", 4, 0, 1, 2, 3),
+    16: ("EUCM", 6, 0, 1, 2, 3),
 }
 CAMERA_MODEL_IDS = {v[0]: k for k, v in CAMERA_MODELS.items()}
 INVALID_POINT3D = 0xFFFFFFFFFFFFFFFF  # kInvalidPoint3DId (util/types.h)

@@ -86,7 +86,8 @@ inline Rigid3d Compose(const Rigid3d& a, const Rigid3d& b) {
 // CameraModelId (sensor/models.h:90-111): the models the MI355X backend supports.
 enum class CameraModelId : int {
   SIMPLE_PINHOLE = 0, PINHOLE = 1, SIMPLE_RADIAL = 2, RADIAL = 3, OPENCV = 4,
-  OPENCV_FISHEYE = 5, SIMPLE_RADIAL_FISHEYE = 8, RADIAL_FISHEYE = 9
+  OPENCV_FISHEYE = 5, FOV = 7, SIMPLE_RADIAL_FISHEYE = 8, RADIAL_FISHEYE = 9,
+  SIMPLE_DIVISION = 12, DIVISION = 13, SIMPLE_FISHEYE = 14, FISHEYE = 15, EUCM = 16
 };
 
 struct CameraModelInfo {
@@ -96,13 +97,16 @@ struct CameraModelInfo {
 
 inline const CameraModelInfo* GetCameraModelInfo(int model_id) {
   static const CameraModelInfo kSimplePinhole{3, {0}, {1, 2}, {}}, kPinhole{4, {0, 1}, {2, 3}, {}},
-      kSimpleRadial{4, {0}, {1, 2}, {3}}, kRadial{5, {0}, {1, 2}, {3, 4}}, kOpenCV{8, {0, 1}, {2, 3}, {4, 5, 6, 7}};
+      kSimpleRadial{4, {0}, {1, 2}, {3}}, kRadial{5, {0}, {1, 2}, {3, 4}}, kOpenCV{8, {0, 1}, {2, 3}, {4, 5, 6, 7}},
+      kTwoFocalOneExtra{5, {0, 1}, {2, 3}, {4}}, kEucm{6, {0, 1}, {2, 3}, {4, 5}};
   switch (model_id) {
-    case 0: return &kSimplePinhole;
-    case 1: return &kPinhole;
-    case 2: case 8: return &kSimpleRadial;   // SIMPLE_RADIAL, SIMPLE_RADIAL_FISHEYE: f cx cy k
+    case 0: case 14: return &kSimplePinhole;  // SIMPLE_PINHOLE, SIMPLE_FISHEYE: f cx cy
+    case 1: case 15: return &kPinhole;        // PINHOLE, FISHEYE: fx fy cx cy
+    case 2: case 8: case 12: return &kSimpleRadial;  // SIMPLE_RADIAL, SIMPLE_RADIAL_FISHEYE, SIMPLE_DIVISION: f cx cy k
     case 3: case 9: return &kRadial;         // RADIAL, RADIAL_FISHEYE: f cx cy k1 k2
     case 4: case 5: return &kOpenCV;         // OPENCV, OPENCV_FISHEYE: fx fy cx cy + four extra
+    case 7: case 13: return &kTwoFocalOneExtra;  // FOV (omega), DIVISION (k): fx fy cx cy + one extra
+    case 16: return &kEucm;                  // EUCM: fx fy cx cy alpha beta
     default: return nullptr;
   }
 }
@@ -420,7 +424,10 @@ class Mi355xBundleAdjuster : public BundleAdjuster {
     }
     size_t n = 0;
     for (size_t i = 0; i < pose_const_.size(); ++i)
-      if (pose_used[i] && !pose_const_[i]) n += pose_fixed_t_[i] >= 0 ? 5 : 6;
+      if (pose_used[i] && !pose_const_[i]) {
+        const int pf = pose_fixed_t_[i];
+        n += (pf >= BA_POSE_ROT_CONST ? 0 : 3) + ((pf >= 0 && (pf & 3) != 3) ? 2 : 3);
+      }
     for (size_t k = 0; k < cam_model_.size(); ++k)
       if (cam_used[k]) n += cam_nvar[k];
     for (size_t j = 0; j < point_const_.size(); ++j)
@@ -593,8 +600,12 @@ class Mi355xBundleAdjuster : public BundleAdjuster {
     } else if (config_.FixedGauge() == BundleAdjustmentGauge::THREE_POINTS) {
       FixGaugeWithThreePoints();
     }
-    if (options_.constant_rig_from_world_rotation)
-      throw std::invalid_argument("constant_rig_from_world_rotation is not supported by the MI355X backend yet");
+    if (options_.constant_rig_from_world_rotation) {
+      // SubsetManifold(7, {0, 1, 2, 3[, 4 + fixed_dim]}) on every variable rig_from_world (:404-408, 513-516)
+      for (size_t i = 0; i < pose_const_.size(); ++i)
+        if (!pose_const_[i])
+          pose_fixed_t_[i] = static_cast<int8_t>(BA_POSE_ROT_CONST + (pose_fixed_t_[i] >= 0 ? pose_fixed_t_[i] : 3));
+    }
   }
 
   // FixGaugeWithTwoCamsFromWorld (:308-416) on the flattened blocks.

@@ -34,6 +34,7 @@ enum {
   BA_SIMPLE_DIVISION = 12, BA_DIVISION = 13, BA_SIMPLE_FISHEYE = 14, BA_FISHEYE = 15, BA_EUCM = 16
 };
 
+#define BA_POSE_ROT_CONST 4
 typedef struct ba_problem {
   int32_t num_poses, num_cams, num_points;
   int64_t num_obs;
@@ -47,8 +48,10 @@ typedef struct ba_problem {
   double* obs_xy;     /* [num_obs][2] Point2D::xy */
   /* constant-ness, as ceres::Problem would hold it after DefaultBundleAdjuster's ctor */
   uint8_t* pose_const;   /* [num_poses] SetParameterBlockConstant */
-  int8_t* pose_fixed_t;  /* [num_poses] -1, or the translation coordinate the gauge holds
-                            (SubsetManifold, bundle_adjustment_ceres.cc:402-415) */
+  int8_t* pose_fixed_t;  /* [num_poses] -1, or the translation coordinate (0..2) the gauge holds
+                            (SubsetManifold, bundle_adjustment_ceres.cc:402-415); + BA_POSE_ROT_CONST (4)
+                            when the rotation is held too (options.constant_rig_from_world_rotation,
+                            :404-408,513-516): 4..6 = rotation and that coordinate, 7 = rotation only */
   uint8_t* cam_const;    /* [num_cams][BA_CAM_STRIDE] per-parameter mask (SubsetManifold, :419-469) */
   uint8_t* point_const;  /* [num_points] */
   /* Rigs with a constant sensor_from_rig (AddImageWithNonTrivialFrame, bundle_adjustment_ceres.cc:

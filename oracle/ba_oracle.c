@@ -155,6 +155,13 @@ static void quat_to_rot(const double* q, double R[9]) {
   R[6] = txz - twy;       R[7] = tyz + twx;       R[8] = 1 - (txx + tyy);
 }
 
+/* pose_fixed_t encoding: -1 = nothing held; 0..2 = that translation coordinate held (two-camera gauge,
+ * bundle_adjustment_ceres.cc:402-415); +4 = additionally the rotation is held
+ * (constant_rig_from_world_rotation, :404-408,513-516): 4..6 rotation and coordinate, 7 rotation only */
+static int pose_fixed_coord(int v) { return v < 0 ? -1 : ((v & 3) == 3 ? -1 : (v & 3)); }
+static int pose_rot_const(int v) { return v >= 4; }
+static int pose_tangent_dim(int v) { return (pose_rot_const(v) ? 0 : 3) + (pose_fixed_coord(v) >= 0 ? 2 : 3); }
+
 static int num_params_of(int model) {
   switch (model) {
     case BAO_SIMPLE_PINHOLE: return 3;
@@ -714,7 +721,7 @@ static void program_build(program* g, const bao_problem* p) {
   int off = 0;
   for (int i = 0; i < p->num_poses; ++i) {
     if (p->pose_const[i] || !pose_used[i]) { g->pose_off[i] = -1; g->pose_dim[i] = 0; continue; }
-    g->pose_dim[i] = p->pose_fixed_t[i] >= 0 ? 5 : 6;
+    g->pose_dim[i] = pose_tangent_dim(p->pose_fixed_t[i]);
     g->pose_off[i] = off;
     off += g->pose_dim[i];
   }
@@ -843,12 +850,16 @@ static void linearize_obs(const program* g, const double* poses, const double* c
   if (L->pose_dim > 0) {
     double PJ[12];
     quat_plus_jac(poses + 7 * (size_t)pi, PJ);
-    const int fixed = p->pose_fixed_t[pi];
+    const int fixed = pose_fixed_coord(p->pose_fixed_t[pi]);
+    const int rotc = pose_rot_const(p->pose_fixed_t[pi]);
     for (int r = 0; r < 2; ++r) {
-      for (int c = 0; c < 3; ++c)
-        L->Jc[r][c] = Jpose[7 * r + 0] * PJ[c] + Jpose[7 * r + 1] * PJ[3 + c] +
-                      Jpose[7 * r + 2] * PJ[6 + c] + Jpose[7 * r + 3] * PJ[9 + c];
-      int d = 3;
+      int d = 0;
+      if (!rotc) {
+        for (int c = 0; c < 3; ++c)
+          L->Jc[r][c] = Jpose[7 * r + 0] * PJ[c] + Jpose[7 * r + 1] * PJ[3 + c] +
+                        Jpose[7 * r + 2] * PJ[6 + c] + Jpose[7 * r + 3] * PJ[9 + c];
+        d = 3;
+      }
       for (int c = 0; c < 3; ++c) {
         if (c == fixed) continue;
         L->Jc[r][d++] = Jpose[7 * r + 4 + c];
@@ -889,10 +900,13 @@ static void apply_step(const program* g, const double* dc, const double* dp, con
   for (int i = 0; i < p->num_poses; ++i) {
     if (g->pose_off[i] < 0) continue;
     const double* d = dc + g->pose_off[i];
-    bao_quat_plus(poses + 7 * (size_t)i, d, nposes + 7 * (size_t)i);
-    int k = 3;
+    int k = 0;
+    if (!pose_rot_const(p->pose_fixed_t[i])) {
+      bao_quat_plus(poses + 7 * (size_t)i, d, nposes + 7 * (size_t)i);
+      k = 3;
+    }
     for (int c = 0; c < 3; ++c) {
-      if (c == p->pose_fixed_t[i]) continue;
+      if (c == pose_fixed_coord(p->pose_fixed_t[i])) continue;
       nposes[7 * (size_t)i + 4 + c] += d[k++];
     }
   }

@@ -4,6 +4,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/diag_$TAG
 mkdir -p $OUT
 cd $ROOT
+ulimit -c 0
 python -m pytest tests/test_pm_gpu.py -m gpu -x -q 2>&1 | grep -v "rccl\|HIP version\|ROCm version\|Hostname" | tail -8 | tee $OUT/pm_tests.log
 python -m pytest tests/test_ba_gpu.py tests/test_cpp_host.py tests/test_bundle_adjuster_cli.py -m gpu -x -q 2>&1 | grep -v "rccl\|HIP version\|ROCm version\|Hostname" | tail -8 | tee $OUT/ba_tests.log
 cd /tmp && export TMPDIR=/tmp

@@ -4,6 +4,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/diag_$TAG
 mkdir -p $OUT
 cd $ROOT
+ulimit -c 0
 COLMAP_AMD_PM_PIPE=0 python -m pytest tests/test_pm_gpu.py -m gpu -x -q 2>&1 | grep -v "rccl\|HIP version\|ROCm version\|Hostname\|RCCL" | tail -6 | tee $OUT/pm_tests_plain.log
 cd /tmp && export TMPDIR=/tmp
 PROBE="python $ROOT/scripts/pm_probe.py --w 2560 --h 1920 --views 21 --arc 72 --nofilter 1"

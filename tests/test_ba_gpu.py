@@ -414,6 +414,38 @@ def test_opencv_model_matches_oracle():
     (scene.RADIAL_FISHEYE, (900.0, 512.0, 384.0, 0.03, -0.004)),
     (scene.OPENCV_FISHEYE, (900.0, 910.0, 512.0, 384.0, 0.03, -0.004, 0.001, -0.0002))])
 def test_fisheye_models_match_oracle(model, params):
+    _model_matches_oracle(model, params)
+
+
+@pytest.mark.parametrize("model,params", [
+    (scene.FOV, (900.0, 910.0, 512.0, 384.0, 0.6)),
+    (scene.SIMPLE_DIVISION, (900.0, 512.0, 384.0, -0.05)),
+    (scene.DIVISION, (900.0, 910.0, 512.0, 384.0, -0.05)),
+    (scene.SIMPLE_FISHEYE, (900.0, 512.0, 384.0)),
+    (scene.FISHEYE, (900.0, 910.0, 512.0, 384.0)),
+    (scene.EUCM, (900.0, 910.0, 512.0, 384.0, 0.56, 0.87))])
+def test_more_camera_models_match_oracle(model, params):
+    """FOV, SIMPLE_DIVISION / DIVISION, SIMPLE_FISHEYE / FISHEYE, EUCM (models_jacobian.h:627-724,
+    1190-1500): the HIP linearisation against the oracle's through full solves."""
+    _model_matches_oracle(model, params)
+
+
+def test_constant_rig_from_world_rotation_matches_oracle():
+    """Pose blocks whose rotation is held (3- and 2-dimensional translation tangents): the HIP solve
+    follows the oracle and leaves every quaternion bit-identical."""
+    rec = scene.SynthesizeDataset(scene.SyntheticDatasetOptions(num_rigs=2, num_frames_per_rig=5, num_points3D=200),
+                                  seed=31)
+    scene.SynthesizeNoise(scene.SyntheticNoiseOptions(0.03, 0.0, 0.05, 0.5), rec, seed=32)
+    fp = _adapter_problem(rec, constant_rig_from_world_rotation=True)
+    assert (fp.pose_fixed_t[fp.pose_const == 0] >= est.POSE_ROT_CONST).all()
+    (a, want), (b, got) = _both(fp, **TIGHT)
+    assert want.IsSolutionUsable() and got.IsSolutionUsable()
+    _assert_close(a, want, b, got, cost_rtol=1e-8, param_atol=1e-6)
+    assert np.array_equal(b.poses[:, :4], fp.poses[:, :4])
+    assert not np.array_equal(b.poses[:, 4:], fp.poses[:, 4:])
+
+
+def _model_matches_oracle(model, params):
     """Equidistant fisheye projection + radial polynomial (models_jacobian.h:51-80,726-942)."""
     rec = scene.SynthesizeDataset(scene.SyntheticDatasetOptions(
         num_rigs=3, num_frames_per_rig=4, num_points3D=250, camera_model_id=model, camera_params=params), seed=21)

@@ -541,3 +541,104 @@ def test_fisheye_models_values_and_jacobians(model, params):
             J[:, i] = (f(x0 + e) - f(x0 - e)) / (2 * h)
         np.testing.assert_allclose(Jpt, J[:, :3], rtol=2e-5, atol=2e-5)
         np.testing.assert_allclose(Jpar, J[:, 3:], rtol=2e-5, atol=5e-5)
+
+
+# Parameter vectors and the (u, v, w) grid of the reference's own model tests (sensor/models_test.cc:186-195,
+# 333-417); analytic Jacobians against central differences as models_jacobian_test.cc does against autodiff.
+_REF_MODEL_PARAMS = [
+    (scene.FOV, [651.123, 655.123, 386.123, 511.123, 0.0]),
+    (scene.FOV, [651.123, 655.123, 386.123, 511.123, 0.9]),
+    (scene.FOV, [651.123, 655.123, 386.123, 511.123, 1e-6]),
+    (scene.FOV, [651.123, 655.123, 386.123, 511.123, 1e-2]),
+    (scene.SIMPLE_DIVISION, [651.123, 386.123, 511.123, 0.0]),
+    (scene.SIMPLE_DIVISION, [651.123, 386.123, 511.123, 0.1]),
+    (scene.SIMPLE_DIVISION, [651.123, 386.123, 511.123, -0.1]),
+    (scene.DIVISION, [651.123, 655.123, 386.123, 511.123, 0.0]),
+    (scene.DIVISION, [651.123, 655.123, 386.123, 511.123, 0.1]),
+    (scene.DIVISION, [651.123, 655.123, 386.123, 511.123, -0.1]),
+    (scene.SIMPLE_FISHEYE, [651.123, 386.123, 511.123]),
+    (scene.FISHEYE, [651.123, 655.123, 386.123, 511.123]),
+    (scene.EUCM, [651.123, 655.123, 386.123, 511.123, 0.56, 0.87]),
+    (scene.EUCM, [400.0, 400.0, 400.0, 400.0, 0.88, 0.64]),
+    (scene.EUCM, [651.123, 655.123, 386.123, 511.123, 0.0, 1.0]),
+    (scene.EUCM, [651.123, 655.123, 386.123, 511.123, 0.5, 1.0]),
+]
+
+
+@pytest.mark.parametrize("model,params", _REF_MODEL_PARAMS)
+def test_more_camera_models_values_and_jacobians(model, params):
+    """FOV (models_jacobian.h:627-724, all three branches of the distortion), SIMPLE_DIVISION / DIVISION
+    (:88-113, 1291-1411), SIMPLE_FISHEYE / FISHEYE (:1190-1288), EUCM (:1413-1500)."""
+    pose = np.array([0, 0, 0, 1, 0, 0, 0.0])
+    params = np.array(params, np.float64)
+    grid = [np.array([u, v, w]) for u in np.arange(-0.5, 0.51, 0.1) for v in np.arange(-0.5, 0.51, 0.1)
+            for w in (0.5, 1.0, 2.0)]
+    for pt in grid[::3] + [np.array([0.0, 0.0, 1.0])]:
+        r0, Jpt, Jpose, Jpar = ba_oracle.reproj_error(model, pt, pose, params, [0, 0])
+        if model == scene.FOV and params[4] ** 2 < 1e-4:   # small-omega series branch of the distortion
+            f = params[4] ** 2 * (pt[0] ** 2 + pt[1] ** 2) / pt[2] ** 2 / 3.0 - params[4] ** 2 / 12.0 + 1.0
+            want = np.array([params[0] * pt[0] / pt[2] * f + params[2], params[1] * pt[1] / pt[2] * f + params[3]])
+        else:
+            want = scene.img_from_cam(model, params, pt[None])[0]
+        np.testing.assert_allclose(r0, want, rtol=1e-12, atol=1e-9)
+
+        def f_(v):
+            return ba_oracle.reproj_error(model, v[:3], pose, v[3:], [0, 0], want_jac=False)[0]
+        x0 = np.concatenate([pt, params])
+        J = np.zeros((2, len(x0)))
+        for i in range(len(x0)):
+            h = 1e-6 * max(1.0, abs(x0[i]))
+            e = np.zeros(len(x0)); e[i] = h
+            if model == scene.FOV and i == 7 and abs(abs(x0[i]) - 1e-2) < 1e-9:
+                # omega^2 = 1e-4 is the branch point between the series and the closed form: stay on
+                # the closed-form side (one-sided second-order difference)
+                J[:, i] = (-3 * f_(x0) + 4 * f_(x0 + e) - f_(x0 + 2 * e)) / (2 * h)
+                continue
+            J[:, i] = (f_(x0 + e) - f_(x0 - e)) / (2 * h)
+        np.testing.assert_allclose(Jpt, J[:, :3], rtol=5e-5, atol=5e-5)
+        np.testing.assert_allclose(Jpar, J[:, 3:], rtol=5e-5, atol=2e-4)
+    # the parameter layout the adapters use (FocalLengthIdxs / PrincipalPointIdxs / ExtraParamsIdxs)
+    n = scene.MODEL_NUM_PARAMS[model]
+    assert sorted(scene.MODEL_FOCAL_IDXS[model] + scene.MODEL_PP_IDXS[model] + scene.MODEL_EXTRA_IDXS[model]) == list(range(n))
+
+
+def test_division_and_eucm_reject_points_outside_their_domain():
+    """No cheirality test for the division model: the discriminant decides (models_jacobian.h:97-101);
+    EUCM rejects a non-positive denominator (:1437-1446). A rejected projection gives a zero residual
+    and zero Jacobians (reprojection_error.h:96-116)."""
+    pose = np.array([0, 0, 0, 1, 0, 0, 0.0])
+    r, Jpt, _, _ = ba_oracle.reproj_error(scene.DIVISION, np.array([3.0, 3.0, 1.0]), pose,
+                                          np.array([600.0, 600, 320, 240, 0.2]), [10.0, 20.0])
+    assert np.all(r == 0) and np.all(Jpt == 0)          # w^2 - 4 rho^2 k < 0
+    r, _, _, _ = ba_oracle.reproj_error(scene.DIVISION, np.array([0.1, 0.1, -1.0]), pose,
+                                        np.array([600.0, 600, 320, 240, -0.1]), [0.0, 0.0])
+    assert np.all(np.isfinite(r)) and np.any(r != 0)    # behind the camera but projectable: not rejected
+    r, _, _, _ = ba_oracle.reproj_error(scene.EUCM, np.array([0.1, 0.1, -1.0]), pose,
+                                        np.array([600.0, 600, 320, 240, 0.3, 1.0]), [5.0, 5.0])
+    assert np.all(r == 0)
+
+
+def test_constant_rig_from_world_rotation():
+    """options.constant_rig_from_world_rotation (bundle_adjustment_ceres.cc:404-408,513-516): every
+    variable rig_from_world keeps its rotation bit for bit (SubsetManifold over the quaternion), only
+    translations -- minus the gauge coordinate of the second gauge frame -- points and intrinsics move."""
+    gt, rec = _dataset(2, 5, 150, scene.SyntheticNoiseOptions(point2D_stddev=0.3, point3D_stddev=0.05,
+                                                               rig_from_world_translation_stddev=0.03), seed=5)
+    before = {i: img.cam_from_world.copy() for i, img in rec.images.items()}
+    opt = est.BundleAdjustmentOptions(constant_rig_from_world_rotation=True)
+    ba = est.BundleAdjuster(opt, _config(rec), rec, solve_fn=ba_oracle.solve_fn)
+    fp = ba.problem_
+    var = fp.pose_const == 0
+    assert var.sum() == len(fp.poses) - 1
+    codes = sorted(fp.pose_fixed_t[var].tolist())
+    assert codes[-1] == 7 and codes.count(7) == var.sum() - 1 and 4 <= codes[0] <= 6   # one frame also holds a coordinate
+    s = ba.Solve()
+    assert s.IsSolutionUsable() and s.final_cost < 0.2 * s.initial_cost
+    # tangent size: 3 per free frame, 2 for the second gauge frame, + points + 2 intrinsics per camera
+    n_cam_params = int((fp.cam_const[:, :4] == 0).sum())
+    assert s.num_effective_parameters == 3 * (var.sum() - 1) + 2 + 3 * int((fp.point_const == 0).sum()) + n_cam_params
+    moved = 0
+    for i, img in rec.images.items():
+        assert np.array_equal(img.cam_from_world[:4], before[i][:4])       # rotations untouched
+        moved += int(not np.array_equal(img.cam_from_world[4:], before[i][4:]))
+    assert moved == len(rec.images) - 1
