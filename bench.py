@@ -130,6 +130,8 @@ def ba_secondary(a, local_rank, with_cpu, rank=0, world=1, dev=None):
         n_obs_rank = est.shard_num_observations(fp, rank, world, best_mode)
     ms, n, _ = C.c_double(), C.c_int64(), C.c_int64()
     lib().ba_last_spmv_timing(C.byref(ms), C.byref(n), C.byref(_))
+    mfma_ms, mfma_n = C.c_double(), C.c_int64()
+    lib().ba_last_mfma_timing(C.byref(mfma_ms), C.byref(mfma_n))
     alg = 352 * n_obs_rank  # 2 passes over the fp64 Jacobian rows: 2 x 2 x (6 + 2 + 3) x 8 B per observation
     avg_ms = ms.value / max(n.value, 1)
     out = {
@@ -146,7 +148,11 @@ def ba_secondary(a, local_rank, with_cpu, rank=0, world=1, dev=None):
                    "cost": [s.initial_cost, s.final_cost], "parallelism": parallelism},
         "roofline": {"bound": "hbm", "kernel": "implicit Schur product (ba_obs_jx + ba_point_pass + ba_block_jtv)",
                      "achieved": alg / (avg_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
-                     "frac": alg / (avg_ms * 1e-3) / 1e9 / 8000.0, "traffic": None,
+                     "frac": alg / (avg_ms * 1e-3) / 1e9 / 8000.0, "traffic": ba_pmc_traffic(n_obs_rank),
+                     # dense camera-block contraction (Schur-Jacobi blocks M_b = sum J^T (I - G) J on
+                     # v_mfma_f64_16x16x4_f64): share of the LM time, and its flop rate
+                     "mfma_time_frac": (mfma_ms.value * 1e-3) / max(seconds, 1e-12),
+                     "mfma_avg_launch_ms": mfma_ms.value / max(mfma_n.value, 1),
                      "algorithmic_bytes_per_launch": alg, "avg_launch_ms": avg_ms, "launches_timed": int(n.value)},
     }
     if sharded:
@@ -161,6 +167,21 @@ def ba_secondary(a, local_rank, with_cpu, rank=0, world=1, dev=None):
                                    sample=f"oracle/ba_oracle.c (fp64, OpenMP), first {sc.num_iterations} LM iterations "
                                           f"of the same problem, {sc.lm_seconds:.1f} s")
     return out
+
+
+def ba_pmc_traffic(n_obs):
+    """FETCH_SIZE + WRITE_SIZE of the three kernels of one implicit Schur product (scripts/profile_ba.sh,
+    separate --pmc passes; profiles/ba_schur_traffic.json), or None when the committed passes were taken
+    on another problem size."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "ba_schur_traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        if int(t["observations"]) != int(n_obs):
+            return None
+        return float(t["fetch_bytes_per_product"]) + float(t["write_bytes_per_product"])
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def pmc_traffic(images_per_launch):

@@ -48,6 +48,8 @@ thread_local std::string g_ba_error;
 thread_local double g_spmv_ms = 0.0;
 thread_local long long g_spmv_launches = 0;
 thread_local long long g_spmv_bytes = 0;
+thread_local double g_mfma_ms = 0.0;       // time inside the f64 MFMA Gram kernel (Schur-Jacobi blocks)
+thread_local long long g_mfma_launches = 0;
 
 #define BA_HIP(expr)                                                                           \
   do {                                                                                         \
@@ -114,8 +116,11 @@ struct View {
   // topology
   const int *o_pose, *o_cam, *o_pt;  // per observation, c-order (sorted by camera, then pose)
   const double* o_xy;                // c-order
-  const int* o_sensor;               // c-order: constant sensor_from_rig of the observation, -1 none; or NULL
-  const double* sensors;             // [n][7]
+  const int* o_sensor;               // c-order: sensor_from_rig of the observation, -1 none; or NULL
+  double* sensors;                   // [n][7] (current / candidate)
+  const int* sens_off;               // [n] tangent offset of a variable sensor_from_rig (6-wide), -1 constant; or NULL
+  double* Jsens;                     // c-order [2 x 6][n_obs] sensor-tangent columns (only with variable sensors)
+  int n_sensors;
   int loss_type;                     // BA_LOSS_*
   double loss_scale;
   const int *c2a, *a2c;              // c-order position <-> p-order position (sorted by point)
@@ -524,6 +529,7 @@ template <bool JAC, int KD>
 __global__ void __launch_bounds__(256) ba_linearize_kernel(View V, const double* __restrict__ poses,
                                                           const double* __restrict__ cams,
                                                           const double* __restrict__ points,
+                                                          const double* __restrict__ sensors,
                                                           double* __restrict__ partials) {
   const int o = blockIdx.x * blockDim.x + threadIdx.x;
   double cost = 0.0;
@@ -536,12 +542,18 @@ __global__ void __launch_bounds__(256) ba_linearize_kernel(View V, const double*
     double JR[12], Juvw[6], Jpar[2 * NPAR], pc[3];
     quat_rotate(q, X, pc, JAC ? JR : nullptr);
     pc[0] += q[4]; pc[1] += q[5]; pc[2] += q[6];
-    // constant sensor_from_rig (RigReprojErrorConstantRigCostFunctor): p_cam = R_s p_rig + t_s
+    // sensor_from_rig (RigReprojErrorCostFunctor / ...ConstantRigCostFunctor, reprojection_error.h:
+    // 344-417): p_cam = R_s p_rig + t_s
     const int si = V.o_sensor ? V.o_sensor[o] : -1;
-    double Rs[9];
+    const int soff = (si >= 0 && V.sens_off) ? V.sens_off[si] : -1;
+    double Rs[9], JRs[12], prig[3] = {pc[0], pc[1], pc[2]};
     if (si >= 0) {
-      const double* sfr = V.sensors + 7 * (size_t)si;
+      const double* sfr = sensors + 7 * (size_t)si;
       quat_to_rot(sfr, Rs);
+      if (JAC && soff >= 0) {
+        double tmp[3];
+        quat_rotate(sfr, prig, tmp, JRs);  // d(R_s p_rig)/dq_s
+      }
       const double p0 = pc[0], p1 = pc[1], p2 = pc[2];
       pc[0] = Rs[0] * p0 + Rs[1] * p1 + Rs[2] * p2 + sfr[4];
       pc[1] = Rs[3] * p0 + Rs[4] * p1 + Rs[5] * p2 + sfr[5];
@@ -561,6 +573,28 @@ __global__ void __launch_bounds__(256) ba_linearize_kernel(View V, const double*
     loss_eval(V.loss_type, V.loss_scale, sq_norm, rho);
     cost = 0.5 * rho[0];
     if (JAC) {
+      double Js[2][6];  // sensor_from_rig tangent columns: J_uvw [dR_s p/dq_s PlusJacobian | I]
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) Js[r][c] = 0.0;
+      if (ok && soff >= 0) {
+        const double* sfr = sensors + 7 * (size_t)si;
+        const double x = sfr[0], y = sfr[1], z = sfr[2], w = sfr[3];
+        const double PJs[12] = {w, z, -y, -z, w, x, y, -x, w, -x, -y, -z};
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          double Jq[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            Jq[c] = Juvw[3 * r] * JRs[c] + Juvw[3 * r + 1] * JRs[4 + c] + Juvw[3 * r + 2] * JRs[8 + c];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            Js[r][c] = Jq[0] * PJs[c] + Jq[1] * PJs[3 + c] + Jq[2] * PJs[6 + c] + Jq[3] * PJs[9 + c];
+            Js[r][3 + c] = Juvw[3 * r + c];
+          }
+        }
+      }
       if (ok && si >= 0) {  // derivative w.r.t. the point in the rig frame: J_uvw R_s
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
@@ -648,6 +682,8 @@ __global__ void __launch_bounds__(256) ba_linearize_kernel(View V, const double*
 #pragma unroll
         for (int c = 0; c < PD; ++c) correct(Jp[0][c], Jp[1][c]);
 #pragma unroll
+        for (int c = 0; c < 6; ++c) correct(Js[0][c], Js[1][c]);
+#pragma unroll
         for (int c = 0; c < KD; ++c) correct(Jk[0][c], Jk[1][c]);
 #pragma unroll
         for (int c = 0; c < 3; ++c) correct(Jx[0][c], Jx[1][c]);
@@ -669,6 +705,11 @@ __global__ void __launch_bounds__(256) ba_linearize_kernel(View V, const double*
         for (int c = 0; c < KD; ++c) {
           const double s = (c < cdim) ? V.scale_c[coff + c] : 0.0;
           V.Jcam[(size_t)(r * KD + c) * N + o] = Jk[r][c] * s;
+        }
+        if (V.sens_off) {
+#pragma unroll
+          for (int c = 0; c < 6; ++c)
+            V.Jsens[(size_t)(r * 6 + c) * N + o] = soff >= 0 ? Js[r][c] * V.scale_c[soff + c] : 0.0;
         }
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -934,6 +975,18 @@ __global__ void ba_obs_jx_kernel(View V, const double* __restrict__ x, double* _
       a0 += V.Jcam[(size_t)c * N + o] * xv;
       a1 += V.Jcam[(size_t)(KD + c) * N + o] * xv;
     }
+  if (V.sens_off) {
+    const int si = V.o_sensor[o];
+    const int soff = si >= 0 ? V.sens_off[si] : -1;
+    if (soff >= 0) {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        const double xv = x[soff + c];
+        a0 += V.Jsens[(size_t)c * N + o] * xv;
+        a1 += V.Jsens[(size_t)(6 + c) * N + o] * xv;
+      }
+    }
+  }
   const int a = V.c2a[o];
   jx[a] = a0;
   jx[N + a] = a1;
@@ -954,6 +1007,12 @@ __global__ void __launch_bounds__(256) ba_model_kernel(View V, const double* __r
       double m = 0.0;
       for (int c = 0; c < pdim; ++c) m += V.Jpose[(size_t)(r * PD + c) * N + o] * dc[poff + c];
       for (int c = 0; c < cdim; ++c) m += V.Jcam[(size_t)(r * V.kd + c) * N + o] * dc[coff + c];
+      if (V.sens_off) {
+        const int si = V.o_sensor[o];
+        const int soff = si >= 0 ? V.sens_off[si] : -1;
+        if (soff >= 0)
+          for (int c = 0; c < 6; ++c) m += V.Jsens[(size_t)(r * 6 + c) * N + o] * dc[soff + c];
+      }
       if (ptoff >= 0)
         for (int c = 0; c < 3; ++c) m += V.Jpt[(size_t)(r * 3 + c) * N + V.c2a[o]] * dp[ptoff + c];
       acc -= m * (V.res[r * N + o] + 0.5 * m);
@@ -969,6 +1028,7 @@ __global__ void __launch_bounds__(256) ba_model_kernel(View V, const double* __r
 
 __device__ __forceinline__ const double* blk_col(const View& V, int kind, int r, int c) {
   const size_t N = (size_t)V.n_obs;
+  if (kind == 2) return V.Jsens + (size_t)(r * 6 + c) * N;  // variable sensor_from_rig block
   return kind == 0 ? V.Jpose + (size_t)(r * PD + c) * N : V.Jcam + (size_t)(r * V.kd + c) * N;
 }
 
@@ -1170,7 +1230,10 @@ __global__ void __launch_bounds__(64) ba_block_schur_cross_kernel(View V, const 
     for (int a2 = V.pt_ptr[xi]; a2 < V.pt_ptr[xi + 1]; ++a2) {
       if (a2 == a) continue;  // the self term is part of (I - G) in the Gram kernel
       const int o2 = V.a2c[a2];
-      const int off2 = kind == 0 ? V.pose_off[V.o_pose[o2]] : V.cam_off[V.o_cam[o2]];
+      int off2;
+      if (kind == 0) off2 = V.pose_off[V.o_pose[o2]];
+      else if (kind == 1) off2 = V.cam_off[V.o_cam[o2]];
+      else off2 = V.o_sensor[o2] >= 0 ? V.sens_off[V.o_sensor[o2]] : -1;
       if (off2 != boff) continue;
 #pragma unroll
       for (int y = 0; y < BD; ++y) {
@@ -1360,6 +1423,36 @@ __global__ void ba_apply_pose_kernel(View V, const double* __restrict__ step, co
     o[4 + c] += d[k++];
   }
 }
+// Plus() on the variable sensor_from_rig blocks (quaternion (x) R^3, like a full pose block)
+__global__ void ba_apply_sensor_kernel(View V, const double* __restrict__ step, const double* __restrict__ in,
+                                       double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= V.n_sensors) return;
+  const double* q = in + 7 * (size_t)i;
+  double* o = out + 7 * (size_t)i;
+  for (int c = 0; c < 7; ++c) o[c] = q[c];
+  const int off = V.sens_off ? V.sens_off[i] : -1;
+  if (off < 0) return;
+  const double* d = step + off;
+  const double n = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+  if (n != 0.0) {
+    const double s = sin(n) / n;
+    const double dx = s * d[0], dy = s * d[1], dz = s * d[2], dw = cos(n);
+    const double x = q[0], y = q[1], z = q[2], w = q[3];
+    o[0] = dw * x + dx * w + dy * z - dz * y;
+    o[1] = dw * y - dx * z + dy * w + dz * x;
+    o[2] = dw * z + dx * y - dy * x + dz * w;
+    o[3] = dw * w - dx * x - dy * y - dz * z;
+  }
+  for (int c = 0; c < 3; ++c) o[4 + c] += d[3 + c];
+}
+__global__ void ba_renorm_sensor_quat_kernel(View V, double* __restrict__ sensors) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= V.n_sensors || !V.sens_off || V.sens_off[i] < 0) return;
+  double* q = sensors + 7 * (size_t)i;
+  const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  for (int c = 0; c < 4; ++c) q[c] /= n;
+}
 __global__ void ba_apply_cam_kernel(View V, const double* __restrict__ step, const double* __restrict__ in,
                                     double* __restrict__ out) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1445,8 +1538,9 @@ struct Solver {
   View V{};
   hipStream_t st = nullptr;
   // topology
-  Buf<int> o_sensor;
-  Buf<double> sensors;
+  Buf<int> o_sensor, sens_off;
+  Buf<double> sensors, sensors2, Jsens;
+  std::vector<int> h_sens_off;
   Buf<int> o_pose, o_cam, o_pt, pose_off, pose_dim, pose_fix, cam_off, cam_dim, cam_var, cam_model, pt_off,
       pt_ptr, blk_off, blk_dim, blk_kind, blk_moff, chunk_blk, chunk_beg, chunk_end, blk_chunk_ptr, c2a, a2c, tile_pt;
   Buf<unsigned char> solo;
@@ -1456,12 +1550,14 @@ struct Solver {
   long long n_paired = 0;  // (observation, block kind) slots that have a partner of the same point in the block
   int kd = 4, bd = PD;  // intrinsics tangent width / widest camera-side block of this problem
   std::vector<int> h_pose_off, h_cam_off, h_pt_off;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
 
   Solver(ba_problem& p_, const ba_options& o_, Comm& c_) : opt(o_), prob(p_), comm(c_) {}
   ~Solver() {
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
+    if (ev2) (void)hipEventDestroy(ev2);
+    if (ev3) (void)hipEventDestroy(ev3);
     if (st) (void)hipStreamDestroy(st);
   }
 
@@ -1518,16 +1614,20 @@ struct Solver {
     std::vector<int64_t> active;
     active.reserve(p.num_obs / comm.world + 1);
     int64_t n_active_global = 0;
-    std::vector<char> pose_used(p.num_poses, 0), cam_used(p.num_cams, 0), pt_used(p.num_points, 0);
+    std::vector<char> pose_used(p.num_poses, 0), cam_used(p.num_cams, 0), pt_used(p.num_points, 0),
+        sens_used(std::max(p.num_sensors, 0) + 1, 0);
     for (int64_t o = 0; o < p.num_obs; ++o) {
       const int pi = p.obs_pose[o], ci = p.obs_cam[o], xi = p.obs_point[o];
       if (pi < 0 || pi >= p.num_poses || ci < 0 || ci >= p.num_cams || xi < 0 || xi >= p.num_points)
         throw std::runtime_error("observation index out of range");
       if (p.obs_sensor && (p.obs_sensor[o] < -1 || p.obs_sensor[o] >= p.num_sensors))
         throw std::runtime_error("observation sensor index out of range");
-      if (p.pose_const[pi] && cam_nvar[ci] == 0 && p.point_const[xi]) continue;
+      const int sv = p.obs_sensor ? p.obs_sensor[o] : -1;
+      const bool sens_var = sv >= 0 && p.sensor_const != nullptr && !p.sensor_const[sv];
+      if (p.pose_const[pi] && cam_nvar[ci] == 0 && p.point_const[xi] && !sens_var) continue;
       ++n_active_global;
       pose_used[pi] = cam_used[ci] = pt_used[xi] = 1;  // layout = all ranks' observations
+      if (sens_var) sens_used[sv] = 1;
       // image sharding (BASELINE.json: "images shard across the GPUs") or point sharding (every
       // observation of a point on one rank: the point-side quantities stay local)
       if ((comm.by_point ? xi : pi) % comm.world == comm.rank) active.push_back(o);
@@ -1570,14 +1670,17 @@ struct Solver {
     std::vector<unsigned char> h_solo(n, 0);
     for (int j = 0; j < p.num_points; ++j)
       for (int a = h_pt_ptr[j]; a < h_pt_ptr[j + 1]; ++a) {
-        int same_pose = 0, same_cam = 0;
-        for (int a2 = h_pt_ptr[j]; a2 < h_pt_ptr[j + 1]; ++a2) {
-          same_pose += p.obs_pose[active[a2]] == p.obs_pose[active[a]];
-          same_cam += p.obs_cam[active[a2]] == p.obs_cam[active[a]];
-        }
-        h_solo[h_a2c[a]] = (unsigned char)((same_pose == 1 ? 1 : 0) | (same_cam == 1 ? 2 : 0));
+        int same_pose = 0, same_cam = 0, same_sens = 0;
         const int64_t oa = active[a];
-        n_paired += (same_pose != 1 && !p.pose_const[p.obs_pose[oa]]) + (same_cam != 1 && cam_nvar[p.obs_cam[oa]] > 0);
+        const int sa = p.obs_sensor ? p.obs_sensor[oa] : -1;
+        for (int a2 = h_pt_ptr[j]; a2 < h_pt_ptr[j + 1]; ++a2) {
+          same_pose += p.obs_pose[active[a2]] == p.obs_pose[oa];
+          same_cam += p.obs_cam[active[a2]] == p.obs_cam[oa];
+          same_sens += sa >= 0 && p.obs_sensor[active[a2]] == sa;
+        }
+        h_solo[h_a2c[a]] = (unsigned char)((same_pose == 1 ? 1 : 0) | (same_cam == 1 ? 2 : 0) | (same_sens <= 1 ? 4 : 0));
+        n_paired += (same_pose != 1 && !p.pose_const[p.obs_pose[oa]]) + (same_cam != 1 && cam_nvar[p.obs_cam[oa]] > 0) +
+                    (same_sens > 1 && sens_used[sa]);
       }
     std::vector<int> h_o_pose(n), h_o_cam(n), h_o_pt(n), h_o_sensor;
     const bool has_sensors = p.obs_sensor != nullptr && p.num_sensors > 0 && p.sensors != nullptr;
@@ -1623,6 +1726,21 @@ struct Solver {
       off += cam_nvar[k];
       moff += cam_nvar[k] * cam_nvar[k];
     }
+    // variable sensor_from_rig blocks (RigReprojErrorCostFunctor's cam_from_rig parameter block,
+    // bundle_adjustment_ceres.cc:804-812): full 6-dimensional pose tangent, block kind 2
+    h_sens_off.assign(std::max(p.num_sensors, 0), -1);
+    std::vector<int> blk_of_sens(std::max(p.num_sensors, 0), -1);
+    int n_var_sensors = 0;
+    for (int sidx = 0; sidx < p.num_sensors; ++sidx) {
+      if (!sens_used[sidx]) continue;
+      h_sens_off[sidx] = off;
+      blk_of_sens[sidx] = (int)h_blk_off.size();
+      h_blk_off.push_back(off); h_blk_dim.push_back(6); h_blk_kind.push_back(2);
+      h_blk_moff.push_back(moff);
+      off += 6;
+      moff += 36;
+      ++n_var_sensors;
+    }
     const int n_c = off;
     moff_total = moff;
     int poff = 0;
@@ -1645,6 +1763,7 @@ struct Solver {
     for (int c = 0; c < n; ++c) {
       add_run(blk_of_pose[h_o_pose[c]], c);
       add_run(blk_of_cam[h_o_cam[c]], c);
+      if (has_sensors && h_o_sensor[c] >= 0) add_run(blk_of_sens[h_o_sensor[c]], c);
     }
     const int CHUNK = chunk_size() & ~1;  // even: the MFMA Gram kernel consumes observation pairs
     std::vector<int> h_chunk_blk, h_chunk_beg, h_chunk_end, h_blk_chunk_ptr(n_blk + 1, 0);
@@ -1661,6 +1780,8 @@ struct Solver {
 
     res_out->num_residuals = (int32_t)(2 * n_active_global);
     res_out->num_effective_parameters = n_c + poff;
+    if (n_var_sensors > 0 && comm.world > 1)
+      throw std::runtime_error("refine_sensor_from_rig is not supported by the sharded solve");
     if (n_active_global == 0) return 0;
     if (n == 0)
       throw std::runtime_error("rank " + std::to_string(comm.rank) + " holds no observation: use fewer ranks "
@@ -1671,6 +1792,9 @@ struct Solver {
     if (has_sensors) {
       o_sensor.upload(h_o_sensor);
       sensors.upload(std::vector<double>(p.sensors, p.sensors + (size_t)7 * p.num_sensors));
+      sensors2.alloc(sensors.n);
+      BA_HIP(hipMemcpy(sensors2.p, sensors.p, sizeof(double) * sensors.n, hipMemcpyDeviceToDevice));
+      if (n_var_sensors > 0) sens_off.upload(h_sens_off);
     }
     pose_off.upload(h_pose_off); pose_dim.upload(h_pose_dim); pose_fix.upload(h_pose_fix);
     cam_off.upload(h_cam_off); cam_dim.upload(h_cam_dim); cam_var.upload(h_cam_var);
@@ -1689,6 +1813,7 @@ struct Solver {
     const size_t N = (size_t)n;
     Jpose.alloc(2 * PD * N); Jcam.alloc(2 * (size_t)kd * N); Jpt.alloc(6 * N); res.alloc(2 * N); res_p.alloc(2 * N);
     jx.alloc(2 * N); v.alloc(2 * N); Gobs.alloc(3 * N);
+    if (n_var_sensors > 0) Jsens.alloc(12 * N);
     scale_c.alloc(n_c); scale_p.alloc(poff); gc.alloc(n_c); gp.alloc(poff); diag_c.alloc(n_c); diag_p.alloc(poff);
     Dc.alloc(n_c); Dp.alloc(poff); rhs.alloc(n_c); x.alloc(n_c); r.alloc(n_c); z.alloc(n_c); pdir.alloc(n_c);
     q.alloc(n_c); dp.alloc(poff); stepc.alloc(n_c); stepp.alloc(poff);
@@ -1706,6 +1831,9 @@ struct Solver {
     V.bd = bd;
     V.o_sensor = has_sensors ? o_sensor.p : nullptr;
     V.sensors = has_sensors ? sensors.p : nullptr;
+    V.sens_off = n_var_sensors > 0 ? sens_off.p : nullptr;
+    V.Jsens = n_var_sensors > 0 ? Jsens.p : nullptr;
+    V.n_sensors = has_sensors ? p.num_sensors : 0;
     if (opt.loss_type < BA_LOSS_TRIVIAL || opt.loss_type > BA_LOSS_HUBER)
       throw std::runtime_error("unknown loss_type " + std::to_string(opt.loss_type));
     if (opt.loss_type != BA_LOSS_TRIVIAL && !(opt.loss_scale > 0.0))
@@ -1726,14 +1854,14 @@ struct Solver {
     return (int)std::min<int64_t>(n_active_global, 1 << 30);
   }
 
-  void launch_linearize(bool jac, const double* P, const double* Cm, const double* X, int slot) {
+  void launch_linearize(bool jac, const double* P, const double* Cm, const double* X, const double* Sn, int slot) {
     const int g = grid_for(V.n_obs, 256);
     if (kd == 4) {
-      if (jac) BA_LAUNCH((ba_linearize_kernel<true, 4>), dim3(g), dim3(256), st, V, P, Cm, X, partials.p);
-      else BA_LAUNCH((ba_linearize_kernel<false, 4>), dim3(g), dim3(256), st, V, P, Cm, X, partials.p);
+      if (jac) BA_LAUNCH((ba_linearize_kernel<true, 4>), dim3(g), dim3(256), st, V, P, Cm, X, Sn, partials.p);
+      else BA_LAUNCH((ba_linearize_kernel<false, 4>), dim3(g), dim3(256), st, V, P, Cm, X, Sn, partials.p);
     } else {
-      if (jac) BA_LAUNCH((ba_linearize_kernel<true, KD_MAX>), dim3(g), dim3(256), st, V, P, Cm, X, partials.p);
-      else BA_LAUNCH((ba_linearize_kernel<false, KD_MAX>), dim3(g), dim3(256), st, V, P, Cm, X, partials.p);
+      if (jac) BA_LAUNCH((ba_linearize_kernel<true, KD_MAX>), dim3(g), dim3(256), st, V, P, Cm, X, Sn, partials.p);
+      else BA_LAUNCH((ba_linearize_kernel<false, KD_MAX>), dim3(g), dim3(256), st, V, P, Cm, X, Sn, partials.p);
     }
     BA_LAUNCH(ba_final_sum_kernel, dim3(1), dim3(1024), st, partials.p, g, scalars.p + slot);
   }
@@ -1831,6 +1959,8 @@ struct Solver {
   }
 
   void apply_step(const double* sc, const double* sp, double* P2, double* C2, double* X2) {
+    if (V.sens_off)
+      BA_LAUNCH(ba_apply_sensor_kernel, dim3(grid_for(V.n_sensors, 128)), dim3(128), st, V, sc, sensors.p, sensors2.p);
     BA_LAUNCH(ba_apply_pose_kernel, dim3(grid_for(V.n_poses, 128)), dim3(128), st, V, sc, poses.p, P2);
     BA_LAUNCH(ba_apply_cam_kernel, dim3(grid_for(V.n_cams, 128)), dim3(128), st, V, sc, cams.p, C2);
     BA_LAUNCH(ba_apply_point_kernel, dim3(grid_for(V.n_points, 128)), dim3(128), st, V, sp, points.p, X2);
@@ -1840,12 +1970,15 @@ struct Solver {
     BA_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     BA_HIP(hipEventCreate(&ev0));
     BA_HIP(hipEventCreate(&ev1));
+    BA_HIP(hipEventCreate(&ev2));
+    BA_HIP(hipEventCreate(&ev3));
     out->termination_type = BA_FAILURE;
     const int n = build(out);
     if (n == 0) return;
     const int nc = V.n_c, np = V.n_p;
     const int gvc = grid_for(nc, 256), gvp = grid_for(np, 256);
     g_spmv_ms = 0.0; g_spmv_launches = 0;
+    g_mfma_ms = 0.0; g_mfma_launches = 0;
     // bytes one implicit-Schur product streams: Jc (2x10) once for jx, Jp (2x3) twice, jx/v, Jc again
     g_spmv_bytes = (long long)V.n_obs * (2 * (PD + kd) * 8 * 2 + 6 * 8 * 2 + 4 * 8 * 3);
 
@@ -1861,7 +1994,7 @@ struct Solver {
 
     for (int iter = 0;; ++iter) {
       if (need_linearize) {
-        launch_linearize(true, poses.p, cams.p, points.p, S_COST);
+        launch_linearize(true, poses.p, cams.p, points.p, sensors.p, S_COST);
         gradient_and_diag();
         if (!have_scale) {
           // Jacobi scaling from the initial Jacobian, then re-linearise with it
@@ -1869,7 +2002,7 @@ struct Solver {
                              opt.jacobi_scaling, scale_c.p);
           BA_LAUNCH(ba_scale_kernel, dim3(std::max(gvp, 1)), dim3(256), st, np, diag_p.p,
                              opt.jacobi_scaling, scale_p.p);
-          launch_linearize(true, poses.p, cams.p, points.p, S_COST);
+          launch_linearize(true, poses.p, cams.p, points.p, sensors.p, S_COST);
           gradient_and_diag();
           have_scale = true;
         }
@@ -1884,6 +2017,8 @@ struct Solver {
         BA_LAUNCH(ba_maxdiff_kernel, dim3(grid_for(poses.n, 256)), dim3(256), st, poses.n, poses.p, poses2.p, scalars.p);
         BA_LAUNCH(ba_maxdiff_kernel, dim3(grid_for(cams.n, 256)), dim3(256), st, cams.n, cams.p, cams2.p, scalars.p);
         BA_LAUNCH(ba_maxdiff_kernel, dim3(grid_for(points.n, 256)), dim3(256), st, points.n, points.p, points2.p, scalars.p);
+        if (V.sens_off)
+          BA_LAUNCH(ba_maxdiff_kernel, dim3(grid_for(sensors.n, 256)), dim3(256), st, sensors.n, sensors.p, sensors2.p, scalars.p);
         const double gmax = scalar_max(S_GMAX);
         if (gmax <= opt.gradient_tolerance) {
           out->termination_type = BA_CONVERGENCE;
@@ -1906,11 +2041,15 @@ struct Solver {
       if (!comm.by_point) comm.allreduce(Craw.p, 6 * (size_t)V.n_points, st);
       BA_LAUNCH(ba_point_blocks_kernel, dim3(grid_for(V.n_points, 128)), dim3(128), st, V, Craw.p, Dp.p, Cinv.p);
       int lin_iters = 0;
+      bool mfma_pending = false;
       if (nc > 0) {
         BA_HIP(hipMemsetAsync(M.p, 0, sizeof(double) * std::max(moff_total, 1), st));
         if (V.n_chunks > 0) {
           BA_LAUNCH(ba_obs_schur_g_kernel, dim3(grid_for(V.n_obs, 256)), dim3(256), st, V, Cinv.p, Gobs.p);
+          BA_HIP(hipEventRecord(ev2, st));
           BA_LAUNCH(ba_block_gram_kernel, dim3(V.n_chunks), dim3(64), st, V, Gobs.p);
+          BA_HIP(hipEventRecord(ev3, st));
+          mfma_pending = true;
           BA_LAUNCH(ba_block_mat_finalize_kernel<false>, dim3(grid_for(V.n_blk, 128)), dim3(128), st, V, M.p);
           if (n_paired > 0) {  // observation pairs of a point inside one block: shared intrinsics, rig frames
             if (bd == PD) BA_LAUNCH(ba_block_schur_cross_kernel<PD>, dim3(V.n_chunks), dim3(64), st, V, Cinv.p);
@@ -1947,7 +2086,11 @@ struct Solver {
       BA_LAUNCH(ba_axpby_kernel, dim3(std::max(gvp, 1)), dim3(256), st, np, -1.0, dp.p, nullptr, stepp.p);
       BA_LAUNCH(ba_model_kernel, dim3(grid_for(V.n_obs, 256)), dim3(256), st, V, stepc.p, stepp.p, partials.p);
       BA_LAUNCH(ba_final_sum_kernel, dim3(1), dim3(1024), st, partials.p, grid_for(V.n_obs, 256), scalars.p + S_MODEL);
-      const double model_change = scalar_sum(S_MODEL);
+      const double model_change = scalar_sum(S_MODEL);  // (synchronises the stream)
+      if (mfma_pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ev2, ev3) == hipSuccess) { g_mfma_ms += ms; g_mfma_launches += 1; }
+      }
       bool accepted = false;
       double new_cost = cost;
       if (!(model_change > 0.0) || !std::isfinite(model_change)) {
@@ -1964,7 +2107,7 @@ struct Solver {
         BA_LAUNCH(ba_axpby_kernel, dim3(std::max(gvc, 1)), dim3(256), st, nc, 1.0, stepc.p, scale_c.p, stepc.p);
         BA_LAUNCH(ba_axpby_kernel, dim3(std::max(gvp, 1)), dim3(256), st, np, 1.0, stepp.p, scale_p.p, stepp.p);
         apply_step(stepc.p, stepp.p, poses2.p, cams2.p, points2.p);
-        launch_linearize(false, poses2.p, cams2.p, points2.p, S_NEWCOST);
+        launch_linearize(false, poses2.p, cams2.p, points2.p, sensors2.p, S_NEWCOST);
         new_cost = scalar_sum(S_NEWCOST);
         const double rho = (cost - new_cost) / model_change;
         if (rho > opt.min_relative_decrease) {
@@ -1972,7 +2115,8 @@ struct Solver {
           std::swap(poses.p, poses2.p);
           std::swap(cams.p, cams2.p);
           std::swap(points.p, points2.p);
-          V.poses = poses.p; V.cams = cams.p; V.points = points.p;
+          if (V.sens_off) std::swap(sensors.p, sensors2.p);
+          V.poses = poses.p; V.cams = cams.p; V.points = points.p; V.sensors = sensors.p;
           const double t = 2.0 * rho - 1.0;
           radius = radius / std::max(1.0 / 3.0, 1.0 - t * t * t);
           radius = std::min(opt.max_trust_region_radius, radius);
@@ -1997,7 +2141,7 @@ struct Solver {
         break;
       }
     }
-    launch_linearize(false, poses.p, cams.p, points.p, S_NEWCOST);
+    launch_linearize(false, poses.p, cams.p, points.p, sensors.p, S_NEWCOST);
     out->final_cost = scalar_sum(S_NEWCOST);
     out->lm_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
     BA_LAUNCH(ba_renorm_quat_kernel, dim3(grid_for(V.n_poses, 128)), dim3(128), st, V, poses.p);
@@ -2005,6 +2149,15 @@ struct Solver {
       // every rank moved its own points only: zero the others' variable points and sum over ranks
       BA_LAUNCH(ba_keep_own_points_kernel, dim3(grid_for(V.n_points, 128)), dim3(128), st, V, comm.rank, comm.world, points.p);
       comm.allreduce(points.p, 3 * (size_t)V.n_points, st);
+    }
+    if (V.sens_off) {
+      BA_LAUNCH(ba_renorm_sensor_quat_kernel, dim3(grid_for(V.n_sensors, 128)), dim3(128), st, V, sensors.p);
+      std::vector<double> hs(sensors.n);
+      BA_HIP(hipMemcpyAsync(hs.data(), sensors.p, sizeof(double) * sensors.n, hipMemcpyDeviceToHost, st));
+      BA_HIP(hipStreamSynchronize(st));
+      for (int sidx = 0; sidx < prob.num_sensors; ++sidx)
+        if (h_sens_off[sidx] >= 0)
+          std::memcpy(prob.sensors + 7 * (size_t)sidx, hs.data() + 7 * (size_t)sidx, 7 * sizeof(double));
     }
     // write back variable blocks only (constant blocks stay bit-identical)
     std::vector<double> hp(poses.n), hc(cams.n), hx(points.n);
@@ -2114,7 +2267,9 @@ static int64_t ShardNumObservations(const ba_problem* p, int32_t rank, int32_t w
   int64_t n = 0;
   for (int64_t o = 0; o < p->num_obs; ++o) {
     const int pi = p->obs_pose[o], xi = p->obs_point[o];
-    if (p->pose_const[pi] && !cam_var[p->obs_cam[o]] && p->point_const[xi]) continue;
+    const int si = p->obs_sensor ? p->obs_sensor[o] : -1;
+    const bool sens_var = si >= 0 && p->sensor_const && !p->sensor_const[si];
+    if (p->pose_const[pi] && !cam_var[p->obs_cam[o]] && p->point_const[xi] && !sens_var) continue;
     if ((by_point ? xi : pi) % world_size == rank) ++n;
   }
   return n;
@@ -2155,6 +2310,12 @@ int ba_rccl_comm_create(const char id[128], int32_t rank, int32_t world_size, in
 
 void ba_rccl_comm_destroy(void* comm) {
   if (comm) (void)ncclCommDestroy(reinterpret_cast<ncclComm_t>(comm));
+}
+
+int ba_last_mfma_timing(double* total_ms, int64_t* launches) {
+  if (total_ms) *total_ms = g_mfma_ms;
+  if (launches) *launches = g_mfma_launches;
+  return 0;
 }
 
 int ba_last_spmv_timing(double* total_ms, int64_t* launches, int64_t* bytes_per_launch) {

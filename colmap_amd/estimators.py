@@ -229,6 +229,8 @@ class FlatProblem:
     # rigs: constant sensor_from_rig per observation (None: every frame is trivial)
     sensors: Optional[np.ndarray] = None      # (N_s, 7) f64
     obs_sensor: Optional[np.ndarray] = None   # (N_o,) i32, -1 = trivial
+    sensor_const: Optional[np.ndarray] = None  # (N_s,) u8, 1 = constant sensor_from_rig (None: all constant)
+    sensor_ids: Optional[list] = None          # camera id of every sensor slot (adapter write-back)
     # id maps for write-back
     pose_ids: List[int] = field(default_factory=list)
     cam_ids: List[int] = field(default_factory=list)
@@ -343,6 +345,8 @@ def flatten(options: BundleAdjustmentOptions, config: BundleAdjustmentConfig,
     pose_is_const: List[int] = []
     sensor_index: Dict[int, int] = {}
     sensor_params: List[np.ndarray] = []
+    sensor_is_const: List[int] = []
+    sensor_rig: List[int] = []
     obs = []  # (pose, cam, point, x, y, sensor)
     num_obs_of_point: Dict[int, int] = {}
 
@@ -361,10 +365,12 @@ def flatten(options: BundleAdjustmentOptions, config: BundleAdjustmentConfig,
             pose_is_const.append(1 if const else 0)
         return pose_index[key]
 
-    def sensor_slot(camera_id, params):
+    def sensor_slot(camera_id, params, const, rig_id):
         if camera_id not in sensor_index:
             sensor_index[camera_id] = len(sensor_params)
             sensor_params.append(np.asarray(params, np.float64))
+            sensor_is_const.append(1 if const else 0)
+            sensor_rig.append(rig_id)
         return sensor_index[camera_id]
 
     def cam_slot(camera_id):
@@ -387,16 +393,15 @@ def flatten(options: BundleAdjustmentOptions, config: BundleAdjustmentConfig,
             return pose_slot(where, params, const_frame), -1
         sensor_from_rig = rec.SensorFromRig(img.image_id)
         const_sensor = (not options.refine_sensor_from_rig) or config.HasConstantSensorFromRigPose(img.camera_id)
-        if not const_sensor:
-            # same restriction as CasparBundleAdjuster (bundle_adjustment_caspar.cc:186-209)
-            raise NotImplementedError("refine_sensor_from_rig with a variable sensor_from_rig is not supported by "
-                                      "the MI355X backend: set refine_sensor_from_rig=false or make the sensor "
-                                      "constant in the config")
         where, params = frame_pose(img)
-        if const_frame:
+        rig_id = rec.frames[img.frame_id_].rig_id
+        if const_frame and const_sensor:
             # both constant: ReprojErrorConstantPoseCostFunctor on the composed pose (:769-772,797-803)
             return pose_slot(("image", img.image_id), scene.rigid_compose(sensor_from_rig, params), True), -1
-        return pose_slot(where, params, False), sensor_slot(img.camera_id, sensor_from_rig)
+        # constant sensor: RigReprojErrorConstantRigCostFunctor (:804-810); variable sensor: the general
+        # RigReprojErrorCostFunctor with sensor_from_rig as a parameter block of its own (:811-820), also
+        # when the frame is constant ("rare enough that we do not have a specialized cost function")
+        return pose_slot(where, params, const_frame), sensor_slot(img.camera_id, sensor_from_rig, const_sensor, rig_id)
 
     parameterized_cams: Set[int] = set()
     gauge_order: List[int] = []  # pose slots of the config's images in image-id order
@@ -421,8 +426,11 @@ def flatten(options: BundleAdjustmentOptions, config: BundleAdjustmentConfig,
             obs.append((slot[0], cam_slot(img.camera_id), point_slot(p2.point3D_id), p2.xy[0], p2.xy[1], slot[1]))
         if n > 0:
             parameterized_cams.add(img.camera_id)
-            gauge_order.append(slot[0])
-            gauge_frames.append(img.frame_id if img.frame_id_ is not None else -img.image_id - 1)
+            # gauge candidates: reference sensors and constant sensor_from_rig only
+            # (IsParameterizedConstSensor, bundle_adjustment_ceres.cc:347-385)
+            if slot[1] < 0 or sensor_is_const[slot[1]]:
+                gauge_order.append(slot[0])
+                gauge_frames.append(img.frame_id if img.frame_id_ is not None else -img.image_id - 1)
     # AddPointToProblem (:826-887): observations from images outside the config, constant pose
     for pid in config.VariablePoints() + config.ConstantPoints():
         pt = rec.points3D[pid]
@@ -488,6 +496,13 @@ def flatten(options: BundleAdjustmentOptions, config: BundleAdjustmentConfig,
     if sensor_params:
         fp.sensors = np.array(sensor_params, np.float64).reshape(-1, 7)
         fp.obs_sensor = np.ascontiguousarray(o[:, 5].astype(np.int32))
+        fp.sensor_const = np.array(sensor_is_const, np.uint8)
+        fp.sensor_ids = sorted(sensor_index, key=sensor_index.get)
+        # a rig whose reference sensor is not part of the problem keeps its sensor_from_rig constant:
+        # the relative poses would not be constrained (ParameterizeImages, :526-543)
+        for k, rig_id in enumerate(sensor_rig):
+            if rec.rigs[rig_id].ref_camera_id not in parameterized_cams:
+                fp.sensor_const[k] = 1
     # gauge (:646-663)
     if config.FixedGauge() == BundleAdjustmentGauge.TWO_CAMS_FROM_WORLD:
         if options.refine_rig_from_world:
@@ -520,6 +535,7 @@ class ba_problem(C.Structure):
         ("pose_const", C.c_void_p), ("pose_fixed_t", C.c_void_p), ("cam_const", C.c_void_p),
         ("point_const", C.c_void_p),
         ("num_sensors", C.c_int32), ("sensors", C.c_void_p), ("obs_sensor", C.c_void_p),
+        ("sensor_const", C.c_void_p),
     ]
 
 
@@ -632,6 +648,9 @@ def marshal_problem(fp: FlatProblem) -> ba_problem:
         p.num_sensors = len(fp.sensors)
         p.sensors = fp.sensors.ctypes.data
         p.obs_sensor = fp.obs_sensor.ctypes.data
+        if fp.sensor_const is not None and not fp.sensor_const.all():
+            assert fp.sensor_const.dtype == np.uint8 and fp.sensor_const.flags["C_CONTIGUOUS"]
+            p.sensor_const = fp.sensor_const.ctypes.data
     return p
 
 
@@ -727,6 +746,12 @@ class BundleAdjuster:
                 rec.frames[ident].rig_from_world = fp.poses[i].copy()
             else:
                 rec.images[ident].cam_from_world = fp.poses[i].copy()
+        if fp.sensors is not None and fp.sensor_const is not None:
+            for k, cid in enumerate(fp.sensor_ids):
+                if not fp.sensor_const[k]:
+                    for rig in rec.rigs.values():
+                        if cid in rig.sensors:
+                            rig.sensors[cid] = fp.sensors[k].copy()
         rec.UpdateCamFromWorld()
         for k, cid in enumerate(fp.cam_ids):
             n = len(rec.cameras[cid].params)

@@ -404,6 +404,8 @@ class Mi355xBundleAdjuster : public BundleAdjuster {
     p.num_sensors = static_cast<int32_t>(sensors_.size() / 7);
     p.sensors = sensors_.empty() ? nullptr : sensors_.data();
     p.obs_sensor = sensors_.empty() ? nullptr : obs_sensor_.data();
+    const bool any_variable_sensor = std::count(sensor_const_.begin(), sensor_const_.end(), 0) > 0;
+    p.sensor_const = any_variable_sensor ? sensor_const_.data() : nullptr;
     return p;
   }
   // Residuals touching >= 1 variable block / variable tangent dimensions, computed on the host
@@ -418,11 +420,15 @@ class Mi355xBundleAdjuster : public BundleAdjuster {
     for (size_t k = 0; k < cam_model_.size(); ++k)
       for (int j = 0; j < GetCameraModelInfo(cam_model_[k])->num_params; ++j)
         cam_nvar[k] += cam_const_[k * BA_CAM_STRIDE + j] ? 0 : 1;
+    std::vector<char> sens_used(sensor_const_.size(), 0);
     for (size_t o = 0; o < obs_pose_.size(); ++o) {
-      if (pose_const_[obs_pose_[o]] && cam_nvar[obs_cam_[o]] == 0 && point_const_[obs_point_[o]]) continue;
+      const int si = obs_sensor_[o];
+      const bool sens_var = si >= 0 && !sensor_const_[si];
+      if (pose_const_[obs_pose_[o]] && cam_nvar[obs_cam_[o]] == 0 && point_const_[obs_point_[o]] && !sens_var) continue;
       pose_used[obs_pose_[o]] = cam_used[obs_cam_[o]] = pt_used[obs_point_[o]] = 1;
+      if (sens_var) sens_used[si] = 1;
     }
-    size_t n = 0;
+    size_t n = 6 * static_cast<size_t>(std::count(sens_used.begin(), sens_used.end(), 1));
     for (size_t i = 0; i < pose_const_.size(); ++i)
       if (pose_used[i] && !pose_const_[i]) {
         const int pf = pose_fixed_t_[i];
@@ -471,12 +477,15 @@ class Mi355xBundleAdjuster : public BundleAdjuster {
     point_ids_.push_back(id);
     return slot;
   }
-  int SensorSlot(camera_t id, const Rigid3d& sensor_from_rig) {
+  int SensorSlot(camera_t id, const Rigid3d& sensor_from_rig, bool constant, rig_t rig_id) {
     auto it = sensor_index_.find(id);
     if (it != sensor_index_.end()) return it->second;
     const int slot = static_cast<int>(sensors_.size() / 7);
     sensor_index_.emplace(id, slot);
     sensors_.insert(sensors_.end(), sensor_from_rig.params.begin(), sensor_from_rig.params.end());
+    sensor_const_.push_back(constant ? 1 : 0);
+    sensor_ids_.push_back(id);
+    sensor_rig_.push_back(rig_id);
     return slot;
   }
   void AddObservation(int pose, int cam, int point, const Point2D& p2, int sensor) {
@@ -498,14 +507,14 @@ class Mi355xBundleAdjuster : public BundleAdjuster {
       return {PoseSlot(in_frame, in_frame ? *image.frame_id : image.image_id, constant_frame, frame_pose), -1};
     const bool constant_sensor =
         !options_.refine_sensor_from_rig || config_.HasConstantSensorFromRigPose(image.camera_id);
-    if (!constant_sensor)
-      throw std::invalid_argument(
-          "refine_sensor_from_rig with a variable sensor_from_rig is not supported by the MI355X backend "
-          "(same restriction as CasparBundleAdjuster, bundle_adjustment_caspar.cc:186-209)");
     const Rigid3d& sensor_from_rig = rec.SensorFromRig(image);
-    if (constant_frame)  // ReprojErrorConstantPoseCostFunctor on the composition (:769-772,797-803)
+    if (constant_frame && constant_sensor)  // ReprojErrorConstantPoseCostFunctor on the composition (:769-772,797-803)
       return {PoseSlot(false, image.image_id, true, Compose(sensor_from_rig, frame_pose)), -1};
-    return {PoseSlot(true, *image.frame_id, false, frame_pose), SensorSlot(image.camera_id, sensor_from_rig)};
+    // constant sensor: RigReprojErrorConstantRigCostFunctor (:804-810); variable sensor: the general
+    // RigReprojErrorCostFunctor with sensor_from_rig as a parameter block of its own (:811-820), also
+    // under a constant frame
+    return {PoseSlot(true, *image.frame_id, constant_frame, frame_pose),
+            SensorSlot(image.camera_id, sensor_from_rig, constant_sensor, rec.frames.at(*image.frame_id).rig_id)};
   }
 
   void Flatten() {  // DefaultBundleAdjuster ctor (bundle_adjustment_ceres.cc:606-664)
@@ -537,9 +546,12 @@ class Mi355xBundleAdjuster : public BundleAdjuster {
       }
       if (num_observations > 0) {
         parameterized_cams.insert(image.camera_id);
-        gauge_slots.push_back(blocks.first);
-        gauge_frames.push_back(image.frame_id ? static_cast<int64_t>(*image.frame_id)
-                                              : -static_cast<int64_t>(image.image_id) - 1);
+        // gauge candidates: reference sensors and constant sensor_from_rig only (IsParameterizedConstSensor, :347-385)
+        if (blocks.second < 0 || sensor_const_[blocks.second]) {
+          gauge_slots.push_back(blocks.first);
+          gauge_frames.push_back(image.frame_id ? static_cast<int64_t>(*image.frame_id)
+                                                : -static_cast<int64_t>(image.image_id) - 1);
+        }
       }
     }
     auto add_point = [&](point3D_t point3D_id) {  // AddPointToProblem (:826-887)
@@ -559,6 +571,9 @@ class Mi355xBundleAdjuster : public BundleAdjuster {
     for (const point3D_t id : config_.VariablePoints()) add_point(id);  // (:633-638)
     for (const point3D_t id : config_.ConstantPoints()) add_point(id);
 
+    // a rig whose reference sensor is not part of the problem keeps its sensor_from_rig constant (:526-543)
+    for (size_t k = 0; k < sensor_const_.size(); ++k)
+      if (!parameterized_cams.count(rec.rigs.at(sensor_rig_[k]).ref_camera_id)) sensor_const_[k] = 1;
     // ParameterizeCameras (:419-469)
     const bool constant_camera =
         !options_.refine_focal_length && !options_.refine_principal_point && !options_.refine_extra_params;
@@ -709,6 +724,11 @@ class Mi355xBundleAdjuster : public BundleAdjuster {
                                             : rec.images.at(pose_refs_[i].id).cam_from_world;
       std::copy(poses_.begin() + 7 * i, poses_.begin() + 7 * i + 7, dst.params.begin());
     }
+    for (size_t k = 0; k < sensor_const_.size(); ++k) {
+      if (sensor_const_[k]) continue;
+      Rigid3d& dst = rec.rigs.at(sensor_rig_[k]).sensors_from_rig.at(sensor_ids_[k]);
+      std::copy(sensors_.begin() + 7 * k, sensors_.begin() + 7 * k + 7, dst.params.begin());
+    }
     rec.UpdateCamFromWorld();
     for (size_t k = 0; k < cam_ids_.size(); ++k) {
       Camera& camera = rec.Camera(cam_ids_[k]);
@@ -729,7 +749,9 @@ class Mi355xBundleAdjuster : public BundleAdjuster {
   std::vector<point3D_t> point_ids_;
   std::vector<double> poses_, cams_, points_, obs_xy_, sensors_;
   std::vector<int32_t> cam_model_, obs_pose_, obs_cam_, obs_point_, obs_sensor_;
-  std::vector<uint8_t> pose_const_, cam_const_, point_const_;
+  std::vector<uint8_t> pose_const_, cam_const_, point_const_, sensor_const_;
+  std::vector<camera_t> sensor_ids_;
+  std::vector<rig_t> sensor_rig_;
   std::vector<int8_t> pose_fixed_t_;
 };
 

@@ -54,14 +54,15 @@ typedef struct ba_problem {
                             :404-408,513-516): 4..6 = rotation and that coordinate, 7 = rotation only */
   uint8_t* cam_const;    /* [num_cams][BA_CAM_STRIDE] per-parameter mask (SubsetManifold, :419-469) */
   uint8_t* point_const;  /* [num_points] */
-  /* Rigs with a constant sensor_from_rig (AddImageWithNonTrivialFrame, bundle_adjustment_ceres.cc:
-   * 752-822; RigReprojErrorConstantRigCostFunctor, cost_functions/reprojection_error.h:386-417): the
-   * pose block of such an observation is the frame's rig_from_world and the camera sees
-   * sensor_from_rig * rig_from_world * X. Variable sensor_from_rig is rejected by the adapter, as
-   * CasparBundleAdjuster does (bundle_adjustment_caspar.cc:186-209). */
+  /* Rigs (AddImageWithNonTrivialFrame, bundle_adjustment_ceres.cc:752-822): the pose block of such an
+   * observation is the frame's rig_from_world and the camera sees sensor_from_rig * rig_from_world * X.
+   * A sensor_from_rig is constant (RigReprojErrorConstantRigCostFunctor, cost_functions/
+   * reprojection_error.h:386-417) or, with options.refine_sensor_from_rig, a 7-parameter block of its
+   * own (RigReprojErrorCostFunctor, :344-384) that is updated in place. */
   int32_t num_sensors;
-  double* sensors;       /* [num_sensors][7] constant Rigid3d::params, or NULL */
+  double* sensors;       /* [num_sensors][7] Rigid3d::params (in/out for variable sensors), or NULL */
   int32_t* obs_sensor;   /* [num_obs] index into sensors, -1 = trivial frame; NULL = all trivial */
+  uint8_t* sensor_const; /* [num_sensors] 1 = constant block; NULL = every sensor_from_rig is constant */
 } ba_problem;
 
 /* ceres::Solver::Options fields that reach the solve (COLMAP's values:
@@ -152,6 +153,9 @@ int ba_solve(ba_problem* problem, const ba_options* options, int32_t gpu_index, 
 /* Per-kernel HIP-event timing of the last ba_solve on this thread (roofline accounting):
  * milliseconds and launch count of the dominant kernel family (implicit Schur product). */
 int ba_last_spmv_timing(double* total_ms, int64_t* launches, int64_t* bytes_per_launch);
+/* The same for the f64 MFMA kernel (Schur-Jacobi blocks, one launch per LM iteration): the fraction of
+ * the LM time spent inside the dense contraction is what the bench line reports as mfma_time_frac. */
+int ba_last_mfma_timing(double* total_ms, int64_t* launches);
 
 const char* ba_last_error(void);
 

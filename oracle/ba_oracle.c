@@ -68,6 +68,9 @@ typedef struct {
   int32_t num_sensors;
   double* sensors;        /* [num_sensors][7] or NULL */
   int32_t* obs_sensor;    /* [num_obs] index into sensors, -1: trivial (NULL: all trivial) */
+  uint8_t* sensor_const;  /* [num_sensors] 1: constant; NULL: all constant. A variable sensor_from_rig is
+                             a parameter block of its own (RigReprojErrorCostFunctor,
+                             reprojection_error.h:344-384) and is updated in place */
 } bao_problem;
 
 typedef struct {
@@ -541,9 +544,32 @@ BAO_API int bao_reproj_error(int model, const double* point, const double* pose,
 /* RigReprojErrorConstantRigCostFunctor (reprojection_error.h:344-417): the same residual seen
  * through a constant sensor_from_rig: p_cam = R_s (R_r X + t_r) + t_s. The reference differentiates
  * it automatically; the chain rule gives J_point = J_uvw R_s R_r, J_pose = J_uvw R_s [dR_rX/dq | I]. */
+static int rig_reproj_error_full(int model, const double* point, const double* rig_from_world,
+                                 const double* sensor_from_rig, const double* params, const double* xy,
+                                 double* residuals, double* J_point, double* J_pose, double* J_params,
+                                 double* J_sensor);
+
 BAO_API int bao_rig_reproj_error(int model, const double* point, const double* rig_from_world,
                                  const double* sensor_from_rig, const double* params, const double* xy,
                                  double* residuals, double* J_point, double* J_pose, double* J_params) {
+  return rig_reproj_error_full(model, point, rig_from_world, sensor_from_rig, params, xy, residuals, J_point,
+                               J_pose, J_params, NULL);
+}
+
+/* The same with the Jacobian w.r.t. sensor_from_rig (2 x 7: quaternion xyzw, translation): the point in
+ * the camera frame is R_s p_rig + t_s, so d/dq_s = J_uvw d(R_s p_rig)/dq_s and d/dt_s = J_uvw. */
+BAO_API int bao_rig_reproj_error_sensor(int model, const double* point, const double* rig_from_world,
+                                        const double* sensor_from_rig, const double* params, const double* xy,
+                                        double* residuals, double* J_point, double* J_pose, double* J_params,
+                                        double* J_sensor) {
+  return rig_reproj_error_full(model, point, rig_from_world, sensor_from_rig, params, xy, residuals, J_point,
+                               J_pose, J_params, J_sensor);
+}
+
+static int rig_reproj_error_full(int model, const double* point, const double* rig_from_world,
+                                 const double* sensor_from_rig, const double* params, const double* xy,
+                                 double* residuals, double* J_point, double* J_pose, double* J_params,
+                                 double* J_sensor) {
   double J_Rp_quat[12], J_uvw[6], pr[3], pc[3], Rs[9];
   const int P = num_params_of(model);
   quat_rotate_jac(rig_from_world, point, pr, J_pose ? J_Rp_quat : NULL);
@@ -552,8 +578,9 @@ BAO_API int bao_rig_reproj_error(int model, const double* point, const double* r
   for (int r = 0; r < 3; ++r)
     pc[r] = Rs[3 * r] * pr[0] + Rs[3 * r + 1] * pr[1] + Rs[3 * r + 2] * pr[2] + sensor_from_rig[4 + r];
   if (!img_from_cam_jac(model, params, pc[0], pc[1], pc[2], &residuals[0], &residuals[1],
-                        J_params, (J_point || J_pose) ? J_uvw : NULL)) {
+                        J_params, (J_point || J_pose || J_sensor) ? J_uvw : NULL)) {
     residuals[0] = residuals[1] = 0.0;
+    if (J_sensor) memset(J_sensor, 0, sizeof(double) * 14);
     if (J_pose) memset(J_pose, 0, sizeof(double) * 14);
     if (J_point) memset(J_point, 0, sizeof(double) * 6);
     if (J_params) memset(J_params, 0, sizeof(double) * 2 * P);
@@ -561,6 +588,16 @@ BAO_API int bao_rig_reproj_error(int model, const double* point, const double* r
   }
   residuals[0] -= xy[0];
   residuals[1] -= xy[1];
+  if (J_sensor) {
+    double J_Rs_quat[12], tmp[3];
+    quat_rotate_jac(sensor_from_rig, pr, tmp, J_Rs_quat);
+    for (int r = 0; r < 2; ++r) {
+      for (int c = 0; c < 4; ++c)
+        J_sensor[7 * r + c] = J_uvw[3 * r] * J_Rs_quat[c] + J_uvw[3 * r + 1] * J_Rs_quat[4 + c] +
+                              J_uvw[3 * r + 2] * J_Rs_quat[8 + c];
+      for (int c = 0; c < 3; ++c) J_sensor[7 * r + 4 + c] = J_uvw[3 * r + c];
+    }
+  }
   if (J_point || J_pose) {
     double Jr[6]; /* J_uvw * R_s: derivative w.r.t. the point in the rig frame */
     for (int r = 0; r < 2; ++r)
@@ -663,7 +700,7 @@ static void quat_plus_jac(const double* q, double J[12]) {
 /* Program: tangent-space layout of the variable blocks                        */
 /* ------------------------------------------------------------------------- */
 
-#define MAX_CB 14 /* max tangent width of the camera-side blocks seen by one residual: 6 + P_t (P_t <= 8) */
+#define MAX_CB 20 /* max tangent width of the camera-side blocks seen by one residual: 6 + P_t (P_t <= 8) + 6 */
 
 typedef struct {
   const bao_problem* p;
@@ -676,18 +713,20 @@ typedef struct {
   int* cam_off;        /* [num_cams] */
   int* cam_dim;
   int* cam_var;        /* [num_cams][12] indices of variable params */
+  int* sens_off;       /* [num_sensors] offset of a variable sensor_from_rig (6 wide), -1 const */
+  const double* sensors; /* sensor_from_rig values the linearisation reads (current or candidate) */
   int* point_off;      /* [num_points] offset into point-side vector (3 each), -1 const */
   int n_c, n_p;        /* sizes of camera-side / point-side tangent vectors */
   /* CSR by point and by camera-side block of active observation slots */
   int64_t *pt_ptr, *pt_idx;
   int n_blk;
-  int *blk_off, *blk_dim, *blk_kind; /* kind 0: pose block, 1: intrinsics block */
+  int *blk_off, *blk_dim, *blk_kind; /* kind 0: pose block, 1: intrinsics block, 2: sensor_from_rig block */
   int64_t *blk_ptr, *blk_idx;
 } program;
 
 static void program_free(program* g) {
   free(g->obs); free(g->pose_off); free(g->pose_dim); free(g->cam_off); free(g->cam_dim);
-  free(g->cam_var); free(g->point_off); free(g->pt_ptr); free(g->pt_idx);
+  free(g->cam_var); free(g->point_off); free(g->pt_ptr); free(g->pt_idx); free(g->sens_off);
   free(g->blk_off); free(g->blk_dim); free(g->blk_kind); free(g->blk_ptr); free(g->blk_idx);
 }
 
@@ -711,12 +750,19 @@ static void program_build(program* g, const bao_problem* p) {
       if (!p->cam_const[(size_t)k * BAO_CAM_STRIDE + j]) cam_nvar[k]++;
   }
   g->obs = (int64_t*)malloc(sizeof(int64_t) * (p->num_obs + 1));
+  const int ns = p->num_sensors > 0 ? p->num_sensors : 0;
+  uint8_t* sens_used = (uint8_t*)calloc((size_t)ns + 1, 1);
+  g->sens_off = (int*)malloc(sizeof(int) * ((size_t)ns + 1));
+  g->sensors = p->sensors;
   for (int64_t o = 0; o < p->num_obs; ++o) {
     const int pi = p->obs_pose[o], ci = p->obs_cam[o], xi = p->obs_point[o];
-    const int var = (!p->pose_const[pi]) || cam_nvar[ci] > 0 || (!p->point_const[xi]);
+    const int si = p->obs_sensor ? p->obs_sensor[o] : -1;
+    const int sens_var = si >= 0 && p->sensor_const && !p->sensor_const[si];
+    const int var = (!p->pose_const[pi]) || cam_nvar[ci] > 0 || (!p->point_const[xi]) || sens_var;
     if (!var) continue; /* all blocks constant: not part of the reduced program */
     g->obs[g->n_obs++] = o;
     pose_used[pi] = cam_used[ci] = point_used[xi] = 1;
+    if (sens_var) sens_used[si] = 1;
   }
   int off = 0;
   for (int i = 0; i < p->num_poses; ++i) {
@@ -734,6 +780,11 @@ static void program_build(program* g, const bao_problem* p) {
     g->cam_dim[k] = d;
     g->cam_off[k] = off;
     off += d;
+  }
+  for (int k = 0; k < ns; ++k) {
+    if (!sens_used[k]) { g->sens_off[k] = -1; continue; }
+    g->sens_off[k] = off;
+    off += 6;
   }
   g->n_c = off;
   int poff = 0;
@@ -755,9 +806,10 @@ static void program_build(program* g, const bao_problem* p) {
   }
   free(fill);
   /* camera-side blocks and their observation lists */
-  g->blk_off = (int*)malloc(sizeof(int) * (p->num_poses + p->num_cams + 1));
-  g->blk_dim = (int*)malloc(sizeof(int) * (p->num_poses + p->num_cams + 1));
-  g->blk_kind = (int*)malloc(sizeof(int) * (p->num_poses + p->num_cams + 1));
+  g->blk_off = (int*)malloc(sizeof(int) * ((size_t)p->num_poses + p->num_cams + ns + 1));
+  g->blk_dim = (int*)malloc(sizeof(int) * ((size_t)p->num_poses + p->num_cams + ns + 1));
+  g->blk_kind = (int*)malloc(sizeof(int) * ((size_t)p->num_poses + p->num_cams + ns + 1));
+  int* blk_of_sens = (int*)malloc(sizeof(int) * ((size_t)ns + 1));
   int* blk_of_pose = (int*)malloc(sizeof(int) * (p->num_poses + 1));
   int* blk_of_cam = (int*)malloc(sizeof(int) * (p->num_cams + 1));
   for (int i = 0; i < p->num_poses; ++i) {
@@ -772,22 +824,34 @@ static void program_build(program* g, const bao_problem* p) {
     blk_of_cam[k] = g->n_blk;
     g->blk_off[g->n_blk] = g->cam_off[k]; g->blk_dim[g->n_blk] = g->cam_dim[k]; g->blk_kind[g->n_blk++] = 1;
   }
+  for (int k = 0; k < ns; ++k) {
+    blk_of_sens[k] = -1;
+    if (g->sens_off[k] < 0) continue;
+    blk_of_sens[k] = g->n_blk;
+    g->blk_off[g->n_blk] = g->sens_off[k]; g->blk_dim[g->n_blk] = 6; g->blk_kind[g->n_blk++] = 2;
+  }
   g->blk_ptr = (int64_t*)calloc((size_t)g->n_blk + 2, sizeof(int64_t));
   for (int64_t a = 0; a < g->n_obs; ++a) {
     const int bp = blk_of_pose[p->obs_pose[g->obs[a]]], bc = blk_of_cam[p->obs_cam[g->obs[a]]];
+    const int si = p->obs_sensor ? p->obs_sensor[g->obs[a]] : -1;
+    const int bs = si >= 0 ? blk_of_sens[si] : -1;
     if (bp >= 0) g->blk_ptr[bp + 1]++;
     if (bc >= 0) g->blk_ptr[bc + 1]++;
+    if (bs >= 0) g->blk_ptr[bs + 1]++;
   }
   for (int b = 0; b < g->n_blk; ++b) g->blk_ptr[b + 1] += g->blk_ptr[b];
   g->blk_idx = (int64_t*)malloc(sizeof(int64_t) * (g->blk_ptr[g->n_blk] + 1));
   int64_t* bfill = (int64_t*)calloc((size_t)g->n_blk + 1, sizeof(int64_t));
   for (int64_t a = 0; a < g->n_obs; ++a) {
     const int bp = blk_of_pose[p->obs_pose[g->obs[a]]], bc = blk_of_cam[p->obs_cam[g->obs[a]]];
+    const int si = p->obs_sensor ? p->obs_sensor[g->obs[a]] : -1;
+    const int bs = si >= 0 ? blk_of_sens[si] : -1;
     if (bp >= 0) g->blk_idx[g->blk_ptr[bp] + bfill[bp]++] = a;
     if (bc >= 0) g->blk_idx[g->blk_ptr[bc] + bfill[bc]++] = a;
+    if (bs >= 0) g->blk_idx[g->blk_ptr[bs] + bfill[bs]++] = a;
   }
-  free(bfill); free(blk_of_pose); free(blk_of_cam);
-  free(pose_used); free(cam_used); free(point_used); free(cam_nvar);
+  free(bfill); free(blk_of_pose); free(blk_of_cam); free(blk_of_sens);
+  free(pose_used); free(cam_used); free(point_used); free(cam_nvar); free(sens_used);
 }
 
 /* OpenMP only pays off on large problems (and a 128-thread team spinning on a 40-point loop
@@ -798,10 +862,16 @@ static void program_build(program* g, const bao_problem* p) {
 typedef struct {
   double r[2];          /* residual (loss-corrected when the Jacobian was requested) */
   double cost;          /* 1/2 rho(|r|^2) of the uncorrected residual */
-  double Jc[2][MAX_CB]; /* pose tangent columns then intrinsics tangent columns */
+  double Jc[2][MAX_CB]; /* pose tangent columns, intrinsics tangent columns, sensor_from_rig tangent columns */
   double Jp[2][3];
-  int pose_dim, cam_dim; /* widths inside Jc */
+  int pose_dim, cam_dim, sens_dim; /* widths inside Jc */
+  int so;                          /* tangent offset of the sensor block, -1 */
 } lin_obs;
+
+/* first column of block kind `kind` inside lin_obs::Jc */
+static inline int lin_base(const lin_obs* L, int kind) {
+  return kind == 0 ? 0 : (kind == 1 ? L->pose_dim : L->pose_dim + L->cam_dim);
+}
 
 static void linearize_obs(const program* g, const double* poses, const double* cams,
                           const double* points, int64_t a, lin_obs* L, int want_jac) {
@@ -809,12 +879,15 @@ static void linearize_obs(const program* g, const double* poses, const double* c
   const int64_t o = g->obs[a];
   const int pi = p->obs_pose[o], ci = p->obs_cam[o], xi = p->obs_point[o];
   const int model = p->cam_model[ci];
-  double Jpt[6], Jpose[14], Jpar[24];
+  double Jpt[6], Jpose[14], Jpar[24], Jsens[14];
   const int si = p->obs_sensor ? p->obs_sensor[o] : -1;
+  L->so = si >= 0 ? g->sens_off[si] : -1;
+  L->sens_dim = L->so >= 0 ? 6 : 0;
   if (si >= 0)
-    bao_rig_reproj_error(model, points + 3 * (size_t)xi, poses + 7 * (size_t)pi, p->sensors + 7 * (size_t)si,
-                         cams + (size_t)ci * BAO_CAM_STRIDE, p->obs_xy + 2 * o, L->r,
-                         want_jac ? Jpt : NULL, want_jac ? Jpose : NULL, want_jac ? Jpar : NULL);
+    rig_reproj_error_full(model, points + 3 * (size_t)xi, poses + 7 * (size_t)pi, g->sensors + 7 * (size_t)si,
+                          cams + (size_t)ci * BAO_CAM_STRIDE, p->obs_xy + 2 * o, L->r,
+                          want_jac ? Jpt : NULL, want_jac ? Jpose : NULL, want_jac ? Jpar : NULL,
+                          (want_jac && L->so >= 0) ? Jsens : NULL);
   else
     bao_reproj_error(model, points + 3 * (size_t)xi, poses + 7 * (size_t)pi,
                      cams + (size_t)ci * BAO_CAM_STRIDE, p->obs_xy + 2 * o, L->r,
@@ -840,6 +913,7 @@ static void linearize_obs(const program* g, const double* poses, const double* c
     }
     BAO_CORRECT(Jpt, 3, 3)
     BAO_CORRECT(Jpose, 7, 7)
+    if (L->so >= 0) { BAO_CORRECT(Jsens, 7, 7) }
     { const int P_ = num_params_of(model); BAO_CORRECT(Jpar, P_, P_) }
 #undef BAO_CORRECT
     L->r[0] *= residual_scaling;
@@ -872,6 +946,18 @@ static void linearize_obs(const program* g, const double* poses, const double* c
       for (int d = 0; d < L->cam_dim; ++d)
         L->Jc[r][L->pose_dim + d] = Jpar[P * r + g->cam_var[(size_t)ci * BAO_CAM_STRIDE + d]];
   }
+  if (L->so >= 0) {
+    double PJ[12];
+    quat_plus_jac(g->sensors + 7 * (size_t)si, PJ);
+    const int base = L->pose_dim + L->cam_dim;
+    for (int r = 0; r < 2; ++r) {
+      for (int c = 0; c < 3; ++c) {
+        L->Jc[r][base + c] = Jsens[7 * r + 0] * PJ[c] + Jsens[7 * r + 1] * PJ[3 + c] +
+                             Jsens[7 * r + 2] * PJ[6 + c] + Jsens[7 * r + 3] * PJ[9 + c];
+        L->Jc[r][base + 3 + c] = Jsens[7 * r + 4 + c];
+      }
+    }
+  }
   if (g->point_off[xi] >= 0)
     for (int r = 0; r < 2; ++r)
       for (int c = 0; c < 3; ++c) L->Jp[r][c] = Jpt[3 * r + c];
@@ -890,6 +976,19 @@ static double evaluate_cost(const program* g, const double* poses, const double*
 }
 
 /* x_plus = Plus(x, delta) for every variable block */
+/* x_plus of the variable sensor_from_rig blocks: Plus() of a full pose block */
+static void apply_step_sensors(const program* g, const double* dc, const double* sensors, double* nsensors) {
+  const bao_problem* p = g->p;
+  if (p->num_sensors <= 0) return;
+  memcpy(nsensors, sensors, sizeof(double) * 7 * (size_t)p->num_sensors);
+  for (int k = 0; k < p->num_sensors; ++k) {
+    if (g->sens_off[k] < 0) continue;
+    const double* d = dc + g->sens_off[k];
+    bao_quat_plus(sensors + 7 * (size_t)k, d, nsensors + 7 * (size_t)k);
+    for (int c = 0; c < 3; ++c) nsensors[7 * (size_t)k + 4 + c] += d[3 + c];
+  }
+}
+
 static void apply_step(const program* g, const double* dc, const double* dp, const double* poses,
                        const double* cams, const double* points, double* nposes, double* ncams,
                        double* npoints) {
@@ -951,6 +1050,7 @@ static inline void gather_c(const program* g, const lin_obs* L, int po, int co, 
                             double* xc) {
   for (int d = 0; d < L->pose_dim; ++d) xc[d] = x[po + d];
   for (int d = 0; d < L->cam_dim; ++d) xc[L->pose_dim + d] = x[co + d];
+  for (int d = 0; d < L->sens_dim; ++d) xc[L->pose_dim + L->cam_dim + d] = x[L->so + d];
 }
 
 static void invert_sym(const double* A, int n, double* Ainv) {
@@ -989,7 +1089,7 @@ static void schur_multiply(const linsys* s, const double* x, double* y, double* 
       cam_offsets(g, a, &po, &co);
       double xc[MAX_CB];
       gather_c(g, L, po, co, x, xc);
-      const int w = L->pose_dim + L->cam_dim;
+      const int w = L->pose_dim + L->cam_dim + L->sens_dim;
       for (int r = 0; r < 2; ++r) {
         double jx = 0.0;
         for (int d = 0; d < w; ++d) jx += L->Jc[r][d] * xc[d];
@@ -1011,12 +1111,12 @@ static void schur_multiply(const linsys* s, const double* x, double* y, double* 
       const lin_obs* L = &s->L[a];
       int po, co;
       cam_offsets(g, a, &po, &co);
-      const int w = L->pose_dim + L->cam_dim;
+      const int w = L->pose_dim + L->cam_dim + L->sens_dim;
       double xc[MAX_CB];
       gather_c(g, L, po, co, x, xc);
       const int xi = p->obs_point[g->obs[a]];
       const double* u = g->point_off[xi] >= 0 ? tmp_p + g->point_off[xi] : NULL;
-      const int base = kind == 0 ? 0 : L->pose_dim;
+      const int base = lin_base(L, kind);
       for (int r = 0; r < 2; ++r) {
         double v = 0.0;
         for (int d = 0; d < w; ++d) v += L->Jc[r][d] * xc[d];
@@ -1169,6 +1269,10 @@ BAO_API int bao_solve(bao_problem* p, const bao_options* opt, bao_result* res) {
   double* ws = (double*)malloc(sizeof(double) * ((size_t)5 * nc + np + 8));
   double* Mblk = (double*)calloc(moff + 1, sizeof(double));
   double* nposes = (double*)malloc(sizeof(double) * 7 * (size_t)p->num_poses + 8);
+  /* candidate values of the variable sensor_from_rig blocks (NULL: none is variable) */
+  double* nsens = NULL;
+  for (int k = 0; k < p->num_sensors; ++k)
+    if (g.sens_off[k] >= 0 && !nsens) nsens = (double*)malloc(sizeof(double) * 7 * (size_t)p->num_sensors + 8);
   double* ncams = (double*)malloc(sizeof(double) * BAO_CAM_STRIDE * (size_t)p->num_cams + 8);
   double* npoints = (double*)malloc(sizeof(double) * 3 * (size_t)p->num_points + 8);
 
@@ -1198,7 +1302,7 @@ BAO_API int bao_solve(bao_problem* p, const bao_options* opt, bao_result* res) {
         double ga[MAX_CB] = {0}, da[MAX_CB] = {0};
         for (int64_t k = g.blk_ptr[b]; k < g.blk_ptr[b + 1]; ++k) {
           const lin_obs* L = &s.L[g.blk_idx[k]];
-          const int base = kind == 0 ? 0 : L->pose_dim;
+          const int base = lin_base(L, kind);
           for (int r = 0; r < 2; ++r)
             for (int d = 0; d < dim; ++d) { const double v = L->Jc[r][base + d]; ga[d] += v * L->r[r]; da[d] += v * v; }
         }
@@ -1222,6 +1326,10 @@ BAO_API int bao_solve(bao_problem* p, const bao_options* opt, bao_result* res) {
         for (int i = 0; i < np; ++i) dp[i] = -gp[i];
         apply_step(&g, dc, dp, p->poses, p->cams, p->points, nposes, ncams, npoints);
         double gmax = 0.0;
+        if (nsens) {
+          apply_step_sensors(&g, dc, p->sensors, nsens);
+          for (size_t i = 0; i < 7 * (size_t)p->num_sensors; ++i) gmax = fmax(gmax, fabs(nsens[i] - p->sensors[i]));
+        }
         for (size_t i = 0; i < 7 * (size_t)p->num_poses; ++i) gmax = fmax(gmax, fabs(nposes[i] - p->poses[i]));
         for (size_t i = 0; i < BAO_CAM_STRIDE * (size_t)p->num_cams; ++i) gmax = fmax(gmax, fabs(ncams[i] - p->cams[i]));
         for (size_t i = 0; i < 3 * (size_t)p->num_points; ++i) gmax = fmax(gmax, fabs(npoints[i] - p->points[i]));
@@ -1242,6 +1350,7 @@ BAO_API int bao_solve(bao_problem* p, const bao_options* opt, bao_result* res) {
         for (int r = 0; r < 2; ++r) {
           for (int d = 0; d < L->pose_dim; ++d) L->Jc[r][d] *= scale_c[po + d];
           for (int d = 0; d < L->cam_dim; ++d) L->Jc[r][L->pose_dim + d] *= scale_c[co + d];
+          for (int d = 0; d < L->sens_dim; ++d) L->Jc[r][L->pose_dim + L->cam_dim + d] *= scale_c[L->so + d];
           if (pto >= 0) for (int c2 = 0; c2 < 3; ++c2) L->Jp[r][c2] *= scale_p[pto + c2];
         }
       }
@@ -1280,7 +1389,7 @@ BAO_API int bao_solve(bao_problem* p, const bao_options* opt, bao_result* res) {
       for (int64_t k = g.blk_ptr[b]; k < g.blk_ptr[b + 1]; ++k) {
         const int64_t a1 = g.blk_idx[k];
         const lin_obs* L1 = &s.L[a1];
-        const int b1 = kind == 0 ? 0 : L1->pose_dim;
+        const int b1 = lin_base(L1, kind);
         for (int r = 0; r < 2; ++r)
           for (int x = 0; x < dim; ++x)
             for (int y = 0; y < dim; ++y) M[x * dim + y] += L1->Jc[r][b1 + x] * L1->Jc[r][b1 + y];
@@ -1295,9 +1404,9 @@ BAO_API int bao_solve(bao_problem* p, const bao_options* opt, bao_result* res) {
         for (int64_t k2 = g.pt_ptr[j]; k2 < g.pt_ptr[j + 1]; ++k2) {
           const int64_t a2 = g.pt_idx[k2];
           int po2, co2; cam_offsets(&g, a2, &po2, &co2);
-          if ((kind == 0 ? po2 : co2) != off) continue;
           const lin_obs* L2 = &s.L[a2];
-          const int b2 = kind == 0 ? 0 : L2->pose_dim;
+          if ((kind == 0 ? po2 : (kind == 1 ? co2 : L2->so)) != off) continue;
+          const int b2 = lin_base(L2, kind);
           for (int y = 0; y < dim; ++y) {
             double W2[3];
             for (int c = 0; c < 3; ++c) W2[c] = L2->Jc[0][b2 + y] * L2->Jp[0][c] + L2->Jc[1][b2 + y] * L2->Jp[1][c];
@@ -1329,7 +1438,7 @@ BAO_API int bao_solve(bao_problem* p, const bao_options* opt, bao_result* res) {
           const lin_obs* L = &s.L[a];
           const int pto = g.point_off[p->obs_point[g.obs[a]]];
           if (pto < 0) continue;
-          const int base = kind == 0 ? 0 : L->pose_dim;
+          const int base = lin_base(L, kind);
           for (int r = 0; r < 2; ++r) {
             const double v = L->Jp[r][0] * u[pto] + L->Jp[r][1] * u[pto + 1] + L->Jp[r][2] * u[pto + 2];
             for (int d = 0; d < dim; ++d) acc[d] -= L->Jc[r][base + d] * v;
@@ -1351,7 +1460,7 @@ BAO_API int bao_solve(bao_problem* p, const bao_options* opt, bao_result* res) {
         int po, co; cam_offsets(&g, a, &po, &co);
         double xc[MAX_CB];
         gather_c(&g, L, po, co, dc, xc);
-        const int w = L->pose_dim + L->cam_dim;
+        const int w = L->pose_dim + L->cam_dim + L->sens_dim;
         for (int r = 0; r < 2; ++r) {
           double jx = 0.0;
           for (int d = 0; d < w; ++d) jx += L->Jc[r][d] * xc[d];
@@ -1372,7 +1481,7 @@ BAO_API int bao_solve(bao_problem* p, const bao_options* opt, bao_result* res) {
       const int pto = g.point_off[p->obs_point[g.obs[a]]];
       double xc[MAX_CB];
       gather_c(&g, L, po, co, dc, xc);
-      const int w = L->pose_dim + L->cam_dim;
+      const int w = L->pose_dim + L->cam_dim + L->sens_dim;
       for (int r = 0; r < 2; ++r) {
         double m = 0.0;
         for (int d = 0; d < w; ++d) m += L->Jc[r][d] * xc[d];
@@ -1392,13 +1501,19 @@ BAO_API int bao_solve(bao_problem* p, const bao_options* opt, bao_result* res) {
       double* dps = ws + nc;
       for (int i = 0; i < np; ++i) dps[i] = dp[i] * scale_p[i];
       apply_step(&g, ws, dps, p->poses, p->cams, p->points, nposes, ncams, npoints);
+      if (nsens) {
+        apply_step_sensors(&g, ws, p->sensors, nsens);
+        g.sensors = nsens;  /* the candidate reads the candidate sensor_from_rig values */
+      }
       new_cost = evaluate_cost(&g, nposes, ncams, npoints);
+      g.sensors = p->sensors;
       const double rho = (cost - new_cost) / model_change;
       if (rho > opt->min_relative_decrease) {
         accepted = 1;
         memcpy(p->poses, nposes, sizeof(double) * 7 * (size_t)p->num_poses);
         memcpy(p->cams, ncams, sizeof(double) * BAO_CAM_STRIDE * (size_t)p->num_cams);
         memcpy(p->points, npoints, sizeof(double) * 3 * (size_t)p->num_points);
+        if (nsens) memcpy(p->sensors, nsens, sizeof(double) * 7 * (size_t)p->num_sensors);
         const double t = 2.0 * rho - 1.0;
         radius = radius / fmax(1.0 / 3.0, 1.0 - t * t * t);
         radius = fmin(opt->max_trust_region_radius, radius);
@@ -1424,6 +1539,13 @@ BAO_API int bao_solve(bao_problem* p, const bao_options* opt, bao_result* res) {
   }
   res->final_cost = evaluate_cost(&g, p->poses, p->cams, p->points);
   res->lm_seconds = now_s() - t_start;
+  for (int k = 0; k < p->num_sensors && nsens; ++k) {
+    if (g.sens_off[k] < 0) continue;
+    double* q = p->sensors + 7 * (size_t)k;
+    const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    for (int c = 0; c < 4; ++c) q[c] /= n;
+  }
+  free(nsens);
   /* quaternions are re-normalised when written back (bundle_adjustment_ceres.cc:491,508) */
   for (int i = 0; i < p->num_poses; ++i) {
     if (g.pose_off[i] < 0) continue;

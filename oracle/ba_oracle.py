@@ -76,6 +76,23 @@ def rig_reproj_error(model, point, rig_from_world, sensor_from_rig, params, xy, 
     return r, Jpt, Jpose, Jpar
 
 
+def rig_reproj_error_sensor(model, point, rig_from_world, sensor_from_rig, params, xy):
+    """RigReprojErrorCostFunctor (variable sensor_from_rig): also the 2 x 7 Jacobian w.r.t. it."""
+    point = np.ascontiguousarray(point, np.float64)
+    pose = np.ascontiguousarray(rig_from_world, np.float64)
+    sens = np.ascontiguousarray(sensor_from_rig, np.float64)
+    prm = np.zeros(12)
+    prm[: len(params)] = params
+    xy = np.ascontiguousarray(xy, np.float64)
+    P = NUM_PARAMS[model]
+    r = np.zeros(2)
+    Jpt, Jpose, Jpar, Jsens = np.zeros((2, 3)), np.zeros((2, 7)), np.zeros((2, P)), np.zeros((2, 7))
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    lib().bao_rig_reproj_error_sensor(C.c_int(model), vp(point), vp(pose), vp(sens), vp(prm), vp(xy), vp(r),
+                                      vp(Jpt), vp(Jpose), vp(Jpar), vp(Jsens))
+    return r, Jpt, Jpose, Jpar, Jsens
+
+
 def loss(loss_type, scale, s):
     """ceres::LossFunction::Evaluate: (rho, rho', rho'') at s = |r|^2."""
     rho = np.zeros(3)

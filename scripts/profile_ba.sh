@@ -26,7 +26,7 @@ import csv, glob, json, collections
 agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
 for f in glob.glob("$OUT/pmc_p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        name = r["Kernel_Name"].split("(")[0].replace("(anonymous namespace)::", "").replace("void ", "").strip()
+        name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].strip()
         a = agg[name][r["Counter_Name"]]
         a[0] += float(r["Counter_Value"]); a[1] += 1
 out = {k: {c: {"avg_per_launch": v[0] / max(v[1], 1), "launches": v[1]} for c, v in d.items()} for k, d in agg.items()}

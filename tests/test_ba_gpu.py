@@ -185,7 +185,7 @@ def test_backend_interface_reference_cases():
 
 def test_error_behaviour():
     fp = _flat(4, 20, 3, seed=1)
-    fp.cam_model[0] = 7  # unsupported model id (FOV)
+    fp.cam_model[0] = 6  # unsupported model id (FULL_OPENCV: 12 parameters)
     with pytest.raises(RuntimeError, match="unsupported camera model"):
         est.solve_flat(fp, gpu_index=0)
     fp = _flat(4, 20, 3, seed=1)
@@ -356,6 +356,43 @@ def test_rig_frames_match_oracle():
     _assert_close(a, want, b, got)
     assert got.final_cost < 0.2 * got.initial_cost
     assert np.array_equal(b.sensors, fp.sensors)       # constant input
+
+
+def test_variable_sensor_from_rig_matches_oracle():
+    """refine_sensor_from_rig (the reference's default): every non-reference sensor_from_rig is a
+    6-dimensional block of its own (RigReprojErrorCostFunctor, reprojection_error.h:344-384; block
+    kind 2: own Jacobian columns, Gram block, PCG vector entries). Same optimum and trajectory as the
+    oracle, the sensor blocks move and stay unit quaternions, plus a robust loss on top."""
+    rec = scene.SynthesizeDataset(scene.SyntheticDatasetOptions(
+        num_rigs=2, num_cameras_per_rig=3, num_frames_per_rig=5, num_points3D=200,
+        num_points2D_without_point3D=0), seed=5)
+    scene.SynthesizeNoise(scene.SyntheticNoiseOptions(0.02, 0.5, 0.05, 0.5), rec, seed=6)
+    for rig in rec.rigs.values():
+        for cid in rig.sensors:
+            rig.sensors[cid] = rig.sensors[cid] + np.array([0, 0, 0, 0, 0.03, -0.02, 0.01])
+    rec.UpdateCamFromWorld()
+    fp = _adapter_problem(rec)
+    assert fp.sensor_const.tolist() == [0, 0, 0, 0]
+    (a, want), (b, got) = _both(fp, **TIGHT)
+    assert want.IsSolutionUsable() and got.IsSolutionUsable()
+    assert got.num_effective_parameters == want.num_effective_parameters
+    _assert_close(a, want, b, got)
+    np.testing.assert_allclose(b.sensors, a.sensors, atol=1e-6)
+    assert not np.array_equal(b.sensors, fp.sensors)
+    np.testing.assert_allclose(np.linalg.norm(b.sensors[:, :4], axis=1), 1.0, atol=1e-12)
+    (a, want), (b, got) = _both(fp, loss_type=int(est.LossFunctionType.CAUCHY), loss_scale=1.0, **TIGHT)
+    _assert_close(a, want, b, got, cost_rtol=1e-7, param_atol=1e-5, traj_rtol=1e-5)
+    np.testing.assert_allclose(b.sensors, a.sensors, atol=1e-5)
+    # a constant frame observed through a variable sensor (the "rare" case of :792-795)
+    cfg = est.BundleAdjustmentConfig()
+    for i in rec.RegImageIds():
+        cfg.AddImage(i)
+    cfg.FixGauge(est.BundleAdjustmentGauge.THREE_POINTS)
+    cfg.SetConstantRigFromWorldPose(next(iter(rec.frames)))
+    fp2 = est.flatten(est.BundleAdjustmentOptions(), cfg, rec)
+    (a, want), (b, got) = _both(fp2, **TIGHT)
+    _assert_close(a, want, b, got)
+    np.testing.assert_allclose(b.sensors, a.sensors, atol=1e-6)
 
 
 def test_radial_model_matches_oracle():

@@ -358,13 +358,60 @@ def test_two_view_rig_counts():
     fp = ba.problem_
     assert len(fp.poses) == 2 and fp.sensors.shape == (1, 7)          # two frames, one non-reference sensor
     assert (fp.obs_sensor >= 0).sum() == 200 * 2 // 2                  # the observations of camera 2
-    # variable sensor_from_rig is rejected like CasparBundleAdjuster does (bundle_adjustment_caspar.cc:186-209)
-    with pytest.raises(NotImplementedError):
-        est.BundleAdjuster(est.BundleAdjustmentOptions(), _config(rec), rec, solve_fn=ba_oracle.solve_fn)
-    # ... unless the config holds that sensor constant (ManyViewRigConstantSensorFromRig, :434-489)
+    # the config can hold that sensor constant (ManyViewRigConstantSensorFromRig, :434-489)
     cfg = _config(rec, est.BundleAdjustmentGauge.THREE_POINTS)
     cfg.SetConstantSensorFromRigPose(2)
-    est.BundleAdjuster(est.BundleAdjustmentOptions(), cfg, rec, solve_fn=ba_oracle.solve_fn)
+    held = est.BundleAdjuster(est.BundleAdjustmentOptions(), cfg, rec.copy(), solve_fn=ba_oracle.solve_fn)
+    assert held.problem_.sensor_const.all()
+    # the reference's own TwoViewRig (:323-376): refine_sensor_from_rig (the default) makes the
+    # sensor_from_rig of camera 2 a parameter block: 800 residuals, 313 effective parameters, and it moves
+    rec2 = rec.copy()
+    before = rec2.rigs[1].sensors[2].copy()
+    ba2 = est.BundleAdjuster(est.BundleAdjustmentOptions(), _config(rec2, est.BundleAdjustmentGauge.THREE_POINTS),
+                             rec2, solve_fn=ba_oracle.solve_fn)
+    assert ba2.problem_.sensor_const.tolist() == [0]
+    s2 = ba2.Solve()
+    assert s2.IsSolutionUsable() and s2.num_residuals == 800 and s2.num_effective_parameters == 313
+    assert not np.array_equal(rec2.rigs[1].sensors[2], before)
+    assert abs(np.linalg.norm(rec2.rigs[1].sensors[2][:4]) - 1.0) < 1e-12
+    assert s2.final_cost <= summary.final_cost * (1 + 1e-9)      # six more degrees of freedom
+
+
+def test_rig_residual_sensor_jacobian():
+    """RigReprojErrorCostFunctor (reprojection_error.h:344-384): analytic Jacobian w.r.t. the
+    sensor_from_rig block against central differences; the value equals the constant-rig residual."""
+    rng = np.random.default_rng(5)
+    for model, params in ((scene.SIMPLE_RADIAL, [600.0, 320, 240, 0.05]), (scene.OPENCV, [600.0, 610, 320, 240, 0.02, -0.01, 1e-3, -1e-3])):
+        for _ in range(5):
+            q = rng.normal(size=4); q /= np.linalg.norm(q)
+            rig = np.concatenate([q, rng.normal(size=3) * 0.2])
+            qs = np.array([0.05, -0.03, 0.02, 1.0]) + rng.normal(size=4) * 0.01; qs /= np.linalg.norm(qs)
+            sens = np.concatenate([qs, [0.3, -0.1, 0.05]])
+            X = scene.quat_to_rot(q).T @ (np.array([rng.normal() * 0.3, rng.normal() * 0.3, 4.0]) - rig[4:])
+            r, Jpt, Jpose, Jpar, Jsens = ba_oracle.rig_reproj_error_sensor(model, X, rig, sens, params, [1.0, 2.0])
+            r0, Jpt0, Jpose0, Jpar0 = ba_oracle.rig_reproj_error(model, X, rig, sens, params, [1.0, 2.0])
+            assert np.array_equal(r, r0) and np.array_equal(Jpose, Jpose0) and np.array_equal(Jpt, Jpt0)
+            J = np.zeros((2, 7))
+            for i in range(7):
+                h = 1e-6
+                e = np.zeros(7); e[i] = h
+                f = lambda sv: ba_oracle.rig_reproj_error(model, X, rig, sv, params, [1.0, 2.0], want_jac=False)[0]
+                J[:, i] = (f(sens + e) - f(sens - e)) / (2 * h)
+            np.testing.assert_allclose(Jsens, J, rtol=1e-5, atol=1e-5)
+
+
+def test_many_view_rig_refines_sensor_from_rig():
+    """bundle_adjustment_ceres_test.cc ManyViewRig (:378-432): with noise on the sensor_from_rig of
+    the non-reference camera the adjustment brings it back to the ground truth."""
+    gt, rec = _rig_dataset(1, 2, 6, 200, scene.SyntheticNoiseOptions(point2D_stddev=0.3))
+    rig = rec.rigs[1]
+    cid = next(iter(rig.sensors))
+    rig.sensors[cid] = rig.sensors[cid] + np.array([0, 0, 0, 0, 0.05, -0.04, 0.03])
+    rec.UpdateCamFromWorld()
+    ba = est.BundleAdjuster(est.BundleAdjustmentOptions(), _config(rec), rec, solve_fn=ba_oracle.solve_fn)
+    s = ba.Solve()
+    assert s.IsSolutionUsable() and s.final_cost < 0.05 * s.initial_cost
+    np.testing.assert_allclose(rec.rigs[1].sensors[cid][4:], gt.rigs[1].sensors[cid][4:], atol=0.01)
 
 
 def test_many_view_rig_recovers_ground_truth():

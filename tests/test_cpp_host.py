@@ -169,6 +169,9 @@ def _ba_cases():
     scene.SynthesizeNoise(scene.SyntheticNoiseOptions(point2D_stddev=1), rec, seed=1)
     cases.append(("two_view_rig", rec, config(rec, G.THREE_POINTS),
                   est.BundleAdjustmentOptions(refine_sensor_from_rig=False), (800, 307)))
+    # TwoViewRig as the reference runs it (:323-376): sensor_from_rig refined: 800 residuals, 313 parameters
+    cases.append(("two_view_rig_variable_sensor", rec.copy(), config(rec, G.THREE_POINTS),
+                  est.BundleAdjustmentOptions(), (800, 313)))
     # constant frame + constant camera + partially contained tracks + ignored / constant points, CAUCHY loss
     rec = scene.SynthesizeDataset(scene.SyntheticDatasetOptions(num_rigs=2, num_cameras_per_rig=3, num_frames_per_rig=3,
                                                                 num_points3D=80), seed=3)
@@ -207,13 +210,6 @@ def test_ba_host_api_and_flattening_counts(ba_host, tmp_path):
         if known is not None:
             assert (residuals, params) == known
             assert config_residuals == residuals          # config.NumResiduals == problem.NumResiduals
-    # a variable sensor_from_rig is rejected (bundle_adjustment_caspar.cc:186-209 precedent)
-    name, rec, cfg, opts, _ = _ba_cases()[1]
-    opts.refine_sensor_from_rig = True
-    spec = str(tmp_path / "variable_sensor.txt")
-    _write_ba_spec(spec, rec, cfg, opts)
-    r = subprocess.run([ba_host, "counts", spec], capture_output=True, text=True)
-    assert r.returncode == 3 and "sensor_from_rig" in r.stderr
 
 
 @pytest.mark.gpu
