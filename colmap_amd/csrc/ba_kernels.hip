@@ -1576,7 +1576,6 @@ struct Solver {
   // rank sees the gradient of its own points only; with image sharding all vectors are replicated).
   double scalar_max(int slot) {
     if (comm.world == 1 || !comm.by_point) return scalar(slot);
-    if (maxbuf.n < (size_t)comm.world) maxbuf.alloc(comm.world);
     BA_HIP(hipMemsetAsync(maxbuf.p, 0, sizeof(double) * comm.world, st));
     BA_HIP(hipMemcpyAsync(maxbuf.p + comm.rank, scalars.p + slot, sizeof(double), hipMemcpyDeviceToDevice, st));
     comm.allreduce(maxbuf.p, comm.world, st);
@@ -1849,6 +1848,7 @@ struct Solver {
     V.blk_chunk_ptr = blk_chunk_ptr.p; V.cpart = cpart.p;
     V.Jpose = Jpose.p; V.Jcam = Jcam.p; V.Jpt = Jpt.p; V.res = res.p; V.res_p = res_p.p;
     V.scale_c = scale_c.p; V.scale_p = scale_p.p; V.scalars = scalars.p;
+    maxbuf.alloc(std::max(comm.world, 1));
     // uploads / memsets above ran on the NULL stream, the solve runs on a non-blocking stream
     BA_HIP(hipDeviceSynchronize());
     return (int)std::min<int64_t>(n_active_global, 1 << 30);

@@ -1,6 +1,7 @@
 """Depth-map fusion: colmap::mvs::StereoFusion (reference mvs/fusion.{h,cc}) and the
 `colmap stereo_fusion` command (exe/mvs.cc:299-386) on top of the fusion C ABI
-(include/colmap_amd_fusion.h, host code like the reference's).
+(include/colmap_amd_fusion.h -> colmap_amd/csrc/fusion.hip: the traversal, the medians and the
+compaction run on the GPU; there is no CPU path).
 
     python -m colmap_amd.fusion --workspace_path DENSE --output_path DENSE/fused.ply \\
         [--input_type geometric] [--StereoFusion.min_num_pixels 5] ...
@@ -94,14 +95,24 @@ class FusedPoints:
     visibility: List[np.ndarray] = field(default_factory=list)  # image indices per point
 
 
-def fuse(options: StereoFusionOptions, images: Sequence[FusionImage], overlapping_images: Sequence[Sequence[int]]
-         ) -> FusedPoints:
-    """StereoFusion::Run on in-memory inputs (fusion.cc:188-343), single-threaded."""
+class _HipEntryPoints:
+    """The fusion_* entry points of libcolmap_amd.so (include/colmap_amd_fusion.h)."""
+
+    def __init__(self):
+        L = lib()
+        L.fusion_last_error.restype = C.c_char_p
+        L.fusion_num_points.restype = C.c_size_t
+        self.run, self.num_points, self.get_points = L.fusion_run, L.fusion_num_points, L.fusion_get_points
+        self.get_visibility, self.free, self.last_error = L.fusion_get_visibility, L.fusion_free, L.fusion_last_error
+
+
+def fuse(options: StereoFusionOptions, images: Sequence[FusionImage], overlapping_images: Sequence[Sequence[int]],
+         entry_points=None) -> FusedPoints:
+    """StereoFusion::Run on in-memory inputs (fusion.cc:188-343) through fusion_run (HIP kernels).
+    `entry_points` lets the tests hand the identical marshalled structs to the checker in oracle/."""
     if not options.Check():
         raise ValueError("Check failed: options_.Check()")
-    L = lib()
-    L.fusion_last_error.restype = C.c_char_p
-    L.fusion_num_points.restype = C.c_size_t
+    L = entry_points or _HipEntryPoints()
     n = len(images)
     arr = (fusion_image * n)()
     keep = []
@@ -138,22 +149,22 @@ def fuse(options: StereoFusionOptions, images: Sequence[FusionImage], overlappin
     idx = np.array([j for lst in overlapping_images for j in lst], np.int32)
     copt = options.to_c()
     res = C.c_void_p()
-    rc = L.fusion_run(C.byref(copt), C.c_int32(n), arr, ptr.ctypes.data_as(C.c_void_p),
-                      idx.ctypes.data_as(C.c_void_p) if len(idx) else None, C.byref(res))
+    rc = L.run(C.byref(copt), C.c_int32(n), arr, ptr.ctypes.data_as(C.c_void_p),
+               idx.ctypes.data_as(C.c_void_p) if len(idx) else None, C.byref(res))
     if rc != 0:
-        raise RuntimeError(L.fusion_last_error().decode())
+        raise RuntimeError(L.last_error().decode())
     try:
-        m = L.fusion_num_points(res)
+        m = L.num_points(res)
         pts = np.zeros((m, 6), np.float32)
         rgb = np.zeros((m, 3), np.uint8)
-        L.fusion_get_points(res, pts.ctypes.data_as(C.c_void_p), rgb.ctypes.data_as(C.c_void_p))
+        L.get_points(res, pts.ctypes.data_as(C.c_void_p), rgb.ctypes.data_as(C.c_void_p))
         total = C.c_size_t(0)
-        L.fusion_get_visibility(res, None, None, C.byref(total))
+        L.get_visibility(res, None, None, C.byref(total))
         vptr = np.zeros(m + 1, np.int64)
         vidx = np.zeros(max(total.value, 1), np.int32)
-        L.fusion_get_visibility(res, vptr.ctypes.data_as(C.c_void_p), vidx.ctypes.data_as(C.c_void_p), C.byref(total))
+        L.get_visibility(res, vptr.ctypes.data_as(C.c_void_p), vidx.ctypes.data_as(C.c_void_p), C.byref(total))
     finally:
-        L.fusion_free(res)
+        L.free(res)
     vis = [vidx[vptr[k]:vptr[k + 1]].copy() for k in range(m)]
     return FusedPoints(pts[:, :3].copy(), pts[:, 3:].copy(), rgb, vis)
 

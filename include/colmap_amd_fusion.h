@@ -4,9 +4,13 @@
  *
  * Replaces colmap::mvs::StereoFusion::Run / Fuse (reference src/colmap/mvs/fusion.cc:135-524) for
  * inputs that are already in memory: the caller (colmap_amd/fusion.py, the `stereo_fusion` command)
- * does the workspace reading the reference does through mvs::Workspace. Host code, like the
- * reference's: one thread, i.e. the reference's behaviour with StereoFusionOptions::num_threads = 1
- * (with more threads the reference's result depends on the thread interleaving).
+ * does the workspace reading the reference does through mvs::Workspace. The inputs are host buffers
+ * (the reference reads them from the workspace files); the traversal, the medians and the compaction
+ * run on the GPU (colmap_amd/csrc/fusion.hip) and there is no CPU path. The pixels of an image take
+ * their turns in a fixed pseudo-random order instead of row-major (the reference's order depends on its
+ * thread pool unless num_threads = 1); the result is the reference's algorithm run in that order.
+ * Differences: at most 1024 pixels per fused point (max_num_pixels is clamped), visibility lists are
+ * sorted (the reference copies an unordered set).
  */
 #ifndef COLMAP_AMD_FUSION_H_
 #define COLMAP_AMD_FUSION_H_
@@ -63,6 +67,9 @@ int fusion_get_points(const fusion_result* r, float* xyz_normal, uint8_t* rgb);
 /* visibility (fusion.cc:514-517): vis_ptr [n+1], vis_idx [vis_ptr[n]]; pass NULLs to query the total */
 int fusion_get_visibility(const fusion_result* r, int64_t* vis_ptr, int32_t* vis_idx, size_t* total);
 void fusion_free(fusion_result* r);
+/* Counters of the last fusion_run on this process: images fused, their pixels, commit rounds, and
+ * walks summed over the rounds (walks / seeds = average number of turns a pixel needed). */
+void fusion_last_stats(int64_t* images, int64_t* seeds, int64_t* rounds, int64_t* walks);
 const char* fusion_last_error(void);
 
 #ifdef __cplusplus

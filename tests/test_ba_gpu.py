@@ -492,5 +492,8 @@ def _model_matches_oracle(model, params):
     (a, want), (b, got) = _both(fp, gradient_tolerance=1e-10, max_num_iterations=60)
     assert want.IsSolutionUsable() and got.IsSolutionUsable()
     assert got.num_effective_parameters == want.num_effective_parameters
-    _assert_close(a, want, b, got, cost_rtol=1e-7, param_atol=1e-5, traj_rtol=1e-5)
+    # EUCM: alpha and beta trade off along a nearly flat valley at this field of view (both solvers
+    # walk it for all 60 iterations), so the intrinsics agree to fewer digits than the cost does
+    atol = 2e-4 if model == scene.EUCM else 1e-5
+    _assert_close(a, want, b, got, cost_rtol=1e-7, param_atol=atol, traj_rtol=1e-5)
     assert got.final_cost < 0.2 * got.initial_cost

@@ -1,11 +1,16 @@
-"""Depth-map fusion (colmap_amd/fusion.py + colmap_amd/csrc/fusion.cpp) against a pure-Python float32
-restatement of StereoFusion::Fuse (reference mvs/fusion.cc:401-524) and against the ground truth of
-the synthetic renderer. Host code only: no GPU."""
+"""Depth-map fusion.
+
+CPU tests: the checker oracle/fusion_oracle.cpp -- mode 0 (the reference's sequential walk,
+mvs/fusion.cc:401-524) is pinned against a pure-Python float32 restatement; mode 1 (the
+order-independent formulation the HIP kernels implement) against its defining properties, the ground
+truth of the synthetic renderer and mode 0. GPU tests: colmap_amd/csrc/fusion.hip through fusion_run
+equals mode 1 bit for bit."""
 import os
 
 import numpy as np
 import pytest
 
+import fusion_oracle
 from colmap_amd import fusion, mvs, workspace as W
 from pm_common import scene, write_dense_workspace
 
@@ -166,78 +171,194 @@ def _fuse_reference(opt, images, overlap):
     return np.array(pts, f32).reshape(-1, 3), np.array(nrm, f32).reshape(-1, 3), np.array(col, np.uint8).reshape(-1, 3), vis
 
 
-def test_fusion_equals_python_restatement():
-    views = scene(4, 32, 24)
-    images = _images(views)
-    opt = fusion.StereoFusionOptions(min_num_pixels=3, max_reproj_error=1.5, max_depth_error=0.02)
-    got = fusion.fuse(opt, images, _overlap(4))
-    wp, wn, wc, wv = _fuse_reference(opt, _images(views), _overlap(4))
-    assert len(got.xyz) == len(wp) > 50
-    assert np.array_equal(got.xyz, wp) and np.array_equal(got.normal, wn) and np.array_equal(got.rgb, wc)
-    assert all(list(a) == b for a, b in zip(got.visibility, wv))
-    # deterministic
-    again = fusion.fuse(opt, _images(views), _overlap(4))
-    assert np.array_equal(again.xyz, got.xyz)
+def _same(a, b):
+    return (len(a.xyz) == len(b.xyz) and np.array_equal(a.xyz, b.xyz) and np.array_equal(a.normal, b.normal)
+            and np.array_equal(a.rgb, b.rgb) and all(np.array_equal(u, v) for u, v in zip(a.visibility, b.visibility)))
 
 
-def test_fused_points_lie_on_the_ground_truth_surface():
-    views = scene(5, 64, 48)
-    got = fusion.fuse(fusion.StereoFusionOptions(), _images(views), _overlap(5))
-    assert len(got.xyz) > 300
-    np.testing.assert_allclose(np.linalg.norm(got.normal, axis=1), 1.0, atol=1e-5)
-    # every fused point reprojects onto the ground-truth depth of the images that saw it
+def _on_surface(views, got, w, h):
+    """every fused point reprojects onto the ground-truth depth of the images that saw it"""
     checked = 0
     for p, vis in zip(got.xyz, got.visibility):
-        assert len(vis) >= 1 and len(set(vis)) == len(vis)
+        assert len(vis) >= 1 and len(set(vis)) == len(vis) and list(vis) == sorted(vis)
         for i in vis:
             v = views[i]
             pc = np.asarray(v.R, np.float64) @ p + np.asarray(v.T, np.float64)
             px = np.asarray(v.K, np.float64) @ (pc / pc[2])
             c, r = int(round(px[0])), int(round(px[1]))
-            if 1 <= c < 63 and 1 <= r < 47:
+            if 1 <= c < w - 1 and 1 <= r < h - 1:
                 d = v.depth[r - 1:r + 2, c - 1:c + 2]
                 assert np.min(np.abs(d - pc[2]) / pc[2]) < 0.03
                 checked += 1
-    assert checked > 500
-    # each pixel is consumed at most once: fused pixels <= valid pixels
-    assert sum(len(v) for v in got.visibility) <= 5 * len(got.xyz)
+    return checked
 
 
-def test_fusion_options_masks_and_bounding_box():
+# ------------------------------------------------------------------------------------------------
+# the checker (CPU)
+# ------------------------------------------------------------------------------------------------
+
+def test_sequential_oracle_equals_python_restatement():
+    views = scene(4, 32, 24)
+    opt = fusion.StereoFusionOptions(min_num_pixels=3, max_reproj_error=1.5, max_depth_error=0.02)
+    got = fusion_oracle.fuse(opt, _images(views), _overlap(4), mode=0)
+    wp, wn, wc, wv = _fuse_reference(opt, _images(views), _overlap(4))
+    assert len(got.xyz) == len(wp) > 50
+    assert np.array_equal(got.xyz, wp) and np.array_equal(got.normal, wn) and np.array_equal(got.rgb, wc)
+    assert all(list(a) == b for a, b in zip(got.visibility, wv))
+    assert _same(fusion_oracle.fuse(opt, _images(views), _overlap(4), mode=0), got)  # deterministic
+
+
+def test_seed_order_against_ground_truth_and_row_major():
+    """mode 1 (the reference's Fuse, turns in the seed order of fusion.hip): points on the rendered
+    surface, every pixel consumed at most once, and the same cloud as the row-major order up to which
+    pixel of a neighbourhood gets its turn first."""
+    views = scene(5, 64, 48)
+    par = fusion_oracle.fuse(fusion.StereoFusionOptions(), _images(views), _overlap(5), mode=1)
+    seq = fusion_oracle.fuse(fusion.StereoFusionOptions(), _images(views), _overlap(5), mode=0)
+    assert len(par.xyz) > 300
+    np.testing.assert_allclose(np.linalg.norm(par.normal, axis=1), 1.0, atol=1e-5)
+    assert _on_surface(views, par, 64, 48) > 500
+    assert sum(len(v) for v in par.visibility) <= 5 * len(par.xyz)
+    assert abs(len(par.xyz) - len(seq.xyz)) <= 0.15 * len(seq.xyz)
+    # nearest row-major point of every point: within about two pixel footprints (one pixel covers
+    # ~0.3 scene units at the scene depth of ~16)
+    d = np.sqrt(((par.xyz[:, None, :] - seq.xyz[None, :, :]) ** 2).sum(-1)).min(1)
+    assert np.median(d) < 0.15 and np.percentile(d, 95) < 0.6, (np.median(d), np.percentile(d, 95))
+
+
+def test_round_schedule_equals_sequential_turns():
+    """mode 2 simulates fusion.hip's schedule (speculative walks, claim words, closure claims of capped
+    walks, commit rounds) on the CPU: bit-identical to the sequential turns of mode 1 on every case the
+    GPU test runs, in a handful of rounds per image."""
+    import ctypes as C
+    for name in sorted(_CASES):
+        opt, images, overlap = _case(name)
+        want = fusion_oracle.fuse(opt, images, overlap, mode=1)
+        got = fusion_oracle.fuse(opt, images, overlap, mode=2)
+        assert _same(got, want), name
+        rounds, walks = C.c_longlong(), C.c_longlong()
+        fusion_oracle.lib().fuo_last_rounds(C.byref(rounds), C.byref(walks))
+        n_img = sum(1 for im in images if im.used)
+        seeds = sum(im.depth_map.size for im in images if im.used)
+        assert rounds.value <= 8 * n_img and walks.value <= 1.5 * seeds, (name, rounds.value, walks.value, seeds)
+
+
+def test_oracle_options_masks_and_bounding_box():
+    _options_masks_and_bounding_box(lambda o, im, ov: fusion_oracle.fuse(o, im, ov, mode=1))
+    _options_masks_and_bounding_box(lambda o, im, ov: fusion_oracle.fuse(o, im, ov, mode=0))
+
+
+def _options_masks_and_bounding_box(fuse):
     views = scene(4, 48, 36)
-    base = fusion.fuse(fusion.StereoFusionOptions(min_num_pixels=2), _images(views), _overlap(4))
+    base = fuse(fusion.StereoFusionOptions(min_num_pixels=2), _images(views), _overlap(4))
     # a higher minimum support yields a subset-sized result
-    strict = fusion.fuse(fusion.StereoFusionOptions(min_num_pixels=4), _images(views), _overlap(4))
+    strict = fuse(fusion.StereoFusionOptions(min_num_pixels=4), _images(views), _overlap(4))
     assert 0 < len(strict.xyz) < len(base.xyz)
     assert all(len(v) >= 1 for v in strict.visibility)
     # bounding box: no point outside
     lo, hi = (-0.3, -0.3, -10.0), (0.3, 0.3, 10.0)
-    boxed = fusion.fuse(fusion.StereoFusionOptions(min_num_pixels=2, bounding_box=(lo, hi)), _images(views), _overlap(4))
+    boxed = fuse(fusion.StereoFusionOptions(min_num_pixels=2, bounding_box=(lo, hi)), _images(views), _overlap(4))
     assert 0 < len(boxed.xyz) < len(base.xyz)
     assert (boxed.xyz >= np.array(lo, np.float32) - 1e-3).all() and (boxed.xyz <= np.array(hi, np.float32) + 1e-3).all()
     # masking all of image 0 removes it from every visibility list
     imgs = _images(views)
     imgs[0].mask = np.ones(views[0].gray.shape, np.uint8)
-    masked = fusion.fuse(fusion.StereoFusionOptions(min_num_pixels=2), imgs, _overlap(4))
+    masked = fuse(fusion.StereoFusionOptions(min_num_pixels=2), imgs, _overlap(4))
     assert all(0 not in v for v in masked.visibility) and len(masked.xyz) > 0
     # an unused image (missing inputs) is skipped the same way
     imgs = _images(views)
     imgs[0].used = False
-    skipped = fusion.fuse(fusion.StereoFusionOptions(min_num_pixels=2), imgs, _overlap(4))
+    skipped = fuse(fusion.StereoFusionOptions(min_num_pixels=2), imgs, _overlap(4))
     assert all(0 not in v for v in skipped.visibility)
     # non-positive depths are never fused
     imgs = _images(views)
     for im in imgs:
         im.depth_map[:] = 0
-    assert len(fusion.fuse(fusion.StereoFusionOptions(), imgs, _overlap(4)).xyz) == 0
+    assert len(fuse(fusion.StereoFusionOptions(), imgs, _overlap(4)).xyz) == 0
     # option checks (fusion.cc:96-106)
     assert not fusion.StereoFusionOptions(min_num_pixels=10, max_num_pixels=5).Check()
     assert not fusion.StereoFusionOptions(max_traversal_depth=0).Check()
     with pytest.raises(ValueError):
-        fusion.fuse(fusion.StereoFusionOptions(check_num_images=0), _images(views), _overlap(4))
+        fuse(fusion.StereoFusionOptions(check_num_images=0), _images(views), _overlap(4))
     # max_num_pixels caps the support of a point
-    capped = fusion.fuse(fusion.StereoFusionOptions(min_num_pixels=2, max_num_pixels=2), _images(views), _overlap(4))
+    capped = fuse(fusion.StereoFusionOptions(min_num_pixels=2, max_num_pixels=2), _images(views), _overlap(4))
     assert len(capped.xyz) > 0 and max(len(v) for v in capped.visibility) <= 2
+
+
+# ------------------------------------------------------------------------------------------------
+# the HIP path against the checker (bit for bit)
+# ------------------------------------------------------------------------------------------------
+
+_CASES = {
+    "defaults_5x64x48": (5, 64, 48, dict(), {}),
+    "tight_4x32x24": (4, 32, 24, dict(min_num_pixels=3, max_reproj_error=1.5, max_depth_error=0.02), {}),
+    "bbox": (4, 48, 36, dict(min_num_pixels=2, bounding_box=((-0.3, -0.3, -10.0), (0.3, 0.3, 10.0))), {}),
+    "cap2": (4, 48, 36, dict(min_num_pixels=2, max_num_pixels=2), {}),
+    "depth1": (4, 48, 36, dict(min_num_pixels=1, max_traversal_depth=1), {}),
+    "depth2": (5, 48, 36, dict(min_num_pixels=2, max_traversal_depth=2), {}),
+    "mask0": (4, 48, 36, dict(min_num_pixels=2), {"mask": 0}),
+    "unused1": (4, 48, 36, dict(min_num_pixels=2), {"unused": 1}),
+    "no_rgb": (4, 48, 36, dict(min_num_pixels=2), {"no_rgb": True}),
+    "loose_7x80x60": (7, 80, 60, dict(min_num_pixels=2, max_reproj_error=4.0, max_depth_error=0.05,
+                                      max_normal_error=30.0), {}),
+    "sparse_overlap": (6, 64, 48, dict(min_num_pixels=2), {"ring": True}),
+    "half_size_maps": (4, 64, 48, dict(min_num_pixels=2), {"half": True}),
+}
+
+
+def _case(name):
+    n, w, h, okw, extra = _CASES[name]
+    views = scene(n, w, h)
+    images = _images(views, with_rgb=not extra.get("no_rgb"))
+    if "mask" in extra:
+        m = np.zeros((h, w), np.uint8)
+        m[::2, 1::3] = 1
+        images[extra["mask"]].mask = m
+    if "unused" in extra:
+        images[extra["unused"]].used = False
+    if extra.get("half"):  # depth maps at half the model image size (max_image_size in the workspace)
+        for im in images:
+            im.depth_map = np.ascontiguousarray(im.depth_map[::2, ::2])
+            im.normal_map = np.ascontiguousarray(im.normal_map[:, ::2, ::2])
+    overlap = [[(i + 1) % n, (i + 2) % n] for i in range(n)] if extra.get("ring") else _overlap(n)
+    return fusion.StereoFusionOptions(**okw), images, overlap
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(_CASES))
+def test_hip_fusion_equals_parallel_oracle(name):
+    opt, images, overlap = _case(name)
+    want = fusion_oracle.fuse(opt, images, overlap, mode=1)
+    got = fusion.fuse(opt, images, overlap)
+    assert len(want.xyz) > 20
+    assert _same(got, want), (len(got.xyz), len(want.xyz))
+    assert _same(fusion.fuse(opt, images, overlap), got)  # atomics decide ownership, not timing
+
+
+@pytest.mark.gpu
+def test_hip_fusion_many_seeds_per_lane():
+    """More seeds than resident lanes (65536): lanes stride over the seeds and reuse their state."""
+    views = scene(3, 320, 240)
+    opt = fusion.StereoFusionOptions(min_num_pixels=2)
+    want = fusion_oracle.fuse(opt, _images(views), _overlap(3), mode=1)
+    got = fusion.fuse(opt, _images(views), _overlap(3))
+    assert len(want.xyz) > 10000 and _same(got, want)
+    assert _on_surface(views, got, 320, 240) > 10000
+
+
+@pytest.mark.gpu
+def test_hip_fusion_options_masks_and_bounding_box():
+    _options_masks_and_bounding_box(fusion.fuse)
+
+
+def test_fusion_needs_a_gpu():
+    """No CPU path: without a device fusion_run reports it."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    views = scene(2, 16, 12)
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        fusion.fuse(fusion.StereoFusionOptions(), _images(views), _overlap(2))
 
 
 def test_ply_and_visibility_files(tmp_path):
@@ -258,6 +379,7 @@ def test_ply_and_visibility_files(tmp_path):
         fusion.read_points_visibility(p + ".vis", 5)
 
 
+@pytest.mark.gpu
 def test_stereo_fusion_command_on_a_workspace(tmp_path):
     """exe/mvs.cc:299-386: workspace with geometric maps + fusion.cfg -> fused.ply + fused.ply.vis."""
     views = scene(5, 64, 48)
