@@ -5,8 +5,8 @@
 // graph (depth, reprojection and normal tests against the pixel it started from), masks what it
 // absorbs and fuses it into one point. In the reference the turns within an image are taken by a
 // thread pool, so the order is row-major only for num_threads = 1. Here the order is a fixed
-// permutation of the pixels (MakeSeedOrder) and the result is exactly the reference's algorithm run
-// in that order -- but the turns are not executed one after the other:
+// pseudo-random permutation of the pixels (ascending seed_hash) and the result is exactly the
+// reference's algorithm run in that order -- but the turns are not executed one after the other:
 //
 //   speculate  every undecided pixel ("seed") walks against the masks committed so far and claims the
 //              pixels it would absorb: 64-bit atomicMax on a per-pixel word  round << 32 | ~rank, so
@@ -92,11 +92,13 @@ struct Params {
   int step;                     // position of `image` in the fusion order
   int image;
   int num_seeds;
-  unsigned long long rank_mul;  // priority (= rank in the seed order) of seed s: s * rank_mul mod num_seeds
-  const int* active;            // seeds still undecided (nullptr: all seeds)
+  const int* rank_of;           // priority of a seed = its rank in the seed order
+  const int* active;            // undecided seeds that have had their first turn offered
   int num_active;
   int* next_active;
   int* next_count;
+  int* lane_walk;               // per lane: recorded pixels of the speculate walk | capped << 31 (state reuse)
+  int reuse;                    // num_active <= kLanes: a lane keeps its walk from speculate to commit
   unsigned* barrier;            // lowest priority value among seeds whose closure overflowed the record
   int elem_cap;                 // min(max_num_pixels, kElemCap)
   int max_level;                // max_traversal_depth - 1
@@ -202,7 +204,8 @@ __device__ Walk walk(const Params& p, int lane, int seed, unsigned long long key
       const unsigned mk = p.mask[im.pix_off + pix];
       if (mk != 0u && mk < p.round) break;  // masked before this round
       bool seen = false;
-      for (int e = 0; e < ne; ++e) seen |= (SLOT(p.e_pix, e) == (unsigned)pix && (int)(SLOT(p.e_meta, e) & 0xFFFFu) == img);
+      for (int e = 0; e < ne; ++e)
+        if (SLOT(p.e_pix, e) == (unsigned)pix) seen |= (int)(SLOT(p.e_meta, e) & 0xFFFFu) == img;
       if (seen) break;  // masked by this walk
       const float depth = im.depth[pix];
       if (depth <= 0.0f) break;
@@ -297,10 +300,8 @@ __device__ Walk walk(const Params& p, int lane, int seed, unsigned long long key
   return w;
 }
 
-__device__ inline int seed_of(const Params& p, int idx) { return p.active ? p.active[idx] : idx; }
-__device__ inline unsigned prio_of(const Params& p, int seed) {
-  return (unsigned)(((unsigned long long)seed * p.rank_mul) % (unsigned long long)p.num_seeds);
-}
+__device__ inline int seed_of(const Params& p, int idx) { return p.active[idx]; }
+__device__ inline unsigned prio_of(const Params& p, int seed) { return (unsigned)p.rank_of[seed]; }
 
 // Round, first half: every undecided seed walks against the committed masks and claims what it would
 // absorb. A seed whose walk hit a cap also claims its closure: under more masks a capped walk can take
@@ -312,11 +313,12 @@ __global__ void __launch_bounds__(kBlock) fusion_speculate_kernel(Params p) {
     const int seed = seed_of(p, idx);
     const unsigned prio = prio_of(p, seed);
     const unsigned long long key = claim_key(p.round, prio);
-    const Walk w = walk<false, true, false>(p, lane, seed, key);
+    const Walk w = p.reuse ? walk<false, true, true>(p, lane, seed, key) : walk<false, true, false>(p, lane, seed, key);
     if (w.capped) {
       const Walk c = walk<true, true, false>(p, lane, seed, key);
       if (c.overflow) atomicMin(p.barrier, prio);
     }
+    if (p.reuse) p.lane_walk[lane] = w.ne | (w.capped ? (int)0x80000000 : 0);  // capped: the closure walk overwrote the state
   }
 }
 
@@ -331,8 +333,9 @@ __global__ void __launch_bounds__(kBlock) fusion_commit_kernel(Params p) {
     const int seed = seed_of(p, idx);
     const unsigned prio = prio_of(p, seed);
     const unsigned long long key = claim_key(p.round, prio);
-    const Walk w = walk<false, false, true>(p, lane, seed, key);
-    const int ne = w.ne;
+    int ne;
+    if (p.reuse && p.lane_walk[lane] >= 0) ne = p.lane_walk[lane];
+    else ne = walk<false, false, true>(p, lane, seed, key).ne;
     bool mine = prio <= barrier;
     for (int e = 0; e < ne && mine; ++e) {
       const DevImage& im = p.images[SLOT(p.e_meta, e) & 0xFFFFu];
@@ -397,18 +400,50 @@ __global__ void __launch_bounds__(kBlock) fusion_commit_kernel(Params p) {
 }
 #undef SLOT
 
+// The order in which the pixels of an image take their turn: ascending hash of the pixel index
+// (fmix32 of MurmurHash3, a bijection of the 32-bit integers, so the keys are distinct). The
+// reference's row-major order is only one of the orders its thread pool can produce; a pseudo-random
+// one keeps walks that compete for the same pixels from forming long chains of decreasing rank.
+__host__ __device__ inline unsigned seed_hash(unsigned s) {
+  s ^= s >> 16; s *= 0x85EBCA6Bu; s ^= s >> 13; s *= 0xC2B2AE35u; s ^= s >> 16;
+  return s;
+}
+
+__global__ void fusion_keys_kernel(int num_seeds, unsigned* __restrict__ keys, int* __restrict__ seeds) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= num_seeds) return;
+  keys[s] = seed_hash((unsigned)s);
+  seeds[s] = s;
+}
+
+__global__ void fusion_invert_kernel(int num_seeds, const int* __restrict__ order, int* __restrict__ rank_of) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < num_seeds) rank_of[order[k]] = k;
+}
+
+// The seeds of ranks [k0, k1) get their first turn: appended to the undecided list unless their own
+// pixel is masked already (then their turn is empty) or has no depth.
+__global__ void fusion_offer_kernel(Params p, const int* __restrict__ order, int k0, int k1) {
+  const int k = k0 + blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= k1) return;
+  const int seed = order[k];
+  const DevImage& im = p.images[p.image];
+  if (p.mask[im.pix_off + seed] != 0u || im.depth[seed] <= 0.0f) return;
+  p.next_active[atomicAdd(p.next_count, 1)] = seed;
+}
+
 // seed order -> output order: entry k is the seed of rank k
-__global__ void fusion_rank_kernel(int num_seeds, unsigned long long seed_mul, const int* __restrict__ valid,
+__global__ void fusion_rank_kernel(int num_seeds, const int* __restrict__ order, const int* __restrict__ valid,
                                    const int* __restrict__ nvis, int* __restrict__ valid_r, int* __restrict__ nvis_r) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k > num_seeds) return;
   if (k == num_seeds) { valid_r[k] = 0; nvis_r[k] = 0; return; }  // the scans run over num_seeds + 1 entries
-  const int s = (int)(((unsigned long long)k * seed_mul) % (unsigned long long)num_seeds);
+  const int s = order[k];
   valid_r[k] = valid[s];
   nvis_r[k] = valid[s] ? nvis[s] : 0;
 }
 
-__global__ void fusion_compact_kernel(int num_seeds, unsigned long long seed_mul, const int* __restrict__ valid_r,
+__global__ void fusion_compact_kernel(int num_seeds, const int* __restrict__ order, const int* __restrict__ valid_r,
                                       const int* __restrict__ scan_valid, const int* __restrict__ nvis_r,
                                       const int* __restrict__ scan_vis, const int* __restrict__ vis_off,
                                       const int* __restrict__ pool, const float* __restrict__ pt,
@@ -417,7 +452,7 @@ __global__ void fusion_compact_kernel(int num_seeds, unsigned long long seed_mul
                                       int* __restrict__ out_vis) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= num_seeds || !valid_r[k]) return;
-  const int s = (int)(((unsigned long long)k * seed_mul) % (unsigned long long)num_seeds);
+  const int s = order[k];
   const int o = scan_valid[k];
   for (int c = 0; c < 6; ++c) out_pt[6 * (size_t)o + c] = pt[6 * (size_t)s + c];
   for (int c = 0; c < 3; ++c) out_col[3 * (size_t)o + c] = col[3 * (size_t)s + c];
@@ -481,31 +516,6 @@ void ComposeInverseProjectionMatrix(const float P[12], float inv_P[12]) {
   }
 }
 
-// The order in which the pixels of an image take their turn (the reference's row-major order is
-// only one of the orders its thread pool can produce): seed of rank k = k * A mod n with A next to
-// n / golden ratio and coprime to n -- consecutive ranks lie far apart in the image, so walks that
-// compete for the same pixels rarely form long chains of decreasing rank and a few rounds settle them.
-struct SeedOrder {
-  unsigned long long seed_mul, rank_mul;  // seed = rank * seed_mul mod n ; rank = seed * rank_mul mod n
-};
-
-SeedOrder MakeSeedOrder(int n) {
-  if (n <= 2) return {1ull, 1ull};
-  auto gcd = [](long long a, long long b) { while (b) { const long long t = a % b; a = b; b = t; } return a; };
-  long long A = (long long)((double)n * 0.6180339887498949);
-  A = std::max<long long>(A, 1);
-  while (gcd(A, n) != 1) ++A;  // n - 1 is coprime to n: terminates below n
-  // inverse of A modulo n (extended Euclid)
-  long long t = 0, nt = 1, r = n, nr = A;
-  while (nr != 0) {
-    const long long q = r / nr;
-    const long long t2 = t - q * nt; t = nt; nt = t2;
-    const long long r2 = r - q * nr; r = nr; nr = r2;
-  }
-  if (t < 0) t += n;
-  return {(unsigned long long)A, (unsigned long long)t};
-}
-
 struct Stats {
   long long images = 0, seeds = 0, rounds = 0, walks = 0;
 };
@@ -553,12 +563,12 @@ void Run(const fusion_options& opt, int n, const fusion_image* images, const int
     FU_CHECK((int64_t)im.depth_width * im.depth_height < (1ll << 31), "depth map size");
     used[i] = 1;
   }
-  std::vector<int> order, pos(n, -1);
+  std::vector<int> order_of_images, pos(n, -1);
   if (n > 0) {
     for (int cur = 0; cur >= 0;) {
       if (used[cur]) {
-        pos[cur] = (int)order.size();
-        order.push_back(cur);
+        pos[cur] = (int)order_of_images.size();
+        order_of_images.push_back(cur);
       }
       fused[cur] = 1;
       int nxt = -1;
@@ -569,7 +579,7 @@ void Run(const fusion_options& opt, int n, const fusion_image* images, const int
       cur = nxt;
     }
   }
-  if (order.empty()) return;
+  if (order_of_images.empty()) return;
 
   // resident maps + descriptors
   std::vector<DevImage> h_img(n);
@@ -668,46 +678,72 @@ void Run(const fusion_options& opt, int n, const fusion_image* images, const int
   DevBuf<unsigned char> tmp;
   tmp.alloc(tmp_bytes + 16);
 
+  DevBuf<unsigned> keys_in, keys_out;
+  DevBuf<int> seeds_in, order, rank_of, lane_walk;
+  keys_in.alloc(ms); keys_out.alloc(ms); seeds_in.alloc(ms); order.alloc(ms); rank_of.alloc(ms); lane_walk.alloc(kLanes);
+  p.rank_of = rank_of.p; p.lane_walk = lane_walk.p;
+  size_t sort_bytes = 0;
+  FU_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, keys_in.p, keys_out.p, seeds_in.p, order.p, (int)ms));
+  DevBuf<unsigned char> sort_tmp;
+  sort_tmp.alloc(sort_bytes + 16);
+
   std::vector<float> h_pt;
   std::vector<unsigned char> h_col;
   std::vector<int> h_nvis, h_vis;
   unsigned round = 2;  // 0 = free, 1 = masked on input
   g_stats = Stats();
-  for (int step = 0; step < (int)order.size(); ++step) {
-    const int I = order[step];
+  for (int step = 0; step < (int)order_of_images.size(); ++step) {
+    const int I = order_of_images[step];
     const int ns = h_img[I].dw * h_img[I].dh;
-    const SeedOrder so = MakeSeedOrder(ns);
-    p.step = step; p.image = I; p.num_seeds = ns; p.rank_mul = so.rank_mul;
+    p.step = step; p.image = I; p.num_seeds = ns;
+    // seed order of this image: pixels sorted by their hash
+    hipLaunchKernelGGL(fusion_keys_kernel, dim3((ns + 255) / 256), dim3(256), 0, 0, ns, keys_in.p, seeds_in.p);
+    size_t sb = sort_bytes;
+    FU_HIP(hipcub::DeviceRadixSort::SortPairs(sort_tmp.p, sb, keys_in.p, keys_out.p, seeds_in.p, order.p, ns));
+    hipLaunchKernelGGL(fusion_invert_kernel, dim3((ns + 255) / 256), dim3(256), 0, 0, ns, order.p, rank_of.p);
     FU_HIP(hipMemsetAsync(d_cursor.p, 0, sizeof(unsigned long long), 0));
     FU_HIP(hipMemsetAsync(valid.p, 0, sizeof(int) * (size_t)ns, 0));
-    p.active = nullptr;
-    p.num_active = ns;
+    // Rounds. The undecided list must hold EVERY undecided seed up to some rank (a seed may only commit
+    // when all seeds before it have claimed), so first turns are offered in rank order: a small head
+    // of the order first, then doubling -- by the time the bulk of the seeds is offered most of their
+    // pixels are masked and their turns are empty.
     int* lists[2] = {list_a.p, list_b.p};
-    for (int it = 0; p.num_active > 0; ++it, ++round) {
+    p.active = lists[0];
+    p.num_active = 0;
+    int offered = 0;
+    const int head = std::max(256, ns / 1024);
+    for (int it = 0; p.num_active > 0 || offered < ns; ++it, ++round) {
       FU_CHECK(round != 0xFFFFFFFFu, "round counter");
       p.round = round;
-      p.next_active = lists[it & 1];
+      p.next_active = lists[(it + 1) & 1];
       FU_HIP(hipMemsetAsync(d_barrier.p, 0xFF, sizeof(unsigned), 0));
       FU_HIP(hipMemsetAsync(d_next_count.p, 0, sizeof(int), 0));
-      const int grid = std::min(kLanes, (p.num_active + kBlock - 1) / kBlock * kBlock) / kBlock;
-      hipLaunchKernelGGL(fusion_speculate_kernel, dim3(grid), dim3(kBlock), 0, 0, p);
-      hipLaunchKernelGGL(fusion_commit_kernel, dim3(grid), dim3(kBlock), 0, 0, p);
+      if (p.num_active > 0) {
+        p.reuse = p.num_active <= kLanes ? 1 : 0;
+        const int grid = std::min(kLanes, (p.num_active + kBlock - 1) / kBlock * kBlock) / kBlock;
+        hipLaunchKernelGGL(fusion_speculate_kernel, dim3(grid), dim3(kBlock), 0, 0, p);
+        hipLaunchKernelGGL(fusion_commit_kernel, dim3(grid), dim3(kBlock), 0, 0, p);
+        g_stats.rounds += 1;
+        g_stats.walks += p.num_active;
+      }
+      if (offered < ns) {
+        const int upto = std::min(ns, std::max(offered + head, 2 * offered));
+        hipLaunchKernelGGL(fusion_offer_kernel, dim3((upto - offered + 255) / 256), dim3(256), 0, 0, p, order.p, offered, upto);
+        offered = upto;
+      }
       int left = 0;
       FU_HIP(hipMemcpy(&left, d_next_count.p, sizeof(int), hipMemcpyDeviceToHost));
       FU_HIP(hipGetLastError());
-      FU_CHECK(left < p.num_active, "fusion round made no progress");  // the first seed of the order always commits
-      g_stats.rounds += 1;
-      g_stats.walks += p.num_active;
       p.active = p.next_active;
       p.num_active = left;
     }
-    hipLaunchKernelGGL(fusion_rank_kernel, dim3((ns + 256) / 256), dim3(256), 0, 0, ns, so.seed_mul, valid.p, nvis.p,
+    hipLaunchKernelGGL(fusion_rank_kernel, dim3((ns + 256) / 256), dim3(256), 0, 0, ns, order.p, valid.p, nvis.p,
                        valid_r.p, nvis_r.p);
     size_t tb = tmp_bytes;
     FU_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, valid_r.p, scan_valid.p, ns + 1));
     tb = tmp_bytes;
     FU_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, nvis_r.p, scan_vis.p, ns + 1));
-    hipLaunchKernelGGL(fusion_compact_kernel, dim3((ns + 255) / 256), dim3(256), 0, 0, ns, so.seed_mul, valid_r.p,
+    hipLaunchKernelGGL(fusion_compact_kernel, dim3((ns + 255) / 256), dim3(256), 0, 0, ns, order.p, valid_r.p,
                        scan_valid.p, nvis_r.p, scan_vis.p, vis_off.p, pool.p, pt.p, col.p, out_pt.p, out_col.p,
                        out_nvis.p, out_vis.p);
     int totals[2] = {0, 0};

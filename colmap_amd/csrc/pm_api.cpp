@@ -572,6 +572,8 @@ void RunBatchAsync(pm_handle** hs, int n) {
       p.sel_out_off = sel_out;
       p.sel_in_off = sel_in;
       p.xcd_map = xcd_map;
+      static const int ablate_env = [] { const char* e = getenv("COLMAP_AMD_PM_ABLATE"); return e ? atoi(e) : 0; }();
+      p.ablate = ablate_env;
       host[(size_t)(k + 1) * n + b] = p;
     }
     std::swap(sel_out, sel_in);  // Rotate(): prev_sel_prob <- sel_prob (reference :1911-1915)
@@ -887,6 +889,19 @@ int pm_get_device_maps(pm_handle* h, const float** depth, const float** normal) 
     PM_CHECK(h && h->ran, "run first");
     if (depth) *depth = h->out_depth.ptr;
     if (normal) *normal = h->out_normal.ptr;
+  });
+}
+
+int pm_copy_maps_to_device(pm_handle* h, float* depth_dev, float* normal_dev) {
+  return Guard([&] {
+    PM_CHECK(h && h->ran, "run first");
+    HIP_CALL(hipSetDevice(h->device));
+    const size_t n = (size_t)h->W * h->H;
+    if (depth_dev)
+      HIP_CALL(hipMemcpyAsync(depth_dev, h->out_depth.ptr, n * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    if (normal_dev)
+      HIP_CALL(hipMemcpyAsync(normal_dev, h->out_normal.ptr, 3 * n * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    HIP_CALL(hipStreamSynchronize(h->stream));
   });
 }
 

@@ -26,6 +26,8 @@ struct PmParams {
   int sel_in_off;   // record offset of prev_sel_prob (read)
   int sel_out_off;  // record offset of sel_prob (backward msgs, then written)
   int C;            // image columns per workgroup
+  int ablate;       // profiling only (COLMAP_AMD_PM_ABLATE): bit 0 skip the NCC task passes, bit 1 skip the
+                    // hypothesis generation, bit 2 skip the backward-message pre-pass; results are garbage
   int xcd_map;      // batched launch: 0 problem = id % batch, 1 neighbouring problems per XCD
   float refK[4];    // rotated {fx, cx, fy, cy}
   float refInvK[4]; // rotated {1/fx, -cx/fx, 1/fy, -cy/fy}

@@ -1861,7 +1861,7 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
     const int c = item / S;
     const int s = item - c * S;
     float beta = 0.5f;
-    for (int row = RH - 1; row >= 0; --row) {
+    for (int row = (p.ablate & 4) ? -1 : RH - 1; row >= 0; --row) {
       float* rec = p.rec + (size_t)pix_index(p, row, col0 + c) * p.rec_stride;
       beta = hmm_message<false>(p, rec[4 + s], beta);
       rec[p.sel_out_off + s] = beta;
@@ -1900,7 +1900,7 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
     __syncthreads();
 
     // ---- P1: hypotheses (lane per column) + patch weights (all lanes) --------
-    if (col_lane) {
+    if (col_lane && !(p.ablate & 2)) {
       const int c = tid;
       const int col = col0 + c;
       const int pix = pix_index(p, row, col);
@@ -2010,7 +2010,7 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
     __syncthreads();
 
     // ---- P4: NCC of hypotheses 1..4 against the drawn views (:1157-1172) -----
-    run_tasks_wave<GEOM, PIPE>(p, L, row, col0, tid, evals);
+    if (!(p.ablate & 1)) run_tasks_wave<GEOM, PIPE>(p, L, row, col0, tid, evals);
     if (tid == 0) { L.ntasks[0] = 0; L.ntasks[1] = 0; }
     __syncthreads();
 
@@ -2065,7 +2065,7 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
     __syncthreads();
 
     // ---- P6: NCC of the winner against the remaining views (:1188-1197) ------
-    run_tasks_wave<false, PIPE>(p, L, row, col0, tid, evals);
+    if (!(p.ablate & 1)) run_tasks_wave<false, PIPE>(p, L, row, col0, tid, evals);
 
     // ---- P7: cost map, forward message, selection probability (:1186-1207) ---
     for (int item = tid; item < ncols * S; item += nt) {

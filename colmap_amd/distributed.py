@@ -7,6 +7,7 @@ the gloo backend (tests/test_distributed.py).
 """
 from __future__ import annotations
 
+import numpy as np
 from typing import List, Sequence, Tuple
 
 
@@ -64,4 +65,57 @@ def exchange_maps(local: dict, device=None) -> dict:
         merged.update(part)
     if device is not None:
         merged = {k: v.to(device) for k, v in merged.items()}
+    return merged
+
+
+_LAST_EXCHANGE: dict = {}
+
+
+def last_exchange_info() -> dict:
+    """How the last exchange_maps_device moved its data: {"transport": "local" | "rccl" | "gloo-staged",
+    "bytes": payload all-gathered per rank, "images": maps this rank ends up with}."""
+    return dict(_LAST_EXCHANGE)
+
+
+def exchange_maps_device(local: dict, device) -> dict:
+    """Device-side all-gather of the photometric maps (image index -> device tensor [4, H, W])
+    between the two passes (replaces the reference's write-to-disk / read-back,
+    patch_match.cc:507-508,530-531). One rank: the tensors are returned as they are (nothing leaves
+    HBM). RCCL: every rank packs its maps into one flat device buffer, padded to the longest, and
+    `all_gather_into_tensor` moves them GPU to GPU; only the (index, shape) lists travel as objects.
+    gloo (CPU-side process groups, several ranks on one GPU in the tests): the same packing with
+    the flat buffer staged through host memory."""
+    import torch
+    import torch.distributed as dist
+    _LAST_EXCHANGE.clear()
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+        _LAST_EXCHANGE.update(transport="local", bytes=0, images=len(local))
+        return dict(local)
+    world = dist.get_world_size()
+    keys = sorted(local)
+    meta_local = [(int(k), tuple(int(x) for x in local[k].shape)) for k in keys]
+    meta: List[list] = [None] * world  # type: ignore
+    dist.all_gather_object(meta, meta_local)
+    sizes = [sum(int(np.prod(shape)) for _, shape in m) for m in meta]
+    longest = max(max(sizes), 1)
+    flat = torch.zeros(longest, dtype=torch.float32, device=device)
+    if keys:
+        flat[:sizes[dist.get_rank()]].copy_(torch.cat([local[k].reshape(-1).to(device=device, dtype=torch.float32) for k in keys]))
+    if dist.get_backend() == "nccl":
+        gathered = torch.empty(world * longest, dtype=torch.float32, device=device)
+        dist.all_gather_into_tensor(gathered, flat)
+        transport = "rccl"
+    else:
+        parts = [torch.empty(longest, dtype=torch.float32) for _ in range(world)]
+        dist.all_gather(parts, flat.cpu())
+        gathered = torch.cat(parts).to(device)
+        transport = "gloo-staged"
+    merged: dict = {}
+    for r, m in enumerate(meta):
+        off = r * longest
+        for k, shape in m:
+            n = int(np.prod(shape))
+            merged[k] = local[k] if r == dist.get_rank() else gathered[off:off + n].view(*shape)
+            off += n
+    _LAST_EXCHANGE.update(transport=transport, bytes=4 * longest, images=len(merged))
     return merged

@@ -113,6 +113,13 @@ class PatchMatchOptions:
         return o
 
 
+def _torch_device(gpu_index):
+    """torch device of a PatchMatchOptions::gpu_index ("-1" = the current device)."""
+    import torch
+    g = int(str(gpu_index).split(",")[0])
+    return torch.device("cuda", g if g >= 0 else torch.cuda.current_device())
+
+
 @dataclass
 class Image:
     """colmap::mvs::Image (reference mvs/image.h:40-98) with its grey bitmap."""
@@ -292,6 +299,17 @@ class PatchMatch:
         H, W, S = self._dims
         return self._get(lib().pm_get_normal_map, (3, H, W))
 
+    def GetDeviceMaps(self):
+        """Depth and normal map as ONE device tensor [4, H, W] (depth, then the three normal slices),
+        copied device-to-device (pm_copy_maps_to_device): input of the geometric pass without a host
+        round trip."""
+        import torch
+        H, W, S = self._dims
+        dev = _torch_device(self.options_.gpu_index)
+        t = torch.empty((4, H, W), dtype=torch.float32, device=dev)
+        _check(lib().pm_copy_maps_to_device(self._h, C.c_void_p(t.data_ptr()), C.c_void_p(t[1:].data_ptr())))
+        return t
+
     def GetSelProbMap(self) -> np.ndarray:
         H, W, S = self._dims
         return self._get(lib().pm_get_sel_prob_map, (S, H, W))
@@ -422,8 +440,9 @@ class PatchMatchController:
         (:410-414) -- the reference's resume mechanism;
       * problems are sharded over ranks like the thread-per-GPU pool (:177,190-204,394) and, unlike
         the reference, up to `batch_size` same-shaped problems of a rank share every kernel launch;
-        between the passes the photometric maps are exchanged in memory
-        (colmap_amd.distributed.exchange_maps) instead of through the file system.
+        between the passes the photometric maps stay in HBM (device-to-device copy out of every
+        handle, colmap_amd.distributed.exchange_maps_device = RCCL all-gather between the ranks) and
+        the geometric pass reads them as device inputs, instead of going through the file system.
     """
 
     def __init__(self, options: PatchMatchOptions, images: Sequence[WorkspaceImage], workspace_path: str,
@@ -452,6 +471,7 @@ class PatchMatchController:
                 raise PatchMatchError(f"No source images for reference image {ref_name}")
             self.problems_.append((ref, src))
         self.timings = {}
+        self.device_bitmaps_: dict = {}
 
     @classmethod
     def FromWorkspace(cls, options: PatchMatchOptions, workspace_path: str, workspace_format: str = "COLMAP",
@@ -509,12 +529,36 @@ class PatchMatchController:
         base = os.path.join(self.workspace_path_, getattr(getattr(self, "workspace_", None), "stereo_folder", "stereo"))
         return os.path.join(base, "depth_maps", name), os.path.join(base, "normal_maps", name)
 
-    def _run_pass(self, options: PatchMatchOptions, maps: Optional[dict]):
+    def _device(self, options: PatchMatchOptions):
+        return _torch_device(options.gpu_index)
+
+    def _device_bitmap(self, idx: int, device):
+        """The grey bitmap of image `idx` in HBM (uploaded once, shared by both passes so that the packed
+        source cache -- keyed by the bitmap address -- keeps hitting)."""
+        import torch
+        t = self.device_bitmaps_.get(idx)
+        if t is None:
+            t = torch.from_numpy(np.ascontiguousarray(self.images_[idx].bitmap, np.uint8)).to(device)
+            self.device_bitmaps_[idx] = t
+        return t
+
+    def _run_pass(self, options: PatchMatchOptions, maps: Optional[dict], device_maps: Optional[dict] = None):
+        """One pass over this rank's problems. `maps`: image index -> (depth, normal) for the geometric
+        pass, host arrays or device tensors. `device_maps`: when given (the photometric pass that
+        precedes a geometric one), filled with image index -> device tensor [4, H, W] and all inputs are
+        handed over as device tensors."""
         import os
         from . import distributed as D
         output_type = "geometric" if options.geom_consistency else "photometric"
         mine = [self.problems_[i] for i in D.shard_problems(len(self.problems_), self.rank_, self.world_)]
-        images = [Image(im.K, im.R, im.T, im.bitmap) for im in self.images_]
+        on_device = device_maps is not None or (maps is not None and any(hasattr(v[0], "data_ptr") for v in maps.values()))
+        if on_device:
+            dev = self._device(options)
+            used = sorted({i for ref, src in mine for i in [ref] + list(src)})
+            images = [Image(im.K, im.R, im.T, self._device_bitmap(i, dev) if i in used else im.bitmap)
+                      for i, im in enumerate(self.images_)]
+        else:
+            images = [Image(im.K, im.R, im.T, im.bitmap) for im in self.images_]
         if self.image_cache_ is None:
             self.image_cache_ = ImageCache(int(options.gpu_index))
             # PatchMatchOptions::cache_size (GB) bounds the reference's CachedWorkspace
@@ -526,6 +570,9 @@ class PatchMatchController:
             dpath, npath = self._paths(ref, output_type)
             if os.path.exists(dpath) and os.path.exists(npath):  # resume (:410-414)
                 results[ref] = (read_mat(dpath), read_mat(npath))
+                if device_maps is not None:
+                    import torch
+                    device_maps[ref] = torch.from_numpy(np.concatenate([results[ref][0][None], results[ref][1]], 0)).to(dev)
                 continue
             todo.append((ref, src))
         # batches of same-shaped problems
@@ -571,6 +618,8 @@ class PatchMatchController:
                     os.makedirs(os.path.dirname(gpath), exist_ok=True)
                     W.write_consistency_graph(gpath, depth.shape[1], depth.shape[0], pm.GetConsistentImageIdxs())
                 results[ref] = (depth, normal)
+                if device_maps is not None:
+                    device_maps[ref] = pm.GetDeviceMaps()
                 pm.close()
             i = j
         return results
@@ -586,11 +635,16 @@ class PatchMatchController:
             photo.geom_consistency = False
             photo.filter = False
             t = time.time()
-            local = self._run_pass(photo, None)
-            # every rank needs the maps of its problems' sources: exchange in memory
-            merged = D.exchange_maps({k: torch.from_numpy(np.concatenate([d[None], n], 0)) for k, (d, n) in local.items()})
-            maps = {k: (np.ascontiguousarray(v[0].numpy()), np.ascontiguousarray(v[1:].numpy())) for k, v in merged.items()}
+            # the photometric maps stay in HBM: device-to-device copy out of every handle, all-gather
+            # over RCCL between the ranks (every rank needs the maps of its problems' sources), and the
+            # geometric pass reads them as device inputs (the files written on the way are the
+            # workspace output the reference also produces, nothing reads them back)
+            dev_maps: dict = {}
+            self._run_pass(photo, None, device_maps=dev_maps)
+            merged = D.exchange_maps_device(dev_maps, self._device(opt))
+            maps = {k: (v[0], v[1:]) for k, v in merged.items()}
             self.timings["photometric_s"] = time.time() - t
+            self.timings["map_exchange"] = D.last_exchange_info()
         t = time.time()
         out = self._run_pass(opt, maps)
         self.timings["geometric_s" if opt.geom_consistency else "photometric_s"] = time.time() - t

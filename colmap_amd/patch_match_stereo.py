@@ -75,7 +75,9 @@ def main(argv=None) -> int:
         print(f"Configuration has {len(ctl.problems_)} problems...")
     ctl.Run()
     if rank == 0:
-        print("Elapsed: " + ", ".join(f"{k} {v:.1f}s" for k, v in ctl.timings.items()))
+        print("Elapsed: " + ", ".join(f"{k} {v:.1f}s" for k, v in ctl.timings.items() if isinstance(v, float)))
+        if "map_exchange" in ctl.timings:
+            print("Photometric maps for the geometric pass: " + str(ctl.timings["map_exchange"]))
     return 0
 
 

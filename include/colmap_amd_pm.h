@@ -161,6 +161,11 @@ int pm_get_evaluation_count(pm_handle* h, unsigned long long* sweep_evals, unsig
 /* Device pointers of the result maps in API layout (valid after pm_synchronize;
  * for consumers that stay on the GPU, e.g. the geometric pass). */
 int pm_get_device_maps(pm_handle* h, const float** depth, const float** normal);
+/* Device-to-device copy of the result maps into caller-owned DEVICE buffers (depth: H*W floats,
+ * normal: 3*H*W floats, either may be NULL), ordered after the run on the handle's stream and
+ * complete on return. Keeps the photometric maps in HBM for the geometric pass (replaces the
+ * reference's write-to-disk / read-back, patch_match.cc:507-508,530-531). */
+int pm_copy_maps_to_device(pm_handle* h, float* depth_dev, float* normal_dev);
 
 /* Debug: per-phase shader-clock totals of the sweep kernel (wave 0 of every
  * workgroup, summed); only for the photometric no-filter radius-5 variant. */

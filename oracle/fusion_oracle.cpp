@@ -155,6 +155,18 @@ struct Fuser {
     return -1;
   }
 
+  // the seed order of fusion.hip: pixels by ascending MurmurHash3 finaliser of their index
+  static std::vector<int> SeedOrder(int n_px) {
+    auto hash = [](uint32_t v) {
+      v ^= v >> 16; v *= 0x85EBCA6Bu; v ^= v >> 13; v *= 0xC2B2AE35u; v ^= v >> 16;
+      return v;
+    };
+    std::vector<int> order(n_px);
+    for (int i = 0; i < n_px; ++i) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return hash((uint32_t)a) < hash((uint32_t)b); });
+    return order;
+  }
+
   void Run() {  // fusion.cc:253-320, one thread
     for (int image_idx = 0; image_idx >= 0; image_idx = FindNextImage(image_idx)) {
       if (used[image_idx]) {
@@ -163,19 +175,7 @@ struct Fuser {
           for (int row = 0; row < height; ++row)
             for (int col = 0; col < width; ++col) Fuse(image_idx, row, col);
         } else {
-          // the seed order of fusion.hip: rank k -> pixel k * A mod n, A next to n / golden ratio and
-          // coprime to n
-          const long long n_px = (long long)width * height;
-          long long A = 1;
-          if (n_px > 2) {
-            A = std::max<long long>((long long)((double)n_px * 0.6180339887498949), 1);
-            auto gcd = [](long long a, long long b) { while (b) { const long long t = a % b; a = b; b = t; } return a; };
-            while (gcd(A, n_px) != 1) ++A;
-          }
-          for (long long k = 0; k < n_px; ++k) {
-            const long long s_ = (k * A) % n_px;
-            Fuse(image_idx, (int)(s_ / width), (int)(s_ % width));
-          }
+          for (const int s_ : SeedOrder(width * height)) Fuse(image_idx, s_ / width, s_ % width);
         }
       }
       fused[image_idx] = 1;
@@ -413,21 +413,17 @@ struct Fuser {
     unsigned round = 2;
     for (int I = 0; I >= 0; I = FindNextImage(I)) {
       if (used[I]) {
-        const long long n_px = (long long)images[I].depth_width * images[I].depth_height;
-        long long A = 1, Ainv = 1;
-        if (n_px > 2) {
-          A = std::max<long long>((long long)((double)n_px * 0.6180339887498949), 1);
-          auto gcd = [](long long a, long long b) { while (b) { const long long t = a % b; a = b; b = t; } return a; };
-          while (gcd(A, n_px) != 1) ++A;
-          for (Ainv = 1; (A * Ainv) % n_px != 1; ++Ainv) {}  // small test sizes only
-        }
+        const int n_px = images[I].depth_width * images[I].depth_height;
+        const std::vector<int> order = SeedOrder(n_px);
+        std::vector<int> rank_of(n_px);
+        for (int k = 0; k < n_px; ++k) rank_of[order[k]] = k;
         std::vector<fusion_result> per_seed(n_px);
-        std::vector<int> active(n_px);
-        for (long long s_ = 0; s_ < n_px; ++s_) active[s_] = (int)s_;
-        for (; !active.empty(); ++round) {
+        std::vector<int> active;
+        int offered = 0;
+        const int head = std::max(256, n_px / 1024);
+        for (; !active.empty() || offered < n_px; ++round) {
           auto key_of = [&](int seed) {
-            const unsigned prio = (unsigned)(((long long)seed * Ainv) % n_px);
-            return ((unsigned long long)round << 32) | (unsigned long long)(0xFFFFFFFFu - prio);
+            return ((unsigned long long)round << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)rank_of[seed]);
           };
           unsigned barrier = 0xFFFFFFFFu;
           for (int seed : active) {  // speculate
@@ -437,14 +433,14 @@ struct Fuser {
             if (w.capped) {
               WalkOut c = Walk(I, seed, stamp, round, true);
               for (const Rec& q : c.recs) claim[q.image][q.pix] = std::max(claim[q.image][q.pix], key);
-              if (c.overflow) barrier = std::min(barrier, 0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFu));
+              if (c.overflow) barrier = std::min(barrier, (unsigned)rank_of[seed]);
             }
           }
           std::vector<int> next;
           for (int seed : active) {  // commit
             const unsigned long long key = key_of(seed);
             WalkOut w = Walk(I, seed, stamp, round, false);
-            bool mine = (0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFu)) <= barrier;
+            bool mine = (unsigned)rank_of[seed] <= barrier;
             for (const Rec& q : w.recs) mine = mine && claim[q.image][q.pix] == key;
             if (!mine) { next.push_back(seed); continue; }
             std::vector<float> px, py, pz, nx, ny, nz;
@@ -460,13 +456,24 @@ struct Fuser {
             }
             Emit(px, py, pz, nx, ny, nz, cr, cg, cb, vis, &per_seed[seed]);
           }
-          FU_CHECK(next.size() < active.size(), "round made no progress");
-          ++rounds_run;
-          walks_run += (long long)active.size();
+          FU_CHECK(active.empty() || next.size() < active.size(), "round made no progress");
+          if (!active.empty()) {
+            ++rounds_run;
+            walks_run += (long long)active.size();
+          }
+          if (offered < n_px) {  // first turns in rank order: a small head, then doubling
+            const int upto = std::min(n_px, std::max(offered + head, 2 * offered));
+            for (int k = offered; k < upto; ++k) {
+              const int seed = order[k];
+              if (stamp[I][seed] != 0 || images[I].depth_map[seed] <= 0.0f) continue;
+              next.push_back(seed);
+            }
+            offered = upto;
+          }
           active.swap(next);
         }
-        for (long long k = 0; k < n_px; ++k) {  // output in rank order
-          const fusion_result& r = per_seed[(k * A) % n_px];
+        for (int k = 0; k < n_px; ++k) {  // output in rank order
+          const fusion_result& r = per_seed[order[k]];
           if (r.rgb.empty()) continue;
           out->xyz_normal.insert(out->xyz_normal.end(), r.xyz_normal.begin(), r.xyz_normal.end());
           out->rgb.insert(out->rgb.end(), r.rgb.begin(), r.rgb.end());

@@ -22,7 +22,7 @@ def run(n, w, h, **kw):
         images.append(fusion.FusionImage(w, h, v.K, v.R, v.T, rgb, v.depth.copy(), v.normal.copy()))
     overlap = [[j for j in range(n) if j != i] for i in range(n)]
     opt = fusion.StereoFusionOptions(**kw)
-    fusion.fuse(opt, images[:2], overlap[:1] + [[0]])  # warm-up (module load)
+    fusion.fuse(opt, images[:2], [[1], [0]])  # warm-up (module load)
     t = time.time()
     pts = fusion.fuse(opt, images, overlap)
     dt = time.time() - t

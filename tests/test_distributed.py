@@ -50,8 +50,15 @@ def _worker(rank, world, port, q):
         counts = D.gather_counts(len(mine))
         local = {i: torch.full((2, 3), float(i)) for i in mine}
         merged = D.exchange_maps(local)
+        # the packed exchange of the geometric pass: ragged shapes, one rank may hold nothing
+        ragged = {i: torch.arange(4 * (2 + i) * 3, dtype=torch.float32).view(4, 2 + i, 3) + 100 * i
+                  for i in (mine if rank == 0 else [])}
+        packed = D.exchange_maps_device(ragged, torch.device("cpu"))
+        info = D.last_exchange_info()
+        ok = sorted(packed) == [0, 2, 4] and all(
+            torch.equal(packed[i], torch.arange(4 * (2 + i) * 3, dtype=torch.float32).view(4, 2 + i, 3) + 100 * i) for i in packed)
         dist.barrier()
-        q.put((rank, mine, t, counts, sorted(merged), [float(merged[k][0, 0]) for k in sorted(merged)]))
+        q.put((rank, mine, t, counts, sorted(merged), [float(merged[k][0, 0]) for k in sorted(merged)], ok, info))
     finally:
         dist.destroy_process_group()
 
@@ -67,7 +74,9 @@ def test_two_rank_gloo_roundtrip():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (r0, mine0, t0, c0, keys0, vals0), (r1, mine1, t1, c1, keys1, vals1) = res
+    (r0, mine0, t0, c0, keys0, vals0, ok0, info0), (r1, mine1, t1, c1, keys1, vals1, ok1, info1) = res
+    assert ok0 and ok1 and info0["transport"] == info1["transport"] == "gloo-staged" and info0["images"] == 3
+    assert info0["bytes"] == 4 * sum(4 * (2 + i) * 3 for i in (0, 2, 4))
     assert mine0 == [0, 2, 4] and mine1 == [1, 3]
     assert t0 == t1 == 2.0                       # MAX over ranks
     assert c0 == c1 == [3, 2]                    # units per rank -> aggregate = 5

@@ -219,7 +219,8 @@ def test_seed_order_against_ground_truth_and_row_major():
     np.testing.assert_allclose(np.linalg.norm(par.normal, axis=1), 1.0, atol=1e-5)
     assert _on_surface(views, par, 64, 48) > 500
     assert sum(len(v) for v in par.visibility) <= 5 * len(par.xyz)
-    assert abs(len(par.xyz) - len(seq.xyz)) <= 0.15 * len(seq.xyz)
+    # a scattered order leaves more leftover clusters below min_num_pixels than the row-major one
+    assert abs(len(par.xyz) - len(seq.xyz)) <= 0.2 * len(seq.xyz)
     # nearest row-major point of every point: within about two pixel footprints (one pixel covers
     # ~0.3 scene units at the scene depth of ~16)
     d = np.sqrt(((par.xyz[:, None, :] - seq.xyz[None, :, :]) ** 2).sum(-1)).min(1)

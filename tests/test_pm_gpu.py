@@ -421,6 +421,56 @@ def test_controller_two_pass_files_and_resume(pm_oracle, tmp_path):
     assert all(np.array_equal(out2[k][0], out[k][0]) for k in out)
 
 
+def _two_rank_controller_worker(rank, world, port, root, q):
+    import os
+    import torch.distributed as dist
+    from colmap_amd import mvs
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        views = scene(4, 64, 48)
+        ws = [mvs.WorkspaceImage(f"img{i}.png", v.K, v.R, v.T, v.gray, syn.depth_range(views, i)) for i, v in enumerate(views)]
+        opt = mvs.PatchMatchOptions(gpu_index="0", geom_consistency=True, filter=True, num_iterations=1)
+        ctl = mvs.PatchMatchController(opt, ws, os.path.join(root, f"rank{rank}"), batch_size=2, rank=rank, world_size=world)
+        out = ctl.Run()
+        q.put((rank, {k: (v[0].copy(), v[1].copy()) for k, v in out.items()}, ctl.timings["map_exchange"]))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_geometric_pass_exchanges_maps_on_device(tmp_path):
+    """Two ranks (sharing GPU 0, gloo process group): each runs the photometric pass of its own
+    reference images, the maps are exchanged as packed device buffers, each runs the geometric pass
+    of its problems against maps that came from the other rank. Bit-identical to the one-rank run
+    (which keeps everything in HBM)."""
+    import socket
+    import torch.multiprocessing as mp
+    from colmap_amd import mvs
+    views = scene(4, 64, 48)
+    ws = [mvs.WorkspaceImage(f"img{i}.png", v.K, v.R, v.T, v.gray, syn.depth_range(views, i)) for i, v in enumerate(views)]
+    opt = mvs.PatchMatchOptions(gpu_index="0", geom_consistency=True, filter=True, num_iterations=1)
+    solo_ctl = mvs.PatchMatchController(opt, ws, str(tmp_path / "solo"), batch_size=2)
+    solo = solo_ctl.Run()
+    assert solo_ctl.timings["map_exchange"]["transport"] == "local"
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_two_rank_controller_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, out0, info0), (_, out1, info1) = res
+    assert sorted(out0) == [0, 2] and sorted(out1) == [1, 3]
+    assert info0["images"] == info1["images"] == 4 and info0["bytes"] == 4 * 2 * 4 * 64 * 48
+    for k, (d, n) in {**out0, **out1}.items():
+        assert np.array_equal(d, solo[k][0]) and np.array_equal(n, solo[k][1])
+
+
 def test_patch_match_stereo_cli_on_a_workspace(tmp_path):
     """`python -m colmap_amd.patch_match_stereo` on an undistorted workspace on disk (exe/mvs.cc:
     228-279): sparse model -> depth ranges and `__auto__` sources, photometric + geometric pass,
