@@ -65,6 +65,8 @@ constexpr int PD = 6;        // pose tangent width (5 when the gauge holds a tra
 // <8, 8>. The kernels whose register footprint depends on them are templates; the others read
 // V.kd / V.bd.
 constexpr int KD_MAX = 8;
+constexpr int KD_WIDE = 12;  // FULL_OPENCV / THIN_PRISM_FISHEYE: up to 12 variable intrinsics (third <KD, BD> tier)
+constexpr int NPAR_WIDE = 12;
 constexpr int NPAR = 8;      // max number of parameters of a supported camera model (J_params is 2 x NPAR)
 static int chunk_size() {     // observations per camera-side reduction chunk (one wave each)
   const char* e = std::getenv("COLMAP_AMD_BA_CHUNK");
@@ -184,6 +186,7 @@ __device__ __host__ __forceinline__ int num_params_of(int model) {
     case BA_RADIAL: case BA_RADIAL_FISHEYE: case BA_FOV: case BA_DIVISION: return 5;
     case BA_EUCM: return 6;
     case BA_OPENCV: case BA_OPENCV_FISHEYE: return 8;
+    case BA_FULL_OPENCV: case BA_THIN_PRISM_FISHEYE: return 12;
     default: return 4;  // PINHOLE, SIMPLE_RADIAL, SIMPLE_RADIAL_FISHEYE, SIMPLE_DIVISION, FISHEYE
   }
 }
@@ -191,7 +194,8 @@ __host__ inline bool model_supported(int model) {
   return model == BA_SIMPLE_PINHOLE || model == BA_PINHOLE || model == BA_SIMPLE_RADIAL || model == BA_RADIAL ||
          model == BA_OPENCV || model == BA_OPENCV_FISHEYE || model == BA_SIMPLE_RADIAL_FISHEYE ||
          model == BA_RADIAL_FISHEYE || model == BA_FOV || model == BA_SIMPLE_DIVISION || model == BA_DIVISION ||
-         model == BA_SIMPLE_FISHEYE || model == BA_FISHEYE || model == BA_EUCM;
+         model == BA_SIMPLE_FISHEYE || model == BA_FISHEYE || model == BA_EUCM || model == BA_FULL_OPENCV ||
+         model == BA_THIN_PRISM_FISHEYE;
 }
 
 // QuaternionRotatePointWithJac, quaternion_utils.h:105-153
@@ -224,7 +228,7 @@ __device__ __forceinline__ void quat_rotate(const double* q, const double* p, do
 }
 
 // ImgFromCamWithJac, sensor/models_jacobian.h:139-321 (+ HasProjectableDepth, models.h:281-285)
-template <bool JAC>
+template <bool JAC, int NP>
 __device__ __forceinline__ bool img_from_cam(int model, const double* prm, double u, double v, double w,
                                              double& x, double& y, double* Jpar, double* Juvw) {
   if (model == BA_SIMPLE_DIVISION || model == BA_DIVISION) {
@@ -248,13 +252,13 @@ __device__ __forceinline__ bool img_from_cam(int model, const double* prm, doubl
       Juvw[0] = f1 * (r + u * dr_du); Juvw[1] = f1 * u * dr_dv; Juvw[2] = f1 * u * dr_dw;
       Juvw[3] = f2 * v * dr_du; Juvw[4] = f2 * (r + v * dr_dv); Juvw[5] = f2 * v * dr_dw;
 #pragma unroll
-      for (int c = 0; c < NPAR; ++c) Jpar[c] = Jpar[NPAR + c] = 0.0;
+      for (int c = 0; c < NP; ++c) Jpar[c] = Jpar[NP + c] = 0.0;
       Jpar[0] = r * u;
-      Jpar[NPAR + (two_f ? 1 : 0)] = r * v;
+      Jpar[NP + (two_f ? 1 : 0)] = r * v;
       Jpar[ic] = 1.0;
-      Jpar[NPAR + ic + 1] = 1.0;
+      Jpar[NP + ic + 1] = 1.0;
       Jpar[ic + 2] = f1 * u * dr_dk;
-      Jpar[NPAR + ic + 2] = f2 * v * dr_dk;
+      Jpar[NP + ic + 2] = f2 * v * dr_dk;
     }
     return true;
   }
@@ -281,8 +285,8 @@ __device__ __forceinline__ bool img_from_cam(int model, const double* prm, doubl
       Juvw[5] = f2 * (-v * dden_dw * inv_den2);
       Jpar[0] = xn; Jpar[1] = 0.0; Jpar[2] = 1.0; Jpar[3] = 0.0;
       Jpar[4] = f1 * (-u * dden_dalpha * inv_den2); Jpar[5] = f1 * (-u * dden_dbeta * inv_den2);
-      Jpar[NPAR + 0] = 0.0; Jpar[NPAR + 1] = yn; Jpar[NPAR + 2] = 0.0; Jpar[NPAR + 3] = 1.0;
-      Jpar[NPAR + 4] = f2 * (-v * dden_dalpha * inv_den2); Jpar[NPAR + 5] = f2 * (-v * dden_dbeta * inv_den2);
+      Jpar[NP + 0] = 0.0; Jpar[NP + 1] = yn; Jpar[NP + 2] = 0.0; Jpar[NP + 3] = 1.0;
+      Jpar[NP + 4] = f2 * (-v * dden_dalpha * inv_den2); Jpar[NP + 5] = f2 * (-v * dden_dbeta * inv_den2);
     }
     return true;
   }
@@ -324,8 +328,8 @@ __device__ __forceinline__ bool img_from_cam(int model, const double* prm, doubl
       Juvw[0] = A0 * inv_w; Juvw[1] = A1 * inv_w; Juvw[2] = -(A0 * a + A1 * b) * inv_w;
       Juvw[3] = A2 * inv_w; Juvw[4] = A3 * inv_w; Juvw[5] = -(A2 * a + A3 * b) * inv_w;
       Jpar[0] = du; Jpar[1] = 0.0; Jpar[2] = 1.0; Jpar[3] = 0.0; Jpar[4] = f1 * a * factor_omega;
-      Jpar[NPAR + 0] = 0.0; Jpar[NPAR + 1] = dv; Jpar[NPAR + 2] = 0.0; Jpar[NPAR + 3] = 1.0;
-      Jpar[NPAR + 4] = f2 * b * factor_omega;
+      Jpar[NP + 0] = 0.0; Jpar[NP + 1] = dv; Jpar[NP + 2] = 0.0; Jpar[NP + 3] = 1.0;
+      Jpar[NP + 4] = f2 * b * factor_omega;
     }
     return true;
   }
@@ -337,7 +341,7 @@ __device__ __forceinline__ bool img_from_cam(int model, const double* prm, doubl
       const double fw = f * inv_w;
       Juvw[0] = fw; Juvw[1] = 0.0; Juvw[2] = -fw * uu; Juvw[3] = 0.0; Juvw[4] = fw; Juvw[5] = -fw * vv;
       Jpar[0] = uu; Jpar[1] = 1.0; Jpar[2] = 0.0;
-      Jpar[NPAR + 0] = vv; Jpar[NPAR + 1] = 0.0; Jpar[NPAR + 2] = 1.0;
+      Jpar[NP + 0] = vv; Jpar[NP + 1] = 0.0; Jpar[NP + 2] = 1.0;
     }
     return true;
   }
@@ -349,7 +353,7 @@ __device__ __forceinline__ bool img_from_cam(int model, const double* prm, doubl
       Juvw[0] = f1 * inv_w; Juvw[1] = 0.0; Juvw[2] = -f1 * inv_w * uu;
       Juvw[3] = 0.0; Juvw[4] = f2 * inv_w; Juvw[5] = -f2 * inv_w * vv;
       Jpar[0] = uu; Jpar[1] = 0.0; Jpar[2] = 1.0; Jpar[3] = 0.0;
-      Jpar[NPAR + 0] = 0.0; Jpar[NPAR + 1] = vv; Jpar[NPAR + 2] = 0.0; Jpar[NPAR + 3] = 1.0;
+      Jpar[NP + 0] = 0.0; Jpar[NP + 1] = vv; Jpar[NP + 2] = 0.0; Jpar[NP + 3] = 1.0;
     }
     return true;
   }
@@ -400,15 +404,102 @@ __device__ __forceinline__ bool img_from_cam(int model, const double* prm, doubl
       Juvw[0] = A0 * inv_w; Juvw[1] = A1 * inv_w; Juvw[2] = -(A0 * a + A1 * b) * inv_w;
       Juvw[3] = A2 * inv_w; Juvw[4] = A3 * inv_w; Juvw[5] = -(A2 * a + A3 * b) * inv_w;
 #pragma unroll
-      for (int c = 0; c < NPAR; ++c) Jpar[c] = Jpar[NPAR + c] = 0.0;
+      for (int c = 0; c < NP; ++c) Jpar[c] = Jpar[NP + c] = 0.0;
       Jpar[0] = fu_d;
-      Jpar[NPAR + (two_f ? 1 : 0)] = fv_d;
+      Jpar[NP + (two_f ? 1 : 0)] = fv_d;
       Jpar[ic] = 1.0;
-      Jpar[NPAR + ic + 1] = 1.0;
+      Jpar[NP + ic + 1] = 1.0;
       for (int i = 0; i < nk; ++i) {
         Jpar[ic + 2 + i] = f1 * fu * tp[i];
-        Jpar[NPAR + ic + 2 + i] = f2 * fv * tp[i];
+        Jpar[NP + ic + 2 + i] = f2 * fv * tp[i];
       }
+    }
+    return true;
+  }
+  if (NP >= 12 && model == BA_FULL_OPENCV) {  // models_jacobian.h:498-625: rational radial term num / den + tangential
+    const double f1 = prm[0], f2 = prm[1], k1 = prm[4], k2 = prm[5], p1 = prm[6], p2 = prm[7];
+    const double k3 = prm[8], k4 = prm[9], k5 = prm[10], k6 = prm[11];
+    const double uu2 = uu * uu, vv2 = vv * vv, uv = uu * vv, r2 = uu2 + vv2, r4 = r2 * r2, r6 = r4 * r2;
+    const double num = 1.0 + k1 * r2 + k2 * r4 + k3 * r6;
+    const double den = 1.0 + k4 * r2 + k5 * r4 + k6 * r6;
+    const double inv_den = 1.0 / den;
+    const double radial = num * inv_den;
+    const double xd = uu * radial + 2.0 * p1 * uv + p2 * (r2 + 2.0 * uu2);
+    const double yd = vv * radial + 2.0 * p2 * uv + p1 * (r2 + 2.0 * vv2);
+    x = f1 * xd + prm[2];
+    y = f2 * yd + prm[3];
+    if (JAC) {
+      const double num_prime = k1 + 2.0 * k2 * r2 + 3.0 * k3 * r4;
+      const double den_prime = k4 + 2.0 * k5 * r2 + 3.0 * k6 * r4;
+      const double d_radial = (num_prime * den - num * den_prime) * inv_den * inv_den;
+      const double cross = 2.0 * uv * d_radial;
+      const double a00 = f1 * (radial + 2.0 * uu2 * d_radial + 2.0 * p1 * vv + 6.0 * p2 * uu);
+      const double a01 = f1 * (cross + 2.0 * p1 * uu + 2.0 * p2 * vv);
+      const double a10 = f2 * (cross + 2.0 * p2 * vv + 2.0 * p1 * uu);
+      const double a11 = f2 * (radial + 2.0 * vv2 * d_radial + 2.0 * p2 * uu + 6.0 * p1 * vv);
+      Juvw[0] = a00 * inv_w; Juvw[1] = a01 * inv_w; Juvw[2] = -(a00 * uu + a01 * vv) * inv_w;
+      Juvw[3] = a10 * inv_w; Juvw[4] = a11 * inv_w; Juvw[5] = -(a10 * uu + a11 * vv) * inv_w;
+      const double n1 = r2 * inv_den, n2 = r4 * inv_den, n3 = r6 * inv_den;
+      const double nn = -num * inv_den * inv_den;
+      const double d4 = nn * r2, d5 = nn * r4, d6 = nn * r6;
+      Jpar[0] = xd; Jpar[1] = 0.0; Jpar[2] = 1.0; Jpar[3] = 0.0;
+      Jpar[4] = f1 * uu * n1; Jpar[5] = f1 * uu * n2; Jpar[6] = f1 * 2.0 * uv; Jpar[7] = f1 * (r2 + 2.0 * uu2);
+      Jpar[8] = f1 * uu * n3; Jpar[9] = f1 * uu * d4; Jpar[10] = f1 * uu * d5; Jpar[11] = f1 * uu * d6;
+      Jpar[NP + 0] = 0.0; Jpar[NP + 1] = yd; Jpar[NP + 2] = 0.0; Jpar[NP + 3] = 1.0;
+      Jpar[NP + 4] = f2 * vv * n1; Jpar[NP + 5] = f2 * vv * n2; Jpar[NP + 6] = f2 * (r2 + 2.0 * vv2);
+      Jpar[NP + 7] = f2 * 2.0 * uv;
+      Jpar[NP + 8] = f2 * vv * n3; Jpar[NP + 9] = f2 * vv * d4; Jpar[NP + 10] = f2 * vv * d5; Jpar[NP + 11] = f2 * vv * d6;
+    }
+    return true;
+  }
+  if (NP >= 12 && model == BA_THIN_PRISM_FISHEYE) {
+    // models_jacobian.h:944-1047: equidistant projection, then radial (k1..k4) + tangential (p1, p2) +
+    // thin-prism (sx1, sy1) distortion in fisheye coordinates
+    const double f1 = prm[0], f2 = prm[1], k1 = prm[4], k2 = prm[5], p1 = prm[6], p2 = prm[7];
+    const double k3 = prm[8], k4 = prm[9], sx1 = prm[10], sy1 = prm[11];
+    const double a = uu, b = vv;
+    const double rr2 = a * a + b * b;
+    const double rr = sqrt(rr2);
+    double fu, fv, Jf0 = 1.0, Jf1 = 0.0, Jf2 = 0.0, Jf3 = 1.0;
+    if (rr < 2.220446049250313e-16) {
+      fu = a;
+      fv = b;
+    } else {
+      const double theta = atan(rr);
+      const double sc = theta / rr;
+      fu = sc * a;
+      fv = sc * b;
+      if (JAC) {
+        const double g = (rr / (1.0 + rr2) - theta) / (rr2 * rr);
+        Jf0 = sc + a * a * g; Jf1 = a * b * g; Jf2 = a * b * g; Jf3 = sc + b * b * g;
+      }
+    }
+    const double fu2 = fu * fu, fv2 = fv * fv, fuv = fu * fv, r2 = fu2 + fv2, r4 = r2 * r2, r6 = r4 * r2, r8 = r4 * r4;
+    const double radial = k1 * r2 + k2 * r4 + k3 * r6 + k4 * r8;
+    const double du = fu * radial + 2.0 * p1 * fuv + p2 * (r2 + 2.0 * fu2) + sx1 * r2;
+    const double dv = fv * radial + 2.0 * p2 * fuv + p1 * (r2 + 2.0 * fv2) + sy1 * r2;
+    const double fu_d = fu + du, fv_d = fv + dv;
+    x = f1 * fu_d + prm[2];
+    y = f2 * fv_d + prm[3];
+    if (JAC) {
+      const double d_radial = k1 + 2.0 * k2 * r2 + 3.0 * k3 * r4 + 4.0 * k4 * r6;
+      const double cross = 2.0 * fuv * d_radial;
+      const double i0 = 1.0 + radial + 2.0 * fu2 * d_radial + 2.0 * p1 * fv + 6.0 * p2 * fu + 2.0 * sx1 * fu;
+      const double i1 = cross + 2.0 * p1 * fu + 2.0 * p2 * fv + 2.0 * sx1 * fv;
+      const double i2 = cross + 2.0 * p2 * fv + 2.0 * p1 * fu + 2.0 * sy1 * fu;
+      const double i3 = 1.0 + radial + 2.0 * fv2 * d_radial + 2.0 * p2 * fu + 6.0 * p1 * fv + 2.0 * sy1 * fv;
+      const double m0 = i0 * Jf0 + i1 * Jf2, m1 = i0 * Jf1 + i1 * Jf3;
+      const double m2 = i2 * Jf0 + i3 * Jf2, m3 = i2 * Jf1 + i3 * Jf3;
+      const double A0 = f1 * m0, A1 = f1 * m1, A2 = f2 * m2, A3 = f2 * m3;
+      Juvw[0] = A0 * inv_w; Juvw[1] = A1 * inv_w; Juvw[2] = -(A0 * a + A1 * b) * inv_w;
+      Juvw[3] = A2 * inv_w; Juvw[4] = A3 * inv_w; Juvw[5] = -(A2 * a + A3 * b) * inv_w;
+      Jpar[0] = fu_d; Jpar[1] = 0.0; Jpar[2] = 1.0; Jpar[3] = 0.0;
+      Jpar[4] = f1 * fu * r2; Jpar[5] = f1 * fu * r4; Jpar[6] = f1 * 2.0 * fuv; Jpar[7] = f1 * (r2 + 2.0 * fu2);
+      Jpar[8] = f1 * fu * r6; Jpar[9] = f1 * fu * r8; Jpar[10] = f1 * r2; Jpar[11] = 0.0;
+      Jpar[NP + 0] = 0.0; Jpar[NP + 1] = fv_d; Jpar[NP + 2] = 0.0; Jpar[NP + 3] = 1.0;
+      Jpar[NP + 4] = f2 * fv * r2; Jpar[NP + 5] = f2 * fv * r4; Jpar[NP + 6] = f2 * (r2 + 2.0 * fv2);
+      Jpar[NP + 7] = f2 * 2.0 * fuv;
+      Jpar[NP + 8] = f2 * fv * r6; Jpar[NP + 9] = f2 * fv * r8; Jpar[NP + 10] = 0.0; Jpar[NP + 11] = f2 * r2;
     }
     return true;
   }
@@ -436,9 +527,9 @@ __device__ __forceinline__ bool img_from_cam(int model, const double* prm, doubl
       Juvw[3] = a10 * inv_w; Juvw[4] = a11 * inv_w; Juvw[5] = -(a10 * uu + a11 * vv) * inv_w;
       Jpar[0] = xd; Jpar[1] = 0.0; Jpar[2] = 1.0; Jpar[3] = 0.0;
       Jpar[4] = f1 * uu * r2; Jpar[5] = f1 * uu * r4; Jpar[6] = f1 * 2.0 * uv; Jpar[7] = f1 * (r2 + 2.0 * uu2);
-      Jpar[NPAR + 0] = 0.0; Jpar[NPAR + 1] = yd; Jpar[NPAR + 2] = 0.0; Jpar[NPAR + 3] = 1.0;
-      Jpar[NPAR + 4] = f2 * vv * r2; Jpar[NPAR + 5] = f2 * vv * r4; Jpar[NPAR + 6] = f2 * (r2 + 2.0 * vv2);
-      Jpar[NPAR + 7] = f2 * 2.0 * uv;
+      Jpar[NP + 0] = 0.0; Jpar[NP + 1] = yd; Jpar[NP + 2] = 0.0; Jpar[NP + 3] = 1.0;
+      Jpar[NP + 4] = f2 * vv * r2; Jpar[NP + 5] = f2 * vv * r4; Jpar[NP + 6] = f2 * (r2 + 2.0 * vv2);
+      Jpar[NP + 7] = f2 * 2.0 * uv;
     }
     return true;
   }
@@ -459,8 +550,8 @@ __device__ __forceinline__ bool img_from_cam(int model, const double* prm, doubl
       Juvw[0] = a00 * inv_w; Juvw[1] = a01 * inv_w; Juvw[2] = -(a00 * uu + a01 * vv) * inv_w;
       Juvw[3] = a10 * inv_w; Juvw[4] = a11 * inv_w; Juvw[5] = -(a10 * uu + a11 * vv) * inv_w;
       Jpar[0] = xd; Jpar[1] = 1.0; Jpar[2] = 0.0; Jpar[3] = f * uu * r2; Jpar[4] = f * uu * r4;
-      Jpar[NPAR + 0] = yd; Jpar[NPAR + 1] = 0.0; Jpar[NPAR + 2] = 1.0; Jpar[NPAR + 3] = f * vv * r2;
-      Jpar[NPAR + 4] = f * vv * r4;
+      Jpar[NP + 0] = yd; Jpar[NP + 1] = 0.0; Jpar[NP + 2] = 1.0; Jpar[NP + 3] = f * vv * r2;
+      Jpar[NP + 4] = f * vv * r4;
     }
     return true;
   }
@@ -474,7 +565,7 @@ __device__ __forceinline__ bool img_from_cam(int model, const double* prm, doubl
     Juvw[0] = fw * (alpha + two_k * uu2); Juvw[1] = fw * tkuv; Juvw[2] = -fw * uu * beta;
     Juvw[3] = fw * tkuv; Juvw[4] = fw * (alpha + two_k * vv2); Juvw[5] = -fw * vv * beta;
     Jpar[0] = xd; Jpar[1] = 1.0; Jpar[2] = 0.0; Jpar[3] = f * uu * r2;
-    Jpar[NPAR + 0] = yd; Jpar[NPAR + 1] = 0.0; Jpar[NPAR + 2] = 1.0; Jpar[NPAR + 3] = f * vv * r2;
+    Jpar[NP + 0] = yd; Jpar[NP + 1] = 0.0; Jpar[NP + 2] = 1.0; Jpar[NP + 3] = f * vv * r2;
   }
   return true;
 }
@@ -539,7 +630,8 @@ __global__ void __launch_bounds__(256) ba_linearize_kernel(View V, const double*
     const double* prm = cams + BA_CAM_STRIDE * (size_t)ci;
     const double* X = points + 3 * (size_t)xi;
     const int model = V.cam_model[ci];
-    double JR[12], Juvw[6], Jpar[2 * NPAR], pc[3];
+    constexpr int NP = KD > KD_MAX ? NPAR_WIDE : NPAR;  // J_params columns (12-parameter models only in the wide tier)
+    double JR[12], Juvw[6], Jpar[2 * NP], pc[3];
     quat_rotate(q, X, pc, JAC ? JR : nullptr);
     pc[0] += q[4]; pc[1] += q[5]; pc[2] += q[6];
     // sensor_from_rig (RigReprojErrorCostFunctor / ...ConstantRigCostFunctor, reprojection_error.h:
@@ -560,7 +652,7 @@ __global__ void __launch_bounds__(256) ba_linearize_kernel(View V, const double*
       pc[2] = Rs[6] * p0 + Rs[7] * p1 + Rs[8] * p2 + sfr[6];
     }
     double rx = 0.0, ry = 0.0;
-    const bool ok = img_from_cam<JAC>(model, prm, pc[0], pc[1], pc[2], rx, ry, Jpar, Juvw);
+    const bool ok = img_from_cam<JAC, NP>(model, prm, pc[0], pc[1], pc[2], rx, ry, Jpar, Juvw);
     if (ok) {
       rx -= V.o_xy[2 * (size_t)o];
       ry -= V.o_xy[2 * (size_t)o + 1];
@@ -652,7 +744,7 @@ __global__ void __launch_bounds__(256) ba_linearize_kernel(View V, const double*
         for (int r = 0; r < 2; ++r)
 #pragma unroll
           for (int c = 0; c < KD; ++c)
-            if (c < cdim) Jk[r][c] = Jpar[NPAR * r + V.cam_var[KD * ci + c]];
+            if (c < cdim) Jk[r][c] = Jpar[NP * r + V.cam_var[KD * ci + c]];
       }
       // point block: J_uvw * R(q)
       if (ok && ptoff >= 0) {
@@ -1590,26 +1682,29 @@ struct Solver {
   int build(ba_result* res_out) {
     const ba_problem& p = prob;
     std::vector<int> cam_nvar(p.num_cams, 0);
-    std::vector<int> wide_cam_var((size_t)p.num_cams * KD_MAX, 0), h_cam_dim(p.num_cams, 0);
-    int max_nvar = 0;
+    std::vector<int> wide_cam_var((size_t)p.num_cams * KD_WIDE, 0), h_cam_dim(p.num_cams, 0);
+    int max_nvar = 0, max_npar = 0;
     for (int k = 0; k < p.num_cams; ++k) {
       const int model = p.cam_model[k];
       if (!model_supported(model))
         throw std::runtime_error("unsupported camera model id " + std::to_string(model) +
                                  " (supported: SIMPLE_PINHOLE, PINHOLE, SIMPLE_RADIAL, RADIAL, OPENCV, "
                                  "OPENCV_FISHEYE, FOV, SIMPLE_RADIAL_FISHEYE, RADIAL_FISHEYE, SIMPLE_DIVISION, "
-                                 "DIVISION, SIMPLE_FISHEYE, FISHEYE, EUCM)");
+                                 "DIVISION, SIMPLE_FISHEYE, FISHEYE, EUCM, FULL_OPENCV, THIN_PRISM_FISHEYE)");
       const int P = num_params_of(model);
       for (int j = 0; j < P; ++j)
-        if (!p.cam_const[(size_t)k * BA_CAM_STRIDE + j]) wide_cam_var[(size_t)k * KD_MAX + cam_nvar[k]++] = j;
+        if (!p.cam_const[(size_t)k * BA_CAM_STRIDE + j]) wide_cam_var[(size_t)k * KD_WIDE + cam_nvar[k]++] = j;
       max_nvar = std::max(max_nvar, cam_nvar[k]);
+      max_npar = std::max(max_npar, P);
     }
-    // <KD, BD> of this problem (see the constants at the top of the file)
-    kd = max_nvar <= 4 ? 4 : KD_MAX;
-    bd = max_nvar <= 4 ? PD : KD_MAX;
+    // <KD, BD> of this problem (see the constants at the top of the file); a 12-parameter model takes
+    // the wide tier whatever its number of variable intrinsics (only that tier evaluates 12 J_params columns)
+    if (max_npar > NPAR || max_nvar > KD_MAX) kd = bd = KD_WIDE;
+    else if (max_nvar <= 4) { kd = 4; bd = PD; }
+    else kd = bd = KD_MAX;
     std::vector<int> h_cam_var((size_t)p.num_cams * kd, 0);
     for (int k = 0; k < p.num_cams; ++k)
-      for (int d = 0; d < cam_nvar[k]; ++d) h_cam_var[(size_t)k * kd + d] = wide_cam_var[(size_t)k * KD_MAX + d];
+      for (int d = 0; d < cam_nvar[k]; ++d) h_cam_var[(size_t)k * kd + d] = wide_cam_var[(size_t)k * KD_WIDE + d];
     std::vector<int64_t> active;
     active.reserve(p.num_obs / comm.world + 1);
     int64_t n_active_global = 0;
@@ -1859,6 +1954,9 @@ struct Solver {
     if (kd == 4) {
       if (jac) BA_LAUNCH((ba_linearize_kernel<true, 4>), dim3(g), dim3(256), st, V, P, Cm, X, Sn, partials.p);
       else BA_LAUNCH((ba_linearize_kernel<false, 4>), dim3(g), dim3(256), st, V, P, Cm, X, Sn, partials.p);
+    } else if (kd == KD_WIDE) {
+      if (jac) BA_LAUNCH((ba_linearize_kernel<true, KD_WIDE>), dim3(g), dim3(256), st, V, P, Cm, X, Sn, partials.p);
+      else BA_LAUNCH((ba_linearize_kernel<false, KD_WIDE>), dim3(g), dim3(256), st, V, P, Cm, X, Sn, partials.p);
     } else {
       if (jac) BA_LAUNCH((ba_linearize_kernel<true, KD_MAX>), dim3(g), dim3(256), st, V, P, Cm, X, Sn, partials.p);
       else BA_LAUNCH((ba_linearize_kernel<false, KD_MAX>), dim3(g), dim3(256), st, V, P, Cm, X, Sn, partials.p);
@@ -1872,6 +1970,7 @@ struct Solver {
     BA_HIP(hipMemsetAsync(diag_c.p, 0, sizeof(double) * std::max(V.n_c, 1), st));
     if (V.n_chunks > 0) {
       if (bd == PD) BA_LAUNCH((ba_block_jtv_kernel<true, PD>), dim3(V.n_chunks), dim3(64), st, V, res.p, gc.p, diag_c.p);
+      else if (bd == KD_WIDE) BA_LAUNCH((ba_block_jtv_kernel<true, KD_WIDE>), dim3(V.n_chunks), dim3(64), st, V, res.p, gc.p, diag_c.p);
       else BA_LAUNCH((ba_block_jtv_kernel<true, KD_MAX>), dim3(V.n_chunks), dim3(64), st, V, res.p, gc.p, diag_c.p);
       BA_LAUNCH(ba_block_vec_finalize_kernel<true>, dim3(grid_for(V.n_blk, 128)), dim3(128), st, V, gc.p, diag_c.p);
     }
@@ -1891,6 +1990,7 @@ struct Solver {
     BA_HIP(hipMemsetAsync(tmpc.p, 0, sizeof(double) * std::max(V.n_c, 1), st));
     if (V.n_chunks > 0) {
       if (bd == PD) BA_LAUNCH((ba_block_jtv_kernel<false, PD>), dim3(V.n_chunks), dim3(64), st, V, vin, tmpc.p, nullptr);
+      else if (bd == KD_WIDE) BA_LAUNCH((ba_block_jtv_kernel<false, KD_WIDE>), dim3(V.n_chunks), dim3(64), st, V, vin, tmpc.p, nullptr);
       else BA_LAUNCH((ba_block_jtv_kernel<false, KD_MAX>), dim3(V.n_chunks), dim3(64), st, V, vin, tmpc.p, nullptr);
       BA_LAUNCH(ba_block_vec_finalize_kernel<false>, dim3(grid_for(V.n_blk, 128)), dim3(128), st, V, tmpc.p, nullptr);
     }
@@ -1911,6 +2011,7 @@ struct Solver {
     const int go = grid_for(V.n_obs, 256);
     if (V.n_obs > 0) {
       if (kd == 4) BA_LAUNCH(ba_obs_jx_kernel<4>, dim3(go), dim3(256), st, V, xin, jx.p);
+      else if (kd == KD_WIDE) BA_LAUNCH(ba_obs_jx_kernel<KD_WIDE>, dim3(go), dim3(256), st, V, xin, jx.p);
       else BA_LAUNCH(ba_obs_jx_kernel<KD_MAX>, dim3(go), dim3(256), st, V, xin, jx.p);
     }
     if (comm.world == 1 || comm.by_point) {
@@ -2053,12 +2154,14 @@ struct Solver {
           BA_LAUNCH(ba_block_mat_finalize_kernel<false>, dim3(grid_for(V.n_blk, 128)), dim3(128), st, V, M.p);
           if (n_paired > 0) {  // observation pairs of a point inside one block: shared intrinsics, rig frames
             if (bd == PD) BA_LAUNCH(ba_block_schur_cross_kernel<PD>, dim3(V.n_chunks), dim3(64), st, V, Cinv.p);
+            else if (bd == KD_WIDE) BA_LAUNCH(ba_block_schur_cross_kernel<KD_WIDE>, dim3(V.n_chunks), dim3(64), st, V, Cinv.p);
             else BA_LAUNCH(ba_block_schur_cross_kernel<KD_MAX>, dim3(V.n_chunks), dim3(64), st, V, Cinv.p);
             BA_LAUNCH(ba_block_mat_finalize_kernel<true>, dim3(grid_for(V.n_blk, 128)), dim3(128), st, V, M.p);
           }
         }
         comm.allreduce(M.p, (size_t)moff_total, st);
         if (bd == PD) BA_LAUNCH(ba_block_invert_kernel<PD>, dim3(grid_for(V.n_blk, 64)), dim3(64), st, V, Dc.p, M.p, Minv.p);
+        else if (bd == KD_WIDE) BA_LAUNCH(ba_block_invert_kernel<KD_WIDE>, dim3(grid_for(V.n_blk, 64)), dim3(64), st, V, Dc.p, M.p, Minv.p);
         else BA_LAUNCH(ba_block_invert_kernel<KD_MAX>, dim3(grid_for(V.n_blk, 64)), dim3(64), st, V, Dc.p, M.p, Minv.p);
         // reduced rhs = g_c - E C^-1 g_p  (g_p, C^-1 are global; the J_c^T part is summed over ranks)
         point_pass<1>();
@@ -2071,6 +2174,7 @@ struct Solver {
       // back-substitution y_p = C^-1 (g_p - E^T y_c); step = -(y_c, y_p)
       if (V.n_obs > 0) {
         if (kd == 4) BA_LAUNCH(ba_obs_jx_kernel<4>, dim3(grid_for(V.n_obs, 256)), dim3(256), st, V, x.p, jx.p);
+        else if (kd == KD_WIDE) BA_LAUNCH(ba_obs_jx_kernel<KD_WIDE>, dim3(grid_for(V.n_obs, 256)), dim3(256), st, V, x.p, jx.p);
         else BA_LAUNCH(ba_obs_jx_kernel<KD_MAX>, dim3(grid_for(V.n_obs, 256)), dim3(256), st, V, x.p, jx.p);
       }
       if (comm.world == 1 || comm.by_point) {

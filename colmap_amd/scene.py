@@ -23,16 +23,18 @@ import numpy as np
 
 # colmap::CameraModelId (sensor/models.h:90-111)
 SIMPLE_PINHOLE, PINHOLE, SIMPLE_RADIAL, RADIAL, OPENCV = 0, 1, 2, 3, 4
-OPENCV_FISHEYE, FOV, SIMPLE_RADIAL_FISHEYE, RADIAL_FISHEYE = 5, 7, 8, 9
+OPENCV_FISHEYE, FULL_OPENCV, FOV, SIMPLE_RADIAL_FISHEYE, RADIAL_FISHEYE, THIN_PRISM_FISHEYE = 5, 6, 7, 8, 9, 10
 SIMPLE_DIVISION, DIVISION, SIMPLE_FISHEYE, FISHEYE, EUCM = 12, 13, 14, 15, 16
 MODEL_NAMES = {SIMPLE_PINHOLE: "SIMPLE_PINHOLE", PINHOLE: "PINHOLE", SIMPLE_RADIAL: "SIMPLE_RADIAL", RADIAL: "RADIAL",
                OPENCV: "OPENCV", OPENCV_FISHEYE: "OPENCV_FISHEYE", FOV: "FOV",
                SIMPLE_RADIAL_FISHEYE: "SIMPLE_RADIAL_FISHEYE", RADIAL_FISHEYE: "RADIAL_FISHEYE",
                SIMPLE_DIVISION: "SIMPLE_DIVISION", DIVISION: "DIVISION", SIMPLE_FISHEYE: "SIMPLE_FISHEYE",
-               FISHEYE: "FISHEYE", EUCM: "EUCM"}
+               FISHEYE: "FISHEYE", EUCM: "EUCM", FULL_OPENCV: "FULL_OPENCV",
+               THIN_PRISM_FISHEYE: "THIN_PRISM_FISHEYE"}
 MODEL_NUM_PARAMS = {SIMPLE_PINHOLE: 3, PINHOLE: 4, SIMPLE_RADIAL: 4, RADIAL: 5, OPENCV: 8,
                     OPENCV_FISHEYE: 8, FOV: 5, SIMPLE_RADIAL_FISHEYE: 4, RADIAL_FISHEYE: 5,
-                    SIMPLE_DIVISION: 4, DIVISION: 5, SIMPLE_FISHEYE: 3, FISHEYE: 4, EUCM: 6}
+                    SIMPLE_DIVISION: 4, DIVISION: 5, SIMPLE_FISHEYE: 3, FISHEYE: 4, EUCM: 6,
+                    FULL_OPENCV: 12, THIN_PRISM_FISHEYE: 12}
 # FocalLengthIdxs / PrincipalPointIdxs / ExtraParamsIdxs (sensor/models.h)
 _ONE_F = (SIMPLE_PINHOLE, SIMPLE_RADIAL, RADIAL, SIMPLE_RADIAL_FISHEYE, RADIAL_FISHEYE, SIMPLE_DIVISION, SIMPLE_FISHEYE)
 MODEL_FOCAL_IDXS = {m: ([0] if m in _ONE_F else [0, 1]) for m in MODEL_NUM_PARAMS}
@@ -250,6 +252,24 @@ def img_from_cam(model_id: int, params: np.ndarray, uvw: np.ndarray) -> np.ndarr
             ks = params[3:]
         radial = sum(k * t2 ** (i + 1) for i, k in enumerate(ks))
         return np.stack([f1 * (fu + fu * radial) + c1, f2 * (fv + fv * radial) + c2], 1)
+    if model_id == FULL_OPENCV:  # FullOpenCVCameraModel::Distortion: rational radial term + tangential
+        f1, f2, c1, c2, k1, k2, p1, p2, k3, k4, k5, k6 = params
+        r2 = uu * uu + vv * vv
+        radial = (1 + k1 * r2 + k2 * r2 ** 2 + k3 * r2 ** 3) / (1 + k4 * r2 + k5 * r2 ** 2 + k6 * r2 ** 3)
+        xd = uu * radial + 2 * p1 * uu * vv + p2 * (r2 + 2 * uu * uu)
+        yd = vv * radial + 2 * p2 * uu * vv + p1 * (r2 + 2 * vv * vv)
+        return np.stack([f1 * xd + c1, f2 * yd + c2], 1)
+    if model_id == THIN_PRISM_FISHEYE:  # ThinPrismFisheyeCameraModel: equidistant, then radial + tangential + thin prism
+        f1, f2, c1, c2, k1, k2, p1, p2, k3, k4, sx1, sy1 = params
+        r = np.sqrt(uu * uu + vv * vv)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            sc = np.where(r < np.finfo(np.float64).eps, 1.0, np.arctan(r) / r)
+        fu, fv = sc * uu, sc * vv
+        t2 = fu * fu + fv * fv
+        radial = k1 * t2 + k2 * t2 ** 2 + k3 * t2 ** 3 + k4 * t2 ** 4
+        du = fu * radial + 2 * p1 * fu * fv + p2 * (t2 + 2 * fu * fu) + sx1 * t2
+        dv = fv * radial + 2 * p2 * fu * fv + p1 * (t2 + 2 * fv * fv) + sy1 * t2
+        return np.stack([f1 * (fu + du) + c1, f2 * (fv + dv) + c2], 1)
     if model_id == OPENCV:  # sensor/models.h OpenCVCameraModel::ImgFromCam / Distortion
         f1, f2, c1, c2, k1, k2, p1, p2 = params
         r2 = uu * uu + vv * vv

@@ -522,7 +522,8 @@ class PatchMatch {
 
 // ---------------------------------------------------------------------------------------------
 // Depth-map fusion (reference mvs/fusion.h:46-139, fusion.cc) on in-memory inputs. The workspace
-// reading of StereoFusion::Run stays with the caller; the traversal is the reference's with one thread.
+// reading of StereoFusion::Run stays with the caller; the traversal runs on the GPU (fusion.hip) and equals the
+// reference's algorithm run sequentially in a fixed pixel order (colmap_amd_fusion.h).
 // ---------------------------------------------------------------------------------------------
 struct StereoFusionOptions {  // fusion.h:46-94 (the fields that reach the traversal)
   int min_num_pixels = 5;

@@ -43,8 +43,8 @@
 /* COLMAP CameraModelId values (sensor/models.h:90-111) */
 enum {
   BAO_SIMPLE_PINHOLE = 0, BAO_PINHOLE = 1, BAO_SIMPLE_RADIAL = 2, BAO_RADIAL = 3, BAO_OPENCV = 4,
-  BAO_OPENCV_FISHEYE = 5, BAO_FOV = 7, BAO_SIMPLE_RADIAL_FISHEYE = 8, BAO_RADIAL_FISHEYE = 9,
-  BAO_SIMPLE_DIVISION = 12, BAO_DIVISION = 13, BAO_SIMPLE_FISHEYE = 14, BAO_FISHEYE = 15, BAO_EUCM = 16
+  BAO_OPENCV_FISHEYE = 5, BAO_FULL_OPENCV = 6, BAO_FOV = 7, BAO_SIMPLE_RADIAL_FISHEYE = 8, BAO_RADIAL_FISHEYE = 9,
+  BAO_THIN_PRISM_FISHEYE = 10, BAO_SIMPLE_DIVISION = 12, BAO_DIVISION = 13, BAO_SIMPLE_FISHEYE = 14, BAO_FISHEYE = 15, BAO_EUCM = 16
 };
 
 typedef struct {
@@ -181,6 +181,8 @@ static int num_params_of(int model) {
     case BAO_SIMPLE_FISHEYE: return 3;
     case BAO_FISHEYE: return 4;
     case BAO_EUCM: return 6;
+    case BAO_FULL_OPENCV: return 12;
+    case BAO_THIN_PRISM_FISHEYE: return 12;
     default: return -1;
   }
 }
@@ -411,6 +413,94 @@ static int img_from_cam_jac(int model, const double* params, double u, double v,
   if (model == BAO_OPENCV_FISHEYE) { /* :862-942 */
     radial_fisheye_with_jac(params[0], params[1], params[2], params[3], params + 4, 4, 1, u, v, w, x, y,
                             J_params, J_uvw);
+    return 1;
+  }
+  if (model == BAO_FULL_OPENCV) { /* models_jacobian.h:498-625 */
+    const double f1 = params[0], f2 = params[1], c1 = params[2], c2 = params[3];
+    const double k1 = params[4], k2 = params[5], p1 = params[6], p2 = params[7];
+    const double k3 = params[8], k4 = params[9], k5 = params[10], k6 = params[11];
+    const double uu2 = uu * uu, vv2 = vv * vv, uv = uu * vv;
+    const double r2 = uu2 + vv2, r4 = r2 * r2, r6 = r4 * r2;
+    /* rational radial term num / den */
+    const double num = 1.0 + k1 * r2 + k2 * r4 + k3 * r6;
+    const double den = 1.0 + k4 * r2 + k5 * r4 + k6 * r6;
+    const double inv_den = 1.0 / den;
+    const double radial = num * inv_den;
+    const double xd = uu * radial + 2.0 * p1 * uv + p2 * (r2 + 2.0 * uu2);
+    const double yd = vv * radial + 2.0 * p2 * uv + p1 * (r2 + 2.0 * vv2);
+    *x = f1 * xd + c1;
+    *y = f2 * yd + c2;
+    if (J_uvw) {
+      const double num_prime = k1 + 2.0 * k2 * r2 + 3.0 * k3 * r4;
+      const double den_prime = k4 + 2.0 * k5 * r2 + 3.0 * k6 * r4;
+      const double d_radial_d_r2 = (num_prime * den - num * den_prime) * inv_den * inv_den;
+      const double cross = 2.0 * uv * d_radial_d_r2;
+      const double xd_duu = radial + 2.0 * uu2 * d_radial_d_r2 + 2.0 * p1 * vv + 6.0 * p2 * uu;
+      const double xd_dvv = cross + 2.0 * p1 * uu + 2.0 * p2 * vv;
+      const double yd_duu = cross + 2.0 * p2 * vv + 2.0 * p1 * uu;
+      const double yd_dvv = radial + 2.0 * vv2 * d_radial_d_r2 + 2.0 * p2 * uu + 6.0 * p1 * vv;
+      const double a00 = f1 * xd_duu, a01 = f1 * xd_dvv, a10 = f2 * yd_duu, a11 = f2 * yd_dvv;
+      J_uvw[0] = a00 * inv_w; J_uvw[1] = a01 * inv_w; J_uvw[2] = -(a00 * uu + a01 * vv) * inv_w;
+      J_uvw[3] = a10 * inv_w; J_uvw[4] = a11 * inv_w; J_uvw[5] = -(a10 * uu + a11 * vv) * inv_w;
+    }
+    if (J_params) {
+      const double rp[3] = {r2, r4, r6};
+      const double neg_num_inv_den2 = -num * inv_den * inv_den;
+      double* r0 = J_params;
+      double* r1 = J_params + 12;
+      r0[0] = xd; r0[1] = 0.0; r0[2] = 1.0; r0[3] = 0.0;
+      r1[0] = 0.0; r1[1] = yd; r1[2] = 0.0; r1[3] = 1.0;
+      r0[4] = f1 * uu * rp[0] * inv_den; r0[5] = f1 * uu * rp[1] * inv_den;
+      r1[4] = f2 * vv * rp[0] * inv_den; r1[5] = f2 * vv * rp[1] * inv_den;
+      r0[6] = f1 * 2.0 * uv; r0[7] = f1 * (r2 + 2.0 * uu2);
+      r1[6] = f2 * (r2 + 2.0 * vv2); r1[7] = f2 * 2.0 * uv;
+      r0[8] = f1 * uu * rp[2] * inv_den; r1[8] = f2 * vv * rp[2] * inv_den;
+      for (int i = 0; i < 3; ++i) {
+        r0[9 + i] = f1 * uu * (neg_num_inv_den2 * rp[i]);
+        r1[9 + i] = f2 * vv * (neg_num_inv_den2 * rp[i]);
+      }
+    }
+    return 1;
+  }
+  if (model == BAO_THIN_PRISM_FISHEYE) { /* models_jacobian.h:944-1047 */
+    const double f1 = params[0], f2 = params[1], c1 = params[2], c2 = params[3];
+    const double k1 = params[4], k2 = params[5], p1 = params[6], p2 = params[7];
+    const double k3 = params[8], k4 = params[9], sx1 = params[10], sy1 = params[11];
+    const double a = uu, b = vv; /* normalised coordinates */
+    double fu, fv, Jf[4] = {0, 0, 0, 0};
+    fisheye_projection_with_jac(a, b, &fu, &fv, J_uvw ? Jf : NULL);
+    const double fu2 = fu * fu, fv2 = fv * fv, fuv = fu * fv;
+    const double r2 = fu2 + fv2, r4 = r2 * r2, r6 = r4 * r2, r8 = r4 * r4;
+    const double radial = k1 * r2 + k2 * r4 + k3 * r6 + k4 * r8;
+    const double du = fu * radial + 2.0 * p1 * fuv + p2 * (r2 + 2.0 * fu2) + sx1 * r2;
+    const double dv = fv * radial + 2.0 * p2 * fuv + p1 * (r2 + 2.0 * fv2) + sy1 * r2;
+    const double fu_d = fu + du, fv_d = fv + dv;
+    *x = f1 * fu_d + c1;
+    *y = f2 * fv_d + c2;
+    if (J_uvw) {
+      const double d_radial = k1 + 2.0 * k2 * r2 + 3.0 * k3 * r4 + 4.0 * k4 * r6;
+      const double cross = 2.0 * fuv * d_radial;
+      const double ipjd[4] = {
+          1.0 + radial + 2.0 * fu2 * d_radial + 2.0 * p1 * fv + 6.0 * p2 * fu + 2.0 * sx1 * fu,
+          cross + 2.0 * p1 * fu + 2.0 * p2 * fv + 2.0 * sx1 * fv,
+          cross + 2.0 * p2 * fv + 2.0 * p1 * fu + 2.0 * sy1 * fu,
+          1.0 + radial + 2.0 * fv2 * d_radial + 2.0 * p2 * fu + 6.0 * p1 * fv + 2.0 * sy1 * fv};
+      const double m[4] = {ipjd[0] * Jf[0] + ipjd[1] * Jf[2], ipjd[0] * Jf[1] + ipjd[1] * Jf[3],
+                           ipjd[2] * Jf[0] + ipjd[3] * Jf[2], ipjd[2] * Jf[1] + ipjd[3] * Jf[3]};
+      const double Jab[4] = {f1 * m[0], f1 * m[1], f2 * m[2], f2 * m[3]};
+      J_uvw[0] = Jab[0] * inv_w; J_uvw[1] = Jab[1] * inv_w; J_uvw[2] = -(Jab[0] * a + Jab[1] * b) * inv_w;
+      J_uvw[3] = Jab[2] * inv_w; J_uvw[4] = Jab[3] * inv_w; J_uvw[5] = -(Jab[2] * a + Jab[3] * b) * inv_w;
+    }
+    if (J_params) {
+      double* r0 = J_params;
+      double* r1 = J_params + 12;
+      r0[0] = fu_d; r0[1] = 0.0; r0[2] = 1.0; r0[3] = 0.0;
+      r1[0] = 0.0; r1[1] = fv_d; r1[2] = 0.0; r1[3] = 1.0;
+      r0[4] = f1 * fu * r2; r0[5] = f1 * fu * r4; r0[6] = f1 * 2.0 * fuv; r0[7] = f1 * (r2 + 2.0 * fu2);
+      r1[4] = f2 * fv * r2; r1[5] = f2 * fv * r4; r1[6] = f2 * (r2 + 2.0 * fv2); r1[7] = f2 * 2.0 * fuv;
+      r0[8] = f1 * fu * r6; r0[9] = f1 * fu * r8; r0[10] = f1 * r2; r0[11] = 0.0;
+      r1[8] = f2 * fv * r6; r1[9] = f2 * fv * r8; r1[10] = 0.0; r1[11] = f2 * r2;
+    }
     return 1;
   }
   if (model == BAO_OPENCV) { /* models_jacobian.h:401-496 */
@@ -700,7 +790,7 @@ static void quat_plus_jac(const double* q, double J[12]) {
 /* Program: tangent-space layout of the variable blocks                        */
 /* ------------------------------------------------------------------------- */
 
-#define MAX_CB 20 /* max tangent width of the camera-side blocks seen by one residual: 6 + P_t (P_t <= 8) + 6 */
+#define MAX_CB 24 /* max tangent width of the camera-side blocks seen by one residual: 6 + P_t (P_t <= 12) + 6 */
 
 typedef struct {
   const bao_problem* p;

@@ -54,7 +54,7 @@ def reproj_error(model, point, pose, params, xy, want_jac=True):
     return r, Jpt, Jpose, Jpar
 
 
-NUM_PARAMS = {0: 3, 1: 4, 2: 4, 3: 5, 4: 8, 5: 8, 7: 5, 8: 4, 9: 5, 12: 4, 13: 5, 14: 3, 15: 4, 16: 6}
+NUM_PARAMS = {0: 3, 1: 4, 2: 4, 3: 5, 4: 8, 5: 8, 6: 12, 10: 12, 7: 5, 8: 4, 9: 5, 12: 4, 13: 5, 14: 3, 15: 4, 16: 6}
 
 
 def rig_reproj_error(model, point, rig_from_world, sensor_from_rig, params, xy, want_jac=True):

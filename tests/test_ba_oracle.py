@@ -609,13 +609,17 @@ _REF_MODEL_PARAMS = [
     (scene.EUCM, [400.0, 400.0, 400.0, 400.0, 0.88, 0.64]),
     (scene.EUCM, [651.123, 655.123, 386.123, 511.123, 0.0, 1.0]),
     (scene.EUCM, [651.123, 655.123, 386.123, 511.123, 0.5, 1.0]),
+    # the parameter vectors of the reference's own model tests (sensor/models_test.cc:318-369)
+    (scene.FULL_OPENCV, [651.123, 655.123, 386.123, 511.123, -0.471, 0.223, -0.001, 0.001, 0.001, 0.02, -0.02, 0.001]),
+    (scene.THIN_PRISM_FISHEYE, [651.123, 655.123, 386.123, 511.123, -0.471, 0.223, -0.001, 0.001, 0.001, 0.02, -0.02, 0.001]),
 ]
 
 
 @pytest.mark.parametrize("model,params", _REF_MODEL_PARAMS)
 def test_more_camera_models_values_and_jacobians(model, params):
     """FOV (models_jacobian.h:627-724, all three branches of the distortion), SIMPLE_DIVISION / DIVISION
-    (:88-113, 1291-1411), SIMPLE_FISHEYE / FISHEYE (:1190-1288), EUCM (:1413-1500)."""
+    (:88-113, 1291-1411), SIMPLE_FISHEYE / FISHEYE (:1190-1288), EUCM (:1413-1500), FULL_OPENCV (:498-625),
+    THIN_PRISM_FISHEYE (:944-1047)."""
     pose = np.array([0, 0, 0, 1, 0, 0, 0.0])
     params = np.array(params, np.float64)
     grid = [np.array([u, v, w]) for u in np.arange(-0.5, 0.51, 0.1) for v in np.arange(-0.5, 0.51, 0.1)

@@ -34,6 +34,14 @@ def test_mvs_host_checks(mvs_host, tmp_path):
     assert "host checks OK" in r.stdout
 
 
+@pytest.mark.gpu
+def test_cpp_stereo_fusion(mvs_host):
+    """colmap_amd::mvs::StereoFusion (C++ class over fusion_run, HIP): two fronto-parallel views of a plane."""
+    r = subprocess.run([mvs_host, "fusion"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "fusion checks OK" in r.stdout
+
+
 def _write_problem(d, views, ref, src, geom, filt, iters, dmin, dmax, maps=None):
     from colmap_amd import mvs
     h, w = views[0].gray.shape
