@@ -231,6 +231,14 @@ class FlatProblem:
     obs_sensor: Optional[np.ndarray] = None   # (N_o,) i32, -1 = trivial
     sensor_const: Optional[np.ndarray] = None  # (N_s,) u8, 1 = constant sensor_from_rig (None: all constant)
     sensor_ids: Optional[list] = None          # camera id of every sensor slot (adapter write-back)
+    # position priors (PosePriorBundleAdjuster): residual = sqrt_info (position + R^-1 t) of the pose block,
+    # or of sensor_from_rig * rig_from_world when prior_sensor >= 0
+    prior_pose: Optional[np.ndarray] = None       # (N_q,) i32
+    prior_sensor: Optional[np.ndarray] = None     # (N_q,) i32, -1 = the pose block is the sensor pose
+    prior_position: Optional[np.ndarray] = None   # (N_q, 3) f64
+    prior_sqrt_info: Optional[np.ndarray] = None  # (N_q, 3, 3) f64: left square root of the information matrix
+    prior_loss_type: int = 0
+    prior_loss_scale: float = 1.0
     # id maps for write-back
     pose_ids: List[int] = field(default_factory=list)
     cam_ids: List[int] = field(default_factory=list)
@@ -536,6 +544,9 @@ class ba_problem(C.Structure):
         ("point_const", C.c_void_p),
         ("num_sensors", C.c_int32), ("sensors", C.c_void_p), ("obs_sensor", C.c_void_p),
         ("sensor_const", C.c_void_p),
+        ("num_priors", C.c_int32), ("prior_pose", C.c_void_p), ("prior_sensor", C.c_void_p),
+        ("prior_position", C.c_void_p), ("prior_sqrt_info", C.c_void_p),
+        ("prior_loss_type", C.c_int32), ("prior_loss_scale", C.c_double),
     ]
 
 
@@ -651,6 +662,18 @@ def marshal_problem(fp: FlatProblem) -> ba_problem:
         if fp.sensor_const is not None and not fp.sensor_const.all():
             assert fp.sensor_const.dtype == np.uint8 and fp.sensor_const.flags["C_CONTIGUOUS"]
             p.sensor_const = fp.sensor_const.ctypes.data
+    if fp.prior_pose is not None and len(fp.prior_pose):
+        n = len(fp.prior_pose)
+        if fp.prior_sensor is None:
+            fp.prior_sensor = np.full(n, -1, np.int32)
+        for name, dt, shape in (("prior_pose", np.int32, (n,)), ("prior_sensor", np.int32, (n,)),
+                                ("prior_position", np.float64, (n, 3)), ("prior_sqrt_info", np.float64, (n, 3, 3))):
+            a = getattr(fp, name)
+            assert a.dtype == dt and a.shape == shape and a.flags["C_CONTIGUOUS"], name
+            setattr(p, name, a.ctypes.data)
+        p.num_priors = n
+        p.prior_loss_type = int(fp.prior_loss_type)
+        p.prior_loss_scale = float(fp.prior_loss_scale)
     return p
 
 

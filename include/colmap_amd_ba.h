@@ -63,6 +63,20 @@ typedef struct ba_problem {
   double* sensors;       /* [num_sensors][7] Rigid3d::params (in/out for variable sensors), or NULL */
   int32_t* obs_sensor;   /* [num_obs] index into sensors, -1 = trivial frame; NULL = all trivial */
   uint8_t* sensor_const; /* [num_sensors] 1 = constant block; NULL = every sensor_from_rig is constant */
+  /* Position priors (PosePriorBundleAdjuster::AddImagePosePriorToProblem, bundle_adjustment_ceres.cc:
+   * 986-1038): per prior a 3-residual block sqrt_info * (position + R(q)^-1 t) on the pose block
+   * (AbsolutePosePositionPriorCostFunctor, cost_functions/pose_prior.h:76-96: the image is the
+   * reference sensor of its frame) or on sensor_from_rig * rig_from_world
+   * (AbsoluteRigPosePositionPriorCostFunctor, :98-129) with CovarianceWeightedCostFunctor's left square
+   * root of the information matrix (cost_functions/utils.h:124-165) and its own loss function
+   * (prior_position_loss_function_type / _scale). Priors whose blocks are all constant are ignored. */
+  int32_t num_priors;
+  int32_t* prior_pose;     /* [num_priors] pose block (cam_from_world, or the frame's rig_from_world) */
+  int32_t* prior_sensor;   /* [num_priors] index into sensors, -1 = no sensor_from_rig; NULL = all -1 */
+  double* prior_position;  /* [num_priors][3] position in the (normalised) world frame */
+  double* prior_sqrt_info; /* [num_priors][9] row-major: cov^-1 = L L^T, this is L^T */
+  int32_t prior_loss_type; /* BA_LOSS_* */
+  double prior_loss_scale;
 } ba_problem;
 
 /* ceres::Solver::Options fields that reach the solve (COLMAP's values:

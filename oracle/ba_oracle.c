@@ -71,6 +71,17 @@ typedef struct {
   uint8_t* sensor_const;  /* [num_sensors] 1: constant; NULL: all constant. A variable sensor_from_rig is
                              a parameter block of its own (RigReprojErrorCostFunctor,
                              reprojection_error.h:344-384) and is updated in place */
+  /* position priors (PosePriorBundleAdjuster::AddImagePosePriorToProblem, bundle_adjustment_ceres.cc:
+   * 986-1038): residual = sqrt_info * (position + R(q)^-1 t) of the sensor_from_world pose
+   * (AbsolutePosePositionPriorCostFunctor, cost_functions/pose_prior.h:76-96), or of
+   * sensor_from_rig * rig_from_world (AbsoluteRigPosePositionPriorCostFunctor, :98-129) */
+  int32_t num_priors;
+  int32_t* prior_pose;      /* [num_priors] pose block (cam_from_world or rig_from_world) */
+  int32_t* prior_sensor;    /* [num_priors] sensor_from_rig index or -1; NULL: all -1 */
+  double* prior_position;   /* [num_priors][3] */
+  double* prior_sqrt_info;  /* [num_priors][9] row-major left factor (cov^-1 = L L^T, stored L^T) */
+  int32_t prior_loss_type;
+  double prior_loss_scale;
 } bao_problem;
 
 typedef struct {
@@ -786,6 +797,59 @@ static void quat_plus_jac(const double* q, double J[12]) {
   J[9] = -x; J[10] = -y; J[11] = -z;
 }
 
+/* Position-prior residual and its ambient Jacobians (pose_prior.h:76-129, autodiff in the
+ * reference; the quaternion normalisation term of Eigen's inverse() lies along q and vanishes under
+ * the manifold's PlusJacobian, so the conjugate is differentiated).
+ *   no sensor:  r0 = pos + R(q)^T t
+ *   sensor:     r0 = pos + R(q_r)^T (t_r + R(q_s)^T t_s)
+ * J_pose / J_sens: 3 x 7 row-major w.r.t. (qx qy qz qw tx ty tz) of rig_from_world / sensor_from_rig. */
+static void position_prior(const double* pos, const double* pose, const double* sens, double r0[3],
+                           double* J_pose, double* J_sens) {
+  double w_[3] = {pose[4], pose[5], pose[6]};
+  double Rs[9];
+  if (sens) {
+    const double qsc[4] = {-sens[0], -sens[1], -sens[2], sens[3]};
+    double v[3];
+    quat_rotate_jac(qsc, sens + 4, v, NULL);
+    for (int c = 0; c < 3; ++c) w_[c] += v[c];
+    quat_to_rot(sens, Rs);
+  }
+  const double qc[4] = {-pose[0], -pose[1], -pose[2], pose[3]};
+  double v[3], Jq[12];
+  quat_rotate_jac(qc, w_, v, J_pose ? Jq : NULL);
+  for (int c = 0; c < 3; ++c) r0[c] = pos[c] + v[c];
+  if (!J_pose) return;
+  double Rr[9];
+  quat_to_rot(pose, Rr);
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c) J_pose[7 * r + c] = -Jq[4 * r + c];  /* d conj / d q */
+    J_pose[7 * r + 3] = Jq[4 * r + 3];
+    for (int c = 0; c < 3; ++c) J_pose[7 * r + 4 + c] = Rr[3 * c + r];  /* R_r^T */
+  }
+  if (sens && J_sens) {
+    const double qsc[4] = {-sens[0], -sens[1], -sens[2], sens[3]};
+    double vs[3], Jqs[12];
+    quat_rotate_jac(qsc, sens + 4, vs, Jqs);
+    for (int r = 0; r < 3; ++r) {
+      for (int c = 0; c < 4; ++c) {  /* R_r^T * d(R(conj q_s) t_s)/dq_s */
+        double a = 0.0;
+        for (int k = 0; k < 3; ++k) a += Rr[3 * k + r] * Jqs[4 * k + c];
+        J_sens[7 * r + c] = c < 3 ? -a : a;
+      }
+      for (int c = 0; c < 3; ++c) {  /* R_r^T R_s^T */
+        double a = 0.0;
+        for (int k = 0; k < 3; ++k) a += Rr[3 * k + r] * Rs[3 * c + k];
+        J_sens[7 * r + 4 + c] = a;
+      }
+    }
+  }
+}
+
+BAO_API void bao_position_prior(const double* pos, const double* pose, const double* sens, double* r0,
+                                double* J_pose, double* J_sens) {
+  position_prior(pos, pose, sens, r0, J_pose, J_sens);
+}
+
 /* ------------------------------------------------------------------------- */
 /* Program: tangent-space layout of the variable blocks                        */
 /* ------------------------------------------------------------------------- */
@@ -1053,9 +1117,107 @@ static void linearize_obs(const program* g, const double* poses, const double* c
       for (int c = 0; c < 3; ++c) L->Jp[r][c] = Jpt[3 * r + c];
 }
 
+/* Linearised position prior: residual (sqrt-information weighted, loss-corrected) and the tangent
+ * columns of its pose block and, when variable, its sensor_from_rig block. */
+typedef struct {
+  double r[3];
+  double J[3][12];     /* [pose tangent (pose_dim) | sensor tangent (sens_dim)] */
+  int pose_dim, sens_dim;
+  int po, so;          /* tangent offsets, -1: constant */
+  double cost;
+} lin_prior;
+
+static int prior_active(const program* g, int k) {
+  const bao_problem* p = g->p;
+  const int si = p->prior_sensor ? p->prior_sensor[k] : -1;
+  return g->pose_off[p->prior_pose[k]] >= 0 || (si >= 0 && g->sens_off[si] >= 0);
+}
+
+static void linearize_prior(const program* g, const double* poses, int k, lin_prior* L, int want_jac) {
+  const bao_problem* p = g->p;
+  const int pi = p->prior_pose[k];
+  const int si = p->prior_sensor ? p->prior_sensor[k] : -1;
+  const double* pose = poses + 7 * (size_t)pi;
+  const double* sens = si >= 0 ? g->sensors + 7 * (size_t)si : NULL;
+  double r0[3], Jpose[21], Jsens[21];
+  L->po = g->pose_off[pi];
+  L->pose_dim = L->po >= 0 ? g->pose_dim[pi] : 0;
+  L->so = si >= 0 ? g->sens_off[si] : -1;
+  L->sens_dim = L->so >= 0 ? 6 : 0;
+  position_prior(p->prior_position + 3 * (size_t)k, pose, sens, r0, want_jac ? Jpose : NULL,
+                 (want_jac && L->so >= 0) ? Jsens : NULL);
+  const double* A = p->prior_sqrt_info + 9 * (size_t)k;
+  for (int r = 0; r < 3; ++r) L->r[r] = A[3 * r] * r0[0] + A[3 * r + 1] * r0[1] + A[3 * r + 2] * r0[2];
+  const double sq_norm = L->r[0] * L->r[0] + L->r[1] * L->r[1] + L->r[2] * L->r[2];
+  double rho[3];
+  bao_loss(p->prior_loss_type, p->prior_loss_scale, sq_norm, rho);
+  L->cost = 0.5 * rho[0];
+  if (!want_jac) return;
+  memset(L->J, 0, sizeof(L->J));
+  double Jt[3][12]; /* unweighted tangent columns */
+  memset(Jt, 0, sizeof(Jt));
+  if (L->pose_dim > 0) {
+    double PJ[12];
+    quat_plus_jac(pose, PJ);
+    const int fixed = pose_fixed_coord(p->pose_fixed_t[pi]);
+    const int rotc = pose_rot_const(p->pose_fixed_t[pi]);
+    for (int r = 0; r < 3; ++r) {
+      int d = 0;
+      if (!rotc) {
+        for (int c = 0; c < 3; ++c)
+          Jt[r][c] = Jpose[7 * r] * PJ[c] + Jpose[7 * r + 1] * PJ[3 + c] + Jpose[7 * r + 2] * PJ[6 + c] +
+                     Jpose[7 * r + 3] * PJ[9 + c];
+        d = 3;
+      }
+      for (int c = 0; c < 3; ++c) {
+        if (c == fixed) continue;
+        Jt[r][d++] = Jpose[7 * r + 4 + c];
+      }
+    }
+  }
+  if (L->so >= 0) {
+    double PJ[12];
+    quat_plus_jac(sens, PJ);
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) {
+        Jt[r][L->pose_dim + c] = Jsens[7 * r] * PJ[c] + Jsens[7 * r + 1] * PJ[3 + c] + Jsens[7 * r + 2] * PJ[6 + c] +
+                                 Jsens[7 * r + 3] * PJ[9 + c];
+        Jt[r][L->pose_dim + 3 + c] = Jsens[7 * r + 4 + c];
+      }
+  }
+  const int w = L->pose_dim + L->sens_dim;
+  for (int r = 0; r < 3; ++r)
+    for (int d = 0; d < w; ++d) L->J[r][d] = A[3 * r] * Jt[0][d] + A[3 * r + 1] * Jt[1][d] + A[3 * r + 2] * Jt[2][d];
+  if (p->prior_loss_type != BAO_LOSS_TRIVIAL) {
+    double sqrt_rho1, residual_scaling, alpha_sq_norm;
+    corrector(sq_norm, rho, &sqrt_rho1, &residual_scaling, &alpha_sq_norm);
+    for (int d = 0; d < w; ++d) {
+      const double rtj = L->r[0] * L->J[0][d] + L->r[1] * L->J[1][d] + L->r[2] * L->J[2][d];
+      for (int r = 0; r < 3; ++r) L->J[r][d] = sqrt_rho1 * (L->J[r][d] - alpha_sq_norm * L->r[r] * rtj);
+    }
+    for (int r = 0; r < 3; ++r) L->r[r] *= residual_scaling;
+  }
+}
+
+/* J x of a prior for a camera-side vector x */
+static void prior_jx(const lin_prior* L, const double* x, double out[3]) {
+  for (int r = 0; r < 3; ++r) {
+    double v = 0.0;
+    for (int d = 0; d < L->pose_dim; ++d) v += L->J[r][d] * x[L->po + d];
+    for (int d = 0; d < L->sens_dim; ++d) v += L->J[r][L->pose_dim + d] * x[L->so + d];
+    out[r] = v;
+  }
+}
+
 static double evaluate_cost(const program* g, const double* poses, const double* cams,
                             const double* points) {
   double cost = 0.0;
+  for (int k = 0; k < g->p->num_priors; ++k) {
+    if (!prior_active(g, k)) continue;
+    lin_prior L;
+    linearize_prior(g, poses, k, &L, 0);
+    cost += L.cost;
+  }
 #pragma omp parallel for reduction(+ : cost) schedule(static) BAO_PAR(g->n_obs)
   for (int64_t a = 0; a < g->n_obs; ++a) {
     lin_obs L;
@@ -1125,6 +1287,8 @@ typedef struct {
   int* blk_dim;
   int64_t* blk_moff;  /* offset into Minv */
   int n_blk;
+  lin_prior* P;       /* [n_prior] linearised position priors (scaled) */
+  int n_prior;
 } linsys;
 
 static int cam_offsets(const program* g, int64_t a, int* po, int* co) {
@@ -1215,6 +1379,16 @@ static void schur_multiply(const linsys* s, const double* x, double* y, double* 
       }
     }
     for (int d = 0; d < dim; ++d) y[off + d] = acc[d];
+  }
+  /* position priors: no point block, they add J^T J x to the camera side directly */
+  for (int k = 0; k < s->n_prior; ++k) {
+    const lin_prior* L = &s->P[k];
+    double jx[3];
+    prior_jx(L, x, jx);
+    for (int r = 0; r < 3; ++r) {
+      for (int d = 0; d < L->pose_dim; ++d) y[L->po + d] += L->J[r][d] * jx[r];
+      for (int d = 0; d < L->sens_dim; ++d) y[L->so + d] += L->J[r][L->pose_dim + d] * jx[r];
+    }
   }
 }
 
@@ -1320,7 +1494,9 @@ BAO_API int bao_solve(bao_problem* p, const bao_options* opt, bao_result* res) {
   g.loss_type = opt->loss_type;
   g.loss_scale = opt->loss_scale;
   memset(res, 0, offsetof(bao_result, log_cost));
-  res->num_residuals = (int32_t)(2 * g.n_obs);
+  int n_prior = 0;
+  for (int k = 0; k < p->num_priors; ++k) n_prior += prior_active(&g, k);
+  res->num_residuals = (int32_t)(2 * g.n_obs) + 3 * n_prior;
   res->num_effective_parameters = g.n_c + g.n_p;
   res->termination_type = BAO_FAILURE;
   if (g.n_obs == 0) { program_free(&g); return 0; }
@@ -1333,6 +1509,8 @@ BAO_API int bao_solve(bao_problem* p, const bao_options* opt, bao_result* res) {
   s.Dc = (double*)calloc(nc + 1, sizeof(double));
   s.Dp = (double*)calloc(np + 1, sizeof(double));
   s.Cinv = (double*)calloc((size_t)p->num_points * 9 + 1, sizeof(double));
+  s.P = (lin_prior*)malloc(sizeof(lin_prior) * (n_prior + 1));
+  s.n_prior = n_prior;
   /* camera-side blocks (same order as program.blk_*) */
   s.blk_off = (int*)malloc(sizeof(int) * (g.n_blk + 1));
   s.blk_dim = (int*)malloc(sizeof(int) * (g.n_blk + 1));
@@ -1383,6 +1561,11 @@ BAO_API int bao_solve(bao_problem* p, const bao_options* opt, bao_result* res) {
         linearize_obs(&g, p->poses, p->cams, p->points, a, &s.L[a], 1);
         c += s.L[a].cost;
       }
+      for (int k = 0, n = 0; k < p->num_priors; ++k) {
+        if (!prior_active(&g, k)) continue;
+        linearize_prior(&g, p->poses, k, &s.P[n], 1);
+        c += s.P[n++].cost;
+      }
       cost = c;
       if (iter == 0) res->initial_cost = cost;
       /* gradient (unscaled) g = J^T r, and column norms: camera side per block, point side per point */
@@ -1397,6 +1580,13 @@ BAO_API int bao_solve(bao_problem* p, const bao_options* opt, bao_result* res) {
             for (int d = 0; d < dim; ++d) { const double v = L->Jc[r][base + d]; ga[d] += v * L->r[r]; da[d] += v * v; }
         }
         for (int d = 0; d < dim; ++d) { gc[off + d] = ga[d]; diag_c[off + d] = da[d]; }
+      }
+      for (int k = 0; k < s.n_prior; ++k) {
+        const lin_prior* L = &s.P[k];
+        for (int r = 0; r < 3; ++r) {
+          for (int d = 0; d < L->pose_dim; ++d) { const double v = L->J[r][d]; gc[L->po + d] += v * L->r[r]; diag_c[L->po + d] += v * v; }
+          for (int d = 0; d < L->sens_dim; ++d) { const double v = L->J[r][L->pose_dim + d]; gc[L->so + d] += v * L->r[r]; diag_c[L->so + d] += v * v; }
+        }
       }
 #pragma omp parallel for schedule(static) BAO_PAR(g.n_obs)
       for (int j = 0; j < p->num_points; ++j) {
@@ -1444,6 +1634,13 @@ BAO_API int bao_solve(bao_problem* p, const bao_options* opt, bao_result* res) {
           if (pto >= 0) for (int c2 = 0; c2 < 3; ++c2) L->Jp[r][c2] *= scale_p[pto + c2];
         }
       }
+      for (int k = 0; k < s.n_prior; ++k) {
+        lin_prior* L = &s.P[k];
+        for (int r = 0; r < 3; ++r) {
+          for (int d = 0; d < L->pose_dim; ++d) L->J[r][d] *= scale_c[L->po + d];
+          for (int d = 0; d < L->sens_dim; ++d) L->J[r][L->pose_dim + d] *= scale_c[L->so + d];
+        }
+      }
       for (int i = 0; i < nc; ++i) { diag_c[i] *= scale_c[i] * scale_c[i]; gc[i] *= scale_c[i]; }
       for (int i = 0; i < np; ++i) { diag_p[i] *= scale_p[i] * scale_p[i]; gp[i] *= scale_p[i]; }
       need_linearize = 0;
@@ -1468,6 +1665,19 @@ BAO_API int bao_solve(bao_problem* p, const bao_options* opt, bao_result* res) {
       }
       for (int x = 0; x < 3; ++x) C[4 * x] += s.Dp[g.point_off[j] + x] * s.Dp[g.point_off[j] + x];
       invert_sym(C, 3, s.Cinv + 9 * (size_t)j);
+    }
+    /* position priors add J_b^T J_b to their blocks of B */
+    for (int k = 0; k < s.n_prior; ++k) {
+      const lin_prior* L = &s.P[k];
+      for (int part = 0; part < 2; ++part) {
+        const int off = part == 0 ? L->po : L->so, dim = part == 0 ? L->pose_dim : L->sens_dim;
+        const int base = part == 0 ? 0 : L->pose_dim;
+        if (off < 0 || dim == 0) continue;
+        double* M = Mblk + s.blk_moff[blk_of[off]];
+        for (int r = 0; r < 3; ++r)
+          for (int x = 0; x < dim; ++x)
+            for (int y = 0; y < dim; ++y) M[x * dim + y] += L->J[r][base + x] * L->J[r][base + y];
+      }
     }
     /* SCHUR_JACOBI: block diagonal of S = B + Dc^2 - E C^-1 E^T, per camera-side block:
      * B_bb = sum_o J_b,o^T J_b,o ; correction = sum over pairs (o, o') of observations of the
@@ -1579,6 +1789,11 @@ BAO_API int bao_solve(bao_problem* p, const bao_options* opt, bao_result* res) {
         model_change -= m * (L->r[r] + 0.5 * m);
       }
     }
+    for (int k = 0; k < s.n_prior; ++k) {
+      double m[3];
+      prior_jx(&s.P[k], dc, m);
+      for (int r = 0; r < 3; ++r) model_change -= m[r] * (s.P[k].r[r] + 0.5 * m[r]);
+    }
     int accepted = 0;
     double new_cost = cost;
     if (!(model_change > 0.0) || !isfinite(model_change)) {
@@ -1644,6 +1859,7 @@ BAO_API int bao_solve(bao_problem* p, const bao_options* opt, bao_result* res) {
     for (int c = 0; c < 4; ++c) q[c] /= n;
   }
 
+  free(s.P);
   free(s.L); free(s.Dc); free(s.Dp); free(s.Cinv); free(s.Minv); free(s.blk_off); free(s.blk_dim);
   free(s.blk_moff); free(blk_of); free(scale_c); free(scale_p); free(gc); free(gp); free(diag_c);
   free(diag_p); free(rhs); free(dc); free(dp); free(ws); free(Mblk); free(nposes); free(ncams);

@@ -106,3 +106,20 @@ def quat_plus(q, d):
     out = np.zeros(4)
     lib().bao_quat_plus(q.ctypes.data_as(C.c_void_p), d.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
     return out
+
+
+def position_prior(position, pose, sensor=None, want_jac=True):
+    """AbsolutePosePositionPriorCostFunctor / AbsoluteRigPosePositionPriorCostFunctor (unweighted):
+    residual (3,), d/d pose (3, 7), d/d sensor_from_rig (3, 7) or None."""
+    pos = np.ascontiguousarray(position, np.float64)
+    pose = np.ascontiguousarray(pose, np.float64)
+    sens = None if sensor is None else np.ascontiguousarray(sensor, np.float64)
+    r = np.zeros(3)
+    Jp = np.zeros((3, 7))
+    Js = np.zeros((3, 7))
+    dp = C.POINTER(C.c_double)
+    lib().bao_position_prior(pos.ctypes.data_as(dp), pose.ctypes.data_as(dp),
+                             sens.ctypes.data_as(dp) if sens is not None else None, r.ctypes.data_as(dp),
+                             Jp.ctypes.data_as(dp) if want_jac else None,
+                             Js.ctypes.data_as(dp) if (want_jac and sens is not None) else None)
+    return r, (Jp if want_jac else None), (Js if (want_jac and sens is not None) else None)

@@ -185,7 +185,7 @@ def test_backend_interface_reference_cases():
 
 def test_error_behaviour():
     fp = _flat(4, 20, 3, seed=1)
-    fp.cam_model[0] = 6  # unsupported model id (FULL_OPENCV: 12 parameters)
+    fp.cam_model[0] = 11  # unsupported model id (RAD_TAN_THIN_PRISM_FISHEYE: 16 parameters > BA_CAM_STRIDE)
     with pytest.raises(RuntimeError, match="unsupported camera model"):
         est.solve_flat(fp, gpu_index=0)
     fp = _flat(4, 20, 3, seed=1)

@@ -693,3 +693,138 @@ def test_constant_rig_from_world_rotation():
         assert np.array_equal(img.cam_from_world[:4], before[i][:4])       # rotations untouched
         moved += int(not np.array_equal(img.cam_from_world[4:], before[i][4:]))
     assert moved == len(rec.images) - 1
+
+
+# ------------------------------------------------------------------------------------------------
+# position priors (cost_functions/pose_prior.h:76-129, PosePriorBundleAdjuster)
+# ------------------------------------------------------------------------------------------------
+
+def _rand_pose(rng):
+    q = rng.normal(size=4)
+    q /= np.linalg.norm(q)
+    return np.concatenate([q, rng.normal(size=3)])
+
+
+def test_position_prior_residual_and_jacobians():
+    """residual = prior + R^-1 t = prior - projection centre (pose_prior.h:88-92); rig variant on the composed
+    pose (:112-124); Jacobians against differences along the manifold (quaternion Plus, translation)."""
+    rng = np.random.default_rng(5)
+    for _ in range(5):
+        pose, sens, pos = _rand_pose(rng), _rand_pose(rng), rng.normal(size=3)
+        r, Jp, _ = ba_oracle.position_prior(pos, pose)
+        centre = -scene.quat_to_rot(pose[:4]).T @ pose[4:]
+        np.testing.assert_allclose(r, pos - centre, atol=1e-13)
+        comp = scene.rigid_compose(sens, pose)
+        r2, Jr, Js = ba_oracle.position_prior(pos, pose, sens)
+        np.testing.assert_allclose(r2, pos + scene.quat_to_rot(comp[:4]).T @ comp[4:], atol=1e-13)
+
+        def plus(x, d):  # manifold Plus of a pose block: quaternion (x) R^3
+            return np.concatenate([ba_oracle.quat_plus(x[:4], d[:3]), x[4:] + d[3:]])
+
+        def tangent(J, x):  # ambient 3 x 7 -> tangent 3 x 6
+            q = x[:4]
+            PJ = np.array([[q[3], q[2], -q[1]], [-q[2], q[3], q[0]], [q[1], -q[0], q[3]], [-q[0], -q[1], -q[2]]])
+            return np.concatenate([J[:, :4] @ PJ, J[:, 4:]], 1)
+        h = 1e-6
+        for which, Jamb in (("pose", Jr), ("sens", Js)):
+            num = np.zeros((3, 6))
+            for i in range(6):
+                d = np.zeros(6)
+                d[i] = h
+                if which == "pose":
+                    a = ba_oracle.position_prior(pos, plus(pose, d), sens, want_jac=False)[0]
+                    b = ba_oracle.position_prior(pos, plus(pose, -d), sens, want_jac=False)[0]
+                else:
+                    a = ba_oracle.position_prior(pos, pose, plus(sens, d), want_jac=False)[0]
+                    b = ba_oracle.position_prior(pos, pose, plus(sens, -d), want_jac=False)[0]
+                num[:, i] = (a - b) / (2 * h)
+            np.testing.assert_allclose(tangent(Jamb, pose if which == "pose" else sens), num, atol=1e-7)
+        np.testing.assert_allclose(tangent(Jp, pose),
+                                   tangent(ba_oracle.position_prior(pos, pose, np.array([0, 0, 0, 1, 0, 0, 0.0]))[1], pose),
+                                   atol=1e-13)
+
+
+def _prior_problem(seed=3, n_img=8, sigma=0.05, with_gauge=False):
+    fp = est.FlatProblem.from_arrays(scene.synthesize_flat(n_img, 120, 4, seed=seed))
+    rng = np.random.default_rng(seed)
+    centres = np.stack([-scene.quat_to_rot(p[:4]).T @ p[4:] for p in fp.poses])
+    fp.prior_pose = np.arange(n_img, dtype=np.int32)
+    fp.prior_position = np.ascontiguousarray(centres + sigma * rng.normal(size=centres.shape))
+    cov = np.diag([0.01, 0.02, 0.04]) + 0.002
+    L = np.linalg.cholesky(np.linalg.inv(cov))          # cov^-1 = L L^T ; left sqrt information = L^T
+    fp.prior_sqrt_info = np.ascontiguousarray(np.repeat(L.T[None], n_img, 0))
+    if with_gauge:
+        assert est.fix_gauge_two_cams(fp)
+    return fp
+
+
+# the gauge directions are held by a handful of priors only: weak curvature, so the inexact-Newton PCG
+# (eta = 0.1) crawls; the reference solves problems of this size with DENSE_SCHUR, i.e. exactly
+_EXACT = dict(eta=1e-10, max_linear_solver_iterations=500)
+
+
+def test_position_priors_fix_the_gauge_and_pull_the_centres():
+    """No gauge fixing: the seven gauge freedoms are constrained by the priors alone
+    (bundle_adjustment_ceres.cc:925-936). 3 residuals per prior; the solve converges and every projection
+    centre ends up close to its prior; the prior cost is part of the reported cost."""
+    fp = _prior_problem()
+    no_prior = _prior_problem()
+    no_prior.prior_pose = None
+    a = fp.copy()
+    s = est.solve_flat(a, est.SolverOptions(max_num_iterations=60, gradient_tolerance=1e-10, **_EXACT), solve_fn=ba_oracle.solve_fn)
+    assert s.num_residuals == 2 * len(fp.obs_pose) + 3 * 8
+    assert s.IsSolutionUsable() and s.final_cost < s.initial_cost
+    centres = np.stack([-scene.quat_to_rot(p[:4]).T @ p[4:] for p in a.poses])
+    assert np.abs(centres - fp.prior_position).max() < 0.2
+    # moving all priors by a common offset moves the whole solution (the priors own the gauge)
+    b = fp.copy()
+    b.prior_position = np.ascontiguousarray(b.prior_position + np.array([0.5, -0.25, 0.125]))
+    est.solve_flat(b, est.SolverOptions(max_num_iterations=60, gradient_tolerance=1e-10, **_EXACT), solve_fn=ba_oracle.solve_fn)
+    cb = np.stack([-scene.quat_to_rot(p[:4]).T @ p[4:] for p in b.poses])
+    np.testing.assert_allclose(cb - centres, np.tile([0.5, -0.25, 0.125], (8, 1)), atol=1e-5)
+    # a robust loss on the priors with one gross outlier: the outlier is down-weighted
+    c = fp.copy()
+    c.prior_position = c.prior_position.copy()
+    c.prior_position[3] += 5.0
+    c.prior_loss_type, c.prior_loss_scale = int(est.LossFunctionType.CAUCHY), 1.0
+    est.solve_flat(c, est.SolverOptions(max_num_iterations=60, gradient_tolerance=1e-10, **_EXACT), solve_fn=ba_oracle.solve_fn)
+    cc = np.stack([-scene.quat_to_rot(p[:4]).T @ p[4:] for p in c.poses])
+    assert np.linalg.norm(cc[3] - c.prior_position[3]) > 4.0 and np.abs(np.delete(cc - c.prior_position, 3, 0)).max() < 0.3
+
+
+def test_position_prior_cost_against_scipy():
+    """The minimum of reprojection + prior cost, cross-checked with scipy.optimize.least_squares on the
+    same residual vector (quaternions re-normalised inside the residual)."""
+    from scipy.optimize import least_squares
+    fp = _prior_problem(seed=9, n_img=5, sigma=0.02)
+    a = fp.copy()
+    s = est.solve_flat(a, est.SolverOptions(max_num_iterations=100, gradient_tolerance=1e-12, function_tolerance=0.0, **_EXACT),
+                       solve_fn=ba_oracle.solve_fn)
+    n_pose, n_pt = len(fp.poses), len(fp.points)
+    f_idx = scene.MODEL_FOCAL_IDXS[int(fp.cam_model[0])] + scene.MODEL_EXTRA_IDXS[int(fp.cam_model[0])]
+
+    def unpack(x):
+        poses = x[:7 * n_pose].reshape(n_pose, 7).copy()
+        poses[:, :4] /= np.linalg.norm(poses[:, :4], axis=1, keepdims=True)
+        pts = x[7 * n_pose:7 * n_pose + 3 * n_pt].reshape(n_pt, 3)
+        cams = fp.cams.copy()
+        cams[:, f_idx] = x[7 * n_pose + 3 * n_pt:].reshape(len(cams), len(f_idx))
+        return poses, pts, cams
+
+    def resid(x):
+        poses, pts, cams = unpack(x)
+        out = []
+        for o in range(len(fp.obs_pose)):
+            pz = poses[fp.obs_pose[o]]
+            pc = scene.quat_to_rot(pz[:4]) @ pts[fp.obs_point[o]] + pz[4:]
+            ci = fp.obs_cam[o]
+            out.append(scene.img_from_cam(int(fp.cam_model[ci]), cams[ci][:scene.MODEL_NUM_PARAMS[int(fp.cam_model[ci])]],
+                                          pc[None])[0] - fp.obs_xy[o])
+        for k in range(len(fp.prior_pose)):
+            pz = poses[fp.prior_pose[k]]
+            out.append(fp.prior_sqrt_info[k] @ (fp.prior_position[k] + scene.quat_to_rot(pz[:4]).T @ pz[4:]))
+        return np.concatenate(out)
+    x0 = np.concatenate([a.poses.ravel(), a.points.ravel(), a.cams[:, f_idx].ravel()])
+    assert abs(0.5 * np.sum(resid(x0) ** 2) - s.final_cost) <= 1e-9 * s.final_cost
+    sol = least_squares(resid, x0, method="trf", xtol=1e-15, ftol=1e-15, gtol=1e-12, max_nfev=200)
+    assert abs(sol.cost - s.final_cost) <= 1e-6 * s.final_cost
