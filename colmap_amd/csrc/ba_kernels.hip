@@ -32,6 +32,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <array>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -1587,6 +1588,224 @@ __global__ void ba_renorm_quat_kernel(View V, double* __restrict__ poses) {
 // ------------------------------------------------------------------------------------------
 // Host-side solver
 // ------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------
+// Position priors (PosePriorBundleAdjuster, bundle_adjustment_ceres.cc:900-1038;
+// AbsolutePosePositionPriorCostFunctor / AbsoluteRigPosePositionPriorCostFunctor,
+// cost_functions/pose_prior.h:76-129). A prior is a 3-residual block on a pose block and, for an image
+// that is not the reference sensor of its frame, on its sensor_from_rig block. It has no point block:
+// it adds to the camera side of the normal equations directly. There are at most as many priors as
+// images, so the kernels are small; sums run in a fixed order (one lane per target block walks its
+// priors, single-workgroup tree reductions for the scalars) to keep the solve bit-reproducible.
+// ------------------------------------------------------------------------------------------
+struct PriorView {
+  int n;                     // active priors
+  const int *pose, *sens;    // [n] pose block index; sensor_from_rig index or -1
+  const double *pos, *A;     // [n][3] position, [n][9] left sqrt information (row-major)
+  const int *po, *so;        // [n] tangent offsets (-1: constant block)
+  const int *pdim;           // [n] pose tangent width (0 when constant)
+  double *r;                 // [3][n] weighted, loss-corrected residual
+  double *J;                 // [3][12][n] tangent columns: pose (pdim), then sensor (6), column scaled
+  double *jx;                // [3][n] J x of the current product
+  int loss_type;
+  double loss_scale;
+  // targets: (block, prior, first column) sorted by block; tb_ptr over the distinct blocks
+  int n_tblk;
+  const int *tb_blk, *tb_ptr, *tg_prior, *tg_base;
+};
+
+// r0 = position + R(q_r)^T (t_r + R(q_s)^T t_s) and its ambient Jacobians (3 x 7 each, row-major)
+__device__ __forceinline__ void prior_residual(const double* pos, const double* pose, const double* sens, double r0[3],
+                                               double* Jpose, double* Jsens) {
+  double w[3] = {pose[4], pose[5], pose[6]};
+  double Rs[9], Jqs[12];
+  if (sens) {
+    const double qsc[4] = {-sens[0], -sens[1], -sens[2], sens[3]};
+    double v[3];
+    quat_rotate(qsc, sens + 4, v, Jsens ? Jqs : nullptr);
+    w[0] += v[0]; w[1] += v[1]; w[2] += v[2];
+    quat_to_rot(sens, Rs);
+  }
+  const double qc[4] = {-pose[0], -pose[1], -pose[2], pose[3]};
+  double v[3], Jq[12];
+  quat_rotate(qc, w, v, Jpose ? Jq : nullptr);
+  r0[0] = pos[0] + v[0]; r0[1] = pos[1] + v[1]; r0[2] = pos[2] + v[2];
+  if (!Jpose) return;
+  double Rr[9];
+  quat_to_rot(pose, Rr);
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c) Jpose[7 * r + c] = -Jq[4 * r + c];  // d conj(q) / d q
+    Jpose[7 * r + 3] = Jq[4 * r + 3];
+    for (int c = 0; c < 3; ++c) Jpose[7 * r + 4 + c] = Rr[3 * c + r];  // R_r^T
+  }
+  if (sens && Jsens) {
+    double tmp[21];
+    for (int r = 0; r < 3; ++r) {
+      for (int c = 0; c < 4; ++c) {
+        const double a = Rr[r] * Jqs[c] + Rr[3 + r] * Jqs[4 + c] + Rr[6 + r] * Jqs[8 + c];
+        tmp[7 * r + c] = c < 3 ? -a : a;
+      }
+      for (int c = 0; c < 3; ++c) tmp[7 * r + 4 + c] = Rr[r] * Rs[3 * c] + Rr[3 + r] * Rs[3 * c + 1] + Rr[6 + r] * Rs[3 * c + 2];
+    }
+    for (int e = 0; e < 21; ++e) Jsens[e] = tmp[e];
+  }
+}
+
+// One workgroup: linearise every prior (JAC: residual + Jacobians), add the summed cost to *cost_slot
+template <bool JAC>
+__global__ void __launch_bounds__(256) ba_prior_linearize_kernel(View V, PriorView Q, const double* __restrict__ poses,
+                                                                 const double* __restrict__ sensors,
+                                                                 double* __restrict__ cost_slot) {
+  __shared__ double red[256];
+  double cost = 0.0;
+  for (int k = threadIdx.x; k < Q.n; k += 256) {
+    const int pi = Q.pose[k], si = Q.sens[k];
+    const double* pose = poses + 7 * (size_t)pi;
+    const double* sens = si >= 0 ? sensors + 7 * (size_t)si : nullptr;
+    const int pdim = Q.pdim[k], so = Q.so[k], po = Q.po[k];
+    double r0[3], Jpose[21], Jsens[21];
+    prior_residual(Q.pos + 3 * (size_t)k, pose, sens, r0, JAC ? Jpose : nullptr, (JAC && so >= 0) ? Jsens : nullptr);
+    const double* A = Q.A + 9 * (size_t)k;
+    double r[3];
+    for (int i = 0; i < 3; ++i) r[i] = A[3 * i] * r0[0] + A[3 * i + 1] * r0[1] + A[3 * i + 2] * r0[2];
+    const double sq_norm = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+    double rho[3];
+    loss_eval(Q.loss_type, Q.loss_scale, sq_norm, rho);
+    cost += 0.5 * rho[0];
+    if (JAC) {
+      double Jt[3][12];
+      for (int i = 0; i < 3; ++i)
+        for (int d = 0; d < 12; ++d) Jt[i][d] = 0.0;
+      if (pdim > 0) {
+        const double x = pose[0], y = pose[1], z = pose[2], w = pose[3];
+        const double PJ[12] = {w, z, -y, -z, w, x, y, -x, w, -x, -y, -z};
+        const int pf = V.pose_fix[pi];
+        const bool rotc = pf >= 4;
+        const int fix = pf < 0 ? -1 : ((pf & 3) == 3 ? -1 : (pf & 3));
+        for (int i = 0; i < 3; ++i) {
+          int d = 0;
+          if (!rotc) {
+            for (int c = 0; c < 3; ++c)
+              Jt[i][c] = Jpose[7 * i] * PJ[c] + Jpose[7 * i + 1] * PJ[3 + c] + Jpose[7 * i + 2] * PJ[6 + c] +
+                         Jpose[7 * i + 3] * PJ[9 + c];
+            d = 3;
+          }
+          for (int c = 0; c < 3; ++c) {
+            if (c == fix) continue;
+            Jt[i][d++] = Jpose[7 * i + 4 + c];
+          }
+        }
+      }
+      if (so >= 0) {
+        const double x = sens[0], y = sens[1], z = sens[2], w = sens[3];
+        const double PJ[12] = {w, z, -y, -z, w, x, y, -x, w, -x, -y, -z};
+        for (int i = 0; i < 3; ++i)
+          for (int c = 0; c < 3; ++c) {
+            Jt[i][pdim + c] = Jsens[7 * i] * PJ[c] + Jsens[7 * i + 1] * PJ[3 + c] + Jsens[7 * i + 2] * PJ[6 + c] +
+                              Jsens[7 * i + 3] * PJ[9 + c];
+            Jt[i][pdim + 3 + c] = Jsens[7 * i + 4 + c];
+          }
+      }
+      const int wdt = pdim + (so >= 0 ? 6 : 0);
+      double J[3][12];
+      for (int i = 0; i < 3; ++i)
+        for (int d = 0; d < 12; ++d)
+          J[i][d] = d < wdt ? A[3 * i] * Jt[0][d] + A[3 * i + 1] * Jt[1][d] + A[3 * i + 2] * Jt[2][d] : 0.0;
+      if (Q.loss_type != BA_LOSS_TRIVIAL) {  // ceres::internal::Corrector on the 3-residual block
+        const double sqrt_rho1 = sqrt(rho[1]);
+        double residual_scaling = sqrt_rho1, alpha_sq_norm = 0.0;
+        if (!(sq_norm == 0.0 || rho[2] <= 0.0)) {
+          const double D = 1.0 + 2.0 * sq_norm * rho[2] / rho[1];
+          const double alpha = 1.0 - sqrt(D);
+          residual_scaling = sqrt_rho1 / (1.0 - alpha);
+          alpha_sq_norm = alpha / sq_norm;
+        }
+        for (int d = 0; d < wdt; ++d) {
+          const double rtj = r[0] * J[0][d] + r[1] * J[1][d] + r[2] * J[2][d];
+          for (int i = 0; i < 3; ++i) J[i][d] = sqrt_rho1 * (J[i][d] - alpha_sq_norm * r[i] * rtj);
+        }
+        for (int i = 0; i < 3; ++i) r[i] *= residual_scaling;
+      }
+      for (int i = 0; i < 3; ++i) {
+        Q.r[(size_t)i * Q.n + k] = r[i];
+        for (int d = 0; d < 12; ++d) {
+          double sc = 1.0;
+          if (d < pdim) sc = V.scale_c[po + d];
+          else if (d < wdt) sc = V.scale_c[so + d - pdim];
+          Q.J[((size_t)i * 12 + d) * Q.n + k] = J[i][d] * sc;
+        }
+      }
+    }
+  }
+  red[threadIdx.x] = cost;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *cost_slot += red[0];
+}
+
+// jx_k = J_k x (3 per prior)
+__global__ void ba_prior_jx_kernel(PriorView Q, const double* __restrict__ x) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= Q.n) return;
+  const int po = Q.po[k], so = Q.so[k], pdim = Q.pdim[k];
+  for (int i = 0; i < 3; ++i) {
+    double v = 0.0;
+    for (int d = 0; d < pdim; ++d) v += Q.J[((size_t)i * 12 + d) * Q.n + k] * x[po + d];
+    if (so >= 0)
+      for (int d = 0; d < 6; ++d) v += Q.J[((size_t)i * 12 + pdim + d) * Q.n + k] * x[so + d];
+    Q.jx[(size_t)i * Q.n + k] = v;
+  }
+}
+
+// Lane per target block, its priors in list order.
+// MODE 0: g += J^T r, diag += column norms; MODE 1: M_b += J^T J; MODE 2: y += J^T jx
+template <int MODE>
+__global__ void ba_prior_accumulate_kernel(View V, PriorView Q, double* __restrict__ out, double* __restrict__ diag) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= Q.n_tblk) return;
+  const int b = Q.tb_blk[t];
+  const int off = V.blk_off[b], dim = V.blk_dim[b];
+  for (int e = Q.tb_ptr[t]; e < Q.tb_ptr[t + 1]; ++e) {
+    const int k = Q.tg_prior[e], base = Q.tg_base[e];
+    for (int i = 0; i < 3; ++i) {
+      const double ri = MODE == 0 ? Q.r[(size_t)i * Q.n + k] : (MODE == 2 ? Q.jx[(size_t)i * Q.n + k] : 0.0);
+      for (int x = 0; x < dim; ++x) {
+        const double jx = Q.J[((size_t)i * 12 + base + x) * Q.n + k];
+        if (MODE == 0) { out[off + x] += jx * ri; diag[off + x] += jx * jx; }
+        if (MODE == 2) out[off + x] += jx * ri;
+        if (MODE == 1)
+          for (int y = 0; y < dim; ++y) out[V.blk_moff[b] + x * dim + y] += jx * Q.J[((size_t)i * 12 + base + y) * Q.n + k];
+      }
+    }
+  }
+}
+
+// model cost change of the priors: - (J step) . (r + J step / 2), added to *slot (one workgroup)
+__global__ void __launch_bounds__(256) ba_prior_model_kernel(PriorView Q, const double* __restrict__ step,
+                                                             double* __restrict__ slot) {
+  __shared__ double red[256];
+  double acc = 0.0;
+  for (int k = threadIdx.x; k < Q.n; k += 256) {
+    const int po = Q.po[k], so = Q.so[k], pdim = Q.pdim[k];
+    for (int i = 0; i < 3; ++i) {
+      double m = 0.0;
+      for (int d = 0; d < pdim; ++d) m += Q.J[((size_t)i * 12 + d) * Q.n + k] * step[po + d];
+      if (so >= 0)
+        for (int d = 0; d < 6; ++d) m += Q.J[((size_t)i * 12 + pdim + d) * Q.n + k] * step[so + d];
+      acc -= m * (Q.r[(size_t)i * Q.n + k] + 0.5 * m);
+    }
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *slot += red[0];
+}
+
 template <typename T>
 struct Buf {
   T* p = nullptr;
@@ -1638,6 +1857,11 @@ struct Solver {
   Buf<unsigned char> solo;
   Buf<double> o_xy, poses, cams, points, poses2, cams2, points2, Jpose, Jcam, Jpt, res, res_p, scale_c, scale_p,
       scalars, gc, gp, diag_c, diag_p, Dc, Dp, Cinv, M, Minv, rhs, x, r, z, pdir, q, dp, jx, v, stepc, stepp, partials, cpart, Craw, tbuf, tmpc, Gobs, pcg_part, maxbuf;
+  // position priors
+  Buf<int> pr_pose, pr_sens, pr_po, pr_so, pr_pdim, pr_tb_blk, pr_tb_ptr, pr_tg_prior, pr_tg_base;
+  Buf<double> pr_pos, pr_A, pr_r, pr_J, pr_jx;
+  PriorView Q{};
+  bool use_priors() const { return Q.n > 0 && comm.rank == 0; }  // sums are all-reduced: one rank contributes them
   int moff_total = 0;
   long long n_paired = 0;  // (observation, block kind) slots that have a partner of the same point in the block
   int kd = 4, bd = PD;  // intrinsics tangent width / widest camera-side block of this problem
@@ -1872,7 +2096,51 @@ struct Solver {
     }
     h_blk_chunk_ptr[n_blk] = (int)h_chunk_blk.size();
 
-    res_out->num_residuals = (int32_t)(2 * n_active_global);
+    // position priors whose pose or sensor_from_rig block is variable
+    {
+      std::vector<int> q_pose, q_sens, q_po, q_so, q_pdim;
+      std::vector<double> q_pos, q_A;
+      std::vector<std::array<int, 3>> targets;  // block, prior, first column
+      if (p.num_priors < 0) throw std::runtime_error("num_priors < 0");
+      for (int k = 0; k < p.num_priors; ++k) {
+        const int pi = p.prior_pose[k];
+        const int si = p.prior_sensor ? p.prior_sensor[k] : -1;
+        if (pi < 0 || pi >= p.num_poses || si < -1 || si >= p.num_sensors) throw std::runtime_error("prior index out of range");
+        const int po = h_pose_off[pi], so = si >= 0 ? h_sens_off[si] : -1;
+        if (po < 0 && so < 0) continue;
+        const int kk = (int)q_pose.size();
+        const int pdim = po >= 0 ? h_pose_dim[pi] : 0;
+        q_pose.push_back(pi); q_sens.push_back(si); q_po.push_back(po); q_so.push_back(so); q_pdim.push_back(pdim);
+        q_pos.insert(q_pos.end(), p.prior_position + 3 * (size_t)k, p.prior_position + 3 * (size_t)k + 3);
+        q_A.insert(q_A.end(), p.prior_sqrt_info + 9 * (size_t)k, p.prior_sqrt_info + 9 * (size_t)k + 9);
+        if (po >= 0) targets.push_back({blk_of_pose[pi], kk, 0});
+        if (so >= 0) targets.push_back({blk_of_sens[si], kk, pdim});
+      }
+      Q = PriorView{};
+      Q.n = (int)q_pose.size();
+      if (Q.n > 0) {
+        if (p.prior_loss_type < BA_LOSS_TRIVIAL || p.prior_loss_type > BA_LOSS_HUBER || !(p.prior_loss_scale > 0.0))
+          throw std::runtime_error("prior loss type / scale");
+        std::stable_sort(targets.begin(), targets.end(), [](const std::array<int, 3>& a, const std::array<int, 3>& b) { return a[0] < b[0]; });
+        std::vector<int> tb_blk, tb_ptr, tg_prior, tg_base;
+        for (size_t e = 0; e < targets.size(); ++e) {
+          if (e == 0 || targets[e][0] != targets[e - 1][0]) { tb_blk.push_back(targets[e][0]); tb_ptr.push_back((int)e); }
+          tg_prior.push_back(targets[e][1]);
+          tg_base.push_back(targets[e][2]);
+        }
+        tb_ptr.push_back((int)targets.size());
+        pr_pose.upload(q_pose); pr_sens.upload(q_sens); pr_po.upload(q_po); pr_so.upload(q_so); pr_pdim.upload(q_pdim);
+        pr_pos.upload(q_pos); pr_A.upload(q_A);
+        pr_tb_blk.upload(tb_blk); pr_tb_ptr.upload(tb_ptr); pr_tg_prior.upload(tg_prior); pr_tg_base.upload(tg_base);
+        pr_r.alloc(3 * (size_t)Q.n); pr_J.alloc(36 * (size_t)Q.n); pr_jx.alloc(3 * (size_t)Q.n);
+        Q.pose = pr_pose.p; Q.sens = pr_sens.p; Q.pos = pr_pos.p; Q.A = pr_A.p; Q.po = pr_po.p; Q.so = pr_so.p;
+        Q.pdim = pr_pdim.p; Q.r = pr_r.p; Q.J = pr_J.p; Q.jx = pr_jx.p;
+        Q.loss_type = p.prior_loss_type; Q.loss_scale = p.prior_loss_scale;
+        Q.n_tblk = (int)tb_blk.size();
+        Q.tb_blk = pr_tb_blk.p; Q.tb_ptr = pr_tb_ptr.p; Q.tg_prior = pr_tg_prior.p; Q.tg_base = pr_tg_base.p;
+      }
+    }
+    res_out->num_residuals = (int32_t)(2 * n_active_global) + 3 * Q.n;
     res_out->num_effective_parameters = n_c + poff;
     if (n_var_sensors > 0 && comm.world > 1)
       throw std::runtime_error("refine_sensor_from_rig is not supported by the sharded solve");
@@ -1962,6 +2230,10 @@ struct Solver {
       else BA_LAUNCH((ba_linearize_kernel<false, KD_MAX>), dim3(g), dim3(256), st, V, P, Cm, X, Sn, partials.p);
     }
     BA_LAUNCH(ba_final_sum_kernel, dim3(1), dim3(1024), st, partials.p, g, scalars.p + slot);
+    if (use_priors()) {
+      if (jac) BA_LAUNCH(ba_prior_linearize_kernel<true>, dim3(1), dim3(256), st, V, Q, P, Sn, scalars.p + slot);
+      else BA_LAUNCH(ba_prior_linearize_kernel<false>, dim3(1), dim3(256), st, V, Q, P, Sn, scalars.p + slot);
+    }
   }
 
   // gradient of the (scaled) Jacobian and its squared column norms
@@ -1977,6 +2249,8 @@ struct Solver {
     BA_HIP(hipMemsetAsync(gp.p, 0, sizeof(double) * std::max(V.n_p, 1), st));
     BA_HIP(hipMemsetAsync(diag_p.p, 0, sizeof(double) * std::max(V.n_p, 1), st));
     BA_LAUNCH(ba_point_grad_kernel, dim3(grid_for(V.n_points, 128)), dim3(128), st, V, gp.p, diag_p.p);
+    if (use_priors())
+      BA_LAUNCH(ba_prior_accumulate_kernel<0>, dim3(grid_for(Q.n_tblk, 64)), dim3(64), st, V, Q, gc.p, diag_c.p);
     comm.allreduce(gc.p, V.n_c, st);
     comm.allreduce(diag_c.p, V.n_c, st);
     if (!comm.by_point) {  // point sharding: a point's gradient and column norms are complete locally
@@ -1986,13 +2260,17 @@ struct Solver {
   }
 
   // y = (sum over ranks of J_c^T v) for this rank's observations, into tmpc
-  void block_jtv_reduced(const double* vin) {
+  void block_jtv_reduced(const double* vin, const double* x_for_priors = nullptr) {
     BA_HIP(hipMemsetAsync(tmpc.p, 0, sizeof(double) * std::max(V.n_c, 1), st));
     if (V.n_chunks > 0) {
       if (bd == PD) BA_LAUNCH((ba_block_jtv_kernel<false, PD>), dim3(V.n_chunks), dim3(64), st, V, vin, tmpc.p, nullptr);
       else if (bd == KD_WIDE) BA_LAUNCH((ba_block_jtv_kernel<false, KD_WIDE>), dim3(V.n_chunks), dim3(64), st, V, vin, tmpc.p, nullptr);
       else BA_LAUNCH((ba_block_jtv_kernel<false, KD_MAX>), dim3(V.n_chunks), dim3(64), st, V, vin, tmpc.p, nullptr);
       BA_LAUNCH(ba_block_vec_finalize_kernel<false>, dim3(grid_for(V.n_blk, 128)), dim3(128), st, V, tmpc.p, nullptr);
+    }
+    if (x_for_priors && use_priors()) {  // + sum over priors J^T (J x)
+      BA_LAUNCH(ba_prior_jx_kernel, dim3(grid_for(Q.n, 64)), dim3(64), st, Q, x_for_priors);
+      BA_LAUNCH(ba_prior_accumulate_kernel<2>, dim3(grid_for(Q.n_tblk, 64)), dim3(64), st, V, Q, tmpc.p, nullptr);
     }
     comm.allreduce(tmpc.p, V.n_c, st);
   }
@@ -2023,7 +2301,7 @@ struct Solver {
       BA_LAUNCH(ba_point_apply_kernel<0>, dim3(grid_for(V.n_points, 128)), dim3(128), st, V, Cinv.p, jx.p, gp.p,
                 tbuf.p, v.p, dp.p);
     }
-    block_jtv_reduced(v.p);
+    block_jtv_reduced(v.p, xin);
     BA_LAUNCH(ba_dsq_x_kernel, dim3(grid_for(V.n_c, 256)), dim3(256), st, V.n_c, Dc.p, xin, qout);
     BA_LAUNCH(ba_add_kernel, dim3(grid_for(V.n_c, 256)), dim3(256), st, V.n_c, tmpc.p, qout);
   }
@@ -2159,6 +2437,8 @@ struct Solver {
             BA_LAUNCH(ba_block_mat_finalize_kernel<true>, dim3(grid_for(V.n_blk, 128)), dim3(128), st, V, M.p);
           }
         }
+        if (use_priors())
+          BA_LAUNCH(ba_prior_accumulate_kernel<1>, dim3(grid_for(Q.n_tblk, 64)), dim3(64), st, V, Q, M.p, nullptr);
         comm.allreduce(M.p, (size_t)moff_total, st);
         if (bd == PD) BA_LAUNCH(ba_block_invert_kernel<PD>, dim3(grid_for(V.n_blk, 64)), dim3(64), st, V, Dc.p, M.p, Minv.p);
         else if (bd == KD_WIDE) BA_LAUNCH(ba_block_invert_kernel<KD_WIDE>, dim3(grid_for(V.n_blk, 64)), dim3(64), st, V, Dc.p, M.p, Minv.p);
@@ -2190,6 +2470,7 @@ struct Solver {
       BA_LAUNCH(ba_axpby_kernel, dim3(std::max(gvp, 1)), dim3(256), st, np, -1.0, dp.p, nullptr, stepp.p);
       BA_LAUNCH(ba_model_kernel, dim3(grid_for(V.n_obs, 256)), dim3(256), st, V, stepc.p, stepp.p, partials.p);
       BA_LAUNCH(ba_final_sum_kernel, dim3(1), dim3(1024), st, partials.p, grid_for(V.n_obs, 256), scalars.p + S_MODEL);
+      if (use_priors()) BA_LAUNCH(ba_prior_model_kernel, dim3(1), dim3(256), st, Q, stepc.p, scalars.p + S_MODEL);
       const double model_change = scalar_sum(S_MODEL);  // (synchronises the stream)
       if (mfma_pending) {
         float ms = 0.f;

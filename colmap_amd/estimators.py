@@ -19,7 +19,7 @@ from __future__ import annotations
 import ctypes as C
 import enum
 from dataclasses import dataclass, field
-from typing import Dict, List, Optional, Set
+from typing import Dict, List, Optional, Sequence, Set
 
 import numpy as np
 
@@ -239,6 +239,7 @@ class FlatProblem:
     prior_sqrt_info: Optional[np.ndarray] = None  # (N_q, 3, 3) f64: left square root of the information matrix
     prior_loss_type: int = 0
     prior_loss_scale: float = 1.0
+    image_slots: Optional[dict] = None            # flatten(): parameterized image id -> (pose slot, sensor slot)
     # id maps for write-back
     pose_ids: List[int] = field(default_factory=list)
     cam_ids: List[int] = field(default_factory=list)
@@ -412,6 +413,7 @@ def flatten(options: BundleAdjustmentOptions, config: BundleAdjustmentConfig,
         return pose_slot(where, params, const_frame), sensor_slot(img.camera_id, sensor_from_rig, const_sensor, rig_id)
 
     parameterized_cams: Set[int] = set()
+    image_slots: Dict[int, tuple] = {}  # parameterized image -> (pose slot, sensor slot or -1)
     gauge_order: List[int] = []  # pose slots of the config's images in image-id order
     gauge_frames: List[int] = []  # and their frame identities
     # AddImageToProblem (:688-697)
@@ -433,6 +435,7 @@ def flatten(options: BundleAdjustmentOptions, config: BundleAdjustmentConfig,
                 slot = image_blocks(img, const_pose)
             obs.append((slot[0], cam_slot(img.camera_id), point_slot(p2.point3D_id), p2.xy[0], p2.xy[1], slot[1]))
         if n > 0:
+            image_slots[image_id] = slot
             parameterized_cams.add(img.camera_id)
             # gauge candidates: reference sensors and constant sensor_from_rig only
             # (IsParameterizedConstSensor, bundle_adjustment_ceres.cc:347-385)
@@ -501,6 +504,7 @@ def flatten(options: BundleAdjustmentOptions, config: BundleAdjustmentConfig,
         pose_const=np.array(pose_is_const, np.uint8), pose_fixed_t=np.full(n_c, -1, np.int8),
         cam_const=cam_const, point_const=point_const, pose_ids=pose_ids, cam_ids=cam_ids,
         point_ids=point_ids)
+    fp.image_slots = image_slots
     if sensor_params:
         fp.sensors = np.array(sensor_params, np.float64).reshape(-1, 7)
         fp.obs_sensor = np.ascontiguousarray(o[:, 5].astype(np.int32))
@@ -784,6 +788,129 @@ class BundleAdjuster:
             if not fp.point_const[j]:
                 rec.points3D[pid].xyz = fp.points[j].copy()
         return summary
+
+
+@dataclass
+class PosePrior:
+    """colmap::PosePrior (geometry/pose_prior.h:43-77), the fields the adjuster reads: the image the prior
+    belongs to (corr_data_id of a camera sensor), its position in the world and the position covariance."""
+    image_id: int
+    position: np.ndarray = field(default_factory=lambda: np.full(3, np.nan))
+    position_covariance: Optional[np.ndarray] = None
+
+    def HasPosition(self) -> bool:
+        return bool(np.isfinite(self.position).all())
+
+    def HasPositionCov(self) -> bool:
+        return self.position_covariance is not None and bool(np.isfinite(self.position_covariance).all())
+
+
+@dataclass
+class PosePriorBundleAdjustmentOptions:
+    """PosePriorBundleAdjustmentOptions + CeresPosePriorBundleAdjustmentOptions (bundle_adjustment.h:252-262,
+    bundle_adjustment_ceres.h:102-112)."""
+    prior_position_fallback_stddev: float = 1.0
+    prior_position_loss_function_type: LossFunctionType = LossFunctionType.TRIVIAL
+    prior_position_loss_scale: float = float(np.sqrt(7.815))  # sqrt(kChiSquare95ThreeDof)
+
+    def Check(self) -> bool:
+        return self.prior_position_fallback_stddev > 0 and self.prior_position_loss_scale > 0
+
+
+def align_to_positions(src: np.ndarray, dst: np.ndarray):
+    """Least-squares similarity (scale, R, t) with dst ~ scale R src + t (Umeyama). The reference estimates
+    the same transform inside RANSAC (AlignReconstructionToPosePriors); here all correspondences are used.
+    Returns None when the points are degenerate (fewer than 3, or collinear)."""
+    src, dst = np.asarray(src, np.float64), np.asarray(dst, np.float64)
+    if len(src) < 3:
+        return None
+    ms, md = src.mean(0), dst.mean(0)
+    a, b = src - ms, dst - md
+    var = (a * a).sum() / len(src)
+    if var < 1e-24:
+        return None
+    U, S, Vt = np.linalg.svd(b.T @ a / len(src))
+    if S[1] < 1e-12 * max(S[0], 1e-300):
+        return None  # collinear: the rotation about the line is not determined
+    D = np.eye(3)
+    if np.linalg.det(U) * np.linalg.det(Vt) < 0:
+        D[2, 2] = -1
+    R = U @ D @ Vt
+    scale = float(np.trace(np.diag(S) @ D) / var)
+    return scale, R, md - scale * R @ ms
+
+
+class PosePriorBundleAdjuster(BundleAdjuster):
+    """PosePriorBundleAdjuster (bundle_adjustment_ceres.cc:900-1085): priors without a position or for
+    images outside the config are dropped; with >= 3 usable priors the reconstruction is aligned to them
+    (similarity), normalised (fixed scale) and every parameterized image with a variable pose or
+    sensor_from_rig block gets a covariance-weighted position residual -- the priors own the gauge; otherwise
+    the two-camera gauge is fixed and the priors are not used. Solve() undoes the normalisation."""
+
+    def __init__(self, options: BundleAdjustmentOptions, prior_options: PosePriorBundleAdjustmentOptions,
+                 config: BundleAdjustmentConfig, pose_priors: Sequence[PosePrior],
+                 reconstruction: scene.Reconstruction, solve_fn=None):
+        assert options.Check() and prior_options.Check()
+        import copy
+        config = copy.deepcopy(config)
+        self.prior_options_ = prior_options
+        self.pose_priors_ = [p for p in pose_priors if p.HasPosition() and config.HasImage(p.image_id)]
+        self.normalized_from_metric_ = np.zeros(3)
+        self.use_prior_position_ = len(self.pose_priors_) >= 3 and self._align(reconstruction)
+        if self.use_prior_position_:
+            self.normalized_from_metric_ = reconstruction.Normalize(fixed_scale=True)
+        else:
+            config.FixGauge(BundleAdjustmentGauge.TWO_CAMS_FROM_WORLD)
+        super().__init__(options, config, reconstruction, solve_fn=solve_fn)
+        if self.use_prior_position_:
+            self._add_priors()
+
+    def _align(self, rec: scene.Reconstruction) -> bool:
+        src = np.array([rec.ProjectionCenter(p.image_id) for p in self.pose_priors_])
+        dst = np.array([p.position for p in self.pose_priors_])
+        tf = align_to_positions(src, dst)
+        if tf is None:
+            return False
+        rec.Transform(*tf)
+        return True
+
+    def _add_priors(self):
+        fp = self.problem_
+        rows = []
+        for pr in self.pose_priors_:
+            slot = (fp.image_slots or {}).get(pr.image_id)
+            if slot is None:  # not parameterized: no reprojection constraints (:955-961)
+                continue
+            pose_slot, sens_slot = slot
+            const_sensor = sens_slot < 0 or bool(fp.sensor_const[sens_slot])
+            if fp.pose_const[pose_slot] and const_sensor:  # (:997-1000)
+                continue
+            cov = (np.asarray(pr.position_covariance, np.float64) if pr.HasPositionCov()
+                   else self.prior_options_.prior_position_fallback_stddev ** 2 * np.eye(3))
+            L = np.linalg.cholesky(np.linalg.inv(cov))  # LeftSqrtInformation: cov^-1 = L L^T, weight = L^T
+            rows.append((pose_slot, sens_slot, np.asarray(pr.position, np.float64) + self.normalized_from_metric_, L.T))
+        if not rows:
+            return
+        fp.prior_pose = np.array([r[0] for r in rows], np.int32)
+        fp.prior_sensor = np.array([r[1] for r in rows], np.int32)
+        fp.prior_position = np.ascontiguousarray(np.stack([r[2] for r in rows]))
+        fp.prior_sqrt_info = np.ascontiguousarray(np.stack([r[3] for r in rows]))
+        fp.prior_loss_type = int(self.prior_options_.prior_position_loss_function_type)
+        fp.prior_loss_scale = float(self.prior_options_.prior_position_loss_scale)
+
+    def Solve(self) -> BundleAdjustmentSummary:
+        summary = super().Solve()
+        self.reconstruction_.Transform(1.0, np.eye(3), -self.normalized_from_metric_)  # Inverse(normalized_from_metric)
+        return summary
+
+
+def CreatePosePriorBundleAdjuster(options: BundleAdjustmentOptions, prior_options: PosePriorBundleAdjustmentOptions,
+                                  config: BundleAdjustmentConfig, pose_priors: Sequence[PosePrior],
+                                  reconstruction: scene.Reconstruction, solve_fn=None) -> PosePriorBundleAdjuster:
+    """colmap::CreatePosePriorBundleAdjuster (bundle_adjustment.cc:373-395)."""
+    if options.backend != BundleAdjustmentBackend.MI355X:
+        raise ValueError(f"backend {options.backend!r} is not built here: only MI355X")
+    return PosePriorBundleAdjuster(options, prior_options, config, pose_priors, reconstruction, solve_fn=solve_fn)
 
 
 def CreateDefaultBundleAdjuster(options: BundleAdjustmentOptions, config: BundleAdjustmentConfig,

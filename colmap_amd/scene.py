@@ -145,6 +145,52 @@ class Reconstruction:
     def RegImageIds(self) -> List[int]:
         return sorted(self.images)
 
+    def ProjectionCenter(self, image_id: int) -> np.ndarray:
+        """Image::ProjectionCenter: -R^T t of cam_from_world."""
+        p = self.images[image_id].cam_from_world
+        return -quat_to_rot(p[:4]).T @ p[4:]
+
+    def Transform(self, scale: float, rot: np.ndarray, trans: np.ndarray):
+        """Reconstruction::Transform(new_from_old_world = Sim3d(scale, rot, trans)) (scene/reconstruction.cc:
+        788-805): sensor_from_rig translations scale, every pose block becomes TransformCameraWorld of
+        itself (R' = R_c R^T, t' = s t_c - R' t), points X' = s R X + t."""
+        R = np.asarray(rot, np.float64).reshape(3, 3)
+        t = np.asarray(trans, np.float64)
+
+        def cam(pose):
+            Rn = quat_to_rot(pose[:4]) @ R.T
+            return np.concatenate([rot_to_quat(Rn), scale * pose[4:] - Rn @ t])
+        for rig in self.rigs.values():
+            for cid, sfr in rig.sensors.items():
+                if not rig.IsRefSensor(cid):
+                    sfr[4:] = scale * sfr[4:]
+        for fr in self.frames.values():
+            fr.rig_from_world = cam(fr.rig_from_world)
+        for img in self.images.values():
+            if img.frame_id_ is None:
+                img.cam_from_world = cam(img.cam_from_world)
+        self.UpdateCamFromWorld()
+        for pt in self.points3D.values():
+            pt.xyz = scale * (R @ pt.xyz) + t
+
+    def ComputeCentroid(self, min_percentile: float = 0.1, max_percentile: float = 0.9) -> np.ndarray:
+        """ComputeBoundingBoxAndCentroid over the projection centres (geometry/normalization.cc:39-92)."""
+        c = np.array([self.ProjectionCenter(i) for i in sorted(self.images)])
+        end = len(c) - 1
+        lo = min(end, int(np.floor(min_percentile * end)))
+        hi = min(end, int(np.ceil(max_percentile * end)))
+        return np.array([np.sort(c[:, k])[lo:hi + 1].mean() for k in range(3)])
+
+    def Normalize(self, fixed_scale: bool = True) -> np.ndarray:
+        """Reconstruction::Normalize(fixed_scale = true) (:698-727): translation by minus the centroid of the
+        projection centres. Returns the translation of normalized_from_metric."""
+        assert fixed_scale, "only the fixed-scale normalisation of the pose-prior adjuster is built"
+        if len(self.images) < 2:
+            return np.zeros(3)
+        t = -self.ComputeCentroid()
+        self.Transform(1.0, np.eye(3), t)
+        return t
+
     def NumPoints3D(self) -> int:
         return len(self.points3D)
 
@@ -188,6 +234,25 @@ def quat_to_rot(q: np.ndarray) -> np.ndarray:
         [1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
         [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
         [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def rot_to_quat(R: np.ndarray) -> np.ndarray:
+    """Rotation matrix -> unit quaternion (xyzw), w >= 0 branch-stable (Shepperd)."""
+    m = np.asarray(R, np.float64)
+    tr = np.trace(m)
+    if tr > 0:
+        s = np.sqrt(tr + 1.0) * 2
+        q = np.array([(m[2, 1] - m[1, 2]) / s, (m[0, 2] - m[2, 0]) / s, (m[1, 0] - m[0, 1]) / s, 0.25 * s])
+    else:
+        i = int(np.argmax(np.diag(m)))
+        j, k = (i + 1) % 3, (i + 2) % 3
+        s = np.sqrt(1.0 + m[i, i] - m[j, j] - m[k, k]) * 2
+        q = np.zeros(4)
+        q[i] = 0.25 * s
+        q[j] = (m[j, i] + m[i, j]) / s
+        q[k] = (m[k, i] + m[i, k]) / s
+        q[3] = (m[k, j] - m[j, k]) / s
+    return q / np.linalg.norm(q)
 
 
 def quat_mul(a: np.ndarray, b: np.ndarray) -> np.ndarray:

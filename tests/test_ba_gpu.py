@@ -499,3 +499,79 @@ def _model_matches_oracle(model, params):
     atol = 2e-4 if model in (scene.EUCM, scene.FULL_OPENCV, scene.THIN_PRISM_FISHEYE) else 1e-5
     _assert_close(a, want, b, got, cost_rtol=1e-7, param_atol=atol, traj_rtol=1e-5)
     assert got.final_cost < 0.2 * got.initial_cost
+
+
+# ------------------------------------------------------------------------------------------------
+# position priors (PosePriorBundleAdjuster, cost_functions/pose_prior.h:76-129)
+# ------------------------------------------------------------------------------------------------
+
+_EXACT = dict(eta=1e-10, max_linear_solver_iterations=500)  # see tests/test_ba_oracle.py
+
+
+def _flat_prior_problem(seed=3, n_img=8, sigma=0.05):
+    fp = _flat(n_img, 120, 4, seed=seed, noise=scene.SyntheticNoiseOptions(0.01, 0.5, 0.02, 0.5))
+    rng = np.random.default_rng(seed)
+    centres = np.stack([-scene.quat_to_rot(p[:4]).T @ p[4:] for p in fp.poses])
+    fp.prior_pose = np.arange(n_img, dtype=np.int32)
+    fp.prior_position = np.ascontiguousarray(centres + sigma * rng.normal(size=centres.shape))
+    cov = np.diag([0.01, 0.02, 0.04]) + 0.002
+    L = np.linalg.cholesky(np.linalg.inv(cov))
+    fp.prior_sqrt_info = np.ascontiguousarray(np.repeat(L.T[None], n_img, 0))
+    return fp
+
+
+@pytest.mark.parametrize("loss", [est.LossFunctionType.TRIVIAL, est.LossFunctionType.CAUCHY])
+def test_position_priors_match_oracle(loss):
+    """Priors instead of a gauge: 3 residuals per prior on the pose blocks, covariance weighted, with their own
+    loss; the HIP solve follows the oracle (cost 1e-8, parameters 1e-6) and is bit-reproducible."""
+    fp = _flat_prior_problem()
+    fp.prior_loss_type, fp.prior_loss_scale = int(loss), 1.5
+    if loss != est.LossFunctionType.TRIVIAL:
+        fp.prior_position = fp.prior_position.copy()
+        fp.prior_position[2] += 3.0  # an outlier for the robust loss
+    (a, want), (b, got) = _both(fp, max_num_iterations=60, gradient_tolerance=1e-10, **_EXACT)
+    assert want.IsSolutionUsable() and got.num_residuals == 2 * len(fp.obs_pose) + 24
+    _assert_close(a, want, b, got, cost_rtol=1e-8, param_atol=1e-6)
+    c = fp.copy()
+    again = est.solve_flat(c, est.SolverOptions(max_num_iterations=60, gradient_tolerance=1e-10, **_EXACT), gpu_index=0)
+    assert again.final_cost == got.final_cost and np.array_equal(c.poses, b.poses)
+    # a gauge-fixed problem with priors on top (priors on constant blocks are ignored)
+    g = fp.copy()
+    assert est.fix_gauge_two_cams(g)
+    (a2, want2), (b2, got2) = _both(g, max_num_iterations=40, gradient_tolerance=1e-10, **_EXACT)
+    assert got2.num_residuals == want2.num_residuals == 2 * len(fp.obs_pose) + 3 * int((g.pose_const == 0).sum())
+    _assert_close(a2, want2, b2, got2, cost_rtol=1e-8, param_atol=1e-6)
+
+
+def test_pose_prior_adjuster_on_rigs_matches_oracle():
+    """CreatePosePriorBundleAdjuster on two-camera rigs with refine_sensor_from_rig: priors of the reference
+    sensors sit on rig_from_world, priors of the other sensors on (sensor_from_rig, rig_from_world)
+    (AbsoluteRigPosePositionPriorCostFunctor); HIP and oracle produce the same reconstruction."""
+    def run(solve_fn):
+        rec = scene.SynthesizeDataset(scene.SyntheticDatasetOptions(num_rigs=2, num_cameras_per_rig=2, num_frames_per_rig=5,
+                                                                    num_points3D=200), seed=51)
+        gt = rec.copy()
+        rng = np.random.default_rng(52)
+        priors = [est.PosePrior(i, gt.ProjectionCenter(i) + 0.01 * rng.normal(size=3),
+                                np.diag([1e-4, 2e-4, 4e-4])) for i in gt.RegImageIds()]
+        scene.SynthesizeNoise(scene.SyntheticNoiseOptions(0.02, 0.3, 0.02, 0.2), rec, seed=53)
+        cfg = est.BundleAdjustmentConfig()
+        for i in rec.RegImageIds():
+            cfg.AddImage(i)
+        opt = est.BundleAdjustmentOptions(refine_sensor_from_rig=True)
+        opt.solver_options = est.SolverOptions(max_num_iterations=60, gradient_tolerance=1e-7, **_EXACT)
+        opt.gpu_index = "0"
+        ba = est.CreatePosePriorBundleAdjuster(opt, est.PosePriorBundleAdjustmentOptions(), cfg, priors, rec, solve_fn=solve_fn)
+        assert ba.use_prior_position_ and (ba.problem_.prior_sensor >= 0).any() and (ba.problem_.prior_sensor < 0).any()
+        assert ba.problem_.sensor_const is not None and not ba.problem_.sensor_const.all()
+        return rec, gt, ba.Solve()
+    rec_o, gt, s_o = run(ba_oracle.solve_fn)
+    rec_h, _, s_h = run(None)
+    assert s_h.num_residuals == s_o.num_residuals and s_h.termination_type == s_o.termination_type
+    assert abs(s_h.final_cost - s_o.final_cost) <= 1e-8 * s_o.final_cost
+    for i in gt.RegImageIds():
+        np.testing.assert_allclose(rec_h.images[i].cam_from_world, rec_o.images[i].cam_from_world, atol=1e-6)
+        assert np.linalg.norm(rec_h.ProjectionCenter(i) - gt.ProjectionCenter(i)) < 0.05
+    for rid, rig in rec_o.rigs.items():
+        for cid, sfr in rig.sensors.items():
+            np.testing.assert_allclose(rec_h.rigs[rid].sensors[cid], sfr, atol=1e-6)

@@ -828,3 +828,38 @@ def test_position_prior_cost_against_scipy():
     assert abs(0.5 * np.sum(resid(x0) ** 2) - s.final_cost) <= 1e-9 * s.final_cost
     sol = least_squares(resid, x0, method="trf", xtol=1e-15, ftol=1e-15, gtol=1e-12, max_nfev=200)
     assert abs(sol.cost - s.final_cost) <= 1e-6 * s.final_cost
+
+
+def test_pose_prior_bundle_adjuster_adapter():
+    """CreatePosePriorBundleAdjuster (bundle_adjustment.cc:373-395, bundle_adjustment_ceres.cc:900-1085) through
+    the oracle: a reconstruction in an arbitrary similarity frame + priors in the metric frame -> the result
+    is in the metric frame (aligned, normalised, solved without a fixed gauge, de-normalised)."""
+    rec = scene.SynthesizeDataset(scene.SyntheticDatasetOptions(num_rigs=2, num_frames_per_rig=4, num_points3D=150), seed=41)
+    gt = rec.copy()
+    rng = np.random.default_rng(42)
+    priors = [est.PosePrior(i, gt.ProjectionCenter(i) + 0.01 * rng.normal(size=3), 1e-4 * np.eye(3)) for i in gt.RegImageIds()]
+    priors.append(est.PosePrior(gt.RegImageIds()[0]))           # no position: dropped
+    scene.SynthesizeNoise(scene.SyntheticNoiseOptions(0.02, 0.3, 0.02, 0.2), rec, seed=43)
+    Rw = scene.quat_to_rot(np.array([0.1, -0.2, 0.3, 0.9]) / np.linalg.norm([0.1, -0.2, 0.3, 0.9]))
+    rec.Transform(1.7, Rw, np.array([3.0, -2.0, 1.0]))        # away from the metric frame
+    cfg = est.BundleAdjustmentConfig()
+    for i in rec.RegImageIds():
+        cfg.AddImage(i)
+    opt = est.BundleAdjustmentOptions()
+    opt.solver_options = est.SolverOptions(max_num_iterations=60, gradient_tolerance=1e-10, **_EXACT)
+    ba = est.CreatePosePriorBundleAdjuster(opt, est.PosePriorBundleAdjustmentOptions(), cfg, priors, rec,
+                                           solve_fn=ba_oracle.solve_fn)
+    assert ba.use_prior_position_ and len(ba.problem_.prior_pose) == len(gt.RegImageIds())
+    assert (ba.problem_.pose_fixed_t == -1).all()               # no gauge fixed: the priors own it
+    s = ba.Solve()
+    assert s.IsSolutionUsable() and s.num_residuals == 2 * len(ba.problem_.obs_pose) + 3 * len(gt.RegImageIds())
+    err = [np.linalg.norm(rec.ProjectionCenter(i) - gt.ProjectionCenter(i)) for i in gt.RegImageIds()]
+    assert max(err) < 0.05, max(err)
+    pts = np.array([np.linalg.norm(rec.points3D[j].xyz - gt.points3D[j].xyz) for j in gt.points3D])
+    assert np.median(pts) < 0.05
+    # fewer than three priors: two-camera gauge, priors unused (:925-936)
+    rec2 = gt.copy()
+    ba2 = est.CreatePosePriorBundleAdjuster(opt, est.PosePriorBundleAdjustmentOptions(), cfg, priors[:2], rec2,
+                                            solve_fn=ba_oracle.solve_fn)
+    assert not ba2.use_prior_position_ and ba2.problem_.prior_pose is None
+    assert (ba2.problem_.pose_const == 1).sum() >= 1
