@@ -1806,6 +1806,55 @@ __global__ void __launch_bounds__(256) ba_prior_model_kernel(PriorView Q, const 
   if (threadIdx.x == 0) *slot += red[0];
 }
 
+// ------------------------------------------------------------------------------------------
+// DENSE_SCHUR tier (ceres::DENSE_SCHUR as CreateSolverOptions selects it for <= 50 images,
+// bundle_adjustment_ceres.cc:203-213): S is formed column by column through the implicit operator
+// (S e_i), then factored and solved by one workgroup. n <= 1024.
+// ------------------------------------------------------------------------------------------
+__global__ void ba_unit_vector_kernel(int n, int i, double* __restrict__ e) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) e[k] = k == i ? 1.0 : 0.0;
+}
+
+// in-place lower Cholesky of the column-major (= row-major, S is symmetric) n x n matrix S, then
+// x = S^-1 b. A non-positive pivot yields NaNs: the LM loop rejects the step like a failed LLT.
+__global__ void __launch_bounds__(1024) ba_dense_cholesky_solve_kernel(int n, double* __restrict__ S,
+                                                                       const double* __restrict__ b,
+                                                                       double* __restrict__ x) {
+  const int tid = threadIdx.x, T = blockDim.x;
+  // S(i, j) = S[j * n + i]: column j is what the j-th operator product wrote
+  for (int k = 0; k < n; ++k) {
+    if (tid == 0) S[(size_t)k * n + k] = sqrt(S[(size_t)k * n + k]);
+    __syncthreads();
+    const double d = S[(size_t)k * n + k];
+    for (int i = k + 1 + tid; i < n; i += T) S[(size_t)k * n + i] /= d;
+    __syncthreads();
+    // trailing update of the lower triangle: column j, rows i >= j
+    const int m = n - k - 1;
+    for (int e = tid; e < m * m; e += T) {
+      const int j = k + 1 + e / m, i = k + 1 + e % m;
+      if (i >= j) S[(size_t)j * n + i] -= S[(size_t)k * n + i] * S[(size_t)k * n + j];
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < n; i += T) x[i] = b[i];
+  __syncthreads();
+  for (int k = 0; k < n; ++k) {  // L y = b
+    if (tid == 0) x[k] /= S[(size_t)k * n + k];
+    __syncthreads();
+    const double yk = x[k];
+    for (int i = k + 1 + tid; i < n; i += T) x[i] -= S[(size_t)k * n + i] * yk;
+    __syncthreads();
+  }
+  for (int k = n - 1; k >= 0; --k) {  // L^T x = y
+    if (tid == 0) x[k] /= S[(size_t)k * n + k];
+    __syncthreads();
+    const double xk = x[k];
+    for (int i = tid; i < k; i += T) x[i] -= S[(size_t)i * n + k] * xk;
+    __syncthreads();
+  }
+}
+
 template <typename T>
 struct Buf {
   T* p = nullptr;
@@ -1857,10 +1906,12 @@ struct Solver {
   Buf<unsigned char> solo;
   Buf<double> o_xy, poses, cams, points, poses2, cams2, points2, Jpose, Jcam, Jpt, res, res_p, scale_c, scale_p,
       scalars, gc, gp, diag_c, diag_p, Dc, Dp, Cinv, M, Minv, rhs, x, r, z, pdir, q, dp, jx, v, stepc, stepp, partials, cpart, Craw, tbuf, tmpc, Gobs, pcg_part, maxbuf;
+  Buf<double> Sdense;  // DENSE_SCHUR tier: the reduced camera system, n_c x n_c
   // position priors
   Buf<int> pr_pose, pr_sens, pr_po, pr_so, pr_pdim, pr_tb_blk, pr_tb_ptr, pr_tg_prior, pr_tg_base;
   Buf<double> pr_pos, pr_A, pr_r, pr_J, pr_jx;
   PriorView Q{};
+  bool use_dense = false;
   bool use_priors() const { return Q.n > 0 && comm.rank == 0; }  // sums are all-reduced: one rank contributes them
   int moff_total = 0;
   long long n_paired = 0;  // (observation, block kind) slots that have a partner of the same point in the block
@@ -2306,6 +2357,18 @@ struct Solver {
     BA_LAUNCH(ba_add_kernel, dim3(grid_for(V.n_c, 256)), dim3(256), st, V.n_c, tmpc.p, qout);
   }
 
+  // DENSE_SCHUR: x = S^-1 rhs with S built from n_c operator products
+  int dense_schur() {
+    const int n = V.n_c;
+    if (Sdense.n < (size_t)n * n) throw std::runtime_error("dense Schur buffer");
+    for (int i = 0; i < n; ++i) {
+      BA_LAUNCH(ba_unit_vector_kernel, dim3(grid_for(n, 256)), dim3(256), st, n, i, pdir.p);
+      schur_multiply(pdir.p, Sdense.p + (size_t)i * n);
+    }
+    BA_LAUNCH(ba_dense_cholesky_solve_kernel, dim3(1), dim3(1024), st, n, Sdense.p, rhs.p, x.p);
+    return 1;
+  }
+
   int pcg(int max_iter, double q_tol) {
     const int n = V.n_c;
     const int gv = grid_for(n, 256);
@@ -2356,6 +2419,14 @@ struct Solver {
     if (n == 0) return;
     const int nc = V.n_c, np = V.n_p;
     const int gvc = grid_for(nc, 256), gvp = grid_for(np, 256);
+    if (opt.linear_solver_type < BA_SOLVER_ITERATIVE_SCHUR || opt.linear_solver_type > BA_SOLVER_AUTO)
+      throw std::runtime_error("linear_solver_type");
+    use_dense = (opt.linear_solver_type == BA_SOLVER_DENSE_SCHUR ||
+                 (opt.linear_solver_type == BA_SOLVER_AUTO && prob.num_poses <= 50)) && nc > 0 && nc <= 1024;
+    if (use_dense) {
+      Sdense.alloc((size_t)nc * nc);
+      BA_HIP(hipDeviceSynchronize());  // the allocation's memset runs on the NULL stream
+    }
     g_spmv_ms = 0.0; g_spmv_launches = 0;
     g_mfma_ms = 0.0; g_mfma_launches = 0;
     // bytes one implicit-Schur product streams: Jc (2x10) once for jx, Jp (2x3) twice, jx/v, Jc again
@@ -2448,7 +2519,7 @@ struct Solver {
         block_jtv_reduced(v.p);
         BA_HIP(hipMemcpyAsync(rhs.p, gc.p, sizeof(double) * nc, hipMemcpyDeviceToDevice, st));
         BA_LAUNCH(ba_add_kernel, dim3(grid_for(nc, 256)), dim3(256), st, nc, tmpc.p, rhs.p);
-        lin_iters = pcg(opt.max_linear_solver_iterations, opt.eta);
+        lin_iters = use_dense ? dense_schur() : pcg(opt.max_linear_solver_iterations, opt.eta);
         out->total_linear_iterations += lin_iters;
       }
       // back-substitution y_p = C^-1 (g_p - E^T y_c); step = -(y_c, y_p)
@@ -2593,6 +2664,7 @@ void ba_options_init(ba_options* o) {
   o->jacobi_scaling = 1;
   o->loss_type = BA_LOSS_TRIVIAL;  // bundle_adjustment_ceres.h:42-51
   o->loss_scale = 1.0;
+  o->linear_solver_type = BA_SOLVER_ITERATIVE_SCHUR;
 }
 
 static int SolveImpl(ba_problem* problem, const ba_options* options, int32_t gpu_index, const ba_comm* c,

@@ -161,6 +161,10 @@ class SolverOptions:
     # (bundle_adjustment_ceres.h:42-51)
     loss_type: int = 0   # LossFunctionType.TRIVIAL
     loss_scale: float = 1.0
+    # ba_options.linear_solver_type: ITERATIVE_SCHUR (implicit Schur PCG + Schur-Jacobi, the benchmarked
+    # path), DENSE_SCHUR (reduced camera system formed and Cholesky-solved) or the reference's choice by
+    # problem size (CeresBundleAdjustmentOptions::CreateSolverOptions, bundle_adjustment_ceres.cc:203-213)
+    linear_solver_type: int = 0
 
 
 @dataclass
@@ -177,7 +181,9 @@ class BundleAdjustmentOptions:
     print_summary: bool = True
     backend: BundleAdjustmentBackend = BundleAdjustmentBackend.MI355X
     gpu_index: str = "-1"
-    solver_options: SolverOptions = field(default_factory=SolverOptions)
+    # adapter level: the reference's solver choice by problem size (CreateSolverOptions,
+    # bundle_adjustment_ceres.cc:203-213); solve_flat's own default stays ITERATIVE_SCHUR
+    solver_options: SolverOptions = field(default_factory=lambda: SolverOptions(linear_solver_type=2))
 
     def Check(self) -> bool:
         return self.min_track_length >= 0
@@ -566,6 +572,7 @@ class ba_options(C.Structure):
         ("max_num_consecutive_invalid_steps", C.c_int32), ("jacobi_scaling", C.c_int32),
         ("num_threads", C.c_int32), ("max_log", C.c_int32),
         ("loss_type", C.c_int32), ("loss_scale", C.c_double),
+        ("linear_solver_type", C.c_int32),
     ]
 
 
@@ -589,6 +596,7 @@ class ba_comm(C.Structure):
 
 
 SHARD_BY_IMAGE, SHARD_BY_POINT = 0, 1
+SOLVER_ITERATIVE_SCHUR, SOLVER_DENSE_SCHUR, SOLVER_AUTO = 0, 1, 2
 POSE_ROT_CONST = 4  # ba_problem.pose_fixed_t: + 4 = the rotation of the pose block is held (colmap_amd_ba.h)
 
 

@@ -313,7 +313,11 @@ struct Mi355xBundleAdjustmentOptions {
   LossFunctionType loss_function_type = LossFunctionType::TRIVIAL;
   double loss_function_scale = 1.0;
   ba_options solver_options;
-  Mi355xBundleAdjustmentOptions() { ba_options_init(&solver_options); }
+  Mi355xBundleAdjustmentOptions() {
+    ba_options_init(&solver_options);
+    // the reference's solver choice by problem size (CreateSolverOptions, bundle_adjustment_ceres.cc:203-213)
+    solver_options.linear_solver_type = BA_SOLVER_AUTO;
+  }
 };
 
 struct BundleAdjustmentOptions {  // :173-209

@@ -102,7 +102,15 @@ typedef struct ba_options {
    * applied to every reprojection residual like CreateLossFunction (bundle_adjustment_ceres.cc:66-80) */
   int32_t loss_type;                    /* BA_LOSS_TRIVIAL */
   double loss_scale;                    /* 1.0 */
+  /* Linear solver of the LM step (ceres::LinearSolverType as CreateSolverOptions picks it,
+   * bundle_adjustment_ceres.cc:203-213): BA_SOLVER_ITERATIVE_SCHUR = the implicit Schur complement with
+   * PCG + Schur-Jacobi (what BASELINE.json benchmarks; default), BA_SOLVER_DENSE_SCHUR = the reduced
+   * camera system S = B - E C^-1 E^T formed explicitly and Cholesky-solved on the device (camera-side
+   * dimension <= 1024), BA_SOLVER_AUTO = the reference's rule: DENSE_SCHUR up to 50 images, else
+   * iterative (its middle tier SPARSE_SCHUR is not built). */
+  int32_t linear_solver_type;           /* BA_SOLVER_ITERATIVE_SCHUR */
 } ba_options;
+enum { BA_SOLVER_ITERATIVE_SCHUR = 0, BA_SOLVER_DENSE_SCHUR = 1, BA_SOLVER_AUTO = 2 };
 
 /* CeresBundleAdjustmentOptions::LossFunctionType */
 enum { BA_LOSS_TRIVIAL = 0, BA_LOSS_SOFT_L1 = 1, BA_LOSS_CAUCHY = 2, BA_LOSS_HUBER = 3 };

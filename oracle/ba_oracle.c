@@ -98,6 +98,10 @@ typedef struct {
    * CreateLossFunction bundle_adjustment_ceres.cc:66-80) */
   int32_t loss_type;
   double loss_scale;
+  /* 0: ITERATIVE_SCHUR + SCHUR_JACOBI (implicit Schur complement, PCG); 1: DENSE_SCHUR (the reduced camera
+   * system is formed and solved exactly by Cholesky); 2: the reference's rule by problem size
+   * (bundle_adjustment_ceres.cc:203-213: <= 50 images dense, else iterative -- SPARSE_SCHUR is not built) */
+  int32_t linear_solver_type;
 } bao_options;
 
 enum { BAO_LOSS_TRIVIAL = 0, BAO_LOSS_SOFT_L1 = 1, BAO_LOSS_CAUCHY = 2, BAO_LOSS_HUBER = 3 };
@@ -1454,6 +1458,53 @@ static int pcg(const linsys* s, const double* b, double* x, int max_iter, double
 /* Levenberg-Marquardt (Ceres TrustRegionMinimizer + LevenbergMarquardtStrategy) */
 /* ------------------------------------------------------------------------- */
 
+/* DENSE_SCHUR: S = B + Dc^2 - E C^-1 E^T column by column through the implicit operator, Cholesky, solve.
+ * Returns 0 when S is not positive definite (the LM loop treats the step as invalid). */
+static int dense_schur_solve(const linsys* s, const double* b, double* x, double* tmp_p) {
+  const int n = s->g->n_c;
+  double* S = (double*)malloc(sizeof(double) * (size_t)n * n);
+  double* e = (double*)calloc(n, sizeof(double));
+  double* col = (double*)malloc(sizeof(double) * n);
+  for (int i = 0; i < n; ++i) {
+    e[i] = 1.0;
+    schur_multiply(s, e, col, tmp_p);
+    e[i] = 0.0;
+    for (int r = 0; r < n; ++r) S[(size_t)r * n + i] = col[r];
+  }
+  int ok = 1;
+  /* in-place lower Cholesky of the lower triangle */
+  for (int k = 0; k < n && ok; ++k) {
+    double d = S[(size_t)k * n + k];
+    if (!(d > 0.0)) { ok = 0; break; }
+    d = sqrt(d);
+    S[(size_t)k * n + k] = d;
+    for (int i = k + 1; i < n; ++i) S[(size_t)i * n + k] /= d;
+    for (int j = k + 1; j < n; ++j) {
+      const double ljk = S[(size_t)j * n + k];
+      for (int i = j; i < n; ++i) S[(size_t)i * n + j] -= S[(size_t)i * n + k] * ljk;
+    }
+  }
+  if (ok) {
+    for (int i = 0; i < n; ++i) {
+      double v = b[i];
+      for (int k = 0; k < i; ++k) v -= S[(size_t)i * n + k] * x[k];
+      x[i] = v / S[(size_t)i * n + i];
+    }
+    for (int i = n - 1; i >= 0; --i) {
+      double v = x[i];
+      for (int k = i + 1; k < n; ++k) v -= S[(size_t)k * n + i] * x[k];
+      x[i] = v / S[(size_t)i * n + i];
+    }
+  } else {
+    for (int i = 0; i < n; ++i) x[i] = NAN;
+  }
+  free(S); free(e); free(col);
+  return ok;
+}
+
+#define BAO_DENSE_MAX_IMAGES 50
+#define BAO_DENSE_MAX_DIM 1024
+
 BAO_API void bao_options_init(bao_options* o) {
   /* COLMAP's CeresBundleAdjustmentOptions ctor (bundle_adjustment_ceres.cc:102-115) over
    * Ceres Solver::Options defaults */
@@ -1475,6 +1526,7 @@ BAO_API void bao_options_init(bao_options* o) {
   o->max_log = 0;
   o->loss_type = BAO_LOSS_TRIVIAL; /* bundle_adjustment_ceres.h:42-51 */
   o->loss_scale = 1.0;
+  o->linear_solver_type = 0;
 }
 
 static double now_s(void) {
@@ -1748,7 +1800,10 @@ BAO_API int bao_solve(bao_problem* p, const bao_options* opt, bao_result* res) {
       }
     }
     int lin_iters = 0;
-    if (nc > 0) lin_iters = pcg(&s, rhs, dc, opt->max_linear_solver_iterations, opt->eta, ws);
+    const int dense = (opt->linear_solver_type == 1 || (opt->linear_solver_type == 2 && p->num_poses <= BAO_DENSE_MAX_IMAGES)) &&
+                      nc <= BAO_DENSE_MAX_DIM;
+    if (nc > 0 && dense) { dense_schur_solve(&s, rhs, dc, ws); lin_iters = 1; }
+    else if (nc > 0) lin_iters = pcg(&s, rhs, dc, opt->max_linear_solver_iterations, opt->eta, ws);
     res->total_linear_iterations += lin_iters;
     /* back-substitution: y_p = C^-1 (g_p - E^T y_c) */
     for (int j = 0; j < p->num_points; ++j) {

@@ -863,3 +863,24 @@ def test_pose_prior_bundle_adjuster_adapter():
                                             solve_fn=ba_oracle.solve_fn)
     assert not ba2.use_prior_position_ and ba2.problem_.prior_pose is None
     assert (ba2.problem_.pose_const == 1).sum() >= 1
+
+
+def test_dense_schur_tier_equals_tight_pcg():
+    """linear_solver_type DENSE_SCHUR (reduced camera system formed + Cholesky, the reference's choice up to
+    50 images, bundle_adjustment_ceres.cc:203-213) reaches the minimum the iterative tier reaches with
+    near-exact linear solves, in far fewer LM iterations than the default inexact PCG needs on a problem
+    whose gauge is held by priors only; AUTO picks it by image count."""
+    fp = _prior_problem()
+    a, b, c = fp.copy(), fp.copy(), fp.copy()
+    so = dict(max_num_iterations=80, gradient_tolerance=1e-9)
+    sa = est.solve_flat(a, est.SolverOptions(linear_solver_type=est.SOLVER_DENSE_SCHUR, **so), solve_fn=ba_oracle.solve_fn)
+    sb = est.solve_flat(b, est.SolverOptions(**so, **_EXACT), solve_fn=ba_oracle.solve_fn)
+    sc = est.solve_flat(c, est.SolverOptions(linear_solver_type=est.SOLVER_AUTO, **so), solve_fn=ba_oracle.solve_fn)
+    assert sa.termination_type == est.BundleAdjustmentTerminationType.CONVERGENCE
+    assert abs(sa.final_cost - sb.final_cost) <= 1e-9 * sb.final_cost
+    np.testing.assert_allclose(a.poses, b.poses, atol=1e-6)
+    assert sc.final_cost == sa.final_cost and sc.num_iterations == sa.num_iterations   # 8 images: AUTO = dense
+    assert (sa.log_linear_iters[:sa.num_iterations] == 1).all()
+    d = fp.copy()
+    sd = est.solve_flat(d, est.SolverOptions(**so), solve_fn=ba_oracle.solve_fn)          # default: inexact PCG
+    assert sd.num_iterations > 2 * sa.num_iterations
