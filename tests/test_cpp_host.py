@@ -195,7 +195,7 @@ def _ba_cases():
     pids = sorted(rec.points3D)
     cfg.AddVariablePoint(pids[0]); cfg.AddVariablePoint(pids[1]); cfg.AddConstantPoint(pids[2]); cfg.IgnorePoint(pids[3])
     so = est.SolverOptions(loss_type=int(est.LossFunctionType.CAUCHY), loss_scale=2.0, max_num_iterations=30,
-                           gradient_tolerance=1e-8)
+                           gradient_tolerance=1e-8, linear_solver_type=est.SOLVER_AUTO)  # the adapters' default
     cases.append(("rigs_mixed_config", rec, cfg,
                   est.BundleAdjustmentOptions(refine_sensor_from_rig=False, min_track_length=3, solver_options=so), None))
     return cases
