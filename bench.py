@@ -338,10 +338,10 @@ def main():
                 "taps_per_s": (evals_sweep + evals_init) * 121 / dt,
                 "valu_frac": (evals_sweep + evals_init) * 121 * 30.0 / dt / 157.3e12,
                 "ncc_evaluations_per_pixel_per_sweep": evals_sweep / max(a.steps * a.batch * a.groups * pix_per_image * 20, 1),
-                "note": "gather/latency-limited fp32 VALU kernel, no dense contraction: VALU issue ~58 % busy, "
-                        "4-byte footprint gathers miss the XCD L2 69 % of the time (fabric reads ~33x the "
-                        "algorithmic bytes); the HBM fraction is reported because BASELINE.json asks for it, "
-                        "see DESIGN.md 1.5 for the PMC accounting",
+                "note": "fp32 VALU-issue-bound kernel without a dense contraction (VALU 82-85 % busy by PMC, "
+                        "DESIGN.md 1.5): taps_per_s / valu_frac carry the useful arithmetic; the HBM fraction is "
+                        "reported because BASELINE.json asks for it. traffic = FETCH_SIZE + WRITE_SIZE of "
+                        "profiles/pm_sweep_traffic.json (4-byte footprint gathers, ~35x the algorithmic bytes)",
             },
         }
         # the CPU baseline and the secondary (single-GPU) BA measurement belong to the N = 1 run only
