@@ -189,7 +189,11 @@ struct Walk {
 // materialising the neighbours. CLOSURE: ignore max_traversal_depth and max_num_pixels -- everything
 // the seed could absorb under any superset of the current masks. CLAIM: atomicMax the claim word of
 // every recorded pixel. ATTR: also record normal and colour (for the fuse step).
-template <bool CLOSURE, bool CLAIM, bool ATTR>
+// FAST (the first claiming walk of a seed in a round): "did this walk absorb the pixel already?" is read off
+// the claim word -- equal to the walk's key: yes; below it (older round / later seed): no, since the walk's own
+// claim would have raised it; above it (an earlier seed of the order holds the pixel): undecided, look
+// through the record. The word is read past the L1 (the claims are L2 atomics).
+template <bool CLOSURE, bool CLAIM, bool ATTR, bool FAST = false>
 __device__ Walk walk(const Params& p, int lane, int seed, unsigned long long key) {
   Walk w{0, false, false};
   const DevImage& I0 = p.images[p.image];
@@ -203,9 +207,22 @@ __device__ Walk walk(const Params& p, int lane, int seed, unsigned long long key
       const int pix = row * im.dw + col;
       const unsigned mk = p.mask[im.pix_off + pix];
       if (mk != 0u && mk < p.round) break;  // masked before this round
-      bool seen = false;
-      for (int e = 0; e < ne; ++e)
-        if (SLOT(p.e_pix, e) == (unsigned)pix) seen |= (int)(SLOT(p.e_meta, e) & 0xFFFFu) == img;
+      bool seen = false, scan = true;
+      if (FAST) {
+        const unsigned long long w0 = __hip_atomic_load(p.claim + im.pix_off + pix, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        seen = w0 == key;
+        scan = w0 > key;
+      }
+      if (scan) {
+        int e = 0;
+        for (; e + 4 <= ne; e += 4) {  // four record entries per round trip
+          const unsigned p0 = SLOT(p.e_pix, e), p1 = SLOT(p.e_pix, e + 1), p2 = SLOT(p.e_pix, e + 2), p3 = SLOT(p.e_pix, e + 3);
+          const unsigned m0 = SLOT(p.e_meta, e), m1 = SLOT(p.e_meta, e + 1), m2 = SLOT(p.e_meta, e + 2), m3 = SLOT(p.e_meta, e + 3);
+          seen |= (p0 == (unsigned)pix && (int)(m0 & 0xFFFFu) == img) | (p1 == (unsigned)pix && (int)(m1 & 0xFFFFu) == img) |
+                  (p2 == (unsigned)pix && (int)(m2 & 0xFFFFu) == img) | (p3 == (unsigned)pix && (int)(m3 & 0xFFFFu) == img);
+        }
+        for (; e < ne; ++e) seen |= SLOT(p.e_pix, e) == (unsigned)pix && (int)(SLOT(p.e_meta, e) & 0xFFFFu) == img;
+      }
       if (seen) break;  // masked by this walk
       const float depth = im.depth[pix];
       if (depth <= 0.0f) break;
@@ -313,7 +330,7 @@ __global__ void __launch_bounds__(kBlock) fusion_speculate_kernel(Params p) {
     const int seed = seed_of(p, idx);
     const unsigned prio = prio_of(p, seed);
     const unsigned long long key = claim_key(p.round, prio);
-    const Walk w = p.reuse ? walk<false, true, true>(p, lane, seed, key) : walk<false, true, false>(p, lane, seed, key);
+    const Walk w = p.reuse ? walk<false, true, true, true>(p, lane, seed, key) : walk<false, true, false, true>(p, lane, seed, key);
     if (w.capped) {
       const Walk c = walk<true, true, false>(p, lane, seed, key);
       if (c.overflow) atomicMin(p.barrier, prio);
