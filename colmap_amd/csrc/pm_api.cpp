@@ -395,11 +395,17 @@ void Create(const pm_options& opt_in, const pm_problem& prob, pm_image_cache* ca
         HIP_CALL(hipStreamSynchronize(h->stream));
         if (cache) {
           std::lock_guard<std::mutex> lock(cache->mu);
-          cache->entries.emplace(key, e);
-          cache->order.push_back(key);
-          cache->bytes += fp_count * sizeof(uint32_t);
+          // two threads may miss the same key at once: only the first insertion is accounted for, the
+          // second adopts the entry that is already there
+          const auto ins = cache->entries.emplace(key, e);
           ++cache->misses;
-          cache->Trim();
+          if (ins.second) {
+            cache->order.push_back(key);
+            cache->bytes += fp_count * sizeof(uint32_t);
+            cache->Trim();
+          } else {
+            e = ins.first->second;
+          }
         }
       }
       h->src_fp[s] = e;
