@@ -66,8 +66,8 @@ constexpr int PD = 6;        // pose tangent width (5 when the gauge holds a tra
 // <8, 8>. The kernels whose register footprint depends on them are templates; the others read
 // V.kd / V.bd.
 constexpr int KD_MAX = 8;
-constexpr int KD_WIDE = 12;  // FULL_OPENCV / THIN_PRISM_FISHEYE: up to 12 variable intrinsics (third <KD, BD> tier)
-constexpr int NPAR_WIDE = 12;
+constexpr int KD_WIDE = 16;  // FULL_OPENCV / THIN_PRISM_FISHEYE (12), RAD_TAN_THIN_PRISM_FISHEYE (16): third <KD, BD> tier
+constexpr int NPAR_WIDE = 16;
 constexpr int NPAR = 8;      // max number of parameters of a supported camera model (J_params is 2 x NPAR)
 static int chunk_size() {     // observations per camera-side reduction chunk (one wave each)
   const char* e = std::getenv("COLMAP_AMD_BA_CHUNK");
@@ -188,6 +188,8 @@ __device__ __host__ __forceinline__ int num_params_of(int model) {
     case BA_EUCM: return 6;
     case BA_OPENCV: case BA_OPENCV_FISHEYE: return 8;
     case BA_FULL_OPENCV: case BA_THIN_PRISM_FISHEYE: return 12;
+    case BA_RAD_TAN_THIN_PRISM_FISHEYE: return 16;
+    case BA_EQUIRECTANGULAR: return 2;
     default: return 4;  // PINHOLE, SIMPLE_RADIAL, SIMPLE_RADIAL_FISHEYE, SIMPLE_DIVISION, FISHEYE
   }
 }
@@ -196,7 +198,7 @@ __host__ inline bool model_supported(int model) {
          model == BA_OPENCV || model == BA_OPENCV_FISHEYE || model == BA_SIMPLE_RADIAL_FISHEYE ||
          model == BA_RADIAL_FISHEYE || model == BA_FOV || model == BA_SIMPLE_DIVISION || model == BA_DIVISION ||
          model == BA_SIMPLE_FISHEYE || model == BA_FISHEYE || model == BA_EUCM || model == BA_FULL_OPENCV ||
-         model == BA_THIN_PRISM_FISHEYE;
+         model == BA_THIN_PRISM_FISHEYE || model == BA_RAD_TAN_THIN_PRISM_FISHEYE || model == BA_EQUIRECTANGULAR;
 }
 
 // QuaternionRotatePointWithJac, quaternion_utils.h:105-153
@@ -260,6 +262,29 @@ __device__ __forceinline__ bool img_from_cam(int model, const double* prm, doubl
       Jpar[NP + ic + 1] = 1.0;
       Jpar[ic + 2] = f1 * u * dr_dk;
       Jpar[NP + ic + 2] = f2 * v * dr_dk;
+    }
+    return true;
+  }
+  if (model == BA_EQUIRECTANGULAR) {
+    // spherical panorama (models_jacobian.h:1502-1565): every non-zero direction projects, no cheirality
+    // test; the two parameters (width, height) are metadata and always constant
+    const double width = prm[0], height = prm[1];
+    const double horizontal = sqrt(u * u + w * w);
+    if (horizontal + fabs(v) < 2.220446049250313e-16) return false;
+    const double theta = atan2(u, w), phi = atan2(-v, horizontal);
+    const double kInv2Pi = 1.0 / (2.0 * 3.14159265358979323846), kInvPi = 1.0 / 3.14159265358979323846;
+    x = (theta * kInv2Pi + 0.5) * width;
+    y = (0.5 - phi * kInvPi) * height;
+    if (JAC) {
+      const double R2 = horizontal * horizontal, N2 = R2 + v * v;
+      const double inv_R2 = 1.0 / R2, inv_N2 = 1.0 / N2, inv_N2_h = inv_N2 / horizontal;
+      Juvw[0] = width * kInv2Pi * (w * inv_R2); Juvw[1] = 0.0; Juvw[2] = width * kInv2Pi * (-u * inv_R2);
+      Juvw[3] = -height * kInvPi * (u * v * inv_N2_h); Juvw[4] = -height * kInvPi * (-horizontal * inv_N2);
+      Juvw[5] = -height * kInvPi * (v * w * inv_N2_h);
+#pragma unroll
+      for (int c = 0; c < NP; ++c) Jpar[c] = Jpar[NP + c] = 0.0;
+      Jpar[0] = theta * kInv2Pi + 0.5;
+      Jpar[NP + 1] = 0.5 - phi * kInvPi;
     }
     return true;
   }
@@ -450,6 +475,76 @@ __device__ __forceinline__ bool img_from_cam(int model, const double* prm, doubl
       Jpar[NP + 4] = f2 * vv * n1; Jpar[NP + 5] = f2 * vv * n2; Jpar[NP + 6] = f2 * (r2 + 2.0 * vv2);
       Jpar[NP + 7] = f2 * 2.0 * uv;
       Jpar[NP + 8] = f2 * vv * n3; Jpar[NP + 9] = f2 * vv * d4; Jpar[NP + 10] = f2 * vv * d5; Jpar[NP + 11] = f2 * vv * d6;
+    }
+    return true;
+  }
+  if (NP >= 16 && model == BA_RAD_TAN_THIN_PRISM_FISHEYE) {
+    // models_jacobian.h:1049-1188: equidistant projection, radial polynomial th_radial(theta^2) with six
+    // coefficients, then tangential (p0, p1) + thin-prism (s0..s3) distortion of the radially distorted point
+    const double f1 = prm[0], f2 = prm[1];
+    const double* k = prm + 4;
+    const double p0 = prm[10], p1 = prm[11], s0 = prm[12], s1 = prm[13], s2 = prm[14], s3 = prm[15];
+    const double a = uu, b = vv;
+    const double rr2 = a * a + b * b;
+    const double rr = sqrt(rr2);
+    double fu, fv, Jf0 = 1.0, Jf1 = 0.0, Jf2 = 0.0, Jf3 = 1.0;
+    if (rr < 2.220446049250313e-16) {
+      fu = a;
+      fv = b;
+    } else {
+      const double theta = atan(rr);
+      const double sc = theta / rr;
+      fu = sc * a;
+      fv = sc * b;
+      if (JAC) {
+        const double g = (rr / (1.0 + rr2) - theta) / (rr2 * rr);
+        Jf0 = sc + a * a * g; Jf1 = a * b * g; Jf2 = a * b * g; Jf3 = sc + b * b * g;
+      }
+    }
+    const double theta2 = fu * fu + fv * fv;
+    double th_radial = 1.0, d_th_radial = 0.0, theta_pow[6], power = 1.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const double prev = power;
+      power *= theta2;
+      theta_pow[i] = power;
+      th_radial += k[i] * power;
+      d_th_radial += (double)(i + 1) * k[i] * prev;
+    }
+    const double xr = th_radial * fu, yr = th_radial * fv;
+    const double xr2 = xr * xr, yr2 = yr * yr, xyr = xr * yr, r2 = xr2 + yr2, r4 = r2 * r2;
+    const double X = xr + 2.0 * p1 * xyr + p0 * (r2 + 2.0 * xr2) + s0 * r2 + s1 * r4;
+    const double Y = yr + 2.0 * p0 * xyr + p1 * (r2 + 2.0 * yr2) + s2 * r2 + s3 * r4;
+    x = f1 * X + prm[2];
+    y = f2 * Y + prm[3];
+    if (JAC) {
+      const double B00 = 1.0 + 2.0 * p1 * yr + 6.0 * p0 * xr + 2.0 * s0 * xr + 4.0 * s1 * xr * r2;
+      const double B01 = 2.0 * p1 * xr + 2.0 * p0 * yr + 2.0 * s0 * yr + 4.0 * s1 * yr * r2;
+      const double B10 = 2.0 * p0 * yr + 2.0 * p1 * xr + 2.0 * s2 * xr + 4.0 * s3 * xr * r2;
+      const double B11 = 1.0 + 2.0 * p0 * xr + 6.0 * p1 * yr + 2.0 * s2 * yr + 4.0 * s3 * yr * r2;
+      const double cross = 2.0 * fu * fv * d_th_radial;
+      const double A0 = th_radial + 2.0 * fu * fu * d_th_radial, A3 = th_radial + 2.0 * fv * fv * d_th_radial;
+      const double n0 = B00 * A0 + B01 * cross, n1 = B00 * cross + B01 * A3;
+      const double n2 = B10 * A0 + B11 * cross, n3 = B10 * cross + B11 * A3;
+      const double m0 = n0 * Jf0 + n1 * Jf2, m1 = n0 * Jf1 + n1 * Jf3;
+      const double m2 = n2 * Jf0 + n3 * Jf2, m3 = n2 * Jf1 + n3 * Jf3;
+      const double J0 = f1 * m0, J1 = f1 * m1, J2 = f2 * m2, J3 = f2 * m3;
+      Juvw[0] = J0 * inv_w; Juvw[1] = J1 * inv_w; Juvw[2] = -(J0 * a + J1 * b) * inv_w;
+      Juvw[3] = J2 * inv_w; Juvw[4] = J3 * inv_w; Juvw[5] = -(J2 * a + J3 * b) * inv_w;
+#pragma unroll
+      for (int c = 0; c < NP; ++c) Jpar[c] = Jpar[NP + c] = 0.0;
+      Jpar[0] = X; Jpar[2] = 1.0;
+      Jpar[NP + 1] = Y; Jpar[NP + 3] = 1.0;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const double dxr = fu * theta_pow[i], dyr = fv * theta_pow[i];
+        Jpar[4 + i] = f1 * (B00 * dxr + B01 * dyr);
+        Jpar[NP + 4 + i] = f2 * (B10 * dxr + B11 * dyr);
+      }
+      Jpar[10] = f1 * (r2 + 2.0 * xr2); Jpar[11] = f1 * 2.0 * xyr;
+      Jpar[NP + 10] = f2 * 2.0 * xyr; Jpar[NP + 11] = f2 * (r2 + 2.0 * yr2);
+      Jpar[12] = f1 * r2; Jpar[13] = f1 * r4;
+      Jpar[NP + 14] = f2 * r2; Jpar[NP + 15] = f2 * r4;
     }
     return true;
   }
@@ -1965,7 +2060,8 @@ struct Solver {
         throw std::runtime_error("unsupported camera model id " + std::to_string(model) +
                                  " (supported: SIMPLE_PINHOLE, PINHOLE, SIMPLE_RADIAL, RADIAL, OPENCV, "
                                  "OPENCV_FISHEYE, FOV, SIMPLE_RADIAL_FISHEYE, RADIAL_FISHEYE, SIMPLE_DIVISION, "
-                                 "DIVISION, SIMPLE_FISHEYE, FISHEYE, EUCM, FULL_OPENCV, THIN_PRISM_FISHEYE)");
+                                 "DIVISION, SIMPLE_FISHEYE, FISHEYE, EUCM, FULL_OPENCV, THIN_PRISM_FISHEYE, "
+                                 "RAD_TAN_THIN_PRISM_FISHEYE, EQUIRECTANGULAR)");
       const int P = num_params_of(model);
       for (int j = 0; j < P; ++j)
         if (!p.cam_const[(size_t)k * BA_CAM_STRIDE + j]) wide_cam_var[(size_t)k * KD_WIDE + cam_nvar[k]++] = j;

@@ -26,7 +26,7 @@ import numpy as np
 from . import scene
 from ._lib import lib
 
-CAM_STRIDE = 12
+CAM_STRIDE = 16
 
 
 class BundleAdjustmentGauge(enum.IntEnum):

@@ -25,21 +25,25 @@ import numpy as np
 SIMPLE_PINHOLE, PINHOLE, SIMPLE_RADIAL, RADIAL, OPENCV = 0, 1, 2, 3, 4
 OPENCV_FISHEYE, FULL_OPENCV, FOV, SIMPLE_RADIAL_FISHEYE, RADIAL_FISHEYE, THIN_PRISM_FISHEYE = 5, 6, 7, 8, 9, 10
 SIMPLE_DIVISION, DIVISION, SIMPLE_FISHEYE, FISHEYE, EUCM = 12, 13, 14, 15, 16
+RAD_TAN_THIN_PRISM_FISHEYE, EQUIRECTANGULAR = 11, 17
 MODEL_NAMES = {SIMPLE_PINHOLE: "SIMPLE_PINHOLE", PINHOLE: "PINHOLE", SIMPLE_RADIAL: "SIMPLE_RADIAL", RADIAL: "RADIAL",
                OPENCV: "OPENCV", OPENCV_FISHEYE: "OPENCV_FISHEYE", FOV: "FOV",
                SIMPLE_RADIAL_FISHEYE: "SIMPLE_RADIAL_FISHEYE", RADIAL_FISHEYE: "RADIAL_FISHEYE",
                SIMPLE_DIVISION: "SIMPLE_DIVISION", DIVISION: "DIVISION", SIMPLE_FISHEYE: "SIMPLE_FISHEYE",
                FISHEYE: "FISHEYE", EUCM: "EUCM", FULL_OPENCV: "FULL_OPENCV",
-               THIN_PRISM_FISHEYE: "THIN_PRISM_FISHEYE"}
+               THIN_PRISM_FISHEYE: "THIN_PRISM_FISHEYE", RAD_TAN_THIN_PRISM_FISHEYE: "RAD_TAN_THIN_PRISM_FISHEYE",
+               EQUIRECTANGULAR: "EQUIRECTANGULAR"}
 MODEL_NUM_PARAMS = {SIMPLE_PINHOLE: 3, PINHOLE: 4, SIMPLE_RADIAL: 4, RADIAL: 5, OPENCV: 8,
                     OPENCV_FISHEYE: 8, FOV: 5, SIMPLE_RADIAL_FISHEYE: 4, RADIAL_FISHEYE: 5,
                     SIMPLE_DIVISION: 4, DIVISION: 5, SIMPLE_FISHEYE: 3, FISHEYE: 4, EUCM: 6,
-                    FULL_OPENCV: 12, THIN_PRISM_FISHEYE: 12}
+                    FULL_OPENCV: 12, THIN_PRISM_FISHEYE: 12, RAD_TAN_THIN_PRISM_FISHEYE: 16, EQUIRECTANGULAR: 2}
 # FocalLengthIdxs / PrincipalPointIdxs / ExtraParamsIdxs (sensor/models.h)
 _ONE_F = (SIMPLE_PINHOLE, SIMPLE_RADIAL, RADIAL, SIMPLE_RADIAL_FISHEYE, RADIAL_FISHEYE, SIMPLE_DIVISION, SIMPLE_FISHEYE)
 MODEL_FOCAL_IDXS = {m: ([0] if m in _ONE_F else [0, 1]) for m in MODEL_NUM_PARAMS}
 MODEL_PP_IDXS = {m: ([1, 2] if m in _ONE_F else [2, 3]) for m in MODEL_NUM_PARAMS}
 MODEL_EXTRA_IDXS = {m: list(range(3 if m in _ONE_F else 4, n)) for m, n in MODEL_NUM_PARAMS.items()}
+# EQUIRECTANGULAR: (width, height) are metadata parameters, never refined (MetaDataParamsIdxs, models.h:2839-2842)
+MODEL_FOCAL_IDXS[EQUIRECTANGULAR] = MODEL_PP_IDXS[EQUIRECTANGULAR] = MODEL_EXTRA_IDXS[EQUIRECTANGULAR] = []
 
 
 @dataclass
@@ -273,6 +277,10 @@ def img_from_cam(model_id: int, params: np.ndarray, uvw: np.ndarray) -> np.ndarr
         u, v, w = uvw[:, 0], uvw[:, 1], uvw[:, 2]
         r = 2.0 / (w + np.sqrt(w * w - 4.0 * (u * u + v * v) * params[ic + 2]))
         return np.stack([f1 * r * u + params[ic], f2 * r * v + params[ic + 1]], 1)
+    if model_id == EQUIRECTANGULAR:  # azimuth over the width, elevation over the height
+        u, v, w = uvw[:, 0], uvw[:, 1], uvw[:, 2]
+        theta, phi = np.arctan2(u, w), np.arctan2(-v, np.sqrt(u * u + w * w))
+        return np.stack([(theta / (2 * np.pi) + 0.5) * params[0], (0.5 - phi / np.pi) * params[1]], 1)
     if model_id == EUCM:
         f1, f2, c1, c2, alpha, beta = params
         u, v, w = uvw[:, 0], uvw[:, 1], uvw[:, 2]
@@ -317,6 +325,20 @@ def img_from_cam(model_id: int, params: np.ndarray, uvw: np.ndarray) -> np.ndarr
             ks = params[3:]
         radial = sum(k * t2 ** (i + 1) for i, k in enumerate(ks))
         return np.stack([f1 * (fu + fu * radial) + c1, f2 * (fv + fv * radial) + c2], 1)
+    if model_id == RAD_TAN_THIN_PRISM_FISHEYE:  # RadTanThinPrismFisheyeModel: radial on theta, then tangential + thin prism
+        f1, f2, c1, c2 = params[:4]
+        ks, (p0, p1), (s0, s1, s2, s3) = params[4:10], params[10:12], params[12:16]
+        r = np.sqrt(uu * uu + vv * vv)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            sc = np.where(r < np.finfo(np.float64).eps, 1.0, np.arctan(r) / r)
+        fu, fv = sc * uu, sc * vv
+        t2 = fu * fu + fv * fv
+        th = 1.0 + sum(k * t2 ** (i + 1) for i, k in enumerate(ks))
+        xr, yr = th * fu, th * fv
+        r2 = xr * xr + yr * yr
+        X = xr + 2 * p1 * xr * yr + p0 * (r2 + 2 * xr * xr) + s0 * r2 + s1 * r2 * r2
+        Y = yr + 2 * p0 * xr * yr + p1 * (r2 + 2 * yr * yr) + s2 * r2 + s3 * r2 * r2
+        return np.stack([f1 * X + c1, f2 * Y + c2], 1)
     if model_id == FULL_OPENCV:  # FullOpenCVCameraModel::Distortion: rational radial term + tangential
         f1, f2, c1, c2, k1, k2, p1, p2, k3, k4, k5, k6 = params
         r2 = uu * uu + vv * vv
@@ -510,7 +532,7 @@ def synthesize_flat(num_frames: int, num_points: int, track_length: int, seed: i
         Rs[i] = quat_to_rot(q)
         poses[i, :4] = q
         poses[i, 4:] = Rs[i] @ (5.0 * view[i])
-    cams = np.zeros((num_frames, 12))
+    cams = np.zeros((num_frames, 16))  # BA_CAM_STRIDE
     model = np.full(num_frames, SIMPLE_RADIAL, np.int32)
     cams[:, :4] = [1280.0, 512.0, 384.0, 0.05]
     if mixed_models:

@@ -39,6 +39,7 @@ CAMERA_MODELS = {
     14: ("SIMPLE_FISHEYE", 3, 0, 0, 1, 2),
     15: ("FISHEYE", 4, 0, 1, 2, 3),
     16: ("EUCM", 6, 0, 1, 2, 3),
+    17: ("EQUIRECTANGULAR", 2, None, None, None, None),  # width, height: no focal length / principal point
 }
 CAMERA_MODEL_IDS = {v[0]: k for k, v in CAMERA_MODELS.items()}
 INVALID_POINT3D = 0xFFFFFFFFFFFFFFFF  # kInvalidPoint3DId (util/types.h)
@@ -55,6 +56,8 @@ class SparseCamera:
     def CalibrationMatrix(self) -> np.ndarray:
         """Camera::CalibrationMatrix (scene/camera.cc:63-72)."""
         _, _, ifx, ify, icx, icy = CAMERA_MODELS[self.model_id]
+        if ifx is None:
+            raise ValueError(f"{CAMERA_MODELS[self.model_id][0]} cameras have no calibration matrix")
         K = np.eye(3)
         K[0, 0], K[1, 1], K[0, 2], K[1, 2] = self.params[ifx], self.params[ify], self.params[icx], self.params[icy]
         return K

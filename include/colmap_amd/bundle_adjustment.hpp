@@ -87,7 +87,8 @@ inline Rigid3d Compose(const Rigid3d& a, const Rigid3d& b) {
 enum class CameraModelId : int {
   SIMPLE_PINHOLE = 0, PINHOLE = 1, SIMPLE_RADIAL = 2, RADIAL = 3, OPENCV = 4,
   OPENCV_FISHEYE = 5, FULL_OPENCV = 6, FOV = 7, SIMPLE_RADIAL_FISHEYE = 8, RADIAL_FISHEYE = 9,
-  THIN_PRISM_FISHEYE = 10, SIMPLE_DIVISION = 12, DIVISION = 13, SIMPLE_FISHEYE = 14, FISHEYE = 15, EUCM = 16
+  THIN_PRISM_FISHEYE = 10, RAD_TAN_THIN_PRISM_FISHEYE = 11, SIMPLE_DIVISION = 12, DIVISION = 13, SIMPLE_FISHEYE = 14, FISHEYE = 15, EUCM = 16,
+  EQUIRECTANGULAR = 17
 };
 
 struct CameraModelInfo {
@@ -99,7 +100,8 @@ inline const CameraModelInfo* GetCameraModelInfo(int model_id) {
   static const CameraModelInfo kSimplePinhole{3, {0}, {1, 2}, {}}, kPinhole{4, {0, 1}, {2, 3}, {}},
       kSimpleRadial{4, {0}, {1, 2}, {3}}, kRadial{5, {0}, {1, 2}, {3, 4}}, kOpenCV{8, {0, 1}, {2, 3}, {4, 5, 6, 7}},
       kTwoFocalOneExtra{5, {0, 1}, {2, 3}, {4}}, kEucm{6, {0, 1}, {2, 3}, {4, 5}},
-      kTwelve{12, {0, 1}, {2, 3}, {4, 5, 6, 7, 8, 9, 10, 11}};
+      kTwelve{12, {0, 1}, {2, 3}, {4, 5, 6, 7, 8, 9, 10, 11}},
+      kSixteen{16, {0, 1}, {2, 3}, {4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}}, kEquirectangular{2, {}, {}, {}};
   switch (model_id) {
     case 0: case 14: return &kSimplePinhole;  // SIMPLE_PINHOLE, SIMPLE_FISHEYE: f cx cy
     case 1: case 15: return &kPinhole;        // PINHOLE, FISHEYE: fx fy cx cy
@@ -108,6 +110,8 @@ inline const CameraModelInfo* GetCameraModelInfo(int model_id) {
     case 4: case 5: return &kOpenCV;         // OPENCV, OPENCV_FISHEYE: fx fy cx cy + four extra
     case 7: case 13: return &kTwoFocalOneExtra;  // FOV (omega), DIVISION (k): fx fy cx cy + one extra
     case 16: return &kEucm;                  // EUCM: fx fy cx cy alpha beta
+    case 11: return &kSixteen;               // RAD_TAN_THIN_PRISM_FISHEYE: k0..k5 p0 p1 s0..s3
+    case 17: return &kEquirectangular;       // EQUIRECTANGULAR: width height, metadata only (never refined)
     case 6: case 10: return &kTwelve;        // FULL_OPENCV (k1 k2 p1 p2 k3 k4 k5 k6), THIN_PRISM_FISHEYE (k1 k2 p1 p2 k3 k4 sx1 sy1)
     default: return nullptr;
   }

@@ -25,13 +25,14 @@
 extern "C" {
 #endif
 
-#define BA_CAM_STRIDE 12 /* doubles reserved per camera parameter block */
+#define BA_CAM_STRIDE 16 /* doubles reserved per camera parameter block (RAD_TAN_THIN_PRISM_FISHEYE has 16) */
 
 /* colmap::CameraModelId values of the supported models (sensor/models.h:90-111) */
 enum {
   BA_SIMPLE_PINHOLE = 0, BA_PINHOLE = 1, BA_SIMPLE_RADIAL = 2, BA_RADIAL = 3, BA_OPENCV = 4,
   BA_OPENCV_FISHEYE = 5, BA_FULL_OPENCV = 6, BA_FOV = 7, BA_SIMPLE_RADIAL_FISHEYE = 8, BA_RADIAL_FISHEYE = 9,
-  BA_THIN_PRISM_FISHEYE = 10, BA_SIMPLE_DIVISION = 12, BA_DIVISION = 13, BA_SIMPLE_FISHEYE = 14, BA_FISHEYE = 15, BA_EUCM = 16
+  BA_THIN_PRISM_FISHEYE = 10, BA_RAD_TAN_THIN_PRISM_FISHEYE = 11, BA_SIMPLE_DIVISION = 12, BA_DIVISION = 13, BA_SIMPLE_FISHEYE = 14, BA_FISHEYE = 15, BA_EUCM = 16,
+  BA_EQUIRECTANGULAR = 17
 };
 
 #define BA_POSE_ROT_CONST 4

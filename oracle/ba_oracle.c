@@ -38,13 +38,14 @@
 #endif
 
 #define BAO_API __attribute__((visibility("default")))
-#define BAO_CAM_STRIDE 12
+#define BAO_CAM_STRIDE 16
 
 /* COLMAP CameraModelId values (sensor/models.h:90-111) */
 enum {
   BAO_SIMPLE_PINHOLE = 0, BAO_PINHOLE = 1, BAO_SIMPLE_RADIAL = 2, BAO_RADIAL = 3, BAO_OPENCV = 4,
   BAO_OPENCV_FISHEYE = 5, BAO_FULL_OPENCV = 6, BAO_FOV = 7, BAO_SIMPLE_RADIAL_FISHEYE = 8, BAO_RADIAL_FISHEYE = 9,
-  BAO_THIN_PRISM_FISHEYE = 10, BAO_SIMPLE_DIVISION = 12, BAO_DIVISION = 13, BAO_SIMPLE_FISHEYE = 14, BAO_FISHEYE = 15, BAO_EUCM = 16
+  BAO_THIN_PRISM_FISHEYE = 10, BAO_RAD_TAN_THIN_PRISM_FISHEYE = 11, BAO_SIMPLE_DIVISION = 12, BAO_DIVISION = 13, BAO_SIMPLE_FISHEYE = 14, BAO_FISHEYE = 15, BAO_EUCM = 16,
+  BAO_EQUIRECTANGULAR = 17
 };
 
 typedef struct {
@@ -198,6 +199,8 @@ static int num_params_of(int model) {
     case BAO_EUCM: return 6;
     case BAO_FULL_OPENCV: return 12;
     case BAO_THIN_PRISM_FISHEYE: return 12;
+    case BAO_RAD_TAN_THIN_PRISM_FISHEYE: return 16;
+    case BAO_EQUIRECTANGULAR: return 2;
     default: return -1;
   }
 }
@@ -271,6 +274,29 @@ static void radial_fisheye_with_jac(double f1, double f2, double c1, double c2, 
 /* ImgFromCamWithJac, sensor/models_jacobian.h:139-321. J_params row-major 2 x P. */
 static int img_from_cam_jac(int model, const double* params, double u, double v, double w,
                             double* x, double* y, double* J_params, double* J_uvw) {
+  if (model == BAO_EQUIRECTANGULAR) { /* models_jacobian.h:1502-1565: no cheirality test, (w, h) are metadata */
+    const double width = params[0], height = params[1];
+    const double horizontal = sqrt(u * u + w * w);
+    if (horizontal + fabs(v) < 2.220446049250313e-16) return 0;
+    const double theta = atan2(u, w);
+    const double phi = atan2(-v, horizontal);
+    const double kInv2Pi = 1.0 / (2.0 * M_PI), kInvPi = 1.0 / M_PI;
+    *x = (theta * kInv2Pi + 0.5) * width;
+    *y = (0.5 - phi * kInvPi) * height;
+    if (J_uvw) {
+      const double R2 = horizontal * horizontal;
+      const double N2 = R2 + v * v;
+      const double dtheta_du = w / R2, dtheta_dw = -u / R2;
+      const double dphi_du = u * v / (N2 * horizontal), dphi_dv = -horizontal / N2, dphi_dw = v * w / (N2 * horizontal);
+      J_uvw[0] = width * kInv2Pi * dtheta_du; J_uvw[1] = 0.0; J_uvw[2] = width * kInv2Pi * dtheta_dw;
+      J_uvw[3] = -height * kInvPi * dphi_du; J_uvw[4] = -height * kInvPi * dphi_dv; J_uvw[5] = -height * kInvPi * dphi_dw;
+    }
+    if (J_params) {
+      J_params[0] = theta * kInv2Pi + 0.5; J_params[1] = 0.0;
+      J_params[2] = 0.0; J_params[3] = 0.5 - phi * kInvPi;
+    }
+    return 1;
+  }
   if (model == BAO_SIMPLE_DIVISION || model == BAO_DIVISION) {
     /* models_jacobian.h:1291-1411 + internal::DivisionScaleWithJac :88-113 (no cheirality test) */
     const int two = model == BAO_DIVISION;
@@ -474,6 +500,63 @@ static int img_from_cam_jac(int model, const double* params, double u, double v,
         r0[9 + i] = f1 * uu * (neg_num_inv_den2 * rp[i]);
         r1[9 + i] = f2 * vv * (neg_num_inv_den2 * rp[i]);
       }
+    }
+    return 1;
+  }
+  if (model == BAO_RAD_TAN_THIN_PRISM_FISHEYE) { /* models_jacobian.h:1049-1188 */
+    const double f1 = params[0], f2 = params[1], c1 = params[2], c2 = params[3];
+    const double* k = params + 4; /* k0..k5 */
+    const double p0 = params[10], p1 = params[11], s0 = params[12], s1 = params[13], s2 = params[14], s3 = params[15];
+    const double a = uu, b = vv;
+    double fu, fv, Jf[4] = {0, 0, 0, 0};
+    fisheye_projection_with_jac(a, b, &fu, &fv, J_uvw ? Jf : NULL);
+    const double theta2 = fu * fu + fv * fv;
+    double th_radial = 1.0, d_th_radial = 0.0, theta_pow[6], power = 1.0;
+    for (int i = 0; i < 6; ++i) {
+      const double prev_power = power;
+      power *= theta2;
+      theta_pow[i] = power;
+      th_radial += k[i] * power;
+      d_th_radial += (double)(i + 1) * k[i] * prev_power;
+    }
+    const double xr = th_radial * fu, yr = th_radial * fv;
+    const double xr2 = xr * xr, yr2 = yr * yr, xyr = xr * yr;
+    const double r2 = xr2 + yr2, r4 = r2 * r2;
+    const double dx_tang = 2.0 * p1 * xyr + p0 * (r2 + 2.0 * xr2);
+    const double dy_tang = 2.0 * p0 * xyr + p1 * (r2 + 2.0 * yr2);
+    const double X = xr + dx_tang + (s0 * r2 + s1 * r4);
+    const double Y = yr + dy_tang + (s2 * r2 + s3 * r4);
+    *x = f1 * X + c1;
+    *y = f2 * Y + c2;
+    const double B[4] = {1.0 + 2.0 * p1 * yr + 6.0 * p0 * xr + 2.0 * s0 * xr + 4.0 * s1 * xr * r2,
+                         2.0 * p1 * xr + 2.0 * p0 * yr + 2.0 * s0 * yr + 4.0 * s1 * yr * r2,
+                         2.0 * p0 * yr + 2.0 * p1 * xr + 2.0 * s2 * xr + 4.0 * s3 * xr * r2,
+                         1.0 + 2.0 * p0 * xr + 6.0 * p1 * yr + 2.0 * s2 * yr + 4.0 * s3 * yr * r2};
+    if (J_uvw) {
+      const double cross = 2.0 * fu * fv * d_th_radial;
+      const double A[4] = {th_radial + 2.0 * fu * fu * d_th_radial, cross, cross, th_radial + 2.0 * fv * fv * d_th_radial};
+      const double m2[4] = {B[0] * A[0] + B[1] * A[2], B[0] * A[1] + B[1] * A[3], B[2] * A[0] + B[3] * A[2], B[2] * A[1] + B[3] * A[3]};
+      const double m[4] = {m2[0] * Jf[0] + m2[1] * Jf[2], m2[0] * Jf[1] + m2[1] * Jf[3],
+                           m2[2] * Jf[0] + m2[3] * Jf[2], m2[2] * Jf[1] + m2[3] * Jf[3]};
+      const double Jab[4] = {f1 * m[0], f1 * m[1], f2 * m[2], f2 * m[3]};
+      J_uvw[0] = Jab[0] * inv_w; J_uvw[1] = Jab[1] * inv_w; J_uvw[2] = -(Jab[0] * a + Jab[1] * b) * inv_w;
+      J_uvw[3] = Jab[2] * inv_w; J_uvw[4] = Jab[3] * inv_w; J_uvw[5] = -(Jab[2] * a + Jab[3] * b) * inv_w;
+    }
+    if (J_params) {
+      double* r0 = J_params;
+      double* r1 = J_params + 16;
+      for (int c = 0; c < 32; ++c) J_params[c] = 0.0;
+      r0[0] = X; r0[2] = 1.0;
+      r1[1] = Y; r1[3] = 1.0;
+      for (int i = 0; i < 6; ++i) {
+        const double dxr = fu * theta_pow[i], dyr = fv * theta_pow[i];
+        r0[4 + i] = f1 * (B[0] * dxr + B[1] * dyr);
+        r1[4 + i] = f2 * (B[2] * dxr + B[3] * dyr);
+      }
+      r0[10] = f1 * (r2 + 2.0 * xr2); r0[11] = f1 * 2.0 * xyr;
+      r1[10] = f2 * 2.0 * xyr; r1[11] = f2 * (r2 + 2.0 * yr2);
+      r0[12] = f1 * r2; r0[13] = f1 * r4;
+      r1[14] = f2 * r2; r1[15] = f2 * r4;
     }
     return 1;
   }
@@ -858,7 +941,7 @@ BAO_API void bao_position_prior(const double* pos, const double* pose, const dou
 /* Program: tangent-space layout of the variable blocks                        */
 /* ------------------------------------------------------------------------- */
 
-#define MAX_CB 24 /* max tangent width of the camera-side blocks seen by one residual: 6 + P_t (P_t <= 12) + 6 */
+#define MAX_CB 28 /* max tangent width of the camera-side blocks seen by one residual: 6 + P_t (P_t <= 16) + 6 */
 
 typedef struct {
   const bao_problem* p;
@@ -1037,7 +1120,7 @@ static void linearize_obs(const program* g, const double* poses, const double* c
   const int64_t o = g->obs[a];
   const int pi = p->obs_pose[o], ci = p->obs_cam[o], xi = p->obs_point[o];
   const int model = p->cam_model[ci];
-  double Jpt[6], Jpose[14], Jpar[24], Jsens[14];
+  double Jpt[6], Jpose[14], Jpar[32], Jsens[14];
   const int si = p->obs_sensor ? p->obs_sensor[o] : -1;
   L->so = si >= 0 ? g->sens_off[si] : -1;
   L->sens_dim = L->so >= 0 ? 6 : 0;

@@ -41,7 +41,7 @@ def solve_fn(p, o, r):
 def reproj_error(model, point, pose, params, xy, want_jac=True):
     point = np.ascontiguousarray(point, np.float64)
     pose = np.ascontiguousarray(pose, np.float64)
-    prm = np.zeros(12)
+    prm = np.zeros(16)
     prm[: len(params)] = params
     xy = np.ascontiguousarray(xy, np.float64)
     P = NUM_PARAMS[model]
@@ -54,7 +54,7 @@ def reproj_error(model, point, pose, params, xy, want_jac=True):
     return r, Jpt, Jpose, Jpar
 
 
-NUM_PARAMS = {0: 3, 1: 4, 2: 4, 3: 5, 4: 8, 5: 8, 6: 12, 10: 12, 7: 5, 8: 4, 9: 5, 12: 4, 13: 5, 14: 3, 15: 4, 16: 6}
+NUM_PARAMS = {0: 3, 1: 4, 2: 4, 3: 5, 4: 8, 5: 8, 6: 12, 10: 12, 11: 16, 17: 2, 7: 5, 8: 4, 9: 5, 12: 4, 13: 5, 14: 3, 15: 4, 16: 6}
 
 
 def rig_reproj_error(model, point, rig_from_world, sensor_from_rig, params, xy, want_jac=True):
@@ -63,7 +63,7 @@ def rig_reproj_error(model, point, rig_from_world, sensor_from_rig, params, xy, 
     point = np.ascontiguousarray(point, np.float64)
     pose = np.ascontiguousarray(rig_from_world, np.float64)
     sens = np.ascontiguousarray(sensor_from_rig, np.float64)
-    prm = np.zeros(12)
+    prm = np.zeros(16)
     prm[: len(params)] = params
     xy = np.ascontiguousarray(xy, np.float64)
     P = NUM_PARAMS[model]
@@ -81,7 +81,7 @@ def rig_reproj_error_sensor(model, point, rig_from_world, sensor_from_rig, param
     point = np.ascontiguousarray(point, np.float64)
     pose = np.ascontiguousarray(rig_from_world, np.float64)
     sens = np.ascontiguousarray(sensor_from_rig, np.float64)
-    prm = np.zeros(12)
+    prm = np.zeros(16)
     prm[: len(params)] = params
     xy = np.ascontiguousarray(xy, np.float64)
     P = NUM_PARAMS[model]

@@ -612,6 +612,9 @@ _REF_MODEL_PARAMS = [
     # the parameter vectors of the reference's own model tests (sensor/models_test.cc:318-369)
     (scene.FULL_OPENCV, [651.123, 655.123, 386.123, 511.123, -0.471, 0.223, -0.001, 0.001, 0.001, 0.02, -0.02, 0.001]),
     (scene.THIN_PRISM_FISHEYE, [651.123, 655.123, 386.123, 511.123, -0.471, 0.223, -0.001, 0.001, 0.001, 0.02, -0.02, 0.001]),
+    (scene.RAD_TAN_THIN_PRISM_FISHEYE, [651.123, 655.123, 386.123, 511.123, -0.0232, 0.0924, -0.0591, 0.003, 0.0048, -0.0009,
+                                        0.0002, 0.0005, -0.0009, -0.0001, 0.00007, -0.00017]),   # models_test.cc:371-390
+    (scene.EQUIRECTANGULAR, [1000.0, 500.0]),
 ]
 
 
@@ -619,7 +622,7 @@ _REF_MODEL_PARAMS = [
 def test_more_camera_models_values_and_jacobians(model, params):
     """FOV (models_jacobian.h:627-724, all three branches of the distortion), SIMPLE_DIVISION / DIVISION
     (:88-113, 1291-1411), SIMPLE_FISHEYE / FISHEYE (:1190-1288), EUCM (:1413-1500), FULL_OPENCV (:498-625),
-    THIN_PRISM_FISHEYE (:944-1047)."""
+    THIN_PRISM_FISHEYE (:944-1047), RAD_TAN_THIN_PRISM_FISHEYE (:1049-1188), EQUIRECTANGULAR (:1502-1565)."""
     pose = np.array([0, 0, 0, 1, 0, 0, 0.0])
     params = np.array(params, np.float64)
     grid = [np.array([u, v, w]) for u in np.arange(-0.5, 0.51, 0.1) for v in np.arange(-0.5, 0.51, 0.1)
@@ -650,7 +653,8 @@ def test_more_camera_models_values_and_jacobians(model, params):
         np.testing.assert_allclose(Jpar, J[:, 3:], rtol=5e-5, atol=2e-4)
     # the parameter layout the adapters use (FocalLengthIdxs / PrincipalPointIdxs / ExtraParamsIdxs)
     n = scene.MODEL_NUM_PARAMS[model]
-    assert sorted(scene.MODEL_FOCAL_IDXS[model] + scene.MODEL_PP_IDXS[model] + scene.MODEL_EXTRA_IDXS[model]) == list(range(n))
+    refinable = [] if model == scene.EQUIRECTANGULAR else list(range(n))  # (width, height) are metadata, never refined
+    assert sorted(scene.MODEL_FOCAL_IDXS[model] + scene.MODEL_PP_IDXS[model] + scene.MODEL_EXTRA_IDXS[model]) == refinable
 
 
 def test_division_and_eucm_reject_points_outside_their_domain():

@@ -27,6 +27,10 @@ def test_ba_oracle_reproduces_golden():
     fp = est.FlatProblem(**{k: g[f"in_{k}"].copy() for k in ("poses", "cams", "cam_model", "points", "obs_pose", "obs_cam",
                                                            "obs_point", "obs_xy", "pose_const", "pose_fixed_t",
                                                            "cam_const", "point_const")})
+    # the fixture was written with 12 doubles per camera block; BA_CAM_STRIDE is 16 now (unused tail: zero / constant)
+    pad = est.CAM_STRIDE - fp.cams.shape[1]
+    fp.cams = np.ascontiguousarray(np.pad(fp.cams, ((0, 0), (0, pad))))
+    fp.cam_const = np.ascontiguousarray(np.pad(fp.cam_const, ((0, 0), (0, pad)), constant_values=1))
     s = est.solve_flat(fp, est.SolverOptions(gradient_tolerance=1e-10, max_num_iterations=200), solve_fn=ba_oracle.solve_fn)
     assert [s.num_residuals, s.num_effective_parameters] == list(g["counts"])
     assert s.initial_cost == g["costs"][0]
