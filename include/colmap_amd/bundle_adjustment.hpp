@@ -69,6 +69,27 @@ inline void QuatToRot(const double* q, double R[9]) {
 }
 
 // a * b: apply b, then a (Rigid3d operator*, geometry/rigid3.h)
+// rotation matrix -> unit quaternion (xyzw)
+inline void RotToQuat(const double R[9], double* q) {
+  const double tr = R[0] + R[4] + R[8];
+  if (tr > 0) {
+    const double s = std::sqrt(tr + 1.0) * 2;
+    q[0] = (R[7] - R[5]) / s; q[1] = (R[2] - R[6]) / s; q[2] = (R[3] - R[1]) / s; q[3] = 0.25 * s;
+  } else {
+    int i = 0;
+    if (R[4] > R[0]) i = 1;
+    if (R[8] > R[4 * i]) i = 2;
+    const int j = (i + 1) % 3, k = (i + 2) % 3;
+    const double s = std::sqrt(1.0 + R[4 * i] - R[4 * j] - R[4 * k]) * 2;
+    q[i] = 0.25 * s;
+    q[j] = (R[3 * j + i] + R[3 * i + j]) / s;
+    q[k] = (R[3 * k + i] + R[3 * i + k]) / s;
+    q[3] = (R[3 * k + j] - R[3 * j + k]) / s;
+  }
+  const double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  for (int c = 0; c < 4; ++c) q[c] /= n;
+}
+
 inline Rigid3d Compose(const Rigid3d& a, const Rigid3d& b) {
   const double *qa = a.params.data(), *qb = b.params.data();
   Rigid3d out;
@@ -191,6 +212,63 @@ class Reconstruction {  // scene/reconstruction.h
   }
   const Rigid3d& SensorFromRig(const ::colmap_amd::Image& image) const {
     return rigs.at(frames.at(*image.frame_id).rig_id).sensors_from_rig.at(image.camera_id);
+  }
+  // Image::ProjectionCenter: -R^T t
+  std::array<double, 3> ProjectionCenter(image_t id) const {
+    const Rigid3d& p = images.at(id).cam_from_world;
+    double R[9];
+    QuatToRot(p.params.data(), R);
+    std::array<double, 3> c{};
+    for (int i = 0; i < 3; ++i) c[i] = -(R[i] * p.params[4] + R[3 + i] * p.params[5] + R[6 + i] * p.params[6]);
+    return c;
+  }
+  // Reconstruction::Transform(new_from_old_world = Sim3d(scale, R, t)) (scene/reconstruction.cc:788-805)
+  void Transform(double scale, const double R[9], const double t[3]) {
+    auto cam = [&](Rigid3d& pose) {  // TransformCameraWorld: R' = R_c R^T, t' = s t_c - R' t
+      double Rc[9], Rn[9];
+      QuatToRot(pose.params.data(), Rc);
+      for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) Rn[3 * i + j] = Rc[3 * i] * R[3 * j] + Rc[3 * i + 1] * R[3 * j + 1] + Rc[3 * i + 2] * R[3 * j + 2];
+      RotToQuat(Rn, pose.params.data());
+      for (int i = 0; i < 3; ++i)
+        pose.params[4 + i] = scale * pose.params[4 + i] - (Rn[3 * i] * t[0] + Rn[3 * i + 1] * t[1] + Rn[3 * i + 2] * t[2]);
+    };
+    for (auto& [rid, rig] : rigs)
+      for (auto& [cid, sfr] : rig.sensors_from_rig)
+        if (!rig.IsRefSensor(cid))
+          for (int i = 0; i < 3; ++i) sfr.params[4 + i] *= scale;
+    for (auto& [fid, frame] : frames) cam(frame.rig_from_world);
+    for (auto& [iid, image] : images)
+      if (!image.frame_id) cam(image.cam_from_world);
+    UpdateCamFromWorld();
+    for (auto& [pid, pt] : points3D) {
+      const std::array<double, 3> x = pt.xyz;
+      for (int i = 0; i < 3; ++i) pt.xyz[i] = scale * (R[3 * i] * x[0] + R[3 * i + 1] * x[1] + R[3 * i + 2] * x[2]) + t[i];
+    }
+  }
+  // Reconstruction::Normalize(fixed_scale = true) (:698-727): translation by minus the centroid of the
+  // projection centres inside the [0.1, 0.9] percentile range (geometry/normalization.cc:39-92).
+  // Returns the translation of normalized_from_metric.
+  std::array<double, 3> NormalizeFixedScale() {
+    std::array<double, 3> t{0, 0, 0};
+    if (images.size() < 2) return t;
+    std::vector<double> coords[3];
+    for (const auto& kv : images) {
+      const auto c = ProjectionCenter(kv.first);
+      for (int k = 0; k < 3; ++k) coords[k].push_back(c[k]);
+    }
+    const size_t end = coords[0].size() - 1;
+    const size_t lo = std::min<size_t>(end, static_cast<size_t>(std::floor(0.1 * end)));
+    const size_t hi = std::min<size_t>(end, static_cast<size_t>(std::ceil(0.9 * end)));
+    for (int k = 0; k < 3; ++k) {
+      std::sort(coords[k].begin(), coords[k].end());
+      double sum = 0;
+      for (size_t i = lo; i <= hi; ++i) sum += coords[k][i];
+      t[k] = -sum / static_cast<double>(hi - lo + 1);
+    }
+    const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    Transform(1.0, I, t.data());
+    return t;
   }
   // Image::CamFromWorld of the images of non-trivial frames
   void UpdateCamFromWorld() {
@@ -416,6 +494,15 @@ class Mi355xBundleAdjuster : public BundleAdjuster {
     p.obs_sensor = sensors_.empty() ? nullptr : obs_sensor_.data();
     const bool any_variable_sensor = std::count(sensor_const_.begin(), sensor_const_.end(), 0) > 0;
     p.sensor_const = any_variable_sensor ? sensor_const_.data() : nullptr;
+    p.num_priors = static_cast<int32_t>(prior_pose_.size());
+    if (p.num_priors > 0) {
+      p.prior_pose = prior_pose_.data();
+      p.prior_sensor = prior_sensor_.data();
+      p.prior_position = prior_position_.data();
+      p.prior_sqrt_info = prior_sqrt_info_.data();
+      p.prior_loss_type = prior_loss_type_;
+      p.prior_loss_scale = prior_loss_scale_;
+    }
     return p;
   }
   // Residuals touching >= 1 variable block / variable tangent dimensions, computed on the host
@@ -555,6 +642,7 @@ class Mi355xBundleAdjuster : public BundleAdjuster {
         AddObservation(blocks.first, CamSlot(image.camera_id), PointSlot(p2.point3D_id), p2, blocks.second);
       }
       if (num_observations > 0) {
+        image_slots_[image_id] = blocks;
         parameterized_cams.insert(image.camera_id);
         // gauge candidates: reference sensors and constant sensor_from_rig only (IsParameterizedConstSensor, :347-385)
         if (blocks.second < 0 || sensor_const_[blocks.second]) {
@@ -763,7 +851,233 @@ class Mi355xBundleAdjuster : public BundleAdjuster {
   std::vector<camera_t> sensor_ids_;
   std::vector<rig_t> sensor_rig_;
   std::vector<int8_t> pose_fixed_t_;
+
+ protected:
+  std::map<image_t, std::pair<int, int>> image_slots_;  // parameterized image -> (pose slot, sensor slot or -1)
+  // position priors of the flattened problem (filled by PosePriorBundleAdjuster)
+  std::vector<int32_t> prior_pose_, prior_sensor_;
+  std::vector<double> prior_position_, prior_sqrt_info_;
+  int32_t prior_loss_type_ = BA_LOSS_TRIVIAL;
+  double prior_loss_scale_ = 1.0;
+  uint8_t PoseConst(int slot) const { return pose_const_[slot]; }
+  uint8_t SensorConst(int slot) const { return sensor_const_[slot]; }
+  Reconstruction& Rec() { return reconstruction_; }
 };
+
+// ---------------------------------------------------------------------------------------------
+// Pose-prior bundle adjustment (bundle_adjustment.h:236-270, bundle_adjustment_ceres.cc:900-1085)
+// ---------------------------------------------------------------------------------------------
+struct PosePrior {  // geometry/pose_prior.h:43-77, the fields the adjuster reads
+  image_t image_id = 0;  // corr_data_id of a camera sensor
+  std::array<double, 3> position{{std::nan(""), std::nan(""), std::nan("")}};
+  std::array<double, 9> position_covariance{{std::nan(""), std::nan(""), std::nan(""), std::nan(""), std::nan(""),
+                                             std::nan(""), std::nan(""), std::nan(""), std::nan("")}};
+  bool HasPosition() const { return std::isfinite(position[0]) && std::isfinite(position[1]) && std::isfinite(position[2]); }
+  bool HasPositionCov() const {
+    for (const double v : position_covariance)
+      if (!std::isfinite(v)) return false;
+    return true;
+  }
+};
+
+struct PosePriorBundleAdjustmentOptions {  // bundle_adjustment.h:252-262 + bundle_adjustment_ceres.h:102-112
+  double prior_position_fallback_stddev = 1.0;
+  int prior_position_loss_function_type = BA_LOSS_TRIVIAL;
+  double prior_position_loss_scale = 2.7955321496988725;  // sqrt(kChiSquare95ThreeDof = 7.815)
+  bool Check() const { return prior_position_fallback_stddev > 0 && prior_position_loss_scale > 0; }
+};
+
+// Least-squares similarity dst ~ scale R src + t over all correspondences (Horn's closed form: the
+// rotation is the dominant eigenvector of a symmetric 4 x 4 matrix, found by Jacobi sweeps). The
+// reference estimates the same transform inside RANSAC (AlignReconstructionToPosePriors). false:
+// fewer than three points or a degenerate (collinear) configuration.
+inline bool AlignToPositions(const std::vector<std::array<double, 3>>& src, const std::vector<std::array<double, 3>>& dst,
+                             double* scale, double R[9], double t[3]) {
+  const size_t n = src.size();
+  if (n < 3 || dst.size() != n) return false;
+  double ms[3] = {0, 0, 0}, md[3] = {0, 0, 0};
+  for (size_t i = 0; i < n; ++i)
+    for (int k = 0; k < 3; ++k) { ms[k] += src[i][k] / n; md[k] += dst[i][k] / n; }
+  double S[9] = {0}, var = 0;  // S = sum a b^T
+  for (size_t i = 0; i < n; ++i) {
+    double a[3], b[3];
+    for (int k = 0; k < 3; ++k) { a[k] = src[i][k] - ms[k]; b[k] = dst[i][k] - md[k]; var += a[k] * a[k]; }
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) S[3 * r + c] += a[r] * b[c];
+  }
+  if (var < 1e-24) return false;
+  // collinearity: second largest eigenvalue of S^T S negligible
+  {
+    double M[9];
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) M[3 * r + c] = S[r] * S[c] + S[3 + r] * S[3 + c] + S[6 + r] * S[6 + c];
+    // eigenvalues of the symmetric 3 x 3 by Jacobi
+    double A[9];
+    std::copy(M, M + 9, A);
+    for (int sweep = 0; sweep < 50; ++sweep)
+      for (int p = 0; p < 3; ++p)
+        for (int q = p + 1; q < 3; ++q) {
+          if (std::abs(A[3 * p + q]) < 1e-300) continue;
+          const double th = 0.5 * std::atan2(2 * A[3 * p + q], A[3 * q + q] - A[3 * p + p]);
+          const double c = std::cos(th), s_ = std::sin(th);
+          for (int k = 0; k < 3; ++k) {
+            const double akp = A[3 * k + p], akq = A[3 * k + q];
+            A[3 * k + p] = c * akp - s_ * akq; A[3 * k + q] = s_ * akp + c * akq;
+          }
+          for (int k = 0; k < 3; ++k) {
+            const double apk = A[3 * p + k], aqk = A[3 * q + k];
+            A[3 * p + k] = c * apk - s_ * aqk; A[3 * q + k] = s_ * apk + c * aqk;
+          }
+        }
+    double ev[3] = {A[0], A[4], A[8]};
+    std::sort(ev, ev + 3);
+    if (std::sqrt(std::max(ev[1], 0.0)) < 1e-12 * std::sqrt(std::max(ev[2], 1e-300))) return false;
+  }
+  const double Sxx = S[0], Sxy = S[1], Sxz = S[2], Syx = S[3], Syy = S[4], Syz = S[5], Szx = S[6], Szy = S[7], Szz = S[8];
+  double N[16] = {Sxx + Syy + Szz, Syz - Szy,       Szx - Sxz,        Sxy - Syx,
+                  Syz - Szy,       Sxx - Syy - Szz, Sxy + Syx,        Szx + Sxz,
+                  Szx - Sxz,       Sxy + Syx,       -Sxx + Syy - Szz, Syz + Szy,
+                  Sxy - Syx,       Szx + Sxz,       Syz + Szy,        -Sxx - Syy + Szz};
+  double V[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  for (int sweep = 0; sweep < 100; ++sweep)
+    for (int p = 0; p < 4; ++p)
+      for (int q = p + 1; q < 4; ++q) {
+        if (std::abs(N[4 * p + q]) < 1e-300) continue;
+        const double th = 0.5 * std::atan2(2 * N[4 * p + q], N[4 * q + q] - N[4 * p + p]);
+        const double c = std::cos(th), s_ = std::sin(th);
+        for (int k = 0; k < 4; ++k) {
+          const double a = N[4 * k + p], b = N[4 * k + q];
+          N[4 * k + p] = c * a - s_ * b; N[4 * k + q] = s_ * a + c * b;
+        }
+        for (int k = 0; k < 4; ++k) {
+          const double a = N[4 * p + k], b = N[4 * q + k];
+          N[4 * p + k] = c * a - s_ * b; N[4 * q + k] = s_ * a + c * b;
+        }
+        for (int k = 0; k < 4; ++k) {
+          const double a = V[4 * k + p], b = V[4 * k + q];
+          V[4 * k + p] = c * a - s_ * b; V[4 * k + q] = s_ * a + c * b;
+        }
+      }
+  int best = 0;
+  for (int k = 1; k < 4; ++k)
+    if (N[5 * k] > N[5 * best]) best = k;
+  const double qw = V[best], qx = V[4 + best], qy = V[8 + best], qz = V[12 + best];  // Horn: (w, x, y, z)
+  const double q[4] = {qx, qy, qz, qw};
+  QuatToRot(q, R);
+  double num = 0;
+  for (size_t i = 0; i < n; ++i) {
+    double a[3], b[3];
+    for (int k = 0; k < 3; ++k) { a[k] = src[i][k] - ms[k]; b[k] = dst[i][k] - md[k]; }
+    for (int r = 0; r < 3; ++r) num += b[r] * (R[3 * r] * a[0] + R[3 * r + 1] * a[1] + R[3 * r + 2] * a[2]);
+  }
+  *scale = num / var;
+  for (int r = 0; r < 3; ++r) t[r] = md[r] - *scale * (R[3 * r] * ms[0] + R[3 * r + 1] * ms[1] + R[3 * r + 2] * ms[2]);
+  return true;
+}
+
+class PosePriorBundleAdjuster : public Mi355xBundleAdjuster {
+ public:
+  struct Prepared {  // what has to happen to the reconstruction BEFORE it is flattened
+    BundleAdjustmentConfig config;
+    std::vector<PosePrior> pose_priors;
+    bool use_prior_position = false;
+    std::array<double, 3> normalized_from_metric{0, 0, 0};
+  };
+  // drops unusable priors, aligns + normalises the reconstruction or falls back to the two-camera gauge
+  // (bundle_adjustment_ceres.cc:913-936)
+  static Prepared Prepare(const BundleAdjustmentConfig& config, const std::vector<PosePrior>& pose_priors,
+                          Reconstruction& rec) {
+    Prepared out;
+    out.config = config;
+    for (const PosePrior& p : pose_priors)
+      if (p.HasPosition() && config.HasImage(p.image_id)) out.pose_priors.push_back(p);
+    if (out.pose_priors.size() >= 3) {
+      std::vector<std::array<double, 3>> src, dst;
+      for (const PosePrior& p : out.pose_priors) { src.push_back(rec.ProjectionCenter(p.image_id)); dst.push_back(p.position); }
+      double scale, R[9], t[3];
+      if (AlignToPositions(src, dst, &scale, R, t)) {
+        rec.Transform(scale, R, t);
+        out.use_prior_position = true;
+      }
+    }
+    if (out.use_prior_position) out.normalized_from_metric = rec.NormalizeFixedScale();
+    else out.config.FixGauge(BundleAdjustmentGauge::TWO_CAMS_FROM_WORLD);
+    return out;
+  }
+
+  PosePriorBundleAdjuster(BundleAdjustmentOptions options, PosePriorBundleAdjustmentOptions prior_options,
+                          Prepared prepared, Reconstruction& reconstruction)
+      : Mi355xBundleAdjuster(std::move(options), prepared.config, reconstruction),
+        prior_options_(prior_options), prepared_(std::move(prepared)) {
+    COLMAP_AMD_BA_CHECK(prior_options_.Check());
+    if (prepared_.use_prior_position) AddPriors();
+  }
+
+  bool UsesPriorPositions() const { return prepared_.use_prior_position; }
+  size_t NumPriors() const { return prior_pose_.size(); }
+
+  std::shared_ptr<BundleAdjustmentSummary> Solve() override {
+    auto summary = Mi355xBundleAdjuster::Solve();
+    const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    const double back[3] = {-prepared_.normalized_from_metric[0], -prepared_.normalized_from_metric[1],
+                            -prepared_.normalized_from_metric[2]};
+    Rec().Transform(1.0, I, back);  // Inverse(normalized_from_metric)
+    return summary;
+  }
+
+ private:
+  void AddPriors() {  // AddImagePosePriorToProblem (:986-1038) for every parameterized image
+    for (const PosePrior& pr : prepared_.pose_priors) {
+      const auto it = image_slots_.find(pr.image_id);
+      if (it == image_slots_.end()) continue;
+      const int pose_slot = it->second.first, sens_slot = it->second.second;
+      const bool const_sensor = sens_slot < 0 || SensorConst(sens_slot);
+      if (PoseConst(pose_slot) && const_sensor) continue;
+      double cov[9];
+      if (pr.HasPositionCov()) std::copy(pr.position_covariance.begin(), pr.position_covariance.end(), cov);
+      else {
+        const double v = prior_options_.prior_position_fallback_stddev * prior_options_.prior_position_fallback_stddev;
+        const double d[9] = {v, 0, 0, 0, v, 0, 0, 0, v};
+        std::copy(d, d + 9, cov);
+      }
+      // LeftSqrtInformation (cost_functions/utils.h:159-161): cov^-1 = L L^T, weight = L^T
+      const double a = cov[0], b = cov[1], c = cov[2], d = cov[4], e = cov[5], f = cov[8];
+      const double A = d * f - e * e, B = c * e - b * f, Cc = b * e - c * d;
+      const double det = a * A + b * B + c * Cc;
+      const double inf[9] = {A / det, B / det, Cc / det, B / det, (a * f - c * c) / det, (b * c - a * e) / det,
+                             Cc / det, (b * c - a * e) / det, (a * d - b * b) / det};
+      double L[9] = {0};
+      L[0] = std::sqrt(inf[0]);
+      L[3] = inf[3] / L[0]; L[6] = inf[6] / L[0];
+      L[4] = std::sqrt(inf[4] - L[3] * L[3]);
+      L[7] = (inf[7] - L[6] * L[3]) / L[4];
+      L[8] = std::sqrt(inf[8] - L[6] * L[6] - L[7] * L[7]);
+      prior_pose_.push_back(pose_slot);
+      prior_sensor_.push_back(sens_slot);
+      for (int k = 0; k < 3; ++k) prior_position_.push_back(pr.position[k] + prepared_.normalized_from_metric[k]);
+      for (int r = 0; r < 3; ++r)
+        for (int col = 0; col < 3; ++col) prior_sqrt_info_.push_back(L[3 * col + r]);  // L^T, row-major
+    }
+    prior_loss_type_ = prior_options_.prior_position_loss_function_type;
+    prior_loss_scale_ = prior_options_.prior_position_loss_scale;
+  }
+
+  PosePriorBundleAdjustmentOptions prior_options_;
+  Prepared prepared_;
+};
+
+// CreatePosePriorBundleAdjuster (bundle_adjustment.cc:373-395)
+inline std::unique_ptr<BundleAdjuster> CreatePosePriorBundleAdjuster(const BundleAdjustmentOptions& options,
+                                                                     const PosePriorBundleAdjustmentOptions& prior_options,
+                                                                     const BundleAdjustmentConfig& config,
+                                                                     std::vector<PosePrior> pose_priors,
+                                                                     Reconstruction& reconstruction) {
+  if (options.backend != BundleAdjustmentBackend::MI355X)
+    throw std::invalid_argument("BundleAdjustmentBackend CERES / CASPAR are not built here (they need Ceres / CUDA)");
+  return std::make_unique<PosePriorBundleAdjuster>(options, prior_options,
+                                                   PosePriorBundleAdjuster::Prepare(config, pose_priors, reconstruction),
+                                                   reconstruction);
+}
 
 // CreateDefaultBundleAdjuster (bundle_adjustment.cc:314-334): backend switch.
 inline std::unique_ptr<BundleAdjuster> CreateDefaultBundleAdjuster(const BundleAdjustmentOptions& options,

@@ -142,10 +142,36 @@ static int Counts(const std::string& path) {
   return 0;
 }
 
-static int Solve(const std::string& path, const std::string& out) {
+// priors file: one line per prior "image_id x y z c00 c01 .. c22" (nan = not given)
+static std::vector<PosePrior> ReadPriors(const std::string& path) {
+  std::vector<PosePrior> priors;
+  std::ifstream f(path);
+  if (!f.is_open()) throw std::runtime_error("cannot open " + path);
+  unsigned long long id;
+  while (f >> id) {
+    PosePrior p;
+    p.image_id = static_cast<image_t>(id);
+    std::string tok;
+    auto num = [&]() { f >> tok; return tok == "nan" ? std::nan("") : std::stod(tok); };
+    for (double& v : p.position) v = num();
+    for (double& v : p.position_covariance) v = num();
+    priors.push_back(p);
+  }
+  return priors;
+}
+
+static int Solve(const std::string& path, const std::string& out, const std::string& priors_path = "") {
   Spec s;
   ReadSpec(path, &s);
-  auto ba = CreateDefaultBundleAdjuster(s.options, s.config, s.rec);
+  std::unique_ptr<BundleAdjuster> ba;
+  if (priors_path.empty()) {
+    ba = CreateDefaultBundleAdjuster(s.options, s.config, s.rec);
+  } else {
+    s.options.mi355x->solver_options.function_tolerance = 1e-12;
+    ba = CreatePosePriorBundleAdjuster(s.options, PosePriorBundleAdjustmentOptions(), s.config, ReadPriors(priors_path), s.rec);
+    auto* pp = dynamic_cast<PosePriorBundleAdjuster*>(ba.get());
+    std::printf("priors used %d count %zu\n", pp->UsesPriorPositions() ? 1 : 0, pp->NumPriors());
+  }
   auto summary = ba->Solve();
   std::ofstream f(out);
   f << std::setprecision(17);
@@ -228,6 +254,57 @@ static int Api() {
   b.params = {0, 0, 0, 1, 0.5, 0, 0};
   const Rigid3d c = Compose(a, b);
   EXPECT(std::abs(c.params[4] - (1 + 0.5 * std::cos(0.5))) < 1e-15 && std::abs(c.params[5] - (2 + 0.5 * std::sin(0.5))) < 1e-15);
+  // AlignToPositions recovers a known similarity; Reconstruction::Transform / NormalizeFixedScale move poses
+  // and points consistently (projection centres transform like points)
+  {
+    const double qs[4] = {0.1, -0.2, 0.3, 0.9};
+    double qn[4], Rt[9];
+    const double nq = std::sqrt(qs[0] * qs[0] + qs[1] * qs[1] + qs[2] * qs[2] + qs[3] * qs[3]);
+    for (int i = 0; i < 4; ++i) qn[i] = qs[i] / nq;
+    QuatToRot(qn, Rt);
+    const double sc = 1.7, tt[3] = {3.0, -2.0, 1.0};
+    std::vector<std::array<double, 3>> src, dst;
+    for (int i = 0; i < 7; ++i) {
+      std::array<double, 3> a_{{std::sin(1.3 * i), std::cos(0.7 * i) * 2, 0.3 * i - 1}}, b_{};
+      for (int r = 0; r < 3; ++r) b_[r] = sc * (Rt[3 * r] * a_[0] + Rt[3 * r + 1] * a_[1] + Rt[3 * r + 2] * a_[2]) + tt[r];
+      src.push_back(a_);
+      dst.push_back(b_);
+    }
+    double s2, R2[9], t2[3];
+    EXPECT(AlignToPositions(src, dst, &s2, R2, t2));
+    EXPECT(std::abs(s2 - sc) < 1e-12);
+    for (int i = 0; i < 9; ++i) EXPECT(std::abs(R2[i] - Rt[i]) < 1e-12);
+    for (int i = 0; i < 3; ++i) EXPECT(std::abs(t2[i] - tt[i]) < 1e-11);
+    std::vector<std::array<double, 3>> line = {{{0, 0, 0}}, {{1, 1, 1}}, {{2, 2, 2}}};
+    EXPECT(!AlignToPositions(line, line, &s2, R2, t2));  // collinear
+    double qr[4];
+    RotToQuat(Rt, qr);
+    for (int i = 0; i < 4; ++i) EXPECT(std::abs(qr[i] - qn[i]) < 1e-14);
+    Reconstruction rec;
+    for (image_t id = 1; id <= 3; ++id) {
+      colmap_amd::Image im;
+      im.image_id = id;
+      im.cam_from_world.params = {0, std::sin(0.1 * id), 0, std::cos(0.1 * id), 0.5 * id, -1.0, 2.0 + id};
+      rec.images[id] = im;
+    }
+    rec.points3D[1].xyz = {1, 2, 3};
+    const auto c_before = rec.ProjectionCenter(2);
+    rec.Transform(sc, Rt, tt);
+    const auto c_after = rec.ProjectionCenter(2);
+    for (int r = 0; r < 3; ++r)
+      EXPECT(std::abs(c_after[r] - (sc * (Rt[3 * r] * c_before[0] + Rt[3 * r + 1] * c_before[1] + Rt[3 * r + 2] * c_before[2]) + tt[r])) < 1e-12);
+    EXPECT(std::abs(rec.points3D[1].xyz[0] - (sc * (Rt[0] * 1 + Rt[1] * 2 + Rt[2] * 3) + tt[0])) < 1e-12);
+    const auto shift = rec.NormalizeFixedScale();
+    double mean[3] = {0, 0, 0};
+    for (image_t id = 1; id <= 3; ++id) {
+      const auto c = rec.ProjectionCenter(id);
+      for (int r = 0; r < 3; ++r) mean[r] += c[r] / 3;
+    }
+    for (int r = 0; r < 3; ++r) EXPECT(std::abs(mean[r]) < 1e-12 && std::isfinite(shift[r]));
+    PosePrior pr;
+    EXPECT(!pr.HasPosition() && !pr.HasPositionCov());
+    EXPECT(PosePriorBundleAdjustmentOptions().Check());
+  }
   std::printf("api OK\n");
   return 0;
 }
@@ -237,10 +314,11 @@ int main(int argc, char** argv) {
     if (argc >= 2 && std::string(argv[1]) == "api") return Api();
     if (argc >= 3 && std::string(argv[1]) == "counts") return Counts(argv[2]);
     if (argc >= 4 && std::string(argv[1]) == "solve") return Solve(argv[2], argv[3]);
+    if (argc >= 5 && std::string(argv[1]) == "prior") return Solve(argv[2], argv[3], argv[4]);
   } catch (const std::exception& e) {
     std::fprintf(stderr, "exception: %s\n", e.what());
     return 3;
   }
-  std::fprintf(stderr, "usage: test_ba_host api | counts FILE | solve FILE OUT\n");
+  std::fprintf(stderr, "usage: test_ba_host api | counts FILE | solve FILE OUT | prior FILE OUT PRIORS\n");
   return 2;
 }

@@ -26,7 +26,7 @@ def _both(fp, **so_kw):
     return (a, want), (b, got)
 
 
-def _assert_close(a, want, b, got, cost_rtol=1e-8, param_atol=1e-6, traj_rtol=1e-7):
+def _assert_close(a, want, b, got, cost_rtol=1e-8, param_atol=1e-6, traj_rtol=1e-7, cam_rtol=1e-7):
     assert got.num_residuals == want.num_residuals
     assert got.num_effective_parameters == want.num_effective_parameters
     assert got.termination_type == want.termination_type
@@ -35,7 +35,7 @@ def _assert_close(a, want, b, got, cost_rtol=1e-8, param_atol=1e-6, traj_rtol=1e
     n = min(4, len(want.log_cost), len(got.log_cost))
     np.testing.assert_allclose(got.log_cost[:n], want.log_cost[:n], rtol=traj_rtol)
     np.testing.assert_allclose(b.points, a.points, atol=param_atol)
-    np.testing.assert_allclose(b.cams, a.cams, rtol=1e-7, atol=param_atol)
+    np.testing.assert_allclose(b.cams, a.cams, rtol=cam_rtol, atol=param_atol)
     np.testing.assert_allclose(b.poses, a.poses, atol=param_atol)
 
 
@@ -520,7 +520,10 @@ def _model_matches_oracle(model, params):
     # walk it for all 60 iterations), so the intrinsics agree to fewer digits than the cost does
     # (the same for the rational / high-order coefficients of the two 12-parameter models)
     atol = 2e-4 if model in (scene.EUCM, scene.FULL_OPENCV, scene.THIN_PRISM_FISHEYE, scene.RAD_TAN_THIN_PRISM_FISHEYE) else 1e-5
-    _assert_close(a, want, b, got, cost_rtol=1e-7, param_atol=atol, traj_rtol=1e-5)
+    # the high-order coefficients of the 12- / 16-parameter models are unobservable at this field of view and
+    # drift to 1e3 .. 1e8: compared relatively
+    wide = model in (scene.FULL_OPENCV, scene.THIN_PRISM_FISHEYE, scene.RAD_TAN_THIN_PRISM_FISHEYE)
+    _assert_close(a, want, b, got, cost_rtol=1e-7, param_atol=atol, traj_rtol=1e-5, cam_rtol=1e-4 if wide else 1e-7)
     assert got.final_cost < 0.2 * got.initial_cost
 
 

@@ -256,3 +256,54 @@ def test_cpp_bundle_adjuster_equals_python_mirror(ba_host, tmp_path):
         for pid, p in mine.points3D.items():
             assert np.array_equal(got["point"][pid], p.xyz)
         assert summary.final_cost < summary.initial_cost
+
+
+@pytest.mark.gpu
+def test_cpp_pose_prior_adjuster_equals_python_mirror(ba_host, tmp_path):
+    """CreatePosePriorBundleAdjuster in C++ (Horn alignment, fixed-scale normalisation, covariance weighting) and
+    in Python (Umeyama alignment): the alignments agree to round-off, so both solves end in the same metric
+    reconstruction; two-camera rigs with refined sensor_from_rig exercise both prior functors."""
+    from colmap_amd import estimators as est, scene
+    rec = scene.SynthesizeDataset(scene.SyntheticDatasetOptions(num_rigs=2, num_cameras_per_rig=2, num_frames_per_rig=4,
+                                                                num_points3D=150), seed=71)
+    gt = rec.copy()
+    rng = np.random.default_rng(72)
+    priors = [est.PosePrior(i, gt.ProjectionCenter(i) + 0.01 * rng.normal(size=3),
+                            np.diag([1e-4, 2e-4, 4e-4]) if i % 2 else None) for i in gt.RegImageIds()]
+    scene.SynthesizeNoise(scene.SyntheticNoiseOptions(0.02, 0.3, 0.02, 0.2), rec, seed=73)
+    Rw = scene.quat_to_rot(np.array([0.1, -0.2, 0.3, 0.9]) / np.linalg.norm([0.1, -0.2, 0.3, 0.9]))
+    rec.Transform(1.3, Rw, np.array([2.0, -1.0, 0.5]))
+    cfg = est.BundleAdjustmentConfig()
+    for i in rec.RegImageIds():
+        cfg.AddImage(i)
+    so = est.SolverOptions(max_num_iterations=40, gradient_tolerance=1e-8, function_tolerance=1e-12,
+                           linear_solver_type=est.SOLVER_AUTO)
+    opts = est.BundleAdjustmentOptions(refine_sensor_from_rig=True, solver_options=so)
+    spec, out, pfile = str(tmp_path / "prior.txt"), str(tmp_path / "prior.out"), str(tmp_path / "priors.txt")
+    _write_ba_spec(spec, rec, cfg, opts)
+    with open(pfile, "w") as f:
+        for p in priors:
+            cov = p.position_covariance if p.position_covariance is not None else np.full((3, 3), np.nan)
+            f.write(f"{p.image_id} " + " ".join(repr(float(v)) for v in list(p.position) + list(np.ravel(cov))) + "\n")
+    r = subprocess.run([ba_host, "prior", spec, out, pfile], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert f"priors used 1 count {len(priors)}" in r.stdout
+    mine = rec.copy()
+    opts.gpu_index = "0"
+    ba = est.CreatePosePriorBundleAdjuster(opts, est.PosePriorBundleAdjustmentOptions(), cfg, priors, mine)
+    summary = ba.Solve()
+    lines = open(out).read().splitlines()
+    head = lines[0].split()
+    assert int(head[1]) == summary.num_residuals and int(head[2]) == summary.num_effective_parameters
+    assert abs(float(head[5]) - summary.final_cost) <= 1e-6 * summary.final_cost
+    got = {"image": {}, "point": {}}
+    for ln in lines[1:]:
+        t = ln.split()
+        if t[0] in got:
+            got[t[0]][int(t[1])] = np.array(t[2:], float)
+    for iid, im in mine.images.items():
+        q_sign = np.sign(got["image"][iid][:4] @ im.cam_from_world[:4])
+        np.testing.assert_allclose(got["image"][iid] * np.r_[np.full(4, q_sign), np.ones(3)], im.cam_from_world, atol=1e-5)
+        assert np.linalg.norm(mine.ProjectionCenter(iid) - gt.ProjectionCenter(iid)) < 0.05
+    for pid, p in mine.points3D.items():
+        np.testing.assert_allclose(got["point"][pid], p.xyz, atol=1e-5)
