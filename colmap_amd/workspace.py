@@ -323,8 +323,83 @@ def read_points3D_text(path: str) -> Dict[int, SparsePoint3D]:
     return pts
 
 
+_SENSOR_TYPE_NAMES = {-1: "INVALID", 0: "CAMERA", 1: "IMU"}  # SensorType (util/types.h:144-148), text spelling
+_SENSOR_TYPE_IDS = {v: k for k, v in _SENSOR_TYPE_NAMES.items()}
+
+
+def read_rigs_text(path: str) -> Dict[int, SparseRig]:
+    """ReadRigsText (reconstruction_io_text.cc:47-108): RIG_ID NUM_SENSORS [REF_TYPE REF_ID] then per other
+    sensor TYPE ID HAS_POSE [QW QX QY QZ TX TY TZ]."""
+    rigs = {}
+    for line in _text_lines(path):
+        t = line.split()
+        rig = SparseRig(int(t[0]))
+        n, i = int(t[1]), 2
+        if n > 0:
+            rig.ref_sensor = (_SENSOR_TYPE_IDS[t[i]], int(t[i + 1]))
+            i += 2
+        for _ in range(max(0, n - 1)):
+            sid = (_SENSOR_TYPE_IDS[t[i]], int(t[i + 1]))
+            has_pose = int(t[i + 2]) == 1
+            i += 3
+            if has_pose:
+                rig.sensors[sid] = np.array(t[i:i + 7], float)
+                i += 7
+            else:
+                rig.sensors[sid] = None
+        rigs[rig.rig_id] = rig
+    return rigs
+
+
+def read_frames_text(path: str) -> Dict[int, SparseFrame]:
+    """ReadFramesText (reconstruction_io_text.cc:160-205): FRAME_ID RIG_ID QW QX QY QZ TX TY TZ NUM_DATA_IDS then
+    (SENSOR_TYPE SENSOR_ID DATA_ID) per data id."""
+    frames = {}
+    for line in _text_lines(path):
+        t = line.split()
+        fid, rid, nd = int(t[0]), int(t[1]), int(t[9])
+        data = [(_SENSOR_TYPE_IDS[t[10 + 3 * k]], int(t[11 + 3 * k]), int(t[12 + 3 * k])) for k in range(nd)]
+        frames[fid] = SparseFrame(fid, rid, np.array(t[2:9], float), data)
+    return frames
+
+
+def write_rigs_frames_text(model: SparseModel, path: str):
+    """WriteRigsText / WriteFramesText (reconstruction_io_text.cc:370-517): 17 significant digits."""
+    r = lambda v: repr(float(v))
+    with open(os.path.join(path, "rigs.txt"), "w") as f:
+        f.write("# Rig calib list with one line of data per calib:\n"
+                "#   RIG_ID, NUM_SENSORS, REF_SENSOR_TYPE, REF_SENSOR_ID, SENSORS[] as (SENSOR_TYPE, SENSOR_ID, HAS_POSE, "
+                "[QW, QX, QY, QZ, TX, TY, TZ])\n")
+        f.write(f"# Number of rigs: {len(model.rigs)}\n")
+        for rid in sorted(model.rigs):
+            rig = model.rigs[rid]
+            ns = (1 if rig.ref_sensor is not None else 0) + len(rig.sensors)
+            parts = [str(rid), str(ns)]
+            if rig.ref_sensor is not None:
+                parts += [_SENSOR_TYPE_NAMES[rig.ref_sensor[0]], str(rig.ref_sensor[1])]
+            for sid in sorted(rig.sensors):
+                pose = rig.sensors[sid]
+                parts += [_SENSOR_TYPE_NAMES[sid[0]], str(sid[1]), "0" if pose is None else "1"]
+                if pose is not None:
+                    parts += [r(v) for v in pose]
+            f.write(" ".join(parts) + "\n")
+    with open(os.path.join(path, "frames.txt"), "w") as f:
+        f.write("# Frame list with one line of data per frame:\n"
+                "#   FRAME_ID, RIG_ID, RIG_FROM_WORLD[QW, QX, QY, QZ, TX, TY, TZ], NUM_DATA_IDS, DATA_IDS[] as "
+                "(SENSOR_TYPE, SENSOR_ID, DATA_ID)\n")
+        f.write(f"# Number of frames: {len(model.frames)}\n")
+        for fid in sorted(model.frames):
+            fr = model.frames[fid]
+            parts = [str(fid), str(fr.rig_id)] + [r(v) for v in fr.rig_from_world] + [str(len(fr.data_ids))]
+            for d in sorted(fr.data_ids):
+                parts += [_SENSOR_TYPE_NAMES[d[0]], str(d[1]), str(d[2])]
+            f.write(" ".join(parts) + "\n")
+
+
 def write_model_text(model: SparseModel, path: str):
     os.makedirs(path, exist_ok=True)
+    if model.rigs or model.frames:  # Reconstruction::WriteText carries rigs.txt / frames.txt too
+        write_rigs_frames_text(model, path)
     with open(os.path.join(path, "cameras.txt"), "w") as f:
         f.write("# Camera list with one line of data per camera:\n#   CAMERA_ID, MODEL, WIDTH, HEIGHT, PARAMS[]\n")
         for cid in sorted(model.cameras):
@@ -358,9 +433,14 @@ def read_sparse_model(path: str) -> SparseModel:
             m.frames = read_frames_binary(os.path.join(path, "frames.bin"))
         return m
     if os.path.exists(os.path.join(path, "cameras.txt")):
-        return SparseModel(read_cameras_text(os.path.join(path, "cameras.txt")),
-                           read_images_text(os.path.join(path, "images.txt")),
-                           read_points3D_text(os.path.join(path, "points3D.txt")))
+        m = SparseModel(read_cameras_text(os.path.join(path, "cameras.txt")),
+                        read_images_text(os.path.join(path, "images.txt")),
+                        read_points3D_text(os.path.join(path, "points3D.txt")))
+        # Reconstruction::ReadText: rigs.txt / frames.txt when present (legacy text models have neither)
+        if os.path.exists(os.path.join(path, "rigs.txt")) and os.path.exists(os.path.join(path, "frames.txt")):
+            m.rigs = read_rigs_text(os.path.join(path, "rigs.txt"))
+            m.frames = read_frames_text(os.path.join(path, "frames.txt"))
+        return m
     raise FileNotFoundError(f"cameras, images, points3D files do not exist at {path}")
 
 

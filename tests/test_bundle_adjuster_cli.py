@@ -42,6 +42,22 @@ def test_model_conversion_round_trip(tmp_path):
         assert all(np.array_equal(p.xy, q.xy) for p, q in zip(b.points2D, img.points2D))
     for pid, pt in rec.points3D.items():
         assert np.array_equal(back.points3D[pid].xyz, pt.xyz) and back.points3D[pid].track == pt.track
+    # the same through the text files (rigs.txt / frames.txt, reconstruction_io_text.cc:47-205,370-517)
+    W.write_model_text(sm, str(tmp_path / "txt"))
+    assert os.path.exists(tmp_path / "txt" / "rigs.txt") and os.path.exists(tmp_path / "txt" / "frames.txt")
+    assert open(tmp_path / "txt" / "rigs.txt").read().splitlines()[3].split()[2] == "CAMERA"
+    txt = W.read_sparse_model(str(tmp_path / "txt"))
+    assert sorted(txt.rigs) == sorted(sm.rigs) and sorted(txt.frames) == sorted(sm.frames)
+    for rid, rig in sm.rigs.items():
+        assert txt.rigs[rid].ref_sensor == rig.ref_sensor and sorted(txt.rigs[rid].sensors) == sorted(rig.sensors)
+        for sid, pose in rig.sensors.items():
+            assert (pose is None and txt.rigs[rid].sensors[sid] is None) or np.array_equal(txt.rigs[rid].sensors[sid], pose)
+    for fid, fr in sm.frames.items():
+        assert txt.frames[fid].rig_id == fr.rig_id and np.array_equal(txt.frames[fid].rig_from_world, fr.rig_from_world)
+        assert sorted(txt.frames[fid].data_ids) == sorted(fr.data_ids)
+    back_txt = cli.reconstruction_from_sparse_model(txt)
+    for iid, img in rec.images.items():
+        assert np.array_equal(back_txt.images[iid].cam_from_world, img.cam_from_world)
     # a legacy model (no rigs.bin / frames.bin) reads as one trivial frame per image
     _, legacy = _dataset(1)
     W.write_model_binary(cli.sparse_model_from_reconstruction(legacy), str(tmp_path / "legacy"))
