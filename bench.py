@@ -357,7 +357,25 @@ def main():
     # N > 1: the secondary (bundle adjustment) leg is ONE solve sharded over all ranks
     if not a.no_ba and world > 1:
         torch.cuda.empty_cache()
-        sec = ba_secondary(a, local_rank, False, rank, world, dev)
+        # The sharded BA leg is the only part of this script with data-path collectives. The primary
+        # measurement above must not be lost to it: if the leg fails on any rank or does not finish in time,
+        # rank 0 prints the line without it and every rank leaves (each rank runs the same watchdog).
+        import threading
+
+        def give_up(reason):
+            if rank == 0:
+                out["secondary"] = {"error": reason}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+        watchdog = threading.Timer(float(os.environ.get("COLMAP_AMD_BENCH_BA_TIMEOUT", "240")),
+                                   give_up, args=("sharded bundle-adjustment leg timed out",))
+        watchdog.daemon = True
+        watchdog.start()
+        try:
+            sec = ba_secondary(a, local_rank, False, rank, world, dev)
+        except Exception as e:  # the other ranks are stuck in a collective now: their watchdogs release them
+            give_up(f"sharded bundle-adjustment leg failed on rank {rank}: {e!r}")
+        watchdog.cancel()
         if rank == 0:
             out["secondary"] = sec
     if rank == 0:
