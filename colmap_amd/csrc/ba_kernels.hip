@@ -1210,6 +1210,34 @@ __global__ void __launch_bounds__(256) ba_model_kernel(View V, const double* __r
   if (threadIdx.x == 0) partials[blockIdx.x] = acc;
 }
 
+// The same quantity from what the back-substitution left behind: jx = J_c y_c (p-order) is still in
+// place, so J step = -(jx + J_p y_p) needs only the point columns, the residual and jx (10 doubles per
+// observation instead of 28). Lane per point over its contiguous p-order segment; y_p = dpv (not negated).
+__global__ void __launch_bounds__(256) ba_model_from_jx_kernel(View V, const double* __restrict__ jx,
+                                                              const double* __restrict__ dpv,
+                                                              double* __restrict__ partials) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  double acc = 0.0;
+  if (j < V.n_points) {
+    const size_t N = (size_t)V.n_obs;
+    const int off = V.pt_off[j];
+    double y[3] = {0.0, 0.0, 0.0};
+    if (off >= 0) { y[0] = dpv[off]; y[1] = dpv[off + 1]; y[2] = dpv[off + 2]; }
+    for (int o = V.pt_ptr[j]; o < V.pt_ptr[j + 1]; ++o)
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        double m = jx[r * N + o];
+        if (off >= 0)
+          m += V.Jpt[(size_t)(r * 3) * N + o] * y[0] + V.Jpt[(size_t)(r * 3 + 1) * N + o] * y[1] +
+               V.Jpt[(size_t)(r * 3 + 2) * N + o] * y[2];
+        m = -m;
+        acc -= m * (V.res_p[r * N + o] + 0.5 * m);
+      }
+  }
+  acc = block_sum(acc);
+  if (threadIdx.x == 0) partials[blockIdx.x] = acc;
+}
+
 // ------------------------------------------------------------------------------------------
 // Camera-side reductions: one wave per chunk of a parameter block's observation list
 // ------------------------------------------------------------------------------------------
@@ -2330,7 +2358,7 @@ struct Solver {
     Craw.alloc(6 * (size_t)p.num_points); tbuf.alloc(poff); tmpc.alloc(n_c);
     scalars.alloc(NSCALAR);
     pcg_part.alloc((size_t)grid_for(n_blk, 256) + 1);
-    partials.alloc((size_t)grid_for(n, 256) + 1);
+    partials.alloc((size_t)std::max(grid_for(n, 256), grid_for(std::max(p.num_points, 1), 256)) + 1);
 
     V.n_obs = n; V.n_poses = p.num_poses; V.n_cams = p.num_cams; V.n_points = p.num_points;
     V.n_c = n_c; V.n_p = poff; V.n_blk = n_blk; V.n_chunks = (int)h_chunk_blk.size();
@@ -2635,8 +2663,9 @@ struct Solver {
       }
       BA_LAUNCH(ba_axpby_kernel, dim3(std::max(gvc, 1)), dim3(256), st, nc, -1.0, x.p, nullptr, stepc.p);
       BA_LAUNCH(ba_axpby_kernel, dim3(std::max(gvp, 1)), dim3(256), st, np, -1.0, dp.p, nullptr, stepp.p);
-      BA_LAUNCH(ba_model_kernel, dim3(grid_for(V.n_obs, 256)), dim3(256), st, V, stepc.p, stepp.p, partials.p);
-      BA_LAUNCH(ba_final_sum_kernel, dim3(1), dim3(1024), st, partials.p, grid_for(V.n_obs, 256), scalars.p + S_MODEL);
+      // model cost change -(J step).(r + J step / 2): jx = J_c y_c of the back-substitution is still in place
+      BA_LAUNCH(ba_model_from_jx_kernel, dim3(grid_for(V.n_points, 256)), dim3(256), st, V, jx.p, dp.p, partials.p);
+      BA_LAUNCH(ba_final_sum_kernel, dim3(1), dim3(1024), st, partials.p, grid_for(V.n_points, 256), scalars.p + S_MODEL);
       if (use_priors()) BA_LAUNCH(ba_prior_model_kernel, dim3(1), dim3(256), st, Q, stepc.p, scalars.p + S_MODEL);
       const double model_change = scalar_sum(S_MODEL);  // (synchronises the stream)
       if (mfma_pending) {
