@@ -353,10 +353,12 @@ def main():
         if not a.no_ba and world == 1:
             del pms_keepalive[:]
             torch.cuda.empty_cache()
+            mvs.release_cached_memory()
             out["secondary"] = ba_secondary(a, local_rank, not a.no_cpu_baseline)
     # N > 1: the secondary (bundle adjustment) leg is ONE solve sharded over all ranks
     if not a.no_ba and world > 1:
         torch.cuda.empty_cache()
+        mvs.release_cached_memory()
         # The sharded BA leg is the only part of this script with data-path collectives. The primary
         # measurement above must not be lost to it: if the leg fails on any rank or does not finish in time,
         # rank 0 prints the line without it and every rank leaves (each rank runs the same watchdog).

@@ -44,18 +44,77 @@ struct PmError : std::runtime_error {
       throw PmError(std::string("HIP error: ") + hipGetErrorString(e_) + " at " #expr); \
   } while (0)
 
+// Device buffers of destroyed handles are kept for the next handle of the same shape (a controller or a
+// benchmark creates and destroys ~10 buffers of up to 1.3 GB per reference image: hipMalloc / hipFree
+// would map, clear and unmap those pages every time and hipFree synchronises the device). Exact-size
+// free lists per device; bounded by COLMAP_AMD_PM_POOL_GB (default 64); pm_release_cached_memory()
+// returns everything to the driver. A buffer only comes back here after pm_destroy synchronised the
+// handle's stream, so the next user cannot race with the previous one.
+class DevPool {
+ public:
+  static DevPool& Get() {
+    static DevPool* pool = new DevPool();  // never destroyed: no hipFree after the runtime is gone
+    return *pool;
+  }
+  void* Take(int dev, size_t bytes) {
+    std::lock_guard<std::mutex> lock(mu_);
+    auto it = free_.find({dev, bytes});
+    if (it == free_.end() || it->second.empty()) return nullptr;
+    void* p = it->second.back();
+    it->second.pop_back();
+    pooled_ -= bytes;
+    return p;
+  }
+  void Give(int dev, size_t bytes, void* p) {
+    {
+      std::lock_guard<std::mutex> lock(mu_);
+      if (pooled_ + bytes <= cap_) {
+        free_[{dev, bytes}].push_back(p);
+        pooled_ += bytes;
+        return;
+      }
+    }
+    (void)hipFree(p);
+  }
+  void Release() {
+    std::lock_guard<std::mutex> lock(mu_);
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    for (auto& kv : free_) {
+      (void)hipSetDevice(kv.first.first);
+      for (void* p : kv.second) (void)hipFree(p);
+    }
+    (void)hipSetDevice(cur);
+    free_.clear();
+    pooled_ = 0;
+  }
+
+ private:
+  DevPool() {
+    const char* e = getenv("COLMAP_AMD_PM_POOL_GB");
+    cap_ = static_cast<size_t>((e ? atof(e) : 64.0) * (1ull << 30));
+  }
+  std::mutex mu_;
+  std::map<std::pair<int, size_t>, std::vector<void*>> free_;
+  size_t pooled_ = 0, cap_ = 0;
+};
+
 template <typename T>
 struct DevBuf {
   T* ptr = nullptr;
   size_t count = 0;
+  int dev = -1;
   void alloc(size_t n) {
     free();
     if (n == 0) return;
-    HIP_CALL(hipMalloc(reinterpret_cast<void**>(&ptr), n * sizeof(T)));
+    HIP_CALL(hipGetDevice(&dev));
+    void* p = DevPool::Get().Take(dev, n * sizeof(T));
+    if (!p) HIP_CALL(hipMalloc(&p, n * sizeof(T)));
+    ptr = static_cast<T*>(p);
     count = n;
   }
   void free() {
-    if (ptr) (void)hipFree(ptr);
+    if (ptr) DevPool::Get().Give(dev, count * sizeof(T), ptr);
     ptr = nullptr;
     count = 0;
   }
@@ -948,6 +1007,8 @@ void pm_destroy(pm_handle* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   delete h;
 }
+
+void pm_release_cached_memory(void) { DevPool::Get().Release(); }
 
 const char* pm_last_error(void) { return g_last_error.c_str(); }
 

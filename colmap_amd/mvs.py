@@ -148,6 +148,11 @@ def _ptr_of(a, dtype, keep: list):
     return arr.ctypes.data, False
 
 
+def release_cached_memory():
+    """pm_release_cached_memory: device buffers of destroyed handles go back to the driver."""
+    lib().pm_release_cached_memory()
+
+
 class ImageCache:
     """Device-side cache of packed source images shared between problems (pm_image_cache)."""
 

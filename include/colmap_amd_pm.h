@@ -180,6 +180,9 @@ int pm_debug_rng_streams(int32_t gpu_index, const uint64_t* seeds, int32_t nseed
                          float* out);
 
 void pm_destroy(pm_handle* h);
+/* Device buffers of destroyed handles are kept (exact-size free lists, bounded by COLMAP_AMD_PM_POOL_GB,
+ * default 64) for the next handle of the same shape; this returns them to the driver. */
+void pm_release_cached_memory(void);
 const char* pm_last_error(void);
 /* Number of visible GPUs (controller: gpu_index == -1 -> all devices,
  * patch_match.cc:375-383). */
