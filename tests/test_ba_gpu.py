@@ -626,3 +626,12 @@ def test_dense_schur_tier_matches_oracle():
                                     linear_solver_type=est.SOLVER_DENSE_SCHUR)
     assert got2.termination_type == est.BundleAdjustmentTerminationType.CONVERGENCE
     _assert_close(a2, want2, b2, got2, cost_rtol=1e-8, param_atol=1e-6)
+
+
+def test_reference_pose_prior_backend_case():
+    """PosePriorBundleAdjusterBackendTest.Nominal (bundle_adjustment_test.cc:423-481) with backend MI355X."""
+    from test_ba_oracle import _reference_pose_prior_backend_case
+    s_hip = _reference_pose_prior_backend_case(None, gpu_index="0")
+    s_cpu = _reference_pose_prior_backend_case(ba_oracle.solve_fn)
+    assert s_hip.num_residuals == s_cpu.num_residuals == 2 * (s_hip.num_residuals - 21) // 2 + 21
+    assert abs(s_hip.final_cost - s_cpu.final_cost) <= 1e-6 * s_cpu.final_cost

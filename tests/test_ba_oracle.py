@@ -888,3 +888,64 @@ def test_dense_schur_tier_equals_tight_pcg():
     d = fp.copy()
     sd = est.solve_flat(d, est.SolverOptions(**so), solve_fn=ba_oracle.solve_fn)          # default: inexact PCG
     assert sd.num_iterations > 2 * sa.num_iterations
+
+
+def test_reference_position_prior_functor_cases():
+    """AbsolutePosePositionPriorCostFunctor.Nominal, AbsoluteRigPosePositionPriorCostFunctor.Nominal and
+    CovarianceWeightedCostFunctor<...> (cost_functions/pose_prior_test.cc:42-107,200-222), restated."""
+    rng = np.random.default_rng(0)
+    ident = np.array([0, 0, 0, 1, 0, 0, 0.0])
+    assert np.abs(ba_oracle.position_prior(np.zeros(3), ident)[0]).max() < 1e-6
+    for _ in range(3):
+        pose = _rand_pose(rng)
+        position_in_world = -scene.quat_to_rot(pose[:4]).T @ pose[4:]          # Inverse(sensor_from_world).translation()
+        np.testing.assert_allclose(ba_oracle.position_prior(np.zeros(3), pose)[0], -position_in_world, atol=1e-6)
+        assert np.abs(ba_oracle.position_prior(position_in_world, pose)[0]).max() < 1e-6
+        # rig variant: sensor_from_world = sensor_from_rig * rig_from_world
+        sens, rig = _rand_pose(rng), _rand_pose(rng)
+        assert np.abs(ba_oracle.position_prior(np.zeros(3), ident, ident)[0]).max() < 1e-6
+        comp = scene.rigid_compose(sens, rig)
+        pos = -scene.quat_to_rot(comp[:4]).T @ comp[4:]
+        np.testing.assert_allclose(ba_oracle.position_prior(np.zeros(3), rig, sens)[0], -pos, atol=1e-6)
+        assert np.abs(ba_oracle.position_prior(pos, rig, sens)[0]).max() < 1e-6
+        # covariance 2 I: residual = -0.5 sqrt(2) * world_from_cam.translation() -- through the solver's weighting:
+        # one prior, cost = 1/2 |L^T r0|^2 with cov^-1 = L L^T
+        L = np.linalg.cholesky(np.linalg.inv(2 * np.eye(3)))
+        np.testing.assert_allclose(L.T @ ba_oracle.position_prior(np.zeros(3), pose)[0],
+                                   -0.5 * np.sqrt(2) * position_in_world, atol=1e-6)
+
+
+def _reference_pose_prior_backend_case(solve_fn, gpu_index="-1"):
+    """PosePriorBundleAdjusterBackendTest.Nominal (bundle_adjustment_test.cc:423-481): 1 rig x 1 camera x 7 frames,
+    100 points, priors = ground-truth positions + N(0, 0.05), noise 0.5 px / 0.1 / 0.5 deg / 0.1."""
+    gt = scene.SynthesizeDataset(scene.SyntheticDatasetOptions(num_rigs=1, num_cameras_per_rig=1, num_frames_per_rig=7,
+                                                               num_points3D=100), seed=0)
+    rec = gt.copy()
+    rng = np.random.default_rng(1)
+    priors = [est.PosePrior(i, gt.ProjectionCenter(i) + 0.05 * rng.normal(size=3)) for i in gt.RegImageIds()]
+    scene.SynthesizeNoise(scene.SyntheticNoiseOptions(0.1, 0.5, 0.1, 0.5), rec, seed=2)
+    cfg = est.BundleAdjustmentConfig()
+    for i in rec.RegImageIds():
+        cfg.AddImage(i)
+    opt = est.BundleAdjustmentOptions()
+    opt.gpu_index = gpu_index
+    ba = est.CreatePosePriorBundleAdjuster(opt, est.PosePriorBundleAdjustmentOptions(), cfg, priors, rec, solve_fn=solve_fn)
+    assert ba.Options().backend == est.BundleAdjustmentBackend.MI355X and ba.Config().NumImages() == 7
+    summary = ba.Solve()
+    assert summary.IsSolutionUsable() and summary.num_residuals > 0
+    # ReconstructionNear(gt, max_rotation_error_deg 0.1, max_proj_center_error 0.1): the matcher first aligns
+    # the two worlds through the projection centres (scene/reconstruction_matchers.h:149-169)
+    ids = gt.RegImageIds()
+    tf = est.align_to_positions(np.array([rec.ProjectionCenter(i) for i in ids]), np.array([gt.ProjectionCenter(i) for i in ids]))
+    rec = rec.copy()
+    rec.Transform(*tf)
+    for i in gt.RegImageIds():
+        a, b = gt.images[i].cam_from_world, rec.images[i].cam_from_world
+        R = scene.quat_to_rot(a[:4]).T @ scene.quat_to_rot(b[:4])
+        assert np.degrees(np.arccos(np.clip((np.trace(R) - 1) / 2, -1, 1))) < 0.1
+        assert np.linalg.norm(gt.ProjectionCenter(i) - rec.ProjectionCenter(i)) < 0.1
+    return summary
+
+
+def test_reference_pose_prior_backend_case_oracle():
+    _reference_pose_prior_backend_case(ba_oracle.solve_fn)

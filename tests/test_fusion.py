@@ -417,3 +417,64 @@ def test_stereo_fusion_command_on_a_workspace(tmp_path):
     out2 = str(tmp_path / "fused2.ply")
     again = pipeline.stereo_fusion(out2, ws, options=fusion.StereoFusionOptions(min_num_pixels=3), output_type="ply")
     assert np.array_equal(again.xyz, pts.xyz) and open(out2, "rb").read() == open(out, "rb").read()
+
+
+# ------------------------------------------------------------------------------------------------
+# the reference's own test of this path (mvs/fusion_test.cc:45-140), restated
+# ------------------------------------------------------------------------------------------------
+
+def _reference_integration_inputs():
+    """StereoFusion.Integration: SynthesizeDataset with one rig, one camera, two frames, 30 x 20 images (the
+    default SIMPLE_RADIAL parameters stay {1280, 512, 384, 0.05}), constant depth 5, normals (0, 0, 1), bitmap
+    colour (0, 64, 128); min_num_pixels 1, max_num_pixels 100, max_traversal_depth 10, check_num_images 10."""
+    from colmap_amd import scene as S
+    rec = S.SynthesizeDataset(S.SyntheticDatasetOptions(num_rigs=1, num_cameras_per_rig=1, num_frames_per_rig=2,
+                                                        camera_width=30, camera_height=20), seed=0)
+    images = []
+    for iid in rec.RegImageIds():
+        im = rec.images[iid]
+        cam = rec.cameras[im.camera_id]
+        K = np.array([[cam.params[0], 0, cam.params[1]], [0, cam.params[0], cam.params[2]], [0, 0, 1]], np.float32)
+        R = S.quat_to_rot(im.cam_from_world[:4]).astype(np.float32)
+        T = im.cam_from_world[4:].astype(np.float32)
+        rgb = np.zeros((20, 30, 3), np.uint8)
+        rgb[:] = (0, 64, 128)
+        normal = np.zeros((3, 20, 30), np.float32)
+        normal[2] = 1.0
+        images.append(fusion.FusionImage(30, 20, K, R, T, rgb, np.full((20, 30), 5.0, np.float32), normal))
+    opt = fusion.StereoFusionOptions(min_num_pixels=1, max_num_pixels=100, max_traversal_depth=10, check_num_images=10)
+    return opt, images, [[1], [0]]
+
+
+def _check_reference_integration(pts):
+    assert len(pts.xyz) > 0 and len(pts.xyz) == len(pts.visibility)       # EXPECT_GT(size, 0), sizes equal
+    assert (pts.xyz > -10.0).all() and (pts.xyz < 10.0).all()              # every coordinate in (-10, 10)
+    assert (pts.rgb == np.array([0, 64, 128], np.uint8)).all()            # colour of the bitmap
+    np.testing.assert_allclose((pts.normal.astype(np.float64) ** 2).sum(1), 1.0, rtol=4 * np.finfo(np.float32).eps)
+    assert all(len(v) > 0 for v in pts.visibility)
+
+
+def test_reference_integration_case_oracle():
+    opt, images, overlap = _reference_integration_inputs()
+    for mode in (0, 1, 2):
+        _check_reference_integration(fusion_oracle.fuse(opt, images, overlap, mode=mode))
+
+
+@pytest.mark.gpu
+def test_reference_integration_case_hip():
+    opt, images, overlap = _reference_integration_inputs()
+    got = fusion.fuse(opt, images, overlap)
+    _check_reference_integration(got)
+    assert _same(got, fusion_oracle.fuse(opt, images, overlap, mode=1))
+
+
+def test_reference_visibility_file_cases(tmp_path):
+    """ReadPointsVisibility.RoundTrip / SizeMismatch (mvs/fusion_test.cc:142-175), same data."""
+    expected = [[0, 1, 2], [1, 3], [], [0, 2, 3, 4]]
+    p = str(tmp_path / "test.vis")
+    fusion.write_points_visibility(p, expected)
+    actual = fusion.read_points_visibility(p, len(expected))
+    assert [list(a) for a in actual] == expected
+    fusion.write_points_visibility(p, [[0, 1], [2]])
+    with pytest.raises(ValueError):
+        fusion.read_points_visibility(p, 5)
