@@ -161,7 +161,7 @@ def ba_secondary(a, local_rank, with_cpu, rank=0, world=1, dev=None):
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import ba_oracle
         c = fp.copy()
-        sc = est.solve_flat(c, est.SolverOptions(max_num_iterations=3), solve_fn=ba_oracle.solve_fn)
+        sc = est.solve_flat(c, est.SolverOptions(max_num_iterations=9), solve_fn=ba_oracle.solve_fn)  # ~10 s on the box's host cores
         out["cpu_baseline"] = dict(value=sc.num_iterations / sc.lm_seconds, unit="LM-iterations/s",
                                    cores=int(ba_oracle.lib().bao_num_threads()), kind="port",
                                    sample=f"oracle/ba_oracle.c (fp64, OpenMP), first {sc.num_iterations} LM iterations "
