@@ -1136,6 +1136,75 @@ __global__ void __launch_bounds__(TILE_PTS) ba_point_pass_tiled_kernel(View V, c
   }
 }
 
+// Point-major reductions over the same tiles, columns staged through LDS (coalesced loads over the tile's
+// observation range, the per-point segment walk reads LDS).
+// MODE 0: g_p = E^T r, the column norms of E and E^T E (upper triangle, [6][n_points]) of the points
+//         (replaces ba_point_grad_kernel + ba_point_gram_kernel when tiles exist)
+// MODE 1: model cost change -(J step).(r + J step / 2) with J step = -(jx + E y_p), partial sum per tile
+template <int MODE>
+__global__ void __launch_bounds__(TILE_PTS) ba_point_reduce_tiled_kernel(View V, const double* __restrict__ jx,
+                                                                         const double* __restrict__ dpv,
+                                                                         double* __restrict__ out0,
+                                                                         double* __restrict__ out1,
+                                                                         double* __restrict__ Craw) {
+  __shared__ double sJ[6][TILE_OBS];
+  __shared__ double sr[2][TILE_OBS];
+  __shared__ double sx[MODE == 1 ? 2 : 1][MODE == 1 ? TILE_OBS : 1];
+  const int t = blockIdx.x;
+  const int p0 = V.tile_pt[t], p1 = V.tile_pt[t + 1];
+  const int a0 = V.pt_ptr[p0], na = V.pt_ptr[p1] - a0;
+  const size_t N = (size_t)V.n_obs;
+  for (int i = threadIdx.x; i < na; i += TILE_PTS) {
+#pragma unroll
+    for (int c = 0; c < 6; ++c) sJ[c][i] = V.Jpt[(size_t)c * N + a0 + i];
+    sr[0][i] = V.res_p[a0 + i];
+    sr[1][i] = V.res_p[N + a0 + i];
+    if (MODE == 1) {
+      sx[0][i] = jx[a0 + i];
+      sx[1][i] = jx[N + a0 + i];
+    }
+  }
+  __syncthreads();
+  const int j = p0 + threadIdx.x;
+  double acc = 0.0;
+  if (j < p1) {
+    const int off = V.pt_off[j];
+    const int beg = V.pt_ptr[j] - a0, end = V.pt_ptr[j + 1] - a0;
+    if (MODE == 0) {
+      double C[6] = {0, 0, 0, 0, 0, 0};
+      if (off >= 0) {
+        double g[3] = {0, 0, 0};
+        for (int o = beg; o < end; ++o)
+#pragma unroll
+          for (int r = 0; r < 2; ++r) {
+            const double rr = sr[r][o];
+            const double a = sJ[r * 3][o], b = sJ[r * 3 + 1][o], c = sJ[r * 3 + 2][o];
+            g[0] += a * rr; g[1] += b * rr; g[2] += c * rr;
+            C[0] += a * a; C[1] += a * b; C[2] += a * c; C[3] += b * b; C[4] += b * c; C[5] += c * c;
+          }
+        for (int c = 0; c < 3; ++c) out0[off + c] = g[c];
+        out1[off] = C[0]; out1[off + 1] = C[3]; out1[off + 2] = C[5];  // column norms = diagonal of E^T E
+      }
+      for (int e = 0; e < 6; ++e) Craw[(size_t)e * V.n_points + j] = C[e];
+    } else {
+      double y[3] = {0.0, 0.0, 0.0};
+      if (off >= 0) { y[0] = dpv[off]; y[1] = dpv[off + 1]; y[2] = dpv[off + 2]; }
+      for (int o = beg; o < end; ++o)
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          double m = sx[r][o];
+          if (off >= 0) m += sJ[r * 3][o] * y[0] + sJ[r * 3 + 1][o] * y[1] + sJ[r * 3 + 2][o] * y[2];
+          m = -m;
+          acc -= m * (sr[r][o] + 0.5 * m);
+        }
+    }
+  }
+  if (MODE == 1) {
+    acc = block_sum(acc);
+    if (threadIdx.x == 0) out0[blockIdx.x] = acc;
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // Observation-parallel passes
 // ------------------------------------------------------------------------------------------
@@ -2358,7 +2427,7 @@ struct Solver {
     Craw.alloc(6 * (size_t)p.num_points); tbuf.alloc(poff); tmpc.alloc(n_c);
     scalars.alloc(NSCALAR);
     pcg_part.alloc((size_t)grid_for(n_blk, 256) + 1);
-    partials.alloc((size_t)std::max(grid_for(n, 256), grid_for(std::max(p.num_points, 1), 256)) + 1);
+    partials.alloc((size_t)std::max(grid_for(n, 256), std::max(p.num_points, 1)) + 1);  // one slot per linearise workgroup / point tile
 
     V.n_obs = n; V.n_poses = p.num_poses; V.n_cams = p.num_cams; V.n_points = p.num_points;
     V.n_c = n_c; V.n_p = poff; V.n_blk = n_blk; V.n_chunks = (int)h_chunk_blk.size();
@@ -2423,7 +2492,14 @@ struct Solver {
     }
     BA_HIP(hipMemsetAsync(gp.p, 0, sizeof(double) * std::max(V.n_p, 1), st));
     BA_HIP(hipMemsetAsync(diag_p.p, 0, sizeof(double) * std::max(V.n_p, 1), st));
-    BA_LAUNCH(ba_point_grad_kernel, dim3(grid_for(V.n_points, 128)), dim3(128), st, V, gp.p, diag_p.p);
+    if (V.n_tiles > 0)
+      BA_LAUNCH(ba_point_reduce_tiled_kernel<0>, dim3(V.n_tiles), dim3(TILE_PTS), st, V, nullptr, nullptr, gp.p, diag_p.p, Craw.p);
+    else {
+      BA_LAUNCH(ba_point_grad_kernel, dim3(grid_for(V.n_points, 128)), dim3(128), st, V, gp.p, diag_p.p);
+      BA_LAUNCH(ba_point_gram_kernel, dim3(grid_for(V.n_points, 128)), dim3(128), st, V, Craw.p);
+    }
+    // E^T E of the points changes only with the linearisation: summed over ranks here, once
+    if (!comm.by_point) comm.allreduce(Craw.p, 6 * (size_t)V.n_points, st);
     if (use_priors())
       BA_LAUNCH(ba_prior_accumulate_kernel<0>, dim3(grid_for(Q.n_tblk, 64)), dim3(64), st, V, Q, gc.p, diag_c.p);
     comm.allreduce(gc.p, V.n_c, st);
@@ -2611,8 +2687,6 @@ struct Solver {
                          opt.min_lm_diagonal, opt.max_lm_diagonal, Dc.p);
       BA_LAUNCH(ba_lm_diag_kernel, dim3(std::max(gvp, 1)), dim3(256), st, np, diag_p.p, radius,
                          opt.min_lm_diagonal, opt.max_lm_diagonal, Dp.p);
-      BA_LAUNCH(ba_point_gram_kernel, dim3(grid_for(V.n_points, 128)), dim3(128), st, V, Craw.p);
-      if (!comm.by_point) comm.allreduce(Craw.p, 6 * (size_t)V.n_points, st);
       BA_LAUNCH(ba_point_blocks_kernel, dim3(grid_for(V.n_points, 128)), dim3(128), st, V, Craw.p, Dp.p, Cinv.p);
       int lin_iters = 0;
       bool mfma_pending = false;
@@ -2664,8 +2738,13 @@ struct Solver {
       BA_LAUNCH(ba_axpby_kernel, dim3(std::max(gvc, 1)), dim3(256), st, nc, -1.0, x.p, nullptr, stepc.p);
       BA_LAUNCH(ba_axpby_kernel, dim3(std::max(gvp, 1)), dim3(256), st, np, -1.0, dp.p, nullptr, stepp.p);
       // model cost change -(J step).(r + J step / 2): jx = J_c y_c of the back-substitution is still in place
-      BA_LAUNCH(ba_model_from_jx_kernel, dim3(grid_for(V.n_points, 256)), dim3(256), st, V, jx.p, dp.p, partials.p);
-      BA_LAUNCH(ba_final_sum_kernel, dim3(1), dim3(1024), st, partials.p, grid_for(V.n_points, 256), scalars.p + S_MODEL);
+      if (V.n_tiles > 0) {
+        BA_LAUNCH(ba_point_reduce_tiled_kernel<1>, dim3(V.n_tiles), dim3(TILE_PTS), st, V, jx.p, dp.p, partials.p, nullptr, nullptr);
+        BA_LAUNCH(ba_final_sum_kernel, dim3(1), dim3(1024), st, partials.p, V.n_tiles, scalars.p + S_MODEL);
+      } else {
+        BA_LAUNCH(ba_model_from_jx_kernel, dim3(grid_for(V.n_points, 256)), dim3(256), st, V, jx.p, dp.p, partials.p);
+        BA_LAUNCH(ba_final_sum_kernel, dim3(1), dim3(1024), st, partials.p, grid_for(V.n_points, 256), scalars.p + S_MODEL);
+      }
       if (use_priors()) BA_LAUNCH(ba_prior_model_kernel, dim3(1), dim3(256), st, Q, stepc.p, scalars.p + S_MODEL);
       const double model_change = scalar_sum(S_MODEL);  // (synchronises the stream)
       if (mfma_pending) {
