@@ -1482,6 +1482,58 @@ __global__ void __launch_bounds__(64) ba_block_gram_kernel(View V, const double*
   }
 }
 
+// The same contraction with the operands staged through LDS: per trip the wave loads 32 consecutive
+// observations of every Jacobian column of the block (and of G) as contiguous 256-byte segments -- half a
+// wave per (row, column) pair -- and the 16 slabs of the trip feed the matrix core from LDS. In the kernel
+// above every lane loads its own operand: 16 different columns per load instruction. Same slab order, same
+// zero padding: the accumulated tile is bit-identical.
+constexpr int GRAM_TRIP = 32;
+__global__ void __launch_bounds__(64) ba_block_gram_lds_kernel(View V, const double* __restrict__ G) {
+  __shared__ double sJ[2][16][GRAM_TRIP + 1];  // [row][column][observation], padded against bank conflicts
+  __shared__ double sG[3][GRAM_TRIP];
+  const int ch = blockIdx.x;
+  const int b = V.chunk_blk[ch];
+  const int kind = V.blk_kind[b], dim = V.blk_dim[b];
+  const int lane = threadIdx.x;
+  const int i = lane & 15, k = lane >> 4;  // column, row-in-slab
+  const int r = k & 1, oo = k >> 1;        // residual row, observation within the slab
+  const int half = lane >> 5, lo = lane & 31;
+  const int beg = V.chunk_beg[ch], end = V.chunk_end[ch];
+  const size_t N = (size_t)V.n_obs;
+  v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+  const bool col_ok = i < dim;
+  for (int s = beg; s < end; s += GRAM_TRIP) {
+    const int n = min(GRAM_TRIP, end - s);
+    for (int cr = half; cr < 2 * dim; cr += 2) {
+      const int rr = cr & 1, c = cr >> 1;
+      sJ[rr][c][lo] = lo < n ? blk_col(V, kind, rr, c)[s + lo] : 0.0;
+    }
+    for (int e = lane; e < 3 * GRAM_TRIP; e += 64) {
+      const int g = e / GRAM_TRIP, o = e - g * GRAM_TRIP;
+      sG[g][o] = o < n ? G[(size_t)g * N + s + o] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int u = 0; u < GRAM_TRIP / 2; ++u) {
+      const int o = 2 * u + oo;
+      double a = 0.0, bb = 0.0;
+      if (col_ok) {
+        const double j0 = sJ[0][i][o], j1 = sJ[1][i][o];
+        const double g00 = sG[0][o], g01 = sG[1][o], g11 = sG[2][o];
+        a = r ? j1 : j0;
+        bb = r ? j1 - (g01 * j0 + g11 * j1) : j0 - (g00 * j0 + g01 * j1);
+      }
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) {
+    const int row = k + 4 * reg;
+    if (row < dim && i < dim) V.cpart[(size_t)ch * V.bd * V.bd + row * dim + i] = acc[reg];
+  }
+}
+
 // Cross terms - sum_{o != o2 in (b,j)} (J_b,o^T E_o) C_j^-1 (J_b,o2^T E_o2)^T of observation pairs of one
 // point inside one block (only launched when such pairs exist). One lane per observation.
 template <int BD>
@@ -2695,7 +2747,9 @@ struct Solver {
         if (V.n_chunks > 0) {
           BA_LAUNCH(ba_obs_schur_g_kernel, dim3(grid_for(V.n_obs, 256)), dim3(256), st, V, Cinv.p, Gobs.p);
           BA_HIP(hipEventRecord(ev2, st));
-          BA_LAUNCH(ba_block_gram_kernel, dim3(V.n_chunks), dim3(64), st, V, Gobs.p);
+          static const bool gram_lds = [] { const char* e = std::getenv("COLMAP_AMD_BA_GRAM_LDS"); return !e || std::atoi(e) != 0; }();
+          if (gram_lds) BA_LAUNCH(ba_block_gram_lds_kernel, dim3(V.n_chunks), dim3(64), st, V, Gobs.p);
+          else BA_LAUNCH(ba_block_gram_kernel, dim3(V.n_chunks), dim3(64), st, V, Gobs.p);
           BA_HIP(hipEventRecord(ev3, st));
           mfma_pending = true;
           BA_LAUNCH(ba_block_mat_finalize_kernel<false>, dim3(grid_for(V.n_blk, 128)), dim3(128), st, V, M.p);
