@@ -199,11 +199,33 @@ def pmc_traffic(images_per_launch):
         return None
 
 
+def spawn_ranks(a):
+    """`python bench.py --gpus N` (N > 1) without a launcher around it: become the launcher. Re-executes
+    this script under torch.distributed.run with one rank per GPU (RCCL over xGMI); rank 0 of that job
+    prints the single JSON line, `n_gpus` in it is the world size RCCL saw."""
+    import socket
+    n_dev = torch.cuda.device_count()
+    if n_dev < a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} requested but only {n_dev} GPU(s) are visible")
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    sys.stdout.flush()
+    os.execvpe(cmd[0], cmd, env)
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(a)  # does not return
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks")
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

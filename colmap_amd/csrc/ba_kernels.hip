@@ -43,6 +43,8 @@
 #include <string>
 #include <vector>
 
+extern "C" void pm_release_cached_memory(void);  // pm_api.cpp (same library)
+
 namespace {
 
 thread_local std::string g_ba_error;
@@ -2106,7 +2108,13 @@ struct Buf {
   void alloc(size_t count) {
     release();
     n = count;
-    BA_HIP(hipMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(count, 1) * sizeof(T)));
+    hipError_t e_alloc = hipMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(count, 1) * sizeof(T));
+    if (e_alloc == hipErrorOutOfMemory) {  // memory cached by the PatchMatch buffer pool is not "in use"
+      (void)hipGetLastError();
+      pm_release_cached_memory();
+      e_alloc = hipMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(count, 1) * sizeof(T));
+    }
+    BA_HIP(e_alloc);
     BA_HIP(hipMemset(p, 0, std::max<size_t>(count, 1) * sizeof(T)));
   }
   void upload(const std::vector<T>& h) {

@@ -47,6 +47,8 @@
 
 #define FUSION_API __attribute__((visibility("default")))
 
+extern "C" void pm_release_cached_memory(void);  // pm_api.cpp (same library)
+
 namespace {
 
 thread_local std::string g_error;
@@ -494,7 +496,13 @@ struct DevBuf {
   void alloc(size_t count) {
     release();
     n = count;
-    FU_HIP(hipMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(count, 1) * sizeof(T)));
+    hipError_t e_alloc = hipMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(count, 1) * sizeof(T));
+    if (e_alloc == hipErrorOutOfMemory) {  // memory cached by the PatchMatch buffer pool is not "in use"
+      (void)hipGetLastError();
+      pm_release_cached_memory();
+      e_alloc = hipMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(count, 1) * sizeof(T));
+    }
+    FU_HIP(e_alloc);
   }
   void upload(const T* h, size_t count) {
     alloc(count);

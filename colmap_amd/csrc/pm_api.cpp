@@ -49,7 +49,9 @@ struct PmError : std::runtime_error {
 // would map, clear and unmap those pages every time and hipFree synchronises the device). Exact-size
 // free lists per device; bounded by COLMAP_AMD_PM_POOL_GB (default 64); pm_release_cached_memory()
 // returns everything to the driver. A buffer only comes back here after pm_destroy synchronised the
-// handle's stream, so the next user cannot race with the previous one.
+// handle's own stream AND the stream its last (batched) run was enqueued on, so the next user cannot
+// race with the previous one. The cap is additionally bounded by a quarter of the device's memory,
+// and a failed hipMalloc releases the pool and retries once (cached memory must never cause an OOM).
 class DevPool {
  public:
   static DevPool& Get() {
@@ -93,6 +95,8 @@ class DevPool {
   DevPool() {
     const char* e = getenv("COLMAP_AMD_PM_POOL_GB");
     cap_ = static_cast<size_t>((e ? atof(e) : 64.0) * (1ull << 30));
+    size_t free_b = 0, total_b = 0;
+    if (!e && hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b > 0) cap_ = std::min(cap_, total_b / 4);
   }
   std::mutex mu_;
   std::map<std::pair<int, size_t>, std::vector<void*>> free_;
@@ -109,7 +113,15 @@ struct DevBuf {
     if (n == 0) return;
     HIP_CALL(hipGetDevice(&dev));
     void* p = DevPool::Get().Take(dev, n * sizeof(T));
-    if (!p) HIP_CALL(hipMalloc(&p, n * sizeof(T)));
+    if (!p) {
+      hipError_t e = hipMalloc(&p, n * sizeof(T));
+      if (e == hipErrorOutOfMemory) {
+        (void)hipGetLastError();
+        DevPool::Get().Release();
+        e = hipMalloc(&p, n * sizeof(T));
+      }
+      HIP_CALL(e);
+    }
     ptr = static_cast<T*>(p);
     count = n;
   }
@@ -1005,6 +1017,10 @@ void pm_destroy(pm_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
+  // a non-leader handle of a batched run has its kernels on the leader's stream; that stream may
+  // already be destroyed (the leader went first), in which case only a device-wide wait is safe
+  // (pm_synchronize resets run_stream, so this is the exception / GC path only)
+  if (h->run_stream && h->run_stream != h->stream) (void)hipDeviceSynchronize();
   delete h;
 }
 

@@ -653,4 +653,5 @@ class PatchMatchController:
         t = time.time()
         out = self._run_pass(opt, maps)
         self.timings["geometric_s" if opt.geom_consistency else "photometric_s"] = time.time() - t
+        release_cached_memory()  # the next stage (fusion, another workspace) gets the HBM back
         return out

@@ -1,0 +1,194 @@
+"""GPU tests that pin the checkers -- and through them the HIP path -- against the REFERENCE ITSELF:
+`oracle/_ref/libref_pm.so` is the reference's own patch_match_cuda.cu / gpu_mat_prng.cu /
+gpu_mat_ref_image.cu compiled for gfx950 where they lie (oracle/Makefile `ref`, oracle/ref_shim/README.md;
+only the texture fetch is a software stand-in, because gfx950 has no image instructions).
+
+What can and cannot be equal:
+  * integer work (PRNG states, the re-quantised reference image, the first random depth) is BIT-EXACT;
+  * deterministic float stages (bilateral sums, random normals, ComputeInitialCost) differ from
+    `pm_oracle order=0` only through exp / sin / cos (device libm in the reference build, fixed
+    polynomials in the oracle and the HIP kernel: <= 2 ulp each): tolerances 2e-6 / 2e-5 below;
+  * full solves are a stochastic argmin over those values, one flipped comparison changes a pixel's
+    trajectory: compared through agreement statistics (stated per test, with the observed values in
+    profiles/r03_pm_ref_parity.json) and against ground truth.
+The HIP path is compared with the reference in the same three ways (its arithmetic order is `order=1`,
+bit-equal to the HIP kernel in tests/test_pm_gpu.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from pm_common import scene, oracle_inputs, hip_problem, paired_options
+from colmap_amd import synthetic as syn
+import ref_pm
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(not ref_pm.available(), reason="oracle/_ref/libref_pm.so not built (make -C oracle ref)")]
+
+_STATS = {}
+
+
+def _record(name, **kw):
+    _STATS[name] = {k: (float(v) if np.isscalar(v) else v) for k, v in kw.items()}
+    out = os.path.join(os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))),
+                       "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "pm_ref_parity.json"), "w") as f:
+        json.dump(_STATS, f, indent=1)
+
+
+def _agreement(a, b):
+    """Fraction of pixels whose depths agree to 1e-3 / 1e-2 relative (both kept or both filtered)."""
+    both = (a > 0) & (b > 0)
+    same_kept = ((a > 0) == (b > 0)).mean()
+    rel = np.abs(a[both] - b[both]) / b[both]
+    return dict(same_kept=same_kept, within_1e3=(rel < 1e-3).mean(), within_1e2=(rel < 1e-2).mean(),
+                median_rel=float(np.median(rel)))
+
+
+def test_reference_constructor_state(pm_oracle):
+    """PatchMatchCuda's constructor (reference patch_match_cuda.cu:1278-1290): PRNG init
+    (gpu_mat_prng.cu:36-48), FilterKernel (gpu_mat_ref_image.cu:39-81), random depth
+    (gpu_mat.h:370-387) and InitNormalMap, against the oracle's restatement."""
+    views = scene()
+    imgs = oracle_inputs(views)
+    dmin, dmax = syn.depth_range(views, 2)
+    o = pm_oracle.default_options(depth_min=dmin, depth_max=dmax, geom_consistency=0, filter=0, max_sweeps=0)
+    ref = ref_pm.RefPatchMatch(o, imgs, 2, [0, 1, 3, 4])
+    st = ref.state()
+    want = pm_oracle.run(o, imgs, 2, [0, 1, 3, 4])
+    o_img, o_s, o_ss = pm_oracle.filter_ref_image(views[2].gray, 5, 1, 5.0, float(np.float32(0.2)))
+    assert np.array_equal(st["ref_image"], o_img)
+    assert np.abs(st["sum"] - o_s).max() < 2e-6 and np.abs(st["sqsum"] - o_ss).max() < 2e-6
+    assert np.array_equal(st["depth"], want["depth"])  # first draw of every pixel's stream, bit-exact
+    assert np.abs(st["normal"] - want["normal"]).max() < 2e-6
+    # every pixel's XORWOW state is the oracle's stream for that pixel's seed, advanced by the draws of
+    # the constructor (1 depth + the normal's rejection loop): found within the first 64 positions
+    H, W = st["depth"].shape
+    L = pm_oracle.lib()
+    import ctypes as C
+    rs = pm_oracle.RNG()
+    # the seed is InitRandomStateKernel's linear thread id (32 x 16 blocks, gpu_mat.h:159-160,333-339)
+    max_adv = 0
+    for (r, c) in [(0, 0), (0, W - 1), (H - 1, 0), (H - 1, W - 1), (H // 2, W // 3), (33, 34), (15, 32), (16, 31)]:
+        gx = (W - 1) // 32 + 1
+        seed = ((r // 16) * gx + (c // 32)) * 512 + (r % 16) * 32 + (c % 32)
+        L.pmo_rng_init(C.byref(rs), C.c_uint64(seed))
+        target = tuple(int(v) for v in st["rng"][r, c])
+        for n in range(65):
+            if tuple(rs.x) + (rs.d,) == target:
+                break
+            L.pmo_rng_next(C.byref(rs))
+        else:
+            raise AssertionError(f"PRNG state of pixel ({r},{c}) is not on the oracle's stream for seed {seed}")
+        max_adv = max(max_adv, n)
+    _record("constructor_state", sum_max_abs=np.abs(st["sum"] - o_s).max(), sqsum_max_abs=np.abs(st["sqsum"] - o_ss).max(),
+            normal_max_abs=np.abs(st["normal"] - want["normal"]).max(), rng_max_draws=max_adv)
+    ref.close()
+
+
+@pytest.mark.parametrize("shape", ["96x72_S4", "96x72_S20"])
+def test_reference_initial_cost(pm_oracle, shape):
+    """ComputeInitialCost (patch_match_cuda.cu:930-985 -> PhotoConsistencyCostComputer::Compute
+    :489-593) of the reference vs the oracle in the reference's order (order=0) and vs the HIP kernel."""
+    from colmap_amd import mvs
+    if shape == "96x72_S4":
+        views, r, src = scene(), 2, [0, 1, 3, 4]
+    else:
+        views = scene(22, 96, 72, 3.6 * 21)
+        r, src = 10, [i for i in range(21) if i != 10]
+    imgs = oracle_inputs(views)
+    dmin, dmax = syn.depth_range(views, r)
+    o = pm_oracle.default_options(depth_min=dmin, depth_max=dmax, geom_consistency=0, filter=0, num_iterations=0)
+    ref = ref_pm.RefPatchMatch(o, imgs, r, src)
+    got = ref.run()
+    ref.close()
+    o.num_iterations, o.max_sweeps, o.order = 5, 0, 0
+    want = pm_oracle.run(o, imgs, r, src, want_cost=True)
+    d0 = np.abs(got["cost"] - want["cost"])
+    assert d0.max() < 2e-5, d0.max()
+    o1, h = paired_options(pm_oracle, depth_min=dmin, depth_max=dmax, geom_consistency=0, filter=0, max_sweeps=0)
+    pm = mvs.PatchMatch(h, hip_problem(views, r, src))
+    pm.Run()
+    d1 = np.abs(got["cost"] - pm.GetCostMap())
+    assert d1.max() < 5e-4 and d1.mean() < 2e-5, (d1.max(), d1.mean())
+    _record("initial_cost_" + shape, oracle_order0_max_abs=d0.max(), oracle_order0_mean_abs=d0.mean(),
+            hip_max_abs=d1.max(), hip_mean_abs=d1.mean())
+
+
+def _solve_three_ways(pm_oracle, views, r, src, maps=None, **kw):
+    from colmap_amd import mvs
+    imgs = oracle_inputs(views, maps is not None, maps)
+    dmin, dmax = syn.depth_range(views, r)
+    o = pm_oracle.default_options(depth_min=dmin, depth_max=dmax, **kw)
+    ref = ref_pm.RefPatchMatch(o, imgs, r, src)
+    out_ref = ref.run()
+    ref.close()
+    o.order = 0
+    out_o0 = pm_oracle.run(o, imgs, r, src)
+    _, h = paired_options(pm_oracle, depth_min=dmin, depth_max=dmax, **kw)
+    pm = mvs.PatchMatch(h, hip_problem(views, r, src, maps))
+    pm.Run()
+    out_hip = dict(depth=pm.GetDepthMap(), normal=pm.GetNormalMap(), mask=pm.GetConsistencyMask())
+    return out_ref, out_o0, out_hip
+
+
+def _gt_stats(depth, gt):
+    kept = depth > 0
+    rel = np.abs(depth[kept] - gt[kept]) / gt[kept]
+    return dict(kept=kept.mean(), median_rel=float(np.median(rel)), within_1pct=(rel < 0.01).mean())
+
+
+def test_reference_full_solve_config0_photometric(pm_oracle):
+    """BASELINE.json config[0] (3 x 640 x 480, f = 600, S = 2, default options, photometric + filter):
+    the reference, the oracle in the reference's order and the HIP path solve the same problem from
+    the same PRNG streams. Required: the three depth maps agree pixel-wise to 1 % on >= 90 % of the
+    pixels all of them keep, keep the same pixels on >= 95 %, and have the same accuracy against
+    ground truth (median relative error within 2e-4, fraction within 1 % within 0.02)."""
+    views = syn.make_scene(3, 640, 480, focal=600.0, arc_deg=8.0)
+    out_ref, out_o0, out_hip = _solve_three_ways(pm_oracle, views, 1, [0, 2], geom_consistency=0, filter=1)
+    gt = views[1].depth
+    a0, a1 = _agreement(out_o0["depth"], out_ref["depth"]), _agreement(out_hip["depth"], out_ref["depth"])
+    g = {k: _gt_stats(v["depth"], gt) for k, v in (("reference", out_ref), ("oracle_order0", out_o0), ("hip", out_hip))}
+    _record("config0_photometric", oracle_order0_vs_reference=a0, hip_vs_reference=a1, ground_truth=g)
+    for a in (a0, a1):
+        assert a["same_kept"] >= 0.95 and a["within_1e2"] >= 0.90, a
+    for k in ("oracle_order0", "hip"):
+        assert abs(g[k]["median_rel"] - g["reference"]["median_rel"]) < 2e-4, g
+        assert abs(g[k]["within_1pct"] - g["reference"]["within_1pct"]) < 0.02, g
+        assert abs(g[k]["kept"] - g["reference"]["kept"]) < 0.02, g
+
+
+def test_reference_full_solve_s20_geometric(pm_oracle):
+    """config[2]'s pass (geometric consistency + both filters, S = 20, M = 15) on 96 x 72 images with
+    ground-truth source maps, two iterations: same agreement bars as above."""
+    views = scene(22, 96, 72, 3.6 * 21)
+    r = 11
+    src = [i for i in range(1, 22) if i != r]
+    maps = [(v.depth, v.normal) for v in views]
+    out_ref, out_o0, out_hip = _solve_three_ways(pm_oracle, views, r, src, maps=maps, geom_consistency=1, filter=1,
+                                                 num_iterations=2)
+    gt = views[r].depth
+    a0, a1 = _agreement(out_o0["depth"], out_ref["depth"]), _agreement(out_hip["depth"], out_ref["depth"])
+    g = {k: _gt_stats(v["depth"], gt) for k, v in (("reference", out_ref), ("oracle_order0", out_o0), ("hip", out_hip))}
+    m0 = (out_o0["mask"] == out_ref["mask"]).mean()
+    m1 = (out_hip["mask"] == out_ref["mask"]).mean()
+    _record("s20_geometric", oracle_order0_vs_reference=a0, hip_vs_reference=a1, ground_truth=g,
+            mask_equal_oracle=m0, mask_equal_hip=m1)
+    for a in (a0, a1):
+        assert a["same_kept"] >= 0.95 and a["within_1e2"] >= 0.90, a
+    assert m0 >= 0.95 and m1 >= 0.95
+    for k in ("oracle_order0", "hip"):
+        assert abs(g[k]["within_1pct"] - g["reference"]["within_1pct"]) < 0.03, g
+
+
+def test_reference_first_sweeps_s4(pm_oracle):
+    """One iteration (four sweeps, no filter) on the 5-view scene: trajectories have had little time to
+    diverge, so the bar is tighter -- >= 97 % of the pixels within 1e-3 relative depth of the reference."""
+    views = scene()
+    out_ref, out_o0, out_hip = _solve_three_ways(pm_oracle, views, 2, [0, 1, 3, 4], geom_consistency=0, filter=0,
+                                                 num_iterations=1)
+    a0, a1 = _agreement(out_o0["depth"], out_ref["depth"]), _agreement(out_hip["depth"], out_ref["depth"])
+    _record("first_iteration_s4", oracle_order0_vs_reference=a0, hip_vs_reference=a1)
+    assert a0["within_1e3"] >= 0.90 and a1["within_1e3"] >= 0.85, (a0, a1)
