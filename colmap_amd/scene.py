@@ -535,7 +535,12 @@ def synthesize_flat(num_frames: int, num_points: int, track_length: int, seed: i
     cams = np.zeros((num_frames, 16))  # BA_CAM_STRIDE
     model = np.full(num_frames, SIMPLE_RADIAL, np.int32)
     cams[:, :4] = [1280.0, 512.0, 384.0, 0.05]
-    if mixed_models:
+    if mixed_models == "three":  # BASELINE config[4] "mixed camera models": thirds of SIMPLE_RADIAL / PINHOLE / OPENCV
+        model[1::3] = PINHOLE
+        cams[1::3, :4] = [1280.0, 1280.0, 512.0, 384.0]
+        model[2::3] = OPENCV
+        cams[2::3, :8] = [1280.0, 1280.0, 512.0, 384.0, 0.05, 0.01, 1e-3, -1e-3]
+    elif mixed_models:
         model[1::2] = PINHOLE
         cams[1::2, :4] = [1280.0, 1280.0, 512.0, 384.0]
     # every frame sees every point (all points project inside 1024x768 from radius 5); each
@@ -551,9 +556,13 @@ def synthesize_flat(num_frames: int, num_points: int, track_length: int, seed: i
         obs_pose.sort(axis=1)
     obs_point = np.repeat(np.arange(num_points), track_length)
     obs_pose = obs_pose.reshape(-1)
-    uvw = np.einsum("nij,nj->ni", Rs[obs_pose], pts[obs_point]) + poses[obs_pose, 4:]
+    # (column-wise: np.einsum over the gathered 20 M x 3 x 3 rotations of config[4] takes a minute)
+    R9, P = Rs.reshape(num_frames, 9), pts[obs_point]
+    uvw = poses[obs_pose, 4:]
+    for i in range(3):
+        uvw[:, i] += R9[obs_pose, 3 * i] * P[:, 0] + R9[obs_pose, 3 * i + 1] * P[:, 1] + R9[obs_pose, 3 * i + 2] * P[:, 2]
     xy = np.zeros((len(obs_pose), 2))
-    for m in (SIMPLE_RADIAL, PINHOLE):
+    for m in (SIMPLE_RADIAL, PINHOLE, OPENCV):
         sel = model[obs_pose] == m
         if sel.any():
             # per-observation params
@@ -563,8 +572,15 @@ def synthesize_flat(num_frames: int, num_points: int, track_length: int, seed: i
             if m == SIMPLE_RADIAL:
                 a = 1 + pr[:, 3] * (uu * uu + vv * vv)
                 xy[sel] = np.stack([pr[:, 0] * a * uu + pr[:, 1], pr[:, 0] * a * vv + pr[:, 2]], 1)
-            else:
+            elif m == PINHOLE:
                 xy[sel] = np.stack([pr[:, 0] * uu + pr[:, 2], pr[:, 1] * vv + pr[:, 3]], 1)
+            else:  # OPENCV (reference sensor/models.h OpenCVCameraModel::Distortion)
+                k1, k2, p1, p2 = pr[:, 4], pr[:, 5], pr[:, 6], pr[:, 7]
+                r2 = uu * uu + vv * vv
+                rad = k1 * r2 + k2 * r2 * r2
+                du = uu * rad + 2 * p1 * uu * vv + p2 * (r2 + 2 * uu * uu)
+                dv = vv * rad + 2 * p2 * uu * vv + p1 * (r2 + 2 * vv * vv)
+                xy[sel] = np.stack([pr[:, 0] * (uu + du) + pr[:, 2], pr[:, 1] * (vv + dv) + pr[:, 3]], 1)
     if noise is not None:
         if noise.rig_from_world_rotation_stddev > 0:
             ang = np.deg2rad(np.clip(rng.normal(0, noise.rig_from_world_rotation_stddev, num_frames), -180, 180))

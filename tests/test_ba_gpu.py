@@ -241,6 +241,60 @@ def test_full_size_properties():
     assert s2.final_cost == s.final_cost and np.array_equal(again.poses, fp.poses)
 
 
+def test_baseline_config3_cost_log_matches_oracle():
+    """BASELINE.json config[3] itself (1000 cameras x 200k points, SIMPLE_RADIAL, 2 M observations): the
+    HIP solve against the oracle on the first 9 LM iterations (what bench.py times the oracle on) --
+    every logged cost to 1e-7 relative, the same PCG iteration counts, the same step decisions."""
+    fp = _flat(1000, 200000, 10, seed=42)
+    assert est.fix_gauge_two_cams(fp)
+    (a, want), (b, got) = _both(fp, max_num_iterations=9)
+    assert got.num_residuals == want.num_residuals == 4000000
+    assert got.num_iterations == want.num_iterations and got.num_successful_steps == want.num_successful_steps
+    assert abs(got.initial_cost - want.initial_cost) <= 1e-12 * want.initial_cost
+    np.testing.assert_allclose(got.log_cost, want.log_cost, rtol=1e-7)
+    np.testing.assert_array_equal(got.log_linear_iters[:4], want.log_linear_iters[:4])
+    np.testing.assert_allclose(b.points, a.points, atol=1e-6)
+    np.testing.assert_allclose(b.poses, a.poses, atol=1e-6)
+
+
+def test_baseline_config4_mixed_models_matches_oracle():
+    """BASELINE.json config[4]'s ingredients at a tenth of its size (500 cameras x 200k points, track 10,
+    thirds of SIMPLE_RADIAL / PINHOLE / OPENCV: the <8, 8> camera-block tier with three models in one
+    launch) against the oracle, first 8 LM iterations."""
+    fp = _flat(500, 200000, 10, seed=43, mixed="three")
+    assert est.fix_gauge_two_cams(fp)
+    assert set(np.unique(fp.cam_model)) == {scene.SIMPLE_RADIAL, scene.PINHOLE, scene.OPENCV}
+    (a, want), (b, got) = _both(fp, max_num_iterations=8)
+    assert got.num_residuals == want.num_residuals == 4000000
+    assert got.num_effective_parameters == want.num_effective_parameters
+    np.testing.assert_allclose(got.log_cost, want.log_cost, rtol=1e-7)
+    np.testing.assert_allclose(b.points, a.points, atol=1e-6)
+    np.testing.assert_allclose(b.cams, a.cams, rtol=1e-7, atol=1e-6)
+
+
+def test_baseline_config4_full_size_properties():
+    """BASELINE.json config[4] at full size on ONE GPU (5000 cameras x 2 M points, 20 M observations,
+    mixed SIMPLE_RADIAL / PINHOLE / OPENCV; ~7 GB of Jacobian in HBM) through size-independent
+    properties: counts, monotone cost, the 1 px noise floor, constant blocks bit-identical."""
+    fp = _flat(5000, 2000000, 10, seed=42, mixed="three")
+    assert est.fix_gauge_two_cams(fp)
+    fp.point_const[::10000] = 1
+    orig_points, orig_cams = fp.points[::10000].copy(), fp.cams[:, 2:4].copy()
+    s = est.solve_flat(fp, est.SolverOptions(max_num_iterations=10), gpu_index=0)
+    assert s.IsSolutionUsable()
+    assert s.num_residuals == 2 * len(fp.obs_pose) == 40000000
+    n_sr, n_ph, n_cv = [(fp.cam_model == m).sum() for m in (scene.SIMPLE_RADIAL, scene.PINHOLE, scene.OPENCV)]
+    assert s.num_effective_parameters == 6 * 4998 + 5 + 2 * n_sr + 2 * n_ph + 6 * n_cv + 3 * (2000000 - 200)
+    assert np.all(np.diff(s.log_cost) <= 1e-9 * s.log_cost[:-1])
+    assert s.final_cost < 0.01 * s.initial_cost
+    assert 0.3 < s.final_cost / (0.5 * s.num_residuals) < 1.2
+    np.testing.assert_allclose(np.linalg.norm(fp.poses[:, :4], axis=1), 1.0, atol=1e-12)
+    assert np.array_equal(fp.points[::10000], orig_points)
+    pp = np.where((fp.cam_model == scene.SIMPLE_RADIAL)[:, None], fp.cams[:, 1:3], fp.cams[:, 2:4])
+    pp0 = np.where((fp.cam_model == scene.SIMPLE_RADIAL)[:, None], [[512.0, 384.0]], orig_cams)
+    assert np.array_equal(pp, pp0)  # principal points never refined
+
+
 def test_tracks_longer_than_a_tile():
     """Tracks with more observations than the LDS tile (512) take the untiled point pass."""
     fp = _flat(600, 6, 600, seed=9, noise=scene.SyntheticNoiseOptions(0.01, 0.5, 0.02, 0.5))
