@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--ba-track", type=int, default=10)
     ap.add_argument("--ba-iters", type=int, default=10)
     ap.add_argument("--cpu-crop", type=str, default="512x384")
+    ap.add_argument("--no-fusion", action="store_true", help="skip the stereo-fusion leg (needs the geometric leg)")
     ap.add_argument("--no-geom", action="store_true",
                     help="skip the geometric-consistency leg (BASELINE config[2]'s two-pass flow at 2560x1920)")
     return ap.parse_args()
@@ -167,6 +168,22 @@ def ba_secondary(a, local_rank, with_cpu, rank=0, world=1, dev=None):
         "pcg_iterations_per_lm_iteration": k_pcg, "ms_per_lm_iteration": t_lm * 1e3,
         "model_bytes": model, "achieved": model / t_lm / 1e9, "frac": model / t_lm / 1e9 / 8000.0,
         "fp64_storage": {"model_bytes": 2 * model, "frac": 2 * model / t_lm / 1e9 / 8000.0}}
+    if world == 1:
+        # The reference's own default tier at this size (SPARSE_SCHUR for 51..1000 images,
+        # bundle_adjustment_ceres.cc:203-213): exact Newton steps from the explicitly formed reduced camera system,
+        # blocked Cholesky on the f64 matrix cores (colmap_amd/csrc/ba_schur_explicit.hip). Reported beside the
+        # benchmarked Schur-PCG tier: which one is faster per LM iteration, and how far each has come.
+        se = est.solve_flat(fp.copy(), est.SolverOptions(max_num_iterations=min(a.ba_iters, 6),
+                                                         linear_solver_type=est.SOLVER_SPARSE_SCHUR), gpu_index=local_rank)
+        out["exact_tier"] = {
+            "linear_solver": "SPARSE_SCHUR (explicit reduced camera system, dense in HBM, blocked f64-MFMA Cholesky)",
+            "LM_iterations_per_s": se.num_iterations / max(se.lm_seconds, 1e-12), "lm_iterations": se.num_iterations,
+            "cost": [se.initial_cost, se.final_cost], "tier_used": se.linear_solver_used,
+            "mfma_time_frac": se.factor_seconds / max(se.lm_seconds, 1e-12),
+            "cholesky_tflops": (out["config"].get("n_c", 0) or 0) and None,
+            "faster_tier_per_lm_iteration": "ITERATIVE_SCHUR (PCG)" if out["value"] > se.num_iterations / max(se.lm_seconds, 1e-12)
+                                            else "SPARSE_SCHUR"}
+        del out["exact_tier"]["cholesky_tflops"]
     if sharded:
         out["sharded"] = sharded
     if with_cpu and world == 1:
@@ -266,11 +283,13 @@ def geometric_leg(a, views, images, cache, local_rank):
     t_geom = time.time() - t1
     ms, n = pms[0].GetSweepTiming()
     ev = [pm.GetEvaluationCount() for pm in pms]
+    nf = 0 if a.no_fusion else min(8, nb)   # filtered maps handed to the fusion leg (host arrays: its ABI takes host data)
+    fmaps = [(refs[k], pms[k].GetDepthMap(), pms[k].GetNormalMap()) for k in range(nf)]
     kept = float(np.mean([(pm.GetDepthMap() > 0).mean() for pm in pms[:2]]))
     for pm in pms:
         pm.close()
     pix = a.width * a.height
-    return {
+    return fmaps, {
         "metric": "PatchMatch Mpix/s @2560x1920, geometric consistency pass",
         "value": nb * pix / 1e6 / t_geom, "unit": "Mpix/s",
         "config": {"workload": f"geom_consistency=true, filter=true (photometric + geometric filters), {a.width}x{a.height}, "
@@ -284,6 +303,35 @@ def geometric_leg(a, views, images, cache, local_rank):
                      "note": "photometric seconds charged to the geometric batch in proportion nb / photometric_images "
                              "(in a whole workspace every image is solved once per pass)"},
     }
+
+
+def fusion_leg(a, views, fmaps):
+    """Stereo fusion (reference mvs/fusion.cc) of the geometric leg's filtered depth /
+    normal maps: 8 neighbouring 2560x1920 images, default StereoFusionOptions, every image overlapping
+    every other. Timed: fusion_run end to end -- host maps in (the ABI takes host arrays, so the PCIe
+    upload is inside), speculate / claim / commit rounds, medians, fused points out."""
+    import ctypes as C
+    from colmap_amd import fusion
+    from colmap_amd._lib import lib
+    imgs = []
+    for (i, depth, normal) in fmaps:
+        K, R, T, g = views[i][0], views[i][1], views[i][2], views[i][3]
+        gray = g.cpu().numpy()
+        imgs.append(fusion.FusionImage(a.width, a.height, K, R, T, np.stack([gray, gray, gray], -1), depth, normal))
+    n = len(imgs)
+    overlap = [[j for j in range(n) if j != i] for i in range(n)]
+    opt = fusion.StereoFusionOptions()
+    t = time.time()
+    pts = fusion.fuse(opt, imgs, overlap)
+    dt = time.time() - t
+    st = [C.c_int64() for _ in range(4)]
+    lib().fusion_last_stats(*[C.byref(x) for x in st])
+    images_, seeds, rounds, walks = [x.value for x in st]
+    return {"metric": "stereo fusion Mpix/s @2560x1920", "value": n * a.width * a.height / 1e6 / dt, "unit": "Mpix/s",
+            "config": {"workload": f"StereoFusion defaults, {n} images {a.width}x{a.height} (geometric leg's filtered maps), "
+                                   f"all-to-all overlap, host inputs (upload inside the timed region)"},
+            "seconds": dt, "fused_points": int(len(pts.xyz)), "seed_pixels": int(seeds),
+            "rounds_per_image": rounds / max(images_, 1), "walks_per_seed_pixel": walks / max(seeds, 1)}
 
 
 def spawn_ranks(a):
@@ -463,7 +511,10 @@ def main():
             host_views = [syn.View(K, R, T, g.cpu().numpy(), None, None) for (K, R, T, g, _, _) in views]
             out["cpu_baseline"] = cpu_baseline(host_views, ref, src, dmin, dmax, (cw, ch))
         if not a.no_geom and world == 1:
-            out["geometric"] = geometric_leg(a, views, images, cache, local_rank)
+            fmaps, out["geometric"] = geometric_leg(a, views, images, cache, local_rank)
+            if fmaps:
+                mvs.release_cached_memory()
+                out["fusion"] = fusion_leg(a, views, fmaps)
         if not a.no_ba and world == 1:
             del pms_keepalive[:]
             torch.cuda.empty_cache()

@@ -13,7 +13,7 @@ CSRC = os.path.join(_ROOT, "csrc")
 LIB_DIR = os.path.join(_ROOT, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libcolmap_amd.so")
 
-SOURCES = ["pm_api.cpp", "pm_kernels.hip", "ba_kernels.hip", "fusion.hip"]
+SOURCES = ["pm_api.cpp", "pm_kernels.hip", "ba_kernels.hip", "ba_schur_explicit.hip", "fusion.hip"]
 
 # -ffp-contract=off: fused multiply-adds only where the source says fmaf(); the
 # arithmetic is specified operation by operation (oracle/pm_oracle.c header).

@@ -27,6 +27,7 @@
 //    Gram tile).
 //  * S x = (B + D^2) x - E C^-1 E^T x is never formed: three kernels per product.
 #include "../../include/colmap_amd_ba.h"
+#include "ba_schur_explicit.h"
 
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
@@ -129,6 +130,10 @@ struct View {
   int loss_type;                     // BA_LOSS_*
   double loss_scale;
   const int *c2a, *a2c;              // c-order position <-> p-order position (sorted by point)
+  // p-order copies of the per-observation topology (the point-side linearisation pass reads them
+  // coalesced); NULL: the c-order pass scatters the point columns through c2a instead
+  const int *a_pose, *a_cam, *a_pt, *a_sensor;
+  const double* a_xy;
   const unsigned char* solo;         // c-order: bit k set = no other observation of this point shares block kind k
   const int *pose_off, *pose_dim, *pose_fix;  // pose_fix: held translation coordinate or -1, + 4 when
                                               // the rotation is held (ba_problem::pose_fixed_t)
@@ -144,6 +149,10 @@ struct View {
   // linearisation
   double *Jpose, *Jcam, *res;  // c-order
   double *Jpt, *res_p;         // p-order
+  // fp32 copies of the same (scaled) columns for the PCG operator only (ba_options / COLMAP_AMD_BA_OPERATOR_F32):
+  // the inexact inner solve streams half the bytes, accumulation stays fp64; cost, gradient, Schur-Jacobi
+  // blocks, reduced right-hand side, back-substitution and step evaluation read the fp64 columns. NULL: off.
+  float *Jpose32, *Jcam32, *Jpt32;
   double *scale_c, *scale_p;
   double* scalars;
 };
@@ -712,9 +721,23 @@ __device__ __forceinline__ void quat_to_rot(const double* q, double R[9]) {
   R[6] = txz - twy; R[7] = tyz + twx; R[8] = 1 - (txx + tyy);
 }
 
+template <typename JT> struct JSel;
+template <> struct JSel<double> {
+  static __device__ __forceinline__ const double* pose(const View& V) { return V.Jpose; }
+  static __device__ __forceinline__ const double* cam(const View& V) { return V.Jcam; }
+  static __device__ __forceinline__ const double* pt(const View& V) { return V.Jpt; }
+};
+template <> struct JSel<float> {
+  static __device__ __forceinline__ const float* pose(const View& V) { return V.Jpose32; }
+  static __device__ __forceinline__ const float* cam(const View& V) { return V.Jcam32; }
+  static __device__ __forceinline__ const float* pt(const View& V) { return V.Jpt32; }
+};
+
 // Evaluate one observation; JAC: also the tangent-space, column-scaled Jacobian blocks.
 // Jpar is laid out 2 x NPAR whatever the model (columns beyond the model's parameters are not read).
-template <bool JAC, int KD>
+// PSIDE: also write the point-side columns and the p-order residual (scattered through c2a); false when
+// ba_linearize_point_kernel produces them in its own p-order pass.
+template <bool JAC, int KD, bool PSIDE = true>
 __global__ void __launch_bounds__(256) ba_linearize_kernel(View V, const double* __restrict__ poses,
                                                           const double* __restrict__ cams,
                                                           const double* __restrict__ points,
@@ -818,7 +841,11 @@ __global__ void __launch_bounds__(256) ba_linearize_kernel(View V, const double*
         const int fix = pf < 0 ? -1 : ((pf & 3) == 3 ? -1 : (pf & 3));
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-          int d = 0;
+          // translation columns with the held coordinate removed; selects, not Jp[r][d++] -- a dynamically
+          // indexed local array lives in scratch
+          const double t0 = fix == 0 ? Juvw[3 * r + 1] : Juvw[3 * r];
+          const double t1 = (fix == 0 || fix == 1) ? Juvw[3 * r + 2] : Juvw[3 * r + 1];
+          const double t2 = fix < 0 ? Juvw[3 * r + 2] : 0.0;
           if (!rotc) {
             double Jq[4];
 #pragma unroll
@@ -827,12 +854,9 @@ __global__ void __launch_bounds__(256) ba_linearize_kernel(View V, const double*
 #pragma unroll
             for (int c = 0; c < 3; ++c)
               Jp[r][c] = Jq[0] * PJ[c] + Jq[1] * PJ[3 + c] + Jq[2] * PJ[6 + c] + Jq[3] * PJ[9 + c];
-            d = 3;
-          }
-#pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            if (c == fix) continue;
-            Jp[r][d++] = Juvw[3 * r + c];
+            Jp[r][3] = t0; Jp[r][4] = t1; Jp[r][5] = t2;
+          } else {
+            Jp[r][0] = t0; Jp[r][1] = t1; Jp[r][2] = t2;
           }
         }
       }
@@ -842,10 +866,17 @@ __global__ void __launch_bounds__(256) ba_linearize_kernel(View V, const double*
         for (int r = 0; r < 2; ++r)
 #pragma unroll
           for (int c = 0; c < KD; ++c)
-            if (c < cdim) Jk[r][c] = Jpar[NP * r + V.cam_var[KD * ci + c]];
+            if (c < cdim) {
+              // select chain instead of Jpar[dynamic index]: a dynamically indexed local array lives in scratch
+              const int idx = V.cam_var[KD * ci + c];
+              double sel = 0.0;
+#pragma unroll
+              for (int j = 0; j < NP; ++j) sel = (idx == j) ? Jpar[NP * r + j] : sel;
+              Jk[r][c] = sel;
+            }
       }
       // point block: J_uvw * R(q)
-      if (ok && ptoff >= 0) {
+      if (PSIDE && ok && ptoff >= 0) {
         double R[9];
         quat_to_rot(q, R);
 #pragma unroll
@@ -875,42 +906,146 @@ __global__ void __launch_bounds__(256) ba_linearize_kernel(View V, const double*
         for (int c = 0; c < 6; ++c) correct(Js[0][c], Js[1][c]);
 #pragma unroll
         for (int c = 0; c < KD; ++c) correct(Jk[0][c], Jk[1][c]);
+        if (PSIDE) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) correct(Jx[0][c], Jx[1][c]);
+          for (int c = 0; c < 3; ++c) correct(Jx[0][c], Jx[1][c]);
+        }
         rx *= residual_scaling;
         ry *= residual_scaling;
       }
       V.res[o] = rx;
       V.res[N + o] = ry;
-      V.res_p[a] = rx;
-      V.res_p[N + a] = ry;
+      if (PSIDE) {
+        V.res_p[a] = rx;
+        V.res_p[N + a] = ry;
+      }
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
 #pragma unroll
         for (int c = 0; c < PD; ++c) {
           const double s = (c < pdim) ? V.scale_c[poff + c] : 0.0;
           V.Jpose[(size_t)(r * PD + c) * N + o] = Jp[r][c] * s;
+          if (V.Jpose32) V.Jpose32[(size_t)(r * PD + c) * N + o] = (float)(Jp[r][c] * s);
         }
 #pragma unroll
         for (int c = 0; c < KD; ++c) {
           const double s = (c < cdim) ? V.scale_c[coff + c] : 0.0;
           V.Jcam[(size_t)(r * KD + c) * N + o] = Jk[r][c] * s;
+          if (V.Jcam32) V.Jcam32[(size_t)(r * KD + c) * N + o] = (float)(Jk[r][c] * s);
         }
         if (V.sens_off) {
 #pragma unroll
           for (int c = 0; c < 6; ++c)
             V.Jsens[(size_t)(r * 6 + c) * N + o] = soff >= 0 ? Js[r][c] * V.scale_c[soff + c] : 0.0;
         }
+        if (PSIDE) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          const double s = (ptoff >= 0) ? V.scale_p[ptoff + c] : 0.0;
-          V.Jpt[(size_t)(r * 3 + c) * N + a] = Jx[r][c] * s;
+          for (int c = 0; c < 3; ++c) {
+            const double s = (ptoff >= 0) ? V.scale_p[ptoff + c] : 0.0;
+            V.Jpt[(size_t)(r * 3 + c) * N + a] = Jx[r][c] * s;
+            if (V.Jpt32) V.Jpt32[(size_t)(r * 3 + c) * N + a] = (float)(Jx[r][c] * s);
+          }
         }
       }
     }
   }
   cost = block_sum(cost);
   if (threadIdx.x == 0) partials[blockIdx.x] = cost;
+}
+
+// Point side of the linearisation in its own p-order pass: one lane per p-order slot re-evaluates the
+// observation (R X + t, the projection and J_uvw: ~200 fp64 flops, free next to the memory traffic) and
+// writes the 2 x 3 point columns and the p-order residual COALESCED. The c-order pass used to scatter these
+// eight doubles per lane through c2a: eight 64-byte write transactions for 64 bytes of payload
+// (WRITE_SIZE 1.14 GB per launch at BA-1 for 0.45 GB of columns). Same expressions in the same order as
+// ba_linearize_kernel, so the columns are bit-identical to the scattered ones.
+template <int KD>
+__global__ void __launch_bounds__(256) ba_linearize_point_kernel(View V, const double* __restrict__ poses,
+                                                                const double* __restrict__ cams,
+                                                                const double* __restrict__ points,
+                                                                const double* __restrict__ sensors) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= V.n_obs) return;
+  const int pi = V.a_pose[a], ci = V.a_cam[a], xi = V.a_pt[a];
+  const double* q = poses + 7 * (size_t)pi;
+  const double* prm = cams + BA_CAM_STRIDE * (size_t)ci;
+  const double* X = points + 3 * (size_t)xi;
+  const int model = V.cam_model[ci];
+  constexpr int NP = KD > KD_MAX ? NPAR_WIDE : NPAR;
+  double Juvw[6], Jpar[2 * NP], pc[3];
+  quat_rotate(q, X, pc, nullptr);
+  pc[0] += q[4]; pc[1] += q[5]; pc[2] += q[6];
+  const int si = V.a_sensor ? V.a_sensor[a] : -1;
+  double Rs[9];
+  if (si >= 0) {
+    const double* sfr = sensors + 7 * (size_t)si;
+    quat_to_rot(sfr, Rs);
+    const double p0 = pc[0], p1 = pc[1], p2 = pc[2];
+    pc[0] = Rs[0] * p0 + Rs[1] * p1 + Rs[2] * p2 + sfr[4];
+    pc[1] = Rs[3] * p0 + Rs[4] * p1 + Rs[5] * p2 + sfr[5];
+    pc[2] = Rs[6] * p0 + Rs[7] * p1 + Rs[8] * p2 + sfr[6];
+  }
+  double rx = 0.0, ry = 0.0;
+  const bool ok = img_from_cam<true, NP>(model, prm, pc[0], pc[1], pc[2], rx, ry, Jpar, Juvw);
+  if (ok) {
+    rx -= V.a_xy[2 * (size_t)a];
+    ry -= V.a_xy[2 * (size_t)a + 1];
+  } else {
+    rx = ry = 0.0;
+  }
+  const double sq_norm = rx * rx + ry * ry;
+  if (ok && si >= 0) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const double j0 = Juvw[3 * r], j1 = Juvw[3 * r + 1], j2 = Juvw[3 * r + 2];
+      Juvw[3 * r] = j0 * Rs[0] + j1 * Rs[3] + j2 * Rs[6];
+      Juvw[3 * r + 1] = j0 * Rs[1] + j1 * Rs[4] + j2 * Rs[7];
+      Juvw[3 * r + 2] = j0 * Rs[2] + j1 * Rs[5] + j2 * Rs[8];
+    }
+  }
+  const int ptoff = V.pt_off[xi];
+  double Jx[2][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
+  if (ok && ptoff >= 0) {
+    double R[9];
+    quat_to_rot(q, R);
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        Jx[r][c] = Juvw[3 * r] * R[c] + Juvw[3 * r + 1] * R[3 + c] + Juvw[3 * r + 2] * R[6 + c];
+  }
+  if (V.loss_type != BA_LOSS_TRIVIAL) {
+    double rho[3];
+    loss_eval(V.loss_type, V.loss_scale, sq_norm, rho);
+    const double sqrt_rho1 = sqrt(rho[1]);
+    double residual_scaling = sqrt_rho1, alpha_sq_norm = 0.0;
+    if (!(sq_norm == 0.0 || rho[2] <= 0.0)) {
+      const double D = 1.0 + 2.0 * sq_norm * rho[2] / rho[1];
+      const double alpha = 1.0 - sqrt(D);
+      residual_scaling = sqrt_rho1 / (1.0 - alpha);
+      alpha_sq_norm = alpha / sq_norm;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const double rtj = rx * Jx[0][c] + ry * Jx[1][c];
+      const double j0 = Jx[0][c], j1 = Jx[1][c];
+      Jx[0][c] = sqrt_rho1 * (j0 - alpha_sq_norm * rx * rtj);
+      Jx[1][c] = sqrt_rho1 * (j1 - alpha_sq_norm * ry * rtj);
+    }
+    rx *= residual_scaling;
+    ry *= residual_scaling;
+  }
+  const size_t N = (size_t)V.n_obs;
+  V.res_p[a] = rx;
+  V.res_p[N + a] = ry;
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const double s = (ptoff >= 0) ? V.scale_p[ptoff + c] : 0.0;
+      V.Jpt[(size_t)(r * 3 + c) * N + a] = Jx[r][c] * s;
+      if (V.Jpt32) V.Jpt32[(size_t)(r * 3 + c) * N + a] = (float)(Jx[r][c] * s);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1074,7 +1209,7 @@ __global__ void ba_point_apply_kernel(View V, const double* __restrict__ Cinv, c
 // Same passes with the point columns staged through LDS: a workgroup owns a tile of consecutive
 // points (<= TILE_PTS points, <= TILE_OBS observations); global loads/stores are coalesced over
 // the tile's observation range, the per-point segment walk reads LDS.
-template <int MODE>
+template <int MODE, typename JT = double>
 __global__ void __launch_bounds__(TILE_PTS) ba_point_pass_tiled_kernel(View V, const double* __restrict__ Cinv,
                                                                        const double* __restrict__ jx,
                                                                        const double* __restrict__ gp,
@@ -1086,9 +1221,10 @@ __global__ void __launch_bounds__(TILE_PTS) ba_point_pass_tiled_kernel(View V, c
   const int p0 = V.tile_pt[t], p1 = V.tile_pt[t + 1];
   const int a0 = V.pt_ptr[p0], na = V.pt_ptr[p1] - a0;
   const size_t N = (size_t)V.n_obs;
+  const JT* __restrict__ Jp = JSel<JT>::pt(V);
   for (int i = threadIdx.x; i < na; i += TILE_PTS) {
 #pragma unroll
-    for (int c = 0; c < 6; ++c) sJ[c][i] = V.Jpt[(size_t)c * N + a0 + i];
+    for (int c = 0; c < 6; ++c) sJ[c][i] = (double)Jp[(size_t)c * N + a0 + i];
     if (MODE != 1) {
       sx[0][i] = jx[a0 + i];
       sx[1][i] = jx[N + a0 + i];
@@ -1212,11 +1348,13 @@ __global__ void __launch_bounds__(TILE_PTS) ba_point_reduce_tiled_kernel(View V,
 // ------------------------------------------------------------------------------------------
 
 // jx_o = Jc_o x  (both residual rows), x a camera-side vector
-template <int KD>
+template <int KD, typename JT = double>
 __global__ void ba_obs_jx_kernel(View V, const double* __restrict__ x, double* __restrict__ jx) {
   const int o = blockIdx.x * blockDim.x + threadIdx.x;
   if (o >= V.n_obs) return;
   const size_t N = (size_t)V.n_obs;
+  const JT* __restrict__ Jpo = JSel<JT>::pose(V);
+  const JT* __restrict__ Jca = JSel<JT>::cam(V);
   const int pi = V.o_pose[o], ci = V.o_cam[o];
   const int pdim = V.pose_dim[pi], poff = V.pose_off[pi], cdim = V.cam_dim[ci], coff = V.cam_off[ci];
   double a0 = 0.0, a1 = 0.0;
@@ -1224,15 +1362,15 @@ __global__ void ba_obs_jx_kernel(View V, const double* __restrict__ x, double* _
   for (int c = 0; c < PD; ++c)
     if (c < pdim) {
       const double xv = x[poff + c];
-      a0 += V.Jpose[(size_t)c * N + o] * xv;
-      a1 += V.Jpose[(size_t)(PD + c) * N + o] * xv;
+      a0 += (double)Jpo[(size_t)c * N + o] * xv;
+      a1 += (double)Jpo[(size_t)(PD + c) * N + o] * xv;
     }
 #pragma unroll
   for (int c = 0; c < KD; ++c)
     if (c < cdim) {
       const double xv = x[coff + c];
-      a0 += V.Jcam[(size_t)c * N + o] * xv;
-      a1 += V.Jcam[(size_t)(KD + c) * N + o] * xv;
+      a0 += (double)Jca[(size_t)c * N + o] * xv;
+      a1 += (double)Jca[(size_t)(KD + c) * N + o] * xv;
     }
   if (V.sens_off) {
     const int si = V.o_sensor[o];
@@ -1313,6 +1451,12 @@ __global__ void __launch_bounds__(256) ba_model_from_jx_kernel(View V, const dou
 // Camera-side reductions: one wave per chunk of a parameter block's observation list
 // ------------------------------------------------------------------------------------------
 
+// fp32 operator copy of the same column (never for variable sensor_from_rig blocks: the fp32 operator is
+// not enabled for problems that have them)
+__device__ __forceinline__ const float* blk_col32(const View& V, int kind, int r, int c) {
+  const size_t N = (size_t)V.n_obs;
+  return kind == 0 ? V.Jpose32 + (size_t)(r * PD + c) * N : V.Jcam32 + (size_t)(r * V.kd + c) * N;
+}
 __device__ __forceinline__ const double* blk_col(const View& V, int kind, int r, int c) {
   const size_t N = (size_t)V.n_obs;
   if (kind == 2) return V.Jsens + (size_t)(r * 6 + c) * N;  // variable sensor_from_rig block
@@ -1320,7 +1464,7 @@ __device__ __forceinline__ const double* blk_col(const View& V, int kind, int r,
 }
 
 // y_b += J_b^T v  (v: 2 rows per observation). With DIAG: also diag_b += colsq(J_b).
-template <bool DIAG, int BD>
+template <bool DIAG, int BD, typename JT = double>
 __global__ void __launch_bounds__(64) ba_block_jtv_kernel(View V, const double* __restrict__ v,
                                                          double* __restrict__ y, double* __restrict__ diag) {
   const int ch = blockIdx.x;
@@ -1343,10 +1487,17 @@ __global__ void __launch_bounds__(64) ba_block_jtv_kernel(View V, const double* 
 #pragma unroll
     for (int c = 0; c < BD; ++c)
       if (c < dim) {
-        const double* c0 = blk_col(V, kind, 0, c);
-        const double* c1 = blk_col(V, kind, 1, c);
-        j0[c] = c0[o]; j1[c] = c1[o];
-        k0[c] = c0[oz]; k1[c] = c1[oz];
+        if constexpr (sizeof(JT) == 4) {
+          const float* c0 = blk_col32(V, kind, 0, c);
+          const float* c1 = blk_col32(V, kind, 1, c);
+          j0[c] = (double)c0[o]; j1[c] = (double)c1[o];
+          k0[c] = (double)c0[oz]; k1[c] = (double)c1[oz];
+        } else {
+          const double* c0 = blk_col(V, kind, 0, c);
+          const double* c1 = blk_col(V, kind, 1, c);
+          j0[c] = c0[o]; j1[c] = c1[o];
+          k0[c] = c0[oz]; k1[c] = c1[oz];
+        }
       }
 #pragma unroll
     for (int c = 0; c < BD; ++c)
@@ -1372,7 +1523,7 @@ __global__ void __launch_bounds__(64) ba_block_jtv_kernel(View V, const double* 
     }
 }
 
-// y_b += sum over the block's chunks, in chunk order (deterministic); lane per block
+// y_b = sum over the block's chunks, in chunk order (deterministic); lane per block
 template <bool DIAG>
 __global__ void ba_block_vec_finalize_kernel(View V, double* __restrict__ y, double* __restrict__ diag) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1384,8 +1535,22 @@ __global__ void ba_block_vec_finalize_kernel(View V, double* __restrict__ y, dou
       s += V.cpart[(size_t)ch * V.bd * V.bd + c];
       if (DIAG) d += V.cpart[(size_t)ch * V.bd * V.bd + V.bd + c];
     }
-    y[off + c] += s;
-    if (DIAG) diag[off + c] += d;
+    y[off + c] = s;  // every camera-side entry belongs to exactly one block: no memset before, no accumulate
+    if (DIAG) diag[off + c] = d;
+  }
+}
+
+// q_b = Dc_b^2 x_b + sum over the block's chunks (the tail of an implicit product on a single GPU without
+// priors: ba_block_vec_finalize_kernel<false> + ba_dsq_x_kernel + ba_add_kernel in one launch, same operations)
+__global__ void ba_block_vec_finalize_q_kernel(View V, const double* __restrict__ Dc, const double* __restrict__ x,
+                                               double* __restrict__ q) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= V.n_blk) return;
+  const int dim = V.blk_dim[b], off = V.blk_off[b];
+  for (int c = 0; c < dim; ++c) {
+    double s = 0.0;
+    for (int ch = V.blk_chunk_ptr[b]; ch < V.blk_chunk_ptr[b + 1]; ++ch) s += V.cpart[(size_t)ch * V.bd * V.bd + c];
+    q[off + c] = Dc[off + c] * Dc[off + c] * x[off + c] + s;
   }
 }
 
@@ -1606,6 +1771,55 @@ __global__ void ba_block_invert_kernel(View V, const double* __restrict__ Dc, co
   if (b >= V.n_blk) return;
   const int n = V.blk_dim[b], off = V.blk_off[b];
   double A[BD][2 * BD];
+  if constexpr (BD <= 8) {
+    // The same Gauss-Jordan elimination with partial pivoting, every loop unrolled to the template width and
+    // predicated on n, the row exchange written as selects: all indices are compile-time constants, so the
+    // augmented matrix lives in registers (the rolled version below keeps it in scratch: 80 us for 2 000 blocks).
+#pragma unroll
+    for (int i = 0; i < BD; ++i) {
+#pragma unroll
+      for (int j = 0; j < BD; ++j) A[i][j] = (i < n && j < n) ? M[V.blk_moff[b] + i * n + j] : (i == j ? 1.0 : 0.0);
+#pragma unroll
+      for (int j = 0; j < BD; ++j) A[i][BD + j] = (i == j) ? 1.0 : 0.0;
+      if (i < n) A[i][i] += Dc[off + i] * Dc[off + i];
+    }
+#pragma unroll
+    for (int c = 0; c < BD; ++c) {
+      if (c < n) {
+        int piv = c;
+        double best = fabs(A[c][c]);
+#pragma unroll
+        for (int r = c + 1; r < BD; ++r)
+          if (r < n && fabs(A[r][c]) > best) { best = fabs(A[r][c]); piv = r; }
+#pragma unroll
+        for (int r = c + 1; r < BD; ++r) {
+          const bool sw = piv == r;
+#pragma unroll
+          for (int j = 0; j < 2 * BD; ++j) {
+            const double t = A[c][j], u = A[r][j];
+            A[c][j] = sw ? u : t;
+            A[r][j] = sw ? t : u;
+          }
+        }
+        const double inv = 1.0 / A[c][c];
+#pragma unroll
+        for (int j = 0; j < 2 * BD; ++j) A[c][j] *= inv;
+#pragma unroll
+        for (int r = 0; r < BD; ++r) {
+          if (r == c || r >= n) continue;
+          const double f = A[r][c];
+#pragma unroll
+          for (int j = 0; j < 2 * BD; ++j) A[r][j] -= f * A[c][j];
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < BD; ++i)
+#pragma unroll
+      for (int j = 0; j < BD; ++j)
+        if (i < n && j < n) Minv[V.blk_moff[b] + i * n + j] = A[i][BD + j];
+    return;
+  }
   for (int i = 0; i < BD; ++i)
     for (int j = 0; j < 2 * BD; ++j) A[i][j] = 0.0;
   for (int i = 0; i < n; ++i) {
@@ -1684,6 +1898,83 @@ __global__ void ba_pcg_dir_kernel(int n, const double* __restrict__ scalars, con
   if (i >= n) return;
   p[i] = first ? z[i] : z[i] + (pcg_rho(part, nparts) / scalars[S_RHO_LAST]) * p[i];
 }
+// One single-workgroup kernel per PCG iteration for everything around the three streaming kernels of the
+// implicit product (single GPU, no priors; the sharded / prior path keeps the separate kernels because
+// all-reduces sit between the steps). A lane owns whole blocks, so every step below touches only entries
+// the same lane produced -- the only synchronisations are the three workgroup sums:
+//   tail of iteration k : q_b = Dc_b^2 p_b + sum of the block's J_b^T v chunk partials; pq = p.q;
+//                         alpha = rho / pq; x += alpha p; r -= alpha q; Q = -x.(b + r) / 2
+//   head of iteration k+1: z_b = Minv_b r_b; rho' = r.z; p = z + (rho' / rho) p
+// HEAD_ONLY starts a solve: x = 0, r = b, p = z = Minv b. scalars: S_RHO = the rho iteration k used (what
+// the host tests), S_RHO_LAST = rho' for the next call, S_PQ, S_Q.
+template <bool HEAD_ONLY>
+__global__ void __launch_bounds__(1024) ba_pcg_fused_kernel(View V, const double* __restrict__ Dc,
+                                                            const double* __restrict__ Minv,
+                                                            const double* __restrict__ rhs, double* __restrict__ scalars,
+                                                            double* __restrict__ x, double* __restrict__ r,
+                                                            double* __restrict__ z, double* __restrict__ p,
+                                                            double* __restrict__ q) {
+  const int bd2 = V.bd * V.bd;
+  double rho = HEAD_ONLY ? 0.0 : scalars[S_RHO_LAST];
+  if (!HEAD_ONLY) {
+    double pq = 0.0;
+    for (int b = threadIdx.x; b < V.n_blk; b += 1024) {
+      const int dim = V.blk_dim[b], off = V.blk_off[b];
+      for (int c = 0; c < dim; ++c) {
+        double sacc = 0.0;
+        for (int ch = V.blk_chunk_ptr[b]; ch < V.blk_chunk_ptr[b + 1]; ++ch) sacc += V.cpart[(size_t)ch * bd2 + c];
+        const double d = Dc[off + c], pv = p[off + c];
+        const double qv = d * d * pv + sacc;
+        q[off + c] = qv;
+        pq += pv * qv;
+      }
+    }
+    pq = block_sum(pq);
+    const double alpha = rho / pq;
+    double Q = 0.0;
+    for (int b = threadIdx.x; b < V.n_blk; b += 1024) {
+      const int dim = V.blk_dim[b], off = V.blk_off[b];
+      for (int c = 0; c < dim; ++c) {
+        const double xn = x[off + c] + alpha * p[off + c];
+        const double rn = r[off + c] - alpha * q[off + c];
+        x[off + c] = xn;
+        r[off + c] = rn;
+        Q += -0.5 * xn * (rhs[off + c] + rn);
+      }
+    }
+    Q = block_sum(Q);
+    if (threadIdx.x == 0) {
+      scalars[S_Q] = Q;
+      scalars[S_PQ] = pq;
+      scalars[S_RHO] = rho;
+    }
+  }
+  double rho_new = 0.0;
+  for (int b = threadIdx.x; b < V.n_blk; b += 1024) {
+    const int n = V.blk_dim[b], off = V.blk_off[b];
+    const double* Mi = Minv + V.blk_moff[b];
+    for (int i = 0; i < n; ++i) {
+      if (HEAD_ONLY) { x[off + i] = 0.0; r[off + i] = rhs[off + i]; }
+    }
+    for (int i = 0; i < n; ++i) {
+      double sacc = 0.0;
+      for (int j = 0; j < n; ++j) sacc += Mi[i * n + j] * r[off + j];
+      z[off + i] = sacc;
+      rho_new += sacc * r[off + i];
+    }
+  }
+  rho_new = block_sum(rho_new);
+  const double beta = HEAD_ONLY ? 0.0 : rho_new / rho;
+  for (int b = threadIdx.x; b < V.n_blk; b += 1024) {
+    const int n = V.blk_dim[b], off = V.blk_off[b];
+    for (int i = 0; i < n; ++i) p[off + i] = HEAD_ONLY ? z[off + i] : z[off + i] + beta * p[off + i];
+  }
+  if (threadIdx.x == 0) {
+    scalars[S_RHO_LAST] = rho_new;
+    if (HEAD_ONLY) scalars[S_RHO] = rho_new;
+  }
+}
+
 __global__ void __launch_bounds__(1024) ba_dot_kernel(int n, const double* __restrict__ a,
                                                       const double* __restrict__ b, double* __restrict__ out) {
   double v = 0.0;
@@ -1811,8 +2102,10 @@ __global__ void ba_apply_point_kernel(View V, const double* __restrict__ step, c
 // max |a - b| over n doubles -> scalars[S_GMAX]
 __global__ void ba_maxdiff_kernel(size_t n, const double* __restrict__ a, const double* __restrict__ b,
                                   double* __restrict__ scalars) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  double v = (i < n) ? fabs(a[i] - b[i]) : 0.0;
+  // grid-stride: at most 256 workgroups, one atomic per wave (the max is order-independent)
+  double v = 0.0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    v = fmax(v, fabs(a[i] - b[i]));
   for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
   if ((threadIdx.x & 63) == 0) atomic_max_pos(scalars + S_GMAX, v);
 }
@@ -2155,10 +2448,19 @@ struct Solver {
   std::vector<int> h_sens_off;
   Buf<int> o_pose, o_cam, o_pt, pose_off, pose_dim, pose_fix, cam_off, cam_dim, cam_var, cam_model, pt_off,
       pt_ptr, blk_off, blk_dim, blk_kind, blk_moff, chunk_blk, chunk_beg, chunk_end, blk_chunk_ptr, c2a, a2c, tile_pt;
+  Buf<int> a_pose, a_cam, a_pt, a_sensor;  // p-order topology for the point-side linearisation pass
+  Buf<double> a_xy;
+  bool split_linearize = true;
+  Buf<float> Jpose32, Jcam32, Jpt32;
+  bool op32 = false;  // PCG operator streams the fp32 copies
   Buf<unsigned char> solo;
   Buf<double> o_xy, poses, cams, points, poses2, cams2, points2, Jpose, Jcam, Jpt, res, res_p, scale_c, scale_p,
       scalars, gc, gp, diag_c, diag_p, Dc, Dp, Cinv, M, Minv, rhs, x, r, z, pdir, q, dp, jx, v, stepc, stepp, partials, cpart, Craw, tbuf, tmpc, Gobs, pcg_part, maxbuf;
-  Buf<double> Sdense;  // DENSE_SCHUR tier: the reduced camera system, n_c x n_c
+  Buf<double> Sdense;  // exact tiers: the reduced camera system, n_c x n_c
+  Buf<double> chol_linv, chol_tmp;  // blocked Cholesky workspace (ba_schur_explicit.h)
+  Buf<int> chol_info;
+  bool dense_by_products = false;   // legacy formation (n_c operator products): image-sharded solves only
+  double factor_ms = 0.0;
   // position priors
   Buf<int> pr_pose, pr_sens, pr_po, pr_so, pr_pdim, pr_tb_blk, pr_tb_ptr, pr_tg_prior, pr_tg_base;
   Buf<double> pr_pos, pr_A, pr_r, pr_J, pr_jx;
@@ -2317,6 +2619,26 @@ struct Solver {
       h_xy[2 * (size_t)c] = p.obs_xy[2 * o];
       h_xy[2 * (size_t)c + 1] = p.obs_xy[2 * o + 1];
     }
+    // the same topology in p-order (position a <-> c-order position h_a2c[a])
+    {
+      const char* e = std::getenv("COLMAP_AMD_BA_SPLIT_LINEARIZE");  // read per solve: tests toggle it
+      split_linearize = !e || std::atoi(e) != 0;
+    }
+    std::vector<int> h_a_pose, h_a_cam, h_a_pt, h_a_sensor;
+    std::vector<double> h_a_xy;
+    {  // (the explicit Schur formation reads it too, whatever the linearisation does)
+      h_a_pose.resize(n); h_a_cam.resize(n); h_a_pt.resize(n); h_a_xy.resize((size_t)2 * n);
+      if (has_sensors) h_a_sensor.resize(n);
+      for (int a = 0; a < n; ++a) {
+        const int64_t o = active[a];
+        h_a_pose[a] = p.obs_pose[o];
+        h_a_cam[a] = p.obs_cam[o];
+        h_a_pt[a] = p.obs_point[o];
+        h_a_xy[2 * (size_t)a] = p.obs_xy[2 * o];
+        h_a_xy[2 * (size_t)a + 1] = p.obs_xy[2 * o + 1];
+        if (has_sensors) h_a_sensor[a] = p.obs_sensor[o];
+      }
+    }
     // tangent layout: pose blocks, then intrinsics blocks (camera side); points
     h_pose_off.assign(p.num_poses, -1);
     h_cam_off.assign(p.num_cams, -1);
@@ -2469,6 +2791,10 @@ struct Solver {
     blk_off.upload(h_blk_off); blk_dim.upload(h_blk_dim); blk_kind.upload(h_blk_kind); blk_moff.upload(h_blk_moff);
     chunk_blk.upload(h_chunk_blk); chunk_beg.upload(h_chunk_beg); chunk_end.upload(h_chunk_end);
     c2a.upload(h_c2a); a2c.upload(h_a2c); solo.upload(h_solo); tile_pt.upload(h_tile_pt);
+    a_pose.upload(h_a_pose); a_cam.upload(h_a_cam); a_pt.upload(h_a_pt); a_xy.upload(h_a_xy);
+    if (has_sensors) a_sensor.upload(h_a_sensor);
+    V.a_pose = a_pose.p; V.a_cam = a_cam.p; V.a_pt = a_pt.p; V.a_xy = a_xy.p;
+    V.a_sensor = has_sensors ? a_sensor.p : nullptr;
     V.n_tiles = (int)h_tile_pt.size() - 1;
     blk_chunk_ptr.upload(h_blk_chunk_ptr);
     cpart.alloc((size_t)h_chunk_blk.size() * bd * bd);
@@ -2480,6 +2806,15 @@ struct Solver {
     Jpose.alloc(2 * PD * N); Jcam.alloc(2 * (size_t)kd * N); Jpt.alloc(6 * N); res.alloc(2 * N); res_p.alloc(2 * N);
     jx.alloc(2 * N); v.alloc(2 * N); Gobs.alloc(3 * N);
     if (n_var_sensors > 0) Jsens.alloc(12 * N);
+    {
+      const char* e32 = std::getenv("COLMAP_AMD_BA_OPERATOR_F32");
+      const bool op32_env = e32 && std::atoi(e32) != 0;
+      op32 = (op32_env || opt.operator_precision == BA_OPERATOR_F32) && n_var_sensors == 0 && V.n_tiles > 0 && comm.world == 1;
+      if (op32) { Jpose32.alloc(2 * PD * N); Jcam32.alloc(2 * (size_t)kd * N); Jpt32.alloc(6 * N); }
+      V.Jpose32 = op32 ? Jpose32.p : nullptr;
+      V.Jcam32 = op32 ? Jcam32.p : nullptr;
+      V.Jpt32 = op32 ? Jpt32.p : nullptr;
+    }
     scale_c.alloc(n_c); scale_p.alloc(poff); gc.alloc(n_c); gp.alloc(poff); diag_c.alloc(n_c); diag_p.alloc(poff);
     Dc.alloc(n_c); Dp.alloc(poff); rhs.alloc(n_c); x.alloc(n_c); r.alloc(n_c); z.alloc(n_c); pdir.alloc(n_c);
     q.alloc(n_c); dp.alloc(poff); stepc.alloc(n_c); stepp.alloc(poff);
@@ -2523,7 +2858,18 @@ struct Solver {
 
   void launch_linearize(bool jac, const double* P, const double* Cm, const double* X, const double* Sn, int slot) {
     const int g = grid_for(V.n_obs, 256);
-    if (kd == 4) {
+    if (jac && split_linearize) {  // camera side in c-order, point side in p-order: every store coalesced
+      if (kd == 4) {
+        BA_LAUNCH((ba_linearize_kernel<true, 4, false>), dim3(g), dim3(256), st, V, P, Cm, X, Sn, partials.p);
+        BA_LAUNCH((ba_linearize_point_kernel<4>), dim3(g), dim3(256), st, V, P, Cm, X, Sn);
+      } else if (kd == KD_WIDE) {
+        BA_LAUNCH((ba_linearize_kernel<true, KD_WIDE, false>), dim3(g), dim3(256), st, V, P, Cm, X, Sn, partials.p);
+        BA_LAUNCH((ba_linearize_point_kernel<KD_WIDE>), dim3(g), dim3(256), st, V, P, Cm, X, Sn);
+      } else {
+        BA_LAUNCH((ba_linearize_kernel<true, KD_MAX, false>), dim3(g), dim3(256), st, V, P, Cm, X, Sn, partials.p);
+        BA_LAUNCH((ba_linearize_point_kernel<KD_MAX>), dim3(g), dim3(256), st, V, P, Cm, X, Sn);
+      }
+    } else if (kd == 4) {
       if (jac) BA_LAUNCH((ba_linearize_kernel<true, 4>), dim3(g), dim3(256), st, V, P, Cm, X, Sn, partials.p);
       else BA_LAUNCH((ba_linearize_kernel<false, 4>), dim3(g), dim3(256), st, V, P, Cm, X, Sn, partials.p);
     } else if (kd == KD_WIDE) {
@@ -2542,16 +2888,16 @@ struct Solver {
 
   // gradient of the (scaled) Jacobian and its squared column norms
   void gradient_and_diag() {
-    BA_HIP(hipMemsetAsync(gc.p, 0, sizeof(double) * std::max(V.n_c, 1), st));
-    BA_HIP(hipMemsetAsync(diag_c.p, 0, sizeof(double) * std::max(V.n_c, 1), st));
-    if (V.n_chunks > 0) {
+    if (V.n_chunks == 0) {
+      BA_HIP(hipMemsetAsync(gc.p, 0, sizeof(double) * std::max(V.n_c, 1), st));
+      BA_HIP(hipMemsetAsync(diag_c.p, 0, sizeof(double) * std::max(V.n_c, 1), st));
+    } else {
       if (bd == PD) BA_LAUNCH((ba_block_jtv_kernel<true, PD>), dim3(V.n_chunks), dim3(64), st, V, res.p, gc.p, diag_c.p);
       else if (bd == KD_WIDE) BA_LAUNCH((ba_block_jtv_kernel<true, KD_WIDE>), dim3(V.n_chunks), dim3(64), st, V, res.p, gc.p, diag_c.p);
       else BA_LAUNCH((ba_block_jtv_kernel<true, KD_MAX>), dim3(V.n_chunks), dim3(64), st, V, res.p, gc.p, diag_c.p);
       BA_LAUNCH(ba_block_vec_finalize_kernel<true>, dim3(grid_for(V.n_blk, 128)), dim3(128), st, V, gc.p, diag_c.p);
     }
-    BA_HIP(hipMemsetAsync(gp.p, 0, sizeof(double) * std::max(V.n_p, 1), st));
-    BA_HIP(hipMemsetAsync(diag_p.p, 0, sizeof(double) * std::max(V.n_p, 1), st));
+    // (g_p and the point column norms are written for every variable point by either kernel)
     if (V.n_tiles > 0)
       BA_LAUNCH(ba_point_reduce_tiled_kernel<0>, dim3(V.n_tiles), dim3(TILE_PTS), st, V, nullptr, nullptr, gp.p, diag_p.p, Craw.p);
     else {
@@ -2572,7 +2918,7 @@ struct Solver {
 
   // y = (sum over ranks of J_c^T v) for this rank's observations, into tmpc
   void block_jtv_reduced(const double* vin, const double* x_for_priors = nullptr) {
-    BA_HIP(hipMemsetAsync(tmpc.p, 0, sizeof(double) * std::max(V.n_c, 1), st));
+    if (V.n_chunks == 0) BA_HIP(hipMemsetAsync(tmpc.p, 0, sizeof(double) * std::max(V.n_c, 1), st));
     if (V.n_chunks > 0) {
       if (bd == PD) BA_LAUNCH((ba_block_jtv_kernel<false, PD>), dim3(V.n_chunks), dim3(64), st, V, vin, tmpc.p, nullptr);
       else if (bd == KD_WIDE) BA_LAUNCH((ba_block_jtv_kernel<false, KD_WIDE>), dim3(V.n_chunks), dim3(64), st, V, vin, tmpc.p, nullptr);
@@ -2596,7 +2942,15 @@ struct Solver {
   }
 
   // q = S x = (B + Dc^2) x - E C^-1 E^T x
-  void schur_multiply(const double* xin, double* qout) {
+  // `inexact`: called by the CG iteration (may stream the fp32 operator copies); the exact formation by
+  // operator products passes false.
+  void schur_multiply(const double* xin, double* qout, bool inexact = false) {
+    if (comm.world == 1 && !use_priors() && V.n_chunks > 0 && V.n_obs > 0) {
+      // single GPU, no priors: nothing sits between J_c^T v and the block sums -> one tail kernel
+      schur_streams(xin, inexact && op32);
+      BA_LAUNCH(ba_block_vec_finalize_q_kernel, dim3(grid_for(V.n_blk, 128)), dim3(128), st, V, Dc.p, xin, qout);
+      return;
+    }
     const int go = grid_for(V.n_obs, 256);
     if (V.n_obs > 0) {
       if (kd == 4) BA_LAUNCH(ba_obs_jx_kernel<4>, dim3(go), dim3(256), st, V, xin, jx.p);
@@ -2621,6 +2975,26 @@ struct Solver {
   int dense_schur() {
     const int n = V.n_c;
     if (Sdense.n < (size_t)n * n) throw std::runtime_error("dense Schur buffer");
+    if (!dense_by_products) {
+      // explicit formation (one wave per point) + blocked Cholesky on the f64 matrix cores
+      ba_explicit::FormArgs fa{};
+      fa.n_obs = V.n_obs; fa.n_points = V.n_points; fa.n_c = n; fa.kd = kd;
+      fa.Jpose = V.Jpose; fa.Jcam = V.Jcam; fa.Jsens = V.sens_off ? V.Jsens : nullptr; fa.Jpt = V.Jpt;
+      fa.Cinv = Cinv.p; fa.a2c = V.a2c; fa.pt_ptr = V.pt_ptr; fa.pt_off = V.pt_off;
+      fa.a_pose = V.a_pose; fa.a_cam = V.a_cam; fa.a_sensor = V.sens_off ? V.a_sensor : nullptr;
+      fa.pose_off = V.pose_off; fa.pose_dim = V.pose_dim; fa.cam_off = V.cam_off; fa.cam_dim = V.cam_dim;
+      fa.sens_off = V.sens_off;
+      ba_explicit::form(fa, Sdense.p, st);
+      if (use_priors()) ba_explicit::add_prior_rows(Sdense.p, n, Q.J, Q.po, Q.so, Q.pdim, Q.n, st);
+      if (comm.world > 1) comm.allreduce(Sdense.p, (size_t)n * n, st);  // point sharding: partial sums per rank
+      ba_explicit::add_lm_diagonal(Sdense.p, n, Dc.p, st);
+      ba_explicit::Workspace ws;
+      ws.Linv = chol_linv.p; ws.tmp = chol_tmp.p; ws.info = chol_info.p;
+      double ms = 0.0;
+      ba_explicit::factor_solve(Sdense.p, n, rhs.p, x.p, ws, st, ev0, ev1, &ms);
+      factor_ms += ms;
+      return 1;
+    }
     for (int i = 0; i < n; ++i) {
       BA_LAUNCH(ba_unit_vector_kernel, dim3(grid_for(n, 256)), dim3(256), st, n, i, pdir.p);
       schur_multiply(pdir.p, Sdense.p + (size_t)i * n);
@@ -2629,7 +3003,60 @@ struct Solver {
     return 1;
   }
 
+  // The three streaming kernels of one implicit product on a single GPU: J_c p (c-order -> p-order),
+  // the point pass, J_c^T v into per-chunk partials. ba_pcg_fused_kernel finishes the product.
+  void schur_streams(const double* xin, bool use32) {
+    const int go = grid_for(V.n_obs, 256);
+    if (use32) {  // the inexact inner solve streams the fp32 copies of the columns (fp64 accumulation)
+      if (kd == 4) BA_LAUNCH((ba_obs_jx_kernel<4, float>), dim3(go), dim3(256), st, V, xin, jx.p);
+      else if (kd == KD_WIDE) BA_LAUNCH((ba_obs_jx_kernel<KD_WIDE, float>), dim3(go), dim3(256), st, V, xin, jx.p);
+      else BA_LAUNCH((ba_obs_jx_kernel<KD_MAX, float>), dim3(go), dim3(256), st, V, xin, jx.p);
+      BA_LAUNCH((ba_point_pass_tiled_kernel<0, float>), dim3(V.n_tiles), dim3(TILE_PTS), st, V, Cinv.p, jx.p, gp.p, v.p, dp.p);
+      if (bd == PD) BA_LAUNCH((ba_block_jtv_kernel<false, PD, float>), dim3(V.n_chunks), dim3(64), st, V, v.p, tmpc.p, nullptr);
+      else if (bd == KD_WIDE) BA_LAUNCH((ba_block_jtv_kernel<false, KD_WIDE, float>), dim3(V.n_chunks), dim3(64), st, V, v.p, tmpc.p, nullptr);
+      else BA_LAUNCH((ba_block_jtv_kernel<false, KD_MAX, float>), dim3(V.n_chunks), dim3(64), st, V, v.p, tmpc.p, nullptr);
+      return;
+    }
+    if (kd == 4) BA_LAUNCH(ba_obs_jx_kernel<4>, dim3(go), dim3(256), st, V, xin, jx.p);
+    else if (kd == KD_WIDE) BA_LAUNCH(ba_obs_jx_kernel<KD_WIDE>, dim3(go), dim3(256), st, V, xin, jx.p);
+    else BA_LAUNCH(ba_obs_jx_kernel<KD_MAX>, dim3(go), dim3(256), st, V, xin, jx.p);
+    point_pass<0>();
+    if (bd == PD) BA_LAUNCH((ba_block_jtv_kernel<false, PD>), dim3(V.n_chunks), dim3(64), st, V, v.p, tmpc.p, nullptr);
+    else if (bd == KD_WIDE) BA_LAUNCH((ba_block_jtv_kernel<false, KD_WIDE>), dim3(V.n_chunks), dim3(64), st, V, v.p, tmpc.p, nullptr);
+    else BA_LAUNCH((ba_block_jtv_kernel<false, KD_MAX>), dim3(V.n_chunks), dim3(64), st, V, v.p, tmpc.p, nullptr);
+  }
+
+  int pcg_fused(int max_iter, double q_tol) {
+    BA_LAUNCH(ba_pcg_fused_kernel<true>, dim3(1), dim3(1024), st, V, Dc.p, Minv.p, rhs.p, scalars.p, x.p, r.p, z.p, pdir.p, q.p);
+    if (scalar(S_RHO) == 0.0) return 0;
+    double Q0 = 0.0;
+    int it;
+    for (it = 1; it <= max_iter; ++it) {
+      BA_HIP(hipEventRecord(ev0, st));
+      schur_streams(pdir.p, op32);
+      BA_HIP(hipEventRecord(ev1, st));
+      BA_LAUNCH(ba_pcg_fused_kernel<false>, dim3(1), dim3(1024), st, V, Dc.p, Minv.p, rhs.p, scalars.p, x.p, r.p, z.p, pdir.p, q.p);
+      double h[NSCALAR];
+      BA_HIP(hipMemcpyAsync(h, scalars.p, sizeof(h), hipMemcpyDeviceToHost, st));
+      BA_HIP(hipStreamSynchronize(st));
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) { g_spmv_ms += ms; g_spmv_launches += 1; }
+      const double rho = h[S_RHO], pq = h[S_PQ], Q1 = h[S_Q];
+      if (!(rho > 0.0) || !std::isfinite(rho) || !(pq > 0.0) || !std::isfinite(pq)) break;
+      const double zeta = it * (Q1 - Q0) / Q1;
+      if (zeta < q_tol) break;
+      Q0 = Q1;
+    }
+    return std::min(it, max_iter);
+  }
+
   int pcg(int max_iter, double q_tol) {
+    const char* ef = std::getenv("COLMAP_AMD_BA_PCG_FUSED");
+    // measured at BA-1: the single-workgroup kernel takes 133 us against 54 us for the five small kernels it
+    // replaces (a lane's blocks are chains of dependent global loads that one workgroup cannot hide): opt-in only
+    const bool fused_env = ef && std::atoi(ef) != 0;
+    if (fused_env && comm.world == 1 && !use_priors() && V.n_chunks > 0 && V.n_obs > 0 && V.n_blk <= 65536)
+      return pcg_fused(max_iter, q_tol);
     const int n = V.n_c;
     const int gv = grid_for(n, 256);
     BA_HIP(hipMemsetAsync(x.p, 0, sizeof(double) * n, st));
@@ -2643,7 +3070,7 @@ struct Solver {
       BA_LAUNCH(ba_pcg_precond_kernel, dim3(nparts), dim3(256), st, V, Minv.p, r.p, z.p, pcg_part.p);
       BA_LAUNCH(ba_pcg_dir_kernel, dim3(gv), dim3(256), st, n, scalars.p, pcg_part.p, nparts, it == 1 ? 1 : 0, z.p, pdir.p);
       BA_HIP(hipEventRecord(ev0, st));
-      schur_multiply(pdir.p, q.p);
+      schur_multiply(pdir.p, q.p, true);
       BA_HIP(hipEventRecord(ev1, st));
       BA_LAUNCH(ba_pcg_update_kernel, dim3(1), dim3(1024), st, n, scalars.p, pcg_part.p, nparts, pdir.p, q.p, rhs.p, x.p, r.p);
       double h[NSCALAR];
@@ -2679,14 +3106,33 @@ struct Solver {
     if (n == 0) return;
     const int nc = V.n_c, np = V.n_p;
     const int gvc = grid_for(nc, 256), gvp = grid_for(np, 256);
-    if (opt.linear_solver_type < BA_SOLVER_ITERATIVE_SCHUR || opt.linear_solver_type > BA_SOLVER_AUTO)
+    if (opt.linear_solver_type < BA_SOLVER_ITERATIVE_SCHUR || opt.linear_solver_type > BA_SOLVER_SPARSE_SCHUR)
       throw std::runtime_error("linear_solver_type");
-    use_dense = (opt.linear_solver_type == BA_SOLVER_DENSE_SCHUR ||
-                 (opt.linear_solver_type == BA_SOLVER_AUTO && prob.num_poses <= 50)) && nc > 0 && nc <= 1024;
+    {
+      // CreateSolverOptions' rule (bundle_adjustment_ceres.cc:203-213, CPU thresholds bundle_adjustment_ceres.h:
+      // 68-69) on the number of pose blocks; both exact tiers run the explicit reduced camera system
+      const int lst = opt.linear_solver_type;
+      int tier = lst;
+      if (lst == BA_SOLVER_AUTO)
+        tier = prob.num_poses <= 50 ? BA_SOLVER_DENSE_SCHUR : (prob.num_poses <= 1000 ? BA_SOLVER_SPARSE_SCHUR : BA_SOLVER_ITERATIVE_SCHUR);
+      const bool want_exact = tier == BA_SOLVER_DENSE_SCHUR || tier == BA_SOLVER_SPARSE_SCHUR;
+      // an image-sharded solve splits a point's observations over the ranks: only the operator-product formation
+      // (every product is all-reduced) is correct there, and only affordable for small systems
+      dense_by_products = want_exact && comm.world > 1 && !comm.by_point;
+      const char* e_prod = std::getenv("COLMAP_AMD_BA_DENSE_BY_PRODUCTS");
+      if (want_exact && e_prod && std::atoi(e_prod) != 0) dense_by_products = true;
+      use_dense = want_exact && nc > 0 && nc <= (dense_by_products ? 1024 : 32768);
+      out->linear_solver_used = use_dense ? tier : BA_SOLVER_ITERATIVE_SCHUR;
+    }
     if (use_dense) {
       Sdense.alloc((size_t)nc * nc);
+      if (!dense_by_products) {
+        ba_explicit::Workspace ws;
+        chol_linv.alloc(ws.linv_doubles(nc)); chol_tmp.alloc(nc); chol_info.alloc(1);
+      }
       BA_HIP(hipDeviceSynchronize());  // the allocation's memset runs on the NULL stream
     }
+    factor_ms = 0.0;
     g_spmv_ms = 0.0; g_spmv_launches = 0;
     g_mfma_ms = 0.0; g_mfma_launches = 0;
     // bytes one implicit-Schur product streams: Jc (2x10) once for jx, Jp (2x3) twice, jx/v, Jc again
@@ -2724,11 +3170,12 @@ struct Solver {
         BA_LAUNCH(ba_scaled_div_kernel, dim3(std::max(gvp, 1)), dim3(256), st, np, -1.0, gp.p, scale_p.p, stepp.p);
         apply_step(stepc.p, stepp.p, poses2.p, cams2.p, points2.p);
         zero_scalar(S_GMAX);
-        BA_LAUNCH(ba_maxdiff_kernel, dim3(grid_for(poses.n, 256)), dim3(256), st, poses.n, poses.p, poses2.p, scalars.p);
-        BA_LAUNCH(ba_maxdiff_kernel, dim3(grid_for(cams.n, 256)), dim3(256), st, cams.n, cams.p, cams2.p, scalars.p);
-        BA_LAUNCH(ba_maxdiff_kernel, dim3(grid_for(points.n, 256)), dim3(256), st, points.n, points.p, points2.p, scalars.p);
+        auto gmd = [](size_t n) { return dim3((unsigned)std::min<size_t>(std::max<size_t>((n + 255) / 256, 1), 256)); };
+        BA_LAUNCH(ba_maxdiff_kernel, gmd(poses.n), dim3(256), st, poses.n, poses.p, poses2.p, scalars.p);
+        BA_LAUNCH(ba_maxdiff_kernel, gmd(cams.n), dim3(256), st, cams.n, cams.p, cams2.p, scalars.p);
+        BA_LAUNCH(ba_maxdiff_kernel, gmd(points.n), dim3(256), st, points.n, points.p, points2.p, scalars.p);
         if (V.sens_off)
-          BA_LAUNCH(ba_maxdiff_kernel, dim3(grid_for(sensors.n, 256)), dim3(256), st, sensors.n, sensors.p, sensors2.p, scalars.p);
+          BA_LAUNCH(ba_maxdiff_kernel, gmd(sensors.n), dim3(256), st, sensors.n, sensors.p, sensors2.p, scalars.p);
         const double gmax = scalar_max(S_GMAX);
         if (gmax <= opt.gradient_tolerance) {
           out->termination_type = BA_CONVERGENCE;
@@ -2751,8 +3198,8 @@ struct Solver {
       int lin_iters = 0;
       bool mfma_pending = false;
       if (nc > 0) {
-        BA_HIP(hipMemsetAsync(M.p, 0, sizeof(double) * std::max(moff_total, 1), st));
-        if (V.n_chunks > 0) {
+        if (V.n_chunks == 0) BA_HIP(hipMemsetAsync(M.p, 0, sizeof(double) * std::max(moff_total, 1), st));
+        if (V.n_chunks > 0) {  // (ba_block_mat_finalize_kernel<false> assigns every entry of every block)
           BA_LAUNCH(ba_obs_schur_g_kernel, dim3(grid_for(V.n_obs, 256)), dim3(256), st, V, Cinv.p, Gobs.p);
           BA_HIP(hipEventRecord(ev2, st));
           static const bool gram_lds = [] { const char* e = std::getenv("COLMAP_AMD_BA_GRAM_LDS"); return !e || std::atoi(e) != 0; }();
@@ -2866,6 +3313,7 @@ struct Solver {
     launch_linearize(false, poses.p, cams.p, points.p, sensors.p, S_NEWCOST);
     out->final_cost = scalar_sum(S_NEWCOST);
     out->lm_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+    out->factor_seconds = factor_ms * 1e-3;
     BA_LAUNCH(ba_renorm_quat_kernel, dim3(grid_for(V.n_poses, 128)), dim3(128), st, V, poses.p);
     if (comm.world > 1 && comm.by_point) {
       // every rank moved its own points only: zero the others' variable points and sum over ranks

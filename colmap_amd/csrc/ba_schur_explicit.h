@@ -1,0 +1,55 @@
+// ba_schur_explicit.h -- the exact linear-solver tiers of the bundle-adjustment backend (DENSE_SCHUR /
+// SPARSE_SCHUR of ceres::LinearSolverType as COLMAP selects them, reference
+// estimators/bundle_adjustment_ceres.cc:203-213): the reduced camera system formed explicitly on the
+// device and solved by a blocked Cholesky factorisation on the f64 matrix cores. Internal interface
+// between ba_kernels.hip (the LM loop) and ba_schur_explicit.hip.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+namespace ba_explicit {
+
+constexpr int kPoseDim = 6;  // row stride of the pose-tangent columns (PD in ba_kernels.hip)
+
+// Everything the formation reads; all pointers are device pointers of the solver's current linearisation.
+struct FormArgs {
+  int n_obs, n_points, n_c;
+  int kd;                       // row stride of the intrinsics-tangent columns
+  const double* Jpose;          // c-order [2 * kPoseDim][n_obs]
+  const double* Jcam;           // c-order [2 * kd][n_obs]
+  const double* Jsens;          // c-order [2 * 6][n_obs] or NULL
+  const double* Jpt;            // p-order [2 * 3][n_obs]
+  const double* Cinv;           // [n_points][9] inverse point blocks (E^T E + Dp^2)^-1
+  const int* a2c;               // p-order slot -> c-order slot
+  const int* pt_ptr;            // [n_points + 1] p-order segments
+  const int* pt_off;            // [n_points] tangent offset of the point, -1 constant
+  const int *a_pose, *a_cam;    // p-order topology
+  const int* a_sensor;          // p-order sensor_from_rig index or NULL
+  const int *pose_off, *pose_dim, *cam_off, *cam_dim;
+  const int* sens_off;          // [n_sensors] tangent offset of a variable sensor_from_rig, or NULL
+};
+
+// S (n_c x n_c, row-major, LOWER triangle valid) = B - E C^-1 E^T of this rank's observations. S is cleared
+// inside. The LM diagonal is added separately (after the sum over ranks of a sharded solve).
+void form(const FormArgs& a, double* S, hipStream_t st);
+void add_lm_diagonal(double* S, int n, const double* Dc /* D, not D^2 */, hipStream_t st);
+
+// Adds J^T J of the position priors to the lower triangle of S. J: [3][12][count] tangent columns (pose_dim
+// pose columns, then 6 sensor_from_rig columns when so >= 0); po / so: tangent offsets (-1 constant).
+void add_prior_rows(double* S, int n, const double* J, const int* po, const int* so, const int* pdim, int count,
+                    hipStream_t st);
+
+struct Workspace {
+  double* Linv = nullptr;  // [ceil(n / 64)][64][64] inverses of the diagonal blocks of L
+  double* tmp = nullptr;   // [n] second vector of the triangular solves
+  int* info = nullptr;     // device flag: != 0 when a pivot was not positive
+  size_t linv_doubles(int n) const { return (size_t)((n + 63) / 64) * 64 * 64; }
+};
+
+// In-place blocked Cholesky S = L L^T (lower, row-major), then x = S^-1 rhs. A non-positive pivot fills x
+// with NaN (the LM loop then rejects the step like a failed LLT). `mfma_ms` (optional, host) receives the
+// time spent inside the matrix-core kernels (panel + trailing update), measured with the two events given.
+void factor_solve(double* S, int n, const double* rhs, double* x, const Workspace& ws, hipStream_t st,
+                  hipEvent_t ev_a, hipEvent_t ev_b, double* mfma_ms);
+
+}  // namespace ba_explicit

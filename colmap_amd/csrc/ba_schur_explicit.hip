@@ -1,0 +1,458 @@
+// ba_schur_explicit.hip -- exact linear-solver tiers (DENSE_SCHUR / SPARSE_SCHUR) of the bundle-adjustment
+// backend for gfx950: the reduced camera system S = B + Dc^2 - E C^-1 E^T formed EXPLICITLY on the device and
+// solved by a blocked Cholesky factorisation whose panel and trailing-update contractions run on the f64
+// matrix cores (v_mfma_f64_16x16x4_f64).
+//
+// What it replaces: Ceres' SchurEliminator + dense / sparse Cholesky of the reduced camera matrix as COLMAP
+// selects them by problem size (reference estimators/bundle_adjustment_ceres.cc:203-213, thresholds
+// bundle_adjustment_ceres.h:68-71). Restated for the CPU in oracle/ba_oracle.c: explicit_schur_solve.
+//
+// MI355X-first choices:
+//  * S is stored DENSE in HBM whatever its block sparsity (n_c = 8 000 at 1 000 images is 512 MB, n_c = 32 768
+//    is 8.6 GB of 288 GB); sparsity is exploited where it costs -- in the formation, which touches only the
+//    camera pairs a point connects -- and the factorisation is a dense GEMM-shaped job for the matrix cores
+//    instead of a sparse supernodal one.
+//  * Formation: one wave per 3-D point. With J_a the 2 x w_a camera-side Jacobian of observation a (pose,
+//    intrinsics and sensor_from_rig tangent columns) and E_a its 2 x 3 point block, the point's contribution is
+//        S[cols_a, cols_b] += J_a^T (delta_ab I - G_ab) J_b,      G_ab = E_a C^-1 E_b^T  (2 x 2)
+//    for every ordered pair (a, b) of its observations: the wave stages the observations of the point in LDS
+//    and its lanes walk the (a, i, b, k) element space with the column index fastest, so the hardware fp64
+//    atomics of a wave instruction fall into few cache lines. Only the lower triangle is written.
+//    (Atomic accumulation: this tier is reproducible to rounding, not bit-wise like the iterative tier.)
+//  * Factorisation: right-looking, 64-wide panels. Diagonal block: one workgroup in LDS, which also inverts
+//    the 64 x 64 triangle so that the panel solve below it becomes a GEMM  X = A_panel L_kk^-T;
+//    the trailing update C_IJ -= X_I X_J^T runs 64 x 64 tiles per workgroup, 2 x 2 MFMA tiles per wave.
+//  * Triangular solves with the stored block inverses: one launch per block step (forward and backward).
+#include "ba_schur_explicit.h"
+
+#include <algorithm>
+#include <cmath>
+#include <stdexcept>
+#include <string>
+
+namespace ba_explicit {
+
+namespace {
+
+#define BAX_HIP(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t e_ = (expr);                                                                        \
+    if (e_ != hipSuccess)                                                                          \
+      throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(e_) + " at " #expr); \
+  } while (0)
+
+constexpr int NB = 64;  // panel width = tile size
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------------------------
+// Formation
+// ---------------------------------------------------------------------------------------------------------
+template <int WMAX>
+struct ObsSlot {
+  double jc[2][WMAX];  // camera-side columns (pose | intrinsics | sensor), scaled as the solver stores them
+  double jp[2][3];     // point block E_a
+  double pj[2][3];     // E_a C^-1
+  int idx[WMAX];       // tangent index of every column
+  int w;
+};
+
+template <int WMAX>
+__device__ __forceinline__ void load_slot(const FormArgs& A, ObsSlot<WMAX>& s, int a, const double* Ci, bool var) {
+  const size_t N = (size_t)A.n_obs;
+  const int c = A.a2c[a];
+  const int pi = A.a_pose[a], ci = A.a_cam[a];
+  const int si = A.a_sensor ? A.a_sensor[a] : -1;
+  const int po = A.pose_off[pi], co = A.cam_off[ci];
+  const int so = (si >= 0 && A.sens_off) ? A.sens_off[si] : -1;
+  int w = 0;
+  if (po >= 0) {
+    const int pdim = A.pose_dim[pi];
+    for (int d = 0; d < pdim; ++d) {
+      s.jc[0][w] = A.Jpose[(size_t)d * N + c];
+      s.jc[1][w] = A.Jpose[(size_t)(kPoseDim + d) * N + c];
+      s.idx[w++] = po + d;
+    }
+  }
+  if (co >= 0) {
+    const int cdim = A.cam_dim[ci];
+    for (int d = 0; d < cdim; ++d) {
+      s.jc[0][w] = A.Jcam[(size_t)d * N + c];
+      s.jc[1][w] = A.Jcam[(size_t)(A.kd + d) * N + c];
+      s.idx[w++] = co + d;
+    }
+  }
+  if (so >= 0) {
+    for (int d = 0; d < 6; ++d) {
+      s.jc[0][w] = A.Jsens[(size_t)d * N + c];
+      s.jc[1][w] = A.Jsens[(size_t)(6 + d) * N + c];
+      s.idx[w++] = so + d;
+    }
+  }
+  s.w = w;
+  for (int r = 0; r < 2; ++r) {
+    double e[3];
+    for (int m = 0; m < 3; ++m) e[m] = A.Jpt[(size_t)(r * 3 + m) * N + a];
+    for (int m = 0; m < 3; ++m) {
+      s.jp[r][m] = e[m];
+      s.pj[r][m] = var ? e[0] * Ci[m] + e[1] * Ci[3 + m] + e[2] * Ci[6 + m] : 0.0;
+    }
+  }
+}
+
+template <int WMAX>
+__global__ void __launch_bounds__(64) form_kernel(FormArgs A, double* __restrict__ S) {
+  constexpr int CH = 16;  // observations of a point staged per chunk
+  __shared__ ObsSlot<WMAX> sa[CH], sb[CH];
+  __shared__ int s_wmax[2];
+  const int j = blockIdx.x;
+  const int beg = A.pt_ptr[j], t = A.pt_ptr[j + 1] - beg;
+  if (t == 0) return;
+  const bool var = A.pt_off[j] >= 0;
+  double Ci[9];
+  for (int m = 0; m < 9; ++m) Ci[m] = var ? A.Cinv[9 * (size_t)j + m] : 0.0;
+  const int lane = threadIdx.x;
+  const size_t n = (size_t)A.n_c;
+  for (int a0 = 0; a0 < t; a0 += CH) {
+    const int na = min(CH, t - a0);
+    __syncthreads();
+    if (lane < na) load_slot<WMAX>(A, sa[lane], beg + a0 + lane, Ci, var);
+    __syncthreads();
+    if (lane == 0) {
+      int wm = 0;
+      for (int q = 0; q < na; ++q) wm = max(wm, sa[q].w);
+      s_wmax[0] = wm;
+    }
+    for (int b0 = 0; b0 < t; b0 += CH) {
+      if (!var && b0 != a0) continue;  // a constant point couples nothing: only J_a^T J_a
+      const int nb = min(CH, t - b0);
+      __syncthreads();
+      if (lane < nb) load_slot<WMAX>(A, sb[lane], beg + b0 + lane, Ci, var);
+      __syncthreads();
+      if (lane == 0) {
+        int wm = 0;
+        for (int q = 0; q < nb; ++q) wm = max(wm, sb[q].w);
+        s_wmax[1] = wm;
+      }
+      __syncthreads();
+      const int wa = s_wmax[0], wb = s_wmax[1];
+      const int total = na * wa * nb * wb;
+      for (int e = lane; e < total; e += 64) {
+        const int k = e % wb;
+        int q = e / wb;
+        const int b = q % nb;
+        q /= nb;
+        const int i = q % wa;
+        const int a = q / wa;
+        const ObsSlot<WMAX>& oa = sa[a];
+        const ObsSlot<WMAX>& ob = sb[b];
+        if (i >= oa.w || k >= ob.w) continue;
+        const int row = oa.idx[i], col = ob.idx[k];
+        if (row < col) continue;  // lower triangle only
+        const bool self = (a0 + a) == (b0 + b);
+        if (!var && !self) continue;
+        double m00 = self ? 1.0 : 0.0, m01 = 0.0, m10 = 0.0, m11 = self ? 1.0 : 0.0;
+        if (var) {
+          m00 -= oa.pj[0][0] * ob.jp[0][0] + oa.pj[0][1] * ob.jp[0][1] + oa.pj[0][2] * ob.jp[0][2];
+          m01 -= oa.pj[0][0] * ob.jp[1][0] + oa.pj[0][1] * ob.jp[1][1] + oa.pj[0][2] * ob.jp[1][2];
+          m10 -= oa.pj[1][0] * ob.jp[0][0] + oa.pj[1][1] * ob.jp[0][1] + oa.pj[1][2] * ob.jp[0][2];
+          m11 -= oa.pj[1][0] * ob.jp[1][0] + oa.pj[1][1] * ob.jp[1][1] + oa.pj[1][2] * ob.jp[1][2];
+        }
+        const double b0v = ob.jc[0][k], b1v = ob.jc[1][k];
+        const double val = oa.jc[0][i] * (m00 * b0v + m01 * b1v) + oa.jc[1][i] * (m10 * b0v + m11 * b1v);
+        unsafeAtomicAdd(S + (size_t)row * n + col, val);
+      }
+    }
+  }
+}
+
+__global__ void diag_kernel(int n, const double* __restrict__ Dc, double* __restrict__ S) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) S[(size_t)i * n + i] += Dc[i] * Dc[i];
+}
+
+// J: [3][12][count] tangent columns of the position priors (pose columns, then sensor columns)
+__global__ void prior_rows_kernel(double* __restrict__ S, int n, const double* __restrict__ J,
+                                  const int* __restrict__ po, const int* __restrict__ so,
+                                  const int* __restrict__ pdim, int count) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= count * 144) return;
+  const int kprior = e / 144, i = (e % 144) / 12, k = e % 12;
+  const int pd = pdim[kprior];
+  const int w = pd + (so[kprior] >= 0 ? 6 : 0);
+  if (i >= w || k >= w) return;
+  const int row = i < pd ? po[kprior] + i : so[kprior] + (i - pd);
+  const int col = k < pd ? po[kprior] + k : so[kprior] + (k - pd);
+  if (row < col) return;
+  double v = 0.0;
+  for (int r = 0; r < 3; ++r)
+    v += J[((size_t)r * 12 + i) * count + kprior] * J[((size_t)r * 12 + k) * count + kprior];
+  unsafeAtomicAdd(S + (size_t)row * n + col, v);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Blocked Cholesky
+// ---------------------------------------------------------------------------------------------------------
+
+// Diagonal block [k0, k0 + kb): L_kk in place (lower), its inverse (64 x 64, zero-padded) to Linv.
+__global__ void __launch_bounds__(256) chol_diag_kernel(double* __restrict__ S, int n, int k0, int kb,
+                                                        double* __restrict__ Linv, int* __restrict__ info) {
+  __shared__ double L[NB][NB + 1];
+  __shared__ double Li[NB][NB + 1];
+  const int tid = threadIdx.x;
+  for (int e = tid; e < NB * NB; e += 256) {
+    const int r = e / NB, c = e % NB;
+    L[r][c] = (r < kb && c <= r) ? S[(size_t)(k0 + r) * n + k0 + c] : 0.0;
+    Li[r][c] = 0.0;
+  }
+  __syncthreads();
+  for (int c = 0; c < kb; ++c) {
+    if (tid == 0) {
+      double d = L[c][c];
+      if (!(d > 0.0)) {
+        *info = 1;
+        d = NAN;
+      }
+      L[c][c] = sqrt(d);
+    }
+    __syncthreads();
+    const double d = L[c][c];
+    for (int r = c + 1 + tid; r < kb; r += 256) L[r][c] /= d;
+    __syncthreads();
+    const int m = kb - c - 1;
+    for (int e = tid; e < m * m; e += 256) {
+      const int cc = c + 1 + e / m, r = c + 1 + e % m;
+      if (r >= cc) L[r][cc] -= L[r][c] * L[cc][c];
+    }
+    __syncthreads();
+  }
+  // inverse of the triangle: thread j solves L x = e_j, x kept in column j of Li
+  if (tid < kb) {
+    const int j = tid;
+    for (int r = j; r < kb; ++r) {
+      double v = (r == j) ? 1.0 : 0.0;
+      for (int m = j; m < r; ++m) v -= L[r][m] * Li[m][j];
+      Li[r][j] = v / L[r][r];
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < NB * NB; e += 256) {
+    const int r = e / NB, c = e % NB;
+    if (r < kb && c <= r) S[(size_t)(k0 + r) * n + k0 + c] = L[r][c];
+    Linv[e] = Li[r][c];
+  }
+}
+
+// Panel below the diagonal block: X = A_panel L_kk^-T, in place. One workgroup per 64 rows; wave w owns rows
+// 16 w .. 16 w + 15 and all four 16-column tiles. MFMA operand layout (as in ba_block_gram_kernel): lane l
+// supplies A[i = l & 15][k = l >> 4] and B[k = l >> 4][j = l & 15]; the result registers hold
+// D[row = (l >> 4) + 4 reg][col = l & 15].
+__global__ void __launch_bounds__(256) chol_panel_kernel(double* __restrict__ S, int n, int k0, int kb,
+                                                         const double* __restrict__ Linv) {
+  __shared__ double sA[NB][NB + 1];
+  __shared__ double sLi[NB][NB + 1];
+  const int tid = threadIdx.x;
+  const int r0 = k0 + kb + NB * blockIdx.x;
+  const int nr = min(NB, n - r0);
+  for (int e = tid; e < NB * NB; e += 256) {
+    const int r = e / NB, c = e % NB;
+    sA[r][c] = (r < nr && c < kb) ? S[(size_t)(r0 + r) * n + k0 + c] : 0.0;
+    sLi[r][c] = Linv[e];
+  }
+  __syncthreads();
+  const int wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 15, lk = lane >> 4;
+  v4f64 acc[4];
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct) acc[ct] = v4f64{0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+  for (int ks = 0; ks < NB / 4; ++ks) {
+    const int m = 4 * ks + lk;
+    const double a = sA[16 * wave + li][m];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      const double b = sLi[16 * ct + li][m];  // B[k][j] = (L_kk^-1)[j][k]
+      acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[ct], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int r = 16 * wave + lk + 4 * reg, c = 16 * ct + li;
+      if (r < nr && c < kb) S[(size_t)(r0 + r) * n + k0 + c] = acc[ct][reg];
+    }
+}
+
+// Trailing update C_IJ -= X_I X_J^T for the 64 x 64 tiles I >= J of the trailing matrix (rows / columns from
+// t0 = k0 + kb). Wave w owns the 32 x 32 quadrant (w >> 1, w & 1): 2 x 2 MFMA tiles; K = kb in halves of 32.
+__global__ void __launch_bounds__(256) chol_update_kernel(double* __restrict__ S, int n, int k0, int kb) {
+  const int I = blockIdx.y, J = blockIdx.x;
+  if (J > I) return;
+  __shared__ double sI[NB][33];
+  __shared__ double sJ[NB][33];
+  const int tid = threadIdx.x;
+  const int t0 = k0 + kb;
+  const int ri = t0 + NB * I, rj = t0 + NB * J;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 15, lk = lane >> 4;
+  const int qi = 32 * (wave >> 1), qj = 32 * (wave & 1);
+  v4f64 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = v4f64{0.0, 0.0, 0.0, 0.0};
+  for (int kh = 0; kh < kb; kh += 32) {
+    __syncthreads();
+    for (int e = tid; e < NB * 32; e += 256) {
+      const int r = e >> 5, m = e & 31;
+      const bool kok = kh + m < kb;
+      sI[r][m] = (kok && ri + r < n) ? S[(size_t)(ri + r) * n + k0 + kh + m] : 0.0;
+      sJ[r][m] = (kok && rj + r < n) ? S[(size_t)(rj + r) * n + k0 + kh + m] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const int m = 4 * ks + lk;
+      const double a0 = sI[qi + li][m], a1 = sI[qi + 16 + li][m];
+      const double b0 = sJ[qj + li][m], b1 = sJ[qj + 16 + li][m];
+      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int r = ri + qi + 16 * a + lk + 4 * reg, c = rj + qj + 16 * b + li;
+        if (r < n && c < n && c <= r) S[(size_t)r * n + c] -= acc[a][b][reg];
+      }
+}
+
+// Forward step k: y_k <- L_kk^-1 y_k (final), rows below: y_i -= L_ik y_k. Every workgroup recomputes the
+// 64-vector (cheap), workgroup 0 publishes it to `yfin`; block.x = 64, grid = 1 + #row tiles below.
+__global__ void __launch_bounds__(64) solve_forward_kernel(const double* __restrict__ S, int n, int k0, int kb,
+                                                           const double* __restrict__ Linv, double* __restrict__ y,
+                                                           double* __restrict__ yfin) {
+  __shared__ double yk[NB];
+  __shared__ double raw[NB];
+  const int tid = threadIdx.x;
+  raw[tid] = tid < kb ? y[k0 + tid] : 0.0;
+  __syncthreads();
+  double v = 0.0;
+  for (int m = 0; m <= tid && m < kb; ++m) v += Linv[tid * NB + m] * raw[m];
+  yk[tid] = tid < kb ? v : 0.0;
+  __syncthreads();
+  if (blockIdx.x == 0) {
+    if (tid < kb) yfin[k0 + tid] = yk[tid];
+    return;
+  }
+  const int r = k0 + kb + NB * (blockIdx.x - 1) + tid;
+  if (r >= n) return;
+  const double* Sr = S + (size_t)r * n + k0;
+  double acc = 0.0;
+  for (int m = 0; m < kb; ++m) acc += Sr[m] * yk[m];
+  y[r] -= acc;
+}
+
+// Backward step k: x_k <- L_kk^-T w_k (final), columns left of it: w_j -= L_kj^T x_k.
+__global__ void __launch_bounds__(64) solve_backward_kernel(const double* __restrict__ S, int n, int k0, int kb,
+                                                            const double* __restrict__ Linv, double* __restrict__ w,
+                                                            double* __restrict__ x) {
+  __shared__ double xk[NB];
+  __shared__ double raw[NB];
+  const int tid = threadIdx.x;
+  raw[tid] = tid < kb ? w[k0 + tid] : 0.0;
+  __syncthreads();
+  double v = 0.0;
+  for (int m = tid; m < kb; ++m) v += Linv[m * NB + tid] * raw[m];  // (L^-1)^T
+  xk[tid] = tid < kb ? v : 0.0;
+  __syncthreads();
+  if (blockIdx.x == 0) {
+    if (tid < kb) x[k0 + tid] = xk[tid];
+    return;
+  }
+  const int c = NB * (blockIdx.x - 1) + tid;
+  if (c >= k0) return;
+  double acc = 0.0;
+  for (int m = 0; m < kb; ++m) acc += S[(size_t)(k0 + m) * n + c] * xk[m];
+  w[c] -= acc;
+}
+
+__global__ void nan_fill_kernel(int n, const int* __restrict__ info, double* __restrict__ x) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && *info != 0) x[i] = NAN;
+}
+
+}  // namespace
+
+void form(const FormArgs& a, double* S, hipStream_t st) {
+  const size_t n = (size_t)a.n_c;
+  BAX_HIP(hipMemsetAsync(S, 0, n * n * sizeof(double), st));
+  if (a.n_points <= 0 || a.n_obs <= 0) return;
+  const int wmax = kPoseDim + a.kd + (a.Jsens ? 6 : 0);
+  if (wmax <= 10) hipLaunchKernelGGL(form_kernel<10>, dim3(a.n_points), dim3(64), 0, st, a, S);
+  else if (wmax <= 14) hipLaunchKernelGGL(form_kernel<14>, dim3(a.n_points), dim3(64), 0, st, a, S);
+  else if (wmax <= 20) hipLaunchKernelGGL(form_kernel<20>, dim3(a.n_points), dim3(64), 0, st, a, S);
+  else hipLaunchKernelGGL(form_kernel<28>, dim3(a.n_points), dim3(64), 0, st, a, S);
+}
+
+void add_lm_diagonal(double* S, int n, const double* Dc, hipStream_t st) {
+  hipLaunchKernelGGL(diag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, Dc, S);
+}
+
+void add_prior_rows(double* S, int n, const double* J, const int* po, const int* so, const int* pdim, int count,
+                    hipStream_t st) {
+  if (count <= 0) return;
+  hipLaunchKernelGGL(prior_rows_kernel, dim3((unsigned)((count * 144 + 255) / 256)), dim3(256), 0, st, S, n, J, po,
+                     so, pdim, count);
+}
+
+void factor_solve(double* S, int n, const double* rhs, double* x, const Workspace& ws, hipStream_t st,
+                  hipEvent_t ev_a, hipEvent_t ev_b, double* mfma_ms) {
+  BAX_HIP(hipMemsetAsync(ws.info, 0, sizeof(int), st));
+  const int nblk = (n + NB - 1) / NB;
+  if (mfma_ms) *mfma_ms = 0.0;
+  // The whole factorisation is bracketed by the two events: the diagonal-block kernels in between are
+  // < 2 % of its time at n >= 2 000, the rest are the two matrix-core kernels.
+  if (ev_a) BAX_HIP(hipEventRecord(ev_a, st));
+  for (int kblk = 0; kblk < nblk; ++kblk) {
+    const int k0 = kblk * NB, kb = std::min(NB, n - k0);
+    double* Li = ws.Linv + (size_t)kblk * NB * NB;
+    hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), 0, st, S, n, k0, kb, Li, ws.info);
+    const int below = n - k0 - kb;
+    if (below > 0) {
+      const int tiles = (below + NB - 1) / NB;
+      hipLaunchKernelGGL(chol_panel_kernel, dim3(tiles), dim3(256), 0, st, S, n, k0, kb, Li);
+      hipLaunchKernelGGL(chol_update_kernel, dim3(tiles, tiles), dim3(256), 0, st, S, n, k0, kb);
+    }
+  }
+  if (ev_b) BAX_HIP(hipEventRecord(ev_b, st));
+  // L y = rhs: x is the working vector (a step reads its own block of it raw -- in every workgroup -- and
+  // updates the rows below), finished blocks go to ws.tmp; then L^T x = y with ws.tmp as the working vector
+  // and x as the output. Working vector and output must be different arrays: workgroup 0 publishes a block
+  // while the other workgroups of the same launch still read its raw values.
+  BAX_HIP(hipMemcpyAsync(x, rhs, sizeof(double) * n, hipMemcpyDeviceToDevice, st));
+  for (int kblk = 0; kblk < nblk; ++kblk) {
+    const int k0 = kblk * NB, kb = std::min(NB, n - k0);
+    const int tiles = (n - k0 - kb + NB - 1) / NB;
+    hipLaunchKernelGGL(solve_forward_kernel, dim3(1 + tiles), dim3(64), 0, st, S, n, k0, kb,
+                       ws.Linv + (size_t)kblk * NB * NB, x, ws.tmp);
+  }
+  for (int kblk = nblk - 1; kblk >= 0; --kblk) {
+    const int k0 = kblk * NB, kb = std::min(NB, n - k0);
+    hipLaunchKernelGGL(solve_backward_kernel, dim3(1 + kblk), dim3(64), 0, st, S, n, k0, kb,
+                       ws.Linv + (size_t)kblk * NB * NB, ws.tmp, x);
+  }
+  hipLaunchKernelGGL(nan_fill_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, ws.info, x);
+  if (mfma_ms && ev_a && ev_b) {
+    BAX_HIP(hipEventSynchronize(ev_b));
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, ev_a, ev_b) == hipSuccess) *mfma_ms = ms;
+  }
+}
+
+}  // namespace ba_explicit

@@ -165,6 +165,9 @@ class SolverOptions:
     # path), DENSE_SCHUR (reduced camera system formed and Cholesky-solved) or the reference's choice by
     # problem size (CeresBundleAdjustmentOptions::CreateSolverOptions, bundle_adjustment_ceres.cc:203-213)
     linear_solver_type: int = 0
+    # ba_options.operator_precision (MI355X option): OPERATOR_F32 lets the inexact inner CG solve stream fp32
+    # copies of the Jacobian columns (fp64 accumulation; everything else stays fp64) -- include/colmap_amd_ba.h
+    operator_precision: int = 0
 
 
 @dataclass
@@ -203,6 +206,8 @@ class BundleAdjustmentSummary:
     lm_seconds: float = 0.0
     log_cost: Optional[np.ndarray] = None
     log_linear_iters: Optional[np.ndarray] = None
+    linear_solver_used: int = 0     # ba_result.linear_solver_used: the tier that ran (SOLVER_*)
+    factor_seconds: float = 0.0     # exact tiers: time inside the blocked Cholesky
 
     def IsSolutionUsable(self) -> bool:
         return self.termination_type in (BundleAdjustmentTerminationType.CONVERGENCE,
@@ -572,7 +577,7 @@ class ba_options(C.Structure):
         ("max_num_consecutive_invalid_steps", C.c_int32), ("jacobi_scaling", C.c_int32),
         ("num_threads", C.c_int32), ("max_log", C.c_int32),
         ("loss_type", C.c_int32), ("loss_scale", C.c_double),
-        ("linear_solver_type", C.c_int32),
+        ("linear_solver_type", C.c_int32), ("operator_precision", C.c_int32),
     ]
 
 
@@ -584,6 +589,7 @@ class ba_result(C.Structure):
         ("initial_cost", C.c_double), ("final_cost", C.c_double), ("lm_seconds", C.c_double),
         ("num_logged", C.c_int32),
         ("log_cost", C.c_void_p), ("log_radius", C.c_void_p), ("log_linear_iters", C.c_void_p),
+        ("linear_solver_used", C.c_int32), ("factor_seconds", C.c_double),
     ]
 
 
@@ -596,7 +602,8 @@ class ba_comm(C.Structure):
 
 
 SHARD_BY_IMAGE, SHARD_BY_POINT = 0, 1
-SOLVER_ITERATIVE_SCHUR, SOLVER_DENSE_SCHUR, SOLVER_AUTO = 0, 1, 2
+SOLVER_ITERATIVE_SCHUR, SOLVER_DENSE_SCHUR, SOLVER_AUTO, SOLVER_SPARSE_SCHUR = 0, 1, 2, 3
+OPERATOR_F64, OPERATOR_F32 = 0, 1
 POSE_ROT_CONST = 4  # ba_problem.pose_fixed_t: + 4 = the rotation of the pose block is held (colmap_amd_ba.h)
 
 
@@ -733,7 +740,8 @@ def solve_flat(fp: FlatProblem, so: Optional[SolverOptions] = None, gpu_index: i
         num_effective_parameters=r.num_effective_parameters,
         total_linear_iterations=r.total_linear_iterations, initial_cost=r.initial_cost,
         final_cost=r.final_cost, lm_seconds=r.lm_seconds, log_cost=log_cost[: r.num_logged].copy(),
-        log_linear_iters=log_lin[: r.num_logged].copy())
+        log_linear_iters=log_lin[: r.num_logged].copy(), linear_solver_used=int(r.linear_solver_used),
+        factor_seconds=float(r.factor_seconds))
 
 
 def shard_num_observations(fp: FlatProblem, rank: int, world_size: int, sharding: int = SHARD_BY_IMAGE) -> int:

@@ -105,13 +105,30 @@ typedef struct ba_options {
   double loss_scale;                    /* 1.0 */
   /* Linear solver of the LM step (ceres::LinearSolverType as CreateSolverOptions picks it,
    * bundle_adjustment_ceres.cc:203-213): BA_SOLVER_ITERATIVE_SCHUR = the implicit Schur complement with
-   * PCG + Schur-Jacobi (what BASELINE.json benchmarks; default), BA_SOLVER_DENSE_SCHUR = the reduced
-   * camera system S = B - E C^-1 E^T formed explicitly and Cholesky-solved on the device (camera-side
-   * dimension <= 1024), BA_SOLVER_AUTO = the reference's rule: DENSE_SCHUR up to 50 images, else
-   * iterative (its middle tier SPARSE_SCHUR is not built). */
+   * PCG + Schur-Jacobi (what BASELINE.json benchmarks; default); BA_SOLVER_DENSE_SCHUR and
+   * BA_SOLVER_SPARSE_SCHUR = the exact tiers: the reduced camera system S = B + D^2 - E C^-1 E^T formed
+   * explicitly on the device (one wave per 3-D point scatters J_a^T (delta_ab - G_ab) J_b into the camera
+   * pairs the point connects) and solved by a blocked Cholesky factorisation on the f64 matrix cores
+   * (colmap_amd/csrc/ba_schur_explicit.hip). Both names run the same code: Ceres' two tiers differ only in
+   * how S is stored, here it is dense in HBM up to a camera-side dimension of 32 768 (8.6 GB).
+   * BA_SOLVER_AUTO = the reference's rule with its CPU thresholds (bundle_adjustment_ceres.h:68-69):
+   * DENSE_SCHUR up to 50 images, SPARSE_SCHUR up to 1000, else iterative -- on the number of pose blocks,
+   * which is what this flat interface knows; the BundleAdjuster adapters resolve AUTO on the image count
+   * themselves. ba_result.linear_solver_used reports the tier that ran (an exact tier requested beyond its
+   * size limit, or in an image-sharded solve beyond dimension 1024, runs the iterative one). */
   int32_t linear_solver_type;           /* BA_SOLVER_ITERATIVE_SCHUR */
+  /* Storage precision of the Jacobian columns the PCG operator S x streams (MI355X option, no reference
+   * counterpart). BA_OPERATOR_F64 (default): everything reads the fp64 columns; the LM / PCG trajectory
+   * follows the fp64 oracle to 1e-7. BA_OPERATOR_F32: the inner, inexact (eta = 0.1) CG solve reads fp32
+   * copies of the scaled columns with fp64 accumulation -- half the bytes per CG iteration; cost, gradient,
+   * Schur-Jacobi blocks, reduced right-hand side, back-substitution and step evaluation stay fp64, so the
+   * converged solution is unchanged (final cost to 1e-8 relative under a tight gradient tolerance) while
+   * intermediate costs follow the fp64 trajectory only to ~1e-6 relative. Ignored (fp64) with variable
+   * sensor_from_rig blocks, tracks longer than a point tile, and in sharded solves. */
+  int32_t operator_precision;           /* BA_OPERATOR_F64 */
 } ba_options;
-enum { BA_SOLVER_ITERATIVE_SCHUR = 0, BA_SOLVER_DENSE_SCHUR = 1, BA_SOLVER_AUTO = 2 };
+enum { BA_SOLVER_ITERATIVE_SCHUR = 0, BA_SOLVER_DENSE_SCHUR = 1, BA_SOLVER_AUTO = 2, BA_SOLVER_SPARSE_SCHUR = 3 };
+enum { BA_OPERATOR_F64 = 0, BA_OPERATOR_F32 = 1 };
 
 /* CeresBundleAdjustmentOptions::LossFunctionType */
 enum { BA_LOSS_TRIVIAL = 0, BA_LOSS_SOFT_L1 = 1, BA_LOSS_CAUCHY = 2, BA_LOSS_HUBER = 3 };
@@ -132,6 +149,8 @@ typedef struct ba_result {
   double* log_cost;                  /* [max_log] or NULL */
   double* log_radius;
   int32_t* log_linear_iters;
+  int32_t linear_solver_used;        /* BA_SOLVER_* tier that ran (never BA_SOLVER_AUTO) */
+  double factor_seconds;             /* exact tiers: time inside the blocked Cholesky (matrix-core kernels), summed */
 } ba_result;
 
 /* Multi-GPU: every rank holds the full parameter set and calls ba_solve_sharded with the SAME

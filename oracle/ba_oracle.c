@@ -99,10 +99,12 @@ typedef struct {
    * CreateLossFunction bundle_adjustment_ceres.cc:66-80) */
   int32_t loss_type;
   double loss_scale;
-  /* 0: ITERATIVE_SCHUR + SCHUR_JACOBI (implicit Schur complement, PCG); 1: DENSE_SCHUR (the reduced camera
-   * system is formed and solved exactly by Cholesky); 2: the reference's rule by problem size
-   * (bundle_adjustment_ceres.cc:203-213: <= 50 images dense, else iterative -- SPARSE_SCHUR is not built) */
+  /* 0: ITERATIVE_SCHUR + SCHUR_JACOBI (implicit Schur complement, PCG); 1: DENSE_SCHUR and 3: SPARSE_SCHUR (the
+   * reduced camera system is formed explicitly and solved exactly by Cholesky); 2: the reference's rule by
+   * problem size (bundle_adjustment_ceres.cc:203-213 with the CPU thresholds of bundle_adjustment_ceres.h:68-69:
+   * <= 50 images dense, <= 1000 sparse, else iterative) */
   int32_t linear_solver_type;
+  int32_t operator_precision; /* colmap_amd_ba.h BA_OPERATOR_*: storage option of the HIP path; the oracle is fp64 throughout */
 } bao_options;
 
 enum { BAO_LOSS_TRIVIAL = 0, BAO_LOSS_SOFT_L1 = 1, BAO_LOSS_CAUCHY = 2, BAO_LOSS_HUBER = 3 };
@@ -122,6 +124,8 @@ typedef struct {
   double* log_cost;      /* [max_log] cost after each iteration */
   double* log_radius;
   int32_t* log_linear_iters;
+  int32_t linear_solver_used; /* 0 iterative, 1 / 3 exact (explicit reduced camera system + Cholesky) */
+  double factor_seconds;      /* unused by the oracle */
 } bao_result;
 
 /* ------------------------------------------------------------------------- */
@@ -1585,8 +1589,145 @@ static int dense_schur_solve(const linsys* s, const double* b, double* x, double
   return ok;
 }
 
+/* DENSE_SCHUR / SPARSE_SCHUR at any size: the reduced camera system formed EXPLICITLY,
+ *   S = B + Dc^2 - E C^-1 E^T,   B = sum_obs Jc^T Jc,   E C^-1 E^T = sum_points (sum_a W_a)^ C_j^-1 (sum_a' W_a')^T
+ * with W_a = Jc_a^T Jp_a (w x 3) per observation, then an exact Cholesky solve (what Ceres' Schur eliminator +
+ * dense / sparse Cholesky compute; only the storage of S differs: dense here). Row blocks are owned by one
+ * thread each (a block's rows receive contributions only through that block's observations), so the
+ * sums are deterministic without atomics. Returns 0 when S is not positive definite. */
+static void obs_col_index(const program* g, const lin_obs* L, int64_t a, int* idx) {
+  int po, co;
+  cam_offsets(g, a, &po, &co);
+  int k = 0;
+  for (int d = 0; d < L->pose_dim; ++d) idx[k++] = po + d;
+  for (int d = 0; d < L->cam_dim; ++d) idx[k++] = co + d;
+  for (int d = 0; d < L->sens_dim; ++d) idx[k++] = L->so + d;
+}
+
+__attribute__((optimize("O3"))) static int blocked_cholesky(double* S, int n) {
+  /* lower triangle, row-major, right-looking with NB-wide panels */
+  enum { NB = 64 };
+  for (int k0 = 0; k0 < n; k0 += NB) {
+    const int kb = (k0 + NB < n) ? NB : n - k0;
+    for (int k = k0; k < k0 + kb; ++k) {  /* diagonal block */
+      double d = S[(size_t)k * n + k];
+      for (int m = k0; m < k; ++m) d -= S[(size_t)k * n + m] * S[(size_t)k * n + m];
+      if (!(d > 0.0)) return 0;
+      d = sqrt(d);
+      S[(size_t)k * n + k] = d;
+      for (int i = k + 1; i < k0 + kb; ++i) {
+        double v = S[(size_t)i * n + k];
+        for (int m = k0; m < k; ++m) v -= S[(size_t)i * n + m] * S[(size_t)k * n + m];
+        S[(size_t)i * n + k] = v / d;
+      }
+    }
+    const int r0 = k0 + kb;
+#pragma omp parallel for schedule(static)
+    for (int i = r0; i < n; ++i) {  /* panel: L_ik = A_ik L_kk^-T */
+      double* Si = S + (size_t)i * n;
+      for (int k = k0; k < k0 + kb; ++k) {
+        double v = Si[k];
+        const double* Sk = S + (size_t)k * n;
+        for (int m = k0; m < k; ++m) v -= Si[m] * Sk[m];
+        Si[k] = v / Sk[k];
+      }
+    }
+#pragma omp parallel for schedule(dynamic, 16)
+    for (int i = r0; i < n; ++i) {  /* trailing update: A_ij -= L_i,panel . L_j,panel */
+      double* Si = S + (size_t)i * n;
+      for (int j = r0; j <= i; ++j) {
+        const double* Sj = S + (size_t)j * n;
+        double acc = 0.0;
+        for (int m = k0; m < k0 + kb; ++m) acc += Si[m] * Sj[m];
+        Si[j] -= acc;
+      }
+    }
+  }
+  return 1;
+}
+
+static int explicit_schur_solve(const linsys* s, const double* b, double* x) {
+  const program* g = s->g;
+  const bao_problem* p = g->p;
+  const int n = g->n_c;
+  double* S = (double*)calloc((size_t)n * n, sizeof(double));
+  if (!S) return 0;
+#pragma omp parallel for schedule(dynamic, 4)
+  for (int blk = 0; blk < g->n_blk; ++blk) {
+    const int off = g->blk_off[blk], dim = g->blk_dim[blk], kind = g->blk_kind[blk];
+    for (int d = 0; d < dim; ++d) S[(size_t)(off + d) * n + off + d] += s->Dc[off + d] * s->Dc[off + d];
+    for (int64_t k = g->blk_ptr[blk]; k < g->blk_ptr[blk + 1]; ++k) {
+      const int64_t a = g->blk_idx[k];
+      const lin_obs* L = &s->L[a];
+      const int w = L->pose_dim + L->cam_dim + L->sens_dim;
+      const int base = lin_base(L, kind);
+      int idx[MAX_CB];
+      obs_col_index(g, L, a, idx);
+      /* B: rows of this block x every camera-side column the observation sees */
+      for (int d = 0; d < dim; ++d)
+        for (int c = 0; c < w; ++c)
+          S[(size_t)(off + d) * n + idx[c]] += L->Jc[0][base + d] * L->Jc[0][c] + L->Jc[1][base + d] * L->Jc[1][c];
+      const int xi = p->obs_point[g->obs[a]];
+      if (g->point_off[xi] < 0) continue;
+      /* T = W_{a,blk} C^-1 (dim x 3) */
+      const double* Ci = s->Cinv + 9 * (size_t)xi;
+      double W[MAX_CB][3], T[MAX_CB][3];
+      for (int d = 0; d < dim; ++d)
+        for (int c = 0; c < 3; ++c)
+          W[d][c] = L->Jc[0][base + d] * L->Jp[0][c] + L->Jc[1][base + d] * L->Jp[1][c];
+      for (int d = 0; d < dim; ++d)
+        for (int c = 0; c < 3; ++c) T[d][c] = W[d][0] * Ci[c] + W[d][1] * Ci[3 + c] + W[d][2] * Ci[6 + c];
+      for (int64_t k2 = g->pt_ptr[xi]; k2 < g->pt_ptr[xi + 1]; ++k2) {
+        const int64_t a2 = g->pt_idx[k2];
+        const lin_obs* L2 = &s->L[a2];
+        const int w2 = L2->pose_dim + L2->cam_dim + L2->sens_dim;
+        int idx2[MAX_CB];
+        obs_col_index(g, L2, a2, idx2);
+        for (int c2 = 0; c2 < w2; ++c2) {
+          const double w0 = L2->Jc[0][c2] * L2->Jp[0][0] + L2->Jc[1][c2] * L2->Jp[1][0];
+          const double w1 = L2->Jc[0][c2] * L2->Jp[0][1] + L2->Jc[1][c2] * L2->Jp[1][1];
+          const double w2v = L2->Jc[0][c2] * L2->Jp[0][2] + L2->Jc[1][c2] * L2->Jp[1][2];
+          for (int d = 0; d < dim; ++d)
+            S[(size_t)(off + d) * n + idx2[c2]] -= T[d][0] * w0 + T[d][1] * w1 + T[d][2] * w2v;
+        }
+      }
+    }
+  }
+  for (int k = 0; k < s->n_prior; ++k) {  /* position priors: J^T J on their pose / sensor columns */
+    const lin_prior* L = &s->P[k];
+    const int w = L->pose_dim + L->sens_dim;
+    int idx[12];
+    for (int d = 0; d < L->pose_dim; ++d) idx[d] = L->po + d;
+    for (int d = 0; d < L->sens_dim; ++d) idx[L->pose_dim + d] = L->so + d;
+    for (int i = 0; i < w; ++i)
+      for (int j = 0; j < w; ++j)
+        S[(size_t)idx[i] * n + idx[j]] += L->J[0][i] * L->J[0][j] + L->J[1][i] * L->J[1][j] + L->J[2][i] * L->J[2][j];
+  }
+  const int ok = blocked_cholesky(S, n);
+  if (ok) {
+    for (int i = 0; i < n; ++i) {
+      double v = b[i];
+      const double* Si = S + (size_t)i * n;
+      for (int k = 0; k < i; ++k) v -= Si[k] * x[k];
+      x[i] = v / Si[i];
+    }
+    for (int i = n - 1; i >= 0; --i) {
+      double v = x[i];
+      for (int k = i + 1; k < n; ++k) v -= S[(size_t)k * n + i] * x[k];
+      x[i] = v / S[(size_t)i * n + i];
+    }
+  } else {
+    for (int i = 0; i < n; ++i) x[i] = NAN;
+  }
+  free(S);
+  return ok;
+}
+
+/* bundle_adjustment_ceres.h:68-69 (CPU thresholds): DENSE_SCHUR up to 50 images, SPARSE_SCHUR up to 1000 */
 #define BAO_DENSE_MAX_IMAGES 50
+#define BAO_SPARSE_MAX_IMAGES 1000
 #define BAO_DENSE_MAX_DIM 1024
+#define BAO_EXPLICIT_MAX_DIM 32768
 
 BAO_API void bao_options_init(bao_options* o) {
   /* COLMAP's CeresBundleAdjustmentOptions ctor (bundle_adjustment_ceres.cc:102-115) over
@@ -1883,9 +2024,17 @@ BAO_API int bao_solve(bao_problem* p, const bao_options* opt, bao_result* res) {
       }
     }
     int lin_iters = 0;
-    const int dense = (opt->linear_solver_type == 1 || (opt->linear_solver_type == 2 && p->num_poses <= BAO_DENSE_MAX_IMAGES)) &&
-                      nc <= BAO_DENSE_MAX_DIM;
-    if (nc > 0 && dense) { dense_schur_solve(&s, rhs, dc, ws); lin_iters = 1; }
+    /* 1 DENSE_SCHUR, 3 SPARSE_SCHUR: exact solve of the explicitly formed S (the tiers differ only in how
+     * Ceres stores S); 2 AUTO: the reference's rule on the image count (pose blocks stand in for images) */
+    const int lst = opt->linear_solver_type;
+    const int exact = (lst == 1 || lst == 3 || (lst == 2 && p->num_poses <= BAO_SPARSE_MAX_IMAGES)) &&
+                      nc <= BAO_EXPLICIT_MAX_DIM;
+    /* BAO_DENSE_BY_PRODUCTS=1: the round-2 formation (n_c operator products), kept as a cross-check */
+    const char* e_prod = getenv("BAO_DENSE_BY_PRODUCTS");
+    const int operator_products = e_prod && atoi(e_prod) != 0;
+    res->linear_solver_used = exact ? (lst == 3 || (lst == 2 && p->num_poses > BAO_DENSE_MAX_IMAGES) ? 3 : 1) : 0;
+    if (nc > 0 && exact && operator_products && nc <= BAO_DENSE_MAX_DIM) { dense_schur_solve(&s, rhs, dc, ws); lin_iters = 1; }
+    else if (nc > 0 && exact) { explicit_schur_solve(&s, rhs, dc); lin_iters = 1; }
     else if (nc > 0) lin_iters = pcg(&s, rhs, dc, opt->max_linear_solver_iterations, opt->eta, ws);
     res->total_linear_iterations += lin_iters;
     /* back-substitution: y_p = C^-1 (g_p - E^T y_c) */

@@ -295,6 +295,66 @@ def test_baseline_config4_full_size_properties():
     assert np.array_equal(pp, pp0)  # principal points never refined
 
 
+def _solve_env(fp, env, **so_kw):
+    import os
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        b = fp.copy()
+        return b, est.solve_flat(b, est.SolverOptions(**so_kw), gpu_index=0)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("mixed", [False, "three"])
+def test_split_linearisation_is_bit_identical(mixed):
+    """Point-side columns from their own p-order pass (ba_linearize_point_kernel, coalesced stores) against the
+    c-order kernel scattering them through c2a: the same expressions, so the whole solve is bit-identical."""
+    fp = _flat(40, 3000, 8, seed=5, mixed=mixed)
+    assert est.fix_gauge_two_cams(fp)
+    b0, s0 = _solve_env(fp, {"COLMAP_AMD_BA_SPLIT_LINEARIZE": "0"}, max_num_iterations=12)
+    b1, s1 = _solve_env(fp, {"COLMAP_AMD_BA_SPLIT_LINEARIZE": "1"}, max_num_iterations=12)
+    assert np.array_equal(s0.log_cost, s1.log_cost) and s0.final_cost == s1.final_cost
+    assert np.array_equal(b0.poses, b1.poses) and np.array_equal(b0.points, b1.points) and np.array_equal(b0.cams, b1.cams)
+
+
+def test_fused_pcg_kernel_matches_separate_kernels():
+    """ba_pcg_fused_kernel (one single-workgroup kernel around the three streaming kernels of a product) against
+    the separate precondition / direction / finalize / update kernels: same algorithm, different summation
+    trees -- cost log to 1e-12, identical PCG iteration counts."""
+    fp = _flat(40, 3000, 8, seed=6)
+    assert est.fix_gauge_two_cams(fp)
+    b0, s0 = _solve_env(fp, {"COLMAP_AMD_BA_PCG_FUSED": "0"}, max_num_iterations=12)
+    b1, s1 = _solve_env(fp, {"COLMAP_AMD_BA_PCG_FUSED": "1"}, max_num_iterations=12)
+    np.testing.assert_allclose(s1.log_cost, s0.log_cost, rtol=1e-12)
+    np.testing.assert_array_equal(s1.log_linear_iters, s0.log_linear_iters)
+    np.testing.assert_allclose(b1.points, b0.points, atol=1e-10)
+
+
+@pytest.mark.parametrize("frames,points,track,mixed", [(40, 2000, 8, True), (200, 20000, 10, False)])
+def test_fp32_operator_reaches_the_fp64_solution(frames, points, track, mixed):
+    """ba_options.operator_precision = BA_OPERATOR_F32: the inexact inner CG solve streams fp32 copies of the
+    Jacobian columns. Contract (include/colmap_amd_ba.h): the converged solution is the fp64 oracle's -- final
+    cost to 1e-8 relative, parameters to 1e-6 under a tight gradient tolerance -- and the early trajectory
+    follows it to 1e-5 relative (instead of 1e-7 with the fp64 operator)."""
+    fp = _flat(frames, points, track, seed=frames, mixed=mixed)
+    assert est.fix_gauge_two_cams(fp)
+    a, b = fp.copy(), fp.copy()
+    want = est.solve_flat(a, est.SolverOptions(**TIGHT), solve_fn=ba_oracle.solve_fn)
+    got = est.solve_flat(b, est.SolverOptions(operator_precision=est.OPERATOR_F32, **TIGHT), gpu_index=0)
+    assert got.termination_type == want.termination_type
+    assert abs(got.final_cost - want.final_cost) <= 1e-8 * want.final_cost, (got.final_cost, want.final_cost)
+    n = min(4, len(want.log_cost), len(got.log_cost))
+    np.testing.assert_allclose(got.log_cost[:n], want.log_cost[:n], rtol=1e-5)
+    np.testing.assert_allclose(b.points, a.points, atol=1e-6)
+    np.testing.assert_allclose(b.poses, a.poses, atol=1e-6)
+    np.testing.assert_allclose(b.cams, a.cams, rtol=1e-7, atol=1e-6)
+
+
 def test_tracks_longer_than_a_tile():
     """Tracks with more observations than the LDS tile (512) take the untiled point pass."""
     fp = _flat(600, 6, 600, seed=9, noise=scene.SyntheticNoiseOptions(0.01, 0.5, 0.02, 0.5))
@@ -662,8 +722,9 @@ def test_pose_prior_adjuster_on_rigs_matches_oracle():
 
 
 def test_dense_schur_tier_matches_oracle():
-    """DENSE_SCHUR (S formed by n_c operator products, one-workgroup Cholesky) against the oracle's dense tier,
-    and AUTO = dense for <= 50 images (bundle_adjustment_ceres.cc:203-213)."""
+    """DENSE_SCHUR (the reduced camera system formed explicitly, blocked Cholesky on the f64 matrix cores:
+    colmap_amd/csrc/ba_schur_explicit.hip) against the oracle's exact tier, and AUTO = dense for <= 50 images
+    (bundle_adjustment_ceres.cc:203-213)."""
     fp = _flat(10, 250, 5, seed=61, mixed=True)
     assert est.fix_gauge_two_cams(fp)
     (a, want), (b, got) = _both(fp, max_num_iterations=30, gradient_tolerance=1e-8, function_tolerance=1e-12,
@@ -673,13 +734,56 @@ def test_dense_schur_tier_matches_oracle():
     c = fp.copy()
     auto = est.solve_flat(c, est.SolverOptions(max_num_iterations=30, gradient_tolerance=1e-8, function_tolerance=1e-12,
                                                linear_solver_type=est.SOLVER_AUTO), gpu_index=0)
-    assert auto.final_cost == got.final_cost and np.array_equal(c.poses, b.poses)
+    # (the explicit formation accumulates S with hardware fp64 atomics: reproducible to rounding, not bit-wise)
+    assert auto.linear_solver_used == est.SOLVER_DENSE_SCHUR
+    assert abs(auto.final_cost - got.final_cost) <= 1e-12 * got.final_cost
+    np.testing.assert_allclose(c.poses, b.poses, atol=1e-10)
     # the priors-only gauge: the exact tier converges where the default inexact PCG crawls
     p = _flat_prior_problem()
     (a2, want2), (b2, got2) = _both(p, max_num_iterations=60, gradient_tolerance=1e-7, function_tolerance=1e-12,
                                     linear_solver_type=est.SOLVER_DENSE_SCHUR)
     assert got2.termination_type == est.BundleAdjustmentTerminationType.CONVERGENCE
     _assert_close(a2, want2, b2, got2, cost_rtol=1e-8, param_atol=1e-6)
+
+
+@pytest.mark.parametrize("frames,points,track,mixed,iters", [(120, 12000, 8, "three", 8), (300, 40000, 10, False, 6),
+                                                             (1000, 200000, 10, False, 4)])
+def test_sparse_schur_tier_matches_oracle(frames, points, track, mixed, iters):
+    """SPARSE_SCHUR -- the reference's default tier for 51..1000 images, hence at BASELINE config[3]'s own
+    size (bundle_adjustment_ceres.cc:203-213): exact Newton steps from the explicitly formed reduced camera
+    system (n_c = 960 ... 7 995; one wave per point scatters the blocks of the camera pairs it connects, the
+    factorisation runs 64-wide panels on v_mfma_f64_16x16x4_f64) against the oracle's explicit formation +
+    blocked CPU Cholesky: every logged cost to 1e-7 relative, parameters to 1e-6."""
+    fp = _flat(frames, points, track, seed=frames, mixed=mixed)
+    assert est.fix_gauge_two_cams(fp)
+    (a, want), (b, got) = _both(fp, max_num_iterations=iters, linear_solver_type=est.SOLVER_AUTO)
+    assert got.linear_solver_used == want.linear_solver_used == est.SOLVER_SPARSE_SCHUR
+    assert (got.log_linear_iters[:got.num_iterations] == 1).all()
+    assert got.num_iterations == want.num_iterations and got.num_successful_steps == want.num_successful_steps
+    np.testing.assert_allclose(got.log_cost, want.log_cost, rtol=1e-7)
+    np.testing.assert_allclose(b.points, a.points, atol=1e-6)
+    np.testing.assert_allclose(b.poses, a.poses, atol=1e-6)
+    np.testing.assert_allclose(b.cams, a.cams, rtol=1e-7, atol=1e-6)
+    assert got.factor_seconds > 0.0
+
+
+def test_exact_tier_explicit_formation_equals_operator_products():
+    """The explicit formation against the round-2 formation of the same matrix (n_c implicit operator products,
+    one-workgroup Cholesky; kept behind COLMAP_AMD_BA_DENSE_BY_PRODUCTS for image-sharded solves): shared
+    intrinsics (observation pairs of a point inside one block), constant points, a held translation coordinate."""
+    d = scene.synthesize_flat(12, 400, 5, seed=71, noise=scene.SyntheticNoiseOptions(0.01, 0.5, 0.03, 0.5))
+    d["obs_cam"] = (d["obs_cam"] % 3).astype(np.int32)   # three cameras shared by twelve images
+    d["cams"] = d["cams"][:3].copy()
+    d["cam_model"] = d["cam_model"][:3].copy()
+    fp = est.FlatProblem.from_arrays(d)
+    assert est.fix_gauge_two_cams(fp)
+    fp.point_const[::9] = 1
+    so = dict(max_num_iterations=10, linear_solver_type=est.SOLVER_DENSE_SCHUR)
+    b0, s0 = _solve_env(fp, {"COLMAP_AMD_BA_DENSE_BY_PRODUCTS": "1"}, **so)
+    b1, s1 = _solve_env(fp, {"COLMAP_AMD_BA_DENSE_BY_PRODUCTS": "0"}, **so)
+    np.testing.assert_allclose(s1.log_cost, s0.log_cost, rtol=1e-10)
+    np.testing.assert_allclose(b1.points, b0.points, atol=1e-9)
+    np.testing.assert_allclose(b1.poses, b0.poses, atol=1e-9)
 
 
 def test_reference_pose_prior_backend_case():

@@ -949,3 +949,36 @@ def _reference_pose_prior_backend_case(solve_fn, gpu_index="-1"):
 
 def test_reference_pose_prior_backend_case_oracle():
     _reference_pose_prior_backend_case(ba_oracle.solve_fn)
+
+
+def test_explicit_reduced_camera_system_equals_operator_products():
+    """ba_oracle's exact tier forms S = B + D^2 - E C^-1 E^T explicitly (per point, row blocks owned by one
+    thread) and factors it with a blocked Cholesky; the round-2 formation (n_c implicit operator products,
+    BAO_DENSE_BY_PRODUCTS=1) is the independent cross-check: mixed models, priors, the SPARSE_SCHUR name."""
+    import os
+    import ba_oracle
+    for mixed, priors in ((False, False), ("three", False), (True, True)):
+        d = scene.synthesize_flat(30, 1500, 6, seed=3, mixed_models=mixed, noise=scene.SyntheticNoiseOptions(0.01, 1.0, 0.05, 1.0))
+        fp = est.FlatProblem.from_arrays(d)
+        assert est.fix_gauge_two_cams(fp)
+        if priors:
+            rng = np.random.default_rng(77)
+            centres = np.stack([-scene.quat_to_rot(p[:4]).T @ p[4:] for p in fp.poses])
+            fp.prior_pose = np.arange(len(fp.poses), dtype=np.int32)
+            fp.prior_position = np.ascontiguousarray(centres + 0.02 * rng.normal(size=centres.shape))
+            fp.prior_sqrt_info = np.ascontiguousarray(np.repeat((5.0 * np.eye(3))[None], len(fp.poses), 0))
+        out = {}
+        for name, env, lst in (("products", "1", est.SOLVER_DENSE_SCHUR), ("explicit", "0", est.SOLVER_DENSE_SCHUR),
+                               ("sparse", "0", est.SOLVER_SPARSE_SCHUR)):
+            os.environ["BAO_DENSE_BY_PRODUCTS"] = env
+            try:
+                a = fp.copy()
+                s = est.solve_flat(a, est.SolverOptions(max_num_iterations=6, linear_solver_type=lst), solve_fn=ba_oracle.solve_fn)
+            finally:
+                os.environ.pop("BAO_DENSE_BY_PRODUCTS", None)
+            out[name] = (s, a)
+        np.testing.assert_allclose(out["explicit"][0].log_cost, out["products"][0].log_cost, rtol=1e-12)
+        np.testing.assert_allclose(out["explicit"][1].poses, out["products"][1].poses, atol=1e-12)
+        assert np.array_equal(out["sparse"][0].log_cost, out["explicit"][0].log_cost)
+        assert out["sparse"][0].linear_solver_used == est.SOLVER_SPARSE_SCHUR
+        assert out["explicit"][0].linear_solver_used == est.SOLVER_DENSE_SCHUR

@@ -7,7 +7,9 @@ What can and cannot be equal:
   * integer work (PRNG states, the re-quantised reference image, the first random depth) is BIT-EXACT;
   * deterministic float stages (bilateral sums, random normals, ComputeInitialCost) differ from
     `pm_oracle order=0` only through exp / sin / cos (device libm in the reference build, fixed
-    polynomials in the oracle and the HIP kernel: <= 2 ulp each): tolerances 2e-6 / 2e-5 below;
+    polynomials in the oracle and the HIP kernel: <= 2 ulp each): bilateral sums within 2e-6, initial NCC
+    costs within 5e-4 (observed max 8.8e-5, mean 9e-7, 99.9th percentile 1.5e-5: a cost is 1 - a ratio of
+    variances, which amplifies ulps where the patch variance is small);
   * full solves are a stochastic argmin over those values, one flipped comparison changes a pixel's
     trajectory: compared through agreement statistics (stated per test, with the observed values in
     profiles/r03_pm_ref_parity.json) and against ground truth.
@@ -107,14 +109,15 @@ def test_reference_initial_cost(pm_oracle, shape):
     o.num_iterations, o.max_sweeps, o.order = 5, 0, 0
     want = pm_oracle.run(o, imgs, r, src, want_cost=True)
     d0 = np.abs(got["cost"] - want["cost"])
-    assert d0.max() < 2e-5, d0.max()
     o1, h = paired_options(pm_oracle, depth_min=dmin, depth_max=dmax, geom_consistency=0, filter=0, max_sweeps=0)
     pm = mvs.PatchMatch(h, hip_problem(views, r, src))
     pm.Run()
     d1 = np.abs(got["cost"] - pm.GetCostMap())
-    assert d1.max() < 5e-4 and d1.mean() < 2e-5, (d1.max(), d1.mean())
     _record("initial_cost_" + shape, oracle_order0_max_abs=d0.max(), oracle_order0_mean_abs=d0.mean(),
-            hip_max_abs=d1.max(), hip_mean_abs=d1.mean())
+            oracle_order0_p999=np.quantile(d0, 0.999), hip_max_abs=d1.max(), hip_mean_abs=d1.mean(),
+            hip_p999=np.quantile(d1, 0.999))
+    assert d0.max() < 5e-4 and d0.mean() < 2e-6, (d0.max(), d0.mean())
+    assert d1.max() < 5e-4 and d1.mean() < 2e-5, (d1.max(), d1.mean())
 
 
 def _solve_three_ways(pm_oracle, views, r, src, maps=None, **kw):
@@ -143,26 +146,29 @@ def _gt_stats(depth, gt):
 def test_reference_full_solve_config0_photometric(pm_oracle):
     """BASELINE.json config[0] (3 x 640 x 480, f = 600, S = 2, default options, photometric + filter):
     the reference, the oracle in the reference's order and the HIP path solve the same problem from
-    the same PRNG streams. Required: the three depth maps agree pixel-wise to 1 % on >= 90 % of the
-    pixels all of them keep, keep the same pixels on >= 95 %, and have the same accuracy against
-    ground truth (median relative error within 2e-4, fraction within 1 % within 0.02)."""
+    the same PRNG streams. Required: the depth maps agree with the reference's pixel-wise to 1e-2 on >= 98 %
+    (1e-3 on >= 90 %) of the pixels both keep, the filters keep the same pixels on >= 99 %, and the accuracy
+    against ground truth is the same (median relative error within 5e-5, fractions within 0.005)."""
     views = syn.make_scene(3, 640, 480, focal=600.0, arc_deg=8.0)
     out_ref, out_o0, out_hip = _solve_three_ways(pm_oracle, views, 1, [0, 2], geom_consistency=0, filter=1)
     gt = views[1].depth
     a0, a1 = _agreement(out_o0["depth"], out_ref["depth"]), _agreement(out_hip["depth"], out_ref["depth"])
     g = {k: _gt_stats(v["depth"], gt) for k, v in (("reference", out_ref), ("oracle_order0", out_o0), ("hip", out_hip))}
     _record("config0_photometric", oracle_order0_vs_reference=a0, hip_vs_reference=a1, ground_truth=g)
+    # observed (profiles/r03_pm_ref_parity.json): same_kept 0.998 / 0.997, within 1e-3 0.937 / 0.925, within 1e-2
+    # 0.992 / 0.990 (oracle order 0 / HIP); ground-truth medians 1.46e-4 / 1.47e-4 / 1.34e-4, kept 0.5120 / 0.5119 / 0.5120
     for a in (a0, a1):
-        assert a["same_kept"] >= 0.95 and a["within_1e2"] >= 0.90, a
+        assert a["same_kept"] >= 0.99 and a["within_1e2"] >= 0.98 and a["within_1e3"] >= 0.90, a
     for k in ("oracle_order0", "hip"):
-        assert abs(g[k]["median_rel"] - g["reference"]["median_rel"]) < 2e-4, g
-        assert abs(g[k]["within_1pct"] - g["reference"]["within_1pct"]) < 0.02, g
-        assert abs(g[k]["kept"] - g["reference"]["kept"]) < 0.02, g
+        assert abs(g[k]["median_rel"] - g["reference"]["median_rel"]) < 5e-5, g
+        assert abs(g[k]["within_1pct"] - g["reference"]["within_1pct"]) < 0.005, g
+        assert abs(g[k]["kept"] - g["reference"]["kept"]) < 0.005, g
 
 
 def test_reference_full_solve_s20_geometric(pm_oracle):
     """config[2]'s pass (geometric consistency + both filters, S = 20, M = 15) on 96 x 72 images with
-    ground-truth source maps, two iterations: same agreement bars as above."""
+    ground-truth source maps, two iterations: >= 99 % of the pixels within 1e-3 of the reference's depth, the
+    same pixels kept and the same consistency masks on >= 99.5 %."""
     views = scene(22, 96, 72, 3.6 * 21)
     r = 11
     src = [i for i in range(1, 22) if i != r]
@@ -176,19 +182,21 @@ def test_reference_full_solve_s20_geometric(pm_oracle):
     m1 = (out_hip["mask"] == out_ref["mask"]).mean()
     _record("s20_geometric", oracle_order0_vs_reference=a0, hip_vs_reference=a1, ground_truth=g,
             mask_equal_oracle=m0, mask_equal_hip=m1)
+    # observed: oracle order 0 reproduces the reference's maps EXACTLY on every pixel (median |difference| 0,
+    # masks equal); HIP: 99.95 % of the pixels within 1e-3, same pixels kept, masks equal
     for a in (a0, a1):
-        assert a["same_kept"] >= 0.95 and a["within_1e2"] >= 0.90, a
-    assert m0 >= 0.95 and m1 >= 0.95
+        assert a["same_kept"] >= 0.995 and a["within_1e3"] >= 0.99, a
+    assert m0 >= 0.995 and m1 >= 0.995
     for k in ("oracle_order0", "hip"):
-        assert abs(g[k]["within_1pct"] - g["reference"]["within_1pct"]) < 0.03, g
+        assert abs(g[k]["within_1pct"] - g["reference"]["within_1pct"]) < 0.005, g
 
 
 def test_reference_first_sweeps_s4(pm_oracle):
     """One iteration (four sweeps, no filter) on the 5-view scene: trajectories have had little time to
-    diverge, so the bar is tighter -- >= 97 % of the pixels within 1e-3 relative depth of the reference."""
+    diverge, so the bar is tighter -- >= 99 % of the pixels within 1e-3 relative depth of the reference."""
     views = scene()
     out_ref, out_o0, out_hip = _solve_three_ways(pm_oracle, views, 2, [0, 1, 3, 4], geom_consistency=0, filter=0,
                                                  num_iterations=1)
     a0, a1 = _agreement(out_o0["depth"], out_ref["depth"]), _agreement(out_hip["depth"], out_ref["depth"])
     _record("first_iteration_s4", oracle_order0_vs_reference=a0, hip_vs_reference=a1)
-    assert a0["within_1e3"] >= 0.90 and a1["within_1e3"] >= 0.85, (a0, a1)
+    assert a0["within_1e3"] >= 0.99 and a1["within_1e3"] >= 0.99, (a0, a1)  # observed 1.0 / 0.9993
