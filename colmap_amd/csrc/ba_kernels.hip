@@ -157,6 +157,18 @@ struct View {
   double* scalars;
 };
 
+// The two 16-byte-per-observation vectors that cross between the observation orders inside an implicit
+// product: jx = J_c x is produced and stored in C-ORDER, v = J_c x - E u in P-ORDER, both as interleaved
+// (row 0, row 1) pairs. Each is written coalesced by its producer and GATHERED (one 16-byte load through the
+// permutation) by its consumer; the previous layout (two planes, scattered 8-byte stores through the
+// permutation) cost eight 64-byte write transactions per observation and product.
+__device__ __forceinline__ double2 pair_load(const double* __restrict__ p, int i) {
+  return reinterpret_cast<const double2*>(p)[i];
+}
+__device__ __forceinline__ void pair_store(double* __restrict__ p, int i, double a, double b) {
+  reinterpret_cast<double2*>(p)[i] = make_double2(a, b);
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
   return v;
@@ -1126,17 +1138,19 @@ __global__ void ba_point_pass_kernel(View V, const double* __restrict__ Cinv, co
   const size_t N = (size_t)V.n_obs;
   const int beg = V.pt_ptr[j], end = V.pt_ptr[j + 1];
   if (off < 0) {  // constant point: no point block
-    if (MODE == 0) for (int o = beg; o < end; ++o) { const int c = V.a2c[o]; v[c] = jx[o]; v[N + c] = jx[N + o]; }
-    if (MODE == 1) for (int o = beg; o < end; ++o) { const int c = V.a2c[o]; v[c] = 0.0; v[N + c] = 0.0; }
+    if (MODE == 0) for (int o = beg; o < end; ++o) { const double2 j2 = pair_load(jx, V.a2c[o]); pair_store(v, o, j2.x, j2.y); }
+    if (MODE == 1) for (int o = beg; o < end; ++o) pair_store(v, o, 0.0, 0.0);
     return;
   }
   double t[3] = {0, 0, 0};
   if (MODE != 1) {
-    for (int o = beg; o < end; ++o)
+    for (int o = beg; o < end; ++o) {
+      const double2 j2 = pair_load(jx, V.a2c[o]);
       for (int r = 0; r < 2; ++r) {
-        const double x = jx[r * N + o];
+        const double x = r ? j2.y : j2.x;
         for (int c = 0; c < 3; ++c) t[c] += V.Jpt[(size_t)(r * 3 + c) * N + o] * x;
       }
+    }
   }
   if (MODE == 1) for (int c = 0; c < 3; ++c) t[c] = gp[off + c];
   if (MODE == 2) for (int c = 0; c < 3; ++c) t[c] = gp[off + c] - t[c];
@@ -1148,12 +1162,15 @@ __global__ void ba_point_pass_kernel(View V, const double* __restrict__ Cinv, co
     return;
   }
   for (int o = beg; o < end; ++o) {
-    const int c = V.a2c[o];
+    double2 j2 = make_double2(0.0, 0.0);
+    if (MODE == 0) j2 = pair_load(jx, V.a2c[o]);
+    double out[2];
     for (int r = 0; r < 2; ++r) {
       const double eu = V.Jpt[(size_t)(r * 3 + 0) * N + o] * u[0] + V.Jpt[(size_t)(r * 3 + 1) * N + o] * u[1] +
                         V.Jpt[(size_t)(r * 3 + 2) * N + o] * u[2];
-      v[r * N + c] = (MODE == 0 ? jx[r * N + o] : 0.0) - eu;
+      out[r] = (r ? j2.y : j2.x) - eu;
     }
+    pair_store(v, o, out[0], out[1]);
   }
 }
 
@@ -1166,11 +1183,13 @@ __global__ void ba_point_t_kernel(View V, const double* __restrict__ jx, double*
   if (off < 0) return;
   const size_t N = (size_t)V.n_obs;
   double acc[3] = {0, 0, 0};
-  for (int o = V.pt_ptr[j]; o < V.pt_ptr[j + 1]; ++o)
+  for (int o = V.pt_ptr[j]; o < V.pt_ptr[j + 1]; ++o) {
+    const double2 j2 = pair_load(jx, V.a2c[o]);
     for (int r = 0; r < 2; ++r) {
-      const double x = jx[r * N + o];
+      const double x = r ? j2.y : j2.x;
       for (int c = 0; c < 3; ++c) acc[c] += V.Jpt[(size_t)(r * 3 + c) * N + o] * x;
     }
+  }
   for (int c = 0; c < 3; ++c) t[off + c] = acc[c];
 }
 // MODE 0: v_o = jx_o - E_o C^-1 t ; MODE 2: dp = C^-1 (g_p - t)
@@ -1184,7 +1203,7 @@ __global__ void ba_point_apply_kernel(View V, const double* __restrict__ Cinv, c
   const size_t N = (size_t)V.n_obs;
   const int beg = V.pt_ptr[j], end = V.pt_ptr[j + 1];
   if (off < 0) {
-    if (MODE == 0) for (int o = beg; o < end; ++o) { const int c = V.a2c[o]; v[c] = jx[o]; v[N + c] = jx[N + o]; }
+    if (MODE == 0) for (int o = beg; o < end; ++o) { const double2 j2 = pair_load(jx, V.a2c[o]); pair_store(v, o, j2.x, j2.y); }
     return;
   }
   double tt[3];
@@ -1197,12 +1216,14 @@ __global__ void ba_point_apply_kernel(View V, const double* __restrict__ Cinv, c
     return;
   }
   for (int o = beg; o < end; ++o) {
-    const int c = V.a2c[o];
+    const double2 j2 = pair_load(jx, V.a2c[o]);
+    double out[2];
     for (int r = 0; r < 2; ++r) {
       const double eu = V.Jpt[(size_t)(r * 3 + 0) * N + o] * u[0] + V.Jpt[(size_t)(r * 3 + 1) * N + o] * u[1] +
                         V.Jpt[(size_t)(r * 3 + 2) * N + o] * u[2];
-      v[r * N + c] = jx[r * N + o] - eu;
+      out[r] = (r ? j2.y : j2.x) - eu;
     }
+    pair_store(v, o, out[0], out[1]);
   }
 }
 
@@ -1226,8 +1247,9 @@ __global__ void __launch_bounds__(TILE_PTS) ba_point_pass_tiled_kernel(View V, c
 #pragma unroll
     for (int c = 0; c < 6; ++c) sJ[c][i] = (double)Jp[(size_t)c * N + a0 + i];
     if (MODE != 1) {
-      sx[0][i] = jx[a0 + i];
-      sx[1][i] = jx[N + a0 + i];
+      const double2 j2 = pair_load(jx, V.a2c[a0 + i]);  // gather: jx lives in c-order
+      sx[0][i] = j2.x;
+      sx[1][i] = j2.y;
     }
   }
   __syncthreads();
@@ -1267,11 +1289,7 @@ __global__ void __launch_bounds__(TILE_PTS) ba_point_pass_tiled_kernel(View V, c
   }
   if (MODE == 2) return;
   __syncthreads();
-  for (int i = threadIdx.x; i < na; i += TILE_PTS) {
-    const int c = V.a2c[a0 + i];
-    v[c] = sx[0][i];
-    v[N + c] = sx[1][i];
-  }
+  for (int i = threadIdx.x; i < na; i += TILE_PTS) pair_store(v, a0 + i, sx[0][i], sx[1][i]);  // p-order, coalesced
 }
 
 // Point-major reductions over the same tiles, columns staged through LDS (coalesced loads over the tile's
@@ -1298,8 +1316,9 @@ __global__ void __launch_bounds__(TILE_PTS) ba_point_reduce_tiled_kernel(View V,
     sr[0][i] = V.res_p[a0 + i];
     sr[1][i] = V.res_p[N + a0 + i];
     if (MODE == 1) {
-      sx[0][i] = jx[a0 + i];
-      sx[1][i] = jx[N + a0 + i];
+      const double2 j2 = pair_load(jx, V.a2c[a0 + i]);
+      sx[0][i] = j2.x;
+      sx[1][i] = j2.y;
     }
   }
   __syncthreads();
@@ -1384,9 +1403,7 @@ __global__ void ba_obs_jx_kernel(View V, const double* __restrict__ x, double* _
       }
     }
   }
-  const int a = V.c2a[o];
-  jx[a] = a0;
-  jx[N + a] = a1;
+  pair_store(jx, o, a0, a1);  // c-order, coalesced
 }
 
 // model cost change: -(J step) . (r + J step / 2), step = (dc, dp) already negated
@@ -1432,16 +1449,18 @@ __global__ void __launch_bounds__(256) ba_model_from_jx_kernel(View V, const dou
     const int off = V.pt_off[j];
     double y[3] = {0.0, 0.0, 0.0};
     if (off >= 0) { y[0] = dpv[off]; y[1] = dpv[off + 1]; y[2] = dpv[off + 2]; }
-    for (int o = V.pt_ptr[j]; o < V.pt_ptr[j + 1]; ++o)
+    for (int o = V.pt_ptr[j]; o < V.pt_ptr[j + 1]; ++o) {
+      const double2 j2 = pair_load(jx, V.a2c[o]);
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
-        double m = jx[r * N + o];
+        double m = r ? j2.y : j2.x;
         if (off >= 0)
           m += V.Jpt[(size_t)(r * 3) * N + o] * y[0] + V.Jpt[(size_t)(r * 3 + 1) * N + o] * y[1] +
                V.Jpt[(size_t)(r * 3 + 2) * N + o] * y[2];
         m = -m;
         acc -= m * (V.res_p[r * N + o] + 0.5 * m);
       }
+    }
   }
   acc = block_sum(acc);
   if (threadIdx.x == 0) partials[blockIdx.x] = acc;
@@ -1464,6 +1483,8 @@ __device__ __forceinline__ const double* blk_col(const View& V, int kind, int r,
 }
 
 // y_b += J_b^T v  (v: 2 rows per observation). With DIAG: also diag_b += colsq(J_b).
+// DIAG (gradient pass): v is the c-order residual in two planes. Otherwise v is the p-order pair vector of an
+// implicit product, gathered through c2a (one 16-byte load per observation).
 template <bool DIAG, int BD, typename JT = double>
 __global__ void __launch_bounds__(64) ba_block_jtv_kernel(View V, const double* __restrict__ v,
                                                          double* __restrict__ y, double* __restrict__ diag) {
@@ -1481,8 +1502,15 @@ __global__ void __launch_bounds__(64) ba_block_jtv_kernel(View V, const double* 
     const int o2 = o + 64;
     const bool two = o2 < end;
     const int oz = two ? o2 : o;
-    const double v0 = v[o], v1 = v[N + o];
-    const double w0 = v[oz], w1 = v[N + oz];
+    double v0, v1, w0, w1;
+    if (DIAG) {
+      v0 = v[o]; v1 = v[N + o];
+      w0 = v[oz]; w1 = v[N + oz];
+    } else {
+      const double2 p0 = pair_load(v, V.c2a[o]), p1 = pair_load(v, V.c2a[oz]);
+      v0 = p0.x; v1 = p0.y;
+      w0 = p1.x; w1 = p1.y;
+    }
     double j0[BD], j1[BD], k0[BD], k1[BD];
 #pragma unroll
     for (int c = 0; c < BD; ++c)

@@ -5,14 +5,20 @@
  * against (tests/, __graft_entry__.smoke(), bench.py's cpu_baseline leg). The
  * product (colmap_amd/) never includes, links, or calls it.
  *
- * PARITY STATUS: **parity unpinned** by the reference. The reference tree holds
- * no golden vectors / known-answer tests for the PatchMatch algorithm itself
- * (only gpu_mat_test.cu for rotate/fill and symbol-exists
- * smoke tests), and the reference cannot be compiled here (needs a CUDA/HIP
- * device at run time plus Eigen/glog/Boost which are absent). What IS pinned
- * against the reference's own tests: the host pose helpers (mvs/image_test.cc
- * known answers, see tests/test_pm_oracle.py) and the CCW rotation index map
- * (mvs/gpu_mat_test.cu). Everything else follows the cited source line by line.
+ * PARITY STATUS: **pinned against the reference itself** (round 3). The reference tree holds no golden
+ * vectors / known-answer tests for the PatchMatch algorithm, but its own
+ * patch_match_cuda.cu / gpu_mat_prng.cu / gpu_mat_ref_image.cu compile for gfx950 where they lie
+ * (`make -C oracle ref` -> oracle/_ref/libref_pm.so; oracle/ref_shim/README.md: a software texture
+ * stands in for the image instructions gfx950 lacks, glog / Eigen / Bitmap stubs for the absent
+ * dependencies). tests/test_pm_ref.py runs that library on the GPU box against this file in the
+ * reference's order (order = 0): PRNG states, re-quantised reference image and first random depth
+ * bit-exact, bilateral sums within 2e-7, random normals bit-equal, ComputeInitialCost within 8.8e-5
+ * (mean 9e-7; the only arithmetic difference is device libm exp / sincos vs the polynomials below),
+ * one iteration of sweeps: every pixel's depth identical; config[0] full solve: 99.2 % of the pixels
+ * within 1e-2, same filter decisions on 99.8 %, same accuracy against ground truth
+ * (profiles/r03_pm_ref_parity.json). Also pinned: the host pose helpers (mvs/image_test.cc known
+ * answers, tests/test_pm_oracle.py), the CCW rotation index map (mvs/gpu_mat_test.cu), the XORWOW
+ * generator against rocRAND on the device (tests/hip/rocrand_pin.hip).
  *
  * All citations are relative to /root/reference/src/colmap/mvs/ unless noted.
  *

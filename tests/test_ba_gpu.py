@@ -778,9 +778,12 @@ def test_exact_tier_explicit_formation_equals_operator_products():
     fp = est.FlatProblem.from_arrays(d)
     assert est.fix_gauge_two_cams(fp)
     fp.point_const[::9] = 1
-    so = dict(max_num_iterations=10, linear_solver_type=est.SOLVER_DENSE_SCHUR)
+    # four exact Newton steps (at the floor of the projected gradient the two formations stop on different
+    # iterations: the accept / reject decisions there are rounding noise)
+    so = dict(max_num_iterations=4, linear_solver_type=est.SOLVER_DENSE_SCHUR)
     b0, s0 = _solve_env(fp, {"COLMAP_AMD_BA_DENSE_BY_PRODUCTS": "1"}, **so)
     b1, s1 = _solve_env(fp, {"COLMAP_AMD_BA_DENSE_BY_PRODUCTS": "0"}, **so)
+    assert len(s1.log_cost) == len(s0.log_cost)
     np.testing.assert_allclose(s1.log_cost, s0.log_cost, rtol=1e-10)
     np.testing.assert_allclose(b1.points, b0.points, atol=1e-9)
     np.testing.assert_allclose(b1.poses, b0.poses, atol=1e-9)
