@@ -158,10 +158,12 @@ struct View {
 };
 
 // The two 16-byte-per-observation vectors that cross between the observation orders inside an implicit
-// product: jx = J_c x is produced and stored in C-ORDER, v = J_c x - E u in P-ORDER, both as interleaved
-// (row 0, row 1) pairs. Each is written coalesced by its producer and GATHERED (one 16-byte load through the
-// permutation) by its consumer; the previous layout (two planes, scattered 8-byte stores through the
-// permutation) cost eight 64-byte write transactions per observation and product.
+// product, jx = J_c x and v = J_c x - E u, are both stored in C-ORDER as interleaved (row 0, row 1) pairs:
+// the camera-side kernels (ba_obs_jx, ba_block_jtv) access them coalesced, and the point pass -- the one
+// kernel that works in p-order -- GATHERS jx (one 16-byte load per observation through a2c) and SCATTERS v
+// (one 16-byte store). Measured at BA-1 per product: two planes with 8-byte scattered stores on both
+// crossings 106 + 81 + 56 us (obs_jx, point pass, jtv); gathers on both crossings 54 + 59 + 107 us (the
+// gather inside the wave-per-chunk reduction of jtv is the expensive one); this layout: see DESIGN.md 2.4.
 __device__ __forceinline__ double2 pair_load(const double* __restrict__ p, int i) {
   return reinterpret_cast<const double2*>(p)[i];
 }
@@ -1138,8 +1140,8 @@ __global__ void ba_point_pass_kernel(View V, const double* __restrict__ Cinv, co
   const size_t N = (size_t)V.n_obs;
   const int beg = V.pt_ptr[j], end = V.pt_ptr[j + 1];
   if (off < 0) {  // constant point: no point block
-    if (MODE == 0) for (int o = beg; o < end; ++o) { const double2 j2 = pair_load(jx, V.a2c[o]); pair_store(v, o, j2.x, j2.y); }
-    if (MODE == 1) for (int o = beg; o < end; ++o) pair_store(v, o, 0.0, 0.0);
+    if (MODE == 0) for (int o = beg; o < end; ++o) { const int c = V.a2c[o]; const double2 j2 = pair_load(jx, c); pair_store(v, c, j2.x, j2.y); }
+    if (MODE == 1) for (int o = beg; o < end; ++o) pair_store(v, V.a2c[o], 0.0, 0.0);
     return;
   }
   double t[3] = {0, 0, 0};
@@ -1162,15 +1164,16 @@ __global__ void ba_point_pass_kernel(View V, const double* __restrict__ Cinv, co
     return;
   }
   for (int o = beg; o < end; ++o) {
+    const int c = V.a2c[o];
     double2 j2 = make_double2(0.0, 0.0);
-    if (MODE == 0) j2 = pair_load(jx, V.a2c[o]);
+    if (MODE == 0) j2 = pair_load(jx, c);
     double out[2];
     for (int r = 0; r < 2; ++r) {
       const double eu = V.Jpt[(size_t)(r * 3 + 0) * N + o] * u[0] + V.Jpt[(size_t)(r * 3 + 1) * N + o] * u[1] +
                         V.Jpt[(size_t)(r * 3 + 2) * N + o] * u[2];
       out[r] = (r ? j2.y : j2.x) - eu;
     }
-    pair_store(v, o, out[0], out[1]);
+    pair_store(v, c, out[0], out[1]);
   }
 }
 
@@ -1203,7 +1206,7 @@ __global__ void ba_point_apply_kernel(View V, const double* __restrict__ Cinv, c
   const size_t N = (size_t)V.n_obs;
   const int beg = V.pt_ptr[j], end = V.pt_ptr[j + 1];
   if (off < 0) {
-    if (MODE == 0) for (int o = beg; o < end; ++o) { const double2 j2 = pair_load(jx, V.a2c[o]); pair_store(v, o, j2.x, j2.y); }
+    if (MODE == 0) for (int o = beg; o < end; ++o) { const int c = V.a2c[o]; const double2 j2 = pair_load(jx, c); pair_store(v, c, j2.x, j2.y); }
     return;
   }
   double tt[3];
@@ -1216,14 +1219,15 @@ __global__ void ba_point_apply_kernel(View V, const double* __restrict__ Cinv, c
     return;
   }
   for (int o = beg; o < end; ++o) {
-    const double2 j2 = pair_load(jx, V.a2c[o]);
+    const int c = V.a2c[o];
+    const double2 j2 = pair_load(jx, c);
     double out[2];
     for (int r = 0; r < 2; ++r) {
       const double eu = V.Jpt[(size_t)(r * 3 + 0) * N + o] * u[0] + V.Jpt[(size_t)(r * 3 + 1) * N + o] * u[1] +
                         V.Jpt[(size_t)(r * 3 + 2) * N + o] * u[2];
       out[r] = (r ? j2.y : j2.x) - eu;
     }
-    pair_store(v, o, out[0], out[1]);
+    pair_store(v, c, out[0], out[1]);
   }
 }
 
@@ -1289,7 +1293,7 @@ __global__ void __launch_bounds__(TILE_PTS) ba_point_pass_tiled_kernel(View V, c
   }
   if (MODE == 2) return;
   __syncthreads();
-  for (int i = threadIdx.x; i < na; i += TILE_PTS) pair_store(v, a0 + i, sx[0][i], sx[1][i]);  // p-order, coalesced
+  for (int i = threadIdx.x; i < na; i += TILE_PTS) pair_store(v, V.a2c[a0 + i], sx[0][i], sx[1][i]);  // one 16-byte scattered store
 }
 
 // Point-major reductions over the same tiles, columns staged through LDS (coalesced loads over the tile's
@@ -1483,8 +1487,8 @@ __device__ __forceinline__ const double* blk_col(const View& V, int kind, int r,
 }
 
 // y_b += J_b^T v  (v: 2 rows per observation). With DIAG: also diag_b += colsq(J_b).
-// DIAG (gradient pass): v is the c-order residual in two planes. Otherwise v is the p-order pair vector of an
-// implicit product, gathered through c2a (one 16-byte load per observation).
+// DIAG (gradient pass): v is the c-order residual in two planes. Otherwise v is the c-order pair vector of an
+// implicit product (one 16-byte load per observation).
 template <bool DIAG, int BD, typename JT = double>
 __global__ void __launch_bounds__(64) ba_block_jtv_kernel(View V, const double* __restrict__ v,
                                                          double* __restrict__ y, double* __restrict__ diag) {
@@ -1507,7 +1511,7 @@ __global__ void __launch_bounds__(64) ba_block_jtv_kernel(View V, const double* 
       v0 = v[o]; v1 = v[N + o];
       w0 = v[oz]; w1 = v[N + oz];
     } else {
-      const double2 p0 = pair_load(v, V.c2a[o]), p1 = pair_load(v, V.c2a[oz]);
+      const double2 p0 = pair_load(v, o), p1 = pair_load(v, oz);
       v0 = p0.x; v1 = p0.y;
       w0 = p1.x; w1 = p1.y;
     }

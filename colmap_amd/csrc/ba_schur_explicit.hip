@@ -205,26 +205,33 @@ __global__ void __launch_bounds__(256) chol_diag_kernel(double* __restrict__ S, 
     Li[r][c] = 0.0;
   }
   __syncthreads();
+  // Column c: A[r][cc] -= A[r][c] A[cc][c] / A[c][c] for r >= cc > c. Column c itself is not touched by its own
+  // step, so one barrier per column suffices (the usual sqrt-and-scale form needs three); the scaling by
+  // 1 / sqrt(pivot) happens once at the end. The pivots A[c][c] are final after step c - 1.
   for (int c = 0; c < kb; ++c) {
-    if (tid == 0) {
-      double d = L[c][c];
-      if (!(d > 0.0)) {
-        *info = 1;
-        d = NAN;
-      }
-      L[c][c] = sqrt(d);
-    }
-    __syncthreads();
-    const double d = L[c][c];
-    for (int r = c + 1 + tid; r < kb; r += 256) L[r][c] /= d;
-    __syncthreads();
+    const double pivot = L[c][c];
+    const double inv = 1.0 / pivot;
     const int m = kb - c - 1;
     for (int e = tid; e < m * m; e += 256) {
       const int cc = c + 1 + e / m, r = c + 1 + e % m;
-      if (r >= cc) L[r][cc] -= L[r][c] * L[cc][c];
+      if (r >= cc) L[r][cc] -= L[r][c] * L[cc][c] * inv;
     }
     __syncthreads();
   }
+  __shared__ double dsq[NB];
+  if (tid < kb) {
+    const double d = L[tid][tid];
+    if (!(d > 0.0)) *info = 1;
+    dsq[tid] = d > 0.0 ? sqrt(d) : NAN;
+  }
+  __syncthreads();
+  for (int e = tid; e < kb * kb; e += 256) {
+    const int r = e / kb, c = e % kb;
+    if (c < r) L[r][c] /= dsq[c];
+  }
+  __syncthreads();
+  if (tid < kb) L[tid][tid] = dsq[tid];
+  __syncthreads();
   // inverse of the triangle: thread j solves L x = e_j, x kept in column j of Li
   if (tid < kb) {
     const int j = tid;
@@ -332,6 +339,60 @@ __global__ void __launch_bounds__(256) chol_update_kernel(double* __restrict__ S
       }
 }
 
+// The same update with 128 x 128 tiles per workgroup: wave w owns the 64 x 64 quadrant (w >> 1, w & 1) as 4 x 4
+// MFMA tiles (64 accumulator doubles per lane), K = kb streamed through LDS in chunks of 16. 16 flop per byte
+// loaded instead of 8: used while the trailing matrix has enough 128-tiles to fill the chip.
+__global__ void __launch_bounds__(256, 2) chol_update128_kernel(double* __restrict__ S, int n, int k0, int kb) {
+  const int I = blockIdx.y, J = blockIdx.x;
+  if (J > I) return;
+  constexpr int T = 128, KC = 16;
+  __shared__ double sI[T][KC + 1];
+  __shared__ double sJ[T][KC + 1];
+  const int tid = threadIdx.x;
+  const int t0 = k0 + kb;
+  const int ri = t0 + T * I, rj = t0 + T * J;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 15, lk = lane >> 4;
+  const int qi = 64 * (wave >> 1), qj = 64 * (wave & 1);
+  v4f64 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = v4f64{0.0, 0.0, 0.0, 0.0};
+  for (int kc = 0; kc < kb; kc += KC) {
+    __syncthreads();
+    for (int e = tid; e < T * KC; e += 256) {
+      const int r = e >> 4, m = e & 15;
+      const bool kok = kc + m < kb;
+      sI[r][m] = (kok && ri + r < n) ? S[(size_t)(ri + r) * n + k0 + kc + m] : 0.0;
+      sJ[r][m] = (kok && rj + r < n) ? S[(size_t)(rj + r) * n + k0 + kc + m] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < KC / 4; ++ks) {
+      const int m = 4 * ks + lk;
+      double av[4], bv[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) av[a] = sI[qi + 16 * a + li][m];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) bv[b] = sJ[qj + 16 * b + li][m];
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], acc[a][b], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int r = ri + qi + 16 * a + lk + 4 * reg, c = rj + qj + 16 * b + li;
+        if (r < n && c < n && c <= r) S[(size_t)r * n + c] -= acc[a][b][reg];
+      }
+}
+
 // Forward step k: y_k <- L_kk^-1 y_k (final), rows below: y_i -= L_ik y_k. Every workgroup recomputes the
 // 64-vector (cheap), workgroup 0 publishes it to `yfin`; block.x = 64, grid = 1 + #row tiles below.
 __global__ void __launch_bounds__(64) solve_forward_kernel(const double* __restrict__ S, int n, int k0, int kb,
@@ -427,7 +488,9 @@ void factor_solve(double* S, int n, const double* rhs, double* x, const Workspac
     if (below > 0) {
       const int tiles = (below + NB - 1) / NB;
       hipLaunchKernelGGL(chol_panel_kernel, dim3(tiles), dim3(256), 0, st, S, n, k0, kb, Li);
-      hipLaunchKernelGGL(chol_update_kernel, dim3(tiles, tiles), dim3(256), 0, st, S, n, k0, kb);
+      const int tiles128 = (below + 127) / 128;
+      if (tiles128 >= 12) hipLaunchKernelGGL(chol_update128_kernel, dim3(tiles128, tiles128), dim3(256), 0, st, S, n, k0, kb);
+      else hipLaunchKernelGGL(chol_update_kernel, dim3(tiles, tiles), dim3(256), 0, st, S, n, k0, kb);
     }
   }
   if (ev_b) BAX_HIP(hipEventRecord(ev_b, st));

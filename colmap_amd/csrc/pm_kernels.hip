@@ -181,6 +181,7 @@ __device__ __forceinline__ float ref_texel(const PmParams& p, int row, int col) 
 // the gathers compile to flat_load (pointer provenance is unknown to the compiler)
 typedef __attribute__((address_space(1))) const uint32_t gbl_u32;
 typedef LDS_AS float lds_f32;
+typedef __attribute__((address_space(1))) const float gbl_f32;
 typedef LDS_AS int lds_i32;
 typedef LDS_AS uint32_t lds_u32;
 typedef LDS_AS uint64_t lds_u64;
@@ -192,12 +193,15 @@ __device__ __forceinline__ float dot3(float a0, float a1, float a2, float b0, fl
 }
 
 // ComposeHomography, patch_match_cuda.cu:271-332
-__device__ __forceinline__ void compose_homography(const float* iK, const lds_f32* pose, int row,
+// (PoseP: pointer to one source image's pose record -- LDS in most kernels, global memory in the
+// pose-global build of the single-wave sweep kernel)
+template <typename PoseP>
+__device__ __forceinline__ void compose_homography(const float* iK, PoseP pose, int row,
                                                    int col, float depth, float n0, float n1,
                                                    float n2, float H[9]) {
-  const lds_f32* K = pose;
-  const lds_f32* R = pose + 4;
-  const lds_f32* T = pose + 13;
+  const PoseP K = pose;
+  const PoseP R = pose + 4;
+  const PoseP T = pose + 13;
   const float dist = depth * (n0 * (iK[0] * col + iK[1]) + n1 * (iK[2] * row + iK[3]) + n2);
   const float inv_dist = 1.0f / dist;
   const float N0 = inv_dist * n0;
@@ -469,10 +473,11 @@ __device__ __forceinline__ void centre_homography(float* Hm, int row, int col, i
 }
 
 // ComputeGeomConsistencyCost, patch_match_cuda.cu:601-667
-__device__ __forceinline__ float geom_cost(const PmParams& p, const lds_f32* pose, int s, float row,
+template <typename PoseP>
+__device__ __forceinline__ float geom_cost(const PmParams& p, PoseP pose, int s, float row,
                                            float col, float depth) {
-  const lds_f32* P = pose + 19;
-  const lds_f32* iP = pose + 31;
+  const PoseP P = pose + 19;
+  const PoseP iP = pose + 31;
   const float* iK = p.refInvK;
   const float f0 = depth * (iK[0] * col + iK[1]);
   const float f1 = depth * (iK[2] * row + iK[3]);
@@ -530,10 +535,11 @@ __device__ __forceinline__ float sel_prob_fn(float alpha, float beta, float prev
 }
 
 // ComputeViewingAngles, patch_match_cuda.cu:241-269
-__device__ __forceinline__ void viewing_angles(const lds_f32* pose, float p0, float p1, float p2,
+template <typename PoseP>
+__device__ __forceinline__ void viewing_angles(PoseP pose, float p0, float p1, float p2,
                                                float n0, float n1, float n2, float& cos_tri,
                                                float& cos_inc) {
-  const lds_f32* C = pose + 16;
+  const PoseP C = pose + 16;
   const float s0 = C[0] - p0, s1 = C[1] - p1, s2 = C[2] - p2;
   const float rx_inv = pm_rsqrt(dot3(p0, p1, p2, p0, p1, p2));
   const float sx_inv = pm_rsqrt(dot3(s0, s1, s2, s0, s1, s2));
@@ -1612,7 +1618,7 @@ __host__ __device__ inline int wave_max_tasks(int C, int S, int M) {
 }
 
 __host__ __device__ inline LdsOffsets lds_offsets_wave(int C, int S, int radius, int ntaps, int M,
-                                                       bool geom, bool pipe) {
+                                                       bool geom, bool pipe, bool pose_global = false) {
   LdsOffsets o;
   uint32_t off = 0;
   auto take = [&](uint32_t bytes) {
@@ -1624,7 +1630,7 @@ __host__ __device__ inline LdsOffsets lds_offsets_wave(int C, int S, int radius,
   const int tw = C + 2 * radius;
   const int max_tasks = wave_max_tasks(C, S, M);
   o.ring = take(pipe ? (uint32_t)kGatherRingBytes : 0u);  // must be at LDS offset 0 (gather_issue)
-  o.poses = take(4u * S * lds_pose_stride(geom));
+  o.poses = take(pose_global ? 0u : 4u * S * lds_pose_stride(geom));
   o.fpb = take(8u * S);
   o.tile = take(4u * win * tw);
   o.wgt = take(4u * C * tap_stride(ntaps));
@@ -1659,24 +1665,39 @@ __host__ __device__ inline LdsOffsets lds_offsets_wave(int C, int S, int radius,
 // divisor is positive at its four corners, so the taps lie inside the corners' bounding box; one
 // texel of margin absorbs the rounding of the per-tap evaluation. NaNs compare false.
 __device__ __forceinline__ bool patch_inside(const PmParams& p, const float Hm[9]) {
+  // With z > 0 at a corner, 1 <= x / z <= w - 2 is z <= x <= (w - 2) z: eight divisions saved per task. The
+  // flag only selects the addressing variant of the gathers (both give the same texels for a patch that is
+  // inside; the one-texel margin dwarfs the rounding of the products), it never changes a result.
   const float e = (float)(2 * p.radius);  // window extent: taps at offsets 0 .. 2 r
-  float xmin = 3.0e38f, xmax = -3.0e38f, ymin = 3.0e38f, ymax = -3.0e38f;
+  const float wx = (float)(p.src_w - 2), wy = (float)(p.src_h - 2);
   bool ok = true;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const float dx = (k & 1) ? e : 0.0f, dy = (k & 2) ? e : 0.0f;
     const float z = Hm[6] * dx + Hm[7] * dy + Hm[8];
-    const float x = (Hm[0] * dx + Hm[1] * dy + Hm[2]) / z;
-    const float y = (Hm[3] * dx + Hm[4] * dy + Hm[5]) / z;
-    ok = ok && (z > 0.0f);
-    xmin = fminf(xmin, x); xmax = fmaxf(xmax, x);
-    ymin = fminf(ymin, y); ymax = fmaxf(ymax, y);
+    const float x = Hm[0] * dx + Hm[1] * dy + Hm[2];
+    const float y = Hm[3] * dx + Hm[4] * dy + Hm[5];
+    ok = ok && (z > 0.0f) && x >= z && y >= z && x <= wx * z && y <= wy * z;
   }
-  return ok && xmin >= 1.0f && ymin >= 1.0f && xmax <= (float)(p.src_w - 2) && ymax <= (float)(p.src_h - 2);
+  return ok;
 }
 
+// Where the single-wave sweep kernel reads a source image's pose record from: the LDS copy (S x 19 or 43
+// floats: 1.5 KB at S = 20), or -- pose-global build -- the table in global memory it was copied from. The
+// records are read lane-per-(column, view) or lane-per-task a few times per row and stay L1-resident;
+// without the LDS copy three columns per wave fit the 10 KB that keep 16 workgroups on a CU.
+template <bool PG> struct PoseSrc;
+template <> struct PoseSrc<false> {
+  typedef const lds_f32* ptr;
+  static __device__ __forceinline__ ptr get(const PmParams&, const Lds& L, int s) { return L.poses + s * L.pstride; }
+};
+template <> struct PoseSrc<true> {
+  typedef gbl_f32* ptr;
+  static __device__ __forceinline__ ptr get(const PmParams& p, const Lds&, int s) { return (gbl_f32*)p.poses + s * kPoseStride; }
+};
+
 // Run the queued NCC tasks (and, with GEOM, the geometric-cost-only list) of one phase.
-template <bool GEOM, bool PIPE>
+template <bool GEOM, bool PIPE, bool PG>
 __device__ __forceinline__ void run_tasks_wave(const PmParams& p, const Lds& L, int row, int col0, int tid,
                                                unsigned& evals) {
   const lds_f32* G = L.tapg;
@@ -1693,7 +1714,7 @@ __device__ __forceinline__ void run_tasks_wave(const PmParams& p, const Lds& L, 
       const uint32_t task = gtasks[t];
       const int c = task >> 13, i = (task >> 9) & 7, s = task & 0x1ff;
       const lds_f32* h = L.hyp + (c * 5 + i) * 4;
-      L.geo[(c * 5 + i) * S + s] = geom_cost(p, L.poses + s * L.pstride, s, (float)row, (float)(col0 + c), h[0]);
+      L.geo[(c * 5 + i) * S + s] = geom_cost(p, PoseSrc<PG>::get(p, L, s), s, (float)row, (float)(col0 + c), h[0]);
     }
   }
   for (int base = 0; base < n; base += kWaveThCap) {
@@ -1705,7 +1726,7 @@ __device__ __forceinline__ void run_tasks_wave(const PmParams& p, const Lds& L, 
       const int i = (task >> 9) & 7;
       const int s = task & 0x1ff;
       const lds_f32* h = L.hyp + (c * 5 + i) * 4;
-      const lds_f32* pose = L.poses + s * L.pstride;
+      const typename PoseSrc<PG>::ptr pose = PoseSrc<PG>::get(p, L, s);
       const int col = col0 + c;
       float Hm[9];
       compose_homography(p.refInvK, pose, row, col, h[0], h[1], h[2], h[3], Hm);
@@ -1820,7 +1841,7 @@ __device__ __forceinline__ void run_tasks_wave(const PmParams& p, const Lds& L, 
   }
 }
 
-template <bool GEOM, bool FILTER_PHOTO, bool FILTER_GEOM, bool PIPE>
+template <bool GEOM, bool FILTER_PHOTO, bool FILTER_GEOM, bool PIPE, bool PG = false>
 __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp) {
   const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y;
   unsigned group = lin / gridDim.y;
@@ -1842,7 +1863,7 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
   const PmParams& p = pp[prob];
   extern __shared__ __attribute__((aligned(16))) char smem[];
   Lds L;
-  lds_bind(L, (lds_char*)smem, lds_offsets_wave(p.C, p.S, p.radius, p.ntaps, p.num_samples, GEOM, PIPE));
+  lds_bind(L, (lds_char*)smem, lds_offsets_wave(p.C, p.S, p.radius, p.ntaps, p.num_samples, GEOM, PIPE, PG));
   const int tid_entry = threadIdx.x;
   const int tid = tid_entry;
   constexpr int nt = 64;
@@ -1854,7 +1875,11 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
   if (PIPE && (uint32_t)(uintptr_t)L.ring != 0u) __builtin_trap();  // gather_issue addresses the ring through a literal M0
   tap_geom_init(L.tapg, tid, p.step, (p.rot & 1) != 0);
 
-  lds_load_poses(p, L, GEOM, tid, nt);
+  if (PG) {  // no LDS copy of the pose records; the packed-image base pointers still go to LDS
+    for (int i = tid; i < p.S; i += nt) L.fpb[i] = (uint64_t)p.src_fp_tab[i];
+  } else {
+    lds_load_poses(p, L, GEOM, tid, nt);
+  }
 
   // ---- backward messages for all rows (:976-989); stored in sel_out ----------
   for (int item = tid; item < ncols * S; item += nt) {
@@ -1939,7 +1964,7 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
       const int s = item - c * S;
       const int col = col0 + c;
       const float* rec = p.rec + (size_t)pix_index(p, row, col) * p.rec_stride;
-      const lds_f32* pose = L.poses + s * L.pstride;
+      const typename PoseSrc<PG>::ptr pose = PoseSrc<PG>::get(p, L, s);
       const lds_f32* h = L.hyp + c * 20;
       const lds_f32* cf = L.colf + c * 8;
       const float cost = rec[4 + s];
@@ -2010,7 +2035,7 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
     __syncthreads();
 
     // ---- P4: NCC of hypotheses 1..4 against the drawn views (:1157-1172) -----
-    if (!(p.ablate & 1)) run_tasks_wave<GEOM, PIPE>(p, L, row, col0, tid, evals);
+    if (!(p.ablate & 1)) run_tasks_wave<GEOM, PIPE, PG>(p, L, row, col0, tid, evals);
     if (tid == 0) { L.ntasks[0] = 0; L.ntasks[1] = 0; }
     __syncthreads();
 
@@ -2065,7 +2090,7 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
     __syncthreads();
 
     // ---- P6: NCC of the winner against the remaining views (:1188-1197) ------
-    if (!(p.ablate & 1)) run_tasks_wave<false, PIPE>(p, L, row, col0, tid, evals);
+    if (!(p.ablate & 1)) run_tasks_wave<false, PIPE, PG>(p, L, row, col0, tid, evals);
 
     // ---- P7: cost map, forward message, selection probability (:1186-1207) ---
     for (int item = tid; item < ncols * S; item += nt) {
@@ -2087,7 +2112,7 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
       rec[p.sel_out_off + s] = prob;
       if (FILTER_PHOTO || FILTER_GEOM) {
         const lds_f32* hb = L.hyp + (c * 5 + 1) * 4;  // == best (stored in P5)
-        const lds_f32* pose = L.poses + s * L.pstride;
+        const typename PoseSrc<PG>::ptr pose = PoseSrc<PG>::get(p, L, s);
         const float bp0 = hb[0] * (iK[0] * col + iK[1]);
         const float bp1 = hb[0] * (iK[2] * row + iK[3]);
         const float bp2 = hb[0];
@@ -2140,6 +2165,11 @@ template <bool GEOM, bool FILTER_PHOTO, bool FILTER_GEOM>
 __global__ void __launch_bounds__(64, 4) pm_sweep_wave4_kernel(const PmParams* __restrict__ pp) {
   sweep_wave_body<GEOM, FILTER_PHOTO, FILTER_GEOM, false>(pp);
 }
+// pose-global build of the same kernel (PoseSrc<true>): three columns per wave at the LDS footprint of two
+template <bool GEOM, bool FILTER_PHOTO, bool FILTER_GEOM>
+__global__ void __launch_bounds__(64, 4) pm_sweep_wave4g_kernel(const PmParams* __restrict__ pp) {
+  sweep_wave_body<GEOM, FILTER_PHOTO, FILTER_GEOM, false, true>(pp);
+}
 
 // Debug: raw XORWOW streams of the generator above (seed = sequence id, as InitRandomStateKernel
 // seeds it), for the bit comparison with rocRAND's rocrand_init / rocrand_uniform in the tests.
@@ -2185,6 +2215,8 @@ int pm_pick_columns(int S, int ntaps, int num_samples, bool geom, int radius, in
   // default: 2 columns per single-wave workgroup of the 11 x 11 kernel (16 workgroups = 4 waves per
   // SIMD resident per CU, the lane-per-(column, view) phases are one pass; measured 604 / 643 / 718 ms
   // per 16-image launch for C = 2 / 3 / 4), 4 for the two-wave kernels
+  static const int cols_env = [] { const char* e = getenv("COLMAP_AMD_PM_COLS"); return e ? atoi(e) : 0; }();  // experiments / tests
+  if (requested <= 0 && cols_env > 0) requested = cols_env;
   int c = requested > 0 ? requested : (ntaps == 121 ? 2 : 4);
   if (c > 64) c = 64;
   while (c > 1 && lds_offsets(c, S, radius, ntaps, num_samples, geom).total > budget) --c;
@@ -2247,13 +2279,18 @@ void pm_launch_sweep(const PmParams& p, const PmParams* dev_params, int batch, i
     // the LDS-DMA pipelined build (3 waves per SIMD, 10 workgroups per CU); COLMAP_AMD_PM_PIPE=1 selects
     // the latter
     static const bool pipe = [] { const char* e = getenv("COLMAP_AMD_PM_PIPE"); return e && atoi(e) != 0; }();
-    const size_t wlds = lds_offsets_wave(p.C, p.S, p.radius, p.ntaps, p.num_samples, geom, pipe).total + lds_pad;
+    // pose records read from global memory instead of an LDS copy: on for >= 3 columns per wave (that is what
+    // makes the third column fit), COLMAP_AMD_PM_POSE_GLOBAL = 0 / 1 forces it
+    static const int pg_env = [] { const char* e = getenv("COLMAP_AMD_PM_POSE_GLOBAL"); return e ? atoi(e) : -1; }();
+    const bool pg = !pipe && (pg_env >= 0 ? pg_env != 0 : p.C >= 3);
+    const size_t wlds = lds_offsets_wave(p.C, p.S, p.radius, p.ntaps, p.num_samples, geom, pipe, pg).total + lds_pad;
     dim3 wblock(64, 1, 1);
     dim3 wgrid = grid;
     if (p.xcd_map == 2) wgrid.x = ((grid.x + 63) / 64) * 64;
 #define PM_LAUNCH_W(G, FP, FG)                                                                              \
   do {                                                                                                      \
     if (pipe) hipLaunchKernelGGL((pm_sweep_wave_kernel<G, FP, FG>), wgrid, wblock, wlds, st, dev_params);   \
+    else if (pg) hipLaunchKernelGGL((pm_sweep_wave4g_kernel<G, FP, FG>), wgrid, wblock, wlds, st, dev_params); \
     else hipLaunchKernelGGL((pm_sweep_wave4_kernel<G, FP, FG>), wgrid, wblock, wlds, st, dev_params);       \
   } while (0)
     if (geom) {

@@ -4,14 +4,14 @@ import numpy as np
 from colmap_amd import estimators as est, scene
 import argparse
 ap = argparse.ArgumentParser(); ap.add_argument("--frames", type=int, default=6); ap.add_argument("--points", type=int, default=40); ap.add_argument("--track", type=int, default=4)
-ap.add_argument("--iters", type=int, default=100); ap.add_argument("--op32", type=int, default=0); ap.add_argument("--oracle", type=int, default=0); ap.add_argument("--gtol", type=float, default=1e-4)
+ap.add_argument("--iters", type=int, default=100); ap.add_argument("--op32", type=int, default=0); ap.add_argument("--lst", type=int, default=0); ap.add_argument("--oracle", type=int, default=0); ap.add_argument("--gtol", type=float, default=1e-4)
 a = ap.parse_args()
 t = time.time(); d = scene.synthesize_flat(a.frames, a.points, a.track, seed=42, noise=scene.SyntheticNoiseOptions(0.01, 1.0, 0.05, 1.0)); print("gen %.2fs" % (time.time() - t))
 fp = est.FlatProblem.from_arrays(d); est.fix_gauge_two_cams(fp)
-so = est.SolverOptions(gradient_tolerance=a.gtol, max_num_iterations=a.iters, operator_precision=a.op32)
+so = est.SolverOptions(gradient_tolerance=a.gtol, max_num_iterations=a.iters, operator_precision=a.op32, linear_solver_type=a.lst)
 for rep in range(2):
     b = fp.copy(); t = time.time(); s = est.solve_flat(b, so, gpu_index=0); dt = time.time() - t
-    print(f"HIP rep{rep}: wall {dt:.3f}s lm {s.lm_seconds:.3f}s iters {s.num_iterations} succ {s.num_successful_steps} pcg {s.total_linear_iterations} cost {s.initial_cost:.6e}->{s.final_cost:.6e} {s.termination_type.name} -> {s.num_iterations/max(s.lm_seconds,1e-9):.2f} LM-it/s")
+    print(f"HIP rep{rep}: tier {s.linear_solver_used} factor {s.factor_seconds:.4f}s wall {dt:.3f}s lm {s.lm_seconds:.3f}s iters {s.num_iterations} succ {s.num_successful_steps} pcg {s.total_linear_iterations} cost {s.initial_cost:.6e}->{s.final_cost:.6e} {s.termination_type.name} -> {s.num_iterations/max(s.lm_seconds,1e-9):.2f} LM-it/s")
 if a.oracle:
     import ba_oracle
     b = fp.copy(); t = time.time(); s = est.solve_flat(b, so, solve_fn=ba_oracle.solve_fn); dt = time.time() - t
