@@ -205,16 +205,27 @@ __global__ void __launch_bounds__(256) chol_diag_kernel(double* __restrict__ S, 
     Li[r][c] = 0.0;
   }
   __syncthreads();
-  // Column c: A[r][cc] -= A[r][c] A[cc][c] / A[c][c] for r >= cc > c. Column c itself is not touched by its own
+  // Column c: A[r][cc] -= (A[r][c] / A[c][c]) A[cc][c] for r >= cc > c. Column c itself is not touched by its own
   // step, so one barrier per column suffices (the usual sqrt-and-scale form needs three); the scaling by
   // 1 / sqrt(pivot) happens once at the end. The pivots A[c][c] are final after step c - 1.
+  const int tr = tid & 63, tq = tid >> 6;  // thread = (row, quarter of the columns): no integer divisions below
   for (int c = 0; c < kb; ++c) {
-    const double pivot = L[c][c];
-    const double inv = 1.0 / pivot;
-    const int m = kb - c - 1;
-    for (int e = tid; e < m * m; e += 256) {
-      const int cc = c + 1 + e / m, r = c + 1 + e % m;
-      if (r >= cc) L[r][cc] -= L[r][c] * L[cc][c] * inv;
+    const double inv = 1.0 / L[c][c];
+    if (tr > c && tr < kb) {
+      const double lrc = L[tr][c] * inv;
+      // four columns per trip, all eight LDS reads issued before the first write (the compiler cannot prove
+      // that the writes to row tr do not alias the reads of column c and would otherwise serialise them)
+      for (int cc = c + 1 + tq; cc <= tr; cc += 16) {
+        const int c1 = cc + 4, c2 = cc + 8, c3 = cc + 12;
+        const double a0 = L[cc][c], b0 = L[tr][cc];
+        const double a1 = c1 <= tr ? L[c1][c] : 0.0, b1 = c1 <= tr ? L[tr][c1] : 0.0;
+        const double a2 = c2 <= tr ? L[c2][c] : 0.0, b2 = c2 <= tr ? L[tr][c2] : 0.0;
+        const double a3 = c3 <= tr ? L[c3][c] : 0.0, b3 = c3 <= tr ? L[tr][c3] : 0.0;
+        L[tr][cc] = b0 - lrc * a0;
+        if (c1 <= tr) L[tr][c1] = b1 - lrc * a1;
+        if (c2 <= tr) L[tr][c2] = b2 - lrc * a2;
+        if (c3 <= tr) L[tr][c3] = b3 - lrc * a3;
+      }
     }
     __syncthreads();
   }
@@ -236,9 +247,16 @@ __global__ void __launch_bounds__(256) chol_diag_kernel(double* __restrict__ S, 
   if (tid < kb) {
     const int j = tid;
     for (int r = j; r < kb; ++r) {
-      double v = (r == j) ? 1.0 : 0.0;
-      for (int m = j; m < r; ++m) v -= L[r][m] * Li[m][j];
-      Li[r][j] = v / L[r][r];
+      double v0 = (r == j) ? 1.0 : 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;  // four chains: the LDS reads pipeline
+      int m = j;
+      for (; m + 3 < r; m += 4) {
+        v0 -= L[r][m] * Li[m][j];
+        v1 -= L[r][m + 1] * Li[m + 1][j];
+        v2 -= L[r][m + 2] * Li[m + 2][j];
+        v3 -= L[r][m + 3] * Li[m + 3][j];
+      }
+      for (; m < r; ++m) v0 -= L[r][m] * Li[m][j];
+      Li[r][j] = ((v0 + v1) + (v2 + v3)) / L[r][r];
     }
   }
   __syncthreads();
@@ -292,14 +310,16 @@ __global__ void __launch_bounds__(256) chol_panel_kernel(double* __restrict__ S,
 
 // Trailing update C_IJ -= X_I X_J^T for the 64 x 64 tiles I >= J of the trailing matrix (rows / columns from
 // t0 = k0 + kb). Wave w owns the 32 x 32 quadrant (w >> 1, w & 1): 2 x 2 MFMA tiles; K = kb in halves of 32.
-__global__ void __launch_bounds__(256) chol_update_kernel(double* __restrict__ S, int n, int k0, int kb) {
+// (general form: C[r][c] -= sum_{m in [k0, k0 + kb)} S[r][m] S[c][m] for rows r >= t0 and columns c in
+//  [t0, cend), lower triangle; cend < n restricts the update to the rest of an outer panel)
+__global__ void __launch_bounds__(256) chol_update_kernel(double* __restrict__ S, int n, int k0, int kb, int t0,
+                                                          int cend) {
   const int I = blockIdx.y, J = blockIdx.x;
-  if (J > I) return;
   __shared__ double sI[NB][33];
   __shared__ double sJ[NB][33];
   const int tid = threadIdx.x;
-  const int t0 = k0 + kb;
   const int ri = t0 + NB * I, rj = t0 + NB * J;
+  if (rj > ri + NB - 1 || rj >= cend) return;
   const int wave = tid >> 6, lane = tid & 63;
   const int li = lane & 15, lk = lane >> 4;
   const int qi = 32 * (wave >> 1), qj = 32 * (wave & 1);
@@ -335,22 +355,22 @@ __global__ void __launch_bounds__(256) chol_update_kernel(double* __restrict__ S
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
         const int r = ri + qi + 16 * a + lk + 4 * reg, c = rj + qj + 16 * b + li;
-        if (r < n && c < n && c <= r) S[(size_t)r * n + c] -= acc[a][b][reg];
+        if (r < n && c < cend && c <= r) S[(size_t)r * n + c] -= acc[a][b][reg];
       }
 }
 
 // The same update with 128 x 128 tiles per workgroup: wave w owns the 64 x 64 quadrant (w >> 1, w & 1) as 4 x 4
 // MFMA tiles (64 accumulator doubles per lane), K = kb streamed through LDS in chunks of 16. 16 flop per byte
 // loaded instead of 8: used while the trailing matrix has enough 128-tiles to fill the chip.
-__global__ void __launch_bounds__(256, 2) chol_update128_kernel(double* __restrict__ S, int n, int k0, int kb) {
+__global__ void __launch_bounds__(256, 2) chol_update128_kernel(double* __restrict__ S, int n, int k0, int kb,
+                                                                int t0, int cend) {
   const int I = blockIdx.y, J = blockIdx.x;
-  if (J > I) return;
   constexpr int T = 128, KC = 16;
   __shared__ double sI[T][KC + 1];
   __shared__ double sJ[T][KC + 1];
   const int tid = threadIdx.x;
-  const int t0 = k0 + kb;
   const int ri = t0 + T * I, rj = t0 + T * J;
+  if (rj > ri + T - 1 || rj >= cend) return;
   const int wave = tid >> 6, lane = tid & 63;
   const int li = lane & 15, lk = lane >> 4;
   const int qi = 64 * (wave >> 1), qj = 64 * (wave & 1);
@@ -389,7 +409,7 @@ __global__ void __launch_bounds__(256, 2) chol_update128_kernel(double* __restri
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
         const int r = ri + qi + 16 * a + lk + 4 * reg, c = rj + qj + 16 * b + li;
-        if (r < n && c < n && c <= r) S[(size_t)r * n + c] -= acc[a][b][reg];
+        if (r < n && c < cend && c <= r) S[(size_t)r * n + c] -= acc[a][b][reg];
       }
 }
 
@@ -439,6 +459,7 @@ __global__ void __launch_bounds__(64) solve_backward_kernel(const double* __rest
   const int c = NB * (blockIdx.x - 1) + tid;
   if (c >= k0) return;
   double acc = 0.0;
+#pragma unroll 8
   for (int m = 0; m < kb; ++m) acc += S[(size_t)(k0 + m) * n + c] * xk[m];
   w[c] -= acc;
 }
@@ -480,18 +501,36 @@ void factor_solve(double* S, int n, const double* rhs, double* x, const Workspac
   // The whole factorisation is bracketed by the two events: the diagonal-block kernels in between are
   // < 2 % of its time at n >= 2 000, the rest are the two matrix-core kernels.
   if (ev_a) BAX_HIP(hipEventRecord(ev_a, st));
-  for (int kblk = 0; kblk < nblk; ++kblk) {
-    const int k0 = kblk * NB, kb = std::min(NB, n - k0);
-    double* Li = ws.Linv + (size_t)kblk * NB * NB;
-    hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), 0, st, S, n, k0, kb, Li, ws.info);
-    const int below = n - k0 - kb;
-    if (below > 0) {
-      const int tiles = (below + NB - 1) / NB;
-      hipLaunchKernelGGL(chol_panel_kernel, dim3(tiles), dim3(256), 0, st, S, n, k0, kb, Li);
-      const int tiles128 = (below + 127) / 128;
-      if (tiles128 >= 12) hipLaunchKernelGGL(chol_update128_kernel, dim3(tiles128, tiles128), dim3(256), 0, st, S, n, k0, kb);
-      else hipLaunchKernelGGL(chol_update_kernel, dim3(tiles, tiles), dim3(256), 0, st, S, n, k0, kb);
+  // Two-level right-looking factorisation. Every update reads and writes the part of the matrix it updates
+  // once, whatever its depth K: with 64-deep updates of the whole trailing matrix the factorisation moves
+  // 2 x (n^2 / 2) x 8 B x n / 64 bytes = 8 flop per byte -- HBM-bound at a sixth of the f64 MFMA peak (measured
+  // 12 TFLOP/s at n = 8 000). So the trailing matrix is updated once per OUTER panel of 256 columns (32 flop
+  // per byte); inside an outer panel the 64-wide steps update only the panel's remaining columns.
+  constexpr int OB = 256;
+  auto update = [&](int k0, int kb, int t0, int cend) {
+    const int rows = n - t0, cols = std::min(cend, n) - t0;
+    if (rows <= 0 || cols <= 0) return;
+    if (rows >= 12 * 128 && cols >= 256) {
+      hipLaunchKernelGGL(chol_update128_kernel, dim3((cols + 127) / 128, (rows + 127) / 128), dim3(256), 0, st, S, n, k0, kb,
+                         t0, std::min(cend, n));
+    } else {
+      hipLaunchKernelGGL(chol_update_kernel, dim3((cols + NB - 1) / NB, (rows + NB - 1) / NB), dim3(256), 0, st, S, n, k0, kb,
+                         t0, std::min(cend, n));
     }
+  };
+  for (int o0 = 0; o0 < n; o0 += OB) {
+    const int oend = std::min(o0 + OB, n);
+    for (int k0 = o0; k0 < oend; k0 += NB) {
+      const int kb = std::min(NB, n - k0);
+      double* Li = ws.Linv + (size_t)(k0 / NB) * NB * NB;
+      hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), 0, st, S, n, k0, kb, Li, ws.info);
+      const int below = n - k0 - kb;
+      if (below > 0) {
+        hipLaunchKernelGGL(chol_panel_kernel, dim3((below + NB - 1) / NB), dim3(256), 0, st, S, n, k0, kb, Li);
+        update(k0, kb, k0 + kb, oend);  // the rest of this outer panel only
+      }
+    }
+    update(o0, oend - o0, oend, n);  // everything right of the outer panel, K = 256
   }
   if (ev_b) BAX_HIP(hipEventRecord(ev_b, st));
   // L y = rhs: x is the working vector (a step reads its own block of it raw -- in every workgroup -- and

@@ -2170,6 +2170,12 @@ template <bool GEOM, bool FILTER_PHOTO, bool FILTER_GEOM>
 __global__ void __launch_bounds__(64, 4) pm_sweep_wave4g_kernel(const PmParams* __restrict__ pp) {
   sweep_wave_body<GEOM, FILTER_PHOTO, FILTER_GEOM, false, true>(pp);
 }
+// ... and at five waves per SIMD (96 VGPRs, 13 dwords of scratch; two columns without the pose copy take 7.5 KB
+// of LDS = 21 workgroups per CU). Experiment: COLMAP_AMD_PM_WAVES=5.
+template <bool GEOM, bool FILTER_PHOTO, bool FILTER_GEOM>
+__global__ void __launch_bounds__(64, 5) pm_sweep_wave5g_kernel(const PmParams* __restrict__ pp) {
+  sweep_wave_body<GEOM, FILTER_PHOTO, FILTER_GEOM, false, true>(pp);
+}
 
 // Debug: raw XORWOW streams of the generator above (seed = sequence id, as InitRandomStateKernel
 // seeds it), for the bit comparison with rocRAND's rocrand_init / rocrand_uniform in the tests.
@@ -2282,7 +2288,9 @@ void pm_launch_sweep(const PmParams& p, const PmParams* dev_params, int batch, i
     // pose records read from global memory instead of an LDS copy: on for >= 3 columns per wave (that is what
     // makes the third column fit), COLMAP_AMD_PM_POSE_GLOBAL = 0 / 1 forces it
     static const int pg_env = [] { const char* e = getenv("COLMAP_AMD_PM_POSE_GLOBAL"); return e ? atoi(e) : -1; }();
-    const bool pg = !pipe && (pg_env >= 0 ? pg_env != 0 : p.C >= 3);
+    static const int waves_env = [] { const char* e = getenv("COLMAP_AMD_PM_WAVES"); return e ? atoi(e) : 4; }();
+    const bool w5 = !pipe && waves_env == 5;
+    const bool pg = !pipe && (w5 || (pg_env >= 0 ? pg_env != 0 : p.C >= 3));
     const size_t wlds = lds_offsets_wave(p.C, p.S, p.radius, p.ntaps, p.num_samples, geom, pipe, pg).total + lds_pad;
     dim3 wblock(64, 1, 1);
     dim3 wgrid = grid;
@@ -2290,6 +2298,7 @@ void pm_launch_sweep(const PmParams& p, const PmParams* dev_params, int batch, i
 #define PM_LAUNCH_W(G, FP, FG)                                                                              \
   do {                                                                                                      \
     if (pipe) hipLaunchKernelGGL((pm_sweep_wave_kernel<G, FP, FG>), wgrid, wblock, wlds, st, dev_params);   \
+    else if (w5) hipLaunchKernelGGL((pm_sweep_wave5g_kernel<G, FP, FG>), wgrid, wblock, wlds, st, dev_params); \
     else if (pg) hipLaunchKernelGGL((pm_sweep_wave4g_kernel<G, FP, FG>), wgrid, wblock, wlds, st, dev_params); \
     else hipLaunchKernelGGL((pm_sweep_wave4_kernel<G, FP, FG>), wgrid, wblock, wlds, st, dev_params);       \
   } while (0)
