@@ -2446,11 +2446,20 @@ struct Buf {
     alloc(h.size());
     if (!h.empty()) BA_HIP(hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
   }
+  // non-owning window into another buffer (sub-vectors of one all-reduce payload)
+  void alias(T* ptr, size_t count) {
+    release();
+    p = ptr;
+    n = count;
+    owns = false;
+  }
   void release() {
-    if (p) (void)hipFree(p);
+    if (p && owns) (void)hipFree(p);
     p = nullptr;
     n = 0;
+    owns = true;
   }
+  bool owns = true;
   ~Buf() { release(); }
 };
 
@@ -2488,6 +2497,7 @@ struct Solver {
   Buf<unsigned char> solo;
   Buf<double> o_xy, poses, cams, points, poses2, cams2, points2, Jpose, Jcam, Jpt, res, res_p, scale_c, scale_p,
       scalars, gc, gp, diag_c, diag_p, Dc, Dp, Cinv, M, Minv, rhs, x, r, z, pdir, q, dp, jx, v, stepc, stepp, partials, cpart, Craw, tbuf, tmpc, Gobs, pcg_part, maxbuf;
+  Buf<double> lin_sums;  // [g_c | diag_c | g_p | diag_p | E^T E]: one all-reduce per linearisation
   Buf<double> Sdense;  // exact tiers: the reduced camera system, n_c x n_c
   Buf<double> chol_linv, chol_tmp;  // blocked Cholesky workspace (ba_schur_explicit.h)
   Buf<int> chol_info;
@@ -2847,11 +2857,18 @@ struct Solver {
       V.Jcam32 = op32 ? Jcam32.p : nullptr;
       V.Jpt32 = op32 ? Jpt32.p : nullptr;
     }
-    scale_c.alloc(n_c); scale_p.alloc(poff); gc.alloc(n_c); gp.alloc(poff); diag_c.alloc(n_c); diag_p.alloc(poff);
+    // gradient, column norms and E^T E of a linearisation are summed over the ranks of a sharded solve in ONE
+    // all-reduce: they live back to back in `lin_sums` [g_c | diag_c | g_p | diag_p | E^T E] (point sharding
+    // reduces the camera-side prefix only)
+    lin_sums.alloc(2 * (size_t)n_c + 2 * (size_t)poff + 6 * (size_t)p.num_points);
+    gc.alias(lin_sums.p, n_c); diag_c.alias(lin_sums.p + n_c, n_c);
+    gp.alias(lin_sums.p + 2 * (size_t)n_c, poff); diag_p.alias(lin_sums.p + 2 * (size_t)n_c + poff, poff);
+    Craw.alias(lin_sums.p + 2 * (size_t)n_c + 2 * (size_t)poff, 6 * (size_t)p.num_points);
+    scale_c.alloc(n_c); scale_p.alloc(poff);
     Dc.alloc(n_c); Dp.alloc(poff); rhs.alloc(n_c); x.alloc(n_c); r.alloc(n_c); z.alloc(n_c); pdir.alloc(n_c);
     q.alloc(n_c); dp.alloc(poff); stepc.alloc(n_c); stepp.alloc(poff);
     Cinv.alloc(9 * (size_t)p.num_points); M.alloc(moff); Minv.alloc(moff);
-    Craw.alloc(6 * (size_t)p.num_points); tbuf.alloc(poff); tmpc.alloc(n_c);
+    tbuf.alloc(poff); tmpc.alloc(n_c);
     scalars.alloc(NSCALAR);
     pcg_part.alloc((size_t)grid_for(n_blk, 256) + 1);
     partials.alloc((size_t)std::max(grid_for(n, 256), std::max(p.num_points, 1)) + 1);  // one slot per linearise workgroup / point tile
@@ -2936,16 +2953,12 @@ struct Solver {
       BA_LAUNCH(ba_point_grad_kernel, dim3(grid_for(V.n_points, 128)), dim3(128), st, V, gp.p, diag_p.p);
       BA_LAUNCH(ba_point_gram_kernel, dim3(grid_for(V.n_points, 128)), dim3(128), st, V, Craw.p);
     }
-    // E^T E of the points changes only with the linearisation: summed over ranks here, once
-    if (!comm.by_point) comm.allreduce(Craw.p, 6 * (size_t)V.n_points, st);
     if (use_priors())
       BA_LAUNCH(ba_prior_accumulate_kernel<0>, dim3(grid_for(Q.n_tblk, 64)), dim3(64), st, V, Q, gc.p, diag_c.p);
-    comm.allreduce(gc.p, V.n_c, st);
-    comm.allreduce(diag_c.p, V.n_c, st);
-    if (!comm.by_point) {  // point sharding: a point's gradient and column norms are complete locally
-      comm.allreduce(gp.p, V.n_p, st);
-      comm.allreduce(diag_p.p, V.n_p, st);
-    }
+    // one all-reduce for everything a linearisation sums over ranks (E^T E of the points changes only here).
+    // Point sharding: a point's gradient, column norms and E^T E are complete locally -> camera-side prefix only.
+    if (comm.by_point) comm.allreduce(lin_sums.p, 2 * (size_t)V.n_c, st);
+    else comm.allreduce(lin_sums.p, lin_sums.n, st);
   }
 
   // y = (sum over ranks of J_c^T v) for this rank's observations, into tmpc

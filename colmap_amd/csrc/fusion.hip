@@ -28,7 +28,8 @@
 //
 // Data layout in HBM: every image's depth map, slice-major normal map and bitmap stay resident for
 // the whole run (4 + 12 + 3 bytes per pixel), plus a 4-byte mask stamp and an 8-byte claim word per
-// depth-map pixel of every image. The state of a walk (<= 1024 absorbed pixels: pixel, image, level,
+// depth-map pixel of every image. The state of a walk (<= record_capacity(max_num_pixels) absorbed pixels,
+// 1 024 .. 16 384 slots -- the reference's default of 10 000 is held in full: pixel, image, level,
 // point, normal, colour; one expansion frame per expanded pixel) lives in global arrays laid out
 // [slot][lane] so that the lanes of a wave touch consecutive addresses; a launch uses a fixed number
 // of resident lanes that stride over the undecided seeds.
@@ -68,7 +69,11 @@ struct Fail : std::runtime_error {
     if (e_ != hipSuccess) throw Fail(std::string(#expr) + ": " + hipGetErrorString(e_));    \
   } while (0)
 
-constexpr int kElemCap = 1024;   // absorbed pixels a seed can record (and the cap on max_num_pixels)
+// Pixels one walk can record = the lane state of a seed: max_num_pixels itself between 1 024 and 16 384 (the
+// reference's default 10 000 is NOT clamped: 40 B x 10 000 x 32 768 lanes = 13 GB of the 288 GB), smaller
+// options keep the 1 024-slot state, larger ones are clamped to 16 384 (21 GB). oracle/fusion_oracle.cpp mirrors it.
+constexpr int kElemCapMin = 1024, kElemCapMax = 16384;
+inline int record_capacity(int max_num_pixels) { return std::min(std::max(max_num_pixels, kElemCapMin), kElemCapMax); }
 constexpr int kLanes = 1 << 15;  // resident lanes per launch (256 CUs x 2 waves)
 constexpr int kBlock = 64;
 constexpr int kRankCount = 128;  // medians: rank counting (staged in LDS) up to this many values, radix select above
@@ -102,7 +107,8 @@ struct Params {
   int* lane_walk;               // per lane: recorded pixels of the speculate walk | capped << 31 (state reuse)
   int reuse;                    // num_active <= kLanes: a lane keeps its walk from speculate to commit
   unsigned* barrier;            // lowest priority value among seeds whose closure overflowed the record
-  int elem_cap;                 // min(max_num_pixels, kElemCap)
+  int elem_cap;                 // min(max_num_pixels, rec_cap)
+  int rec_cap;                  // record_capacity(max_num_pixels): slots of the lane state
   int max_level;                // max_traversal_depth - 1
   int min_num_pixels;
   double max_depth_error;
@@ -116,6 +122,7 @@ struct Params {
   float* pt;            // [num_seeds][6]
   unsigned char* col;   // [num_seeds][3]
   int* pool;            // visibility lists, allocated with an atomic cursor
+  long long pool_cap;   // entries; the host checks the cursor against it after every image
   unsigned long long* pool_cursor;
 };
 
@@ -255,7 +262,7 @@ __device__ Walk walk(const Params& p, int lane, int seed, unsigned long long key
         xyz[r] = im.inv_P[4 * r] * hx + im.inv_P[4 * r + 1] * hy + im.inv_P[4 * r + 2] * depth + im.inv_P[4 * r + 3] * 1.0f;
       const bool in_box = !(xyz[0] < p.bmin[0] || xyz[1] < p.bmin[1] || xyz[2] < p.bmin[2] || xyz[0] > p.bmax[0] ||
                             xyz[1] > p.bmax[1] || xyz[2] > p.bmax[2]);
-      if (ne >= kElemCap) {  // record capacity: the walk ends
+      if (ne >= p.rec_cap) {  // record capacity: the walk ends
         w.capped = true; w.overflow = true; nf = 0;
         break;
       }
@@ -406,7 +413,9 @@ __global__ void __launch_bounds__(kBlock) fusion_commit_kernel(Params p) {
       last = best;
       ++nvis;
     }
-    const int off = (int)atomicAdd(p.pool_cursor, (unsigned long long)nvis);
+    const unsigned long long off64 = atomicAdd(p.pool_cursor, (unsigned long long)nvis);
+    const bool fits = off64 + (unsigned long long)nvis <= (unsigned long long)p.pool_cap;  // else: the host fails the run
+    const int off = fits ? (int)off64 : 0;
     int last = -1;
     for (int v = 0; v < nvis; ++v) {
       int best = 0x7FFFFFFF;
@@ -414,7 +423,7 @@ __global__ void __launch_bounds__(kBlock) fusion_commit_kernel(Params p) {
         const int ia = (int)(SLOT(p.e_meta, SLOT(p.frame, a)) & 0xFFFFu);
         if (ia > last && ia < best) best = ia;
       }
-      p.pool[off + v] = best;
+      if (fits) p.pool[off + v] = best;
       last = best;
     }
     p.vis_off[seed] = off;
@@ -648,7 +657,10 @@ void Run(const fusion_options& opt, int n, const fusion_image* images, const int
     total_pix += (long long)npix;
     max_seeds = std::max(max_seeds, (int)npix);
   }
-  FU_CHECK(total_pix < (1ll << 31), "total number of depth-map pixels");  // visibility pool offsets are int
+  // mask / claim words are indexed with 64-bit offsets: no limit on the workspace size. The visibility pool is
+  // refilled per reference image (cursor reset every step) and its int offsets only have to cover what ONE
+  // image's walks absorb: capacity min(total pixels, 2^31 - 1), an overflow fails the run instead of wrapping.
+  const long long pool_cap = std::min<long long>(total_pix, 0x7FFFFFFFll);
   DevBuf<DevImage> d_img;
   d_img.upload(h_img.data(), h_img.size());
   DevBuf<int> d_optr, d_oidx;
@@ -679,7 +691,8 @@ void Run(const fusion_options& opt, int n, const fusion_image* images, const int
   Params p;
   std::memset(&p, 0, sizeof(p));
   p.images = d_img.p; p.optr = d_optr.p; p.oidx = d_oidx.p; p.mask = d_mask.p; p.claim = d_claim.p;
-  p.elem_cap = std::min(opt.max_num_pixels, kElemCap);
+  p.rec_cap = record_capacity(opt.max_num_pixels);
+  p.elem_cap = std::min(opt.max_num_pixels, p.rec_cap);
   p.max_level = opt.max_traversal_depth - 1;
   p.min_num_pixels = opt.min_num_pixels;
   p.max_depth_error = opt.max_depth_error;
@@ -688,7 +701,7 @@ void Run(const fusion_options& opt, int n, const fusion_image* images, const int
   for (int c = 0; c < 3; ++c) { p.bmin[c] = opt.bbox_min[c]; p.bmax[c] = opt.bbox_max[c]; }
   DevBuf<unsigned> e_pix, e_meta, e_rgb, frame;
   DevBuf<float> e_f[6];
-  const size_t state = (size_t)kElemCap * kLanes;
+  const size_t state = (size_t)p.rec_cap * kLanes;
   e_pix.alloc(state); e_meta.alloc(state); e_rgb.alloc(state); frame.alloc(state);
   for (auto& b : e_f) b.alloc(state);
   p.e_pix = e_pix.p; p.e_meta = e_meta.p; p.e_rgb = e_rgb.p; p.frame = frame.p;
@@ -699,7 +712,8 @@ void Run(const fusion_options& opt, int n, const fusion_image* images, const int
   const size_t ms = (size_t)max_seeds;
   valid.alloc(ms); nvis.alloc(ms); vis_off.alloc(ms); valid_r.alloc(ms + 1); nvis_r.alloc(ms + 1);
   scan_valid.alloc(ms + 1); scan_vis.alloc(ms + 1); list_a.alloc(ms); list_b.alloc(ms);
-  pool.alloc((size_t)total_pix); out_nvis.alloc(ms); out_vis.alloc((size_t)total_pix);
+  pool.alloc((size_t)pool_cap); out_nvis.alloc(ms); out_vis.alloc((size_t)pool_cap);
+  p.pool_cap = pool_cap;
   pt.alloc(6 * ms); out_pt.alloc(6 * ms); col.alloc(3 * ms); out_col.alloc(3 * ms);
   p.valid = valid.p; p.nvis = nvis.p; p.vis_off = vis_off.p; p.pt = pt.p; p.col = col.p; p.pool = pool.p;
   p.pool_cursor = d_cursor.p; p.barrier = d_barrier.p; p.next_count = d_next_count.p;
@@ -776,6 +790,9 @@ void Run(const fusion_options& opt, int n, const fusion_image* images, const int
     hipLaunchKernelGGL(fusion_compact_kernel, dim3((ns + 255) / 256), dim3(256), 0, 0, ns, order.p, valid_r.p,
                        scan_valid.p, nvis_r.p, scan_vis.p, vis_off.p, pool.p, pt.p, col.p, out_pt.p, out_col.p,
                        out_nvis.p, out_vis.p);
+    unsigned long long used = 0;
+    FU_HIP(hipMemcpy(&used, d_cursor.p, sizeof(used), hipMemcpyDeviceToHost));
+    FU_CHECK(used <= (unsigned long long)pool_cap, "visibility pool overflow (more than 2^31 - 1 visibility entries for one reference image)");
     int totals[2] = {0, 0};
     FU_HIP(hipMemcpy(&totals[0], scan_valid.p + ns, sizeof(int), hipMemcpyDeviceToHost));
     FU_HIP(hipMemcpy(&totals[1], scan_vis.p + ns, sizeof(int), hipMemcpyDeviceToHost));

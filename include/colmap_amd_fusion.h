@@ -9,8 +9,9 @@
  * run on the GPU (colmap_amd/csrc/fusion.hip) and there is no CPU path. The pixels of an image take
  * their turns in a fixed pseudo-random order instead of row-major (the reference's order depends on its
  * thread pool unless num_threads = 1); the result is the reference's algorithm run in that order.
- * Differences: at most 1024 pixels per fused point (max_num_pixels is clamped), visibility lists are
- * sorted (the reference copies an unordered set).
+ * Differences: max_num_pixels above 16 384 is clamped (the reference's default 10 000 is honoured in full),
+ * visibility lists are sorted (the reference copies an unordered set). No limit on the number of images
+ * other than HBM (~40 B per depth-map pixel resident; 64-bit pixel offsets).
  */
 #ifndef COLMAP_AMD_FUSION_H_
 #define COLMAP_AMD_FUSION_H_

@@ -102,7 +102,9 @@ struct fusion_result {
 
 namespace {
 
-constexpr int kRecordCap = 1024;  // mode 1: pixels one walk can absorb (the lane state of fusion.hip)
+// modes 1 / 2: pixels one walk can record = the lane state of fusion.hip (record_capacity there): max_num_pixels
+// itself between 1 024 and 16 384, so the reference's default 10 000 is not clamped
+inline int RecordCapacity(int max_num_pixels) { return std::min(std::max(max_num_pixels, 1024), 16384); }
 
 struct Fuser {
   int mode = 0;
@@ -192,6 +194,7 @@ struct Fuser {
     std::vector<int> vis_order;  // insertion order of distinct images
     std::unordered_set<int> vis;
     int recorded = 0;
+    const int kRecordCap = RecordCapacity(opt.max_num_pixels);
     const size_t max_pixels = mode == 0 ? (size_t)opt.max_num_pixels : (size_t)std::min(opt.max_num_pixels, kRecordCap);
 
     while (!queue.empty()) {
@@ -324,6 +327,7 @@ struct Fuser {
     std::vector<FusionData> queue;
     queue.push_back({I, seed / images[I].depth_width, seed % images[I].depth_width, 0});
     float ref_point[4] = {0, 0, 0, 0}, ref_normal[3] = {0, 0, 0};
+    const int kRecordCap = RecordCapacity(opt.max_num_pixels);
     const size_t max_pixels = (size_t)std::min(opt.max_num_pixels, kRecordCap);
     size_t n_in = 0;
     while (!queue.empty()) {
