@@ -17,6 +17,7 @@ include/colmap_amd_ba.h, the way CasparBundleAdjuster does for its solver
 from __future__ import annotations
 
 import ctypes as C
+import dataclasses
 import enum
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Set
@@ -776,8 +777,16 @@ class BundleAdjuster:
         if len(fp.obs_pose) == 0:
             return BundleAdjustmentSummary()  # zero residuals -> default summary (:667-669)
         gpu = [int(x) for x in str(self.options_.gpu_index).split(",") if x.strip()]
-        summary = solve_flat(fp, self.options_.solver_options, gpu[0] if gpu else -1,
-                             solve_fn=self._solve_fn)
+        so = self.options_.solver_options
+        if so.linear_solver_type == SOLVER_AUTO:
+            # CreateSolverOptions' rule on config.NumImages() (bundle_adjustment_ceres.cc:131,203-213; CPU
+            # thresholds bundle_adjustment_ceres.h:68-69) -- resolved here, where the image count is known: the
+            # flat C interface only sees pose blocks (a rig frame with several sensors is one block)
+            n_img = self.config_.NumImages()
+            tier = SOLVER_DENSE_SCHUR if n_img <= 50 else (SOLVER_SPARSE_SCHUR if n_img <= 1000 else SOLVER_ITERATIVE_SCHUR)
+            so = dataclasses.replace(so, linear_solver_type=tier)
+        summary = solve_flat(fp, so, gpu[0] if gpu else -1, solve_fn=self._solve_fn)
+        self.linear_solver_requested_, self.linear_solver_used_ = so.linear_solver_type, summary.linear_solver_used
         if summary.num_residuals == 0:
             return BundleAdjustmentSummary()
         # WriteResultsToReconstruction: only variable blocks (bundle_adjustment_caspar.cc:767-801)
@@ -828,6 +837,7 @@ class PosePriorBundleAdjustmentOptions:
     prior_position_fallback_stddev: float = 1.0
     prior_position_loss_function_type: LossFunctionType = LossFunctionType.TRIVIAL
     prior_position_loss_scale: float = float(np.sqrt(7.815))  # sqrt(kChiSquare95ThreeDof)
+    alignment_ransac_options: Optional["RANSACOptions"] = None  # bundle_adjustment.h:258 (None: defaults)
 
     def Check(self) -> bool:
         return self.prior_position_fallback_stddev > 0 and self.prior_position_loss_scale > 0
@@ -854,6 +864,77 @@ def align_to_positions(src: np.ndarray, dst: np.ndarray):
     R = U @ D @ Vt
     scale = float(np.trace(np.diag(S) @ D) / var)
     return scale, R, md - scale * R @ ms
+
+
+K_CHI_SQUARE_95_THREE_DOF = 7.814727903251179  # math/math.h:47
+
+
+@dataclass
+class RANSACOptions:
+    """colmap::RANSACOptions (optim/ransac.h:50-83), the fields the alignment uses."""
+    max_error: float = 0.0          # <= 0: from the priors' covariances (alignment.cc:284-294)
+    min_inlier_ratio: float = 0.1
+    confidence: float = 0.99
+    dyn_num_trials_multiplier: float = 3.0
+    min_num_trials: int = 0
+    max_num_trials: int = 10000
+    random_seed: int = 0            # (the reference's -1 = nondeterministic; a fixed stream here)
+
+
+def _lcg(state: int) -> int:
+    return (state * 6364136223846793005 + 1442695040888963407) & 0xFFFFFFFFFFFFFFFF
+
+
+def align_to_positions_robust(src: np.ndarray, dst: np.ndarray, max_error: float, opt: Optional[RANSACOptions] = None):
+    """AlignReconstructionToPosePriors' estimator (estimators/alignment.cc:240-299 -> EstimateSim3dRobust):
+    RANSAC over 3-point similarity hypotheses with the position error |dst - (s R src + t)| <= max_error as the
+    inlier test, a local refit on the inliers of every improving hypothesis, and the final least-squares
+    similarity over the best inlier set. One outlier prior no longer skews the frame every prior residual is
+    expressed in. Deterministic sample stream (64-bit LCG), mirrored by AlignToPositionsRobust in
+    include/colmap_amd/bundle_adjustment.hpp. Returns (scale, R, t) or None."""
+    opt = opt or RANSACOptions()
+    src, dst = np.asarray(src, np.float64), np.asarray(dst, np.float64)
+    n = len(src)
+    if n < 3 or not max_error > 0:
+        return None
+
+    def inliers_of(tf):
+        s, R, t = tf
+        return np.linalg.norm(dst - (s * src @ R.T + t), axis=1) <= max_error
+
+    best_inl, best_count = None, 0
+    state = _lcg(0x9E3779B97F4A7C15 ^ (opt.random_seed & 0xFFFFFFFF))
+    needed = float(opt.max_num_trials)
+    trial = 0
+    while trial < opt.max_num_trials and (trial < needed or trial < opt.min_num_trials):
+        trial += 1
+        idx = []
+        while len(idx) < 3:
+            state = _lcg(state)
+            k = int((state >> 33) % n)
+            if k not in idx:
+                idx.append(k)
+        tf = align_to_positions(src[idx], dst[idx])
+        if tf is None:
+            continue
+        inl = inliers_of(tf)
+        count = int(inl.sum())
+        if count <= best_count:
+            continue
+        for _ in range(4):  # local optimisation: refit on the support while it grows
+            tf2 = align_to_positions(src[inl], dst[inl]) if count >= 3 else None
+            if tf2 is None:
+                break
+            inl2 = inliers_of(tf2)
+            if int(inl2.sum()) <= count:
+                break
+            inl, count = inl2, int(inl2.sum())
+        best_inl, best_count = inl, count
+        w = min(max(best_count / n, opt.min_inlier_ratio), 1.0 - 1e-12)
+        needed = opt.dyn_num_trials_multiplier * np.log(1.0 - opt.confidence) / np.log(1.0 - w ** 3)
+    if best_count < 3:
+        return None
+    return align_to_positions(src[best_inl], dst[best_inl])
 
 
 class PosePriorBundleAdjuster(BundleAdjuster):
@@ -884,7 +965,15 @@ class PosePriorBundleAdjuster(BundleAdjuster):
     def _align(self, rec: scene.Reconstruction) -> bool:
         src = np.array([rec.ProjectionCenter(p.image_id) for p in self.pose_priors_])
         dst = np.array([p.position for p in self.pose_priors_])
-        tf = align_to_positions(src, dst)
+        ropt = getattr(self.prior_options_, "alignment_ransac_options", None) or RANSACOptions()
+        max_error = ropt.max_error
+        if max_error <= 0:  # alignment.cc:284-294: 95 % chi-square quantile of the median prior variance
+            rms = [float(np.trace(p.position_covariance)) / 3.0 for p in self.pose_priors_
+                   if p.HasPositionCov() and np.trace(p.position_covariance) > 0]
+            if not rms:
+                rms = [self.prior_options_.prior_position_fallback_stddev ** 2]
+            max_error = float(np.sqrt(K_CHI_SQUARE_95_THREE_DOF * np.median(rms)))
+        tf = align_to_positions_robust(src, dst, max_error, ropt)
         if tf is None:
             return False
         rec.Transform(*tf)

@@ -429,10 +429,14 @@ class BundleAdjuster {  // :212-228
   virtual std::shared_ptr<BundleAdjustmentSummary> Solve() = 0;
   const BundleAdjustmentOptions& Options() const { return options_; }
   const BundleAdjustmentConfig& Config() const { return config_; }
+  // BA_SOLVER_* tier the last Solve() asked for (AUTO resolved on the image count) and the one that ran
+  int LinearSolverRequested() const { return linear_solver_requested_; }
+  int LinearSolverUsed() const { return linear_solver_used_; }
 
  protected:
   BundleAdjustmentOptions options_;
   BundleAdjustmentConfig config_;
+  int linear_solver_requested_ = BA_SOLVER_ITERATIVE_SCHUR, linear_solver_used_ = BA_SOLVER_ITERATIVE_SCHUR;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -452,6 +456,14 @@ class Mi355xBundleAdjuster : public BundleAdjuster {
     ba_options so = options_.mi355x->solver_options;
     so.loss_type = static_cast<int32_t>(options_.mi355x->loss_function_type);
     so.loss_scale = options_.mi355x->loss_function_scale;
+    if (so.linear_solver_type == BA_SOLVER_AUTO) {
+      // CreateSolverOptions' rule on config.NumImages() (bundle_adjustment_ceres.cc:131,203-213; CPU thresholds
+      // bundle_adjustment_ceres.h:68-69), resolved here where the image count is known: the flat C interface
+      // only sees pose blocks (a rig frame with several sensors is one block)
+      const size_t n_img = config_.NumImages();
+      so.linear_solver_type = n_img <= 50 ? BA_SOLVER_DENSE_SCHUR : (n_img <= 1000 ? BA_SOLVER_SPARSE_SCHUR : BA_SOLVER_ITERATIVE_SCHUR);
+    }
+    linear_solver_requested_ = so.linear_solver_type;
     ba_result res{};
     int gpu = -1;
     if (!options_.gpu_index.empty()) gpu = std::stoi(options_.gpu_index);  // single GPU (:189-191)
@@ -467,6 +479,7 @@ class Mi355xBundleAdjuster : public BundleAdjuster {
     summary->initial_cost = res.initial_cost;
     summary->final_cost = res.final_cost;
     summary->lm_seconds = res.lm_seconds;
+    linear_solver_used_ = res.linear_solver_used;  // differs from the requested tier when that one did not apply
     return summary;
   }
 
@@ -884,6 +897,7 @@ struct PosePriorBundleAdjustmentOptions {  // bundle_adjustment.h:252-262 + bund
   double prior_position_fallback_stddev = 1.0;
   int prior_position_loss_function_type = BA_LOSS_TRIVIAL;
   double prior_position_loss_scale = 2.7955321496988725;  // sqrt(kChiSquare95ThreeDof = 7.815)
+  struct RANSACOptions* alignment_ransac_options = nullptr;  // bundle_adjustment.h:258 (nullptr: defaults)
   bool Check() const { return prior_position_fallback_stddev > 0 && prior_position_loss_scale > 0; }
 };
 
@@ -975,6 +989,82 @@ inline bool AlignToPositions(const std::vector<std::array<double, 3>>& src, cons
   return true;
 }
 
+// colmap::RANSACOptions (optim/ransac.h:50-83), the fields the alignment uses
+struct RANSACOptions {
+  double max_error = 0.0;  // <= 0: from the priors' covariances (alignment.cc:284-294)
+  double min_inlier_ratio = 0.1;
+  double confidence = 0.99;
+  double dyn_num_trials_multiplier = 3.0;
+  int min_num_trials = 0;
+  int max_num_trials = 10000;
+  int random_seed = 0;  // (the reference's -1 = nondeterministic; a fixed stream here)
+};
+
+// AlignReconstructionToPosePriors' estimator (estimators/alignment.cc:240-299 -> EstimateSim3dRobust): RANSAC
+// over 3-point similarity hypotheses, inlier test |dst - (s R src + t)| <= max_error, local refit on the support
+// of every improving hypothesis, final least-squares similarity over the best inlier set. Same deterministic
+// sample stream as colmap_amd/estimators.py::align_to_positions_robust.
+inline bool AlignToPositionsRobust(const std::vector<std::array<double, 3>>& src, const std::vector<std::array<double, 3>>& dst,
+                                   double max_error, const RANSACOptions& opt, double* scale, double R[9], double t[3]) {
+  const size_t n = src.size();
+  if (n < 3 || dst.size() != n || !(max_error > 0)) return false;
+  auto lcg = [](uint64_t s) { return s * 6364136223846793005ull + 1442695040888963407ull; };
+  auto subset = [&](const std::vector<char>& inl, std::vector<std::array<double, 3>>* a, std::vector<std::array<double, 3>>* b) {
+    a->clear(); b->clear();
+    for (size_t i = 0; i < n; ++i) if (inl[i]) { a->push_back(src[i]); b->push_back(dst[i]); }
+  };
+  auto support = [&](double s_, const double* R_, const double* t_, std::vector<char>* inl) {
+    size_t c = 0;
+    inl->assign(n, 0);
+    for (size_t i = 0; i < n; ++i) {
+      double e2 = 0;
+      for (int r = 0; r < 3; ++r) {
+        const double d = dst[i][r] - (s_ * (R_[3 * r] * src[i][0] + R_[3 * r + 1] * src[i][1] + R_[3 * r + 2] * src[i][2]) + t_[r]);
+        e2 += d * d;
+      }
+      if (std::sqrt(e2) <= max_error) { (*inl)[i] = 1; ++c; }
+    }
+    return c;
+  };
+  std::vector<char> best_inl, inl, inl2;
+  size_t best = 0;
+  uint64_t state = lcg(0x9E3779B97F4A7C15ull ^ (uint64_t)(uint32_t)opt.random_seed);
+  double needed = opt.max_num_trials;
+  std::vector<std::array<double, 3>> a, b;
+  for (int trial = 0; trial < opt.max_num_trials && (trial < needed || trial < opt.min_num_trials);) {
+    ++trial;
+    size_t idx[3];
+    for (int k = 0; k < 3;) {
+      state = lcg(state);
+      const size_t c = (size_t)((state >> 33) % n);
+      bool dup = false;
+      for (int j = 0; j < k; ++j) dup = dup || idx[j] == c;
+      if (!dup) idx[k++] = c;
+    }
+    a = {src[idx[0]], src[idx[1]], src[idx[2]]};
+    b = {dst[idx[0]], dst[idx[1]], dst[idx[2]]};
+    double s_, R_[9], t_[3];
+    if (!AlignToPositions(a, b, &s_, R_, t_)) continue;
+    size_t count = support(s_, R_, t_, &inl);
+    if (count <= best) continue;
+    for (int it = 0; it < 4 && count >= 3; ++it) {  // local optimisation
+      subset(inl, &a, &b);
+      if (!AlignToPositions(a, b, &s_, R_, t_)) break;
+      const size_t c2 = support(s_, R_, t_, &inl2);
+      if (c2 <= count) break;
+      inl.swap(inl2);
+      count = c2;
+    }
+    best_inl = inl;
+    best = count;
+    const double w = std::min(std::max((double)best / n, opt.min_inlier_ratio), 1.0 - 1e-12);
+    needed = opt.dyn_num_trials_multiplier * std::log(1.0 - opt.confidence) / std::log(1.0 - w * w * w);
+  }
+  if (best < 3) return false;
+  subset(best_inl, &a, &b);
+  return AlignToPositions(a, b, scale, R, t);
+}
+
 class PosePriorBundleAdjuster : public Mi355xBundleAdjuster {
  public:
   struct Prepared {  // what has to happen to the reconstruction BEFORE it is flattened
@@ -986,7 +1076,7 @@ class PosePriorBundleAdjuster : public Mi355xBundleAdjuster {
   // drops unusable priors, aligns + normalises the reconstruction or falls back to the two-camera gauge
   // (bundle_adjustment_ceres.cc:913-936)
   static Prepared Prepare(const BundleAdjustmentConfig& config, const std::vector<PosePrior>& pose_priors,
-                          Reconstruction& rec) {
+                          Reconstruction& rec, const PosePriorBundleAdjustmentOptions& prior_options = PosePriorBundleAdjustmentOptions()) {
     Prepared out;
     out.config = config;
     for (const PosePrior& p : pose_priors)
@@ -995,7 +1085,20 @@ class PosePriorBundleAdjuster : public Mi355xBundleAdjuster {
       std::vector<std::array<double, 3>> src, dst;
       for (const PosePrior& p : out.pose_priors) { src.push_back(rec.ProjectionCenter(p.image_id)); dst.push_back(p.position); }
       double scale, R[9], t[3];
-      if (AlignToPositions(src, dst, &scale, R, t)) {
+      const RANSACOptions ropt = prior_options.alignment_ransac_options ? *prior_options.alignment_ransac_options : RANSACOptions();
+      double max_error = ropt.max_error;
+      if (!(max_error > 0)) {  // alignment.cc:284-294: 95 % chi-square quantile (3 dof) of the median prior variance
+        std::vector<double> rms;
+        for (const PosePrior& p : out.pose_priors) {
+          const double tr = p.position_covariance[0] + p.position_covariance[4] + p.position_covariance[8];
+          if (p.HasPositionCov() && tr > 0) rms.push_back(tr / 3.0);
+        }
+        if (rms.empty()) rms.push_back(prior_options.prior_position_fallback_stddev * prior_options.prior_position_fallback_stddev);
+        std::sort(rms.begin(), rms.end());
+        const double med = rms.size() % 2 ? rms[rms.size() / 2] : 0.5 * (rms[rms.size() / 2 - 1] + rms[rms.size() / 2]);
+        max_error = std::sqrt(7.814727903251179 * med);
+      }
+      if (AlignToPositionsRobust(src, dst, max_error, ropt, &scale, R, t)) {
         rec.Transform(scale, R, t);
         out.use_prior_position = true;
       }
@@ -1075,7 +1178,7 @@ inline std::unique_ptr<BundleAdjuster> CreatePosePriorBundleAdjuster(const Bundl
   if (options.backend != BundleAdjustmentBackend::MI355X)
     throw std::invalid_argument("BundleAdjustmentBackend CERES / CASPAR are not built here (they need Ceres / CUDA)");
   return std::make_unique<PosePriorBundleAdjuster>(options, prior_options,
-                                                   PosePriorBundleAdjuster::Prepare(config, pose_priors, reconstruction),
+                                                   PosePriorBundleAdjuster::Prepare(config, pose_priors, reconstruction, prior_options),
                                                    reconstruction);
 }
 

@@ -982,3 +982,29 @@ def test_explicit_reduced_camera_system_equals_operator_products():
         assert np.array_equal(out["sparse"][0].log_cost, out["explicit"][0].log_cost)
         assert out["sparse"][0].linear_solver_used == est.SOLVER_SPARSE_SCHUR
         assert out["explicit"][0].linear_solver_used == est.SOLVER_DENSE_SCHUR
+
+
+def test_robust_alignment_to_pose_priors_rejects_an_outlier():
+    """AlignReconstructionToPosePriors runs RANSAC (estimators/alignment.cc:240-299): one wild GPS prior among
+    twelve must not skew the similarity the reconstruction is aligned with (round 2 used plain least squares
+    over all priors). The outlier is rejected, the other priors are inliers, the frame is the inliers' frame."""
+    rng = np.random.default_rng(5)
+    src = rng.normal(size=(12, 3))
+    Rz = np.array([[0.0, -1.0, 0.0], [1.0, 0.0, 0.0], [0.0, 0.0, 1.0]])
+    dst = 2.0 * src @ Rz.T + np.array([1.0, -2.0, 0.5]) + 0.01 * rng.normal(size=(12, 3))
+    dst[4] += np.array([30.0, -20.0, 10.0])  # the outlier
+    plain = est.align_to_positions(src, dst)
+    robust = est.align_to_positions_robust(src, dst, max_error=0.1)
+    assert robust is not None
+    s, R, t = robust
+    assert abs(s - 2.0) < 0.02 and np.allclose(R, Rz, atol=0.02) and np.allclose(t, [1.0, -2.0, 0.5], atol=0.05)
+    assert abs(plain[0] - 2.0) > 0.2 or not np.allclose(plain[2], [1.0, -2.0, 0.5], atol=0.5)  # least squares IS skewed
+    clean = np.delete(np.arange(12), 4)
+    ref = est.align_to_positions(src[clean], dst[clean])  # = the refit on the inlier set
+    assert np.allclose(s, ref[0]) and np.allclose(R, ref[1]) and np.allclose(t, ref[2])
+    # without outliers (noise well inside max_error) the robust estimate is the least-squares one
+    dst2 = dst.copy()
+    dst2[4] = 2.0 * src[4] @ Rz.T + np.array([1.0, -2.0, 0.5])
+    a, b = est.align_to_positions(src, dst2), est.align_to_positions_robust(src, dst2, max_error=0.1)
+    assert np.allclose(a[0], b[0]) and np.allclose(a[1], b[1]) and np.allclose(a[2], b[2])
+    assert est.align_to_positions_robust(src[:2], dst[:2], max_error=0.1) is None
