@@ -1655,7 +1655,7 @@ __host__ __device__ inline LdsOffsets lds_offsets_wave(int C, int S, int radius,
   o.th = take(36u * kWaveThCap);
   o.ntasks = take(16u);
   o.tapg = take(4u * 256);
-  o.tin = take((uint32_t)kWaveThCap);
+  o.tin = take(2u * (uint32_t)kWaveThCap);  // [0, cap): inside flags; [cap, 2 cap): task order of the batch (inside first)
   o.total = off;
   return o;
 }
@@ -1720,6 +1720,7 @@ __device__ __forceinline__ void run_tasks_wave(const PmParams& p, const Lds& L, 
   for (int base = 0; base < n; base += kWaveThCap) {
     const int nb = min(kWaveThCap, n - base);
     // pass A, lane per task: homography of the (hypothesis, view) pair (+ geometric cost)
+    bool inside = false;
     if (tid < nb) {
       const uint32_t task = tasks[base + tid];
       const int c = task >> 13;
@@ -1732,8 +1733,21 @@ __device__ __forceinline__ void run_tasks_wave(const PmParams& p, const Lds& L, 
       compose_homography(p.refInvK, pose, row, col, h[0], h[1], h[2], h[3], Hm);
       centre_homography(Hm, row, col, p.radius);
       for (int k = 0; k < 9; ++k) L.th[tid * 9 + k] = Hm[k];
-      L.tin[tid] = patch_inside(p, Hm) ? 1 : 0;
+      inside = patch_inside(p, Hm);
+      L.tin[tid] = inside ? 1 : 0;
       if (GEOM) L.geo[(c * 5 + i) * S + s] = geom_cost(p, pose, s, (float)row, (float)col, h[0]);
+    }
+    {
+      // Order of the batch's tasks for pass B: the tasks whose patch is inside the source image first. A round
+      // takes the cheaper unclamped addressing only when all four of its patches are inside; with the tasks in
+      // list order one outside patch in four spoils the round, sorted they collect in the last rounds. Results
+      // are stored per task, so the order cannot change a bit.
+      const unsigned long long m1 = __ballot(inside ? 1 : 0);
+      const unsigned long long valid = nb >= 64 ? ~0ull : ((1ull << nb) - 1ull);
+      const unsigned long long m0 = valid & ~m1;
+      const unsigned long long below = (1ull << tid) - 1ull;
+      if (tid < nb)
+        L.tin[kWaveThCap + (inside ? __popcll(m1 & below) : __popcll(m1) + __popcll(m0 & below))] = (uint8_t)tid;
     }
     __syncthreads();
     // pass B, 16-lane group per task, software-pipelined: the gathers of a group's NEXT task are
@@ -1754,7 +1768,7 @@ __device__ __forceinline__ void run_tasks_wave(const PmParams& p, const Lds& L, 
       auto prep = [&](int r, int& t, int& c, bool& own, bool& fast) -> uint32_t {
         const int tr = g + 4 * r;
         own = tr < nb;
-        t = own ? tr : nb - 1;
+        t = L.tin[kWaveThCap + (own ? tr : nb - 1)];
         const uint32_t task = tasks[base + t];
         c = task >> 13;
         // wave-uniform: the unclamped addressing only when all four patches of the round are inside
