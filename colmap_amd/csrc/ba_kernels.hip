@@ -3029,8 +3029,10 @@ struct Solver {
       fa.a_pose = V.a_pose; fa.a_cam = V.a_cam; fa.a_sensor = V.sens_off ? V.a_sensor : nullptr;
       fa.pose_off = V.pose_off; fa.pose_dim = V.pose_dim; fa.cam_off = V.cam_off; fa.cam_dim = V.cam_dim;
       fa.sens_off = V.sens_off;
+      fa.fixed_point = opt.jacobi_scaling != 0;  // columns of norm < 1: integer accumulation, bit-reproducible
       ba_explicit::form(fa, Sdense.p, st);
-      if (use_priors()) ba_explicit::add_prior_rows(Sdense.p, n, Q.J, Q.po, Q.so, Q.pdim, Q.n, st);
+      if (use_priors()) ba_explicit::add_prior_rows(Sdense.p, n, Q.J, Q.po, Q.so, Q.pdim, Q.n, fa.fixed_point, st);
+      ba_explicit::finish(Sdense.p, n, fa.fixed_point, st);
       if (comm.world > 1) comm.allreduce(Sdense.p, (size_t)n * n, st);  // point sharding: partial sums per rank
       ba_explicit::add_lm_diagonal(Sdense.p, n, Dc.p, st);
       ba_explicit::Workspace ws;

@@ -27,6 +27,7 @@ struct FormArgs {
   const int* a_sensor;          // p-order sensor_from_rig index or NULL
   const int *pose_off, *pose_dim, *cam_off, *cam_dim;
   const int* sens_off;          // [n_sensors] tangent offset of a variable sensor_from_rig, or NULL
+  bool fixed_point;             // accumulate in 64-bit fixed point (needs Jacobi-scaled columns): bit-reproducible
 };
 
 // S (n_c x n_c, row-major, LOWER triangle valid) = B - E C^-1 E^T of this rank's observations. S is cleared
@@ -37,7 +38,9 @@ void add_lm_diagonal(double* S, int n, const double* Dc /* D, not D^2 */, hipStr
 // Adds J^T J of the position priors to the lower triangle of S. J: [3][12][count] tangent columns (pose_dim
 // pose columns, then 6 sensor_from_rig columns when so >= 0); po / so: tangent offsets (-1 constant).
 void add_prior_rows(double* S, int n, const double* J, const int* po, const int* so, const int* pdim, int count,
-                    hipStream_t st);
+                    bool fixed_point, hipStream_t st);
+// After form (+ add_prior_rows): turns the fixed-point accumulators into doubles (no-op for fp64 accumulation).
+void finish(double* S, int n_c, bool fixed_point, hipStream_t st);
 
 struct Workspace {
   double* Linv = nullptr;  // [ceil(n / 64)][64][64] inverses of the diagonal blocks of L

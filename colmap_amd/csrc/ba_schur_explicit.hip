@@ -17,8 +17,9 @@
 //        S[cols_a, cols_b] += J_a^T (delta_ab I - G_ab) J_b,      G_ab = E_a C^-1 E_b^T  (2 x 2)
 //    for every ordered pair (a, b) of its observations: the wave stages the observations of the point in LDS
 //    and its lanes walk the (a, i, b, k) element space with the column index fastest, so the hardware fp64
-//    atomics of a wave instruction fall into few cache lines. Only the lower triangle is written.
-//    (Atomic accumulation: this tier is reproducible to rounding, not bit-wise like the iterative tier.)
+//    atomics of a wave instruction fall into few cache lines. Only the lower triangle is written. The atomics
+//    are INTEGER adds of 2^-60 fixed-point terms (form_kernel<.., FIXED>): order-independent, so this tier is
+//    bit-reproducible like the iterative one.
 //  * Factorisation: right-looking, 64-wide panels. Diagonal block: one workgroup in LDS, which also inverts
 //    the 64 x 64 triangle so that the panel solve below it becomes a GEMM  X = A_panel L_kk^-T;
 //    the trailing update C_IJ -= X_I X_J^T runs 64 x 64 tiles per workgroup, 2 x 2 MFMA tiles per wave.
@@ -99,7 +100,16 @@ __device__ __forceinline__ void load_slot(const FormArgs& A, ObsSlot<WMAX>& s, i
   }
 }
 
-template <int WMAX>
+// FIXED: contributions are accumulated as 64-bit fixed-point numbers (2^-60 units) with INTEGER atomics --
+// integer addition is associative, so the sum does not depend on the order the hardware serves the atomics
+// in and the whole exact tier is bit-reproducible run to run. With Jacobi scaling every column of the
+// Jacobian has norm < 1, so every entry of B - E C^-1 E^T and every partial sum of it is bounded by 1
+// (Cauchy-Schwarz): +-8 of range is ample and 2^-60 = 8.7e-19 is finer than the fp64 rounding of the terms.
+// Without Jacobi scaling (ba_options.jacobi_scaling = 0) there is no such bound: hardware fp64 atomics then
+// (reproducible to rounding only).
+constexpr double kFixedScale = 1152921504606846976.0;  // 2^60
+
+template <int WMAX, bool FIXED>
 __global__ void __launch_bounds__(64) form_kernel(FormArgs A, double* __restrict__ S) {
   constexpr int CH = 16;  // observations of a point staged per chunk
   __shared__ ObsSlot<WMAX> sa[CH], sb[CH];
@@ -159,10 +169,22 @@ __global__ void __launch_bounds__(64) form_kernel(FormArgs A, double* __restrict
         }
         const double b0v = ob.jc[0][k], b1v = ob.jc[1][k];
         const double val = oa.jc[0][i] * (m00 * b0v + m01 * b1v) + oa.jc[1][i] * (m10 * b0v + m11 * b1v);
-        unsafeAtomicAdd(S + (size_t)row * n + col, val);
+        if (FIXED)
+          atomicAdd(reinterpret_cast<unsigned long long*>(S) + (size_t)row * n + col,
+                    (unsigned long long)(long long)__double2ll_rn(val * kFixedScale));
+        else
+          unsafeAtomicAdd(S + (size_t)row * n + col, val);
       }
     }
   }
+}
+
+// in place: 64-bit fixed point -> double (lower triangle; the upper one is never read)
+__global__ void fixed_to_double_kernel(double* __restrict__ S, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * n) return;
+  const long long q = reinterpret_cast<const long long*>(S)[i];
+  S[i] = (double)q * (1.0 / kFixedScale);
 }
 
 __global__ void diag_kernel(int n, const double* __restrict__ Dc, double* __restrict__ S) {
@@ -171,6 +193,7 @@ __global__ void diag_kernel(int n, const double* __restrict__ Dc, double* __rest
 }
 
 // J: [3][12][count] tangent columns of the position priors (pose columns, then sensor columns)
+template <bool FIXED>
 __global__ void prior_rows_kernel(double* __restrict__ S, int n, const double* __restrict__ J,
                                   const int* __restrict__ po, const int* __restrict__ so,
                                   const int* __restrict__ pdim, int count) {
@@ -186,7 +209,11 @@ __global__ void prior_rows_kernel(double* __restrict__ S, int n, const double* _
   double v = 0.0;
   for (int r = 0; r < 3; ++r)
     v += J[((size_t)r * 12 + i) * count + kprior] * J[((size_t)r * 12 + k) * count + kprior];
-  unsafeAtomicAdd(S + (size_t)row * n + col, v);
+  if (FIXED)  // (several images of a rig frame put several priors on one pose block: same integer accumulation)
+    atomicAdd(reinterpret_cast<unsigned long long*>(S) + (size_t)row * n + col,
+              (unsigned long long)(long long)__double2ll_rn(v * kFixedScale));
+  else
+    unsafeAtomicAdd(S + (size_t)row * n + col, v);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -476,10 +503,22 @@ void form(const FormArgs& a, double* S, hipStream_t st) {
   BAX_HIP(hipMemsetAsync(S, 0, n * n * sizeof(double), st));
   if (a.n_points <= 0 || a.n_obs <= 0) return;
   const int wmax = kPoseDim + a.kd + (a.Jsens ? 6 : 0);
-  if (wmax <= 10) hipLaunchKernelGGL(form_kernel<10>, dim3(a.n_points), dim3(64), 0, st, a, S);
-  else if (wmax <= 14) hipLaunchKernelGGL(form_kernel<14>, dim3(a.n_points), dim3(64), 0, st, a, S);
-  else if (wmax <= 20) hipLaunchKernelGGL(form_kernel<20>, dim3(a.n_points), dim3(64), 0, st, a, S);
-  else hipLaunchKernelGGL(form_kernel<28>, dim3(a.n_points), dim3(64), 0, st, a, S);
+#define BAX_FORM(W)                                                                                              \
+  do {                                                                                                           \
+    if (a.fixed_point) hipLaunchKernelGGL((form_kernel<W, true>), dim3(a.n_points), dim3(64), 0, st, a, S);      \
+    else hipLaunchKernelGGL((form_kernel<W, false>), dim3(a.n_points), dim3(64), 0, st, a, S);                   \
+  } while (0)
+  if (wmax <= 10) BAX_FORM(10);
+  else if (wmax <= 14) BAX_FORM(14);
+  else if (wmax <= 20) BAX_FORM(20);
+  else BAX_FORM(28);
+#undef BAX_FORM
+}
+
+void finish(double* S, int n_c, bool fixed_point, hipStream_t st) {
+  const size_t n = (size_t)n_c;
+  if (fixed_point)
+    hipLaunchKernelGGL(fixed_to_double_kernel, dim3((unsigned)((n * n + 255) / 256)), dim3(256), 0, st, S, n);
 }
 
 void add_lm_diagonal(double* S, int n, const double* Dc, hipStream_t st) {
@@ -487,10 +526,11 @@ void add_lm_diagonal(double* S, int n, const double* Dc, hipStream_t st) {
 }
 
 void add_prior_rows(double* S, int n, const double* J, const int* po, const int* so, const int* pdim, int count,
-                    hipStream_t st) {
+                    bool fixed_point, hipStream_t st) {
   if (count <= 0) return;
-  hipLaunchKernelGGL(prior_rows_kernel, dim3((unsigned)((count * 144 + 255) / 256)), dim3(256), 0, st, S, n, J, po,
-                     so, pdim, count);
+  const dim3 grid((unsigned)((count * 144 + 255) / 256));
+  if (fixed_point) hipLaunchKernelGGL(prior_rows_kernel<true>, grid, dim3(256), 0, st, S, n, J, po, so, pdim, count);
+  else hipLaunchKernelGGL(prior_rows_kernel<false>, grid, dim3(256), 0, st, S, n, J, po, so, pdim, count);
 }
 
 void factor_solve(double* S, int n, const double* rhs, double* x, const Workspace& ws, hipStream_t st,
