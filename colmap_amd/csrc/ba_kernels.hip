@@ -2514,6 +2514,8 @@ struct Solver {
   int kd = 4, bd = PD;  // intrinsics tangent width / widest camera-side block of this problem
   std::vector<int> h_pose_off, h_cam_off, h_pt_off;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
+  hipStream_t st_chol = nullptr;  // second stream + events of the Cholesky lookahead (exact tiers)
+  hipEvent_t ev_chol_panel = nullptr, ev_chol_u2 = nullptr;
 
   Solver(ba_problem& p_, const ba_options& o_, Comm& c_) : opt(o_), prob(p_), comm(c_) {}
   ~Solver() {
@@ -2521,6 +2523,9 @@ struct Solver {
     if (ev1) (void)hipEventDestroy(ev1);
     if (ev2) (void)hipEventDestroy(ev2);
     if (ev3) (void)hipEventDestroy(ev3);
+    if (ev_chol_panel) (void)hipEventDestroy(ev_chol_panel);
+    if (ev_chol_u2) (void)hipEventDestroy(ev_chol_u2);
+    if (st_chol) (void)hipStreamDestroy(st_chol);
     if (st) (void)hipStreamDestroy(st);
   }
 
@@ -3037,6 +3042,7 @@ struct Solver {
       ba_explicit::add_lm_diagonal(Sdense.p, n, Dc.p, st);
       ba_explicit::Workspace ws;
       ws.Linv = chol_linv.p; ws.tmp = chol_tmp.p; ws.info = chol_info.p;
+      ws.st2 = st_chol; ws.ev_panel = ev_chol_panel; ws.ev_u2 = ev_chol_u2;
       double ms = 0.0;
       ba_explicit::factor_solve(Sdense.p, n, rhs.p, x.p, ws, st, ev0, ev1, &ms);
       factor_ms += ms;
@@ -3176,6 +3182,12 @@ struct Solver {
       if (!dense_by_products) {
         ba_explicit::Workspace ws;
         chol_linv.alloc(ws.linv_doubles(nc)); chol_tmp.alloc(nc); chol_info.alloc(1);
+        const char* e_la = std::getenv("COLMAP_AMD_BA_CHOL_LOOKAHEAD");
+        if (!e_la || std::atoi(e_la) != 0) {
+          BA_HIP(hipStreamCreateWithFlags(&st_chol, hipStreamNonBlocking));
+          BA_HIP(hipEventCreateWithFlags(&ev_chol_panel, hipEventDisableTiming));
+          BA_HIP(hipEventCreateWithFlags(&ev_chol_u2, hipEventDisableTiming));
+        }
       }
       BA_HIP(hipDeviceSynchronize());  // the allocation's memset runs on the NULL stream
     }

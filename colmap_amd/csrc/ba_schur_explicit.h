@@ -46,6 +46,9 @@ struct Workspace {
   double* Linv = nullptr;  // [ceil(n / 64)][64][64] inverses of the diagonal blocks of L
   double* tmp = nullptr;   // [n] second vector of the triangular solves
   int* info = nullptr;     // device flag: != 0 when a pivot was not positive
+  // optional lookahead: a second stream and two events (all three or none)
+  hipStream_t st2 = nullptr;
+  hipEvent_t ev_panel = nullptr, ev_u2 = nullptr;
   size_t linv_doubles(int n) const { return (size_t)((n + 63) / 64) * 64 * 64; }
 };
 

@@ -270,27 +270,50 @@ __global__ void __launch_bounds__(256) chol_diag_kernel(double* __restrict__ S, 
   __syncthreads();
   if (tid < kb) L[tid][tid] = dsq[tid];
   __syncthreads();
-  // inverse of the triangle: thread j solves L x = e_j, x kept in column j of Li
-  if (tid < kb) {
-    const int j = tid;
-    for (int r = j; r < kb; ++r) {
-      double v0 = (r == j) ? 1.0 : 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;  // four chains: the LDS reads pipeline
-      int m = j;
-      for (; m + 3 < r; m += 4) {
-        v0 -= L[r][m] * Li[m][j];
-        v1 -= L[r][m + 1] * Li[m + 1][j];
-        v2 -= L[r][m + 2] * Li[m + 2][j];
-        v3 -= L[r][m + 3] * Li[m + 3][j];
-      }
-      for (; m < r; ++m) v0 -= L[r][m] * Li[m][j];
-      Li[r][j] = ((v0 + v1) + (v2 + v3)) / L[r][r];
+  // Inverse of the triangle by 16 x 16 blocks (rows / columns beyond kb hold zeros except a unit diagonal, so a
+  // short last block needs no special case): the four diagonal blocks by forward substitution (16 lanes each),
+  // then block diagonals at distance d = 1, 2, 3:  Linv_ij = -Linv_ii (sum_{k=j}^{i-1} L_ik Linv_kj), every
+  // 16 x 16 product with one output element per thread. (The rolled per-column substitution this replaces was a
+  // third of the kernel's 86 us.)
+  __shared__ double T[3][16][17];
+  for (int e = tid; e < NB; e += 256)
+    if (e >= kb) L[e][e] = 1.0;
+  __syncthreads();
+  if (tid < 64) {
+    const int bi = tid >> 4, j = tid & 15, o = 16 * bi;
+    for (int r = j; r < 16; ++r) {
+      double v = (r == j) ? 1.0 : 0.0;
+      for (int m = j; m < r; ++m) v -= L[o + r][o + m] * Li[o + m][o + j];
+      Li[o + r][o + j] = v / L[o + r][o + r];
     }
   }
   __syncthreads();
+  {
+    const int er = tid >> 4, ec = tid & 15;  // output element of a 16 x 16 product
+    for (int d = 1; d < 4; ++d) {
+      for (int q = 0; q + d < 4; ++q) {  // block (i, j) = (q + d, q)
+        const int i = q + d, j = q;
+        double acc = 0.0;
+        for (int k = j; k < i; ++k)
+#pragma unroll
+          for (int m = 0; m < 16; ++m) acc += L[16 * i + er][16 * k + m] * Li[16 * k + m][16 * j + ec];
+        T[q][er][ec] = acc;
+      }
+      __syncthreads();
+      for (int q = 0; q + d < 4; ++q) {
+        const int i = q + d, j = q;
+        double acc = 0.0;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) acc += Li[16 * i + er][16 * i + m] * T[q][m][ec];
+        Li[16 * i + er][16 * j + ec] = -acc;
+      }
+      __syncthreads();
+    }
+  }
   for (int e = tid; e < NB * NB; e += 256) {
     const int r = e / NB, c = e % NB;
     if (r < kb && c <= r) S[(size_t)(k0 + r) * n + k0 + c] = L[r][c];
-    Linv[e] = Li[r][c];
+    Linv[e] = (r < kb && c < kb) ? Li[r][c] : 0.0;
   }
 }
 
@@ -337,15 +360,15 @@ __global__ void __launch_bounds__(256) chol_panel_kernel(double* __restrict__ S,
 
 // Trailing update C_IJ -= X_I X_J^T for the 64 x 64 tiles I >= J of the trailing matrix (rows / columns from
 // t0 = k0 + kb). Wave w owns the 32 x 32 quadrant (w >> 1, w & 1): 2 x 2 MFMA tiles; K = kb in halves of 32.
-// (general form: C[r][c] -= sum_{m in [k0, k0 + kb)} S[r][m] S[c][m] for rows r >= t0 and columns c in
-//  [t0, cend), lower triangle; cend < n restricts the update to the rest of an outer panel)
-__global__ void __launch_bounds__(256) chol_update_kernel(double* __restrict__ S, int n, int k0, int kb, int t0,
-                                                          int cend) {
+// (general form: C[r][c] -= sum_{m in [k0, k0 + kb)} S[r][m] S[c][m] for rows r >= row0 and columns c in
+//  [col0, cend), lower triangle; a column window restricts the update to part of the trailing matrix)
+__global__ void __launch_bounds__(256) chol_update_kernel(double* __restrict__ S, int n, int k0, int kb, int row0,
+                                                          int col0, int cend) {
   const int I = blockIdx.y, J = blockIdx.x;
   __shared__ double sI[NB][33];
   __shared__ double sJ[NB][33];
   const int tid = threadIdx.x;
-  const int ri = t0 + NB * I, rj = t0 + NB * J;
+  const int ri = row0 + NB * I, rj = col0 + NB * J;
   if (rj > ri + NB - 1 || rj >= cend) return;
   const int wave = tid >> 6, lane = tid & 63;
   const int li = lane & 15, lk = lane >> 4;
@@ -390,13 +413,13 @@ __global__ void __launch_bounds__(256) chol_update_kernel(double* __restrict__ S
 // MFMA tiles (64 accumulator doubles per lane), K = kb streamed through LDS in chunks of 16. 16 flop per byte
 // loaded instead of 8: used while the trailing matrix has enough 128-tiles to fill the chip.
 __global__ void __launch_bounds__(256, 2) chol_update128_kernel(double* __restrict__ S, int n, int k0, int kb,
-                                                                int t0, int cend) {
+                                                                int row0, int col0, int cend) {
   const int I = blockIdx.y, J = blockIdx.x;
   constexpr int T = 128, KC = 16;
   __shared__ double sI[T][KC + 1];
   __shared__ double sJ[T][KC + 1];
   const int tid = threadIdx.x;
-  const int ri = t0 + T * I, rj = t0 + T * J;
+  const int ri = row0 + T * I, rj = col0 + T * J;
   if (rj > ri + T - 1 || rj >= cend) return;
   const int wave = tid >> 6, lane = tid & 63;
   const int li = lane & 15, lk = lane >> 4;
@@ -547,17 +570,28 @@ void factor_solve(double* S, int n, const double* rhs, double* x, const Workspac
   // 12 TFLOP/s at n = 8 000). So the trailing matrix is updated once per OUTER panel of 256 columns (32 flop
   // per byte); inside an outer panel the 64-wide steps update only the panel's remaining columns.
   constexpr int OB = 256;
-  auto update = [&](int k0, int kb, int t0, int cend) {
-    const int rows = n - t0, cols = std::min(cend, n) - t0;
+  // update(k0, kb, t0, cend): C[r][c] -= sum_m S[r][m] S[c][m], m in [k0, k0 + kb), rows r >= t0, columns
+  // c in [t0, cend). update_cols(.., c0, cend): the same for columns [c0, cend) only (rows r >= c0: the lower
+  // triangle has no entries above the diagonal of the first column).
+  auto launch = [&](int k0, int kb, int row0, int col0, int cend, hipStream_t s_) {
+    const int rows = n - row0, cols = std::min(cend, n) - col0;
     if (rows <= 0 || cols <= 0) return;
     if (rows >= 12 * 128 && cols >= 256) {
-      hipLaunchKernelGGL(chol_update128_kernel, dim3((cols + 127) / 128, (rows + 127) / 128), dim3(256), 0, st, S, n, k0, kb,
-                         t0, std::min(cend, n));
+      hipLaunchKernelGGL(chol_update128_kernel, dim3((cols + 127) / 128, (rows + 127) / 128), dim3(256), 0, s_, S, n, k0, kb,
+                         row0, col0, std::min(cend, n));
     } else {
-      hipLaunchKernelGGL(chol_update_kernel, dim3((cols + NB - 1) / NB, (rows + NB - 1) / NB), dim3(256), 0, st, S, n, k0, kb,
-                         t0, std::min(cend, n));
+      hipLaunchKernelGGL(chol_update_kernel, dim3((cols + NB - 1) / NB, (rows + NB - 1) / NB), dim3(256), 0, s_, S, n, k0, kb,
+                         row0, col0, std::min(cend, n));
     }
   };
+  auto update = [&](int k0, int kb, int t0, int cend, hipStream_t s_) { launch(k0, kb, t0, t0, cend, s_); };
+  auto update_cols = [&](int k0, int kb, int /*t0*/, int c0, int cend, hipStream_t s_) { launch(k0, kb, c0, c0, cend, s_); };
+  // Lookahead over two streams (ws.st2 set): the outer update of panel o is split into U1 = the columns of the
+  // NEXT outer panel (main stream, the next panel's steps need them) and U2 = everything right of that (second
+  // stream), so U2(o) runs while the 64-wide steps of panel o + 1 -- serial, latency-bound kernels -- are under
+  // way. U1(o + 1) writes a region U2(o) also writes: the main stream waits for U2(o) before it.
+  const bool lookahead = ws.st2 != nullptr && ws.ev_panel != nullptr && ws.ev_u2 != nullptr;
+  bool u2_pending = false;
   for (int o0 = 0; o0 < n; o0 += OB) {
     const int oend = std::min(o0 + OB, n);
     for (int k0 = o0; k0 < oend; k0 += NB) {
@@ -567,11 +601,26 @@ void factor_solve(double* S, int n, const double* rhs, double* x, const Workspac
       const int below = n - k0 - kb;
       if (below > 0) {
         hipLaunchKernelGGL(chol_panel_kernel, dim3((below + NB - 1) / NB), dim3(256), 0, st, S, n, k0, kb, Li);
-        update(k0, kb, k0 + kb, oend);  // the rest of this outer panel only
+        update(k0, kb, k0 + kb, oend, st);  // the rest of this outer panel only
       }
     }
-    update(o0, oend - o0, oend, n);  // everything right of the outer panel, K = 256
+    if (oend >= n) break;
+    if (!lookahead) {
+      update(o0, oend - o0, oend, n, st);  // everything right of the outer panel, K = 256
+      continue;
+    }
+    const int next_end = std::min(oend + OB, n);
+    BAX_HIP(hipEventRecord(ws.ev_panel, st));                       // panel o is final
+    if (u2_pending) BAX_HIP(hipStreamWaitEvent(st, ws.ev_u2, 0));   // U2(o - 1) wrote where U1(o) writes
+    update(o0, oend - o0, oend, next_end, st);                      // U1: columns of the next outer panel
+    if (next_end < n) {
+      BAX_HIP(hipStreamWaitEvent(ws.st2, ws.ev_panel, 0));
+      update_cols(o0, oend - o0, oend, next_end, n, ws.st2);        // U2: columns right of the next outer panel
+      BAX_HIP(hipEventRecord(ws.ev_u2, ws.st2));
+      u2_pending = true;
+    }
   }
+  if (u2_pending) BAX_HIP(hipStreamWaitEvent(st, ws.ev_u2, 0));
   if (ev_b) BAX_HIP(hipEventRecord(ev_b, st));
   // L y = rhs: x is the working vector (a step reads its own block of it raw -- in every workgroup -- and
   // updates the rows below), finished blocks go to ws.tmp; then L^T x = y with ws.tmp as the working vector
