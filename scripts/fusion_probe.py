@@ -35,6 +35,9 @@ def run(n, w, h, **kw):
 
 
 if __name__ == "__main__":
-    run(5, 320, 240)
-    run(8, 640, 480)
-    run(8, 1280, 960)
+    if len(sys.argv) > 1:   # fusion_probe.py N W H
+        run(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]))
+    else:
+        run(5, 320, 240)
+        run(8, 640, 480)
+        run(8, 1280, 960)
