@@ -1687,6 +1687,7 @@ __global__ void __launch_bounds__(64) ba_block_gram_kernel(View V, const double*
 // above every lane loads its own operand: 16 different columns per load instruction. Same slab order, same
 // zero padding: the accumulated tile is bit-identical.
 constexpr int GRAM_TRIP = 32;
+template <int BD>  // widest block of the problem: bounds the prefetch registers (6, 8 or 16 column pairs per lane)
 __global__ void __launch_bounds__(64) ba_block_gram_lds_kernel(View V, const double* __restrict__ G) {
   __shared__ double sJ[2][16][GRAM_TRIP + 1];  // [row][column][observation], padded against bank conflicts
   __shared__ double sG[3][GRAM_TRIP];
@@ -1701,17 +1702,39 @@ __global__ void __launch_bounds__(64) ba_block_gram_lds_kernel(View V, const dou
   const size_t N = (size_t)V.n_obs;
   v4f64 acc = {0.0, 0.0, 0.0, 0.0};
   const bool col_ok = i < dim;
-  for (int s = beg; s < end; s += GRAM_TRIP) {
+  // The operands of trip t + 1 are loaded into registers while the matrix core works on trip t (a lane's
+  // share: one 32-observation segment of <= 16 (row, column) pairs -- pairs cr = half, half + 2, ... -- and
+  // up to two entries of G): the global-load latency used to sit between every two trips of a wave. Same
+  // values in the same LDS slots: bit-identical tiles.
+  double pj[BD], pg[2];
+  auto prefetch = [&](int s) {
     const int n = min(GRAM_TRIP, end - s);
-    for (int cr = half; cr < 2 * dim; cr += 2) {
-      const int rr = cr & 1, c = cr >> 1;
-      sJ[rr][c][lo] = lo < n ? blk_col(V, kind, rr, c)[s + lo] : 0.0;
+#pragma unroll
+    for (int q = 0; q < BD; ++q) {
+      const int cr = half + 2 * q;
+      pj[q] = (cr < 2 * dim && lo < n) ? blk_col(V, kind, cr & 1, cr >> 1)[s + lo] : 0.0;
     }
-    for (int e = lane; e < 3 * GRAM_TRIP; e += 64) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int e = lane + 64 * q;
       const int g = e / GRAM_TRIP, o = e - g * GRAM_TRIP;
-      sG[g][o] = o < n ? G[(size_t)g * N + s + o] : 0.0;
+      pg[q] = (e < 3 * GRAM_TRIP && o < n) ? G[(size_t)g * N + s + o] : 0.0;
+    }
+  };
+  if (beg < end) prefetch(beg);
+  for (int s = beg; s < end; s += GRAM_TRIP) {
+#pragma unroll
+    for (int q = 0; q < BD; ++q) {
+      const int cr = half + 2 * q;
+      if (cr < 2 * dim) sJ[cr & 1][cr >> 1][lo] = pj[q];
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int e = lane + 64 * q;
+      if (e < 3 * GRAM_TRIP) sG[e / GRAM_TRIP][e % GRAM_TRIP] = pg[q];
     }
     __syncthreads();
+    if (s + GRAM_TRIP < end) prefetch(s + GRAM_TRIP);
 #pragma unroll 4
     for (int u = 0; u < GRAM_TRIP / 2; ++u) {
       const int o = 2 * u + oo;
@@ -3262,7 +3285,9 @@ struct Solver {
           BA_LAUNCH(ba_obs_schur_g_kernel, dim3(grid_for(V.n_obs, 256)), dim3(256), st, V, Cinv.p, Gobs.p);
           BA_HIP(hipEventRecord(ev2, st));
           static const bool gram_lds = [] { const char* e = std::getenv("COLMAP_AMD_BA_GRAM_LDS"); return !e || std::atoi(e) != 0; }();
-          if (gram_lds) BA_LAUNCH(ba_block_gram_lds_kernel, dim3(V.n_chunks), dim3(64), st, V, Gobs.p);
+          if (gram_lds && bd == PD) BA_LAUNCH(ba_block_gram_lds_kernel<PD>, dim3(V.n_chunks), dim3(64), st, V, Gobs.p);
+          else if (gram_lds && bd == KD_MAX) BA_LAUNCH(ba_block_gram_lds_kernel<KD_MAX>, dim3(V.n_chunks), dim3(64), st, V, Gobs.p);
+          else if (gram_lds) BA_LAUNCH(ba_block_gram_lds_kernel<KD_WIDE>, dim3(V.n_chunks), dim3(64), st, V, Gobs.p);
           else BA_LAUNCH(ba_block_gram_kernel, dim3(V.n_chunks), dim3(64), st, V, Gobs.p);
           BA_HIP(hipEventRecord(ev3, st));
           mfma_pending = true;
