@@ -1617,8 +1617,14 @@ __host__ __device__ inline int wave_max_tasks(int C, int S, int M) {
   return C * (4 * ms > S ? 4 * ms : S);
 }
 
+// `lean` (pm_sweep_wave4l_kernel): no LDS copies of the packed-image base pointers and of the pixel records'
+// cost / backward message / previous selection probability (read from global memory where they are needed:
+// all of them were touched earlier in the same row step and sit in L1 / L2), 36 task slots per batch instead
+// of 40 -- three columns per wave then take 10 192 B = 8 allocation granules at S = 20.
+constexpr int kWaveThCapLean = 36;  // (nine full rounds of four tasks)
 __host__ __device__ inline LdsOffsets lds_offsets_wave(int C, int S, int radius, int ntaps, int M,
-                                                       bool geom, bool pipe, bool pose_global = false) {
+                                                       bool geom, bool pipe, bool pose_global = false,
+                                                       bool lean = false) {
   LdsOffsets o;
   uint32_t off = 0;
   auto take = [&](uint32_t bytes) {
@@ -1631,15 +1637,15 @@ __host__ __device__ inline LdsOffsets lds_offsets_wave(int C, int S, int radius,
   const int max_tasks = wave_max_tasks(C, S, M);
   o.ring = take(pipe ? (uint32_t)kGatherRingBytes : 0u);  // must be at LDS offset 0 (gather_issue)
   o.poses = take(pose_global ? 0u : 4u * S * lds_pose_stride(geom));
-  o.fpb = take(8u * S);
+  o.fpb = take(lean ? 0u : 8u * S);
   o.tile = take(4u * win * tw);
   o.wgt = take(4u * C * tap_stride(ntaps));
   o.refc = take(4u * C * tap_stride(ntaps));
   o.fm = take(4u * C * S);
   o.q = take(4u * C * S);
-  o.costv = take(4u * C * S);
-  o.betav = take(4u * C * S);
-  o.prevv = take(4u * C * S);
+  o.costv = take(lean ? 0u : 4u * C * S);
+  o.betav = take(lean ? 0u : 4u * C * S);
+  o.prevv = take(lean ? 0u : 4u * C * S);
   o.ncc = take(4u * C * 4 * S);               // hypotheses 1..4 (0 is the cached cost map)
   o.geo = take(geom ? 4u * C * 5 * S : 0u);
   o.hyp = take(4u * C * 20);
@@ -1652,10 +1658,11 @@ __host__ __device__ inline LdsOffsets lds_offsets_wave(int C, int S, int radius,
   o.csum = take(4u * C * 5);
   o.tasks = take(2u * max_tasks + (geom ? 2u * C * S : 0u));  // 16-bit task words: NCC tasks, then
                                                               // (GEOM) the geometric-cost-only list
-  o.th = take(36u * kWaveThCap);
+  const uint32_t cap = lean ? (uint32_t)kWaveThCapLean : (uint32_t)kWaveThCap;
+  o.th = take(36u * cap);
   o.ntasks = take(16u);
   o.tapg = take(4u * 256);
-  o.tin = take(2u * (uint32_t)kWaveThCap);  // [0, cap): inside flags; [cap, 2 cap): task order of the batch (inside first)
+  o.tin = take(2u * cap);  // [0, cap): inside flags; [cap, 2 cap): task order of the batch (inside first)
   o.total = off;
   return o;
 }
@@ -1697,10 +1704,13 @@ template <> struct PoseSrc<true> {
 };
 
 // Run the queued NCC tasks (and, with GEOM, the geometric-cost-only list) of one phase.
-template <bool GEOM, bool PIPE, bool PG>
+template <bool GEOM, bool PIPE, bool PG, bool LEAN = false>
 __device__ __forceinline__ void run_tasks_wave(const PmParams& p, const Lds& L, int row, int col0, int tid,
                                                unsigned& evals) {
+  constexpr int CAP = LEAN ? kWaveThCapLean : kWaveThCap;  // task slots per batch (LDS layout: lds_offsets_wave)
   const lds_f32* G = L.tapg;
+  // base pointer of source image s' packed footprints: LDS copy, or (LEAN) the table in global memory
+#define PM_FP_BASE(sv) (LEAN ? (gbl_u32*)p.src_fp_tab[sv] : (gbl_u32*)L.fpb[sv])
   const int n = L.ntasks[0];
   evals += (unsigned)n;
   const LDS_AS uint16_t* tasks = (const LDS_AS uint16_t*)L.tasks;
@@ -1717,8 +1727,8 @@ __device__ __forceinline__ void run_tasks_wave(const PmParams& p, const Lds& L, 
       L.geo[(c * 5 + i) * S + s] = geom_cost(p, PoseSrc<PG>::get(p, L, s), s, (float)row, (float)(col0 + c), h[0]);
     }
   }
-  for (int base = 0; base < n; base += kWaveThCap) {
-    const int nb = min(kWaveThCap, n - base);
+  for (int base = 0; base < n; base += CAP) {
+    const int nb = min(CAP, n - base);
     // pass A, lane per task: homography of the (hypothesis, view) pair (+ geometric cost)
     bool inside = false;
     if (tid < nb) {
@@ -1747,7 +1757,7 @@ __device__ __forceinline__ void run_tasks_wave(const PmParams& p, const Lds& L, 
       const unsigned long long m0 = valid & ~m1;
       const unsigned long long below = (1ull << tid) - 1ull;
       if (tid < nb)
-        L.tin[kWaveThCap + (inside ? __popcll(m1 & below) : __popcll(m1) + __popcll(m0 & below))] = (uint8_t)tid;
+        L.tin[CAP + (inside ? __popcll(m1 & below) : __popcll(m1) + __popcll(m0 & below))] = (uint8_t)tid;
     }
     __syncthreads();
     // pass B, 16-lane group per task, software-pipelined: the gathers of a group's NEXT task are
@@ -1768,7 +1778,7 @@ __device__ __forceinline__ void run_tasks_wave(const PmParams& p, const Lds& L, 
       auto prep = [&](int r, int& t, int& c, bool& own, bool& fast) -> uint32_t {
         const int tr = g + 4 * r;
         own = tr < nb;
-        t = L.tin[kWaveThCap + (own ? tr : nb - 1)];
+        t = L.tin[CAP + (own ? tr : nb - 1)];
         const uint32_t task = tasks[base + t];
         c = task >> 13;
         // wave-uniform: the unclamped addressing only when all four patches of the round are inside
@@ -1781,8 +1791,8 @@ __device__ __forceinline__ void run_tasks_wave(const PmParams& p, const Lds& L, 
   do {                                                                                     \
     bool fast_;                                                                            \
     const uint32_t sv_ = prep(r, t, c, own, fast_);                                        \
-    if (fast_) ncc_front<STAGE, true>(p, L.th + (t) * 9, (gbl_u32*)L.fpb[sv_] + fp_origin, G, j, st); \
-    else ncc_front<STAGE, false>(p, L.th + (t) * 9, (gbl_u32*)L.fpb[sv_], G, j, st);       \
+    if (fast_) ncc_front<STAGE, true>(p, L.th + (t) * 9, PM_FP_BASE(sv_) + fp_origin, G, j, st); \
+    else ncc_front<STAGE, false>(p, L.th + (t) * 9, PM_FP_BASE(sv_), G, j, st);       \
   } while (0)
 #define PM_BACK(STAGE, NEWER, st, t, c, own)                                               \
   do {                                                                                     \
@@ -1806,8 +1816,8 @@ __device__ __forceinline__ void run_tasks_wave(const PmParams& p, const Lds& L, 
           bool fast_;
           const uint32_t sv_ = prep(r, ta, ca, wa, fast_);
           uint32_t tex_[8];
-          if (fast_) ncc_front<-1, true>(p, L.th + ta * 9, (gbl_u32*)L.fpb[sv_] + fp_origin, G, j, A, tex_);
-          else ncc_front<-1, false>(p, L.th + ta * 9, (gbl_u32*)L.fpb[sv_], G, j, A, tex_);
+          if (fast_) ncc_front<-1, true>(p, L.th + ta * 9, PM_FP_BASE(sv_) + fp_origin, G, j, A, tex_);
+          else ncc_front<-1, false>(p, L.th + ta * 9, PM_FP_BASE(sv_), G, j, A, tex_);
           __builtin_amdgcn_sched_barrier(0);
           TapRegs R_;
           tap_regs_load(R_, L.wgt + ca * 128, L.refc + ca * 128, j);
@@ -1854,8 +1864,9 @@ __device__ __forceinline__ void run_tasks_wave(const PmParams& p, const Lds& L, 
     __syncthreads();
   }
 }
+#undef PM_FP_BASE
 
-template <bool GEOM, bool FILTER_PHOTO, bool FILTER_GEOM, bool PIPE, bool PG = false>
+template <bool GEOM, bool FILTER_PHOTO, bool FILTER_GEOM, bool PIPE, bool PG = false, bool LEAN = false>
 __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp) {
   const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y;
   unsigned group = lin / gridDim.y;
@@ -1877,7 +1888,7 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
   const PmParams& p = pp[prob];
   extern __shared__ __attribute__((aligned(16))) char smem[];
   Lds L;
-  lds_bind(L, (lds_char*)smem, lds_offsets_wave(p.C, p.S, p.radius, p.ntaps, p.num_samples, GEOM, PIPE, PG));
+  lds_bind(L, (lds_char*)smem, lds_offsets_wave(p.C, p.S, p.radius, p.ntaps, p.num_samples, GEOM, PIPE, PG, LEAN));
   const int tid_entry = threadIdx.x;
   const int tid = tid_entry;
   constexpr int nt = 64;
@@ -1891,6 +1902,12 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
 
   if (PG) {  // no LDS copy of the pose records; the packed-image base pointers still go to LDS
     for (int i = tid; i < p.S; i += nt) L.fpb[i] = (uint64_t)p.src_fp_tab[i];
+  } else if (LEAN) {  // pose records in LDS, no copy of the base pointers
+    L.pstride = lds_pose_stride(GEOM);
+    for (int i = tid; i < p.S * L.pstride; i += nt) {
+      const int s = i / L.pstride;
+      L.poses[i] = p.poses[s * kPoseStride + (i - s * L.pstride)];
+    }
   } else {
     lds_load_poses(p, L, GEOM, tid, nt);
   }
@@ -1984,9 +2001,11 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
       const float cost = rec[4 + s];
       const float beta = rec[p.sel_out_off + s];
       const float prev = rec[p.sel_in_off + s];
-      L.costv[item] = cost;
-      L.betav[item] = beta;
-      L.prevv[item] = prev;
+      if (!LEAN) {
+        L.costv[item] = cost;
+        L.betav[item] = beta;
+        L.prevv[item] = prev;
+      }
       const float alpha = hmm_message<true>(p, cost, L.fm[item]);
       const float sp = sel_prob_fn(alpha, beta, prev, p.prev_sel_prob_weight);
       float cos_tri, cos_inc;
@@ -2049,7 +2068,7 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
     __syncthreads();
 
     // ---- P4: NCC of hypotheses 1..4 against the drawn views (:1157-1172) -----
-    if (!(p.ablate & 1)) run_tasks_wave<GEOM, PIPE, PG>(p, L, row, col0, tid, evals);
+    if (!(p.ablate & 1)) run_tasks_wave<GEOM, PIPE, PG, LEAN>(p, L, row, col0, tid, evals);
     if (tid == 0) { L.ntasks[0] = 0; L.ntasks[1] = 0; }
     __syncthreads();
 
@@ -2061,7 +2080,8 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
       for (int m = 0; m < M; ++m) {
         const int src = L.sv[c * M + m];
         if (src < 0) continue;
-        acc += (i == 0) ? L.costv[c * S + src] : L.ncc[(c * 4 + i - 1) * S + src];
+        if (i == 0) acc += LEAN ? p.rec[(size_t)pix_index(p, row, col0 + c) * p.rec_stride + 4 + src] : L.costv[c * S + src];
+        else acc += L.ncc[(c * 4 + i - 1) * S + src];
         if (GEOM) acc += p.geom_reg * L.geo[(c * 5 + i) * S + src];
       }
       L.csum[item] = acc;
@@ -2104,7 +2124,7 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
     __syncthreads();
 
     // ---- P6: NCC of the winner against the remaining views (:1188-1197) ------
-    if (!(p.ablate & 1)) run_tasks_wave<false, PIPE, PG>(p, L, row, col0, tid, evals);
+    if (!(p.ablate & 1)) run_tasks_wave<false, PIPE, PG, LEAN>(p, L, row, col0, tid, evals);
 
     // ---- P7: cost map, forward message, selection probability (:1186-1207) ---
     for (int item = tid; item < ncols * S; item += nt) {
@@ -2115,13 +2135,15 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
       float* rec = p.rec + (size_t)pix_index(p, row, col) * p.rec_stride;
       float cost;
       if (k == 0) {
-        cost = L.costv[item];
+        cost = LEAN ? rec[4 + s] : L.costv[item];
       } else {
         cost = L.ncc[(c * 4 + k - 1) * S + s];
         rec[4 + s] = cost;
       }
       const float alpha = hmm_message<true>(p, cost, L.fm[item]);
-      const float prob = sel_prob_fn(alpha, L.betav[item], L.prevv[item], p.prev_sel_prob_weight);
+      const float beta_ = LEAN ? rec[p.sel_out_off + s] : L.betav[item];  // the backward message, until the store below
+      const float prev_ = LEAN ? rec[p.sel_in_off + s] : L.prevv[item];
+      const float prob = sel_prob_fn(alpha, beta_, prev_, p.prev_sel_prob_weight);
       L.fm[item] = alpha;
       rec[p.sel_out_off + s] = prob;
       if (FILTER_PHOTO || FILTER_GEOM) {
@@ -2183,6 +2205,11 @@ __global__ void __launch_bounds__(64, 4) pm_sweep_wave4_kernel(const PmParams* _
 template <bool GEOM, bool FILTER_PHOTO, bool FILTER_GEOM>
 __global__ void __launch_bounds__(64, 4) pm_sweep_wave4g_kernel(const PmParams* __restrict__ pp) {
   sweep_wave_body<GEOM, FILTER_PHOTO, FILTER_GEOM, false, true>(pp);
+}
+// lean-LDS build (lds_offsets_wave `lean`): three columns per wave in 10 240 B without the pose-global loads
+template <bool GEOM, bool FILTER_PHOTO, bool FILTER_GEOM>
+__global__ void __launch_bounds__(64, 4) pm_sweep_wave4l_kernel(const PmParams* __restrict__ pp) {
+  sweep_wave_body<GEOM, FILTER_PHOTO, FILTER_GEOM, false, false, true>(pp);
 }
 // ... and at five waves per SIMD (96 VGPRs, 13 dwords of scratch; two columns without the pose copy take 7.5 KB
 // of LDS = 21 workgroups per CU). Experiment: COLMAP_AMD_PM_WAVES=5.
@@ -2304,14 +2331,17 @@ void pm_launch_sweep(const PmParams& p, const PmParams* dev_params, int batch, i
     static const int pg_env = [] { const char* e = getenv("COLMAP_AMD_PM_POSE_GLOBAL"); return e ? atoi(e) : -1; }();
     static const int waves_env = [] { const char* e = getenv("COLMAP_AMD_PM_WAVES"); return e ? atoi(e) : 4; }();
     const bool w5 = !pipe && waves_env == 5;
-    const bool pg = !pipe && (w5 || (pg_env >= 0 ? pg_env != 0 : p.C >= 3));
-    const size_t wlds = lds_offsets_wave(p.C, p.S, p.radius, p.ntaps, p.num_samples, geom, pipe, pg).total + lds_pad;
+    static const int lean_env = [] { const char* e = getenv("COLMAP_AMD_PM_LEAN"); return e ? atoi(e) : -1; }();
+    const bool lean = !pipe && !w5 && (lean_env >= 0 ? lean_env != 0 : (p.C >= 3 && pg_env < 0));
+    const bool pg = !pipe && !lean && (w5 || (pg_env >= 0 ? pg_env != 0 : p.C >= 3));
+    const size_t wlds = lds_offsets_wave(p.C, p.S, p.radius, p.ntaps, p.num_samples, geom, pipe, pg, lean).total + lds_pad;
     dim3 wblock(64, 1, 1);
     dim3 wgrid = grid;
     if (p.xcd_map == 2) wgrid.x = ((grid.x + 63) / 64) * 64;
 #define PM_LAUNCH_W(G, FP, FG)                                                                              \
   do {                                                                                                      \
     if (pipe) hipLaunchKernelGGL((pm_sweep_wave_kernel<G, FP, FG>), wgrid, wblock, wlds, st, dev_params);   \
+    else if (lean) hipLaunchKernelGGL((pm_sweep_wave4l_kernel<G, FP, FG>), wgrid, wblock, wlds, st, dev_params); \
     else if (w5) hipLaunchKernelGGL((pm_sweep_wave5g_kernel<G, FP, FG>), wgrid, wblock, wlds, st, dev_params); \
     else if (pg) hipLaunchKernelGGL((pm_sweep_wave4g_kernel<G, FP, FG>), wgrid, wblock, wlds, st, dev_params); \
     else hipLaunchKernelGGL((pm_sweep_wave4_kernel<G, FP, FG>), wgrid, wblock, wlds, st, dev_params);       \
