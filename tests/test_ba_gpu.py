@@ -375,19 +375,32 @@ def _with_priors(fp):
     return fp
 
 
-def _sharded_worker(rank, world, port, backend, q, sharding=0, priors=False):
+def _sharded_problem(priors=False, shared=False):
+    if shared:  # three cameras shared by twelve images: observation pairs of a point inside one intrinsics block,
+        # on DIFFERENT ranks under image sharding (the cross terms a rank cannot see drop out of its preconditioner)
+        d = scene.synthesize_flat(12, 300, 5, seed=21, noise=scene.SyntheticNoiseOptions(0.01, 1.0, 0.05, 1.0))
+        d["obs_cam"] = (d["obs_cam"] % 3).astype(np.int32)
+        d["cams"] = d["cams"][:3].copy()
+        d["cam_model"] = d["cam_model"][:3].copy()
+        fp = est.FlatProblem.from_arrays(d)
+    else:
+        fp = _flat(12, 300, 5, seed=21, mixed=True)
+    assert est.fix_gauge_two_cams(fp)
+    if priors:
+        _with_priors(fp)
+    return fp
+
+
+def _sharded_worker(rank, world, port, backend, q, sharding=0, priors=False, shared=False, solver=0):
     import os
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        fp = _flat(12, 300, 5, seed=21, mixed=True)
-        assert est.fix_gauge_two_cams(fp)
-        if priors:
-            _with_priors(fp)
+        fp = _sharded_problem(priors, shared)
         comm = est.Communicator(backend, gpu_index=0, sharding=sharding)
-        s = est.solve_flat(fp, est.SolverOptions(**TIGHT), gpu_index=0, comm=comm)
+        s = est.solve_flat(fp, est.SolverOptions(linear_solver_type=solver, **TIGHT), gpu_index=0, comm=comm)
         q.put((rank, s.final_cost, s.num_residuals, s.num_iterations, fp.poses.copy(), fp.points.copy(), comm.calls))
         comm.close()
         dist.barrier()
@@ -426,6 +439,55 @@ def test_two_rank_sharded_solve_matches_single_gpu(sharding, priors):
     assert abs(c0 - s1.final_cost) <= 1e-9 * s1.final_cost
     np.testing.assert_allclose(pts0, single.points, atol=1e-7)
     np.testing.assert_allclose(poses0, single.poses, atol=1e-7)
+
+
+def _run_sharded(world, sharding, priors=False, shared=False, solver=0):
+    import socket
+    import torch.multiprocessing as mp
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, "callback", q, sharding, priors, shared, solver))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return res
+
+
+@pytest.mark.parametrize("sharding", [est.SHARD_BY_IMAGE, est.SHARD_BY_POINT])
+def test_three_rank_sharded_solve_with_shared_intrinsics(sharding):
+    """World size 3 and intrinsics blocks shared across ranks (12 images, 3 cameras): under image sharding the
+    observation pairs of a point that sit on different ranks drop out of the Schur-Jacobi preconditioner
+     -- a different, still symmetric positive definite preconditioner, so the CG trajectory differs
+    but the converged solution is the single-rank one; all ranks hold identical bits."""
+    single = _sharded_problem(shared=True)
+    s1 = est.solve_flat(single, est.SolverOptions(**TIGHT), gpu_index=0)
+    res = _run_sharded(3, sharding, shared=True)
+    for r in res[1:]:
+        assert r[1] == res[0][1] and np.array_equal(r[4], res[0][4]) and np.array_equal(r[5], res[0][5])
+    assert res[0][2] == s1.num_residuals
+    assert abs(res[0][1] - s1.final_cost) <= 1e-8 * s1.final_cost
+    np.testing.assert_allclose(res[0][5], single.points, atol=1e-6)
+    np.testing.assert_allclose(res[0][4], single.poses, atol=1e-6)
+
+
+@pytest.mark.parametrize("sharding", [est.SHARD_BY_IMAGE, est.SHARD_BY_POINT])
+def test_two_rank_sharded_exact_tier(sharding):
+    """DENSE_SCHUR in a sharded solve: point sharding sums the ranks' explicitly formed partial systems (every
+    observation pair of a point is on one rank), image sharding falls back to the operator-product formation
+    (every product is all-reduced; camera-side dimension <= 1024). Both reproduce the single-rank exact solve."""
+    single = _sharded_problem()
+    s1 = est.solve_flat(single, est.SolverOptions(linear_solver_type=est.SOLVER_DENSE_SCHUR, **TIGHT), gpu_index=0)
+    assert s1.linear_solver_used == est.SOLVER_DENSE_SCHUR
+    res = _run_sharded(2, sharding, solver=est.SOLVER_DENSE_SCHUR)
+    assert res[0][1] == res[1][1] and np.array_equal(res[0][4], res[1][4]) and np.array_equal(res[0][5], res[1][5])
+    assert abs(res[0][1] - s1.final_cost) <= 1e-9 * s1.final_cost
+    np.testing.assert_allclose(res[0][5], single.points, atol=1e-7)
+    np.testing.assert_allclose(res[0][4], single.poses, atol=1e-7)
 
 
 def test_rccl_transport_world_size_one():
