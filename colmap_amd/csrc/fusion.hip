@@ -755,14 +755,16 @@ void Run(const fusion_options& opt, int n, const fusion_image* images, const int
     p.active = lists[0];
     p.num_active = 0;
     int offered = 0;
-    // First chunk = ns / 64, then doubling. Measured on 8 x 1280 x 960 (profiles/r03_fusion_schedule.log): first
-    // chunk ns / 1024 -> 16.5 rounds per image, 9.8 Mpix/s; ns / 256 -> 14.5, 10.5; ns / 64 -> 12.75, 10.9; growing
-    // by 4 instead of 2 saves rounds but doubles the walks that lose their claims (6.6 Mpix/s). The result does not
-    // depend on the schedule (bit-exact against the sequential algorithm for any of them). Knobs for experiments:
-    // COLMAP_AMD_FUSION_HEAD_DIV, COLMAP_AMD_FUSION_GROWTH.
+    // First chunk = min(ns / 64, kLanes), then doubling. Measured (profiles/r03_fusion_schedule.log): on 8 x 1280 x 960
+    // first chunk ns / 1024 -> 16.5 rounds per image, 9.8 Mpix/s; ns / 256 -> 14.5, 10.5; ns / 64 -> 12.75, 10.9; on
+    // 8 x 2560 x 1920 ns / 64 exceeds the resident lanes, the first rounds lose the walk reuse between speculate and
+    // commit, and on PatchMatch's own (noisier) maps that costs more than the saved rounds (bench leg 10.6 against
+    // 14.8 Mpix/s) -- hence the cap. Growing by 4 instead of 2 saves rounds but doubles the walks that lose their
+    // claims (6.6 Mpix/s). The result does not depend on the schedule (bit-exact against the sequential algorithm
+    // for any of them). Knobs for experiments: COLMAP_AMD_FUSION_HEAD_DIV, COLMAP_AMD_FUSION_GROWTH.
     static const int head_div = [] { const char* e = getenv("COLMAP_AMD_FUSION_HEAD_DIV"); return e && atoi(e) > 0 ? atoi(e) : 64; }();
     static const int growth = [] { const char* e = getenv("COLMAP_AMD_FUSION_GROWTH"); return e && atoi(e) > 1 ? atoi(e) : 2; }();
-    const int head = std::max(256, ns / head_div);
+    const int head = std::min(kLanes, std::max(256, ns / head_div));
     for (int it = 0; p.num_active > 0 || offered < ns; ++it, ++round) {
       FU_CHECK(round != 0xFFFFFFFFu, "round counter");
       p.round = round;

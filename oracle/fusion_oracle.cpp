@@ -424,7 +424,7 @@ struct Fuser {
         std::vector<fusion_result> per_seed(n_px);
         std::vector<int> active;
         int offered = 0;
-        const int head = std::max(256, n_px / 64);  // the schedule of fusion.hip (its default first chunk)
+        const int head = std::min(1 << 15, std::max(256, n_px / 64));  // the schedule of fusion.hip (its default first chunk)
         for (; !active.empty() || offered < n_px; ++round) {
           auto key_of = [&](int seed) {
             return ((unsigned long long)round << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)rank_of[seed]);
