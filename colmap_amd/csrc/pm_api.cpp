@@ -439,7 +439,7 @@ void Create(const pm_options& opt_in, const pm_problem& prob, pm_image_cache* ca
   const size_t slot = (size_t)h->src_w * h->src_h;
   {
     DevBuf<uint8_t> staging;
-    const size_t fp_count = (size_t)(h->src_w + 3) * (h->src_h + 3);
+    const size_t fp_count = pm_fp_entries(h->src_w, h->src_h);
     std::vector<const uint32_t*> tab(S);
     h->src_fp.resize(S);
     for (int s = 0; s < S; ++s) {
@@ -523,8 +523,8 @@ void Create(const pm_options& opt_in, const pm_problem& prob, pm_image_cache* ca
   PmParams& b = h->base;
   std::memset(&b, 0, sizeof(b));
   b.W = W; b.H = H; b.S = S; b.src_w = h->src_w; b.src_h = h->src_h;
-  b.fp_xmax = (float)(h->src_w + 2); b.fp_ymax = (float)(h->src_h + 2);
-  b.fp_pitch = (float)(h->src_w + 3);
+  b.fp_xmax = (float)(h->src_w + kFpRingX); b.fp_ymax = (float)(h->src_h + kFpRingY);
+  b.fp_tpr1 = pm_fp_width(h->src_w) / 8 - 1;
   b.radius = opt.window_radius;
   b.step = opt.window_step;
   b.ntap1d = (2 * b.radius) / b.step + 1;

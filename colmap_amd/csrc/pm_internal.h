@@ -10,6 +10,17 @@ namespace colmap_amd {
 constexpr int kPoseStride = 43;  // K4 R9 T3 C3 P12 invP12 (reference patch_match_cuda.cu:1762)
 constexpr int kRngWords = 6;     // XORWOW: x[5] + d
 
+// Packed source images ("footprints": one dword per texel position = its 2 x 2 bilinear neighbourhood) are
+// stored in tiles of 8 x 4 entries = one 128-byte cache line, tiles row-major. A warped 11 x 11 window (13 x 13
+// entries at scale 1) then touches ~10 lines instead of the ~18 of a row-major image -- the sweep kernel's time
+// is dominated by the L2 misses of these gathers (profiles/r03_pm_gather_diag.log). Entry (ex, ey) holds texel
+// position (ex - kFpRingX, ey - kFpRingY); positions -2 and w (h) are the all-zero border ring a clamped tap
+// reads, the ring offsets are tile multiples so that texel (0, 0) starts a tile.
+constexpr int kFpRingX = 8, kFpRingY = 4;
+inline int pm_fp_width(int w) { return (w + kFpRingX + 1 + 7) & ~7; }    // entries per row (multiple of 8)
+inline int pm_fp_height(int h) { return (h + kFpRingY + 1 + 3) & ~3; }   // rows (multiple of 4)
+inline size_t pm_fp_entries(int w, int h) { return (size_t)pm_fp_width(w) * pm_fp_height(h); }
+
 // Per-sweep kernel parameters (reference SweepOptions, patch_match_cuda.cu:914-931,
 // plus the geometry of the virtual rotation).
 struct PmParams {
@@ -18,8 +29,8 @@ struct PmParams {
   int rot;          // number of 90-degree CCW rotations of the sweep frame (0..3)
   int S;            // number of source images
   int src_w, src_h; // source slot size (max over sources)
-  float fp_xmax, fp_ymax;  // src_w + 2, src_h + 2: last column / row of the packed image
-  float fp_pitch;          // src_w + 3 as float
+  float fp_xmax, fp_ymax;  // src_w + kFpRingX, src_h + kFpRingY: last used column / row of the packed image
+  int fp_tpr1;             // tiles per row of the packed image, minus one (fp_tiled)
   int radius, step, ntap1d, ntaps;
   int num_samples;
   int rec_stride;   // floats per pixel record: 4 + 3*S
@@ -43,7 +54,7 @@ struct PmParams {
   int filter_min_num_consistent;
   // device pointers
   float* rec;               // [H*W][rec_stride]
-  const uint32_t* const* src_fp_tab;  // [S] pointers to [src_h+3][src_w+3] packed 2x2 footprints
+  const uint32_t* const* src_fp_tab;  // [S] pointers to packed 2x2 footprints, pm_fp_entries(src_w, src_h) each
                                       // (separate allocations: shareable between problems)
   const float* src_depth;   // [S][src_h][src_w] or null
   const uint8_t* ref_img;   // [H][W]

@@ -243,19 +243,30 @@ __device__ __forceinline__ v2f pk_bcast(float a) { return (v2f)(a); }
 // non-finite taps read an all-zero footprint entry (SampleLayeredBilinear,
 // patch_match_cuda.cu:426-442; the +0.5 / -0.5 texel centre round trip of the reference cancels
 // and is not evaluated in device order).
+// Entry index of packed-image position (ix, iy) (pm_internal.h: 8 x 4-entry tiles, tiles row-major):
+//   ((iy >> 2) * tiles_per_row + (ix >> 3)) * 32 + (iy & 3) * 8 + (ix & 7)
+//     = ix + 3 (ix & ~7) + 8 (iy + (iy & ~3) (tiles_per_row - 1))          -- two 24-bit multiply-adds and a shift-add
+// PM_FP_TILED=0 builds the row-major layout of the same padded image (A/B measurements).
+#ifndef PM_FP_TILED
+#define PM_FP_TILED 1
+#endif
+__device__ __forceinline__ unsigned fp_tiled(unsigned ix, unsigned iy, unsigned tpr1) {
+#if PM_FP_TILED
+  const unsigned a = __umul24(ix & ~7u, 3u) + ix;
+  const unsigned v = __umul24(iy & ~3u, tpr1) + iy;
+  return (v << 3) + a;
+#else
+  return __umul24(iy, 8u * (tpr1 + 1u)) + ix;
+#endif
+}
+
 template <bool FOFF>
-__device__ __forceinline__ uint32_t tap_gather(const PmParams& p, gbl_u32* fp, unsigned fpw, float fx2,
-                                               float fy2) {
-  // fx2 = floor(x) + 2, fy2 = floor(y) + 2 (the ring offset is added in the float domain, packed)
-  const float cx = __builtin_amdgcn_fmed3f(fx2, 0.0f, p.fp_xmax);
-  const float cy = __builtin_amdgcn_fmed3f(fy2, 0.0f, p.fp_ymax);
-  if (FOFF) {
-    // packed images below 2^24 entries: the entry index row * pitch + col is exact in fp32, one
-    // fma + one conversion instead of two conversions + an integer multiply-add
-    return fp[(unsigned)(int)fmaf(cy, p.fp_pitch, cx)];
-  }
-  // 24-bit multiply-add (full rate; v_mul_lo_u32 is quarter rate): rows and pitch < 2^24
-  return fp[__umul24((unsigned)(int)cy, fpw) + (unsigned)(int)cx];
+__device__ __forceinline__ uint32_t tap_gather(const PmParams& p, gbl_u32* fp, float fxr, float fyr) {
+  // fxr = floor(x) + kFpRingX, fyr = floor(y) + kFpRingY (the ring offset is added in the float domain, packed);
+  // positions left of -2 / beyond w clamp to the all-zero ring entries
+  const float cx = __builtin_amdgcn_fmed3f(fxr, (float)(kFpRingX - 2), p.fp_xmax);
+  const float cy = __builtin_amdgcn_fmed3f(fyr, (float)(kFpRingY - 2), p.fp_ymax);
+  return fp[fp_tiled((unsigned)(int)cx, (unsigned)(int)cy, (unsigned)p.fp_tpr1)];
 }
 
 // Byte k of a packed footprint entry as float. Inline asm keeps the four conversions as four
@@ -336,7 +347,6 @@ __device__ __forceinline__ void ncc_group(const PmParams& p, const lds_f32* H, g
               h7 = H[7], h8 = H[8];
   const int n1d = N1D > 0 ? N1D : p.ntap1d;
   const int ntaps = n1d * n1d;
-  const unsigned fpw = (unsigned)(p.src_w + 3);
   const lds_f32* wj = wgt + j;
   const lds_f32* rj = refc + j;
   v2f a_sum = pk_bcast(0.0f), a_sq = pk_bcast(0.0f), a_ref = pk_bcast(0.0f);
@@ -392,10 +402,10 @@ __device__ __forceinline__ void ncc_group(const PmParams& p, const lds_f32* H, g
       fy[1] = floorf(py[1]);
       wx[q] = px - fx;
       wy[q] = py - fy;
-      const v2f fx2 = fx + pk_bcast(2.0f);
-      const v2f fy2 = fy + pk_bcast(2.0f);
-      tex[2 * q] = tap_gather<(N1D > 0)>(p, fp, fpw, fx2[0], fy2[0]);
-      tex[2 * q + 1] = tap_gather<(N1D > 0)>(p, fp, fpw, fx2[1], fy2[1]);
+      const v2f fx2 = fx + pk_bcast((float)kFpRingX);
+      const v2f fy2 = fy + pk_bcast((float)kFpRingY);
+      tex[2 * q] = tap_gather<(N1D > 0)>(p, fp, fx2[0], fy2[0]);
+      tex[2 * q + 1] = tap_gather<(N1D > 0)>(p, fp, fx2[1], fy2[1]);
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -640,23 +650,22 @@ __device__ __forceinline__ void perturb_normal(const float* iK, int row, int col
 // Setup kernels
 // ---------------------------------------------------------------------------
 
-// 2x2 footprint packing with a zero ring: entry (ey, ex) covers texels
-// (x, y) = (ex-2, ey-2) .. (x+1, y+1) for x in [-2, w], y in [-2, h]; out-of-image
-// texels are 0 (border mode, patch_match_cuda.cu:1627-1629). Entries x = -2 and
-// x = w (y likewise) are entirely zero, so clamping a tap's integer coordinate to
-// [-2, w] reproduces the border for arbitrarily distant taps.
+// 2x2 footprint packing with a zero ring, tiled (pm_internal.h): entry (ex, ey) covers texels
+// (x, y) = (ex - kFpRingX, ey - kFpRingY) .. (x+1, y+1); out-of-image texels are 0 (border mode,
+// patch_match_cuda.cu:1627-1629). Entries x = -2 and x = w (y likewise) are entirely zero, so clamping a tap's
+// integer coordinate to [-2, w] reproduces the border for arbitrarily distant taps.
 __global__ void pm_build_footprint_kernel(const uint8_t* __restrict__ src, uint32_t* __restrict__ fp,
-                                          int w, int h) {
+                                          int w, int h, int pw, int ph) {
   const int ex = blockIdx.x * blockDim.x + threadIdx.x;
   const int ey = blockIdx.y;
   const int s = blockIdx.z;
-  if (ex >= w + 3) return;
-  const int x = ex - 2, y = ey - 2;
+  if (ex >= pw) return;
+  const int x = ex - kFpRingX, y = ey - kFpRingY;
   const uint8_t* img = src + (size_t)s * w * h;
   auto tex = [&](int xx, int yy) -> uint32_t {
     return (xx >= 0 && yy >= 0 && xx < w && yy < h) ? (uint32_t)img[(size_t)yy * w + xx] : 0u;
   };
-  fp[((size_t)s * (h + 3) + ey) * (w + 3) + ex] =
+  fp[(size_t)s * pw * ph + fp_tiled((unsigned)ex, (unsigned)ey, (unsigned)(pw / 8 - 1))] =
       tex(x, y) | (tex(x + 1, y) << 8) | (tex(x, y + 1) << 16) | (tex(x + 1, y + 1) << 24);
 }
 
@@ -773,6 +782,7 @@ struct Lds {
 struct LdsOffsets {
   uint32_t poses, fpb, tile, wgt, refc, fm, q, costv, betav, prevv, ncc, geo, hyp, colf, us, sv, best, csum,
       flags, tasks, th, ntasks, tapg, ring, tin, total;
+  uint32_t priv_stride = 0;  // multi-wave sweep kernel: bytes between the private regions of consecutive waves
 };
 
 // Pose record kept in LDS: K4 R9 T3 C3 always; the projection matrices P12 invP12 only serve the
@@ -1089,16 +1099,21 @@ __device__ __forceinline__ void tap_geom_init(lds_f32* tapg, int tid, int step, 
     if (transpose) {
       const int sw = wrow; wrow = wcol; wcol = sw;
     }
+#if defined(PM_DIAG_GATHER)
+    // 3 = gather instruction k reads window row k only (lanes beyond the row's 11 taps repeat its last tap; rows
+    // 8..10 are not read): no two instructions of an evaluation share a cache line
+    if (PM_DIAG_GATHER == 3) { wrow = transpose ? (j < 10 ? j : 10) : k; wcol = transpose ? k : (j < 10 ? j : 10); }
+#endif
     tapg[idx] = (float)((is_dy ? wrow : wcol) * step);
   }
 }
 
 // Address of the footprint entry of a tap (see tap_gather<true>: clamp in the float domain, fp32
 // entry index).
-__device__ __forceinline__ gbl_u32* tap_address(const PmParams& p, gbl_u32* fp, float fx2, float fy2) {
-  const float cx = __builtin_amdgcn_fmed3f(fx2, 0.0f, p.fp_xmax);
-  const float cy = __builtin_amdgcn_fmed3f(fy2, 0.0f, p.fp_ymax);
-  return fp + (unsigned)(int)fmaf(cy, p.fp_pitch, cx);
+__device__ __forceinline__ gbl_u32* tap_address(const PmParams& p, gbl_u32* fp, float fxr, float fyr) {
+  const float cx = __builtin_amdgcn_fmed3f(fxr, (float)(kFpRingX - 2), p.fp_xmax);
+  const float cy = __builtin_amdgcn_fmed3f(fyr, (float)(kFpRingY - 2), p.fp_ymax);
+  return fp + fp_tiled((unsigned)(int)cx, (unsigned)(int)cy, (unsigned)p.fp_tpr1);
 }
 
 // The footprint gathers of the software-pipelined NCC loop land in LDS, not in registers
@@ -1198,18 +1213,34 @@ __device__ __forceinline__ void ncc_front(const PmParams& p, const lds_f32* H, g
     st.wy[q] = py - fy;
     gbl_u32 *a0, *a1;
     if (FAST) {
-      // fp already points at the entry of texel (0, 0) (the caller added 2 * pitch + 2). Lanes whose
+      // fp already points at the entry of texel (0, 0) (the caller added the offset of tile (1, 1)). Lanes whose
       // tap lies beyond the window (t >= 121: weight 0, divisor forced to 1, so the coordinate is
       // the un-normalised numerator) have no inside guarantee: they read entry (0, 0) instead.
       const bool v0 = j + 16 * (2 * q) < 121, v1 = j + 16 * (2 * q + 1) < 121;
-      a0 = fp + (v0 ? (unsigned)(int)fmaf(fy[0], p.fp_pitch, fx[0]) : 0u);
-      a1 = fp + (v1 ? (unsigned)(int)fmaf(fy[1], p.fp_pitch, fx[1]) : 0u);
+      a0 = fp + (v0 ? fp_tiled((unsigned)(int)fx[0], (unsigned)(int)fy[0], (unsigned)p.fp_tpr1) : 0u);
+      a1 = fp + (v1 ? fp_tiled((unsigned)(int)fx[1], (unsigned)(int)fy[1], (unsigned)p.fp_tpr1) : 0u);
     } else {
-      const v2f fx2 = fx + pk_bcast(2.0f);
-      const v2f fy2 = fy + pk_bcast(2.0f);
+      const v2f fx2 = fx + pk_bcast((float)kFpRingX);
+      const v2f fy2 = fy + pk_bcast((float)kFpRingY);
       a0 = tap_address(p, fp, fx2[0], fy2[0]);
       a1 = tap_address(p, fp, fx2[1], fy2[1]);
     }
+#if defined(PM_DIAG_GATHER)
+    // Diagnostic builds only (scripts/profile_pm_gather_diag.sh; results are garbage, only the launch time means
+    // something): 1 = every gather reads the image's first entry (one cache line per instruction: what the kernel
+    // costs without the address path), 2 = entry indices wrapped into an 8 KB window per image (same lines per
+    // instruction, everything L2-resident: what the cache misses cost).
+    if (PM_DIAG_GATHER == 1) { a0 = fp; a1 = fp; }
+    if (PM_DIAG_GATHER == 2) { a0 = fp + ((unsigned)(a0 - fp) & 2047u); a1 = fp + ((unsigned)(a1 - fp) & 2047u); }
+    // 4 (row-major builds): the row of every tap rounded down to a multiple of four -- a window touches a quarter of
+    // its cache lines, everything else unchanged: how the time scales with the number of lines missed
+    if (PM_DIAG_GATHER == 4) {
+      const unsigned pw_ = 8u * ((unsigned)p.fp_tpr1 + 1u);
+      const unsigned i0_ = (unsigned)(a0 - fp), i1_ = (unsigned)(a1 - fp);
+      a0 = fp + (i0_ - (i0_ / pw_ & 3u) * pw_);
+      a1 = fp + (i1_ - (i1_ / pw_ & 3u) * pw_);
+    }
+#endif
     if (STAGE >= 0) {
       gather_issue_k<(STAGE >= 0 ? STAGE : 0)>(2 * q, a0);
       gather_issue_k<(STAGE >= 0 ? STAGE : 0)>(2 * q + 1, a1);
@@ -1622,11 +1653,58 @@ __host__ __device__ inline int wave_max_tasks(int C, int S, int M) {
 // all of them were touched earlier in the same row step and sit in L1 / L2), 36 task slots per batch instead
 // of 40 -- three columns per wave then take 10 192 B = 8 allocation granules at S = 20.
 constexpr int kWaveThCapLean = 36;  // (nine full rounds of four tasks)
+//
+// `nw` > 1 (pm_sweep_quad_kernel): nw waves per workgroup, each sweeping its own column group. The read-only
+// tables that are the same for every column group of a problem -- pose records, packed-image base pointers,
+// tap-offset table: 2.7 KB at S = 20 -- exist once per workgroup at the start of the LDS block; everything
+// else is private to a wave and repeats with `priv_stride`. Offsets of the private items are those of wave 0.
+// `cap` = NCC task slots per batch (kWaveThCap, or 64 where the shared tables make room for it).
 __host__ __device__ inline LdsOffsets lds_offsets_wave(int C, int S, int radius, int ntaps, int M,
                                                        bool geom, bool pipe, bool pose_global = false,
-                                                       bool lean = false) {
+                                                       bool lean = false, int cap_slots = 0, int nw = 1) {
   LdsOffsets o;
   uint32_t off = 0;
+  if (nw > 1) {
+    auto take = [&](uint32_t bytes) {
+      const uint32_t at = off;
+      off += (bytes + 15u) & ~15u;
+      return at;
+    };
+    const int win = 2 * radius + 1;
+    const int tw = C + 2 * radius;
+    const int max_tasks = wave_max_tasks(C, S, M);
+    const uint32_t cap = cap_slots > 0 ? (uint32_t)cap_slots : (uint32_t)kWaveThCap;
+    o.ring = 0;
+    o.poses = take(4u * S * lds_pose_stride(geom));
+    o.fpb = take(8u * S);
+    o.tapg = take(4u * 256);
+    const uint32_t shared = off;
+    o.tile = take(4u * win * tw);
+    o.wgt = take(4u * C * tap_stride(ntaps));
+    o.refc = take(4u * C * tap_stride(ntaps));
+    o.fm = take(4u * C * S);
+    o.q = take(4u * C * S);
+    o.costv = take(4u * C * S);
+    o.betav = take(4u * C * S);
+    o.prevv = take(4u * C * S);
+    o.ncc = take(4u * C * 4 * S);
+    o.geo = take(geom ? 4u * C * 5 * S : 0u);
+    o.hyp = take(4u * C * 20);
+    o.colf = take(4u * C * 8);
+    const uint32_t us_bytes = 4u * C * M > 1u * C * S ? 4u * C * M : 1u * C * S;
+    o.us = take(us_bytes);
+    o.flags = o.us;
+    o.sv = take(4u * C * M);
+    o.best = take(4u * C);
+    o.csum = take(4u * C * 5);
+    o.tasks = take(2u * max_tasks + (geom ? 2u * C * S : 0u));
+    o.th = take(36u * cap);
+    o.ntasks = take(16u);
+    o.tin = take(2u * cap);
+    o.priv_stride = off - shared;
+    o.total = shared + (uint32_t)nw * o.priv_stride;
+    return o;
+  }
   auto take = [&](uint32_t bytes) {
     const uint32_t at = off;
     off += (bytes + 15u) & ~15u;
@@ -1658,7 +1736,7 @@ __host__ __device__ inline LdsOffsets lds_offsets_wave(int C, int S, int radius,
   o.csum = take(4u * C * 5);
   o.tasks = take(2u * max_tasks + (geom ? 2u * C * S : 0u));  // 16-bit task words: NCC tasks, then
                                                               // (GEOM) the geometric-cost-only list
-  const uint32_t cap = lean ? (uint32_t)kWaveThCapLean : (uint32_t)kWaveThCap;
+  const uint32_t cap = lean ? (uint32_t)kWaveThCapLean : (cap_slots > 0 ? (uint32_t)cap_slots : (uint32_t)kWaveThCap);
   o.th = take(36u * cap);
   o.ntasks = take(16u);
   o.tapg = take(4u * 256);
@@ -1703,11 +1781,25 @@ template <> struct PoseSrc<true> {
   static __device__ __forceinline__ ptr get(const PmParams& p, const Lds&, int s) { return (gbl_f32*)p.poses + s * kPoseStride; }
 };
 
+// Synchronisation point between the lane-parallel phases of ONE wave. A single-wave workgroup's
+// __syncthreads() compiles to the two fences without an s_barrier; the multi-wave workgroup spells that out so
+// that its waves stay independent of each other.
+template <int NW>
+__device__ __forceinline__ void wave_sync() {
+  if (NW == 1) {
+    __syncthreads();
+  } else {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  }
+}
+
 // Run the queued NCC tasks (and, with GEOM, the geometric-cost-only list) of one phase.
-template <bool GEOM, bool PIPE, bool PG, bool LEAN = false>
+template <bool GEOM, bool PIPE, bool PG, bool LEAN = false, int NW = 1, int CAPT = kWaveThCap>
 __device__ __forceinline__ void run_tasks_wave(const PmParams& p, const Lds& L, int row, int col0, int tid,
                                                unsigned& evals) {
-  constexpr int CAP = LEAN ? kWaveThCapLean : kWaveThCap;  // task slots per batch (LDS layout: lds_offsets_wave)
+  constexpr int CAP = LEAN ? kWaveThCapLean : CAPT;  // task slots per batch (LDS layout: lds_offsets_wave)
   const lds_f32* G = L.tapg;
   // base pointer of source image s' packed footprints: LDS copy, or (LEAN) the table in global memory
 #define PM_FP_BASE(sv) (LEAN ? (gbl_u32*)p.src_fp_tab[sv] : (gbl_u32*)L.fpb[sv])
@@ -1759,7 +1851,7 @@ __device__ __forceinline__ void run_tasks_wave(const PmParams& p, const Lds& L, 
       if (tid < nb)
         L.tin[CAP + (inside ? __popcll(m1 & below) : __popcll(m1) + __popcll(m0 & below))] = (uint8_t)tid;
     }
-    __syncthreads();
+    wave_sync<NW>();
     // pass B, 16-lane group per task, software-pipelined: the gathers of a group's NEXT task are
     // issued (ncc_front) before the texels of its current task are consumed (ncc_back), so a wave
     // waits for memory only when a round's arithmetic is shorter than the gather latency. Two stage
@@ -1774,7 +1866,7 @@ __device__ __forceinline__ void run_tasks_wave(const PmParams& p, const Lds& L, 
       NccStage A, B;
       int ta, tb, ca, cb;
       bool wa, wb;
-      const int fp_origin = 2 * (p.src_w + 3) + 2;  // entry of texel (0, 0) in a packed image
+      const int fp_origin = (int)fp_tiled(kFpRingX, kFpRingY, (unsigned)p.fp_tpr1);  // entry of texel (0, 0): tile (1, 1) of the packed image
       auto prep = [&](int r, int& t, int& c, bool& own, bool& fast) -> uint32_t {
         const int tr = g + 4 * r;
         own = tr < nb;
@@ -1851,7 +1943,7 @@ __device__ __forceinline__ void run_tasks_wave(const PmParams& p, const Lds& L, 
 #undef PM_FRONT
 #undef PM_BACK
     }
-    __syncthreads();
+    wave_sync<NW>();
     // lane per task: normalisation, variances, square root, division
     if (tid < nb) {
       const uint32_t task = tasks[base + tid];
@@ -1861,13 +1953,15 @@ __device__ __forceinline__ void run_tasks_wave(const PmParams& p, const Lds& L, 
       L.ncc[(c * 4 + i - 1) * S + s] = ncc_finish(L.th[tid * 9 + 0], L.th[tid * 9 + 1], L.th[tid * 9 + 2],
                                                   L.colf[c * 8 + 0], L.colf[c * 8 + 1], L.colf[c * 8 + 5]);
     }
-    __syncthreads();
+    wave_sync<NW>();
   }
 }
 #undef PM_FP_BASE
 
-template <bool GEOM, bool FILTER_PHOTO, bool FILTER_GEOM, bool PIPE, bool PG = false, bool LEAN = false>
+template <bool GEOM, bool FILTER_PHOTO, bool FILTER_GEOM, bool PIPE, bool PG = false, bool LEAN = false, int NW = 1,
+          int CAPT = kWaveThCap>
 __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp) {
+  static_assert(NW == 1 || (!PIPE && !PG && !LEAN), "the multi-wave workgroup exists for the plain build only");
   const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y;
   unsigned group = lin / gridDim.y;
   unsigned prob = lin - group * gridDim.y;
@@ -1888,8 +1982,23 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
   const PmParams& p = pp[prob];
   extern __shared__ __attribute__((aligned(16))) char smem[];
   Lds L;
-  lds_bind(L, (lds_char*)smem, lds_offsets_wave(p.C, p.S, p.radius, p.ntaps, p.num_samples, GEOM, PIPE, PG, LEAN));
-  const int tid_entry = threadIdx.x;
+  // NW > 1: wave w of the workgroup sweeps column group NW * group + w out of its own LDS region; the pose
+  // records, base pointers and tap offsets are shared (lds_offsets_wave). After the one workgroup barrier
+  // behind their initialisation the waves never meet again: every later synchronisation point is
+  // wave_sync<NW>(), a memory fence without s_barrier -- exactly what __syncthreads() compiles to in the
+  // single-wave workgroups.
+  const int wave = NW == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  {
+    const LdsOffsets o = lds_offsets_wave(p.C, p.S, p.radius, p.ntaps, p.num_samples, GEOM, PIPE, PG, LEAN, CAPT, NW);
+    lds_bind(L, (lds_char*)smem + wave * o.priv_stride, o);
+    if (NW > 1) {
+      L.poses = (lds_f32*)((lds_char*)smem + o.poses);
+      L.fpb = (lds_u64*)((lds_char*)smem + o.fpb);
+      L.tapg = (lds_f32*)((lds_char*)smem + o.tapg);
+    }
+  }
+  if (NW > 1) group = group * NW + wave;
+  const int tid_entry = threadIdx.x & 63;
   const int tid = tid_entry;
   constexpr int nt = 64;
   const int S = p.S, M = p.num_samples, C = p.C;
@@ -1898,9 +2007,13 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
   const int ncols = min(C, RW - col0);
   const float* iK = p.refInvK;
   if (PIPE && (uint32_t)(uintptr_t)L.ring != 0u) __builtin_trap();  // gather_issue addresses the ring through a literal M0
-  tap_geom_init(L.tapg, tid, p.step, (p.rot & 1) != 0);
+  if (NW == 1 || wave == 0) tap_geom_init(L.tapg, tid, p.step, (p.rot & 1) != 0);
 
-  if (PG) {  // no LDS copy of the pose records; the packed-image base pointers still go to LDS
+  if (NW > 1) {
+    lds_load_poses(p, L, GEOM, threadIdx.x, 64 * NW);
+    __syncthreads();                  // the only workgroup barrier of the kernel
+    if (col0 >= RW) return;           // surplus wave of the last workgroup (grid.x = ceil(groups / NW))
+  } else if (PG) {  // no LDS copy of the pose records; the packed-image base pointers still go to LDS
     for (int i = tid; i < p.S; i += nt) L.fpb[i] = (uint64_t)p.src_fp_tab[i];
   } else if (LEAN) {  // pose records in LDS, no copy of the base pointers
     L.pstride = lds_pose_stride(GEOM);
@@ -1939,7 +2052,7 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
     h1[0] = rec[0]; h1[1] = sx; h1[2] = sy; h1[3] = rec[3];
   }
   for (int r = -p.radius; r < p.radius; ++r) tile_load_row(p, L, col0, r, tid, nt);
-  __syncthreads();
+  wave_sync<NW>();
 
   const int tid0 = tid_entry;
   unsigned evals = 0;  // NCC evaluations of this workgroup (< 2^32: RH * C * (4 M + S) per sweep)
@@ -1953,7 +2066,7 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
     // ---- P0: scroll the reference tile (LocalRefImage::Read, :357-410) -------
     tile_load_row(p, L, col0, row + p.radius, tid, nt);
     if (tid == 0) { L.ntasks[0] = 0; L.ntasks[1] = 0; }
-    __syncthreads();
+    wave_sync<NW>();
 
     // ---- P1: hypotheses (lane per column) + patch weights (all lanes) --------
     if (col_lane && !(p.ablate & 2)) {
@@ -1986,7 +2099,7 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
     }
     patch_weights(p, L, row, tid, nt);
     for (int item = tid; item < ncols * 4 * S; item += nt) L.ncc[item] = -1.0f;
-    __syncthreads();
+    wave_sync<NW>();
 
     // ---- P2: per-view selection priors (:1070-1104), lane per (column, view) --
     patch_weight_sums(p, L, ncols, tid, nt);
@@ -2017,7 +2130,7 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
       const float rp = res_prob(Hm, (float)row, (float)col, p.radius);
       L.q[item] = sp * tp * ip * rp;
     }
-    __syncthreads();
+    wave_sync<NW>();
 
     // ---- P3a: TransformPDFToCDF (:683-696), sequential sum order, lane per column
     if (col_lane) {
@@ -2034,7 +2147,7 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
         q[i] = cum;
       }
     }
-    __syncthreads();
+    wave_sync<NW>();
     // ---- P3b: Monte-Carlo view draws (:1128-1138), lane per (column, draw) ----
     for (int item = tid; item < ncols * M; item += nt) {
       const int c = item / M;
@@ -2046,7 +2159,7 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
       }
       L.sv[item] = src;
     }
-    __syncthreads();
+    wave_sync<NW>();
     // ---- P3c: one task set per distinct drawn view, lane per (column, view) ---
     {
       LDS_AS uint16_t* tasks = (LDS_AS uint16_t*)L.tasks;
@@ -2065,12 +2178,12 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
         }
       }
     }
-    __syncthreads();
+    wave_sync<NW>();
 
     // ---- P4: NCC of hypotheses 1..4 against the drawn views (:1157-1172) -----
-    if (!(p.ablate & 1)) run_tasks_wave<GEOM, PIPE, PG, LEAN>(p, L, row, col0, tid, evals);
+    if (!(p.ablate & 1)) run_tasks_wave<GEOM, PIPE, PG, LEAN, NW, CAPT>(p, L, row, col0, tid, evals);
     if (tid == 0) { L.ntasks[0] = 0; L.ntasks[1] = 0; }
-    __syncthreads();
+    wave_sync<NW>();
 
     // ---- P5a: accumulate in draw order (:1144-1172), lane per (column, hypothesis)
     for (int item = tid; item < ncols * 5; item += nt) {
@@ -2086,7 +2199,7 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
       }
       L.csum[item] = acc;
     }
-    __syncthreads();
+    wave_sync<NW>();
     // ---- P5b: argmin, store, next row's previous state (:1176-1182,1279-1282) --
     if (col_lane) {
       const int c = tid;
@@ -2107,7 +2220,7 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
       lds_f32* h1 = L.hyp + (c * 5 + 1) * 4;
       h1[0] = bd; h1[1] = b0; h1[2] = b1; h1[3] = b2;
     }
-    __syncthreads();
+    wave_sync<NW>();
     // ---- P5c: winner vs. the views not evaluated yet, lane per (column, view) --
     {
       LDS_AS uint16_t* tasks = (LDS_AS uint16_t*)L.tasks;
@@ -2121,10 +2234,10 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
         }
       }
     }
-    __syncthreads();
+    wave_sync<NW>();
 
     // ---- P6: NCC of the winner against the remaining views (:1188-1197) ------
-    if (!(p.ablate & 1)) run_tasks_wave<false, PIPE, PG, LEAN>(p, L, row, col0, tid, evals);
+    if (!(p.ablate & 1)) run_tasks_wave<false, PIPE, PG, LEAN, NW, CAPT>(p, L, row, col0, tid, evals);
 
     // ---- P7: cost map, forward message, selection probability (:1186-1207) ---
     for (int item = tid; item < ncols * S; item += nt) {
@@ -2167,7 +2280,7 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
       }
     }
     if (FILTER_PHOTO || FILTER_GEOM) {
-      __syncthreads();
+      wave_sync<NW>();
       if (col_lane) {
         const int c = tid;
         int num = 0;
@@ -2182,7 +2295,7 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
         }
       }
     }
-    __syncthreads();
+    wave_sync<NW>();
   }
 
   if (col_lane) {
@@ -2216,6 +2329,19 @@ __global__ void __launch_bounds__(64, 4) pm_sweep_wave4l_kernel(const PmParams* 
 template <bool GEOM, bool FILTER_PHOTO, bool FILTER_GEOM>
 __global__ void __launch_bounds__(64, 5) pm_sweep_wave5g_kernel(const PmParams* __restrict__ pp) {
   sweep_wave_body<GEOM, FILTER_PHOTO, FILTER_GEOM, false, true>(pp);
+}
+
+// Four waves per workgroup, each with its own column group, sharing one LDS copy of the read-only per-problem
+// tables (sweep_wave_body, NW = 4). The 2.7 KB saved per wave make room for a third column AND 64 task slots per
+// batch at S = 20 within 4 x 10 240 B = four workgroups = 16 waves per CU.
+constexpr int kQuadWaves = 4;
+template <bool GEOM, bool FILTER_PHOTO, bool FILTER_GEOM>
+__global__ void __launch_bounds__(64 * kQuadWaves, 4) pm_sweep_quad_kernel(const PmParams* __restrict__ pp) {
+  sweep_wave_body<GEOM, FILTER_PHOTO, FILTER_GEOM, false, false, false, kQuadWaves, 64>(pp);
+}
+template <bool GEOM, bool FILTER_PHOTO, bool FILTER_GEOM>
+__global__ void __launch_bounds__(64 * kQuadWaves, 4) pm_sweep_quad40_kernel(const PmParams* __restrict__ pp) {
+  sweep_wave_body<GEOM, FILTER_PHOTO, FILTER_GEOM, false, false, false, kQuadWaves, kWaveThCap>(pp);
 }
 
 // Debug: raw XORWOW streams of the generator above (seed = sequence id, as InitRandomStateKernel
@@ -2257,6 +2383,20 @@ size_t pm_sweep_lds_bytes(const PmParams& p, bool geom) {
   return lds_offsets(p.C, p.S, p.radius, p.ntaps, p.num_samples, geom).total;
 }
 
+// LDS budget of one four-wave workgroup when four of them share a CU: 160 KB / 4 in 1280-byte granules.
+constexpr size_t kQuadLdsBudget = 40960;
+static bool pm_quad_enabled() {  // read per call: the tests switch it inside one process
+  const char* e = getenv("COLMAP_AMD_PM_QUAD");
+  return !e || atoi(e) != 0;
+}
+// task slots per batch of the four-wave kernel for this shape: 64, 40, or 0 = does not fit (single-wave kernel)
+static int pm_quad_cap(int C, int S, int radius, int ntaps, int M, bool geom) {
+  if (ntaps != 121) return 0;
+  for (int cap : {64, kWaveThCap})
+    if (lds_offsets_wave(C, S, radius, ntaps, M, geom, false, false, false, cap, kQuadWaves).total <= kQuadLdsBudget) return cap;
+  return 0;
+}
+
 int pm_pick_columns(int S, int ntaps, int num_samples, bool geom, int radius, int requested) {
   const size_t budget = 60 * 1024;
   // default: 2 columns per single-wave workgroup of the 11 x 11 kernel (16 workgroups = 4 waves per
@@ -2265,6 +2405,8 @@ int pm_pick_columns(int S, int ntaps, int num_samples, bool geom, int radius, in
   static const int cols_env = [] { const char* e = getenv("COLMAP_AMD_PM_COLS"); return e ? atoi(e) : 0; }();  // experiments / tests
   if (requested <= 0 && cols_env > 0) requested = cols_env;
   int c = requested > 0 ? requested : (ntaps == 121 ? 2 : 4);
+  // (the four-wave workgroups of pm_sweep_quad_kernel have room for a third column at S = 20, where the
+  // lane-per-(column, view) phases would fill 60 of 64 lanes in one pass: measured 621 ms against 606 ms for two)
   if (c > 64) c = 64;
   while (c > 1 && lds_offsets(c, S, radius, ntaps, num_samples, geom).total > budget) --c;
   return c;
@@ -2273,13 +2415,14 @@ int pm_pick_columns(int S, int ntaps, int num_samples, bool geom, int radius, in
 // The fixed-window (11 x 11) kernels index packed images through fp32 (tap_gather<true>): exact
 // while an image has fewer than 2^24 entries; larger images take the generic kernels.
 static bool pm_fixed_window_ok(const PmParams& p) {
-  return (long long)(p.src_w + 3) * (p.src_h + 3) < (1ll << 24);
+  return (long long)pm_fp_entries(p.src_w, p.src_h) < (1ll << 24);
 }
 
 void pm_launch_build_footprint(const uint8_t* src, uint32_t* fp, int S, int w, int h, hipStream_t st) {
   dim3 block(256, 1, 1);
-  dim3 grid((w + 3 + 255) / 256, h + 3, S);
-  hipLaunchKernelGGL(pm_build_footprint_kernel, grid, block, 0, st, src, fp, w, h);
+  const int pw = pm_fp_width(w), ph = pm_fp_height(h);
+  dim3 grid((pw + 255) / 256, ph, S);
+  hipLaunchKernelGGL(pm_build_footprint_kernel, grid, block, 0, st, src, fp, w, h, pw, ph);
 }
 
 void pm_launch_filter_ref(const uint8_t* gray, int W, int H, int radius, int step, float sigma_spatial,
@@ -2340,6 +2483,30 @@ void pm_launch_sweep(const PmParams& p, const PmParams* dev_params, int batch, i
     dim3 wblock(64, 1, 1);
     dim3 wgrid = grid;
     if (p.xcd_map == 2) wgrid.x = ((grid.x + 63) / 64) * 64;
+    // Four-wave workgroups with shared read-only tables (pm_sweep_quad_kernel) when four of them fit a CU, i.e.
+    // the same 16 waves per CU as the single-wave kernel at its best: with 64 task slots per batch if that
+    // fits, else with 40. COLMAP_AMD_PM_QUAD=0 keeps the single-wave workgroups.
+    const int quad_cap = pm_quad_cap(p.C, p.S, p.radius, p.ntaps, p.num_samples, geom);
+    if (!pipe && !lean && !w5 && !pg && p.xcd_map != 2 && pm_quad_enabled() && quad_cap > 0) {
+      const size_t qlds = lds_offsets_wave(p.C, p.S, p.radius, p.ntaps, p.num_samples, geom, false, false, false,
+                                           quad_cap, kQuadWaves).total + lds_pad;
+      dim3 qblock(64 * kQuadWaves, 1, 1);
+      dim3 qgrid((grid.x + kQuadWaves - 1) / kQuadWaves, grid.y, 1);
+#define PM_LAUNCH_Q(G, FP, FG)                                                                               \
+  do {                                                                                                       \
+    if (quad_cap == 64) hipLaunchKernelGGL((pm_sweep_quad_kernel<G, FP, FG>), qgrid, qblock, qlds, st, dev_params); \
+    else hipLaunchKernelGGL((pm_sweep_quad40_kernel<G, FP, FG>), qgrid, qblock, qlds, st, dev_params);      \
+  } while (0)
+      if (geom) {
+        if (filter_photo && filter_geom) PM_LAUNCH_Q(true, true, true);
+        else PM_LAUNCH_Q(true, false, false);
+      } else {
+        if (filter_photo) PM_LAUNCH_Q(false, true, false);
+        else PM_LAUNCH_Q(false, false, false);
+      }
+#undef PM_LAUNCH_Q
+      return;
+    }
 #define PM_LAUNCH_W(G, FP, FG)                                                                              \
   do {                                                                                                      \
     if (pipe) hipLaunchKernelGGL((pm_sweep_wave_kernel<G, FP, FG>), wgrid, wblock, wlds, st, dev_params);   \

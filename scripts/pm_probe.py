@@ -2,6 +2,9 @@
 import argparse, sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
+if os.environ.get("PM_PROBE_LIB"):   # a diagnostic build of the library (scripts/profile_pm_gather_diag.sh)
+    from colmap_amd import build as _b
+    _b.LIB_PATH = os.path.abspath(os.environ["PM_PROBE_LIB"])
 from colmap_amd import mvs, synthetic as syn
 
 ap = argparse.ArgumentParser()
@@ -10,6 +13,7 @@ ap.add_argument("--views", type=int, default=9); ap.add_argument("--iters", type
 ap.add_argument("--cols", type=int, default=0); ap.add_argument("--threads", type=int, default=0)
 ap.add_argument("--conc", type=int, default=1); ap.add_argument("--arc", type=float, default=30.0)
 ap.add_argument("--sweeps", type=int, default=0); ap.add_argument("--prof", type=int, default=0); ap.add_argument("--batched", type=int, default=1); ap.add_argument("--nofilter", type=int, default=0)
+ap.add_argument("--geom", type=int, default=0)  # geometric consistency against the scene's ground-truth maps
 a = ap.parse_args()
 t = time.time()
 views = syn.make_scene(a.views, a.w, a.h, arc_deg=a.arc, device="cuda")
@@ -17,11 +21,13 @@ print(f"render {time.time()-t:.2f}s")
 ref = a.views // 2
 src = [i for i in range(a.views) if i != ref]
 dmin, dmax = syn.depth_range(views, ref)
-opt = mvs.PatchMatchOptions(gpu_index="0", depth_min=dmin, depth_max=dmax, sigma_spatial=5.0, geom_consistency=False,
+opt = mvs.PatchMatchOptions(gpu_index="0", depth_min=dmin, depth_max=dmax, sigma_spatial=5.0, geom_consistency=bool(a.geom),
                             filter=not a.nofilter, num_iterations=a.iters, columns_per_group=a.cols, threads_per_group=a.threads,
                             max_sweeps=a.sweeps)
 images = [mvs.Image(v.K, v.R, v.T, torch.from_numpy(v.gray).cuda()) for v in views]
-pms = [mvs.PatchMatch(opt, mvs.PatchMatch.Problem(ref, src, images)) for _ in range(a.conc)]
+dm = [torch.from_numpy(v.depth).cuda() for v in views] if a.geom else None
+nm = [torch.from_numpy(v.normal).cuda() for v in views] if a.geom else None
+pms = [mvs.PatchMatch(opt, mvs.PatchMatch.Problem(ref, src, images, dm, nm)) for _ in range(a.conc)]
 t = time.time()
 for pm in pms: pm.Create()
 torch.cuda.synchronize(); tc = time.time() - t

@@ -125,6 +125,22 @@ def test_group_shapes_do_not_change_results(pm_oracle, cols, threads):
     _assert_equal(want, got)
 
 
+@pytest.mark.parametrize("quad", ["0", "1"])
+@pytest.mark.parametrize("geom", [0, 1])
+def test_four_wave_workgroups_equal_single_wave_workgroups(pm_oracle, monkeypatch, quad, geom):
+    """pm_sweep_quad_kernel (four waves per workgroup sharing the read-only LDS tables, three columns per wave,
+    64 task slots per batch) against the single-wave workgroups (COLMAP_AMD_PM_QUAD=0), both against the oracle:
+    ragged width (67 columns = 22 groups of three + one column; 23 groups = 5 workgroups + 3 waves), S = 6."""
+    monkeypatch.setenv("COLMAP_AMD_PM_QUAD", quad)
+    views = scene(7, 67, 45)
+    maps = None
+    if geom:
+        maps = [(v.depth.copy(), v.normal.copy()) for v in views]
+    want, got, _ = _run_both(pm_oracle, views, 3, [0, 1, 2, 4, 5, 6], maps=maps, geom_consistency=geom, filter=1,
+                             num_iterations=1)
+    _assert_equal(want, got)
+
+
 def test_single_source_and_many_samples(pm_oracle):
     views = scene(4, 64, 48)
     want, got, _ = _run_both(pm_oracle, views, 1, [2], geom_consistency=0, filter=1,
