@@ -477,12 +477,13 @@ def main():
                 "shared_source_images": not a.no_image_cache,
                 "parallelism": f"reference images sharded over {world} GPU(s), no data-path collective",
             },
-            # The kernel has no dense contraction and is fp32 VALU-issue bound (PMC:
-            # VALU 82-85 % busy): `bound` says so, `achieved / peak / frac` keep the HBM figures BASELINE.json
-            # asks for (algorithmic bytes / launch time against 8 TB/s), the VALU-side figures follow below.
+            # The kernel has no dense contraction: its time is about half fp32 VALU issue (PMC:
+            # VALU 82-85 % busy) and half stalls on the cache misses of its scattered 4-byte gathers (diagnostic
+            # builds, profiles/r03_pm_gather_diag.log). `bound` says so, `achieved / peak / frac` keep the HBM figures
+            # BASELINE.json asks for (algorithmic bytes / launch time against 8 TB/s), the VALU-side figures follow.
             "roofline": {
-                "bound": "valu-fp32 (HBM fraction reported as BASELINE.json asks)",
-                "kernel": "pm_sweep_wave4_kernel",
+                "bound": "valu-fp32 issue + gather-miss stalls (HBM fraction reported as BASELINE.json asks)",
+                "kernel": "pm_sweep_quad_kernel",
                 "achieved": achieved,
                 "peak": 8000.0,
                 "unit": "GB/s",
@@ -498,10 +499,12 @@ def main():
                 "taps_per_s": (evals_sweep + evals_init) * 121 / dt,
                 "valu_frac": (evals_sweep + evals_init) * 121 * 30.0 / dt / 157.3e12,
                 "ncc_evaluations_per_pixel_per_sweep": evals_sweep / max(a.steps * a.batch * a.groups * pix_per_image * 20, 1),
-                "note": "fp32 VALU-issue-bound kernel without a dense contraction (VALU 82-85 % busy by PMC, "
+                "note": "kernel without a dense contraction: VALU 82-85 % busy by PMC, yet with every gather forced onto "
+                        "cached lines the launch takes 280-340 ms instead of ~600 (profiles/r03_pm_gather_diag.log, "
                         "DESIGN.md 1.5): taps_per_s / valu_frac carry the useful arithmetic; the HBM fraction is "
                         "reported because BASELINE.json asks for it. traffic = FETCH_SIZE + WRITE_SIZE of "
-                        "profiles/pm_sweep_traffic.json (4-byte footprint gathers, ~35x the algorithmic bytes)",
+                        "profiles/pm_sweep_traffic.json (4-byte footprint gathers, ~35x the algorithmic bytes; "
+                        "measured before the tiled image layout)",
             },
         }
         # the CPU baseline and the secondary (single-GPU) BA measurement belong to the N = 1 run only

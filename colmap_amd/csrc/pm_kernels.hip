@@ -1232,6 +1232,9 @@ __device__ __forceinline__ void ncc_front(const PmParams& p, const lds_f32* H, g
     // instruction, everything L2-resident: what the cache misses cost).
     if (PM_DIAG_GATHER == 1) { a0 = fp; a1 = fp; }
     if (PM_DIAG_GATHER == 2) { a0 = fp + ((unsigned)(a0 - fp) & 2047u); a1 = fp + ((unsigned)(a1 - fp) & 2047u); }
+    // 5 = entry indices wrapped into a 2 MB window per image: the lines no longer fit the L2 (36 images x 2 MB) but sit
+    // in few pages and in the 256 MB infinity cache -- separates address translation / HBM from L2 capacity
+    if (PM_DIAG_GATHER == 5) { a0 = fp + ((unsigned)(a0 - fp) & 0x7FFFFu); a1 = fp + ((unsigned)(a1 - fp) & 0x7FFFFu); }
     // 4 (row-major builds): the row of every tap rounded down to a multiple of four -- a window touches a quarter of
     // its cache lines, everything else unchanged: how the time scales with the number of lines missed
     if (PM_DIAG_GATHER == 4) {
