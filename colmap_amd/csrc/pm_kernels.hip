@@ -250,8 +250,17 @@ __device__ __forceinline__ v2f pk_bcast(float a) { return (v2f)(a); }
 #ifndef PM_FP_TILED
 #define PM_FP_TILED 1
 #endif
+// PM_FP_FORMAT=16 (experimental build, scripts/profile_pm_gather_diag.sh): half the bytes. An entry is the VERTICAL
+// pair {t(x, y), t(x, y+1)} in two bytes, the image row-major; a tap reads the dword that starts at its entry --
+// entries (x, y) and (x+1, y), i.e. the same four texels -- with one 2-byte-aligned global_load_dword. 354 instead
+// of 708 MB of packed sources for the benchmark's 36 images. The texels arrive as c00 c01 c10 c11 (PM_FP_C10 / C01).
+#ifndef PM_FP_FORMAT
+#define PM_FP_FORMAT 32
+#endif
 __device__ __forceinline__ unsigned fp_tiled(unsigned ix, unsigned iy, unsigned tpr1) {
-#if PM_FP_TILED
+#if PM_FP_FORMAT == 16
+  return __umul24(iy, 8u * (tpr1 + 1u)) + ix;
+#elif PM_FP_TILED
   const unsigned a = __umul24(ix & ~7u, 3u) + ix;
   const unsigned v = __umul24(iy & ~3u, tpr1) + iy;
   return (v << 3) + a;
@@ -259,6 +268,21 @@ __device__ __forceinline__ unsigned fp_tiled(unsigned ix, unsigned iy, unsigned 
   return __umul24(iy, 8u * (tpr1 + 1u)) + ix;
 #endif
 }
+#if PM_FP_FORMAT == 16
+struct __attribute__((packed, aligned(2))) FpDword { uint32_t v; };
+typedef __attribute__((address_space(1))) const FpDword gbl_fpdword;
+typedef __attribute__((address_space(1))) const uint16_t gbl_u16;
+// pointer to entry `idx` of a packed image / the four texels of the tap whose entry `a` points at
+__device__ __forceinline__ gbl_u32* fp_entry(gbl_u32* fp, unsigned idx) { return (gbl_u32*)((gbl_u16*)fp + idx); }
+__device__ __forceinline__ uint32_t fp_load(gbl_u32* a) { return ((gbl_fpdword*)a)->v; }
+#define PM_FP_C10 ubyte2
+#define PM_FP_C01 ubyte1
+#else
+__device__ __forceinline__ gbl_u32* fp_entry(gbl_u32* fp, unsigned idx) { return fp + idx; }
+__device__ __forceinline__ uint32_t fp_load(gbl_u32* a) { return *a; }
+#define PM_FP_C10 ubyte1
+#define PM_FP_C01 ubyte2
+#endif
 
 template <bool FOFF>
 __device__ __forceinline__ uint32_t tap_gather(const PmParams& p, gbl_u32* fp, float fxr, float fyr) {
@@ -266,7 +290,7 @@ __device__ __forceinline__ uint32_t tap_gather(const PmParams& p, gbl_u32* fp, f
   // positions left of -2 / beyond w clamp to the all-zero ring entries
   const float cx = __builtin_amdgcn_fmed3f(fxr, (float)(kFpRingX - 2), p.fp_xmax);
   const float cy = __builtin_amdgcn_fmed3f(fyr, (float)(kFpRingY - 2), p.fp_ymax);
-  return fp[fp_tiled((unsigned)(int)cx, (unsigned)(int)cy, (unsigned)p.fp_tpr1)];
+  return fp_load(fp_entry(fp, fp_tiled((unsigned)(int)cx, (unsigned)(int)cy, (unsigned)p.fp_tpr1)));
 }
 
 // Byte k of a packed footprint entry as float. Inline asm keeps the four conversions as four
@@ -418,8 +442,8 @@ __device__ __forceinline__ void ncc_group(const PmParams& p, const lds_f32* H, g
         const int t = j + 16 * (kb + 2 * q + e);
         const uint32_t x = t < ntaps ? tex[2 * q + e] : 0u;
         c00[e] = ubyte0(x);
-        c10[e] = ubyte1(x);
-        c01[e] = ubyte2(x);
+        c10[e] = PM_FP_C10(x);
+        c01[e] = PM_FP_C01(x);
         c11[e] = ubyte3(x);
       }
       const v2f top = pk_fma(wx[q], c10 - c00, c00);
@@ -665,8 +689,13 @@ __global__ void pm_build_footprint_kernel(const uint8_t* __restrict__ src, uint3
   auto tex = [&](int xx, int yy) -> uint32_t {
     return (xx >= 0 && yy >= 0 && xx < w && yy < h) ? (uint32_t)img[(size_t)yy * w + xx] : 0u;
   };
+#if PM_FP_FORMAT == 16
+  // (allocated as pm_fp_entries dwords = twice what the halfwords need: the dword of the last entry stays in bounds)
+  ((uint16_t*)fp)[(size_t)s * pw * ph * 2 + (size_t)ey * pw + ex] = (uint16_t)(tex(x, y) | (tex(x, y + 1) << 8));
+#else
   fp[(size_t)s * pw * ph + fp_tiled((unsigned)ex, (unsigned)ey, (unsigned)(pw / 8 - 1))] =
       tex(x, y) | (tex(x + 1, y) << 8) | (tex(x, y + 1) << 16) | (tex(x + 1, y + 1) << 24);
+#endif
 }
 
 // FilterKernel, gpu_mat_ref_image.cu:39-81
@@ -1113,7 +1142,7 @@ __device__ __forceinline__ void tap_geom_init(lds_f32* tapg, int tid, int step, 
 __device__ __forceinline__ gbl_u32* tap_address(const PmParams& p, gbl_u32* fp, float fxr, float fyr) {
   const float cx = __builtin_amdgcn_fmed3f(fxr, (float)(kFpRingX - 2), p.fp_xmax);
   const float cy = __builtin_amdgcn_fmed3f(fyr, (float)(kFpRingY - 2), p.fp_ymax);
-  return fp + fp_tiled((unsigned)(int)cx, (unsigned)(int)cy, (unsigned)p.fp_tpr1);
+  return fp_entry(fp, fp_tiled((unsigned)(int)cx, (unsigned)(int)cy, (unsigned)p.fp_tpr1));
 }
 
 // The footprint gathers of the software-pipelined NCC loop land in LDS, not in registers
@@ -1217,15 +1246,15 @@ __device__ __forceinline__ void ncc_front(const PmParams& p, const lds_f32* H, g
       // tap lies beyond the window (t >= 121: weight 0, divisor forced to 1, so the coordinate is
       // the un-normalised numerator) have no inside guarantee: they read entry (0, 0) instead.
       const bool v0 = j + 16 * (2 * q) < 121, v1 = j + 16 * (2 * q + 1) < 121;
-      a0 = fp + (v0 ? fp_tiled((unsigned)(int)fx[0], (unsigned)(int)fy[0], (unsigned)p.fp_tpr1) : 0u);
-      a1 = fp + (v1 ? fp_tiled((unsigned)(int)fx[1], (unsigned)(int)fy[1], (unsigned)p.fp_tpr1) : 0u);
+      a0 = fp_entry(fp, v0 ? fp_tiled((unsigned)(int)fx[0], (unsigned)(int)fy[0], (unsigned)p.fp_tpr1) : 0u);
+      a1 = fp_entry(fp, v1 ? fp_tiled((unsigned)(int)fx[1], (unsigned)(int)fy[1], (unsigned)p.fp_tpr1) : 0u);
     } else {
       const v2f fx2 = fx + pk_bcast((float)kFpRingX);
       const v2f fy2 = fy + pk_bcast((float)kFpRingY);
       a0 = tap_address(p, fp, fx2[0], fy2[0]);
       a1 = tap_address(p, fp, fx2[1], fy2[1]);
     }
-#if defined(PM_DIAG_GATHER)
+#if defined(PM_DIAG_GATHER) && PM_FP_FORMAT == 32
     // Diagnostic builds only (scripts/profile_pm_gather_diag.sh; results are garbage, only the launch time means
     // something): 1 = every gather reads the image's first entry (one cache line per instruction: what the kernel
     // costs without the address path), 2 = entry indices wrapped into an 8 KB window per image (same lines per
@@ -1248,8 +1277,8 @@ __device__ __forceinline__ void ncc_front(const PmParams& p, const lds_f32* H, g
       gather_issue_k<(STAGE >= 0 ? STAGE : 0)>(2 * q, a0);
       gather_issue_k<(STAGE >= 0 ? STAGE : 0)>(2 * q + 1, a1);
     } else {
-      tex[2 * q] = *a0;
-      tex[2 * q + 1] = *a1;
+      tex[2 * q] = fp_load(a0);
+      tex[2 * q + 1] = fp_load(a1);
     }
   }
 }
@@ -1286,8 +1315,8 @@ __device__ __forceinline__ void ncc_back(const NccStage& st, const uint32_t tex[
     for (int e = 0; e < 2; ++e) {
       const uint32_t x = j + 16 * (2 * q + e) < 121 ? tex[2 * q + e] : 0u;
       c00[e] = ubyte0(x);
-      c10[e] = ubyte1(x);
-      c01[e] = ubyte2(x);
+      c10[e] = PM_FP_C10(x);
+      c01[e] = PM_FP_C01(x);
       c11[e] = ubyte3(x);
     }
     const v2f top = pk_fma(st.wx[q], c10 - c00, c00);
@@ -1886,7 +1915,7 @@ __device__ __forceinline__ void run_tasks_wave(const PmParams& p, const Lds& L, 
   do {                                                                                     \
     bool fast_;                                                                            \
     const uint32_t sv_ = prep(r, t, c, own, fast_);                                        \
-    if (fast_) ncc_front<STAGE, true>(p, L.th + (t) * 9, PM_FP_BASE(sv_) + fp_origin, G, j, st); \
+    if (fast_) ncc_front<STAGE, true>(p, L.th + (t) * 9, fp_entry(PM_FP_BASE(sv_), fp_origin), G, j, st); \
     else ncc_front<STAGE, false>(p, L.th + (t) * 9, PM_FP_BASE(sv_), G, j, st);       \
   } while (0)
 #define PM_BACK(STAGE, NEWER, st, t, c, own)                                               \
@@ -1911,7 +1940,7 @@ __device__ __forceinline__ void run_tasks_wave(const PmParams& p, const Lds& L, 
           bool fast_;
           const uint32_t sv_ = prep(r, ta, ca, wa, fast_);
           uint32_t tex_[8];
-          if (fast_) ncc_front<-1, true>(p, L.th + ta * 9, PM_FP_BASE(sv_) + fp_origin, G, j, A, tex_);
+          if (fast_) ncc_front<-1, true>(p, L.th + ta * 9, fp_entry(PM_FP_BASE(sv_), fp_origin), G, j, A, tex_);
           else ncc_front<-1, false>(p, L.th + ta * 9, PM_FP_BASE(sv_), G, j, A, tex_);
           __builtin_amdgcn_sched_barrier(0);
           TapRegs R_;
@@ -2471,7 +2500,7 @@ void pm_launch_sweep(const PmParams& p, const PmParams* dev_params, int batch, i
     // plain build (4 waves per SIMD) by default: measured 604 ms per 16-image launch against 649 ms for
     // the LDS-DMA pipelined build (3 waves per SIMD, 10 workgroups per CU); COLMAP_AMD_PM_PIPE=1 selects
     // the latter
-    static const bool pipe = [] { const char* e = getenv("COLMAP_AMD_PM_PIPE"); return e && atoi(e) != 0; }();
+    static const bool pipe = [] { const char* e = getenv("COLMAP_AMD_PM_PIPE"); return PM_FP_FORMAT == 32 && e && atoi(e) != 0; }();  // (LDS-DMA gathers need dword-aligned entries)
     // pose records read from global memory instead of an LDS copy: on for >= 3 columns per wave (that is what
     // makes the third column fit), COLMAP_AMD_PM_POSE_GLOBAL = 0 / 1 forces it
     static const int pg_env = [] { const char* e = getenv("COLMAP_AMD_PM_POSE_GLOBAL"); return e ? atoi(e) : -1; }();
