@@ -254,11 +254,14 @@ __device__ __forceinline__ v2f pk_bcast(float a) { return (v2f)(a); }
 // pair {t(x, y), t(x, y+1)} in two bytes, the image row-major; a tap reads the dword that starts at its entry --
 // entries (x, y) and (x+1, y), i.e. the same four texels -- with one 2-byte-aligned global_load_dword. 354 instead
 // of 708 MB of packed sources for the benchmark's 36 images. The texels arrive as c00 c01 c10 c11 (PM_FP_C10 / C01).
+// PM_FP_FORMAT=8 (experimental likewise): the plain one-byte image with the zero ring, row-major; a tap takes two
+// unaligned 2-byte loads (rows y and y + 1) and puts them together as the 4-byte footprint. 177 MB for those 36
+// images: the one format whose working set fits the 256 MB infinity cache (profiles/r03_pm_gather_diag.log).
 #ifndef PM_FP_FORMAT
 #define PM_FP_FORMAT 32
 #endif
 __device__ __forceinline__ unsigned fp_tiled(unsigned ix, unsigned iy, unsigned tpr1) {
-#if PM_FP_FORMAT == 16
+#if PM_FP_FORMAT == 16 || PM_FP_FORMAT == 8
   return __umul24(iy, 8u * (tpr1 + 1u)) + ix;
 #elif PM_FP_TILED
   const unsigned a = __umul24(ix & ~7u, 3u) + ix;
@@ -274,12 +277,25 @@ typedef __attribute__((address_space(1))) const FpDword gbl_fpdword;
 typedef __attribute__((address_space(1))) const uint16_t gbl_u16;
 // pointer to entry `idx` of a packed image / the four texels of the tap whose entry `a` points at
 __device__ __forceinline__ gbl_u32* fp_entry(gbl_u32* fp, unsigned idx) { return (gbl_u32*)((gbl_u16*)fp + idx); }
-__device__ __forceinline__ uint32_t fp_load(gbl_u32* a) { return ((gbl_fpdword*)a)->v; }
+__device__ __forceinline__ uint32_t fp_load(gbl_u32* a, unsigned) { return ((gbl_fpdword*)a)->v; }
 #define PM_FP_C10 ubyte2
 #define PM_FP_C01 ubyte1
+#elif PM_FP_FORMAT == 8
+struct __attribute__((packed, aligned(1))) FpHalf { uint16_t v; };
+typedef __attribute__((address_space(1))) const FpHalf gbl_fphalf;
+typedef __attribute__((address_space(1))) const uint8_t gbl_u8;
+__device__ __forceinline__ gbl_u32* fp_entry(gbl_u32* fp, unsigned idx) { return (gbl_u32*)((gbl_u8*)fp + idx); }
+__device__ __forceinline__ uint32_t fp_load(gbl_u32* a, unsigned tpr1) {
+  const gbl_u8* b = (gbl_u8*)a;
+  const uint32_t lo = ((gbl_fphalf*)b)->v;                        // t(x, y),     t(x + 1, y)
+  const uint32_t hi = ((gbl_fphalf*)(b + 8u * (tpr1 + 1u)))->v;   // t(x, y + 1), t(x + 1, y + 1)
+  return lo | (hi << 16);
+}
+#define PM_FP_C10 ubyte1
+#define PM_FP_C01 ubyte2
 #else
 __device__ __forceinline__ gbl_u32* fp_entry(gbl_u32* fp, unsigned idx) { return fp + idx; }
-__device__ __forceinline__ uint32_t fp_load(gbl_u32* a) { return *a; }
+__device__ __forceinline__ uint32_t fp_load(gbl_u32* a, unsigned) { return *a; }
 #define PM_FP_C10 ubyte1
 #define PM_FP_C01 ubyte2
 #endif
@@ -290,7 +306,7 @@ __device__ __forceinline__ uint32_t tap_gather(const PmParams& p, gbl_u32* fp, f
   // positions left of -2 / beyond w clamp to the all-zero ring entries
   const float cx = __builtin_amdgcn_fmed3f(fxr, (float)(kFpRingX - 2), p.fp_xmax);
   const float cy = __builtin_amdgcn_fmed3f(fyr, (float)(kFpRingY - 2), p.fp_ymax);
-  return fp_load(fp_entry(fp, fp_tiled((unsigned)(int)cx, (unsigned)(int)cy, (unsigned)p.fp_tpr1)));
+  return fp_load(fp_entry(fp, fp_tiled((unsigned)(int)cx, (unsigned)(int)cy, (unsigned)p.fp_tpr1)), (unsigned)p.fp_tpr1);
 }
 
 // Byte k of a packed footprint entry as float. Inline asm keeps the four conversions as four
@@ -692,6 +708,10 @@ __global__ void pm_build_footprint_kernel(const uint8_t* __restrict__ src, uint3
 #if PM_FP_FORMAT == 16
   // (allocated as pm_fp_entries dwords = twice what the halfwords need: the dword of the last entry stays in bounds)
   ((uint16_t*)fp)[(size_t)s * pw * ph * 2 + (size_t)ey * pw + ex] = (uint16_t)(tex(x, y) | (tex(x, y + 1) << 8));
+#elif PM_FP_FORMAT == 8
+  // (allocated as pm_fp_entries dwords = four times the bytes: the extra zero row below the last one is in bounds)
+  ((uint8_t*)fp)[(size_t)s * pw * ph * 4 + (size_t)ey * pw + ex] = (uint8_t)tex(x, y);
+  if (ey == ph - 1) ((uint8_t*)fp)[(size_t)s * pw * ph * 4 + (size_t)ph * pw + ex] = 0;
 #else
   fp[(size_t)s * pw * ph + fp_tiled((unsigned)ex, (unsigned)ey, (unsigned)(pw / 8 - 1))] =
       tex(x, y) | (tex(x + 1, y) << 8) | (tex(x, y + 1) << 16) | (tex(x + 1, y + 1) << 24);
@@ -1277,8 +1297,8 @@ __device__ __forceinline__ void ncc_front(const PmParams& p, const lds_f32* H, g
       gather_issue_k<(STAGE >= 0 ? STAGE : 0)>(2 * q, a0);
       gather_issue_k<(STAGE >= 0 ? STAGE : 0)>(2 * q + 1, a1);
     } else {
-      tex[2 * q] = fp_load(a0);
-      tex[2 * q + 1] = fp_load(a1);
+      tex[2 * q] = fp_load(a0, (unsigned)p.fp_tpr1);
+      tex[2 * q + 1] = fp_load(a1, (unsigned)p.fp_tpr1);
     }
   }
 }
@@ -2500,7 +2520,7 @@ void pm_launch_sweep(const PmParams& p, const PmParams* dev_params, int batch, i
     // plain build (4 waves per SIMD) by default: measured 604 ms per 16-image launch against 649 ms for
     // the LDS-DMA pipelined build (3 waves per SIMD, 10 workgroups per CU); COLMAP_AMD_PM_PIPE=1 selects
     // the latter
-    static const bool pipe = [] { const char* e = getenv("COLMAP_AMD_PM_PIPE"); return PM_FP_FORMAT == 32 && e && atoi(e) != 0; }();  // (LDS-DMA gathers need dword-aligned entries)
+    static const bool pipe = [] { const char* e = getenv("COLMAP_AMD_PM_PIPE"); return PM_FP_FORMAT == 32 && e && atoi(e) != 0; }();  // (LDS-DMA gathers need the dword entries)
     // pose records read from global memory instead of an LDS copy: on for >= 3 columns per wave (that is what
     // makes the third column fit), COLMAP_AMD_PM_POSE_GLOBAL = 0 / 1 forces it
     static const int pg_env = [] { const char* e = getenv("COLMAP_AMD_PM_POSE_GLOBAL"); return e ? atoi(e) : -1; }();

@@ -7,7 +7,8 @@
 #   2  entry indices wrapped into 8 KB per image (same lines per instruction, no L2 misses)
 #   4  (row-major) tap rows rounded down to multiples of four: a quarter of the cache lines, same pages
 #   5  entry indices wrapped into 2 MB per image: L2 misses as in the product, few pages, infinity-cache resident
-#   PM_FP_FORMAT=16  not a diagnostic but an experimental product format: 2-byte entries, same results bit for bit
+#   PM_FP_FORMAT=16 / 8  not diagnostics but experimental product formats (2-byte entries / 1-byte texels): the same
+#      results bit for bit, 354 / 177 MB of packed sources instead of 708 MB for the benchmark's batch
 #   3  one window row per gather instruction -- MISLEADING: the garbage sums drive the hypotheses out of the images,
 #      the clamped taps then all read the zero ring (fast for the wrong reason; see ROUND_NOTES.md round 3)
 # Build here (no GPU needed):   bash scripts/profile_pm_gather_diag.sh build
@@ -26,6 +27,7 @@ if [ "$1" = build ]; then
   one librowmajor.so "-DPM_FP_TILED=0" &
   one libdiag4.so "-DPM_FP_TILED=0 -DPM_DIAG_GATHER=4" &
   one libfp16.so "-DPM_FP_FORMAT=16" &   # experimental: 2-byte entries (vertical texel pairs), unaligned dword gathers
+  one libfp8.so "-DPM_FP_FORMAT=8" &     # experimental: 1-byte texels, two unaligned 2-byte loads per tap
   wait
   ls -la $D
 else
@@ -41,6 +43,10 @@ else
   echo "product build, geometric consistency:             $(probe --geom 1)" | tee -a $OUT/pm_gather_diag.log
   echo "PM_FP_FORMAT=16 (2-byte entries):                 $(PM_PROBE_LIB=$D/libfp16.so probe)" | tee -a $OUT/pm_gather_diag.log
   echo "PM_FP_FORMAT=16, geometric consistency:           $(PM_PROBE_LIB=$D/libfp16.so probe --geom 1)" | tee -a $OUT/pm_gather_diag.log
-  # the experimental format must reproduce the oracle bit for bit like the product build
-  (cd $ROOT && COLMAP_AMD_TEST_LIB=$D/libfp16.so timeout 600 python -m pytest tests/test_pm_gpu.py -m gpu -q -x 2>&1 | tail -3) | tee -a $OUT/pm_gather_diag.log
+  echo "PM_FP_FORMAT=8 (1-byte texels):                   $(PM_PROBE_LIB=$D/libfp8.so probe)" | tee -a $OUT/pm_gather_diag.log
+  echo "PM_FP_FORMAT=8, geometric consistency:            $(PM_PROBE_LIB=$D/libfp8.so probe --geom 1)" | tee -a $OUT/pm_gather_diag.log
+  # the experimental formats must reproduce the oracle bit for bit like the product build
+  for f in 16 8; do
+    (cd $ROOT && COLMAP_AMD_TEST_LIB=$D/libfp$f.so timeout 600 python -m pytest tests/test_pm_gpu.py -m gpu -q -x 2>&1 | tail -3) | tee -a $OUT/pm_gather_diag.log
+  done
 fi
