@@ -321,6 +321,7 @@ struct pm_handle {
   DevBuf<float> poses;  // [4][S][43]
   DevBuf<float> out_depth, out_normal, out_sel, out_cost;
   DevBuf<unsigned long long> prof;
+  DevBuf<unsigned long long> trace;  // progress trace of the last sweep launch (debug)
   DevBuf<unsigned long long> evals;  // NCC evaluations of the sweep launches of the last run
   DevBuf<PmParams> plan;  // per-launch parameter blocks of the last (batched) run
   hipStream_t run_stream = nullptr;  // stream the last run was enqueued on
@@ -1001,6 +1002,36 @@ int pm_enable_phase_profile(pm_handle* h, int enable) {
       h->base.prof = h->prof.ptr;
     } else {
       h->base.prof = nullptr;
+    }
+  });
+}
+
+int pm_enable_progress_trace(pm_handle* h, int enable) {
+  return Guard([&] {
+    PM_CHECK(h, "null");
+    HIP_CALL(hipSetDevice(h->device));
+    if (enable) {
+      const int longest = std::max(h->W, h->H);
+      h->base.trace_stride = longest / 128 + 2;
+      const size_t groups = (size_t)(longest + h->base.C - 1) / h->base.C;
+      h->trace.alloc(groups * h->base.trace_stride);
+      HIP_CALL(hipMemset(h->trace.ptr, 0, groups * h->base.trace_stride * sizeof(unsigned long long)));
+      h->base.trace = h->trace.ptr;
+    } else {
+      h->base.trace = nullptr;
+    }
+  });
+}
+
+int pm_get_progress_trace(pm_handle* h, unsigned long long* out, size_t capacity, int32_t* groups, int32_t* samples) {
+  return Guard([&] {
+    PM_CHECK(h && h->trace.ptr && groups && samples, "trace not enabled");
+    HIP_CALL(hipSetDevice(h->device));
+    *samples = h->base.trace_stride;
+    *groups = (int32_t)(h->trace.count / h->base.trace_stride);
+    if (out) {
+      PM_CHECK(capacity >= h->trace.count, "buffer too small");
+      HIP_CALL(hipMemcpy(out, h->trace.ptr, h->trace.count * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     }
   });
 }

@@ -66,6 +66,9 @@ struct PmParams {
   unsigned long long* prof; // optional phase-cycle counters [10] (debug), else null
   unsigned long long* evals; // NCC evaluations executed by the sweep kernels of this run (one atomic
                              // add per workgroup at its end), always allocated
+  unsigned long long* trace; // optional progress trace (debug, pm_enable_progress_trace): [column group][row / 128]
+                             // device-wide clock when the group's wave reached that row, last sweep launch; else null
+  int trace_stride;          // samples per column group
 };
 
 size_t pm_sweep_lds_bytes(const PmParams& p, bool geom);

@@ -2115,6 +2115,8 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
     int tid = tid0;
     asm volatile("" : "+v"(tid));
     const bool col_lane = tid < ncols;
+    if (p.trace && (row & 127) == 0 && tid == 0)  // debug: pm_enable_progress_trace
+      p.trace[(size_t)group * p.trace_stride + (row >> 7)] = __builtin_amdgcn_s_memrealtime();
     // ---- P0: scroll the reference tile (LocalRefImage::Read, :357-410) -------
     tile_load_row(p, L, col0, row + p.radius, tid, nt);
     if (tid == 0) { L.ntasks[0] = 0; L.ntasks[1] = 0; }

@@ -369,6 +369,18 @@ class PatchMatch:
     def EnablePhaseProfile(self, enable=True):
         _check(lib().pm_enable_phase_profile(self._h, 1 if enable else 0))
 
+    def EnableProgressTrace(self, enable=True):
+        """Debug: record when every wave of the 11 x 11 sweep kernel reaches rows 0, 128, 256, ... (last launch)."""
+        _check(lib().pm_enable_progress_trace(self._h, 1 if enable else 0))
+
+    def GetProgressTrace(self):
+        """(groups, samples) uint64 array of 100 MHz device-clock stamps; 0 = row not reached."""
+        g, s = C.c_int32(), C.c_int32()
+        _check(lib().pm_get_progress_trace(self._h, None, C.c_size_t(0), C.byref(g), C.byref(s)))
+        out = np.zeros((g.value, s.value), np.uint64)
+        _check(lib().pm_get_progress_trace(self._h, out.ctypes.data_as(C.c_void_p), C.c_size_t(out.size), C.byref(g), C.byref(s)))
+        return out
+
     def GetPhaseProfile(self):
         out = (C.c_ulonglong * 10)()
         _check(lib().pm_get_phase_profile(self._h, out))

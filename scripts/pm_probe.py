@@ -13,6 +13,7 @@ ap.add_argument("--views", type=int, default=9); ap.add_argument("--iters", type
 ap.add_argument("--cols", type=int, default=0); ap.add_argument("--threads", type=int, default=0)
 ap.add_argument("--conc", type=int, default=1); ap.add_argument("--arc", type=float, default=30.0)
 ap.add_argument("--sweeps", type=int, default=0); ap.add_argument("--prof", type=int, default=0); ap.add_argument("--batched", type=int, default=1); ap.add_argument("--nofilter", type=int, default=0)
+ap.add_argument("--trace", type=int, default=0)  # progress trace of the last sweep launch: how far the waves drift apart
 ap.add_argument("--geom", type=int, default=0)  # geometric consistency against the scene's ground-truth maps
 a = ap.parse_args()
 t = time.time()
@@ -33,6 +34,8 @@ for pm in pms: pm.Create()
 torch.cuda.synchronize(); tc = time.time() - t
 if a.prof:
     for pm in pms: pm.EnablePhaseProfile()
+if a.trace:
+    for pm in pms: pm.EnableProgressTrace()
 t = time.time()
 if a.batched:
     mvs.run_batch(pms)
@@ -48,6 +51,26 @@ if a.prof:
     pr = pms[0].GetPhaseProfile(); tot = sum(pr)
     names = ["setup+backward", "P0 tile", "P1 hyp+weights", "P2 priors", "P3 cdf+draws", "P4 ncc", "P5 argmin", "P6 ncc-winner", "P7-8 update", "-"]
     print("phase profile: " + ", ".join(f"{n} {100*v/max(tot,1):.1f}%" for n, v in zip(names, pr)))
+if a.trace:
+    # rows of the LAST sweep launch; stamps in 10 ns units. For every sample row: when the first / median / last wave
+    # of the launch (all problems) got there, and the same for the first generation of waves (the column groups that
+    # start together at launch: the first 4096 / conc column groups of every problem) -- the spread of a generation is
+    # the band of rows in use at a time.
+    tr = np.stack([pm.GetProgressTrace() for pm in pms]).astype(np.float64)   # (problem, group, sample)
+    tr[tr == 0] = np.nan
+    t0 = np.nanmin(tr)
+    us = (tr - t0) / 100.0
+    gen0 = max(1, 4096 // len(pms))
+    print(f"progress trace: {us.shape[1]} column groups x {us.shape[2]} samples, first generation = groups 0..{gen0 - 1}")
+    for k in range(us.shape[2]):
+        col = us[:, :, k]
+        if np.all(np.isnan(col)): continue
+        g0 = us[:, :gen0, k]
+        print(f"  row {128 * k:5d}: all groups {np.nanmin(col):9.0f} / {np.nanmedian(col):9.0f} / {np.nanmax(col):9.0f} us"
+              f"   first generation {np.nanmin(g0):9.0f} / {np.nanmedian(g0):9.0f} / {np.nanmax(g0):9.0f} us")
+    dt = np.diff(us[:, :gen0, :], axis=2)
+    print(f"  first generation: {np.nanmedian(dt) / 128:.1f} us per row (median), fastest / slowest wave over the whole sweep "
+          f"{np.nanmin(np.nansum(dt, axis=2)):.0f} / {np.nanmax(np.nansum(dt, axis=2)):.0f} us")
 d = pms[0].GetDepthMap(); gt = views[ref].depth
 ok = d > 0
 rel = np.abs(d[ok] - gt[ok]) / gt[ok]
