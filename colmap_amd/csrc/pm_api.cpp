@@ -676,6 +676,9 @@ void RunBatchAsync(pm_handle** hs, int n) {
     const bool last_sweep = k == total_sweeps - 1;
     const bool fphoto = last_sweep && opt.filter;
     const bool fgeom = last_sweep && opt.filter && geom;
+    for (int b = 0; b < n; ++b)  // debug progress trace: every launch starts from an empty buffer
+      if (hs[b]->trace.ptr)
+        HIP_CALL(hipMemsetAsync(hs[b]->trace.ptr, 0, hs[b]->trace.count * sizeof(unsigned long long), h0->stream));
     HIP_CALL(hipEventRecord(h0->ev[2 * k], h0->stream));
     pm_launch_sweep(host[(size_t)(k + 1) * n], h0->plan.ptr + (size_t)(k + 1) * n, n, h0->threads,
                     geom, fphoto, fgeom, h0->stream);

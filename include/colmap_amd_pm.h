@@ -172,8 +172,7 @@ int pm_copy_maps_to_device(pm_handle* h, float* depth_dev, float* normal_dev);
 int pm_enable_phase_profile(pm_handle* h, int enable);
 int pm_get_phase_profile(pm_handle* h, unsigned long long* out10);
 /* Debug: progress trace of the 11 x 11 sweep kernel. When enabled every wave stores the device-wide clock
- * (100 MHz, s_memrealtime) at rows 0, 128, 256, ... of its column group; each sweep launch overwrites the previous
- * one's samples. out[group * samples + row / 128]; 0 = not reached. How far the waves of a launch drift apart in
+ * (100 MHz, s_memrealtime) at rows 0, 128, 256, ... of its column group; the buffer holds the last sweep launch. out[group * samples + row / 128]; 0 = not reached. How far the waves of a launch drift apart in
  * the sweep direction decides how much source-image data is in use at a time. */
 int pm_enable_progress_trace(pm_handle* h, int enable);
 int pm_get_progress_trace(pm_handle* h, unsigned long long* out, size_t capacity, int32_t* groups, int32_t* samples);

@@ -58,9 +58,10 @@ if a.trace:
     # the band of rows in use at a time.
     tr = np.stack([pm.GetProgressTrace() for pm in pms]).astype(np.float64)   # (problem, group, sample)
     tr[tr == 0] = np.nan
+    tr = tr[:, ~np.isnan(tr[0, :, 0]), :]       # the column groups the last launch had (its frame may be the narrow one)
     t0 = np.nanmin(tr)
     us = (tr - t0) / 100.0
-    gen0 = max(1, 4096 // len(pms))
+    gen0 = max(1, min(us.shape[1], 4096 // len(pms)))
     print(f"progress trace: {us.shape[1]} column groups x {us.shape[2]} samples, first generation = groups 0..{gen0 - 1}")
     for k in range(us.shape[2]):
         col = us[:, :, k]
