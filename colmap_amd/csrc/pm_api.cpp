@@ -322,6 +322,9 @@ struct pm_handle {
   DevBuf<float> out_depth, out_normal, out_sel, out_cost;
   DevBuf<unsigned long long> prof;
   DevBuf<unsigned long long> trace;  // progress trace of the last sweep launch (debug)
+  DevBuf<float> band_state;          // band-scheduled sweep kernel (experimental): state records, counters, ticket
+  DevBuf<int> band_done;
+  DevBuf<unsigned> band_ticket;
   DevBuf<unsigned long long> evals;  // NCC evaluations of the sweep launches of the last run
   DevBuf<PmParams> plan;  // per-launch parameter blocks of the last (batched) run
   hipStream_t run_stream = nullptr;  // stream the last run was enqueued on
@@ -638,6 +641,23 @@ void RunBatchAsync(pm_handle** hs, int n) {
   static const int xcd_map_env = [] { const char* e = getenv("COLMAP_AMD_PM_XCD_MAP"); return e ? atoi(e) : 0; }();
   const int xcd_map = (xcd_map_env == 1 && n % 8 == 0) ? 1 : (xcd_map_env == 2 ? 2 : 0);
   int sel_out = h0->base.sel_out_off, sel_in = h0->base.sel_in_off;
+  // COLMAP_AMD_PM_BAND=1 (rows per band: COLMAP_AMD_PM_BAND_ROWS, default 64): the experimental band-scheduled sweep
+  // kernel for the 11 x 11 window; read per run so that the tests can switch it inside one process
+  int band_rows = 0;
+  {
+    const char* e = getenv("COLMAP_AMD_PM_BAND");
+    const char* r = getenv("COLMAP_AMD_PM_BAND_ROWS");
+    if (e && atoi(e) != 0 && h0->base.ntap1d == 11 && h0->base.C <= 8) band_rows = r && atoi(r) > 0 ? atoi(r) : 64;
+  }
+  if (band_rows > 0) {
+    const int longest = std::max(h0->W, h0->H);
+    for (int b = 0; b < n; ++b) {
+      const size_t groups = (size_t)(longest + hs[b]->base.C - 1) / hs[b]->base.C;
+      hs[b]->band_state.alloc(groups * hs[b]->base.C * (kRngWords + hs[b]->S + 4));
+      hs[b]->band_done.alloc(groups);
+    }
+    h0->band_ticket.alloc(1);
+  }
   for (int k = 0; k < limit; ++k) {
     const int iter = k / 4, sweep = k % 4;
     for (int b = 0; b < n; ++b) {
@@ -652,6 +672,16 @@ void RunBatchAsync(pm_handle** hs, int n) {
       p.xcd_map = xcd_map;
       static const int ablate_env = [] { const char* e = getenv("COLMAP_AMD_PM_ABLATE"); return e ? atoi(e) : 0; }();
       p.ablate = ablate_env;
+      if (band_rows > 0) {  // experimental band-scheduled kernel: pm_kernels.hip, sweep_band_body
+        const int rw = (p.rot & 1) ? p.H : p.W, rh = (p.rot & 1) ? p.W : p.H;
+        p.band_state = hs[b]->band_state.ptr;
+        p.band_done = hs[b]->band_done.ptr;
+        p.band_ticket = h0->band_ticket.ptr;
+        p.band_nprob = n;
+        p.band_groups = (rw + p.C - 1) / p.C;
+        p.band_rows = band_rows;
+        p.band_count = (rh + band_rows - 1) / band_rows;
+      }
       host[(size_t)(k + 1) * n + b] = p;
     }
     std::swap(sel_out, sel_in);  // Rotate(): prev_sel_prob <- sel_prob (reference :1911-1915)
@@ -676,6 +706,11 @@ void RunBatchAsync(pm_handle** hs, int n) {
     const bool last_sweep = k == total_sweeps - 1;
     const bool fphoto = last_sweep && opt.filter;
     const bool fgeom = last_sweep && opt.filter && geom;
+    if (band_rows > 0) {  // band-scheduled kernel: counters and ticket start at zero in every launch
+      for (int b = 0; b < n; ++b)
+        HIP_CALL(hipMemsetAsync(hs[b]->band_done.ptr, 0, hs[b]->band_done.count * sizeof(int), h0->stream));
+      HIP_CALL(hipMemsetAsync(h0->band_ticket.ptr, 0, sizeof(unsigned), h0->stream));
+    }
     for (int b = 0; b < n; ++b)  // debug progress trace: every launch starts from an empty buffer
       if (hs[b]->trace.ptr)
         HIP_CALL(hipMemsetAsync(hs[b]->trace.ptr, 0, hs[b]->trace.count * sizeof(unsigned long long), h0->stream));

@@ -69,6 +69,11 @@ struct PmParams {
   unsigned long long* trace; // optional progress trace (debug, pm_enable_progress_trace): [column group][row / 128]
                              // device-wide clock when the group's wave reached that row, last sweep launch; else null
   int trace_stride;          // samples per column group
+  // band-scheduled sweep kernel (experimental, COLMAP_AMD_PM_BAND=1; pm_kernels.hip: sweep_band_body)
+  float* band_state;         // [column group][C * (kRngWords + S + 4)] state of a column group between two bands
+  int* band_done;            // [column group] bands finished in this launch
+  unsigned* band_ticket;     // one counter per launch, shared by the problems of a batch
+  int band_nprob, band_groups, band_count, band_rows;  // problems in the launch, column groups per problem, bands, rows per band
 };
 
 size_t pm_sweep_lds_bytes(const PmParams& p, bool geom);

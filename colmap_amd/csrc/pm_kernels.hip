@@ -2358,6 +2358,367 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
   if (tid == 0 && p.evals) atomicAdd(p.evals, (unsigned long long)evals);
 }
 
+// ---------------------------------------------------------------------------
+// Band-scheduled build of the same sweep (EXPERIMENTAL, COLMAP_AMD_PM_BAND=1; written at the end of round 3 after the
+// GPU budget was spent: it compiles, it has never run). Why: profiles/r03_pm_progress_trace.log -- the waves of a launch
+// drift so far apart in the sweep direction that half of every source image is in use at a time, and the gathers
+// miss the L2 and the infinity cache. Here a persistent grid of single-wave workgroups takes work items (band of
+// `band_rows` rows, column group, problem) from one ticket counter in band-major order: every column group of every
+// problem finishes band b before anybody starts band b + 2 or so. A column group's state crosses a band boundary
+// through global memory (PRNG words, forward messages, previous hypothesis: C x (6 + S + 4) words); an item waits
+// for the band above it on a per-group counter -- its ticket is older, so whoever holds it is running: no deadlock --
+// with agent-scope fences on both sides (the two waves may sit on different XCDs). The row step itself is
+// sweep_wave_body's, verbatim: results cannot depend on the schedule.
+// ---------------------------------------------------------------------------
+template <bool GEOM, bool FILTER_PHOTO, bool FILTER_GEOM, int CAPT>
+__device__ __forceinline__ void sweep_band_body(const PmParams* __restrict__ pp) {
+  constexpr bool PIPE = false, PG = false, LEAN = false;
+  constexpr int NW = 1;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid_entry = threadIdx.x;
+  const int tid = tid_entry;
+  constexpr int nt = 64;
+  const unsigned nprob = (unsigned)pp[0].band_nprob, ngroups = (unsigned)pp[0].band_groups;
+  const unsigned per_band = nprob * ngroups;
+  const unsigned total = per_band * (unsigned)pp[0].band_count;
+  for (;;) {
+    unsigned ticket = 0;
+    if (tid == 0) ticket = atomicAdd(pp[0].band_ticket, 1u);
+    ticket = (unsigned)__builtin_amdgcn_readfirstlane((int)ticket);
+    if (ticket >= total) break;
+    const unsigned band = ticket / per_band;
+    const unsigned idx = ticket - band * per_band;
+    const unsigned group = idx / nprob;       // consecutive tickets: the same columns of the batch's reference images
+    const unsigned prob = idx - group * nprob;
+    const PmParams& p = pp[prob];
+    const int S = p.S, M = p.num_samples, C = p.C;
+    const int RW = rot_width(p), RH = rot_height(p);
+    const int col0 = group * C;
+    const int r0 = (int)band * p.band_rows;
+    if (col0 >= RW || r0 >= RH) continue;
+    const int r1 = min(RH, r0 + p.band_rows);
+    const int ncols = min(C, RW - col0);
+    const float* iK = p.refInvK;
+    // the band above (older ticket: held by a running wave or finished)
+    if (band > 0)
+      while (__hip_atomic_load(p.band_done + group, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (int)band)
+        __builtin_amdgcn_s_sleep(16);
+    __threadfence();
+    Lds L;
+    lds_bind(L, (lds_char*)smem, lds_offsets_wave(p.C, p.S, p.radius, p.ntaps, p.num_samples, GEOM, false, false, false, CAPT, 1));
+    tap_geom_init(L.tapg, tid, p.step, (p.rot & 1) != 0);
+    lds_load_poses(p, L, GEOM, tid, nt);
+    const int words = C * (kRngWords + S + 4);       // state record of a column group
+    float* state = p.band_state + (size_t)group * words;
+    Rng rng;
+    rng.x0 = rng.x1 = rng.x2 = rng.x3 = rng.x4 = rng.d = 0;
+    const bool col_lane = tid < ncols;
+    if (band == 0) {
+      // ---- backward messages for all rows (:976-989); stored in sel_out ----------
+      for (int item = tid; item < ncols * S; item += nt) {
+        const int c = item / S;
+        const int s = item - c * S;
+        float beta = 0.5f;
+        for (int row = (p.ablate & 4) ? -1 : RH - 1; row >= 0; --row) {
+          float* rec = p.rec + (size_t)pix_index(p, row, col0 + c) * p.rec_stride;
+          beta = hmm_message<false>(p, rec[4 + s], beta);
+          rec[p.sel_out_off + s] = beta;
+        }
+        L.fm[c * S + s] = 0.5f;
+      }
+      // ---- per-column state kept by the column's lane (:1022-1028) ---------------
+      if (col_lane) {
+        const int pix0 = pix_index(p, 0, col0 + tid);
+        rng = rng_load(p.rng + (size_t)pix0 * kRngWords);
+        const float* rec = p.rec + (size_t)pix0 * p.rec_stride;
+        float sx, sy;
+        normal_to_sweep(p.rot, rec[1], rec[2], sx, sy);
+        lds_f32* h1 = L.hyp + (tid * 5 + 1) * 4;
+        h1[0] = rec[0]; h1[1] = sx; h1[2] = sy; h1[3] = rec[3];
+      }
+    } else {
+      // ---- the column group's state at the end of the band above -------------------
+      for (int item = tid; item < ncols * S; item += nt) L.fm[item] = state[C * kRngWords + item];
+      if (col_lane) {
+        rng = rng_load((const uint32_t*)state + tid * kRngWords);
+        lds_f32* h1 = L.hyp + (tid * 5 + 1) * 4;
+        const float* hs = state + C * (kRngWords + S) + tid * 4;
+        h1[0] = hs[0]; h1[1] = hs[1]; h1[2] = hs[2]; h1[3] = hs[3];
+      }
+    }
+    for (int r = r0 - p.radius; r < r0 + p.radius; ++r) tile_load_row(p, L, col0, r, tid, nt);
+    wave_sync<NW>();
+
+    const int tid0 = tid_entry;
+    unsigned evals = 0;  // NCC evaluations of this item (< 2^32: RH * C * (4 M + S) per sweep)
+    for (int row = r0; row < r1; ++row) {
+      // The lane id is laundered through an empty asm once per row: everything the phases derive from
+      // it (item -> column / view, LDS addresses) is then recomputed per row instead of being hoisted
+      // out of the row loop and held in VGPRs across the NCC loop, whose two gather stages need them.
+      int tid = tid0;
+      asm volatile("" : "+v"(tid));
+      const bool col_lane = tid < ncols;
+      if (p.trace && (row & 127) == 0 && tid == 0)  // debug: pm_enable_progress_trace
+        p.trace[(size_t)group * p.trace_stride + (row >> 7)] = __builtin_amdgcn_s_memrealtime();
+      // ---- P0: scroll the reference tile (LocalRefImage::Read, :357-410) -------
+      tile_load_row(p, L, col0, row + p.radius, tid, nt);
+      if (tid == 0) { L.ntasks[0] = 0; L.ntasks[1] = 0; }
+      wave_sync<NW>();
+
+      // ---- P1: hypotheses (lane per column) + patch weights (all lanes) --------
+      if (col_lane && !(p.ablate & 2)) {
+        const int c = tid;
+        const int col = col0 + c;
+        const int pix = pix_index(p, row, col);
+        const float* rec = p.rec + (size_t)pix * p.rec_stride;
+        lds_f32* h = L.hyp + c * 20;
+        h[4] = propagate_depth(iK, h[4], h[6], h[7], (float)(row - 1), (float)row);
+        const float cd = rec[0];
+        float cn0, cn1;
+        normal_to_sweep(p.rot, rec[1], rec[2], cn0, cn1);
+        const float cn2 = rec[3];
+        const float dmin = (1.0f - p.perturbation) * cd;
+        const float dmax = (1.0f + p.perturbation) * cd;
+        const float rd = rng_uniform(rng) * (dmax - dmin) + dmin;
+        float rn0, rn1, rn2;
+        perturb_normal(iK, row, col, p.perturbation_pi, cn0, cn1, cn2, rng, rn0, rn1, rn2);
+        for (int m = 0; m < M; ++m) L.us[c * M + m] = rng_uniform(rng) - FLT_EPSILON;  // :1129
+        h[0] = cd; h[1] = cn0; h[2] = cn1; h[3] = cn2;
+        h[8] = rd; h[9] = rn0; h[10] = rn1; h[11] = rn2;
+        h[12] = cd; h[13] = rn0; h[14] = rn1; h[15] = rn2;
+        h[16] = rd; h[17] = cn0; h[18] = cn1; h[19] = cn2;
+        lds_f32* cf = L.colf + c * 8;
+        cf[0] = p.ref_sum[pix];
+        cf[1] = p.ref_sqsum[pix];
+        cf[2] = cd * (iK[0] * col + iK[1]);
+        cf[3] = cd * (iK[2] * row + iK[3]);
+        cf[4] = cd;
+      }
+      patch_weights(p, L, row, tid, nt);
+      for (int item = tid; item < ncols * 4 * S; item += nt) L.ncc[item] = -1.0f;
+      wave_sync<NW>();
+
+      // ---- P2: per-view selection priors (:1070-1104), lane per (column, view) --
+      patch_weight_sums(p, L, ncols, tid, nt);
+      for (int item = tid; item < ncols * S; item += nt) {
+        const int c = item / S;
+        const int s = item - c * S;
+        const int col = col0 + c;
+        const float* rec = p.rec + (size_t)pix_index(p, row, col) * p.rec_stride;
+        const typename PoseSrc<PG>::ptr pose = PoseSrc<PG>::get(p, L, s);
+        const lds_f32* h = L.hyp + c * 20;
+        const lds_f32* cf = L.colf + c * 8;
+        const float cost = rec[4 + s];
+        const float beta = rec[p.sel_out_off + s];
+        const float prev = rec[p.sel_in_off + s];
+        if (!LEAN) {
+          L.costv[item] = cost;
+          L.betav[item] = beta;
+          L.prevv[item] = prev;
+        }
+        const float alpha = hmm_message<true>(p, cost, L.fm[item]);
+        const float sp = sel_prob_fn(alpha, beta, prev, p.prev_sel_prob_weight);
+        float cos_tri, cos_inc;
+        viewing_angles(pose, cf[2], cf[3], cf[4], h[1], h[2], h[3], cos_tri, cos_inc);
+        const float tp = tri_prob(p, cos_tri);
+        const float ip = inc_prob(p, cos_inc);
+        float Hm[9];
+        compose_homography(iK, pose, row, col, h[0], h[1], h[2], h[3], Hm);
+        const float rp = res_prob(Hm, (float)row, (float)col, p.radius);
+        L.q[item] = sp * tp * ip * rp;
+      }
+      wave_sync<NW>();
+
+      // ---- P3a: TransformPDFToCDF (:683-696), sequential sum order, lane per column
+      if (col_lane) {
+        const int c = tid;
+        lds_f32* q = L.q + c * S;
+        float prob_sum = 0.0f;
+  #pragma unroll 4
+        for (int i = 0; i < S; ++i) prob_sum += q[i];
+        const float inv_prob_sum = 1.0f / prob_sum;
+        float cum = 0.0f;
+  #pragma unroll 4
+        for (int i = 0; i < S; ++i) {
+          cum += q[i] * inv_prob_sum;
+          q[i] = cum;
+        }
+      }
+      wave_sync<NW>();
+      // ---- P3b: Monte-Carlo view draws (:1128-1138), lane per (column, draw) ----
+      for (int item = tid; item < ncols * M; item += nt) {
+        const int c = item / M;
+        const float u = L.us[item];
+        const lds_f32* q = L.q + c * S;
+        int src = -1;
+        for (int s = 0; s < S; ++s) {
+          if (q[s] > u) { src = s; break; }
+        }
+        L.sv[item] = src;
+      }
+      wave_sync<NW>();
+      // ---- P3c: one task set per distinct drawn view, lane per (column, view) ---
+      {
+        LDS_AS uint16_t* tasks = (LDS_AS uint16_t*)L.tasks;
+        for (int item = tid; item < ncols * S; item += nt) {
+          const int c = item / S;
+          const int s = item - c * S;
+          bool drawn = false;
+          for (int m = 0; m < M; ++m) drawn |= (L.sv[c * M + m] == s);
+          if (drawn) {
+            const int base = __hip_atomic_fetch_add(L.ntasks, 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            for (int i = 1; i < 5; ++i) tasks[base + i - 1] = (uint16_t)task16_pack(c, i, s, 0);
+            if (GEOM) {
+              const int gb = __hip_atomic_fetch_add(L.ntasks + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              tasks[wave_max_tasks(C, S, M) + gb] = (uint16_t)task16_pack(c, 0, s, 1);
+            }
+          }
+        }
+      }
+      wave_sync<NW>();
+
+      // ---- P4: NCC of hypotheses 1..4 against the drawn views (:1157-1172) -----
+      if (!(p.ablate & 1)) run_tasks_wave<GEOM, PIPE, PG, LEAN, NW, CAPT>(p, L, row, col0, tid, evals);
+      if (tid == 0) { L.ntasks[0] = 0; L.ntasks[1] = 0; }
+      wave_sync<NW>();
+
+      // ---- P5a: accumulate in draw order (:1144-1172), lane per (column, hypothesis)
+      for (int item = tid; item < ncols * 5; item += nt) {
+        const int c = item / 5;
+        const int i = item - c * 5;
+        float acc = 0.0f;
+        for (int m = 0; m < M; ++m) {
+          const int src = L.sv[c * M + m];
+          if (src < 0) continue;
+          if (i == 0) acc += LEAN ? p.rec[(size_t)pix_index(p, row, col0 + c) * p.rec_stride + 4 + src] : L.costv[c * S + src];
+          else acc += L.ncc[(c * 4 + i - 1) * S + src];
+          if (GEOM) acc += p.geom_reg * L.geo[(c * 5 + i) * S + src];
+        }
+        L.csum[item] = acc;
+      }
+      wave_sync<NW>();
+      // ---- P5b: argmin, store, next row's previous state (:1176-1182,1279-1282) --
+      if (col_lane) {
+        const int c = tid;
+        int min_idx = 0;
+        float min_cost = L.csum[c * 5];
+  #pragma unroll
+        for (int i = 1; i < 5; ++i) {
+          const float ci = L.csum[c * 5 + i];
+          if (ci <= min_cost) { min_cost = ci; min_idx = i; }
+        }
+        L.best[c] = min_idx;
+        const lds_f32* hb = L.hyp + (c * 5 + min_idx) * 4;
+        const float bd = hb[0], b0 = hb[1], b1 = hb[2], b2 = hb[3];
+        float* rec = p.rec + (size_t)pix_index(p, row, col0 + c) * p.rec_stride;
+        float nx, ny;
+        normal_from_sweep(p.rot, b0, b1, nx, ny);
+        rec[0] = bd; rec[1] = nx; rec[2] = ny; rec[3] = b2;
+        lds_f32* h1 = L.hyp + (c * 5 + 1) * 4;
+        h1[0] = bd; h1[1] = b0; h1[2] = b1; h1[3] = b2;
+      }
+      wave_sync<NW>();
+      // ---- P5c: winner vs. the views not evaluated yet, lane per (column, view) --
+      {
+        LDS_AS uint16_t* tasks = (LDS_AS uint16_t*)L.tasks;
+        for (int item = tid; item < ncols * S; item += nt) {
+          const int c = item / S;
+          const int s = item - c * S;
+          const int k = L.best[c];
+          if (k != 0 && L.ncc[(c * 4 + k - 1) * S + s] < 0.0f) {
+            const int base = __hip_atomic_fetch_add(L.ntasks, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            tasks[base] = (uint16_t)task16_pack(c, k, s, 0);
+          }
+        }
+      }
+      wave_sync<NW>();
+
+      // ---- P6: NCC of the winner against the remaining views (:1188-1197) ------
+      if (!(p.ablate & 1)) run_tasks_wave<false, PIPE, PG, LEAN, NW, CAPT>(p, L, row, col0, tid, evals);
+
+      // ---- P7: cost map, forward message, selection probability (:1186-1207) ---
+      for (int item = tid; item < ncols * S; item += nt) {
+        const int c = item / S;
+        const int s = item - c * S;
+        const int col = col0 + c;
+        const int k = L.best[c];
+        float* rec = p.rec + (size_t)pix_index(p, row, col) * p.rec_stride;
+        float cost;
+        if (k == 0) {
+          cost = LEAN ? rec[4 + s] : L.costv[item];
+        } else {
+          cost = L.ncc[(c * 4 + k - 1) * S + s];
+          rec[4 + s] = cost;
+        }
+        const float alpha = hmm_message<true>(p, cost, L.fm[item]);
+        const float beta_ = LEAN ? rec[p.sel_out_off + s] : L.betav[item];  // the backward message, until the store below
+        const float prev_ = LEAN ? rec[p.sel_in_off + s] : L.prevv[item];
+        const float prob = sel_prob_fn(alpha, beta_, prev_, p.prev_sel_prob_weight);
+        L.fm[item] = alpha;
+        rec[p.sel_out_off + s] = prob;
+        if (FILTER_PHOTO || FILTER_GEOM) {
+          const lds_f32* hb = L.hyp + (c * 5 + 1) * 4;  // == best (stored in P5)
+          const typename PoseSrc<PG>::ptr pose = PoseSrc<PG>::get(p, L, s);
+          const float bp0 = hb[0] * (iK[0] * col + iK[1]);
+          const float bp1 = hb[0] * (iK[2] * row + iK[3]);
+          const float bp2 = hb[0];
+          float cos_tri, cos_inc;
+          viewing_angles(pose, bp0, bp1, bp2, hb[1], hb[2], hb[3], cos_tri, cos_inc);
+          int ok = 0;
+          if (!(cos_tri > p.filter_cos_min_tri || cos_inc <= 0.0f)) {
+            const float min_ncc_prob = ncc_prob(p, 1.0f - p.filter_min_ncc);
+            bool photo_ok = true, geom_ok = true;
+            if (FILTER_PHOTO) photo_ok = prob >= min_ncc_prob;
+            if (FILTER_GEOM)
+              geom_ok = geom_cost(p, pose, s, (float)row, (float)col, hb[0]) <= p.filter_geom_max_cost;
+            ok = (photo_ok && geom_ok) ? 1 : 0;
+          }
+          L.flags[item] = ok;
+        }
+      }
+      if (FILTER_PHOTO || FILTER_GEOM) {
+        wave_sync<NW>();
+        if (col_lane) {
+          const int c = tid;
+          int num = 0;
+          for (int s = 0; s < S; ++s) num += L.flags[c * S + s];
+          const int pix = pix_index(p, row, col0 + c);
+          if (num < p.filter_min_num_consistent) {
+            float* rec = p.rec + (size_t)pix * p.rec_stride;
+            rec[0] = 0.0f; rec[1] = 0.0f; rec[2] = 0.0f; rec[3] = 0.0f;
+          } else {
+            for (int s = 0; s < S; ++s)
+              if (L.flags[c * S + s]) p.mask[(size_t)s * p.W * p.H + pix] = 1;
+          }
+        }
+      }
+      wave_sync<NW>();
+    }
+
+
+    if (r1 == RH) {
+      if (col_lane) rng_store(p.rng + (size_t)pix_index(p, 0, col0 + tid) * kRngWords, rng);  // :1285-1287
+    } else {
+      for (int item = tid; item < ncols * S; item += nt) state[C * kRngWords + item] = L.fm[item];
+      if (col_lane) {
+        rng_store((uint32_t*)state + tid * kRngWords, rng);
+        const lds_f32* h1 = L.hyp + (tid * 5 + 1) * 4;
+        float* hs = state + C * (kRngWords + S) + tid * 4;
+        hs[0] = h1[0]; hs[1] = h1[1]; hs[2] = h1[2]; hs[3] = h1[3];
+      }
+    }
+    if (tid == 0 && p.evals) atomicAdd(p.evals, (unsigned long long)evals);
+    __threadfence();   // the band's stores (pixel records, state) before the counter
+    if (tid == 0) __hip_atomic_store(p.band_done + group, (int)band + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    wave_sync<NW>();   // LDS is reused by the next item
+  }
+}
+
+template <bool GEOM, bool FILTER_PHOTO, bool FILTER_GEOM>
+__global__ void __launch_bounds__(64, 4) pm_sweep_band_kernel(const PmParams* __restrict__ pp) {
+  sweep_band_body<GEOM, FILTER_PHOTO, FILTER_GEOM, kWaveThCap>(pp);
+}
+
 // Two builds of the same body: the software-pipelined one (3 waves per SIMD, 4 KB gather ring in
 // LDS) and the plain one (4 waves per SIMD by registers, no ring).
 template <bool GEOM, bool FILTER_PHOTO, bool FILTER_GEOM>
@@ -2537,6 +2898,30 @@ void pm_launch_sweep(const PmParams& p, const PmParams* dev_params, int batch, i
     dim3 wblock(64, 1, 1);
     dim3 wgrid = grid;
     if (p.xcd_map == 2) wgrid.x = ((grid.x + 63) / 64) * 64;
+    // Experimental: band-scheduled persistent waves (sweep_band_body). The caller (pm_api.cpp) has filled the band
+    // fields of the parameter blocks when COLMAP_AMD_PM_BAND is set; the grid is what is resident at once.
+    if (p.band_ticket && !pipe && !lean && !w5 && !pg) {
+      const size_t blds = lds_offsets_wave(p.C, p.S, p.radius, p.ntaps, p.num_samples, geom, false, false, false, kWaveThCap, 1).total + lds_pad;
+      int dev = 0, cus = 0, per_cu = 0;
+      (void)hipGetDevice(&dev);
+      (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+      const long long items = (long long)p.band_nprob * p.band_groups * p.band_count;
+#define PM_LAUNCH_B(G, FP, FG)                                                                               \
+  do {                                                                                                       \
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pm_sweep_band_kernel<G, FP, FG>, 64, blds);  \
+    const long long resident = (long long)std::max(per_cu, 1) * std::max(cus, 1);                            \
+    hipLaunchKernelGGL((pm_sweep_band_kernel<G, FP, FG>), dim3((unsigned)std::min(items, resident)), wblock, blds, st, dev_params); \
+  } while (0)
+      if (geom) {
+        if (filter_photo && filter_geom) PM_LAUNCH_B(true, true, true);
+        else PM_LAUNCH_B(true, false, false);
+      } else {
+        if (filter_photo) PM_LAUNCH_B(false, true, false);
+        else PM_LAUNCH_B(false, false, false);
+      }
+#undef PM_LAUNCH_B
+      return;
+    }
     // Four-wave workgroups with shared read-only tables (pm_sweep_quad_kernel) when four of them fit a CU, i.e.
     // the same 16 waves per CU as the single-wave kernel at its best: with 64 task slots per batch if that
     // fits, else with 40. COLMAP_AMD_PM_QUAD=0 keeps the single-wave workgroups.

@@ -8,6 +8,8 @@ The oracle runs in `order=1` (the kernel's evaluation order of the NCC sums);
 tests/test_pm_oracle.py bounds the difference between that order and the
 reference's sequential order (`order=0`).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -138,6 +140,23 @@ def test_four_wave_workgroups_equal_single_wave_workgroups(pm_oracle, monkeypatc
         maps = [(v.depth.copy(), v.normal.copy()) for v in views]
     want, got, _ = _run_both(pm_oracle, views, 3, [0, 1, 2, 4, 5, 6], maps=maps, geom_consistency=geom, filter=1,
                              num_iterations=1)
+    _assert_equal(want, got)
+
+
+@pytest.mark.skipif(not os.environ.get("COLMAP_AMD_TEST_EXPERIMENTAL"),
+                    reason="experimental band-scheduled sweep kernel (never run on a GPU yet): COLMAP_AMD_TEST_EXPERIMENTAL=1")
+@pytest.mark.parametrize("band_rows", ["16", "7", "64"])
+@pytest.mark.parametrize("geom", [0, 1])
+def test_band_scheduled_sweep_equals_oracle(pm_oracle, monkeypatch, band_rows, geom):
+    """COLMAP_AMD_PM_BAND=1: persistent waves take (band of rows, column group, problem) items in band-major order and
+    hand a column group's state from band to band through global memory (pm_kernels.hip: sweep_band_body). The schedule
+    must not change a bit: bands of 16, 7 (ragged: 45 and 67 rows are no multiples) and 64 (one band) rows."""
+    monkeypatch.setenv("COLMAP_AMD_PM_BAND", "1")
+    monkeypatch.setenv("COLMAP_AMD_PM_BAND_ROWS", band_rows)
+    views = scene(7, 67, 45)
+    maps = [(v.depth.copy(), v.normal.copy()) for v in views] if geom else None
+    want, got, _ = _run_both(pm_oracle, views, 3, [0, 1, 2, 4, 5, 6], maps=maps, geom_consistency=geom, filter=1,
+                             num_iterations=2)
     _assert_equal(want, got)
 
 
