@@ -665,6 +665,10 @@ void RunBatchAsync(pm_handle** hs, int n) {
       // exponentially reduce the perturbation, linearly increase the influence of the
       // previous selection probabilities (reference :1446-1451)
       p.perturbation = 1.0f / std::pow(2.0f, iter + sweep / 4.0f);
+      {  // diagnostic only (results are garbage): fixed perturbation, to time a launch without far-flung random hypotheses
+        static const char* e = getenv("COLMAP_AMD_PM_DIAG_PERT");
+        if (e) p.perturbation = (float)atof(e);
+      }
       p.perturbation_pi = (float)(p.perturbation * M_PI);
       p.prev_sel_prob_weight = (float)(iter * 4 + sweep) / total_num_steps;
       p.sel_out_off = sel_out;
@@ -672,6 +676,7 @@ void RunBatchAsync(pm_handle** hs, int n) {
       p.xcd_map = xcd_map;
       static const int ablate_env = [] { const char* e = getenv("COLMAP_AMD_PM_ABLATE"); return e ? atoi(e) : 0; }();
       p.ablate = ablate_env;
+      { const char* e = getenv("COLMAP_AMD_PM_ROWSYNC"); p.rowsync = e ? atoi(e) : 0; }
       if (band_rows > 0) {  // experimental band-scheduled kernel: pm_kernels.hip, sweep_band_body
         const int rw = (p.rot & 1) ? p.H : p.W, rh = (p.rot & 1) ? p.W : p.H;
         p.band_state = hs[b]->band_state.ptr;
@@ -997,6 +1002,15 @@ int pm_get_sweep_timing(pm_handle* h, double* total_ms, int32_t* num_launches) {
     PM_CHECK(h, "null");
     if (total_ms) *total_ms = h->sweep_ms;
     if (num_launches) *num_launches = h->sweep_launches;
+  });
+}
+
+int pm_get_sweep_times(pm_handle* h, float* ms, int32_t capacity, int32_t* num_launches) {
+  return Guard([&] {
+    PM_CHECK(h && num_launches, "null");
+    *num_launches = h->sweep_launches;
+    for (int i = 0; ms && i < h->sweep_launches && i < capacity; ++i)
+      HIP_CALL(hipEventElapsedTime(&ms[i], h->ev[2 * i], h->ev[2 * i + 1]));
   });
 }
 

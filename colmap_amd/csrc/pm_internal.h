@@ -39,6 +39,7 @@ struct PmParams {
   int C;            // image columns per workgroup
   int ablate;       // profiling only (COLMAP_AMD_PM_ABLATE): bit 0 skip the NCC task passes, bit 1 skip the
                     // hypothesis generation, bit 2 skip the backward-message pre-pass; results are garbage
+  int rowsync;      // experiment: workgroup barrier every `rowsync` rows of the multi-wave sweep kernels (0 = never)
   int xcd_map;      // batched launch: 0 problem = id % batch, 1 neighbouring problems per XCD
   float refK[4];    // rotated {fx, cx, fy, cy}
   float refInvK[4]; // rotated {1/fx, -cx/fx, 1/fy, -cy/fy}

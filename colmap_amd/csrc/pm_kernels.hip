@@ -1284,6 +1284,13 @@ __device__ __forceinline__ void ncc_front(const PmParams& p, const lds_f32* H, g
     // 5 = entry indices wrapped into a 2 MB window per image: the lines no longer fit the L2 (36 images x 2 MB) but sit
     // in few pages and in the 256 MB infinity cache -- separates address translation / HBM from L2 capacity
     if (PM_DIAG_GATHER == 5) { a0 = fp + ((unsigned)(a0 - fp) & 0x7FFFFu); a1 = fp + ((unsigned)(a1 - fp) & 0x7FFFFu); }
+    // 6 = the 2 MB page of every entry kept, the offset inside the page wrapped into 16 KB: the product's address
+    // translations with cache-resident data -- what the TLB misses cost
+    if (PM_DIAG_GATHER == 6) {
+      const unsigned i0_ = (unsigned)(a0 - fp), i1_ = (unsigned)(a1 - fp);
+      a0 = fp + ((i0_ & ~0x7FFFFu) | (i0_ & 0xFFFu));
+      a1 = fp + ((i1_ & ~0x7FFFFu) | (i1_ & 0xFFFu));
+    }
     // 4 (row-major builds): the row of every tap rounded down to a multiple of four -- a window touches a quarter of
     // its cache lines, everything else unchanged: how the time scales with the number of lines missed
     if (PM_DIAG_GATHER == 4) {
@@ -2350,6 +2357,9 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
       }
     }
     wave_sync<NW>();
+    // experiment (COLMAP_AMD_PM_ROWSYNC=k): the waves of a workgroup meet every k rows, so that adjacent column
+    // groups gather the same source lines at the same time
+    if (NW > 1 && p.rowsync > 0 && (row + 1) % p.rowsync == 0) __syncthreads();
   }
 
   if (col_lane) {
@@ -2759,6 +2769,12 @@ __global__ void __launch_bounds__(64 * kQuadWaves, 4) pm_sweep_quad40_kernel(con
   sweep_wave_body<GEOM, FILTER_PHOTO, FILTER_GEOM, false, false, false, kQuadWaves, kWaveThCap>(pp);
 }
 
+// experiment: 8 / 16 waves per workgroup (with COLMAP_AMD_PM_ROWSYNC)
+template <bool GEOM, bool FILTER_PHOTO, bool FILTER_GEOM, int NW>
+__global__ void __launch_bounds__(64 * NW, 16 / NW) pm_sweep_strip_kernel(const PmParams* __restrict__ pp) {
+  sweep_wave_body<GEOM, FILTER_PHOTO, FILTER_GEOM, false, false, false, NW, 64>(pp);
+}
+
 // Debug: raw XORWOW streams of the generator above (seed = sequence id, as InitRandomStateKernel
 // seeds it), for the bit comparison with rocRAND's rocrand_init / rocrand_uniform in the tests.
 __global__ void pm_rng_streams_kernel(const unsigned long long* __restrict__ seeds, int nseeds, int ndraws,
@@ -2926,6 +2942,22 @@ void pm_launch_sweep(const PmParams& p, const PmParams* dev_params, int batch, i
     // the same 16 waves per CU as the single-wave kernel at its best: with 64 task slots per batch if that
     // fits, else with 40. COLMAP_AMD_PM_QUAD=0 keeps the single-wave workgroups.
     const int quad_cap = pm_quad_cap(p.C, p.S, p.radius, p.ntaps, p.num_samples, geom);
+    {
+      const char* e = getenv("COLMAP_AMD_PM_NW");
+      const int nw = e ? atoi(e) : 0;
+      if ((nw == 8 || nw == 16) && !geom && !filter_photo) {
+        const size_t slds = lds_offsets_wave(p.C, p.S, p.radius, p.ntaps, p.num_samples, geom, false, false, false, 64, nw).total;
+        dim3 sgrid((grid.x + nw - 1) / nw, grid.y, 1);
+        if (nw == 8) {
+          (void)hipFuncSetAttribute((const void*)pm_sweep_strip_kernel<false, false, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds);
+          hipLaunchKernelGGL((pm_sweep_strip_kernel<false, false, false, 8>), sgrid, dim3(512), slds, st, dev_params);
+        } else {
+          (void)hipFuncSetAttribute((const void*)pm_sweep_strip_kernel<false, false, false, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds);
+          hipLaunchKernelGGL((pm_sweep_strip_kernel<false, false, false, 16>), sgrid, dim3(1024), slds, st, dev_params);
+        }
+        return;
+      }
+    }
     if (!pipe && !lean && !w5 && !pg && p.xcd_map != 2 && pm_quad_enabled() && quad_cap > 0) {
       const size_t qlds = lds_offsets_wave(p.C, p.S, p.radius, p.ntaps, p.num_samples, geom, false, false, false,
                                            quad_cap, kQuadWaves).total + lds_pad;

@@ -393,6 +393,15 @@ class PatchMatch:
         return ms.value, n.value
 
 
+    def GetSweepTimes(self):
+        """ms of every sweep launch of the last run (pm_get_sweep_times)."""
+        n = C.c_int32(0)
+        _check(lib().pm_get_sweep_times(self._h, None, 0, C.byref(n)))
+        out = (C.c_float * max(n.value, 1))()
+        _check(lib().pm_get_sweep_times(self._h, out, n.value, C.byref(n)))
+        return [out[i] for i in range(n.value)]
+
+
 def run_batch(pms: Sequence[PatchMatch], wait: bool = True):
     """Solve several same-shaped problems in one batched run (pm_run_batch): every
     kernel launch covers all of them. Bit-identical to running them one by one."""

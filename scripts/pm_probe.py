@@ -47,6 +47,7 @@ ms, n = pms[0].GetSweepTiming()
 mpix = a.w * a.h * a.conc / 1e6
 print(f"W={a.w} H={a.h} S={len(src)} conc={a.conc} C={a.cols} T={a.threads}: create {tc:.3f}s run {tr:.3f}s "
       f"-> {mpix/tr:.3f} Mpix/s (run only), {mpix/(tr+tc):.3f} incl create; sweep kernel avg {ms/max(n,1):.2f} ms x{n}")
+print("per launch ms: " + " ".join(f"{v:.0f}" for v in pms[0].GetSweepTimes()))
 if a.prof:
     pr = pms[0].GetPhaseProfile(); tot = sum(pr)
     names = ["setup+backward", "P0 tile", "P1 hyp+weights", "P2 priors", "P3 cdf+draws", "P4 ncc", "P5 argmin", "P6 ncc-winner", "P7-8 update", "-"]
