@@ -173,6 +173,7 @@ def ba_secondary(a, local_rank, with_cpu, rank=0, world=1, dev=None):
         # bundle_adjustment_ceres.cc:203-213): exact Newton steps from the explicitly formed reduced camera system,
         # blocked Cholesky on the f64 matrix cores (colmap_amd/csrc/ba_schur_explicit.hip). Reported beside the
         # benchmarked Schur-PCG tier: which one is faster per LM iteration, and how far each has come.
+        n_c = int(est.num_camera_parameters(fp))
         se = est.solve_flat(fp.copy(), est.SolverOptions(max_num_iterations=min(a.ba_iters, 6),
                                                          linear_solver_type=est.SOLVER_SPARSE_SCHUR), gpu_index=local_rank)
         out["exact_tier"] = {
@@ -180,10 +181,12 @@ def ba_secondary(a, local_rank, with_cpu, rank=0, world=1, dev=None):
             "LM_iterations_per_s": se.num_iterations / max(se.lm_seconds, 1e-12), "lm_iterations": se.num_iterations,
             "cost": [se.initial_cost, se.final_cost], "tier_used": se.linear_solver_used,
             "mfma_time_frac": se.factor_seconds / max(se.lm_seconds, 1e-12),
-            "cholesky_tflops": (out["config"].get("n_c", 0) or 0) and None,
+            # n_c^3 / 3 flop per factorisation of the reduced camera system (one per LM iteration) over the time
+            # inside the blocked Cholesky; n_c = variable camera parameters (6 per pose + intrinsics - gauge)
+            "cholesky_tflops": n_c ** 3 / 3.0 * se.num_iterations / max(se.factor_seconds, 1e-12) / 1e12,
+            "reduced_system_size": n_c,
             "faster_tier_per_lm_iteration": "ITERATIVE_SCHUR (PCG)" if out["value"] > se.num_iterations / max(se.lm_seconds, 1e-12)
                                             else "SPARSE_SCHUR"}
-        del out["exact_tier"]["cholesky_tflops"]
     if sharded:
         out["sharded"] = sharded
     if with_cpu and world == 1:
@@ -220,19 +223,25 @@ def ba_pmc_traffic(n_obs):
         return None
 
 
-def pmc_traffic(images_per_launch):
+def pmc_traffic(images_per_launch, kernel):
     """HBM-side bytes per sweep launch from the committed rocprofv3 PMC passes (FETCH_SIZE +
-    WRITE_SIZE of pm_sweep_kernel, scripts/profile_pm.sh; counters cannot be read from inside
-    this process). None when no pass matches this launch shape."""
+    WRITE_SIZE of the sweep kernel, scripts/profile_pm.sh; counters cannot be read from inside
+    this process). None unless the passes were taken on THIS kernel, image layout and launch shape."""
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pm_sweep_traffic.json")
     try:
         with open(path) as f:
             t = json.load(f)
-        if int(t["images_per_launch"]) != int(images_per_launch):
+        if int(t["images_per_launch"]) != int(images_per_launch) or t.get("kernel") != kernel \
+                or t.get("layout") != PM_IMAGE_LAYOUT:
             return None
         return float(t["fetch_bytes_per_launch"]) + float(t["write_bytes_per_launch"])
     except (OSError, KeyError, ValueError):
         return None
+
+
+# packed source-image layout of the library this script measures (pm_internal.h: kFpStrip); a traffic file taken on
+# another layout does not describe this build
+PM_IMAGE_LAYOUT = "strips16x2-dword-footprints"
 
 
 def geometric_leg(a, views, images, cache, local_rank):
@@ -410,6 +419,7 @@ def main():
     sweep_ms, sweep_n = 0.0, 0
     evals_sweep, evals_init = 0, 0   # NCC evaluations executed in the timed steps (this rank)
     pms_keepalive = []
+    kernel_names = set()   # sweep kernels the timed steps launched (the library reports what it ran)
 
     def run_step(step, record):
         nonlocal sweep_ms, sweep_n, evals_sweep, evals_init
@@ -424,6 +434,7 @@ def main():
             for pm in pms:
                 pm.Synchronize()
         if record:
+            kernel_names.add(grps[0][0].GetSweepKernelName())
             ms, n = grps[0][0].GetSweepTiming()
             sweep_ms += ms
             sweep_n += n
@@ -455,6 +466,7 @@ def main():
         alg_bytes = (40 + 24 * S) * pix_per_image * a.batch  # one launch sweeps the whole batch
         avg_ms = sweep_ms / max(sweep_n, 1)
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+        kernel_name = " + ".join(sorted(kernel_names))
         out = {
             "metric": "PatchMatch Mpix/s @2560×1920",
             "value": value,
@@ -477,18 +489,18 @@ def main():
                 "shared_source_images": not a.no_image_cache,
                 "parallelism": f"reference images sharded over {world} GPU(s), no data-path collective",
             },
-            # The kernel has no dense contraction: its time is about half fp32 VALU issue (PMC:
-            # VALU 82-85 % busy) and half stalls on the cache misses of its scattered 4-byte gathers (diagnostic
-            # builds, profiles/r03_pm_gather_diag.log). `bound` says so, `achieved / peak / frac` keep the HBM figures
-            # BASELINE.json asks for (algorithmic bytes / launch time against 8 TB/s), the VALU-side figures follow.
+            # The kernel has no dense contraction. Counters (profiles/r04_pm_pmc_diagnosis.json, r04_pm_pmc_summary.json):
+            # the VALU is active 86-96 % of the launch AND the texture-address path 78 % -- both pipes are close to
+            # full at once. `bound` says so, `achieved / peak / frac` keep the HBM figures BASELINE.json asks for
+            # (algorithmic bytes / launch time against 8 TB/s), the VALU-side figures follow.
             "roofline": {
-                "bound": "valu-fp32 issue + gather-miss stalls (HBM fraction reported as BASELINE.json asks)",
-                "kernel": "pm_sweep_quad_kernel",
+                "bound": "valu-fp32 issue and texture-address (gather) rate, both > 78 % busy (HBM fraction reported as BASELINE.json asks)",
+                "kernel": kernel_name,
                 "achieved": achieved,
                 "peak": 8000.0,
                 "unit": "GB/s",
                 "frac": achieved / 8000.0,
-                "traffic": pmc_traffic(a.batch),
+                "traffic": pmc_traffic(a.batch, kernel_name),
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "avg_launch_ms": avg_ms,
                 "launches_timed": sweep_n,
@@ -499,12 +511,12 @@ def main():
                 "taps_per_s": (evals_sweep + evals_init) * 121 / dt,
                 "valu_frac": (evals_sweep + evals_init) * 121 * 30.0 / dt / 157.3e12,
                 "ncc_evaluations_per_pixel_per_sweep": evals_sweep / max(a.steps * a.batch * a.groups * pix_per_image * 20, 1),
-                "note": "kernel without a dense contraction: VALU 82-85 % busy by PMC, yet with every gather forced onto "
-                        "cached lines the launch takes 280-340 ms instead of ~600 (profiles/r03_pm_gather_diag.log, "
-                        "DESIGN.md 1.5): taps_per_s / valu_frac carry the useful arithmetic; the HBM fraction is "
-                        "reported because BASELINE.json asks for it. traffic = FETCH_SIZE + WRITE_SIZE of "
-                        "profiles/pm_sweep_traffic.json (4-byte footprint gathers, ~35x the algorithmic bytes; "
-                        "measured before the tiled image layout)",
+                "note": "kernel without a dense contraction: by PMC the VALU is active 86 % of the launch and the "
+                        "texture-address unit 78 % (gathers of 64 scattered dwords, ~40 L1 accesses each); "
+                        "taps_per_s / valu_frac carry the useful arithmetic; the HBM fraction is reported because "
+                        "BASELINE.json asks for it. traffic = FETCH_SIZE + WRITE_SIZE per launch from "
+                        "profiles/pm_sweep_traffic.json, null unless that file was measured on this kernel and "
+                        "image layout (DESIGN.md 1.5)",
             },
         }
         # the CPU baseline and the secondary (single-GPU) BA measurement belong to the N = 1 run only

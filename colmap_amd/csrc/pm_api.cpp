@@ -267,11 +267,109 @@ void CheckProblem(const pm_options& o, const pm_problem& p) {
 
 }  // namespace
 
+// Packed source images come out of slabs of equally sized slots (one hipMalloc per slab, at most 3.5 GB):
+// the images of a problem are then neighbours in the address space, which is what lets the 11 x 11 sweep kernels
+// address all of them through ONE buffer resource (pm_kernels.hip: fp_resource -- every image must end within 4 GB
+// of the lowest one). A problem whose sources straddle two slabs that lie further apart takes the explicit-index
+// build of the kernels instead; nothing else depends on the slabs. Slots return to their slab when the last
+// problem (or the image cache) drops the image; pm_release_cached_memory() frees the slabs that are empty.
+class FpSlabPool {
+ public:
+  static FpSlabPool& Get() {
+    static FpSlabPool* pool = new FpSlabPool();  // leaked on purpose, like DevPool
+    return *pool;
+  }
+  uint32_t* Take(size_t bytes) {
+    int dev = 0;
+    HIP_CALL(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu_);
+    for (auto it = slabs_.rbegin(); it != slabs_.rend(); ++it)
+      if (it->dev == dev && it->slot_bytes == bytes && !it->free_slots.empty()) {
+        const int k = it->free_slots.back();
+        it->free_slots.pop_back();
+        return reinterpret_cast<uint32_t*>(it->base + (size_t)k * bytes);
+      }
+    Slab sl;
+    sl.dev = dev;
+    sl.slot_bytes = bytes;
+    // slab size: 3.5 GB for full-size images (178 slots at 2560 x 1920), 256 MB for small ones
+    const size_t target = bytes >= (4u << 20) ? (size_t)(3.5 * (1ull << 30)) : (256u << 20);
+    int n = (int)std::max<size_t>(1, std::min<size_t>(4096, target / bytes));
+    void* p = nullptr;
+    hipError_t e = hipErrorOutOfMemory;
+    for (; n >= 1; n /= 2) {  // a slab that does not fit any more shrinks down to a single slot
+      e = hipMalloc(&p, (size_t)n * bytes);
+      if (e == hipSuccess) break;
+      (void)hipGetLastError();
+      if (n == 1) break;
+    }
+    if (e == hipErrorOutOfMemory) {
+      DevPool::Get().Release();
+      n = 1;
+      e = hipMalloc(&p, bytes);
+    }
+    HIP_CALL(e);
+    sl.base = static_cast<char*>(p);
+    sl.nslots = n;
+    for (int k = n - 1; k >= 1; --k) sl.free_slots.push_back(k);
+    slabs_.push_back(sl);
+    return reinterpret_cast<uint32_t*>(sl.base);
+  }
+  void Give(uint32_t* ptr) {
+    std::lock_guard<std::mutex> lock(mu_);
+    char* c = reinterpret_cast<char*>(ptr);
+    for (auto& sl : slabs_)
+      if (c >= sl.base && c < sl.base + (size_t)sl.nslots * sl.slot_bytes) {
+        sl.free_slots.push_back((int)((c - sl.base) / sl.slot_bytes));
+        return;
+      }
+  }
+  void Release() {  // frees the slabs none of whose slots is in use
+    std::lock_guard<std::mutex> lock(mu_);
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    size_t keep = 0;
+    for (size_t i = 0; i < slabs_.size(); ++i) {
+      if ((int)slabs_[i].free_slots.size() == slabs_[i].nslots) {
+        (void)hipSetDevice(slabs_[i].dev);
+        (void)hipFree(slabs_[i].base);
+      } else {
+        if (keep != i) slabs_[keep] = std::move(slabs_[i]);
+        ++keep;
+      }
+    }
+    slabs_.resize(keep);
+    (void)hipSetDevice(cur);
+  }
+
+ private:
+  struct Slab {
+    char* base = nullptr;
+    size_t slot_bytes = 0;
+    int nslots = 0, dev = 0;
+    std::vector<int> free_slots;
+  };
+  std::mutex mu_;
+  std::vector<Slab> slabs_;
+};
+
+struct FpBuf {
+  uint32_t* ptr = nullptr;
+  size_t count = 0;
+  void alloc(size_t n) {
+    ptr = FpSlabPool::Get().Take(n * sizeof(uint32_t));
+    count = n;
+  }
+  ~FpBuf() {
+    if (ptr) FpSlabPool::Get().Give(ptr);
+  }
+};
+
 // A packed source image (2x2 footprints + zero ring) in HBM. Shared between problems through
 // pm_image_cache: neighbouring reference images use mostly the same sources (28 distinct images
 // for 8 consecutive references with S = 20), so a batch gathers from one copy instead of eight.
 struct FpEntry {
-  DevBuf<uint32_t> data;
+  FpBuf data;
 };
 
 struct pm_image_cache {
@@ -322,9 +420,9 @@ struct pm_handle {
   DevBuf<float> out_depth, out_normal, out_sel, out_cost;
   DevBuf<unsigned long long> prof;
   DevBuf<unsigned long long> trace;  // progress trace of the last sweep launch (debug)
-  DevBuf<float> band_state;          // band-scheduled sweep kernel (experimental): state records, counters, ticket
-  DevBuf<int> band_done;
-  DevBuf<unsigned> band_ticket;
+  DevBuf<uint32_t> src_fp_off;       // [S] the packed source images as slots of the problem's buffer resource
+  const uint32_t* fp_base = nullptr; // its base (lowest address among them); null: the images lie too far apart
+  const char* sweep_kernel = "";     // kernel of the last sweep launch (pm_get_sweep_kernel_name)
   DevBuf<unsigned long long> evals;  // NCC evaluations of the sweep launches of the last run
   DevBuf<PmParams> plan;  // per-launch parameter blocks of the last (batched) run
   hipStream_t run_stream = nullptr;  // stream the last run was enqueued on
@@ -489,6 +587,26 @@ void Create(const pm_options& opt_in, const pm_problem& prob, pm_image_cache* ca
     h->src_fp_tab.alloc(S);
     HIP_CALL(hipMemcpyAsync(h->src_fp_tab.ptr, tab.data(), S * sizeof(const uint32_t*), hipMemcpyHostToDevice,
                             h->stream));
+    // The 11 x 11 sweep kernels read all S images through ONE buffer resource when they can (pm_kernels.hip:
+    // fp_resource): base = the lowest image address, an image = the slot (address - base) / kFpStrip in the offset
+    // register. The address unit forms the buffer offset in 32 bits, so every image must END within 4 GB of the
+    // base; problems whose images lie further apart (separate allocations, shared through the image cache) take
+    // the explicit-index build of the same kernels (fp_base = null).
+    {
+      const uint32_t* lo = tab[0];
+      for (int s = 0; s < S; ++s) lo = std::min(lo, tab[s]);
+      std::vector<uint32_t> offs(S);
+      bool ok = ((uintptr_t)lo % 256) == 0;
+      for (int s = 0; s < S; ++s) {
+        const uint64_t d = (uint64_t)((const char*)tab[s] - (const char*)lo);
+        ok = ok && d % 256 == 0 && d + fp_count * sizeof(uint32_t) + 4096 < (1ull << 32);
+        offs[s] = (uint32_t)((d / kFpStrip) & 0xffffffffull);
+      }
+      h->src_fp_off.alloc(S);
+      HIP_CALL(hipMemcpyAsync(h->src_fp_off.ptr, offs.data(), S * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+      HIP_CALL(hipStreamSynchronize(h->stream));  // `offs` dies with this scope
+      h->fp_base = ok ? lo : nullptr;
+    }
     HIP_CALL(hipStreamSynchronize(h->stream));
   }
   if (opt.geom_consistency) {
@@ -528,7 +646,7 @@ void Create(const pm_options& opt_in, const pm_problem& prob, pm_image_cache* ca
   std::memset(&b, 0, sizeof(b));
   b.W = W; b.H = H; b.S = S; b.src_w = h->src_w; b.src_h = h->src_h;
   b.fp_xmax = (float)(h->src_w + kFpRingX); b.fp_ymax = (float)(h->src_h + kFpRingY);
-  b.fp_tpr1 = pm_fp_width(h->src_w) / 8 - 1;
+  b.fp_rows1 = pm_fp_height(h->src_h) - 1;
   b.radius = opt.window_radius;
   b.step = opt.window_step;
   b.ntap1d = (2 * b.radius) / b.step + 1;
@@ -567,6 +685,8 @@ void Create(const pm_options& opt_in, const pm_problem& prob, pm_image_cache* ca
   h->rng.alloc((size_t)W * H * kRngWords);
   b.rec = h->rec.ptr;
   b.src_fp_tab = h->src_fp_tab.ptr;
+  b.fp_base = h->fp_base;
+  b.src_fp_off = h->src_fp_off.ptr;
   b.src_depth = h->src_depth.ptr;
   b.ref_img = h->ref_img.ptr;
   b.ref_sum = h->ref_sum.ptr;
@@ -641,23 +761,9 @@ void RunBatchAsync(pm_handle** hs, int n) {
   static const int xcd_map_env = [] { const char* e = getenv("COLMAP_AMD_PM_XCD_MAP"); return e ? atoi(e) : 0; }();
   const int xcd_map = (xcd_map_env == 1 && n % 8 == 0) ? 1 : (xcd_map_env == 2 ? 2 : 0);
   int sel_out = h0->base.sel_out_off, sel_in = h0->base.sel_in_off;
-  // COLMAP_AMD_PM_BAND=1 (rows per band: COLMAP_AMD_PM_BAND_ROWS, default 64): the experimental band-scheduled sweep
-  // kernel for the 11 x 11 window; read per run so that the tests can switch it inside one process
-  int band_rows = 0;
-  {
-    const char* e = getenv("COLMAP_AMD_PM_BAND");
-    const char* r = getenv("COLMAP_AMD_PM_BAND_ROWS");
-    if (e && atoi(e) != 0 && h0->base.ntap1d == 11 && h0->base.C <= 8) band_rows = r && atoi(r) > 0 ? atoi(r) : 64;
-  }
-  if (band_rows > 0) {
-    const int longest = std::max(h0->W, h0->H);
-    for (int b = 0; b < n; ++b) {
-      const size_t groups = (size_t)(longest + hs[b]->base.C - 1) / hs[b]->base.C;
-      hs[b]->band_state.alloc(groups * hs[b]->base.C * (kRngWords + hs[b]->S + 4));
-      hs[b]->band_done.alloc(groups);
-    }
-    h0->band_ticket.alloc(1);
-  }
+  // one kernel serves the whole batch: buffer-resource addressing only if every problem's images allow it
+  bool fp_resource_all = true;
+  for (int b = 0; b < n; ++b) fp_resource_all = fp_resource_all && hs[b]->fp_base != nullptr;
   for (int k = 0; k < limit; ++k) {
     const int iter = k / 4, sweep = k % 4;
     for (int b = 0; b < n; ++b) {
@@ -676,17 +782,7 @@ void RunBatchAsync(pm_handle** hs, int n) {
       p.xcd_map = xcd_map;
       static const int ablate_env = [] { const char* e = getenv("COLMAP_AMD_PM_ABLATE"); return e ? atoi(e) : 0; }();
       p.ablate = ablate_env;
-      { const char* e = getenv("COLMAP_AMD_PM_ROWSYNC"); p.rowsync = e ? atoi(e) : 0; }
-      if (band_rows > 0) {  // experimental band-scheduled kernel: pm_kernels.hip, sweep_band_body
-        const int rw = (p.rot & 1) ? p.H : p.W, rh = (p.rot & 1) ? p.W : p.H;
-        p.band_state = hs[b]->band_state.ptr;
-        p.band_done = hs[b]->band_done.ptr;
-        p.band_ticket = h0->band_ticket.ptr;
-        p.band_nprob = n;
-        p.band_groups = (rw + p.C - 1) / p.C;
-        p.band_rows = band_rows;
-        p.band_count = (rh + band_rows - 1) / band_rows;
-      }
+      if (!fp_resource_all) p.fp_base = nullptr;
       host[(size_t)(k + 1) * n + b] = p;
     }
     std::swap(sel_out, sel_in);  // Rotate(): prev_sel_prob <- sel_prob (reference :1911-1915)
@@ -711,17 +807,12 @@ void RunBatchAsync(pm_handle** hs, int n) {
     const bool last_sweep = k == total_sweeps - 1;
     const bool fphoto = last_sweep && opt.filter;
     const bool fgeom = last_sweep && opt.filter && geom;
-    if (band_rows > 0) {  // band-scheduled kernel: counters and ticket start at zero in every launch
-      for (int b = 0; b < n; ++b)
-        HIP_CALL(hipMemsetAsync(hs[b]->band_done.ptr, 0, hs[b]->band_done.count * sizeof(int), h0->stream));
-      HIP_CALL(hipMemsetAsync(h0->band_ticket.ptr, 0, sizeof(unsigned), h0->stream));
-    }
     for (int b = 0; b < n; ++b)  // debug progress trace: every launch starts from an empty buffer
       if (hs[b]->trace.ptr)
         HIP_CALL(hipMemsetAsync(hs[b]->trace.ptr, 0, hs[b]->trace.count * sizeof(unsigned long long), h0->stream));
     HIP_CALL(hipEventRecord(h0->ev[2 * k], h0->stream));
-    pm_launch_sweep(host[(size_t)(k + 1) * n], h0->plan.ptr + (size_t)(k + 1) * n, n, h0->threads,
-                    geom, fphoto, fgeom, h0->stream);
+    h0->sweep_kernel = pm_launch_sweep(host[(size_t)(k + 1) * n], h0->plan.ptr + (size_t)(k + 1) * n, n,
+                                       h0->threads, geom, fphoto, fgeom, h0->stream);
     HIP_CALL(hipEventRecord(h0->ev[2 * k + 1], h0->stream));
   }
   for (int b = 0; b < n; ++b) {
@@ -1005,6 +1096,13 @@ int pm_get_sweep_timing(pm_handle* h, double* total_ms, int32_t* num_launches) {
   });
 }
 
+int pm_get_sweep_kernel_name(pm_handle* h, const char** name) {
+  return Guard([&] {
+    PM_CHECK(h && name, "null");
+    *name = h->sweep_kernel;
+  });
+}
+
 int pm_get_sweep_times(pm_handle* h, float* ms, int32_t capacity, int32_t* num_launches) {
   return Guard([&] {
     PM_CHECK(h && num_launches, "null");
@@ -1107,7 +1205,10 @@ void pm_destroy(pm_handle* h) {
   delete h;
 }
 
-void pm_release_cached_memory(void) { DevPool::Get().Release(); }
+void pm_release_cached_memory(void) {
+  DevPool::Get().Release();
+  FpSlabPool::Get().Release();
+}
 
 const char* pm_last_error(void) { return g_last_error.c_str(); }
 

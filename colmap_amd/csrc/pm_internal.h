@@ -11,13 +11,24 @@ constexpr int kPoseStride = 43;  // K4 R9 T3 C3 P12 invP12 (reference patch_matc
 constexpr int kRngWords = 6;     // XORWOW: x[5] + d
 
 // Packed source images ("footprints": one dword per texel position = its 2 x 2 bilinear neighbourhood) are
-// stored in tiles of 8 x 4 entries = one 128-byte cache line, tiles row-major. A warped 11 x 11 window (13 x 13
-// entries at scale 1) then touches ~10 lines instead of the ~18 of a row-major image -- the sweep kernel's time
-// is dominated by the L2 misses of these gathers (profiles/r03_pm_gather_diag.log). Entry (ex, ey) holds texel
-// position (ex - kFpRingX, ey - kFpRingY); positions -2 and w (h) are the all-zero border ring a clamped tap
-// reads, the ring offsets are tile multiples so that texel (0, 0) starts a tile.
-constexpr int kFpRingX = 8, kFpRingY = 4;
-inline int pm_fp_width(int w) { return (w + kFpRingX + 1 + 7) & ~7; }    // entries per row (multiple of 8)
+// stored as vertical strips of kFpStrip = 16 entries: inside a strip the rows follow each other, 64 bytes each, so
+// a 128-byte cache line is a 16 x 2 block of entries and the entry index is
+//   (ex / 16) * 16 * rows + 16 * ey + (ex % 16).
+// Why strips: (a) the 11 x 11 sweep kernels leave that index to the address unit (swizzled buffer resource,
+// pm_kernels.hip: fp_resource), which is what makes 2-D blocking free; (b) the texture-address unit serves a quad
+// of lanes in one cycle only when its four addresses lie within 16 bytes (scripts/ubench/gather_rates.hip,
+// profiles/r04_ubench_gather_rates.log) -- the taps of a quad are neighbours along x, so wide strip rows keep
+// the quads of a warped 11 x 11 window fast (16 x 2: 17-19 cycles per gather instruction in the microbenchmark,
+// 8 x 4: 24, lane-per-line: 64) while two rows per line still halve the lines a window touches against a
+// row-major image. Entry (ex, ey) holds texel position (ex - kFpRingX, ey - kFpRingY); positions -2 and w (h) are
+// the all-zero border ring a clamped tap reads; the ring offsets are one strip / whole lines so that texel (0, 0)
+// starts a cache line.
+#ifndef PM_FP_STRIP
+#define PM_FP_STRIP 16  // entries per strip row: 16 (x 2 rows per 128-byte cache line); measured 8 (x 4): +4.4 %, 32 (x 1): +1.2 % launch time
+#endif
+constexpr int kFpStrip = PM_FP_STRIP;
+constexpr int kFpRingX = kFpStrip, kFpRingY = 4;
+inline int pm_fp_width(int w) { return (w + kFpRingX + 1 + kFpStrip - 1) & ~(kFpStrip - 1); }    // entries per row (whole strips)
 inline int pm_fp_height(int h) { return (h + kFpRingY + 1 + 3) & ~3; }   // rows (multiple of 4)
 inline size_t pm_fp_entries(int w, int h) { return (size_t)pm_fp_width(w) * pm_fp_height(h); }
 
@@ -30,7 +41,7 @@ struct PmParams {
   int S;            // number of source images
   int src_w, src_h; // source slot size (max over sources)
   float fp_xmax, fp_ymax;  // src_w + kFpRingX, src_h + kFpRingY: last used column / row of the packed image
-  int fp_tpr1;             // tiles per row of the packed image, minus one (fp_tiled)
+  int fp_rows1;            // rows of the packed image (pm_fp_height), minus one (fp_index)
   int radius, step, ntap1d, ntaps;
   int num_samples;
   int rec_stride;   // floats per pixel record: 4 + 3*S
@@ -39,8 +50,7 @@ struct PmParams {
   int C;            // image columns per workgroup
   int ablate;       // profiling only (COLMAP_AMD_PM_ABLATE): bit 0 skip the NCC task passes, bit 1 skip the
                     // hypothesis generation, bit 2 skip the backward-message pre-pass; results are garbage
-  int rowsync;      // experiment: workgroup barrier every `rowsync` rows of the multi-wave sweep kernels (0 = never)
-  int xcd_map;      // batched launch: 0 problem = id % batch, 1 neighbouring problems per XCD
+  int xcd_map;      // batched launch of the generic kernel: 0 problem = id % batch, 1 neighbouring problems per XCD
   float refK[4];    // rotated {fx, cx, fy, cy}
   float refInvK[4]; // rotated {1/fx, -cx/fx, 1/fy, -cy/fy}
   float perturbation;
@@ -57,6 +67,8 @@ struct PmParams {
   float* rec;               // [H*W][rec_stride]
   const uint32_t* const* src_fp_tab;  // [S] pointers to packed 2x2 footprints, pm_fp_entries(src_w, src_h) each
                                       // (separate allocations: shareable between problems)
+  const uint32_t* fp_base;            // lowest address among them: base of the problem's buffer resource, or null
+  const uint32_t* src_fp_off;         // [S] (address - fp_base) / kFpStrip: the images as slots of that resource
   const float* src_depth;   // [S][src_h][src_w] or null
   const uint8_t* ref_img;   // [H][W]
   const float* ref_sum;     // [H][W]
@@ -70,11 +82,6 @@ struct PmParams {
   unsigned long long* trace; // optional progress trace (debug, pm_enable_progress_trace): [column group][row / 128]
                              // device-wide clock when the group's wave reached that row, last sweep launch; else null
   int trace_stride;          // samples per column group
-  // band-scheduled sweep kernel (experimental, COLMAP_AMD_PM_BAND=1; pm_kernels.hip: sweep_band_body)
-  float* band_state;         // [column group][C * (kRngWords + S + 4)] state of a column group between two bands
-  int* band_done;            // [column group] bands finished in this launch
-  unsigned* band_ticket;     // one counter per launch, shared by the problems of a batch
-  int band_nprob, band_groups, band_count, band_rows;  // problems in the launch, column groups per problem, bands, rows per band
 };
 
 size_t pm_sweep_lds_bytes(const PmParams& p, bool geom);
@@ -89,8 +96,9 @@ void pm_launch_init_state(const PmParams& p, bool random_init, float depth_min, 
 // `p` describes the (identical) shape of every problem of the batch; `dev_params` is the
 // device array of per-problem parameter blocks the kernel indexes with its batch coordinate.
 void pm_launch_initial_cost(const PmParams& p, const PmParams* dev_params, int batch, hipStream_t st);
-void pm_launch_sweep(const PmParams& p, const PmParams* dev_params, int batch, int threads, bool geom,
-                     bool filter_photo, bool filter_geom, hipStream_t st);
+// returns the name of the kernel it launched
+const char* pm_launch_sweep(const PmParams& p, const PmParams* dev_params, int batch, int threads, bool geom,
+                            bool filter_photo, bool filter_geom, hipStream_t st);
 void pm_launch_rng_streams(const unsigned long long* seeds, int nseeds, int ndraws, float* out,
                            hipStream_t st);
 void pm_launch_extract(const PmParams& p, int sel_off, float* depth, float* normal, float* sel,

@@ -238,75 +238,25 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ v2f pk_bcast(float a) { return (v2f)(a); }
 
-// Footprint gather of one tap: floor of the warped coordinate clamped to the zero ring
-// [-2, w] x [-2, h] in the float domain (one v_med3 each), so that arbitrarily distant /
-// non-finite taps read an all-zero footprint entry (SampleLayeredBilinear,
-// patch_match_cuda.cu:426-442; the +0.5 / -0.5 texel centre round trip of the reference cancels
-// and is not evaluated in device order).
-// Entry index of packed-image position (ix, iy) (pm_internal.h: 8 x 4-entry tiles, tiles row-major):
-//   ((iy >> 2) * tiles_per_row + (ix >> 3)) * 32 + (iy & 3) * 8 + (ix & 7)
-//     = ix + 3 (ix & ~7) + 8 (iy + (iy & ~3) (tiles_per_row - 1))          -- two 24-bit multiply-adds and a shift-add
-// PM_FP_TILED=0 builds the row-major layout of the same padded image (A/B measurements).
-#ifndef PM_FP_TILED
-#define PM_FP_TILED 1
-#endif
-// PM_FP_FORMAT=16 (experimental build, scripts/profile_pm_gather_diag.sh): half the bytes. An entry is the VERTICAL
-// pair {t(x, y), t(x, y+1)} in two bytes, the image row-major; a tap reads the dword that starts at its entry --
-// entries (x, y) and (x+1, y), i.e. the same four texels -- with one 2-byte-aligned global_load_dword. 354 instead
-// of 708 MB of packed sources for the benchmark's 36 images. The texels arrive as c00 c01 c10 c11 (PM_FP_C10 / C01).
-// PM_FP_FORMAT=8 (experimental likewise): the plain one-byte image with the zero ring, row-major; a tap takes two
-// unaligned 2-byte loads (rows y and y + 1) and puts them together as the 4-byte footprint. 177 MB for those 36
-// images: the one format whose working set fits the 256 MB infinity cache (profiles/r03_pm_gather_diag.log).
-#ifndef PM_FP_FORMAT
-#define PM_FP_FORMAT 32
-#endif
-__device__ __forceinline__ unsigned fp_tiled(unsigned ix, unsigned iy, unsigned tpr1) {
-#if PM_FP_FORMAT == 16 || PM_FP_FORMAT == 8
-  return __umul24(iy, 8u * (tpr1 + 1u)) + ix;
-#elif PM_FP_TILED
-  const unsigned a = __umul24(ix & ~7u, 3u) + ix;
-  const unsigned v = __umul24(iy & ~3u, tpr1) + iy;
-  return (v << 3) + a;
-#else
-  return __umul24(iy, 8u * (tpr1 + 1u)) + ix;
-#endif
+// Packed source images ("footprints"): entry (ex, ey) is one dword = the 2 x 2 bilinear neighbourhood of texel
+// position (ex - kFpRingX, ey - kFpRingY) .. (+1, +1), with an all-zero border ring (pm_build_footprint_kernel).
+// Layout (pm_internal.h): vertical STRIPS of kFpStrip entries; inside a strip the rows follow each other, so
+//   entry index = (ex / strip) * strip * rows + strip * ey + (ex % strip) = ex + (ex & ~(strip - 1)) * (rows - 1) + strip * ey.
+// The 11 x 11 sweep kernels never compute this index: a swizzled buffer resource (fp_resource) lets the address
+// unit form it from the pair (ex, 4 * ey + slot); see ncc_front.
+__device__ __forceinline__ unsigned fp_index(unsigned ix, unsigned iy, unsigned rows1) {
+  return __umul24(ix & ~(unsigned)(kFpStrip - 1), rows1) + ix + iy * (unsigned)kFpStrip;
 }
-#if PM_FP_FORMAT == 16
-struct __attribute__((packed, aligned(2))) FpDword { uint32_t v; };
-typedef __attribute__((address_space(1))) const FpDword gbl_fpdword;
-typedef __attribute__((address_space(1))) const uint16_t gbl_u16;
-// pointer to entry `idx` of a packed image / the four texels of the tap whose entry `a` points at
-__device__ __forceinline__ gbl_u32* fp_entry(gbl_u32* fp, unsigned idx) { return (gbl_u32*)((gbl_u16*)fp + idx); }
-__device__ __forceinline__ uint32_t fp_load(gbl_u32* a, unsigned) { return ((gbl_fpdword*)a)->v; }
-#define PM_FP_C10 ubyte2
-#define PM_FP_C01 ubyte1
-#elif PM_FP_FORMAT == 8
-struct __attribute__((packed, aligned(1))) FpHalf { uint16_t v; };
-typedef __attribute__((address_space(1))) const FpHalf gbl_fphalf;
-typedef __attribute__((address_space(1))) const uint8_t gbl_u8;
-__device__ __forceinline__ gbl_u32* fp_entry(gbl_u32* fp, unsigned idx) { return (gbl_u32*)((gbl_u8*)fp + idx); }
-__device__ __forceinline__ uint32_t fp_load(gbl_u32* a, unsigned tpr1) {
-  const gbl_u8* b = (gbl_u8*)a;
-  const uint32_t lo = ((gbl_fphalf*)b)->v;                        // t(x, y),     t(x + 1, y)
-  const uint32_t hi = ((gbl_fphalf*)(b + 8u * (tpr1 + 1u)))->v;   // t(x, y + 1), t(x + 1, y + 1)
-  return lo | (hi << 16);
-}
-#define PM_FP_C10 ubyte1
-#define PM_FP_C01 ubyte2
-#else
-__device__ __forceinline__ gbl_u32* fp_entry(gbl_u32* fp, unsigned idx) { return fp + idx; }
-__device__ __forceinline__ uint32_t fp_load(gbl_u32* a, unsigned) { return *a; }
-#define PM_FP_C10 ubyte1
-#define PM_FP_C01 ubyte2
-#endif
 
-template <bool FOFF>
+// Footprint gather of one tap (generic kernels): floor of the warped coordinate clamped to the zero ring
+// [-2, w] x [-2, h] in the float domain (one v_med3 each), so that arbitrarily distant / non-finite taps read an
+// all-zero footprint entry (SampleLayeredBilinear, patch_match_cuda.cu:426-442; the +0.5 / -0.5 texel centre
+// round trip of the reference cancels and is not evaluated in device order).
+// fxr = floor(x) + kFpRingX, fyr = floor(y) + kFpRingY (the ring offset is added in the float domain, packed).
 __device__ __forceinline__ uint32_t tap_gather(const PmParams& p, gbl_u32* fp, float fxr, float fyr) {
-  // fxr = floor(x) + kFpRingX, fyr = floor(y) + kFpRingY (the ring offset is added in the float domain, packed);
-  // positions left of -2 / beyond w clamp to the all-zero ring entries
   const float cx = __builtin_amdgcn_fmed3f(fxr, (float)(kFpRingX - 2), p.fp_xmax);
   const float cy = __builtin_amdgcn_fmed3f(fyr, (float)(kFpRingY - 2), p.fp_ymax);
-  return fp_load(fp_entry(fp, fp_tiled((unsigned)(int)cx, (unsigned)(int)cy, (unsigned)p.fp_tpr1)), (unsigned)p.fp_tpr1);
+  return fp[fp_index((unsigned)(int)cx, (unsigned)(int)cy, (unsigned)p.fp_rows1)];
 }
 
 // Byte k of a packed footprint entry as float. Inline asm keeps the four conversions as four
@@ -444,8 +394,8 @@ __device__ __forceinline__ void ncc_group(const PmParams& p, const lds_f32* H, g
       wy[q] = py - fy;
       const v2f fx2 = fx + pk_bcast((float)kFpRingX);
       const v2f fy2 = fy + pk_bcast((float)kFpRingY);
-      tex[2 * q] = tap_gather<(N1D > 0)>(p, fp, fx2[0], fy2[0]);
-      tex[2 * q + 1] = tap_gather<(N1D > 0)>(p, fp, fx2[1], fy2[1]);
+      tex[2 * q] = tap_gather(p, fp, fx2[0], fy2[0]);
+      tex[2 * q + 1] = tap_gather(p, fp, fx2[1], fy2[1]);
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -458,8 +408,8 @@ __device__ __forceinline__ void ncc_group(const PmParams& p, const lds_f32* H, g
         const int t = j + 16 * (kb + 2 * q + e);
         const uint32_t x = t < ntaps ? tex[2 * q + e] : 0u;
         c00[e] = ubyte0(x);
-        c10[e] = PM_FP_C10(x);
-        c01[e] = PM_FP_C01(x);
+        c10[e] = ubyte1(x);
+        c01[e] = ubyte2(x);
         c11[e] = ubyte3(x);
       }
       const v2f top = pk_fma(wx[q], c10 - c00, c00);
@@ -705,17 +655,8 @@ __global__ void pm_build_footprint_kernel(const uint8_t* __restrict__ src, uint3
   auto tex = [&](int xx, int yy) -> uint32_t {
     return (xx >= 0 && yy >= 0 && xx < w && yy < h) ? (uint32_t)img[(size_t)yy * w + xx] : 0u;
   };
-#if PM_FP_FORMAT == 16
-  // (allocated as pm_fp_entries dwords = twice what the halfwords need: the dword of the last entry stays in bounds)
-  ((uint16_t*)fp)[(size_t)s * pw * ph * 2 + (size_t)ey * pw + ex] = (uint16_t)(tex(x, y) | (tex(x, y + 1) << 8));
-#elif PM_FP_FORMAT == 8
-  // (allocated as pm_fp_entries dwords = four times the bytes: the extra zero row below the last one is in bounds)
-  ((uint8_t*)fp)[(size_t)s * pw * ph * 4 + (size_t)ey * pw + ex] = (uint8_t)tex(x, y);
-  if (ey == ph - 1) ((uint8_t*)fp)[(size_t)s * pw * ph * 4 + (size_t)ph * pw + ex] = 0;
-#else
-  fp[(size_t)s * pw * ph + fp_tiled((unsigned)ex, (unsigned)ey, (unsigned)(pw / 8 - 1))] =
+  fp[(size_t)s * pw * ph + fp_index((unsigned)ex, (unsigned)ey, (unsigned)(ph - 1))] =
       tex(x, y) | (tex(x + 1, y) << 8) | (tex(x, y + 1) << 16) | (tex(x + 1, y + 1) << 24);
-#endif
 }
 
 // FilterKernel, gpu_mat_ref_image.cu:39-81
@@ -802,7 +743,8 @@ __global__ void pm_init_state_kernel(const PmParams p, int random_init, float de
 struct Lds {
   lds_f32* poses;   // [S][pstride]
   int pstride;
-  lds_u64* fpb;     // [S] packed source images (global addresses)
+  lds_u64* fpb;     // [S] packed source images (global addresses; generic kernels)
+  lds_u32* fpo;     // [S] packed source images as slots of the problem's buffer resource (11 x 11 sweep kernels)
   lds_f32* tile;    // [win][C + 2r] reference colours, ring-buffered rows
   lds_f32* wgt;     // [C][tap_stride] bilateral weights (0 beyond ntaps)
   lds_f32* refc;    // [C][tap_stride] reference colours of the taps
@@ -894,6 +836,7 @@ __device__ __forceinline__ void lds_load_poses(const PmParams& p, Lds& L, bool g
 __device__ __forceinline__ void lds_bind(Lds& L, lds_char* base, const LdsOffsets& o) {
   L.poses = (lds_f32*)(base + o.poses);
   L.fpb = (lds_u64*)(base + o.fpb);
+  L.fpo = (lds_u32*)(base + o.fpb);
   L.tile = (lds_f32*)(base + o.tile);
   L.wgt = (lds_f32*)(base + o.wgt);
   L.refc = (lds_f32*)(base + o.refc);
@@ -1124,13 +1067,11 @@ __device__ __forceinline__ int run_tasks(const PmParams& p, const Lds& L, int ro
 }
 
 // ---------------------------------------------------------------------------
-// Single-wave workgroups (pm_sweep_wave_kernel below): the NCC evaluation split into the part
-// before the footprint gathers (warp, shared division, clamp, address: ncc_front) and the part
-// after them (byte conversion, lerp, window sums: ncc_back), so that all eight gathers of a lane
-// are in flight before the first texel is consumed. Arithmetic and order are those of ncc_group
-// (oracle/pm_oracle.c: ncc_cost_device); fixed 11 x 11 window (121 taps = one 128-tap chunk).
+// 11 x 11 sweep kernels: the NCC evaluation split into the part before the footprint gathers (warp, shared
+// division, address: ncc_front) and the part after them (byte conversion, lerp, window sums: ncc_back), so that
+// all eight gathers of a lane are in flight before the first texel is consumed.
 // ---------------------------------------------------------------------------
-struct NccStage {  // VGPR half of a pipeline stage; the eight texels are in flight to the LDS ring
+struct NccStage {  // what the back half needs from the front half besides the texels: the bilinear fractions
   v2f wx[4], wy[4];
 };
 
@@ -1148,75 +1089,50 @@ __device__ __forceinline__ void tap_geom_init(lds_f32* tapg, int tid, int step, 
     if (transpose) {
       const int sw = wrow; wrow = wcol; wcol = sw;
     }
-#if defined(PM_DIAG_GATHER)
-    // 3 = gather instruction k reads window row k only (lanes beyond the row's 11 taps repeat its last tap; rows
-    // 8..10 are not read): no two instructions of an evaluation share a cache line
-    if (PM_DIAG_GATHER == 3) { wrow = transpose ? (j < 10 ? j : 10) : k; wcol = transpose ? k : (j < 10 ? j : 10); }
-#endif
     tapg[idx] = (float)((is_dy ? wrow : wcol) * step);
   }
 }
 
-// Address of the footprint entry of a tap (see tap_gather<true>: clamp in the float domain, fp32
-// entry index).
-__device__ __forceinline__ gbl_u32* tap_address(const PmParams& p, gbl_u32* fp, float fxr, float fyr) {
-  const float cx = __builtin_amdgcn_fmed3f(fxr, (float)(kFpRingX - 2), p.fp_xmax);
-  const float cy = __builtin_amdgcn_fmed3f(fyr, (float)(kFpRingY - 2), p.fp_ymax);
-  return fp_entry(fp, fp_tiled((unsigned)(int)cx, (unsigned)(int)cy, (unsigned)p.fp_tpr1));
+// ---------------------------------------------------------------------------
+// Packed-image gathers of the 11 x 11 sweep kernels: MUBUF loads through ONE swizzled buffer resource per problem.
+// With swizzling enabled the address unit computes (gfx9 buffer addressing; verified on gfx950 by
+// scripts/ubench/mubuf_addr.hip, profiles/r04_ubench_mubuf_addr.log)
+//   address = base + ((index / IS) * stride + (offset / 4) * 4) * IS + (index % IS) * 4
+// for index stride IS and element size 4. With IS = kFpStrip, stride = 4 * rows, index = ex and
+// offset = 4 * ey + slot this is the strip layout's entry (ex, ey) of the packed image that starts `IS * slot`
+// bytes behind the base: the tap address costs ONE VALU instruction (v_lshl_add_u32) instead of the seven of an
+// explicit block index plus a 64-bit add. `slot` of a source image = (its address - lowest address of the
+// problem's sources) / IS (pm_api.cpp: the images of a problem must lie within IS * 4 GB of each other, which
+// the allocator's pool makes the normal case; otherwise the generic kernel runs).
+// ---------------------------------------------------------------------------
+typedef int v4i __attribute__((ext_vector_type(4)));
+__device__ uint32_t llvm_struct_buffer_load_u32(v4i rsrc, int vindex, int voffset, int soffset, int aux)
+    __asm("llvm.amdgcn.struct.buffer.load.i32");
+
+__device__ __forceinline__ v4i fp_resource(const PmParams& p) {
+  const uint64_t b = (uint64_t)p.fp_base;
+  const uint32_t stride = 4u * ((uint32_t)p.fp_rows1 + 1u);  // bytes; < 16384 (pm_fp_resource_ok)
+  v4i r;
+  r[0] = (int)(uint32_t)b;
+  r[1] = (int)(((uint32_t)(b >> 32) & 0xffffu) | (stride << 16) | 0x80000000u);  // swizzle enable
+  r[2] = 0x7fffffff;                                                             // records: no range limit in use
+  // raw 32-bit data format; element size 4 bytes, index stride = strip width
+  r[3] = 0x00020000 | (1 << 19) | ((kFpStrip == 8 ? 0 : kFpStrip == 16 ? 1 : kFpStrip == 32 ? 2 : 3) << 21);
+  return r;
 }
 
-// The footprint gathers of the software-pipelined NCC loop land in LDS, not in registers
-// (global_load_lds_dword: every lane's dword goes to M0 + slot offset + 4 * lane; "LDS-DMA"):
-//  * the compiler's wait-count insertion merges the loop-carried "loads in flight" state
-//    conservatively and would wait with vmcnt(0) right after the NEXT task's gathers were issued,
-//    exposing the full gather latency again; these asm loads are invisible to that pass and
-//    gather_wait<NEWER>() is the explicit wait (vector-memory loads complete in issue order; any
-//    other VMEM operation the compiler places in between only makes the wait more conservative);
-//  * a register with a load in flight must not be touched by compiler-generated code (a copy
-//    inserted by register allocation before the wait would read stale data -- observed with both
-//    VGPR and AGPR destinations); a landing zone in LDS has no such hazard and costs no VGPRs:
-//    the texels are read back with ds_read_b32 after the wait.
-// Ring: [2 stages][8 gathers][64 lanes] dwords = 4 KB per workgroup.
-constexpr int kGatherRingBytes = 2 * 8 * 64 * 4;
-
-template <int SLOT>
-__device__ __forceinline__ void gather_issue(gbl_u32* addr) {
-  // LDS address of lane l = M0[15:0] + instruction offset + 4 l. The instruction offset would be
-  // added to the GLOBAL address as well, so the slot is selected through M0 (a scalar move per
-  // gather; the compiler does not use M0 in this kernel). The ring is the first thing in the
-  // workgroup's LDS (offset 0: checked at kernel entry), which makes M0 a literal.
-  asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dword %0, off" : : "v"(addr), "n"(SLOT * 256) : "memory");
-}
-// slot index known after unrolling: the switch folds to the one asm statement
-template <int STAGE>
-__device__ __forceinline__ void gather_issue_k(int k, gbl_u32* addr) {
-  switch (k) {
-    case 0: gather_issue<8 * STAGE + 0>(addr); break;
-    case 1: gather_issue<8 * STAGE + 1>(addr); break;
-    case 2: gather_issue<8 * STAGE + 2>(addr); break;
-    case 3: gather_issue<8 * STAGE + 3>(addr); break;
-    case 4: gather_issue<8 * STAGE + 4>(addr); break;
-    case 5: gather_issue<8 * STAGE + 5>(addr); break;
-    case 6: gather_issue<8 * STAGE + 6>(addr); break;
-    default: gather_issue<8 * STAGE + 7>(addr); break;
-  }
-}
-// Wait until at most NEWER vector-memory operations issued after a stage's eight gathers are
-// outstanding; the "memory" clobber keeps the LDS reads of the texels behind it.
-template <int NEWER>
-__device__ __forceinline__ void gather_wait() {
-  asm volatile("s_waitcnt vmcnt(%0)" : : "n"(NEWER) : "memory");
-}
-
-// STAGE 0 / 1: the gathers go to that stage of the LDS ring (software-pipelined loop); STAGE < 0:
-// plain loads into `tex` (the compiler tracks and waits for them).
+// Front half of an evaluation: warp, shared division, address, gathers. Arithmetic and order are those of
+// ncc_group (oracle/pm_oracle.c: ncc_cost_device); fixed 11 x 11 window (121 taps = one 128-tap chunk).
 // FAST: every tap of the four evaluations of this round is known to fall inside the packed image
-// (patch_inside below), so the clamp of the tap coordinate to the zero ring and the ring offset
-// are dropped: the address is formed from floor(x), floor(y) >= 0 directly against the entry of
-// texel (0, 0). Same entry, same bits.
-template <int STAGE, bool FAST>
-__device__ __forceinline__ void ncc_front(const PmParams& p, const lds_f32* H, gbl_u32* fp,
-                                          const lds_f32* tg, int j, NccStage& st, uint32_t* tex = nullptr) {
+// (patch_inside below), so the clamp of the tap coordinate to the zero ring is dropped: index and row are the
+// truncated coordinates themselves (>= 1, truncation = floor), `slot` then already points at texel (0, 0), and
+// the fractions come from v_fract_f32 (== x - floor(x) exactly for x >= 0). Same entry, same bits.
+// MUBUF = false: the same entries through explicit strip indices and global loads (`gbase` = the image, or with
+// FAST its entry of texel (0, 0)) -- three more VALU instructions per tap; for problems whose packed images do not
+// fit one buffer resource (further than 4 GB apart: the address unit forms the buffer offset in 32 bits).
+template <bool FAST, bool MUBUF>
+__device__ __forceinline__ void ncc_front(const PmParams& p, const v4i srd, const lds_f32* H, uint32_t slot,
+                                          gbl_u32* gbase, const lds_f32* tg, int j, NccStage& st, uint32_t* tex) {
   const float h0 = H[0], h1 = H[1], h2 = H[2], h3 = H[3], h4 = H[4], h5 = H[5], h6 = H[6],
               h7 = H[7], h8 = H[8];
   v2f csrc[4], rsrc[4], pre[4], suf[4];
@@ -1253,63 +1169,45 @@ __device__ __forceinline__ void ncc_front(const PmParams& p, const lds_f32* H, g
     const v2f inv_z = (pre[q] * suf[q]) * pk_bcast(rinv);
     const v2f px = inv_z * csrc[q];
     const v2f py = inv_z * rsrc[q];
-    v2f fx, fy;
-    fx[0] = floorf(px[0]);
-    fx[1] = floorf(px[1]);
-    fy[0] = floorf(py[0]);
-    fy[1] = floorf(py[1]);
-    st.wx[q] = px - fx;
-    st.wy[q] = py - fy;
-    gbl_u32 *a0, *a1;
+    int ix[2], iy[2];
     if (FAST) {
-      // fp already points at the entry of texel (0, 0) (the caller added the offset of tile (1, 1)). Lanes whose
-      // tap lies beyond the window (t >= 121: weight 0, divisor forced to 1, so the coordinate is
-      // the un-normalised numerator) have no inside guarantee: they read entry (0, 0) instead.
-      const bool v0 = j + 16 * (2 * q) < 121, v1 = j + 16 * (2 * q + 1) < 121;
-      a0 = fp_entry(fp, v0 ? fp_tiled((unsigned)(int)fx[0], (unsigned)(int)fy[0], (unsigned)p.fp_tpr1) : 0u);
-      a1 = fp_entry(fp, v1 ? fp_tiled((unsigned)(int)fx[1], (unsigned)(int)fy[1], (unsigned)p.fp_tpr1) : 0u);
+      st.wx[q][0] = __builtin_amdgcn_fractf(px[0]);
+      st.wx[q][1] = __builtin_amdgcn_fractf(px[1]);
+      st.wy[q][0] = __builtin_amdgcn_fractf(py[0]);
+      st.wy[q][1] = __builtin_amdgcn_fractf(py[1]);
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        // Lanes whose tap lies beyond the window (t >= 121: weight 0, divisor forced to 1, so the coordinate is
+        // the un-normalised numerator) have no inside guarantee: they read texel (0, 0) instead.
+        const bool v = j + 16 * (2 * q + e) < 121;
+        ix[e] = v ? (int)px[e] : 0;
+        iy[e] = v ? (int)py[e] : 0;
+      }
     } else {
+      v2f fx, fy;
+      fx[0] = floorf(px[0]);
+      fx[1] = floorf(px[1]);
+      fy[0] = floorf(py[0]);
+      fy[1] = floorf(py[1]);
+      st.wx[q] = px - fx;
+      st.wy[q] = py - fy;
       const v2f fx2 = fx + pk_bcast((float)kFpRingX);
       const v2f fy2 = fy + pk_bcast((float)kFpRingY);
-      a0 = tap_address(p, fp, fx2[0], fy2[0]);
-      a1 = tap_address(p, fp, fx2[1], fy2[1]);
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        ix[e] = (int)__builtin_amdgcn_fmed3f(fx2[e], (float)(kFpRingX - 2), p.fp_xmax);
+        iy[e] = (int)__builtin_amdgcn_fmed3f(fy2[e], (float)(kFpRingY - 2), p.fp_ymax);
+      }
     }
-#if defined(PM_DIAG_GATHER) && PM_FP_FORMAT == 32
-    // Diagnostic builds only (scripts/profile_pm_gather_diag.sh; results are garbage, only the launch time means
-    // something): 1 = every gather reads the image's first entry (one cache line per instruction: what the kernel
-    // costs without the address path), 2 = entry indices wrapped into an 8 KB window per image (same lines per
-    // instruction, everything L2-resident: what the cache misses cost).
-    if (PM_DIAG_GATHER == 1) { a0 = fp; a1 = fp; }
-    if (PM_DIAG_GATHER == 2) { a0 = fp + ((unsigned)(a0 - fp) & 2047u); a1 = fp + ((unsigned)(a1 - fp) & 2047u); }
-    // 5 = entry indices wrapped into a 2 MB window per image: the lines no longer fit the L2 (36 images x 2 MB) but sit
-    // in few pages and in the 256 MB infinity cache -- separates address translation / HBM from L2 capacity
-    if (PM_DIAG_GATHER == 5) { a0 = fp + ((unsigned)(a0 - fp) & 0x7FFFFu); a1 = fp + ((unsigned)(a1 - fp) & 0x7FFFFu); }
-    // 6 = the 2 MB page of every entry kept, the offset inside the page wrapped into 16 KB: the product's address
-    // translations with cache-resident data -- what the TLB misses cost
-    if (PM_DIAG_GATHER == 6) {
-      const unsigned i0_ = (unsigned)(a0 - fp), i1_ = (unsigned)(a1 - fp);
-      a0 = fp + ((i0_ & ~0x7FFFFu) | (i0_ & 0xFFFu));
-      a1 = fp + ((i1_ & ~0x7FFFFu) | (i1_ & 0xFFFu));
-    }
-    // 4 (row-major builds): the row of every tap rounded down to a multiple of four -- a window touches a quarter of
-    // its cache lines, everything else unchanged: how the time scales with the number of lines missed
-    if (PM_DIAG_GATHER == 4) {
-      const unsigned pw_ = 8u * ((unsigned)p.fp_tpr1 + 1u);
-      const unsigned i0_ = (unsigned)(a0 - fp), i1_ = (unsigned)(a1 - fp);
-      a0 = fp + (i0_ - (i0_ / pw_ & 3u) * pw_);
-      a1 = fp + (i1_ - (i1_ / pw_ & 3u) * pw_);
-    }
-#endif
-    if (STAGE >= 0) {
-      gather_issue_k<(STAGE >= 0 ? STAGE : 0)>(2 * q, a0);
-      gather_issue_k<(STAGE >= 0 ? STAGE : 0)>(2 * q + 1, a1);
+    if (MUBUF) {
+      tex[2 * q] = llvm_struct_buffer_load_u32(srd, ix[0], (int)(((uint32_t)iy[0] << 2) + slot), 0, 0);
+      tex[2 * q + 1] = llvm_struct_buffer_load_u32(srd, ix[1], (int)(((uint32_t)iy[1] << 2) + slot), 0, 0);
     } else {
-      tex[2 * q] = fp_load(a0, (unsigned)p.fp_tpr1);
-      tex[2 * q + 1] = fp_load(a1, (unsigned)p.fp_tpr1);
+      tex[2 * q] = gbase[fp_index((unsigned)ix[0], (unsigned)iy[0], (unsigned)p.fp_rows1)];
+      tex[2 * q + 1] = gbase[fp_index((unsigned)ix[1], (unsigned)iy[1], (unsigned)p.fp_rows1)];
     }
   }
 }
-
 // The three 16-lane tree sums of an evaluation in one instruction block: 12 v_add_f32_dpp, each
 // value's next step separated from its previous one by the other two values' steps (the DPP
 // read-after-VALU-write hazard needs two wait states; inline asm is not seen by the compiler's
@@ -1342,8 +1240,8 @@ __device__ __forceinline__ void ncc_back(const NccStage& st, const uint32_t tex[
     for (int e = 0; e < 2; ++e) {
       const uint32_t x = j + 16 * (2 * q + e) < 121 ? tex[2 * q + e] : 0u;
       c00[e] = ubyte0(x);
-      c10[e] = PM_FP_C10(x);
-      c01[e] = PM_FP_C01(x);
+      c10[e] = ubyte1(x);
+      c01[e] = ubyte2(x);
       c11[e] = ubyte3(x);
     }
     const v2f top = pk_fma(st.wx[q], c10 - c00, c00);
@@ -1681,21 +1579,15 @@ __global__ void __launch_bounds__(256, 3) pm_sweep_kernel(const PmParams* __rest
 }
 
 // ---------------------------------------------------------------------------
-// SweepFromTopToBottom, single-wave workgroups (the default for the 11 x 11 window).
-//
-// Same algorithm, phases and arithmetic as pm_sweep_kernel above -- results are bit-identical --
-// but a workgroup is ONE wavefront that owns C (= 4) columns:
-//  * no workgroup barriers: with at most 64 threads per workgroup the compiler drops every
-//    s_barrier, the phases of a row step are ordered by LDS program order alone, and a wave is never
-//    parked behind its partner wave (in the two-wave version the waves spent most of their
-//    time at the ~14 barriers of a row step while 3 waves per SIMD had to hide the gathers);
-//  * twice as many independent waves per CU at the same register budget (12 workgroups per CU:
-//    the LDS carve-up below fits 12,800 B = 10 allocation granules of 1,280 B);
-//  * NCC tasks run in batches of kWaveThCap: homographies of a batch lane-per-task, then rounds of
-//    four 16-lane evaluations (ncc_front -> all eight gathers in flight -> ncc_back), then the
-//    normalisation lane-per-task.
+// Wave-per-column-group sweep kernels for the 11 x 11 window (sweep_wave_body): every wave owns C adjacent columns
+// of the sweep frame and walks them row by row without ever meeting another wave -- the phases of a row step are
+// separated by LDS fences only. Two builds of ONE body: single-wave workgroups (pm_sweep_wave4_kernel) and
+// four-wave workgroups whose waves share one LDS copy of the read-only per-problem tables
+// (pm_sweep_quad_kernel, the default). Other windows take the generic kernel above.
 // ---------------------------------------------------------------------------
-constexpr int kWaveThCap = 40;  // NCC tasks per batch (homography ring in LDS; sized so that C = 3, S = 20 fits 10 workgroups per CU)
+constexpr int kWaveThCap = 40;  // NCC task slots per batch of the single-wave build (homography ring in LDS)
+constexpr int kQuadWaves = 4;   // waves per workgroup of the default build ...
+constexpr int kQuadThCap = 64;  // ... and its task slots per batch (the shared tables make room for them)
 
 __device__ __forceinline__ uint32_t task16_pack(int c, int i, int s, int geom_only) {
   return ((uint32_t)c << 13) | ((uint32_t)geom_only << 12) | ((uint32_t)i << 9) | (uint32_t)s;
@@ -1707,63 +1599,14 @@ __host__ __device__ inline int wave_max_tasks(int C, int S, int M) {
   return C * (4 * ms > S ? 4 * ms : S);
 }
 
-// `lean` (pm_sweep_wave4l_kernel): no LDS copies of the packed-image base pointers and of the pixel records'
-// cost / backward message / previous selection probability (read from global memory where they are needed:
-// all of them were touched earlier in the same row step and sit in L1 / L2), 36 task slots per batch instead
-// of 40 -- three columns per wave then take 10 192 B = 8 allocation granules at S = 20.
-constexpr int kWaveThCapLean = 36;  // (nine full rounds of four tasks)
-//
-// `nw` > 1 (pm_sweep_quad_kernel): nw waves per workgroup, each sweeping its own column group. The read-only
-// tables that are the same for every column group of a problem -- pose records, packed-image base pointers,
-// tap-offset table: 2.7 KB at S = 20 -- exist once per workgroup at the start of the LDS block; everything
-// else is private to a wave and repeats with `priv_stride`. Offsets of the private items are those of wave 0.
-// `cap` = NCC task slots per batch (kWaveThCap, or 64 where the shared tables make room for it).
-__host__ __device__ inline LdsOffsets lds_offsets_wave(int C, int S, int radius, int ntaps, int M,
-                                                       bool geom, bool pipe, bool pose_global = false,
-                                                       bool lean = false, int cap_slots = 0, int nw = 1) {
+// LDS carve-up of a workgroup of `nw` waves, each sweeping its own column group. The read-only tables that are
+// the same for every column group of a problem -- pose records, packed-image slots, tap-offset table: 2.6 KB at
+// S = 20 -- exist once per workgroup at the start of the block; everything else is private to a wave and repeats
+// with `priv_stride` (the offsets of the private items are those of wave 0). `cap` = NCC task slots per batch.
+__host__ __device__ inline LdsOffsets lds_offsets_wave(int C, int S, int radius, int ntaps, int M, bool geom,
+                                                       int cap, int nw) {
   LdsOffsets o;
   uint32_t off = 0;
-  if (nw > 1) {
-    auto take = [&](uint32_t bytes) {
-      const uint32_t at = off;
-      off += (bytes + 15u) & ~15u;
-      return at;
-    };
-    const int win = 2 * radius + 1;
-    const int tw = C + 2 * radius;
-    const int max_tasks = wave_max_tasks(C, S, M);
-    const uint32_t cap = cap_slots > 0 ? (uint32_t)cap_slots : (uint32_t)kWaveThCap;
-    o.ring = 0;
-    o.poses = take(4u * S * lds_pose_stride(geom));
-    o.fpb = take(8u * S);
-    o.tapg = take(4u * 256);
-    const uint32_t shared = off;
-    o.tile = take(4u * win * tw);
-    o.wgt = take(4u * C * tap_stride(ntaps));
-    o.refc = take(4u * C * tap_stride(ntaps));
-    o.fm = take(4u * C * S);
-    o.q = take(4u * C * S);
-    o.costv = take(4u * C * S);
-    o.betav = take(4u * C * S);
-    o.prevv = take(4u * C * S);
-    o.ncc = take(4u * C * 4 * S);
-    o.geo = take(geom ? 4u * C * 5 * S : 0u);
-    o.hyp = take(4u * C * 20);
-    o.colf = take(4u * C * 8);
-    const uint32_t us_bytes = 4u * C * M > 1u * C * S ? 4u * C * M : 1u * C * S;
-    o.us = take(us_bytes);
-    o.flags = o.us;
-    o.sv = take(4u * C * M);
-    o.best = take(4u * C);
-    o.csum = take(4u * C * 5);
-    o.tasks = take(2u * max_tasks + (geom ? 2u * C * S : 0u));
-    o.th = take(36u * cap);
-    o.ntasks = take(16u);
-    o.tin = take(2u * cap);
-    o.priv_stride = off - shared;
-    o.total = shared + (uint32_t)nw * o.priv_stride;
-    return o;
-  }
   auto take = [&](uint32_t bytes) {
     const uint32_t at = off;
     off += (bytes + 15u) & ~15u;
@@ -1772,17 +1615,19 @@ __host__ __device__ inline LdsOffsets lds_offsets_wave(int C, int S, int radius,
   const int win = 2 * radius + 1;
   const int tw = C + 2 * radius;
   const int max_tasks = wave_max_tasks(C, S, M);
-  o.ring = take(pipe ? (uint32_t)kGatherRingBytes : 0u);  // must be at LDS offset 0 (gather_issue)
-  o.poses = take(pose_global ? 0u : 4u * S * lds_pose_stride(geom));
-  o.fpb = take(lean ? 0u : 8u * S);
+  o.ring = 0;
+  o.poses = take(4u * S * lds_pose_stride(geom));
+  o.fpb = take(8u * S);                       // packed images: 32-bit slots of the buffer resource (Lds::fpo) or addresses (fpb)
+  o.tapg = take(4u * 256);
+  const uint32_t shared = off;
   o.tile = take(4u * win * tw);
   o.wgt = take(4u * C * tap_stride(ntaps));
   o.refc = take(4u * C * tap_stride(ntaps));
   o.fm = take(4u * C * S);
   o.q = take(4u * C * S);
-  o.costv = take(lean ? 0u : 4u * C * S);
-  o.betav = take(lean ? 0u : 4u * C * S);
-  o.prevv = take(lean ? 0u : 4u * C * S);
+  o.costv = take(4u * C * S);
+  o.betav = take(4u * C * S);
+  o.prevv = take(4u * C * S);
   o.ncc = take(4u * C * 4 * S);               // hypotheses 1..4 (0 is the cached cost map)
   o.geo = take(geom ? 4u * C * 5 * S : 0u);
   o.hyp = take(4u * C * 20);
@@ -1795,12 +1640,11 @@ __host__ __device__ inline LdsOffsets lds_offsets_wave(int C, int S, int radius,
   o.csum = take(4u * C * 5);
   o.tasks = take(2u * max_tasks + (geom ? 2u * C * S : 0u));  // 16-bit task words: NCC tasks, then
                                                               // (GEOM) the geometric-cost-only list
-  const uint32_t cap = lean ? (uint32_t)kWaveThCapLean : (cap_slots > 0 ? (uint32_t)cap_slots : (uint32_t)kWaveThCap);
-  o.th = take(36u * cap);
+  o.th = take(36u * (uint32_t)cap);
   o.ntasks = take(16u);
-  o.tapg = take(4u * 256);
-  o.tin = take(2u * cap);  // [0, cap): inside flags; [cap, 2 cap): task order of the batch (inside first)
-  o.total = off;
+  o.tin = take(2u * (uint32_t)cap);  // [0, cap): inside flags; [cap, 2 cap): task order of the batch (inside first)
+  o.priv_stride = off - shared;
+  o.total = shared + (uint32_t)nw * o.priv_stride;
   return o;
 }
 
@@ -1826,20 +1670,6 @@ __device__ __forceinline__ bool patch_inside(const PmParams& p, const float Hm[9
   return ok;
 }
 
-// Where the single-wave sweep kernel reads a source image's pose record from: the LDS copy (S x 19 or 43
-// floats: 1.5 KB at S = 20), or -- pose-global build -- the table in global memory it was copied from. The
-// records are read lane-per-(column, view) or lane-per-task a few times per row and stay L1-resident;
-// without the LDS copy three columns per wave fit the 10 KB that keep 16 workgroups on a CU.
-template <bool PG> struct PoseSrc;
-template <> struct PoseSrc<false> {
-  typedef const lds_f32* ptr;
-  static __device__ __forceinline__ ptr get(const PmParams&, const Lds& L, int s) { return L.poses + s * L.pstride; }
-};
-template <> struct PoseSrc<true> {
-  typedef gbl_f32* ptr;
-  static __device__ __forceinline__ ptr get(const PmParams& p, const Lds&, int s) { return (gbl_f32*)p.poses + s * kPoseStride; }
-};
-
 // Synchronisation point between the lane-parallel phases of ONE wave. A single-wave workgroup's
 // __syncthreads() compiles to the two fences without an s_barrier; the multi-wave workgroup spells that out so
 // that its waves stay independent of each other.
@@ -1855,13 +1685,10 @@ __device__ __forceinline__ void wave_sync() {
 }
 
 // Run the queued NCC tasks (and, with GEOM, the geometric-cost-only list) of one phase.
-template <bool GEOM, bool PIPE, bool PG, bool LEAN = false, int NW = 1, int CAPT = kWaveThCap>
-__device__ __forceinline__ void run_tasks_wave(const PmParams& p, const Lds& L, int row, int col0, int tid,
-                                               unsigned& evals) {
-  constexpr int CAP = LEAN ? kWaveThCapLean : CAPT;  // task slots per batch (LDS layout: lds_offsets_wave)
+template <bool GEOM, int NW, int CAP, bool MUBUF>
+__device__ __forceinline__ void run_tasks_wave(const PmParams& p, const Lds& L, const v4i srd, int row, int col0,
+                                               int tid, unsigned& evals) {
   const lds_f32* G = L.tapg;
-  // base pointer of source image s' packed footprints: LDS copy, or (LEAN) the table in global memory
-#define PM_FP_BASE(sv) (LEAN ? (gbl_u32*)p.src_fp_tab[sv] : (gbl_u32*)L.fpb[sv])
   const int n = L.ntasks[0];
   evals += (unsigned)n;
   const LDS_AS uint16_t* tasks = (const LDS_AS uint16_t*)L.tasks;
@@ -1875,9 +1702,12 @@ __device__ __forceinline__ void run_tasks_wave(const PmParams& p, const Lds& L, 
       const uint32_t task = gtasks[t];
       const int c = task >> 13, i = (task >> 9) & 7, s = task & 0x1ff;
       const lds_f32* h = L.hyp + (c * 5 + i) * 4;
-      L.geo[(c * 5 + i) * S + s] = geom_cost(p, PoseSrc<PG>::get(p, L, s), s, (float)row, (float)(col0 + c), h[0]);
+      L.geo[(c * 5 + i) * S + s] = geom_cost(p, L.poses + s * L.pstride, s, (float)row, (float)(col0 + c), h[0]);
     }
   }
+  // slot offset of texel (0, 0) relative to entry (0, 0): one strip (kFpRingX entries) and kFpRingY rows
+  const uint32_t origin = 4u * ((uint32_t)p.fp_rows1 + 1u) + 4u * (uint32_t)kFpRingY;
+  const uint32_t gorigin = fp_index(kFpRingX, kFpRingY, (unsigned)p.fp_rows1);  // the same as an entry index
   for (int base = 0; base < n; base += CAP) {
     const int nb = min(CAP, n - base);
     // pass A, lane per task: homography of the (hypothesis, view) pair (+ geometric cost)
@@ -1888,7 +1718,7 @@ __device__ __forceinline__ void run_tasks_wave(const PmParams& p, const Lds& L, 
       const int i = (task >> 9) & 7;
       const int s = task & 0x1ff;
       const lds_f32* h = L.hyp + (c * 5 + i) * 4;
-      const typename PoseSrc<PG>::ptr pose = PoseSrc<PG>::get(p, L, s);
+      const lds_f32* pose = L.poses + s * L.pstride;
       const int col = col0 + c;
       float Hm[9];
       compose_homography(p.refInvK, pose, row, col, h[0], h[1], h[2], h[3], Hm);
@@ -1911,96 +1741,39 @@ __device__ __forceinline__ void run_tasks_wave(const PmParams& p, const Lds& L, 
         L.tin[CAP + (inside ? __popcll(m1 & below) : __popcll(m1) + __popcll(m0 & below))] = (uint8_t)tid;
     }
     wave_sync<NW>();
-    // pass B, 16-lane group per task, software-pipelined: the gathers of a group's NEXT task are
-    // issued (ncc_front) before the texels of its current task are consumed (ncc_back), so a wave
-    // waits for memory only when a round's arithmetic is shorter than the gather latency. Two stage
-    // register sets ping-pong (loop unrolled by two: no register copies). Control flow is
-    // wave-uniform -- every group runs ceil(nb / 4) rounds, a group without a task in the last
-    // round recomputes the batch's last task and drops the result -- so that front / back pairs
-    // sit in straight-line code (the compiler then waits with vmcnt(8), not vmcnt(0)) and the DPP
-    // rows are always fully active.
+    // pass B, 16-lane group per task: one round = four tasks; all eight gathers of a lane are in flight before
+    // the first texel is consumed (ncc_front / ncc_back). Control flow is wave-uniform -- every group runs
+    // ceil(nb / 4) rounds, a group without a task in the last round recomputes the batch's last task and drops
+    // the result -- so that the DPP rows are always fully active.
     {
       const int rounds = (nb + 3) >> 2;
-      const lds_u32* ring = L.ring;
-      NccStage A, B;
-      int ta, tb, ca, cb;
-      bool wa, wb;
-      const int fp_origin = (int)fp_tiled(kFpRingX, kFpRingY, (unsigned)p.fp_tpr1);  // entry of texel (0, 0): tile (1, 1) of the packed image
-      auto prep = [&](int r, int& t, int& c, bool& own, bool& fast) -> uint32_t {
+      for (int r = 0; r < rounds; ++r) {
         const int tr = g + 4 * r;
-        own = tr < nb;
-        t = L.tin[CAP + (own ? tr : nb - 1)];
+        const bool own = tr < nb;
+        const int t = L.tin[CAP + (own ? tr : nb - 1)];
         const uint32_t task = tasks[base + t];
-        c = task >> 13;
+        const int c = task >> 13;
         // wave-uniform: the unclamped addressing only when all four patches of the round are inside
         // (a recomputed task may already hold its sums instead of its homography: it must take the
         // clamping path, where any coordinate is safe and the result is dropped)
-        fast = __all(own && L.tin[t] != 0) != 0;
-        return task & 0x1ff;
-      };
-#define PM_FRONT(STAGE, r, st, t, c, own)                                                  \
-  do {                                                                                     \
-    bool fast_;                                                                            \
-    const uint32_t sv_ = prep(r, t, c, own, fast_);                                        \
-    if (fast_) ncc_front<STAGE, true>(p, L.th + (t) * 9, fp_entry(PM_FP_BASE(sv_), fp_origin), G, j, st); \
-    else ncc_front<STAGE, false>(p, L.th + (t) * 9, PM_FP_BASE(sv_), G, j, st);       \
-  } while (0)
-#define PM_BACK(STAGE, NEWER, st, t, c, own)                                               \
-  do {                                                                                     \
-    TapRegs R_;                                                                            \
-    tap_regs_load(R_, L.wgt + (c) * 128, L.refc + (c) * 128, j);                           \
-    uint32_t tex_[8];                                                                      \
-    gather_wait<NEWER>();                                                                  \
-    _Pragma("unroll") for (int k_ = 0; k_ < 8; ++k_) tex_[k_] = ring[((STAGE) * 8 + k_) * 64 + tid]; \
-    float s_sum_, s_sq_, s_ref_;                                                           \
-    ncc_back(st, tex_, R_, j, s_sum_, s_sq_, s_ref_);                                      \
-    if (j == 0 && (own)) {                                                                 \
-      L.th[(t) * 9 + 0] = s_sum_; /* the homography of this task is no longer needed */    \
-      L.th[(t) * 9 + 1] = s_sq_;                                                           \
-      L.th[(t) * 9 + 2] = s_ref_;                                                          \
-    }                                                                                      \
-  } while (0)
-      if (!PIPE) {
-        // plain variant: one round at a time, all eight gathers of a lane in flight before the first
-        // texel is consumed (fewer registers and no LDS ring: more waves per SIMD instead)
-        for (int r = 0; r < rounds; ++r) {
-          bool fast_;
-          const uint32_t sv_ = prep(r, ta, ca, wa, fast_);
-          uint32_t tex_[8];
-          if (fast_) ncc_front<-1, true>(p, L.th + ta * 9, fp_entry(PM_FP_BASE(sv_), fp_origin), G, j, A, tex_);
-          else ncc_front<-1, false>(p, L.th + ta * 9, PM_FP_BASE(sv_), G, j, A, tex_);
-          __builtin_amdgcn_sched_barrier(0);
-          TapRegs R_;
-          tap_regs_load(R_, L.wgt + ca * 128, L.refc + ca * 128, j);
-          float s_sum_, s_sq_, s_ref_;
-          ncc_back(A, tex_, R_, j, s_sum_, s_sq_, s_ref_);
-          if (j == 0 && wa) {
-            L.th[ta * 9 + 0] = s_sum_;
-            L.th[ta * 9 + 1] = s_sq_;
-            L.th[ta * 9 + 2] = s_ref_;
-          }
+        const bool fast = __all(own && L.tin[t] != 0) != 0;
+        const uint32_t slot = MUBUF ? L.fpo[task & 0x1ff] : 0u;
+        gbl_u32* gbase = MUBUF ? nullptr : (gbl_u32*)L.fpb[task & 0x1ff];
+        NccStage A;
+        uint32_t tex[8];
+        if (fast) ncc_front<true, MUBUF>(p, srd, L.th + t * 9, slot + origin, gbase + gorigin, G, j, A, tex);
+        else ncc_front<false, MUBUF>(p, srd, L.th + t * 9, slot, gbase, G, j, A, tex);
+        __builtin_amdgcn_sched_barrier(0);
+        TapRegs R;
+        tap_regs_load(R, L.wgt + c * 128, L.refc + c * 128, j);
+        float s_sum, s_sq, s_ref;
+        ncc_back(A, tex, R, j, s_sum, s_sq, s_ref);
+        if (j == 0 && own) {
+          L.th[t * 9 + 0] = s_sum;  // the homography of this task is no longer needed
+          L.th[t * 9 + 1] = s_sq;
+          L.th[t * 9 + 2] = s_ref;
         }
-      } else {
-      PM_FRONT(0, 0, A, ta, ca, wa);
-      for (int r = 0;;) {
-        if (r + 1 >= rounds) {
-          PM_BACK(0, 0, A, ta, ca, wa);
-          break;
-        }
-        PM_FRONT(1, r + 1, B, tb, cb, wb);
-        PM_BACK(0, 8, A, ta, ca, wa);
-        ++r;
-        if (r + 1 >= rounds) {
-          PM_BACK(1, 0, B, tb, cb, wb);
-          break;
-        }
-        PM_FRONT(0, r + 1, A, ta, ca, wa);
-        PM_BACK(1, 8, B, tb, cb, wb);
-        ++r;
       }
-      }
-#undef PM_FRONT
-#undef PM_BACK
     }
     wave_sync<NW>();
     // lane per task: normalisation, variances, square root, division
@@ -2015,46 +1788,29 @@ __device__ __forceinline__ void run_tasks_wave(const PmParams& p, const Lds& L, 
     wave_sync<NW>();
   }
 }
-#undef PM_FP_BASE
 
-template <bool GEOM, bool FILTER_PHOTO, bool FILTER_GEOM, bool PIPE, bool PG = false, bool LEAN = false, int NW = 1,
-          int CAPT = kWaveThCap>
+template <bool GEOM, bool FILTER_PHOTO, bool FILTER_GEOM, int NW, int CAP, bool MUBUF>
 __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp) {
-  static_assert(NW == 1 || (!PIPE && !PG && !LEAN), "the multi-wave workgroup exists for the plain build only");
   const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y;
   unsigned group = lin / gridDim.y;
   unsigned prob = lin - group * gridDim.y;
   if (pp[0].xcd_map == 1) prob = (prob & 7u) * (gridDim.y >> 3) + (prob >> 3);  // see pm_sweep_kernel
-  if (pp[0].xcd_map == 2) {
-    // column-contiguous XCDs: workgroups are dealt to the 8 XCDs round-robin by linear id, so XCD
-    // x = lin % 8 takes, of every problem, the chunks of 8 adjacent column groups k = x, x + 8, ...
-    // (32 adjacent columns share one 128-byte line of a packed source row). The launcher pads
-    // grid.x to a multiple of 64 groups; surplus workgroups exit.
-    const unsigned x = lin & 7u, i = lin >> 3;
-    prob = i % gridDim.y;
-    const unsigned t = i / gridDim.y;
-    group = (((t >> 3) << 3) + x) * 8u + (t & 7u);
-    const PmParams& q = pp[prob];
-    const unsigned rw = (q.rot & 1) ? q.H : q.W;
-    if (group * q.C >= rw) return;
-  }
   const PmParams& p = pp[prob];
   extern __shared__ __attribute__((aligned(16))) char smem[];
   Lds L;
   // NW > 1: wave w of the workgroup sweeps column group NW * group + w out of its own LDS region; the pose
-  // records, base pointers and tap offsets are shared (lds_offsets_wave). After the one workgroup barrier
+  // records, packed-image slots and tap offsets are shared (lds_offsets_wave). After the one workgroup barrier
   // behind their initialisation the waves never meet again: every later synchronisation point is
   // wave_sync<NW>(), a memory fence without s_barrier -- exactly what __syncthreads() compiles to in the
   // single-wave workgroups.
   const int wave = NW == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   {
-    const LdsOffsets o = lds_offsets_wave(p.C, p.S, p.radius, p.ntaps, p.num_samples, GEOM, PIPE, PG, LEAN, CAPT, NW);
+    const LdsOffsets o = lds_offsets_wave(p.C, p.S, p.radius, p.ntaps, p.num_samples, GEOM, CAP, NW);
     lds_bind(L, (lds_char*)smem + wave * o.priv_stride, o);
-    if (NW > 1) {
-      L.poses = (lds_f32*)((lds_char*)smem + o.poses);
-      L.fpb = (lds_u64*)((lds_char*)smem + o.fpb);
-      L.tapg = (lds_f32*)((lds_char*)smem + o.tapg);
-    }
+    L.poses = (lds_f32*)((lds_char*)smem + o.poses);
+    L.fpo = (lds_u32*)((lds_char*)smem + o.fpb);
+    L.fpb = (lds_u64*)((lds_char*)smem + o.fpb);
+    L.tapg = (lds_f32*)((lds_char*)smem + o.tapg);
   }
   if (NW > 1) group = group * NW + wave;
   const int tid_entry = threadIdx.x & 63;
@@ -2065,23 +1821,23 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
   const int col0 = group * C;
   const int ncols = min(C, RW - col0);
   const float* iK = p.refInvK;
-  if (PIPE && (uint32_t)(uintptr_t)L.ring != 0u) __builtin_trap();  // gather_issue addresses the ring through a literal M0
-  if (NW == 1 || wave == 0) tap_geom_init(L.tapg, tid, p.step, (p.rot & 1) != 0);
-
-  if (NW > 1) {
-    lds_load_poses(p, L, GEOM, threadIdx.x, 64 * NW);
-    __syncthreads();                  // the only workgroup barrier of the kernel
-    if (col0 >= RW) return;           // surplus wave of the last workgroup (grid.x = ceil(groups / NW))
-  } else if (PG) {  // no LDS copy of the pose records; the packed-image base pointers still go to LDS
-    for (int i = tid; i < p.S; i += nt) L.fpb[i] = (uint64_t)p.src_fp_tab[i];
-  } else if (LEAN) {  // pose records in LDS, no copy of the base pointers
+  const v4i srd = MUBUF ? fp_resource(p) : (v4i)(0);
+  if (wave == 0) tap_geom_init(L.tapg, tid, p.step, (p.rot & 1) != 0);
+  {
+    // pose records and packed-image slots, once per workgroup
     L.pstride = lds_pose_stride(GEOM);
-    for (int i = tid; i < p.S * L.pstride; i += nt) {
+    for (int i = threadIdx.x; i < p.S * L.pstride; i += 64 * NW) {
       const int s = i / L.pstride;
       L.poses[i] = p.poses[s * kPoseStride + (i - s * L.pstride)];
     }
-  } else {
-    lds_load_poses(p, L, GEOM, tid, nt);
+    for (int i = threadIdx.x; i < p.S; i += 64 * NW) {
+      if (MUBUF) L.fpo[i] = p.src_fp_off[i];
+      else L.fpb[i] = (uint64_t)p.src_fp_tab[i];
+    }
+  }
+  if (NW > 1) {
+    __syncthreads();                  // the only workgroup barrier of the kernel
+    if (col0 >= RW) return;           // surplus wave of the last workgroup (grid.x = ceil(groups / NW))
   }
 
   // ---- backward messages for all rows (:976-989); stored in sel_out ----------
@@ -2114,11 +1870,11 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
   wave_sync<NW>();
 
   const int tid0 = tid_entry;
-  unsigned evals = 0;  // NCC evaluations of this workgroup (< 2^32: RH * C * (4 M + S) per sweep)
+  unsigned evals = 0;  // NCC evaluations of this wave (< 2^32: RH * C * (4 M + S) per sweep)
   for (int row = 0; row < RH; ++row) {
     // The lane id is laundered through an empty asm once per row: everything the phases derive from
     // it (item -> column / view, LDS addresses) is then recomputed per row instead of being hoisted
-    // out of the row loop and held in VGPRs across the NCC loop, whose two gather stages need them.
+    // out of the row loop and held in VGPRs across the NCC loop, which needs them.
     int tid = tid0;
     asm volatile("" : "+v"(tid));
     const bool col_lane = tid < ncols;
@@ -2169,17 +1925,15 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
       const int s = item - c * S;
       const int col = col0 + c;
       const float* rec = p.rec + (size_t)pix_index(p, row, col) * p.rec_stride;
-      const typename PoseSrc<PG>::ptr pose = PoseSrc<PG>::get(p, L, s);
+      const lds_f32* pose = L.poses + s * L.pstride;
       const lds_f32* h = L.hyp + c * 20;
       const lds_f32* cf = L.colf + c * 8;
       const float cost = rec[4 + s];
       const float beta = rec[p.sel_out_off + s];
       const float prev = rec[p.sel_in_off + s];
-      if (!LEAN) {
-        L.costv[item] = cost;
-        L.betav[item] = beta;
-        L.prevv[item] = prev;
-      }
+      L.costv[item] = cost;
+      L.betav[item] = beta;
+      L.prevv[item] = prev;
       const float alpha = hmm_message<true>(p, cost, L.fm[item]);
       const float sp = sel_prob_fn(alpha, beta, prev, p.prev_sel_prob_weight);
       float cos_tri, cos_inc;
@@ -2242,7 +1996,7 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
     wave_sync<NW>();
 
     // ---- P4: NCC of hypotheses 1..4 against the drawn views (:1157-1172) -----
-    if (!(p.ablate & 1)) run_tasks_wave<GEOM, PIPE, PG, LEAN, NW, CAPT>(p, L, row, col0, tid, evals);
+    if (!(p.ablate & 1)) run_tasks_wave<GEOM, NW, CAP, MUBUF>(p, L, srd, row, col0, tid, evals);
     if (tid == 0) { L.ntasks[0] = 0; L.ntasks[1] = 0; }
     wave_sync<NW>();
 
@@ -2254,7 +2008,7 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
       for (int m = 0; m < M; ++m) {
         const int src = L.sv[c * M + m];
         if (src < 0) continue;
-        if (i == 0) acc += LEAN ? p.rec[(size_t)pix_index(p, row, col0 + c) * p.rec_stride + 4 + src] : L.costv[c * S + src];
+        if (i == 0) acc += L.costv[c * S + src];
         else acc += L.ncc[(c * 4 + i - 1) * S + src];
         if (GEOM) acc += p.geom_reg * L.geo[(c * 5 + i) * S + src];
       }
@@ -2298,7 +2052,7 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
     wave_sync<NW>();
 
     // ---- P6: NCC of the winner against the remaining views (:1188-1197) ------
-    if (!(p.ablate & 1)) run_tasks_wave<false, PIPE, PG, LEAN, NW, CAPT>(p, L, row, col0, tid, evals);
+    if (!(p.ablate & 1)) run_tasks_wave<false, NW, CAP, MUBUF>(p, L, srd, row, col0, tid, evals);
 
     // ---- P7: cost map, forward message, selection probability (:1186-1207) ---
     for (int item = tid; item < ncols * S; item += nt) {
@@ -2309,20 +2063,18 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
       float* rec = p.rec + (size_t)pix_index(p, row, col) * p.rec_stride;
       float cost;
       if (k == 0) {
-        cost = LEAN ? rec[4 + s] : L.costv[item];
+        cost = L.costv[item];
       } else {
         cost = L.ncc[(c * 4 + k - 1) * S + s];
         rec[4 + s] = cost;
       }
       const float alpha = hmm_message<true>(p, cost, L.fm[item]);
-      const float beta_ = LEAN ? rec[p.sel_out_off + s] : L.betav[item];  // the backward message, until the store below
-      const float prev_ = LEAN ? rec[p.sel_in_off + s] : L.prevv[item];
-      const float prob = sel_prob_fn(alpha, beta_, prev_, p.prev_sel_prob_weight);
+      const float prob = sel_prob_fn(alpha, L.betav[item], L.prevv[item], p.prev_sel_prob_weight);
       L.fm[item] = alpha;
       rec[p.sel_out_off + s] = prob;
       if (FILTER_PHOTO || FILTER_GEOM) {
         const lds_f32* hb = L.hyp + (c * 5 + 1) * 4;  // == best (stored in P5)
-        const typename PoseSrc<PG>::ptr pose = PoseSrc<PG>::get(p, L, s);
+        const lds_f32* pose = L.poses + s * L.pstride;
         const float bp0 = hb[0] * (iK[0] * col + iK[1]);
         const float bp1 = hb[0] * (iK[2] * row + iK[3]);
         const float bp2 = hb[0];
@@ -2357,9 +2109,6 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
       }
     }
     wave_sync<NW>();
-    // experiment (COLMAP_AMD_PM_ROWSYNC=k): the waves of a workgroup meet every k rows, so that adjacent column
-    // groups gather the same source lines at the same time
-    if (NW > 1 && p.rowsync > 0 && (row + 1) % p.rowsync == 0) __syncthreads();
   }
 
   if (col_lane) {
@@ -2368,411 +2117,16 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
   if (tid == 0 && p.evals) atomicAdd(p.evals, (unsigned long long)evals);
 }
 
-// ---------------------------------------------------------------------------
-// Band-scheduled build of the same sweep (EXPERIMENTAL, COLMAP_AMD_PM_BAND=1; written at the end of round 3 after the
-// GPU budget was spent: it compiles, it has never run). Why: profiles/r03_pm_progress_trace.log -- the waves of a launch
-// drift so far apart in the sweep direction that half of every source image is in use at a time, and the gathers
-// miss the L2 and the infinity cache. Here a persistent grid of single-wave workgroups takes work items (band of
-// `band_rows` rows, column group, problem) from one ticket counter in band-major order: every column group of every
-// problem finishes band b before anybody starts band b + 2 or so. A column group's state crosses a band boundary
-// through global memory (PRNG words, forward messages, previous hypothesis: C x (6 + S + 4) words); an item waits
-// for the band above it on a per-group counter -- its ticket is older, so whoever holds it is running: no deadlock --
-// with agent-scope fences on both sides (the two waves may sit on different XCDs). The row step itself is
-// sweep_wave_body's, verbatim: results cannot depend on the schedule.
-// ---------------------------------------------------------------------------
-template <bool GEOM, bool FILTER_PHOTO, bool FILTER_GEOM, int CAPT>
-__device__ __forceinline__ void sweep_band_body(const PmParams* __restrict__ pp) {
-  constexpr bool PIPE = false, PG = false, LEAN = false;
-  constexpr int NW = 1;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid_entry = threadIdx.x;
-  const int tid = tid_entry;
-  constexpr int nt = 64;
-  const unsigned nprob = (unsigned)pp[0].band_nprob, ngroups = (unsigned)pp[0].band_groups;
-  const unsigned per_band = nprob * ngroups;
-  const unsigned total = per_band * (unsigned)pp[0].band_count;
-  for (;;) {
-    unsigned ticket = 0;
-    if (tid == 0) ticket = atomicAdd(pp[0].band_ticket, 1u);
-    ticket = (unsigned)__builtin_amdgcn_readfirstlane((int)ticket);
-    if (ticket >= total) break;
-    const unsigned band = ticket / per_band;
-    const unsigned idx = ticket - band * per_band;
-    const unsigned group = idx / nprob;       // consecutive tickets: the same columns of the batch's reference images
-    const unsigned prob = idx - group * nprob;
-    const PmParams& p = pp[prob];
-    const int S = p.S, M = p.num_samples, C = p.C;
-    const int RW = rot_width(p), RH = rot_height(p);
-    const int col0 = group * C;
-    const int r0 = (int)band * p.band_rows;
-    if (col0 >= RW || r0 >= RH) continue;
-    const int r1 = min(RH, r0 + p.band_rows);
-    const int ncols = min(C, RW - col0);
-    const float* iK = p.refInvK;
-    // the band above (older ticket: held by a running wave or finished)
-    if (band > 0)
-      while (__hip_atomic_load(p.band_done + group, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (int)band)
-        __builtin_amdgcn_s_sleep(16);
-    __threadfence();
-    Lds L;
-    lds_bind(L, (lds_char*)smem, lds_offsets_wave(p.C, p.S, p.radius, p.ntaps, p.num_samples, GEOM, false, false, false, CAPT, 1));
-    tap_geom_init(L.tapg, tid, p.step, (p.rot & 1) != 0);
-    lds_load_poses(p, L, GEOM, tid, nt);
-    const int words = C * (kRngWords + S + 4);       // state record of a column group
-    float* state = p.band_state + (size_t)group * words;
-    Rng rng;
-    rng.x0 = rng.x1 = rng.x2 = rng.x3 = rng.x4 = rng.d = 0;
-    const bool col_lane = tid < ncols;
-    if (band == 0) {
-      // ---- backward messages for all rows (:976-989); stored in sel_out ----------
-      for (int item = tid; item < ncols * S; item += nt) {
-        const int c = item / S;
-        const int s = item - c * S;
-        float beta = 0.5f;
-        for (int row = (p.ablate & 4) ? -1 : RH - 1; row >= 0; --row) {
-          float* rec = p.rec + (size_t)pix_index(p, row, col0 + c) * p.rec_stride;
-          beta = hmm_message<false>(p, rec[4 + s], beta);
-          rec[p.sel_out_off + s] = beta;
-        }
-        L.fm[c * S + s] = 0.5f;
-      }
-      // ---- per-column state kept by the column's lane (:1022-1028) ---------------
-      if (col_lane) {
-        const int pix0 = pix_index(p, 0, col0 + tid);
-        rng = rng_load(p.rng + (size_t)pix0 * kRngWords);
-        const float* rec = p.rec + (size_t)pix0 * p.rec_stride;
-        float sx, sy;
-        normal_to_sweep(p.rot, rec[1], rec[2], sx, sy);
-        lds_f32* h1 = L.hyp + (tid * 5 + 1) * 4;
-        h1[0] = rec[0]; h1[1] = sx; h1[2] = sy; h1[3] = rec[3];
-      }
-    } else {
-      // ---- the column group's state at the end of the band above -------------------
-      for (int item = tid; item < ncols * S; item += nt) L.fm[item] = state[C * kRngWords + item];
-      if (col_lane) {
-        rng = rng_load((const uint32_t*)state + tid * kRngWords);
-        lds_f32* h1 = L.hyp + (tid * 5 + 1) * 4;
-        const float* hs = state + C * (kRngWords + S) + tid * 4;
-        h1[0] = hs[0]; h1[1] = hs[1]; h1[2] = hs[2]; h1[3] = hs[3];
-      }
-    }
-    for (int r = r0 - p.radius; r < r0 + p.radius; ++r) tile_load_row(p, L, col0, r, tid, nt);
-    wave_sync<NW>();
-
-    const int tid0 = tid_entry;
-    unsigned evals = 0;  // NCC evaluations of this item (< 2^32: RH * C * (4 M + S) per sweep)
-    for (int row = r0; row < r1; ++row) {
-      // The lane id is laundered through an empty asm once per row: everything the phases derive from
-      // it (item -> column / view, LDS addresses) is then recomputed per row instead of being hoisted
-      // out of the row loop and held in VGPRs across the NCC loop, whose two gather stages need them.
-      int tid = tid0;
-      asm volatile("" : "+v"(tid));
-      const bool col_lane = tid < ncols;
-      if (p.trace && (row & 127) == 0 && tid == 0)  // debug: pm_enable_progress_trace
-        p.trace[(size_t)group * p.trace_stride + (row >> 7)] = __builtin_amdgcn_s_memrealtime();
-      // ---- P0: scroll the reference tile (LocalRefImage::Read, :357-410) -------
-      tile_load_row(p, L, col0, row + p.radius, tid, nt);
-      if (tid == 0) { L.ntasks[0] = 0; L.ntasks[1] = 0; }
-      wave_sync<NW>();
-
-      // ---- P1: hypotheses (lane per column) + patch weights (all lanes) --------
-      if (col_lane && !(p.ablate & 2)) {
-        const int c = tid;
-        const int col = col0 + c;
-        const int pix = pix_index(p, row, col);
-        const float* rec = p.rec + (size_t)pix * p.rec_stride;
-        lds_f32* h = L.hyp + c * 20;
-        h[4] = propagate_depth(iK, h[4], h[6], h[7], (float)(row - 1), (float)row);
-        const float cd = rec[0];
-        float cn0, cn1;
-        normal_to_sweep(p.rot, rec[1], rec[2], cn0, cn1);
-        const float cn2 = rec[3];
-        const float dmin = (1.0f - p.perturbation) * cd;
-        const float dmax = (1.0f + p.perturbation) * cd;
-        const float rd = rng_uniform(rng) * (dmax - dmin) + dmin;
-        float rn0, rn1, rn2;
-        perturb_normal(iK, row, col, p.perturbation_pi, cn0, cn1, cn2, rng, rn0, rn1, rn2);
-        for (int m = 0; m < M; ++m) L.us[c * M + m] = rng_uniform(rng) - FLT_EPSILON;  // :1129
-        h[0] = cd; h[1] = cn0; h[2] = cn1; h[3] = cn2;
-        h[8] = rd; h[9] = rn0; h[10] = rn1; h[11] = rn2;
-        h[12] = cd; h[13] = rn0; h[14] = rn1; h[15] = rn2;
-        h[16] = rd; h[17] = cn0; h[18] = cn1; h[19] = cn2;
-        lds_f32* cf = L.colf + c * 8;
-        cf[0] = p.ref_sum[pix];
-        cf[1] = p.ref_sqsum[pix];
-        cf[2] = cd * (iK[0] * col + iK[1]);
-        cf[3] = cd * (iK[2] * row + iK[3]);
-        cf[4] = cd;
-      }
-      patch_weights(p, L, row, tid, nt);
-      for (int item = tid; item < ncols * 4 * S; item += nt) L.ncc[item] = -1.0f;
-      wave_sync<NW>();
-
-      // ---- P2: per-view selection priors (:1070-1104), lane per (column, view) --
-      patch_weight_sums(p, L, ncols, tid, nt);
-      for (int item = tid; item < ncols * S; item += nt) {
-        const int c = item / S;
-        const int s = item - c * S;
-        const int col = col0 + c;
-        const float* rec = p.rec + (size_t)pix_index(p, row, col) * p.rec_stride;
-        const typename PoseSrc<PG>::ptr pose = PoseSrc<PG>::get(p, L, s);
-        const lds_f32* h = L.hyp + c * 20;
-        const lds_f32* cf = L.colf + c * 8;
-        const float cost = rec[4 + s];
-        const float beta = rec[p.sel_out_off + s];
-        const float prev = rec[p.sel_in_off + s];
-        if (!LEAN) {
-          L.costv[item] = cost;
-          L.betav[item] = beta;
-          L.prevv[item] = prev;
-        }
-        const float alpha = hmm_message<true>(p, cost, L.fm[item]);
-        const float sp = sel_prob_fn(alpha, beta, prev, p.prev_sel_prob_weight);
-        float cos_tri, cos_inc;
-        viewing_angles(pose, cf[2], cf[3], cf[4], h[1], h[2], h[3], cos_tri, cos_inc);
-        const float tp = tri_prob(p, cos_tri);
-        const float ip = inc_prob(p, cos_inc);
-        float Hm[9];
-        compose_homography(iK, pose, row, col, h[0], h[1], h[2], h[3], Hm);
-        const float rp = res_prob(Hm, (float)row, (float)col, p.radius);
-        L.q[item] = sp * tp * ip * rp;
-      }
-      wave_sync<NW>();
-
-      // ---- P3a: TransformPDFToCDF (:683-696), sequential sum order, lane per column
-      if (col_lane) {
-        const int c = tid;
-        lds_f32* q = L.q + c * S;
-        float prob_sum = 0.0f;
-  #pragma unroll 4
-        for (int i = 0; i < S; ++i) prob_sum += q[i];
-        const float inv_prob_sum = 1.0f / prob_sum;
-        float cum = 0.0f;
-  #pragma unroll 4
-        for (int i = 0; i < S; ++i) {
-          cum += q[i] * inv_prob_sum;
-          q[i] = cum;
-        }
-      }
-      wave_sync<NW>();
-      // ---- P3b: Monte-Carlo view draws (:1128-1138), lane per (column, draw) ----
-      for (int item = tid; item < ncols * M; item += nt) {
-        const int c = item / M;
-        const float u = L.us[item];
-        const lds_f32* q = L.q + c * S;
-        int src = -1;
-        for (int s = 0; s < S; ++s) {
-          if (q[s] > u) { src = s; break; }
-        }
-        L.sv[item] = src;
-      }
-      wave_sync<NW>();
-      // ---- P3c: one task set per distinct drawn view, lane per (column, view) ---
-      {
-        LDS_AS uint16_t* tasks = (LDS_AS uint16_t*)L.tasks;
-        for (int item = tid; item < ncols * S; item += nt) {
-          const int c = item / S;
-          const int s = item - c * S;
-          bool drawn = false;
-          for (int m = 0; m < M; ++m) drawn |= (L.sv[c * M + m] == s);
-          if (drawn) {
-            const int base = __hip_atomic_fetch_add(L.ntasks, 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            for (int i = 1; i < 5; ++i) tasks[base + i - 1] = (uint16_t)task16_pack(c, i, s, 0);
-            if (GEOM) {
-              const int gb = __hip_atomic_fetch_add(L.ntasks + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-              tasks[wave_max_tasks(C, S, M) + gb] = (uint16_t)task16_pack(c, 0, s, 1);
-            }
-          }
-        }
-      }
-      wave_sync<NW>();
-
-      // ---- P4: NCC of hypotheses 1..4 against the drawn views (:1157-1172) -----
-      if (!(p.ablate & 1)) run_tasks_wave<GEOM, PIPE, PG, LEAN, NW, CAPT>(p, L, row, col0, tid, evals);
-      if (tid == 0) { L.ntasks[0] = 0; L.ntasks[1] = 0; }
-      wave_sync<NW>();
-
-      // ---- P5a: accumulate in draw order (:1144-1172), lane per (column, hypothesis)
-      for (int item = tid; item < ncols * 5; item += nt) {
-        const int c = item / 5;
-        const int i = item - c * 5;
-        float acc = 0.0f;
-        for (int m = 0; m < M; ++m) {
-          const int src = L.sv[c * M + m];
-          if (src < 0) continue;
-          if (i == 0) acc += LEAN ? p.rec[(size_t)pix_index(p, row, col0 + c) * p.rec_stride + 4 + src] : L.costv[c * S + src];
-          else acc += L.ncc[(c * 4 + i - 1) * S + src];
-          if (GEOM) acc += p.geom_reg * L.geo[(c * 5 + i) * S + src];
-        }
-        L.csum[item] = acc;
-      }
-      wave_sync<NW>();
-      // ---- P5b: argmin, store, next row's previous state (:1176-1182,1279-1282) --
-      if (col_lane) {
-        const int c = tid;
-        int min_idx = 0;
-        float min_cost = L.csum[c * 5];
-  #pragma unroll
-        for (int i = 1; i < 5; ++i) {
-          const float ci = L.csum[c * 5 + i];
-          if (ci <= min_cost) { min_cost = ci; min_idx = i; }
-        }
-        L.best[c] = min_idx;
-        const lds_f32* hb = L.hyp + (c * 5 + min_idx) * 4;
-        const float bd = hb[0], b0 = hb[1], b1 = hb[2], b2 = hb[3];
-        float* rec = p.rec + (size_t)pix_index(p, row, col0 + c) * p.rec_stride;
-        float nx, ny;
-        normal_from_sweep(p.rot, b0, b1, nx, ny);
-        rec[0] = bd; rec[1] = nx; rec[2] = ny; rec[3] = b2;
-        lds_f32* h1 = L.hyp + (c * 5 + 1) * 4;
-        h1[0] = bd; h1[1] = b0; h1[2] = b1; h1[3] = b2;
-      }
-      wave_sync<NW>();
-      // ---- P5c: winner vs. the views not evaluated yet, lane per (column, view) --
-      {
-        LDS_AS uint16_t* tasks = (LDS_AS uint16_t*)L.tasks;
-        for (int item = tid; item < ncols * S; item += nt) {
-          const int c = item / S;
-          const int s = item - c * S;
-          const int k = L.best[c];
-          if (k != 0 && L.ncc[(c * 4 + k - 1) * S + s] < 0.0f) {
-            const int base = __hip_atomic_fetch_add(L.ntasks, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            tasks[base] = (uint16_t)task16_pack(c, k, s, 0);
-          }
-        }
-      }
-      wave_sync<NW>();
-
-      // ---- P6: NCC of the winner against the remaining views (:1188-1197) ------
-      if (!(p.ablate & 1)) run_tasks_wave<false, PIPE, PG, LEAN, NW, CAPT>(p, L, row, col0, tid, evals);
-
-      // ---- P7: cost map, forward message, selection probability (:1186-1207) ---
-      for (int item = tid; item < ncols * S; item += nt) {
-        const int c = item / S;
-        const int s = item - c * S;
-        const int col = col0 + c;
-        const int k = L.best[c];
-        float* rec = p.rec + (size_t)pix_index(p, row, col) * p.rec_stride;
-        float cost;
-        if (k == 0) {
-          cost = LEAN ? rec[4 + s] : L.costv[item];
-        } else {
-          cost = L.ncc[(c * 4 + k - 1) * S + s];
-          rec[4 + s] = cost;
-        }
-        const float alpha = hmm_message<true>(p, cost, L.fm[item]);
-        const float beta_ = LEAN ? rec[p.sel_out_off + s] : L.betav[item];  // the backward message, until the store below
-        const float prev_ = LEAN ? rec[p.sel_in_off + s] : L.prevv[item];
-        const float prob = sel_prob_fn(alpha, beta_, prev_, p.prev_sel_prob_weight);
-        L.fm[item] = alpha;
-        rec[p.sel_out_off + s] = prob;
-        if (FILTER_PHOTO || FILTER_GEOM) {
-          const lds_f32* hb = L.hyp + (c * 5 + 1) * 4;  // == best (stored in P5)
-          const typename PoseSrc<PG>::ptr pose = PoseSrc<PG>::get(p, L, s);
-          const float bp0 = hb[0] * (iK[0] * col + iK[1]);
-          const float bp1 = hb[0] * (iK[2] * row + iK[3]);
-          const float bp2 = hb[0];
-          float cos_tri, cos_inc;
-          viewing_angles(pose, bp0, bp1, bp2, hb[1], hb[2], hb[3], cos_tri, cos_inc);
-          int ok = 0;
-          if (!(cos_tri > p.filter_cos_min_tri || cos_inc <= 0.0f)) {
-            const float min_ncc_prob = ncc_prob(p, 1.0f - p.filter_min_ncc);
-            bool photo_ok = true, geom_ok = true;
-            if (FILTER_PHOTO) photo_ok = prob >= min_ncc_prob;
-            if (FILTER_GEOM)
-              geom_ok = geom_cost(p, pose, s, (float)row, (float)col, hb[0]) <= p.filter_geom_max_cost;
-            ok = (photo_ok && geom_ok) ? 1 : 0;
-          }
-          L.flags[item] = ok;
-        }
-      }
-      if (FILTER_PHOTO || FILTER_GEOM) {
-        wave_sync<NW>();
-        if (col_lane) {
-          const int c = tid;
-          int num = 0;
-          for (int s = 0; s < S; ++s) num += L.flags[c * S + s];
-          const int pix = pix_index(p, row, col0 + c);
-          if (num < p.filter_min_num_consistent) {
-            float* rec = p.rec + (size_t)pix * p.rec_stride;
-            rec[0] = 0.0f; rec[1] = 0.0f; rec[2] = 0.0f; rec[3] = 0.0f;
-          } else {
-            for (int s = 0; s < S; ++s)
-              if (L.flags[c * S + s]) p.mask[(size_t)s * p.W * p.H + pix] = 1;
-          }
-        }
-      }
-      wave_sync<NW>();
-    }
-
-
-    if (r1 == RH) {
-      if (col_lane) rng_store(p.rng + (size_t)pix_index(p, 0, col0 + tid) * kRngWords, rng);  // :1285-1287
-    } else {
-      for (int item = tid; item < ncols * S; item += nt) state[C * kRngWords + item] = L.fm[item];
-      if (col_lane) {
-        rng_store((uint32_t*)state + tid * kRngWords, rng);
-        const lds_f32* h1 = L.hyp + (tid * 5 + 1) * 4;
-        float* hs = state + C * (kRngWords + S) + tid * 4;
-        hs[0] = h1[0]; hs[1] = h1[1]; hs[2] = h1[2]; hs[3] = h1[3];
-      }
-    }
-    if (tid == 0 && p.evals) atomicAdd(p.evals, (unsigned long long)evals);
-    __threadfence();   // the band's stores (pixel records, state) before the counter
-    if (tid == 0) __hip_atomic_store(p.band_done + group, (int)band + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    wave_sync<NW>();   // LDS is reused by the next item
-  }
-}
-
-template <bool GEOM, bool FILTER_PHOTO, bool FILTER_GEOM>
-__global__ void __launch_bounds__(64, 4) pm_sweep_band_kernel(const PmParams* __restrict__ pp) {
-  sweep_band_body<GEOM, FILTER_PHOTO, FILTER_GEOM, kWaveThCap>(pp);
-}
-
-// Two builds of the same body: the software-pipelined one (3 waves per SIMD, 4 KB gather ring in
-// LDS) and the plain one (4 waves per SIMD by registers, no ring).
-template <bool GEOM, bool FILTER_PHOTO, bool FILTER_GEOM>
-__global__ void __launch_bounds__(64, 3) pm_sweep_wave_kernel(const PmParams* __restrict__ pp) {
-  sweep_wave_body<GEOM, FILTER_PHOTO, FILTER_GEOM, true>(pp);
-}
-template <bool GEOM, bool FILTER_PHOTO, bool FILTER_GEOM>
+// MUBUF: packed images addressed through the problem's buffer resource (the normal case), or by explicit indices
+template <bool GEOM, bool FILTER_PHOTO, bool FILTER_GEOM, bool MUBUF>
 __global__ void __launch_bounds__(64, 4) pm_sweep_wave4_kernel(const PmParams* __restrict__ pp) {
-  sweep_wave_body<GEOM, FILTER_PHOTO, FILTER_GEOM, false>(pp);
+  sweep_wave_body<GEOM, FILTER_PHOTO, FILTER_GEOM, 1, kWaveThCap, MUBUF>(pp);
 }
-// pose-global build of the same kernel (PoseSrc<true>): three columns per wave at the LDS footprint of two
-template <bool GEOM, bool FILTER_PHOTO, bool FILTER_GEOM>
-__global__ void __launch_bounds__(64, 4) pm_sweep_wave4g_kernel(const PmParams* __restrict__ pp) {
-  sweep_wave_body<GEOM, FILTER_PHOTO, FILTER_GEOM, false, true>(pp);
-}
-// lean-LDS build (lds_offsets_wave `lean`): three columns per wave in 10 240 B without the pose-global loads
-template <bool GEOM, bool FILTER_PHOTO, bool FILTER_GEOM>
-__global__ void __launch_bounds__(64, 4) pm_sweep_wave4l_kernel(const PmParams* __restrict__ pp) {
-  sweep_wave_body<GEOM, FILTER_PHOTO, FILTER_GEOM, false, false, true>(pp);
-}
-// ... and at five waves per SIMD (96 VGPRs, 13 dwords of scratch; two columns without the pose copy take 7.5 KB
-// of LDS = 21 workgroups per CU). Experiment: COLMAP_AMD_PM_WAVES=5.
-template <bool GEOM, bool FILTER_PHOTO, bool FILTER_GEOM>
-__global__ void __launch_bounds__(64, 5) pm_sweep_wave5g_kernel(const PmParams* __restrict__ pp) {
-  sweep_wave_body<GEOM, FILTER_PHOTO, FILTER_GEOM, false, true>(pp);
-}
-
 // Four waves per workgroup, each with its own column group, sharing one LDS copy of the read-only per-problem
-// tables (sweep_wave_body, NW = 4). The 2.7 KB saved per wave make room for a third column AND 64 task slots per
-// batch at S = 20 within 4 x 10 240 B = four workgroups = 16 waves per CU.
-constexpr int kQuadWaves = 4;
-template <bool GEOM, bool FILTER_PHOTO, bool FILTER_GEOM>
+// tables: four workgroups = 16 waves per CU with 64 task slots per batch at S = 20 (geometric pass included).
+template <bool GEOM, bool FILTER_PHOTO, bool FILTER_GEOM, bool MUBUF>
 __global__ void __launch_bounds__(64 * kQuadWaves, 4) pm_sweep_quad_kernel(const PmParams* __restrict__ pp) {
-  sweep_wave_body<GEOM, FILTER_PHOTO, FILTER_GEOM, false, false, false, kQuadWaves, 64>(pp);
-}
-template <bool GEOM, bool FILTER_PHOTO, bool FILTER_GEOM>
-__global__ void __launch_bounds__(64 * kQuadWaves, 4) pm_sweep_quad40_kernel(const PmParams* __restrict__ pp) {
-  sweep_wave_body<GEOM, FILTER_PHOTO, FILTER_GEOM, false, false, false, kQuadWaves, kWaveThCap>(pp);
-}
-
-// experiment: 8 / 16 waves per workgroup (with COLMAP_AMD_PM_ROWSYNC)
-template <bool GEOM, bool FILTER_PHOTO, bool FILTER_GEOM, int NW>
-__global__ void __launch_bounds__(64 * NW, 16 / NW) pm_sweep_strip_kernel(const PmParams* __restrict__ pp) {
-  sweep_wave_body<GEOM, FILTER_PHOTO, FILTER_GEOM, false, false, false, NW, 64>(pp);
+  sweep_wave_body<GEOM, FILTER_PHOTO, FILTER_GEOM, kQuadWaves, kQuadThCap, MUBUF>(pp);
 }
 
 // Debug: raw XORWOW streams of the generator above (seed = sequence id, as InitRandomStateKernel
@@ -2820,33 +2174,24 @@ static bool pm_quad_enabled() {  // read per call: the tests switch it inside on
   const char* e = getenv("COLMAP_AMD_PM_QUAD");
   return !e || atoi(e) != 0;
 }
-// task slots per batch of the four-wave kernel for this shape: 64, 40, or 0 = does not fit (single-wave kernel)
-static int pm_quad_cap(int C, int S, int radius, int ntaps, int M, bool geom) {
-  if (ntaps != 121) return 0;
-  for (int cap : {64, kWaveThCap})
-    if (lds_offsets_wave(C, S, radius, ntaps, M, geom, false, false, false, cap, kQuadWaves).total <= kQuadLdsBudget) return cap;
-  return 0;
-}
 
 int pm_pick_columns(int S, int ntaps, int num_samples, bool geom, int radius, int requested) {
   const size_t budget = 60 * 1024;
-  // default: 2 columns per single-wave workgroup of the 11 x 11 kernel (16 workgroups = 4 waves per
-  // SIMD resident per CU, the lane-per-(column, view) phases are one pass; measured 604 / 643 / 718 ms
-  // per 16-image launch for C = 2 / 3 / 4), 4 for the two-wave kernels
+  // default: 2 columns per wave of the 11 x 11 kernels (16 waves resident per CU, the lane-per-(column, view)
+  // phases are one pass; measured 604 / 643 / 718 ms per 16-image launch for C = 2 / 3 / 4), 4 for the generic kernel
   static const int cols_env = [] { const char* e = getenv("COLMAP_AMD_PM_COLS"); return e ? atoi(e) : 0; }();  // experiments / tests
   if (requested <= 0 && cols_env > 0) requested = cols_env;
   int c = requested > 0 ? requested : (ntaps == 121 ? 2 : 4);
-  // (the four-wave workgroups of pm_sweep_quad_kernel have room for a third column at S = 20, where the
-  // lane-per-(column, view) phases would fill 60 of 64 lanes in one pass: measured 621 ms against 606 ms for two)
   if (c > 64) c = 64;
   while (c > 1 && lds_offsets(c, S, radius, ntaps, num_samples, geom).total > budget) --c;
   return c;
 }
 
-// The fixed-window (11 x 11) kernels index packed images through fp32 (tap_gather<true>): exact
-// while an image has fewer than 2^24 entries; larger images take the generic kernels.
-static bool pm_fixed_window_ok(const PmParams& p) {
-  return (long long)pm_fp_entries(p.src_w, p.src_h) < (1ll << 24);
+// Can the 11 x 11 sweep kernels address this problem's packed source images through one buffer resource
+// (fp_resource)? The host has found all images inside a 4 GB window (pm_api.cpp) and the stride field of the
+// resource holds 4 * rows < 2^14.
+static bool pm_fp_resource_ok(const PmParams& p) {
+  return p.fp_base != nullptr && p.src_fp_off != nullptr && 4 * (p.fp_rows1 + 1) < (1 << 14);
 }
 
 void pm_launch_build_footprint(const uint8_t* src, uint32_t* fp, int S, int w, int h, hipStream_t st) {
@@ -2879,145 +2224,74 @@ void pm_launch_initial_cost(const PmParams& p, const PmParams* dev_params, int b
   const size_t lds = lds_offsets(p.C, p.S, p.radius, p.ntaps, p.num_samples, false).total;
   dim3 block(64, 1, 1);
   dim3 grid((p.W + p.C - 1) / p.C, p.H, batch);
-  if (p.ntap1d == 11 && pm_fixed_window_ok(p)) hipLaunchKernelGGL(pm_initial_cost_kernel<11>, grid, block, lds, st, dev_params);
+  if (p.ntap1d == 11) hipLaunchKernelGGL(pm_initial_cost_kernel<11>, grid, block, lds, st, dev_params);
   else hipLaunchKernelGGL(pm_initial_cost_kernel<0>, grid, block, lds, st, dev_params);
 }
 
-void pm_launch_sweep(const PmParams& p, const PmParams* dev_params, int batch, int threads, bool geom,
-                     bool filter_photo, bool filter_geom, hipStream_t st) {
-  // debug knob: extra dynamic LDS per workgroup limits the workgroups resident per CU (occupancy curve)
-  static const size_t lds_pad = [] { const char* e = getenv("COLMAP_AMD_PM_LDS_PAD"); return e ? (size_t)atol(e) : 0; }();
-  const size_t lds = pm_sweep_lds_bytes(p, geom) + lds_pad;
+// Which sweep kernel runs (three families):
+//  * pm_sweep_quad_kernel  -- 11 x 11 window, four-wave workgroups: the default whenever four workgroups fit a CU;
+//  * pm_sweep_wave4_kernel -- the same body in single-wave workgroups (shapes whose four-wave LDS block is too
+//    large, COLMAP_AMD_PM_QUAD=0 for A/B runs and tests);
+//  * pm_sweep_kernel       -- any window, 256-thread workgroups with barriers (round 1's design): other window
+//    sizes, the phase profile, COLMAP_AMD_PM_WAVE=0.
+// The two 11 x 11 kernels exist with and without the buffer-resource addressing of the packed images (fp_resource).
+// All three produce the same bits.
+const char* pm_launch_sweep(const PmParams& p, const PmParams* dev_params, int batch, int threads, bool geom,
+                            bool filter_photo, bool filter_geom, hipStream_t st) {
   const int rw = (p.rot & 1) ? p.H : p.W;
-  dim3 block(threads, 1, 1);
-  dim3 grid((rw + p.C - 1) / p.C, batch, 1);
-  // Default for the 11 x 11 window: single-wave workgroups (pm_sweep_wave_kernel); the two-wave
-  // kernel remains for other windows, very wide groups and as the A/B reference
-  // (COLMAP_AMD_PM_WAVE=0).
+  const unsigned groups = (unsigned)((rw + p.C - 1) / p.C);
   static const bool wave_enabled = [] { const char* e = getenv("COLMAP_AMD_PM_WAVE"); return !e || atoi(e) != 0; }();
-  if (wave_enabled && !p.prof && p.ntap1d == 11 && p.step >= 1 && pm_fixed_window_ok(p) && p.S <= 512 && p.C <= 8) {
-    // plain build (4 waves per SIMD) by default: measured 604 ms per 16-image launch against 649 ms for
-    // the LDS-DMA pipelined build (3 waves per SIMD, 10 workgroups per CU); COLMAP_AMD_PM_PIPE=1 selects
-    // the latter
-    static const bool pipe = [] { const char* e = getenv("COLMAP_AMD_PM_PIPE"); return PM_FP_FORMAT == 32 && e && atoi(e) != 0; }();  // (LDS-DMA gathers need the dword entries)
-    // pose records read from global memory instead of an LDS copy: on for >= 3 columns per wave (that is what
-    // makes the third column fit), COLMAP_AMD_PM_POSE_GLOBAL = 0 / 1 forces it
-    static const int pg_env = [] { const char* e = getenv("COLMAP_AMD_PM_POSE_GLOBAL"); return e ? atoi(e) : -1; }();
-    static const int waves_env = [] { const char* e = getenv("COLMAP_AMD_PM_WAVES"); return e ? atoi(e) : 4; }();
-    const bool w5 = !pipe && waves_env == 5;
-    static const int lean_env = [] { const char* e = getenv("COLMAP_AMD_PM_LEAN"); return e ? atoi(e) : -1; }();
-    // measured (16 x 2560 x 1920, S = 20): C = 3 lean 675 ms, C = 2 lean 702 ms against 608 ms for the default -- the
-    // global re-reads of the 256-byte-strided pixel records cost far more than the occupancy they buy: opt-in only
-    const bool lean = !pipe && !w5 && lean_env > 0;
-    const bool pg = !pipe && !lean && (w5 || (pg_env >= 0 ? pg_env != 0 : p.C >= 3));
-    const size_t wlds = lds_offsets_wave(p.C, p.S, p.radius, p.ntaps, p.num_samples, geom, pipe, pg, lean).total + lds_pad;
-    dim3 wblock(64, 1, 1);
-    dim3 wgrid = grid;
-    if (p.xcd_map == 2) wgrid.x = ((grid.x + 63) / 64) * 64;
-    // Experimental: band-scheduled persistent waves (sweep_band_body). The caller (pm_api.cpp) has filled the band
-    // fields of the parameter blocks when COLMAP_AMD_PM_BAND is set; the grid is what is resident at once.
-    if (p.band_ticket && !pipe && !lean && !w5 && !pg) {
-      const size_t blds = lds_offsets_wave(p.C, p.S, p.radius, p.ntaps, p.num_samples, geom, false, false, false, kWaveThCap, 1).total + lds_pad;
-      int dev = 0, cus = 0, per_cu = 0;
-      (void)hipGetDevice(&dev);
-      (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-      const long long items = (long long)p.band_nprob * p.band_groups * p.band_count;
-#define PM_LAUNCH_B(G, FP, FG)                                                                               \
-  do {                                                                                                       \
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pm_sweep_band_kernel<G, FP, FG>, 64, blds);  \
-    const long long resident = (long long)std::max(per_cu, 1) * std::max(cus, 1);                            \
-    hipLaunchKernelGGL((pm_sweep_band_kernel<G, FP, FG>), dim3((unsigned)std::min(items, resident)), wblock, blds, st, dev_params); \
+#define PM_LAUNCH_V4(KERNEL, MB, GRID, BLOCK, LDS)                                                   \
+  do {                                                                                              \
+    if (geom) {                                                                                     \
+      if (filter_photo && filter_geom) hipLaunchKernelGGL((KERNEL<true, true, true, MB>), GRID, BLOCK, LDS, st, dev_params);  \
+      else hipLaunchKernelGGL((KERNEL<true, false, false, MB>), GRID, BLOCK, LDS, st, dev_params);  \
+    } else {                                                                                        \
+      if (filter_photo) hipLaunchKernelGGL((KERNEL<false, true, false, MB>), GRID, BLOCK, LDS, st, dev_params);  \
+      else hipLaunchKernelGGL((KERNEL<false, false, false, MB>), GRID, BLOCK, LDS, st, dev_params); \
+    }                                                                                               \
   } while (0)
-      if (geom) {
-        if (filter_photo && filter_geom) PM_LAUNCH_B(true, true, true);
-        else PM_LAUNCH_B(true, false, false);
-      } else {
-        if (filter_photo) PM_LAUNCH_B(false, true, false);
-        else PM_LAUNCH_B(false, false, false);
-      }
-#undef PM_LAUNCH_B
-      return;
-    }
-    // Four-wave workgroups with shared read-only tables (pm_sweep_quad_kernel) when four of them fit a CU, i.e.
-    // the same 16 waves per CU as the single-wave kernel at its best: with 64 task slots per batch if that
-    // fits, else with 40. COLMAP_AMD_PM_QUAD=0 keeps the single-wave workgroups.
-    const int quad_cap = pm_quad_cap(p.C, p.S, p.radius, p.ntaps, p.num_samples, geom);
-    {
-      const char* e = getenv("COLMAP_AMD_PM_NW");
-      const int nw = e ? atoi(e) : 0;
-      if ((nw == 8 || nw == 16) && !geom && !filter_photo) {
-        const size_t slds = lds_offsets_wave(p.C, p.S, p.radius, p.ntaps, p.num_samples, geom, false, false, false, 64, nw).total;
-        dim3 sgrid((grid.x + nw - 1) / nw, grid.y, 1);
-        if (nw == 8) {
-          (void)hipFuncSetAttribute((const void*)pm_sweep_strip_kernel<false, false, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds);
-          hipLaunchKernelGGL((pm_sweep_strip_kernel<false, false, false, 8>), sgrid, dim3(512), slds, st, dev_params);
-        } else {
-          (void)hipFuncSetAttribute((const void*)pm_sweep_strip_kernel<false, false, false, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds);
-          hipLaunchKernelGGL((pm_sweep_strip_kernel<false, false, false, 16>), sgrid, dim3(1024), slds, st, dev_params);
-        }
-        return;
-      }
-    }
-    if (!pipe && !lean && !w5 && !pg && p.xcd_map != 2 && pm_quad_enabled() && quad_cap > 0) {
-      const size_t qlds = lds_offsets_wave(p.C, p.S, p.radius, p.ntaps, p.num_samples, geom, false, false, false,
-                                           quad_cap, kQuadWaves).total + lds_pad;
-      dim3 qblock(64 * kQuadWaves, 1, 1);
-      dim3 qgrid((grid.x + kQuadWaves - 1) / kQuadWaves, grid.y, 1);
-#define PM_LAUNCH_Q(G, FP, FG)                                                                               \
-  do {                                                                                                       \
-    if (quad_cap == 64) hipLaunchKernelGGL((pm_sweep_quad_kernel<G, FP, FG>), qgrid, qblock, qlds, st, dev_params); \
-    else hipLaunchKernelGGL((pm_sweep_quad40_kernel<G, FP, FG>), qgrid, qblock, qlds, st, dev_params);      \
+#define PM_LAUNCH_V(KERNEL, GRID, BLOCK, LDS)                \
+  do {                                                       \
+    if (mubuf) PM_LAUNCH_V4(KERNEL, true, GRID, BLOCK, LDS); \
+    else PM_LAUNCH_V4(KERNEL, false, GRID, BLOCK, LDS);      \
   } while (0)
-      if (geom) {
-        if (filter_photo && filter_geom) PM_LAUNCH_Q(true, true, true);
-        else PM_LAUNCH_Q(true, false, false);
-      } else {
-        if (filter_photo) PM_LAUNCH_Q(false, true, false);
-        else PM_LAUNCH_Q(false, false, false);
-      }
-#undef PM_LAUNCH_Q
-      return;
+  if (wave_enabled && !p.prof && p.ntap1d == 11 && p.step >= 1 && p.S <= 512 && p.C <= 8) {
+    // COLMAP_AMD_PM_FP_GLOBAL=1 (tests): explicit indices although the buffer resource would do
+    const char* fg = getenv("COLMAP_AMD_PM_FP_GLOBAL");
+    const bool mubuf = pm_fp_resource_ok(p) && !(fg && atoi(fg) != 0);
+    const size_t qlds = lds_offsets_wave(p.C, p.S, p.radius, p.ntaps, p.num_samples, geom, kQuadThCap, kQuadWaves).total;
+    if (pm_quad_enabled() && qlds <= kQuadLdsBudget) {
+      PM_LAUNCH_V(pm_sweep_quad_kernel, dim3((groups + kQuadWaves - 1) / kQuadWaves, batch, 1), dim3(64 * kQuadWaves, 1, 1), qlds);
+      return mubuf ? "pm_sweep_quad_kernel" : "pm_sweep_quad_kernel (explicit indices)";
     }
-#define PM_LAUNCH_W(G, FP, FG)                                                                              \
-  do {                                                                                                      \
-    if (pipe) hipLaunchKernelGGL((pm_sweep_wave_kernel<G, FP, FG>), wgrid, wblock, wlds, st, dev_params);   \
-    else if (lean) hipLaunchKernelGGL((pm_sweep_wave4l_kernel<G, FP, FG>), wgrid, wblock, wlds, st, dev_params); \
-    else if (w5) hipLaunchKernelGGL((pm_sweep_wave5g_kernel<G, FP, FG>), wgrid, wblock, wlds, st, dev_params); \
-    else if (pg) hipLaunchKernelGGL((pm_sweep_wave4g_kernel<G, FP, FG>), wgrid, wblock, wlds, st, dev_params); \
-    else hipLaunchKernelGGL((pm_sweep_wave4_kernel<G, FP, FG>), wgrid, wblock, wlds, st, dev_params);       \
-  } while (0)
-    if (geom) {
-      if (filter_photo && filter_geom) PM_LAUNCH_W(true, true, true);
-      else PM_LAUNCH_W(true, false, false);
-    } else {
-      if (filter_photo) PM_LAUNCH_W(false, true, false);
-      else PM_LAUNCH_W(false, false, false);
+    const size_t wlds = lds_offsets_wave(p.C, p.S, p.radius, p.ntaps, p.num_samples, geom, kWaveThCap, 1).total;
+    if (wlds <= 64 * 1024) {
+      PM_LAUNCH_V(pm_sweep_wave4_kernel, dim3(groups, batch, 1), dim3(64, 1, 1), wlds);
+      return mubuf ? "pm_sweep_wave4_kernel" : "pm_sweep_wave4_kernel (explicit indices)";
     }
-#undef PM_LAUNCH_W
-    return;
   }
+#undef PM_LAUNCH_V4
+#undef PM_LAUNCH_V
+  const size_t lds = pm_sweep_lds_bytes(p, geom);
+  dim3 block(threads, 1, 1);
+  dim3 grid(groups, batch, 1);
 #define PM_LAUNCH_N(N, G, FP, FG, PR) \
   hipLaunchKernelGGL((pm_sweep_kernel<N, G, FP, FG, PR>), grid, block, lds, st, dev_params)
-#define PM_LAUNCH(G, FP, FG)                      \
-  do {                                            \
-    if (p.ntap1d == 11 && pm_fixed_window_ok(p)) PM_LAUNCH_N(11, G, FP, FG, false); \
-    else PM_LAUNCH_N(0, G, FP, FG, false);        \
-  } while (0)
-  if (p.prof && !geom && !filter_photo && p.ntap1d == 11 && pm_fixed_window_ok(p)) {
+  if (p.prof && !geom && !filter_photo && p.ntap1d == 11) {
     PM_LAUNCH_N(11, false, false, false, true);
-    return;
+    return "pm_sweep_kernel";
   }
   if (geom) {
-    if (filter_photo && filter_geom) PM_LAUNCH(true, true, true);
-    else PM_LAUNCH(true, false, false);
+    if (filter_photo && filter_geom) PM_LAUNCH_N(0, true, true, true, false);
+    else PM_LAUNCH_N(0, true, false, false, false);
   } else {
-    if (filter_photo) PM_LAUNCH(false, true, false);
-    else PM_LAUNCH(false, false, false);
+    if (filter_photo) PM_LAUNCH_N(0, false, true, false, false);
+    else PM_LAUNCH_N(0, false, false, false, false);
   }
 #undef PM_LAUNCH_N
-#undef PM_LAUNCH
+  return "pm_sweep_kernel";
 }
-
 void pm_launch_rng_streams(const unsigned long long* seeds, int nseeds, int ndraws, float* out,
                            hipStream_t st) {
   hipLaunchKernelGGL(pm_rng_streams_kernel, dim3((nseeds + 63) / 64), dim3(64), 0, st, seeds, nseeds,

@@ -745,6 +745,17 @@ def solve_flat(fp: FlatProblem, so: Optional[SolverOptions] = None, gpu_index: i
         factor_seconds=float(r.factor_seconds))
 
 
+def num_camera_parameters(fp: FlatProblem) -> int:
+    """Size n_c of the reduced camera system (the matrix the exact tiers factor): the variable entries of the pose
+    and intrinsics blocks, i.e. everything that is not a point."""
+    free = np.asarray(fp.pose_const) == 0
+    n = 6 * int(np.count_nonzero(free)) - int(np.count_nonzero(free & (np.asarray(fp.pose_fixed_t) >= 0)))
+    n += int(np.count_nonzero(np.asarray(fp.cam_const) == 0))
+    if fp.sensors is not None and fp.sensor_const is not None:
+        n += 6 * int(np.count_nonzero(np.asarray(fp.sensor_const) == 0))
+    return n
+
+
 def shard_num_observations(fp: FlatProblem, rank: int, world_size: int, sharding: int = SHARD_BY_IMAGE) -> int:
     """Observations rank `rank` works on under image / point sharding (host-only, no GPU needed)."""
     L = lib()

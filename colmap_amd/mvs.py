@@ -393,6 +393,11 @@ class PatchMatch:
         return ms.value, n.value
 
 
+    def GetSweepKernelName(self):
+        name = C.c_char_p()
+        _check(lib().pm_get_sweep_kernel_name(self._h, C.byref(name)))
+        return (name.value or b"").decode()
+
     def GetSweepTimes(self):
         """ms of every sweep launch of the last run (pm_get_sweep_times)."""
         n = C.c_int32(0)

@@ -2,6 +2,7 @@
 # Runs on the GPU box: rocprofv3 kernel-trace stats of bench.py (PatchMatch part) + PMC passes of the
 # sweep kernel on the same launch shape (16 reference images per launch). Counter passes are separate
 # runs with --kernel-trace only (no other trace domain), restricted to the sweep kernel.
+# The kernel trace is of the primary leg only (--no-geom --no-ba): every sweep launch in it covers $BATCH images.
 # Outputs under gpurun_out/prof_$TAG; copy the summaries into profiles/ afterwards.
 TAG=${1:-r02}
 BATCH=${2:-16}
@@ -12,7 +13,7 @@ ulimit -c 0
 cd /tmp && export TMPDIR=/tmp
 echo "== kernel trace / stats of bench.py"
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- \
-  python $ROOT/bench.py --steps 1 --warmup 1 --batch $BATCH --no-cpu-baseline --no-ba \
+  python $ROOT/bench.py --steps 1 --warmup 1 --batch $BATCH --no-cpu-baseline --no-ba --no-geom \
   > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
 tail -c 600 $OUT/bench_under_rocprof.json
 python $ROOT/scripts/summarize_prof.py $OUT > /dev/null 2>&1
@@ -25,7 +26,7 @@ for ctrs in "FETCH_SIZE" "WRITE_SIZE" \
             "TA_TA_BUSY_sum TCP_PENDING_STALL_CYCLES_sum TCP_TOTAL_CACHE_ACCESSES_sum GRBM_GUI_ACTIVE"; do
   i=$((i+1))
   echo "== pmc pass $i: $ctrs"
-  timeout 240 rocprofv3 --kernel-trace --output-format csv --kernel-include-regex "pm_sweep" --pmc $ctrs \
+  timeout 120 rocprofv3 --kernel-trace --output-format csv --kernel-include-regex "pm_sweep" --pmc $ctrs \
     -d $OUT/pmc_p$i -o pmc -- $PROBE --sweeps 4 > $OUT/pmc_p$i.log 2>&1 || tail -3 $OUT/pmc_p$i.log
   python $ROOT/scripts/summarize_prof.py $OUT --per-dispatch > /dev/null 2>&1
   find $OUT/pmc_p$i -type f -size +1M -delete

@@ -25,6 +25,10 @@ __global__ void __launch_bounds__(64) k_gather(const unsigned* __restrict__ buf,
     if (width == 4) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) v[k] = base[(off[k] + pos) & mask];
+    } else if (width == 5) {   // dword loads at 2-byte granularity: offsets count halfwords
+      struct __attribute__((packed, aligned(2))) U { unsigned v; };
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = ((const U*)((const unsigned short*)base + ((off[k] + pos) & (2 * mask - 1))))->v;
     } else if (width == 2) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) v[k] = ((const unsigned short*)base)[(off[k] + pos) & (2 * mask + 1)];
@@ -113,6 +117,18 @@ int main(int argc, char** argv) {
     const int g = l / 16, j = l % 16, t = j + 16 * k, tt = t < 121 ? t : 0;
     return tiled(3 + g + tt % 11, 1 + tt / 11); }, 32);
 
+  // 2-byte entries, row-major (pitch 128 halfwords here), tap (tx, ty) of an 11 x 11 window at scale s: entry
+  // floor(x0 + tx * s), row floor(y0 + ty * s); offsets in halfwords (meaningful in the halfword-granular section)
+  for (float sc : {0.9f, 1.0f, 1.1f, 1.25f}) {
+    char nm[128]; snprintf(nm, sizeof nm, "halfword entries row-major, window at scale %.2f, 4 unrelated tasks", sc);
+    add(nm, [=](int k, int l) { const int g = l / 16, j = l % 16, t = j + 16 * k, tt = t < 121 ? t : 0;
+      const int x = (int)(5.3f + g * 7 + (tt % 11) * sc), y = (int)(1.2f + (tt / 11) * sc);
+      return (unsigned)(g * 4096 + y * 128 + x); }, 64);
+    snprintf(nm, sizeof nm, "dword entries in 16 x 2 blocks, window at scale %.2f, 4 unrelated tasks", sc);
+    add(nm, [=](int k, int l) { const int g = l / 16, j = l % 16, t = j + 16 * k, tt = t < 121 ? t : 0;
+      const int x = (int)(5.3f + g * 7 + (tt % 11) * sc), y = (int)(1.2f + (tt / 11) * sc);
+      return (unsigned)(g * 2048 + (x >> 4) * 512 + y * 16 + (x & 15)); }, 64);
+  }
   unsigned *d_buf, *d_pat, *d_out;
   hipMalloc(&d_buf, region * 4 * 4);
   hipMemset(d_buf, 1, region * 4 * 4);
@@ -123,8 +139,8 @@ int main(int argc, char** argv) {
   int cus = 0; hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0);
   const int waves_per_cu = 16;
   printf("gfx950 gather rates: %d CUs x %d waves, 8 loads per iteration, %d iterations, clock %.2f GHz\n", cus, waves_per_cu, iters, ghz);
-  for (int width : {4, 1}) {
-    printf("--- %d-byte loads per lane\n", width);
+  for (int width : {4, 5}) {
+    printf(width == 5 ? "--- 4-byte loads per lane at 2-byte granularity (offsets count halfwords)\n" : "--- %d-byte loads per lane\n", width);
     for (auto& p : pats) {
       hipMemcpy(d_pat, p.off.data(), p.off.size() * 4, hipMemcpyHostToDevice);
       // distinct 128-byte lines / 64-byte halves / 32-byte sectors of load 0 (per instruction and per quad)

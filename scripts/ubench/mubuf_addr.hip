@@ -29,7 +29,7 @@ __global__ void k_load(const uint32_t* base, uint32_t w1_hi, uint32_t num_record
     asm volatile("buffer_load_dword %0, %1, %2, 0 offen\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(vo), "s"(srd) : "memory");
   } else if (mode == 1) {
     asm volatile("buffer_load_dword %0, %1, %2, 0 idxen\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(vi), "s"(srd) : "memory");
-  } else {
+  } else {  // modes 2, 3
     uint64_t both = (uint64_t)vi | ((uint64_t)vo << 32);   // v[n] = index, v[n+1] = offset
     asm volatile("buffer_load_dword %0, %1, %2, 0 idxen offen\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(both), "s"(srd) : "memory");
   }
@@ -58,6 +58,7 @@ int main() {
     {"idxen offen, stride = row pitch 10304 (index = row, offset = 4 x)", 2, pitch, false, 0, 0, 1u << 24, 20000, pitch},
     {"idxen offen, stride = row pitch, offsets beyond the stride (image base folded into the offset)", 2, pitch, false, 0, 0, 1u << 24, 2000, 1u << 27},
     {"idxen offen, stride 4 (index = x), offset = row * pitch + image base", 2, 4, false, 0, 0, 1u << 24, 2576, 1u << 27},
+    {"idxen offen, stride 5152 (index = row), offset = 2 x + base: dword loads at 2-byte alignment", 3, 5152, false, 0, 0, 1u << 24, 20000, 5152},
     {"swizzle: stride 16, index_stride 8, element 4 (index = x), small offsets", 2, 16, true, 0, 1, 1u << 24, 2576, 16},
     {"swizzle: stride 16, index_stride 8, element 4 (index = x), large offsets", 2, 16, true, 0, 1, 1u << 24, 2576, 1u << 24},
     {"swizzle: stride 128, index_stride 8, element 4 (index = x), large offsets", 2, 128, true, 0, 1, 1u << 24, 2576, 1u << 24},
@@ -65,7 +66,7 @@ int main() {
   for (const Case& c : cases) {
     for (int i = 0; i < n; ++i) {
       idx[i] = c.max_idx ? rnd(c.max_idx) : 0u;
-      off[i] = c.max_off ? (rnd(c.max_off) & ~3u) : 0u;
+      off[i] = c.max_off ? (rnd(c.max_off) & (c.mode == 3 ? ~1u : ~3u)) : 0u;
     }
     hipMemcpy(d_idx, idx.data(), n * 4, hipMemcpyHostToDevice);
     hipMemcpy(d_off, off.data(), n * 4, hipMemcpyHostToDevice);
@@ -80,7 +81,13 @@ int main() {
       const uint64_t lin = (uint64_t)idx[i] * c.stride + off[i];
       const uint32_t is = istr[c.istride_sel], es = esz[c.esize_sel];
       const uint64_t swz = ((uint64_t)(idx[i] / is) * c.stride + (uint64_t)(off[i] / es) * es) * is + (idx[i] % is) * es + off[i] % es;
-      if (lin / 4 < ndw) { ++inrange; ok_lin += out[i] == (uint32_t)(lin / 4); }
+      if (lin / 4 < ndw) {
+        ++inrange;
+        // value of the 4 bytes at byte address lin of an array of little-endian dword indices
+        const uint64_t w0 = lin / 4, sh = (lin % 4) * 8;
+        const uint32_t expect = sh ? (uint32_t)(((w0 | ((w0 + 1) << 32)) >> sh) & 0xffffffffu) : (uint32_t)w0;
+        ok_lin += out[i] == expect;
+      }
       if (swz / 4 < ndw) ok_swz += out[i] == (uint32_t)(swz / 4);
       zeros += out[i] == 0u;
     }

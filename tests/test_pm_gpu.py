@@ -127,37 +127,40 @@ def test_group_shapes_do_not_change_results(pm_oracle, cols, threads):
     _assert_equal(want, got)
 
 
+@pytest.mark.parametrize("fp_global", ["0", "1"])
 @pytest.mark.parametrize("quad", ["0", "1"])
 @pytest.mark.parametrize("geom", [0, 1])
-def test_four_wave_workgroups_equal_single_wave_workgroups(pm_oracle, monkeypatch, quad, geom):
-    """pm_sweep_quad_kernel (four waves per workgroup sharing the read-only LDS tables, three columns per wave,
-    64 task slots per batch) against the single-wave workgroups (COLMAP_AMD_PM_QUAD=0), both against the oracle:
+def test_four_wave_workgroups_equal_single_wave_workgroups(pm_oracle, monkeypatch, quad, geom, fp_global):
+    """pm_sweep_quad_kernel (four waves per workgroup sharing the read-only LDS tables, 64 task slots per batch)
+    against the single-wave workgroups (COLMAP_AMD_PM_QUAD=0), both against the oracle:
     ragged width (67 columns = 22 groups of three + one column; 23 groups = 5 workgroups + 3 waves), S = 6."""
     monkeypatch.setenv("COLMAP_AMD_PM_QUAD", quad)
+    # packed images addressed through the buffer resource (the default) or by explicit indices (what problems whose
+    # images lie more than 4 GB apart get)
+    monkeypatch.setenv("COLMAP_AMD_PM_FP_GLOBAL", fp_global)
     views = scene(7, 67, 45)
     maps = None
     if geom:
         maps = [(v.depth.copy(), v.normal.copy()) for v in views]
-    want, got, _ = _run_both(pm_oracle, views, 3, [0, 1, 2, 4, 5, 6], maps=maps, geom_consistency=geom, filter=1,
-                             num_iterations=1)
+    want, got, pm = _run_both(pm_oracle, views, 3, [0, 1, 2, 4, 5, 6], maps=maps, geom_consistency=geom, filter=1,
+                              num_iterations=1)
     _assert_equal(want, got)
+    assert pm.GetSweepKernelName() == ("pm_sweep_quad_kernel" if quad == "1" else "pm_sweep_wave4_kernel") + \
+        (" (explicit indices)" if fp_global == "1" else "")
 
 
-@pytest.mark.skipif(not os.environ.get("COLMAP_AMD_TEST_EXPERIMENTAL"),
-                    reason="experimental band-scheduled sweep kernel (never run on a GPU yet): COLMAP_AMD_TEST_EXPERIMENTAL=1")
-@pytest.mark.parametrize("band_rows", ["16", "7", "64"])
-@pytest.mark.parametrize("geom", [0, 1])
-def test_band_scheduled_sweep_equals_oracle(pm_oracle, monkeypatch, band_rows, geom):
-    """COLMAP_AMD_PM_BAND=1: persistent waves take (band of rows, column group, problem) items in band-major order and
-    hand a column group's state from band to band through global memory (pm_kernels.hip: sweep_band_body). The schedule
-    must not change a bit: bands of 16, 7 (ragged: 45 and 67 rows are no multiples) and 64 (one band) rows."""
-    monkeypatch.setenv("COLMAP_AMD_PM_BAND", "1")
-    monkeypatch.setenv("COLMAP_AMD_PM_BAND_ROWS", band_rows)
-    views = scene(7, 67, 45)
-    maps = [(v.depth.copy(), v.normal.copy()) for v in views] if geom else None
-    want, got, _ = _run_both(pm_oracle, views, 3, [0, 1, 2, 4, 5, 6], maps=maps, geom_consistency=geom, filter=1,
-                             num_iterations=2)
+@pytest.mark.parametrize("wave", ["0", "1"])
+def test_generic_kernel_equals_wave_kernels(pm_oracle, wave):
+    """The generic sweep kernel (any window size; explicit strip indices through global loads) and the 11 x 11 wave
+    kernels (indices formed by the address unit from a swizzled buffer resource) read the same packed images: the
+    5 x 5 window (window_radius 2) only runs the former, the default window the latter -- both against the oracle,
+    and the handle reports which kernel ran."""
+    views = scene(5, 67, 45)
+    radius = 2 if wave == "0" else 5
+    want, got, pm = _run_both(pm_oracle, views, 2, [0, 1, 3, 4], geom_consistency=0, filter=1, num_iterations=1,
+                              window_radius=radius)
     _assert_equal(want, got)
+    assert pm.GetSweepKernelName() == ("pm_sweep_kernel" if wave == "0" else "pm_sweep_quad_kernel")
 
 
 def test_single_source_and_many_samples(pm_oracle):
