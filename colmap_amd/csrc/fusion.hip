@@ -105,7 +105,8 @@ struct Params {
   int* next_active;
   int* next_count;
   int* lane_walk;               // per lane: recorded pixels of the speculate walk | capped << 31 (state reuse)
-  int reuse;                    // num_active <= kLanes: a lane keeps its walk from speculate to commit
+  int lanes;                    // lanes of a launch = columns of the lane state: min(kLanes, seeds of the largest image)
+  int reuse;                    // num_active <= lanes: a lane keeps its walk from speculate to commit
   unsigned* barrier;            // lowest priority value among seeds whose closure overflowed the record
   int elem_cap;                 // min(max_num_pixels, rec_cap)
   int rec_cap;                  // record_capacity(max_num_pixels): slots of the lane state
@@ -114,7 +115,7 @@ struct Params {
   double max_depth_error;
   float max_sq_reproj, min_cos_normal;
   float bmin[3], bmax[3];
-  // lane state [slot][kLanes]
+  // lane state [slot][lanes]
   unsigned *e_pix, *e_meta, *e_rgb, *frame;
   float *e_x, *e_y, *e_z, *e_nx, *e_ny, *e_nz;
   // per-seed outputs
@@ -135,7 +136,7 @@ __device__ inline unsigned long long claim_key(unsigned round, unsigned prio) {
   return ((unsigned long long)round << 32) | (unsigned long long)(0xFFFFFFFFu - prio);
 }
 
-#define SLOT(buf, e) buf[(size_t)(e) * kLanes + lane]
+#define SLOT(buf, e) buf[(size_t)(e) * p.lanes + lane]
 
 // k-th smallest (0-based) of m floats: MSB-first radix select on the order-preserving integer key
 template <typename Get>
@@ -338,7 +339,7 @@ __device__ inline unsigned prio_of(const Params& p, int seed) { return (unsigned
 // seed after it in the order (barrier).
 __global__ void __launch_bounds__(kBlock) fusion_speculate_kernel(Params p) {
   const int lane = blockIdx.x * kBlock + threadIdx.x;
-  for (int idx = lane; idx < p.num_active; idx += kLanes) {
+  for (int idx = lane; idx < p.num_active; idx += p.lanes) {
     const int seed = seed_of(p, idx);
     const unsigned prio = prio_of(p, seed);
     const unsigned long long key = claim_key(p.round, prio);
@@ -360,7 +361,7 @@ __global__ void __launch_bounds__(kBlock) fusion_commit_kernel(Params p) {
   float* col = stage + threadIdx.x;
   const int lane = blockIdx.x * kBlock + threadIdx.x;
   const unsigned barrier = *p.barrier;
-  for (int idx = lane; idx < p.num_active; idx += kLanes) {
+  for (int idx = lane; idx < p.num_active; idx += p.lanes) {
     const int seed = seed_of(p, idx);
     const unsigned prio = prio_of(p, seed);
     const unsigned long long key = claim_key(p.round, prio);
@@ -691,8 +692,12 @@ void Run(const fusion_options& opt, int n, const fusion_image* images, const int
   Params p;
   std::memset(&p, 0, sizeof(p));
   p.images = d_img.p; p.optr = d_optr.p; p.oidx = d_oidx.p; p.mask = d_mask.p; p.claim = d_claim.p;
-  p.rec_cap = record_capacity(opt.max_num_pixels);
+  // Lane state: a walk cannot record more pixels than the workspace has, and no more lanes than the largest
+  // image has seeds are ever active -- the state is sized by both (a 4 x 48 x 36 workspace takes 2 MB, not
+  // the 13 GB of 10 000 slots x 32 768 lanes).
+  p.rec_cap = (int)std::min<long long>(record_capacity(opt.max_num_pixels), std::max<long long>(total_pix, 1));
   p.elem_cap = std::min(opt.max_num_pixels, p.rec_cap);
+  p.lanes = std::min(kLanes, (max_seeds + kBlock - 1) / kBlock * kBlock);
   p.max_level = opt.max_traversal_depth - 1;
   p.min_num_pixels = opt.min_num_pixels;
   p.max_depth_error = opt.max_depth_error;
@@ -701,7 +706,7 @@ void Run(const fusion_options& opt, int n, const fusion_image* images, const int
   for (int c = 0; c < 3; ++c) { p.bmin[c] = opt.bbox_min[c]; p.bmax[c] = opt.bbox_max[c]; }
   DevBuf<unsigned> e_pix, e_meta, e_rgb, frame;
   DevBuf<float> e_f[6];
-  const size_t state = (size_t)p.rec_cap * kLanes;
+  const size_t state = (size_t)p.rec_cap * p.lanes;
   e_pix.alloc(state); e_meta.alloc(state); e_rgb.alloc(state); frame.alloc(state);
   for (auto& b : e_f) b.alloc(state);
   p.e_pix = e_pix.p; p.e_meta = e_meta.p; p.e_rgb = e_rgb.p; p.frame = frame.p;
@@ -724,7 +729,7 @@ void Run(const fusion_options& opt, int n, const fusion_image* images, const int
 
   DevBuf<unsigned> keys_in, keys_out;
   DevBuf<int> seeds_in, order, rank_of, lane_walk;
-  keys_in.alloc(ms); keys_out.alloc(ms); seeds_in.alloc(ms); order.alloc(ms); rank_of.alloc(ms); lane_walk.alloc(kLanes);
+  keys_in.alloc(ms); keys_out.alloc(ms); seeds_in.alloc(ms); order.alloc(ms); rank_of.alloc(ms); lane_walk.alloc(p.lanes);
   p.rank_of = rank_of.p; p.lane_walk = lane_walk.p;
   size_t sort_bytes = 0;
   FU_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, keys_in.p, keys_out.p, seeds_in.p, order.p, (int)ms));
@@ -764,7 +769,7 @@ void Run(const fusion_options& opt, int n, const fusion_image* images, const int
     // for any of them). Knobs for experiments: COLMAP_AMD_FUSION_HEAD_DIV, COLMAP_AMD_FUSION_GROWTH.
     static const int head_div = [] { const char* e = getenv("COLMAP_AMD_FUSION_HEAD_DIV"); return e && atoi(e) > 0 ? atoi(e) : 64; }();
     static const int growth = [] { const char* e = getenv("COLMAP_AMD_FUSION_GROWTH"); return e && atoi(e) > 1 ? atoi(e) : 2; }();
-    const int head = std::min(kLanes, std::max(256, ns / head_div));
+    const int head = std::min(p.lanes, std::max(256, ns / head_div));
     for (int it = 0; p.num_active > 0 || offered < ns; ++it, ++round) {
       FU_CHECK(round != 0xFFFFFFFFu, "round counter");
       p.round = round;
@@ -772,8 +777,8 @@ void Run(const fusion_options& opt, int n, const fusion_image* images, const int
       FU_HIP(hipMemsetAsync(d_barrier.p, 0xFF, sizeof(unsigned), 0));
       FU_HIP(hipMemsetAsync(d_next_count.p, 0, sizeof(int), 0));
       if (p.num_active > 0) {
-        p.reuse = p.num_active <= kLanes ? 1 : 0;
-        const int grid = std::min(kLanes, (p.num_active + kBlock - 1) / kBlock * kBlock) / kBlock;
+        p.reuse = p.num_active <= p.lanes ? 1 : 0;
+        const int grid = std::min(p.lanes, (p.num_active + kBlock - 1) / kBlock * kBlock) / kBlock;
         hipLaunchKernelGGL(fusion_speculate_kernel, dim3(grid), dim3(kBlock), 0, 0, p);
         hipLaunchKernelGGL(fusion_commit_kernel, dim3(grid), dim3(kBlock), 0, 0, p);
         g_stats.rounds += 1;
