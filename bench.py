@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--ba-iters", type=int, default=10)
     ap.add_argument("--cpu-crop", type=str, default="512x384")
     ap.add_argument("--no-fusion", action="store_true", help="skip the stereo-fusion leg (needs the geometric leg)")
+    ap.add_argument("--no-dropin", action="store_true",
+                    help="skip the seam leg (one problem at a time / one host thread per problem, as the reference's controller calls it)")
     ap.add_argument("--no-geom", action="store_true",
                     help="skip the geometric-consistency leg (BASELINE config[2]'s two-pass flow at 2560x1920)")
     return ap.parse_args()
@@ -242,6 +244,60 @@ def pmc_traffic(images_per_launch, kernel):
 # packed source-image layout of the library this script measures (pm_internal.h: kFpStrip); a traffic file taken on
 # another layout does not describe this build
 PM_IMAGE_LAYOUT = "strips16x2-dword-footprints"
+
+
+def dropin_leg(a, problem, batched_value):
+    """The same problems through the seam exactly as the reference drives it: its
+    controller keeps ONE problem in flight per entry of --PatchMatchStereo.gpu_index (mvs/patch_match.cc:177,
+    190-204); listing a GPU several times gives that many worker threads on it (:375-383). Measured:
+      one_at_a_time    one PatchMatchCuda-shaped handle after the other (pm_create / pm_run / pm_get_*): a single
+                       2560 x 1920 problem has 1280 column groups for 4096 resident waves;
+      threads          `--batch` host threads, each with its own handle and stream on this GPU (the repeated-index
+                       route), all running at once;
+      batched          pm_run_batch of `--batch` problems (the primary number above: what the controller-side
+                       batching patch of INTEGRATION.md gives)."""
+    import threading
+    from colmap_amd import mvs
+    n1 = 2
+    pms = [problem(j)[0] for j in range(n1)]
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for pm in pms:
+        pm.Run()
+        pm.GetDepthMap()
+    torch.cuda.synchronize()
+    t_one = (time.time() - t0) / n1
+    for pm in pms:
+        pm.close()
+    nt = a.batch
+    pms = [problem(j)[0] for j in range(nt)]
+    errs = []
+
+    def work(pm):
+        try:
+            pm.Run()
+            pm.GetDepthMap()
+        except Exception as e:  # noqa: BLE001 (reported in the line)
+            errs.append(repr(e))
+    torch.cuda.synchronize()
+    t0 = time.time()
+    th = [threading.Thread(target=work, args=(pm,)) for pm in pms]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    torch.cuda.synchronize()
+    t_thr = time.time() - t0
+    for pm in pms:
+        pm.close()
+    mpix = a.width * a.height / 1e6
+    out = {"one_at_a_time_Mpix_per_s": mpix / t_one, "threads": nt, "threads_Mpix_per_s": nt * mpix / t_thr,
+           "batched_Mpix_per_s": batched_value,
+           "note": "create + run + depth-map read-back per problem, image cache shared; the controller of the "
+                   "reference calls it this way (one problem per worker thread)"}
+    if errs:
+        out["errors"] = errs[:3]
+    return out
 
 
 def geometric_leg(a, views, images, cache, local_rank):
@@ -525,6 +581,8 @@ def main():
             cw, ch = [int(x) for x in a.cpu_crop.split("x")]
             host_views = [syn.View(K, R, T, g.cpu().numpy(), None, None) for (K, R, T, g, _, _) in views]
             out["cpu_baseline"] = cpu_baseline(host_views, ref, src, dmin, dmax, (cw, ch))
+        if not a.no_dropin and world == 1:
+            out["dropin"] = dropin_leg(a, problem, value)
         if not a.no_geom and world == 1:
             fmaps, out["geometric"] = geometric_leg(a, views, images, cache, local_rank)
             if fmaps:

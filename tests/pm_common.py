@@ -108,3 +108,22 @@ def write_dense_workspace(path, views, num_points=400, seed=0, cfg_spec="__auto_
     W.write_model_binary(sm, os.path.join(path, "sparse"))
     W.write_patch_match_config(os.path.join(path, "stereo", "patch-match.cfg"), names, cfg_spec)
     return names
+
+
+def bench_crop_problem(device=None):
+    """The problem bench.py hands to the oracle for `cpu_baseline`: a 512 x 384 centre crop of a 2560 x 1920
+    reference image against its 20 full-resolution sources (S = 20, M = 15). Returns (views with the crop in the
+    reference's place, ref index, source indices, the crop view, depth range)."""
+    W, H, S, cw, ch = 2560, 1920, 20, 512, 384
+    views = syn.make_scene(S + 1, W, H, arc_deg=3.6 * S, **({"device": device} if device else {}))
+    ref = S // 2
+    src = [i for i in range(S + 1) if i != ref]
+    x0, y0 = (W - cw) // 2, (H - ch) // 2
+    v = views[ref]
+    K = v.K.copy()
+    K[0, 2] -= x0
+    K[1, 2] -= y0
+    crop = syn.View(K, v.R, v.T, np.ascontiguousarray(v.gray[y0:y0 + ch, x0:x0 + cw]),
+                    np.ascontiguousarray(v.depth[y0:y0 + ch, x0:x0 + cw]), None)
+    mixed = [crop if i == ref else u for i, u in enumerate(views)]
+    return mixed, ref, src, crop, (float(v.depth.min() * 0.9), float(v.depth.max() * 1.1))

@@ -335,19 +335,8 @@ def test_bench_cpu_baseline_crop_problem(pm_oracle):
     filter): the HIP path on the same inputs gives the same bits -- full-resolution source images
     (packed 2563 x 1923 footprints, fp32 entry index), S = 20, M = 15."""
     from colmap_amd import mvs
-    W, H, S, cw, ch = 2560, 1920, 20, 512, 384
-    views = syn.make_scene(S + 1, W, H, arc_deg=3.6 * S, device="cuda")
-    ref = S // 2
-    src = [i for i in range(S + 1) if i != ref]
-    x0, y0 = (W - cw) // 2, (H - ch) // 2
-    v = views[ref]
-    K = v.K.copy()
-    K[0, 2] -= x0
-    K[1, 2] -= y0
-    crop = syn.View(K, v.R, v.T, np.ascontiguousarray(v.gray[y0:y0 + ch, x0:x0 + cw]),
-                    np.ascontiguousarray(v.depth[y0:y0 + ch, x0:x0 + cw]), None)
-    mixed = [crop if i == ref else u for i, u in enumerate(views)]
-    dmin, dmax = float(v.depth.min() * 0.9), float(v.depth.max() * 1.1)
+    from pm_common import bench_crop_problem
+    mixed, ref, src, crop, (dmin, dmax) = bench_crop_problem(device="cuda")
     o, h = paired_options(pm_oracle, depth_min=dmin, depth_max=dmax, geom_consistency=0, filter=1)
     want = pm_oracle.run(o, oracle_inputs(mixed), ref, src, want_cost=True)
     pm = mvs.PatchMatch(h, hip_problem(mixed, ref, src))

@@ -120,16 +120,43 @@ def test_reference_initial_cost(pm_oracle, shape):
     assert d1.max() < 5e-4 and d1.mean() < 2e-5, (d1.max(), d1.mean())
 
 
-def _solve_three_ways(pm_oracle, views, r, src, maps=None, **kw):
+def _noise_floor(name, out_ref, out_fast):
+    """How far the reference moves away from ITSELF when its own arithmetic is perturbed by <= 2 ulp per
+    operation (oracle/_ref/libref_pm_fast.so: the same sources with -ffp-contract=fast): the agreement no
+    independent implementation can be asked to exceed. None when the perturbed build is not there."""
+    if out_fast is None:
+        return None
+    f = _agreement(out_fast["depth"], out_ref["depth"])
+    _STATS.setdefault("noise_floor", {})[name] = {k: float(v) for k, v in f.items()}
+    return f
+
+
+def _bars(floor, defaults):
+    """Bars of a statistical comparison with the reference: where the reference's own floor is known, the floor
+    minus a margin (a quarter of the floor's distance from perfect agreement, at least 0.005) -- NOT what the HIP
+    path happened to reach; the round-3 constants only when the perturbed reference build is missing."""
+    if floor is None:
+        return dict(defaults)
+    return {k: floor[k] - max(0.005, 0.25 * (1.0 - floor[k])) for k in defaults}
+
+
+def _solve_three_ways(pm_oracle, views, r, src, maps=None, depth_range=None, with_fast=False, with_oracle=True, **kw):
     from colmap_amd import mvs
     imgs = oracle_inputs(views, maps is not None, maps)
-    dmin, dmax = syn.depth_range(views, r)
+    dmin, dmax = depth_range if depth_range else syn.depth_range(views, r)
     o = pm_oracle.default_options(depth_min=dmin, depth_max=dmax, **kw)
     ref = ref_pm.RefPatchMatch(o, imgs, r, src)
     out_ref = ref.run()
     ref.close()
+    if with_fast:
+        out_fast = None
+        if ref_pm.fast_available():
+            reff = ref_pm.RefPatchMatch(o, imgs, r, src, fast=True)
+            out_fast = reff.run()
+            reff.close()
+        _solve_three_ways.fast = out_fast
     o.order = 0
-    out_o0 = pm_oracle.run(o, imgs, r, src)
+    out_o0 = pm_oracle.run(o, imgs, r, src) if with_oracle else None
     _, h = paired_options(pm_oracle, depth_min=dmin, depth_max=dmax, **kw)
     pm = mvs.PatchMatch(h, hip_problem(views, r, src, maps))
     pm.Run()
@@ -150,15 +177,18 @@ def test_reference_full_solve_config0_photometric(pm_oracle):
     (1e-3 on >= 90 %) of the pixels both keep, the filters keep the same pixels on >= 99 %, and the accuracy
     against ground truth is the same (median relative error within 5e-5, fractions within 0.005)."""
     views = syn.make_scene(3, 640, 480, focal=600.0, arc_deg=8.0)
-    out_ref, out_o0, out_hip = _solve_three_ways(pm_oracle, views, 1, [0, 2], geom_consistency=0, filter=1)
+    out_ref, out_o0, out_hip = _solve_three_ways(pm_oracle, views, 1, [0, 2], with_fast=True, geom_consistency=0, filter=1)
     gt = views[1].depth
     a0, a1 = _agreement(out_o0["depth"], out_ref["depth"]), _agreement(out_hip["depth"], out_ref["depth"])
+    floor = _noise_floor("config0_photometric", out_ref, _solve_three_ways.fast)
     g = {k: _gt_stats(v["depth"], gt) for k, v in (("reference", out_ref), ("oracle_order0", out_o0), ("hip", out_hip))}
-    _record("config0_photometric", oracle_order0_vs_reference=a0, hip_vs_reference=a1, ground_truth=g)
-    # observed (profiles/r03_pm_ref_parity.json): same_kept 0.998 / 0.997, within 1e-3 0.937 / 0.925, within 1e-2
-    # 0.992 / 0.990 (oracle order 0 / HIP); ground-truth medians 1.46e-4 / 1.47e-4 / 1.34e-4, kept 0.5120 / 0.5119 / 0.5120
+    _record("config0_photometric", oracle_order0_vs_reference=a0, hip_vs_reference=a1, ground_truth=g, floor=floor)
+    # round 3 observed same_kept 0.998 / 0.997, within 1e-3 0.937 / 0.925, within 1e-2 0.992 / 0.990 (oracle order 0 /
+    # HIP). The bars are the reference's own floor under a 2-ulp perturbation minus a margin (_bars), not those values.
+    bars = _bars(floor, dict(same_kept=0.99, within_1e2=0.98, within_1e3=0.90))
+    _STATS["config0_photometric"]["bars"] = bars
     for a in (a0, a1):
-        assert a["same_kept"] >= 0.99 and a["within_1e2"] >= 0.98 and a["within_1e3"] >= 0.90, a
+        assert all(a[k] >= bars[k] for k in bars), (a, bars, floor)
     for k in ("oracle_order0", "hip"):
         assert abs(g[k]["median_rel"] - g["reference"]["median_rel"]) < 5e-5, g
         assert abs(g[k]["within_1pct"] - g["reference"]["within_1pct"]) < 0.005, g
@@ -195,8 +225,43 @@ def test_reference_first_sweeps_s4(pm_oracle):
     """One iteration (four sweeps, no filter) on the 5-view scene: trajectories have had little time to
     diverge, so the bar is tighter -- >= 99 % of the pixels within 1e-3 relative depth of the reference."""
     views = scene()
-    out_ref, out_o0, out_hip = _solve_three_ways(pm_oracle, views, 2, [0, 1, 3, 4], geom_consistency=0, filter=0,
-                                                 num_iterations=1)
+    out_ref, out_o0, out_hip = _solve_three_ways(pm_oracle, views, 2, [0, 1, 3, 4], with_fast=True, geom_consistency=0,
+                                                 filter=0, num_iterations=1)
     a0, a1 = _agreement(out_o0["depth"], out_ref["depth"]), _agreement(out_hip["depth"], out_ref["depth"])
-    _record("first_iteration_s4", oracle_order0_vs_reference=a0, hip_vs_reference=a1)
-    assert a0["within_1e3"] >= 0.99 and a1["within_1e3"] >= 0.99, (a0, a1)  # observed 1.0 / 0.9993
+    floor = _noise_floor("first_iteration_s4", out_ref, _solve_three_ways.fast)
+    bars = _bars(floor, dict(within_1e3=0.99))
+    _record("first_iteration_s4", oracle_order0_vs_reference=a0, hip_vs_reference=a1, floor=floor, bars=bars)
+    assert a0["within_1e3"] >= bars["within_1e3"] and a1["within_1e3"] >= bars["within_1e3"], (a0, a1, bars)  # round 3: 1.0 / 0.9993
+
+
+def test_reference_full_solve_bench_crop(pm_oracle):
+    """The benchmark's own configuration through the reference build: BASELINE.json config[1]'s problem as
+    bench.py's `cpu_baseline` crops it (512 x 384 centre crop of a 2560 x 1920 reference image, its 20
+    full-resolution sources, S = 20, M = 15, the full 5 x 4 sweep schedule of patch_match_cuda.cu:1393-1546,
+    photometric + filter). Reference vs oracle in the reference's order vs HIP, against the reference's own
+    noise floor (the same sources, -ffp-contract=fast) and against ground truth."""
+    from pm_common import bench_crop_problem
+    mixed, r, src, crop, rng = bench_crop_problem()
+    # (the oracle in the reference's order takes 12 minutes of host time on this problem -- it recomputes the patch
+    # weights per evaluation like the reference -- and agreed with the reference on 99.74 % / 99.85 % of the pixels
+    # (1e-3 / 1e-2) when it was run, profiles/r04_pm_ref_parity.json; COLMAP_AMD_TEST_SLOW=1 runs it again)
+    slow = bool(os.environ.get("COLMAP_AMD_TEST_SLOW"))
+    out_ref, out_o0, out_hip = _solve_three_ways(pm_oracle, mixed, r, src, depth_range=rng, with_fast=True,
+                                                 with_oracle=slow, geom_consistency=0, filter=1)
+    gt = crop.depth
+    cmp = [("hip", out_hip)] + ([("oracle_order0", out_o0)] if slow else [])
+    agree = {k: _agreement(v["depth"], out_ref["depth"]) for k, v in cmp}
+    floor = _noise_floor("bench_crop", out_ref, _solve_three_ways.fast)
+    g = {k: _gt_stats(v["depth"], gt) for k, v in [("reference", out_ref)] + cmp}
+    m1 = (out_hip["mask"] == out_ref["mask"]).mean()
+    # measured: floor 0.99685 / 0.99818 (1e-3 / 1e-2), HIP 0.99685 / 0.99798, consistency masks equal on 99.94 %
+    bars = _bars(floor, dict(same_kept=0.98, within_1e2=0.97, within_1e3=0.85))
+    _record("bench_crop", **{k + "_vs_reference": v for k, v in agree.items()}, ground_truth=g, mask_equal_hip=m1,
+            floor=floor, bars=bars)
+    for a in agree.values():
+        assert all(a[k] >= bars[k] for k in bars), (a, bars, floor)
+    assert m1 >= 0.995
+    for k, _ in cmp:
+        assert abs(g[k]["median_rel"] - g["reference"]["median_rel"]) < 1e-4, g
+        assert abs(g[k]["within_1pct"] - g["reference"]["within_1pct"]) < 0.01, g
+        assert abs(g[k]["kept"] - g["reference"]["kept"]) < 0.01, g
