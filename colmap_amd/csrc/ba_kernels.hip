@@ -128,6 +128,7 @@ struct View {
   double* Jsens;                     // c-order [2 x 6][n_obs] sensor-tangent columns (only with variable sensors)
   int n_sensors;
   int loss_type;                     // BA_LOSS_*
+  const int* stop;                   // pipelined PCG: kernels of an iteration enqueued past convergence return at once; else NULL
   double loss_scale;
   const int *c2a, *a2c;              // c-order position <-> p-order position (sorted by point)
   // p-order copies of the per-observation topology (the point-side linearisation pass reads them
@@ -1242,6 +1243,7 @@ __global__ void __launch_bounds__(TILE_PTS) ba_point_pass_tiled_kernel(View V, c
                                                                        double* __restrict__ dp) {
   __shared__ double sJ[6][TILE_OBS];
   __shared__ double sx[2][TILE_OBS];
+  if (V.stop && *V.stop) return;
   const int t = blockIdx.x;
   const int p0 = V.tile_pt[t], p1 = V.tile_pt[t + 1];
   const int a0 = V.pt_ptr[p0], na = V.pt_ptr[p1] - a0;
@@ -1375,6 +1377,7 @@ template <int KD, typename JT = double>
 __global__ void ba_obs_jx_kernel(View V, const double* __restrict__ x, double* __restrict__ jx) {
   const int o = blockIdx.x * blockDim.x + threadIdx.x;
   if (o >= V.n_obs) return;
+  if (V.stop && *V.stop) return;
   const size_t N = (size_t)V.n_obs;
   const JT* __restrict__ Jpo = JSel<JT>::pose(V);
   const JT* __restrict__ Jca = JSel<JT>::cam(V);
@@ -1492,6 +1495,7 @@ __device__ __forceinline__ const double* blk_col(const View& V, int kind, int r,
 template <bool DIAG, int BD, typename JT = double>
 __global__ void __launch_bounds__(64) ba_block_jtv_kernel(View V, const double* __restrict__ v,
                                                          double* __restrict__ y, double* __restrict__ diag) {
+  if (V.stop && *V.stop) return;
   const int ch = blockIdx.x;
   const int b = V.chunk_blk[ch];
   const int kind = V.blk_kind[b], dim = V.blk_dim[b], off = V.blk_off[b];
@@ -2030,6 +2034,150 @@ __global__ void __launch_bounds__(1024) ba_pcg_fused_kernel(View V, const double
   }
 }
 
+// ---------------------------------------------------------------------------
+// Pipelined PCG (single GPU, no priors): three small multi-workgroup kernels per iteration around the three
+// streaming kernels of the implicit product, the stopping test on the device, the host one iteration behind.
+//   dir_k   (thread per entry)  closes iteration k-1 -- Q = sum of its partials, the stopping test of Ceres'
+//           CG (zeta = k (Q_k - Q_{k-1}) / Q_k < eta), the iteration's scalars into a pinned host slot -- and, unless
+//           it stopped, p = z + (rho_k / rho_{k-1}) p;
+//   tail_k  (lane per block)    q_b = Dc_b^2 p_b + sum of the block's J_b^T v chunk partials, partials of p.q;
+//   step_k  (lane per block)    alpha = rho / pq, x += alpha p, r -= alpha q, partials of Q = -x.(b + r) / 2,
+//           z_b = Minv_b r_b, partials of rho' = r.z.
+// Sums over workgroups are added in index order by every thread that needs them (a handful of values): deterministic.
+// Partials alternate between two banks by iteration parity, so a kernel never reads what its own grid is writing.
+// The host enqueues iteration k+1 before it looks at iteration k; once the device has set `stop` every later kernel
+// (the streaming kernels through View::stop) returns at entry.
+// ---------------------------------------------------------------------------
+struct PcgHostSlot {
+  double rho, pq, Q;
+  int stop, iter;
+};
+struct PcgDev {
+  double* part;        // [2 banks][3: pq, rho, Q][nparts]
+  int nparts;
+  int* stop;           // device flag
+  PcgHostSlot* host;   // [2] pinned, device-visible
+  double* qhist;       // [2] Q of the last two iterations
+};
+__device__ __forceinline__ double pcg_sum(const double* __restrict__ part, int nparts) {
+  double s = 0.0;
+  for (int w = 0; w < nparts; ++w) s += part[w];
+  return s;
+}
+// x = 0, r = b, z = Minv r, partials of rho_1 into bank 1
+__global__ void __launch_bounds__(256) ba_pcgp_init_kernel(View V, PcgDev D, const double* __restrict__ Minv,
+                                                           const double* __restrict__ rhs, double* __restrict__ x,
+                                                           double* __restrict__ r, double* __restrict__ z) {
+  double rho = 0.0;
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b < V.n_blk) {
+    const int n = V.blk_dim[b], off = V.blk_off[b];
+    const double* Mi = Minv + V.blk_moff[b];
+    for (int i = 0; i < n; ++i) { x[off + i] = 0.0; r[off + i] = rhs[off + i]; }
+    for (int i = 0; i < n; ++i) {
+      double sacc = 0.0;
+      for (int j = 0; j < n; ++j) sacc += Mi[i * n + j] * rhs[off + j];
+      z[off + i] = sacc;
+      rho += sacc * rhs[off + i];
+    }
+  }
+  rho = block_sum(rho);
+  if (threadIdx.x == 0) D.part[(1 * 3 + 1) * D.nparts + blockIdx.x] = rho;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { *D.stop = 0; D.qhist[0] = 0.0; D.qhist[1] = 0.0; }
+}
+__global__ void ba_pcgp_dir_kernel(int n, PcgDev D, int k, int max_iter, double q_tol, const double* __restrict__ z,
+                                   double* __restrict__ p) {
+  if (*D.stop) return;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const double* bank_prev = D.part + (size_t)((k - 1) & 1) * 3 * D.nparts;   // what iteration k-1 consumed / produced
+  const double* bank = D.part + (size_t)(k & 1) * 3 * D.nparts;
+  const double rho_new = pcg_sum(bank + D.nparts, D.nparts);                // rho_k
+  bool stop = false;
+  double rho_prev = 0.0, pq = 0.0, Q1 = 0.0;
+  if (k == 1) {
+    stop = rho_new == 0.0;                                                    // zero right-hand side: nothing to solve
+  } else {
+    rho_prev = pcg_sum(bank_prev + D.nparts, D.nparts);                       // rho_{k-1}
+    pq = pcg_sum(bank_prev, D.nparts);
+    Q1 = pcg_sum(bank_prev + 2 * D.nparts, D.nparts);
+    const double Q0 = D.qhist[k & 1];                                         // Q_{k-2}
+    const int it = k - 1;
+    if (!(rho_prev > 0.0) || !isfinite(rho_prev) || !(pq > 0.0) || !isfinite(pq)) stop = true;
+    else if ((double)it * (Q1 - Q0) / Q1 < q_tol) stop = true;
+    else if (it >= max_iter) stop = true;
+  }
+  if (i == 0) {
+    PcgHostSlot h;
+    h.rho = rho_prev; h.pq = pq; h.Q = Q1; h.stop = stop ? 1 : 0; h.iter = k - 1;
+    D.host[(k - 1) & 1] = h;
+    if (k > 1) D.qhist[(k - 1) & 1] = Q1;
+    __threadfence_system();
+  }
+  if (stop) {
+    // every workgroup decides alike from the same partials; the flag is for the kernels behind this one. No
+    // workgroup may return before all have read it as 0, which the kernel boundary cannot give: workgroups that
+    // start late would see 1 and skip -- harmless, they would have stopped as well.
+    if (i == 0) *D.stop = 1;
+    return;
+  }
+  if (i >= n) return;
+  p[i] = k == 1 ? z[i] : z[i] + (rho_new / rho_prev) * p[i];
+}
+__global__ void __launch_bounds__(256) ba_pcgp_tail_kernel(View V, PcgDev D, int k, const double* __restrict__ Dc,
+                                                           const double* __restrict__ p, double* __restrict__ q) {
+  if (*D.stop) return;
+  const int bd2 = V.bd * V.bd;
+  double pq = 0.0;
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b < V.n_blk) {
+    const int dim = V.blk_dim[b], off = V.blk_off[b];
+    for (int c = 0; c < dim; ++c) {
+      double sacc = 0.0;
+      for (int ch = V.blk_chunk_ptr[b]; ch < V.blk_chunk_ptr[b + 1]; ++ch) sacc += V.cpart[(size_t)ch * bd2 + c];
+      const double d = Dc[off + c], pv = p[off + c];
+      const double qv = d * d * pv + sacc;
+      q[off + c] = qv;
+      pq += pv * qv;
+    }
+  }
+  pq = block_sum(pq);
+  if (threadIdx.x == 0) D.part[(size_t)(k & 1) * 3 * D.nparts + blockIdx.x] = pq;
+}
+__global__ void __launch_bounds__(256) ba_pcgp_step_kernel(View V, PcgDev D, int k, const double* __restrict__ Minv,
+                                                           const double* __restrict__ rhs, const double* __restrict__ p,
+                                                           const double* __restrict__ q, double* __restrict__ x,
+                                                           double* __restrict__ r, double* __restrict__ z) {
+  if (*D.stop) return;
+  double* bank = D.part + (size_t)(k & 1) * 3 * D.nparts;
+  double* bank_next = D.part + (size_t)((k + 1) & 1) * 3 * D.nparts;
+  const double alpha = pcg_sum(bank + D.nparts, D.nparts) / pcg_sum(bank, D.nparts);
+  double Q = 0.0, rho = 0.0;
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b < V.n_blk) {
+    const int n = V.blk_dim[b], off = V.blk_off[b];
+    const double* Mi = Minv + V.blk_moff[b];
+    for (int i = 0; i < n; ++i) {
+      const double xn = x[off + i] + alpha * p[off + i];
+      const double rn = r[off + i] - alpha * q[off + i];
+      x[off + i] = xn;
+      r[off + i] = rn;
+      Q += -0.5 * xn * (rhs[off + i] + rn);
+    }
+    for (int i = 0; i < n; ++i) {
+      double sacc = 0.0;
+      for (int j = 0; j < n; ++j) sacc += Mi[i * n + j] * r[off + j];
+      z[off + i] = sacc;
+      rho += sacc * r[off + i];
+    }
+  }
+  Q = block_sum(Q);
+  rho = block_sum(rho);
+  if (threadIdx.x == 0) {
+    bank[2 * D.nparts + blockIdx.x] = Q;
+    bank_next[D.nparts + blockIdx.x] = rho;
+  }
+}
+
 __global__ void __launch_bounds__(1024) ba_dot_kernel(int n, const double* __restrict__ a,
                                                       const double* __restrict__ b, double* __restrict__ out) {
   double v = 0.0;
@@ -2521,6 +2669,13 @@ struct Solver {
   Buf<double> o_xy, poses, cams, points, poses2, cams2, points2, Jpose, Jcam, Jpt, res, res_p, scale_c, scale_p,
       scalars, gc, gp, diag_c, diag_p, Dc, Dp, Cinv, M, Minv, rhs, x, r, z, pdir, q, dp, jx, v, stepc, stepp, partials, cpart, Craw, tbuf, tmpc, Gobs, pcg_part, maxbuf;
   Buf<double> lin_sums;  // [g_c | diag_c | g_p | diag_p | E^T E]: one all-reduce per linearisation
+  // pipelined PCG (pcg_pipelined): partial sums, stop flag, Q history on the device; per-iteration scalars in pinned
+  // host memory the device writes directly; events of two iterations in flight
+  Buf<double> pcgp_part, pcgp_qhist;
+  Buf<int> pcgp_stop;
+  PcgHostSlot* pcgp_host = nullptr;      // [2], hipHostMalloc
+  PcgHostSlot* pcgp_host_dev = nullptr;  // the same, as the device sees it
+  hipEvent_t pcgp_ev_dir[2] = {nullptr, nullptr}, pcgp_ev_s0[2] = {nullptr, nullptr}, pcgp_ev_s1[2] = {nullptr, nullptr};
   Buf<double> Sdense;  // exact tiers: the reduced camera system, n_c x n_c
   Buf<double> chol_linv, chol_tmp;  // blocked Cholesky workspace (ba_schur_explicit.h)
   Buf<int> chol_info;
@@ -2542,6 +2697,12 @@ struct Solver {
 
   Solver(ba_problem& p_, const ba_options& o_, Comm& c_) : opt(o_), prob(p_), comm(c_) {}
   ~Solver() {
+    for (int k = 0; k < 2; ++k) {
+      if (pcgp_ev_dir[k]) (void)hipEventDestroy(pcgp_ev_dir[k]);
+      if (pcgp_ev_s0[k]) (void)hipEventDestroy(pcgp_ev_s0[k]);
+      if (pcgp_ev_s1[k]) (void)hipEventDestroy(pcgp_ev_s1[k]);
+    }
+    if (pcgp_host) (void)hipHostFree(pcgp_host);
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
     if (ev2) (void)hipEventDestroy(ev2);
@@ -2557,6 +2718,11 @@ struct Solver {
     BA_HIP(hipMemcpyAsync(&v, scalars.p + slot, sizeof(double), hipMemcpyDeviceToHost, st));
     BA_HIP(hipStreamSynchronize(st));
     return v;
+  }
+  // all scalar slots with ONE copy and ONE synchronisation (single-GPU solves read two results per sync point)
+  void scalars_to_host(double* h) {
+    BA_HIP(hipMemcpyAsync(h, scalars.p, sizeof(double) * NSCALAR, hipMemcpyDeviceToHost, st));
+    BA_HIP(hipStreamSynchronize(st));
   }
   double scalar_sum(int slot) {  // value summed over ranks
     comm.allreduce(scalars.p + slot, 1, st);
@@ -3126,6 +3292,51 @@ struct Solver {
     return std::min(it, max_iter);
   }
 
+  int pcg_pipelined(int max_iter, double q_tol) {
+    const int n = V.n_c, gv = std::max(grid_for(n, 256), 1), nparts = grid_for(V.n_blk, 256);
+    if (!pcgp_host) {
+      BA_HIP(hipHostMalloc((void**)&pcgp_host, 2 * sizeof(PcgHostSlot), hipHostMallocMapped));
+      BA_HIP(hipHostGetDevicePointer((void**)&pcgp_host_dev, pcgp_host, 0));
+      pcgp_part.alloc((size_t)2 * 3 * nparts);
+      pcgp_qhist.alloc(2);
+      pcgp_stop.alloc(1);
+      for (int k = 0; k < 2; ++k) {
+        BA_HIP(hipEventCreateWithFlags(&pcgp_ev_dir[k], hipEventDisableTiming));
+        BA_HIP(hipEventCreate(&pcgp_ev_s0[k]));
+        BA_HIP(hipEventCreate(&pcgp_ev_s1[k]));
+      }
+    }
+    PcgDev D;
+    D.part = pcgp_part.p; D.nparts = nparts; D.stop = pcgp_stop.p; D.host = pcgp_host_dev; D.qhist = pcgp_qhist.p;
+    BA_LAUNCH(ba_pcgp_init_kernel, dim3(nparts), dim3(256), st, V, D, Minv.p, rhs.p, x.p, r.p, z.p);
+    V.stop = pcgp_stop.p;  // the streaming kernels of an iteration enqueued past convergence return at entry
+    auto enqueue = [&](int k) {
+      BA_LAUNCH(ba_pcgp_dir_kernel, dim3(gv), dim3(256), st, n, D, k, max_iter, q_tol, z.p, pdir.p);
+      BA_HIP(hipEventRecord(pcgp_ev_dir[k & 1], st));
+      BA_HIP(hipEventRecord(pcgp_ev_s0[k & 1], st));
+      schur_streams(pdir.p, op32);
+      BA_HIP(hipEventRecord(pcgp_ev_s1[k & 1], st));
+      BA_LAUNCH(ba_pcgp_tail_kernel, dim3(nparts), dim3(256), st, V, D, k, Dc.p, pdir.p, q.p);
+      BA_LAUNCH(ba_pcgp_step_kernel, dim3(nparts), dim3(256), st, V, D, k, Minv.p, rhs.p, pdir.p, q.p, x.p, r.p, z.p);
+    };
+    enqueue(1);
+    BA_HIP(hipEventSynchronize(pcgp_ev_dir[1]));
+    int done = 0;
+    if (!pcgp_host[0].stop) {  // (zero right-hand side otherwise)
+      for (int k = 1;; ++k) {
+        enqueue(k + 1);                                   // its dir kernel closes iteration k
+        BA_HIP(hipEventSynchronize(pcgp_ev_dir[(k + 1) & 1]));
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, pcgp_ev_s0[k & 1], pcgp_ev_s1[k & 1]) == hipSuccess) { g_spmv_ms += ms; g_spmv_launches += 1; }
+        const PcgHostSlot h = pcgp_host[k & 1];
+        if (h.iter != k) throw std::runtime_error("pipelined PCG: host slot out of step");
+        if (h.stop) { done = std::min(k, max_iter); break; }
+      }
+    }
+    V.stop = nullptr;
+    return done;
+  }
+
   int pcg(int max_iter, double q_tol) {
     const char* ef = std::getenv("COLMAP_AMD_BA_PCG_FUSED");
     // measured at BA-1: the single-workgroup kernel takes 133 us against 54 us for the five small kernels it
@@ -3133,6 +3344,10 @@ struct Solver {
     const bool fused_env = ef && std::atoi(ef) != 0;
     if (fused_env && comm.world == 1 && !use_priors() && V.n_chunks > 0 && V.n_obs > 0 && V.n_blk <= 65536)
       return pcg_fused(max_iter, q_tol);
+    // single GPU, no priors: three small kernels per iteration, stopping test on the device, host one iteration
+    // behind (COLMAP_AMD_BA_PCG_PIPELINED=0: the step-by-step loop below, which sharded / prior solves always take)
+    static const bool pipelined = [] { const char* e = std::getenv("COLMAP_AMD_BA_PCG_PIPELINED"); return !e || std::atoi(e) != 0; }();
+    if (pipelined && comm.world == 1 && !use_priors() && V.n_chunks > 0 && V.n_obs > 0) return pcg_pipelined(max_iter, q_tol);
     const int n = V.n_c;
     const int gv = grid_for(n, 256);
     BA_HIP(hipMemsetAsync(x.p, 0, sizeof(double) * n, st));
@@ -3244,8 +3459,11 @@ struct Solver {
           gradient_and_diag();
           have_scale = true;
         }
-        cost = scalar_sum(S_COST);
-        if (iter == 0) out->initial_cost = cost;
+        const bool one_sync = comm.world == 1;  // cost and gradient norm read together below
+        if (!one_sync) {
+          cost = scalar_sum(S_COST);
+          if (iter == 0) out->initial_cost = cost;
+        }
         // projected-gradient test: ||x - Plus(x, -g)||_inf with the unscaled gradient g = s * g_scaled
         // (the stored Jacobian is column-scaled: g_scaled = s * g, so g = g_scaled / s)
         BA_LAUNCH(ba_scaled_div_kernel, dim3(std::max(gvc, 1)), dim3(256), st, nc, -1.0, gc.p, scale_c.p, stepc.p);
@@ -3258,7 +3476,16 @@ struct Solver {
         BA_LAUNCH(ba_maxdiff_kernel, gmd(points.n), dim3(256), st, points.n, points.p, points2.p, scalars.p);
         if (V.sens_off)
           BA_LAUNCH(ba_maxdiff_kernel, gmd(sensors.n), dim3(256), st, sensors.n, sensors.p, sensors2.p, scalars.p);
-        const double gmax = scalar_max(S_GMAX);
+        double gmax;
+        if (one_sync) {
+          double h[NSCALAR];
+          scalars_to_host(h);
+          cost = h[S_COST];
+          if (iter == 0) out->initial_cost = cost;
+          gmax = h[S_GMAX];
+        } else {
+          gmax = scalar_max(S_GMAX);
+        }
         if (gmax <= opt.gradient_tolerance) {
           out->termination_type = BA_CONVERGENCE;
           out->num_iterations = iter;
@@ -3339,7 +3566,23 @@ struct Solver {
         BA_LAUNCH(ba_final_sum_kernel, dim3(1), dim3(1024), st, partials.p, grid_for(V.n_points, 256), scalars.p + S_MODEL);
       }
       if (use_priors()) BA_LAUNCH(ba_prior_model_kernel, dim3(1), dim3(256), st, Q, stepc.p, scalars.p + S_MODEL);
-      const double model_change = scalar_sum(S_MODEL);  // (synchronises the stream)
+      // Single GPU: the candidate is evaluated before the model change is known (it is almost always valid; an
+      // invalid step wastes one cost evaluation) and both numbers come back with one synchronisation.
+      const bool speculate = comm.world == 1;
+      double spec_new_cost = 0.0;
+      double model_change;
+      if (speculate) {
+        BA_LAUNCH(ba_axpby_kernel, dim3(std::max(gvc, 1)), dim3(256), st, nc, 1.0, stepc.p, scale_c.p, stepc.p);
+        BA_LAUNCH(ba_axpby_kernel, dim3(std::max(gvp, 1)), dim3(256), st, np, 1.0, stepp.p, scale_p.p, stepp.p);
+        apply_step(stepc.p, stepp.p, poses2.p, cams2.p, points2.p);
+        launch_linearize(false, poses2.p, cams2.p, points2.p, sensors2.p, S_NEWCOST);
+        double h[NSCALAR];
+        scalars_to_host(h);
+        model_change = h[S_MODEL];
+        spec_new_cost = h[S_NEWCOST];
+      } else {
+        model_change = scalar_sum(S_MODEL);  // (synchronises the stream)
+      }
       if (mfma_pending) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, ev2, ev3) == hipSuccess) { g_mfma_ms += ms; g_mfma_launches += 1; }
@@ -3357,11 +3600,15 @@ struct Solver {
       } else {
         invalid_steps = 0;
         // undo the Jacobi scaling of the step and evaluate the candidate
-        BA_LAUNCH(ba_axpby_kernel, dim3(std::max(gvc, 1)), dim3(256), st, nc, 1.0, stepc.p, scale_c.p, stepc.p);
-        BA_LAUNCH(ba_axpby_kernel, dim3(std::max(gvp, 1)), dim3(256), st, np, 1.0, stepp.p, scale_p.p, stepp.p);
-        apply_step(stepc.p, stepp.p, poses2.p, cams2.p, points2.p);
-        launch_linearize(false, poses2.p, cams2.p, points2.p, sensors2.p, S_NEWCOST);
-        new_cost = scalar_sum(S_NEWCOST);
+        if (speculate) {
+          new_cost = spec_new_cost;
+        } else {
+          BA_LAUNCH(ba_axpby_kernel, dim3(std::max(gvc, 1)), dim3(256), st, nc, 1.0, stepc.p, scale_c.p, stepc.p);
+          BA_LAUNCH(ba_axpby_kernel, dim3(std::max(gvp, 1)), dim3(256), st, np, 1.0, stepp.p, scale_p.p, stepp.p);
+          apply_step(stepc.p, stepp.p, poses2.p, cams2.p, points2.p);
+          launch_linearize(false, poses2.p, cams2.p, points2.p, sensors2.p, S_NEWCOST);
+          new_cost = scalar_sum(S_NEWCOST);
+        }
         const double rho = (cost - new_cost) / model_change;
         if (rho > opt.min_relative_decrease) {
           accepted = true;
