@@ -370,11 +370,13 @@ def geometric_leg(a, views, images, cache, local_rank):
     }
 
 
-def fusion_leg(a, views, fmaps):
+def fusion_leg(a, views, fmaps, with_cpu=True):
     """Stereo fusion (reference mvs/fusion.cc) of the geometric leg's filtered depth /
     normal maps: 8 neighbouring 2560x1920 images, default StereoFusionOptions, every image overlapping
-    every other. Timed: fusion_run end to end -- host maps in (the ABI takes host arrays, so the PCIe
-    upload is inside), speculate / claim / commit rounds, medians, fused points out."""
+    every other. `value` = pixels / the time on the device (rounds, medians, compaction, read-back of the points:
+    fusion_last_timing); the host-to-HBM upload of the maps the ABI takes as host arrays is reported beside it.
+    cpu_baseline: the oracle in the reference's sequential order (mode 0: one thread, as mvs/fusion.cc runs with
+    num_threads = 1) on the first four of the same images."""
     import ctypes as C
     from colmap_amd import fusion
     from colmap_amd._lib import lib
@@ -392,11 +394,52 @@ def fusion_leg(a, views, fmaps):
     st = [C.c_int64() for _ in range(4)]
     lib().fusion_last_stats(*[C.byref(x) for x in st])
     images_, seeds, rounds, walks = [x.value for x in st]
-    return {"metric": "stereo fusion Mpix/s @2560x1920", "value": n * a.width * a.height / 1e6 / dt, "unit": "Mpix/s",
-            "config": {"workload": f"StereoFusion defaults, {n} images {a.width}x{a.height} (geometric leg's filtered maps), "
-                                   f"all-to-all overlap, host inputs (upload inside the timed region)"},
-            "seconds": dt, "fused_points": int(len(pts.xyz)), "seed_pixels": int(seeds),
-            "rounds_per_image": rounds / max(images_, 1), "walks_per_seed_pixel": walks / max(seeds, 1)}
+    up, dev = C.c_double(), C.c_double()
+    lib().fusion_last_timing(C.byref(up), C.byref(dev))
+    mpix = n * a.width * a.height / 1e6
+    # bytes the algorithm has to move once: depth 4 + normal 12 + colour 3 per pixel in, mask stamp 4 + claim word 8
+    # read-modify-write, ~40 bytes per fused point out
+    alg = n * a.width * a.height * (4 + 12 + 3 + 2 * 4 + 2 * 8) + 40 * len(pts.xyz)
+    out = {"metric": "stereo fusion Mpix/s @2560x1920", "value": mpix / max(dev.value, 1e-9), "unit": "Mpix/s",
+           "config": {"workload": f"StereoFusion defaults, {n} images {a.width}x{a.height} (geometric leg's filtered maps), "
+                                  f"all-to-all overlap; device time only (upload of the host maps reported separately)"},
+           "seconds": {"device": dev.value, "upload_and_setup": up.value, "end_to_end": dt},
+           "end_to_end_Mpix_per_s": mpix / dt,
+           "fused_points": int(len(pts.xyz)), "seed_pixels": int(seeds),
+           "rounds_per_image": rounds / max(images_, 1), "walks_per_seed_pixel": walks / max(seeds, 1),
+           "roofline": {"bound": "latency: every round waits for its longest walk (a chain of dependent gathers); "
+                                 "rounds x that latency, not bytes, set the time",
+                        "achieved": alg / max(dev.value, 1e-9) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                        "frac": alg / max(dev.value, 1e-9) / 1e9 / 8000.0, "algorithmic_bytes": alg,
+                        "ms_per_round": dev.value * 1e3 / max(rounds, 1), "traffic": None}}
+    if with_cpu:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import fusion_oracle
+        m = min(4, n)
+        sub = imgs[:m]
+        t = time.time()
+        ref = fusion_oracle.fuse(opt, sub, [[j for j in range(m) if j != i] for i in range(m)], mode=0)
+        dc = time.time() - t
+        out["cpu_baseline"] = {"value": m * a.width * a.height / 1e6 / dc, "unit": "Mpix/s", "cores": 1, "kind": "port",
+                               "sample": f"oracle/fusion_oracle.cpp mode 0 (the reference's row-major order, one thread) on "
+                                         f"the first {m} of the same images, {len(ref.xyz)} points"}
+    return out
+
+
+def spawn_command(gpus, argv, port, script=None):
+    """Command line and environment of the self-spawned multi-GPU run (spawn_ranks): one rank per GPU under
+    torch.distributed.run, rendezvous on 127.0.0.1 (the container hostname may not resolve), dmabuf IPC for RCCL."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), script or os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return cmd, env
+
+
+def check_world(gpus, world):
+    """The launcher must have started exactly --gpus ranks (the driver's contract: `--gpus N` under
+    torch.distributed.run with --nproc-per-node N)."""
+    if world != gpus:
+        raise SystemExit(f"bench.py: --gpus {gpus} but the launcher started WORLD_SIZE={world} ranks")
 
 
 def spawn_ranks(a):
@@ -410,9 +453,7 @@ def spawn_ranks(a):
     with socket.socket() as sock:
         sock.bind(("127.0.0.1", 0))
         port = sock.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd, env = spawn_command(a.gpus, sys.argv[1:], port)
     sys.stdout.flush()
     os.execvpe(cmd[0], cmd, env)
 
@@ -424,8 +465,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != a.gpus:
-        raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    check_world(a.gpus, world)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -587,7 +627,7 @@ def main():
             fmaps, out["geometric"] = geometric_leg(a, views, images, cache, local_rank)
             if fmaps:
                 mvs.release_cached_memory()
-                out["fusion"] = fusion_leg(a, views, fmaps)
+                out["fusion"] = fusion_leg(a, views, fmaps, not a.no_cpu_baseline)
         if not a.no_ba and world == 1:
             del pms_keepalive[:]
             torch.cuda.empty_cache()

@@ -37,6 +37,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <chrono>
 #include <cfloat>
 #include <cmath>
 #include <cstring>
@@ -558,6 +559,7 @@ void ComposeInverseProjectionMatrix(const float P[12], float inv_P[12]) {
 
 struct Stats {
   long long images = 0, seeds = 0, rounds = 0, walks = 0;
+  double upload_seconds = 0.0, device_seconds = 0.0;  // host maps -> HBM + workspace setup | rounds, medians, compaction, read-back
 };
 Stats g_stats;
 
@@ -588,6 +590,7 @@ namespace {
 
 void Run(const fusion_options& opt, int n, const fusion_image* images, const int32_t* optr, const int32_t* oidx,
          fusion_result* out) {
+  const auto t_begin = std::chrono::steady_clock::now();
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
     throw Fail("no HIP device: the fusion kernels need a GPU (there is no CPU path)");
@@ -741,6 +744,9 @@ void Run(const fusion_options& opt, int n, const fusion_image* images, const int
   std::vector<int> h_nvis, h_vis;
   unsigned round = 2;  // 0 = free, 1 = masked on input
   g_stats = Stats();
+  FU_HIP(hipDeviceSynchronize());
+  const auto t_setup = std::chrono::steady_clock::now();
+  g_stats.upload_seconds = std::chrono::duration<double>(t_setup - t_begin).count();
   for (int step = 0; step < (int)order_of_images.size(); ++step) {
     const int I = order_of_images[step];
     const int ns = h_img[I].dw * h_img[I].dh;
@@ -829,6 +835,7 @@ void Run(const fusion_options& opt, int n, const fusion_image* images, const int
       out->vis_ptr.push_back(base);
     }
   }
+  g_stats.device_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_setup).count();
 }
 
 }  // namespace
@@ -902,6 +909,11 @@ FUSION_API int fusion_get_visibility(const fusion_result* r, int64_t* vis_ptr, i
 }
 
 FUSION_API void fusion_free(fusion_result* r) { delete r; }
+
+FUSION_API void fusion_last_timing(double* upload_seconds, double* device_seconds) {
+  if (upload_seconds) *upload_seconds = g_stats.upload_seconds;
+  if (device_seconds) *device_seconds = g_stats.device_seconds;
+}
 
 FUSION_API void fusion_last_stats(int64_t* images, int64_t* seeds, int64_t* rounds, int64_t* walks) {
   if (images) *images = g_stats.images;

@@ -71,6 +71,9 @@ void fusion_free(fusion_result* r);
 /* Counters of the last fusion_run on this process: images fused, their pixels, commit rounds, and
  * walks summed over the rounds (walks / seeds = average number of turns a pixel needed). */
 void fusion_last_stats(int64_t* images, int64_t* seeds, int64_t* rounds, int64_t* walks);
+/* ... and where its time went: host maps -> HBM plus workspace set-up, and everything after (the rounds on the
+ * device, medians, compaction, read-back of the points). */
+void fusion_last_timing(double* upload_seconds, double* device_seconds);
 const char* fusion_last_error(void);
 
 #ifdef __cplusplus

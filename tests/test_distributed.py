@@ -110,3 +110,37 @@ def test_ba_image_sharding_partitions_the_observations():
 
 
 import numpy as np  # noqa: E402
+
+
+def test_bench_self_spawn_command_and_world_check(monkeypatch, tmp_path):
+    """bench.py --gpus N without a launcher re-executes itself under torch.distributed.run (spawn_ranks): the command
+    it builds -- one rank per GPU, rendezvous on 127.0.0.1, its own flags passed through, dmabuf IPC for RCCL -- and
+    the WORLD_SIZE check of the contract, executed here without a GPU. The command is then really run with a stand-in
+    script on the gloo-capable CPU: two ranks come up and see WORLD_SIZE = 2."""
+    import importlib.util, os, subprocess, sys, socket
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    monkeypatch.delenv("HSA_ENABLE_IPC_MODE_LEGACY", raising=False)
+    cmd, env = bench.spawn_command(4, ["--gpus", "4", "--steps", "3"], 29555)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29555"
+    assert cmd[-5] == os.path.join(root, "bench.py") and cmd[-4:] == ["--gpus", "4", "--steps", "3"]
+    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    bench.check_world(4, 4)
+    with pytest.raises(SystemExit, match="WORLD_SIZE=2"):
+        bench.check_world(4, 2)
+    # the same command line, executed for real with a stand-in for the script
+    script = tmp_path / "rank.py"
+    script.write_text("import os, sys\nopen(os.path.join(os.path.dirname(__file__), 'rank' + os.environ['RANK']), 'w')"
+                      ".write(os.environ['WORLD_SIZE'] + ' ' + ' '.join(sys.argv[1:]))\n")
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd, env = bench.spawn_command(2, ["--gpus", "2"], port, script=str(script))
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    for r in (0, 1):
+        assert (tmp_path / f"rank{r}").read_text() == "2 --gpus 2"
