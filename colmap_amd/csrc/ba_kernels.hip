@@ -1822,6 +1822,78 @@ __global__ void __launch_bounds__(64) ba_block_schur_cross_kernel(View V, const 
       }
 }
 
+// ------------------------------------------------------------------------------------------
+// Image-sharded solves: the cross-rank part of the Schur-Jacobi blocks of SHARED intrinsics.
+// For an intrinsics block b and a point p let W_{b,p} = sum over the observations o of p that use b of
+// J_b,o^T J_p,o (dim_b x 3). The block is M_b = B_b - sum_p W_{b,p} C_p^-1 W_{b,p}^T. A rank sees only its own
+// observations: its G term plus its pair term is B_b^r - sum_p W^r C^-1 W^r^T, and the sum of that over the
+// ranks misses every pair of observations of one point that sit on DIFFERENT ranks. Correction, for the
+// (point, block) incidences whose observations span more than one rank (the host lists them; every rank sees the
+// whole problem): all-reduce W, then
+//   M_b += sum_p W^r C^-1 W^r^T                      (every rank, its own part: undoes what it subtracted)
+//   M_b -= sum_{p : p mod world = rank} W C^-1 W^T    (the exact term, each incidence on one rank)
+// before the all-reduce of M. The image-sharded solve then has the single-GPU preconditioner, CG trajectory and
+// iteration counts (tests/test_ba_gpu.py: test_three_rank_sharded_solve_with_shared_intrinsics).
+// ------------------------------------------------------------------------------------------
+struct IncView {
+  int n;                 // incidences that span ranks
+  const int* pt;         // [n] point
+  const int* blk;        // [n] block
+  const int* ptr;        // [n + 1] this rank's observations of the incidence (c-order indices) ...
+  const int* obs;        // ... as a CSR list
+};
+template <int KDT>
+__global__ void ba_inc_w_kernel(View V, IncView I, double* __restrict__ W) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= I.n) return;
+  const int dim = V.blk_dim[I.blk[i]];
+  const size_t N = (size_t)V.n_obs;
+  double w[KDT][3];
+#pragma unroll
+  for (int x = 0; x < KDT; ++x) w[x][0] = w[x][1] = w[x][2] = 0.0;
+  for (int k = I.ptr[i]; k < I.ptr[i + 1]; ++k) {
+    const int o = I.obs[k], a = V.c2a[o];
+#pragma unroll
+    for (int x = 0; x < KDT; ++x)
+      if (x < dim) {
+        const double j0 = blk_col(V, 1, 0, x)[o], j1 = blk_col(V, 1, 1, x)[o];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) w[x][c] += j0 * V.Jpt[(size_t)c * N + a] + j1 * V.Jpt[(size_t)(3 + c) * N + a];
+      }
+  }
+#pragma unroll
+  for (int x = 0; x < KDT; ++x)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) W[((size_t)i * KDT + x) * 3 + c] = w[x][c];
+}
+template <int KDT>
+__global__ void ba_inc_correct_kernel(View V, IncView I, const double* __restrict__ Cinv, const double* __restrict__ Wloc,
+                                      const double* __restrict__ Wtot, int rank, int world, double* __restrict__ M) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= I.n) return;
+  const int b = I.blk[i], dim = V.blk_dim[b], xi = I.pt[i];
+  if (V.pt_off[xi] < 0) return;  // a constant point has no C^-1: its observations do not couple
+  const double* Ci = Cinv + 9 * (size_t)xi;
+  double* Mb = M + V.blk_moff[b];
+  const bool mine = xi % world == rank;
+  for (int pass = 0; pass < 2; ++pass) {
+    if (pass == 1 && !mine) break;
+    const double* Wp = (pass == 0 ? Wloc : Wtot) + (size_t)i * KDT * 3;
+    const double sign = pass == 0 ? 1.0 : -1.0;
+    double T[KDT][3];
+#pragma unroll
+    for (int x = 0; x < KDT; ++x)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) T[x][c] = Wp[x * 3 + 0] * Ci[c] + Wp[x * 3 + 1] * Ci[3 + c] + Wp[x * 3 + 2] * Ci[6 + c];
+#pragma unroll
+    for (int x = 0; x < KDT; ++x)
+#pragma unroll
+      for (int y = 0; y < KDT; ++y)
+        if (x < dim && y < dim)
+          atomicAdd(Mb + x * dim + y, sign * (T[x][0] * Wp[y * 3 + 0] + T[x][1] * Wp[y * 3 + 1] + T[x][2] * Wp[y * 3 + 2]));
+  }
+}
+
 // M_b += Dc^2 on the diagonal, then invert (Gauss-Jordan with partial pivoting); lane per block
 template <int BD>
 __global__ void ba_block_invert_kernel(View V, const double* __restrict__ Dc, const double* __restrict__ M,
@@ -2669,6 +2741,10 @@ struct Solver {
   Buf<double> o_xy, poses, cams, points, poses2, cams2, points2, Jpose, Jcam, Jpt, res, res_p, scale_c, scale_p,
       scalars, gc, gp, diag_c, diag_p, Dc, Dp, Cinv, M, Minv, rhs, x, r, z, pdir, q, dp, jx, v, stepc, stepp, partials, cpart, Craw, tbuf, tmpc, Gobs, pcg_part, maxbuf;
   Buf<double> lin_sums;  // [g_c | diag_c | g_p | diag_p | E^T E]: one all-reduce per linearisation
+  // image-sharded solves: (point, shared intrinsics block) incidences whose observations span ranks (ba_inc_* kernels)
+  Buf<int> inc_pt, inc_blk, inc_ptr, inc_obs;
+  Buf<double> inc_wloc, inc_wtot;
+  IncView IV{};
   // pipelined PCG (pcg_pipelined): partial sums, stop flag, Q history on the device; per-iteration scalars in pinned
   // host memory the device writes directly; events of two iterations in flight
   Buf<double> pcgp_part, pcgp_qhist;
@@ -3025,6 +3101,52 @@ struct Solver {
     cam_model.upload(std::vector<int>(p.cam_model, p.cam_model + p.num_cams));
     pt_off.upload(h_pt_off); pt_ptr.upload(h_pt_ptr);
     blk_off.upload(h_blk_off); blk_dim.upload(h_blk_dim); blk_kind.upload(h_blk_kind); blk_moff.upload(h_blk_moff);
+    // Image sharding: (point, intrinsics block) incidences whose observations sit on more than one rank -- the
+    // pairs the local Schur-Jacobi terms cannot see (ba_inc_* kernels). Every rank walks the whole problem, so all
+    // ranks build the same list in the same order; a rank's own observations of an incidence go into a CSR list.
+    IV = IncView{};
+    if (comm.world > 1 && !comm.by_point) {
+      // global pass: per (point, camera) the set of ranks that hold an observation of it
+      std::vector<std::pair<long long, int>> keys;  // (point * num_cams + cam, rank)
+      for (int64_t o = 0; o < p.num_obs; ++o) {
+        const int pi = p.obs_pose[o], ci = p.obs_cam[o], xi = p.obs_point[o];
+        const int sv = p.obs_sensor ? p.obs_sensor[o] : -1;
+        const bool sens_var = sv >= 0 && p.sensor_const != nullptr && !p.sensor_const[sv];
+        if (p.pose_const[pi] && cam_nvar[ci] == 0 && p.point_const[xi] && !sens_var) continue;  // not active
+        if (cam_nvar[ci] == 0 || p.point_const[xi]) continue;                                     // no coupling through this block
+        keys.emplace_back((long long)xi * p.num_cams + ci, pi % comm.world);
+      }
+      std::sort(keys.begin(), keys.end());
+      keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+      std::vector<long long> spanning;
+      for (size_t k = 0; k + 1 < keys.size(); ++k)
+        if (keys[k].first == keys[k + 1].first && (spanning.empty() || spanning.back() != keys[k].first))
+          spanning.push_back(keys[k].first);
+      if (!spanning.empty()) {
+        const int ni = (int)spanning.size();
+        std::vector<int> h_pt(ni), h_blk(ni), h_ptr(ni + 1, 0), h_obs;
+        for (int i = 0; i < ni; ++i) {
+          h_pt[i] = (int)(spanning[i] / p.num_cams);
+          h_blk[i] = blk_of_cam[(int)(spanning[i] % p.num_cams)];
+        }
+        // this rank's observations, c-order index c, by incidence
+        std::vector<std::pair<int, int>> mine;  // (incidence, c)
+        for (int c = 0; c < n; ++c) {
+          const long long key = (long long)h_o_pt[c] * p.num_cams + h_o_cam[c];
+          const auto it = std::lower_bound(spanning.begin(), spanning.end(), key);
+          if (it != spanning.end() && *it == key) mine.emplace_back((int)(it - spanning.begin()), c);
+        }
+        std::sort(mine.begin(), mine.end());
+        for (const auto& m : mine) h_ptr[m.first + 1]++;
+        for (int i = 0; i < ni; ++i) h_ptr[i + 1] += h_ptr[i];
+        h_obs.reserve(mine.size());
+        for (const auto& m : mine) h_obs.push_back(m.second);
+        if (h_obs.empty()) h_obs.push_back(0);
+        inc_pt.upload(h_pt); inc_blk.upload(h_blk); inc_ptr.upload(h_ptr); inc_obs.upload(h_obs);
+        inc_wloc.alloc((size_t)ni * KD_WIDE * 3); inc_wtot.alloc((size_t)ni * KD_WIDE * 3);
+        IV.n = ni; IV.pt = inc_pt.p; IV.blk = inc_blk.p; IV.ptr = inc_ptr.p; IV.obs = inc_obs.p;
+      }
+    }
     chunk_blk.upload(h_chunk_blk); chunk_beg.upload(h_chunk_beg); chunk_end.upload(h_chunk_end);
     c2a.upload(h_c2a); a2c.upload(h_a2c); solo.upload(h_solo); tile_pt.upload(h_tile_pt);
     a_pose.upload(h_a_pose); a_cam.upload(h_a_cam); a_pt.upload(h_a_pt); a_xy.upload(h_a_xy);
@@ -3528,6 +3650,20 @@ struct Solver {
         }
         if (use_priors())
           BA_LAUNCH(ba_prior_accumulate_kernel<1>, dim3(grid_for(Q.n_tblk, 64)), dim3(64), st, V, Q, M.p, nullptr);
+        if (IV.n > 0) {  // image sharding: pairs of observations of a point in a shared intrinsics block on different ranks
+          const int gi = grid_for(IV.n, 128);
+          const size_t wn = (size_t)IV.n * (kd == KD_WIDE ? KD_WIDE : KD_MAX) * 3;
+          if (kd == KD_WIDE) BA_LAUNCH(ba_inc_w_kernel<KD_WIDE>, dim3(gi), dim3(128), st, V, IV, inc_wloc.p);
+          else BA_LAUNCH(ba_inc_w_kernel<KD_MAX>, dim3(gi), dim3(128), st, V, IV, inc_wloc.p);
+          BA_HIP(hipMemcpyAsync(inc_wtot.p, inc_wloc.p, sizeof(double) * wn, hipMemcpyDeviceToDevice, st));
+          comm.allreduce(inc_wtot.p, wn, st);
+          if (kd == KD_WIDE)
+            BA_LAUNCH(ba_inc_correct_kernel<KD_WIDE>, dim3(gi), dim3(128), st, V, IV, Cinv.p, inc_wloc.p, inc_wtot.p, comm.rank,
+                      comm.world, M.p);
+          else
+            BA_LAUNCH(ba_inc_correct_kernel<KD_MAX>, dim3(gi), dim3(128), st, V, IV, Cinv.p, inc_wloc.p, inc_wtot.p, comm.rank,
+                      comm.world, M.p);
+        }
         comm.allreduce(M.p, (size_t)moff_total, st);
         if (bd == PD) BA_LAUNCH(ba_block_invert_kernel<PD>, dim3(grid_for(V.n_blk, 64)), dim3(64), st, V, Dc.p, M.p, Minv.p);
         else if (bd == KD_WIDE) BA_LAUNCH(ba_block_invert_kernel<KD_WIDE>, dim3(grid_for(V.n_blk, 64)), dim3(64), st, V, Dc.p, M.p, Minv.p);
