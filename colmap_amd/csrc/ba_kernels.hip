@@ -3826,6 +3826,8 @@ struct Solver {
 
 extern "C" {
 
+int32_t ba_abi_version(void) { return COLMAP_AMD_BA_ABI_VERSION; }
+
 void ba_options_init(ba_options* o) {
   // CeresBundleAdjustmentOptions ctor (bundle_adjustment_ceres.cc:102-115) over Ceres defaults
   std::memset(o, 0, sizeof(*o));

@@ -710,6 +710,18 @@ def marshal_options(so: SolverOptions, max_log: int = 0, num_threads: int = 0) -
     return o
 
 
+BA_ABI_VERSION = 3  # include/colmap_amd_ba.h: COLMAP_AMD_BA_ABI_VERSION (the ctypes mirrors below follow that layout)
+
+
+def _check_abi(L):
+    """The struct mirrors in this module must match the library's header: a library built from another
+    header would read / write past the end of ba_options / ba_result."""
+    L.ba_abi_version.restype = C.c_int32
+    v = int(L.ba_abi_version())
+    if v != BA_ABI_VERSION:
+        raise RuntimeError(f"libcolmap_amd.so speaks BA ABI version {v}, this module {BA_ABI_VERSION}: rebuild the library")
+
+
 def solve_flat(fp: FlatProblem, so: Optional[SolverOptions] = None, gpu_index: int = -1,
                max_log: int = 256, solve_fn=None, comm: Optional[Communicator] = None) -> BundleAdjustmentSummary:
     """ba_solve on a flat problem (in place). `solve_fn` lets the tests route the identical
@@ -728,6 +740,7 @@ def solve_flat(fp: FlatProblem, so: Optional[SolverOptions] = None, gpu_index: i
             cc = comm.to_c()
             rc = L.ba_solve_sharded(C.byref(p), C.byref(o), C.c_int32(gpu_index), C.byref(cc), C.byref(r))
         else:
+            _check_abi(L)
             rc = L.ba_solve(C.byref(p), C.byref(o), C.c_int32(gpu_index), C.byref(r))
         if rc != 0:
             raise RuntimeError(L.ba_last_error().decode())

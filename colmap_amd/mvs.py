@@ -569,7 +569,7 @@ class PatchMatchController:
         import torch
         t = self.device_bitmaps_.get(idx)
         if t is None:
-            t = torch.from_numpy(np.ascontiguousarray(self.images_[idx].bitmap, np.uint8)).to(device)
+            t = torch.from_numpy(np.array(self.images_[idx].bitmap, np.uint8, order="C", copy=True)).to(device)  # (a read-only array cannot be wrapped)
             self.device_bitmaps_[idx] = t
         return t
 
@@ -679,5 +679,7 @@ class PatchMatchController:
         t = time.time()
         out = self._run_pass(opt, maps)
         self.timings["geometric_s" if opt.geom_consistency else "photometric_s"] = time.time() - t
-        release_cached_memory()  # the next stage (fusion, another workspace) gets the HBM back
+        # The pooled device buffers stay: in the reference's two-pass flow the geometric pass follows at once and reuses
+        # them, and every allocator of the library retries after releasing the pool when a hipMalloc fails (pm_api.cpp,
+        # fusion.hip, ba_kernels.hip). A caller that is done with PatchMatch calls release_cached_memory() itself.
         return out

@@ -467,6 +467,8 @@ class Mi355xBundleAdjuster : public BundleAdjuster {
     ba_result res{};
     int gpu = -1;
     if (!options_.gpu_index.empty()) gpu = std::stoi(options_.gpu_index);  // single GPU (:189-191)
+    if (ba_abi_version() != COLMAP_AMD_BA_ABI_VERSION)
+      throw std::runtime_error("libcolmap_amd.so and colmap_amd_ba.h disagree on the layout of ba_options / ba_result");
     if (ba_solve(&p, &so, gpu, &res) != 0) throw std::runtime_error(ba_last_error());
     if (res.num_residuals == 0) return summary;
     WriteBack();

@@ -200,6 +200,12 @@ int ba_last_spmv_timing(double* total_ms, int64_t* launches, int64_t* bytes_per_
 int ba_last_mfma_timing(double* total_ms, int64_t* launches);
 
 const char* ba_last_error(void);
+/* Layout version of ba_options / ba_result / ba_problem as this header declares them. The structs have grown by
+ * appended fields (operator_precision, linear_solver_used, factor_seconds); a caller built against another header
+ * would pass shorter structs. Callers compare ba_abi_version() with COLMAP_AMD_BA_ABI_VERSION once, before the first
+ * solve (the C++ and Python adapters of this repository do). */
+#define COLMAP_AMD_BA_ABI_VERSION 3
+int32_t ba_abi_version(void);
 
 #ifdef __cplusplus
 }
