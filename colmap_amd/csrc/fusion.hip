@@ -3,36 +3,44 @@
 // What it computes: StereoFusion::Run / Fuse of the reference (src/colmap/mvs/fusion.cc:253-524) --
 // for every image I in FindNextImage order (:51-73), every pixel of I in turn walks the consistency
 // graph (depth, reprojection and normal tests against the pixel it started from), masks what it
-// absorbs and fuses it into one point. In the reference the turns within an image are taken by a
-// thread pool, so the order is row-major only for num_threads = 1. Here the order is a fixed
-// pseudo-random permutation of the pixels (ascending seed_hash) and the result is exactly the
-// reference's algorithm run in that order -- but the turns are not executed one after the other:
+// absorbs and fuses it into one point. In the reference the turns of an image are taken by a thread
+// pool whose tasks are stripes of ten rows, each walked row-major by one thread (:253-269, 293-300).
+// The turn order here IS that pool's schedule with its T = num_threads threads advancing in step
+// (thread t takes stripes t, t + T, ...; every tick each thread takes the next pixel of its stripe):
+// T = 1 is the reference with one thread, bit for bit; the default is one thread per stripe. The result
+// is defined as the reference's Fuse() executed sequentially in that order (rank = tick * T + thread),
+// the points collected per thread and concatenated like fusion.cc:322-337.
 //
-//   speculate  every undecided pixel ("seed") walks against the masks committed so far and claims the
-//              pixels it would absorb: 64-bit atomicMax on a per-pixel word  round << 32 | ~rank, so
-//              the earliest seed of the order holds the claim. A walk that hit a cap (traversal depth,
-//              max_num_pixels) also claims its closure, because under more masks it may take another
-//              path but cannot leave the closure.
-//   commit     the same walk again; a seed that holds the claim on every pixel it absorbs cannot be
-//              affected by any seed before it (their walks only shrink when more pixels get masked), so
-//              its turn is final: it stamps its pixels into the mask and fuses them -- Percentile-50
-//              medians of position, normal and colour (math/math.h:205-234), minimum size, normal
-//              length, sorted distinct images. Everything else goes into the next round; the first
-//              undecided seed of the order always commits, typically almost all do.
-//   compact    per image, a device scan in rank order writes the points in the order the sequential
-//              algorithm would have produced them.
+// How it runs: one WAVE per pool thread walks that thread's turns one after the other, the T waves
+// concurrently, in passes over a window of ticks:
+//   word      every pixel has one 64-bit word: 0 free, ~0 committed (masked for good), or
+//             epoch << 32 | ~rank = tentative mark of the turn `rank` of this pass (atomicMax: the lowest
+//             rank keeps the word). A wave treats committed pixels and the marks of its OWN thread as
+//             masked; marks of other threads read as free.
+//   cut       whenever a mark meets a mark of another turn of the same pass, the later of the two turns has
+//             seen (or will have seen) masks the sequential order would not have given it:
+//             rstar = min(rstar, its rank). A wave whose record buffer is full cuts at its own rank.
+//   commit    every turn of rank < rstar is final -- it met no mark of a lower rank of another thread and
+//             the lower ranks of its own thread are final, so on every pixel it looked at it saw the
+//             sequential masks: its pixels become committed and are fused (Percentile-50 medians of
+//             position, normal and colour, math/math.h:205-234; minimum size; normal length; sorted
+//             distinct images). Everything else is forgotten by bumping the epoch; the next pass starts at
+//             rstar. The lowest rank of a pass is never the later of two turns: every pass makes progress.
+//   walk      the 64 lanes of a wave share ONE walk: the neighbours of an absorbed pixel are projected, and
+//             their mask word, depth and normal fetched and tested, one neighbour per lane (those tests
+//             depend only on the walk's first pixel, and a pixel masked when pushed stays masked), the
+//             survivors go on a stack in LDS; popping looks at the words of the top 64 entries at once.
+//   compact   per image, a device scan in (thread, tick) order; the host concatenates per thread.
 //
 // The checker is oracle/fusion_oracle.cpp: mode 1 runs the reference's Fuse() sequentially in the same
-// seed order (tests/test_fusion.py compares bit for bit), mode 0 in row-major order. All arithmetic is
-// float / double as the reference writes it; the library is built with -ffp-contract=off.
+// order (tests/test_fusion.py compares bit for bit), mode 2 simulates the passes above with the waves
+// interleaved at random, mode 0 is row-major (= num_threads 1). All arithmetic is float / double as the
+// reference writes it; the library is built with -ffp-contract=off.
 //
-// Data layout in HBM: every image's depth map, slice-major normal map and bitmap stay resident for
-// the whole run (4 + 12 + 3 bytes per pixel), plus a 4-byte mask stamp and an 8-byte claim word per
-// depth-map pixel of every image. The state of a walk (<= record_capacity(max_num_pixels) absorbed pixels,
-// 1 024 .. 16 384 slots -- the reference's default of 10 000 is held in full: pixel, image, level,
-// point, normal, colour; one expansion frame per expanded pixel) lives in global arrays laid out
-// [slot][lane] so that the lanes of a wave touch consecutive addresses; a launch uses a fixed number
-// of resident lanes that stride over the undecided seeds.
+// Data layout in HBM: all depth maps in one array, all normal maps in one array of xyz triples (one
+// cache line per pixel instead of three slices), the bitmaps, one 8-byte word per depth-map pixel, all
+// indexed by a 64-bit global pixel offset; per wave a record buffer (pixel, image | in-box) of the turns of
+// the pass, a list of its walks, nine float columns for the medians, and the overflow of its stack.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
@@ -70,404 +78,539 @@ struct Fail : std::runtime_error {
     if (e_ != hipSuccess) throw Fail(std::string(#expr) + ": " + hipGetErrorString(e_));    \
   } while (0)
 
-// Pixels one walk can record = the lane state of a seed: max_num_pixels itself between 1 024 and 16 384 (the
-// reference's default 10 000 is NOT clamped: 40 B x 10 000 x 32 768 lanes = 13 GB of the 288 GB), smaller
-// options keep the 1 024-slot state, larger ones are clamped to 16 384 (21 GB). oracle/fusion_oracle.cpp mirrors it.
+// Pixels one walk can record: max_num_pixels itself between 1 024 and 16 384 (the reference's default 10 000 is NOT
+// clamped), smaller options keep 1 024, larger ones are clamped to 16 384. oracle/fusion_oracle.cpp mirrors it.
 constexpr int kElemCapMin = 1024, kElemCapMax = 16384;
 inline int record_capacity(int max_num_pixels) { return std::min(std::max(max_num_pixels, kElemCapMin), kElemCapMax); }
-constexpr int kLanes = 1 << 15;  // resident lanes per launch (256 CUs x 2 waves)
-constexpr int kBlock = 64;
-constexpr int kRankCount = 128;  // medians: rank counting (staged in LDS) up to this many values, radix select above
+constexpr int kRowStride = 10;        // rows of a pool task (fusion.cc:250-254)
+constexpr int kWave = 64;
+constexpr int kRecordBuf = 1 << 15;   // recorded pixels of one wave in one pass (>= kElemCapMax: a pass's first turn always fits)
+constexpr int kWindowFirst = 256, kWindowMin = 16, kWindowMax = 8192;  // ticks of a pass: doubled after a pass without a cut, halved after a cut
+constexpr int kStackLds = 2048;       // stack entries of a walk held in LDS (16 B each); the rest spills to HBM
+constexpr int kStackSpill = 1 << 14;  // ... first size of that spill per wave (grown by the host when a walk overflows it)
+constexpr int kCommitWaves = 4;       // waves per pool thread in the commit kernel
+constexpr int kStage = 2048;          // medians: values staged in LDS and ranked by counting; radix select above
+constexpr unsigned long long kCommitted = ~0ull;
 
 struct DevImage {
   float P[12], inv_P[12], inv_R[9];
   float sx, sy;          // depth map size / model image size
-  const float* depth;
-  const float* normal;   // [3][dh][dw]
   const uint8_t* rgb;    // [bh][bw][3] or nullptr
   int dw, dh, bw, bh;
-  long long pix_off;     // first mask / claim word of this image
+  long long pix_off;     // global offset of the image's first pixel (word / depth / normal arrays)
   int pos;               // step at which the image is fused; -1: not used
+};
+
+struct PassCtl {         // device-resident control words of the pass loop (read back once per pass)
+  unsigned rstar[2];     // lowest rank that must not commit, slot = pass parity (the other slot is reset by the commit kernel)
+  unsigned flags;        // bit 0: a walk overflowed the stack spill
+  unsigned pad;
+  unsigned long long walks, nodes, cursor;  // turns walked, pixels recorded (statistics); visibility pool cursor
 };
 
 struct Params {
   const DevImage* images;
   const int* optr;
   const int* oidx;
-  unsigned* mask;               // per pixel: 0 free, 1 masked on input, else the round that absorbed it
-  unsigned long long* claim;    // per pixel: round << 32 | ~priority of the best claimer of that round
-  unsigned round;               // current round stamp (>= 2, grows over the whole run)
-  int step;                     // position of `image` in the fusion order
-  int image;
-  int num_seeds;
-  const int* rank_of;           // priority of a seed = its rank in the seed order
-  const int* active;            // undecided seeds that have had their first turn offered
-  int num_active;
-  int* next_active;
-  int* next_count;
-  int* lane_walk;               // per lane: recorded pixels of the speculate walk | capped << 31 (state reuse)
-  int lanes;                    // lanes of a launch = columns of the lane state: min(kLanes, seeds of the largest image)
-  int reuse;                    // num_active <= lanes: a lane keeps its walk from speculate to commit
-  unsigned* barrier;            // lowest priority value among seeds whose closure overflowed the record
+  unsigned long long* word;     // per pixel: 0 free | kCommitted | epoch << 32 | ~rank
+  const float* depth;           // all depth maps, by global pixel offset
+  const float* normal;          // all normal maps as xyz triples, by global pixel offset
+  PassCtl* ctl;
+  unsigned epoch;
+  int slot;                     // pass parity
+  int step, image;
+  // the pool schedule of this image: T threads, stripes of L = 10 W ticks
+  int T, W, H, ns;
+  unsigned L;
+  // this pass: ticks [tau0 (+1 for threads below rmod), tau_end), ranks below `limit`
+  unsigned tau0, rmod, tau_end, limit;
   int elem_cap;                 // min(max_num_pixels, rec_cap)
-  int rec_cap;                  // record_capacity(max_num_pixels): slots of the lane state
+  int rec_cap;                  // record_capacity(max_num_pixels), at most the pixels of the workspace
   int max_level;                // max_traversal_depth - 1
   int min_num_pixels;
   double max_depth_error;
   float max_sq_reproj, min_cos_normal;
   float bmin[3], bmax[3];
-  // lane state [slot][lanes]
-  unsigned *e_pix, *e_meta, *e_rgb, *frame;
-  float *e_x, *e_y, *e_z, *e_nx, *e_ny, *e_nz;
+  // per wave (= pool thread): records [T][kRecordBuf], walks [T][window], values [T][9][kRecordBuf], stack spill [T][spill]
+  unsigned *rec_pix, *rec_meta;
+  unsigned* rec_box;            // [T][kRecordBuf]: at first + a, the record index of the a-th in-box pixel of the walk starting at first
+  unsigned *w_tau, *w_first, *w_count;
+  int* n_walks;
+  int window_cap;
+  float* vals;
+  unsigned long long* spill_goff;
+  uint2* spill_pm;
+  int spill_cap;
   // per-seed outputs
   int *valid, *nvis, *vis_off;
   float* pt;            // [num_seeds][6]
   unsigned char* col;   // [num_seeds][3]
   int* pool;            // visibility lists, allocated with an atomic cursor
   long long pool_cap;   // entries; the host checks the cursor against it after every image
-  unsigned long long* pool_cursor;
 };
 
-// meta word of a recorded pixel: image (16 bits) | level (15 bits) << 16 | in-box << 31
-__device__ inline unsigned pack_meta(int image, int level, bool in_box) {
-  return (unsigned)image | ((unsigned)level << 16) | (in_box ? 0x80000000u : 0u);
+__device__ inline unsigned long long ld_word(const unsigned long long* p) {  // the words are L2 atomics: read past the L1
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline unsigned ld_u32(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// masked for pool thread t: committed, or a tentative mark of this pass made by t itself
+__device__ inline bool masked_for(unsigned long long w, unsigned epoch, unsigned T, unsigned t) {
+  if (w == kCommitted) return true;
+  return (unsigned)(w >> 32) == epoch && (0xFFFFFFFFu - (unsigned)w) % T == t;
 }
 
-__device__ inline unsigned long long claim_key(unsigned round, unsigned prio) {
-  return ((unsigned long long)round << 32) | (unsigned long long)(0xFFFFFFFFu - prio);
+__device__ inline int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ inline unsigned uniform(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ inline float uniform(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+__device__ inline unsigned long long uniform(unsigned long long v) {
+  const unsigned lo = uniform((unsigned)v), hi = uniform((unsigned)(v >> 32));
+  return ((unsigned long long)hi << 32) | lo;
+}
+__device__ inline unsigned long long shfl64(unsigned long long v, int src) {
+  const unsigned lo = (unsigned)__shfl((int)(unsigned)v, src), hi = (unsigned)__shfl((int)(unsigned)(v >> 32), src);
+  return ((unsigned long long)hi << 32) | lo;
 }
 
-#define SLOT(buf, e) buf[(size_t)(e) * p.lanes + lane]
+// pixel of image (W x H) whose turn pool thread t takes in tick tau, or -1 (struct Pool of the oracle)
+__device__ inline int seed_of(const Params& p, unsigned tau, unsigned t) {
+  const unsigned k = (tau / p.L) * (unsigned)p.T + t;
+  if (k >= (unsigned)p.ns) return -1;
+  const unsigned pos = tau % p.L;
+  const unsigned row = kRowStride * k + pos / (unsigned)p.W;
+  if (row >= (unsigned)p.H) return -1;
+  return (int)(row * (unsigned)p.W + pos % (unsigned)p.W);
+}
 
-// k-th smallest (0-based) of m floats: MSB-first radix select on the order-preserving integer key
-template <typename Get>
-__device__ float radix_select(int m, int k, Get get) {
-  unsigned prefix = 0u, care = 0u;
-  for (int bit = 31; bit >= 0; --bit) {
-    care |= 1u << bit;
-    int zeros = 0;
-    for (int a = 0; a < m; ++a) {
-      const unsigned u = __float_as_uint(get(a));
-      const unsigned key = u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
-      zeros += ((key & care) == prefix);
-    }
-    if (k >= zeros) {
-      k -= zeros;
-      prefix |= 1u << bit;
-    }
+struct WaveStack {  // the walk's stack: entries [0, kStackLds) in LDS, the rest in the wave's spill
+  unsigned long long* lds_goff;
+  uint2* lds_pm;     // x = pixel, y = image | level << 16
+  unsigned long long* spill_goff;
+  uint2* spill_pm;
+  __device__ void put(int i, unsigned long long goff, uint2 pm) const {
+    if (i < kStackLds) { lds_goff[i] = goff; lds_pm[i] = pm; }
+    else { spill_goff[i - kStackLds] = goff; spill_pm[i - kStackLds] = pm; }
   }
-  const unsigned u = (prefix >> 31) ? (prefix ^ 0x80000000u) : ~prefix;
-  return __uint_as_float(u);
+  __device__ void get(int i, unsigned long long* goff, uint2* pm) const {
+    if (i < kStackLds) { *goff = lds_goff[i]; *pm = lds_pm[i]; }
+    else { *goff = spill_goff[i - kStackLds]; *pm = spill_pm[i - kStackLds]; }
+  }
+};
+
+// One turn of pool thread t: StereoFusion::Fuse's traversal (fusion.cc:401-489) from `seed` (free for t, positive
+// depth), executed by the 64 lanes of the wave together (every variable that steers the control flow is wave-uniform).
+// rec_n: pixels the wave has recorded in this pass; n_walks: its walks. false: record buffer or stack spill full --
+// the turn is abandoned and cuts the pass at its own rank.
+__device__ bool walk_turn(const Params& p, const WaveStack& st, int lane, unsigned t, unsigned tau, unsigned rank, int seed,
+                          float seed_depth, int* rec_n, int* n_walks, unsigned long long* stat_nodes) {
+  const unsigned long long key = ((unsigned long long)p.epoch << 32) | (unsigned long long)(0xFFFFFFFFu - rank);
+  unsigned* const rec_pix = p.rec_pix + (size_t)t * kRecordBuf;
+  unsigned* const rec_meta = p.rec_meta + (size_t)t * kRecordBuf;
+  const int first = *rec_n;
+  int n = first, recorded = 0, nin = 0, sp = 0;
+  float ref[3] = {0.f, 0.f, 0.f}, refn[3] = {0.f, 0.f, 0.f};
+  int img = p.image, pix = seed, level = 0;
+  unsigned long long goff = (unsigned long long)p.images[p.image].pix_off + (unsigned long long)seed;
+  float depth = seed_depth;
+  bool ok = true;
+  for (;;) {
+    // ---- absorb (img, pix, level): fusion.cc:437-472 ----
+    const DevImage& im = p.images[img];
+    const int row = pix / im.dw, col = pix - row * im.dw;
+    const float hx = (float)col * depth, hy = (float)row * depth;
+    float xyz[3];
+    for (int r = 0; r < 3; ++r)
+      xyz[r] = im.inv_P[4 * r] * hx + im.inv_P[4 * r + 1] * hy + im.inv_P[4 * r + 2] * depth + im.inv_P[4 * r + 3] * 1.0f;
+    const bool in_box = !(xyz[0] < p.bmin[0] || xyz[1] < p.bmin[1] || xyz[2] < p.bmin[2] || xyz[0] > p.bmax[0] ||
+                          xyz[1] > p.bmax[1] || xyz[2] > p.bmax[2]);
+    if (recorded >= p.rec_cap) break;  // record capacity of one walk: the walk ends
+    if (n >= kRecordBuf) { ok = false; break; }
+    unsigned long long old = 0ull;
+    if (lane == 0) {
+      rec_pix[n] = (unsigned)pix;
+      rec_meta[n] = (unsigned)img | (in_box ? 0x80000000u : 0u);
+      old = atomicMax(p.word + goff, key);
+    }
+    old = shfl64(old, 0);
+    ++n; ++recorded;
+    if ((unsigned)(old >> 32) == p.epoch) {  // a mark of another turn of this pass: the later turn must not commit
+      const unsigned other = 0xFFFFFFFFu - (unsigned)old;
+      if (other != rank && lane == 0) atomicMin(&p.ctl->rstar[p.slot], other > rank ? other : rank);
+    }
+    bool expand = false;
+    if (in_box) {
+      ++nin;
+      if (level == 0) {
+        const float* nl = p.normal + 3 * goff;
+        const float nl0 = nl[0], nl1 = nl[1], nl2 = nl[2];
+        for (int r = 0; r < 3; ++r) refn[r] = im.inv_R[3 * r] * nl0 + im.inv_R[3 * r + 1] * nl1 + im.inv_R[3 * r + 2] * nl2;
+        ref[0] = xyz[0]; ref[1] = xyz[1]; ref[2] = xyz[2];
+      }
+      if (nin >= p.elem_cap) break;  // max_num_pixels reached (fusion.cc:470-472)
+      expand = level < p.max_level;
+    }
+    if (expand) {
+      // ---- neighbours (fusion.cc:474-488), one per lane; pushed in list order if they pass the tests of
+      // fusion.cc:407-447 that do not depend on the masks, and are not masked now ----
+      const int o0 = p.optr[img], nov = p.optr[img + 1] - o0;
+      for (int base = 0; base < nov; base += kWave) {
+        const int k = base + lane;
+        bool pass = false;
+        unsigned long long qoff = 0ull;
+        int q = 0, next = 0;
+        if (k < nov) {
+          next = p.oidx[o0 + k];
+          const DevImage& nx = p.images[next];
+          if (nx.pos >= p.step) {  // used, and not fused in an earlier step
+            float np[3];
+            for (int r = 0; r < 3; ++r) np[r] = nx.P[4 * r] * xyz[0] + nx.P[4 * r + 1] * xyz[1] + nx.P[4 * r + 2] * xyz[2] + nx.P[4 * r + 3];
+            const float fcol = roundf(np[0] / np[2]), frow = roundf(np[1] / np[2]);
+            if (fcol >= 0.0f && frow >= 0.0f && fcol < (float)nx.dw && frow < (float)nx.dh) {
+              const int qcol = (int)fcol, qrow = (int)frow;
+              q = qrow * nx.dw + qcol;
+              qoff = (unsigned long long)nx.pix_off + (unsigned long long)q;
+              const unsigned long long w = ld_word(p.word + qoff);
+              const float d = p.depth[qoff];
+              const float* nl = p.normal + 3 * qoff;
+              const float nl0 = nl[0], nl1 = nl[1], nl2 = nl[2];
+              if (!masked_for(w, p.epoch, (unsigned)p.T, t) && d > 0.0f) {
+                float proj[3];
+                for (int r = 0; r < 3; ++r)
+                  proj[r] = nx.P[4 * r] * ref[0] + nx.P[4 * r + 1] * ref[1] + nx.P[4 * r + 2] * ref[2] + nx.P[4 * r + 3] * 1.0f;
+                const float depth_error = fabsf((proj[2] - d) / d);
+                const float col_diff = proj[0] / proj[2] - (float)qcol;
+                const float row_diff = proj[1] / proj[2] - (float)qrow;
+                float nrm[3];
+                for (int r = 0; r < 3; ++r) nrm[r] = nx.inv_R[3 * r] * nl0 + nx.inv_R[3 * r + 1] * nl1 + nx.inv_R[3 * r + 2] * nl2;
+                const float c = refn[0] * nrm[0] + refn[1] * nrm[1] + refn[2] * nrm[2];
+                pass = !((double)depth_error > p.max_depth_error) && !(col_diff * col_diff + row_diff * row_diff > p.max_sq_reproj) &&
+                       !(c < p.min_cos_normal);
+              }
+            }
+          }
+        }
+        const unsigned long long m = __ballot(pass);
+        const int cnt = __popcll(m);
+        if (sp + cnt > kStackLds + p.spill_cap) { ok = false; break; }
+        if (pass) st.put(sp + __popcll(m & ((1ull << lane) - 1ull)), qoff, make_uint2((unsigned)q, (unsigned)next | ((unsigned)(level + 1) << 16)));
+        sp += cnt;
+      }
+      if (!ok) {
+        if (lane == 0) atomicOr(&p.ctl->flags, 1u);
+        break;
+      }
+      __syncthreads();  // the pushes (LDS / spill) before the pops of other lanes
+    }
+    // ---- next pixel: the topmost stack entry that is not masked (fusion.cc:408-414); 64 entries per look ----
+    bool found = false;
+    while (sp > 0) {
+      const int idx = sp - 1 - lane;
+      unsigned long long eoff = 0ull;
+      uint2 epm = make_uint2(0u, 0u);
+      bool free_ = false;
+      float ed = 0.0f;
+      if (idx >= 0) {
+        st.get(idx, &eoff, &epm);
+        const unsigned long long w = ld_word(p.word + eoff);
+        ed = p.depth[eoff];
+        free_ = !masked_for(w, p.epoch, (unsigned)p.T, t);
+      }
+      const unsigned long long m = __ballot(free_);
+      if (m == 0ull) {
+        sp = sp > kWave ? sp - kWave : 0;
+        continue;
+      }
+      const int j = __ffsll((long long)m) - 1;
+      sp = sp - 1 - j;
+      goff = shfl64(eoff, j);
+      pix = __shfl((int)epm.x, j);
+      const unsigned meta = (unsigned)__shfl((int)epm.y, j);
+      depth = __shfl(ed, j);
+      img = (int)(meta & 0xFFFFu);
+      level = (int)(meta >> 16);
+      found = true;
+      break;
+    }
+    __syncthreads();  // the reads of this look before the pushes of the next expansion
+    if (!found) break;
+    goff = uniform(goff); pix = uniform(pix); img = uniform(img); level = uniform(level); depth = uniform(depth);
+  }
+  if (!ok) {  // abandoned: nothing of it is recorded, the pass is cut at this turn
+    if (lane == 0) atomicMin(&p.ctl->rstar[p.slot], rank);
+    return false;
+  }
+  if (lane == 0) {
+    const int wi = *n_walks;
+    p.w_tau[(size_t)t * p.window_cap + wi] = tau;
+    p.w_first[(size_t)t * p.window_cap + wi] = (unsigned)first;
+    p.w_count[(size_t)t * p.window_cap + wi] = (unsigned)(n - first);
+  }
+  *stat_nodes += (unsigned long long)(n - first);
+  *rec_n = n;
+  *n_walks += 1;
+  return true;
 }
 
-// colmap::Percentile(values, 50) of m values (math/math.h:205-234): the two middle order statistics,
-// interpolated in double like the reference.
-// `col` is the lane's private column of a [kRankCount][kBlock] LDS array: up to kRankCount values are staged there
-// once and ranked out of LDS (m^2 reads of ~64 cycles instead of m^2 global loads).
+// A pass, first half: wave t takes the turns of pool thread t in the window one after the other.
+__global__ void __launch_bounds__(kWave) fusion_walk_kernel(Params p) {
+  __shared__ unsigned long long s_goff[kStackLds];
+  __shared__ uint2 s_pm[kStackLds];
+  const unsigned t = blockIdx.x;
+  const int lane = threadIdx.x;
+  WaveStack st{s_goff, s_pm, p.spill_goff + (size_t)t * p.spill_cap, p.spill_pm + (size_t)t * p.spill_cap};
+  const unsigned long long img_off = (unsigned long long)p.images[p.image].pix_off;
+  unsigned tau = p.tau0 + (t < p.rmod ? 1u : 0u);
+  int rec_n = 0, n_walks = 0;
+  unsigned long long walks = 0ull, nodes = 0ull;
+  while (tau < p.tau_end) {
+    // the next 64 turns of this thread: which start pixels are free (for this thread) and have a depth?
+    const unsigned my_tau = tau + (unsigned)lane;
+    int s = -1;
+    float d = 0.0f;
+    bool cand = false;
+    if (my_tau < p.tau_end) {
+      s = seed_of(p, my_tau, t);
+      if (s >= 0) {
+        const unsigned long long w = ld_word(p.word + img_off + (unsigned long long)s);
+        d = p.depth[img_off + (unsigned long long)s];
+        cand = d > 0.0f && !masked_for(w, p.epoch, (unsigned)p.T, t);
+      }
+    }
+    unsigned rs = ld_u32(&p.ctl->rstar[p.slot]);  // other waves lower it while this one runs: lane 0's view counts
+    rs = uniform((unsigned)__shfl((int)(rs < p.limit ? rs : p.limit), 0));
+    const unsigned long long m = __ballot(cand);
+    if (m == 0ull) {
+      tau = p.tau_end - tau > (unsigned)kWave ? tau + (unsigned)kWave : p.tau_end;
+      if ((unsigned long long)tau * (unsigned)p.T + t >= (unsigned long long)rs) break;  // nothing from here on can commit in this pass
+      continue;
+    }
+    const int j = __ffsll((long long)m) - 1;
+    tau += (unsigned)j;
+    const unsigned rank = tau * (unsigned)p.T + t;
+    if (rank >= rs) break;
+    const int seed = uniform(__shfl(s, j));
+    const float sd = uniform(__shfl(d, j));
+    ++walks;
+    if (!walk_turn(p, st, lane, t, tau, rank, seed, sd, &rec_n, &n_walks, &nodes)) break;
+    tau += 1u;
+  }
+  if (lane == 0) {
+    p.n_walks[t] = n_walks;
+    atomicAdd(&p.ctl->walks, walks);
+    atomicAdd(&p.ctl->nodes, nodes);
+  }
+}
+
+// lanes of ONE wave hand data to each other through LDS / global memory: release + acquire at workgroup scope (the wave
+// executes in lock step, so no barrier instruction is needed; the fences keep compiler and memory pipeline in order)
+__device__ inline void wave_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+template <typename T>
+__device__ inline T wave_min(T v) {
+  for (int o = 32; o > 0; o >>= 1) {
+    const T w = __shfl_xor(v, o);
+    v = w < v ? w : v;
+  }
+  return v;
+}
+__device__ inline int wave_sum(int v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// colmap::Percentile(values, 50) (math/math.h:205-234) of the m values get(0 .. m-1), by the 64 lanes of a wave:
+// the two middle order statistics, interpolated in double like the reference. Up to kStage values are staged in
+// the wave's LDS column `s` and ranked by counting (value v is the k-th smallest iff #less <= k < #less-or-equal);
+// above that an MSB-first radix select on the order-preserving integer key reads them where they are.
 template <typename Get>
-__device__ double median_of(int m, Get get, float* col) {
+__device__ double wave_median(int m, Get get, float* s, int lane) {
   const double idx = 0.5 * (double)(m - 1);
   const double lf = floor(idx), rc = ceil(idx);
   const int li = (int)lf, ri = (int)rc;
-  double left = 0.0, right = 0.0;
-  if (m <= kRankCount) {
-    for (int a = 0; a < m; ++a) col[a * kBlock] = get(a);
-    for (int a = 0; a < m; ++a) {
-      const float v = col[a * kBlock];
+  float left = 0.0f, right = 0.0f;
+  if (m <= kStage) {
+    for (int a = lane; a < m; a += kWave) s[a] = get(a);
+    wave_fence();
+    for (int a0 = 0; a0 < m; a0 += kWave) {
+      const int a = a0 + lane;
+      const float v = a < m ? s[a] : 0.0f;
       int lt = 0, le = 0;
       for (int b = 0; b < m; ++b) {
-        const float w = col[b * kBlock];
+        const float w = s[b];
         lt += w < v;
         le += w <= v;
       }
-      if (lt <= li && li < le) left = (double)v;
-      if (lt <= ri && ri < le) right = (double)v;
+      const unsigned long long ml = __ballot(a < m && lt <= li && li < le);
+      const unsigned long long mr = __ballot(a < m && lt <= ri && ri < le);
+      if (ml) left = __shfl(v, __ffsll((long long)ml) - 1);
+      if (mr) right = __shfl(v, __ffsll((long long)mr) - 1);
     }
+    wave_fence();  // the column is refilled by the next call
   } else {
-    right = (double)radix_select(m, ri, get);
-    left = li == ri ? right : (double)radix_select(m, li, get);
-  }
-  if (li == ri) return right;
-  return (rc - idx) * left + (idx - lf) * right;
-}
-
-struct Walk {
-  int ne;         // recorded (absorbed) pixels, bounding-box rejects included
-  bool capped;    // a cap of the reference's walk was hit (traversal depth, max_num_pixels, record size)
-  bool overflow;  // CLOSURE: the record is full, the closure is not known
-};
-
-// StereoFusion::Fuse's traversal (fusion.cc:401-489) of `seed` against the masks committed before
-// round p.round. The reference's stack of expanded neighbours is kept as one frame per expanded pixel
-// (pixel slot, next overlap entry to try, counted down): the same depth-first order without
-// materialising the neighbours. CLOSURE: ignore max_traversal_depth and max_num_pixels -- everything
-// the seed could absorb under any superset of the current masks. CLAIM: atomicMax the claim word of
-// every recorded pixel. ATTR: also record normal and colour (for the fuse step).
-// FAST (the first claiming walk of a seed in a round): "did this walk absorb the pixel already?" is read off
-// the claim word -- equal to the walk's key: yes; below it (older round / later seed): no, since the walk's own
-// claim would have raised it; above it (an earlier seed of the order holds the pixel): undecided, look
-// through the record. The word is read past the L1 (the claims are L2 atomics).
-template <bool CLOSURE, bool CLAIM, bool ATTR, bool FAST = false>
-__device__ Walk walk(const Params& p, int lane, int seed, unsigned long long key) {
-  Walk w{0, false, false};
-  const DevImage& I0 = p.images[p.image];
-  int ne = 0, nin = 0, nf = 0;
-  float ref[3] = {0.f, 0.f, 0.f}, refn[3] = {0.f, 0.f, 0.f};
-  int img = p.image, row = seed / I0.dw, col = seed % I0.dw, level = 0;
-  bool have = true;
-  while (have) {
-    do {  // ---- visit (img, row, col, level): fusion.cc:416-472 ----
-      const DevImage& im = p.images[img];
-      const int pix = row * im.dw + col;
-      const unsigned mk = p.mask[im.pix_off + pix];
-      if (mk != 0u && mk < p.round) break;  // masked before this round
-      bool seen = false, scan = true;
-      if (FAST) {
-        const unsigned long long w0 = __hip_atomic_load(p.claim + im.pix_off + pix, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        seen = w0 == key;
-        scan = w0 > key;
-      }
-      if (scan) {
-        int e = 0;
-        for (; e + 4 <= ne; e += 4) {  // four record entries per round trip
-          const unsigned p0 = SLOT(p.e_pix, e), p1 = SLOT(p.e_pix, e + 1), p2 = SLOT(p.e_pix, e + 2), p3 = SLOT(p.e_pix, e + 3);
-          const unsigned m0 = SLOT(p.e_meta, e), m1 = SLOT(p.e_meta, e + 1), m2 = SLOT(p.e_meta, e + 2), m3 = SLOT(p.e_meta, e + 3);
-          seen |= (p0 == (unsigned)pix && (int)(m0 & 0xFFFFu) == img) | (p1 == (unsigned)pix && (int)(m1 & 0xFFFFu) == img) |
-                  (p2 == (unsigned)pix && (int)(m2 & 0xFFFFu) == img) | (p3 == (unsigned)pix && (int)(m3 & 0xFFFFu) == img);
+    for (int which = 0; which < 2; ++which) {
+      int k = which == 0 ? ri : li;
+      if (which == 1 && li == ri) { left = right; break; }
+      unsigned prefix = 0u, care = 0u;
+      for (int bit = 31; bit >= 0; --bit) {
+        care |= 1u << bit;
+        int zeros = 0;
+        for (int a = lane; a < m; a += kWave) {
+          const unsigned u = __float_as_uint(get(a));
+          const unsigned key = u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+          zeros += ((key & care) == prefix);
         }
-        for (; e < ne; ++e) seen |= SLOT(p.e_pix, e) == (unsigned)pix && (int)(SLOT(p.e_meta, e) & 0xFFFFu) == img;
-      }
-      if (seen) break;  // masked by this walk
-      const float depth = im.depth[pix];
-      if (depth <= 0.0f) break;
-      if (level > 0) {
-        float proj[3];
-        for (int r = 0; r < 3; ++r)
-          proj[r] = im.P[4 * r] * ref[0] + im.P[4 * r + 1] * ref[1] + im.P[4 * r + 2] * ref[2] + im.P[4 * r + 3] * 1.0f;
-        const float depth_error = fabsf((proj[2] - depth) / depth);
-        if ((double)depth_error > p.max_depth_error) break;
-        const float col_diff = proj[0] / proj[2] - (float)col;
-        const float row_diff = proj[1] / proj[2] - (float)row;
-        if (col_diff * col_diff + row_diff * row_diff > p.max_sq_reproj) break;
-      }
-      const size_t slice = (size_t)im.dw * im.dh;
-      const float nl0 = im.normal[pix], nl1 = im.normal[slice + pix], nl2 = im.normal[2 * slice + pix];
-      float nrm[3];
-      for (int r = 0; r < 3; ++r) nrm[r] = im.inv_R[3 * r] * nl0 + im.inv_R[3 * r + 1] * nl1 + im.inv_R[3 * r + 2] * nl2;
-      if (level > 0) {
-        const float c = refn[0] * nrm[0] + refn[1] * nrm[1] + refn[2] * nrm[2];
-        if (c < p.min_cos_normal) break;
-      }
-      const float hx = (float)col * depth, hy = (float)row * depth;
-      float xyz[3];
-      for (int r = 0; r < 3; ++r)
-        xyz[r] = im.inv_P[4 * r] * hx + im.inv_P[4 * r + 1] * hy + im.inv_P[4 * r + 2] * depth + im.inv_P[4 * r + 3] * 1.0f;
-      const bool in_box = !(xyz[0] < p.bmin[0] || xyz[1] < p.bmin[1] || xyz[2] < p.bmin[2] || xyz[0] > p.bmax[0] ||
-                            xyz[1] > p.bmax[1] || xyz[2] > p.bmax[2]);
-      if (ne >= p.rec_cap) {  // record capacity: the walk ends
-        w.capped = true; w.overflow = true; nf = 0;
-        break;
-      }
-      SLOT(p.e_pix, ne) = (unsigned)pix;
-      SLOT(p.e_meta, ne) = pack_meta(img, level, in_box);
-      SLOT(p.e_x, ne) = xyz[0]; SLOT(p.e_y, ne) = xyz[1]; SLOT(p.e_z, ne) = xyz[2];
-      if (ATTR) {
-        unsigned rgb = 0u;
-        if (im.rgb) {  // nearest neighbour at the bitmap scale (bitmap.cc:329-334), colour 0 outside
-          const int xx = (int)round((double)((float)col / im.sx));
-          const int yy = (int)round((double)((float)row / im.sy));
-          if (xx >= 0 && yy >= 0 && xx < im.bw && yy < im.bh) {
-            const uint8_t* c3 = im.rgb + 3 * ((size_t)yy * im.bw + xx);
-            rgb = (unsigned)c3[0] | ((unsigned)c3[1] << 8) | ((unsigned)c3[2] << 16);
-          }
+        zeros = wave_sum(zeros);
+        if (k >= zeros) {
+          k -= zeros;
+          prefix |= 1u << bit;
         }
-        SLOT(p.e_nx, ne) = nrm[0]; SLOT(p.e_ny, ne) = nrm[1]; SLOT(p.e_nz, ne) = nrm[2];
-        SLOT(p.e_rgb, ne) = rgb;
       }
-      if (CLAIM) atomicMax(p.claim + im.pix_off + pix, key);
-      ++ne;
-      if (!in_box) break;
-      ++nin;
-      if (level == 0) {
-        ref[0] = xyz[0]; ref[1] = xyz[1]; ref[2] = xyz[2];
-        refn[0] = nrm[0]; refn[1] = nrm[1]; refn[2] = nrm[2];
-      }
-      if (!CLOSURE && nin >= p.elem_cap) {  // max_num_pixels reached (fusion.cc:470-472)
-        w.capped = true; nf = 0;
-        break;
-      }
-      if (!CLOSURE && level >= p.max_level) {
-        w.capped = true;
-        break;
-      }
-      if (level >= 32766) { w.capped = true; w.overflow = true; nf = 0; break; }
-      SLOT(p.frame, nf) = (unsigned)(ne - 1) | ((unsigned)(p.optr[img + 1] - p.optr[img]) << 12);
-      ++nf;
-    } while (false);
-    // ---- next node: top frame, neighbours in reverse list order (fusion.cc:474-488) ----
-    have = false;
-    while (nf > 0 && !have) {
-      const unsigned f = SLOT(p.frame, nf - 1);
-      const int e = (int)(f & 0xFFFu);
-      int k = (int)(f >> 12);
-      if (k == 0) { --nf; continue; }
-      --k;
-      SLOT(p.frame, nf - 1) = (unsigned)e | ((unsigned)k << 12);
-      const unsigned meta = SLOT(p.e_meta, e);
-      const int pimg = (int)(meta & 0xFFFFu);
-      const int next = p.oidx[p.optr[pimg] + k];
-      const DevImage& nx = p.images[next];
-      if (nx.pos < p.step) continue;  // not used (-1) or fused in an earlier step
-      const float x = SLOT(p.e_x, e), y = SLOT(p.e_y, e), z = SLOT(p.e_z, e);
-      float np[3];
-      for (int r = 0; r < 3; ++r) np[r] = nx.P[4 * r] * x + nx.P[4 * r + 1] * y + nx.P[4 * r + 2] * z + nx.P[4 * r + 3];
-      const float fcol = roundf(np[0] / np[2]), frow = roundf(np[1] / np[2]);
-      if (!(fcol >= 0.0f && frow >= 0.0f && fcol < (float)nx.dw && frow < (float)nx.dh)) continue;
-      img = next; row = (int)frow; col = (int)fcol; level = (int)((meta >> 16) & 0x7FFFu) + 1;
-      have = true;
+      const unsigned u = (prefix >> 31) ? (prefix ^ 0x80000000u) : ~prefix;
+      (which == 0 ? right : left) = __uint_as_float(u);
     }
   }
-  w.ne = ne;
-  return w;
+  if (li == ri) return (double)right;
+  return (rc - idx) * (double)left + (idx - lf) * (double)right;
 }
 
-__device__ inline int seed_of(const Params& p, int idx) { return p.active[idx]; }
-__device__ inline unsigned prio_of(const Params& p, int seed) { return (unsigned)p.rank_of[seed]; }
-
-// Round, first half: every undecided seed walks against the committed masks and claims what it would
-// absorb. A seed whose walk hit a cap also claims its closure: under more masks a capped walk can take
-// another path, but never leaves the closure. A closure that does not fit the record holds back every
-// seed after it in the order (barrier).
-__global__ void __launch_bounds__(kBlock) fusion_speculate_kernel(Params p) {
-  const int lane = blockIdx.x * kBlock + threadIdx.x;
-  for (int idx = lane; idx < p.num_active; idx += p.lanes) {
-    const int seed = seed_of(p, idx);
-    const unsigned prio = prio_of(p, seed);
-    const unsigned long long key = claim_key(p.round, prio);
-    const Walk w = p.reuse ? walk<false, true, true, true>(p, lane, seed, key) : walk<false, true, false, true>(p, lane, seed, key);
-    if (w.capped) {
-      const Walk c = walk<true, true, false>(p, lane, seed, key);
-      if (c.overflow) atomicMin(p.barrier, prio);
+// A pass, second half: the turns of rank < rstar are final -- their pixels become committed and are fused
+// (fusion.cc:449-466, 491-523). Block t = pool thread t; first every recorded pixel gets its point, normal and
+// colour (nine float columns), then wave w fuses walks w, w + 4, ...
+__global__ void __launch_bounds__(kWave * kCommitWaves) fusion_commit_kernel(Params p) {
+  __shared__ float stage[kCommitWaves][kStage];
+  const unsigned t = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+  const unsigned* rec_pix = p.rec_pix + (size_t)t * kRecordBuf;
+  const unsigned* rec_meta = p.rec_meta + (size_t)t * kRecordBuf;
+  float* const vals = p.vals + (size_t)t * 9 * kRecordBuf;
+  const int nw = p.n_walks[t];
+  unsigned rs = p.ctl->rstar[p.slot];
+  rs = rs < p.limit ? rs : p.limit;
+  if (t == 0 && tid == 0) p.ctl->rstar[p.slot ^ 1] = 0xFFFFFFFFu;  // the next pass's slot
+  int total = 0;
+  if (nw > 0) total = (int)(p.w_first[(size_t)t * p.window_cap + nw - 1] + p.w_count[(size_t)t * p.window_cap + nw - 1]);
+  for (int e = tid; e < total; e += kWave * kCommitWaves) {
+    const unsigned meta = rec_meta[e];
+    if (!(meta >> 31)) continue;
+    const int img = (int)(meta & 0xFFFFu), pix = (int)rec_pix[e];
+    const DevImage& im = p.images[img];
+    const unsigned long long goff = (unsigned long long)im.pix_off + (unsigned long long)pix;
+    const int row = pix / im.dw, col = pix - row * im.dw;
+    const float depth = p.depth[goff];
+    const float* nl = p.normal + 3 * goff;
+    const float nl0 = nl[0], nl1 = nl[1], nl2 = nl[2];
+    const float hx = (float)col * depth, hy = (float)row * depth;
+    for (int r = 0; r < 3; ++r) {
+      vals[(size_t)r * kRecordBuf + e] = im.inv_P[4 * r] * hx + im.inv_P[4 * r + 1] * hy + im.inv_P[4 * r + 2] * depth + im.inv_P[4 * r + 3] * 1.0f;
+      vals[(size_t)(3 + r) * kRecordBuf + e] = im.inv_R[3 * r] * nl0 + im.inv_R[3 * r + 1] * nl1 + im.inv_R[3 * r + 2] * nl2;
     }
-    if (p.reuse) p.lane_walk[lane] = w.ne | (w.capped ? (int)0x80000000 : 0);  // capped: the closure walk overwrote the state
+    unsigned rgb = 0u;
+    if (im.rgb) {  // nearest neighbour at the bitmap scale (bitmap.cc:329-334), colour 0 outside
+      const int xx = (int)round((double)((float)col / im.sx));
+      const int yy = (int)round((double)((float)row / im.sy));
+      if (xx >= 0 && yy >= 0 && xx < im.bw && yy < im.bh) {
+        const uint8_t* c3 = im.rgb + 3 * ((size_t)yy * im.bw + xx);
+        rgb = (unsigned)c3[0] | ((unsigned)c3[1] << 8) | ((unsigned)c3[2] << 16);
+      }
+    }
+    for (int ch = 0; ch < 3; ++ch) vals[(size_t)(6 + ch) * kRecordBuf + e] = (float)((rgb >> (8 * ch)) & 0xFFu);
   }
-}
-
-// Round, second half: the same walk again (deterministic: masks written in this round carry this
-// round's stamp and read as free). A seed that holds the claim of every pixel it absorbs -- no seed
-// before it in the order can take any of them, now or after its own re-walk -- is final: it masks
-// its pixels and fuses them (fusion.cc:491-523). The others wait for the next round.
-__global__ void __launch_bounds__(kBlock) fusion_commit_kernel(Params p) {
-  __shared__ float stage[kRankCount * kBlock];
-  float* col = stage + threadIdx.x;
-  const int lane = blockIdx.x * kBlock + threadIdx.x;
-  const unsigned barrier = *p.barrier;
-  for (int idx = lane; idx < p.num_active; idx += p.lanes) {
-    const int seed = seed_of(p, idx);
-    const unsigned prio = prio_of(p, seed);
-    const unsigned long long key = claim_key(p.round, prio);
-    int ne;
-    if (p.reuse && p.lane_walk[lane] >= 0) ne = p.lane_walk[lane];
-    else ne = walk<false, false, true>(p, lane, seed, key).ne;
-    bool mine = prio <= barrier;
-    for (int e = 0; e < ne && mine; ++e) {
-      const DevImage& im = p.images[SLOT(p.e_meta, e) & 0xFFFFu];
-      mine = p.claim[im.pix_off + SLOT(p.e_pix, e)] == key;
-    }
-    if (!mine) {
-      p.next_active[atomicAdd(p.next_count, 1)] = seed;
-      continue;
-    }
-    int m = 0;  // in-box pixels, their slots compacted into `frame`
-    for (int e = 0; e < ne; ++e) {
-      const unsigned meta = SLOT(p.e_meta, e);
-      p.mask[p.images[meta & 0xFFFFu].pix_off + SLOT(p.e_pix, e)] = p.round;
-      if (!(meta >> 31)) continue;
-      SLOT(p.frame, m) = (unsigned)e;
-      ++m;
+  __syncthreads();
+  float* const col = stage[wave];
+  for (int wi = wave; wi < nw; wi += kCommitWaves) {
+    const unsigned tau = p.w_tau[(size_t)t * p.window_cap + wi];
+    if (tau * (unsigned)p.T + t >= rs) continue;  // not final: forgotten with the epoch
+    const int first = (int)p.w_first[(size_t)t * p.window_cap + wi], count = (int)p.w_count[(size_t)t * p.window_cap + wi];
+    unsigned* const box = p.rec_box + (size_t)t * kRecordBuf + first;
+    int m = 0;  // in-box pixels; their record indices compacted into `box`
+    for (int e0 = 0; e0 < count; e0 += kWave) {
+      const int e = e0 + lane;
+      bool inb = false;
+      if (e < count) {
+        const unsigned meta = rec_meta[first + e];
+        const unsigned long long goff = (unsigned long long)p.images[meta & 0xFFFFu].pix_off + (unsigned long long)rec_pix[first + e];
+        __hip_atomic_store(p.word + goff, kCommitted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        inb = (meta >> 31) != 0u;
+      }
+      const unsigned long long mk = __ballot(inb);
+      const int at = m + __popcll(mk & ((1ull << lane) - 1ull));
+      if (inb) box[at] = (unsigned)(first + e);
+      m += __popcll(mk);
     }
     if (m < p.min_num_pixels || m == 0) continue;
-    const float fnx = (float)median_of(m, [&](int a) { return SLOT(p.e_nx, SLOT(p.frame, a)); }, col);
-    const float fny = (float)median_of(m, [&](int a) { return SLOT(p.e_ny, SLOT(p.frame, a)); }, col);
-    const float fnz = (float)median_of(m, [&](int a) { return SLOT(p.e_nz, SLOT(p.frame, a)); }, col);
+    wave_fence();  // `box` is written and read by different lanes of this wave
+    auto rec_of = [&](int a) -> int { return (int)box[a]; };
+    double med[9];
+    for (int ch = 0; ch < 9; ++ch) {
+      const float* column = vals + (size_t)ch * kRecordBuf;
+      med[ch] = wave_median(m, [&](int a) { return column[rec_of(a)]; }, col, lane);
+    }
+    const float fnx = (float)med[3], fny = (float)med[4], fnz = (float)med[5];
     const float norm = sqrtf(fnx * fnx + fny * fny + fnz * fnz);
     if (norm < FLT_EPSILON) continue;
-    float* out = p.pt + 6 * (size_t)seed;
-    out[0] = (float)median_of(m, [&](int a) { return SLOT(p.e_x, SLOT(p.frame, a)); }, col);
-    out[1] = (float)median_of(m, [&](int a) { return SLOT(p.e_y, SLOT(p.frame, a)); }, col);
-    out[2] = (float)median_of(m, [&](int a) { return SLOT(p.e_z, SLOT(p.frame, a)); }, col);
-    out[3] = fnx / norm; out[4] = fny / norm; out[5] = fnz / norm;
-    for (int ch = 0; ch < 3; ++ch) {
-      const float v = roundf((float)median_of(m, [&](int a) {
-        return (float)((SLOT(p.e_rgb, SLOT(p.frame, a)) >> (8 * ch)) & 0xFFu);
-      }, col));
-      p.col[3 * (size_t)seed + ch] = (unsigned char)fminf(255.0f, fmaxf(0.0f, v));
-    }
     // distinct images, ascending (the reference copies an unordered set)
     int nvis = 0;
     for (int last = -1;;) {
       int best = 0x7FFFFFFF;
-      for (int a = 0; a < m; ++a) {
-        const int ia = (int)(SLOT(p.e_meta, SLOT(p.frame, a)) & 0xFFFFu);
+      for (int a = lane; a < m; a += kWave) {
+        const int ia = (int)(rec_meta[rec_of(a)] & 0xFFFFu);
         if (ia > last && ia < best) best = ia;
       }
+      best = wave_min(best);
       if (best == 0x7FFFFFFF) break;
       last = best;
       ++nvis;
     }
-    const unsigned long long off64 = atomicAdd(p.pool_cursor, (unsigned long long)nvis);
+    unsigned long long off64 = 0ull;
+    if (lane == 0) off64 = atomicAdd(&p.ctl->cursor, (unsigned long long)nvis);
+    off64 = shfl64(off64, 0);
     const bool fits = off64 + (unsigned long long)nvis <= (unsigned long long)p.pool_cap;  // else: the host fails the run
     const int off = fits ? (int)off64 : 0;
     int last = -1;
     for (int v = 0; v < nvis; ++v) {
       int best = 0x7FFFFFFF;
-      for (int a = 0; a < m; ++a) {
-        const int ia = (int)(SLOT(p.e_meta, SLOT(p.frame, a)) & 0xFFFFu);
+      for (int a = lane; a < m; a += kWave) {
+        const int ia = (int)(rec_meta[rec_of(a)] & 0xFFFFu);
         if (ia > last && ia < best) best = ia;
       }
-      if (fits) p.pool[off + v] = best;
+      best = wave_min(best);
+      if (fits && lane == 0) p.pool[off + v] = best;
       last = best;
     }
-    p.vis_off[seed] = off;
-    p.nvis[seed] = nvis;
-    p.valid[seed] = 1;
+    if (lane == 0) {
+      const int seed = (int)rec_pix[first];  // a walk's first record is its start pixel
+      float* out = p.pt + 6 * (size_t)seed;
+      out[0] = (float)med[0]; out[1] = (float)med[1]; out[2] = (float)med[2];
+      out[3] = fnx / norm; out[4] = fny / norm; out[5] = fnz / norm;
+      for (int ch = 0; ch < 3; ++ch) {
+        const float v = roundf((float)med[6 + ch]);
+        p.col[3 * (size_t)seed + ch] = (unsigned char)fminf(255.0f, fmaxf(0.0f, v));
+      }
+      p.vis_off[seed] = off;
+      p.nvis[seed] = nvis;
+      p.valid[seed] = 1;
+    }
   }
 }
-#undef SLOT
 
-// The order in which the pixels of an image take their turn: ascending hash of the pixel index
-// (fmix32 of MurmurHash3, a bijection of the 32-bit integers, so the keys are distinct). The
-// reference's row-major order is only one of the orders its thread pool can produce; a pseudo-random
-// one keeps walks that compete for the same pixels from forming long chains of decreasing rank.
-__host__ __device__ inline unsigned seed_hash(unsigned s) {
-  s ^= s >> 16; s *= 0x85EBCA6Bu; s ^= s >> 13; s *= 0xC2B2AE35u; s ^= s >> 16;
-  return s;
-}
-
-__global__ void fusion_keys_kernel(int num_seeds, unsigned* __restrict__ keys, int* __restrict__ seeds) {
+// Output order of an image's points: as the reference collects them -- per pool thread, in the order of its
+// turns (fusion.cc:322-337): key = (thread, tick).
+__global__ void fusion_keys_kernel(int num_seeds, int W, int T, unsigned L, int G, unsigned* __restrict__ keys,
+                                   int* __restrict__ seeds) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= num_seeds) return;
-  keys[s] = seed_hash((unsigned)s);
+  const int row = s / W, col = s - row * W;
+  const int k = row / kRowStride;
+  const unsigned tau = (unsigned)(k / T) * L + (unsigned)((row - k * kRowStride) * W + col);
+  keys[s] = (unsigned)(k % T) * ((unsigned)G * L) + tau;
   seeds[s] = s;
 }
 
-__global__ void fusion_invert_kernel(int num_seeds, const int* __restrict__ order, int* __restrict__ rank_of) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k < num_seeds) rank_of[order[k]] = k;
-}
-
-// The seeds of ranks [k0, k1) get their first turn: appended to the undecided list unless their own
-// pixel is masked already (then their turn is empty) or has no depth.
-__global__ void fusion_offer_kernel(Params p, const int* __restrict__ order, int k0, int k1) {
-  const int k = k0 + blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= k1) return;
-  const int seed = order[k];
-  const DevImage& im = p.images[p.image];
-  if (p.mask[im.pix_off + seed] != 0u || im.depth[seed] <= 0.0f) return;
-  p.next_active[atomicAdd(p.next_count, 1)] = seed;
-}
-
-// seed order -> output order: entry k is the seed of rank k
+// output order -> compacted output: entry k is the seed at position k of the order
 __global__ void fusion_rank_kernel(int num_seeds, const int* __restrict__ order, const int* __restrict__ valid,
                                    const int* __restrict__ nvis, int* __restrict__ valid_r, int* __restrict__ nvis_r) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -478,13 +621,13 @@ __global__ void fusion_rank_kernel(int num_seeds, const int* __restrict__ order,
   nvis_r[k] = valid[s] ? nvis[s] : 0;
 }
 
-__global__ void fusion_compact_kernel(int num_seeds, const int* __restrict__ order, const int* __restrict__ valid_r,
+__global__ void fusion_compact_kernel(int num_seeds, int W, int T, const int* __restrict__ order, const int* __restrict__ valid_r,
                                       const int* __restrict__ scan_valid, const int* __restrict__ nvis_r,
                                       const int* __restrict__ scan_vis, const int* __restrict__ vis_off,
                                       const int* __restrict__ pool, const float* __restrict__ pt,
                                       const unsigned char* __restrict__ col, float* __restrict__ out_pt,
                                       unsigned char* __restrict__ out_col, int* __restrict__ out_nvis,
-                                      int* __restrict__ out_vis) {
+                                      int* __restrict__ out_vis, int* __restrict__ out_thread) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= num_seeds || !valid_r[k]) return;
   const int s = order[k];
@@ -492,12 +635,28 @@ __global__ void fusion_compact_kernel(int num_seeds, const int* __restrict__ ord
   for (int c = 0; c < 6; ++c) out_pt[6 * (size_t)o + c] = pt[6 * (size_t)s + c];
   for (int c = 0; c < 3; ++c) out_col[3 * (size_t)o + c] = col[3 * (size_t)s + c];
   out_nvis[o] = nvis_r[k];
+  out_thread[o] = ((s / W) / kRowStride) % T;
   for (int w = 0; w < nvis_r[k]; ++w) out_vis[scan_vis[k] + w] = pool[vis_off[s] + w];
 }
 
-__global__ void fusion_premask_kernel(size_t n, const unsigned char* __restrict__ in, unsigned* __restrict__ mask) {
+__global__ void fusion_premask_kernel(size_t n, const unsigned char* __restrict__ in, unsigned long long* __restrict__ word) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n && in[i]) mask[i] = 1u;  // masked before the first round
+  if (i < n && in[i]) word[i] = kCommitted;  // masked before the first turn
+}
+
+// slice-major normal map [3][n] -> xyz triples [n][3]
+__global__ void fusion_normal_kernel(size_t n, const float* __restrict__ in, float* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  out[3 * i] = in[i];
+  out[3 * i + 1] = in[n + i];
+  out[3 * i + 2] = in[2 * n + i];
+}
+
+__global__ void fusion_ctl_reset_kernel(PassCtl* ctl) {
+  ctl->rstar[0] = ctl->rstar[1] = 0xFFFFFFFFu;
+  ctl->flags = 0u;
+  ctl->walks = ctl->nodes = ctl->cursor = 0ull;
 }
 
 template <typename T>
@@ -558,8 +717,9 @@ void ComposeInverseProjectionMatrix(const float P[12], float inv_P[12]) {
 }
 
 struct Stats {
-  long long images = 0, seeds = 0, rounds = 0, walks = 0;
-  double upload_seconds = 0.0, device_seconds = 0.0;  // host maps -> HBM + workspace setup | rounds, medians, compaction, read-back
+  long long images = 0, seeds = 0, rounds = 0, walks = 0;  // rounds = passes; walks = turns walked (committed or not)
+  long long nodes = 0, cuts = 0;                            // pixels recorded by those walks; passes that ended in a cut
+  double upload_seconds = 0.0, device_seconds = 0.0;  // host maps -> HBM + workspace setup | passes, medians, compaction, read-back
 };
 Stats g_stats;
 
@@ -587,6 +747,11 @@ struct fusion_result {
 };
 
 namespace {
+
+int EnvInt(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e && *e ? atoi(e) : dflt;
+}
 
 void Run(const fusion_options& opt, int n, const fusion_image* images, const int32_t* optr, const int32_t* oidx,
          fusion_result* out) {
@@ -623,13 +788,19 @@ void Run(const fusion_options& opt, int n, const fusion_image* images, const int
     }
   }
   if (order_of_images.empty()) return;
+  for (int i = 0; i < n; ++i)
+    for (int k = optr[i]; k < optr[i + 1]; ++k) FU_CHECK(oidx[k] >= 0 && oidx[k] < n, "overlap index");
+  int max_overlap = 1;
+  for (int i = 0; i < n; ++i) {
+    FU_CHECK(optr[i + 1] - optr[i] < (1 << 20), "overlap list length");
+    max_overlap = std::max(max_overlap, optr[i + 1] - optr[i]);
+  }
 
   // resident maps + descriptors
   std::vector<DevImage> h_img(n);
-  std::vector<DevBuf<float>> d_depth(n), d_normal(n);
   std::vector<DevBuf<uint8_t>> d_rgb(n);
   long long total_pix = 0;
-  int max_seeds = 0;
+  int max_seeds = 0, max_threads = 1, max_height = 1;
   for (int i = 0; i < n; ++i) {
     DevImage& d = h_img[i];
     std::memset(&d, 0, sizeof(d));
@@ -647,10 +818,6 @@ void Run(const fusion_options& opt, int n, const fusion_image* images, const int
     ComposeInverseProjectionMatrix(d.P, d.inv_P);
     for (int r = 0; r < 3; ++r)
       for (int c = 0; c < 3; ++c) d.inv_R[3 * r + c] = im.R[3 * c + r];
-    d_depth[i].upload(im.depth_map, npix);
-    d_normal[i].upload(im.normal_map, 3 * npix);
-    d.depth = d_depth[i].p;
-    d.normal = d_normal[i].p;
     if (im.rgb) {
       FU_CHECK(im.bitmap_width > 0 && im.bitmap_height > 0, "bitmap size");
       d_rgb[i].upload(im.rgb, 3 * (size_t)im.bitmap_width * im.bitmap_height);
@@ -660,179 +827,211 @@ void Run(const fusion_options& opt, int n, const fusion_image* images, const int
     d.pix_off = total_pix;
     total_pix += (long long)npix;
     max_seeds = std::max(max_seeds, (int)npix);
+    max_height = std::max(max_height, im.depth_height);
   }
-  // mask / claim words are indexed with 64-bit offsets: no limit on the workspace size. The visibility pool is
-  // refilled per reference image (cursor reset every step) and its int offsets only have to cover what ONE
-  // image's walks absorb: capacity min(total pixels, 2^31 - 1), an overflow fails the run instead of wrapping.
+  // pool threads: one wave each. num_threads <= 0: one thread per stripe (the reference's default pool, all cores, is at
+  // least that large for ordinary images and then behaves the same in step).
+  auto threads_of = [&](int height) {
+    const int ns = (height + kRowStride - 1) / kRowStride;
+    return opt.num_threads <= 0 ? ns : std::min(opt.num_threads, ns);
+  };
+  max_threads = threads_of(max_height);
+  // all depth maps / normal maps (as xyz triples) / words in one array each, indexed by the global pixel offset
+  DevBuf<float> d_depth, d_normal, d_stage;
+  DevBuf<unsigned long long> d_word;
+  d_depth.alloc((size_t)total_pix);
+  d_normal.alloc(3 * (size_t)total_pix);
+  d_stage.alloc(3 * (size_t)max_seeds);
+  d_word.alloc((size_t)total_pix);
+  FU_HIP(hipMemset(d_word.p, 0, sizeof(unsigned long long) * (size_t)total_pix));
+  for (int i = 0; i < n; ++i) {
+    if (!used[i]) continue;
+    const size_t npix = (size_t)images[i].depth_width * images[i].depth_height;
+    FU_HIP(hipMemcpy(d_depth.p + h_img[i].pix_off, images[i].depth_map, npix * sizeof(float), hipMemcpyHostToDevice));
+    FU_HIP(hipMemcpy(d_stage.p, images[i].normal_map, 3 * npix * sizeof(float), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(fusion_normal_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, 0, npix, d_stage.p,
+                       d_normal.p + 3 * (size_t)h_img[i].pix_off);
+    if (images[i].mask) {
+      DevBuf<uint8_t> m;
+      m.upload(images[i].mask, npix);
+      hipLaunchKernelGGL(fusion_premask_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, 0, npix, m.p,
+                         d_word.p + h_img[i].pix_off);
+      FU_HIP(hipDeviceSynchronize());
+    }
+    FU_HIP(hipDeviceSynchronize());  // the staging buffer is reused by the next image
+  }
+  d_stage.release();
+  // The visibility pool is refilled per reference image (cursor reset every step) and its int offsets only have to cover
+  // what ONE image's walks absorb: capacity min(total pixels, 2^31 - 1), an overflow fails the run instead of wrapping.
   const long long pool_cap = std::min<long long>(total_pix, 0x7FFFFFFFll);
   DevBuf<DevImage> d_img;
   d_img.upload(h_img.data(), h_img.size());
   DevBuf<int> d_optr, d_oidx;
   d_optr.upload(optr, (size_t)n + 1);
   d_oidx.upload(oidx, (size_t)optr[n]);
-  for (int i = 0; i < n; ++i)
-    for (int k = optr[i]; k < optr[i + 1]; ++k) FU_CHECK(oidx[k] >= 0 && oidx[k] < n, "overlap index");
-  for (int i = 0; i < n; ++i) FU_CHECK(optr[i + 1] - optr[i] < (1 << 20), "overlap list length");
-
-  DevBuf<unsigned> d_mask, d_barrier;
-  DevBuf<unsigned long long> d_claim, d_cursor;
-  DevBuf<int> d_next_count;
-  d_mask.alloc((size_t)total_pix);
-  d_claim.alloc((size_t)total_pix);
-  FU_HIP(hipMemset(d_mask.p, 0, sizeof(unsigned) * (size_t)total_pix));
-  FU_HIP(hipMemset(d_claim.p, 0, sizeof(unsigned long long) * (size_t)total_pix));
-  d_cursor.alloc(1); d_barrier.alloc(1); d_next_count.alloc(1);
-  for (int i = 0; i < n; ++i) {
-    if (!used[i] || !images[i].mask) continue;
-    const size_t npix = (size_t)images[i].depth_width * images[i].depth_height;
-    DevBuf<uint8_t> m;
-    m.upload(images[i].mask, npix);
-    hipLaunchKernelGGL(fusion_premask_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, 0, npix, m.p,
-                       d_mask.p + h_img[i].pix_off);
-    FU_HIP(hipDeviceSynchronize());
-  }
 
   Params p;
   std::memset(&p, 0, sizeof(p));
-  p.images = d_img.p; p.optr = d_optr.p; p.oidx = d_oidx.p; p.mask = d_mask.p; p.claim = d_claim.p;
-  // Lane state: a walk cannot record more pixels than the workspace has, and no more lanes than the largest
-  // image has seeds are ever active -- the state is sized by both (a 4 x 48 x 36 workspace takes 2 MB, not
-  // the 13 GB of 10 000 slots x 32 768 lanes).
+  p.images = d_img.p; p.optr = d_optr.p; p.oidx = d_oidx.p; p.word = d_word.p; p.depth = d_depth.p; p.normal = d_normal.p;
   p.rec_cap = (int)std::min<long long>(record_capacity(opt.max_num_pixels), std::max<long long>(total_pix, 1));
   p.elem_cap = std::min(opt.max_num_pixels, p.rec_cap);
-  p.lanes = std::min(kLanes, (max_seeds + kBlock - 1) / kBlock * kBlock);
   p.max_level = opt.max_traversal_depth - 1;
   p.min_num_pixels = opt.min_num_pixels;
   p.max_depth_error = opt.max_depth_error;
   p.max_sq_reproj = static_cast<float>(opt.max_reproj_error * opt.max_reproj_error);
   p.min_cos_normal = static_cast<float>(std::cos(opt.max_normal_error * 0.017453292519943295769));
   for (int c = 0; c < 3; ++c) { p.bmin[c] = opt.bbox_min[c]; p.bmax[c] = opt.bbox_max[c]; }
-  DevBuf<unsigned> e_pix, e_meta, e_rgb, frame;
-  DevBuf<float> e_f[6];
-  const size_t state = (size_t)p.rec_cap * p.lanes;
-  e_pix.alloc(state); e_meta.alloc(state); e_rgb.alloc(state); frame.alloc(state);
-  for (auto& b : e_f) b.alloc(state);
-  p.e_pix = e_pix.p; p.e_meta = e_meta.p; p.e_rgb = e_rgb.p; p.frame = frame.p;
-  p.e_x = e_f[0].p; p.e_y = e_f[1].p; p.e_z = e_f[2].p; p.e_nx = e_f[3].p; p.e_ny = e_f[4].p; p.e_nz = e_f[5].p;
-  DevBuf<int> valid, nvis, vis_off, valid_r, nvis_r, scan_valid, scan_vis, pool, out_nvis, out_vis, list_a, list_b;
+  // per-wave state. Schedule knobs for experiments (the result does not depend on them: bit-exact against the
+  // sequential algorithm for any window): COLMAP_AMD_FUSION_WINDOW_FIRST / _MAX.
+  const int window_first = std::max(1, EnvInt("COLMAP_AMD_FUSION_WINDOW_FIRST", kWindowFirst));
+  const int window_max = std::max(window_first, EnvInt("COLMAP_AMD_FUSION_WINDOW_MAX", kWindowMax));
+  const size_t TT = (size_t)max_threads;
+  DevBuf<unsigned> rec_pix, rec_meta, rec_box, w_tau, w_first, w_count;
+  DevBuf<int> n_walks;
+  DevBuf<float> vals;
+  DevBuf<unsigned long long> spill_goff;
+  DevBuf<uint2> spill_pm;
+  DevBuf<PassCtl> d_ctl;
+  rec_pix.alloc(TT * kRecordBuf); rec_meta.alloc(TT * kRecordBuf); rec_box.alloc(TT * kRecordBuf);
+  w_tau.alloc(TT * window_max); w_first.alloc(TT * window_max); w_count.alloc(TT * window_max);
+  n_walks.alloc(TT); vals.alloc(TT * 9 * kRecordBuf);
+  int spill_cap = kStackSpill;
+  spill_goff.alloc(TT * spill_cap); spill_pm.alloc(TT * spill_cap);
+  d_ctl.alloc(1);
+  p.rec_pix = rec_pix.p; p.rec_meta = rec_meta.p; p.rec_box = rec_box.p;
+  p.w_tau = w_tau.p; p.w_first = w_first.p; p.w_count = w_count.p; p.n_walks = n_walks.p; p.window_cap = window_max;
+  p.vals = vals.p; p.spill_goff = spill_goff.p; p.spill_pm = spill_pm.p; p.spill_cap = spill_cap; p.ctl = d_ctl.p;
+  // a stack can never hold more than (pixels a walk records) x (longest overlap list) entries
+  const long long spill_bound = (long long)p.rec_cap * max_overlap + kWave;
+
+  DevBuf<int> valid, nvis, vis_off, valid_r, nvis_r, scan_valid, scan_vis, pool, out_nvis, out_vis, out_thread;
   DevBuf<float> pt, out_pt;
   DevBuf<unsigned char> col, out_col;
   const size_t ms = (size_t)max_seeds;
   valid.alloc(ms); nvis.alloc(ms); vis_off.alloc(ms); valid_r.alloc(ms + 1); nvis_r.alloc(ms + 1);
-  scan_valid.alloc(ms + 1); scan_vis.alloc(ms + 1); list_a.alloc(ms); list_b.alloc(ms);
-  pool.alloc((size_t)pool_cap); out_nvis.alloc(ms); out_vis.alloc((size_t)pool_cap);
+  scan_valid.alloc(ms + 1); scan_vis.alloc(ms + 1);
+  pool.alloc((size_t)pool_cap); out_nvis.alloc(ms); out_vis.alloc((size_t)pool_cap); out_thread.alloc(ms);
   p.pool_cap = pool_cap;
   pt.alloc(6 * ms); out_pt.alloc(6 * ms); col.alloc(3 * ms); out_col.alloc(3 * ms);
   p.valid = valid.p; p.nvis = nvis.p; p.vis_off = vis_off.p; p.pt = pt.p; p.col = col.p; p.pool = pool.p;
-  p.pool_cursor = d_cursor.p; p.barrier = d_barrier.p; p.next_count = d_next_count.p;
   size_t tmp_bytes = 0;
   FU_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, valid_r.p, scan_valid.p, (int)ms + 1));
   DevBuf<unsigned char> tmp;
   tmp.alloc(tmp_bytes + 16);
-
   DevBuf<unsigned> keys_in, keys_out;
-  DevBuf<int> seeds_in, order, rank_of, lane_walk;
-  keys_in.alloc(ms); keys_out.alloc(ms); seeds_in.alloc(ms); order.alloc(ms); rank_of.alloc(ms); lane_walk.alloc(p.lanes);
-  p.rank_of = rank_of.p; p.lane_walk = lane_walk.p;
+  DevBuf<int> seeds_in, order;
+  keys_in.alloc(ms); keys_out.alloc(ms); seeds_in.alloc(ms); order.alloc(ms);
   size_t sort_bytes = 0;
   FU_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, keys_in.p, keys_out.p, seeds_in.p, order.p, (int)ms));
   DevBuf<unsigned char> sort_tmp;
   sort_tmp.alloc(sort_bytes + 16);
 
-  std::vector<float> h_pt;
-  std::vector<unsigned char> h_col;
-  std::vector<int> h_nvis, h_vis;
-  unsigned round = 2;  // 0 = free, 1 = masked on input
+  // the points of every image, in (thread, tick) order, with their thread; concatenated per thread at the end
+  struct Chunk {
+    std::vector<float> pt;
+    std::vector<unsigned char> col;
+    std::vector<int> nvis, vis, thread;
+  };
+  std::vector<Chunk> chunks;
+  unsigned epoch = 1;  // 0 would make the free word look like a mark
   g_stats = Stats();
   FU_HIP(hipDeviceSynchronize());
   const auto t_setup = std::chrono::steady_clock::now();
   g_stats.upload_seconds = std::chrono::duration<double>(t_setup - t_begin).count();
   for (int step = 0; step < (int)order_of_images.size(); ++step) {
     const int I = order_of_images[step];
-    const int ns = h_img[I].dw * h_img[I].dh;
-    p.step = step; p.image = I; p.num_seeds = ns;
-    // seed order of this image: pixels sorted by their hash
-    hipLaunchKernelGGL(fusion_keys_kernel, dim3((ns + 255) / 256), dim3(256), 0, 0, ns, keys_in.p, seeds_in.p);
-    size_t sb = sort_bytes;
-    FU_HIP(hipcub::DeviceRadixSort::SortPairs(sort_tmp.p, sb, keys_in.p, keys_out.p, seeds_in.p, order.p, ns));
-    hipLaunchKernelGGL(fusion_invert_kernel, dim3((ns + 255) / 256), dim3(256), 0, 0, ns, order.p, rank_of.p);
-    FU_HIP(hipMemsetAsync(d_cursor.p, 0, sizeof(unsigned long long), 0));
-    FU_HIP(hipMemsetAsync(valid.p, 0, sizeof(int) * (size_t)ns, 0));
-    // Rounds. The undecided list must hold EVERY undecided seed up to some rank (a seed may only commit
-    // when all seeds before it have claimed), so first turns are offered in rank order: a small head
-    // of the order first, then doubling -- by the time the bulk of the seeds is offered most of their
-    // pixels are masked and their turns are empty.
-    int* lists[2] = {list_a.p, list_b.p};
-    p.active = lists[0];
-    p.num_active = 0;
-    int offered = 0;
-    // First chunk = min(ns / 64, kLanes), then doubling. Measured (profiles/r03_fusion_schedule.log): on 8 x 1280 x 960
-    // first chunk ns / 1024 -> 16.5 rounds per image, 9.8 Mpix/s; ns / 256 -> 14.5, 10.5; ns / 64 -> 12.75, 10.9; on
-    // 8 x 2560 x 1920 ns / 64 exceeds the resident lanes, the first rounds lose the walk reuse between speculate and
-    // commit, and on PatchMatch's own (noisier) maps that costs more than the saved rounds (bench leg 10.6 against
-    // 14.8 Mpix/s) -- hence the cap. Growing by 4 instead of 2 saves rounds but doubles the walks that lose their
-    // claims (6.6 Mpix/s). The result does not depend on the schedule (bit-exact against the sequential algorithm
-    // for any of them). Knobs for experiments: COLMAP_AMD_FUSION_HEAD_DIV, COLMAP_AMD_FUSION_GROWTH.
-    static const int head_div = [] { const char* e = getenv("COLMAP_AMD_FUSION_HEAD_DIV"); return e && atoi(e) > 0 ? atoi(e) : 64; }();
-    static const int growth = [] { const char* e = getenv("COLMAP_AMD_FUSION_GROWTH"); return e && atoi(e) > 1 ? atoi(e) : 2; }();
-    const int head = std::min(p.lanes, std::max(256, ns / head_div));
-    for (int it = 0; p.num_active > 0 || offered < ns; ++it, ++round) {
-      FU_CHECK(round != 0xFFFFFFFFu, "round counter");
-      p.round = round;
-      p.next_active = lists[(it + 1) & 1];
-      FU_HIP(hipMemsetAsync(d_barrier.p, 0xFF, sizeof(unsigned), 0));
-      FU_HIP(hipMemsetAsync(d_next_count.p, 0, sizeof(int), 0));
-      if (p.num_active > 0) {
-        p.reuse = p.num_active <= p.lanes ? 1 : 0;
-        const int grid = std::min(p.lanes, (p.num_active + kBlock - 1) / kBlock * kBlock) / kBlock;
-        hipLaunchKernelGGL(fusion_speculate_kernel, dim3(grid), dim3(kBlock), 0, 0, p);
-        hipLaunchKernelGGL(fusion_commit_kernel, dim3(grid), dim3(kBlock), 0, 0, p);
-        g_stats.rounds += 1;
-        g_stats.walks += p.num_active;
-      }
-      if (offered < ns) {
-        const int upto = (int)std::min<long long>(ns, std::max<long long>((long long)offered + head, (long long)growth * offered));
-        hipLaunchKernelGGL(fusion_offer_kernel, dim3((upto - offered + 255) / 256), dim3(256), 0, 0, p, order.p, offered, upto);
-        offered = upto;
-      }
-      int left = 0;
-      FU_HIP(hipMemcpy(&left, d_next_count.p, sizeof(int), hipMemcpyDeviceToHost));
+    const int W = h_img[I].dw, H = h_img[I].dh, ns_px = W * H;
+    const int ns = (H + kRowStride - 1) / kRowStride, T = threads_of(H), G = (ns + T - 1) / T;
+    const unsigned long long L = (unsigned long long)kRowStride * W, ticks = (unsigned long long)G * L;
+    const unsigned long long r_end = ticks * (unsigned long long)T;
+    FU_CHECK(r_end < 0xFFFFFFF0ull, "turns of one image < 2^32");
+    p.step = step; p.image = I; p.T = T; p.W = W; p.H = H; p.ns = ns; p.L = (unsigned)L;
+    hipLaunchKernelGGL(fusion_ctl_reset_kernel, dim3(1), dim3(1), 0, 0, d_ctl.p);
+    FU_HIP(hipMemsetAsync(valid.p, 0, sizeof(int) * (size_t)ns_px, 0));
+    // passes: ranks [r_next, limit) are walked speculatively, [r_next, rstar) commit
+    unsigned long long r_next = 0;
+    long long window = window_first;
+    PassCtl h_ctl;
+    std::memset(&h_ctl, 0, sizeof(h_ctl));
+    for (int pass = 0; r_next < r_end; ++pass, ++epoch) {
+      FU_CHECK(epoch < 0xFFFFFFFEu, "epoch counter");
+      const unsigned long long tau0 = r_next / (unsigned long long)T;
+      const unsigned long long tau_end = std::min<unsigned long long>(tau0 + (unsigned long long)window, ticks);
+      p.epoch = epoch; p.slot = pass & 1;
+      p.tau0 = (unsigned)tau0; p.rmod = (unsigned)(r_next % (unsigned long long)T);
+      p.tau_end = (unsigned)tau_end; p.limit = (unsigned)(tau_end * (unsigned long long)T);
+      hipLaunchKernelGGL(fusion_walk_kernel, dim3(T), dim3(kWave), 0, 0, p);
+      hipLaunchKernelGGL(fusion_commit_kernel, dim3(T), dim3(kWave * kCommitWaves), 0, 0, p);
+      FU_HIP(hipMemcpy(&h_ctl, d_ctl.p, sizeof(h_ctl), hipMemcpyDeviceToHost));
       FU_HIP(hipGetLastError());
-      p.active = p.next_active;
-      p.num_active = left;
+      const unsigned long long rstar = std::min<unsigned long long>(h_ctl.rstar[pass & 1], p.limit);
+      g_stats.rounds += 1;
+      if (h_ctl.flags & 1u) {  // a walk overflowed the stack spill: it cut the pass at its own rank; give it room
+        FU_CHECK((long long)spill_cap < spill_bound, "stack overflow beyond its bound");
+        spill_cap = (int)std::min<long long>(4ll * spill_cap, spill_bound);
+        spill_goff.alloc(TT * spill_cap); spill_pm.alloc(TT * spill_cap);
+        p.spill_goff = spill_goff.p; p.spill_pm = spill_pm.p; p.spill_cap = spill_cap;
+        FU_HIP(hipMemsetAsync(&d_ctl.p->flags, 0, sizeof(unsigned), 0));
+      } else {
+        FU_CHECK(rstar > r_next, "pass made no progress");
+      }
+      const bool cut = rstar < (unsigned long long)p.limit;
+      if (cut) g_stats.cuts += 1;
+      window = cut ? std::max<long long>(kWindowMin, window / 2) : std::min<long long>(window_max, 2 * window);
+      r_next = rstar;
     }
-    hipLaunchKernelGGL(fusion_rank_kernel, dim3((ns + 256) / 256), dim3(256), 0, 0, ns, order.p, valid.p, nvis.p,
+    g_stats.walks += (long long)h_ctl.walks;
+    g_stats.nodes += (long long)h_ctl.nodes;
+    FU_CHECK(h_ctl.cursor <= (unsigned long long)pool_cap, "visibility pool overflow (more than 2^31 - 1 visibility entries for one reference image)");
+    // output order of this image: (thread, tick)
+    hipLaunchKernelGGL(fusion_keys_kernel, dim3((ns_px + 255) / 256), dim3(256), 0, 0, ns_px, W, T, (unsigned)L, G, keys_in.p, seeds_in.p);
+    size_t sb = sort_bytes;
+    FU_HIP(hipcub::DeviceRadixSort::SortPairs(sort_tmp.p, sb, keys_in.p, keys_out.p, seeds_in.p, order.p, ns_px));
+    hipLaunchKernelGGL(fusion_rank_kernel, dim3((ns_px + 256) / 256), dim3(256), 0, 0, ns_px, order.p, valid.p, nvis.p,
                        valid_r.p, nvis_r.p);
     size_t tb = tmp_bytes;
-    FU_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, valid_r.p, scan_valid.p, ns + 1));
+    FU_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, valid_r.p, scan_valid.p, ns_px + 1));
     tb = tmp_bytes;
-    FU_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, nvis_r.p, scan_vis.p, ns + 1));
-    hipLaunchKernelGGL(fusion_compact_kernel, dim3((ns + 255) / 256), dim3(256), 0, 0, ns, order.p, valid_r.p,
+    FU_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, nvis_r.p, scan_vis.p, ns_px + 1));
+    hipLaunchKernelGGL(fusion_compact_kernel, dim3((ns_px + 255) / 256), dim3(256), 0, 0, ns_px, W, T, order.p, valid_r.p,
                        scan_valid.p, nvis_r.p, scan_vis.p, vis_off.p, pool.p, pt.p, col.p, out_pt.p, out_col.p,
-                       out_nvis.p, out_vis.p);
-    unsigned long long used = 0;
-    FU_HIP(hipMemcpy(&used, d_cursor.p, sizeof(used), hipMemcpyDeviceToHost));
-    FU_CHECK(used <= (unsigned long long)pool_cap, "visibility pool overflow (more than 2^31 - 1 visibility entries for one reference image)");
+                       out_nvis.p, out_vis.p, out_thread.p);
     int totals[2] = {0, 0};
-    FU_HIP(hipMemcpy(&totals[0], scan_valid.p + ns, sizeof(int), hipMemcpyDeviceToHost));
-    FU_HIP(hipMemcpy(&totals[1], scan_vis.p + ns, sizeof(int), hipMemcpyDeviceToHost));
+    FU_HIP(hipMemcpy(&totals[0], scan_valid.p + ns_px, sizeof(int), hipMemcpyDeviceToHost));
+    FU_HIP(hipMemcpy(&totals[1], scan_vis.p + ns_px, sizeof(int), hipMemcpyDeviceToHost));
     FU_HIP(hipGetLastError());
     g_stats.images += 1;
-    g_stats.seeds += ns;
+    g_stats.seeds += ns_px;
     const size_t np = (size_t)totals[0], nv = (size_t)totals[1];
     if (np == 0) continue;
-    h_pt.resize(6 * np); h_col.resize(3 * np); h_nvis.resize(np); h_vis.resize(nv);
-    FU_HIP(hipMemcpy(h_pt.data(), out_pt.p, sizeof(float) * 6 * np, hipMemcpyDeviceToHost));
-    FU_HIP(hipMemcpy(h_col.data(), out_col.p, 3 * np, hipMemcpyDeviceToHost));
-    FU_HIP(hipMemcpy(h_nvis.data(), out_nvis.p, sizeof(int) * np, hipMemcpyDeviceToHost));
-    if (nv) FU_HIP(hipMemcpy(h_vis.data(), out_vis.p, sizeof(int) * nv, hipMemcpyDeviceToHost));
-    out->xyz_normal.insert(out->xyz_normal.end(), h_pt.begin(), h_pt.end());
-    out->rgb.insert(out->rgb.end(), h_col.begin(), h_col.end());
-    out->vis_idx.insert(out->vis_idx.end(), h_vis.begin(), h_vis.end());
-    int64_t base = out->vis_ptr.back();
-    for (size_t k = 0; k < np; ++k) {
-      base += h_nvis[k];
-      out->vis_ptr.push_back(base);
+    chunks.emplace_back();
+    Chunk& c = chunks.back();
+    c.pt.resize(6 * np); c.col.resize(3 * np); c.nvis.resize(np); c.vis.resize(nv); c.thread.resize(np);
+    FU_HIP(hipMemcpy(c.pt.data(), out_pt.p, sizeof(float) * 6 * np, hipMemcpyDeviceToHost));
+    FU_HIP(hipMemcpy(c.col.data(), out_col.p, 3 * np, hipMemcpyDeviceToHost));
+    FU_HIP(hipMemcpy(c.nvis.data(), out_nvis.p, sizeof(int) * np, hipMemcpyDeviceToHost));
+    FU_HIP(hipMemcpy(c.thread.data(), out_thread.p, sizeof(int) * np, hipMemcpyDeviceToHost));
+    if (nv) FU_HIP(hipMemcpy(c.vis.data(), out_vis.p, sizeof(int) * nv, hipMemcpyDeviceToHost));
+  }
+  // task_fused_points_[thread] concatenated over the threads (fusion.cc:322-337): every chunk is sorted by thread
+  std::vector<size_t> at(chunks.size(), 0), vat(chunks.size(), 0);
+  for (int t = 0; t < max_threads; ++t) {
+    for (size_t ci = 0; ci < chunks.size(); ++ci) {
+      const Chunk& c = chunks[ci];
+      const size_t b = at[ci];
+      size_t e = b, nv = 0;
+      while (e < c.thread.size() && c.thread[e] == t) nv += (size_t)c.nvis[e++];
+      if (e == b) continue;
+      out->xyz_normal.insert(out->xyz_normal.end(), c.pt.begin() + 6 * b, c.pt.begin() + 6 * e);
+      out->rgb.insert(out->rgb.end(), c.col.begin() + 3 * b, c.col.begin() + 3 * e);
+      out->vis_idx.insert(out->vis_idx.end(), c.vis.begin() + vat[ci], c.vis.begin() + vat[ci] + nv);
+      int64_t base = out->vis_ptr.back();
+      for (size_t k = b; k < e; ++k) {
+        base += c.nvis[k];
+        out->vis_ptr.push_back(base);
+      }
+      at[ci] = e;
+      vat[ci] += nv;
     }
   }
   g_stats.device_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_setup).count();
@@ -855,6 +1054,7 @@ FUSION_API void fusion_options_init(fusion_options* o) {
     o->bbox_min[c] = -FLT_MAX;
     o->bbox_max[c] = FLT_MAX;
   }
+  o->num_threads = -1;
 }
 
 // StereoFusionOptions::Check (fusion.cc:96-106)

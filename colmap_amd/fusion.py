@@ -28,7 +28,8 @@ FLT_MAX = float(np.finfo(np.float32).max)
 class fusion_options(C.Structure):
     _fields_ = [("min_num_pixels", C.c_int32), ("max_num_pixels", C.c_int32), ("max_traversal_depth", C.c_int32),
                 ("check_num_images", C.c_int32), ("max_reproj_error", C.c_double), ("max_depth_error", C.c_double),
-                ("max_normal_error", C.c_double), ("bbox_min", C.c_float * 3), ("bbox_max", C.c_float * 3)]
+                ("max_normal_error", C.c_double), ("bbox_min", C.c_float * 3), ("bbox_max", C.c_float * 3),
+                ("num_threads", C.c_int32)]
 
 
 class fusion_image(C.Structure):
@@ -65,7 +66,7 @@ class StereoFusionOptions:
         o = fusion_options()
         lib().fusion_options_init(C.byref(o))
         for name in ("min_num_pixels", "max_num_pixels", "max_traversal_depth", "check_num_images",
-                     "max_reproj_error", "max_depth_error", "max_normal_error"):
+                     "max_reproj_error", "max_depth_error", "max_normal_error", "num_threads"):
             setattr(o, name, getattr(self, name))
         o.bbox_min[:] = [float(v) for v in self.bounding_box[0]]
         o.bbox_max[:] = [float(v) for v in self.bounding_box[1]]

@@ -34,6 +34,12 @@ typedef struct fusion_options {
   double max_depth_error;      /* 0.01 relative */
   double max_normal_error;     /* 10 degrees */
   float bbox_min[3], bbox_max[3]; /* -FLT_MAX / FLT_MAX */
+  /* StereoFusionOptions::num_threads (mvs/fusion.h:53): the size of the reference's thread pool, whose tasks are
+   * stripes of ten rows walked row-major (fusion.cc:253-269, 293-300). The turn order IS that pool's schedule with
+   * its threads advancing in step: thread t takes stripes t, t + T, t + 2T, ... and every tick each thread takes
+   * the next pixel of its stripe. 1 = plain row-major (the reference with one thread, bit for bit);
+   * <= 0 (the default -1) = one thread per stripe. */
+  int32_t num_threads;
 } fusion_options;
 
 /* One workspace image: mvs::Image pose at the MODEL image size, its colour bitmap, and the depth /

@@ -1,0 +1,230 @@
+// hip_runtime.h of tests/hip_emul -- TEST INFRASTRUCTURE ONLY: a minimal HIP-on-CPU stand-in, just large enough to run
+// colmap_amd/csrc/fusion.hip (host loop AND wave-cooperative kernels, unmodified source) in a container without a
+// GPU, so that its logic can be compared with oracle/fusion_oracle.cpp by `pytest -m "not gpu"`. Never part of the
+// product: the shipped library is built by hipcc against the real headers (colmap_amd/build.py).
+//
+// Execution model: a launch runs its blocks one after the other; the threads of a block are ucontext fibers of ONE OS
+// thread, switched only inside the cross-lane primitives (ballot / shuffle / readfirstlane / wave barrier /
+// __syncthreads), each of which is a barrier over the 64 lanes of the calling fiber's wave (or the block). A lane
+// therefore runs ahead of its wave between two primitives -- code that hands data from lane to lane through memory
+// without a barrier in between, which lock-step hardware forgives, fails here. readfirstlane asserts that the value
+// really is uniform. A barrier some lanes never reach is reported instead of hanging.
+#pragma once
+#include <ucontext.h>
+
+#include <cassert>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __shared__ static
+#define __launch_bounds__(...)
+
+struct dim3 {
+  unsigned x, y, z;
+  dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct uint2 { unsigned x, y; };
+inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
+
+typedef int hipError_t;
+typedef void* hipStream_t;
+enum { hipSuccess = 0, hipErrorOutOfMemory = 2 };
+enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice };
+inline const char* hipGetErrorString(hipError_t) { return "hip_emul error"; }
+inline hipError_t hipGetLastError() { return hipSuccess; }
+inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+inline hipError_t hipMalloc(void** p, size_t bytes) { *p = std::malloc(bytes ? bytes : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
+inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { std::memcpy(d, s, n); return hipSuccess; }
+inline hipError_t hipMemset(void* d, int v, size_t n) { std::memset(d, v, n); return hipSuccess; }
+inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { std::memset(d, v, n); return hipSuccess; }
+
+namespace hip_emul {
+
+constexpr int kWaveSize = 64;
+constexpr size_t kFiberStack = 256 * 1024;
+
+struct Fiber {
+  ucontext_t ctx;
+  char* stack = nullptr;
+  dim3 tid;
+  bool done = true;
+};
+
+struct Barrier {
+  int count = 0;
+  unsigned long gen = 0;
+};
+
+struct Block {
+  std::vector<Fiber> fibers;
+  ucontext_t sched;
+  int cur = 0, nthreads = 0;
+  Barrier block_bar;
+  std::vector<Barrier> wave_bar;
+  std::vector<unsigned long long> slot;  // one per thread: operand of the collective in flight
+  unsigned long progress = 0;            // barriers completed (deadlock detection)
+  const std::function<void()>* body = nullptr;
+};
+
+inline Block& blk() { static Block b; return b; }
+inline dim3& block_idx() { static dim3 v; return v; }
+inline dim3& block_dim() { static dim3 v; return v; }
+inline dim3& grid_dim() { static dim3 v; return v; }
+inline Fiber* cur_fiber() { return &blk().fibers[blk().cur]; }
+inline int lane_id() { return (int)(cur_fiber()->tid.x % kWaveSize); }
+inline int wave_id() { return (int)(cur_fiber()->tid.x / kWaveSize); }
+inline int wave_lanes(int w) { const int n = blk().nthreads - w * kWaveSize; return n < kWaveSize ? n : kWaveSize; }
+
+inline void yield() {
+  Block& b = blk();
+  swapcontext(&b.fibers[b.cur].ctx, &b.sched);
+}
+
+inline void barrier(Barrier& bar, int members) {
+  const unsigned long g = bar.gen;
+  if (++bar.count == members) {
+    bar.count = 0;
+    ++bar.gen;
+    ++blk().progress;
+  } else {
+    while (bar.gen == g) yield();
+  }
+}
+inline void wave_barrier() { barrier(blk().wave_bar[wave_id()], wave_lanes(wave_id())); }
+inline void block_barrier() { barrier(blk().block_bar, blk().nthreads); }
+
+inline void trampoline() {
+  Block& b = blk();
+  (*b.body)();
+  b.fibers[b.cur].done = true;
+  swapcontext(&b.fibers[b.cur].ctx, &b.sched);
+}
+
+inline void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
+  Block& b = blk();
+  const int nt = (int)block.x;
+  if ((int)b.fibers.size() < nt) b.fibers.resize(nt);
+  b.nthreads = nt;
+  b.body = &body;
+  b.wave_bar.assign((nt + kWaveSize - 1) / kWaveSize, Barrier());
+  b.slot.assign(nt, 0ull);
+  block_dim() = block;
+  grid_dim() = grid;
+  // HIP_EMUL_BLOCK_ORDER=reverse runs the blocks of every launch last to first: the other extreme of the orders in
+  // which concurrently resident workgroups can reach a shared word
+  static const bool reverse = [] { const char* e = std::getenv("HIP_EMUL_BLOCK_ORDER"); return e && e[0] == 'r'; }();
+  for (unsigned bi = 0; bi < grid.x; ++bi) {
+    const unsigned bid = reverse ? grid.x - 1 - bi : bi;
+    block_idx() = dim3(bid);
+    b.block_bar = Barrier();
+    for (auto& w : b.wave_bar) w = Barrier();
+    for (int i = 0; i < nt; ++i) {
+      Fiber& f = b.fibers[i];
+      if (!f.stack) f.stack = (char*)std::malloc(kFiberStack);
+      getcontext(&f.ctx);
+      f.ctx.uc_stack.ss_sp = f.stack;
+      f.ctx.uc_stack.ss_size = kFiberStack;
+      f.ctx.uc_link = nullptr;
+      makecontext(&f.ctx, (void (*)())trampoline, 0);
+      f.tid = dim3((unsigned)i);
+      f.done = false;
+    }
+    int live = nt;
+    while (live > 0) {
+      const unsigned long before = b.progress;
+      const int live_before = live;
+      for (int i = 0; i < nt; ++i) {
+        if (b.fibers[i].done) continue;
+        b.cur = i;
+        swapcontext(&b.sched, &b.fibers[i].ctx);
+        if (b.fibers[i].done) --live;
+      }
+      if (live > 0 && b.progress == before && live == live_before) {
+        std::fprintf(stderr, "hip_emul: block %u is stuck at a barrier some of its lanes never reach\n", bid);
+        std::abort();
+      }
+    }
+  }
+}
+
+// collectives over the wave of the calling lane
+template <typename F>
+inline unsigned long long collective(unsigned long long mine, F&& f) {
+  Block& b = blk();
+  const int w = wave_id(), base = w * kWaveSize;
+  b.slot[base + lane_id()] = mine;
+  wave_barrier();
+  const unsigned long long r = f(&b.slot[base], wave_lanes(w));
+  wave_barrier();
+  return r;
+}
+
+}  // namespace hip_emul
+
+#define threadIdx (hip_emul::cur_fiber()->tid)
+#define blockIdx (hip_emul::block_idx())
+#define blockDim (hip_emul::block_dim())
+#define gridDim (hip_emul::grid_dim())
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
+  hip_emul::launch((grid), (block), std::function<void()>([&]() { kernel(__VA_ARGS__); }))
+
+inline void __syncthreads() { hip_emul::block_barrier(); }
+inline void __builtin_amdgcn_wave_barrier() { hip_emul::wave_barrier(); }
+#define __builtin_amdgcn_fence(order, scope) ((void)0)
+
+inline unsigned long long __ballot(int pred) {
+  return hip_emul::collective(pred ? 1ull : 0ull, [](const unsigned long long* s, int n) {
+    unsigned long long m = 0ull;
+    for (int i = 0; i < n; ++i) m |= (s[i] ? 1ull : 0ull) << i;
+    return m;
+  });
+}
+inline unsigned long long hip_emul_shfl_bits(unsigned long long v, int src) {
+  return hip_emul::collective(v, [src](const unsigned long long* s, int n) { return s[(src % hip_emul::kWaveSize + hip_emul::kWaveSize) % hip_emul::kWaveSize < n ? (src % hip_emul::kWaveSize + hip_emul::kWaveSize) % hip_emul::kWaveSize : 0]; });
+}
+inline int __shfl(int v, int src) { return (int)(unsigned)hip_emul_shfl_bits((unsigned)v, src); }
+inline unsigned __shfl(unsigned v, int src) { return (unsigned)hip_emul_shfl_bits(v, src); }
+inline float __shfl(float v, int src) {
+  unsigned u;
+  std::memcpy(&u, &v, 4);
+  u = (unsigned)hip_emul_shfl_bits(u, src);
+  std::memcpy(&v, &u, 4);
+  return v;
+}
+inline int __shfl_xor(int v, int mask) { return __shfl(v, hip_emul::lane_id() ^ mask); }
+inline float __shfl_xor(float v, int mask) { return __shfl(v, hip_emul::lane_id() ^ mask); }
+inline int __builtin_amdgcn_readfirstlane(int v) {
+  return (int)(unsigned)hip_emul::collective((unsigned)v, [](const unsigned long long* s, int n) {
+    for (int i = 1; i < n; ++i)
+      if (s[i] != s[0]) {
+        std::fprintf(stderr, "hip_emul: readfirstlane of a value that is not wave-uniform (lane 0: %llx, lane %d: %llx)\n", s[0], i, s[i]);
+        std::abort();
+      }
+    return s[0];
+  });
+}
+inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+inline int __ffsll(long long v) { return __builtin_ffsll(v); }
+inline unsigned __float_as_uint(float f) { unsigned u; std::memcpy(&u, &f, 4); return u; }
+inline float __uint_as_float(unsigned u) { float f; std::memcpy(&f, &u, 4); return f; }
+inline int __float_as_int(float f) { int u; std::memcpy(&u, &f, 4); return u; }
+inline float __int_as_float(int u) { float f; std::memcpy(&f, &u, 4); return f; }
+
+// atomics: one OS thread, fibers switch only inside the primitives above
+#define __HIP_MEMORY_SCOPE_AGENT 0
+template <typename T> inline T __hip_atomic_load(const T* p, int, int) { return *p; }
+template <typename T> inline void __hip_atomic_store(T* p, T v, int, int) { *p = v; }
+template <typename T> inline T atomicMax(T* p, T v) { const T o = *p; if (v > o) *p = v; return o; }
+template <typename T> inline T atomicMin(T* p, T v) { const T o = *p; if (v < o) *p = v; return o; }
+template <typename T> inline T atomicAdd(T* p, T v) { const T o = *p; *p = o + v; return o; }
+template <typename T> inline T atomicOr(T* p, T v) { const T o = *p; *p = o | v; return o; }
