@@ -84,12 +84,27 @@ constexpr int kElemCapMin = 1024, kElemCapMax = 16384;
 inline int record_capacity(int max_num_pixels) { return std::min(std::max(max_num_pixels, kElemCapMin), kElemCapMax); }
 constexpr int kRowStride = 10;        // rows of a pool task (fusion.cc:250-254)
 constexpr int kWave = 64;
-constexpr int kRecordBuf = 1 << 15;   // recorded pixels of one wave in one pass (>= kElemCapMax: a pass's first turn always fits)
+// The four capacities below only decide WHERE the data of a walk lives and when a pass is cut, never the result.
+// tests/hip_emul builds this file a second time with tiny values (-DFUSION_RECORD_BUF=... etc.) so that the overflow
+// paths (record buffer full, stack spill, spill growth, radix-select medians) run on inputs of a few thousand pixels.
+#ifndef FUSION_RECORD_BUF
+#define FUSION_RECORD_BUF (1 << 15)
+#endif
+#ifndef FUSION_STACK_LDS
+#define FUSION_STACK_LDS 2048
+#endif
+#ifndef FUSION_STACK_SPILL
+#define FUSION_STACK_SPILL (1 << 14)
+#endif
+#ifndef FUSION_MEDIAN_STAGE
+#define FUSION_MEDIAN_STAGE 2048
+#endif
+constexpr int kRecordBuf = FUSION_RECORD_BUF;   // recorded pixels of one wave in one pass (>= the record capacity of a walk: a pass's first turn always fits)
 constexpr int kWindowFirst = 256, kWindowMin = 16, kWindowMax = 8192;  // ticks of a pass: doubled after a pass without a cut, halved after a cut
-constexpr int kStackLds = 2048;       // stack entries of a walk held in LDS (16 B each); the rest spills to HBM
-constexpr int kStackSpill = 1 << 14;  // ... first size of that spill per wave (grown by the host when a walk overflows it)
+constexpr int kStackLds = FUSION_STACK_LDS;     // stack entries of a walk held in LDS (16 B each); the rest spills to HBM
+constexpr int kStackSpill = FUSION_STACK_SPILL; // ... first size of that spill per wave (grown by the host when a walk overflows it)
 constexpr int kCommitWaves = 4;       // waves per pool thread in the commit kernel
-constexpr int kStage = 2048;          // medians: values staged in LDS and ranked by counting; radix select above
+constexpr int kStage = FUSION_MEDIAN_STAGE;     // medians: values staged in LDS and ranked by counting; radix select above
 constexpr unsigned long long kCommitted = ~0ull;
 
 struct DevImage {
@@ -875,6 +890,7 @@ void Run(const fusion_options& opt, int n, const fusion_image* images, const int
   p.images = d_img.p; p.optr = d_optr.p; p.oidx = d_oidx.p; p.word = d_word.p; p.depth = d_depth.p; p.normal = d_normal.p;
   p.rec_cap = (int)std::min<long long>(record_capacity(opt.max_num_pixels), std::max<long long>(total_pix, 1));
   p.elem_cap = std::min(opt.max_num_pixels, p.rec_cap);
+  FU_CHECK(p.rec_cap <= kRecordBuf, "record buffer of a wave smaller than the record capacity of one walk");
   p.max_level = opt.max_traversal_depth - 1;
   p.min_num_pixels = opt.min_num_pixels;
   p.max_depth_error = opt.max_depth_error;

@@ -7,8 +7,9 @@
  * does the workspace reading the reference does through mvs::Workspace. The inputs are host buffers
  * (the reference reads them from the workspace files); the traversal, the medians and the compaction
  * run on the GPU (colmap_amd/csrc/fusion.hip) and there is no CPU path. The pixels of an image take
- * their turns in a fixed pseudo-random order instead of row-major (the reference's order depends on its
- * thread pool unless num_threads = 1); the result is the reference's algorithm run in that order.
+ * their turns in the order of the reference's own thread-pool schedule (stripes of ten rows, fusion.cc:253-269,
+ * its num_threads threads advancing in step: deterministic, where the reference's order depends on thread
+ * timing unless num_threads = 1); the result is the reference's algorithm run sequentially in that order.
  * Differences: max_num_pixels above 16 384 is clamped (the reference's default 10 000 is honoured in full),
  * visibility lists are sorted (the reference copies an unordered set). No limit on the number of images
  * other than HBM (~40 B per depth-map pixel resident; 64-bit pixel offsets).
@@ -24,7 +25,7 @@ extern "C" {
 #endif
 
 /* colmap::mvs::StereoFusionOptions (mvs/fusion.h:46-94); the workspace-side fields (mask_path,
- * num_threads, max_image_size, use_cache, cache_size) stay with the caller. */
+ * max_image_size, use_cache, cache_size) stay with the caller. */
 typedef struct fusion_options {
   int32_t min_num_pixels;      /* 5 */
   int32_t max_num_pixels;      /* 10000 */

@@ -1,7 +1,9 @@
 """ctypes binding of oracle/libfusion_oracle.so (fusion_oracle.cpp) -- TEST INFRASTRUCTURE ONLY.
 
-    fuse(options, images, overlapping_images, mode)   mode 0: the reference's sequential walk
-                                                      mode 1: the order-independent formulation of fusion.hip
+    fuse(options, images, overlapping_images, mode)   mode 0: the reference's sequential walk, pixels row-major
+                                                      mode 1: the same walk, turns in the order of the reference's
+                                                              pool schedule (what fusion.hip computes)
+                                                      mode 2: simulation of fusion.hip's passes (== mode 1)
 
 Takes the same arguments as colmap_amd.fusion.fuse and reuses its marshalling, so both sides see the
 identical structs.

@@ -9,9 +9,10 @@
 // therefore runs ahead of its wave between two primitives -- code that hands data from lane to lane through memory
 // without a barrier in between, which lock-step hardware forgives, fails here. readfirstlane asserts that the value
 // really is uniform. A barrier some lanes never reach is reported instead of hanging.
+//
+// Fibers are switched by a dozen instructions of x86-64 assembly (callee-saved registers + stack pointer): ucontext's
+// swapcontext makes a signal-mask system call per switch, and a cross-lane primitive costs 128 switches.
 #pragma once
-#include <ucontext.h>
-
 #include <cassert>
 #include <cmath>
 #include <cstdint>
@@ -53,8 +54,20 @@ namespace hip_emul {
 constexpr int kWaveSize = 64;
 constexpr size_t kFiberStack = 256 * 1024;
 
+#if !defined(__x86_64__)
+#error "tests/hip_emul switches fibers with x86-64 assembly"
+#endif
+// saves the callee-saved registers of the caller on its stack, stores that stack pointer in *save, and resumes the
+// context whose stack pointer is `load` (System V ABI: rdi = save, rsi = load)
+__attribute__((naked, noinline, used)) static void ctx_switch(void** save, void* load) {
+  __asm__ volatile(
+      "pushq %rbp\n\tpushq %rbx\n\tpushq %r12\n\tpushq %r13\n\tpushq %r14\n\tpushq %r15\n\t"
+      "movq %rsp, (%rdi)\n\tmovq %rsi, %rsp\n\t"
+      "popq %r15\n\tpopq %r14\n\tpopq %r13\n\tpopq %r12\n\tpopq %rbx\n\tpopq %rbp\n\tret\n\t");
+}
+
 struct Fiber {
-  ucontext_t ctx;
+  void* sp = nullptr;
   char* stack = nullptr;
   dim3 tid;
   bool done = true;
@@ -67,7 +80,7 @@ struct Barrier {
 
 struct Block {
   std::vector<Fiber> fibers;
-  ucontext_t sched;
+  void* sched = nullptr;
   int cur = 0, nthreads = 0;
   Barrier block_bar;
   std::vector<Barrier> wave_bar;
@@ -87,7 +100,7 @@ inline int wave_lanes(int w) { const int n = blk().nthreads - w * kWaveSize; ret
 
 inline void yield() {
   Block& b = blk();
-  swapcontext(&b.fibers[b.cur].ctx, &b.sched);
+  ctx_switch(&b.fibers[b.cur].sp, b.sched);
 }
 
 inline void barrier(Barrier& bar, int members) {
@@ -107,7 +120,8 @@ inline void trampoline() {
   Block& b = blk();
   (*b.body)();
   b.fibers[b.cur].done = true;
-  swapcontext(&b.fibers[b.cur].ctx, &b.sched);
+  ctx_switch(&b.fibers[b.cur].sp, b.sched);
+  std::abort();  // a finished fiber is never resumed
 }
 
 inline void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
@@ -131,11 +145,12 @@ inline void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
     for (int i = 0; i < nt; ++i) {
       Fiber& f = b.fibers[i];
       if (!f.stack) f.stack = (char*)std::malloc(kFiberStack);
-      getcontext(&f.ctx);
-      f.ctx.uc_stack.ss_sp = f.stack;
-      f.ctx.uc_stack.ss_size = kFiberStack;
-      f.ctx.uc_link = nullptr;
-      makecontext(&f.ctx, (void (*)())trampoline, 0);
+      // first switch into the fiber "returns" into trampoline with the stack aligned as after a call
+      void** top = (void**)(((uintptr_t)f.stack + kFiberStack) & ~(uintptr_t)15);
+      top[-1] = nullptr;                 // return address of trampoline (it never returns)
+      top[-2] = (void*)&trampoline;
+      for (int r = 3; r <= 8; ++r) top[-r] = nullptr;  // rbp rbx r12 r13 r14 r15
+      f.sp = (void*)(top - 8);
       f.tid = dim3((unsigned)i);
       f.done = false;
     }
@@ -146,7 +161,7 @@ inline void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
       for (int i = 0; i < nt; ++i) {
         if (b.fibers[i].done) continue;
         b.cur = i;
-        swapcontext(&b.sched, &b.fibers[i].ctx);
+        ctx_switch(&b.sched, b.fibers[i].sp);
         if (b.fibers[i].done) --live;
       }
       if (live > 0 && b.progress == before && live == live_before) {
