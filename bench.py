@@ -373,8 +373,9 @@ def geometric_leg(a, views, images, cache, local_rank):
 def fusion_leg(a, views, fmaps, with_cpu=True):
     """Stereo fusion (reference mvs/fusion.cc) of the geometric leg's filtered depth /
     normal maps: 8 neighbouring 2560x1920 images, default StereoFusionOptions, every image overlapping
-    every other. `value` = pixels / the time on the device (rounds, medians, compaction, read-back of the points:
+    every other. `value` = pixels / the time on the device (passes, medians, compaction, read-back of the points:
     fusion_last_timing); the host-to-HBM upload of the maps the ABI takes as host arrays is reported beside it.
+    Turn order = the reference's pool schedule, one thread per ten-row stripe.
     cpu_baseline: the oracle in the reference's sequential order (mode 0: one thread, as mvs/fusion.cc runs with
     num_threads = 1) on the first four of the same images."""
     import ctypes as C
@@ -406,12 +407,14 @@ def fusion_leg(a, views, fmaps, with_cpu=True):
            "seconds": {"device": dev.value, "upload_and_setup": up.value, "end_to_end": dt},
            "end_to_end_Mpix_per_s": mpix / dt,
            "fused_points": int(len(pts.xyz)), "seed_pixels": int(seeds),
-           "rounds_per_image": rounds / max(images_, 1), "walks_per_seed_pixel": walks / max(seeds, 1),
-           "roofline": {"bound": "latency: every round waits for its longest walk (a chain of dependent gathers); "
-                                 "rounds x that latency, not bytes, set the time",
+           "passes_per_image": rounds / max(images_, 1), "walks_per_seed_pixel": walks / max(seeds, 1),
+           "roofline": {"bound": "latency: one sequential wave per pool thread (ten-row stripe) walks its turns in the "
+                                 "reference's order; a wave's absorbed pixels x the round trip of a node's dependent "
+                                 "loads (mask word, depth, normal), not bytes, set the time",
                         "achieved": alg / max(dev.value, 1e-9) / 1e9, "peak": 8000.0, "unit": "GB/s",
                         "frac": alg / max(dev.value, 1e-9) / 1e9 / 8000.0, "algorithmic_bytes": alg,
-                        "ms_per_round": dev.value * 1e3 / max(rounds, 1), "traffic": None}}
+                        "ms_per_pass": dev.value * 1e3 / max(rounds, 1),
+                        "pool_threads": (a.height + 9) // 10, "traffic": None}}
     if with_cpu:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import fusion_oracle
