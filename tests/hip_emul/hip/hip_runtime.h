@@ -1,7 +1,8 @@
 // hip_runtime.h of tests/hip_emul -- TEST INFRASTRUCTURE ONLY: a minimal HIP-on-CPU stand-in, just large enough to run
-// colmap_amd/csrc/fusion.hip (host loop AND wave-cooperative kernels, unmodified source) in a container without a
-// GPU, so that its logic can be compared with oracle/fusion_oracle.cpp by `pytest -m "not gpu"`. Never part of the
-// product: the shipped library is built by hipcc against the real headers (colmap_amd/build.py).
+// colmap_amd/csrc/fusion.hip and the bundle-adjustment sources ba_kernels.hip / ba_schur_explicit.hip (host loops AND
+// kernels, unmodified source) in a container without a GPU, so that their logic can be compared with the checkers
+// in oracle/ by `pytest -m "not gpu"`. Never part of the product: the shipped library is built by hipcc against the
+// real headers (colmap_amd/build.py).
 //
 // Execution model: a launch runs its blocks one after the other; the threads of a block are ucontext fibers of ONE OS
 // thread, switched only inside the cross-lane primitives (ballot / shuffle / readfirstlane / wave barrier /
@@ -13,6 +14,8 @@
 // Fibers are switched by a dozen instructions of x86-64 assembly (callee-saved registers + stack pointer): ucontext's
 // swapcontext makes a signal-mask system call per switch, and a cross-lane primitive costs 128 switches.
 #pragma once
+#include <time.h>
+
 #include <cassert>
 #include <cmath>
 #include <cstdint>
@@ -27,6 +30,7 @@
 #define __host__
 #define __shared__ static
 #define __launch_bounds__(...)
+#define __forceinline__ inline
 
 struct dim3 {
   unsigned x, y, z;
@@ -34,20 +38,54 @@ struct dim3 {
 };
 struct uint2 { unsigned x, y; };
 inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
+struct alignas(16) double2 { double x, y; };
+inline double2 make_double2(double x, double y) { return double2{x, y}; }
+struct alignas(8) float2 { float x, y; };
+inline float2 make_float2(float x, float y) { return float2{x, y}; }
+struct alignas(16) float4 { float x, y, z, w; };
+inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+// HIP declares min / max for device code at global scope
+inline int min(int a, int b) { return a < b ? a : b; }
+inline int max(int a, int b) { return a > b ? a : b; }
 
 typedef int hipError_t;
-typedef void* hipStream_t;
-enum { hipSuccess = 0, hipErrorOutOfMemory = 2 };
+struct hip_emul_stream {};
+typedef hip_emul_stream* hipStream_t;
+struct hip_emul_event { double t = 0.0; };
+typedef hip_emul_event* hipEvent_t;
+enum { hipSuccess = 0, hipErrorOutOfMemory = 2, hipErrorInvalidValue = 1 };
 enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice };
+enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2, hipHostMallocMapped = 2 };
 inline const char* hipGetErrorString(hipError_t) { return "hip_emul error"; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
 inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+inline hipError_t hipSetDevice(int) { return hipSuccess; }
 inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 inline hipError_t hipMalloc(void** p, size_t bytes) { *p = std::malloc(bytes ? bytes : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
-inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { std::memcpy(d, s, n); return hipSuccess; }
+inline hipError_t hipHostMalloc(void** p, size_t bytes, unsigned = 0) { *p = std::calloc(bytes ? bytes : 1, 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+inline hipError_t hipHostGetDevicePointer(void** dev, void* host, unsigned) { *dev = host; return hipSuccess; }
+inline hipError_t hipHostFree(void* p) { std::free(p); return hipSuccess; }
+inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { std::memmove(d, s, n); return hipSuccess; }
+inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { std::memmove(d, s, n); return hipSuccess; }
 inline hipError_t hipMemset(void* d, int v, size_t n) { std::memset(d, v, n); return hipSuccess; }
 inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { std::memset(d, v, n); return hipSuccess; }
+// streams are synchronous (a launch has finished when hipLaunchKernelGGL returns); events carry wall-clock time
+inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = new hip_emul_stream(); return hipSuccess; }
+inline hipError_t hipStreamDestroy(hipStream_t s) { delete s; return hipSuccess; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new hip_emul_event(); return hipSuccess; }
+inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = new hip_emul_event(); return hipSuccess; }
+inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
+inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) {
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  e->t = ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+  return hipSuccess;
+}
+inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(b->t - a->t); return hipSuccess; }
 
 namespace hip_emul {
 
@@ -94,8 +132,8 @@ inline dim3& block_idx() { static dim3 v; return v; }
 inline dim3& block_dim() { static dim3 v; return v; }
 inline dim3& grid_dim() { static dim3 v; return v; }
 inline Fiber* cur_fiber() { return &blk().fibers[blk().cur]; }
-inline int lane_id() { return (int)(cur_fiber()->tid.x % kWaveSize); }
-inline int wave_id() { return (int)(cur_fiber()->tid.x / kWaveSize); }
+inline int lane_id() { return blk().cur % kWaveSize; }
+inline int wave_id() { return blk().cur / kWaveSize; }
 inline int wave_lanes(int w) { const int n = blk().nthreads - w * kWaveSize; return n < kWaveSize ? n : kWaveSize; }
 
 inline void yield() {
@@ -126,7 +164,7 @@ inline void trampoline() {
 
 inline void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
   Block& b = blk();
-  const int nt = (int)block.x;
+  const int nt = (int)(block.x * block.y * block.z);
   if ((int)b.fibers.size() < nt) b.fibers.resize(nt);
   b.nthreads = nt;
   b.body = &body;
@@ -137,9 +175,10 @@ inline void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
   // HIP_EMUL_BLOCK_ORDER=reverse runs the blocks of every launch last to first: the other extreme of the orders in
   // which concurrently resident workgroups can reach a shared word
   static const bool reverse = [] { const char* e = std::getenv("HIP_EMUL_BLOCK_ORDER"); return e && e[0] == 'r'; }();
-  for (unsigned bi = 0; bi < grid.x; ++bi) {
-    const unsigned bid = reverse ? grid.x - 1 - bi : bi;
-    block_idx() = dim3(bid);
+  const unsigned nblocks = grid.x * grid.y * grid.z;
+  for (unsigned bi = 0; bi < nblocks; ++bi) {
+    const unsigned bid = reverse ? nblocks - 1 - bi : bi;
+    block_idx() = dim3(bid % grid.x, (bid / grid.x) % grid.y, bid / (grid.x * grid.y));
     b.block_bar = Barrier();
     for (auto& w : b.wave_bar) w = Barrier();
     for (int i = 0; i < nt; ++i) {
@@ -151,7 +190,7 @@ inline void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
       top[-2] = (void*)&trampoline;
       for (int r = 3; r <= 8; ++r) top[-r] = nullptr;  // rbp rbx r12 r13 r14 r15
       f.sp = (void*)(top - 8);
-      f.tid = dim3((unsigned)i);
+      f.tid = dim3((unsigned)i % block.x, ((unsigned)i / block.x) % block.y, (unsigned)i / (block.x * block.y));
       f.done = false;
     }
     int live = nt;
@@ -207,17 +246,27 @@ inline unsigned long long __ballot(int pred) {
 inline unsigned long long hip_emul_shfl_bits(unsigned long long v, int src) {
   return hip_emul::collective(v, [src](const unsigned long long* s, int n) { return s[(src % hip_emul::kWaveSize + hip_emul::kWaveSize) % hip_emul::kWaveSize < n ? (src % hip_emul::kWaveSize + hip_emul::kWaveSize) % hip_emul::kWaveSize : 0]; });
 }
-inline int __shfl(int v, int src) { return (int)(unsigned)hip_emul_shfl_bits((unsigned)v, src); }
-inline unsigned __shfl(unsigned v, int src) { return (unsigned)hip_emul_shfl_bits(v, src); }
-inline float __shfl(float v, int src) {
+inline int __shfl(int v, int src, int = 64) { return (int)(unsigned)hip_emul_shfl_bits((unsigned)v, src); }
+inline unsigned __shfl(unsigned v, int src, int = 64) { return (unsigned)hip_emul_shfl_bits(v, src); }
+inline float __shfl(float v, int src, int = 64) {
   unsigned u;
   std::memcpy(&u, &v, 4);
   u = (unsigned)hip_emul_shfl_bits(u, src);
   std::memcpy(&v, &u, 4);
   return v;
 }
-inline int __shfl_xor(int v, int mask) { return __shfl(v, hip_emul::lane_id() ^ mask); }
-inline float __shfl_xor(float v, int mask) { return __shfl(v, hip_emul::lane_id() ^ mask); }
+inline double __shfl(double v, int src, int = 64) {
+  unsigned long long u;
+  std::memcpy(&u, &v, 8);
+  u = hip_emul_shfl_bits(u, src);
+  std::memcpy(&v, &u, 8);
+  return v;
+}
+inline int __shfl_xor(int v, int mask, int = 64) { return __shfl(v, hip_emul::lane_id() ^ mask); }
+inline float __shfl_xor(float v, int mask, int = 64) { return __shfl(v, hip_emul::lane_id() ^ mask); }
+inline double __shfl_xor(double v, int mask, int = 64) { return __shfl(v, hip_emul::lane_id() ^ mask); }
+inline int __shfl_down(int v, int d, int = 64) { return __shfl(v, hip_emul::lane_id() + d < 64 ? hip_emul::lane_id() + d : hip_emul::lane_id()); }
+inline double __shfl_down(double v, int d, int = 64) { return __shfl(v, hip_emul::lane_id() + d < 64 ? hip_emul::lane_id() + d : hip_emul::lane_id()); }
 inline int __builtin_amdgcn_readfirstlane(int v) {
   return (int)(unsigned)hip_emul::collective((unsigned)v, [](const unsigned long long* s, int n) {
     for (int i = 1; i < n; ++i)
@@ -236,10 +285,49 @@ inline int __float_as_int(float f) { int u; std::memcpy(&u, &f, 4); return u; }
 inline float __int_as_float(int u) { float f; std::memcpy(&f, &u, 4); return f; }
 
 // atomics: one OS thread, fibers switch only inside the primitives above
+#if defined(__clang__)  // clang knows __hip_atomic_load / _store as builtins on every target
+#ifndef __HIP_MEMORY_SCOPE_AGENT
+#define __HIP_MEMORY_SCOPE_AGENT 4
+#endif
+#else
 #define __HIP_MEMORY_SCOPE_AGENT 0
 template <typename T> inline T __hip_atomic_load(const T* p, int, int) { return *p; }
 template <typename T> inline void __hip_atomic_store(T* p, T v, int, int) { *p = v; }
+#endif
+template <typename T> inline T unsafeAtomicAdd(T* p, T v) { const T o = *p; *p = o + v; return o; }
+inline void __threadfence() {}
+inline void __threadfence_system() {}
+using std::isfinite;  // device code calls the global overloads of the HIP headers
+using std::isnan;
 template <typename T> inline T atomicMax(T* p, T v) { const T o = *p; if (v > o) *p = v; return o; }
 template <typename T> inline T atomicMin(T* p, T v) { const T o = *p; if (v < o) *p = v; return o; }
 template <typename T> inline T atomicAdd(T* p, T v) { const T o = *p; *p = o + v; return o; }
 template <typename T> inline T atomicOr(T* p, T v) { const T o = *p; *p = o | v; return o; }
+inline long long __double2ll_rn(double v) { return (long long)std::nearbyint(v); }  // round to nearest even (default mode)
+inline long long __double_as_longlong(double v) { long long u; std::memcpy(&u, &v, 8); return u; }
+inline double __longlong_as_double(long long u) { double v; std::memcpy(&v, &u, 8); return v; }
+
+// v_mfma_f64_16x16x4_f64: D = A (16 x 4) * B (4 x 16) + C over one wave. Lane l supplies A[l & 15][l >> 4] and
+// B[l >> 4][l & 15]; register r of lane l holds C / D [(l >> 4) + 4 * r][l & 15] (cdna_hip_programming.md section 3:
+// the f64 form does NOT use the f32 row map; the sources state the same mapping where they unpack the tile). The four products of an entry are added in k order
+// with separate multiply and add roundings replaced by fma, like the hardware's fused accumulation.
+typedef double hip_emul_v4f64 __attribute__((ext_vector_type(4)));
+inline hip_emul_v4f64 hip_emul_mfma_f64_16x16x4(double a, double b, hip_emul_v4f64 c) {
+  static double As[16][16][4], Bs[16][4][16];  // per wave of the block; filled between two barriers of the calling wave
+  const int l = hip_emul::lane_id();
+  double (*A)[4] = As[hip_emul::wave_id()];
+  double (*B)[16] = Bs[hip_emul::wave_id()];
+  hip_emul::wave_barrier();          // the previous call's readers are done
+  A[l & 15][l >> 4] = a;
+  B[l >> 4][l & 15] = b;
+  hip_emul::wave_barrier();
+  const int j = l & 15;
+  for (int r = 0; r < 4; ++r) {
+    const int i = (l >> 4) + 4 * r;
+    double acc = c[r];
+    for (int k = 0; k < 4; ++k) acc = std::fma(A[i][k], B[k][j], acc);
+    c[r] = acc;
+  }
+  return c;
+}
+#define __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, cbsz, abid, blgp) hip_emul_mfma_f64_16x16x4((a), (b), (c))
