@@ -3346,9 +3346,10 @@ struct Solver {
       fa.pose_off = V.pose_off; fa.pose_dim = V.pose_dim; fa.cam_off = V.cam_off; fa.cam_dim = V.cam_dim;
       fa.sens_off = V.sens_off;
       fa.fixed_point = opt.jacobi_scaling != 0;  // columns of norm < 1: integer accumulation, bit-reproducible
+      fa.bad = chol_info.p + 1;                  // raised by a term the fixed point cannot hold (NaN, out of bound)
       ba_explicit::form(fa, Sdense.p, st);
-      if (use_priors()) ba_explicit::add_prior_rows(Sdense.p, n, Q.J, Q.po, Q.so, Q.pdim, Q.n, fa.fixed_point, st);
-      ba_explicit::finish(Sdense.p, n, fa.fixed_point, st);
+      if (use_priors()) ba_explicit::add_prior_rows(Sdense.p, n, Q.J, Q.po, Q.so, Q.pdim, Q.n, fa.fixed_point, fa.bad, st);
+      ba_explicit::finish(Sdense.p, n, fa.fixed_point, fa.bad, st);
       if (comm.world > 1) comm.allreduce(Sdense.p, (size_t)n * n, st);  // point sharding: partial sums per rank
       ba_explicit::add_lm_diagonal(Sdense.p, n, Dc.p, st);
       ba_explicit::Workspace ws;
@@ -3541,7 +3542,7 @@ struct Solver {
       Sdense.alloc((size_t)nc * nc);
       if (!dense_by_products) {
         ba_explicit::Workspace ws;
-        chol_linv.alloc(ws.linv_doubles(nc)); chol_tmp.alloc(nc); chol_info.alloc(1);
+        chol_linv.alloc(ws.linv_doubles(nc)); chol_tmp.alloc(nc); chol_info.alloc(2);  // [pivot flag, formation flag]
         const char* e_la = std::getenv("COLMAP_AMD_BA_CHOL_LOOKAHEAD");
         if (!e_la || std::atoi(e_la) != 0) {
           BA_HIP(hipStreamCreateWithFlags(&st_chol, hipStreamNonBlocking));

@@ -28,6 +28,12 @@ struct FormArgs {
   const int *pose_off, *pose_dim, *cam_off, *cam_dim;
   const int* sens_off;          // [n_sensors] tangent offset of a variable sensor_from_rig, or NULL
   bool fixed_point;             // accumulate in 64-bit fixed point (needs Jacobi-scaled columns): bit-reproducible
+  // Fixed-point accumulation only: device flag (or NULL) raised when a term is not representable -- NaN / Inf, or
+  // outside the bound Jacobi scaling guarantees (|term| < 1; the 2^-60 fixed point wraps at +-8). fp64 atomics would
+  // have propagated the NaN; the integer conversion would turn it into a finite but wrong matrix. form() clears it,
+  // add_prior_rows() raises it too, finish() then poisons S[0][0] with NaN: the sum over the ranks of a sharded solve
+  // carries it to every rank, the first pivot fails, and factor_solve() fills x with NaN like a failed LLT.
+  int* bad;
 };
 
 // S (n_c x n_c, row-major, LOWER triangle valid) = B - E C^-1 E^T of this rank's observations. S is cleared
@@ -38,9 +44,9 @@ void add_lm_diagonal(double* S, int n, const double* Dc /* D, not D^2 */, hipStr
 // Adds J^T J of the position priors to the lower triangle of S. J: [3][12][count] tangent columns (pose_dim
 // pose columns, then 6 sensor_from_rig columns when so >= 0); po / so: tangent offsets (-1 constant).
 void add_prior_rows(double* S, int n, const double* J, const int* po, const int* so, const int* pdim, int count,
-                    bool fixed_point, hipStream_t st);
+                    bool fixed_point, int* bad /* FormArgs::bad or NULL */, hipStream_t st);
 // After form (+ add_prior_rows): turns the fixed-point accumulators into doubles (no-op for fp64 accumulation).
-void finish(double* S, int n_c, bool fixed_point, hipStream_t st);
+void finish(double* S, int n_c, bool fixed_point, const int* bad /* FormArgs::bad or NULL */, hipStream_t st);
 
 struct Workspace {
   double* Linv = nullptr;  // [ceil(n / 64)][64][64] inverses of the diagonal blocks of L
@@ -52,7 +58,7 @@ struct Workspace {
   size_t linv_doubles(int n) const { return (size_t)((n + 63) / 64) * 64 * 64; }
 };
 
-// In-place blocked Cholesky S = L L^T (lower, row-major), then x = S^-1 rhs. A non-positive pivot fills x
+// In-place blocked Cholesky S = L L^T (lower, row-major), then x = S^-1 rhs. A non-positive (or NaN) pivot fills x
 // with NaN (the LM loop then rejects the step like a failed LLT). `mfma_ms` (optional, host) receives the
 // time spent inside the matrix-core kernels (panel + trailing update), measured with the two events given.
 void factor_solve(double* S, int n, const double* rhs, double* x, const Workspace& ws, hipStream_t st,

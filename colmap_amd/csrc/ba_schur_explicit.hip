@@ -108,6 +108,7 @@ __device__ __forceinline__ void load_slot(const FormArgs& A, ObsSlot<WMAX>& s, i
 // Without Jacobi scaling (ba_options.jacobi_scaling = 0) there is no such bound: hardware fp64 atomics then
 // (reproducible to rounding only).
 constexpr double kFixedScale = 1152921504606846976.0;  // 2^60
+constexpr double kFixedTermBound = 2.0;  // |term| < 1 under Jacobi scaling; NaN, Inf and anything beyond 2 raise FormArgs::bad
 
 template <int WMAX, bool FIXED>
 __global__ void __launch_bounds__(64) form_kernel(FormArgs A, double* __restrict__ S) {
@@ -169,22 +170,25 @@ __global__ void __launch_bounds__(64) form_kernel(FormArgs A, double* __restrict
         }
         const double b0v = ob.jc[0][k], b1v = ob.jc[1][k];
         const double val = oa.jc[0][i] * (m00 * b0v + m01 * b1v) + oa.jc[1][i] * (m10 * b0v + m11 * b1v);
-        if (FIXED)
+        if (FIXED) {
+          if (!(fabs(val) < kFixedTermBound) && A.bad) *A.bad = 1;  // (every writer stores the same value)
           atomicAdd(reinterpret_cast<unsigned long long*>(S) + (size_t)row * n + col,
                     (unsigned long long)(long long)__double2ll_rn(val * kFixedScale));
-        else
+        } else {
           unsafeAtomicAdd(S + (size_t)row * n + col, val);
+        }
       }
     }
   }
 }
 
 // in place: 64-bit fixed point -> double (lower triangle; the upper one is never read)
-__global__ void fixed_to_double_kernel(double* __restrict__ S, size_t n) {
+__global__ void fixed_to_double_kernel(double* __restrict__ S, size_t n, const int* __restrict__ bad) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n * n) return;
   const long long q = reinterpret_cast<const long long*>(S)[i];
   S[i] = (double)q * (1.0 / kFixedScale);
+  if (i == 0 && bad && *bad != 0) S[0] = NAN;  // a term the fixed point could not hold: the factorisation must fail
 }
 
 __global__ void diag_kernel(int n, const double* __restrict__ Dc, double* __restrict__ S) {
@@ -196,7 +200,7 @@ __global__ void diag_kernel(int n, const double* __restrict__ Dc, double* __rest
 template <bool FIXED>
 __global__ void prior_rows_kernel(double* __restrict__ S, int n, const double* __restrict__ J,
                                   const int* __restrict__ po, const int* __restrict__ so,
-                                  const int* __restrict__ pdim, int count) {
+                                  const int* __restrict__ pdim, int count, int* __restrict__ bad) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= count * 144) return;
   const int kprior = e / 144, i = (e % 144) / 12, k = e % 12;
@@ -209,11 +213,13 @@ __global__ void prior_rows_kernel(double* __restrict__ S, int n, const double* _
   double v = 0.0;
   for (int r = 0; r < 3; ++r)
     v += J[((size_t)r * 12 + i) * count + kprior] * J[((size_t)r * 12 + k) * count + kprior];
-  if (FIXED)  // (several images of a rig frame put several priors on one pose block: same integer accumulation)
+  if (FIXED) {  // (several images of a rig frame put several priors on one pose block: same integer accumulation)
+    if (!(fabs(v) < kFixedTermBound) && bad) *bad = 1;
     atomicAdd(reinterpret_cast<unsigned long long*>(S) + (size_t)row * n + col,
               (unsigned long long)(long long)__double2ll_rn(v * kFixedScale));
-  else
+  } else {
     unsafeAtomicAdd(S + (size_t)row * n + col, v);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -524,6 +530,7 @@ __global__ void nan_fill_kernel(int n, const int* __restrict__ info, double* __r
 void form(const FormArgs& a, double* S, hipStream_t st) {
   const size_t n = (size_t)a.n_c;
   BAX_HIP(hipMemsetAsync(S, 0, n * n * sizeof(double), st));
+  if (a.bad) BAX_HIP(hipMemsetAsync(a.bad, 0, sizeof(int), st));
   if (a.n_points <= 0 || a.n_obs <= 0) return;
   const int wmax = kPoseDim + a.kd + (a.Jsens ? 6 : 0);
 #define BAX_FORM(W)                                                                                              \
@@ -538,10 +545,10 @@ void form(const FormArgs& a, double* S, hipStream_t st) {
 #undef BAX_FORM
 }
 
-void finish(double* S, int n_c, bool fixed_point, hipStream_t st) {
+void finish(double* S, int n_c, bool fixed_point, const int* bad, hipStream_t st) {
   const size_t n = (size_t)n_c;
   if (fixed_point)
-    hipLaunchKernelGGL(fixed_to_double_kernel, dim3((unsigned)((n * n + 255) / 256)), dim3(256), 0, st, S, n);
+    hipLaunchKernelGGL(fixed_to_double_kernel, dim3((unsigned)((n * n + 255) / 256)), dim3(256), 0, st, S, n, bad);
 }
 
 void add_lm_diagonal(double* S, int n, const double* Dc, hipStream_t st) {
@@ -549,11 +556,11 @@ void add_lm_diagonal(double* S, int n, const double* Dc, hipStream_t st) {
 }
 
 void add_prior_rows(double* S, int n, const double* J, const int* po, const int* so, const int* pdim, int count,
-                    bool fixed_point, hipStream_t st) {
+                    bool fixed_point, int* bad, hipStream_t st) {
   if (count <= 0) return;
   const dim3 grid((unsigned)((count * 144 + 255) / 256));
-  if (fixed_point) hipLaunchKernelGGL(prior_rows_kernel<true>, grid, dim3(256), 0, st, S, n, J, po, so, pdim, count);
-  else hipLaunchKernelGGL(prior_rows_kernel<false>, grid, dim3(256), 0, st, S, n, J, po, so, pdim, count);
+  if (fixed_point) hipLaunchKernelGGL(prior_rows_kernel<true>, grid, dim3(256), 0, st, S, n, J, po, so, pdim, count, bad);
+  else hipLaunchKernelGGL(prior_rows_kernel<false>, grid, dim3(256), 0, st, S, n, J, po, so, pdim, count, bad);
 }
 
 void factor_solve(double* S, int n, const double* rhs, double* x, const Workspace& ws, hipStream_t st,

@@ -618,12 +618,174 @@ static inline float tree16(const float p[16]) {
   return ((q[0] + q[7]) + (q[3] + q[4])) + ((q[1] + q[6]) + (q[2] + q[5]));
 }
 
+/* Diagnostic only (scripts/pm_order_decomposition.py): PMO_DEVICE_MIX=<bits> reverts ONE ingredient of the device
+ * order at a time to the reference's form, to attribute the difference between the two orders --
+ *   1  sums accumulated tap by tap in window order (no lane dealing, no even/odd halves, no tree)
+ *   2  warped coordinates by the reference's running sums (:554-568) instead of fma(H0, dx, fma(H1, dy, C2))
+ *   4  one division per tap instead of the shared one of eight taps
+ *   8  the reference's bilinear sample (texel-centre round trip, texels normalised first)
+ * 15 = ncc_cost() with memoised weights, bit for bit. 16 = every intermediate in double (ncc_cost_double). 0 / unset = the
+ * device order. */
+static int g_device_mix = -1;
+static int device_mix(void) {
+  if (g_device_mix < 0) {
+    const char* e = getenv("PMO_DEVICE_MIX");
+    g_device_mix = e && *e ? atoi(e) & 31 : 0;
+  }
+  return g_device_mix;
+}
+PMO_API void pmo_set_device_mix(int bits) { g_device_mix = bits & 31; }
+
+/* 16: the same cost from the same float inputs (homography entries, weights, reference colours, patch sums) with every
+ * intermediate in double -- the yardstick both float orders are measured against */
+static float ncc_cost_double(const pmo_state* st, const ncc_params* np, const float tf[9], int s, int row, int col,
+                             float ref_sum, float ref_sqsum, const float* weights, const float* refc) {
+  const int n1d = (2 * np->radius) / np->step + 1;
+  double sum = 0.0, sq = 0.0, sref = 0.0, wsum = 0.0;
+  for (int wr = 0, pos = 0; wr < n1d; ++wr)
+    for (int wc = 0; wc < n1d; ++wc, ++pos) {
+      const double x = (double)(col - np->radius + wc * np->step), y = (double)(row - np->radius + wr * np->step);
+      const double z = (double)tf[6] * x + (double)tf[7] * y + (double)tf[8];
+      const double px = ((double)tf[0] * x + (double)tf[1] * y + (double)tf[2]) / z;
+      const double py = ((double)tf[3] * x + (double)tf[4] * y + (double)tf[5]) / z;
+      double c = 0.0;
+      if (px == px && py == py && fabs(px) < 1e9 && fabs(py) < 1e9) {
+        const double fx = floor(px), fy = floor(py), wx = px - fx, wy = py - fy;
+        const int ix = (int)fx, iy = (int)fy;
+        const double c00 = tex_src_raw(st, s, ix, iy), c10 = tex_src_raw(st, s, ix + 1, iy);
+        const double c01 = tex_src_raw(st, s, ix, iy + 1), c11 = tex_src_raw(st, s, ix + 1, iy + 1);
+        const double top = c00 + wx * (c10 - c00), bot = c01 + wx * (c11 - c01);
+        c = (top + wy * (bot - top)) / 255.0;
+      }
+      const double bw = weights[pos];
+      sum += bw * c; sq += bw * c * c; sref += bw * c * (double)refc[pos]; wsum += bw;
+    }
+  sum /= wsum; sq /= wsum; sref /= wsum;
+  const double rvar = (double)ref_sqsum - (double)ref_sum * (double)ref_sum, svar = sq - sum * sum;
+  if (rvar < 1e-5 || svar < 1e-5) return 2.0f;
+  const double cost = 1.0 - (sref - (double)ref_sum * sum) / sqrt(rvar * svar);
+  return (float)fmax(0.0, fmin(2.0, cost));
+}
+
+static float ncc_cost_device_mixed(const pmo_state* st, const ncc_params* np, const float tf[9], int s, int row, int col,
+                                   float ref_sum, float ref_sqsum, const float* weights, const float* refc, int mix) {
+  if (mix & 16) return ncc_cost_double(st, np, tf, s, row, col, ref_sum, ref_sqsum, weights, refc);
+  const int n1d = (2 * np->radius) / np->step + 1;
+  const int ntaps = n1d * n1d;
+  const int transpose = st->rot & 1;
+  const float x0f = (float)(col - np->radius), y0f = (float)(row - np->radius);
+  const float c2 = fmaf(tf[0], x0f, fmaf(tf[1], y0f, tf[2]));
+  const float c5 = fmaf(tf[3], x0f, fmaf(tf[4], y0f, tf[5]));
+  const float c8 = fmaf(tf[6], x0f, fmaf(tf[7], y0f, tf[8]));
+  /* per tap (window position pos = wrow * n1d + wcol): warped coordinates and divisor */
+  float csrc[1024], rsrc[1024], zz[1024], inv[1024];
+  if (ntaps > 1024) return 2.0f;
+  if (mix & 2) {  /* the reference's stepping */
+    float tform_step[8];
+    for (int i = 0; i < 8; ++i) tform_step[i] = np->step * tf[i];
+    const int row_start = row - np->radius, col_start = col - np->radius;
+    float col_src = tf[0] * col_start + tf[1] * row_start + tf[2];
+    float row_src = tf[3] * col_start + tf[4] * row_start + tf[5];
+    float z = tf[6] * col_start + tf[7] * row_start + tf[8];
+    float bc = col_src, br = row_src, bz = z;
+    for (int wr = 0, pos = 0; wr < n1d; ++wr) {
+      for (int wc = 0; wc < n1d; ++wc, ++pos) {
+        csrc[pos] = col_src; rsrc[pos] = row_src; zz[pos] = z;
+        col_src += tform_step[0]; row_src += tform_step[3]; z += tform_step[6];
+      }
+      bc += tform_step[1]; br += tform_step[4]; bz += tform_step[7];
+      col_src = bc; row_src = br; z = bz;
+    }
+  } else {
+    for (int wr = 0, pos = 0; wr < n1d; ++wr)
+      for (int wc = 0; wc < n1d; ++wc, ++pos) {
+        const float dx = (float)(wc * np->step), dy = (float)(wr * np->step);
+        csrc[pos] = fmaf(tf[0], dx, fmaf(tf[1], dy, c2));
+        rsrc[pos] = fmaf(tf[3], dx, fmaf(tf[4], dy, c5));
+        zz[pos] = fmaf(tf[6], dx, fmaf(tf[7], dy, c8));
+      }
+  }
+  /* which window position lane j holds as its k-th tap (the device's dealing) */
+  #define PMO_POS_OF(t) (transpose ? ((t) % n1d) * n1d + (t) / n1d : (t))
+  if (mix & 4) {
+    for (int pos = 0; pos < ntaps; ++pos) inv[pos] = 1.0f / zz[pos];
+  } else {
+    const int nchunk = (ntaps + 127) / 128;
+    for (int j = 0; j < 16; ++j)
+      for (int cb = 0; cb < nchunk; ++cb) {
+        float z8[8], pre[8], run = 1.0f;
+        int p8[8];
+        for (int k = 0; k < 8; ++k) {
+          const int t = j + 16 * (8 * cb + k);
+          p8[k] = t < ntaps ? PMO_POS_OF(t) : -1;
+          z8[k] = p8[k] >= 0 ? zz[p8[k]] : 1.0f;
+          pre[k] = run;
+          run = run * z8[k];
+        }
+        const float rinv = 1.0f / run;
+        float suf = 1.0f;
+        for (int k = 7; k >= 0; --k) {
+          if (p8[k] >= 0) inv[p8[k]] = (pre[k] * suf) * rinv;
+          suf = suf * z8[k];
+        }
+      }
+  }
+  float color[1024];
+  for (int pos = 0; pos < ntaps; ++pos)
+    color[pos] = (mix & 8) ? tex_src_bilinear(st, s, fmaf(inv[pos], csrc[pos], 0.5f), fmaf(inv[pos], rsrc[pos], 0.5f))
+                           : tex_src_bilinear_raw(st, s, inv[pos] * csrc[pos], inv[pos] * rsrc[pos]);
+  float src_color_sum, src_color_squared_sum, src_ref_color_sum, bilateral_weight_sum;
+  if (mix & 1) {
+    src_color_sum = src_color_squared_sum = src_ref_color_sum = bilateral_weight_sum = 0.0f;
+    for (int pos = 0; pos < ntaps; ++pos) {
+      const float bw = weights[pos], bws = bw * color[pos];
+      src_color_sum += bws;
+      src_color_squared_sum = fmaf(bws, color[pos], src_color_squared_sum);
+      src_ref_color_sum = fmaf(bws, refc[pos], src_ref_color_sum);
+      bilateral_weight_sum += bw;
+    }
+  } else {
+    float a_sum[16], a_sq[16], a_ref[16], a_w[16];
+    for (int j = 0; j < 16; ++j) {
+      float e_sum[2] = {0.0f, 0.0f}, e_sq[2] = {0.0f, 0.0f}, e_ref[2] = {0.0f, 0.0f};
+      a_w[j] = 0.0f;
+      for (int kk = 0; j + 16 * kk < ntaps; ++kk) {
+        const int pos = PMO_POS_OF(j + 16 * kk);
+        const float bw = weights[pos], bws = bw * color[pos];
+        e_sum[kk & 1] += bws;
+        e_sq[kk & 1] = fmaf(bws, color[pos], e_sq[kk & 1]);
+        e_ref[kk & 1] = fmaf(bws, refc[pos], e_ref[kk & 1]);
+        a_w[j] += bw;
+      }
+      a_sum[j] = e_sum[0] + e_sum[1];
+      a_sq[j] = e_sq[0] + e_sq[1];
+      a_ref[j] = e_ref[0] + e_ref[1];
+    }
+    src_color_sum = tree16(a_sum);
+    src_color_squared_sum = tree16(a_sq);
+    src_ref_color_sum = tree16(a_ref);
+    bilateral_weight_sum = tree16(a_w);
+  }
+  #undef PMO_POS_OF
+  const float inv_bws = 1.0f / bilateral_weight_sum;
+  src_color_sum *= inv_bws;
+  src_color_squared_sum *= inv_bws;
+  src_ref_color_sum *= inv_bws;
+  const float ref_color_var = ref_sqsum - ref_sum * ref_sum;
+  const float src_color_var = src_color_squared_sum - src_color_sum * src_color_sum;
+  if (ref_color_var < 1e-5f || src_color_var < 1e-5f) return 2.0f;
+  const float covar = src_ref_color_sum - ref_sum * src_color_sum;
+  const float var = sqrtf(ref_color_var * src_color_var);
+  return fmaxf(0.0f, fminf(2.0f, 1.0f - covar / var));
+}
+
 static float ncc_cost_device(const pmo_state* st, const ncc_params* np, const float inv_K[4],
                              const float* pose, int s, int row, int col, float depth,
                              const float normal[3], float ref_sum, float ref_sqsum,
                              const float* weights, const float* refc) {
   float tf[9];
   compose_homography(inv_K, pose, row, col, depth, normal, tf);
+  if (device_mix() != 0) return ncc_cost_device_mixed(st, np, tf, s, row, col, ref_sum, ref_sqsum, weights, refc, device_mix());
   const int n1d = (2 * np->radius) / np->step + 1;
   const int ntaps = n1d * n1d;
   /* In the odd sweep directions (the buffers are rotated by 90 or 270 degrees) the device deals the

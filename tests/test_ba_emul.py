@@ -103,3 +103,74 @@ def test_rigs_priors_and_robust_loss():
     G.test_constant_rig_from_world_rotation_matches_oracle()
     G.test_pose_prior_adjuster_on_rigs_matches_oracle()
     G.test_robust_losses_match_oracle(est.LossFunctionType.SOFT_L1, 1.0)
+
+
+# ------------------------------------------------------------------------------------------------
+# the explicit formation called directly (ba_schur_explicit.h is an internal C++ interface: mangled names)
+# ------------------------------------------------------------------------------------------------
+
+class _FormArgs(C.Structure):
+    _fields_ = [("n_obs", C.c_int), ("n_points", C.c_int), ("n_c", C.c_int), ("kd", C.c_int)] + \
+               [(n, C.c_void_p) for n in ("Jpose", "Jcam", "Jsens", "Jpt", "Cinv", "a2c", "pt_ptr", "pt_off", "a_pose", "a_cam",
+                                          "a_sensor", "pose_off", "pose_dim", "cam_off", "cam_dim", "sens_off")] + \
+               [("fixed_point", C.c_bool), ("bad", C.c_void_p)]
+
+
+class _Workspace(C.Structure):
+    _fields_ = [("Linv", C.c_void_p), ("tmp", C.c_void_p), ("info", C.c_void_p), ("st2", C.c_void_p),
+                ("ev_panel", C.c_void_p), ("ev_u2", C.c_void_p)]
+
+
+def _explicit_entry_points():
+    L = _emul_lib()
+    names = subprocess.run(["nm", "-D", "--defined-only", L._name], capture_output=True, text=True, check=True).stdout.split()
+    pick = lambda key: getattr(L, next(n for n in names if key in n))
+    return pick("ba_explicit4formE"), pick("ba_explicit6finishE"), pick("ba_explicit12factor_solveE")
+
+
+@pytest.mark.parametrize("scale,expect_bad", [(0.1, False), (100.0, True)])
+def test_fixed_point_formation_and_its_overflow_flag(scale, expect_bad):
+    """form_kernel<.., FIXED> on two observations of one point in two pose blocks against numpy:
+    S = sum_ab J_a^T (delta_ab I - E_a C^-1 E_b^T) J_b, accumulated in 2^-60 fixed point. With columns scaled as Jacobi
+    scaling leaves them (|term| < 1) the matrix is exact to the quantum; a term the fixed point cannot hold raises
+    FormArgs::bad, finish() poisons S[0][0] and the factorisation answers NaN (the LM loop rejects such a step) --
+    the integer conversion alone would have produced a finite, wrong matrix."""
+    import numpy as np
+    form, finish, factor_solve = _explicit_entry_points()
+    rng = np.random.default_rng(5)
+    N, n_c = 2, 12
+    Jpose = (scale * rng.uniform(-1, 1, (12, N)))          # c-order planes [2 * 6][N]
+    Jpt = (scale * rng.uniform(-1, 1, (6, N)))             # p-order planes [2 * 3][N]
+    E = [np.array([[Jpt[r * 3 + m, a] for m in range(3)] for r in range(2)]) for a in range(N)]
+    Cinv = np.linalg.inv(sum(e.T @ e for e in E) + 0.5 * scale * scale * np.eye(3))
+    ints = lambda v: np.ascontiguousarray(v, np.int32)
+    arrs = dict(Jpose=np.ascontiguousarray(Jpose), Jcam=np.zeros((8, N)), Jpt=np.ascontiguousarray(Jpt),
+                Cinv=np.ascontiguousarray(Cinv.reshape(1, 9)), a2c=ints([0, 1]), pt_ptr=ints([0, 2]), pt_off=ints([0]),
+                a_pose=ints([0, 1]), a_cam=ints([0, 0]), pose_off=ints([0, 6]), pose_dim=ints([6, 6]), cam_off=ints([-1]),
+                cam_dim=ints([0]))
+    bad = np.zeros(1, np.int32)
+    fa = _FormArgs(n_obs=N, n_points=1, n_c=n_c, kd=4, fixed_point=True, bad=bad.ctypes.data)
+    for k, v in arrs.items():
+        setattr(fa, k, v.ctypes.data)
+    S = np.full((n_c, n_c), 7.0)
+    form(C.byref(fa), S.ctypes.data_as(C.c_void_p), None)
+    finish(S.ctypes.data_as(C.c_void_p), C.c_int(n_c), C.c_bool(True), bad.ctypes.data_as(C.c_void_p), None)
+    J = [np.array([[Jpose[r * 6 + d, a] for d in range(6)] for r in range(2)]) for a in range(N)]
+    want = np.zeros((n_c, n_c))
+    for a in range(N):
+        for b in range(N):
+            M = (np.eye(2) if a == b else 0.0) - E[a] @ Cinv @ E[b].T
+            want[6 * a:6 * a + 6, 6 * b:6 * b + 6] += J[a].T @ M @ J[b]
+    assert bool(bad[0]) == expect_bad
+    if not expect_bad:
+        low = np.tril_indices(n_c)
+        assert np.abs(want).max() < 1.0
+        np.testing.assert_allclose(S[low], want[low], rtol=0, atol=144 * 2.0 ** -60 + 1e-17)
+        return
+    assert np.isnan(S[0, 0])
+    x, rhs = np.zeros(n_c), np.ones(n_c)
+    linv, tmp, info = np.zeros(64 * 64), np.zeros(n_c), np.zeros(1, np.int32)
+    ws = _Workspace(Linv=linv.ctypes.data, tmp=tmp.ctypes.data, info=info.ctypes.data)
+    factor_solve(S.ctypes.data_as(C.c_void_p), C.c_int(n_c), rhs.ctypes.data_as(C.c_void_p), x.ctypes.data_as(C.c_void_p),
+                 C.byref(ws), None, None, None, None)
+    assert info[0] == 1 and np.isnan(x).all()
