@@ -18,7 +18,9 @@ SOURCES = ["pm_api.cpp", "pm_kernels.hip", "ba_kernels.hip", "ba_schur_explicit.
 # -ffp-contract=off: fused multiply-adds only where the source says fmaf(); the
 # arithmetic is specified operation by operation (oracle/pm_oracle.c header).
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-               "-Wall", "-Wno-unused-function", "-munsafe-fp-atomics"]
+               "-Wall", "-Wno-unused-function", "-munsafe-fp-atomics",
+               # <pm_gfx950_asm.h>: the inline-assembly helpers of the PatchMatch kernels (tests/hip_emul shadows it)
+               "-I", os.path.join(CSRC, "gfx950")]
 
 
 def _sources():
@@ -34,6 +36,7 @@ def needs_build() -> bool:
         return True
     t = os.path.getmtime(LIB_PATH)
     deps = _sources() + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    deps += [os.path.join(CSRC, "gfx950", f) for f in os.listdir(os.path.join(CSRC, "gfx950"))]
     inc = os.path.join(os.path.dirname(_ROOT), "include")
     deps += [os.path.join(inc, f) for f in os.listdir(inc)]
     return any(os.path.getmtime(d) > t for d in deps)

@@ -32,6 +32,8 @@
 // independently; compile with -ffp-contract=off.
 #include "pm_internal.h"
 
+#include <pm_gfx950_asm.h>  // ubyte0..3, reduce16x3, launder_vgpr, llvm_struct_buffer_load_u32 (gfx950/; see its header)
+
 #include <float.h>
 #include <math.h>
 #include <stdlib.h>
@@ -259,20 +261,7 @@ __device__ __forceinline__ uint32_t tap_gather(const PmParams& p, gbl_u32* fp, f
   return fp[fp_index((unsigned)(int)cx, (unsigned)(int)cy, (unsigned)p.fp_rows1)];
 }
 
-// Byte k of a packed footprint entry as float. Inline asm keeps the four conversions as four
-// full-rate v_cvt_f32_ubyteK: left to itself the compiler rewrites (float)b - (float)a into an
-// integer subtract + v_cvt_f32_i32 pair per difference (8 instead of 5 instructions per tap).
-#define PM_UBYTE(K)                                                              \
-  __device__ __forceinline__ float ubyte##K(uint32_t x) {                        \
-    float f;                                                                     \
-    asm("v_cvt_f32_ubyte" #K " %0, %1" : "=v"(f) : "v"(x));                      \
-    return f;                                                                    \
-  }
-PM_UBYTE(0)
-PM_UBYTE(1)
-PM_UBYTE(2)
-PM_UBYTE(3)
-#undef PM_UBYTE
+// (ubyte0 .. ubyte3 -- byte k of a packed footprint entry as float, v_cvt_f32_ubyteK -- live in <pm_gfx950_asm.h>)
 
 // Cross-lane add inside a 16-lane DPP row. The four steps (row_mirror,
 // row_half_mirror, quad reverse, quad swap) leave in every lane
@@ -1105,9 +1094,7 @@ __device__ __forceinline__ void tap_geom_init(lds_f32* tapg, int tid, int step, 
 // problem's sources) / IS (pm_api.cpp: the images of a problem must lie within IS * 4 GB of each other, which
 // the allocator's pool makes the normal case; otherwise the generic kernel runs).
 // ---------------------------------------------------------------------------
-typedef int v4i __attribute__((ext_vector_type(4)));
-__device__ uint32_t llvm_struct_buffer_load_u32(v4i rsrc, int vindex, int voffset, int soffset, int aux)
-    __asm("llvm.amdgcn.struct.buffer.load.i32");
+// (v4i and llvm_struct_buffer_load_u32: <pm_gfx950_asm.h>)
 
 __device__ __forceinline__ v4i fp_resource(const PmParams& p) {
   const uint64_t b = (uint64_t)p.fp_base;
@@ -1208,27 +1195,8 @@ __device__ __forceinline__ void ncc_front(const PmParams& p, const v4i srd, cons
     }
   }
 }
-// The three 16-lane tree sums of an evaluation in one instruction block: 12 v_add_f32_dpp, each
-// value's next step separated from its previous one by the other two values' steps (the DPP
-// read-after-VALU-write hazard needs two wait states; inline asm is not seen by the compiler's
-// hazard recogniser, hence the leading s_nop). Same tree as reduce16.
-__device__ __forceinline__ void reduce16x3(float& a, float& b, float& c) {
-  asm volatile(
-      "s_nop 1\n\t"
-      "v_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %1, %1, %1 row_mirror row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %2, %2, %2 row_mirror row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %2, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %0, %0, %0 quad_perm:[3,2,1,0] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %1, %1, %1 quad_perm:[3,2,1,0] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %2, %2, %2 quad_perm:[3,2,1,0] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
-      : "+v"(a), "+v"(b), "+v"(c));
-}
+// (reduce16x3 -- the three 16-lane tree sums of an evaluation as one block of 12 v_add_f32_dpp -- lives in
+// <pm_gfx950_asm.h>; same tree as reduce16)
 
 __device__ __forceinline__ void ncc_back(const NccStage& st, const uint32_t tex[8], const TapRegs& R, int j,
                                          float& s_sum, float& s_sq, float& s_ref) {
@@ -1876,7 +1844,7 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
     // it (item -> column / view, LDS addresses) is then recomputed per row instead of being hoisted
     // out of the row loop and held in VGPRs across the NCC loop, which needs them.
     int tid = tid0;
-    asm volatile("" : "+v"(tid));
+    launder_vgpr(tid);
     const bool col_lane = tid < ncols;
     if (p.trace && (row & 127) == 0 && tid == 0)  // debug: pm_enable_progress_trace
       p.trace[(size_t)group * p.trace_stride + (row >> 7)] = __builtin_amdgcn_s_memrealtime();

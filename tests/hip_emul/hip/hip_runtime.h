@@ -28,7 +28,10 @@
 #define __global__
 #define __device__
 #define __host__
-#define __shared__ static
+// LDS: one OS thread runs every lane of every workgroup, so "per workgroup" storage is storage of that thread.
+// thread_local rather than static because it also combines with `extern` (dynamic LDS: `extern __shared__ char smem[]`
+// refers to the array a build script defines, see build_pm.sh); at block scope thread_local implies static.
+#define __shared__ thread_local
 #define __launch_bounds__(...)
 #define __forceinline__ inline
 
@@ -61,7 +64,10 @@ inline hipError_t hipGetLastError() { return hipSuccess; }
 inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
 inline hipError_t hipSetDevice(int) { return hipSuccess; }
 inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
-inline hipError_t hipMalloc(void** p, size_t bytes) { *p = std::malloc(bytes ? bytes : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+inline hipError_t hipMalloc(void** p, size_t bytes) {  // device allocations are page-aligned (the host code relies on 256 B)
+  *p = nullptr;
+  return posix_memalign(p, 4096, bytes ? bytes : 1) == 0 ? hipSuccess : hipErrorOutOfMemory;
+}
 inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
 inline hipError_t hipHostMalloc(void** p, size_t bytes, unsigned = 0) { *p = std::calloc(bytes ? bytes : 1, 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 inline hipError_t hipHostGetDevicePointer(void** dev, void* host, unsigned) { *dev = host; return hipSuccess; }
@@ -122,6 +128,10 @@ struct Block {
   int cur = 0, nthreads = 0;
   Barrier block_bar;
   std::vector<Barrier> wave_bar;
+  std::vector<int> wave_live;            // lanes of a wave / of the block that have not returned from the kernel
+  int block_live = 0;
+  std::vector<Barrier> row_bar;          // DPP rows of 16 lanes: a row operation only involves its own row (the
+  std::vector<int> row_live;             // other rows of the wave may be switched off by divergent control flow)
   std::vector<unsigned long long> slot;  // one per thread: operand of the collective in flight
   unsigned long progress = 0;            // barriers completed (deadlock detection)
   const std::function<void()>* body = nullptr;
@@ -141,28 +151,45 @@ inline void yield() {
   ctx_switch(&b.fibers[b.cur].sp, b.sched);
 }
 
-inline void barrier(Barrier& bar, int members) {
-  const unsigned long g = bar.gen;
-  if (++bar.count == members) {
+// A barrier is complete when every lane that is still running has arrived: lanes that have returned from the kernel
+// no longer take part (as on the hardware, where s_barrier counts the waves that have not ended and an exited lane is
+// simply inactive in cross-lane operations).
+inline void release_if_complete(Barrier& bar, int live) {
+  if (bar.count > 0 && bar.count >= live) {
     bar.count = 0;
     ++bar.gen;
     ++blk().progress;
-  } else {
-    while (bar.gen == g) yield();
   }
 }
-inline void wave_barrier() { barrier(blk().wave_bar[wave_id()], wave_lanes(wave_id())); }
-inline void block_barrier() { barrier(blk().block_bar, blk().nthreads); }
+inline void barrier(Barrier& bar, const int& live) {
+  const unsigned long g = bar.gen;
+  ++bar.count;
+  release_if_complete(bar, live);
+  while (bar.gen == g) yield();
+}
+inline void wave_barrier() { barrier(blk().wave_bar[wave_id()], blk().wave_live[wave_id()]); }
+inline void block_barrier() { barrier(blk().block_bar, blk().block_live); }
+inline void row_barrier() { barrier(blk().row_bar[blk().cur / 16], blk().row_live[blk().cur / 16]); }
 
 inline void trampoline() {
   Block& b = blk();
   (*b.body)();
   b.fibers[b.cur].done = true;
+  b.slot[b.cur] = 0ull;  // an exited lane contributes 0 to later ballots of its wave
+  const int w = b.cur / kWaveSize;
+  --b.wave_live[w];
+  --b.block_live;
+  --b.row_live[b.cur / 16];
+  release_if_complete(b.row_bar[b.cur / 16], b.row_live[b.cur / 16]);
+  release_if_complete(b.wave_bar[w], b.wave_live[w]);
+  release_if_complete(b.block_bar, b.block_live);
   ctx_switch(&b.fibers[b.cur].sp, b.sched);
   std::abort();  // a finished fiber is never resumed
 }
 
-inline void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
+inline void launch(const char* name, dim3 grid, dim3 block, const std::function<void()>& body) {
+  static const bool trace = std::getenv("HIP_EMUL_TRACE") != nullptr;
+  if (trace) std::fprintf(stderr, "hip_emul: %s grid (%u, %u, %u) block %u\n", name, grid.x, grid.y, grid.z, block.x);
   Block& b = blk();
   const int nt = (int)(block.x * block.y * block.z);
   if ((int)b.fibers.size() < nt) b.fibers.resize(nt);
@@ -181,6 +208,13 @@ inline void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
     block_idx() = dim3(bid % grid.x, (bid / grid.x) % grid.y, bid / (grid.x * grid.y));
     b.block_bar = Barrier();
     for (auto& w : b.wave_bar) w = Barrier();
+    b.wave_live.assign(b.wave_bar.size(), 0);
+    for (int i = 0; i < nt; ++i) ++b.wave_live[i / kWaveSize];
+    b.row_bar.assign((nt + 15) / 16, Barrier());
+    b.row_live.assign((nt + 15) / 16, 0);
+    for (int i = 0; i < nt; ++i) ++b.row_live[i / 16];
+    b.block_live = nt;
+    std::fill(b.slot.begin(), b.slot.end(), 0ull);
     for (int i = 0; i < nt; ++i) {
       Fiber& f = b.fibers[i];
       if (!f.stack) f.stack = (char*)std::malloc(kFiberStack);
@@ -204,7 +238,8 @@ inline void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
         if (b.fibers[i].done) --live;
       }
       if (live > 0 && b.progress == before && live == live_before) {
-        std::fprintf(stderr, "hip_emul: block %u is stuck at a barrier some of its lanes never reach\n", bid);
+        std::fprintf(stderr, "hip_emul: %s: block %u is stuck at a barrier some of its lanes never reach (live %d; block barrier %d arrived; wave 0: %d of %d)\n",
+                     name, bid, live, b.block_bar.count, b.wave_bar[0].count, b.wave_live[0]);
         std::abort();
       }
     }
@@ -230,7 +265,7 @@ inline unsigned long long collective(unsigned long long mine, F&& f) {
 #define blockDim (hip_emul::block_dim())
 #define gridDim (hip_emul::grid_dim())
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
-  hip_emul::launch((grid), (block), std::function<void()>([&]() { kernel(__VA_ARGS__); }))
+  hip_emul::launch(#kernel, (grid), (block), std::function<void()>([&]() { kernel(__VA_ARGS__); }))
 
 inline void __syncthreads() { hip_emul::block_barrier(); }
 inline void __builtin_amdgcn_wave_barrier() { hip_emul::wave_barrier(); }
@@ -331,3 +366,55 @@ inline hip_emul_v4f64 hip_emul_mfma_f64_16x16x4(double a, double b, hip_emul_v4f
   return c;
 }
 #define __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, cbsz, abid, blgp) hip_emul_mfma_f64_16x16x4((a), (b), (c))
+
+// ---- what the PatchMatch kernels use beyond the above ----
+inline float __builtin_amdgcn_fractf(float x) { return x - std::floor(x); }  // v_fract_f32 (finite x >= 0 in the kernels)
+inline float __builtin_amdgcn_fmed3f(float a, float b, float c) {            // v_med3_f32: the median; a NaN operand gives min3
+  if (a != a || b != b || c != c) return std::fmin(std::fmin(a, b), c);
+  return std::fmax(std::fmin(a, b), std::fmin(std::fmax(a, b), c));
+}
+inline void __builtin_amdgcn_sched_barrier(int) {}
+inline unsigned long long __builtin_amdgcn_s_memrealtime() { return 0ull; }
+inline unsigned __umul24(unsigned a, unsigned b) { return (a & 0xffffffu) * (b & 0xffffffu); }
+#ifndef __HIP_MEMORY_SCOPE_WORKGROUP
+#define __HIP_MEMORY_SCOPE_WORKGROUP 3
+#endif
+#ifndef __HIP_MEMORY_SCOPE_WAVEFRONT
+#define __HIP_MEMORY_SCOPE_WAVEFRONT 2
+#endif
+#if !defined(__clang__)  // (a clang builtin on every target)
+template <typename T, typename U> inline T __hip_atomic_fetch_add(T* p, U v, int, int) { const T o = *p; *p = (T)(o + (T)v); return o; }
+#endif
+inline int __all(int pred) { return __ballot(pred) == __ballot(1); }
+inline int __any(int pred) { return __ballot(pred) != 0ull; }
+// v_mov_b32_dpp: lane l of a row of 16 reads lane src(l) of the same row (row_mask / bank_mask 0xf, bound_ctrl off:
+// every source lane exists, `old` is never taken). Controls the kernels use: quad_perm (0x00-0xFF), row_mirror (0x140),
+// row_half_mirror (0x141), row_shr:n (0x110+n) / row_shl:n (0x100+n) / row_ror:n (0x120+n).
+inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int, int, bool bound_ctrl) {
+  const int l = hip_emul::lane_id(), row = l & ~15, r = l & 15;
+  int from = -1;
+  if (ctrl >= 0 && ctrl <= 0xFF) from = row + (r & ~3) + ((ctrl >> (2 * (r & 3))) & 3);
+  else if (ctrl == 0x140) from = row + 15 - r;
+  else if (ctrl == 0x141) from = row + (r & 8) + 7 - (r & 7);
+  else if (ctrl > 0x100 && ctrl <= 0x10F) from = r + (ctrl & 15) < 16 ? l + (ctrl & 15) : -1;   // row_shl
+  else if (ctrl > 0x110 && ctrl <= 0x11F) from = r - (ctrl & 15) >= 0 ? l - (ctrl & 15) : -1;   // row_shr
+  else if (ctrl > 0x120 && ctrl <= 0x12F) from = row + ((r - (ctrl & 15)) & 15);               // row_ror
+  else { std::fprintf(stderr, "hip_emul: DPP control 0x%x not modelled\n", ctrl); std::abort(); }
+  // a collective over the ROW only
+  hip_emul::Block& b = hip_emul::blk();
+  b.slot[b.cur] = (unsigned)src;
+  hip_emul::row_barrier();
+  const int base = (b.cur / hip_emul::kWaveSize) * hip_emul::kWaveSize;
+  const unsigned long long got = from >= 0 && base + from < b.nthreads ? b.slot[base + from] : ~0ull;
+  hip_emul::row_barrier();
+  if (got == ~0ull) return bound_ctrl ? 0 : old;
+  return (int)(unsigned)got;
+}
+// host API the PatchMatch host code uses
+inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+inline hipError_t hipMemGetInfo(size_t* free_, size_t* total) { *free_ = (size_t)8 << 30; *total = (size_t)16 << 30; return hipSuccess; }
+inline hipError_t hipMemcpy2DAsync(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height,
+                                   hipMemcpyKind, hipStream_t) {
+  for (size_t r = 0; r < height; ++r) std::memmove((char*)dst + r * dpitch, (const char*)src + r * spitch, width);
+  return hipSuccess;
+}
