@@ -174,3 +174,37 @@ def test_fixed_point_formation_and_its_overflow_flag(scale, expect_bad):
     factor_solve(S.ctypes.data_as(C.c_void_p), C.c_int(n_c), rhs.ctypes.data_as(C.c_void_p), x.ctypes.data_as(C.c_void_p),
                  C.byref(ws), None, None, None, None)
     assert info[0] == 1 and np.isnan(x).all()
+
+
+# ------------------------------------------------------------------------------------------------
+# sharded solves: N > 1 ranks of the HIP solver on the CPU (gloo + the sum-over-ranks callback)
+# ------------------------------------------------------------------------------------------------
+
+def _emul_sharded_worker(*args, **kw):
+    """Child process of the sharded GPU tests (spawned: a fresh interpreter): the same worker, its library swapped."""
+    from colmap_amd import estimators as est_child
+    est_child.lib = _emul_lib
+    import test_ba_gpu as G_child
+    G_child._sharded_worker(*args, **kw)
+
+
+@pytest.fixture
+def sharded_workers_on_the_stand_in(monkeypatch):
+    monkeypatch.setattr(G, "_sharded_worker", _emul_sharded_worker)
+
+
+def test_two_rank_point_sharded_solve(sharded_workers_on_the_stand_in):
+    """ba_solve_sharded, observations sharded by point, two ranks: every rank linearises its own observations, one
+    fused all-reduce per linearisation and one per implicit product; ranks agree bitwise and with the single-rank solve."""
+    G.test_two_rank_sharded_solve_matches_single_gpu(est.SHARD_BY_POINT, False)
+
+
+def test_three_rank_image_sharded_solve_with_shared_intrinsics(sharded_workers_on_the_stand_in):
+    """Image sharding over three ranks with intrinsics blocks shared across ranks: the all-reduced incidence products
+    (ba_inc_* kernels) give the sharded solve the single-rank Schur-Jacobi preconditioner -- the same CG iteration counts."""
+    G.test_three_rank_sharded_solve_with_shared_intrinsics(est.SHARD_BY_IMAGE)
+
+
+def test_two_rank_sharded_exact_tier(sharded_workers_on_the_stand_in):
+    """DENSE_SCHUR sharded by point: the ranks' explicitly formed partial systems are summed (fixed point) and factored."""
+    G.test_two_rank_sharded_exact_tier(est.SHARD_BY_POINT)
