@@ -139,3 +139,11 @@ def test_batched_run_equals_single_runs(pm_oracle):
         got = dict(depth=pm.GetDepthMap(), normal=pm.GetNormalMap(), sel_prob=pm.GetSelProbMap(), cost=pm.GetCostMap(),
                    mask=pm.GetConsistencyMask())
         G._assert_equal(want, got)
+
+
+def test_host_side_cases_of_the_gpu_suite(pm_oracle):
+    """Error behaviour of the C ABI, source images larger than the reference's slot, one source with 25 samples: the GPU
+    tests themselves, library swapped."""
+    G.test_error_behaviour()
+    G.test_sources_larger_than_reference_slot(pm_oracle)
+    G.test_single_source_and_many_samples(pm_oracle)
