@@ -147,3 +147,9 @@ def test_host_side_cases_of_the_gpu_suite(pm_oracle):
     G.test_error_behaviour()
     G.test_sources_larger_than_reference_slot(pm_oracle)
     G.test_single_source_and_many_samples(pm_oracle)
+
+
+def test_committed_golden_fixture():
+    """tests/golden/pm_48x36.npz (committed answer of the device-order oracle: one iteration + filter, every output map)
+    reproduced by the product's kernels on the stand-in -- the GPU test of the same name, library swapped."""
+    G.test_against_committed_golden_fixture()
