@@ -30,6 +30,9 @@
 //             their mask word, depth and normal fetched and tested, one neighbour per lane (those tests
 //             depend only on the walk's first pixel, and a pixel masked when pushed stays masked), the
 //             survivors go on a stack in LDS; popping looks at the words of the top 64 entries at once.
+//             A walk is a chain of dependent round trips to memory, so the chain is kept short (walk_turn):
+//             descriptors and overlap lists from an LDS copy, the mark's return value looked at after the
+//             neighbour loads are in flight, the entry pushed last taken without a second look.
 //   compact   per image, a device scan in (thread, tick) order; the host concatenates per thread.
 //
 // The checker is oracle/fusion_oracle.cpp: mode 1 runs the reference's Fuse() sequentially in the same
@@ -104,6 +107,7 @@ constexpr int kWindowFirst = 256, kWindowMin = 16, kWindowMax = 8192;  // ticks 
 constexpr int kStackLds = FUSION_STACK_LDS;     // stack entries of a walk held in LDS (16 B each); the rest spills to HBM
 constexpr int kStackSpill = FUSION_STACK_SPILL; // ... first size of that spill per wave (grown by the host when a walk overflows it)
 constexpr int kCommitWaves = 4;       // waves per pool thread in the commit kernel
+constexpr int kTableBytes = 20 * 1024;  // LDS copy of the image descriptors + overlap lists of the walk kernel, when they fit
 constexpr int kStage = FUSION_MEDIAN_STAGE;     // medians: values staged in LDS and ranked by counting; radix select above
 constexpr unsigned long long kCommitted = ~0ull;
 
@@ -115,6 +119,8 @@ struct DevImage {
   long long pix_off;     // global offset of the image's first pixel (word / depth / normal arrays)
   int pos;               // step at which the image is fused; -1: not used
 };
+
+static_assert(sizeof(DevImage) % 8 == 0, "descriptors are copied to LDS word by word and hold 8-byte members");
 
 struct PassCtl {         // device-resident control words of the pass loop (read back once per pass)
   unsigned rstar[2];     // lowest rank that must not commit, slot = pass parity (the other slot is reset by the commit kernel)
@@ -155,7 +161,12 @@ struct Params {
   float* vals;
   unsigned long long* spill_goff;
   uint2* spill_pm;
+  float* spill_d;
   int spill_cap;
+  // what the walk kernel copies into LDS at entry (a node's chain of dependent loads then starts in LDS instead of
+  // HBM): 1 = image descriptors + overlap offsets, 2 = also the overlap lists; 0 = neither fits kTableBytes
+  int lds_tables;
+  int n_images, n_overlap;
   // per-seed outputs
   int *valid, *nvis, *vis_off;
   float* pt;            // [num_seeds][6]
@@ -197,27 +208,50 @@ __device__ inline int seed_of(const Params& p, unsigned tau, unsigned t) {
   return (int)(row * (unsigned)p.W + pos % (unsigned)p.W);
 }
 
+// LDS pointers carry address space 3 explicitly: the accesses are ds_* instructions, and the compiler cannot merge the
+// two halves of put / get into one access through a selected generic pointer (it did: a pointer table in scratch).
+#define FUSION_LDS __attribute__((address_space(3)))
 struct WaveStack {  // the walk's stack: entries [0, kStackLds) in LDS, the rest in the wave's spill
-  unsigned long long* lds_goff;
-  uint2* lds_pm;     // x = pixel, y = image | level << 16
+  FUSION_LDS unsigned long long* lds_goff;
+  FUSION_LDS uint2* lds_pm;     // x = pixel, y = image | level << 16
+  FUSION_LDS float* lds_d;      // depth of the pixel (loaded when the entry was tested: a pop needs no second load for it)
   unsigned long long* spill_goff;
   uint2* spill_pm;
-  __device__ void put(int i, unsigned long long goff, uint2 pm) const {
-    if (i < kStackLds) { lds_goff[i] = goff; lds_pm[i] = pm; }
-    else { spill_goff[i - kStackLds] = goff; spill_pm[i - kStackLds] = pm; }
+  float* spill_d;
+  __device__ void put(int i, unsigned long long goff, uint2 pm, float d) const {
+    if (i < kStackLds) { lds_goff[i] = goff; lds_pm[i].x = pm.x; lds_pm[i].y = pm.y; lds_d[i] = d; }
+    else { spill_goff[i - kStackLds] = goff; spill_pm[i - kStackLds] = pm; spill_d[i - kStackLds] = d; }
   }
-  __device__ void get(int i, unsigned long long* goff, uint2* pm) const {
-    if (i < kStackLds) { *goff = lds_goff[i]; *pm = lds_pm[i]; }
-    else { *goff = spill_goff[i - kStackLds]; *pm = spill_pm[i - kStackLds]; }
+  __device__ void get(int i, unsigned long long* goff, uint2* pm, float* d) const {
+    if (i < kStackLds) { *goff = lds_goff[i]; pm->x = lds_pm[i].x; pm->y = lds_pm[i].y; *d = lds_d[i]; }
+    else { *goff = spill_goff[i - kStackLds]; *pm = spill_pm[i - kStackLds]; *d = spill_d[i - kStackLds]; }
   }
+};
+
+// Image descriptors and overlap lists as the walk reads them: the arrays in HBM, or the wave's copy in LDS
+// (generic pointers: the same loads serve both).
+struct WalkTables {
+  const DevImage* images;
+  const int* optr;
+  const int* oidx;
 };
 
 // One turn of pool thread t: StereoFusion::Fuse's traversal (fusion.cc:401-489) from `seed` (free for t, positive
 // depth), executed by the 64 lanes of the wave together (every variable that steers the control flow is wave-uniform).
 // rec_n: pixels the wave has recorded in this pass; n_walks: its walks. false: record buffer or stack spill full --
 // the turn is abandoned and cuts the pass at its own rank.
-__device__ bool walk_turn(const Params& p, const WaveStack& st, int lane, unsigned t, unsigned tau, unsigned rank, int seed,
-                          float seed_depth, int* rec_n, int* n_walks, unsigned long long* stat_nodes) {
+//
+// The time of a walk is a chain of dependent memory round trips per absorbed pixel, so the chain is kept short:
+//  * the mark (atomicMax) is issued first and its return value looked at LAST, after the neighbour loads of the
+//    same pixel are in flight (what it decides -- the rank cut -- does not steer the walk);
+//  * descriptors and overlap lists come from LDS when they fit (WalkTables): the chain to a neighbour's mask word,
+//    depth and normal is then one trip to HBM instead of three;
+//  * the topmost entry pushed by an expansion is taken without looking at its mask word again: it was free when it
+//    was tested a moment ago and the only mark made since is that of the pixel being expanded, which is another pixel;
+//    its depth travels in the stack entry. Older entries are looked at again when they surface (the walk may have
+//    absorbed them by another path).
+__device__ __forceinline__ bool walk_turn(const Params& p, const WalkTables& tb, const WaveStack& st, int lane, unsigned t, unsigned tau,
+                          unsigned rank, int seed, float seed_depth, int* rec_n, int* n_walks, unsigned long long* stat_nodes) {
   const unsigned long long key = ((unsigned long long)p.epoch << 32) | (unsigned long long)(0xFFFFFFFFu - rank);
   unsigned* const rec_pix = p.rec_pix + (size_t)t * kRecordBuf;
   unsigned* const rec_meta = p.rec_meta + (size_t)t * kRecordBuf;
@@ -225,12 +259,12 @@ __device__ bool walk_turn(const Params& p, const WaveStack& st, int lane, unsign
   int n = first, recorded = 0, nin = 0, sp = 0;
   float ref[3] = {0.f, 0.f, 0.f}, refn[3] = {0.f, 0.f, 0.f};
   int img = p.image, pix = seed, level = 0;
-  unsigned long long goff = (unsigned long long)p.images[p.image].pix_off + (unsigned long long)seed;
+  unsigned long long goff = (unsigned long long)tb.images[p.image].pix_off + (unsigned long long)seed;
   float depth = seed_depth;
   bool ok = true;
   for (;;) {
     // ---- absorb (img, pix, level): fusion.cc:437-472 ----
-    const DevImage& im = p.images[img];
+    const DevImage& im = tb.images[img];
     const int row = pix / im.dw, col = pix - row * im.dw;
     const float hx = (float)col * depth, hy = (float)row * depth;
     float xyz[3];
@@ -244,15 +278,10 @@ __device__ bool walk_turn(const Params& p, const WaveStack& st, int lane, unsign
     if (lane == 0) {
       rec_pix[n] = (unsigned)pix;
       rec_meta[n] = (unsigned)img | (in_box ? 0x80000000u : 0u);
-      old = atomicMax(p.word + goff, key);
+      old = atomicMax(p.word + goff, key);  // (looked at below, after the neighbour loads have been issued)
     }
-    old = shfl64(old, 0);
     ++n; ++recorded;
-    if ((unsigned)(old >> 32) == p.epoch) {  // a mark of another turn of this pass: the later turn must not commit
-      const unsigned other = 0xFFFFFFFFu - (unsigned)old;
-      if (other != rank && lane == 0) atomicMin(&p.ctl->rstar[p.slot], other > rank ? other : rank);
-    }
-    bool expand = false;
+    bool expand = false, capped = false;
     if (in_box) {
       ++nin;
       if (level == 0) {
@@ -261,21 +290,23 @@ __device__ bool walk_turn(const Params& p, const WaveStack& st, int lane, unsign
         for (int r = 0; r < 3; ++r) refn[r] = im.inv_R[3 * r] * nl0 + im.inv_R[3 * r + 1] * nl1 + im.inv_R[3 * r + 2] * nl2;
         ref[0] = xyz[0]; ref[1] = xyz[1]; ref[2] = xyz[2];
       }
-      if (nin >= p.elem_cap) break;  // max_num_pixels reached (fusion.cc:470-472)
-      expand = level < p.max_level;
+      capped = nin >= p.elem_cap;  // max_num_pixels reached (fusion.cc:470-472): the walk ends after the mark is settled
+      expand = !capped && level < p.max_level;
     }
+    int pushed = 0;  // entries this expansion put on the stack
     if (expand) {
       // ---- neighbours (fusion.cc:474-488), one per lane; pushed in list order if they pass the tests of
       // fusion.cc:407-447 that do not depend on the masks, and are not masked now ----
-      const int o0 = p.optr[img], nov = p.optr[img + 1] - o0;
+      const int o0 = tb.optr[img], nov = tb.optr[img + 1] - o0;
       for (int base = 0; base < nov; base += kWave) {
         const int k = base + lane;
         bool pass = false;
         unsigned long long qoff = 0ull;
         int q = 0, next = 0;
+        float d = 0.0f;
         if (k < nov) {
-          next = p.oidx[o0 + k];
-          const DevImage& nx = p.images[next];
+          next = tb.oidx[o0 + k];
+          const DevImage& nx = tb.images[next];
           if (nx.pos >= p.step) {  // used, and not fused in an earlier step
             float np[3];
             for (int r = 0; r < 3; ++r) np[r] = nx.P[4 * r] * xyz[0] + nx.P[4 * r + 1] * xyz[1] + nx.P[4 * r + 2] * xyz[2] + nx.P[4 * r + 3];
@@ -285,10 +316,12 @@ __device__ bool walk_turn(const Params& p, const WaveStack& st, int lane, unsign
               q = qrow * nx.dw + qcol;
               qoff = (unsigned long long)nx.pix_off + (unsigned long long)q;
               const unsigned long long w = ld_word(p.word + qoff);
-              const float d = p.depth[qoff];
+              d = p.depth[qoff];
               const float* nl = p.normal + 3 * qoff;
               const float nl0 = nl[0], nl1 = nl[1], nl2 = nl[2];
-              if (!masked_for(w, p.epoch, (unsigned)p.T, t) && d > 0.0f) {
+              // (qoff != goff: the pixel being expanded -- an image listed as its own neighbour -- is masked by the
+              // mark issued a moment ago, which this load is not ordered behind)
+              if (qoff != goff && !masked_for(w, p.epoch, (unsigned)p.T, t) && d > 0.0f) {
                 float proj[3];
                 for (int r = 0; r < 3; ++r)
                   proj[r] = nx.P[4 * r] * ref[0] + nx.P[4 * r + 1] * ref[1] + nx.P[4 * r + 2] * ref[2] + nx.P[4 * r + 3] * 1.0f;
@@ -307,27 +340,43 @@ __device__ bool walk_turn(const Params& p, const WaveStack& st, int lane, unsign
         const unsigned long long m = __ballot(pass);
         const int cnt = __popcll(m);
         if (sp + cnt > kStackLds + p.spill_cap) { ok = false; break; }
-        if (pass) st.put(sp + __popcll(m & ((1ull << lane) - 1ull)), qoff, make_uint2((unsigned)q, (unsigned)next | ((unsigned)(level + 1) << 16)));
+        if (pass) st.put(sp + __popcll(m & ((1ull << lane) - 1ull)), qoff, make_uint2((unsigned)q, (unsigned)next | ((unsigned)(level + 1) << 16)), d);
         sp += cnt;
+        pushed += cnt;
       }
-      if (!ok) {
-        if (lane == 0) atomicOr(&p.ctl->flags, 1u);
-        break;
-      }
-      __syncthreads();  // the pushes (LDS / spill) before the pops of other lanes
     }
-    // ---- next pixel: the topmost stack entry that is not masked (fusion.cc:408-414); 64 entries per look ----
+    // ---- the mark's old value: a mark of another turn of this pass means the later of the two turns must not commit ----
+    old = shfl64(old, 0);
+    if ((unsigned)(old >> 32) == p.epoch) {
+      const unsigned other = 0xFFFFFFFFu - (unsigned)old;
+      if (other != rank && lane == 0) atomicMin(&p.ctl->rstar[p.slot], other > rank ? other : rank);
+    }
+    if (!ok) {
+      if (lane == 0) atomicOr(&p.ctl->flags, 1u);
+      break;
+    }
+    if (capped) break;
+    if (expand) __syncthreads();  // the pushes (LDS / spill) before the pops of other lanes
+    // ---- next pixel: the topmost stack entry that is not masked (fusion.cc:408-414) ----
     bool found = false;
-    while (sp > 0) {
+    if (pushed > 0) {  // the entry this expansion pushed last: known to be free, its depth is in the entry
+      uint2 epm;
+      st.get(sp - 1, &goff, &epm, &depth);
+      sp -= 1;
+      pix = (int)epm.x;
+      img = (int)(epm.y & 0xFFFFu);
+      level = (int)(epm.y >> 16);
+      found = true;
+    }
+    while (!found && sp > 0) {  // older entries: 64 per look, their mask words read again
       const int idx = sp - 1 - lane;
       unsigned long long eoff = 0ull;
       uint2 epm = make_uint2(0u, 0u);
       bool free_ = false;
       float ed = 0.0f;
       if (idx >= 0) {
-        st.get(idx, &eoff, &epm);
+        st.get(idx, &eoff, &epm, &ed);
         const unsigned long long w = ld_word(p.word + eoff);
-        ed = p.depth[eoff];
         free_ = !masked_for(w, p.epoch, (unsigned)p.T, t);
       }
       const unsigned long long m = __ballot(free_);
@@ -344,7 +393,6 @@ __device__ bool walk_turn(const Params& p, const WaveStack& st, int lane, unsign
       img = (int)(meta & 0xFFFFu);
       level = (int)(meta >> 16);
       found = true;
-      break;
     }
     __syncthreads();  // the reads of this look before the pushes of the next expansion
     if (!found) break;
@@ -370,10 +418,27 @@ __device__ bool walk_turn(const Params& p, const WaveStack& st, int lane, unsign
 __global__ void __launch_bounds__(kWave) fusion_walk_kernel(Params p) {
   __shared__ unsigned long long s_goff[kStackLds];
   __shared__ uint2 s_pm[kStackLds];
+  __shared__ float s_d[kStackLds];
+  __shared__ __attribute__((aligned(16))) int s_tab[kTableBytes / 4];
   const unsigned t = blockIdx.x;
   const int lane = threadIdx.x;
-  WaveStack st{s_goff, s_pm, p.spill_goff + (size_t)t * p.spill_cap, p.spill_pm + (size_t)t * p.spill_cap};
-  const unsigned long long img_off = (unsigned long long)p.images[p.image].pix_off;
+  WalkTables tb{p.images, p.optr, p.oidx};
+  if (p.lds_tables >= 1) {  // descriptors + overlap offsets (+ the lists) into LDS: word-wise copies
+    const int wi = (int)(sizeof(DevImage) / 4) * p.n_images, wo = p.n_images + 1;
+    const int* src = reinterpret_cast<const int*>(p.images);
+    for (int i = lane; i < wi; i += kWave) s_tab[i] = src[i];
+    for (int i = lane; i < wo; i += kWave) s_tab[wi + i] = p.optr[i];
+    tb.images = reinterpret_cast<const DevImage*>(s_tab);
+    tb.optr = s_tab + wi;
+    if (p.lds_tables >= 2) {
+      for (int i = lane; i < p.n_overlap; i += kWave) s_tab[wi + wo + i] = p.oidx[i];
+      tb.oidx = s_tab + wi + wo;
+    }
+    __syncthreads();
+  }
+  WaveStack st{(FUSION_LDS unsigned long long*)s_goff, (FUSION_LDS uint2*)s_pm, (FUSION_LDS float*)s_d,
+               p.spill_goff + (size_t)t * p.spill_cap, p.spill_pm + (size_t)t * p.spill_cap, p.spill_d + (size_t)t * p.spill_cap};
+  const unsigned long long img_off = (unsigned long long)tb.images[p.image].pix_off;
   unsigned tau = p.tau0 + (t < p.rmod ? 1u : 0u);
   int rec_n = 0, n_walks = 0;
   unsigned long long walks = 0ull, nodes = 0ull;
@@ -406,7 +471,7 @@ __global__ void __launch_bounds__(kWave) fusion_walk_kernel(Params p) {
     const int seed = uniform(__shfl(s, j));
     const float sd = uniform(__shfl(d, j));
     ++walks;
-    if (!walk_turn(p, st, lane, t, tau, rank, seed, sd, &rec_n, &n_walks, &nodes)) break;
+    if (!walk_turn(p, tb, st, lane, t, tau, rank, seed, sd, &rec_n, &n_walks, &nodes)) break;
     tau += 1u;
   }
   if (lane == 0) {
@@ -907,16 +972,25 @@ void Run(const fusion_options& opt, int n, const fusion_image* images, const int
   DevBuf<float> vals;
   DevBuf<unsigned long long> spill_goff;
   DevBuf<uint2> spill_pm;
+  DevBuf<float> spill_d;
   DevBuf<PassCtl> d_ctl;
   rec_pix.alloc(TT * kRecordBuf); rec_meta.alloc(TT * kRecordBuf); rec_box.alloc(TT * kRecordBuf);
   w_tau.alloc(TT * window_max); w_first.alloc(TT * window_max); w_count.alloc(TT * window_max);
   n_walks.alloc(TT); vals.alloc(TT * 9 * kRecordBuf);
   int spill_cap = kStackSpill;
-  spill_goff.alloc(TT * spill_cap); spill_pm.alloc(TT * spill_cap);
+  spill_goff.alloc(TT * spill_cap); spill_pm.alloc(TT * spill_cap); spill_d.alloc(TT * spill_cap);
   d_ctl.alloc(1);
   p.rec_pix = rec_pix.p; p.rec_meta = rec_meta.p; p.rec_box = rec_box.p;
   p.w_tau = w_tau.p; p.w_first = w_first.p; p.w_count = w_count.p; p.n_walks = n_walks.p; p.window_cap = window_max;
-  p.vals = vals.p; p.spill_goff = spill_goff.p; p.spill_pm = spill_pm.p; p.spill_cap = spill_cap; p.ctl = d_ctl.p;
+  p.vals = vals.p; p.spill_goff = spill_goff.p; p.spill_pm = spill_pm.p; p.spill_d = spill_d.p; p.spill_cap = spill_cap; p.ctl = d_ctl.p;
+  // LDS copies of the walk kernel: descriptors + overlap offsets, and the overlap lists, when they fit
+  p.n_images = n;
+  p.n_overlap = optr[n];
+  {
+    const size_t desc = (size_t)n * sizeof(DevImage) + ((size_t)n + 1) * sizeof(int);
+    p.lds_tables = desc > (size_t)kTableBytes ? 0 : (desc + (size_t)optr[n] * sizeof(int) > (size_t)kTableBytes ? 1 : 2);
+    if (const char* e = getenv("COLMAP_AMD_FUSION_LDS_TABLES")) p.lds_tables = std::min(p.lds_tables, std::max(0, atoi(e)));
+  }
   // a stack can never hold more than (pixels a walk records) x (longest overlap list) entries
   const long long spill_bound = (long long)p.rec_cap * max_overlap + kWave;
 
@@ -985,8 +1059,8 @@ void Run(const fusion_options& opt, int n, const fusion_image* images, const int
       if (h_ctl.flags & 1u) {  // a walk overflowed the stack spill: it cut the pass at its own rank; give it room
         FU_CHECK((long long)spill_cap < spill_bound, "stack overflow beyond its bound");
         spill_cap = (int)std::min<long long>(4ll * spill_cap, spill_bound);
-        spill_goff.alloc(TT * spill_cap); spill_pm.alloc(TT * spill_cap);
-        p.spill_goff = spill_goff.p; p.spill_pm = spill_pm.p; p.spill_cap = spill_cap;
+        spill_goff.alloc(TT * spill_cap); spill_pm.alloc(TT * spill_cap); spill_d.alloc(TT * spill_cap);
+        p.spill_goff = spill_goff.p; p.spill_pm = spill_pm.p; p.spill_d = spill_d.p; p.spill_cap = spill_cap;
         FU_HIP(hipMemsetAsync(&d_ctl.p->flags, 0, sizeof(unsigned), 0));
       } else {
         FU_CHECK(rstar > r_next, "pass made no progress");

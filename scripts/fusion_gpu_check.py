@@ -104,7 +104,10 @@ def run():
         except Exception as e:  # keep going: later stages still tell something
             say(f"{name}: FAILED {type(e).__name__}: {e}")
     loose = dict(min_num_pixels=2, max_reproj_error=3.0, max_depth_error=0.05, max_normal_error=30.0)
-    for (n, w, h, sigma) in [(4, 640, 480, 0.002), (4, 1280, 960, 0.002), (8, 1280, 960, 0.002), (4, 2560, 1920, 0.002)]:
+    sizes = [(4, 640, 480, 0.002), (4, 1280, 960, 0.002), (8, 1280, 960, 0.002), (4, 2560, 1920, 0.002)]
+    if "--quick" in sys.argv:  # a call with seconds of budget: the two sizes whose checker answers within a second first
+        sizes = [(4, 640, 480, 0.002), (4, 1280, 960, 0.002), (4, 2560, 1920, 0.002)]
+    for (n, w, h, sigma) in sizes:
         try:
             ims = plane_scene(n, w, h, sigma)
             one(f"plane_{n}x{w}x{h}_sigma{sigma}", fusion.StereoFusionOptions(**loose), ims,
@@ -115,4 +118,4 @@ def run():
 
 
 if __name__ == "__main__":
-    make() if sys.argv[1:] == ["make"] else run()
+    make() if sys.argv[1:2] == ["make"] else run()

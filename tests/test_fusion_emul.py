@@ -158,3 +158,48 @@ def test_emulated_kernel_pool_sizes(emul, num_threads):
     assert len(want.xyz) > 2000 and _same(got, want)
     if num_threads == 1:
         assert _same(got, fusion_oracle.fuse(opt, images, overlap, mode=0))
+
+
+@pytest.mark.parametrize("tables", ["0", "1"])
+def test_emulated_kernel_table_tiers(tables):
+    """The walk kernel reads image descriptors and overlap lists from an LDS copy when they fit (tier 2, what every
+    other test here runs), descriptors only (1), or from HBM (0): COLMAP_AMD_FUSION_LDS_TABLES caps the tier. Same
+    points. (A separate process per tier: the variable is read by the library.)"""
+    code = ("import sys; sys.path[:0] = [%r, %r, %r]\n"
+            "import test_fusion_emul as T, fusion_oracle\n"
+            "from colmap_amd import fusion\n"
+            "E = T._EmulEntryPoints('libfusion_emul.so')\n"
+            "for name in ('defaults_5x64x48', 'sparse_overlap', 'mask0'):\n"
+            "    opt, im, ov = T._case(name)\n"
+            "    assert T._same(fusion.fuse(opt, im, ov, entry_points=E), fusion_oracle.fuse(opt, im, ov, mode=1)), name\n"
+            "print('tiers ok')\n") % (os.path.dirname(_HERE), os.path.join(os.path.dirname(_HERE), "..", "oracle"),
+                                       os.path.join(os.path.dirname(_HERE), ".."))
+    env = dict(os.environ, COLMAP_AMD_FUSION_LDS_TABLES=tables)
+    out = subprocess.run([os.sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "tiers ok" in out.stdout, out.stderr[-2000:]
+
+
+def test_emulated_kernel_more_images_than_the_lds_table_holds(emul):
+    """130 images: the descriptors alone exceed the table (tier 0 chosen by the host), every image overlapping its
+    four ring neighbours."""
+    n = 130
+    views = scene(n, 12, 10)
+    images = _images(views)
+    overlap = [[(i + d) % n for d in (-2, -1, 1, 2)] for i in range(n)]
+    opt = fusion.StereoFusionOptions(min_num_pixels=2, max_reproj_error=3.0, max_depth_error=0.05, max_normal_error=30.0)
+    want = fusion_oracle.fuse(opt, images, overlap, mode=1)
+    got = fusion.fuse(opt, images, overlap, entry_points=emul)
+    assert len(want.xyz) > 100 and _same(got, want)
+
+
+def test_emulated_kernel_image_listed_as_its_own_neighbour(emul):
+    """Degenerate overlap lists (an image among its own neighbours, a neighbour listed twice): the pixel being expanded
+    is masked by its own mark -- which the kernel issues without waiting for it -- and is not walked into again."""
+    views = scene(4, 32, 24)
+    images = _images(views)
+    overlap = [[i] + [j for j in range(4) if j != i] + [(i + 1) % 4] for i in range(4)]
+    opt = fusion.StereoFusionOptions(min_num_pixels=2)
+    want = fusion_oracle.fuse(opt, images, overlap, mode=1)
+    got = fusion.fuse(opt, images, overlap, entry_points=emul)
+    assert len(want.xyz) > 100 and _same(got, want)
+    assert _same(want, fusion_oracle.fuse(opt, images, [[j for j in range(4) if j != i] for i in range(4)], mode=1))
