@@ -208,3 +208,32 @@ def test_three_rank_image_sharded_solve_with_shared_intrinsics(sharded_workers_o
 def test_two_rank_sharded_exact_tier(sharded_workers_on_the_stand_in):
     """DENSE_SCHUR sharded by point: the ranks' explicitly formed partial systems are summed (fixed point) and factored."""
     G.test_two_rank_sharded_exact_tier(est.SHARD_BY_POINT)
+
+
+# ------------------------------------------------------------------------------------------------
+# COLMAP_AMD_TEST_SLOW=1: the remaining comparisons of the GPU suite that take 15-100 s each on the stand-in
+# ------------------------------------------------------------------------------------------------
+
+_slow = pytest.mark.skipif(os.environ.get("COLMAP_AMD_TEST_SLOW", "0") == "0", reason="COLMAP_AMD_TEST_SLOW=1 runs the long stand-in cases")
+
+
+@_slow
+def test_slow_kernel_variants():
+    G.test_split_linearisation_is_bit_identical(False)
+    G.test_split_linearisation_is_bit_identical("three")
+    G.test_fused_pcg_kernel_matches_separate_kernels()
+    G.test_run_to_run_determinism()
+    G.test_tracks_longer_than_a_tile()
+
+
+@_slow
+def test_slow_models_priors_and_operator_precision():
+    G.test_variable_sensor_from_rig_matches_oracle()
+    G.test_radial_model_matches_oracle()
+    G.test_opencv_model_matches_oracle()
+    G.test_position_priors_match_oracle(est.LossFunctionType.TRIVIAL)
+    G.test_position_priors_match_oracle(est.LossFunctionType.CAUCHY)
+    G.test_robust_losses_match_oracle(est.LossFunctionType.CAUCHY, 1.0)
+    G.test_robust_losses_match_oracle(est.LossFunctionType.HUBER, 2.0)
+    G.test_fp32_operator_reaches_the_fp64_solution(40, 2000, 8, True)
+    G.test_solution_matches_oracle(40, 2000, 8, True)
