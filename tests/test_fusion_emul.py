@@ -203,3 +203,48 @@ def test_emulated_kernel_image_listed_as_its_own_neighbour(emul):
     got = fusion.fuse(opt, images, overlap, entry_points=emul)
     assert len(want.xyz) > 100 and _same(got, want)
     assert _same(want, fusion_oracle.fuse(opt, images, [[j for j in range(4) if j != i] for i in range(4)], mode=1))
+
+
+def _random_configuration(rng):
+    n = int(rng.integers(2, 8))
+    w, h = [(24, 18), (32, 24), (20, 50), (48, 36), (16, 64)][int(rng.integers(5))]
+    sigma = float(rng.choice([0.0, 0.003, 0.01, 0.03]))
+    images = _images(scene(n, w, h), with_rgb=bool(rng.integers(2)))
+    for im in images:
+        if sigma > 0:
+            im.depth_map = (im.depth_map * (1 + sigma * rng.standard_normal(im.depth_map.shape))).astype(np.float32)
+        if rng.random() < 0.3:
+            im.depth_map = im.depth_map.copy()
+            im.depth_map[rng.random(im.depth_map.shape) < 0.1] = 0
+        if rng.random() < 0.2:
+            im.mask = (rng.random(im.depth_map.shape) < 0.15).astype(np.uint8)
+    style = int(rng.integers(4))
+    if style == 0:
+        overlap = [[j for j in range(n) if j != i] for i in range(n)]
+    elif style == 1:
+        overlap = [[(i + 1) % n] for i in range(n)]
+    elif style == 2:   # short random lists: duplicates, the image itself
+        overlap = [[int(x) for x in rng.integers(0, n, size=int(rng.integers(1, 9)))] for _ in range(n)]
+    else:              # more than 64 neighbours: an expansion takes two 64-lane chunks
+        overlap = [[int(x) for x in rng.integers(0, n, size=70)] for _ in range(n)]
+    okw = dict(min_num_pixels=int(rng.integers(1, 6)), max_num_pixels=int(rng.choice([2, 5, 50, 1000])),
+               max_traversal_depth=int(rng.choice([1, 2, 3, 100])), max_reproj_error=float(rng.choice([1.0, 2.0, 4.0])),
+               max_depth_error=float(rng.choice([0.01, 0.05])), max_normal_error=float(rng.choice([10.0, 30.0])),
+               num_threads=int(rng.choice([-1, 1, 2, 3])))
+    okw["min_num_pixels"] = min(okw["min_num_pixels"], okw["max_num_pixels"])
+    if rng.random() < 0.2:
+        okw["bounding_box"] = ((-0.5, -0.5, -10.0), (0.5, 0.5, 10.0))
+    return fusion.StereoFusionOptions(**okw), images, overlap, (n, w, h, sigma, style, okw)
+
+
+@pytest.mark.parametrize("which,seed,count", [("emul", 11, 10), ("emul_small", 12, 6)])
+def test_emulated_kernel_random_configurations(request, which, seed, count):
+    """Seeded random scenes, options, pool sizes, masks, holes and overlap lists (all-to-all, chains, short random lists with
+    duplicates and the image itself, 70-entry lists = two chunks per expansion) through both capacity builds, bit for bit
+    against the sequential definition. (50 further configurations were run when the walk kernel was rewritten.)"""
+    E = request.getfixturevalue(which)
+    rng = np.random.default_rng(seed)
+    for _ in range(count):
+        opt, images, overlap, what = _random_configuration(rng)
+        want = fusion_oracle.fuse(opt, images, overlap, mode=1)
+        assert _same(fusion.fuse(opt, images, overlap, entry_points=E), want), what
