@@ -533,6 +533,9 @@ struct StereoFusionOptions {  // fusion.h:46-94 (the fields that reach the trave
   double max_depth_error = 0.01f;
   double max_normal_error = 10.0f;
   int check_num_images = 50;
+  // fusion.h:53: the size of the reference's thread pool -- here the (deterministic) turn order: its threads take the
+  // ten-row stripes t, t + T, ... in step; 1 = row-major = the reference with one thread; -1 = one thread per stripe
+  int num_threads = -1;
   float bounding_box_min[3] = {-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f};
   float bounding_box_max[3] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f};
 
@@ -572,6 +575,7 @@ class StereoFusion {
     o.max_reproj_error = options_.max_reproj_error;
     o.max_depth_error = options_.max_depth_error;
     o.max_normal_error = options_.max_normal_error;
+    o.num_threads = options_.num_threads;  // the size of the reference's pool = the turn order (colmap_amd_fusion.h)
     std::memcpy(o.bbox_min, options_.bounding_box_min, sizeof(o.bbox_min));
     std::memcpy(o.bbox_max, options_.bounding_box_max, sizeof(o.bbox_max));
     std::vector<fusion_image> images(inputs.size());

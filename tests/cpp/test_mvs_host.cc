@@ -217,6 +217,40 @@ static int FusionChecks() {
     strict.Run(in, {{1}, {0}});
     EXPECT(strict.GetFusedPoints().size() <= pts.size());
   }
+  // StereoFusionOptions::num_threads is the size of the reference's pool and thereby the turn order (colmap_amd_fusion.h):
+  // one thread = row-major turns, the points come out by ascending row of their first pixel; two threads take the
+  // ten-row stripes 0, 2 and 1, 3 of a 40-row image and the points are concatenated per thread (fusion.cc:322-337).
+  {
+    const int w = 16, h = 40;
+    auto imgs = MakeImages(2, w, h);
+    std::vector<DepthMap> dm(2, DepthMap(w, h, 1, 10));
+    std::vector<NormalMap> nm(2, NormalMap(w, h));
+    for (auto& d : dm) d.Fill(4.0f);
+    for (auto& n : nm)
+      for (int r = 0; r < h; ++r)
+        for (int c = 0; c < w; ++c) n.Set(r, c, 2, -1.0f);
+    std::vector<FusionInput> in(2);
+    for (int i = 0; i < 2; ++i) {
+      in[i].image = &imgs[i];
+      in[i].depth_map = &dm[i];
+      in[i].normal_map = &nm[i];
+    }
+    auto rows_ascend = [](const std::vector<PlyPoint>& pts) {
+      for (size_t k = 1; k < pts.size(); ++k)
+        if (pts[k].y < pts[k - 1].y - 1e-4f) return false;
+      return true;
+    };
+    StereoFusionOptions fo;
+    fo.min_num_pixels = 2;
+    fo.num_threads = 1;
+    StereoFusion one(fo);
+    one.Run(in, {{1}, {0}});
+    EXPECT(one.GetFusedPoints().size() > 100 && rows_ascend(one.GetFusedPoints()));
+    fo.num_threads = 2;
+    StereoFusion two(fo);
+    two.Run(in, {{1}, {0}});
+    EXPECT(two.GetFusedPoints().size() == one.GetFusedPoints().size() && !rows_ascend(two.GetFusedPoints()));
+  }
   std::printf("fusion checks OK\n");
   return 0;
 }
