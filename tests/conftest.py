@@ -12,10 +12,46 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     # experimental builds of the library (scripts/profile_pm_gather_diag.sh: e.g. the 16-bit packed-image format) are
     # put through the same parity tests by pointing the loader at them
+    if os.environ.get("COLMAP_AMD_TEST_EMUL", "0") != "0":
+        _use_stand_in()
     alt = os.environ.get("COLMAP_AMD_TEST_LIB")
     if alt:
         from colmap_amd import build as _b
         _b.LIB_PATH = os.path.abspath(alt)
+
+
+class _StandInLibrary:
+    """The three CPU builds of tests/hip_emul behind one object with the entry points of libcolmap_amd.so."""
+
+    def __init__(self, libs):
+        self._libs = libs
+
+    def __getattr__(self, name):
+        for L in self._libs:
+            try:
+                return getattr(L, name)
+            except AttributeError:
+                pass
+        raise AttributeError(name)
+
+
+def _use_stand_in():
+    """COLMAP_AMD_TEST_EMUL=1: every loader of the C-ABI library hands out the CPU stand-in builds instead, so that ANY
+    test marked gpu can be tried without a GPU (`COLMAP_AMD_TEST_EMUL=1 pytest -m gpu tests/test_pm_gpu.py -k window`):
+    a developer's tool next to the curated tests/test_*_emul.py; tests that need torch.cuda itself still need a GPU.
+    Never set by the product or by the default test runs."""
+    import ctypes as C
+    import subprocess
+    emul = os.path.join(ROOT, "tests", "hip_emul")
+    for script in ("build.sh", "build_ba.sh", "build_pm.sh"):
+        subprocess.check_call(["sh", os.path.join(emul, script)])
+    lib = _StandInLibrary([C.CDLL(os.path.join(emul, n)) for n in ("libpm_emul.so", "libba_emul.so", "libfusion_emul.so")])
+    lib.pm_last_error.restype = C.c_char_p
+    lib.pm_device_count.restype = C.c_int
+    lib.ba_last_error.restype = C.c_char_p
+    from colmap_amd import _lib, estimators, fusion, mvs
+    for mod in (_lib, estimators, fusion, mvs):
+        mod.lib = lambda: lib
 
 
 @pytest.fixture(scope="session")
