@@ -246,6 +246,14 @@ inline void launch(const char* name, dim3 grid, dim3 block, const std::function<
   }
 }
 
+// dynamic LDS of a launch: the array a build script defines for `extern __shared__` holds a CU's 160 KB
+inline void check_dynamic_lds(const char* name, size_t bytes) {
+  if (bytes > 160u * 1024u) {
+    std::fprintf(stderr, "hip_emul: %s asks for %zu bytes of dynamic LDS\n", name, bytes);
+    std::abort();
+  }
+}
+
 // collectives over the wave of the calling lane
 template <typename F>
 inline unsigned long long collective(unsigned long long mine, F&& f) {
@@ -265,7 +273,8 @@ inline unsigned long long collective(unsigned long long mine, F&& f) {
 #define blockDim (hip_emul::block_dim())
 #define gridDim (hip_emul::grid_dim())
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
-  hip_emul::launch(#kernel, (grid), (block), std::function<void()>([&]() { kernel(__VA_ARGS__); }))
+  (hip_emul::check_dynamic_lds(#kernel, (size_t)(shmem)), \
+   hip_emul::launch(#kernel, (grid), (block), std::function<void()>([&]() { kernel(__VA_ARGS__); })))
 
 inline void __syncthreads() { hip_emul::block_barrier(); }
 inline void __builtin_amdgcn_wave_barrier() { hip_emul::wave_barrier(); }
