@@ -18,9 +18,7 @@ SOURCES = ["pm_api.cpp", "pm_kernels.hip", "ba_kernels.hip", "ba_schur_explicit.
 # -ffp-contract=off: fused multiply-adds only where the source says fmaf(); the
 # arithmetic is specified operation by operation (oracle/pm_oracle.c header).
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-               "-Wall", "-Wno-unused-function", "-munsafe-fp-atomics",
-               # <pm_gfx950_asm.h>: the inline-assembly helpers of the PatchMatch kernels (tests/hip_emul shadows it)
-               "-I", os.path.join(CSRC, "gfx950")]
+               "-Wall", "-Wno-unused-function", "-munsafe-fp-atomics"]
 
 
 def _sources():

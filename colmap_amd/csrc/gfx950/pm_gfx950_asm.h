@@ -1,8 +1,8 @@
 // pm_gfx950_asm.h -- the places where the PatchMatch kernels (pm_kernels.hip) speak gfx950 assembly directly:
-// instruction selections the compiler does not make on its own. Included as <pm_gfx950_asm.h> (colmap_amd/build.py puts
-// this directory on the include path) so that tests/hip_emul -- the CPU stand-in that runs the unmodified kernels
-// against the oracle -- can put its own restatement of these five helpers first on the path, the same way it
-// stands in for <hip/hip_runtime.h>. There is one implementation in the product: this one.
+// instruction selections the compiler does not make on its own. They sit in a header of their own so that
+// tests/hip_emul -- the CPU stand-in that runs the unmodified kernels against the oracle -- can restate these five
+// helpers in C++ (it compiles pm_kernels.hip through a link in a directory that holds its own gfx950/pm_gfx950_asm.h,
+// the same way it stands in for <hip/hip_runtime.h>). There is one implementation in the product: this one.
 #pragma once
 
 #include <hip/hip_runtime.h>

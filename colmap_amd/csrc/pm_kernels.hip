@@ -32,7 +32,7 @@
 // independently; compile with -ffp-contract=off.
 #include "pm_internal.h"
 
-#include <pm_gfx950_asm.h>  // ubyte0..3, reduce16x3, launder_vgpr, llvm_struct_buffer_load_u32 (gfx950/; see its header)
+#include "gfx950/pm_gfx950_asm.h"  // ubyte0..3, reduce16x3, launder_vgpr, llvm_struct_buffer_load_u32 (see its header)
 
 #include <float.h>
 #include <math.h>

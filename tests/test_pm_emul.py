@@ -32,7 +32,7 @@ def _emul_lib():
     if _LIB is None:
         path = os.path.join(_HERE, "libpm_emul.so")
         deps = [os.path.join(_CSRC, f) for f in ("pm_kernels.hip", "pm_api.cpp", "pm_internal.h")]
-        deps += [os.path.join(_HERE, "hip", "hip_runtime.h"), os.path.join(_HERE, "pm", "pm_gfx950_asm.h"),
+        deps += [os.path.join(_HERE, "hip", "hip_runtime.h"), os.path.join(_HERE, "pm", "gfx950", "pm_gfx950_asm.h"),
                  os.path.join(_HERE, "pm", "pm_stubs.cpp"), os.path.join(_HERE, "build_pm.sh"),
                  os.path.join(os.path.dirname(_HERE), "..", "include", "colmap_amd_pm.h")]
         if not os.path.exists(path) or any(os.path.getmtime(d) > os.path.getmtime(path) for d in deps):
