@@ -261,7 +261,7 @@ __device__ __forceinline__ uint32_t tap_gather(const PmParams& p, gbl_u32* fp, f
   return fp[fp_index((unsigned)(int)cx, (unsigned)(int)cy, (unsigned)p.fp_rows1)];
 }
 
-// (ubyte0 .. ubyte3 -- byte k of a packed footprint entry as float, v_cvt_f32_ubyteK -- live in <pm_gfx950_asm.h>)
+// (ubyte0 .. ubyte3 -- byte k of a packed footprint entry as float, v_cvt_f32_ubyteK -- live in gfx950/pm_gfx950_asm.h)
 
 // Cross-lane add inside a 16-lane DPP row. The four steps (row_mirror,
 // row_half_mirror, quad reverse, quad swap) leave in every lane
@@ -1094,7 +1094,7 @@ __device__ __forceinline__ void tap_geom_init(lds_f32* tapg, int tid, int step, 
 // problem's sources) / IS (pm_api.cpp: the images of a problem must lie within IS * 4 GB of each other, which
 // the allocator's pool makes the normal case; otherwise the generic kernel runs).
 // ---------------------------------------------------------------------------
-// (v4i and llvm_struct_buffer_load_u32: <pm_gfx950_asm.h>)
+// (v4i and llvm_struct_buffer_load_u32: gfx950/pm_gfx950_asm.h)
 
 __device__ __forceinline__ v4i fp_resource(const PmParams& p) {
   const uint64_t b = (uint64_t)p.fp_base;
@@ -1196,7 +1196,7 @@ __device__ __forceinline__ void ncc_front(const PmParams& p, const v4i srd, cons
   }
 }
 // (reduce16x3 -- the three 16-lane tree sums of an evaluation as one block of 12 v_add_f32_dpp -- lives in
-// <pm_gfx950_asm.h>; same tree as reduce16)
+// gfx950/pm_gfx950_asm.h; same tree as reduce16)
 
 __device__ __forceinline__ void ncc_back(const NccStage& st, const uint32_t tex[8], const TapRegs& R, int j,
                                          float& s_sum, float& s_sq, float& s_ref) {

@@ -7,7 +7,7 @@ tests/hip_emul/ is a HIP stand-in for exactly this purpose (lanes as fibers; cro
 __syncthreads as barriers over the lanes still running; LDS as thread storage; buffer_load through a swizzled resource
 by the address formula the kernel states). The five inline-assembly helpers of the kernels live in one header of the
 product, colmap_amd/csrc/gfx950/pm_gfx950_asm.h, which the stand-in shadows with C++ restatements
-(tests/hip_emul/pm/pm_gfx950_asm.h) -- everything else is the product's source as hipcc compiles it. Test
+(tests/hip_emul/pm/gfx950/pm_gfx950_asm.h) -- everything else is the product's source as hipcc compiles it. Test
 infrastructure, never loaded by the product (its library is built by hipcc and has no CPU path). Sizes are small: a
 lane is a fiber here, one cross-lane operation costs a microsecond per lane. The GPU tests run the same comparisons
 through the hipcc build at the BASELINE shapes."""
