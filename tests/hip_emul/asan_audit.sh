@@ -1,0 +1,35 @@
+#!/bin/sh
+# AddressSanitizer audit of the kernels through the CPU stand-in (see asan_audit.py). ~10 minutes on a few cores.
+set -e
+here=$(cd "$(dirname "$0")" && pwd)
+root=$(cd "$here/../.." && pwd)
+cxx=${HIP_EMUL_CXX:-/opt/rocm/lib/llvm/bin/clang++}
+rt=$(ls "$(dirname "$cxx")"/../lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | head -1)
+out=${HIP_EMUL_ASAN_DIR:-$(mktemp -d)}
+export HIP_EMUL_ASAN_DIR="$out"
+printf 'extern "C" void pm_release_cached_memory(void) {}\n' > "$out/stubs.cpp"
+ln -sf "$root/colmap_amd/csrc/pm_kernels.hip" "$here/pm/pm_kernels.hip"
+F="-O1 -g -fsanitize=address -shared-libasan -fno-omit-frame-pointer -std=c++17 -fPIC -shared -mavx2 -mfma -ffp-contract=off -Wno-unknown-attributes"
+"$cxx" $F -fvisibility=hidden -I "$here" -x c++ "$root/colmap_amd/csrc/fusion.hip" "$out/stubs.cpp" -o "$out/libfusion_asan.so" &
+p1=$!
+"$cxx" $F -fvisibility=hidden -DFUSION_RECORD_BUF=1024 -DFUSION_STACK_LDS=8 -DFUSION_STACK_SPILL=8 -DFUSION_MEDIAN_STAGE=4 \
+    -I "$here" -x c++ "$root/colmap_amd/csrc/fusion.hip" "$out/stubs.cpp" -o "$out/libfusion_small_asan.so" &
+p2=$!
+"$cxx" $F -fvisibility-inlines-hidden -Wl,-Bsymbolic -I "$here" -x c++ "$root/colmap_amd/csrc/ba_kernels.hip" \
+    "$root/colmap_amd/csrc/ba_schur_explicit.hip" "$out/stubs.cpp" -o "$out/libba_asan.so" &
+p3=$!
+"$cxx" $F -fvisibility-inlines-hidden -Wl,-Bsymbolic -I "$here" -I "$root/colmap_amd/csrc" -x c++ "$here/pm/pm_kernels.hip" \
+    "$root/colmap_amd/csrc/pm_api.cpp" "$here/pm/pm_stubs.cpp" -o "$out/libpm_asan.so" &
+p4=$!
+wait $p1; wait $p2; wait $p3; wait $p4
+rc=0
+for w in fusion fusion_small ba pm; do
+  LD_PRELOAD="$rt" ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0:halt_on_error=1 \
+      python "$here/asan_audit.py" $w > "$out/audit_$w.log" 2>&1 &
+done
+wait
+for w in fusion fusion_small ba pm; do
+  if grep -q "AUDIT DONE $w" "$out/audit_$w.log"; then echo "$w: clean ($(grep -c ' ok' "$out/audit_$w.log") comparisons)";
+  else echo "$w: FAILED -- see $out/audit_$w.log"; tail -20 "$out/audit_$w.log"; rc=1; fi
+done
+exit $rc
