@@ -66,7 +66,12 @@ inline hipError_t hipSetDevice(int) { return hipSuccess; }
 inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 inline hipError_t hipMalloc(void** p, size_t bytes) {  // device allocations are page-aligned (the host code relies on 256 B)
   *p = nullptr;
-  return posix_memalign(p, 4096, bytes ? bytes : 1) == 0 ? hipSuccess : hipErrorOutOfMemory;
+  if (posix_memalign(p, 4096, bytes ? bytes : 1) != 0) return hipErrorOutOfMemory;
+  // HIP_EMUL_POISON=1: fresh device memory holds 0xCD bytes (NaN-like floats, huge indices) instead of whatever the
+  // allocator returns -- a kernel that relies on hipMalloc'd memory being zero shows up as a mismatch or a crash
+  static const bool poison = [] { const char* e = std::getenv("HIP_EMUL_POISON"); return e && e[0] != '0'; }();
+  if (poison) std::memset(*p, 0xCD, bytes ? bytes : 1);
+  return hipSuccess;
 }
 inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
 inline hipError_t hipHostMalloc(void** p, size_t bytes, unsigned = 0) { *p = std::calloc(bytes ? bytes : 1, 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
