@@ -207,6 +207,10 @@ inline void launch(const char* name, dim3 grid, dim3 block, const std::function<
   // HIP_EMUL_BLOCK_ORDER=reverse runs the blocks of every launch last to first: the other extreme of the orders in
   // which concurrently resident workgroups can reach a shared word
   static const bool reverse = [] { const char* e = std::getenv("HIP_EMUL_BLOCK_ORDER"); return e && e[0] == 'r'; }();
+  // HIP_EMUL_LANE_ORDER=reverse resumes the lanes of a workgroup last to first between two barriers: the last wave runs
+  // ahead of the first -- a missing barrier between a producer and a consumer wave (or lane) that the forward order
+  // happens to satisfy shows up under the other one
+  static const bool lane_reverse = [] { const char* e = std::getenv("HIP_EMUL_LANE_ORDER"); return e && e[0] == 'r'; }();
   const unsigned nblocks = grid.x * grid.y * grid.z;
   for (unsigned bi = 0; bi < nblocks; ++bi) {
     const unsigned bid = reverse ? nblocks - 1 - bi : bi;
@@ -236,7 +240,8 @@ inline void launch(const char* name, dim3 grid, dim3 block, const std::function<
     while (live > 0) {
       const unsigned long before = b.progress;
       const int live_before = live;
-      for (int i = 0; i < nt; ++i) {
+      for (int k = 0; k < nt; ++k) {
+        const int i = lane_reverse ? nt - 1 - k : k;
         if (b.fibers[i].done) continue;
         b.cur = i;
         ctx_switch(&b.sched, b.fibers[i].sp);
