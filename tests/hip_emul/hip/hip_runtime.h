@@ -192,6 +192,16 @@ inline void trampoline() {
   std::abort();  // a finished fiber is never resumed
 }
 
+// The array a build defines for `extern __shared__` registers itself here (pm/pm_stubs.cpp) so that HIP_EMUL_POISON can
+// refill it before every workgroup: LDS holds whatever the previous workgroup left on the hardware, and a kernel that
+// reads a word of it before writing it is a bug that zero-initialised thread storage would hide.
+inline unsigned char*& dynamic_lds_base() { static unsigned char* p = nullptr; return p; }
+inline size_t& dynamic_lds_size() { static size_t n = 0; return n; }
+inline void poison_dynamic_lds() {
+  static const bool poison = [] { const char* e = std::getenv("HIP_EMUL_POISON"); return e && e[0] != '0'; }();
+  if (poison && dynamic_lds_base()) std::memset(dynamic_lds_base(), 0xCD, dynamic_lds_size());
+}
+
 inline void launch(const char* name, dim3 grid, dim3 block, const std::function<void()>& body) {
   static const bool trace = std::getenv("HIP_EMUL_TRACE") != nullptr;
   if (trace) std::fprintf(stderr, "hip_emul: %s grid (%u, %u, %u) block %u\n", name, grid.x, grid.y, grid.z, block.x);
@@ -215,6 +225,7 @@ inline void launch(const char* name, dim3 grid, dim3 block, const std::function<
   for (unsigned bi = 0; bi < nblocks; ++bi) {
     const unsigned bid = reverse ? nblocks - 1 - bi : bi;
     block_idx() = dim3(bid % grid.x, (bid / grid.x) % grid.y, bid / (grid.x * grid.y));
+    poison_dynamic_lds();
     b.block_bar = Barrier();
     for (auto& w : b.wave_bar) w = Barrier();
     b.wave_live.assign(b.wave_bar.size(), 0);
