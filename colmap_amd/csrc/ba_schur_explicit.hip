@@ -227,100 +227,75 @@ __global__ void prior_rows_kernel(double* __restrict__ S, int n, const double* _
 // ---------------------------------------------------------------------------------------------------------
 
 // Diagonal block [k0, k0 + kb): L_kk in place (lower), its inverse (64 x 64, zero-padded) to Linv.
-__global__ void __launch_bounds__(256) chol_diag_kernel(double* __restrict__ S, int n, int k0, int kb,
+// TWO WAVES, each with a 64 x 64 matrix in registers (64 doubles = 128 VGPRs per lane; every loop below is unrolled
+// so that the register indices are compile-time constants):
+//   wave 0, lane r = row r of the block: the factorisation. The job is a chain of 64 dependent column steps -- pivot,
+//     reciprocal, multipliers, rank-1 update -- and its time is 64 x the latency of that chain, not arithmetic: the
+//     four-wave LDS version this replaces paid ~1 400 cycles per column (LDS round trips between dependent reads and
+//     writes, 16 threads per row, a full division in front of every step) and 69 us per block at BA-1, 125 of them in a
+//     row on the critical path of the factorisation. Here a column step is: the pivot by v_readlane, one division,
+//     column c of the matrix handed from lane to lane through 512 bytes of LDS (every lane reads all of it: broadcast
+//     reads, two values per ds_read), and 63 - c register FMAs per lane. Entries above the diagonal take part in
+//     the arithmetic as don't-cares (no divergence). As before the scaling by 1 / sqrt(pivot) happens once at the end
+//     (one sqrt + division per LANE instead of per column step): the loop works on A~ with L = A~ D^-1/2, D = diag(pivots).
+//   wave 1, lane j = column j of the inverse: forward substitution with the SAME column broadcasts, step by step
+//     behind wave 0 (Y = A~^-1: y_r /= d_r, y_rr -= A~[rr][r] y_r for the rows below; L^-1 = D^1/2 Y). Rows above j
+//     come out as exact zeros. (One wave doing both needs 256 VGPRs for the two matrices alone.)
+// Rows / columns beyond kb carry a unit diagonal and are not stored.
+__global__ void __launch_bounds__(128) chol_diag_kernel(double* __restrict__ S, int n, int k0, int kb,
                                                         double* __restrict__ Linv, int* __restrict__ info) {
-  __shared__ double L[NB][NB + 1];
-  __shared__ double Li[NB][NB + 1];
-  const int tid = threadIdx.x;
-  for (int e = tid; e < NB * NB; e += 256) {
-    const int r = e / NB, c = e % NB;
-    L[r][c] = (r < kb && c <= r) ? S[(size_t)(k0 + r) * n + k0 + c] : 0.0;
-    Li[r][c] = 0.0;
-  }
+  __shared__ double Ls[NB][NB + 1];
+  __shared__ double col[2][NB];
+  __shared__ double dsq[NB];  // sqrt(pivot)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int r = wave; r < NB; r += 2)  // coalesced: lane = column
+    Ls[r][lane] = (r < kb && lane <= r) ? S[(size_t)(k0 + r) * n + k0 + lane] : (r == lane ? 1.0 : 0.0);
   __syncthreads();
-  // Column c: A[r][cc] -= (A[r][c] / A[c][c]) A[cc][c] for r >= cc > c. Column c itself is not touched by its own
-  // step, so one barrier per column suffices (the usual sqrt-and-scale form needs three); the scaling by
-  // 1 / sqrt(pivot) happens once at the end. The pivots A[c][c] are final after step c - 1.
-  const int tr = tid & 63, tq = tid >> 6;  // thread = (row, quarter of the columns): no integer divisions below
-  for (int c = 0; c < kb; ++c) {
-    const double inv = 1.0 / L[c][c];
-    if (tr > c && tr < kb) {
-      const double lrc = L[tr][c] * inv;
-      // four columns per trip, all eight LDS reads issued before the first write (the compiler cannot prove
-      // that the writes to row tr do not alias the reads of column c and would otherwise serialise them)
-      for (int cc = c + 1 + tq; cc <= tr; cc += 16) {
-        const int c1 = cc + 4, c2 = cc + 8, c3 = cc + 12;
-        const double a0 = L[cc][c], b0 = L[tr][cc];
-        const double a1 = c1 <= tr ? L[c1][c] : 0.0, b1 = c1 <= tr ? L[tr][c1] : 0.0;
-        const double a2 = c2 <= tr ? L[c2][c] : 0.0, b2 = c2 <= tr ? L[tr][c2] : 0.0;
-        const double a3 = c3 <= tr ? L[c3][c] : 0.0, b3 = c3 <= tr ? L[tr][c3] : 0.0;
-        L[tr][cc] = b0 - lrc * a0;
-        if (c1 <= tr) L[tr][c1] = b1 - lrc * a1;
-        if (c2 <= tr) L[tr][c2] = b2 - lrc * a2;
-        if (c3 <= tr) L[tr][c3] = b3 - lrc * a3;
-      }
+  double a[NB];
+  // (The two waves run separate straight-line code with the same number of barriers -- 64 in the loop, one after it:
+  //  merged into one loop with per-step branches the register allocation falls apart, 7 KB of scratch.)
+  if (wave == 0) {
+#pragma unroll
+    for (int c = 0; c < NB; ++c) a[c] = Ls[lane][c];  // row `lane` of A~
+    double dmine = 0.0;                                // pivot of column `lane` (final after step lane - 1)
+#pragma unroll
+    for (int c = 0; c < NB; ++c) {
+      const double d = __shfl(a[c], c);
+      dmine = lane == c ? a[c] : dmine;
+      const double l = a[c] * (1.0 / d);  // multiplier of row `lane` (rows <= c: a don't-care)
+      col[c & 1][lane] = a[c];
+      __syncthreads();  // column c (its entry c is the pivot) is published; the other buffer is free again
+#pragma unroll
+      for (int cc = c + 1; cc < NB; ++cc) a[cc] -= l * col[c & 1][cc];
+    }
+    const bool okp = dmine > 0.0;
+    if (!okp) *info = 1;
+    const double rs = okp ? 1.0 / sqrt(dmine) : NAN;
+    dsq[lane] = dmine * rs;
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < NB; ++c) {
+      const double v = a[c] * __shfl(rs, c);
+      Ls[lane][c] = c < lane ? v : (c == lane ? dmine * rs : 0.0);
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < NB; ++r) a[r] = r == lane ? 1.0 : 0.0;  // column `lane` of Y
+#pragma unroll
+    for (int r = 0; r < NB; ++r) {
+      __syncthreads();
+      const double yr = a[r] * (1.0 / col[r & 1][r]);
+      a[r] = yr;
+#pragma unroll
+      for (int rr = r + 1; rr < NB; ++rr) a[rr] -= yr * col[r & 1][rr];
     }
     __syncthreads();
-  }
-  __shared__ double dsq[NB];
-  if (tid < kb) {
-    const double d = L[tid][tid];
-    if (!(d > 0.0)) *info = 1;
-    dsq[tid] = d > 0.0 ? sqrt(d) : NAN;
-  }
-  __syncthreads();
-  for (int e = tid; e < kb * kb; e += 256) {
-    const int r = e / kb, c = e % kb;
-    if (c < r) L[r][c] /= dsq[c];
-  }
-  __syncthreads();
-  if (tid < kb) L[tid][tid] = dsq[tid];
-  __syncthreads();
-  // Inverse of the triangle by 16 x 16 blocks (rows / columns beyond kb hold zeros except a unit diagonal, so a
-  // short last block needs no special case): the four diagonal blocks by forward substitution (16 lanes each),
-  // then block diagonals at distance d = 1, 2, 3:  Linv_ij = -Linv_ii (sum_{k=j}^{i-1} L_ik Linv_kj), every
-  // 16 x 16 product with one output element per thread. (The rolled per-column substitution this replaces was a
-  // third of the kernel's 86 us.)
-  __shared__ double T[3][16][17];
-  for (int e = tid; e < NB; e += 256)
-    if (e >= kb) L[e][e] = 1.0;
-  __syncthreads();
-  if (tid < 64) {
-    const int bi = tid >> 4, j = tid & 15, o = 16 * bi;
-    for (int r = j; r < 16; ++r) {
-      double v = (r == j) ? 1.0 : 0.0;
-      for (int m = j; m < r; ++m) v -= L[o + r][o + m] * Li[o + m][o + j];
-      Li[o + r][o + j] = v / L[o + r][o + r];
-    }
-  }
-  __syncthreads();
-  {
-    const int er = tid >> 4, ec = tid & 15;  // output element of a 16 x 16 product
-    for (int d = 1; d < 4; ++d) {
-      for (int q = 0; q + d < 4; ++q) {  // block (i, j) = (q + d, q)
-        const int i = q + d, j = q;
-        double acc = 0.0;
-        for (int k = j; k < i; ++k)
 #pragma unroll
-          for (int m = 0; m < 16; ++m) acc += L[16 * i + er][16 * k + m] * Li[16 * k + m][16 * j + ec];
-        T[q][er][ec] = acc;
-      }
-      __syncthreads();
-      for (int q = 0; q + d < 4; ++q) {
-        const int i = q + d, j = q;
-        double acc = 0.0;
-#pragma unroll
-        for (int m = 0; m < 16; ++m) acc += Li[16 * i + er][16 * i + m] * T[q][m][ec];
-        Li[16 * i + er][16 * j + ec] = -acc;
-      }
-      __syncthreads();
-    }
+    for (int r = 0; r < NB; ++r) Linv[r * NB + lane] = (r < kb && lane < kb) ? a[r] * dsq[r] : 0.0;
   }
-  for (int e = tid; e < NB * NB; e += 256) {
-    const int r = e / NB, c = e % NB;
-    if (r < kb && c <= r) S[(size_t)(k0 + r) * n + k0 + c] = L[r][c];
-    Linv[e] = (r < kb && c < kb) ? Li[r][c] : 0.0;
-  }
+  __syncthreads();
+  for (int r = wave; r < NB; r += 2)  // coalesced again: lane = column
+    if (r < kb && lane <= r) S[(size_t)(k0 + r) * n + k0 + lane] = Ls[r][lane];
 }
 
 // Panel below the diagonal block: X = A_panel L_kk^-T, in place. One workgroup per 64 rows; wave w owns rows
@@ -418,15 +393,20 @@ __global__ void __launch_bounds__(256) chol_update_kernel(double* __restrict__ S
 // The same update with 128 x 128 tiles per workgroup: wave w owns the 64 x 64 quadrant (w >> 1, w & 1) as 4 x 4
 // MFMA tiles (64 accumulator doubles per lane), K = kb streamed through LDS in chunks of 16. 16 flop per byte
 // loaded instead of 8: used while the trailing matrix has enough 128-tiles to fill the chip.
+// The next chunk's 16 doubles per thread are fetched into registers right after the barrier that publishes the
+// current chunk, so the global-load latency runs under the 64 matrix-core instructions of the chunk instead of in
+// front of them (the version without the prefetch left the matrix cores idle for a load round trip per chunk:
+// 14 TFLOP/s over the trailing updates at BA-1). A diagonal tile (I == J) reads its rows once.
 __global__ void __launch_bounds__(256, 2) chol_update128_kernel(double* __restrict__ S, int n, int k0, int kb,
                                                                 int row0, int col0, int cend) {
   const int I = blockIdx.y, J = blockIdx.x;
-  constexpr int T = 128, KC = 16;
+  constexpr int T = 128, KC = 16, PF = T * KC / 256;
   __shared__ double sI[T][KC + 1];
   __shared__ double sJ[T][KC + 1];
   const int tid = threadIdx.x;
   const int ri = row0 + T * I, rj = col0 + T * J;
   if (rj > ri + T - 1 || rj >= cend) return;
+  const bool same = ri == rj;  // diagonal tile: X_J = X_I
   const int wave = tid >> 6, lane = tid & 63;
   const int li = lane & 15, lk = lane >> 4;
   const int qi = 64 * (wave >> 1), qj = 64 * (wave & 1);
@@ -435,15 +415,30 @@ __global__ void __launch_bounds__(256, 2) chol_update128_kernel(double* __restri
   for (int a = 0; a < 4; ++a)
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = v4f64{0.0, 0.0, 0.0, 0.0};
+  // thread -> (row r = tid / 16 + 16 i, column m = tid % 16) of a chunk: 16 lanes read 128 contiguous bytes of a row
+  const int pr = tid >> 4, pm = tid & 15;
+  const double* gI = S + (size_t)(ri + pr) * n + k0 + pm;
+  const double* gJ = S + (size_t)(rj + pr) * n + k0 + pm;
+  double pI[PF], pJ[PF];
+  auto fetch = [&](int kc) {
+    const bool kok = kc + pm < kb;
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+      const int r = pr + 16 * i;
+      pI[i] = (kok && ri + r < n) ? gI[(size_t)16 * i * n + kc] : 0.0;
+      pJ[i] = (!same && kok && rj + r < n) ? gJ[(size_t)16 * i * n + kc] : 0.0;
+    }
+  };
+  fetch(0);
   for (int kc = 0; kc < kb; kc += KC) {
-    __syncthreads();
-    for (int e = tid; e < T * KC; e += 256) {
-      const int r = e >> 4, m = e & 15;
-      const bool kok = kc + m < kb;
-      sI[r][m] = (kok && ri + r < n) ? S[(size_t)(ri + r) * n + k0 + kc + m] : 0.0;
-      sJ[r][m] = (kok && rj + r < n) ? S[(size_t)(rj + r) * n + k0 + kc + m] : 0.0;
+    __syncthreads();  // the previous chunk's readers are done
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+      sI[pr + 16 * i][pm] = pI[i];
+      sJ[pr + 16 * i][pm] = same ? pI[i] : pJ[i];
     }
     __syncthreads();
+    if (kc + KC < kb) fetch(kc + KC);
 #pragma unroll
     for (int ks = 0; ks < KC / 4; ++ks) {
       const int m = 4 * ks + lk;
@@ -583,7 +578,7 @@ void factor_solve(double* S, int n, const double* rhs, double* x, const Workspac
   auto launch = [&](int k0, int kb, int row0, int col0, int cend, hipStream_t s_) {
     const int rows = n - row0, cols = std::min(cend, n) - col0;
     if (rows <= 0 || cols <= 0) return;
-    if (rows >= 12 * 128 && cols >= 256) {
+    if (rows >= ws.min_rows128 && cols >= 256) {
       hipLaunchKernelGGL(chol_update128_kernel, dim3((cols + 127) / 128, (rows + 127) / 128), dim3(256), 0, s_, S, n, k0, kb,
                          row0, col0, std::min(cend, n));
     } else {
@@ -604,7 +599,7 @@ void factor_solve(double* S, int n, const double* rhs, double* x, const Workspac
     for (int k0 = o0; k0 < oend; k0 += NB) {
       const int kb = std::min(NB, n - k0);
       double* Li = ws.Linv + (size_t)(k0 / NB) * NB * NB;
-      hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), 0, st, S, n, k0, kb, Li, ws.info);
+      hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(128), 0, st, S, n, k0, kb, Li, ws.info);
       const int below = n - k0 - kb;
       if (below > 0) {
         hipLaunchKernelGGL(chol_panel_kernel, dim3((below + NB - 1) / NB), dim3(256), 0, st, S, n, k0, kb, Li);

@@ -118,7 +118,7 @@ class _FormArgs(C.Structure):
 
 class _Workspace(C.Structure):
     _fields_ = [("Linv", C.c_void_p), ("tmp", C.c_void_p), ("info", C.c_void_p), ("st2", C.c_void_p),
-                ("ev_panel", C.c_void_p), ("ev_u2", C.c_void_p)]
+                ("ev_panel", C.c_void_p), ("ev_u2", C.c_void_p), ("min_rows128", C.c_int)]
 
 
 def _explicit_entry_points():
@@ -170,10 +170,59 @@ def test_fixed_point_formation_and_its_overflow_flag(scale, expect_bad):
     assert np.isnan(S[0, 0])
     x, rhs = np.zeros(n_c), np.ones(n_c)
     linv, tmp, info = np.zeros(64 * 64), np.zeros(n_c), np.zeros(1, np.int32)
-    ws = _Workspace(Linv=linv.ctypes.data, tmp=tmp.ctypes.data, info=info.ctypes.data)
+    ws = _Workspace(Linv=linv.ctypes.data, tmp=tmp.ctypes.data, info=info.ctypes.data, min_rows128=12 * 128)
     factor_solve(S.ctypes.data_as(C.c_void_p), C.c_int(n_c), rhs.ctypes.data_as(C.c_void_p), x.ctypes.data_as(C.c_void_p),
                  C.byref(ws), None, None, None, None)
     assert info[0] == 1 and np.isnan(x).all()
+
+
+def _factor_solve_directly(A, rhs, min_rows128):
+    import numpy as np
+    _, _, factor_solve = _explicit_entry_points()
+    n = A.shape[0]
+    S = np.tril(A).copy()
+    S[np.triu_indices(n, 1)] = 1e300  # the upper triangle is never read
+    x = np.zeros(n)
+    linv, tmp, info = np.zeros(((n + 63) // 64) * 64 * 64), np.zeros(n), np.zeros(1, np.int32)
+    ws = _Workspace(Linv=linv.ctypes.data, tmp=tmp.ctypes.data, info=info.ctypes.data, min_rows128=min_rows128)
+    factor_solve(S.ctypes.data_as(C.c_void_p), C.c_int(n), np.ascontiguousarray(rhs).ctypes.data_as(C.c_void_p),
+                 x.ctypes.data_as(C.c_void_p), C.byref(ws), None, None, None, None)
+    return S, linv.reshape(-1, 64, 64), x, int(info[0])
+
+
+@pytest.mark.parametrize("n,min_rows128", [(45, 12 * 128), (64, 12 * 128), (333, 12 * 128), (600, 256)])
+def test_blocked_cholesky_directly_against_numpy(n, min_rows128):
+    """factor_solve on a random SPD matrix: the factor, the stored inverses of its diagonal blocks and the solution
+    against numpy. n = 45 / 64: one (short / full) diagonal block -- chol_diag_kernel alone (two waves: the
+    factorisation in one, the inverse of the triangle in the other); 333: six panels, a ragged last block, two outer
+    panels; 600 with the tile threshold lowered: the 128 x 128 trailing update with its register prefetch, including
+    diagonal tiles and a ragged edge."""
+    import numpy as np
+    rng = np.random.default_rng(n)
+    B = rng.standard_normal((n, n + 8))
+    A = B @ B.T / n + 0.5 * np.eye(n)
+    rhs = rng.standard_normal(n)
+    S, linv, x, info = _factor_solve_directly(A, rhs, min_rows128)
+    assert info == 0
+    L = np.linalg.cholesky(A)
+    low = np.tril_indices(n)
+    np.testing.assert_allclose(S[low], L[low], rtol=0, atol=1e-12)
+    for k in range((n + 63) // 64):
+        kb = min(64, n - 64 * k)
+        blk = L[64 * k:64 * k + kb, 64 * k:64 * k + kb]
+        np.testing.assert_allclose(linv[k][:kb, :kb], np.linalg.inv(blk), rtol=0, atol=1e-11)
+        assert (linv[k][kb:, :] == 0).all() and (linv[k][:, kb:] == 0).all()
+        assert (np.triu(linv[k][:kb, :kb], 1) == 0).all()
+    np.testing.assert_allclose(x, np.linalg.solve(A, rhs), rtol=0, atol=1e-10)
+
+
+def test_blocked_cholesky_reports_a_failed_pivot():
+    import numpy as np
+    n = 100
+    A = np.eye(n)
+    A[70, 70] = -1.0
+    _, _, x, info = _factor_solve_directly(A, np.ones(n), 12 * 128)
+    assert info == 1 and np.isnan(x).all()
 
 
 # ------------------------------------------------------------------------------------------------
