@@ -309,10 +309,20 @@ __global__ void __launch_bounds__(256) chol_panel_kernel(double* __restrict__ S,
   const int tid = threadIdx.x;
   const int r0 = k0 + kb + NB * blockIdx.x;
   const int nr = min(NB, n - r0);
-  for (int e = tid; e < NB * NB; e += 256) {
-    const int r = e / NB, c = e % NB;
-    sA[r][c] = (r < nr && c < kb) ? S[(size_t)(r0 + r) * n + k0 + c] : 0.0;
-    sLi[r][c] = Linv[e];
+  {  // all 32 loads of a thread in flight together (rolled, the loop waited for every pair before its LDS writes)
+    const int c = tid & 63, rq = tid >> 6;
+    double va[16], vl[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int r = rq + 4 * i;
+      va[i] = (r < nr && c < kb) ? S[(size_t)(r0 + r) * n + k0 + c] : 0.0;
+      vl[i] = Linv[r * NB + c];
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      sA[rq + 4 * i][c] = va[i];
+      sLi[rq + 4 * i][c] = vl[i];
+    }
   }
   __syncthreads();
   const int wave = tid >> 6, lane = tid & 63;
@@ -354,20 +364,44 @@ __global__ void __launch_bounds__(256) chol_update_kernel(double* __restrict__ S
   const int wave = tid >> 6, lane = tid & 63;
   const int li = lane & 15, lk = lane >> 4;
   const int qi = 32 * (wave >> 1), qj = 32 * (wave & 1);
+  // The accumulators start from the tile itself and the A operand enters negated, D = C - X_I X_J^T: the 16 loads of
+  // a lane are in flight together with the first operand loads and the epilogue only stores. (The read-modify-write
+  // epilogue this replaces compiled to one branch + load + wait + store per element: 16 serial round trips per lane.)
   v4f64 acc[2][2];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b) acc[a][b] = v4f64{0.0, 0.0, 0.0, 0.0};
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int r = ri + qi + 16 * a + lk + 4 * reg, c = rj + qj + 16 * b + li;
+        acc[a][b][reg] = S[(r < n && c < n) ? (size_t)r * n + c : (size_t)ri * n + rj];  // (out of range: any valid address)
+      }
+  // thread -> (row r = tid / 32 + 8 i, column m = tid % 32) of a half: all 16 loads of a thread are issued together,
+  // and those of the next half right after the barrier that publishes this one (under its 32 matrix-core instructions)
+  const int pr = tid >> 5, pm = tid & 31;
+  const double* gI = S + (size_t)(ri + pr) * n + k0 + pm;
+  const double* gJ = S + (size_t)(rj + pr) * n + k0 + pm;
+  double pI[8], pJ[8];
+  auto fetch = [&](int kh) {
+    const bool kok = kh + pm < kb;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int r = pr + 8 * i;
+      pI[i] = (kok && ri + r < n) ? gI[(size_t)8 * i * n + kh] : 0.0;
+      pJ[i] = (kok && rj + r < n) ? gJ[(size_t)8 * i * n + kh] : 0.0;
+    }
+  };
+  fetch(0);
   for (int kh = 0; kh < kb; kh += 32) {
     __syncthreads();
-    for (int e = tid; e < NB * 32; e += 256) {
-      const int r = e >> 5, m = e & 31;
-      const bool kok = kh + m < kb;
-      sI[r][m] = (kok && ri + r < n) ? S[(size_t)(ri + r) * n + k0 + kh + m] : 0.0;
-      sJ[r][m] = (kok && rj + r < n) ? S[(size_t)(rj + r) * n + k0 + kh + m] : 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      sI[pr + 8 * i][pm] = -pI[i];
+      sJ[pr + 8 * i][pm] = pJ[i];
     }
     __syncthreads();
+    if (kh + 32 < kb) fetch(kh + 32);
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
       const int m = 4 * ks + lk;
@@ -386,7 +420,7 @@ __global__ void __launch_bounds__(256) chol_update_kernel(double* __restrict__ S
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
         const int r = ri + qi + 16 * a + lk + 4 * reg, c = rj + qj + 16 * b + li;
-        if (r < n && c < cend && c <= r) S[(size_t)r * n + c] -= acc[a][b][reg];
+        if (r < n && c < cend && c <= r) S[(size_t)r * n + c] = acc[a][b][reg];
       }
 }
 
@@ -396,7 +430,9 @@ __global__ void __launch_bounds__(256) chol_update_kernel(double* __restrict__ S
 // The next chunk's 16 doubles per thread are fetched into registers right after the barrier that publishes the
 // current chunk, so the global-load latency runs under the 64 matrix-core instructions of the chunk instead of in
 // front of them (the version without the prefetch left the matrix cores idle for a load round trip per chunk:
-// 14 TFLOP/s over the trailing updates at BA-1). A diagonal tile (I == J) reads its rows once.
+// 14 TFLOP/s over the trailing updates at BA-1). A diagonal tile (I == J) reads its rows once. As in the 64 x 64
+// kernel the accumulators start from the tile and the epilogue only stores (it was 64 serial load-wait-store round
+// trips per lane).
 __global__ void __launch_bounds__(256, 2) chol_update128_kernel(double* __restrict__ S, int n, int k0, int kb,
                                                                 int row0, int col0, int cend) {
   const int I = blockIdx.y, J = blockIdx.x;
@@ -414,7 +450,12 @@ __global__ void __launch_bounds__(256, 2) chol_update128_kernel(double* __restri
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = v4f64{0.0, 0.0, 0.0, 0.0};
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int r = ri + qi + 16 * a + lk + 4 * reg, c = rj + qj + 16 * b + li;
+        acc[a][b][reg] = S[(r < n && c < n) ? (size_t)r * n + c : (size_t)ri * n + rj];  // (out of range: any valid address)
+      }
   // thread -> (row r = tid / 16 + 16 i, column m = tid % 16) of a chunk: 16 lanes read 128 contiguous bytes of a row
   const int pr = tid >> 4, pm = tid & 15;
   const double* gI = S + (size_t)(ri + pr) * n + k0 + pm;
@@ -434,7 +475,7 @@ __global__ void __launch_bounds__(256, 2) chol_update128_kernel(double* __restri
     __syncthreads();  // the previous chunk's readers are done
 #pragma unroll
     for (int i = 0; i < PF; ++i) {
-      sI[pr + 16 * i][pm] = pI[i];
+      sI[pr + 16 * i][pm] = -pI[i];  // D = C - X_I X_J^T
       sJ[pr + 16 * i][pm] = same ? pI[i] : pJ[i];
     }
     __syncthreads();
@@ -460,59 +501,83 @@ __global__ void __launch_bounds__(256, 2) chol_update128_kernel(double* __restri
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
         const int r = ri + qi + 16 * a + lk + 4 * reg, c = rj + qj + 16 * b + li;
-        if (r < n && c < cend && c <= r) S[(size_t)r * n + c] -= acc[a][b][reg];
+        if (r < n && c < cend && c <= r) S[(size_t)r * n + c] = acc[a][b][reg];
       }
 }
 
 // Forward step k: y_k <- L_kk^-1 y_k (final), rows below: y_i -= L_ik y_k. Every workgroup recomputes the
-// 64-vector (cheap), workgroup 0 publishes it to `yfin`; block.x = 64, grid = 1 + #row tiles below.
-__global__ void __launch_bounds__(64) solve_forward_kernel(const double* __restrict__ S, int n, int k0, int kb,
-                                                           const double* __restrict__ Linv, double* __restrict__ y,
-                                                           double* __restrict__ yfin) {
+// 64-vector (cheap), workgroup 0 publishes it to `yfin`; block.x = 256, grid = 1 + #row tiles below.
+// Thread = (row, quarter): a quarter of the 64 terms of a row each (16 loads in flight per thread instead of a chain of
+// 64), the four partial sums added in quarter order (a fixed tree: reproducible).
+__global__ void __launch_bounds__(256) solve_forward_kernel(const double* __restrict__ S, int n, int k0, int kb,
+                                                            const double* __restrict__ Linv, double* __restrict__ y,
+                                                            double* __restrict__ yfin) {
   __shared__ double yk[NB];
   __shared__ double raw[NB];
-  const int tid = threadIdx.x;
-  raw[tid] = tid < kb ? y[k0 + tid] : 0.0;
+  __shared__ double part[4][NB];
+  const int row = threadIdx.x & 63, q = threadIdx.x >> 6;
+  if (q == 0) raw[row] = row < kb ? y[k0 + row] : 0.0;
   __syncthreads();
-  double v = 0.0;
-  for (int m = 0; m <= tid && m < kb; ++m) v += Linv[tid * NB + m] * raw[m];
-  yk[tid] = tid < kb ? v : 0.0;
+  {
+    double v = 0.0;  // (L^-1 is lower triangular and zero-padded: terms beyond the diagonal are exact zeros)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v += Linv[row * NB + 16 * q + j] * raw[16 * q + j];
+    part[q][row] = v;
+  }
+  __syncthreads();
+  if (q == 0) yk[row] = row < kb ? ((part[0][row] + part[1][row]) + (part[2][row] + part[3][row])) : 0.0;
   __syncthreads();
   if (blockIdx.x == 0) {
-    if (tid < kb) yfin[k0 + tid] = yk[tid];
+    if (q == 0 && row < kb) yfin[k0 + row] = yk[row];
     return;
   }
-  const int r = k0 + kb + NB * (blockIdx.x - 1) + tid;
-  if (r >= n) return;
-  const double* Sr = S + (size_t)r * n + k0;
+  const int r = k0 + kb + NB * (blockIdx.x - 1) + row;
   double acc = 0.0;
-  for (int m = 0; m < kb; ++m) acc += Sr[m] * yk[m];
-  y[r] -= acc;
+  if (r < n) {
+    const double* Sr = S + (size_t)r * n + k0 + 16 * q;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc += (16 * q + j < kb ? Sr[j] : 0.0) * yk[16 * q + j];
+  }
+  part[q][row] = acc;
+  __syncthreads();
+  if (q == 0 && r < n) y[r] -= (part[0][row] + part[1][row]) + (part[2][row] + part[3][row]);
 }
 
-// Backward step k: x_k <- L_kk^-T w_k (final), columns left of it: w_j -= L_kj^T x_k.
-__global__ void __launch_bounds__(64) solve_backward_kernel(const double* __restrict__ S, int n, int k0, int kb,
-                                                            const double* __restrict__ Linv, double* __restrict__ w,
-                                                            double* __restrict__ x) {
+// Backward step k: x_k <- L_kk^-T w_k (final), columns left of it: w_j -= L_kj^T x_k. Same thread layout.
+__global__ void __launch_bounds__(256) solve_backward_kernel(const double* __restrict__ S, int n, int k0, int kb,
+                                                             const double* __restrict__ Linv, double* __restrict__ w,
+                                                             double* __restrict__ x) {
   __shared__ double xk[NB];
   __shared__ double raw[NB];
-  const int tid = threadIdx.x;
-  raw[tid] = tid < kb ? w[k0 + tid] : 0.0;
+  __shared__ double part[4][NB];
+  const int col = threadIdx.x & 63, q = threadIdx.x >> 6;
+  if (q == 0) raw[col] = col < kb ? w[k0 + col] : 0.0;
   __syncthreads();
-  double v = 0.0;
-  for (int m = tid; m < kb; ++m) v += Linv[m * NB + tid] * raw[m];  // (L^-1)^T
-  xk[tid] = tid < kb ? v : 0.0;
+  {
+    double v = 0.0;  // (L^-1)^T: column `col` of L^-1 (zeros above the diagonal)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v += Linv[(16 * q + j) * NB + col] * raw[16 * q + j];
+    part[q][col] = v;
+  }
+  __syncthreads();
+  if (q == 0) xk[col] = col < kb ? ((part[0][col] + part[1][col]) + (part[2][col] + part[3][col])) : 0.0;
   __syncthreads();
   if (blockIdx.x == 0) {
-    if (tid < kb) x[k0 + tid] = xk[tid];
+    if (q == 0 && col < kb) x[k0 + col] = xk[col];
     return;
   }
-  const int c = NB * (blockIdx.x - 1) + tid;
-  if (c >= k0) return;
+  const int c = NB * (blockIdx.x - 1) + col;
   double acc = 0.0;
-#pragma unroll 8
-  for (int m = 0; m < kb; ++m) acc += S[(size_t)(k0 + m) * n + c] * xk[m];
-  w[c] -= acc;
+  if (c < k0) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int m = 16 * q + j;
+      acc += (m < kb ? S[(size_t)(k0 + m) * n + c] : 0.0) * xk[m];
+    }
+  }
+  part[q][col] = acc;
+  __syncthreads();
+  if (q == 0 && c < k0) w[c] -= (part[0][col] + part[1][col]) + (part[2][col] + part[3][col]);
 }
 
 __global__ void nan_fill_kernel(int n, const int* __restrict__ info, double* __restrict__ x) {
@@ -632,12 +697,12 @@ void factor_solve(double* S, int n, const double* rhs, double* x, const Workspac
   for (int kblk = 0; kblk < nblk; ++kblk) {
     const int k0 = kblk * NB, kb = std::min(NB, n - k0);
     const int tiles = (n - k0 - kb + NB - 1) / NB;
-    hipLaunchKernelGGL(solve_forward_kernel, dim3(1 + tiles), dim3(64), 0, st, S, n, k0, kb,
+    hipLaunchKernelGGL(solve_forward_kernel, dim3(1 + tiles), dim3(256), 0, st, S, n, k0, kb,
                        ws.Linv + (size_t)kblk * NB * NB, x, ws.tmp);
   }
   for (int kblk = nblk - 1; kblk >= 0; --kblk) {
     const int k0 = kblk * NB, kb = std::min(NB, n - k0);
-    hipLaunchKernelGGL(solve_backward_kernel, dim3(1 + kblk), dim3(64), 0, st, S, n, k0, kb,
+    hipLaunchKernelGGL(solve_backward_kernel, dim3(1 + kblk), dim3(256), 0, st, S, n, k0, kb,
                        ws.Linv + (size_t)kblk * NB * NB, ws.tmp, x);
   }
   hipLaunchKernelGGL(nan_fill_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, ws.info, x);
