@@ -2769,6 +2769,8 @@ struct Solver {
   std::vector<int> h_pose_off, h_cam_off, h_pt_off;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
   hipStream_t st_chol = nullptr;  // second stream + events of the Cholesky lookahead (exact tiers)
+  ba_explicit::PairLists pair_lists;  // pair-major formation of the exact tiers (built at the first formation)
+  bool pair_lists_tried = false;
   hipEvent_t ev_chol_panel = nullptr, ev_chol_u2 = nullptr;
 
   Solver(ba_problem& p_, const ba_options& o_, Comm& c_) : opt(o_), prob(p_), comm(c_) {}
@@ -2786,6 +2788,7 @@ struct Solver {
     if (ev_chol_panel) (void)hipEventDestroy(ev_chol_panel);
     if (ev_chol_u2) (void)hipEventDestroy(ev_chol_u2);
     if (st_chol) (void)hipStreamDestroy(st_chol);
+    ba_explicit::free_pair_lists(pair_lists);
     if (st) (void)hipStreamDestroy(st);
   }
 
@@ -3343,10 +3346,17 @@ struct Solver {
       fa.Jpose = V.Jpose; fa.Jcam = V.Jcam; fa.Jsens = V.sens_off ? V.Jsens : nullptr; fa.Jpt = V.Jpt;
       fa.Cinv = Cinv.p; fa.a2c = V.a2c; fa.pt_ptr = V.pt_ptr; fa.pt_off = V.pt_off;
       fa.a_pose = V.a_pose; fa.a_cam = V.a_cam; fa.a_sensor = V.sens_off ? V.a_sensor : nullptr;
+      fa.a_pt = V.a_pt; fa.n_poses = V.n_poses;
       fa.pose_off = V.pose_off; fa.pose_dim = V.pose_dim; fa.cam_off = V.cam_off; fa.cam_dim = V.cam_dim;
       fa.sens_off = V.sens_off;
       fa.fixed_point = opt.jacobi_scaling != 0;  // columns of norm < 1: integer accumulation, bit-reproducible
       fa.bad = chol_info.p + 1;                  // raised by a term the fixed point cannot hold (NaN, out of bound)
+      if (!pair_lists_tried) {  // pair-major formation: the incidence lists depend on the topology only
+        pair_lists_tried = true;
+        const char* e_pairs = std::getenv("COLMAP_AMD_BA_FORM_PAIRS");  // 0: the point-major kernel (one atomic per term)
+        if (!e_pairs || std::atoi(e_pairs) != 0) (void)ba_explicit::build_pair_lists(fa, pair_lists, st);
+      }
+      fa.pairs = pair_lists.inc ? &pair_lists : nullptr;
       ba_explicit::form(fa, Sdense.p, st);
       if (use_priors()) ba_explicit::add_prior_rows(Sdense.p, n, Q.J, Q.po, Q.so, Q.pdim, Q.n, fa.fixed_point, fa.bad, st);
       ba_explicit::finish(Sdense.p, n, fa.fixed_point, fa.bad, st);

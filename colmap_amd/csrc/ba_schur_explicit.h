@@ -11,9 +11,21 @@ namespace ba_explicit {
 
 constexpr int kPoseDim = 6;  // row stride of the pose-tangent columns (PD in ba_kernels.hip)
 
+// Pair-major incidence lists of the formation (topology only: built once per solve by build_pair_lists, owned by
+// the caller, released by free_pair_lists). An incidence is an unordered pair {a, b} of observations of one variable
+// 3-D point, or the self pair (a, a) of any observation; the list is sorted by the (unordered) pair of pose blocks the
+// two observations belong to, in a deterministic order (stable radix sort of a deterministic emission).
+struct PairLists {
+  unsigned long long* inc = nullptr;  // [n_inc] (p-order slot of the first observation << 32) | slot of the second
+  long long n_inc = 0;
+  double* rec = nullptr;              // per-observation records of the current linearisation (rewritten by form())
+  size_t rec_doubles = 0;             // capacity of rec
+};
+
 // Everything the formation reads; all pointers are device pointers of the solver's current linearisation.
 struct FormArgs {
   int n_obs, n_points, n_c;
+  int n_poses;                  // number of pose blocks (variable or not): bounds the sort keys of the pair lists
   int kd;                       // row stride of the intrinsics-tangent columns
   const double* Jpose;          // c-order [2 * kPoseDim][n_obs]
   const double* Jcam;           // c-order [2 * kd][n_obs]
@@ -24,6 +36,8 @@ struct FormArgs {
   const int* pt_ptr;            // [n_points + 1] p-order segments
   const int* pt_off;            // [n_points] tangent offset of the point, -1 constant
   const int *a_pose, *a_cam;    // p-order topology
+  const int* a_pt;              // p-order: point of the observation (pair-major formation only; may be NULL without it)
+  const PairLists* pairs;       // pair-major formation (see form()); NULL: the point-major kernel with one atomic per term
   const int* a_sensor;          // p-order sensor_from_rig index or NULL
   const int *pose_off, *pose_dim, *cam_off, *cam_dim;
   const int* sens_off;          // [n_sensors] tangent offset of a variable sensor_from_rig, or NULL
@@ -38,7 +52,19 @@ struct FormArgs {
 
 // S (n_c x n_c, row-major, LOWER triangle valid) = B - E C^-1 E^T of this rank's observations. S is cleared
 // inside. The LM diagonal is added separately (after the sum over ranks of a sharded solve).
+// Two formations of the same matrix:
+//  * a.pairs == NULL: one wave per 3-D point, one atomic add per term (6.4e8 of them at 1 000 images x 200 000 points);
+//  * a.pairs != NULL: pair-major. A record per observation (F = J^T E C^-1, G = J^T E: w x 3 each, and the columns of
+//    J), then one wave per 64 consecutive incidences of the sorted list: lane (r, c) accumulates
+//    -F_a[r] . G_b[c] (+ J_a[:, r] . J_a[:, c] for a self pair) in a register while the pair of blocks stays the
+//    same and adds the sum to S once per run -- 15-20 x fewer atomics, no atomic inside a run, and 4 loads of
+//    16 bytes per incidence and lane from two contiguous records instead of a point's staged observations.
 void form(const FormArgs& a, double* S, hipStream_t st);
+// Builds the lists for the topology in `a` (synchronises `st`). false: not applicable (no p-order point indices, more
+// pose blocks or incidences than the 32-bit sort keys / counts hold, records beyond 32 GB, or an allocation failed) --
+// nothing is left allocated, the caller passes pairs = NULL.
+bool build_pair_lists(const FormArgs& a, PairLists& pl, hipStream_t st);
+void free_pair_lists(PairLists& pl);
 void add_lm_diagonal(double* S, int n, const double* Dc /* D, not D^2 */, hipStream_t st);
 
 // Adds J^T J of the position priors to the lower triangle of S. J: [3][12][count] tangent columns (pose_dim

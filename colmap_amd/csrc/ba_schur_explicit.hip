@@ -26,7 +26,10 @@
 //  * Triangular solves with the stored block inverses: one launch per block step (forward and backward).
 #include "ba_schur_explicit.h"
 
+#include <hipcub/hipcub.hpp>
+
 #include <algorithm>
+#include <climits>
 #include <cmath>
 #include <stdexcept>
 #include <string>
@@ -180,6 +183,244 @@ __global__ void __launch_bounds__(64) form_kernel(FormArgs A, double* __restrict
       }
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Pair-major formation (FormArgs::pairs): records, incidence lists, one wave per 64 incidences
+// ---------------------------------------------------------------------------------------------------------
+// Record of an observation, W rows of 8 doubles, row r = column r of its camera-side Jacobian J (2 x w):
+//   { F[r][0..2], J[0][r],  G[r][0..2], J[1][r] }      F = J^T (E C^-1) (w x 3),  G = J^T E (w x 3)
+// (rows r >= w are zero), then the tangent index of every row as ints (-1 beyond w, padded to a multiple of four)
+// and four ints {pose, camera, sensor_from_rig, w}. With it the contribution of an ordered pair (a, b) of observations
+// of one point is  J_a^T (delta_ab I - E_a C^-1 E_b^T) J_b = delta_ab J_a^T J_a - F_a G_b^T.
+constexpr int rec_rows4(int W) { return (W + 3) / 4 * 4; }
+constexpr int rec_stride(int W) { return 8 * W + (rec_rows4(W) + 4) / 2; }  // doubles; even: records stay 16-byte aligned
+inline int pick_width(const FormArgs& a) {  // the instantiated widths of both formations
+  const int wmax = kPoseDim + a.kd + (a.Jsens ? 6 : 0);
+  return wmax <= 10 ? 10 : wmax <= 14 ? 14 : wmax <= 20 ? 20 : 28;
+}
+
+template <int W>
+__global__ void __launch_bounds__(128) form_records_kernel(FormArgs A, double* __restrict__ rec) {
+  constexpr int ST = rec_stride(W), W4 = rec_rows4(W);
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= A.n_obs) return;
+  const size_t N = (size_t)A.n_obs;
+  const int j = A.a_pt[a];
+  const bool var = A.pt_off[j] >= 0;
+  double e[2][3], pj[2][3];
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int m = 0; m < 3; ++m) e[r][m] = A.Jpt[(size_t)(r * 3 + m) * N + a];
+  double Ci[9];
+#pragma unroll
+  for (int m = 0; m < 9; ++m) Ci[m] = var ? A.Cinv[9 * (size_t)j + m] : 0.0;
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int m = 0; m < 3; ++m) pj[r][m] = var ? e[r][0] * Ci[m] + e[r][1] * Ci[3 + m] + e[r][2] * Ci[6 + m] : 0.0;
+  double* R = rec + (size_t)a * ST;
+  int* RI = reinterpret_cast<int*>(R + 8 * W);
+  const int c = A.a2c[a];
+  const int pi = A.a_pose[a], ci = A.a_cam[a];
+  const int si = A.a_sensor ? A.a_sensor[a] : -1;
+  const int po = A.pose_off[pi], co = A.cam_off[ci];
+  const int so = (si >= 0 && A.sens_off) ? A.sens_off[si] : -1;
+  int w = 0;
+  auto put = [&](double j0, double j1, int idx) {
+    double2* row = reinterpret_cast<double2*>(R + 8 * w);
+    row[0] = make_double2(j0 * pj[0][0] + j1 * pj[1][0], j0 * pj[0][1] + j1 * pj[1][1]);
+    row[1] = make_double2(j0 * pj[0][2] + j1 * pj[1][2], j0);
+    row[2] = make_double2(j0 * e[0][0] + j1 * e[1][0], j0 * e[0][1] + j1 * e[1][1]);
+    row[3] = make_double2(j0 * e[0][2] + j1 * e[1][2], j1);
+    RI[w] = idx;
+    ++w;
+  };
+  if (po >= 0) {
+    const int pdim = A.pose_dim[pi];
+    for (int d = 0; d < pdim; ++d) put(A.Jpose[(size_t)d * N + c], A.Jpose[(size_t)(kPoseDim + d) * N + c], po + d);
+  }
+  if (co >= 0) {
+    const int cdim = A.cam_dim[ci];
+    for (int d = 0; d < cdim; ++d) put(A.Jcam[(size_t)d * N + c], A.Jcam[(size_t)(A.kd + d) * N + c], co + d);
+  }
+  if (so >= 0)
+    for (int d = 0; d < 6; ++d) put(A.Jsens[(size_t)d * N + c], A.Jsens[(size_t)(6 + d) * N + c], so + d);
+  const int wv = w;
+  for (; w < W; ++w) {
+    double2* row = reinterpret_cast<double2*>(R + 8 * w);
+    row[0] = row[1] = row[2] = row[3] = make_double2(0.0, 0.0);
+    RI[w] = -1;
+  }
+  for (int r = W; r < W4; ++r) RI[r] = -1;
+  RI[W4] = pi;
+  RI[W4 + 1] = ci;
+  RI[W4 + 2] = si;
+  RI[W4 + 3] = wv;
+}
+
+// Number of incidences of every point (self pairs of all its observations; the unordered pairs too when the point
+// is variable -- a constant point couples nothing), n_points + 1 entries for the exclusive scan.
+__global__ void inc_count_kernel(FormArgs A, unsigned long long* __restrict__ cnt) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j > A.n_points) return;
+  unsigned long long v = 0ull;
+  if (j < A.n_points) {
+    const unsigned long long t = (unsigned long long)(A.pt_ptr[j + 1] - A.pt_ptr[j]);
+    v = A.pt_off[j] >= 0 ? t * (t + 1) / 2 : t;
+  }
+  cnt[j] = v;
+}
+
+// The incidences of point j at off[j] ...: key = the unordered pair of pose blocks as a triangular index, value =
+// the two p-order slots, the observation of the higher pose block first.
+__global__ void inc_emit_kernel(FormArgs A, const unsigned long long* __restrict__ off, unsigned* __restrict__ keys,
+                                unsigned long long* __restrict__ vals) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= A.n_points) return;
+  const int beg = A.pt_ptr[j], t = A.pt_ptr[j + 1] - beg;
+  const bool var = A.pt_off[j] >= 0;
+  unsigned long long o = off[j];
+  auto tri = [](unsigned long long hi, unsigned long long lo) { return (unsigned)(hi * (hi + 1) / 2 + lo); };
+  for (int a = 0; a < t; ++a) {
+    const unsigned long long sa = (unsigned long long)(beg + a);
+    const unsigned long long pa = (unsigned long long)A.a_pose[beg + a];
+    keys[o] = tri(pa, pa);
+    vals[o] = (sa << 32) | sa;
+    ++o;
+    if (!var) continue;
+    for (int b = a + 1; b < t; ++b) {
+      const unsigned long long sb = (unsigned long long)(beg + b);
+      const unsigned long long pb = (unsigned long long)A.a_pose[beg + b];
+      const bool a_first = pa >= pb;
+      keys[o] = a_first ? tri(pa, pb) : tri(pb, pa);
+      vals[o] = a_first ? ((sa << 32) | sb) : ((sb << 32) | sa);
+      ++o;
+    }
+  }
+}
+
+// One wave per 64 consecutive incidences. Lane -> the entries e = lane + 64 j of the W x W block, e = (r, c): row r of
+// the first observation's record against row c of the second's. A run = consecutive incidences whose two observations
+// have the same (pose, camera, sensor) triples (normally: the same two images): the targets in S are the same, the sum
+// stays in a register and goes to S once, with one (integer, for FIXED) atomic add per entry -- runs of one pair of
+// blocks can straddle waves, and blocks shared between images (intrinsics, rig poses) are reached from many pairs.
+// Lower triangle: an unordered pair {a, b} stands for both ordered pairs, (a, b) at (idx_a[r], idx_b[c]) and its
+// transpose; exactly one of the two lies in the lower triangle unless the indices are equal (a shared block's
+// diagonal), where both do: weight 2. A self pair is one ordered pair: entries with idx[r] >= idx[c] only.
+// The order of the additions inside a run is the order of the sorted list (deterministic); across runs the
+// fixed-point atomics are order-independent: the tier stays bit-reproducible.
+template <int W, bool FIXED>
+__global__ void __launch_bounds__(64, (W * W + 63) / 64 <= 2 ? 8 : 1) form_pairs_kernel(FormArgs A, const unsigned long long* __restrict__ inc,
+                                                        long long n_inc, const double* __restrict__ rec,
+                                                        double* __restrict__ S) {
+  constexpr int ST = rec_stride(W), W4 = rec_rows4(W), NE = (W * W + 63) / 64;
+  const int lane = threadIdx.x;
+  const long long base = (long long)blockIdx.x * 64;
+  const int cnt = (int)(n_inc - base < 64 ? n_inc - base : 64);
+  const unsigned long long mine = lane < cnt ? inc[base + lane] : 0ull;
+  const int mine_hi = (int)(unsigned)(mine >> 32), mine_lo = (int)(unsigned)mine;
+  int er[NE], ec[NE];
+  double acc[NE];
+  float wgt[NE];     // 0: no such entry / upper triangle; 1; 2: the diagonal of a block both observations share
+  unsigned tgt[NE];  // element index in S (n_c < 65 536: form() checks)
+#pragma unroll
+  for (int j = 0; j < NE; ++j) {
+    const int e = lane + 64 * j;
+    er[j] = e / W;  // (>= W: no such entry)
+    ec[j] = e % W;
+    acc[j] = 0.0;
+    wgt[j] = 0.f;
+    tgt[j] = 0u;
+  }
+  const unsigned n = (unsigned)A.n_c;
+  int s0 = -2, s1 = -2, s2 = -2, s3 = -2, s4 = -2, s5 = -2;
+  bool cself = false;
+  auto flush = [&]() {
+#pragma unroll
+    for (int j = 0; j < NE; ++j) {
+      if (wgt[j] != 0.f) {
+        const double val = acc[j] * (double)wgt[j];
+        if (FIXED) {
+          if (!(fabs(val) < kFixedTermBound) && A.bad) *A.bad = 1;  // (every writer stores the same value)
+          atomicAdd(reinterpret_cast<unsigned long long*>(S) + tgt[j],
+                    (unsigned long long)(long long)__double2ll_rn(val * kFixedScale));
+        } else {
+          unsafeAtomicAdd(S + tgt[j], val);
+        }
+      }
+      acc[j] = 0.0;
+    }
+  };
+  // (A second register set that prefetches incidence t + 1 under the arithmetic of incidence t was built and dropped:
+  //  it costs as many registers as it hides latency -- 116 VGPRs = 4 waves per SIMD with two incidences in flight each
+  //  against 64 = 8 waves with one -- and the compiler's wait counts around the conditional loads of self pairs serialise
+  //  the two sets anyway.)
+  struct Batch {
+    const double *rh, *rl;
+    bool self;
+    int h0, h1, h2, l0, l1, l2;
+    double2 f0[NE], f1[NE], g0[NE], g1[NE];
+    double j1r[NE], j0c[NE];
+  };
+  auto load = [&](int t, Batch& B) {
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane(mine_hi, t), lo = (unsigned)__builtin_amdgcn_readlane(mine_lo, t);
+    B.rh = rec + (size_t)hi * ST;
+    B.rl = rec + (size_t)lo * ST;
+    B.self = hi == lo;
+#pragma unroll
+    for (int j = 0; j < NE; ++j) {
+      const int r = er[j] < W ? er[j] : 0;
+      const double2* fr = reinterpret_cast<const double2*>(B.rh + 8 * r);
+      const double2* gr = reinterpret_cast<const double2*>(B.rl + 8 * ec[j]);
+      B.f0[j] = fr[0];
+      B.f1[j] = fr[1];
+      B.g0[j] = gr[2];
+      B.g1[j] = gr[3];
+      // a self pair adds J[:, r] . J[:, c]: J[0][r] and J[1][c] come with the two halves above
+      B.j1r[j] = B.self ? B.rh[8 * r + 7] : 0.0;
+      B.j0c[j] = B.self ? B.rl[8 * ec[j] + 3] : 0.0;
+    }
+    const int* hh = reinterpret_cast<const int*>(B.rh + 8 * W);
+    const int* hl = reinterpret_cast<const int*>(B.rl + 8 * W);
+    B.h0 = hh[W4]; B.h1 = hh[W4 + 1]; B.h2 = hh[W4 + 2];
+    B.l0 = hl[W4]; B.l1 = hl[W4 + 1]; B.l2 = hl[W4 + 2];
+  };
+  auto process = [&](const Batch& B) {
+    if (B.h0 != s0 || B.h1 != s1 || B.h2 != s2 || B.l0 != s3 || B.l1 != s4 || B.l2 != s5 || B.self != cself) {
+      flush();
+      s0 = B.h0; s1 = B.h1; s2 = B.h2; s3 = B.l0; s4 = B.l1; s5 = B.l2;
+      cself = B.self;
+      const int* hh = reinterpret_cast<const int*>(B.rh + 8 * W);
+      const int* hl = reinterpret_cast<const int*>(B.rl + 8 * W);
+#pragma unroll
+      for (int j = 0; j < NE; ++j) {
+        const int ih = er[j] < W ? hh[er[j]] : -1;
+        const int il = hl[ec[j]];
+        const bool valid = ih >= 0 && il >= 0;
+        if (B.self) {
+          wgt[j] = (valid && ih >= il) ? 1.f : 0.f;
+          tgt[j] = valid ? (unsigned)ih * n + (unsigned)il : 0u;
+        } else {
+          wgt[j] = valid ? (ih == il ? 2.f : 1.f) : 0.f;
+          tgt[j] = valid ? (unsigned)(ih > il ? ih : il) * n + (unsigned)(ih > il ? il : ih) : 0u;
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NE; ++j) {
+      double v = -(B.f0[j].x * B.g0[j].x + B.f0[j].y * B.g0[j].y + B.f1[j].x * B.g1[j].x);
+      if (B.self) v += B.f1[j].y * B.j0c[j] + B.j1r[j] * B.g1[j].y;
+      acc[j] += v;
+    }
+  };
+  Batch b0;
+  for (int t = 0; t < cnt; ++t) {
+    load(t, b0);
+    process(b0);
+  }
+  flush();
 }
 
 // in place: 64-bit fixed point -> double (lower triangle; the upper one is never read)
@@ -592,17 +833,103 @@ void form(const FormArgs& a, double* S, hipStream_t st) {
   BAX_HIP(hipMemsetAsync(S, 0, n * n * sizeof(double), st));
   if (a.bad) BAX_HIP(hipMemsetAsync(a.bad, 0, sizeof(int), st));
   if (a.n_points <= 0 || a.n_obs <= 0) return;
-  const int wmax = kPoseDim + a.kd + (a.Jsens ? 6 : 0);
+  const int width = pick_width(a);
+  if (a.pairs && a.pairs->inc && a.pairs->n_inc > 0 && a.a_pt && a.n_c < 65536) {
+    const PairLists& pl = *a.pairs;
+    const unsigned go = (unsigned)((a.n_obs + 127) / 128), gp = (unsigned)((pl.n_inc + 63) / 64);
+#define BAX_PAIRS(W)                                                                                                       \
+  do {                                                                                                                     \
+    if (pl.rec_doubles < (size_t)a.n_obs * rec_stride(W)) throw std::runtime_error("pair lists: record buffer");            \
+    hipLaunchKernelGGL((form_records_kernel<W>), dim3(go), dim3(128), 0, st, a, pl.rec);                                   \
+    if (a.fixed_point)                                                                                                     \
+      hipLaunchKernelGGL((form_pairs_kernel<W, true>), dim3(gp), dim3(64), 0, st, a, pl.inc, pl.n_inc, pl.rec, S);         \
+    else                                                                                                                   \
+      hipLaunchKernelGGL((form_pairs_kernel<W, false>), dim3(gp), dim3(64), 0, st, a, pl.inc, pl.n_inc, pl.rec, S);        \
+  } while (0)
+    if (width == 10) BAX_PAIRS(10);
+    else if (width == 14) BAX_PAIRS(14);
+    else if (width == 20) BAX_PAIRS(20);
+    else BAX_PAIRS(28);
+#undef BAX_PAIRS
+    return;
+  }
 #define BAX_FORM(W)                                                                                              \
   do {                                                                                                           \
     if (a.fixed_point) hipLaunchKernelGGL((form_kernel<W, true>), dim3(a.n_points), dim3(64), 0, st, a, S);      \
     else hipLaunchKernelGGL((form_kernel<W, false>), dim3(a.n_points), dim3(64), 0, st, a, S);                   \
   } while (0)
-  if (wmax <= 10) BAX_FORM(10);
-  else if (wmax <= 14) BAX_FORM(14);
-  else if (wmax <= 20) BAX_FORM(20);
+  if (width == 10) BAX_FORM(10);
+  else if (width == 14) BAX_FORM(14);
+  else if (width == 20) BAX_FORM(20);
   else BAX_FORM(28);
 #undef BAX_FORM
+}
+
+void free_pair_lists(PairLists& pl) {
+  if (pl.inc) (void)hipFree(pl.inc);
+  if (pl.rec) (void)hipFree(pl.rec);
+  pl = PairLists{};
+}
+
+bool build_pair_lists(const FormArgs& a, PairLists& pl, hipStream_t st) {
+  free_pair_lists(pl);
+  if (!a.a_pt || a.n_points <= 0 || a.n_obs <= 0 || a.n_poses <= 0) return false;
+  if ((unsigned long long)a.n_poses * ((unsigned long long)a.n_poses + 1) / 2 > 0xffffffffull) return false;
+  const size_t rec_doubles = (size_t)a.n_obs * rec_stride(pick_width(a));
+  if (rec_doubles * sizeof(double) > ((size_t)32 << 30)) return false;
+  unsigned long long *cnt = nullptr, *off = nullptr, *vals_in = nullptr, *vals_out = nullptr;
+  unsigned *keys_in = nullptr, *keys_out = nullptr;
+  void* tmp = nullptr;
+  double* rec = nullptr;
+  auto release = [&](bool keep) {
+    if (cnt) (void)hipFree(cnt);
+    if (off) (void)hipFree(off);
+    if (vals_in) (void)hipFree(vals_in);
+    if (keys_in) (void)hipFree(keys_in);
+    if (keys_out) (void)hipFree(keys_out);
+    if (tmp) (void)hipFree(tmp);
+    if (!keep) {
+      if (vals_out) (void)hipFree(vals_out);
+      if (rec) (void)hipFree(rec);
+      (void)hipGetLastError();  // an allocation that failed is not an error of the solve
+    }
+  };
+  auto alloc = [&](void** p_, size_t bytes) { return hipMalloc(p_, bytes ? bytes : 1) == hipSuccess; };
+  const int np1 = a.n_points + 1;
+  size_t scan_bytes = 0;
+  if (hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, cnt, off, np1) != hipSuccess) return false;
+  if (!alloc((void**)&cnt, sizeof(*cnt) * np1) || !alloc((void**)&off, sizeof(*off) * np1) || !alloc(&tmp, scan_bytes)) {
+    release(false);
+    return false;
+  }
+  hipLaunchKernelGGL(inc_count_kernel, dim3((unsigned)((np1 + 255) / 256)), dim3(256), 0, st, a, cnt);
+  BAX_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, scan_bytes, cnt, off, np1, st));
+  unsigned long long total = 0;
+  BAX_HIP(hipMemcpyAsync(&total, off + a.n_points, sizeof(total), hipMemcpyDeviceToHost, st));
+  BAX_HIP(hipStreamSynchronize(st));
+  (void)hipFree(tmp);
+  tmp = nullptr;
+  if (total == 0 || total > (unsigned long long)INT_MAX) {
+    release(false);
+    return false;
+  }
+  size_t sort_bytes = 0;
+  if (hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, keys_in, keys_out, vals_in, vals_out, (int)total) != hipSuccess ||
+      !alloc((void**)&keys_in, sizeof(unsigned) * total) || !alloc((void**)&keys_out, sizeof(unsigned) * total) ||
+      !alloc((void**)&vals_in, sizeof(*vals_in) * total) || !alloc((void**)&vals_out, sizeof(*vals_out) * total) ||
+      !alloc(&tmp, sort_bytes) || !alloc((void**)&rec, sizeof(double) * rec_doubles)) {
+    release(false);
+    return false;
+  }
+  hipLaunchKernelGGL(inc_emit_kernel, dim3((unsigned)((a.n_points + 127) / 128)), dim3(128), 0, st, a, off, keys_in, vals_in);
+  BAX_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, sort_bytes, keys_in, keys_out, vals_in, vals_out, (int)total, 0, 32, st));
+  BAX_HIP(hipStreamSynchronize(st));
+  release(true);
+  pl.inc = vals_out;
+  pl.n_inc = (long long)total;
+  pl.rec = rec;
+  pl.rec_doubles = rec_doubles;
+  return true;
 }
 
 void finish(double* S, int n_c, bool fixed_point, const int* bad, hipStream_t st) {

@@ -332,6 +332,8 @@ inline float __shfl_xor(float v, int mask, int = 64) { return __shfl(v, hip_emul
 inline double __shfl_xor(double v, int mask, int = 64) { return __shfl(v, hip_emul::lane_id() ^ mask); }
 inline int __shfl_down(int v, int d, int = 64) { return __shfl(v, hip_emul::lane_id() + d < 64 ? hip_emul::lane_id() + d : hip_emul::lane_id()); }
 inline double __shfl_down(double v, int d, int = 64) { return __shfl(v, hip_emul::lane_id() + d < 64 ? hip_emul::lane_id() + d : hip_emul::lane_id()); }
+// v_readlane_b32 with a wave-uniform lane select
+inline int __builtin_amdgcn_readlane(int v, int src) { return (int)(unsigned)hip_emul_shfl_bits((unsigned)v, src); }
 inline int __builtin_amdgcn_readfirstlane(int v) {
   return (int)(unsigned)hip_emul::collective((unsigned)v, [](const unsigned long long* s, int n) {
     for (int i = 1; i < n; ++i)

@@ -110,9 +110,9 @@ def test_rigs_priors_and_robust_loss():
 # ------------------------------------------------------------------------------------------------
 
 class _FormArgs(C.Structure):
-    _fields_ = [("n_obs", C.c_int), ("n_points", C.c_int), ("n_c", C.c_int), ("kd", C.c_int)] + \
+    _fields_ = [("n_obs", C.c_int), ("n_points", C.c_int), ("n_c", C.c_int), ("n_poses", C.c_int), ("kd", C.c_int)] + \
                [(n, C.c_void_p) for n in ("Jpose", "Jcam", "Jsens", "Jpt", "Cinv", "a2c", "pt_ptr", "pt_off", "a_pose", "a_cam",
-                                          "a_sensor", "pose_off", "pose_dim", "cam_off", "cam_dim", "sens_off")] + \
+                                          "a_pt", "pairs", "a_sensor", "pose_off", "pose_dim", "cam_off", "cam_dim", "sens_off")] + \
                [("fixed_point", C.c_bool), ("bad", C.c_void_p)]
 
 
@@ -121,10 +121,18 @@ class _Workspace(C.Structure):
                 ("ev_panel", C.c_void_p), ("ev_u2", C.c_void_p), ("min_rows128", C.c_int)]
 
 
-def _explicit_entry_points():
+class _PairLists(C.Structure):
+    _fields_ = [("inc", C.c_void_p), ("n_inc", C.c_longlong), ("rec", C.c_void_p), ("rec_doubles", C.c_size_t)]
+
+
+def _explicit_entry_points(pairs=False):
     L = _emul_lib()
     names = subprocess.run(["nm", "-D", "--defined-only", L._name], capture_output=True, text=True, check=True).stdout.split()
     pick = lambda key: getattr(L, next(n for n in names if key in n))
+    if pairs:
+        build, free = pick("ba_explicit16build_pair_listsE"), pick("ba_explicit15free_pair_listsE")
+        build.restype = C.c_bool
+        return build, free
     return pick("ba_explicit4formE"), pick("ba_explicit6finishE"), pick("ba_explicit12factor_solveE")
 
 
@@ -174,6 +182,126 @@ def test_fixed_point_formation_and_its_overflow_flag(scale, expect_bad):
     factor_solve(S.ctypes.data_as(C.c_void_p), C.c_int(n_c), rhs.ctypes.data_as(C.c_void_p), x.ctypes.data_as(C.c_void_p),
                  C.byref(ws), None, None, None, None)
     assert info[0] == 1 and np.isnan(x).all()
+
+
+def _random_formation_problem(seed, n_poses, n_points, shared_cams, rigs):
+    """A random linearisation in the layouts FormArgs describes (c-order planes, p-order point columns, p-order
+    topology) with constant poses / cameras / points, tracks of 1-7 observations, optionally cameras shared between
+    images and rig frames (several images per pose block, each with its own sensor_from_rig block)."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    n_cams = 2 if shared_cams else n_poses
+    n_sens = 3 if rigs else 0
+    obs = []  # (point, pose, cam, sensor)
+    for j in range(n_points):
+        t = int(rng.integers(1, 8))
+        images = set()
+        while len(images) < t:
+            pose = int(rng.integers(n_poses))
+            sens = int(rng.integers(n_sens)) if rigs else -1
+            images.add((pose, sens))
+        for pose, sens in sorted(images):
+            obs.append((j, pose, pose % n_cams, sens))
+    N = len(obs)
+    perm = rng.permutation(N)  # p-order slot a -> c-order slot
+    off = 0
+    pose_off, pose_dim = [], []
+    for i in range(n_poses):
+        d = [6, 6, 6, 5, 0][int(rng.integers(5))]
+        pose_dim.append(d); pose_off.append(off if d else -1); off += d
+    cam_off, cam_dim = [], []
+    for i in range(n_cams):
+        d = [2, 3, 0][int(rng.integers(3))]
+        cam_dim.append(d); cam_off.append(off if d else -1); off += d
+    sens_off = []
+    for i in range(n_sens):
+        v = bool(rng.integers(2))
+        sens_off.append(off if v else -1); off += 6 if v else 0
+    n_c = off
+    pt_off = [(-1 if rng.integers(5) == 0 else 3 * j) for j in range(n_points)]
+    scale = 0.08
+    Jpose, Jcam, Jsens = (scale * rng.uniform(-1, 1, (12, N)) for _ in range(3))
+    Jcam = scale * rng.uniform(-1, 1, (8, N))
+    Jpt = scale * rng.uniform(-1, 1, (6, N))
+    pt_ptr = np.zeros(n_points + 1, np.int32)
+    for j, *_ in obs:
+        pt_ptr[j + 1] += 1
+    pt_ptr = np.cumsum(pt_ptr).astype(np.int32)
+    Cinv = np.zeros((n_points, 9))
+    want = np.zeros((n_c, n_c))
+    for j in range(n_points):
+        sl = range(pt_ptr[j], pt_ptr[j + 1])
+        E = {a: Jpt[:, a].reshape(2, 3) for a in sl}
+        Ci = np.linalg.inv(sum(E[a].T @ E[a] for a in sl) + 0.01 * np.eye(3))
+        Cinv[j] = Ci.reshape(9)
+        cols = {}
+        for a in sl:
+            _, pose, cam, sens = obs[a]
+            c = perm[a]
+            J, idx = [], []
+            if pose_off[pose] >= 0:
+                for d in range(pose_dim[pose]):
+                    J.append((Jpose[d, c], Jpose[6 + d, c])); idx.append(pose_off[pose] + d)
+            if cam_off[cam] >= 0:
+                for d in range(cam_dim[cam]):
+                    J.append((Jcam[d, c], Jcam[4 + d, c])); idx.append(cam_off[cam] + d)
+            if sens >= 0 and sens_off[sens] >= 0:
+                for d in range(6):
+                    J.append((Jsens[d, c], Jsens[6 + d, c])); idx.append(sens_off[sens] + d)
+            cols[a] = (np.array(J).reshape(-1, 2).T, idx)
+        for a in sl:
+            for b in sl:
+                if pt_off[j] < 0 and a != b:
+                    continue
+                M = (np.eye(2) if a == b else 0.0) - (E[a] @ Ci @ E[b].T if pt_off[j] >= 0 else 0.0)
+                (Ja, ia), (Jb, ib) = cols[a], cols[b]
+                if ia and ib:
+                    want[np.ix_(ia, ib)] += Ja.T @ M @ Jb
+    ints = lambda v: np.ascontiguousarray(v, np.int32)
+    arrs = dict(Jpose=np.ascontiguousarray(Jpose), Jcam=np.ascontiguousarray(Jcam), Jpt=np.ascontiguousarray(Jpt),
+                Cinv=np.ascontiguousarray(Cinv), a2c=ints(perm), pt_ptr=ints(pt_ptr), pt_off=ints(pt_off),
+                a_pose=ints([o[1] for o in obs]), a_cam=ints([o[2] for o in obs]), a_pt=ints([o[0] for o in obs]),
+                pose_off=ints(pose_off), pose_dim=ints(pose_dim), cam_off=ints(cam_off), cam_dim=ints(cam_dim))
+    if rigs:
+        arrs.update(Jsens=np.ascontiguousarray(Jsens), a_sensor=ints([o[3] for o in obs]), sens_off=ints(sens_off))
+    return dict(N=N, n_points=n_points, n_c=n_c, n_poses=n_poses, arrs=arrs, want=want)
+
+
+@pytest.mark.parametrize("shared_cams,rigs,fixed", [(False, False, True), (True, False, True), (True, True, True),
+                                                    (True, True, False)])
+def test_pair_major_formation_against_numpy_and_the_point_major_kernel(shared_cams, rigs, fixed):
+    """form() both ways on a random linearisation -- per-image cameras; cameras shared between images (their blocks are
+    reached from many pairs of images, and a pair of observations of one shared block meets its diagonal twice); rig
+    frames (several images per pose block: runs of one pair of pose blocks change their targets) -- with constant poses,
+    cameras, sensors and points and 5-wide pose blocks: the pair-major formation (records, incidence lists sorted by
+    pose pair, one wave per 64 incidences) and the point-major kernel (one atomic per term) against numpy, fixed-point
+    and fp64 accumulation."""
+    import numpy as np
+    form, finish, _ = _explicit_entry_points()
+    build, free = _explicit_entry_points(pairs=True)
+    P = _random_formation_problem(11 + 2 * shared_cams + rigs, n_poses=9, n_points=60, shared_cams=shared_cams, rigs=rigs)
+    bad = np.zeros(1, np.int32)
+    fa = _FormArgs(n_obs=P["N"], n_points=P["n_points"], n_c=P["n_c"], n_poses=P["n_poses"], kd=4, fixed_point=fixed,
+                   bad=bad.ctypes.data)
+    for k, v in P["arrs"].items():
+        setattr(fa, k, v.ctypes.data)
+    n_c, low = P["n_c"], np.tril_indices(P["n_c"])
+    assert np.abs(P["want"]).max() < 1.0
+    got = {}
+    for which in ("points", "pairs"):
+        pl = _PairLists()
+        if which == "pairs":
+            assert build(C.byref(fa), C.byref(pl), None) and pl.n_inc >= P["N"]
+            fa.pairs = C.addressof(pl)
+        S = np.full((n_c, n_c), 7.0)
+        form(C.byref(fa), S.ctypes.data_as(C.c_void_p), None)
+        finish(S.ctypes.data_as(C.c_void_p), C.c_int(n_c), C.c_bool(fixed), bad.ctypes.data_as(C.c_void_p), None)
+        fa.pairs = None
+        free(C.byref(pl))
+        assert bad[0] == 0 and pl.inc is None
+        np.testing.assert_allclose(S[low], P["want"][low], rtol=0, atol=2e-15)
+        got[which] = S[low]
+    np.testing.assert_allclose(got["pairs"], got["points"], rtol=0, atol=1e-15)
 
 
 def _factor_solve_directly(A, rhs, min_rows128):
