@@ -410,8 +410,9 @@ __global__ void __launch_bounds__(64, (W * W + 63) / 64 <= 2 ? 8 : 1) form_pairs
     }
 #pragma unroll
     for (int j = 0; j < NE; ++j) {
-      double v = -(B.f0[j].x * B.g0[j].x + B.f0[j].y * B.g0[j].y + B.f1[j].x * B.g1[j].x);
-      if (B.self) v += B.f1[j].y * B.j0c[j] + B.j1r[j] * B.g1[j].y;
+      double v = fma(B.f1[j].x, B.g1[j].x, fma(B.f0[j].y, B.g0[j].y, B.f0[j].x * B.g0[j].x));
+      if (B.self) v = fma(B.f1[j].y, B.j0c[j], B.j1r[j] * B.g1[j].y) - v;
+      else v = -v;
       acc[j] += v;
     }
   };
@@ -507,7 +508,7 @@ __global__ void __launch_bounds__(128) chol_diag_kernel(double* __restrict__ S, 
       col[c & 1][lane] = a[c];
       __syncthreads();  // column c (its entry c is the pivot) is published; the other buffer is free again
 #pragma unroll
-      for (int cc = c + 1; cc < NB; ++cc) a[cc] -= l * col[c & 1][cc];
+      for (int cc = c + 1; cc < NB; ++cc) a[cc] = fma(-l, col[c & 1][cc], a[cc]);  // (the library is built with -ffp-contract=off)
     }
     const bool okp = dmine > 0.0;
     if (!okp) *info = 1;
@@ -528,7 +529,7 @@ __global__ void __launch_bounds__(128) chol_diag_kernel(double* __restrict__ S, 
       const double yr = a[r] * (1.0 / col[r & 1][r]);
       a[r] = yr;
 #pragma unroll
-      for (int rr = r + 1; rr < NB; ++rr) a[rr] -= yr * col[r & 1][rr];
+      for (int rr = r + 1; rr < NB; ++rr) a[rr] = fma(-yr, col[r & 1][rr], a[rr]);
     }
     __syncthreads();
 #pragma unroll
