@@ -75,6 +75,7 @@ def test_exact_tiers():
     """DENSE_SCHUR / AUTO against the checker's exact tier; explicit formation against operator products."""
     G.test_dense_schur_tier_matches_oracle()
     G.test_exact_tier_explicit_formation_equals_operator_products()
+    G.test_exact_tier_pair_major_formation_equals_point_major(60, 3000, 6, True)
 
 
 def test_blocked_cholesky_beyond_one_panel():

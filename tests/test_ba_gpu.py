@@ -851,6 +851,33 @@ def test_exact_tier_is_bit_reproducible():
     assert np.array_equal(runs[0][0].poses, runs[1][0].poses) and np.array_equal(runs[0][0].points, runs[1][0].points)
 
 
+@pytest.mark.parametrize("frames,points,track,shared", [(120, 6000, 8, False), (60, 3000, 6, True)])
+def test_exact_tier_pair_major_formation_equals_point_major(frames, points, track, shared):
+    """The two formations of the reduced camera system (ba_schur_explicit.h: form) inside whole solves: pair-major
+    (records + sorted incidence lists, one wave per 64 incidences, runs accumulated in registers; the default) against
+    point-major (one wave per point, one atomic per term; COLMAP_AMD_BA_FORM_PAIRS=0). Different summation orders of
+    the same terms: the exact Newton steps agree to rounding. With cameras shared between images the intrinsics blocks
+    are reached from every pair of images (the atomics of the pair-major flush) and pairs of observations of one shared
+    block meet its diagonal twice."""
+    d = scene.synthesize_flat(frames, points, track, seed=frames, noise=scene.SyntheticNoiseOptions(0.01, 0.5, 0.03, 0.5))
+    if shared:
+        d["obs_cam"] = (d["obs_cam"] % 3).astype(np.int32)
+        d["cams"] = d["cams"][:3].copy()
+        d["cam_model"] = d["cam_model"][:3].copy()
+    fp = est.FlatProblem.from_arrays(d)
+    assert est.fix_gauge_two_cams(fp)
+    fp.point_const[::11] = 1
+    so = dict(max_num_iterations=4, linear_solver_type=est.SOLVER_SPARSE_SCHUR)
+    b0, s0 = _solve_env(fp, {"COLMAP_AMD_BA_FORM_PAIRS": "0"}, **so)
+    b1, s1 = _solve_env(fp, {"COLMAP_AMD_BA_FORM_PAIRS": "1"}, **so)
+    assert s0.linear_solver_used == s1.linear_solver_used == est.SOLVER_SPARSE_SCHUR
+    assert len(s1.log_cost) == len(s0.log_cost)
+    np.testing.assert_allclose(s1.log_cost, s0.log_cost, rtol=1e-11)
+    np.testing.assert_allclose(b1.points, b0.points, atol=1e-9)
+    np.testing.assert_allclose(b1.poses, b0.poses, atol=1e-9)
+    np.testing.assert_allclose(b1.cams, b0.cams, rtol=1e-9, atol=1e-9)
+
+
 def test_exact_tier_explicit_formation_equals_operator_products():
     """The explicit formation against the round-2 formation of the same matrix (n_c implicit operator products,
     one-workgroup Cholesky; kept behind COLMAP_AMD_BA_DENSE_BY_PRODUCTS for image-sharded solves): shared
