@@ -475,6 +475,14 @@ __global__ void prior_rows_kernel(double* __restrict__ S, int n, const double* _
 // Blocked Cholesky
 // ---------------------------------------------------------------------------------------------------------
 
+// v_readlane_b32 x 2 (HIP's __shfl is a ds_bpermute: an LDS round trip on the critical chain of the kernel below)
+__device__ __forceinline__ double readlane_f64(double v, int src) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, src);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), src);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 // Diagonal block [k0, k0 + kb): L_kk in place (lower), its inverse (64 x 64, zero-padded) to Linv.
 // TWO WAVES, each with a 64 x 64 matrix in registers (64 doubles = 128 VGPRs per lane; every loop below is unrolled
 // so that the register indices are compile-time constants):
@@ -509,7 +517,7 @@ __global__ void __launch_bounds__(128) chol_diag_kernel(double* __restrict__ S, 
     double dmine = 0.0;                                // pivot of column `lane` (final after step lane - 1)
 #pragma unroll
     for (int c = 0; c < NB; ++c) {
-      const double d = __shfl(a[c], c);
+      const double d = readlane_f64(a[c], c);
       dmine = lane == c ? a[c] : dmine;
       const double l = a[c] * (1.0 / d);  // multiplier of row `lane` (rows <= c: a don't-care)
       col[c & 1][lane] = a[c];
@@ -524,7 +532,7 @@ __global__ void __launch_bounds__(128) chol_diag_kernel(double* __restrict__ S, 
     __syncthreads();
 #pragma unroll
     for (int c = 0; c < NB; ++c) {
-      const double v = a[c] * __shfl(rs, c);
+      const double v = a[c] * readlane_f64(rs, c);
       Ls[lane][c] = c < lane ? v : (c == lane ? dmine * rs : 0.0);
     }
   } else {
