@@ -1688,17 +1688,24 @@ __global__ void __launch_bounds__(64) ba_block_gram_kernel(View V, const double*
 // The same contraction with the operands staged through LDS: per trip the wave loads 32 consecutive
 // observations of every Jacobian column of the block (and of G) as contiguous 256-byte segments -- half a
 // wave per (row, column) pair -- and the 16 slabs of the trip feed the matrix core from LDS. In the kernel
-// above every lane loads its own operand: 16 different columns per load instruction. Same slab order, same
-// zero padding: the accumulated tile is bit-identical.
+// above every lane loads its own operand: 16 different columns per load instruction. Same slabs, same zero
+// padding; the trips of a chunk are dealt to four waves whose tiles are added at the end, so the result differs
+// from the kernel above by the order of the additions (rounding).
 constexpr int GRAM_TRIP = 32;
+constexpr int GRAM_WAVES = 4;
 template <int BD>  // widest block of the problem: bounds the prefetch registers (6, 8 or 16 column pairs per lane)
-__global__ void __launch_bounds__(64) ba_block_gram_lds_kernel(View V, const double* __restrict__ G) {
-  __shared__ double sJ[2][16][GRAM_TRIP + 1];  // [row][column][observation], padded against bank conflicts
-  __shared__ double sG[3][GRAM_TRIP];
+__global__ void __launch_bounds__(64 * GRAM_WAVES) ba_block_gram_lds_kernel(View V, const double* __restrict__ G) {
+  // One workgroup per chunk, FOUR waves, wave w taking the trips w, w + 4, ... of the chunk with its own LDS tile and
+  // accumulator; the four partial tiles are added in wave order at the end (a fixed tree). One wave per chunk left
+  // ~2 waves per SIMD on the chip (a chunk is up to 2 048 observations, a camera one or two chunks), each a serial
+  // chain of 64 trips of (LDS round trip + 16 dependent-issue matrix-core instructions): latency, not bandwidth.
+  __shared__ double sJ[GRAM_WAVES][2][16][GRAM_TRIP + 1];  // [wave][row][column][observation], padded against bank conflicts
+  __shared__ double sG[GRAM_WAVES][3][GRAM_TRIP];
+  __shared__ double sAcc[GRAM_WAVES - 1][4][64];
   const int ch = blockIdx.x;
   const int b = V.chunk_blk[ch];
   const int kind = V.blk_kind[b], dim = V.blk_dim[b];
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 15, k = lane >> 4;  // column, row-in-slab
   const int r = k & 1, oo = k >> 1;        // residual row, observation within the slab
   const int half = lane >> 5, lo = lane & 31;
@@ -1706,10 +1713,9 @@ __global__ void __launch_bounds__(64) ba_block_gram_lds_kernel(View V, const dou
   const size_t N = (size_t)V.n_obs;
   v4f64 acc = {0.0, 0.0, 0.0, 0.0};
   const bool col_ok = i < dim;
-  // The operands of trip t + 1 are loaded into registers while the matrix core works on trip t (a lane's
+  // The operands of the wave's next trip are loaded into registers while the matrix core works on this one (a lane's
   // share: one 32-observation segment of <= 16 (row, column) pairs -- pairs cr = half, half + 2, ... -- and
-  // up to two entries of G): the global-load latency used to sit between every two trips of a wave. Same
-  // values in the same LDS slots: bit-identical tiles.
+  // up to two entries of G).
   double pj[BD], pg[2];
   auto prefetch = [&](int s) {
     const int n = min(GRAM_TRIP, end - s);
@@ -1725,38 +1731,54 @@ __global__ void __launch_bounds__(64) ba_block_gram_lds_kernel(View V, const dou
       pg[q] = (e < 3 * GRAM_TRIP && o < n) ? G[(size_t)g * N + s + o] : 0.0;
     }
   };
-  if (beg < end) prefetch(beg);
-  for (int s = beg; s < end; s += GRAM_TRIP) {
+  auto wave_sync = [] {  // the tile is handed from lane to lane of ONE wave
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  };
+  constexpr int STEP = GRAM_WAVES * GRAM_TRIP;
+  const int first = beg + wave * GRAM_TRIP;
+  if (first < end) prefetch(first);
+  for (int s = first; s < end; s += STEP) {
 #pragma unroll
     for (int q = 0; q < BD; ++q) {
       const int cr = half + 2 * q;
-      if (cr < 2 * dim) sJ[cr & 1][cr >> 1][lo] = pj[q];
+      if (cr < 2 * dim) sJ[wave][cr & 1][cr >> 1][lo] = pj[q];
     }
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int e = lane + 64 * q;
-      if (e < 3 * GRAM_TRIP) sG[e / GRAM_TRIP][e % GRAM_TRIP] = pg[q];
+      if (e < 3 * GRAM_TRIP) sG[wave][e / GRAM_TRIP][e % GRAM_TRIP] = pg[q];
     }
-    __syncthreads();
-    if (s + GRAM_TRIP < end) prefetch(s + GRAM_TRIP);
+    wave_sync();
+    if (s + STEP < end) prefetch(s + STEP);
 #pragma unroll 4
     for (int u = 0; u < GRAM_TRIP / 2; ++u) {
       const int o = 2 * u + oo;
       double a = 0.0, bb = 0.0;
       if (col_ok) {
-        const double j0 = sJ[0][i][o], j1 = sJ[1][i][o];
-        const double g00 = sG[0][o], g01 = sG[1][o], g11 = sG[2][o];
+        const double j0 = sJ[wave][0][i][o], j1 = sJ[wave][1][i][o];
+        const double g00 = sG[wave][0][o], g01 = sG[wave][1][o], g11 = sG[wave][2][o];
         a = r ? j1 : j0;
         bb = r ? j1 - (g01 * j0 + g11 * j1) : j0 - (g00 * j0 + g01 * j1);
       }
       acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, acc, 0, 0, 0);
     }
-    __syncthreads();
+    wave_sync();
   }
+  if (wave > 0) {
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) sAcc[wave - 1][reg][lane] = acc[reg];
+  }
+  __syncthreads();
+  if (wave > 0) return;
 #pragma unroll
   for (int reg = 0; reg < 4; ++reg) {
     const int row = k + 4 * reg;
-    if (row < dim && i < dim) V.cpart[(size_t)ch * V.bd * V.bd + row * dim + i] = acc[reg];
+    double t = acc[reg];
+#pragma unroll
+    for (int w = 0; w < GRAM_WAVES - 1; ++w) t += sAcc[w][reg][lane];
+    if (row < dim && i < dim) V.cpart[(size_t)ch * V.bd * V.bd + row * dim + i] = t;
   }
 }
 
@@ -3645,9 +3667,9 @@ struct Solver {
           BA_LAUNCH(ba_obs_schur_g_kernel, dim3(grid_for(V.n_obs, 256)), dim3(256), st, V, Cinv.p, Gobs.p);
           BA_HIP(hipEventRecord(ev2, st));
           static const bool gram_lds = [] { const char* e = std::getenv("COLMAP_AMD_BA_GRAM_LDS"); return !e || std::atoi(e) != 0; }();
-          if (gram_lds && bd == PD) BA_LAUNCH(ba_block_gram_lds_kernel<PD>, dim3(V.n_chunks), dim3(64), st, V, Gobs.p);
-          else if (gram_lds && bd == KD_MAX) BA_LAUNCH(ba_block_gram_lds_kernel<KD_MAX>, dim3(V.n_chunks), dim3(64), st, V, Gobs.p);
-          else if (gram_lds) BA_LAUNCH(ba_block_gram_lds_kernel<KD_WIDE>, dim3(V.n_chunks), dim3(64), st, V, Gobs.p);
+          if (gram_lds && bd == PD) BA_LAUNCH(ba_block_gram_lds_kernel<PD>, dim3(V.n_chunks), dim3(64 * GRAM_WAVES), st, V, Gobs.p);
+          else if (gram_lds && bd == KD_MAX) BA_LAUNCH(ba_block_gram_lds_kernel<KD_MAX>, dim3(V.n_chunks), dim3(64 * GRAM_WAVES), st, V, Gobs.p);
+          else if (gram_lds) BA_LAUNCH(ba_block_gram_lds_kernel<KD_WIDE>, dim3(V.n_chunks), dim3(64 * GRAM_WAVES), st, V, Gobs.p);
           else BA_LAUNCH(ba_block_gram_kernel, dim3(V.n_chunks), dim3(64), st, V, Gobs.p);
           BA_HIP(hipEventRecord(ev3, st));
           mfma_pending = true;
