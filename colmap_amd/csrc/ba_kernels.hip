@@ -1694,14 +1694,13 @@ __global__ void __launch_bounds__(64) ba_block_gram_kernel(View V, const double*
 constexpr int GRAM_TRIP = 32;
 constexpr int GRAM_WAVES = 4;
 template <int BD>  // widest block of the problem: bounds the prefetch registers (6, 8 or 16 column pairs per lane)
-__global__ void __launch_bounds__(64 * GRAM_WAVES) ba_block_gram_lds_kernel(View V, const double* __restrict__ G) {
+__global__ void __launch_bounds__(64 * GRAM_WAVES, BD <= 8 ? 4 : 2) ba_block_gram_lds_kernel(View V, const double* __restrict__ G) {
   // One workgroup per chunk, FOUR waves, wave w taking the trips w, w + 4, ... of the chunk with its own LDS tile and
   // accumulator; the four partial tiles are added in wave order at the end (a fixed tree). One wave per chunk left
   // ~2 waves per SIMD on the chip (a chunk is up to 2 048 observations, a camera one or two chunks), each a serial
   // chain of 64 trips of (LDS round trip + 16 dependent-issue matrix-core instructions): latency, not bandwidth.
   __shared__ double sJ[GRAM_WAVES][2][16][GRAM_TRIP + 1];  // [wave][row][column][observation], padded against bank conflicts
   __shared__ double sG[GRAM_WAVES][3][GRAM_TRIP];
-  __shared__ double sAcc[GRAM_WAVES - 1][4][64];
   const int ch = blockIdx.x;
   const int b = V.chunk_blk[ch];
   const int kind = V.blk_kind[b], dim = V.blk_dim[b];
@@ -1766,9 +1765,10 @@ __global__ void __launch_bounds__(64 * GRAM_WAVES) ba_block_gram_lds_kernel(View
     }
     wave_sync();
   }
+  double* part = &sJ[wave][0][0][0];  // the wave's own tile memory (its last trip is behind a wave_sync): [4][64]
   if (wave > 0) {
 #pragma unroll
-    for (int reg = 0; reg < 4; ++reg) sAcc[wave - 1][reg][lane] = acc[reg];
+    for (int reg = 0; reg < 4; ++reg) part[reg * 64 + lane] = acc[reg];
   }
   __syncthreads();
   if (wave > 0) return;
@@ -1777,7 +1777,7 @@ __global__ void __launch_bounds__(64 * GRAM_WAVES) ba_block_gram_lds_kernel(View
     const int row = k + 4 * reg;
     double t = acc[reg];
 #pragma unroll
-    for (int w = 0; w < GRAM_WAVES - 1; ++w) t += sAcc[w][reg][lane];
+    for (int w = 1; w < GRAM_WAVES; ++w) t += (&sJ[w][0][0][0])[reg * 64 + lane];
     if (row < dim && i < dim) V.cpart[(size_t)ch * V.bd * V.bd + row * dim + i] = t;
   }
 }
