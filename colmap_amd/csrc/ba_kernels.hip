@@ -1593,15 +1593,18 @@ __global__ void ba_block_vec_finalize_q_kernel(View V, const double* __restrict_
 // M_b (+)= sum over the block's chunks of the dim x dim partials; lane per block
 template <bool ACCUMULATE>
 __global__ void ba_block_mat_finalize_kernel(View V, double* __restrict__ M) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  // thread per (block, entry): a lane per block walked dim^2 x chunks dependent loads one after the other (37 us for
+  // the 2 000 blocks of 1 000 images); the chunk order of the sum is unchanged
+  const int bb = V.bd * V.bd;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = t / bb, e = t - b * bb;
   if (b >= V.n_blk) return;
   const int dim = V.blk_dim[b];
+  if (e >= dim * dim) return;
   double* Mb = M + V.blk_moff[b];
-  for (int e = 0; e < dim * dim; ++e) {
-    double s = 0.0;
-    for (int ch = V.blk_chunk_ptr[b]; ch < V.blk_chunk_ptr[b + 1]; ++ch) s += V.cpart[(size_t)ch * V.bd * V.bd + e];
-    Mb[e] = ACCUMULATE ? Mb[e] + s : s;
-  }
+  double s = 0.0;
+  for (int ch = V.blk_chunk_ptr[b]; ch < V.blk_chunk_ptr[b + 1]; ++ch) s += V.cpart[(size_t)ch * bb + e];
+  Mb[e] = ACCUMULATE ? Mb[e] + s : s;
 }
 
 // Schur-Jacobi diagonal blocks on the f64 matrix cores.
@@ -2217,6 +2220,10 @@ __global__ void ba_pcgp_dir_kernel(int n, PcgDev D, int k, int max_iter, double 
   if (i >= n) return;
   p[i] = k == 1 ? z[i] : z[i] + (rho_new / rho_prev) * p[i];
 }
+// (tail and step kernels: a lane per block, every loop over the block's components unrolled to the template width and
+//  predicated on its dimension -- rolled, each trip waited for its own loads: 6 - 12 dependent round trips per lane and
+//  launch; the order of every sum is the rolled loops', so the results are bit-identical)
+template <int BD>
 __global__ void __launch_bounds__(256) ba_pcgp_tail_kernel(View V, PcgDev D, int k, const double* __restrict__ Dc,
                                                            const double* __restrict__ p, double* __restrict__ q) {
   if (*D.stop) return;
@@ -2225,18 +2232,31 @@ __global__ void __launch_bounds__(256) ba_pcgp_tail_kernel(View V, PcgDev D, int
   const int b = blockIdx.x * 256 + threadIdx.x;
   if (b < V.n_blk) {
     const int dim = V.blk_dim[b], off = V.blk_off[b];
-    for (int c = 0; c < dim; ++c) {
-      double sacc = 0.0;
-      for (int ch = V.blk_chunk_ptr[b]; ch < V.blk_chunk_ptr[b + 1]; ++ch) sacc += V.cpart[(size_t)ch * bd2 + c];
-      const double d = Dc[off + c], pv = p[off + c];
-      const double qv = d * d * pv + sacc;
-      q[off + c] = qv;
-      pq += pv * qv;
+    const int ch0 = V.blk_chunk_ptr[b], ch1 = V.blk_chunk_ptr[b + 1];
+    double sacc[BD], d[BD], pv[BD];
+#pragma unroll
+    for (int c = 0; c < BD; ++c) {
+      sacc[c] = 0.0;
+      d[c] = c < dim ? Dc[off + c] : 0.0;
+      pv[c] = c < dim ? p[off + c] : 0.0;
+    }
+    for (int ch = ch0; ch < ch1; ++ch) {
+#pragma unroll
+      for (int c = 0; c < BD; ++c) sacc[c] += c < dim ? V.cpart[(size_t)ch * bd2 + c] : 0.0;
+    }
+#pragma unroll
+    for (int c = 0; c < BD; ++c) {
+      if (c < dim) {
+        const double qv = d[c] * d[c] * pv[c] + sacc[c];
+        q[off + c] = qv;
+        pq += pv[c] * qv;
+      }
     }
   }
   pq = block_sum(pq);
   if (threadIdx.x == 0) D.part[(size_t)(k & 1) * 3 * D.nparts + blockIdx.x] = pq;
 }
+template <int BD>
 __global__ void __launch_bounds__(256) ba_pcgp_step_kernel(View V, PcgDev D, int k, const double* __restrict__ Minv,
                                                            const double* __restrict__ rhs, const double* __restrict__ p,
                                                            const double* __restrict__ q, double* __restrict__ x,
@@ -2250,18 +2270,50 @@ __global__ void __launch_bounds__(256) ba_pcgp_step_kernel(View V, PcgDev D, int
   if (b < V.n_blk) {
     const int n = V.blk_dim[b], off = V.blk_off[b];
     const double* Mi = Minv + V.blk_moff[b];
-    for (int i = 0; i < n; ++i) {
-      const double xn = x[off + i] + alpha * p[off + i];
-      const double rn = r[off + i] - alpha * q[off + i];
-      x[off + i] = xn;
-      r[off + i] = rn;
-      Q += -0.5 * xn * (rhs[off + i] + rn);
+    double xv[BD], pv[BD], rv[BD], qv[BD], bv[BD];
+#pragma unroll
+    for (int i = 0; i < BD; ++i) {
+      const bool ok = i < n;
+      xv[i] = ok ? x[off + i] : 0.0;
+      pv[i] = ok ? p[off + i] : 0.0;
+      rv[i] = ok ? r[off + i] : 0.0;
+      qv[i] = ok ? q[off + i] : 0.0;
+      bv[i] = ok ? rhs[off + i] : 0.0;
     }
-    for (int i = 0; i < n; ++i) {
-      double sacc = 0.0;
-      for (int j = 0; j < n; ++j) sacc += Mi[i * n + j] * r[off + j];
-      z[off + i] = sacc;
-      rho += sacc * r[off + i];
+    double mi[BD][BD];
+    if constexpr (BD <= 8) {
+#pragma unroll
+      for (int i = 0; i < BD; ++i)
+#pragma unroll
+        for (int j = 0; j < BD; ++j) mi[i][j] = (i < n && j < n) ? Mi[i * n + j] : 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < BD; ++i) {
+      if (i < n) {
+        const double xn = xv[i] + alpha * pv[i];
+        const double rn = rv[i] - alpha * qv[i];
+        x[off + i] = xn;
+        r[off + i] = rn;
+        rv[i] = rn;
+        Q += -0.5 * xn * (bv[i] + rn);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < BD; ++i) {
+      if (i < n) {
+        double sacc = 0.0;
+        if constexpr (BD <= 8) {
+#pragma unroll
+          for (int j = 0; j < BD; ++j)
+            if (j < n) sacc += mi[i][j] * rv[j];
+        } else {  // (the 16-wide tier: 256 matrix entries per lane do not fit in registers)
+#pragma unroll
+          for (int j = 0; j < BD; ++j)
+            if (j < n) sacc += Mi[i * n + j] * rv[j];
+        }
+        z[off + i] = sacc;
+        rho += sacc * rv[i];
+      }
     }
   }
   Q = block_sum(Q);
@@ -3471,8 +3523,16 @@ struct Solver {
       BA_HIP(hipEventRecord(pcgp_ev_s0[k & 1], st));
       schur_streams(pdir.p, op32);
       BA_HIP(hipEventRecord(pcgp_ev_s1[k & 1], st));
-      BA_LAUNCH(ba_pcgp_tail_kernel, dim3(nparts), dim3(256), st, V, D, k, Dc.p, pdir.p, q.p);
-      BA_LAUNCH(ba_pcgp_step_kernel, dim3(nparts), dim3(256), st, V, D, k, Minv.p, rhs.p, pdir.p, q.p, x.p, r.p, z.p);
+      if (bd == PD) {
+        BA_LAUNCH(ba_pcgp_tail_kernel<PD>, dim3(nparts), dim3(256), st, V, D, k, Dc.p, pdir.p, q.p);
+        BA_LAUNCH(ba_pcgp_step_kernel<PD>, dim3(nparts), dim3(256), st, V, D, k, Minv.p, rhs.p, pdir.p, q.p, x.p, r.p, z.p);
+      } else if (bd == KD_MAX) {
+        BA_LAUNCH(ba_pcgp_tail_kernel<KD_MAX>, dim3(nparts), dim3(256), st, V, D, k, Dc.p, pdir.p, q.p);
+        BA_LAUNCH(ba_pcgp_step_kernel<KD_MAX>, dim3(nparts), dim3(256), st, V, D, k, Minv.p, rhs.p, pdir.p, q.p, x.p, r.p, z.p);
+      } else {
+        BA_LAUNCH(ba_pcgp_tail_kernel<KD_WIDE>, dim3(nparts), dim3(256), st, V, D, k, Dc.p, pdir.p, q.p);
+        BA_LAUNCH(ba_pcgp_step_kernel<KD_WIDE>, dim3(nparts), dim3(256), st, V, D, k, Minv.p, rhs.p, pdir.p, q.p, x.p, r.p, z.p);
+      }
     };
     enqueue(1);
     BA_HIP(hipEventSynchronize(pcgp_ev_dir[1]));
@@ -3673,12 +3733,12 @@ struct Solver {
           else BA_LAUNCH(ba_block_gram_kernel, dim3(V.n_chunks), dim3(64), st, V, Gobs.p);
           BA_HIP(hipEventRecord(ev3, st));
           mfma_pending = true;
-          BA_LAUNCH(ba_block_mat_finalize_kernel<false>, dim3(grid_for(V.n_blk, 128)), dim3(128), st, V, M.p);
+          BA_LAUNCH(ba_block_mat_finalize_kernel<false>, dim3(grid_for(V.n_blk * bd * bd, 128)), dim3(128), st, V, M.p);
           if (n_paired > 0) {  // observation pairs of a point inside one block: shared intrinsics, rig frames
             if (bd == PD) BA_LAUNCH(ba_block_schur_cross_kernel<PD>, dim3(V.n_chunks), dim3(64), st, V, Cinv.p);
             else if (bd == KD_WIDE) BA_LAUNCH(ba_block_schur_cross_kernel<KD_WIDE>, dim3(V.n_chunks), dim3(64), st, V, Cinv.p);
             else BA_LAUNCH(ba_block_schur_cross_kernel<KD_MAX>, dim3(V.n_chunks), dim3(64), st, V, Cinv.p);
-            BA_LAUNCH(ba_block_mat_finalize_kernel<true>, dim3(grid_for(V.n_blk, 128)), dim3(128), st, V, M.p);
+            BA_LAUNCH(ba_block_mat_finalize_kernel<true>, dim3(grid_for(V.n_blk * bd * bd, 128)), dim3(128), st, V, M.p);
           }
         }
         if (use_priors())
