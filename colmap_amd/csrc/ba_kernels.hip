@@ -1624,7 +1624,7 @@ __global__ void ba_block_mat_finalize_kernel(View V, double* __restrict__ M) {
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 
 // G_o = E_o C_j^-1 E_o^T (g00, g01, g11), lane per observation in p-order, stored at the c-order
-// position; constant points (no point block) have G = 0.
+// position as a record {g00, g01, g11, 0}; constant points (no point block) have G = 0.
 __global__ void __launch_bounds__(256) ba_obs_schur_g_kernel(View V, const double* __restrict__ Cinv,
                                                              double* __restrict__ G) {
   const int a = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1646,9 +1646,11 @@ __global__ void __launch_bounds__(256) ba_obs_schur_g_kernel(View V, const doubl
     g01 = t00 * e10 + t01 * e11 + t02 * e12;
     g11 = t10 * e10 + t11 * e11 + t12 * e12;
   }
-  G[c] = g00;
-  G[N + c] = g01;
-  G[2 * N + c] = g11;
+  // one 32-byte record per observation at its c-order position (a whole sector per lane; three planes meant three
+  // scattered 8-byte stores, each a partial write of its own sector)
+  double2* rec = reinterpret_cast<double2*>(G + 4 * (size_t)c);
+  rec[0] = make_double2(g00, g01);
+  rec[1] = make_double2(g11, 0.0);
 }
 
 __global__ void __launch_bounds__(64) ba_block_gram_kernel(View V, const double* __restrict__ G) {
@@ -1659,7 +1661,6 @@ __global__ void __launch_bounds__(64) ba_block_gram_kernel(View V, const double*
   const int i = lane & 15, k = lane >> 4;  // column, row-in-slab
   const int r = k & 1, oo = k >> 1;        // residual row, observation within the slab
   const int beg = V.chunk_beg[ch], end = V.chunk_end[ch];
-  const size_t N = (size_t)V.n_obs;
   v4f64 acc = {0.0, 0.0, 0.0, 0.0};
   const bool col_ok = i < dim;
   const double* col0 = col_ok ? blk_col(V, kind, 0, i) : nullptr;
@@ -1673,7 +1674,8 @@ __global__ void __launch_bounds__(64) ba_block_gram_kernel(View V, const double*
       a[u] = bb[u] = 0.0;
       if (col_ok && idx < end) {
         const double j0 = col0[idx], j1 = col1[idx];
-        const double g00 = G[idx], g01 = G[N + idx], g11 = G[2 * N + idx];
+        const double2 ga = reinterpret_cast<const double2*>(G)[2 * (size_t)idx];
+        const double g00 = ga.x, g01 = ga.y, g11 = G[4 * (size_t)idx + 2];
         a[u] = r ? j1 : j0;
         bb[u] = r ? j1 - (g01 * j0 + g11 * j1) : j0 - (g00 * j0 + g01 * j1);
       }
@@ -1703,7 +1705,7 @@ __global__ void __launch_bounds__(64 * GRAM_WAVES, BD <= 8 ? 4 : 2) ba_block_gra
   // ~2 waves per SIMD on the chip (a chunk is up to 2 048 observations, a camera one or two chunks), each a serial
   // chain of 64 trips of (LDS round trip + 16 dependent-issue matrix-core instructions): latency, not bandwidth.
   __shared__ double sJ[GRAM_WAVES][2][16][GRAM_TRIP + 1];  // [wave][row][column][observation], padded against bank conflicts
-  __shared__ double sG[GRAM_WAVES][3][GRAM_TRIP];
+  __shared__ double sG[GRAM_WAVES][3][GRAM_TRIP + 1];
   const int ch = blockIdx.x;
   const int b = V.chunk_blk[ch];
   const int kind = V.blk_kind[b], dim = V.blk_dim[b];
@@ -1712,7 +1714,6 @@ __global__ void __launch_bounds__(64 * GRAM_WAVES, BD <= 8 ? 4 : 2) ba_block_gra
   const int r = k & 1, oo = k >> 1;        // residual row, observation within the slab
   const int half = lane >> 5, lo = lane & 31;
   const int beg = V.chunk_beg[ch], end = V.chunk_end[ch];
-  const size_t N = (size_t)V.n_obs;
   v4f64 acc = {0.0, 0.0, 0.0, 0.0};
   const bool col_ok = i < dim;
   // The operands of the wave's next trip are loaded into registers while the matrix core works on this one (a lane's
@@ -1727,10 +1728,9 @@ __global__ void __launch_bounds__(64 * GRAM_WAVES, BD <= 8 ? 4 : 2) ba_block_gra
       pj[q] = (cr < 2 * dim && lo < n) ? blk_col(V, kind, cr & 1, cr >> 1)[s + lo] : 0.0;
     }
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
+    for (int q = 0; q < 2; ++q) {  // the trip's 32 records of G: 1 KB, contiguous
       const int e = lane + 64 * q;
-      const int g = e / GRAM_TRIP, o = e - g * GRAM_TRIP;
-      pg[q] = (e < 3 * GRAM_TRIP && o < n) ? G[(size_t)g * N + s + o] : 0.0;
+      pg[q] = (e >> 2) < n ? G[4 * (size_t)s + e] : 0.0;
     }
   };
   auto wave_sync = [] {  // the tile is handed from lane to lane of ONE wave
@@ -1750,7 +1750,7 @@ __global__ void __launch_bounds__(64 * GRAM_WAVES, BD <= 8 ? 4 : 2) ba_block_gra
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int e = lane + 64 * q;
-      if (e < 3 * GRAM_TRIP) sG[wave][e / GRAM_TRIP][e % GRAM_TRIP] = pg[q];
+      if ((e & 3) < 3) sG[wave][e & 3][e >> 2] = pg[q];
     }
     wave_sync();
     if (s + STEP < end) prefetch(s + STEP);
@@ -3239,7 +3239,7 @@ struct Solver {
     poses2.alloc(poses.n); cams2.alloc(cams.n); points2.alloc(points.n);
     const size_t N = (size_t)n;
     Jpose.alloc(2 * PD * N); Jcam.alloc(2 * (size_t)kd * N); Jpt.alloc(6 * N); res.alloc(2 * N); res_p.alloc(2 * N);
-    jx.alloc(2 * N); v.alloc(2 * N); Gobs.alloc(3 * N);
+    jx.alloc(2 * N); v.alloc(2 * N); Gobs.alloc(4 * N);
     if (n_var_sensors > 0) Jsens.alloc(12 * N);
     {
       const char* e32 = std::getenv("COLMAP_AMD_BA_OPERATOR_F32");
