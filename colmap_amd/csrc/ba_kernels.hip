@@ -1562,32 +1562,33 @@ __global__ void __launch_bounds__(64) ba_block_jtv_kernel(View V, const double* 
 // y_b = sum over the block's chunks, in chunk order (deterministic); lane per block
 template <bool DIAG>
 __global__ void ba_block_vec_finalize_kernel(View V, double* __restrict__ y, double* __restrict__ diag) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  // thread per (block, component) -- a lane per block walked its components' loads one after the other
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = t / V.bd, c = t - b * V.bd;
   if (b >= V.n_blk) return;
   const int dim = V.blk_dim[b], off = V.blk_off[b];
-  for (int c = 0; c < dim; ++c) {
-    double s = 0.0, d = 0.0;
-    for (int ch = V.blk_chunk_ptr[b]; ch < V.blk_chunk_ptr[b + 1]; ++ch) {
-      s += V.cpart[(size_t)ch * V.bd * V.bd + c];
-      if (DIAG) d += V.cpart[(size_t)ch * V.bd * V.bd + V.bd + c];
-    }
-    y[off + c] = s;  // every camera-side entry belongs to exactly one block: no memset before, no accumulate
-    if (DIAG) diag[off + c] = d;
+  if (c >= dim) return;
+  double s = 0.0, d = 0.0;
+  for (int ch = V.blk_chunk_ptr[b]; ch < V.blk_chunk_ptr[b + 1]; ++ch) {
+    s += V.cpart[(size_t)ch * V.bd * V.bd + c];
+    if (DIAG) d += V.cpart[(size_t)ch * V.bd * V.bd + V.bd + c];
   }
+  y[off + c] = s;  // every camera-side entry belongs to exactly one block: no memset before, no accumulate
+  if (DIAG) diag[off + c] = d;
 }
 
 // q_b = Dc_b^2 x_b + sum over the block's chunks (the tail of an implicit product on a single GPU without
 // priors: ba_block_vec_finalize_kernel<false> + ba_dsq_x_kernel + ba_add_kernel in one launch, same operations)
 __global__ void ba_block_vec_finalize_q_kernel(View V, const double* __restrict__ Dc, const double* __restrict__ x,
                                                double* __restrict__ q) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = t / V.bd, c = t - b * V.bd;
   if (b >= V.n_blk) return;
   const int dim = V.blk_dim[b], off = V.blk_off[b];
-  for (int c = 0; c < dim; ++c) {
-    double s = 0.0;
-    for (int ch = V.blk_chunk_ptr[b]; ch < V.blk_chunk_ptr[b + 1]; ++ch) s += V.cpart[(size_t)ch * V.bd * V.bd + c];
-    q[off + c] = Dc[off + c] * Dc[off + c] * x[off + c] + s;
-  }
+  if (c >= dim) return;
+  double s = 0.0;
+  for (int ch = V.blk_chunk_ptr[b]; ch < V.blk_chunk_ptr[b + 1]; ++ch) s += V.cpart[(size_t)ch * V.bd * V.bd + c];
+  q[off + c] = Dc[off + c] * Dc[off + c] * x[off + c] + s;
 }
 
 // M_b (+)= sum over the block's chunks of the dim x dim partials; lane per block
@@ -3337,7 +3338,7 @@ struct Solver {
       if (bd == PD) BA_LAUNCH((ba_block_jtv_kernel<true, PD>), dim3(V.n_chunks), dim3(64), st, V, res.p, gc.p, diag_c.p);
       else if (bd == KD_WIDE) BA_LAUNCH((ba_block_jtv_kernel<true, KD_WIDE>), dim3(V.n_chunks), dim3(64), st, V, res.p, gc.p, diag_c.p);
       else BA_LAUNCH((ba_block_jtv_kernel<true, KD_MAX>), dim3(V.n_chunks), dim3(64), st, V, res.p, gc.p, diag_c.p);
-      BA_LAUNCH(ba_block_vec_finalize_kernel<true>, dim3(grid_for(V.n_blk, 128)), dim3(128), st, V, gc.p, diag_c.p);
+      BA_LAUNCH(ba_block_vec_finalize_kernel<true>, dim3(grid_for(V.n_blk * bd, 128)), dim3(128), st, V, gc.p, diag_c.p);
     }
     // (g_p and the point column norms are written for every variable point by either kernel)
     if (V.n_tiles > 0)
@@ -3361,7 +3362,7 @@ struct Solver {
       if (bd == PD) BA_LAUNCH((ba_block_jtv_kernel<false, PD>), dim3(V.n_chunks), dim3(64), st, V, vin, tmpc.p, nullptr);
       else if (bd == KD_WIDE) BA_LAUNCH((ba_block_jtv_kernel<false, KD_WIDE>), dim3(V.n_chunks), dim3(64), st, V, vin, tmpc.p, nullptr);
       else BA_LAUNCH((ba_block_jtv_kernel<false, KD_MAX>), dim3(V.n_chunks), dim3(64), st, V, vin, tmpc.p, nullptr);
-      BA_LAUNCH(ba_block_vec_finalize_kernel<false>, dim3(grid_for(V.n_blk, 128)), dim3(128), st, V, tmpc.p, nullptr);
+      BA_LAUNCH(ba_block_vec_finalize_kernel<false>, dim3(grid_for(V.n_blk * bd, 128)), dim3(128), st, V, tmpc.p, nullptr);
     }
     if (x_for_priors && use_priors()) {  // + sum over priors J^T (J x)
       BA_LAUNCH(ba_prior_jx_kernel, dim3(grid_for(Q.n, 64)), dim3(64), st, Q, x_for_priors);
@@ -3386,7 +3387,7 @@ struct Solver {
     if (comm.world == 1 && !use_priors() && V.n_chunks > 0 && V.n_obs > 0) {
       // single GPU, no priors: nothing sits between J_c^T v and the block sums -> one tail kernel
       schur_streams(xin, inexact && op32);
-      BA_LAUNCH(ba_block_vec_finalize_q_kernel, dim3(grid_for(V.n_blk, 128)), dim3(128), st, V, Dc.p, xin, qout);
+      BA_LAUNCH(ba_block_vec_finalize_q_kernel, dim3(grid_for(V.n_blk * bd, 128)), dim3(128), st, V, Dc.p, xin, qout);
       return;
     }
     const int go = grid_for(V.n_obs, 256);
