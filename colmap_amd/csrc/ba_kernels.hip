@@ -3413,7 +3413,7 @@ struct Solver {
   // DENSE_SCHUR: x = S^-1 rhs with S built from n_c operator products
   int dense_schur() {
     const int n = V.n_c;
-    if (Sdense.n < (size_t)n * n) throw std::runtime_error("dense Schur buffer");
+    if (Sdense.n < (size_t)n * n + n) throw std::runtime_error("dense Schur buffer");
     if (!dense_by_products) {
       // explicit formation (one wave per point) + blocked Cholesky on the f64 matrix cores
       ba_explicit::FormArgs fa{};
@@ -3632,7 +3632,7 @@ struct Solver {
       out->linear_solver_used = use_dense ? tier : BA_SOLVER_ITERATIVE_SCHUR;
     }
     if (use_dense) {
-      Sdense.alloc((size_t)nc * nc);
+      Sdense.alloc((size_t)nc * nc + nc);  // + the row of the right-hand side (ba_explicit::factor_solve)
       if (!dense_by_products) {
         ba_explicit::Workspace ws;
         chol_linv.alloc(ws.linv_doubles(nc)); chol_tmp.alloc(nc); chol_info.alloc(2);  // [pivot flag, formation flag]

@@ -87,7 +87,8 @@ struct Workspace {
   size_t linv_doubles(int n) const { return (size_t)((n + 63) / 64) * 64 * 64; }
 };
 
-// In-place blocked Cholesky S = L L^T (lower, row-major), then x = S^-1 rhs. A non-positive (or NaN) pivot fills x
+// In-place blocked Cholesky S = L L^T (lower, row-major), then x = S^-1 rhs. THE BUFFER OF S HOLDS n + 1 ROWS of n
+// doubles: the right-hand side is factored along as row n (forward substitution without a sweep of its own). A non-positive (or NaN) pivot fills x
 // with NaN (the LM loop then rejects the step like a failed LLT). `mfma_ms` (optional, host) receives the
 // time spent inside the matrix-core kernels (panel + trailing update), measured with the two events given.
 void factor_solve(double* S, int n, const double* rhs, double* x, const Workspace& ws, hipStream_t st,

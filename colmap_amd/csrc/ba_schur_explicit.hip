@@ -559,13 +559,13 @@ __global__ void __launch_bounds__(128) chol_diag_kernel(double* __restrict__ S, 
 // 16 w .. 16 w + 15 and all four 16-column tiles. MFMA operand layout (as in ba_block_gram_kernel): lane l
 // supplies A[i = l & 15][k = l >> 4] and B[k = l >> 4][j = l & 15]; the result registers hold
 // D[row = (l >> 4) + 4 reg][col = l & 15].
-__global__ void __launch_bounds__(256) chol_panel_kernel(double* __restrict__ S, int n, int k0, int kb,
+__global__ void __launch_bounds__(256) chol_panel_kernel(double* __restrict__ S, int n, int nrows, int k0, int kb,
                                                          const double* __restrict__ Linv) {
   __shared__ double sA[NB][NB + 1];
   __shared__ double sLi[NB][NB + 1];
   const int tid = threadIdx.x;
   const int r0 = k0 + kb + NB * blockIdx.x;
-  const int nr = min(NB, n - r0);
+  const int nr = min(NB, nrows - r0);
   {  // all 32 loads of a thread in flight together (rolled, the loop waited for every pair before its LDS writes)
     const int c = tid & 63, rq = tid >> 6;
     double va[16], vl[16];
@@ -610,8 +610,8 @@ __global__ void __launch_bounds__(256) chol_panel_kernel(double* __restrict__ S,
 // t0 = k0 + kb). Wave w owns the 32 x 32 quadrant (w >> 1, w & 1): 2 x 2 MFMA tiles; K = kb in halves of 32.
 // (general form: C[r][c] -= sum_{m in [k0, k0 + kb)} S[r][m] S[c][m] for rows r >= row0 and columns c in
 //  [col0, cend), lower triangle; a column window restricts the update to part of the trailing matrix)
-__global__ void __launch_bounds__(256) chol_update_kernel(double* __restrict__ S, int n, int k0, int kb, int row0,
-                                                          int col0, int cend) {
+__global__ void __launch_bounds__(256) chol_update_kernel(double* __restrict__ S, int n, int nrows, int k0, int kb,
+                                                          int row0, int col0, int cend) {
   const int I = blockIdx.y, J = blockIdx.x;
   __shared__ double sI[NB][33];
   __shared__ double sJ[NB][33];
@@ -632,7 +632,7 @@ __global__ void __launch_bounds__(256) chol_update_kernel(double* __restrict__ S
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
         const int r = ri + qi + 16 * a + lk + 4 * reg, c = rj + qj + 16 * b + li;
-        acc[a][b][reg] = S[(r < n && c < n) ? (size_t)r * n + c : (size_t)ri * n + rj];  // (out of range: any valid address)
+        acc[a][b][reg] = S[(r < nrows && c < n) ? (size_t)r * n + c : (size_t)ri * n + rj];  // (out of range: any valid address)
       }
   // thread -> (row r = tid / 32 + 8 i, column m = tid % 32) of a half: all 16 loads of a thread are issued together,
   // and those of the next half right after the barrier that publishes this one (under its 32 matrix-core instructions)
@@ -645,7 +645,7 @@ __global__ void __launch_bounds__(256) chol_update_kernel(double* __restrict__ S
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int r = pr + 8 * i;
-      pI[i] = (kok && ri + r < n) ? gI[(size_t)8 * i * n + kh] : 0.0;
+      pI[i] = (kok && ri + r < nrows) ? gI[(size_t)8 * i * n + kh] : 0.0;
       pJ[i] = (kok && rj + r < n) ? gJ[(size_t)8 * i * n + kh] : 0.0;
     }
   };
@@ -677,7 +677,7 @@ __global__ void __launch_bounds__(256) chol_update_kernel(double* __restrict__ S
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
         const int r = ri + qi + 16 * a + lk + 4 * reg, c = rj + qj + 16 * b + li;
-        if (r < n && c < cend && c <= r) S[(size_t)r * n + c] = acc[a][b][reg];
+        if (r < nrows && c < cend && c <= r) S[(size_t)r * n + c] = acc[a][b][reg];
       }
 }
 
@@ -690,7 +690,7 @@ __global__ void __launch_bounds__(256) chol_update_kernel(double* __restrict__ S
 // 14 TFLOP/s over the trailing updates at BA-1). A diagonal tile (I == J) reads its rows once. As in the 64 x 64
 // kernel the accumulators start from the tile and the epilogue only stores (it was 64 serial load-wait-store round
 // trips per lane).
-__global__ void __launch_bounds__(256, 2) chol_update128_kernel(double* __restrict__ S, int n, int k0, int kb,
+__global__ void __launch_bounds__(256, 2) chol_update128_kernel(double* __restrict__ S, int n, int nrows, int k0, int kb,
                                                                 int row0, int col0, int cend) {
   const int I = blockIdx.y, J = blockIdx.x;
   constexpr int T = 128, KC = 16, PF = T * KC / 256;
@@ -711,7 +711,7 @@ __global__ void __launch_bounds__(256, 2) chol_update128_kernel(double* __restri
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
         const int r = ri + qi + 16 * a + lk + 4 * reg, c = rj + qj + 16 * b + li;
-        acc[a][b][reg] = S[(r < n && c < n) ? (size_t)r * n + c : (size_t)ri * n + rj];  // (out of range: any valid address)
+        acc[a][b][reg] = S[(r < nrows && c < n) ? (size_t)r * n + c : (size_t)ri * n + rj];  // (out of range: any valid address)
       }
   // thread -> (row r = tid / 16 + 16 i, column m = tid % 16) of a chunk: 16 lanes read 128 contiguous bytes of a row
   const int pr = tid >> 4, pm = tid & 15;
@@ -723,7 +723,7 @@ __global__ void __launch_bounds__(256, 2) chol_update128_kernel(double* __restri
 #pragma unroll
     for (int i = 0; i < PF; ++i) {
       const int r = pr + 16 * i;
-      pI[i] = (kok && ri + r < n) ? gI[(size_t)16 * i * n + kc] : 0.0;
+      pI[i] = (kok && ri + r < nrows) ? gI[(size_t)16 * i * n + kc] : 0.0;
       pJ[i] = (!same && kok && rj + r < n) ? gJ[(size_t)16 * i * n + kc] : 0.0;
     }
   };
@@ -758,49 +758,14 @@ __global__ void __launch_bounds__(256, 2) chol_update128_kernel(double* __restri
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
         const int r = ri + qi + 16 * a + lk + 4 * reg, c = rj + qj + 16 * b + li;
-        if (r < n && c < cend && c <= r) S[(size_t)r * n + c] = acc[a][b][reg];
+        if (r < nrows && c < cend && c <= r) S[(size_t)r * n + c] = acc[a][b][reg];
       }
 }
 
-// Forward step k: y_k <- L_kk^-1 y_k (final), rows below: y_i -= L_ik y_k. Every workgroup recomputes the
-// 64-vector (cheap), workgroup 0 publishes it to `yfin`; block.x = 256, grid = 1 + #row tiles below.
-// Thread = (row, quarter): a quarter of the 64 terms of a row each (16 loads in flight per thread instead of a chain of
-// 64), the four partial sums added in quarter order (a fixed tree: reproducible).
-__global__ void __launch_bounds__(256) solve_forward_kernel(const double* __restrict__ S, int n, int k0, int kb,
-                                                            const double* __restrict__ Linv, double* __restrict__ y,
-                                                            double* __restrict__ yfin) {
-  __shared__ double yk[NB];
-  __shared__ double raw[NB];
-  __shared__ double part[4][NB];
-  const int row = threadIdx.x & 63, q = threadIdx.x >> 6;
-  if (q == 0) raw[row] = row < kb ? y[k0 + row] : 0.0;
-  __syncthreads();
-  {
-    double v = 0.0;  // (L^-1 is lower triangular and zero-padded: terms beyond the diagonal are exact zeros)
-#pragma unroll
-    for (int j = 0; j < 16; ++j) v += Linv[row * NB + 16 * q + j] * raw[16 * q + j];
-    part[q][row] = v;
-  }
-  __syncthreads();
-  if (q == 0) yk[row] = row < kb ? ((part[0][row] + part[1][row]) + (part[2][row] + part[3][row])) : 0.0;
-  __syncthreads();
-  if (blockIdx.x == 0) {
-    if (q == 0 && row < kb) yfin[k0 + row] = yk[row];
-    return;
-  }
-  const int r = k0 + kb + NB * (blockIdx.x - 1) + row;
-  double acc = 0.0;
-  if (r < n) {
-    const double* Sr = S + (size_t)r * n + k0 + 16 * q;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) acc += (16 * q + j < kb ? Sr[j] : 0.0) * yk[16 * q + j];
-  }
-  part[q][row] = acc;
-  __syncthreads();
-  if (q == 0 && r < n) y[r] -= (part[0][row] + part[1][row]) + (part[2][row] + part[3][row]);
-}
-
-// Backward step k: x_k <- L_kk^-T w_k (final), columns left of it: w_j -= L_kj^T x_k. Same thread layout.
+// Backward step k: x_k <- L_kk^-T w_k (final), columns left of it: w_j -= L_kj^T x_k. block.x = 256, grid = 1 + #column
+// tiles left of the block; every workgroup recomputes the 64-vector (cheap), workgroup 0 publishes it.
+// Thread = (column, quarter): a quarter of the 64 terms each (16 loads in flight per thread instead of a chain of 64),
+// the four partial sums added in quarter order (a fixed tree: reproducible).
 __global__ void __launch_bounds__(256) solve_backward_kernel(const double* __restrict__ S, int n, int k0, int kb,
                                                              const double* __restrict__ Linv, double* __restrict__ w,
                                                              double* __restrict__ x) {
@@ -971,6 +936,13 @@ void factor_solve(double* S, int n, const double* rhs, double* x, const Workspac
   BAX_HIP(hipMemsetAsync(ws.info, 0, sizeof(int), st));
   const int nblk = (n + NB - 1) / NB;
   if (mfma_ms) *mfma_ms = 0.0;
+  // The forward substitution rides along with the factorisation: the right-hand side is row n of the matrix (the
+  // caller's buffer has n + 1 rows). Factoring [[S, b], [b^T, .]] leaves y^T = (L^-1 b)^T in that row -- the panel
+  // kernel turns its block k into y_k, the trailing updates subtract L_jk y_k from the blocks to its right -- so the
+  // 125 launches of a forward sweep at n = 8 000 (one per block step, each a dependent chain) are gone; the row's own
+  // diagonal entry does not exist and is never touched. Every row bound below is nrows, every column bound n.
+  const int nrows = n + 1;
+  BAX_HIP(hipMemcpyAsync(S + (size_t)n * n, rhs, sizeof(double) * n, hipMemcpyDeviceToDevice, st));
   // The whole factorisation is bracketed by the two events: the diagonal-block kernels in between are
   // < 2 % of its time at n >= 2 000, the rest are the two matrix-core kernels.
   if (ev_a) BAX_HIP(hipEventRecord(ev_a, st));
@@ -984,14 +956,14 @@ void factor_solve(double* S, int n, const double* rhs, double* x, const Workspac
   // c in [t0, cend). update_cols(.., c0, cend): the same for columns [c0, cend) only (rows r >= c0: the lower
   // triangle has no entries above the diagonal of the first column).
   auto launch = [&](int k0, int kb, int row0, int col0, int cend, hipStream_t s_) {
-    const int rows = n - row0, cols = std::min(cend, n) - col0;
+    const int rows = nrows - row0, cols = std::min(cend, n) - col0;
     if (rows <= 0 || cols <= 0) return;
     if (rows >= ws.min_rows128 && cols >= 256) {
-      hipLaunchKernelGGL(chol_update128_kernel, dim3((cols + 127) / 128, (rows + 127) / 128), dim3(256), 0, s_, S, n, k0, kb,
-                         row0, col0, std::min(cend, n));
+      hipLaunchKernelGGL(chol_update128_kernel, dim3((cols + 127) / 128, (rows + 127) / 128), dim3(256), 0, s_, S, n, nrows,
+                         k0, kb, row0, col0, std::min(cend, n));
     } else {
-      hipLaunchKernelGGL(chol_update_kernel, dim3((cols + NB - 1) / NB, (rows + NB - 1) / NB), dim3(256), 0, s_, S, n, k0, kb,
-                         row0, col0, std::min(cend, n));
+      hipLaunchKernelGGL(chol_update_kernel, dim3((cols + NB - 1) / NB, (rows + NB - 1) / NB), dim3(256), 0, s_, S, n, nrows,
+                         k0, kb, row0, col0, std::min(cend, n));
     }
   };
   auto update = [&](int k0, int kb, int t0, int cend, hipStream_t s_) { launch(k0, kb, t0, t0, cend, s_); };
@@ -1008,11 +980,9 @@ void factor_solve(double* S, int n, const double* rhs, double* x, const Workspac
       const int kb = std::min(NB, n - k0);
       double* Li = ws.Linv + (size_t)(k0 / NB) * NB * NB;
       hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(128), 0, st, S, n, k0, kb, Li, ws.info);
-      const int below = n - k0 - kb;
-      if (below > 0) {
-        hipLaunchKernelGGL(chol_panel_kernel, dim3((below + NB - 1) / NB), dim3(256), 0, st, S, n, k0, kb, Li);
-        update(k0, kb, k0 + kb, oend, st);  // the rest of this outer panel only
-      }
+      const int below = nrows - k0 - kb;  // (>= 1: the right-hand side's row)
+      hipLaunchKernelGGL(chol_panel_kernel, dim3((below + NB - 1) / NB), dim3(256), 0, st, S, n, nrows, k0, kb, Li);
+      update(k0, kb, k0 + kb, oend, st);  // the rest of this outer panel only
     }
     if (oend >= n) break;
     if (!lookahead) {
@@ -1032,17 +1002,11 @@ void factor_solve(double* S, int n, const double* rhs, double* x, const Workspac
   }
   if (u2_pending) BAX_HIP(hipStreamWaitEvent(st, ws.ev_u2, 0));
   if (ev_b) BAX_HIP(hipEventRecord(ev_b, st));
-  // L y = rhs: x is the working vector (a step reads its own block of it raw -- in every workgroup -- and
-  // updates the rows below), finished blocks go to ws.tmp; then L^T x = y with ws.tmp as the working vector
-  // and x as the output. Working vector and output must be different arrays: workgroup 0 publishes a block
-  // while the other workgroups of the same launch still read its raw values.
-  BAX_HIP(hipMemcpyAsync(x, rhs, sizeof(double) * n, hipMemcpyDeviceToDevice, st));
-  for (int kblk = 0; kblk < nblk; ++kblk) {
-    const int k0 = kblk * NB, kb = std::min(NB, n - k0);
-    const int tiles = (n - k0 - kb + NB - 1) / NB;
-    hipLaunchKernelGGL(solve_forward_kernel, dim3(1 + tiles), dim3(256), 0, st, S, n, k0, kb,
-                       ws.Linv + (size_t)kblk * NB * NB, x, ws.tmp);
-  }
+  // L^T x = y with y = row n of the factor, ws.tmp as the working vector (a step reads its own block of it raw -- in
+  // every workgroup -- and updates the columns to its left) and x as the output. Working vector and output must be
+  // different arrays: workgroup 0 publishes a block while the other workgroups of the same launch still read its raw
+  // values.
+  BAX_HIP(hipMemcpyAsync(ws.tmp, S + (size_t)n * n, sizeof(double) * n, hipMemcpyDeviceToDevice, st));
   for (int kblk = nblk - 1; kblk >= 0; --kblk) {
     const int k0 = kblk * NB, kb = std::min(NB, n - k0);
     hipLaunchKernelGGL(solve_backward_kernel, dim3(1 + kblk), dim3(256), 0, st, S, n, k0, kb,

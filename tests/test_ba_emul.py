@@ -161,7 +161,7 @@ def test_fixed_point_formation_and_its_overflow_flag(scale, expect_bad):
     fa = _FormArgs(n_obs=N, n_points=1, n_c=n_c, kd=4, fixed_point=True, bad=bad.ctypes.data)
     for k, v in arrs.items():
         setattr(fa, k, v.ctypes.data)
-    S = np.full((n_c, n_c), 7.0)
+    S = np.full((n_c + 1, n_c), 7.0)  # (n_c + 1 rows: factor_solve's buffer)
     form(C.byref(fa), S.ctypes.data_as(C.c_void_p), None)
     finish(S.ctypes.data_as(C.c_void_p), C.c_int(n_c), C.c_bool(True), bad.ctypes.data_as(C.c_void_p), None)
     J = [np.array([[Jpose[r * 6 + d, a] for d in range(6)] for r in range(2)]) for a in range(N)]
@@ -309,8 +309,8 @@ def _factor_solve_directly(A, rhs, min_rows128):
     import numpy as np
     _, _, factor_solve = _explicit_entry_points()
     n = A.shape[0]
-    S = np.tril(A).copy()
-    S[np.triu_indices(n, 1)] = 1e300  # the upper triangle is never read
+    S = np.full((n + 1, n), 1e300)  # the upper triangle is never read; row n: the right-hand side rides along
+    S[np.tril_indices(n)] = A[np.tril_indices(n)]
     x = np.zeros(n)
     linv, tmp, info = np.zeros(((n + 63) // 64) * 64 * 64), np.zeros(n), np.zeros(1, np.int32)
     ws = _Workspace(Linv=linv.ctypes.data, tmp=tmp.ctypes.data, info=info.ctypes.data, min_rows128=min_rows128)
