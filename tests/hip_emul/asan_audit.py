@@ -57,9 +57,20 @@ elif which == 'ba':
     run(T.test_rig_frames_match_oracle); run(T.test_pose_prior_adjuster_on_rigs_matches_oracle)
     run(T.test_reference_pose_prior_backend_case); run(T.test_constant_rig_from_world_rotation_matches_oracle)
     run(T._model_matches_oracle, model=17, params=(1024.0, 768.0))
+    run(T.test_exact_tier_pair_major_formation_equals_point_major, frames=60, points=3000, track=6, shared=True)
     import test_ba_emul as TE
     TE.est.lib = lambda: lib
     TE.test_blocked_cholesky_beyond_one_panel(); print('blocked cholesky ok', flush=True)
+    # the internal C++ interface called directly: both formations, the factorisation with the right-hand side's row
+    TE._LIB = C.CDLL(D + 'libba_asan.so')
+    for shared_cams, rigs, fixed in ((False, False, True), (True, False, True), (True, True, True), (True, True, False)):
+        TE.test_pair_major_formation_against_numpy_and_the_point_major_kernel(shared_cams, rigs, fixed)
+        print('formation', shared_cams, rigs, fixed, 'ok', flush=True)
+    for n, m128 in ((45, 12 * 128), (64, 12 * 128), (333, 12 * 128), (600, 256)):
+        TE.test_blocked_cholesky_directly_against_numpy(n, m128); print('factor_solve', n, 'ok', flush=True)
+    TE.test_blocked_cholesky_reports_a_failed_pivot(); print('failed pivot ok', flush=True)
+    for scale, expect_bad in ((0.1, False), (100.0, True)):
+        TE.test_fixed_point_formation_and_its_overflow_flag(scale, expect_bad); print('fixed point', scale, 'ok', flush=True)
 elif which == 'pm':
     import test_pm_emul as T
     run(T.test_initial_state_cost_pose_tables_and_reference_filter)

@@ -3,6 +3,7 @@
 #   sh asan_audit.sh                 AddressSanitizer (out-of-bounds / use-after-free accesses to global memory and LDS)
 #   sh asan_audit.sh undefined       UndefinedBehaviorSanitizer (+ float-cast-overflow: shifts, signed overflow, misaligned
 #                                    accesses, float -> int conversions out of range)
+#   HIP_EMUL_AUDIT_ONLY="ba" sh asan_audit.sh [mode]      only the named components (fusion fusion_small ba pm)
 set -e
 here=$(cd "$(dirname "$0")" && pwd)
 root=$(cd "$here/../.." && pwd)
@@ -33,12 +34,13 @@ p3=$!
 p4=$!
 wait $p1; wait $p2; wait $p3; wait $p4
 rc=0
-for w in fusion fusion_small ba pm; do
+parts=${HIP_EMUL_AUDIT_ONLY:-fusion fusion_small ba pm}
+for w in $parts; do
   LD_PRELOAD="$rt" ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0:halt_on_error=1 UBSAN_OPTIONS=halt_on_error=0 \
       python "$here/asan_audit.py" $w > "$out/audit_$w.log" 2>&1 &
 done
 wait
-for w in fusion fusion_small ba pm; do
+for w in $parts; do
   if grep -q "runtime error" "$out/audit_$w.log"; then echo "$w: undefined behaviour reported -- see $out/audit_$w.log"; grep "runtime error" "$out/audit_$w.log" | sort | uniq -c | head -20; rc=1;
   elif grep -q "AUDIT DONE $w" "$out/audit_$w.log"; then echo "$w: clean ($(grep -c ' ok' "$out/audit_$w.log") comparisons)";
   else echo "$w: FAILED -- see $out/audit_$w.log"; tail -20 "$out/audit_$w.log"; rc=1; fi

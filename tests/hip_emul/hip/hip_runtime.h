@@ -370,7 +370,12 @@ template <typename T> inline T atomicMax(T* p, T v) { const T o = *p; if (v > o)
 template <typename T> inline T atomicMin(T* p, T v) { const T o = *p; if (v < o) *p = v; return o; }
 template <typename T> inline T atomicAdd(T* p, T v) { const T o = *p; *p = o + v; return o; }
 template <typename T> inline T atomicOr(T* p, T v) { const T o = *p; *p = o | v; return o; }
-inline long long __double2ll_rn(double v) { return (long long)std::nearbyint(v); }  // round to nearest even (default mode)
+inline long long __double2ll_rn(double v) {  // round to nearest even (default mode); the device conversion saturates, NaN -> 0
+  if (v != v) return 0;
+  if (v >= 9223372036854775808.0) return 0x7fffffffffffffffLL;
+  if (v < -9223372036854775808.0) return (long long)0x8000000000000000ULL;
+  return (long long)std::nearbyint(v);
+}
 inline long long __double_as_longlong(double v) { long long u; std::memcpy(&u, &v, 8); return u; }
 inline double __longlong_as_double(long long u) { double v; std::memcpy(&v, &u, 8); return v; }
 
