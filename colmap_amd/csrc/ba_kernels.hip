@@ -2844,8 +2844,7 @@ struct Solver {
   std::vector<int> h_pose_off, h_cam_off, h_pt_off;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
   hipStream_t st_chol = nullptr;  // second stream + events of the Cholesky lookahead (exact tiers)
-  ba_explicit::PairLists pair_lists;  // pair-major formation of the exact tiers (built at the first formation)
-  bool pair_lists_tried = false;
+  ba_explicit::PairLists pair_lists;  // pair-major formation of the exact tiers (built with the solve's other structures)
   hipEvent_t ev_chol_panel = nullptr, ev_chol_u2 = nullptr;
 
   Solver(ba_problem& p_, const ba_options& o_, Comm& c_) : opt(o_), prob(p_), comm(c_) {}
@@ -3410,27 +3409,29 @@ struct Solver {
     BA_LAUNCH(ba_add_kernel, dim3(grid_for(V.n_c, 256)), dim3(256), st, V.n_c, tmpc.p, qout);
   }
 
+  // what the explicit formation of the exact tiers reads (ba_schur_explicit.h)
+  ba_explicit::FormArgs form_args() {
+    ba_explicit::FormArgs fa{};
+    fa.n_obs = V.n_obs; fa.n_points = V.n_points; fa.n_c = V.n_c; fa.kd = kd;
+    fa.Jpose = V.Jpose; fa.Jcam = V.Jcam; fa.Jsens = V.sens_off ? V.Jsens : nullptr; fa.Jpt = V.Jpt;
+    fa.Cinv = Cinv.p; fa.a2c = V.a2c; fa.pt_ptr = V.pt_ptr; fa.pt_off = V.pt_off;
+    fa.a_pose = V.a_pose; fa.a_cam = V.a_cam; fa.a_sensor = V.sens_off ? V.a_sensor : nullptr;
+    fa.a_pt = V.a_pt; fa.n_poses = V.n_poses;
+    fa.pose_off = V.pose_off; fa.pose_dim = V.pose_dim; fa.cam_off = V.cam_off; fa.cam_dim = V.cam_dim;
+    fa.sens_off = V.sens_off;
+    fa.fixed_point = opt.jacobi_scaling != 0;  // columns of norm < 1: integer accumulation, bit-reproducible
+    fa.bad = chol_info.p + 1;                  // raised by a term the fixed point cannot hold (NaN, out of bound)
+    fa.pairs = nullptr;
+    return fa;
+  }
+
   // DENSE_SCHUR: x = S^-1 rhs with S built from n_c operator products
   int dense_schur() {
     const int n = V.n_c;
     if (Sdense.n < (size_t)n * n + n) throw std::runtime_error("dense Schur buffer");
     if (!dense_by_products) {
-      // explicit formation (one wave per point) + blocked Cholesky on the f64 matrix cores
-      ba_explicit::FormArgs fa{};
-      fa.n_obs = V.n_obs; fa.n_points = V.n_points; fa.n_c = n; fa.kd = kd;
-      fa.Jpose = V.Jpose; fa.Jcam = V.Jcam; fa.Jsens = V.sens_off ? V.Jsens : nullptr; fa.Jpt = V.Jpt;
-      fa.Cinv = Cinv.p; fa.a2c = V.a2c; fa.pt_ptr = V.pt_ptr; fa.pt_off = V.pt_off;
-      fa.a_pose = V.a_pose; fa.a_cam = V.a_cam; fa.a_sensor = V.sens_off ? V.a_sensor : nullptr;
-      fa.a_pt = V.a_pt; fa.n_poses = V.n_poses;
-      fa.pose_off = V.pose_off; fa.pose_dim = V.pose_dim; fa.cam_off = V.cam_off; fa.cam_dim = V.cam_dim;
-      fa.sens_off = V.sens_off;
-      fa.fixed_point = opt.jacobi_scaling != 0;  // columns of norm < 1: integer accumulation, bit-reproducible
-      fa.bad = chol_info.p + 1;                  // raised by a term the fixed point cannot hold (NaN, out of bound)
-      if (!pair_lists_tried) {  // pair-major formation: the incidence lists depend on the topology only
-        pair_lists_tried = true;
-        const char* e_pairs = std::getenv("COLMAP_AMD_BA_FORM_PAIRS");  // 0: the point-major kernel (one atomic per term)
-        if (!e_pairs || std::atoi(e_pairs) != 0) (void)ba_explicit::build_pair_lists(fa, pair_lists, st);
-      }
+      // explicit formation (pair-major, or one wave per point) + blocked Cholesky on the f64 matrix cores
+      ba_explicit::FormArgs fa = form_args();
       fa.pairs = pair_lists.inc ? &pair_lists : nullptr;
       ba_explicit::form(fa, Sdense.p, st);
       if (use_priors()) ba_explicit::add_prior_rows(Sdense.p, n, Q.J, Q.po, Q.so, Q.pdim, Q.n, fa.fixed_point, fa.bad, st);
@@ -3642,6 +3643,10 @@ struct Solver {
           BA_HIP(hipEventCreateWithFlags(&ev_chol_panel, hipEventDisableTiming));
           BA_HIP(hipEventCreateWithFlags(&ev_chol_u2, hipEventDisableTiming));
         }
+        // pair-major formation: its incidence lists depend on the topology only -- built here, with the other
+        // per-solve structures, not inside the LM loop (COLMAP_AMD_BA_FORM_PAIRS=0: the point-major kernel)
+        const char* e_pairs = std::getenv("COLMAP_AMD_BA_FORM_PAIRS");
+        if (!e_pairs || std::atoi(e_pairs) != 0) (void)ba_explicit::build_pair_lists(form_args(), pair_lists, st);
       }
       BA_HIP(hipDeviceSynchronize());  // the allocation's memset runs on the NULL stream
     }
