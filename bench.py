@@ -191,6 +191,24 @@ def ba_secondary(a, local_rank, with_cpu, rank=0, world=1, dev=None):
             "reduced_system_size": n_c,
             "faster_tier_per_lm_iteration": "ITERATIVE_SCHUR (PCG)" if out["value"] > se.num_iterations / max(se.lm_seconds, 1e-12)
                                             else "SPARSE_SCHUR"}
+        # the same solve with the point-major formation (one atomic per term, the round-3 kernel): the difference in
+        # seconds per LM iteration is the formation's (the factorisation is the same code; `factor_ms_per_lm_iteration`)
+        old_env = os.environ.get("COLMAP_AMD_BA_FORM_PAIRS")
+        os.environ["COLMAP_AMD_BA_FORM_PAIRS"] = "0"
+        try:
+            sp = est.solve_flat(fp.copy(), est.SolverOptions(max_num_iterations=min(a.ba_iters, 6),
+                                                             linear_solver_type=est.SOLVER_SPARSE_SCHUR), gpu_index=local_rank)
+        finally:
+            if old_env is None:
+                os.environ.pop("COLMAP_AMD_BA_FORM_PAIRS", None)
+            else:
+                os.environ["COLMAP_AMD_BA_FORM_PAIRS"] = old_env
+        out["exact_tier"]["formation"] = {
+            "pair_major_ms_per_lm_iteration": 1e3 * se.lm_seconds / max(se.num_iterations, 1),
+            "point_major_ms_per_lm_iteration": 1e3 * sp.lm_seconds / max(sp.num_iterations, 1),
+            "factor_ms_per_lm_iteration": 1e3 * se.factor_seconds / max(se.num_iterations, 1),
+            "same_cost_log": bool(len(sp.log_cost) == len(se.log_cost) and
+                                  np.allclose(sp.log_cost, se.log_cost, rtol=1e-9, atol=0.0))}
     if sharded:
         out["sharded"] = sharded
     if with_cpu and world == 1:
