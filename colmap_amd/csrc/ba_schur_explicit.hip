@@ -883,11 +883,18 @@ bool build_pair_lists(const FormArgs& a, PairLists& pl, hipStream_t st) {
     release(false);
     return false;
   }
+  // (from here on a failing call releases everything and reports "not applicable": the caller falls back to the
+  //  point-major kernel; a sticky device error will surface at the caller's next checked call)
+  auto failed = [&](hipError_t e) {
+    if (e == hipSuccess) return false;
+    release(false);
+    return true;
+  };
   hipLaunchKernelGGL(inc_count_kernel, dim3((unsigned)((np1 + 255) / 256)), dim3(256), 0, st, a, cnt);
-  BAX_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, scan_bytes, cnt, off, np1, st));
+  if (failed(hipcub::DeviceScan::ExclusiveSum(tmp, scan_bytes, cnt, off, np1, st))) return false;
   unsigned long long total = 0;
-  BAX_HIP(hipMemcpyAsync(&total, off + a.n_points, sizeof(total), hipMemcpyDeviceToHost, st));
-  BAX_HIP(hipStreamSynchronize(st));
+  if (failed(hipMemcpyAsync(&total, off + a.n_points, sizeof(total), hipMemcpyDeviceToHost, st))) return false;
+  if (failed(hipStreamSynchronize(st))) return false;
   (void)hipFree(tmp);
   tmp = nullptr;
   if (total == 0 || total > (unsigned long long)INT_MAX) {
@@ -903,8 +910,9 @@ bool build_pair_lists(const FormArgs& a, PairLists& pl, hipStream_t st) {
     return false;
   }
   hipLaunchKernelGGL(inc_emit_kernel, dim3((unsigned)((a.n_points + 127) / 128)), dim3(128), 0, st, a, off, keys_in, vals_in);
-  BAX_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, sort_bytes, keys_in, keys_out, vals_in, vals_out, (int)total, 0, 32, st));
-  BAX_HIP(hipStreamSynchronize(st));
+  if (failed(hipcub::DeviceRadixSort::SortPairs(tmp, sort_bytes, keys_in, keys_out, vals_in, vals_out, (int)total, 0, 32, st)))
+    return false;
+  if (failed(hipStreamSynchronize(st))) return false;
   release(true);
   pl.inc = vals_out;
   pl.n_inc = (long long)total;
