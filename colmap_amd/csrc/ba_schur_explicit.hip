@@ -195,11 +195,13 @@ __global__ void __launch_bounds__(64) form_kernel(FormArgs A, double* __restrict
 // ---------------------------------------------------------------------------------------------------------
 // Pair-major formation (FormArgs::pairs): records, incidence lists, one wave per 64 incidences
 // ---------------------------------------------------------------------------------------------------------
-// Record of an observation, W rows of 8 doubles, row r = column r of its camera-side Jacobian J (2 x w):
-//   { F[r][0..2], J[0][r],  G[r][0..2], J[1][r] }      F = J^T (E C^-1) (w x 3),  G = J^T E (w x 3)
+// Record of an observation: two blocks of W rows of 4 doubles, row r = column r of its camera-side Jacobian J (2 x w):
+//   F block: { F[r][0..2], J[0][r] }      G block: { G[r][0..2], J[1][r] }      F = J^T (E C^-1), G = J^T E (w x 3 each)
 // (rows r >= w are zero), then the tangent index of every row as ints (-1 beyond w, padded to a multiple of four)
 // and four ints {pose, camera, sensor_from_rig, w}. With it the contribution of an ordered pair (a, b) of observations
-// of one point is  J_a^T (delta_ab I - E_a C^-1 E_b^T) J_b = delta_ab J_a^T J_a - F_a G_b^T.
+// of one point is  J_a^T (delta_ab I - E_a C^-1 E_b^T) J_b = delta_ab J_a^T J_a - F_a G_b^T: a pair reads the F block
+// of one record and the G block of the other -- each a contiguous 32 W bytes (the two halves of a row side by side
+// would leave half of every fetched line unused).
 constexpr int rec_rows4(int W) { return (W + 3) / 4 * 4; }
 constexpr int rec_stride(int W) { return 8 * W + (rec_rows4(W) + 4) / 2; }  // doubles; even: records stay 16-byte aligned
 inline int pick_width(const FormArgs& a) {  // the instantiated widths of both formations
@@ -236,11 +238,12 @@ __global__ void __launch_bounds__(128) form_records_kernel(FormArgs A, double* _
   const int so = (si >= 0 && A.sens_off) ? A.sens_off[si] : -1;
   int w = 0;
   auto put = [&](double j0, double j1, int idx) {
-    double2* row = reinterpret_cast<double2*>(R + 8 * w);
-    row[0] = make_double2(j0 * pj[0][0] + j1 * pj[1][0], j0 * pj[0][1] + j1 * pj[1][1]);
-    row[1] = make_double2(j0 * pj[0][2] + j1 * pj[1][2], j0);
-    row[2] = make_double2(j0 * e[0][0] + j1 * e[1][0], j0 * e[0][1] + j1 * e[1][1]);
-    row[3] = make_double2(j0 * e[0][2] + j1 * e[1][2], j1);
+    double2* fr = reinterpret_cast<double2*>(R + 4 * w);
+    double2* gr = reinterpret_cast<double2*>(R + 4 * W + 4 * w);
+    fr[0] = make_double2(j0 * pj[0][0] + j1 * pj[1][0], j0 * pj[0][1] + j1 * pj[1][1]);
+    fr[1] = make_double2(j0 * pj[0][2] + j1 * pj[1][2], j0);
+    gr[0] = make_double2(j0 * e[0][0] + j1 * e[1][0], j0 * e[0][1] + j1 * e[1][1]);
+    gr[1] = make_double2(j0 * e[0][2] + j1 * e[1][2], j1);
     RI[w] = idx;
     ++w;
   };
@@ -256,8 +259,9 @@ __global__ void __launch_bounds__(128) form_records_kernel(FormArgs A, double* _
     for (int d = 0; d < 6; ++d) put(A.Jsens[(size_t)d * N + c], A.Jsens[(size_t)(6 + d) * N + c], so + d);
   const int wv = w;
   for (; w < W; ++w) {
-    double2* row = reinterpret_cast<double2*>(R + 8 * w);
-    row[0] = row[1] = row[2] = row[3] = make_double2(0.0, 0.0);
+    double2* fr = reinterpret_cast<double2*>(R + 4 * w);
+    double2* gr = reinterpret_cast<double2*>(R + 4 * W + 4 * w);
+    fr[0] = fr[1] = gr[0] = gr[1] = make_double2(0.0, 0.0);
     RI[w] = -1;
   }
   for (int r = W; r < W4; ++r) RI[r] = -1;
@@ -379,15 +383,15 @@ __global__ void __launch_bounds__(64, (W * W + 63) / 64 <= 2 ? 8 : 1) form_pairs
 #pragma unroll
     for (int j = 0; j < NE; ++j) {
       const int r = er[j] < W ? er[j] : 0;
-      const double2* fr = reinterpret_cast<const double2*>(B.rh + 8 * r);
-      const double2* gr = reinterpret_cast<const double2*>(B.rl + 8 * ec[j]);
+      const double2* fr = reinterpret_cast<const double2*>(B.rh + 4 * r);                // F block of the first record
+      const double2* gr = reinterpret_cast<const double2*>(B.rl + 4 * W + 4 * ec[j]);    // G block of the second
       B.f0[j] = fr[0];
       B.f1[j] = fr[1];
-      B.g0[j] = gr[2];
-      B.g1[j] = gr[3];
-      // a self pair adds J[:, r] . J[:, c]: J[0][r] and J[1][c] come with the two halves above
-      B.j1r[j] = B.self ? B.rh[8 * r + 7] : 0.0;
-      B.j0c[j] = B.self ? B.rl[8 * ec[j] + 3] : 0.0;
+      B.g0[j] = gr[0];
+      B.g1[j] = gr[1];
+      // a self pair adds J[:, r] . J[:, c]: J[0][r] and J[1][c] come with the two rows above
+      B.j1r[j] = B.self ? B.rh[4 * W + 4 * r + 3] : 0.0;
+      B.j0c[j] = B.self ? B.rl[4 * ec[j] + 3] : 0.0;
     }
     const int* hh = reinterpret_cast<const int*>(B.rh + 8 * W);
     const int* hl = reinterpret_cast<const int*>(B.rl + 8 * W);
