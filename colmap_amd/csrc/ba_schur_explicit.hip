@@ -19,8 +19,8 @@
 //    are listed ONCE per solve on the device, sorted by the pair of pose blocks (hipCUB radix sort, stable: the
 //    order is deterministic); then one wave per 64 consecutive incidences, lane (r, c) accumulating
 //    -F_a[r] . G_b[c] in a register while the two images stay the same and adding the sum to S once per run.
-//    At 1 000 images x 200 000 points x track 10: 1.1e7 incidences, 4 x 16-byte loads per incidence and lane out of
-//    two contiguous 704-byte records, ~4e7 atomics -- against 6.4e8 atomics (one per term) for
+//    At 1 000 images x 200 000 points x track 10: 1.1e7 incidences, 4 x 16-byte loads per incidence and lane (the F
+//    block of one 704-byte record, the G block of the other), ~4e7 atomics -- against 6.4e8 atomics (one per term) for
 //  * the point-major formation (COLMAP_AMD_BA_FORM_PAIRS=0, and the fallback when the lists cannot be built): one
 //    wave per 3-D point stages the observations of the point in LDS and its lanes walk the (a, i, b, k) element
 //    space with the column index fastest. Only the lower triangle is written.
