@@ -2109,23 +2109,24 @@ __global__ void pm_rng_streams_kernel(const unsigned long long* __restrict__ see
 }
 
 // pixel records -> API layout (Mat<float> slice-major, mat.h:107-109)
-__global__ void pm_extract_kernel(const PmParams p, int sel_off, float* __restrict__ depth,
-                                  float* __restrict__ normal, float* __restrict__ sel,
-                                  float* __restrict__ cost) {
-  const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+// Thread = (pixel, field of its record): four neighbouring lanes read four consecutive floats of one record (16
+// contiguous bytes per quad: what the address unit coalesces), every thread issues ONE load, and a field's plane is
+// written by 16 lanes per wave as 64 contiguous bytes. A lane per pixel walking its 176-byte record -- every load of
+// the wave 64 lines apart, the loop over the sources rolled, one wait per trip -- took 3.9 ms per 2560 x 1920 image
+// (220 GB/s) for a copy of 0.87 GB.
+__global__ void __launch_bounds__(256) pm_extract_kernel(const PmParams p, int sel_off, float* __restrict__ depth,
+                                                         float* __restrict__ normal, float* __restrict__ sel,
+                                                         float* __restrict__ cost) {
+  const int pix = blockIdx.x * 64 + (threadIdx.x >> 2);
+  const int f = 4 * blockIdx.y + (threadIdx.x & 3);
   const int n = p.W * p.H;
-  if (pix >= n) return;
-  const float* rec = p.rec + (size_t)pix * p.rec_stride;
-  if (depth) depth[pix] = rec[0];
-  if (normal) {
-    normal[pix] = rec[1];
-    normal[(size_t)n + pix] = rec[2];
-    normal[(size_t)2 * n + pix] = rec[3];
-  }
-  for (int s = 0; s < p.S; ++s) {
-    if (sel) sel[(size_t)s * n + pix] = rec[sel_off + s];
-    if (cost) cost[(size_t)s * n + pix] = rec[4 + s];
-  }
+  if (pix >= n || f >= p.rec_stride) return;
+  float* out = nullptr;
+  if (f == 0) out = depth;
+  else if (f < 4) out = normal ? normal + (size_t)(f - 1) * n : nullptr;
+  else if (f < 4 + p.S) out = cost ? cost + (size_t)(f - 4) * n : nullptr;
+  else if (f >= sel_off && f < sel_off + p.S) out = sel ? sel + (size_t)(f - sel_off) * n : nullptr;
+  if (out) out[pix] = p.rec[(size_t)pix * p.rec_stride + f];
 }
 
 // ---------------------------------------------------------------------------
@@ -2269,7 +2270,7 @@ void pm_launch_rng_streams(const unsigned long long* seeds, int nseeds, int ndra
 void pm_launch_extract(const PmParams& p, int sel_off, float* depth, float* normal, float* sel,
                        float* cost, hipStream_t st) {
   const int n = p.W * p.H;
-  hipLaunchKernelGGL(pm_extract_kernel, dim3((n + 255) / 256), dim3(256), 0, st, p, sel_off, depth,
+  hipLaunchKernelGGL(pm_extract_kernel, dim3((n + 63) / 64, (p.rec_stride + 3) / 4), dim3(256), 0, st, p, sel_off, depth,
                      normal, sel, cost);
 }
 
