@@ -20,3 +20,13 @@ def run():
     np.testing.assert_allclose(b.poses, a.poses, atol=1e-6)
     print(f"smoke: BA HIP == oracle (final cost {got.final_cost:.9e}, rel diff "
           f"{abs(got.final_cost - want.final_cost) / want.final_cost:.1e}) on 12 cameras x 300 points")
+    # the exact tier (explicit reduced camera system, pair-major formation, blocked Cholesky) on the same problem
+    se = est.SolverOptions(gradient_tolerance=1e-8, function_tolerance=1e-12, max_num_iterations=30,
+                           linear_solver_type=est.SOLVER_DENSE_SCHUR)
+    a, b = fp.copy(), fp.copy()
+    want = est.solve_flat(a, se, solve_fn=ba_oracle.solve_fn)
+    got = est.solve_flat(b, se, gpu_index=0)
+    assert got.linear_solver_used == est.SOLVER_DENSE_SCHUR
+    assert abs(got.final_cost - want.final_cost) <= 1e-8 * want.final_cost, (got.final_cost, want.final_cost)
+    np.testing.assert_allclose(b.poses, a.poses, atol=1e-6)
+    print(f"smoke: BA exact tier HIP == oracle (final cost {got.final_cost:.9e}, {got.num_iterations} exact Newton steps)")
