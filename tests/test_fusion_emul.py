@@ -255,3 +255,32 @@ def test_emulated_kernel_random_configurations(request, which, seed, count):
         opt, images, overlap, what = _random_configuration(rng)
         want = fusion_oracle.fuse(opt, images, overlap, mode=1)
         assert _same(fusion.fuse(opt, images, overlap, entry_points=E), want), what
+
+
+def test_visibility_lists_behave_like_the_lists_they_stand_for(tmp_path):
+    """fusion.VisibilityLists (what fuse() returns instead of millions of small arrays): len / indexing / slicing /
+    iteration, and the .vis file written from it byte for byte the file written from plain lists
+    (WritePointsVisibility, fusion.cc:526-541), read back to the same lists; a truncated file is refused."""
+    import numpy as np
+    from colmap_amd import fusion as F
+    rng = np.random.default_rng(3)
+    lists = [sorted(rng.choice(9, size=int(rng.integers(0, 6)), replace=False).tolist()) for _ in range(200)]
+    ptr = np.concatenate([[0], np.cumsum([len(v) for v in lists])])
+    idx = np.array([i for v in lists for i in v], np.int32)
+    vis = F.VisibilityLists(ptr, idx)
+    assert len(vis) == 200 and [list(v) for v in vis] == lists
+    assert list(vis[7]) == lists[7] and list(vis[-1]) == lists[-1] and [list(v) for v in vis[10:13]] == lists[10:13]
+    with pytest.raises(IndexError):
+        vis[200]
+    a, b = str(tmp_path / "a.vis"), str(tmp_path / "b.vis")
+    F.write_points_visibility(a, vis)
+    F.write_points_visibility(b, lists)
+    assert open(a, "rb").read() == open(b, "rb").read()
+    back = F.read_points_visibility(a, 200)
+    assert [list(v) for v in back] == lists
+    with pytest.raises(ValueError):
+        F.read_points_visibility(a, 199)
+    raw = open(a, "rb").read()
+    open(a, "wb").write(raw[:-4])
+    with pytest.raises(ValueError):
+        F.read_points_visibility(a, 200)
