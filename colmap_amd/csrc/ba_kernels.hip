@@ -194,7 +194,15 @@ __device__ __forceinline__ double block_sum(double v) {
 __global__ void __launch_bounds__(1024) ba_final_sum_kernel(const double* __restrict__ partials, int n,
                                                             double* __restrict__ out) {
   double acc = 0.0;
-  for (int i = threadIdx.x; i < n; i += 1024) acc += partials[i];
+  int i = threadIdx.x;
+  for (; i + 7 * 1024 < n; i += 8 * 1024) {  // eight loads in flight, added in the rolled loop's order
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = partials[i + u * 1024];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += v[u];
+  }
+  for (; i < n; i += 1024) acc += partials[i];
   const double total = block_sum(acc);
   if (threadIdx.x == 0) *out = total;
 }
