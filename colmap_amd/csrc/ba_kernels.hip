@@ -2462,8 +2462,16 @@ __global__ void ba_maxdiff_kernel(size_t n, const double* __restrict__ a, const 
                                   double* __restrict__ scalars) {
   // grid-stride: at most 256 workgroups, one atomic per wave (the max is order-independent)
   double v = 0.0;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-    v = fmax(v, fabs(a[i] - b[i]));
+  const size_t step = (size_t)gridDim.x * blockDim.x;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + 3 * step < n; i += 4 * step) {  // eight loads in flight per trip (rolled: one pair, one wait)
+    double x[4], y[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { x[u] = a[i + u * step]; y[u] = b[i + u * step]; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v = fmax(v, fabs(x[u] - y[u]));
+  }
+  for (; i < n; i += step) v = fmax(v, fabs(a[i] - b[i]));
   for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
   if ((threadIdx.x & 63) == 0) atomic_max_pos(scalars + S_GMAX, v);
 }
