@@ -3655,7 +3655,11 @@ struct Solver {
         chol_linv.alloc(ws.linv_doubles(nc)); chol_tmp.alloc(nc); chol_info.alloc(2);  // [pivot flag, formation flag]
         const char* e_la = std::getenv("COLMAP_AMD_BA_CHOL_LOOKAHEAD");
         if (!e_la || std::atoi(e_la) != 0) {
-          BA_HIP(hipStreamCreateWithFlags(&st_chol, hipStreamNonBlocking));
+          // the second stream carries bulk trailing updates that run beside the serial chain of small kernels on the
+          // main stream: lowest priority, so that a freed workgroup slot goes to the chain first
+          int prio_least = 0, prio_greatest = 0;
+          BA_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+          BA_HIP(hipStreamCreateWithPriority(&st_chol, hipStreamNonBlocking, prio_least));
           BA_HIP(hipEventCreateWithFlags(&ev_chol_panel, hipEventDisableTiming));
           BA_HIP(hipEventCreateWithFlags(&ev_chol_u2, hipEventDisableTiming));
         }

@@ -503,7 +503,11 @@ __device__ __forceinline__ double readlane_f64(double v, int src) {
 //     behind wave 0 (Y = A~^-1: y_r /= d_r, y_rr -= A~[rr][r] y_r for the rows below; L^-1 = D^1/2 Y). Rows above j
 //     come out as exact zeros. (One wave doing both needs 256 VGPRs for the two matrices alone.)
 // Rows / columns beyond kb carry a unit diagonal and are not stored.
-__global__ void __launch_bounds__(128) chol_diag_kernel(double* __restrict__ S, int n, int k0, int kb,
+// Register budget: 256 per lane (launch bound 2 waves per SIMD), not the 263 the allocator would like -- this kernel
+// runs beside the lookahead stream's 128 x 128 trailing updates, whose waves hold 256 of a SIMD's 512 registers each:
+// a wave that needs more than the other half could only start on a CU the bulk update has drained completely, i.e.
+// the serial chain would wait for the update it is supposed to overlap.
+__global__ void __launch_bounds__(128, 2) chol_diag_kernel(double* __restrict__ S, int n, int k0, int kb,
                                                         double* __restrict__ Linv, int* __restrict__ info) {
   __shared__ double Ls[NB][NB + 1];
   __shared__ double col[2][NB];
