@@ -197,8 +197,9 @@ __global__ void __launch_bounds__(64) form_kernel(FormArgs A, double* __restrict
 // ---------------------------------------------------------------------------------------------------------
 // Record of an observation: two blocks of W rows of 4 doubles, row r = column r of its camera-side Jacobian J (2 x w):
 //   F block: { F[r][0..2], J[0][r] }      G block: { G[r][0..2], J[1][r] }      F = J^T (E C^-1), G = J^T E (w x 3 each)
-// (rows r >= w are zero), then the tangent index of every row as ints (-1 beyond w, padded to a multiple of four)
-// and four ints {pose, camera, sensor_from_rig, w}. With it the contribution of an ordered pair (a, b) of observations
+// (rows at FIXED slots: pose columns 0..5, intrinsics 6..6+kd-1, sensor_from_rig columns after them; a column the
+// observation does not have is a zero row), then the tangent index of every row as ints (-1: no such column; padded to
+// a multiple of four) and four ints {pose, camera, sensor_from_rig, number of columns}. With it the contribution of an ordered pair (a, b) of observations
 // of one point is  J_a^T (delta_ab I - E_a C^-1 E_b^T) J_b = delta_ab J_a^T J_a - F_a G_b^T: a pair reads the F block
 // of one record and the G block of the other -- each a contiguous 32 W bytes (the two halves of a row side by side
 // would leave half of every fetched line unused).
@@ -236,34 +237,57 @@ __global__ void __launch_bounds__(128) form_records_kernel(FormArgs A, double* _
   const int si = A.a_sensor ? A.a_sensor[a] : -1;
   const int po = A.pose_off[pi], co = A.cam_off[ci];
   const int so = (si >= 0 && A.sens_off) ? A.sens_off[si] : -1;
-  int w = 0;
-  auto put = [&](double j0, double j1, int idx) {
-    double2* fr = reinterpret_cast<double2*>(R + 4 * w);
-    double2* gr = reinterpret_cast<double2*>(R + 4 * W + 4 * w);
+  // Fixed slots: row d = pose column d, row 6 + d = intrinsics column d, row 6 + kd + d = sensor column d; a column the
+  // observation does not have (constant block, 5-wide pose, fewer refined intrinsics) is a zero row with index -1. Every
+  // loop has a compile-time trip count: all loads of a lane are in flight together (rolled over the block's dimension,
+  // each trip waited for its own pair of loads -- 8 to 20 serial round trips per lane).
+  int wv = 0;
+  auto put = [&](int slot, bool ok, double j0, double j1, int idx) {
+    double2* fr = reinterpret_cast<double2*>(R + 4 * slot);
+    double2* gr = reinterpret_cast<double2*>(R + 4 * W + 4 * slot);
     fr[0] = make_double2(j0 * pj[0][0] + j1 * pj[1][0], j0 * pj[0][1] + j1 * pj[1][1]);
     fr[1] = make_double2(j0 * pj[0][2] + j1 * pj[1][2], j0);
     gr[0] = make_double2(j0 * e[0][0] + j1 * e[1][0], j0 * e[0][1] + j1 * e[1][1]);
     gr[1] = make_double2(j0 * e[0][2] + j1 * e[1][2], j1);
-    RI[w] = idx;
-    ++w;
+    RI[slot] = ok ? idx : -1;
+    wv += ok ? 1 : 0;
   };
-  if (po >= 0) {
-    const int pdim = A.pose_dim[pi];
-    for (int d = 0; d < pdim; ++d) put(A.Jpose[(size_t)d * N + c], A.Jpose[(size_t)(kPoseDim + d) * N + c], po + d);
+  const int pdim = po >= 0 ? A.pose_dim[pi] : 0;
+  const int cdim = co >= 0 ? A.cam_dim[ci] : 0;
+  {
+    double j0[kPoseDim], j1[kPoseDim];
+#pragma unroll
+    for (int d = 0; d < kPoseDim; ++d) {
+      j0[d] = d < pdim ? A.Jpose[(size_t)d * N + c] : 0.0;
+      j1[d] = d < pdim ? A.Jpose[(size_t)(kPoseDim + d) * N + c] : 0.0;
+    }
+#pragma unroll
+    for (int d = 0; d < kPoseDim; ++d) put(d, d < pdim, j0[d], j1[d], po + d);
   }
-  if (co >= 0) {
-    const int cdim = A.cam_dim[ci];
-    for (int d = 0; d < cdim; ++d) put(A.Jcam[(size_t)d * N + c], A.Jcam[(size_t)(A.kd + d) * N + c], co + d);
+  {
+    constexpr int KDMAX = W - kPoseDim;  // (>= kd for every instance: pick_width)
+    double j0[KDMAX], j1[KDMAX];
+#pragma unroll
+    for (int d = 0; d < KDMAX; ++d) {
+      j0[d] = d < cdim ? A.Jcam[(size_t)d * N + c] : 0.0;
+      j1[d] = d < cdim ? A.Jcam[(size_t)(A.kd + d) * N + c] : 0.0;
+    }
+#pragma unroll
+    for (int d = 0; d < KDMAX; ++d)
+      if (d < A.kd) put(kPoseDim + d, d < cdim, j0[d], j1[d], co + d);
   }
-  if (so >= 0)
-    for (int d = 0; d < 6; ++d) put(A.Jsens[(size_t)d * N + c], A.Jsens[(size_t)(6 + d) * N + c], so + d);
-  const int wv = w;
-  for (; w < W; ++w) {
-    double2* fr = reinterpret_cast<double2*>(R + 4 * w);
-    double2* gr = reinterpret_cast<double2*>(R + 4 * W + 4 * w);
-    fr[0] = fr[1] = gr[0] = gr[1] = make_double2(0.0, 0.0);
-    RI[w] = -1;
+  const int s0 = kPoseDim + A.kd;  // first sensor slot
+  if (A.Jsens) {
+    double j0[6], j1[6];
+#pragma unroll
+    for (int d = 0; d < 6; ++d) {
+      j0[d] = so >= 0 ? A.Jsens[(size_t)d * N + c] : 0.0;
+      j1[d] = so >= 0 ? A.Jsens[(size_t)(6 + d) * N + c] : 0.0;
+    }
+#pragma unroll
+    for (int d = 0; d < 6; ++d) put(s0 + d, so >= 0, j0[d], j1[d], so + d);
   }
+  for (int r = s0 + (A.Jsens ? 6 : 0); r < W; ++r) put(r, false, 0.0, 0.0, -1);  // (slots the problem never uses)
   for (int r = W; r < W4; ++r) RI[r] = -1;
   RI[W4] = pi;
   RI[W4 + 1] = ci;
@@ -513,8 +537,17 @@ __global__ void __launch_bounds__(128, 2) chol_diag_kernel(double* __restrict__ 
   __shared__ double col[2][NB];
   __shared__ double dsq[NB];  // sqrt(pivot)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int r = wave; r < NB; r += 2)  // coalesced: lane = column
-    Ls[r][lane] = (r < kb && lane <= r) ? S[(size_t)(k0 + r) * n + k0 + lane] : (r == lane ? 1.0 : 0.0);
+  {  // coalesced: lane = column; the 32 loads of a lane in flight together (rolled: 32 serial round trips, more than
+     // the factorisation itself takes)
+    double stage[NB / 2];
+#pragma unroll
+    for (int i = 0; i < NB / 2; ++i) {
+      const int r = wave + 2 * i;
+      stage[i] = (r < kb && lane <= r) ? S[(size_t)(k0 + r) * n + k0 + lane] : (r == lane ? 1.0 : 0.0);
+    }
+#pragma unroll
+    for (int i = 0; i < NB / 2; ++i) Ls[wave + 2 * i][lane] = stage[i];
+  }
   __syncthreads();
   double a[NB];
   // (The two waves run separate straight-line code with the same number of barriers -- 64 in the loop, one after it:
