@@ -1930,7 +1930,7 @@ __global__ void ba_inc_correct_kernel(View V, IncView I, const double* __restric
 
 // M_b += Dc^2 on the diagonal, then invert (Gauss-Jordan with partial pivoting); lane per block
 template <int BD>
-__global__ void ba_block_invert_kernel(View V, const double* __restrict__ Dc, const double* __restrict__ M,
+__global__ void __launch_bounds__(64) ba_block_invert_kernel(View V, const double* __restrict__ Dc, const double* __restrict__ M,
                                        double* __restrict__ Minv) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= V.n_blk) return;
