@@ -2170,7 +2170,9 @@ __device__ __forceinline__ double pcg_sum(const double* __restrict__ part, int n
   for (int w = 0; w < nparts; ++w) s += part[w];
   return s;
 }
-// x = 0, r = b, z = Minv r, partials of rho_1 into bank 1
+// x = 0, r = b, z = Minv r, partials of rho_1 into bank 1 (component loops unrolled to the block width like the step
+// kernel's: the sums in the rolled order)
+template <int BD>
 __global__ void __launch_bounds__(256) ba_pcgp_init_kernel(View V, PcgDev D, const double* __restrict__ Minv,
                                                            const double* __restrict__ rhs, double* __restrict__ x,
                                                            double* __restrict__ r, double* __restrict__ z) {
@@ -2179,12 +2181,35 @@ __global__ void __launch_bounds__(256) ba_pcgp_init_kernel(View V, PcgDev D, con
   if (b < V.n_blk) {
     const int n = V.blk_dim[b], off = V.blk_off[b];
     const double* Mi = Minv + V.blk_moff[b];
-    for (int i = 0; i < n; ++i) { x[off + i] = 0.0; r[off + i] = rhs[off + i]; }
-    for (int i = 0; i < n; ++i) {
-      double sacc = 0.0;
-      for (int j = 0; j < n; ++j) sacc += Mi[i * n + j] * rhs[off + j];
-      z[off + i] = sacc;
-      rho += sacc * rhs[off + i];
+    double bv[BD];
+#pragma unroll
+    for (int i = 0; i < BD; ++i) bv[i] = i < n ? rhs[off + i] : 0.0;
+    double mi[BD][BD];
+    if constexpr (BD <= 8) {
+#pragma unroll
+      for (int i = 0; i < BD; ++i)
+#pragma unroll
+        for (int j = 0; j < BD; ++j) mi[i][j] = (i < n && j < n) ? Mi[i * n + j] : 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < BD; ++i)
+      if (i < n) { x[off + i] = 0.0; r[off + i] = bv[i]; }
+#pragma unroll
+    for (int i = 0; i < BD; ++i) {
+      if (i < n) {
+        double sacc = 0.0;
+        if constexpr (BD <= 8) {
+#pragma unroll
+          for (int j = 0; j < BD; ++j)
+            if (j < n) sacc += mi[i][j] * bv[j];
+        } else {
+#pragma unroll
+          for (int j = 0; j < BD; ++j)
+            if (j < n) sacc += Mi[i * n + j] * bv[j];
+        }
+        z[off + i] = sacc;
+        rho += sacc * bv[i];
+      }
     }
   }
   rho = block_sum(rho);
@@ -3533,7 +3558,9 @@ struct Solver {
     }
     PcgDev D;
     D.part = pcgp_part.p; D.nparts = nparts; D.stop = pcgp_stop.p; D.host = pcgp_host_dev; D.qhist = pcgp_qhist.p;
-    BA_LAUNCH(ba_pcgp_init_kernel, dim3(nparts), dim3(256), st, V, D, Minv.p, rhs.p, x.p, r.p, z.p);
+    if (bd == PD) BA_LAUNCH(ba_pcgp_init_kernel<PD>, dim3(nparts), dim3(256), st, V, D, Minv.p, rhs.p, x.p, r.p, z.p);
+    else if (bd == KD_MAX) BA_LAUNCH(ba_pcgp_init_kernel<KD_MAX>, dim3(nparts), dim3(256), st, V, D, Minv.p, rhs.p, x.p, r.p, z.p);
+    else BA_LAUNCH(ba_pcgp_init_kernel<KD_WIDE>, dim3(nparts), dim3(256), st, V, D, Minv.p, rhs.p, x.p, r.p, z.p);
     V.stop = pcgp_stop.p;  // the streaming kernels of an iteration enqueued past convergence return at entry
     auto enqueue = [&](int k) {
       BA_LAUNCH(ba_pcgp_dir_kernel, dim3(gv), dim3(256), st, n, D, k, max_iter, q_tol, z.p, pdir.p);
