@@ -81,7 +81,7 @@ struct Workspace {
   // optional lookahead: a second stream and two events (all three or none)
   hipStream_t st2 = nullptr;
   hipEvent_t ev_panel = nullptr, ev_u2 = nullptr;
-  // trailing updates with at least this many rows (and 256 columns) run 128 x 128 tiles, smaller ones 64 x 64
+  // trailing updates with at least this many rows (and more than 256 columns) run 128 x 128 tiles, smaller ones 64 x 64
   // (a knob for the tests: the stand-in cannot afford the sizes at which the large tiles pay)
   int min_rows128 = 12 * 128;
   size_t linv_doubles(int n) const { return (size_t)((n + 63) / 64) * 64 * 64; }

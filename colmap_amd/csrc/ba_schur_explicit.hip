@@ -1007,7 +1007,10 @@ void factor_solve(double* S, int n, const double* rhs, double* x, const Workspac
   auto launch = [&](int k0, int kb, int row0, int col0, int cend, hipStream_t s_) {
     const int rows = nrows - row0, cols = std::min(cend, n) - col0;
     if (rows <= 0 || cols <= 0) return;
-    if (rows >= ws.min_rows128 && cols >= 256) {
+    // 128 x 128 tiles where they are many (the bulk of the trailing matrix); the 256 columns of the next outer panel
+    // (U1, on the critical path: rows / 64 workgroups of 128-tiles would leave more than half of the 256 CUs without
+    // work) and small remainders take 64 x 64 tiles: four times the workgroups, a quarter of the work each
+    if (rows >= ws.min_rows128 && cols > 256) {
       hipLaunchKernelGGL(chol_update128_kernel, dim3((cols + 127) / 128, (rows + 127) / 128), dim3(256), 0, s_, S, n, nrows,
                          k0, kb, row0, col0, std::min(cend, n));
     } else {

@@ -66,7 +66,7 @@ elif which == 'ba':
     for shared_cams, rigs, fixed in ((False, False, True), (True, False, True), (True, True, True), (True, True, False)):
         TE.test_pair_major_formation_against_numpy_and_the_point_major_kernel(shared_cams, rigs, fixed)
         print('formation', shared_cams, rigs, fixed, 'ok', flush=True)
-    for n, m128 in ((45, 12 * 128), (64, 12 * 128), (333, 12 * 128), (600, 256)):
+    for n, m128 in ((45, 12 * 128), (64, 12 * 128), (333, 12 * 128), (900, 256)):
         TE.test_blocked_cholesky_directly_against_numpy(n, m128); print('factor_solve', n, 'ok', flush=True)
     TE.test_blocked_cholesky_reports_a_failed_pivot(); print('failed pivot ok', flush=True)
     for scale, expect_bad in ((0.1, False), (100.0, True)):
