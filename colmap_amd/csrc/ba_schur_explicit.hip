@@ -30,7 +30,8 @@
 //    factorisation in one, the inverse of the triangle in the other), so that the panel solve below it becomes a
 //    GEMM  X = A_panel L_kk^-T; the trailing update C_IJ -= X_I X_J^T runs 128 x 128 (4 x 4 MFMA tiles per wave,
 //    next K chunk prefetched into registers) or 64 x 64 tiles per workgroup, accumulators initialised from the tile.
-//  * Triangular solves with the stored block inverses: one launch per block step (forward and backward).
+//  * Triangular solves with the stored block inverses: the forward one rides along with the factorisation (the
+//    right-hand side is row n of the matrix), the backward one takes one launch per outer panel of 256 columns.
 #include "ba_schur_explicit.h"
 
 #include <hipcub/hipcub.hpp>
@@ -803,44 +804,70 @@ __global__ void __launch_bounds__(256, 2) chol_update128_kernel(double* __restri
       }
 }
 
-// Backward step k: x_k <- L_kk^-T w_k (final), columns left of it: w_j -= L_kj^T x_k. block.x = 256, grid = 1 + #column
-// tiles left of the block; every workgroup recomputes the 64-vector (cheap), workgroup 0 publishes it.
-// Thread = (column, quarter): a quarter of the 64 terms each (16 loads in flight per thread instead of a chain of 64),
-// the four partial sums added in quarter order (a fixed tree: reproducible).
-__global__ void __launch_bounds__(256) solve_backward_kernel(const double* __restrict__ S, int n, int k0, int kb,
-                                                             const double* __restrict__ Linv, double* __restrict__ w,
-                                                             double* __restrict__ x) {
-  __shared__ double xk[NB];
-  __shared__ double raw[NB];
+// Backward substitution, one launch per OUTER panel of up to 256 columns [p0, p0 + pw): x_P <- L_PP^-T w_P (final), then
+// the columns left of the panel: w_j -= L_Pj^T x_P. Every workgroup recomputes x_P -- the panel's up to four 64-blocks
+// from the last to the first, each  x_k = L_kk^-T w_k  with the stored inverse, then  w_j -= L_kj^T x_k  for the blocks
+// j < k of the panel: ten small matrix-vector products out of L2 -- and workgroup 0 publishes it; workgroup 1 + t
+// updates the 64 columns of tile t with all 256 terms. 32 launches at n = 8 000 instead of 125 (one per 64-block, each a
+// dependent launch of ~10 us). Thread = (column, quarter): a quarter of the terms each, the four partial sums added in
+// quarter order (a fixed tree: reproducible). Working vector w and output x must be different arrays: workgroup 0
+// publishes the panel while the other workgroups of the same launch still read its raw values.
+__global__ void __launch_bounds__(256) solve_backward_panel_kernel(const double* __restrict__ S, int n, int p0, int pw,
+                                                                   const double* __restrict__ Linv, double* __restrict__ w,
+                                                                   double* __restrict__ x) {
+  constexpr int OBK = 256;
+  __shared__ double xs[OBK];
+  __shared__ double wv[OBK];
   __shared__ double part[4][NB];
-  const int col = threadIdx.x & 63, q = threadIdx.x >> 6;
-  if (q == 0) raw[col] = col < kb ? w[k0 + col] : 0.0;
+  const int tid = threadIdx.x, col = tid & 63, q = tid >> 6;
+  wv[tid] = tid < pw ? w[p0 + tid] : 0.0;
+  xs[tid] = 0.0;
   __syncthreads();
-  {
-    double v = 0.0;  // (L^-1)^T: column `col` of L^-1 (zeros above the diagonal)
+  const int nb = (pw + NB - 1) / NB;
+  for (int kb = nb - 1; kb >= 0; --kb) {
+    const int k0 = p0 + NB * kb, kw = min(NB, pw - NB * kb);
+    const double* Li = Linv + (size_t)kb * NB * NB;
+    {
+      double v = 0.0;  // (L^-1)^T: column `col` of L^-1 (zeros above the diagonal, zero-padded beyond kw)
 #pragma unroll
-    for (int j = 0; j < 16; ++j) v += Linv[(16 * q + j) * NB + col] * raw[16 * q + j];
-    part[q][col] = v;
+      for (int j = 0; j < 16; ++j) v += Li[(16 * q + j) * NB + col] * wv[NB * kb + 16 * q + j];
+      part[q][col] = v;
+    }
+    __syncthreads();
+    if (q == 0) xs[NB * kb + col] = col < kw ? ((part[0][col] + part[1][col]) + (part[2][col] + part[3][col])) : 0.0;
+    __syncthreads();
+    for (int jb = 0; jb < kb; ++jb) {
+      double acc = 0.0;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int m = 16 * q + j;
+        acc += (m < kw ? S[(size_t)(k0 + m) * n + p0 + NB * jb + col] : 0.0) * xs[NB * kb + m];
+      }
+      part[q][col] = acc;
+      __syncthreads();
+      if (q == 0) wv[NB * jb + col] -= (part[0][col] + part[1][col]) + (part[2][col] + part[3][col]);
+      __syncthreads();
+    }
   }
-  __syncthreads();
-  if (q == 0) xk[col] = col < kb ? ((part[0][col] + part[1][col]) + (part[2][col] + part[3][col])) : 0.0;
-  __syncthreads();
   if (blockIdx.x == 0) {
-    if (q == 0 && col < kb) x[k0 + col] = xk[col];
+    if (tid < pw) x[p0 + tid] = xs[tid];
     return;
   }
   const int c = NB * (blockIdx.x - 1) + col;
   double acc = 0.0;
-  if (c < k0) {
+  if (c < p0) {
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const int m = 16 * q + j;
-      acc += (m < kb ? S[(size_t)(k0 + m) * n + c] : 0.0) * xk[m];
+    for (int mb = 0; mb < OBK / NB; ++mb) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int m = NB * mb + 16 * q + j;
+        acc += (m < pw ? S[(size_t)(p0 + m) * n + c] : 0.0) * xs[m];
+      }
     }
   }
   part[q][col] = acc;
   __syncthreads();
-  if (q == 0 && c < k0) w[c] -= (part[0][col] + part[1][col]) + (part[2][col] + part[3][col]);
+  if (q == 0 && c < p0) w[c] -= (part[0][col] + part[1][col]) + (part[2][col] + part[3][col]);
 }
 
 __global__ void nan_fill_kernel(int n, const int* __restrict__ info, double* __restrict__ x) {
@@ -983,7 +1010,6 @@ void add_prior_rows(double* S, int n, const double* J, const int* po, const int*
 void factor_solve(double* S, int n, const double* rhs, double* x, const Workspace& ws, hipStream_t st,
                   hipEvent_t ev_a, hipEvent_t ev_b, double* mfma_ms) {
   BAX_HIP(hipMemsetAsync(ws.info, 0, sizeof(int), st));
-  const int nblk = (n + NB - 1) / NB;
   if (mfma_ms) *mfma_ms = 0.0;
   // The forward substitution rides along with the factorisation: the right-hand side is row n of the matrix (the
   // caller's buffer has n + 1 rows). Factoring [[S, b], [b^T, .]] leaves y^T = (L^-1 b)^T in that row -- the panel
@@ -1054,15 +1080,13 @@ void factor_solve(double* S, int n, const double* rhs, double* x, const Workspac
   }
   if (u2_pending) BAX_HIP(hipStreamWaitEvent(st, ws.ev_u2, 0));
   if (ev_b) BAX_HIP(hipEventRecord(ev_b, st));
-  // L^T x = y with y = row n of the factor, ws.tmp as the working vector (a step reads its own block of it raw -- in
-  // every workgroup -- and updates the columns to its left) and x as the output. Working vector and output must be
-  // different arrays: workgroup 0 publishes a block while the other workgroups of the same launch still read its raw
-  // values.
+  // L^T x = y with y = row n of the factor, ws.tmp as the working vector (a step reads its own panel of it raw -- in
+  // every workgroup -- and updates the columns to its left) and x as the output, one launch per outer panel.
   BAX_HIP(hipMemcpyAsync(ws.tmp, S + (size_t)n * n, sizeof(double) * n, hipMemcpyDeviceToDevice, st));
-  for (int kblk = nblk - 1; kblk >= 0; --kblk) {
-    const int k0 = kblk * NB, kb = std::min(NB, n - k0);
-    hipLaunchKernelGGL(solve_backward_kernel, dim3(1 + kblk), dim3(256), 0, st, S, n, k0, kb,
-                       ws.Linv + (size_t)kblk * NB * NB, ws.tmp, x);
+  for (int p0 = (n - 1) / OB * OB; p0 >= 0; p0 -= OB) {
+    const int pw = std::min(OB, n - p0);
+    hipLaunchKernelGGL(solve_backward_panel_kernel, dim3(1 + p0 / NB), dim3(256), 0, st, S, n, p0, pw,
+                       ws.Linv + (size_t)(p0 / NB) * NB * NB, ws.tmp, x);
   }
   hipLaunchKernelGGL(nan_fill_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, ws.info, x);
   if (mfma_ms && ev_a && ev_b) {
