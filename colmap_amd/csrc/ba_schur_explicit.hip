@@ -26,10 +26,12 @@
 //    space with the column index fastest. Only the lower triangle is written.
 //    In both, the atomics are INTEGER adds of 2^-60 fixed-point values (FIXED): order-independent, so this tier is
 //    bit-reproducible like the iterative one (the pair-major sums inside a run are in list order).
-//  * Factorisation: right-looking, 64-wide panels. Diagonal block: two waves with the matrices in registers (the
-//    factorisation in one, the inverse of the triangle in the other), so that the panel solve below it becomes a
-//    GEMM  X = A_panel L_kk^-T; the trailing update C_IJ -= X_I X_J^T runs 128 x 128 (4 x 4 MFMA tiles per wave,
-//    next K chunk prefetched into registers) or 64 x 64 tiles per workgroup, accumulators initialised from the tile.
+//  * Factorisation: right-looking, outer panels of 256 columns. Inside a panel 64-wide steps on the panel's own rows only
+//    -- diagonal block: two waves with the matrices in registers (the factorisation in one, the inverse of the triangle
+//    in the other), so that the panel solve below it becomes a GEMM  X = A_panel L_kk^-T --, then the strip below the
+//    panel in one pass (chol_strip_kernel: a workgroup's 64 x 256 tile stays in the accumulators through the block-column
+//    recursion), then the trailing update C_IJ -= X_I X_J^T in 128 x 128 (4 x 4 MFMA tiles per wave, next K chunk
+//    prefetched into registers) or 64 x 64 tiles per workgroup, accumulators initialised from the tile.
 //  * Triangular solves with the stored block inverses: the forward one rides along with the factorisation (the
 //    right-hand side is row n of the matrix), the backward one takes one launch per outer panel of 256 columns.
 #include "ba_schur_explicit.h"
@@ -648,6 +650,95 @@ __global__ void __launch_bounds__(256) chol_panel_kernel(double* __restrict__ S,
     }
 }
 
+// The strip below an outer panel [o0, o0 + ow), ow <= 256: X = A_strip L_PP^-T for the rows [row0, nrows), in place, once
+// the panel's diagonal block L_PP is final (its 64-blocks L_jk in S, the inverses of its diagonal blocks in Linv). One
+// workgroup per 64 rows, the 64 x 256 tile in the matrix-core accumulators (wave w: rows 16 w .. 16 w + 15, sixteen 16 x 16
+// tiles = 64 doubles per lane) for the whole block-column recursion
+//     X_k = A_k L_kk^-T ;   A_j -= X_k L_jk^T   (j > k),      k = 0 .. 3,
+// so the strip is read once and written once. (Done 64 columns at a time over all rows -- panel kernel, then the update of
+// the panel's remaining columns -- the same arithmetic passed ten times over the strip: 4.9 GB per factorisation at
+// n = 8 000, and every pass was a launch on the critical chain.) X_k goes from accumulator layout to operand layout
+// through a per-wave LDS tile; L_kk^-1 / L_jk are staged in LDS for all four waves.
+__global__ void __launch_bounds__(256, 2) chol_strip_kernel(double* __restrict__ S, int n, int nrows, int o0, int ow, int row0,
+                                                         const double* __restrict__ Linv) {
+  __shared__ double xs[4][16][NB + 1];
+  __shared__ double sB[NB][NB + 1];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 15, lk = lane >> 4;
+  const int r0 = row0 + NB * blockIdx.x + 16 * wave;  // first row of the wave
+  v4f64 acc[16];
+#pragma unroll
+  for (int t = 0; t < 16; ++t)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int r = r0 + lk + 4 * reg, c = 16 * t + li;
+      acc[t][reg] = (r < nrows && c < ow) ? S[(size_t)r * n + o0 + c] : 0.0;
+    }
+  auto stage = [&](int k) {  // block k of the tile, accumulator layout -> xs[wave][row][column]
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) xs[wave][lk + 4 * reg][16 * tt + li] = acc[4 * k + tt][reg];
+  };
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (NB * k >= ow) break;  // (a short last outer panel)
+    stage(k);
+    __syncthreads();  // xs written; the previous readers of sB are done
+    {
+      const double* Li = Linv + (size_t)k * NB * NB;
+      double v[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) v[i] = Li[tid + 256 * i];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) sB[(tid + 256 * i) >> 6][(tid + 256 * i) & 63] = v[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {  // X_k = A_k L_kk^-T
+      v4f64 x = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int ks = 0; ks < NB / 4; ++ks) {
+        const int m = 4 * ks + lk;
+        x = __builtin_amdgcn_mfma_f64_16x16x4f64(xs[wave][li][m], sB[16 * ct + li][m], x, 0, 0, 0);
+      }
+      acc[4 * k + ct] = x;
+    }
+    __syncthreads();  // every wave has read xs (its own) and sB
+    stage(k);         // X_k in operand position for the updates
+#pragma unroll
+    for (int j = k + 1; j < 4; ++j) {
+      if (NB * j >= ow) break;
+      {
+        double v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int e = tid + 256 * i, jc = e >> 6, m = e & 63;
+          v[i] = (NB * j + jc < ow && NB * k + m < ow) ? S[(size_t)(o0 + NB * j + jc) * n + o0 + NB * k + m] : 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sB[(tid + 256 * i) >> 6][(tid + 256 * i) & 63] = v[i];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int ks = 0; ks < NB / 4; ++ks) {
+          const int m = 4 * ks + lk;
+          acc[4 * j + ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(-xs[wave][li][m], sB[16 * ct + li][m], acc[4 * j + ct], 0, 0, 0);
+        }
+      __syncthreads();  // before sB is overwritten
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 16; ++t)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int r = r0 + lk + 4 * reg, c = 16 * t + li;
+      if (r < nrows && c < ow) S[(size_t)r * n + o0 + c] = acc[t][reg];
+    }
+}
+
 // Trailing update C_IJ -= X_I X_J^T for the 64 x 64 tiles I >= J of the trailing matrix (rows / columns from
 // t0 = k0 + kb). Wave w owns the 32 x 32 quadrant (w >> 1, w & 1): 2 x 2 MFMA tiles; K = kb in halves of 32.
 // (general form: C[r][c] -= sum_{m in [k0, k0 + kb)} S[r][m] S[c][m] for rows r >= row0 and columns c in
@@ -1030,22 +1121,22 @@ void factor_solve(double* S, int n, const double* rhs, double* x, const Workspac
   // update(k0, kb, t0, cend): C[r][c] -= sum_m S[r][m] S[c][m], m in [k0, k0 + kb), rows r >= t0, columns
   // c in [t0, cend). update_cols(.., c0, cend): the same for columns [c0, cend) only (rows r >= c0: the lower
   // triangle has no entries above the diagonal of the first column).
-  auto launch = [&](int k0, int kb, int row0, int col0, int cend, hipStream_t s_) {
-    const int rows = nrows - row0, cols = std::min(cend, n) - col0;
+  auto launch = [&](int k0, int kb, int row0, int col0, int cend, hipStream_t s_, int rows_end) {
+    const int rows = rows_end - row0, cols = std::min(cend, n) - col0;
     if (rows <= 0 || cols <= 0) return;
     // 128 x 128 tiles where they are many (the bulk of the trailing matrix); the 256 columns of the next outer panel
     // (U1, on the critical path: rows / 64 workgroups of 128-tiles would leave more than half of the 256 CUs without
     // work) and small remainders take 64 x 64 tiles: four times the workgroups, a quarter of the work each
     if (rows >= ws.min_rows128 && cols > 256) {
-      hipLaunchKernelGGL(chol_update128_kernel, dim3((cols + 127) / 128, (rows + 127) / 128), dim3(256), 0, s_, S, n, nrows,
+      hipLaunchKernelGGL(chol_update128_kernel, dim3((cols + 127) / 128, (rows + 127) / 128), dim3(256), 0, s_, S, n, rows_end,
                          k0, kb, row0, col0, std::min(cend, n));
     } else {
-      hipLaunchKernelGGL(chol_update_kernel, dim3((cols + NB - 1) / NB, (rows + NB - 1) / NB), dim3(256), 0, s_, S, n, nrows,
+      hipLaunchKernelGGL(chol_update_kernel, dim3((cols + NB - 1) / NB, (rows + NB - 1) / NB), dim3(256), 0, s_, S, n, rows_end,
                          k0, kb, row0, col0, std::min(cend, n));
     }
   };
-  auto update = [&](int k0, int kb, int t0, int cend, hipStream_t s_) { launch(k0, kb, t0, t0, cend, s_); };
-  auto update_cols = [&](int k0, int kb, int /*t0*/, int c0, int cend, hipStream_t s_) { launch(k0, kb, c0, c0, cend, s_); };
+  auto update = [&](int k0, int kb, int t0, int cend, hipStream_t s_) { launch(k0, kb, t0, t0, cend, s_, nrows); };
+  auto update_cols = [&](int k0, int kb, int /*t0*/, int c0, int cend, hipStream_t s_) { launch(k0, kb, c0, c0, cend, s_, nrows); };
   // Lookahead over two streams (ws.st2 set): the outer update of panel o is split into U1 = the columns of the
   // NEXT outer panel (main stream, the next panel's steps need them) and U2 = everything right of that (second
   // stream), so U2(o) runs while the 64-wide steps of panel o + 1 -- serial, latency-bound kernels -- are under
@@ -1058,10 +1149,16 @@ void factor_solve(double* S, int n, const double* rhs, double* x, const Workspac
       const int kb = std::min(NB, n - k0);
       double* Li = ws.Linv + (size_t)(k0 / NB) * NB * NB;
       hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(128), 0, st, S, n, k0, kb, Li, ws.info);
-      const int below = nrows - k0 - kb;  // (>= 1: the right-hand side's row)
-      hipLaunchKernelGGL(chol_panel_kernel, dim3((below + NB - 1) / NB), dim3(256), 0, st, S, n, nrows, k0, kb, Li);
-      update(k0, kb, k0 + kb, oend, st);  // the rest of this outer panel only
+      // the 64-wide steps stay inside the outer panel's own rows [k0 + kb, oend): at most three workgroups each
+      const int below = oend - k0 - kb;
+      if (below > 0) {
+        hipLaunchKernelGGL(chol_panel_kernel, dim3((below + NB - 1) / NB), dim3(256), 0, st, S, n, oend, k0, kb, Li);
+        launch(k0, kb, k0 + kb, k0 + kb, oend, st, oend);
+      }
     }
+    // everything below the outer panel (incl. the right-hand side's row): the whole block-column recursion in one pass
+    hipLaunchKernelGGL(chol_strip_kernel, dim3((nrows - oend + NB - 1) / NB), dim3(256), 0, st, S, n, nrows, o0, oend - o0, oend,
+                       ws.Linv + (size_t)(o0 / NB) * NB * NB);
     if (oend >= n) break;
     if (!lookahead) {
       update(o0, oend - o0, oend, n, st);  // everything right of the outer panel, K = 256
