@@ -38,6 +38,26 @@ def solve_fn(p, o, r):
     return lib().bao_solve(p, o, r)
 
 
+_lib_fast = None
+
+
+def lib_fast():
+    """The same source compiled with -O3 and the compiler's default contraction (oracle/Makefile): a few-ulp perturbation
+    of the oracle's own arithmetic. Only tests/ba_compare.py uses it, to measure the noise floor of a comparison."""
+    global _lib_fast
+    if _lib_fast is None:
+        path = os.path.join(_HERE, "libba_oracle_fast.so")
+        if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(os.path.join(_HERE, "ba_oracle.c")):
+            subprocess.check_call(["make", "-C", _HERE, "libba_oracle_fast.so"], stdout=subprocess.DEVNULL)
+        _lib_fast = C.CDLL(path)
+        _lib_fast.bao_solve.restype = C.c_int
+    return _lib_fast
+
+
+def solve_fn_fast(p, o, r):
+    return lib_fast().bao_solve(p, o, r)
+
+
 def reproj_error(model, point, pose, params, xy, want_jac=True):
     point = np.ascontiguousarray(point, np.float64)
     pose = np.ascontiguousarray(pose, np.float64)

@@ -1,0 +1,94 @@
+"""How two bundle-adjustment solutions of ONE problem are compared (test infrastructure).
+
+What a solve determines is compared directly: the cost (relative), the first LM iterations, the poses and the points
+(absolute). The intrinsics are compared through what they DO -- the pixel every observed point lands on, projected
+through either camera from the same pose and point -- not coefficient by coefficient: the reference's own test does the
+same (`ReconstructionNear`, bundle_adjustment_test.cc:344-349, compares poses and centres, never raw distortion
+coefficients), and high-order coefficients that the scene does not observe (k3 / k4 of OPENCV_FISHEYE at a narrow field
+of view, the rational terms of FULL_OPENCV) drift to 1e2 .. 1e8 in BOTH solvers while the projection inside the observed
+region stays put.
+
+Every bar is the larger of a base value (what well-conditioned problems reach with room to spare) and a multiple of the
+measured NOISE FLOOR of that very problem: the oracle against a build of itself with the compiler's default
+floating-point contraction (`oracle/libba_oracle_fast.so`, a few-ulp perturbation per operation). A problem whose
+solution moves by 1e-5 under such a perturbation cannot be asked to agree to 1e-7 with anything.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+
+import ba_oracle
+
+FLOOR_MARGIN = 10.0      # a bar is never tighter than this many times the measured floor
+MAX_PROJECTIONS = 3000   # observations sampled (fixed stride) for the projection comparison
+
+
+def projection_diff_px(a, b) -> float:
+    """Largest distance, in pixels, between the projections of the observed points through the cameras of solution `a`
+    and of solution `b` -- both from a's poses and points, so that only the intrinsics differ."""
+    n = len(a.obs_pose)
+    idx = np.arange(0, n, max(1, n // MAX_PROJECTIONS))
+    worst = 0.0
+    zero = np.zeros(2)
+    for o in idx:
+        k = int(a.obs_cam[o])
+        model = int(a.cam_model[k])
+        P = ba_oracle.NUM_PARAMS[model]
+        pt, pose = a.points[a.obs_point[o]], a.poses[a.obs_pose[o]]
+        s = -1 if a.obs_sensor is None else int(a.obs_sensor[o])
+        if s >= 0:
+            ra = ba_oracle.rig_reproj_error(model, pt, pose, a.sensors[s], a.cams[k, :P], zero, want_jac=False)[0]
+            rb = ba_oracle.rig_reproj_error(model, pt, pose, a.sensors[s], b.cams[k, :P], zero, want_jac=False)[0]
+        else:
+            ra = ba_oracle.reproj_error(model, pt, pose, a.cams[k, :P], zero, want_jac=False)[0]
+            rb = ba_oracle.reproj_error(model, pt, pose, b.cams[k, :P], zero, want_jac=False)[0]
+        worst = max(worst, float(np.abs(ra - rb).max()))
+    return worst
+
+
+@dataclass
+class Diff:
+    cost_rel: float
+    traj_rel: float
+    points: float
+    poses: float
+    sensors: float
+    proj_px: float
+
+    def scaled(self, f):
+        return Diff(*(f * getattr(self, k) for k in self.__dataclass_fields__))
+
+
+def diff(a, ra, b, rb, n_traj=4) -> Diff:
+    n = min(n_traj, len(ra.log_cost), len(rb.log_cost))
+    la, lb = np.asarray(ra.log_cost[:n], float), np.asarray(rb.log_cost[:n], float)
+    sens = 0.0
+    if a.sensors is not None and len(a.sensors):
+        sens = float(np.abs(a.sensors - b.sensors).max())
+    return Diff(cost_rel=abs(ra.final_cost - rb.final_cost) / max(abs(ra.final_cost), 1e-300),
+                traj_rel=float((np.abs(la - lb) / np.maximum(np.abs(la), 1e-300)).max()) if n else 0.0,
+                points=float(np.abs(a.points - b.points).max()), poses=float(np.abs(a.poses - b.poses).max()),
+                sensors=sens, proj_px=projection_diff_px(a, b))
+
+
+def assert_solutions_close(a, want, b, got, floor: Diff | None, cost_rtol=1e-8, param_atol=1e-6, traj_rtol=1e-7,
+                           proj_atol=1e-5):
+    """`(a, want)` = the oracle's solution and summary, `(b, got)` = the HIP solve's; `floor` = diff(oracle, perturbed
+    oracle) of the same problem or None (bars = base values). Counts and the termination type are exact."""
+    assert got.num_residuals == want.num_residuals
+    assert got.num_effective_parameters == want.num_effective_parameters
+    assert abs(got.initial_cost - want.initial_cost) <= 1e-12 * want.initial_cost
+    f = (floor or Diff(0, 0, 0, 0, 0, 0)).scaled(FLOOR_MARGIN)
+    d = diff(a, want, b, got)
+    bars = Diff(cost_rel=max(cost_rtol, f.cost_rel), traj_rel=max(traj_rtol, f.traj_rel),
+                points=max(param_atol, f.points), poses=max(param_atol, f.poses),
+                sensors=max(param_atol, f.sensors), proj_px=max(proj_atol, f.proj_px))
+    bad = [f"{k}: {getattr(d, k):.3e} > {getattr(bars, k):.3e}" for k in d.__dataclass_fields__
+           if not getattr(d, k) <= getattr(bars, k)]
+    assert not bad, "HIP vs oracle beyond the bar (floor x %g = %s): %s" % (FLOOR_MARGIN, f, "; ".join(bad))
+    # the termination type is compared last: two solvers at the noise floor of an ill-conditioned problem may stop one
+    # LM iteration apart, but never with a different verdict
+    assert got.termination_type == want.termination_type
+    return d, bars

@@ -9,6 +9,9 @@ exact; constant blocks are bit-identical.
 import numpy as np
 import pytest
 
+import os
+
+import ba_compare
 import ba_oracle
 from colmap_amd import estimators as est
 from colmap_amd import scene
@@ -18,25 +21,28 @@ pytestmark = pytest.mark.gpu
 TIGHT = dict(gradient_tolerance=1e-10, max_num_iterations=200)
 
 
+FLOOR_MAX_OBS = 60000   # problems up to this size also run the perturbed oracle (tests/ba_compare.py)
+
+
 def _both(fp, **so_kw):
     so = est.SolverOptions(**so_kw)
     a, b = fp.copy(), fp.copy()
     want = est.solve_flat(a, so, solve_fn=ba_oracle.solve_fn)
     got = est.solve_flat(b, so, gpu_index=0)
+    if len(fp.obs_pose) <= FLOOR_MAX_OBS and so.max_num_iterations > 1:
+        # the noise floor of THIS problem: the oracle against itself under a few-ulp perturbation of its arithmetic
+        c = fp.copy()
+        a.floor = ba_compare.diff(a, want, c, est.solve_flat(c, so, solve_fn=ba_oracle.solve_fn_fast))
     return (a, want), (b, got)
 
 
-def _assert_close(a, want, b, got, cost_rtol=1e-8, param_atol=1e-6, traj_rtol=1e-7, cam_rtol=1e-7):
-    assert got.num_residuals == want.num_residuals
-    assert got.num_effective_parameters == want.num_effective_parameters
-    assert got.termination_type == want.termination_type
-    assert abs(got.initial_cost - want.initial_cost) <= 1e-12 * want.initial_cost
-    assert abs(got.final_cost - want.final_cost) <= cost_rtol * want.final_cost, (got.final_cost, want.final_cost)
-    n = min(4, len(want.log_cost), len(got.log_cost))
-    np.testing.assert_allclose(got.log_cost[:n], want.log_cost[:n], rtol=traj_rtol)
-    np.testing.assert_allclose(b.points, a.points, atol=param_atol)
-    np.testing.assert_allclose(b.cams, a.cams, rtol=cam_rtol, atol=param_atol)
-    np.testing.assert_allclose(b.poses, a.poses, atol=param_atol)
+def _assert_close(a, want, b, got, cost_rtol=1e-8, param_atol=1e-6, traj_rtol=1e-7, proj_atol=5e-5):
+    """Cost, trajectory, poses, points; the intrinsics through the projections of the observed points (pixels). Every bar
+    is max(base value, 10 x the measured floor of the problem): see tests/ba_compare.py."""
+    d, bars = ba_compare.assert_solutions_close(a, want, b, got, getattr(a, "floor", None), cost_rtol=cost_rtol,
+                                                param_atol=param_atol, traj_rtol=traj_rtol, proj_atol=proj_atol)
+    if os.environ.get("COLMAP_AMD_TEST_PRINT_DIFFS"):
+        print("\nDIFF", d, "\nFLOOR", getattr(a, "floor", None))
 
 
 def _flat(frames, points, track, seed, mixed=False, noise=None):
@@ -269,7 +275,7 @@ def test_baseline_config4_mixed_models_matches_oracle():
     assert got.num_effective_parameters == want.num_effective_parameters
     np.testing.assert_allclose(got.log_cost, want.log_cost, rtol=1e-7)
     np.testing.assert_allclose(b.points, a.points, atol=1e-6)
-    np.testing.assert_allclose(b.cams, a.cams, rtol=1e-7, atol=1e-6)
+    assert ba_compare.projection_diff_px(a, b) <= 5e-5   # the intrinsics, through what they project (tests/ba_compare.py)
 
 
 def test_baseline_config4_full_size_properties():
@@ -352,7 +358,7 @@ def test_fp32_operator_reaches_the_fp64_solution(frames, points, track, mixed):
     np.testing.assert_allclose(got.log_cost[:n], want.log_cost[:n], rtol=1e-5)
     np.testing.assert_allclose(b.points, a.points, atol=1e-6)
     np.testing.assert_allclose(b.poses, a.poses, atol=1e-6)
-    np.testing.assert_allclose(b.cams, a.cams, rtol=1e-7, atol=1e-6)
+    assert ba_compare.projection_diff_px(a, b) <= 5e-5   # the intrinsics, through what they project (tests/ba_compare.py)
 
 
 def test_tracks_longer_than_a_tile():
@@ -707,8 +713,7 @@ def _model_matches_oracle(model, params):
     atol = 2e-4 if model in (scene.EUCM, scene.FULL_OPENCV, scene.THIN_PRISM_FISHEYE, scene.RAD_TAN_THIN_PRISM_FISHEYE) else 1e-5
     # the high-order coefficients of the 12- / 16-parameter models are unobservable at this field of view and
     # drift to 1e3 .. 1e8: compared relatively
-    wide = model in (scene.FULL_OPENCV, scene.THIN_PRISM_FISHEYE, scene.RAD_TAN_THIN_PRISM_FISHEYE)
-    _assert_close(a, want, b, got, cost_rtol=1e-7, param_atol=atol, traj_rtol=1e-5, cam_rtol=1e-4 if wide else 1e-7)
+    _assert_close(a, want, b, got, cost_rtol=1e-7, param_atol=atol, traj_rtol=1e-5)
     assert got.final_cost < 0.2 * got.initial_cost
 
 
@@ -833,7 +838,7 @@ def test_sparse_schur_tier_matches_oracle(frames, points, track, mixed, iters):
     np.testing.assert_allclose(got.log_cost, want.log_cost, rtol=1e-7)
     np.testing.assert_allclose(b.points, a.points, atol=1e-6)
     np.testing.assert_allclose(b.poses, a.poses, atol=1e-6)
-    np.testing.assert_allclose(b.cams, a.cams, rtol=1e-7, atol=1e-6)
+    assert ba_compare.projection_diff_px(a, b) <= 5e-5   # the intrinsics, through what they project (tests/ba_compare.py)
     assert got.factor_seconds > 0.0
 
 
