@@ -40,17 +40,25 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and not needs_build():
+def build(force: bool = False, verbose: bool = False, dev: bool = False, out: str = "") -> str:
+    """dev=True: a profiling build -- development switches also readable from the environment
+    (-DCOLMAP_AMD_ENV_SWITCHES) and the garbage-producing PatchMatch diagnostics compiled in (-DCOLMAP_AMD_DIAG_BUILD);
+    written to `out` (default lib/libcolmap_amd_dev.so), never the library the package loads."""
+    if dev:
+        out = out or os.path.join(LIB_DIR, "libcolmap_amd_dev.so")
+    elif not force and not needs_build():
         return LIB_PATH
+    out = out or LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + HIPCC_FLAGS + _sources() + ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib", "-o", LIB_PATH]
+    extra = ["-DCOLMAP_AMD_ENV_SWITCHES", "-DCOLMAP_AMD_DIAG_BUILD"] if dev else []
+    cmd = [hipcc] + HIPCC_FLAGS + extra + _sources() + ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib", "-o", out]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    return LIB_PATH
+    return out
 
 
 if __name__ == "__main__":
-    print(build(force=True, verbose=True))
+    import sys
+    print(build(force=True, verbose=True, dev="--dev" in sys.argv))

@@ -28,6 +28,7 @@
 //  * S x = (B + D^2) x - E C^-1 E^T x is never formed: three kernels per product.
 #include "../../include/colmap_amd_ba.h"
 #include "ba_schur_explicit.h"
+#include "switches.h"
 
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
@@ -43,6 +44,8 @@
 #include <stdexcept>
 #include <string>
 #include <vector>
+
+using colmap_amd::dev_switch_int;
 
 extern "C" void pm_release_cached_memory(void);  // pm_api.cpp (same library)
 
@@ -73,8 +76,7 @@ constexpr int KD_WIDE = 16;  // FULL_OPENCV / THIN_PRISM_FISHEYE (12), RAD_TAN_T
 constexpr int NPAR_WIDE = 16;
 constexpr int NPAR = 8;      // max number of parameters of a supported camera model (J_params is 2 x NPAR)
 static int chunk_size() {     // observations per camera-side reduction chunk (one wave each)
-  const char* e = std::getenv("COLMAP_AMD_BA_CHUNK");
-  const int v = e ? std::atoi(e) : 512;
+  const int v = dev_switch_int("COLMAP_AMD_BA_CHUNK", 512);
   return v >= 64 ? v : 512;
 }
 constexpr int NSCALAR = 16;
@@ -1875,7 +1877,15 @@ struct IncView {
   const int* blk;        // [n] block
   const int* ptr;        // [n + 1] this rank's observations of the incidence (c-order indices) ...
   const int* obs;        // ... as a CSR list
+  // The incidences are sorted by block; a block's run is cut into chunks of <= kIncChunk of them (fixed-order sums:
+  // ba_inc_correct_kernel writes one partial per chunk, ba_inc_finalize_kernel adds a block's partials in chunk order)
+  int n_chunks;
+  const int* chunk_blk;  // [n_chunks]
+  const int* chunk_beg;  // [n_chunks + 1] first incidence of the chunk (chunk_beg[c + 1] = its end)
+  const int* blk_chunk;  // [n_blk + 1] chunks of every block
+  double* part;          // [n_chunks][KDT * KDT] partial sums
 };
+constexpr int kIncChunk = 128;
 template <int KDT>
 __global__ void ba_inc_w_kernel(View V, IncView I, double* __restrict__ W) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1900,32 +1910,49 @@ __global__ void ba_inc_w_kernel(View V, IncView I, double* __restrict__ W) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) W[((size_t)i * KDT + x) * 3 + c] = w[x][c];
 }
+// One workgroup per chunk of incidences of ONE block, thread per entry (x, y) of the block: the thread walks the
+// chunk's incidences in list order and writes its partial sum -- no atomics, the order of every sum is fixed by the
+// host-built lists (a solve is reproducible run to run whatever the hardware's timing).
 template <int KDT>
-__global__ void ba_inc_correct_kernel(View V, IncView I, const double* __restrict__ Cinv, const double* __restrict__ Wloc,
-                                      const double* __restrict__ Wtot, int rank, int world, double* __restrict__ M) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= I.n) return;
-  const int b = I.blk[i], dim = V.blk_dim[b], xi = I.pt[i];
-  if (V.pt_off[xi] < 0) return;  // a constant point has no C^-1: its observations do not couple
-  const double* Ci = Cinv + 9 * (size_t)xi;
-  double* Mb = M + V.blk_moff[b];
-  const bool mine = xi % world == rank;
-  for (int pass = 0; pass < 2; ++pass) {
-    if (pass == 1 && !mine) break;
-    const double* Wp = (pass == 0 ? Wloc : Wtot) + (size_t)i * KDT * 3;
-    const double sign = pass == 0 ? 1.0 : -1.0;
-    double T[KDT][3];
-#pragma unroll
-    for (int x = 0; x < KDT; ++x)
-#pragma unroll
-      for (int c = 0; c < 3; ++c) T[x][c] = Wp[x * 3 + 0] * Ci[c] + Wp[x * 3 + 1] * Ci[3 + c] + Wp[x * 3 + 2] * Ci[6 + c];
-#pragma unroll
-    for (int x = 0; x < KDT; ++x)
-#pragma unroll
-      for (int y = 0; y < KDT; ++y)
-        if (x < dim && y < dim)
-          atomicAdd(Mb + x * dim + y, sign * (T[x][0] * Wp[y * 3 + 0] + T[x][1] * Wp[y * 3 + 1] + T[x][2] * Wp[y * 3 + 2]));
+__global__ void __launch_bounds__(KDT * KDT) ba_inc_correct_kernel(View V, IncView I, const double* __restrict__ Cinv,
+                                                                 const double* __restrict__ Wloc, const double* __restrict__ Wtot,
+                                                                 int rank, int world) {
+  const int ch = blockIdx.x;
+  const int b = I.chunk_blk[ch], dim = V.blk_dim[b];
+  const int x = threadIdx.x / KDT, y = threadIdx.x % KDT;
+  double acc = 0.0;
+  if (x < dim && y < dim) {
+    for (int i = I.chunk_beg[ch]; i < I.chunk_beg[ch + 1]; ++i) {
+      const int xi = I.pt[i];
+      if (V.pt_off[xi] < 0) continue;  // a constant point has no C^-1: its observations do not couple
+      const double* Ci = Cinv + 9 * (size_t)xi;
+      const bool mine = xi % world == rank;
+      for (int pass = 0; pass < 2; ++pass) {
+        if (pass == 1 && !mine) break;
+        const double* Wp = (pass == 0 ? Wloc : Wtot) + (size_t)i * KDT * 3;
+        const double t0 = Wp[x * 3 + 0] * Ci[0] + Wp[x * 3 + 1] * Ci[3] + Wp[x * 3 + 2] * Ci[6];
+        const double t1 = Wp[x * 3 + 0] * Ci[1] + Wp[x * 3 + 1] * Ci[4] + Wp[x * 3 + 2] * Ci[7];
+        const double t2 = Wp[x * 3 + 0] * Ci[2] + Wp[x * 3 + 1] * Ci[5] + Wp[x * 3 + 2] * Ci[8];
+        const double term = t0 * Wp[y * 3 + 0] + t1 * Wp[y * 3 + 1] + t2 * Wp[y * 3 + 2];
+        acc += pass == 0 ? term : -term;
+      }
+    }
   }
+  I.part[(size_t)ch * KDT * KDT + threadIdx.x] = acc;
+}
+// M_b += the block's chunk partials, in chunk order; thread per (block, entry)
+template <int KDT>
+__global__ void ba_inc_finalize_kernel(View V, IncView I, double* __restrict__ M) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = t / (KDT * KDT), e = t % (KDT * KDT);
+  if (b >= V.n_blk) return;
+  const int c0 = I.blk_chunk[b], c1 = I.blk_chunk[b + 1];
+  if (c0 == c1) return;
+  const int dim = V.blk_dim[b], x = e / KDT, y = e % KDT;
+  if (x >= dim || y >= dim) return;
+  double s = 0.0;
+  for (int c = c0; c < c1; ++c) s += I.part[(size_t)c * KDT * KDT + e];
+  M[V.blk_moff[b] + x * dim + y] += s;
 }
 
 // M_b += Dc^2 on the diagonal, then invert (Gauss-Jordan with partial pivoting); lane per block
@@ -2824,7 +2851,7 @@ struct Buf {
 
 inline int grid_for(size_t n, int block) { return (int)((n + block - 1) / block); }
 
-static const bool g_ba_debug = std::getenv("COLMAP_AMD_BA_DEBUG") != nullptr;
+static const bool g_ba_debug = dev_switch_int("COLMAP_AMD_BA_DEBUG", 0) != 0;  // sync + check after every launch
 #define BA_LAUNCH(kernel, grid, block, stream, ...)                                    \
   do {                                                                                 \
     hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__);                   \
@@ -2858,7 +2885,8 @@ struct Solver {
       scalars, gc, gp, diag_c, diag_p, Dc, Dp, Cinv, M, Minv, rhs, x, r, z, pdir, q, dp, jx, v, stepc, stepp, partials, cpart, Craw, tbuf, tmpc, Gobs, pcg_part, maxbuf;
   Buf<double> lin_sums;  // [g_c | diag_c | g_p | diag_p | E^T E]: one all-reduce per linearisation
   // image-sharded solves: (point, shared intrinsics block) incidences whose observations span ranks (ba_inc_* kernels)
-  Buf<int> inc_pt, inc_blk, inc_ptr, inc_obs;
+  Buf<int> inc_pt, inc_blk, inc_ptr, inc_obs, inc_chunk_blk, inc_chunk_beg, inc_blk_chunk;
+  Buf<double> inc_part;
   Buf<double> inc_wloc, inc_wtot;
   IncView IV{};
   // pipelined PCG (pcg_pipelined): partial sums, stop flag, Q history on the device; per-iteration scalars in pinned
@@ -3051,8 +3079,7 @@ struct Solver {
     }
     // the same topology in p-order (position a <-> c-order position h_a2c[a])
     {
-      const char* e = std::getenv("COLMAP_AMD_BA_SPLIT_LINEARIZE");  // read per solve: tests toggle it
-      split_linearize = !e || std::atoi(e) != 0;
+      split_linearize = dev_switch_int("COLMAP_AMD_BA_SPLIT_LINEARIZE", 1) != 0;  // read per solve: tests toggle it
     }
     std::vector<int> h_a_pose, h_a_cam, h_a_pt, h_a_sensor;
     std::vector<double> h_a_xy;
@@ -3243,16 +3270,24 @@ struct Solver {
       if (!spanning.empty()) {
         const int ni = (int)spanning.size();
         std::vector<int> h_pt(ni), h_blk(ni), h_ptr(ni + 1, 0), h_obs;
+        // device order of the incidences: by block, then by (point, camera) key -- a block's run is contiguous, so
+        // its terms are summed in one fixed order (ba_inc_correct_kernel); `pos` = key-order index -> device index
+        std::vector<int> by_blk(ni), pos(ni);
+        std::iota(by_blk.begin(), by_blk.end(), 0);
+        std::stable_sort(by_blk.begin(), by_blk.end(), [&](int a, int b) {
+          return blk_of_cam[(int)(spanning[a] % p.num_cams)] < blk_of_cam[(int)(spanning[b] % p.num_cams)];
+        });
         for (int i = 0; i < ni; ++i) {
-          h_pt[i] = (int)(spanning[i] / p.num_cams);
-          h_blk[i] = blk_of_cam[(int)(spanning[i] % p.num_cams)];
+          pos[by_blk[i]] = i;
+          h_pt[i] = (int)(spanning[by_blk[i]] / p.num_cams);
+          h_blk[i] = blk_of_cam[(int)(spanning[by_blk[i]] % p.num_cams)];
         }
         // this rank's observations, c-order index c, by incidence
         std::vector<std::pair<int, int>> mine;  // (incidence, c)
         for (int c = 0; c < n; ++c) {
           const long long key = (long long)h_o_pt[c] * p.num_cams + h_o_cam[c];
           const auto it = std::lower_bound(spanning.begin(), spanning.end(), key);
-          if (it != spanning.end() && *it == key) mine.emplace_back((int)(it - spanning.begin()), c);
+          if (it != spanning.end() && *it == key) mine.emplace_back(pos[(int)(it - spanning.begin())], c);
         }
         std::sort(mine.begin(), mine.end());
         for (const auto& m : mine) h_ptr[m.first + 1]++;
@@ -3260,6 +3295,23 @@ struct Solver {
         h_obs.reserve(mine.size());
         for (const auto& m : mine) h_obs.push_back(m.second);
         if (h_obs.empty()) h_obs.push_back(0);
+        // chunks of <= kIncChunk incidences of one block, and every block's range of chunks
+        const int nblk = (int)h_blk_off.size();
+        std::vector<int> h_cblk, h_cbeg, h_bchunk(nblk + 1, 0);
+        for (int i = 0; i < ni;) {
+          int e = i;
+          while (e < ni && h_blk[e] == h_blk[i] && e - i < kIncChunk) ++e;
+          h_cblk.push_back(h_blk[i]);
+          h_cbeg.push_back(i);
+          h_bchunk[h_blk[i] + 1]++;
+          i = e;
+        }
+        h_cbeg.push_back(ni);
+        for (int b = 0; b < nblk; ++b) h_bchunk[b + 1] += h_bchunk[b];
+        inc_chunk_blk.upload(h_cblk); inc_chunk_beg.upload(h_cbeg); inc_blk_chunk.upload(h_bchunk);
+        inc_part.alloc(h_cblk.size() * (size_t)KD_WIDE * KD_WIDE);
+        IV.n_chunks = (int)h_cblk.size(); IV.chunk_blk = inc_chunk_blk.p; IV.chunk_beg = inc_chunk_beg.p;
+        IV.blk_chunk = inc_blk_chunk.p; IV.part = inc_part.p;
         inc_pt.upload(h_pt); inc_blk.upload(h_blk); inc_ptr.upload(h_ptr); inc_obs.upload(h_obs);
         inc_wloc.alloc((size_t)ni * KD_WIDE * 3); inc_wtot.alloc((size_t)ni * KD_WIDE * 3);
         IV.n = ni; IV.pt = inc_pt.p; IV.blk = inc_blk.p; IV.ptr = inc_ptr.p; IV.obs = inc_obs.p;
@@ -3283,8 +3335,7 @@ struct Solver {
     jx.alloc(2 * N); v.alloc(2 * N); Gobs.alloc(4 * N);
     if (n_var_sensors > 0) Jsens.alloc(12 * N);
     {
-      const char* e32 = std::getenv("COLMAP_AMD_BA_OPERATOR_F32");
-      const bool op32_env = e32 && std::atoi(e32) != 0;
+      const bool op32_env = dev_switch_int("COLMAP_AMD_BA_OPERATOR_F32", 0) != 0;
       op32 = (op32_env || opt.operator_precision == BA_OPERATOR_F32) && n_var_sensors == 0 && V.n_tiles > 0 && comm.world == 1;
       if (op32) { Jpose32.alloc(2 * PD * N); Jcam32.alloc(2 * (size_t)kd * N); Jpt32.alloc(6 * N); }
       V.Jpose32 = op32 ? Jpose32.p : nullptr;
@@ -3598,15 +3649,14 @@ struct Solver {
   }
 
   int pcg(int max_iter, double q_tol) {
-    const char* ef = std::getenv("COLMAP_AMD_BA_PCG_FUSED");
     // measured at BA-1: the single-workgroup kernel takes 133 us against 54 us for the five small kernels it
     // replaces (a lane's blocks are chains of dependent global loads that one workgroup cannot hide): opt-in only
-    const bool fused_env = ef && std::atoi(ef) != 0;
+    const bool fused_env = dev_switch_int("COLMAP_AMD_BA_PCG_FUSED", 0) != 0;
     if (fused_env && comm.world == 1 && !use_priors() && V.n_chunks > 0 && V.n_obs > 0 && V.n_blk <= 65536)
       return pcg_fused(max_iter, q_tol);
     // single GPU, no priors: three small kernels per iteration, stopping test on the device, host one iteration
     // behind (COLMAP_AMD_BA_PCG_PIPELINED=0: the step-by-step loop below, which sharded / prior solves always take)
-    static const bool pipelined = [] { const char* e = std::getenv("COLMAP_AMD_BA_PCG_PIPELINED"); return !e || std::atoi(e) != 0; }();
+    const bool pipelined = dev_switch_int("COLMAP_AMD_BA_PCG_PIPELINED", 1) != 0;
     if (pipelined && comm.world == 1 && !use_priors() && V.n_chunks > 0 && V.n_obs > 0) return pcg_pipelined(max_iter, q_tol);
     const int n = V.n_c;
     const int gv = grid_for(n, 256);
@@ -3670,8 +3720,7 @@ struct Solver {
       // an image-sharded solve splits a point's observations over the ranks: only the operator-product formation
       // (every product is all-reduced) is correct there, and only affordable for small systems
       dense_by_products = want_exact && comm.world > 1 && !comm.by_point;
-      const char* e_prod = std::getenv("COLMAP_AMD_BA_DENSE_BY_PRODUCTS");
-      if (want_exact && e_prod && std::atoi(e_prod) != 0) dense_by_products = true;
+      if (want_exact && dev_switch_int("COLMAP_AMD_BA_DENSE_BY_PRODUCTS", 0) != 0) dense_by_products = true;
       use_dense = want_exact && nc > 0 && nc <= (dense_by_products ? 1024 : 32768);
       out->linear_solver_used = use_dense ? tier : BA_SOLVER_ITERATIVE_SCHUR;
     }
@@ -3680,8 +3729,7 @@ struct Solver {
       if (!dense_by_products) {
         ba_explicit::Workspace ws;
         chol_linv.alloc(ws.linv_doubles(nc)); chol_tmp.alloc(nc); chol_info.alloc(2);  // [pivot flag, formation flag]
-        const char* e_la = std::getenv("COLMAP_AMD_BA_CHOL_LOOKAHEAD");
-        if (!e_la || std::atoi(e_la) != 0) {
+        if (dev_switch_int("COLMAP_AMD_BA_CHOL_LOOKAHEAD", 1) != 0) {
           // the second stream carries bulk trailing updates that run beside the serial chain of small kernels on the
           // main stream: lowest priority, so that a freed workgroup slot goes to the chain first
           int prio_least = 0, prio_greatest = 0;
@@ -3692,8 +3740,7 @@ struct Solver {
         }
         // pair-major formation: its incidence lists depend on the topology only -- built here, with the other
         // per-solve structures, not inside the LM loop (COLMAP_AMD_BA_FORM_PAIRS=0: the point-major kernel)
-        const char* e_pairs = std::getenv("COLMAP_AMD_BA_FORM_PAIRS");
-        if (!e_pairs || std::atoi(e_pairs) != 0) (void)ba_explicit::build_pair_lists(form_args(), pair_lists, st);
+        if (dev_switch_int("COLMAP_AMD_BA_FORM_PAIRS", 1) != 0) (void)ba_explicit::build_pair_lists(form_args(), pair_lists, st);
       }
       BA_HIP(hipDeviceSynchronize());  // the allocation's memset runs on the NULL stream
     }
@@ -3779,7 +3826,7 @@ struct Solver {
         if (V.n_chunks > 0) {  // (ba_block_mat_finalize_kernel<false> assigns every entry of every block)
           BA_LAUNCH(ba_obs_schur_g_kernel, dim3(grid_for(V.n_obs, 256)), dim3(256), st, V, Cinv.p, Gobs.p);
           BA_HIP(hipEventRecord(ev2, st));
-          static const bool gram_lds = [] { const char* e = std::getenv("COLMAP_AMD_BA_GRAM_LDS"); return !e || std::atoi(e) != 0; }();
+          const bool gram_lds = dev_switch_int("COLMAP_AMD_BA_GRAM_LDS", 1) != 0;
           if (gram_lds && bd == PD) BA_LAUNCH(ba_block_gram_lds_kernel<PD>, dim3(V.n_chunks), dim3(64 * GRAM_WAVES), st, V, Gobs.p);
           else if (gram_lds && bd == KD_MAX) BA_LAUNCH(ba_block_gram_lds_kernel<KD_MAX>, dim3(V.n_chunks), dim3(64 * GRAM_WAVES), st, V, Gobs.p);
           else if (gram_lds) BA_LAUNCH(ba_block_gram_lds_kernel<KD_WIDE>, dim3(V.n_chunks), dim3(64 * GRAM_WAVES), st, V, Gobs.p);
@@ -3803,12 +3850,15 @@ struct Solver {
           else BA_LAUNCH(ba_inc_w_kernel<KD_MAX>, dim3(gi), dim3(128), st, V, IV, inc_wloc.p);
           BA_HIP(hipMemcpyAsync(inc_wtot.p, inc_wloc.p, sizeof(double) * wn, hipMemcpyDeviceToDevice, st));
           comm.allreduce(inc_wtot.p, wn, st);
-          if (kd == KD_WIDE)
-            BA_LAUNCH(ba_inc_correct_kernel<KD_WIDE>, dim3(gi), dim3(128), st, V, IV, Cinv.p, inc_wloc.p, inc_wtot.p, comm.rank,
-                      comm.world, M.p);
-          else
-            BA_LAUNCH(ba_inc_correct_kernel<KD_MAX>, dim3(gi), dim3(128), st, V, IV, Cinv.p, inc_wloc.p, inc_wtot.p, comm.rank,
-                      comm.world, M.p);
+          if (kd == KD_WIDE) {
+            BA_LAUNCH(ba_inc_correct_kernel<KD_WIDE>, dim3(IV.n_chunks), dim3(KD_WIDE * KD_WIDE), st, V, IV, Cinv.p, inc_wloc.p,
+                      inc_wtot.p, comm.rank, comm.world);
+            BA_LAUNCH(ba_inc_finalize_kernel<KD_WIDE>, dim3(grid_for((size_t)V.n_blk * KD_WIDE * KD_WIDE, 256)), dim3(256), st, V, IV, M.p);
+          } else {
+            BA_LAUNCH(ba_inc_correct_kernel<KD_MAX>, dim3(IV.n_chunks), dim3(KD_MAX * KD_MAX), st, V, IV, Cinv.p, inc_wloc.p,
+                      inc_wtot.p, comm.rank, comm.world);
+            BA_LAUNCH(ba_inc_finalize_kernel<KD_MAX>, dim3(grid_for((size_t)V.n_blk * KD_MAX * KD_MAX, 256)), dim3(256), st, V, IV, M.p);
+          }
         }
         comm.allreduce(M.p, (size_t)moff_total, st);
         if (bd == PD) BA_LAUNCH(ba_block_invert_kernel<PD>, dim3(grid_for(V.n_blk, 64)), dim3(64), st, V, Dc.p, M.p, Minv.p);

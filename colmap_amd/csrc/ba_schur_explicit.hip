@@ -514,26 +514,37 @@ __device__ __forceinline__ double readlane_f64(double v, int src) {
   return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
+// 1 / d to ~1 ulp without the IEEE division sequence (v_div_scale x 2, v_div_fmas, v_div_fixup around the same
+// v_rcp_f64 + two Newton steps): the pivots are positive normal numbers, and the reciprocal sits on the serial chain
+// of every column step below.
+__device__ __forceinline__ double rcp_f64(double d) {
+  double y = __builtin_amdgcn_rcp(d);
+  y = fma(fma(-d, y, 1.0), y, y);
+  y = fma(fma(-d, y, 1.0), y, y);
+  return y;
+}
+
 // Diagonal block [k0, k0 + kb): L_kk in place (lower), its inverse (64 x 64, zero-padded) to Linv.
 // TWO WAVES, each with a 64 x 64 matrix in registers (64 doubles = 128 VGPRs per lane; every loop below is unrolled
 // so that the register indices are compile-time constants):
 //   wave 0, lane r = row r of the block: the factorisation. The job is a chain of 64 dependent column steps -- pivot,
-//     reciprocal, multipliers, rank-1 update -- and its time is 64 x the latency of that chain, not arithmetic: the
-//     four-wave LDS version this replaces paid ~1 400 cycles per column (LDS round trips between dependent reads and
-//     writes, 16 threads per row, a full division in front of every step) and 69 us per block at BA-1, 125 of them in a
-//     row on the critical path of the factorisation. Here a column step is: the pivot by v_readlane, one division,
-//     column c of the matrix handed from lane to lane through 512 bytes of LDS (every lane reads all of it: broadcast
-//     reads, two values per ds_read), and 63 - c register FMAs per lane. Entries above the diagonal take part in
-//     the arithmetic as don't-cares (no divergence). As before the scaling by 1 / sqrt(pivot) happens once at the end
-//     (one sqrt + division per LANE instead of per column step): the loop works on A~ with L = A~ D^-1/2, D = diag(pivots).
-//   wave 1, lane j = column j of the inverse: forward substitution with the SAME column broadcasts, step by step
-//     behind wave 0 (Y = A~^-1: y_r /= d_r, y_rr -= A~[rr][r] y_r for the rows below; L^-1 = D^1/2 Y). Rows above j
-//     come out as exact zeros. (One wave doing both needs 256 VGPRs for the two matrices alone.)
+//     reciprocal, multipliers, rank-1 update -- 125 of these kernels in a row on the critical path of the
+//     factorisation at BA-1. A column step needs column c of the matrix in EVERY lane (lane r updates a[cc] with
+//     entry cc of the column): entry cc is a[c] of lane cc, so it is broadcast straight out of the register file --
+//     two v_readlane_b32 into an SGPR pair, the FMA takes it as its scalar operand. (Round 4 handed the column from
+//     lane to lane through LDS: 32 broadcast ds_reads per step which the register budget let the compiler keep only
+//     two deep in flight -- ~2 000 cycles of exposed LDS latency per step, 40-54 us per block in the round-5 trace;
+//     the readlane form has no memory operation in the update at all.) Entries above the diagonal take part in the
+//     arithmetic as don't-cares (no divergence). The scaling by 1 / sqrt(pivot) happens once at the end (one sqrt +
+//     division per LANE instead of per column step): the loop works on A~ with L = A~ D^-1/2, D = diag(pivots).
+//   wave 1, lane j = column j of the inverse: forward substitution one step behind wave 0 (Y = A~^-1: y_r /= d_r,
+//     y_rr -= A~[rr][r] y_r for the rows below; L^-1 = D^1/2 Y). Column r of A~ reaches it through 512 bytes of LDS
+//     (ONE ds_read per lane and step: lane rr takes entry rr) and is broadcast by readlane like in wave 0. Rows
+//     above j come out as exact zeros. (One wave doing both needs 256 VGPRs for the two matrices alone.)
 // Rows / columns beyond kb carry a unit diagonal and are not stored.
-// Register budget: 256 per lane (launch bound 2 waves per SIMD), not the 263 the allocator would like -- this kernel
-// runs beside the lookahead stream's 128 x 128 trailing updates, whose waves hold 256 of a SIMD's 512 registers each:
-// a wave that needs more than the other half could only start on a CU the bulk update has drained completely, i.e.
-// the serial chain would wait for the update it is supposed to overlap.
+// Register budget: 256 per lane (launch bound 2 waves per SIMD) -- this kernel runs beside the lookahead stream's
+// 128 x 128 trailing updates, whose waves hold 256 of a SIMD's 512 registers each: a wave that needs more than the
+// other half could only start on a CU the bulk update has drained completely.
 __global__ void __launch_bounds__(128, 2) chol_diag_kernel(double* __restrict__ S, int n, int k0, int kb,
                                                         double* __restrict__ Linv, int* __restrict__ info) {
   __shared__ double Ls[NB][NB + 1];
@@ -561,13 +572,14 @@ __global__ void __launch_bounds__(128, 2) chol_diag_kernel(double* __restrict__ 
     double dmine = 0.0;                                // pivot of column `lane` (final after step lane - 1)
 #pragma unroll
     for (int c = 0; c < NB; ++c) {
-      const double d = readlane_f64(a[c], c);
-      dmine = lane == c ? a[c] : dmine;
-      const double l = a[c] * (1.0 / d);  // multiplier of row `lane` (rows <= c: a don't-care)
-      col[c & 1][lane] = a[c];
-      __syncthreads();  // column c (its entry c is the pivot) is published; the other buffer is free again
+      const double ac = a[c];                          // entry `lane` of column c
+      const double d = readlane_f64(ac, c);
+      dmine = lane == c ? ac : dmine;
+      col[c & 1][lane] = ac;
+      const double l = ac * rcp_f64(d);  // multiplier of row `lane` (rows <= c: a don't-care)
+      __syncthreads();  // column c (its entry c is the pivot) is published for wave 1; the other buffer is free again
 #pragma unroll
-      for (int cc = c + 1; cc < NB; ++cc) a[cc] = fma(-l, col[c & 1][cc], a[cc]);  // (the library is built with -ffp-contract=off)
+      for (int cc = c + 1; cc < NB; ++cc) a[cc] = fma(-l, readlane_f64(ac, cc), a[cc]);  // (-ffp-contract=off: explicit fma)
     }
     const bool okp = dmine > 0.0;
     if (!okp) *info = 1;
@@ -585,10 +597,11 @@ __global__ void __launch_bounds__(128, 2) chol_diag_kernel(double* __restrict__ 
 #pragma unroll
     for (int r = 0; r < NB; ++r) {
       __syncthreads();
-      const double yr = a[r] * (1.0 / col[r & 1][r]);
+      const double v = col[r & 1][lane];               // entry `lane` of column r of A~
+      const double yr = a[r] * rcp_f64(readlane_f64(v, r));
       a[r] = yr;
 #pragma unroll
-      for (int rr = r + 1; rr < NB; ++rr) a[rr] = fma(-yr, col[r & 1][rr], a[rr]);
+      for (int rr = r + 1; rr < NB; ++rr) a[rr] = fma(-yr, readlane_f64(v, rr), a[rr]);
     }
     __syncthreads();
 #pragma unroll

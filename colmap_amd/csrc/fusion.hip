@@ -57,6 +57,9 @@
 #include <vector>
 
 #include "../../include/colmap_amd_fusion.h"
+#include "switches.h"
+
+using colmap_amd::dev_switch_int;
 
 #define FUSION_API __attribute__((visibility("default")))
 
@@ -829,8 +832,7 @@ struct fusion_result {
 namespace {
 
 int EnvInt(const char* name, int dflt) {
-  const char* e = getenv(name);
-  return e && *e ? atoi(e) : dflt;
+  return dev_switch_int(name, dflt);
 }
 
 void Run(const fusion_options& opt, int n, const fusion_image* images, const int32_t* optr, const int32_t* oidx,
@@ -989,7 +991,7 @@ void Run(const fusion_options& opt, int n, const fusion_image* images, const int
   {
     const size_t desc = (size_t)n * sizeof(DevImage) + ((size_t)n + 1) * sizeof(int);
     p.lds_tables = desc > (size_t)kTableBytes ? 0 : (desc + (size_t)optr[n] * sizeof(int) > (size_t)kTableBytes ? 1 : 2);
-    if (const char* e = getenv("COLMAP_AMD_FUSION_LDS_TABLES")) p.lds_tables = std::min(p.lds_tables, std::max(0, atoi(e)));
+    p.lds_tables = std::min(p.lds_tables, std::max(0, dev_switch_int("COLMAP_AMD_FUSION_LDS_TABLES", 2)));
   }
   // a stack can never hold more than (pixels a walk records) x (longest overlap list) entries
   const long long spill_bound = (long long)p.rec_cap * max_overlap + kWave;

@@ -9,6 +9,7 @@
 #include "pm_internal.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -93,8 +94,9 @@ class DevPool {
 
  private:
   DevPool() {
-    const char* e = getenv("COLMAP_AMD_PM_POOL_GB");
-    cap_ = static_cast<size_t>((e ? atof(e) : 64.0) * (1ull << 30));
+    const double gb = dev_switch_double("COLMAP_AMD_PM_POOL_GB", -1.0);
+    const bool e = gb >= 0.0;
+    cap_ = static_cast<size_t>((e ? gb : 64.0) * (1ull << 30));
     size_t free_b = 0, total_b = 0;
     if (!e && hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b > 0) cap_ = std::min(cap_, total_b / 4);
   }
@@ -273,6 +275,15 @@ void CheckProblem(const pm_options& o, const pm_problem& p) {
 // of the lowest one). A problem whose sources straddle two slabs that lie further apart takes the explicit-index
 // build of the kernels instead; nothing else depends on the slabs. Slots return to their slab when the last
 // problem (or the image cache) drops the image; pm_release_cached_memory() frees the slabs that are empty.
+// Test hook (pm_debug_set_image_slab_limits): slab size and the span one buffer resource may cover. The defaults are the
+// hardware's (3.5 GB slabs, 32-bit buffer offsets); the tests shrink both to exercise the re-homing of shared images
+// with a few small images instead of > 4 GB of them.
+static size_t g_fp_slab_slots = 0;                 // 0: by image size (below)
+static std::atomic<unsigned long long> g_fp_rehomed{0};
+static inline uint64_t FpSpanLimit(size_t image_bytes) {
+  return g_fp_slab_slots ? (uint64_t)g_fp_slab_slots * image_bytes + 4097 : (1ull << 32);
+}
+
 class FpSlabPool {
  public:
   static FpSlabPool& Get() {
@@ -295,10 +306,13 @@ class FpSlabPool {
     // slab size: 3.5 GB for full-size images (178 slots at 2560 x 1920), 256 MB for small ones
     const size_t target = bytes >= (4u << 20) ? (size_t)(3.5 * (1ull << 30)) : (256u << 20);
     int n = (int)std::max<size_t>(1, std::min<size_t>(4096, target / bytes));
+    // test mode: n slots per slab and as much unused memory behind them, so that two slabs never fit one span
+    const size_t pad = g_fp_slab_slots ? 2 : 1;
+    if (g_fp_slab_slots) n = (int)g_fp_slab_slots;
     void* p = nullptr;
     hipError_t e = hipErrorOutOfMemory;
     for (; n >= 1; n /= 2) {  // a slab that does not fit any more shrinks down to a single slot
-      e = hipMalloc(&p, (size_t)n * bytes);
+      e = hipMalloc(&p, pad * n * bytes);
       if (e == hipSuccess) break;
       (void)hipGetLastError();
       if (n == 1) break;
@@ -314,6 +328,37 @@ class FpSlabPool {
     for (int k = n - 1; k >= 1; --k) sl.free_slots.push_back(k);
     slabs_.push_back(sl);
     return reinterpret_cast<uint32_t*>(sl.base);
+  }
+  // The slab (identified by its base address) that holds `ptr`; null for a pointer the pool does not own.
+  const char* SlabOf(const uint32_t* ptr) {
+    std::lock_guard<std::mutex> lock(mu_);
+    const char* c = reinterpret_cast<const char*>(ptr);
+    for (auto& sl : slabs_)
+      if (c >= sl.base && c < sl.base + (size_t)sl.nslots * sl.slot_bytes) return sl.base;
+    return nullptr;
+  }
+  // A free slot of the given slab, or null when it has none (or its slots have another size).
+  uint32_t* TakeFrom(const char* slab, size_t bytes) {
+    std::lock_guard<std::mutex> lock(mu_);
+    for (auto& sl : slabs_)
+      if (sl.base == slab && sl.slot_bytes == bytes && !sl.free_slots.empty()) {
+        const int k = sl.free_slots.back();
+        sl.free_slots.pop_back();
+        return reinterpret_cast<uint32_t*>(sl.base + (size_t)k * bytes);
+      }
+    return nullptr;
+  }
+  // Free slots of the newest slab of this size on the current device (0: none).
+  int FreeInNewest(size_t bytes, const char** slab) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(mu_);
+    for (auto it = slabs_.rbegin(); it != slabs_.rend(); ++it)
+      if (it->dev == dev && it->slot_bytes == bytes) {
+        *slab = it->base;
+        return (int)it->free_slots.size();
+      }
+    return 0;
   }
   void Give(uint32_t* ptr) {
     std::lock_guard<std::mutex> lock(mu_);
@@ -360,6 +405,10 @@ struct FpBuf {
     ptr = FpSlabPool::Get().Take(n * sizeof(uint32_t));
     count = n;
   }
+  void adopt(uint32_t* p, size_t n) {  // a slot taken from the pool by the caller
+    ptr = p;
+    count = n;
+  }
   ~FpBuf() {
     if (ptr) FpSlabPool::Get().Give(ptr);
   }
@@ -398,6 +447,10 @@ struct pm_image_cache {
   }
 };
 
+// Problems alive per device (created, not yet destroyed): what a launch can expect to share the GPU with
+// (RunBatchAsync: columns per wave by occupancy).
+static std::atomic<int> g_live_handles[16];
+
 struct pm_handle {
   pm_options opt;
   int device = 0;
@@ -435,7 +488,9 @@ struct pm_handle {
   double sweep_ms = 0.0;
   int sweep_launches = 0;
 
+  bool counted = false;  // in g_live_handles
   ~pm_handle() {
+    if (counted) --g_live_handles[device & 15];
     for (auto e : ev) (void)hipEventDestroy(e);
     if (stream) (void)hipStreamDestroy(stream);
   }
@@ -499,6 +554,74 @@ PmParams ParamsForSweep(const pm_handle* h, int rot) {
   return p;
 }
 
+// True when the packed images of `tab` can be read through one buffer resource (see Create).
+bool FpSpanFits(const std::vector<const uint32_t*>& tab, size_t fp_count) {
+  const uint32_t* lo = tab[0];
+  for (auto p : tab) lo = std::min(lo, p);
+  bool ok = ((uintptr_t)lo % 256) == 0;
+  for (auto p : tab) {
+    const uint64_t d = (uint64_t)((const char*)p - (const char*)lo);
+    ok = ok && d % 256 == 0 && d + fp_count * sizeof(uint32_t) + 4096 < FpSpanLimit(fp_count * sizeof(uint32_t));
+  }
+  return ok;
+}
+
+void RehomeSourceImages(pm_handle* h, pm_image_cache* cache, const pm_problem& prob, size_t fp_count,
+                        std::vector<const uint32_t*>* tab) {
+  FpSlabPool& pool = FpSlabPool::Get();
+  const size_t bytes = fp_count * sizeof(uint32_t);
+  const int S = h->S;
+  std::vector<const char*> slab(S);
+  for (int s = 0; s < S; ++s) slab[s] = pool.SlabOf((*tab)[s]);
+  // candidates, best first: the slab with most of the problem's images, then the newest slab
+  std::map<const char*, int> votes;
+  for (int s = 0; s < S; ++s)
+    if (slab[s]) ++votes[slab[s]];
+  std::vector<std::pair<int, const char*>> cand;
+  for (auto& v : votes) cand.push_back({v.second, v.first});
+  std::sort(cand.begin(), cand.end(), [](auto& a, auto& b) { return a.first > b.first; });
+  const char* newest = nullptr;
+  if (pool.FreeInNewest(bytes, &newest) > 0 && !votes.count(newest)) cand.push_back({0, newest});
+  auto try_slab = [&](const char* target) -> bool {
+    std::vector<std::pair<int, uint32_t*>> moved;
+    for (int s = 0; s < S; ++s) {
+      if (slab[s] == target) continue;
+      uint32_t* p = pool.TakeFrom(target, bytes);
+      if (!p) {  // not enough room in this slab: hand the slots back
+        for (auto& m : moved) pool.Give(m.second);
+        return false;
+      }
+      moved.push_back({s, p});
+    }
+    for (auto& m : moved) {
+      const int s = m.first;
+      HIP_CALL(hipMemcpyAsync(m.second, (*tab)[s], bytes, hipMemcpyDeviceToDevice, h->stream));
+      auto e = std::make_shared<FpEntry>();
+      e->data.adopt(m.second, fp_count);
+      if (cache) {
+        const pm_image& im = prob.images[h->src_idxs[s]];
+        const auto key = std::make_tuple((const void*)im.gray, im.width, im.height, h->src_w, h->src_h);
+        std::lock_guard<std::mutex> lock(cache->mu);
+        auto it = cache->entries.find(key);
+        if (it != cache->entries.end() && it->second == h->src_fp[s]) it->second = e;
+      }
+      HIP_CALL(hipStreamSynchronize(h->stream));  // the old copy may be released with the next line
+      h->src_fp[s] = e;
+      (*tab)[s] = m.second;
+      ++g_fp_rehomed;
+    }
+    return true;
+  };
+  for (auto& c : cand)
+    if (try_slab(c.second)) return;
+  // every slab the problem touches is full: a fresh one (Take opens it when no slab has a free slot)
+  uint32_t* probe = pool.Take(bytes);
+  const char* fresh = pool.SlabOf(probe);
+  pool.Give(probe);
+  if (fresh && try_slab(fresh)) return;
+  // no slab has room for all of them: the problem takes the explicit-index build of the kernels
+}
+
 void Create(const pm_options& opt_in, const pm_problem& prob, pm_image_cache* cache, pm_handle* h) {
   CheckOptions(opt_in);
   CheckProblem(opt_in, prob);
@@ -523,6 +646,8 @@ void Create(const pm_options& opt_in, const pm_problem& prob, pm_image_cache* ca
     PM_CHECK(cache->device == h->device, "image cache and problem are on the same GPU");
   }
   HIP_CALL(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  ++g_live_handles[h->device & 15];
+  h->counted = true;
 
   const pm_image& ref = prob.images[prob.ref_image_idx];
   h->W = ref.width;
@@ -584,6 +709,11 @@ void Create(const pm_options& opt_in, const pm_problem& prob, pm_image_cache* ca
       h->src_fp[s] = e;
       tab[s] = e->data.ptr;
     }
+    // One buffer resource per problem (below) needs the S images within 4 GB of each other. Images shared through
+    // the cache may sit in slabs that lie further apart (a long run packs more images than one slab holds): those of
+    // them outside the slab that holds most of the problem's images are then re-homed -- copied device to device into
+    // a free slot of that slab, the cache handed the new copy; problems that still use the old one keep it alive.
+    if (!FpSpanFits(tab, fp_count)) RehomeSourceImages(h, cache, prob, fp_count, &tab);
     h->src_fp_tab.alloc(S);
     HIP_CALL(hipMemcpyAsync(h->src_fp_tab.ptr, tab.data(), S * sizeof(const uint32_t*), hipMemcpyHostToDevice,
                             h->stream));
@@ -599,7 +729,7 @@ void Create(const pm_options& opt_in, const pm_problem& prob, pm_image_cache* ca
       bool ok = ((uintptr_t)lo % 256) == 0;
       for (int s = 0; s < S; ++s) {
         const uint64_t d = (uint64_t)((const char*)tab[s] - (const char*)lo);
-        ok = ok && d % 256 == 0 && d + fp_count * sizeof(uint32_t) + 4096 < (1ull << 32);
+        ok = ok && d % 256 == 0 && d + fp_count * sizeof(uint32_t) + 4096 < FpSpanLimit(fp_count * sizeof(uint32_t));
         offs[s] = (uint32_t)((d / kFpStrip) & 0xffffffffull);
       }
       h->src_fp_off.alloc(S);
@@ -750,6 +880,31 @@ void RunBatchAsync(pm_handle** hs, int n) {
     // work enqueued on other streams at create time must be complete
     HIP_CALL(hipStreamSynchronize(h->stream));
   }
+  // Columns per wave by occupancy. A wave sweeps C columns top to bottom, so a launch has (problems x columns / C)
+  // waves for 16 wave slots per CU. C = 2 is the fastest shape when the GPU is full (pm_pick_columns), but ONE
+  // 2560 x 1920 problem -- how the reference's controller drives the seam, one problem per GPU thread
+  // (mvs/patch_match.cc:190-204) -- then has 960 .. 1 280 waves for 4 096 slots: with fewer than ~3/4 of the slots
+  // covered by everything alive on the device, one column per wave doubles the waves. The results do not depend
+  // on C (tests: group shapes); an explicit columns_per_group is respected.
+  {
+    bool automatic = h0->base.ntaps == 121;
+    for (int b = 0; b < n; ++b) automatic = automatic && hs[b]->opt.columns_per_group <= 0;
+    if (automatic && dev_switch_int("COLMAP_AMD_PM_COLS", 0) <= 0) {
+      static std::atomic<int> cus[16];
+      int ncu = cus[h0->device & 15].load();
+      if (ncu == 0) {
+        HIP_CALL(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h0->device));
+        ncu = std::max(ncu, 1);
+        cus[h0->device & 15] = ncu;
+      }
+      const long long slots = 16ll * ncu;
+      const int alive = std::max(n, g_live_handles[h0->device & 15].load());
+      const long long waves2 = (long long)alive * ((std::min(h0->W, h0->H) + 1) / 2);
+      // (images too small to fill the GPU either way keep the common shape: their time is launch latency)
+      const int C = (std::min(h0->W, h0->H) >= 512 && waves2 * 4 < slots * 3) ? 1 : 2;
+      for (int b = 0; b < n; ++b) hs[b]->base.C = std::min(hs[b]->base.C, C);
+    }
+  }
   const int total_sweeps = opt.num_iterations * 4;
   const int limit = opt.max_sweeps > 0 ? std::min(opt.max_sweeps, total_sweeps)
                                        : (opt.max_sweeps < 0 ? 0 : total_sweeps);
@@ -758,7 +913,7 @@ void RunBatchAsync(pm_handle** hs, int n) {
   for (int b = 0; b < n; ++b) host[b] = ParamsForSweep(hs[b], 0);
   const float total_num_steps = (float)total_sweeps;
   // workgroup -> (problem, column group) mapping of a batched sweep launch (pm_sweep_kernel)
-  static const int xcd_map_env = [] { const char* e = getenv("COLMAP_AMD_PM_XCD_MAP"); return e ? atoi(e) : 0; }();
+  const int xcd_map_env = dev_switch_int("COLMAP_AMD_PM_XCD_MAP", 0);
   const int xcd_map = (xcd_map_env == 1 && n % 8 == 0) ? 1 : (xcd_map_env == 2 ? 2 : 0);
   int sel_out = h0->base.sel_out_off, sel_in = h0->base.sel_in_off;
   // one kernel serves the whole batch: buffer-resource addressing only if every problem's images allow it
@@ -771,17 +926,22 @@ void RunBatchAsync(pm_handle** hs, int n) {
       // exponentially reduce the perturbation, linearly increase the influence of the
       // previous selection probabilities (reference :1446-1451)
       p.perturbation = 1.0f / std::pow(2.0f, iter + sweep / 4.0f);
+#ifdef COLMAP_AMD_DIAG_BUILD
       {  // diagnostic only (results are garbage): fixed perturbation, to time a launch without far-flung random hypotheses
-        static const char* e = getenv("COLMAP_AMD_PM_DIAG_PERT");
-        if (e) p.perturbation = (float)atof(e);
+        const double pert = dev_switch_double("COLMAP_AMD_PM_DIAG_PERT", -1.0);
+        if (pert >= 0.0) p.perturbation = (float)pert;
       }
+#endif
       p.perturbation_pi = (float)(p.perturbation * M_PI);
       p.prev_sel_prob_weight = (float)(iter * 4 + sweep) / total_num_steps;
       p.sel_out_off = sel_out;
       p.sel_in_off = sel_in;
       p.xcd_map = xcd_map;
-      static const int ablate_env = [] { const char* e = getenv("COLMAP_AMD_PM_ABLATE"); return e ? atoi(e) : 0; }();
-      p.ablate = ablate_env;
+#ifdef COLMAP_AMD_DIAG_BUILD
+      p.ablate = dev_switch_int("COLMAP_AMD_PM_ABLATE", 0);  // profiling builds only: results are garbage
+#else
+      p.ablate = 0;
+#endif
       if (!fp_resource_all) p.fp_base = nullptr;
       host[(size_t)(k + 1) * n + b] = p;
     }
@@ -1208,6 +1368,11 @@ void pm_destroy(pm_handle* h) {
 void pm_release_cached_memory(void) {
   DevPool::Get().Release();
   FpSlabPool::Get().Release();
+}
+
+unsigned long long pm_debug_set_image_slab_slots(size_t slots) {
+  g_fp_slab_slots = slots;
+  return g_fp_rehomed.load();
 }
 
 const char* pm_last_error(void) { return g_last_error.c_str(); }

@@ -5,6 +5,13 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "switches.h"
+
+// PmParams::ablate (skip phases of the sweep to time the rest: results are garbage) is only ever non-zero in a
+// profiling build (-DCOLMAP_AMD_DIAG_BUILD: pm_api.cpp sets it from a development switch); the kernels keep their three
+// scalar tests on it so that the shipped instruction stream is the profiled one.
+#define PM_ABLATE(p) ((p).ablate)
+
 namespace colmap_amd {
 
 constexpr int kPoseStride = 43;  // K4 R9 T3 C3 P12 invP12 (reference patch_match_cuda.cu:1762)

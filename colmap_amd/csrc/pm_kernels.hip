@@ -1813,7 +1813,7 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
     const int c = item / S;
     const int s = item - c * S;
     float beta = 0.5f;
-    for (int row = (p.ablate & 4) ? -1 : RH - 1; row >= 0; --row) {
+    for (int row = (PM_ABLATE(p) & 4) ? -1 : RH - 1; row >= 0; --row) {
       float* rec = p.rec + (size_t)pix_index(p, row, col0 + c) * p.rec_stride;
       beta = hmm_message<false>(p, rec[4 + s], beta);
       rec[p.sel_out_off + s] = beta;
@@ -1854,7 +1854,7 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
     wave_sync<NW>();
 
     // ---- P1: hypotheses (lane per column) + patch weights (all lanes) --------
-    if (col_lane && !(p.ablate & 2)) {
+    if (col_lane && !(PM_ABLATE(p) & 2)) {
       const int c = tid;
       const int col = col0 + c;
       const int pix = pix_index(p, row, col);
@@ -1964,7 +1964,7 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
     wave_sync<NW>();
 
     // ---- P4: NCC of hypotheses 1..4 against the drawn views (:1157-1172) -----
-    if (!(p.ablate & 1)) run_tasks_wave<GEOM, NW, CAP, MUBUF>(p, L, srd, row, col0, tid, evals);
+    if (!(PM_ABLATE(p) & 1)) run_tasks_wave<GEOM, NW, CAP, MUBUF>(p, L, srd, row, col0, tid, evals);
     if (tid == 0) { L.ntasks[0] = 0; L.ntasks[1] = 0; }
     wave_sync<NW>();
 
@@ -2020,7 +2020,7 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
     wave_sync<NW>();
 
     // ---- P6: NCC of the winner against the remaining views (:1188-1197) ------
-    if (!(p.ablate & 1)) run_tasks_wave<false, NW, CAP, MUBUF>(p, L, srd, row, col0, tid, evals);
+    if (!(PM_ABLATE(p) & 1)) run_tasks_wave<false, NW, CAP, MUBUF>(p, L, srd, row, col0, tid, evals);
 
     // ---- P7: cost map, forward message, selection probability (:1186-1207) ---
     for (int item = tid; item < ncols * S; item += nt) {
@@ -2140,15 +2140,14 @@ size_t pm_sweep_lds_bytes(const PmParams& p, bool geom) {
 // LDS budget of one four-wave workgroup when four of them share a CU: 160 KB / 4 in 1280-byte granules.
 constexpr size_t kQuadLdsBudget = 40960;
 static bool pm_quad_enabled() {  // read per call: the tests switch it inside one process
-  const char* e = getenv("COLMAP_AMD_PM_QUAD");
-  return !e || atoi(e) != 0;
+  return dev_switch_int("COLMAP_AMD_PM_QUAD", 1) != 0;
 }
 
 int pm_pick_columns(int S, int ntaps, int num_samples, bool geom, int radius, int requested) {
   const size_t budget = 60 * 1024;
   // default: 2 columns per wave of the 11 x 11 kernels (16 waves resident per CU, the lane-per-(column, view)
   // phases are one pass; measured 604 / 643 / 718 ms per 16-image launch for C = 2 / 3 / 4), 4 for the generic kernel
-  static const int cols_env = [] { const char* e = getenv("COLMAP_AMD_PM_COLS"); return e ? atoi(e) : 0; }();  // experiments / tests
+  const int cols_env = dev_switch_int("COLMAP_AMD_PM_COLS", 0);  // experiments / tests
   if (requested <= 0 && cols_env > 0) requested = cols_env;
   int c = requested > 0 ? requested : (ntaps == 121 ? 2 : 4);
   if (c > 64) c = 64;
@@ -2209,7 +2208,7 @@ const char* pm_launch_sweep(const PmParams& p, const PmParams* dev_params, int b
                             bool filter_photo, bool filter_geom, hipStream_t st) {
   const int rw = (p.rot & 1) ? p.H : p.W;
   const unsigned groups = (unsigned)((rw + p.C - 1) / p.C);
-  static const bool wave_enabled = [] { const char* e = getenv("COLMAP_AMD_PM_WAVE"); return !e || atoi(e) != 0; }();
+  const bool wave_enabled = dev_switch_int("COLMAP_AMD_PM_WAVE", 1) != 0;
 #define PM_LAUNCH_V4(KERNEL, MB, GRID, BLOCK, LDS)                                                   \
   do {                                                                                              \
     if (geom) {                                                                                     \
@@ -2227,8 +2226,7 @@ const char* pm_launch_sweep(const PmParams& p, const PmParams* dev_params, int b
   } while (0)
   if (wave_enabled && !p.prof && p.ntap1d == 11 && p.step >= 1 && p.S <= 512 && p.C <= 8) {
     // COLMAP_AMD_PM_FP_GLOBAL=1 (tests): explicit indices although the buffer resource would do
-    const char* fg = getenv("COLMAP_AMD_PM_FP_GLOBAL");
-    const bool mubuf = pm_fp_resource_ok(p) && !(fg && atoi(fg) != 0);
+    const bool mubuf = pm_fp_resource_ok(p) && dev_switch_int("COLMAP_AMD_PM_FP_GLOBAL", 0) == 0;
     const size_t qlds = lds_offsets_wave(p.C, p.S, p.radius, p.ntaps, p.num_samples, geom, kQuadThCap, kQuadWaves).total;
     if (pm_quad_enabled() && qlds <= kQuadLdsBudget) {
       PM_LAUNCH_V(pm_sweep_quad_kernel, dim3((groups + kQuadWaves - 1) / kQuadWaves, batch, 1), dim3(64 * kQuadWaves, 1, 1), qlds);

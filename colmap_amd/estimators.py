@@ -736,11 +736,11 @@ def solve_flat(fp: FlatProblem, so: Optional[SolverOptions] = None, gpu_index: i
     r.log_cost, r.log_radius, r.log_linear_iters = log_cost.ctypes.data, log_radius.ctypes.data, log_lin.ctypes.data
     if solve_fn is None:
         L = lib()
+        _check_abi(L)   # before either entry point: both take the same ctypes mirrors
         if comm is not None:
             cc = comm.to_c()
             rc = L.ba_solve_sharded(C.byref(p), C.byref(o), C.c_int32(gpu_index), C.byref(cc), C.byref(r))
         else:
-            _check_abi(L)
             rc = L.ba_solve(C.byref(p), C.byref(o), C.c_int32(gpu_index), C.byref(r))
         if rc != 0:
             raise RuntimeError(L.ba_last_error().decode())
@@ -759,13 +759,33 @@ def solve_flat(fp: FlatProblem, so: Optional[SolverOptions] = None, gpu_index: i
 
 
 def num_camera_parameters(fp: FlatProblem) -> int:
-    """Size n_c of the reduced camera system (the matrix the exact tiers factor): the variable entries of the pose
-    and intrinsics blocks, i.e. everything that is not a point."""
-    free = np.asarray(fp.pose_const) == 0
-    n = 6 * int(np.count_nonzero(free)) - int(np.count_nonzero(free & (np.asarray(fp.pose_fixed_t) >= 0)))
-    n += int(np.count_nonzero(np.asarray(fp.cam_const) == 0))
-    if fp.sensors is not None and fp.sensor_const is not None:
-        n += 6 * int(np.count_nonzero(np.asarray(fp.sensor_const) == 0))
+    """Size n_c of the reduced camera system (the matrix the exact tiers factor), by the library's own rule
+    (ba_kernels.hip: tangent layout): blocks that at least one ACTIVE observation uses (an observation is active when any
+    of its blocks is variable); a pose block has 3 rotation dimensions unless its rotation is held (pose_fixed_t >=
+    POSE_ROT_CONST) plus 3 translation dimensions, 2 when one translation coordinate is held; an intrinsics block its
+    variable entries; a variable sensor_from_rig block 6."""
+    pose_const = np.asarray(fp.pose_const) != 0
+    cam_nvar = (np.asarray(fp.cam_const) == 0).sum(1)
+    pt_const = np.asarray(fp.point_const) != 0
+    op, oc, ox = np.asarray(fp.obs_pose), np.asarray(fp.obs_cam), np.asarray(fp.obs_point)
+    sens_var_obs = np.zeros(len(op), bool)
+    sens_var = None
+    if fp.sensors is not None and fp.obs_sensor is not None and fp.sensor_const is not None:
+        sens_var = np.asarray(fp.sensor_const) == 0
+        osn = np.asarray(fp.obs_sensor)
+        sens_var_obs = (osn >= 0) & sens_var[np.maximum(osn, 0)]
+    active = ~(pose_const[op] & (cam_nvar[oc] == 0) & pt_const[ox] & ~sens_var_obs)
+    pose_used = np.zeros(len(pose_const), bool)
+    pose_used[op[active]] = True
+    cam_used = np.zeros(len(cam_nvar), bool)
+    cam_used[oc[active]] = True
+    pf = np.asarray(fp.pose_fixed_t).astype(np.int64)
+    dim = np.where(pf >= POSE_ROT_CONST, 0, 3) + np.where((pf >= 0) & ((pf & 3) != 3), 2, 3)
+    n = int(dim[pose_used & ~pose_const].sum()) + int(cam_nvar[cam_used].sum())
+    if sens_var is not None:
+        used = np.zeros(len(sens_var), bool)
+        used[osn[active & (osn >= 0)]] = True
+        n += 6 * int(np.count_nonzero(sens_var & used))
     return n
 
 

@@ -189,6 +189,18 @@ int pm_get_progress_trace(pm_handle* h, unsigned long long* out, size_t capacity
 int pm_debug_rng_streams(int32_t gpu_index, const uint64_t* seeds, int32_t nseeds, int32_t ndraws,
                          float* out);
 
+/* Development switches (colmap_amd/csrc/switches.h): selects a kernel variant kept for A/B comparisons ("COLMAP_AMD_PM_QUAD",
+ * "COLMAP_AMD_BA_FORM_PAIRS", ...) for this process; value NULL restores the built-in default. The library reads no
+ * environment variables; tests and bench.py's A/B legs call this. Serves all three paths (PatchMatch, BA, fusion). */
+void colmap_amd_set_switch(const char* name, const char* value);
+
+/* Debug: packed source images are allocated from slabs (3.5 GB for full-size images) and the images of one problem
+ * must lie within 4 GB of each other to be read through one buffer resource; cached images that do not are re-homed
+ * (copied into the slab that holds most of the problem's images). `slots` > 0 puts the allocator into a test mode --
+ * `slots` images per slab, the span limit = one slab -- so that a handful of small images exercises that path; 0 =
+ * the hardware's limits. Call before any image is packed. Returns the number of images re-homed so far. */
+unsigned long long pm_debug_set_image_slab_slots(size_t slots);
+
 void pm_destroy(pm_handle* h);
 /* Device buffers of destroyed handles are kept (exact-size free lists, bounded by COLMAP_AMD_PM_POOL_GB,
  * default 64) for the next handle of the same shape; this returns them to the driver. */

@@ -18,6 +18,10 @@
 //           claim word, the lowest rank that lost a claim cuts the committed prefix. The threads are interleaved
 //           pseudo-randomly, so the test "mode 2 == mode 1" is the executable form of the argument that the
 //           parallel schedule equals the sequential one whatever the timing.
+//   mode 3  the reference's pool AS IT RUNS: T = num_threads real threads (<= 0: all cores) pulling the stripes of an
+//           image from a shared counter and racing on the pixel masks exactly as mvs/fusion.cc does (its result is
+//           timing-dependent for T > 1, and so is this mode's). Not a checker of anything: it exists to TIME the
+//           reference's own multi-threaded path on the host's cores (bench.py cpu_baseline of the fusion leg).
 // All arithmetic float like the reference (Eigen::Vector3f / Matrix<float,3,4>), medians through
 // colmap::Percentile (math/math.h:205-224). Build: oracle/Makefile (-ffp-contract=off).
 #include <algorithm>
@@ -26,7 +30,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <stdexcept>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <unordered_set>
 #include <vector>
 
@@ -207,6 +213,20 @@ struct Fuser {
         if (mode == 0) {
           for (int row = 0; row < height; ++row)
             for (int col = 0; col < width; ++col) Fuse(image_idx, row, col, out);
+        } else if (mode == 3) {  // fusion.cc:253-269, 293-300: the pool, for real
+          const int ns = (height + 9) / 10;
+          int T = opt.num_threads <= 0 ? (int)std::max(1u, std::thread::hardware_concurrency()) : opt.num_threads;
+          T = std::min(T, ns);
+          if ((int)per_thread.size() < T) per_thread.resize(T);
+          std::atomic<int> next{0};
+          std::vector<std::thread> pool;
+          for (int t = 0; t < T; ++t)
+            pool.emplace_back([&, t] {
+              for (int k = next++; k < ns; k = next++)
+                for (int row = 10 * k; row < std::min(10 * k + 10, height); ++row)
+                  for (int col = 0; col < width; ++col) Fuse(image_idx, row, col, &per_thread[t]);
+            });
+          for (auto& th : pool) th.join();
         } else {
           const Pool pl(width, height, opt.num_threads);
           if ((int)per_thread.size() < pl.T) per_thread.resize(pl.T);
@@ -233,7 +253,7 @@ struct Fuser {
     std::unordered_set<int> vis;
     int recorded = 0;
     const int kRecordCap = RecordCapacity(opt.max_num_pixels);
-    const size_t max_pixels = mode == 0 ? (size_t)opt.max_num_pixels : (size_t)std::min(opt.max_num_pixels, kRecordCap);
+    const size_t max_pixels = (mode == 0 || mode == 3) ? (size_t)opt.max_num_pixels : (size_t)std::min(opt.max_num_pixels, kRecordCap);
 
     while (!queue.empty()) {
       const FusionData data = queue.back();
@@ -280,7 +300,7 @@ struct Fuser {
         if (xx >= 0 && yy >= 0 && xx < im.bitmap_width && yy < im.bitmap_height)
           std::memcpy(color, im.rgb + 3 * ((size_t)yy * im.bitmap_width + xx), 3);
       }
-      if (mode != 0 && recorded >= kRecordCap) break;
+      if (mode != 0 && mode != 3 && recorded >= kRecordCap) break;
       ++recorded;
       mask[pix] = 1;
       if (xyz[0] < opt.bbox_min[0] || xyz[1] < opt.bbox_min[1] || xyz[2] < opt.bbox_min[2] ||
@@ -303,7 +323,7 @@ struct Fuser {
         float np[3];
         for (int r = 0; r < 3; ++r) np[r] = Pn[4 * r] * xyz[0] + Pn[4 * r + 1] * xyz[1] + Pn[4 * r + 2] * xyz[2] + Pn[4 * r + 3];
         int next_col, next_row;
-        if (mode == 0) {
+        if (mode == 0 || mode == 3) {
           next_col = static_cast<int>(std::round(np[0] / np[2]));
           next_row = static_cast<int>(std::round(np[1] / np[2]));
           if (next_col < 0 || next_row < 0 || next_col >= images[next].depth_width || next_row >= images[next].depth_height)
@@ -677,7 +697,7 @@ FUO_API int fuo_run(int32_t mode, const fusion_options* options, int32_t num_ima
   const int rc = Guard([&] {
     FU_CHECK(options && images && overlap_ptr && out, "null argument");
     FU_CHECK(fuo_options_check(options) == 0, "options.Check()");
-    FU_CHECK(mode >= 0 && mode <= 2, "mode");
+    FU_CHECK(mode >= 0 && mode <= 3, "mode");
     FU_CHECK(num_images > 0, "num_images > 0");
     for (int i = 0; i < num_images; ++i) {
       FU_CHECK(overlap_ptr[i] <= overlap_ptr[i + 1], "overlap_ptr is monotone");

@@ -5,8 +5,14 @@ from colmap_amd import estimators as est, scene
 import argparse
 ap = argparse.ArgumentParser(); ap.add_argument("--frames", type=int, default=6); ap.add_argument("--points", type=int, default=40); ap.add_argument("--track", type=int, default=4)
 ap.add_argument("--iters", type=int, default=100); ap.add_argument("--op32", type=int, default=0); ap.add_argument("--lst", type=int, default=0); ap.add_argument("--oracle", type=int, default=0); ap.add_argument("--gtol", type=float, default=1e-4)
+ap.add_argument("--switch", action="append", default=[], help="development switch NAME=VALUE (csrc/switches.h), repeatable")
+ap.add_argument("--shared", type=int, default=0, help="share this many cameras between all images (0: one camera per image)")
 a = ap.parse_args()
+for kv in a.switch:
+    k, v = kv.split("=", 1); est.lib().colmap_amd_set_switch(k.encode(), v.encode())
 t = time.time(); d = scene.synthesize_flat(a.frames, a.points, a.track, seed=42, noise=scene.SyntheticNoiseOptions(0.01, 1.0, 0.05, 1.0)); print("gen %.2fs" % (time.time() - t))
+if a.shared > 0:
+    d["obs_cam"] = (d["obs_cam"] % a.shared).astype(np.int32); d["cams"] = d["cams"][:a.shared].copy(); d["cam_model"] = d["cam_model"][:a.shared].copy()
 fp = est.FlatProblem.from_arrays(d); est.fix_gauge_two_cams(fp)
 so = est.SolverOptions(gradient_tolerance=a.gtol, max_num_iterations=a.iters, operator_precision=a.op32, linear_solver_type=a.lst)
 for rep in range(2):

@@ -27,7 +27,7 @@ for st in "$@"; do
   case $name in
     tests)    if [[ "$arg" == *.py* ]]; then sel="$arg"; else sel="tests -k \"$arg\""; fi
               eval timeout 1500 python -m pytest $sel -m gpu -q --timeout 900 2>&1 | quiet | tail -25 | tee -a $OUT/tests.log ;;
-    alltests) timeout 2400 python -m pytest tests -m gpu -q --timeout 900 2>&1 | quiet | tail -30 | tee $OUT/alltests.log ;;
+    alltests) timeout 2400 python -m pytest tests -m gpu -q --timeout 900 --durations=40 2>&1 | quiet | tail -80 | tee $OUT/alltests.log ;;
     smoke)    timeout 600 python __graft_entry__.py smoke 2>&1 | quiet | tail -8 | tee $OUT/smoke.log ;;
     bench)    timeout 1200 python bench.py $arg > $OUT/bench.json 2> $OUT/bench.err; tail -c 6000 $OUT/bench.json; tail -3 $OUT/bench.err ;;
     ba)       for i in 1 2 3; do timeout 300 python scripts/ba_probe.py --frames 1000 --points 200000 --track 10 --iters ${arg:-10} 2>&1 | tail -1; done | tee -a $OUT/ba_probe.log ;;

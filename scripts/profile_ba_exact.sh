@@ -22,9 +22,9 @@ run() {  # name, env assignment (or "X=0"), probe arguments
   cut -c1-150 $OUT/${name}_kernel_stats.csv | head -16
 }
 echo "== exact tier, pair-major formation"
-run exact_pairs COLMAP_AMD_BA_FORM_PAIRS=1 --iters 6 --lst 3
+run exact_pairs X=0 --iters 6 --lst 3
 echo "== exact tier, point-major formation"
-run exact_points COLMAP_AMD_BA_FORM_PAIRS=0 --iters 6 --lst 3
+run exact_points X=0 --iters 6 --lst 3 --switch COLMAP_AMD_BA_FORM_PAIRS=0
 echo "== iterative tier"
-run iterative COLMAP_AMD_BA_FORM_PAIRS=1 --iters 10
+run iterative X=0 --iters 10
 du -sh $OUT

@@ -52,6 +52,10 @@ class _StandInLibrary:
     def __init__(self, libs):
         self._libs = libs
 
+    def colmap_amd_set_switch(self, name, value):   # every stand-in library keeps its own table
+        for L in self._libs:
+            L.colmap_amd_set_switch(name, value)
+
     def __getattr__(self, name):
         for L in self._libs:
             try:

@@ -62,6 +62,8 @@ enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2, hipHostMallocMapped 
 inline const char* hipGetErrorString(hipError_t) { return "hip_emul error"; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
 inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 63 };
+inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v = 256; return hipSuccess; }
 inline hipError_t hipSetDevice(int) { return hipSuccess; }
 inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 inline hipError_t hipMalloc(void** p, size_t bytes) {  // device allocations are page-aligned (the host code relies on 256 B)
@@ -407,6 +409,7 @@ inline hip_emul_v4f64 hip_emul_mfma_f64_16x16x4(double a, double b, hip_emul_v4f
 #define __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, cbsz, abid, blgp) hip_emul_mfma_f64_16x16x4((a), (b), (c))
 
 // ---- what the PatchMatch kernels use beyond the above ----
+inline double __builtin_amdgcn_rcp(double x) { return 1.0 / x; }   // v_rcp_f64 (the kernels refine it by Newton steps)
 inline float __builtin_amdgcn_fractf(float x) { return x - std::floor(x); }  // v_fract_f32 (finite x >= 0 in the kernels)
 inline float __builtin_amdgcn_fmed3f(float a, float b, float c) {            // v_med3_f32: the median; a NaN operand gives min3
   if (a != a || b != b || c != c) return std::fmin(std::fmin(a, b), c);

@@ -302,18 +302,11 @@ def test_baseline_config4_full_size_properties():
 
 
 def _solve_env(fp, env, **so_kw):
-    import os
-    old = {k: os.environ.get(k) for k in env}
-    os.environ.update(env)
-    try:
+    """One solve with development switches of the library set (tests/switches.py; the library reads no environment)."""
+    from switches import switches
+    with switches(est.lib(), **env):
         b = fp.copy()
         return b, est.solve_flat(b, est.SolverOptions(**so_kw), gpu_index=0)
-    finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
 
 
 @pytest.mark.parametrize("mixed", [False, "three"])

@@ -117,6 +117,7 @@ def test_emulated_kernel_blocks_in_reverse_order():
             "import test_fusion_emul as T, fusion_oracle\n"
             "from colmap_amd import fusion\n"
             "E = T._EmulEntryPoints('libfusion_emul.so')\n"
+            "E.lib.colmap_amd_set_switch(b'COLMAP_AMD_FUSION_LDS_TABLES', b'%s')\n"
             "im, ov = T._noisy(4, 24, 160, 0.01), T._overlap(4)\n"
             "opt = fusion.StereoFusionOptions(**T._LOOSE)\n"
             "assert T._same(fusion.fuse(opt, im, ov, entry_points=E), fusion_oracle.fuse(opt, im, ov, mode=1))\n"
@@ -170,19 +171,19 @@ def test_emulated_kernel_pool_sizes(emul, num_threads):
 @pytest.mark.parametrize("tables", ["0", "1"])
 def test_emulated_kernel_table_tiers(tables):
     """The walk kernel reads image descriptors and overlap lists from an LDS copy when they fit (tier 2, what every
-    other test here runs), descriptors only (1), or from HBM (0): COLMAP_AMD_FUSION_LDS_TABLES caps the tier. Same
-    points. (A separate process per tier: the variable is read by the library.)"""
+    other test here runs), descriptors only (1), or from HBM (0): the development switch COLMAP_AMD_FUSION_LDS_TABLES caps the tier. Same
+    points. (A separate process per tier.)"""
     code = ("import sys; sys.path[:0] = [%r, %r, %r]\n"
             "import test_fusion_emul as T, fusion_oracle\n"
             "from colmap_amd import fusion\n"
             "E = T._EmulEntryPoints('libfusion_emul.so')\n"
+            "E.lib.colmap_amd_set_switch(b'COLMAP_AMD_FUSION_LDS_TABLES', b'%s')\n"
             "for name in ('defaults_5x64x48', 'sparse_overlap', 'mask0'):\n"
             "    opt, im, ov = T._case(name)\n"
             "    assert T._same(fusion.fuse(opt, im, ov, entry_points=E), fusion_oracle.fuse(opt, im, ov, mode=1)), name\n"
             "print('tiers ok')\n") % (os.path.dirname(_HERE), os.path.join(os.path.dirname(_HERE), "..", "oracle"),
-                                       os.path.join(os.path.dirname(_HERE), ".."))
-    env = dict(os.environ, COLMAP_AMD_FUSION_LDS_TABLES=tables)
-    out = subprocess.run([os.sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+                                       os.path.join(os.path.dirname(_HERE), ".."), tables)
+    out = subprocess.run([os.sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "tiers ok" in out.stdout, out.stderr[-2000:]
 
 

@@ -97,11 +97,13 @@ def test_geometric_consistency_pass_and_both_filters(pm_oracle):
 
 
 @pytest.mark.parametrize("quad,fp_global", [("0", "0"), ("1", "1")])
-def test_single_wave_workgroups_and_explicit_indices(pm_oracle, monkeypatch, quad, fp_global):
+def test_single_wave_workgroups_and_explicit_indices(pm_oracle, request, quad, fp_global):
     """pm_sweep_wave4_kernel (single-wave workgroups) through the buffer resource, and the four-wave kernel with
     explicit strip indices (what problems whose images lie more than 4 GB apart get); ragged width, S = 6."""
-    monkeypatch.setenv("COLMAP_AMD_PM_QUAD", quad)
-    monkeypatch.setenv("COLMAP_AMD_PM_FP_GLOBAL", fp_global)
+    from switches import set_switch
+    for k, v in (("COLMAP_AMD_PM_QUAD", quad), ("COLMAP_AMD_PM_FP_GLOBAL", fp_global)):
+        set_switch(mvs.lib(), k, v)
+    request.addfinalizer(lambda: [set_switch(_emul_lib(), k, None) for k in ("COLMAP_AMD_PM_QUAD", "COLMAP_AMD_PM_FP_GLOBAL")])
     views = scene(7, 35, 27)
     want, got, pm = G._run_both(pm_oracle, views, 3, [0, 1, 2, 4, 5, 6], geom_consistency=0, filter=1, num_iterations=1)
     G._assert_equal(want, got)
@@ -145,6 +147,7 @@ def test_host_side_cases_of_the_gpu_suite(pm_oracle):
     """Error behaviour of the C ABI, source images larger than the reference's slot, one source with 25 samples: the GPU
     tests themselves, library swapped."""
     G.test_error_behaviour()
+    G.test_cached_images_in_distant_slabs_are_rehomed(pm_oracle)
     G.test_sources_larger_than_reference_slot(pm_oracle)
     G.test_single_source_and_many_samples(pm_oracle)
 

@@ -8,6 +8,7 @@ The oracle runs in `order=1` (the kernel's evaluation order of the NCC sums);
 tests/test_pm_oracle.py bounds the difference between that order and the
 reference's sequential order (`order=0`).
 """
+import ctypes as C
 import os
 
 import numpy as np
@@ -130,14 +131,17 @@ def test_group_shapes_do_not_change_results(pm_oracle, cols, threads):
 @pytest.mark.parametrize("fp_global", ["0", "1"])
 @pytest.mark.parametrize("quad", ["0", "1"])
 @pytest.mark.parametrize("geom", [0, 1])
-def test_four_wave_workgroups_equal_single_wave_workgroups(pm_oracle, monkeypatch, quad, geom, fp_global):
+def test_four_wave_workgroups_equal_single_wave_workgroups(pm_oracle, request, quad, geom, fp_global):
     """pm_sweep_quad_kernel (four waves per workgroup sharing the read-only LDS tables, 64 task slots per batch)
     against the single-wave workgroups (COLMAP_AMD_PM_QUAD=0), both against the oracle:
     ragged width (67 columns = 22 groups of three + one column; 23 groups = 5 workgroups + 3 waves), S = 6."""
-    monkeypatch.setenv("COLMAP_AMD_PM_QUAD", quad)
+    from colmap_amd import mvs
+    from switches import set_switch
     # packed images addressed through the buffer resource (the default) or by explicit indices (what problems whose
-    # images lie more than 4 GB apart get)
-    monkeypatch.setenv("COLMAP_AMD_PM_FP_GLOBAL", fp_global)
+    # images lie more than 4 GB apart and cannot be re-homed get)
+    for k, v in (("COLMAP_AMD_PM_QUAD", quad), ("COLMAP_AMD_PM_FP_GLOBAL", fp_global)):
+        set_switch(mvs.lib(), k, v)
+    request.addfinalizer(lambda: [set_switch(mvs.lib(), k, None) for k in ("COLMAP_AMD_PM_QUAD", "COLMAP_AMD_PM_FP_GLOBAL")])
     views = scene(7, 67, 45)
     maps = None
     if geom:
@@ -243,6 +247,43 @@ def test_image_cache_shares_sources_without_changing_results(pm_oracle):
     cache.set_capacity(0)
     assert cache.stats()["entries"] == 0
     cache.close()
+
+
+def test_cached_images_in_distant_slabs_are_rehomed(pm_oracle):
+    """Packed source images come out of slabs, and the images of one problem must lie within one buffer resource's
+    span (4 GB on the hardware). In the allocator's test mode -- four images per slab, the span = one slab -- a walk
+    along seven views makes problems whose cached sources sit in two slabs: those are copied into one slab
+    (pm_api.cpp RehomeSourceImages), every problem keeps the buffer-resource kernels, and the results are the bits
+    of the uncached runs."""
+    from colmap_amd import mvs
+    L = mvs.lib()
+    L.pm_debug_set_image_slab_slots.restype = C.c_ulonglong
+    mvs.release_cached_memory()
+    before = L.pm_debug_set_image_slab_slots(C.c_size_t(4))
+    try:
+        views = scene(7, 35, 27)
+        images = hip_problem(views, 1, [0, 2]).images
+        probs = [(1, [0, 2, 3]), (4, [3, 5, 6]), (2, [0, 3, 6]), (5, [1, 4, 6])]
+        cache = mvs.ImageCache(0)
+        for ref, src in probs:
+            dmin, dmax = syn.depth_range(views, ref)
+            _, h = paired_options(pm_oracle, depth_min=dmin, depth_max=dmax, geom_consistency=0, filter=1,
+                                  num_iterations=1)
+            a = mvs.PatchMatch(h, mvs.PatchMatch.Problem(ref, src, images), cache)
+            b = mvs.PatchMatch(h, mvs.PatchMatch.Problem(ref, src, images))
+            a.Run()
+            b.Run()
+            assert "explicit" not in a.GetSweepKernelName() and "explicit" not in b.GetSweepKernelName()
+            np.testing.assert_array_equal(a.GetDepthMap(), b.GetDepthMap())
+            np.testing.assert_array_equal(a.GetNormalMap(), b.GetNormalMap())
+            np.testing.assert_array_equal(a.GetSelProbMap(), b.GetSelProbMap())
+            a.close()
+            b.close()
+        cache.close()
+        assert L.pm_debug_set_image_slab_slots(C.c_size_t(4)) > before   # and the path was taken
+    finally:
+        mvs.release_cached_memory()
+        L.pm_debug_set_image_slab_slots(C.c_size_t(0))
 
 
 def test_error_behaviour():
