@@ -35,6 +35,7 @@
 //  * Triangular solves with the stored block inverses: the forward one rides along with the factorisation (the
 //    right-hand side is row n of the matrix), the backward one takes one launch per outer panel of 256 columns.
 #include "ba_schur_explicit.h"
+#include "gfx950/ba_gfx950_asm.h"  // order_after (see its header)
 
 #include <hipcub/hipcub.hpp>
 
@@ -524,23 +525,85 @@ __device__ __forceinline__ double rcp_f64(double d) {
   return y;
 }
 
+// a[cc] -= m * column[cc] for cc in (c, NB): the rank-1 update of one column step, for a lane that holds one row (or
+// one column of the inverse) in registers. `colp` = the step's column in LDS, the same 512 bytes for every lane
+// (broadcast reads). The reads go out in chunks of 16 values (eight ds_read_b128), chunk k + 1 in flight while chunk
+// k's FMAs issue, and -- what makes this a function of its own -- chunk k + 1 is tied by a true dependence
+// (order_after) to a result of chunk k - 1: at most two chunks (64 VGPRs) are ever live beside the 128 of the matrix.
+// Left to itself the compiler either hoists all reads of a step to its top (spills) or, under the register cap, keeps
+// two reads in flight: 32 exposed LDS round trips per step, ~2 000 cycles, 40-54 us per diagonal block in the
+// round-5 trace (v_readlane broadcasts instead of LDS measured the same: 42-68 us -- every SGPR pair is a round trip).
+template <int C>
+__device__ __forceinline__ void rank1_update(double (&a)[NB], const double m, const double* colp, int& tok) {
+  constexpr int E0 = (C + 1) & ~1;                 // first chunk starts on a 16-byte boundary
+  constexpr int NCH = (NB - E0 + 15) / 16;
+  if constexpr (NCH > 0) {
+    double buf[2][16];
+    auto fetch = [&](int k, int off) {
+#pragma unroll
+      for (int i = 0; i < 16; i += 2) {
+        const int e = E0 + 16 * k + i;
+        if (e < NB) {
+          const double2 t = *reinterpret_cast<const double2*>(colp + e + off);
+          buf[k & 1][i] = t.x;
+          buf[k & 1][i + 1] = t.y;
+        }
+      }
+    };
+    fetch(0, 0);
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      if (k + 1 < NCH) {
+        if (k >= 1) order_after(tok, a[E0 + 16 * k - 1]);  // (the last entry chunk k - 1 updated)
+        fetch(k + 1, tok);
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int cc = E0 + 16 * k + i;
+        if (cc > C && cc < NB) a[cc] = fma(-m, buf[k & 1][i], a[cc]);  // (-ffp-contract=off: explicit fma)
+      }
+    }
+  }
+}
+
+template <int C>
+__device__ __forceinline__ void chol_steps_factor(double (&a)[NB], double& dmine, double (*col)[NB], int lane, int& tok) {
+  if constexpr (C < NB) {
+    const double ac = a[C];                          // entry `lane` of column C
+    const double d = readlane_f64(ac, C);
+    dmine = lane == C ? ac : dmine;
+    col[C & 1][lane] = ac;
+    const double l = ac * rcp_f64(d);  // multiplier of row `lane` (rows <= C: a don't-care)
+    __syncthreads();  // column C (its entry C is the pivot) is published; the other buffer is free again
+    rank1_update<C>(a, l, col[C & 1], tok);
+    chol_steps_factor<C + 1>(a, dmine, col, lane, tok);
+  }
+}
+
+template <int R>
+__device__ __forceinline__ void chol_steps_inverse(double (&a)[NB], double (*col)[NB], int& tok) {
+  if constexpr (R < NB) {
+    __syncthreads();
+    const double yr = a[R] * rcp_f64(col[R & 1][R]);
+    a[R] = yr;
+    rank1_update<R>(a, yr, col[R & 1], tok);
+    chol_steps_inverse<R + 1>(a, col, tok);
+  }
+}
+
 // Diagonal block [k0, k0 + kb): L_kk in place (lower), its inverse (64 x 64, zero-padded) to Linv.
 // TWO WAVES, each with a 64 x 64 matrix in registers (64 doubles = 128 VGPRs per lane; every loop below is unrolled
 // so that the register indices are compile-time constants):
 //   wave 0, lane r = row r of the block: the factorisation. The job is a chain of 64 dependent column steps -- pivot,
 //     reciprocal, multipliers, rank-1 update -- 125 of these kernels in a row on the critical path of the
-//     factorisation at BA-1. A column step needs column c of the matrix in EVERY lane (lane r updates a[cc] with
-//     entry cc of the column): entry cc is a[c] of lane cc, so it is broadcast straight out of the register file --
-//     two v_readlane_b32 into an SGPR pair, the FMA takes it as its scalar operand. (Round 4 handed the column from
-//     lane to lane through LDS: 32 broadcast ds_reads per step which the register budget let the compiler keep only
-//     two deep in flight -- ~2 000 cycles of exposed LDS latency per step, 40-54 us per block in the round-5 trace;
-//     the readlane form has no memory operation in the update at all.) Entries above the diagonal take part in the
-//     arithmetic as don't-cares (no divergence). The scaling by 1 / sqrt(pivot) happens once at the end (one sqrt +
-//     division per LANE instead of per column step): the loop works on A~ with L = A~ D^-1/2, D = diag(pivots).
-//   wave 1, lane j = column j of the inverse: forward substitution one step behind wave 0 (Y = A~^-1: y_r /= d_r,
-//     y_rr -= A~[rr][r] y_r for the rows below; L^-1 = D^1/2 Y). Column r of A~ reaches it through 512 bytes of LDS
-//     (ONE ds_read per lane and step: lane rr takes entry rr) and is broadcast by readlane like in wave 0. Rows
-//     above j come out as exact zeros. (One wave doing both needs 256 VGPRs for the two matrices alone.)
+//     factorisation at BA-1. A column step: the pivot by v_readlane, its reciprocal (rcp_f64), column c of the matrix
+//     handed from lane to lane through 512 bytes of LDS, and 63 - c register FMAs per lane against broadcast reads of
+//     that column, pipelined two chunks deep (rank1_update). Entries above the diagonal take part in the arithmetic as
+//     don't-cares (no divergence). The scaling by 1 / sqrt(pivot) happens once at the end (one sqrt + division per
+//     LANE instead of per column step): the loop works on A~ with L = A~ D^-1/2, D = diag(pivots).
+//   wave 1, lane j = column j of the inverse: forward substitution with the SAME column broadcasts, step by step
+//     behind wave 0 (Y = A~^-1: y_r /= d_r, y_rr -= A~[rr][r] y_r for the rows below; L^-1 = D^1/2 Y). Rows above j
+//     come out as exact zeros. (One wave doing both needs 256 VGPRs for the two matrices alone.)
 // Rows / columns beyond kb carry a unit diagonal and are not stored.
 // Register budget: 256 per lane (launch bound 2 waves per SIMD) -- this kernel runs beside the lookahead stream's
 // 128 x 128 trailing updates, whose waves hold 256 of a SIMD's 512 registers each: a wave that needs more than the
@@ -548,7 +611,7 @@ __device__ __forceinline__ double rcp_f64(double d) {
 __global__ void __launch_bounds__(128, 2) chol_diag_kernel(double* __restrict__ S, int n, int k0, int kb,
                                                         double* __restrict__ Linv, int* __restrict__ info) {
   __shared__ double Ls[NB][NB + 1];
-  __shared__ double col[2][NB];
+  __shared__ __attribute__((aligned(16))) double col[2][NB];
   __shared__ double dsq[NB];  // sqrt(pivot)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   {  // coalesced: lane = column; the 32 loads of a lane in flight together (rolled: 32 serial round trips, more than
@@ -564,23 +627,14 @@ __global__ void __launch_bounds__(128, 2) chol_diag_kernel(double* __restrict__ 
   }
   __syncthreads();
   double a[NB];
+  int tok = 0;
   // (The two waves run separate straight-line code with the same number of barriers -- 64 in the loop, one after it:
   //  merged into one loop with per-step branches the register allocation falls apart, 7 KB of scratch.)
   if (wave == 0) {
 #pragma unroll
     for (int c = 0; c < NB; ++c) a[c] = Ls[lane][c];  // row `lane` of A~
     double dmine = 0.0;                                // pivot of column `lane` (final after step lane - 1)
-#pragma unroll
-    for (int c = 0; c < NB; ++c) {
-      const double ac = a[c];                          // entry `lane` of column c
-      const double d = readlane_f64(ac, c);
-      dmine = lane == c ? ac : dmine;
-      col[c & 1][lane] = ac;
-      const double l = ac * rcp_f64(d);  // multiplier of row `lane` (rows <= c: a don't-care)
-      __syncthreads();  // column c (its entry c is the pivot) is published for wave 1; the other buffer is free again
-#pragma unroll
-      for (int cc = c + 1; cc < NB; ++cc) a[cc] = fma(-l, readlane_f64(ac, cc), a[cc]);  // (-ffp-contract=off: explicit fma)
-    }
+    chol_steps_factor<0>(a, dmine, col, lane, tok);
     const bool okp = dmine > 0.0;
     if (!okp) *info = 1;
     const double rs = okp ? 1.0 / sqrt(dmine) : NAN;
@@ -594,15 +648,7 @@ __global__ void __launch_bounds__(128, 2) chol_diag_kernel(double* __restrict__ 
   } else {
 #pragma unroll
     for (int r = 0; r < NB; ++r) a[r] = r == lane ? 1.0 : 0.0;  // column `lane` of Y
-#pragma unroll
-    for (int r = 0; r < NB; ++r) {
-      __syncthreads();
-      const double v = col[r & 1][lane];               // entry `lane` of column r of A~
-      const double yr = a[r] * rcp_f64(readlane_f64(v, r));
-      a[r] = yr;
-#pragma unroll
-      for (int rr = r + 1; rr < NB; ++rr) a[rr] = fma(-yr, readlane_f64(v, rr), a[rr]);
-    }
+    chol_steps_inverse<0>(a, col, tok);
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < NB; ++r) Linv[r * NB + lane] = (r < kb && lane < kb) ? a[r] * dsq[r] : 0.0;

@@ -3,8 +3,8 @@
 The reference keeps separate solver-tier thresholds for its CPU and GPU (Ceres-CUDA) solvers
 (estimators/bundle_adjustment_ceres.h:68-71: 50 / 1000 images on the CPU, 200 / 4000 on the GPU). The MI355X backend's
 AUTO rule (colmap_amd/estimators.py: resolve_linear_solver, include/colmap_amd/bundle_adjustment.hpp) is set from THIS
-table: for every size, the seconds each tier needs to bring the cost down to the level the slowest-converging tier
-reaches (within 1e-6 relative), with the LM time spread evenly over a solve's iterations.
+table: for every size, the seconds each tier needs to bring the cost to within 1e-4 (relative) of the best final cost any
+tier reaches in 30 LM iterations (None: not reached), with the LM time spread evenly over a solve's iterations.
 
     gpurun -- 'python scripts/ba_tier_crossover.py > gpurun_out/ba_tier_crossover.json'
 """
@@ -28,17 +28,19 @@ for frames in SIZES:
         est.solve_flat(fp.copy(), est.SolverOptions(max_num_iterations=1, linear_solver_type=tier), gpu_index=0)   # warm-up
         s = est.solve_flat(fp.copy(), so, gpu_index=0)
         runs[name] = s
-    target = max(s.final_cost for s in runs.values()) * (1 + 1e-6)
+    target = min(s.final_cost for s in runs.values()) * (1 + 1e-4)
     row = {"images": frames, "points": 200 * frames, "observations": int(len(fp.obs_pose)),
            "n_c": int(est.num_camera_parameters(fp)), "target_cost": target, "tiers": {}}
     for name, s in runs.items():
         log = np.asarray(s.log_cost)
-        hit = int(np.argmax(log <= target)) if (log <= target).any() else len(log) - 1   # log[k] = cost after k iterations
+        reached = bool((log <= target).any())
+        hit = int(np.argmax(log <= target)) if reached else None   # log[k] = cost after k iterations
         per_it = s.lm_seconds / max(s.num_iterations, 1)
         row["tiers"][name] = {"iterations_to_target": hit, "lm_iterations": int(s.num_iterations),
-                              "ms_per_lm_iteration": 1e3 * per_it, "ms_to_target": 1e3 * per_it * max(hit, 1),
+                              "ms_per_lm_iteration": 1e3 * per_it,
+                              "ms_to_target": 1e3 * per_it * max(hit, 1) if reached else None,
                               "final_cost": float(s.final_cost), "tier_used": int(s.linear_solver_used)}
-    row["fastest"] = min(row["tiers"], key=lambda k: row["tiers"][k]["ms_to_target"])
+    row["fastest"] = min(row["tiers"], key=lambda k: row["tiers"][k]["ms_to_target"] if row["tiers"][k]["ms_to_target"] is not None else 1e30)
     rows.append(row)
     print(json.dumps(row), file=sys.stderr, flush=True)
 print(json.dumps({"rows": rows}, indent=1))
