@@ -205,6 +205,46 @@ def ba_secondary(a, local_rank, with_cpu, rank=0, world=1, dev=None):
             "factor_ms_per_lm_iteration": 1e3 * se.factor_seconds / max(se.num_iterations, 1),
             "same_cost_log": bool(len(sp.log_cost) == len(se.log_cost) and
                                   np.allclose(sp.log_cost, se.log_cost, rtol=1e-9, atol=0.0))}
+    if world == 1:
+        # what the drop-in adapter does with DEFAULT options at this size: AUTO resolved on the image count with the
+        # backend's measured GPU thresholds (estimators.resolve_linear_solver)
+        tier = est.resolve_linear_solver(a.ba_frames)
+        names = {est.SOLVER_ITERATIVE_SCHUR: "ITERATIVE_SCHUR", est.SOLVER_DENSE_SCHUR: "DENSE_SCHUR", est.SOLVER_SPARSE_SCHUR: "SPARSE_SCHUR"}
+        out["default_route"] = {
+            "what": "Mi355xBundleAdjuster / estimators.BundleAdjuster with default options (linear_solver_type = AUTO)",
+            "tier": names[tier],
+            "LM_iterations_per_s": out["value"] if tier == est.SOLVER_ITERATIVE_SCHUR else out["exact_tier"]["LM_iterations_per_s"]}
+        # SURVEY.md 8(d)'s second BA-1 variant: ONE camera shared by all images (num_rigs = 1) -- the case the
+        # reference's FAQ warns about (doc/faq.rst:626-632: shared intrinsics densify the Schur complement): the single
+        # intrinsics block is reached from every observation, the Schur-Jacobi cross terms carry real load
+        d1 = dict(d)
+        d1["obs_cam"] = np.zeros_like(d["obs_cam"])
+        d1["cams"] = d["cams"][:1].copy()
+        d1["cam_model"] = d["cam_model"][:1].copy()
+        fp1 = est.FlatProblem.from_arrays(d1)
+        est.fix_gauge_two_cams(fp1)
+        est.solve_flat(fp1.copy(), est.SolverOptions(max_num_iterations=2), gpu_index=local_rank)  # warm-up
+        s1 = est.solve_flat(fp1.copy(), so, gpu_index=local_rank)
+        e1 = est.solve_flat(fp1.copy(), est.SolverOptions(max_num_iterations=min(a.ba_iters, 6),
+                                                          linear_solver_type=est.SOLVER_SPARSE_SCHUR), gpu_index=local_rank)
+        out["shared_intrinsics"] = {
+            "workload": f"the same {a.ba_frames} images x {a.ba_points} points with ONE SIMPLE_RADIAL camera shared by all images",
+            "iterative": {"LM_iterations_per_s": s1.num_iterations / max(s1.lm_seconds, 1e-12), "lm_iterations": s1.num_iterations,
+                          "pcg_iterations": int(s1.total_linear_iterations), "cost": [s1.initial_cost, s1.final_cost]},
+            "exact": {"LM_iterations_per_s": e1.num_iterations / max(e1.lm_seconds, 1e-12), "lm_iterations": e1.num_iterations,
+                      "cost": [e1.initial_cost, e1.final_cost], "reduced_system_size": int(est.num_camera_parameters(fp1))}}
+        if with_cpu:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import ba_oracle
+            c1 = fp1.copy()
+            o1 = est.solve_flat(c1, est.SolverOptions(max_num_iterations=9), solve_fn=ba_oracle.solve_fn)
+            h1 = est.solve_flat(fp1.copy(), est.SolverOptions(max_num_iterations=9), gpu_index=local_rank)
+            m1 = min(len(o1.log_cost), len(h1.log_cost))
+            out["shared_intrinsics"]["hip_vs_oracle_max_rel_cost_diff"] = \
+                float(np.max(np.abs(h1.log_cost[:m1] - o1.log_cost[:m1]) / o1.log_cost[:m1])) if m1 else None
+            out["shared_intrinsics"]["hip_vs_oracle_same_pcg_iterations"] = bool(
+                np.array_equal(h1.log_linear_iters[:m1], o1.log_linear_iters[:m1]))
+            out["shared_intrinsics"]["oracle_LM_iterations_per_s"] = o1.num_iterations / max(o1.lm_seconds, 1e-12)
     if sharded:
         out["sharded"] = sharded
     if with_cpu and world == 1:

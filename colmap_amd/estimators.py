@@ -188,6 +188,14 @@ class BundleAdjustmentOptions:
     # adapter level: the reference's solver choice by problem size (CreateSolverOptions,
     # bundle_adjustment_ceres.cc:203-213); solve_flat's own default stays ITERATIVE_SCHUR
     solver_options: SolverOptions = field(default_factory=lambda: SolverOptions(linear_solver_type=2))
+    # The AUTO rule's thresholds. The reference keeps one pair per device class (bundle_adjustment_ceres.h:68-71:
+    # 50 / 1000 images for its CPU solvers, 200 / 4000 for Ceres-CUDA); this backend's pair is MEASURED on the MI355X
+    # (scripts/ba_tier_crossover.py, profiles/r05_ba_tier_crossover.json): both exact tiers form the
+    # reduced camera system densely (cost ~ n_c^3), so they win per unit of cost reduction up to ~500 images
+    # (0.9 / 2.8 / 7.1 ms per LM iteration at 50 / 200 / 500 images against 1.0 / 1.4 / 1.5 for Schur-PCG, which
+    # needs 4 .. 25x the iterations for the same cost) and lose from ~700 on (10.4 vs 1.9 ms, 16.5 vs 2.7 at 1000).
+    max_num_images_direct_dense_gpu_solver: int = 200
+    max_num_images_direct_sparse_gpu_solver: int = 500
 
     def Check(self) -> bool:
         return self.min_track_length >= 0
@@ -798,6 +806,14 @@ def shard_num_observations(fp: FlatProblem, rank: int, world_size: int, sharding
     return int(fn(C.byref(p), C.c_int32(rank), C.c_int32(world_size)))
 
 
+def resolve_linear_solver(num_images: int, max_dense: int = 200, max_sparse: int = 500) -> int:
+    """The AUTO rule (CreateSolverOptions, bundle_adjustment_ceres.cc:203-213): DENSE_SCHUR up to `max_dense` images,
+    SPARSE_SCHUR up to `max_sparse`, ITERATIVE_SCHUR beyond."""
+    if num_images <= max_dense:
+        return SOLVER_DENSE_SCHUR
+    return SOLVER_SPARSE_SCHUR if num_images <= max_sparse else SOLVER_ITERATIVE_SCHUR
+
+
 class BundleAdjuster:
     """colmap::BundleAdjuster (bundle_adjustment.h:212-228) for backend MI355X."""
 
@@ -823,11 +839,13 @@ class BundleAdjuster:
         gpu = [int(x) for x in str(self.options_.gpu_index).split(",") if x.strip()]
         so = self.options_.solver_options
         if so.linear_solver_type == SOLVER_AUTO:
-            # CreateSolverOptions' rule on config.NumImages() (bundle_adjustment_ceres.cc:131,203-213; CPU
-            # thresholds bundle_adjustment_ceres.h:68-69) -- resolved here, where the image count is known: the
-            # flat C interface only sees pose blocks (a rig frame with several sensors is one block)
+            # CreateSolverOptions' rule on config.NumImages() (bundle_adjustment_ceres.cc:131,203-213) with this
+            # backend's measured GPU thresholds (the reference's own GPU pair: bundle_adjustment_ceres.h:70-71) --
+            # resolved here, where the image count is known: the flat C interface only sees pose blocks (a rig frame
+            # with several sensors is one block)
             n_img = self.config_.NumImages()
-            tier = SOLVER_DENSE_SCHUR if n_img <= 50 else (SOLVER_SPARSE_SCHUR if n_img <= 1000 else SOLVER_ITERATIVE_SCHUR)
+            tier = resolve_linear_solver(n_img, self.options_.max_num_images_direct_dense_gpu_solver,
+                                         self.options_.max_num_images_direct_sparse_gpu_solver)
             so = dataclasses.replace(so, linear_solver_type=tier)
         summary = solve_flat(fp, so, gpu[0] if gpu else -1, solve_fn=self._solve_fn)
         self.linear_solver_requested_, self.linear_solver_used_ = so.linear_solver_type, summary.linear_solver_used

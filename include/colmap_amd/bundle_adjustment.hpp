@@ -395,6 +395,12 @@ struct Mi355xBundleAdjustmentOptions {
   LossFunctionType loss_function_type = LossFunctionType::TRIVIAL;
   double loss_function_scale = 1.0;
   ba_options solver_options;
+  // The AUTO rule's thresholds. The reference keeps one pair per device class (bundle_adjustment_ceres.h:68-71:
+  // 50 / 1000 images for its CPU solvers, 200 / 4000 for Ceres-CUDA); this backend's pair is measured on the MI355X
+  // (scripts/ba_tier_crossover.py, profiles/r05_ba_tier_crossover.json): the exact tiers form the
+  // reduced camera system densely and win per unit of cost reduction up to ~500 images, Schur-PCG from ~700 on.
+  int max_num_images_direct_dense_gpu_solver = 200;
+  int max_num_images_direct_sparse_gpu_solver = 500;
   Mi355xBundleAdjustmentOptions() {
     ba_options_init(&solver_options);
     // the reference's solver choice by problem size (CreateSolverOptions, bundle_adjustment_ceres.cc:203-213)
@@ -457,11 +463,14 @@ class Mi355xBundleAdjuster : public BundleAdjuster {
     so.loss_type = static_cast<int32_t>(options_.mi355x->loss_function_type);
     so.loss_scale = options_.mi355x->loss_function_scale;
     if (so.linear_solver_type == BA_SOLVER_AUTO) {
-      // CreateSolverOptions' rule on config.NumImages() (bundle_adjustment_ceres.cc:131,203-213; CPU thresholds
-      // bundle_adjustment_ceres.h:68-69), resolved here where the image count is known: the flat C interface
-      // only sees pose blocks (a rig frame with several sensors is one block)
+      // CreateSolverOptions' rule on config.NumImages() (bundle_adjustment_ceres.cc:131,203-213) with this backend's
+      // measured GPU thresholds (the reference's own GPU pair: bundle_adjustment_ceres.h:70-71), resolved here where
+      // the image count is known: the flat C interface only sees pose blocks (a rig frame with several sensors is
+      // one block)
       const size_t n_img = config_.NumImages();
-      so.linear_solver_type = n_img <= 50 ? BA_SOLVER_DENSE_SCHUR : (n_img <= 1000 ? BA_SOLVER_SPARSE_SCHUR : BA_SOLVER_ITERATIVE_SCHUR);
+      const size_t nd = (size_t)std::max(options_.mi355x->max_num_images_direct_dense_gpu_solver, 0);
+      const size_t ns = (size_t)std::max(options_.mi355x->max_num_images_direct_sparse_gpu_solver, 0);
+      so.linear_solver_type = n_img <= nd ? BA_SOLVER_DENSE_SCHUR : (n_img <= ns ? BA_SOLVER_SPARSE_SCHUR : BA_SOLVER_ITERATIVE_SCHUR);
     }
     linear_solver_requested_ = so.linear_solver_type;
     ba_result res{};
