@@ -51,6 +51,7 @@
 #include <chrono>
 #include <cfloat>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <stdexcept>
 #include <string>
@@ -838,6 +839,15 @@ int EnvInt(const char* name, int dflt) {
 void Run(const fusion_options& opt, int n, const fusion_image* images, const int32_t* optr, const int32_t* oidx,
          fusion_result* out) {
   const auto t_begin = std::chrono::steady_clock::now();
+  // development switch COLMAP_AMD_FUSION_TIMING=1: where the set-up time goes (stderr)
+  const bool timing = dev_switch_int("COLMAP_AMD_FUSION_TIMING", 0) != 0;
+  auto mark = [&, last = t_begin](const char* what) mutable {
+    if (!timing) return;
+    (void)hipDeviceSynchronize();
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "fusion set-up: %-28s %8.1f ms\n", what, 1e3 * std::chrono::duration<double>(now - last).count());
+    last = now;
+  };
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
     throw Fail("no HIP device: the fusion kernels need a GPU (there is no CPU path)");
@@ -918,6 +928,7 @@ void Run(const fusion_options& opt, int n, const fusion_image* images, const int
     return opt.num_threads <= 0 ? ns : std::min(opt.num_threads, ns);
   };
   max_threads = threads_of(max_height);
+  mark("descriptors + colour upload");
   // all depth maps / normal maps (as xyz triples) / words in one array each, indexed by the global pixel offset
   DevBuf<float> d_depth, d_normal, d_stage;
   DevBuf<unsigned long long> d_word;
@@ -926,6 +937,7 @@ void Run(const fusion_options& opt, int n, const fusion_image* images, const int
   d_stage.alloc(3 * (size_t)max_seeds);
   d_word.alloc((size_t)total_pix);
   FU_HIP(hipMemset(d_word.p, 0, sizeof(unsigned long long) * (size_t)total_pix));
+  mark("map allocations + memset");
   for (int i = 0; i < n; ++i) {
     if (!used[i]) continue;
     const size_t npix = (size_t)images[i].depth_width * images[i].depth_height;
@@ -943,6 +955,7 @@ void Run(const fusion_options& opt, int n, const fusion_image* images, const int
     FU_HIP(hipDeviceSynchronize());  // the staging buffer is reused by the next image
   }
   d_stage.release();
+  mark("depth / normal upload");
   // The visibility pool is refilled per reference image (cursor reset every step) and its int offsets only have to cover
   // what ONE image's walks absorb: capacity min(total pixels, 2^31 - 1), an overflow fails the run instead of wrapping.
   const long long pool_cap = std::min<long long>(total_pix, 0x7FFFFFFFll);
@@ -993,6 +1006,7 @@ void Run(const fusion_options& opt, int n, const fusion_image* images, const int
     p.lds_tables = desc > (size_t)kTableBytes ? 0 : (desc + (size_t)optr[n] * sizeof(int) > (size_t)kTableBytes ? 1 : 2);
     p.lds_tables = std::min(p.lds_tables, std::max(0, dev_switch_int("COLMAP_AMD_FUSION_LDS_TABLES", 2)));
   }
+  mark("per-wave state allocations");
   // a stack can never hold more than (pixels a walk records) x (longest overlap list) entries
   const long long spill_bound = (long long)p.rec_cap * max_overlap + kWave;
 
@@ -1026,6 +1040,7 @@ void Run(const fusion_options& opt, int n, const fusion_image* images, const int
   };
   std::vector<Chunk> chunks;
   unsigned epoch = 1;  // 0 would make the free word look like a mark
+  mark("scratch allocations");
   g_stats = Stats();
   FU_HIP(hipDeviceSynchronize());
   const auto t_setup = std::chrono::steady_clock::now();

@@ -679,7 +679,9 @@ class PatchMatchController:
         t = time.time()
         out = self._run_pass(opt, maps)
         self.timings["geometric_s" if opt.geom_consistency else "photometric_s"] = time.time() - t
-        # The pooled device buffers stay: in the reference's two-pass flow the geometric pass follows at once and reuses
-        # them, and every allocator of the library retries after releasing the pool when a hipMalloc fails (pm_api.cpp,
-        # fusion.hip, ba_kernels.hip). A caller that is done with PatchMatch calls release_cached_memory() itself.
+        # The pooled device buffers (and the packed-image slabs) served both passes; the controller is done with
+        # PatchMatch now, so they go back to the driver -- torch allocations of the same process (this controller's own
+        # device bitmaps, whatever runs next) and other processes on the GPU would otherwise meet a plain OOM, since only
+        # the library's own allocators retry after releasing the pool. Slabs with a live slot stay.
+        release_cached_memory()
         return out
