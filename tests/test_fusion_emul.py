@@ -117,7 +117,6 @@ def test_emulated_kernel_blocks_in_reverse_order():
             "import test_fusion_emul as T, fusion_oracle\n"
             "from colmap_amd import fusion\n"
             "E = T._EmulEntryPoints('libfusion_emul.so')\n"
-            "E.lib.colmap_amd_set_switch(b'COLMAP_AMD_FUSION_LDS_TABLES', b'%s')\n"
             "im, ov = T._noisy(4, 24, 160, 0.01), T._overlap(4)\n"
             "opt = fusion.StereoFusionOptions(**T._LOOSE)\n"
             "assert T._same(fusion.fuse(opt, im, ov, entry_points=E), fusion_oracle.fuse(opt, im, ov, mode=1))\n"
