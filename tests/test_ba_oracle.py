@@ -1008,3 +1008,30 @@ def test_robust_alignment_to_pose_priors_rejects_an_outlier():
     a, b = est.align_to_positions(src, dst2), est.align_to_positions_robust(src, dst2, max_error=0.1)
     assert np.allclose(a[0], b[0]) and np.allclose(a[1], b[1]) and np.allclose(a[2], b[2])
     assert est.align_to_positions_robust(src[:2], dst[:2], max_error=0.1) is None
+
+
+def test_adapter_auto_rule_uses_the_measured_gpu_thresholds():
+    """CreateSolverOptions' rule (bundle_adjustment_ceres.cc:203-213) in the adapters, with this backend's GPU pair
+    (the reference keeps one pair per device class, bundle_adjustment_ceres.h:68-71): DENSE_SCHUR up to 200 images,
+    SPARSE_SCHUR up to 500, ITERATIVE_SCHUR beyond -- options of BundleAdjustmentOptions like the reference's, resolved
+    by the adapter on config.NumImages() before the flat C interface is called (the oracle stands in for it here)."""
+    assert est.resolve_linear_solver(1) == est.resolve_linear_solver(200) == est.SOLVER_DENSE_SCHUR
+    assert est.resolve_linear_solver(201) == est.resolve_linear_solver(500) == est.SOLVER_SPARSE_SCHUR
+    assert est.resolve_linear_solver(501) == est.resolve_linear_solver(100000) == est.SOLVER_ITERATIVE_SCHUR
+    o = est.BundleAdjustmentOptions()
+    assert (o.max_num_images_direct_dense_gpu_solver, o.max_num_images_direct_sparse_gpu_solver) == (200, 500)
+    rec = scene.SynthesizeDataset(scene.SyntheticDatasetOptions(num_rigs=2, num_frames_per_rig=4, num_points3D=60), seed=5)
+    scene.SynthesizeNoise(scene.SyntheticNoiseOptions(0.02, 0.5, 0.03, 0.5), rec, seed=6)
+    used = []
+    for dense, sparse, want in ((200, 500, est.SOLVER_DENSE_SCHUR), (4, 500, est.SOLVER_SPARSE_SCHUR), (4, 6, est.SOLVER_ITERATIVE_SCHUR)):
+        cfg = est.BundleAdjustmentConfig()
+        for i in rec.RegImageIds():
+            cfg.AddImage(i)
+        cfg.FixGauge(est.BundleAdjustmentGauge.TWO_CAMS_FROM_WORLD)
+        opt = est.BundleAdjustmentOptions(max_num_images_direct_dense_gpu_solver=dense, max_num_images_direct_sparse_gpu_solver=sparse)
+        import copy
+        ba = est.BundleAdjuster(opt, cfg, copy.deepcopy(rec), solve_fn=ba_oracle.solve_fn)
+        s = ba.Solve()
+        assert s.IsSolutionUsable() and ba.linear_solver_requested_ == want
+        used.append(ba.linear_solver_used_)
+    assert used == [est.SOLVER_DENSE_SCHUR, est.SOLVER_SPARSE_SCHUR, est.SOLVER_ITERATIVE_SCHUR]
