@@ -147,6 +147,17 @@ struct View {
   const int *blk_off, *blk_dim, *blk_kind, *blk_moff;
   const int *chunk_blk, *chunk_beg, *chunk_end;  // chunks are c-order ranges
   const int* blk_chunk_ptr;  // chunks of block b: [blk_chunk_ptr[b], blk_chunk_ptr[b+1])
+  const int* blk_fin_end;    // the finalize kernels add the rows [blk_chunk_ptr[b], blk_fin_end[b]): all of the block's
+                             // chunks, or only the first one for a HEAVY block (more than kHeavyChunks chunks: a camera
+                             // shared by many images), whose rows ba_cpart_heavy_reduce_kernel has summed into it
+  const int* heavy_blk;      // [n_heavy] the heavy blocks
+  int n_heavy;
+  // Observation pairs of one point inside one block (shared intrinsics, rig frames), per block kind k with such pairs:
+  // a_boff[k][a] = tangent offset of p-order observation a's block of kind k (-1: none / constant), Wp[k][a] =
+  // J_k,a^T E_a (wdim[k] x 3), rebuilt with every linearisation by ba_obs_w_kernel. Null for a kind without pairs.
+  const int* a_boff[3];
+  double* Wp[3];
+  int wdim[3];
   double* cpart;             // [n_chunks][bd*bd] per-chunk partial results (no atomics)
   int kd, bd;                // intrinsics tangent width (Jcam / cam_var row stride), widest block
   // linearisation
@@ -1569,6 +1580,34 @@ __global__ void __launch_bounds__(64) ba_block_jtv_kernel(View V, const double* 
     }
 }
 
+// A block with thousands of chunks -- ONE camera shared by every image of a 1 000-image problem has 4 000 -- makes every
+// finalize kernel below a single thread walking thousands of dependent loads (1.3 ms each at BA-1 with shared intrinsics:
+// 60 % of that solve, profiles/r05_ba_shared_intrinsics_kernel_stats_before.csv). For such HEAVY blocks this kernel first
+// sums the first `width` entries of all the block's rows into its first row: one workgroup per (heavy block, 64 or 16
+// entries), the threads of an entry stride over the rows, their partial sums are added in thread order -- a fixed tree,
+// the same bits on every run. The finalize kernels then read that one row (View::blk_fin_end).
+constexpr int kHeavyChunks = 64;  // (development switch COLMAP_AMD_BA_HEAVY_CHUNKS: the tests lower it to reach the path)
+__global__ void __launch_bounds__(1024) ba_cpart_heavy_reduce_kernel(View V, int width) {
+  __shared__ double part[1024];
+  const int b = V.heavy_blk[blockIdx.x];
+  const int epw = width <= 16 ? 16 : 64;            // entries per workgroup
+  const int groups = 1024 / epw;
+  const int el = threadIdx.x % epw, g = threadIdx.x / epw;
+  const int e = el + epw * blockIdx.y;
+  const int bb = V.bd * V.bd;
+  const int ch0 = V.blk_chunk_ptr[b], ch1 = V.blk_chunk_ptr[b + 1];
+  double s = 0.0;
+  if (e < width)
+    for (int ch = ch0 + g; ch < ch1; ch += groups) s += V.cpart[(size_t)ch * bb + e];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  if (g == 0 && e < width) {
+    double t = 0.0;
+    for (int k = 0; k < groups; ++k) t += part[k * epw + el];
+    V.cpart[(size_t)ch0 * bb + e] = t;
+  }
+}
+
 // y_b = sum over the block's chunks, in chunk order (deterministic); lane per block
 template <bool DIAG>
 __global__ void ba_block_vec_finalize_kernel(View V, double* __restrict__ y, double* __restrict__ diag) {
@@ -1579,7 +1618,7 @@ __global__ void ba_block_vec_finalize_kernel(View V, double* __restrict__ y, dou
   const int dim = V.blk_dim[b], off = V.blk_off[b];
   if (c >= dim) return;
   double s = 0.0, d = 0.0;
-  for (int ch = V.blk_chunk_ptr[b]; ch < V.blk_chunk_ptr[b + 1]; ++ch) {
+  for (int ch = V.blk_chunk_ptr[b]; ch < V.blk_fin_end[b]; ++ch) {
     s += V.cpart[(size_t)ch * V.bd * V.bd + c];
     if (DIAG) d += V.cpart[(size_t)ch * V.bd * V.bd + V.bd + c];
   }
@@ -1597,7 +1636,7 @@ __global__ void ba_block_vec_finalize_q_kernel(View V, const double* __restrict_
   const int dim = V.blk_dim[b], off = V.blk_off[b];
   if (c >= dim) return;
   double s = 0.0;
-  for (int ch = V.blk_chunk_ptr[b]; ch < V.blk_chunk_ptr[b + 1]; ++ch) s += V.cpart[(size_t)ch * V.bd * V.bd + c];
+  for (int ch = V.blk_chunk_ptr[b]; ch < V.blk_fin_end[b]; ++ch) s += V.cpart[(size_t)ch * V.bd * V.bd + c];
   q[off + c] = Dc[off + c] * Dc[off + c] * x[off + c] + s;
 }
 
@@ -1614,7 +1653,7 @@ __global__ void ba_block_mat_finalize_kernel(View V, double* __restrict__ M) {
   if (e >= dim * dim) return;
   double* Mb = M + V.blk_moff[b];
   double s = 0.0;
-  for (int ch = V.blk_chunk_ptr[b]; ch < V.blk_chunk_ptr[b + 1]; ++ch) s += V.cpart[(size_t)ch * bb + e];
+  for (int ch = V.blk_chunk_ptr[b]; ch < V.blk_fin_end[b]; ++ch) s += V.cpart[(size_t)ch * bb + e];
   Mb[e] = ACCUMULATE ? Mb[e] + s : s;
 }
 
@@ -1798,15 +1837,53 @@ __global__ void __launch_bounds__(64 * GRAM_WAVES, BD <= 8 ? 4 : 2) ba_block_gra
 
 // Cross terms - sum_{o != o2 in (b,j)} (J_b,o^T E_o) C_j^-1 (J_b,o2^T E_o2)^T of observation pairs of one
 // point inside one block (only launched when such pairs exist). One lane per observation.
+// W_o = J_b,o^T E_o (dim x 3) of every observation that has a partner of its point in one of its blocks, stored in
+// p-order: the partners of an observation are then NEIGHBOURS in memory (ba_block_schur_cross_kernel walks them), and
+// a W is computed once per linearisation instead of once per partner visit.
+template <int BD>
+__global__ void ba_obs_w_kernel(View V) {
+  const int o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= V.n_obs) return;
+  const unsigned so = V.solo[o];
+  const size_t N = (size_t)V.n_obs;
+  const int a = V.c2a[o];
+  double e[2][3];
+  bool have_e = false;
+#pragma unroll
+  for (int kind = 0; kind < 3; ++kind) {
+    if (V.Wp[kind] == nullptr || ((so >> kind) & 1) || V.a_boff[kind][a] < 0) continue;
+    if (!have_e) {
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) e[r][c] = V.Jpt[(size_t)(r * 3 + c) * N + a];
+      have_e = true;
+    }
+    const int wd = V.wdim[kind];
+    double* w = V.Wp[kind] + (size_t)a * wd * 3;
+#pragma unroll
+    for (int x = 0; x < BD; ++x) {
+      if (x >= wd) continue;
+      const double j0 = blk_col(V, kind, 0, x)[o], j1 = blk_col(V, kind, 1, x)[o];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) w[x * 3 + c] = j0 * e[0][c] + j1 * e[1][c];
+    }
+  }
+}
+
 template <int BD>
 __global__ void __launch_bounds__(64) ba_block_schur_cross_kernel(View V, const double* __restrict__ Cinv) {
   const int ch = blockIdx.x;
   const int b = V.chunk_blk[ch];
   const int kind = V.blk_kind[b], dim = V.blk_dim[b], boff = V.blk_off[b];
   const size_t N = (size_t)V.n_obs;
+  const int* ab = V.a_boff[kind];
+  const double* Wk = V.Wp[kind];
+  const int wd = V.wdim[kind];
   double acc[BD * BD];
 #pragma unroll
   for (int e = 0; e < BD * BD; ++e) acc[e] = 0.0;
+  if (ab != nullptr)  // (a kind without pairs: every observation is solo, the partials below are zeros)
   for (int o = V.chunk_beg[ch] + threadIdx.x; o < V.chunk_end[ch]; o += 64) {
     if ((V.solo[o] >> kind) & 1) continue;  // no partner in this block
     const int xi = V.o_pt[o];
@@ -1828,20 +1905,12 @@ __global__ void __launch_bounds__(64) ba_block_schur_cross_kernel(View V, const 
       for (int c = 0; c < 3; ++c) T[x][c] = W1[x][0] * Ci[c] + W1[x][1] * Ci[3 + c] + W1[x][2] * Ci[6 + c];
     for (int a2 = V.pt_ptr[xi]; a2 < V.pt_ptr[xi + 1]; ++a2) {
       if (a2 == a) continue;  // the self term is part of (I - G) in the Gram kernel
-      const int o2 = V.a2c[a2];
-      int off2;
-      if (kind == 0) off2 = V.pose_off[V.o_pose[o2]];
-      else if (kind == 1) off2 = V.cam_off[V.o_cam[o2]];
-      else off2 = V.o_sensor[o2] >= 0 ? V.sens_off[V.o_sensor[o2]] : -1;
-      if (off2 != boff) continue;
+      if (ab[a2] != boff) continue;
+      const double* w2 = Wk + (size_t)a2 * wd * 3;  // the partner's W (ba_obs_w_kernel: the same expression, the same bits)
 #pragma unroll
       for (int y = 0; y < BD; ++y) {
         if (y >= dim) continue;
-        double W2[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
-          W2[c] = blk_col(V, kind, 0, y)[o2] * V.Jpt[(size_t)c * N + a2] +
-                  blk_col(V, kind, 1, y)[o2] * V.Jpt[(size_t)(3 + c) * N + a2];
+        const double W2[3] = {w2[y * 3], w2[y * 3 + 1], w2[y * 3 + 2]};
 #pragma unroll
         for (int x = 0; x < BD; ++x)
           if (x < dim) acc[x * BD + y] -= T[x][0] * W2[0] + T[x][1] * W2[1] + T[x][2] * W2[2];
@@ -2114,7 +2183,7 @@ __global__ void __launch_bounds__(1024) ba_pcg_fused_kernel(View V, const double
       const int dim = V.blk_dim[b], off = V.blk_off[b];
       for (int c = 0; c < dim; ++c) {
         double sacc = 0.0;
-        for (int ch = V.blk_chunk_ptr[b]; ch < V.blk_chunk_ptr[b + 1]; ++ch) sacc += V.cpart[(size_t)ch * bd2 + c];
+        for (int ch = V.blk_chunk_ptr[b]; ch < V.blk_fin_end[b]; ++ch) sacc += V.cpart[(size_t)ch * bd2 + c];
         const double d = Dc[off + c], pv = p[off + c];
         const double qv = d * d * pv + sacc;
         q[off + c] = qv;
@@ -2293,7 +2362,7 @@ __global__ void __launch_bounds__(256) ba_pcgp_tail_kernel(View V, PcgDev D, int
   const int b = blockIdx.x * 256 + threadIdx.x;
   if (b < V.n_blk) {
     const int dim = V.blk_dim[b], off = V.blk_off[b];
-    const int ch0 = V.blk_chunk_ptr[b], ch1 = V.blk_chunk_ptr[b + 1];
+    const int ch0 = V.blk_chunk_ptr[b], ch1 = V.blk_fin_end[b];
     double sacc[BD], d[BD], pv[BD];
 #pragma unroll
     for (int c = 0; c < BD; ++c) {
@@ -2874,7 +2943,8 @@ struct Solver {
   Buf<double> sensors, sensors2, Jsens;
   std::vector<int> h_sens_off;
   Buf<int> o_pose, o_cam, o_pt, pose_off, pose_dim, pose_fix, cam_off, cam_dim, cam_var, cam_model, pt_off,
-      pt_ptr, blk_off, blk_dim, blk_kind, blk_moff, chunk_blk, chunk_beg, chunk_end, blk_chunk_ptr, c2a, a2c, tile_pt;
+      pt_ptr, blk_off, blk_dim, blk_kind, blk_moff, chunk_blk, chunk_beg, chunk_end, blk_chunk_ptr, blk_fin_end, heavy_blk, c2a, a2c, tile_pt;
+  int n_heavy = 0;
   Buf<int> a_pose, a_cam, a_pt, a_sensor;  // p-order topology for the point-side linearisation pass
   Buf<double> a_xy;
   bool split_linearize = true;
@@ -2909,6 +2979,9 @@ struct Solver {
   bool use_priors() const { return Q.n > 0 && comm.rank == 0; }  // sums are all-reduced: one rank contributes them
   int moff_total = 0;
   long long n_paired = 0;  // (observation, block kind) slots that have a partner of the same point in the block
+  long long n_paired_kind[3] = {0, 0, 0};
+  Buf<int> a_boff[3];
+  Buf<double> Wp[3];
   int kd = 4, bd = PD;  // intrinsics tangent width / widest camera-side block of this problem
   std::vector<int> h_pose_off, h_cam_off, h_pt_off;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
@@ -2933,6 +3006,14 @@ struct Solver {
     if (st_chol) (void)hipStreamDestroy(st_chol);
     ba_explicit::free_pair_lists(pair_lists);
     if (st) (void)hipStreamDestroy(st);
+  }
+
+  // Before a finalize kernel: the heavy blocks' rows summed into their first row (ba_cpart_heavy_reduce_kernel).
+  // `width` = the entries of a row the finalize kernel is going to read.
+  void heavy_reduce(int width) {
+    if (n_heavy <= 0) return;
+    const int epw = width <= 16 ? 16 : 64;
+    BA_LAUNCH(ba_cpart_heavy_reduce_kernel, dim3(n_heavy, (width + epw - 1) / epw), dim3(1024), st, V, width);
   }
 
   double scalar(int slot) {
@@ -3063,6 +3144,9 @@ struct Solver {
         h_solo[h_a2c[a]] = (unsigned char)((same_pose == 1 ? 1 : 0) | (same_cam == 1 ? 2 : 0) | (same_sens <= 1 ? 4 : 0));
         n_paired += (same_pose != 1 && !p.pose_const[p.obs_pose[oa]]) + (same_cam != 1 && cam_nvar[p.obs_cam[oa]] > 0) +
                     (same_sens > 1 && sens_used[sa]);
+        n_paired_kind[0] += same_pose != 1 && !p.pose_const[p.obs_pose[oa]];
+        n_paired_kind[1] += same_cam != 1 && cam_nvar[p.obs_cam[oa]] > 0;
+        n_paired_kind[2] += same_sens > 1 && sens_used[sa];
       }
     std::vector<int> h_o_pose(n), h_o_cam(n), h_o_pt(n), h_o_sensor;
     const bool has_sensors = p.obs_sensor != nullptr && p.num_sensors > 0 && p.sensors != nullptr;
@@ -3178,6 +3262,13 @@ struct Solver {
         }
     }
     h_blk_chunk_ptr[n_blk] = (int)h_chunk_blk.size();
+    std::vector<int> h_blk_fin_end(std::max(n_blk, 1), 0), h_heavy;
+    const int heavy_chunks = std::max(dev_switch_int("COLMAP_AMD_BA_HEAVY_CHUNKS", kHeavyChunks), 1);
+    for (int b = 0; b < n_blk; ++b) {
+      const bool heavy = h_blk_chunk_ptr[b + 1] - h_blk_chunk_ptr[b] > heavy_chunks;
+      h_blk_fin_end[b] = heavy ? h_blk_chunk_ptr[b] + 1 : h_blk_chunk_ptr[b + 1];
+      if (heavy) h_heavy.push_back(b);
+    }
 
     // position priors whose pose or sensor_from_rig block is variable
     {
@@ -3317,6 +3408,22 @@ struct Solver {
         IV.n = ni; IV.pt = inc_pt.p; IV.blk = inc_blk.p; IV.ptr = inc_ptr.p; IV.obs = inc_obs.p;
       }
     }
+    // pairs of observations of one point inside one block: p-order block offsets per kind and room for the W's
+    // (ba_obs_w_kernel / ba_block_schur_cross_kernel), only for the kinds that have such pairs
+    for (int kind = 0; kind < 3; ++kind) {
+      V.a_boff[kind] = nullptr; V.Wp[kind] = nullptr;
+      V.wdim[kind] = kind == 1 ? kd : 6;
+      if (n_paired_kind[kind] <= 0) continue;
+      std::vector<int> h_ab(n, -1);
+      for (int a = 0; a < n; ++a) {
+        if (kind == 0) h_ab[a] = h_pose_off[h_a_pose[a]];
+        else if (kind == 1) h_ab[a] = h_cam_off[h_a_cam[a]];
+        else h_ab[a] = (has_sensors && h_a_sensor[a] >= 0) ? h_sens_off[h_a_sensor[a]] : -1;
+      }
+      a_boff[kind].upload(h_ab);
+      Wp[kind].alloc((size_t)n * V.wdim[kind] * 3);
+      V.a_boff[kind] = a_boff[kind].p; V.Wp[kind] = Wp[kind].p;
+    }
     chunk_blk.upload(h_chunk_blk); chunk_beg.upload(h_chunk_beg); chunk_end.upload(h_chunk_end);
     c2a.upload(h_c2a); a2c.upload(h_a2c); solo.upload(h_solo); tile_pt.upload(h_tile_pt);
     a_pose.upload(h_a_pose); a_cam.upload(h_a_cam); a_pt.upload(h_a_pt); a_xy.upload(h_a_xy);
@@ -3325,6 +3432,10 @@ struct Solver {
     V.a_sensor = has_sensors ? a_sensor.p : nullptr;
     V.n_tiles = (int)h_tile_pt.size() - 1;
     blk_chunk_ptr.upload(h_blk_chunk_ptr);
+    blk_fin_end.upload(h_blk_fin_end);
+    n_heavy = (int)h_heavy.size();
+    if (h_heavy.empty()) h_heavy.push_back(0);
+    heavy_blk.upload(h_heavy);
     cpart.alloc((size_t)h_chunk_blk.size() * bd * bd);
     poses.upload(std::vector<double>(p.poses, p.poses + 7 * (size_t)p.num_poses));
     cams.upload(std::vector<double>(p.cams, p.cams + BA_CAM_STRIDE * (size_t)p.num_cams));
@@ -3382,6 +3493,7 @@ struct Solver {
     V.chunk_blk = chunk_blk.p; V.chunk_beg = chunk_beg.p; V.chunk_end = chunk_end.p;
     V.c2a = c2a.p; V.a2c = a2c.p; V.solo = solo.p; V.tile_pt = tile_pt.p;
     V.blk_chunk_ptr = blk_chunk_ptr.p; V.cpart = cpart.p;
+    V.blk_fin_end = blk_fin_end.p; V.heavy_blk = heavy_blk.p; V.n_heavy = n_heavy;
     V.Jpose = Jpose.p; V.Jcam = Jcam.p; V.Jpt = Jpt.p; V.res = res.p; V.res_p = res_p.p;
     V.scale_c = scale_c.p; V.scale_p = scale_p.p; V.scalars = scalars.p;
     maxbuf.alloc(std::max(comm.world, 1));
@@ -3429,6 +3541,7 @@ struct Solver {
       if (bd == PD) BA_LAUNCH((ba_block_jtv_kernel<true, PD>), dim3(V.n_chunks), dim3(64), st, V, res.p, gc.p, diag_c.p);
       else if (bd == KD_WIDE) BA_LAUNCH((ba_block_jtv_kernel<true, KD_WIDE>), dim3(V.n_chunks), dim3(64), st, V, res.p, gc.p, diag_c.p);
       else BA_LAUNCH((ba_block_jtv_kernel<true, KD_MAX>), dim3(V.n_chunks), dim3(64), st, V, res.p, gc.p, diag_c.p);
+      heavy_reduce(2 * bd);
       BA_LAUNCH(ba_block_vec_finalize_kernel<true>, dim3(grid_for(V.n_blk * bd, 128)), dim3(128), st, V, gc.p, diag_c.p);
     }
     // (g_p and the point column norms are written for every variable point by either kernel)
@@ -3453,6 +3566,7 @@ struct Solver {
       if (bd == PD) BA_LAUNCH((ba_block_jtv_kernel<false, PD>), dim3(V.n_chunks), dim3(64), st, V, vin, tmpc.p, nullptr);
       else if (bd == KD_WIDE) BA_LAUNCH((ba_block_jtv_kernel<false, KD_WIDE>), dim3(V.n_chunks), dim3(64), st, V, vin, tmpc.p, nullptr);
       else BA_LAUNCH((ba_block_jtv_kernel<false, KD_MAX>), dim3(V.n_chunks), dim3(64), st, V, vin, tmpc.p, nullptr);
+      heavy_reduce(bd);
       BA_LAUNCH(ba_block_vec_finalize_kernel<false>, dim3(grid_for(V.n_blk * bd, 128)), dim3(128), st, V, tmpc.p, nullptr);
     }
     if (x_for_priors && use_priors()) {  // + sum over priors J^T (J x)
@@ -3478,6 +3592,7 @@ struct Solver {
     if (comm.world == 1 && !use_priors() && V.n_chunks > 0 && V.n_obs > 0) {
       // single GPU, no priors: nothing sits between J_c^T v and the block sums -> one tail kernel
       schur_streams(xin, inexact && op32);
+      heavy_reduce(bd);
       BA_LAUNCH(ba_block_vec_finalize_q_kernel, dim3(grid_for(V.n_blk * bd, 128)), dim3(128), st, V, Dc.p, xin, qout);
       return;
     }
@@ -3578,6 +3693,7 @@ struct Solver {
       BA_HIP(hipEventRecord(ev0, st));
       schur_streams(pdir.p, op32);
       BA_HIP(hipEventRecord(ev1, st));
+      heavy_reduce(bd);
       BA_LAUNCH(ba_pcg_fused_kernel<false>, dim3(1), dim3(1024), st, V, Dc.p, Minv.p, rhs.p, scalars.p, x.p, r.p, z.p, pdir.p, q.p);
       double h[NSCALAR];
       BA_HIP(hipMemcpyAsync(h, scalars.p, sizeof(h), hipMemcpyDeviceToHost, st));
@@ -3619,6 +3735,7 @@ struct Solver {
       BA_HIP(hipEventRecord(pcgp_ev_s0[k & 1], st));
       schur_streams(pdir.p, op32);
       BA_HIP(hipEventRecord(pcgp_ev_s1[k & 1], st));
+      heavy_reduce(bd);
       if (bd == PD) {
         BA_LAUNCH(ba_pcgp_tail_kernel<PD>, dim3(nparts), dim3(256), st, V, D, k, Dc.p, pdir.p, q.p);
         BA_LAUNCH(ba_pcgp_step_kernel<PD>, dim3(nparts), dim3(256), st, V, D, k, Minv.p, rhs.p, pdir.p, q.p, x.p, r.p, z.p);
@@ -3833,11 +3950,16 @@ struct Solver {
           else BA_LAUNCH(ba_block_gram_kernel, dim3(V.n_chunks), dim3(64), st, V, Gobs.p);
           BA_HIP(hipEventRecord(ev3, st));
           mfma_pending = true;
+          heavy_reduce(bd * bd);
           BA_LAUNCH(ba_block_mat_finalize_kernel<false>, dim3(grid_for(V.n_blk * bd * bd, 128)), dim3(128), st, V, M.p);
           if (n_paired > 0) {  // observation pairs of a point inside one block: shared intrinsics, rig frames
+            if (bd == PD) BA_LAUNCH(ba_obs_w_kernel<PD>, dim3(grid_for(V.n_obs, 256)), dim3(256), st, V);
+            else if (bd == KD_WIDE) BA_LAUNCH(ba_obs_w_kernel<KD_WIDE>, dim3(grid_for(V.n_obs, 256)), dim3(256), st, V);
+            else BA_LAUNCH(ba_obs_w_kernel<KD_MAX>, dim3(grid_for(V.n_obs, 256)), dim3(256), st, V);
             if (bd == PD) BA_LAUNCH(ba_block_schur_cross_kernel<PD>, dim3(V.n_chunks), dim3(64), st, V, Cinv.p);
             else if (bd == KD_WIDE) BA_LAUNCH(ba_block_schur_cross_kernel<KD_WIDE>, dim3(V.n_chunks), dim3(64), st, V, Cinv.p);
             else BA_LAUNCH(ba_block_schur_cross_kernel<KD_MAX>, dim3(V.n_chunks), dim3(64), st, V, Cinv.p);
+            heavy_reduce(bd * bd);
             BA_LAUNCH(ba_block_mat_finalize_kernel<true>, dim3(grid_for(V.n_blk * bd * bd, 128)), dim3(128), st, V, M.p);
           }
         }

@@ -130,6 +130,30 @@ def test_shared_intrinsics_and_three_point_gauge():
     assert got.final_cost < 0.05 * got.initial_cost
 
 
+def test_heavy_blocks_reduce_their_chunks_first():
+    """A camera shared by many images is ONE block with thousands of chunk partials; such heavy blocks are summed by
+    ba_cpart_heavy_reduce_kernel (a fixed tree over all threads of a workgroup) before the finalize kernels read them,
+    instead of one thread walking them all. Forced here on a small shared-intrinsics problem (64 observations per chunk,
+    every block with more than one chunk heavy): the default path's trajectory to rounding, the oracle's to 1e-7, the
+    same PCG iteration counts -- for the iterative tier, whose every product ends in a finalize, and the exact tier."""
+    d = scene.synthesize_flat(10, 200, 5, seed=11, noise=scene.SyntheticNoiseOptions(0.01, 0.5, 0.03, 0.5))
+    d["obs_cam"] = np.zeros_like(d["obs_cam"])
+    d["cams"] = d["cams"][:1].copy()
+    d["cam_model"] = d["cam_model"][:1].copy()
+    fp = est.FlatProblem.from_arrays(d)
+    assert est.fix_gauge_two_cams(fp)
+    for tier in (est.SOLVER_ITERATIVE_SCHUR, est.SOLVER_DENSE_SCHUR):
+        so = dict(max_num_iterations=8, linear_solver_type=tier)
+        b0, s0 = _solve_env(fp, {}, **so)
+        b1, s1 = _solve_env(fp, {"COLMAP_AMD_BA_CHUNK": "64", "COLMAP_AMD_BA_HEAVY_CHUNKS": "1"}, **so)
+        a = fp.copy()
+        want = est.solve_flat(a, est.SolverOptions(**so), solve_fn=ba_oracle.solve_fn)
+        np.testing.assert_allclose(s1.log_cost, s0.log_cost, rtol=1e-11)
+        np.testing.assert_array_equal(s1.log_linear_iters[:4], s0.log_linear_iters[:4])
+        np.testing.assert_allclose(s1.log_cost[:5], want.log_cost[:5], rtol=1e-7)
+        np.testing.assert_allclose(b1.points, b0.points, atol=1e-8)
+
+
 def test_only_points_variable_and_only_cameras_variable():
     fp = _flat(6, 80, 4, seed=13)
     pts_only = fp.copy()
