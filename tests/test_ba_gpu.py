@@ -290,6 +290,29 @@ def test_baseline_config3_cost_log_matches_oracle():
     np.testing.assert_allclose(b.poses, a.poses, atol=1e-6)
 
 
+def test_baseline_config3_shared_intrinsics_matches_oracle():
+    """SURVEY 8(d)'s second variant of BASELINE.json config[3]: the same 1000 cameras x 200k points with ONE camera shared
+    by all images (the case the reference's FAQ warns about, doc/faq.rst:626-632, and the common single-camera capture).
+    The one intrinsics block is reached from all 2 M observations -- 4 000 chunk partials (ba_cpart_heavy_reduce_kernel),
+    1.8 M observation pairs inside the block (ba_obs_w_kernel + ba_block_schur_cross_kernel) -- at the size where those
+    paths carry real load: first 6 LM iterations against the oracle, costs 1e-7, the same PCG iteration counts."""
+    d = scene.synthesize_flat(1000, 200000, 10, seed=42, noise=scene.SyntheticNoiseOptions(0.01, 1.0, 0.05, 1.0))
+    d["obs_cam"] = np.zeros_like(d["obs_cam"])
+    d["cams"] = d["cams"][:1].copy()
+    d["cam_model"] = d["cam_model"][:1].copy()
+    fp = est.FlatProblem.from_arrays(d)
+    assert est.fix_gauge_two_cams(fp)
+    (a, want), (b, got) = _both(fp, max_num_iterations=6)
+    assert got.num_residuals == want.num_residuals == 4000000
+    assert got.num_effective_parameters == want.num_effective_parameters == 3 * 200000 + 6 * 998 + 5 + 2
+    assert got.num_iterations == want.num_iterations and got.num_successful_steps == want.num_successful_steps
+    np.testing.assert_allclose(got.log_cost, want.log_cost, rtol=1e-7)
+    np.testing.assert_array_equal(got.log_linear_iters[:4], want.log_linear_iters[:4])
+    np.testing.assert_allclose(b.points, a.points, atol=1e-6)
+    np.testing.assert_allclose(b.poses, a.poses, atol=1e-6)
+    assert ba_compare.projection_diff_px(a, b) <= 5e-5
+
+
 def test_baseline_config4_mixed_models_matches_oracle():
     """BASELINE.json config[4]'s ingredients at a tenth of its size (500 cameras x 200k points, track 10,
     thirds of SIMPLE_RADIAL / PINHOLE / OPENCV: the <8, 8> camera-block tier with three models in one
