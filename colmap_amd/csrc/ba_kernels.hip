@@ -2024,6 +2024,73 @@ __global__ void ba_inc_finalize_kernel(View V, IncView I, double* __restrict__ M
   M[V.blk_moff[b] + x * dim + y] += s;
 }
 
+// ------------------------------------------------------------------------------------------
+// Single GPU: the pair terms of the Schur-Jacobi blocks per INCIDENCE instead of per pair.
+// For a point p and a block b that holds t >= 2 of p's observations the cross terms are
+//   - sum_{o != o2} W_o C^-1 W_o2^T  =  - ( Ws C^-1 Ws^T - sum_o W_o C^-1 W_o^T ),   Ws = sum_o W_o,
+// t + 1 products instead of t (t - 1): ba_block_schur_cross_kernel walks every partner of every observation (O(t^2) per
+// incidence, 1.26 ms at BA-1 with one shared camera). The host lists the incidences sorted by block (PairView = the
+// IncView layout, `obs` holding p-order observation indices), W_o comes from the p-order buffer of ba_obs_w_kernel (an
+// incidence's members are neighbours there). One workgroup per chunk of <= kPairChunk incidences of ONE block, thread per
+// entry (x, y), partial per chunk; ba_pair_finalize_kernel adds a block's partials with a fixed tree. No atomics.
+// (Small chunks: a workgroup walks its incidences one after the other with dim^2 of its KDT^2 lanes busy -- what makes it
+// fast is many workgroups in flight, 6 250 at BA-1 with one shared camera.)
+// ------------------------------------------------------------------------------------------
+constexpr int kPairChunk = 32;
+template <int KDT>
+__global__ void __launch_bounds__(KDT * KDT) ba_pair_cross_kernel(View V, IncView I, const double* __restrict__ Cinv) {
+  const int ch = blockIdx.x;
+  const int b = I.chunk_blk[ch], dim = V.blk_dim[b], kind = V.blk_kind[b];
+  const int x = threadIdx.x / KDT, y = threadIdx.x % KDT;
+  const double* Wk = V.Wp[kind];
+  const int ws = V.wdim[kind] * 3;
+  double acc = 0.0;
+  if (x < dim && y < dim) {
+    for (int i = I.chunk_beg[ch]; i < I.chunk_beg[ch + 1]; ++i) {
+      const double* Ci = Cinv + 9 * (size_t)I.pt[i];
+      double sx[3] = {0.0, 0.0, 0.0}, sy[3] = {0.0, 0.0, 0.0}, self = 0.0;
+      for (int k = I.ptr[i]; k < I.ptr[i + 1]; ++k) {
+        const double* w = Wk + (size_t)I.obs[k] * ws;
+        const double wx0 = w[x * 3], wx1 = w[x * 3 + 1], wx2 = w[x * 3 + 2];
+        const double wy0 = w[y * 3], wy1 = w[y * 3 + 1], wy2 = w[y * 3 + 2];
+        sx[0] += wx0; sx[1] += wx1; sx[2] += wx2;
+        sy[0] += wy0; sy[1] += wy1; sy[2] += wy2;
+        const double t0 = wx0 * Ci[0] + wx1 * Ci[3] + wx2 * Ci[6];
+        const double t1 = wx0 * Ci[1] + wx1 * Ci[4] + wx2 * Ci[7];
+        const double t2 = wx0 * Ci[2] + wx1 * Ci[5] + wx2 * Ci[8];
+        self += t0 * wy0 + t1 * wy1 + t2 * wy2;
+      }
+      const double t0 = sx[0] * Ci[0] + sx[1] * Ci[3] + sx[2] * Ci[6];
+      const double t1 = sx[0] * Ci[1] + sx[1] * Ci[4] + sx[2] * Ci[7];
+      const double t2 = sx[0] * Ci[2] + sx[1] * Ci[5] + sx[2] * Ci[8];
+      acc -= (t0 * sy[0] + t1 * sy[1] + t2 * sy[2]) - self;
+    }
+  }
+  I.part[(size_t)ch * KDT * KDT + threadIdx.x] = acc;
+}
+// M_b += the partials of block b's chunks: one workgroup per block that has pair incidences (I.pair_blk), 64 entries per
+// grid.y slice, 16 threads per entry striding over the chunks, their sums added in thread order (a fixed tree).
+template <int KDT>
+__global__ void __launch_bounds__(1024) ba_pair_finalize_kernel(View V, IncView I, const int* __restrict__ pair_blk,
+                                                                double* __restrict__ M) {
+  __shared__ double part[1024];
+  const int b = pair_blk[blockIdx.x];
+  const int el = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int e = el + 64 * blockIdx.y;
+  const int c0 = I.blk_chunk[b], c1 = I.blk_chunk[b + 1];
+  double s = 0.0;
+  if (e < KDT * KDT)
+    for (int c = c0 + g; c < c1; c += 16) s += I.part[(size_t)c * KDT * KDT + e];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  const int dim = V.blk_dim[b], x = e / KDT, y = e % KDT;
+  if (g == 0 && e < KDT * KDT && x < dim && y < dim) {
+    double t = 0.0;
+    for (int k = 0; k < 16; ++k) t += part[k * 64 + el];
+    M[V.blk_moff[b] + x * dim + y] += t;
+  }
+}
+
 // M_b += Dc^2 on the diagonal, then invert (Gauss-Jordan with partial pivoting); lane per block
 template <int BD>
 __global__ void __launch_bounds__(64) ba_block_invert_kernel(View V, const double* __restrict__ Dc, const double* __restrict__ M,
@@ -2959,6 +3026,10 @@ struct Solver {
   Buf<double> inc_part;
   Buf<double> inc_wloc, inc_wtot;
   IncView IV{};
+  IncView PV{};  // single GPU: (point, block) incidences with >= 2 observations in the block (ba_pair_cross_kernel)
+  Buf<int> pv_pt, pv_blk, pv_ptr, pv_mem, pv_chunk_blk, pv_chunk_beg, pv_blk_chunk, pv_pair_blk;
+  Buf<double> pv_part;
+  int n_pair_blk = 0;
   // pipelined PCG (pcg_pipelined): partial sums, stop flag, Q history on the device; per-iteration scalars in pinned
   // host memory the device writes directly; events of two iterations in flight
   Buf<double> pcgp_part, pcgp_qhist;
@@ -3423,6 +3494,72 @@ struct Solver {
       a_boff[kind].upload(h_ab);
       Wp[kind].alloc((size_t)n * V.wdim[kind] * 3);
       V.a_boff[kind] = a_boff[kind].p; V.Wp[kind] = Wp[kind].p;
+    }
+    // single GPU: the pair incidences themselves, sorted by block (ba_pair_cross_kernel); a sharded solve keeps the
+    // per-observation kernel for its local pairs (the cross-rank ones are IV's)
+    PV = IncView{};
+    n_pair_blk = 0;
+    if (n_paired > 0 && comm.world == 1 && dev_switch_int("COLMAP_AMD_BA_PAIR_INCIDENCES", 1) != 0) {
+      std::vector<int> blk_of_off(std::max(off, 0) + 1, -1);  // tangent offset -> block
+      for (int b = 0; b < n_blk; ++b) blk_of_off[h_blk_off[b]] = b;
+      struct Inc { int blk, pt, first, count; };
+      std::vector<Inc> incs;
+      std::vector<int> members;  // p-order observation indices, grouped per incidence
+      std::vector<std::pair<int, int>> grp;  // (block offset, a) of one point and kind
+      for (int kind = 0; kind < 3; ++kind) {
+        if (n_paired_kind[kind] <= 0) continue;
+        std::vector<int> h_ab(n);
+        for (int a = 0; a < n; ++a) {
+          if (kind == 0) h_ab[a] = h_pose_off[h_a_pose[a]];
+          else if (kind == 1) h_ab[a] = h_cam_off[h_a_cam[a]];
+          else h_ab[a] = (has_sensors && h_a_sensor[a] >= 0) ? h_sens_off[h_a_sensor[a]] : -1;
+        }
+        for (int j = 0; j < p.num_points; ++j) {
+          if (h_pt_off[j] < 0) continue;  // a constant point has no C^-1: its observations do not couple
+          grp.clear();
+          for (int a = h_pt_ptr[j]; a < h_pt_ptr[j + 1]; ++a)
+            if (h_ab[a] >= 0) grp.emplace_back(h_ab[a], a);
+          std::sort(grp.begin(), grp.end());
+          for (size_t i = 0; i < grp.size();) {
+            size_t e = i;
+            while (e < grp.size() && grp[e].first == grp[i].first) ++e;
+            if (e - i >= 2) {
+              incs.push_back({blk_of_off[grp[i].first], j, (int)members.size(), (int)(e - i)});
+              for (size_t k = i; k < e; ++k) members.push_back(grp[k].second);
+            }
+            i = e;
+          }
+        }
+      }
+      if (!incs.empty()) {
+        std::stable_sort(incs.begin(), incs.end(), [](const Inc& a, const Inc& b) { return a.blk < b.blk; });
+        const int ni = (int)incs.size();
+        std::vector<int> h_pt(ni), h_blk(ni), h_ptr(ni + 1, 0), h_mem;
+        h_mem.reserve(members.size());
+        for (int i = 0; i < ni; ++i) {
+          h_pt[i] = incs[i].pt; h_blk[i] = incs[i].blk;
+          h_mem.insert(h_mem.end(), members.begin() + incs[i].first, members.begin() + incs[i].first + incs[i].count);
+          h_ptr[i + 1] = (int)h_mem.size();
+        }
+        std::vector<int> h_cblk, h_cbeg, h_bchunk(n_blk + 1, 0), h_pblk;
+        for (int i = 0; i < ni;) {
+          int e = i;
+          while (e < ni && h_blk[e] == h_blk[i] && e - i < kPairChunk) ++e;
+          if (h_pblk.empty() || h_pblk.back() != h_blk[i]) h_pblk.push_back(h_blk[i]);
+          h_cblk.push_back(h_blk[i]); h_cbeg.push_back(i);
+          h_bchunk[h_blk[i] + 1]++;
+          i = e;
+        }
+        h_cbeg.push_back(ni);
+        for (int b = 0; b < n_blk; ++b) h_bchunk[b + 1] += h_bchunk[b];
+        pv_pt.upload(h_pt); pv_blk.upload(h_blk); pv_ptr.upload(h_ptr); pv_mem.upload(h_mem);
+        pv_chunk_blk.upload(h_cblk); pv_chunk_beg.upload(h_cbeg); pv_blk_chunk.upload(h_bchunk); pv_pair_blk.upload(h_pblk);
+        pv_part.alloc(h_cblk.size() * (size_t)KD_WIDE * KD_WIDE);
+        PV.n = ni; PV.pt = pv_pt.p; PV.blk = pv_blk.p; PV.ptr = pv_ptr.p; PV.obs = pv_mem.p;
+        PV.n_chunks = (int)h_cblk.size(); PV.chunk_blk = pv_chunk_blk.p; PV.chunk_beg = pv_chunk_beg.p;
+        PV.blk_chunk = pv_blk_chunk.p; PV.part = pv_part.p;
+        n_pair_blk = (int)h_pblk.size();
+      }
     }
     chunk_blk.upload(h_chunk_blk); chunk_beg.upload(h_chunk_beg); chunk_end.upload(h_chunk_end);
     c2a.upload(h_c2a); a2c.upload(h_a2c); solo.upload(h_solo); tile_pt.upload(h_tile_pt);
@@ -3956,11 +4093,21 @@ struct Solver {
             if (bd == PD) BA_LAUNCH(ba_obs_w_kernel<PD>, dim3(grid_for(V.n_obs, 256)), dim3(256), st, V);
             else if (bd == KD_WIDE) BA_LAUNCH(ba_obs_w_kernel<KD_WIDE>, dim3(grid_for(V.n_obs, 256)), dim3(256), st, V);
             else BA_LAUNCH(ba_obs_w_kernel<KD_MAX>, dim3(grid_for(V.n_obs, 256)), dim3(256), st, V);
-            if (bd == PD) BA_LAUNCH(ba_block_schur_cross_kernel<PD>, dim3(V.n_chunks), dim3(64), st, V, Cinv.p);
-            else if (bd == KD_WIDE) BA_LAUNCH(ba_block_schur_cross_kernel<KD_WIDE>, dim3(V.n_chunks), dim3(64), st, V, Cinv.p);
-            else BA_LAUNCH(ba_block_schur_cross_kernel<KD_MAX>, dim3(V.n_chunks), dim3(64), st, V, Cinv.p);
-            heavy_reduce(bd * bd);
-            BA_LAUNCH(ba_block_mat_finalize_kernel<true>, dim3(grid_for(V.n_blk * bd * bd, 128)), dim3(128), st, V, M.p);
+            if (PV.n > 0) {  // per incidence (single GPU)
+              if (bd == KD_WIDE) {
+                BA_LAUNCH(ba_pair_cross_kernel<KD_WIDE>, dim3(PV.n_chunks), dim3(KD_WIDE * KD_WIDE), st, V, PV, Cinv.p);
+                BA_LAUNCH(ba_pair_finalize_kernel<KD_WIDE>, dim3(n_pair_blk, KD_WIDE * KD_WIDE / 64), dim3(1024), st, V, PV, pv_pair_blk.p, M.p);
+              } else {
+                BA_LAUNCH(ba_pair_cross_kernel<KD_MAX>, dim3(PV.n_chunks), dim3(KD_MAX * KD_MAX), st, V, PV, Cinv.p);
+                BA_LAUNCH(ba_pair_finalize_kernel<KD_MAX>, dim3(n_pair_blk, 1), dim3(1024), st, V, PV, pv_pair_blk.p, M.p);
+              }
+            } else {  // per observation (sharded solves: the local pairs)
+              if (bd == PD) BA_LAUNCH(ba_block_schur_cross_kernel<PD>, dim3(V.n_chunks), dim3(64), st, V, Cinv.p);
+              else if (bd == KD_WIDE) BA_LAUNCH(ba_block_schur_cross_kernel<KD_WIDE>, dim3(V.n_chunks), dim3(64), st, V, Cinv.p);
+              else BA_LAUNCH(ba_block_schur_cross_kernel<KD_MAX>, dim3(V.n_chunks), dim3(64), st, V, Cinv.p);
+              heavy_reduce(bd * bd);
+              BA_LAUNCH(ba_block_mat_finalize_kernel<true>, dim3(grid_for(V.n_blk * bd * bd, 128)), dim3(128), st, V, M.p);
+            }
           }
         }
         if (use_priors())

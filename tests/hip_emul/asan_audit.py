@@ -53,6 +53,7 @@ elif which == 'ba':
     run(T.test_solution_matches_oracle, frames=12, points=300, track=5, mixed=False)
     run(T.test_constant_blocks_are_untouched_bitwise); run(T.test_shared_intrinsics_and_three_point_gauge)
     run(T.test_heavy_blocks_reduce_their_chunks_first)   # heavy-block pre-reduction + p-order W buffers
+    run(T.test_pair_terms_per_incidence_equal_per_observation)   # pair terms per (point, block) incidence
     run(T.test_only_points_variable_and_only_cameras_variable); run(T.test_backend_interface_reference_cases)
     run(T.test_dense_schur_tier_matches_oracle); run(T.test_exact_tier_explicit_formation_equals_operator_products)
     run(T.test_rig_frames_match_oracle); run(T.test_pose_prior_adjuster_on_rigs_matches_oracle)

@@ -62,6 +62,7 @@ def test_constant_blocks_gauges_and_partial_problems():
     G.test_constant_blocks_are_untouched_bitwise()
     G.test_shared_intrinsics_and_three_point_gauge()
     G.test_heavy_blocks_reduce_their_chunks_first()
+    G.test_pair_terms_per_incidence_equal_per_observation()
     G.test_only_points_variable_and_only_cameras_variable()
     G.test_error_behaviour()
 

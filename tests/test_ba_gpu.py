@@ -154,6 +154,28 @@ def test_heavy_blocks_reduce_their_chunks_first():
         np.testing.assert_allclose(b1.points, b0.points, atol=1e-8)
 
 
+def test_pair_terms_per_incidence_equal_per_observation():
+    """The Schur-Jacobi pair terms of observations that share a block (shared intrinsics) computed per (point, block)
+    incidence -- -(Ws C^-1 Ws^T - sum_o W_o C^-1 W_o^T), ba_pair_cross_kernel, what a single-GPU solve runs -- against the
+    per-observation walk over all partners (ba_block_schur_cross_kernel, what sharded solves keep for their local
+    pairs): the same blocks to rounding, the same PCG iteration counts. Three cameras shared by twelve images, some
+    points constant, Cauchy loss."""
+    d = scene.synthesize_flat(12, 400, 6, seed=71, noise=scene.SyntheticNoiseOptions(0.01, 0.5, 0.03, 0.5))
+    d["obs_cam"] = (d["obs_cam"] % 3).astype(np.int32)
+    d["cams"] = d["cams"][:3].copy()
+    d["cam_model"] = d["cam_model"][:3].copy()
+    fp = est.FlatProblem.from_arrays(d)
+    assert est.fix_gauge_two_cams(fp)
+    fp.point_const[::9] = 1
+    so = dict(max_num_iterations=10, loss_type=int(est.LossFunctionType.CAUCHY), loss_scale=2.0)
+    b0, s0 = _solve_env(fp, {"COLMAP_AMD_BA_PAIR_INCIDENCES": "0"}, **so)
+    b1, s1 = _solve_env(fp, {}, **so)
+    np.testing.assert_allclose(s1.log_cost, s0.log_cost, rtol=1e-11)
+    np.testing.assert_array_equal(s1.log_linear_iters, s0.log_linear_iters)
+    np.testing.assert_allclose(b1.points, b0.points, atol=1e-9)
+    np.testing.assert_allclose(b1.cams, b0.cams, rtol=1e-9, atol=1e-9)
+
+
 def test_only_points_variable_and_only_cameras_variable():
     fp = _flat(6, 80, 4, seed=13)
     pts_only = fp.copy()
