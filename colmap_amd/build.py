@@ -40,25 +40,54 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False, dev: bool = False, out: str = "") -> str:
-    """dev=True: a profiling build -- development switches also readable from the environment
-    (-DCOLMAP_AMD_ENV_SWITCHES) and the garbage-producing PatchMatch diagnostics compiled in (-DCOLMAP_AMD_DIAG_BUILD);
-    written to `out` (default lib/libcolmap_amd_dev.so), never the library the package loads."""
+def _header_deps():
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    deps += [os.path.join(CSRC, "gfx950", f) for f in os.listdir(os.path.join(CSRC, "gfx950"))]
+    inc = os.path.join(os.path.dirname(_ROOT), "include")
+    for d, _, fs in os.walk(inc):
+        deps += [os.path.join(d, f) for f in fs]
+    return deps
+
+
+def build(force: bool = False, verbose: bool = False, dev: bool = False, out: str = "", incremental: bool = False) -> str:
+    """Compiles every source to an object of its own, in parallel, and links them. force: recompile everything;
+    incremental: recompile only the objects older than their source or any header (the default call does nothing while
+    the library is newer than all of them). dev=True: a profiling build -- development switches also readable from the
+    environment (-DCOLMAP_AMD_ENV_SWITCHES) and the garbage-producing PatchMatch diagnostics compiled in
+    (-DCOLMAP_AMD_DIAG_BUILD); written to `out` (default lib/libcolmap_amd_dev.so), never the library the package loads."""
     if dev:
         out = out or os.path.join(LIB_DIR, "libcolmap_amd_dev.so")
-    elif not force and not needs_build():
+    elif not force and not incremental and not needs_build():
         return LIB_PATH
     out = out or LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
+    obj_dir = os.path.join(LIB_DIR, "obj_dev" if dev else "obj")
+    os.makedirs(obj_dir, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     extra = ["-DCOLMAP_AMD_ENV_SWITCHES", "-DCOLMAP_AMD_DIAG_BUILD"] if dev else []
-    cmd = [hipcc] + HIPCC_FLAGS + extra + _sources() + ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib", "-o", out]
+    flags = [f for f in HIPCC_FLAGS if f != "-shared"] + extra
+    newest_header = max(os.path.getmtime(d) for d in _header_deps())
+    jobs, objs = [], []
+    for src in _sources():
+        obj = os.path.join(obj_dir, os.path.basename(src) + ".o")
+        objs.append(obj)
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), newest_header):
+            continue
+        cmd = [hipcc] + flags + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        jobs.append((src, subprocess.Popen(cmd)))
+    failed = [src for src, j in jobs if j.wait() != 0]
+    if failed:
+        raise subprocess.CalledProcessError(1, f"hipcc -c {failed}")
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib", "-o", out]
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
     return out
 
 
 if __name__ == "__main__":
     import sys
-    print(build(force=True, verbose=True, dev="--dev" in sys.argv))
+    # default: recompile what is older than its source / headers and link; --all: recompile every object
+    print(build(force="--all" in sys.argv, incremental=True, verbose=True, dev="--dev" in sys.argv))

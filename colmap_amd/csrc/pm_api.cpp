@@ -958,7 +958,7 @@ void RunBatchAsync(pm_handle** hs, int n) {
     pm_handle* h = hs[b];
     if (h->mask.ptr) HIP_CALL(hipMemsetAsync(h->mask.ptr, 0, h->mask.count, h0->stream));
     if (h->prof.ptr)
-      HIP_CALL(hipMemsetAsync(h->prof.ptr, 0, 10 * sizeof(unsigned long long), h0->stream));
+      HIP_CALL(hipMemsetAsync(h->prof.ptr, 0, kPmProfSlots * sizeof(unsigned long long), h0->stream));
     HIP_CALL(hipMemsetAsync(h->evals.ptr, 0, sizeof(unsigned long long), h0->stream));
   }
   pm_launch_initial_cost(host[0], h0->plan.ptr, n, h0->stream);
@@ -1308,7 +1308,7 @@ int pm_enable_phase_profile(pm_handle* h, int enable) {
     PM_CHECK(h, "null");
     HIP_CALL(hipSetDevice(h->device));
     if (enable) {
-      h->prof.alloc(10);
+      h->prof.alloc(kPmProfSlots);
       h->base.prof = h->prof.ptr;
     } else {
       h->base.prof = nullptr;
@@ -1351,6 +1351,15 @@ int pm_get_phase_profile(pm_handle* h, unsigned long long* out10) {
     PM_CHECK(h && out10 && h->prof.ptr, "profile not enabled");
     HIP_CALL(hipSetDevice(h->device));
     HIP_CALL(hipMemcpy(out10, h->prof.ptr, 10 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  });
+}
+
+int pm_get_phase_profile_slots(pm_handle* h, unsigned long long* out, int32_t capacity) {
+  return Guard([&] {
+    PM_CHECK(h && out && h->prof.ptr, "profile not enabled");
+    PM_CHECK(capacity >= kPmProfSlots, "buffer too small");
+    HIP_CALL(hipSetDevice(h->device));
+    HIP_CALL(hipMemcpy(out, h->prof.ptr, kPmProfSlots * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   });
 }
 

@@ -16,6 +16,7 @@ namespace colmap_amd {
 
 constexpr int kPoseStride = 43;  // K4 R9 T3 C3 P12 invP12 (reference patch_match_cuda.cu:1762)
 constexpr int kRngWords = 6;     // XORWOW: x[5] + d
+constexpr int kPmProfSlots = 24; // phase-profile counters per handle (pm_kernels.hip: kProf*; the generic kernel uses 10)
 
 // Packed source images ("footprints": one dword per texel position = its 2 x 2 bilinear neighbourhood) are
 // stored as vertical strips of kFpStrip = 16 entries: inside a strip the rows follow each other, 64 bytes each, so
@@ -83,7 +84,7 @@ struct PmParams {
   uint32_t* rng;            // [H*W][6]
   uint8_t* mask;            // [S][H][W] or null
   const float* poses;       // [S][43] for this rotation
-  unsigned long long* prof; // optional phase-cycle counters [10] (debug), else null
+  unsigned long long* prof; // optional phase-cycle counters [kPmProfSlots] (debug), else null
   unsigned long long* evals; // NCC evaluations executed by the sweep kernels of this run (one atomic
                              // add per workgroup at its end), always allocated
   unsigned long long* trace; // optional progress trace (debug, pm_enable_progress_trace): [column group][row / 128]

@@ -1235,6 +1235,14 @@ __device__ __forceinline__ void ncc_back(const NccStage& st, const uint32_t tex[
     prof_t = now_;                                           \
   }
 
+// Static ISA census (scripts/isa_phase_census.py compiles this file with -DPM_ISA_MARKERS and counts the
+// instructions between the comment markers); expands to nothing in every other build.
+#ifdef PM_ISA_MARKERS
+#define PM_MARK(name) asm volatile("; PMARK " name)
+#else
+#define PM_MARK(name)
+#endif
+
 template <int N1D, bool GEOM, bool FILTER_PHOTO, bool FILTER_GEOM, bool PROF>
 __global__ void __launch_bounds__(256, 3) pm_sweep_kernel(const PmParams* __restrict__ pp) {
   // Batch of reference images: one launch, grid.y problems. Workgroups are dealt to the 8 XCDs
@@ -1653,9 +1661,10 @@ __device__ __forceinline__ void wave_sync() {
 }
 
 // Run the queued NCC tasks (and, with GEOM, the geometric-cost-only list) of one phase.
-template <bool GEOM, int NW, int CAP, bool MUBUF>
+template <bool GEOM, int NW, int CAP, bool MUBUF, bool PROF>
 __device__ __forceinline__ void run_tasks_wave(const PmParams& p, const Lds& L, const v4i srd, int row, int col0,
-                                               int tid, unsigned& evals) {
+                                               int tid, unsigned& evals, unsigned long long* prof_acc,
+                                               unsigned long long& prof_t, const int prof_slot0) {
   const lds_f32* G = L.tapg;
   const int n = L.ntasks[0];
   evals += (unsigned)n;
@@ -1678,6 +1687,7 @@ __device__ __forceinline__ void run_tasks_wave(const PmParams& p, const Lds& L, 
   const uint32_t gorigin = fp_index(kFpRingX, kFpRingY, (unsigned)p.fp_rows1);  // the same as an entry index
   for (int base = 0; base < n; base += CAP) {
     const int nb = min(CAP, n - base);
+    PM_MARK("passA");
     // pass A, lane per task: homography of the (hypothesis, view) pair (+ geometric cost)
     bool inside = false;
     if (tid < nb) {
@@ -1715,6 +1725,8 @@ __device__ __forceinline__ void run_tasks_wave(const PmParams& p, const Lds& L, 
     // the result -- so that the DPP rows are always fully active.
     {
       const int rounds = (nb + 3) >> 2;
+      PM_PROF_MARK(prof_slot0 - 1)
+      PM_MARK("passB");
       for (int r = 0; r < rounds; ++r) {
         const int tr = g + 4 * r;
         const bool own = tr < nb;
@@ -1744,6 +1756,8 @@ __device__ __forceinline__ void run_tasks_wave(const PmParams& p, const Lds& L, 
       }
     }
     wave_sync<NW>();
+    PM_PROF_MARK(prof_slot0)
+    PM_MARK("finish");
     // lane per task: normalisation, variances, square root, division
     if (tid < nb) {
       const uint32_t task = tasks[base + tid];
@@ -1754,10 +1768,17 @@ __device__ __forceinline__ void run_tasks_wave(const PmParams& p, const Lds& L, 
                                                   L.colf[c * 8 + 0], L.colf[c * 8 + 1], L.colf[c * 8 + 5]);
     }
     wave_sync<NW>();
+    PM_PROF_MARK(prof_slot0 + 1)
   }
 }
 
-template <bool GEOM, bool FILTER_PHOTO, bool FILTER_GEOM, int NW, int CAP, bool MUBUF>
+// Phase profile of the wave kernels (PROF instantiation, pm_enable_phase_profile): every wave accumulates shader-clock
+// deltas per phase in scalar registers and adds them to p.prof[] when it retires. Slots:
+constexpr int kProfSetup = 0, kProfP0 = 1, kProfP1 = 2, kProfP1w = 3, kProfP2 = 4, kProfP3a = 5, kProfP3b = 6,
+              kProfP3c = 7, kProfP4A = 8, kProfP4B = 9, kProfP4F = 10, kProfP5a = 11, kProfP5b = 12, kProfP5c = 13,
+              kProfP6A = 14, kProfP6B = 15, kProfP6F = 16, kProfP7 = 17, kProfP8 = 18, kProfSlots = kPmProfSlots;
+
+template <bool GEOM, bool FILTER_PHOTO, bool FILTER_GEOM, int NW, int CAP, bool MUBUF, bool PROF = false>
 __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp) {
   const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y;
   unsigned group = lin / gridDim.y;
@@ -1838,6 +1859,8 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
   wave_sync<NW>();
 
   const int tid0 = tid_entry;
+  unsigned long long prof_acc[kProfSlots] = {};
+  unsigned long long prof_t = PROF ? __builtin_readcyclecounter() : 0ull;
   unsigned evals = 0;  // NCC evaluations of this wave (< 2^32: RH * C * (4 M + S) per sweep)
   for (int row = 0; row < RH; ++row) {
     // The lane id is laundered through an empty asm once per row: everything the phases derive from
@@ -1848,11 +1871,15 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
     const bool col_lane = tid < ncols;
     if (p.trace && (row & 127) == 0 && tid == 0)  // debug: pm_enable_progress_trace
       p.trace[(size_t)group * p.trace_stride + (row >> 7)] = __builtin_amdgcn_s_memrealtime();
+    PM_PROF_MARK(row == 0 ? kProfSetup : kProfP8)
+    PM_MARK("P0");
     // ---- P0: scroll the reference tile (LocalRefImage::Read, :357-410) -------
     tile_load_row(p, L, col0, row + p.radius, tid, nt);
     if (tid == 0) { L.ntasks[0] = 0; L.ntasks[1] = 0; }
     wave_sync<NW>();
 
+    PM_PROF_MARK(kProfP0)
+    PM_MARK("P1");
     // ---- P1: hypotheses (lane per column) + patch weights (all lanes) --------
     if (col_lane && !(PM_ABLATE(p) & 2)) {
       const int c = tid;
@@ -1882,9 +1909,13 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
       cf[3] = cd * (iK[2] * row + iK[3]);
       cf[4] = cd;
     }
+    PM_PROF_MARK(kProfP1)
+    PM_MARK("P1w");
     patch_weights(p, L, row, tid, nt);
     for (int item = tid; item < ncols * 4 * S; item += nt) L.ncc[item] = -1.0f;
     wave_sync<NW>();
+    PM_PROF_MARK(kProfP1w)
+    PM_MARK("P2");
 
     // ---- P2: per-view selection priors (:1070-1104), lane per (column, view) --
     patch_weight_sums(p, L, ncols, tid, nt);
@@ -1915,6 +1946,8 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
     }
     wave_sync<NW>();
 
+    PM_PROF_MARK(kProfP2)
+    PM_MARK("P3a");
     // ---- P3a: TransformPDFToCDF (:683-696), sequential sum order, lane per column
     if (col_lane) {
       const int c = tid;
@@ -1931,6 +1964,8 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
       }
     }
     wave_sync<NW>();
+    PM_PROF_MARK(kProfP3a)
+    PM_MARK("P3b");
     // ---- P3b: Monte-Carlo view draws (:1128-1138), lane per (column, draw) ----
     for (int item = tid; item < ncols * M; item += nt) {
       const int c = item / M;
@@ -1943,6 +1978,8 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
       L.sv[item] = src;
     }
     wave_sync<NW>();
+    PM_PROF_MARK(kProfP3b)
+    PM_MARK("P3c");
     // ---- P3c: one task set per distinct drawn view, lane per (column, view) ---
     {
       LDS_AS uint16_t* tasks = (LDS_AS uint16_t*)L.tasks;
@@ -1963,11 +2000,16 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
     }
     wave_sync<NW>();
 
+    PM_PROF_MARK(kProfP3c)
+    PM_MARK("P4");
     // ---- P4: NCC of hypotheses 1..4 against the drawn views (:1157-1172) -----
-    if (!(PM_ABLATE(p) & 1)) run_tasks_wave<GEOM, NW, CAP, MUBUF>(p, L, srd, row, col0, tid, evals);
+    if (!(PM_ABLATE(p) & 1))
+      run_tasks_wave<GEOM, NW, CAP, MUBUF, PROF>(p, L, srd, row, col0, tid, evals, prof_acc, prof_t, kProfP4B);
     if (tid == 0) { L.ntasks[0] = 0; L.ntasks[1] = 0; }
     wave_sync<NW>();
 
+    PM_PROF_MARK(kProfP4F)
+    PM_MARK("P5a");
     // ---- P5a: accumulate in draw order (:1144-1172), lane per (column, hypothesis)
     for (int item = tid; item < ncols * 5; item += nt) {
       const int c = item / 5;
@@ -1983,6 +2025,8 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
       L.csum[item] = acc;
     }
     wave_sync<NW>();
+    PM_PROF_MARK(kProfP5a)
+    PM_MARK("P5b");
     // ---- P5b: argmin, store, next row's previous state (:1176-1182,1279-1282) --
     if (col_lane) {
       const int c = tid;
@@ -2004,6 +2048,8 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
       h1[0] = bd; h1[1] = b0; h1[2] = b1; h1[3] = b2;
     }
     wave_sync<NW>();
+    PM_PROF_MARK(kProfP5b)
+    PM_MARK("P5c");
     // ---- P5c: winner vs. the views not evaluated yet, lane per (column, view) --
     {
       LDS_AS uint16_t* tasks = (LDS_AS uint16_t*)L.tasks;
@@ -2019,8 +2065,13 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
     }
     wave_sync<NW>();
 
+    PM_PROF_MARK(kProfP5c)
+    PM_MARK("P6");
     // ---- P6: NCC of the winner against the remaining views (:1188-1197) ------
-    if (!(PM_ABLATE(p) & 1)) run_tasks_wave<false, NW, CAP, MUBUF>(p, L, srd, row, col0, tid, evals);
+    if (!(PM_ABLATE(p) & 1))
+      run_tasks_wave<false, NW, CAP, MUBUF, PROF>(p, L, srd, row, col0, tid, evals, prof_acc, prof_t, kProfP6B);
+    PM_PROF_MARK(kProfP6F)
+    PM_MARK("P7");
 
     // ---- P7: cost map, forward message, selection probability (:1186-1207) ---
     for (int item = tid; item < ncols * S; item += nt) {
@@ -2060,8 +2111,10 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
         L.flags[item] = ok;
       }
     }
+    PM_PROF_MARK(kProfP7)
     if (FILTER_PHOTO || FILTER_GEOM) {
       wave_sync<NW>();
+      PM_MARK("P8");
       if (col_lane) {
         const int c = tid;
         int num = 0;
@@ -2077,12 +2130,20 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
       }
     }
     wave_sync<NW>();
+    PM_MARK("ROWEND");
   }
 
   if (col_lane) {
     rng_store(p.rng + (size_t)pix_index(p, 0, col0 + tid) * kRngWords, rng);  // :1285-1287
   }
   if (tid == 0 && p.evals) atomicAdd(p.evals, (unsigned long long)evals);
+  if (PROF) {
+    PM_PROF_MARK(kProfP8)
+    if (tid == 0 && p.prof) {
+      for (int i = 0; i < kProfSlots - 1; ++i) atomicAdd(p.prof + i, prof_acc[i]);
+      atomicAdd(p.prof + kProfSlots - 1, 1ull);  // waves that reported
+    }
+  }
 }
 
 // MUBUF: packed images addressed through the problem's buffer resource (the normal case), or by explicit indices
@@ -2095,6 +2156,11 @@ __global__ void __launch_bounds__(64, 4) pm_sweep_wave4_kernel(const PmParams* _
 template <bool GEOM, bool FILTER_PHOTO, bool FILTER_GEOM, bool MUBUF>
 __global__ void __launch_bounds__(64 * kQuadWaves, 4) pm_sweep_quad_kernel(const PmParams* __restrict__ pp) {
   sweep_wave_body<GEOM, FILTER_PHOTO, FILTER_GEOM, kQuadWaves, kQuadThCap, MUBUF>(pp);
+}
+// The same kernel with the phase clocks compiled in (pm_enable_phase_profile; photometric sweeps).
+template <bool FILTER_PHOTO>
+__global__ void __launch_bounds__(64 * kQuadWaves, 4) pm_sweep_quad_prof_kernel(const PmParams* __restrict__ pp) {
+  sweep_wave_body<false, FILTER_PHOTO, false, kQuadWaves, kQuadThCap, true, true>(pp);
 }
 
 // Debug: raw XORWOW streams of the generator above (seed = sequence id, as InitRandomStateKernel
@@ -2224,16 +2290,23 @@ const char* pm_launch_sweep(const PmParams& p, const PmParams* dev_params, int b
     if (mubuf) PM_LAUNCH_V4(KERNEL, true, GRID, BLOCK, LDS); \
     else PM_LAUNCH_V4(KERNEL, false, GRID, BLOCK, LDS);      \
   } while (0)
-  if (wave_enabled && !p.prof && p.ntap1d == 11 && p.step >= 1 && p.S <= 512 && p.C <= 8) {
+  if (wave_enabled && p.ntap1d == 11 && p.step >= 1 && p.S <= 512 && p.C <= 8) {
     // COLMAP_AMD_PM_FP_GLOBAL=1 (tests): explicit indices although the buffer resource would do
     const bool mubuf = pm_fp_resource_ok(p) && dev_switch_int("COLMAP_AMD_PM_FP_GLOBAL", 0) == 0;
     const size_t qlds = lds_offsets_wave(p.C, p.S, p.radius, p.ntaps, p.num_samples, geom, kQuadThCap, kQuadWaves).total;
-    if (pm_quad_enabled() && qlds <= kQuadLdsBudget) {
+    if (p.prof && pm_quad_enabled() && qlds <= kQuadLdsBudget && mubuf && !geom) {
+      // phase profile (pm_enable_phase_profile): the shipped kernel with its phase clocks compiled in
+      const dim3 pgrid((groups + kQuadWaves - 1) / kQuadWaves, batch, 1), pblock(64 * kQuadWaves, 1, 1);
+      if (filter_photo) hipLaunchKernelGGL(pm_sweep_quad_prof_kernel<true>, pgrid, pblock, qlds, st, dev_params);
+      else hipLaunchKernelGGL(pm_sweep_quad_prof_kernel<false>, pgrid, pblock, qlds, st, dev_params);
+      return "pm_sweep_quad_prof_kernel";
+    }
+    if (!p.prof && pm_quad_enabled() && qlds <= kQuadLdsBudget) {
       PM_LAUNCH_V(pm_sweep_quad_kernel, dim3((groups + kQuadWaves - 1) / kQuadWaves, batch, 1), dim3(64 * kQuadWaves, 1, 1), qlds);
       return mubuf ? "pm_sweep_quad_kernel" : "pm_sweep_quad_kernel (explicit indices)";
     }
     const size_t wlds = lds_offsets_wave(p.C, p.S, p.radius, p.ntaps, p.num_samples, geom, kWaveThCap, 1).total;
-    if (wlds <= 64 * 1024) {
+    if (!p.prof && wlds <= 64 * 1024) {
       PM_LAUNCH_V(pm_sweep_wave4_kernel, dim3(groups, batch, 1), dim3(64, 1, 1), wlds);
       return mubuf ? "pm_sweep_wave4_kernel" : "pm_sweep_wave4_kernel (explicit indices)";
     }

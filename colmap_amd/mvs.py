@@ -386,6 +386,18 @@ class PatchMatch:
         _check(lib().pm_get_phase_profile(self._h, out))
         return list(out)
 
+    PHASE_NAMES = ("setup", "P0_tile", "P1_hypotheses", "P1w_patch_weights", "P2_priors", "P3a_cdf", "P3b_draws",
+                   "P3c_tasks", "P4_homographies", "P4_tap_rounds", "P4_normalise", "P5a_sums", "P5b_argmin",
+                   "P5c_winner_tasks", "P6_homographies", "P6_tap_rounds", "P6_normalise", "P7_messages", "P8_rowend")
+
+    def GetPhaseProfileSlots(self):
+        """{phase: shader-clock cycles summed over the waves} of the profiled four-wave kernel + 'waves'."""
+        out = (C.c_ulonglong * 24)()
+        _check(lib().pm_get_phase_profile_slots(self._h, out, 24))
+        d = {n: int(out[i]) for i, n in enumerate(self.PHASE_NAMES)}
+        d["waves"] = int(out[23])
+        return d
+
     def GetSweepTiming(self):
         ms = C.c_double(0)
         n = C.c_int32(0)

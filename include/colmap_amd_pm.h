@@ -172,10 +172,17 @@ int pm_get_device_maps(pm_handle* h, const float** depth, const float** normal);
  * reference's write-to-disk / read-back, patch_match.cc:507-508,530-531). */
 int pm_copy_maps_to_device(pm_handle* h, float* depth_dev, float* normal_dev);
 
-/* Debug: per-phase shader-clock totals of the sweep kernel (wave 0 of every
- * workgroup, summed); only for the photometric no-filter radius-5 variant. */
+/* Debug: per-phase shader-clock totals of the sweep kernel, photometric sweeps of the 11 x 11 window. With the
+ * profile enabled the run launches the profiling build of the shipped four-wave kernel (every wave adds its
+ * phase totals when it retires): pm_get_phase_profile_slots returns PM_PROFILE_SLOTS counters -- 0 set-up + backward
+ * messages, 1 tile scroll, 2 hypotheses, 3 patch weights, 4 priors, 5 CDF, 6 draws, 7 task lists, 8-10 hypothesis
+ * NCC (homographies, tap rounds, normalisation), 11-13 sums / argmin / winner tasks, 14-16 winner NCC, 17 messages and
+ * record stores, 18 filter + row end, 23 = number of waves that reported. pm_get_phase_profile returns the first ten
+ * (the generic kernel's coarser split when that kernel ran). */
+#define PM_PROFILE_SLOTS 24
 int pm_enable_phase_profile(pm_handle* h, int enable);
 int pm_get_phase_profile(pm_handle* h, unsigned long long* out10);
+int pm_get_phase_profile_slots(pm_handle* h, unsigned long long* out, int32_t capacity);
 /* Debug: progress trace of the 11 x 11 sweep kernel. When enabled every wave stores the device-wide clock
  * (100 MHz, s_memrealtime) at rows 0, 128, 256, ... of its column group; the buffer holds the last sweep launch. out[group * samples + row / 128]; 0 = not reached. How far the waves of a launch drift apart in
  * the sweep direction decides how much source-image data is in use at a time. */

@@ -73,6 +73,9 @@ def run(a):
         for pm in pms:
             pm.Create()
         tc = time.time() - t
+        if a.profile:
+            for pm in pms:
+                pm.EnablePhaseProfile()
         t = time.time()
         mvs.run_batch(pms, wait=True)
         tr = time.time() - t
@@ -83,6 +86,23 @@ def run(a):
               f"{mpix / tr:.3f} Mpix/s (run), {mpix / (tr + tc):.3f} incl. create; sweep launch avg {ms / max(n, 1):.2f} ms x {n}; "
               f"NCC evaluations per pixel per sweep {sum(e[0] for e in ev) / (batch * w * h * max(n, 1)):.2f}", flush=True)
         print("  per launch ms: " + " ".join(f"{v:.0f}" for v in pms[0].GetSweepTimes()), flush=True)
+        if a.profile:
+            import json
+            tot = {}
+            for pm in pms:
+                for k, v in pm.GetPhaseProfileSlots().items():
+                    tot[k] = tot.get(k, 0) + v
+            waves = tot.pop("waves")
+            cyc = sum(tot.values())
+            out = {"kernel": pms[0].GetSweepKernelName(), "shape": f"{batch} x {w}x{h} S={S}", "sweep_launches": n,
+                   "sweep_launch_ms_avg": ms / max(n, 1), "waves_reported": waves, "cycles_total": cyc,
+                   "cycles_per_wave_row": cyc / max(waves, 1) / (h if True else w),
+                   "share": {k: round(v / cyc, 4) for k, v in tot.items()}, "cycles": tot}
+            print("PHASE_PROFILE " + json.dumps(out), flush=True)
+            if a.profile_out:
+                os.makedirs(os.path.dirname(a.profile_out), exist_ok=True)
+                with open(a.profile_out, "w") as f:
+                    json.dump(out, f, indent=1)
         if rep == a.reps - 1:
             d = pms[0].GetDepthMap()
             print(f"  kept by the filter: {(d > 0).mean():.3f}")
@@ -99,6 +119,8 @@ if __name__ == "__main__":
     ap.add_argument("--ring", type=int, default=100); ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--cols", type=int, default=0); ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--sweeps", type=int, default=0)
+    ap.add_argument("--profile", action="store_true", help="launch the phase-profiling build of the sweep kernel")
+    ap.add_argument("--profile-out", default="")
     a = ap.parse_args()
     if a.mode == "make":
         if a.batch <= 0:
