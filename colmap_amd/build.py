@@ -49,6 +49,27 @@ def _header_deps():
     return deps
 
 
+def _includes_of(src, seen=None):
+    """The in-tree headers `src` includes, transitively (quoted includes resolved against the file's directory, csrc/
+    and include/): an object is rebuilt only when one of THESE is newer, not when any header of the tree is."""
+    import re
+    seen = set() if seen is None else seen
+    inc_root = os.path.join(os.path.dirname(_ROOT), "include")
+    try:
+        text = open(src, errors="replace").read()
+    except OSError:
+        return seen
+    for name in re.findall(r'^\s*#\s*include\s*["<]([^">]+)[">]', text, re.M):
+        for base in (os.path.dirname(src), CSRC, inc_root):
+            path = os.path.normpath(os.path.join(base, name))
+            if os.path.isfile(path) and path.startswith(os.path.dirname(_ROOT)):
+                if path not in seen:
+                    seen.add(path)
+                    _includes_of(path, seen)
+                break
+    return seen
+
+
 def build(force: bool = False, verbose: bool = False, dev: bool = False, out: str = "", incremental: bool = False) -> str:
     """Compiles every source to an object of its own, in parallel, and links them. force: recompile everything;
     incremental: recompile only the objects older than their source or any header (the default call does nothing while
@@ -66,12 +87,12 @@ def build(force: bool = False, verbose: bool = False, dev: bool = False, out: st
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     extra = ["-DCOLMAP_AMD_ENV_SWITCHES", "-DCOLMAP_AMD_DIAG_BUILD"] if dev else []
     flags = [f for f in HIPCC_FLAGS if f != "-shared"] + extra
-    newest_header = max(os.path.getmtime(d) for d in _header_deps())
     jobs, objs = [], []
     for src in _sources():
         obj = os.path.join(obj_dir, os.path.basename(src) + ".o")
         objs.append(obj)
-        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), newest_header):
+        newest = max([os.path.getmtime(src)] + [os.path.getmtime(d) for d in _includes_of(src)])
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > newest:
             continue
         cmd = [hipcc] + flags + ["-c", src, "-o", obj]
         if verbose:

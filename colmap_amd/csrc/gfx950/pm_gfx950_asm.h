@@ -53,6 +53,9 @@ __device__ __forceinline__ void reduce16x3(float& a, float& b, float& c) {
 // statement sits in (the sweep kernels re-derive their per-lane indices per row instead of holding them in VGPRs
 // across the NCC loop, which needs the registers).
 __device__ __forceinline__ void launder_vgpr(int& v) { asm volatile("" : "+v"(v)); }
+// The same for an LDS address: what follows addresses relative to this one register (small immediate offsets)
+// instead of re-deriving base + constant per access.
+__device__ __forceinline__ void launder_lds(const __attribute__((address_space(3))) float*& v) { asm volatile("" : "+v"(v)); }
 
 // MUBUF load with index and offset (buffer_load_dword ... idxen offen) through a buffer resource: no builtin for
 // struct buffer loads in this clang, the intrinsic is reachable by name.

@@ -468,6 +468,7 @@ struct pm_handle {
   DevBuf<uint8_t> ref_img;
   DevBuf<float> ref_sum, ref_sqsum;
   DevBuf<uint32_t> rng;
+  DevBuf<float> draws;  // the random numbers of one sweep per pixel (pm_draw_kernel), shapes served by the 11 x 11 kernel
   DevBuf<uint8_t> mask;
   DevBuf<float> poses;  // [4][S][43]
   DevBuf<float> out_depth, out_normal, out_sel, out_cost;
@@ -823,6 +824,17 @@ void Create(const pm_options& opt_in, const pm_problem& prob, pm_image_cache* ca
   b.ref_sqsum = h->ref_sqsum.ptr;
   b.rng = h->rng.ptr;
   b.mask = nullptr;
+  b.draws = nullptr;
+  {
+    // the 11 x 11 kernel reads the sweep's random numbers from a per-pixel table (one column per wave is the
+    // shape RunBatchAsync may lower to; if that fits the workgroup's LDS budget the table is needed)
+    PmParams probe = b;
+    probe.C = 1;
+    if (pm_sweep_uses_draws(probe, opt.geom_consistency != 0)) {
+      h->draws.alloc((size_t)W * H * pm_draw_stride(b.num_samples));
+      b.draws = h->draws.ptr;
+    }
+  }
 
   PmParams p0 = ParamsForSweep(h, 0);
   if (opt.geom_consistency) {
@@ -886,6 +898,11 @@ void RunBatchAsync(pm_handle** hs, int n) {
   // (mvs/patch_match.cc:190-204) -- then has 960 .. 1 280 waves for 4 096 slots: with fewer than ~3/4 of the slots
   // covered by everything alive on the device, one column per wave doubles the waves. The results do not depend
   // on C (tests: group shapes); an explicit columns_per_group is respected.
+  // One launch geometry for the batch: the columns per wave of THIS run are a property of the run (every parameter
+  // block of the run carries it), never written back to a handle -- a handle re-run in another batch, or traced, sees
+  // its own shape again.
+  int run_C = h0->base.C;
+  for (int b = 1; b < n; ++b) run_C = std::min(run_C, hs[b]->base.C);
   {
     bool automatic = h0->base.ntaps == 121;
     for (int b = 0; b < n; ++b) automatic = automatic && hs[b]->opt.columns_per_group <= 0;
@@ -902,7 +919,7 @@ void RunBatchAsync(pm_handle** hs, int n) {
       const long long waves2 = (long long)alive * ((std::min(h0->W, h0->H) + 1) / 2);
       // (images too small to fill the GPU either way keep the common shape: their time is launch latency)
       const int C = (std::min(h0->W, h0->H) >= 512 && waves2 * 4 < slots * 3) ? 1 : 2;
-      for (int b = 0; b < n; ++b) hs[b]->base.C = std::min(hs[b]->base.C, C);
+      run_C = std::min(run_C, C);
     }
   }
   const int total_sweeps = opt.num_iterations * 4;
@@ -910,7 +927,10 @@ void RunBatchAsync(pm_handle** hs, int n) {
                                        : (opt.max_sweeps < 0 ? 0 : total_sweeps);
   // parameter blocks: [initial cost | sweep 0 | ... | sweep limit-1] x n problems
   std::vector<PmParams> host((size_t)(limit + 1) * n);
-  for (int b = 0; b < n; ++b) host[b] = ParamsForSweep(hs[b], 0);
+  for (int b = 0; b < n; ++b) {
+    host[b] = ParamsForSweep(hs[b], 0);
+    host[b].C = run_C;
+  }
   const float total_num_steps = (float)total_sweeps;
   // workgroup -> (problem, column group) mapping of a batched sweep launch (pm_sweep_kernel)
   const int xcd_map_env = dev_switch_int("COLMAP_AMD_PM_XCD_MAP", 0);
@@ -937,6 +957,7 @@ void RunBatchAsync(pm_handle** hs, int n) {
       p.sel_out_off = sel_out;
       p.sel_in_off = sel_in;
       p.xcd_map = xcd_map;
+      p.C = run_C;
 #ifdef COLMAP_AMD_DIAG_BUILD
       p.ablate = dev_switch_int("COLMAP_AMD_PM_ABLATE", 0);  // profiling builds only: results are garbage
 #else
@@ -1323,7 +1344,7 @@ int pm_enable_progress_trace(pm_handle* h, int enable) {
     if (enable) {
       const int longest = std::max(h->W, h->H);
       h->base.trace_stride = longest / 128 + 2;
-      const size_t groups = (size_t)(longest + h->base.C - 1) / h->base.C;
+      const size_t groups = (size_t)longest;  // one column per wave is the finest launch shape (RunBatchAsync may choose it)
       h->trace.alloc(groups * h->base.trace_stride);
       HIP_CALL(hipMemset(h->trace.ptr, 0, groups * h->base.trace_stride * sizeof(unsigned long long)));
       h->base.trace = h->trace.ptr;

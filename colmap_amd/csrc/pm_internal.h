@@ -82,6 +82,8 @@ struct PmParams {
   const float* ref_sum;     // [H][W]
   const float* ref_sqsum;   // [H][W]
   uint32_t* rng;            // [H*W][6]
+  float* draws;             // [rot H][rot W][pm_draw_stride]: the sweep's random numbers per pixel of the sweep frame
+                            // (pm_draw_kernel -> 11 x 11 sweep kernel), or null: the generic kernel draws in place
   uint8_t* mask;            // [S][H][W] or null
   const float* poses;       // [S][43] for this rotation
   unsigned long long* prof; // optional phase-cycle counters [kPmProfSlots] (debug), else null
@@ -92,6 +94,10 @@ struct PmParams {
   int trace_stride;          // samples per column group
 };
 
+// floats per pixel of PmParams::draws: perturbed depth, perturbed normal, M uniforms (whole float4s)
+__host__ __device__ inline int pm_draw_stride(int M) { return 4 + ((M + 3) & ~3); }
+// does the sweep of this shape run the 11 x 11 kernel that reads PmParams::draws?
+bool pm_sweep_uses_draws(const PmParams& p, bool geom);
 size_t pm_sweep_lds_bytes(const PmParams& p, bool geom);
 int pm_pick_columns(int S, int ntaps, int num_samples, bool geom, int radius, int requested);
 

@@ -742,7 +742,10 @@ struct Lds {
   lds_f32* costv;   // [C][S] cost_map values of this row
   lds_f32* betav;   // [C][S] backward messages of this row
   lds_f32* prevv;   // [C][S] previous sel probs of this row
-  lds_f32* ncc;     // [C][5][S] NCC per hypothesis/view, < 0: not computed
+  lds_f32* ncc;     // [C][5][S] NCC per hypothesis/view, < 0: not computed (generic kernel)
+  lds_f32* cost5;   // wave kernel: [C][5][S + 1] cost-map row (hypothesis 0), NCC of hypotheses 1..4; slot S of a row = 0
+  lds_u32* drawn;   // wave kernel: [C][(S + 31) / 32] bitmap of the views drawn in this row
+  lds_u32* desc;    // wave kernel: [cap] pass-B descriptor per slot of the batch (run_tasks_wave)
   lds_f32* geo;     // [C][5][S] geometric cost (GEOM only)
   lds_f32* hyp;     // [C][5][4] depth, normal
   lds_f32* colf;    // [C][8] ref_sum, ref_sqsum, point[3], pad
@@ -754,14 +757,15 @@ struct Lds {
   lds_u32* tasks;
   lds_f32* th;      // [max_tasks][9] homography of each queued NCC task
   lds_i32* ntasks;
-  lds_f32* tapg;    // wave kernel: [2][8][16] window offsets (dx, dy) of tap j + 16 k, times step
+  lds_f32* tapg;    // wave kernel: [4][128] tap tables (tap_tables_init)
   lds_u32* ring;    // wave kernel: [2][8][64] landing zone of the footprint gathers
-  LDS_AS uint8_t* tin;  // wave kernel: [kWaveThCap] 1 = every tap of the task's patch is inside the image
+  LDS_AS uint8_t* tin;  // (unused: the wave kernel's Lds::desc lives at this offset)
 };
 
 struct LdsOffsets {
   uint32_t poses, fpb, tile, wgt, refc, fm, q, costv, betav, prevv, ncc, geo, hyp, colf, us, sv, best, csum,
       flags, tasks, th, ntasks, tapg, ring, tin, total;
+  uint32_t drawn = 0;
   uint32_t priv_stride = 0;  // multi-wave sweep kernel: bytes between the private regions of consecutive waves
 };
 
@@ -835,6 +839,9 @@ __device__ __forceinline__ void lds_bind(Lds& L, lds_char* base, const LdsOffset
   L.betav = (lds_f32*)(base + o.betav);
   L.prevv = (lds_f32*)(base + o.prevv);
   L.ncc = (lds_f32*)(base + o.ncc);
+  L.cost5 = (lds_f32*)(base + o.ncc);
+  L.drawn = (lds_u32*)(base + o.drawn);
+  L.desc = (lds_u32*)(base + o.tin);
   L.geo = (lds_f32*)(base + o.geo);
   L.hyp = (lds_f32*)(base + o.hyp);
   L.colf = (lds_f32*)(base + o.colf);
@@ -1063,24 +1070,6 @@ __device__ __forceinline__ int run_tasks(const PmParams& p, const Lds& L, int ro
 struct NccStage {  // what the back half needs from the front half besides the texels: the bilinear fractions
   v2f wx[4], wy[4];
 };
-
-// Window offsets (dx, dy) * step of the taps j + 16 k of the 11 x 11 window, as an LDS table
-// [2][8][16] (dx then dy; k; lane j) filled once per workgroup: the 16 lane constants would
-// otherwise occupy 16 VGPRs for the whole kernel. `transpose`: column-major tap order of the odd
-// sweep directions (patch_weights).
-__device__ __forceinline__ void tap_geom_init(lds_f32* tapg, int tid, int step, bool transpose) {
-  for (int idx = tid; idx < 256; idx += 64) {
-    const int j = idx & 15, k = (idx >> 4) & 7, is_dy = idx >> 7;
-    const int t = j + 16 * k;
-    const int tt = t < 121 ? t : 0;
-    int wrow = tt / 11;
-    int wcol = tt - wrow * 11;
-    if (transpose) {
-      const int sw = wrow; wrow = wcol; wcol = sw;
-    }
-    tapg[idx] = (float)((is_dy ? wrow : wcol) * step);
-  }
-}
 
 // ---------------------------------------------------------------------------
 // Packed-image gathers of the 11 x 11 sweep kernels: MUBUF loads through ONE swizzled buffer resource per problem.
@@ -1555,15 +1544,21 @@ __global__ void __launch_bounds__(256, 3) pm_sweep_kernel(const PmParams* __rest
 }
 
 // ---------------------------------------------------------------------------
-// Wave-per-column-group sweep kernels for the 11 x 11 window (sweep_wave_body): every wave owns C adjacent columns
+// Wave-per-column-group sweep kernel for the 11 x 11 window (sweep_wave_body): every wave owns C adjacent columns
 // of the sweep frame and walks them row by row without ever meeting another wave -- the phases of a row step are
-// separated by LDS fences only. Two builds of ONE body: single-wave workgroups (pm_sweep_wave4_kernel) and
-// four-wave workgroups whose waves share one LDS copy of the read-only per-problem tables
-// (pm_sweep_quad_kernel, the default). Other windows take the generic kernel above.
+// separated by LDS fences only. Four waves form a workgroup and share one LDS copy of the read-only per-problem
+// tables (pm_sweep_quad_kernel). Other windows take the generic kernel above.
+//
+// What a row step does NOT do (round 6): everything of the reference's row step that depends only on the state the
+// sweep starts from -- the column's random numbers, i.e. the perturbed depth and normal (:1055-1062) and the M
+// uniforms of the view draws (:1129) -- is produced for all rows by pm_draw_kernel (lane per column, 64 columns per
+// wave instead of 2 of 64 lanes) into PmParams::draws before the sweep launch. The lane-per-column steps that remain
+// (CDF, argmin) are sequential sums the reference's order pins; draws, task lists and the Monte-Carlo sums are
+// organised so that no lane loops over what another lane could hold (binary search in the CDF, a drawn-view bitmap,
+// ballots instead of atomics, zero slots instead of "no view" branches).
 // ---------------------------------------------------------------------------
-constexpr int kWaveThCap = 40;  // NCC task slots per batch of the single-wave build (homography ring in LDS)
-constexpr int kQuadWaves = 4;   // waves per workgroup of the default build ...
-constexpr int kQuadThCap = 64;  // ... and its task slots per batch (the shared tables make room for them)
+constexpr int kQuadWaves = 4;   // waves per workgroup
+constexpr int kQuadThCap = 64;  // NCC task slots per batch (homographies in LDS)
 
 __device__ __forceinline__ uint32_t task16_pack(int c, int i, int s, int geom_only) {
   return ((uint32_t)c << 13) | ((uint32_t)geom_only << 12) | ((uint32_t)i << 9) | (uint32_t)s;
@@ -1576,7 +1571,7 @@ __host__ __device__ inline int wave_max_tasks(int C, int S, int M) {
 }
 
 // LDS carve-up of a workgroup of `nw` waves, each sweeping its own column group. The read-only tables that are
-// the same for every column group of a problem -- pose records, packed-image slots, tap-offset table: 2.6 KB at
+// the same for every column group of a problem -- pose records, packed-image slots, tap tables: 3.7 KB at
 // S = 20 -- exist once per workgroup at the start of the block; everything else is private to a wave and repeats
 // with `priv_stride` (the offsets of the private items are those of wave 0). `cap` = NCC task slots per batch.
 __host__ __device__ inline LdsOffsets lds_offsets_wave(int C, int S, int radius, int ntaps, int M, bool geom,
@@ -1594,34 +1589,99 @@ __host__ __device__ inline LdsOffsets lds_offsets_wave(int C, int S, int radius,
   o.ring = 0;
   o.poses = take(4u * S * lds_pose_stride(geom));
   o.fpb = take(8u * S);                       // packed images: 32-bit slots of the buffer resource (Lds::fpo) or addresses (fpb)
-  o.tapg = take(4u * 256);
+  o.tapg = take(4u * 512);                    // tap tables: dx, dy (NCC warp), packed tile offsets, spatial exponent (patch weights)
   const uint32_t shared = off;
   o.tile = take(4u * win * tw);
   o.wgt = take(4u * C * tap_stride(ntaps));
   o.refc = take(4u * C * tap_stride(ntaps));
   o.fm = take(4u * C * S);
   o.q = take(4u * C * S);
-  o.costv = take(4u * C * S);
   o.betav = take(4u * C * S);
   o.prevv = take(4u * C * S);
-  o.ncc = take(4u * C * 4 * S);               // hypotheses 1..4 (0 is the cached cost map)
-  o.geo = take(geom ? 4u * C * 5 * S : 0u);
+  o.ncc = take(4u * C * 5 * (S + 1));         // Lds::cost5: [C][5][S + 1] cost map row (hypothesis 0), NCC of hypotheses 1..4, zero slot
+  o.costv = o.ncc;
+  o.geo = take(geom ? 4u * C * 5 * (S + 1) : 0u);
   o.hyp = take(4u * C * 20);
   o.colf = take(4u * C * 8);
-  const uint32_t us_bytes = 4u * C * M > 1u * C * S ? 4u * C * M : 1u * C * S;
-  o.us = take(us_bytes);
-  o.flags = o.us;                             // filter flags reuse the (then dead) uniform draws
+  o.flags = take(1u * C * S);                 // filter flags
+  o.us = o.flags;
   o.sv = take(4u * C * M);
   o.best = take(4u * C);
   o.csum = take(4u * C * 5);
+  o.drawn = take(4u * C * ((S + 31) / 32));   // bitmap of the views drawn in this row
   o.tasks = take(2u * max_tasks + (geom ? 2u * C * S : 0u));  // 16-bit task words: NCC tasks, then
                                                               // (GEOM) the geometric-cost-only list
   o.th = take(36u * (uint32_t)cap);
-  o.ntasks = take(16u);
-  o.tin = take(2u * (uint32_t)cap);  // [0, cap): inside flags; [cap, 2 cap): task order of the batch (inside first)
+  o.ntasks = 0;
+  o.tin = take(4u * (uint32_t)cap);           // Lds::desc: pass-B descriptor per slot of the batch (inside-first order)
   o.priv_stride = off - shared;
   o.total = shared + (uint32_t)nw * o.priv_stride;
   return o;
+}
+
+// Tap tables of the 11 x 11 window, [4][128] in LDS, filled once per workgroup; tap t = wrow * 11 + wcol, or with
+// `transpose` (odd sweep directions, patch_weights) t = wcol * 11 + wrow:
+//   [0]   (float) wcol * step        window offsets of the NCC warp (ncc_front reads taps j + 16 k)
+//   [1]   (float) wrow * step
+//   [2]   (int)   (wrow * step) << 16 | wcol * step                  tile offsets of the patch-weight pass
+//   [3]   (float) -(wr^2 + wc^2) * spatial_norm, wr = wrow * step - radius: the spatial term of the bilateral weight
+//         (BilateralWeightComputer::Compute, gpu_mat_ref_image.h:70-90: the same product, taken once per kernel)
+__device__ __forceinline__ void tap_tables_init(lds_f32* tapg, int tid, int nthreads, int step, int radius,
+                                                float spatial_norm, bool transpose) {
+  for (int t = tid; t < 128; t += nthreads) {
+    const int tt = t < 121 ? t : 0;
+    int wrow = tt / 11;
+    int wcol = tt - wrow * 11;
+    if (transpose) {
+      const int sw = wrow; wrow = wcol; wcol = sw;
+    }
+    tapg[t] = (float)(wcol * step);
+    tapg[128 + t] = (float)(wrow * step);
+    ((lds_i32*)tapg)[256 + t] = ((wrow * step) << 16) | (wcol * step);
+    const float wr = (float)(wrow * step - radius), wc = (float)(wcol * step - radius);
+    const float sds = wr * wr + wc * wc;
+    tapg[384 + t] = -sds * spatial_norm;
+  }
+}
+
+// item / n for 0 <= item < 4096, n <= 512 with inv_n = 1.0f / n (one IEEE division per kernel): the quotient's
+// fraction lies in [0.5 / n, 1 - 0.5 / n], far from the 2^-21 the float product can be off by.
+__device__ __forceinline__ int item_div(int item, float inv_n) { return (int)(((float)item + 0.5f) * inv_n); }
+
+// lanes of the wave below this one whose bit is set in `mask`
+__device__ __forceinline__ int lanes_below(unsigned long long mask) {
+  return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// Load one sweep-frame row of the reference image into ring slot `slot` of the LDS tile.
+__device__ __forceinline__ void tile_load_row_slot(const PmParams& p, const Lds& L, int col0, int row, int slot,
+                                                   int tid) {
+  const int tw = p.C + 2 * p.radius;
+  for (int lc = tid; lc < tw; lc += 64) L.tile[slot * tw + lc] = ref_texel(p, row, col0 - p.radius + lc);
+}
+
+// Bilateral weights + reference colours of the patches centred on (row, col0 + c), 11 x 11 window (patch_weights
+// with the per-tap integer divisions and the spatial term taken from the tap tables). slot_c / slot_top = ring slots
+// of rows `row` and `row - radius`. Taps 121..127 of every column keep the zeros written once before the row loop.
+__device__ __forceinline__ void patch_weights_wave(const PmParams& p, const Lds& L, int slot_c, int slot_top,
+                                                   int tid) {
+  const int win = 2 * p.radius + 1;
+  const int tw = p.C + 2 * p.radius;
+  const lds_i32* tapi = (const lds_i32*)L.tapg + 256;
+  const lds_f32* taps = L.tapg + 384;
+  for (int item = tid; item < p.C * 128; item += 64) {
+    const int c = item >> 7;
+    const int tap = item & 127;
+    if (tap >= 121) continue;
+    const int ti = tapi[tap];
+    int slot = slot_top + (ti >> 16);
+    if (slot >= win) slot -= win;
+    const float center = L.tile[slot_c * tw + c + p.radius];
+    const float color = L.tile[slot * tw + c + (ti & 0xffff)];
+    const float cd = center - color;
+    L.wgt[item] = pm_exp(taps[tap] - cd * cd * p.color_norm);
+    L.refc[item] = color;
+  }
 }
 
 // Does every tap of the patch with (centred) homography Hm provably fall on texels x in [0, w - 1],
@@ -1631,18 +1691,27 @@ __host__ __device__ inline LdsOffsets lds_offsets_wave(int C, int S, int radius,
 __device__ __forceinline__ bool patch_inside(const PmParams& p, const float Hm[9]) {
   // With z > 0 at a corner, 1 <= x / z <= w - 2 is z <= x <= (w - 2) z: eight divisions saved per task. The
   // flag only selects the addressing variant of the gathers (both give the same texels for a patch that is
-  // inside; the one-texel margin dwarfs the rounding of the products), it never changes a result.
+  // inside; the one-texel margin dwarfs the rounding of the products), it never changes a result -- so the corner
+  // values are taken incrementally (two products and three sums per coordinate instead of eight and eight).
   const float e = (float)(2 * p.radius);  // window extent: taps at offsets 0 .. 2 r
   const float wx = (float)(p.src_w - 2), wy = (float)(p.src_h - 2);
+  float x[4], y[4], z[4];
+  {
+    const float a = Hm[0] * e, b = Hm[1] * e;
+    x[0] = Hm[2]; x[1] = a + x[0]; x[2] = b + x[0]; x[3] = a + x[2];
+  }
+  {
+    const float a = Hm[3] * e, b = Hm[4] * e;
+    y[0] = Hm[5]; y[1] = a + y[0]; y[2] = b + y[0]; y[3] = a + y[2];
+  }
+  {
+    const float a = Hm[6] * e, b = Hm[7] * e;
+    z[0] = Hm[8]; z[1] = a + z[0]; z[2] = b + z[0]; z[3] = a + z[2];
+  }
   bool ok = true;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const float dx = (k & 1) ? e : 0.0f, dy = (k & 2) ? e : 0.0f;
-    const float z = Hm[6] * dx + Hm[7] * dy + Hm[8];
-    const float x = Hm[0] * dx + Hm[1] * dy + Hm[2];
-    const float y = Hm[3] * dx + Hm[4] * dy + Hm[5];
-    ok = ok && (z > 0.0f) && x >= z && y >= z && x <= wx * z && y <= wy * z;
-  }
+  for (int k = 0; k < 4; ++k)
+    ok = ok && (z[k] > 0.0f) && x[k] >= z[k] && y[k] >= z[k] && x[k] <= wx * z[k] && y[k] <= wy * z[k];
   return ok;
 }
 
@@ -1660,26 +1729,24 @@ __device__ __forceinline__ void wave_sync() {
   }
 }
 
-// Run the queued NCC tasks (and, with GEOM, the geometric-cost-only list) of one phase.
+// Run the `n` queued NCC tasks (and, with GEOM, the `ng` entries of the geometric-cost-only list) of one phase.
 template <bool GEOM, int NW, int CAP, bool MUBUF, bool PROF>
 __device__ __forceinline__ void run_tasks_wave(const PmParams& p, const Lds& L, const v4i srd, int row, int col0,
-                                               int tid, unsigned& evals, unsigned long long* prof_acc,
+                                               int tid, int n, int ng, unsigned& evals, unsigned long long* prof_acc,
                                                unsigned long long& prof_t, const int prof_slot0) {
   const lds_f32* G = L.tapg;
-  const int n = L.ntasks[0];
   evals += (unsigned)n;
   const LDS_AS uint16_t* tasks = (const LDS_AS uint16_t*)L.tasks;
   const int g = tid >> 4, j = tid & 15;
-  const int S = p.S;
+  const int S = p.S, S1 = p.S + 1;
   if (GEOM) {
     // geometric consistency cost of hypothesis 0 against the drawn views (no NCC: cached cost map)
-    const int ng = L.ntasks[1];
     const LDS_AS uint16_t* gtasks = tasks + wave_max_tasks(p.C, S, p.num_samples);
     for (int t = tid; t < ng; t += 64) {
       const uint32_t task = gtasks[t];
       const int c = task >> 13, i = (task >> 9) & 7, s = task & 0x1ff;
       const lds_f32* h = L.hyp + (c * 5 + i) * 4;
-      L.geo[(c * 5 + i) * S + s] = geom_cost(p, L.poses + s * L.pstride, s, (float)row, (float)(col0 + c), h[0]);
+      L.geo[(c * 5 + i) * S1 + s] = geom_cost(p, L.poses + s * L.pstride, s, (float)row, (float)(col0 + c), h[0]);
     }
   }
   // slot offset of texel (0, 0) relative to entry (0, 0): one strip (kFpRingX entries) and kFpRingY rows
@@ -1690,6 +1757,7 @@ __device__ __forceinline__ void run_tasks_wave(const PmParams& p, const Lds& L, 
     PM_MARK("passA");
     // pass A, lane per task: homography of the (hypothesis, view) pair (+ geometric cost)
     bool inside = false;
+    uint32_t desc = 0;
     if (tid < nb) {
       const uint32_t task = tasks[base + tid];
       const int c = task >> 13;
@@ -1703,20 +1771,19 @@ __device__ __forceinline__ void run_tasks_wave(const PmParams& p, const Lds& L, 
       centre_homography(Hm, row, col, p.radius);
       for (int k = 0; k < 9; ++k) L.th[tid * 9 + k] = Hm[k];
       inside = patch_inside(p, Hm);
-      L.tin[tid] = inside ? 1 : 0;
-      if (GEOM) L.geo[(c * 5 + i) * S + s] = geom_cost(p, pose, s, (float)row, (float)col, h[0]);
+      desc = (uint32_t)tid | (inside ? 0x80u : 0u) | ((uint32_t)c << 8) | ((uint32_t)s << 16);
+      if (GEOM) L.geo[(c * 5 + i) * S1 + s] = geom_cost(p, pose, s, (float)row, (float)col, h[0]);
     }
     {
       // Order of the batch's tasks for pass B: the tasks whose patch is inside the source image first. A round
       // takes the cheaper unclamped addressing only when all four of its patches are inside; with the tasks in
       // list order one outside patch in four spoils the round, sorted they collect in the last rounds. Results
-      // are stored per task, so the order cannot change a bit.
+      // are stored per task, so the order cannot change a bit. A slot's descriptor = everything pass B needs to
+      // know about its task: slot of the homography (bits 0-5), inside flag (7), column (8-15), view (16-).
       const unsigned long long m1 = __ballot(inside ? 1 : 0);
       const unsigned long long valid = nb >= 64 ? ~0ull : ((1ull << nb) - 1ull);
       const unsigned long long m0 = valid & ~m1;
-      const unsigned long long below = (1ull << tid) - 1ull;
-      if (tid < nb)
-        L.tin[CAP + (inside ? __popcll(m1 & below) : __popcll(m1) + __popcll(m0 & below))] = (uint8_t)tid;
+      if (tid < nb) L.desc[inside ? lanes_below(m1) : __popcll(m1) + lanes_below(m0)] = desc;
     }
     wave_sync<NW>();
     // pass B, 16-lane group per task: one round = four tasks; all eight gathers of a lane are in flight before
@@ -1730,28 +1797,30 @@ __device__ __forceinline__ void run_tasks_wave(const PmParams& p, const Lds& L, 
       for (int r = 0; r < rounds; ++r) {
         const int tr = g + 4 * r;
         const bool own = tr < nb;
-        const int t = L.tin[CAP + (own ? tr : nb - 1)];
-        const uint32_t task = tasks[base + t];
-        const int c = task >> 13;
+        const uint32_t d = L.desc[own ? tr : nb - 1];
         // wave-uniform: the unclamped addressing only when all four patches of the round are inside
         // (a recomputed task may already hold its sums instead of its homography: it must take the
         // clamping path, where any coordinate is safe and the result is dropped)
-        const bool fast = __all(own && L.tin[t] != 0) != 0;
-        const uint32_t slot = MUBUF ? L.fpo[task & 0x1ff] : 0u;
-        gbl_u32* gbase = MUBUF ? nullptr : (gbl_u32*)L.fpb[task & 0x1ff];
+        const bool fast = __all(own && (d & 0x80u) != 0u) != 0;
+        const uint32_t slot = MUBUF ? L.fpo[d >> 16] : 0u;
+        gbl_u32* gbase = MUBUF ? nullptr : (gbl_u32*)L.fpb[d >> 16];
+        const lds_f32* H = L.th + (d & 63u) * 9u;
+        launder_lds(H);  // one address register for the nine reads (offsets 0..32) instead of a base + constant each
         NccStage A;
         uint32_t tex[8];
-        if (fast) ncc_front<true, MUBUF>(p, srd, L.th + t * 9, slot + origin, gbase + gorigin, G, j, A, tex);
-        else ncc_front<false, MUBUF>(p, srd, L.th + t * 9, slot, gbase, G, j, A, tex);
+        if (fast) ncc_front<true, MUBUF>(p, srd, H, slot + origin, gbase + gorigin, G, j, A, tex);
+        else ncc_front<false, MUBUF>(p, srd, H, slot, gbase, G, j, A, tex);
         __builtin_amdgcn_sched_barrier(0);
         TapRegs R;
-        tap_regs_load(R, L.wgt + c * 128, L.refc + c * 128, j);
+        const int c128 = (int)((d >> 8) & 0xffu) * 128;
+        tap_regs_load(R, L.wgt + c128, L.refc + c128, j);
         float s_sum, s_sq, s_ref;
         ncc_back(A, tex, R, j, s_sum, s_sq, s_ref);
         if (j == 0 && own) {
-          L.th[t * 9 + 0] = s_sum;  // the homography of this task is no longer needed
-          L.th[t * 9 + 1] = s_sq;
-          L.th[t * 9 + 2] = s_ref;
+          lds_f32* Hw = L.th + (d & 63u) * 9u;
+          Hw[0] = s_sum;  // the homography of this task is no longer needed
+          Hw[1] = s_sq;
+          Hw[2] = s_ref;
         }
       }
     }
@@ -1764,15 +1833,15 @@ __device__ __forceinline__ void run_tasks_wave(const PmParams& p, const Lds& L, 
       const int c = task >> 13;
       const int i = (task >> 9) & 7;
       const int s = task & 0x1ff;
-      L.ncc[(c * 4 + i - 1) * S + s] = ncc_finish(L.th[tid * 9 + 0], L.th[tid * 9 + 1], L.th[tid * 9 + 2],
-                                                  L.colf[c * 8 + 0], L.colf[c * 8 + 1], L.colf[c * 8 + 5]);
+      L.cost5[(c * 5 + i) * S1 + s] = ncc_finish(L.th[tid * 9 + 0], L.th[tid * 9 + 1], L.th[tid * 9 + 2],
+                                                 L.colf[c * 8 + 0], L.colf[c * 8 + 1], L.colf[c * 8 + 5]);
     }
     wave_sync<NW>();
     PM_PROF_MARK(prof_slot0 + 1)
   }
 }
 
-// Phase profile of the wave kernels (PROF instantiation, pm_enable_phase_profile): every wave accumulates shader-clock
+// Phase profile of the wave kernel (PROF instantiation, pm_enable_phase_profile): every wave accumulates shader-clock
 // deltas per phase in scalar registers and adds them to p.prof[] when it retires. Slots:
 constexpr int kProfSetup = 0, kProfP0 = 1, kProfP1 = 2, kProfP1w = 3, kProfP2 = 4, kProfP3a = 5, kProfP3b = 6,
               kProfP3c = 7, kProfP4A = 8, kProfP4B = 9, kProfP4F = 10, kProfP5a = 11, kProfP5b = 12, kProfP5c = 13,
@@ -1788,7 +1857,7 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   Lds L;
   // NW > 1: wave w of the workgroup sweeps column group NW * group + w out of its own LDS region; the pose
-  // records, packed-image slots and tap offsets are shared (lds_offsets_wave). After the one workgroup barrier
+  // records, packed-image slots and tap tables are shared (lds_offsets_wave). After the one workgroup barrier
   // behind their initialisation the waves never meet again: every later synchronisation point is
   // wave_sync<NW>(), a memory fence without s_barrier -- exactly what __syncthreads() compiles to in the
   // single-wave workgroups.
@@ -1806,12 +1875,18 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
   const int tid = tid_entry;
   constexpr int nt = 64;
   const int S = p.S, M = p.num_samples, C = p.C;
+  const int S1 = S + 1;            // row length of cost5 / geo: S views + the zero slot a draw without a view reads
+  const int DW = (S + 31) >> 5;    // words per column of the drawn-view bitmap
+  const float inv_S = 1.0f / (float)S, inv_M = 1.0f / (float)M;
   const int RW = rot_width(p), RH = rot_height(p);
   const int col0 = group * C;
   const int ncols = min(C, RW - col0);
+  const int win = 2 * p.radius + 1;
   const float* iK = p.refInvK;
   const v4i srd = MUBUF ? fp_resource(p) : (v4i)(0);
-  if (wave == 0) tap_geom_init(L.tapg, tid, p.step, (p.rot & 1) != 0);
+  gbl_f32* draws = (gbl_f32*)p.draws;
+  const int dstride = pm_draw_stride(M);
+  if (wave == 0) tap_tables_init(L.tapg, tid, 64, p.step, p.radius, p.spatial_norm, (p.rot & 1) != 0);
   {
     // pose records and packed-image slots, once per workgroup
     L.pstride = lds_pose_stride(GEOM);
@@ -1831,7 +1906,7 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
 
   // ---- backward messages for all rows (:976-989); stored in sel_out ----------
   for (int item = tid; item < ncols * S; item += nt) {
-    const int c = item / S;
+    const int c = item_div(item, inv_S);
     const int s = item - c * S;
     float beta = 0.5f;
     for (int row = (PM_ABLATE(p) & 4) ? -1 : RH - 1; row >= 0; --row) {
@@ -1842,18 +1917,23 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
     L.fm[c * S + s] = 0.5f;
   }
 
-  // ---- per-column state kept by the column's lane (:1022-1028) ---------------
-  Rng rng;
-  rng.x0 = rng.x1 = rng.x2 = rng.x3 = rng.x4 = rng.d = 0;
-  const bool col_lane = tid < ncols;
-  if (col_lane) {
+  // ---- per-column state kept across rows: the previous row's plane (:1022-1028) ----
+  if (tid < ncols) {
     const int pix0 = pix_index(p, 0, col0 + tid);
-    rng = rng_load(p.rng + (size_t)pix0 * kRngWords);
     const float* rec = p.rec + (size_t)pix0 * p.rec_stride;
     float sx, sy;
     normal_to_sweep(p.rot, rec[1], rec[2], sx, sy);
     lds_f32* h1 = L.hyp + (tid * 5 + 1) * 4;
     h1[0] = rec[0]; h1[1] = sx; h1[2] = sy; h1[3] = rec[3];
+  }
+  // written once: the zero slots behind the S views of every (column, hypothesis) row and the seven padding taps
+  for (int i = tid; i < C * 5; i += nt) {
+    L.cost5[i * S1 + S] = 0.0f;
+    if (GEOM) L.geo[i * S1 + S] = 0.0f;
+  }
+  for (int i = tid; i < C * 8; i += nt) {
+    const int at = (i >> 3) * 128 + 120 + (i & 7);
+    if ((i & 7) != 0) { L.wgt[at] = 0.0f; L.refc[at] = 0.0f; }
   }
   for (int r = -p.radius; r < p.radius; ++r) tile_load_row(p, L, col0, r, tid, nt);
   wave_sync<NW>();
@@ -1862,6 +1942,9 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
   unsigned long long prof_acc[kProfSlots] = {};
   unsigned long long prof_t = PROF ? __builtin_readcyclecounter() : 0ull;
   unsigned evals = 0;  // NCC evaluations of this wave (< 2^32: RH * C * (4 M + S) per sweep)
+  // ring slots of the tile rows row - radius, row, row + radius (advance by one per row, modulo the window)
+  int slot_top = p.radius + 1 == win ? 0 : p.radius + 1, slot_c = 0, slot_new = p.radius;
+  const int step0 = 1 << (31 - __builtin_clz(S));  // largest power of two <= S (CDF search)
   for (int row = 0; row < RH; ++row) {
     // The lane id is laundered through an empty asm once per row: everything the phases derive from
     // it (item -> column / view, LDS addresses) is then recomputed per row instead of being hoisted
@@ -1874,30 +1957,25 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
     PM_PROF_MARK(row == 0 ? kProfSetup : kProfP8)
     PM_MARK("P0");
     // ---- P0: scroll the reference tile (LocalRefImage::Read, :357-410) -------
-    tile_load_row(p, L, col0, row + p.radius, tid, nt);
-    if (tid == 0) { L.ntasks[0] = 0; L.ntasks[1] = 0; }
+    tile_load_row_slot(p, L, col0, row + p.radius, slot_new, tid);
     wave_sync<NW>();
 
     PM_PROF_MARK(kProfP0)
     PM_MARK("P1");
-    // ---- P1: hypotheses (lane per column) + patch weights (all lanes) --------
+    // ---- P1: hypotheses, lane per column (:1047-1068); the random ones come from pm_draw_kernel ----
     if (col_lane && !(PM_ABLATE(p) & 2)) {
       const int c = tid;
       const int col = col0 + c;
       const int pix = pix_index(p, row, col);
       const float* rec = p.rec + (size_t)pix * p.rec_stride;
+      gbl_f32* dr = draws + ((size_t)row * RW + col) * dstride;
       lds_f32* h = L.hyp + c * 20;
       h[4] = propagate_depth(iK, h[4], h[6], h[7], (float)(row - 1), (float)row);
       const float cd = rec[0];
       float cn0, cn1;
       normal_to_sweep(p.rot, rec[1], rec[2], cn0, cn1);
       const float cn2 = rec[3];
-      const float dmin = (1.0f - p.perturbation) * cd;
-      const float dmax = (1.0f + p.perturbation) * cd;
-      const float rd = rng_uniform(rng) * (dmax - dmin) + dmin;
-      float rn0, rn1, rn2;
-      perturb_normal(iK, row, col, p.perturbation_pi, cn0, cn1, cn2, rng, rn0, rn1, rn2);
-      for (int m = 0; m < M; ++m) L.us[c * M + m] = rng_uniform(rng) - FLT_EPSILON;  // :1129
+      const float rd = dr[0], rn0 = dr[1], rn1 = dr[2], rn2 = dr[3];
       h[0] = cd; h[1] = cn0; h[2] = cn1; h[3] = cn2;
       h[8] = rd; h[9] = rn0; h[10] = rn1; h[11] = rn2;
       h[12] = cd; h[13] = rn0; h[14] = rn1; h[15] = rn2;
@@ -1911,8 +1989,8 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
     }
     PM_PROF_MARK(kProfP1)
     PM_MARK("P1w");
-    patch_weights(p, L, row, tid, nt);
-    for (int item = tid; item < ncols * 4 * S; item += nt) L.ncc[item] = -1.0f;
+    patch_weights_wave(p, L, slot_c, slot_top, tid);
+    if (tid < ncols * DW) L.drawn[tid] = 0u;
     wave_sync<NW>();
     PM_PROF_MARK(kProfP1w)
     PM_MARK("P2");
@@ -1920,7 +1998,7 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
     // ---- P2: per-view selection priors (:1070-1104), lane per (column, view) --
     patch_weight_sums(p, L, ncols, tid, nt);
     for (int item = tid; item < ncols * S; item += nt) {
-      const int c = item / S;
+      const int c = item_div(item, inv_S);
       const int s = item - c * S;
       const int col = col0 + c;
       const float* rec = p.rec + (size_t)pix_index(p, row, col) * p.rec_stride;
@@ -1930,7 +2008,7 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
       const float cost = rec[4 + s];
       const float beta = rec[p.sel_out_off + s];
       const float prev = rec[p.sel_in_off + s];
-      L.costv[item] = cost;
+      L.cost5[c * 5 * S1 + s] = cost;
       L.betav[item] = beta;
       L.prevv[item] = prev;
       const float alpha = hmm_message<true>(p, cost, L.fm[item]);
@@ -1966,36 +2044,62 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
     wave_sync<NW>();
     PM_PROF_MARK(kProfP3a)
     PM_MARK("P3b");
-    // ---- P3b: Monte-Carlo view draws (:1128-1138), lane per (column, draw) ----
+    // ---- P3b: Monte-Carlo view draws (:1128-1138), lane per (column, draw): the first view whose CDF value exceeds
+    // the uniform. The CDF is non-decreasing unless it holds a NaN (then its last value is one: the running sum never
+    // recovers), so the first such view = the number of leading views that do NOT exceed it, found by bisection; a
+    // column whose CDF ends in a NaN takes the reference's linear scan. sv = S: no view (the zero slot of P5a).
     for (int item = tid; item < ncols * M; item += nt) {
-      const int c = item / M;
-      const float u = L.us[item];
+      const int c = item_div(item, inv_M);
+      const int m = item - c * M;
+      const float u = draws[((size_t)row * RW + col0 + c) * dstride + 4 + m];
       const lds_f32* q = L.q + c * S;
-      int src = -1;
-      for (int s = 0; s < S; ++s) {
-        if (q[s] > u) { src = s; break; }
+      const float last = q[S - 1];
+      int lo = 0;
+      if (last != last) {
+        lo = S;
+        for (int s = 0; s < S; ++s) {
+          if (q[s] > u) { lo = s; break; }
+        }
+      } else {
+        for (int step = step0; step > 0; step >>= 1) {
+          const int idx = lo + step;
+          if (idx <= S && !(q[idx - 1] > u)) lo = idx;
+        }
       }
-      L.sv[item] = src;
+      L.sv[item] = lo;
+      if (lo < S)
+        __hip_atomic_fetch_or(L.drawn + c * DW + (lo >> 5), 1u << (lo & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     wave_sync<NW>();
     PM_PROF_MARK(kProfP3b)
     PM_MARK("P3c");
-    // ---- P3c: one task set per distinct drawn view, lane per (column, view) ---
+    // ---- P3c: one task set per distinct drawn view, lane per (column, view); list positions from a ballot ----
+    int n4 = 0, ng = 0;
     {
       LDS_AS uint16_t* tasks = (LDS_AS uint16_t*)L.tasks;
-      for (int item = tid; item < ncols * S; item += nt) {
-        const int c = item / S;
-        const int s = item - c * S;
+      for (int item0 = 0; item0 < ncols * S; item0 += nt) {
+        const int item = item0 + tid;
         bool drawn = false;
-        for (int m = 0; m < M; ++m) drawn |= (L.sv[c * M + m] == s);
-        if (drawn) {
-          const int base = __hip_atomic_fetch_add(L.ntasks, 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          for (int i = 1; i < 5; ++i) tasks[base + i - 1] = (uint16_t)task16_pack(c, i, s, 0);
-          if (GEOM) {
-            const int gb = __hip_atomic_fetch_add(L.ntasks + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            tasks[wave_max_tasks(C, S, M) + gb] = (uint16_t)task16_pack(c, 0, s, 1);
-          }
+        int c = 0, s = 0;
+        if (item < ncols * S) {
+          c = item_div(item, inv_S);
+          s = item - c * S;
+          drawn = ((L.drawn[c * DW + (s >> 5)] >> (s & 31)) & 1u) != 0u;
         }
+        const unsigned long long bal = __ballot(drawn ? 1 : 0);
+        if (drawn) {
+          const int below = lanes_below(bal);
+          const uint32_t t1 = task16_pack(c, 1, s, 0);
+          const uint32_t w01 = t1 | ((t1 + 512u) << 16);   // hypotheses 1, 2
+          const uint32_t w23 = w01 + (1024u | (1024u << 16));  // hypotheses 3, 4
+          LDS_AS uint32_t* tw = (LDS_AS uint32_t*)(tasks + n4 + 4 * below);
+          tw[0] = w01;
+          tw[1] = w23;
+          if (GEOM) tasks[wave_max_tasks(C, S, M) + ng + below] = (uint16_t)task16_pack(c, 0, s, 1);
+        }
+        const int cnt = __popcll(bal);
+        n4 += 4 * cnt;
+        ng += cnt;
       }
     }
     wave_sync<NW>();
@@ -2004,23 +2108,22 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
     PM_MARK("P4");
     // ---- P4: NCC of hypotheses 1..4 against the drawn views (:1157-1172) -----
     if (!(PM_ABLATE(p) & 1))
-      run_tasks_wave<GEOM, NW, CAP, MUBUF, PROF>(p, L, srd, row, col0, tid, evals, prof_acc, prof_t, kProfP4B);
-    if (tid == 0) { L.ntasks[0] = 0; L.ntasks[1] = 0; }
-    wave_sync<NW>();
+      run_tasks_wave<GEOM, NW, CAP, MUBUF, PROF>(p, L, srd, row, col0, tid, n4, ng, evals, prof_acc, prof_t, kProfP4B);
 
     PM_PROF_MARK(kProfP4F)
     PM_MARK("P5a");
-    // ---- P5a: accumulate in draw order (:1144-1172), lane per (column, hypothesis)
+    // ---- P5a: accumulate in draw order (:1144-1172), lane per (column, hypothesis); a draw without a view adds the
+    // row's zero slot
     for (int item = tid; item < ncols * 5; item += nt) {
       const int c = item / 5;
-      const int i = item - c * 5;
+      const lds_f32* costs = L.cost5 + item * S1;
+      const lds_f32* geos = L.geo + item * S1;
+      const lds_i32* sv = L.sv + c * M;
       float acc = 0.0f;
       for (int m = 0; m < M; ++m) {
-        const int src = L.sv[c * M + m];
-        if (src < 0) continue;
-        if (i == 0) acc += L.costv[c * S + src];
-        else acc += L.ncc[(c * 4 + i - 1) * S + src];
-        if (GEOM) acc += p.geom_reg * L.geo[(c * 5 + i) * S + src];
+        const int src = sv[m];
+        acc += costs[src];
+        if (GEOM) acc += p.geom_reg * geos[src];
       }
       L.csum[item] = acc;
     }
@@ -2050,17 +2153,25 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
     wave_sync<NW>();
     PM_PROF_MARK(kProfP5b)
     PM_MARK("P5c");
-    // ---- P5c: winner vs. the views not evaluated yet, lane per (column, view) --
+    // ---- P5c: winner vs. the views not evaluated yet (= not drawn), lane per (column, view) --
+    int n1 = 0;
     {
       LDS_AS uint16_t* tasks = (LDS_AS uint16_t*)L.tasks;
-      for (int item = tid; item < ncols * S; item += nt) {
-        const int c = item / S;
-        const int s = item - c * S;
-        const int k = L.best[c];
-        if (k != 0 && L.ncc[(c * 4 + k - 1) * S + s] < 0.0f) {
-          const int base = __hip_atomic_fetch_add(L.ntasks, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          tasks[base] = (uint16_t)task16_pack(c, k, s, 0);
+      for (int item0 = 0; item0 < ncols * S; item0 += nt) {
+        const int item = item0 + tid;
+        bool take = false;
+        uint32_t task = 0;
+        if (item < ncols * S) {
+          const int c = item_div(item, inv_S);
+          const int s = item - c * S;
+          const int k = L.best[c];
+          const bool drawn = ((L.drawn[c * DW + (s >> 5)] >> (s & 31)) & 1u) != 0u;
+          take = k != 0 && !drawn;
+          task = task16_pack(c, k, s, 0);
         }
+        const unsigned long long bal = __ballot(take ? 1 : 0);
+        if (take) tasks[n1 + lanes_below(bal)] = (uint16_t)task;
+        n1 += __popcll(bal);
       }
     }
     wave_sync<NW>();
@@ -2069,24 +2180,19 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
     PM_MARK("P6");
     // ---- P6: NCC of the winner against the remaining views (:1188-1197) ------
     if (!(PM_ABLATE(p) & 1))
-      run_tasks_wave<false, NW, CAP, MUBUF, PROF>(p, L, srd, row, col0, tid, evals, prof_acc, prof_t, kProfP6B);
+      run_tasks_wave<false, NW, CAP, MUBUF, PROF>(p, L, srd, row, col0, tid, n1, 0, evals, prof_acc, prof_t, kProfP6B);
     PM_PROF_MARK(kProfP6F)
     PM_MARK("P7");
 
     // ---- P7: cost map, forward message, selection probability (:1186-1207) ---
     for (int item = tid; item < ncols * S; item += nt) {
-      const int c = item / S;
+      const int c = item_div(item, inv_S);
       const int s = item - c * S;
       const int col = col0 + c;
       const int k = L.best[c];
       float* rec = p.rec + (size_t)pix_index(p, row, col) * p.rec_stride;
-      float cost;
-      if (k == 0) {
-        cost = L.costv[item];
-      } else {
-        cost = L.ncc[(c * 4 + k - 1) * S + s];
-        rec[4 + s] = cost;
-      }
+      const float cost = L.cost5[(c * 5 + k) * S1 + s];
+      if (k != 0) rec[4 + s] = cost;
       const float alpha = hmm_message<true>(p, cost, L.fm[item]);
       const float prob = sel_prob_fn(alpha, L.betav[item], L.prevv[item], p.prev_sel_prob_weight);
       L.fm[item] = alpha;
@@ -2131,11 +2237,11 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
     }
     wave_sync<NW>();
     PM_MARK("ROWEND");
+    slot_top = slot_top + 1 == win ? 0 : slot_top + 1;
+    slot_c = slot_c + 1 == win ? 0 : slot_c + 1;
+    slot_new = slot_new + 1 == win ? 0 : slot_new + 1;
   }
 
-  if (col_lane) {
-    rng_store(p.rng + (size_t)pix_index(p, 0, col0 + tid) * kRngWords, rng);  // :1285-1287
-  }
   if (tid == 0 && p.evals) atomicAdd(p.evals, (unsigned long long)evals);
   if (PROF) {
     PM_PROF_MARK(kProfP8)
@@ -2146,13 +2252,9 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
   }
 }
 
-// MUBUF: packed images addressed through the problem's buffer resource (the normal case), or by explicit indices
-template <bool GEOM, bool FILTER_PHOTO, bool FILTER_GEOM, bool MUBUF>
-__global__ void __launch_bounds__(64, 4) pm_sweep_wave4_kernel(const PmParams* __restrict__ pp) {
-  sweep_wave_body<GEOM, FILTER_PHOTO, FILTER_GEOM, 1, kWaveThCap, MUBUF>(pp);
-}
 // Four waves per workgroup, each with its own column group, sharing one LDS copy of the read-only per-problem
 // tables: four workgroups = 16 waves per CU with 64 task slots per batch at S = 20 (geometric pass included).
+// MUBUF: packed images addressed through the problem's buffer resource (the normal case), or by explicit indices
 template <bool GEOM, bool FILTER_PHOTO, bool FILTER_GEOM, bool MUBUF>
 __global__ void __launch_bounds__(64 * kQuadWaves, 4) pm_sweep_quad_kernel(const PmParams* __restrict__ pp) {
   sweep_wave_body<GEOM, FILTER_PHOTO, FILTER_GEOM, kQuadWaves, kQuadThCap, MUBUF>(pp);
@@ -2161,6 +2263,50 @@ __global__ void __launch_bounds__(64 * kQuadWaves, 4) pm_sweep_quad_kernel(const
 template <bool FILTER_PHOTO>
 __global__ void __launch_bounds__(64 * kQuadWaves, 4) pm_sweep_quad_prof_kernel(const PmParams* __restrict__ pp) {
   sweep_wave_body<false, FILTER_PHOTO, false, kQuadWaves, kQuadThCap, true, true>(pp);
+}
+
+// ---------------------------------------------------------------------------
+// The random numbers of one sweep, for every pixel, before the sweep (the 11 x 11 kernel above reads them from
+// PmParams::draws). A column of the sweep frame owns one XORWOW stream (reference: one curand state per thread =
+// column, :1022-1028, stored back at :1285-1287) and consumes it row by row: the perturbed depth (:1055-1058), the
+// 3 .. 12 draws of PerturbNormal (:133-196, its retries depend on the pixel's current normal -- known before the sweep,
+// the sweep writes a pixel's plane only when it reaches its row) and the M uniforms of the view draws (:1129). None of
+// it depends on what the sweep decides in the rows above, so it is taken out of the sequential row step, where it ran
+// on C of 64 lanes: here a lane is a column and a wave covers 64 of them. Per pixel: {rd, rn0, rn1, rn2, u[M]}.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) pm_draw_kernel(const PmParams* __restrict__ pp) {
+  const PmParams& p = pp[blockIdx.y];
+  const int RW = rot_width(p), RH = rot_height(p);
+  const int col = blockIdx.x * 64 + threadIdx.x;
+  if (col >= RW) return;
+  const int M = p.num_samples;
+  const int dstride = pm_draw_stride(M);
+  const float* iK = p.refInvK;
+  uint32_t* rng_at = p.rng + (size_t)pix_index(p, 0, col) * kRngWords;
+  Rng rng = rng_load(rng_at);
+  float* out = p.draws + (size_t)col * dstride;
+  const float* rec = p.rec + (size_t)pix_index(p, 0, col) * p.rec_stride;
+  float cd = rec[0], r1 = rec[1], r2 = rec[2], cn2 = rec[3];
+  for (int row = 0; row < RH; ++row) {
+    // next row's plane in flight while this row's numbers are drawn
+    float nd = 0.0f, n1 = 0.0f, n2 = 0.0f, n3 = 0.0f;
+    if (row + 1 < RH) {
+      const float* nrec = p.rec + (size_t)pix_index(p, row + 1, col) * p.rec_stride;
+      nd = nrec[0]; n1 = nrec[1]; n2 = nrec[2]; n3 = nrec[3];
+    }
+    float cn0, cn1;
+    normal_to_sweep(p.rot, r1, r2, cn0, cn1);
+    const float dmin = (1.0f - p.perturbation) * cd;
+    const float dmax = (1.0f + p.perturbation) * cd;
+    const float rd = rng_uniform(rng) * (dmax - dmin) + dmin;
+    float rn0, rn1, rn2;
+    perturb_normal(iK, row, col, p.perturbation_pi, cn0, cn1, cn2, rng, rn0, rn1, rn2);
+    float* o = out + (size_t)row * RW * dstride;
+    o[0] = rd; o[1] = rn0; o[2] = rn1; o[3] = rn2;
+    for (int m = 0; m < M; ++m) o[4 + m] = rng_uniform(rng) - FLT_EPSILON;  // :1129
+    cd = nd; r1 = n1; r2 = n2; cn2 = n3;
+  }
+  rng_store(rng_at, rng);  // :1285-1287
 }
 
 // Debug: raw XORWOW streams of the generator above (seed = sequence id, as InitRandomStateKernel
@@ -2205,18 +2351,27 @@ size_t pm_sweep_lds_bytes(const PmParams& p, bool geom) {
 
 // LDS budget of one four-wave workgroup when four of them share a CU: 160 KB / 4 in 1280-byte granules.
 constexpr size_t kQuadLdsBudget = 40960;
-static bool pm_quad_enabled() {  // read per call: the tests switch it inside one process
-  return dev_switch_int("COLMAP_AMD_PM_QUAD", 1) != 0;
+
+// Is this shape served by the 11 x 11 four-wave kernel (else: the generic kernel)?
+static bool pm_wave_shape(int ntap1d, int step, int S, int C) { return ntap1d == 11 && step >= 1 && S <= 512 && C <= 8; }
+
+bool pm_sweep_uses_draws(const PmParams& p, bool geom) {
+  return pm_wave_shape(p.ntap1d, p.step, p.S, p.C) &&
+         lds_offsets_wave(p.C, p.S, p.radius, p.ntaps, p.num_samples, geom, kQuadThCap, kQuadWaves).total <= kQuadLdsBudget;
 }
 
 int pm_pick_columns(int S, int ntaps, int num_samples, bool geom, int radius, int requested) {
   const size_t budget = 60 * 1024;
-  // default: 2 columns per wave of the 11 x 11 kernels (16 waves resident per CU, the lane-per-(column, view)
+  // default: 2 columns per wave of the 11 x 11 kernel (16 waves resident per CU, the lane-per-(column, view)
   // phases are one pass; measured 604 / 643 / 718 ms per 16-image launch for C = 2 / 3 / 4), 4 for the generic kernel
   const int cols_env = dev_switch_int("COLMAP_AMD_PM_COLS", 0);  // experiments / tests
   if (requested <= 0 && cols_env > 0) requested = cols_env;
   int c = requested > 0 ? requested : (ntaps == 121 ? 2 : 4);
   if (c > 64) c = 64;
+  if (ntaps == 121 && requested <= 0) {
+    // many source images: one column per wave while that keeps the four-wave workgroup within its LDS budget
+    while (c > 1 && lds_offsets_wave(c, S, radius, ntaps, num_samples, geom, kQuadThCap, kQuadWaves).total > kQuadLdsBudget) --c;
+  }
   while (c > 1 && lds_offsets(c, S, radius, ntaps, num_samples, geom).total > budget) --c;
   return c;
 }
@@ -2262,14 +2417,13 @@ void pm_launch_initial_cost(const PmParams& p, const PmParams* dev_params, int b
   else hipLaunchKernelGGL(pm_initial_cost_kernel<0>, grid, block, lds, st, dev_params);
 }
 
-// Which sweep kernel runs (three families):
-//  * pm_sweep_quad_kernel  -- 11 x 11 window, four-wave workgroups: the default whenever four workgroups fit a CU;
-//  * pm_sweep_wave4_kernel -- the same body in single-wave workgroups (shapes whose four-wave LDS block is too
-//    large, COLMAP_AMD_PM_QUAD=0 for A/B runs and tests);
-//  * pm_sweep_kernel       -- any window, 256-thread workgroups with barriers (round 1's design): other window
-//    sizes, the phase profile, COLMAP_AMD_PM_WAVE=0.
-// The two 11 x 11 kernels exist with and without the buffer-resource addressing of the packed images (fp_resource).
-// All three produce the same bits.
+// Which sweep kernel runs (two families):
+//  * pm_sweep_quad_kernel -- 11 x 11 window, four-wave workgroups whose waves each sweep their own column group, fed
+//    by pm_draw_kernel (the sweep's random numbers): whenever four workgroups fit a CU;
+//  * pm_sweep_kernel      -- any window, 256-thread workgroups with barriers (round 1's design): other window
+//    sizes, more source images than the four-wave LDS block holds, COLMAP_AMD_PM_WAVE=0.
+// The 11 x 11 kernel exists with and without the buffer-resource addressing of the packed images (fp_resource).
+// Both families produce the same bits.
 const char* pm_launch_sweep(const PmParams& p, const PmParams* dev_params, int batch, int threads, bool geom,
                             bool filter_photo, bool filter_geom, hipStream_t st) {
   const int rw = (p.rot & 1) ? p.H : p.W;
@@ -2285,43 +2439,28 @@ const char* pm_launch_sweep(const PmParams& p, const PmParams* dev_params, int b
       else hipLaunchKernelGGL((KERNEL<false, false, false, MB>), GRID, BLOCK, LDS, st, dev_params); \
     }                                                                                               \
   } while (0)
-#define PM_LAUNCH_V(KERNEL, GRID, BLOCK, LDS)                \
-  do {                                                       \
-    if (mubuf) PM_LAUNCH_V4(KERNEL, true, GRID, BLOCK, LDS); \
-    else PM_LAUNCH_V4(KERNEL, false, GRID, BLOCK, LDS);      \
-  } while (0)
-  if (wave_enabled && p.ntap1d == 11 && p.step >= 1 && p.S <= 512 && p.C <= 8) {
+  if (wave_enabled && p.draws != nullptr && pm_sweep_uses_draws(p, geom)) {
     // COLMAP_AMD_PM_FP_GLOBAL=1 (tests): explicit indices although the buffer resource would do
     const bool mubuf = pm_fp_resource_ok(p) && dev_switch_int("COLMAP_AMD_PM_FP_GLOBAL", 0) == 0;
     const size_t qlds = lds_offsets_wave(p.C, p.S, p.radius, p.ntaps, p.num_samples, geom, kQuadThCap, kQuadWaves).total;
-    if (p.prof && pm_quad_enabled() && qlds <= kQuadLdsBudget && mubuf && !geom) {
+    const dim3 qgrid((groups + kQuadWaves - 1) / kQuadWaves, batch, 1), qblock(64 * kQuadWaves, 1, 1);
+    hipLaunchKernelGGL(pm_draw_kernel, dim3((rw + 63) / 64, batch, 1), dim3(64, 1, 1), 0, st, dev_params);
+    if (p.prof && mubuf && !geom) {
       // phase profile (pm_enable_phase_profile): the shipped kernel with its phase clocks compiled in
-      const dim3 pgrid((groups + kQuadWaves - 1) / kQuadWaves, batch, 1), pblock(64 * kQuadWaves, 1, 1);
-      if (filter_photo) hipLaunchKernelGGL(pm_sweep_quad_prof_kernel<true>, pgrid, pblock, qlds, st, dev_params);
-      else hipLaunchKernelGGL(pm_sweep_quad_prof_kernel<false>, pgrid, pblock, qlds, st, dev_params);
+      if (filter_photo) hipLaunchKernelGGL(pm_sweep_quad_prof_kernel<true>, qgrid, qblock, qlds, st, dev_params);
+      else hipLaunchKernelGGL(pm_sweep_quad_prof_kernel<false>, qgrid, qblock, qlds, st, dev_params);
       return "pm_sweep_quad_prof_kernel";
     }
-    if (!p.prof && pm_quad_enabled() && qlds <= kQuadLdsBudget) {
-      PM_LAUNCH_V(pm_sweep_quad_kernel, dim3((groups + kQuadWaves - 1) / kQuadWaves, batch, 1), dim3(64 * kQuadWaves, 1, 1), qlds);
-      return mubuf ? "pm_sweep_quad_kernel" : "pm_sweep_quad_kernel (explicit indices)";
-    }
-    const size_t wlds = lds_offsets_wave(p.C, p.S, p.radius, p.ntaps, p.num_samples, geom, kWaveThCap, 1).total;
-    if (!p.prof && wlds <= 64 * 1024) {
-      PM_LAUNCH_V(pm_sweep_wave4_kernel, dim3(groups, batch, 1), dim3(64, 1, 1), wlds);
-      return mubuf ? "pm_sweep_wave4_kernel" : "pm_sweep_wave4_kernel (explicit indices)";
-    }
+    if (mubuf) PM_LAUNCH_V4(pm_sweep_quad_kernel, true, qgrid, qblock, qlds);
+    else PM_LAUNCH_V4(pm_sweep_quad_kernel, false, qgrid, qblock, qlds);
+    return mubuf ? "pm_sweep_quad_kernel" : "pm_sweep_quad_kernel (explicit indices)";
   }
 #undef PM_LAUNCH_V4
-#undef PM_LAUNCH_V
   const size_t lds = pm_sweep_lds_bytes(p, geom);
   dim3 block(threads, 1, 1);
   dim3 grid(groups, batch, 1);
 #define PM_LAUNCH_N(N, G, FP, FG, PR) \
   hipLaunchKernelGGL((pm_sweep_kernel<N, G, FP, FG, PR>), grid, block, lds, st, dev_params)
-  if (p.prof && !geom && !filter_photo && p.ntap1d == 11) {
-    PM_LAUNCH_N(11, false, false, false, true);
-    return "pm_sweep_kernel";
-  }
   if (geom) {
     if (filter_photo && filter_geom) PM_LAUNCH_N(0, true, true, true, false);
     else PM_LAUNCH_N(0, true, false, false, false);

@@ -349,6 +349,15 @@ inline int __builtin_amdgcn_readfirstlane(int v) {
   });
 }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+// v_mbcnt_lo / v_mbcnt_hi: bits of the mask half that belong to lanes below the calling one, added to `base`
+inline unsigned __builtin_amdgcn_mbcnt_lo(unsigned mask, unsigned base) {
+  const int l = hip_emul::lane_id();
+  return base + (unsigned)__builtin_popcount(l >= 32 ? mask : (mask & ((1u << l) - 1u)));
+}
+inline unsigned __builtin_amdgcn_mbcnt_hi(unsigned mask, unsigned base) {
+  const int l = hip_emul::lane_id();
+  return base + (l > 32 ? (unsigned)__builtin_popcount(mask & ((1u << (l - 32)) - 1u)) : 0u);
+}
 inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 inline unsigned __float_as_uint(float f) { unsigned u; std::memcpy(&u, &f, 4); return u; }
 inline float __uint_as_float(unsigned u) { float f; std::memcpy(&f, &u, 4); return f; }

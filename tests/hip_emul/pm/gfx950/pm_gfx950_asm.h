@@ -31,6 +31,7 @@ inline void reduce16x3(float& a, float& b, float& c) {
 }
 
 inline void launder_vgpr(int&) {}
+inline void launder_lds(const __attribute__((address_space(3))) float*&) {}
 
 // buffer_load_dword idxen offen through a buffer resource (gfx9 buffer addressing, the form pm_kernels.hip states and
 // scripts/ubench/mubuf_addr.hip verified on gfx950): with swizzling

@@ -74,8 +74,8 @@ def test_mat_file_roundtrip(tmp_path):
 
 
 def test_sweep_kernels_compile_to_the_intended_structure(tmp_path):
-    """Compile the kernels to ISA (CPU only) and check what the design relies on: three sweep-kernel families only
-    (generic, single-wave, four-wave); the 11 x 11 kernels gather through the swizzled buffer resource
+    """Compile the kernels to ISA (CPU only) and check what the design relies on: two sweep-kernel families only
+    (generic, four-wave + its profiling build); the 11 x 11 kernels gather through the swizzled buffer resource
     (buffer_load_dword ... idxen offen: the packed-image index is formed by the address unit, pm_kernels.hip:
     ncc_front) with no global gather left in them, hold 4 waves per SIMD (<= 128 VGPRs) and never spill."""
     import os, re, subprocess
@@ -87,9 +87,9 @@ def test_sweep_kernels_compile_to_the_intended_structure(tmp_path):
                           ["-S", "--cuda-device-only", "-o", out, src], stderr=subprocess.DEVNULL)
     text = open(out).read()
     sweep = set(re.findall(r"^_ZN10colmap_amd\d+(pm_sweep_(?:[a-z0-9]+_)?kernel)I\w+:", text, re.M))
-    assert sweep == {"pm_sweep_kernel", "pm_sweep_wave4_kernel", "pm_sweep_quad_kernel"}, sweep
-    kernels = re.findall(r"^(_ZN10colmap_amd\d+pm_sweep_(?:quad|wave4)_kernel\w+):.*?\.end_amdhsa_kernel", text, re.S | re.M)
-    assert len(kernels) == 16   # 2 families x 4 (geom, filter) variants x 2 addressing modes
+    assert sweep == {"pm_sweep_kernel", "pm_sweep_quad_kernel", "pm_sweep_quad_prof_kernel"}, sweep
+    kernels = re.findall(r"^(_ZN10colmap_amd\d+pm_sweep_quad_kernel\w+):.*?\.end_amdhsa_kernel", text, re.S | re.M)
+    assert len(kernels) == 8   # 4 (geom, filter) variants x 2 addressing modes
     for name in kernels:
         body = text[text.index(name + ":"):]
         body = body[:body.index(".end_amdhsa_kernel")]

@@ -96,19 +96,17 @@ def test_geometric_consistency_pass_and_both_filters(pm_oracle):
     G._assert_equal(want, got)
 
 
-@pytest.mark.parametrize("quad,fp_global", [("0", "0"), ("1", "1")])
-def test_single_wave_workgroups_and_explicit_indices(pm_oracle, request, quad, fp_global):
-    """pm_sweep_wave4_kernel (single-wave workgroups) through the buffer resource, and the four-wave kernel with
-    explicit strip indices (what problems whose images lie more than 4 GB apart get); ragged width, S = 6."""
+@pytest.mark.parametrize("fp_global", ["0", "1"])
+def test_buffer_resource_and_explicit_indices(pm_oracle, request, fp_global):
+    """The four-wave kernel through the buffer resource, and with explicit strip indices (what problems whose images lie
+    more than 4 GB apart get); ragged width, S = 6."""
     from switches import set_switch
-    for k, v in (("COLMAP_AMD_PM_QUAD", quad), ("COLMAP_AMD_PM_FP_GLOBAL", fp_global)):
-        set_switch(mvs.lib(), k, v)
-    request.addfinalizer(lambda: [set_switch(_emul_lib(), k, None) for k in ("COLMAP_AMD_PM_QUAD", "COLMAP_AMD_PM_FP_GLOBAL")])
+    set_switch(mvs.lib(), "COLMAP_AMD_PM_FP_GLOBAL", fp_global)
+    request.addfinalizer(lambda: set_switch(_emul_lib(), "COLMAP_AMD_PM_FP_GLOBAL", None))
     views = scene(7, 35, 27)
     want, got, pm = G._run_both(pm_oracle, views, 3, [0, 1, 2, 4, 5, 6], geom_consistency=0, filter=1, num_iterations=1)
     G._assert_equal(want, got)
-    assert pm.GetSweepKernelName() == ("pm_sweep_quad_kernel" if quad == "1" else "pm_sweep_wave4_kernel") + \
-        (" (explicit indices)" if fp_global == "1" else "")
+    assert pm.GetSweepKernelName() == "pm_sweep_quad_kernel" + (" (explicit indices)" if fp_global == "1" else "")
 
 
 @pytest.mark.parametrize("radius,step", [(2, 1), (5, 2)])

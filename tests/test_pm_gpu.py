@@ -129,19 +129,16 @@ def test_group_shapes_do_not_change_results(pm_oracle, cols, threads):
 
 
 @pytest.mark.parametrize("fp_global", ["0", "1"])
-@pytest.mark.parametrize("quad", ["0", "1"])
 @pytest.mark.parametrize("geom", [0, 1])
-def test_four_wave_workgroups_equal_single_wave_workgroups(pm_oracle, request, quad, geom, fp_global):
+def test_four_wave_workgroups_ragged_width_both_addressing_modes(pm_oracle, request, geom, fp_global):
     """pm_sweep_quad_kernel (four waves per workgroup sharing the read-only LDS tables, 64 task slots per batch)
-    against the single-wave workgroups (COLMAP_AMD_PM_QUAD=0), both against the oracle:
-    ragged width (67 columns = 22 groups of three + one column; 23 groups = 5 workgroups + 3 waves), S = 6."""
+    against the oracle: ragged width (67 columns = 33 groups of two + one column; 34 groups = 8 workgroups + 2 waves),
+    S = 6; packed images addressed through the buffer resource (the default) or by explicit indices (what problems
+    whose images lie more than 4 GB apart and cannot be re-homed get)."""
     from colmap_amd import mvs
     from switches import set_switch
-    # packed images addressed through the buffer resource (the default) or by explicit indices (what problems whose
-    # images lie more than 4 GB apart and cannot be re-homed get)
-    for k, v in (("COLMAP_AMD_PM_QUAD", quad), ("COLMAP_AMD_PM_FP_GLOBAL", fp_global)):
-        set_switch(mvs.lib(), k, v)
-    request.addfinalizer(lambda: [set_switch(mvs.lib(), k, None) for k in ("COLMAP_AMD_PM_QUAD", "COLMAP_AMD_PM_FP_GLOBAL")])
+    set_switch(mvs.lib(), "COLMAP_AMD_PM_FP_GLOBAL", fp_global)
+    request.addfinalizer(lambda: set_switch(mvs.lib(), "COLMAP_AMD_PM_FP_GLOBAL", None))
     views = scene(7, 67, 45)
     maps = None
     if geom:
@@ -149,8 +146,7 @@ def test_four_wave_workgroups_equal_single_wave_workgroups(pm_oracle, request, q
     want, got, pm = _run_both(pm_oracle, views, 3, [0, 1, 2, 4, 5, 6], maps=maps, geom_consistency=geom, filter=1,
                               num_iterations=1)
     _assert_equal(want, got)
-    assert pm.GetSweepKernelName() == ("pm_sweep_quad_kernel" if quad == "1" else "pm_sweep_wave4_kernel") + \
-        (" (explicit indices)" if fp_global == "1" else "")
+    assert pm.GetSweepKernelName() == "pm_sweep_quad_kernel" + (" (explicit indices)" if fp_global == "1" else "")
 
 
 @pytest.mark.parametrize("wave", ["0", "1"])
