@@ -1558,7 +1558,18 @@ __global__ void __launch_bounds__(256, 3) pm_sweep_kernel(const PmParams* __rest
 // ballots instead of atomics, zero slots instead of "no view" branches).
 // ---------------------------------------------------------------------------
 constexpr int kQuadWaves = 4;   // waves per workgroup
-constexpr int kQuadThCap = 64;  // NCC task slots per batch (homographies in LDS)
+// Five workgroups = 20 waves per CU for the photometric sweeps at S = 20: 96 VGPRs (two loop-invariant register pairs
+// live in scratch and are re-read once per NCC batch, outside the tap rounds) and 31.7 KB of LDS with 56 task slots
+// per batch (a row has ~42 + ~30 tasks at C = 2); measured 490 -> 480 ms per 16-image launch against four workgroups
+// with 64 slots. The geometric pass (38 KB of LDS) stays at four.
+#ifndef PM_QUAD_CAP
+#define PM_QUAD_CAP 56
+#endif
+#ifndef PM_QUAD_OCC
+#define PM_QUAD_OCC 5
+#endif
+constexpr int kQuadThCap = PM_QUAD_CAP;  // NCC task slots per batch (homographies in LDS)
+constexpr int kQuadOcc = PM_QUAD_OCC;    // workgroups per CU the photometric build is compiled for
 
 __device__ __forceinline__ uint32_t task16_pack(int c, int i, int s, int geom_only) {
   return ((uint32_t)c << 13) | ((uint32_t)geom_only << 12) | ((uint32_t)i << 9) | (uint32_t)s;
@@ -2256,7 +2267,7 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
 // tables: four workgroups = 16 waves per CU with 64 task slots per batch at S = 20 (geometric pass included).
 // MUBUF: packed images addressed through the problem's buffer resource (the normal case), or by explicit indices
 template <bool GEOM, bool FILTER_PHOTO, bool FILTER_GEOM, bool MUBUF>
-__global__ void __launch_bounds__(64 * kQuadWaves, 4) pm_sweep_quad_kernel(const PmParams* __restrict__ pp) {
+__global__ void __launch_bounds__(64 * kQuadWaves, GEOM ? 4 : kQuadOcc) pm_sweep_quad_kernel(const PmParams* __restrict__ pp) {
   sweep_wave_body<GEOM, FILTER_PHOTO, FILTER_GEOM, kQuadWaves, kQuadThCap, MUBUF>(pp);
 }
 // The same kernel with the phase clocks compiled in (pm_enable_phase_profile; photometric sweeps).

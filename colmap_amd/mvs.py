@@ -398,6 +398,12 @@ class PatchMatch:
         d["waves"] = int(out[23])
         return d
 
+    def GetLaunchShape(self):
+        """(reference images per sweep launch, sweep launches in flight together) of the last run."""
+        a, b = C.c_int32(1), C.c_int32(1)
+        _check(lib().pm_get_launch_shape(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def GetSweepTiming(self):
         ms = C.c_double(0)
         n = C.c_int32(0)

@@ -127,8 +127,13 @@ int pm_synchronize(pm_handle* h);
  * kernel launch covers all n reference images (the reference runs one problem per
  * GPU at a time, patch_match.cc:394; a single 2560-wide image cannot fill 256 CUs).
  * Results are bit-identical to n separate pm_run() calls. Timing of the batched
- * sweep launches is reported by pm_get_sweep_timing(handles[0]). */
+ * sweep launches is reported by pm_get_sweep_timing(handles[0]) (see pm_get_launch_shape). */
 int pm_run_batch(pm_handle** handles, int32_t n);
+/* How the last run of this handle was launched: reference images per sweep launch (its sub-batch: pm_run_batch
+ * runs 16 or more problems as two sub-batches on two streams so that the drain of one sweep launch is filled by
+ * the other's) and how many such launches were in flight together. pm_get_sweep_timing times the launches of the
+ * handle's own sub-batch. */
+int pm_get_launch_shape(pm_handle* h, int32_t* images_per_launch, int32_t* concurrent_launches);
 int pm_run_batch_async(pm_handle** handles, int32_t n); /* then pm_synchronize() each, before destroying any */
 
 /* PatchMatchCuda::GetDepthMap / GetNormalMap / GetSelProbMap

@@ -77,12 +77,25 @@ def run(a):
             for pm in pms:
                 pm.EnablePhaseProfile()
         t = time.time()
-        mvs.run_batch(pms, wait=True)
+        if a.split > 1:
+            # sub-batches on their own streams (each run_batch enqueues on its first handle's stream), issued together:
+            # the tail of one sub-batch's sweep launch overlaps with the other sub-batches' launches
+            import threading
+            per = (len(pms) + a.split - 1) // a.split
+            th = [threading.Thread(target=mvs.run_batch, args=(pms[i:i + per],), kwargs={"wait": True})
+                  for i in range(0, len(pms), per)]
+            for x in th:
+                x.start()
+            for x in th:
+                x.join()
+        else:
+            mvs.run_batch(pms, wait=True)
         tr = time.time() - t
         ms, n = pms[0].GetSweepTiming()
         ev = [pm.GetEvaluationCount() for pm in pms]
         mpix = batch * w * h / 1e6
-        print(f"rep {rep}: {w}x{h} S={S} batch={batch} kernel {pms[0].GetSweepKernelName()}: create {tc:.2f}s run {tr:.3f}s -> "
+        ipl, conc = pms[0].GetLaunchShape()
+        print(f"rep {rep}: {w}x{h} S={S} batch={batch} ({ipl} images per launch, {conc} launches in flight) kernel {pms[0].GetSweepKernelName()}: create {tc:.2f}s run {tr:.3f}s -> "
               f"{mpix / tr:.3f} Mpix/s (run), {mpix / (tr + tc):.3f} incl. create; sweep launch avg {ms / max(n, 1):.2f} ms x {n}; "
               f"NCC evaluations per pixel per sweep {sum(e[0] for e in ev) / (batch * w * h * max(n, 1)):.2f}", flush=True)
         print("  per launch ms: " + " ".join(f"{v:.0f}" for v in pms[0].GetSweepTimes()), flush=True)
@@ -119,6 +132,7 @@ if __name__ == "__main__":
     ap.add_argument("--ring", type=int, default=100); ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--cols", type=int, default=0); ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--sweeps", type=int, default=0)
+    ap.add_argument("--split", type=int, default=1, help="run the batch as N concurrent sub-batches (one stream each)")
     ap.add_argument("--profile", action="store_true", help="launch the phase-profiling build of the sweep kernel")
     ap.add_argument("--profile-out", default="")
     a = ap.parse_args()

@@ -85,6 +85,7 @@ inline hipError_t hipMemset(void* d, int v, size_t n) { std::memset(d, v, n); re
 inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { std::memset(d, v, n); return hipSuccess; }
 // streams are synchronous (a launch has finished when hipLaunchKernelGGL returns); events carry wall-clock time
 inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = new hip_emul_stream(); return hipSuccess; }
+inline hipError_t hipExtStreamCreateWithCUMask(hipStream_t* s, uint32_t, const uint32_t*) { *s = new hip_emul_stream(); return hipSuccess; }
 inline hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned, int) { *s = new hip_emul_stream(); return hipSuccess; }
 inline hipError_t hipDeviceGetStreamPriorityRange(int* least, int* greatest) { *least = 0; *greatest = -1; return hipSuccess; }
 inline hipError_t hipStreamDestroy(hipStream_t s) { delete s; return hipSuccess; }
