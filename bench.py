@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--ba-points", type=int, default=200000)
     ap.add_argument("--ba-track", type=int, default=10)
     ap.add_argument("--ba-iters", type=int, default=10)
+    ap.add_argument("--ba2-frames", type=int, default=5000, help="BASELINE config[4] on one GPU (secondary.ba2)")
+    ap.add_argument("--ba2-points", type=int, default=2000000)
+    ap.add_argument("--no-ba2", action="store_true")
     ap.add_argument("--cpu-crop", type=str, default="512x384")
     ap.add_argument("--no-fusion", action="store_true", help="skip the stereo-fusion leg (needs the geometric leg)")
     ap.add_argument("--no-dropin", action="store_true",
@@ -245,6 +248,23 @@ def ba_secondary(a, local_rank, with_cpu, rank=0, world=1, dev=None):
             out["shared_intrinsics"]["hip_vs_oracle_same_pcg_iterations"] = bool(
                 np.array_equal(h1.log_linear_iters[:m1], o1.log_linear_iters[:m1]))
             out["shared_intrinsics"]["oracle_LM_iterations_per_s"] = o1.num_iterations / max(o1.lm_seconds, 1e-12)
+    if world == 1:
+        # what a caller pays besides the LM loop (the mapper calls BA hundreds of times: set-up is product time), and the
+        # same problem solved to the reference's own stopping rule instead of the first `--ba-iters` iterations
+        import time as _time
+        out["setup_seconds"] = s.setup_seconds
+        out["whole_solve_LM_iterations_per_s"] = s.num_iterations / max(s.lm_seconds + s.setup_seconds, 1e-12)
+        t0 = _time.time()
+        sc_ = est.solve_flat(fp.copy(), est.SolverOptions(), gpu_index=local_rank)   # COLMAP's defaults: <= 100 iterations, gradient 1e-4
+        out["to_convergence"] = {
+            "options": "defaults (max_num_iterations 100, gradient_tolerance 1e-4, function / parameter tolerance 0)",
+            "termination": sc_.termination_type.name, "lm_iterations": sc_.num_iterations,
+            "successful_steps": sc_.num_successful_steps, "pcg_iterations": int(sc_.total_linear_iterations),
+            "lm_seconds": sc_.lm_seconds, "setup_seconds": sc_.setup_seconds, "wall_seconds": _time.time() - t0,
+            "LM_iterations_per_s": sc_.num_iterations / max(sc_.lm_seconds, 1e-12),
+            "cost": [sc_.initial_cost, sc_.final_cost]}
+        if not a.no_ba2:
+            out["ba2"] = ba2_leg(a, local_rank, with_cpu)
     if sharded:
         out["sharded"] = sharded
     if with_cpu and world == 1:
@@ -263,6 +283,67 @@ def ba_secondary(a, local_rank, with_cpu, rank=0, world=1, dev=None):
                                    hip_vs_oracle_max_rel_cost_diff=rel, hip_vs_oracle_iterations_compared=m,
                                    hip_vs_oracle_same_pcg_iterations=bool(
                                        np.array_equal(sh.log_linear_iters[:m], sc.log_linear_iters[:m])))
+    return out
+
+
+def ba2_leg(a, local_rank, with_cpu):
+    """BASELINE.json config[4] on ONE GPU (it fits: 20 M observations x ~0.7 KB): 5000 cameras x 2 M points, track
+    length 10, half PINHOLE / half SIMPLE_RADIAL (benchmark/runtime/bundle_adjustment.cc:40-81's generator), Schur-PCG,
+    first `--ba-iters` LM iterations; bytes resident on the device during the solve; parity of the first cost values
+    against the fp64 oracle at a tenth of the size through the same code path (the oracle needs minutes at full size)."""
+    import ctypes as C
+    import threading
+    import time as _time
+    from colmap_amd import estimators as est, scene
+    frames, points, track = a.ba2_frames, a.ba2_points, a.ba_track
+    noise = scene.SyntheticNoiseOptions(0.01, 1.0, 0.05, 1.0)
+    t0 = _time.time()
+    d = scene.synthesize_flat(frames, points, track, seed=44, mixed_models=True, noise=noise)
+    fp = est.FlatProblem.from_arrays(d)
+    est.fix_gauge_two_cams(fp)
+    t_gen = _time.time() - t0
+    models = {int(m): int((fp.cam_model == m).sum()) for m in np.unique(fp.cam_model)}
+    free0 = torch.cuda.mem_get_info(local_rank)[0]
+    low = [free0]
+    stop = threading.Event()
+
+    def watch():   # bytes resident during the solve = the lowest free-memory reading while it runs
+        while not stop.is_set():
+            low[0] = min(low[0], torch.cuda.mem_get_info(local_rank)[0])
+            _time.sleep(0.02)
+    th = threading.Thread(target=watch, daemon=True)
+    th.start()
+    try:
+        s = est.solve_flat(fp.copy(), est.SolverOptions(max_num_iterations=a.ba_iters), gpu_index=local_rank)
+    finally:
+        stop.set()
+        th.join()
+    n_obs = len(fp.obs_pose)
+    out = {"workload": f"global BA, {frames} cameras x {points} points, track length {track} ({n_obs} observations), "
+                       f"camera models {models} (CameraModelId: count), gauge TWO_CAMS_FROM_WORLD, implicit Schur PCG, "
+                       f"first {a.ba_iters} LM iterations, one GPU",
+           "LM_iterations_per_s": s.num_iterations / max(s.lm_seconds, 1e-12), "lm_iterations": s.num_iterations,
+           "pcg_iterations": int(s.total_linear_iterations), "ms_per_lm_iteration": 1e3 * s.lm_seconds / max(s.num_iterations, 1),
+           "setup_seconds": s.setup_seconds, "cost": [s.initial_cost, s.final_cost],
+           "device_bytes_resident": int(free0 - low[0]), "bytes_per_observation": (free0 - low[0]) / max(n_obs, 1),
+           "host_generation_seconds": t_gen,
+           "roofline_lm_iteration_fp64_storage_frac":
+               2 * n_obs * (256.0 + 176.0 * s.total_linear_iterations / max(s.num_iterations, 1)) /
+               (s.lm_seconds / max(s.num_iterations, 1)) / 1e9 / 8000.0}
+    if with_cpu:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import ba_oracle
+        d10 = scene.synthesize_flat(frames // 10, points // 10, track, seed=44, mixed_models=True, noise=noise)
+        f10 = est.FlatProblem.from_arrays(d10)
+        est.fix_gauge_two_cams(f10)
+        o10 = est.solve_flat(f10.copy(), est.SolverOptions(max_num_iterations=3), solve_fn=ba_oracle.solve_fn)
+        h10 = est.solve_flat(f10.copy(), est.SolverOptions(max_num_iterations=3), gpu_index=local_rank)
+        m = min(len(o10.log_cost), len(h10.log_cost))
+        out["parity_at_one_tenth"] = {
+            "workload": f"{frames // 10} cameras x {points // 10} points, same generator and code path",
+            "hip_vs_oracle_max_rel_cost_diff": float(np.max(np.abs(h10.log_cost[:m] - o10.log_cost[:m]) / o10.log_cost[:m])) if m else None,
+            "iterations_compared": m,
+            "same_pcg_iterations": bool(np.array_equal(h10.log_linear_iters[:m], o10.log_linear_iters[:m]))}
     return out
 
 

@@ -57,6 +57,7 @@ thread_local long long g_spmv_launches = 0;
 thread_local long long g_spmv_bytes = 0;
 thread_local double g_mfma_ms = 0.0;       // time inside the f64 MFMA Gram kernel (Schur-Jacobi blocks)
 thread_local long long g_mfma_launches = 0;
+thread_local long long g_pcg_pipelined_solves = 0, g_pcg_stepwise_solves = 0;  // linear solves per PCG loop, last ba_solve
 
 #define BA_HIP(expr)                                                                           \
   do {                                                                                         \
@@ -2420,9 +2421,13 @@ __global__ void ba_pcgp_dir_kernel(int n, PcgDev D, int k, int max_iter, double 
 // (tail and step kernels: a lane per block, every loop over the block's components unrolled to the template width and
 //  predicated on its dimension -- rolled, each trip waited for its own loads: 6 - 12 dependent round trips per lane and
 //  launch; the order of every sum is the rolled loops', so the results are bit-identical)
+// `reduced` (point-sharded solves): J_c^T v of every block, already summed over the block's chunks AND over the ranks
+// (ba_block_vec_finalize_kernel + all-reduce) -- the tail then only adds D^2 p and takes p.q; null: this GPU's chunk
+// partials are the whole sum.
 template <int BD>
 __global__ void __launch_bounds__(256) ba_pcgp_tail_kernel(View V, PcgDev D, int k, const double* __restrict__ Dc,
-                                                           const double* __restrict__ p, double* __restrict__ q) {
+                                                           const double* __restrict__ p, double* __restrict__ q,
+                                                           const double* __restrict__ reduced) {
   if (*D.stop) return;
   const int bd2 = V.bd * V.bd;
   double pq = 0.0;
@@ -2437,9 +2442,14 @@ __global__ void __launch_bounds__(256) ba_pcgp_tail_kernel(View V, PcgDev D, int
       d[c] = c < dim ? Dc[off + c] : 0.0;
       pv[c] = c < dim ? p[off + c] : 0.0;
     }
-    for (int ch = ch0; ch < ch1; ++ch) {
+    if (reduced) {
 #pragma unroll
-      for (int c = 0; c < BD; ++c) sacc[c] += c < dim ? V.cpart[(size_t)ch * bd2 + c] : 0.0;
+      for (int c = 0; c < BD; ++c) sacc[c] = c < dim ? reduced[off + c] : 0.0;
+    } else {
+      for (int ch = ch0; ch < ch1; ++ch) {
+#pragma unroll
+        for (int c = 0; c < BD; ++c) sacc[c] += c < dim ? V.cpart[(size_t)ch * bd2 + c] : 0.0;
+      }
     }
 #pragma unroll
     for (int c = 0; c < BD; ++c) {
@@ -3017,6 +3027,7 @@ struct Solver {
   bool split_linearize = true;
   Buf<float> Jpose32, Jcam32, Jpt32;
   bool op32 = false;  // PCG operator streams the fp32 copies
+  bool pcg_all_ranks_have_work = false;  // sharded solves: every rank has observations and chunk lists (agreed in run())
   Buf<unsigned char> solo;
   Buf<double> o_xy, poses, cams, points, poses2, cams2, points2, Jpose, Jcam, Jpt, res, res_p, scale_c, scale_p,
       scalars, gc, gp, diag_c, diag_p, Dc, Dp, Cinv, M, Minv, rhs, x, r, z, pdir, q, dp, jx, v, stepc, stepp, partials, cpart, Craw, tbuf, tmpc, Gobs, pcg_part, maxbuf;
@@ -3873,14 +3884,25 @@ struct Solver {
       schur_streams(pdir.p, op32);
       BA_HIP(hipEventRecord(pcgp_ev_s1[k & 1], st));
       heavy_reduce(bd);
+      const double* reduced = nullptr;
+      if (comm.world > 1) {
+        // point sharding: every rank holds J_c^T v of its own observations -- block sums, then ONE all-reduce of the
+        // camera-space vector (n_c doubles: 64 KB at BA-1) on the solver's stream. With the RCCL transport nothing
+        // here touches the host: the iteration stays enqueued one ahead, the stop flag is computed identically on
+        // every rank from the identical reduced vector (an iteration enqueued past convergence still runs its
+        // all-reduce on every rank, on stale data nobody reads).
+        BA_LAUNCH(ba_block_vec_finalize_kernel<false>, dim3(grid_for(V.n_blk * bd, 128)), dim3(128), st, V, tmpc.p, nullptr);
+        comm.allreduce(tmpc.p, (size_t)n, st);
+        reduced = tmpc.p;
+      }
       if (bd == PD) {
-        BA_LAUNCH(ba_pcgp_tail_kernel<PD>, dim3(nparts), dim3(256), st, V, D, k, Dc.p, pdir.p, q.p);
+        BA_LAUNCH(ba_pcgp_tail_kernel<PD>, dim3(nparts), dim3(256), st, V, D, k, Dc.p, pdir.p, q.p, reduced);
         BA_LAUNCH(ba_pcgp_step_kernel<PD>, dim3(nparts), dim3(256), st, V, D, k, Minv.p, rhs.p, pdir.p, q.p, x.p, r.p, z.p);
       } else if (bd == KD_MAX) {
-        BA_LAUNCH(ba_pcgp_tail_kernel<KD_MAX>, dim3(nparts), dim3(256), st, V, D, k, Dc.p, pdir.p, q.p);
+        BA_LAUNCH(ba_pcgp_tail_kernel<KD_MAX>, dim3(nparts), dim3(256), st, V, D, k, Dc.p, pdir.p, q.p, reduced);
         BA_LAUNCH(ba_pcgp_step_kernel<KD_MAX>, dim3(nparts), dim3(256), st, V, D, k, Minv.p, rhs.p, pdir.p, q.p, x.p, r.p, z.p);
       } else {
-        BA_LAUNCH(ba_pcgp_tail_kernel<KD_WIDE>, dim3(nparts), dim3(256), st, V, D, k, Dc.p, pdir.p, q.p);
+        BA_LAUNCH(ba_pcgp_tail_kernel<KD_WIDE>, dim3(nparts), dim3(256), st, V, D, k, Dc.p, pdir.p, q.p, reduced);
         BA_LAUNCH(ba_pcgp_step_kernel<KD_WIDE>, dim3(nparts), dim3(256), st, V, D, k, Minv.p, rhs.p, pdir.p, q.p, x.p, r.p, z.p);
       }
     };
@@ -3911,7 +3933,14 @@ struct Solver {
     // single GPU, no priors: three small kernels per iteration, stopping test on the device, host one iteration
     // behind (COLMAP_AMD_BA_PCG_PIPELINED=0: the step-by-step loop below, which sharded / prior solves always take)
     const bool pipelined = dev_switch_int("COLMAP_AMD_BA_PCG_PIPELINED", 1) != 0;
-    if (pipelined && comm.world == 1 && !use_priors() && V.n_chunks > 0 && V.n_obs > 0) return pcg_pipelined(max_iter, q_tol);
+    // ... and point-sharded solves whose ranks all hold observations (pcg_all_ranks_have_work: agreed once per solve,
+    // the ranks must take the same path); image-sharded ones all-reduce inside the point pass as well and keep the loop below
+    const bool local_ok = !use_priors() && V.n_chunks > 0 && V.n_obs > 0;
+    if (pipelined && local_ok && (comm.world == 1 || (comm.by_point && pcg_all_ranks_have_work))) {
+      ++g_pcg_pipelined_solves;
+      return pcg_pipelined(max_iter, q_tol);
+    }
+    ++g_pcg_stepwise_solves;
     const int n = V.n_c;
     const int gv = grid_for(n, 256);
     BA_HIP(hipMemsetAsync(x.p, 0, sizeof(double) * n, st));
@@ -3951,6 +3980,7 @@ struct Solver {
   }
 
   void run(ba_result* out) {
+    const auto t_entry = std::chrono::steady_clock::now();
     BA_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     BA_HIP(hipEventCreate(&ev0));
     BA_HIP(hipEventCreate(&ev1));
@@ -3998,9 +4028,18 @@ struct Solver {
       }
       BA_HIP(hipDeviceSynchronize());  // the allocation's memset runs on the NULL stream
     }
+    if (comm.world > 1) {
+      // which PCG loop runs must not depend on the rank: one sum over ranks of "this rank could not take the pipelined one"
+      const double mine = (!use_priors() && V.n_chunks > 0 && V.n_obs > 0) ? 0.0 : 1.0;
+      BA_HIP(hipMemcpyAsync(scalars.p + S_ITER, &mine, sizeof(double), hipMemcpyHostToDevice, st));
+      BA_HIP(hipStreamSynchronize(st));
+      comm.allreduce(scalars.p + S_ITER, 1, st);
+      pcg_all_ranks_have_work = scalar(S_ITER) == 0.0;
+    }
     factor_ms = 0.0;
     g_spmv_ms = 0.0; g_spmv_launches = 0;
     g_mfma_ms = 0.0; g_mfma_launches = 0;
+    g_pcg_pipelined_solves = 0; g_pcg_stepwise_solves = 0;
     // bytes one implicit-Schur product streams: Jc (2x10) once for jx, Jp (2x3) twice, jx/v, Jc again
     g_spmv_bytes = (long long)V.n_obs * (2 * (PD + kd) * 8 * 2 + 6 * 8 * 2 + 4 * 8 * 3);
 
@@ -4013,6 +4052,25 @@ struct Solver {
     BA_LAUNCH(ba_scale_kernel, dim3(std::max(gvp, 1)), dim3(256), st, np, diag_p.p, 0, scale_p.p);
     BA_HIP(hipStreamSynchronize(st));
     const auto t_start = std::chrono::steady_clock::now();
+    out->setup_seconds = std::chrono::duration<double>(t_start - t_entry).count();
+    // ceres::IterationCallback as COLMAP uses it (controllers/bundle_adjustment.cc:40-57): asked between two
+    // iterations; the parameter blocks hold the last accepted step when it ends the solve
+    auto user_stop = [&](int iteration, double cost_now, double cost_change, bool step_ok, double rad, int lin) -> bool {
+      if (!opt.iteration_callback) return false;
+      ba_iteration_summary sm;
+      sm.iteration = iteration;
+      sm.step_is_successful = step_ok ? 1 : 0;
+      sm.linear_solver_iterations = lin;
+      sm.cost = cost_now;
+      sm.cost_change = cost_change;
+      sm.trust_region_radius = rad;
+      sm.cumulative_time_in_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+      const int rc = opt.iteration_callback(opt.iteration_callback_user, &sm);
+      if (rc == BA_CALLBACK_CONTINUE) return false;
+      out->termination_type = rc == BA_CALLBACK_TERMINATE ? BA_USER_SUCCESS : BA_USER_FAILURE;
+      out->num_iterations = iteration;
+      return true;
+    };
 
     for (int iter = 0;; ++iter) {
       if (need_linearize) {
@@ -4061,6 +4119,7 @@ struct Solver {
           break;
         }
         need_linearize = false;
+        if (iter == 0 && user_stop(0, cost, 0.0, true, radius, 0)) break;
       }
       if (iter >= opt.max_num_iterations) {
         out->termination_type = BA_NO_CONVERGENCE;
@@ -4241,6 +4300,7 @@ struct Solver {
         out->num_iterations = iter + 1;
         break;
       }
+      if (user_stop(iter + 1, accepted ? new_cost : cost, accepted ? cost - new_cost : 0.0, accepted, radius, lin_iters)) break;
     }
     launch_linearize(false, poses.p, cams.p, points.p, sensors.p, S_NEWCOST);
     out->final_cost = scalar_sum(S_NEWCOST);
@@ -4420,6 +4480,12 @@ void ba_rccl_comm_destroy(void* comm) {
 int ba_last_mfma_timing(double* total_ms, int64_t* launches) {
   if (total_ms) *total_ms = g_mfma_ms;
   if (launches) *launches = g_mfma_launches;
+  return 0;
+}
+
+int ba_last_pcg_loops(int64_t* pipelined_solves, int64_t* stepwise_solves) {
+  if (pipelined_solves) *pipelined_solves = g_pcg_pipelined_solves;
+  if (stepwise_solves) *stepwise_solves = g_pcg_stepwise_solves;
   return 0;
 }
 

@@ -596,9 +596,19 @@ void RehomeSourceImages(pm_handle* h, pm_image_cache* cache, const pm_problem& p
       }
       moved.push_back({s, p});
     }
+    // all copies first, one synchronisation, THEN the new entries become visible (to this handle and, through the
+    // cache, to other threads' Create calls, which launch on their own streams): nobody can pick up a half-written
+    // image. If a copy fails the taken slots go back to the pool and nothing has changed.
+    try {
+      for (auto& m : moved)
+        HIP_CALL(hipMemcpyAsync(m.second, (*tab)[m.first], bytes, hipMemcpyDeviceToDevice, h->stream));
+      HIP_CALL(hipStreamSynchronize(h->stream));
+    } catch (...) {
+      for (auto& m : moved) pool.Give(m.second);
+      throw;
+    }
     for (auto& m : moved) {
       const int s = m.first;
-      HIP_CALL(hipMemcpyAsync(m.second, (*tab)[s], bytes, hipMemcpyDeviceToDevice, h->stream));
       auto e = std::make_shared<FpEntry>();
       e->data.adopt(m.second, fp_count);
       if (cache) {
@@ -608,8 +618,7 @@ void RehomeSourceImages(pm_handle* h, pm_image_cache* cache, const pm_problem& p
         auto it = cache->entries.find(key);
         if (it != cache->entries.end() && it->second == h->src_fp[s]) it->second = e;
       }
-      HIP_CALL(hipStreamSynchronize(h->stream));  // the old copy may be released with the next line
-      h->src_fp[s] = e;
+      h->src_fp[s] = e;   // (the old copy is released here at the earliest: the copies above are complete)
       (*tab)[s] = m.second;
       ++g_fp_rehomed;
     }

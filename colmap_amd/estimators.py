@@ -169,6 +169,10 @@ class SolverOptions:
     # ba_options.operator_precision (MI355X option): OPERATOR_F32 lets the inexact inner CG solve stream fp32
     # copies of the Jacobian columns (fp64 accumulation; everything else stays fp64) -- include/colmap_amd_ba.h
     operator_precision: int = 0
+    # ba_options.iteration_callback: callable(summary) -> CALLBACK_CONTINUE / CALLBACK_TERMINATE / CALLBACK_ABORT, asked
+    # after the initial evaluation and after every LM iteration (ceres::Solver::Options::callbacks as the reference's
+    # controller uses them, controllers/bundle_adjustment.cc:40-57); `summary` has the fields of ba_iteration_summary
+    iteration_callback: Optional[object] = None
 
 
 @dataclass
@@ -217,6 +221,7 @@ class BundleAdjustmentSummary:
     log_linear_iters: Optional[np.ndarray] = None
     linear_solver_used: int = 0     # ba_result.linear_solver_used: the tier that ran (SOLVER_*)
     factor_seconds: float = 0.0     # exact tiers: time inside the blocked Cholesky
+    setup_seconds: float = 0.0      # flattening into the device layout, index lists, upload: everything before the LM loop
 
     def IsSolutionUsable(self) -> bool:
         return self.termination_type in (BundleAdjustmentTerminationType.CONVERGENCE,
@@ -587,7 +592,18 @@ class ba_options(C.Structure):
         ("num_threads", C.c_int32), ("max_log", C.c_int32),
         ("loss_type", C.c_int32), ("loss_scale", C.c_double),
         ("linear_solver_type", C.c_int32), ("operator_precision", C.c_int32),
+        ("iteration_callback", C.c_void_p), ("iteration_callback_user", C.c_void_p),
     ]
+
+
+class ba_iteration_summary(C.Structure):
+    _fields_ = [("iteration", C.c_int32), ("step_is_successful", C.c_int32), ("linear_solver_iterations", C.c_int32),
+                ("cost", C.c_double), ("cost_change", C.c_double), ("trust_region_radius", C.c_double),
+                ("cumulative_time_in_seconds", C.c_double)]
+
+
+ITERATION_CALLBACK_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(ba_iteration_summary))
+CALLBACK_CONTINUE, CALLBACK_TERMINATE, CALLBACK_ABORT = 0, 1, 2
 
 
 class ba_result(C.Structure):
@@ -598,7 +614,7 @@ class ba_result(C.Structure):
         ("initial_cost", C.c_double), ("final_cost", C.c_double), ("lm_seconds", C.c_double),
         ("num_logged", C.c_int32),
         ("log_cost", C.c_void_p), ("log_radius", C.c_void_p), ("log_linear_iters", C.c_void_p),
-        ("linear_solver_used", C.c_int32), ("factor_seconds", C.c_double),
+        ("linear_solver_used", C.c_int32), ("factor_seconds", C.c_double), ("setup_seconds", C.c_double),
     ]
 
 
@@ -708,9 +724,20 @@ def marshal_problem(fp: FlatProblem) -> ba_problem:
 def marshal_options(so: SolverOptions, max_log: int = 0, num_threads: int = 0) -> ba_options:
     o = ba_options()
     for name, _ in ba_options._fields_:
-        if name in ("num_threads", "max_log"):
+        if name in ("num_threads", "max_log", "iteration_callback", "iteration_callback_user"):
             continue
         setattr(o, name, getattr(so, name))
+    if so.iteration_callback is not None:
+        fn = so.iteration_callback
+
+        def _trampoline(_user, summary):
+            try:
+                return int(fn(summary.contents))
+            except Exception:  # an exception cannot cross the C frame: abort the solve instead
+                return CALLBACK_ABORT
+        cfn = ITERATION_CALLBACK_FN(_trampoline)
+        o._iteration_callback_keepalive = cfn   # the struct must outlive the solve together with the thunk
+        o.iteration_callback = C.cast(cfn, C.c_void_p).value
     o.loss_type = int(so.loss_type)
     o.jacobi_scaling = 1 if so.jacobi_scaling else 0
     o.num_threads = num_threads
@@ -718,7 +745,7 @@ def marshal_options(so: SolverOptions, max_log: int = 0, num_threads: int = 0) -
     return o
 
 
-BA_ABI_VERSION = 3  # include/colmap_amd_ba.h: COLMAP_AMD_BA_ABI_VERSION (the ctypes mirrors below follow that layout)
+BA_ABI_VERSION = 4  # include/colmap_amd_ba.h: COLMAP_AMD_BA_ABI_VERSION (the ctypes mirrors below follow that layout)
 
 
 def _check_abi(L):
@@ -763,7 +790,7 @@ def solve_flat(fp: FlatProblem, so: Optional[SolverOptions] = None, gpu_index: i
         total_linear_iterations=r.total_linear_iterations, initial_cost=r.initial_cost,
         final_cost=r.final_cost, lm_seconds=r.lm_seconds, log_cost=log_cost[: r.num_logged].copy(),
         log_linear_iters=log_lin[: r.num_logged].copy(), linear_solver_used=int(r.linear_solver_used),
-        factor_seconds=float(r.factor_seconds))
+        factor_seconds=float(r.factor_seconds), setup_seconds=float(r.setup_seconds))
 
 
 def num_camera_parameters(fp: FlatProblem) -> int:

@@ -301,7 +301,7 @@ struct BundleAdjustmentSummary {  // :63-74
   // solver statistics of the MI355X backend (CeresBundleAdjustmentSummary carries ceres's)
   int num_iterations = 0, num_successful_steps = 0, num_effective_parameters = 0;
   int64_t total_linear_iterations = 0;
-  double initial_cost = 0, final_cost = 0, lm_seconds = 0;
+  double initial_cost = 0, final_cost = 0, lm_seconds = 0, setup_seconds = 0;
 
   bool IsSolutionUsable() const {
     return termination_type == BundleAdjustmentTerminationType::CONVERGENCE ||
@@ -394,6 +394,10 @@ struct Mi355xBundleAdjustmentOptions {
   enum class LossFunctionType { TRIVIAL = 0, SOFT_L1 = 1, CAUCHY = 2, HUBER = 3 };
   LossFunctionType loss_function_type = LossFunctionType::TRIVIAL;
   double loss_function_scale = 1.0;
+  // Passed to ba_solve as it is. The reference's controller stops a running adjustment through
+  // solver_options.callbacks (controllers/bundle_adjustment.cc:40-57,84-86); here that is
+  // solver_options.iteration_callback / iteration_callback_user (colmap_amd_ba.h): return BA_CALLBACK_TERMINATE from
+  // it when BaseController::CheckIfStopped() says so and Solve() returns USER_SUCCESS with the last accepted step.
   ba_options solver_options;
   // The AUTO rule's thresholds. The reference keeps one pair per device class (bundle_adjustment_ceres.h:68-71:
   // 50 / 1000 images for its CPU solvers, 200 / 4000 for Ceres-CUDA); this backend's pair is measured on the MI355X
@@ -490,6 +494,7 @@ class Mi355xBundleAdjuster : public BundleAdjuster {
     summary->initial_cost = res.initial_cost;
     summary->final_cost = res.final_cost;
     summary->lm_seconds = res.lm_seconds;
+    summary->setup_seconds = res.setup_seconds;
     linear_solver_used_ = res.linear_solver_used;  // differs from the requested tier when that one did not apply
     return summary;
   }

@@ -82,6 +82,7 @@ typedef struct ba_problem {
 
 /* ceres::Solver::Options fields that reach the solve (COLMAP's values:
  * bundle_adjustment_ceres.cc:102-115; the rest are Ceres defaults). */
+struct ba_iteration_summary;
 typedef struct ba_options {
   int32_t max_num_iterations;           /* 100 */
   int32_t max_linear_solver_iterations; /* 200 */
@@ -126,7 +127,28 @@ typedef struct ba_options {
    * intermediate costs follow the fp64 trajectory only to ~1e-6 relative. Ignored (fp64) with variable
    * sensor_from_rig blocks, tracks longer than a point tile, and in sharded solves. */
   int32_t operator_precision;           /* BA_OPERATOR_F64 */
+  /* Iteration callback = ceres::Solver::Options::callbacks as COLMAP uses them: the controller's
+   * BundleAdjustmentIterationCallback asks CheckIfStopped() after every iteration and ends the solve with
+   * SOLVER_TERMINATE_SUCCESSFULLY (controllers/bundle_adjustment.cc:40-57,84-86). Called on the calling thread after
+   * the initial evaluation (iteration 0) and after every LM iteration, from the host loop between two iterations'
+   * launches; the return value is BA_CALLBACK_CONTINUE, BA_CALLBACK_TERMINATE (-> termination_type BA_USER_SUCCESS) or
+   * BA_CALLBACK_ABORT (-> BA_USER_FAILURE). Either way the parameter blocks hold the last ACCEPTED step
+   * (estimators/bundle_adjustment.h:63-69: USER_SUCCESS is a usable solution). In a sharded solve every rank calls it
+   * and all ranks must return the same value. NULL = none. */
+  int (*iteration_callback)(void* user, const struct ba_iteration_summary* summary);
+  void* iteration_callback_user;
 } ba_options;
+/* what a callback sees (the fields of ceres::IterationSummary COLMAP's callers read) */
+typedef struct ba_iteration_summary {
+  int32_t iteration;            /* 0 = initial evaluation */
+  int32_t step_is_successful;   /* the step of this iteration was accepted */
+  int32_t linear_solver_iterations;
+  double cost;                  /* of the current (last accepted) state */
+  double cost_change;           /* old - new for an accepted step, else 0 */
+  double trust_region_radius;
+  double cumulative_time_in_seconds; /* since the LM loop started */
+} ba_iteration_summary;
+enum { BA_CALLBACK_CONTINUE = 0, BA_CALLBACK_TERMINATE = 1, BA_CALLBACK_ABORT = 2 };
 enum { BA_SOLVER_ITERATIVE_SCHUR = 0, BA_SOLVER_DENSE_SCHUR = 1, BA_SOLVER_AUTO = 2, BA_SOLVER_SPARSE_SCHUR = 3 };
 enum { BA_OPERATOR_F64 = 0, BA_OPERATOR_F32 = 1 };
 
@@ -134,7 +156,7 @@ enum { BA_OPERATOR_F64 = 0, BA_OPERATOR_F32 = 1 };
 enum { BA_LOSS_TRIVIAL = 0, BA_LOSS_SOFT_L1 = 1, BA_LOSS_CAUCHY = 2, BA_LOSS_HUBER = 3 };
 
 /* colmap::BundleAdjustmentTerminationType (bundle_adjustment.h:50-57) */
-enum { BA_CONVERGENCE = 0, BA_NO_CONVERGENCE = 1, BA_FAILURE = 2 };
+enum { BA_CONVERGENCE = 0, BA_NO_CONVERGENCE = 1, BA_FAILURE = 2, BA_USER_SUCCESS = 3, BA_USER_FAILURE = 4 };
 
 /* colmap::BundleAdjustmentSummary (bundle_adjustment.h:63-74) + solver statistics */
 typedef struct ba_result {
@@ -151,6 +173,11 @@ typedef struct ba_result {
   int32_t* log_linear_iters;
   int32_t linear_solver_used;        /* BA_SOLVER_* tier that ran (never BA_SOLVER_AUTO) */
   double factor_seconds;             /* exact tiers: time inside the blocked Cholesky (matrix-core kernels), summed */
+  double setup_seconds;              /* everything before the LM loop: flattening into the device layout, sorting, index
+                                        lists, upload (the mapper calls BA hundreds of times: sfm/incremental_mapper.cc:
+                                        939,1086,1201 -- set-up is product time; lm_seconds + setup_seconds + the final
+                                        write-back is the whole-solve time the reference's harness reports,
+                                        benchmark/runtime/bundle_adjustment.cc:146-157) */
 } ba_result;
 
 /* Multi-GPU: every rank holds the full parameter set and calls ba_solve_sharded with the SAME
@@ -198,13 +225,18 @@ int ba_last_spmv_timing(double* total_ms, int64_t* launches, int64_t* bytes_per_
 /* The same for the f64 MFMA kernel (Schur-Jacobi blocks, one launch per LM iteration): the fraction of
  * the LM time spent inside the dense contraction is what the bench line reports as mfma_time_frac. */
 int ba_last_mfma_timing(double* total_ms, int64_t* launches);
+/* Which PCG loop the linear solves of the last ba_solve / ba_solve_sharded on this thread took: the pipelined one
+ * (iteration k + 1 enqueued before iteration k is looked at, stopping test on the device, no blocking host read per
+ * iteration: single-GPU solves and point-sharded ones -- there the one collective per iteration is an all-reduce of the
+ * camera-space vector on the solver's stream) or the step-by-step one (image-sharded solves, solves with priors). */
+int ba_last_pcg_loops(int64_t* pipelined_solves, int64_t* stepwise_solves);
 
 const char* ba_last_error(void);
 /* Layout version of ba_options / ba_result / ba_problem as this header declares them. The structs have grown by
- * appended fields (operator_precision, linear_solver_used, factor_seconds); a caller built against another header
+ * appended fields (operator_precision, linear_solver_used, factor_seconds, iteration_callback, setup_seconds); a caller built against another header
  * would pass shorter structs. Callers compare ba_abi_version() with COLMAP_AMD_BA_ABI_VERSION once, before the first
  * solve (the C++ and Python adapters of this repository do). */
-#define COLMAP_AMD_BA_ABI_VERSION 3
+#define COLMAP_AMD_BA_ABI_VERSION 4
 int32_t ba_abi_version(void);
 
 #ifdef __cplusplus

@@ -7,12 +7,13 @@
 # Outputs under gpurun_out/prof_$TAG; copy the summaries into profiles/ afterwards.
 TAG=${1:-lite}
 SWEEPS=${2:-4}   # sweep launches per counter pass (the kernel trace runs the full 20)
+BATCH=${3:-16}   # reference images per step (pm_run_batch runs 16 as two concurrent launches of 8)
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 ulimit -c 0
 cd /tmp && export TMPDIR=/tmp
-PROBE="python $ROOT/scripts/pm_probe_lite.py run --reps 1"
+PROBE="python $ROOT/scripts/pm_probe_lite.py run --reps 1 --batch $BATCH"
 echo "== kernel trace / stats"
 timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o probe -- $PROBE \
   > $OUT/probe_under_rocprof.log 2> $OUT/probe_under_rocprof.err

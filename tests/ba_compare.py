@@ -22,7 +22,10 @@ import numpy as np
 import ba_oracle
 
 FLOOR_MARGIN = 10.0      # a bar is never tighter than this many times the measured floor
-MAX_PROJECTIONS = 3000   # observations sampled (fixed stride) for the projection comparison
+MAX_PROJECTIONS = 20000  # every observation up to this many, beyond it a fixed-stride sample of this size
+# the models whose intrinsics a scene always observes (focal lengths, principal point, one radial term): compared
+# coefficient by coefficient as well as through their projections
+WELL_CONDITIONED_MODELS = (0, 1, 2)   # SIMPLE_PINHOLE, PINHOLE, SIMPLE_RADIAL
 
 
 def projection_diff_px(a, b) -> float:
@@ -48,6 +51,20 @@ def projection_diff_px(a, b) -> float:
     return worst
 
 
+def cams_rel_diff(a, b) -> float:
+    """Largest relative difference between the variable intrinsics of the well-conditioned camera models."""
+    worst = 0.0
+    for k in range(len(a.cam_model)):
+        model = int(a.cam_model[k])
+        if model not in WELL_CONDITIONED_MODELS:
+            continue
+        P = ba_oracle.NUM_PARAMS[model]
+        ca, cb = np.asarray(a.cams[k, :P], float), np.asarray(b.cams[k, :P], float)
+        scale = np.maximum(np.abs(ca), 1.0 if model != 2 else np.array([1.0, 1.0, 1.0, 1e-2]))
+        worst = max(worst, float((np.abs(ca - cb) / scale).max()))
+    return worst
+
+
 @dataclass
 class Diff:
     cost_rel: float
@@ -56,9 +73,16 @@ class Diff:
     poses: float
     sensors: float
     proj_px: float
+    cams_rel: float = 0.0
+
 
     def scaled(self, f):
         return Diff(*(f * getattr(self, k) for k in self.__dataclass_fields__))
+
+
+# No floor, however large it measures, loosens a bar beyond this: a problem whose own perturbed solve moves further
+# than that is reported (the comparison fails) instead of passing with an arbitrary disagreement.
+CEILING = Diff(cost_rel=1e-4, traj_rel=1e-4, points=1e-2, poses=1e-2, sensors=1e-2, proj_px=1e-2, cams_rel=1e-3)
 
 
 def diff(a, ra, b, rb, n_traj=4) -> Diff:
@@ -70,11 +94,11 @@ def diff(a, ra, b, rb, n_traj=4) -> Diff:
     return Diff(cost_rel=abs(ra.final_cost - rb.final_cost) / max(abs(ra.final_cost), 1e-300),
                 traj_rel=float((np.abs(la - lb) / np.maximum(np.abs(la), 1e-300)).max()) if n else 0.0,
                 points=float(np.abs(a.points - b.points).max()), poses=float(np.abs(a.poses - b.poses).max()),
-                sensors=sens, proj_px=projection_diff_px(a, b))
+                sensors=sens, proj_px=projection_diff_px(a, b), cams_rel=cams_rel_diff(a, b))
 
 
 def assert_solutions_close(a, want, b, got, floor=None, cost_rtol=1e-8, param_atol=1e-6, traj_rtol=1e-7,
-                           proj_atol=1e-5):
+                           proj_atol=1e-5, cams_rtol=1e-6):
     """`(a, want)` = the oracle's solution and summary, `(b, got)` = the HIP solve's; `floor` = a callable returning
     diff(oracle, perturbed oracle) of the same problem, or None. The base bars are tried first; only a comparison that
     misses one of them pays for the perturbed oracle solve, and is then held to max(base, FLOOR_MARGIN x floor). Counts
@@ -84,7 +108,7 @@ def assert_solutions_close(a, want, b, got, floor=None, cost_rtol=1e-8, param_at
     assert abs(got.initial_cost - want.initial_cost) <= 1e-12 * want.initial_cost
     d = diff(a, want, b, got)
     base = Diff(cost_rel=cost_rtol, traj_rel=traj_rtol, points=param_atol, poses=param_atol, sensors=param_atol,
-                proj_px=proj_atol)
+                proj_px=proj_atol, cams_rel=cams_rtol)
 
     def misses(bars):
         return [f"{k}: {getattr(d, k):.3e} > {getattr(bars, k):.3e}" for k in d.__dataclass_fields__
@@ -93,7 +117,7 @@ def assert_solutions_close(a, want, b, got, floor=None, cost_rtol=1e-8, param_at
     bars, f = base, None
     if misses(base) and floor is not None:
         f = (floor() if callable(floor) else floor).scaled(FLOOR_MARGIN)
-        bars = Diff(*(max(getattr(base, k), getattr(f, k)) for k in d.__dataclass_fields__))
+        bars = Diff(*(max(getattr(base, k), min(getattr(f, k), getattr(CEILING, k))) for k in d.__dataclass_fields__))
     bad = misses(bars)
     assert not bad, "HIP vs oracle beyond the bar (floor x %g = %s): %s" % (FLOOR_MARGIN, f, "; ".join(bad))
     # the termination type is compared last: two solvers at the noise floor of an ill-conditioned problem may stop one

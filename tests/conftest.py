@@ -33,10 +33,38 @@ _LONG_TAIL = ("camera_models", "fisheye_models", "test_opencv_model", "test_radi
               "pose_prior", "_cli", "test_cpp_", "full_size_properties", "stereo_fusion_command")
 
 
+# The two long solves through the reference's own build (tests/test_pm_ref.py: minutes each of a kernel that occupies a
+# few dozen CUs) run in background processes from the moment the collection shows they are selected, and their tests
+# come LAST: the reference solves overlap with the whole rest of the suite instead of adding to it (ref_pm_cases.py).
+_REF_BACKGROUND = {"test_reference_full_solve_config0_photometric": ("config0_photometric", True),
+                   "test_reference_full_solve_bench_crop": ("bench_crop_384x288", False)}
+
+
 def _gpu_tier(nodeid: str) -> int:
+    if any(k in nodeid for k in _REF_BACKGROUND):
+        return 3
     if any(k in nodeid for k in _LONG_TAIL):
         return 2
     return 0 if any(k in nodeid for k in _CONTRACT) else 1
+
+
+def _start_reference_workers(items):
+    selected = [v for k, v in _REF_BACKGROUND.items() if any(k in it.nodeid for it in items)]
+    if not selected:
+        return
+    try:
+        import ref_pm
+        import ref_pm_cases
+        import torch
+        if not (ref_pm.available() and torch.cuda.is_available()):
+            return
+        slow = int(os.environ.get("COLMAP_AMD_TEST_SLOW", "0") or 0)
+        for name, oracle0 in selected:
+            ref_pm_cases.start(name, fast=False, oracle0=oracle0 or slow >= 2)
+            if slow and ref_pm.fast_available():
+                ref_pm_cases.start(name, fast=True)
+    except Exception as e:   # the tests then solve in-process
+        sys.stderr.write(f"conftest: reference workers not started ({e!r})\n")
 
 
 def pytest_collection_modifyitems(config, items):
@@ -44,6 +72,12 @@ def pytest_collection_modifyitems(config, items):
     ordered = sorted((items[i] for i in gpu), key=lambda it: _gpu_tier(it.nodeid))   # stable: file order inside a tier
     for slot, it in zip(gpu, ordered):
         items[slot] = it
+
+
+def pytest_collection_finish(session):
+    # after deselection (-m / -k): only what will really run starts a worker
+    if not session.config.option.collectonly:
+        _start_reference_workers(session.items)
 
 
 class _StandInLibrary:

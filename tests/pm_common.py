@@ -110,11 +110,11 @@ def write_dense_workspace(path, views, num_points=400, seed=0, cfg_spec="__auto_
     return names
 
 
-def bench_crop_problem(device=None):
+def bench_crop_problem(device=None, cw=512, ch=384):
     """The problem bench.py hands to the oracle for `cpu_baseline`: a 512 x 384 centre crop of a 2560 x 1920
     reference image against its 20 full-resolution sources (S = 20, M = 15). Returns (views with the crop in the
     reference's place, ref index, source indices, the crop view, depth range)."""
-    W, H, S, cw, ch = 2560, 1920, 20, 512, 384
+    W, H, S = 2560, 1920, 20
     views = syn.make_scene(S + 1, W, H, arc_deg=3.6 * S, **({"device": device} if device else {}))
     ref = S // 2
     src = [i for i in range(S + 1) if i != ref]

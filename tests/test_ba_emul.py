@@ -65,6 +65,7 @@ def test_constant_blocks_gauges_and_partial_problems():
     G.test_pair_terms_per_incidence_equal_per_observation()
     G.test_only_points_variable_and_only_cameras_variable()
     G.test_error_behaviour()
+    G.test_iteration_callback_stops_with_the_last_accepted_state()
 
 
 def test_reference_backend_cases_and_golden_fixture():

@@ -251,6 +251,36 @@ def test_error_behaviour():
                                         est.BundleAdjustmentConfig(), scene.Reconstruction())
 
 
+def test_iteration_callback_stops_with_the_last_accepted_state():
+    """ba_options.iteration_callback = the reference's BundleAdjustmentIterationCallback
+    (controllers/bundle_adjustment.cc:40-57,84-86): a callback that asks to terminate after iteration 3 ends the
+    solve with USER_SUCCESS (estimators/bundle_adjustment.h:50-57: a usable solution), the parameter blocks hold
+    iteration 3's accepted state -- the same bits a solve limited to three iterations leaves -- and the callback saw
+    iterations 0..3 with the logged costs; BA_CALLBACK_ABORT gives USER_FAILURE."""
+    seen = []
+
+    def stop_at_3(sm):
+        seen.append((sm.iteration, sm.cost, sm.step_is_successful, sm.linear_solver_iterations))
+        return est.CALLBACK_TERMINATE if sm.iteration >= 3 else est.CALLBACK_CONTINUE
+
+    a = _flat(12, 300, 5, seed=3)
+    b = _flat(12, 300, 5, seed=3)
+    sa = est.solve_flat(a, est.SolverOptions(iteration_callback=stop_at_3, **TIGHT), gpu_index=0)
+    sb = est.solve_flat(b, est.SolverOptions(gradient_tolerance=1e-10, max_num_iterations=3), gpu_index=0)
+    assert sa.termination_type == est.BundleAdjustmentTerminationType.USER_SUCCESS
+    assert sa.num_iterations == 3 and [it for it, *_ in seen] == [0, 1, 2, 3]
+    assert seen[0][1] == sa.initial_cost
+    assert [c for _, c, *_ in seen[1:]] == list(sa.log_cost) and list(sa.log_cost) == list(sb.log_cost)
+    assert sa.final_cost == sb.final_cost == sa.log_cost[-1]
+    for name in ("poses", "cams", "points"):
+        assert np.array_equal(getattr(a, name), getattr(b, name)), name
+    assert sa.setup_seconds > 0.0 and sa.lm_seconds > 0.0
+    c = _flat(12, 300, 5, seed=3)
+    sc = est.solve_flat(c, est.SolverOptions(iteration_callback=lambda sm: est.CALLBACK_ABORT, **TIGHT), gpu_index=0)
+    assert sc.termination_type == est.BundleAdjustmentTerminationType.USER_FAILURE and sc.num_iterations == 0
+    assert np.array_equal(c.points, _flat(12, 300, 5, seed=3).points)   # nothing was accepted
+
+
 def test_against_committed_golden_fixture():
     """tests/golden/ba_6x40.npz (oracle solution, committed) reproduced by the HIP solver."""
     import os
@@ -472,8 +502,11 @@ def _sharded_worker(rank, world, port, backend, q, sharding=0, priors=False, sha
         fp = _sharded_problem(priors, shared)
         comm = est.Communicator(backend, gpu_index=0, sharding=sharding)
         s = est.solve_flat(fp, est.SolverOptions(linear_solver_type=solver, **TIGHT), gpu_index=0, comm=comm)
+        import ctypes as C
+        pl, sw = C.c_int64(), C.c_int64()
+        est.lib().ba_last_pcg_loops(C.byref(pl), C.byref(sw))
         q.put((rank, s.final_cost, s.num_residuals, s.num_iterations, fp.poses.copy(), fp.points.copy(), comm.calls,
-               None if s.log_linear_iters is None else np.asarray(s.log_linear_iters).copy()))
+               None if s.log_linear_iters is None else np.asarray(s.log_linear_iters).copy(), (pl.value, sw.value)))
         comm.close()
         dist.barrier()
     finally:
@@ -504,10 +537,19 @@ def test_two_rank_sharded_solve_matches_single_gpu(sharding, priors):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (r0, c0, n0, it0, poses0, pts0, calls0, _), (r1, c1, n1, it1, poses1, pts1, calls1, _) = res
+    (r0, c0, n0, it0, poses0, pts0, calls0, lin0, loops0), (r1, c1, n1, it1, poses1, pts1, calls1, lin1, loops1) = res
     assert c0 == c1 and np.array_equal(poses0, poses1) and np.array_equal(pts0, pts1)   # ranks agree bitwise
     assert n0 == n1 == s1.num_residuals
     assert calls0 == calls1 > 0
+    if sharding == est.SHARD_BY_POINT and not priors:
+        # the pipelined PCG loop (host one iteration behind, stopping test on the device; the one collective per
+        # iteration is the all-reduce of the camera-space vector) on every rank, and the single-rank iteration counts
+        assert loops0 == loops1 and loops0[0] > 0 and loops0[1] == 0, (loops0, loops1)
+        # (the first dozen LM iterations: near the 1e-10 gradient the counts differ by summation order)
+        k = min(12, s1.num_iterations, it0)
+        assert np.array_equal(lin0, lin1) and np.array_equal(lin0[:k], np.asarray(s1.log_linear_iters)[:k]), (lin0, s1.log_linear_iters)
+    else:
+        assert loops0 == loops1 and loops0[0] == 0
     assert abs(c0 - s1.final_cost) <= 1e-9 * s1.final_cost
     np.testing.assert_allclose(pts0, single.points, atol=1e-7)
     np.testing.assert_allclose(poses0, single.poses, atol=1e-7)
