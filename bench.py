@@ -80,6 +80,7 @@ def cpu_baseline(views, ref, src, dmin, dmax, crop_wh):
         else:
             imgs.append(dict(K=vv.K, R=vv.R, T=vv.T, gray=vv.gray))
     o = pm_oracle.default_options(depth_min=dmin, depth_max=dmax, geom_consistency=0, filter=1)
+    o.num_threads = os.cpu_count() or 0   # every host core (importing torch caps OpenMP's default at the physical cores)
     t = time.time()
     pm_oracle.run(o, imgs, ref, src)
     dt = time.time() - t
@@ -240,7 +241,7 @@ def ba_secondary(a, local_rank, with_cpu, rank=0, world=1, dev=None):
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import ba_oracle
             c1 = fp1.copy()
-            o1 = est.solve_flat(c1, est.SolverOptions(max_num_iterations=9), solve_fn=ba_oracle.solve_fn)
+            o1 = est.solve_flat(c1, est.SolverOptions(max_num_iterations=9), solve_fn=ba_oracle.solve_fn, num_threads=os.cpu_count() or 0)
             h1 = est.solve_flat(fp1.copy(), est.SolverOptions(max_num_iterations=9), gpu_index=local_rank)
             m1 = min(len(o1.log_cost), len(h1.log_cost))
             out["shared_intrinsics"]["hip_vs_oracle_max_rel_cost_diff"] = \
@@ -271,7 +272,8 @@ def ba_secondary(a, local_rank, with_cpu, rank=0, world=1, dev=None):
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import ba_oracle
         c = fp.copy()
-        sc = est.solve_flat(c, est.SolverOptions(max_num_iterations=9), solve_fn=ba_oracle.solve_fn)  # ~10 s on the box's host cores
+        sc = est.solve_flat(c, est.SolverOptions(max_num_iterations=9), solve_fn=ba_oracle.solve_fn,
+                            num_threads=os.cpu_count() or 0)  # ~10 s on the box's host cores (all of them)
         # parity on the benchmark problem itself: the HIP cost log of the same 9 iterations against the oracle's
         sh = est.solve_flat(fp.copy(), est.SolverOptions(max_num_iterations=9), gpu_index=local_rank)
         m = min(len(sc.log_cost), len(sh.log_cost))
@@ -336,7 +338,8 @@ def ba2_leg(a, local_rank, with_cpu):
         d10 = scene.synthesize_flat(frames // 10, points // 10, track, seed=44, mixed_models=True, noise=noise)
         f10 = est.FlatProblem.from_arrays(d10)
         est.fix_gauge_two_cams(f10)
-        o10 = est.solve_flat(f10.copy(), est.SolverOptions(max_num_iterations=3), solve_fn=ba_oracle.solve_fn)
+        o10 = est.solve_flat(f10.copy(), est.SolverOptions(max_num_iterations=3), solve_fn=ba_oracle.solve_fn,
+                             num_threads=os.cpu_count() or 0)
         h10 = est.solve_flat(f10.copy(), est.SolverOptions(max_num_iterations=3), gpu_index=local_rank)
         m = min(len(o10.log_cost), len(h10.log_cost))
         out["parity_at_one_tenth"] = {

@@ -10,6 +10,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <condition_variable>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -1005,7 +1007,8 @@ void RunBatchAsync(pm_handle** hs, int n, hipStream_t run_st = nullptr) {
     for (int b = 0; b < n; ++b)  // debug progress trace: every launch starts from an empty buffer
       if (hs[b]->trace.ptr)
         HIP_CALL(hipMemsetAsync(hs[b]->trace.ptr, 0, hs[b]->trace.count * sizeof(unsigned long long), st));
-    HIP_CALL(hipEventRecord(h0->ev[2 * k], st));
+    pm_launch_draws(host[(size_t)(k + 1) * n], h0->plan.ptr + (size_t)(k + 1) * n, n, geom, st);
+    HIP_CALL(hipEventRecord(h0->ev[2 * k], st));   // the events bracket the sweep kernel alone
     h0->sweep_kernel = pm_launch_sweep(host[(size_t)(k + 1) * n], h0->plan.ptr + (size_t)(k + 1) * n, n,
                                        h0->threads, geom, fphoto, fgeom, st);
     HIP_CALL(hipEventRecord(h0->ev[2 * k + 1], st));
@@ -1113,6 +1116,95 @@ int Guard(F&& f) {
 }
 
 }  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------
+// pm_run from several host threads at once -- how the reference's controller drives the seam, one problem per worker
+// thread (mvs/patch_match.cc:190-204, its `gpu_index = 0,0,...` idiom for several problems per GPU) -- is coalesced:
+// the calls that arrive together run as ONE batch (RunBatchSplitAsync: every launch covers all of them), each caller
+// returns when its own problem is done. The first arrival leads: it waits while further calls keep arriving (at most
+// 3 ms, until 300 us pass without one, or until every live handle of the device has called), runs the calls that can
+// share launches with the oldest pending one (same image size / source count / options: what pm_run_batch requires),
+// and hands leadership on. Results do not depend on it (a batch equals its single runs bit for bit); a lone caller pays
+// at most the 300 us. COLMAP_AMD_PM_COALESCE=0 (development switch) runs every call on its own.
+// ---------------------------------------------------------------------------------------------------------------
+struct RunCall {
+  pm_handle* h;
+  bool done = false;
+  std::string err;
+};
+struct RunCoalescer {
+  std::mutex mu;
+  std::condition_variable cv;
+  std::vector<RunCall*> pending;
+  bool leader_active = false;
+};
+static RunCoalescer g_coalescer[16];
+
+static bool BatchCompatible(const pm_handle* a, const pm_handle* b) {
+  const pm_options& x = a->opt;
+  const pm_options& y = b->opt;
+  return a->device == b->device && a->W == b->W && a->H == b->H && a->S == b->S && a->src_w == b->src_w &&
+         a->src_h == b->src_h && x.window_radius == y.window_radius && x.window_step == y.window_step &&
+         x.num_samples == y.num_samples && x.num_iterations == y.num_iterations &&
+         x.geom_consistency == y.geom_consistency && x.filter == y.filter && x.max_sweeps == y.max_sweeps &&
+         a->base.prof == nullptr && b->base.prof == nullptr && a->base.trace == nullptr && b->base.trace == nullptr;
+}
+
+void RunCoalesced(pm_handle* h) {
+  if (dev_switch_int("COLMAP_AMD_PM_COALESCE", 1) == 0 || h->base.prof || h->base.trace) {
+    RunAsync(h);
+    Synchronize(h);
+    return;
+  }
+  RunCoalescer& Q = g_coalescer[h->device & 15];
+  RunCall me{h};
+  std::unique_lock<std::mutex> lock(Q.mu);
+  Q.pending.push_back(&me);
+  Q.cv.notify_all();  // a gathering leader counts arrivals
+  while (!me.done) {
+    if (Q.leader_active) {
+      Q.cv.wait(lock);
+      continue;
+    }
+    Q.leader_active = true;
+    {
+      const auto deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds(3);
+      size_t seen = Q.pending.size();
+      while ((int)seen < g_live_handles[h->device & 15].load() && std::chrono::steady_clock::now() < deadline) {
+        Q.cv.wait_for(lock, std::chrono::microseconds(300));
+        if (Q.pending.size() == seen) break;  // quiet: nobody else is about to call
+        seen = Q.pending.size();
+      }
+    }
+    std::vector<RunCall*> batch, rest;
+    for (RunCall* c : Q.pending) (BatchCompatible(Q.pending[0]->h, c->h) ? batch : rest).push_back(c);
+    Q.pending.swap(rest);
+    lock.unlock();
+    std::string err;
+    try {
+      std::vector<pm_handle*> hs;
+      for (RunCall* c : batch) hs.push_back(c->h);
+      if (hs.size() == 1) {
+        RunAsync(hs[0]);
+      } else {
+        RunBatchSplitAsync(hs.data(), (int)hs.size());
+      }
+      for (pm_handle* x : hs) Synchronize(x);
+    } catch (const std::exception& e) {
+      err = e.what();
+      if (err.empty()) err = "pm_run failed";
+    }
+    lock.lock();
+    for (RunCall* c : batch) {
+      c->done = true;
+      c->err = err;
+    }
+    Q.leader_active = false;
+    Q.cv.notify_all();
+  }
+  lock.unlock();
+  if (!me.err.empty()) throw std::runtime_error(me.err);
+}
 
 extern "C" {
 
@@ -1222,8 +1314,7 @@ int pm_synchronize(pm_handle* h) {
 int pm_run(pm_handle* h) {
   return Guard([&] {
     PM_CHECK(h, "null handle");
-    RunAsync(h);
-    Synchronize(h);
+    RunCoalesced(h);
   });
 }
 

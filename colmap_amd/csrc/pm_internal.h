@@ -110,6 +110,9 @@ void pm_launch_init_state(const PmParams& p, bool random_init, float depth_min, 
 // `p` describes the (identical) shape of every problem of the batch; `dev_params` is the
 // device array of per-problem parameter blocks the kernel indexes with its batch coordinate.
 void pm_launch_initial_cost(const PmParams& p, const PmParams* dev_params, int batch, hipStream_t st);
+// the random numbers of the next sweep launch (11 x 11 kernel; no-op for shapes the generic kernel serves): call before
+// pm_launch_sweep with the same arguments
+void pm_launch_draws(const PmParams& p, const PmParams* dev_params, int batch, bool geom, hipStream_t st);
 // returns the name of the kernel it launched
 const char* pm_launch_sweep(const PmParams& p, const PmParams* dev_params, int batch, int threads, bool geom,
                             bool filter_photo, bool filter_geom, hipStream_t st);

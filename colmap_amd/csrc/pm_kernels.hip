@@ -1854,7 +1854,7 @@ __device__ __forceinline__ void run_tasks_wave(const PmParams& p, const Lds& L, 
 
 // Phase profile of the wave kernel (PROF instantiation, pm_enable_phase_profile): every wave accumulates shader-clock
 // deltas per phase in scalar registers and adds them to p.prof[] when it retires. Slots:
-constexpr int kProfSetup = 0, kProfP0 = 1, kProfP1 = 2, kProfP1w = 3, kProfP2 = 4, kProfP3a = 5, kProfP3b = 6,
+[[maybe_unused]] constexpr int kProfSetup = 0, kProfP0 = 1, kProfP1 = 2, kProfP1w = 3, kProfP2 = 4, kProfP3a = 5, kProfP3b = 6,
               kProfP3c = 7, kProfP4A = 8, kProfP4B = 9, kProfP4F = 10, kProfP5a = 11, kProfP5b = 12, kProfP5c = 13,
               kProfP6A = 14, kProfP6B = 15, kProfP6F = 16, kProfP7 = 17, kProfP8 = 18, kProfSlots = kPmProfSlots;
 
@@ -2286,6 +2286,10 @@ __global__ void __launch_bounds__(64 * kQuadWaves, 4) pm_sweep_quad_prof_kernel(
 // on C of 64 lanes: here a lane is a column and a wave covers 64 of them. Per pixel: {rd, rn0, rn1, rn2, u[M]}.
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(64) pm_draw_kernel(const PmParams* __restrict__ pp) {
+  // A few hundred waves, each a long serial chain, usually beside the other sub-batch's sweep launch (20 waves per CU
+  // that are never short of work): without priority a draw wave gets one issue slot in twenty and the sweep behind it
+  // waits 45-100 ms instead of 7.
+  __builtin_amdgcn_s_setprio(3);
   const PmParams& p = pp[blockIdx.y];
   const int RW = rot_width(p), RH = rot_height(p);
   const int col = blockIdx.x * 64 + threadIdx.x;
@@ -2435,11 +2439,21 @@ void pm_launch_initial_cost(const PmParams& p, const PmParams* dev_params, int b
 //    sizes, more source images than the four-wave LDS block holds, COLMAP_AMD_PM_WAVE=0.
 // The 11 x 11 kernel exists with and without the buffer-resource addressing of the packed images (fp_resource).
 // Both families produce the same bits.
+// The sweep's random numbers (pm_draw_kernel), launched in front of a sweep that reads them; a launch of its own so
+// that the caller's events bracket the sweep kernel alone.
+static bool pm_sweep_takes_wave_kernel(const PmParams& p, bool geom) {
+  return dev_switch_int("COLMAP_AMD_PM_WAVE", 1) != 0 && p.draws != nullptr && pm_sweep_uses_draws(p, geom);
+}
+void pm_launch_draws(const PmParams& p, const PmParams* dev_params, int batch, bool geom, hipStream_t st) {
+  if (!pm_sweep_takes_wave_kernel(p, geom)) return;
+  const int rw = (p.rot & 1) ? p.H : p.W;
+  hipLaunchKernelGGL(pm_draw_kernel, dim3((rw + 63) / 64, batch, 1), dim3(64, 1, 1), 0, st, dev_params);
+}
+
 const char* pm_launch_sweep(const PmParams& p, const PmParams* dev_params, int batch, int threads, bool geom,
                             bool filter_photo, bool filter_geom, hipStream_t st) {
   const int rw = (p.rot & 1) ? p.H : p.W;
   const unsigned groups = (unsigned)((rw + p.C - 1) / p.C);
-  const bool wave_enabled = dev_switch_int("COLMAP_AMD_PM_WAVE", 1) != 0;
 #define PM_LAUNCH_V4(KERNEL, MB, GRID, BLOCK, LDS)                                                   \
   do {                                                                                              \
     if (geom) {                                                                                     \
@@ -2450,12 +2464,11 @@ const char* pm_launch_sweep(const PmParams& p, const PmParams* dev_params, int b
       else hipLaunchKernelGGL((KERNEL<false, false, false, MB>), GRID, BLOCK, LDS, st, dev_params); \
     }                                                                                               \
   } while (0)
-  if (wave_enabled && p.draws != nullptr && pm_sweep_uses_draws(p, geom)) {
+  if (pm_sweep_takes_wave_kernel(p, geom)) {   // (pm_launch_draws has run in front of this launch)
     // COLMAP_AMD_PM_FP_GLOBAL=1 (tests): explicit indices although the buffer resource would do
     const bool mubuf = pm_fp_resource_ok(p) && dev_switch_int("COLMAP_AMD_PM_FP_GLOBAL", 0) == 0;
     const size_t qlds = lds_offsets_wave(p.C, p.S, p.radius, p.ntaps, p.num_samples, geom, kQuadThCap, kQuadWaves).total;
     const dim3 qgrid((groups + kQuadWaves - 1) / kQuadWaves, batch, 1), qblock(64 * kQuadWaves, 1, 1);
-    hipLaunchKernelGGL(pm_draw_kernel, dim3((rw + 63) / 64, batch, 1), dim3(64, 1, 1), 0, st, dev_params);
     if (p.prof && mubuf && !geom) {
       // phase profile (pm_enable_phase_profile): the shipped kernel with its phase clocks compiled in
       if (filter_photo) hipLaunchKernelGGL(pm_sweep_quad_prof_kernel<true>, qgrid, qblock, qlds, st, dev_params);

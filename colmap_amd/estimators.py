@@ -193,13 +193,14 @@ class BundleAdjustmentOptions:
     # bundle_adjustment_ceres.cc:203-213); solve_flat's own default stays ITERATIVE_SCHUR
     solver_options: SolverOptions = field(default_factory=lambda: SolverOptions(linear_solver_type=2))
     # The AUTO rule's thresholds. The reference keeps one pair per device class (bundle_adjustment_ceres.h:68-71:
-    # 50 / 1000 images for its CPU solvers, 200 / 4000 for Ceres-CUDA); this backend's pair is MEASURED on the MI355X
-    # (scripts/ba_tier_crossover.py, profiles/r05_ba_tier_crossover.json): both exact tiers form the
-    # reduced camera system densely (cost ~ n_c^3), so they win per unit of cost reduction up to ~500 images
-    # (0.9 / 2.8 / 7.1 ms per LM iteration at 50 / 200 / 500 images against 1.0 / 1.4 / 1.5 for Schur-PCG, which
-    # needs 4 .. 25x the iterations for the same cost) and lose from ~700 on (10.4 vs 1.9 ms, 16.5 vs 2.7 at 1000).
+    # 50 / 1000 images for its CPU solvers, 200 / 4000 for Ceres-CUDA). Measured on the MI355X over three seeds per size
+    # (scripts/ba_tier_crossover.py, profiles/r06_ba_tier_crossover.json; criterion: time to the cost the
+    # exact tier has after three LM steps): the exact tiers get there first at every size from 50 to 4000 images (at 350
+    # and 1000 Schur-PCG is level with them, 14.4 vs 14.5 ms and 44.9 vs 47.4 ms; from 1500 on it does not reach that
+    # cost within 30 LM iterations on any seed), so the rule is the reference's own GPU pair -- monotone in the image
+    # count, exact wherever the reduced camera system fits the dense formation (n_c <= 32 768, about 4000 images).
     max_num_images_direct_dense_gpu_solver: int = 200
-    max_num_images_direct_sparse_gpu_solver: int = 500
+    max_num_images_direct_sparse_gpu_solver: int = 4000
 
     def Check(self) -> bool:
         return self.min_track_length >= 0
@@ -758,12 +759,13 @@ def _check_abi(L):
 
 
 def solve_flat(fp: FlatProblem, so: Optional[SolverOptions] = None, gpu_index: int = -1,
-               max_log: int = 256, solve_fn=None, comm: Optional[Communicator] = None) -> BundleAdjustmentSummary:
+               max_log: int = 256, solve_fn=None, comm: Optional[Communicator] = None,
+               num_threads: int = 0) -> BundleAdjustmentSummary:
     """ba_solve on a flat problem (in place). `solve_fn` lets the tests route the identical
     marshalled structs to the oracle library instead."""
     so = so or SolverOptions()
     p = marshal_problem(fp)
-    o = marshal_options(so, max_log=max_log)
+    o = marshal_options(so, max_log=max_log, num_threads=num_threads)   # (threads: the CPU checker's; unused on the GPU)
     r = ba_result()
     log_cost = np.zeros(max(max_log, 1))
     log_radius = np.zeros(max(max_log, 1))
@@ -833,7 +835,7 @@ def shard_num_observations(fp: FlatProblem, rank: int, world_size: int, sharding
     return int(fn(C.byref(p), C.c_int32(rank), C.c_int32(world_size)))
 
 
-def resolve_linear_solver(num_images: int, max_dense: int = 200, max_sparse: int = 500) -> int:
+def resolve_linear_solver(num_images: int, max_dense: int = 200, max_sparse: int = 4000) -> int:
     """The AUTO rule (CreateSolverOptions, bundle_adjustment_ceres.cc:203-213): DENSE_SCHUR up to `max_dense` images,
     SPARSE_SCHUR up to `max_sparse`, ITERATIVE_SCHUR beyond."""
     if num_images <= max_dense:

@@ -400,11 +400,13 @@ struct Mi355xBundleAdjustmentOptions {
   // it when BaseController::CheckIfStopped() says so and Solve() returns USER_SUCCESS with the last accepted step.
   ba_options solver_options;
   // The AUTO rule's thresholds. The reference keeps one pair per device class (bundle_adjustment_ceres.h:68-71:
-  // 50 / 1000 images for its CPU solvers, 200 / 4000 for Ceres-CUDA); this backend's pair is measured on the MI355X
-  // (scripts/ba_tier_crossover.py, profiles/r05_ba_tier_crossover.json): the exact tiers form the
-  // reduced camera system densely and win per unit of cost reduction up to ~500 images, Schur-PCG from ~700 on.
+  // 50 / 1000 images for its CPU solvers, 200 / 4000 for Ceres-CUDA). Measured on the MI355X over three seeds per size
+  // (scripts/ba_tier_crossover.py, profiles/r06_ba_tier_crossover.json; criterion: time to the cost the
+  // exact tier has after three LM steps): the exact tiers get there first from 50 to 4000 images (Schur-PCG is level with
+  // them at 350 and 1000 and does not reach that cost within 30 LM iterations from 1500 on), so the rule is the
+  // reference's own GPU pair -- monotone, exact wherever the reduced camera system fits the dense formation.
   int max_num_images_direct_dense_gpu_solver = 200;
-  int max_num_images_direct_sparse_gpu_solver = 500;
+  int max_num_images_direct_sparse_gpu_solver = 4000;
   Mi355xBundleAdjustmentOptions() {
     ba_options_init(&solver_options);
     // the reference's solver choice by problem size (CreateSolverOptions, bundle_adjustment_ceres.cc:203-213)

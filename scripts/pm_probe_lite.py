@@ -38,7 +38,7 @@ def make(a):
         rng.append((float(d.min()), float(d.max())))
         print(f"view {i + 1}/{n} rendered ({time.time() - t:.0f}s)", flush=True)
     os.makedirs(os.path.dirname(NPZ), exist_ok=True)
-    np.savez(NPZ, gray=gray, K=np.stack(K), R=np.stack(R), T=np.stack(T), range=np.array(rng), S=a.S, batch=a.batch)
+    np.savez_compressed(NPZ, gray=gray, K=np.stack(K), R=np.stack(R), T=np.stack(T), range=np.array(rng), S=a.S, batch=a.batch)
     print(NPZ, os.path.getsize(NPZ) / 1e6, "MB")
 
 
@@ -47,6 +47,9 @@ def run(a):
         from colmap_amd import build as _b
         _b.LIB_PATH = os.path.abspath(os.environ["PM_PROBE_LIB"])
     from colmap_amd import mvs
+    for kv in a.switch:   # development switches of the library (csrc/switches.h), e.g. COLMAP_AMD_PM_WAVE=0
+        k, v = kv.split("=", 1)
+        mvs.lib().colmap_amd_set_switch(k.encode(), v.encode())
     z = np.load(NPZ)
     S, batch = int(z["S"]), int(z["batch"]) if a.batch <= 0 else a.batch
     half = S // 2
@@ -132,6 +135,7 @@ if __name__ == "__main__":
     ap.add_argument("--ring", type=int, default=100); ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--cols", type=int, default=0); ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--sweeps", type=int, default=0)
+    ap.add_argument("--switch", action="append", default=[], help="development switch NAME=VALUE (repeatable)")
     ap.add_argument("--split", type=int, default=1, help="run the batch as N concurrent sub-batches (one stream each)")
     ap.add_argument("--profile", action="store_true", help="launch the phase-profiling build of the sweep kernel")
     ap.add_argument("--profile-out", default="")

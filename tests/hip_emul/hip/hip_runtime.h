@@ -305,6 +305,7 @@ inline unsigned long long collective(unsigned long long mine, F&& f) {
 inline void __syncthreads() { hip_emul::block_barrier(); }
 inline void __builtin_amdgcn_wave_barrier() { hip_emul::wave_barrier(); }
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
+#define __builtin_amdgcn_s_setprio(p) ((void)0)
 
 inline unsigned long long __ballot(int pred) {
   return hip_emul::collective(pred ? 1ull : 0ull, [](const unsigned long long* s, int n) {

@@ -1013,17 +1013,19 @@ def test_robust_alignment_to_pose_priors_rejects_an_outlier():
 def test_adapter_auto_rule_uses_the_measured_gpu_thresholds():
     """CreateSolverOptions' rule (bundle_adjustment_ceres.cc:203-213) in the adapters, with this backend's GPU pair
     (the reference keeps one pair per device class, bundle_adjustment_ceres.h:68-71): DENSE_SCHUR up to 200 images,
-    SPARSE_SCHUR up to 500, ITERATIVE_SCHUR beyond -- options of BundleAdjustmentOptions like the reference's, resolved
+    SPARSE_SCHUR up to 4000, ITERATIVE_SCHUR beyond -- options of BundleAdjustmentOptions like the reference's, resolved
     by the adapter on config.NumImages() before the flat C interface is called (the oracle stands in for it here)."""
     assert est.resolve_linear_solver(1) == est.resolve_linear_solver(200) == est.SOLVER_DENSE_SCHUR
-    assert est.resolve_linear_solver(201) == est.resolve_linear_solver(500) == est.SOLVER_SPARSE_SCHUR
-    assert est.resolve_linear_solver(501) == est.resolve_linear_solver(100000) == est.SOLVER_ITERATIVE_SCHUR
+    assert est.resolve_linear_solver(201) == est.resolve_linear_solver(1000) == est.resolve_linear_solver(4000) == est.SOLVER_SPARSE_SCHUR
+    assert est.resolve_linear_solver(4001) == est.resolve_linear_solver(100000) == est.SOLVER_ITERATIVE_SCHUR
+    tiers = [est.resolve_linear_solver(n) for n in range(1, 6000, 7)]
+    assert tiers == sorted(tiers, key=[est.SOLVER_DENSE_SCHUR, est.SOLVER_SPARSE_SCHUR, est.SOLVER_ITERATIVE_SCHUR].index)   # monotone in the image count
     o = est.BundleAdjustmentOptions()
-    assert (o.max_num_images_direct_dense_gpu_solver, o.max_num_images_direct_sparse_gpu_solver) == (200, 500)
+    assert (o.max_num_images_direct_dense_gpu_solver, o.max_num_images_direct_sparse_gpu_solver) == (200, 4000)
     rec = scene.SynthesizeDataset(scene.SyntheticDatasetOptions(num_rigs=2, num_frames_per_rig=4, num_points3D=60), seed=5)
     scene.SynthesizeNoise(scene.SyntheticNoiseOptions(0.02, 0.5, 0.03, 0.5), rec, seed=6)
     used = []
-    for dense, sparse, want in ((200, 500, est.SOLVER_DENSE_SCHUR), (4, 500, est.SOLVER_SPARSE_SCHUR), (4, 6, est.SOLVER_ITERATIVE_SCHUR)):
+    for dense, sparse, want in ((200, 4000, est.SOLVER_DENSE_SCHUR), (4, 4000, est.SOLVER_SPARSE_SCHUR), (4, 6, est.SOLVER_ITERATIVE_SCHUR)):
         cfg = est.BundleAdjustmentConfig()
         for i in rec.RegImageIds():
             cfg.AddImage(i)

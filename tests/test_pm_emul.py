@@ -126,6 +126,11 @@ def test_baseline_source_count_s20_m15(pm_oracle):
     G._assert_equal(want, got, ("depth", "normal", "cost", "sel_prob"))
 
 
+def test_concurrent_runs_from_host_threads_share_launches(pm_oracle):
+    """pm_run from several host threads at once is coalesced into batched launches (pm_api.cpp: RunCoalesced)."""
+    G.test_concurrent_runs_from_host_threads_share_launches(pm_oracle)
+
+
 def test_batched_run_equals_single_runs(pm_oracle):
     views = scene(5, 35, 27)
     pms, wants = [], []

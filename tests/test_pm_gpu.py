@@ -207,6 +207,51 @@ def test_batched_run_equals_single_runs(pm_oracle):
         mvs.run_batch([pms[0], mvs.PatchMatch(h2, hip_problem(other, 1, [0, 2, 3]))])
 
 
+def test_concurrent_runs_from_host_threads_share_launches(pm_oracle):
+    """pm_run called from several host threads at once -- how the reference's controller drives the seam, one
+    problem per worker thread (mvs/patch_match.cc:190-204) -- is coalesced into batched launches: the results are the
+    oracle's bits for every problem, and at least two of the calls shared their sweep launches. A problem of another
+    shape that calls at the same time is solved on its own."""
+    import threading
+    from colmap_amd import mvs
+    views = scene(6, 67, 45)
+    probs = [(1, [0, 2, 3]), (2, [1, 3, 4]), (3, [1, 2, 4]), (4, [2, 3, 5])]
+    pms, wants = [], []
+    for ref, src in probs:
+        dmin, dmax = syn.depth_range(views, ref)
+        o, h = paired_options(pm_oracle, depth_min=dmin, depth_max=dmax, geom_consistency=0, filter=1, num_iterations=1)
+        wants.append(pm_oracle.run(o, oracle_inputs(views), ref, src, want_cost=True))
+        pms.append(mvs.PatchMatch(h, hip_problem(views, ref, src)))
+    other = scene(4, 40, 30)
+    dmin, dmax = syn.depth_range(other, 1)
+    o2, h2 = paired_options(pm_oracle, depth_min=dmin, depth_max=dmax, geom_consistency=0, filter=1, num_iterations=1)
+    wants.append(pm_oracle.run(o2, oracle_inputs(other), 1, [0, 2, 3], want_cost=True))
+    pms.append(mvs.PatchMatch(h2, hip_problem(other, 1, [0, 2, 3])))
+    for pm in pms:
+        pm.Create()
+    gate, errs = threading.Barrier(len(pms)), []
+
+    def work(pm):
+        try:
+            gate.wait()
+            pm.Run()
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+    th = [threading.Thread(target=work, args=(pm,)) for pm in pms]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    for pm, want in zip(pms, wants):
+        got = dict(depth=pm.GetDepthMap(), normal=pm.GetNormalMap(), sel_prob=pm.GetSelProbMap(),
+                   cost=pm.GetCostMap(), mask=pm.GetConsistencyMask())
+        _assert_equal(want, got)
+    shapes = [pm.GetLaunchShape()[0] for pm in pms]
+    assert max(shapes[:4]) >= 2, shapes          # calls that arrived together shared launches
+    assert shapes[4] == 1, shapes                # the odd shape ran alone
+
+
 def test_image_cache_shares_sources_without_changing_results(pm_oracle):
     """pm_create_cached: problems that name the same bitmaps gather from one packed copy; the
     outputs are the bits of the uncached run, and eviction never drops an image in use."""
