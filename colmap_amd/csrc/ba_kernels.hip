@@ -2997,11 +2997,13 @@ struct Buf {
 
 inline int grid_for(size_t n, int block) { return (int)((n + block - 1) / block); }
 
-static const bool g_ba_debug = dev_switch_int("COLMAP_AMD_BA_DEBUG", 0) != 0;  // sync + check after every launch
+// sync + check after every launch; read per launch (an atomic load unless some switch is set), so that
+// colmap_amd_set_switch("COLMAP_AMD_BA_DEBUG", "1") takes effect whenever it is called
+static inline bool ba_debug() { return dev_switch_int("COLMAP_AMD_BA_DEBUG", 0) != 0; }
 #define BA_LAUNCH(kernel, grid, block, stream, ...)                                    \
   do {                                                                                 \
     hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__);                   \
-    if (g_ba_debug) {                                                                  \
+    if (ba_debug()) {                                                                  \
       hipError_t e_ = hipStreamSynchronize(stream);                                    \
       if (e_ == hipSuccess) e_ = hipGetLastError();                                    \
       std::fprintf(stderr, "[ba] %s grid=%d -> %s\n", #kernel, (int)(grid).x, hipGetErrorString(e_)); \
@@ -3131,6 +3133,15 @@ struct Solver {
   // Reduced program: active observations (>= 1 variable block), tangent offsets, CSR structures.
   int build(ba_result* res_out) {
     const ba_problem& p = prob;
+    // COLMAP_AMD_BA_TIMING=1 (development switch): where the set-up time goes, to stderr
+    const bool timing = dev_switch_int("COLMAP_AMD_BA_TIMING", 0) != 0;
+    auto t_stage = std::chrono::steady_clock::now();
+    auto stage = [&](const char* name) {
+      if (!timing) return;
+      const auto now = std::chrono::steady_clock::now();
+      std::fprintf(stderr, "[ba set-up] %-14s %8.2f ms\n", name, 1e3 * std::chrono::duration<double>(now - t_stage).count());
+      t_stage = now;
+    };
     std::vector<int> cam_nvar(p.num_cams, 0);
     std::vector<int> wide_cam_var((size_t)p.num_cams * KD_WIDE, 0), h_cam_dim(p.num_cams, 0);
     int max_nvar = 0, max_npar = 0;
@@ -3178,21 +3189,37 @@ struct Solver {
       if ((comm.by_point ? xi : pi) % comm.world == comm.rank) active.push_back(o);
     }
     const int n = (int)active.size();
+    stage("scan");
+    // The two orders of the observations, by stable COUNTING sorts (the keys are block indices; comparison sorts of
+    // 2 M ... 20 M observations were most of the 0.3 s ... 5.5 s a solve spent before its first kernel):
     // p-order: sorted by point (stable: keeps the caller's order inside a track)
-    std::stable_sort(active.begin(), active.end(),
-                     [&](int64_t a, int64_t b) { return p.obs_point[a] < p.obs_point[b]; });
     std::vector<int> h_pt_ptr(p.num_points + 1, 0);
     for (int a = 0; a < n; ++a) h_pt_ptr[p.obs_point[active[a]] + 1]++;
     for (int j = 0; j < p.num_points; ++j) h_pt_ptr[j + 1] += h_pt_ptr[j];
-    // c-order: p-order positions sorted by (camera, pose) -> every camera-side block is a range
+    {
+      std::vector<int> cursor(h_pt_ptr.begin(), h_pt_ptr.end() - 1);
+      std::vector<int64_t> sorted((size_t)n);
+      for (int a = 0; a < n; ++a) sorted[(size_t)cursor[p.obs_point[active[a]]]++] = active[a];
+      active.swap(sorted);
+    }
+    // c-order: p-order positions sorted by (camera, pose) -> every camera-side block is a range. Least significant
+    // key first: stable by pose, then stable by camera; ties keep the p-order (what std::stable_sort on the pair gave).
     std::vector<int> h_c2a(n), h_a2c(n);
-    std::iota(h_c2a.begin(), h_c2a.end(), 0);
-    std::stable_sort(h_c2a.begin(), h_c2a.end(), [&](int a, int b) {
-      const int64_t oa = active[a], ob = active[b];
-      if (p.obs_cam[oa] != p.obs_cam[ob]) return p.obs_cam[oa] < p.obs_cam[ob];
-      return p.obs_pose[oa] < p.obs_pose[ob];
-    });
+    {
+      std::vector<int> by_pose((size_t)n), cnt((size_t)std::max(p.num_poses, p.num_cams) + 1, 0);
+      for (int a = 0; a < n; ++a) cnt[(size_t)p.obs_pose[active[a]] + 1]++;
+      for (int i = 0; i < p.num_poses; ++i) cnt[(size_t)i + 1] += cnt[i];
+      for (int a = 0; a < n; ++a) by_pose[(size_t)cnt[p.obs_pose[active[a]]]++] = a;
+      std::fill(cnt.begin(), cnt.end(), 0);
+      for (int a = 0; a < n; ++a) cnt[(size_t)p.obs_cam[active[a]] + 1]++;
+      for (int k = 0; k < p.num_cams; ++k) cnt[(size_t)k + 1] += cnt[k];
+      for (int i = 0; i < n; ++i) {
+        const int a = by_pose[i];
+        h_c2a[(size_t)cnt[p.obs_cam[active[a]]]++] = a;
+      }
+    }
     for (int c = 0; c < n; ++c) h_a2c[h_c2a[c]] = c;
+    stage("orders");
     // point tiles for the LDS-staged point passes
     std::vector<int> h_tile_pt;
     {
@@ -3211,42 +3238,11 @@ struct Solver {
       }
       if (!ok) h_tile_pt.assign(1, 0);
     }
-    // solo flags: does another observation of the same point use the same pose / camera?
-    std::vector<unsigned char> h_solo(n, 0);
-    for (int j = 0; j < p.num_points; ++j)
-      for (int a = h_pt_ptr[j]; a < h_pt_ptr[j + 1]; ++a) {
-        int same_pose = 0, same_cam = 0, same_sens = 0;
-        const int64_t oa = active[a];
-        const int sa = p.obs_sensor ? p.obs_sensor[oa] : -1;
-        for (int a2 = h_pt_ptr[j]; a2 < h_pt_ptr[j + 1]; ++a2) {
-          same_pose += p.obs_pose[active[a2]] == p.obs_pose[oa];
-          same_cam += p.obs_cam[active[a2]] == p.obs_cam[oa];
-          same_sens += sa >= 0 && p.obs_sensor[active[a2]] == sa;
-        }
-        h_solo[h_a2c[a]] = (unsigned char)((same_pose == 1 ? 1 : 0) | (same_cam == 1 ? 2 : 0) | (same_sens <= 1 ? 4 : 0));
-        n_paired += (same_pose != 1 && !p.pose_const[p.obs_pose[oa]]) + (same_cam != 1 && cam_nvar[p.obs_cam[oa]] > 0) +
-                    (same_sens > 1 && sens_used[sa]);
-        n_paired_kind[0] += same_pose != 1 && !p.pose_const[p.obs_pose[oa]];
-        n_paired_kind[1] += same_cam != 1 && cam_nvar[p.obs_cam[oa]] > 0;
-        n_paired_kind[2] += same_sens > 1 && sens_used[sa];
-      }
-    std::vector<int> h_o_pose(n), h_o_cam(n), h_o_pt(n), h_o_sensor;
-    const bool has_sensors = p.obs_sensor != nullptr && p.num_sensors > 0 && p.sensors != nullptr;
-    if (has_sensors) h_o_sensor.resize(n);
-    std::vector<double> h_xy((size_t)2 * n);
-    for (int c = 0; c < n; ++c) {
-      const int64_t o = active[h_c2a[c]];
-      if (has_sensors) h_o_sensor[c] = p.obs_sensor[o];
-      h_o_pose[c] = p.obs_pose[o];
-      h_o_cam[c] = p.obs_cam[o];
-      h_o_pt[c] = p.obs_point[o];
-      h_xy[2 * (size_t)c] = p.obs_xy[2 * o];
-      h_xy[2 * (size_t)c + 1] = p.obs_xy[2 * o + 1];
-    }
     // the same topology in p-order (position a <-> c-order position h_a2c[a])
     {
       split_linearize = dev_switch_int("COLMAP_AMD_BA_SPLIT_LINEARIZE", 1) != 0;  // read per solve: tests toggle it
     }
+    const bool has_sensors = p.obs_sensor != nullptr && p.num_sensors > 0 && p.sensors != nullptr;
     std::vector<int> h_a_pose, h_a_cam, h_a_pt, h_a_sensor;
     std::vector<double> h_a_xy;
     {  // (the explicit Schur formation reads it too, whatever the linearisation does)
@@ -3262,6 +3258,40 @@ struct Solver {
         if (has_sensors) h_a_sensor[a] = p.obs_sensor[o];
       }
     }
+    // solo flags: does another observation of the same point use the same pose / camera? (a track's entries of the
+    // p-order arrays are neighbours in memory: the quadratic loop over a track stays in cache)
+    std::vector<unsigned char> h_solo(n, 0);
+    for (int j = 0; j < p.num_points; ++j)
+      for (int a = h_pt_ptr[j]; a < h_pt_ptr[j + 1]; ++a) {
+        int same_pose = 0, same_cam = 0, same_sens = 0;
+        const int64_t oa = active[a];
+        const int sa = p.obs_sensor ? p.obs_sensor[oa] : -1;
+        const int pose_a = h_a_pose[a], cam_a = h_a_cam[a];
+        for (int a2 = h_pt_ptr[j]; a2 < h_pt_ptr[j + 1]; ++a2) {
+          same_pose += h_a_pose[a2] == pose_a;
+          same_cam += h_a_cam[a2] == cam_a;
+          same_sens += sa >= 0 && p.obs_sensor[active[a2]] == sa;
+        }
+        h_solo[h_a2c[a]] = (unsigned char)((same_pose == 1 ? 1 : 0) | (same_cam == 1 ? 2 : 0) | (same_sens <= 1 ? 4 : 0));
+        n_paired += (same_pose != 1 && !p.pose_const[p.obs_pose[oa]]) + (same_cam != 1 && cam_nvar[p.obs_cam[oa]] > 0) +
+                    (same_sens > 1 && sens_used[sa]);
+        n_paired_kind[0] += same_pose != 1 && !p.pose_const[p.obs_pose[oa]];
+        n_paired_kind[1] += same_cam != 1 && cam_nvar[p.obs_cam[oa]] > 0;
+        n_paired_kind[2] += same_sens > 1 && sens_used[sa];
+      }
+    std::vector<int> h_o_pose(n), h_o_cam(n), h_o_pt(n), h_o_sensor;
+    if (has_sensors) h_o_sensor.resize(n);
+    std::vector<double> h_xy((size_t)2 * n);
+    for (int c = 0; c < n; ++c) {
+      const int64_t o = active[h_c2a[c]];
+      if (has_sensors) h_o_sensor[c] = p.obs_sensor[o];
+      h_o_pose[c] = p.obs_pose[o];
+      h_o_cam[c] = p.obs_cam[o];
+      h_o_pt[c] = p.obs_point[o];
+      h_xy[2 * (size_t)c] = p.obs_xy[2 * o];
+      h_xy[2 * (size_t)c + 1] = p.obs_xy[2 * o + 1];
+    }
+    stage("topology");
     // tangent layout: pose blocks, then intrinsics blocks (camera side); points
     h_pose_off.assign(p.num_poses, -1);
     h_cam_off.assign(p.num_cams, -1);
@@ -3405,6 +3435,7 @@ struct Solver {
       throw std::runtime_error("rank " + std::to_string(comm.rank) + " holds no observation: use fewer ranks "
                                "than images");
 
+    stage("blocks+chunks");
     // upload
     o_pose.upload(h_o_pose); o_cam.upload(h_o_cam); o_pt.upload(h_o_pt); o_xy.upload(h_xy);
     if (has_sensors) {
@@ -3645,6 +3676,7 @@ struct Solver {
     V.Jpose = Jpose.p; V.Jcam = Jcam.p; V.Jpt = Jpt.p; V.res = res.p; V.res_p = res_p.p;
     V.scale_c = scale_c.p; V.scale_p = scale_p.p; V.scalars = scalars.p;
     maxbuf.alloc(std::max(comm.world, 1));
+    stage("upload+alloc");
     // uploads / memsets above ran on the NULL stream, the solve runs on a non-blocking stream
     BA_HIP(hipDeviceSynchronize());
     return (int)std::min<int64_t>(n_active_global, 1 << 30);

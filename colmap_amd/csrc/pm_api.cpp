@@ -50,7 +50,7 @@ struct PmError : std::runtime_error {
 // Device buffers of destroyed handles are kept for the next handle of the same shape (a controller or a
 // benchmark creates and destroys ~10 buffers of up to 1.3 GB per reference image: hipMalloc / hipFree
 // would map, clear and unmap those pages every time and hipFree synchronises the device). Exact-size
-// free lists per device; bounded by COLMAP_AMD_PM_POOL_GB (default 64); pm_release_cached_memory()
+// free lists per device; bounded by 64 GB unless pm_set_cached_memory_limit says otherwise; pm_release_cached_memory()
 // returns everything to the driver. A buffer only comes back here after pm_destroy synchronised the
 // handle's own stream AND the stream its last (batched) run was enqueued on, so the next user cannot
 // race with the previous one. The cap is additionally bounded by a quarter of the device's memory,
@@ -81,6 +81,16 @@ class DevPool {
     }
     (void)hipFree(p);
   }
+  // pm_set_cached_memory_limit: bytes the free lists may hold from now on (what is pooled beyond it goes back at once)
+  void SetCap(size_t bytes) {
+    bool shrink;
+    {
+      std::lock_guard<std::mutex> lock(mu_);
+      cap_ = bytes;
+      shrink = pooled_ > cap_;
+    }
+    if (shrink) Release();
+  }
   void Release() {
     std::lock_guard<std::mutex> lock(mu_);
     int cur = 0;
@@ -96,11 +106,9 @@ class DevPool {
 
  private:
   DevPool() {
-    const double gb = dev_switch_double("COLMAP_AMD_PM_POOL_GB", -1.0);
-    const bool e = gb >= 0.0;
-    cap_ = static_cast<size_t>((e ? gb : 64.0) * (1ull << 30));
+    cap_ = 64ull << 30;
     size_t free_b = 0, total_b = 0;
-    if (!e && hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b > 0) cap_ = std::min(cap_, total_b / 4);
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b > 0) cap_ = std::min(cap_, total_b / 4);
   }
   std::mutex mu_;
   std::map<std::pair<int, size_t>, std::vector<void*>> free_;
@@ -1555,6 +1563,13 @@ void pm_destroy(pm_handle* h) {
   // (pm_synchronize resets run_stream, so this is the exception / GC path only)
   if (h->run_stream && h->run_stream != h->stream) (void)hipDeviceSynchronize();
   delete h;
+}
+
+int pm_set_cached_memory_limit(double gigabytes) {
+  return Guard([&] {
+    PM_CHECK(gigabytes >= 0.0 && gigabytes <= 1e6, "limit in GB, >= 0");
+    DevPool::Get().SetCap(static_cast<size_t>(gigabytes * (double)(1ull << 30)));
+  });
 }
 
 void pm_release_cached_memory(void) {

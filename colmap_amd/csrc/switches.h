@@ -7,6 +7,7 @@
 // perturbation) are compiled in only with -DCOLMAP_AMD_DIAG_BUILD (pm_internal.h).
 #pragma once
 
+#include <atomic>
 #include <cstdlib>
 #include <map>
 #include <mutex>
@@ -17,6 +18,7 @@ namespace colmap_amd {
 struct DevSwitchTable {
   std::mutex mu;
   std::map<std::string, std::string> values;
+  std::atomic<int> count{0};  // entries of `values`: a process that never set a switch (the product) never takes the lock
   static DevSwitchTable& Get() {
     static DevSwitchTable* t = new DevSwitchTable();  // leaked on purpose: read from static destructors' launch paths
     return *t;
@@ -25,8 +27,7 @@ struct DevSwitchTable {
 
 // Value of a switch as a string; false when it is unset.
 inline bool dev_switch(const char* name, std::string* out) {
-  {
-    DevSwitchTable& t = DevSwitchTable::Get();
+  if (DevSwitchTable& t = DevSwitchTable::Get(); t.count.load(std::memory_order_acquire) != 0) {
     std::lock_guard<std::mutex> lock(t.mu);
     auto it = t.values.find(name);
     if (it != t.values.end()) {
@@ -62,4 +63,5 @@ extern "C" __attribute__((weak, visibility("default"))) void colmap_amd_set_swit
   std::lock_guard<std::mutex> lock(t.mu);
   if (value) t.values[name] = value;
   else t.values.erase(name);
+  t.count.store((int)t.values.size(), std::memory_order_release);
 }

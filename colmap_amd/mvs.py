@@ -153,6 +153,11 @@ def release_cached_memory():
     lib().pm_release_cached_memory()
 
 
+def set_cached_memory_limit(gigabytes: float):
+    """pm_set_cached_memory_limit: bound of the free lists that keep the device buffers of destroyed handles."""
+    _check(lib().pm_set_cached_memory_limit(C.c_double(gigabytes)))
+
+
 class ImageCache:
     """Device-side cache of packed source images shared between problems (pm_image_cache)."""
 

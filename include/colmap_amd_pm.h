@@ -214,9 +214,12 @@ void colmap_amd_set_switch(const char* name, const char* value);
 unsigned long long pm_debug_set_image_slab_slots(size_t slots);
 
 void pm_destroy(pm_handle* h);
-/* Device buffers of destroyed handles are kept (exact-size free lists, bounded by COLMAP_AMD_PM_POOL_GB,
- * default 64) for the next handle of the same shape; this returns them to the driver. */
+/* Device buffers of destroyed handles are kept (exact-size free lists, at most 64 GB and a quarter of the device's
+ * memory unless pm_set_cached_memory_limit says otherwise) for the next handle of the same shape;
+ * pm_release_cached_memory returns them to the driver, pm_set_cached_memory_limit(gigabytes) changes the bound from
+ * then on (0 = keep nothing; what is held beyond the new bound is released at once). */
 void pm_release_cached_memory(void);
+int pm_set_cached_memory_limit(double gigabytes);
 const char* pm_last_error(void);
 /* Number of visible GPUs (controller: gpu_index == -1 -> all devices,
  * patch_match.cc:375-383). */

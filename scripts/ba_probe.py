@@ -17,7 +17,7 @@ fp = est.FlatProblem.from_arrays(d); est.fix_gauge_two_cams(fp)
 so = est.SolverOptions(gradient_tolerance=a.gtol, max_num_iterations=a.iters, operator_precision=a.op32, linear_solver_type=a.lst)
 for rep in range(2):
     b = fp.copy(); t = time.time(); s = est.solve_flat(b, so, gpu_index=0); dt = time.time() - t
-    print(f"HIP rep{rep}: tier {s.linear_solver_used} factor {s.factor_seconds:.4f}s wall {dt:.3f}s lm {s.lm_seconds:.3f}s iters {s.num_iterations} succ {s.num_successful_steps} pcg {s.total_linear_iterations} cost {s.initial_cost:.6e}->{s.final_cost:.6e} {s.termination_type.name} -> {s.num_iterations/max(s.lm_seconds,1e-9):.2f} LM-it/s")
+    print(f"HIP rep{rep}: tier {s.linear_solver_used} factor {s.factor_seconds:.4f}s wall {dt:.3f}s setup {s.setup_seconds:.3f}s lm {s.lm_seconds:.3f}s iters {s.num_iterations} succ {s.num_successful_steps} pcg {s.total_linear_iterations} cost {s.initial_cost:.6e}->{s.final_cost:.6e} {s.termination_type.name} -> {s.num_iterations/max(s.lm_seconds,1e-9):.2f} LM-it/s")
 if a.oracle:
     import ba_oracle
     b = fp.copy(); t = time.time(); s = est.solve_flat(b, so, solve_fn=ba_oracle.solve_fn); dt = time.time() - t
