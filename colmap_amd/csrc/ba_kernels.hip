@@ -42,6 +42,7 @@
 #include <cstring>
 #include <numeric>
 #include <stdexcept>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -2997,6 +2998,22 @@ struct Buf {
 
 inline int grid_for(size_t n, int block) { return (int)((n + block - 1) / block); }
 
+// Host-side set-up loops over the observations (gathers into the device orders: random reads that one core serves at
+// a cache miss a time): contiguous index ranges on up to 16 threads. fn(begin, end, thread).
+template <typename F>
+inline void host_parallel_for(int64_t n, F&& fn) {
+  const int64_t grain = 1 << 16;
+  int T = (int)std::min<int64_t>(std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u), (n + grain - 1) / grain);
+  if (T <= 1) {
+    fn((int64_t)0, n, 0);
+    return;
+  }
+  std::vector<std::thread> th;
+  th.reserve(T);
+  for (int t = 0; t < T; ++t) th.emplace_back([&, t] { fn(n * t / T, n * (t + 1) / T, t); });
+  for (auto& x : th) x.join();
+}
+
 // sync + check after every launch; read per launch (an atomic load unless some switch is set), so that
 // colmap_amd_set_switch("COLMAP_AMD_BA_DEBUG", "1") takes effect whenever it is called
 static inline bool ba_debug() { return dev_switch_int("COLMAP_AMD_BA_DEBUG", 0) != 0; }
@@ -3248,49 +3265,64 @@ struct Solver {
     {  // (the explicit Schur formation reads it too, whatever the linearisation does)
       h_a_pose.resize(n); h_a_cam.resize(n); h_a_pt.resize(n); h_a_xy.resize((size_t)2 * n);
       if (has_sensors) h_a_sensor.resize(n);
-      for (int a = 0; a < n; ++a) {
-        const int64_t o = active[a];
-        h_a_pose[a] = p.obs_pose[o];
-        h_a_cam[a] = p.obs_cam[o];
-        h_a_pt[a] = p.obs_point[o];
-        h_a_xy[2 * (size_t)a] = p.obs_xy[2 * o];
-        h_a_xy[2 * (size_t)a + 1] = p.obs_xy[2 * o + 1];
-        if (has_sensors) h_a_sensor[a] = p.obs_sensor[o];
-      }
+      host_parallel_for(n, [&](int64_t a0, int64_t a1, int) {
+        for (int64_t a = a0; a < a1; ++a) {
+          const int64_t o = active[a];
+          h_a_pose[a] = p.obs_pose[o];
+          h_a_cam[a] = p.obs_cam[o];
+          h_a_pt[a] = p.obs_point[o];
+          h_a_xy[2 * (size_t)a] = p.obs_xy[2 * o];
+          h_a_xy[2 * (size_t)a + 1] = p.obs_xy[2 * o + 1];
+          if (has_sensors) h_a_sensor[a] = p.obs_sensor[o];
+        }
+      });
     }
     // solo flags: does another observation of the same point use the same pose / camera? (a track's entries of the
     // p-order arrays are neighbours in memory: the quadratic loop over a track stays in cache)
     std::vector<unsigned char> h_solo(n, 0);
-    for (int j = 0; j < p.num_points; ++j)
-      for (int a = h_pt_ptr[j]; a < h_pt_ptr[j + 1]; ++a) {
-        int same_pose = 0, same_cam = 0, same_sens = 0;
-        const int64_t oa = active[a];
-        const int sa = p.obs_sensor ? p.obs_sensor[oa] : -1;
-        const int pose_a = h_a_pose[a], cam_a = h_a_cam[a];
-        for (int a2 = h_pt_ptr[j]; a2 < h_pt_ptr[j + 1]; ++a2) {
-          same_pose += h_a_pose[a2] == pose_a;
-          same_cam += h_a_cam[a2] == cam_a;
-          same_sens += sa >= 0 && p.obs_sensor[active[a2]] == sa;
-        }
-        h_solo[h_a2c[a]] = (unsigned char)((same_pose == 1 ? 1 : 0) | (same_cam == 1 ? 2 : 0) | (same_sens <= 1 ? 4 : 0));
-        n_paired += (same_pose != 1 && !p.pose_const[p.obs_pose[oa]]) + (same_cam != 1 && cam_nvar[p.obs_cam[oa]] > 0) +
-                    (same_sens > 1 && sens_used[sa]);
-        n_paired_kind[0] += same_pose != 1 && !p.pose_const[p.obs_pose[oa]];
-        n_paired_kind[1] += same_cam != 1 && cam_nvar[p.obs_cam[oa]] > 0;
-        n_paired_kind[2] += same_sens > 1 && sens_used[sa];
+    {
+      long long paired_t[16][4] = {};   // per thread: n_paired, n_paired_kind[0..2]
+      host_parallel_for(p.num_points, [&](int64_t j0, int64_t j1, int t) {
+        long long* acc = paired_t[t];
+        for (int64_t j = j0; j < j1; ++j)
+          for (int a = h_pt_ptr[j]; a < h_pt_ptr[j + 1]; ++a) {
+            int same_pose = 0, same_cam = 0, same_sens = 0;
+            const int sa = has_sensors ? h_a_sensor[a] : (p.obs_sensor ? p.obs_sensor[active[a]] : -1);
+            const int pose_a = h_a_pose[a], cam_a = h_a_cam[a];
+            for (int a2 = h_pt_ptr[j]; a2 < h_pt_ptr[j + 1]; ++a2) {
+              same_pose += h_a_pose[a2] == pose_a;
+              same_cam += h_a_cam[a2] == cam_a;
+              same_sens += sa >= 0 && (has_sensors ? h_a_sensor[a2] : p.obs_sensor[active[a2]]) == sa;
+            }
+            h_solo[h_a2c[a]] = (unsigned char)((same_pose == 1 ? 1 : 0) | (same_cam == 1 ? 2 : 0) | (same_sens <= 1 ? 4 : 0));
+            const int k0 = same_pose != 1 && !p.pose_const[pose_a];
+            const int k1 = same_cam != 1 && cam_nvar[cam_a] > 0;
+            const int k2 = same_sens > 1 && sens_used[sa];
+            acc[0] += k0 + k1 + k2;
+            acc[1] += k0;
+            acc[2] += k1;
+            acc[3] += k2;
+          }
+      });
+      for (int t = 0; t < 16; ++t) {
+        n_paired += paired_t[t][0];
+        for (int k = 0; k < 3; ++k) n_paired_kind[k] += paired_t[t][1 + k];
       }
+    }
     std::vector<int> h_o_pose(n), h_o_cam(n), h_o_pt(n), h_o_sensor;
     if (has_sensors) h_o_sensor.resize(n);
     std::vector<double> h_xy((size_t)2 * n);
-    for (int c = 0; c < n; ++c) {
-      const int64_t o = active[h_c2a[c]];
-      if (has_sensors) h_o_sensor[c] = p.obs_sensor[o];
-      h_o_pose[c] = p.obs_pose[o];
-      h_o_cam[c] = p.obs_cam[o];
-      h_o_pt[c] = p.obs_point[o];
-      h_xy[2 * (size_t)c] = p.obs_xy[2 * o];
-      h_xy[2 * (size_t)c + 1] = p.obs_xy[2 * o + 1];
-    }
+    host_parallel_for(n, [&](int64_t c0, int64_t c1, int) {
+      for (int64_t c = c0; c < c1; ++c) {
+        const int a = h_c2a[c];   // c-order from the p-order copies: one indirection, 4-byte indices
+        if (has_sensors) h_o_sensor[c] = h_a_sensor[a];
+        h_o_pose[c] = h_a_pose[a];
+        h_o_cam[c] = h_a_cam[a];
+        h_o_pt[c] = h_a_pt[a];
+        h_xy[2 * (size_t)c] = h_a_xy[2 * (size_t)a];
+        h_xy[2 * (size_t)c + 1] = h_a_xy[2 * (size_t)a + 1];
+      }
+    });
     stage("topology");
     // tangent layout: pose blocks, then intrinsics blocks (camera side); points
     h_pose_off.assign(p.num_poses, -1);

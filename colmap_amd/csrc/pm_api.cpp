@@ -1129,8 +1129,9 @@ int Guard(F&& f) {
 // pm_run from several host threads at once -- how the reference's controller drives the seam, one problem per worker
 // thread (mvs/patch_match.cc:190-204, its `gpu_index = 0,0,...` idiom for several problems per GPU) -- is coalesced:
 // the calls that arrive together run as ONE batch (RunBatchSplitAsync: every launch covers all of them), each caller
-// returns when its own problem is done. The first arrival leads: it waits while further calls keep arriving (at most
-// 3 ms, until 300 us pass without one, or until every live handle of the device has called), runs the calls that can
+// returns when its own problem is done. The first arrival leads: it waits while further calls keep arriving (until
+// 300 us pass without one, at most 3 ms -- 250 ms while other threads are still inside pm_create --, or until every
+// live handle of the device has called), runs the calls that can
 // share launches with the oldest pending one (same image size / source count / options: what pm_run_batch requires),
 // and hands leadership on. Results do not depend on it (a batch equals its single runs bit for bit); a lone caller pays
 // at most the 300 us. COLMAP_AMD_PM_COALESCE=0 (development switch) runs every call on its own.
@@ -1147,6 +1148,7 @@ struct RunCoalescer {
   bool leader_active = false;
 };
 static RunCoalescer g_coalescer[16];
+static std::atomic<int> g_creating{0};   // pm_create calls in progress (any device)
 
 static bool BatchCompatible(const pm_handle* a, const pm_handle* b) {
   const pm_options& x = a->opt;
@@ -1176,11 +1178,17 @@ void RunCoalesced(pm_handle* h) {
     }
     Q.leader_active = true;
     {
-      const auto deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds(3);
+      // gather: while other threads are inside pm_create (they are about to call: the controller's workers create and
+      // run in a loop) up to 250 ms, otherwise until 300 us pass without an arrival (at most 3 ms); never beyond the
+      // number of live handles. A caller that is alone -- nobody creating, nobody arriving -- leaves after 300 us.
+      const auto t0 = std::chrono::steady_clock::now();
       size_t seen = Q.pending.size();
-      while ((int)seen < g_live_handles[h->device & 15].load() && std::chrono::steady_clock::now() < deadline) {
+      while ((int)seen < g_live_handles[h->device & 15].load() + g_creating.load()) {
+        const auto waited = std::chrono::steady_clock::now() - t0;
+        const bool others_creating = g_creating.load() > 0;
+        if (waited > (others_creating ? std::chrono::milliseconds(250) : std::chrono::milliseconds(3))) break;
         Q.cv.wait_for(lock, std::chrono::microseconds(300));
-        if (Q.pending.size() == seen) break;  // quiet: nobody else is about to call
+        if (Q.pending.size() == seen && g_creating.load() == 0) break;  // quiet: nobody else is about to call
         seen = Q.pending.size();
       }
     }
@@ -1283,6 +1291,10 @@ int pm_image_cache_stats(pm_image_cache* cache, size_t* entries, size_t* hits, s
 static int CreateImpl(const pm_options* options, const pm_problem* problem, pm_image_cache* cache, pm_handle** out) {
   if (out) *out = nullptr;
   pm_handle* h = nullptr;
+  struct Creating {   // a pm_run that gathers concurrent calls waits for creations in flight (RunCoalesced)
+    Creating() { ++g_creating; }
+    ~Creating() { --g_creating; }
+  } creating;
   const int rc = Guard([&] {
     PM_CHECK(options && problem && out, "null argument");
     h = new pm_handle();
