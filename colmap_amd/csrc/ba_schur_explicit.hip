@@ -35,7 +35,7 @@
 //  * Triangular solves with the stored block inverses: the forward one rides along with the factorisation (the
 //    right-hand side is row n of the matrix), the backward one takes one launch per outer panel of 256 columns.
 #include "ba_schur_explicit.h"
-#include "gfx950/ba_gfx950_asm.h"  // order_after (see its header)
+#include "switches.h"
 
 #include <hipcub/hipcub.hpp>
 
@@ -537,137 +537,190 @@ __device__ __forceinline__ double rcp_f64(double d) {
   return y;
 }
 
-// a[cc] -= m * column[cc] for cc in (c, NB): the rank-1 update of one column step, for a lane that holds one row (or
-// one column of the inverse) in registers. `colp` = the step's column in LDS, the same 512 bytes for every lane
-// (broadcast reads). The reads go out in chunks of 16 values (eight ds_read_b128), chunk k + 1 in flight while chunk
-// k's FMAs issue, and -- what makes this a function of its own -- chunk k + 1 is tied by a true dependence
-// (order_after) to a result of chunk k - 1: at most two chunks (64 VGPRs) are ever live beside the 128 of the matrix.
-// Left to itself the compiler either hoists all reads of a step to its top (spills) or, under the register cap, keeps
-// two reads in flight: 32 exposed LDS round trips per step, ~2 000 cycles, 40-54 us per diagonal block in the
-// round-5 trace (v_readlane broadcasts instead of LDS measured the same: 42-68 us -- every SGPR pair is a round trip).
+// Diagonal block [k0, k0 + kb): L_kk in place (lower), its inverse (64 x 64, zero-padded) to Linv -- 125 of these
+// kernels in a row sit on the critical path of the factorisation at BA-1. A BLOCKED factorisation over 16 x 16 tiles
+// with the off-diagonal work on the matrix cores (round 6). It replaces the register kernel of rounds 4-5 (two waves,
+// a 64 x 64 matrix in 128 registers each, a chain of 64 column steps with up to 63 dependent-issue fp64 FMAs per step in
+// ~85 KB of straight-line code: 22-28 us alone, 35 us on average and up to 160 us beside the lookahead stream's bulk
+// update -- instruction fetch through a busy fabric, vector fp64 FMAs sharing the matrix cores' pipeline, ROUND_NOTES
+// round 5). Blocked, the serial part is four 16-step eliminations of a 16 x 16 tile (at most 15 FMAs per step),
+// everything else is 16 x 16 x 16 products, in 10 KB of code: 20 us alone, 28.7 us on average in the BA-1 solve
+// (profiles/r06_ba_chol_diag_blocked.txt), and the translation unit compiles in seconds instead of four minutes.
+//   for kk = 0 .. 3:  (a) wave 0: tile (kk, kk) -> L16, L16^-1         lanes 0..15 = rows of A~ (elimination without
+//                         scaling: the loop works on A~ with L = A~ D^-1/2, D = diag(pivots), one sqrt per lane at the
+//                         end), lanes 16..31 = columns of Y = A~^-1, the same column broadcasts (16 doubles through LDS
+//                         per step) and the same instructions for both
+//                     (b) L[i][kk] = A[i][kk] L16^-T (i > kk);   Y[kk][j] = L16^-1 R[kk][j] (j < kk)
+//                     (c) A[i][j] -= L[i][kk] L[j][kk]^T (kk < j <= i);   R[i][j] -= L[i][kk] Y[kk][j] (j <= kk < i)
+// R starts as the identity (its diagonal tiles live in the registers of (a)) and ends as L^-1: the inverse rides along
+// with the factorisation, block forward substitution on the identity, without a barrier of its own. The matrix and R
+// live in LDS (55 KB); four waves share the tiles of (b) and (c); three workgroup barriers per kk. Rows / columns beyond
+// kb carry a unit diagonal and are not stored.
+// Measured and dropped (round 6, profiles/r06_ba_chol_chain_variants.txt): ONE launch per outer panel of 256 columns
+// doing the four diagonal blocks, the panel solves and the inner updates in one four-wave workgroup with the X blocks
+// in 122 KB of LDS (chol_outer_kernel) -- 150-160 us per panel on an idle GPU against 217 us for the ten launches it
+// replaced, but 250-330 us beside the bulk update where the separate launches spread over several CUs: 63.3 against
+// 65.0 LM-it/s at BA-1.
 template <int C>
-__device__ __forceinline__ void rank1_update(double (&a)[NB], const double m, const double* colp, int& tok) {
-  constexpr int E0 = (C + 1) & ~1;                 // first chunk starts on a 16-byte boundary
-  constexpr int NCH = (NB - E0 + 15) / 16;
-  if constexpr (NCH > 0) {
-    double buf[2][16];
-    auto fetch = [&](int k, int off) {
-#pragma unroll
-      for (int i = 0; i < 16; i += 2) {
-        const int e = E0 + 16 * k + i;
-        if (e < NB) {
-          const double2 t = *reinterpret_cast<const double2*>(colp + e + off);
-          buf[k & 1][i] = t.x;
-          buf[k & 1][i + 1] = t.y;
-        }
-      }
-    };
-    fetch(0, 0);
-#pragma unroll
-    for (int k = 0; k < NCH; ++k) {
-      if (k + 1 < NCH) {
-        if (k >= 1) order_after(tok, a[E0 + 16 * k - 1]);  // (the last entry chunk k - 1 updated)
-        fetch(k + 1, tok);
-      }
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int cc = E0 + 16 * k + i;
-        if (cc > C && cc < NB) a[cc] = fma(-m, buf[k & 1][i], a[cc]);  // (-ffp-contract=off: explicit fma)
-      }
-    }
-  }
-}
-
-template <int C>
-__device__ __forceinline__ void chol_steps_factor(double (&a)[NB], double& dmine, double (*col)[NB], int lane, int& tok) {
-  if constexpr (C < NB) {
-    const double ac = a[C];                          // entry `lane` of column C
-    const double d = readlane_f64(ac, C);
+__device__ __forceinline__ void diag16_steps(double (&a)[16], double& dmine, double* col, int lane) {
+  if constexpr (C < 16) {
+    const double ac = a[C];
+    const double d = readlane_f64(ac, C);  // the pivot: entry C of row C (factor lane C)
     dmine = lane == C ? ac : dmine;
-    col[C & 1][lane] = ac;
-    const double l = ac * rcp_f64(d);  // multiplier of row `lane` (rows <= C: a don't-care)
-    __syncthreads();  // column C (its entry C is the pivot) is published; the other buffer is free again
-    rank1_update<C>(a, l, col[C & 1], tok);
-    chol_steps_factor<C + 1>(a, dmine, col, lane, tok);
+    double* cb = col + 32 * (C & 1);
+    cb[lane < 16 ? lane : 16 + (lane & 15)] = ac;  // column C of A~ for every lane (the other lanes' stores land in a
+                                                    // dummy half of the buffer: a guarded store is a branch per step)
+    const double m = ac * rcp_f64(d);      // factor lanes: the multiplier of row `lane`; inverse lanes: y_C
+    a[C] = lane >= 16 ? m : ac;
+    // (one wave: LDS serves a wave's instructions in order, the fences only pin the compiler's order)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int cc = C + 1; cc < 16; ++cc) a[cc] = fma(-m, cb[cc], a[cc]);
+    __builtin_amdgcn_sched_barrier(0);  // (keeps the broadcast values of a step from staying live across later steps)
+    diag16_steps<C + 1>(a, dmine, col, lane);
   }
 }
 
-template <int R>
-__device__ __forceinline__ void chol_steps_inverse(double (&a)[NB], double (*col)[NB], int& tok) {
-  if constexpr (R < NB) {
+constexpr int TB = 16, NT = NB / TB, RS = TB + 1, RBLK = TB * RS, RP_DOUBLES = NT * (NT + 1) / 2 * RBLK;
+__device__ __forceinline__ double* r_tile(double* Rp, int i, int j) { return Rp + (i * (i + 1) / 2 + j) * RBLK; }
+
+// The kk loop above on a block that lies in LDS: Am = the block (lower triangle, unit diagonal beyond kb), Rp = zeros,
+// both published by a barrier. Afterwards Am holds L (lower), Rp the tiles (i, j <= i) of L^-1 (rows of RS doubles; the
+// upper parts of its diagonal tiles are exact zeros), published by the last barrier. Returns (wave 0, lanes < 16) whether
+// a pivot below kb was not positive. NWAVES = waves of the workgroup.
+template <int NWAVES>
+__device__ __forceinline__ bool diag64_blocked(double (*Am)[NB + 1], double* Rp, double* col, int kb, int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  bool bad = false;
+#pragma unroll 1
+  for (int kk = 0; kk < NT; ++kk) {
+    const int d0 = TB * kk;
+    if (wave == 0) {  // (a)
+      double a[TB];
+#pragma unroll
+      for (int c = 0; c < TB; ++c) {  // (unconditional reads + selects: guarded reads are a branch and a wait each)
+        const double v = Am[d0 + li][d0 + c];
+        a[c] = lane < TB ? v : (c == li ? 1.0 : 0.0);
+      }
+      double dmine = 1.0;
+      diag16_steps<0>(a, dmine, col, lane);
+      const bool okp = dmine > 0.0;
+      bad = bad || (lane < TB && d0 + lane < kb && !okp);
+      const double rs = okp ? 1.0 / sqrt(dmine) : NAN;
+      const double dsq = dmine * rs;  // sqrt(pivot)
+      double* Rd = r_tile(Rp, kk, kk);
+#pragma unroll
+      for (int c = 0; c < TB; ++c) {
+        const double rs_c = readlane_f64(rs, c), dsq_c = readlane_f64(dsq, c);
+        // factor lanes: L[lane][c];   inverse lanes: (L16^-1)[c][li] = sqrt(d_c) Y[c][li]
+        double* dst = lane < TB ? &Am[d0 + li][d0 + c] : &Rd[c * RS + li];
+        const double val = lane < TB ? (c < lane ? a[c] * rs_c : (c == lane ? dsq : 0.0)) : a[c] * dsq_c;
+        if (lane < 2 * TB) *dst = val;
+      }
+    }
     __syncthreads();
-    const double yr = a[R] * rcp_f64(col[R & 1][R]);
-    a[R] = yr;
-    rank1_update<R>(a, yr, col[R & 1], tok);
-    chol_steps_inverse<R + 1>(a, col, tok);
+    // (b) three tiles: L[i][kk] for i > kk, Y[kk][j] for j < kk
+    for (int item = wave; item < NT - 1; item += NWAVES) {
+      const double* Li = r_tile(Rp, kk, kk);
+      v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+      if (item < NT - 1 - kk) {
+        const int i = kk + 1 + item;
+#pragma unroll
+        for (int ks = 0; ks < TB / 4; ++ks) {
+          const int m = 4 * ks + lk;
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Am[TB * i + li][d0 + m], Li[li * RS + m], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) Am[TB * i + lk + 4 * reg][d0 + li] = acc[reg];
+      } else {
+        const int j = item - (NT - 1 - kk);
+        double* Rj = r_tile(Rp, kk, j);
+#pragma unroll
+        for (int ks = 0; ks < TB / 4; ++ks) {
+          const int m = 4 * ks + lk;
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Li[li * RS + m], Rj[m * RS + li], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) Rj[(lk + 4 * reg) * RS + li] = acc[reg];
+      }
+    }
+    __syncthreads();
+    {  // (c) tiles (i, j), i > kk: j <= kk updates R, j > kk the matrix
+      int t = 0;
+#pragma unroll 1
+      for (int i = kk + 1; i < NT; ++i)
+#pragma unroll 1
+        for (int j = 0; j <= i; ++j, ++t) {
+          if (t % NWAVES != wave) continue;
+          const bool upd_r = j <= kk;
+          double* Ct = upd_r ? r_tile(Rp, i, j) : &Am[TB * i][TB * j];
+          const int cs = upd_r ? RS : NB + 1;
+          const double* Bt = upd_r ? r_tile(Rp, kk, j) : &Am[TB * j][d0];
+          v4f64 acc;
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) acc[reg] = Ct[(lk + 4 * reg) * cs + li];
+#pragma unroll
+          for (int ks = 0; ks < TB / 4; ++ks) {
+            const int m = 4 * ks + lk;
+            const double b = upd_r ? Bt[m * RS + li] : Bt[li * (NB + 1) + m];  // Y[kk][j][m][c]  |  L[j][kk][c][m]
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-Am[TB * i + li][d0 + m], b, acc, 0, 0, 0);
+          }
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) Ct[(lk + 4 * reg) * cs + li] = acc[reg];
+        }
+    }
+    __syncthreads();
+  }
+  return bad;
+}
+
+// Block [k0, k0 + kb) of S into Am (lane = column, coalesced; the NB / NWAVES loads of a thread in flight together; an
+// unconditional load of a valid address -- a guarded one is a branch and a wait), Rp = 0; no barrier.
+template <int NWAVES>
+__device__ __forceinline__ void diag64_load(const double* __restrict__ S, int n, int k0, int kb, double (*Am)[NB + 1],
+                                            double* Rp, int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+  double stage[NB / NWAVES];
+#pragma unroll
+  for (int i = 0; i < NB / NWAVES; ++i) {
+    const int r = wave + NWAVES * i;
+    const bool ok = r < kb && lane <= r;
+    const double v = S[ok ? (size_t)(k0 + r) * n + k0 + lane : (size_t)k0 * n + k0];
+    stage[i] = ok ? v : (r == lane ? 1.0 : 0.0);
+  }
+#pragma unroll
+  for (int i = 0; i < NB / NWAVES; ++i) Am[wave + NWAVES * i][lane] = stage[i];
+  for (int e = tid; e < RP_DOUBLES; e += 64 * NWAVES) Rp[e] = 0.0;
+}
+
+// L (lower) back to S, the zero-padded 64 x 64 inverse to Linv.
+template <int NWAVES>
+__device__ __forceinline__ void diag64_store(double* __restrict__ S, int n, int k0, int kb, double (*Am)[NB + 1], double* Rp,
+                                             double* __restrict__ Linv, int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll 1
+  for (int i = 0; i < NB / NWAVES; ++i) {
+    const int r = wave + NWAVES * i;
+    if (r < kb && lane <= r) S[(size_t)(k0 + r) * n + k0 + lane] = Am[r][lane];
+    const int ti = r / TB, tj = lane / TB;
+    Linv[r * NB + lane] = (r < kb && lane < kb && tj <= ti) ? r_tile(Rp, ti, tj)[(r % TB) * RS + lane % TB] : 0.0;
   }
 }
 
-// Diagonal block [k0, k0 + kb): L_kk in place (lower), its inverse (64 x 64, zero-padded) to Linv.
-// TWO WAVES, each with a 64 x 64 matrix in registers (64 doubles = 128 VGPRs per lane; every loop below is unrolled
-// so that the register indices are compile-time constants):
-//   wave 0, lane r = row r of the block: the factorisation. The job is a chain of 64 dependent column steps -- pivot,
-//     reciprocal, multipliers, rank-1 update -- 125 of these kernels in a row on the critical path of the
-//     factorisation at BA-1. A column step: the pivot by v_readlane, its reciprocal (rcp_f64), column c of the matrix
-//     handed from lane to lane through 512 bytes of LDS, and 63 - c register FMAs per lane against broadcast reads of
-//     that column, pipelined two chunks deep (rank1_update). Entries above the diagonal take part in the arithmetic as
-//     don't-cares (no divergence). The scaling by 1 / sqrt(pivot) happens once at the end (one sqrt + division per
-//     LANE instead of per column step): the loop works on A~ with L = A~ D^-1/2, D = diag(pivots).
-//   wave 1, lane j = column j of the inverse: forward substitution with the SAME column broadcasts, step by step
-//     behind wave 0 (Y = A~^-1: y_r /= d_r, y_rr -= A~[rr][r] y_r for the rows below; L^-1 = D^1/2 Y). Rows above j
-//     come out as exact zeros. (One wave doing both needs 256 VGPRs for the two matrices alone.)
-// Rows / columns beyond kb carry a unit diagonal and are not stored.
-// Register budget: 256 per lane (launch bound 2 waves per SIMD) -- this kernel runs beside the lookahead stream's
-// 128 x 128 trailing updates, whose waves hold 256 of a SIMD's 512 registers each: a wave that needs more than the
-// other half could only start on a CU the bulk update has drained completely.
-__global__ void __launch_bounds__(128, 2) chol_diag_kernel(double* __restrict__ S, int n, int k0, int kb,
-                                                        double* __restrict__ Linv, int* __restrict__ info) {
-  __shared__ double Ls[NB][NB + 1];
-  __shared__ __attribute__((aligned(16))) double col[2][NB];
-  __shared__ double dsq[NB];  // sqrt(pivot)
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  {  // coalesced: lane = column; the 32 loads of a lane in flight together (rolled: 32 serial round trips, more than
-     // the factorisation itself takes)
-    double stage[NB / 2];
-#pragma unroll
-    for (int i = 0; i < NB / 2; ++i) {
-      const int r = wave + 2 * i;
-      stage[i] = (r < kb && lane <= r) ? S[(size_t)(k0 + r) * n + k0 + lane] : (r == lane ? 1.0 : 0.0);
-    }
-#pragma unroll
-    for (int i = 0; i < NB / 2; ++i) Ls[wave + 2 * i][lane] = stage[i];
-  }
+// (two workgroups' worth of registers at most: the kernel has to fit beside the bulk update's 256-register waves)
+__global__ void __launch_bounds__(256, 2) chol_diag_kernel(double* __restrict__ S, int n, int k0, int kb,
+                                                             double* __restrict__ Linv, int* __restrict__ info) {
+  __shared__ double Am[NB][NB + 1];   // the block; tiles (i, j <= i) are final L once kk passed j
+  __shared__ double Rp[RP_DOUBLES];   // R / Y / L^-1: tile (i, j <= i) at (i (i + 1) / 2 + j) * RBLK, rows of 17
+  __shared__ __attribute__((aligned(16))) double col[4 * TB];
+  const int tid = threadIdx.x;
+  diag64_load<4>(S, n, k0, kb, Am, Rp, tid);
   __syncthreads();
-  double a[NB];
-  int tok = 0;
-  // (The two waves run separate straight-line code with the same number of barriers -- 64 in the loop, one after it:
-  //  merged into one loop with per-step branches the register allocation falls apart, 7 KB of scratch.)
-  if (wave == 0) {
-#pragma unroll
-    for (int c = 0; c < NB; ++c) a[c] = Ls[lane][c];  // row `lane` of A~
-    double dmine = 0.0;                                // pivot of column `lane` (final after step lane - 1)
-    chol_steps_factor<0>(a, dmine, col, lane, tok);
-    const bool okp = dmine > 0.0;
-    if (!okp) *info = 1;
-    const double rs = okp ? 1.0 / sqrt(dmine) : NAN;
-    dsq[lane] = dmine * rs;
-    __syncthreads();
-#pragma unroll
-    for (int c = 0; c < NB; ++c) {
-      const double v = a[c] * readlane_f64(rs, c);
-      Ls[lane][c] = c < lane ? v : (c == lane ? dmine * rs : 0.0);
-    }
-  } else {
-#pragma unroll
-    for (int r = 0; r < NB; ++r) a[r] = r == lane ? 1.0 : 0.0;  // column `lane` of Y
-    chol_steps_inverse<0>(a, col, tok);
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < NB; ++r) Linv[r * NB + lane] = (r < kb && lane < kb) ? a[r] * dsq[r] : 0.0;
-  }
-  __syncthreads();
-  for (int r = wave; r < NB; r += 2)  // coalesced again: lane = column
-    if (r < kb && lane <= r) S[(size_t)(k0 + r) * n + k0 + lane] = Ls[r][lane];
+  if (diag64_blocked<4>(Am, Rp, col, kb, tid)) *info = 1;
+  diag64_store<4>(S, n, k0, kb, Am, Rp, Linv, tid);
 }
 
 // Panel below the diagonal block: X = A_panel L_kk^-T, in place. One workgroup per 64 rows; wave w owns rows
@@ -1219,7 +1272,7 @@ void factor_solve(double* S, int n, const double* rhs, double* x, const Workspac
     for (int k0 = o0; k0 < oend; k0 += NB) {
       const int kb = std::min(NB, n - k0);
       double* Li = ws.Linv + (size_t)(k0 / NB) * NB * NB;
-      hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(128), 0, st, S, n, k0, kb, Li, ws.info);
+      hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), 0, st, S, n, k0, kb, Li, ws.info);
       // the 64-wide steps stay inside the outer panel's own rows [k0 + kb, oend): at most three workgroups each
       const int below = oend - k0 - kb;
       if (below > 0) {

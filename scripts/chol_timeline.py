@@ -18,11 +18,11 @@ rows.sort()
 # the last complete factorisation: from the last form_pairs / form_kernel to the last solve_backward_panel_kernel after it
 idx_form = max(i for i, r in enumerate(rows) if r[2] in ("form_pairs_kernel", "form_kernel"))
 # (the very last formation may belong to a rejected step without a following factorisation: walk back until one has diag kernels after it)
-while not any(r[2] == "chol_diag_kernel" for r in rows[idx_form:]):
+while not any(r[2].startswith("chol_diag") or r[2] == "chol_outer_kernel" for r in rows[idx_form:]):
     idx_form = max(i for i, r in enumerate(rows[:idx_form]) if r[2] in ("form_pairs_kernel", "form_kernel"))
 seg = [r for r in rows[idx_form:] if r[2].startswith("chol_") or r[2].startswith("solve_")]
 t0 = seg[0][0]
-chain_names = {"chol_diag_kernel", "chol_panel_kernel", "chol_strip_kernel"}
+chain_names = {"chol_diag_kernel", "chol_diag_mfma_kernel", "chol_outer_kernel", "chol_panel_kernel", "chol_strip_kernel"}
 end = max(r[1] for r in seg if r[2].startswith("chol_"))
 print(f"factorisation: {len(seg)} kernels, {(end - t0) / 1e3:.1f} us from the first diagonal block to the last update")
 tot = collections.Counter()
@@ -31,12 +31,13 @@ for s, e, n, q, st in seg:
 for n, v in tot.most_common():
     print(f"  {n:32s} {v / 1e3:10.1f} us")
 # per outer panel of 4 diagonal blocks: wall time, kernel time on the chain, idle time of the chain
-diag = [r for r in seg if r[2] == "chol_diag_kernel"]
+diag = [r for r in seg if r[2].startswith("chol_diag") or r[2] == "chol_outer_kernel"]
+step = 1 if any(r[2] == "chol_outer_kernel" for r in diag) else 4
 print("panel  start_us  wall_us  diag_us  chain_busy_us  chain_idle_us  bulk_overlap_us")
 bulk = [(s, e) for s, e, n, q, st in seg if n == "chol_update128_kernel"]
-for p in range(0, len(diag), 4):
+for p in range(0, len(diag), step):
     a = diag[p][0]
-    b = diag[p + 4][0] if p + 4 < len(diag) else end
+    b = diag[p + step][0] if p + step < len(diag) else end
     inside = [r for r in seg if a <= r[0] < b and r[2] != "chol_update128_kernel"]
     # union of the intervals of the non-bulk kernels
     iv = sorted((r[0], r[1]) for r in inside)
@@ -50,9 +51,9 @@ for p in range(0, len(diag), 4):
             cur_e = max(cur_e, e)
     if cur_e is not None:
         busy += cur_e - cur_s
-    dsum = sum(r[1] - r[0] for r in inside if r[2] == "chol_diag_kernel")
+    dsum = sum(r[1] - r[0] for r in inside if r[2].startswith("chol_diag") or r[2] == "chol_outer_kernel")
     bo = sum(max(0, min(e, b) - max(s, a)) for s, e in bulk)
-    print(f"{p // 4:5d} {(a - t0) / 1e3:9.1f} {(b - a) / 1e3:8.1f} {dsum / 1e3:8.1f} {busy / 1e3:14.1f} {(b - a - busy) / 1e3:14.1f} {bo / 1e3:15.1f}")
+    print(f"{p // step:5d} {(a - t0) / 1e3:9.1f} {(b - a) / 1e3:8.1f} {dsum / 1e3:8.1f} {busy / 1e3:14.1f} {(b - a - busy) / 1e3:14.1f} {bo / 1e3:15.1f}")
 # the first panels in detail
 print("first 60 kernels: start_us dur_us name")
 for s, e, n, q, st in seg[:60]:

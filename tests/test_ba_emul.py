@@ -325,8 +325,8 @@ def _factor_solve_directly(A, rhs, min_rows128):
 @pytest.mark.parametrize("n,min_rows128", [(45, 12 * 128), (64, 12 * 128), (333, 12 * 128), (900, 256)])
 def test_blocked_cholesky_directly_against_numpy(n, min_rows128):
     """factor_solve on a random SPD matrix: the factor, the stored inverses of its diagonal blocks and the solution
-    against numpy. n = 45 / 64: one (short / full) diagonal block -- chol_diag_kernel alone (two waves: the
-    factorisation in one, the inverse of the triangle in the other); 333: six panels, a ragged last block, two outer
+    against numpy. n = 45 / 64: one (short / full) diagonal block -- chol_diag_kernel alone (blocked over 16 x 16 tiles,
+    the inverse of the triangle riding along); 333: six panels, a ragged last block, two outer
     panels; 900 with the tile threshold lowered: the 128 x 128 trailing update (the columns right of the next outer panel)
     with its register prefetch, including diagonal tiles and a ragged edge."""
     import numpy as np
