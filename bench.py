@@ -390,8 +390,9 @@ def dropin_leg(a, problem, batched_value):
     """The same problems through the seam exactly as the reference drives it: its
     controller keeps ONE problem in flight per entry of --PatchMatchStereo.gpu_index (mvs/patch_match.cc:177,
     190-204); listing a GPU several times gives that many worker threads on it (:375-383). Measured:
-      one_at_a_time    one PatchMatchCuda-shaped handle after the other (pm_create / pm_run / pm_get_*): a single
-                       2560 x 1920 problem has 1280 column groups for 4096 resident waves;
+      one_at_a_time    one PatchMatchCuda-shaped handle after the other (pm_create / pm_run / pm_get_* / pm_destroy): a
+                       single 2560 x 1920 problem has 1920 .. 2560 columns for 5120 resident waves -- the library then
+                       runs one column per wave group and a helper wave per column (pm_sweep_pair_kernel);
       threads          `--batch` host threads, each with its own handle and stream on this GPU (the repeated-index
                        route), all running at once;
       batched          pm_run_batch of `--batch` problems (the primary number above: what the controller-side
@@ -399,15 +400,16 @@ def dropin_leg(a, problem, batched_value):
     import threading
     from colmap_amd import mvs
     n1 = 2
-    pms = [problem(j)[0] for j in range(n1)]
-    torch.cuda.synchronize()
-    t0 = time.time()
-    for pm in pms:
+    t_one, one_kernel = 0.0, ""
+    for j in range(n1):   # one handle alive at a time, as in the reference's worker thread (mvs/patch_match.cc:394-440)
+        pm = problem(j)[0]
+        torch.cuda.synchronize()
+        t0 = time.time()
         pm.Run()
         pm.GetDepthMap()
-    torch.cuda.synchronize()
-    t_one = (time.time() - t0) / n1
-    for pm in pms:
+        torch.cuda.synchronize()
+        t_one += (time.time() - t0) / n1
+        one_kernel = pm.GetSweepKernelName()
         pm.close()
     nt = a.batch
     pms = [problem(j)[0] for j in range(nt)]
@@ -431,7 +433,7 @@ def dropin_leg(a, problem, batched_value):
     for pm in pms:
         pm.close()
     mpix = a.width * a.height / 1e6
-    out = {"one_at_a_time_Mpix_per_s": mpix / t_one, "threads": nt, "threads_Mpix_per_s": nt * mpix / t_thr,
+    out = {"one_at_a_time_Mpix_per_s": mpix / t_one, "one_at_a_time_kernel": one_kernel, "threads": nt, "threads_Mpix_per_s": nt * mpix / t_thr,
            "batched_Mpix_per_s": batched_value,
            "note": "create + run + depth-map read-back per problem, image cache shared; the controller of the "
                    "reference calls it this way (one problem per worker thread)"}

@@ -925,7 +925,7 @@ void RunBatchAsync(pm_handle** hs, int n, hipStream_t run_st = nullptr) {
   // One launch geometry for the batch: the columns per wave of THIS run are a property of the run (every parameter
   // block of the run carries it), never written back to a handle -- a handle re-run in another batch, or traced, sees
   // its own shape again.
-  int run_C = h0->base.C;
+  int run_C = h0->base.C, run_help = 1;
   for (int b = 1; b < n; ++b) run_C = std::min(run_C, hs[b]->base.C);
   {
     bool automatic = h0->base.ntaps == 121;
@@ -944,6 +944,17 @@ void RunBatchAsync(pm_handle** hs, int n, hipStream_t run_st = nullptr) {
       // (images too small to fill the GPU either way keep the common shape: their time is launch latency)
       const int C = (std::min(h0->W, h0->H) >= 512 && waves2 * 4 < slots * 3) ? 1 : 2;
       run_C = std::min(run_C, C);
+      // ... and when even one wave per column leaves the GPU half empty (20 wave slots per CU for the photometric
+      // kernel; ONE 2560 x 1920 problem = 1 920 .. 2 560 waves for 5 120), a second wave per column shares the NCC
+      // rounds (pm_sweep_pair_kernel): bit-identical, test_group_shapes_do_not_change_results.
+      if (C == 1 && run_C == 1 && 2 * waves2 * 10 <= 20ll * ncu * 6) run_help = 2;
+    }
+    // COLMAP_AMD_PM_HELP (tests, A/B runs): 1 = never, 2 = always (one column per wave, any image size)
+    const int help_switch = dev_switch_int("COLMAP_AMD_PM_HELP", 0);
+    if (help_switch == 1) run_help = 1;
+    if (help_switch == 2 && h0->base.ntaps == 121) {
+      run_C = 1;
+      run_help = 2;
     }
   }
   const int total_sweeps = opt.num_iterations * 4;
@@ -954,6 +965,7 @@ void RunBatchAsync(pm_handle** hs, int n, hipStream_t run_st = nullptr) {
   for (int b = 0; b < n; ++b) {
     host[b] = ParamsForSweep(hs[b], 0);
     host[b].C = run_C;
+    host[b].help = run_help;
   }
   const float total_num_steps = (float)total_sweeps;
   // workgroup -> (problem, column group) mapping of a batched sweep launch (pm_sweep_kernel)
@@ -982,6 +994,7 @@ void RunBatchAsync(pm_handle** hs, int n, hipStream_t run_st = nullptr) {
       p.sel_in_off = sel_in;
       p.xcd_map = xcd_map;
       p.C = run_C;
+      p.help = run_help;
 #ifdef COLMAP_AMD_DIAG_BUILD
       p.ablate = dev_switch_int("COLMAP_AMD_PM_ABLATE", 0);  // profiling builds only: results are garbage
 #else

@@ -56,6 +56,7 @@ struct PmParams {
   int sel_in_off;   // record offset of prev_sel_prob (read)
   int sel_out_off;  // record offset of sel_prob (backward msgs, then written)
   int C;            // image columns per workgroup
+  int help;         // waves per column group of the 11 x 11 sweep kernel: 2 = a helper wave shares pass B (pm_sweep_pair_kernel, C = 1)
   int ablate;       // profiling only (COLMAP_AMD_PM_ABLATE): bit 0 skip the NCC task passes, bit 1 skip the
                     // hypothesis generation, bit 2 skip the backward-message pre-pass; results are garbage
   int xcd_map;      // batched launch of the generic kernel: 0 problem = id % batch, 1 neighbouring problems per XCD

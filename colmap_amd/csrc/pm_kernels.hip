@@ -1740,15 +1740,63 @@ __device__ __forceinline__ void wave_sync() {
   }
 }
 
+// Mailbox of a wave pair (pm_sweep_pair_kernel): the words behind Lds::best[C] -- its 16-byte slot holds C <= 2 entries,
+// the pair kernel runs one column per group -- carry the size of the published batch and whether it is the phase's last.
+constexpr int kPairNb = 2, kPairLast = 3;
+
+// Pass B of a batch of NCC tasks, 16-lane group per task: one round = four tasks; all eight gathers of a lane are in
+// flight before the first texel is consumed (ncc_front / ncc_back). Control flow is wave-uniform -- every group runs
+// whole rounds, a group without a task in the last round recomputes the batch's last task and drops the result -- so
+// that the DPP rows are always fully active. A wave runs the rounds first, first + stride, ...: stride 1 normally;
+// with a helper wave (pm_sweep_pair_kernel) the two waves of a column group take alternate rounds, the helper the
+// batch's last one. The sums of a task replace its homography in L.th (slots are disjoint between rounds).
+template <bool MUBUF>
+__device__ __forceinline__ void ncc_rounds_wave(const PmParams& p, const Lds& L, const v4i srd, const lds_f32* G, int tid,
+                                                int nb, int first, int stride) {
+  const int g = tid >> 4, j = tid & 15;
+  // slot offset of texel (0, 0) relative to entry (0, 0): one strip (kFpRingX entries) and kFpRingY rows
+  const uint32_t origin = 4u * ((uint32_t)p.fp_rows1 + 1u) + 4u * (uint32_t)kFpRingY;
+  const uint32_t gorigin = fp_index(kFpRingX, kFpRingY, (unsigned)p.fp_rows1);  // the same as an entry index
+  const int rounds = (nb + 3) >> 2;
+  for (int r = first; r < rounds; r += stride) {
+    const int tr = g + 4 * r;
+    const bool own = tr < nb;
+    const uint32_t d = L.desc[own ? tr : nb - 1];
+    // wave-uniform: the unclamped addressing only when all four patches of the round are inside
+    // (a recomputed task may already hold its sums instead of its homography: it must take the
+    // clamping path, where any coordinate is safe and the result is dropped)
+    const bool fast = __all(own && (d & 0x80u) != 0u) != 0;
+    const uint32_t slot = MUBUF ? L.fpo[d >> 16] : 0u;
+    gbl_u32* gbase = MUBUF ? nullptr : (gbl_u32*)L.fpb[d >> 16];
+    const lds_f32* H = L.th + (d & 63u) * 9u;
+    launder_lds(H);  // one address register for the nine reads (offsets 0..32) instead of a base + constant each
+    NccStage A;
+    uint32_t tex[8];
+    if (fast) ncc_front<true, MUBUF>(p, srd, H, slot + origin, gbase + gorigin, G, j, A, tex);
+    else ncc_front<false, MUBUF>(p, srd, H, slot, gbase, G, j, A, tex);
+    __builtin_amdgcn_sched_barrier(0);
+    TapRegs R;
+    const int c128 = (int)((d >> 8) & 0xffu) * 128;
+    tap_regs_load(R, L.wgt + c128, L.refc + c128, j);
+    float s_sum, s_sq, s_ref;
+    ncc_back(A, tex, R, j, s_sum, s_sq, s_ref);
+    if (j == 0 && own) {
+      lds_f32* Hw = L.th + (d & 63u) * 9u;
+      Hw[0] = s_sum;  // the homography of this task is no longer needed
+      Hw[1] = s_sq;
+      Hw[2] = s_ref;
+    }
+  }
+}
+
 // Run the `n` queued NCC tasks (and, with GEOM, the `ng` entries of the geometric-cost-only list) of one phase.
-template <bool GEOM, int NW, int CAP, bool MUBUF, bool PROF>
+template <bool GEOM, int NW, int CAP, bool MUBUF, bool PROF, int HELP = 1>
 __device__ __forceinline__ void run_tasks_wave(const PmParams& p, const Lds& L, const v4i srd, int row, int col0,
                                                int tid, int n, int ng, unsigned& evals, unsigned long long* prof_acc,
                                                unsigned long long& prof_t, const int prof_slot0) {
   const lds_f32* G = L.tapg;
   evals += (unsigned)n;
   const LDS_AS uint16_t* tasks = (const LDS_AS uint16_t*)L.tasks;
-  const int g = tid >> 4, j = tid & 15;
   const int S = p.S, S1 = p.S + 1;
   if (GEOM) {
     // geometric consistency cost of hypothesis 0 against the drawn views (no NCC: cached cost map)
@@ -1760,9 +1808,14 @@ __device__ __forceinline__ void run_tasks_wave(const PmParams& p, const Lds& L, 
       L.geo[(c * 5 + i) * S1 + s] = geom_cost(p, L.poses + s * L.pstride, s, (float)row, (float)(col0 + c), h[0]);
     }
   }
-  // slot offset of texel (0, 0) relative to entry (0, 0): one strip (kFpRingX entries) and kFpRingY rows
-  const uint32_t origin = 4u * ((uint32_t)p.fp_rows1 + 1u) + 4u * (uint32_t)kFpRingY;
-  const uint32_t gorigin = fp_index(kFpRingX, kFpRingY, (unsigned)p.fp_rows1);  // the same as an entry index
+  if (HELP > 1 && n == 0) {  // the helper waits for one batch per phase at least
+    if (tid == 0) {
+      L.best[kPairNb] = 0;
+      L.best[kPairLast] = 1;
+    }
+    __syncthreads();
+    __syncthreads();
+  }
   for (int base = 0; base < n; base += CAP) {
     const int nb = min(CAP, n - base);
     PM_MARK("passA");
@@ -1797,44 +1850,21 @@ __device__ __forceinline__ void run_tasks_wave(const PmParams& p, const Lds& L, 
       if (tid < nb) L.desc[inside ? lanes_below(m1) : __popcll(m1) + lanes_below(m0)] = desc;
     }
     wave_sync<NW>();
-    // pass B, 16-lane group per task: one round = four tasks; all eight gathers of a lane are in flight before
-    // the first texel is consumed (ncc_front / ncc_back). Control flow is wave-uniform -- every group runs
-    // ceil(nb / 4) rounds, a group without a task in the last round recomputes the batch's last task and drops
-    // the result -- so that the DPP rows are always fully active.
+    // pass B (ncc_rounds_wave); with a helper wave (HELP = 2, pm_sweep_pair_kernel) this wave takes every other round
+    if (HELP > 1) {
+      if (tid == 0) {
+        L.best[kPairNb] = nb;
+        L.best[kPairLast] = base + CAP >= n ? 1 : 0;
+      }
+      __syncthreads();  // the batch is published: homographies, descriptors, its size
+    }
+    PM_PROF_MARK(prof_slot0 - 1)
+    PM_MARK("passB");
     {
       const int rounds = (nb + 3) >> 2;
-      PM_PROF_MARK(prof_slot0 - 1)
-      PM_MARK("passB");
-      for (int r = 0; r < rounds; ++r) {
-        const int tr = g + 4 * r;
-        const bool own = tr < nb;
-        const uint32_t d = L.desc[own ? tr : nb - 1];
-        // wave-uniform: the unclamped addressing only when all four patches of the round are inside
-        // (a recomputed task may already hold its sums instead of its homography: it must take the
-        // clamping path, where any coordinate is safe and the result is dropped)
-        const bool fast = __all(own && (d & 0x80u) != 0u) != 0;
-        const uint32_t slot = MUBUF ? L.fpo[d >> 16] : 0u;
-        gbl_u32* gbase = MUBUF ? nullptr : (gbl_u32*)L.fpb[d >> 16];
-        const lds_f32* H = L.th + (d & 63u) * 9u;
-        launder_lds(H);  // one address register for the nine reads (offsets 0..32) instead of a base + constant each
-        NccStage A;
-        uint32_t tex[8];
-        if (fast) ncc_front<true, MUBUF>(p, srd, H, slot + origin, gbase + gorigin, G, j, A, tex);
-        else ncc_front<false, MUBUF>(p, srd, H, slot, gbase, G, j, A, tex);
-        __builtin_amdgcn_sched_barrier(0);
-        TapRegs R;
-        const int c128 = (int)((d >> 8) & 0xffu) * 128;
-        tap_regs_load(R, L.wgt + c128, L.refc + c128, j);
-        float s_sum, s_sq, s_ref;
-        ncc_back(A, tex, R, j, s_sum, s_sq, s_ref);
-        if (j == 0 && own) {
-          lds_f32* Hw = L.th + (d & 63u) * 9u;
-          Hw[0] = s_sum;  // the homography of this task is no longer needed
-          Hw[1] = s_sq;
-          Hw[2] = s_ref;
-        }
-      }
+      ncc_rounds_wave<MUBUF>(p, L, srd, G, tid, nb, HELP > 1 ? (rounds & 1) : 0, HELP);
     }
+    if (HELP > 1) __syncthreads();  // the helper's sums are in
     wave_sync<NW>();
     PM_PROF_MARK(prof_slot0)
     PM_MARK("finish");
@@ -1858,7 +1888,12 @@ __device__ __forceinline__ void run_tasks_wave(const PmParams& p, const Lds& L, 
               kProfP3c = 7, kProfP4A = 8, kProfP4B = 9, kProfP4F = 10, kProfP5a = 11, kProfP5b = 12, kProfP5c = 13,
               kProfP6A = 14, kProfP6B = 15, kProfP6F = 16, kProfP7 = 17, kProfP8 = 18, kProfSlots = kPmProfSlots;
 
-template <bool GEOM, bool FILTER_PHOTO, bool FILTER_GEOM, int NW, int CAP, bool MUBUF, bool PROF = false>
+// HELP = 2 (pm_sweep_pair_kernel, NW = 2): the two waves of a workgroup serve ONE column group. Wave 0 walks the
+// rows as always; wave 1 is bound to the same LDS region and only runs pass B of the NCC phases, every other round of
+// four evaluations (ncc_rounds_wave), between two workgroup barriers per batch: half the serial time of a row is
+// pass B. For launches that cannot fill the GPU with one wave per column (ONE 2560 x 1920 problem = 2 560 waves for
+// 5 120 slots: how the reference's controller drives the seam).
+template <bool GEOM, bool FILTER_PHOTO, bool FILTER_GEOM, int NW, int CAP, bool MUBUF, bool PROF = false, int HELP = 1>
 __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp) {
   const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y;
   unsigned group = lin / gridDim.y;
@@ -1874,14 +1909,14 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
   // single-wave workgroups.
   const int wave = NW == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   {
-    const LdsOffsets o = lds_offsets_wave(p.C, p.S, p.radius, p.ntaps, p.num_samples, GEOM, CAP, NW);
-    lds_bind(L, (lds_char*)smem + wave * o.priv_stride, o);
+    const LdsOffsets o = lds_offsets_wave(p.C, p.S, p.radius, p.ntaps, p.num_samples, GEOM, CAP, HELP > 1 ? 1 : NW);
+    lds_bind(L, (lds_char*)smem + (HELP > 1 ? 0 : wave) * o.priv_stride, o);
     L.poses = (lds_f32*)((lds_char*)smem + o.poses);
     L.fpo = (lds_u32*)((lds_char*)smem + o.fpb);
     L.fpb = (lds_u64*)((lds_char*)smem + o.fpb);
     L.tapg = (lds_f32*)((lds_char*)smem + o.tapg);
   }
-  if (NW > 1) group = group * NW + wave;
+  if (NW > 1 && HELP == 1) group = group * NW + wave;
   const int tid_entry = threadIdx.x & 63;
   const int tid = tid_entry;
   constexpr int nt = 64;
@@ -1911,8 +1946,24 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
     }
   }
   if (NW > 1) {
-    __syncthreads();                  // the only workgroup barrier of the kernel
+    __syncthreads();                  // the only workgroup barrier of the kernel (HELP = 1)
     if (col0 >= RW) return;           // surplus wave of the last workgroup (grid.x = ceil(groups / NW))
+  }
+  if (HELP > 1 && wave != 0) {
+    // the helper: per row and NCC phase, the batches wave 0 publishes (two barriers each, run_tasks_wave)
+    for (int row = 0; row < RH; ++row)
+      for (int phase = 0; phase < 2; ++phase) {
+        int last;
+        do {
+          __syncthreads();
+          const int nb = L.best[kPairNb];
+          last = L.best[kPairLast];
+          const int rounds = (nb + 3) >> 2;
+          if (nb > 0) ncc_rounds_wave<MUBUF>(p, L, srd, L.tapg, tid, nb, (rounds - 1) & 1, HELP);
+          __syncthreads();
+        } while (!last);
+      }
+    return;
   }
 
   // ---- backward messages for all rows (:976-989); stored in sel_out ----------
@@ -2118,8 +2169,8 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
     PM_PROF_MARK(kProfP3c)
     PM_MARK("P4");
     // ---- P4: NCC of hypotheses 1..4 against the drawn views (:1157-1172) -----
-    if (!(PM_ABLATE(p) & 1))
-      run_tasks_wave<GEOM, NW, CAP, MUBUF, PROF>(p, L, srd, row, col0, tid, n4, ng, evals, prof_acc, prof_t, kProfP4B);
+    if (HELP > 1 || !(PM_ABLATE(p) & 1))
+      run_tasks_wave<GEOM, NW, CAP, MUBUF, PROF, HELP>(p, L, srd, row, col0, tid, n4, ng, evals, prof_acc, prof_t, kProfP4B);
 
     PM_PROF_MARK(kProfP4F)
     PM_MARK("P5a");
@@ -2190,8 +2241,8 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
     PM_PROF_MARK(kProfP5c)
     PM_MARK("P6");
     // ---- P6: NCC of the winner against the remaining views (:1188-1197) ------
-    if (!(PM_ABLATE(p) & 1))
-      run_tasks_wave<false, NW, CAP, MUBUF, PROF>(p, L, srd, row, col0, tid, n1, 0, evals, prof_acc, prof_t, kProfP6B);
+    if (HELP > 1 || !(PM_ABLATE(p) & 1))
+      run_tasks_wave<false, NW, CAP, MUBUF, PROF, HELP>(p, L, srd, row, col0, tid, n1, 0, evals, prof_acc, prof_t, kProfP6B);
     PM_PROF_MARK(kProfP6F)
     PM_MARK("P7");
 
@@ -2269,6 +2320,11 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
 template <bool GEOM, bool FILTER_PHOTO, bool FILTER_GEOM, bool MUBUF>
 __global__ void __launch_bounds__(64 * kQuadWaves, GEOM ? 4 : kQuadOcc) pm_sweep_quad_kernel(const PmParams* __restrict__ pp) {
   sweep_wave_body<GEOM, FILTER_PHOTO, FILTER_GEOM, kQuadWaves, kQuadThCap, MUBUF>(pp);
+}
+// Two waves per column group (sweep_wave_body, HELP = 2): launches that one wave per column cannot fill the GPU with.
+template <bool GEOM, bool FILTER_PHOTO, bool FILTER_GEOM>
+__global__ void __launch_bounds__(128, GEOM ? 4 : kQuadOcc) pm_sweep_pair_kernel(const PmParams* __restrict__ pp) {
+  sweep_wave_body<GEOM, FILTER_PHOTO, FILTER_GEOM, 2, kQuadThCap, true, false, 2>(pp);
 }
 // The same kernel with the phase clocks compiled in (pm_enable_phase_profile; photometric sweeps).
 template <bool FILTER_PHOTO>
@@ -2474,6 +2530,18 @@ const char* pm_launch_sweep(const PmParams& p, const PmParams* dev_params, int b
       if (filter_photo) hipLaunchKernelGGL(pm_sweep_quad_prof_kernel<true>, qgrid, qblock, qlds, st, dev_params);
       else hipLaunchKernelGGL(pm_sweep_quad_prof_kernel<false>, qgrid, qblock, qlds, st, dev_params);
       return "pm_sweep_quad_prof_kernel";
+    }
+    if (p.help > 1 && mubuf && p.C == 1) {
+      const size_t plds = lds_offsets_wave(p.C, p.S, p.radius, p.ntaps, p.num_samples, geom, kQuadThCap, 1).total;
+      const dim3 pgrid(groups, batch, 1), pblock(128, 1, 1);
+      if (geom) {
+        if (filter_photo && filter_geom) hipLaunchKernelGGL((pm_sweep_pair_kernel<true, true, true>), pgrid, pblock, plds, st, dev_params);
+        else hipLaunchKernelGGL((pm_sweep_pair_kernel<true, false, false>), pgrid, pblock, plds, st, dev_params);
+      } else {
+        if (filter_photo) hipLaunchKernelGGL((pm_sweep_pair_kernel<false, true, false>), pgrid, pblock, plds, st, dev_params);
+        else hipLaunchKernelGGL((pm_sweep_pair_kernel<false, false, false>), pgrid, pblock, plds, st, dev_params);
+      }
+      return "pm_sweep_pair_kernel";
     }
     if (mubuf) PM_LAUNCH_V4(pm_sweep_quad_kernel, true, qgrid, qblock, qlds);
     else PM_LAUNCH_V4(pm_sweep_quad_kernel, false, qgrid, qblock, qlds);

@@ -159,8 +159,10 @@ int pm_get_pose_tables(pm_handle* h, float* poses /*4*S*43*/, float* ref_K /*16*
 int pm_get_sweep_timing(pm_handle* h, double* total_ms, int32_t* num_launches);
 /* ... and launch by launch: ms[i] = duration of sweep launch i of the last run (i < min(capacity, *num_launches)). */
 int pm_get_sweep_times(pm_handle* h, float* ms, int32_t capacity, int32_t* num_launches);
-/* Name of the sweep kernel the last run launched ("pm_sweep_quad_kernel", "pm_sweep_wave4_kernel",
- * "pm_sweep_kernel"; static string, valid for the life of the library; the handle that led the batch). */
+/* Name of the sweep kernel the last run launched ("pm_sweep_quad_kernel"; "pm_sweep_pair_kernel" = two waves per
+ * column, what a launch that cannot fill the GPU with one wave per column runs -- a lone large problem;
+ * "pm_sweep_kernel" = other window sizes; static string, valid for the life of the library; the handle that led the
+ * batch). */
 int pm_get_sweep_kernel_name(pm_handle* h, const char** name);
 /* Bilaterally weighted NCC evaluations (PhotoConsistencyCostComputer::Compute,
  * patch_match_cuda.cu:489-593; (2 r / step + 1)^2 taps each) the last run actually executed: in the

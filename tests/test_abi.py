@@ -87,16 +87,21 @@ def test_sweep_kernels_compile_to_the_intended_structure(tmp_path):
                           ["-S", "--cuda-device-only", "-o", out, src], stderr=subprocess.DEVNULL)
     text = open(out).read()
     sweep = set(re.findall(r"^_ZN10colmap_amd\d+(pm_sweep_(?:[a-z0-9]+_)*kernel)I\w+:", text, re.M))
-    assert sweep == {"pm_sweep_kernel", "pm_sweep_quad_kernel", "pm_sweep_quad_prof_kernel"}, sweep
+    assert sweep == {"pm_sweep_kernel", "pm_sweep_quad_kernel", "pm_sweep_quad_prof_kernel", "pm_sweep_pair_kernel"}, sweep
     kernels = re.findall(r"^(_ZN10colmap_amd\d+pm_sweep_quad_kernel\w+):.*?\.end_amdhsa_kernel", text, re.S | re.M)
     assert len(kernels) == 8   # 4 (geom, filter) variants x 2 addressing modes
-    for name in kernels:
+    # two waves per column group (a lone large problem): buffer resource only, the helper wave's loop is a third task pass
+    pairs = re.findall(r"^(_ZN10colmap_amd\d+pm_sweep_pair_kernel\w+):.*?\.end_amdhsa_kernel", text, re.S | re.M)
+    assert len(pairs) == 4
+    for name in kernels + pairs:
         body = text[text.index(name + ":"):]
         body = body[:body.index(".end_amdhsa_kernel")]
         lines = [l.split(";")[0].strip() for l in body.splitlines()]
         lines = [l for l in lines if l and not l.startswith(".")]
         gathers = [l for l in lines if l.startswith("buffer_load_dword")]
-        if name.endswith("Lb1EEEvPKNS_8PmParamsE"):   # MUBUF = true
+        if "pm_sweep_pair_kernel" in name:
+            assert len(gathers) == 3 * 8 * 2 and all("idxen offen" in l for l in gathers), len(gathers)
+        elif name.endswith("Lb1EEEvPKNS_8PmParamsE"):   # MUBUF = true
             # P4 and P6 loops x 8 gathers x (clamping + unclamped addressing)
             assert len(gathers) == 2 * 8 * 2 and all("idxen offen" in l for l in gathers), len(gathers)
         else:
@@ -105,12 +110,12 @@ def test_sweep_kernels_compile_to_the_intended_structure(tmp_path):
         meta = meta[:meta.index(".wavefront_size")] if ".wavefront_size" in meta else meta[:2000]
         # photometric builds: 5 workgroups = 20 waves per CU (<= 96 VGPRs; a few loop-invariant registers may live in
         # scratch -- re-read once per NCC batch, never inside the tap rounds); geometric builds: 4 (<= 128, no scratch)
-        geom = "pm_sweep_quad_kernelILb1E" in name
+        geom = "pm_sweep_quad_kernelILb1E" in name or "pm_sweep_pair_kernelILb1E" in name
         assert int(re.search(r"\.vgpr_count:\s+(\d+)", meta).group(1)) <= (128 if geom else 96)
         assert int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", meta).group(1)) <= (0 if geom else 64)
         scratch = [i for i, l in enumerate(lines) if l.startswith("scratch_")]
         loop_gathers = [i for i, l in enumerate(lines) if l.startswith("buffer_load_dword") and "idxen" in l]
         if scratch and loop_gathers:
             # no scratch access inside the tap rounds: between the first and last gather of either task pass
-            first, last = loop_gathers[0], loop_gathers[len(loop_gathers) // 2 - 1]
+            first, last = loop_gathers[0], loop_gathers[15]
             assert not [i for i in scratch if first < i < last]

@@ -109,6 +109,22 @@ def test_buffer_resource_and_explicit_indices(pm_oracle, request, fp_global):
     assert pm.GetSweepKernelName() == "pm_sweep_quad_kernel" + (" (explicit indices)" if fp_global == "1" else "")
 
 
+@pytest.mark.parametrize("geom", [0, 1])
+def test_two_waves_per_column_pair_kernel(pm_oracle, request, geom):
+    """pm_sweep_pair_kernel (a helper wave shares pass B of the NCC phases: what a lone large problem runs) against the
+    oracle: ragged width, S = 6 (batches of 24 and 6 tasks: both waves get rounds, odd and even counts), photometric
+    with filter and the geometric pass with both filters."""
+    from switches import set_switch
+    set_switch(mvs.lib(), "COLMAP_AMD_PM_HELP", "2")
+    request.addfinalizer(lambda: set_switch(_emul_lib(), "COLMAP_AMD_PM_HELP", None))
+    views = scene(7, 35, 27)
+    maps = [(v.depth.copy(), v.normal.copy()) for v in views] if geom else None
+    want, got, pm = G._run_both(pm_oracle, views, 3, [0, 1, 2, 4, 5, 6], maps=maps, geom_consistency=geom, filter=1,
+                                num_iterations=1)
+    G._assert_equal(want, got)
+    assert pm.GetSweepKernelName() == "pm_sweep_pair_kernel"
+
+
 @pytest.mark.parametrize("radius,step", [(2, 1), (5, 2)])
 def test_generic_kernel_other_windows(pm_oracle, radius, step):
     views = scene(4, 40, 30)

@@ -149,6 +149,22 @@ def test_four_wave_workgroups_ragged_width_both_addressing_modes(pm_oracle, requ
     assert pm.GetSweepKernelName() == "pm_sweep_quad_kernel" + (" (explicit indices)" if fp_global == "1" else "")
 
 
+@pytest.mark.parametrize("geom", [0, 1])
+def test_two_waves_per_column_pair_kernel(pm_oracle, request, geom):
+    """pm_sweep_pair_kernel (a helper wave shares pass B of the NCC phases: what a lone large problem runs, chosen by
+    occupancy in RunBatchAsync, forced here) against the oracle: ragged width, S = 6."""
+    from colmap_amd import mvs
+    from switches import set_switch
+    set_switch(mvs.lib(), "COLMAP_AMD_PM_HELP", "2")
+    request.addfinalizer(lambda: set_switch(mvs.lib(), "COLMAP_AMD_PM_HELP", None))
+    views = scene(7, 67, 45)
+    maps = [(v.depth.copy(), v.normal.copy()) for v in views] if geom else None
+    want, got, pm = _run_both(pm_oracle, views, 3, [0, 1, 2, 4, 5, 6], maps=maps, geom_consistency=geom, filter=1,
+                              num_iterations=1)
+    _assert_equal(want, got)
+    assert pm.GetSweepKernelName() == "pm_sweep_pair_kernel"
+
+
 @pytest.mark.parametrize("wave", ["0", "1"])
 def test_generic_kernel_equals_wave_kernels(pm_oracle, wave):
     """The generic sweep kernel (any window size; explicit strip indices through global loads) and the 11 x 11 wave
