@@ -52,6 +52,9 @@ def parse():
     ap.add_argument("--ba2-points", type=int, default=2000000)
     ap.add_argument("--no-ba2", action="store_true")
     ap.add_argument("--cpu-crop", type=str, default="512x384")
+    ap.add_argument("--reference-build", action="store_true",
+                    help="also time the reference's own kernel (oracle/_ref/libref_pm.so, its .cu files compiled for gfx950 "
+                         "with a software texture fetch) on the CPU baseline's crop, one iteration = 4 sweeps; minutes")
     ap.add_argument("--no-fusion", action="store_true", help="skip the stereo-fusion leg (needs the geometric leg)")
     ap.add_argument("--no-dropin", action="store_true",
                     help="skip the seam leg (one problem at a time / one host thread per problem, as the reference's controller calls it)")
@@ -384,6 +387,41 @@ def pmc_traffic(images_per_launch, kernel):
 # packed source-image layout of the library this script measures (pm_internal.h: kFpStrip); a traffic file taken on
 # another layout does not describe this build
 PM_IMAGE_LAYOUT = "strips16x2-dword-footprints"
+
+
+def reference_build_leg(views, ref, src, dmin, dmax, crop_wh):
+    """The reference's OWN PatchMatchCuda on this GPU: oracle/_ref/libref_pm.so = patch_match_cuda.cu / gpu_mat_prng.cu /
+    gpu_mat_ref_image.cu compiled for gfx950 where they lie (make -C oracle ref; only the texture fetch is a software
+    stand-in, gfx950 has no image instructions). Baseline leg only (checker code, like cpu_baseline): the same crop of one
+    reference image against its full-resolution sources, num_iterations = 1 (four sweeps, one per direction; the
+    reference has no smaller unit), scaled to the five iterations of a solve."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import pm_oracle
+    import ref_pm
+    if not ref_pm.available():
+        return {"error": "oracle/_ref/libref_pm.so not built (make -C oracle ref needs /root/reference)"}
+    cw, ch = crop_wh
+    v = views[ref]
+    H, W = v.gray.shape
+    x0, y0 = (W - cw) // 2, (H - ch) // 2
+    K = v.K.copy()
+    K[0, 2] -= x0
+    K[1, 2] -= y0
+    imgs = [dict(K=K, R=vv.R, T=vv.T, gray=np.ascontiguousarray(vv.gray[y0:y0 + ch, x0:x0 + cw])) if i == ref
+            else dict(K=vv.K, R=vv.R, T=vv.T, gray=vv.gray) for i, vv in enumerate(views)]
+    o = pm_oracle.default_options(depth_min=dmin, depth_max=dmax, geom_consistency=0, filter=1, num_iterations=1)
+    r = ref_pm.RefPatchMatch(o, imgs, ref, src)
+    t = time.time()
+    out = r.run()
+    dt = time.time() - t
+    r.close()
+    return {"Mpix_per_s": cw * ch / 1e6 / (5.0 * dt), "seconds_for_4_sweeps": dt, "kept_by_filter": float((out["depth"] > 0).mean()),
+            "sample": f"{cw}x{ch} centre crop of one {W}x{H} reference image, S={len(src)} full-resolution sources, "
+                      f"num_iterations=1 timed, x5 for the 5x4 sweeps of a solve",
+            "note": "the reference's kernel as written (one thread per image column, 32-thread blocks, per-thread state in "
+                    "scratch) with a software texture stand-in: a same-node figure for the reference's SOURCE, not for "
+                    "COLMAP on an NVIDIA GPU"}
 
 
 def dropin_leg(a, problem, batched_value):
@@ -794,6 +832,8 @@ def main():
             cw, ch = [int(x) for x in a.cpu_crop.split("x")]
             host_views = [syn.View(K, R, T, g.cpu().numpy(), None, None) for (K, R, T, g, _, _) in views]
             out["cpu_baseline"] = cpu_baseline(host_views, ref, src, dmin, dmax, (cw, ch))
+            if a.reference_build:
+                out["reference_hip_build"] = reference_build_leg(host_views, ref, src, dmin, dmax, (cw, ch))
         if not a.no_dropin and world == 1:
             out["dropin"] = dropin_leg(a, problem, value)
         if not a.no_geom and world == 1:

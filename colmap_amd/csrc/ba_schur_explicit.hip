@@ -207,6 +207,7 @@ __global__ void __launch_bounds__(64) form_kernel(FormArgs A, double* __restrict
 // of one point is  J_a^T (delta_ab I - E_a C^-1 E_b^T) J_b = delta_ab J_a^T J_a - F_a G_b^T: a pair reads the F block
 // of one record and the G block of the other -- each a contiguous 32 W bytes (the two halves of a row side by side
 // would leave half of every fetched line unused).
+constexpr int kIncBatch = 4;  // incidences staged per batch by form_pairs_kernel
 constexpr int rec_rows4(int W) { return (W + 3) / 4 * 4; }
 constexpr int rec_stride(int W) { return 8 * W + (rec_rows4(W) + 4) / 2; }  // doubles; even: records stay 16-byte aligned
 inline int pick_width(const FormArgs& a) {  // the instantiated widths of both formations
@@ -363,7 +364,7 @@ __global__ void inc_emit_kernel(FormArgs A, const unsigned long long* __restrict
 // The order of the additions inside a run is the order of the sorted list (deterministic); across runs the
 // fixed-point atomics are order-independent: the tier stays bit-reproducible.
 template <int W, bool FIXED>
-__global__ void __launch_bounds__(64, (W * W + 63) / 64 <= 2 ? 8 : 1) form_pairs_kernel(FormArgs A, const unsigned long long* __restrict__ inc,
+__global__ void __launch_bounds__(64, (W * W + 63) / 64 <= 2 ? 5 : 1) form_pairs_kernel(FormArgs A, const unsigned long long* __restrict__ inc,
                                                         long long n_inc, const double* __restrict__ rec,
                                                         double* __restrict__ S) {
   constexpr int ST = rec_stride(W), W4 = rec_rows4(W), NE = (W * W + 63) / 64;
@@ -404,53 +405,61 @@ __global__ void __launch_bounds__(64, (W * W + 63) / 64 <= 2 ? 8 : 1) form_pairs
       acc[j] = 0.0;
     }
   };
-  // (A second register set that prefetches incidence t + 1 under the arithmetic of incidence t was built and dropped:
-  //  it costs as many registers as it hides latency -- 116 VGPRs = 4 waves per SIMD with two incidences in flight each
-  //  against 64 = 8 waves with one -- and the compiler's wait counts around the conditional loads of self pairs serialise
-  //  the two sets anyway.)
-  struct Batch {
-    const double *rh, *rl;
-    bool self;
-    int h0, h1, h2, l0, l1, l2;
-    double2 f0[NE], f1[NE], g0[NE], g1[NE];
-    double j1r[NE], j0c[NE];
-  };
-  auto load = [&](int t, Batch& B) {
-    const unsigned hi = (unsigned)__builtin_amdgcn_readlane(mine_hi, t), lo = (unsigned)__builtin_amdgcn_readlane(mine_lo, t);
-    B.rh = rec + (size_t)hi * ST;
-    B.rl = rec + (size_t)lo * ST;
-    B.self = hi == lo;
+  // Incidences are taken in batches of kIncBatch through LDS (round 6). A lane that fetches its own rows -- F row r of one
+  // record, G row c of the other, for each of its NE entries, plus the headers: 8 NE + 6 loads per incidence, all
+  // dependent on the incidence word -- keeps ONE incidence in flight per wave, and the kernel was the latency of 64
+  // such round trips per wave (3.8 ms at BA-1 for 8.4 GB; a second register set was built in round 4 and dropped: as many
+  // registers as it hides latency). Staged, the wave fetches the two blocks and the two headers of an incidence as
+  // 4 W + (W4 + 4) / 2 contiguous 16-byte pieces, dealt over the lanes: 3 loads per lane cover FOUR incidences at W = 10,
+  // the next batch's pieces are in flight (in registers) while this batch is consumed out of LDS, and the arithmetic
+  // reads rows out of LDS. Same sums in the same order: the staging is invisible to the result.
+  constexpr int HC = (W4 + 4) / 4;            // 16-byte pieces of a header
+  constexpr int NCH = 4 * W + 2 * HC;         // pieces per incidence: F block, G block, header of each record
+  constexpr int STI = 2 * NCH;                // doubles per staged incidence
+  constexpr int NLD = (kIncBatch * NCH + 63) / 64;
+  __shared__ __attribute__((aligned(16))) double stage[kIncBatch * STI];
+  double2 pre[NLD];
+  auto fetch = [&](int t0) {  // the pieces of incidences t0 .. t0 + kIncBatch - 1 (those below cnt) into `pre`
 #pragma unroll
-    for (int j = 0; j < NE; ++j) {
-      const int r = er[j] < W ? er[j] : 0;
-      const double2* fr = reinterpret_cast<const double2*>(B.rh + 4 * r);                // F block of the first record
-      const double2* gr = reinterpret_cast<const double2*>(B.rl + 4 * W + 4 * ec[j]);    // G block of the second
-      B.f0[j] = fr[0];
-      B.f1[j] = fr[1];
-      B.g0[j] = gr[0];
-      B.g1[j] = gr[1];
-      // a self pair adds J[:, r] . J[:, c]: J[0][r] and J[1][c] come with the two rows above
-      B.j1r[j] = B.self ? B.rh[4 * W + 4 * r + 3] : 0.0;
-      B.j0c[j] = B.self ? B.rl[4 * ec[j] + 3] : 0.0;
+    for (int k = 0; k < NLD; ++k) {
+      const int e = lane + 64 * k;
+      const int q = e / NCH, d = e - q * NCH;
+      const int t = t0 + q;
+      pre[k] = double2{0.0, 0.0};
+      // (the incidence words sit in lane t's registers: a shuffle, with every lane taking part)
+      const unsigned hi = (unsigned)__shfl(mine_hi, t & 63), lo = (unsigned)__shfl(mine_lo, t & 63);
+      if (q < kIncBatch && t < cnt) {
+        const double* rh = rec + (size_t)hi * ST;
+        const double* rl = rec + (size_t)lo * ST;
+        const double* src = d < 2 * W ? rh + 2 * d
+                          : d < 4 * W ? rl + 4 * W + 2 * (d - 2 * W)
+                          : d < 4 * W + HC ? rh + 8 * W + 2 * (d - 4 * W) : rl + 8 * W + 2 * (d - 4 * W - HC);
+        pre[k] = *reinterpret_cast<const double2*>(src);
+      }
     }
-    const int* hh = reinterpret_cast<const int*>(B.rh + 8 * W);
-    const int* hl = reinterpret_cast<const int*>(B.rl + 8 * W);
-    B.h0 = hh[W4]; B.h1 = hh[W4 + 1]; B.h2 = hh[W4 + 2];
-    B.l0 = hl[W4]; B.l1 = hl[W4 + 1]; B.l2 = hl[W4 + 2];
   };
-  auto process = [&](const Batch& B) {
-    if (B.h0 != s0 || B.h1 != s1 || B.h2 != s2 || B.l0 != s3 || B.l1 != s4 || B.l2 != s5 || B.self != cself) {
+  auto publish = [&]() {
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      const int e = lane + 64 * k;
+      if (e < kIncBatch * NCH) *reinterpret_cast<double2*>(stage + 2 * e) = pre[k];
+    }
+  };
+  auto process = [&](int t, const double* I) {  // I = the staged incidence: F block, G block, header hi, header lo
+    const bool self = __builtin_amdgcn_readlane(mine_hi, t) == __builtin_amdgcn_readlane(mine_lo, t);
+    const int* hh = reinterpret_cast<const int*>(I + 8 * W);
+    const int* hl = hh + (W4 + 4);
+    const int h0 = hh[W4], h1 = hh[W4 + 1], h2 = hh[W4 + 2], l0 = hl[W4], l1 = hl[W4 + 1], l2 = hl[W4 + 2];
+    if (h0 != s0 || h1 != s1 || h2 != s2 || l0 != s3 || l1 != s4 || l2 != s5 || self != cself) {
       flush();
-      s0 = B.h0; s1 = B.h1; s2 = B.h2; s3 = B.l0; s4 = B.l1; s5 = B.l2;
-      cself = B.self;
-      const int* hh = reinterpret_cast<const int*>(B.rh + 8 * W);
-      const int* hl = reinterpret_cast<const int*>(B.rl + 8 * W);
+      s0 = h0; s1 = h1; s2 = h2; s3 = l0; s4 = l1; s5 = l2;
+      cself = self;
 #pragma unroll
       for (int j = 0; j < NE; ++j) {
         const int ih = er[j] < W ? hh[er[j]] : -1;
         const int il = hl[ec[j]];
         const bool valid = ih >= 0 && il >= 0;
-        if (B.self) {
+        if (self) {
           wgt[j] = (valid && ih >= il) ? 1.f : 0.f;
           tgt[j] = valid ? (unsigned)ih * n + (unsigned)il : 0u;
         } else {
@@ -461,16 +470,34 @@ __global__ void __launch_bounds__(64, (W * W + 63) / 64 <= 2 ? 8 : 1) form_pairs
     }
 #pragma unroll
     for (int j = 0; j < NE; ++j) {
-      double v = fma(B.f1[j].x, B.g1[j].x, fma(B.f0[j].y, B.g0[j].y, B.f0[j].x * B.g0[j].x));
-      if (B.self) v = fma(B.f1[j].y, B.j0c[j], B.j1r[j] * B.g1[j].y) - v;
-      else v = -v;
+      const int r = er[j] < W ? er[j] : 0;
+      const double2* fr = reinterpret_cast<const double2*>(I + 4 * r);                // F row r of the first record
+      const double2* gr = reinterpret_cast<const double2*>(I + 4 * W + 4 * ec[j]);    // G row c of the second
+      const double2 f0 = fr[0], f1 = fr[1], g0 = gr[0], g1 = gr[1];
+      double v = fma(f1.x, g1.x, fma(f0.y, g0.y, f0.x * g0.x));
+      if (self) {
+        // a self pair adds J[:, r] . J[:, c]: J[0][c] rides in F row c, J[1][r] in G row r (one record: both staged)
+        const double j1r = I[4 * W + 4 * r + 3], j0c = I[4 * ec[j] + 3];
+        v = fma(f1.y, j0c, j1r * g1.y) - v;
+      } else {
+        v = -v;
+      }
       acc[j] += v;
     }
   };
-  Batch b0;
-  for (int t = 0; t < cnt; ++t) {
-    load(t, b0);
-    process(b0);
+  fetch(0);
+  for (int t0 = 0; t0 < cnt; t0 += kIncBatch) {
+    publish();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (t0 + kIncBatch < cnt) fetch(t0 + kIncBatch);
+#pragma unroll
+    for (int q = 0; q < kIncBatch; ++q)
+      if (t0 + q < cnt) process(t0 + q, stage + q * STI);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();  // every lane has read the batch before the next one overwrites it
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
   flush();
 }
