@@ -2314,6 +2314,109 @@ __device__ __forceinline__ void sweep_wave_body(const PmParams* __restrict__ pp)
   }
 }
 
+// ---------------------------------------------------------------------------
+// ComputeInitialCost (patch_match_cuda.cu:863-912) for the 11 x 11 window in the sweep kernel's shape (round 6): a wave
+// takes kInitRows consecutive rows of its column group, scrolls the reference tile by one row per step, and evaluates
+// the ncols x S costs of a row as one or more batches of the sweep's own pass B (ncc_rounds_wave: inside-first order,
+// unclamped addressing, gathers through the buffer resource). pm_initial_cost_kernel above -- one wave per (row, column
+// group): pose records, eleven tile rows and the weights of 2 x 121 taps fetched per 40 evaluations, the evaluations
+// through ncc_group's explicit addressing -- spent 41 ms per 2560 x 1920 image, as much as a sweep for half its
+// evaluations. Same arithmetic, same bits (every pixel is independent; tests: initial state and cost).
+// ---------------------------------------------------------------------------
+constexpr int kInitRows = 32;
+template <bool MUBUF>
+__global__ void __launch_bounds__(64 * kQuadWaves, kQuadOcc) pm_initial_cost_wave_kernel(const PmParams* __restrict__ pp) {
+  constexpr int NW = kQuadWaves, CAP = kQuadThCap;
+  const PmParams& p = pp[blockIdx.z];
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  Lds L;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  {
+    const LdsOffsets o = lds_offsets_wave(p.C, p.S, p.radius, p.ntaps, p.num_samples, false, CAP, NW);
+    lds_bind(L, (lds_char*)smem + wave * o.priv_stride, o);
+    L.poses = (lds_f32*)((lds_char*)smem + o.poses);
+    L.fpo = (lds_u32*)((lds_char*)smem + o.fpb);
+    L.fpb = (lds_u64*)((lds_char*)smem + o.fpb);
+    L.tapg = (lds_f32*)((lds_char*)smem + o.tapg);
+  }
+  const int tid0 = threadIdx.x & 63;
+  const int S = p.S, C = p.C;
+  const int col0 = (blockIdx.x * NW + wave) * C;
+  const int ncols = min(C, p.W - col0);
+  const int win = 2 * p.radius + 1;
+  const int row0 = blockIdx.y * kInitRows, row1 = min(row0 + kInitRows, p.H);
+  const v4i srd = MUBUF ? fp_resource(p) : (v4i)(0);
+  if (wave == 0) tap_tables_init(L.tapg, tid0, 64, p.step, p.radius, p.spatial_norm, false);
+  L.pstride = lds_pose_stride(false);
+  for (int i = threadIdx.x; i < S * L.pstride; i += 64 * NW) {
+    const int s = i / L.pstride;
+    L.poses[i] = p.poses[s * kPoseStride + (i - s * L.pstride)];
+  }
+  for (int i = threadIdx.x; i < S; i += 64 * NW) {
+    if (MUBUF) L.fpo[i] = p.src_fp_off[i];
+    else L.fpb[i] = (uint64_t)p.src_fp_tab[i];
+  }
+  __syncthreads();
+  if (col0 >= p.W) return;
+  for (int i = tid0; i < C * 8; i += 64) {  // the seven padding taps of every column: written once
+    const int at = (i >> 3) * 128 + 120 + (i & 7);
+    if ((i & 7) != 0) { L.wgt[at] = 0.0f; L.refc[at] = 0.0f; }
+  }
+  for (int r = row0 - p.radius; r < row0 + p.radius; ++r) tile_load_row(p, L, col0, r, tid0, 64);
+  wave_sync<NW>();
+  int slot_c = row0 % win, slot_top = (row0 - p.radius) % win, slot_new = (row0 + p.radius) % win;
+  if (slot_top < 0) slot_top += win;
+  const int n = ncols * S;
+  for (int row = row0; row < row1; ++row) {
+    int tid = tid0;
+    launder_vgpr(tid);  // (as in the sweep: nothing derived from the lane id lives across the NCC rounds)
+    tile_load_row_slot(p, L, col0, row + p.radius, slot_new, tid);
+    wave_sync<NW>();
+    patch_weights_wave(p, L, slot_c, slot_top, tid);
+    wave_sync<NW>();
+    patch_weight_sums(p, L, ncols, tid, 64);
+    for (int base = 0; base < n; base += CAP) {
+      const int nb = min(CAP, n - base);
+      // pass A, lane per (column, view): the homography of the pixel's initial plane
+      bool inside = false;
+      uint32_t desc = 0;
+      if (tid < nb) {
+        const int t = base + tid;
+        const int c = t / S, sv = t - c * S;
+        const int col = col0 + c;
+        const float* rec = p.rec + (size_t)(row * p.W + col) * p.rec_stride;
+        float Hm[9];
+        compose_homography(p.refInvK, L.poses + sv * L.pstride, row, col, rec[0], rec[1], rec[2], rec[3], Hm);
+        centre_homography(Hm, row, col, p.radius);
+        for (int k = 0; k < 9; ++k) L.th[tid * 9 + k] = Hm[k];
+        inside = patch_inside(p, Hm);
+        desc = (uint32_t)tid | (inside ? 0x80u : 0u) | ((uint32_t)c << 8) | ((uint32_t)sv << 16);
+      }
+      {
+        const unsigned long long m1 = __ballot(inside ? 1 : 0);
+        const unsigned long long valid = nb >= 64 ? ~0ull : ((1ull << nb) - 1ull);
+        const unsigned long long m0 = valid & ~m1;
+        if (tid < nb) L.desc[inside ? lanes_below(m1) : __popcll(m1) + lanes_below(m0)] = desc;
+      }
+      wave_sync<NW>();
+      ncc_rounds_wave<MUBUF>(p, L, srd, L.tapg, tid, nb, 0, 1);
+      wave_sync<NW>();
+      if (tid < nb) {
+        const int t = base + tid;
+        const int c = t / S, sv = t - c * S;
+        const int pix = row * p.W + col0 + c;
+        p.rec[(size_t)pix * p.rec_stride + 4 + sv] =
+            ncc_finish(L.th[tid * 9 + 0], L.th[tid * 9 + 1], L.th[tid * 9 + 2], p.ref_sum[pix], p.ref_sqsum[pix],
+                       L.colf[c * 8 + 5]);
+      }
+      wave_sync<NW>();
+    }
+    slot_top = slot_top + 1 == win ? 0 : slot_top + 1;
+    slot_c = slot_c + 1 == win ? 0 : slot_c + 1;
+    slot_new = slot_new + 1 == win ? 0 : slot_new + 1;
+  }
+}
+
 // Four waves per workgroup, each with its own column group, sharing one LDS copy of the read-only per-problem
 // tables: four workgroups = 16 waves per CU with 64 task slots per batch at S = 20 (geometric pass included).
 // MUBUF: packed images addressed through the problem's buffer resource (the normal case), or by explicit indices
@@ -2481,6 +2584,16 @@ void pm_launch_init_state(const PmParams& p, bool random_init, float depth_min, 
 }
 
 void pm_launch_initial_cost(const PmParams& p, const PmParams* dev_params, int batch, hipStream_t st) {
+  // 11 x 11 window and a shape the four-wave LDS block holds: the sweep-shaped kernel (COLMAP_AMD_PM_WAVE=0: tests)
+  if (dev_switch_int("COLMAP_AMD_PM_WAVE", 1) != 0 && pm_sweep_uses_draws(p, false)) {
+    const bool mubuf = pm_fp_resource_ok(p) && dev_switch_int("COLMAP_AMD_PM_FP_GLOBAL", 0) == 0;
+    const size_t qlds = lds_offsets_wave(p.C, p.S, p.radius, p.ntaps, p.num_samples, false, kQuadThCap, kQuadWaves).total;
+    const unsigned groups = (unsigned)((p.W + p.C - 1) / p.C);
+    const dim3 grid((groups + kQuadWaves - 1) / kQuadWaves, (unsigned)((p.H + kInitRows - 1) / kInitRows), batch);
+    if (mubuf) hipLaunchKernelGGL(pm_initial_cost_wave_kernel<true>, grid, dim3(64 * kQuadWaves), qlds, st, dev_params);
+    else hipLaunchKernelGGL(pm_initial_cost_wave_kernel<false>, grid, dim3(64 * kQuadWaves), qlds, st, dev_params);
+    return;
+  }
   const size_t lds = lds_offsets(p.C, p.S, p.radius, p.ntaps, p.num_samples, false).total;
   dim3 block(64, 1, 1);
   dim3 grid((p.W + p.C - 1) / p.C, p.H, batch);
