@@ -84,4 +84,9 @@ elif which == 'pm':
     run(G.test_group_shapes_do_not_change_results, cols=3, threads=64)
     run(G.test_sources_larger_than_reference_slot); run(G.test_error_behaviour)
     run(G.test_cached_images_in_distant_slabs_are_rehomed)   # slab allocator's test mode: cached images re-homed
+    class _Req:   # (the tests' `request` fixture: only addfinalizer is used)
+        def __init__(s): s.f = []
+        def addfinalizer(s, f): s.f.append(f)
+    for geom in (0, 1):   # two waves per column group (pm_sweep_pair_kernel): helper wave, mailbox words, barriers
+        rq = _Req(); run(T.test_two_waves_per_column_pair_kernel, request=rq, geom=geom); [f() for f in rq.f]
 print('AUDIT DONE', which)

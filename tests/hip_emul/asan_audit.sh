@@ -20,7 +20,6 @@ out=${HIP_EMUL_ASAN_DIR:-$(mktemp -d)}
 export HIP_EMUL_ASAN_DIR="$out"
 printf 'extern "C" void pm_release_cached_memory(void) {}\n' > "$out/stubs.cpp"
 ln -sf "$root/colmap_amd/csrc/pm_kernels.hip" "$here/pm/pm_kernels.hip"
-ln -sf "$root/colmap_amd/csrc/ba_schur_explicit.hip" "$here/ba/ba_schur_explicit.hip"
 F="-O1 -g $san -fno-omit-frame-pointer -std=c++17 -fPIC -shared -mavx2 -mfma -ffp-contract=off -Wno-unknown-attributes"
 "$cxx" $F -fvisibility=hidden -I "$here" -x c++ "$root/colmap_amd/csrc/fusion.hip" "$out/stubs.cpp" -o "$out/libfusion_asan.so" &
 p1=$!
@@ -28,7 +27,7 @@ p1=$!
     -I "$here" -x c++ "$root/colmap_amd/csrc/fusion.hip" "$out/stubs.cpp" -o "$out/libfusion_small_asan.so" &
 p2=$!
 "$cxx" $F -fvisibility-inlines-hidden -Wl,-Bsymbolic -I "$here" -I "$root/colmap_amd/csrc" -x c++ "$root/colmap_amd/csrc/ba_kernels.hip" \
-    "$here/ba/ba_schur_explicit.hip" "$out/stubs.cpp" -o "$out/libba_asan.so" &
+    "$root/colmap_amd/csrc/ba_schur_explicit.hip" "$out/stubs.cpp" -o "$out/libba_asan.so" &
 p3=$!
 "$cxx" $F -fvisibility-inlines-hidden -Wl,-Bsymbolic -I "$here" -I "$root/colmap_amd/csrc" -x c++ "$here/pm/pm_kernels.hip" \
     "$root/colmap_amd/csrc/pm_api.cpp" "$here/pm/pm_stubs.cpp" -o "$out/libpm_asan.so" &
