@@ -129,7 +129,7 @@ static_assert(sizeof(DevImage) % 8 == 0, "descriptors are copied to LDS word by 
 struct PassCtl {         // device-resident control words of the pass loop (read back once per pass)
   unsigned rstar[2];     // lowest rank that must not commit, slot = pass parity (the other slot is reset by the commit kernel)
   unsigned flags;        // bit 0: a walk overflowed the stack spill
-  unsigned pad;
+  unsigned redone;       // breadth-first walks that met the traversal limits and were repeated depth-first (statistics)
   unsigned long long walks, nodes, cursor;  // turns walked, pixels recorded (statistics); visibility pool cursor
 };
 
@@ -171,6 +171,10 @@ struct Params {
   // HBM): 1 = image descriptors + overlap offsets, 2 = also the overlap lists; 0 = neither fits kTableBytes
   int lds_tables;
   int n_images, n_overlap;
+  // breadth-first walks (walk_turn_wide): lanes per popped entry = the longest overlap list, entries popped together =
+  // 64 / that; 0 = depth-first walks only. wide_bound = the walk size up to which the absorbed SET cannot depend on
+  // the order of the traversal; a walk that would pass it takes its marks back and is repeated depth-first.
+  int wide_group, wide_bound;
   // per-seed outputs
   int *valid, *nvis, *vis_off;
   float* pt;            // [num_seeds][6]
@@ -418,6 +422,162 @@ __device__ __forceinline__ bool walk_turn(const Params& p, const WalkTables& tb,
   return true;
 }
 
+// The same turn with the frontier expanded SEVERAL ENTRIES AT A TIME (round 6). walk_turn is a chain of one memory
+// round trip per absorbed pixel -- pop an entry, mark it, fetch its neighbours' words / depths / normals, push the
+// survivors -- with up to check_num_images lanes busy; here the top 64 / wide_group stack entries are popped together,
+// lane (u, k) = (popped entry, neighbour): their marks (atomicMax) and the neighbour loads of ALL of them go out in one
+// round trip, so a walk takes about as many trips as it has levels instead of as many as it has pixels.
+// Why the result is the same: which pixels a walk absorbs is a closure -- a pixel is absorbed iff it is reachable from the
+// seed over pixels that pass the tests of fusion.cc:407-447, and those tests compare with the SEED's point and normal,
+// not with the path -- so the absorbed set does not depend on the order of the traversal, and neither do the medians, the
+// sorted visibility list or the marks, AS LONG AS none of the three limits of the traversal can bind: the level limit
+// (fusion.cc:473: levels are at most the number of absorbed pixels), max_num_pixels and the record capacity. All three
+// are implied by "the walk absorbs at most wide_bound = min(max_traversal_depth - 1, max_num_pixels - 1, record capacity)
+// pixels"; a walk that would exceed it takes its marks back (compare-and-swap of its own key to "free": a mark another
+// turn has replaced since stays, and whoever looked at the word in between has at worst recorded a conflict that cuts
+// the pass early -- never a wrong mask) and the turn is repeated by walk_turn: return value 2. An entry that was absorbed
+// by another path since it was pushed -- or twice in one batch -- is recognised by the old value of its own mark.
+__device__ __forceinline__ int walk_turn_wide(const Params& p, const WalkTables& tb, const WaveStack& st, int lane, unsigned t, unsigned tau,
+                               unsigned rank, int seed, float seed_depth, int* rec_n, int* n_walks, unsigned long long* stat_nodes) {
+  const unsigned long long key = ((unsigned long long)p.epoch << 32) | (unsigned long long)(0xFFFFFFFFu - rank);
+  unsigned* const rec_pix = p.rec_pix + (size_t)t * kRecordBuf;
+  unsigned* const rec_meta = p.rec_meta + (size_t)t * kRecordBuf;
+  const int first = *rec_n;
+  const int G = p.wide_group, NBF = kWave / G;
+  const int u_wide = lane / G, k_wide = lane - u_wide * G;
+  int n = first, sp = 1;
+  float ref[3] = {0.f, 0.f, 0.f}, refn[3] = {0.f, 0.f, 0.f};
+  if (lane == 0)
+    st.put(0, (unsigned long long)tb.images[p.image].pix_off + (unsigned long long)seed, make_uint2((unsigned)seed, (unsigned)p.image), seed_depth);
+  __syncthreads();
+  bool ok = true, narrow = false;
+  while (sp > 0) {
+    const int npop = sp < NBF ? sp : NBF;
+    if (n - first + npop > p.wide_bound) { ok = false; narrow = true; break; }
+    if (n + npop > kRecordBuf) { ok = false; break; }
+    // ---- the popped entries: lane (u, k) reads entry u; the seed (alone in the first batch) is read by every lane, so
+    // that the walk's reference point and normal below are computed identically everywhere ----
+    const bool first_batch = n == first;
+    const int u = first_batch ? 0 : u_wide, k = first_batch ? lane : k_wide;
+    const bool have = u < npop;
+    unsigned long long goff = 0ull;
+    uint2 epm = make_uint2(0u, 0u);
+    float depth = 0.0f;
+    if (have) st.get(sp - 1 - u, &goff, &epm, &depth);
+    __syncthreads();  // every lane has its entry before the pushes below reuse the slots
+    const int pix = (int)epm.x, img = (int)(epm.y & 0xFFFFu), level = (int)(epm.y >> 16);
+    unsigned long long old = 0ull;
+    if (have && k == 0) old = atomicMax(p.word + goff, key);  // (looked at below, after the neighbour loads have been issued)
+    const DevImage& im = tb.images[img];
+    const int row = pix / im.dw, col = pix - row * im.dw;
+    const float hx = (float)col * depth, hy = (float)row * depth;
+    float xyz[3];
+    for (int r = 0; r < 3; ++r)
+      xyz[r] = im.inv_P[4 * r] * hx + im.inv_P[4 * r + 1] * hy + im.inv_P[4 * r + 2] * depth + im.inv_P[4 * r + 3] * 1.0f;
+    const bool in_box = !(xyz[0] < p.bmin[0] || xyz[1] < p.bmin[1] || xyz[2] < p.bmin[2] || xyz[0] > p.bmax[0] ||
+                          xyz[1] > p.bmax[1] || xyz[2] > p.bmax[2]);
+    if (first_batch) {  // the seed: the walk's reference point and normal, for every lane
+      const float* nl = p.normal + 3 * goff;
+      const float nl0 = nl[0], nl1 = nl[1], nl2 = nl[2];
+      for (int r = 0; r < 3; ++r) refn[r] = im.inv_R[3 * r] * nl0 + im.inv_R[3 * r + 1] * nl1 + im.inv_R[3 * r + 2] * nl2;
+      for (int r = 0; r < 3; ++r) ref[r] = xyz[r];
+    }
+    // ---- neighbour k of entry u (fusion.cc:474-488 and the mask-independent tests of :407-447) ----
+    bool pass = false;
+    unsigned long long qoff = 0ull;
+    int q = 0, next = 0;
+    float d = 0.0f;
+    if (have && in_box && level < p.max_level) {
+      const int o0 = tb.optr[img], nov = tb.optr[img + 1] - o0;
+      if (k < nov) {
+        next = tb.oidx[o0 + k];
+        const DevImage& nx = tb.images[next];
+        if (nx.pos >= p.step) {  // used, and not fused in an earlier step
+          float np[3];
+          for (int r = 0; r < 3; ++r) np[r] = nx.P[4 * r] * xyz[0] + nx.P[4 * r + 1] * xyz[1] + nx.P[4 * r + 2] * xyz[2] + nx.P[4 * r + 3];
+          const float fcol = roundf(np[0] / np[2]), frow = roundf(np[1] / np[2]);
+          if (fcol >= 0.0f && frow >= 0.0f && fcol < (float)nx.dw && frow < (float)nx.dh) {
+            const int qcol = (int)fcol, qrow = (int)frow;
+            q = qrow * nx.dw + qcol;
+            qoff = (unsigned long long)nx.pix_off + (unsigned long long)q;
+            const unsigned long long w = ld_word(p.word + qoff);
+            d = p.depth[qoff];
+            const float* nl = p.normal + 3 * qoff;
+            const float nl0 = nl[0], nl1 = nl[1], nl2 = nl[2];
+            if (qoff != goff && !masked_for(w, p.epoch, (unsigned)p.T, t) && d > 0.0f) {
+              float proj[3];
+              for (int r = 0; r < 3; ++r)
+                proj[r] = nx.P[4 * r] * ref[0] + nx.P[4 * r + 1] * ref[1] + nx.P[4 * r + 2] * ref[2] + nx.P[4 * r + 3] * 1.0f;
+              const float depth_error = fabsf((proj[2] - d) / d);
+              const float col_diff = proj[0] / proj[2] - (float)qcol;
+              const float row_diff = proj[1] / proj[2] - (float)qrow;
+              float nrm[3];
+              for (int r = 0; r < 3; ++r) nrm[r] = nx.inv_R[3 * r] * nl0 + nx.inv_R[3 * r + 1] * nl1 + nx.inv_R[3 * r + 2] * nl2;
+              const float c = refn[0] * nrm[0] + refn[1] * nrm[1] + refn[2] * nrm[2];
+              pass = !((double)depth_error > p.max_depth_error) && !(col_diff * col_diff + row_diff * row_diff > p.max_sq_reproj) &&
+                     !(c < p.min_cos_normal);
+            }
+          }
+        }
+      }
+    }
+    // ---- the marks' old values: is the entry absorbed (free for this thread until now)? ----
+    old = shfl64(old, (!first_batch && u * G < kWave) ? u * G : 0);
+    const bool absorbed = have && !masked_for(old, p.epoch, (unsigned)p.T, t);
+    if (absorbed && k == 0 && (unsigned)(old >> 32) == p.epoch) {  // a mark of another turn of this pass: the later turn must not commit
+      const unsigned other = 0xFFFFFFFFu - (unsigned)old;
+      if (other != rank) atomicMin(&p.ctl->rstar[p.slot], other > rank ? other : rank);
+    }
+    {
+      const unsigned long long ma = __ballot(absorbed && k == 0);
+      if (absorbed && k == 0) {
+        const int at = n + __popcll(ma & ((1ull << lane) - 1ull));
+        rec_pix[at] = (unsigned)pix;
+        rec_meta[at] = (unsigned)img | (in_box ? 0x80000000u : 0u);
+      }
+      n += __popcll(ma);
+    }
+    // ---- push the survivors of the absorbed entries ----
+    pass = pass && absorbed;
+    const unsigned long long m = __ballot(pass);
+    const int cnt = __popcll(m);
+    const int base = sp - npop;
+    if (base + cnt > kStackLds + p.spill_cap) {
+      if (lane == 0) atomicOr(&p.ctl->flags, 1u);
+      ok = false;
+      break;
+    }
+    if (pass) st.put(base + __popcll(m & ((1ull << lane) - 1ull)), qoff, make_uint2((unsigned)q, (unsigned)next | ((unsigned)(level + 1) << 16)), d);
+    sp = base + cnt;
+    __syncthreads();  // the pushes (LDS / spill) before the pops of the next batch
+  }
+  if (narrow) {  // the limits of the traversal could bind: undo the marks, the caller repeats the turn depth-first
+    __syncthreads();  // (the records below were written by other lanes)
+    for (int e = first + lane; e < n; e += kWave) {
+      const unsigned long long goff = (unsigned long long)tb.images[rec_meta[e] & 0xFFFFu].pix_off + (unsigned long long)rec_pix[e];
+      unsigned long long expect = key;
+      __hip_atomic_compare_exchange_strong(p.word + goff, &expect, 0ull, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (lane == 0) atomicAdd(&p.ctl->redone, 1u);
+    __syncthreads();
+    return 2;
+  }
+  if (!ok) {  // abandoned: nothing of it is recorded, the pass is cut at this turn
+    if (lane == 0) atomicMin(&p.ctl->rstar[p.slot], rank);
+    return 0;
+  }
+  if (lane == 0) {
+    const int wi = *n_walks;
+    p.w_tau[(size_t)t * p.window_cap + wi] = tau;
+    p.w_first[(size_t)t * p.window_cap + wi] = (unsigned)first;
+    p.w_count[(size_t)t * p.window_cap + wi] = (unsigned)(n - first);
+  }
+  *stat_nodes += (unsigned long long)(n - first);
+  *rec_n = n;
+  *n_walks += 1;
+  return 1;
+}
+
 // A pass, first half: wave t takes the turns of pool thread t in the window one after the other.
 __global__ void __launch_bounds__(kWave) fusion_walk_kernel(Params p) {
   __shared__ unsigned long long s_goff[kStackLds];
@@ -475,7 +635,9 @@ __global__ void __launch_bounds__(kWave) fusion_walk_kernel(Params p) {
     const int seed = uniform(__shfl(s, j));
     const float sd = uniform(__shfl(d, j));
     ++walks;
-    if (!walk_turn(p, tb, st, lane, t, tau, rank, seed, sd, &rec_n, &n_walks, &nodes)) break;
+    int done = p.wide_group > 0 ? walk_turn_wide(p, tb, st, lane, t, tau, rank, seed, sd, &rec_n, &n_walks, &nodes) : 2;
+    if (done == 2) done = walk_turn(p, tb, st, lane, t, tau, rank, seed, sd, &rec_n, &n_walks, &nodes) ? 1 : 0;
+    if (!done) break;
     tau += 1u;
   }
   if (lane == 0) {
@@ -740,6 +902,7 @@ __global__ void fusion_normal_kernel(size_t n, const float* __restrict__ in, flo
 __global__ void fusion_ctl_reset_kernel(PassCtl* ctl) {
   ctl->rstar[0] = ctl->rstar[1] = 0xFFFFFFFFu;
   ctl->flags = 0u;
+  ctl->redone = 0u;
   ctl->walks = ctl->nodes = ctl->cursor = 0ull;
 }
 
@@ -803,6 +966,7 @@ void ComposeInverseProjectionMatrix(const float P[12], float inv_P[12]) {
 struct Stats {
   long long images = 0, seeds = 0, rounds = 0, walks = 0;  // rounds = passes; walks = turns walked (committed or not)
   long long nodes = 0, cuts = 0;                            // pixels recorded by those walks; passes that ended in a cut
+  long long redone = 0;                                     // breadth-first walks repeated depth-first
   double upload_seconds = 0.0, device_seconds = 0.0;  // host maps -> HBM + workspace setup | passes, medians, compaction, read-back
 };
 Stats g_stats;
@@ -1006,6 +1170,14 @@ void Run(const fusion_options& opt, int n, const fusion_image* images, const int
     p.lds_tables = desc > (size_t)kTableBytes ? 0 : (desc + (size_t)optr[n] * sizeof(int) > (size_t)kTableBytes ? 1 : 2);
     p.lds_tables = std::min(p.lds_tables, std::max(0, dev_switch_int("COLMAP_AMD_FUSION_LDS_TABLES", 2)));
   }
+  // breadth-first walks (walk_turn_wide) where their result provably equals the depth-first one (COLMAP_AMD_FUSION_WIDE=0:
+  // depth-first only; tests compare both)
+  {
+    const int bound = std::min(std::min(p.max_level, p.elem_cap - 1), p.rec_cap);
+    const bool wide = dev_switch_int("COLMAP_AMD_FUSION_WIDE", 1) != 0 && max_overlap <= kWave / 2 && bound >= 16;
+    p.wide_group = wide ? std::max(max_overlap, 1) : 0;
+    p.wide_bound = bound;
+  }
   mark("per-wave state allocations");
   // a stack can never hold more than (pixels a walk records) x (longest overlap list) entries
   const long long spill_bound = (long long)p.rec_cap * max_overlap + kWave;
@@ -1089,6 +1261,7 @@ void Run(const fusion_options& opt, int n, const fusion_image* images, const int
     }
     g_stats.walks += (long long)h_ctl.walks;
     g_stats.nodes += (long long)h_ctl.nodes;
+    g_stats.redone += (long long)h_ctl.redone;
     FU_CHECK(h_ctl.cursor <= (unsigned long long)pool_cap, "visibility pool overflow (more than 2^31 - 1 visibility entries for one reference image)");
     // output order of this image: (thread, tick)
     hipLaunchKernelGGL(fusion_keys_kernel, dim3((ns_px + 255) / 256), dim3(256), 0, 0, ns_px, W, T, (unsigned)L, G, keys_in.p, seeds_in.p);
@@ -1228,6 +1401,8 @@ FUSION_API void fusion_last_stats(int64_t* images, int64_t* seeds, int64_t* roun
   if (rounds) *rounds = g_stats.rounds;
   if (walks) *walks = g_stats.walks;
 }
+
+FUSION_API int64_t fusion_last_redone_walks(void) { return g_stats.redone; }
 
 FUSION_API const char* fusion_last_error(void) { return g_error.c_str(); }
 

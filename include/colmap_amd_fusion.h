@@ -81,6 +81,9 @@ void fusion_last_stats(int64_t* images, int64_t* seeds, int64_t* rounds, int64_t
 /* ... and where its time went: host maps -> HBM plus workspace set-up, and everything after (the rounds on the
  * device, medians, compaction, read-back of the points). */
 void fusion_last_timing(double* upload_seconds, double* device_seconds);
+/* ... and how many of its walks were started breadth-first, met a limit of the traversal (max_traversal_depth,
+ * max_num_pixels) and were repeated depth-first (colmap_amd/csrc/fusion.hip: walk_turn_wide). */
+int64_t fusion_last_redone_walks(void);
 const char* fusion_last_error(void);
 
 #ifdef __cplusplus

@@ -129,21 +129,44 @@ def test_emulated_kernel_blocks_in_reverse_order():
 
 @pytest.mark.parametrize("shape", [(5, 64, 48, 0.003), (4, 24, 160, 0.01)] if os.environ.get("COLMAP_AMD_TEST_SLOW", "0") != "0"
                          else [(4, 24, 160, 0.01)])
-def test_emulated_kernel_overflow_paths(emul, emul_small, shape):
+@pytest.mark.parametrize("wide", [0, 1])
+def test_emulated_kernel_overflow_paths(emul, emul_small, shape, wide):
     """The same source with a record buffer of 1 024 pixels per wave, 8 stack entries in LDS, a first stack spill of 8
     entries and medians staged up to 4 values: a wave whose buffer is full cuts the pass at its own turn, a walk
     whose stack overflows the spill cuts the pass and the host grows the spill, larger supports take the
     radix-select median. More passes than the product's capacities need; bit for bit the same points."""
+    from switches import switches
     n, w, h, sigma = shape
     images, overlap = _noisy(n, w, h, sigma), _overlap(n)
     opt = fusion.StereoFusionOptions(max_num_pixels=1000, **_LOOSE)
     want = fusion_oracle.fuse(opt, images, overlap, mode=1)
-    got = fusion.fuse(opt, images, overlap, entry_points=emul_small)
-    small_passes = emul_small.passes()
-    assert len(want.xyz) > 1500 and _same(got, want)
-    assert max(len(v) for v in got.visibility) >= 4
+    # wide = 0: depth-first walks only (the stack of a walk is deepest); 1: the default, breadth-first where that is exact
+    with switches(emul_small.lib, COLMAP_AMD_FUSION_WIDE=wide), switches(emul.lib, COLMAP_AMD_FUSION_WIDE=wide):
+        got = fusion.fuse(opt, images, overlap, entry_points=emul_small)
+        small_passes = emul_small.passes()
+        assert len(want.xyz) > 1500 and _same(got, want)
+        assert max(len(v) for v in got.visibility) >= 4
+        assert _same(fusion.fuse(opt, images, overlap, entry_points=emul), want)
+        if wide == 0:
+            assert small_passes > emul.passes(), (small_passes, emul.passes())
+
+
+def test_wide_walks_fall_back_to_depth_first_at_the_traversal_limits(emul):
+    """Breadth-first walks (walk_turn_wide) are exact only while no limit of the traversal can bind; a walk that would
+    absorb more than min(max_traversal_depth - 1, max_num_pixels - 1, record capacity) pixels takes its marks back and
+    is repeated depth-first. With max_traversal_depth = 20 on noisy maps with loose thresholds many walks pass 19
+    pixels: same cloud as the sequential definition, with and without breadth-first walks."""
+    from switches import switches
+    images, overlap = _noisy(4, 24, 160, 0.01), _overlap(4)
+    opt = fusion.StereoFusionOptions(max_traversal_depth=20, **_LOOSE)
+    want = fusion_oracle.fuse(opt, images, overlap, mode=1)
+    emul.lib.fusion_last_redone_walks.restype = C.c_int64
+    with switches(emul.lib, COLMAP_AMD_FUSION_WIDE=0):
+        assert _same(fusion.fuse(opt, images, overlap, entry_points=emul), want)
+        assert emul.lib.fusion_last_redone_walks() == 0
     assert _same(fusion.fuse(opt, images, overlap, entry_points=emul), want)
-    assert small_passes > emul.passes(), (small_passes, emul.passes())
+    assert emul.lib.fusion_last_redone_walks() > 20, emul.lib.fusion_last_redone_walks()
+    assert len(want.xyz) > 1500
 
 
 def test_small_build_refuses_a_record_capacity_it_cannot_hold(emul_small):
