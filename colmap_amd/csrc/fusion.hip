@@ -220,6 +220,8 @@ __device__ inline int seed_of(const Params& p, unsigned tau, unsigned t) {
 // two halves of put / get into one access through a selected generic pointer (it did: a pointer table in scratch).
 #define FUSION_LDS __attribute__((address_space(3)))
 struct WaveStack {  // the walk's stack: entries [0, kStackLds) in LDS, the rest in the wave's spill
+  FUSION_LDS unsigned long long* cand;  // [kWave] walk_turn_wide: the pixel every lane wants to push ...
+  FUSION_LDS int* slot;                 // [2 * kWave] ... and which lane holds a hash slot: duplicates of one batch are dropped
   FUSION_LDS unsigned long long* lds_goff;
   FUSION_LDS uint2* lds_pm;     // x = pixel, y = image | level << 16
   FUSION_LDS float* lds_d;      // depth of the pixel (loaded when the entry was tested: a pop needs no second load for it)
@@ -539,6 +541,20 @@ __device__ __forceinline__ int walk_turn_wide(const Params& p, const WalkTables&
     }
     // ---- push the survivors of the absorbed entries ----
     pass = pass && absorbed;
+    {
+      // The same pixel is usually a neighbour of several entries of the batch (every absorbed pixel of image A projects
+      // near the same pixel of image B): pushed once per parent it would come back as that many stack entries, all but
+      // one of them dead. One survivor per pixel: the lane that holds the pixel's hash slot (lanes whose slot is held by
+      // another pixel all stay: harmless).
+      const int hs = (int)((qoff * 0x9E3779B97F4A7C15ull) >> 57);  // 7 bits
+      st.cand[lane] = pass ? qoff : ~0ull;
+      if (pass) st.slot[hs] = lane;
+      __syncthreads();
+      if (pass) {
+        const int holder = st.slot[hs];
+        if (holder != lane && st.cand[holder] == qoff) pass = false;
+      }
+    }
     const unsigned long long m = __ballot(pass);
     const int cnt = __popcll(m);
     const int base = sp - npop;
@@ -600,7 +616,10 @@ __global__ void __launch_bounds__(kWave) fusion_walk_kernel(Params p) {
     }
     __syncthreads();
   }
-  WaveStack st{(FUSION_LDS unsigned long long*)s_goff, (FUSION_LDS uint2*)s_pm, (FUSION_LDS float*)s_d,
+  __shared__ unsigned long long s_cand[kWave];
+  __shared__ int s_slot[2 * kWave];
+  WaveStack st{(FUSION_LDS unsigned long long*)s_cand, (FUSION_LDS int*)s_slot,
+               (FUSION_LDS unsigned long long*)s_goff, (FUSION_LDS uint2*)s_pm, (FUSION_LDS float*)s_d,
                p.spill_goff + (size_t)t * p.spill_cap, p.spill_pm + (size_t)t * p.spill_cap, p.spill_d + (size_t)t * p.spill_cap};
   const unsigned long long img_off = (unsigned long long)tb.images[p.image].pix_off;
   unsigned tau = p.tau0 + (t < p.rmod ? 1u : 0u);
