@@ -222,6 +222,7 @@ __device__ inline int seed_of(const Params& p, unsigned tau, unsigned t) {
 struct WaveStack {  // the walk's stack: entries [0, kStackLds) in LDS, the rest in the wave's spill
   FUSION_LDS unsigned long long* cand;  // [kWave] walk_turn_wide: the pixel every lane wants to push ...
   FUSION_LDS int* slot;                 // [2 * kWave] ... and which lane holds a hash slot: duplicates of one batch are dropped
+  FUSION_LDS unsigned long long* win;   // [1] bit d: the start pixel of tick win_tau0 + d of this pool thread was absorbed by the current walk
   FUSION_LDS unsigned long long* lds_goff;
   FUSION_LDS uint2* lds_pm;     // x = pixel, y = image | level << 16
   FUSION_LDS float* lds_d;      // depth of the pixel (loaded when the entry was tested: a pop needs no second load for it)
@@ -246,6 +247,20 @@ struct WalkTables {
   const int* oidx;
 };
 
+// The start pixels of the next 64 ticks of a pool thread are looked at ONCE (fusion_walk_kernel): between two of its turns
+// only its own walks can change which of them are free for it -- other threads' marks read as free, commits happen
+// between passes. A walk therefore notes which pixels of that window it absorbed (pixel of the image being fused ->
+// stripe -> thread and tick, the inverse of seed_of).
+__device__ inline void note_window_pixel(const Params& p, const WaveStack& st, unsigned t, unsigned win_tau0, int img, int pix) {
+  if (img != p.image) return;
+  const unsigned row = (unsigned)pix / (unsigned)p.W, col = (unsigned)pix - row * (unsigned)p.W;
+  const unsigned k = row / (unsigned)kRowStride;
+  if (k % (unsigned)p.T != t) return;
+  const unsigned tick = (k / (unsigned)p.T) * p.L + (row - k * (unsigned)kRowStride) * (unsigned)p.W + col;
+  const unsigned d = tick - win_tau0;
+  if (d < (unsigned)kWave) __hip_atomic_fetch_or(st.win, 1ull << d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 // One turn of pool thread t: StereoFusion::Fuse's traversal (fusion.cc:401-489) from `seed` (free for t, positive
 // depth), executed by the 64 lanes of the wave together (every variable that steers the control flow is wave-uniform).
 // rec_n: pixels the wave has recorded in this pass; n_walks: its walks. false: record buffer or stack spill full --
@@ -261,7 +276,7 @@ struct WalkTables {
 //    its depth travels in the stack entry. Older entries are looked at again when they surface (the walk may have
 //    absorbed them by another path).
 __device__ __forceinline__ bool walk_turn(const Params& p, const WalkTables& tb, const WaveStack& st, int lane, unsigned t, unsigned tau,
-                          unsigned rank, int seed, float seed_depth, int* rec_n, int* n_walks, unsigned long long* stat_nodes) {
+                          unsigned win_tau0, unsigned rank, int seed, float seed_depth, int* rec_n, int* n_walks, unsigned long long* stat_nodes) {
   const unsigned long long key = ((unsigned long long)p.epoch << 32) | (unsigned long long)(0xFFFFFFFFu - rank);
   unsigned* const rec_pix = p.rec_pix + (size_t)t * kRecordBuf;
   unsigned* const rec_meta = p.rec_meta + (size_t)t * kRecordBuf;
@@ -289,6 +304,7 @@ __device__ __forceinline__ bool walk_turn(const Params& p, const WalkTables& tb,
       rec_pix[n] = (unsigned)pix;
       rec_meta[n] = (unsigned)img | (in_box ? 0x80000000u : 0u);
       old = atomicMax(p.word + goff, key);  // (looked at below, after the neighbour loads have been issued)
+      note_window_pixel(p, st, t, win_tau0, img, pix);
     }
     ++n; ++recorded;
     bool expand = false, capped = false;
@@ -440,7 +456,7 @@ __device__ __forceinline__ bool walk_turn(const Params& p, const WalkTables& tb,
 // the pass early -- never a wrong mask) and the turn is repeated by walk_turn: return value 2. An entry that was absorbed
 // by another path since it was pushed -- or twice in one batch -- is recognised by the old value of its own mark.
 __device__ __forceinline__ int walk_turn_wide(const Params& p, const WalkTables& tb, const WaveStack& st, int lane, unsigned t, unsigned tau,
-                               unsigned rank, int seed, float seed_depth, int* rec_n, int* n_walks, unsigned long long* stat_nodes) {
+                               unsigned win_tau0, unsigned rank, int seed, float seed_depth, int* rec_n, int* n_walks, unsigned long long* stat_nodes) {
   const unsigned long long key = ((unsigned long long)p.epoch << 32) | (unsigned long long)(0xFFFFFFFFu - rank);
   unsigned* const rec_pix = p.rec_pix + (size_t)t * kRecordBuf;
   unsigned* const rec_meta = p.rec_meta + (size_t)t * kRecordBuf;
@@ -533,6 +549,7 @@ __device__ __forceinline__ int walk_turn_wide(const Params& p, const WalkTables&
     {
       const unsigned long long ma = __ballot(absorbed && k == 0);
       if (absorbed && k == 0) {
+        note_window_pixel(p, st, t, win_tau0, img, pix);
         const int at = n + __popcll(ma & ((1ull << lane) - 1ull));
         rec_pix[at] = (unsigned)pix;
         rec_meta[at] = (unsigned)img | (in_box ? 0x80000000u : 0u);
@@ -618,15 +635,19 @@ __global__ void __launch_bounds__(kWave) fusion_walk_kernel(Params p) {
   }
   __shared__ unsigned long long s_cand[kWave];
   __shared__ int s_slot[2 * kWave];
-  WaveStack st{(FUSION_LDS unsigned long long*)s_cand, (FUSION_LDS int*)s_slot,
+  __shared__ unsigned long long s_win[1];
+  WaveStack st{(FUSION_LDS unsigned long long*)s_cand, (FUSION_LDS int*)s_slot, (FUSION_LDS unsigned long long*)s_win,
                (FUSION_LDS unsigned long long*)s_goff, (FUSION_LDS uint2*)s_pm, (FUSION_LDS float*)s_d,
                p.spill_goff + (size_t)t * p.spill_cap, p.spill_pm + (size_t)t * p.spill_cap, p.spill_d + (size_t)t * p.spill_cap};
   const unsigned long long img_off = (unsigned long long)tb.images[p.image].pix_off;
   unsigned tau = p.tau0 + (t < p.rmod ? 1u : 0u);
   int rec_n = 0, n_walks = 0;
   unsigned long long walks = 0ull, nodes = 0ull;
-  while (tau < p.tau_end) {
-    // the next 64 turns of this thread: which start pixels are free (for this thread) and have a depth?
+  bool stop = false;
+  while (!stop && tau < p.tau_end) {
+    // the next 64 turns of this thread: which start pixels are free (for this thread) and have a depth? Looked at once
+    // per window: until the window is used up only this wave's own walks can change the answer, and they say so
+    // (note_window_pixel) -- one round trip per 64 ticks instead of one per walk.
     const unsigned my_tau = tau + (unsigned)lane;
     int s = -1;
     float d = 0.0f;
@@ -641,23 +662,33 @@ __global__ void __launch_bounds__(kWave) fusion_walk_kernel(Params p) {
     }
     unsigned rs = ld_u32(&p.ctl->rstar[p.slot]);  // other waves lower it while this one runs: lane 0's view counts
     rs = uniform((unsigned)__shfl((int)(rs < p.limit ? rs : p.limit), 0));
-    const unsigned long long m = __ballot(cand);
-    if (m == 0ull) {
-      tau = p.tau_end - tau > (unsigned)kWave ? tau + (unsigned)kWave : p.tau_end;
-      if ((unsigned long long)tau * (unsigned)p.T + t >= (unsigned long long)rs) break;  // nothing from here on can commit in this pass
-      continue;
+    unsigned long long m = __ballot(cand);
+    const unsigned win_tau0 = tau;
+    const unsigned next_tau = p.tau_end - tau > (unsigned)kWave ? tau + (unsigned)kWave : p.tau_end;
+    while (m != 0ull) {
+      const int j = __ffsll((long long)m) - 1;
+      m &= m - 1ull;
+      const unsigned tj = win_tau0 + (unsigned)j;
+      const unsigned rank = tj * (unsigned)p.T + t;
+      if (rank >= rs) { stop = true; break; }
+      const int seed = uniform(__shfl(s, j));
+      const float sd = uniform(__shfl(d, j));
+      ++walks;
+      if (lane == 0) *st.win = 0ull;
+      __syncthreads();
+      int done = p.wide_group > 0 ? walk_turn_wide(p, tb, st, lane, t, tj, win_tau0, rank, seed, sd, &rec_n, &n_walks, &nodes) : 2;
+      if (done == 2) {
+        if (lane == 0) *st.win = 0ull;  // (the repeated walk notes its own pixels)
+        __syncthreads();
+        done = walk_turn(p, tb, st, lane, t, tj, win_tau0, rank, seed, sd, &rec_n, &n_walks, &nodes) ? 1 : 0;
+      }
+      if (!done) { stop = true; break; }
+      __syncthreads();
+      m &= ~*st.win;  // start pixels of this window the walk absorbed are no longer free for this thread
+      __syncthreads();
     }
-    const int j = __ffsll((long long)m) - 1;
-    tau += (unsigned)j;
-    const unsigned rank = tau * (unsigned)p.T + t;
-    if (rank >= rs) break;
-    const int seed = uniform(__shfl(s, j));
-    const float sd = uniform(__shfl(d, j));
-    ++walks;
-    int done = p.wide_group > 0 ? walk_turn_wide(p, tb, st, lane, t, tau, rank, seed, sd, &rec_n, &n_walks, &nodes) : 2;
-    if (done == 2) done = walk_turn(p, tb, st, lane, t, tau, rank, seed, sd, &rec_n, &n_walks, &nodes) ? 1 : 0;
-    if (!done) break;
-    tau += 1u;
+    if (!stop && (unsigned long long)next_tau * (unsigned)p.T + t >= (unsigned long long)rs) break;  // nothing from here on can commit in this pass
+    tau = next_tau;
   }
   if (lane == 0) {
     p.n_walks[t] = n_walks;
