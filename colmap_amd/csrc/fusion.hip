@@ -456,7 +456,8 @@ __device__ __forceinline__ bool walk_turn(const Params& p, const WalkTables& tb,
 // the pass early -- never a wrong mask) and the turn is repeated by walk_turn: return value 2. An entry that was absorbed
 // by another path since it was pushed -- or twice in one batch -- is recognised by the old value of its own mark.
 __device__ __forceinline__ int walk_turn_wide(const Params& p, const WalkTables& tb, const WaveStack& st, int lane, unsigned t, unsigned tau,
-                               unsigned win_tau0, unsigned rank, int seed, float seed_depth, int* rec_n, int* n_walks, unsigned long long* stat_nodes) {
+                               unsigned win_tau0, unsigned rank, int seed, float seed_depth, int* rec_n, int* n_walks, unsigned long long* stat_nodes,
+                               int resume_sp = -1, const float* resume_ref = nullptr, const float* resume_refn = nullptr) {
   const unsigned long long key = ((unsigned long long)p.epoch << 32) | (unsigned long long)(0xFFFFFFFFu - rank);
   unsigned* const rec_pix = p.rec_pix + (size_t)t * kRecordBuf;
   unsigned* const rec_meta = p.rec_meta + (size_t)t * kRecordBuf;
@@ -465,8 +466,15 @@ __device__ __forceinline__ int walk_turn_wide(const Params& p, const WalkTables&
   const int u_wide = lane / G, k_wide = lane - u_wide * G;
   int n = first, sp = 1;
   float ref[3] = {0.f, 0.f, 0.f}, refn[3] = {0.f, 0.f, 0.f};
-  if (lane == 0)
+  if (resume_sp >= 0) {
+    // the seed's batch has been taken already (seed_group): the seed is marked and recorded at `first`, its surviving
+    // neighbours are on the stack, the reference point and normal come with the call
+    n = first + 1;
+    sp = resume_sp;
+    for (int r = 0; r < 3; ++r) { ref[r] = resume_ref[r]; refn[r] = resume_refn[r]; }
+  } else if (lane == 0) {
     st.put(0, (unsigned long long)tb.images[p.image].pix_off + (unsigned long long)seed, make_uint2((unsigned)seed, (unsigned)p.image), seed_depth);
+  }
   __syncthreads();
   bool ok = true, narrow = false;
   while (sp > 0) {
@@ -666,6 +674,151 @@ __global__ void __launch_bounds__(kWave) fusion_walk_kernel(Params p) {
     const unsigned win_tau0 = tau;
     const unsigned next_tau = p.tau_end - tau > (unsigned)kWave ? tau + (unsigned)kWave : p.tau_end;
     while (m != 0ull) {
+      // ---- several start pixels at once (seed_group below): worthwhile when the thread has a run of turns whose walks
+      // absorb nothing but their start pixel (stripes the other images do not see: ten times the turns of an ordinary
+      // stripe, and a pass lasts as long as its slowest wave) ----
+      if (p.wide_group > 0 && (m & (m - 1ull)) != 0ull && rec_n + kWave <= kRecordBuf && n_walks + kWave <= p.window_cap) {
+        const int G = p.wide_group, NBF = kWave / G;
+        const int u = lane / G, k = lane - u * G;
+        // the group: the lowest NBF candidates of the window whose ranks can still commit
+        int ng = 0, my_j = 0;
+        {
+          unsigned long long mm = m;
+          for (int g = 0; g < NBF && mm != 0ull; ++g) {
+            const int jj = __ffsll((long long)mm) - 1;
+            mm &= mm - 1ull;
+            if ((win_tau0 + (unsigned)jj) * (unsigned)p.T + t >= rs) break;
+            if (u == g) my_j = jj;
+            ++ng;
+          }
+        }
+        if (ng >= 2) {
+          const bool have = u < ng;
+          const int seed_u = __shfl(s, my_j);
+          const float depth_u = __shfl(d, my_j);
+          const unsigned tau_u = win_tau0 + (unsigned)my_j;
+          const unsigned rank_u = tau_u * (unsigned)p.T + t;
+          const unsigned long long key_u = ((unsigned long long)p.epoch << 32) | (unsigned long long)(0xFFFFFFFFu - rank_u);
+          const unsigned long long goff = img_off + (unsigned long long)seed_u;
+          unsigned long long old = 0ull;
+          if (have && k == 0) old = atomicMax(p.word + goff, key_u);
+          const DevImage& im = tb.images[p.image];
+          const int row = seed_u / im.dw, col = seed_u - row * im.dw;
+          const float hx = (float)col * depth_u, hy = (float)row * depth_u;
+          float xyz[3], refn[3];
+          for (int r = 0; r < 3; ++r)
+            xyz[r] = im.inv_P[4 * r] * hx + im.inv_P[4 * r + 1] * hy + im.inv_P[4 * r + 2] * depth_u + im.inv_P[4 * r + 3] * 1.0f;
+          const bool in_box = !(xyz[0] < p.bmin[0] || xyz[1] < p.bmin[1] || xyz[2] < p.bmin[2] || xyz[0] > p.bmax[0] ||
+                                xyz[1] > p.bmax[1] || xyz[2] > p.bmax[2]);
+          {
+            const float* nl = p.normal + 3 * goff;
+            const float nl0 = nl[0], nl1 = nl[1], nl2 = nl[2];
+            for (int r = 0; r < 3; ++r) refn[r] = im.inv_R[3 * r] * nl0 + im.inv_R[3 * r + 1] * nl1 + im.inv_R[3 * r + 2] * nl2;
+          }
+          // neighbour k of start pixel u: the tests of walk_turn_wide with this pixel as the walk's reference
+          bool pass = false;
+          unsigned long long qoff = 0ull;
+          int q = 0, next = 0;
+          float qd = 0.0f;
+          if (have && in_box && 0 < p.max_level) {
+            const int o0 = tb.optr[p.image], nov = tb.optr[p.image + 1] - o0;
+            if (k < nov) {
+              next = tb.oidx[o0 + k];
+              const DevImage& nx = tb.images[next];
+              if (nx.pos >= p.step) {
+                float np[3];
+                for (int r = 0; r < 3; ++r) np[r] = nx.P[4 * r] * xyz[0] + nx.P[4 * r + 1] * xyz[1] + nx.P[4 * r + 2] * xyz[2] + nx.P[4 * r + 3];
+                const float fcol = roundf(np[0] / np[2]), frow = roundf(np[1] / np[2]);
+                if (fcol >= 0.0f && frow >= 0.0f && fcol < (float)nx.dw && frow < (float)nx.dh) {
+                  const int qcol = (int)fcol, qrow = (int)frow;
+                  q = qrow * nx.dw + qcol;
+                  qoff = (unsigned long long)nx.pix_off + (unsigned long long)q;
+                  const unsigned long long w = ld_word(p.word + qoff);
+                  qd = p.depth[qoff];
+                  const float* nl = p.normal + 3 * qoff;
+                  const float nl0 = nl[0], nl1 = nl[1], nl2 = nl[2];
+                  if (qoff != goff && !masked_for(w, p.epoch, (unsigned)p.T, t) && qd > 0.0f) {
+                    float proj[3];
+                    for (int r = 0; r < 3; ++r)
+                      proj[r] = nx.P[4 * r] * xyz[0] + nx.P[4 * r + 1] * xyz[1] + nx.P[4 * r + 2] * xyz[2] + nx.P[4 * r + 3] * 1.0f;
+                    const float depth_error = fabsf((proj[2] - qd) / qd);
+                    const float col_diff = proj[0] / proj[2] - (float)qcol;
+                    const float row_diff = proj[1] / proj[2] - (float)qrow;
+                    float nrm[3];
+                    for (int r = 0; r < 3; ++r) nrm[r] = nx.inv_R[3 * r] * nl0 + nx.inv_R[3 * r + 1] * nl1 + nx.inv_R[3 * r + 2] * nl2;
+                    const float c = refn[0] * nrm[0] + refn[1] * nrm[1] + refn[2] * nrm[2];
+                    pass = !((double)depth_error > p.max_depth_error) && !(col_diff * col_diff + row_diff * row_diff > p.max_sq_reproj) &&
+                           !(c < p.min_cos_normal);
+                  }
+                }
+              }
+            }
+          }
+          // marks of other turns of this pass under the start pixels: the later turn must not commit (as in the walks)
+          if (have && k == 0 && (unsigned)(old >> 32) == p.epoch) {
+            const unsigned other = 0xFFFFFFFFu - (unsigned)old;
+            if (other != rank_u) atomicMin(&p.ctl->rstar[p.slot], other > rank_u ? other : rank_u);
+          }
+          // the first start pixel with a surviving neighbour: the turns before it are complete (they absorbed their
+          // start pixel and nothing else, which no other turn of the group can tell from the sequential run); it goes on
+          // as an ordinary walk; the turns behind it take their marks back and are looked at again after that walk
+          const unsigned long long pm = __ballot(pass);
+          int ustar = ng;
+          for (int g = ng - 1; g >= 0; --g)
+            if ((pm >> (g * G)) & ((1ull << G) - 1ull)) ustar = g;
+          if (have && k == 0 && u > ustar) {
+            unsigned long long expect = key_u;
+            __hip_atomic_compare_exchange_strong(p.word + goff, &expect, 0ull, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          const int nrec = ustar < ng ? ustar + 1 : ng;
+          if (have && k == 0 && u < nrec) {
+            unsigned* const rp = p.rec_pix + (size_t)t * kRecordBuf;
+            unsigned* const rm = p.rec_meta + (size_t)t * kRecordBuf;
+            rp[rec_n + u] = (unsigned)seed_u;
+            rm[rec_n + u] = (unsigned)p.image | (in_box ? 0x80000000u : 0u);
+            if (u < ustar) {
+              p.w_tau[(size_t)t * p.window_cap + n_walks + u] = tau_u;
+              p.w_first[(size_t)t * p.window_cap + n_walks + u] = (unsigned)(rec_n + u);
+              p.w_count[(size_t)t * p.window_cap + n_walks + u] = 1u;
+            }
+          }
+          // the candidates that are settled leave the window: start pixels 0 .. min(ustar, ng - 1) of the group
+          {
+            unsigned long long mm = m;
+            for (int g = 0; g < nrec; ++g) mm &= mm - 1ull;
+            m = mm;
+          }
+          walks += (unsigned long long)nrec;
+          nodes += (unsigned long long)ustar;
+          rec_n += ustar;
+          n_walks += ustar;
+          if (ustar == ng) continue;
+          // ---- start pixel ustar goes on: its survivors onto the stack, its point and normal to every lane ----
+          const int src = ustar * G;
+          const bool mine = pass && u == ustar;
+          const unsigned long long sm = __ballot(mine);
+          if (mine) st.put(__popcll(sm & ((1ull << lane) - 1ull)), qoff, make_uint2((unsigned)q, (unsigned)next | (1u << 16)), qd);
+          float wref[3], wrefn[3];
+          for (int r = 0; r < 3; ++r) { wref[r] = __shfl(xyz[r], src); wrefn[r] = __shfl(refn[r], src); }
+          const unsigned tj = uniform((unsigned)__shfl((int)tau_u, src));
+          const unsigned rank = tj * (unsigned)p.T + t;
+          const int seed = uniform(__shfl(seed_u, src));
+          const float sd = uniform(__shfl(depth_u, src));
+          if (lane == 0) *st.win = 0ull;
+          __syncthreads();
+          int done = walk_turn_wide(p, tb, st, lane, t, tj, win_tau0, rank, seed, sd, &rec_n, &n_walks, &nodes, __popcll(sm), wref, wrefn);
+          if (done == 2) {
+            if (lane == 0) *st.win = 0ull;
+            __syncthreads();
+            done = walk_turn(p, tb, st, lane, t, tj, win_tau0, rank, seed, sd, &rec_n, &n_walks, &nodes) ? 1 : 0;
+          }
+          if (!done) { stop = true; break; }
+          __syncthreads();
+          m &= ~*st.win;
+          __syncthreads();
+          continue;
+        }
+      }
       const int j = __ffsll((long long)m) - 1;
       m &= m - 1ull;
       const unsigned tj = win_tau0 + (unsigned)j;
