@@ -340,6 +340,33 @@ def test_hip_fusion_equals_parallel_oracle(name):
 
 
 @pytest.mark.gpu
+def test_hip_fusion_depth_first_walks_and_the_fallback_to_them():
+    """The walks of the default build are breadth-first where that is provably the depth-first result
+    (colmap_amd/csrc/fusion.hip: walk_turn_wide, seed_group). COLMAP_AMD_FUSION_WIDE=0 runs the depth-first walk alone:
+    same cloud; and with max_traversal_depth = 20 on noisy maps many breadth-first walks meet the bound, take their
+    marks back and are repeated depth-first: same cloud again (fusion_last_redone_walks says how many)."""
+    import ctypes as C
+    from colmap_amd._lib import lib
+    from switches import switches
+    rng = np.random.default_rng(1)
+    images = _images(scene(4, 24, 160))
+    for im in images:
+        im.depth_map = (im.depth_map * (1 + 0.01 * rng.standard_normal(im.depth_map.shape))).astype(np.float32)
+    loose = dict(min_num_pixels=2, max_reproj_error=3.0, max_depth_error=0.05, max_normal_error=30.0)
+    lib().fusion_last_redone_walks.restype = C.c_int64
+    for kw in (dict(), dict(max_traversal_depth=20)):
+        opt = fusion.StereoFusionOptions(**loose, **kw)
+        want = fusion_oracle.fuse(opt, images, _overlap(4), mode=1)
+        assert len(want.xyz) > 1500
+        assert _same(fusion.fuse(opt, images, _overlap(4)), want)
+        redone = lib().fusion_last_redone_walks()
+        assert (redone > 20) == bool(kw), redone
+        with switches(lib(), COLMAP_AMD_FUSION_WIDE=0):
+            assert _same(fusion.fuse(opt, images, _overlap(4)), want)
+            assert lib().fusion_last_redone_walks() == 0
+
+
+@pytest.mark.gpu
 def test_hip_fusion_many_seeds_per_lane():
     """24 pool threads (waves) over 230 k pixels, 55 k points."""
     views = scene(3, 320, 240)
