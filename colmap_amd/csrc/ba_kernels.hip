@@ -145,6 +145,7 @@ struct View {
   const int *cam_off, *cam_dim, *cam_var, *cam_model;
   const int *pt_off, *pt_ptr;
   const int* tile_pt;  // point tiles: points [tile_pt[t], tile_pt[t+1]) have <= TILE_OBS observations
+  const int4* tile_info;  // {first point, end point, first p-order observation, observations} of tile t: one load
   int n_tiles;         // 0: some track is longer than a tile, use the untiled kernel
   const int *blk_off, *blk_dim, *blk_kind, *blk_moff;
   const int *chunk_blk, *chunk_beg, *chunk_end;  // chunks are c-order ranges
@@ -1154,6 +1155,8 @@ __global__ void ba_point_blocks_kernel(View V, const double* __restrict__ Craw, 
 // MODE 0 (Schur product): u = C^-1 E^T jx ; v_o = jx_o - E_o u
 // MODE 1 (reduced rhs):   u = C^-1 g_p     ; v_o = -E_o u
 // MODE 2 (back-subst.):   dp = C^-1 (g_p - E^T jx)
+// MODE 3 (tiled kernel only): MODE 2 + the model cost change of the step, one partial sum per tile
+// MODE 4 (tiled kernel only): MODE 1 + G_o = E_o C^-1 E_o^T of every observation for the Schur-Jacobi blocks
 template <int MODE>
 __global__ void ba_point_pass_kernel(View V, const double* __restrict__ Cinv, const double* __restrict__ jx,
                                      const double* __restrict__ gp, double* __restrict__ v,
@@ -1255,70 +1258,174 @@ __global__ void ba_point_apply_kernel(View V, const double* __restrict__ Cinv, c
   }
 }
 
-// Same passes with the point columns staged through LDS: a workgroup owns a tile of consecutive
-// points (<= TILE_PTS points, <= TILE_OBS observations); global loads/stores are coalesced over
-// the tile's observation range, the per-point segment walk reads LDS.
+// Same passes over tiles of consecutive points (<= TILE_PTS points, <= TILE_OBS observations per workgroup), a LANE
+// PER OBSERVATION: the lane keeps its observation's six point columns, its (gathered) jx pair and its c-order
+// position in registers from the first load to the final store; only the six products E_o[r][c] jx_o[r] of every
+// observation and the 3-vector u = C^-1 t of every point cross the lanes, through 30 KB of LDS. A point's lane adds
+// its observations' products in the order of the untiled kernel (bit-identical sums) -- 60 LDS reads per point where
+// the columns used to be walked twice (160 reads and two dependent passes per point on 51 of 256 lanes at track length 10). Everything
+// a lane needs later (C^-1, g_p, the tangent offset, the observation range) is requested before the first barrier.
 template <int MODE, typename JT = double>
 __global__ void __launch_bounds__(TILE_PTS) ba_point_pass_tiled_kernel(View V, const double* __restrict__ Cinv,
                                                                        const double* __restrict__ jx,
                                                                        const double* __restrict__ gp,
                                                                        double* __restrict__ v,
-                                                                       double* __restrict__ dp) {
-  __shared__ double sJ[6][TILE_OBS];
-  __shared__ double sx[2][TILE_OBS];
-  if (V.stop && *V.stop) return;
-  const int t = blockIdx.x;
-  const int p0 = V.tile_pt[t], p1 = V.tile_pt[t + 1];
-  const int a0 = V.pt_ptr[p0], na = V.pt_ptr[p1] - a0;
+                                                                       double* __restrict__ dp,
+                                                                       double* __restrict__ model_part = nullptr,
+                                                                       double* __restrict__ Gout = nullptr) {
+  constexpr bool kRhs = MODE == 1 || MODE == 4, kG = MODE == 4;
+  constexpr bool kDp = MODE == 2 || MODE == 3, kModel = MODE == 3, kStoreV = MODE <= 1 || MODE == 4;
+  constexpr int KPT = TILE_OBS / TILE_PTS;  // observations per lane
+  __shared__ double st[6][kRhs ? 1 : TILE_OBS];  // the six products E_o[r][c] * jx_o[r] of every observation
+  __shared__ double su[3][MODE == 2 ? 1 : TILE_PTS];  // u of the tile's points (0 for a constant point; MODE 3: y_p)
+  __shared__ unsigned char sfix[MODE == 2 ? 1 : TILE_PTS];
+  __shared__ double sci[kG ? 9 : 1][kG ? TILE_PTS : 1];  // MODE 4: C^-1 of the tile's points for the observations' lanes
+  [[maybe_unused]] double res2[KPT][2];
+  const int t = blockIdx.x, tid = threadIdx.x;
+  // (the stop flag of the pipelined PCG is looked at AFTER the loads below are on their way: a workgroup's life is a
+  //  chain of dependent round trips -- flag, tile, positions, gather -- and this takes the first one off it; a
+  //  stopped launch only writes scratch nobody reads)
+  const int stop = V.stop ? *V.stop : 0;
+  const int4 ti = V.tile_info[t];
+  const int p0 = ti.x, p1 = ti.y, a0 = ti.z, na = ti.w;
   const size_t N = (size_t)V.n_obs;
   const JT* __restrict__ Jp = JSel<JT>::pt(V);
-  for (int i = threadIdx.x; i < na; i += TILE_PTS) {
+  double J[KPT][6];
+  double2 x2[KPT];
+  int cpos[KPT], lpt[KPT];
 #pragma unroll
-    for (int c = 0; c < 6; ++c) sJ[c][i] = (double)Jp[(size_t)c * N + a0 + i];
-    if (MODE != 1) {
-      const double2 j2 = pair_load(jx, V.a2c[a0 + i]);  // gather: jx lives in c-order
-      sx[0][i] = j2.x;
-      sx[1][i] = j2.y;
+  for (int k = 0; k < KPT; ++k) {
+    const int i = tid + k * TILE_PTS;
+    x2[k] = make_double2(0.0, 0.0);
+    cpos[k] = 0; lpt[k] = 0;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) J[k][c] = 0.0;
+    if (i < na) {
+      cpos[k] = V.a2c[a0 + i];
+      if (MODE != 2) lpt[k] = V.a_pt[a0 + i] - p0;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) J[k][c] = (double)Jp[(size_t)c * N + a0 + i];
+      if (!kRhs) x2[k] = pair_load(jx, cpos[k]);  // gather: jx lives in c-order
+      if (kModel) { res2[k][0] = V.res_p[a0 + i]; res2[k][1] = V.res_p[N + a0 + i]; }
     }
   }
-  __syncthreads();
-  const int j = p0 + threadIdx.x;
+  // the point's lane: what it needs after the barrier is on its way now
+  const int j = p0 + tid;
+  int off = -1, beg = 0, end = 0;
+  double Ci[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
   if (j < p1) {
-    const int off = V.pt_off[j];
-    const int beg = V.pt_ptr[j] - a0, end = V.pt_ptr[j + 1] - a0;
-    if (off < 0) {
-      if (MODE == 1) for (int o = beg; o < end; ++o) { sx[0][o] = 0.0; sx[1][o] = 0.0; }
-    } else {
-      double tt[3] = {0, 0, 0};
-      if (MODE != 1) {
-        for (int o = beg; o < end; ++o)
+    off = V.pt_off[j];
+    beg = V.pt_ptr[j] - a0;
+    end = V.pt_ptr[j + 1] - a0;
+    if (off >= 0) {
 #pragma unroll
-          for (int r = 0; r < 2; ++r) {
-            const double x = sx[r][o];
+      for (int e = 0; e < 9; ++e) Ci[e] = Cinv[9 * (size_t)j + e];
+      if (MODE != 0) {
 #pragma unroll
-            for (int c = 0; c < 3; ++c) tt[c] += sJ[r * 3 + c][o] * x;
-          }
+        for (int c = 0; c < 3; ++c) g[c] = gp[off + c];
       }
-      if (MODE == 1) for (int c = 0; c < 3; ++c) tt[c] = gp[off + c];
-      if (MODE == 2) for (int c = 0; c < 3; ++c) tt[c] = gp[off + c] - tt[c];
-      const double* Ci = Cinv + 9 * (size_t)j;
-      double u[3];
-      for (int r = 0; r < 3; ++r) u[r] = Ci[3 * r] * tt[0] + Ci[3 * r + 1] * tt[1] + Ci[3 * r + 2] * tt[2];
-      if (MODE == 2) {
-        for (int c = 0; c < 3; ++c) dp[off + c] = u[c];
-      } else {
-        for (int o = beg; o < end; ++o)
+    }
+  }
+  if (stop) return;
+  if (!kRhs) {
 #pragma unroll
-          for (int r = 0; r < 2; ++r) {
-            const double eu = sJ[r * 3 + 0][o] * u[0] + sJ[r * 3 + 1][o] * u[1] + sJ[r * 3 + 2][o] * u[2];
-            sx[r][o] = (MODE == 0 ? sx[r][o] : 0.0) - eu;
-          }
+    for (int k = 0; k < KPT; ++k) {
+      const int i = tid + k * TILE_PTS;
+      if (i < na) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          st[c][i] = J[k][c] * x2[k].x;
+          st[3 + c][i] = J[k][3 + c] * x2[k].y;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (j < p1) {
+    double u[3] = {0.0, 0.0, 0.0};
+    if (off >= 0) {
+      double tt[3] = {0.0, 0.0, 0.0};
+      if (!kRhs) {
+        // (the order of the untiled kernel and of the oracle: observation, residual row, component -- an inner
+        //  solve of fifty CG iterations on an ill-conditioned system amplifies any other association to 1e-6)
+        for (int o = beg; o < end; ++o) {
+#pragma unroll
+          for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) tt[c] += st[r * 3 + c][o];
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) tt[c] = kRhs ? g[c] : kDp ? g[c] - tt[c] : tt[c];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) u[r] = Ci[3 * r] * tt[0] + Ci[3 * r + 1] * tt[1] + Ci[3 * r + 2] * tt[2];
+      if (kDp) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) dp[off + c] = u[c];
+      }
+    }
+    if (MODE != 2) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) su[c][tid] = u[c];
+      sfix[tid] = off < 0 ? 1 : 0;
+      if (kG) {
+#pragma unroll
+        for (int e = 0; e < 9; ++e) sci[e][tid] = Ci[e];
       }
     }
   }
   if (MODE == 2) return;
   __syncthreads();
-  for (int i = threadIdx.x; i < na; i += TILE_PTS) pair_store(v, V.a2c[a0 + i], sx[0][i], sx[1][i]);  // one 16-byte scattered store
+  double acc = 0.0;
+#pragma unroll
+  for (int k = 0; k < KPT; ++k) {
+    const int i = tid + k * TILE_PTS;
+    if (i < na) {
+      const int lp = lpt[k];
+      const double u0 = su[0][lp], u1 = su[1][lp], u2 = su[2][lp];
+      if (kModel) {  // model cost change -(J step).(r + J step / 2), J step = -(jx + E y_p) (ba_model_from_jx_kernel)
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          double m = r ? x2[k].y : x2[k].x;
+          if (!sfix[lp]) m += J[k][r * 3] * u0 + J[k][r * 3 + 1] * u1 + J[k][r * 3 + 2] * u2;
+          m = -m;
+          acc -= m * (res2[k][r] + 0.5 * m);
+        }
+        continue;
+      }
+      if (kG) {  // G_o = E_o C^-1 E_o^T (ba_obs_schur_g_kernel: the same expressions), one 32-byte record at the c-order position
+        double g00 = 0.0, g01 = 0.0, g11 = 0.0;
+        if (!sfix[lp]) {
+          double ci[9];
+#pragma unroll
+          for (int e = 0; e < 9; ++e) ci[e] = sci[e][lp];
+          const double e00 = J[k][0], e01 = J[k][1], e02 = J[k][2], e10 = J[k][3], e11 = J[k][4], e12 = J[k][5];
+          const double t00 = e00 * ci[0] + e01 * ci[3] + e02 * ci[6], t01 = e00 * ci[1] + e01 * ci[4] + e02 * ci[7],
+                       t02 = e00 * ci[2] + e01 * ci[5] + e02 * ci[8];
+          const double t10 = e10 * ci[0] + e11 * ci[3] + e12 * ci[6], t11 = e10 * ci[1] + e11 * ci[4] + e12 * ci[7],
+                       t12 = e10 * ci[2] + e11 * ci[5] + e12 * ci[8];
+          g00 = t00 * e00 + t01 * e01 + t02 * e02;
+          g01 = t00 * e10 + t01 * e11 + t02 * e12;
+          g11 = t10 * e10 + t11 * e11 + t12 * e12;
+        }
+        double2* rec = reinterpret_cast<double2*>(Gout + 4 * (size_t)cpos[k]);
+        rec[0] = make_double2(g00, g01);
+        rec[1] = make_double2(g11, 0.0);
+      }
+      double out[2];
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const double eu = J[k][r * 3 + 0] * u0 + J[k][r * 3 + 1] * u1 + J[k][r * 3 + 2] * u2;
+        const double xr = MODE == 0 ? (r ? x2[k].y : x2[k].x) : 0.0;
+        out[r] = sfix[lp] ? xr : xr - eu;  // constant point: no point block, v = jx (MODE 0) / 0 (MODE 1)
+      }
+      if (kStoreV) pair_store(v, cpos[k], out[0], out[1]);  // one 16-byte scattered store
+    }
+  }
+  if (kModel) {
+    acc = block_sum(acc);
+    if (tid == 0) model_part[t] = acc;
+  }
 }
 
 // Point-major reductions over the same tiles, columns staged through LDS (coalesced loads over the tile's
@@ -2314,7 +2421,8 @@ __global__ void __launch_bounds__(1024) ba_pcg_fused_kernel(View V, const double
 //   tail_k  (lane per block)    q_b = Dc_b^2 p_b + sum of the block's J_b^T v chunk partials, partials of p.q;
 //   step_k  (lane per block)    alpha = rho / pq, x += alpha p, r -= alpha q, partials of Q = -x.(b + r) / 2,
 //           z_b = Minv_b r_b, partials of rho' = r.z.
-// Sums over workgroups are added in index order by every thread that needs them (a handful of values): deterministic.
+// Sums over workgroups are added by every wave that needs them in one fixed order (pcg_sum: strided lanes, then the
+// xor tree): deterministic, the same bits everywhere.
 // Partials alternate between two banks by iteration parity, so a kernel never reads what its own grid is writing.
 // The host enqueues iteration k+1 before it looks at iteration k; once the device has set `stop` every later kernel
 // (the streaming kernels through View::stop) returns at entry.
@@ -2330,19 +2438,23 @@ struct PcgDev {
   PcgHostSlot* host;   // [2] pinned, device-visible
   double* qhist;       // [2] Q of the last two iterations
 };
+// (every wave of every workgroup adds the partials alike -- lane l takes the entries l, l + 64, ..., then the fixed
+//  xor tree of wave_sum: one load round trip whatever nparts is, and the same bits in every wave. All 64 lanes of
+//  the calling wave must be here.)
+constexpr int PCGP_T = 64;  // lanes (= blocks) per workgroup of the init / tail / step kernels: 4 x the CUs of 256
 __device__ __forceinline__ double pcg_sum(const double* __restrict__ part, int nparts) {
   double s = 0.0;
-  for (int w = 0; w < nparts; ++w) s += part[w];
-  return s;
+  for (int w = (int)(threadIdx.x & 63); w < nparts; w += 64) s += part[w];
+  return wave_sum(s);
 }
 // x = 0, r = b, z = Minv r, partials of rho_1 into bank 1 (component loops unrolled to the block width like the step
 // kernel's: the sums in the rolled order)
 template <int BD>
-__global__ void __launch_bounds__(256) ba_pcgp_init_kernel(View V, PcgDev D, const double* __restrict__ Minv,
+__global__ void __launch_bounds__(PCGP_T) ba_pcgp_init_kernel(View V, PcgDev D, const double* __restrict__ Minv,
                                                            const double* __restrict__ rhs, double* __restrict__ x,
                                                            double* __restrict__ r, double* __restrict__ z) {
   double rho = 0.0;
-  const int b = blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.x * PCGP_T + threadIdx.x;
   if (b < V.n_blk) {
     const int n = V.blk_dim[b], off = V.blk_off[b];
     const double* Mi = Minv + V.blk_moff[b];
@@ -2426,13 +2538,13 @@ __global__ void ba_pcgp_dir_kernel(int n, PcgDev D, int k, int max_iter, double 
 // (ba_block_vec_finalize_kernel + all-reduce) -- the tail then only adds D^2 p and takes p.q; null: this GPU's chunk
 // partials are the whole sum.
 template <int BD>
-__global__ void __launch_bounds__(256) ba_pcgp_tail_kernel(View V, PcgDev D, int k, const double* __restrict__ Dc,
+__global__ void __launch_bounds__(PCGP_T) ba_pcgp_tail_kernel(View V, PcgDev D, int k, const double* __restrict__ Dc,
                                                            const double* __restrict__ p, double* __restrict__ q,
                                                            const double* __restrict__ reduced) {
   if (*D.stop) return;
   const int bd2 = V.bd * V.bd;
   double pq = 0.0;
-  const int b = blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.x * PCGP_T + threadIdx.x;
   if (b < V.n_blk) {
     const int dim = V.blk_dim[b], off = V.blk_off[b];
     const int ch0 = V.blk_chunk_ptr[b], ch1 = V.blk_fin_end[b];
@@ -2447,9 +2559,18 @@ __global__ void __launch_bounds__(256) ba_pcgp_tail_kernel(View V, PcgDev D, int
 #pragma unroll
       for (int c = 0; c < BD; ++c) sacc[c] = c < dim ? reduced[off + c] : 0.0;
     } else {
-      for (int ch = ch0; ch < ch1; ++ch) {
+      for (int ch = ch0; ch < ch1; ch += 4) {  // four chunks' rows per round trip, added in chunk order
+        double row[4][BD];
 #pragma unroll
-        for (int c = 0; c < BD; ++c) sacc[c] += c < dim ? V.cpart[(size_t)ch * bd2 + c] : 0.0;
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+          for (int c = 0; c < BD; ++c) row[k][c] = (ch + k < ch1 && c < dim) ? V.cpart[(size_t)(ch + k) * bd2 + c] : 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (ch + k < ch1) {
+#pragma unroll
+            for (int c = 0; c < BD; ++c) sacc[c] += row[k][c];
+          }
       }
     }
 #pragma unroll
@@ -2465,7 +2586,7 @@ __global__ void __launch_bounds__(256) ba_pcgp_tail_kernel(View V, PcgDev D, int
   if (threadIdx.x == 0) D.part[(size_t)(k & 1) * 3 * D.nparts + blockIdx.x] = pq;
 }
 template <int BD>
-__global__ void __launch_bounds__(256) ba_pcgp_step_kernel(View V, PcgDev D, int k, const double* __restrict__ Minv,
+__global__ void __launch_bounds__(PCGP_T) ba_pcgp_step_kernel(View V, PcgDev D, int k, const double* __restrict__ Minv,
                                                            const double* __restrict__ rhs, const double* __restrict__ p,
                                                            const double* __restrict__ q, double* __restrict__ x,
                                                            double* __restrict__ r, double* __restrict__ z) {
@@ -2474,7 +2595,7 @@ __global__ void __launch_bounds__(256) ba_pcgp_step_kernel(View V, PcgDev D, int
   double* bank_next = D.part + (size_t)((k + 1) & 1) * 3 * D.nparts;
   const double alpha = pcg_sum(bank + D.nparts, D.nparts) / pcg_sum(bank, D.nparts);
   double Q = 0.0, rho = 0.0;
-  const int b = blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.x * PCGP_T + threadIdx.x;
   if (b < V.n_blk) {
     const int n = V.blk_dim[b], off = V.blk_off[b];
     const double* Mi = Minv + V.blk_moff[b];
@@ -3040,6 +3161,7 @@ struct Solver {
   std::vector<int> h_sens_off;
   Buf<int> o_pose, o_cam, o_pt, pose_off, pose_dim, pose_fix, cam_off, cam_dim, cam_var, cam_model, pt_off,
       pt_ptr, blk_off, blk_dim, blk_kind, blk_moff, chunk_blk, chunk_beg, chunk_end, blk_chunk_ptr, blk_fin_end, heavy_blk, c2a, a2c, tile_pt;
+  Buf<int4> tile_info;
   int n_heavy = 0;
   Buf<int> a_pose, a_cam, a_pt, a_sensor;  // p-order topology for the point-side linearisation pass
   Buf<double> a_xy;
@@ -3637,6 +3759,14 @@ struct Solver {
     }
     chunk_blk.upload(h_chunk_blk); chunk_beg.upload(h_chunk_beg); chunk_end.upload(h_chunk_end);
     c2a.upload(h_c2a); a2c.upload(h_a2c); solo.upload(h_solo); tile_pt.upload(h_tile_pt);
+    {
+      std::vector<int4> h_tile_info(std::max<size_t>(h_tile_pt.size(), 2) - 1, make_int4(0, 0, 0, 0));
+      for (size_t t = 0; t + 1 < h_tile_pt.size(); ++t) {
+        const int q0 = h_tile_pt[t], q1 = h_tile_pt[t + 1];
+        h_tile_info[t] = make_int4(q0, q1, h_pt_ptr[q0], h_pt_ptr[q1] - h_pt_ptr[q0]);
+      }
+      tile_info.upload(h_tile_info);
+    }
     a_pose.upload(h_a_pose); a_cam.upload(h_a_cam); a_pt.upload(h_a_pt); a_xy.upload(h_a_xy);
     if (has_sensors) a_sensor.upload(h_a_sensor);
     V.a_pose = a_pose.p; V.a_cam = a_cam.p; V.a_pt = a_pt.p; V.a_xy = a_xy.p;
@@ -3702,7 +3832,7 @@ struct Solver {
     V.pt_off = pt_off.p; V.pt_ptr = pt_ptr.p;
     V.blk_off = blk_off.p; V.blk_dim = blk_dim.p; V.blk_kind = blk_kind.p; V.blk_moff = blk_moff.p;
     V.chunk_blk = chunk_blk.p; V.chunk_beg = chunk_beg.p; V.chunk_end = chunk_end.p;
-    V.c2a = c2a.p; V.a2c = a2c.p; V.solo = solo.p; V.tile_pt = tile_pt.p;
+    V.c2a = c2a.p; V.a2c = a2c.p; V.solo = solo.p; V.tile_pt = tile_pt.p; V.tile_info = tile_info.p;
     V.blk_chunk_ptr = blk_chunk_ptr.p; V.cpart = cpart.p;
     V.blk_fin_end = blk_fin_end.p; V.heavy_blk = heavy_blk.p; V.n_heavy = n_heavy;
     V.Jpose = Jpose.p; V.Jcam = Jcam.p; V.Jpt = Jpt.p; V.res = res.p; V.res_p = res_p.p;
@@ -3922,7 +4052,7 @@ struct Solver {
   }
 
   int pcg_pipelined(int max_iter, double q_tol) {
-    const int n = V.n_c, gv = std::max(grid_for(n, 256), 1), nparts = grid_for(V.n_blk, 256);
+    const int n = V.n_c, gv = std::max(grid_for(n, 256), 1), nparts = grid_for(V.n_blk, PCGP_T);
     if (!pcgp_host) {
       BA_HIP(hipHostMalloc((void**)&pcgp_host, 2 * sizeof(PcgHostSlot), hipHostMallocMapped));
       BA_HIP(hipHostGetDevicePointer((void**)&pcgp_host_dev, pcgp_host, 0));
@@ -3937,9 +4067,9 @@ struct Solver {
     }
     PcgDev D;
     D.part = pcgp_part.p; D.nparts = nparts; D.stop = pcgp_stop.p; D.host = pcgp_host_dev; D.qhist = pcgp_qhist.p;
-    if (bd == PD) BA_LAUNCH(ba_pcgp_init_kernel<PD>, dim3(nparts), dim3(256), st, V, D, Minv.p, rhs.p, x.p, r.p, z.p);
-    else if (bd == KD_MAX) BA_LAUNCH(ba_pcgp_init_kernel<KD_MAX>, dim3(nparts), dim3(256), st, V, D, Minv.p, rhs.p, x.p, r.p, z.p);
-    else BA_LAUNCH(ba_pcgp_init_kernel<KD_WIDE>, dim3(nparts), dim3(256), st, V, D, Minv.p, rhs.p, x.p, r.p, z.p);
+    if (bd == PD) BA_LAUNCH(ba_pcgp_init_kernel<PD>, dim3(nparts), dim3(PCGP_T), st, V, D, Minv.p, rhs.p, x.p, r.p, z.p);
+    else if (bd == KD_MAX) BA_LAUNCH(ba_pcgp_init_kernel<KD_MAX>, dim3(nparts), dim3(PCGP_T), st, V, D, Minv.p, rhs.p, x.p, r.p, z.p);
+    else BA_LAUNCH(ba_pcgp_init_kernel<KD_WIDE>, dim3(nparts), dim3(PCGP_T), st, V, D, Minv.p, rhs.p, x.p, r.p, z.p);
     V.stop = pcgp_stop.p;  // the streaming kernels of an iteration enqueued past convergence return at entry
     auto enqueue = [&](int k) {
       BA_LAUNCH(ba_pcgp_dir_kernel, dim3(gv), dim3(256), st, n, D, k, max_iter, q_tol, z.p, pdir.p);
@@ -3960,14 +4090,14 @@ struct Solver {
         reduced = tmpc.p;
       }
       if (bd == PD) {
-        BA_LAUNCH(ba_pcgp_tail_kernel<PD>, dim3(nparts), dim3(256), st, V, D, k, Dc.p, pdir.p, q.p, reduced);
-        BA_LAUNCH(ba_pcgp_step_kernel<PD>, dim3(nparts), dim3(256), st, V, D, k, Minv.p, rhs.p, pdir.p, q.p, x.p, r.p, z.p);
+        BA_LAUNCH(ba_pcgp_tail_kernel<PD>, dim3(nparts), dim3(PCGP_T), st, V, D, k, Dc.p, pdir.p, q.p, reduced);
+        BA_LAUNCH(ba_pcgp_step_kernel<PD>, dim3(nparts), dim3(PCGP_T), st, V, D, k, Minv.p, rhs.p, pdir.p, q.p, x.p, r.p, z.p);
       } else if (bd == KD_MAX) {
-        BA_LAUNCH(ba_pcgp_tail_kernel<KD_MAX>, dim3(nparts), dim3(256), st, V, D, k, Dc.p, pdir.p, q.p, reduced);
-        BA_LAUNCH(ba_pcgp_step_kernel<KD_MAX>, dim3(nparts), dim3(256), st, V, D, k, Minv.p, rhs.p, pdir.p, q.p, x.p, r.p, z.p);
+        BA_LAUNCH(ba_pcgp_tail_kernel<KD_MAX>, dim3(nparts), dim3(PCGP_T), st, V, D, k, Dc.p, pdir.p, q.p, reduced);
+        BA_LAUNCH(ba_pcgp_step_kernel<KD_MAX>, dim3(nparts), dim3(PCGP_T), st, V, D, k, Minv.p, rhs.p, pdir.p, q.p, x.p, r.p, z.p);
       } else {
-        BA_LAUNCH(ba_pcgp_tail_kernel<KD_WIDE>, dim3(nparts), dim3(256), st, V, D, k, Dc.p, pdir.p, q.p, reduced);
-        BA_LAUNCH(ba_pcgp_step_kernel<KD_WIDE>, dim3(nparts), dim3(256), st, V, D, k, Minv.p, rhs.p, pdir.p, q.p, x.p, r.p, z.p);
+        BA_LAUNCH(ba_pcgp_tail_kernel<KD_WIDE>, dim3(nparts), dim3(PCGP_T), st, V, D, k, Dc.p, pdir.p, q.p, reduced);
+        BA_LAUNCH(ba_pcgp_step_kernel<KD_WIDE>, dim3(nparts), dim3(PCGP_T), st, V, D, k, Minv.p, rhs.p, pdir.p, q.p, x.p, r.p, z.p);
       }
     };
     enqueue(1);
@@ -4200,8 +4330,14 @@ struct Solver {
       bool mfma_pending = false;
       if (nc > 0) {
         if (V.n_chunks == 0) BA_HIP(hipMemsetAsync(M.p, 0, sizeof(double) * std::max(moff_total, 1), st));
+        const bool rhs_pass_fused = V.n_chunks > 0 && V.n_tiles > 0 && (comm.world == 1 || comm.by_point);
         if (V.n_chunks > 0) {  // (ba_block_mat_finalize_kernel<false> assigns every entry of every block)
-          BA_LAUNCH(ba_obs_schur_g_kernel, dim3(grid_for(V.n_obs, 256)), dim3(256), st, V, Cinv.p, Gobs.p);
+          // (tiles, points local: the reduced right-hand side's point pass -- which holds E_o and needs C^-1 anyway --
+          //  leaves G_o behind; v is not touched until block_jtv_reduced below)
+          if (rhs_pass_fused)
+            BA_LAUNCH((ba_point_pass_tiled_kernel<4>), dim3(V.n_tiles), dim3(TILE_PTS), st, V, Cinv.p, jx.p, gp.p, v.p, dp.p, (double*)nullptr, Gobs.p);
+          else
+            BA_LAUNCH(ba_obs_schur_g_kernel, dim3(grid_for(V.n_obs, 256)), dim3(256), st, V, Cinv.p, Gobs.p);
           BA_HIP(hipEventRecord(ev2, st));
           const bool gram_lds = dev_switch_int("COLMAP_AMD_BA_GRAM_LDS", 1) != 0;
           if (gram_lds && bd == PD) BA_LAUNCH(ba_block_gram_lds_kernel<PD>, dim3(V.n_chunks), dim3(64 * GRAM_WAVES), st, V, Gobs.p);
@@ -4257,7 +4393,7 @@ struct Solver {
         else if (bd == KD_WIDE) BA_LAUNCH(ba_block_invert_kernel<KD_WIDE>, dim3(grid_for(V.n_blk, 64)), dim3(64), st, V, Dc.p, M.p, Minv.p);
         else BA_LAUNCH(ba_block_invert_kernel<KD_MAX>, dim3(grid_for(V.n_blk, 64)), dim3(64), st, V, Dc.p, M.p, Minv.p);
         // reduced rhs = g_c - E C^-1 g_p  (g_p, C^-1 are global; the J_c^T part is summed over ranks)
-        point_pass<1>();
+        if (!rhs_pass_fused) point_pass<1>();
         block_jtv_reduced(v.p);
         BA_HIP(hipMemcpyAsync(rhs.p, gc.p, sizeof(double) * nc, hipMemcpyDeviceToDevice, st));
         BA_LAUNCH(ba_add_kernel, dim3(grid_for(nc, 256)), dim3(256), st, nc, tmpc.p, rhs.p);
@@ -4270,7 +4406,11 @@ struct Solver {
         else if (kd == KD_WIDE) BA_LAUNCH(ba_obs_jx_kernel<KD_WIDE>, dim3(grid_for(V.n_obs, 256)), dim3(256), st, V, x.p, jx.p);
         else BA_LAUNCH(ba_obs_jx_kernel<KD_MAX>, dim3(grid_for(V.n_obs, 256)), dim3(256), st, V, x.p, jx.p);
       }
-      if (comm.world == 1 || comm.by_point) {
+      // (tiles: the same launch leaves the model cost change's partial sums behind -- columns, jx and y_p are in its registers)
+      const bool model_fused = (comm.world == 1 || comm.by_point) && V.n_tiles > 0;
+      if (model_fused) {
+        BA_LAUNCH((ba_point_pass_tiled_kernel<3>), dim3(V.n_tiles), dim3(TILE_PTS), st, V, Cinv.p, jx.p, gp.p, v.p, dp.p, partials.p);
+      } else if (comm.world == 1 || comm.by_point) {
         point_pass<2>();
       } else {
         BA_HIP(hipMemsetAsync(tbuf.p, 0, sizeof(double) * std::max(np, 1), st));
@@ -4282,7 +4422,9 @@ struct Solver {
       BA_LAUNCH(ba_axpby_kernel, dim3(std::max(gvc, 1)), dim3(256), st, nc, -1.0, x.p, nullptr, stepc.p);
       BA_LAUNCH(ba_axpby_kernel, dim3(std::max(gvp, 1)), dim3(256), st, np, -1.0, dp.p, nullptr, stepp.p);
       // model cost change -(J step).(r + J step / 2): jx = J_c y_c of the back-substitution is still in place
-      if (V.n_tiles > 0) {
+      if (model_fused) {
+        BA_LAUNCH(ba_final_sum_kernel, dim3(1), dim3(1024), st, partials.p, V.n_tiles, scalars.p + S_MODEL);
+      } else if (V.n_tiles > 0) {
         BA_LAUNCH(ba_point_reduce_tiled_kernel<1>, dim3(V.n_tiles), dim3(TILE_PTS), st, V, jx.p, dp.p, partials.p, nullptr, nullptr);
         BA_LAUNCH(ba_final_sum_kernel, dim3(1), dim3(1024), st, partials.p, V.n_tiles, scalars.p + S_MODEL);
       } else {

@@ -43,6 +43,8 @@ struct uint2 { unsigned x, y; };
 inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
 struct alignas(16) double2 { double x, y; };
 inline double2 make_double2(double x, double y) { return double2{x, y}; }
+struct alignas(16) int4 { int x, y, z, w; };
+inline int4 make_int4(int x, int y, int z, int w) { return int4{x, y, z, w}; }
 struct alignas(8) float2 { float x, y; };
 inline float2 make_float2(float x, float y) { return float2{x, y}; }
 struct alignas(16) float4 { float x, y, z, w; };
