@@ -43,6 +43,7 @@
 #include <numeric>
 #include <stdexcept>
 #include <thread>
+#include <type_traits>
 #include <string>
 #include <vector>
 
@@ -776,7 +777,11 @@ template <> struct JSel<float> {
 // Jpar is laid out 2 x NPAR whatever the model (columns beyond the model's parameters are not read).
 // PSIDE: also write the point-side columns and the p-order residual (scattered through c2a); false when
 // ba_linearize_point_kernel produces them in its own p-order pass.
-template <bool JAC, int KD, bool PSIDE = true>
+// ONLY >= 0: the PLAIN instantiation for the commonest problem shape -- every camera of model ONLY, no sensor_from_rig
+// observations, trivial loss, no fp32 operator copies (the host checks; launch_linearize). The same expressions with the
+// model switch, the rig branch and the corrector folded away at compile time: bit-identical columns, two thirds of the
+// registers.
+template <bool JAC, int KD, bool PSIDE = true, int ONLY = -1>
 __global__ void __launch_bounds__(256) ba_linearize_kernel(View V, const double* __restrict__ poses,
                                                           const double* __restrict__ cams,
                                                           const double* __restrict__ points,
@@ -789,14 +794,15 @@ __global__ void __launch_bounds__(256) ba_linearize_kernel(View V, const double*
     const double* q = poses + 7 * (size_t)pi;
     const double* prm = cams + BA_CAM_STRIDE * (size_t)ci;
     const double* X = points + 3 * (size_t)xi;
-    const int model = V.cam_model[ci];
+    constexpr bool PLAIN = ONLY >= 0;
+    const int model = PLAIN ? ONLY : V.cam_model[ci];
     constexpr int NP = KD > KD_MAX ? NPAR_WIDE : NPAR;  // J_params columns (12-parameter models only in the wide tier)
     double JR[12], Juvw[6], Jpar[2 * NP], pc[3];
     quat_rotate(q, X, pc, JAC ? JR : nullptr);
     pc[0] += q[4]; pc[1] += q[5]; pc[2] += q[6];
     // sensor_from_rig (RigReprojErrorCostFunctor / ...ConstantRigCostFunctor, reprojection_error.h:
     // 344-417): p_cam = R_s p_rig + t_s
-    const int si = V.o_sensor ? V.o_sensor[o] : -1;
+    const int si = (!PLAIN && V.o_sensor) ? V.o_sensor[o] : -1;
     const int soff = (si >= 0 && V.sens_off) ? V.sens_off[si] : -1;
     double Rs[9], JRs[12], prig[3] = {pc[0], pc[1], pc[2]};
     if (si >= 0) {
@@ -822,7 +828,8 @@ __global__ void __launch_bounds__(256) ba_linearize_kernel(View V, const double*
     // robust loss: cost = 1/2 rho(|r|^2)
     const double sq_norm = rx * rx + ry * ry;
     double rho[3];
-    loss_eval(V.loss_type, V.loss_scale, sq_norm, rho);
+    if (PLAIN) { rho[0] = sq_norm; rho[1] = 1.0; rho[2] = 0.0; }
+    else loss_eval(V.loss_type, V.loss_scale, sq_norm, rho);
     cost = 0.5 * rho[0];
     if (JAC) {
       double Js[2][6];  // sensor_from_rig tangent columns: J_uvw [dR_s p/dq_s PlusJacobian | I]
@@ -925,7 +932,7 @@ __global__ void __launch_bounds__(256) ba_linearize_kernel(View V, const double*
             Jx[r][c] = Juvw[3 * r] * R[c] + Juvw[3 * r + 1] * R[3 + c] + Juvw[3 * r + 2] * R[6 + c];
       }
       // ceres::internal::Corrector: r' = residual_scaling r, J' = sqrt(rho') (J - alpha/|r|^2 r r^T J)
-      if (V.loss_type != BA_LOSS_TRIVIAL) {
+      if (!PLAIN && V.loss_type != BA_LOSS_TRIVIAL) {
         const double sqrt_rho1 = sqrt(rho[1]);
         double residual_scaling = sqrt_rho1, alpha_sq_norm = 0.0;
         if (!(sq_norm == 0.0 || rho[2] <= 0.0)) {
@@ -964,15 +971,15 @@ __global__ void __launch_bounds__(256) ba_linearize_kernel(View V, const double*
         for (int c = 0; c < PD; ++c) {
           const double s = (c < pdim) ? V.scale_c[poff + c] : 0.0;
           V.Jpose[(size_t)(r * PD + c) * N + o] = Jp[r][c] * s;
-          if (V.Jpose32) V.Jpose32[(size_t)(r * PD + c) * N + o] = (float)(Jp[r][c] * s);
+          if (!PLAIN && V.Jpose32) V.Jpose32[(size_t)(r * PD + c) * N + o] = (float)(Jp[r][c] * s);
         }
 #pragma unroll
         for (int c = 0; c < KD; ++c) {
           const double s = (c < cdim) ? V.scale_c[coff + c] : 0.0;
           V.Jcam[(size_t)(r * KD + c) * N + o] = Jk[r][c] * s;
-          if (V.Jcam32) V.Jcam32[(size_t)(r * KD + c) * N + o] = (float)(Jk[r][c] * s);
+          if (!PLAIN && V.Jcam32) V.Jcam32[(size_t)(r * KD + c) * N + o] = (float)(Jk[r][c] * s);
         }
-        if (V.sens_off) {
+        if (!PLAIN && V.sens_off) {
 #pragma unroll
           for (int c = 0; c < 6; ++c)
             V.Jsens[(size_t)(r * 6 + c) * N + o] = soff >= 0 ? Js[r][c] * V.scale_c[soff + c] : 0.0;
@@ -982,7 +989,7 @@ __global__ void __launch_bounds__(256) ba_linearize_kernel(View V, const double*
           for (int c = 0; c < 3; ++c) {
             const double s = (ptoff >= 0) ? V.scale_p[ptoff + c] : 0.0;
             V.Jpt[(size_t)(r * 3 + c) * N + a] = Jx[r][c] * s;
-            if (V.Jpt32) V.Jpt32[(size_t)(r * 3 + c) * N + a] = (float)(Jx[r][c] * s);
+            if (!PLAIN && V.Jpt32) V.Jpt32[(size_t)(r * 3 + c) * N + a] = (float)(Jx[r][c] * s);
           }
         }
       }
@@ -998,7 +1005,7 @@ __global__ void __launch_bounds__(256) ba_linearize_kernel(View V, const double*
 // eight doubles per lane through c2a: eight 64-byte write transactions for 64 bytes of payload
 // (WRITE_SIZE 1.14 GB per launch at BA-1 for 0.45 GB of columns). Same expressions in the same order as
 // ba_linearize_kernel, so the columns are bit-identical to the scattered ones.
-template <int KD>
+template <int KD, int ONLY = -1>
 __global__ void __launch_bounds__(256) ba_linearize_point_kernel(View V, const double* __restrict__ poses,
                                                                 const double* __restrict__ cams,
                                                                 const double* __restrict__ points,
@@ -1009,12 +1016,13 @@ __global__ void __launch_bounds__(256) ba_linearize_point_kernel(View V, const d
   const double* q = poses + 7 * (size_t)pi;
   const double* prm = cams + BA_CAM_STRIDE * (size_t)ci;
   const double* X = points + 3 * (size_t)xi;
-  const int model = V.cam_model[ci];
+  constexpr bool PLAIN = ONLY >= 0;
+  const int model = PLAIN ? ONLY : V.cam_model[ci];
   constexpr int NP = KD > KD_MAX ? NPAR_WIDE : NPAR;
   double Juvw[6], Jpar[2 * NP], pc[3];
   quat_rotate(q, X, pc, nullptr);
   pc[0] += q[4]; pc[1] += q[5]; pc[2] += q[6];
-  const int si = V.a_sensor ? V.a_sensor[a] : -1;
+  const int si = (!PLAIN && V.a_sensor) ? V.a_sensor[a] : -1;
   double Rs[9];
   if (si >= 0) {
     const double* sfr = sensors + 7 * (size_t)si;
@@ -1053,7 +1061,7 @@ __global__ void __launch_bounds__(256) ba_linearize_point_kernel(View V, const d
       for (int c = 0; c < 3; ++c)
         Jx[r][c] = Juvw[3 * r] * R[c] + Juvw[3 * r + 1] * R[3 + c] + Juvw[3 * r + 2] * R[6 + c];
   }
-  if (V.loss_type != BA_LOSS_TRIVIAL) {
+  if (!PLAIN && V.loss_type != BA_LOSS_TRIVIAL) {
     double rho[3];
     loss_eval(V.loss_type, V.loss_scale, sq_norm, rho);
     const double sqrt_rho1 = sqrt(rho[1]);
@@ -1083,7 +1091,7 @@ __global__ void __launch_bounds__(256) ba_linearize_point_kernel(View V, const d
     for (int c = 0; c < 3; ++c) {
       const double s = (ptoff >= 0) ? V.scale_p[ptoff + c] : 0.0;
       V.Jpt[(size_t)(r * 3 + c) * N + a] = Jx[r][c] * s;
-      if (V.Jpt32) V.Jpt32[(size_t)(r * 3 + c) * N + a] = (float)(Jx[r][c] * s);
+      if (!PLAIN && V.Jpt32) V.Jpt32[(size_t)(r * 3 + c) * N + a] = (float)(Jx[r][c] * s);
     }
 }
 
@@ -1706,8 +1714,18 @@ __global__ void __launch_bounds__(1024) ba_cpart_heavy_reduce_kernel(View V, int
   const int bb = V.bd * V.bd;
   const int ch0 = V.blk_chunk_ptr[b], ch1 = V.blk_chunk_ptr[b + 1];
   double s = 0.0;
-  if (e < width)
-    for (int ch = ch0 + g; ch < ch1; ch += groups) s += V.cpart[(size_t)ch * bb + e];
+  if (e < width) {
+    // eight rows per round trip (a thread's 60-odd rows used to be one dependent load each), added in row order
+    constexpr int U = 8;
+    for (int ch = ch0 + g; ch < ch1; ch += U * groups) {
+      double row[U];
+#pragma unroll
+      for (int k = 0; k < U; ++k) row[k] = ch + k * groups < ch1 ? V.cpart[(size_t)(ch + k * groups) * bb + e] : 0.0;
+#pragma unroll
+      for (int k = 0; k < U; ++k)
+        if (ch + k * groups < ch1) s += row[k];
+    }
+  }
   part[threadIdx.x] = s;
   __syncthreads();
   if (g == 0 && e < width) {
@@ -3168,6 +3186,7 @@ struct Solver {
   bool split_linearize = true;
   Buf<float> Jpose32, Jcam32, Jpt32;
   bool op32 = false;  // PCG operator streams the fp32 copies
+  int plain_model = -1;  // >= 0: every camera has this model (SIMPLE_PINHOLE / PINHOLE / SIMPLE_RADIAL), no rig observations, trivial loss, no fp32 copies
   bool pcg_all_ranks_have_work = false;  // sharded solves: every rank has observations and chunk lists (agreed in run())
   Buf<unsigned char> solo;
   Buf<double> o_xy, poses, cams, points, poses2, cams2, points2, Jpose, Jcam, Jpt, res, res_p, scale_c, scale_p,
@@ -3794,6 +3813,17 @@ struct Solver {
       V.Jcam32 = op32 ? Jcam32.p : nullptr;
       V.Jpt32 = op32 ? Jpt32.p : nullptr;
     }
+    {
+      plain_model = -1;
+      const bool plain_ok = dev_switch_int("COLMAP_AMD_BA_PLAIN_LINEARIZE", 1) != 0 && !op32 && !has_sensors &&
+                            opt.loss_type == BA_LOSS_TRIVIAL && p.num_cams > 0;
+      if (plain_ok) {
+        const int m0 = p.cam_model[0];
+        bool same = m0 == BA_SIMPLE_PINHOLE || m0 == BA_PINHOLE || m0 == BA_SIMPLE_RADIAL;
+        for (int k = 1; same && k < p.num_cams; ++k) same = p.cam_model[k] == m0;
+        if (same) plain_model = m0;
+      }
+    }
     // gradient, column norms and E^T E of a linearisation are summed over the ranks of a sharded solve in ONE
     // all-reduce: they live back to back in `lin_sums` [g_c | diag_c | g_p | diag_p | E^T E] (point sharding
     // reduces the camera-side prefix only)
@@ -3846,7 +3876,21 @@ struct Solver {
 
   void launch_linearize(bool jac, const double* P, const double* Cm, const double* X, const double* Sn, int slot) {
     const int g = grid_for(V.n_obs, 256);
-    if (jac && split_linearize) {  // camera side in c-order, point side in p-order: every store coalesced
+    if (split_linearize && kd == 4 && plain_model >= 0) {
+      // one camera model, no rig observations, trivial loss, no fp32 copies: the PLAIN instantiations (same bits)
+      auto launch = [&](auto tag) {
+        constexpr int M = decltype(tag)::value;
+        if (jac) {
+          BA_LAUNCH((ba_linearize_kernel<true, 4, false, M>), dim3(g), dim3(256), st, V, P, Cm, X, Sn, partials.p);
+          BA_LAUNCH((ba_linearize_point_kernel<4, M>), dim3(g), dim3(256), st, V, P, Cm, X, Sn);
+        } else {
+          BA_LAUNCH((ba_linearize_kernel<false, 4, true, M>), dim3(g), dim3(256), st, V, P, Cm, X, Sn, partials.p);
+        }
+      };
+      if (plain_model == BA_SIMPLE_PINHOLE) launch(std::integral_constant<int, BA_SIMPLE_PINHOLE>{});
+      else if (plain_model == BA_PINHOLE) launch(std::integral_constant<int, BA_PINHOLE>{});
+      else launch(std::integral_constant<int, BA_SIMPLE_RADIAL>{});
+    } else if (jac && split_linearize) {  // camera side in c-order, point side in p-order: every store coalesced
       if (kd == 4) {
         BA_LAUNCH((ba_linearize_kernel<true, 4, false>), dim3(g), dim3(256), st, V, P, Cm, X, Sn, partials.p);
         BA_LAUNCH((ba_linearize_point_kernel<4>), dim3(g), dim3(256), st, V, P, Cm, X, Sn);

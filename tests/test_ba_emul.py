@@ -402,6 +402,8 @@ _slow = pytest.mark.skipif(os.environ.get("COLMAP_AMD_TEST_SLOW", "0") == "0", r
 def test_slow_kernel_variants():
     G.test_split_linearisation_is_bit_identical(False)
     G.test_split_linearisation_is_bit_identical("three")
+    for m in ("SIMPLE_RADIAL", "PINHOLE", "SIMPLE_PINHOLE"):
+        G.test_plain_linearisation_is_bit_identical(m)
     G.test_fused_pcg_kernel_matches_separate_kernels()
     G.test_run_to_run_determinism()
     G.test_tracks_longer_than_a_tile()

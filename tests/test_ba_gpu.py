@@ -423,6 +423,26 @@ def test_split_linearisation_is_bit_identical(mixed):
     assert np.array_equal(b0.poses, b1.poses) and np.array_equal(b0.points, b1.points) and np.array_equal(b0.cams, b1.cams)
 
 
+@pytest.mark.parametrize("model", ["SIMPLE_RADIAL", "PINHOLE", "SIMPLE_PINHOLE"])
+def test_plain_linearisation_is_bit_identical(model):
+    """One camera model, no rig observations, trivial loss: the linearisation kernels instantiated for that model (the
+    model switch, the rig branch and the loss corrector folded away at compile time -- 92 instead of 168 registers)
+    against the generic kernels: the same expressions, so the whole solve is bit-identical."""
+    fp = _flat(40, 3000, 8, seed=7)
+    if model == "PINHOLE":
+        fp.cam_model[:] = scene.PINHOLE
+        fp.cams[:, :4] = [1280.0, 1280.0, 512.0, 384.0]
+    elif model == "SIMPLE_PINHOLE":
+        fp.cam_model[:] = scene.SIMPLE_PINHOLE
+        fp.cams[:, :4] = [1280.0, 512.0, 384.0, 0.0]
+    assert est.fix_gauge_two_cams(fp)
+    b0, s0 = _solve_env(fp, {"COLMAP_AMD_BA_PLAIN_LINEARIZE": "0"}, max_num_iterations=12)
+    b1, s1 = _solve_env(fp, {"COLMAP_AMD_BA_PLAIN_LINEARIZE": "1"}, max_num_iterations=12)
+    assert s1.final_cost < 0.1 * s1.initial_cost
+    assert np.array_equal(s0.log_cost, s1.log_cost) and s0.final_cost == s1.final_cost
+    assert np.array_equal(b0.poses, b1.poses) and np.array_equal(b0.points, b1.points) and np.array_equal(b0.cams, b1.cams)
+
+
 def test_fused_pcg_kernel_matches_separate_kernels():
     """ba_pcg_fused_kernel (one single-workgroup kernel around the three streaming kernels of a product) against
     the separate precondition / direction / finalize / update kernels: same algorithm, different summation
