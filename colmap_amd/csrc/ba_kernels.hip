@@ -2708,30 +2708,30 @@ __global__ void __launch_bounds__(1024) ba_pcg_update_kernel(int n, double* __re
   }
 }
 // y = a * x / s  (s may be null)
-__global__ void ba_scaled_div_kernel(int n, double a, const double* __restrict__ x, const double* __restrict__ s,
-                                     double* __restrict__ y) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) y[i] = a * x[i] / (s ? s[i] : 1.0);
-}
 __global__ void ba_axpby_kernel(int n, double a, const double* __restrict__ x, const double* __restrict__ s,
                                 double* __restrict__ y) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) y[i] = a * x[i] * (s ? s[i] : 1.0);
 }
 
-// x_plus = Plus(x, step): quaternion (x) translation, subset of intrinsics, points
-__global__ void ba_apply_pose_kernel(View V, const double* __restrict__ step, const double* __restrict__ in,
-                                     double* __restrict__ out) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= V.n_poses) return;
-  const double* q = in + 7 * (size_t)i;
-  double* o = out + 7 * (size_t)i;
+// x_plus = Plus(x, step): quaternion (x) translation, subset of intrinsics, points -- ONE launch for all parameter
+// blocks (workgroups are dealt to points, poses, cameras, sensors in that order), and the step is read through a
+// StepSrc, so that the vector kernels that used to prepare it are gone:
+//   tf 0: step = a            tf 1: step = (-1 * a) / s   (projected-gradient test: a = scaled gradient, s = column scale)
+//   tf 3: step = (-a) * s     (candidate: a = the solver's y, s = column scale)          -- the same roundings as
+// two vector kernels (y = a x / s, y = a x s) applied one after the other, which this replaces.
+// MAXDIFF: also max |x_plus - x| over everything -> scalars[S_GMAX] (replaces three ba_maxdiff launches).
+struct StepSrc {
+  const double* a;
+  const double* s;
+  int tf;
+};
+__device__ __forceinline__ double step_val(const StepSrc& S, int k) {
+  const double x = S.a[k];
+  return S.tf == 0 ? x : S.tf == 1 ? (-1.0 * x) / S.s[k] : (-1.0 * x) * S.s[k];
+}
+__device__ __forceinline__ double plus_quat_trans(const double* q, double* o, const double d[6], bool rotc, int fix) {
   for (int c = 0; c < 7; ++c) o[c] = q[c];
-  const int off = V.pose_off[i];
-  if (off < 0) return;
-  const double* d = step + off;
-  const int pf = V.pose_fix[i];
-  const bool rotc = pf >= 4;
   const double n = rotc ? 0.0 : sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
   if (n != 0.0) {
     const double s = sin(n) / n;
@@ -2743,34 +2743,86 @@ __global__ void ba_apply_pose_kernel(View V, const double* __restrict__ step, co
     o[3] = dw * w - dx * x - dy * y - dz * z;
   }
   int k = rotc ? 0 : 3;
-  const int fix = pf < 0 ? -1 : ((pf & 3) == 3 ? -1 : (pf & 3));
   for (int c = 0; c < 3; ++c) {
     if (c == fix) continue;
     o[4 + c] += d[k++];
   }
+  double m = 0.0;
+  for (int c = 0; c < 7; ++c) m = fmax(m, fabs(o[c] - q[c]));
+  return m;
 }
-// Plus() on the variable sensor_from_rig blocks (quaternion (x) R^3, like a full pose block)
-__global__ void ba_apply_sensor_kernel(View V, const double* __restrict__ step, const double* __restrict__ in,
-                                       double* __restrict__ out) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= V.n_sensors) return;
-  const double* q = in + 7 * (size_t)i;
-  double* o = out + 7 * (size_t)i;
-  for (int c = 0; c < 7; ++c) o[c] = q[c];
-  const int off = V.sens_off ? V.sens_off[i] : -1;
-  if (off < 0) return;
-  const double* d = step + off;
-  const double n = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
-  if (n != 0.0) {
-    const double s = sin(n) / n;
-    const double dx = s * d[0], dy = s * d[1], dz = s * d[2], dw = cos(n);
-    const double x = q[0], y = q[1], z = q[2], w = q[3];
-    o[0] = dw * x + dx * w + dy * z - dz * y;
-    o[1] = dw * y - dx * z + dy * w + dz * x;
-    o[2] = dw * z + dx * y - dy * x + dz * w;
-    o[3] = dw * w - dx * x - dy * y - dz * z;
+template <bool MAXDIFF>
+__global__ void __launch_bounds__(128) ba_apply_all_kernel(View V, StepSrc Sc, StepSrc Sp, const double* __restrict__ Pin,
+                                                           double* __restrict__ P2, const double* __restrict__ Cin,
+                                                           double* __restrict__ C2, const double* __restrict__ Xin,
+                                                           double* __restrict__ X2, const double* __restrict__ Sin,
+                                                           double* __restrict__ S2) {
+  const int nb_pt = (V.n_points + 127) / 128, nb_pose = (V.n_poses + 127) / 128, nb_cam = (V.n_cams + 127) / 128;
+  int blk = blockIdx.x;
+  double m = 0.0;
+  if (blk < nb_pt) {
+    const int j = blk * 128 + threadIdx.x;
+    if (j < V.n_points) {
+      const int off = V.pt_off[j];
+      for (int c = 0; c < 3; ++c) {
+        const double xin = Xin[3 * (size_t)j + c];
+        const double xo = xin + (off >= 0 ? step_val(Sp, off + c) : 0.0);
+        X2[3 * (size_t)j + c] = xo;
+        m = fmax(m, fabs(xo - xin));
+      }
+    }
+  } else if ((blk -= nb_pt) < nb_pose) {
+    const int i = blk * 128 + threadIdx.x;
+    if (i < V.n_poses) {
+      const double* q = Pin + 7 * (size_t)i;
+      double* o = P2 + 7 * (size_t)i;
+      const int off = V.pose_off[i];
+      if (off < 0) {
+        for (int c = 0; c < 7; ++c) o[c] = q[c];
+      } else {
+        const int pf = V.pose_fix[i];
+        const bool rotc = pf >= 4;
+        const int fix = pf < 0 ? -1 : ((pf & 3) == 3 ? -1 : (pf & 3));
+        const int dim = V.pose_dim[i];
+        double d[6];
+        for (int c = 0; c < 6; ++c) d[c] = c < dim ? step_val(Sc, off + c) : 0.0;
+        m = plus_quat_trans(q, o, d, rotc, fix);
+      }
+    }
+  } else if ((blk -= nb_pose) < nb_cam) {
+    const int k = blk * 128 + threadIdx.x;
+    if (k < V.n_cams) {
+      for (int c = 0; c < BA_CAM_STRIDE; ++c) C2[BA_CAM_STRIDE * (size_t)k + c] = Cin[BA_CAM_STRIDE * (size_t)k + c];
+      const int off = V.cam_off[k];
+      if (off >= 0)
+        for (int d = 0; d < V.cam_dim[k]; ++d) {
+          const int idx = V.cam_var[V.kd * k + d];
+          const double cin = Cin[BA_CAM_STRIDE * (size_t)k + idx];
+          const double co = cin + step_val(Sc, off + d);
+          C2[BA_CAM_STRIDE * (size_t)k + idx] = co;
+          m = fmax(m, fabs(co - cin));
+        }
+    }
+  } else {
+    blk -= nb_cam;
+    const int i = blk * 128 + threadIdx.x;
+    if (i < V.n_sensors) {
+      const double* q = Sin + 7 * (size_t)i;
+      double* o = S2 + 7 * (size_t)i;
+      const int off = V.sens_off ? V.sens_off[i] : -1;
+      if (off < 0) {
+        for (int c = 0; c < 7; ++c) o[c] = q[c];
+      } else {
+        double d[6];
+        for (int c = 0; c < 6; ++c) d[c] = step_val(Sc, off + c);
+        m = plus_quat_trans(q, o, d, false, -1);
+      }
+    }
   }
-  for (int c = 0; c < 3; ++c) o[4 + c] += d[3 + c];
+  if (MAXDIFF) {
+    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0) atomic_max_pos(V.scalars + S_GMAX, m);
+  }
 }
 __global__ void ba_renorm_sensor_quat_kernel(View V, double* __restrict__ sensors) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2778,40 +2830,6 @@ __global__ void ba_renorm_sensor_quat_kernel(View V, double* __restrict__ sensor
   double* q = sensors + 7 * (size_t)i;
   const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
   for (int c = 0; c < 4; ++c) q[c] /= n;
-}
-__global__ void ba_apply_cam_kernel(View V, const double* __restrict__ step, const double* __restrict__ in,
-                                    double* __restrict__ out) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= V.n_cams) return;
-  for (int c = 0; c < BA_CAM_STRIDE; ++c) out[BA_CAM_STRIDE * (size_t)k + c] = in[BA_CAM_STRIDE * (size_t)k + c];
-  const int off = V.cam_off[k];
-  if (off < 0) return;
-  for (int d = 0; d < V.cam_dim[k]; ++d) out[BA_CAM_STRIDE * (size_t)k + V.cam_var[V.kd * k + d]] += step[off + d];
-}
-__global__ void ba_apply_point_kernel(View V, const double* __restrict__ step, const double* __restrict__ in,
-                                      double* __restrict__ out) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= V.n_points) return;
-  const int off = V.pt_off[j];
-  for (int c = 0; c < 3; ++c) out[3 * (size_t)j + c] = in[3 * (size_t)j + c] + (off >= 0 ? step[off + c] : 0.0);
-}
-// max |a - b| over n doubles -> scalars[S_GMAX]
-__global__ void ba_maxdiff_kernel(size_t n, const double* __restrict__ a, const double* __restrict__ b,
-                                  double* __restrict__ scalars) {
-  // grid-stride: at most 256 workgroups, one atomic per wave (the max is order-independent)
-  double v = 0.0;
-  const size_t step = (size_t)gridDim.x * blockDim.x;
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  for (; i + 3 * step < n; i += 4 * step) {  // eight loads in flight per trip (rolled: one pair, one wait)
-    double x[4], y[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) { x[u] = a[i + u * step]; y[u] = b[i + u * step]; }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) v = fmax(v, fabs(x[u] - y[u]));
-  }
-  for (; i < n; i += step) v = fmax(v, fabs(a[i] - b[i]));
-  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
-  if ((threadIdx.x & 63) == 0) atomic_max_pos(scalars + S_GMAX, v);
 }
 // point sharding: zero the variable points another rank owns (point index % world != rank)
 __global__ void ba_keep_own_points_kernel(View V, int rank, int world, double* __restrict__ points) {
@@ -4209,12 +4227,19 @@ struct Solver {
     return std::min(it, max_iter);
   }
 
-  void apply_step(const double* sc, const double* sp, double* P2, double* C2, double* X2) {
-    if (V.sens_off)
-      BA_LAUNCH(ba_apply_sensor_kernel, dim3(grid_for(V.n_sensors, 128)), dim3(128), st, V, sc, sensors.p, sensors2.p);
-    BA_LAUNCH(ba_apply_pose_kernel, dim3(grid_for(V.n_poses, 128)), dim3(128), st, V, sc, poses.p, P2);
-    BA_LAUNCH(ba_apply_cam_kernel, dim3(grid_for(V.n_cams, 128)), dim3(128), st, V, sc, cams.p, C2);
-    BA_LAUNCH(ba_apply_point_kernel, dim3(grid_for(V.n_points, 128)), dim3(128), st, V, sp, points.p, X2);
+  // Plus() of every parameter block in one launch; `tf` says how the step is read (StepSrc), `maxdiff` adds
+  // max |x_plus - x| into scalars[S_GMAX]
+  void apply_step(const double* sc, const double* sc_scale, const double* sp, const double* sp_scale, int tf, bool maxdiff,
+                  double* P2, double* C2, double* X2) {
+    const int nb = grid_for(V.n_points, 128) + grid_for(V.n_poses, 128) + grid_for(V.n_cams, 128) +
+                   (V.sens_off ? grid_for(V.n_sensors, 128) : 0);
+    const StepSrc Sc{sc, sc_scale, tf}, Sp{sp, sp_scale, tf};
+    if (maxdiff)
+      BA_LAUNCH(ba_apply_all_kernel<true>, dim3(std::max(nb, 1)), dim3(128), st, V, Sc, Sp, poses.p, P2, cams.p, C2, points.p, X2,
+                sensors.p, sensors2.p);
+    else
+      BA_LAUNCH(ba_apply_all_kernel<false>, dim3(std::max(nb, 1)), dim3(128), st, V, Sc, Sp, poses.p, P2, cams.p, C2, points.p, X2,
+                sensors.p, sensors2.p);
   }
 
   void run(ba_result* out) {
@@ -4331,16 +4356,9 @@ struct Solver {
         }
         // projected-gradient test: ||x - Plus(x, -g)||_inf with the unscaled gradient g = s * g_scaled
         // (the stored Jacobian is column-scaled: g_scaled = s * g, so g = g_scaled / s)
-        BA_LAUNCH(ba_scaled_div_kernel, dim3(std::max(gvc, 1)), dim3(256), st, nc, -1.0, gc.p, scale_c.p, stepc.p);
-        BA_LAUNCH(ba_scaled_div_kernel, dim3(std::max(gvp, 1)), dim3(256), st, np, -1.0, gp.p, scale_p.p, stepp.p);
-        apply_step(stepc.p, stepp.p, poses2.p, cams2.p, points2.p);
+        // (one launch: the step -g / s is formed on the fly, Plus() of all blocks, the max of the differences)
         zero_scalar(S_GMAX);
-        auto gmd = [](size_t n) { return dim3((unsigned)std::min<size_t>(std::max<size_t>((n + 255) / 256, 1), 256)); };
-        BA_LAUNCH(ba_maxdiff_kernel, gmd(poses.n), dim3(256), st, poses.n, poses.p, poses2.p, scalars.p);
-        BA_LAUNCH(ba_maxdiff_kernel, gmd(cams.n), dim3(256), st, cams.n, cams.p, cams2.p, scalars.p);
-        BA_LAUNCH(ba_maxdiff_kernel, gmd(points.n), dim3(256), st, points.n, points.p, points2.p, scalars.p);
-        if (V.sens_off)
-          BA_LAUNCH(ba_maxdiff_kernel, gmd(sensors.n), dim3(256), st, sensors.n, sensors.p, sensors2.p, scalars.p);
+        apply_step(gc.p, scale_c.p, gp.p, scale_p.p, 1, true, poses2.p, cams2.p, points2.p);
         double gmax;
         if (one_sync) {
           double h[NSCALAR];
@@ -4463,8 +4481,8 @@ struct Solver {
         BA_LAUNCH(ba_point_apply_kernel<2>, dim3(grid_for(V.n_points, 128)), dim3(128), st, V, Cinv.p, jx.p, gp.p,
                   tbuf.p, v.p, dp.p);
       }
-      BA_LAUNCH(ba_axpby_kernel, dim3(std::max(gvc, 1)), dim3(256), st, nc, -1.0, x.p, nullptr, stepc.p);
-      BA_LAUNCH(ba_axpby_kernel, dim3(std::max(gvp, 1)), dim3(256), st, np, -1.0, dp.p, nullptr, stepp.p);
+      // (the negated, unscaled camera-side step: only the priors' model term reads it; Plus() forms its own)
+      if (use_priors()) BA_LAUNCH(ba_axpby_kernel, dim3(std::max(gvc, 1)), dim3(256), st, nc, -1.0, x.p, nullptr, stepc.p);
       // model cost change -(J step).(r + J step / 2): jx = J_c y_c of the back-substitution is still in place
       if (model_fused) {
         BA_LAUNCH(ba_final_sum_kernel, dim3(1), dim3(1024), st, partials.p, V.n_tiles, scalars.p + S_MODEL);
@@ -4482,9 +4500,7 @@ struct Solver {
       double spec_new_cost = 0.0;
       double model_change;
       if (speculate) {
-        BA_LAUNCH(ba_axpby_kernel, dim3(std::max(gvc, 1)), dim3(256), st, nc, 1.0, stepc.p, scale_c.p, stepc.p);
-        BA_LAUNCH(ba_axpby_kernel, dim3(std::max(gvp, 1)), dim3(256), st, np, 1.0, stepp.p, scale_p.p, stepp.p);
-        apply_step(stepc.p, stepp.p, poses2.p, cams2.p, points2.p);
+        apply_step(x.p, scale_c.p, dp.p, scale_p.p, 3, false, poses2.p, cams2.p, points2.p);  // step = (-y) * column scale
         launch_linearize(false, poses2.p, cams2.p, points2.p, sensors2.p, S_NEWCOST);
         double h[NSCALAR];
         scalars_to_host(h);
@@ -4513,9 +4529,7 @@ struct Solver {
         if (speculate) {
           new_cost = spec_new_cost;
         } else {
-          BA_LAUNCH(ba_axpby_kernel, dim3(std::max(gvc, 1)), dim3(256), st, nc, 1.0, stepc.p, scale_c.p, stepc.p);
-          BA_LAUNCH(ba_axpby_kernel, dim3(std::max(gvp, 1)), dim3(256), st, np, 1.0, stepp.p, scale_p.p, stepp.p);
-          apply_step(stepc.p, stepp.p, poses2.p, cams2.p, points2.p);
+          apply_step(x.p, scale_c.p, dp.p, scale_p.p, 3, false, poses2.p, cams2.p, points2.p);
           launch_linearize(false, poses2.p, cams2.p, points2.p, sensors2.p, S_NEWCOST);
           new_cost = scalar_sum(S_NEWCOST);
         }
