@@ -1969,11 +1969,14 @@ __global__ void __launch_bounds__(64 * GRAM_WAVES, BD <= 8 ? 4 : 2) ba_block_gra
 // a W is computed once per linearisation instead of once per partner visit.
 template <int BD>
 __global__ void ba_obs_w_kernel(View V) {
-  const int o = blockIdx.x * blockDim.x + threadIdx.x;
-  if (o >= V.n_obs) return;
+  // a lane per P-ORDER slot: the point columns and the stores of W (wd x 3 doubles per slot, neighbours in memory) are
+  // coalesced, only the block's 2 x wd camera-side entries are gathered through a2c (a lane per c-order slot gathered
+  // the six point columns AND scattered the 12 .. 24 stores: 370 us at BA-1 with one shared camera)
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= V.n_obs) return;
+  const int o = V.a2c[a];
   const unsigned so = V.solo[o];
   const size_t N = (size_t)V.n_obs;
-  const int a = V.c2a[o];
   double e[2][3];
   bool have_e = false;
 #pragma unroll
